@@ -1,0 +1,157 @@
+/*
+ * tracy_hip.h -- C ABI of the MI355X-native tracy alignment / deconvolution hot path.
+ *
+ * The reference (gear-genomics/tracy v0.9.1) has no FFI: its boundary for this path is the set of
+ * header-only C++ templates listed below.  Each entry point here is the batched, device-side
+ * replacement for one of them; tracy_amd/host/tracy_amd.hpp keeps the reference's per-call C++
+ * signatures (batch of one) on top of this ABI, INTEGRATION.md shows the binding a tracy maintainer
+ * would add.
+ *
+ *   reference interface (under /root/reference/src)                         replaced by
+ *   -------------------------------------------------------------------     ---------------------------
+ *   gotohScore(a1,a2,ac,sc)                gotoh.h:12-68                    tracyhip_gotoh_score
+ *   gotoh(a1,a2,align,ac,sc)               gotoh.h:71-174                   tracyhip_gotoh_align
+ *   needleScore / needle                   needle.h:12-57 / 59-138          tracyhip_needle_score / _align
+ *   _createAlignment (string / profile)    align.h:196-223, 254-293         tracyhip_alignment_rows
+ *   DnaScore<int>, AlignConfig<H,V>        align.h:11-32, 37-80             tracyhip_params
+ *   sage() hot section                     sage.h:191-311                   tracyhip_align_traces
+ *   findBreakpoint                         decompose.h:7-56                 tracyhip_find_breakpoint
+ *   decomposeAlleles                       decompose.h:179-376              tracyhip_decompose_alleles
+ *   allelicFraction                        decompose.h:412-621              tracyhip_allelic_fraction
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every buffer passed in; nothing is retained after return.
+ *   - "metadata on the host, payload where `mem` says": offset / length / index arrays are ALWAYS host
+ *     arrays; sequence payloads and result arrays are host pointers (TRACYHIP_MEM_HOST, staged through
+ *     the library's device buffers) or device pointers (TRACYHIP_MEM_DEVICE, zero copy).
+ *   - every call returns TRACYHIP_OK (0) or a negative error; tracyhip_last_error() gives the text.
+ *     The reference's DP functions cannot fail (gotoh.h has no checks); the extra errors here are
+ *     bad arguments, HIP failures, out-of-memory and parameter ranges the int32 kernels cannot hold.
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute call fails.
+ */
+#ifndef TRACY_HIP_H
+#define TRACY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRACYHIP_OK 0
+#define TRACYHIP_ERR_ARG (-1)      /* NULL pointer, inconsistent sizes */
+#define TRACYHIP_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define TRACYHIP_ERR_OOM (-3)      /* device or host allocation failed */
+#define TRACYHIP_ERR_RANGE (-4)    /* scores / lengths outside what the int32 kernels represent */
+#define TRACYHIP_ERR_NODEVICE (-5) /* no gfx950 device visible */
+
+#define TRACYHIP_MEM_HOST 0
+#define TRACYHIP_MEM_DEVICE 1
+
+/* sequence payload kinds: what TAlign1/TAlign2 is in the reference call */
+#define TRACYHIP_SEQ_CHAR 0    /* std::string: raw bytes, scored by byte equality (align.h:96-101) */
+#define TRACYHIP_SEQ_PROFILE 1 /* boost::multi_array<float,2>[6][len], p[k][j] at k*len+j (align.h:103-118) */
+
+typedef struct tracyhip_ctx tracyhip_ctx;
+
+/* DnaScore<int> (align.h:11-32; inf is the fixed 1000000) + AlignConfig<hfree,vfree> (align.h:37-80) */
+typedef struct {
+  int32_t match;
+  int32_t mismatch;
+  int32_t go;
+  int32_t ge;
+  int32_t hfree; /* THorizontal: horizontal moves are free on the first and last ROW */
+  int32_t vfree; /* TVertical:   vertical moves are free on the first and last COLUMN */
+} tracyhip_params;
+
+/* a set of sequences packed back to back */
+typedef struct {
+  int32_t kind;           /* TRACYHIP_SEQ_* */
+  const void* data;       /* chars, or floats: sequence s occupies [offset[s], offset[s] + (kind ? 6 : 1) * length[s]) */
+  const uint64_t* offset; /* HOST array, element offsets (bytes for CHAR, floats for PROFILE) */
+  const uint32_t* length; /* HOST array, number of columns */
+  uint32_t count;         /* number of sequences */
+} tracyhip_seqset;
+
+/* npairs independent DP problems: pair i aligns a1[a1_index[i]] (rows) with a2[a2_index[i]] (columns) */
+typedef struct {
+  uint32_t npairs;
+  tracyhip_seqset a1;
+  tracyhip_seqset a2;
+  const uint32_t* a1_index; /* HOST array or NULL (= identity) */
+  const uint32_t* a2_index; /* HOST array or NULL (= identity) */
+} tracyhip_pairs;
+
+/* ---- lifecycle --------------------------------------------------------------------------------- */
+int tracyhip_device_count(int* count);
+int tracyhip_create(int device, tracyhip_ctx** ctx);
+int tracyhip_destroy(tracyhip_ctx* ctx);
+/* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int tracyhip_set_stream(tracyhip_ctx* ctx, void* hip_stream);
+/* upper bound for the library's device workspace (traceback planes are chunked to fit); 0 = default */
+int tracyhip_set_workspace_limit(tracyhip_ctx* ctx, uint64_t bytes);
+int tracyhip_synchronize(tracyhip_ctx* ctx);
+const char* tracyhip_last_error(void);
+const char* tracyhip_version(void);
+
+/* ---- DP ---------------------------------------------------------------------------------------- */
+/* gotohScore, gotoh.h:12-68: scores[i] = s[n] of pair i. */
+int tracyhip_gotoh_score(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm,
+                         int mem, int32_t* scores);
+/* gotoh, gotoh.h:71-174.  ops receives the reference's `btr` (gotoh.h:147-167): 's','h','v' in PUSH
+ * ORDER, i.e. from the end of the alignment to its start; pair i writes ops_len[i] <= m+n bytes at
+ * ops + ops_offset[i] (ops_offset is a HOST array).  scores may be NULL. */
+int tracyhip_gotoh_align(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm,
+                         int mem, int32_t* scores, uint8_t* ops, const uint64_t* ops_offset,
+                         uint32_t* ops_len);
+/* needleScore / needle, needle.h:12-57 / 59-138 (linear gap cost ge; profiles scored in double). */
+int tracyhip_needle_score(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm,
+                          int mem, int32_t* scores);
+int tracyhip_needle_align(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm,
+                          int mem, int32_t* scores, uint8_t* ops, const uint64_t* ops_offset,
+                          uint32_t* ops_len);
+/* _createAlignment, align.h:196-223 (CHAR) / 254-293 (PROFILE: consensus characters).  For pair i,
+ * row0/row1 receive ops_len[i] bytes each at rows0 + ops_offset[i] / rows1 + ops_offset[i]. */
+int tracyhip_alignment_rows(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, const uint8_t* ops,
+                            const uint64_t* ops_offset, const uint32_t* ops_len, uint8_t* rows0,
+                            uint8_t* rows1);
+
+/* ---- whole `tracy align` hot section (sage.h:191-311) for a batch of traces ---------------------
+ * Per trace t:   full profile  P_f = float[6][mf]        (createProfile(tr,bc), sage.h:193)
+ *                trimmed profile = columns [trim_left, mf - trim_right) of P_f (sage.h:197; identical
+ *                values: createProfile computes each column independently, profile.h:28-51)
+ *                reference window  R = bytes[n]           (loadSingleFasta output, sage.h:226)
+ * Steps (all on the device): gotohScore(trim, R) and gotohScore(trim, revcomp R) (sage.h:239-240);
+ * forward iff gsFwd > gsRev (:247); gotoh(trim, oriented R) (:258); trimReferenceSlice (:259,
+ * fmindex.h:429-463); gotoh(full, trimmed slice) (:311). */
+typedef struct {
+  uint32_t ntraces;
+  tracyhip_seqset profiles; /* kind PROFILE, one full profile per trace */
+  tracyhip_seqset refs;     /* kind CHAR */
+  const uint32_t* ref_index; /* HOST array or NULL (= identity) */
+  uint32_t trim_left;       /* SageConfig.trimLeft  (sage.h:88) */
+  uint32_t trim_right;      /* SageConfig.trimRight (sage.h:89) */
+} tracyhip_align_job;
+
+typedef struct {
+  int32_t* score_fwd;     /* [ntraces] gsFwd */
+  int32_t* score_rev;     /* [ntraces] gsRev */
+  uint8_t* forward;       /* [ntraces] 1 = rs.forward */
+  int32_t* score_prelim;  /* [ntraces] score of the preliminary alignment (sage.h:258), may be NULL */
+  uint32_t* slice_begin;  /* [ntraces] ri: offset of the trimmed slice in the ORIENTED reference */
+  uint32_t* slice_len;    /* [ntraces] length of the trimmed slice (after substr clamping) */
+  uint32_t* ref_pos;      /* [ntraces] rs.pos after trimReferenceSlice (rs.pos starts at 0, sage.h:244) */
+  int32_t* score_final;   /* [ntraces] score of the final alignment (sage.h:311) */
+  uint8_t* ops;           /* final alignment, push order, at ops + ops_offset[t] (capacity mf + slice) */
+  const uint64_t* ops_offset; /* HOST array */
+  uint32_t* ops_len;      /* [ntraces] */
+} tracyhip_align_result;
+
+int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm,
+                          int mem, const tracyhip_align_result* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,56 @@
+"""ctypes driver of the host wave emulator (tests only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_LIB = None
+
+MODE_CHAR, MODE_QP, MODE_PROF = 0, 1, 2
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libemu_wave.so")
+        srcs = [os.path.join(_HERE, "emu_wave.cpp"), os.path.join(_ROOT, "tracy_amd/csrc/dp_kernels.h"),
+                os.path.join(_ROOT, "tracy_amd/csrc/dp_lane.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["g++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
+                                   "-o", so, srcs[0]], stderr=subprocess.DEVNULL)
+        _LIB = C.CDLL(so)
+    return _LIB
+
+
+def run(a1, a2, score, hfree, vfree, mode, K, trace=True, needle=False, revcomp=False, a1_view=None):
+    """a1/a2: bytes or float32 [6][len] arrays.  a1_view=(offset, m): use columns [offset, offset+m) of a1."""
+    def prep(x):
+        if isinstance(x, (bytes, bytearray)):
+            buf = np.frombuffer(bytes(x) + b"\0", dtype=np.uint8).copy()
+            return buf, len(x), len(x)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        return x, x.shape[1], x.shape[1]
+    b1, m, s1 = prep(a1)
+    if mode == MODE_QP:  # the API layer encodes reference characters into profile-row codes
+        lut = np.full(256, 6, dtype=np.uint8)
+        for chars, code in ((b"Aa", 0), (b"Cc", 1), (b"Gg", 2), (b"Tt", 3), (b"Nn", 4), (b"-", 5)):
+            for ch in chars:
+                lut[ch] = code
+        a2 = lut[np.frombuffer(bytes(a2), dtype=np.uint8)].tobytes()
+    b2, n, s2 = prep(a2)
+    p1 = b1.ctypes.data
+    if a1_view is not None:
+        off, m = a1_view
+        p1 += off * b1.itemsize
+    sc = C.c_int32(0)
+    ops = C.create_string_buffer(m + n + 2)
+    ol = C.c_uint32(0)
+    err = C.c_int32(0)
+    rc = lib().emu_dp(int(needle), mode, K, int(trace), C.c_void_p(p1), m, s1, C.c_void_p(b2.ctypes.data), n, s2,
+                      1 if revcomp else 0, *[int(x) for x in score], int(hfree), int(vfree), C.byref(sc), ops,
+                      C.byref(ol), C.byref(err))
+    assert rc == 0
+    return sc.value, (ops.raw[:ol.value] if trace else None), err.value

@@ -1,0 +1,100 @@
+// emu_wave.cpp -- host execution of the wave-level kernel bodies (TEST INFRASTRUCTURE ONLY).
+// Runs tracy_amd/csrc/dp_kernels.h with a 64-thread "wave" (one std::thread per lane, barriers at every
+// cross-lane shift) so that the index math, tag arithmetic, traceback layout and walker can be checked
+// against the oracle in the CPU-only container.  Never linked into the product library.
+#include <barrier>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../tracy_amd/csrc/dp_kernels.h"
+
+using namespace tracyhip;
+
+namespace {
+struct WaveShared {
+  std::barrier<> bar{64};
+  int32_t xchg[64];
+  std::vector<char> lds;
+};
+
+struct HostWave {
+  uint32_t lane_;
+  WaveShared* sh;
+  uint32_t lane() const { return lane_; }
+  int32_t shift_up(int32_t x) {  // lane L receives lane L-1's value (DPP wave_shr:1); lane 0 gets 0
+    sh->xchg[lane_] = x;
+    sh->bar.arrive_and_wait();
+    int32_t r = lane_ ? sh->xchg[lane_ - 1] : 0;
+    sh->bar.arrive_and_wait();
+    return r;
+  }
+  void sync() { sh->bar.arrive_and_wait(); }
+  void sync_global() { sh->bar.arrive_and_wait(); }
+  char* lds() { return sh->lds.data(); }
+};
+
+template <int K, int MODE, bool TRACE, bool NEEDLE>
+void run_wave(const DpArgs& a) {
+  WaveShared sh;
+  sh.lds.assign(lds_bytes(MODE == MODE_QP ? MODE_QP : MODE_PROF, K) + 64, 0);
+  std::vector<std::thread> th;
+  for (uint32_t l = 0; l < 64; ++l) {
+    th.emplace_back([&, l]() {
+      HostWave w{l, &sh};
+      if constexpr (NEEDLE) {
+        if constexpr (MODE != MODE_QP) needle_body<HostWave, K, MODE, TRACE>(w, a, 0);
+      } else {
+        gotoh_body<HostWave, K, MODE, TRACE>(w, a, 0);
+      }
+    });
+  }
+  for (auto& t : th) t.join();
+}
+
+template <int K, bool NEEDLE>
+void dispatch(int mode, bool trace, const DpArgs& a) {
+  if (mode == MODE_CHAR) trace ? run_wave<K, MODE_CHAR, true, NEEDLE>(a) : run_wave<K, MODE_CHAR, false, NEEDLE>(a);
+  else if (mode == MODE_QP) trace ? run_wave<K, MODE_QP, true, NEEDLE>(a) : run_wave<K, MODE_QP, false, NEEDLE>(a);
+  else trace ? run_wave<K, MODE_PROF, true, NEEDLE>(a) : run_wave<K, MODE_PROF, false, NEEDLE>(a);
+}
+}  // namespace
+
+extern "C" {
+// One pair through the kernel bodies.  a1/a2: bytes (CHAR) or float[6][len] (PROFILE side of the mode).
+// Returns 0 on success; score/ops (push order)/ops_len are outputs; ops may be null for score-only.
+int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, uint32_t a1_stride, const void* a2,
+           uint32_t n, uint32_t a2_stride, uint32_t flags, int32_t match, int32_t mismatch, int32_t go, int32_t ge,
+           int32_t hfree, int32_t vfree, int32_t* score, uint8_t* ops, uint32_t* ops_len, int32_t* err_out) {
+  PairDesc d{};
+  d.m = m; d.n = n; d.a1_stride = a1_stride; d.a2_stride = a2_stride; d.flags = flags;
+  const uint32_t P = num_passes(m ? m : 1, K);
+  std::vector<uint64_t> bits((size_t)P * steps_per_pass(n) * 64 + 64, 0xDEADBEEFDEADBEEFull);
+  std::vector<int32_t> scratch(2 * (size_t)(n + 2), 0);
+  int32_t err = 0;
+  DpArgs a{};
+  a.pairs = &d; a.a1 = a1; a.a2 = a2;
+  a.bits = bits.data(); a.bits32 = reinterpret_cast<uint32_t*>(bits.data());
+  a.scratch = scratch.data(); a.scores = score; a.err = &err;
+  a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = hfree; a.vfree = vfree;
+  *score = 0x7fffffff;
+  switch (K) {
+    case 4: needle ? dispatch<4, true>(mode, trace, a) : dispatch<4, false>(mode, trace, a); break;
+    case 8: needle ? dispatch<8, true>(mode, trace, a) : dispatch<8, false>(mode, trace, a); break;
+    case 16: needle ? dispatch<16, true>(mode, trace, a) : dispatch<16, false>(mode, trace, a); break;
+    default: return -1;
+  }
+  if (trace && ops) {
+    uint64_t off = 0;
+    WalkArgs wa{};
+    wa.pairs = &d; wa.bits = bits.data(); wa.ops = ops; wa.ops_off = &off; wa.ops_len = ops_len; wa.err = &err;
+    wa.npairs = 1; wa.K = K;
+    if (needle) needle_walk_one(wa, reinterpret_cast<uint32_t*>(bits.data()), 0);
+    else gotoh_walk_one(wa, 0);
+  }
+  if (err_out) *err_out = err;
+  return 0;
+}
+}

@@ -1,0 +1,122 @@
+"""The wave-level kernel bodies (tracy_amd/csrc/dp_kernels.h) executed on the host by a 64-thread
+lock-step emulator, compared bit for bit with the oracle.  This checks everything in the HIP kernels
+except the __global__ wrappers, the DPP shift and the memory system."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import pyoracle as orc
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+import emu  # noqa: E402
+
+SC = (3, -5, -10, -4)
+CONFIGS = [(0, 0), (1, 0), (0, 1), (1, 1)]
+
+
+def rand_seq(rng, n, alpha=b"ACGT"):
+    return bytes(rng.choice(list(alpha), size=n).tolist())
+
+
+def rand_profile(rng, n, sharp=True):
+    p = np.zeros((6, n), dtype=np.float32)
+    x = rng.random((4, n)).astype(np.float32)
+    if sharp:
+        x = x ** 6
+    p[:4] = x / x.sum(axis=0, keepdims=True)
+    return p
+
+
+def mutate(rng, s, rate=0.1):
+    out = bytearray()
+    for ch in s:
+        u = rng.random()
+        if u < rate / 3:
+            continue
+        if u < 2 * rate / 3:
+            out.append(int(rng.choice(list(b"ACGT"))))
+        if u < rate:
+            out.append(int(rng.choice(list(b"ACGT"))))
+        else:
+            out.append(ch)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("K", [4, 8, 16])
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_char_mode(K, cfg):
+    rng = np.random.default_rng(100 + K + cfg[0] * 2 + cfg[1])
+    sizes = [(0, 5), (5, 0), (1, 1), (3, 70), (70, 3), (64 * K // 8, 40), (50, 90)]
+    if K == 4:
+        sizes += [(300, 120), (257, 33)]  # more than one pass (64*K = 256 rows)
+    for (m, n) in sizes:
+        alpha = b"AC" if (m + n) % 3 == 0 else b"ACGT"
+        s2 = rand_seq(rng, n, alpha)
+        s1 = mutate(rng, s2[: max(m, 0)] + rand_seq(rng, max(0, m - n), alpha))[:m] if m else b""
+        s1 = (s1 + rand_seq(rng, m, alpha))[:m]
+        want = orc.gotoh_str(s1, s2, cfg[0], cfg[1], SC)
+        got = emu.run(s1, s2, SC, cfg[0], cfg[1], emu.MODE_CHAR, K, trace=True)
+        assert (got[0], got[1]) == want, (m, n, K, cfg)
+        got_s = emu.run(s1, s2, SC, cfg[0], cfg[1], emu.MODE_CHAR, K, trace=False)
+        assert got_s[0] == want[0]
+
+
+@pytest.mark.parametrize("K", [4, 16])
+def test_qp_mode_and_revcomp(K):
+    rng = np.random.default_rng(7 + K)
+    for (m, n) in [(1, 9), (40, 120), (64, 64), (130, 50)] + ([(300, 80)] if K == 4 else []):
+        p1 = rand_profile(rng, m)
+        ref = rand_seq(rng, n, b"ACGTACGTACGTNn-x")
+        p2 = orc.create_profile_str(ref)
+        for cfg in [(1, 0), (1, 1), (0, 0)]:
+            want = orc.gotoh_prof(p1, p2, cfg[0], cfg[1], SC)
+            got = emu.run(p1, ref, SC, cfg[0], cfg[1], emu.MODE_QP, K, trace=True)
+            assert (got[0], got[1]) == want and got[2] == 0
+            assert emu.run(p1, ref, SC, cfg[0], cfg[1], emu.MODE_QP, K, trace=False)[0] == want[0]
+        # reverse-complemented reference (sage.h:236-240): read backwards + complemented codes
+        want = orc.gotoh_score_prof(p1, orc.revcomp_profile(p2), 1, 0, SC)
+        assert emu.run(p1, ref, SC, 1, 0, emu.MODE_QP, K, trace=False, revcomp=True)[0] == want
+    # trimmed view of a full profile (row stride stays the full length)
+    p1 = rand_profile(rng, 60)
+    ref = rand_seq(rng, 90)
+    want = orc.gotoh_prof(p1[:, 7:52], orc.create_profile_str(ref), 1, 0, SC)
+    got = emu.run(p1, ref, SC, 1, 0, emu.MODE_QP, K, trace=True, a1_view=(7, 45))
+    assert (got[0], got[1]) == want
+
+
+@pytest.mark.parametrize("K", [4, 8])
+def test_profile_profile_mode(K):
+    rng = np.random.default_rng(21 + K)
+    for (m, n) in [(5, 7), (33, 70), (100, 20)] + ([(270, 30)] if K == 4 else []):
+        p1, p2 = rand_profile(rng, m, sharp=False), rand_profile(rng, n)
+        for cfg in [(1, 0), (1, 1)]:
+            want = orc.gotoh_prof(p1, p2, cfg[0], cfg[1], SC)
+            got = emu.run(p1, p2, SC, cfg[0], cfg[1], emu.MODE_PROF, K, trace=True)
+            assert (got[0], got[1]) == want
+            assert emu.run(p1, p2, SC, cfg[0], cfg[1], emu.MODE_PROF, K, trace=False)[0] == want[0]
+
+
+@pytest.mark.parametrize("K", [4, 16])
+def test_needle(K):
+    sc = (5, -4, -10, -1)
+    rng = np.random.default_rng(31 + K)
+    for (m, n) in [(0, 3), (4, 0), (9, 9), (40, 77), (90, 30)] + ([(260, 40)] if K == 4 else []):
+        s1, s2 = rand_seq(rng, m, b"AC"), rand_seq(rng, n, b"AC")
+        for cfg in CONFIGS:
+            want = orc.needle_str(s1, s2, cfg[0], cfg[1], sc)
+            got = emu.run(s1, s2, sc, cfg[0], cfg[1], emu.MODE_CHAR, K, trace=True, needle=True)
+            assert (got[0], got[1]) == want
+            assert emu.run(s1, s2, sc, cfg[0], cfg[1], emu.MODE_CHAR, K, trace=False, needle=True)[0] == want[0]
+    p1, p2 = rand_profile(rng, 20, sharp=False), rand_profile(rng, 33, sharp=False)
+    want = orc.needle_prof(p1, p2, 1, 1, sc)
+    got = emu.run(p1, p2, sc, 1, 1, emu.MODE_PROF, K, trace=True, needle=True)
+    assert (got[0], got[1]) == want
+
+
+def test_qp_overflow_flag():
+    rng = np.random.default_rng(5)
+    p1 = rand_profile(rng, 10)
+    _, _, err = emu.run(p1, b"ACGTACGT", (3000, -5, -10, -4), 1, 0, emu.MODE_QP, 4, trace=True)
+    assert err & 1

@@ -1,0 +1,141 @@
+"""GPU parity: the HIP kernels, called through the C ABI, against the oracle (bit exact)."""
+import numpy as np
+import pytest
+
+import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+SC = (3, -5, -10, -4)
+CONFIGS = [(0, 0), (1, 0), (0, 1), (1, 1)]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import tracy_amd
+    c = tracy_amd.Context(0)
+    yield c
+    c.close()
+
+
+def rand_seq(rng, n, alpha=b"ACGT"):
+    return bytes(rng.choice(list(alpha), size=n).tolist())
+
+
+def rand_profile(rng, n, sharp=True):
+    p = np.zeros((6, n), dtype=np.float32)
+    x = rng.random((4, n)).astype(np.float32)
+    if sharp:
+        x = x ** 6
+    p[:4] = x / x.sum(axis=0, keepdims=True)
+    return p
+
+
+def noisy_copy(rng, s, rate=0.05):
+    out = bytearray()
+    for ch in s:
+        u = rng.random()
+        if u < rate / 3:
+            continue
+        if u < 2 * rate / 3:
+            out.append(int(rng.choice(list(b"ACGT"))))
+        out.append(int(rng.choice(list(b"ACGT"))) if u > 1 - rate / 3 else ch)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS)
+def test_gotoh_char_ragged_batch(ctx, cfg):
+    rng = np.random.default_rng(1 + cfg[0] * 2 + cfg[1])
+    sizes = [(0, 0), (0, 7), (9, 0), (1, 1), (3, 200), (200, 3), (64, 64), (65, 130), (255, 257), (256, 300),
+             (257, 100), (511, 513), (700, 90), (1024, 300), (1025, 64), (1500, 200)]
+    a1, a2 = [], []
+    for (m, n) in sizes:
+        ref = rand_seq(rng, n, b"AC" if (m + n) % 2 else b"ACGT")
+        q = noisy_copy(rng, (ref * (m // max(n, 1) + 1))[:m]) if n else rand_seq(rng, m)
+        q = (q + rand_seq(rng, m))[:m]
+        a1.append(q)
+        a2.append(ref)
+    params = SC + cfg
+    scores, btr, rows = ctx.align(a1, a2, params, rows=True)
+    sc_only = ctx.score(a1, a2, params)
+    for i, (q, r) in enumerate(zip(a1, a2)):
+        want = orc.gotoh_str(q, r, cfg[0], cfg[1], SC)
+        assert (int(scores[i]), btr[i]) == want, (sizes[i], cfg)
+        assert int(sc_only[i]) == want[0]
+        assert rows[i] == orc.create_alignment_str(want[1], q, r)
+
+
+def test_gotoh_profile_vs_string_reference(ctx):
+    """gotoh(trace profile, _createProfile(reference)) -- the `tracy align` call shape (sage.h:239-258)"""
+    rng = np.random.default_rng(5)
+    profs, refs = [], []
+    for (m, n) in [(1, 30), (40, 400), (300, 1200), (900, 2000), (1000, 1100), (1100, 700)]:
+        profs.append(rand_profile(rng, m))
+        refs.append(rand_seq(rng, n, b"ACGTACGTACGTACGTNn-x"))
+    for cfg in [(1, 0), (1, 1), (0, 0)]:
+        scores, btr, rows = ctx.align(profs, refs, SC + cfg, rows=True)
+        sc_only = ctx.score(profs, refs, SC + cfg)
+        for i in range(len(profs)):
+            p2 = orc.create_profile_str(refs[i])
+            want = orc.gotoh_prof(profs[i], p2, cfg[0], cfg[1], SC)
+            assert (int(scores[i]), btr[i]) == want
+            assert int(sc_only[i]) == want[0]
+            assert rows[i] == orc.create_alignment_prof(want[1], profs[i], p2)
+
+
+def test_gotoh_profile_profile(ctx):
+    rng = np.random.default_rng(6)
+    p1 = [rand_profile(rng, m, sharp=False) for m in (5, 100, 513, 600)]
+    p2 = [rand_profile(rng, n) for n in (9, 333, 200, 700)]
+    for cfg in [(1, 0), (1, 1)]:
+        scores, btr, rows = ctx.align(p1, p2, SC + cfg, rows=True)
+        sc_only = ctx.score(p1, p2, SC + cfg)
+        for i in range(len(p1)):
+            want = orc.gotoh_prof(p1[i], p2[i], cfg[0], cfg[1], SC)
+            assert (int(scores[i]), btr[i]) == want
+            assert int(sc_only[i]) == want[0]
+            assert rows[i] == orc.create_alignment_prof(want[1], p1[i], p2[i])
+
+
+def test_needle(ctx):
+    sc = (5, -4, -10, -1)
+    rng = np.random.default_rng(8)
+    a1 = [rand_seq(rng, m, b"AC") for m in (0, 4, 90, 300, 1100)]
+    a2 = [rand_seq(rng, n, b"AC") for n in (5, 0, 77, 310, 400)]
+    for cfg in CONFIGS:
+        scores, btr = ctx.align(a1, a2, sc + cfg, needle=True)
+        sc_only = ctx.score(a1, a2, sc + cfg, needle=True)
+        for i in range(len(a1)):
+            want = orc.needle_str(a1[i], a2[i], cfg[0], cfg[1], sc)
+            assert (int(scores[i]), btr[i]) == want
+            assert int(sc_only[i]) == want[0]
+    p1, p2 = [rand_profile(rng, 120, sharp=False)], [rand_profile(rng, 333, sharp=False)]
+    scores, btr = ctx.align(p1, p2, sc + (1, 1), needle=True)
+    assert (int(scores[0]), btr[0]) == orc.needle_prof(p1[0], p2[0], 1, 1, sc)
+
+
+def test_all_pairs_indexing_and_chunking(ctx):
+    """shared sequences through index arrays; a tiny workspace limit forces several traceback chunks"""
+    rng = np.random.default_rng(9)
+    seqs = [rand_seq(rng, int(rng.integers(50, 400))) for _ in range(12)]
+    idx1 = [i for i in range(12) for j in range(12) if i < j]
+    idx2 = [j for i in range(12) for j in range(12) if i < j]
+    ctx.set_workspace_limit(2 << 20)
+    try:
+        scores, btr = ctx.align(seqs, seqs, SC + (1, 1), idx1=idx1, idx2=idx2)
+    finally:
+        ctx.set_workspace_limit(0)
+    for k, (i, j) in enumerate(zip(idx1, idx2)):
+        assert (int(scores[k]), btr[k]) == orc.gotoh_str(seqs[i], seqs[j], 1, 1, SC)
+
+
+def test_error_reporting(ctx):
+    import tracy_amd
+    with pytest.raises(tracy_amd.TracyHipError) as e:
+        ctx.score([b"ACGT"], [b"ACGT"], (5000, -5, -10, -4, 1, 0))
+    assert e.value.code == tracy_amd.capi.ERR_RANGE
+    rng = np.random.default_rng(3)
+    big = rand_profile(rng, 20) * np.float32(1e6)
+    with pytest.raises(tracy_amd.TracyHipError) as e:
+        ctx.score([big], [b"ACGTACGT"], SC + (1, 0))
+    assert e.value.code == tracy_amd.capi.ERR_RANGE

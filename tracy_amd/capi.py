@@ -1,0 +1,210 @@
+"""ctypes binding of include/tracy_hip.h (plumbing for tests and bench.py; plain pointers and sizes).
+
+Loading fails loudly when the in-tree library is missing: build it with `python tracy_amd/build.py`
+(or __graft_entry__.build()).  Nothing here computes on the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+OK, ERR_ARG, ERR_HIP, ERR_OOM, ERR_RANGE, ERR_NODEVICE = 0, -1, -2, -3, -4, -5
+MEM_HOST, MEM_DEVICE = 0, 1
+SEQ_CHAR, SEQ_PROFILE = 0, 1
+
+
+class TracyHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("tracyhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("go", C.c_int32), ("ge", C.c_int32),
+                ("hfree", C.c_int32), ("vfree", C.c_int32)]
+
+
+class SeqSet(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("data", C.c_void_p), ("offset", C.POINTER(C.c_uint64)),
+                ("length", C.POINTER(C.c_uint32)), ("count", C.c_uint32)]
+
+
+class Pairs(C.Structure):
+    _fields_ = [("npairs", C.c_uint32), ("a1", SeqSet), ("a2", SeqSet), ("a1_index", C.POINTER(C.c_uint32)),
+                ("a2_index", C.POINTER(C.c_uint32))]
+
+
+class AlignJob(C.Structure):
+    _fields_ = [("ntraces", C.c_uint32), ("profiles", SeqSet), ("refs", SeqSet), ("ref_index", C.POINTER(C.c_uint32)),
+                ("trim_left", C.c_uint32), ("trim_right", C.c_uint32)]
+
+
+class AlignResult(C.Structure):
+    _fields_ = [("score_fwd", C.c_void_p), ("score_rev", C.c_void_p), ("forward", C.c_void_p),
+                ("score_prelim", C.c_void_p), ("slice_begin", C.c_void_p), ("slice_len", C.c_void_p),
+                ("ref_pos", C.c_void_p), ("score_final", C.c_void_p), ("ops", C.c_void_p),
+                ("ops_offset", C.POINTER(C.c_uint64)), ("ops_len", C.c_void_p)]
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libtracy_hip.so")
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        p = library_path()
+        if not os.path.exists(p):
+            raise ImportError("tracy_amd: %s is missing -- run `python tracy_amd/build.py` (hipcc, gfx950). "
+                              "There is no CPU fallback." % p)
+        _LIB = C.CDLL(p)
+        _LIB.tracyhip_last_error.restype = C.c_char_p
+        _LIB.tracyhip_version.restype = C.c_char_p
+    return _LIB
+
+
+def _check(rc):
+    if rc != OK:
+        raise TracyHipError(rc, lib().tracyhip_last_error().decode())
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().tracyhip_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+class PackedSeqs:
+    """Host-side packing of a list of sequences (bytes) or profiles (float32 [6][len])."""
+
+    def __init__(self, seqs, kind=None):
+        if kind is None:
+            kind = SEQ_CHAR if (len(seqs) == 0 or isinstance(seqs[0], (bytes, bytearray))) else SEQ_PROFILE
+        self.kind = kind
+        self.count = len(seqs)
+        self.length = np.zeros(max(self.count, 1), dtype=np.uint32)
+        self.offset = np.zeros(max(self.count, 1), dtype=np.uint64)
+        pos = 0
+        parts = []
+        for i, s in enumerate(seqs):
+            if kind == SEQ_CHAR:
+                a = np.frombuffer(bytes(s), dtype=np.uint8)
+                ln = a.size
+            else:
+                a = np.ascontiguousarray(s, dtype=np.float32)
+                assert a.ndim == 2 and a.shape[0] == 6
+                ln = a.shape[1]
+                a = a.reshape(-1)
+            self.length[i] = ln
+            self.offset[i] = pos
+            pos += a.size
+            parts.append(a)
+        dt = np.uint8 if kind == SEQ_CHAR else np.float32
+        self.data = np.concatenate(parts) if parts and pos else np.zeros(1, dtype=dt)
+        self.nelem = pos
+
+    def seqset(self, data_ptr=None):
+        s = SeqSet()
+        s.kind = self.kind
+        s.data = data_ptr if data_ptr is not None else self.data.ctypes.data
+        s.offset = self.offset.ctypes.data_as(C.POINTER(C.c_uint64))
+        s.length = self.length.ctypes.data_as(C.POINTER(C.c_uint32))
+        s.count = self.count
+        return s
+
+
+class Context:
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().tracyhip_create(int(device), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().tracyhip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _check(lib().tracyhip_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_workspace_limit(self, nbytes):
+        _check(lib().tracyhip_set_workspace_limit(self._h, C.c_uint64(nbytes)))
+
+    def synchronize(self):
+        _check(lib().tracyhip_synchronize(self._h))
+
+    # ---- host-buffer convenience wrappers (lists in, numpy out) -----------------------------------
+    @staticmethod
+    def _pairs(a1, a2, idx1=None, idx2=None):
+        p1 = a1 if isinstance(a1, PackedSeqs) else PackedSeqs(a1)
+        p2 = a2 if isinstance(a2, PackedSeqs) else PackedSeqs(a2)
+        pr = Pairs()
+        keep = [p1, p2]
+        if idx1 is not None:
+            idx1 = np.ascontiguousarray(idx1, dtype=np.uint32)
+            idx2 = np.ascontiguousarray(idx2, dtype=np.uint32)
+            pr.npairs = len(idx1)
+            pr.a1_index = idx1.ctypes.data_as(C.POINTER(C.c_uint32))
+            pr.a2_index = idx2.ctypes.data_as(C.POINTER(C.c_uint32))
+            keep += [idx1, idx2]
+        else:
+            assert p1.count == p2.count
+            pr.npairs = p1.count
+        pr.a1 = p1.seqset()
+        pr.a2 = p2.seqset()
+        return pr, keep, p1, p2
+
+    def _pair_lengths(self, pr, p1, p2, idx1, idx2):
+        if idx1 is None:
+            return p1.length[:pr.npairs].astype(np.uint64), p2.length[:pr.npairs].astype(np.uint64)
+        return p1.length[np.asarray(idx1)].astype(np.uint64), p2.length[np.asarray(idx2)].astype(np.uint64)
+
+    def score(self, a1, a2, params, needle=False, idx1=None, idx2=None):
+        pr, keep, p1, p2 = self._pairs(a1, a2, idx1, idx2)
+        prm = Params(*params)
+        out = np.zeros(max(pr.npairs, 1), dtype=np.int32)
+        fn = lib().tracyhip_needle_score if needle else lib().tracyhip_gotoh_score
+        _check(fn(self._h, C.byref(pr), C.byref(prm), MEM_HOST, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out[:pr.npairs]
+
+    def align(self, a1, a2, params, needle=False, idx1=None, idx2=None, rows=False):
+        """returns (scores, [btr bytes per pair, push order]) and optionally the alignment rows"""
+        pr, keep, p1, p2 = self._pairs(a1, a2, idx1, idx2)
+        prm = Params(*params)
+        n = pr.npairs
+        l1, l2 = self._pair_lengths(pr, p1, p2, idx1, idx2)
+        cap = (l1 + l2).astype(np.uint64)
+        off = np.zeros(max(n, 1), dtype=np.uint64)
+        if n:
+            off[1:n] = np.cumsum(cap)[:-1]
+        total = int(cap.sum()) if n else 0
+        ops = np.zeros(max(total, 1), dtype=np.uint8)
+        olen = np.zeros(max(n, 1), dtype=np.uint32)
+        scores = np.zeros(max(n, 1), dtype=np.int32)
+        fn = lib().tracyhip_needle_align if needle else lib().tracyhip_gotoh_align
+        _check(fn(self._h, C.byref(pr), C.byref(prm), MEM_HOST, scores.ctypes.data_as(C.POINTER(C.c_int32)),
+                  ops.ctypes.data_as(C.POINTER(C.c_uint8)), off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                  olen.ctypes.data_as(C.POINTER(C.c_uint32))))
+        btr = [ops[int(off[i]):int(off[i]) + int(olen[i])].tobytes() for i in range(n)]
+        if not rows:
+            return scores[:n], btr
+        r0 = np.zeros(max(total, 1), dtype=np.uint8)
+        r1 = np.zeros(max(total, 1), dtype=np.uint8)
+        _check(lib().tracyhip_alignment_rows(self._h, C.byref(pr), MEM_HOST, ops.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                             off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                             olen.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                             r0.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                             r1.ctypes.data_as(C.POINTER(C.c_uint8))))
+        rws = [(r0[int(off[i]):int(off[i]) + int(olen[i])].tobytes(), r1[int(off[i]):int(off[i]) + int(olen[i])].tobytes())
+               for i in range(n)]
+        return scores[:n], btr, rws

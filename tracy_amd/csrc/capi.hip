@@ -1,0 +1,504 @@
+// capi.hip -- the extern "C" boundary (include/tracy_hip.h): argument checking, staging, bucketing of
+// pairs by strip height K, workspace chunking, kernel launches.  No compute happens on the host and
+// there is no CPU fallback: every entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tracy_hip.h"
+#include "capi_internal.h"
+#include "launch.h"
+
+using namespace tracyhip;
+
+namespace tracyhip {
+
+static thread_local std::string g_last_error;
+
+int set_error(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+hipError_t DevBuf::ensure(size_t bytes) {
+  if (bytes <= cap) return hipSuccess;
+  if (p) {
+    hipError_t e = hipFree(p);
+    p = nullptr;
+    cap = 0;
+    if (e != hipSuccess) return e;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {  // retry with the exact size before giving up
+    (void)hipGetLastError();
+    want = bytes;
+    e = hipMalloc(&p, want);
+  }
+  if (e == hipSuccess) cap = want;
+  else p = nullptr;
+  return e;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+hipError_t PinBuf::ensure(size_t bytes) {
+  if (bytes <= cap) return hipSuccess;
+  if (p) (void)hipHostFree(p);
+  p = nullptr;
+  cap = 0;
+  size_t want = bytes + bytes / 4 + 256;
+  hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+  if (e == hipSuccess) cap = want;
+  else p = nullptr;
+  return e;
+}
+void PinBuf::release() {
+  if (p) (void)hipHostFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+// smallest P*K over the strip heights compiled for the mode; ties go to the taller strip
+int choose_k(uint32_t m, int mode) {
+  static const int ks_all[] = {16, 8, 4};
+  static const int ks_prof[] = {8, 4};
+  const int* ks = (mode == MODE_PROF) ? ks_prof : ks_all;
+  const int nk = (mode == MODE_PROF) ? 2 : 3;
+  int best = ks[0];
+  uint64_t best_cost = ~0ull;
+  for (int i = 0; i < nk; ++i) {
+    const uint64_t cost = (uint64_t)num_passes(m ? m : 1, ks[i]) * ks[i];
+    if (cost < best_cost) { best_cost = cost; best = ks[i]; }
+  }
+  return best;
+}
+
+uint64_t seqset_extent(const tracyhip_seqset& s) {
+  uint64_t ext = 0;
+  const uint64_t mult = (s.kind == TRACYHIP_SEQ_PROFILE) ? 6 : 1;
+  for (uint32_t i = 0; i < s.count; ++i) ext = std::max<uint64_t>(ext, s.offset[i] + mult * s.length[i]);
+  return ext;
+}
+
+}  // namespace tracyhip
+
+// ---- small device helpers ------------------------------------------------------------------------
+__global__ void encode_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)base_code(in[i]);
+}
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess)                                                                           \
+      return set_error(_e == hipErrorOutOfMemory ? TRACYHIP_ERR_OOM : TRACYHIP_ERR_HIP, "%s failed: %s (%s:%d)", \
+                       #expr, hipGetErrorString(_e), __FILE__, __LINE__);                           \
+  } while (0)
+
+namespace tracyhip {
+
+int ctx_begin(tracyhip_ctx* ctx) {
+  if (!ctx) return set_error(TRACYHIP_ERR_ARG, "null context");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return TRACYHIP_OK;
+}
+
+int stage_in(tracyhip_ctx* ctx, DevBuf& buf, const void* src, uint64_t bytes, int mem, const void** dev) {
+  if (mem == TRACYHIP_MEM_DEVICE || bytes == 0) {
+    *dev = src;
+    return TRACYHIP_OK;
+  }
+  HIP_TRY(buf.ensure(bytes));
+  HIP_TRY(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  *dev = buf.p;
+  return TRACYHIP_OK;
+}
+
+int check_params(const tracyhip_params* prm, uint64_t max_mn) {
+  if (!prm) return set_error(TRACYHIP_ERR_ARG, "null params");
+  auto ab = [](int32_t x) { return (int64_t)(x < 0 ? -(int64_t)x : x); };
+  if (ab(prm->match) > 2047 || ab(prm->mismatch) > 2047)
+    return set_error(TRACYHIP_ERR_RANGE, "|match|,|mismatch| must be <= 2047 (int16 query profile x16)");
+  const int64_t c = ab(prm->go) + ab(prm->ge) + std::max(ab(prm->match), ab(prm->mismatch));
+  if ((int64_t)(max_mn + 2) * c + 1000000 >= (1ll << 27))
+    return set_error(TRACYHIP_ERR_RANGE, "(m+n) * cost exceeds the exact range of the x16 int32 kernels");
+  return TRACYHIP_OK;
+}
+
+// ---- the DP driver shared by gotoh/needle score/align -----------------------------------------------
+int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, bool needle, bool trace,
+           int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len) {
+  const uint32_t np = (uint32_t)pb.desc.size();
+  if (np == 0) return TRACYHIP_OK;
+  hipStream_t st = ctx->stream;
+
+  // order: strip height, then longest first (long problems start early, short ones fill the tail)
+  std::vector<uint32_t> order(np);
+  for (uint32_t i = 0; i < np; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    if (pb.k[x] != pb.k[y]) return pb.k[x] > pb.k[y];
+    return (uint64_t)pb.desc[x].m * pb.desc[x].n > (uint64_t)pb.desc[y].m * pb.desc[y].n;
+  });
+
+  // workspace plan: chunks of consecutive (sorted) pairs whose traceback words fit the limit
+  const uint64_t word_bytes = needle ? 4 : 8;
+  uint64_t limit = ctx->ws_limit;
+  if (limit == 0) {
+    size_t fr = 0, tot = 0;
+    HIP_TRY(hipMemGetInfo(&fr, &tot));
+    limit = (uint64_t)(fr * 0.70);
+  }
+  HIP_TRY(ctx->h_desc.ensure(sizeof(PairDesc) * (size_t)np));
+  PairDesc* hd = static_cast<PairDesc*>(ctx->h_desc.p);
+  struct Chunk { uint32_t lo, hi; uint64_t words, scratch; };
+  std::vector<Chunk> chunks;
+  {
+    Chunk c{0, 0, 0, 0};
+    for (uint32_t j = 0; j < np; ++j) {
+      PairDesc d = pb.desc[order[j]];
+      const int K = pb.k[order[j]];
+      const uint32_t P = (d.m && d.n) ? num_passes(d.m, K) : 0;
+      const uint64_t words = trace ? (uint64_t)P * steps_per_pass(d.n) * 64 : 0;
+      const uint64_t scr = (P > 1) ? (uint64_t)d.n + 2 : 0;
+      if (words * word_bytes > limit)
+        return set_error(TRACYHIP_ERR_OOM, "one pair needs %llu bytes of traceback planes, workspace limit is %llu",
+                         (unsigned long long)(words * word_bytes), (unsigned long long)limit);
+      if (c.hi > c.lo && (c.words + words) * word_bytes > limit) {
+        chunks.push_back(c);
+        c = Chunk{j, j, 0, 0};
+      }
+      d.bits_off = c.words;
+      d.scratch_off = c.scratch;
+      c.words += words;
+      c.scratch += scr;
+      c.hi = j + 1;
+      hd[j] = d;
+    }
+    chunks.push_back(c);
+  }
+  uint64_t max_words = 0, max_scr = 0;
+  for (const Chunk& c : chunks) { max_words = std::max(max_words, c.words); max_scr = std::max(max_scr, c.scratch); }
+  HIP_TRY(ctx->d_desc.ensure(sizeof(PairDesc) * (size_t)np));
+  HIP_TRY(hipMemcpyAsync(ctx->d_desc.p, hd, sizeof(PairDesc) * (size_t)np, hipMemcpyHostToDevice, st));
+  if (trace) HIP_TRY(ctx->d_bits.ensure(max_words * word_bytes));
+  if (max_scr) HIP_TRY(ctx->d_scratch.ensure(max_scr * 8));
+  HIP_TRY(ctx->d_err.ensure(sizeof(int32_t)));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t), st));
+
+  DpArgs a{};
+  a.a1 = pb.d_a1;
+  a.a2 = pb.d_a2;
+  a.bits = static_cast<uint64_t*>(ctx->d_bits.p);
+  a.bits32 = static_cast<uint32_t*>(ctx->d_bits.p);
+  a.scratch = static_cast<int32_t*>(ctx->d_scratch.p);
+  a.scores = d_scores;
+  a.err = static_cast<int32_t*>(ctx->d_err.p);
+  a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge;
+  a.hfree = prm->hfree; a.vfree = prm->vfree;
+  const PairDesc* dd = static_cast<const PairDesc*>(ctx->d_desc.p);
+
+  for (const Chunk& c : chunks) {
+    uint32_t j = c.lo;
+    while (j < c.hi) {  // one launch per run of equal K
+      uint32_t e = j;
+      const int K = pb.k[order[j]];
+      while (e < c.hi && pb.k[order[e]] == K) ++e;
+      a.pairs = dd + j;
+      HIP_TRY(needle ? launch_needle(pb.mode, K, trace, a, e - j, st) : launch_gotoh(pb.mode, K, trace, a, e - j, st));
+      if (trace) {
+        WalkArgs wa{};
+        wa.pairs = dd + j;
+        wa.bits = a.bits;
+        wa.ops = d_ops;
+        wa.ops_off = d_ops_off;
+        wa.ops_len = d_ops_len;
+        wa.err = a.err;
+        wa.npairs = e - j;
+        wa.K = K;
+        HIP_TRY(needle ? launch_needle_walk(wa, a.bits32, st) : launch_gotoh_walk(wa, st));
+      }
+      j = e;
+    }
+  }
+  int32_t herr = 0;
+  HIP_TRY(hipMemcpyAsync(&herr, ctx->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (herr & 1) return set_error(TRACYHIP_ERR_RANGE, "a query-profile score does not fit int16 (profile values too large)");
+  if (herr & 2) return set_error(TRACYHIP_ERR_RANGE, "traceback left the matrix (degenerate scoring parameters)");
+  return TRACYHIP_OK;
+}
+
+// validate a pair list and turn it into device-side descriptors + staged payloads
+int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool needle, DpProblem& pb, uint64_t* max_mn) {
+  if (!pairs) return set_error(TRACYHIP_ERR_ARG, "null pairs");
+  const tracyhip_seqset& s1 = pairs->a1;
+  const tracyhip_seqset& s2 = pairs->a2;
+  if (pairs->npairs && (!s1.offset || !s1.length || !s2.offset || !s2.length))
+    return set_error(TRACYHIP_ERR_ARG, "null offset/length arrays");
+  if (s1.kind == TRACYHIP_SEQ_CHAR && s2.kind == TRACYHIP_SEQ_CHAR) pb.mode = MODE_CHAR;
+  else if (s1.kind == TRACYHIP_SEQ_PROFILE && s2.kind == TRACYHIP_SEQ_CHAR) pb.mode = MODE_QP;
+  else if (s1.kind == TRACYHIP_SEQ_PROFILE && s2.kind == TRACYHIP_SEQ_PROFILE) pb.mode = MODE_PROF;
+  else return set_error(TRACYHIP_ERR_ARG, "unsupported sequence kinds (a1 CHAR with a2 PROFILE)");
+  if (needle && pb.mode == MODE_QP)
+    return set_error(TRACYHIP_ERR_ARG, "needle takes two strings or two profiles (needle.h:12-14)");
+  pb.a1_profile = s1.kind == TRACYHIP_SEQ_PROFILE;
+  pb.a2_profile = s2.kind == TRACYHIP_SEQ_PROFILE;
+  const uint64_t e1 = seqset_extent(s1), e2 = seqset_extent(s2);
+  if ((e1 && !s1.data) || (e2 && !s2.data)) return set_error(TRACYHIP_ERR_ARG, "null sequence data");
+  int rc;
+  if ((rc = stage_in(ctx, ctx->d_in1, s1.data, e1 * (pb.a1_profile ? 4 : 1), mem, &pb.d_a1))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_in2, s2.data, e2 * (pb.a2_profile ? 4 : 1), mem, &pb.d_a2))) return rc;
+  pb.d_a2_chars = pb.d_a2;
+  if (pb.mode == MODE_QP && e2) {  // reference characters -> profile-row codes (align.h:121-136)
+    HIP_TRY(ctx->d_codes.ensure(e2));
+    hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((e2 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<const uint8_t*>(pb.d_a2), static_cast<uint8_t*>(ctx->d_codes.p), e2);
+    HIP_TRY(hipGetLastError());
+    pb.d_a2 = ctx->d_codes.p;
+  }
+  pb.desc.resize(pairs->npairs);
+  pb.k.resize(pairs->npairs);
+  *max_mn = 0;
+  for (uint32_t i = 0; i < pairs->npairs; ++i) {
+    const uint32_t i1 = pairs->a1_index ? pairs->a1_index[i] : i;
+    const uint32_t i2 = pairs->a2_index ? pairs->a2_index[i] : i;
+    if (i1 >= s1.count || i2 >= s2.count) return set_error(TRACYHIP_ERR_ARG, "pair %u indexes past the sequence sets", i);
+    PairDesc d{};
+    d.a1_off = s1.offset[i1];
+    d.a2_off = s2.offset[i2];
+    d.m = s1.length[i1];
+    d.n = s2.length[i2];
+    d.a1_stride = d.m;
+    d.a2_stride = d.n;
+    d.out = i;
+    pb.desc[i] = d;
+    pb.k[i] = choose_k(d.m, pb.mode);
+    *max_mn = std::max<uint64_t>(*max_mn, (uint64_t)d.m + d.n);
+  }
+  return TRACYHIP_OK;
+}
+
+}  // namespace tracyhip
+
+// ====================================================================================================
+extern "C" {
+
+const char* tracyhip_last_error(void) { return g_last_error.c_str(); }
+const char* tracyhip_version(void) { return "tracy_amd 0.1 (gfx950)"; }
+
+int tracyhip_device_count(int* count) {
+  if (!count) return set_error(TRACYHIP_ERR_ARG, "null count");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *count = 0;
+    return set_error(TRACYHIP_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return TRACYHIP_OK;
+}
+
+int tracyhip_create(int device, tracyhip_ctx** out) {
+  if (!out) return set_error(TRACYHIP_ERR_ARG, "null out pointer");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return set_error(TRACYHIP_ERR_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
+  }
+  if (device < 0 || device >= n) return set_error(TRACYHIP_ERR_ARG, "device %d out of range [0,%d)", device, n);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_error(TRACYHIP_ERR_NODEVICE, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
+  HIP_TRY(hipSetDevice(device));
+  tracyhip_ctx* c = new tracyhip_ctx();
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return set_error(TRACYHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  c->own_stream = c->stream;
+  *out = c;
+  return TRACYHIP_OK;
+}
+
+int tracyhip_destroy(tracyhip_ctx* c) {
+  if (!c) return TRACYHIP_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  c->release_all();
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return TRACYHIP_OK;
+}
+
+int tracyhip_set_stream(tracyhip_ctx* c, void* s) {
+  if (!c) return set_error(TRACYHIP_ERR_ARG, "null context");
+  c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
+  return TRACYHIP_OK;
+}
+
+int tracyhip_set_workspace_limit(tracyhip_ctx* c, uint64_t bytes) {
+  if (!c) return set_error(TRACYHIP_ERR_ARG, "null context");
+  c->ws_limit = bytes;
+  return TRACYHIP_OK;
+}
+
+int tracyhip_synchronize(tracyhip_ctx* c) {
+  int rc = ctx_begin(c);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return TRACYHIP_OK;
+}
+
+static int dp_entry(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm, int mem, bool needle,
+                    bool trace, int32_t* scores, uint8_t* ops, const uint64_t* ops_offset, uint32_t* ops_len) {
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  if (mem != TRACYHIP_MEM_HOST && mem != TRACYHIP_MEM_DEVICE) return set_error(TRACYHIP_ERR_ARG, "bad mem kind");
+  if (!pairs) return set_error(TRACYHIP_ERR_ARG, "null pairs");
+  if (!trace && !scores && pairs->npairs) return set_error(TRACYHIP_ERR_ARG, "null scores");
+  if (trace && pairs->npairs && (!ops || !ops_offset || !ops_len)) return set_error(TRACYHIP_ERR_ARG, "null ops/ops_offset/ops_len");
+  DpProblem pb;
+  uint64_t max_mn = 0;
+  if ((rc = build_problem(ctx, pairs, mem, needle, pb, &max_mn))) return rc;
+  if ((rc = check_params(prm, max_mn))) return rc;
+  const uint32_t np = pairs->npairs;
+  if (np == 0) return TRACYHIP_OK;
+  hipStream_t st = ctx->stream;
+
+  int32_t* d_scores = scores;
+  uint8_t* d_ops = ops;
+  uint32_t* d_len = ops_len;
+  uint64_t ops_total = 0;
+  if (trace)
+    for (uint32_t i = 0; i < np; ++i) ops_total = std::max<uint64_t>(ops_total, ops_offset[i] + pb.desc[i].m + pb.desc[i].n);
+  if (mem == TRACYHIP_MEM_HOST) {
+    if (scores) { HIP_TRY(ctx->d_scores.ensure(sizeof(int32_t) * (size_t)np)); d_scores = static_cast<int32_t*>(ctx->d_scores.p); }
+    if (trace) {
+      HIP_TRY(ctx->d_ops.ensure(ops_total ? ops_total : 1));
+      HIP_TRY(ctx->d_ops_len.ensure(sizeof(uint32_t) * (size_t)np));
+      d_ops = static_cast<uint8_t*>(ctx->d_ops.p);
+      d_len = static_cast<uint32_t*>(ctx->d_ops_len.p);
+    }
+  }
+  const uint64_t* d_off = nullptr;
+  if (trace) {
+    HIP_TRY(ctx->h_off.ensure(sizeof(uint64_t) * (size_t)np));
+    std::memcpy(ctx->h_off.p, ops_offset, sizeof(uint64_t) * (size_t)np);
+    HIP_TRY(ctx->d_ops_off.ensure(sizeof(uint64_t) * (size_t)np));
+    HIP_TRY(hipMemcpyAsync(ctx->d_ops_off.p, ctx->h_off.p, sizeof(uint64_t) * (size_t)np, hipMemcpyHostToDevice, st));
+    d_off = static_cast<const uint64_t*>(ctx->d_ops_off.p);
+  }
+  if ((rc = run_dp(ctx, pb, prm, needle, trace, d_scores, d_ops, d_off, d_len))) return rc;
+  if (mem == TRACYHIP_MEM_HOST) {
+    if (scores) HIP_TRY(hipMemcpyAsync(scores, d_scores, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost, st));
+    if (trace) {
+      if (ops_total) HIP_TRY(hipMemcpyAsync(ops, d_ops, ops_total, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(ops_len, d_len, sizeof(uint32_t) * (size_t)np, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  return TRACYHIP_OK;
+}
+
+int tracyhip_gotoh_score(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm, int mem, int32_t* scores) {
+  return dp_entry(ctx, pairs, prm, mem, false, false, scores, nullptr, nullptr, nullptr);
+}
+int tracyhip_gotoh_align(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm, int mem,
+                         int32_t* scores, uint8_t* ops, const uint64_t* ops_offset, uint32_t* ops_len) {
+  return dp_entry(ctx, pairs, prm, mem, false, true, scores, ops, ops_offset, ops_len);
+}
+int tracyhip_needle_score(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm, int mem, int32_t* scores) {
+  return dp_entry(ctx, pairs, prm, mem, true, false, scores, nullptr, nullptr, nullptr);
+}
+int tracyhip_needle_align(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm, int mem,
+                          int32_t* scores, uint8_t* ops, const uint64_t* ops_offset, uint32_t* ops_len) {
+  return dp_entry(ctx, pairs, prm, mem, true, true, scores, ops, ops_offset, ops_len);
+}
+
+int tracyhip_alignment_rows(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, const uint8_t* ops,
+                            const uint64_t* ops_offset, const uint32_t* ops_len, uint8_t* rows0, uint8_t* rows1) {
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  if (!pairs) return set_error(TRACYHIP_ERR_ARG, "null pairs");
+  const uint32_t np = pairs->npairs;
+  if (np == 0) return TRACYHIP_OK;
+  if (!ops || !ops_offset || !ops_len || !rows0 || !rows1) return set_error(TRACYHIP_ERR_ARG, "null ops/rows");
+  // kinds are taken as given here (no query-profile encoding): build descriptors by hand
+  const tracyhip_seqset& s1 = pairs->a1;
+  const tracyhip_seqset& s2 = pairs->a2;
+  const bool p1 = s1.kind == TRACYHIP_SEQ_PROFILE, p2 = s2.kind == TRACYHIP_SEQ_PROFILE;
+  hipStream_t st = ctx->stream;
+  const void *d_a1, *d_a2;
+  if ((rc = stage_in(ctx, ctx->d_in1, s1.data, seqset_extent(s1) * (p1 ? 4 : 1), mem, &d_a1))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_in2, s2.data, seqset_extent(s2) * (p2 ? 4 : 1), mem, &d_a2))) return rc;
+  HIP_TRY(ctx->h_desc.ensure(sizeof(PairDesc) * (size_t)np));
+  PairDesc* hd = static_cast<PairDesc*>(ctx->h_desc.p);
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < np; ++i) {
+    const uint32_t i1 = pairs->a1_index ? pairs->a1_index[i] : i;
+    const uint32_t i2 = pairs->a2_index ? pairs->a2_index[i] : i;
+    if (i1 >= s1.count || i2 >= s2.count) return set_error(TRACYHIP_ERR_ARG, "pair %u indexes past the sequence sets", i);
+    PairDesc d{};
+    d.a1_off = s1.offset[i1]; d.a2_off = s2.offset[i2];
+    d.m = s1.length[i1]; d.n = s2.length[i2];
+    d.a1_stride = d.m; d.a2_stride = d.n; d.out = i;
+    hd[i] = d;
+    if (mem == TRACYHIP_MEM_HOST && ops_len[i] > d.m + d.n) return set_error(TRACYHIP_ERR_ARG, "ops_len[%u] exceeds m+n", i);
+    total = std::max<uint64_t>(total, ops_offset[i] + d.m + d.n);
+  }
+  HIP_TRY(ctx->d_desc.ensure(sizeof(PairDesc) * (size_t)np));
+  HIP_TRY(hipMemcpyAsync(ctx->d_desc.p, hd, sizeof(PairDesc) * (size_t)np, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx->h_off.ensure(sizeof(uint64_t) * (size_t)np));
+  std::memcpy(ctx->h_off.p, ops_offset, sizeof(uint64_t) * (size_t)np);
+  HIP_TRY(ctx->d_ops_off.ensure(sizeof(uint64_t) * (size_t)np));
+  HIP_TRY(hipMemcpyAsync(ctx->d_ops_off.p, ctx->h_off.p, sizeof(uint64_t) * (size_t)np, hipMemcpyHostToDevice, st));
+  RowsArgs ra{};
+  ra.pairs = static_cast<const PairDesc*>(ctx->d_desc.p);
+  ra.a1 = d_a1; ra.a2 = d_a2;
+  ra.a1_profile = p1; ra.a2_profile = p2;
+  ra.a2_onehot = (p1 && !p2);  // gotoh(profile, _createProfile(string)): row 1 shows consensus chars of the one-hot profile
+  ra.ops_off = static_cast<const uint64_t*>(ctx->d_ops_off.p);
+  ra.npairs = np;
+  if (mem == TRACYHIP_MEM_HOST) {
+    HIP_TRY(ctx->d_ops.ensure(total ? total : 1));
+    HIP_TRY(ctx->d_ops_len.ensure(sizeof(uint32_t) * (size_t)np));
+    HIP_TRY(ctx->d_rows0.ensure(total ? total : 1));
+    HIP_TRY(ctx->d_rows1.ensure(total ? total : 1));
+    if (total) HIP_TRY(hipMemcpyAsync(ctx->d_ops.p, ops, total, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->d_ops_len.p, ops_len, sizeof(uint32_t) * (size_t)np, hipMemcpyHostToDevice, st));
+    ra.ops = static_cast<const uint8_t*>(ctx->d_ops.p);
+    ra.ops_len = static_cast<const uint32_t*>(ctx->d_ops_len.p);
+    ra.rows0 = static_cast<uint8_t*>(ctx->d_rows0.p);
+    ra.rows1 = static_cast<uint8_t*>(ctx->d_rows1.p);
+  } else {
+    ra.ops = ops; ra.ops_len = ops_len; ra.rows0 = rows0; ra.rows1 = rows1;
+  }
+  HIP_TRY(launch_alignment_rows(ra, st));
+  if (mem == TRACYHIP_MEM_HOST && total) {
+    HIP_TRY(hipMemcpyAsync(rows0, ra.rows0, total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(rows1, ra.rows1, total, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  return TRACYHIP_OK;
+}
+
+}  // extern "C"

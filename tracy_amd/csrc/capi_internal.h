@@ -1,0 +1,72 @@
+// capi_internal.h -- context and helpers shared by the C-ABI translation units.
+#ifndef TRACY_AMD_CAPI_INTERNAL_H
+#define TRACY_AMD_CAPI_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/tracy_hip.h"
+#include "dp_kernels.h"
+
+namespace tracyhip {
+
+struct DevBuf {  // grow-only device buffer
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes);
+  void release();
+};
+struct PinBuf {  // grow-only pinned host buffer (descriptor uploads)
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes);
+  void release();
+};
+
+int set_error(int code, const char* fmt, ...);
+int choose_k(uint32_t m, int mode);
+uint64_t seqset_extent(const tracyhip_seqset& s);
+
+// a validated batch: descriptors in caller order + device pointers of the payloads
+struct DpProblem {
+  int mode = MODE_CHAR;
+  bool a1_profile = false, a2_profile = false;
+  const void* d_a1 = nullptr;
+  const void* d_a2 = nullptr;        // MODE_QP: encoded codes
+  const void* d_a2_chars = nullptr;  // the raw a2 payload on the device
+  std::vector<PairDesc> desc;
+  std::vector<int> k;
+};
+
+}  // namespace tracyhip
+
+struct tracyhip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  uint64_t ws_limit = 0;
+  tracyhip::DevBuf d_desc, d_bits, d_scratch, d_in1, d_in2, d_codes, d_scores, d_ops, d_ops_off, d_ops_len, d_err,
+      d_rows0, d_rows1;
+  tracyhip::DevBuf d_tmp[8];  // pipeline intermediates (align_traces / decompose)
+  tracyhip::PinBuf h_desc, h_off, h_tmp;
+  void release_all() {
+    tracyhip::DevBuf* all[] = {&d_desc, &d_bits, &d_scratch, &d_in1, &d_in2, &d_codes, &d_scores, &d_ops,
+                               &d_ops_off, &d_ops_len, &d_err, &d_rows0, &d_rows1};
+    for (auto* b : all) b->release();
+    for (auto& b : d_tmp) b.release();
+    h_desc.release();
+    h_off.release();
+    h_tmp.release();
+  }
+};
+
+namespace tracyhip {
+int ctx_begin(tracyhip_ctx* ctx);
+int stage_in(tracyhip_ctx* ctx, DevBuf& buf, const void* src, uint64_t bytes, int mem, const void** dev);
+int check_params(const tracyhip_params* prm, uint64_t max_mn);
+int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, bool needle, bool trace,
+           int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len);
+int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool needle, DpProblem& pb, uint64_t* max_mn);
+}  // namespace tracyhip
+#endif

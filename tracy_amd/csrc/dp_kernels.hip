@@ -1,0 +1,165 @@
+// dp_kernels.hip -- gfx950 __global__ wrappers and launchers for the wave bodies in dp_kernels.h.
+// One 64-thread workgroup (= one wave) per pair; the launch grid is the number of pairs in the bucket
+// (thousands), so every CU holds several independent waves and nothing is shared between workgroups
+// (no inter-workgroup traffic => no XCD placement concerns; block b lands on XCD b % 8 and only ever
+// touches its own pair's inputs and traceback stripe).
+#include <hip/hip_runtime.h>
+
+#include "dp_kernels.h"
+#include "launch.h"
+
+namespace tracyhip {
+
+struct DeviceWave {
+  __device__ __forceinline__ uint32_t lane() const { return threadIdx.x; }
+  // lane L <- lane L-1 (wave_shr:1); lane 0 keeps `old` = 0 and is overwritten by the caller
+  __device__ __forceinline__ int32_t shift_up(int32_t x) const {
+    return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false);
+  }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+  __device__ __forceinline__ void sync_global() const { __threadfence(); }
+  __device__ __forceinline__ char* lds() const {
+    extern __shared__ __attribute__((aligned(16))) char tracy_smem[];
+    return tracy_smem;
+  }
+};
+
+template <int K, int MODE, bool TRACE>
+__global__ __launch_bounds__(64) void gotoh_kernel(DpArgs a) {
+  DeviceWave w;
+  gotoh_body<DeviceWave, K, MODE, TRACE>(w, a, blockIdx.x);
+}
+
+template <int K, int MODE, bool TRACE>
+__global__ __launch_bounds__(64) void needle_kernel(DpArgs a) {
+  DeviceWave w;
+  needle_body<DeviceWave, K, MODE, TRACE>(w, a, blockIdx.x);
+}
+
+__global__ __launch_bounds__(64) void gotoh_walk_kernel(WalkArgs a) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.npairs) gotoh_walk_one(a, i);
+}
+
+__global__ __launch_bounds__(64) void needle_walk_kernel(WalkArgs a, const uint32_t* bits32) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.npairs) needle_walk_one(a, bits32, i);
+}
+
+// _createAlignment (align.h:196-223 / 254-293): one lane per output column, forward order.
+// ops are in push order, so column ai corresponds to ops[L-1-ai]; the consumed-row / consumed-column
+// counts at ai are prefix sums, computed here by one sequential lane per pair (O(L), L <= m+n).
+__global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.npairs) return;
+  const PairDesc d = a.pairs[i];
+  const uint64_t off = a.ops_off[d.out];
+  const uint32_t L = a.ops_len[d.out];
+  const uint8_t* ops = a.ops + off;
+  uint8_t* r0 = a.rows0 + off;
+  uint8_t* r1 = a.rows1 + off;
+  uint32_t row = 0, col = 0;
+  for (uint32_t ai = 0; ai < L; ++ai) {
+    const uint8_t op = ops[L - 1 - ai];
+    uint8_t c0 = '-', c1 = '-';
+    if (op != 'h') {  // consumes a1
+      if (a.a1_profile) {
+        float p[6];
+        for (int k = 0; k < 6; ++k) p[k] = static_cast<const float*>(a.a1)[d.a1_off + (uint64_t)k * d.a1_stride + row];
+        c0 = cons_char(p);
+      } else {
+        c0 = static_cast<const uint8_t*>(a.a1)[d.a1_off + row];
+      }
+      ++row;
+    }
+    if (op != 'v') {  // consumes a2
+      if (a.a2_profile) {
+        float p[6];
+        for (int k = 0; k < 6; ++k) p[k] = static_cast<const float*>(a.a2)[d.a2_off + (uint64_t)k * d.a2_stride + col];
+        c1 = cons_char(p);
+      } else {
+        c1 = static_cast<const uint8_t*>(a.a2)[d.a2_off + col];
+        if (a.a2_onehot) {  // consensus character of _createProfile(string) (align.h:121-136, 254-270)
+          const uint32_t code = base_code(c1);
+          c1 = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'T' : code == 6 ? 'A' : 'N';
+        }
+      }
+      ++col;
+    }
+    r0[ai] = c0;
+    r1[ai] = c1;
+  }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------
+template <int K, int MODE, bool TRACE>
+static hipError_t launch_gotoh_t(const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  hipLaunchKernelGGL((gotoh_kernel<K, MODE, TRACE>), dim3(npairs), dim3(64), lds_bytes(MODE, K), s, a);
+  return hipGetLastError();
+}
+template <int K, int MODE, bool TRACE>
+static hipError_t launch_needle_t(const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  hipLaunchKernelGGL((needle_kernel<K, MODE, TRACE>), dim3(npairs), dim3(64), lds_bytes(MODE, K), s, a);
+  return hipGetLastError();
+}
+
+template <int MODE, bool TRACE>
+static hipError_t launch_gotoh_k(int K, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  switch (K) {
+    case 4: return launch_gotoh_t<4, MODE, TRACE>(a, npairs, s);
+    case 8: return launch_gotoh_t<8, MODE, TRACE>(a, npairs, s);
+    case 16:
+      if constexpr (MODE != MODE_PROF) return launch_gotoh_t<16, MODE, TRACE>(a, npairs, s);
+      return hipErrorInvalidValue;
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_gotoh(int mode, int K, bool trace, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  if (npairs == 0) return hipSuccess;
+  switch (mode) {
+    case MODE_CHAR: return trace ? launch_gotoh_k<MODE_CHAR, true>(K, a, npairs, s) : launch_gotoh_k<MODE_CHAR, false>(K, a, npairs, s);
+    case MODE_QP: return trace ? launch_gotoh_k<MODE_QP, true>(K, a, npairs, s) : launch_gotoh_k<MODE_QP, false>(K, a, npairs, s);
+    case MODE_PROF: return trace ? launch_gotoh_k<MODE_PROF, true>(K, a, npairs, s) : launch_gotoh_k<MODE_PROF, false>(K, a, npairs, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int MODE, bool TRACE>
+static hipError_t launch_needle_k(int K, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  switch (K) {
+    case 4: return launch_needle_t<4, MODE, TRACE>(a, npairs, s);
+    case 8: return launch_needle_t<8, MODE, TRACE>(a, npairs, s);
+    case 16:
+      if constexpr (MODE != MODE_PROF) return launch_needle_t<16, MODE, TRACE>(a, npairs, s);
+      return hipErrorInvalidValue;
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_needle(int mode, int K, bool trace, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  if (npairs == 0) return hipSuccess;
+  switch (mode) {
+    case MODE_CHAR: return trace ? launch_needle_k<MODE_CHAR, true>(K, a, npairs, s) : launch_needle_k<MODE_CHAR, false>(K, a, npairs, s);
+    case MODE_PROF: return trace ? launch_needle_k<MODE_PROF, true>(K, a, npairs, s) : launch_needle_k<MODE_PROF, false>(K, a, npairs, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_gotoh_walk(const WalkArgs& a, hipStream_t s) {
+  if (a.npairs == 0) return hipSuccess;
+  hipLaunchKernelGGL(gotoh_walk_kernel, dim3((a.npairs + 63) / 64), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_needle_walk(const WalkArgs& a, const uint32_t* bits32, hipStream_t s) {
+  if (a.npairs == 0) return hipSuccess;
+  hipLaunchKernelGGL(needle_walk_kernel, dim3((a.npairs + 63) / 64), dim3(64), 0, s, a, bits32);
+  return hipGetLastError();
+}
+hipError_t launch_alignment_rows(const RowsArgs& a, hipStream_t s) {
+  if (a.npairs == 0) return hipSuccess;
+  hipLaunchKernelGGL(alignment_rows_kernel, dim3((a.npairs + 63) / 64), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace tracyhip

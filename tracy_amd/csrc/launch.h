@@ -1,0 +1,32 @@
+// launch.h -- host-visible launcher declarations (kernels live in dp_kernels.hip).
+#ifndef TRACY_AMD_LAUNCH_H
+#define TRACY_AMD_LAUNCH_H
+
+#include <hip/hip_runtime.h>
+
+#include "dp_kernels.h"
+
+namespace tracyhip {
+
+struct RowsArgs {
+  const PairDesc* pairs;
+  const void* a1;
+  const void* a2;
+  int32_t a1_profile, a2_profile;
+  int32_t a2_onehot;  // a2 is a string standing for its one-hot profile: show _profileConsChar of that profile
+  const uint8_t* ops;
+  const uint64_t* ops_off;  // indexed by PairDesc::out
+  const uint32_t* ops_len;
+  uint8_t* rows0;
+  uint8_t* rows1;
+  uint32_t npairs;
+};
+
+hipError_t launch_gotoh(int mode, int K, bool trace, const DpArgs& a, uint32_t npairs, hipStream_t s);
+hipError_t launch_needle(int mode, int K, bool trace, const DpArgs& a, uint32_t npairs, hipStream_t s);
+hipError_t launch_gotoh_walk(const WalkArgs& a, hipStream_t s);
+hipError_t launch_needle_walk(const WalkArgs& a, const uint32_t* bits32, hipStream_t s);
+hipError_t launch_alignment_rows(const RowsArgs& a, hipStream_t s);
+
+}  // namespace tracyhip
+#endif

@@ -139,3 +139,43 @@ def test_error_reporting(ctx):
     with pytest.raises(tracy_amd.TracyHipError) as e:
         ctx.score([big], [b"ACGTACGT"], SC + (1, 0))
     assert e.value.code == tracy_amd.capi.ERR_RANGE
+
+
+def synth_trace_profile(rng, ref, mf, reverse, noise=0.02):
+    """profile of a trace copied from `ref` (or its reverse complement) with substitutions/indels"""
+    from sage_oracle import revcomp
+    src = revcomp(ref) if reverse else ref
+    start = int(rng.integers(0, max(1, len(src) - mf)))
+    seq = noisy_copy(rng, src[start:start + mf + 20], noise)[:mf]
+    seq = (seq + rand_seq(rng, mf))[:mf]
+    p = np.zeros((6, mf), dtype=np.float32)
+    idx = {65: 0, 67: 1, 71: 2, 84: 3}
+    for j, ch in enumerate(seq):
+        if ch not in idx:
+            ch = int(rng.choice(list(b"ACGT")))
+        main = np.float32(rng.uniform(0.7, 1.0))
+        rest = rng.random(3).astype(np.float32)
+        rest = rest / rest.sum() * (np.float32(1) - main)
+        col = np.zeros(4, dtype=np.float32)
+        col[idx[ch]] = main
+        col[[k for k in range(4) if k != idx[ch]]] = rest
+        p[:4, j] = col
+    return p
+
+
+def test_align_traces_pipeline(ctx):
+    """tracyhip_align_traces == sage.h:191-311 composed from the oracle"""
+    from sage_oracle import align_trace
+    rng = np.random.default_rng(42)
+    refs, profs = [], []
+    for i, (mf, n) in enumerate([(300, 900), (420, 1500), (260, 700), (1000, 2500), (150, 400), (90, 300)]):
+        ref = rand_seq(rng, n, b"ACGTACGTACGTACGTN")
+        refs.append(ref)
+        profs.append(synth_trace_profile(rng, ref, mf, reverse=bool(i % 2)))
+    got = ctx.align_traces(profs, refs, SC, 50, 50)
+    for i in range(len(refs)):
+        want = align_trace(profs[i], refs[i], SC, 50, 50)
+        for k in ("score_fwd", "score_rev", "forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
+            assert int(got[k][i]) == int(want[k]), (i, k)
+        assert got["btr"][i] == want["btr"], i
+    assert sorted(got["forward"].tolist()) == [0, 0, 0, 1, 1, 1]

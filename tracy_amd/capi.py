@@ -208,3 +208,52 @@ class Context:
         rws = [(r0[int(off[i]):int(off[i]) + int(olen[i])].tobytes(), r1[int(off[i]):int(off[i]) + int(olen[i])].tobytes())
                for i in range(n)]
         return scores[:n], btr, rws
+
+
+def _align_traces(self, profiles, refs, params, trim_left=50, trim_right=50, ref_index=None):
+    """tracyhip_align_traces with host buffers.  profiles: list of float32 [6][mf]; refs: list of bytes.
+    Returns a dict of numpy arrays + the list of final traceback strings (push order)."""
+    pp = profiles if isinstance(profiles, PackedSeqs) else PackedSeqs(profiles, SEQ_PROFILE)
+    pr = refs if isinstance(refs, PackedSeqs) else PackedSeqs(refs, SEQ_CHAR)
+    nt = pp.count
+    job = AlignJob()
+    job.ntraces = nt
+    job.profiles = pp.seqset()
+    job.refs = pr.seqset()
+    keep = []
+    if ref_index is not None:
+        ref_index = np.ascontiguousarray(ref_index, dtype=np.uint32)
+        job.ref_index = ref_index.ctypes.data_as(C.POINTER(C.c_uint32))
+        rlen = pr.length[ref_index]
+        keep.append(ref_index)
+    else:
+        rlen = pr.length[:nt]
+    job.trim_left = trim_left
+    job.trim_right = trim_right
+    cap = pp.length[:nt].astype(np.uint64) + rlen.astype(np.uint64)
+    off = np.zeros(max(nt, 1), dtype=np.uint64)
+    if nt:
+        off[1:nt] = np.cumsum(cap)[:-1]
+    res = {
+        "score_fwd": np.zeros(max(nt, 1), np.int32), "score_rev": np.zeros(max(nt, 1), np.int32),
+        "forward": np.zeros(max(nt, 1), np.uint8), "score_prelim": np.zeros(max(nt, 1), np.int32),
+        "slice_begin": np.zeros(max(nt, 1), np.uint32), "slice_len": np.zeros(max(nt, 1), np.uint32),
+        "ref_pos": np.zeros(max(nt, 1), np.uint32), "score_final": np.zeros(max(nt, 1), np.int32),
+        "ops": np.zeros(max(int(cap.sum()) if nt else 0, 1), np.uint8), "ops_len": np.zeros(max(nt, 1), np.uint32),
+    }
+    out = AlignResult()
+    for k in ("score_fwd", "score_rev", "forward", "score_prelim", "slice_begin", "slice_len", "ref_pos",
+              "score_final", "ops", "ops_len"):
+        setattr(out, k, res[k].ctypes.data)
+    out.ops_offset = off.ctypes.data_as(C.POINTER(C.c_uint64))
+    prm = Params(params[0], params[1], params[2], params[3], 1, 0)
+    _check(lib().tracyhip_align_traces(self._h, C.byref(job), C.byref(prm), MEM_HOST, C.byref(out)))
+    btr = [res["ops"][int(off[i]):int(off[i]) + int(res["ops_len"][i])].tobytes() for i in range(nt)]
+    for k in list(res):
+        if k != "ops":
+            res[k] = res[k][:nt]
+    res["btr"] = btr
+    return res
+
+
+Context.align_traces = _align_traces

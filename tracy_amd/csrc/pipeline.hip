@@ -1,0 +1,312 @@
+// pipeline.hip -- tracyhip_align_traces: the hot section of `tracy align` (sage.h:191-311) for a batch
+// of traces, all DP on the device.  Host work between stages is limited to reading back a few bytes
+// per trace (orientation scores, trimmed-slice geometry) to plan the next launch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../include/tracy_hip.h"
+#include "capi_internal.h"
+#include "launch.h"
+
+using namespace tracyhip;
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess)                                                                           \
+      return set_error(_e == hipErrorOutOfMemory ? TRACYHIP_ERR_OOM : TRACYHIP_ERR_HIP, "%s failed: %s (%s:%d)", \
+                       #expr, hipGetErrorString(_e), __FILE__, __LINE__);                           \
+  } while (0)
+
+namespace {
+
+struct TrimOut {
+  uint32_t ri;       // offset of the trimmed slice in the oriented reference
+  uint32_t len;      // its length after std::string::substr clamping
+  uint32_t pos;      // rs.pos after the update (rs.pos starts at 0)
+  uint32_t pad;
+};
+
+// trimReferenceSlice (fmindex.h:429-463) evaluated directly on the traceback string.  ops are in push
+// order (end -> start); alignment column j (forward) is ops[L-1-j].  Row 0 holds a trace base unless
+// the op is 'h', row 1 holds a reference base unless the op is 'v' (align.h:204-214).
+__global__ __launch_bounds__(64) void trim_kernel(const uint8_t* __restrict__ ops, const uint64_t* __restrict__ ops_off,
+                                                  const uint32_t* __restrict__ ops_len, const uint32_t* __restrict__ ref_len,
+                                                  const uint8_t* __restrict__ forward, uint32_t trim_left,
+                                                  uint32_t trim_right, uint32_t ntraces, TrimOut* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntraces) return;
+  const uint8_t* o = ops + ops_off[t];
+  const uint32_t L = ops_len[t];
+  uint32_t ri = 0;
+  int32_t s = -1, e = -1;
+  for (uint32_t j = 0; j < L; ++j) {
+    const uint8_t op = o[L - 1 - j];
+    if (op != 'h') {
+      if (s == -1) s = (int32_t)j;
+      e = (int32_t)j + 1;
+    }
+    if ((s == -1) && (op != 'v')) ++ri;
+  }
+  uint32_t risize = 0;
+  for (int32_t j = s; j < e; ++j)
+    if (o[L - 1 - j] != 'v') ++risize;
+  if (ri >= trim_left) { ri -= trim_left; risize += trim_left; }
+  const uint32_t n = ref_len[t];
+  if ((uint32_t)(ri + risize + trim_right) < n) risize += trim_right;
+  TrimOut r;
+  r.ri = ri;
+  r.len = (ri <= n) ? ((risize < n - ri) ? risize : n - ri) : 0;  // substr(ri, risize)
+  r.pos = 0;
+  if (forward[t]) r.pos = ri;
+  else {
+    const int32_t offset = (int32_t)n - (int32_t)ri - (int32_t)risize;
+    if (offset >= 0) r.pos = (uint32_t)offset;  // negative: the reference only warns (fmindex.h:457-459)
+  }
+  r.pad = 0;
+  out[t] = r;
+}
+
+// loadSingleFasta hands over upper-case [ACGTN] only (fasta.h:54-95); anything else makes the string
+// and profile reverse complements (fmindex.h:8-24 vs profile.h:74-90) disagree, so it is rejected.
+__global__ void validate_ref_kernel(const uint8_t* __restrict__ in, uint64_t n, int32_t* err) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint8_t c = in[i];
+    if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N')) atomicOr(err, 4);
+  }
+}
+
+__global__ void encode_codes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)base_code(in[i]);
+}
+
+template <class T>
+int copy_out(tracyhip_ctx* ctx, int mem, T* user, const T* dev, size_t count) {
+  if (!user || count == 0 || user == dev) return TRACYHIP_OK;
+  HIP_TRY(hipMemcpyAsync(user, dev, sizeof(T) * count, mem == TRACYHIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+  return TRACYHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
+                                     const tracyhip_align_result* out) {
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  if (!job || !out || !prm) return set_error(TRACYHIP_ERR_ARG, "null job/result/params");
+  if (mem != TRACYHIP_MEM_HOST && mem != TRACYHIP_MEM_DEVICE) return set_error(TRACYHIP_ERR_ARG, "bad mem kind");
+  const uint32_t nt = job->ntraces;
+  if (nt == 0) return TRACYHIP_OK;
+  const tracyhip_seqset& sp = job->profiles;
+  const tracyhip_seqset& sr = job->refs;
+  if (sp.kind != TRACYHIP_SEQ_PROFILE || sr.kind != TRACYHIP_SEQ_CHAR) return set_error(TRACYHIP_ERR_ARG, "profiles must be PROFILE, refs CHAR");
+  if (!sp.offset || !sp.length || !sr.offset || !sr.length || sp.count < nt) return set_error(TRACYHIP_ERR_ARG, "bad sequence sets");
+  if (!out->score_fwd || !out->score_rev || !out->forward || !out->slice_begin || !out->slice_len || !out->ref_pos ||
+      !out->score_final || !out->ops || !out->ops_offset || !out->ops_len)
+    return set_error(TRACYHIP_ERR_ARG, "null result array");
+  hipStream_t st = ctx->stream;
+  tracyhip_params p = *prm;
+  p.hfree = 1;  // AlignConfig<true,false> semiglobal (sage.h:165)
+  p.vfree = 0;
+
+  // ---- stage payloads, encode the references once ----
+  const uint64_t ep = seqset_extent(sp), er = seqset_extent(sr);
+  const void *d_prof, *d_ref;
+  if ((rc = stage_in(ctx, ctx->d_in1, sp.data, ep * 4, mem, &d_prof))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_in2, sr.data, er, mem, &d_ref))) return rc;
+  HIP_TRY(ctx->d_err.ensure(sizeof(int32_t)));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t), st));
+  HIP_TRY(ctx->d_codes.ensure(er ? er : 1));
+  if (er) {
+    hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er,
+                       static_cast<int32_t*>(ctx->d_err.p));
+    hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
+                       static_cast<uint8_t*>(ctx->d_codes.p), er);
+    HIP_TRY(hipGetLastError());
+  }
+  {
+    int32_t herr = 0;
+    HIP_TRY(hipMemcpyAsync(&herr, ctx->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (herr & 4) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
+  }
+
+  // ---- geometry per trace ----
+  std::vector<uint32_t> mf(nt), mt(nt), tl(nt), rn(nt), ridx(nt);
+  uint64_t max_mn = 0;
+  for (uint32_t t = 0; t < nt; ++t) {
+    ridx[t] = job->ref_index ? job->ref_index[t] : t;
+    if (ridx[t] >= sr.count) return set_error(TRACYHIP_ERR_ARG, "ref_index[%u] out of range", t);
+    mf[t] = sp.length[t];
+    rn[t] = sr.length[ridx[t]];
+    uint32_t l = job->trim_left, r = job->trim_right;
+    if ((uint64_t)l + r >= mf[t]) { l = 0; r = 0; }  // createProfile, profile.h:24-27
+    tl[t] = l;
+    mt[t] = mf[t] - (l + r);
+    max_mn = std::max<uint64_t>(max_mn, (uint64_t)mf[t] + rn[t]);
+  }
+  if ((rc = check_params(&p, max_mn))) return rc;
+
+  // device result arrays (user's in DEVICE mode, ours in HOST mode)
+  auto dev_arr = [&](DevBuf& b, void* user, size_t bytes, void** dptr) -> int {
+    if (mem == TRACYHIP_MEM_DEVICE) { *dptr = user; return TRACYHIP_OK; }
+    HIP_TRY(b.ensure(bytes));
+    *dptr = b.p;
+    return TRACYHIP_OK;
+  };
+
+  // ---- 1. orientation scores: gotohScore(trim, fwd) / gotohScore(trim, rev)  (sage.h:239-240) ----
+  HIP_TRY(ctx->d_tmp[0].ensure(sizeof(int32_t) * 2 * (size_t)nt));
+  int32_t* d_sc2 = static_cast<int32_t*>(ctx->d_tmp[0].p);
+  {
+    DpProblem pb;
+    pb.mode = MODE_QP;
+    pb.a1_profile = true;
+    pb.d_a1 = d_prof;
+    pb.d_a2 = ctx->d_codes.p;
+    pb.desc.resize(2 * (size_t)nt);
+    pb.k.resize(2 * (size_t)nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+      PairDesc d{};
+      d.a1_off = sp.offset[t] + tl[t];
+      d.a1_stride = mf[t];
+      d.m = mt[t];
+      d.a2_off = sr.offset[ridx[t]];
+      d.n = rn[t];
+      d.a2_stride = rn[t];
+      d.out = t;
+      pb.desc[t] = d;
+      d.out = nt + t;
+      d.flags = PAIR_A2_REVCOMP;
+      pb.desc[nt + t] = d;
+      pb.k[t] = pb.k[nt + t] = choose_k(d.m, MODE_QP);
+    }
+    if ((rc = run_dp(ctx, pb, &p, false, false, d_sc2, nullptr, nullptr, nullptr))) return rc;
+  }
+  std::vector<int32_t> h_sc2(2 * (size_t)nt);
+  HIP_TRY(hipMemcpyAsync(h_sc2.data(), d_sc2, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<uint8_t> h_fwd(nt);
+  for (uint32_t t = 0; t < nt; ++t) h_fwd[t] = h_sc2[t] > h_sc2[nt + t] ? 1 : 0;  // forward iff gsFwd > gsRev (sage.h:247)
+
+  // ---- 2. preliminary alignment gotoh(trim, oriented reference) (sage.h:258) ----
+  std::vector<uint64_t> off1(nt);
+  uint64_t tot1 = 0;
+  for (uint32_t t = 0; t < nt; ++t) { off1[t] = tot1; tot1 += (uint64_t)mt[t] + rn[t]; }
+  HIP_TRY(ctx->d_tmp[1].ensure(tot1 ? tot1 : 1));                       // ops of the preliminary alignment
+  HIP_TRY(ctx->d_tmp[2].ensure(sizeof(uint64_t) * (size_t)nt));          // their offsets
+  HIP_TRY(ctx->d_tmp[3].ensure(sizeof(uint32_t) * (size_t)nt));          // their lengths
+  HIP_TRY(ctx->d_tmp[4].ensure(sizeof(int32_t) * (size_t)nt));           // preliminary scores
+  HIP_TRY(ctx->h_tmp.ensure(sizeof(uint64_t) * (size_t)nt + (size_t)nt * 8));
+  std::memcpy(ctx->h_tmp.p, off1.data(), sizeof(uint64_t) * (size_t)nt);
+  HIP_TRY(hipMemcpyAsync(ctx->d_tmp[2].p, ctx->h_tmp.p, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+  {
+    DpProblem pb;
+    pb.mode = MODE_QP;
+    pb.a1_profile = true;
+    pb.d_a1 = d_prof;
+    pb.d_a2 = ctx->d_codes.p;
+    pb.desc.resize(nt);
+    pb.k.resize(nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+      PairDesc d{};
+      d.a1_off = sp.offset[t] + tl[t];
+      d.a1_stride = mf[t];
+      d.m = mt[t];
+      d.a2_off = sr.offset[ridx[t]];
+      d.n = rn[t];
+      d.a2_stride = rn[t];
+      d.out = t;
+      d.flags = h_fwd[t] ? 0 : PAIR_A2_REVCOMP;
+      pb.desc[t] = d;
+      pb.k[t] = choose_k(d.m, MODE_QP);
+    }
+    if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(ctx->d_tmp[4].p), static_cast<uint8_t*>(ctx->d_tmp[1].p),
+                     static_cast<const uint64_t*>(ctx->d_tmp[2].p), static_cast<uint32_t*>(ctx->d_tmp[3].p))))
+      return rc;
+  }
+
+  // ---- 3. trimReferenceSlice (sage.h:259) ----
+  HIP_TRY(ctx->d_tmp[5].ensure(sizeof(TrimOut) * (size_t)nt));
+  HIP_TRY(ctx->d_tmp[6].ensure(sizeof(uint32_t) * (size_t)nt + (size_t)nt));
+  uint32_t* d_rn = static_cast<uint32_t*>(ctx->d_tmp[6].p);
+  uint8_t* d_fwd = reinterpret_cast<uint8_t*>(d_rn + nt);
+  {
+    uint8_t* hp = static_cast<uint8_t*>(ctx->h_tmp.p) + sizeof(uint64_t) * (size_t)nt;
+    std::memcpy(hp, rn.data(), sizeof(uint32_t) * (size_t)nt);
+    std::memcpy(hp + sizeof(uint32_t) * (size_t)nt, h_fwd.data(), nt);
+    HIP_TRY(hipMemcpyAsync(d_rn, hp, sizeof(uint32_t) * (size_t)nt + nt, hipMemcpyHostToDevice, st));
+  }
+  hipLaunchKernelGGL(trim_kernel, dim3((nt + 63) / 64), dim3(64), 0, st, static_cast<const uint8_t*>(ctx->d_tmp[1].p),
+                     static_cast<const uint64_t*>(ctx->d_tmp[2].p), static_cast<const uint32_t*>(ctx->d_tmp[3].p), d_rn, d_fwd,
+                     job->trim_left, job->trim_right, nt, static_cast<TrimOut*>(ctx->d_tmp[5].p));
+  HIP_TRY(hipGetLastError());
+  std::vector<TrimOut> h_trim(nt);
+  HIP_TRY(hipMemcpyAsync(h_trim.data(), ctx->d_tmp[5].p, sizeof(TrimOut) * (size_t)nt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+
+  // ---- 4. final alignment gotoh(full profile, profile of the trimmed slice) (sage.h:260, 311) ----
+  void *d_final_sc, *d_ops, *d_olen;
+  uint64_t ops_total = 0;
+  for (uint32_t t = 0; t < nt; ++t) ops_total = std::max<uint64_t>(ops_total, out->ops_offset[t] + mf[t] + h_trim[t].len);
+  if ((rc = dev_arr(ctx->d_scores, out->score_final, sizeof(int32_t) * (size_t)nt, &d_final_sc))) return rc;
+  if ((rc = dev_arr(ctx->d_ops, out->ops, ops_total ? ops_total : 1, &d_ops))) return rc;
+  if ((rc = dev_arr(ctx->d_ops_len, out->ops_len, sizeof(uint32_t) * (size_t)nt, &d_olen))) return rc;
+  HIP_TRY(ctx->h_off.ensure(sizeof(uint64_t) * (size_t)nt));
+  std::memcpy(ctx->h_off.p, out->ops_offset, sizeof(uint64_t) * (size_t)nt);
+  HIP_TRY(ctx->d_ops_off.ensure(sizeof(uint64_t) * (size_t)nt));
+  HIP_TRY(hipMemcpyAsync(ctx->d_ops_off.p, ctx->h_off.p, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+  {
+    DpProblem pb;
+    pb.mode = MODE_QP;
+    pb.a1_profile = true;
+    pb.d_a1 = d_prof;
+    pb.d_a2 = ctx->d_codes.p;
+    pb.desc.resize(nt);
+    pb.k.resize(nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+      PairDesc d{};
+      d.a1_off = sp.offset[t];
+      d.a1_stride = mf[t];
+      d.m = mf[t];
+      d.n = h_trim[t].len;
+      d.a2_stride = d.n;
+      // oriented slice [ri, ri+len): forward reads it in place, reverse reads original
+      // [n-ri-len, n-ri) backwards with complemented codes
+      d.a2_off = sr.offset[ridx[t]] + (h_fwd[t] ? h_trim[t].ri : rn[t] - h_trim[t].ri - h_trim[t].len);
+      d.flags = h_fwd[t] ? 0 : PAIR_A2_REVCOMP;
+      d.out = t;
+      pb.desc[t] = d;
+      pb.k[t] = choose_k(d.m, MODE_QP);
+    }
+    if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(d_final_sc), static_cast<uint8_t*>(d_ops),
+                     static_cast<const uint64_t*>(ctx->d_ops_off.p), static_cast<uint32_t*>(d_olen))))
+      return rc;
+  }
+
+  // ---- results ----
+  std::vector<uint32_t> h_begin(nt), h_len(nt), h_pos(nt);
+  for (uint32_t t = 0; t < nt; ++t) { h_begin[t] = h_trim[t].ri; h_len[t] = h_trim[t].len; h_pos[t] = h_trim[t].pos; }
+  const hipMemcpyKind up = (mem == TRACYHIP_MEM_HOST) ? hipMemcpyHostToHost : hipMemcpyHostToDevice;
+  HIP_TRY(hipMemcpyAsync(out->score_fwd, h_sc2.data(), sizeof(int32_t) * (size_t)nt, up, st));
+  HIP_TRY(hipMemcpyAsync(out->score_rev, h_sc2.data() + nt, sizeof(int32_t) * (size_t)nt, up, st));
+  HIP_TRY(hipMemcpyAsync(out->forward, h_fwd.data(), nt, up, st));
+  HIP_TRY(hipMemcpyAsync(out->slice_begin, h_begin.data(), sizeof(uint32_t) * (size_t)nt, up, st));
+  HIP_TRY(hipMemcpyAsync(out->slice_len, h_len.data(), sizeof(uint32_t) * (size_t)nt, up, st));
+  HIP_TRY(hipMemcpyAsync(out->ref_pos, h_pos.data(), sizeof(uint32_t) * (size_t)nt, up, st));
+  if (out->score_prelim) {
+    if ((rc = copy_out(ctx, mem, out->score_prelim, static_cast<const int32_t*>(ctx->d_tmp[4].p), nt))) return rc;
+  }
+  if (mem == TRACYHIP_MEM_HOST) {
+    if ((rc = copy_out(ctx, mem, out->score_final, static_cast<const int32_t*>(d_final_sc), nt))) return rc;
+    if ((rc = copy_out(ctx, mem, out->ops, static_cast<const uint8_t*>(d_ops), ops_total))) return rc;
+    if ((rc = copy_out(ctx, mem, out->ops_len, static_cast<const uint32_t*>(d_olen), nt))) return rc;
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  return TRACYHIP_OK;
+}

@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py -- `tracy align` hot path (sage.h:191-311) on N MI355X, one process per GPU.
+
+A step = one pass of tracyhip_align_traces over this rank's batch of synthetic traces (BASELINE.json
+configs[1]: 10k x 1 kb traces vs 10 kb reference windows per GPU; inputs resident in HBM before the
+timed region).  Per trace: 2 score-only Gotoh DPs (forward / reverse-complement reference), 1 traceback
+DP of the trimmed profile, trimReferenceSlice, 1 traceback DP of the full profile vs the trimmed slice.
+Weak scaling: the per-GPU batch is fixed; traces shard by index with no data-path collective, the only
+RCCL call is the final gather of the fixed-size result records.
+
+Prints ONE JSON line on rank 0 (see the keys at the bottom).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SCORE = (3, -5, -10, -4)  # match, mismatch, gapopen, gapext (sage.h:79-82)
+TRIM = 50                 # trimLeft = trimRight = 50 (sage.h:88-89)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured copy ceiling)
+
+
+def cpu_baseline(profs, refs, nthreads, budget_traces):
+    """The oracle (CPU restatement of the reference path, `kind: port`) timed on this host, one trace per
+    thread.  Only this leg may touch oracle/."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from sage_oracle import align_trace
+    import pyoracle
+    pyoracle.lib()
+    n = min(budget_traces, len(profs))
+    work = [(np.ascontiguousarray(profs[i]), refs[i].tobytes()) for i in range(n)]
+
+    def one(w):
+        r = align_trace(w[0], w[1], SCORE, TRIM, TRIM)
+        mf = w[0].shape[1]
+        mt = mf - 2 * TRIM
+        return 3 * mt * len(w[1]) + mf * r["slice_len"], r
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=nthreads) as ex:
+        res = list(ex.map(one, work))
+    dt = time.perf_counter() - t0
+    cells = sum(r[0] for r in res)
+    return cells / dt / 1e9, n, dt, [r[1] for r in res]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--traces", type=int, default=10000, help="traces per GPU per step")
+    ap.add_argument("--ref-len", type=int, default=10000)
+    ap.add_argument("--trace-len", type=int, default=1000)
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="traces for the CPU baseline (-1: 2 per thread, capped)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    import tracy_amd
+    from tracy_amd import capi, hostlib
+
+    nt, n, mf = args.traces, args.ref_len, args.trace_len
+    # ---- synthetic inputs (seeded per trace: seed = 1000 + global trace index), resident in HBM ----
+    refs, profs, rev = hostlib.synth_align(1000 + rank * nt, nt, n, mf, 0)
+    d_refs = torch.from_numpy(refs).cuda()
+    d_profs = torch.from_numpy(profs).cuda()
+    pp_off = (np.arange(nt, dtype=np.uint64) * np.uint64(6 * mf))
+    pp_len = np.full(nt, mf, dtype=np.uint32)
+    rr_off = (np.arange(nt, dtype=np.uint64) * np.uint64(n))
+    rr_len = np.full(nt, n, dtype=np.uint32)
+    ops_cap = mf + n
+    ops_off = (np.arange(nt, dtype=np.uint64) * np.uint64(ops_cap))
+
+    job = capi.AlignJob()
+    job.ntraces = nt
+    job.profiles = capi.SeqSet(capi.SEQ_PROFILE, d_profs.data_ptr(), pp_off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                               pp_len.ctypes.data_as(C.POINTER(C.c_uint32)), nt)
+    job.refs = capi.SeqSet(capi.SEQ_CHAR, d_refs.data_ptr(), rr_off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                           rr_len.ctypes.data_as(C.POINTER(C.c_uint32)), nt)
+    job.trim_left = TRIM
+    job.trim_right = TRIM
+    dev = torch.device("cuda", local)
+    r_i32 = {k: torch.zeros(nt, dtype=torch.int32, device=dev) for k in
+             ("score_fwd", "score_rev", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final", "ops_len")}
+    r_fwd = torch.zeros(nt, dtype=torch.uint8, device=dev)
+    r_ops = torch.zeros(nt * ops_cap, dtype=torch.uint8, device=dev)
+    out = capi.AlignResult()
+    for k, v in r_i32.items():
+        setattr(out, k, v.data_ptr())
+    out.forward = r_fwd.data_ptr()
+    out.ops = r_ops.data_ptr()
+    out.ops_offset = ops_off.ctypes.data_as(C.POINTER(C.c_uint64))
+    prm = capi.Params(SCORE[0], SCORE[1], SCORE[2], SCORE[3], 1, 0)
+
+    ctx = tracy_amd.Context(local)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    lib = capi.lib()
+
+    def step():
+        rc = lib.tracyhip_align_traces(ctx._h, C.byref(job), C.byref(prm), capi.MEM_DEVICE, C.byref(out))
+        if rc != 0:
+            raise RuntimeError("tracyhip_align_traces: %s" % lib.tracyhip_last_error().decode())
+        if dist is not None:  # final gather of the fixed-size result records over RCCL / xGMI
+            rec = torch.stack([r_i32["score_final"], r_i32["slice_begin"], r_i32["slice_len"], r_i32["ops_len"]], dim=1)
+            bucket = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
+            dist.gather(rec, bucket, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    lib.tracyhip_timing_enable(ctx._h, 1)
+    lib.tracyhip_timing_reset(ctx._h)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    lib.tracyhip_timing_enable(ctx._h, 0)
+
+    # ---- work done: DP cells of the four Gotoh calls per trace ----
+    slice_len = r_i32["slice_len"].cpu().numpy().astype(np.int64)
+    mt = mf - 2 * TRIM
+    cells_rank = int(3 * mt * n * nt + (mf * slice_len).sum())
+    tm = torch.tensor([elapsed, float(cells_rank)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = tm.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tm.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max, cells_all = float(tmax[0]), float(tsum[1])
+    else:
+        elapsed_max, cells_all = elapsed, float(cells_rank)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    gcups = cells_all * args.steps / elapsed_max / 1e9
+    kt = capi.KernelTiming()
+    rl = {}
+    for name, which in (("score", 0), ("trace", 1), ("walk", 2)):
+        lib.tracyhip_timing_get(ctx._h, which, C.byref(kt))
+        rl[name] = dict(ms=kt.ms, launches=int(kt.launches), cells=int(kt.cells), bytes=int(kt.bytes))
+    tr = rl["trace"]
+    # dominant HBM kernel = the traceback DP of the trimmed profile (the largest launches of TIMER_TRACE)
+    ach = tr["bytes"] / (tr["ms"] * 1e-3) / 1e9 if tr["ms"] > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "gotoh_kernel<K,QP,TRACE> (traceback DP)", "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(tr["ms"] / max(tr["launches"], 1), 3), "launches": tr["launches"],
+                "algorithmic_bytes_per_launch": tr["bytes"] // max(tr["launches"], 1),
+                "trace_kernel_gcups": round(tr["cells"] / (tr["ms"] * 1e-3) / 1e9, 1) if tr["ms"] > 0 else 0.0,
+                "score_kernel_gcups": round(rl["score"]["cells"] / (rl["score"]["ms"] * 1e-3) / 1e9, 1) if rl["score"]["ms"] > 0 else 0.0,
+                "walk_ms_per_step": round(rl["walk"]["ms"] / max(args.steps, 1), 3)}
+
+    line = {
+        "metric": "GCUPS (tracy align: Gotoh affine-gap DP cells per second, whole job)",
+        "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "traces_per_s": round(nt * world * args.steps / elapsed_max, 1),
+        "config": {"workload": "configs[1]: %d synthetic %d-base traces `align` vs %d-base reference windows per GPU, "
+                               "full Gotoh (2 score-only + 2 traceback DPs per trace), scoring 3/-5/-10/-4, trims 50/50"
+                               % (nt, mf, n), "traces_per_gpu": nt, "trace_len": mf, "ref_len": n,
+                   "parallelism": "batch-sharded x%d, no data-path collective" % world},
+        "roofline": roofline,
+    }
+    if world == 1:
+        nthreads = min(os.cpu_count() or 1, 64)
+        sample = args.cpu_sample if args.cpu_sample >= 0 else max(8, min(2 * nthreads, 64))
+        if sample > 0:
+            v, ns, dt, ores = cpu_baseline(profs, refs, nthreads, sample)
+            line["cpu_baseline"] = {"value": round(v, 4), "unit": "GCUPS", "cores": min(nthreads, ns), "kind": "port",
+                                    "sample": "%d of the same traces through the oracle's sage.h chain, one trace per thread, %.1f s"
+                                              % (ns, dt)}
+            # the same traces must come out bit-identical on the GPU
+            sf = r_i32["score_final"].cpu().numpy()
+            ol = r_i32["ops_len"].cpu().numpy()
+            ops = r_ops.cpu().numpy()
+            ok = all(int(sf[i]) == o["score_final"] and ops[i * ops_cap:i * ops_cap + int(ol[i])].tobytes() == o["btr"]
+                     for i, o in enumerate(ores))
+            line["parity_checked"] = {"traces": ns, "bit_identical": bool(ok)}
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

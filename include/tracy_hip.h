@@ -151,6 +151,23 @@ typedef struct {
 int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm,
                           int mem, const tracyhip_align_result* out);
 
+/* ---- kernel timing (HIP events recorded on the context's stream around each DP / walker launch) ---
+ * The reference has only the optional gperftools wrapper (sage.h:60-62); this is the hook bench.py uses
+ * for its roofline line.  bytes = ALGORITHMIC bytes of the launches: 0.5 B per traceback cell + the
+ * inputs once (1 B per reference base, 24 B per profile column, 1 B per string base) + 4 B score. */
+#define TRACYHIP_TIMER_SCORE 0 /* score-only DP kernels */
+#define TRACYHIP_TIMER_TRACE 1 /* traceback DP kernels  */
+#define TRACYHIP_TIMER_WALK 2  /* traceback walkers     */
+typedef struct {
+  double ms;         /* summed launch durations */
+  uint64_t launches;
+  uint64_t cells;    /* DP cells (m*n summed over pairs) */
+  uint64_t bytes;    /* algorithmic HBM bytes */
+} tracyhip_kernel_timing;
+int tracyhip_timing_enable(tracyhip_ctx* ctx, int on);
+int tracyhip_timing_reset(tracyhip_ctx* ctx);
+int tracyhip_timing_get(tracyhip_ctx* ctx, int which, tracyhip_kernel_timing* out);
+
 #ifdef __cplusplus
 }
 #endif

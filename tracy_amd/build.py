@@ -55,5 +55,25 @@ def build(force=False, verbose=False):
     return SO
 
 
+
+
+HOST_SO = os.path.join(LIBDIR, "libtracy_host.so")
+
+
+def build_host(force=False, verbose=False):
+    """host-side C++ (basecall / createProfile / synthetic workloads): plain g++, no GPU code"""
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdir = os.path.join(HERE, "host")
+    srcs = [os.path.join(hdir, f) for f in os.listdir(hdir)]
+    if force or stale(HOST_SO, srcs):
+        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-Wall",
+               "-o", HOST_SO, os.path.join(hdir, "tracy_host_capi.cpp")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOST_SO
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

@@ -257,3 +257,7 @@ def _align_traces(self, profiles, refs, params, trim_left=50, trim_right=50, ref
 
 
 Context.align_traces = _align_traces
+
+
+class KernelTiming(C.Structure):
+    _fields_ = [("ms", C.c_double), ("launches", C.c_uint64), ("cells", C.c_uint64), ("bytes", C.c_uint64)]

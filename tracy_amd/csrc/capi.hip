@@ -111,6 +111,42 @@ __global__ void encode_kernel(const uint8_t* __restrict__ in, uint8_t* __restric
 
 namespace tracyhip {
 
+static hipError_t get_event(tracyhip_ctx* ctx, hipEvent_t* e) {
+  if (!ctx->free_events.empty()) { *e = ctx->free_events.back(); ctx->free_events.pop_back(); return hipSuccess; }
+  return hipEventCreate(e);
+}
+int timing_begin(tracyhip_ctx* ctx, int which, uint64_t cells, uint64_t bytes) {
+  if (!ctx->timing) return TRACYHIP_OK;
+  tracyhip_ctx::Pending p{which, nullptr, nullptr, cells, bytes};
+  HIP_TRY(get_event(ctx, &p.e0));
+  HIP_TRY(get_event(ctx, &p.e1));
+  HIP_TRY(hipEventRecord(p.e0, ctx->stream));
+  ctx->pending.push_back(p);
+  return TRACYHIP_OK;
+}
+int timing_end(tracyhip_ctx* ctx) {
+  if (!ctx->timing || ctx->pending.empty()) return TRACYHIP_OK;
+  HIP_TRY(hipEventRecord(ctx->pending.back().e1, ctx->stream));
+  return TRACYHIP_OK;
+}
+int timing_collect(tracyhip_ctx* ctx) {
+  for (auto& p : ctx->pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+      ctx->acc[p.which].ms += ms;
+      ctx->acc[p.which].launches += 1;
+      ctx->acc[p.which].cells += p.cells;
+      ctx->acc[p.which].bytes += p.bytes;
+    } else {
+      (void)hipGetLastError();
+    }
+    ctx->free_events.push_back(p.e0);
+    ctx->free_events.push_back(p.e1);
+  }
+  ctx->pending.clear();
+  return TRACYHIP_OK;
+}
+
 int ctx_begin(tracyhip_ctx* ctx) {
   if (!ctx) return set_error(TRACYHIP_ERR_ARG, "null context");
   HIP_TRY(hipSetDevice(ctx->device));
@@ -218,7 +254,19 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
       const int K = pb.k[order[j]];
       while (e < c.hi && pb.k[order[e]] == K) ++e;
       a.pairs = dd + j;
+      int trc;
+      if (ctx->timing) {
+        uint64_t cells = 0, bytes = 0;
+        for (uint32_t q = j; q < e; ++q) {
+          const PairDesc& d = hd[q];
+          const uint64_t mn = (uint64_t)d.m * d.n;
+          cells += mn;
+          bytes += (trace ? mn / 2 : 0) + (pb.a1_profile ? 24ull * d.m : d.m) + (pb.a2_profile ? 24ull * d.n : d.n) + 4;
+        }
+        if ((trc = timing_begin(ctx, trace ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
+      }
       HIP_TRY(needle ? launch_needle(pb.mode, K, trace, a, e - j, st) : launch_gotoh(pb.mode, K, trace, a, e - j, st));
+      if ((trc = timing_end(ctx))) return trc;
       if (trace) {
         WalkArgs wa{};
         wa.pairs = dd + j;
@@ -229,7 +277,9 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
         wa.err = a.err;
         wa.npairs = e - j;
         wa.K = K;
+        if ((trc = timing_begin(ctx, TRACYHIP_TIMER_WALK, 0, 0))) return trc;
         HIP_TRY(needle ? launch_needle_walk(wa, a.bits32, st) : launch_gotoh_walk(wa, st));
+        if ((trc = timing_end(ctx))) return trc;
       }
       j = e;
     }
@@ -237,6 +287,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   int32_t herr = 0;
   HIP_TRY(hipMemcpyAsync(&herr, ctx->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  timing_collect(ctx);
   if (herr & 1) return set_error(TRACYHIP_ERR_RANGE, "a query-profile score does not fit int16 (profile values too large)");
   if (herr & 2) return set_error(TRACYHIP_ERR_RANGE, "traceback left the matrix (degenerate scoring parameters)");
   return TRACYHIP_OK;
@@ -344,6 +395,8 @@ int tracyhip_destroy(tracyhip_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   c->release_all();
+  for (auto& p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+  for (auto e : c->free_events) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return TRACYHIP_OK;
@@ -358,6 +411,22 @@ int tracyhip_set_stream(tracyhip_ctx* c, void* s) {
 int tracyhip_set_workspace_limit(tracyhip_ctx* c, uint64_t bytes) {
   if (!c) return set_error(TRACYHIP_ERR_ARG, "null context");
   c->ws_limit = bytes;
+  return TRACYHIP_OK;
+}
+
+int tracyhip_timing_enable(tracyhip_ctx* c, int on) {
+  if (!c) return set_error(TRACYHIP_ERR_ARG, "null context");
+  c->timing = on != 0;
+  return TRACYHIP_OK;
+}
+int tracyhip_timing_reset(tracyhip_ctx* c) {
+  if (!c) return set_error(TRACYHIP_ERR_ARG, "null context");
+  for (auto& a : c->acc) a = tracyhip_kernel_timing{};
+  return TRACYHIP_OK;
+}
+int tracyhip_timing_get(tracyhip_ctx* c, int which, tracyhip_kernel_timing* out) {
+  if (!c || !out || which < 0 || which > 2) return set_error(TRACYHIP_ERR_ARG, "bad timing query");
+  *out = c->acc[which];
   return TRACYHIP_OK;
 }
 

@@ -50,6 +50,12 @@ struct tracyhip_ctx {
       d_rows0, d_rows1;
   tracyhip::DevBuf d_tmp[8];  // pipeline intermediates (align_traces / decompose)
   tracyhip::PinBuf h_desc, h_off, h_tmp;
+  // kernel timing
+  struct Pending { int which; hipEvent_t e0, e1; uint64_t cells, bytes; };
+  bool timing = false;
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> free_events;
+  tracyhip_kernel_timing acc[3] = {};
   void release_all() {
     tracyhip::DevBuf* all[] = {&d_desc, &d_bits, &d_scratch, &d_in1, &d_in2, &d_codes, &d_scores, &d_ops,
                                &d_ops_off, &d_ops_len, &d_err, &d_rows0, &d_rows1};
@@ -62,6 +68,9 @@ struct tracyhip_ctx {
 };
 
 namespace tracyhip {
+int timing_begin(tracyhip_ctx* ctx, int which, uint64_t cells, uint64_t bytes);  // record start event
+int timing_end(tracyhip_ctx* ctx);                                              // record stop event
+int timing_collect(tracyhip_ctx* ctx);                                          // after a stream sync
 int ctx_begin(tracyhip_ctx* ctx);
 int stage_in(tracyhip_ctx* ctx, DevBuf& buf, const void* src, uint64_t bytes, int mem, const void** dev);
 int check_params(const tracyhip_params* prm, uint64_t max_mn);

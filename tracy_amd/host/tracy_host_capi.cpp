@@ -1,0 +1,157 @@
+// tracy_host_capi.cpp -- C wrappers over tracy_host.hpp + the seeded synthetic workload generator used
+// by bench.py and the parity tests.  Host-only library (libtracy_host.so):
+// basecalling / profile creation are host stages in the reference too.
+#include <algorithm>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "tracy_host.hpp"
+
+using namespace tracy_amd;
+
+namespace {
+
+struct SplitMix64 {
+  uint64_t s;
+  explicit SplitMix64(uint64_t seed) : s(seed) {}
+  uint64_t next() {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  uint32_t below(uint32_t n) { return n ? (uint32_t)(next() % n) : 0; }
+  double unit() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+const char kBases[4] = {'A', 'C', 'G', 'T'};
+inline int base_index(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; }
+inline char complement(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
+
+// add a triangular peak (half-width 5 samples) of height amp centred at x
+void add_peak(std::vector<int32_t>& ch, int32_t x, double amp) {
+  for (int d = -5; d <= 5; ++d) {
+    const int32_t i = x + d;
+    if (i < 0 || i >= (int32_t)ch.size()) continue;
+    ch[i] += (int32_t)(amp * (1.0 - std::abs(d) / 6.0));
+  }
+}
+
+// One `tracy align` case: a uniform ACGT window of n bases, a trace of mf bases copied from it at a
+// random offset (forward or reverse-complement, 1 % substitutions, 0.2 % 1-3 bp indels), rendered as a
+// 4-channel chromatogram with 12 samples per base, primary amplitude U[400,1200] and a background peak
+// of 5-15 % in another channel.  hetero > 0 adds a second allele (see synth_decompose_case).
+void synth_sequence(SplitMix64& rng, uint32_t n, uint32_t mf, std::string& ref, std::string& seq, bool& reverse) {
+  ref.resize(n);
+  for (uint32_t i = 0; i < n; ++i) ref[i] = kBases[rng.below(4)];
+  const uint32_t span = (n > mf + 40) ? n - mf - 40 : 0;
+  uint32_t lo = std::min<uint32_t>(500, span / 2);
+  const uint32_t start = lo + rng.below(span - 2 * lo + 1);
+  reverse = (rng.next() & 1) != 0;
+  std::string src = ref.substr(start, std::min<uint32_t>(n - start, mf + 40));
+  if (reverse) {
+    std::reverse(src.begin(), src.end());
+    for (auto& c : src) c = complement(c);
+  }
+  seq.clear();
+  for (size_t i = 0; i < src.size() && seq.size() < mf; ++i) {
+    const double u = rng.unit();
+    if (u < 0.001) { i += rng.below(3); continue; }                                                  // deletion
+    if (u < 0.002) { const uint32_t k = 1 + rng.below(3); for (uint32_t j = 0; j < k; ++j) seq.push_back(kBases[rng.below(4)]); }  // insertion
+    if (u > 0.99) seq.push_back(kBases[rng.below(4)]);                                               // substitution
+    else seq.push_back(src[i]);
+  }
+  while (seq.size() < mf) seq.push_back(kBases[rng.below(4)]);
+  seq.resize(mf);
+}
+
+void render_trace(SplitMix64& rng, std::string const& allele1, std::string const* allele2, double frac1, Trace& tr) {
+  const size_t len = allele2 ? std::max(allele1.size(), allele2->size()) : allele1.size();
+  const size_t samples = 12 * len + 12;
+  tr.traceACGT.assign(4, std::vector<int32_t>(samples, 0));
+  tr.basecallpos.resize(len);
+  for (size_t j = 0; j < len; ++j) {
+    const int32_t x = (int32_t)(6 + 12 * j);
+    tr.basecallpos[j] = x;
+    const double amp = 400.0 + 800.0 * rng.unit();
+    const double bg = amp * (0.05 + 0.10 * rng.unit());
+    int used[2] = {-1, -1};
+    if (j < allele1.size()) { used[0] = base_index(allele1[j]); add_peak(tr.traceACGT[used[0]], x, allele2 ? amp * frac1 : amp); }
+    if (allele2 && j < allele2->size()) { used[1] = base_index((*allele2)[j]); add_peak(tr.traceACGT[used[1]], x, amp * (1.0 - frac1)); }
+    int b = (int)rng.below(4);
+    while (b == used[0] || b == used[1]) b = (b + 1) & 3;
+    add_peak(tr.traceACGT[b], x, bg);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// flat-array wrappers -----------------------------------------------------------------------------------
+size_t tracyhost_basecall(const int32_t* trace, size_t nsamples, const int32_t* basecallpos, size_t npos, float sigratio,
+                          char* primary, char* secondary, char* consensus, int32_t* bcpos) {
+  Trace tr;
+  tr.traceACGT.resize(4);
+  for (int k = 0; k < 4; ++k) tr.traceACGT[k].assign(trace + k * nsamples, trace + (k + 1) * nsamples);
+  tr.basecallpos.assign(basecallpos, basecallpos + npos);
+  BaseCalls bc;
+  basecall(tr, bc, sigratio);
+  const size_t n = bc.primary.size();
+  std::memcpy(primary, bc.primary.data(), n);
+  std::memcpy(secondary, bc.secondary.data(), n);
+  std::memcpy(consensus, bc.consensus.data(), n);
+  std::memcpy(bcpos, bc.bcPos.data(), n * sizeof(int32_t));
+  return n;
+}
+
+int32_t tracyhost_create_profile(const int32_t* trace, size_t nsamples, const int32_t* bcpos, const char* primary,
+                                 const char* secondary, size_t nbc, int32_t trimleft, int32_t trimright, float* out) {
+  Trace tr;
+  tr.traceACGT.resize(4);
+  for (int k = 0; k < 4; ++k) tr.traceACGT[k].assign(trace + k * nsamples, trace + (k + 1) * nsamples);
+  BaseCalls bc;
+  bc.bcPos.assign(bcpos, bcpos + nbc);
+  bc.primary.assign(primary, nbc);
+  bc.secondary.assign(secondary, nbc);
+  Profile p;
+  createProfile(tr, bc, p, trimleft, trimright);
+  std::memcpy(out, p.data(), sizeof(float) * 6 * p.cols);
+  return (int32_t)p.cols;
+}
+
+char tracyhost_iupac(char a, char b) { return iupac(a, b); }
+
+// Seeded synthetic `tracy align` workload: ntraces cases, case i seeded with seed0 + i.  refs: ntraces x n
+// bytes; profiles: ntraces x 6 x mf floats (createProfile of the basecalled synthetic chromatogram; when
+// the basecaller drops a window the profile is padded with uniform 0.25 columns to keep mf columns).
+// reverse[i] = 1 when the trace was copied from the reverse strand.  Multi-threaded over cases.
+void tracyhost_synth_align(uint64_t seed0, uint32_t ntraces, uint32_t n, uint32_t mf, uint8_t* refs, float* profiles,
+                           uint8_t* reverse, uint32_t nthreads) {
+  if (nthreads == 0) nthreads = std::max(1u, std::thread::hardware_concurrency());
+  auto work = [&](uint32_t tid) {
+    for (uint32_t i = tid; i < ntraces; i += nthreads) {
+      SplitMix64 rng(seed0 + i);
+      std::string ref, seq;
+      bool rev;
+      synth_sequence(rng, n, mf, ref, seq, rev);
+      Trace tr;
+      render_trace(rng, seq, nullptr, 1.0, tr);
+      BaseCalls bc;
+      basecall(tr, bc, 0.33f);
+      Profile p;
+      createProfile(tr, bc, p, 0, 0);
+      std::memcpy(refs + (size_t)i * n, ref.data(), n);
+      float* dst = profiles + (size_t)i * 6 * mf;
+      for (int k = 0; k < 6; ++k)
+        for (uint32_t j = 0; j < mf; ++j) dst[(size_t)k * mf + j] = (j < p.cols) ? p(k, j) : (k < 4 ? 0.25f : 0.0f);
+      if (reverse) reverse[i] = rev ? 1 : 0;
+    }
+  };
+  std::vector<std::thread> th;
+  for (uint32_t t = 0; t < nthreads; ++t) th.emplace_back(work, t);
+  for (auto& t : th) t.join();
+}
+
+}  // extern "C"

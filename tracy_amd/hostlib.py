@@ -1,0 +1,58 @@
+"""ctypes binding of the host-side C++ library (libtracy_host.so): basecalling, trace -> profile and the
+seeded synthetic workloads.  These stages run on the host in the reference as well (abif.h, profile.h)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        p = os.path.join(_HERE, "lib", "libtracy_host.so")
+        if not os.path.exists(p):
+            raise ImportError("tracy_amd: %s is missing -- run `python tracy_amd/build.py`" % p)
+        _LIB = C.CDLL(p)
+        _LIB.tracyhost_basecall.restype = C.c_size_t
+        _LIB.tracyhost_iupac.restype = C.c_char
+    return _LIB
+
+
+def basecall(trace, basecallpos, sigratio=0.33):
+    trace = np.ascontiguousarray(trace, dtype=np.int32)
+    pos = np.ascontiguousarray(basecallpos, dtype=np.int32)
+    n = len(pos)
+    pri = C.create_string_buffer(n + 1)
+    sec = C.create_string_buffer(n + 1)
+    con = C.create_string_buffer(n + 1)
+    bc = np.zeros(max(n, 1), dtype=np.int32)
+    k = lib().tracyhost_basecall(trace.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(trace.shape[1]),
+                                 pos.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(n), C.c_float(sigratio), pri, sec,
+                                 con, bc.ctypes.data_as(C.POINTER(C.c_int32)))
+    return pri.raw[:k], sec.raw[:k], con.raw[:k], bc[:k].copy()
+
+
+def create_profile(trace, bcpos, primary, secondary, trimleft=0, trimright=0):
+    trace = np.ascontiguousarray(trace, dtype=np.int32)
+    bcpos = np.ascontiguousarray(bcpos, dtype=np.int32)
+    nbc = len(bcpos)
+    out = np.zeros(6 * max(nbc, 1), dtype=np.float32)
+    sz = lib().tracyhost_create_profile(trace.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(trace.shape[1]),
+                                        bcpos.ctypes.data_as(C.POINTER(C.c_int32)), bytes(primary), bytes(secondary),
+                                        C.c_size_t(nbc), int(trimleft), int(trimright),
+                                        out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[:6 * sz].reshape(6, sz).copy()
+
+
+def synth_align(seed0, ntraces, n, mf, nthreads=0):
+    """returns refs uint8 [ntraces][n], profiles float32 [ntraces][6][mf], reverse uint8 [ntraces]"""
+    refs = np.zeros((ntraces, n), dtype=np.uint8)
+    profs = np.zeros((ntraces, 6, mf), dtype=np.float32)
+    rev = np.zeros(ntraces, dtype=np.uint8)
+    lib().tracyhost_synth_align(C.c_uint64(seed0), C.c_uint32(ntraces), C.c_uint32(n), C.c_uint32(mf),
+                                refs.ctypes.data_as(C.POINTER(C.c_uint8)), profs.ctypes.data_as(C.POINTER(C.c_float)),
+                                rev.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_uint32(nthreads))
+    return refs, profs, rev

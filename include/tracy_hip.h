@@ -16,7 +16,9 @@
  *   DnaScore<int>, AlignConfig<H,V>        align.h:11-32, 37-80             tracyhip_params
  *   sage() hot section                     sage.h:191-311                   tracyhip_align_traces
  *   findBreakpoint                         decompose.h:7-56                 tracyhip_find_breakpoint
+ *   findHomozygousBreakpoint               decompose.h:59-128               tracyhip_find_homozygous_breakpoint
  *   decomposeAlleles                       decompose.h:179-376              tracyhip_decompose_alleles
+ *   generateSecondaryDecomposed            decompose.h:378-410              tracyhip_secondary_decomposed
  *   allelicFraction                        decompose.h:412-621              tracyhip_allelic_fraction
  *
  * Conventions
@@ -150,6 +152,69 @@ typedef struct {
 
 int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm,
                           int mem, const tracyhip_align_result* out);
+
+/* ---- allele deconvolution (`tracy decompose`, indigo.h:190-388) ------------------------------------ */
+/* TraceBreakpoint, fmindex.h:51-56 */
+typedef struct {
+  int32_t indelshift;
+  int32_t traceleft;
+  uint32_t breakpoint;
+  float best_diff;
+} tracyhip_breakpoint;
+
+/* Trace + BaseCalls of a batch (abif.h:28-57), flattened.  signal/bcpos/primary/secondary are payloads
+ * (host or device per `mem`), the offset/length arrays are HOST arrays. */
+typedef struct {
+  uint32_t ntraces;
+  const int32_t* signal;         /* trace t: channels A,C,G,T at signal + signal_offset[t] + k*nsamples[t] */
+  const uint64_t* signal_offset;
+  const uint32_t* nsamples;
+  const int32_t* bcpos;          /* bc.bcPos of trace t at bcpos + bc_offset[t] */
+  uint8_t* primary;              /* bc.primary   at primary   + bc_offset[t] (rewritten by decomposeAlleles) */
+  uint8_t* secondary;            /* bc.secondary at secondary + bc_offset[t] (rewritten by decomposeAlleles) */
+  const uint64_t* bc_offset;
+  const uint32_t* bc_len;        /* bc.consensus.size() */
+} tracyhip_basecalls;
+
+/* the IndigoConfig fields decomposeAlleles reads (indigo.h:16-40; CLI defaults 50, 50, 1000, 5) */
+typedef struct {
+  int32_t trim_left;
+  int32_t trim_right;
+  int32_t maxindel;
+  int32_t madc;
+} tracyhip_decomp_params;
+
+/* what decomposeAlleles printed / chose: kind 0 = an indel shift was applied, 1 = "Complex mutation,
+ * decomposition: ins, del, error" (decompose.h:315), 2 = "No InDel detected" (decompose.h:327) */
+typedef struct {
+  int32_t kind;
+  int32_t best_ins;
+  int32_t best_del;
+  int32_t best_fr;
+  uint32_t dcp_n; /* rows written to the decomposition table */
+  uint32_t pad;
+} tracyhip_decomp_status;
+
+/* findBreakpoint, decompose.h:7-56: one breakpoint per profile of the set. */
+int tracyhip_find_breakpoint(tracyhip_ctx* ctx, const tracyhip_seqset* profiles, int mem, tracyhip_breakpoint* out);
+/* findHomozygousBreakpoint, decompose.h:59-128, applied to the traces whose bps[t].indelshift == 0
+ * (indigo.h:314-317).  status[t]: 1 ok, 0 "No valid alignment", -1 "Alignment too short". */
+int tracyhip_find_homozygous_breakpoint(tracyhip_ctx* ctx, uint32_t ntraces, const uint8_t* rows0, const uint8_t* rows1,
+                                        const uint64_t* rows_offset, const uint32_t* rows_len, int mem,
+                                        tracyhip_breakpoint* bps, int32_t* status);
+/* decomposeAlleles, decompose.h:179-376.  rows0/rows1: the 2-row alignment of the trimmed trace vs the
+ * reference slice (tracyhip_alignment_rows); bps: payload array; refslice_len: HOST array (rs.refslice.size()).
+ * The decomposition table of trace t (pairs indel, error; decompose.h:273-285) goes to dcp_* + dcp_offset[t],
+ * capacity 2*maxindel+2 entries. */
+int tracyhip_decompose_alleles(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, const uint8_t* rows0, const uint8_t* rows1,
+                               const uint64_t* rows_offset, const uint32_t* rows_len, const tracyhip_breakpoint* bps,
+                               const uint32_t* refslice_len, const tracyhip_decomp_params* prm, int mem,
+                               int32_t* dcp_indel, int32_t* dcp_err, const uint64_t* dcp_offset, tracyhip_decomp_status* status);
+/* generateSecondaryDecomposed, decompose.h:378-410: secdecomp + bc_offset[t] receives bc.secDecompose. */
+int tracyhip_secondary_decomposed(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, int mem, uint8_t* secdecomp);
+/* allelicFraction, decompose.h:412-621: fractions[2t], fractions[2t+1] = the returned pair. */
+int tracyhip_allelic_fraction(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, const uint8_t* secdecomp, uint32_t trim_left,
+                              uint32_t trim_right, int mem, double* fractions);
 
 /* ---- kernel timing (HIP events recorded on the context's stream around each DP / walker launch) ---
  * The reference has only the optional gperftools wrapper (sage.h:60-62); this is the hook bench.py uses

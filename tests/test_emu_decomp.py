@@ -1,0 +1,129 @@
+"""decompose phase functions (tracy_amd/csrc/decompose_kernels.h) run on the host vs the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pyoracle as orc
+from decomp_cases import case_list, oracle_decompose
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so = os.path.join(HERE, "emu", "libemu_decomp.so")
+    srcs = [os.path.join(HERE, "emu", "emu_decomp.cpp"), os.path.join(ROOT, "tracy_amd/csrc/decompose_kernels.h"),
+            os.path.join(ROOT, "tracy_amd/csrc/dp_lane.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0]],
+                              stderr=subprocess.DEVNULL)
+    lib = C.CDLL(so)
+    lib.emu_phase.restype = C.c_char
+    lib.emu_secdecomp.restype = C.c_uint8
+    return lib
+
+
+@pytest.fixture(scope="module")
+def cases():
+    return case_list()
+
+
+def run_emu_decompose(emu, c, maxindel=1000, madc=5):
+    r0, r1 = c["rows"]
+    pri = C.create_string_buffer(c["pri"], len(c["pri"]) + 1)
+    sec = C.create_string_buffer(c["sec"], len(c["sec"]) + 1)
+    di = (C.c_int32 * (2 * maxindel + 4))()
+    de = (C.c_int32 * (2 * maxindel + 4))()
+    out = (C.c_int32 * 6)()
+    emu.emu_decompose(r0, r1, len(r0), pri, sec, len(c["pri"]), c["bp"].breakpoint, len(c["ref"]), 50, 50, maxindel, madc,
+                      di, de, out)
+    n = out[4]
+    return pri.raw[:len(c["pri"])], sec.raw[:len(c["sec"])], [(di[i], de[i]) for i in range(n)], tuple(out[:4])
+
+
+def test_decompose_phases_match_oracle(emu, cases):
+    kinds = set()
+    for c in cases:
+        want = oracle_decompose(c)
+        got = run_emu_decompose(emu, c)
+        assert got[0] == want["pri"] and got[1] == want["sec"]
+        assert got[2] == want["dcp"]
+        assert got[3][0] == want["status"][0]
+        if want["status"][0] != 0:
+            assert got[3] == want["status"]
+        kinds.add(want["status"][0])
+    assert 0 in kinds  # at least one plain indel shift among the synthetic traces
+    # small maxindel / different MAD cut-off exercise the clamps
+    c = cases[0]
+    for (mi, madc) in [(1, 5), (7, 5), (40, 0), (300, 9)]:
+        want = orc.decompose_alleles(c["rows"][0], c["rows"][1], c["pri"], c["sec"], c["bp"], len(c["ref"]), 50, 50, mi, madc)
+        got = run_emu_decompose(emu, c, mi, madc)
+        assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2] and got[3][0] == want[3][0]
+
+
+def test_complex_and_none_paths(emu):
+    """hand-made alignments: identical sequences (no indel: kind 2) and a shifted tail with junk (complex)"""
+    rng = np.random.default_rng(3)
+    L = 400
+    ref = bytes(rng.choice(list(b"ACGT"), size=L).tolist())
+    pri = b"A" * 50 + ref[:300] + b"A" * 50
+    sec = pri
+    row0 = ref[:300] + b"-" * 100
+    row1 = ref
+    for bpv in (120, 300):
+        bp = orc.Breakpoint(0, 1, bpv, 0.0)
+        c = dict(rows=(row0, row1), pri=pri, sec=sec, bp=bp, ref=ref)
+        want = orc.decompose_alleles(row0, row1, pri, sec, bp, len(ref), 50, 50, 1000, 5)
+        got = run_emu_decompose(emu, c)
+        assert (got[0], got[1], got[2]) == (want[0], want[1], want[2]) and got[3] == want[3]
+    # heterozygous tail: secondary carries the reference shifted by 3 with an extra insertion -> complex search
+    tail = ref[150:300]
+    sec2 = bytearray(pri)
+    shifted = ref[153:303]
+    sec2[50 + 150:50 + 300] = shifted
+    bp = orc.Breakpoint(1, 1, 150, 0.5)
+    c = dict(rows=(row0, row1), pri=pri, sec=bytes(sec2), bp=bp, ref=ref)
+    want = orc.decompose_alleles(row0, row1, pri, bytes(sec2), bp, len(ref), 50, 50, 1000, 5)
+    got = run_emu_decompose(emu, c)
+    assert (got[0], got[1], got[2]) == (want[0], want[1], want[2]) and got[3][0] == want[3][0]
+
+
+def test_breakpoints_and_small_functions(emu, cases):
+    for c in cases:
+        p = np.ascontiguousarray(c["prof"], dtype=np.float32)
+        out = (C.c_int32 * 4)()
+        bd = C.c_float(0)
+        emu.emu_find_breakpoint(p.ctypes.data_as(C.POINTER(C.c_float)), p.shape[1], p.shape[1], out, C.byref(bd))
+        want = orc.find_breakpoint(p)
+        assert (out[0], out[1], out[2]) == (want.indelshift, want.traceleft, want.breakpoint)
+        assert np.float32(bd.value) == np.float32(want.bestDiff)
+        r0, r1 = c["rows"]
+        rc = emu.emu_homozygous(r0, r1, len(r0), out, C.byref(bd))
+        wrc, wbp = orc.find_homozygous_breakpoint(r0, r1)
+        assert rc == wrc and (out[0], out[1], out[2]) == (wbp.indelshift, wbp.traceleft, wbp.breakpoint)
+        assert np.float32(bd.value) == np.float32(wbp.bestDiff)
+    # degenerate alignments: the two failure codes
+    out = (C.c_int32 * 4)()
+    bd = C.c_float(0)
+    assert emu.emu_homozygous(b"----", b"ACGT", 4, out, C.byref(bd)) == orc.find_homozygous_breakpoint(b"----", b"ACGT")[0] == 0
+    short = b"ACGTACGTAC" * 3
+    assert emu.emu_homozygous(short, short, len(short), out, C.byref(bd)) == orc.find_homozygous_breakpoint(short, short)[0] == -1
+    # phaseRefAllele over the whole alphabet
+    lib = orc.lib()
+    for p in b"ACGTN":
+        for s in b"ACGTNRYSWKMX":
+            for r in b"ACGTN-X":
+                pri = bytes([p]); sec = bytes([s])
+                want = orc.decompose_alleles(bytes([p]) , bytes([r]), pri, sec, orc.Breakpoint(1, 1, 5, 1.0), 10, 0, 0, 1, 5)
+                got = emu.emu_phase(C.c_char(bytes([p])), C.c_char(bytes([s])), C.c_char(bytes([r])))
+                # the walk applies the phase when row1 != primary: compare through its effect
+                if r != p:
+                    exp_sec = want[1]
+                    if got != b"N":
+                        assert want[0] == bytes([r]) and exp_sec == got
+                    else:
+                        assert want[0] == pri and exp_sec == sec

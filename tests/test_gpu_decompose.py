@@ -1,0 +1,93 @@
+"""GPU parity of the allele-deconvolution kernels (decompose.h) through the C ABI, against the oracle."""
+import numpy as np
+import pytest
+
+import pyoracle as orc
+from decomp_cases import SC, case_list, oracle_decompose
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import tracy_amd
+    c = tracy_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def cases():
+    return case_list()
+
+
+def test_find_breakpoint(ctx, cases):
+    rng = np.random.default_rng(0)
+    profs = [c["prof"] for c in cases]
+    flat = np.zeros((6, 300), dtype=np.float32)
+    flat[:4] = 0.25
+    short = np.ascontiguousarray(cases[0]["prof"][:, :20])
+    noise = np.zeros((6, 777), dtype=np.float32)
+    x = rng.random((4, 777)).astype(np.float32)
+    noise[:4] = x / x.sum(axis=0)
+    profs += [flat, short, noise]
+    got = ctx.find_breakpoint(profs)
+    for p, g in zip(profs, got):
+        w = orc.find_breakpoint(p)
+        assert (g.indelshift, g.traceleft, g.breakpoint) == (w.indelshift, w.traceleft, w.breakpoint)
+        assert np.float32(g.best_diff) == np.float32(w.bestDiff)
+
+
+def test_homozygous_breakpoint(ctx, cases):
+    from tracy_amd import capi
+    rows = [c["rows"] for c in cases] + [(b"----", b"ACGT"), (b"ACGTACGTAC" * 3, b"ACGTACGTAC" * 3)]
+    bps = [capi.Breakpoint(0, 1, 0, 0.0) for _ in rows]
+    got, status = ctx.find_homozygous_breakpoint(rows, bps)
+    for r, g, s in zip(rows, got, status):
+        rc, w = orc.find_homozygous_breakpoint(r[0], r[1])
+        assert int(s) == rc
+        if rc == 1:
+            assert (g.indelshift, g.traceleft, g.breakpoint) == (w.indelshift, w.traceleft, w.breakpoint)
+            assert np.float32(g.best_diff) == np.float32(w.bestDiff)
+    # traces with an indel shift are left untouched (indigo.h:314-317)
+    bps = [capi.Breakpoint(1, 0, 123, 0.5) for _ in rows]
+    got, status = ctx.find_homozygous_breakpoint(rows, bps)
+    assert all(g.breakpoint == 123 and g.indelshift == 1 for g in got)
+
+
+def test_decompose_chain(ctx, cases):
+    """decomposeAlleles -> generateSecondaryDecomposed -> allelicFraction, batched, vs the oracle"""
+    from tracy_amd import capi
+    want = [oracle_decompose(c) for c in cases]
+    hbc = capi.HostBaseCalls([c["sig"] for c in cases], [c["bcpos"] for c in cases], [c["pri"] for c in cases],
+                             [c["sec"] for c in cases])
+    bps = [capi.Breakpoint(c["bp"].indelshift, c["bp"].traceleft, c["bp"].breakpoint, c["bp"].bestDiff) for c in cases]
+    pri, sec, dcp, status = ctx.decompose_alleles(hbc, [c["rows"] for c in cases], bps, [len(c["ref"]) for c in cases])
+    for i, w in enumerate(want):
+        assert pri[i] == w["pri"] and sec[i] == w["sec"], i
+        assert dcp[i] == w["dcp"], i
+        assert status[i][0] == w["status"][0]
+        if w["status"][0] != 0:
+            assert status[i] == w["status"]
+    sd = ctx.secondary_decomposed(hbc)
+    for i, w in enumerate(want):
+        assert hbc.split(sd)[i] == w["secdecomp"]
+    fr = ctx.allelic_fraction(hbc, sd, 50, 50)
+    for i, w in enumerate(want):
+        assert (float(fr[i, 0]), float(fr[i, 1])) == w["af"], (i, fr[i], w["af"])
+    assert any(w["af"] != (0.5, 0.5) for w in want)
+
+
+def test_decompose_parameter_edges(ctx, cases):
+    from tracy_amd import capi
+    c = cases[0]
+    for (mi, madc) in [(1, 5), (7, 5), (40, 0), (300, 9)]:
+        hbc = capi.HostBaseCalls([c["sig"]], [c["bcpos"]], [c["pri"]], [c["sec"]])
+        bps = [capi.Breakpoint(c["bp"].indelshift, c["bp"].traceleft, c["bp"].breakpoint, c["bp"].bestDiff)]
+        pri, sec, dcp, status = ctx.decompose_alleles(hbc, [c["rows"]], bps, [len(c["ref"])], 50, 50, mi, madc)
+        w = orc.decompose_alleles(c["rows"][0], c["rows"][1], c["pri"], c["sec"], c["bp"], len(c["ref"]), 50, 50, mi, madc)
+        assert (pri[0], sec[0], dcp[0]) == (w[0], w[1], w[2]) and status[0][0] == w[3][0]
+    # allelic fraction: identical alleles -> (0.5, 0.5); untrimmed corner
+    hbc = capi.HostBaseCalls([c["sig"]], [c["bcpos"]], [c["pri"]], [c["pri"]])
+    fr = ctx.allelic_fraction(hbc, np.frombuffer(c["pri"], dtype=np.uint8), 50, 50)
+    assert tuple(fr[0]) == (0.5, 0.5)

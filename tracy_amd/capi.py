@@ -261,3 +261,143 @@ Context.align_traces = _align_traces
 
 class KernelTiming(C.Structure):
     _fields_ = [("ms", C.c_double), ("launches", C.c_uint64), ("cells", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+# ---- allele deconvolution --------------------------------------------------------------------------
+class Breakpoint(C.Structure):
+    _fields_ = [("indelshift", C.c_int32), ("traceleft", C.c_int32), ("breakpoint", C.c_uint32), ("best_diff", C.c_float)]
+
+
+class BaseCallsBatch(C.Structure):
+    _fields_ = [("ntraces", C.c_uint32), ("signal", C.c_void_p), ("signal_offset", C.POINTER(C.c_uint64)),
+                ("nsamples", C.POINTER(C.c_uint32)), ("bcpos", C.c_void_p), ("primary", C.c_void_p),
+                ("secondary", C.c_void_p), ("bc_offset", C.POINTER(C.c_uint64)), ("bc_len", C.POINTER(C.c_uint32))]
+
+
+class DecompParams(C.Structure):
+    _fields_ = [("trim_left", C.c_int32), ("trim_right", C.c_int32), ("maxindel", C.c_int32), ("madc", C.c_int32)]
+
+
+class DecompStatus(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("best_ins", C.c_int32), ("best_del", C.c_int32), ("best_fr", C.c_int32),
+                ("dcp_n", C.c_uint32), ("pad", C.c_uint32)]
+
+
+def _u64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class HostBaseCalls:
+    """pack lists of (signal [4][ns] int32, bcpos, primary, secondary) for the host-buffer entry points"""
+
+    def __init__(self, signals, bcpos, primary, secondary):
+        n = len(signals)
+        self.n = n
+        self.nsamples = np.array([s.shape[1] for s in signals], dtype=np.uint32)
+        self.sig_off = np.zeros(max(n, 1), dtype=np.uint64)
+        self.bc_len = np.array([len(p) for p in primary], dtype=np.uint32)
+        self.bc_off = np.zeros(max(n, 1), dtype=np.uint64)
+        so, bo = 0, 0
+        for i in range(n):
+            self.sig_off[i] = so
+            so += 4 * int(self.nsamples[i])
+            self.bc_off[i] = bo
+            bo += int(self.bc_len[i])
+        self.signal = np.concatenate([np.ascontiguousarray(s, dtype=np.int32).reshape(-1) for s in signals]) if n else np.zeros(1, np.int32)
+        self.bcpos = np.concatenate([np.ascontiguousarray(b, dtype=np.int32) for b in bcpos]) if n else np.zeros(1, np.int32)
+        self.primary = np.frombuffer(b"".join(bytes(p) for p in primary), dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
+        self.secondary = np.frombuffer(b"".join(bytes(p) for p in secondary), dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
+
+    def struct(self):
+        b = BaseCallsBatch()
+        b.ntraces = self.n
+        b.signal = self.signal.ctypes.data
+        b.signal_offset = _u64p(self.sig_off)
+        b.nsamples = _u32p(self.nsamples)
+        b.bcpos = self.bcpos.ctypes.data
+        b.primary = self.primary.ctypes.data
+        b.secondary = self.secondary.ctypes.data
+        b.bc_offset = _u64p(self.bc_off)
+        b.bc_len = _u32p(self.bc_len)
+        return b
+
+    def split(self, arr):
+        return [arr[int(self.bc_off[i]):int(self.bc_off[i]) + int(self.bc_len[i])].tobytes() for i in range(self.n)]
+
+
+def _find_breakpoint(self, profiles):
+    pp = profiles if isinstance(profiles, PackedSeqs) else PackedSeqs(profiles, SEQ_PROFILE)
+    out = (Breakpoint * max(pp.count, 1))()
+    ss = pp.seqset()
+    _check(lib().tracyhip_find_breakpoint(self._h, C.byref(ss), MEM_HOST, out))
+    return [out[i] for i in range(pp.count)]
+
+
+def _pack_rows(rows):
+    n = len(rows)
+    lens = np.array([len(r[0]) for r in rows], dtype=np.uint32)
+    off = np.zeros(max(n, 1), dtype=np.uint64)
+    if n:
+        off[1:n] = np.cumsum(lens.astype(np.uint64))[:-1]
+    r0 = np.frombuffer(b"".join(r[0] for r in rows) + b"\0", dtype=np.uint8).copy()
+    r1 = np.frombuffer(b"".join(r[1] for r in rows) + b"\0", dtype=np.uint8).copy()
+    return r0, r1, off, lens
+
+
+def _find_homozygous_breakpoint(self, rows, bps):
+    n = len(rows)
+    r0, r1, off, lens = _pack_rows(rows)
+    arr = (Breakpoint * max(n, 1))(*bps)
+    status = np.zeros(max(n, 1), dtype=np.int32)
+    _check(lib().tracyhip_find_homozygous_breakpoint(self._h, n, r0.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                     r1.ctypes.data_as(C.POINTER(C.c_uint8)), _u64p(off), _u32p(lens), MEM_HOST,
+                                                     arr, status.ctypes.data_as(C.POINTER(C.c_int32))))
+    return [arr[i] for i in range(n)], status[:n]
+
+
+def _decompose_alleles(self, hbc, rows, bps, refslice_len, trim_left=50, trim_right=50, maxindel=1000, madc=5):
+    n = hbc.n
+    r0, r1, off, lens = _pack_rows(rows)
+    arr = (Breakpoint * max(n, 1))(*bps)
+    rl = np.ascontiguousarray(refslice_len, dtype=np.uint32)
+    cap = 2 * maxindel + 2
+    doff = (np.arange(max(n, 1), dtype=np.uint64) * np.uint64(cap))
+    di = np.zeros(max(n, 1) * cap, dtype=np.int32)
+    de = np.zeros(max(n, 1) * cap, dtype=np.int32)
+    st = (DecompStatus * max(n, 1))()
+    prm = DecompParams(trim_left, trim_right, maxindel, madc)
+    b = hbc.struct()
+    _check(lib().tracyhip_decompose_alleles(self._h, C.byref(b), r0.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                            r1.ctypes.data_as(C.POINTER(C.c_uint8)), _u64p(off), _u32p(lens), arr, _u32p(rl),
+                                            C.byref(prm), MEM_HOST, di.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            de.ctypes.data_as(C.POINTER(C.c_int32)), _u64p(doff), st))
+    dcp = [[(int(di[i * cap + k]), int(de[i * cap + k])) for k in range(st[i].dcp_n)] for i in range(n)]
+    status = [(st[i].kind, st[i].best_ins, st[i].best_del, st[i].best_fr) for i in range(n)]
+    return hbc.split(hbc.primary), hbc.split(hbc.secondary), dcp, status
+
+
+def _secondary_decomposed(self, hbc):
+    out = np.zeros(max(len(hbc.primary), 1), dtype=np.uint8)
+    b = hbc.struct()
+    _check(lib().tracyhip_secondary_decomposed(self._h, C.byref(b), MEM_HOST, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return out
+
+
+def _allelic_fraction(self, hbc, secdecomp, trim_left=50, trim_right=50):
+    fr = np.zeros(2 * max(hbc.n, 1), dtype=np.float64)
+    b = hbc.struct()
+    sd = np.ascontiguousarray(secdecomp, dtype=np.uint8)
+    _check(lib().tracyhip_allelic_fraction(self._h, C.byref(b), sd.ctypes.data_as(C.POINTER(C.c_uint8)), trim_left, trim_right,
+                                           MEM_HOST, fr.ctypes.data_as(C.POINTER(C.c_double))))
+    return fr[:2 * hbc.n].reshape(-1, 2)
+
+
+Context.find_breakpoint = _find_breakpoint
+Context.find_homozygous_breakpoint = _find_homozygous_breakpoint
+Context.decompose_alleles = _decompose_alleles
+Context.secondary_decomposed = _secondary_decomposed
+Context.allelic_fraction = _allelic_fraction

@@ -1,0 +1,447 @@
+// decompose_kernels.h -- allele deconvolution (decompose.h) as per-trace workgroup phases.
+//
+// One 64-lane workgroup per trace.  Serial bookkeeping (the walk to the breakpoint, pick rules, table
+// emission) runs on lane 0; the expensive parts -- the indel-shift scans (decompose.h:214-224, 251-261,
+// 293-313) and the rewrite of the basecalls (:317-326, 351-371) -- spread over the lanes.  Phases
+// communicate only through the DecompShared block (LDS on the device) and are separated by barriers,
+// so tests/emu can run the same phase functions on the host by looping over lanes.
+//
+// Everything here is byte/integer work and must be bit-exact with the reference, including its
+// unsigned wrap-arounds.
+#ifndef TRACY_AMD_DECOMPOSE_KERNELS_H
+#define TRACY_AMD_DECOMPOSE_KERNELS_H
+
+#include "dp_lane.h"
+
+namespace tracyhip {
+
+// iupac(char,char), abif.h:142-161
+TR_HD char iupac2(char one, char two) {
+  int a = one == 'C' ? 1 : one == 'G' ? 2 : one == 'T' ? 3 : 0;
+  int b = two == 'C' ? 1 : two == 'G' ? 2 : two == 'T' ? 3 : 0;
+  if (b < a) { const int t = a; a = b; b = t; }
+  if (a == 0 && b == 2) return 'R';
+  if (a == 1 && b == 3) return 'Y';
+  if (a == 1 && b == 2) return 'S';
+  if (a == 0 && b == 3) return 'W';
+  if (a == 2 && b == 3) return 'K';
+  if (a == 0 && b == 1) return 'M';
+  return 'N';
+}
+
+// phaseRefAllele, decompose.h:147-175 (p, s = primary/secondary at the position, r = reference char)
+TR_HD char phase_ref_allele(char p, char s, char r) {
+  if (r == '-' || s == 'N') return 'N';
+  if (s == r) return p;
+  char x = 0, y = 0;  // the two bases the IUPAC secondary stands for
+  switch (s) {
+    case 'R': x = 'A'; y = 'G'; break;
+    case 'Y': x = 'C'; y = 'T'; break;
+    case 'S': x = 'C'; y = 'G'; break;
+    case 'W': x = 'A'; y = 'T'; break;
+    case 'K': x = 'G'; y = 'T'; break;
+    case 'M': x = 'A'; y = 'C'; break;
+    default: return 'N';
+  }
+  if (r == x) return iupac2(p, y);
+  if (r == y) return iupac2(p, x);
+  return 'N';
+}
+
+struct DecompParams {  // the IndigoConfig fields decomposeAlleles reads (indigo.h:16-40)
+  int32_t trimLeft, trimRight, maxindel, madc;
+};
+
+// per-trace descriptor (device memory)
+struct DecompDesc {
+  uint64_t rows_off;     // alignment rows: row0 at rows0 + rows_off, row1 at rows1 + rows_off
+  uint64_t bc_off;       // primary / secondary (in-out copies) at bc_off, nbc bytes each
+  uint64_t dcp_off;      // decomposition table: dcp_indel/dcp_err + dcp_off, capacity 2*maxindel+2
+  uint32_t L;            // alignment columns
+  uint32_t nbc;          // bc.consensus.size()
+  uint32_t refslice_len; // rs.refslice.size()
+  uint32_t breakpoint;   // bp.breakpoint (trimmed-trace coordinates)
+};
+
+struct DecompOut {       // per trace
+  int32_t kind;          // 0 = an indel shift was applied, 1 = complex (:315), 2 = none (:327)
+  int32_t bestIns, bestDel, bestFR;
+  uint32_t dcp_n;
+  uint32_t pad;
+};
+
+struct DecompArgs {
+  const DecompDesc* desc;
+  const uint8_t* rows0;
+  const uint8_t* rows1;
+  uint8_t* primary;
+  uint8_t* secondary;
+  int32_t* dcp_indel;
+  int32_t* dcp_err;
+  DecompOut* out;
+  DecompParams prm;
+  uint32_t ntraces;
+};
+
+constexpr int kMaxIndelDev = 1024;  // maxindel handled in LDS (CLI default 1000)
+
+struct DecompShared {
+  int32_t fref[kMaxIndelDev];
+  int32_t fins[kMaxIndelDev];
+  int32_t hist[kMaxIndelDev * 2 + 2];
+  uint32_t nfref, nfins;
+  uint32_t varIndex, refPointer, alignIndex;
+  uint32_t maxdel, maxins, bp;
+  int32_t pick_del, pick_ins;  // smallest picked deletion / insertion, -1 = none
+  int32_t ndel, nins;          // number of picks
+  int32_t maxpick_del, maxpick_ins;
+  int32_t best_fr[64], best_ins[64], best_del[64];
+};
+
+// failedref of one shift (decompose.h:215-222 and the two other copies of that loop)
+TR_HD int32_t count_failed(const uint8_t* row1, uint32_t L, const uint8_t* pri, const uint8_t* sec, uint64_t vend,
+                           uint32_t jstart, uint32_t vi) {
+  int32_t failed = 0;
+  for (uint32_t j = jstart; (j < L) && ((uint64_t)vi < vend); ++j, ++vi) {
+    const char r = (char)row1[j], p = (char)pri[vi];
+    if (r != p) {
+      if (phase_ref_allele(p, (char)sec[vi], r) == 'N') ++failed;
+    }
+  }
+  return failed;
+}
+
+// ---- phase 1 (lane 0): walk to the breakpoint, phasing as we go (decompose.h:184-208), scan bounds ----
+TR_HD void decomp_phase_walk(const DecompArgs& a, const DecompDesc& d, DecompShared& sh) {
+  const uint8_t* row0 = a.rows0 + d.rows_off;
+  const uint8_t* row1 = a.rows1 + d.rows_off;
+  uint8_t* pri = a.primary + d.bc_off;
+  uint8_t* sec = a.secondary + d.bc_off;
+  const int32_t ltrim = a.prm.trimLeft, rtrim = a.prm.trimRight;
+  uint32_t varIndex = 0, refPointer = 0, alignIndex = 0;
+  uint32_t vi = (uint32_t)ltrim;
+  const uint32_t bp = d.breakpoint + (uint32_t)ltrim;
+  for (uint32_t j = 0; j < d.L; ++j) {
+    if (row0[j] != '-') {
+      if (row1[j] != pri[vi]) {
+        const char s = phase_ref_allele((char)pri[vi], (char)sec[vi], (char)row1[j]);
+        if (s != 'N') { pri[vi] = row1[j]; sec[vi] = (uint8_t)s; }
+      }
+      ++vi;
+      if (vi == bp) { alignIndex = j; varIndex = vi; break; }
+    }
+    if (row1[j] != '-') ++refPointer;
+  }
+  uint32_t maxdel = 2;
+  if ((uint64_t)d.refslice_len > (uint64_t)(uint32_t)(refPointer + (uint32_t)rtrim + 2u))
+    maxdel = (uint32_t)((uint64_t)d.refslice_len - (uint64_t)(uint32_t)(refPointer + (uint32_t)rtrim));
+  sh.varIndex = varIndex;
+  sh.refPointer = refPointer;
+  sh.alignIndex = alignIndex;
+  sh.maxdel = maxdel;
+  sh.bp = bp;
+  sh.maxins = (uint32_t)((int32_t)d.nbc - (int32_t)((uint32_t)rtrim + bp));
+  uint32_t nf = 0;
+  for (uint32_t del = 0; (del < (uint32_t)a.prm.maxindel) && (del < maxdel / 2); ++del) ++nf;
+  sh.nfref = nf;
+  uint32_t ni = 1;
+  for (uint32_t ins = 1; (ins < (uint32_t)a.prm.maxindel) && (ins < sh.maxins / 2); ++ins) ++ni;
+  sh.nfins = ni;
+}
+
+// ---- phase 2 (all lanes): deletion and insertion scans ----
+TR_HD void decomp_phase_scan(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, uint32_t lane) {
+  const uint8_t* row1 = a.rows1 + d.rows_off;
+  const uint8_t* pri = a.primary + d.bc_off;
+  const uint8_t* sec = a.secondary + d.bc_off;
+  const uint64_t vend = (uint64_t)d.nbc - (uint64_t)(int64_t)a.prm.trimRight;
+  for (uint32_t del = lane; del < sh.nfref; del += 64)
+    sh.fref[del] = count_failed(row1, d.L, pri, sec, vend, sh.alignIndex + del + 1, sh.varIndex);
+  for (uint32_t ins = 1 + lane; ins < sh.nfins; ins += 64)
+    sh.fins[ins] = count_failed(row1, d.L, pri, sec, vend, sh.alignIndex + 1, sh.varIndex + ins);
+}
+
+// value at sorted position n/2 (getMedian, decompose.h:129-135) of small non-negative ints via a histogram
+TR_HD int32_t median_hist(const int32_t* v, uint32_t n, int32_t* hist, uint32_t nh) {
+  for (uint32_t i = 0; i < nh; ++i) hist[i] = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t x = (uint32_t)v[i];
+    ++hist[x < nh ? x : nh - 1];
+  }
+  uint32_t seen = 0;
+  for (uint32_t x = 0; x < nh; ++x) {
+    seen += (uint32_t)hist[x];
+    if (seen > n / 2) return (int32_t)x;
+  }
+  return 0;
+}
+
+// ---- phase 3 (lane 0): cut-offs, picks, decomposition table (decompose.h:227-285) ----
+TR_HD void decomp_phase_pick(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, DecompOut& out) {
+  const uint32_t nfref = sh.nfref, nfins = sh.nfins;
+  const uint32_t nh = (uint32_t)kMaxIndelDev * 2 + 2;
+  sh.fins[0] = sh.fref[0];  // decompose.h:249
+  const int32_t med = median_hist(sh.fref, nfref, sh.hist, nh);
+  // MAD: median of |x - med|; values stay below nh as well
+  {
+    for (uint32_t i = 0; i < nh; ++i) sh.hist[i] = 0;
+    for (uint32_t i = 0; i < nfref; ++i) {
+      int32_t dv = sh.fref[i] - med;
+      if (dv < 0) dv = -dv;
+      ++sh.hist[(uint32_t)dv < nh ? (uint32_t)dv : nh - 1];
+    }
+  }
+  int32_t mad = 0;
+  {
+    uint32_t seen = 0;
+    for (uint32_t x = 0; x < nh; ++x) {
+      seen += (uint32_t)sh.hist[x];
+      if (seen > nfref / 2) { mad = (int32_t)x; break; }
+    }
+  }
+  int32_t thres = 0;
+  if (med > a.prm.madc * mad) thres = med - a.prm.madc * mad;
+  if (thres < 10) thres = 10;
+
+  int32_t ndel = 0, first_del = -1, max_del = -1;
+  for (uint32_t i = 0; i < nfref; ++i) {
+    if (sh.fref[i] < thres) {
+      bool take = false;
+      if ((i + 1 < nfref) && (2 * sh.fref[i] < sh.fref[i + 1])) take = true;
+      else if ((i > 0) && (2 * sh.fref[i] < sh.fref[i - 1])) take = true;
+      else if ((i == 0) && (i + 2 < nfref) && (2 * sh.fref[i] < sh.fref[i + 2])) take = true;
+      if (take) { if (first_del < 0) first_del = (int32_t)i; max_del = (int32_t)i; ++ndel; }
+    }
+  }
+  int32_t nins = 0, first_ins = -1, max_ins = -1;
+  for (uint32_t i = 0; i < nfins; ++i) {
+    if (sh.fins[i] < thres) {
+      bool take = false;
+      if ((i + 1 < nfins) && (2 * sh.fins[i] < sh.fins[i + 1])) take = true;
+      else if ((i > 0) && (2 * sh.fins[i] < sh.fins[i - 1])) take = true;
+      else if ((i == 0) && (i + 2 < nfins) && (2 * sh.fins[i] < sh.fins[i + 2])) take = true;
+      if (take) { if (first_ins < 0) first_ins = (int32_t)i; max_ins = (int32_t)i; ++nins; }
+    }
+  }
+  sh.ndel = ndel; sh.nins = nins;
+  sh.pick_del = first_del; sh.pick_ins = first_ins;
+
+  // decomposition table (decompose.h:273-285); picks are ascending so the largest is the last one
+  int32_t defins = 15;
+  if (ndel == 0 && nins == 0) defins = 50;
+  if (nins && max_ins + 15 > defins) defins = max_ins + 15;
+  if (defins > (int32_t)nfins) defins = (int32_t)nfins;
+  int32_t defdel = 15;
+  if (ndel == 0 && nins == 0) defdel = 50;
+  if (ndel && max_del + 15 > defdel) defdel = max_del + 15;
+  if (defdel > (int32_t)nfref) defdel = (int32_t)nfref;
+  int32_t* di = a.dcp_indel + d.dcp_off;
+  int32_t* de = a.dcp_err + d.dcp_off;
+  uint32_t nd = 0;
+  for (int32_t i = defdel - 1; i >= 0; --i) { di[nd] = -i; de[nd] = sh.fref[i]; ++nd; }
+  for (int32_t i = 1; i < defins; ++i) { di[nd] = i; de[nd] = sh.fins[i]; ++nd; }
+  out.dcp_n = nd;
+  out.kind = 0;
+  out.bestIns = 0; out.bestDel = 0; out.bestFR = 1000;
+  out.pad = 0;
+}
+
+// ---- phase 4 (all lanes, only when nothing was picked): complex ins x del search (:290-313) ----
+// Lane l takes ins = l, l+64, ...; within one ins the del loop is sequential (prevFailedRef).  The
+// reference accepts a candidate iff 2*f < prev and f < bestFR (strict), so the overall winner is the
+// smallest f among the 2*f < prev candidates, earliest (ins, del) on ties.
+TR_HD void decomp_phase_complex(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, uint32_t lane) {
+  const uint8_t* row1 = a.rows1 + d.rows_off;
+  const uint8_t* pri = a.primary + d.bc_off;
+  const uint8_t* sec = a.secondary + d.bc_off;
+  const uint64_t vend = (uint64_t)d.nbc - (uint64_t)(int64_t)a.prm.trimRight;
+  int32_t bfr = 1000, bi = 0, bd = 0;
+  for (uint32_t ins = lane; (ins < (uint32_t)a.prm.maxindel) && (ins < sh.maxins / 2); ins += 64) {
+    int32_t prev = 0;
+    for (uint32_t del = 0; (del < (uint32_t)a.prm.maxindel) && (del < sh.maxdel / 2); ++del) {
+      const int32_t f = count_failed(row1, d.L, pri, sec, vend, sh.alignIndex + del + 1, sh.varIndex + ins);
+      if (2 * f < prev && f < bfr) { bfr = f; bi = (int32_t)ins; bd = (int32_t)del; }
+      prev = f;
+    }
+  }
+  sh.best_fr[lane] = bfr; sh.best_ins[lane] = bi; sh.best_del[lane] = bd;
+}
+TR_HD void decomp_phase_complex_reduce(DecompShared& sh, DecompOut& out) {
+  int32_t bfr = 1000, bi = 0, bd = 0;
+  for (int l = 0; l < 64; ++l) {
+    const int32_t f = sh.best_fr[l];
+    if (f == 1000) continue;
+    if (f < bfr || (f == bfr && (sh.best_ins[l] < bi || (sh.best_ins[l] == bi && sh.best_del[l] < bd)))) {
+      bfr = f; bi = sh.best_ins[l]; bd = sh.best_del[l];
+    }
+  }
+  out.bestFR = bfr; out.bestIns = bi; out.bestDel = bd;
+  out.kind = (bfr != 1000) ? 1 : 2;
+}
+
+// ---- phase 5 (all lanes): rewrite the basecalls along the chosen shift (:317-326, 351-371) ----
+// Each position vi is touched once and only reads its own primary/secondary: lanes split the range.
+TR_HD void decomp_phase_apply(const DecompArgs& a, const DecompDesc& d, const DecompShared& sh, const DecompOut& out,
+                              uint32_t lane) {
+  const uint8_t* row0 = a.rows0 + d.rows_off;
+  const uint8_t* row1 = a.rows1 + d.rows_off;
+  uint8_t* pri = a.primary + d.bc_off;
+  uint8_t* sec = a.secondary + d.bc_off;
+  const uint64_t vend = (uint64_t)d.nbc - (uint64_t)(int64_t)a.prm.trimRight;
+  uint32_t jstart, vi0;
+  if (sh.ndel == 0 && sh.nins == 0) {
+    if (out.kind == 1) { jstart = sh.alignIndex + (uint32_t)out.bestDel + 1; vi0 = sh.varIndex + (uint32_t)out.bestIns; }
+    else {  // "No InDel detected, traverse the whole alignment" (:327-343): vi advances only on trace bases
+      if (lane != 0) return;
+      uint32_t vi = (uint32_t)a.prm.trimLeft;
+      for (uint32_t j = 0; j < d.L; ++j) {
+        if (row0[j] != '-') {
+          if (row1[j] != pri[vi]) {
+            const char s = phase_ref_allele((char)pri[vi], (char)sec[vi], (char)row1[j]);
+            if (s != 'N') { pri[vi] = row1[j]; sec[vi] = (uint8_t)s; }
+          }
+          ++vi;
+        }
+      }
+      return;
+    }
+  } else if (sh.ndel != 0) { jstart = sh.alignIndex + (uint32_t)sh.pick_del + 1; vi0 = sh.varIndex; }
+  else { jstart = sh.alignIndex + 1; vi0 = sh.varIndex + (uint32_t)sh.pick_ins; }
+  for (uint64_t k = lane;; k += 64) {
+    const uint64_t j = (uint64_t)jstart + k, vi = (uint64_t)vi0 + k;
+    if (!(j < d.L && vi < vend)) break;
+    if (row1[j] != pri[vi]) {
+      const char s = phase_ref_allele((char)pri[vi], (char)sec[vi], (char)row1[j]);
+      if (s != 'N') { pri[vi] = row1[j]; sec[vi] = (uint8_t)s; }
+    }
+  }
+}
+
+// =====================================================================================================
+// findBreakpoint (decompose.h:7-56).  sig[] (double, one per column) lives in LDS / scratch.
+// =====================================================================================================
+struct BreakpointOut {  // TraceBreakpoint, fmindex.h:51-56
+  int32_t indelshift;
+  int32_t traceleft;
+  uint32_t breakpoint;
+  float bestDiff;
+};
+
+// column j: best - second best of the 6 profile rows, both floored at 0.001 (decompose.h:12-24)
+TR_HD double signal_ratio(const float* p, uint32_t stride, uint32_t j) {
+  double best = 0.001, snd = 0.001;
+  for (uint32_t i = 0; i < 6; ++i) {
+    const float v = p[(uint64_t)i * stride + j];
+    if (v > best) { snd = best; best = v; }
+    else if (v > snd) { snd = v; }
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __dsub_rn(best, snd);
+#else
+  return best - snd;
+#endif
+}
+
+// |mean(right 25) - mean(left 25)| at i, summed in the reference's order (decompose.h:32-38)
+TR_HD double window_diff(const double* sig, uint32_t i, double* left_out, double* right_out) {
+  double ls = 0, rs = 0;
+  for (uint32_t k = i - 25; k < i; ++k) ls += sig[k];
+  for (uint32_t k = i; k < i + 25; ++k) rs += sig[k];
+  const double left = ls / 25.0, right = rs / 25.0;
+  *left_out = left;
+  *right_out = right;
+  const double dd = right - left;
+  return dd < 0 ? -dd : dd;
+}
+
+// the sequential maximum search with the float-typed bestDiff field (decompose.h:27-55)
+TR_HD void breakpoint_select(const double* diff, const uint8_t* left_lt_right, uint32_t ncol, BreakpointOut& bp) {
+  bp.bestDiff = 0;
+  bp.traceleft = 1;
+  bp.breakpoint = 0;
+  if (25 < ncol) {
+    for (uint32_t i = 25; i < ncol - 25; ++i) {
+      if (diff[i] > (double)bp.bestDiff) {
+        bp.breakpoint = i;
+        bp.bestDiff = (float)diff[i];
+        bp.traceleft = left_lt_right[i] ? 0 : 1;
+      }
+    }
+  }
+  bp.indelshift = 1;
+  if ((double)bp.bestDiff < 0.25) {
+    bp.indelshift = 0;
+    bp.breakpoint = ncol;
+    bp.traceleft = 1;
+    bp.bestDiff = 0;
+  }
+}
+
+// findHomozygousBreakpoint (decompose.h:59-128) on the two alignment rows; one lane per trace.
+// Returns 1 on success, 0 / -1 for the reference's two failure messages (it returns false for both).
+TR_HD int homozygous_breakpoint(const uint8_t* row0, const uint8_t* row1, uint32_t L, BreakpointOut& bp) {
+  int64_t alignStart = 0, alignEnd = 0, varIndex = 0;
+  for (int64_t j = 0; j < (int64_t)L; ++j) {
+    if (row0[j] != '-' && row1[j] != '-') { alignStart = j; break; }
+    if (row0[j] != '-') ++varIndex;
+  }
+  for (int32_t j = (int32_t)(L - 1); j >= 0; --j) {
+    if (row0[j] != '-' && row1[j] != '-') { alignEnd = j; break; }
+  }
+  if (alignStart >= alignEnd) return 0;
+  bp.bestDiff = 0;
+  bp.traceleft = 1;
+  bp.breakpoint = 0;
+  if (alignEnd < alignStart + 50) return -1;
+  for (uint32_t i = (uint32_t)alignStart; (int64_t)i < alignStart + 25; ++i)
+    if (row0[i] != '-') ++varIndex;
+  // mismatch counts of the two 25-column windows slide by one column per step: keep them as integers
+  // (the reference recounts them as doubles; the counts are exact either way)
+  int32_t lcount = 0, rcount = 0;
+  {
+    const uint32_t i0 = (uint32_t)(alignStart + 25);
+    for (uint32_t k = i0 - 25; k < i0; ++k) lcount += (row0[k] != row1[k]);
+    for (uint32_t k = i0; k < i0 + 25; ++k) rcount += (row0[k] != row1[k]);
+  }
+  for (uint32_t i = (uint32_t)(alignStart + 25); (int64_t)i < alignEnd - 25; ++i) {
+    if (row0[i] != '-') ++varIndex;
+    const double left = (double)lcount / 25.0, right = (double)rcount / 25.0;
+    double diff = right - left;
+    if (diff < 0) diff = -diff;
+    if (diff > (double)bp.bestDiff) {
+      bp.breakpoint = (uint32_t)varIndex;
+      bp.bestDiff = (float)diff;
+      bp.traceleft = (left < right) ? 1 : 0;
+    }
+    // slide: column i leaves the right window and enters the left one
+    lcount += (row0[i] != row1[i]) - (row0[i - 25] != row1[i - 25]);
+    rcount += (row0[i + 25] != row1[i + 25]) - (row0[i] != row1[i]);
+  }
+  bp.indelshift = 1;
+  if ((double)bp.bestDiff < 0.25) {
+    bp.indelshift = 0;
+    bp.breakpoint = (uint32_t)varIndex;
+    bp.traceleft = 1;
+    bp.bestDiff = 0;
+  }
+  return 1;
+}
+
+// generateSecondaryDecomposed (decompose.h:378-410), one position
+TR_HD uint8_t secondary_decomposed(uint8_t p, uint8_t s, const int32_t* trace, uint64_t nsamples, int32_t pos) {
+  if (p == s) return p;
+  if (s == 'A' || s == 'C' || s == 'G' || s == 'T') return s;
+  const int32_t A = trace[pos], Cc = trace[nsamples + pos], G = trace[2 * nsamples + pos], T = trace[3 * nsamples + pos];
+  switch (s) {
+    case 'R': return A > G ? 'A' : 'G';
+    case 'Y': return Cc > T ? 'C' : 'T';
+    case 'S': return Cc > G ? 'C' : 'G';
+    case 'W': return A > T ? 'A' : 'T';
+    case 'K': return G > T ? 'G' : 'T';
+    case 'M': return A > Cc ? 'A' : 'C';
+    default: return 'N';
+  }
+}
+
+}  // namespace tracyhip
+#endif

@@ -1,0 +1,452 @@
+// decompose_kernels.hip -- gfx950 kernels for the allele-deconvolution stage (decompose.h) and their
+// C-ABI entry points.  Byte/integer and fp64 work, no MFMA; see decompose_kernels.h for the phases.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../include/tracy_hip.h"
+#include "capi_internal.h"
+#include "decompose_kernels.h"
+
+using namespace tracyhip;
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess)                                                                           \
+      return set_error(_e == hipErrorOutOfMemory ? TRACYHIP_ERR_OOM : TRACYHIP_ERR_HIP, "%s failed: %s (%s:%d)", \
+                       #expr, hipGetErrorString(_e), __FILE__, __LINE__);                           \
+  } while (0)
+
+namespace {
+
+__device__ __forceinline__ void wg_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __syncthreads();
+}
+
+// ---- decomposeAlleles: one 64-lane workgroup per trace ---------------------------------------------
+__global__ __launch_bounds__(64) void decompose_kernel(DecompArgs a, const BreakpointOut* bps) {
+  __shared__ DecompShared sh;
+  const uint32_t t = blockIdx.x;
+  DecompDesc d = a.desc[t];
+  d.breakpoint = bps[t].breakpoint;
+  const uint32_t lane = threadIdx.x;
+  DecompOut out;
+  if (lane == 0) decomp_phase_walk(a, d, sh);
+  wg_sync();
+  decomp_phase_scan(a, d, sh, lane);
+  wg_sync();
+  if (lane == 0) decomp_phase_pick(a, d, sh, out);
+  wg_sync();
+  const bool complex_case = (sh.ndel == 0 && sh.nins == 0);
+  if (complex_case) {
+    decomp_phase_complex(a, d, sh, lane);
+    wg_sync();
+    if (lane == 0) {
+      decomp_phase_complex_reduce(sh, out);
+      sh.best_fr[0] = out.bestFR; sh.best_ins[0] = out.bestIns; sh.best_del[0] = out.bestDel;
+      sh.hist[0] = out.kind;
+    }
+    wg_sync();
+    if (lane != 0) { out.bestFR = sh.best_fr[0]; out.bestIns = sh.best_ins[0]; out.bestDel = sh.best_del[0]; out.kind = sh.hist[0]; }
+  } else if (lane != 0) {
+    out.kind = 0; out.bestIns = 0; out.bestDel = 0; out.bestFR = 1000;
+  }
+  decomp_phase_apply(a, d, sh, out, lane);
+  if (lane == 0) a.out[t] = out;
+}
+
+// ---- findBreakpoint: one workgroup per profile; sig/diff in dynamic LDS (ncol doubles each) --------
+struct BpDesc { uint64_t off; uint32_t stride; uint32_t ncol; };
+__global__ __launch_bounds__(64) void breakpoint_kernel(const BpDesc* desc, const float* prof, BreakpointOut* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const BpDesc d = desc[blockIdx.x];
+  double* sig = reinterpret_cast<double*>(smem);
+  double* diff = sig + d.ncol;
+  uint8_t* ltr = reinterpret_cast<uint8_t*>(diff + d.ncol);
+  const float* p = prof + d.off;
+  for (uint32_t j = threadIdx.x; j < d.ncol; j += 64) sig[j] = signal_ratio(p, d.stride, j);
+  __syncthreads();
+  if (25 < d.ncol) {
+    for (uint32_t i = 25 + threadIdx.x; i < d.ncol - 25; i += 64) {
+      double l, r;
+      diff[i] = window_diff(sig, i, &l, &r);
+      ltr[i] = (l < r) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    BreakpointOut bp;
+    breakpoint_select(diff, ltr, d.ncol, bp);
+    out[blockIdx.x] = bp;
+  }
+}
+
+struct RowsDesc { uint64_t off; uint32_t L; uint32_t pad; };
+__global__ __launch_bounds__(64) void homozygous_kernel(const RowsDesc* desc, const uint8_t* rows0, const uint8_t* rows1,
+                                                        uint32_t n, BreakpointOut* bps, int32_t* status) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  BreakpointOut bp = bps[t];
+  if (bp.indelshift) { status[t] = 1; return; }  // only when the trace shows no shift (indigo.h:314-317)
+  const RowsDesc d = desc[t];
+  status[t] = homozygous_breakpoint(rows0 + d.off, rows1 + d.off, d.L, bp);
+  bps[t] = bp;
+}
+
+struct BcDesc { uint64_t sig_off; uint64_t bc_off; uint32_t nsamples; uint32_t nbc; };
+__global__ void secdecomp_kernel(const BcDesc* desc, const int32_t* signal, const int32_t* bcpos, const uint8_t* pri,
+                                 const uint8_t* sec, uint8_t* outp) {
+  const BcDesc d = desc[blockIdx.y];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.nbc) outp[d.bc_off + i] = secondary_decomposed(pri[d.bc_off + i], sec[d.bc_off + i], signal + d.sig_off, d.nsamples, bcpos[d.bc_off + i]);
+}
+
+// ---- allelicFraction (decompose.h:412-621) -----------------------------------------------------------
+// Block of 256 threads per trace.  The reference keeps the first candidate (i,j,k ascending) whose full
+// SSE is strictly below everything before it, starting from SSE(0.5,0.5,0,0); its `break` only skips
+// terms of candidates that already lost.  Here every (i,j) pair belongs to one thread, which walks k in
+// order, prunes with a block-wide bound (strictly greater partial sums only) and keeps (min SSE, first
+// index); a final reduction takes the lowest index among equal minima.  All arithmetic is the reference's
+// fp64 sequence (sub, mul, add; no FMA).
+constexpr int AF_THREADS = 256;
+__global__ __launch_bounds__(AF_THREADS) void allelic_fraction_kernel(const BcDesc* desc, const int32_t* signal,
+                                                                      const int32_t* bcpos, const uint8_t* pri_all,
+                                                                      const uint8_t* sec_all, uint32_t trimLeft,
+                                                                      uint32_t trimRight, double* fractions) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double vals[100];
+  __shared__ unsigned long long bound_bits;
+  __shared__ double red_sse[AF_THREADS];
+  __shared__ uint32_t red_idx[AF_THREADS];
+  __shared__ uint32_t s_d;
+  __shared__ double s_sse0;
+  const BcDesc d = desc[blockIdx.x];
+  const uint8_t* pri = pri_all + d.bc_off;
+  const uint8_t* sec = sec_all + d.bc_off;
+  // trimmedSeq (abif.h:68-75)
+  uint32_t off = trimLeft, len;
+  if ((uint64_t)(uint32_t)(trimLeft + trimRight + 1) >= (uint64_t)d.nbc) { off = 0; len = d.nbc; }
+  else len = d.nbc - trimLeft - trimRight;
+  // LDS carve: tp[4][cap] doubles, cls[4][cap] bytes; cap = len
+  double* tp = reinterpret_cast<double*>(smem);
+  uint8_t* cls = reinterpret_cast<uint8_t*>(tp + 4 * (size_t)len);
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    double x = 0;
+    for (int a = 0; a < 100; ++a) { vals[a] = x; x = __dadd_rn(x, 0.01); }  // for (double i = 0; i <= 1; i += 0.01)
+    uint32_t dn = 0;
+    for (uint32_t i = 0; i < len; ++i) if (pri[off + i] != sec[off + i]) ++dn;
+    s_d = dn;
+  }
+  __syncthreads();
+  const uint32_t dn = s_d;
+  if (dn == 0) {
+    if (tid == 0) { fractions[2 * blockIdx.x] = 0.5; fractions[2 * blockIdx.x + 1] = 0.5; }
+    return;
+  }
+  if (tid == 0) {
+    const int32_t* sg = signal + d.sig_off;
+    uint32_t np = 0;
+    for (uint32_t i = 0; i < len; ++i) {
+      const uint8_t pc = pri[off + i], sc = sec[off + i];
+      if (pc == sc) continue;
+      const uint32_t bi_ = (i + trimLeft < d.nbc) ? i + trimLeft : d.nbc - 1;  // the reference indexes bcPos[i + trimLeft] (decompose.h:445)
+      const uint32_t tpos = (uint32_t)bcpos[d.bc_off + bi_];
+      int32_t s4[4];
+      for (int k = 0; k < 4; ++k) s4[k] = sg[(uint64_t)k * d.nsamples + tpos];
+      const double sigsum = (double)(s4[0] + s4[1] + s4[2] + s4[3]);
+      for (int k = 0; k < 4; ++k) { tp[(size_t)k * dn + np] = __ddiv_rn((double)s4[k], sigsum); cls[(size_t)k * dn + np] = 0; }
+      const int pi = pc == 'A' ? 0 : pc == 'C' ? 1 : pc == 'G' ? 2 : pc == 'T' ? 3 : -1;
+      const int si = sc == 'A' ? 0 : sc == 'C' ? 1 : sc == 'G' ? 2 : sc == 'T' ? 3 : -1;
+      if (pi >= 0 && si >= 0) {
+        int rest[2], nr = 0;
+        for (int k = 0; k < 4; ++k) if (k != pi && k != si) rest[nr++] = k;
+        cls[(size_t)pi * dn + np] = 1;
+        cls[(size_t)si * dn + np] = 2;
+        const bool first = s4[rest[0]] > s4[rest[1]];  // tertiary = the larger of the two remaining channels
+        cls[(size_t)rest[first ? 0 : 1] * dn + np] = 3;
+        cls[(size_t)rest[first ? 1 : 0] * dn + np] = 4;
+      }
+      ++np;
+    }
+    // SSE of the start point (0.5, 0.5, 0, 0), decompose.h:586-591
+    double sse = 0;
+    const double start[5] = {0.0, 0.5, 0.5, 0.0, 0.0};
+    for (uint32_t q = 0; q < 4 * dn; ++q) {
+      const double df = __dsub_rn(start[cls[q]], tp[q]);
+      sse = __dadd_rn(sse, __dmul_rn(df, df));
+    }
+    s_sse0 = sse;
+    bound_bits = (unsigned long long)__double_as_longlong(sse);
+  }
+  __syncthreads();
+  double my_sse = s_sse0;
+  uint32_t my_idx = 0xffffffffu;
+  const uint32_t terms = 4 * dn;
+  for (uint32_t pr = tid; pr < 10000; pr += AF_THREADS) {
+    const uint32_t ia = pr / 100, ib = pr % 100;
+    const double vi = vals[ia], vj = vals[ib];
+    const double sij = __dadd_rn(vi, vj);
+    if (!(sij <= 1.0)) continue;
+    for (uint32_t ic = 0; ic < 100; ++ic) {
+      const double vk = vals[ic];
+      const double sijk = __dadd_rn(sij, vk);
+      if (!(sijk <= 1.0)) break;  // vals ascend: the reference's `if` fails for every later k as well
+      const double vl = __dsub_rn(1.0, sijk);
+      const double pv[5] = {0.0, vi, vj, vk, vl};
+      const double bound = __longlong_as_double((long long)bound_bits);
+      double sse = 0;
+      uint32_t q = 0;
+      for (; q < terms; ++q) {
+        const double df = __dsub_rn(pv[cls[q]], tp[q]);
+        sse = __dadd_rn(sse, __dmul_rn(df, df));
+        if (sse > bound) break;
+      }
+      if (q == terms && sse < my_sse) {
+        my_sse = sse;
+        my_idx = (ia * 100 + ib) * 100 + ic;
+        atomicMin(&bound_bits, (unsigned long long)__double_as_longlong(sse));
+      }
+    }
+  }
+  red_sse[tid] = my_sse;
+  red_idx[tid] = my_idx;
+  __syncthreads();
+  if (tid == 0) {
+    double best = s_sse0;
+    uint32_t bidx = 0xffffffffu;
+    for (int q = 0; q < AF_THREADS; ++q) {
+      if (red_idx[q] == 0xffffffffu) continue;
+      if (red_sse[q] < best || (red_sse[q] == best && bidx != 0xffffffffu && red_idx[q] < bidx)) { best = red_sse[q]; bidx = red_idx[q]; }
+    }
+    double bi = 0.5, bj = 0.5;
+    if (bidx != 0xffffffffu) { bi = vals[bidx / 10000]; bj = vals[(bidx / 100) % 100]; }
+    fractions[2 * blockIdx.x] = bi;
+    fractions[2 * blockIdx.x + 1] = bj;
+  }
+}
+
+template <class T>
+int to_device(tracyhip_ctx* ctx, DevBuf& b, const std::vector<T>& v, const T** out) {
+  HIP_TRY(b.ensure(sizeof(T) * std::max<size_t>(v.size(), 1)));
+  if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, ctx->stream));
+  *out = static_cast<const T*>(b.p);
+  return TRACYHIP_OK;
+}
+
+// stage an in/out or output payload: DEVICE -> use as is; HOST -> device buffer (+ optional upload)
+int stage_io(tracyhip_ctx* ctx, DevBuf& b, void* user, uint64_t bytes, int mem, bool upload, void** dev) {
+  if (mem == TRACYHIP_MEM_DEVICE) { *dev = user; return TRACYHIP_OK; }
+  HIP_TRY(b.ensure(bytes ? bytes : 1));
+  if (upload && bytes) HIP_TRY(hipMemcpyAsync(b.p, user, bytes, hipMemcpyHostToDevice, ctx->stream));
+  *dev = b.p;
+  return TRACYHIP_OK;
+}
+int unstage(tracyhip_ctx* ctx, void* user, const void* dev, uint64_t bytes, int mem) {
+  if (mem == TRACYHIP_MEM_DEVICE || bytes == 0) return TRACYHIP_OK;
+  HIP_TRY(hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return TRACYHIP_OK;
+}
+
+uint64_t extent64(const uint64_t* off, const uint32_t* len, uint32_t n, uint64_t mult = 1) {
+  uint64_t e = 0;
+  for (uint32_t i = 0; i < n; ++i) e = std::max<uint64_t>(e, off[i] + mult * len[i]);
+  return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tracyhip_find_breakpoint(tracyhip_ctx* ctx, const tracyhip_seqset* profiles, int mem, tracyhip_breakpoint* out) {
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  if (!profiles || !out) return set_error(TRACYHIP_ERR_ARG, "null argument");
+  if (profiles->kind != TRACYHIP_SEQ_PROFILE) return set_error(TRACYHIP_ERR_ARG, "findBreakpoint takes profiles");
+  const uint32_t n = profiles->count;
+  if (n == 0) return TRACYHIP_OK;
+  static_assert(sizeof(tracyhip_breakpoint) == sizeof(BreakpointOut), "layout");
+  hipStream_t st = ctx->stream;
+  const void* d_prof;
+  if ((rc = stage_in(ctx, ctx->d_in1, profiles->data, seqset_extent(*profiles) * 4, mem, &d_prof))) return rc;
+  std::vector<BpDesc> hd(n);
+  uint32_t maxcol = 0;
+  for (uint32_t i = 0; i < n; ++i) { hd[i] = BpDesc{profiles->offset[i], profiles->length[i], profiles->length[i]}; maxcol = std::max(maxcol, profiles->length[i]); }
+  const size_t lds = (size_t)maxcol * 17 + 32;
+  if (lds > 150 * 1024) return set_error(TRACYHIP_ERR_RANGE, "profile with %u columns exceeds the LDS staging of findBreakpoint", maxcol);
+  const BpDesc* dd;
+  if ((rc = to_device(ctx, ctx->d_desc, hd, &dd))) return rc;
+  void* d_out;
+  if ((rc = stage_io(ctx, ctx->d_tmp[0], out, sizeof(BreakpointOut) * (size_t)n, mem, false, &d_out))) return rc;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(breakpoint_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(breakpoint_kernel, dim3(n), dim3(64), lds, st, dd, static_cast<const float*>(d_prof), static_cast<BreakpointOut*>(d_out));
+  HIP_TRY(hipGetLastError());
+  if ((rc = unstage(ctx, out, d_out, sizeof(BreakpointOut) * (size_t)n, mem))) return rc;
+  HIP_TRY(hipStreamSynchronize(st));
+  return TRACYHIP_OK;
+}
+
+int tracyhip_find_homozygous_breakpoint(tracyhip_ctx* ctx, uint32_t ntraces, const uint8_t* rows0, const uint8_t* rows1,
+                                        const uint64_t* rows_offset, const uint32_t* rows_len, int mem,
+                                        tracyhip_breakpoint* bps, int32_t* status) {
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  if (ntraces == 0) return TRACYHIP_OK;
+  if (!rows0 || !rows1 || !rows_offset || !rows_len || !bps || !status) return set_error(TRACYHIP_ERR_ARG, "null argument");
+  hipStream_t st = ctx->stream;
+  const uint64_t ext = extent64(rows_offset, rows_len, ntraces);
+  const void *d_r0, *d_r1;
+  if ((rc = stage_in(ctx, ctx->d_rows0, rows0, ext, mem, &d_r0))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_rows1, rows1, ext, mem, &d_r1))) return rc;
+  std::vector<RowsDesc> hd(ntraces);
+  for (uint32_t i = 0; i < ntraces; ++i) hd[i] = RowsDesc{rows_offset[i], rows_len[i], 0};
+  const RowsDesc* dd;
+  if ((rc = to_device(ctx, ctx->d_desc, hd, &dd))) return rc;
+  void *d_bp, *d_stat;
+  if ((rc = stage_io(ctx, ctx->d_tmp[0], bps, sizeof(BreakpointOut) * (size_t)ntraces, mem, true, &d_bp))) return rc;
+  if ((rc = stage_io(ctx, ctx->d_tmp[1], status, sizeof(int32_t) * (size_t)ntraces, mem, false, &d_stat))) return rc;
+  hipLaunchKernelGGL(homozygous_kernel, dim3((ntraces + 63) / 64), dim3(64), 0, st, dd, static_cast<const uint8_t*>(d_r0),
+                     static_cast<const uint8_t*>(d_r1), ntraces, static_cast<BreakpointOut*>(d_bp), static_cast<int32_t*>(d_stat));
+  HIP_TRY(hipGetLastError());
+  if ((rc = unstage(ctx, bps, d_bp, sizeof(BreakpointOut) * (size_t)ntraces, mem))) return rc;
+  if ((rc = unstage(ctx, status, d_stat, sizeof(int32_t) * (size_t)ntraces, mem))) return rc;
+  HIP_TRY(hipStreamSynchronize(st));
+  return TRACYHIP_OK;
+}
+
+int tracyhip_decompose_alleles(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, const uint8_t* rows0, const uint8_t* rows1,
+                               const uint64_t* rows_offset, const uint32_t* rows_len, const tracyhip_breakpoint* bps,
+                               const uint32_t* refslice_len, const tracyhip_decomp_params* prm, int mem,
+                               int32_t* dcp_indel, int32_t* dcp_err, const uint64_t* dcp_offset, tracyhip_decomp_status* status) {
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  if (!bc || !prm) return set_error(TRACYHIP_ERR_ARG, "null argument");
+  const uint32_t n = bc->ntraces;
+  if (n == 0) return TRACYHIP_OK;
+  if (!rows0 || !rows1 || !rows_offset || !rows_len || !bps || !refslice_len || !dcp_indel || !dcp_err || !dcp_offset || !status ||
+      !bc->primary || !bc->secondary || !bc->bc_offset || !bc->bc_len)
+    return set_error(TRACYHIP_ERR_ARG, "null argument");
+  if (prm->maxindel < 1 || prm->maxindel > kMaxIndelDev) return set_error(TRACYHIP_ERR_RANGE, "maxindel must be in [1, %d]", kMaxIndelDev);
+  static_assert(sizeof(tracyhip_decomp_status) == sizeof(DecompOut), "layout");
+  hipStream_t st = ctx->stream;
+  const uint64_t rext = extent64(rows_offset, rows_len, n), bext = extent64(bc->bc_offset, bc->bc_len, n);
+  uint64_t dext = 0;
+  std::vector<DecompDesc> hd(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (bc->bc_len[i] >= 2u * kMaxIndelDev) return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the device histogram holds < %d", i, bc->bc_len[i], 2 * kMaxIndelDev);
+    hd[i] = DecompDesc{rows_offset[i], bc->bc_offset[i], dcp_offset[i], rows_len[i], bc->bc_len[i], refslice_len[i], 0};
+    dext = std::max<uint64_t>(dext, dcp_offset[i] + 2ull * prm->maxindel + 2);
+  }
+  const void *d_r0, *d_r1, *d_bp;
+  if ((rc = stage_in(ctx, ctx->d_rows0, rows0, rext, mem, &d_r0))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_rows1, rows1, rext, mem, &d_r1))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_tmp[0], bps, sizeof(BreakpointOut) * (size_t)n, mem, &d_bp))) return rc;
+  void *d_pri, *d_sec, *d_di, *d_de, *d_stat;
+  if ((rc = stage_io(ctx, ctx->d_tmp[1], bc->primary, bext, mem, true, &d_pri))) return rc;
+  if ((rc = stage_io(ctx, ctx->d_tmp[2], bc->secondary, bext, mem, true, &d_sec))) return rc;
+  if ((rc = stage_io(ctx, ctx->d_tmp[3], dcp_indel, dext * 4, mem, false, &d_di))) return rc;
+  if ((rc = stage_io(ctx, ctx->d_tmp[4], dcp_err, dext * 4, mem, false, &d_de))) return rc;
+  if ((rc = stage_io(ctx, ctx->d_tmp[5], status, sizeof(DecompOut) * (size_t)n, mem, false, &d_stat))) return rc;
+  const DecompDesc* dd;
+  if ((rc = to_device(ctx, ctx->d_desc, hd, &dd))) return rc;
+  DecompArgs a{};
+  a.desc = dd;
+  a.rows0 = static_cast<const uint8_t*>(d_r0);
+  a.rows1 = static_cast<const uint8_t*>(d_r1);
+  a.primary = static_cast<uint8_t*>(d_pri);
+  a.secondary = static_cast<uint8_t*>(d_sec);
+  a.dcp_indel = static_cast<int32_t*>(d_di);
+  a.dcp_err = static_cast<int32_t*>(d_de);
+  a.out = static_cast<DecompOut*>(d_stat);
+  a.prm = DecompParams{prm->trim_left, prm->trim_right, prm->maxindel, prm->madc};
+  a.ntraces = n;
+  hipLaunchKernelGGL(decompose_kernel, dim3(n), dim3(64), 0, st, a, static_cast<const BreakpointOut*>(d_bp));
+  HIP_TRY(hipGetLastError());
+  if ((rc = unstage(ctx, bc->primary, d_pri, bext, mem))) return rc;
+  if ((rc = unstage(ctx, bc->secondary, d_sec, bext, mem))) return rc;
+  if ((rc = unstage(ctx, dcp_indel, d_di, dext * 4, mem))) return rc;
+  if ((rc = unstage(ctx, dcp_err, d_de, dext * 4, mem))) return rc;
+  if ((rc = unstage(ctx, status, d_stat, sizeof(DecompOut) * (size_t)n, mem))) return rc;
+  HIP_TRY(hipStreamSynchronize(st));
+  return TRACYHIP_OK;
+}
+
+static int bc_descs(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, int mem, const BcDesc** dd, const void** d_sig,
+                    const void** d_pos, uint64_t* bext) {
+  const uint32_t n = bc->ntraces;
+  if (!bc->signal || !bc->signal_offset || !bc->nsamples || !bc->bcpos || !bc->bc_offset || !bc->bc_len)
+    return set_error(TRACYHIP_ERR_ARG, "null basecall arrays");
+  std::vector<BcDesc> hd(n);
+  uint64_t sext = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    hd[i] = BcDesc{bc->signal_offset[i], bc->bc_offset[i], bc->nsamples[i], bc->bc_len[i]};
+    sext = std::max<uint64_t>(sext, bc->signal_offset[i] + 4ull * bc->nsamples[i]);
+  }
+  *bext = extent64(bc->bc_offset, bc->bc_len, n);
+  int rc;
+  if ((rc = stage_in(ctx, ctx->d_in1, bc->signal, sext * 4, mem, d_sig))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_in2, bc->bcpos, *bext * 4, mem, d_pos))) return rc;
+  return to_device(ctx, ctx->d_desc, hd, dd);
+}
+
+int tracyhip_secondary_decomposed(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, int mem, uint8_t* secdecomp) {
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  if (!bc || !secdecomp) return set_error(TRACYHIP_ERR_ARG, "null argument");
+  const uint32_t n = bc->ntraces;
+  if (n == 0) return TRACYHIP_OK;
+  if (!bc->primary || !bc->secondary) return set_error(TRACYHIP_ERR_ARG, "null basecalls");
+  const BcDesc* dd;
+  const void *d_sig, *d_pos, *d_pri, *d_sec;
+  uint64_t bext;
+  if ((rc = bc_descs(ctx, bc, mem, &dd, &d_sig, &d_pos, &bext))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_tmp[1], bc->primary, bext, mem, &d_pri))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_tmp[2], bc->secondary, bext, mem, &d_sec))) return rc;
+  void* d_out;
+  if ((rc = stage_io(ctx, ctx->d_tmp[3], secdecomp, bext, mem, false, &d_out))) return rc;
+  uint32_t maxbc = 0;
+  for (uint32_t i = 0; i < n; ++i) maxbc = std::max(maxbc, bc->bc_len[i]);
+  hipLaunchKernelGGL(secdecomp_kernel, dim3((maxbc + 255) / 256, n), dim3(256), 0, ctx->stream, dd, static_cast<const int32_t*>(d_sig),
+                     static_cast<const int32_t*>(d_pos), static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sec),
+                     static_cast<uint8_t*>(d_out));
+  HIP_TRY(hipGetLastError());
+  if ((rc = unstage(ctx, secdecomp, d_out, bext, mem))) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TRACYHIP_OK;
+}
+
+int tracyhip_allelic_fraction(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, const uint8_t* secdecomp, uint32_t trim_left,
+                              uint32_t trim_right, int mem, double* fractions) {
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  if (!bc || !secdecomp || !fractions) return set_error(TRACYHIP_ERR_ARG, "null argument");
+  const uint32_t n = bc->ntraces;
+  if (n == 0) return TRACYHIP_OK;
+  if (!bc->primary) return set_error(TRACYHIP_ERR_ARG, "null basecalls");
+  const BcDesc* dd;
+  const void *d_sig, *d_pos, *d_pri, *d_sec;
+  uint64_t bext;
+  if ((rc = bc_descs(ctx, bc, mem, &dd, &d_sig, &d_pos, &bext))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_tmp[1], bc->primary, bext, mem, &d_pri))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_tmp[2], secdecomp, bext, mem, &d_sec))) return rc;
+  void* d_out;
+  if ((rc = stage_io(ctx, ctx->d_tmp[3], fractions, sizeof(double) * 2 * (size_t)n, mem, false, &d_out))) return rc;
+  uint32_t maxbc = 0;
+  for (uint32_t i = 0; i < n; ++i) maxbc = std::max(maxbc, bc->bc_len[i]);
+  const size_t lds = (size_t)maxbc * 36 + 64;
+  if (lds > 100 * 1024) return set_error(TRACYHIP_ERR_RANGE, "trace with %u basecalls exceeds the LDS staging of allelicFraction", maxbc);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(allelic_fraction_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(allelic_fraction_kernel, dim3(n), dim3(AF_THREADS), lds, ctx->stream, dd, static_cast<const int32_t*>(d_sig),
+                     static_cast<const int32_t*>(d_pos), static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sec), trim_left,
+                     trim_right, static_cast<double*>(d_out));
+  HIP_TRY(hipGetLastError());
+  if ((rc = unstage(ctx, fractions, d_out, sizeof(double) * 2 * (size_t)n, mem))) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return TRACYHIP_OK;
+}
+
+}  // extern "C"

@@ -154,4 +154,48 @@ void tracyhost_synth_align(uint64_t seed0, uint32_t ntraces, uint32_t n, uint32_
   for (auto& t : th) t.join();
 }
 
+
+// Seeded synthetic `tracy decompose` case: reference window of n bases; allele 1 =
+// mf bases copied from it (forward strand), allele 2 = allele 1 with one heterozygous indel (length
+// U[1,maxlen], insertion or deletion) at a position U[150, mf-300] plus 0.5 % heterozygous SNVs; the two
+// alleles are mixed frac1 : 1-frac1 in the chromatogram.  kind: 0 = het indel, 1 = SNVs only (no indel).
+// Outputs: ref[n]; signal[4][12*(mf+40)+12] (zero padded), basecallpos[npos]; returns npos.
+uint32_t tracyhost_synth_decompose(uint64_t seed, uint32_t n, uint32_t mf, uint32_t maxlen, int kind, double frac1,
+                                   uint8_t* ref_out, int32_t* signal, uint32_t nsamples_cap, int32_t* basecallpos,
+                                   int32_t* indel_out) {
+  SplitMix64 rng(seed);
+  std::string ref(n, 'A');
+  for (uint32_t i = 0; i < n; ++i) ref[i] = kBases[rng.below(4)];
+  const uint32_t start = (n > mf + 200) ? 100 + rng.below(n - mf - 200) : 0;
+  std::string a1 = ref.substr(start, mf + 40);
+  std::string a2 = a1;
+  int32_t indel = 0;
+  if (kind == 0) {
+    const uint32_t pos = 150 + rng.below(mf > 450 ? mf - 450 : 1);
+    const uint32_t len = 1 + rng.below(maxlen);
+    if (rng.next() & 1) {  // deletion in allele 2
+      a2.erase(pos, len);
+      indel = -(int32_t)len;
+    } else {
+      std::string ins(len, 'A');
+      for (auto& c : ins) c = kBases[rng.below(4)];
+      a2.insert(pos, ins);
+      indel = (int32_t)len;
+    }
+  }
+  for (size_t i = 0; i < a2.size(); ++i)
+    if (rng.unit() < 0.005) a2[i] = kBases[(base_index(a2[i]) + 1 + rng.below(3)) & 3];
+  a1.resize(mf);
+  a2.resize(mf);
+  Trace tr;
+  render_trace(rng, a1, &a2, frac1, tr);
+  const size_t ns = tr.traceACGT[0].size();
+  for (int k = 0; k < 4; ++k)
+    for (uint32_t i = 0; i < nsamples_cap; ++i) signal[(size_t)k * nsamples_cap + i] = i < ns ? tr.traceACGT[k][i] : 0;
+  for (size_t i = 0; i < tr.basecallpos.size(); ++i) basecallpos[i] = tr.basecallpos[i];
+  std::memcpy(ref_out, ref.data(), n);
+  if (indel_out) *indel_out = indel;
+  return (uint32_t)tr.basecallpos.size();
+}
+
 }  // extern "C"

@@ -56,3 +56,18 @@ def synth_align(seed0, ntraces, n, mf, nthreads=0):
                                 refs.ctypes.data_as(C.POINTER(C.c_uint8)), profs.ctypes.data_as(C.POINTER(C.c_float)),
                                 rev.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_uint32(nthreads))
     return refs, profs, rev
+
+
+def synth_decompose(seed, n, mf, maxlen=30, kind=0, frac1=0.6):
+    """one synthetic heterozygous trace: returns ref (bytes), signal int32 [4][ns], basecallpos int32, indel"""
+    ns = 12 * mf + 12
+    ref = np.zeros(n, dtype=np.uint8)
+    sig = np.zeros((4, ns), dtype=np.int32)
+    pos = np.zeros(mf + 64, dtype=np.int32)
+    indel = C.c_int32(0)
+    lib().tracyhost_synth_decompose.restype = C.c_uint32
+    npos = lib().tracyhost_synth_decompose(C.c_uint64(seed), C.c_uint32(n), C.c_uint32(mf), C.c_uint32(maxlen), int(kind),
+                                           C.c_double(frac1), ref.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                           sig.ctypes.data_as(C.POINTER(C.c_int32)), C.c_uint32(ns),
+                                           pos.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(indel))
+    return ref.tobytes(), sig, pos[:npos].copy(), indel.value

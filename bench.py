@@ -79,6 +79,7 @@ def main():
 
     import tracy_amd
     from tracy_amd import capi, hostlib
+    from tracy_amd.shard import gather_records
 
     nt, n, mf = args.traces, args.ref_len, args.trace_len
     # ---- synthetic inputs (seeded per trace: seed = 1000 + global trace index), resident in HBM ----
@@ -123,8 +124,7 @@ def main():
             raise RuntimeError("tracyhip_align_traces: %s" % lib.tracyhip_last_error().decode())
         if dist is not None:  # final gather of the fixed-size result records over RCCL / xGMI
             rec = torch.stack([r_i32["score_final"], r_i32["slice_begin"], r_i32["slice_len"], r_i32["ops_len"]], dim=1)
-            bucket = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
-            dist.gather(rec, bucket, dst=0)
+            gather_records(dist, rec, dst=0)
 
     for _ in range(args.warmup):
         step()

@@ -15,6 +15,7 @@
  *   _createAlignment (string / profile)    align.h:196-223, 254-293         tracyhip_alignment_rows
  *   DnaScore<int>, AlignConfig<H,V>        align.h:11-32, 37-80             tracyhip_params
  *   sage() hot section                     sage.h:191-311                   tracyhip_align_traces
+ *   indigo() hot section                   indigo.h:190-388                 tracyhip_decompose_traces
  *   findBreakpoint                         decompose.h:7-56                 tracyhip_find_breakpoint
  *   findHomozygousBreakpoint               decompose.h:59-128               tracyhip_find_homozygous_breakpoint
  *   decomposeAlleles                       decompose.h:179-376              tracyhip_decompose_alleles
@@ -215,6 +216,49 @@ int tracyhip_secondary_decomposed(tracyhip_ctx* ctx, const tracyhip_basecalls* b
 /* allelicFraction, decompose.h:412-621: fractions[2t], fractions[2t+1] = the returned pair. */
 int tracyhip_allelic_fraction(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, const uint8_t* secdecomp, uint32_t trim_left,
                               uint32_t trim_right, int mem, double* fractions);
+
+/* ---- whole `tracy decompose` hot section (indigo.h:190-388) for a batch of traces, FASTA reference ----
+ * findBreakpoint(trimmed profile) -> orientation scores -> gotoh(trimmed, oriented reference) with the
+ * score gate of indigo.h:303-309 -> findHomozygousBreakpoint when no shift was seen -> decomposeAlleles ->
+ * generateSecondaryDecomposed -> allelicFraction -> per allele: gotoh(seq, rs.refslice), trimReferenceSlice,
+ * gotoh(seq, trimmed slice) -> gotoh(primary, secondary) global.  bc.primary / bc.secondary are rewritten
+ * in place (decomposed basecalls).  prm->hfree/vfree are ignored (the configs are fixed by indigo.h). */
+typedef struct {
+  uint32_t ntraces;
+  tracyhip_seqset profiles;      /* kind PROFILE: createProfile(tr, bc) of every trace, bc_len[t] columns */
+  tracyhip_basecalls bc;
+  tracyhip_seqset refs;          /* kind CHAR, upper-case [ACGTN] */
+  const uint32_t* ref_index;     /* HOST array or NULL */
+  tracyhip_decomp_params dprm;
+} tracyhip_decompose_job;
+
+typedef struct {
+  tracyhip_breakpoint* bp;       /* [ntraces] breakpoint used by decomposeAlleles */
+  int32_t* status;               /* [ntraces] 0 ok; -1 "Alignment of trace to reference failed!" (indigo.h:306-309);
+                                    -2 findHomozygousBreakpoint failed (:316).  Later outputs of such traces are unspecified. */
+  int32_t* score_fwd;
+  int32_t* score_rev;
+  uint8_t* forward;
+  int32_t* score_trim;           /* aliTrimScore (indigo.h:302) */
+  int32_t* dcp_indel;            /* decomposition table, trace t at dcp_offset[t], capacity 2*maxindel+2 */
+  int32_t* dcp_err;
+  const uint64_t* dcp_offset;    /* HOST array */
+  tracyhip_decomp_status* dstatus;
+  uint8_t* secdecomp;            /* bc.secDecompose, trace t at bc.bc_offset[t] */
+  double* fractions;             /* [2*ntraces] allelicFraction */
+  /* allele alignments k = 0 (primary vs its trimmed slice), 1 (secondary), 2 (primary vs secondary, global);
+   * ops in push order, capacity len(seq) + len(reference) (k < 2) or 2*len(seq) (k = 2) */
+  uint32_t* slice_begin[2];
+  uint32_t* slice_len[2];
+  uint32_t* ref_pos[2];
+  int32_t* score[3];
+  uint8_t* ops[3];
+  const uint64_t* ops_offset[3]; /* HOST arrays */
+  uint32_t* ops_len[3];
+} tracyhip_decompose_result;
+
+int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
+                              const tracyhip_decompose_result* out);
 
 /* ---- kernel timing (HIP events recorded on the context's stream around each DP / walker launch) ---
  * The reference has only the optional gperftools wrapper (sage.h:60-62); this is the hook bench.py uses

@@ -91,3 +91,38 @@ def test_decompose_parameter_edges(ctx, cases):
     hbc = capi.HostBaseCalls([c["sig"]], [c["bcpos"]], [c["pri"]], [c["pri"]])
     fr = ctx.allelic_fraction(hbc, np.frombuffer(c["pri"], dtype=np.uint8), 50, 50)
     assert tuple(fr[0]) == (0.5, 0.5)
+
+
+def test_decompose_traces_pipeline(ctx):
+    """tracyhip_decompose_traces == indigo.h:190-388 composed from the oracle"""
+    from indigo_oracle import decompose_trace
+    from sage_oracle import revcomp
+    from tracy_amd import capi, hostlib
+    sigs, poss, refs, bcs = [], [], [], []
+    for i, (seed, kind, frac) in enumerate([(21, 0, 0.6), (22, 0, 0.55), (23, 1, 0.6), (24, 0, 0.7), (25, 0, 0.5)]):
+        ref, sig, pos, indel = hostlib.synth_decompose(seed, 1400, 480, 25, kind, frac)
+        if i % 2:  # the trace reads the reverse strand of its reference window
+            ref = revcomp(ref)
+        pri, sec, con, bcpos = hostlib.basecall(sig, pos, 0.33)
+        sigs.append(sig); poss.append(pos); refs.append(ref); bcs.append((pri, sec, bcpos))
+    profs = [hostlib.create_profile(sigs[i], bcs[i][2], bcs[i][0], bcs[i][1], 0, 0) for i in range(len(sigs))]
+    hbc = capi.HostBaseCalls(sigs, [b[2] for b in bcs], [b[0] for b in bcs], [b[1] for b in bcs])
+    got = ctx.decompose_traces(profs, hbc, refs, SC)
+    for i in range(len(sigs)):
+        w = decompose_trace(sigs[i], bcs[i][2], bcs[i][0], bcs[i][1], refs[i], SC)
+        assert int(got["status"][i]) == w["status"] == 0
+        for k in ("score_fwd", "score_rev", "forward", "score_trim"):
+            assert int(got[k][i]) == int(w[k]), (i, k)
+        g = got["bp"][i]
+        assert (g.indelshift, g.traceleft, g.breakpoint) == (w["bp"].indelshift, w["bp"].traceleft, w["bp"].breakpoint)
+        assert got["primary"][i] == w["primary"] and got["secondary"][i] == w["secondary"]
+        assert got["secdecomp_list"][i] == w["secdecomp"]
+        assert got["dcp"][i] == w["dcp"]
+        assert (float(got["fractions"][2 * i]), float(got["fractions"][2 * i + 1])) == w["af"]
+        for k in range(3):
+            assert int(got["score%d" % k][i]) == w["score%d" % k], (i, k)
+            assert got["btr%d" % k][i] == w["btr%d" % k], (i, k)
+        for k in range(2):
+            for nm in ("slice_begin", "slice_len", "ref_pos"):
+                assert int(got["%s%d" % (nm, k)][i]) == int(w["%s%d" % (nm, k)]), (i, nm, k)
+    assert sorted(got["forward"].tolist()) == [0, 0, 1, 1, 1]

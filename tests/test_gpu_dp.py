@@ -179,3 +179,17 @@ def test_align_traces_pipeline(ctx):
             assert int(got[k][i]) == int(want[k]), (i, k)
         assert got["btr"][i] == want["btr"], i
     assert sorted(got["forward"].tolist()) == [0, 0, 0, 1, 1, 1]
+
+
+def test_cpp_host_mirror(tmp_path):
+    """tracy_amd/host/tracy_amd.hpp keeps the reference's call shape: gotoh(a1, a2, align, ac, sc)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_mirror")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(root, "tests/cpp/test_mirror.cpp"),
+                           "-L" + os.path.join(root, "tracy_amd/lib"), "-ltracy_hip", "-L" + os.path.join(root, "oracle"),
+                           "-ltracy_oracle", "-Wl,-rpath," + os.path.join(root, "tracy_amd/lib"),
+                           "-Wl,-rpath," + os.path.join(root, "oracle"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr

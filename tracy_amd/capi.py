@@ -401,3 +401,82 @@ Context.find_homozygous_breakpoint = _find_homozygous_breakpoint
 Context.decompose_alleles = _decompose_alleles
 Context.secondary_decomposed = _secondary_decomposed
 Context.allelic_fraction = _allelic_fraction
+
+
+class DecomposeJob(C.Structure):
+    _fields_ = [("ntraces", C.c_uint32), ("profiles", SeqSet), ("bc", BaseCallsBatch), ("refs", SeqSet),
+                ("ref_index", C.POINTER(C.c_uint32)), ("dprm", DecompParams)]
+
+
+class DecomposeResult(C.Structure):
+    _fields_ = [("bp", C.c_void_p), ("status", C.c_void_p), ("score_fwd", C.c_void_p), ("score_rev", C.c_void_p),
+                ("forward", C.c_void_p), ("score_trim", C.c_void_p), ("dcp_indel", C.c_void_p), ("dcp_err", C.c_void_p),
+                ("dcp_offset", C.POINTER(C.c_uint64)), ("dstatus", C.c_void_p), ("secdecomp", C.c_void_p),
+                ("fractions", C.c_void_p), ("slice_begin", C.c_void_p * 2), ("slice_len", C.c_void_p * 2),
+                ("ref_pos", C.c_void_p * 2), ("score", C.c_void_p * 3), ("ops", C.c_void_p * 3),
+                ("ops_offset", C.POINTER(C.c_uint64) * 3), ("ops_len", C.c_void_p * 3)]
+
+
+def _decompose_traces(self, profiles, hbc, refs, params, trim_left=50, trim_right=50, maxindel=1000, madc=5):
+    """tracyhip_decompose_traces with host buffers; hbc: HostBaseCalls (primary/secondary rewritten in place)"""
+    pp = profiles if isinstance(profiles, PackedSeqs) else PackedSeqs(profiles, SEQ_PROFILE)
+    pr = refs if isinstance(refs, PackedSeqs) else PackedSeqs(refs, SEQ_CHAR)
+    nt = pp.count
+    job = DecomposeJob()
+    job.ntraces = nt
+    job.profiles = pp.seqset()
+    job.bc = hbc.struct()
+    job.refs = pr.seqset()
+    job.dprm = DecompParams(trim_left, trim_right, maxindel, madc)
+    cap = 2 * maxindel + 2
+    doff = np.arange(max(nt, 1), dtype=np.uint64) * np.uint64(cap)
+    mf = pp.length[:nt].astype(np.uint64)
+    rn = pr.length[:nt].astype(np.uint64)
+    res = {
+        "bp": (Breakpoint * max(nt, 1))(), "status": np.zeros(max(nt, 1), np.int32),
+        "score_fwd": np.zeros(max(nt, 1), np.int32), "score_rev": np.zeros(max(nt, 1), np.int32),
+        "forward": np.zeros(max(nt, 1), np.uint8), "score_trim": np.zeros(max(nt, 1), np.int32),
+        "dcp_indel": np.zeros(max(nt, 1) * cap, np.int32), "dcp_err": np.zeros(max(nt, 1) * cap, np.int32),
+        "dstatus": (DecompStatus * max(nt, 1))(), "secdecomp": np.zeros(max(len(hbc.primary), 1), np.uint8),
+        "fractions": np.zeros(2 * max(nt, 1), np.float64),
+    }
+    out = DecomposeResult()
+    out.bp = C.addressof(res["bp"])
+    out.dstatus = C.addressof(res["dstatus"])
+    for k in ("status", "score_fwd", "score_rev", "forward", "score_trim", "dcp_indel", "dcp_err", "secdecomp", "fractions"):
+        setattr(out, k, res[k].ctypes.data)
+    out.dcp_offset = _u64p(doff)
+    keep = []
+    for k in range(3):
+        caps = (mf + (rn if k < 2 else mf)).astype(np.uint64)
+        off = np.zeros(max(nt, 1), dtype=np.uint64)
+        if nt:
+            off[1:nt] = np.cumsum(caps)[:-1]
+        ops = np.zeros(max(int(caps.sum()), 1), np.uint8)
+        olen = np.zeros(max(nt, 1), np.uint32)
+        sc = np.zeros(max(nt, 1), np.int32)
+        out.score[k] = sc.ctypes.data
+        out.ops[k] = ops.ctypes.data
+        out.ops_offset[k] = _u64p(off)
+        out.ops_len[k] = olen.ctypes.data
+        res["score%d" % k] = sc
+        keep.append((off, ops, olen))
+        if k < 2:
+            for nm in ("slice_begin", "slice_len", "ref_pos"):
+                a = np.zeros(max(nt, 1), np.uint32)
+                getattr(out, nm)[k] = a.ctypes.data
+                res["%s%d" % (nm, k)] = a
+    prm = Params(params[0], params[1], params[2], params[3], 1, 0)
+    _check(lib().tracyhip_decompose_traces(self._h, C.byref(job), C.byref(prm), MEM_HOST, C.byref(out)))
+    for k in range(3):
+        off, ops, olen = keep[k]
+        res["btr%d" % k] = [ops[int(off[i]):int(off[i]) + int(olen[i])].tobytes() for i in range(nt)]
+    res["dcp"] = [[(int(res["dcp_indel"][i * cap + j]), int(res["dcp_err"][i * cap + j])) for j in range(res["dstatus"][i].dcp_n)]
+                  for i in range(nt)]
+    res["primary"] = hbc.split(hbc.primary)
+    res["secondary"] = hbc.split(hbc.secondary)
+    res["secdecomp_list"] = hbc.split(res["secdecomp"])
+    return res
+
+
+Context.decompose_traces = _decompose_traces

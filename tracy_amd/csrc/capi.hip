@@ -531,8 +531,10 @@ int tracyhip_alignment_rows(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int 
     d.m = s1.length[i1]; d.n = s2.length[i2];
     d.a1_stride = d.m; d.a2_stride = d.n; d.out = i;
     hd[i] = d;
-    if (mem == TRACYHIP_MEM_HOST && ops_len[i] > d.m + d.n) return set_error(TRACYHIP_ERR_ARG, "ops_len[%u] exceeds m+n", i);
-    total = std::max<uint64_t>(total, ops_offset[i] + d.m + d.n);
+    if (mem == TRACYHIP_MEM_HOST) {  // host buffers only need to cover the strings themselves
+      if (ops_len[i] > d.m + d.n) return set_error(TRACYHIP_ERR_ARG, "ops_len[%u] exceeds m+n", i);
+      total = std::max<uint64_t>(total, ops_offset[i] + ops_len[i]);
+    }
   }
   HIP_TRY(ctx->d_desc.ensure(sizeof(PairDesc) * (size_t)np));
   HIP_TRY(hipMemcpyAsync(ctx->d_desc.p, hd, sizeof(PairDesc) * (size_t)np, hipMemcpyHostToDevice, st));

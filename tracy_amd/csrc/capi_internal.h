@@ -48,7 +48,8 @@ struct tracyhip_ctx {
   uint64_t ws_limit = 0;
   tracyhip::DevBuf d_desc, d_bits, d_scratch, d_in1, d_in2, d_codes, d_scores, d_ops, d_ops_off, d_ops_len, d_err,
       d_rows0, d_rows1;
-  tracyhip::DevBuf d_tmp[8];  // pipeline intermediates (align_traces / decompose)
+  tracyhip::DevBuf d_tmp[8];
+  tracyhip::DevBuf d_pipe[64];  // decompose pipeline intermediates  // pipeline intermediates (align_traces / decompose)
   tracyhip::PinBuf h_desc, h_off, h_tmp;
   // kernel timing
   struct Pending { int which; hipEvent_t e0, e1; uint64_t cells, bytes; };
@@ -61,6 +62,7 @@ struct tracyhip_ctx {
                                &d_ops_off, &d_ops_len, &d_err, &d_rows0, &d_rows1};
     for (auto* b : all) b->release();
     for (auto& b : d_tmp) b.release();
+    for (auto& b : d_pipe) b.release();
     h_desc.release();
     h_off.release();
     h_tmp.release();

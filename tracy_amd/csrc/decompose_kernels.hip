@@ -9,6 +9,7 @@
 #include "../../include/tracy_hip.h"
 #include "capi_internal.h"
 #include "decompose_kernels.h"
+#include "decompose_launch.h"
 
 using namespace tracyhip;
 
@@ -60,7 +61,6 @@ __global__ __launch_bounds__(64) void decompose_kernel(DecompArgs a, const Break
 }
 
 // ---- findBreakpoint: one workgroup per profile; sig/diff in dynamic LDS (ncol doubles each) --------
-struct BpDesc { uint64_t off; uint32_t stride; uint32_t ncol; };
 __global__ __launch_bounds__(64) void breakpoint_kernel(const BpDesc* desc, const float* prof, BreakpointOut* out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const BpDesc d = desc[blockIdx.x];
@@ -85,7 +85,6 @@ __global__ __launch_bounds__(64) void breakpoint_kernel(const BpDesc* desc, cons
   }
 }
 
-struct RowsDesc { uint64_t off; uint32_t L; uint32_t pad; };
 __global__ __launch_bounds__(64) void homozygous_kernel(const RowsDesc* desc, const uint8_t* rows0, const uint8_t* rows1,
                                                         uint32_t n, BreakpointOut* bps, int32_t* status) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -97,7 +96,6 @@ __global__ __launch_bounds__(64) void homozygous_kernel(const RowsDesc* desc, co
   bps[t] = bp;
 }
 
-struct BcDesc { uint64_t sig_off; uint64_t bc_off; uint32_t nsamples; uint32_t nbc; };
 __global__ void secdecomp_kernel(const BcDesc* desc, const int32_t* signal, const int32_t* bcpos, const uint8_t* pri,
                                  const uint8_t* sec, uint8_t* outp) {
   const BcDesc d = desc[blockIdx.y];
@@ -260,6 +258,52 @@ uint64_t extent64(const uint64_t* off, const uint32_t* len, uint32_t n, uint64_t
 
 }  // namespace
 
+namespace tracyhip {
+
+int launch_breakpoint(tracyhip_ctx* ctx, const BpDesc* d_desc, uint32_t n, uint32_t maxcol, const float* d_prof, BreakpointOut* d_out) {
+  if (n == 0) return TRACYHIP_OK;
+  const size_t lds = (size_t)maxcol * 17 + 32;
+  if (lds > 150 * 1024) return set_error(TRACYHIP_ERR_RANGE, "profile with %u columns exceeds the LDS staging of findBreakpoint", maxcol);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(breakpoint_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(breakpoint_kernel, dim3(n), dim3(64), lds, ctx->stream, d_desc, d_prof, d_out);
+  HIP_TRY(hipGetLastError());
+  return TRACYHIP_OK;
+}
+int launch_homozygous(tracyhip_ctx* ctx, const RowsDesc* d_desc, const uint8_t* d_rows0, const uint8_t* d_rows1, uint32_t n,
+                      BreakpointOut* d_bps, int32_t* d_status) {
+  if (n == 0) return TRACYHIP_OK;
+  hipLaunchKernelGGL(homozygous_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_desc, d_rows0, d_rows1, n, d_bps, d_status);
+  HIP_TRY(hipGetLastError());
+  return TRACYHIP_OK;
+}
+int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut* d_bps) {
+  if (a.ntraces == 0) return TRACYHIP_OK;
+  hipLaunchKernelGGL(decompose_kernel, dim3(a.ntraces), dim3(64), 0, ctx->stream, a, d_bps);
+  HIP_TRY(hipGetLastError());
+  return TRACYHIP_OK;
+}
+int launch_secdecomp(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig, const int32_t* d_pos,
+                     const uint8_t* d_pri, const uint8_t* d_sec, uint8_t* d_out) {
+  if (n == 0 || maxbc == 0) return TRACYHIP_OK;
+  hipLaunchKernelGGL(secdecomp_kernel, dim3((maxbc + 255) / 256, n), dim3(256), 0, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, d_out);
+  HIP_TRY(hipGetLastError());
+  return TRACYHIP_OK;
+}
+int launch_allelic_fraction(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig,
+                            const int32_t* d_pos, const uint8_t* d_pri, const uint8_t* d_sec, uint32_t trim_left, uint32_t trim_right,
+                            double* d_out) {
+  if (n == 0) return TRACYHIP_OK;
+  const size_t lds = (size_t)maxbc * 36 + 64;
+  if (lds > 100 * 1024) return set_error(TRACYHIP_ERR_RANGE, "trace with %u basecalls exceeds the LDS staging of allelicFraction", maxbc);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(allelic_fraction_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(allelic_fraction_kernel, dim3(n), dim3(AF_THREADS), lds, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, trim_left,
+                     trim_right, d_out);
+  HIP_TRY(hipGetLastError());
+  return TRACYHIP_OK;
+}
+
+}  // namespace tracyhip
+
 extern "C" {
 
 int tracyhip_find_breakpoint(tracyhip_ctx* ctx, const tracyhip_seqset* profiles, int mem, tracyhip_breakpoint* out) {
@@ -276,15 +320,11 @@ int tracyhip_find_breakpoint(tracyhip_ctx* ctx, const tracyhip_seqset* profiles,
   std::vector<BpDesc> hd(n);
   uint32_t maxcol = 0;
   for (uint32_t i = 0; i < n; ++i) { hd[i] = BpDesc{profiles->offset[i], profiles->length[i], profiles->length[i]}; maxcol = std::max(maxcol, profiles->length[i]); }
-  const size_t lds = (size_t)maxcol * 17 + 32;
-  if (lds > 150 * 1024) return set_error(TRACYHIP_ERR_RANGE, "profile with %u columns exceeds the LDS staging of findBreakpoint", maxcol);
   const BpDesc* dd;
   if ((rc = to_device(ctx, ctx->d_desc, hd, &dd))) return rc;
   void* d_out;
   if ((rc = stage_io(ctx, ctx->d_tmp[0], out, sizeof(BreakpointOut) * (size_t)n, mem, false, &d_out))) return rc;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(breakpoint_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(breakpoint_kernel, dim3(n), dim3(64), lds, st, dd, static_cast<const float*>(d_prof), static_cast<BreakpointOut*>(d_out));
-  HIP_TRY(hipGetLastError());
+  if ((rc = launch_breakpoint(ctx, dd, n, maxcol, static_cast<const float*>(d_prof), static_cast<BreakpointOut*>(d_out)))) return rc;
   if ((rc = unstage(ctx, out, d_out, sizeof(BreakpointOut) * (size_t)n, mem))) return rc;
   HIP_TRY(hipStreamSynchronize(st));
   return TRACYHIP_OK;
@@ -309,9 +349,9 @@ int tracyhip_find_homozygous_breakpoint(tracyhip_ctx* ctx, uint32_t ntraces, con
   void *d_bp, *d_stat;
   if ((rc = stage_io(ctx, ctx->d_tmp[0], bps, sizeof(BreakpointOut) * (size_t)ntraces, mem, true, &d_bp))) return rc;
   if ((rc = stage_io(ctx, ctx->d_tmp[1], status, sizeof(int32_t) * (size_t)ntraces, mem, false, &d_stat))) return rc;
-  hipLaunchKernelGGL(homozygous_kernel, dim3((ntraces + 63) / 64), dim3(64), 0, st, dd, static_cast<const uint8_t*>(d_r0),
-                     static_cast<const uint8_t*>(d_r1), ntraces, static_cast<BreakpointOut*>(d_bp), static_cast<int32_t*>(d_stat));
-  HIP_TRY(hipGetLastError());
+  if ((rc = launch_homozygous(ctx, dd, static_cast<const uint8_t*>(d_r0), static_cast<const uint8_t*>(d_r1), ntraces,
+                              static_cast<BreakpointOut*>(d_bp), static_cast<int32_t*>(d_stat))))
+    return rc;
   if ((rc = unstage(ctx, bps, d_bp, sizeof(BreakpointOut) * (size_t)ntraces, mem))) return rc;
   if ((rc = unstage(ctx, status, d_stat, sizeof(int32_t) * (size_t)ntraces, mem))) return rc;
   HIP_TRY(hipStreamSynchronize(st));
@@ -364,8 +404,7 @@ int tracyhip_decompose_alleles(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, 
   a.out = static_cast<DecompOut*>(d_stat);
   a.prm = DecompParams{prm->trim_left, prm->trim_right, prm->maxindel, prm->madc};
   a.ntraces = n;
-  hipLaunchKernelGGL(decompose_kernel, dim3(n), dim3(64), 0, st, a, static_cast<const BreakpointOut*>(d_bp));
-  HIP_TRY(hipGetLastError());
+  if ((rc = launch_decompose(ctx, a, static_cast<const BreakpointOut*>(d_bp)))) return rc;
   if ((rc = unstage(ctx, bc->primary, d_pri, bext, mem))) return rc;
   if ((rc = unstage(ctx, bc->secondary, d_sec, bext, mem))) return rc;
   if ((rc = unstage(ctx, dcp_indel, d_di, dext * 4, mem))) return rc;
@@ -410,10 +449,9 @@ int tracyhip_secondary_decomposed(tracyhip_ctx* ctx, const tracyhip_basecalls* b
   if ((rc = stage_io(ctx, ctx->d_tmp[3], secdecomp, bext, mem, false, &d_out))) return rc;
   uint32_t maxbc = 0;
   for (uint32_t i = 0; i < n; ++i) maxbc = std::max(maxbc, bc->bc_len[i]);
-  hipLaunchKernelGGL(secdecomp_kernel, dim3((maxbc + 255) / 256, n), dim3(256), 0, ctx->stream, dd, static_cast<const int32_t*>(d_sig),
-                     static_cast<const int32_t*>(d_pos), static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sec),
-                     static_cast<uint8_t*>(d_out));
-  HIP_TRY(hipGetLastError());
+  if ((rc = launch_secdecomp(ctx, dd, n, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos),
+                             static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sec), static_cast<uint8_t*>(d_out))))
+    return rc;
   if ((rc = unstage(ctx, secdecomp, d_out, bext, mem))) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return TRACYHIP_OK;
@@ -437,13 +475,10 @@ int tracyhip_allelic_fraction(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, c
   if ((rc = stage_io(ctx, ctx->d_tmp[3], fractions, sizeof(double) * 2 * (size_t)n, mem, false, &d_out))) return rc;
   uint32_t maxbc = 0;
   for (uint32_t i = 0; i < n; ++i) maxbc = std::max(maxbc, bc->bc_len[i]);
-  const size_t lds = (size_t)maxbc * 36 + 64;
-  if (lds > 100 * 1024) return set_error(TRACYHIP_ERR_RANGE, "trace with %u basecalls exceeds the LDS staging of allelicFraction", maxbc);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(allelic_fraction_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(allelic_fraction_kernel, dim3(n), dim3(AF_THREADS), lds, ctx->stream, dd, static_cast<const int32_t*>(d_sig),
-                     static_cast<const int32_t*>(d_pos), static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sec), trim_left,
-                     trim_right, static_cast<double*>(d_out));
-  HIP_TRY(hipGetLastError());
+  if ((rc = launch_allelic_fraction(ctx, dd, n, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos),
+                                    static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sec), trim_left, trim_right,
+                                    static_cast<double*>(d_out))))
+    return rc;
   if ((rc = unstage(ctx, fractions, d_out, sizeof(double) * 2 * (size_t)n, mem))) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return TRACYHIP_OK;

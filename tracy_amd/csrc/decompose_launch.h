@@ -1,0 +1,26 @@
+// decompose_launch.h -- device-level launchers of the deconvolution kernels (device pointers only);
+// shared by the per-function C-ABI entry points and the tracyhip_decompose_traces pipeline.
+#ifndef TRACY_AMD_DECOMPOSE_LAUNCH_H
+#define TRACY_AMD_DECOMPOSE_LAUNCH_H
+
+#include "capi_internal.h"
+#include "decompose_kernels.h"
+
+namespace tracyhip {
+
+struct BpDesc { uint64_t off; uint32_t stride; uint32_t ncol; };     // profile view: p[k][j] at off + k*stride + j
+struct RowsDesc { uint64_t off; uint32_t L; uint32_t pad; };
+struct BcDesc { uint64_t sig_off; uint64_t bc_off; uint32_t nsamples; uint32_t nbc; };
+
+int launch_breakpoint(tracyhip_ctx* ctx, const BpDesc* d_desc, uint32_t n, uint32_t maxcol, const float* d_prof, BreakpointOut* d_out);
+int launch_homozygous(tracyhip_ctx* ctx, const RowsDesc* d_desc, const uint8_t* d_rows0, const uint8_t* d_rows1, uint32_t n,
+                      BreakpointOut* d_bps, int32_t* d_status);
+int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut* d_bps);
+int launch_secdecomp(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig, const int32_t* d_pos,
+                     const uint8_t* d_pri, const uint8_t* d_sec, uint8_t* d_out);
+int launch_allelic_fraction(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig,
+                            const int32_t* d_pos, const uint8_t* d_pri, const uint8_t* d_sec, uint32_t trim_left, uint32_t trim_right,
+                            double* d_out);
+
+}  // namespace tracyhip
+#endif

@@ -247,6 +247,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         uint32_t w0 = 0, w1 = 0;
         if (MODE == MODE_CHAR) {
           sub_c.cc = (int32_t)a2c[ci];
+          if (d.flags & PAIR_A2_REVCOMP) sub_c.cc = (int32_t)complement_char((uint8_t)sub_c.cc);
           if (TRACE) trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub_c, w0, w1, nb_h, nb_f);
           else score_step<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub_c, nb_h, nb_f);
         } else if (MODE == MODE_QP) {

@@ -78,7 +78,9 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
         for (int k = 0; k < 6; ++k) p[k] = static_cast<const float*>(a.a2)[d.a2_off + (uint64_t)k * d.a2_stride + col];
         c1 = cons_char(p);
       } else {
-        c1 = static_cast<const uint8_t*>(a.a2)[d.a2_off + col];
+        const bool rc = a.a2_revcomp_flag && (d.flags & PAIR_A2_REVCOMP);
+        c1 = static_cast<const uint8_t*>(a.a2)[d.a2_off + (rc ? d.n - 1 - col : col)];
+        if (rc) c1 = complement_char(c1);
         if (a.a2_onehot) {  // consensus character of _createProfile(string) (align.h:121-136, 254-270)
           const uint32_t code = base_code(c1);
           c1 = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'T' : code == 6 ? 'A' : 'N';

@@ -214,6 +214,11 @@ TR_HD uint32_t base_code(uint8_t c) {
 // reverseComplementProfile (profile.h:74-90) seen on codes: rows 0<->3, 1<->2; 4, 5 and "other" stay
 TR_HD uint32_t complement_code(uint32_t code) { return code < 4 ? 3u - code : code; }
 
+// reverseComplement(std::string) (fmindex.h:8-24) for the [ACGTN] alphabet it rewrites
+TR_HD uint8_t complement_char(uint8_t c) {
+  return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+}
+
 // _score for a float profile row against a one-hot column b (align.h:103-118): the 20 terms whose
 // p2 entry is 0 contribute +-0 and leave the float accumulator unchanged, so only k2 == b remains.
 TR_HD int32_t onehot_score(const float p1[5], uint32_t b, float fmatch, float fmismatch) {

@@ -13,6 +13,7 @@ struct RowsArgs {
   const void* a1;
   const void* a2;
   int32_t a1_profile, a2_profile;
+  int32_t a2_revcomp_flag;  // honour PairDesc::flags & PAIR_A2_REVCOMP when reading a2 characters
   int32_t a2_onehot;  // a2 is a string standing for its one-hot profile: show _profileConsChar of that profile
   const uint8_t* ops;
   const uint64_t* ops_off;  // indexed by PairDesc::out

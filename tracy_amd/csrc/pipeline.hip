@@ -310,3 +310,386 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   HIP_TRY(hipStreamSynchronize(st));
   return TRACYHIP_OK;
 }
+
+// =====================================================================================================
+// tracyhip_decompose_traces: the hot section of `tracy decompose` (indigo.h:190-388), FASTA reference.
+// =====================================================================================================
+#include "decompose_launch.h"
+
+namespace {
+
+template <class T>
+int upload(tracyhip_ctx* ctx, DevBuf& b, const std::vector<T>& v, const T** out) {
+  HIP_TRY(b.ensure(sizeof(T) * std::max<size_t>(v.size(), 1)));
+  if (!v.empty()) HIP_TRY(hipMemcpy(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+  *out = static_cast<const T*>(b.p);
+  return TRACYHIP_OK;
+}
+
+struct DevOut {  // a result array: the user's (DEVICE) or a staging buffer (HOST) copied back at the end
+  void* dev = nullptr;
+  void* user = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
+                                         const tracyhip_decompose_result* out) {
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  if (!job || !out || !prm) return set_error(TRACYHIP_ERR_ARG, "null job/result/params");
+  if (mem != TRACYHIP_MEM_HOST && mem != TRACYHIP_MEM_DEVICE) return set_error(TRACYHIP_ERR_ARG, "bad mem kind");
+  const uint32_t nt = job->ntraces;
+  if (nt == 0) return TRACYHIP_OK;
+  const tracyhip_seqset& sp = job->profiles;
+  const tracyhip_seqset& sr = job->refs;
+  const tracyhip_basecalls& bc = job->bc;
+  const tracyhip_decomp_params& dp = job->dprm;
+  if (sp.kind != TRACYHIP_SEQ_PROFILE || sr.kind != TRACYHIP_SEQ_CHAR || sp.count < nt || bc.ntraces != nt)
+    return set_error(TRACYHIP_ERR_ARG, "bad sequence sets");
+  if (!bc.signal || !bc.signal_offset || !bc.nsamples || !bc.bcpos || !bc.primary || !bc.secondary || !bc.bc_offset || !bc.bc_len)
+    return set_error(TRACYHIP_ERR_ARG, "null basecall arrays");
+  if (dp.maxindel < 1 || dp.maxindel > kMaxIndelDev) return set_error(TRACYHIP_ERR_RANGE, "maxindel must be in [1, %d]", kMaxIndelDev);
+  if (!out->bp || !out->status || !out->score_fwd || !out->score_rev || !out->forward || !out->score_trim || !out->dcp_indel ||
+      !out->dcp_err || !out->dcp_offset || !out->dstatus || !out->secdecomp || !out->fractions)
+    return set_error(TRACYHIP_ERR_ARG, "null result array");
+  for (int k = 0; k < 3; ++k)
+    if (!out->score[k] || !out->ops[k] || !out->ops_offset[k] || !out->ops_len[k]) return set_error(TRACYHIP_ERR_ARG, "null allele alignment arrays");
+  for (int k = 0; k < 2; ++k)
+    if (!out->slice_begin[k] || !out->slice_len[k] || !out->ref_pos[k]) return set_error(TRACYHIP_ERR_ARG, "null allele slice arrays");
+  hipStream_t st = ctx->stream;
+  tracyhip_params p = *prm;
+  p.hfree = 1;  // AlignConfig<true,false> semiglobal (indigo.h:164)
+  p.vfree = 0;
+  tracyhip_params pglobal = *prm;
+  pglobal.hfree = 0;  // AlignConfig<false,false> (indigo.h:381)
+  pglobal.vfree = 0;
+  const uint32_t TL = (uint32_t)dp.trim_left, TR = (uint32_t)dp.trim_right;
+
+  // ---- geometry ----
+  std::vector<uint32_t> mf(nt), mt(nt), tl(nt), rn(nt), ridx(nt), sl(nt), soff(nt);  // sl/soff: trimmedSeq(length, offset)
+  uint64_t max_mn = 0;
+  uint32_t maxbc = 0, maxcol = 0;
+  for (uint32_t t = 0; t < nt; ++t) {
+    ridx[t] = job->ref_index ? job->ref_index[t] : t;
+    if (ridx[t] >= sr.count) return set_error(TRACYHIP_ERR_ARG, "ref_index[%u] out of range", t);
+    mf[t] = sp.length[t];
+    rn[t] = sr.length[ridx[t]];
+    if (bc.bc_len[t] != mf[t]) return set_error(TRACYHIP_ERR_ARG, "trace %u: profile has %u columns but %u basecalls", t, mf[t], bc.bc_len[t]);
+    if (bc.bc_len[t] >= 2u * kMaxIndelDev) return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the device histogram holds < %d", t, bc.bc_len[t], 2 * kMaxIndelDev);
+    uint32_t l = TL, r = TR;
+    if ((uint64_t)l + r >= mf[t]) { l = 0; r = 0; }  // createProfile, profile.h:24-27
+    tl[t] = l;
+    mt[t] = mf[t] - (l + r);
+    if ((uint64_t)(uint32_t)(TL + TR + 1) >= (uint64_t)mf[t]) { soff[t] = 0; sl[t] = mf[t]; }  // trimmedSeq, abif.h:68-75
+    else { soff[t] = TL; sl[t] = mf[t] - TL - TR; }
+    max_mn = std::max<uint64_t>(max_mn, (uint64_t)mf[t] + rn[t]);
+    maxbc = std::max(maxbc, mf[t]);
+    maxcol = std::max(maxcol, mt[t]);
+  }
+  if ((rc = check_params(&p, max_mn))) return rc;
+
+  // ---- payloads ----
+  const uint64_t ep = seqset_extent(sp), er = seqset_extent(sr);
+  uint64_t sext = 0, bext = 0;
+  for (uint32_t t = 0; t < nt; ++t) {
+    sext = std::max<uint64_t>(sext, bc.signal_offset[t] + 4ull * bc.nsamples[t]);
+    bext = std::max<uint64_t>(bext, bc.bc_offset[t] + bc.bc_len[t]);
+  }
+  int nbuf = 0;
+  auto buf = [&]() -> DevBuf& { return ctx->d_pipe[nbuf++]; };
+  const void *d_prof, *d_ref, *d_sig, *d_pos;
+  if ((rc = stage_in(ctx, buf(), sp.data, ep * 4, mem, &d_prof))) return rc;
+  if ((rc = stage_in(ctx, buf(), sr.data, er, mem, &d_ref))) return rc;
+  if ((rc = stage_in(ctx, buf(), bc.signal, sext * 4, mem, &d_sig))) return rc;
+  if ((rc = stage_in(ctx, buf(), bc.bcpos, bext * 4, mem, &d_pos))) return rc;
+  std::vector<DevOut> outs;
+  auto io = [&](void* user, size_t bytes, bool upload_first, void** dptr) -> int {
+    if (mem == TRACYHIP_MEM_DEVICE) { *dptr = user; return TRACYHIP_OK; }
+    DevBuf& b = buf();
+    HIP_TRY(b.ensure(bytes ? bytes : 1));
+    if (upload_first && bytes) HIP_TRY(hipMemcpyAsync(b.p, user, bytes, hipMemcpyHostToDevice, st));
+    *dptr = b.p;
+    outs.push_back(DevOut{b.p, user, bytes});
+    return TRACYHIP_OK;
+  };
+  void *d_pri, *d_sec, *d_bp, *d_sd, *d_fr, *d_di, *d_de, *d_dst, *d_strim;
+  uint64_t dext = 0;
+  for (uint32_t t = 0; t < nt; ++t) dext = std::max<uint64_t>(dext, out->dcp_offset[t] + 2ull * dp.maxindel + 2);
+  if ((rc = io(bc.primary, bext, true, &d_pri))) return rc;
+  if ((rc = io(bc.secondary, bext, true, &d_sec))) return rc;
+  if ((rc = io(out->bp, sizeof(BreakpointOut) * (size_t)nt, false, &d_bp))) return rc;
+  if ((rc = io(out->secdecomp, bext, false, &d_sd))) return rc;
+  if ((rc = io(out->fractions, sizeof(double) * 2 * (size_t)nt, false, &d_fr))) return rc;
+  if ((rc = io(out->dcp_indel, dext * 4, false, &d_di))) return rc;
+  if ((rc = io(out->dcp_err, dext * 4, false, &d_de))) return rc;
+  if ((rc = io(out->dstatus, sizeof(DecompOut) * (size_t)nt, false, &d_dst))) return rc;
+  if ((rc = io(out->score_trim, sizeof(int32_t) * (size_t)nt, false, &d_strim))) return rc;
+
+  // references: validate + encode
+  HIP_TRY(ctx->d_err.ensure(sizeof(int32_t)));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t), st));
+  HIP_TRY(ctx->d_codes.ensure(er ? er : 1));
+  if (er) {
+    hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er,
+                       static_cast<int32_t*>(ctx->d_err.p));
+    hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
+                       static_cast<uint8_t*>(ctx->d_codes.p), er);
+    HIP_TRY(hipGetLastError());
+    int32_t herr = 0;
+    HIP_TRY(hipMemcpyAsync(&herr, ctx->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (herr & 4) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
+  }
+
+  // ---- 1. findBreakpoint(trimmedtrace) (indigo.h:196) ----
+  {
+    std::vector<BpDesc> hd(nt);
+    for (uint32_t t = 0; t < nt; ++t) hd[t] = BpDesc{sp.offset[t] + tl[t], mf[t], mt[t]};
+    const BpDesc* dd;
+    if ((rc = upload(ctx, buf(), hd, &dd))) return rc;
+    if ((rc = launch_breakpoint(ctx, dd, nt, maxcol, static_cast<const float*>(d_prof), static_cast<BreakpointOut*>(d_bp)))) return rc;
+  }
+
+  // ---- 2. orientation (indigo.h:235-247) ----
+  DevBuf& b_sc2 = buf();
+  HIP_TRY(b_sc2.ensure(sizeof(int32_t) * 2 * (size_t)nt));
+  auto qp_desc = [&](uint32_t t, bool trimmed) {
+    PairDesc d{};
+    d.a1_off = sp.offset[t] + (trimmed ? tl[t] : 0);
+    d.a1_stride = mf[t];
+    d.m = trimmed ? mt[t] : mf[t];
+    d.a2_off = sr.offset[ridx[t]];
+    d.n = rn[t];
+    d.a2_stride = rn[t];
+    d.out = t;
+    return d;
+  };
+  {
+    DpProblem pb;
+    pb.mode = MODE_QP; pb.a1_profile = true; pb.d_a1 = d_prof; pb.d_a2 = ctx->d_codes.p;
+    pb.desc.resize(2 * (size_t)nt); pb.k.resize(2 * (size_t)nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+      PairDesc d = qp_desc(t, true);
+      pb.desc[t] = d;
+      d.out = nt + t; d.flags = PAIR_A2_REVCOMP;
+      pb.desc[nt + t] = d;
+      pb.k[t] = pb.k[nt + t] = choose_k(d.m, MODE_QP);
+    }
+    if ((rc = run_dp(ctx, pb, &p, false, false, static_cast<int32_t*>(b_sc2.p), nullptr, nullptr, nullptr))) return rc;
+  }
+  std::vector<int32_t> h_sc2(2 * (size_t)nt);
+  HIP_TRY(hipMemcpy(h_sc2.data(), b_sc2.p, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost));
+  std::vector<uint8_t> h_fwd(nt);
+  for (uint32_t t = 0; t < nt; ++t) h_fwd[t] = h_sc2[t] > h_sc2[nt + t] ? 1 : 0;
+
+  // ---- 3. gotoh(trimmedtrace, prefslice) + alignment rows (indigo.h:302) ----
+  std::vector<uint64_t> off1(nt);
+  uint64_t tot1 = 0;
+  for (uint32_t t = 0; t < nt; ++t) { off1[t] = tot1; tot1 += (uint64_t)mt[t] + rn[t]; }
+  DevBuf &b_ops1 = buf(), &b_len1 = buf(), &b_r0 = buf(), &b_r1 = buf();
+  HIP_TRY(b_ops1.ensure(tot1 ? tot1 : 1));
+  HIP_TRY(b_len1.ensure(sizeof(uint32_t) * (size_t)nt));
+  HIP_TRY(b_r0.ensure(tot1 ? tot1 : 1));
+  HIP_TRY(b_r1.ensure(tot1 ? tot1 : 1));
+  const uint64_t* d_off1;
+  if ((rc = upload(ctx, buf(), off1, &d_off1))) return rc;
+  std::vector<PairDesc> desc_trim(nt);
+  {
+    DpProblem pb;
+    pb.mode = MODE_QP; pb.a1_profile = true; pb.d_a1 = d_prof; pb.d_a2 = ctx->d_codes.p;
+    pb.desc.resize(nt); pb.k.resize(nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+      PairDesc d = qp_desc(t, true);
+      d.flags = h_fwd[t] ? 0 : PAIR_A2_REVCOMP;
+      pb.desc[t] = d;
+      desc_trim[t] = d;
+      pb.k[t] = choose_k(d.m, MODE_QP);
+    }
+    if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(d_strim), static_cast<uint8_t*>(b_ops1.p), d_off1,
+                     static_cast<uint32_t*>(b_len1.p))))
+      return rc;
+  }
+  {
+    const PairDesc* dd;
+    if ((rc = upload(ctx, buf(), desc_trim, &dd))) return rc;
+    RowsArgs ra{};
+    ra.pairs = dd;
+    ra.a1 = d_prof; ra.a2 = d_ref;  // row 1 shows the consensus characters of the (oriented) one-hot reference profile
+    ra.a1_profile = 1; ra.a2_profile = 0; ra.a2_revcomp_flag = 1; ra.a2_onehot = 1;
+    ra.ops = static_cast<const uint8_t*>(b_ops1.p);
+    ra.ops_off = d_off1;
+    ra.ops_len = static_cast<const uint32_t*>(b_len1.p);
+    ra.rows0 = static_cast<uint8_t*>(b_r0.p);
+    ra.rows1 = static_cast<uint8_t*>(b_r1.p);
+    ra.npairs = nt;
+    HIP_TRY(launch_alignment_rows(ra, st));
+  }
+  std::vector<uint32_t> h_len1(nt);
+  std::vector<int32_t> h_strim(nt);
+  HIP_TRY(hipMemcpyAsync(h_len1.data(), b_len1.p, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(h_strim.data(), d_strim, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<int32_t> h_status(nt, 0);
+  for (uint32_t t = 0; t < nt; ++t) {  // indigo.h:303-309
+    const double seqsize = (double)mt[t];
+    const double thr = seqsize * 0.35 * prm->match + seqsize * (1 - 0.35) * prm->mismatch;
+    if ((double)h_strim[t] <= thr) h_status[t] = -1;
+  }
+
+  // ---- 4. findHomozygousBreakpoint where the trace shows no shift (indigo.h:314-317) ----
+  DevBuf& b_hst = buf();
+  HIP_TRY(b_hst.ensure(sizeof(int32_t) * (size_t)nt));
+  {
+    std::vector<RowsDesc> hd(nt);
+    for (uint32_t t = 0; t < nt; ++t) hd[t] = RowsDesc{off1[t], h_len1[t], 0};
+    const RowsDesc* dd;
+    if ((rc = upload(ctx, buf(), hd, &dd))) return rc;
+    if ((rc = launch_homozygous(ctx, dd, static_cast<const uint8_t*>(b_r0.p), static_cast<const uint8_t*>(b_r1.p), nt,
+                                static_cast<BreakpointOut*>(d_bp), static_cast<int32_t*>(b_hst.p))))
+      return rc;
+  }
+
+  // ---- 5. decomposeAlleles, generateSecondaryDecomposed, allelicFraction (indigo.h:340-350) ----
+  {
+    std::vector<DecompDesc> hd(nt);
+    for (uint32_t t = 0; t < nt; ++t) hd[t] = DecompDesc{off1[t], bc.bc_offset[t], out->dcp_offset[t], h_len1[t], mf[t], rn[t], 0};
+    const DecompDesc* dd;
+    if ((rc = upload(ctx, buf(), hd, &dd))) return rc;
+    DecompArgs a{};
+    a.desc = dd;
+    a.rows0 = static_cast<const uint8_t*>(b_r0.p);
+    a.rows1 = static_cast<const uint8_t*>(b_r1.p);
+    a.primary = static_cast<uint8_t*>(d_pri);
+    a.secondary = static_cast<uint8_t*>(d_sec);
+    a.dcp_indel = static_cast<int32_t*>(d_di);
+    a.dcp_err = static_cast<int32_t*>(d_de);
+    a.out = static_cast<DecompOut*>(d_dst);
+    a.prm = DecompParams{dp.trim_left, dp.trim_right, dp.maxindel, dp.madc};
+    a.ntraces = nt;
+    if ((rc = launch_decompose(ctx, a, static_cast<const BreakpointOut*>(d_bp)))) return rc;
+    std::vector<BcDesc> hb(nt);
+    for (uint32_t t = 0; t < nt; ++t) hb[t] = BcDesc{bc.signal_offset[t], bc.bc_offset[t], bc.nsamples[t], mf[t]};
+    const BcDesc* db;
+    if ((rc = upload(ctx, buf(), hb, &db))) return rc;
+    if ((rc = launch_secdecomp(ctx, db, nt, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos),
+                               static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sec), static_cast<uint8_t*>(d_sd))))
+      return rc;
+    if ((rc = launch_allelic_fraction(ctx, db, nt, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos),
+                                      static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sd), TL, TR,
+                                      static_cast<double*>(d_fr))))
+      return rc;
+  }
+  std::vector<int32_t> h_hst(nt);
+  HIP_TRY(hipMemcpyAsync(h_hst.data(), b_hst.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (uint32_t t = 0; t < nt; ++t)
+    if (h_status[t] == 0 && h_hst[t] != 1) h_status[t] = -2;
+
+  // ---- 6. allele-specific alignments (indigo.h:355-387): string x string Gotoh ----
+  // allele k in {0: primary, 1: secDecompose}: gotoh(seq, rs.refslice) -> trimReferenceSlice -> gotoh(seq, slice)
+  DevBuf &b_opsA = buf(), &b_lenA = buf(), &b_trimA = buf(), &b_rnfw = buf();
+  HIP_TRY(b_opsA.ensure(tot1 + 2ull * TL * nt + 16));
+  HIP_TRY(b_lenA.ensure(sizeof(uint32_t) * (size_t)nt));
+  HIP_TRY(b_trimA.ensure(sizeof(TrimOut) * (size_t)nt));
+  HIP_TRY(b_rnfw.ensure(sizeof(uint32_t) * (size_t)nt + nt));
+  {
+    std::vector<uint8_t> tmp(sizeof(uint32_t) * (size_t)nt + nt);
+    std::memcpy(tmp.data(), rn.data(), sizeof(uint32_t) * (size_t)nt);
+    std::memcpy(tmp.data() + sizeof(uint32_t) * (size_t)nt, h_fwd.data(), nt);
+    HIP_TRY(hipMemcpy(b_rnfw.p, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+  }
+  std::vector<uint64_t> offA(nt);
+  {
+    uint64_t tot = 0;
+    for (uint32_t t = 0; t < nt; ++t) { offA[t] = tot; tot += (uint64_t)sl[t] + rn[t]; }
+  }
+  const uint64_t* d_offA;
+  if ((rc = upload(ctx, buf(), offA, &d_offA))) return rc;
+  std::vector<TrimOut> h_trimA[2];
+  void *d_scoreK[3], *d_opsK[3], *d_lenK[3];
+  for (int k = 0; k < 3; ++k) {
+    uint64_t cap = 0;
+    for (uint32_t t = 0; t < nt; ++t) cap = std::max<uint64_t>(cap, out->ops_offset[k][t] + (uint64_t)sl[t] + (k < 2 ? rn[t] : sl[t]));
+    if ((rc = io(out->score[k], sizeof(int32_t) * (size_t)nt, false, &d_scoreK[k]))) return rc;
+    if ((rc = io(out->ops[k], cap ? cap : 1, false, &d_opsK[k]))) return rc;
+    if ((rc = io(out->ops_len[k], sizeof(uint32_t) * (size_t)nt, false, &d_lenK[k]))) return rc;
+  }
+  for (int k = 0; k < 2; ++k) {
+    const void* seq = (k == 0) ? d_pri : d_sd;
+    DpProblem pb;
+    pb.mode = MODE_CHAR; pb.d_a1 = seq; pb.d_a2 = d_ref;
+    pb.desc.resize(nt); pb.k.resize(nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+      PairDesc d{};
+      d.a1_off = bc.bc_offset[t] + soff[t];
+      d.m = sl[t]; d.a1_stride = sl[t];
+      d.a2_off = sr.offset[ridx[t]];
+      d.n = rn[t]; d.a2_stride = rn[t];
+      d.flags = h_fwd[t] ? 0 : PAIR_A2_REVCOMP;
+      d.out = t;
+      pb.desc[t] = d;
+      pb.k[t] = choose_k(d.m, MODE_CHAR);
+    }
+    if ((rc = run_dp(ctx, pb, &p, false, true, nullptr, static_cast<uint8_t*>(b_opsA.p), d_offA, static_cast<uint32_t*>(b_lenA.p)))) return rc;
+    hipLaunchKernelGGL(trim_kernel, dim3((nt + 63) / 64), dim3(64), 0, st, static_cast<const uint8_t*>(b_opsA.p), d_offA,
+                       static_cast<const uint32_t*>(b_lenA.p), static_cast<const uint32_t*>(b_rnfw.p),
+                       reinterpret_cast<const uint8_t*>(static_cast<const uint32_t*>(b_rnfw.p) + nt), TL, TR, nt,
+                       static_cast<TrimOut*>(b_trimA.p));
+    HIP_TRY(hipGetLastError());
+    h_trimA[k].resize(nt);
+    HIP_TRY(hipMemcpyAsync(h_trimA[k].data(), b_trimA.p, sizeof(TrimOut) * (size_t)nt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t t = 0; t < nt; ++t) {
+      PairDesc& d = pb.desc[t];
+      d.n = h_trimA[k][t].len; d.a2_stride = d.n;
+      d.a2_off = sr.offset[ridx[t]] + (h_fwd[t] ? h_trimA[k][t].ri : rn[t] - h_trimA[k][t].ri - h_trimA[k][t].len);
+    }
+    const uint64_t* d_offK;
+    std::vector<uint64_t> offK(out->ops_offset[k], out->ops_offset[k] + nt);
+    if ((rc = upload(ctx, buf(), offK, &d_offK))) return rc;
+    if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(d_scoreK[k]), static_cast<uint8_t*>(d_opsK[k]), d_offK,
+                     static_cast<uint32_t*>(d_lenK[k]))))
+      return rc;
+  }
+  {  // allele 1 vs allele 2, global (indigo.h:379-387)
+    DpProblem pb;
+    pb.mode = MODE_CHAR; pb.d_a1 = d_pri; pb.d_a2 = d_sd;
+    pb.desc.resize(nt); pb.k.resize(nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+      PairDesc d{};
+      d.a1_off = bc.bc_offset[t] + soff[t];
+      d.a2_off = bc.bc_offset[t] + soff[t];
+      d.m = sl[t]; d.n = sl[t]; d.a1_stride = sl[t]; d.a2_stride = sl[t];
+      d.out = t;
+      pb.desc[t] = d;
+      pb.k[t] = choose_k(d.m, MODE_CHAR);
+    }
+    const uint64_t* d_offK;
+    std::vector<uint64_t> offK(out->ops_offset[2], out->ops_offset[2] + nt);
+    if ((rc = upload(ctx, buf(), offK, &d_offK))) return rc;
+    if ((rc = run_dp(ctx, pb, &pglobal, false, true, static_cast<int32_t*>(d_scoreK[2]), static_cast<uint8_t*>(d_opsK[2]), d_offK,
+                     static_cast<uint32_t*>(d_lenK[2]))))
+      return rc;
+  }
+
+  // ---- results ----
+  const hipMemcpyKind up = (mem == TRACYHIP_MEM_HOST) ? hipMemcpyHostToHost : hipMemcpyHostToDevice;
+  std::vector<uint32_t> hb[2], hl[2], hp[2];
+  for (int k = 0; k < 2; ++k) {
+    hb[k].resize(nt); hl[k].resize(nt); hp[k].resize(nt);
+    for (uint32_t t = 0; t < nt; ++t) { hb[k][t] = h_trimA[k][t].ri; hl[k][t] = h_trimA[k][t].len; hp[k][t] = h_trimA[k][t].pos; }
+    HIP_TRY(hipMemcpyAsync(out->slice_begin[k], hb[k].data(), sizeof(uint32_t) * (size_t)nt, up, st));
+    HIP_TRY(hipMemcpyAsync(out->slice_len[k], hl[k].data(), sizeof(uint32_t) * (size_t)nt, up, st));
+    HIP_TRY(hipMemcpyAsync(out->ref_pos[k], hp[k].data(), sizeof(uint32_t) * (size_t)nt, up, st));
+  }
+  HIP_TRY(hipMemcpyAsync(out->score_fwd, h_sc2.data(), sizeof(int32_t) * (size_t)nt, up, st));
+  HIP_TRY(hipMemcpyAsync(out->score_rev, h_sc2.data() + nt, sizeof(int32_t) * (size_t)nt, up, st));
+  HIP_TRY(hipMemcpyAsync(out->forward, h_fwd.data(), nt, up, st));
+  HIP_TRY(hipMemcpyAsync(out->status, h_status.data(), sizeof(int32_t) * (size_t)nt, up, st));
+  for (const DevOut& o : outs)
+    if (o.bytes) HIP_TRY(hipMemcpyAsync(o.user, o.dev, o.bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return TRACYHIP_OK;
+}

@@ -36,7 +36,7 @@ struct HostWave {
   char* lds() { return sh->lds.data(); }
 };
 
-template <int K, int MODE, bool TRACE, bool NEEDLE>
+template <int K, int MODE, bool TRACE, bool NEEDLE, bool NARROW = false>
 void run_wave(const DpArgs& a) {
   WaveShared sh;
   sh.lds.assign(lds_bytes(MODE == MODE_QP ? MODE_QP : MODE_PROF, K) + 64, 0);
@@ -47,11 +47,17 @@ void run_wave(const DpArgs& a) {
       if constexpr (NEEDLE) {
         if constexpr (MODE != MODE_QP) needle_body<HostWave, K, MODE, TRACE>(w, a, 0);
       } else {
-        gotoh_body<HostWave, K, MODE, TRACE>(w, a, 0);
+        gotoh_body<HostWave, K, MODE, TRACE, NARROW>(w, a, 0);
       }
     });
   }
   for (auto& t : th) t.join();
+}
+
+template <int K>
+void dispatch_narrow(int mode, const DpArgs& a) {
+  if (mode == MODE_CHAR) run_wave<K, MODE_CHAR, false, false, true>(a);
+  else run_wave<K, MODE_QP, false, false, true>(a);
 }
 
 template <int K, bool NEEDLE>
@@ -80,6 +86,17 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
   a.scratch = scratch.data(); a.scores = score; a.err = &err;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = hfree; a.vfree = vfree;
   *score = 0x7fffffff;
+  if (flags & 0x100u) {  // 16-bit score-only kernel
+    d.flags &= 0xffu;
+    switch (K) {
+      case 4: dispatch_narrow<4>(mode, a); break;
+      case 8: dispatch_narrow<8>(mode, a); break;
+      case 16: dispatch_narrow<16>(mode, a); break;
+      default: return -1;
+    }
+    if (err_out) *err_out = err;
+    return 0;
+  }
   switch (K) {
     case 4: needle ? dispatch<4, true>(mode, trace, a) : dispatch<4, false>(mode, trace, a); break;
     case 8: needle ? dispatch<8, true>(mode, trace, a) : dispatch<8, false>(mode, trace, a); break;

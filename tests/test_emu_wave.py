@@ -120,3 +120,25 @@ def test_qp_overflow_flag():
     p1 = rand_profile(rng, 10)
     _, _, err = emu.run(p1, b"ACGTACGT", (3000, -5, -10, -4), 1, 0, emu.MODE_QP, 4, trace=True)
     assert err & 1
+
+
+@pytest.mark.parametrize("K", [4, 16])
+def test_narrow_score_kernel(K):
+    """the 16-bit score-only formulation (free end gaps on the first/last row) gives the same scores"""
+    rng = np.random.default_rng(77 + K)
+    for (m, n) in [(1, 40), (63, 300), (130, 90), (64 * K, 50)] + ([(300, 120)] if K == 4 else []):
+        p1 = rand_profile(rng, m)
+        ref = rand_seq(rng, n, b"ACGTACGTACGTNn-x")
+        p2 = orc.create_profile_str(ref)
+        for cfg in [(1, 0), (1, 1)]:
+            want = orc.gotoh_score_prof(p1, p2, cfg[0], cfg[1], SC)
+            assert emu.run(p1, ref, SC, cfg[0], cfg[1], emu.MODE_QP, K, trace=False, narrow=True)[0] == want
+        want = orc.gotoh_score_prof(p1, orc.revcomp_profile(p2), 1, 0, SC)
+        assert emu.run(p1, ref, SC, 1, 0, emu.MODE_QP, K, trace=False, revcomp=True, narrow=True)[0] == want
+        s1 = rand_seq(rng, m, b"ACGT")
+        s2 = rand_seq(rng, n, b"ACGT")
+        for cfg in [(1, 0), (1, 1)]:
+            assert emu.run(s1, s2, SC, cfg[0], cfg[1], emu.MODE_CHAR, K, trace=False, narrow=True)[0] == orc.gotoh_score_str(s1, s2, cfg[0], cfg[1], SC)
+    # all-mismatch / long-gap extremes stay inside the int16 window
+    s1, s2 = b"A" * 250, b"C" * 400
+    assert emu.run(s1, s2, SC, 1, 0, emu.MODE_CHAR, K, trace=False, narrow=True)[0] == orc.gotoh_score_str(s1, s2, 1, 0, SC)

@@ -48,6 +48,42 @@
 #define OP_PKSUBU16(R) "v_pk_sub_u16 " R ", " R ", %8 clamp\n"
 #define OP_PKMAD16(R) "v_pk_mad_i16 " R ", " R ", %8, %9\n"
 
+#define OP_SUB(R) "v_sub_u32 " R ", " R ", %8\n"
+#define OP_OR(R) "v_or_b32 " R ", " R ", %8\n"
+#define OP_XOR(R) "v_xor_b32 " R ", " R ", %8\n"
+#define OP_LSHL(R) "v_lshlrev_b32 " R ", 1, " R "\n"
+#define OP_ASHR(R) "v_ashrrev_i32 " R ", 1, " R "\n"
+#define OP_MOV(R) "v_mov_b32 " R ", %8\n"
+#define OP_CMPGT(R) "v_cmp_gt_i32 vcc, " R ", %8\n"
+#define OP_CMPGT16(R) "v_cmp_gt_i16 vcc, " R ", %8\n"
+#define OP_CMPE64(R) "v_cmp_gt_i32 s[20:21], " R ", %8\n"
+#define OP_CNDMASK2(R) "v_cndmask_b32 " R ", " R ", %8, s[20:21]\n"
+#define OP_ADDC(R) "v_addc_co_u32 " R ", vcc, " R ", " R ", vcc\n"
+#define OP_ADDU16(R) "v_add_u16 " R ", " R ", %8\n"
+#define OP_MAXU16(R) "v_max_u16 " R ", " R ", %8\n"
+#define OP_MINI16(R) "v_min_i16 " R ", " R ", %8\n"
+#define OP_MAX3I16(R) "v_max3_i16 " R ", " R ", %8, %9\n"
+#define OP_LSHLOR(R) "v_lshl_or_b32 " R ", " R ", 4, %8\n"
+#define OP_ANDOR(R) "v_and_or_b32 " R ", " R ", %8, %9\n"
+#define OP_OR3(R) "v_or3_b32 " R ", " R ", %8, %9\n"
+#define OP_MAXU32(R) "v_max_u32 " R ", " R ", %8\n"
+#define OP_MINI32(R) "v_min_i32 " R ", " R ", %8\n"
+#define OP_MAXF16(R) "v_max_f16 " R ", " R ", %8\n"
+#define OP_ADDF16(R) "v_add_f16 " R ", " R ", %8\n"
+#define OP_MULF32(R) "v_mul_f32 " R ", " R ", %8\n"
+#define OP_SUBF32(R) "v_sub_f32 " R ", " R ", %8\n"
+#define OP_BFE(R) "v_bfe_i32 " R ", " R ", 0, 16\n"
+#define OP_ADD_E64(R) "v_add_u32_e64 " R ", " R ", %8\n"
+#define OP_SUBU16(R) "v_sub_u16 " R ", " R ", %8\n"
+#define OP_MULLO16(R) "v_mul_lo_u16 " R ", " R ", %8\n"
+#define OP_PKADDF16(R) "v_pk_add_f16 " R ", " R ", %8\n"
+#define OP_PKMAXF16(R) "v_pk_max_f16 " R ", " R ", %8\n"
+DEFK(k_sub, OP_SUB) DEFK(k_or, OP_OR) DEFK(k_xor, OP_XOR) DEFK(k_lshl, OP_LSHL) DEFK(k_ashr, OP_ASHR) DEFK(k_mov, OP_MOV)
+DEFK(k_cmpgt, OP_CMPGT) DEFK(k_cmpgt16, OP_CMPGT16) DEFK(k_cmpe64, OP_CMPE64) DEFK(k_cndmask2, OP_CNDMASK2) DEFK(k_addc, OP_ADDC)
+DEFK(k_addu16, OP_ADDU16) DEFK(k_maxu16, OP_MAXU16) DEFK(k_mini16, OP_MINI16) DEFK(k_max3i16, OP_MAX3I16) DEFK(k_lshlor, OP_LSHLOR)
+DEFK(k_andor, OP_ANDOR) DEFK(k_or3, OP_OR3) DEFK(k_maxu32, OP_MAXU32) DEFK(k_mini32, OP_MINI32) DEFK(k_maxf16, OP_MAXF16) DEFK(k_addf16, OP_ADDF16)
+DEFK(k_mulf32, OP_MULF32) DEFK(k_subf32, OP_SUBF32) DEFK(k_bfe, OP_BFE) DEFK(k_adde64, OP_ADD_E64) DEFK(k_subu16, OP_SUBU16) DEFK(k_mullo16, OP_MULLO16)
+DEFK(k_pkaddf16, OP_PKADDF16) DEFK(k_pkmaxf16, OP_PKMAXF16)
 DEFK(k_add, OP_ADD) DEFK(k_max, OP_MAX) DEFK(k_max3, OP_MAX3) DEFK(k_and, OP_AND) DEFK(k_bfi, OP_BFI)
 DEFK(k_align, OP_ALIGN) DEFK(k_add3, OP_ADD3) DEFK(k_pkadd16, OP_PKADD16) DEFK(k_pkmax16, OP_PKMAX16)
 DEFK(k_pkaddu16, OP_PKADDU16) DEFK(k_addf, OP_ADDF) DEFK(k_maxf, OP_MAXF) DEFK(k_max3f, OP_MAX3F)
@@ -75,7 +111,12 @@ int main() {
                        {"v_lshl_add_u32", k_lshladd}, {"v_add_i16", k_addi16}, {"v_max_i16", k_maxi16},
                        {"v_perm_b32", k_perm}, {"v_mad_i32_i24", k_madi24}, {"v_med3_i32", k_med3},
                        {"v_min3_i32", k_min3}, {"v_pk_min_u16", k_pkminu16}, {"v_pk_sub_u16 clamp", k_pksubu16},
-                       {"v_pk_mad_i16", k_pkmad16}};
+                       {"v_pk_mad_i16", k_pkmad16},
+ {"v_sub_u32", k_sub}, {"v_or_b32", k_or}, {"v_xor_b32", k_xor}, {"v_lshlrev_b32", k_lshl}, {"v_ashrrev_i32", k_ashr}, {"v_mov_b32", k_mov},
+ {"v_cmp_gt_i32 vcc", k_cmpgt}, {"v_cmp_gt_i16 vcc", k_cmpgt16}, {"v_cmp_gt_i32 sgpr", k_cmpe64}, {"v_cndmask_b32 sgpr", k_cndmask2}, {"v_addc_co_u32", k_addc},
+ {"v_add_u16", k_addu16}, {"v_max_u16", k_maxu16}, {"v_min_i16", k_mini16}, {"v_max3_i16", k_max3i16}, {"v_lshl_or_b32", k_lshlor}, {"v_and_or_b32", k_andor},
+ {"v_or3_b32", k_or3}, {"v_max_u32", k_maxu32}, {"v_min_i32", k_mini32}, {"v_max_f16", k_maxf16}, {"v_add_f16", k_addf16}, {"v_mul_f32", k_mulf32}, {"v_sub_f32", k_subf32},
+ {"v_bfe_i32", k_bfe}, {"v_add_u32_e64", k_adde64}, {"v_sub_u16", k_subu16}, {"v_mul_lo_u16", k_mullo16}, {"v_pk_add_f16", k_pkaddf16}, {"v_pk_max_f16", k_pkmaxf16}};
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);

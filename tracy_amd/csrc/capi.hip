@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -167,11 +168,11 @@ int stage_in(tracyhip_ctx* ctx, DevBuf& buf, const void* src, uint64_t bytes, in
 int check_params(const tracyhip_params* prm, uint64_t max_mn) {
   if (!prm) return set_error(TRACYHIP_ERR_ARG, "null params");
   auto ab = [](int32_t x) { return (int64_t)(x < 0 ? -(int64_t)x : x); };
-  if (ab(prm->match) > 2047 || ab(prm->mismatch) > 2047)
-    return set_error(TRACYHIP_ERR_RANGE, "|match|,|mismatch| must be <= 2047 (int16 query profile x16)");
+  if (ab(prm->match) > 1000 || ab(prm->mismatch) > 1000)
+    return set_error(TRACYHIP_ERR_RANGE, "|match|,|mismatch| must be <= 1000 (int16 query profile x32)");
   const int64_t c = ab(prm->go) + ab(prm->ge) + std::max(ab(prm->match), ab(prm->mismatch));
-  if ((int64_t)(max_mn + 2) * c + 1000000 >= (1ll << 27))
-    return set_error(TRACYHIP_ERR_RANGE, "(m+n) * cost exceeds the exact range of the x16 int32 kernels");
+  if ((int64_t)(max_mn + 2) * c + 1000000 >= (1ll << 26))
+    return set_error(TRACYHIP_ERR_RANGE, "(m+n) * cost exceeds the exact range of the x32 int32 kernels");
   return TRACYHIP_OK;
 }
 
@@ -265,7 +266,18 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
         }
         if ((trc = timing_begin(ctx, trace ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
       }
-      HIP_TRY(needle ? launch_needle(pb.mode, K, trace, a, e - j, st) : launch_gotoh(pb.mode, K, trace, a, e - j, st));
+      bool narrow = false;
+      if (!needle && !trace && prm->hfree && (pb.mode == MODE_QP || pb.mode == MODE_CHAR)) {
+        // 16-bit score kernel: every real DP value of these pairs must fit int16 with room below for the sentinel
+        auto ab = [](int32_t x) { return (int64_t)(x < 0 ? -(int64_t)x : x); };
+        uint32_t maxm = 0;
+        for (uint32_t q = j; q < e; ++q) maxm = std::max(maxm, hd[q].m);
+        const int64_t rows = (int64_t)num_passes(maxm ? maxm : 1, K) * 64 * K;
+        const int64_t low = ab(prm->go) + rows * ab(prm->ge) + 2 * (ab(prm->go) + ab(prm->ge)) + ab(prm->mismatch) + ab(prm->match);
+        const int64_t high = rows * std::max(ab(prm->match), ab(prm->mismatch));
+        narrow = (low < -(int64_t)kNegInf16 - ab(prm->ge) - 64) && (high < 30000) && (prm->go <= 0) && (prm->ge <= 0) && !ctx->no_narrow;
+      }
+      HIP_TRY(needle ? launch_needle(pb.mode, K, trace, a, e - j, st) : launch_gotoh(pb.mode, K, trace, narrow, a, e - j, st));
       if ((trc = timing_end(ctx))) return trc;
       if (trace) {
         WalkArgs wa{};
@@ -386,6 +398,7 @@ int tracyhip_create(int device, tracyhip_ctx** out) {
     return set_error(TRACYHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
   }
   c->own_stream = c->stream;
+  c->no_narrow = getenv("TRACYHIP_NO_NARROW") != nullptr;
   *out = c;
   return TRACYHIP_OK;
 }

@@ -54,6 +54,7 @@ struct tracyhip_ctx {
   // kernel timing
   struct Pending { int which; hipEvent_t e0, e1; uint64_t cells, bytes; };
   bool timing = false;
+  bool no_narrow = false;  // TRACYHIP_NO_NARROW=1: force the int32 score kernel (A/B measurements)
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
   tracyhip_kernel_timing acc[3] = {};

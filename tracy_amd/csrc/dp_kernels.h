@@ -65,16 +65,18 @@ struct SubChar {
   int32_t cc;
   int32_t vmatch, vmis;
   TR_HD int32_t operator()(int i) const { return rc[i] == cc ? vmatch : vmis; }
+  TR_HD int32_t lo16(int i) const { return rc[i] == cc ? vmatch : vmis; }
 };
 
 template <int K>
 struct SubTable {
   int32_t sv[K];
   TR_HD int32_t operator()(int i) const { return sv[i]; }
+  TR_HD int32_t lo16(int i) const { return sv[i]; }
 };
 
 // LDS query-profile table: int16 [6 codes][64*K rows] (codes 5 = '-' and 6 = other share the zero row)
-template <int K>
+template <int K, bool NARROW = false>
 TR_HD void qp_load(const int16_t* tab, uint32_t code, uint32_t lane, SubTable<K>& s) {
   const uint32_t row = (code < 5u ? code : 5u) * (64u * K) + lane * K;
   const uint32_t* p = reinterpret_cast<const uint32_t*>(tab + row);
@@ -82,7 +84,7 @@ TR_HD void qp_load(const int16_t* tab, uint32_t code, uint32_t lane, SubTable<K>
 #pragma unroll
   for (int j = 0; j < K / 2; ++j) {
     const uint32_t w = p[j];
-    s.sv[2 * j] = (int32_t)(int16_t)(w & 0xffffu);
+    s.sv[2 * j] = NARROW ? (int32_t)w : (int32_t)(int16_t)(w & 0xffffu);  // 16-bit consumers read the low half only
     s.sv[2 * j + 1] = ((int32_t)w) >> 16;
   }
 }
@@ -100,6 +102,7 @@ struct SubProf {
     for (int k = 0; k < 5; ++k) a[k] = p1[k * (64 * K) + row0 + i];
     return (int32_t)((uint32_t)profile_score(a, b, fmatch, fmis) << shift);
   }
+  TR_HD int32_t lo16(int i) const { return (*this)(i); }
 };
 
 // LDS bytes a (mode, K) kernel needs
@@ -114,8 +117,9 @@ TR_HD uint32_t a2_index(const PairDesc& d, uint32_t c /*1-based column*/) {
 // ------------------------------------------------------------------------------------------------
 // Gotoh, one pair per wave.  TRACE=true: tagged x16 arithmetic + traceback words; false: plain int32.
 // ------------------------------------------------------------------------------------------------
-template <class W, int K, int MODE, bool TRACE>
+template <class W, int K, int MODE, bool TRACE, bool NARROW = false>
 TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
+  static_assert(!(NARROW && TRACE), "the 16-bit formulation exists for the score-only kernel");
   const PairDesc d = a.pairs[pair_idx];
   const uint32_t L = w.lane();
   const uint32_t m = d.m, n = d.n;
@@ -141,7 +145,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const uint32_t T = steps_per_pass(n);
   uint64_t* bits = TRACE ? a.bits + d.bits_off : nullptr;
   int32_t* scratch = a.scratch ? a.scratch + 2 * d.scratch_off : nullptr;
-  const int32_t neg = (int32_t)((uint32_t)kNegInf << SH);
+  const int32_t neg = NARROW ? kNegInf16 : (int32_t)((uint32_t)kNegInf << SH);
 
   for (uint32_t p = 0; p < P; ++p) {
     const uint32_t base = p * 64u * K;  // rows base+1 .. base+64K
@@ -249,12 +253,14 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
           sub_c.cc = (int32_t)a2c[ci];
           if (d.flags & PAIR_A2_REVCOMP) sub_c.cc = (int32_t)complement_char((uint8_t)sub_c.cc);
           if (TRACE) trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub_c, w0, w1, nb_h, nb_f);
+          else if (NARROW) score_step16<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub_c, nb_h, nb_f);
           else score_step<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub_c, nb_h, nb_f);
         } else if (MODE == MODE_QP) {
           uint32_t code = a2c[ci];  // MODE_QP: a2 holds profile-row codes (encode_kernel), not characters
           if (d.flags & PAIR_A2_REVCOMP) code = complement_code(code);
-          qp_load<K>(qp_tab, code, L, sub_t);
+          qp_load<K, NARROW>(qp_tab, code, L, sub_t);
           if (TRACE) trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub_t, w0, w1, nb_h, nb_f);
+          else if (NARROW) score_step16<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub_t, nb_h, nb_f);
           else score_step<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub_t, nb_h, nb_f);
         } else {
 #pragma unroll
@@ -281,7 +287,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         int32_t v = 0;
 #pragma unroll
         for (int i = 0; i < K; ++i)
-          if ((uint32_t)i == g % K) v = TRACE ? (ts.Hc[i] >> SH) : ss.Hl[i];
+          if ((uint32_t)i == g % K) v = TRACE ? (ts.Hc[i] >> SH) : (NARROW ? sext16(ss.Hl[i]) : ss.Hl[i]);
         a.scores[d.out] = v;
       }
     }

@@ -24,10 +24,10 @@ struct DeviceWave {
   }
 };
 
-template <int K, int MODE, bool TRACE>
+template <int K, int MODE, bool TRACE, bool NARROW = false>
 __global__ __launch_bounds__(64) void gotoh_kernel(DpArgs a) {
   DeviceWave w;
-  gotoh_body<DeviceWave, K, MODE, TRACE>(w, a, blockIdx.x);
+  gotoh_body<DeviceWave, K, MODE, TRACE, NARROW>(w, a, blockIdx.x);
 }
 
 template <int K, int MODE, bool TRACE>
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
 }
 
 // ---- launchers ---------------------------------------------------------------------------------
-template <int K, int MODE, bool TRACE>
+template <int K, int MODE, bool TRACE, bool NARROW = false>
 static hipError_t launch_gotoh_t(const DpArgs& a, uint32_t npairs, hipStream_t s) {
-  hipLaunchKernelGGL((gotoh_kernel<K, MODE, TRACE>), dim3(npairs), dim3(64), lds_bytes(MODE, K), s, a);
+  hipLaunchKernelGGL((gotoh_kernel<K, MODE, TRACE, NARROW>), dim3(npairs), dim3(64), lds_bytes(MODE, K), s, a);
   return hipGetLastError();
 }
 template <int K, int MODE, bool TRACE>
@@ -116,9 +116,22 @@ static hipError_t launch_gotoh_k(int K, const DpArgs& a, uint32_t npairs, hipStr
     default: return hipErrorInvalidValue;
   }
 }
+template <int MODE>
+static hipError_t launch_gotoh_narrow(int K, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  switch (K) {
+    case 4: return launch_gotoh_t<4, MODE, false, true>(a, npairs, s);
+    case 8: return launch_gotoh_t<8, MODE, false, true>(a, npairs, s);
+    case 16: return launch_gotoh_t<16, MODE, false, true>(a, npairs, s);
+    default: return hipErrorInvalidValue;
+  }
+}
 
-hipError_t launch_gotoh(int mode, int K, bool trace, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+hipError_t launch_gotoh(int mode, int K, bool trace, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s) {
   if (npairs == 0) return hipSuccess;
+  if (narrow && !trace) {
+    if (mode == MODE_CHAR) return launch_gotoh_narrow<MODE_CHAR>(K, a, npairs, s);
+    if (mode == MODE_QP) return launch_gotoh_narrow<MODE_QP>(K, a, npairs, s);
+  }
   switch (mode) {
     case MODE_CHAR: return trace ? launch_gotoh_k<MODE_CHAR, true>(K, a, npairs, s) : launch_gotoh_k<MODE_CHAR, false>(K, a, npairs, s);
     case MODE_QP: return trace ? launch_gotoh_k<MODE_QP, true>(K, a, npairs, s) : launch_gotoh_k<MODE_QP, false>(K, a, npairs, s);

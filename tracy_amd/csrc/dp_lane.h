@@ -13,16 +13,19 @@
 //   H = max(Hdiag + sub, E, F)                            s[col]   gotoh.h:132
 //   bit3 = (H == E); bit4 = !bit3 && (H == F); bit1 = (E != Eleft + hgap(ge)); bit2 = (F != Fup + vgap(ge))
 //
-// Tagged formulation used by the traceback kernel: all scores are kept multiplied by 16 and the four
-// predicates ride in the low nibble of the maxima, so no compare instructions are needed:
-//   X1 = Hleft16 + (hopen*16 + 8)      X2 = Eleft16 + (hext*16 + 8 + 1)      Et = max(X1, X2)
-//   Y1 = Hup16   + (vopen*16 + 4)      Y2 = Fup16   + (vext*16 + 4 + 2)      Ft = max(Y1, Y2)
-//   Dt = Hdiag16 + sub*16                                                     Ht = max3(Dt, Et, Ft)
-// Equal scores are separated by the tags exactly as the reference's predicates order them:
-//   extend beats open on ties (bit1/bit2 are set only when open wins strictly), E beats F beats diag.
-//   nibble = (Ht & 12) | (Ft & 2) | (Et & 1):
-//     bits[3:2] = 10 -> bit3, 01 -> bit4, 00 -> diagonal;  bit 1 = !bit2;  bit 0 = !bit1.
-// Scores stay exact because tags never exceed 15 and are stripped (& ~15) before a value is reused.
+// Tagged formulation used by the traceback kernel: all scores are kept multiplied by 32 and the four
+// predicates ride in the low 5 bits of the maxima, so no compare instructions are needed:
+//   X1 = Hleft32 + (hopen*32 + 7)      X2 = Eleft32 + (hext*32 + 10)     Et = max(X1, X2)   tag 7 / 10
+//   Y1 = Hup32   + (vopen*32 + 1)      Y2 = Fup32   + (vext*32 + 6)      Ft = max(Y1, Y2)   tag 1 / 6
+//   Dt = Hdiag32 + sub*32                                                 Ht = max3(Dt, Et, Ft)
+// Equal scores are separated by the tags exactly as the reference's predicates order them: extend beats
+// open on ties (bit1/bit2 are set only when open wins strictly: 10 > 7, 6 > 1), E beats F beats diagonal
+// (min E tag 7 > max F tag 6 > 0).  The stored nibble is (Et + Ft + Ht) mod 16: with these tag values
+// the twelve (bit1, bit2, source) combinations give twelve different nibbles (kNibbleDecode), so two
+// plain adds replace the compare / select / bit-field sequence.  On gfx950 v_add_u32 and v_and_b32 issue
+// in ~2 cycles per wave64 while v_max_i32, v_max3_i32, v_bfi_b32, v_alignbit_b32 take ~4
+// (tools/ubench/valu_rate.hip), which is what this encoding is shaped for.
+// Scores stay exact because tags never exceed 31 and are stripped (& ~31) before a value is reused.
 #ifndef TRACY_AMD_DP_LANE_H
 #define TRACY_AMD_DP_LANE_H
 
@@ -37,22 +40,12 @@
 namespace tracyhip {
 
 constexpr int32_t kNegInf = -1000000;  // -sc.inf, align.h:26,30
-constexpr int kTagShift = 4;
+constexpr int kTagShift = 5;
+constexpr int32_t kTagMask = 31;
+constexpr int32_t kTagEOpen = 7, kTagEExt = 10, kTagFOpen = 1, kTagFExt = 6;
 
 TR_HD int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
 TR_HD int32_t imax3(int32_t a, int32_t b, int32_t c) { return imax(imax(a, b), c); }
-
-// (a & mask) | (b & ~mask); v_bfi_b32 on the device (the generic form gets split into 3 ands + or3
-// once the compiler sees only the low nibble is live)
-TR_HD uint32_t bit_select(uint32_t mask, uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  uint32_t d;
-  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
-  return d;
-#else
-  return (a & mask) | (b & ~mask);
-#endif
-}
 
 // shift a nibble into the top of a 32-bit accumulator: v_alignbit_b32
 TR_HD uint32_t push_nibble(uint32_t acc, uint32_t nib_src) { return (acc >> 4) | (nib_src << 28); }
@@ -60,38 +53,47 @@ TR_HD uint32_t push_nibble(uint32_t acc, uint32_t nib_src) { return (acc >> 4) |
 // ---- traceback lane -------------------------------------------------------------------------
 template <int K>
 struct TraceLane {
-  int32_t Hc[K];   // H[r][c-1] * 16
-  int32_t Ec[K];   // E[r][c-1] * 16
-  int32_t cx1[K];  // horizontal open  constant of row r: hgap(go+ge)*16 + 8
-  int32_t cx2[K];  // horizontal extend constant of row r: hgap(ge)*16 + 9
+  int32_t Hc[K];   // H[r][c-1] * 32
+  int32_t Ec[K];   // E[r][c-1] * 32
+  int32_t cx1[K];  // horizontal open  constant of row r: hgap(go+ge)*32 + 7
+  int32_t cx2[K];  // horizontal extend constant of row r: hgap(ge)*32 + 10
 };
 
-TR_HD int32_t trace_cx1(int32_t open_cost) { return open_cost * 16 + 8; }
-TR_HD int32_t trace_cx2(int32_t ext_cost) { return ext_cost * 16 + 9; }
-TR_HD int32_t trace_cy1(int32_t open_cost) { return open_cost * 16 + 4; }
-TR_HD int32_t trace_cy2(int32_t ext_cost) { return ext_cost * 16 + 6; }
+TR_HD int32_t trace_cx1(int32_t open_cost) { return open_cost * 32 + kTagEOpen; }
+TR_HD int32_t trace_cx2(int32_t ext_cost) { return ext_cost * 32 + kTagEExt; }
+TR_HD int32_t trace_cy1(int32_t open_cost) { return open_cost * 32 + kTagFOpen; }
+TR_HD int32_t trace_cy2(int32_t ext_cost) { return ext_cost * 32 + kTagFExt; }
 
-// One column of the strip.  up_h/up_f: H,F (x16, clean) of the row above at this column; diag: H of
-// the row above at the previous column; sub(i) returns the substitution score of slot i x16.
+// One column of the strip.  up_h/up_f: H,F (x32, clean) of the row above at this column; diag: H of
+// the row above at the previous column; sub(i) returns the substitution score of slot i x32.
 // Outputs: w0/w1 = 16 nibbles (slot i at bits 4i of w1:w0), bot_h/bot_f = clean H,F of the last slot.
+//
+// Two sweeps over the strip so that every state register is updated in place (no end-of-step copies):
+//   A (bottom-up, independent of the vertical chain): Hc[i] <- Hdiag + sub = old Hc[i-1] + sub(i),
+//     Ec[i] <- Et.  Going upwards, old Hc[i] has been consumed by slot i+1 before slot i overwrites it.
+//   B (top-down, the F/H chain): Ft, Ht, nibble, strip the tags.
 template <int K, class Sub>
 TR_HD void trace_step(TraceLane<K>& s, int32_t up_h, int32_t up_f, int32_t diag, int32_t cy1, int32_t cy2,
                       const Sub& sub, uint32_t& w0, uint32_t& w1, int32_t& bot_h, int32_t& bot_f) {
+#pragma unroll
+  for (int i = K - 1; i >= 0; --i) {
+    const int32_t et = imax(s.Hc[i] + s.cx1[i], s.Ec[i] + s.cx2[i]);
+    const int32_t dt = (i == 0 ? diag : s.Hc[i - 1]) + sub(i);
+    s.Hc[i] = dt;
+    s.Ec[i] = et;
+  }
   uint32_t a0 = 0, a1 = 0;
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const int32_t et = imax(s.Hc[i] + s.cx1[i], s.Ec[i] + s.cx2[i]);
     const int32_t ft = imax(up_h + cy1, up_f + cy2);
-    const int32_t dt = diag + sub(i);
-    const int32_t ht = imax3(dt, et, ft);
-    const uint32_t nib = bit_select(3u, bit_select(1u, (uint32_t)et, (uint32_t)ft), (uint32_t)ht);
+    const int32_t ht = imax3(s.Hc[i], s.Ec[i], ft);
+    const uint32_t nib = (uint32_t)s.Ec[i] + (uint32_t)ft + (uint32_t)ht;  // low 4 bits = tag sum mod 16
     if (i < 8) a0 = push_nibble(a0, nib);
     else a1 = push_nibble(a1, nib);
-    diag = s.Hc[i];
-    s.Hc[i] = ht & ~15;
-    s.Ec[i] = et & ~15;
+    s.Hc[i] = ht & ~kTagMask;
+    s.Ec[i] = s.Ec[i] & ~kTagMask;
     up_h = s.Hc[i];
-    up_f = ft & ~15;
+    up_f = ft & ~kTagMask;
   }
   if (K <= 8) a0 >>= (4 * (8 - K)) & 31;
   else a1 >>= (4 * (16 - K)) & 31;
@@ -101,16 +103,30 @@ TR_HD void trace_step(TraceLane<K>& s, int32_t up_h, int32_t up_f, int32_t diag,
   bot_f = up_f;
 }
 
-// decode one stored nibble into the reference's four trace bits
+// decode one stored nibble into the reference's four trace bits: nibble = (Te + Tf + W) mod 16 with
+// Te in {7 open, 10 extend}, Tf in {1 open, 6 extend}, W in {0 diagonal, Te (E won), Tf (F won)}
 struct TraceBits {
   bool bit1, bit2, bit3, bit4;
 };
 TR_HD TraceBits decode_nibble(uint32_t nib) {
-  TraceBits b;
-  b.bit3 = (nib >> 3) & 1u;
-  b.bit4 = (nib >> 2) & 1u;
-  b.bit2 = !((nib >> 1) & 1u);
-  b.bit1 = !(nib & 1u);
+  TraceBits b = {false, false, false, false};
+#pragma unroll
+  for (int eo = 0; eo < 2; ++eo) {
+#pragma unroll
+    for (int fo = 0; fo < 2; ++fo) {
+      const int te = eo ? kTagEOpen : kTagEExt, tf = fo ? kTagFOpen : kTagFExt;
+#pragma unroll
+      for (int src = 0; src < 3; ++src) {
+        const int wv = src == 0 ? 0 : src == 1 ? te : tf;
+        if ((uint32_t)((te + tf + wv) & 15) == nib) {
+          b.bit1 = eo != 0;   // E opened from H strictly (gotoh.h:137)
+          b.bit2 = fo != 0;   // F opened from H strictly (gotoh.h:138)
+          b.bit3 = src == 1;  // H == E (gotoh.h:135)
+          b.bit4 = src == 2;  // else H == F (gotoh.h:136)
+        }
+      }
+    }
+  }
   return b;
 }
 
@@ -126,14 +142,71 @@ struct ScoreLane {
 template <int K, class Sub>
 TR_HD void score_step(ScoreLane<K>& s, int32_t up_h, int32_t up_f, int32_t diag, int32_t vopen, int32_t vext,
                       const Sub& sub, int32_t& bot_h, int32_t& bot_f) {
+  // same two in-place sweeps as trace_step
+#pragma unroll
+  for (int i = K - 1; i >= 0; --i) {
+    const int32_t e = imax(s.Hl[i] + s.hopen[i], s.El[i] + s.hext[i]);
+    const int32_t d = (i == 0 ? diag : s.Hl[i - 1]) + sub(i);
+    s.Hl[i] = d;
+    s.El[i] = e;
+  }
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const int32_t e = imax(s.Hl[i] + s.hopen[i], s.El[i] + s.hext[i]);
     const int32_t f = imax(up_h + vopen, up_f + vext);
-    const int32_t h = imax3(diag + sub(i), e, f);
-    diag = s.Hl[i];
+    const int32_t h = imax3(s.Hl[i], s.El[i], f);
     s.Hl[i] = h;
+    up_h = h;
+    up_f = f;
+  }
+  bot_h = up_h;
+  bot_f = up_f;
+}
+
+// ---- narrow (16-bit) score-only lane ------------------------------------------------------------
+// gfx950 issues the 16-bit VOP2 forms v_add_u16 / v_max_i16 in ~2 cycles per wave64, v_max_i32 and
+// v_max3_i32 in ~4 (tools/ubench/valu_rate.hip).  With free end gaps on the first/last row every real
+// DP value lies in [go + rows*ge + 2(go+ge), rows*match], which fits int16 for Sanger-sized traces, and
+// the -inf sentinel only has to lose its one comparison (kNegInf16 + ge < any real value): the 16-bit
+// kernel then computes exactly the same maxima.  Registers are int32; only their low halves are live.
+constexpr int32_t kNegInf16 = -20000;
+
+TR_HD int32_t add16(int32_t a, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int32_t d;
+  asm("v_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+#else
+  return (int32_t)(uint16_t)((uint32_t)a + (uint32_t)b);
+#endif
+}
+TR_HD int32_t max16(int32_t a, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int32_t d;
+  asm("v_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+#else
+  const int16_t x = (int16_t)(uint16_t)a, y = (int16_t)(uint16_t)b;
+  return (int32_t)(uint16_t)(x > y ? x : y);
+#endif
+}
+TR_HD int32_t sext16(int32_t a) { return (int32_t)(int16_t)(uint16_t)a; }
+
+// sub.lo16(i): a register whose low 16 bits hold the substitution score of slot i
+template <int K, class Sub>
+TR_HD void score_step16(ScoreLane<K>& s, int32_t up_h, int32_t up_f, int32_t diag, int32_t vopen, int32_t vext,
+                        const Sub& sub, int32_t& bot_h, int32_t& bot_f) {
+#pragma unroll
+  for (int i = K - 1; i >= 0; --i) {
+    const int32_t e = max16(add16(s.Hl[i], s.hopen[i]), add16(s.El[i], s.hext[i]));
+    const int32_t d = add16(i == 0 ? diag : s.Hl[i - 1], sub.lo16(i));
+    s.Hl[i] = d;
     s.El[i] = e;
+  }
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int32_t f = max16(add16(up_h, vopen), add16(up_f, vext));
+    const int32_t h = max16(max16(s.Hl[i], s.El[i]), f);
+    s.Hl[i] = h;
     up_h = h;
     up_f = f;
   }

@@ -23,7 +23,8 @@ struct RowsArgs {
   uint32_t npairs;
 };
 
-hipError_t launch_gotoh(int mode, int K, bool trace, const DpArgs& a, uint32_t npairs, hipStream_t s);
+// narrow: use the 16-bit score-only kernel (caller has checked the value range, see narrow_ok)
+hipError_t launch_gotoh(int mode, int K, bool trace, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s);
 hipError_t launch_needle(int mode, int K, bool trace, const DpArgs& a, uint32_t npairs, hipStream_t s);
 hipError_t launch_gotoh_walk(const WalkArgs& a, hipStream_t s);
 hipError_t launch_needle_walk(const WalkArgs& a, const uint32_t* bits32, hipStream_t s);

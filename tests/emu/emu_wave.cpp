@@ -31,6 +31,21 @@ struct HostWave {
     sh->bar.arrive_and_wait();
     return r;
   }
+  uint64_t ballot(bool p) {
+    sh->xchg[lane_] = p ? 1 : 0;
+    sh->bar.arrive_and_wait();
+    uint64_t m = 0;
+    for (int l = 0; l < 64; ++l) m |= (uint64_t)(sh->xchg[l] & 1) << l;
+    sh->bar.arrive_and_wait();
+    return m;
+  }
+  uint32_t bcast(uint32_t x, uint32_t src) {
+    sh->xchg[lane_] = (int32_t)x;
+    sh->bar.arrive_and_wait();
+    const uint32_t r = (uint32_t)sh->xchg[src & 63];
+    sh->bar.arrive_and_wait();
+    return r;
+  }
   void sync() { sh->bar.arrive_and_wait(); }
   void sync_global() { sh->bar.arrive_and_wait(); }
   char* lds() { return sh->lds.data(); }
@@ -109,7 +124,18 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
     wa.pairs = &d; wa.bits = bits.data(); wa.ops = ops; wa.ops_off = &off; wa.ops_len = ops_len; wa.err = &err;
     wa.npairs = 1; wa.K = K;
     if (needle) needle_walk_one(wa, reinterpret_cast<uint32_t*>(bits.data()), 0);
-    else gotoh_walk_one(wa, 0);
+    else {
+      // both walkers: the one-lane reference walk and the wave-cooperative one must agree
+      gotoh_walk_one(wa, 0);
+      std::vector<uint8_t> ref_ops(ops, ops + *ops_len);
+      const uint32_t ref_len = *ops_len;
+      std::memset(ops, 0, (size_t)m + n);
+      WaveShared sh;
+      std::vector<std::thread> th;
+      for (uint32_t l = 0; l < 64; ++l) th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_walk_wave<HostWave>(w, wa, 0); });
+      for (auto& t : th) t.join();
+      if (*ops_len != ref_len || std::memcmp(ops, ref_ops.data(), ref_len) != 0) err |= 0x100;
+    }
   }
   if (err_out) *err_out = err;
   return 0;

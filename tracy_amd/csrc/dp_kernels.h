@@ -352,6 +352,86 @@ TR_HD void gotoh_walk_one(const WalkArgs& a, uint32_t pair_idx) {
 
 
 // ------------------------------------------------------------------------------------------------
+// Wave-cooperative traceback walker: the same state machine (gotoh.h:143-167), but one wave per pair
+// and up to 64 cells per memory round trip.  In state 's' the walk continues diagonally while a cell
+// has neither bit3 nor bit4; in 'h' ('v') it continues left (up) until the first cell with bit1 (bit2).
+// Each lane fetches the nibble of one candidate cell of the current run, a ballot finds where the run
+// ends, and the run is emitted with one coalesced store.  W provides lane(), ballot(pred), bcast(x, l).
+// ------------------------------------------------------------------------------------------------
+template <class W>
+TR_HD void gotoh_walk_wave(W& w, const WalkArgs& a, uint32_t pair_idx) {
+  const PairDesc d = a.pairs[pair_idx];
+  const uint64_t* bits = a.bits + d.bits_off;
+  uint8_t* out = a.ops + a.ops_off[d.out];
+  const uint32_t n = d.n, lane = w.lane();
+  const int K = a.K;
+  uint32_t row = d.m, col = d.n, k = 0;
+  int state = 0;  // 0 = s, 1 = h, 2 = v
+  const uint32_t limit = d.m + d.n;
+  bool bad = false;
+  while ((row > 0 || col > 0) && k <= limit) {
+    if (row == 0) {  // first row: bit3 everywhere, bit1 nowhere -> 'h' down to column 0 (gotoh.h:112-116)
+      for (uint32_t i = lane; i < col; i += 64) out[k + i] = 'h';
+      k += col; col = 0;
+      break;
+    }
+    if (col == 0) {  // first column: bit4 only -> 'v' down to row 0 (gotoh.h:117-123)
+      if (state == 1) { bad = true; break; }
+      for (uint32_t i = lane; i < row; i += 64) out[k + i] = 'v';
+      k += row; row = 0;
+      break;
+    }
+    // candidate cell of this lane along the current run
+    const uint32_t r = (state == 1) ? row : row - lane;
+    const uint32_t c = (state == 2) ? col : col - lane;
+    const bool inside = (state == 1) ? (lane < col) : (state == 2) ? (lane < row) : (lane < row && lane < col);
+    TraceBits b = {false, false, false, false};
+    if (inside) {
+      const CellAddr ca = cell_addr(r, K);
+      const uint64_t wd = bits[word_index(ca.pass, c + ca.lane, ca.lane, n)];
+      b = decode_nibble((uint32_t)(wd >> (4u * ca.slot)) & 15u);
+    }
+    const bool stop = !inside || (state == 0 ? (b.bit3 || b.bit4) : state == 1 ? b.bit1 : b.bit2);
+    const uint64_t m = w.ballot(stop);
+    uint32_t first = 64;
+    if (m) {
+      first = 0;
+      while (!((m >> first) & 1ull)) ++first;
+    }
+    if (state == 0) {
+      // cells 0..first-1 are diagonal steps
+      if (lane < first) out[k + lane] = 's';
+      k += first; row -= first; col -= first;
+      if (first < 64 && row > 0 && col > 0) {  // the stopping cell is inside: switch matrix, no move
+        const uint32_t code = w.bcast((uint32_t)(b.bit3 ? 1 : 2), first);
+        state = (int)code;
+      }
+      // first < 64 with row == 0 or col == 0: handled by the boundary rules on the next iteration
+    } else if (state == 1) {
+      // every visited cell emits 'h'; the one with bit1 is the last of the run
+      const uint32_t inside_n = col < 64 ? col : 64;
+      const bool hit = first < inside_n;
+      const uint32_t cnt = hit ? first + 1 : inside_n;
+      if (lane < cnt) out[k + lane] = 'h';
+      k += cnt; col -= cnt;
+      if (hit) state = 0;
+    } else {
+      const uint32_t inside_n = row < 64 ? row : 64;
+      const bool hit = first < inside_n;
+      const uint32_t cnt = hit ? first + 1 : inside_n;
+      if (lane < cnt) out[k + lane] = 'v';
+      k += cnt; row -= cnt;
+      if (hit) state = 0;
+      else if (row == 0 && col > 0) { bad = true; break; }  // 'v' ran into row 0: unreachable with sane parameters
+    }
+  }
+  if (row > 0 || col > 0 || bad) {
+    if (lane == 0) flag_error(a.err, 2);
+  }
+  if (lane == 0) a.ops_len[d.out] = k;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Needleman-Wunsch with linear gaps (needle.h:12-138), same wave decomposition.  Profiles are scored
 // in double with a float accumulator (needle.h:26 makes TProfile double; align.h:112-116).
 // ------------------------------------------------------------------------------------------------

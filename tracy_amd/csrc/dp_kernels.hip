@@ -16,6 +16,8 @@ struct DeviceWave {
   __device__ __forceinline__ int32_t shift_up(int32_t x) const {
     return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false);
   }
+  __device__ __forceinline__ uint64_t ballot(bool p) const { return __ballot(p); }
+  __device__ __forceinline__ uint32_t bcast(uint32_t x, uint32_t src_lane) const { return (uint32_t)__shfl((int)x, (int)src_lane, 64); }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   __device__ __forceinline__ void sync_global() const { __threadfence(); }
   __device__ __forceinline__ char* lds() const {
@@ -37,8 +39,8 @@ __global__ __launch_bounds__(64) void needle_kernel(DpArgs a) {
 }
 
 __global__ __launch_bounds__(64) void gotoh_walk_kernel(WalkArgs a) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < a.npairs) gotoh_walk_one(a, i);
+  DeviceWave w;
+  gotoh_walk_wave<DeviceWave>(w, a, blockIdx.x);
 }
 
 __global__ __launch_bounds__(64) void needle_walk_kernel(WalkArgs a, const uint32_t* bits32) {
@@ -163,7 +165,7 @@ hipError_t launch_needle(int mode, int K, bool trace, const DpArgs& a, uint32_t 
 
 hipError_t launch_gotoh_walk(const WalkArgs& a, hipStream_t s) {
   if (a.npairs == 0) return hipSuccess;
-  hipLaunchKernelGGL(gotoh_walk_kernel, dim3((a.npairs + 63) / 64), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(gotoh_walk_kernel, dim3(a.npairs), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_needle_walk(const WalkArgs& a, const uint32_t* bits32, hipStream_t s) {

@@ -106,6 +106,8 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
     switch (K) {
       case 4: dispatch_narrow<4>(mode, a); break;
       case 8: dispatch_narrow<8>(mode, a); break;
+      case 12: dispatch_narrow<12>(mode, a); break;
+      case 15: dispatch_narrow<15>(mode, a); break;
       case 16: dispatch_narrow<16>(mode, a); break;
       default: return -1;
     }
@@ -115,6 +117,8 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
   switch (K) {
     case 4: needle ? dispatch<4, true>(mode, trace, a) : dispatch<4, false>(mode, trace, a); break;
     case 8: needle ? dispatch<8, true>(mode, trace, a) : dispatch<8, false>(mode, trace, a); break;
+    case 12: if (needle) return -1; dispatch<12, false>(mode, trace, a); break;
+    case 15: if (needle) return -1; dispatch<15, false>(mode, trace, a); break;
     case 16: needle ? dispatch<16, true>(mode, trace, a) : dispatch<16, false>(mode, trace, a); break;
     default: return -1;
   }

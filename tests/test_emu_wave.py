@@ -142,3 +142,21 @@ def test_narrow_score_kernel(K):
     # all-mismatch / long-gap extremes stay inside the int16 window
     s1, s2 = b"A" * 250, b"C" * 400
     assert emu.run(s1, s2, SC, 1, 0, emu.MODE_CHAR, K, trace=False, narrow=True)[0] == orc.gotoh_score_str(s1, s2, 1, 0, SC)
+
+
+@pytest.mark.parametrize("K", [12, 15])
+def test_odd_strip_heights(K):
+    rng = np.random.default_rng(K)
+    for (m, n) in [(1, 30), (64 * K, 70), (64 * K - 7, 90), (64 * K + 20, 40)]:
+        p1 = rand_profile(rng, m)
+        ref = rand_seq(rng, n, b"ACGTACGTN-")
+        p2 = orc.create_profile_str(ref)
+        want = orc.gotoh_prof(p1, p2, 1, 0, SC)
+        got = emu.run(p1, ref, SC, 1, 0, emu.MODE_QP, K, trace=True)
+        assert (got[0], got[1]) == want
+        assert emu.run(p1, ref, SC, 1, 0, emu.MODE_QP, K, trace=False)[0] == want[0]
+        assert emu.run(p1, ref, SC, 1, 0, emu.MODE_QP, K, trace=False, narrow=True)[0] == want[0]
+        s1 = rand_seq(rng, m)
+        want = orc.gotoh_str(s1, ref, 1, 1, SC)
+        got = emu.run(s1, ref, SC, 1, 1, emu.MODE_CHAR, K, trace=True)
+        assert (got[0], got[1]) == want

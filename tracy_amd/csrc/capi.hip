@@ -73,11 +73,12 @@ void PinBuf::release() {
 }
 
 // smallest P*K over the strip heights compiled for the mode; ties go to the taller strip
-int choose_k(uint32_t m, int mode) {
-  static const int ks_all[] = {16, 8, 4};
+int choose_k(uint32_t m, int mode, bool needle) {
+  static const int ks_all[] = {16, 15, 12, 8, 4};
+  static const int ks_needle[] = {16, 8, 4};
   static const int ks_prof[] = {8, 4};
-  const int* ks = (mode == MODE_PROF) ? ks_prof : ks_all;
-  const int nk = (mode == MODE_PROF) ? 2 : 3;
+  const int* ks = (mode == MODE_PROF) ? ks_prof : needle ? ks_needle : ks_all;
+  const int nk = (mode == MODE_PROF) ? 2 : needle ? 3 : 5;
   int best = ks[0];
   uint64_t best_cost = ~0ull;
   for (int i = 0; i < nk; ++i) {
@@ -349,7 +350,7 @@ int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool 
     d.a2_stride = d.n;
     d.out = i;
     pb.desc[i] = d;
-    pb.k[i] = choose_k(d.m, pb.mode);
+    pb.k[i] = choose_k(d.m, pb.mode, needle);
     *max_mn = std::max<uint64_t>(*max_mn, (uint64_t)d.m + d.n);
   }
   return TRACYHIP_OK;

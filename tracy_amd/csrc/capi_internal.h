@@ -25,7 +25,7 @@ struct PinBuf {  // grow-only pinned host buffer (descriptor uploads)
 };
 
 int set_error(int code, const char* fmt, ...);
-int choose_k(uint32_t m, int mode);
+int choose_k(uint32_t m, int mode, bool needle = false);
 uint64_t seqset_extent(const tracyhip_seqset& s);
 
 // a validated batch: descriptors in caller order + device pointers of the payloads

@@ -76,16 +76,19 @@ struct SubTable {
 };
 
 // LDS query-profile table: int16 [6 codes][64*K rows] (codes 5 = '-' and 6 = other share the zero row)
+// table row stride per lane: K rounded up to an even count (int16 pairs), so odd strip heights work too
+TR_HD constexpr int qp_stride(int K) { return (K + 1) & ~1; }
+
 template <int K, bool NARROW = false>
 TR_HD void qp_load(const int16_t* tab, uint32_t code, uint32_t lane, SubTable<K>& s) {
-  const uint32_t row = (code < 5u ? code : 5u) * (64u * K) + lane * K;
+  constexpr int KP = qp_stride(K);
+  const uint32_t row = (code < 5u ? code : 5u) * (64u * KP) + lane * KP;
   const uint32_t* p = reinterpret_cast<const uint32_t*>(tab + row);
-  static_assert(K % 2 == 0, "K must be even");
 #pragma unroll
-  for (int j = 0; j < K / 2; ++j) {
+  for (int j = 0; j < KP / 2; ++j) {
     const uint32_t w = p[j];
     s.sv[2 * j] = NARROW ? (int32_t)w : (int32_t)(int16_t)(w & 0xffffu);  // 16-bit consumers read the low half only
-    s.sv[2 * j + 1] = ((int32_t)w) >> 16;
+    if (2 * j + 1 < K) s.sv[2 * j + 1] = ((int32_t)w) >> 16;
   }
 }
 
@@ -107,7 +110,7 @@ struct SubProf {
 
 // LDS bytes a (mode, K) kernel needs
 TR_HD constexpr uint32_t lds_bytes(int mode, int K) {
-  return mode == MODE_QP ? 6u * 64u * K * 2u : mode == MODE_PROF ? 5u * 64u * K * 4u : 0u;
+  return mode == MODE_QP ? 6u * 64u * (uint32_t)qp_stride(K) * 2u : mode == MODE_PROF ? 5u * 64u * K * 4u : 0u;
 }
 
 TR_HD uint32_t a2_index(const PairDesc& d, uint32_t c /*1-based column*/) {
@@ -205,9 +208,9 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
           const int32_t q = (r <= m) ? onehot_score(pr, b, fmatch, fmis) : 0;
           const int32_t qs = (int32_t)((uint32_t)q << SH);
           overflow |= (qs > 32767) || (qs < -32768);
-          qp_tab[b * (64 * K) + L * K + i] = (int16_t)qs;
+          qp_tab[b * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)qs;
         }
-        qp_tab[5 * (64 * K) + L * K + i] = 0;
+        qp_tab[5 * (64 * qp_stride(K)) + L * qp_stride(K) + i] = 0;
       }
       if (overflow) flag_error(a.err, 1);
       w.sync();

@@ -112,6 +112,12 @@ static hipError_t launch_gotoh_k(int K, const DpArgs& a, uint32_t npairs, hipStr
   switch (K) {
     case 4: return launch_gotoh_t<4, MODE, TRACE>(a, npairs, s);
     case 8: return launch_gotoh_t<8, MODE, TRACE>(a, npairs, s);
+    case 12:
+      if constexpr (MODE != MODE_PROF) return launch_gotoh_t<12, MODE, TRACE>(a, npairs, s);
+      return hipErrorInvalidValue;
+    case 15:
+      if constexpr (MODE != MODE_PROF) return launch_gotoh_t<15, MODE, TRACE>(a, npairs, s);
+      return hipErrorInvalidValue;
     case 16:
       if constexpr (MODE != MODE_PROF) return launch_gotoh_t<16, MODE, TRACE>(a, npairs, s);
       return hipErrorInvalidValue;
@@ -123,6 +129,8 @@ static hipError_t launch_gotoh_narrow(int K, const DpArgs& a, uint32_t npairs, h
   switch (K) {
     case 4: return launch_gotoh_t<4, MODE, false, true>(a, npairs, s);
     case 8: return launch_gotoh_t<8, MODE, false, true>(a, npairs, s);
+    case 12: return launch_gotoh_t<12, MODE, false, true>(a, npairs, s);
+    case 15: return launch_gotoh_t<15, MODE, false, true>(a, npairs, s);
     case 16: return launch_gotoh_t<16, MODE, false, true>(a, npairs, s);
     default: return hipErrorInvalidValue;
   }

@@ -164,7 +164,7 @@ def main():
     gcups = cells_all * args.steps / elapsed_max / 1e9
     kt = capi.KernelTiming()
     rl = {}
-    for name, which in (("score", 0), ("trace", 1), ("walk", 2)):
+    for name, which in (("score", 0), ("trace", 1), ("walk", 2), ("band", 3)):
         lib.tracyhip_timing_get(ctx._h, which, C.byref(kt))
         rl[name] = dict(ms=kt.ms, launches=int(kt.launches), cells=int(kt.cells), bytes=int(kt.bytes))
     tr = rl["trace"]
@@ -176,7 +176,10 @@ def main():
                 "algorithmic_bytes_per_launch": tr["bytes"] // max(tr["launches"], 1),
                 "trace_kernel_gcups": round(tr["cells"] / (tr["ms"] * 1e-3) / 1e9, 1) if tr["ms"] > 0 else 0.0,
                 "score_kernel_gcups": round(rl["score"]["cells"] / (rl["score"]["ms"] * 1e-3) / 1e9, 1) if rl["score"]["ms"] > 0 else 0.0,
-                "walk_ms_per_step": round(rl["walk"]["ms"] / max(args.steps, 1), 3)}
+                "walk_ms_per_step": round(rl["walk"]["ms"] / max(args.steps, 1), 3),
+                "score_ms_per_step": round(rl["score"]["ms"] / max(args.steps, 1), 3),
+                "band_trace_ms_per_step": round(rl["band"]["ms"] / max(args.steps, 1), 3),
+                "band_trace_effective_gcups": round(rl["band"]["cells"] / (rl["band"]["ms"] * 1e-3) / 1e9, 1) if rl["band"]["ms"] > 0 else 0.0}
 
     line = {
         "metric": "GCUPS (tracy align: Gotoh affine-gap DP cells per second, whole job)",

@@ -267,6 +267,7 @@ int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decompose_job* j
 #define TRACYHIP_TIMER_SCORE 0 /* score-only DP kernels */
 #define TRACYHIP_TIMER_TRACE 1 /* traceback DP kernels  */
 #define TRACYHIP_TIMER_WALK 2  /* traceback walkers     */
+#define TRACYHIP_TIMER_BAND 3  /* band tracebacks (checkpointed traceback of the align / decompose pipelines) */
 typedef struct {
   double ms;         /* summed launch durations */
   uint64_t launches;

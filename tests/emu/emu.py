@@ -54,3 +54,33 @@ def run(a1, a2, score, hfree, vfree, mode, K, trace=True, needle=False, revcomp=
                       C.byref(ol), C.byref(err))
     assert rc == 0
     return sc.value, (ops.raw[:ol.value] if trace else None), err.value
+
+
+def run_band(a1, a2, score, hfree, vfree, mode, K, B=32, narrow=True, revcomp=False, a1_view=None):
+    """checkpointed score kernel + band traceback of one pair; returns (score, btr, err)"""
+    if isinstance(a1, (bytes, bytearray)):
+        b1 = np.frombuffer(bytes(a1) + b"\0", dtype=np.uint8).copy()
+        m, s1 = len(a1), len(a1)
+    else:
+        b1 = np.ascontiguousarray(a1, dtype=np.float32)
+        m, s1 = b1.shape[1], b1.shape[1]
+    if mode == MODE_QP:
+        lut = np.full(256, 6, dtype=np.uint8)
+        for chars, code in ((b"Aa", 0), (b"Cc", 1), (b"Gg", 2), (b"Tt", 3), (b"Nn", 4), (b"-", 5)):
+            for ch in chars:
+                lut[ch] = code
+        a2 = lut[np.frombuffer(bytes(a2), dtype=np.uint8)].tobytes()
+    b2 = np.frombuffer(bytes(a2) + b"\0", dtype=np.uint8).copy()
+    n = len(a2)
+    p1 = b1.ctypes.data
+    if a1_view is not None:
+        off, m = a1_view
+        p1 += off * b1.itemsize
+    sc = C.c_int32(0)
+    ops = C.create_string_buffer(m + n + 2)
+    ol = C.c_uint32(0)
+    err = C.c_int32(0)
+    rc = lib().emu_band(mode, K, int(narrow), B, C.c_void_p(p1), m, s1, C.c_void_p(b2.ctypes.data), n, 1 if revcomp else 0,
+                        *[int(x) for x in score], int(hfree), int(vfree), C.byref(sc), ops, C.byref(ol), C.byref(err))
+    assert rc == 0
+    return sc.value, ops.raw[:ol.value], err.value

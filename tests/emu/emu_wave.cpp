@@ -83,7 +83,60 @@ void dispatch(int mode, bool trace, const DpArgs& a) {
 }
 }  // namespace
 
+template <int K, int MODE, bool NARROW>
+void run_ckpt_pair(const DpArgs& a, const WalkArgs& wa) {
+  {  // checkpointed score pass
+    WaveShared sh;
+    sh.lds.assign(lds_bytes(MODE_QP, K) + 64, 0);
+    std::vector<std::thread> th;
+    for (uint32_t l = 0; l < 64; ++l)
+      th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_body<HostWave, K, MODE, false, NARROW, true>(w, a, 0); });
+    for (auto& t : th) t.join();
+  }
+  {  // band traceback
+    WaveShared sh;
+    sh.lds.assign(lds_bytes(MODE_QP, K) + 64, 0);
+    std::vector<std::thread> th;
+    for (uint32_t l = 0; l < 64; ++l)
+      th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_band_trace_body<HostWave, K, MODE>(w, a, wa, 0); });
+    for (auto& t : th) t.join();
+  }
+}
+
 extern "C" {
+// checkpointed score pass + band traceback of one pair (single pass: m <= 64*K)
+int emu_band(int mode, int K, int narrow, uint32_t B, const void* a1, uint32_t m, uint32_t a1_stride, const void* a2, uint32_t n,
+             uint32_t flags, int32_t match, int32_t mismatch, int32_t go, int32_t ge, int32_t hfree, int32_t vfree,
+             int32_t* score, uint8_t* ops, uint32_t* ops_len, int32_t* err_out) {
+  PairDesc d{};
+  d.m = m; d.n = n; d.a1_stride = a1_stride; d.a2_stride = n; d.flags = flags;
+  const uint32_t steps = n + 64;
+  std::vector<int32_t> ckpt((size_t)(steps / B + 2) * ckpt_fields(K) * 64, 0x7f7f7f7f);
+  std::vector<int32_t> lastrow(2 * (size_t)(n + 2), 0x7f7f7f7f);
+  std::vector<uint64_t> band((size_t)B * 64 + 64, 0xDEADBEEFDEADBEEFull);
+  int32_t err = 0;
+  DpArgs a{};
+  a.pairs = &d; a.a1 = a1; a.a2 = a2; a.scores = score; a.err = &err;
+  a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = hfree; a.vfree = vfree;
+  a.ckpt = ckpt.data(); a.lastrow = lastrow.data(); a.band = band.data(); a.ckpt_B = B;
+  uint64_t off = 0;
+  WalkArgs wa{};
+  wa.pairs = &d; wa.ops = ops; wa.ops_off = &off; wa.ops_len = ops_len; wa.err = &err; wa.npairs = 1; wa.K = K;
+  *score = 0x7fffffff;
+#define EMU_CK(KK)                                                                                     \
+  case KK:                                                                                              \
+    if (mode == MODE_CHAR) { if (narrow) run_ckpt_pair<KK, MODE_CHAR, true>(a, wa); else run_ckpt_pair<KK, MODE_CHAR, false>(a, wa); } \
+    else { if (narrow) run_ckpt_pair<KK, MODE_QP, true>(a, wa); else run_ckpt_pair<KK, MODE_QP, false>(a, wa); }                        \
+    break;
+  switch (K) {
+    EMU_CK(4) EMU_CK(8) EMU_CK(15) EMU_CK(16)
+    default: return -1;
+  }
+#undef EMU_CK
+  if (err_out) *err_out = err;
+  return 0;
+}
+
 // One pair through the kernel bodies.  a1/a2: bytes (CHAR) or float[6][len] (PROFILE side of the mode).
 // Returns 0 on success; score/ops (push order)/ops_len are outputs; ops may be null for score-only.
 int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, uint32_t a1_stride, const void* a2,

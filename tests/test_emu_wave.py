@@ -160,3 +160,36 @@ def test_odd_strip_heights(K):
         want = orc.gotoh_str(s1, ref, 1, 1, SC)
         got = emu.run(s1, ref, SC, 1, 1, emu.MODE_CHAR, K, trace=True)
         assert (got[0], got[1]) == want
+
+
+@pytest.mark.parametrize("K", [4, 15, 16])
+def test_band_traceback(K):
+    """checkpointed score pass + band traceback == full-matrix traceback (same btr, same score)"""
+    rng = np.random.default_rng(900 + K)
+    cases = [(1, 1), (1, 50), (40, 1), (30, 200), (64 * K, 130), (64 * K - 9, 300), (100, 97), (K + 1, 40), (2 * K - 1, 33)]
+    for (m, n) in cases:
+        if m > 64 * K:
+            continue
+        ref = rand_seq(rng, n, b"ACGTACGTACGTN")
+        start = int(rng.integers(0, max(1, n - m)))
+        q = mutate(rng, ref[start:start + m] + rand_seq(rng, m), 0.08)[:m]
+        q = (q + rand_seq(rng, m))[:m]
+        idx = {65: 0, 67: 1, 71: 2, 84: 3}
+        p1 = np.zeros((6, m), dtype=np.float32)
+        for jx, ch in enumerate(q):
+            col = rng.random(4).astype(np.float32) * np.float32(0.1)
+            col[idx.get(ch, 0)] += np.float32(1.0)
+            p1[:4, jx] = col / col.sum()
+        p2 = orc.create_profile_str(ref)
+        for B in (16, 64):
+            # band mode domain: free end gaps on the first/last row only (AlignConfig<true,false>), ge < 0
+            for narrow in (True, False):
+                want = orc.gotoh_prof(p1, p2, 1, 0, SC)
+                got = emu.run_band(p1, ref, SC, 1, 0, emu.MODE_QP, K, B=B, narrow=narrow)
+                assert (got[0], got[1]) == want and got[2] == 0, (m, n, K, B, narrow)
+            want = orc.gotoh_str(q, ref, 1, 0, SC)
+            got = emu.run_band(q, ref, SC, 1, 0, emu.MODE_CHAR, K, B=B, narrow=True)
+            assert (got[0], got[1]) == want and got[2] == 0
+        want = orc.gotoh_prof(p1, orc.revcomp_profile(p2), 1, 0, SC)
+        got = emu.run_band(p1, ref, SC, 1, 0, emu.MODE_QP, K, B=32, narrow=True, revcomp=True)
+        assert (got[0], got[1]) == want

@@ -178,8 +178,18 @@ int check_params(const tracyhip_params* prm, uint64_t max_mn) {
 }
 
 // ---- the DP driver shared by gotoh/needle score/align -----------------------------------------------
+// 16-bit score kernel: every real DP value must fit int16 with room below for the sentinel
+bool narrow_ok(const tracyhip_params* prm, uint32_t maxm, int K) {
+  if (!prm->hfree || prm->go > 0 || prm->ge > 0) return false;
+  auto ab = [](int32_t x) { return (int64_t)(x < 0 ? -(int64_t)x : x); };
+  const int64_t rows = (int64_t)num_passes(maxm ? maxm : 1, K) * 64 * K;
+  const int64_t low = ab(prm->go) + rows * ab(prm->ge) + 2 * (ab(prm->go) + ab(prm->ge)) + ab(prm->mismatch) + ab(prm->match);
+  const int64_t high = rows * std::max(ab(prm->match), ab(prm->mismatch));
+  return (low < -(int64_t)kNegInf16 - ab(prm->ge) - 64) && (high < 30000);
+}
+
 int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, bool needle, bool trace,
-           int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len) {
+           int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len, int stage, const DpCkpt* ck) {
   const uint32_t np = (uint32_t)pb.desc.size();
   if (np == 0) return TRACYHIP_OK;
   hipStream_t st = ctx->stream;
@@ -210,7 +220,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
       PairDesc d = pb.desc[order[j]];
       const int K = pb.k[order[j]];
       const uint32_t P = (d.m && d.n) ? num_passes(d.m, K) : 0;
-      const uint64_t words = trace ? (uint64_t)P * steps_per_pass(d.n) * 64 : 0;
+      const uint64_t words = (trace && stage == DP_PLAIN) ? (uint64_t)P * steps_per_pass(d.n) * 64 : 0;
       const uint64_t scr = (P > 1) ? (uint64_t)d.n + 2 : 0;
       if (words * word_bytes > limit)
         return set_error(TRACYHIP_ERR_OOM, "one pair needs %llu bytes of traceback planes, workspace limit is %llu",
@@ -232,7 +242,12 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   for (const Chunk& c : chunks) { max_words = std::max(max_words, c.words); max_scr = std::max(max_scr, c.scratch); }
   HIP_TRY(ctx->d_desc.ensure(sizeof(PairDesc) * (size_t)np));
   HIP_TRY(hipMemcpyAsync(ctx->d_desc.p, hd, sizeof(PairDesc) * (size_t)np, hipMemcpyHostToDevice, st));
-  if (trace) HIP_TRY(ctx->d_bits.ensure(max_words * word_bytes));
+  if (trace && stage == DP_PLAIN) HIP_TRY(ctx->d_bits.ensure(max_words * word_bytes));
+  if (stage == DP_BAND) {
+    uint32_t maxrun = 0;
+    for (const Chunk& c : chunks) maxrun = std::max(maxrun, c.hi - c.lo);
+    HIP_TRY(ctx->d_band.ensure((size_t)maxrun * ck->B * 64 * 8));
+  }
   if (max_scr) HIP_TRY(ctx->d_scratch.ensure(max_scr * 8));
   HIP_TRY(ctx->d_err.ensure(sizeof(int32_t)));
   HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t), st));
@@ -247,6 +262,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   a.err = static_cast<int32_t*>(ctx->d_err.p);
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge;
   a.hfree = prm->hfree; a.vfree = prm->vfree;
+  if (ck) { a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.band = static_cast<uint64_t*>(ctx->d_band.p); }
   const PairDesc* dd = static_cast<const PairDesc*>(ctx->d_desc.p);
 
   for (const Chunk& c : chunks) {
@@ -265,22 +281,24 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
           cells += mn;
           bytes += (trace ? mn / 2 : 0) + (pb.a1_profile ? 24ull * d.m : d.m) + (pb.a2_profile ? 24ull * d.n : d.n) + 4;
         }
-        if ((trc = timing_begin(ctx, trace ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
+        if (stage == DP_BAND) bytes = 0;  // band traceback recomputes a few bands into an L2-resident buffer: no matrix-sized traffic
+        if ((trc = timing_begin(ctx, stage == DP_BAND ? TRACYHIP_TIMER_BAND : trace ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
       }
       bool narrow = false;
-      if (!needle && !trace && prm->hfree && (pb.mode == MODE_QP || pb.mode == MODE_CHAR)) {
-        // 16-bit score kernel: every real DP value of these pairs must fit int16 with room below for the sentinel
-        auto ab = [](int32_t x) { return (int64_t)(x < 0 ? -(int64_t)x : x); };
+      if (!needle && !trace && (pb.mode == MODE_QP || pb.mode == MODE_CHAR) && !ctx->no_narrow) {
         uint32_t maxm = 0;
         for (uint32_t q = j; q < e; ++q) maxm = std::max(maxm, hd[q].m);
-        const int64_t rows = (int64_t)num_passes(maxm ? maxm : 1, K) * 64 * K;
-        const int64_t low = ab(prm->go) + rows * ab(prm->ge) + 2 * (ab(prm->go) + ab(prm->ge)) + ab(prm->mismatch) + ab(prm->match);
-        const int64_t high = rows * std::max(ab(prm->match), ab(prm->mismatch));
-        narrow = (low < -(int64_t)kNegInf16 - ab(prm->ge) - 64) && (high < 30000) && (prm->go <= 0) && (prm->ge <= 0) && !ctx->no_narrow;
+        narrow = narrow_ok(prm, maxm, K);
       }
-      HIP_TRY(needle ? launch_needle(pb.mode, K, trace, a, e - j, st) : launch_gotoh(pb.mode, K, trace, narrow, a, e - j, st));
+      if (stage == DP_CKPT) HIP_TRY(launch_gotoh_ckpt(pb.mode, K, narrow, a, e - j, st));
+      else if (stage == DP_BAND) {
+        WalkArgs wa{};
+        wa.pairs = dd + j; wa.ops = d_ops; wa.ops_off = d_ops_off; wa.ops_len = d_ops_len; wa.err = a.err; wa.npairs = e - j; wa.K = K;
+        HIP_TRY(launch_band_trace(pb.mode, K, a, wa, e - j, st));
+      } else
+        HIP_TRY(needle ? launch_needle(pb.mode, K, trace, a, e - j, st) : launch_gotoh(pb.mode, K, trace, narrow, a, e - j, st));
       if ((trc = timing_end(ctx))) return trc;
-      if (trace) {
+      if (trace && stage == DP_PLAIN) {
         WalkArgs wa{};
         wa.pairs = dd + j;
         wa.bits = a.bits;
@@ -439,7 +457,7 @@ int tracyhip_timing_reset(tracyhip_ctx* c) {
   return TRACYHIP_OK;
 }
 int tracyhip_timing_get(tracyhip_ctx* c, int which, tracyhip_kernel_timing* out) {
-  if (!c || !out || which < 0 || which > 2) return set_error(TRACYHIP_ERR_ARG, "bad timing query");
+  if (!c || !out || which < 0 || which > 3) return set_error(TRACYHIP_ERR_ARG, "bad timing query");
   *out = c->acc[which];
   return TRACYHIP_OK;
 }

@@ -49,7 +49,8 @@ struct tracyhip_ctx {
   tracyhip::DevBuf d_desc, d_bits, d_scratch, d_in1, d_in2, d_codes, d_scores, d_ops, d_ops_off, d_ops_len, d_err,
       d_rows0, d_rows1;
   tracyhip::DevBuf d_tmp[8];
-  tracyhip::DevBuf d_pipe[64];  // decompose pipeline intermediates  // pipeline intermediates (align_traces / decompose)
+  tracyhip::DevBuf d_pipe[64];
+  tracyhip::DevBuf d_ckpt, d_lastrow, d_band;  // decompose pipeline intermediates  // pipeline intermediates (align_traces / decompose)
   tracyhip::PinBuf h_desc, h_off, h_tmp;
   // kernel timing
   struct Pending { int which; hipEvent_t e0, e1; uint64_t cells, bytes; };
@@ -57,13 +58,14 @@ struct tracyhip_ctx {
   bool no_narrow = false;  // TRACYHIP_NO_NARROW=1: force the int32 score kernel (A/B measurements)
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
-  tracyhip_kernel_timing acc[3] = {};
+  tracyhip_kernel_timing acc[4] = {};
   void release_all() {
     tracyhip::DevBuf* all[] = {&d_desc, &d_bits, &d_scratch, &d_in1, &d_in2, &d_codes, &d_scores, &d_ops,
                                &d_ops_off, &d_ops_len, &d_err, &d_rows0, &d_rows1};
     for (auto* b : all) b->release();
     for (auto& b : d_tmp) b.release();
     for (auto& b : d_pipe) b.release();
+    d_ckpt.release(); d_lastrow.release(); d_band.release();
     h_desc.release();
     h_off.release();
     h_tmp.release();
@@ -77,8 +79,19 @@ int timing_collect(tracyhip_ctx* ctx);                                          
 int ctx_begin(tracyhip_ctx* ctx);
 int stage_in(tracyhip_ctx* ctx, DevBuf& buf, const void* src, uint64_t bytes, int mem, const void** dev);
 int check_params(const tracyhip_params* prm, uint64_t max_mn);
+// stage: DP_PLAIN = score-only or full-matrix traceback; DP_CKPT = score-only pass that also writes wavefront
+// checkpoints + last-row values (PairDesc::ckpt_off / lastrow_off set by the caller); DP_BAND = band traceback
+// from those checkpoints (trace must be true).
+enum { DP_PLAIN = 0, DP_CKPT = 1, DP_BAND = 2 };
+struct DpCkpt {
+  int32_t* d_ckpt = nullptr;
+  int32_t* d_lastrow = nullptr;
+  uint32_t B = 256;
+};
 int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, bool needle, bool trace,
-           int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len);
+           int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len, int stage = DP_PLAIN,
+           const DpCkpt* ck = nullptr);
+bool narrow_ok(const tracyhip_params* prm, uint32_t maxm, int K);
 int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool needle, DpProblem& pb, uint64_t* max_mn);
 }  // namespace tracyhip
 #endif

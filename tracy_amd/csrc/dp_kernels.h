@@ -33,6 +33,8 @@ struct PairDesc {
   uint32_t n;           // columns = _size(a2, 1)
   uint32_t out;         // index into the per-pair outputs
   uint32_t flags;
+  uint64_t ckpt_off;    // wavefront checkpoints of this pair (int32 units) -- checkpointed score / band traceback
+  uint64_t lastrow_off; // {H, E} of row m per column (int32 units, 2 per column)
 };
 
 struct DpArgs {
@@ -46,6 +48,10 @@ struct DpArgs {
   int32_t* err;         // device error flags (bit 0: query-profile value does not fit int16)
   int32_t match, mismatch, go, ge;
   int32_t hfree, vfree;
+  int32_t* ckpt;        // wavefront checkpoints (score kernel writes, band traceback reads)
+  int32_t* lastrow;     // last-row {H, E} per column
+  uint64_t* band;       // band traceback: per-workgroup nibble words of the current band (ckpt_B * 64 words each)
+  uint32_t ckpt_B;      // steps between wavefront checkpoints
 };
 
 // device error flags are OR-ed (several kernels share the word)
@@ -120,9 +126,16 @@ TR_HD uint32_t a2_index(const PairDesc& d, uint32_t c /*1-based column*/) {
 // ------------------------------------------------------------------------------------------------
 // Gotoh, one pair per wave.  TRACE=true: tagged x16 arithmetic + traceback words; false: plain int32.
 // ------------------------------------------------------------------------------------------------
-template <class W, int K, int MODE, bool TRACE, bool NARROW = false>
+// wavefront checkpoint record per lane: Hl[K], El[K], bot_h, bot_f, prev_up_h (plain int32 scores)
+TR_HD constexpr uint32_t ckpt_fields(int K) { return 2u * K + 3u; }
+TR_HD uint64_t ckpt_index(uint32_t j /*1-based*/, uint32_t field, uint32_t lane, int K) {
+  return ((uint64_t)(j - 1) * ckpt_fields(K) + field) * 64u + lane;
+}
+
+template <class W, int K, int MODE, bool TRACE, bool NARROW = false, bool CKPT = false>
 TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   static_assert(!(NARROW && TRACE), "the 16-bit formulation exists for the score-only kernel");
+  static_assert(!(CKPT && TRACE), "checkpoints are written by the score-only kernel");
   const PairDesc d = a.pairs[pair_idx];
   const uint32_t L = w.lane();
   const uint32_t m = d.m, n = d.n;
@@ -157,15 +170,23 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     const uint32_t t_end = n + lanes_used - 1;
     const bool last_pass = (p + 1 == P);
 
+    // Checkpointed score pass (single pass, free end gaps on row 0): rows are anchored at the BOTTOM of the
+    // strips, so row m always sits in the last slot of the last used lane (its H is bot_h, its E is El[K-1]);
+    // the `pad` slots above row 1 hold H = E = 0 with a zero extension cost and a zero substitution
+    // score: they reproduce row 0 (H = 0) for every column and hand F = go+ge down, which makes row 1 open
+    // its vertical gap from H exactly as it does against the -inf of the reference (needs ge < 0).
+    const uint32_t pad = CKPT ? lanes_used * K - m : 0u;
     // ---- per-lane state at column 0 (gotoh.h:117-123) ----
     TraceLane<K> ts;
     ScoreLane<K> ss;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-      const uint32_t r = base + L * K + i + 1;
+      const uint32_t r = base + L * K + i + 1 - pad;  // wraps for padding slots (r - 1 >= m)
       const bool hz = hfree && (r == m);
       const int32_t h0 = edge_value(vfree, go, ge, (int32_t)r);
-      if (TRACE) {
+      if (CKPT && (L * K + i < pad)) {
+        ss.Hl[i] = 0; ss.El[i] = 0; ss.hopen[i] = go + ge; ss.hext[i] = 0;
+      } else if (TRACE) {
         ts.Hc[i] = (int32_t)((uint32_t)h0 << SH);
         ts.Ec[i] = neg;
         ts.cx1[i] = trace_cx1(hz ? 0 : go + ge);
@@ -177,7 +198,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         ss.hext[i] = hz ? 0 : ge;
       }
     }
-    const uint32_t row_above = base + L * K;
+    const uint32_t row_above = (base + L * K > pad) ? base + L * K - pad : 0u;
     int32_t prev_up_h = (row_above == 0) ? 0 : (int32_t)((uint32_t)edge_value(vfree, go, ge, (int32_t)row_above) << SH);
     int32_t bot_h = 0, bot_f = 0;
 
@@ -188,8 +209,8 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     if (MODE == MODE_CHAR) {
 #pragma unroll
       for (int i = 0; i < K; ++i) {
-        const uint32_t r = base + L * K + i + 1;
-        sub_c.rc[i] = (r <= m) ? (int32_t)a1c[r - 1] : -1;
+        const uint32_t r = base + L * K + i + 1 - pad;
+        sub_c.rc[i] = (r - 1 < m) ? (int32_t)a1c[r - 1] : -1;
       }
       sub_c.vmatch = (int32_t)((uint32_t)a.match << SH);
       sub_c.vmis = (int32_t)((uint32_t)a.mismatch << SH);
@@ -199,13 +220,13 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       bool overflow = false;
 #pragma unroll
       for (int i = 0; i < K; ++i) {
-        const uint32_t r = base + L * K + i + 1;
+        const uint32_t r = base + L * K + i + 1 - pad;
         float pr[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) pr[k] = (r <= m) ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+        for (int k = 0; k < 5; ++k) pr[k] = (r - 1 < m) ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
 #pragma unroll
         for (uint32_t b = 0; b < 5; ++b) {
-          const int32_t q = (r <= m) ? onehot_score(pr, b, fmatch, fmis) : 0;
+          const int32_t q = (r - 1 < m) ? onehot_score(pr, b, fmatch, fmis) : 0;
           const int32_t qs = (int32_t)((uint32_t)q << SH);
           overflow |= (qs > 32767) || (qs < -32768);
           qp_tab[b * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)qs;
@@ -279,12 +300,31 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
           scratch[2 * c] = bot_h;
           scratch[2 * c + 1] = bot_f;
         }
+        if (CKPT && L == lanes_used - 1) {  // {H, E} of row m (last slot of the last used lane) for the band traceback
+          int32_t* lr = a.lastrow + d.lastrow_off;
+          lr[2 * c] = NARROW ? sext16(bot_h) : bot_h;
+          lr[2 * c + 1] = NARROW ? sext16(ss.El[K - 1]) : ss.El[K - 1];
+        }
+      }
+      if (CKPT && (t % a.ckpt_B) == 0) {  // wavefront checkpoint: the whole frontier, one coalesced store per field
+        int32_t* ck = a.ckpt + d.ckpt_off;
+        const uint32_t j = t / a.ckpt_B;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          ck[ckpt_index(j, (uint32_t)i, L, K)] = NARROW ? sext16(ss.Hl[i]) : ss.Hl[i];
+          ck[ckpt_index(j, (uint32_t)(K + i), L, K)] = NARROW ? sext16(ss.El[i]) : ss.El[i];
+        }
+        ck[ckpt_index(j, 2u * K, L, K)] = NARROW ? sext16(bot_h) : bot_h;
+        ck[ckpt_index(j, 2u * K + 1, L, K)] = NARROW ? sext16(bot_f) : bot_f;
+        ck[ckpt_index(j, 2u * K + 2, L, K)] = NARROW ? sext16(prev_up_h) : prev_up_h;
       }
     }
     (void)T;
 
     // ---- score = H[m][n] (gotoh.h:173) sits in the lane / slot that owns row m ----
-    if (last_pass && a.scores) {
+    if (CKPT) {
+      if (a.scores && L == lanes_used - 1) a.scores[d.out] = NARROW ? sext16(bot_h) : bot_h;
+    } else if (last_pass && a.scores) {
       const uint32_t g = m - 1 - base;
       if (L == g / K) {
         int32_t v = 0;
@@ -355,83 +395,271 @@ TR_HD void gotoh_walk_one(const WalkArgs& a, uint32_t pair_idx) {
 
 
 // ------------------------------------------------------------------------------------------------
-// Wave-cooperative traceback walker: the same state machine (gotoh.h:143-167), but one wave per pair
-// and up to 64 cells per memory round trip.  In state 's' the walk continues diagonally while a cell
-// has neither bit3 nor bit4; in 'h' ('v') it continues left (up) until the first cell with bit1 (bit2).
-// Each lane fetches the nibble of one candidate cell of the current run, a ballot finds where the run
-// ends, and the run is emitted with one coalesced store.  W provides lane(), ballot(pred), bcast(x, l).
+// Wave-cooperative traceback walker: the state machine of gotoh.h:143-167, one wave per pair, up to 64
+// cells per memory round trip.  In state 's' the walk continues diagonally while a cell has neither bit3
+// nor bit4; in 'h' ('v') it continues left (up) until the first cell with bit1 (bit2).  Each lane fetches
+// the nibble of one candidate cell of the current run, ballots find where the run ends, and the run is
+// emitted with one coalesced store.  W provides lane(), ballot(pred), bcast(x, l).
+//
+// walk_core walks while the current cell is an interior cell whose sweep step (column + owning lane)
+// is > tmin; fetch(r, c) returns the stored nibble of an interior cell inside that range.
 // ------------------------------------------------------------------------------------------------
-template <class W>
-TR_HD void gotoh_walk_wave(W& w, const WalkArgs& a, uint32_t pair_idx) {
-  const PairDesc d = a.pairs[pair_idx];
-  const uint64_t* bits = a.bits + d.bits_off;
-  uint8_t* out = a.ops + a.ops_off[d.out];
-  const uint32_t n = d.n, lane = w.lane();
-  const int K = a.K;
-  uint32_t row = d.m, col = d.n, k = 0;
-  int state = 0;  // 0 = s, 1 = h, 2 = v
-  const uint32_t limit = d.m + d.n;
-  bool bad = false;
-  while ((row > 0 || col > 0) && k <= limit) {
-    if (row == 0) {  // first row: bit3 everywhere, bit1 nowhere -> 'h' down to column 0 (gotoh.h:112-116)
-      for (uint32_t i = lane; i < col; i += 64) out[k + i] = 'h';
-      k += col; col = 0;
-      break;
-    }
-    if (col == 0) {  // first column: bit4 only -> 'v' down to row 0 (gotoh.h:117-123)
-      if (state == 1) { bad = true; break; }
-      for (uint32_t i = lane; i < row; i += 64) out[k + i] = 'v';
-      k += row; row = 0;
-      break;
-    }
-    // candidate cell of this lane along the current run
+TR_HD uint32_t first_set(uint64_t m) {
+  uint32_t i = 0;
+  if (!m) return 64;
+  while (!((m >> i) & 1ull)) ++i;
+  return i;
+}
+
+template <class W, class Fetch>
+TR_HD void walk_core(W& w, const Fetch& fetch, uint32_t& row, uint32_t& col, int& state, uint32_t& k, uint8_t* out,
+                     uint32_t tmin, int K, uint32_t limit, uint32_t pad = 0) {
+  const uint32_t lane = w.lane();
+  while (row > 0 && col > 0 && k <= limit) {
+    if (col + cell_addr(row + pad, K).lane <= tmin) break;  // the current cell belongs to an earlier band
     const uint32_t r = (state == 1) ? row : row - lane;
     const uint32_t c = (state == 2) ? col : col - lane;
     const bool inside = (state == 1) ? (lane < col) : (state == 2) ? (lane < row) : (lane < row && lane < col);
+    const bool inband = inside && (c + cell_addr(r + pad, K).lane > tmin);
     TraceBits b = {false, false, false, false};
-    if (inside) {
-      const CellAddr ca = cell_addr(r, K);
-      const uint64_t wd = bits[word_index(ca.pass, c + ca.lane, ca.lane, n)];
-      b = decode_nibble((uint32_t)(wd >> (4u * ca.slot)) & 15u);
-    }
-    const bool stop = !inside || (state == 0 ? (b.bit3 || b.bit4) : state == 1 ? b.bit1 : b.bit2);
-    const uint64_t m = w.ballot(stop);
-    uint32_t first = 64;
-    if (m) {
-      first = 0;
-      while (!((m >> first) & 1ull)) ++first;
-    }
-    if (state == 0) {
-      // cells 0..first-1 are diagonal steps
-      if (lane < first) out[k + lane] = 's';
-      k += first; row -= first; col -= first;
-      if (first < 64 && row > 0 && col > 0) {  // the stopping cell is inside: switch matrix, no move
-        const uint32_t code = w.bcast((uint32_t)(b.bit3 ? 1 : 2), first);
-        state = (int)code;
-      }
-      // first < 64 with row == 0 or col == 0: handled by the boundary rules on the next iteration
-    } else if (state == 1) {
-      // every visited cell emits 'h'; the one with bit1 is the last of the run
-      const uint32_t inside_n = col < 64 ? col : 64;
-      const bool hit = first < inside_n;
-      const uint32_t cnt = hit ? first + 1 : inside_n;
-      if (lane < cnt) out[k + lane] = 'h';
-      k += cnt; col -= cnt;
-      if (hit) state = 0;
+    if (inband) b = decode_nibble(fetch(r, c));
+    const bool hit = inband && (state == 0 ? (b.bit3 || b.bit4) : state == 1 ? b.bit1 : b.bit2);
+    const uint32_t first_hit = first_set(w.ballot(hit));
+    const uint32_t first_out = first_set(w.ballot(!inband));
+    if (state == 0) {  // cells before the first hit / boundary are diagonal steps
+      const uint32_t x = first_hit < first_out ? first_hit : first_out;
+      if (lane < x) out[k + lane] = 's';
+      k += x; row -= x; col -= x;
+      if (first_hit < first_out) state = (int)w.bcast((uint32_t)(b.bit3 ? 1 : 2), first_hit);  // switch matrix, no move
+    } else if (state == 1) {  // every visited cell emits 'h'; the one with bit1 is the last of the run
+      const bool found = first_hit < first_out;
+      const uint32_t x = found ? first_hit + 1 : first_out;
+      if (lane < x) out[k + lane] = 'h';
+      k += x; col -= x;
+      if (found) state = 0;
     } else {
-      const uint32_t inside_n = row < 64 ? row : 64;
-      const bool hit = first < inside_n;
-      const uint32_t cnt = hit ? first + 1 : inside_n;
-      if (lane < cnt) out[k + lane] = 'v';
-      k += cnt; row -= cnt;
-      if (hit) state = 0;
-      else if (row == 0 && col > 0) { bad = true; break; }  // 'v' ran into row 0: unreachable with sane parameters
+      const bool found = first_hit < first_out;
+      const uint32_t x = found ? first_hit + 1 : first_out;
+      if (lane < x) out[k + lane] = 'v';
+      k += x; row -= x;
+      if (found) state = 0;
     }
   }
-  if (row > 0 || col > 0 || bad) {
-    if (lane == 0) flag_error(a.err, 2);
+}
+
+// first row / first column tails (gotoh.h:112-123): 'h' down to column 0, or 'v' down to row 0
+template <class W>
+TR_HD bool walk_tails(W& w, uint32_t& row, uint32_t& col, int state, uint32_t& k, uint8_t* out) {
+  const uint32_t lane = w.lane();
+  if (row == 0) {
+    if (state == 2 && col > 0) return false;  // 'v' ran into row 0: unreachable with sane parameters
+    for (uint32_t i = lane; i < col; i += 64) out[k + i] = 'h';
+    k += col; col = 0;
+  } else if (col == 0) {
+    if (state == 1) return false;
+    for (uint32_t i = lane; i < row; i += 64) out[k + i] = 'v';
+    k += row; row = 0;
   }
-  if (lane == 0) a.ops_len[d.out] = k;
+  return true;
+}
+
+struct FullMatrixFetch {
+  const uint64_t* bits;
+  uint32_t n;
+  int K;
+  TR_HD uint32_t operator()(uint32_t r, uint32_t c) const {
+    const CellAddr ca = cell_addr(r, K);
+    const uint64_t wd = bits[word_index(ca.pass, c + ca.lane, ca.lane, n)];
+    return (uint32_t)(wd >> (4u * ca.slot)) & 15u;
+  }
+};
+
+template <class W>
+TR_HD void gotoh_walk_wave(W& w, const WalkArgs& a, uint32_t pair_idx) {
+  const PairDesc d = a.pairs[pair_idx];
+  uint8_t* out = a.ops + a.ops_off[d.out];
+  uint32_t row = d.m, col = d.n, k = 0;
+  int state = 0;
+  FullMatrixFetch fetch{a.bits + d.bits_off, d.n, a.K};
+  walk_core(w, fetch, row, col, state, k, out, 0u, a.K, d.m + d.n);
+  const bool ok = walk_tails(w, row, col, state, k, out);
+  if (!ok || row > 0 || col > 0) {
+    if (w.lane() == 0) flag_error(a.err, 2);
+  }
+  if (w.lane() == 0) a.ops_len[d.out] = k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Band traceback: the traceback of a pair whose score pass left wavefront checkpoints every ckpt_B steps
+// and the {H, E} values of row m.  Instead of storing 0.5 B for every cell of the matrix, only the bands
+// of the sweep that the path actually crosses are recomputed (with the tagged traceback arithmetic) into
+// a small per-workgroup buffer and walked at once.  The recomputed nibbles are functions of exact DP
+// values restored from the checkpoints, so the emitted btr is identical to the full-matrix traceback.
+//   1. row m: the trailing run is decided from the saved {H, E}: bit3 = (H == E), bit1 = (E != Eleft + hext);
+//      as soon as the walk wants to leave row m (bit3 clear) the band machinery takes over at that cell.
+//   2. bands: restore the frontier of step j*B, sweep steps j*B+1 .. step(current cell), walk inside the band.
+// Single-pass problems (m <= 64*K) with string or query-profile scoring.
+// ------------------------------------------------------------------------------------------------
+struct BandFetch {
+  const uint64_t* band;
+  uint32_t t0;
+  int K;
+  uint32_t pad;
+  TR_HD uint32_t operator()(uint32_t r, uint32_t c) const {
+    const CellAddr ca = cell_addr(r + pad, K);
+    const uint64_t wd = band[(uint64_t)(c + ca.lane - t0 - 1u) * 64u + ca.lane];
+    return (uint32_t)(wd >> (4u * ca.slot)) & 15u;
+  }
+};
+
+template <class W, int K, int MODE>
+TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint32_t pair_idx) {
+  static_assert(MODE == MODE_CHAR || MODE == MODE_QP, "band traceback: string or query-profile scoring");
+  const PairDesc d = a.pairs[pair_idx];
+  const uint32_t L = w.lane();
+  const uint32_t m = d.m, n = d.n;
+  const int32_t go = a.go, ge = a.ge;
+  const bool hfree = a.hfree != 0, vfree = a.vfree != 0;
+  constexpr int SH = kTagShift;
+  uint8_t* out = wa.ops + wa.ops_off[d.out];
+  uint32_t row = m, col = n, k = 0;
+  int state = 0;
+  bool ok = true;
+  if (m > 0 && n > 0) {
+    const uint8_t* a1c = static_cast<const uint8_t*>(a.a1) + (MODE == MODE_CHAR ? d.a1_off : 0);
+    const float* a1p = static_cast<const float*>(a.a1) + (MODE != MODE_CHAR ? d.a1_off : 0);
+    const uint8_t* a2c = static_cast<const uint8_t*>(a.a2) + d.a2_off;
+    int16_t* qp_tab = reinterpret_cast<int16_t*>(w.lds());
+    const float fmatch = (float)a.match, fmis = (float)a.mismatch;
+    const int32_t neg = (int32_t)((uint32_t)kNegInf << SH);
+    const uint32_t lanes_used = (m + K - 1) / K;
+    const uint32_t pad = lanes_used * K - m;  // bottom-anchored rows, as in the checkpointed score pass
+    const uint32_t B = a.ckpt_B;
+    const int32_t* ck = a.ckpt + d.ckpt_off;
+    const int32_t* lr = a.lastrow + d.lastrow_off;
+    uint64_t* band = a.band + (uint64_t)pair_idx * B * 64u;
+
+    // ---- substitution set-up (as gotoh_body) ----
+    SubChar<K> sub_c;
+    SubTable<K> sub_t;
+    if (MODE == MODE_CHAR) {
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        const uint32_t r = L * K + i + 1 - pad;
+        sub_c.rc[i] = (r - 1 < m) ? (int32_t)a1c[r - 1] : -1;
+      }
+      sub_c.vmatch = (int32_t)((uint32_t)a.match << SH);
+      sub_c.vmis = (int32_t)((uint32_t)a.mismatch << SH);
+      sub_c.cc = 0;
+    } else {
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        const uint32_t r = L * K + i + 1 - pad;
+        float pr[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) pr[q] = (r - 1 < m) ? a1p[(uint64_t)q * d.a1_stride + (r - 1)] : 0.0f;
+#pragma unroll
+        for (uint32_t bb = 0; bb < 5; ++bb) {
+          const int32_t qv = (r - 1 < m) ? onehot_score(pr, bb, fmatch, fmis) : 0;
+          qp_tab[bb * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)((uint32_t)qv << SH);
+        }
+        qp_tab[5 * (64 * qp_stride(K)) + L * qp_stride(K) + i] = 0;
+      }
+      w.sync();
+    }
+
+    // ---- 1. row m from the saved {H, E} ----
+    const int32_t hextm = hfree ? 0 : ge;
+    const uint32_t limit = m + n;
+    while (col > 0 && k <= limit) {
+      if (state == 0) {
+        if (lr[2 * col] == lr[2 * col + 1]) state = 1;  // bit3: H == E (gotoh.h:135)
+        else break;
+      }
+      const bool valid = L < col;
+      const uint32_t cl = col - (valid ? L : 0);
+      const bool bit1 = valid && (cl == 1 ? true : (lr[2 * cl + 1] != lr[2 * (cl - 1) + 1] + hextm));  // gotoh.h:137
+      const uint32_t first_hit = first_set(w.ballot(bit1));
+      const uint32_t first_out = first_set(w.ballot(!valid));
+      const bool found = first_hit < first_out;
+      const uint32_t x = found ? first_hit + 1 : first_out;
+      if (L < x) out[k + L] = 'h';
+      k += x; col -= x;
+      if (found) state = 0;
+    }
+
+    // ---- 2. bands ----
+    while (row > 0 && col > 0 && k <= limit) {
+      const uint32_t t_cur = col + cell_addr(row + pad, K).lane;
+      const uint32_t j = (t_cur - 1) / B;
+      const uint32_t t0 = j * B;
+      TraceLane<K> ts;
+      int32_t bot_h, bot_f, prev_up_h;
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        const uint32_t r = L * K + i + 1 - pad;
+        const bool padding = (L * K + i < pad);
+        const bool hz = hfree && (r == m);
+        ts.cx1[i] = trace_cx1(hz ? 0 : go + ge);
+        ts.cx2[i] = trace_cx2((hz || padding) ? 0 : ge);
+        if (j == 0) {
+          ts.Hc[i] = padding ? 0 : (int32_t)((uint32_t)edge_value(vfree, go, ge, (int32_t)r) << SH);
+          ts.Ec[i] = padding ? 0 : neg;
+        } else {
+          ts.Hc[i] = (int32_t)((uint32_t)ck[ckpt_index(j, (uint32_t)i, L, K)] << SH);
+          ts.Ec[i] = (int32_t)((uint32_t)ck[ckpt_index(j, (uint32_t)(K + i), L, K)] << SH);
+        }
+      }
+      if (j == 0) {
+        const uint32_t row_above = (L * K > pad) ? L * K - pad : 0u;
+        prev_up_h = (row_above == 0) ? 0 : (int32_t)((uint32_t)edge_value(vfree, go, ge, (int32_t)row_above) << SH);
+        bot_h = 0; bot_f = 0;
+      } else {
+        bot_h = (int32_t)((uint32_t)ck[ckpt_index(j, 2u * K, L, K)] << SH);
+        bot_f = (int32_t)((uint32_t)ck[ckpt_index(j, 2u * K + 1, L, K)] << SH);
+        prev_up_h = (int32_t)((uint32_t)ck[ckpt_index(j, 2u * K + 2, L, K)] << SH);
+      }
+      for (uint32_t t = t0 + 1; t <= t_cur; ++t) {
+        const int32_t c = (int32_t)t - (int32_t)L;
+        int32_t up_h = w.shift_up(bot_h);
+        int32_t up_f = w.shift_up(bot_f);
+        uint32_t w0 = 0, w1 = 0;
+        if ((c >= 1) && (c <= (int32_t)n)) {
+          if (L == 0) {
+            up_h = (int32_t)((uint32_t)edge_value(hfree, go, ge, c) << SH);
+            up_f = neg;
+          }
+          const bool vz = vfree && (c == (int32_t)n);
+          const int32_t vopen = vz ? 0 : go + ge, vext = vz ? 0 : ge;
+          const uint32_t ci = a2_index(d, (uint32_t)c);
+          int32_t nb_h, nb_f;
+          if (MODE == MODE_CHAR) {
+            sub_c.cc = (int32_t)a2c[ci];
+            if (d.flags & PAIR_A2_REVCOMP) sub_c.cc = (int32_t)complement_char((uint8_t)sub_c.cc);
+            trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub_c, w0, w1, nb_h, nb_f);
+          } else {
+            uint32_t code = a2c[ci];
+            if (d.flags & PAIR_A2_REVCOMP) code = complement_code(code);
+            qp_load<K, false>(qp_tab, code, L, sub_t);
+            trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub_t, w0, w1, nb_h, nb_f);
+          }
+          prev_up_h = up_h;
+          bot_h = nb_h;
+          bot_f = nb_f;
+        }
+        if (L < lanes_used) band[(uint64_t)(t - t0 - 1u) * 64u + L] = ((uint64_t)w1 << 32) | w0;
+      }
+      w.sync_global();
+      BandFetch fetch{band, t0, K, pad};
+      walk_core(w, fetch, row, col, state, k, out, t0, K, limit, pad);
+      w.sync_global();
+    }
+  }
+  ok = walk_tails(w, row, col, state, k, out);
+  if (!ok || row > 0 || col > 0) {
+    if (L == 0) flag_error(wa.err, 2);
+  }
+  if (L == 0) wa.ops_len[d.out] = k;
 }
 
 // ------------------------------------------------------------------------------------------------

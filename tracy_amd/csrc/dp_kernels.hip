@@ -32,6 +32,18 @@ __global__ __launch_bounds__(64) void gotoh_kernel(DpArgs a) {
   gotoh_body<DeviceWave, K, MODE, TRACE, NARROW>(w, a, blockIdx.x);
 }
 
+// checkpointed score pass (wavefront checkpoints + last row) and the band traceback that consumes them
+template <int K, int MODE, bool NARROW>
+__global__ __launch_bounds__(64) void gotoh_ckpt_kernel(DpArgs a) {
+  DeviceWave w;
+  gotoh_body<DeviceWave, K, MODE, false, NARROW, true>(w, a, blockIdx.x);
+}
+template <int K, int MODE>
+__global__ __launch_bounds__(64) void gotoh_band_kernel(DpArgs a, WalkArgs wa) {
+  DeviceWave w;
+  gotoh_band_trace_body<DeviceWave, K, MODE>(w, a, wa, blockIdx.x);
+}
+
 template <int K, int MODE, bool TRACE>
 __global__ __launch_bounds__(64) void needle_kernel(DpArgs a) {
   DeviceWave w;
@@ -169,6 +181,44 @@ hipError_t launch_needle(int mode, int K, bool trace, const DpArgs& a, uint32_t 
     case MODE_PROF: return trace ? launch_needle_k<MODE_PROF, true>(K, a, npairs, s) : launch_needle_k<MODE_PROF, false>(K, a, npairs, s);
     default: return hipErrorInvalidValue;
   }
+}
+
+template <int MODE>
+static hipError_t launch_ckpt_m(int K, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+#define TRACY_CK(KK)                                                                                                   \
+  case KK:                                                                                                              \
+    if (narrow) hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE, true>), dim3(npairs), dim3(64), lds_bytes(MODE, KK), s, a);  \
+    else hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE, false>), dim3(npairs), dim3(64), lds_bytes(MODE, KK), s, a);        \
+    return hipGetLastError();
+  switch (K) {
+    TRACY_CK(4) TRACY_CK(8) TRACY_CK(12) TRACY_CK(15) TRACY_CK(16)
+    default: return hipErrorInvalidValue;
+  }
+#undef TRACY_CK
+}
+hipError_t launch_gotoh_ckpt(int mode, int K, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  if (npairs == 0) return hipSuccess;
+  if (mode == MODE_CHAR) return launch_ckpt_m<MODE_CHAR>(K, narrow, a, npairs, s);
+  if (mode == MODE_QP) return launch_ckpt_m<MODE_QP>(K, narrow, a, npairs, s);
+  return hipErrorInvalidValue;
+}
+template <int MODE>
+static hipError_t launch_band_m(int K, const DpArgs& a, const WalkArgs& wa, uint32_t npairs, hipStream_t s) {
+#define TRACY_BD(KK)                                                                                                   \
+  case KK:                                                                                                              \
+    hipLaunchKernelGGL((gotoh_band_kernel<KK, MODE>), dim3(npairs), dim3(64), lds_bytes(MODE, KK), s, a, wa);           \
+    return hipGetLastError();
+  switch (K) {
+    TRACY_BD(4) TRACY_BD(8) TRACY_BD(12) TRACY_BD(15) TRACY_BD(16)
+    default: return hipErrorInvalidValue;
+  }
+#undef TRACY_BD
+}
+hipError_t launch_band_trace(int mode, int K, const DpArgs& a, const WalkArgs& wa, uint32_t npairs, hipStream_t s) {
+  if (npairs == 0) return hipSuccess;
+  if (mode == MODE_CHAR) return launch_band_m<MODE_CHAR>(K, a, wa, npairs, s);
+  if (mode == MODE_QP) return launch_band_m<MODE_QP>(K, a, wa, npairs, s);
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_gotoh_walk(const WalkArgs& a, hipStream_t s) {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -161,8 +162,42 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   };
 
   // ---- 1. orientation scores: gotohScore(trim, fwd) / gotohScore(trim, rev)  (sage.h:239-240) ----
+  // When every trimmed profile fits one pass of its strip height, the score pass also leaves wavefront
+  // checkpoints and the last-row values, and stage 2 recomputes only the bands its path crosses
+  // (band traceback) instead of storing the whole traceback matrix.
   HIP_TRY(ctx->d_tmp[0].ensure(sizeof(int32_t) * 2 * (size_t)nt));
   int32_t* d_sc2 = static_cast<int32_t*>(ctx->d_tmp[0].p);
+  bool use_band = getenv("TRACYHIP_NO_BAND") == nullptr && p.ge < 0 && p.go <= 0;  // hfree = 1, vfree = 0 here
+  DpCkpt ck;
+  ck.B = 256;
+  std::vector<uint64_t> ck_off(2 * (size_t)nt), lr_off(2 * (size_t)nt);
+  {
+    uint64_t ck_tot = 0, lr_tot = 0;
+    for (uint32_t t = 0; t < nt && use_band; ++t) {
+      const int K = choose_k(mt[t], MODE_QP);
+      if (mt[t] == 0 || rn[t] == 0 || num_passes(mt[t], K) != 1) { use_band = false; break; }
+      const uint32_t lanes_used = (mt[t] + K - 1) / K;
+      const uint64_t J = ((uint64_t)rn[t] + lanes_used - 1) / ck.B;
+      for (int o = 0; o < 2; ++o) {
+        ck_off[(size_t)o * nt + t] = ck_tot;
+        lr_off[(size_t)o * nt + t] = lr_tot;
+        ck_tot += J * ckpt_fields(K) * 64;
+        lr_tot += 2ull * ((uint64_t)rn[t] + 1);
+      }
+    }
+    if (use_band) {
+      size_t fr = 0, tot = 0;
+      HIP_TRY(hipMemGetInfo(&fr, &tot));
+      const uint64_t need = (ck_tot + lr_tot) * 4 + (uint64_t)nt * ck.B * 64 * 8;
+      if (need > (uint64_t)(fr * 0.8) + ctx->d_ckpt.cap + ctx->d_lastrow.cap + ctx->d_band.cap) use_band = false;
+      else {
+        HIP_TRY(ctx->d_ckpt.ensure(ck_tot * 4 + 64));
+        HIP_TRY(ctx->d_lastrow.ensure(lr_tot * 4 + 64));
+        ck.d_ckpt = static_cast<int32_t*>(ctx->d_ckpt.p);
+        ck.d_lastrow = static_cast<int32_t*>(ctx->d_lastrow.p);
+      }
+    }
+  }
   {
     DpProblem pb;
     pb.mode = MODE_QP;
@@ -180,13 +215,17 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
       d.n = rn[t];
       d.a2_stride = rn[t];
       d.out = t;
+      d.ckpt_off = ck_off[t];
+      d.lastrow_off = lr_off[t];
       pb.desc[t] = d;
       d.out = nt + t;
       d.flags = PAIR_A2_REVCOMP;
+      d.ckpt_off = ck_off[(size_t)nt + t];
+      d.lastrow_off = lr_off[(size_t)nt + t];
       pb.desc[nt + t] = d;
       pb.k[t] = pb.k[nt + t] = choose_k(d.m, MODE_QP);
     }
-    if ((rc = run_dp(ctx, pb, &p, false, false, d_sc2, nullptr, nullptr, nullptr))) return rc;
+    if ((rc = run_dp(ctx, pb, &p, false, false, d_sc2, nullptr, nullptr, nullptr, use_band ? DP_CKPT : DP_PLAIN, use_band ? &ck : nullptr))) return rc;
   }
   std::vector<int32_t> h_sc2(2 * (size_t)nt);
   HIP_TRY(hipMemcpyAsync(h_sc2.data(), d_sc2, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
@@ -223,11 +262,22 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
       d.a2_stride = rn[t];
       d.out = t;
       d.flags = h_fwd[t] ? 0 : PAIR_A2_REVCOMP;
+      const size_t o = h_fwd[t] ? t : (size_t)nt + t;  // the winning orientation's checkpoints
+      d.ckpt_off = ck_off[o];
+      d.lastrow_off = lr_off[o];
       pb.desc[t] = d;
       pb.k[t] = choose_k(d.m, MODE_QP);
     }
-    if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(ctx->d_tmp[4].p), static_cast<uint8_t*>(ctx->d_tmp[1].p),
-                     static_cast<const uint64_t*>(ctx->d_tmp[2].p), static_cast<uint32_t*>(ctx->d_tmp[3].p))))
+    if (use_band) {
+      // the preliminary score equals the winning orientation score (same DP): no score array needed from the band pass
+      if ((rc = run_dp(ctx, pb, &p, false, true, nullptr, static_cast<uint8_t*>(ctx->d_tmp[1].p),
+                       static_cast<const uint64_t*>(ctx->d_tmp[2].p), static_cast<uint32_t*>(ctx->d_tmp[3].p), DP_BAND, &ck)))
+        return rc;
+      std::vector<int32_t> h_pre(nt);
+      for (uint32_t t = 0; t < nt; ++t) h_pre[t] = h_fwd[t] ? h_sc2[t] : h_sc2[nt + t];
+      HIP_TRY(hipMemcpy(ctx->d_tmp[4].p, h_pre.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice));
+    } else if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(ctx->d_tmp[4].p), static_cast<uint8_t*>(ctx->d_tmp[1].p),
+                            static_cast<const uint64_t*>(ctx->d_tmp[2].p), static_cast<uint32_t*>(ctx->d_tmp[3].p))))
       return rc;
   }
 

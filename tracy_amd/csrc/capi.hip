@@ -197,18 +197,21 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   // order: strip height, then longest first (long problems start early, short ones fill the tail)
   std::vector<uint32_t> order(np);
   for (uint32_t i = 0; i < np; ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+  auto before = [&](uint32_t x, uint32_t y) {
     if (pb.k[x] != pb.k[y]) return pb.k[x] > pb.k[y];
     return (uint64_t)pb.desc[x].m * pb.desc[x].n > (uint64_t)pb.desc[y].m * pb.desc[y].n;
-  });
+  };
+  if (!std::is_sorted(order.begin(), order.end(), before)) std::stable_sort(order.begin(), order.end(), before);
 
   // workspace plan: chunks of consecutive (sorted) pairs whose traceback words fit the limit
   const uint64_t word_bytes = needle ? 4 : 8;
   uint64_t limit = ctx->ws_limit;
-  if (limit == 0) {
+  if (limit == 0 && trace && stage == DP_PLAIN) {  // only the full-matrix traceback needs a workspace plan
     size_t fr = 0, tot = 0;
     HIP_TRY(hipMemGetInfo(&fr, &tot));
-    limit = (uint64_t)(fr * 0.70);
+    limit = (uint64_t)(fr * 0.70) + ctx->d_bits.cap;  // what is free now plus what this context already holds
+  } else if (limit == 0) {
+    limit = ~0ull;
   }
   HIP_TRY(ctx->h_desc.ensure(sizeof(PairDesc) * (size_t)np));
   PairDesc* hd = static_cast<PairDesc*>(ctx->h_desc.p);

@@ -5,10 +5,19 @@
 // touches its own pair's inputs and traceback stripe).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "dp_kernels.h"
 #include "launch.h"
 
 namespace tracyhip {
+
+// development knob: extra dynamic LDS per workgroup (bytes) to study occupancy sensitivity
+static uint32_t lds_pad() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TRACYHIP_LDS_PAD"); v = e ? atoi(e) : 0; }
+  return (uint32_t)v;
+}
 
 struct DeviceWave {
   __device__ __forceinline__ uint32_t lane() const { return threadIdx.x; }
@@ -187,7 +196,7 @@ template <int MODE>
 static hipError_t launch_ckpt_m(int K, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s) {
 #define TRACY_CK(KK)                                                                                                   \
   case KK:                                                                                                              \
-    if (narrow) hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE, true>), dim3(npairs), dim3(64), lds_bytes(MODE, KK), s, a);  \
+    if (narrow) hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE, true>), dim3(npairs), dim3(64), lds_bytes(MODE, KK) + lds_pad(), s, a);  \
     else hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE, false>), dim3(npairs), dim3(64), lds_bytes(MODE, KK), s, a);        \
     return hipGetLastError();
   switch (K) {

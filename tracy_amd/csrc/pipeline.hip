@@ -34,29 +34,56 @@ struct TrimOut {
 // trimReferenceSlice (fmindex.h:429-463) evaluated directly on the traceback string.  ops are in push
 // order (end -> start); alignment column j (forward) is ops[L-1-j].  Row 0 holds a trace base unless
 // the op is 'h', row 1 holds a reference base unless the op is 'v' (align.h:204-214).
+// The reference scans for s = first column with a trace base and e = last such column + 1, then counts
+// reference bases before s (ri) and inside [s, e) (risize).  Every column before s and from e on is an
+// 'h' (a reference base), and the alignment consumes all n reference bases, so ri = s and
+// risize = n - s - (L - e): only the two ends of the string have to be looked at.  One wave per trace.
 __global__ __launch_bounds__(64) void trim_kernel(const uint8_t* __restrict__ ops, const uint64_t* __restrict__ ops_off,
                                                   const uint32_t* __restrict__ ops_len, const uint32_t* __restrict__ ref_len,
                                                   const uint8_t* __restrict__ forward, uint32_t trim_left,
                                                   uint32_t trim_right, uint32_t ntraces, TrimOut* __restrict__ out) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = blockIdx.x;
   if (t >= ntraces) return;
   const uint8_t* o = ops + ops_off[t];
   const uint32_t L = ops_len[t];
-  uint32_t ri = 0;
+  const uint32_t lane = threadIdx.x;
+  // s: first forward column that is not 'h'  <=>  scanning the push-order string from its end
   int32_t s = -1, e = -1;
-  for (uint32_t j = 0; j < L; ++j) {
-    const uint8_t op = o[L - 1 - j];
-    if (op != 'h') {
-      if (s == -1) s = (int32_t)j;
-      e = (int32_t)j + 1;
-    }
-    if ((s == -1) && (op != 'v')) ++ri;
+  for (uint32_t base = 0; base < L; base += 64) {
+    const uint32_t j = base + lane;
+    const bool hit = (j < L) && (o[L - 1 - j] != 'h');
+    const unsigned long long m = __ballot(hit);
+    if (m) { s = (int32_t)(base + (uint32_t)__builtin_ctzll(m)); break; }
   }
-  uint32_t risize = 0;
-  for (int32_t j = s; j < e; ++j)
-    if (o[L - 1 - j] != 'v') ++risize;
-  if (ri >= trim_left) { ri -= trim_left; risize += trim_left; }
+  if (s >= 0) {  // e: last forward column that is not 'h', + 1  <=>  scanning the push-order string from its start
+    for (uint32_t base = 0; base < L; base += 64) {
+      const uint32_t q = base + lane;  // push-order index q <-> forward column L-1-q
+      const bool hit = (q < L) && (o[q] != 'h');
+      const unsigned long long m = __ballot(hit);
+      if (m) { e = (int32_t)(L - (base + (uint32_t)__builtin_ctzll(m))); break; }
+    }
+  }
+  if (lane != 0) return;
   const uint32_t n = ref_len[t];
+  uint32_t ri, risize;
+  if (s < 0) {  // no trace base at all: every column counts towards ri (fmindex.h:435-441), the span is empty
+    uint32_t cnt = 0;
+    for (uint32_t j = 0; j < L; ++j) cnt += (o[j] != 'v');
+    ri = cnt;
+    risize = 0;
+  } else {
+    ri = (uint32_t)s;
+    // reference bases inside [s, e): all n bases minus the leading s columns and the trailing L - e columns
+    uint32_t inside = 0;
+    const uint32_t lead = (uint32_t)s, trail = L - (uint32_t)e;
+    // columns before s and from e on are 'h' only when the string really is a complete alignment; count exactly
+    // when the totals do not add up (defensive: degenerate inputs)
+    uint32_t refcols = 0;
+    if (lead + trail <= n) inside = n - lead - trail;
+    else { for (int32_t j = s; j < e; ++j) refcols += (o[L - 1 - j] != 'v'); inside = refcols; }
+    risize = inside;
+  }
+  if (ri >= trim_left) { ri -= trim_left; risize += trim_left; }
   if ((uint32_t)(ri + risize + trim_right) < n) risize += trim_right;
   TrimOut r;
   r.ri = ri;
@@ -292,7 +319,7 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
     std::memcpy(hp + sizeof(uint32_t) * (size_t)nt, h_fwd.data(), nt);
     HIP_TRY(hipMemcpyAsync(d_rn, hp, sizeof(uint32_t) * (size_t)nt + nt, hipMemcpyHostToDevice, st));
   }
-  hipLaunchKernelGGL(trim_kernel, dim3((nt + 63) / 64), dim3(64), 0, st, static_cast<const uint8_t*>(ctx->d_tmp[1].p),
+  hipLaunchKernelGGL(trim_kernel, dim3(nt), dim3(64), 0, st, static_cast<const uint8_t*>(ctx->d_tmp[1].p),
                      static_cast<const uint64_t*>(ctx->d_tmp[2].p), static_cast<const uint32_t*>(ctx->d_tmp[3].p), d_rn, d_fwd,
                      job->trim_left, job->trim_right, nt, static_cast<TrimOut*>(ctx->d_tmp[5].p));
   HIP_TRY(hipGetLastError());
@@ -683,7 +710,7 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
       pb.k[t] = choose_k(d.m, MODE_CHAR);
     }
     if ((rc = run_dp(ctx, pb, &p, false, true, nullptr, static_cast<uint8_t*>(b_opsA.p), d_offA, static_cast<uint32_t*>(b_lenA.p)))) return rc;
-    hipLaunchKernelGGL(trim_kernel, dim3((nt + 63) / 64), dim3(64), 0, st, static_cast<const uint8_t*>(b_opsA.p), d_offA,
+    hipLaunchKernelGGL(trim_kernel, dim3(nt), dim3(64), 0, st, static_cast<const uint8_t*>(b_opsA.p), d_offA,
                        static_cast<const uint32_t*>(b_lenA.p), static_cast<const uint32_t*>(b_rnfw.p),
                        reinterpret_cast<const uint8_t*>(static_cast<const uint32_t*>(b_rnfw.p) + nt), TL, TR, nt,
                        static_cast<TrimOut*>(b_trimA.p));

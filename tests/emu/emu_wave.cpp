@@ -118,7 +118,7 @@ int emu_band(int mode, int K, int narrow, uint32_t B, const void* a1, uint32_t m
   DpArgs a{};
   a.pairs = &d; a.a1 = a1; a.a2 = a2; a.scores = score; a.err = &err;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = hfree; a.vfree = vfree;
-  a.ckpt = ckpt.data(); a.lastrow = lastrow.data(); a.band = band.data(); a.ckpt_B = B;
+  a.ckpt = ckpt.data(); a.lastrow = lastrow.data(); a.band = band.data(); a.ckpt_B = B; a.ckpt_narrow = narrow ? 1 : 0;
   uint64_t off = 0;
   WalkArgs wa{};
   wa.pairs = &d; wa.ops = ops; wa.ops_off = &off; wa.ops_len = ops_len; wa.err = &err; wa.npairs = 1; wa.K = K;

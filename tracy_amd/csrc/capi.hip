@@ -189,7 +189,7 @@ bool narrow_ok(const tracyhip_params* prm, uint32_t maxm, int K) {
 }
 
 int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, bool needle, bool trace,
-           int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len, int stage, const DpCkpt* ck) {
+           int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len, int stage, DpCkpt* ck) {
   const uint32_t np = (uint32_t)pb.desc.size();
   if (np == 0) return TRACYHIP_OK;
   hipStream_t st = ctx->stream;
@@ -265,7 +265,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   a.err = static_cast<int32_t*>(ctx->d_err.p);
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge;
   a.hfree = prm->hfree; a.vfree = prm->vfree;
-  if (ck) { a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.band = static_cast<uint64_t*>(ctx->d_band.p); }
+  if (ck) { a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.band = static_cast<uint64_t*>(ctx->d_band.p); a.ckpt_narrow = ck->narrow ? 1 : 0; }
   const PairDesc* dd = static_cast<const PairDesc*>(ctx->d_desc.p);
 
   for (const Chunk& c : chunks) {
@@ -293,7 +293,11 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
         for (uint32_t q = j; q < e; ++q) maxm = std::max(maxm, hd[q].m);
         narrow = narrow_ok(prm, maxm, K);
       }
-      if (stage == DP_CKPT) HIP_TRY(launch_gotoh_ckpt(pb.mode, K, narrow, a, e - j, st));
+      if (stage == DP_CKPT) {
+        // one representation for the whole batch: the caller checks narrow_ok for the largest problem
+        narrow = ck->narrow;
+        HIP_TRY(launch_gotoh_ckpt(pb.mode, K, narrow, a, e - j, st));
+      }
       else if (stage == DP_BAND) {
         WalkArgs wa{};
         wa.pairs = dd + j; wa.ops = d_ops; wa.ops_off = d_ops_off; wa.ops_len = d_ops_len; wa.err = a.err; wa.npairs = e - j; wa.K = K;

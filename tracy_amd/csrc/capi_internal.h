@@ -87,10 +87,11 @@ struct DpCkpt {
   int32_t* d_ckpt = nullptr;
   int32_t* d_lastrow = nullptr;
   uint32_t B = 256;
+  bool narrow = false;  // set by the DP_CKPT stage (16-bit kernel used), read by the DP_BAND stage
 };
 int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, bool needle, bool trace,
            int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len, int stage = DP_PLAIN,
-           const DpCkpt* ck = nullptr);
+           DpCkpt* ck = nullptr);
 bool narrow_ok(const tracyhip_params* prm, uint32_t maxm, int K);
 int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool needle, DpProblem& pb, uint64_t* max_mn);
 }  // namespace tracyhip

@@ -52,6 +52,7 @@ struct DpArgs {
   int32_t* lastrow;     // last-row {H, E} per column
   uint64_t* band;       // band traceback: per-workgroup nibble words of the current band (ckpt_B * 64 words each)
   uint32_t ckpt_B;      // steps between wavefront checkpoints
+  int32_t ckpt_narrow;  // checkpoints hold raw registers of the 16-bit kernel (values in the low halves)
 };
 
 // device error flags are OR-ed (several kernels share the word)
@@ -88,7 +89,8 @@ TR_HD constexpr int qp_stride(int K) { return (K + 1) & ~1; }
 template <int K, bool NARROW = false>
 TR_HD void qp_load(const int16_t* tab, uint32_t code, uint32_t lane, SubTable<K>& s) {
   constexpr int KP = qp_stride(K);
-  const uint32_t row = (code < 5u ? code : 5u) * (64u * KP) + lane * KP;
+  // codes 5 ('-') and 6 (other) score 0 against every row: one shared zero strip after the five code rows
+  const uint32_t row = (code < 5u) ? code * (64u * KP) + lane * KP : 5u * (64u * KP);
   const uint32_t* p = reinterpret_cast<const uint32_t*>(tab + row);
 #pragma unroll
   for (int j = 0; j < KP / 2; ++j) {
@@ -96,6 +98,25 @@ TR_HD void qp_load(const int16_t* tab, uint32_t code, uint32_t lane, SubTable<K>
     s.sv[2 * j] = NARROW ? (int32_t)w : (int32_t)(int16_t)(w & 0xffffu);  // 16-bit consumers read the low half only
     if (2 * j + 1 < K) s.sv[2 * j + 1] = ((int32_t)w) >> 16;
   }
+}
+
+// packed strip: the K int16 query-profile values of a lane for one column, as loaded from LDS (ping-pong
+// buffers hold the strips of the current and the next column)
+template <int K>
+struct SubPacked {
+  uint32_t pw[(K + 1) / 2];
+  TR_HD int32_t operator()(int i) const {
+    return (i & 1) ? ((int32_t)pw[i / 2] >> 16) : (int32_t)(int16_t)(pw[i / 2] & 0xffffu);
+  }
+  TR_HD int32_t lo16(int i) const { return (i & 1) ? ((int32_t)pw[i / 2] >> 16) : (int32_t)pw[i / 2]; }
+};
+template <int K>
+TR_HD void qp_fetch(const int16_t* tab, uint32_t code, uint32_t lane, SubPacked<K>& q) {
+  constexpr int KP = qp_stride(K);
+  const uint32_t row = (code < 5u) ? code * (64u * KP) + lane * KP : 5u * (64u * KP);
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(tab + row);
+#pragma unroll
+  for (int j = 0; j < KP / 2; ++j) q.pw[j] = p[j];
 }
 
 template <int K>
@@ -116,7 +137,7 @@ struct SubProf {
 
 // LDS bytes a (mode, K) kernel needs
 TR_HD constexpr uint32_t lds_bytes(int mode, int K) {
-  return mode == MODE_QP ? 6u * 64u * (uint32_t)qp_stride(K) * 2u : mode == MODE_PROF ? 5u * 64u * K * 4u : 0u;
+  return mode == MODE_QP ? (5u * 64u + 1u) * (uint32_t)qp_stride(K) * 2u : mode == MODE_PROF ? 5u * 64u * K * 4u : 0u;
 }
 
 TR_HD uint32_t a2_index(const PairDesc& d, uint32_t c /*1-based column*/) {
@@ -218,8 +239,8 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     } else if (MODE == MODE_QP) {
       w.sync();  // previous pass may still be reading the table
       bool overflow = false;
-#pragma unroll
-      for (int i = 0; i < K; ++i) {
+#pragma unroll 1
+      for (int i = 0; i < K; ++i) {  // not unrolled: the set-up must not dictate the kernel's register budget
         const uint32_t r = base + L * K + i + 1 - pad;
         float pr[5];
 #pragma unroll
@@ -231,8 +252,8 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
           overflow |= (qs > 32767) || (qs < -32768);
           qp_tab[b * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)qs;
         }
-        qp_tab[5 * (64 * qp_stride(K)) + L * qp_stride(K) + i] = 0;
       }
+      if (L < (uint32_t)qp_stride(K)) qp_tab[5 * (64 * qp_stride(K)) + L] = 0;
       if (overflow) flag_error(a.err, 1);
       w.sync();
     } else {
@@ -253,7 +274,16 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     }
 
     // ---- anti-diagonal sweep ----
-    for (uint32_t t = 1; t <= t_end; ++t) {
+    // One step = one column of this lane's strip.  The per-column inputs are fetched ahead of use so that
+    // their latency overlaps the K-cell compute of earlier steps instead of stalling the wave: the
+    // reference code two steps ahead (it selects the LDS row), the LDS strip one step ahead into the other
+    // half of a ping-pong pair (the loop is unrolled by two so no register copies are needed).
+    auto col_at = [&](int32_t cc) -> uint32_t {  // clamp: prefetches of idle lanes stay in bounds
+      const int32_t x = cc < 1 ? 1 : (cc > (int32_t)n ? (int32_t)n : cc);
+      return a2_index(d, (uint32_t)x);
+    };
+    const bool rcflag = (d.flags & PAIR_A2_REVCOMP) != 0;
+    auto do_step = [&](uint32_t t, const auto& sub) {
       const int32_t c = (int32_t)t - (int32_t)L;
       int32_t up_h = w.shift_up(bot_h);
       int32_t up_f = w.shift_up(bot_f);
@@ -270,28 +300,11 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         }
         const bool vz = vfree && (c == (int32_t)n);
         const int32_t vopen = vz ? 0 : go + ge, vext = vz ? 0 : ge;
-        const uint32_t ci = a2_index(d, (uint32_t)c);
         int32_t nb_h, nb_f;
         uint32_t w0 = 0, w1 = 0;
-        if (MODE == MODE_CHAR) {
-          sub_c.cc = (int32_t)a2c[ci];
-          if (d.flags & PAIR_A2_REVCOMP) sub_c.cc = (int32_t)complement_char((uint8_t)sub_c.cc);
-          if (TRACE) trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub_c, w0, w1, nb_h, nb_f);
-          else if (NARROW) score_step16<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub_c, nb_h, nb_f);
-          else score_step<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub_c, nb_h, nb_f);
-        } else if (MODE == MODE_QP) {
-          uint32_t code = a2c[ci];  // MODE_QP: a2 holds profile-row codes (encode_kernel), not characters
-          if (d.flags & PAIR_A2_REVCOMP) code = complement_code(code);
-          qp_load<K, NARROW>(qp_tab, code, L, sub_t);
-          if (TRACE) trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub_t, w0, w1, nb_h, nb_f);
-          else if (NARROW) score_step16<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub_t, nb_h, nb_f);
-          else score_step<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub_t, nb_h, nb_f);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 5; ++k) sub_p.b[k] = a2p[(uint64_t)k * d.a2_stride + ci];
-          if (TRACE) trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub_p, w0, w1, nb_h, nb_f);
-          else score_step<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub_p, nb_h, nb_f);
-        }
+        if (TRACE) trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub, w0, w1, nb_h, nb_f);
+        else if (NARROW) score_step16<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub, nb_h, nb_f);
+        else score_step<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub, nb_h, nb_f);
         prev_up_h = up_h;
         bot_h = nb_h;
         bot_f = nb_f;
@@ -307,16 +320,56 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         }
       }
       if (CKPT && (t % a.ckpt_B) == 0) {  // wavefront checkpoint: the whole frontier, one coalesced store per field
-        int32_t* ck = a.ckpt + d.ckpt_off;
-        const uint32_t j = t / a.ckpt_B;
+        // raw registers are stored (the 16-bit kernel keeps its values in the low halves; the band traceback
+        // sign-extends them on restore, DpArgs::ckpt_narrow)
+        int32_t* ck = a.ckpt + d.ckpt_off + (uint64_t)(t / a.ckpt_B - 1) * (ckpt_fields(K) * 64u) + L;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-          ck[ckpt_index(j, (uint32_t)i, L, K)] = NARROW ? sext16(ss.Hl[i]) : ss.Hl[i];
-          ck[ckpt_index(j, (uint32_t)(K + i), L, K)] = NARROW ? sext16(ss.El[i]) : ss.El[i];
+          ck[(uint32_t)i * 64u] = ss.Hl[i];
+          ck[(uint32_t)(K + i) * 64u] = ss.El[i];
         }
-        ck[ckpt_index(j, 2u * K, L, K)] = NARROW ? sext16(bot_h) : bot_h;
-        ck[ckpt_index(j, 2u * K + 1, L, K)] = NARROW ? sext16(bot_f) : bot_f;
-        ck[ckpt_index(j, 2u * K + 2, L, K)] = NARROW ? sext16(prev_up_h) : prev_up_h;
+        ck[(2u * K) * 64u] = bot_h;
+        ck[(2u * K + 1) * 64u] = bot_f;
+        ck[(2u * K + 2) * 64u] = prev_up_h;
+      }
+    };
+    if (MODE == MODE_QP) {
+      SubPacked<K> qa, qb;
+      const int32_t c1 = 1 - (int32_t)L;
+      uint32_t raw_next;
+      {
+        const uint32_t raw1 = a2c[col_at(c1)];
+        raw_next = a2c[col_at(c1 + 1)];
+        qp_fetch<K>(qp_tab, rcflag ? complement_code(raw1) : raw1, L, qa);
+      }
+      for (uint32_t t = 1; t <= t_end; t += 2) {
+        {
+          const uint32_t raw_nn = a2c[col_at((int32_t)t - (int32_t)L + 2)];
+          qp_fetch<K>(qp_tab, rcflag ? complement_code(raw_next) : raw_next, L, qb);
+          do_step(t, qa);
+          raw_next = raw_nn;
+        }
+        if (t + 1 > t_end) break;
+        {
+          const uint32_t raw_nn = a2c[col_at((int32_t)t - (int32_t)L + 3)];
+          qp_fetch<K>(qp_tab, rcflag ? complement_code(raw_next) : raw_next, L, qa);
+          do_step(t + 1, qb);
+          raw_next = raw_nn;
+        }
+      }
+    } else if (MODE == MODE_CHAR) {
+      int32_t cc_next = (int32_t)a2c[col_at(1 - (int32_t)L)];
+      for (uint32_t t = 1; t <= t_end; ++t) {
+        sub_c.cc = rcflag ? (int32_t)complement_char((uint8_t)cc_next) : cc_next;
+        cc_next = (int32_t)a2c[col_at((int32_t)t - (int32_t)L + 1)];
+        do_step(t, sub_c);
+      }
+    } else {
+      for (uint32_t t = 1; t <= t_end; ++t) {
+        const uint32_t ci = col_at((int32_t)t - (int32_t)L);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) sub_p.b[k] = a2p[(uint64_t)k * d.a2_stride + ci];
+        do_step(t, sub_p);
       }
     }
     (void)T;
@@ -552,7 +605,7 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
       sub_c.vmis = (int32_t)((uint32_t)a.mismatch << SH);
       sub_c.cc = 0;
     } else {
-#pragma unroll
+#pragma unroll 1
       for (int i = 0; i < K; ++i) {
         const uint32_t r = L * K + i + 1 - pad;
         float pr[5];
@@ -563,8 +616,8 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
           const int32_t qv = (r - 1 < m) ? onehot_score(pr, bb, fmatch, fmis) : 0;
           qp_tab[bb * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)((uint32_t)qv << SH);
         }
-        qp_tab[5 * (64 * qp_stride(K)) + L * qp_stride(K) + i] = 0;
       }
+      if (L < (uint32_t)qp_stride(K)) qp_tab[5 * (64 * qp_stride(K)) + L] = 0;
       w.sync();
     }
 
@@ -606,8 +659,9 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
           ts.Hc[i] = padding ? 0 : (int32_t)((uint32_t)edge_value(vfree, go, ge, (int32_t)r) << SH);
           ts.Ec[i] = padding ? 0 : neg;
         } else {
-          ts.Hc[i] = (int32_t)((uint32_t)ck[ckpt_index(j, (uint32_t)i, L, K)] << SH);
-          ts.Ec[i] = (int32_t)((uint32_t)ck[ckpt_index(j, (uint32_t)(K + i), L, K)] << SH);
+          const int32_t hv = ck[ckpt_index(j, (uint32_t)i, L, K)], ev = ck[ckpt_index(j, (uint32_t)(K + i), L, K)];
+          ts.Hc[i] = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(hv) : hv) << SH);
+          ts.Ec[i] = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(ev) : ev) << SH);
         }
       }
       if (j == 0) {
@@ -615,9 +669,11 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
         prev_up_h = (row_above == 0) ? 0 : (int32_t)((uint32_t)edge_value(vfree, go, ge, (int32_t)row_above) << SH);
         bot_h = 0; bot_f = 0;
       } else {
-        bot_h = (int32_t)((uint32_t)ck[ckpt_index(j, 2u * K, L, K)] << SH);
-        bot_f = (int32_t)((uint32_t)ck[ckpt_index(j, 2u * K + 1, L, K)] << SH);
-        prev_up_h = (int32_t)((uint32_t)ck[ckpt_index(j, 2u * K + 2, L, K)] << SH);
+        const int32_t bh = ck[ckpt_index(j, 2u * K, L, K)], bf = ck[ckpt_index(j, 2u * K + 1, L, K)];
+        const int32_t pu = ck[ckpt_index(j, 2u * K + 2, L, K)];
+        bot_h = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(bh) : bh) << SH);
+        bot_f = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(bf) : bf) << SH);
+        prev_up_h = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(pu) : pu) << SH);
       }
       for (uint32_t t = t0 + 1; t <= t_cur; ++t) {
         const int32_t c = (int32_t)t - (int32_t)L;

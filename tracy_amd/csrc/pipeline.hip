@@ -220,6 +220,9 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
       else {
         HIP_TRY(ctx->d_ckpt.ensure(ck_tot * 4 + 64));
         HIP_TRY(ctx->d_lastrow.ensure(lr_tot * 4 + 64));
+        uint32_t maxmt = 0;
+        for (uint32_t t = 0; t < nt; ++t) maxmt = std::max(maxmt, mt[t]);
+        ck.narrow = !ctx->no_narrow && narrow_ok(&p, maxmt, 16);  // conservative: the tallest strip
         ck.d_ckpt = static_cast<int32_t*>(ctx->d_ckpt.p);
         ck.d_lastrow = static_cast<int32_t*>(ctx->d_lastrow.p);
       }

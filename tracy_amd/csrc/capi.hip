@@ -180,7 +180,8 @@ int check_params(const tracyhip_params* prm, uint64_t max_mn) {
 // ---- the DP driver shared by gotoh/needle score/align -----------------------------------------------
 // 16-bit score kernel: every real DP value must fit int16 with room below for the sentinel
 bool narrow_ok(const tracyhip_params* prm, uint32_t maxm, int K) {
-  if (!prm->hfree || prm->go > 0 || prm->ge > 0) return false;
+  // free end gaps on the first/last row only, strictly negative extension, one pass of the strip height
+  if (!prm->hfree || prm->vfree || prm->go > 0 || prm->ge >= 0 || num_passes(maxm ? maxm : 1, K) != 1) return false;
   auto ab = [](int32_t x) { return (int64_t)(x < 0 ? -(int64_t)x : x); };
   const int64_t rows = (int64_t)num_passes(maxm ? maxm : 1, K) * 64 * K;
   const int64_t low = ab(prm->go) + rows * ab(prm->ge) + 2 * (ab(prm->go) + ab(prm->ge)) + ab(prm->mismatch) + ab(prm->match);

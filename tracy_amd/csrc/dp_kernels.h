@@ -157,6 +157,8 @@ template <class W, int K, int MODE, bool TRACE, bool NARROW = false, bool CKPT =
 TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   static_assert(!(NARROW && TRACE), "the 16-bit formulation exists for the score-only kernel");
   static_assert(!(CKPT && TRACE), "checkpoints are written by the score-only kernel");
+  // NARROW / CKPT kernels: single pass, free end gaps on the first/last row only, rows anchored at the bottom
+  constexpr bool BOTTOM = NARROW || CKPT;
   const PairDesc d = a.pairs[pair_idx];
   const uint32_t L = w.lane();
   const uint32_t m = d.m, n = d.n;
@@ -196,7 +198,9 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     // the `pad` slots above row 1 hold H = E = 0 with a zero extension cost and a zero substitution
     // score: they reproduce row 0 (H = 0) for every column and hand F = go+ge down, which makes row 1 open
     // its vertical gap from H exactly as it does against the -inf of the reference (needs ge < 0).
-    const uint32_t pad = CKPT ? lanes_used * K - m : 0u;
+    const uint32_t pad = BOTTOM ? lanes_used * K - m : 0u;
+    const int32_t goe = go + ge;
+    const int32_t goe_n = NARROW ? goe : 0;  // the 16-bit kernel keeps Hg = H + (go+ge) (score_step16g)
     // ---- per-lane state at column 0 (gotoh.h:117-123) ----
     TraceLane<K> ts;
     ScoreLane<K> ss;
@@ -205,22 +209,23 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       const uint32_t r = base + L * K + i + 1 - pad;  // wraps for padding slots (r - 1 >= m)
       const bool hz = hfree && (r == m);
       const int32_t h0 = edge_value(vfree, go, ge, (int32_t)r);
-      if (CKPT && (L * K + i < pad)) {
-        ss.Hl[i] = 0; ss.El[i] = 0; ss.hopen[i] = go + ge; ss.hext[i] = 0;
+      if (BOTTOM && (L * K + i < pad)) {
+        ss.Hl[i] = goe_n; ss.El[i] = 0; ss.hopen[i] = go + ge; ss.hext[i] = 0;
       } else if (TRACE) {
         ts.Hc[i] = (int32_t)((uint32_t)h0 << SH);
         ts.Ec[i] = neg;
         ts.cx1[i] = trace_cx1(hz ? 0 : go + ge);
         ts.cx2[i] = trace_cx2(hz ? 0 : ge);
       } else {
-        ss.Hl[i] = h0;
+        ss.Hl[i] = h0 + goe_n;
         ss.El[i] = neg;
         ss.hopen[i] = hz ? 0 : go + ge;
         ss.hext[i] = hz ? 0 : ge;
       }
     }
     const uint32_t row_above = (base + L * K > pad) ? base + L * K - pad : 0u;
-    int32_t prev_up_h = (row_above == 0) ? 0 : (int32_t)((uint32_t)edge_value(vfree, go, ge, (int32_t)row_above) << SH);
+    int32_t prev_up_h = ((row_above == 0) ? 0 : (int32_t)((uint32_t)edge_value(vfree, go, ge, (int32_t)row_above) << SH)) + goe_n;
+    const int32_t delta_last = (NARROW && hfree && L == lanes_used - 1) ? -goe : 0;  // row m: horizontal open costs 0
     int32_t bot_h = 0, bot_f = 0;
 
     // ---- substitution set-up for this pass ----
@@ -233,8 +238,8 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         const uint32_t r = base + L * K + i + 1 - pad;
         sub_c.rc[i] = (r - 1 < m) ? (int32_t)a1c[r - 1] : -1;
       }
-      sub_c.vmatch = (int32_t)((uint32_t)a.match << SH);
-      sub_c.vmis = (int32_t)((uint32_t)a.mismatch << SH);
+      sub_c.vmatch = (int32_t)((uint32_t)a.match << SH) - goe_n;
+      sub_c.vmis = (int32_t)((uint32_t)a.mismatch << SH) - goe_n;
       sub_c.cc = 0;
     } else if (MODE == MODE_QP) {
       w.sync();  // previous pass may still be reading the table
@@ -248,12 +253,12 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
 #pragma unroll
         for (uint32_t b = 0; b < 5; ++b) {
           const int32_t q = (r - 1 < m) ? onehot_score(pr, b, fmatch, fmis) : 0;
-          const int32_t qs = (int32_t)((uint32_t)q << SH);
+          const int32_t qs = (int32_t)((uint32_t)q << SH) - goe_n;
           overflow |= (qs > 32767) || (qs < -32768);
           qp_tab[b * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)qs;
         }
       }
-      if (L < (uint32_t)qp_stride(K)) qp_tab[5 * (64 * qp_stride(K)) + L] = 0;
+      if (L < (uint32_t)qp_stride(K)) qp_tab[5 * (64 * qp_stride(K)) + L] = (int16_t)(-goe_n);
       if (overflow) flag_error(a.err, 1);
       w.sync();
     } else {
@@ -291,7 +296,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       if (active) {
         if (L == 0) {
           if (p == 0) {  // row 0 (gotoh.h:112-116)
-            up_h = (int32_t)((uint32_t)edge_value(hfree, go, ge, c) << SH);
+            up_h = (int32_t)((uint32_t)edge_value(hfree, go, ge, c) << SH) + goe_n;
             up_f = neg;
           } else {  // last row of the previous pass
             up_h = scratch[2 * c];
@@ -303,7 +308,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         int32_t nb_h, nb_f;
         uint32_t w0 = 0, w1 = 0;
         if (TRACE) trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub, w0, w1, nb_h, nb_f);
-        else if (NARROW) score_step16<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub, nb_h, nb_f);
+        else if (NARROW) score_step16g<K>(ss, up_h, up_f, prev_up_h, vext, goe, delta_last, sub, nb_h, nb_f);
         else score_step<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub, nb_h, nb_f);
         prev_up_h = up_h;
         bot_h = nb_h;
@@ -315,7 +320,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         }
         if (CKPT && L == lanes_used - 1) {  // {H, E} of row m (last slot of the last used lane) for the band traceback
           int32_t* lr = a.lastrow + d.lastrow_off;
-          lr[2 * c] = NARROW ? sext16(bot_h) : bot_h;
+          lr[2 * c] = NARROW ? sext16(bot_h - goe) : bot_h;
           lr[2 * c + 1] = NARROW ? sext16(ss.El[K - 1]) : ss.El[K - 1];
         }
       }
@@ -375,8 +380,8 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     (void)T;
 
     // ---- score = H[m][n] (gotoh.h:173) sits in the lane / slot that owns row m ----
-    if (CKPT) {
-      if (a.scores && L == lanes_used - 1) a.scores[d.out] = NARROW ? sext16(bot_h) : bot_h;
+    if (BOTTOM) {
+      if (a.scores && L == lanes_used - 1) a.scores[d.out] = NARROW ? sext16(bot_h - goe) : bot_h;
     } else if (last_pass && a.scores) {
       const uint32_t g = m - 1 - base;
       if (L == g / K) {
@@ -660,7 +665,7 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
           ts.Ec[i] = padding ? 0 : neg;
         } else {
           const int32_t hv = ck[ckpt_index(j, (uint32_t)i, L, K)], ev = ck[ckpt_index(j, (uint32_t)(K + i), L, K)];
-          ts.Hc[i] = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(hv) : hv) << SH);
+          ts.Hc[i] = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(hv - (go + ge)) : hv) << SH);
           ts.Ec[i] = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(ev) : ev) << SH);
         }
       }
@@ -671,9 +676,9 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
       } else {
         const int32_t bh = ck[ckpt_index(j, 2u * K, L, K)], bf = ck[ckpt_index(j, 2u * K + 1, L, K)];
         const int32_t pu = ck[ckpt_index(j, 2u * K + 2, L, K)];
-        bot_h = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(bh) : bh) << SH);
+        bot_h = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(bh - (go + ge)) : bh) << SH);
         bot_f = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(bf) : bf) << SH);
-        prev_up_h = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(pu) : pu) << SH);
+        prev_up_h = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(pu - (go + ge)) : pu) << SH);
       }
       for (uint32_t t = t0 + 1; t <= t_cur; ++t) {
         const int32_t c = (int32_t)t - (int32_t)L;

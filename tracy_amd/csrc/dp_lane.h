@@ -214,6 +214,36 @@ TR_HD void score_step16(ScoreLane<K>& s, int32_t up_h, int32_t up_f, int32_t dia
   bot_f = up_f;
 }
 
+// 16-bit score step with the gap-open term shared between the horizontal and the vertical move.
+// Each cell stores Hg = H + (go+ge) instead of H: the cell to the right needs H + hopen, the cell below
+// H + vopen, and both equal Hg except on the free last row (delta_last = hopen_m - (go+ge), applied to the
+// last slot only: rows are anchored at the bottom, so row m is always slot K-1).  The diagonal term
+// H + sub becomes Hg + (sub - (go+ge)): the constant is folded into the query-profile table.
+// 8 VALU ops per cell: E: add, max; F: add, max; diagonal: add; H: max, max; Hg: add.
+template <int K, class Sub>
+TR_HD void score_step16g(ScoreLane<K>& s, int32_t up_hg, int32_t up_f, int32_t diag_hg, int32_t vext, int32_t goe,
+                         int32_t delta_last, const Sub& subg, int32_t& bot_hg, int32_t& bot_f) {
+#pragma unroll
+  for (int i = K - 1; i >= 0; --i) {
+    const int32_t hl = (i == K - 1) ? add16(s.Hl[i], delta_last) : s.Hl[i];
+    const int32_t e = max16(hl, add16(s.El[i], s.hext[i]));
+    const int32_t d = add16(i == 0 ? diag_hg : s.Hl[i - 1], subg.lo16(i));
+    s.Hl[i] = d;
+    s.El[i] = e;
+  }
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int32_t f = max16(up_hg, add16(up_f, vext));
+    const int32_t h = max16(max16(s.Hl[i], s.El[i]), f);
+    const int32_t hg = add16(h, goe);
+    s.Hl[i] = hg;
+    up_hg = hg;
+    up_f = f;
+  }
+  bot_hg = up_hg;
+  bot_f = up_f;
+}
+
 // ---- Needleman-Wunsch lane (needle.h:101-110): one value per cell, two trace bits ----------------
 //   S = max(max(Sdiag + sub, Sup + vgap(ge)), Sleft + hgap(ge)); bit3 = (S == hor) else bit4 = (S == ver)
 // tags: hor*4 + 2, ver*4 + 1, diag*4 + 0  -> low two bits of the max are (bit3, bit4).

@@ -104,24 +104,39 @@ __global__ void secdecomp_kernel(const BcDesc* desc, const int32_t* signal, cons
 }
 
 // ---- allelicFraction (decompose.h:412-621) -----------------------------------------------------------
-// Block of 256 threads per trace.  The reference keeps the first candidate (i,j,k ascending) whose full
-// SSE is strictly below everything before it, starting from SSE(0.5,0.5,0,0); its `break` only skips
-// terms of candidates that already lost.  Here every (i,j) pair belongs to one thread, which walks k in
-// order, prunes with a block-wide bound (strictly greater partial sums only) and keeps (min SSE, first
-// index); a final reduction takes the lowest index among equal minima.  All arithmetic is the reference's
-// fp64 sequence (sub, mul, add; no FMA).
+// Block of 256 threads per trace.  The reference keeps the first candidate (i,j,k ascending) whose full SSE
+// is strictly below everything before it, starting from SSE(0.5,0.5,0,0); its `break` only skips terms of
+// candidates that already lost.  Its answer is therefore argmin over the 171 700 grid points of the SSE as
+// summed in the reference's order (fp64, sub/mul/add, no FMA), first index on ties, provided it beats the
+// start point.  Summing 4*d terms for every grid point is what costs the reference its time; here the
+// candidates are first screened with the closed form  SSE = sum_c (n_c v_c^2 - 2 v_c S_c + Q_c)  over the
+// five classes c (position belongs to the primary / secondary / tertiary / quaternary allele or none),
+// which differs from the sequentially rounded sum by far less than kScreenMargin; only candidates whose
+// screened value lies within that margin of the screened minimum can attain (or tie) the exact minimum and
+// are evaluated exactly, in the reference's order.  The selected pair is bit-identical.
 constexpr int AF_THREADS = 256;
+constexpr double kScreenMargin = 1e-6;  // >> 4d * 2^-53 * SSE rounding differences (SSE <= 4d <= 8192)
+
+__device__ __forceinline__ double af_exact_sse(const double* tp, const uint8_t* cls, uint32_t terms, const double pv[5]) {
+  double sse = 0;
+  for (uint32_t q = 0; q < terms; ++q) {
+    const double df = __dsub_rn(pv[cls[q]], tp[q]);
+    sse = __dadd_rn(sse, __dmul_rn(df, df));
+  }
+  return sse;
+}
+
 __global__ __launch_bounds__(AF_THREADS) void allelic_fraction_kernel(const BcDesc* desc, const int32_t* signal,
                                                                       const int32_t* bcpos, const uint8_t* pri_all,
                                                                       const uint8_t* sec_all, uint32_t trimLeft,
                                                                       uint32_t trimRight, double* fractions) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double vals[100];
-  __shared__ unsigned long long bound_bits;
   __shared__ double red_sse[AF_THREADS];
   __shared__ uint32_t red_idx[AF_THREADS];
   __shared__ uint32_t s_d;
-  __shared__ double s_sse0;
+  __shared__ double s_sse0, s_amin;
+  __shared__ double cN[5], cS[5], cQ[5];
   const BcDesc d = desc[blockIdx.x];
   const uint8_t* pri = pri_all + d.bc_off;
   const uint8_t* sec = sec_all + d.bc_off;
@@ -129,8 +144,7 @@ __global__ __launch_bounds__(AF_THREADS) void allelic_fraction_kernel(const BcDe
   uint32_t off = trimLeft, len;
   if ((uint64_t)(uint32_t)(trimLeft + trimRight + 1) >= (uint64_t)d.nbc) { off = 0; len = d.nbc; }
   else len = d.nbc - trimLeft - trimRight;
-  // LDS carve: tp[4][cap] doubles, cls[4][cap] bytes; cap = len
-  double* tp = reinterpret_cast<double*>(smem);
+  double* tp = reinterpret_cast<double*>(smem);                 // [4][dn], the reference's m-outer / n-inner order
   uint8_t* cls = reinterpret_cast<uint8_t*>(tp + 4 * (size_t)len);
   const int tid = threadIdx.x;
   if (tid == 0) {
@@ -171,17 +185,44 @@ __global__ __launch_bounds__(AF_THREADS) void allelic_fraction_kernel(const BcDe
       }
       ++np;
     }
-    // SSE of the start point (0.5, 0.5, 0, 0), decompose.h:586-591
-    double sse = 0;
+    // SSE of the start point (0.5, 0.5, 0, 0), decompose.h:586-591, and the per-class moments for the screen
     const double start[5] = {0.0, 0.5, 0.5, 0.0, 0.0};
-    for (uint32_t q = 0; q < 4 * dn; ++q) {
-      const double df = __dsub_rn(start[cls[q]], tp[q]);
-      sse = __dadd_rn(sse, __dmul_rn(df, df));
-    }
-    s_sse0 = sse;
-    bound_bits = (unsigned long long)__double_as_longlong(sse);
+    s_sse0 = af_exact_sse(tp, cls, 4 * dn, start);
+    for (int c = 0; c < 5; ++c) { cN[c] = 0; cS[c] = 0; cQ[c] = 0; }
+    for (uint32_t q = 0; q < 4 * dn; ++q) { const int c = cls[q]; cN[c] += 1.0; cS[c] += tp[q]; cQ[c] += tp[q] * tp[q]; }
   }
   __syncthreads();
+  const double n1 = cN[1], n2 = cN[2], n3 = cN[3], n4 = cN[4];
+  const double s1 = cS[1], s2 = cS[2], s3 = cS[3], s4c = cS[4];
+  const double qtot = cQ[0] + cQ[1] + cQ[2] + cQ[3] + cQ[4];
+  auto screen = [&](double vi, double vj, double vk, double vl) {
+    return qtot + vi * (n1 * vi - 2.0 * s1) + vj * (n2 * vj - 2.0 * s2) + vk * (n3 * vk - 2.0 * s3) + vl * (n4 * vl - 2.0 * s4c);
+  };
+  // pass 1: screened minimum over the grid
+  double my_min = 1e300;
+  for (uint32_t pr = tid; pr < 10000; pr += AF_THREADS) {
+    const uint32_t ia = pr / 100, ib = pr % 100;
+    const double vi = vals[ia], vj = vals[ib];
+    const double sij = __dadd_rn(vi, vj);
+    if (!(sij <= 1.0)) continue;
+    for (uint32_t ic = 0; ic < 100; ++ic) {
+      const double vk = vals[ic];
+      const double sijk = __dadd_rn(sij, vk);
+      if (!(sijk <= 1.0)) break;  // vals ascend: the reference's `if` fails for every later k as well
+      const double a = screen(vi, vj, vk, __dsub_rn(1.0, sijk));
+      my_min = a < my_min ? a : my_min;
+    }
+  }
+  red_sse[tid] = my_min;
+  __syncthreads();
+  if (tid == 0) {
+    double m = red_sse[0];
+    for (int q = 1; q < AF_THREADS; ++q) m = red_sse[q] < m ? red_sse[q] : m;
+    s_amin = m;
+  }
+  __syncthreads();
+  // pass 2: exact evaluation (the reference's summation) of everything within the margin of the screened minimum
+  const double cut = s_amin + kScreenMargin;
   double my_sse = s_sse0;
   uint32_t my_idx = 0xffffffffu;
   const uint32_t terms = 4 * dn;
@@ -193,22 +234,12 @@ __global__ __launch_bounds__(AF_THREADS) void allelic_fraction_kernel(const BcDe
     for (uint32_t ic = 0; ic < 100; ++ic) {
       const double vk = vals[ic];
       const double sijk = __dadd_rn(sij, vk);
-      if (!(sijk <= 1.0)) break;  // vals ascend: the reference's `if` fails for every later k as well
+      if (!(sijk <= 1.0)) break;
       const double vl = __dsub_rn(1.0, sijk);
+      if (screen(vi, vj, vk, vl) > cut) continue;
       const double pv[5] = {0.0, vi, vj, vk, vl};
-      const double bound = __longlong_as_double((long long)bound_bits);
-      double sse = 0;
-      uint32_t q = 0;
-      for (; q < terms; ++q) {
-        const double df = __dsub_rn(pv[cls[q]], tp[q]);
-        sse = __dadd_rn(sse, __dmul_rn(df, df));
-        if (sse > bound) break;
-      }
-      if (q == terms && sse < my_sse) {
-        my_sse = sse;
-        my_idx = (ia * 100 + ib) * 100 + ic;
-        atomicMin(&bound_bits, (unsigned long long)__double_as_longlong(sse));
-      }
+      const double sse = af_exact_sse(tp, cls, terms, pv);
+      if (sse < my_sse) { my_sse = sse; my_idx = (ia * 100 + ib) * 100 + ic; }  // ascending order inside a thread
     }
   }
   red_sse[tid] = my_sse;

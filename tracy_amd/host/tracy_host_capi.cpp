@@ -198,4 +198,45 @@ uint32_t tracyhost_synth_decompose(uint64_t seed, uint32_t n, uint32_t mf, uint3
   return (uint32_t)tr.basecallpos.size();
 }
 
+
+// Batch of synthetic `tracy decompose` inputs (config 3), multi-threaded: trace i is seeded with seed0 + i,
+// 80 % heterozygous indels (kind 0), 20 % SNV-only (kind 1), allele mix 60/40.  Every trace is basecalled
+// (0.33) and profiled here; traces whose basecaller dropped a window are regenerated with the next seed
+// stride so that all traces have exactly mf basecalls.  Layouts: refs [nt][n]; signal [nt][4][ns] with
+// ns = 12*mf+12; bcpos / primary / secondary [nt][mf]; profiles [nt][6][mf].
+void tracyhost_synth_decompose_batch(uint64_t seed0, uint32_t nt, uint32_t n, uint32_t mf, uint8_t* refs, int32_t* signal,
+                                     int32_t* bcpos, uint8_t* primary, uint8_t* secondary, float* profiles, uint32_t nthreads) {
+  if (nthreads == 0) nthreads = std::max(1u, std::thread::hardware_concurrency());
+  const uint32_t ns = 12 * mf + 12;
+  auto work = [&](uint32_t tid) {
+    std::vector<int32_t> pos(mf + 64);
+    for (uint32_t i = tid; i < nt; i += nthreads) {
+      for (uint64_t attempt = 0;; ++attempt) {
+        const uint64_t seed = seed0 + i + attempt * 1000003ull * nt;
+        int32_t indel = 0;
+        int32_t* sig = signal + (size_t)i * 4 * ns;
+        const uint32_t npos = tracyhost_synth_decompose(seed, n, mf, 30, (i % 5 == 4) ? 1 : 0, 0.6, refs + (size_t)i * n, sig, ns,
+                                                        pos.data(), &indel);
+        Trace tr;
+        tr.traceACGT.resize(4);
+        for (int k = 0; k < 4; ++k) tr.traceACGT[k].assign(sig + (size_t)k * ns, sig + (size_t)(k + 1) * ns);
+        tr.basecallpos.assign(pos.begin(), pos.begin() + npos);
+        BaseCalls bc;
+        basecall(tr, bc, 0.33f);
+        if (bc.primary.size() != mf) continue;
+        Profile p;
+        createProfile(tr, bc, p, 0, 0);
+        std::memcpy(bcpos + (size_t)i * mf, bc.bcPos.data(), sizeof(int32_t) * mf);
+        std::memcpy(primary + (size_t)i * mf, bc.primary.data(), mf);
+        std::memcpy(secondary + (size_t)i * mf, bc.secondary.data(), mf);
+        std::memcpy(profiles + (size_t)i * 6 * mf, p.data(), sizeof(float) * 6 * mf);
+        break;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (uint32_t t = 0; t < nthreads; ++t) th.emplace_back(work, t);
+  for (auto& t : th) t.join();
+}
+
 }  // extern "C"

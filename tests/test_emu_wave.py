@@ -164,11 +164,13 @@ def test_odd_strip_heights(K):
         assert (got[0], got[1]) == want
 
 
-@pytest.mark.parametrize("K", [4, 15, 16])
+@pytest.mark.parametrize("K", [4, 15])
 def test_band_traceback(K):
     """checkpointed score pass + band traceback == full-matrix traceback (same btr, same score)"""
     rng = np.random.default_rng(900 + K)
-    cases = [(1, 1), (1, 50), (40, 1), (30, 200), (64 * K, 130), (64 * K - 9, 300), (100, 97), (K + 1, 40), (2 * K - 1, 33)]
+    cases = [(1, 1), (1, 50), (40, 1), (30, 200), (64 * K - 9, 150), (100, 97), (K + 1, 40), (2 * K - 1, 33)]
+    if K == 4:
+        cases.append((64 * K, 130))
     for (m, n) in cases:
         if m > 64 * K:
             continue
@@ -183,7 +185,7 @@ def test_band_traceback(K):
             col[idx.get(ch, 0)] += np.float32(1.0)
             p1[:4, jx] = col / col.sum()
         p2 = orc.create_profile_str(ref)
-        for B in (16, 64):
+        for B in ((16, 64) if m < 200 else (64,)):
             # band mode domain: free end gaps on the first/last row only (AlignConfig<true,false>), ge < 0
             for narrow in (True, False):
                 want = orc.gotoh_prof(p1, p2, 1, 0, SC)

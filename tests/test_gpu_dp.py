@@ -181,6 +181,29 @@ def test_align_traces_pipeline(ctx):
     assert sorted(got["forward"].tolist()) == [0, 0, 0, 1, 1, 1]
 
 
+def test_align_traces_fallback_paths(ctx):
+    """traces longer than one pass (mf > 1024 + trims) and scoring outside the band/16-bit domain (ge = 0)
+    take the int32 + full-matrix traceback path of the same pipeline"""
+    from sage_oracle import align_trace
+    rng = np.random.default_rng(43)
+    refs, profs = [], []
+    for i, (mf, n) in enumerate([(1300, 2600), (1150, 1900), (400, 1200)]):
+        ref = rand_seq(rng, n, b"ACGT")
+        refs.append(ref)
+        profs.append(synth_trace_profile(rng, ref, mf, reverse=bool(i % 2)))
+    for sc in (SC, (3, -5, -10, 0), (2, -3, -2, -1)):
+        got = ctx.align_traces(profs, refs, sc, 50, 50)
+        for i in range(len(refs)):
+            want = align_trace(profs[i], refs[i], sc, 50, 50)
+            for k in ("score_fwd", "score_rev", "forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
+                assert int(got[k][i]) == int(want[k]), (sc, i, k)
+            assert got["btr"][i] == want["btr"], (sc, i)
+    # mixed batch: short traces ride the band path, the batch as a whole falls back when one trace needs two passes
+    got = ctx.align_traces(profs[2:], refs[2:], SC, 50, 50)
+    want = align_trace(profs[2], refs[2], SC, 50, 50)
+    assert got["btr"][0] == want["btr"] and int(got["score_final"][0]) == want["score_final"]
+
+
 def test_cpp_host_mirror(tmp_path):
     """tracy_amd/host/tracy_amd.hpp keeps the reference's call shape: gotoh(a1, a2, align, ac, sc)"""
     import os

@@ -33,3 +33,298 @@ def align_trace(profile_full, ref, score, trim_left=50, trim_right=50):
     sc2, btr2 = orc.gotoh_prof(profile_full, refprof, 1, 0, score)
     return dict(score_fwd=gs_fwd, score_rev=gs_rev, forward=int(forward), score_prelim=sc1, slice_begin=ri,
                 slice_len=len(sl), ref_pos=pos_add, score_final=sc2, btr=btr2, refslice=sl)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# `tracy align` host stages around the DP, restated in Python straight from the reference text (tests only;
+# independent of tracy_amd/host/sage_out.hpp, which it cross-checks).  PARITY UNPINNED: the reference
+# headers need Boost/htslib/sdsl and cannot be compiled here.
+# ---------------------------------------------------------------------------------------------------------
+def _u32(x):
+    return x & 0xFFFFFFFF
+
+
+def _i32(x):
+    x &= 0xFFFFFFFF
+    return x - (1 << 32) if x & 0x80000000 else x
+
+
+def is_ambiguous(c):
+    return c not in b"ACGT"
+
+
+def find_best_trace_section(secondary, bcpos, win=10):
+    """abif.h:164-220 -> (penalty list, best index, per-base penalty)"""
+    n = len(secondary)
+    pen = [0] * n
+    half = win // 2
+    amb = sum(1 for i in range(min(win, n)) if is_ambiguous(secondary[i:i + 1]))
+    for i in range(min(half, n)):
+        pen[i] = amb
+    for i in range(win, n):
+        if is_ambiguous(secondary[i - win:i - win + 1]):
+            amb -= 1
+        if is_ambiguous(secondary[i:i + 1]):
+            amb += 1
+        pen[i - half] = amb
+    if n >= half:
+        for i in range(n - half, n):
+            pen[i] = amb
+    mean = 0.0
+    for i in range(1, n):
+        mean += bcpos[i] - bcpos[i - 1]
+    denom = float(_u32(n - 1)) if n != 0 else float(2 ** 64 - 1)
+    mean = mean / denom if denom != 0 else (float("nan") if mean == 0 else float("inf"))
+    peak_var = 0
+    i = 0
+    while i + win < n:
+        old = bcpos[i - 1] if i > 0 else 0
+        lo, hi = _u32(bcpos[n - 1]), 0
+        for k in range(win):
+            d = _u32(bcpos[i + k] - old)
+            old = bcpos[i + k]
+            lo, hi = min(lo, d), max(hi, d)
+        peak_var = _u32(int((abs(hi - mean) + abs(lo - mean)) / 2))
+        pen[i + half] = _i32(pen[i + half] + peak_var)
+        if i == 0:
+            for k in range(half):
+                pen[k] = _i32(pen[k] + peak_var)
+        i += 1
+    if n >= half:
+        for i in range(n - half, n):
+            pen[i] = _i32(pen[i] + peak_var)
+    source = int(0.1 * n)
+    best_idx, best_val = 0, 99999999
+    i = 0
+    while i + source < n:
+        v = sum(pen[i:i + source])
+        if v < best_val:
+            best_val, best_idx = v, i + source // 2
+        i += 1
+    per_base = best_val / source if source else float("inf")
+    return pen, best_idx, per_base
+
+
+def trim_trace(stringency, secondary, bcpos):
+    """trim.h:35-73 -> (leftTrim, rightTrim)"""
+    import numpy as np
+    win = 10
+    n = len(secondary)
+    pen, best, per_base = find_best_trace_section(secondary, bcpos, win)
+    limit = float(np.float32(stringency)) * per_base
+    right, left = n, 0
+    local = float(sum(pen[best:min(best + win, n)]))
+    i = best
+    while i + win < n:
+        local -= pen[i]
+        local += pen[i + win]
+        if local > limit * win:
+            right = i
+            break
+        i += 1
+    local = float(sum(pen[best:min(best + win, n)]))
+    i = best - 1
+    while i >= 0:
+        if i + win < n:
+            local -= pen[i + win]
+        local += pen[i]
+        if local > limit * win:
+            left = i + win - 1
+            break
+        i -= 1
+    right = n - right if right < n else 0
+    return left, right
+
+
+def load_single_fasta(path):
+    """fasta.h:54-95 -> (name, seq) or None"""
+    name, body = "", ""
+    for line in open(path, "rb").read().decode("latin1").split("\n"):
+        if not line:
+            continue
+        if line[0] == ">":
+            if name:
+                return None
+            name = line[1:-1] if line.endswith("\r") else line[1:]
+        else:
+            body += (line[:-1] if line.endswith("\r") else line).upper()
+    out = []
+    for ch in body:
+        if ch in "ACGTN":
+            out.append(ch)
+        elif ch in "WSMKRYBDHV":
+            out.append("N")
+        else:
+            return None
+    for bad in "\\,'\"()[]{}<>:\t\r#":
+        name = name.replace(bad, "")
+    return name, "".join(out)
+
+
+def _fmt_double(x):
+    return "%g" % x
+
+
+def plot_alignment(row0, row1, chrom, pos, refslice_len, forward, score, linelimit=60, key=0, a1a2=(0.0, 0.0)):
+    """fmindex.h:329-427 -> file text"""
+    r0, r1 = row0.decode(), row1.decode()
+    o = []
+    ri, riend, vi = pos + 1, pos + refslice_len, 1
+    fald = linelimit + 14
+
+    def seq_block(row):
+        count = 0
+        for ch in row:
+            if ch != "-":
+                o.append(ch)
+                if (count + 1) % fald == 0:
+                    o.append("\n")
+                count += 1
+        if count % fald != 0:
+            o.append("\n")
+    if key == 0:
+        o.append(">Alt\n")
+    elif key == 2:
+        o.append(">Alt2 (Estimated allelic Fraction: %s)\n" % _fmt_double(a1a2[1]))
+    else:
+        o.append(">Alt1 (Estimated allelic Fraction: %s)\n" % _fmt_double(a1a2[0]))
+    seq_block(r0)
+    if key != 3:
+        if forward:
+            o.append(">Ref %s:%d-%d forward\n" % (chrom, ri, riend))
+        else:
+            o.append(">Ref %s:%d-%d reversecomplement\n" % (chrom, pos + refslice_len - (riend - pos) + 1, pos + refslice_len - (ri - pos) + 1))
+    else:
+        o.append(">Alt2 (Estimated allelic Fraction: %s)\n" % _fmt_double(a1a2[1]))
+    seq_block(r1)
+    o.append("\n")
+    o.append("Alignment score: %d\n" % score)
+    o.append("#" + "-" * (fald - 1) + "\n\n")
+    blocks, s, e = 0, 0, len(r0)
+    while s < e:
+        seg0, seg1 = r0[s:s + linelimit], r1[s:s + linelimit]
+        o.append(("Alt%10d " % vi) if key != 3 else ("Alt1%9d " % vi))
+        o.append(seg0 + "\n")
+        vi += sum(1 for ch in seg0 if ch != "-")
+        o.append(" " * 14 + "".join("|" if a == b else " " for a, b in zip(seg0, seg1)) + "\n")
+        if key != 3:
+            o.append("Ref%10d " % (ri if forward else pos + refslice_len - (ri - pos) + 1))
+        else:
+            o.append("Alt2%9d " % ri)
+        o.append(seg1 + "\n\n")
+        ri += sum(1 for ch in seg1 if ch != "-")
+        s += linelimit
+        blocks += 1
+    for _ in range(blocks, 6):
+        o.append("\n" * 4)
+    o.append(("#" + "-" * (fald - 1) + "\n") * 2)
+    o.append("\n\n")
+    return "".join(o)
+
+
+def alignment_trace_padding(row, signal, bcpos, primary, secondary, consensus, estqual):
+    """json.h:383-472 -> dict(signal [4][ns'], bcPos, primary, secondary, consensus, estQual, leadingGaps, trailingGaps)"""
+    step = 6
+    if len(bcpos) > 1:
+        avg = 0.0
+        for i in range(1, len(bcpos)):
+            avg += bcpos[i] - bcpos[i - 1]
+        step = int(avg / (len(bcpos) - 1))
+    ins_pos, ins_size = [], []
+    pos, ingap, gapsize, leading = 0, False, 0, 0
+    for ch in row:
+        if ch == ord("-"):
+            gapsize = gapsize + 1 if ingap else 1
+            ingap = True
+        else:
+            if ingap:
+                ingap = False
+                if pos:
+                    ins_pos.append(int((bcpos[pos - 1] + bcpos[pos]) / 2.0))
+                    ins_size.append(gapsize)
+                else:
+                    leading = gapsize
+            pos += 1
+    trailing = gapsize if ingap else 0
+    out = [[], [], [], []]
+    nb = dict(bcPos=[], primary=bytearray(), secondary=bytearray(), consensus=bytearray(), estQual=[])
+    bc, idx, offset, ins = 0, bcpos[0], 0, 0
+    ins_idx = ins_pos[0] if ins_pos else -1
+    for x in range(len(signal[0])):
+        for k in range(4):
+            out[k].append(int(signal[k][x]))
+        if ins_idx == x:
+            for _ in range(ins_size[ins]):
+                nb["bcPos"].append(x + offset + int(step / 2.0))
+                nb["estQual"].append(0)
+                for f in ("primary", "secondary", "consensus"):
+                    nb[f].append(ord("-"))
+                for _s in range(step):
+                    for k in range(4):
+                        out[k].append(-99)
+                    offset += 1
+            if ins < len(ins_pos) - 1:
+                ins += 1
+                ins_idx = ins_pos[ins]
+        if idx == x:
+            nb["bcPos"].append(idx + offset)
+            nb["estQual"].append(int(estqual[bc]))
+            nb["primary"].append(primary[bc])
+            nb["secondary"].append(secondary[bc])
+            nb["consensus"].append(consensus[bc])
+            if bc < len(bcpos) - 1:
+                bc += 1
+                idx = bcpos[bc]
+    nb.update(signal=out, leadingGaps=leading, trailingGaps=trailing)
+    return nb
+
+
+def trace_align_json(padded, chrom, pos, forward, row0, row1):
+    """json.h:108-217 -> file text"""
+    sig, bcpos = padded["signal"], padded["bcPos"]
+    ns = len(sig[0])
+    o = ["{\n", "\"gappedTrace\":\n", "{\n", "\"traceFileName\": \"trace\",\n", "\"leadingGaps\": %d,\n" % padded["leadingGaps"],
+         "\"trailingGaps\": %d,\n" % padded["trailingGaps"]]
+    for k, nm in enumerate(("peakA", "peakC", "peakG", "peakT")):
+        o.append("\"%s\": [%s],\n" % (nm, ", ".join(str(v) for v in sig[k])))
+
+    def visited():
+        """(sample index, call index) pairs the reference's cursor loop emits"""
+        bc, idx, res = 0, bcpos[0], []
+        for i in range(ns):
+            if idx == i:
+                res.append((i, bc))
+                if bc < len(bcpos) - 1:
+                    bc += 1
+                    idx = bcpos[bc]
+        return res
+    vis = visited()
+
+    def joined(items):
+        # the separator is written before every item whose sample index differs from bcPos[0]
+        return "".join((", " if i != bcpos[0] else "") + txt for (i, txt) in items)
+    o.append("\"basecallPos\": [%s],\n" % joined([(i, str(i + 1)) for i, _ in vis]))
+    o.append("\"basecallQual\": [%s],\n" % joined([(i, str(padded["estQual"][b])) for i, b in vis]))
+    items, gapless = [], 0
+    for i, b in vis:
+        p, s = chr(padded["primary"][b]), chr(padded["secondary"][b])
+        if p != "-":
+            gapless += 1
+            items.append((i, "\"%d\":\"%d:%s%s\"" % (i + 1, gapless, p, ("|" + s) if p != s else "")))
+        else:
+            items.append((i, "\"%d\":\"-\"" % (i + 1)))
+    o.append("\"basecalls\": {%s}\n" % joined(items))
+    o.append("}\n")
+    o.append(",\n")
+    o.append("\"refchr\": \"%s\",\n" % chrom)
+    o.append("\"refpos\": %d,\n" % (pos + 1))
+    o.append("\"altalign\": \"%s\",\n" % row0.decode())
+    o.append("\"refalign\": \"%s\",\n" % row1.decode())
+    o.append("\"forward\": %d\n" % (1 if forward else 0))
+    o.append("}\n")
+    return "".join(o)
+
+
+def align_fasta_text(stem, chrom, forward, row0, row1):
+    """sage.h:328-339"""
+    return ">%s\n%s\n>%s %s\n%s\n" % (stem, row0.decode(), chrom, "(forward)" if forward else "(reverse)", row1.decode())

@@ -74,6 +74,25 @@ def build_host(force=False, verbose=False):
     return HOST_SO
 
 
+CLI = os.path.join(HERE, "bin", "tracy_amd_cli")
+
+
+def build_cli(force=False, verbose=False):
+    """`tracy align` command line over the C ABI (tracy_amd/cli): g++ host code linked against libtracy_hip.so"""
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    hdir = os.path.join(HERE, "host")
+    src = os.path.join(HERE, "cli", "tracy_amd_cli.cpp")
+    srcs = [src, SO, os.path.join(os.path.dirname(HERE), "include", "tracy_hip.h")] + [os.path.join(hdir, f) for f in os.listdir(hdir)]
+    if force or stale(CLI, srcs):
+        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-o", CLI, src, "-L" + LIBDIR, "-ltracy_hip",
+               "-Wl,-rpath,$ORIGIN/../lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return CLI
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host(force="--force" in sys.argv, verbose=True))
+    print(build_cli(force="--force" in sys.argv, verbose=True))

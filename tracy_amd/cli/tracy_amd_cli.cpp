@@ -1,0 +1,457 @@
+// tracy_amd_cli.cpp -- `tracy align` rebuilt on the C ABI: the option
+// set, progress lines, exit codes and the four output files of /root/reference/src/sage.h:58-356, plus
+// a --batch manifest mode that pushes many traces through ONE device batch (tracyhip_align_traces).
+//
+//   tracy_amd_cli align [options] -r reference.fa|wildtype.ab1 trace.ab1
+//   tracy_amd_cli align [options] --batch manifest.tsv        lines: trace <TAB> reference <TAB> outprefix
+//
+// Host stages (as in the reference): ABIF/SCF parsing, basecalling, trimming estimate, profiles, file
+// writers.  Device stages: every Gotoh DP, orientation, trimReferenceSlice, alignment rows.  There is no
+// CPU fallback: without a GPU the command fails with the library's error text.
+// Not built yet: references given as an indexed .fa.gz genome (FM-index seeding, fmindex.h:173-326).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+#include "../../include/tracy_hip.h"
+#include "../host/sage_out.hpp"
+
+using namespace tracy_amd;
+
+namespace {
+
+struct SageConfig {  // sage.h:37-56
+  uint16_t linelimit = 60, trimLeft = 50, trimRight = 50;
+  float pratio = 0.33f, trimStringency = 0;
+  int32_t gapopen = -10, gapext = -4, match = 3, mismatch = -5;
+  std::string outprefix = "out", genome, ab, batch;
+  int device = 0;
+};
+
+struct Job {
+  std::string trace_path, ref_path, outprefix;
+  Trace tr;
+  BaseCalls bc;
+  uint32_t trimLeft = 0, trimRight = 0;
+  Profile full;
+  ReferenceSlice rs;
+  std::string fasta;         // filetype 1: the loaded record (forward strand)
+  Profile wt_fwd;            // filetype 2: wildtype profile
+  std::string wt_primary;
+  int32_t score = 0;
+  AlignRows rows;
+  bool ok = false;
+};
+
+std::string stamp() {  // boost::posix_time::to_simple_string(second_clock::local_time())
+  char buf[64];
+  std::time_t t = std::time(nullptr);
+  std::tm tmv;
+  localtime_r(&t, &tmv);
+  std::strftime(buf, sizeof(buf), "%Y-%b-%d %H:%M:%S", &tmv);
+  return std::string("[") + buf + "] ";
+}
+
+bool regular_nonempty(std::string const& p) {
+  struct stat st;
+  return ::stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0;
+}
+
+std::string file_name(std::string const& p) {
+  const std::size_t s = p.find_last_of('/');
+  return s == std::string::npos ? p : p.substr(s + 1);
+}
+
+std::string stem(std::string const& p) {
+  std::string f = file_name(p);
+  const std::size_t d = f.find_last_of('.');
+  return (d == std::string::npos || d == 0) ? f : f.substr(0, d);
+}
+
+void usage(const char* cmd) {
+  std::cout << "Usage: tracy " << cmd << " [OPTIONS] -r genome.fa trace.ab1" << std::endl;
+  std::cout << "Generic options:\n"
+               "  -? [ --help ]                    show help message\n"
+               "  -r [ --reference ] arg           fasta or wildtype ab1 file\n"
+               "  -p [ --pratio ] arg (=0.33)      peak ratio to call base\n"
+               "  -b [ --batch ] arg               manifest: trace<TAB>reference<TAB>outprefix per line\n"
+               "  -d [ --device ] arg (=0)         GPU ordinal\n"
+               "\nAlignment options:\n"
+               "  -g [ --gapopen ] arg (=-10)      gap open\n"
+               "  -e [ --gapext ] arg (=-4)        gap extension\n"
+               "  -m [ --match ] arg (=3)          match\n"
+               "  -n [ --mismatch ] arg (=-5)      mismatch\n"
+               "\nTrimming options:\n"
+               "  -t [ --trim ] arg (=0)           trimming stringency [1:9], 0: use trimLeft and trimRight\n"
+               "  -q [ --trimLeft ] arg (=50)      trim size left\n"
+               "  -u [ --trimRight ] arg (=50)     trim size right\n"
+               "\nOutput options:\n"
+               "  -l [ --linelimit ] arg (=60)     alignment line length\n"
+               "  -o [ --outprefix ] arg (=out)    output prefix\n\n";
+}
+
+// returns 0 ok, 1 show usage
+int parse(int argc, char** argv, SageConfig& c) {
+  static const std::map<std::string, char> longs = {
+      {"help", '?'}, {"reference", 'r'}, {"pratio", 'p'}, {"batch", 'b'}, {"device", 'd'}, {"gapopen", 'g'}, {"gapext", 'e'},
+      {"match", 'm'}, {"mismatch", 'n'}, {"trim", 't'}, {"trimLeft", 'q'}, {"trimRight", 'u'}, {"linelimit", 'l'}, {"outprefix", 'o'}};
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    char opt = 0;
+    std::string val;
+    bool has_val = false;
+    if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
+      std::string name = a.substr(2);
+      const std::size_t eq = name.find('=');
+      if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); has_val = true; }
+      auto it = longs.find(name);
+      if (it == longs.end()) { std::cerr << "unrecognised option '" << a << "'" << std::endl; return 1; }
+      opt = it->second;
+    } else if (a.size() >= 2 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9')) {
+      opt = a[1];
+      if (a.size() > 2) { val = a.substr(2); has_val = true; }
+    } else {
+      c.ab = a;
+      continue;
+    }
+    if (opt == '?') return 1;
+    if (!has_val) {
+      if (i + 1 >= argc) { std::cerr << "the required argument for option '" << a << "' is missing" << std::endl; return 1; }
+      val = argv[++i];
+    }
+    switch (opt) {
+      case 'r': c.genome = val; break;
+      case 'p': c.pratio = std::strtof(val.c_str(), nullptr); break;
+      case 'b': c.batch = val; break;
+      case 'd': c.device = std::atoi(val.c_str()); break;
+      case 'g': c.gapopen = std::atoi(val.c_str()); break;
+      case 'e': c.gapext = std::atoi(val.c_str()); break;
+      case 'm': c.match = std::atoi(val.c_str()); break;
+      case 'n': c.mismatch = std::atoi(val.c_str()); break;
+      case 't': c.trimStringency = std::strtof(val.c_str(), nullptr); break;
+      case 'q': c.trimLeft = (uint16_t)std::atoi(val.c_str()); break;
+      case 'u': c.trimRight = (uint16_t)std::atoi(val.c_str()); break;
+      case 'l': c.linelimit = (uint16_t)std::atoi(val.c_str()); break;
+      case 'o': c.outprefix = val; break;
+      default: std::cerr << "unrecognised option '" << a << "'" << std::endl; return 1;
+    }
+  }
+  return (c.ab.empty() && c.batch.empty()) ? 1 : 0;
+}
+
+bool load_trace(std::string const& path, Trace& tr) {
+  const int32_t ft = traceFormat(path);
+  if (ft == 0) return readab(path, tr);
+  if (ft == 1) return readscf(path, tr);
+  std::cerr << "Unknown trace file type!" << std::endl;
+  return false;
+}
+
+// host stages up to the device batch (sage.h:141-207, 222-231, 261-277); returns the CLI exit code
+int prepare(SageConfig const& c, Job& j) {
+  if (!load_trace(j.trace_path, j.tr)) return -1;
+  if (j.tr.basecallpos.empty()) {
+    std::cerr << "Trace file lacks basecalls!" << std::endl;
+    return -1;
+  }
+  basecall(j.tr, j.bc, c.pratio);
+  j.trimLeft = c.trimLeft;
+  j.trimRight = c.trimRight;
+  if (c.trimStringency >= 1) {
+    uint32_t l = 0, r = 0;
+    trimTrace(c.trimStringency, j.bc, l, r);
+    j.trimLeft = (uint16_t)l;   // SageConfig stores the trims as uint16_t (sage.h:39-40)
+    j.trimRight = (uint16_t)r;
+  }
+  if (j.trimLeft + j.trimRight >= j.bc.bcPos.size()) {
+    std::cerr << "The sum of the left and right trim size is larger than the trace!" << std::endl;
+    return -1;
+  }
+  traceTxtOut(j.outprefix + ".abif", j.bc, j.tr, j.trimLeft, j.trimRight);
+  createProfile(j.tr, j.bc, j.full);
+  j.rs.filetype = genomeType(j.ref_path);
+  if (j.rs.filetype == -1) {
+    std::cerr << "Unknown reference file format!" << std::endl;
+    return -1;
+  }
+  if (j.rs.filetype == 0) {
+    std::cerr << "Indexed genomes (FM-index seeding) are not part of this build; pass a FASTA slice (<= 50 kbp) or a wildtype trace."
+              << std::endl;
+    return -1;
+  }
+  if (j.rs.filetype == 1) {
+    std::string name;
+    if (!loadSingleFasta(j.ref_path, name, j.fasta)) return -1;
+    if (j.fasta.size() > kMaxSingleFasta) {
+      std::cerr << "Reference is larger than 50Kbp. Please use a smaller reference slice or an indexed genome!" << std::endl;
+      return -1;
+    }
+    j.rs.chr = name;
+  } else {
+    Trace gtr;
+    if (!load_trace(j.ref_path, gtr)) return -1;
+    BaseCalls gbc;
+    basecall(gtr, gbc, c.pratio);
+    createProfile(gtr, gbc, j.wt_fwd);
+    j.wt_primary = gbc.primary;
+    j.rs.chr = "wildtype";
+  }
+  return 0;
+}
+
+struct Device {
+  tracyhip_ctx* ctx = nullptr;
+  ~Device() { if (ctx) tracyhip_destroy(ctx); }
+};
+
+bool gpu_fail(const char* what) {
+  std::cerr << "tracy_amd: " << what << ": " << tracyhip_last_error() << std::endl;
+  return false;
+}
+
+// rows of gotoh(profile a1, a2) from its op string
+bool alignment_rows(tracyhip_ctx* ctx, tracyhip_seqset const& s1, tracyhip_seqset const& s2, std::vector<uint8_t> const& ops,
+                    std::vector<uint64_t> const& off, std::vector<uint32_t> const& len, std::vector<Job*> const& jobs) {
+  tracyhip_pairs pr{};
+  pr.npairs = (uint32_t)jobs.size();
+  pr.a1 = s1;
+  pr.a2 = s2;
+  std::vector<uint8_t> r0(ops.size() ? ops.size() : 1), r1(ops.size() ? ops.size() : 1);
+  if (tracyhip_alignment_rows(ctx, &pr, TRACYHIP_MEM_HOST, ops.data(), off.data(), len.data(), r0.data(), r1.data()) != TRACYHIP_OK)
+    return gpu_fail("alignment rows");
+  for (std::size_t i = 0; i < jobs.size(); ++i) {
+    jobs[i]->rows.row0.assign(reinterpret_cast<char*>(r0.data()) + off[i], len[i]);
+    jobs[i]->rows.row1.assign(reinterpret_cast<char*>(r1.data()) + off[i], len[i]);
+  }
+  return true;
+}
+
+// FASTA references: sage.h:233-260 + :311 for every job sharing one (trimLeft, trimRight)
+bool align_fasta_group(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
+  const uint32_t nt = (uint32_t)jobs.size();
+  std::vector<float> prof;
+  std::vector<uint8_t> refs;
+  std::vector<uint64_t> poff(nt), roff(nt), ooff(nt);
+  std::vector<uint32_t> plen(nt), rlen(nt);
+  uint64_t ocap = 0;
+  for (uint32_t i = 0; i < nt; ++i) {
+    Job& j = *jobs[i];
+    poff[i] = prof.size();
+    plen[i] = (uint32_t)j.full.cols;
+    prof.insert(prof.end(), j.full.v.begin(), j.full.v.end());
+    roff[i] = refs.size();
+    rlen[i] = (uint32_t)j.fasta.size();
+    refs.insert(refs.end(), j.fasta.begin(), j.fasta.end());
+    ooff[i] = ocap;
+    ocap += (uint64_t)plen[i] + rlen[i];
+  }
+  tracyhip_align_job job{};
+  job.ntraces = nt;
+  job.profiles = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, prof.data(), poff.data(), plen.data(), nt};
+  job.refs = tracyhip_seqset{TRACYHIP_SEQ_CHAR, refs.data(), roff.data(), rlen.data(), nt};
+  job.trim_left = jobs[0]->trimLeft;
+  job.trim_right = jobs[0]->trimRight;
+  std::vector<int32_t> sf(nt), sr(nt), sfin(nt);
+  std::vector<uint8_t> fwd(nt), ops(ocap ? ocap : 1);
+  std::vector<uint32_t> sb(nt), sl(nt), rp(nt), olen(nt);
+  tracyhip_align_result res{};
+  res.score_fwd = sf.data(); res.score_rev = sr.data(); res.forward = fwd.data();
+  res.slice_begin = sb.data(); res.slice_len = sl.data(); res.ref_pos = rp.data();
+  res.score_final = sfin.data(); res.ops = ops.data(); res.ops_offset = ooff.data(); res.ops_len = olen.data();
+  if (tracyhip_align_traces(ctx, &job, &prm, TRACYHIP_MEM_HOST, &res) != TRACYHIP_OK) return gpu_fail("align");
+  // the reference slices the final alignment ran against (trimReferenceSlice, fmindex.h:429-463)
+  std::vector<uint8_t> slices;
+  std::vector<uint64_t> soff(nt);
+  for (uint32_t i = 0; i < nt; ++i) {
+    Job& j = *jobs[i];
+    j.rs.forward = fwd[i] != 0;
+    std::string oriented = j.fasta;
+    if (!j.rs.forward) reverseComplement(oriented);
+    j.rs.refslice = oriented.substr(sb[i], sl[i]);
+    j.rs.pos = rp[i];
+    j.score = sfin[i];
+    soff[i] = slices.size();
+    slices.insert(slices.end(), j.rs.refslice.begin(), j.rs.refslice.end());
+  }
+  tracyhip_seqset s2{TRACYHIP_SEQ_CHAR, slices.data(), soff.data(), sl.data(), nt};
+  return alignment_rows(ctx, job.profiles, s2, ops, ooff, olen, jobs);
+}
+
+// wildtype-trace references: sage.h:261-301 + :311 (profile x profile)
+bool align_wildtype_group(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
+  const uint32_t nt = (uint32_t)jobs.size();
+  std::vector<Profile> trimmed(nt), wrev(nt);
+  std::vector<float> ptrim, pfull, pref;  // pref: forward then reverse-complement wildtype profile per job
+  std::vector<uint64_t> toff(nt), foff(nt), woff(2 * nt), ooff(nt);
+  std::vector<uint32_t> tlen(nt), flen(nt), wlen(2 * nt), idx1(2 * nt), idx2(2 * nt);
+  for (uint32_t i = 0; i < nt; ++i) {
+    Job& j = *jobs[i];
+    createProfile(j.tr, j.bc, trimmed[i], (int32_t)j.trimLeft, (int32_t)j.trimRight);
+    reverseComplementProfile(j.wt_fwd, wrev[i]);
+    toff[i] = ptrim.size(); tlen[i] = (uint32_t)trimmed[i].cols;
+    ptrim.insert(ptrim.end(), trimmed[i].v.begin(), trimmed[i].v.end());
+    foff[i] = pfull.size(); flen[i] = (uint32_t)j.full.cols;
+    pfull.insert(pfull.end(), j.full.v.begin(), j.full.v.end());
+    for (int r = 0; r < 2; ++r) {
+      Profile const& p = r ? wrev[i] : j.wt_fwd;
+      woff[2 * i + r] = pref.size(); wlen[2 * i + r] = (uint32_t)p.cols;
+      pref.insert(pref.end(), p.v.begin(), p.v.end());
+      idx1[2 * i + r] = i; idx2[2 * i + r] = 2 * i + r;
+    }
+  }
+  tracyhip_pairs sp{};
+  sp.npairs = 2 * nt;
+  sp.a1 = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, ptrim.data(), toff.data(), tlen.data(), nt};
+  sp.a2 = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, pref.data(), woff.data(), wlen.data(), 2 * nt};
+  sp.a1_index = idx1.data(); sp.a2_index = idx2.data();
+  std::vector<int32_t> gs(2 * nt);
+  if (tracyhip_gotoh_score(ctx, &sp, &prm, TRACYHIP_MEM_HOST, gs.data()) != TRACYHIP_OK) return gpu_fail("orientation scores");
+  std::vector<uint32_t> pick(nt), olen(nt);
+  uint64_t ocap = 0;
+  for (uint32_t i = 0; i < nt; ++i) {
+    Job& j = *jobs[i];
+    j.rs.forward = gs[2 * i] > gs[2 * i + 1];
+    j.rs.refslice = j.wt_primary;
+    if (!j.rs.forward) reverseComplement(j.rs.refslice);
+    j.rs.pos = 0;
+    pick[i] = 2 * i + (j.rs.forward ? 0 : 1);
+    ooff[i] = ocap;
+    ocap += (uint64_t)flen[i] + wlen[pick[i]];
+  }
+  tracyhip_pairs fp{};
+  fp.npairs = nt;
+  fp.a1 = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, pfull.data(), foff.data(), flen.data(), nt};
+  fp.a2 = sp.a2;
+  fp.a2_index = pick.data();
+  std::vector<int32_t> sc(nt);
+  std::vector<uint8_t> ops(ocap ? ocap : 1);
+  if (tracyhip_gotoh_align(ctx, &fp, &prm, TRACYHIP_MEM_HOST, sc.data(), ops.data(), ooff.data(), olen.data()) != TRACYHIP_OK)
+    return gpu_fail("final alignment");
+  tracyhip_pairs rp = fp;
+  std::vector<uint8_t> r0(ops.size()), r1(ops.size());
+  if (tracyhip_alignment_rows(ctx, &rp, TRACYHIP_MEM_HOST, ops.data(), ooff.data(), olen.data(), r0.data(), r1.data()) != TRACYHIP_OK)
+    return gpu_fail("alignment rows");
+  for (uint32_t i = 0; i < nt; ++i) {
+    jobs[i]->score = sc[i];
+    jobs[i]->rows.row0.assign(reinterpret_cast<char*>(r0.data()) + ooff[i], olen[i]);
+    jobs[i]->rows.row1.assign(reinterpret_cast<char*>(r1.data()) + ooff[i], olen[i]);
+  }
+  return true;
+}
+
+// sage.h:313-345
+void write_outputs(SageConfig const& c, Job const& j) {
+  PaddedTrace padded;
+  alignmentTracePadding(j.rows.row0, j.tr, j.bc, padded);
+  {
+    std::ofstream f((j.outprefix + ".align.fa").c_str());
+    alignFastaOut(f, stem(j.trace_path), j.rs, j.rows);
+  }
+  plotAlignment(j.outprefix + ".txt", j.rows, j.rs, j.score, c.linelimit);
+  traceAlignJsonOut(j.outprefix + ".json", padded, j.rs, j.rows);
+}
+
+int align_main(int argc, char** argv) {
+  SageConfig c;
+  if (parse(argc, argv, c)) {
+    usage(argv[0]);
+    return -1;
+  }
+  if (c.trimStringency > 9) c.trimStringency = 9;
+  std::vector<Job> jobs;
+  const bool batch = !c.batch.empty();
+  if (batch) {
+    std::ifstream mf(c.batch.c_str());
+    if (!mf) {
+      std::cerr << "Manifest is missing: " << c.batch << std::endl;
+      return 1;
+    }
+    std::string line;
+    while (std::getline(mf, line)) {
+      if (line.empty() || line[0] == '#') continue;
+      std::istringstream ss(line);
+      Job j;
+      if (!std::getline(ss, j.trace_path, '\t') || !std::getline(ss, j.ref_path, '\t') || !std::getline(ss, j.outprefix, '\t')) {
+        std::cerr << "Malformed manifest line: " << line << std::endl;
+        return 1;
+      }
+      jobs.push_back(std::move(j));
+    }
+  } else {
+    Job j;
+    j.trace_path = c.ab;
+    j.ref_path = c.genome;
+    j.outprefix = c.outprefix;
+    jobs.push_back(std::move(j));
+  }
+  for (Job const& j : jobs) {
+    if (!regular_nonempty(j.ref_path)) {
+      std::cerr << "Reference file is missing: " << file_name(j.ref_path) << std::endl;
+      return 1;
+    }
+    if (!regular_nonempty(j.trace_path)) {
+      std::cerr << "Input trace file is missing: " << file_name(j.trace_path) << std::endl;
+      return 1;
+    }
+  }
+  std::cout << stamp() << "tracy ";
+  for (int i = 0; i < argc; ++i) std::cout << argv[i] << ' ';
+  std::cout << std::endl;
+
+  std::cout << stamp() << "Load ab1 file" << std::endl;
+  int failed = 0;
+  for (Job& j : jobs) {
+    const int rc = prepare(c, j);
+    if (rc != 0) {
+      if (!batch) return rc;
+      std::cerr << "skipping " << j.trace_path << std::endl;
+      ++failed;
+    } else {
+      j.ok = true;
+    }
+  }
+
+  std::cout << stamp() << "Find reference match" << std::endl;
+  Device dev;
+  if (tracyhip_create(c.device, &dev.ctx) != TRACYHIP_OK) {
+    gpu_fail("no usable GPU");
+    return -1;
+  }
+  tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};  // AlignConfig<true,false>, sage.h:165
+  std::map<std::pair<uint32_t, uint32_t>, std::vector<Job*>> fasta_groups;
+  std::vector<Job*> wildtype;
+  for (Job& j : jobs) {
+    if (!j.ok) continue;
+    if (j.rs.filetype == 1) fasta_groups[std::make_pair(j.trimLeft, j.trimRight)].push_back(&j);
+    else wildtype.push_back(&j);
+  }
+  std::cout << stamp() << "Alignment" << std::endl;
+  for (auto& g : fasta_groups)
+    if (!align_fasta_group(dev.ctx, prm, g.second)) return -1;
+  if (!wildtype.empty() && !align_wildtype_group(dev.ctx, prm, wildtype)) return -1;
+
+  std::cout << stamp() << "Output" << std::endl;
+  for (Job const& j : jobs)
+    if (j.ok) write_outputs(c, j);
+  std::cout << stamp() << "Done." << std::endl;
+  return failed ? 2 : 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 2 || std::strcmp(argv[1], "align") != 0) {
+    std::cout << "Usage: tracy_amd_cli align [OPTIONS] -r genome.fa trace.ab1" << std::endl;
+    std::cout << "       tracy_amd_cli align [OPTIONS] --batch manifest.tsv" << std::endl;
+    return argc < 2 ? 0 : 1;
+  }
+  return align_main(argc - 1, argv + 1);
+}

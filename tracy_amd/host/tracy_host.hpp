@@ -7,7 +7,8 @@
 //   Trace, BaseCalls                      abif.h:28-57
 //   trimmedSeq                            abif.h:68-75
 //   iupac(char,char), isAmbiguous         abif.h:135-161
-//   basecall(Trace, BaseCalls&, float)    abif.h:408-511   (estimateQualities is not needed on this path)
+//   basecall(Trace, BaseCalls&, float)    abif.h:408-511
+//   findBestTraceSection, estimateQualities   abif.h:164-253
 //   createProfile(tr, bc, p, tl, tr)      profile.h:21-52
 //   reverseComplementProfile              profile.h:74-90
 //   _createProfile(std::string)           align.h:121-136
@@ -17,7 +18,9 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace tracy_amd {
@@ -26,6 +29,10 @@ struct Trace {  // abif.h:28-43
   typedef int32_t TValue;
   typedef std::vector<TValue> TMountains;
   typedef std::vector<TMountains> TACGTMountains;
+  typedef std::vector<uint8_t> TQual;
+  std::string basecalls1;  // the file's own primary / secondary calls (ABIF PBAS.2 / P2BA.1); unused by the DP path
+  std::string basecalls2;
+  TQual qual;
   TMountains basecallpos;
   TACGTMountains traceACGT;  // [4][samples], A C G T
 };
@@ -37,6 +44,7 @@ struct BaseCalls {  // abif.h:46-57
   std::string secondary;
   std::string secDecompose;
   TPosition bcPos;
+  std::vector<uint8_t> estQual;
 };
 
 // float[6][cols], element (k, j) at k*cols + j -- the layout the C ABI takes (TRACYHIP_SEQ_PROFILE)
@@ -85,6 +93,77 @@ inline bool window_peaks(Trace::TACGTMountains const& tr, float s, float e, int3
   return true;
 }
 }  // namespace detail
+
+// findBestTraceSection, abif.h:164-220: per-base penalty = ambiguous secondary calls in a window of
+// `win` + deviation of the peak spacing from its mean; returns (centre of the best 10 % stretch, its
+// mean penalty).  All index arithmetic is 32-bit unsigned as in the reference.
+inline std::pair<uint32_t, double> findBestTraceSection(BaseCalls const& bc, std::vector<int32_t>& penalty, uint32_t win) {
+  const uint32_t n = (uint32_t)bc.secondary.size();
+  const uint32_t half = win / 2;
+  int32_t amb = 0;
+  for (uint32_t i = 0; i < win && i < n; ++i) amb += isAmbiguous(bc.secondary[i]) ? 1 : 0;
+  for (uint32_t i = 0; i < half && i < n; ++i) penalty[i] = amb;
+  for (uint32_t i = win; i < n; ++i) {
+    amb += (isAmbiguous(bc.secondary[i]) ? 1 : 0) - (isAmbiguous(bc.secondary[i - win]) ? 1 : 0);
+    penalty[i - half] = amb;
+  }
+  for (uint32_t i = n - half; i < n; ++i) penalty[i] = amb;
+
+  double mean = 0;
+  for (uint32_t i = 1; i < n; ++i) mean += (bc.bcPos[i] - bc.bcPos[i - 1]);
+  mean /= (bc.secondary.size() - 1);
+
+  uint32_t spread = 0;
+  for (uint32_t i = 0; i + win < n; ++i) {
+    uint32_t last = i > 0 ? (uint32_t)bc.bcPos[i - 1] : 0;
+    uint32_t lo = (uint32_t)bc.bcPos[n - 1], hi = 0;
+    for (uint32_t k = 0; k < win; ++k) {
+      const uint32_t d = (uint32_t)bc.bcPos[i + k] - last;
+      last = (uint32_t)bc.bcPos[i + k];
+      if (d < lo) lo = d;
+      if (d > hi) hi = d;
+    }
+    spread = (uint32_t)(int32_t)((std::abs((double)hi - mean) + std::abs((double)lo - mean)) / 2);
+    penalty[i + half] = (int32_t)((uint32_t)penalty[i + half] + spread);
+    if (i == 0)
+      for (uint32_t k = 0; k < half; ++k) penalty[k] = (int32_t)((uint32_t)penalty[k] + spread);
+  }
+  for (uint32_t i = n - half; i < n; ++i) penalty[i] = (int32_t)((uint32_t)penalty[i] + spread);
+
+  const uint32_t stretch = (uint32_t)(int32_t)(0.1 * bc.secondary.size());
+  uint32_t best_at = 0;
+  int32_t best = 99999999;
+  for (uint32_t i = 0; i + stretch < n; ++i) {
+    int32_t sum = 0;
+    for (uint32_t k = 0; k < stretch; ++k) sum += penalty[i + k];
+    if (sum < best) {
+      best = sum;
+      best_at = i + (uint32_t)(int32_t)(stretch / 2);
+    }
+  }
+  return std::make_pair(best_at, (double)best / (double)stretch);
+}
+
+inline uint32_t findBestTraceSection(BaseCalls const& bc) {  // abif.h:222-229
+  std::vector<int32_t> penalty(bc.secondary.size(), 0);
+  return findBestTraceSection(bc, penalty, 10).first;
+}
+
+// estimateQualities, abif.h:232-253: penalties rescaled to 60..0
+inline void estimateQualities(BaseCalls& bc) {
+  bc.estQual.resize(bc.primary.size(), 0);
+  std::vector<int32_t> penalty(bc.secondary.size(), 0);
+  findBestTraceSection(bc, penalty, 10);
+  int32_t top = 0;
+  for (int32_t v : penalty)
+    if (v >= top) top = v;
+  const double scaling = 60.0 / (double)top;
+  for (std::size_t i = 0; i < penalty.size(); ++i) {
+    const double q = 60.0 - scaling * (double)penalty[i];
+    int32_t v = (q != q) ? 0 : (q < 0 ? 0 : q > 60 ? 60 : (int32_t)q);  // NaN (all penalties 0) truncates below 0 on x86
+    bc.estQual[i] = (uint8_t)v;
+  }
+}
 
 // basecall(), abif.h:408-511
 inline void basecall(Trace const& tr, BaseCalls& bc, float sigratio) {
@@ -139,6 +218,7 @@ inline void basecall(Trace const& tr, BaseCalls& bc, float sigratio) {
       bc.primary.push_back(letters[sel]); bc.secondary.push_back(letters[sel]); bc.consensus.push_back(letters[sel]);
     }
   }
+  estimateQualities(bc);
 }
 
 namespace detail {

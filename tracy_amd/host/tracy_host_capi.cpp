@@ -6,6 +6,8 @@
 #include <thread>
 #include <vector>
 
+#include "sage_out.hpp"
+#include "trace_io.hpp"
 #include "tracy_host.hpp"
 
 using namespace tracy_amd;
@@ -122,6 +124,135 @@ int32_t tracyhost_create_profile(const int32_t* trace, size_t nsamples, const in
 }
 
 char tracyhost_iupac(char a, char b) { return iupac(a, b); }
+
+// basecall + the per-base quality estimate it ends with (abif.h:232-253, 510)
+size_t tracyhost_basecall_qual(const int32_t* trace, size_t nsamples, const int32_t* basecallpos, size_t npos, float sigratio,
+                               char* primary, char* secondary, char* consensus, int32_t* bcpos, uint8_t* estqual) {
+  Trace tr;
+  tr.traceACGT.resize(4);
+  for (int k = 0; k < 4; ++k) tr.traceACGT[k].assign(trace + k * nsamples, trace + (k + 1) * nsamples);
+  tr.basecallpos.assign(basecallpos, basecallpos + npos);
+  BaseCalls bc;
+  basecall(tr, bc, sigratio);
+  const size_t n = bc.primary.size();
+  std::memcpy(primary, bc.primary.data(), n);
+  std::memcpy(secondary, bc.secondary.data(), n);
+  std::memcpy(consensus, bc.consensus.data(), n);
+  std::memcpy(bcpos, bc.bcPos.data(), n * sizeof(int32_t));
+  std::memcpy(estqual, bc.estQual.data(), n);
+  return n;
+}
+
+// chromatogram files: format 0 = ABIF, 1 = SCF (scf.h:18-34).  The handle owns a Trace.
+void* tracyhost_trace_read(const char* path, int32_t* format) {
+  const int32_t ft = traceFormat(path);
+  if (format) *format = ft;
+  Trace* tr = new Trace();
+  const bool ok = ft == 0 ? readab(path, *tr) : ft == 1 ? readscf(path, *tr) : false;
+  if (!ok) { delete tr; return nullptr; }
+  return tr;
+}
+void tracyhost_trace_dims(const void* h, uint64_t* nsamples, uint64_t* ncalls) {
+  const Trace* tr = static_cast<const Trace*>(h);
+  size_t ns = 0;
+  for (auto const& c : tr->traceACGT) ns = std::max(ns, c.size());
+  *nsamples = ns;
+  *ncalls = tr->basecallpos.size();
+}
+// signal: [4][nsamples] (channels shorter than nsamples are zero padded); text outputs have ncalls bytes
+void tracyhost_trace_get(const void* h, int32_t* signal, int32_t* basecallpos, char* basecalls1, char* basecalls2, uint8_t* qual) {
+  const Trace* tr = static_cast<const Trace*>(h);
+  uint64_t ns, nc;
+  tracyhost_trace_dims(h, &ns, &nc);
+  for (size_t k = 0; k < 4; ++k)
+    for (size_t i = 0; i < ns; ++i) signal[k * ns + i] = (k < tr->traceACGT.size() && i < tr->traceACGT[k].size()) ? tr->traceACGT[k][i] : 0;
+  std::memcpy(basecallpos, tr->basecallpos.data(), nc * sizeof(int32_t));
+  if (basecalls1) std::memcpy(basecalls1, tr->basecalls1.data(), std::min<size_t>(nc, tr->basecalls1.size()));
+  if (basecalls2) std::memcpy(basecalls2, tr->basecalls2.data(), std::min<size_t>(nc, tr->basecalls2.size()));
+  if (qual) std::memcpy(qual, tr->qual.data(), std::min<size_t>(nc, tr->qual.size()));
+}
+void tracyhost_trace_free(void* h) { delete static_cast<Trace*>(h); }
+
+// the build's ABIF writer: signal [4][nsamples] in A,C,G,T order, written in dye order `order`
+int32_t tracyhost_writeab(const char* path, const int32_t* signal, size_t nsamples, const int32_t* peaks, size_t npeaks,
+                          const char* primary, size_t nprimary, const uint8_t* qual, size_t nqual, const char* secondary,
+                          size_t nsecondary, const char* order) {
+  Trace::TACGTMountains acgt(4);
+  for (int k = 0; k < 4; ++k) acgt[k].assign(signal + k * nsamples, signal + (k + 1) * nsamples);
+  return writeab(path, acgt, std::vector<int32_t>(peaks, peaks + npeaks), std::string(primary, nprimary),
+                 std::vector<uint8_t>(qual, qual + nqual), secondary ? std::string(secondary, nsecondary) : std::string(),
+                 order ? order : "GATC") ? 0 : -1;
+}
+
+// basecall + traceTxtOut (abif.h:513-533) into `outfile`
+int32_t tracyhost_trace_txt(const char* outfile, const int32_t* trace, size_t nsamples, const int32_t* basecallpos, size_t npos,
+                            float sigratio, uint32_t left_trim, uint32_t right_trim) {
+  Trace tr;
+  tr.traceACGT.resize(4);
+  for (int k = 0; k < 4; ++k) tr.traceACGT[k].assign(trace + k * nsamples, trace + (k + 1) * nsamples);
+  tr.basecallpos.assign(basecallpos, basecallpos + npos);
+  BaseCalls bc;
+  basecall(tr, bc, sigratio);
+  if (bc.bcPos.empty()) return -1;
+  traceTxtOut(std::string(outfile), bc, tr, left_trim, right_trim);
+  return 0;
+}
+
+// the three alignment files of `tracy align` (sage.h:313-345) for a trace given as arrays and its final
+// alignment rows: <prefix>.align.fa, <prefix>.txt, <prefix>.json
+int32_t tracyhost_align_outputs(const char* prefix, const char* trace_stem, const int32_t* trace, size_t nsamples,
+                                const int32_t* basecallpos, size_t npos, float sigratio, const char* row0, const char* row1,
+                                size_t cols, const char* chr, const char* refslice, size_t nref, uint32_t pos, int32_t forward,
+                                int32_t score, uint32_t linelimit) {
+  Trace tr;
+  tr.traceACGT.resize(4);
+  for (int k = 0; k < 4; ++k) tr.traceACGT[k].assign(trace + k * nsamples, trace + (k + 1) * nsamples);
+  tr.basecallpos.assign(basecallpos, basecallpos + npos);
+  BaseCalls bc;
+  basecall(tr, bc, sigratio);
+  if (bc.bcPos.empty()) return -1;
+  AlignRows rows;
+  rows.row0.assign(row0, cols);
+  rows.row1.assign(row1, cols);
+  ReferenceSlice rs;
+  rs.forward = forward != 0;
+  rs.pos = pos;
+  rs.chr = chr;
+  rs.refslice.assign(refslice, nref);
+  PaddedTrace padded;
+  alignmentTracePadding(rows.row0, tr, bc, padded);
+  const std::string pre(prefix);
+  {
+    std::ofstream f((pre + ".align.fa").c_str());
+    alignFastaOut(f, trace_stem, rs, rows);
+  }
+  plotAlignment(pre + ".txt", rows, rs, score, linelimit);
+  traceAlignJsonOut(pre + ".json", padded, rs, rows);
+  return 0;
+}
+
+// trimTrace (trim.h:35-73) of the basecalled trace
+int32_t tracyhost_trim_trace(const int32_t* trace, size_t nsamples, const int32_t* basecallpos, size_t npos, float sigratio,
+                             float stringency, uint32_t* left, uint32_t* right) {
+  Trace tr;
+  tr.traceACGT.resize(4);
+  for (int k = 0; k < 4; ++k) tr.traceACGT[k].assign(trace + k * nsamples, trace + (k + 1) * nsamples);
+  tr.basecallpos.assign(basecallpos, basecallpos + npos);
+  BaseCalls bc;
+  basecall(tr, bc, sigratio);
+  trimTrace(stringency, bc, *left, *right);
+  return 0;
+}
+
+// loadSingleFasta (fasta.h:54-95): returns the sequence length, -1 on error; name/seq need capacity
+int64_t tracyhost_load_fasta(const char* path, char* name, size_t name_cap, char* seq, size_t seq_cap) {
+  std::string n, s;
+  if (!loadSingleFasta(path, n, s)) return -1;
+  if (n.size() + 1 > name_cap || s.size() > seq_cap) return -2;
+  std::memcpy(name, n.c_str(), n.size() + 1);
+  std::memcpy(seq, s.data(), s.size());
+  return (int64_t)s.size();
+}
 
 // Seeded synthetic `tracy align` workload: ntraces cases, case i seeded with seed0 + i.  refs: ntraces x n
 // bytes; profiles: ntraces x 6 x mf floats (createProfile of the basecalled synthetic chromatogram; when

@@ -88,3 +88,102 @@ def synth_decompose_batch(seed0, nt, n, mf, nthreads=0):
                                           out["secondary"].ctypes.data_as(C.POINTER(C.c_uint8)),
                                           out["profiles"].ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(nthreads))
     return out
+
+
+def basecall_qual(trace, basecallpos, sigratio=0.33):
+    """basecall() including the estimated per-base qualities (abif.h:232-253)"""
+    trace = np.ascontiguousarray(trace, dtype=np.int32)
+    pos = np.ascontiguousarray(basecallpos, dtype=np.int32)
+    n = len(pos)
+    pri, sec, con = (C.create_string_buffer(n + 1) for _ in range(3))
+    bc = np.zeros(max(n, 1), dtype=np.int32)
+    q = np.zeros(max(n, 1), dtype=np.uint8)
+    fn = lib().tracyhost_basecall_qual
+    fn.restype = C.c_size_t
+    k = fn(trace.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(trace.shape[1]), pos.ctypes.data_as(C.POINTER(C.c_int32)),
+           C.c_size_t(n), C.c_float(sigratio), pri, sec, con, bc.ctypes.data_as(C.POINTER(C.c_int32)),
+           q.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return pri.raw[:k], sec.raw[:k], con.raw[:k], bc[:k].copy(), q[:k].copy()
+
+
+def _read_trace_with(l, prefix, path, with_format):
+    rd = getattr(l, prefix + "trace_read")
+    rd.restype = C.c_void_p
+    fmt = C.c_int32(-1)
+    h = rd(os.fsencode(path), C.byref(fmt)) if with_format else rd(os.fsencode(path))
+    if not h:
+        return None
+    h = C.c_void_p(h)
+    try:
+        ns, nc = C.c_uint64(0), C.c_uint64(0)
+        getattr(l, prefix + "trace_dims")(h, C.byref(ns), C.byref(nc))
+        sig = np.zeros((4, max(ns.value, 1)), dtype=np.int32)
+        pos = np.zeros(max(nc.value, 1), dtype=np.int32)
+        b1, b2 = C.create_string_buffer(nc.value + 1), C.create_string_buffer(nc.value + 1)
+        q = np.zeros(max(nc.value, 1), dtype=np.uint8)
+        getattr(l, prefix + "trace_get")(h, sig.ctypes.data_as(C.POINTER(C.c_int32)), pos.ctypes.data_as(C.POINTER(C.c_int32)), b1, b2,
+                                         q.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return dict(format=fmt.value, signal=sig[:, :ns.value].copy(), basecallpos=pos[:nc.value].copy(), basecalls1=b1.raw[:nc.value],
+                    basecalls2=b2.raw[:nc.value], qual=q[:nc.value].copy())
+    finally:
+        getattr(l, prefix + "trace_free")(h)
+
+
+def read_trace(path):
+    """ABIF (readab, abif.h:286-405) or SCF (readscf, scf.h:38-102) chromatogram -> dict, None when unreadable"""
+    return _read_trace_with(lib(), "tracyhost_", path, True)
+
+
+def write_abif(path, signal, peaks, primary, qual, secondary=b"", order=b"GATC"):
+    """the build's own ABIF writer: signal int32 [4][ns] in A,C,G,T order"""
+    signal = np.ascontiguousarray(signal, dtype=np.int32)
+    peaks = np.ascontiguousarray(peaks, dtype=np.int32)
+    qual = np.ascontiguousarray(qual, dtype=np.uint8)
+    rc = lib().tracyhost_writeab(os.fsencode(path), signal.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(signal.shape[1]),
+                                 peaks.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(len(peaks)), bytes(primary),
+                                 C.c_size_t(len(primary)), qual.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(len(qual)),
+                                 bytes(secondary) if secondary else None, C.c_size_t(len(secondary)), bytes(order))
+    if rc != 0:
+        raise IOError("tracy_amd: cannot write %s" % path)
+
+
+def trace_txt(outfile, trace, basecallpos, sigratio=0.33, left_trim=0, right_trim=0):
+    """basecall + traceTxtOut (abif.h:513-533)"""
+    trace = np.ascontiguousarray(trace, dtype=np.int32)
+    pos = np.ascontiguousarray(basecallpos, dtype=np.int32)
+    return lib().tracyhost_trace_txt(os.fsencode(outfile), trace.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(trace.shape[1]),
+                                     pos.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(len(pos)), C.c_float(sigratio),
+                                     C.c_uint32(left_trim), C.c_uint32(right_trim))
+
+
+def align_outputs(prefix, trace_stem, trace, basecallpos, sigratio, row0, row1, chrom, refslice, pos, forward, score, linelimit=60):
+    """writes <prefix>.align.fa / .txt / .json exactly as `tracy align` does (sage.h:313-345)"""
+    trace = np.ascontiguousarray(trace, dtype=np.int32)
+    bp = np.ascontiguousarray(basecallpos, dtype=np.int32)
+    return lib().tracyhost_align_outputs(os.fsencode(prefix), trace_stem.encode(), trace.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         C.c_size_t(trace.shape[1]), bp.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(len(bp)),
+                                         C.c_float(sigratio), bytes(row0), bytes(row1), C.c_size_t(len(row0)), chrom.encode(),
+                                         bytes(refslice), C.c_size_t(len(refslice)), C.c_uint32(pos), int(bool(forward)), int(score),
+                                         C.c_uint32(linelimit))
+
+
+def trim_trace(trace, basecallpos, sigratio, stringency):
+    trace = np.ascontiguousarray(trace, dtype=np.int32)
+    bp = np.ascontiguousarray(basecallpos, dtype=np.int32)
+    l, r = C.c_uint32(0), C.c_uint32(0)
+    lib().tracyhost_trim_trace(trace.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(trace.shape[1]), bp.ctypes.data_as(C.POINTER(C.c_int32)),
+                               C.c_size_t(len(bp)), C.c_float(sigratio), C.c_float(stringency), C.byref(l), C.byref(r))
+    return l.value, r.value
+
+
+def load_fasta(path):
+    """loadSingleFasta (fasta.h:54-95) -> (name, seq) or None"""
+    name = C.create_string_buffer(4096)
+    cap = os.path.getsize(path) + 16
+    seq = C.create_string_buffer(cap)
+    fn = lib().tracyhost_load_fasta
+    fn.restype = C.c_int64
+    n = fn(os.fsencode(path), name, C.c_size_t(4096), seq, C.c_size_t(cap))
+    if n < 0:
+        return None
+    return name.value.decode("latin1"), seq.raw[:n].decode()

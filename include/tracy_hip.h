@@ -235,7 +235,8 @@ typedef struct {
 typedef struct {
   tracyhip_breakpoint* bp;       /* [ntraces] breakpoint used by decomposeAlleles */
   int32_t* status;               /* [ntraces] 0 ok; -1 "Alignment of trace to reference failed!" (indigo.h:306-309);
-                                    -2 findHomozygousBreakpoint failed (:316).  Later outputs of such traces are unspecified. */
+                                    findHomozygousBreakpoint failed (:316): -2 "No valid alignment found ..." (decompose.h:81),
+                                    -3 "Alignment too short ..." (:92).  Later outputs of such traces are unspecified. */
   int32_t* score_fwd;
   int32_t* score_rev;
   uint8_t* forward;

@@ -143,3 +143,101 @@ def test_batch_manifest_and_errors(tmp_path):
     assert p.returncode == 255 and "larger than the trace" in p.stderr
     p = subprocess.run([CLI, "align"], capture_output=True, text=True)
     assert p.returncode == 255 and "Usage: tracy align" in p.stdout
+
+
+# ---- `decompose` ------------------------------------------------------------------------------------------
+def decompose_case(tmp, tag, seed, n=1500, mf=500, kind=0, reverse=False):
+    from tracy_amd import hostlib
+    ref, sig, pos, indel = hostlib.synth_decompose(seed, n, mf, 12, kind, 0.6)
+    trace_path = os.path.join(tmp, tag + ".ab1")
+    hostlib.write_abif(trace_path, np.minimum(sig, 32000), pos, b"N" * len(pos), np.full(len(pos), 30, np.uint8))
+    if reverse:
+        ref = so.revcomp(ref)
+    ref_path = os.path.join(tmp, tag + ".fa")
+    open(ref_path, "w").write(">amplicon_%s\n%s\n" % (tag, ref.decode()))
+    return trace_path, ref_path, indel
+
+
+def expected_decompose(trace_path, ref_path, trim=(50, 50), linelimit=60, variants=True):
+    import indigo_oracle as io
+    from tracy_amd import hostlib
+    t = hostlib.read_trace(trace_path)
+    tr, pos = t["signal"], t["basecallpos"]
+    pri, sec, con, bcpos, q = hostlib.basecall_qual(tr, pos, 0.33)
+    name, ref = so.load_single_fasta(ref_path)
+    w = io.decompose_trace(tr, bcpos, pri, sec, ref.encode(), SC, trim[0], trim[1])
+    assert w["status"] == 0
+    forward = bool(w["forward"])
+    refslice = ref.encode() if forward else so.revcomp(ref.encode())
+    p_t, s_t = io.trimmed_seq(w["primary"], *trim), io.trimmed_seq(w["secdecomp"], *trim)
+    rep = dict(a1a2=w["af"], dcp=w["dcp"], indelshift=bool(w["bp"].indelshift), breakpoint=int(w["bp"].breakpoint), var=[])
+    files = {".decomp": io.write_decomposition(w["dcp"])}
+    slices = []
+    for k, seq in enumerate((p_t, s_t)):
+        sl = refslice[w["slice_begin%d" % k]:w["slice_begin%d" % k] + w["slice_len%d" % k]]
+        slices.append(sl)
+        rows = orc.create_alignment_str(w["btr%d" % k], seq, sl)
+        rep["align%d" % (k + 1)] = rows
+        rep["score%d" % (k + 1)] = w["score%d" % k]
+        rep["rs%d" % (k + 1)] = dict(chr=name, pos=w["ref_pos%d" % k], forward=forward)
+        files[".align%d" % (k + 1)] = so.plot_alignment(rows[0], rows[1], name, w["ref_pos%d" % k], len(sl), forward, w["score%d" % k], linelimit,
+                                                         key=k + 1, a1a2=w["af"])
+    rows3 = orc.create_alignment_str(w["btr2"], p_t, s_t)
+    rep["align3"], rep["score3"] = rows3, w["score2"]
+    files[".align3"] = so.plot_alignment(rows3[0], rows3[1], "Alt2", 0, len(s_t), True, w["score2"], linelimit, key=3, a1a2=w["af"])
+    if not rep["indelshift"]:
+        rep["breakpoint"] = io.nearest_snp(trim[0], trim[1], w["primary"], w["secondary"], so.find_best_trace_section(w["secondary"], bcpos.tolist())[1])
+    if variants:
+        for k, seq in enumerate((p_t, s_t)):
+            rs = rep["rs%d" % (k + 1)]
+            if forward:
+                io.call_variants(rep["align%d" % (k + 1)][0], rep["align%d" % (k + 1)][1], name, rs["pos"], rep["var"])
+            else:
+                rseq, rsl = so.revcomp(seq), so.revcomp(slices[k])
+                _, btr = orc.gotoh_str(rseq, rsl, 1, 0, SC)
+                r0, r1 = orc.create_alignment_str(btr, rseq, rsl)
+                io.call_variants(r0, r1, name, rs["pos"], rep["var"])
+        io.sort_variants(rep["var"])
+    cfg = dict(trimLeft=trim[0], trimRight=trim[1], pratio=0.33, genome=os.path.basename(ref_path), input=os.path.basename(trace_path), qualCut=45)
+    files[".json"] = io.allele_json(cfg, tr, bcpos.tolist(), q.tolist(), w["primary"], w["secondary"], rep)
+    return files, rep, w
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+def test_decompose_cli_single_trace(tmp_path, reverse):
+    trace_path, ref_path, indel = decompose_case(str(tmp_path), "d%d" % reverse, 4200 + reverse, reverse=reverse)
+    prefix = str(tmp_path / "dec")
+    p = subprocess.run([CLI, "decompose", "-v", "-r", ref_path, "-o", prefix, trace_path], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    files, rep, w = expected_decompose(trace_path, ref_path)
+    for ext, txt in files.items():
+        assert open(prefix + ext).read() == txt, ext
+    assert rep["indelshift"] and indel != 0 and any(a == indel for a, b in rep["dcp"])
+    assert len(rep["var"]) > 0
+    recs = [ln.split("\t") for ln in open(prefix + ".vcf").read().split("\n") if ln and not ln.startswith("#")]
+    assert [(r[0], int(r[1]), r[3], r[4]) for r in recs] == [(v["chr"], v["pos"], v["ref"], v["alt"]) for v in rep["var"]]
+    assert [r[9].split(":")[0] for r in recs] == [{0: "0/0", 1: "0/1", 2: "1/1"}[v["gt"]] for v in rep["var"]]
+    steps = [ln.split("] ", 1)[1] for ln in p.stdout.strip().split("\n") if ln.startswith("[")][1:]
+    assert steps == ["Load ab1 file", "Find Reference Match", "Alignment", "InDel Search", "Decompose Chromatogram", "Estimate allelic fractions",
+                     "Allele-specific alignments", "Variant Calling", "Done."]
+
+
+def test_decompose_cli_batch_and_failures(tmp_path):
+    rows = []
+    for i in range(4):
+        t, r, _ = decompose_case(str(tmp_path), "m%d" % i, 5100 + i, n=1200 + 100 * i, mf=400 + 30 * i, kind=(1 if i == 2 else 0), reverse=bool(i % 2))
+        rows.append((t, r, str(tmp_path / ("dres%d" % i))))
+    man = str(tmp_path / "manifest.tsv")
+    open(man, "w").write("".join("\t".join(r) + "\n" for r in rows))
+    p = subprocess.run([CLI, "decompose", "--batch", man, "-l", "50"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    for t, r, pre in rows:
+        files, rep, w = expected_decompose(t, r, linelimit=50, variants=False)
+        for ext, txt in files.items():
+            assert open(pre + ext).read() == txt, (pre, ext)
+    # a reference far shorter than the trace cannot reach the score gate of indigo.h:303-309
+    rng = np.random.default_rng(1)
+    bad = str(tmp_path / "unrelated.fa")
+    open(bad, "w").write(">unrelated\n%s\n" % bytes(rng.choice(list(b"ACGT"), size=30).tolist()).decode())
+    p = subprocess.run([CLI, "decompose", "-r", bad, "-o", str(tmp_path / "bad"), rows[0][0]], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 255 and "Alignment of trace to reference failed!" in p.stderr

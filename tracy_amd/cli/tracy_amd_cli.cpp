@@ -1,14 +1,18 @@
-// tracy_amd_cli.cpp -- `tracy align` rebuilt on the C ABI: the option
-// set, progress lines, exit codes and the four output files of /root/reference/src/sage.h:58-356, plus
-// a --batch manifest mode that pushes many traces through ONE device batch (tracyhip_align_traces).
+// tracy_amd_cli.cpp -- `tracy align` and `tracy decompose` rebuilt on the C ABI (SURVEY.md section 8(f)
+// rank 1): the option sets, progress lines, exit codes and output files of /root/reference/src/sage.h:58-356
+// and indigo.h:42-455, plus a --batch manifest mode that pushes many traces through ONE device batch
+// (tracyhip_align_traces / tracyhip_decompose_traces).
 //
-//   tracy_amd_cli align [options] -r reference.fa|wildtype.ab1 trace.ab1
-//   tracy_amd_cli align [options] --batch manifest.tsv        lines: trace <TAB> reference <TAB> outprefix
+//   tracy_amd_cli align     [options] -r reference.fa|wildtype.ab1 trace.ab1
+//   tracy_amd_cli decompose [options] -r reference.fa trace.ab1
+//   tracy_amd_cli <cmd>     [options] --batch manifest.tsv     lines: trace <TAB> reference <TAB> outprefix
 //
 // Host stages (as in the reference): ABIF/SCF parsing, basecalling, trimming estimate, profiles, file
 // writers.  Device stages: every Gotoh DP, orientation, trimReferenceSlice, alignment rows.  There is no
 // CPU fallback: without a GPU the command fails with the library's error text.
-// Not built yet: references given as an indexed .fa.gz genome (FM-index seeding, fmindex.h:173-326).
+// Not built yet: references given as an indexed .fa.gz genome (FM-index seeding, fmindex.h:173-326); a
+// wildtype-trace reference for `decompose`; --annotate (needs the network).  Variants (-v) are written as
+// VCF text because htslib (BCF) is not available.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,17 +26,19 @@
 #include <vector>
 
 #include "../../include/tracy_hip.h"
+#include "../host/indigo_out.hpp"
 #include "../host/sage_out.hpp"
 
 using namespace tracy_amd;
 
 namespace {
 
-struct SageConfig {  // sage.h:37-56
-  uint16_t linelimit = 60, trimLeft = 50, trimRight = 50;
+struct SageConfig {  // sage.h:37-56 + the extra fields of IndigoConfig (indigo.h:16-40)
+  uint16_t linelimit = 60, trimLeft = 50, trimRight = 50, maxindel = 1000, madc = 5, qualCut = 45;
   float pratio = 0.33f, trimStringency = 0;
   int32_t gapopen = -10, gapext = -4, match = 3, mismatch = -5;
-  std::string outprefix = "out", genome, ab, batch;
+  bool callvariants = false;
+  std::string outprefix = "out", genome, ab, batch, annotate;
   int device = 0;
 };
 
@@ -49,6 +55,11 @@ struct Job {
   int32_t score = 0;
   AlignRows rows;
   bool ok = false;
+  // decompose
+  std::string primary, secondary, secdecomp;  // decomposed basecalls
+  int32_t status = 0;
+  tracyhip_decomp_status dstatus{};
+  AlleleReport rep;
 };
 
 std::string stamp() {  // boost::posix_time::to_simple_string(second_clock::local_time())
@@ -76,15 +87,17 @@ std::string stem(std::string const& p) {
   return (d == std::string::npos || d == 0) ? f : f.substr(0, d);
 }
 
-void usage(const char* cmd) {
-  std::cout << "Usage: tracy " << cmd << " [OPTIONS] -r genome.fa trace.ab1" << std::endl;
+void usage_options(bool decompose) {
   std::cout << "Generic options:\n"
                "  -? [ --help ]                    show help message\n"
                "  -r [ --reference ] arg           fasta or wildtype ab1 file\n"
                "  -p [ --pratio ] arg (=0.33)      peak ratio to call base\n"
                "  -b [ --batch ] arg               manifest: trace<TAB>reference<TAB>outprefix per line\n"
-               "  -d [ --device ] arg (=0)         GPU ordinal\n"
-               "\nAlignment options:\n"
+               "  -d [ --device ] arg (=0)         GPU ordinal\n";
+  if (decompose)
+    std::cout << "  -i [ --maxindel ] arg (=1000)    max. indel size in Sanger trace\n"
+                 "  -v [ --callVariants ]            call variants in trace\n";
+  std::cout << "\nAlignment options:\n"
                "  -g [ --gapopen ] arg (=-10)      gap open\n"
                "  -e [ --gapext ] arg (=-4)        gap extension\n"
                "  -m [ --match ] arg (=3)          match\n"
@@ -98,11 +111,18 @@ void usage(const char* cmd) {
                "  -o [ --outprefix ] arg (=out)    output prefix\n\n";
 }
 
+void usage(const char* cmd) {
+  std::cout << "Usage: tracy " << cmd << " [OPTIONS] -r genome.fa trace.ab1" << std::endl;
+  usage_options(false);
+}
+
 // returns 0 ok, 1 show usage
 int parse(int argc, char** argv, SageConfig& c) {
   static const std::map<std::string, char> longs = {
       {"help", '?'}, {"reference", 'r'}, {"pratio", 'p'}, {"batch", 'b'}, {"device", 'd'}, {"gapopen", 'g'}, {"gapext", 'e'},
-      {"match", 'm'}, {"mismatch", 'n'}, {"trim", 't'}, {"trimLeft", 'q'}, {"trimRight", 'u'}, {"linelimit", 'l'}, {"outprefix", 'o'}};
+      {"match", 'm'}, {"mismatch", 'n'}, {"trim", 't'}, {"trimLeft", 'q'}, {"trimRight", 'u'}, {"linelimit", 'l'}, {"outprefix", 'o'},
+      {"genome", 'r'}, {"maxindel", 'i'}, {"madc", 'c'}, {"qualCut", 'z'}, {"callVariants", 'v'}, {"annotate", 'a'}, {"kmer", 'k'},
+      {"support", 's'}};
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     char opt = 0;
@@ -123,6 +143,7 @@ int parse(int argc, char** argv, SageConfig& c) {
       continue;
     }
     if (opt == '?') return 1;
+    if (opt == 'v') { c.callvariants = true; continue; }
     if (!has_val) {
       if (i + 1 >= argc) { std::cerr << "the required argument for option '" << a << "' is missing" << std::endl; return 1; }
       val = argv[++i];
@@ -141,9 +162,15 @@ int parse(int argc, char** argv, SageConfig& c) {
       case 'u': c.trimRight = (uint16_t)std::atoi(val.c_str()); break;
       case 'l': c.linelimit = (uint16_t)std::atoi(val.c_str()); break;
       case 'o': c.outprefix = val; break;
+      case 'i': c.maxindel = (uint16_t)std::atoi(val.c_str()); break;
+      case 'c': c.madc = (uint16_t)std::atoi(val.c_str()); break;
+      case 'z': c.qualCut = (uint16_t)std::atoi(val.c_str()); break;
+      case 'a': c.annotate = val; break;
+      case 'k': case 's': break;  // k-mer anchoring only applies to indexed genomes
       default: std::cerr << "unrecognised option '" << a << "'" << std::endl; return 1;
     }
   }
+  if (c.maxindel < 1) c.maxindel = 1;
   return (c.ab.empty() && c.batch.empty()) ? 1 : 0;
 }
 
@@ -156,7 +183,7 @@ bool load_trace(std::string const& path, Trace& tr) {
 }
 
 // host stages up to the device batch (sage.h:141-207, 222-231, 261-277); returns the CLI exit code
-int prepare(SageConfig const& c, Job& j) {
+int prepare(SageConfig const& c, Job& j, bool decompose = false) {
   if (!load_trace(j.trace_path, j.tr)) return -1;
   if (j.tr.basecallpos.empty()) {
     std::cerr << "Trace file lacks basecalls!" << std::endl;
@@ -185,6 +212,10 @@ int prepare(SageConfig const& c, Job& j) {
   if (j.rs.filetype == 0) {
     std::cerr << "Indexed genomes (FM-index seeding) are not part of this build; pass a FASTA slice (<= 50 kbp) or a wildtype trace."
               << std::endl;
+    return -1;
+  }
+  if (decompose && j.rs.filetype == 2) {
+    std::cerr << "A wildtype-trace reference for decompose is not part of this build; pass a FASTA slice (<= 50 kbp)." << std::endl;
     return -1;
   }
   if (j.rs.filetype == 1) {
@@ -359,16 +390,9 @@ void write_outputs(SageConfig const& c, Job const& j) {
   traceAlignJsonOut(j.outprefix + ".json", padded, j.rs, j.rows);
 }
 
-int align_main(int argc, char** argv) {
-  SageConfig c;
-  if (parse(argc, argv, c)) {
-    usage(argv[0]);
-    return -1;
-  }
-  if (c.trimStringency > 9) c.trimStringency = 9;
-  std::vector<Job> jobs;
-  const bool batch = !c.batch.empty();
-  if (batch) {
+// one job from the command line, or one per manifest line; returns the CLI exit code
+int collect_jobs(SageConfig const& c, std::vector<Job>& jobs) {
+  if (!c.batch.empty()) {
     std::ifstream mf(c.batch.c_str());
     if (!mf) {
       std::cerr << "Manifest is missing: " << c.batch << std::endl;
@@ -392,6 +416,25 @@ int align_main(int argc, char** argv) {
     j.outprefix = c.outprefix;
     jobs.push_back(std::move(j));
   }
+  return 0;
+}
+
+void echo_command(int argc, char** argv) {
+  std::cout << stamp() << "tracy ";
+  for (int i = 0; i < argc; ++i) std::cout << argv[i] << ' ';
+  std::cout << std::endl;
+}
+
+int align_main(int argc, char** argv) {
+  SageConfig c;
+  if (parse(argc, argv, c)) {
+    usage(argv[0]);
+    return -1;
+  }
+  if (c.trimStringency > 9) c.trimStringency = 9;
+  std::vector<Job> jobs;
+  const bool batch = !c.batch.empty();
+  if (int rc = collect_jobs(c, jobs)) return rc;
   for (Job const& j : jobs) {
     if (!regular_nonempty(j.ref_path)) {
       std::cerr << "Reference file is missing: " << file_name(j.ref_path) << std::endl;
@@ -402,9 +445,7 @@ int align_main(int argc, char** argv) {
       return 1;
     }
   }
-  std::cout << stamp() << "tracy ";
-  for (int i = 0; i < argc; ++i) std::cout << argv[i] << ' ';
-  std::cout << std::endl;
+  echo_command(argc, argv);
 
   std::cout << stamp() << "Load ab1 file" << std::endl;
   int failed = 0;
@@ -445,13 +486,341 @@ int align_main(int argc, char** argv) {
   return failed ? 2 : 0;
 }
 
+
+// ---- `tracy decompose` (indigo.h:42-455) ----------------------------------------------------------------
+
+// char x char alignments through the C ABI: scores, rows
+bool align_strings(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<std::string> const& a1, std::vector<std::string> const& a2,
+                   std::vector<int32_t>& scores, std::vector<AlignRows>& rows) {
+  const uint32_t np = (uint32_t)a1.size();
+  scores.assign(np, 0);
+  rows.assign(np, AlignRows());
+  if (np == 0) return true;
+  std::vector<uint8_t> d1, d2;
+  std::vector<uint64_t> o1(np), o2(np), oo(np);
+  std::vector<uint32_t> l1(np), l2(np), olen(np);
+  uint64_t cap = 0;
+  for (uint32_t i = 0; i < np; ++i) {
+    o1[i] = d1.size(); l1[i] = (uint32_t)a1[i].size(); d1.insert(d1.end(), a1[i].begin(), a1[i].end());
+    o2[i] = d2.size(); l2[i] = (uint32_t)a2[i].size(); d2.insert(d2.end(), a2[i].begin(), a2[i].end());
+    oo[i] = cap; cap += (uint64_t)l1[i] + l2[i];
+  }
+  d1.push_back(0); d2.push_back(0);
+  tracyhip_pairs pr{};
+  pr.npairs = np;
+  pr.a1 = tracyhip_seqset{TRACYHIP_SEQ_CHAR, d1.data(), o1.data(), l1.data(), np};
+  pr.a2 = tracyhip_seqset{TRACYHIP_SEQ_CHAR, d2.data(), o2.data(), l2.data(), np};
+  std::vector<uint8_t> ops(cap ? cap : 1), r0(cap ? cap : 1), r1(cap ? cap : 1);
+  if (tracyhip_gotoh_align(ctx, &pr, &prm, TRACYHIP_MEM_HOST, scores.data(), ops.data(), oo.data(), olen.data()) != TRACYHIP_OK)
+    return gpu_fail("alignment");
+  if (tracyhip_alignment_rows(ctx, &pr, TRACYHIP_MEM_HOST, ops.data(), oo.data(), olen.data(), r0.data(), r1.data()) != TRACYHIP_OK)
+    return gpu_fail("alignment rows");
+  for (uint32_t i = 0; i < np; ++i) {
+    rows[i].row0.assign(reinterpret_cast<char*>(r0.data()) + oo[i], olen[i]);
+    rows[i].row1.assign(reinterpret_cast<char*>(r1.data()) + oo[i], olen[i]);
+  }
+  return true;
+}
+
+// rows of alignments whose op strings came back from tracyhip_decompose_traces
+bool rows_from_ops(tracyhip_ctx* ctx, std::vector<std::string> const& a1, std::vector<std::string> const& a2, std::vector<uint8_t> const& ops,
+                   std::vector<uint64_t> const& off, std::vector<uint32_t> const& len, std::vector<AlignRows>& rows) {
+  const uint32_t np = (uint32_t)a1.size();
+  rows.assign(np, AlignRows());
+  std::vector<uint8_t> d1, d2;
+  std::vector<uint64_t> o1(np), o2(np);
+  std::vector<uint32_t> l1(np), l2(np);
+  for (uint32_t i = 0; i < np; ++i) {
+    o1[i] = d1.size(); l1[i] = (uint32_t)a1[i].size(); d1.insert(d1.end(), a1[i].begin(), a1[i].end());
+    o2[i] = d2.size(); l2[i] = (uint32_t)a2[i].size(); d2.insert(d2.end(), a2[i].begin(), a2[i].end());
+  }
+  d1.push_back(0); d2.push_back(0);
+  tracyhip_pairs pr{};
+  pr.npairs = np;
+  pr.a1 = tracyhip_seqset{TRACYHIP_SEQ_CHAR, d1.data(), o1.data(), l1.data(), np};
+  pr.a2 = tracyhip_seqset{TRACYHIP_SEQ_CHAR, d2.data(), o2.data(), l2.data(), np};
+  std::vector<uint8_t> r0(ops.size()), r1(ops.size());
+  if (tracyhip_alignment_rows(ctx, &pr, TRACYHIP_MEM_HOST, ops.data(), off.data(), len.data(), r0.data(), r1.data()) != TRACYHIP_OK)
+    return gpu_fail("alignment rows");
+  for (uint32_t i = 0; i < np; ++i) {
+    rows[i].row0.assign(reinterpret_cast<char*>(r0.data()) + off[i], len[i]);
+    rows[i].row1.assign(reinterpret_cast<char*>(r1.data()) + off[i], len[i]);
+  }
+  return true;
+}
+
+// indigo.h:190-388 for every job sharing one (trimLeft, trimRight): the whole chain runs on the device
+bool decompose_group(tracyhip_ctx* ctx, SageConfig const& c, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
+  const uint32_t nt = (uint32_t)jobs.size();
+  std::vector<float> prof;
+  std::vector<uint8_t> refs, pri, sec;
+  std::vector<int32_t> sig, pos;
+  std::vector<uint64_t> poff(nt), roff(nt), soff(nt), boff(nt), dcpoff(nt);
+  std::vector<uint32_t> plen(nt), rlen(nt), ns(nt), blen(nt);
+  const uint32_t dcap = 2u * c.maxindel + 2;
+  std::vector<uint64_t> ooff[3];
+  uint64_t ocap[3] = {0, 0, 0};
+  for (int k = 0; k < 3; ++k) ooff[k].resize(nt);
+  for (uint32_t i = 0; i < nt; ++i) {
+    Job& j = *jobs[i];
+    poff[i] = prof.size(); plen[i] = (uint32_t)j.full.cols;
+    prof.insert(prof.end(), j.full.v.begin(), j.full.v.end());
+    roff[i] = refs.size(); rlen[i] = (uint32_t)j.fasta.size();
+    refs.insert(refs.end(), j.fasta.begin(), j.fasta.end());
+    soff[i] = sig.size(); ns[i] = (uint32_t)j.tr.traceACGT[0].size();
+    for (int k = 0; k < 4; ++k) {
+      std::vector<int32_t> ch = j.tr.traceACGT[k];
+      ch.resize(ns[i], 0);
+      sig.insert(sig.end(), ch.begin(), ch.end());
+    }
+    boff[i] = pos.size(); blen[i] = (uint32_t)j.bc.bcPos.size();
+    pos.insert(pos.end(), j.bc.bcPos.begin(), j.bc.bcPos.end());
+    pri.insert(pri.end(), j.bc.primary.begin(), j.bc.primary.end());
+    sec.insert(sec.end(), j.bc.secondary.begin(), j.bc.secondary.end());
+    dcpoff[i] = (uint64_t)i * dcap;
+    for (int k = 0; k < 3; ++k) {
+      ooff[k][i] = ocap[k];
+      ocap[k] += (uint64_t)blen[i] + (k < 2 ? rlen[i] : blen[i]);
+    }
+  }
+  tracyhip_decompose_job job{};
+  job.ntraces = nt;
+  job.profiles = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, prof.data(), poff.data(), plen.data(), nt};
+  job.bc = tracyhip_basecalls{nt, sig.data(), soff.data(), ns.data(), pos.data(), pri.data(), sec.data(), boff.data(), blen.data()};
+  job.refs = tracyhip_seqset{TRACYHIP_SEQ_CHAR, refs.data(), roff.data(), rlen.data(), nt};
+  job.dprm = tracyhip_decomp_params{(int32_t)jobs[0]->trimLeft, (int32_t)jobs[0]->trimRight, (int32_t)c.maxindel, (int32_t)c.madc};
+  std::vector<tracyhip_breakpoint> bp(nt);
+  std::vector<int32_t> status(nt), sf(nt), sr(nt), strim(nt), dci((size_t)nt * dcap), dce((size_t)nt * dcap);
+  std::vector<uint8_t> fwd(nt), sd(pri.size() ? pri.size() : 1);
+  std::vector<tracyhip_decomp_status> dst(nt);
+  std::vector<double> fr(2 * (size_t)nt);
+  std::vector<uint32_t> sb[2], sl[2], rp[2], olen[3];
+  std::vector<int32_t> sc[3];
+  std::vector<uint8_t> ops[3];
+  tracyhip_decompose_result res{};
+  res.bp = bp.data(); res.status = status.data(); res.score_fwd = sf.data(); res.score_rev = sr.data(); res.forward = fwd.data();
+  res.score_trim = strim.data(); res.dcp_indel = dci.data(); res.dcp_err = dce.data(); res.dcp_offset = dcpoff.data();
+  res.dstatus = dst.data(); res.secdecomp = sd.data(); res.fractions = fr.data();
+  for (int k = 0; k < 3; ++k) {
+    if (k < 2) {
+      sb[k].resize(nt); sl[k].resize(nt); rp[k].resize(nt);
+      res.slice_begin[k] = sb[k].data(); res.slice_len[k] = sl[k].data(); res.ref_pos[k] = rp[k].data();
+    }
+    sc[k].resize(nt); olen[k].resize(nt); ops[k].resize(ocap[k] ? ocap[k] : 1);
+    res.score[k] = sc[k].data(); res.ops[k] = ops[k].data(); res.ops_offset[k] = ooff[k].data(); res.ops_len[k] = olen[k].data();
+  }
+  if (tracyhip_decompose_traces(ctx, &job, &prm, TRACYHIP_MEM_HOST, &res) != TRACYHIP_OK) return gpu_fail("decompose");
+
+  std::vector<std::string> a1[3], a2[3];
+  for (uint32_t i = 0; i < nt; ++i) {
+    Job& j = *jobs[i];
+    j.status = status[i];
+    j.dstatus = dst[i];
+    j.primary.assign(reinterpret_cast<char*>(pri.data()) + boff[i], blen[i]);
+    j.secondary.assign(reinterpret_cast<char*>(sec.data()) + boff[i], blen[i]);
+    j.secdecomp.assign(reinterpret_cast<char*>(sd.data()) + boff[i], blen[i]);
+    j.rs.forward = fwd[i] != 0;
+    j.rs.refslice = j.fasta;
+    if (!j.rs.forward) reverseComplement(j.rs.refslice);
+    j.rs.pos = 0;
+    AlleleReport& r = j.rep;
+    r.bp.indelshift = bp[i].indelshift != 0;
+    r.bp.traceleft = bp[i].traceleft != 0;
+    r.bp.breakpoint = bp[i].breakpoint;
+    r.bp.bestDiff = bp[i].best_diff;
+    r.a1a2 = std::make_pair(fr[2 * i], fr[2 * i + 1]);
+    r.dcp.clear();
+    for (uint32_t k = 0; k < dst[i].dcp_n; ++k) r.dcp.emplace_back(dci[dcpoff[i] + k], dce[dcpoff[i] + k]);
+    const std::string p_t = trimmedSeq(j.primary, j.trimLeft, j.trimRight), s_t = trimmedSeq(j.secdecomp, j.trimLeft, j.trimRight);
+    ReferenceSlice* slot[2] = {&r.rs1, &r.rs2};
+    for (int k = 0; k < 2; ++k) {
+      *slot[k] = j.rs;
+      const bool usable = status[i] == 0;
+      slot[k]->refslice = usable ? j.rs.refslice.substr(sb[k][i], sl[k][i]) : std::string();
+      slot[k]->pos = usable ? rp[k][i] : 0;
+      a1[k].push_back(k == 0 ? p_t : s_t);
+      a2[k].push_back(slot[k]->refslice);
+    }
+    a1[2].push_back(p_t);
+    a2[2].push_back(s_t);
+    r.a1Score = sc[0][i]; r.a2Score = sc[1][i]; r.a3Score = sc[2][i];
+    if (status[i] != 0)
+      for (int k = 0; k < 3; ++k) olen[k][i] = 0;
+  }
+  for (int k = 0; k < 3; ++k) {
+    std::vector<AlignRows> rows;
+    if (!rows_from_ops(ctx, a1[k], a2[k], ops[k], ooff[k], olen[k], rows)) return false;
+    for (uint32_t i = 0; i < nt; ++i) (k == 0 ? jobs[i]->rep.align1 : k == 1 ? jobs[i]->rep.align2 : jobs[i]->rep.align3) = rows[i];
+  }
+  return true;
+}
+
+// variants of both alleles (indigo.h:393-421); reverse-strand traces are re-aligned as reverse complements
+bool call_variants(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
+  std::vector<std::string> s1, s2;
+  std::vector<ReferenceSlice> rev;
+  std::vector<Job*> owner;
+  for (Job* jp : jobs) {
+    Job& j = *jp;
+    AlleleReport& r = j.rep;
+    if (j.rs.forward) {
+      callVariants(r.align1, r.rs1, r.var);
+      callVariants(r.align2, r.rs2, r.var);
+      continue;
+    }
+    const std::string seq[2] = {trimmedSeq(j.primary, j.trimLeft, j.trimRight), trimmedSeq(j.secdecomp, j.trimLeft, j.trimRight)};
+    ReferenceSlice const* rs[2] = {&r.rs1, &r.rs2};
+    for (int k = 0; k < 2; ++k) {
+      std::string q = seq[k];
+      reverseComplement(q);
+      ReferenceSlice rr;
+      reverseReferenceSlice(*rs[k], rr);
+      s1.push_back(q);
+      s2.push_back(rr.refslice);
+      rev.push_back(rr);
+      owner.push_back(jp);
+    }
+  }
+  std::vector<int32_t> scores;
+  std::vector<AlignRows> rows;
+  if (!align_strings(ctx, prm, s1, s2, scores, rows)) return false;
+  for (std::size_t i = 0; i < rows.size(); ++i) callVariants(rows[i], rev[i], owner[i]->rep.var);
+  for (Job* jp : jobs) std::sort(jp->rep.var.begin(), jp->rep.var.end());
+  return true;
+}
+
+// indigo.h:340-343, 359-387, 389-394, 436-442
+void write_decompose_outputs(SageConfig const& c, Job& j) {
+  AlleleReport& r = j.rep;
+  {
+    std::ofstream f((j.outprefix + ".decomp").c_str());
+    writeDecomposition(f, r.dcp);
+  }
+  ReferenceSlice secrs;
+  secrs.refslice = trimmedSeq(j.secdecomp, j.trimLeft, j.trimRight);
+  secrs.forward = true;
+  secrs.pos = 0;
+  secrs.chr = "Alt2";
+  const int32_t score[3] = {r.a1Score, r.a2Score, r.a3Score};
+  AlignRows const* al[3] = {&r.align1, &r.align2, &r.align3};
+  ReferenceSlice const* rs[3] = {&r.rs1, &r.rs2, &secrs};
+  for (int k = 0; k < 3; ++k) {
+    std::ofstream f((j.outprefix + ".align" + std::to_string(k + 1)).c_str());
+    plotAlignment(f, *al[k], *rs[k], k + 1, score[k], r.a1a2, c.linelimit);
+  }
+  // the report shows the decomposed basecalls
+  BaseCalls bc = j.bc;
+  bc.primary = j.primary;
+  bc.secondary = j.secondary;
+  bc.secDecompose = j.secdecomp;
+  if (!r.bp.indelshift) r.bp.breakpoint = nearestSNP(j.trimLeft, j.trimRight, bc, findBestTraceSection(bc));  // centre on the first SNP
+  ReportConfig rc;
+  rc.trimLeft = (uint16_t)j.trimLeft;
+  rc.trimRight = (uint16_t)j.trimRight;
+  rc.qualCut = c.qualCut;
+  rc.pratio = c.pratio;
+  rc.genomeName = file_name(j.ref_path);
+  rc.inputName = file_name(j.trace_path);
+  if (c.callvariants) {
+    std::ofstream f((j.outprefix + ".vcf").c_str());
+    vcfTextOutput(f, rc, bc, r.var, j.rs);
+  }
+  std::ofstream f((j.outprefix + ".json").c_str());
+  traceAlleleAlignJsonOut(f, rc, bc, j.tr, r);
+}
+
+int decompose_main(int argc, char** argv) {
+  SageConfig c;
+  if (parse(argc, argv, c)) {
+    std::cout << "Usage: tracy " << argv[0] << " [OPTIONS] trace.ab1" << std::endl;
+    usage_options(true);
+    return -1;
+  }
+  if (c.trimStringency > 9) c.trimStringency = 9;
+  if (!c.annotate.empty()) {
+    std::cerr << "Variant annotation needs the Ensembl REST service and is not part of this build." << std::endl;
+    return -1;
+  }
+  std::vector<Job> jobs;
+  const bool batch = !c.batch.empty();
+  if (int rc = collect_jobs(c, jobs)) return rc;
+  for (Job const& j : jobs) {
+    if (!regular_nonempty(j.trace_path)) {
+      std::cerr << "Trace file is missing: " << j.trace_path << std::endl;
+      return 1;
+    }
+    if (!regular_nonempty(j.ref_path)) {
+      std::cerr << "Reference file is missing: " << file_name(j.ref_path) << std::endl;
+      return 1;
+    }
+  }
+  echo_command(argc, argv);
+  std::cout << stamp() << "Load ab1 file" << std::endl;
+  int failed = 0;
+  for (Job& j : jobs) {
+    const int rc = prepare(c, j, true);
+    if (rc != 0) {
+      if (!batch) return rc;
+      std::cerr << "skipping " << j.trace_path << std::endl;
+      ++failed;
+    } else {
+      j.ok = true;
+    }
+  }
+  std::cout << stamp() << "Find Reference Match" << std::endl;
+  Device dev;
+  if (tracyhip_create(c.device, &dev.ctx) != TRACYHIP_OK) {
+    gpu_fail("no usable GPU");
+    return -1;
+  }
+  tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};
+  std::map<std::pair<uint32_t, uint32_t>, std::vector<Job*>> groups;
+  for (Job& j : jobs)
+    if (j.ok) groups[std::make_pair(j.trimLeft, j.trimRight)].push_back(&j);
+  std::cout << stamp() << "Alignment" << std::endl;
+  for (auto& g : groups)
+    if (!decompose_group(dev.ctx, c, prm, g.second)) return -1;
+  std::cout << stamp() << "InDel Search" << std::endl;
+  std::vector<Job*> good;
+  for (Job& j : jobs) {
+    if (!j.ok) continue;
+    if (j.status != 0) {
+      if (j.status == -1) std::cerr << "Alignment of trace to reference failed!" << std::endl;
+      else if (j.status == -2) std::cerr << "No valid alignment found between consensus and reference!" << std::endl;
+      else std::cerr << "Alignment too short between consensus and reference!" << std::endl;
+      if (!batch) return -1;
+      std::cerr << "skipping " << j.trace_path << std::endl;
+      j.ok = false;
+      ++failed;
+      continue;
+    }
+    good.push_back(&j);
+  }
+  std::cout << stamp() << "Decompose Chromatogram" << std::endl;
+  for (Job* j : good) {
+    if (j->dstatus.kind == 1)
+      std::cout << "Complex mutation, decomposition: ins: " << j->dstatus.best_ins << ", del: " << j->dstatus.best_del
+                << ", error: " << j->dstatus.best_fr << std::endl;
+    else if (j->dstatus.kind == 2)
+      std::cout << "No InDel detected, traverse the whole alignment." << std::endl;
+  }
+  std::cout << stamp() << "Estimate allelic fractions" << std::endl;
+  std::cout << stamp() << "Allele-specific alignments" << std::endl;
+  if (c.callvariants) {
+    std::cout << stamp() << "Variant Calling" << std::endl;
+    if (!call_variants(dev.ctx, prm, good)) return -1;
+  }
+  for (Job* j : good) write_decompose_outputs(c, *j);
+  std::cout << stamp() << "Done." << std::endl;
+  return failed ? 2 : 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (argc < 2 || std::strcmp(argv[1], "align") != 0) {
-    std::cout << "Usage: tracy_amd_cli align [OPTIONS] -r genome.fa trace.ab1" << std::endl;
-    std::cout << "       tracy_amd_cli align [OPTIONS] --batch manifest.tsv" << std::endl;
-    return argc < 2 ? 0 : 1;
-  }
-  return align_main(argc - 1, argv + 1);
+  if (argc >= 2 && std::strcmp(argv[1], "align") == 0) return align_main(argc - 1, argv + 1);
+  if (argc >= 2 && std::strcmp(argv[1], "decompose") == 0) return decompose_main(argc - 1, argv + 1);
+  std::cout << "Usage: tracy_amd_cli align|decompose [OPTIONS] -r genome.fa trace.ab1" << std::endl;
+  std::cout << "       tracy_amd_cli align|decompose [OPTIONS] --batch manifest.tsv" << std::endl;
+  return argc < 2 ? 0 : 1;
 }

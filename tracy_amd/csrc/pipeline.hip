@@ -665,7 +665,7 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
   HIP_TRY(hipMemcpyAsync(h_hst.data(), b_hst.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   for (uint32_t t = 0; t < nt; ++t)
-    if (h_status[t] == 0 && h_hst[t] != 1) h_status[t] = -2;
+    if (h_status[t] == 0 && h_hst[t] != 1) h_status[t] = h_hst[t] == 0 ? -2 : -3;
 
   // ---- 6. allele-specific alignments (indigo.h:355-387): string x string Gotoh ----
   // allele k in {0: primary, 1: secDecompose}: gotoh(seq, rs.refslice) -> trimReferenceSlice -> gotoh(seq, slice)

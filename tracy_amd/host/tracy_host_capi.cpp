@@ -6,6 +6,7 @@
 #include <thread>
 #include <vector>
 
+#include "indigo_out.hpp"
 #include "sage_out.hpp"
 #include "trace_io.hpp"
 #include "tracy_host.hpp"
@@ -228,6 +229,115 @@ int32_t tracyhost_align_outputs(const char* prefix, const char* trace_stem, cons
   }
   plotAlignment(pre + ".txt", rows, rs, score, linelimit);
   traceAlignJsonOut(pre + ".json", padded, rs, rows);
+  return 0;
+}
+
+// the files `tracy decompose` writes after the device chain (indigo.h:340-442): <prefix>.decomp, .align1,
+// .align2, .align3, .json and, with call_variants, <prefix>.vcf.  The trace is given as arrays (basecalled
+// here, then overlaid with the decomposed calls); alignments as gapped rows.
+struct tracyhost_decompose_report {
+  const char* prefix;
+  const char* genome_name;
+  const char* input_name;
+  const int32_t* trace;
+  uint64_t nsamples;
+  const int32_t* basecallpos;
+  uint64_t npos;
+  float pratio;
+  uint32_t trim_left, trim_right, qual_cut, linelimit;
+  const char* primary;    // decomposed calls, ncalls bytes each
+  const char* secondary;
+  const char* secdecomp;
+  uint64_t ncalls;
+  const char* rows[3][2]; // final1, final2, final3
+  uint64_t cols[3];
+  const char* var_rows[2][2];  // alignments variants are called on (the reverse-complement ones for reverse traces)
+  uint64_t var_cols[2];
+  int32_t call_variants;
+  const char* chr;
+  int32_t forward;
+  uint32_t pos[2];        // allele1.pos, allele2.pos
+  uint64_t slice_len[2];  // allele1/2 .refslice.size()
+  uint64_t ref_len;       // rs.refslice.size()
+  int32_t score[3];
+  int32_t indelshift;
+  uint32_t breakpoint;
+  double a1, a2;
+  const int32_t* dcp_indel;
+  const int32_t* dcp_err;
+  uint64_t dcp_n;
+};
+
+int32_t tracyhost_decompose_outputs(const tracyhost_decompose_report* rp) {
+  Trace tr;
+  tr.traceACGT.resize(4);
+  for (int k = 0; k < 4; ++k) tr.traceACGT[k].assign(rp->trace + k * rp->nsamples, rp->trace + (k + 1) * rp->nsamples);
+  tr.basecallpos.assign(rp->basecallpos, rp->basecallpos + rp->npos);
+  BaseCalls bc;
+  basecall(tr, bc, rp->pratio);
+  if (bc.bcPos.size() != rp->ncalls) return -1;
+  bc.primary.assign(rp->primary, rp->ncalls);
+  bc.secondary.assign(rp->secondary, rp->ncalls);
+  bc.secDecompose.assign(rp->secdecomp, rp->ncalls);
+  AlleleReport r;
+  AlignRows* al[3] = {&r.align1, &r.align2, &r.align3};
+  for (int k = 0; k < 3; ++k) {
+    al[k]->row0.assign(rp->rows[k][0], rp->cols[k]);
+    al[k]->row1.assign(rp->rows[k][1], rp->cols[k]);
+  }
+  ReferenceSlice rs;
+  rs.chr = rp->chr;
+  rs.forward = rp->forward != 0;
+  rs.filetype = 1;
+  rs.refslice.assign(rp->ref_len, 'N');
+  ReferenceSlice* slot[2] = {&r.rs1, &r.rs2};
+  for (int k = 0; k < 2; ++k) {
+    *slot[k] = rs;
+    slot[k]->pos = rp->pos[k];
+    slot[k]->refslice.assign(rp->slice_len[k], 'N');
+  }
+  r.a1Score = rp->score[0]; r.a2Score = rp->score[1]; r.a3Score = rp->score[2];
+  r.bp.indelshift = rp->indelshift != 0;
+  r.bp.breakpoint = rp->breakpoint;
+  r.a1a2 = std::make_pair(rp->a1, rp->a2);
+  for (uint64_t i = 0; i < rp->dcp_n; ++i) r.dcp.emplace_back(rp->dcp_indel[i], rp->dcp_err[i]);
+  const std::string pre(rp->prefix);
+  {
+    std::ofstream f((pre + ".decomp").c_str());
+    writeDecomposition(f, r.dcp);
+  }
+  ReferenceSlice secrs;
+  secrs.refslice = trimmedSeq(bc.secDecompose, rp->trim_left, rp->trim_right);
+  secrs.forward = true;
+  secrs.chr = "Alt2";
+  ReferenceSlice const* prs[3] = {&r.rs1, &r.rs2, &secrs};
+  for (int k = 0; k < 3; ++k) {
+    std::ofstream f((pre + ".align" + std::to_string(k + 1)).c_str());
+    plotAlignment(f, *al[k], *prs[k], k + 1, rp->score[k], r.a1a2, rp->linelimit);
+  }
+  if (!r.bp.indelshift) r.bp.breakpoint = nearestSNP(rp->trim_left, rp->trim_right, bc, findBestTraceSection(bc));
+  ReportConfig rc;
+  rc.trimLeft = (uint16_t)rp->trim_left;
+  rc.trimRight = (uint16_t)rp->trim_right;
+  rc.qualCut = (uint16_t)rp->qual_cut;
+  rc.pratio = rp->pratio;
+  rc.genomeName = rp->genome_name;
+  rc.inputName = rp->input_name;
+  if (rp->call_variants) {
+    for (int k = 0; k < 2; ++k) {
+      AlignRows v;
+      v.row0.assign(rp->var_rows[k][0], rp->var_cols[k]);
+      v.row1.assign(rp->var_rows[k][1], rp->var_cols[k]);
+      ReferenceSlice vrs = *slot[k];
+      if (!rs.forward) reverseReferenceSlice(*slot[k], vrs);
+      callVariants(v, vrs, r.var);
+    }
+    std::sort(r.var.begin(), r.var.end());
+    std::ofstream f((pre + ".vcf").c_str());
+    vcfTextOutput(f, rc, bc, r.var, rs);
+  }
+  std::ofstream f((pre + ".json").c_str());
+  traceAlleleAlignJsonOut(f, rc, bc, tr, r);
   return 0;
 }
 

@@ -187,3 +187,44 @@ def load_fasta(path):
     if n < 0:
         return None
     return name.value.decode("latin1"), seq.raw[:n].decode()
+
+
+class DecomposeReport(C.Structure):
+    _fields_ = [("prefix", C.c_char_p), ("genome_name", C.c_char_p), ("input_name", C.c_char_p), ("trace", C.POINTER(C.c_int32)),
+                ("nsamples", C.c_uint64), ("basecallpos", C.POINTER(C.c_int32)), ("npos", C.c_uint64), ("pratio", C.c_float),
+                ("trim_left", C.c_uint32), ("trim_right", C.c_uint32), ("qual_cut", C.c_uint32), ("linelimit", C.c_uint32),
+                ("primary", C.c_char_p), ("secondary", C.c_char_p), ("secdecomp", C.c_char_p), ("ncalls", C.c_uint64),
+                ("rows", (C.c_char_p * 2) * 3), ("cols", C.c_uint64 * 3), ("var_rows", (C.c_char_p * 2) * 2), ("var_cols", C.c_uint64 * 2),
+                ("call_variants", C.c_int32), ("chr", C.c_char_p), ("forward", C.c_int32), ("pos", C.c_uint32 * 2),
+                ("slice_len", C.c_uint64 * 2), ("ref_len", C.c_uint64), ("score", C.c_int32 * 3), ("indelshift", C.c_int32),
+                ("breakpoint", C.c_uint32), ("a1", C.c_double), ("a2", C.c_double), ("dcp_indel", C.POINTER(C.c_int32)),
+                ("dcp_err", C.POINTER(C.c_int32)), ("dcp_n", C.c_uint64)]
+
+
+def decompose_outputs(prefix, genome_name, input_name, trace, basecallpos, pratio, trims, qual_cut, linelimit, primary, secondary, secdecomp,
+                      rows, var_rows, chrom, forward, pos, slice_len, ref_len, scores, indelshift, breakpoint, a1a2, dcp):
+    """writes the files of `tracy decompose` (indigo.h:340-442); rows: 3 x (row0, row1); var_rows: None or 2 x (row0, row1)"""
+    trace = np.ascontiguousarray(trace, dtype=np.int32)
+    bp = np.ascontiguousarray(basecallpos, dtype=np.int32)
+    di = np.array([a for a, _ in dcp], dtype=np.int32)
+    de = np.array([b for _, b in dcp], dtype=np.int32)
+    r = DecomposeReport()
+    r.prefix, r.genome_name, r.input_name, r.chr = os.fsencode(prefix), genome_name.encode(), input_name.encode(), chrom.encode()
+    r.trace, r.nsamples = trace.ctypes.data_as(C.POINTER(C.c_int32)), trace.shape[1]
+    r.basecallpos, r.npos, r.pratio = bp.ctypes.data_as(C.POINTER(C.c_int32)), len(bp), pratio
+    r.trim_left, r.trim_right, r.qual_cut, r.linelimit = trims[0], trims[1], qual_cut, linelimit
+    r.primary, r.secondary, r.secdecomp, r.ncalls = bytes(primary), bytes(secondary), bytes(secdecomp), len(primary)
+    for k in range(3):
+        r.rows[k][0], r.rows[k][1], r.cols[k] = bytes(rows[k][0]), bytes(rows[k][1]), len(rows[k][0])
+    r.call_variants = 1 if var_rows else 0
+    if var_rows:
+        for k in range(2):
+            r.var_rows[k][0], r.var_rows[k][1], r.var_cols[k] = bytes(var_rows[k][0]), bytes(var_rows[k][1]), len(var_rows[k][0])
+    r.forward, r.ref_len, r.indelshift, r.breakpoint = int(bool(forward)), ref_len, int(bool(indelshift)), breakpoint
+    for k in range(2):
+        r.pos[k], r.slice_len[k] = pos[k], slice_len[k]
+    for k in range(3):
+        r.score[k] = scores[k]
+    r.a1, r.a2 = a1a2
+    r.dcp_indel, r.dcp_err, r.dcp_n = di.ctypes.data_as(C.POINTER(C.c_int32)), de.ctypes.data_as(C.POINTER(C.c_int32)), len(dcp)
+    return lib().tracyhost_decompose_outputs(C.byref(r))

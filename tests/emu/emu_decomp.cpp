@@ -12,7 +12,7 @@ extern "C" {
 
 int emu_decompose(const uint8_t* row0, const uint8_t* row1, uint32_t L, uint8_t* primary, uint8_t* secondary, uint32_t nbc,
                   uint32_t breakpoint, uint32_t refslice_len, int32_t trimLeft, int32_t trimRight, int32_t maxindel,
-                  int32_t madc, int32_t* dcp_indel, int32_t* dcp_err, int32_t* out6) {
+                  int32_t madc, int32_t* dcp_indel, int32_t* dcp_err, int32_t* out6, int32_t force_bytewise) {
   DecompDesc d{0, 0, 0, L, nbc, refslice_len, breakpoint};
   DecompOut out{};
   DecompArgs a{};
@@ -22,14 +22,17 @@ int emu_decompose(const uint8_t* row0, const uint8_t* row1, uint32_t L, uint8_t*
   a.ntraces = 1;
   static DecompShared sh;
   std::memset(&sh, 0, sizeof(sh));
-  decomp_phase_walk(a, d, sh);
-  for (uint32_t l = 0; l < 64; ++l) decomp_phase_scan(a, d, sh, l);
-  decomp_phase_pick(a, d, sh, out);
-  if (sh.ndel == 0 && sh.nins == 0) {
-    for (uint32_t l = 0; l < 64; ++l) decomp_phase_complex(a, d, sh, l);
-    decomp_phase_complex_reduce(sh, out);
+  for (int st = 0; st < kDecompSteps; ++st) {
+    if (decomp_step_all_lanes(st)) {
+      // every lane keeps its own copy of `out` on the device; lane 0's copy is the one that is stored
+      DecompOut scratch = out;
+      for (uint32_t l = 1; l < 64; ++l) { DecompOut o = scratch; decomp_step(st, a, d, sh, o, l); }
+      decomp_step(st, a, d, sh, out, 0);
+    } else {
+      decomp_step(st, a, d, sh, out, 0);
+    }
+    if (force_bytewise && st == 4) sh.exotic = 1;
   }
-  for (uint32_t l = 0; l < 64; ++l) decomp_phase_apply(a, d, sh, out, l);
   out6[0] = out.kind; out6[1] = out.bestIns; out6[2] = out.bestDel; out6[3] = out.bestFR; out6[4] = (int32_t)out.dcp_n;
   return 0;
 }

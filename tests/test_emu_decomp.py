@@ -32,7 +32,7 @@ def cases():
     return case_list()
 
 
-def run_emu_decompose(emu, c, maxindel=1000, madc=5):
+def run_emu_decompose(emu, c, maxindel=1000, madc=5, bytewise=0):
     r0, r1 = c["rows"]
     pri = C.create_string_buffer(c["pri"], len(c["pri"]) + 1)
     sec = C.create_string_buffer(c["sec"], len(c["sec"]) + 1)
@@ -40,7 +40,7 @@ def run_emu_decompose(emu, c, maxindel=1000, madc=5):
     de = (C.c_int32 * (2 * maxindel + 4))()
     out = (C.c_int32 * 6)()
     emu.emu_decompose(r0, r1, len(r0), pri, sec, len(c["pri"]), c["bp"].breakpoint, len(c["ref"]), 50, 50, maxindel, madc,
-                      di, de, out)
+                      di, de, out, bytewise)
     n = out[4]
     return pri.raw[:len(c["pri"])], sec.raw[:len(c["sec"])], [(di[i], de[i]) for i in range(n)], tuple(out[:4])
 
@@ -50,6 +50,7 @@ def test_decompose_phases_match_oracle(emu, cases):
     for c in cases:
         want = oracle_decompose(c)
         got = run_emu_decompose(emu, c)
+        assert got == run_emu_decompose(emu, c, bytewise=1)  # bit-set scans == byte-wise fallback
         assert got[0] == want["pri"] and got[1] == want["sec"]
         assert got[2] == want["dcp"]
         assert got[3][0] == want["status"][0]
@@ -63,6 +64,73 @@ def test_decompose_phases_match_oracle(emu, cases):
         want = orc.decompose_alleles(c["rows"][0], c["rows"][1], c["pri"], c["sec"], c["bp"], len(c["ref"]), 50, 50, mi, madc)
         got = run_emu_decompose(emu, c, mi, madc)
         assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2] and got[3][0] == want[3][0]
+
+
+def test_random_alignments_stress_the_scans(emu):
+    """random gapped alignments with IUPAC secondaries, exotic reference letters, breakpoints anywhere (also never
+    reached), small and large trims: every path of the scans (simple, complex, none; bit sets and byte-wise)"""
+    rng = np.random.default_rng(2024)
+    kinds = {}
+    for it in range(60):
+        nb = int(rng.integers(60, 420))
+        tl, tr = (int(rng.integers(0, 30)), int(rng.integers(0, 30))) if it % 3 else (50, 50)
+        if tl + tr >= nb - 5:
+            tl = tr = 2
+        mt = nb - tl - tr
+        core = bytes(rng.choice(list(b"ACGT"), size=mt + 40).tolist())
+        pri = bytearray(rng.choice(list(b"ACGT"), size=nb).tolist())
+        pri[tl:tl + mt] = core[:mt]
+        sec = bytearray(pri)
+        shift = int(rng.integers(-12, 13))
+        bpv = int(rng.integers(0, mt + 10))
+        for i in range(tl + min(bpv, mt), nb - tr):
+            # heterozygous tail: the secondary follows the reference shifted by `shift` (sometimes as IUPAC of both)
+            src = i - tl + shift
+            if 0 <= src < len(core):
+                other = core[src]
+                if other != pri[i]:
+                    sec[i] = other if rng.random() < 0.7 else ord(orc.lib().orc_iupac2(bytes([pri[i]]), bytes([other])))
+            if rng.random() < 0.03:
+                sec[i] = ord("N")
+        # alignment rows: the trimmed trace against a reference carrying the core plus flanks, a few gaps
+        r0, r1 = bytearray(), bytearray()
+        lead = int(rng.integers(0, 30))
+        r0 += b"-" * lead
+        r1 += bytes(rng.choice(list(b"ACGT"), size=lead).tolist())
+        for i in range(mt):
+            u = rng.random()
+            if u < 0.01:
+                r0 += b"-"; r1 += bytes([int(rng.choice(list(b"ACGT")))])
+            if u > 0.99:
+                r0 += bytes([pri[tl + i]]); r1 += b"-"
+                continue
+            r0 += bytes([pri[tl + i]])
+            r1 += bytes([core[i]]) if rng.random() > 0.02 else bytes([int(rng.choice(list(b"ACGTN")))])
+        trail = int(rng.integers(0, 600))
+        r0 += b"-" * trail
+        r1 += bytes(rng.choice(list(b"ACGT"), size=trail).tolist())
+        if it % 10 == 9:
+            r1[len(r1) // 2] = ord("X")  # exotic reference letter: the kernel falls back to byte-wise scans
+        bp = orc.Breakpoint(1, 1, bpv, 0.5)
+        c = dict(rows=(bytes(r0), bytes(r1)), pri=bytes(pri), sec=bytes(sec), bp=bp, ref=bytes(r1).replace(b"-", b""))
+        mi = int(rng.choice([1000, 1000, 37, 200]))
+        want = orc.decompose_alleles(c["rows"][0], c["rows"][1], c["pri"], c["sec"], bp, len(c["ref"]), tl, tr, mi, 5)
+        for bw in (0, 1):
+            r0b, r1b = c["rows"]
+            p = C.create_string_buffer(c["pri"], nb + 1)
+            s = C.create_string_buffer(c["sec"], nb + 1)
+            di = (C.c_int32 * (2 * mi + 4))()
+            de = (C.c_int32 * (2 * mi + 4))()
+            out = (C.c_int32 * 6)()
+            emu.emu_decompose(r0b, r1b, len(r0b), p, s, nb, bpv, len(c["ref"]), tl, tr, mi, 5, di, de, out, bw)
+            got = (p.raw[:nb], s.raw[:nb], [(di[i], de[i]) for i in range(out[4])], tuple(out[:4]))
+            assert got[0] == want[0] and got[1] == want[1], (it, bw)
+            assert got[2] == want[2], (it, bw)
+            assert got[3][0] == want[3][0], (it, bw)
+            if want[3][0] == 1:
+                assert got[3] == tuple(want[3][:4]), (it, bw, got[3], want[3])
+        kinds[want[3][0]] = kinds.get(want[3][0], 0) + 1
+    assert kinds.get(0, 0) > 5 and kinds.get(1, 0) > 5 and kinds.get(2, 0) >= 1, kinds
 
 
 def test_complex_and_none_paths(emu):
@@ -79,6 +147,7 @@ def test_complex_and_none_paths(emu):
         c = dict(rows=(row0, row1), pri=pri, sec=sec, bp=bp, ref=ref)
         want = orc.decompose_alleles(row0, row1, pri, sec, bp, len(ref), 50, 50, 1000, 5)
         got = run_emu_decompose(emu, c)
+        assert got == run_emu_decompose(emu, c, bytewise=1)
         assert (got[0], got[1], got[2]) == (want[0], want[1], want[2]) and got[3] == want[3]
     # heterozygous tail: secondary carries the reference shifted by 3 with an extra insertion -> complex search
     tail = ref[150:300]
@@ -89,6 +158,7 @@ def test_complex_and_none_paths(emu):
     c = dict(rows=(row0, row1), pri=pri, sec=bytes(sec2), bp=bp, ref=ref)
     want = orc.decompose_alleles(row0, row1, pri, bytes(sec2), bp, len(ref), 50, 50, 1000, 5)
     got = run_emu_decompose(emu, c)
+    assert got == run_emu_decompose(emu, c, bytewise=1)
     assert (got[0], got[1], got[2]) == (want[0], want[1], want[2]) and got[3][0] == want[3][0]
 
 

@@ -50,7 +50,9 @@ struct tracyhip_ctx {
       d_rows0, d_rows1;
   tracyhip::DevBuf d_tmp[8];
   tracyhip::DevBuf d_pipe[64];
-  tracyhip::DevBuf d_ckpt, d_lastrow, d_band;  // decompose pipeline intermediates  // pipeline intermediates (align_traces / decompose)
+  tracyhip::DevBuf d_ckpt, d_lastrow, d_band;  // pipeline intermediates (align_traces / decompose)
+  tracyhip::DevBuf d_aftab;                    // allelicFraction grid enumeration (trace independent)
+  bool aftab_ready = false;
   tracyhip::PinBuf h_desc, h_off, h_tmp;
   // kernel timing
   struct Pending { int which; hipEvent_t e0, e1; uint64_t cells, bytes; };
@@ -66,6 +68,7 @@ struct tracyhip_ctx {
     for (auto& b : d_tmp) b.release();
     for (auto& b : d_pipe) b.release();
     d_ckpt.release(); d_lastrow.release(); d_band.release();
+    d_aftab.release(); aftab_ready = false;
     h_desc.release();
     h_off.release();
     h_tmp.release();

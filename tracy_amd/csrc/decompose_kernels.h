@@ -85,20 +85,70 @@ struct DecompArgs {
 
 constexpr int kMaxIndelDev = 1024;  // maxindel handled in LDS (CLI default 1000)
 
+// ---- bit-set formulation of the shift scans ---------------------------------------------------------
+// Every scan of decomposeAlleles (decompose.h:214-224, 251-261, 293-313) counts, for a pair of offsets
+// (del, ins), the positions t with  !compatible(row1[alignIndex+1+del+t], basecall[varIndex+ins+t]).
+// The reference character falls in one of six classes (A C G T N '-'); per class c keep
+//   is_c[q]  = 1 iff row1[alignIndex+1+q] is of class c                  (q < kWinBits)
+//   bad_c[s] = 1 iff basecall varIndex+s is NOT compatible with class c  (s < kVarBits)
+// then  failed(del, ins) = sum_c popc( bad_c[ins+t] & is_c[del+t] ), t < min(Lw-del, NV-ins).
+// Writing s = ins+t and u = del-ins this is  sum over s in [ins, min(NV, Lw-u))  of  Z_u[s],
+// Z_u[s] = OR_c bad_c[s] & is_c[s+u]: the upper limit depends on the DIAGONAL u only, so one pass
+// over a diagonal yields failed() for all its (ins, del) as suffix popcounts -- the complex ins x del
+// search costs O((maxins+maxdel) * NV/64) word operations instead of O(maxins * maxdel * NV) byte compares.
+constexpr int kRefClasses = 6;
+constexpr int kVarBits = 2 * kMaxIndelDev;                 // basecalls per trace handled (nbc < 2*kMaxIndelDev)
+constexpr int kWinBits = kVarBits + kMaxIndelDev;          // reference columns a scan can reach
+constexpr int kVarWords = kVarBits / 64 + 2;               // + zero padding for unaligned 64-bit fetches
+constexpr int kWinWords = kWinBits / 64 + 2;
+
+TR_HD int ref_class(uint8_t r) {
+  return r == 'A' ? 0 : r == 'C' ? 1 : r == 'G' ? 2 : r == 'T' ? 3 : r == 'N' ? 4 : r == '-' ? 5 : 6;
+}
+TR_HD char class_char(int c) { return c == 0 ? 'A' : c == 1 ? 'C' : c == 2 ? 'G' : c == 3 ? 'T' : c == 4 ? 'N' : '-'; }
+// the predicate the scans count the negation of (decompose.h:218-220)
+TR_HD bool ref_compatible(char p, char s, char r) { return r == p || phase_ref_allele(p, s, r) != 'N'; }
+
+TR_HD int popc64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __popcll(x);
+#else
+  return __builtin_popcountll(x);
+#endif
+}
+// 64 bits starting at (possibly negative) bit position pos of a zero-padded bit set of nw words
+TR_HD uint64_t bits_at(const uint64_t* a, int32_t pos, int32_t nw) {
+  const int32_t w = pos >> 6;  // arithmetic shift: floor
+  const uint32_t sft = (uint32_t)pos & 63u;
+  const uint64_t lo = (w >= 0 && w < nw) ? a[w] : 0;
+  if (sft == 0) return lo;
+  const uint64_t hi = (w + 1 >= 0 && w + 1 < nw) ? a[w + 1] : 0;
+  return (lo >> sft) | (hi << (64 - sft));
+}
+TR_HD uint64_t low_mask(int32_t nbits) { return nbits >= 64 ? ~0ull : nbits <= 0 ? 0ull : ((1ull << nbits) - 1ull); }
+
 struct DecompShared {
   int32_t fref[kMaxIndelDev];
   int32_t fins[kMaxIndelDev];
   int32_t hist[kMaxIndelDev * 2 + 2];
+  uint64_t is_c[kRefClasses][kWinWords];
+  uint64_t bad_c[kRefClasses][kVarWords];
+  uint32_t seg0[64], seg1[64];  // per-lane segment counts of trace / reference bases (alignment walk)
   uint32_t nfref, nfins;
   uint32_t varIndex, refPointer, alignIndex;
   uint32_t maxdel, maxins, bp;
+  uint32_t found;               // the walk reached the breakpoint
+  uint32_t exotic;              // the scan window holds a character outside ACGTN- : byte-wise fallback
+  uint32_t classes;             // bit c set iff class c occurs in the window
+  int32_t Lw, NV;               // columns from alignIndex+1 to L, basecalls from varIndex to vend (clamped to the bit sets)
   int32_t pick_del, pick_ins;  // smallest picked deletion / insertion, -1 = none
   int32_t ndel, nins;          // number of picks
   int32_t maxpick_del, maxpick_ins;
   int32_t best_fr[64], best_ins[64], best_del[64];
 };
 
-// failedref of one shift (decompose.h:215-222 and the two other copies of that loop)
+// failedref of one shift (decompose.h:215-222 and the two other copies of that loop), byte-wise: the
+// fallback for windows with exotic characters and the cross-check of the bit-set path in tests/emu
 TR_HD int32_t count_failed(const uint8_t* row1, uint32_t L, const uint8_t* pri, const uint8_t* sec, uint64_t vend,
                            uint32_t jstart, uint32_t vi) {
   int32_t failed = 0;
@@ -111,33 +161,83 @@ TR_HD int32_t count_failed(const uint8_t* row1, uint32_t L, const uint8_t* pri, 
   return failed;
 }
 
-// ---- phase 1 (lane 0): walk to the breakpoint, phasing as we go (decompose.h:184-208), scan bounds ----
-TR_HD void decomp_phase_walk(const DecompArgs& a, const DecompDesc& d, DecompShared& sh) {
+TR_HD uint64_t decomp_vend(const DecompArgs& a, const DecompDesc& d) {
+  return (uint64_t)d.nbc - (uint64_t)(int64_t)a.prm.trimRight;  // size_t arithmetic of decompose.h:216
+}
+
+// segment of alignment columns lane l walks
+TR_HD void lane_segment(uint32_t L, uint32_t lane, uint32_t& lo, uint32_t& hi) {
+  const uint32_t seg = (L + 63) / 64;
+  lo = lane * seg < L ? lane * seg : L;
+  hi = lo + seg < L ? lo + seg : L;
+}
+
+// ---- phase 0 (all lanes): trace / reference bases per segment of the alignment ----
+TR_HD void decomp_phase_count(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, uint32_t lane) {
+  const uint8_t* row0 = a.rows0 + d.rows_off;
+  const uint8_t* row1 = a.rows1 + d.rows_off;
+  uint32_t lo, hi, c0 = 0, c1 = 0;
+  lane_segment(d.L, lane, lo, hi);
+  for (uint32_t j = lo; j < hi; ++j) {
+    c0 += row0[j] != '-';
+    c1 += row1[j] != '-';
+  }
+  sh.seg0[lane] = c0;
+  sh.seg1[lane] = c1;
+  if (lane == 0) { sh.found = 0; sh.alignIndex = 0; sh.varIndex = 0; sh.exotic = 0; sh.classes = 0; }
+}
+
+// phase the basecall at vi against reference character r (decompose.h:196-203)
+TR_HD void phase_position(uint8_t* pri, uint8_t* sec, uint32_t vi, uint8_t r) {
+  if (r != pri[vi]) {
+    const char s = phase_ref_allele((char)pri[vi], (char)sec[vi], (char)r);
+    if (s != 'N') { pri[vi] = r; sec[vi] = (uint8_t)s; }
+  }
+}
+
+// ---- phase 1 (all lanes): walk to the breakpoint, phasing as we go (decompose.h:184-208) ----
+// The k-th trace base of the alignment is basecall trimLeft+k-1; the walk stops after the base that
+// makes vi == bp, i.e. after trace base number bp - trimLeft.  Every lane walks its own segment.
+TR_HD void decomp_phase_walk(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, uint32_t lane) {
   const uint8_t* row0 = a.rows0 + d.rows_off;
   const uint8_t* row1 = a.rows1 + d.rows_off;
   uint8_t* pri = a.primary + d.bc_off;
   uint8_t* sec = a.secondary + d.bc_off;
-  const int32_t ltrim = a.prm.trimLeft, rtrim = a.prm.trimRight;
-  uint32_t varIndex = 0, refPointer = 0, alignIndex = 0;
-  uint32_t vi = (uint32_t)ltrim;
-  const uint32_t bp = d.breakpoint + (uint32_t)ltrim;
-  for (uint32_t j = 0; j < d.L; ++j) {
+  const uint32_t ltrim = (uint32_t)a.prm.trimLeft;
+  const uint32_t bp = d.breakpoint + ltrim;
+  uint32_t base0 = 0, base1 = 0;
+  for (uint32_t l = 0; l < lane; ++l) { base0 += sh.seg0[l]; base1 += sh.seg1[l]; }
+  const uint32_t stop = bp - ltrim;  // 1-based number of the last trace base walked (0 or > total: never reached)
+  if (stop != 0 && base0 >= stop) return;
+  uint32_t lo, hi;
+  lane_segment(d.L, lane, lo, hi);
+  uint32_t k = base0, ref = base1;
+  for (uint32_t j = lo; j < hi; ++j) {
     if (row0[j] != '-') {
-      if (row1[j] != pri[vi]) {
-        const char s = phase_ref_allele((char)pri[vi], (char)sec[vi], (char)row1[j]);
-        if (s != 'N') { pri[vi] = row1[j]; sec[vi] = (uint8_t)s; }
+      phase_position(pri, sec, ltrim + k, row1[j]);
+      ++k;
+      if (k == stop) {
+        sh.found = 1; sh.alignIndex = j; sh.varIndex = ltrim + k; sh.refPointer = ref;
+        return;
       }
-      ++vi;
-      if (vi == bp) { alignIndex = j; varIndex = vi; break; }
     }
-    if (row1[j] != '-') ++refPointer;
+    if (row1[j] != '-') ++ref;
   }
+}
+
+// ---- phase 2 (lane 0): scan bounds (decompose.h:210-213, 248-250) ----
+TR_HD void decomp_phase_bounds(const DecompArgs& a, const DecompDesc& d, DecompShared& sh) {
+  const int32_t rtrim = a.prm.trimRight;
+  const uint32_t bp = d.breakpoint + (uint32_t)a.prm.trimLeft;
+  if (!sh.found) {
+    uint32_t ref = 0;
+    for (int l = 0; l < 64; ++l) ref += sh.seg1[l];
+    sh.refPointer = ref;
+  }
+  const uint32_t refPointer = sh.refPointer;
   uint32_t maxdel = 2;
   if ((uint64_t)d.refslice_len > (uint64_t)(uint32_t)(refPointer + (uint32_t)rtrim + 2u))
     maxdel = (uint32_t)((uint64_t)d.refslice_len - (uint64_t)(uint32_t)(refPointer + (uint32_t)rtrim));
-  sh.varIndex = varIndex;
-  sh.refPointer = refPointer;
-  sh.alignIndex = alignIndex;
   sh.maxdel = maxdel;
   sh.bp = bp;
   sh.maxins = (uint32_t)((int32_t)d.nbc - (int32_t)((uint32_t)rtrim + bp));
@@ -147,18 +247,92 @@ TR_HD void decomp_phase_walk(const DecompArgs& a, const DecompDesc& d, DecompSha
   uint32_t ni = 1;
   for (uint32_t ins = 1; (ins < (uint32_t)a.prm.maxindel) && (ins < sh.maxins / 2); ++ins) ++ni;
   sh.nfins = ni;
+  // extent of the bit sets
+  const uint32_t winstart = sh.alignIndex + 1;
+  const int64_t lw = (int64_t)d.L - (int64_t)winstart;
+  sh.Lw = (int32_t)(lw < 0 ? 0 : lw > kWinBits ? kWinBits : lw);
+  uint64_t vend = decomp_vend(a, d);
+  if (vend > d.nbc) vend = d.nbc;  // rtrim < 0 or > nbc: the reference reads out of bounds there
+  const int64_t nv = (int64_t)vend - (int64_t)sh.varIndex;
+  sh.NV = (int32_t)(nv < 0 ? 0 : nv > kVarBits ? kVarBits : nv);
 }
 
-// ---- phase 2 (all lanes): deletion and insertion scans ----
-TR_HD void decomp_phase_scan(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, uint32_t lane) {
+// ---- phase 3 (all lanes): build the class bit sets; lane l builds word l, l+64, ... of each ----
+TR_HD void decomp_phase_bitsets(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, uint32_t lane) {
   const uint8_t* row1 = a.rows1 + d.rows_off;
   const uint8_t* pri = a.primary + d.bc_off;
   const uint8_t* sec = a.secondary + d.bc_off;
-  const uint64_t vend = (uint64_t)d.nbc - (uint64_t)(int64_t)a.prm.trimRight;
-  for (uint32_t del = lane; del < sh.nfref; del += 64)
-    sh.fref[del] = count_failed(row1, d.L, pri, sec, vend, sh.alignIndex + del + 1, sh.varIndex);
-  for (uint32_t ins = 1 + lane; ins < sh.nfins; ins += 64)
-    sh.fins[ins] = count_failed(row1, d.L, pri, sec, vend, sh.alignIndex + 1, sh.varIndex + ins);
+  const uint32_t winstart = sh.alignIndex + 1;
+  uint32_t seen = 0, exotic = 0;
+  for (int32_t w = (int32_t)lane; w < kWinWords; w += 64) {
+    uint64_t bits[kRefClasses] = {0, 0, 0, 0, 0, 0};
+    for (int32_t q = 64 * w; q < 64 * w + 64 && q < sh.Lw; ++q) {
+      const int c = ref_class(row1[winstart + (uint32_t)q]);
+      if (c >= kRefClasses) { exotic = 1; continue; }
+      bits[c] |= 1ull << (q & 63);
+      seen |= 1u << c;
+    }
+    for (int c = 0; c < kRefClasses; ++c) sh.is_c[c][w] = bits[c];
+  }
+  for (int32_t w = (int32_t)lane; w < kVarWords; w += 64) {
+    uint64_t bits[kRefClasses] = {0, 0, 0, 0, 0, 0};
+    for (int32_t s = 64 * w; s < 64 * w + 64 && s < sh.NV; ++s) {
+      const char p = (char)pri[sh.varIndex + (uint32_t)s], sc = (char)sec[sh.varIndex + (uint32_t)s];
+      for (int c = 0; c < kRefClasses; ++c)
+        if (!ref_compatible(p, sc, class_char(c))) bits[c] |= 1ull << (s & 63);
+    }
+    for (int c = 0; c < kRefClasses; ++c) sh.bad_c[c][w] = bits[c];
+  }
+  // lane-private results are merged through the per-lane scratch arrays (no atomics needed)
+  sh.best_fr[lane] = (int32_t)seen;
+  sh.best_ins[lane] = (int32_t)exotic;
+}
+
+// ---- phase 4 (lane 0): merge the per-lane class / exotic flags ----
+TR_HD void decomp_phase_flags(DecompShared& sh) {
+  uint32_t seen = 0, exotic = 0;
+  for (int l = 0; l < 64; ++l) { seen |= (uint32_t)sh.best_fr[l]; exotic |= (uint32_t)sh.best_ins[l]; }
+  sh.classes = seen;
+  sh.exotic = exotic;
+}
+
+// Z_u word: bits s in [64*w, 64*w+64) of  OR_c bad_c[s] & is_c[s+u], cut at s < limit
+TR_HD uint64_t diag_word(const DecompShared& sh, int32_t u, int32_t w, int32_t limit) {
+  uint64_t z = 0;
+  for (int c = 0; c < kRefClasses; ++c) {
+    if (!((sh.classes >> c) & 1u)) continue;
+    z |= sh.bad_c[c][w] & bits_at(sh.is_c[c], 64 * w + u, kWinWords);
+  }
+  return z & low_mask(limit - 64 * w);
+}
+// number of positions s >= from of diagonal u  ( = failed(del, ins) for del - ins == u, from == ins)
+TR_HD int32_t diag_count_from(const DecompShared& sh, int32_t u, int32_t from) {
+  const int32_t lim_ref = sh.Lw - u;
+  const int32_t limit = sh.NV < lim_ref ? sh.NV : lim_ref;
+  int32_t f = 0;
+  for (int32_t w = from >> 6; 64 * w < limit; ++w) {
+    uint64_t z = diag_word(sh, u, w, limit);
+    if (w == (from >> 6)) z &= ~low_mask(from & 63);
+    f += popc64(z);
+  }
+  return f;
+}
+
+// ---- phase 5 (all lanes): deletion and insertion scans (decompose.h:214-224, 251-261) ----
+TR_HD void decomp_phase_scan(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, uint32_t lane) {
+  if (sh.exotic) {
+    const uint8_t* row1 = a.rows1 + d.rows_off;
+    const uint8_t* pri = a.primary + d.bc_off;
+    const uint8_t* sec = a.secondary + d.bc_off;
+    const uint64_t vend = decomp_vend(a, d);
+    for (uint32_t del = lane; del < sh.nfref; del += 64)
+      sh.fref[del] = count_failed(row1, d.L, pri, sec, vend, sh.alignIndex + del + 1, sh.varIndex);
+    for (uint32_t ins = 1 + lane; ins < sh.nfins; ins += 64)
+      sh.fins[ins] = count_failed(row1, d.L, pri, sec, vend, sh.alignIndex + 1, sh.varIndex + ins);
+  } else {
+    for (uint32_t del = lane; del < sh.nfref; del += 64) sh.fref[del] = diag_count_from(sh, (int32_t)del, 0);
+    for (uint32_t ins = 1 + lane; ins < sh.nfins; ins += 64) sh.fins[ins] = diag_count_from(sh, -(int32_t)ins, (int32_t)ins);
+  }
 }
 
 // value at sorted position n/2 (getMedian, decompose.h:129-135) of small non-negative ints via a histogram
@@ -246,22 +420,56 @@ TR_HD void decomp_phase_pick(const DecompArgs& a, const DecompDesc& d, DecompSha
   out.pad = 0;
 }
 
-// ---- phase 4 (all lanes, only when nothing was picked): complex ins x del search (:290-313) ----
-// Lane l takes ins = l, l+64, ...; within one ins the del loop is sequential (prevFailedRef).  The
-// reference accepts a candidate iff 2*f < prev and f < bestFR (strict), so the overall winner is the
-// smallest f among the 2*f < prev candidates, earliest (ins, del) on ties.
+// ---- phase 7 (all lanes, only when nothing was picked): complex ins x del search (:290-313) ----
+// The reference runs ins outer / del inner with prevFailedRef reset to 0 per ins, and accepts a candidate
+// iff 2*f < prev and f < bestFR (strict): the overall winner is the smallest f among the 2*f < prev
+// candidates, earliest (ins, del) on ties.  Lane l takes the diagonals u = del - ins = umin + l, + 64, ...;
+// the predecessor f(ins, del-1) lies on diagonal u-1, which the lane sweeps in lock-step (suffix counts).
+TR_HD void complex_consider(int32_t f, int32_t prev, int32_t ins, int32_t del, int32_t& bfr, int32_t& bi, int32_t& bd) {
+  if (!(2 * f < prev && f < 1000)) return;
+  if (f < bfr || (f == bfr && (ins < bi || (ins == bi && del < bd)))) { bfr = f; bi = ins; bd = del; }
+}
 TR_HD void decomp_phase_complex(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, uint32_t lane) {
-  const uint8_t* row1 = a.rows1 + d.rows_off;
-  const uint8_t* pri = a.primary + d.bc_off;
-  const uint8_t* sec = a.secondary + d.bc_off;
-  const uint64_t vend = (uint64_t)d.nbc - (uint64_t)(int64_t)a.prm.trimRight;
   int32_t bfr = 1000, bi = 0, bd = 0;
-  for (uint32_t ins = lane; (ins < (uint32_t)a.prm.maxindel) && (ins < sh.maxins / 2); ins += 64) {
-    int32_t prev = 0;
-    for (uint32_t del = 0; (del < (uint32_t)a.prm.maxindel) && (del < sh.maxdel / 2); ++del) {
-      const int32_t f = count_failed(row1, d.L, pri, sec, vend, sh.alignIndex + del + 1, sh.varIndex + ins);
-      if (2 * f < prev && f < bfr) { bfr = f; bi = (int32_t)ins; bd = (int32_t)del; }
-      prev = f;
+  // loop limits of decompose.h:293-294
+  int32_t NI = 0, ND = 0;
+  for (uint32_t ins = 0; (ins < (uint32_t)a.prm.maxindel) && (ins < sh.maxins / 2); ++ins) ++NI;
+  for (uint32_t del = 0; (del < (uint32_t)a.prm.maxindel) && (del < sh.maxdel / 2); ++del) ++ND;
+  if (sh.exotic) {
+    const uint8_t* row1 = a.rows1 + d.rows_off;
+    const uint8_t* pri = a.primary + d.bc_off;
+    const uint8_t* sec = a.secondary + d.bc_off;
+    const uint64_t vend = decomp_vend(a, d);
+    for (int32_t ins = (int32_t)lane; ins < NI; ins += 64) {
+      int32_t prev = 0;
+      for (int32_t del = 0; del < ND; ++del) {
+        const int32_t f = count_failed(row1, d.L, pri, sec, vend, sh.alignIndex + (uint32_t)del + 1, sh.varIndex + (uint32_t)ins);
+        complex_consider(f, prev, ins, del, bfr, bi, bd);
+        prev = f;
+      }
+    }
+  } else if (NI > 0 && ND > 1) {
+    // del = 0 has prev = 0 and can never be accepted; diagonals u in [1 - (NI-1), ND-1] hold the del >= 1 entries
+    for (int32_t u = 2 - NI + (int32_t)lane; u <= ND - 1; u += 64) {
+      const int32_t ins_lo = u >= 1 ? 0 : 1 - u;
+      const int32_t ins_hi = (NI - 1) < (ND - 1 - u) ? (NI - 1) : (ND - 1 - u);
+      if (ins_lo > ins_hi) continue;
+      const int32_t lim_u = sh.NV < sh.Lw - u ? sh.NV : sh.Lw - u;            // diagonal u:   s < lim_u
+      const int32_t lim_p = sh.NV < sh.Lw - (u - 1) ? sh.NV : sh.Lw - (u - 1);  // diagonal u-1
+      const int32_t top = (lim_u > lim_p ? lim_u : lim_p);
+      int32_t suf_u = 0, suf_p = 0;
+      int32_t ins = ins_hi;
+      for (int32_t w = top > 0 ? (top - 1) >> 6 : -1; w >= (ins_lo >> 6); --w) {
+        const uint64_t zu = diag_word(sh, u, w, lim_u), zp = diag_word(sh, u - 1, w, lim_p);
+        for (; ins >= ins_lo && ins >= 64 * w; --ins) {
+          if (ins >= 64 * w + 64) continue;  // above the populated words: both counts are zero there
+          const int sft = ins & 63;
+          complex_consider(suf_u + popc64(zu >> sft), suf_p + popc64(zp >> sft), ins, ins + u, bfr, bi, bd);
+        }
+        suf_u += popc64(zu);
+        suf_p += popc64(zp);
+      }
+      // entries whose ins lies above every populated word have f = prev = 0: never accepted (2*0 < 0 fails)
     }
   }
   sh.best_fr[lane] = bfr; sh.best_ins[lane] = bi; sh.best_del[lane] = bd;
@@ -279,7 +487,7 @@ TR_HD void decomp_phase_complex_reduce(DecompShared& sh, DecompOut& out) {
   out.kind = (bfr != 1000) ? 1 : 2;
 }
 
-// ---- phase 5 (all lanes): rewrite the basecalls along the chosen shift (:317-326, 351-371) ----
+// ---- phase 9 (all lanes): rewrite the basecalls along the chosen shift (:317-326, 351-371) ----
 // Each position vi is touched once and only reads its own primary/secondary: lanes split the range.
 TR_HD void decomp_phase_apply(const DecompArgs& a, const DecompDesc& d, const DecompShared& sh, const DecompOut& out,
                               uint32_t lane) {
@@ -287,19 +495,18 @@ TR_HD void decomp_phase_apply(const DecompArgs& a, const DecompDesc& d, const De
   const uint8_t* row1 = a.rows1 + d.rows_off;
   uint8_t* pri = a.primary + d.bc_off;
   uint8_t* sec = a.secondary + d.bc_off;
-  const uint64_t vend = (uint64_t)d.nbc - (uint64_t)(int64_t)a.prm.trimRight;
+  const uint64_t vend = decomp_vend(a, d);
   uint32_t jstart, vi0;
   if (sh.ndel == 0 && sh.nins == 0) {
     if (out.kind == 1) { jstart = sh.alignIndex + (uint32_t)out.bestDel + 1; vi0 = sh.varIndex + (uint32_t)out.bestIns; }
     else {  // "No InDel detected, traverse the whole alignment" (:327-343): vi advances only on trace bases
-      if (lane != 0) return;
-      uint32_t vi = (uint32_t)a.prm.trimLeft;
-      for (uint32_t j = 0; j < d.L; ++j) {
+      uint32_t base0 = 0, lo, hi;
+      for (uint32_t l = 0; l < lane; ++l) base0 += sh.seg0[l];
+      lane_segment(d.L, lane, lo, hi);
+      uint32_t vi = (uint32_t)a.prm.trimLeft + base0;
+      for (uint32_t j = lo; j < hi; ++j) {
         if (row0[j] != '-') {
-          if (row1[j] != pri[vi]) {
-            const char s = phase_ref_allele((char)pri[vi], (char)sec[vi], (char)row1[j]);
-            if (s != 'N') { pri[vi] = row1[j]; sec[vi] = (uint8_t)s; }
-          }
+          phase_position(pri, sec, vi, row1[j]);
           ++vi;
         }
       }
@@ -310,10 +517,33 @@ TR_HD void decomp_phase_apply(const DecompArgs& a, const DecompDesc& d, const De
   for (uint64_t k = lane;; k += 64) {
     const uint64_t j = (uint64_t)jstart + k, vi = (uint64_t)vi0 + k;
     if (!(j < d.L && vi < vend)) break;
-    if (row1[j] != pri[vi]) {
-      const char s = phase_ref_allele((char)pri[vi], (char)sec[vi], (char)row1[j]);
-      if (s != 'N') { pri[vi] = row1[j]; sec[vi] = (uint8_t)s; }
-    }
+    phase_position(pri, sec, (uint32_t)vi, row1[j]);
+  }
+}
+
+// ---- the phase schedule, shared by the HIP kernel (a barrier after every step) and tests/emu (lanes looped) ----
+constexpr int kDecompSteps = 10;
+// whether step `st` runs on all lanes (true) or on lane 0 only (false)
+TR_HD bool decomp_step_all_lanes(int st) { return st == 0 || st == 1 || st == 3 || st == 5 || st == 7 || st == 9; }
+TR_HD void decomp_step(int st, const DecompArgs& a, const DecompDesc& d, DecompShared& sh, DecompOut& out, uint32_t lane) {
+  switch (st) {
+    case 0: decomp_phase_count(a, d, sh, lane); break;
+    case 1: decomp_phase_walk(a, d, sh, lane); break;
+    case 2: decomp_phase_bounds(a, d, sh); break;
+    case 3: decomp_phase_bitsets(a, d, sh, lane); break;
+    case 4: decomp_phase_flags(sh); break;
+    case 5: decomp_phase_scan(a, d, sh, lane); break;
+    case 6: decomp_phase_pick(a, d, sh, out); break;
+    case 7: if (sh.ndel == 0 && sh.nins == 0) decomp_phase_complex(a, d, sh, lane); break;
+    case 8:
+      if (sh.ndel == 0 && sh.nins == 0) decomp_phase_complex_reduce(sh, out);
+      sh.best_fr[0] = out.bestFR; sh.best_ins[0] = out.bestIns; sh.best_del[0] = out.bestDel; sh.hist[0] = out.kind;
+      break;
+    case 9:
+      if (lane != 0) { out.bestFR = sh.best_fr[0]; out.bestIns = sh.best_ins[0]; out.bestDel = sh.best_del[0]; out.kind = sh.hist[0]; }
+      decomp_phase_apply(a, d, sh, out, lane);
+      break;
+    default: break;
   }
 }
 

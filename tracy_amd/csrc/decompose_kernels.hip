@@ -35,28 +35,11 @@ __global__ __launch_bounds__(64) void decompose_kernel(DecompArgs a, const Break
   DecompDesc d = a.desc[t];
   d.breakpoint = bps[t].breakpoint;
   const uint32_t lane = threadIdx.x;
-  DecompOut out;
-  if (lane == 0) decomp_phase_walk(a, d, sh);
-  wg_sync();
-  decomp_phase_scan(a, d, sh, lane);
-  wg_sync();
-  if (lane == 0) decomp_phase_pick(a, d, sh, out);
-  wg_sync();
-  const bool complex_case = (sh.ndel == 0 && sh.nins == 0);
-  if (complex_case) {
-    decomp_phase_complex(a, d, sh, lane);
+  DecompOut out{};
+  for (int st = 0; st < kDecompSteps; ++st) {
+    if (lane == 0 || decomp_step_all_lanes(st)) decomp_step(st, a, d, sh, out, lane);
     wg_sync();
-    if (lane == 0) {
-      decomp_phase_complex_reduce(sh, out);
-      sh.best_fr[0] = out.bestFR; sh.best_ins[0] = out.bestIns; sh.best_del[0] = out.bestDel;
-      sh.hist[0] = out.kind;
-    }
-    wg_sync();
-    if (lane != 0) { out.bestFR = sh.best_fr[0]; out.bestIns = sh.best_ins[0]; out.bestDel = sh.best_del[0]; out.kind = sh.hist[0]; }
-  } else if (lane != 0) {
-    out.kind = 0; out.bestIns = 0; out.bestDel = 0; out.bestFR = 1000;
   }
-  decomp_phase_apply(a, d, sh, out, lane);
   if (lane == 0) a.out[t] = out;
 }
 
@@ -117,26 +100,57 @@ __global__ void secdecomp_kernel(const BcDesc* desc, const int32_t* signal, cons
 constexpr int AF_THREADS = 256;
 constexpr double kScreenMargin = 1e-6;  // >> 4d * 2^-53 * SSE rounding differences (SSE <= 4d <= 8192)
 
+constexpr int AF_SURVIVORS = 32;  // near-minimum candidates evaluated cooperatively; any further ones by their finder
+
+// the reference's summation for one candidate (decompose.h:596-606): sequential over the 4*dn terms
 __device__ __forceinline__ double af_exact_sse(const double* tp, const uint8_t* cls, uint32_t terms, const double pv[5]) {
+  // the class value is picked with selects: a dynamically indexed private array would live in scratch memory
+  const double p0 = pv[0], p1 = pv[1], p2 = pv[2], p3 = pv[3], p4 = pv[4];
+  auto term = [&](uint32_t q) {
+    const uint32_t c = cls[q];
+    const double v = c == 1 ? p1 : c == 2 ? p2 : c == 3 ? p3 : c == 4 ? p4 : p0;
+    const double df = __dsub_rn(v, tp[q]);
+    return __dmul_rn(df, df);
+  };
   double sse = 0;
-  for (uint32_t q = 0; q < terms; ++q) {
-    const double df = __dsub_rn(pv[cls[q]], tp[q]);
-    sse = __dadd_rn(sse, __dmul_rn(df, df));
+  uint32_t q = 0;
+  for (; q + 4 <= terms; q += 4) {  // the squares are independent; only the additions form the sequential chain
+    const double x0 = term(q), x1 = term(q + 1), x2 = term(q + 2), x3 = term(q + 3);
+    sse = __dadd_rn(sse, x0); sse = __dadd_rn(sse, x1); sse = __dadd_rn(sse, x2); sse = __dadd_rn(sse, x3);
   }
+  for (; q < terms; ++q) sse = __dadd_rn(sse, term(q));
   return sse;
+}
+
+// The (i, j, k) grid of decompose.h:593-595 is the same for every trace: i, j, k run over the 100 doubles
+// 0, 0.01, 0.01+0.01, ... and a triple is visited iff i+j <= 1 and (i+j)+k <= 1 in double arithmetic.  The host
+// enumerates the visited (i, j) pairs once with the number of k values each admits, sorted by that number:
+// dealing the sorted list round-robin gives the 64 lanes of a wave k-loops of (almost) equal length.
+struct AfGrid {
+  uint32_t npairs;
+  const uint32_t* pair;  // [npairs] (i_index * 100 + j_index) | k_count << 16, k_count descending
+};
+constexpr int AF_STEPS = 21;  // >= ceil(npairs / AF_THREADS) (5151 pairs)
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
 }
 
 __global__ __launch_bounds__(AF_THREADS) void allelic_fraction_kernel(const BcDesc* desc, const int32_t* signal,
                                                                       const int32_t* bcpos, const uint8_t* pri_all,
                                                                       const uint8_t* sec_all, uint32_t trimLeft,
-                                                                      uint32_t trimRight, double* fractions) {
+                                                                      uint32_t trimRight, AfGrid grid, double* fractions) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ double vals[100];
+  __shared__ double vals[100], f1[100], f2[100], f3[100];
   __shared__ double red_sse[AF_THREADS];
   __shared__ uint32_t red_idx[AF_THREADS];
-  __shared__ uint32_t s_d;
-  __shared__ double s_sse0, s_amin;
-  __shared__ double cN[5], cS[5], cQ[5];
+  __shared__ uint32_t s_cnt[AF_THREADS];
+  __shared__ uint32_t s_nsurv;
+  __shared__ uint32_t s_surv[AF_SURVIVORS];
+  __shared__ double s_pv[AF_SURVIVORS + 1][5];
+  __shared__ double s_amin;
+  __shared__ double s_mom[AF_THREADS / 64][9];
   const BcDesc d = desc[blockIdx.x];
   const uint8_t* pri = pri_all + d.bc_off;
   const uint8_t* sec = sec_all + d.bc_off;
@@ -147,23 +161,33 @@ __global__ __launch_bounds__(AF_THREADS) void allelic_fraction_kernel(const BcDe
   double* tp = reinterpret_cast<double*>(smem);                 // [4][dn], the reference's m-outer / n-inner order
   uint8_t* cls = reinterpret_cast<uint8_t*>(tp + 4 * (size_t)len);
   const int tid = threadIdx.x;
-  if (tid == 0) {
-    double x = 0;
-    for (int a = 0; a < 100; ++a) { vals[a] = x; x = __dadd_rn(x, 0.01); }  // for (double i = 0; i <= 1; i += 0.01)
-    uint32_t dn = 0;
-    for (uint32_t i = 0; i < len; ++i) if (pri[off + i] != sec[off + i]) ++dn;
-    s_d = dn;
+  // positions where primary != secondary (decompose.h:431-436), compacted in order: every thread owns a chunk
+  const uint32_t chunk = (len + AF_THREADS - 1) / AF_THREADS;
+  const uint32_t c_lo = min((uint32_t)tid * chunk, len), c_hi = min(c_lo + chunk, len);
+  {
+    uint32_t n = 0;
+    for (uint32_t i = c_lo; i < c_hi; ++i) n += pri[off + i] != sec[off + i];
+    s_cnt[tid] = n;
+    if (tid == 0) {
+      double x = 0;
+      for (int a = 0; a < 100; ++a) { vals[a] = x; x = __dadd_rn(x, 0.01); }  // for (double i = 0; i <= 1; i += 0.01)
+      s_nsurv = 0;
+    }
   }
   __syncthreads();
-  const uint32_t dn = s_d;
+  uint32_t np = 0, dn = 0;
+  for (int t = 0; t < AF_THREADS; ++t) {
+    const uint32_t c = s_cnt[t];
+    if (t < tid) np += c;
+    dn += c;
+  }
   if (dn == 0) {
     if (tid == 0) { fractions[2 * blockIdx.x] = 0.5; fractions[2 * blockIdx.x + 1] = 0.5; }
     return;
   }
-  if (tid == 0) {
+  {
     const int32_t* sg = signal + d.sig_off;
-    uint32_t np = 0;
-    for (uint32_t i = 0; i < len; ++i) {
+    for (uint32_t i = c_lo; i < c_hi; ++i) {
       const uint8_t pc = pri[off + i], sc = sec[off + i];
       if (pc == sc) continue;
       const uint32_t bi_ = (i + trimLeft < d.nbc) ? i + trimLeft : d.nbc - 1;  // the reference indexes bcPos[i + trimLeft] (decompose.h:445)
@@ -185,68 +209,129 @@ __global__ __launch_bounds__(AF_THREADS) void allelic_fraction_kernel(const BcDe
       }
       ++np;
     }
-    // SSE of the start point (0.5, 0.5, 0, 0), decompose.h:586-591, and the per-class moments for the screen
-    const double start[5] = {0.0, 0.5, 0.5, 0.0, 0.0};
-    s_sse0 = af_exact_sse(tp, cls, 4 * dn, start);
-    for (int c = 0; c < 5; ++c) { cN[c] = 0; cS[c] = 0; cQ[c] = 0; }
-    for (uint32_t q = 0; q < 4 * dn; ++q) { const int c = cls[q]; cN[c] += 1.0; cS[c] += tp[q]; cQ[c] += tp[q] * tp[q]; }
   }
   __syncthreads();
-  const double n1 = cN[1], n2 = cN[2], n3 = cN[3], n4 = cN[4];
-  const double s1 = cS[1], s2 = cS[2], s3 = cS[3], s4c = cS[4];
-  const double qtot = cQ[0] + cQ[1] + cQ[2] + cQ[3] + cQ[4];
-  auto screen = [&](double vi, double vj, double vk, double vl) {
-    return qtot + vi * (n1 * vi - 2.0 * s1) + vj * (n2 * vj - 2.0 * s2) + vk * (n3 * vk - 2.0 * s3) + vl * (n4 * vl - 2.0 * s4c);
-  };
-  // pass 1: screened minimum over the grid
-  double my_min = 1e300;
-  for (uint32_t pr = tid; pr < 10000; pr += AF_THREADS) {
-    const uint32_t ia = pr / 100, ib = pr % 100;
-    const double vi = vals[ia], vj = vals[ib];
-    const double sij = __dadd_rn(vi, vj);
-    if (!(sij <= 1.0)) continue;
-    for (uint32_t ic = 0; ic < 100; ++ic) {
-      const double vk = vals[ic];
-      const double sijk = __dadd_rn(sij, vk);
-      if (!(sijk <= 1.0)) break;  // vals ascend: the reference's `if` fails for every later k as well
-      const double a = screen(vi, vj, vk, __dsub_rn(1.0, sijk));
-      my_min = a < my_min ? a : my_min;
+  const uint32_t terms = 4 * dn;
+  // per-class moments for the screen: sum_c (n_c v^2 - 2 v S_c) + Q, Q = sum of all squares
+  {
+    double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // n1..n4, S1..S4, Q
+    for (uint32_t q = tid; q < terms; q += AF_THREADS) {
+      const int c = cls[q];
+      const double x = tp[q];
+      m[8] += x * x;
+      for (int k = 1; k <= 4; ++k) { m[k - 1] += (c == k) ? 1.0 : 0.0; m[3 + k] += (c == k) ? x : 0.0; }
+    }
+    for (int k = 0; k < 9; ++k) {
+      const double w = wave_sum(m[k]);
+      if ((tid & 63) == 0) s_mom[tid >> 6][k] = w;
     }
   }
-  red_sse[tid] = my_min;
+  __syncthreads();
+  double mom[9];
+  for (int k = 0; k < 9; ++k) {
+    double v = 0;
+    for (int w = 0; w < AF_THREADS / 64; ++w) v += s_mom[w][k];
+    mom[k] = v;
+  }
+  const double n4 = mom[3], s4c2 = 2.0 * mom[7], qtot = mom[8];
+  if (tid < 100) {
+    const double v = vals[tid];
+    f1[tid] = v * (mom[0] * v - 2.0 * mom[4]);
+    f2[tid] = v * (mom[1] * v - 2.0 * mom[5]);
+    f3[tid] = v * (mom[2] * v - 2.0 * mom[6]);
+  }
+  __syncthreads();
+  // closed-form SSE of candidate (pair, ic): the SAME expression in both passes
+  auto screen = [&](double fij, double sij, uint32_t ic) {
+    const double vl = __dsub_rn(1.0, __dadd_rn(sij, vals[ic]));
+    return (fij + f3[ic]) + vl * (n4 * vl - s4c2);
+  };
+  // pass 1: minimum of every pair this thread owns (kept in registers: the step loop is fully unrolled)
+  double pair_min[AF_STEPS];
+  double my_min = 1e300;
+#pragma unroll
+  for (int st = 0; st < AF_STEPS; ++st) {
+    const uint32_t p = (uint32_t)st * AF_THREADS + (uint32_t)tid;
+    double pm = 1e300;
+    if (p < grid.npairs) {
+      const uint32_t e = grid.pair[p];
+      const uint32_t ia = (e & 0xffffu) / 100u, ib = (e & 0xffffu) % 100u, cnt = e >> 16;
+      const double sij = __dadd_rn(vals[ia], vals[ib]);
+      const double fij = qtot + f1[ia] + f2[ib];
+      for (uint32_t ic = 0; ic < cnt; ++ic) {
+        const double a = screen(fij, sij, ic);
+        pm = a < pm ? a : pm;
+      }
+    }
+    pair_min[st] = pm;
+    my_min = pm < my_min ? pm : my_min;
+  }
+  {
+    double m = my_min;
+    for (int o = 32; o > 0; o >>= 1) { const double x = __shfl_down(m, o, 64); m = x < m ? x : m; }
+    if ((tid & 63) == 0) red_sse[tid >> 6] = m;
+  }
   __syncthreads();
   if (tid == 0) {
     double m = red_sse[0];
-    for (int q = 1; q < AF_THREADS; ++q) m = red_sse[q] < m ? red_sse[q] : m;
+    for (int q = 1; q < AF_THREADS / 64; ++q) m = red_sse[q] < m ? red_sse[q] : m;
     s_amin = m;
   }
   __syncthreads();
-  // pass 2: exact evaluation (the reference's summation) of everything within the margin of the screened minimum
+  // pass 2: re-scan only the pairs that reach the margin of the screened minimum, list their near-minimum
+  // candidates; those get the exact (sequentially rounded) sum of the reference
   const double cut = s_amin + kScreenMargin;
-  double my_sse = s_sse0;
+  double my_sse = 1e300;
   uint32_t my_idx = 0xffffffffu;
-  const uint32_t terms = 4 * dn;
-  for (uint32_t pr = tid; pr < 10000; pr += AF_THREADS) {
-    const uint32_t ia = pr / 100, ib = pr % 100;
-    const double vi = vals[ia], vj = vals[ib];
-    const double sij = __dadd_rn(vi, vj);
-    if (!(sij <= 1.0)) continue;
-    for (uint32_t ic = 0; ic < 100; ++ic) {
-      const double vk = vals[ic];
-      const double sijk = __dadd_rn(sij, vk);
-      if (!(sijk <= 1.0)) break;
-      const double vl = __dsub_rn(1.0, sijk);
-      if (screen(vi, vj, vk, vl) > cut) continue;
-      const double pv[5] = {0.0, vi, vj, vk, vl};
-      const double sse = af_exact_sse(tp, cls, terms, pv);
-      if (sse < my_sse) { my_sse = sse; my_idx = (ia * 100 + ib) * 100 + ic; }  // ascending order inside a thread
+  auto exact_of = [&](uint32_t idx) {
+    const double vi = vals[idx / 10000], vj = vals[(idx / 100) % 100], vk = vals[idx % 100];
+    const double pv[5] = {0.0, vi, vj, vk, __dsub_rn(1.0, __dadd_rn(__dadd_rn(vi, vj), vk))};
+    return af_exact_sse(tp, cls, terms, pv);
+  };
+#pragma unroll
+  for (int st = 0; st < AF_STEPS; ++st) {
+    if (!(pair_min[st] <= cut)) continue;
+    const uint32_t e = grid.pair[(uint32_t)st * AF_THREADS + (uint32_t)tid];
+    const uint32_t code = e & 0xffffu, ia = code / 100u, ib = code % 100u, cnt = e >> 16;
+    const double sij = __dadd_rn(vals[ia], vals[ib]);
+    const double fij = qtot + f1[ia] + f2[ib];
+    for (uint32_t ic = 0; ic < cnt; ++ic) {
+      if (screen(fij, sij, ic) > cut) continue;
+      const uint32_t idx = code * 100u + ic;
+      const uint32_t slot = atomicAdd(&s_nsurv, 1u);
+      if (slot < AF_SURVIVORS) { s_surv[slot] = idx; continue; }
+      const double sse = exact_of(idx);  // list full: evaluate right here
+      if (sse < my_sse || (sse == my_sse && idx < my_idx)) { my_sse = sse; my_idx = idx; }
     }
+  }
+  __syncthreads();
+  // exact stage: lane 0 sums the start point (0.5, 0.5, 0, 0) (decompose.h:586-591), lanes 1.. one listed
+  // survivor each -- the same sequential loop side by side, class values looked up in LDS
+  const uint32_t nsurv = min(s_nsurv, (uint32_t)AF_SURVIVORS);
+  if ((uint32_t)tid <= nsurv) {
+    double pv[5] = {0.0, 0.5, 0.5, 0.0, 0.0};
+    if (tid > 0) {
+      const uint32_t idx = s_surv[tid - 1];
+      const double vi = vals[idx / 10000], vj = vals[(idx / 100) % 100], vk = vals[idx % 100];
+      pv[1] = vi; pv[2] = vj; pv[3] = vk;
+      pv[4] = __dsub_rn(1.0, __dadd_rn(__dadd_rn(vi, vj), vk));
+    }
+    for (int c = 0; c < 5; ++c) s_pv[tid][c] = pv[c];
+    const double* mine = s_pv[tid];
+    double sse = 0;
+    for (uint32_t q = 0; q < terms; ++q) {
+      const double df = __dsub_rn(mine[cls[q]], tp[q]);
+      sse = __dadd_rn(sse, __dmul_rn(df, df));
+    }
+    if (tid == 0) s_amin = sse;  // sse0 (s_amin is free again)
+    else if (sse < my_sse || (sse == my_sse && s_surv[tid - 1] < my_idx)) { my_sse = sse; my_idx = s_surv[tid - 1]; }
   }
   red_sse[tid] = my_sse;
   red_idx[tid] = my_idx;
   __syncthreads();
   if (tid == 0) {
-    double best = s_sse0;
+    // lowest-index strict minimum below the start SSE == the reference's chain of strict improvements
+    double best = s_amin;
     uint32_t bidx = 0xffffffffu;
     for (int q = 0; q < AF_THREADS; ++q) {
       if (red_idx[q] == 0xffffffffu) continue;
@@ -320,15 +405,50 @@ int launch_secdecomp(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32
   HIP_TRY(hipGetLastError());
   return TRACYHIP_OK;
 }
+// the trace-independent enumeration of the (i, j, k) grid, uploaded once per context
+static int ensure_af_grid(tracyhip_ctx* ctx, AfGrid& g) {
+  static const std::vector<uint32_t> tab = [] {  // thread-safe one-time initialisation
+    std::vector<uint32_t> t;
+    double vals[100];
+    double x = 0;
+    for (int a = 0; a < 100; ++a) { vals[a] = x; x = x + 0.01; }
+    for (int ia = 0; ia < 100; ++ia)
+      for (int ib = 0; ib < 100; ++ib) {
+        const double sij = vals[ia] + vals[ib];
+        if (!(sij <= 1.0)) continue;
+        uint32_t cnt = 0;
+        for (int ic = 0; ic < 100; ++ic) {
+          if (!(sij + vals[ic] <= 1.0)) break;  // vals ascend: later k fail as well
+          ++cnt;
+        }
+        if (cnt) t.push_back((uint32_t)(ia * 100 + ib) | (cnt << 16));
+      }
+    std::stable_sort(t.begin(), t.end(), [](uint32_t a, uint32_t b) { return (a >> 16) > (b >> 16); });
+    return t;
+  }();
+  if (tab.size() > (size_t)AF_STEPS * AF_THREADS) return set_error(TRACYHIP_ERR_RANGE, "allelicFraction grid larger than the unrolled schedule");
+  if (!ctx->aftab_ready) {
+    HIP_TRY(ctx->d_aftab.ensure(tab.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpyAsync(ctx->d_aftab.p, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    ctx->aftab_ready = true;
+  }
+  g.npairs = (uint32_t)tab.size();
+  g.pair = static_cast<const uint32_t*>(ctx->d_aftab.p);
+  return TRACYHIP_OK;
+}
+
 int launch_allelic_fraction(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig,
                             const int32_t* d_pos, const uint8_t* d_pri, const uint8_t* d_sec, uint32_t trim_left, uint32_t trim_right,
                             double* d_out) {
   if (n == 0) return TRACYHIP_OK;
-  const size_t lds = (size_t)maxbc * 36 + 64;
-  if (lds > 100 * 1024) return set_error(TRACYHIP_ERR_RANGE, "trace with %u basecalls exceeds the LDS staging of allelicFraction", maxbc);
+  const size_t lds = (size_t)maxbc * 36 + 64;  // tp (4 doubles per basecall) + class bytes
+  if (lds > 150 * 1024) return set_error(TRACYHIP_ERR_RANGE, "trace with %u basecalls exceeds the LDS staging of allelicFraction", maxbc);
+  AfGrid grid{};
+  int rc = ensure_af_grid(ctx, grid);
+  if (rc) return rc;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(allelic_fraction_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(allelic_fraction_kernel, dim3(n), dim3(AF_THREADS), lds, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, trim_left,
-                     trim_right, d_out);
+                     trim_right, grid, d_out);
   HIP_TRY(hipGetLastError());
   return TRACYHIP_OK;
 }

@@ -179,11 +179,22 @@ def main():
     # wavefront checkpoints).  Its algorithmic HBM bytes are the inputs once + 4 B per score, so the
     # HBM roofline fraction is tiny by construction: the kernel is VALU-issue bound (see "valu").
     score_launch_ms = sc["ms"] / max(sc["launches"], 1)
-    ops_per_cell = 9.5  # 16-bit formulation: 5 v_add_u16 + 4 v_max_i16 + 0.5 v_ashrrev_i32 per cell
+    ops_per_cell = 8.0  # 16-bit formulation with the shared gap-open term: 4 v_add_u16 + 4 v_max_i16 per cell
+    # HBM bytes of one launch as measured by rocprofv3 PMC passes (WRITE_SIZE + FETCH_SIZE, separate passes, summary
+    # committed under profiles/): mostly the wavefront checkpoints + last-row values the band traceback restarts from
+    traffic, traffic_src = None, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))
+        per = {c: [r for r in pmc if r["counter"] == c and "gotoh_ckpt_kernel" in r["kernel"]] for c in ("WRITE_SIZE", "FETCH_SIZE")}
+        if per["WRITE_SIZE"] and per["FETCH_SIZE"]:
+            traffic = int(per["WRITE_SIZE"][0]["bytes"] + per["FETCH_SIZE"][0]["bytes"])
+            traffic_src = "profiles/r01_pmc_hbm.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE of this command, same batch)"
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = {"bound": "hbm", "kernel": "gotoh_ckpt_kernel<K,QP,narrow> (score-only Gotoh, fwd+rev orientation; dominant: %.0f%% of the step)"
                 % (100.0 * sc["ms"] / steps / (elapsed_max / steps * 1e3)),
                 "achieved": round(gbs(sc), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs(sc) / HBM_PEAK_GBS, 5),
-                "traffic": None, "avg_launch_ms": round(score_launch_ms, 3), "launches": sc["launches"],
+                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(score_launch_ms, 3), "launches": sc["launches"],
                 "algorithmic_bytes_per_launch": sc["bytes"] // max(sc["launches"], 1), "kernel_gcups": round(kgcups(sc), 1),
                 "valu": {"achieved": round(kgcups(sc) * ops_per_cell / 1e3, 2), "peak": 78.6, "unit": "T lane-ops/s",
                          "frac": round(kgcups(sc) * ops_per_cell / 1e3 / 78.6, 3),

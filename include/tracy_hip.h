@@ -135,6 +135,10 @@ typedef struct {
   const uint32_t* ref_index; /* HOST array or NULL (= identity) */
   uint32_t trim_left;       /* SageConfig.trimLeft  (sage.h:88) */
   uint32_t trim_right;      /* SageConfig.trimRight (sage.h:89) */
+  const uint8_t* oriented;  /* HOST array or NULL.  Non-NULL = the indexed-genome path (sage.h:217-221): the caller anchored
+                               every trace by k-mer seeding (getReferenceSlice, fmindex.h:236-326) and passes refs that are
+                               ALREADY oriented (reverse-complemented for reverse traces); oriented[t] = rs.forward.  No
+                               orientation scores are computed: score_fwd and score_rev both receive gotohScore(trim, ref). */
 } tracyhip_align_job;
 
 typedef struct {

@@ -328,3 +328,120 @@ def trace_align_json(padded, chrom, pos, forward, row0, row1):
 def align_fasta_text(stem, chrom, forward, row0, row1):
     """sage.h:328-339"""
     return ">%s\n%s\n>%s %s\n%s\n" % (stem, row0.decode(), chrom, "(forward)" if forward else "(reverse)", row1.decode())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# k-mer seeding in an indexed genome (fmindex.h:173-326), brute-force restatement over the "dump" text
+# (upper-cased contigs joined by newlines).  Tests only; cross-checks tracy_amd/host/seed.hpp.
+# ---------------------------------------------------------------------------------------------------------
+class BruteGenome:
+    def __init__(self, contigs):
+        """contigs: list of (name, sequence str)"""
+        self.names = [n for n, _ in contigs]
+        self.lengths = [len(s) for _, s in contigs]
+        self.text = "".join(s.upper() + "\n" for _, s in contigs)
+        self._cache = {}
+
+    def locate(self, pat):
+        if pat not in self._cache:
+            out, p = [], self.text.find(pat)
+            while p != -1:
+                out.append(p)
+                p = self.text.find(pat, p + 1)
+            self._cache[pat] = out
+        return self._cache[pat]
+
+
+def _revcomp_str(s):
+    """reverseComplement(std::string&), fmindex.h:11-25: letters outside ACGTN keep the ORIGINAL byte of that position"""
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    rev = s[::-1].upper()
+    return "".join(comp.get(rev[i], s[i]) for i in range(len(s)))
+
+
+def scan_sequence(g, consensus, trim_left, trim_right, kmer, unique):
+    hits = []
+    ncount = sum(1 for i in range(trim_left, min(trim_left + kmer, len(consensus))) if consensus[i] == "N")
+    k = trim_left
+    while k < len(consensus) - trim_right and k < len(consensus):
+        if ncount == 0:
+            seq = consensus[k:k + kmer]
+            loc = g.locate(seq)
+            if unique:
+                if len(loc) == 1:
+                    hits.append(loc[0] - k)
+            elif 0 < len(loc) < 1000:
+                hits.extend(p - k for p in loc)
+        if consensus[k] == "N":
+            ncount -= 1
+        if k + kmer < len(consensus) and consensus[k + kmer] == "N":
+            ncount += 1
+        k += 1
+    return hits
+
+
+def find_max_freq(hits):
+    if not hits:
+        return 0, 0
+    hits = sorted(hits)
+    best, gpos, run = 1, hits[0], 1
+    for i in range(1, len(hits)):
+        if hits[i] == hits[i - 1]:
+            run += 1
+            if run > best:
+                best, gpos = run, hits[i]
+        else:
+            run = 1
+    return best, gpos
+
+
+def get_reference_slice(g, consensus, trim_left=50, trim_right=50, kmer=15, min_support=3, maxindel=1000):
+    """fmindex.h:236-326 for an indexed genome -> dict(forward, kmersupport, pos, chr, refslice) or None"""
+    rv = _revcomp_str(consensus)
+    res = None
+    for unique in (True, False):
+        ff, bf = find_max_freq(scan_sequence(g, consensus, trim_left, trim_right, kmer, unique))
+        fr, br = find_max_freq(scan_sequence(g, rv, trim_right, trim_left, kmer, unique))
+        if ff >= min_support and ff > 2 * fr:
+            res = (True, ff, bf)
+            break
+        if fr >= min_support and fr > 2 * ff:
+            res = (False, fr, br)
+            break
+    if res is None:
+        return None
+    forward, support, best = res
+    cumsum, ref = 0, 0
+    while best >= cumsum + g.lengths[ref] + 1:
+        cumsum += g.lengths[ref] + 1
+        ref += 1
+    seqlen = g.lengths[ref] + 1
+    chrpos = max(best - cumsum, 0)
+    slicestart = chrpos - maxindel if chrpos > maxindel else 0
+    sliceend = seqlen
+    tmpend = chrpos + len(consensus) + maxindel
+    if tmpend < seqlen:
+        sliceend = tmpend
+    last = min(sliceend, g.lengths[ref] - 1)  # faidx_fetch_seq: inclusive end, clipped
+    start = sum(n + 1 for n in g.lengths[:ref])
+    sl = g.text[start + slicestart:start + last + 1] if slicestart <= last else ""
+    if not forward:
+        sl = _revcomp_str(sl)
+    return dict(forward=forward, kmersupport=support, pos=slicestart, chr=g.names[ref], contig=ref, refslice=sl)
+
+
+def align_trace_oriented(profile_full, window, forward, score, trim_left=50, trim_right=50):
+    """the indexed-genome branch of sage.h (:217-221, 258-260, 311): `window` is already oriented"""
+    import numpy as np
+    mf = profile_full.shape[1]
+    tl, tr = trim_left, trim_right
+    if tl + tr >= mf:
+        tl = tr = 0
+    trimmed = np.ascontiguousarray(profile_full[:, tl:mf - tr])
+    pref = orc.create_profile_str(window)
+    sc1, btr1 = orc.gotoh_prof(trimmed, pref, 1, 0, score)
+    r0, r1 = orc.create_alignment_prof(btr1, trimmed, pref)
+    ri, risize, pos_add, _ = orc.trim_reference_slice(r0, r1, trim_left, trim_right, len(window), forward)
+    sl = window[ri:ri + risize]
+    sc2, btr2 = orc.gotoh_prof(profile_full, orc.create_profile_str(sl), 1, 0, score)
+    return dict(score_prelim=sc1, slice_begin=ri, slice_len=len(sl), ref_pos=pos_add, score_final=sc2, btr=btr2, refslice=sl)

@@ -241,3 +241,116 @@ def test_decompose_cli_batch_and_failures(tmp_path):
     open(bad, "w").write(">unrelated\n%s\n" % bytes(rng.choice(list(b"ACGT"), size=30).tolist()).decode())
     p = subprocess.run([CLI, "decompose", "-r", bad, "-o", str(tmp_path / "bad"), rows[0][0]], capture_output=True, text=True, timeout=300)
     assert p.returncode == 255 and "Alignment of trace to reference failed!" in p.stderr
+
+
+# ---- indexed genome: host k-mer seeding + device extend (BASELINE configs[3]) ---------------------------------
+def write_genome(rng, tmp, ncontigs=3, clen=20000):
+    import gzip
+    contigs = [("ctg%d" % i, bytes(rng.choice(list(b"ACGT"), size=clen + 777 * i).tolist()).decode()) for i in range(ncontigs)]
+    path = os.path.join(tmp, "genome.fa.gz")
+    with gzip.open(path, "wt") as f:
+        for name, seq in contigs:
+            f.write(">%s some description\n" % name)
+            for i in range(0, len(seq), 80):
+                f.write(seq[i:i + 80] + "\n")
+    return path, contigs
+
+
+def genomic_trace(rng, tmp, tag, contigs, nb=500, reverse=False):
+    """ABIF trace whose bases are a stretch of a contig (with a few edits)"""
+    from tracy_amd import hostlib
+    ci = int(rng.integers(0, len(contigs)))
+    seq = contigs[ci][1]
+    start = int(rng.integers(0, len(seq) - nb - 10))
+    core = bytearray(seq[start:start + nb + 6].encode())
+    del core[200:203]
+    core[250] = ord("A") if core[250] != ord("A") else ord("G")
+    core = bytes(core[:nb])
+    if reverse:
+        core = so.revcomp(core)
+    tr = np.zeros((4, 12 * nb + 12), np.int32)
+    pos = 6 + 12 * np.arange(nb, dtype=np.int32)
+    tri = 1.0 - np.abs(np.arange(-5, 6)) / 6.0
+    for j, ch in enumerate(core):
+        amp = rng.uniform(500, 1100)
+        tr[b"ACGT".index(ch), pos[j] - 5:pos[j] + 6] += (amp * tri).astype(np.int32)
+        tr[int(rng.integers(0, 4)), pos[j] - 5:pos[j] + 6] += (amp * 0.08 * tri).astype(np.int32)
+    path = os.path.join(tmp, tag + ".ab1")
+    hostlib.write_abif(path, tr, pos, core, np.full(nb, 40, np.uint8))
+    return path
+
+
+def expected_indexed(trace_path, contigs, stem, linelimit=60):
+    from tracy_amd import hostlib
+    t = hostlib.read_trace(trace_path)
+    tr, pos = t["signal"], t["basecallpos"]
+    pri, sec, con, bcpos, q = hostlib.basecall_qual(tr, pos, 0.33)
+    full = orc.create_profile_trace(tr, bcpos, pri, sec, 0, 0)
+    g = so.BruteGenome(contigs)
+    rs = so.get_reference_slice(g, con.decode())
+    assert rs is not None
+    r = so.align_trace_oriented(full, rs["refslice"].encode(), rs["forward"], SC)
+    refp = orc.create_profile_str(r["refslice"])
+    row0, row1 = orc.create_alignment_prof(r["btr"], full, refp)
+    padded = so.alignment_trace_padding(row0, tr, bcpos, pri, sec, con, q)
+    rpos = rs["pos"] + r["ref_pos"]
+    return {
+        ".txt": so.plot_alignment(row0, row1, rs["chr"], rpos, len(r["refslice"]), rs["forward"], r["score_final"], linelimit),
+        ".json": so.trace_align_json(padded, rs["chr"], rpos, rs["forward"], row0, row1),
+        ".align.fa": so.align_fasta_text(stem, rs["chr"], rs["forward"], row0, row1),
+    }, rs
+
+
+def test_align_against_indexed_genome(tmp_path):
+    rng = np.random.default_rng(2718)
+    gpath, contigs = write_genome(rng, str(tmp_path))
+    rows = []
+    for i in range(4):
+        t = genomic_trace(rng, str(tmp_path), "g%d" % i, contigs, nb=int(rng.integers(300, 700)), reverse=bool(i % 2))
+        rows.append((t, gpath, str(tmp_path / ("gres%d" % i))))
+    # single-trace form
+    p = subprocess.run([CLI, "align", "-r", gpath, "-o", rows[0][2], rows[0][0]], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "Load FM-Index" in p.stdout
+    want, rs = expected_indexed(rows[0][0], contigs, "g0")
+    for ext, txt in want.items():
+        assert open(rows[0][2] + ext).read() == txt, ext
+    # batch form: one index, one device batch
+    man = str(tmp_path / "gm.tsv")
+    open(man, "w").write("".join("\t".join(r) + "\n" for r in rows))
+    p = subprocess.run([CLI, "align", "--batch", man], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    seen = set()
+    for t, _, pre in rows:
+        want, rs = expected_indexed(t, contigs, os.path.splitext(os.path.basename(t))[0])
+        seen.add(rs["forward"])
+        for ext, txt in want.items():
+            assert open(pre + ext).read() == txt, (pre, ext)
+    assert seen == {True, False}
+    # a trace that is nowhere in the genome cannot be anchored
+    lost = genomic_trace(rng, str(tmp_path), "lost", [("x", bytes(rng.choice(list(b"ACGT"), size=5000).tolist()).decode())])
+    p = subprocess.run([CLI, "align", "-r", gpath, "-o", str(tmp_path / "lost"), lost], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 255 and "Couldn't anchor the Sanger trace" in p.stderr
+
+
+def test_oriented_pipeline_mode_through_the_abi():
+    """tracyhip_align_traces with job.oriented (no orientation scores) == the oracle's indexed-genome branch"""
+    import tracy_amd
+    from tracy_amd import hostlib
+    refs, profs, rev = hostlib.synth_align(4400, 12, 2600, 500, 2)
+    ctx = tracy_amd.Context(0)
+    windows, fwd = [], []
+    for i in range(12):
+        w = refs[i].tobytes()
+        if rev[i]:
+            w = so.revcomp(w)          # what seeding hands over: the window in trace orientation
+        windows.append(w)
+        fwd.append(0 if rev[i] else 1)
+    got = ctx.align_traces(list(profs), windows, SC, 50, 50, oriented=fwd)
+    for i in range(12):
+        want = so.align_trace_oriented(profs[i], windows[i], bool(fwd[i]), SC)
+        for k in ("score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
+            assert int(got[k][i]) == int(want[k]), (i, k)
+        assert got["btr"][i] == want["btr"] and int(got["forward"][i]) == fwd[i]
+        assert int(got["score_fwd"][i]) == int(got["score_rev"][i]) == int(want["score_prelim"])
+    ctx.close()

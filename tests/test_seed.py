@@ -1,0 +1,109 @@
+"""Host k-mer seeding for indexed genomes (tracy_amd/host/seed.hpp; fmindex.h:173-326, BASELINE configs[3]) against a
+brute-force restatement over the same text.  PARITY UNPINNED: the reference queries an sdsl-lite FM index (absent);
+any exact index yields the same occurrence sets."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import sage_oracle as so
+
+
+def rand_dna(rng, n):
+    return bytes(rng.choice(list(b"ACGT"), size=n).tolist()).decode()
+
+
+@pytest.fixture(scope="module")
+def genome(tmp_path_factory):
+    from tracy_amd import hostlib
+    rng = np.random.default_rng(123)
+    rep = rand_dna(rng, 400)
+    c1 = rand_dna(rng, 30000)
+    c1 = c1[:5000] + rep + c1[5000:12000] + "N" * 300 + c1[12000:20000] + rep + c1[20000:]      # a repeat + an N run
+    c2 = rand_dna(rng, 9000)
+    c2 = c2[:3000] + rep + c2[3000:]
+    c3 = rand_dna(rng, 2500)                                                                    # shorter than a window
+    low = c2[:100].lower() + c2[100:]                                                           # lower case is upper-cased
+    contigs = [("chrA", c1), ("chrB description text", c2), ("chrC", c3)]
+    path = str(tmp_path_factory.mktemp("genome") / "toy.fa.gz")
+    with gzip.open(path, "wt") as f:
+        for (name, seq), body in zip(contigs, (c1, low, c3)):
+            f.write(">%s\n" % name)
+            for i in range(0, len(body), 60):
+                f.write(body[i:i + 60] + "\n")
+    g = hostlib.Genome(path, 15, 2)
+    brute = so.BruteGenome([("chrA", c1), ("chrB", c2), ("chrC", c3)])
+    return g, brute, path
+
+
+def make_reads(rng, brute, n):
+    reads = []
+    text_contigs = brute.text.split("\n")[:-1]
+    for i in range(n):
+        ci = int(rng.integers(0, 3))
+        seq = text_contigs[ci]
+        L = int(rng.integers(150, 900))
+        L = min(L, len(seq) - 1)
+        start = int(rng.choice([0, len(seq) - L, rng.integers(0, len(seq) - L + 1)]))
+        r = list(seq[start:start + L])
+        for k in range(len(r)):
+            u = rng.random()
+            if u < 0.01:
+                r[k] = "ACGT"[int(rng.integers(0, 4))]
+            elif u < 0.02:
+                r[k] = "N"
+        r = "".join(r)
+        if i % 2:
+            r = so._revcomp_str(r)
+        reads.append(r)
+    reads.append(rand_dna(rng, 500))                    # unrelated: cannot be anchored
+    reads.append("N" * 300)                             # no usable k-mer
+    return reads
+
+
+def test_counts_match_brute_force(genome):
+    g, brute, _ = genome
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        p = int(rng.integers(0, len(brute.text) - 15))
+        pat = brute.text[p:p + 15]
+        assert g.count(pat.encode()) == len(brute.locate(pat)), pat
+    assert g.count(b"ACGTACGTACGTACG") == len(brute.locate("ACGTACGTACGTACG"))
+    assert g.count(b"ACGTAC") == len(brute.locate("ACGTAC"))  # shorter than k: answered by a scan
+
+
+@pytest.mark.parametrize("trims,kmer_support,maxindel", [((50, 50), 3, 1000), ((10, 5), 3, 200), ((0, 0), 8, 1000)])
+def test_get_reference_slice(genome, trims, kmer_support, maxindel):
+    g, brute, _ = genome
+    rng = np.random.default_rng(77 + trims[0])
+    reads = make_reads(rng, brute, 40)
+    got = g.seed([r.encode() for r in reads], trims[0], trims[1], kmer_support, maxindel, 2)
+    anchored = 0
+    for i, r in enumerate(reads):
+        want = so.get_reference_slice(brute, r, trims[0], trims[1], 15, kmer_support, maxindel)
+        if want is None:
+            assert got["status"][i] == 0, i
+            continue
+        anchored += 1
+        assert got["status"][i] == 1, i
+        assert bool(got["forward"][i]) == want["forward"] and int(got["kmersupport"][i]) == want["kmersupport"], i
+        assert int(got["pos"][i]) == want["pos"] and int(got["contig"][i]) == want["contig"], i
+        assert got["slices"][i].decode() == want["refslice"], i
+    # (with trimRight < kmer the tail patterns get shorter than k and even an unrelated read can collect votes --
+    # the reference behaves the same way, fmindex.h:211-214)
+    assert anchored >= 30 and got["status"][-1] == 0
+    if trims[1] >= 15:
+        assert got["status"][-2] == 0
+
+
+def test_repeat_reads_need_the_second_pass(genome):
+    """a read lying inside the 3-copy repeat has no unique 15-mers: the first pass fails, the multi-hit pass ties"""
+    g, brute, _ = genome
+    rep_start = brute.text.find(brute.text[5000:5400])
+    read = brute.text[rep_start + 20:rep_start + 380]
+    want = so.get_reference_slice(brute, read, 10, 10)
+    got = g.seed([read.encode()], 10, 10)
+    assert (got["status"][0] == 1) == (want is not None)
+    if want is not None:
+        assert got["slices"][0].decode() == want["refslice"] and int(got["pos"][0]) == want["pos"]

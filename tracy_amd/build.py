@@ -67,7 +67,7 @@ def build_host(force=False, verbose=False):
     srcs = [os.path.join(hdir, f) for f in os.listdir(hdir)]
     if force or stale(HOST_SO, srcs):
         cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-Wall",
-               "-o", HOST_SO, os.path.join(hdir, "tracy_host_capi.cpp")]
+               "-o", HOST_SO, os.path.join(hdir, "tracy_host_capi.cpp"), "-lz"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -85,7 +85,7 @@ def build_cli(force=False, verbose=False):
     srcs = [src, SO, os.path.join(os.path.dirname(HERE), "include", "tracy_hip.h")] + [os.path.join(hdir, f) for f in os.listdir(hdir)]
     if force or stale(CLI, srcs):
         cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-o", CLI, src, "-L" + LIBDIR, "-ltracy_hip",
-               "-Wl,-rpath,$ORIGIN/../lib"]
+               "-Wl,-rpath,$ORIGIN/../lib", "-lz", "-pthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

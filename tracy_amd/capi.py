@@ -38,7 +38,7 @@ class Pairs(C.Structure):
 
 class AlignJob(C.Structure):
     _fields_ = [("ntraces", C.c_uint32), ("profiles", SeqSet), ("refs", SeqSet), ("ref_index", C.POINTER(C.c_uint32)),
-                ("trim_left", C.c_uint32), ("trim_right", C.c_uint32)]
+                ("trim_left", C.c_uint32), ("trim_right", C.c_uint32), ("oriented", C.POINTER(C.c_uint8))]
 
 
 class AlignResult(C.Structure):
@@ -210,8 +210,9 @@ class Context:
         return scores[:n], btr, rws
 
 
-def _align_traces(self, profiles, refs, params, trim_left=50, trim_right=50, ref_index=None):
+def _align_traces(self, profiles, refs, params, trim_left=50, trim_right=50, ref_index=None, oriented=None):
     """tracyhip_align_traces with host buffers.  profiles: list of float32 [6][mf]; refs: list of bytes.
+    oriented: None, or rs.forward per trace when the references are already oriented (indexed-genome path).
     Returns a dict of numpy arrays + the list of final traceback strings (push order)."""
     pp = profiles if isinstance(profiles, PackedSeqs) else PackedSeqs(profiles, SEQ_PROFILE)
     pr = refs if isinstance(refs, PackedSeqs) else PackedSeqs(refs, SEQ_CHAR)
@@ -230,6 +231,10 @@ def _align_traces(self, profiles, refs, params, trim_left=50, trim_right=50, ref
         rlen = pr.length[:nt]
     job.trim_left = trim_left
     job.trim_right = trim_right
+    if oriented is not None:
+        oriented = np.ascontiguousarray(oriented, dtype=np.uint8)
+        job.oriented = oriented.ctypes.data_as(C.POINTER(C.c_uint8))
+        keep.append(oriented)
     cap = pp.length[:nt].astype(np.uint64) + rlen.astype(np.uint64)
     off = np.zeros(max(nt, 1), dtype=np.uint64)
     if nt:

@@ -10,8 +10,9 @@
 // Host stages (as in the reference): ABIF/SCF parsing, basecalling, trimming estimate, profiles, file
 // writers.  Device stages: every Gotoh DP, orientation, trimReferenceSlice, alignment rows.  There is no
 // CPU fallback: without a GPU the command fails with the library's error text.
-// Not built yet: references given as an indexed .fa.gz genome (FM-index seeding, fmindex.h:173-326); a
-// wildtype-trace reference for `decompose`; --annotate (needs the network).  Variants (-v) are written as
+// `align` also takes an indexed genome (gzip-compressed multi-FASTA): the trace is anchored by k-mer votes
+// (seed.hpp, fmindex.h:173-326) and aligned against the window around the hit.
+// Not built yet: indexed genomes and wildtype-trace references for `decompose`; --annotate (needs the network).  Variants (-v) are written as
 // VCF text because htslib (BCF) is not available.
 #include <cstdio>
 #include <cstdlib>
@@ -28,13 +29,14 @@
 #include "../../include/tracy_hip.h"
 #include "../host/indigo_out.hpp"
 #include "../host/sage_out.hpp"
+#include "../host/seed.hpp"
 
 using namespace tracy_amd;
 
 namespace {
 
 struct SageConfig {  // sage.h:37-56 + the extra fields of IndigoConfig (indigo.h:16-40)
-  uint16_t linelimit = 60, trimLeft = 50, trimRight = 50, maxindel = 1000, madc = 5, qualCut = 45;
+  uint16_t linelimit = 60, trimLeft = 50, trimRight = 50, maxindel = 1000, madc = 5, qualCut = 45, kmer = 15, minKmerSupport = 3;
   float pratio = 0.33f, trimStringency = 0;
   int32_t gapopen = -10, gapext = -4, match = 3, mismatch = -5;
   bool callvariants = false;
@@ -49,7 +51,8 @@ struct Job {
   uint32_t trimLeft = 0, trimRight = 0;
   Profile full;
   ReferenceSlice rs;
-  std::string fasta;         // filetype 1: the loaded record (forward strand)
+  std::string fasta;         // filetype 1: the loaded record (forward strand); filetype 0: the oriented window
+  uint32_t slice_start = 0;  // filetype 0: offset of the window in its contig
   Profile wt_fwd;            // filetype 2: wildtype profile
   std::string wt_primary;
   int32_t score = 0;
@@ -166,7 +169,8 @@ int parse(int argc, char** argv, SageConfig& c) {
       case 'c': c.madc = (uint16_t)std::atoi(val.c_str()); break;
       case 'z': c.qualCut = (uint16_t)std::atoi(val.c_str()); break;
       case 'a': c.annotate = val; break;
-      case 'k': case 's': break;  // k-mer anchoring only applies to indexed genomes
+      case 'k': c.kmer = (uint16_t)std::atoi(val.c_str()); break;
+      case 's': c.minKmerSupport = (uint16_t)std::atoi(val.c_str()); break;
       default: std::cerr << "unrecognised option '" << a << "'" << std::endl; return 1;
     }
   }
@@ -180,6 +184,23 @@ bool load_trace(std::string const& path, Trace& tr) {
   if (ft == 1) return readscf(path, tr);
   std::cerr << "Unknown trace file type!" << std::endl;
   return false;
+}
+
+// k-mer tables of the indexed genomes named on the command line / in the manifest, built on first use
+// (the reference loads the .fm9 written by `tracy index`; here the table is rebuilt in memory, seed.hpp)
+const GenomeIndex* genome_index(SageConfig const& c, std::string const& path) {
+  static std::map<std::string, GenomeIndex> cache;
+  auto it = cache.find(path);
+  if (it != cache.end()) return &it->second;
+  std::cout << stamp() << "Load FM-Index" << std::endl;
+  GenomeIndex& g = cache[path];
+  if (!g.load(path)) {
+    std::cerr << "Couldn't recognize reference file format!" << std::endl;
+    cache.erase(path);
+    return nullptr;
+  }
+  g.build(c.kmer);
+  return &g;
 }
 
 // host stages up to the device batch (sage.h:141-207, 222-231, 261-277); returns the CLI exit code
@@ -210,9 +231,20 @@ int prepare(SageConfig const& c, Job& j, bool decompose = false) {
     return -1;
   }
   if (j.rs.filetype == 0) {
-    std::cerr << "Indexed genomes (FM-index seeding) are not part of this build; pass a FASTA slice (<= 50 kbp) or a wildtype trace."
-              << std::endl;
-    return -1;
+    // indexed genome (sage.h:217-221): anchor the trace by k-mer votes, take the window around the hit
+    if (decompose) {
+      std::cerr << "Indexed genomes for decompose are not part of this build; pass a FASTA slice (<= 50 kbp)." << std::endl;
+      return -1;
+    }
+    const GenomeIndex* idx = genome_index(c, j.ref_path);
+    if (!idx) return -1;
+    SeedConfig sc;
+    sc.trimLeft = (uint16_t)j.trimLeft; sc.trimRight = (uint16_t)j.trimRight; sc.kmer = c.kmer; sc.minKmerSupport = c.minKmerSupport;
+    sc.maxindel = c.maxindel;
+    if (!getReferenceSlice(sc, *idx, j.bc.consensus, j.rs)) return -1;
+    j.fasta = j.rs.refslice;  // already oriented
+    j.slice_start = j.rs.pos;
+    return 0;
   }
   if (decompose && j.rs.filetype == 2) {
     std::cerr << "A wildtype-trace reference for decompose is not part of this build; pass a FASTA slice (<= 50 kbp)." << std::endl;
@@ -290,6 +322,10 @@ bool align_fasta_group(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vecto
   job.refs = tracyhip_seqset{TRACYHIP_SEQ_CHAR, refs.data(), roff.data(), rlen.data(), nt};
   job.trim_left = jobs[0]->trimLeft;
   job.trim_right = jobs[0]->trimRight;
+  const bool seeded = jobs[0]->rs.filetype == 0;  // groups never mix seeded and FASTA references
+  std::vector<uint8_t> orient(nt);
+  for (uint32_t i = 0; i < nt; ++i) orient[i] = jobs[i]->rs.forward ? 1 : 0;
+  if (seeded) job.oriented = orient.data();
   std::vector<int32_t> sf(nt), sr(nt), sfin(nt);
   std::vector<uint8_t> fwd(nt), ops(ocap ? ocap : 1);
   std::vector<uint32_t> sb(nt), sl(nt), rp(nt), olen(nt);
@@ -305,9 +341,9 @@ bool align_fasta_group(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vecto
     Job& j = *jobs[i];
     j.rs.forward = fwd[i] != 0;
     std::string oriented = j.fasta;
-    if (!j.rs.forward) reverseComplement(oriented);
+    if (!seeded && !j.rs.forward) reverseComplement(oriented);
     j.rs.refslice = oriented.substr(sb[i], sl[i]);
-    j.rs.pos = rp[i];
+    j.rs.pos = j.slice_start + rp[i];
     j.score = sfin[i];
     soff[i] = slices.size();
     slices.insert(slices.end(), j.rs.refslice.begin(), j.rs.refslice.end());
@@ -467,15 +503,18 @@ int align_main(int argc, char** argv) {
     return -1;
   }
   tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};  // AlignConfig<true,false>, sage.h:165
-  std::map<std::pair<uint32_t, uint32_t>, std::vector<Job*>> fasta_groups;
+  std::map<std::pair<uint32_t, uint32_t>, std::vector<Job*>> fasta_groups, seeded_groups;
   std::vector<Job*> wildtype;
   for (Job& j : jobs) {
     if (!j.ok) continue;
     if (j.rs.filetype == 1) fasta_groups[std::make_pair(j.trimLeft, j.trimRight)].push_back(&j);
+    else if (j.rs.filetype == 0) seeded_groups[std::make_pair(j.trimLeft, j.trimRight)].push_back(&j);
     else wildtype.push_back(&j);
   }
   std::cout << stamp() << "Alignment" << std::endl;
   for (auto& g : fasta_groups)
+    if (!align_fasta_group(dev.ctx, prm, g.second)) return -1;
+  for (auto& g : seeded_groups)
     if (!align_fasta_group(dev.ctx, prm, g.second)) return -1;
   if (!wildtype.empty() && !align_wildtype_group(dev.ctx, prm, wildtype)) return -1;
 

@@ -70,22 +70,32 @@ __global__ __launch_bounds__(64) void needle_walk_kernel(WalkArgs a, const uint3
 }
 
 // _createAlignment (align.h:196-223 / 254-293): one lane per output column, forward order.
-// ops are in push order, so column ai corresponds to ops[L-1-ai]; the consumed-row / consumed-column
-// counts at ai are prefix sums, computed here by one sequential lane per pair (O(L), L <= m+n).
+// ops are in push order, so column ai corresponds to ops[L-1-ai].  One wave per pair: 64 columns per round,
+// the consumed-row / consumed-column counts of a column are prefix popcounts of the wave's ballots.
 __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.npairs) return;
+  const uint32_t i = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
   const PairDesc d = a.pairs[i];
   const uint64_t off = a.ops_off[d.out];
   const uint32_t L = a.ops_len[d.out];
   const uint8_t* ops = a.ops + off;
   uint8_t* r0 = a.rows0 + off;
   uint8_t* r1 = a.rows1 + off;
-  uint32_t row = 0, col = 0;
-  for (uint32_t ai = 0; ai < L; ++ai) {
-    const uint8_t op = ops[L - 1 - ai];
+  const uint64_t below = (1ull << lane) - 1ull;
+  uint32_t row_base = 0, col_base = 0;
+  for (uint32_t base = 0; base < L; base += 64) {
+    const uint32_t ai = base + lane;
+    const bool active = ai < L;
+    const uint8_t op = active ? ops[L - 1 - ai] : 0;
+    const bool takes_row = active && op != 'h';  // consumes a1
+    const bool takes_col = active && op != 'v';  // consumes a2
+    const uint64_t mrow = __ballot(takes_row), mcol = __ballot(takes_col);
+    const uint32_t row = row_base + (uint32_t)__popcll(mrow & below);
+    const uint32_t col = col_base + (uint32_t)__popcll(mcol & below);
+    row_base += (uint32_t)__popcll(mrow);
+    col_base += (uint32_t)__popcll(mcol);
     uint8_t c0 = '-', c1 = '-';
-    if (op != 'h') {  // consumes a1
+    if (takes_row) {
       if (a.a1_profile) {
         float p[6];
         for (int k = 0; k < 6; ++k) p[k] = static_cast<const float*>(a.a1)[d.a1_off + (uint64_t)k * d.a1_stride + row];
@@ -93,9 +103,8 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
       } else {
         c0 = static_cast<const uint8_t*>(a.a1)[d.a1_off + row];
       }
-      ++row;
     }
-    if (op != 'v') {  // consumes a2
+    if (takes_col) {
       if (a.a2_profile) {
         float p[6];
         for (int k = 0; k < 6; ++k) p[k] = static_cast<const float*>(a.a2)[d.a2_off + (uint64_t)k * d.a2_stride + col];
@@ -109,10 +118,11 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
           c1 = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'T' : code == 6 ? 'A' : 'N';
         }
       }
-      ++col;
     }
-    r0[ai] = c0;
-    r1[ai] = c1;
+    if (active) {
+      r0[ai] = c0;
+      r1[ai] = c1;
+    }
   }
 }
 
@@ -242,7 +252,7 @@ hipError_t launch_needle_walk(const WalkArgs& a, const uint32_t* bits32, hipStre
 }
 hipError_t launch_alignment_rows(const RowsArgs& a, hipStream_t s) {
   if (a.npairs == 0) return hipSuccess;
-  hipLaunchKernelGGL(alignment_rows_kernel, dim3((a.npairs + 63) / 64), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(alignment_rows_kernel, dim3(a.npairs), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 

@@ -197,6 +197,9 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   bool use_band = getenv("TRACYHIP_NO_BAND") == nullptr && p.ge < 0 && p.go <= 0;  // hfree = 1, vfree = 0 here
   DpCkpt ck;
   ck.B = 256;
+  // job->oriented: the references are already oriented by the caller (k-mer seeding): one score pass, no decision
+  const bool given = job->oriented != nullptr;
+  const int norient = given ? 1 : 2;
   std::vector<uint64_t> ck_off(2 * (size_t)nt), lr_off(2 * (size_t)nt);
   {
     uint64_t ck_tot = 0, lr_tot = 0;
@@ -205,7 +208,7 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
       if (mt[t] == 0 || rn[t] == 0 || num_passes(mt[t], K) != 1) { use_band = false; break; }
       const uint32_t lanes_used = (mt[t] + K - 1) / K;
       const uint64_t J = ((uint64_t)rn[t] + lanes_used - 1) / ck.B;
-      for (int o = 0; o < 2; ++o) {
+      for (int o = 0; o < norient; ++o) {
         ck_off[(size_t)o * nt + t] = ck_tot;
         lr_off[(size_t)o * nt + t] = lr_tot;
         ck_tot += J * ckpt_fields(K) * 64;
@@ -234,8 +237,8 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
     pb.a1_profile = true;
     pb.d_a1 = d_prof;
     pb.d_a2 = ctx->d_codes.p;
-    pb.desc.resize(2 * (size_t)nt);
-    pb.k.resize(2 * (size_t)nt);
+    pb.desc.resize((size_t)norient * nt);
+    pb.k.resize((size_t)norient * nt);
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc d{};
       d.a1_off = sp.offset[t] + tl[t];
@@ -248,6 +251,8 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
       d.ckpt_off = ck_off[t];
       d.lastrow_off = lr_off[t];
       pb.desc[t] = d;
+      pb.k[t] = choose_k(d.m, MODE_QP);
+      if (given) continue;
       d.out = nt + t;
       d.flags = PAIR_A2_REVCOMP;
       d.ckpt_off = ck_off[(size_t)nt + t];
@@ -257,11 +262,15 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
     }
     if ((rc = run_dp(ctx, pb, &p, false, false, d_sc2, nullptr, nullptr, nullptr, use_band ? DP_CKPT : DP_PLAIN, use_band ? &ck : nullptr))) return rc;
   }
-  std::vector<int32_t> h_sc2(2 * (size_t)nt);
-  HIP_TRY(hipMemcpyAsync(h_sc2.data(), d_sc2, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
+  std::vector<int32_t> h_sc2(2 * (size_t)nt, 0);
+  HIP_TRY(hipMemcpyAsync(h_sc2.data(), d_sc2, sizeof(int32_t) * (size_t)norient * nt, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  std::vector<uint8_t> h_fwd(nt);
-  for (uint32_t t = 0; t < nt; ++t) h_fwd[t] = h_sc2[t] > h_sc2[nt + t] ? 1 : 0;  // forward iff gsFwd > gsRev (sage.h:247)
+  std::vector<uint8_t> h_fwd(nt);   // rs.forward: decides how rs.pos moves in trimReferenceSlice
+  std::vector<uint8_t> h_rc(nt);    // the reference window has to be read as its reverse complement
+  for (uint32_t t = 0; t < nt; ++t) {
+    if (given) { h_fwd[t] = job->oriented[t] ? 1 : 0; h_rc[t] = 0; }
+    else { h_fwd[t] = h_sc2[t] > h_sc2[nt + t] ? 1 : 0; h_rc[t] = !h_fwd[t]; }  // forward iff gsFwd > gsRev (sage.h:247)
+  }
 
   // ---- 2. preliminary alignment gotoh(trim, oriented reference) (sage.h:258) ----
   std::vector<uint64_t> off1(nt);
@@ -291,8 +300,8 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
       d.n = rn[t];
       d.a2_stride = rn[t];
       d.out = t;
-      d.flags = h_fwd[t] ? 0 : PAIR_A2_REVCOMP;
-      const size_t o = h_fwd[t] ? t : (size_t)nt + t;  // the winning orientation's checkpoints
+      d.flags = h_rc[t] ? PAIR_A2_REVCOMP : 0;
+      const size_t o = h_rc[t] ? (size_t)nt + t : t;  // the winning orientation's checkpoints
       d.ckpt_off = ck_off[o];
       d.lastrow_off = lr_off[o];
       pb.desc[t] = d;
@@ -304,7 +313,7 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
                        static_cast<const uint64_t*>(ctx->d_tmp[2].p), static_cast<uint32_t*>(ctx->d_tmp[3].p), DP_BAND, &ck)))
         return rc;
       std::vector<int32_t> h_pre(nt);
-      for (uint32_t t = 0; t < nt; ++t) h_pre[t] = h_fwd[t] ? h_sc2[t] : h_sc2[nt + t];
+      for (uint32_t t = 0; t < nt; ++t) h_pre[t] = h_rc[t] ? h_sc2[nt + t] : h_sc2[t];
       HIP_TRY(hipMemcpy(ctx->d_tmp[4].p, h_pre.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice));
     } else if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(ctx->d_tmp[4].p), static_cast<uint8_t*>(ctx->d_tmp[1].p),
                             static_cast<const uint64_t*>(ctx->d_tmp[2].p), static_cast<uint32_t*>(ctx->d_tmp[3].p))))
@@ -358,8 +367,8 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
       d.a2_stride = d.n;
       // oriented slice [ri, ri+len): forward reads it in place, reverse reads original
       // [n-ri-len, n-ri) backwards with complemented codes
-      d.a2_off = sr.offset[ridx[t]] + (h_fwd[t] ? h_trim[t].ri : rn[t] - h_trim[t].ri - h_trim[t].len);
-      d.flags = h_fwd[t] ? 0 : PAIR_A2_REVCOMP;
+      d.a2_off = sr.offset[ridx[t]] + (h_rc[t] ? rn[t] - h_trim[t].ri - h_trim[t].len : h_trim[t].ri);
+      d.flags = h_rc[t] ? PAIR_A2_REVCOMP : 0;
       d.out = t;
       pb.desc[t] = d;
       pb.k[t] = choose_k(d.m, MODE_QP);
@@ -374,6 +383,7 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   for (uint32_t t = 0; t < nt; ++t) { h_begin[t] = h_trim[t].ri; h_len[t] = h_trim[t].len; h_pos[t] = h_trim[t].pos; }
   const hipMemcpyKind up = (mem == TRACYHIP_MEM_HOST) ? hipMemcpyHostToHost : hipMemcpyHostToDevice;
   HIP_TRY(hipMemcpyAsync(out->score_fwd, h_sc2.data(), sizeof(int32_t) * (size_t)nt, up, st));
+  if (given) std::copy(h_sc2.begin(), h_sc2.begin() + nt, h_sc2.begin() + nt);  // one orientation: both arrays report its score
   HIP_TRY(hipMemcpyAsync(out->score_rev, h_sc2.data() + nt, sizeof(int32_t) * (size_t)nt, up, st));
   HIP_TRY(hipMemcpyAsync(out->forward, h_fwd.data(), nt, up, st));
   HIP_TRY(hipMemcpyAsync(out->slice_begin, h_begin.data(), sizeof(uint32_t) * (size_t)nt, up, st));

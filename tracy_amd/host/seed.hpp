@@ -1,0 +1,305 @@
+// seed.hpp -- host-side anchoring of a trace in an indexed genome (BASELINE
+// configs[3]): exact k-mer hits of the basecalled consensus vote for a genome offset and an orientation, and a
+// reference window of trace length + 2*maxindel around the winner is handed to the device pipeline.
+//
+// Mirrors of /root/reference/src (names, argument meaning):
+//   findMaxFreq                          fmindex.h:173-198
+//   scanSequence                         fmindex.h:203-232
+//   getReferenceSlice                    fmindex.h:236-326
+// The reference asks an sdsl-lite FM index (csa_wt<>, count / locate; built by `tracy index`, index.h:79-124)
+// over the upper-cased genome with one '\n' between contigs.  sdsl-lite is not available here and the stored
+// .fm9 format is not reproduced: GenomeIndex below answers the same two queries -- number and positions of the
+// exact occurrences of a pattern in that text -- from a sorted k-mer table built in memory (any exact index
+// gives identical hit sets; the hits are sorted before use, fmindex.h:180).  PARITY UNPINNED (no sdsl, no
+// reference tests); tests/ cross-check against a brute-force search.
+// Sequence lengths follow the reference's convention seqlen = contig length + 1 (the separator).
+#ifndef TRACY_AMD_SEED_HPP
+#define TRACY_AMD_SEED_HPP
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "sage_out.hpp"
+
+namespace tracy_amd {
+
+class GenomeIndex {
+ public:
+  // upper-cased contigs joined by '\n' (the "dump" text of index.h:101-116), one trailing '\n'
+  std::string text;
+  std::vector<std::string> names;   // faidx_iseq: header up to the first whitespace
+  std::vector<uint32_t> lengths;    // contig lengths
+  std::vector<uint64_t> starts;     // offset of contig i in `text`
+  uint32_t k = 0;
+
+  // plain or gzip-compressed multi-FASTA
+  bool load(std::string const& path) {
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) return false;
+    text.clear(); names.clear(); lengths.clear(); starts.clear();
+    std::string line;
+    char buf[1 << 16];
+    bool first = true;
+    auto flush_line = [&]() {
+      if (!line.empty() && line.back() == '\r') line.pop_back();
+      if (!line.empty() && line[0] == '>') {
+        if (!first) { lengths.push_back((uint32_t)(text.size() - starts.back())); text.push_back('\n'); }
+        first = false;
+        const std::size_t ws = line.find_first_of(" \t");
+        names.push_back(line.substr(1, ws == std::string::npos ? std::string::npos : ws - 1));
+        starts.push_back(text.size());
+      } else if (!first) {
+        for (char c : line) text.push_back((char)std::toupper((unsigned char)c));
+      }
+      line.clear();
+    };
+    int n;
+    while ((n = gzread(f, buf, sizeof(buf))) > 0) {
+      for (int i = 0; i < n; ++i) {
+        if (buf[i] == '\n') flush_line();
+        else line.push_back(buf[i]);
+      }
+    }
+    if (!line.empty()) flush_line();
+    gzclose(f);
+    if (first) return false;
+    lengths.push_back((uint32_t)(text.size() - starts.back()));
+    text.push_back('\n');
+    return true;
+  }
+
+  // table of every k-mer over ACGT (k <= 32), sorted by code then position
+  void build(uint32_t kmer, uint32_t nthreads = 0) {
+    k = kmer;
+    table_.clear();
+    if (k == 0 || k > 32 || text.size() < k) return;
+    const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    uint64_t code = 0;
+    uint32_t valid = 0;
+    table_.reserve(text.size());
+    for (std::size_t p = 0; p < text.size(); ++p) {
+      const int b = base2(text[p]);
+      if (b < 0) { valid = 0; code = 0; continue; }
+      code = ((code << 2) | (uint64_t)b) & mask;
+      if (++valid >= k) table_.push_back(Entry{code, (uint64_t)(p + 1 - k)});
+    }
+    if (nthreads == 0) nthreads = std::max(1u, std::thread::hardware_concurrency());
+    sort_table(nthreads);
+    // bucket directory over the leading bits of the code: a lookup touches one directory slot + one short run
+    bucket_bits_ = std::min<uint32_t>(2 * k, 24);
+    const uint32_t shift = 2 * k - bucket_bits_;
+    bucket_.assign(((std::size_t)1 << bucket_bits_) + 1, 0);
+    for (Entry const& e : table_) ++bucket_[(std::size_t)(e.code >> shift) + 1];
+    for (std::size_t b = 1; b < bucket_.size(); ++b) bucket_[b] += bucket_[b - 1];
+  }
+
+  // table range of one k-mer code (k-mers over ACGT only)
+  void code_range(uint64_t code, std::size_t& lo, std::size_t& hi) const {
+    const std::size_t b = (std::size_t)(code >> (2 * k - bucket_bits_));
+    std::size_t i = bucket_[b];
+    const std::size_t e = bucket_[b + 1];
+    while (i < e && table_[i].code < code) ++i;  // buckets hold a handful of entries
+    lo = i;
+    while (i < e && table_[i].code == code) ++i;
+    hi = i;
+  }
+  uint64_t position(std::size_t i) const { return table_[i].pos; }
+  static int base_code(char c) { return base2(c); }
+
+  // occurrences of `pat` in the text (exact, over all characters the pattern may hold)
+  std::size_t count(std::string const& pat) const {
+    std::size_t lo, hi;
+    if (range(pat, lo, hi)) return hi - lo;
+    return scan(pat, nullptr);
+  }
+  void locate(std::string const& pat, std::vector<uint64_t>& out) const {
+    out.clear();
+    std::size_t lo, hi;
+    if (range(pat, lo, hi)) {
+      for (std::size_t i = lo; i < hi; ++i) out.push_back(table_[i].pos);
+      return;
+    }
+    scan(pat, &out);
+  }
+
+ private:
+  struct Entry { uint64_t code, pos; };
+  std::vector<Entry> table_;
+  std::vector<uint64_t> bucket_;  // table_ index of the first entry of every code prefix
+  uint32_t bucket_bits_ = 0;
+
+  static int base2(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+
+  // full-length ACGT patterns are answered from the table; anything else (shorter tail patterns when
+  // trimRight < kmer, patterns with other letters) by a scan of the text
+  bool range(std::string const& pat, std::size_t& lo, std::size_t& hi) const {
+    if (pat.size() != k || k == 0) return false;
+    uint64_t code = 0;
+    for (char c : pat) {
+      const int b = base2(c);
+      if (b < 0) return false;
+      code = (code << 2) | (uint64_t)b;
+    }
+    auto cmp = [](Entry const& e, uint64_t v) { return e.code < v; };
+    const std::size_t b = (std::size_t)(code >> (2 * k - bucket_bits_));
+    auto first = std::lower_bound(table_.begin() + bucket_[b], table_.begin() + bucket_[b + 1], code, cmp);
+    auto last = first;
+    while (last != table_.begin() + bucket_[b + 1] && last->code == code) ++last;
+    lo = (std::size_t)(first - table_.begin());
+    hi = (std::size_t)(last - table_.begin());
+    return true;
+  }
+  std::size_t scan(std::string const& pat, std::vector<uint64_t>* out) const {
+    if (pat.empty()) return 0;
+    std::size_t n = 0;
+    for (std::size_t p = text.find(pat); p != std::string::npos; p = text.find(pat, p + 1)) {
+      ++n;
+      if (out) out->push_back(p);
+    }
+    return n;
+  }
+  void sort_table(uint32_t nthreads) {
+    auto less = [](Entry const& a, Entry const& b) { return a.code < b.code || (a.code == b.code && a.pos < b.pos); };
+    if (nthreads <= 1 || table_.size() < (1u << 16)) {
+      std::sort(table_.begin(), table_.end(), less);
+      return;
+    }
+    // sort chunks in parallel, then merge pairwise
+    const std::size_t n = table_.size();
+    std::vector<std::size_t> cut;
+    for (uint32_t t = 0; t <= nthreads; ++t) cut.push_back(n * t / nthreads);
+    {
+      std::vector<std::thread> th;
+      for (uint32_t t = 0; t < nthreads; ++t) th.emplace_back([&, t]() { std::sort(table_.begin() + cut[t], table_.begin() + cut[t + 1], less); });
+      for (auto& x : th) x.join();
+    }
+    while (cut.size() > 2) {
+      std::vector<std::size_t> next;
+      std::vector<std::thread> th;
+      for (std::size_t i = 0; i + 2 < cut.size(); i += 2)
+        th.emplace_back([&, i]() { std::inplace_merge(table_.begin() + cut[i], table_.begin() + cut[i + 1], table_.begin() + cut[i + 2], less); });
+      for (auto& x : th) x.join();
+      for (std::size_t i = 0; i < cut.size(); i += 2) next.push_back(cut[i]);
+      if (next.back() != n) next.push_back(n);
+      cut.swap(next);
+    }
+  }
+};
+
+// findMaxFreq, fmindex.h:173-198: most frequent value of `hits` (sorted in place; smallest value on ties)
+inline uint32_t findMaxFreq(std::vector<int64_t>& hits, int64_t& gpos) {
+  gpos = 0;
+  if (hits.empty()) return 0;
+  std::sort(hits.begin(), hits.end());
+  int32_t best = 1, run = 1;
+  gpos = hits[0];
+  for (std::size_t i = 1; i < hits.size(); ++i) {
+    if (hits[i] == hits[i - 1]) {
+      if (++run > best) { best = run; gpos = hits[i]; }
+    } else {
+      run = 1;
+    }
+  }
+  return (uint32_t)best;
+}
+
+// scanSequence, fmindex.h:203-232: every k-mer of consensus[trimLeft, size - trimRight) without 'N' votes for
+// (genome position - offset in the trace).  unique: only k-mers that occur exactly once; otherwise every
+// occurrence of k-mers that occur fewer than 1000 times.  The window counter is 16 bits wide as in the reference.
+inline void scanSequence(GenomeIndex const& idx, std::string const& consensus, uint16_t trimLeft, uint16_t trimRight, uint16_t kmer,
+                         std::vector<int64_t>& hits, bool unique) {
+  int32_t ncount = 0;
+  for (uint16_t i = trimLeft; (i < trimLeft + kmer) && (i < consensus.size()); ++i)
+    if (consensus[i] == 'N') ++ncount;
+  std::vector<uint64_t> where;
+  // fast path: a full-length window over ACGT is looked up by its rolling 2-bit code
+  const bool table_ok = kmer == idx.k && kmer >= 1 && kmer <= 32;
+  const uint64_t mask = kmer >= 32 ? ~0ull : ((1ull << (2 * kmer)) - 1ull);
+  uint64_t code = 0;
+  uint32_t run = 0;  // ACGT letters ending at the window's last position (capped at kmer)
+  auto push_letter = [&](std::size_t q) {
+    const int b = q < consensus.size() ? GenomeIndex::base_code(consensus[q]) : -1;
+    if (b < 0) { run = 0; code = 0; return; }
+    code = ((code << 2) | (uint64_t)b) & mask;
+    if (run < kmer) ++run;
+  };
+  for (uint32_t q = trimLeft; q + 1 < (uint32_t)trimLeft + kmer; ++q) push_letter(q);
+  for (uint16_t p = trimLeft; (p < (consensus.size() - trimRight)) && (p < consensus.size()); ++p) {
+    push_letter((std::size_t)p + kmer - 1);
+    if (ncount == 0) {
+      if (table_ok && run == kmer) {
+        std::size_t lo, hi;
+        idx.code_range(code, lo, hi);
+        const std::size_t occs = hi - lo;
+        if (unique ? occs == 1 : (occs > 0 && occs < 1000))
+          for (std::size_t i = lo; i < hi; ++i) hits.push_back((int64_t)(idx.position(i) - (uint64_t)p));
+      } else {
+        const std::string seq = consensus.substr(p, kmer);
+        const std::size_t occs = idx.count(seq);
+        if (unique ? occs == 1 : (occs > 0 && occs < 1000)) {
+          idx.locate(seq, where);
+          for (uint64_t w : where) hits.push_back((int64_t)(w - (uint64_t)p));
+        }
+      }
+    }
+    if (consensus[p] == 'N') --ncount;
+    if (((uint32_t)(p + kmer) < consensus.size()) && (consensus[p + kmer] == 'N')) ++ncount;
+  }
+}
+
+struct SeedConfig {  // the SageConfig / IndigoConfig fields getReferenceSlice reads
+  uint16_t trimLeft = 50, trimRight = 50, kmer = 15, minKmerSupport = 3, maxindel = 1000;
+};
+
+// getReferenceSlice, fmindex.h:236-326 for an indexed genome (rs.filetype == 0): orientation and offset by
+// k-mer votes (unique hits first, then all hits below 1000 occurrences), then the window
+// [chrpos - maxindel, chrpos + |consensus| + maxindel] of that contig (inclusive end, clipped like faidx_fetch_seq),
+// reverse-complemented for reverse traces.
+inline bool getReferenceSlice(SeedConfig const& c, GenomeIndex const& idx, std::string const& consensus, ReferenceSlice& rs) {
+  std::string rv = consensus;
+  reverseComplement(rv);
+  std::vector<int64_t> hitFwd, hitRev;
+  int64_t bestFwd = 0, bestRev = 0, bestPos = 0;
+  bool anchored = false;
+  for (int pass = 0; pass < 2 && !anchored; ++pass) {
+    hitFwd.clear();
+    hitRev.clear();
+    scanSequence(idx, consensus, c.trimLeft, c.trimRight, c.kmer, hitFwd, pass == 0);
+    scanSequence(idx, rv, c.trimRight, c.trimLeft, c.kmer, hitRev, pass == 0);
+    const uint32_t freqFwd = findMaxFreq(hitFwd, bestFwd), freqRev = findMaxFreq(hitRev, bestRev);
+    if (freqFwd >= c.minKmerSupport && freqFwd > 2 * freqRev) {
+      rs.forward = true; rs.kmersupport = freqFwd; bestPos = bestFwd; anchored = true;
+    } else if (freqRev >= c.minKmerSupport && freqRev > 2 * freqFwd) {
+      rs.forward = false; rs.kmersupport = freqRev; bestPos = bestRev; anchored = true;
+    }
+  }
+  if (!anchored) {
+    std::cerr << "Couldn't anchor the Sanger trace in the selected reference genome." << std::endl;
+    return false;
+  }
+  int64_t cumsum = 0;
+  uint32_t ref = 0;
+  for (; ref + 1 < idx.lengths.size() && bestPos >= cumsum + (int64_t)idx.lengths[ref] + 1; ++ref) cumsum += (int64_t)idx.lengths[ref] + 1;
+  const uint32_t seqlen = idx.lengths[ref] + 1;
+  rs.chr = idx.names[ref];
+  const int64_t chrposSigned = bestPos - cumsum;
+  const uint32_t chrpos = chrposSigned > 0 ? (uint32_t)chrposSigned : 0;
+  uint32_t slicestart = 0, sliceend = seqlen;
+  if (chrpos > c.maxindel) slicestart = chrpos - c.maxindel;
+  const uint32_t tmpend = chrpos + (uint32_t)consensus.size() + c.maxindel;
+  if (tmpend < seqlen) sliceend = tmpend;
+  rs.pos = slicestart;
+  // faidx_fetch_seq: inclusive end, clipped to the contig
+  const int64_t last = std::min<int64_t>((int64_t)sliceend, (int64_t)idx.lengths[ref] - 1);
+  rs.refslice = (int64_t)slicestart <= last ? idx.text.substr(idx.starts[ref] + slicestart, (std::size_t)(last - slicestart + 1)) : std::string();
+  if (!rs.forward) reverseComplement(rs.refslice);
+  return true;
+}
+
+}  // namespace tracy_amd
+#endif

@@ -8,6 +8,7 @@
 
 #include "indigo_out.hpp"
 #include "sage_out.hpp"
+#include "seed.hpp"
 #include "trace_io.hpp"
 #include "tracy_host.hpp"
 
@@ -339,6 +340,53 @@ int32_t tracyhost_decompose_outputs(const tracyhost_decompose_report* rp) {
   std::ofstream f((pre + ".json").c_str());
   traceAlleleAlignJsonOut(f, rc, bc, tr, r);
   return 0;
+}
+
+// ---- k-mer seeding in an indexed genome (seed.hpp; fmindex.h:173-326) --------------------------------
+void* tracyhost_genome_open(const char* path, uint32_t kmer, uint32_t nthreads) {
+  GenomeIndex* g = new GenomeIndex();
+  if (!g->load(path)) { delete g; return nullptr; }
+  g->build(kmer, nthreads);
+  return g;
+}
+void tracyhost_genome_free(void* h) { delete static_cast<GenomeIndex*>(h); }
+uint32_t tracyhost_genome_contigs(const void* h) { return (uint32_t)static_cast<const GenomeIndex*>(h)->names.size(); }
+uint64_t tracyhost_genome_count(const void* h, const char* pat, size_t n) { return static_cast<const GenomeIndex*>(h)->count(std::string(pat, n)); }
+
+// getReferenceSlice for a batch of consensus strings (trace t: consensus + cons_off[t], cons_len[t] bytes), one
+// thread per stripe of traces.  Per trace: status 1 = anchored, 0 = not; forward, kmersupport, pos (window start
+// in the contig), contig index, and the ORIENTED window at slices + t * slice_cap (slice_len[t] bytes).
+void tracyhost_seed_batch(const void* h, uint32_t ntraces, const char* consensus, const uint64_t* cons_off, const uint32_t* cons_len,
+                          uint32_t trim_left, uint32_t trim_right, uint32_t kmer, uint32_t min_support, uint32_t maxindel,
+                          uint32_t nthreads, int32_t* status, uint8_t* forward, uint32_t* kmersupport, uint32_t* pos, uint32_t* contig,
+                          char* slices, uint64_t slice_cap, uint32_t* slice_len) {
+  const GenomeIndex* g = static_cast<const GenomeIndex*>(h);
+  if (nthreads == 0) nthreads = std::max(1u, std::thread::hardware_concurrency());
+  SeedConfig sc;
+  sc.trimLeft = (uint16_t)trim_left; sc.trimRight = (uint16_t)trim_right; sc.kmer = (uint16_t)kmer;
+  sc.minKmerSupport = (uint16_t)min_support; sc.maxindel = (uint16_t)maxindel;
+  auto work = [&](uint32_t tid) {
+    for (uint32_t t = tid; t < ntraces; t += nthreads) {
+      ReferenceSlice rs;
+      rs.filetype = 0;
+      const bool ok = getReferenceSlice(sc, *g, std::string(consensus + cons_off[t], cons_len[t]), rs);
+      status[t] = ok ? 1 : 0;
+      slice_len[t] = 0;
+      if (!ok) continue;
+      forward[t] = rs.forward ? 1 : 0;
+      kmersupport[t] = rs.kmersupport;
+      pos[t] = rs.pos;
+      uint32_t ci = 0;
+      while (ci < g->names.size() && g->names[ci] != rs.chr) ++ci;
+      contig[t] = ci;
+      const size_t n = std::min<size_t>(rs.refslice.size(), slice_cap);
+      std::memcpy(slices + (size_t)t * slice_cap, rs.refslice.data(), n);
+      slice_len[t] = (uint32_t)n;
+    }
+  };
+  std::vector<std::thread> th;
+  for (uint32_t t = 0; t < nthreads; ++t) th.emplace_back(work, t);
+  for (auto& t : th) t.join();
 }
 
 // trimTrace (trim.h:35-73) of the basecalled trace

@@ -228,3 +228,51 @@ def decompose_outputs(prefix, genome_name, input_name, trace, basecallpos, prati
     r.a1, r.a2 = a1a2
     r.dcp_indel, r.dcp_err, r.dcp_n = di.ctypes.data_as(C.POINTER(C.c_int32)), de.ctypes.data_as(C.POINTER(C.c_int32)), len(dcp)
     return lib().tracyhost_decompose_outputs(C.byref(r))
+
+
+class Genome:
+    """indexed genome for k-mer seeding (tracy_amd/host/seed.hpp): plain or gzip-compressed multi-FASTA"""
+
+    def __init__(self, path, kmer=15, nthreads=0):
+        fn = lib().tracyhost_genome_open
+        fn.restype = C.c_void_p
+        h = fn(os.fsencode(path), C.c_uint32(kmer), C.c_uint32(nthreads))
+        if not h:
+            raise IOError("tracy_amd: cannot read genome %s" % path)
+        self._h = C.c_void_p(h)
+        self.kmer = kmer
+
+    def close(self):
+        if self._h:
+            lib().tracyhost_genome_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def count(self, pattern):
+        fn = lib().tracyhost_genome_count
+        fn.restype = C.c_uint64
+        return int(fn(self._h, bytes(pattern), C.c_size_t(len(pattern))))
+
+    def seed(self, consensus, trim_left=50, trim_right=50, min_support=3, maxindel=1000, nthreads=0):
+        """getReferenceSlice (fmindex.h:236-326) for a list of consensus strings -> dict of arrays + oriented windows"""
+        n = len(consensus)
+        lens = np.array([len(c) for c in consensus], dtype=np.uint32)
+        offs = np.zeros(max(n, 1), dtype=np.uint64)
+        if n:
+            offs[1:n] = np.cumsum(lens.astype(np.uint64))[:-1]
+        blob = b"".join(bytes(c) for c in consensus) + b"\0"
+        cap = int(lens.max() if n else 0) + 2 * maxindel + 2
+        out = dict(status=np.zeros(max(n, 1), np.int32), forward=np.zeros(max(n, 1), np.uint8), kmersupport=np.zeros(max(n, 1), np.uint32),
+                   pos=np.zeros(max(n, 1), np.uint32), contig=np.zeros(max(n, 1), np.uint32), slice_len=np.zeros(max(n, 1), np.uint32))
+        slices = np.zeros((max(n, 1), cap), dtype=np.uint8)
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        lib().tracyhost_seed_batch(self._h, C.c_uint32(n), blob, p(offs, C.c_uint64), p(lens, C.c_uint32), C.c_uint32(trim_left),
+                                   C.c_uint32(trim_right), C.c_uint32(self.kmer), C.c_uint32(min_support), C.c_uint32(maxindel),
+                                   C.c_uint32(nthreads), p(out["status"], C.c_int32), p(out["forward"], C.c_uint8),
+                                   p(out["kmersupport"], C.c_uint32), p(out["pos"], C.c_uint32), p(out["contig"], C.c_uint32),
+                                   slices.ctypes.data_as(C.c_char_p), C.c_uint64(cap), p(out["slice_len"], C.c_uint32))
+        out = {k: v[:n] for k, v in out.items()}
+        out["slices"] = [slices[i, :out["slice_len"][i]].tobytes() for i in range(n)]
+        return out

@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""Turn gpurun_out/prof_round (tools/profile_round.sh) into the summaries committed under profiles/:
+   rNN_bench_kernel_stats.csv, rNN_decompose_kernel_stats.csv  -- rocprofv3 --kernel-trace --stats
+   rNN_pmc_hbm.json   -- WRITE_SIZE / FETCH_SIZE per kernel, per launch (separate PMC passes; KB -> bytes)
+   rNN_pmc_valu.json  -- VALU instructions / busy cycles per kernel, per launch
+   rNN_bench_line_under_rocprof.json, rNN_bench_line.json, rNN_decompose_line.json"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
+DST = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(SRC, pattern))
+    return f[0] if f else None
+
+
+def last_json_line(path):
+    for ln in reversed(open(path).read().strip().split("\n")):
+        if ln.startswith("{"):
+            return json.loads(ln)
+    return None
+
+
+for name, sub in (("bench", "bench_stats"), ("decompose", "dec_stats")):
+    f = one(sub + "/*/*kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, name)))
+for src, dst in (("bench_line.json", "bench_line_under_rocprof"), ("bench_plain.json", "bench_line"), ("dec_line.json", "decompose_line")):
+    p = os.path.join(SRC, src)
+    if os.path.exists(p):
+        d = last_json_line(p)
+        if d:
+            json.dump(d, open(os.path.join(DST, "%s_%s.json" % (tag, dst)), "w"), indent=1)
+
+
+def per_kernel(pass_dir, scale):
+    f = one(pass_dir + "/*/*counter_collection.csv")
+    if not f:
+        return []
+    acc = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        k = (r["Kernel_Name"], r["Counter_Name"])
+        a = acc.setdefault(k, {"sum": 0.0, "disp": set(), "grid": r.get("Grid_Size", "")})
+        a["sum"] += float(r["Counter_Value"])
+        a["disp"].add(r["Dispatch_Id"])
+    dur = collections.defaultdict(list)
+    t = one(pass_dir + "/*/*kernel_trace.csv")
+    if t:
+        for r in csv.DictReader(open(t)):
+            dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    out = []
+    for (kern, ctr), a in acc.items():
+        if not kern.startswith("void tracyhip") and "tracyhip" not in kern and "anonymous" not in kern:
+            continue
+        n = max(len(a["disp"]), 1)
+        ms = dur.get(kern, [])
+        out.append({"counter": ctr, "kernel": kern, "launches": n, "per_launch": a["sum"] / n * scale,
+                    "avg_launch_ms": sum(ms) / len(ms) if ms else None})
+    return out
+
+
+hbm = []
+for c in ("WRITE_SIZE", "FETCH_SIZE"):
+    for r in per_kernel("pmc_" + c, 1024.0):  # the counters report KB
+        r["bytes"] = r.pop("per_launch")
+        hbm.append(r)
+if hbm:
+    json.dump(hbm, open(os.path.join(DST, "%s_pmc_hbm.json" % tag), "w"), indent=1)
+valu = per_kernel("pmc_valu", 1.0)
+if valu:
+    json.dump(valu, open(os.path.join(DST, "%s_pmc_valu.json" % tag), "w"), indent=1)
+print("profiles written for", tag, ":", sorted(f for f in os.listdir(DST) if f.startswith(tag)))

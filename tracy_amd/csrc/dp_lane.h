@@ -191,6 +191,34 @@ TR_HD int32_t max16(int32_t a, int32_t b) {
 }
 TR_HD int32_t sext16(int32_t a) { return (int32_t)(int16_t)(uint16_t)a; }
 
+// max(a, b + c) in one asm statement (see chain16)
+TR_HD int32_t maxadd16(int32_t a, int32_t b, int32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int32_t d;
+  asm("v_add_u16 %0, %2, %3\n\tv_max_i16 %0, %1, %0" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+#else
+  return max16(a, add16(b, c));
+#endif
+}
+
+// the vertical chain of one cell in ONE asm statement:  f = max(up_hg, up_f + vext);  hg = max(t, f) + goe.
+// Separate asm statements make the compiler put an s_nop between every dependent pair (it cannot see what an
+// asm writes); plain VALU -> VALU dependencies are interlocked by the hardware and need none.
+TR_HD void chain16(int32_t up_hg, int32_t up_f, int32_t vext, int32_t t, int32_t goe, int32_t& f, int32_t& hg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int32_t f_, hg_;
+  asm("v_add_u16 %0, %3, %4\n\tv_max_i16 %0, %2, %0\n\tv_max_i16 %1, %5, %0\n\tv_add_u16 %1, %1, %6"
+      : "=&v"(f_), "=&v"(hg_)
+      : "v"(up_hg), "v"(up_f), "v"(vext), "v"(t), "v"(goe));
+  f = f_;
+  hg = hg_;
+#else
+  f = max16(up_hg, add16(up_f, vext));
+  hg = add16(max16(t, f), goe);
+#endif
+}
+
 // sub.lo16(i): a register whose low 16 bits hold the substitution score of slot i
 template <int K, class Sub>
 TR_HD void score_step16(ScoreLane<K>& s, int32_t up_h, int32_t up_f, int32_t diag, int32_t vopen, int32_t vext,
@@ -226,16 +254,15 @@ TR_HD void score_step16g(ScoreLane<K>& s, int32_t up_hg, int32_t up_f, int32_t d
 #pragma unroll
   for (int i = K - 1; i >= 0; --i) {
     const int32_t hl = (i == K - 1) ? add16(s.Hl[i], delta_last) : s.Hl[i];
-    const int32_t e = max16(hl, add16(s.El[i], s.hext[i]));
+    const int32_t e = maxadd16(hl, s.El[i], s.hext[i]);
     const int32_t d = add16(i == 0 ? diag_hg : s.Hl[i - 1], subg.lo16(i));
     s.Hl[i] = d;
     s.El[i] = e;
   }
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const int32_t f = max16(up_hg, add16(up_f, vext));
-    const int32_t h = max16(max16(s.Hl[i], s.El[i]), f);
-    const int32_t hg = add16(h, goe);
+    int32_t f, hg;
+    chain16(up_hg, up_f, vext, max16(s.Hl[i], s.El[i]), goe, f, hg);
     s.Hl[i] = hg;
     up_hg = hg;
     up_f = f;

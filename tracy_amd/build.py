@@ -92,7 +92,25 @@ def build_cli(force=False, verbose=False):
     return CLI
 
 
+MSA_SO = os.path.join(LIBDIR, "libtracy_msa.so")
+
+
+def build_msa(force=False, verbose=False):
+    """progressive multiple alignment over the C ABI (tracy_amd/host/msa.hpp): g++ host code linked against libtracy_hip.so"""
+    hdir = os.path.join(HERE, "host")
+    src = os.path.join(hdir, "msa_capi.cpp")
+    srcs = [src, SO, os.path.join(hdir, "msa.hpp"), os.path.join(hdir, "tracy_host.hpp"), os.path.join(os.path.dirname(HERE), "include", "tracy_hip.h")]
+    if force or stale(MSA_SO, srcs):
+        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-o", MSA_SO, src, "-L" + LIBDIR, "-ltracy_hip",
+               "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return MSA_SO
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_host(force="--force" in sys.argv, verbose=True))
     print(build_cli(force="--force" in sys.argv, verbose=True))
+    print(build_msa(force="--force" in sys.argv, verbose=True))

@@ -8,7 +8,7 @@ import msa_oracle as mo
 def random_alignment(rng, nrow, ncol):
     rows = []
     for i in range(nrow):
-        r = rng.choice(list("ACGTacgtNn-X"), size=ncol, p=[.2, .2, .2, .2, .01, .01, .01, .01, .01, .01, .1, .03]).tolist()
+        r = rng.choice(list("ACGTacgtNn-X"), size=ncol, p=[.2, .2, .2, .2, .01, .01, .01, .01, .01, .01, .11, .03]).tolist()
         lead, trail = int(rng.integers(0, ncol // 2)), int(rng.integers(0, ncol // 3))
         for j in range(lead):
             r[j] = "-"
@@ -41,4 +41,5 @@ def test_upgma_truncating_average():
     d = [[-1] * 7 for _ in range(7)]
     d[0][1], d[0][2], d[1][2] = 10, 3, -4
     root, p = mo.upgma(d, 3)
-    assert p[3][1:] == [0, 1] and d[2][3] == 0  # (3 + -4) / 2 == 0 in C++, not -1
+    # (3 + -4) / 2 == 0 in C++ (not -1 as Python's floor division): 0 > -1, so sequence 2 still joins the tree
+    assert p[3][1:] == [0, 1] and p[4][1:] == [2, 3] and root == 4

@@ -54,7 +54,7 @@ struct HostWave {
 template <int K, int MODE, bool TRACE, bool NEEDLE, bool NARROW = false>
 void run_wave(const DpArgs& a) {
   WaveShared sh;
-  sh.lds.assign(lds_bytes(MODE == MODE_QP ? MODE_QP : MODE_PROF, K) + 64, 0);
+  sh.lds.assign((MODE == MODE_QP ? lds_bytes(MODE_QP, K) : needle_lds_bytes(MODE_PROF, K)) + 64, 0);
   std::vector<std::thread> th;
   for (uint32_t l = 0; l < 64; ++l) {
     th.emplace_back([&, l]() {

@@ -96,6 +96,19 @@ def test_profile_profile_mode(K):
             got = emu.run(p1, p2, SC, cfg[0], cfg[1], emu.MODE_PROF, K, trace=True)
             assert (got[0], got[1]) == want
             assert emu.run(p1, p2, SC, cfg[0], cfg[1], emu.MODE_PROF, K, trace=False)[0] == want[0]
+    # alignment profiles carry weight in rows 4 ('N') and 5 ('-'): the 25-term path (row 4 is not all zero)
+    p1, p2 = rand_profile(rng, 40, sharp=False), rand_profile(rng, 55)
+    p1[4, 7] = np.float32(0.25)
+    p1[5, 9] = np.float32(0.5)
+    for q in (p1, p2):
+        for cfg in [(1, 1)]:
+            want = orc.gotoh_prof(q, p2, cfg[0], cfg[1], SC)
+            got = emu.run(q, p2, SC, cfg[0], cfg[1], emu.MODE_PROF, K, trace=True)
+            assert (got[0], got[1]) == want
+    p2[4, 54] = np.float32(1.0)  # only the second profile has an N column
+    want = orc.gotoh_prof(rand_profile(np.random.default_rng(1), 30), p2, 1, 1, SC)
+    got = emu.run(rand_profile(np.random.default_rng(1), 30), p2, SC, 1, 1, emu.MODE_PROF, K, trace=True)
+    assert (got[0], got[1]) == want
 
 
 @pytest.mark.parametrize("K", [4, 16])

@@ -87,6 +87,11 @@ def test_gotoh_profile_profile(ctx):
     rng = np.random.default_rng(6)
     p1 = [rand_profile(rng, m, sharp=False) for m in (5, 100, 513, 600)]
     p2 = [rand_profile(rng, n) for n in (9, 333, 200, 700)]
+    # rows 4 ('N') / 5 ('-') carry weight in alignment profiles: pairs 1 and 2 take the 25-term path, 0 and 3 the
+    # 16-term path (row 4 zero in both profiles)
+    p1[1][4, 50] = np.float32(0.2)
+    p1[1][5, 51] = np.float32(0.4)
+    p2[2][4, 199] = np.float32(1.0)
     for cfg in [(1, 0), (1, 1)]:
         scores, btr, rows = ctx.align(p1, p2, SC + cfg, rows=True)
         sc_only = ctx.score(p1, p2, SC + cfg)

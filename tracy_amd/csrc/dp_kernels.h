@@ -119,25 +119,23 @@ TR_HD void qp_fetch(const int16_t* tab, uint32_t code, uint32_t lane, SubPacked<
   for (int j = 0; j < KP / 2; ++j) q.pw[j] = p[j];
 }
 
-template <int K>
+// profile x profile: the profile columns of this lane's K rows live in registers for the whole pass, the column
+// of a2 changes per step.  NT = 4 leaves out row 4 ('N') when it is zero in both profiles (profile_score<4>).
+template <int K, int NT = 5>
 struct SubProf {
-  const float* p1;  // LDS [5][64*K]
-  uint32_t row0;    // lane * K
+  float a[K][5];
   float b[5];
   float fmatch, fmis;
   int shift;
-  TR_HD int32_t operator()(int i) const {
-    float a[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) a[k] = p1[k * (64 * K) + row0 + i];
-    return (int32_t)((uint32_t)profile_score(a, b, fmatch, fmis) << shift);
-  }
+  TR_HD int32_t operator()(int i) const { return (int32_t)((uint32_t)profile_score<NT>(a[i], b, fmatch, fmis) << shift); }
   TR_HD int32_t lo16(int i) const { return (*this)(i); }
 };
 
 // LDS bytes a (mode, K) kernel needs
+// LDS bytes of the Needleman-Wunsch kernels (profile rows are staged in LDS there)
+TR_HD constexpr uint32_t needle_lds_bytes(int mode, int K) { return mode == MODE_PROF ? 5u * 64u * K * 4u : 0u; }
 TR_HD constexpr uint32_t lds_bytes(int mode, int K) {
-  return mode == MODE_QP ? (5u * 64u + 1u) * (uint32_t)qp_stride(K) * 2u : mode == MODE_PROF ? 5u * 64u * K * 4u : 0u;
+  return mode == MODE_QP ? (5u * 64u + 1u) * (uint32_t)qp_stride(K) * 2u : 0u;  // MODE_PROF keeps its rows in registers
 }
 
 TR_HD uint32_t a2_index(const PairDesc& d, uint32_t c /*1-based column*/) {
@@ -177,8 +175,15 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const uint8_t* a2c = static_cast<const uint8_t*>(a.a2) + (MODE != MODE_PROF ? d.a2_off : 0);
   const float* a2p = static_cast<const float*>(a.a2) + (MODE == MODE_PROF ? d.a2_off : 0);
   int16_t* qp_tab = reinterpret_cast<int16_t*>(w.lds());
-  float* p1_tab = reinterpret_cast<float*>(w.lds());
   const float fmatch = (float)a.match, fmis = (float)a.mismatch;
+  // profile x profile: is row 4 ('N') zero in both profiles?  (NaN counts as non-zero.)
+  bool skip4 = false;
+  if (MODE == MODE_PROF) {
+    bool nz = false;
+    for (uint32_t r = L; r < m; r += 64) nz |= !(a1p[4ull * d.a1_stride + r] == 0.0f);
+    for (uint32_t c = L; c < n; c += 64) nz |= !(a2p[4ull * d.a2_stride + c] == 0.0f);
+    skip4 = w.ballot(nz) == 0;
+  }
 
   const uint32_t P = num_passes(m, K);
   const uint32_t T = steps_per_pass(n);
@@ -262,17 +267,12 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       if (overflow) flag_error(a.err, 1);
       w.sync();
     } else {
-      w.sync();
 #pragma unroll
       for (int i = 0; i < K; ++i) {
         const uint32_t r = base + L * K + i + 1;
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
-          p1_tab[k * (64 * K) + L * K + i] = (r <= m) ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+        for (int k = 0; k < 5; ++k) sub_p.a[i][k] = (r <= m) ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
       }
-      w.sync();
-      sub_p.p1 = p1_tab;
-      sub_p.row0 = L * K;
       sub_p.fmatch = fmatch;
       sub_p.fmis = fmis;
       sub_p.shift = SH;
@@ -370,11 +370,33 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         do_step(t, sub_c);
       }
     } else {
-      for (uint32_t t = 1; t <= t_end; ++t) {
-        const uint32_t ci = col_at((int32_t)t - (int32_t)L);
+      // the column of a2 is fetched one step ahead of its use
+      auto sweep = [&](auto& sub) {
+        float nb[5];
+        {
+          const uint32_t ci = col_at(1 - (int32_t)L);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) sub_p.b[k] = a2p[(uint64_t)k * d.a2_stride + ci];
-        do_step(t, sub_p);
+          for (int k = 0; k < 5; ++k) nb[k] = a2p[(uint64_t)k * d.a2_stride + ci];
+        }
+        for (uint32_t t = 1; t <= t_end; ++t) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) sub.b[k] = nb[k];
+          const uint32_t ci = col_at((int32_t)t - (int32_t)L + 1);
+#pragma unroll
+          for (int k = 0; k < 5; ++k) nb[k] = a2p[(uint64_t)k * d.a2_stride + ci];
+          do_step(t, sub);
+        }
+      };
+      if (skip4) {
+        SubProf<K, 4> s4;
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+#pragma unroll
+          for (int k = 0; k < 5; ++k) s4.a[i][k] = sub_p.a[i][k];
+        s4.fmatch = fmatch; s4.fmis = fmis; s4.shift = SH;
+        sweep(s4);
+      } else {
+        sweep(sub_p);
       }
     }
     (void)T;

@@ -134,7 +134,7 @@ static hipError_t launch_gotoh_t(const DpArgs& a, uint32_t npairs, hipStream_t s
 }
 template <int K, int MODE, bool TRACE>
 static hipError_t launch_needle_t(const DpArgs& a, uint32_t npairs, hipStream_t s) {
-  hipLaunchKernelGGL((needle_kernel<K, MODE, TRACE>), dim3(npairs), dim3(64), lds_bytes(MODE, K), s, a);
+  hipLaunchKernelGGL((needle_kernel<K, MODE, TRACE>), dim3(npairs), dim3(64), needle_lds_bytes(MODE, K), s, a);
   return hipGetLastError();
 }
 

@@ -366,12 +366,15 @@ TR_HD int32_t onehot_score(const float p1[5], uint32_t b, float fmatch, float fm
 }
 
 // full 25-term float _score (align.h:112-116), k1 outer / k2 inner, every operation rounded to float
+template <int NT = 5>
 TR_HD int32_t profile_score(const float a[5], const float b[5], float fmatch, float fmismatch) {
+  // NT = 4: row 4 ('N') of BOTH profiles is zero everywhere (trace profiles, profile.h:37-38).  Its nine terms are
+  // +-0, and acc + (+-0) == acc for every acc this sum can hold (acc is never -0), so they are left out exactly.
   float acc = 0.0f;
 #pragma unroll
-  for (int k1 = 0; k1 < 5; ++k1) {
+  for (int k1 = 0; k1 < NT; ++k1) {
 #pragma unroll
-    for (int k2 = 0; k2 < 5; ++k2) {
+    for (int k2 = 0; k2 < NT; ++k2) {
       const float w = (k1 == k2) ? fmatch : fmismatch;
 #if defined(__HIP_DEVICE_COMPILE__)
       acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(a[k1], b[k2]), w));

@@ -78,6 +78,21 @@
 #define OP_MULLO16(R) "v_mul_lo_u16 " R ", " R ", %8\n"
 #define OP_PKADDF16(R) "v_pk_add_f16 " R ", " R ", %8\n"
 #define OP_PKMAXF16(R) "v_pk_max_f16 " R ", " R ", %8\n"
+#define OP_PKMULF32(R) "v_pk_mul_f32 " R ", " R ", %10\n"
+#define OP_PKADDF32(R) "v_pk_add_f32 " R ", " R ", %10\n"
+#define CHAIN8D(OP)                                                                                \
+  asm volatile(OP("%0") OP("%1") OP("%2") OP("%3") OP("%4") OP("%5") OP("%6") OP("%7")            \
+               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7)  \
+               : "v"(x), "v"(y), "v"(dz));
+#define DEFKD(NAME, OP)                                                                            \
+  __global__ __launch_bounds__(256) void NAME(int* out, int iters, int x, int y) {                \
+    double d0 = threadIdx.x, d1 = d0 + 1, d2 = d0 + 2, d3 = d0 + 3, d4 = d0 + 4, d5 = d0 + 5, d6 = d0 + 6, d7 = d0 + 7, dz = 1.0; \
+    for (int i = 0; i < iters; ++i) {                                                              \
+      CHAIN8D(OP) CHAIN8D(OP) CHAIN8D(OP) CHAIN8D(OP) CHAIN8D(OP) CHAIN8D(OP) CHAIN8D(OP) CHAIN8D(OP) \
+    }                                                                                              \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (int)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);    \
+  }
+DEFKD(k_pkmulf32, OP_PKMULF32) DEFKD(k_pkaddf32, OP_PKADDF32)
 DEFK(k_sub, OP_SUB) DEFK(k_or, OP_OR) DEFK(k_xor, OP_XOR) DEFK(k_lshl, OP_LSHL) DEFK(k_ashr, OP_ASHR) DEFK(k_mov, OP_MOV)
 DEFK(k_cmpgt, OP_CMPGT) DEFK(k_cmpgt16, OP_CMPGT16) DEFK(k_cmpe64, OP_CMPE64) DEFK(k_cndmask2, OP_CNDMASK2) DEFK(k_addc, OP_ADDC)
 DEFK(k_addu16, OP_ADDU16) DEFK(k_maxu16, OP_MAXU16) DEFK(k_mini16, OP_MINI16) DEFK(k_max3i16, OP_MAX3I16) DEFK(k_lshlor, OP_LSHLOR)
@@ -116,7 +131,8 @@ int main() {
  {"v_cmp_gt_i32 vcc", k_cmpgt}, {"v_cmp_gt_i16 vcc", k_cmpgt16}, {"v_cmp_gt_i32 sgpr", k_cmpe64}, {"v_cndmask_b32 sgpr", k_cndmask2}, {"v_addc_co_u32", k_addc},
  {"v_add_u16", k_addu16}, {"v_max_u16", k_maxu16}, {"v_min_i16", k_mini16}, {"v_max3_i16", k_max3i16}, {"v_lshl_or_b32", k_lshlor}, {"v_and_or_b32", k_andor},
  {"v_or3_b32", k_or3}, {"v_max_u32", k_maxu32}, {"v_min_i32", k_mini32}, {"v_max_f16", k_maxf16}, {"v_add_f16", k_addf16}, {"v_mul_f32", k_mulf32}, {"v_sub_f32", k_subf32},
- {"v_bfe_i32", k_bfe}, {"v_add_u32_e64", k_adde64}, {"v_sub_u16", k_subu16}, {"v_mul_lo_u16", k_mullo16}, {"v_pk_add_f16", k_pkaddf16}, {"v_pk_max_f16", k_pkmaxf16}};
+ {"v_bfe_i32", k_bfe}, {"v_add_u32_e64", k_adde64}, {"v_sub_u16", k_subu16}, {"v_mul_lo_u16", k_mullo16}, {"v_pk_add_f16", k_pkaddf16}, {"v_pk_max_f16", k_pkmaxf16},
+ {"v_pk_mul_f32", k_pkmulf32}, {"v_pk_add_f32", k_pkaddf32}};
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);

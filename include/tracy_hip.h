@@ -234,6 +234,8 @@ typedef struct {
   tracyhip_seqset refs;          /* kind CHAR, upper-case [ACGTN] */
   const uint32_t* ref_index;     /* HOST array or NULL */
   tracyhip_decomp_params dprm;
+  const uint8_t* oriented;       /* HOST array or NULL; as in tracyhip_align_job: refs already oriented by k-mer seeding
+                                    (indigo.h:213-218), oriented[t] = rs.forward; score_fwd / score_rev are then zero */
 } tracyhip_decompose_job;
 
 typedef struct {

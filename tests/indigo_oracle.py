@@ -12,16 +12,22 @@ def trimmed_seq(s, ltrim, rtrim):
     return s[ltrim:len(s) - rtrim]
 
 
-def decompose_trace(sig, bcpos, pri, sec, ref, score, tl=50, tr=50, maxindel=1000, madc=5):
+def decompose_trace(sig, bcpos, pri, sec, ref, score, tl=50, tr=50, maxindel=1000, madc=5, oriented_forward=None):
+    """oriented_forward: None = single-FASTA path (orientation by score, indigo.h:219-247); True/False = indexed-genome
+    path (indigo.h:213-218): `ref` is the window already oriented by k-mer seeding and the flag is rs.forward"""
     trimmed = orc.create_profile_trace(sig, bcpos, pri, sec, tl, tr)
     bp = orc.find_breakpoint(trimmed)
     fwdp = orc.create_profile_str(ref)
-    revp = orc.revcomp_profile(fwdp)
-    gs_fwd = orc.gotoh_score_prof(trimmed, fwdp, 1, 0, score)
-    gs_rev = orc.gotoh_score_prof(trimmed, revp, 1, 0, score)
-    forward = gs_fwd > gs_rev
-    refslice = ref if forward else revcomp(ref)
-    pref = fwdp if forward else revp
+    if oriented_forward is None:
+        revp = orc.revcomp_profile(fwdp)
+        gs_fwd = orc.gotoh_score_prof(trimmed, fwdp, 1, 0, score)
+        gs_rev = orc.gotoh_score_prof(trimmed, revp, 1, 0, score)
+        forward = gs_fwd > gs_rev
+        refslice = ref if forward else revcomp(ref)
+        pref = fwdp if forward else revp
+    else:
+        gs_fwd = gs_rev = 0
+        forward, refslice, pref = bool(oriented_forward), ref, fwdp
     sc1, btr1 = orc.gotoh_prof(trimmed, pref, 1, 0, score)
     rows = orc.create_alignment_prof(btr1, trimmed, pref)
     seqsize = float(trimmed.shape[1])

@@ -354,3 +354,55 @@ def test_oriented_pipeline_mode_through_the_abi():
         assert got["btr"][i] == want["btr"] and int(got["forward"][i]) == fwd[i]
         assert int(got["score_fwd"][i]) == int(got["score_rev"][i]) == int(want["score_prelim"])
     ctx.close()
+
+
+def test_decompose_against_indexed_genome(tmp_path):
+    """indigo.h:213-218: seeding picks the window and the strand, the device chain runs without orientation scores"""
+    import indigo_oracle as io
+    from tracy_amd import hostlib
+    rng = np.random.default_rng(31415)
+    # the genome holds the reference allele of two synthetic heterozygous traces (one on each strand)
+    cases = []
+    contigs = []
+    for i in range(2):
+        ref, sig, pos, indel = hostlib.synth_decompose(8800 + i, 2600, 600, 10, 0, 0.6)
+        body = ref.decode()
+        flank = lambda n: bytes(rng.choice(list(b"ACGT"), size=n).tolist()).decode()
+        seq = flank(3000) + body + flank(2500)
+        if i == 1:
+            seq = so.revcomp(seq.encode()).decode()
+        contigs.append(("chr%d" % (i + 1), seq))
+        tpath = str(tmp_path / ("ix%d.ab1" % i))
+        hostlib.write_abif(tpath, np.minimum(sig, 32000), pos, b"N" * len(pos), np.full(len(pos), 30, np.uint8))
+        cases.append(tpath)
+    import gzip
+    gpath = str(tmp_path / "g.fa.gz")
+    with gzip.open(gpath, "wt") as f:
+        for name, seq in contigs:
+            f.write(">%s\n%s\n" % (name, seq))
+    man = str(tmp_path / "ix.tsv")
+    open(man, "w").write("".join("%s\t%s\t%s\n" % (t, gpath, str(tmp_path / ("ixres%d" % i))) for i, t in enumerate(cases)))
+    p = subprocess.run([CLI, "decompose", "--batch", man], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    g = so.BruteGenome(contigs)
+    strands = set()
+    for i, tpath in enumerate(cases):
+        t = hostlib.read_trace(tpath)
+        tr, pos = t["signal"], t["basecallpos"]
+        pri, sec, con, bcpos, q = hostlib.basecall_qual(tr, pos, 0.33)
+        rs = so.get_reference_slice(g, con.decode())
+        assert rs is not None
+        strands.add(rs["forward"])
+        window = rs["refslice"].encode()
+        w = io.decompose_trace(tr, bcpos, pri, sec, window, SC, 50, 50, oriented_forward=rs["forward"])
+        assert w["status"] == 0
+        pre = str(tmp_path / ("ixres%d" % i))
+        assert open(pre + ".decomp").read() == io.write_decomposition(w["dcp"])
+        p_t, s_t = io.trimmed_seq(w["primary"], 50, 50), io.trimmed_seq(w["secdecomp"], 50, 50)
+        for k, seq in enumerate((p_t, s_t)):
+            sl = window[w["slice_begin%d" % k]:w["slice_begin%d" % k] + w["slice_len%d" % k]]
+            rows = orc.create_alignment_str(w["btr%d" % k], seq, sl)
+            want = so.plot_alignment(rows[0], rows[1], rs["chr"], rs["pos"] + w["ref_pos%d" % k], len(sl), rs["forward"], w["score%d" % k], 60,
+                                     key=k + 1, a1a2=w["af"])
+            assert open(pre + ".align%d" % (k + 1)).read() == want, (i, k)
+    assert strands == {True, False}

@@ -10,9 +10,9 @@
 // Host stages (as in the reference): ABIF/SCF parsing, basecalling, trimming estimate, profiles, file
 // writers.  Device stages: every Gotoh DP, orientation, trimReferenceSlice, alignment rows.  There is no
 // CPU fallback: without a GPU the command fails with the library's error text.
-// `align` also takes an indexed genome (gzip-compressed multi-FASTA): the trace is anchored by k-mer votes
+// Both commands also take an indexed genome (gzip-compressed multi-FASTA): the trace is anchored by k-mer votes
 // (seed.hpp, fmindex.h:173-326) and aligned against the window around the hit.
-// Not built yet: indexed genomes and wildtype-trace references for `decompose`; --annotate (needs the network).  Variants (-v) are written as
+// Not built yet: wildtype-trace references for `decompose`; --annotate (needs the network).  Variants (-v) are written as
 // VCF text because htslib (BCF) is not available.
 #include <cstdio>
 #include <cstdlib>
@@ -232,10 +232,6 @@ int prepare(SageConfig const& c, Job& j, bool decompose = false) {
   }
   if (j.rs.filetype == 0) {
     // indexed genome (sage.h:217-221): anchor the trace by k-mer votes, take the window around the hit
-    if (decompose) {
-      std::cerr << "Indexed genomes for decompose are not part of this build; pass a FASTA slice (<= 50 kbp)." << std::endl;
-      return -1;
-    }
     const GenomeIndex* idx = genome_index(c, j.ref_path);
     if (!idx) return -1;
     SeedConfig sc;
@@ -628,6 +624,10 @@ bool decompose_group(tracyhip_ctx* ctx, SageConfig const& c, tracyhip_params con
   job.bc = tracyhip_basecalls{nt, sig.data(), soff.data(), ns.data(), pos.data(), pri.data(), sec.data(), boff.data(), blen.data()};
   job.refs = tracyhip_seqset{TRACYHIP_SEQ_CHAR, refs.data(), roff.data(), rlen.data(), nt};
   job.dprm = tracyhip_decomp_params{(int32_t)jobs[0]->trimLeft, (int32_t)jobs[0]->trimRight, (int32_t)c.maxindel, (int32_t)c.madc};
+  const bool seeded = jobs[0]->rs.filetype == 0;  // groups never mix seeded and FASTA references
+  std::vector<uint8_t> orient(nt);
+  for (uint32_t i = 0; i < nt; ++i) orient[i] = jobs[i]->rs.forward ? 1 : 0;
+  if (seeded) job.oriented = orient.data();
   std::vector<tracyhip_breakpoint> bp(nt);
   std::vector<int32_t> status(nt), sf(nt), sr(nt), strim(nt), dci((size_t)nt * dcap), dce((size_t)nt * dcap);
   std::vector<uint8_t> fwd(nt), sd(pri.size() ? pri.size() : 1);
@@ -660,8 +660,8 @@ bool decompose_group(tracyhip_ctx* ctx, SageConfig const& c, tracyhip_params con
     j.secdecomp.assign(reinterpret_cast<char*>(sd.data()) + boff[i], blen[i]);
     j.rs.forward = fwd[i] != 0;
     j.rs.refslice = j.fasta;
-    if (!j.rs.forward) reverseComplement(j.rs.refslice);
-    j.rs.pos = 0;
+    if (!seeded && !j.rs.forward) reverseComplement(j.rs.refslice);
+    j.rs.pos = j.slice_start;
     AlleleReport& r = j.rep;
     r.bp.indelshift = bp[i].indelshift != 0;
     r.bp.traceleft = bp[i].traceleft != 0;
@@ -676,7 +676,7 @@ bool decompose_group(tracyhip_ctx* ctx, SageConfig const& c, tracyhip_params con
       *slot[k] = j.rs;
       const bool usable = status[i] == 0;
       slot[k]->refslice = usable ? j.rs.refslice.substr(sb[k][i], sl[k][i]) : std::string();
-      slot[k]->pos = usable ? rp[k][i] : 0;
+      slot[k]->pos = usable ? j.slice_start + rp[k][i] : 0;
       a1[k].push_back(k == 0 ? p_t : s_t);
       a2[k].push_back(slot[k]->refslice);
     }
@@ -762,7 +762,12 @@ void write_decompose_outputs(SageConfig const& c, Job& j) {
   rc.inputName = file_name(j.trace_path);
   if (c.callvariants) {
     std::ofstream f((j.outprefix + ".vcf").c_str());
-    vcfTextOutput(f, rc, bc, r.var, j.rs);
+    std::vector<std::pair<std::string, uint64_t>> contigs;
+    if (j.rs.filetype == 0) {
+      const GenomeIndex* g = genome_index(c, j.ref_path);
+      for (std::size_t i = 0; g && i < g->names.size(); ++i) contigs.emplace_back(g->names[i], (uint64_t)g->lengths[i] + 1);
+    }
+    vcfTextOutput(f, rc, bc, r.var, j.rs, j.rs.filetype == 0 ? &contigs : nullptr);
   }
   std::ofstream f((j.outprefix + ".json").c_str());
   traceAlleleAlignJsonOut(f, rc, bc, j.tr, r);
@@ -813,9 +818,9 @@ int decompose_main(int argc, char** argv) {
     return -1;
   }
   tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};
-  std::map<std::pair<uint32_t, uint32_t>, std::vector<Job*>> groups;
+  std::map<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>, std::vector<Job*>> groups;  // (seeded?, trims)
   for (Job& j : jobs)
-    if (j.ok) groups[std::make_pair(j.trimLeft, j.trimRight)].push_back(&j);
+    if (j.ok) groups[std::make_pair(j.rs.filetype == 0 ? 1u : 0u, std::make_pair(j.trimLeft, j.trimRight))].push_back(&j);
   std::cout << stamp() << "Alignment" << std::endl;
   for (auto& g : groups)
     if (!decompose_group(dev.ctx, c, prm, g.second)) return -1;

@@ -556,7 +556,11 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
     d.out = t;
     return d;
   };
-  {
+  // job->oriented: the references were anchored and oriented by the caller (indexed genome, indigo.h:213-218):
+  // no orientation scores; oriented[t] = rs.forward only steers rs.pos in trimReferenceSlice
+  const bool given = job->oriented != nullptr;
+  std::vector<int32_t> h_sc2(2 * (size_t)nt, 0);
+  if (!given) {
     DpProblem pb;
     pb.mode = MODE_QP; pb.a1_profile = true; pb.d_a1 = d_prof; pb.d_a2 = ctx->d_codes.p;
     pb.desc.resize(2 * (size_t)nt); pb.k.resize(2 * (size_t)nt);
@@ -568,11 +572,13 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
       pb.k[t] = pb.k[nt + t] = choose_k(d.m, MODE_QP);
     }
     if ((rc = run_dp(ctx, pb, &p, false, false, static_cast<int32_t*>(b_sc2.p), nullptr, nullptr, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(h_sc2.data(), b_sc2.p, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost));
   }
-  std::vector<int32_t> h_sc2(2 * (size_t)nt);
-  HIP_TRY(hipMemcpy(h_sc2.data(), b_sc2.p, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost));
-  std::vector<uint8_t> h_fwd(nt);
-  for (uint32_t t = 0; t < nt; ++t) h_fwd[t] = h_sc2[t] > h_sc2[nt + t] ? 1 : 0;
+  std::vector<uint8_t> h_fwd(nt), h_rc(nt);  // rs.forward / "read the window as its reverse complement"
+  for (uint32_t t = 0; t < nt; ++t) {
+    if (given) { h_fwd[t] = job->oriented[t] ? 1 : 0; h_rc[t] = 0; }
+    else { h_fwd[t] = h_sc2[t] > h_sc2[nt + t] ? 1 : 0; h_rc[t] = !h_fwd[t]; }
+  }
 
   // ---- 3. gotoh(trimmedtrace, prefslice) + alignment rows (indigo.h:302) ----
   std::vector<uint64_t> off1(nt);
@@ -592,7 +598,7 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
     pb.desc.resize(nt); pb.k.resize(nt);
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc d = qp_desc(t, true);
-      d.flags = h_fwd[t] ? 0 : PAIR_A2_REVCOMP;
+      d.flags = h_rc[t] ? PAIR_A2_REVCOMP : 0;
       pb.desc[t] = d;
       desc_trim[t] = d;
       pb.k[t] = choose_k(d.m, MODE_QP);
@@ -717,7 +723,7 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
       d.m = sl[t]; d.a1_stride = sl[t];
       d.a2_off = sr.offset[ridx[t]];
       d.n = rn[t]; d.a2_stride = rn[t];
-      d.flags = h_fwd[t] ? 0 : PAIR_A2_REVCOMP;
+      d.flags = h_rc[t] ? PAIR_A2_REVCOMP : 0;
       d.out = t;
       pb.desc[t] = d;
       pb.k[t] = choose_k(d.m, MODE_CHAR);
@@ -734,7 +740,7 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc& d = pb.desc[t];
       d.n = h_trimA[k][t].len; d.a2_stride = d.n;
-      d.a2_off = sr.offset[ridx[t]] + (h_fwd[t] ? h_trimA[k][t].ri : rn[t] - h_trimA[k][t].ri - h_trimA[k][t].len);
+      d.a2_off = sr.offset[ridx[t]] + (h_rc[t] ? rn[t] - h_trimA[k][t].ri - h_trimA[k][t].len : h_trimA[k][t].ri);
     }
     const uint64_t* d_offK;
     std::vector<uint64_t> offK(out->ops_offset[k], out->ops_offset[k] + nt);

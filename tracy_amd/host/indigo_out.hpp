@@ -256,7 +256,10 @@ inline void traceAlleleAlignJsonOut(std::ostream& out, ReportConfig const& c, Ba
 
 // variants as VCF text: the header lines, columns, INFO and FORMAT values vcfOutput (variants.h:141-261)
 // puts into its BCF
-inline void vcfTextOutput(std::ostream& out, ReportConfig const& c, BaseCalls const& bc, std::vector<Variant> const& var, ReferenceSlice const& rs) {
+// contigs: (name, length + 1) of every sequence of an indexed genome (rs.filetype == 0, variants.h:176-186); NULL
+// for a single FASTA / wildtype reference, whose one contig line carries rs.refslice.size()
+inline void vcfTextOutput(std::ostream& out, ReportConfig const& c, BaseCalls const& bc, std::vector<Variant> const& var, ReferenceSlice const& rs,
+                          std::vector<std::pair<std::string, uint64_t>> const* contigs = nullptr) {
   char date[16];
   std::time_t t = std::time(nullptr);
   std::tm tmv;
@@ -270,9 +273,13 @@ inline void vcfTextOutput(std::ostream& out, ReportConfig const& c, BaseCalls co
       << "##INFO=<ID=METHOD,Number=1,Type=String,Description=\"Type of approach used to detect variant\">\n"
       << "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
       << "##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Genotype Quality\">\n"
-      << "##reference=" << c.genomeName << "\n"
-      << "##contig=<ID=" << rs.chr << ",length=" << rs.refslice.size() << ">\n"
-      << "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsample\n";
+      << "##reference=" << c.genomeName << "\n";
+  if (contigs) {
+    for (auto const& ctg : *contigs) out << "##contig=<ID=" << ctg.first << ",length=" << ctg.second << ">\n";
+  } else {
+    out << "##contig=<ID=" << rs.chr << ",length=" << rs.refslice.size() << ">\n";
+  }
+  out << "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsample\n";
   for (Variant const& v : var) {
     const uint32_t q = variantCallIndex(c, bc, rs.forward, v.basenum);
     const int32_t qual = strInclN(v.alt) ? 0 : (int32_t)bc.estQual[q];

@@ -236,6 +236,9 @@ typedef struct {
   tracyhip_decomp_params dprm;
   const uint8_t* oriented;       /* HOST array or NULL; as in tracyhip_align_job: refs already oriented by k-mer seeding
                                     (indigo.h:213-218), oriented[t] = rs.forward; score_fwd / score_rev are then zero */
+  tracyhip_seqset ref_profiles;  /* data NULL = unused.  Wildtype-trace reference (indigo.h:249-289): profile of the wildtype
+                                    trace, oriented by the caller (needs `oriented`), parallel to refs, which then hold the
+                                    wildtype's (oriented) primary basecalls = rs.refslice */
 } tracyhip_decompose_job;
 
 typedef struct {

@@ -12,12 +12,14 @@ def trimmed_seq(s, ltrim, rtrim):
     return s[ltrim:len(s) - rtrim]
 
 
-def decompose_trace(sig, bcpos, pri, sec, ref, score, tl=50, tr=50, maxindel=1000, madc=5, oriented_forward=None):
+def decompose_trace(sig, bcpos, pri, sec, ref, score, tl=50, tr=50, maxindel=1000, madc=5, oriented_forward=None, wildtype_profile=None):
     """oriented_forward: None = single-FASTA path (orientation by score, indigo.h:219-247); True/False = indexed-genome
     path (indigo.h:213-218): `ref` is the window already oriented by k-mer seeding and the flag is rs.forward"""
     trimmed = orc.create_profile_trace(sig, bcpos, pri, sec, tl, tr)
     bp = orc.find_breakpoint(trimmed)
-    fwdp = orc.create_profile_str(ref)
+    # wildtype_profile: the reference is a wildtype trace (indigo.h:249-289): `ref` = its primary basecalls, the
+    # preliminary alignment runs against its profile
+    fwdp = orc.create_profile_str(ref) if wildtype_profile is None else wildtype_profile
     if oriented_forward is None:
         revp = orc.revcomp_profile(fwdp)
         gs_fwd = orc.gotoh_score_prof(trimmed, fwdp, 1, 0, score)

@@ -406,3 +406,43 @@ def test_decompose_against_indexed_genome(tmp_path):
                                      key=k + 1, a1a2=w["af"])
             assert open(pre + ".align%d" % (k + 1)).read() == want, (i, k)
     assert strands == {True, False}
+
+
+def test_decompose_against_wildtype_trace(tmp_path):
+    """indigo.h:249-289: the reference is a wildtype chromatogram -- profile x profile preliminary alignment, allele
+    alignments against its primary basecalls"""
+    import indigo_oracle as io
+    from tracy_amd import hostlib
+    for reverse in (False, True):
+        ref, sig, pos, indel = hostlib.synth_decompose(9900 + reverse, 700, 520, 8, 0, 0.6)
+        tpath = str(tmp_path / ("wtd%d.ab1" % reverse))
+        hostlib.write_abif(tpath, np.minimum(sig, 32000), pos, b"N" * len(pos), np.full(len(pos), 30, np.uint8))
+        # wildtype trace: clean peaks of the reference window (reverse strand for the second case)
+        wseq = ref if not reverse else so.revcomp(ref)
+        wt = np.zeros((4, 12 * len(wseq) + 12), np.int32)
+        wpos = 6 + 12 * np.arange(len(wseq), dtype=np.int32)
+        tri = (900 * (1.0 - np.abs(np.arange(-5, 6)) / 6.0)).astype(np.int32)
+        for j, ch in enumerate(wseq):
+            wt[b"ACGT".index(ch), wpos[j] - 5:wpos[j] + 6] += tri
+        wpath = str(tmp_path / ("wtref%d.ab1" % reverse))
+        hostlib.write_abif(wpath, wt, wpos, wseq, np.full(len(wseq), 40, np.uint8))
+        pre = str(tmp_path / ("wtres%d" % reverse))
+        p = subprocess.run([CLI, "decompose", "-r", wpath, "-o", pre, tpath], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr
+        t = hostlib.read_trace(tpath)
+        tr, tpos = t["signal"], t["basecallpos"]
+        pri, sec, con, bcpos, q = hostlib.basecall_qual(tr, tpos, 0.33)
+        g = hostlib.read_trace(wpath)
+        gpri, gsec, _, gpos = hostlib.basecall(g["signal"], g["basecallpos"], 0.33)
+        wprof = orc.create_profile_trace(g["signal"], gpos, gpri, gsec, 0, 0)
+        w = io.decompose_trace(tr, bcpos, pri, sec, gpri, SC, 50, 50, wildtype_profile=wprof)
+        assert w["status"] == 0 and bool(w["forward"]) == (not reverse)
+        refslice = gpri if w["forward"] else so.revcomp(gpri)
+        assert open(pre + ".decomp").read() == io.write_decomposition(w["dcp"])
+        p_t, s_t = io.trimmed_seq(w["primary"], 50, 50), io.trimmed_seq(w["secdecomp"], 50, 50)
+        for k, seq in enumerate((p_t, s_t)):
+            sl = refslice[w["slice_begin%d" % k]:w["slice_begin%d" % k] + w["slice_len%d" % k]]
+            rows = orc.create_alignment_str(w["btr%d" % k], seq, sl)
+            want = so.plot_alignment(rows[0], rows[1], "wildtype", w["ref_pos%d" % k], len(sl), bool(w["forward"]), w["score%d" % k], 60,
+                                     key=k + 1, a1a2=w["af"])
+            assert open(pre + ".align%d" % (k + 1)).read() == want, (reverse, k)

@@ -410,7 +410,7 @@ Context.allelic_fraction = _allelic_fraction
 
 class DecomposeJob(C.Structure):
     _fields_ = [("ntraces", C.c_uint32), ("profiles", SeqSet), ("bc", BaseCallsBatch), ("refs", SeqSet),
-                ("ref_index", C.POINTER(C.c_uint32)), ("dprm", DecompParams), ("oriented", C.POINTER(C.c_uint8))]
+                ("ref_index", C.POINTER(C.c_uint32)), ("dprm", DecompParams), ("oriented", C.POINTER(C.c_uint8)), ("ref_profiles", SeqSet)]
 
 
 class DecomposeResult(C.Structure):
@@ -422,7 +422,8 @@ class DecomposeResult(C.Structure):
                 ("ops_offset", C.POINTER(C.c_uint64) * 3), ("ops_len", C.c_void_p * 3)]
 
 
-def _decompose_traces(self, profiles, hbc, refs, params, trim_left=50, trim_right=50, maxindel=1000, madc=5, oriented=None):
+def _decompose_traces(self, profiles, hbc, refs, params, trim_left=50, trim_right=50, maxindel=1000, madc=5, oriented=None,
+                      ref_profiles=None):
     """tracyhip_decompose_traces with host buffers; hbc: HostBaseCalls (primary/secondary rewritten in place);
     oriented: None, or rs.forward per trace when the references are already oriented (indexed-genome path)"""
     pp = profiles if isinstance(profiles, PackedSeqs) else PackedSeqs(profiles, SEQ_PROFILE)
@@ -437,6 +438,9 @@ def _decompose_traces(self, profiles, hbc, refs, params, trim_left=50, trim_righ
     if oriented is not None:
         oriented = np.ascontiguousarray(oriented, dtype=np.uint8)
         job.oriented = oriented.ctypes.data_as(C.POINTER(C.c_uint8))
+    if ref_profiles is not None:  # wildtype-trace reference: oriented profiles parallel to refs (= oriented primary calls)
+        prp = ref_profiles if isinstance(ref_profiles, PackedSeqs) else PackedSeqs(ref_profiles, SEQ_PROFILE)
+        job.ref_profiles = prp.seqset()
     cap = 2 * maxindel + 2
     doff = np.arange(max(nt, 1), dtype=np.uint64) * np.uint64(cap)
     mf = pp.length[:nt].astype(np.uint64)

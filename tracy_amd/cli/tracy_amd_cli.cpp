@@ -12,7 +12,7 @@
 // CPU fallback: without a GPU the command fails with the library's error text.
 // Both commands also take an indexed genome (gzip-compressed multi-FASTA): the trace is anchored by k-mer votes
 // (seed.hpp, fmindex.h:173-326) and aligned against the window around the hit.
-// Not built yet: wildtype-trace references for `decompose`; --annotate (needs the network).  Variants (-v) are written as
+// Not built: --annotate (needs the network), BCF output (no htslib).  Variants (-v) are written as
 // VCF text because htslib (BCF) is not available.
 #include <cstdio>
 #include <cstdlib>
@@ -241,10 +241,6 @@ int prepare(SageConfig const& c, Job& j, bool decompose = false) {
     j.fasta = j.rs.refslice;  // already oriented
     j.slice_start = j.rs.pos;
     return 0;
-  }
-  if (decompose && j.rs.filetype == 2) {
-    std::cerr << "A wildtype-trace reference for decompose is not part of this build; pass a FASTA slice (<= 50 kbp)." << std::endl;
-    return -1;
   }
   if (j.rs.filetype == 1) {
     std::string name;
@@ -584,9 +580,48 @@ bool rows_from_ops(tracyhip_ctx* ctx, std::vector<std::string> const& a1, std::v
   return true;
 }
 
+// wildtype-trace references (indigo.h:249-289): strand by gotohScore(trimmed trace, wildtype profile / its reverse
+// complement); leaves the oriented profile in j.wt_fwd and the oriented primary calls in j.fasta
+bool orient_wildtype(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
+  const uint32_t nt = (uint32_t)jobs.size();
+  std::vector<Profile> trimmed(nt), wrev(nt);
+  std::vector<float> ptrim, pref;
+  std::vector<uint64_t> toff(nt), woff(2 * nt);
+  std::vector<uint32_t> tlen(nt), wlen(2 * nt), idx1(2 * nt), idx2(2 * nt);
+  for (uint32_t i = 0; i < nt; ++i) {
+    Job& j = *jobs[i];
+    createProfile(j.tr, j.bc, trimmed[i], (int32_t)j.trimLeft, (int32_t)j.trimRight);
+    reverseComplementProfile(j.wt_fwd, wrev[i]);
+    toff[i] = ptrim.size(); tlen[i] = (uint32_t)trimmed[i].cols;
+    ptrim.insert(ptrim.end(), trimmed[i].v.begin(), trimmed[i].v.end());
+    for (int r = 0; r < 2; ++r) {
+      Profile const& p = r ? wrev[i] : j.wt_fwd;
+      woff[2 * i + r] = pref.size(); wlen[2 * i + r] = (uint32_t)p.cols;
+      pref.insert(pref.end(), p.v.begin(), p.v.end());
+      idx1[2 * i + r] = i; idx2[2 * i + r] = 2 * i + r;
+    }
+  }
+  tracyhip_pairs sp{};
+  sp.npairs = 2 * nt;
+  sp.a1 = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, ptrim.data(), toff.data(), tlen.data(), nt};
+  sp.a2 = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, pref.data(), woff.data(), wlen.data(), 2 * nt};
+  sp.a1_index = idx1.data(); sp.a2_index = idx2.data();
+  std::vector<int32_t> gs(2 * nt);
+  if (tracyhip_gotoh_score(ctx, &sp, &prm, TRACYHIP_MEM_HOST, gs.data()) != TRACYHIP_OK) return gpu_fail("orientation scores");
+  for (uint32_t i = 0; i < nt; ++i) {
+    Job& j = *jobs[i];
+    j.rs.forward = gs[2 * i] > gs[2 * i + 1];
+    j.fasta = j.wt_primary;
+    if (!j.rs.forward) { reverseComplement(j.fasta); j.wt_fwd = wrev[i]; }
+  }
+  return true;
+}
+
 // indigo.h:190-388 for every job sharing one (trimLeft, trimRight): the whole chain runs on the device
 bool decompose_group(tracyhip_ctx* ctx, SageConfig const& c, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
   const uint32_t nt = (uint32_t)jobs.size();
+  const bool wildtype = jobs[0]->rs.filetype == 2;  // groups never mix reference kinds
+  if (wildtype && !orient_wildtype(ctx, prm, jobs)) return false;
   std::vector<float> prof;
   std::vector<uint8_t> refs, pri, sec;
   std::vector<int32_t> sig, pos;
@@ -624,10 +659,19 @@ bool decompose_group(tracyhip_ctx* ctx, SageConfig const& c, tracyhip_params con
   job.bc = tracyhip_basecalls{nt, sig.data(), soff.data(), ns.data(), pos.data(), pri.data(), sec.data(), boff.data(), blen.data()};
   job.refs = tracyhip_seqset{TRACYHIP_SEQ_CHAR, refs.data(), roff.data(), rlen.data(), nt};
   job.dprm = tracyhip_decomp_params{(int32_t)jobs[0]->trimLeft, (int32_t)jobs[0]->trimRight, (int32_t)c.maxindel, (int32_t)c.madc};
-  const bool seeded = jobs[0]->rs.filetype == 0;  // groups never mix seeded and FASTA references
+  const bool seeded = jobs[0]->rs.filetype == 0 || wildtype;  // the reference arrives oriented
   std::vector<uint8_t> orient(nt);
   for (uint32_t i = 0; i < nt; ++i) orient[i] = jobs[i]->rs.forward ? 1 : 0;
   if (seeded) job.oriented = orient.data();
+  std::vector<float> wprof;
+  std::vector<uint64_t> wpoff(nt);
+  if (wildtype) {
+    for (uint32_t i = 0; i < nt; ++i) {
+      wpoff[i] = wprof.size();
+      wprof.insert(wprof.end(), jobs[i]->wt_fwd.v.begin(), jobs[i]->wt_fwd.v.end());
+    }
+    job.ref_profiles = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, wprof.data(), wpoff.data(), rlen.data(), nt};
+  }
   std::vector<tracyhip_breakpoint> bp(nt);
   std::vector<int32_t> status(nt), sf(nt), sr(nt), strim(nt), dci((size_t)nt * dcap), dce((size_t)nt * dcap);
   std::vector<uint8_t> fwd(nt), sd(pri.size() ? pri.size() : 1);
@@ -818,9 +862,9 @@ int decompose_main(int argc, char** argv) {
     return -1;
   }
   tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};
-  std::map<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>, std::vector<Job*>> groups;  // (seeded?, trims)
+  std::map<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>, std::vector<Job*>> groups;  // (reference kind, trims)
   for (Job& j : jobs)
-    if (j.ok) groups[std::make_pair(j.rs.filetype == 0 ? 1u : 0u, std::make_pair(j.trimLeft, j.trimRight))].push_back(&j);
+    if (j.ok) groups[std::make_pair((uint32_t)j.rs.filetype, std::make_pair(j.trimLeft, j.trimRight))].push_back(&j);
   std::cout << stamp() << "Alignment" << std::endl;
   for (auto& g : groups)
     if (!decompose_group(dev.ctx, c, prm, g.second)) return -1;

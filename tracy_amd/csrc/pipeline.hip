@@ -489,9 +489,21 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
   }
   int nbuf = 0;
   auto buf = [&]() -> DevBuf& { return ctx->d_pipe[nbuf++]; };
-  const void *d_prof, *d_ref, *d_sig, *d_pos;
+  // wildtype-trace reference (indigo.h:249-289): the alignment of the trimmed trace runs against the wildtype PROFILE
+  // (already oriented by the caller), everything after it against its primary basecalls (refs)
+  const tracyhip_seqset& srp = job->ref_profiles;
+  const bool wildtype = srp.data != nullptr;
+  if (wildtype) {
+    if (!job->oriented) return set_error(TRACYHIP_ERR_ARG, "ref_profiles needs `oriented` (the caller picks the strand)");
+    if (srp.kind != TRACYHIP_SEQ_PROFILE || srp.count != sr.count || !srp.offset || !srp.length)
+      return set_error(TRACYHIP_ERR_ARG, "ref_profiles must be a PROFILE set parallel to refs");
+    for (uint32_t i = 0; i < sr.count; ++i)
+      if (srp.length[i] != sr.length[i]) return set_error(TRACYHIP_ERR_ARG, "ref_profiles[%u] and refs[%u] differ in length", i, i);
+  }
+  const void *d_prof, *d_ref, *d_sig, *d_pos, *d_refprof = nullptr;
   if ((rc = stage_in(ctx, buf(), sp.data, ep * 4, mem, &d_prof))) return rc;
   if ((rc = stage_in(ctx, buf(), sr.data, er, mem, &d_ref))) return rc;
+  if (wildtype && (rc = stage_in(ctx, buf(), srp.data, seqset_extent(srp) * 4, mem, &d_refprof))) return rc;
   if ((rc = stage_in(ctx, buf(), bc.signal, sext * 4, mem, &d_sig))) return rc;
   if ((rc = stage_in(ctx, buf(), bc.bcpos, bext * 4, mem, &d_pos))) return rc;
   std::vector<DevOut> outs;
@@ -530,7 +542,7 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
     int32_t herr = 0;
     HIP_TRY(hipMemcpyAsync(&herr, ctx->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (herr & 4) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
+    if ((herr & 4) && !wildtype) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
   }
 
   // ---- 1. findBreakpoint(trimmedtrace) (indigo.h:196) ----
@@ -594,14 +606,16 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
   std::vector<PairDesc> desc_trim(nt);
   {
     DpProblem pb;
-    pb.mode = MODE_QP; pb.a1_profile = true; pb.d_a1 = d_prof; pb.d_a2 = ctx->d_codes.p;
+    pb.mode = wildtype ? MODE_PROF : MODE_QP; pb.a1_profile = true; pb.a2_profile = wildtype; pb.d_a1 = d_prof;
+    pb.d_a2 = wildtype ? d_refprof : ctx->d_codes.p;
     pb.desc.resize(nt); pb.k.resize(nt);
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc d = qp_desc(t, true);
       d.flags = h_rc[t] ? PAIR_A2_REVCOMP : 0;
+      if (wildtype) d.a2_off = srp.offset[ridx[t]];
       pb.desc[t] = d;
       desc_trim[t] = d;
-      pb.k[t] = choose_k(d.m, MODE_QP);
+      pb.k[t] = choose_k(d.m, pb.mode);
     }
     if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(d_strim), static_cast<uint8_t*>(b_ops1.p), d_off1,
                      static_cast<uint32_t*>(b_len1.p))))
@@ -612,8 +626,8 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
     if ((rc = upload(ctx, buf(), desc_trim, &dd))) return rc;
     RowsArgs ra{};
     ra.pairs = dd;
-    ra.a1 = d_prof; ra.a2 = d_ref;  // row 1 shows the consensus characters of the (oriented) one-hot reference profile
-    ra.a1_profile = 1; ra.a2_profile = 0; ra.a2_revcomp_flag = 1; ra.a2_onehot = 1;
+    ra.a1 = d_prof; ra.a2 = wildtype ? d_refprof : d_ref;  // row 1: consensus characters of the (oriented) reference profile
+    ra.a1_profile = 1; ra.a2_profile = wildtype ? 1 : 0; ra.a2_revcomp_flag = 1; ra.a2_onehot = wildtype ? 0 : 1;
     ra.ops = static_cast<const uint8_t*>(b_ops1.p);
     ra.ops_off = d_off1;
     ra.ops_len = static_cast<const uint32_t*>(b_len1.p);

@@ -222,13 +222,21 @@ def main():
         "roofline": roofline,
     }
     if world == 1:
-        nthreads = min(os.cpu_count() or 1, 64)
-        sample = args.cpu_sample if args.cpu_sample >= 0 else max(8, min(2 * nthreads, 64))
+        nthreads = os.cpu_count() or 1  # all host cores, one trace per thread
+        sample = args.cpu_sample if args.cpu_sample >= 0 else max(8, min(2 * nthreads, 512))
         if sample > 0:
             v, ns, dt, ores = cpu_baseline(profs, refs, nthreads, sample)
+            v1, n1, dt1, _ = cpu_baseline(profs, refs, 1, 2)  # what one `tracy` process achieves
+            model = ""
+            try:
+                model = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
+            except (OSError, StopIteration):
+                pass
             line["cpu_baseline"] = {"value": round(v, 4), "unit": "GCUPS", "cores": min(nthreads, ns), "kind": "port",
                                     "sample": "%d of the same traces through the oracle's sage.h chain, one trace per thread, %.1f s"
-                                              % (ns, dt)}
+                                              % (ns, dt),
+                                    "single_thread": {"value": round(v1, 4), "unit": "GCUPS", "sample": "%d traces, %.1f s" % (n1, dt1)},
+                                    "cpu_model": model, "host_threads": nthreads}
             # the same traces must come out bit-identical on the GPU
             sf = r_i32["score_final"].cpu().numpy()
             ol = r_i32["ops_len"].cpu().numpy()

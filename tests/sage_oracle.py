@@ -279,11 +279,11 @@ def alignment_trace_padding(row, signal, bcpos, primary, secondary, consensus, e
     return nb
 
 
-def trace_align_json(padded, chrom, pos, forward, row0, row1):
-    """json.h:108-217 -> file text"""
+def assembly_trace_text(padded, name="trace"):
+    """assemblyTrace, json.h:108-194 -> text of one gapped-trace object"""
     sig, bcpos = padded["signal"], padded["bcPos"]
     ns = len(sig[0])
-    o = ["{\n", "\"gappedTrace\":\n", "{\n", "\"traceFileName\": \"trace\",\n", "\"leadingGaps\": %d,\n" % padded["leadingGaps"],
+    o = ["{\n", "\"traceFileName\": \"%s\",\n" % name, "\"leadingGaps\": %d,\n" % padded["leadingGaps"],
          "\"trailingGaps\": %d,\n" % padded["trailingGaps"]]
     for k, nm in enumerate(("peakA", "peakC", "peakG", "peakT")):
         o.append("\"%s\": [%s],\n" % (nm, ", ".join(str(v) for v in sig[k])))
@@ -315,6 +315,12 @@ def trace_align_json(padded, chrom, pos, forward, row0, row1):
             items.append((i, "\"%d\":\"-\"" % (i + 1)))
     o.append("\"basecalls\": {%s}\n" % joined(items))
     o.append("}\n")
+    return "".join(o)
+
+
+def trace_align_json(padded, chrom, pos, forward, row0, row1):
+    """json.h:197-217 -> file text"""
+    o = ["{\n", "\"gappedTrace\":\n", assembly_trace_text(padded, "trace")]
     o.append(",\n")
     o.append("\"refchr\": \"%s\",\n" % chrom)
     o.append("\"refpos\": %d,\n" % (pos + 1))

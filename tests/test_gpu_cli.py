@@ -446,3 +446,66 @@ def test_decompose_against_wildtype_trace(tmp_path):
             want = so.plot_alignment(rows[0], rows[1], "wildtype", w["ref_pos%d" % k], len(sl), bool(w["forward"]), w["score%d" % k], 60,
                                      key=k + 1, a1a2=w["af"])
             assert open(pre + ".align%d" % (k + 1)).read() == want, (reverse, k)
+
+
+# ---- `assemble` (BASELINE configs[4] at test size) ---------------------------------------------------------------
+def tiled_traces(rng, tmp, n, region_len=1500, tlen=420, some_reverse=True, noisy_ends=True):
+    from tracy_amd import hostlib
+    region = bytes(rng.choice(list(b"ACGT"), size=region_len).tolist())
+    paths = []
+    for i in range(n):
+        start = int(i * (region_len - tlen) / max(n - 1, 1))
+        seq = bytearray(region[start:start + tlen])
+        for k in range(len(seq)):
+            if rng.random() < 0.01:
+                seq[k] = int(rng.choice(list(b"ACGT")))
+        seq = bytes(seq)
+        if some_reverse and i % 3 == 1:
+            seq = so.revcomp(seq)
+        nb = len(seq)
+        tr = np.zeros((4, 12 * nb + 12), np.int32)
+        pos = 6 + 12 * np.arange(nb, dtype=np.int32)
+        tri = 1.0 - np.abs(np.arange(-5, 6)) / 6.0
+        for j, ch in enumerate(seq):
+            amp = rng.uniform(500, 1100)
+            tr[b"ACGT".index(ch), pos[j] - 5:pos[j] + 6] += (amp * tri).astype(np.int32)
+            noisy = noisy_ends and (j < 25 or j > nb - 30)
+            tr[int(rng.integers(0, 4)), pos[j] - 5:pos[j] + 6] += (amp * (0.6 if noisy else 0.06) * tri).astype(np.int32)
+        p = os.path.join(tmp, "tile%02d.ab1" % i)
+        hostlib.write_abif(p, tr, pos, seq, np.full(nb, 40, np.uint8))
+        paths.append(p)
+    return region, paths
+
+
+def test_assemble_reference_guided(tmp_path):
+    import assemble_oracle as ao
+    rng = np.random.default_rng(1618)
+    region, paths = tiled_traces(rng, str(tmp_path), 5)
+    junk_region, junk = tiled_traces(np.random.default_rng(3), str(tmp_path / ".."), 1, region_len=500, tlen=300)
+    ref_path = str(tmp_path / "region.fa")
+    open(ref_path, "w").write(">region\n%s\n" % region.decode())
+    pre = str(tmp_path / "asm")
+    p = subprocess.run([CLI, "assemble", "-r", ref_path, "-o", pre, "-i", "-a", "fastq"] + paths + junk, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr
+    assert "is not matching to the reference" in p.stderr
+    want, sidx = ao.assemble_ref_guided(paths + junk, ref_path, SC, inccons=True, fmt="fastq")
+    assert len(sidx) == 5 and not all(s["forward"] for s in sidx)
+    for ext, txt in want.items():
+        assert open(pre + ext).read() == txt, ext
+
+
+def test_assemble_de_novo(tmp_path):
+    import assemble_oracle as ao
+    rng = np.random.default_rng(2236)
+    region, paths = tiled_traces(rng, str(tmp_path), 5, region_len=1200, tlen=400)
+    _, lonely = tiled_traces(np.random.default_rng(8), str(tmp_path / ".."), 1, region_len=500, tlen=300)
+    pre = str(tmp_path / "dn")
+    p = subprocess.run([CLI, "assemble", "-o", pre, "--called", "0.3"] + paths + lonely, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr
+    assert "is not matching to any of the other traces" in p.stderr
+    want, info = ao.assemble_denovo(paths + lonely, SC, called=0.3)
+    assert info["keep"] == [0, 1, 2, 3, 4]
+    for ext, txt in want.items():
+        assert open(pre + ext).read() == txt, ext
+    cons = open(pre + ".cons.fa").read().split("\n")[1]
+    assert len(cons) > 1000  # the tiles were merged into one contig of about the region's length

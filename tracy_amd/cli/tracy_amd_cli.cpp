@@ -6,6 +6,7 @@
 //   tracy_amd_cli align     [options] -r reference.fa|wildtype.ab1 trace.ab1
 //   tracy_amd_cli decompose [options] -r reference.fa trace.ab1
 //   tracy_amd_cli <cmd>     [options] --batch manifest.tsv     lines: trace <TAB> reference <TAB> outprefix
+//   tracy_amd_cli assemble  [options] [-r reference.fa] trace1.ab1 trace2.ab1 ...   (assemble_cli.inc)
 //
 // Host stages (as in the reference): ABIF/SCF parsing, basecalling, trimming estimate, profiles, file
 // writers.  Device stages: every Gotoh DP, orientation, trimReferenceSlice, alignment rows.  There is no
@@ -27,6 +28,7 @@
 #include <vector>
 
 #include "../../include/tracy_hip.h"
+#include "../host/assemble_out.hpp"
 #include "../host/indigo_out.hpp"
 #include "../host/sage_out.hpp"
 #include "../host/seed.hpp"
@@ -903,12 +905,16 @@ int decompose_main(int argc, char** argv) {
   return failed ? 2 : 0;
 }
 
+#include "assemble_cli.inc"
+
 }  // namespace
 
 int main(int argc, char** argv) {
   if (argc >= 2 && std::strcmp(argv[1], "align") == 0) return align_main(argc - 1, argv + 1);
   if (argc >= 2 && std::strcmp(argv[1], "decompose") == 0) return decompose_main(argc - 1, argv + 1);
+  if (argc >= 2 && std::strcmp(argv[1], "assemble") == 0) return assemble_main(argc - 1, argv + 1);
   std::cout << "Usage: tracy_amd_cli align|decompose [OPTIONS] -r genome.fa trace.ab1" << std::endl;
   std::cout << "       tracy_amd_cli align|decompose [OPTIONS] --batch manifest.tsv" << std::endl;
+  std::cout << "       tracy_amd_cli assemble [OPTIONS] [-r reference.fa] trace1.ab1 trace2.ab1 ..." << std::endl;
   return argc < 2 ? 0 : 1;
 }

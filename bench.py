@@ -29,29 +29,36 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measure
 
 
 def cpu_baseline(profs, refs, nthreads, budget_traces):
-    """The oracle (CPU restatement of the reference path, `kind: port`) timed on this host, one trace per
-    thread.  Only this leg may touch oracle/."""
-    from concurrent.futures import ThreadPoolExecutor
+    """The oracle (CPU restatement of the reference path, `kind: port`) timed on this host: the sage.h chain in C, one
+    trace per C thread (oracle/tracy_oracle_chain.c).  Only this leg may touch oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from sage_oracle import align_trace
     import pyoracle
     pyoracle.lib()
     n = min(budget_traces, len(profs))
-    work = [(np.ascontiguousarray(profs[i]), refs[i].tobytes()) for i in range(n)]
-
-    def one(w):
-        r = align_trace(w[0], w[1], SCORE, TRIM, TRIM)
-        mf = w[0].shape[1]
-        mt = mf - 2 * TRIM
-        return 3 * mt * len(w[1]) + mf * r["slice_len"], r
-
+    p = np.ascontiguousarray(profs[:n], dtype=np.float32)
+    r = np.ascontiguousarray(refs[:n], dtype=np.uint8)
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=nthreads) as ex:
-        res = list(ex.map(one, work))
+    res, cells = pyoracle.sage_chain_batch(p, r, SCORE, TRIM, TRIM, nthreads)
     dt = time.perf_counter() - t0
-    cells = sum(r[0] for r in res)
-    return cells / dt / 1e9, n, dt, [r[1] for r in res]
+    return cells / dt / 1e9, n, dt, res
+
+
+def usable_cores():
+    """cores this process can really run on: the affinity mask, capped by the cgroup CPU quota of the container"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def main():
@@ -222,8 +229,8 @@ def main():
         "roofline": roofline,
     }
     if world == 1:
-        nthreads = os.cpu_count() or 1  # all host cores, one trace per thread
-        sample = args.cpu_sample if args.cpu_sample >= 0 else max(8, min(2 * nthreads, 512))
+        nthreads = usable_cores()  # all host cores this process may use, one trace per thread
+        sample = args.cpu_sample if args.cpu_sample >= 0 else max(8, min(40 * nthreads, 2048))  # ~10 s of CPU work
         if sample > 0:
             v, ns, dt, ores = cpu_baseline(profs, refs, nthreads, sample)
             v1, n1, dt1, _ = cpu_baseline(profs, refs, 1, 2)  # what one `tracy` process achieves
@@ -233,10 +240,10 @@ def main():
             except (OSError, StopIteration):
                 pass
             line["cpu_baseline"] = {"value": round(v, 4), "unit": "GCUPS", "cores": min(nthreads, ns), "kind": "port",
-                                    "sample": "%d of the same traces through the oracle's sage.h chain, one trace per thread, %.1f s"
+                                    "sample": "%d of the same traces through the oracle's sage.h chain (C, pthreads), one trace per thread, %.1f s"
                                               % (ns, dt),
                                     "single_thread": {"value": round(v1, 4), "unit": "GCUPS", "sample": "%d traces, %.1f s" % (n1, dt1)},
-                                    "cpu_model": model, "host_threads": nthreads}
+                                    "cpu_model": model, "host_threads": os.cpu_count(), "usable_cores": nthreads}
             # the same traces must come out bit-identical on the GPU
             sf = r_i32["score_final"].cpu().numpy()
             ol = r_i32["ops_len"].cpu().numpy()

@@ -38,7 +38,7 @@ class TrimResult(C.Structure):
 def build(force=False):
     so = os.path.join(_HERE, "libtracy_oracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("tracy_oracle.c", "tracy_oracle_decompose.c", "tracy_oracle_abif.c",
-                                             "tracy_oracle.h", "tracy_oracle_decompose.h")]
+                                             "tracy_oracle_chain.c", "tracy_oracle.h", "tracy_oracle_decompose.h")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "libtracy_oracle.so"], stdout=subprocess.DEVNULL)
@@ -270,3 +270,33 @@ def basecall(trace, basecallpos, sigratio=0.33):
 
 def ref_basecall(trace, basecallpos, sigratio=0.33):
     return _basecall(ref_lib().ref_basecall, trace, basecallpos, sigratio)
+
+
+class ChainResult(C.Structure):
+    _fields_ = [("score_fwd", C.c_int32), ("score_rev", C.c_int32), ("forward", C.c_int32), ("score_prelim", C.c_int32),
+                ("slice_begin", C.c_uint32), ("slice_len", C.c_uint32), ("ref_pos", C.c_uint32), ("score_final", C.c_int32),
+                ("btr_len", C.c_uint32), ("cells", C.c_uint64)]
+
+
+def sage_chain_batch(profiles, refs, score, trim_left=50, trim_right=50, nthreads=1):
+    """the `tracy align` hot section (sage.h:233-260, 311) for traces of equal shape, one trace per C thread
+    (tracy_oracle_chain.c).  profiles: float32 [nt][6][mf]; refs: uint8 [nt][n].  Returns (list of dicts, total cells)."""
+    profiles = np.ascontiguousarray(profiles, dtype=np.float32)
+    refs = np.ascontiguousarray(refs, dtype=np.uint8)
+    nt, _, mf = profiles.shape
+    n = refs.shape[1]
+    out = (ChainResult * max(nt, 1))()
+    cap = mf + n
+    btr = np.zeros((max(nt, 1), cap), dtype=np.uint8)
+    sc = Score(*score)
+    rc = lib().orc_sage_chain_batch(profiles.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(mf), refs.ctypes.data_as(C.c_char_p), C.c_size_t(n),
+                                    C.c_uint32(nt), C.byref(sc), C.c_uint32(trim_left), C.c_uint32(trim_right), C.c_uint32(nthreads), out,
+                                    btr.ctypes.data_as(C.c_char_p), C.c_size_t(cap))
+    if rc != 0:
+        raise MemoryError("oracle chain failed")
+    res = []
+    for t in range(nt):
+        r = out[t]
+        res.append(dict(score_fwd=r.score_fwd, score_rev=r.score_rev, forward=r.forward, score_prelim=r.score_prelim, slice_begin=r.slice_begin,
+                        slice_len=r.slice_len, ref_pos=r.ref_pos, score_final=r.score_final, btr=btr[t, :r.btr_len].tobytes()))
+    return res, int(sum(out[t].cells for t in range(nt)))

@@ -125,3 +125,19 @@ def test_profile_helpers():
     assert prof[4:].sum() == 0
     # column 1: C primary, S secondary -> C and G called
     assert prof[0, 1] < prof[1, 1] and prof[3, 1] < prof[2, 1]
+
+
+def test_c_chain_matches_the_python_composition():
+    """oracle/tracy_oracle_chain.c (the CPU baseline of bench.py, one trace per pthread) == the chain composed in Python
+    from the same oracle functions (tests/sage_oracle.py), forward and reverse traces, odd trims"""
+    import sage_oracle as so
+    from tracy_amd import hostlib
+    refs, profs, rev = hostlib.synth_align(700, 6, 1500, 300, 2)
+    for (tl, tr) in [(50, 50), (0, 7), (200, 200)]:
+        res, cells = orc.sage_chain_batch(profs, refs, (3, -5, -10, -4), tl, tr, 3)
+        assert cells > 0 and len(set(r["forward"] for r in res)) == 2
+        for i in range(6):
+            w = so.align_trace(profs[i], refs[i].tobytes(), (3, -5, -10, -4), tl, tr)
+            for k in ("score_fwd", "score_rev", "forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
+                assert int(res[i][k]) == int(w[k]), (i, k)
+            assert res[i]["btr"] == w["btr"]

@@ -131,7 +131,7 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
         from indigo_oracle import decompose_trace
         ns_ = min(args.cpu_sample, nt)
-        nthreads = min(os.cpu_count() or 1, 64)
+        nthreads = min(os.cpu_count() or 1, 16)
         work = list(range(ns_))
 
         def one(i):

@@ -1,0 +1,136 @@
+#!/usr/bin/env python
+"""fuzz_parity.py -- randomized GPU-vs-oracle campaign (development tool, run through gpurun): ragged random pairs in
+every DP mode / AlignConfig / scoring, ragged `tracy align` batches, `tracy decompose` batches.  Prints one JSON line
+with the number of cases compared and the mismatches (0 expected); exits non-zero on any mismatch."""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+
+def rand_seq(rng, n, alpha=b"ACGT"):
+    return bytes(rng.choice(list(alpha), size=n).tolist())
+
+
+def rand_profile(rng, n, kind):
+    p = np.zeros((6, n), np.float32)
+    x = rng.random((4, n)).astype(np.float32)
+    if kind == 0:
+        x = x ** 8
+    p[:4] = x / x.sum(axis=0, keepdims=True)
+    if kind == 2 and n:  # alignment-like profile with N / gap weight
+        j = rng.integers(0, n, size=max(1, n // 10))
+        p[4, j] = np.float32(0.25)
+        p[5, j] = np.float32(0.125)
+    return p
+
+
+def related(rng, s, rate=0.1):
+    out = bytearray()
+    for ch in s:
+        u = rng.random()
+        if u < rate / 3:
+            continue
+        if u < 2 * rate / 3:
+            out.append(int(rng.choice(list(b"ACGT"))))
+        out.append(int(rng.choice(list(b"ACGT"))) if u > 1 - rate / 3 else ch)
+    return bytes(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=1500)
+    ap.add_argument("--traces", type=int, default=96)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import pyoracle as orc
+    import tracy_amd
+    from tracy_amd import capi, hostlib
+    import sage_oracle as so
+    import indigo_oracle as io
+    rng = np.random.default_rng(args.seed)
+    ctx = tracy_amd.Context(0)
+    bad, done = [], {}
+    pool = ThreadPoolExecutor(max_workers=16)
+
+    # ---- 1. DP modes ----
+    scorings = [(3, -5, -10, -4), (5, -4, -10, -1), (1, -1, -2, -1), (2, -3, 0, -2), (7, -9, -30, -3)]
+    for mode in ("char", "qp", "prof"):
+        for cfg in [(1, 0), (1, 1), (0, 0), (0, 1)]:
+            sc = scorings[int(rng.integers(0, len(scorings)))]
+            n_pairs = args.pairs // 12
+            a1, a2 = [], []
+            for _ in range(n_pairs):
+                m = int(rng.choice([0, 1, 2, 63, 64, 65, rng.integers(1, 700), rng.integers(1, 1500)]))
+                n = int(rng.choice([0, 1, 3, 64, rng.integers(1, 900)]))
+                if mode == "char":
+                    s2 = rand_seq(rng, n, b"ACGTN")
+                    s1 = (related(rng, s2) + rand_seq(rng, m))[:m] if rng.random() < 0.7 else rand_seq(rng, m)
+                    a1.append(s1); a2.append(s2)
+                elif mode == "qp":
+                    a1.append(rand_profile(rng, m, int(rng.integers(0, 2)))); a2.append(rand_seq(rng, n, b"ACGTACGTNn-x"))
+                else:
+                    m, n = min(m, 400), min(n, 400)
+                    a1.append(rand_profile(rng, m, int(rng.integers(0, 3)))); a2.append(rand_profile(rng, n, int(rng.integers(0, 3))))
+            scores, btr = ctx.align(a1, a2, sc + cfg)
+            sonly = ctx.score(a1, a2, sc + cfg)
+
+            def want(i):
+                if mode == "char":
+                    return orc.gotoh_str(a1[i], a2[i], cfg[0], cfg[1], sc)
+                p2 = orc.create_profile_str(a2[i]) if mode == "qp" else a2[i]
+                return orc.gotoh_prof(a1[i], p2, cfg[0], cfg[1], sc)
+            for i, w in enumerate(pool.map(want, range(n_pairs))):
+                if (int(scores[i]), btr[i]) != w or int(sonly[i]) != w[0]:
+                    bad.append(("dp", mode, cfg, sc, i, len(a1[i]) if mode == "char" else a1[i].shape[1]))
+            done["dp_" + mode] = done.get("dp_" + mode, 0) + n_pairs
+
+    # ---- 2. `tracy align` batches, ragged ----
+    nt = args.traces
+    profs, refs = [], []
+    for i in range(nt):
+        mf = int(rng.integers(120, 1100))
+        n = int(rng.integers(mf + 50, 4000))
+        r, p, _ = hostlib.synth_align(int(rng.integers(0, 1 << 30)), 1, n, mf, 1)
+        profs.append(p[0]); refs.append(r[0].tobytes())
+    for (tl, tr) in [(50, 50), (0, 0), (13, 77)]:
+        got = ctx.align_traces(profs, refs, (3, -5, -10, -4), tl, tr)
+        for i, w in enumerate(pool.map(lambda i: so.align_trace(profs[i], refs[i], (3, -5, -10, -4), tl, tr), range(nt))):
+            ok = all(int(got[k][i]) == int(w[k]) for k in ("score_fwd", "score_rev", "forward", "score_prelim", "slice_begin", "slice_len", "ref_pos",
+                                                            "score_final")) and got["btr"][i] == w["btr"]
+            if not ok:
+                bad.append(("align", tl, tr, i))
+        done["align"] = done.get("align", 0) + nt
+
+    # ---- 3. `tracy decompose` batches ----
+    nd = max(8, args.traces // 2)
+    mf, n = 700, 2200
+    d = hostlib.synth_decompose_batch(int(rng.integers(0, 1 << 30)), nd, n, mf, 0)
+    hbc = capi.HostBaseCalls([d["signal"][i] for i in range(nd)], [d["bcpos"][i] for i in range(nd)], [d["primary"][i].tobytes() for i in range(nd)],
+                             [d["secondary"][i].tobytes() for i in range(nd)])
+    got = ctx.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, [d["refs"][i].tobytes() for i in range(nd)], (3, -5, -10, -4))
+
+    def dwant(i):
+        return io.decompose_trace(d["signal"][i], d["bcpos"][i], d["primary"][i].tobytes(), d["secondary"][i].tobytes(), d["refs"][i].tobytes(),
+                                  (3, -5, -10, -4))
+    for i, w in enumerate(pool.map(dwant, range(nd))):
+        fr = np.asarray(got["fractions"]).reshape(-1, 2)
+        ok = got["primary"][i] == w["primary"] and got["secdecomp_list"][i] == w["secdecomp"] and (float(fr[i, 0]), float(fr[i, 1])) == w["af"]
+        ok = ok and got["dcp"][i] == w["dcp"] and all(got["btr%d" % k][i] == w["btr%d" % k] and int(got["score%d" % k][i]) == w["score%d" % k] for k in range(3))
+        if not ok:
+            bad.append(("decompose", i))
+    done["decompose"] = nd
+    print(json.dumps({"compared": done, "mismatches": len(bad), "first": [str(b) for b in bad[:5]]}))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -11,3 +11,15 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_libraries():
+    """build whatever is missing or stale (no-ops otherwise): the gfx950 library cross-compiles without a GPU"""
+    from tracy_amd import build as b
+    b.build()
+    b.build_host()
+    b.build_cli()
+    b.build_msa()
+    import pyoracle
+    pyoracle.build()

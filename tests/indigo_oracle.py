@@ -158,14 +158,11 @@ def nearest_snp(trim_left, trim_right, primary, secondary, rtp):
     return rtp - trim_left if rtp > trim_left else trim_left
 
 
-def allele_json(cfg, signal, bcpos, estqual, primary, secondary, rep):
-    """json.h:17-105 + 260-381.  cfg: dict(trimLeft, trimRight, pratio, genome, input, qualCut); rep: dict(rs1, rs2 (chr,pos,forward),
-    align1..3 (row0,row1), score1..3, indelshift, breakpoint, a1a2, dcp, var)"""
+def trace_json_body(signal, bcpos, estqual, primary, secondary):
+    """_traceJsonOut, json.h:33-105"""
     ns = len(signal[0])
     pri, sec = primary.decode(), secondary.decode()
-    o = ["{\n"]
-    o.append("\"meta\": {\"program\": \"tracy\", \"version\": \"0.9.1\", \"arguments\": {\"trimLeft\": %d, \"trimRight\": %d, \"pratio\": %s, "
-             "\"genome\": \"%s\", \"input\": \"%s\"}},\n" % (cfg["trimLeft"], cfg["trimRight"], "%g" % cfg["pratio"], cfg["genome"], cfg["input"]))
+    o = []
     o.append("\"pos\": [%s],\n" % ", ".join(str(i + 1) for i in range(ns)))
     for k, nm in enumerate(("peakA", "peakC", "peakG", "peakT")):
         o.append("\"%s\": [%s],\n" % (nm, ", ".join(str(int(v)) for v in signal[k])))
@@ -189,6 +186,18 @@ def allele_json(cfg, signal, bcpos, estqual, primary, secondary, rep):
         items.append((i, t + "\""))
     o.append("\"basecalls\": {%s},\n" % joined(items))
     o.append("\"primarySeq\": \"%s\",\n\"secondarySeq\": \"%s\"\n" % (pri, sec))
+    return "".join(o)
+
+
+def allele_json(cfg, signal, bcpos, estqual, primary, secondary, rep):
+    """json.h:17-105 + 260-381.  cfg: dict(trimLeft, trimRight, pratio, genome, input, qualCut); rep: dict(rs1, rs2 (chr,pos,forward),
+    align1..3 (row0,row1), score1..3, indelshift, breakpoint, a1a2, dcp, var)"""
+    ns = len(signal[0])
+    pri, sec = primary.decode(), secondary.decode()
+    o = ["{\n"]
+    o.append("\"meta\": {\"program\": \"tracy\", \"version\": \"0.9.1\", \"arguments\": {\"trimLeft\": %d, \"trimRight\": %d, \"pratio\": %s, "
+             "\"genome\": \"%s\", \"input\": \"%s\"}},\n" % (cfg["trimLeft"], cfg["trimRight"], "%g" % cfg["pratio"], cfg["genome"], cfg["input"]))
+    o.append(trace_json_body(signal, bcpos, estqual, primary, secondary))
     o.append(",\n")
     xw = x_window(bcpos, cfg["trimLeft"] + rep["breakpoint"])
     o.append("\"chartConfig\": { \"x\": { \"axis\": { \"range\": [%d, %d] }}},\n" % xw)

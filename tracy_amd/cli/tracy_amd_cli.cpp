@@ -905,6 +905,111 @@ int decompose_main(int argc, char** argv) {
   return failed ? 2 : 0;
 }
 
+// ---- `tracy basecall` (teal.h:24-117): host only, no device needed -------------------------------------------
+int basecall_main(int argc, char** argv) {
+  float pratio = 0.33f, trimStringency = 0;
+  uint16_t trimLeft = 0, trimRight = 0;
+  std::string format = "json", otype = "primary", outfile = "out.json", tracein;
+  static const std::map<std::string, char> longs = {{"help", '?'}, {"pratio", 'p'}, {"format", 'f'}, {"otype", 'y'}, {"trim", 't'},
+                                                    {"trimLeft", 'q'}, {"trimRight", 'u'}, {"output", 'o'}};
+  bool bad = false;
+  for (int i = 1; i < argc && !bad; ++i) {
+    std::string a = argv[i], val;
+    char opt = 0;
+    bool has_val = false;
+    if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
+      std::string name = a.substr(2);
+      const std::size_t eq = name.find('=');
+      if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); has_val = true; }
+      auto it = longs.find(name);
+      if (it == longs.end()) { std::cerr << "unrecognised option '" << a << "'" << std::endl; bad = true; break; }
+      opt = it->second;
+    } else if (a.size() >= 2 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9')) {
+      opt = a[1];
+      if (a.size() > 2) { val = a.substr(2); has_val = true; }
+    } else {
+      tracein = a;
+      continue;
+    }
+    if (opt == '?') { bad = true; break; }
+    if (!has_val) {
+      if (i + 1 >= argc) { std::cerr << "the required argument for option '" << a << "' is missing" << std::endl; bad = true; break; }
+      val = argv[++i];
+    }
+    switch (opt) {
+      case 'p': pratio = std::strtof(val.c_str(), nullptr); break;
+      case 'f': format = val; break;
+      case 'y': otype = val; break;
+      case 't': trimStringency = std::strtof(val.c_str(), nullptr); break;
+      case 'q': trimLeft = (uint16_t)std::atoi(val.c_str()); break;
+      case 'u': trimRight = (uint16_t)std::atoi(val.c_str()); break;
+      case 'o': outfile = val; break;
+      default: std::cerr << "unrecognised option '" << a << "'" << std::endl; bad = true; break;
+    }
+  }
+  if (bad || tracein.empty()) {
+    std::cout << "Usage: tracy " << argv[0] << " [OPTIONS] trace.ab1" << std::endl;
+    std::cout << "Generic options:\n"
+                 "  -? [ --help ]                    show help message\n"
+                 "  -p [ --pratio ] arg (=0.33)      peak ratio to call a base\n"
+                 "  -f [ --format ] arg (=json)      output format [json|tsv|fasta|fastq]\n"
+                 "  -y [ --otype ] arg (=primary)    fasta/fastq sequence [primary|secondary|consensus]\n"
+                 "  -t [ --trim ] arg (=0)           trimming stringency [1:9], 0: use trimLeft and trimRight\n"
+                 "  -q [ --trimLeft ] arg (=0)       trim size left\n"
+                 "  -u [ --trimRight ] arg (=0)      trim size right\n"
+                 "  -o [ --output ] arg (=out.json)  basecalling output\n\n";
+    return -1;
+  }
+  echo_command(argc, argv);
+  if (!regular_nonempty(tracein)) {
+    std::cerr << "Input trace file is missing: " << tracein << std::endl;
+    return 1;
+  }
+  Trace tr;
+  if (!load_trace(tracein, tr)) return -1;
+  BaseCalls bc;
+  basecall(tr, bc, pratio);
+  if (trimStringency >= 1) {
+    uint32_t l = 0, r = 0;
+    trimTrace(trimStringency, bc, l, r);
+    trimLeft = (uint16_t)l;
+    trimRight = (uint16_t)r;
+  }
+  if ((uint32_t)trimLeft + trimRight >= bc.bcPos.size()) {
+    std::cerr << "The sum of the left and right trim size is larger than the trace!" << std::endl;
+    return -1;
+  }
+  if (format == "tsv") {
+    traceTxtOut(outfile, bc, tr, trimLeft, trimRight);
+  } else if (format == "fasta" || format == "fastq") {  // traceFastaOut / traceFastqOut, fasta.h:98-155
+    std::ofstream f(outfile.c_str());
+    std::string const* seq = otype == "primary" ? &bc.primary : otype == "secondary" ? &bc.secondary : otype == "consensus" ? &bc.consensus : nullptr;
+    if (seq) {
+      f << (format == "fasta" ? ">" : "@") << otype << std::endl;
+      for (uint32_t i = trimLeft; i < seq->size() - trimRight; ++i) f << (*seq)[i];
+      f << std::endl;
+    }
+    if (format == "fastq") {
+      f << "+" << std::endl;
+      uint32_t call = 0;
+      int32_t next = bc.bcPos[0];
+      for (int32_t x = 0; x < (int32_t)tr.traceACGT[0].size(); ++x) {
+        if (next != x) continue;
+        if (call >= trimLeft && call < bc.primary.size() - trimRight) f << (char)(bc.estQual[call] + 33);
+        if (call < bc.bcPos.size() - 1) next = bc.bcPos[++call];
+      }
+      f << std::endl;
+    }
+  } else {  // traceJsonOut, json.h:96-105
+    std::ofstream f(outfile.c_str());
+    f << "{" << std::endl;
+    traceJsonBody(f, bc, tr);
+    f << std::endl << "}" << std::endl;
+  }
+  std::cout << stamp() << "Done." << std::endl;
+  return 0;
+}
+
 #include "assemble_cli.inc"
 
 }  // namespace
@@ -913,8 +1018,10 @@ int main(int argc, char** argv) {
   if (argc >= 2 && std::strcmp(argv[1], "align") == 0) return align_main(argc - 1, argv + 1);
   if (argc >= 2 && std::strcmp(argv[1], "decompose") == 0) return decompose_main(argc - 1, argv + 1);
   if (argc >= 2 && std::strcmp(argv[1], "assemble") == 0) return assemble_main(argc - 1, argv + 1);
+  if (argc >= 2 && std::strcmp(argv[1], "basecall") == 0) return basecall_main(argc - 1, argv + 1);
   std::cout << "Usage: tracy_amd_cli align|decompose [OPTIONS] -r genome.fa trace.ab1" << std::endl;
   std::cout << "       tracy_amd_cli align|decompose [OPTIONS] --batch manifest.tsv" << std::endl;
   std::cout << "       tracy_amd_cli assemble [OPTIONS] [-r reference.fa] trace1.ab1 trace2.ab1 ..." << std::endl;
+  std::cout << "       tracy_amd_cli basecall [OPTIONS] trace.ab1" << std::endl;
   return argc < 2 ? 0 : 1;
 }

@@ -509,3 +509,40 @@ def test_assemble_de_novo(tmp_path):
         assert open(pre + ext).read() == txt, ext
     cons = open(pre + ".cons.fa").read().split("\n")[1]
     assert len(cons) > 1000  # the tiles were merged into one contig of about the region's length
+
+
+# ---- `consensus` ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("reverse,opts", [(False, []), (True, ["-a", "-i", "-b", "amplicon7", "-l", "45", "-q", "30", "-s", "20"])])
+def test_consensus_of_two_traces(tmp_path, reverse, opts):
+    import consensus_oracle as co
+    rng = np.random.default_rng(4242 + reverse)
+    region, paths = tiled_traces(rng, str(tmp_path), 2, region_len=700, tlen=480, some_reverse=False, noisy_ends=False)
+    if reverse:  # second trace from the other strand
+        _, alt = tiled_traces(np.random.default_rng(4243), str(tmp_path / ".."), 2, region_len=700, tlen=480, some_reverse=False, noisy_ends=False)
+        from tracy_amd import hostlib
+        t = hostlib.read_trace(paths[1])
+        sig = np.ascontiguousarray(t["signal"][::-1, ::-1])
+        pos = (sig.shape[1] - 1 - t["basecallpos"][::-1]).astype(np.int32)
+        hostlib.write_abif(paths[1], sig, pos, b"N" * len(pos), np.full(len(pos), 30, np.uint8))
+    pre = str(tmp_path / "cons")
+    p = subprocess.run([CLI, "consensus", "-o", pre] + opts + paths, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    kw = {}
+    if opts:
+        kw = dict(trims=(30, 50, 50, 20), label="amplicon7", union=False, iupac=True, linelimit=45)
+    want, forward = co.consensus(paths[0], paths[1], SC, **kw)
+    assert forward == (not reverse)
+    for ext, txt in want.items():
+        assert open(pre + ext).read() == txt, ext
+    assert os.path.exists(pre + "_1st.abif") and os.path.exists(pre + "_2nd.abif")
+
+
+def test_consensus_without_overlap(tmp_path):
+    rng = np.random.default_rng(5)
+    _, a = tiled_traces(rng, str(tmp_path), 1, region_len=400, tlen=300, some_reverse=False)
+    os.rename(a[0], str(tmp_path / "x.ab1"))
+    _, b = tiled_traces(np.random.default_rng(6), str(tmp_path), 1, region_len=400, tlen=300, some_reverse=False)
+    p = subprocess.run([CLI, "consensus", "-o", str(tmp_path / "n"), str(tmp_path / "x.ab1"), b[0]], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 1 and "No sufficient trace overlap" in p.stderr
+    p = subprocess.run([CLI, "consensus", b[0]], capture_output=True, text=True)
+    assert p.returncode == 1 and "Exactly 2 input trace files" in p.stderr

@@ -82,7 +82,7 @@ def build_cli(force=False, verbose=False):
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     hdir = os.path.join(HERE, "host")
     src = os.path.join(HERE, "cli", "tracy_amd_cli.cpp")
-    srcs = [src, os.path.join(HERE, "cli", "assemble_cli.inc"), SO, os.path.join(os.path.dirname(HERE), "include", "tracy_hip.h")]
+    srcs = [src, os.path.join(HERE, "cli", "assemble_cli.inc"), os.path.join(HERE, "cli", "consensus_cli.inc"), SO, os.path.join(os.path.dirname(HERE), "include", "tracy_hip.h")]
     srcs += [os.path.join(hdir, f) for f in os.listdir(hdir)]
     if force or stale(CLI, srcs):
         cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-o", CLI, src, "-L" + LIBDIR, "-ltracy_hip",

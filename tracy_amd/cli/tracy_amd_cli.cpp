@@ -29,6 +29,7 @@
 
 #include "../../include/tracy_hip.h"
 #include "../host/assemble_out.hpp"
+#include "../host/consensus_out.hpp"
 #include "../host/indigo_out.hpp"
 #include "../host/sage_out.hpp"
 #include "../host/seed.hpp"
@@ -1011,6 +1012,7 @@ int basecall_main(int argc, char** argv) {
 }
 
 #include "assemble_cli.inc"
+#include "consensus_cli.inc"
 
 }  // namespace
 
@@ -1019,9 +1021,11 @@ int main(int argc, char** argv) {
   if (argc >= 2 && std::strcmp(argv[1], "decompose") == 0) return decompose_main(argc - 1, argv + 1);
   if (argc >= 2 && std::strcmp(argv[1], "assemble") == 0) return assemble_main(argc - 1, argv + 1);
   if (argc >= 2 && std::strcmp(argv[1], "basecall") == 0) return basecall_main(argc - 1, argv + 1);
+  if (argc >= 2 && std::strcmp(argv[1], "consensus") == 0) return consensus_main(argc - 1, argv + 1);
   std::cout << "Usage: tracy_amd_cli align|decompose [OPTIONS] -r genome.fa trace.ab1" << std::endl;
   std::cout << "       tracy_amd_cli align|decompose [OPTIONS] --batch manifest.tsv" << std::endl;
   std::cout << "       tracy_amd_cli assemble [OPTIONS] [-r reference.fa] trace1.ab1 trace2.ab1 ..." << std::endl;
   std::cout << "       tracy_amd_cli basecall [OPTIONS] trace.ab1" << std::endl;
+  std::cout << "       tracy_amd_cli consensus [OPTIONS] trace1.ab1 trace2.ab1" << std::endl;
   return argc < 2 ? 0 : 1;
 }

@@ -64,8 +64,8 @@ def usable_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--traces", type=int, default=10000, help="traces per GPU per step")
     ap.add_argument("--ref-len", type=int, default=10000)
     ap.add_argument("--trace-len", type=int, default=1000)

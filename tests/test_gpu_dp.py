@@ -221,3 +221,18 @@ def test_cpp_host_mirror(tmp_path):
                            "-Wl,-rpath," + os.path.join(root, "oracle"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_align_traces_against_the_largest_fasta_window(ctx):
+    """MAX_SINGLE_FASTA_SIZE (fasta.h:10-12): 50 kbp references, forward and reverse traces, through the checkpointed
+    score pass + band traceback"""
+    import sage_oracle as so
+    from tracy_amd import hostlib
+    refs, profs, rev = hostlib.synth_align(31, 3, 50000, 800, 2)
+    got = ctx.align_traces(list(profs), [r.tobytes() for r in refs], SC, 50, 50)
+    for i in range(3):
+        want = so.align_trace(profs[i], refs[i].tobytes(), SC, 50, 50)
+        for k in ("score_fwd", "score_rev", "forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
+            assert int(got[k][i]) == int(want[k]), (i, k)
+        assert got["btr"][i] == want["btr"]
+        assert int(got["forward"][i]) == 1 - int(rev[i])

@@ -109,6 +109,12 @@ class GenomeIndex {
     hi = i;
   }
   uint64_t position(std::size_t i) const { return table_[i].pos; }
+  // cache warm-up for a batch of look-ups: the directory slot first, then (once that is in cache) the table run
+  void prefetch_slot(uint64_t code) const { __builtin_prefetch(&bucket_[(std::size_t)(code >> (2 * k - bucket_bits_))]); }
+  void prefetch_run(uint64_t code) const {
+    const std::size_t i = bucket_[(std::size_t)(code >> (2 * k - bucket_bits_))];
+    if (i < table_.size()) __builtin_prefetch(&table_[i]);
+  }
   static int base_code(char c) { return base2(c); }
 
   // occurrences of `pat` in the text (exact, over all characters the pattern may hold)
@@ -228,6 +234,21 @@ inline void scanSequence(GenomeIndex const& idx, std::string const& consensus, u
     code = ((code << 2) | (uint64_t)b) & mask;
     if (run < kmer) ++run;
   };
+  // the table look-ups of one trace are independent: compute every window code first and warm the cache in two
+  // sweeps (directory slots, then table runs) so that the look-ups below do not pay one memory latency each
+  std::vector<uint64_t> codes;
+  if (table_ok) {
+    for (uint32_t q = trimLeft; q + 1 < (uint32_t)trimLeft + kmer; ++q) push_letter(q);
+    for (uint16_t p = trimLeft; (p < (consensus.size() - trimRight)) && (p < consensus.size()); ++p) {
+      push_letter((std::size_t)p + kmer - 1);
+      codes.push_back(run == kmer ? code : ~0ull);  // ~0 never is a valid code for k < 32; k = 32 re-checks below
+      if (run == kmer) idx.prefetch_slot(code);
+    }
+    for (uint64_t c : codes)
+      if (c != ~0ull || kmer == 32) idx.prefetch_run(c == ~0ull ? 0 : c);
+    code = 0;
+    run = 0;
+  }
   for (uint32_t q = trimLeft; q + 1 < (uint32_t)trimLeft + kmer; ++q) push_letter(q);
   for (uint16_t p = trimLeft; (p < (consensus.size() - trimRight)) && (p < consensus.size()); ++p) {
     push_letter((std::size_t)p + kmer - 1);

@@ -69,10 +69,12 @@ def main():
     plist = [profs_arr[i] for i in ok]
     wins = [sd["slices"][i] for i in ok]
     fwd = [int(sd["forward"][i]) for i in ok]
-    ctx.align_traces(plist, wins, SCORE, 50, 50, oriented=fwd)
+    from tracy_amd import capi
+    pp, pw = capi.PackedSeqs(plist, capi.SEQ_PROFILE), capi.PackedSeqs(wins, capi.SEQ_CHAR)  # packed host buffers, as a C caller holds them
+    ctx.align_traces(pp, pw, SCORE, 50, 50, oriented=fwd)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = ctx.align_traces(plist, wins, SCORE, 50, 50, oriented=fwd)
+        res = ctx.align_traces(pp, pw, SCORE, 50, 50, oriented=fwd)
     t_ext = (time.perf_counter() - t0) / args.steps
     cells = sum((mf - 100) * len(w) for w in wins) * 2 + int((mf * res["slice_len"].astype(np.int64)).sum())
     right = int(sum(1 for k, i in enumerate(ok) if abs(int(sd["pos"][i]) + int(res["ref_pos"][k]) - (int(starts[i]) - (50 if not i % 2 else 0))) <= 60))

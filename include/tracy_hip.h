@@ -139,11 +139,15 @@ typedef struct {
                                every trace by k-mer seeding (getReferenceSlice, fmindex.h:236-326) and passes refs that are
                                ALREADY oriented (reverse-complemented for reverse traces); oriented[t] = rs.forward.  No
                                orientation scores are computed: score_fwd and score_rev both receive gotohScore(trim, ref). */
+  uint32_t exact_orientation_scores; /* 0 (default): the strand is decided as the reference does (forward iff gsFwd > gsRev), but
+                               the LOSING orientation may be represented by a certified upper bound of its score instead of the
+                               score itself (a prefix of its DP suffices to prove it cannot win; see pipeline.hip).  1: both
+                               gotohScore calls run in full and score_fwd / score_rev are exact. */
 } tracyhip_align_job;
 
 typedef struct {
-  int32_t* score_fwd;     /* [ntraces] gsFwd */
-  int32_t* score_rev;     /* [ntraces] gsRev */
+  int32_t* score_fwd;     /* [ntraces] gsFwd (exact for the winning orientation; see exact_orientation_scores) */
+  int32_t* score_rev;     /* [ntraces] gsRev (idem) */
   uint8_t* forward;       /* [ntraces] 1 = rs.forward */
   int32_t* score_prelim;  /* [ntraces] score of the preliminary alignment (sage.h:258), may be NULL */
   uint32_t* slice_begin;  /* [ntraces] ri: offset of the trimmed slice in the ORIENTED reference */

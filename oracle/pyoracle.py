@@ -300,3 +300,16 @@ def sage_chain_batch(profiles, refs, score, trim_left=50, trim_right=50, nthread
         res.append(dict(score_fwd=r.score_fwd, score_rev=r.score_rev, forward=r.forward, score_prelim=r.score_prelim, slice_begin=r.slice_begin,
                         slice_len=r.slice_len, ref_pos=r.ref_pos, score_final=r.score_final, btr=btr[t, :r.btr_len].tobytes()))
     return res, int(sum(out[t].cells for t in range(nt)))
+
+
+def gotoh_row_state(p1, p2, R, score):
+    """H(R, j) and F(R, j), j = 0..n, of the semiglobal DP on the first R rows (oracle of the prefix-bound kernel)"""
+    p1 = np.ascontiguousarray(p1, dtype=np.float32)
+    p2 = np.ascontiguousarray(p2, dtype=np.float32)
+    m, n = p1.shape[1], p2.shape[1]
+    H = np.zeros(n + 1, np.int32)
+    F = np.zeros(n + 1, np.int32)
+    sc = Score(*score)
+    lib().orc_gotoh_row_state(p1.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(m), p2.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(n),
+                              C.c_size_t(R), C.byref(sc), H.ctypes.data_as(C.POINTER(C.c_int32)), F.ctypes.data_as(C.POINTER(C.c_int32)))
+    return H, F

@@ -98,3 +98,44 @@ int orc_sage_chain_batch(const float* profiles, size_t mf, const char* refs, siz
   free(jobs);
   return 0;
 }
+
+/* ---- row state of the semiglobal Gotoh DP (test oracle of the prefix-bound kernel) --------------------------------
+ * H(R, j) and F(R, j), j = 0..n, of gotoh.h:39-66 run on the first R rows of p1 with AlignConfig<true,false> where row R
+ * is NOT the last row (its horizontal moves cost go/ge).  Any alignment of all m rows passes row R in state H or F,
+ * so max_j max(H, F)(R, j) + (an upper bound for the remaining rows) bounds the final score from above. */
+static int32_t prof_score_f(const float* p1, size_t m, size_t row, const float* p2, size_t n, size_t col, const orc_score* sc) {
+  float acc = 0.0f; /* align.h:103-118 */
+  for (int k1 = 0; k1 < 5; ++k1)
+    for (int k2 = 0; k2 < 5; ++k2)
+      acc = acc + (p1[(size_t)k1 * m + row] * p2[(size_t)k2 * n + col]) * (float)(k1 == k2 ? sc->match : sc->mismatch);
+  return (int32_t)acc;
+}
+
+void orc_gotoh_row_state(const float* p1, size_t m, const float* p2, size_t n, size_t R, const orc_score* sc, int32_t* H_out,
+                         int32_t* F_out) {
+  int32_t* s = (int32_t*)malloc(sizeof(int32_t) * (n + 1));
+  int32_t* v = (int32_t*)malloc(sizeof(int32_t) * (n + 1));
+  const int32_t inf = ORC_INF;
+  for (size_t c = 0; c <= n; ++c) { s[c] = 0; v[c] = -inf; } /* row 0: free horizontal end gap */
+  for (size_t r = 1; r <= R; ++r) {
+    int32_t diag = s[0];
+    s[0] = sc->go + (int32_t)r * sc->ge;
+    v[0] = -inf; /* column 0 carries no vertical state of its own besides H */
+    int32_t e = -inf;
+    for (size_t c = 1; c <= n; ++c) {
+      const int32_t eo = s[c - 1] + sc->go + sc->ge, ee = e + sc->ge;
+      e = eo > ee ? eo : ee;
+      const int32_t fo = s[c] + sc->go + sc->ge, fe = v[c] + sc->ge;
+      const int32_t f = fo > fe ? fo : fe;
+      int32_t h = diag + prof_score_f(p1, m, r - 1, p2, n, c - 1, sc);
+      if (e > h) h = e;
+      if (f > h) h = f;
+      diag = s[c];
+      s[c] = h;
+      v[c] = f;
+    }
+  }
+  for (size_t c = 0; c <= n; ++c) { H_out[c] = s[c]; F_out[c] = v[c]; }
+  free(s);
+  free(v);
+}

@@ -84,3 +84,32 @@ def run_band(a1, a2, score, hfree, vfree, mode, K, B=32, narrow=True, revcomp=Fa
                         *[int(x) for x in score], int(hfree), int(vfree), C.byref(sc), ops, C.byref(ol), C.byref(err))
     assert rc == 0
     return sc.value, ops.raw[:ol.value], err.value
+
+
+def run_prefix(profiles, refs, score, K, revcomp=None):
+    """prefix-bound kernel body on one emulated wave: up to 8 pairs (profile float32 [6][m], reference bytes).
+    Returns the list of max_j max(H, F)(R, j), R = 8*K, and the error flags."""
+    npairs = len(profiles)
+    assert npairs <= 8
+    lut = np.full(256, 6, dtype=np.uint8)
+    for chars, code in ((b"Aa", 0), (b"Cc", 1), (b"Gg", 2), (b"Tt", 3), (b"Nn", 4), (b"-", 5)):
+        for ch in chars:
+            lut[ch] = code
+    a1 = np.concatenate([np.ascontiguousarray(p, dtype=np.float32).ravel() for p in profiles])
+    a1_off = np.zeros(npairs, np.uint64)
+    m = np.array([p.shape[1] for p in profiles], np.uint32)
+    if npairs > 1:
+        a1_off[1:] = np.cumsum(6 * m.astype(np.uint64))[:-1]
+    a2 = np.concatenate([lut[np.frombuffer(bytes(r), dtype=np.uint8)] for r in refs] + [np.zeros(1, np.uint8)])
+    n = np.array([len(r) for r in refs], np.uint32)
+    a2_off = np.zeros(npairs, np.uint64)
+    if npairs > 1:
+        a2_off[1:] = np.cumsum(n.astype(np.uint64))[:-1]
+    flags = np.array([1 if (revcomp and revcomp[i]) else 0 for i in range(npairs)], np.uint32)
+    out = np.zeros(npairs, np.int32)
+    err = C.c_int32(0)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = lib().emu_prefix(K, npairs, p(a1, C.c_float), p(a1_off, C.c_uint64), p(m, C.c_uint32), p(a2, C.c_uint8), p(a2_off, C.c_uint64),
+                          p(n, C.c_uint32), p(flags, C.c_uint32), *[int(x) for x in score], p(out, C.c_int32), C.byref(err))
+    assert rc == 0
+    return out.tolist(), err.value

@@ -103,7 +103,43 @@ void run_ckpt_pair(const DpArgs& a, const WalkArgs& wa) {
   }
 }
 
+template <int K>
+void run_prefix_wave(const DpArgs& a, uint32_t npairs) {
+  WaveShared sh;
+  sh.lds.assign(lds_bytes(MODE_QP, K) + 64, 0);
+  std::vector<std::thread> th;
+  for (uint32_t l = 0; l < 64; ++l)
+    th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_prefix_body<HostWave, K, kPrefixLanes>(w, a, 0, npairs); });
+  for (auto& t : th) t.join();
+}
+
 extern "C" {
+// prefix bound of up to 64 / kPrefixLanes pairs in one wave: pair i has profile a1 + a1_off[i] (m[i] columns, row stride
+// m[i]) and reference codes a2 + a2_off[i] (n[i] bytes, already encoded with base_code); flags[i] & 1 = reverse complement
+int emu_prefix(int K, uint32_t npairs, const float* a1, const uint64_t* a1_off, const uint32_t* m, const uint8_t* a2,
+               const uint64_t* a2_off, const uint32_t* n, const uint32_t* flags, int32_t match, int32_t mismatch, int32_t go, int32_t ge,
+               int32_t* out, int32_t* err_out) {
+  std::vector<PairDesc> d(npairs);
+  for (uint32_t i = 0; i < npairs; ++i) {
+    d[i] = PairDesc{};
+    d[i].a1_off = a1_off[i]; d[i].a2_off = a2_off[i]; d[i].m = m[i]; d[i].n = n[i]; d[i].a1_stride = m[i]; d[i].a2_stride = n[i];
+    d[i].flags = flags[i]; d[i].out = i;
+  }
+  int32_t err = 0;
+  DpArgs a{};
+  a.pairs = d.data(); a.a1 = a1; a.a2 = a2; a.scores = out; a.err = &err;
+  a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = 1; a.vfree = 0;
+  switch (K) {
+    case 4: run_prefix_wave<4>(a, npairs); break;
+    case 8: run_prefix_wave<8>(a, npairs); break;
+    case 15: run_prefix_wave<15>(a, npairs); break;
+    case 16: run_prefix_wave<16>(a, npairs); break;
+    default: return -1;
+  }
+  if (err_out) *err_out = err;
+  return 0;
+}
+
 // checkpointed score pass + band traceback of one pair (single pass: m <= 64*K)
 int emu_band(int mode, int K, int narrow, uint32_t B, const void* a1, uint32_t m, uint32_t a1_stride, const void* a2, uint32_t n,
              uint32_t flags, int32_t match, int32_t mismatch, int32_t go, int32_t ge, int32_t hfree, int32_t vfree,

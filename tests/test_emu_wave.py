@@ -210,3 +210,38 @@ def test_band_traceback(K):
         want = orc.gotoh_prof(p1, orc.revcomp_profile(p2), 1, 0, SC)
         got = emu.run_band(p1, ref, SC, 1, 0, emu.MODE_QP, K, B=32, narrow=True, revcomp=True)
         assert (got[0], got[1]) == want
+
+
+@pytest.mark.parametrize("K", [4, 15])
+def test_prefix_bound_kernel(K):
+    """gotoh_prefix_body: eight pairs per wave, rows 1..8K; result == max over the columns of H and F of row 8K as
+    computed by the row-state oracle (forward and reverse-complemented references, ragged lengths, partial waves)"""
+    rng = np.random.default_rng(4000 + K)
+    R = 8 * K
+    for npairs in (8, 3):
+        profs, refs, rc = [], [], []
+        for i in range(npairs):
+            m = R + 1 + int(rng.integers(0, 200))
+            n = int(rng.integers(5, 400))
+            profs.append(rand_profile(rng, m))
+            refs.append(rand_seq(rng, n, b"ACGTACGTACGTN"))
+            rc.append(bool(i % 2))
+        # one pair whose trace really lies on the reference: the bound must reach high values there
+        refs[0] = rand_seq(rng, 300, b"ACGT")
+        idx = {65: 0, 67: 1, 71: 2, 84: 3}
+        p = np.zeros((6, profs[0].shape[1]), np.float32)
+        src = (refs[0] * 3)[20:20 + p.shape[1]]
+        for j, ch in enumerate(src):
+            col = rng.random(4).astype(np.float32) * np.float32(0.1)
+            col[idx[ch]] += np.float32(1)
+            p[:4, j] = col / col.sum()
+        profs[0], rc[0] = p, False
+        got, err = emu.run_prefix(profs, refs, SC, K, rc)
+        assert err == 0
+        for i in range(npairs):
+            p2 = orc.create_profile_str(refs[i])
+            if rc[i]:
+                p2 = orc.revcomp_profile(p2)
+            H, F = orc.gotoh_row_state(profs[i], p2, R, SC)
+            assert got[i] == int(max(H.max(), F.max())), (K, npairs, i)
+        assert got[0] > 0

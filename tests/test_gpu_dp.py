@@ -236,3 +236,35 @@ def test_align_traces_against_the_largest_fasta_window(ctx):
             assert int(got[k][i]) == int(want[k]), (i, k)
         assert got["btr"][i] == want["btr"]
         assert int(got["forward"][i]) == 1 - int(rev[i])
+
+
+def test_strand_by_certificate(ctx):
+    """default mode of tracyhip_align_traces: the losing strand may be represented by a certified upper bound of its
+    score (prefix pass + row maxima); strand, slice, preliminary and final alignment are those of the reference, the
+    winner's score is exact and the loser's entry bounds its true score from above without reaching the winner's"""
+    import sage_oracle as so
+    from tracy_amd import hostlib
+    refs, profs, rev = hostlib.synth_align(8100, 24, 4000, 700, 2)
+    profs = list(profs)
+    # two hard cases: a trace unrelated to its window (bounds close together) and a noisy trace
+    rng = np.random.default_rng(3)
+    profs[5] = rand_profile(rng, 700)
+    noisy = profs[6].copy()
+    noisy[:4] = 0.6 * noisy[:4] + 0.4 * rand_profile(rng, 700, sharp=False)[:4]
+    profs[6] = np.ascontiguousarray(noisy / noisy[:4].sum(axis=0, keepdims=True))
+    refl = [r.tobytes() for r in refs]
+    fast = ctx.align_traces(profs, refl, SC, 50, 50, exact_scores=False)
+    exact = ctx.align_traces(profs, refl, SC, 50, 50, exact_scores=True)
+    nb = 0
+    for i in range(24):
+        want = so.align_trace(profs[i], refl[i], SC, 50, 50)
+        for k in ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
+            assert int(fast[k][i]) == int(want[k]) == int(exact[k][i]), (i, k)
+        assert fast["btr"][i] == want["btr"] == exact["btr"][i]
+        assert int(exact["score_fwd"][i]) == want["score_fwd"] and int(exact["score_rev"][i]) == want["score_rev"]
+        w, l = ("score_fwd", "score_rev") if want["forward"] else ("score_rev", "score_fwd")
+        assert int(fast[w][i]) == want[w]
+        assert int(fast[l][i]) >= want[l]
+        assert (int(fast[l][i]) < int(fast[w][i])) if want["forward"] else (int(fast[l][i]) <= int(fast[w][i]))
+        nb += int(fast[l][i]) != want[l]
+    assert nb >= 12  # most losers were decided by their bound

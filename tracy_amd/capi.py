@@ -38,7 +38,8 @@ class Pairs(C.Structure):
 
 class AlignJob(C.Structure):
     _fields_ = [("ntraces", C.c_uint32), ("profiles", SeqSet), ("refs", SeqSet), ("ref_index", C.POINTER(C.c_uint32)),
-                ("trim_left", C.c_uint32), ("trim_right", C.c_uint32), ("oriented", C.POINTER(C.c_uint8))]
+                ("trim_left", C.c_uint32), ("trim_right", C.c_uint32), ("oriented", C.POINTER(C.c_uint8)),
+                ("exact_orientation_scores", C.c_uint32)]
 
 
 class AlignResult(C.Structure):
@@ -210,7 +211,7 @@ class Context:
         return scores[:n], btr, rws
 
 
-def _align_traces(self, profiles, refs, params, trim_left=50, trim_right=50, ref_index=None, oriented=None):
+def _align_traces(self, profiles, refs, params, trim_left=50, trim_right=50, ref_index=None, oriented=None, exact_scores=True):
     """tracyhip_align_traces with host buffers.  profiles: list of float32 [6][mf]; refs: list of bytes.
     oriented: None, or rs.forward per trace when the references are already oriented (indexed-genome path).
     Returns a dict of numpy arrays + the list of final traceback strings (push order)."""
@@ -231,6 +232,7 @@ def _align_traces(self, profiles, refs, params, trim_left=50, trim_right=50, ref
         rlen = pr.length[:nt]
     job.trim_left = trim_left
     job.trim_right = trim_right
+    job.exact_orientation_scores = 1 if exact_scores else 0  # False: the losing strand may carry a certified upper bound
     if oriented is not None:
         oriented = np.ascontiguousarray(oriented, dtype=np.uint8)
         job.oriented = oriented.ctypes.data_as(C.POINTER(C.c_uint8))

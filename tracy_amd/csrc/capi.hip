@@ -281,7 +281,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
         uint64_t cells = 0, bytes = 0;
         for (uint32_t q = j; q < e; ++q) {
           const PairDesc& d = hd[q];
-          const uint64_t mn = (uint64_t)d.m * d.n;
+          const uint64_t mn = (uint64_t)(stage == DP_PREFIX ? std::min<uint32_t>(d.m, (uint32_t)kPrefixLanes * K) : d.m) * d.n;
           cells += mn;
           bytes += (trace ? mn / 2 : 0) + (pb.a1_profile ? 24ull * d.m : d.m) + (pb.a2_profile ? 24ull * d.n : d.n) + 4;
         }
@@ -294,7 +294,9 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
         for (uint32_t q = j; q < e; ++q) maxm = std::max(maxm, hd[q].m);
         narrow = narrow_ok(prm, maxm, K);
       }
-      if (stage == DP_CKPT) {
+      if (stage == DP_PREFIX) {
+        HIP_TRY(launch_gotoh_prefix(K, a, e - j, st));
+      } else if (stage == DP_CKPT) {
         // one representation for the whole batch: the caller checks narrow_ok for the largest problem
         narrow = ck->narrow;
         HIP_TRY(launch_gotoh_ckpt(pb.mode, K, narrow, a, e - j, st));

@@ -84,8 +84,9 @@ int stage_in(tracyhip_ctx* ctx, DevBuf& buf, const void* src, uint64_t bytes, in
 int check_params(const tracyhip_params* prm, uint64_t max_mn);
 // stage: DP_PLAIN = score-only or full-matrix traceback; DP_CKPT = score-only pass that also writes wavefront
 // checkpoints + last-row values (PairDesc::ckpt_off / lastrow_off set by the caller); DP_BAND = band traceback
-// from those checkpoints (trace must be true).
-enum { DP_PLAIN = 0, DP_CKPT = 1, DP_BAND = 2 };
+// from those checkpoints (trace must be true); DP_PREFIX = prefix bound of the semiglobal score (rows 1 .. kPrefixLanes*K of
+// profile x code pairs, 16-bit domain): d_scores receives max_j max(H, F) of that row.
+enum { DP_PLAIN = 0, DP_CKPT = 1, DP_BAND = 2, DP_PREFIX = 3 };
 struct DpCkpt {
   int32_t* d_ckpt = nullptr;
   int32_t* d_lastrow = nullptr;

@@ -419,6 +419,125 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Prefix bound of the semiglobal score (AlignConfig<true,false>, 16-bit formulation, profile x reference codes).
+// GL lanes per pair, 64/GL pairs per wave: lane group g sweeps rows 1..R (R = GL*K) of its pair over all columns
+// and reports  max_j max(H(R, j), F(R, j)).  Every alignment of the whole trace passes row R in state H or F, and
+// each of the remaining rows adds at most max(0, its best substitution score) (gaps cost <= 0 in this domain), so
+// that maximum + the row-maxima of rows R+1..m bounds gotohScore from above.  The align pipeline uses it to decide
+// the strand without running the second orientation over all m rows (pipeline.hip).
+// Domain (checked by the caller): hfree, !vfree, ge < 0, go <= 0, m > R, narrow_ok (int16 range).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPrefixLanes = 8;  // lanes per pair of the prefix-bound kernel: rows 1 .. 8*K, eight pairs per wave
+
+template <class W, int K, int GL>
+TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_t npairs) {
+  static_assert(64 % GL == 0, "whole groups per wave");
+  const uint32_t L = w.lane();
+  const uint32_t Lg = L % GL;
+  const uint32_t pair_idx = group_base + L / GL;
+  const bool valid = pair_idx < npairs;
+  PairDesc d{};
+  if (valid) d = a.pairs[pair_idx];
+  const uint32_t m = d.m, n = valid ? d.n : 0u;
+  const int32_t go = a.go, ge = a.ge, goe = go + ge;
+  const float fmatch = (float)a.match, fmis = (float)a.mismatch;
+  const float* a1p = static_cast<const float*>(a.a1) + d.a1_off;
+  const uint8_t* a2c = static_cast<const uint8_t*>(a.a2) + d.a2_off;
+  int16_t* qp_tab = reinterpret_cast<int16_t*>(w.lds());
+  constexpr uint32_t R = (uint32_t)GL * K;
+
+  // wave-uniform sweep length: the longest reference of the groups in this wave
+  uint32_t nmax = 0;
+  for (uint32_t g = 0; g < 64u / GL; ++g) {
+    const uint32_t ng = w.bcast(n, g * GL);
+    nmax = ng > nmax ? ng : nmax;
+  }
+  const uint32_t t_end = nmax + GL - 1;
+
+  // per-lane state at column 0 (gotoh.h:117-123): H(r, 0) = go + r*ge, kept as Hg = H + (go+ge)
+  ScoreLane<K> ss;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const uint32_t r = Lg * K + i + 1;
+    ss.Hl[i] = edge_value(false, go, ge, (int32_t)r) + goe;
+    ss.El[i] = kNegInf16;
+    ss.hopen[i] = goe;
+    ss.hext[i] = ge;
+  }
+  const uint32_t row_above = Lg * K;
+  int32_t prev_up_h = (row_above == 0 ? 0 : edge_value(false, go, ge, (int32_t)row_above)) + goe;
+  int32_t bot_h = 0, bot_f = 0;
+
+  // query-profile strips of this lane's rows (values - (go+ge), as in the 16-bit score kernel)
+  {
+    bool overflow = false;
+#pragma unroll 1
+    for (int i = 0; i < K; ++i) {
+      const uint32_t r = Lg * K + i + 1;
+      float pr[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) pr[k] = (valid && r - 1 < m) ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+#pragma unroll
+      for (uint32_t b = 0; b < 5; ++b) {
+        const int32_t qs = ((valid && r - 1 < m) ? onehot_score(pr, b, fmatch, fmis) : 0) - goe;
+        overflow |= (qs > 32767) || (qs < -32768);
+        qp_tab[b * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)qs;
+      }
+    }
+    if (L < (uint32_t)qp_stride(K)) qp_tab[5 * (64 * qp_stride(K)) + L] = (int16_t)(-goe);
+    if (overflow) flag_error(a.err, 1);
+    w.sync();
+  }
+
+  auto col_at = [&](int32_t cc) -> uint32_t {  // clamp: prefetches of idle lanes stay in bounds
+    const int32_t x = cc < 1 ? 1 : (cc > (int32_t)n ? (int32_t)n : cc);
+    return a2_index(d, (uint32_t)x);
+  };
+  const bool rcflag = (d.flags & PAIR_A2_REVCOMP) != 0;
+  auto code_at = [&](int32_t cc) -> uint32_t {
+    if (n == 0) return 5u;
+    const uint32_t raw = a2c[col_at(cc)];
+    return rcflag ? complement_code(raw) : raw;
+  };
+  // running maxima of H (as Hg) and F of row R: the last slot of the group's last lane
+  int32_t mx_hg = edge_value(false, go, ge, (int32_t)R) + goe, mx_f = kNegInf16;
+  auto do_step = [&](uint32_t t, const SubPacked<K>& sub) {
+    const int32_t c = (int32_t)t - (int32_t)Lg;
+    int32_t up_h = w.shift_up(bot_h);
+    int32_t up_f = w.shift_up(bot_f);
+    const bool active = (c >= 1) && (c <= (int32_t)n);
+    if (active) {
+      if (Lg == 0) {  // row 0 (gotoh.h:112-116): free horizontal end gap
+        up_h = goe;
+        up_f = kNegInf16;
+      }
+      int32_t nb_h, nb_f;
+      score_step16g<K>(ss, up_h, up_f, prev_up_h, ge, goe, 0, sub, nb_h, nb_f);
+      prev_up_h = up_h;
+      bot_h = nb_h;
+      bot_f = nb_f;
+      if (Lg == GL - 1) {
+        mx_hg = max16(mx_hg, nb_h);
+        mx_f = max16(mx_f, nb_f);
+      }
+    }
+  };
+  SubPacked<K> qa, qb;
+  qp_fetch<K>(qp_tab, code_at(1 - (int32_t)Lg), L, qa);
+  for (uint32_t t = 1; t <= t_end; t += 2) {
+    qp_fetch<K>(qp_tab, code_at((int32_t)t - (int32_t)Lg + 1), L, qb);
+    do_step(t, qa);
+    if (t + 1 > t_end) break;
+    qp_fetch<K>(qp_tab, code_at((int32_t)t - (int32_t)Lg + 2), L, qa);
+    do_step(t + 1, qb);
+  }
+  if (valid && Lg == GL - 1 && a.scores) {
+    const int32_t h = sext16(mx_hg) - goe, f = sext16(mx_f);
+    a.scores[d.out] = h > f ? h : f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Traceback walker (gotoh.h:143-167): one lane per pair.  Emits the reference's `btr` in push order.
 // ------------------------------------------------------------------------------------------------
 struct WalkArgs {

@@ -47,6 +47,12 @@ __global__ __launch_bounds__(64) void gotoh_ckpt_kernel(DpArgs a) {
   DeviceWave w;
   gotoh_body<DeviceWave, K, MODE, false, NARROW, true>(w, a, blockIdx.x);
 }
+// prefix bound of the semiglobal score: GL lanes per pair, 64/GL pairs per workgroup
+template <int K, int GL>
+__global__ __launch_bounds__(64) void gotoh_prefix_kernel(DpArgs a, uint32_t npairs) {
+  DeviceWave w;
+  gotoh_prefix_body<DeviceWave, K, GL>(w, a, blockIdx.x * (64u / GL), npairs);
+}
 template <int K, int MODE>
 __global__ __launch_bounds__(64) void gotoh_band_kernel(DpArgs a, WalkArgs wa) {
   DeviceWave w;
@@ -240,6 +246,19 @@ hipError_t launch_band_trace(int mode, int K, const DpArgs& a, const WalkArgs& w
   return hipErrorInvalidValue;
 }
 
+hipError_t launch_gotoh_prefix(int K, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  if (npairs == 0) return hipSuccess;
+  constexpr int GL = kPrefixLanes;
+  const dim3 grid((npairs + 64 / GL - 1) / (64 / GL));
+#define TRACY_PREFIX_CASE(KK) \
+  case KK: hipLaunchKernelGGL((gotoh_prefix_kernel<KK, GL>), grid, dim3(64), lds_bytes(MODE_QP, KK), s, a, npairs); break;
+  switch (K) {
+    TRACY_PREFIX_CASE(4) TRACY_PREFIX_CASE(8) TRACY_PREFIX_CASE(12) TRACY_PREFIX_CASE(15) TRACY_PREFIX_CASE(16)
+    default: return hipErrorInvalidValue;
+  }
+#undef TRACY_PREFIX_CASE
+  return hipGetLastError();
+}
 hipError_t launch_gotoh_walk(const WalkArgs& a, hipStream_t s) {
   if (a.npairs == 0) return hipSuccess;
   hipLaunchKernelGGL(gotoh_walk_kernel, dim3(a.npairs), dim3(64), 0, s, a);

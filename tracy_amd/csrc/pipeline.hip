@@ -108,6 +108,26 @@ __global__ void validate_ref_kernel(const uint8_t* __restrict__ in, uint64_t n, 
   }
 }
 
+// upper bound for what rows [first, m) of a trimmed profile view can still add to a semiglobal score: every row
+// adds at most max(0, its best one-hot substitution score) (gaps cost <= 0 when go <= 0 and ge < 0)
+struct RowMaxDesc { uint64_t off; uint32_t stride, m, first; };
+__global__ __launch_bounds__(64) void rowmax_rest_kernel(const RowMaxDesc* desc, const float* prof, float fmatch, float fmis, int32_t* out) {
+  const RowMaxDesc d = desc[blockIdx.x];
+  int32_t sum = 0;
+  for (uint32_t r = d.first + threadIdx.x; r < d.m; r += 64) {
+    float pr[5];
+    for (int k = 0; k < 5; ++k) pr[k] = prof[d.off + (uint64_t)k * d.stride + r];
+    int32_t best = 0;
+    for (uint32_t b = 0; b < 5; ++b) {
+      const int32_t q = onehot_score(pr, b, fmatch, fmis);
+      best = q > best ? q : best;
+    }
+    sum += best;
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+  if (threadIdx.x == 0) out[blockIdx.x] = sum;
+}
+
 __global__ void encode_codes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (uint8_t)base_code(in[i]);
@@ -231,42 +251,111 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
       }
     }
   }
-  {
+  auto stage1_desc = [&](uint32_t t, int orient) {  // orient 0 = forward, 1 = reverse complement
+    PairDesc d{};
+    d.a1_off = sp.offset[t] + tl[t];
+    d.a1_stride = mf[t];
+    d.m = mt[t];
+    d.a2_off = sr.offset[ridx[t]];
+    d.n = rn[t];
+    d.a2_stride = rn[t];
+    d.out = (uint32_t)orient * nt + t;
+    d.flags = orient ? PAIR_A2_REVCOMP : 0;
+    d.ckpt_off = ck_off[(size_t)orient * nt + t];
+    d.lastrow_off = lr_off[(size_t)orient * nt + t];
+    return d;
+  };
+  auto run_stage1 = [&](std::vector<std::pair<uint32_t, int>> const& what, int stage) -> int {
     DpProblem pb;
     pb.mode = MODE_QP;
     pb.a1_profile = true;
     pb.d_a1 = d_prof;
     pb.d_a2 = ctx->d_codes.p;
-    pb.desc.resize((size_t)norient * nt);
-    pb.k.resize((size_t)norient * nt);
-    for (uint32_t t = 0; t < nt; ++t) {
-      PairDesc d{};
-      d.a1_off = sp.offset[t] + tl[t];
-      d.a1_stride = mf[t];
-      d.m = mt[t];
-      d.a2_off = sr.offset[ridx[t]];
-      d.n = rn[t];
-      d.a2_stride = rn[t];
-      d.out = t;
-      d.ckpt_off = ck_off[t];
-      d.lastrow_off = lr_off[t];
-      pb.desc[t] = d;
-      pb.k[t] = choose_k(d.m, MODE_QP);
-      if (given) continue;
-      d.out = nt + t;
-      d.flags = PAIR_A2_REVCOMP;
-      d.ckpt_off = ck_off[(size_t)nt + t];
-      d.lastrow_off = lr_off[(size_t)nt + t];
-      pb.desc[nt + t] = d;
-      pb.k[t] = pb.k[nt + t] = choose_k(d.m, MODE_QP);
+    pb.desc.reserve(what.size());
+    pb.k.reserve(what.size());
+    for (auto const& w : what) {
+      pb.desc.push_back(stage1_desc(w.first, w.second));
+      pb.k.push_back(choose_k(mt[w.first], MODE_QP));
     }
-    if ((rc = run_dp(ctx, pb, &p, false, false, d_sc2, nullptr, nullptr, nullptr, use_band ? DP_CKPT : DP_PLAIN, use_band ? &ck : nullptr))) return rc;
-  }
+    return run_dp(ctx, pb, &p, false, false, d_sc2, nullptr, nullptr, nullptr, stage, stage == DP_CKPT ? &ck : nullptr);
+  };
   std::vector<int32_t> h_sc2(2 * (size_t)nt, 0);
-  HIP_TRY(hipMemcpyAsync(h_sc2.data(), d_sc2, sizeof(int32_t) * (size_t)norient * nt, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
   std::vector<uint8_t> h_fwd(nt);   // rs.forward: decides how rs.pos moves in trimReferenceSlice
   std::vector<uint8_t> h_rc(nt);    // the reference window has to be read as its reverse complement
+  auto fetch_scores = [&]() -> int {
+    HIP_TRY(hipMemcpyAsync(h_sc2.data(), d_sc2, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return TRACYHIP_OK;
+  };
+  // Strand by certificate: a cheap prefix pass (rows 1 .. 8K of both orientations, eight pairs per wave) bounds each
+  // orientation's score from above; the orientation with the larger bound is scored in full, and if the other one's bound
+  // stays below that score the strand is decided without ever sweeping the loser over all rows (its score array then
+  // holds the bound).  Traces whose bounds are close, or whose certificate fails, get both full passes: the decision is
+  // always the reference's `gsFwd > gsRev`.
+  bool use_prefix = !given && use_band && ck.narrow && !job->exact_orientation_scores && getenv("TRACYHIP_NO_PREFIX") == nullptr;
+  for (uint32_t t = 0; t < nt && use_prefix; ++t)
+    if (mt[t] <= (uint32_t)kPrefixLanes * choose_k(mt[t], MODE_QP)) use_prefix = false;
+  if (use_prefix) {
+    std::vector<std::pair<uint32_t, int>> all2;
+    for (int o = 0; o < 2; ++o)
+      for (uint32_t t = 0; t < nt; ++t) all2.emplace_back(t, o);
+    if ((rc = run_stage1(all2, DP_PREFIX))) return rc;
+    std::vector<RowMaxDesc> hrm(nt);
+    for (uint32_t t = 0; t < nt; ++t)
+      hrm[t] = RowMaxDesc{sp.offset[t] + tl[t], mf[t], mt[t], (uint32_t)kPrefixLanes * choose_k(mt[t], MODE_QP)};
+    HIP_TRY(ctx->d_tmp[7].ensure(sizeof(RowMaxDesc) * (size_t)nt + sizeof(int32_t) * (size_t)nt));
+    RowMaxDesc* d_rm = static_cast<RowMaxDesc*>(ctx->d_tmp[7].p);
+    int32_t* d_ub = reinterpret_cast<int32_t*>(d_rm + nt);
+    HIP_TRY(hipMemcpyAsync(d_rm, hrm.data(), sizeof(RowMaxDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, st, d_rm, static_cast<const float*>(d_prof), (float)p.match, (float)p.mismatch, d_ub);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> h_ub(nt);
+    HIP_TRY(hipMemcpyAsync(h_ub.data(), d_ub, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+    if ((rc = fetch_scores())) return rc;
+    std::vector<int64_t> bound(2 * (size_t)nt);
+    for (uint32_t t = 0; t < nt; ++t)
+      for (int o = 0; o < 2; ++o) bound[(size_t)o * nt + t] = (int64_t)h_sc2[(size_t)o * nt + t] + h_ub[t];
+    // full passes: the likely winner of every trace; both orientations where the bounds are within 10 % of each other
+    std::vector<std::pair<uint32_t, int>> full;
+    std::vector<int8_t> guess(nt), both(nt, 0);
+    for (uint32_t t = 0; t < nt; ++t) {
+      const int64_t bf = bound[t], br = bound[nt + t];
+      guess[t] = bf >= br ? 0 : 1;
+      const int64_t bw = guess[t] ? br : bf, bl = guess[t] ? bf : br;
+      both[t] = (bw <= 0 || bl * 10 > bw * 9) ? 1 : 0;
+      full.emplace_back(t, (int)guess[t]);
+      if (both[t]) full.emplace_back(t, 1 - guess[t]);
+    }
+    if ((rc = run_stage1(full, DP_CKPT))) return rc;
+    std::vector<int32_t> pref = h_sc2;
+    if ((rc = fetch_scores())) return rc;
+    std::vector<std::pair<uint32_t, int>> retry;
+    for (uint32_t t = 0; t < nt; ++t) {
+      if (both[t]) continue;
+      const size_t w = (size_t)guess[t] * nt + t, l = (size_t)(1 - guess[t]) * nt + t;
+      // guess forward: forward iff gsFwd > gsRev, certified by bound(rev) < gsFwd; guess reverse: certified by bound(fwd) <= gsRev
+      const bool certified = guess[t] == 0 ? bound[l] < (int64_t)h_sc2[w] : bound[l] <= (int64_t)h_sc2[w];
+      if (certified) h_sc2[l] = (int32_t)std::min<int64_t>(bound[l], 0x7fffffff);
+      else retry.emplace_back(t, 1 - guess[t]);
+    }
+    if (!retry.empty()) {
+      std::vector<int32_t> keep = h_sc2;
+      // d_sc2 is overwritten only at the retried entries; merge them into the host copy
+      if ((rc = run_stage1(retry, DP_CKPT))) return rc;
+      std::vector<int32_t> got(2 * (size_t)nt);
+      HIP_TRY(hipMemcpyAsync(got.data(), d_sc2, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      h_sc2 = keep;
+      for (auto const& r : retry) h_sc2[(size_t)r.second * nt + r.first] = got[(size_t)r.second * nt + r.first];
+    }
+    (void)pref;
+  } else {
+    std::vector<std::pair<uint32_t, int>> all;
+    for (int o = 0; o < norient; ++o)
+      for (uint32_t t = 0; t < nt; ++t) all.emplace_back(t, o);
+    if ((rc = run_stage1(all, use_band ? DP_CKPT : DP_PLAIN))) return rc;
+    if ((rc = fetch_scores())) return rc;
+  }
   for (uint32_t t = 0; t < nt; ++t) {
     if (given) { h_fwd[t] = job->oriented[t] ? 1 : 0; h_rc[t] = 0; }
     else { h_fwd[t] = h_sc2[t] > h_sc2[nt + t] ? 1 : 0; h_rc[t] = !h_fwd[t]; }  // forward iff gsFwd > gsRev (sage.h:247)

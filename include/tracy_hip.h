@@ -282,6 +282,7 @@ int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decompose_job* j
 #define TRACYHIP_TIMER_TRACE 1 /* traceback DP kernels  */
 #define TRACYHIP_TIMER_WALK 2  /* traceback walkers     */
 #define TRACYHIP_TIMER_BAND 3  /* band tracebacks (checkpointed traceback of the align / decompose pipelines) */
+#define TRACYHIP_TIMER_PREFIX 4 /* prefix-bound kernels (strand by certificate); cells = rows actually swept x columns */
 typedef struct {
   double ms;         /* summed launch durations */
   uint64_t launches;

@@ -68,6 +68,23 @@ def per_kernel(pass_dir, scale):
     return out
 
 
+# the default command (both legs): per (kernel, grid) launch statistics from the kernel trace
+f = one("bench_default_stats/*/*kernel_trace.csv")
+if f:
+    grp = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        if "tracyhip" not in r["Kernel_Name"]:
+            continue
+        grp.setdefault((r["Kernel_Name"], r.get("Grid_Size", r.get("Grid_Size_X", ""))), []).append(
+            (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    with open(os.path.join(DST, "%s_bench_default_kernel_by_grid.csv" % tag), "w") as o:
+        o.write("kernel,grid_size,launches,avg_ms,min_ms,max_ms\n")
+        for (k, g), v in grp.items():
+            o.write('"%s",%s,%d,%.4f,%.4f,%.4f\n' % (k, g, len(v), sum(v) / len(v), min(v), max(v)))
+    p = os.path.join(SRC, "bench_default_line.json")
+    if os.path.exists(p) and last_json_line(p):
+        json.dump(last_json_line(p), open(os.path.join(DST, "%s_bench_default_line_under_rocprof.json" % tag), "w"), indent=1)
+
 hbm = []
 for c in ("WRITE_SIZE", "FETCH_SIZE"):
     for r in per_kernel("pmc_" + c, 1024.0):  # the counters report KB

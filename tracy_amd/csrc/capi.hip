@@ -286,7 +286,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
           bytes += (trace ? mn / 2 : 0) + (pb.a1_profile ? 24ull * d.m : d.m) + (pb.a2_profile ? 24ull * d.n : d.n) + 4;
         }
         if (stage == DP_BAND) bytes = 0;  // band traceback recomputes a few bands into an L2-resident buffer: no matrix-sized traffic
-        if ((trc = timing_begin(ctx, stage == DP_BAND ? TRACYHIP_TIMER_BAND : trace ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
+        if ((trc = timing_begin(ctx, stage == DP_BAND ? TRACYHIP_TIMER_BAND : stage == DP_PREFIX ? TRACYHIP_TIMER_PREFIX : trace ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
       }
       bool narrow = false;
       if (!needle && !trace && (pb.mode == MODE_QP || pb.mode == MODE_CHAR) && !ctx->no_narrow) {
@@ -467,7 +467,7 @@ int tracyhip_timing_reset(tracyhip_ctx* c) {
   return TRACYHIP_OK;
 }
 int tracyhip_timing_get(tracyhip_ctx* c, int which, tracyhip_kernel_timing* out) {
-  if (!c || !out || which < 0 || which > 3) return set_error(TRACYHIP_ERR_ARG, "bad timing query");
+  if (!c || !out || which < 0 || which > 4) return set_error(TRACYHIP_ERR_ARG, "bad timing query");
   *out = c->acc[which];
   return TRACYHIP_OK;
 }

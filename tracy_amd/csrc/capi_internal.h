@@ -60,7 +60,7 @@ struct tracyhip_ctx {
   bool no_narrow = false;  // TRACYHIP_NO_NARROW=1: force the int32 score kernel (A/B measurements)
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
-  tracyhip_kernel_timing acc[4] = {};
+  tracyhip_kernel_timing acc[5] = {};
   void release_all() {
     tracyhip::DevBuf* all[] = {&d_desc, &d_bits, &d_scratch, &d_in1, &d_in2, &d_codes, &d_scores, &d_ops,
                                &d_ops_off, &d_ops_len, &d_err, &d_rows0, &d_rows1};

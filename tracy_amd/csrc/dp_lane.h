@@ -248,24 +248,51 @@ TR_HD void score_step16(ScoreLane<K>& s, int32_t up_h, int32_t up_f, int32_t dia
 // last slot only: rows are anchored at the bottom, so row m is always slot K-1).  The diagonal term
 // H + sub becomes Hg + (sub - (go+ge)): the constant is folded into the query-profile table.
 // 8 VALU ops per cell: E: add, max; F: add, max; diagonal: add; H: max, max; Hg: add.
+// The state registers are updated IN PLACE by two asm statements per cell (tied "+v" operands).  The steps of the
+// sweep sit under `if (active)`: with out-of-place results the join needs the new value back in the old register,
+// and whenever the scheduler lets two generations of a slot overlap that costs a v_mov per cell and step.
+//   cell_left16:  E = max(Hg + delta, E + hext);  Hg <- Hg(row above, previous column) + sub     (3 ops, 4 on row m)
+//   cell_down16:  f = max(up_hg, up_f + vext);  Hg <- max(max(Hg, E), f) + goe                    (5 ops)
+TR_HD void cell_left16(int32_t& hl, int32_t& el, int32_t hext, int32_t diag_hg, int32_t sub) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_add_u16 %1, %1, %2\n\tv_max_i16 %1, %0, %1\n\tv_add_u16 %0, %3, %4" : "+v"(hl), "+v"(el) : "v"(hext), "v"(diag_hg), "v"(sub));
+#else
+  el = max16(hl, add16(el, hext));
+  hl = add16(diag_hg, sub);
+#endif
+}
+TR_HD void cell_left16_last(int32_t& hl, int32_t& el, int32_t hext, int32_t diag_hg, int32_t sub, int32_t delta) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_add_u16 %0, %0, %5\n\tv_add_u16 %1, %1, %2\n\tv_max_i16 %1, %0, %1\n\tv_add_u16 %0, %3, %4"
+      : "+v"(hl), "+v"(el) : "v"(hext), "v"(diag_hg), "v"(sub), "v"(delta));
+#else
+  el = max16(add16(hl, delta), add16(el, hext));
+  hl = add16(diag_hg, sub);
+#endif
+}
+TR_HD void cell_down16(int32_t& hl, int32_t el, int32_t up_hg, int32_t& up_f, int32_t vext, int32_t goe) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("v_max_i16 %0, %0, %2\n\tv_add_u16 %1, %1, %4\n\tv_max_i16 %1, %3, %1\n\tv_max_i16 %0, %0, %1\n\tv_add_u16 %0, %0, %5"
+      : "+v"(hl), "+v"(up_f) : "v"(el), "v"(up_hg), "v"(vext), "v"(goe));
+#else
+  up_f = max16(up_hg, add16(up_f, vext));
+  hl = add16(max16(max16(hl, el), up_f), goe);
+#endif
+}
+
 template <int K, class Sub>
 TR_HD void score_step16g(ScoreLane<K>& s, int32_t up_hg, int32_t up_f, int32_t diag_hg, int32_t vext, int32_t goe,
                          int32_t delta_last, const Sub& subg, int32_t& bot_hg, int32_t& bot_f) {
 #pragma unroll
   for (int i = K - 1; i >= 0; --i) {
-    const int32_t hl = (i == K - 1) ? add16(s.Hl[i], delta_last) : s.Hl[i];
-    const int32_t e = maxadd16(hl, s.El[i], s.hext[i]);
-    const int32_t d = add16(i == 0 ? diag_hg : s.Hl[i - 1], subg.lo16(i));
-    s.Hl[i] = d;
-    s.El[i] = e;
+    const int32_t dg = i == 0 ? diag_hg : s.Hl[i - 1];
+    if (i == K - 1) cell_left16_last(s.Hl[i], s.El[i], s.hext[i], dg, subg.lo16(i), delta_last);
+    else cell_left16(s.Hl[i], s.El[i], s.hext[i], dg, subg.lo16(i));
   }
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    int32_t f, hg;
-    chain16(up_hg, up_f, vext, max16(s.Hl[i], s.El[i]), goe, f, hg);
-    s.Hl[i] = hg;
-    up_hg = hg;
-    up_f = f;
+    cell_down16(s.Hl[i], s.El[i], up_hg, up_f, vext, goe);
+    up_hg = s.Hl[i];
   }
   bot_hg = up_hg;
   bot_f = up_f;

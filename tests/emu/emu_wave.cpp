@@ -113,6 +113,14 @@ void run_prefix_wave(const DpArgs& a, uint32_t npairs) {
   for (auto& t : th) t.join();
 }
 
+// MODE_QP kernels read the code buffer without clamping (idle lanes, look-ahead): the library pads it (kCodePad in
+// capi_internal.h); the emulator does the same, with a byte that is not a code so that a use of it would show
+static std::vector<uint8_t> padded_codes(const void* a2, size_t bytes) {
+  std::vector<uint8_t> v(bytes + 256, 0xEE);
+  if (bytes) std::memcpy(v.data() + 128, a2, bytes);
+  return v;
+}
+
 extern "C" {
 // prefix bound of up to 64 / kPrefixLanes pairs in one wave: pair i has profile a1 + a1_off[i] (m[i] columns, row stride
 // m[i]) and reference codes a2 + a2_off[i] (n[i] bytes, already encoded with base_code); flags[i] & 1 = reverse complement
@@ -153,6 +161,8 @@ int emu_band(int mode, int K, int narrow, uint32_t B, const void* a1, uint32_t m
   int32_t err = 0;
   DpArgs a{};
   a.pairs = &d; a.a1 = a1; a.a2 = a2; a.scores = score; a.err = &err;
+  std::vector<uint8_t> codes;
+  if (mode == MODE_QP) { codes = padded_codes(a2, n); a.a2 = codes.data() + 128; }
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = hfree; a.vfree = vfree;
   a.ckpt = ckpt.data(); a.lastrow = lastrow.data(); a.band = band.data(); a.ckpt_B = B; a.ckpt_narrow = narrow ? 1 : 0;
   uint64_t off = 0;
@@ -186,6 +196,8 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
   int32_t err = 0;
   DpArgs a{};
   a.pairs = &d; a.a1 = a1; a.a2 = a2;
+  std::vector<uint8_t> codes;
+  if (mode == MODE_QP && !needle) { codes = padded_codes(a2, n); a.a2 = codes.data() + 128; }
   a.bits = bits.data(); a.bits32 = reinterpret_cast<uint32_t*>(bits.data());
   a.scratch = scratch.data(); a.scores = score; a.err = &err;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = hfree; a.vfree = vfree;

@@ -356,11 +356,11 @@ int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool 
   if ((rc = stage_in(ctx, ctx->d_in2, s2.data, e2 * (pb.a2_profile ? 4 : 1), mem, &pb.d_a2))) return rc;
   pb.d_a2_chars = pb.d_a2;
   if (pb.mode == MODE_QP && e2) {  // reference characters -> profile-row codes (align.h:121-136)
-    HIP_TRY(ctx->d_codes.ensure(e2));
+    HIP_TRY(ctx->ensure_codes(e2, ctx->stream));
     hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((e2 + 255) / 256)), dim3(256), 0, ctx->stream,
-                       static_cast<const uint8_t*>(pb.d_a2), static_cast<uint8_t*>(ctx->d_codes.p), e2);
+                       static_cast<const uint8_t*>(pb.d_a2), ctx->codes(), e2);
     HIP_TRY(hipGetLastError());
-    pb.d_a2 = ctx->d_codes.p;
+    pb.d_a2 = ctx->codes();
   }
   pb.desc.resize(pairs->npairs);
   pb.k.resize(pairs->npairs);

@@ -25,6 +25,11 @@ struct PinBuf {  // grow-only pinned host buffer (descriptor uploads)
 };
 
 int set_error(int code, const char* fmt, ...);
+
+// Reference codes (MODE_QP a2) live in ctx->d_codes with tracyhip::kCodePad spare bytes on both sides: the sweep kernels
+// prefetch the column two steps ahead of every lane without clamping it, so idle lanes read up to 64 + 3 bytes
+// before the first / behind the last base of a sequence (any byte value is a valid table row selector).
+constexpr size_t kCodePad = 128;
 int choose_k(uint32_t m, int mode, bool needle = false);
 uint64_t seqset_extent(const tracyhip_seqset& s);
 
@@ -51,6 +56,13 @@ struct tracyhip_ctx {
   tracyhip::DevBuf d_tmp[8];
   tracyhip::DevBuf d_pipe[64];
   tracyhip::DevBuf d_ckpt, d_lastrow, d_band;  // pipeline intermediates (align_traces / decompose)
+  hipError_t ensure_codes(size_t bytes, hipStream_t st) {
+    hipError_t e = d_codes.ensure(bytes + 2 * tracyhip::kCodePad);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(d_codes.p, 5, tracyhip::kCodePad, st)) != hipSuccess) return e;
+    return hipMemsetAsync(static_cast<uint8_t*>(d_codes.p) + tracyhip::kCodePad + bytes, 5, tracyhip::kCodePad, st);
+  }
+  uint8_t* codes() const { return static_cast<uint8_t*>(d_codes.p) + tracyhip::kCodePad; }
   tracyhip::DevBuf d_aftab;                    // allelicFraction grid enumeration (trace independent)
   bool aftab_ready = false;
   tracyhip::PinBuf h_desc, h_off, h_tmp;

@@ -110,13 +110,24 @@ struct SubPacked {
   }
   TR_HD int32_t lo16(int i) const { return (i & 1) ? ((int32_t)pw[i / 2] >> 16) : (int32_t)pw[i / 2]; }
 };
+// strip pointers of one lane into the query-profile table: row `code` of the lane's strip for codes < 5, the shared
+// all-zero-column strip for the rest (the LDS base address is folded into both, once per pass)
+struct QpLane {
+  const char* strip;
+  const char* zero;
+};
 template <int K>
-TR_HD void qp_fetch(const int16_t* tab, uint32_t code, uint32_t lane, SubPacked<K>& q) {
-  constexpr int KP = qp_stride(K);
-  const uint32_t row = (code < 5u) ? code * (64u * KP) + lane * KP : 5u * (64u * KP);
-  const uint32_t* p = reinterpret_cast<const uint32_t*>(tab + row);
+TR_HD QpLane qp_lane(const int16_t* tab, uint32_t lane) {
+  constexpr uint32_t KP = qp_stride(K);
+  const char* t = reinterpret_cast<const char*>(tab);
+  return QpLane{t + lane * (KP * 2u), t + 5u * (64u * KP * 2u)};
+}
+template <int K>
+TR_HD void qp_fetch(const QpLane& ql, uint32_t code, SubPacked<K>& q) {
+  constexpr uint32_t KP = qp_stride(K);
+  const uint32_t* p = reinterpret_cast<const uint32_t*>((code < 5u) ? ql.strip + code * (64u * KP * 2u) : ql.zero);
 #pragma unroll
-  for (int j = 0; j < KP / 2; ++j) q.pw[j] = p[j];
+  for (int j = 0; j < (int)KP / 2; ++j) q.pw[j] = p[j];
 }
 
 // profile x profile: the profile columns of this lane's K rows live in registers for the whole pass, the column
@@ -137,6 +148,9 @@ TR_HD constexpr uint32_t needle_lds_bytes(int mode, int K) { return mode == MODE
 TR_HD constexpr uint32_t lds_bytes(int mode, int K) {
   return mode == MODE_QP ? (5u * 64u + 1u) * (uint32_t)qp_stride(K) * 2u : 0u;  // MODE_PROF keeps its rows in registers
 }
+
+// MODE_QP sweeps read the code buffer up to kCodeBias bytes before / behind a sequence (idle lanes, look-ahead)
+constexpr uint32_t kCodeBias = 96;
 
 TR_HD uint32_t a2_index(const PairDesc& d, uint32_t c /*1-based column*/) {
   return (d.flags & PAIR_A2_REVCOMP) ? d.n - c : c - 1u;
@@ -234,6 +248,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     int32_t bot_h = 0, bot_f = 0;
 
     // ---- substitution set-up for this pass ----
+    const bool rc_view = (d.flags & PAIR_A2_REVCOMP) != 0;
     SubChar<K> sub_c;
     SubTable<K> sub_t;
     SubProf<K> sub_p;
@@ -260,7 +275,10 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
           const int32_t q = (r - 1 < m) ? onehot_score(pr, b, fmatch, fmis) : 0;
           const int32_t qs = (int32_t)((uint32_t)q << SH) - goe_n;
           overflow |= (qs > 32767) || (qs < -32768);
-          qp_tab[b * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)qs;
+          // reverse-complement view of a2: the complement is folded into the table (row of code b serves code 3-b),
+          // the sweep selects rows with the raw codes
+          const uint32_t row = (rc_view && b < 4u) ? 3u - b : b;
+          qp_tab[row * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)qs;
         }
       }
       if (L < (uint32_t)qp_stride(K)) qp_tab[5 * (64 * qp_stride(K)) + L] = (int16_t)(-goe_n);
@@ -303,8 +321,13 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
             up_f = scratch[2 * c + 1];
           }
         }
-        const bool vz = vfree && (c == (int32_t)n);
-        const int32_t vopen = vz ? 0 : go + ge, vext = vz ? 0 : ge;
+        int32_t vopen = go + ge, vext = ge;
+        if (vfree) {  // free end gap in the last column.  vfree is wave-uniform: keep it a scalar branch
+#if defined(__HIP_DEVICE_COMPILE__)
+          asm volatile("" ::: "memory");
+#endif
+          if (c == (int32_t)n) vopen = vext = 0;
+        }
         int32_t nb_h, nb_f;
         uint32_t w0 = 0, w1 = 0;
         if (TRACE) trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub, w0, w1, nb_h, nb_f);
@@ -339,25 +362,33 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       }
     };
     if (MODE == MODE_QP) {
+      // The code of column c = t - L (+ look-ahead) is read WITHOUT clamping: the code buffer carries kCodePad spare
+      // bytes on both sides (capi_internal.h), idle lanes read into them (or into a neighbouring sequence) and discard
+      // the result.  Forward view: byte c-1; reverse-complement view: byte n-c (its complement sits in the table).
+      // byte(t) = lane_base + dir * t with dir = +-1 uniform over the wave: one VALU add per step.
       SubPacked<K> qa, qb;
-      const int32_t c1 = 1 - (int32_t)L;
+      const QpLane ql = qp_lane<K>(qp_tab, L);
+      const uint8_t* a2v = a2c - kCodeBias;
+      const int32_t lane_base = (int32_t)kCodeBias + (rcflag ? (int32_t)n + (int32_t)L : -(int32_t)L - 1);
+      const int32_t dir = rcflag ? -1 : 1;  // wave-uniform: dir * t is scalar work
+      auto raw_at = [&](int32_t tt) -> uint32_t { return a2v[(uint32_t)(lane_base + dir * tt)]; };
       uint32_t raw_next;
       {
-        const uint32_t raw1 = a2c[col_at(c1)];
-        raw_next = a2c[col_at(c1 + 1)];
-        qp_fetch<K>(qp_tab, rcflag ? complement_code(raw1) : raw1, L, qa);
+        const uint32_t raw1 = raw_at(1);
+        raw_next = raw_at(2);
+        qp_fetch<K>(ql, raw1, qa);
       }
       for (uint32_t t = 1; t <= t_end; t += 2) {
         {
-          const uint32_t raw_nn = a2c[col_at((int32_t)t - (int32_t)L + 2)];
-          qp_fetch<K>(qp_tab, rcflag ? complement_code(raw_next) : raw_next, L, qb);
+          const uint32_t raw_nn = raw_at((int32_t)t + 2);
+          qp_fetch<K>(ql, raw_next, qb);
           do_step(t, qa);
           raw_next = raw_nn;
         }
         if (t + 1 > t_end) break;
         {
-          const uint32_t raw_nn = a2c[col_at((int32_t)t - (int32_t)L + 3)];
-          qp_fetch<K>(qp_tab, rcflag ? complement_code(raw_next) : raw_next, L, qa);
+          const uint32_t raw_nn = raw_at((int32_t)t + 3);
+          qp_fetch<K>(ql, raw_next, qa);
           do_step(t + 1, qb);
           raw_next = raw_nn;
         }
@@ -523,12 +554,13 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
     }
   };
   SubPacked<K> qa, qb;
-  qp_fetch<K>(qp_tab, code_at(1 - (int32_t)Lg), L, qa);
+  const QpLane ql = qp_lane<K>(qp_tab, L);
+  qp_fetch<K>(ql, code_at(1 - (int32_t)Lg), qa);
   for (uint32_t t = 1; t <= t_end; t += 2) {
-    qp_fetch<K>(qp_tab, code_at((int32_t)t - (int32_t)Lg + 1), L, qb);
+    qp_fetch<K>(ql, code_at((int32_t)t - (int32_t)Lg + 1), qb);
     do_step(t, qa);
     if (t + 1 > t_end) break;
-    qp_fetch<K>(qp_tab, code_at((int32_t)t - (int32_t)Lg + 2), L, qa);
+    qp_fetch<K>(ql, code_at((int32_t)t - (int32_t)Lg + 2), qa);
     do_step(t + 1, qb);
   }
   if (valid && Lg == GL - 1 && a.scores) {

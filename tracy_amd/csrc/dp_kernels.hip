@@ -21,9 +21,9 @@ static uint32_t lds_pad() {
 
 struct DeviceWave {
   __device__ __forceinline__ uint32_t lane() const { return threadIdx.x; }
-  // lane L <- lane L-1 (wave_shr:1); lane 0 keeps `old` = 0 and is overwritten by the caller
+  // lane L <- lane L-1 (wave_shr:1); lane 0 has no source lane and reads 0 (bound_ctrl), the caller overwrites it
   __device__ __forceinline__ int32_t shift_up(int32_t x) const {
-    return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true);
   }
   __device__ __forceinline__ uint64_t ballot(bool p) const { return __ballot(p); }
   __device__ __forceinline__ uint32_t bcast(uint32_t x, uint32_t src_lane) const { return (uint32_t)__shfl((int)x, (int)src_lane, 64); }

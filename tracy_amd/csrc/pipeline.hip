@@ -169,12 +169,12 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   if ((rc = stage_in(ctx, ctx->d_in2, sr.data, er, mem, &d_ref))) return rc;
   HIP_TRY(ctx->d_err.ensure(sizeof(int32_t)));
   HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t), st));
-  HIP_TRY(ctx->d_codes.ensure(er ? er : 1));
+  HIP_TRY(ctx->ensure_codes(er ? er : 1, st));
   if (er) {
     hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er,
                        static_cast<int32_t*>(ctx->d_err.p));
     hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
-                       static_cast<uint8_t*>(ctx->d_codes.p), er);
+                       ctx->codes(), er);
     HIP_TRY(hipGetLastError());
   }
   {
@@ -270,7 +270,7 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
     pb.mode = MODE_QP;
     pb.a1_profile = true;
     pb.d_a1 = d_prof;
-    pb.d_a2 = ctx->d_codes.p;
+    pb.d_a2 = ctx->codes();
     pb.desc.reserve(what.size());
     pb.k.reserve(what.size());
     for (auto const& w : what) {
@@ -377,7 +377,7 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
     pb.mode = MODE_QP;
     pb.a1_profile = true;
     pb.d_a1 = d_prof;
-    pb.d_a2 = ctx->d_codes.p;
+    pb.d_a2 = ctx->codes();
     pb.desc.resize(nt);
     pb.k.resize(nt);
     for (uint32_t t = 0; t < nt; ++t) {
@@ -444,7 +444,7 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
     pb.mode = MODE_QP;
     pb.a1_profile = true;
     pb.d_a1 = d_prof;
-    pb.d_a2 = ctx->d_codes.p;
+    pb.d_a2 = ctx->codes();
     pb.desc.resize(nt);
     pb.k.resize(nt);
     for (uint32_t t = 0; t < nt; ++t) {
@@ -621,12 +621,12 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
   // references: validate + encode
   HIP_TRY(ctx->d_err.ensure(sizeof(int32_t)));
   HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t), st));
-  HIP_TRY(ctx->d_codes.ensure(er ? er : 1));
+  HIP_TRY(ctx->ensure_codes(er ? er : 1, st));
   if (er) {
     hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er,
                        static_cast<int32_t*>(ctx->d_err.p));
     hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
-                       static_cast<uint8_t*>(ctx->d_codes.p), er);
+                       ctx->codes(), er);
     HIP_TRY(hipGetLastError());
     int32_t herr = 0;
     HIP_TRY(hipMemcpyAsync(&herr, ctx->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -663,7 +663,7 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
   std::vector<int32_t> h_sc2(2 * (size_t)nt, 0);
   if (!given) {
     DpProblem pb;
-    pb.mode = MODE_QP; pb.a1_profile = true; pb.d_a1 = d_prof; pb.d_a2 = ctx->d_codes.p;
+    pb.mode = MODE_QP; pb.a1_profile = true; pb.d_a1 = d_prof; pb.d_a2 = ctx->codes();
     pb.desc.resize(2 * (size_t)nt); pb.k.resize(2 * (size_t)nt);
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc d = qp_desc(t, true);
@@ -696,7 +696,7 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
   {
     DpProblem pb;
     pb.mode = wildtype ? MODE_PROF : MODE_QP; pb.a1_profile = true; pb.a2_profile = wildtype; pb.d_a1 = d_prof;
-    pb.d_a2 = wildtype ? d_refprof : ctx->d_codes.p;
+    pb.d_a2 = wildtype ? d_refprof : ctx->codes();
     pb.desc.resize(nt); pb.k.resize(nt);
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc d = qp_desc(t, true);

@@ -167,22 +167,20 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   const void *d_prof, *d_ref;
   if ((rc = stage_in(ctx, ctx->d_in1, sp.data, ep * 4, mem, &d_prof))) return rc;
   if ((rc = stage_in(ctx, ctx->d_in2, sr.data, er, mem, &d_ref))) return rc;
-  HIP_TRY(ctx->d_err.ensure(sizeof(int32_t)));
-  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t), st));
+  // The validation verdict (second word of d_err; run_dp owns the first) is read back together with the orientation
+  // scores: no host round trip between the encode and the first score pass.
+  HIP_TRY(ctx->d_err.ensure(2 * sizeof(int32_t)));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, 2 * sizeof(int32_t), st));
+  int32_t* d_verr = static_cast<int32_t*>(ctx->d_err.p) + 1;
   HIP_TRY(ctx->ensure_codes(er ? er : 1, st));
   if (er) {
-    hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er,
-                       static_cast<int32_t*>(ctx->d_err.p));
+    hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er, d_verr);
     hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
                        ctx->codes(), er);
     HIP_TRY(hipGetLastError());
   }
-  {
-    int32_t herr = 0;
-    HIP_TRY(hipMemcpyAsync(&herr, ctx->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (herr & 4) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
-  }
+  int32_t h_verr = 0;
+  bool verr_fetched = false;
 
   // ---- geometry per trace ----
   std::vector<uint32_t> mf(nt), mt(nt), tl(nt), rn(nt), ridx(nt);
@@ -236,10 +234,11 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
       }
     }
     if (use_band) {
-      size_t fr = 0, tot = 0;
-      HIP_TRY(hipMemGetInfo(&fr, &tot));
       const uint64_t need = (ck_tot + lr_tot) * 4 + (uint64_t)nt * ck.B * 64 * 8;
-      if (need > (uint64_t)(fr * 0.8) + ctx->d_ckpt.cap + ctx->d_lastrow.cap + ctx->d_band.cap) use_band = false;
+      const bool have = ctx->d_ckpt.cap >= ck_tot * 4 + 64 && ctx->d_lastrow.cap >= lr_tot * 4 + 64 && ctx->d_band.cap >= (uint64_t)nt * ck.B * 64 * 8;
+      size_t fr = 0, tot = 0;
+      if (!have) HIP_TRY(hipMemGetInfo(&fr, &tot));  // (a driver call: skipped when the grow-only buffers already fit)
+      if (!have && need > (uint64_t)(fr * 0.8) + ctx->d_ckpt.cap + ctx->d_lastrow.cap + ctx->d_band.cap) use_band = false;
       else {
         HIP_TRY(ctx->d_ckpt.ensure(ck_tot * 4 + 64));
         HIP_TRY(ctx->d_lastrow.ensure(lr_tot * 4 + 64));
@@ -284,7 +283,10 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   std::vector<uint8_t> h_rc(nt);    // the reference window has to be read as its reverse complement
   auto fetch_scores = [&]() -> int {
     HIP_TRY(hipMemcpyAsync(h_sc2.data(), d_sc2, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
+    if (!verr_fetched) HIP_TRY(hipMemcpyAsync(&h_verr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    verr_fetched = true;
+    if (h_verr & 4) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
     return TRACYHIP_OK;
   };
   // Strand by certificate: a cheap prefix pass (rows 1 .. 8K of both orientations, eight pairs per wave) bounds each

@@ -769,6 +769,7 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
     const int32_t* ck = a.ckpt + d.ckpt_off;
     const int32_t* lr = a.lastrow + d.lastrow_off;
     uint64_t* band = a.band + (uint64_t)pair_idx * B * 64u;
+    const bool rcflag = (d.flags & PAIR_A2_REVCOMP) != 0;
 
     // ---- substitution set-up (as gotoh_body) ----
     SubChar<K> sub_c;
@@ -792,7 +793,8 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
 #pragma unroll
         for (uint32_t bb = 0; bb < 5; ++bb) {
           const int32_t qv = (r - 1 < m) ? onehot_score(pr, bb, fmatch, fmis) : 0;
-          qp_tab[bb * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)((uint32_t)qv << SH);
+          const uint32_t rowsel = (rcflag && bb < 4u) ? 3u - bb : bb;  // complement folded into the table (as gotoh_body)
+          qp_tab[rowsel * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)((uint32_t)qv << SH);
         }
       }
       if (L < (uint32_t)qp_stride(K)) qp_tab[5 * (64 * qp_stride(K)) + L] = 0;
@@ -853,7 +855,7 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
         bot_f = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(bf) : bf) << SH);
         prev_up_h = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(pu - (go + ge)) : pu) << SH);
       }
-      for (uint32_t t = t0 + 1; t <= t_cur; ++t) {
+      auto band_step = [&](uint32_t t, const auto& sub) {
         const int32_t c = (int32_t)t - (int32_t)L;
         int32_t up_h = w.shift_up(bot_h);
         int32_t up_f = w.shift_up(bot_f);
@@ -865,23 +867,49 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
           }
           const bool vz = vfree && (c == (int32_t)n);
           const int32_t vopen = vz ? 0 : go + ge, vext = vz ? 0 : ge;
-          const uint32_t ci = a2_index(d, (uint32_t)c);
           int32_t nb_h, nb_f;
-          if (MODE == MODE_CHAR) {
-            sub_c.cc = (int32_t)a2c[ci];
-            if (d.flags & PAIR_A2_REVCOMP) sub_c.cc = (int32_t)complement_char((uint8_t)sub_c.cc);
-            trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub_c, w0, w1, nb_h, nb_f);
-          } else {
-            uint32_t code = a2c[ci];
-            if (d.flags & PAIR_A2_REVCOMP) code = complement_code(code);
-            qp_load<K, false>(qp_tab, code, L, sub_t);
-            trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub_t, w0, w1, nb_h, nb_f);
-          }
+          trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub, w0, w1, nb_h, nb_f);
           prev_up_h = up_h;
           bot_h = nb_h;
           bot_f = nb_f;
         }
         if (L < lanes_used) band[(uint64_t)(t - t0 - 1u) * 64u + L] = ((uint64_t)w1 << 32) | w0;
+      };
+      if (MODE == MODE_CHAR) {
+        for (uint32_t t = t0 + 1; t <= t_cur; ++t) {
+          const int32_t c = (int32_t)t - (int32_t)L;
+          if ((c >= 1) && (c <= (int32_t)n)) {
+            sub_c.cc = (int32_t)a2c[a2_index(d, (uint32_t)c)];
+            if (rcflag) sub_c.cc = (int32_t)complement_char((uint8_t)sub_c.cc);
+          }
+          band_step(t, sub_c);
+        }
+      } else {
+        // same software pipeline as the sweep of gotoh_body: the code two steps ahead (unclamped read of the padded
+        // code buffer), the LDS strip one step ahead into the other half of a ping-pong pair
+        SubPacked<K> qa, qb;
+        const QpLane ql = qp_lane<K>(qp_tab, L);
+        const uint8_t* a2v = a2c - kCodeBias;
+        const int32_t lane_base = (int32_t)kCodeBias + (rcflag ? (int32_t)n + (int32_t)L : -(int32_t)L - 1);
+        const int32_t dir = rcflag ? -1 : 1;
+        auto raw_at = [&](uint32_t tt) -> uint32_t { return a2v[(uint32_t)(lane_base + dir * (int32_t)tt)]; };
+        uint32_t raw_next = raw_at(t0 + 2);
+        qp_fetch<K>(ql, raw_at(t0 + 1), qa);
+        for (uint32_t t = t0 + 1; t <= t_cur; t += 2) {
+          {
+            const uint32_t raw_nn = raw_at(t + 2);
+            qp_fetch<K>(ql, raw_next, qb);
+            band_step(t, qa);
+            raw_next = raw_nn;
+          }
+          if (t + 1 > t_cur) break;
+          {
+            const uint32_t raw_nn = raw_at(t + 3);
+            qp_fetch<K>(ql, raw_next, qa);
+            band_step(t + 1, qb);
+            raw_next = raw_nn;
+          }
+        }
       }
       w.sync_global();
       BandFetch fetch{band, t0, K, pad};

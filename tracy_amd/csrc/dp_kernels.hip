@@ -28,7 +28,13 @@ struct DeviceWave {
   __device__ __forceinline__ uint64_t ballot(bool p) const { return __ballot(p); }
   __device__ __forceinline__ uint32_t bcast(uint32_t x, uint32_t src_lane) const { return (uint32_t)__shfl((int)x, (int)src_lane, 64); }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
-  __device__ __forceinline__ void sync_global() const { __threadfence(); }
+  // global memory written by some lanes of this wave is read by others afterwards (band buffer, pass hand-over): the
+  // workgroup IS the wave, so workgroup scope is all that is needed.  An agent-scope fence (__threadfence) writes back
+  // and invalidates the XCD's L2 on this multi-XCD part -- hundreds of microseconds per call.
+  __device__ __forceinline__ void sync_global() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
   __device__ __forceinline__ char* lds() const {
     extern __shared__ __attribute__((aligned(16))) char tracy_smem[];
     return tracy_smem;

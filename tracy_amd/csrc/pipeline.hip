@@ -215,6 +215,7 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   bool use_band = getenv("TRACYHIP_NO_BAND") == nullptr && p.ge < 0 && p.go <= 0;  // hfree = 1, vfree = 0 here
   DpCkpt ck;
   ck.B = 256;
+  if (const char* e = getenv("TRACYHIP_CKPT_B")) { const int b = atoi(e); if (b >= 32 && b <= 1024) ck.B = (uint32_t)b; }  // developer knob
   // job->oriented: the references are already oriented by the caller (k-mer seeding): one score pass, no decision
   const bool given = job->oriented != nullptr;
   const int norient = given ? 1 : 2;

@@ -109,6 +109,17 @@ def main():
             if not ok:
                 bad.append(("align", tl, tr, i))
         done["align"] = done.get("align", 0) + nt
+        # the library's default mode (strand by certificate): same decision and alignment; the winner's orientation
+        # score is exact, the loser's is its exact score or a certified upper bound of it
+        fast = ctx.align_traces(profs, refs, (3, -5, -10, -4), tl, tr, exact_scores=False)
+        for i in range(nt):
+            ok = all(int(fast[k][i]) == int(got[k][i]) for k in ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"))
+            ok = ok and fast["btr"][i] == got["btr"][i]
+            win, lose = ("score_fwd", "score_rev") if int(got["forward"][i]) else ("score_rev", "score_fwd")
+            ok = ok and int(fast[win][i]) == int(got[win][i]) and int(fast[lose][i]) >= int(got[lose][i])
+            if not ok:
+                bad.append(("align_certificate", tl, tr, i))
+        done["align_certificate"] = done.get("align_certificate", 0) + nt
 
     # ---- 3. `tracy decompose` batches ----
     nd = max(8, args.traces // 2)

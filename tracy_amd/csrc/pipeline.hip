@@ -296,12 +296,18 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   // holds the bound).  Traces whose bounds are close, or whose certificate fails, get both full passes: the decision is
   // always the reference's `gsFwd > gsRev`.
   bool use_prefix = !given && use_band && ck.narrow && !job->exact_orientation_scores && getenv("TRACYHIP_NO_PREFIX") == nullptr;
-  for (uint32_t t = 0; t < nt && use_prefix; ++t)
-    if (mt[t] <= (uint32_t)kPrefixLanes * choose_k(mt[t], MODE_QP)) use_prefix = false;
+  // traces no taller than the prefix (8K rows) have nothing left to bound: they get both full passes
+  std::vector<uint8_t> elig(nt, 0);
+  if (use_prefix) {
+    uint32_t ne = 0;
+    for (uint32_t t = 0; t < nt; ++t) ne += elig[t] = mt[t] > (uint32_t)kPrefixLanes * choose_k(mt[t], MODE_QP);
+    if (ne == 0) use_prefix = false;
+  }
   if (use_prefix) {
     std::vector<std::pair<uint32_t, int>> all2;
     for (int o = 0; o < 2; ++o)
-      for (uint32_t t = 0; t < nt; ++t) all2.emplace_back(t, o);
+      for (uint32_t t = 0; t < nt; ++t)
+        if (elig[t]) all2.emplace_back(t, o);
     if ((rc = run_stage1(all2, DP_PREFIX))) return rc;
     std::vector<RowMaxDesc> hrm(nt);
     for (uint32_t t = 0; t < nt; ++t)
@@ -325,7 +331,7 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
       const int64_t bf = bound[t], br = bound[nt + t];
       guess[t] = bf >= br ? 0 : 1;
       const int64_t bw = guess[t] ? br : bf, bl = guess[t] ? bf : br;
-      both[t] = (bw <= 0 || bl * 10 > bw * 9) ? 1 : 0;
+      both[t] = (!elig[t] || bw <= 0 || bl * 10 > bw * 9) ? 1 : 0;
       full.emplace_back(t, (int)guess[t]);
       if (both[t]) full.emplace_back(t, 1 - guess[t]);
     }

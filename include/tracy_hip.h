@@ -243,6 +243,8 @@ typedef struct {
   tracyhip_seqset ref_profiles;  /* data NULL = unused.  Wildtype-trace reference (indigo.h:249-289): profile of the wildtype
                                     trace, oriented by the caller (needs `oriented`), parallel to refs, which then hold the
                                     wildtype's (oriented) primary basecalls = rs.refslice */
+  uint32_t exact_orientation_scores; /* as in tracyhip_align_job: 0 (default) = strand by certificate, the losing
+                                    orientation's score may be a certified upper bound; 1 = both scores exact */
 } tracyhip_decompose_job;
 
 typedef struct {

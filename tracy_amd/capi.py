@@ -412,7 +412,8 @@ Context.allelic_fraction = _allelic_fraction
 
 class DecomposeJob(C.Structure):
     _fields_ = [("ntraces", C.c_uint32), ("profiles", SeqSet), ("bc", BaseCallsBatch), ("refs", SeqSet),
-                ("ref_index", C.POINTER(C.c_uint32)), ("dprm", DecompParams), ("oriented", C.POINTER(C.c_uint8)), ("ref_profiles", SeqSet)]
+                ("ref_index", C.POINTER(C.c_uint32)), ("dprm", DecompParams), ("oriented", C.POINTER(C.c_uint8)), ("ref_profiles", SeqSet),
+                ("exact_orientation_scores", C.c_uint32)]
 
 
 class DecomposeResult(C.Structure):
@@ -425,7 +426,7 @@ class DecomposeResult(C.Structure):
 
 
 def _decompose_traces(self, profiles, hbc, refs, params, trim_left=50, trim_right=50, maxindel=1000, madc=5, oriented=None,
-                      ref_profiles=None):
+                      ref_profiles=None, exact_scores=True):
     """tracyhip_decompose_traces with host buffers; hbc: HostBaseCalls (primary/secondary rewritten in place);
     oriented: None, or rs.forward per trace when the references are already oriented (indexed-genome path)"""
     pp = profiles if isinstance(profiles, PackedSeqs) else PackedSeqs(profiles, SEQ_PROFILE)
@@ -437,6 +438,7 @@ def _decompose_traces(self, profiles, hbc, refs, params, trim_left=50, trim_righ
     job.bc = hbc.struct()
     job.refs = pr.seqset()
     job.dprm = DecompParams(trim_left, trim_right, maxindel, madc)
+    job.exact_orientation_scores = 1 if exact_scores else 0  # False: the losing strand may carry a certified upper bound
     if oriented is not None:
         oriented = np.ascontiguousarray(oriented, dtype=np.uint8)
         job.oriented = oriented.ctypes.data_as(C.POINTER(C.c_uint8))

@@ -140,72 +140,40 @@ int copy_out(tracyhip_ctx* ctx, int mem, T* user, const T* dev, size_t count) {
   return TRACYHIP_OK;
 }
 
-}  // namespace
+// =====================================================================================================
+// Orientation + preliminary alignment of trimmed traces against their reference windows: the part `tracy align`
+// (sage.h:223-258) and `tracy decompose` (indigo.h:235-302, FASTA / indexed reference) have in common.
+// =====================================================================================================
+struct OrientIn {
+  uint32_t nt;
+  const void* d_prof;       // device: profile payload (float)
+  const uint64_t* a1_off;   // host [nt]: first column of the trimmed view (float index)
+  const uint32_t* mf;       // host [nt]: row stride of the profile (full trace length)
+  const uint32_t* mt;       // host [nt]: columns of the trimmed view
+  const uint64_t* a2_off;   // host [nt]: reference window in the code buffer
+  const uint32_t* rn;       // host [nt]: its length
+  const uint8_t* oriented;  // host [nt] or null: orientation given by the caller (no scores, no decision)
+  bool exact;               // both orientation scores exact (no strand by certificate)
+  int32_t* d_verr;          // device: verdict word of the reference validation, or null (checked with the first read-back)
+  uint8_t* d_ops;           // device outputs of the preliminary alignment (push order)
+  const uint64_t* d_ops_off;
+  uint32_t* d_ops_len;
+  int32_t* d_score;         // device [nt] or null
+};
+struct OrientOut {
+  std::vector<int32_t> sc2;     // [2 nt] forward / reverse scores (the loser's may be a certified upper bound)
+  std::vector<uint8_t> fwd, rc; // rs.forward; "read the window as its reverse complement"
+};
 
-extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
-                                     const tracyhip_align_result* out) {
-  int rc = ctx_begin(ctx);
-  if (rc) return rc;
-  if (!job || !out || !prm) return set_error(TRACYHIP_ERR_ARG, "null job/result/params");
-  if (mem != TRACYHIP_MEM_HOST && mem != TRACYHIP_MEM_DEVICE) return set_error(TRACYHIP_ERR_ARG, "bad mem kind");
-  const uint32_t nt = job->ntraces;
-  if (nt == 0) return TRACYHIP_OK;
-  const tracyhip_seqset& sp = job->profiles;
-  const tracyhip_seqset& sr = job->refs;
-  if (sp.kind != TRACYHIP_SEQ_PROFILE || sr.kind != TRACYHIP_SEQ_CHAR) return set_error(TRACYHIP_ERR_ARG, "profiles must be PROFILE, refs CHAR");
-  if (!sp.offset || !sp.length || !sr.offset || !sr.length || sp.count < nt) return set_error(TRACYHIP_ERR_ARG, "bad sequence sets");
-  if (!out->score_fwd || !out->score_rev || !out->forward || !out->slice_begin || !out->slice_len || !out->ref_pos ||
-      !out->score_final || !out->ops || !out->ops_offset || !out->ops_len)
-    return set_error(TRACYHIP_ERR_ARG, "null result array");
+int orient_and_align(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn& in, OrientOut& o) {
+  int rc;
   hipStream_t st = ctx->stream;
-  tracyhip_params p = *prm;
-  p.hfree = 1;  // AlignConfig<true,false> semiglobal (sage.h:165)
-  p.vfree = 0;
-
-  // ---- stage payloads, encode the references once ----
-  const uint64_t ep = seqset_extent(sp), er = seqset_extent(sr);
-  const void *d_prof, *d_ref;
-  if ((rc = stage_in(ctx, ctx->d_in1, sp.data, ep * 4, mem, &d_prof))) return rc;
-  if ((rc = stage_in(ctx, ctx->d_in2, sr.data, er, mem, &d_ref))) return rc;
-  // The validation verdict (second word of d_err; run_dp owns the first) is read back together with the orientation
-  // scores: no host round trip between the encode and the first score pass.
-  HIP_TRY(ctx->d_err.ensure(2 * sizeof(int32_t)));
-  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, 2 * sizeof(int32_t), st));
-  int32_t* d_verr = static_cast<int32_t*>(ctx->d_err.p) + 1;
-  HIP_TRY(ctx->ensure_codes(er ? er : 1, st));
-  if (er) {
-    hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er, d_verr);
-    hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
-                       ctx->codes(), er);
-    HIP_TRY(hipGetLastError());
-  }
+  const uint32_t nt = in.nt;
+  const void* d_prof = in.d_prof;
+  const uint32_t *mf = in.mf, *mt = in.mt, *rn = in.rn;
+  int32_t* d_verr = in.d_verr;
   int32_t h_verr = 0;
   bool verr_fetched = false;
-
-  // ---- geometry per trace ----
-  std::vector<uint32_t> mf(nt), mt(nt), tl(nt), rn(nt), ridx(nt);
-  uint64_t max_mn = 0;
-  for (uint32_t t = 0; t < nt; ++t) {
-    ridx[t] = job->ref_index ? job->ref_index[t] : t;
-    if (ridx[t] >= sr.count) return set_error(TRACYHIP_ERR_ARG, "ref_index[%u] out of range", t);
-    mf[t] = sp.length[t];
-    rn[t] = sr.length[ridx[t]];
-    uint32_t l = job->trim_left, r = job->trim_right;
-    if ((uint64_t)l + r >= mf[t]) { l = 0; r = 0; }  // createProfile, profile.h:24-27
-    tl[t] = l;
-    mt[t] = mf[t] - (l + r);
-    max_mn = std::max<uint64_t>(max_mn, (uint64_t)mf[t] + rn[t]);
-  }
-  if ((rc = check_params(&p, max_mn))) return rc;
-
-  // device result arrays (user's in DEVICE mode, ours in HOST mode)
-  auto dev_arr = [&](DevBuf& b, void* user, size_t bytes, void** dptr) -> int {
-    if (mem == TRACYHIP_MEM_DEVICE) { *dptr = user; return TRACYHIP_OK; }
-    HIP_TRY(b.ensure(bytes));
-    *dptr = b.p;
-    return TRACYHIP_OK;
-  };
-
   // ---- 1. orientation scores: gotohScore(trim, fwd) / gotohScore(trim, rev)  (sage.h:239-240) ----
   // When every trimmed profile fits one pass of its strip height, the score pass also leaves wavefront
   // checkpoints and the last-row values, and stage 2 recomputes only the bands its path crosses
@@ -216,8 +184,8 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   DpCkpt ck;
   ck.B = 256;
   if (const char* e = getenv("TRACYHIP_CKPT_B")) { const int b = atoi(e); if (b >= 32 && b <= 1024) ck.B = (uint32_t)b; }  // developer knob
-  // job->oriented: the references are already oriented by the caller (k-mer seeding): one score pass, no decision
-  const bool given = job->oriented != nullptr;
+  // in.oriented: the references are already oriented by the caller (k-mer seeding): one score pass, no decision
+  const bool given = in.oriented != nullptr;
   const int norient = given ? 1 : 2;
   std::vector<uint64_t> ck_off(2 * (size_t)nt), lr_off(2 * (size_t)nt);
   {
@@ -253,10 +221,10 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   }
   auto stage1_desc = [&](uint32_t t, int orient) {  // orient 0 = forward, 1 = reverse complement
     PairDesc d{};
-    d.a1_off = sp.offset[t] + tl[t];
+    d.a1_off = in.a1_off[t];
     d.a1_stride = mf[t];
     d.m = mt[t];
-    d.a2_off = sr.offset[ridx[t]];
+    d.a2_off = in.a2_off[t];
     d.n = rn[t];
     d.a2_stride = rn[t];
     d.out = (uint32_t)orient * nt + t;
@@ -279,12 +247,15 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
     }
     return run_dp(ctx, pb, &p, false, false, d_sc2, nullptr, nullptr, nullptr, stage, stage == DP_CKPT ? &ck : nullptr);
   };
-  std::vector<int32_t> h_sc2(2 * (size_t)nt, 0);
-  std::vector<uint8_t> h_fwd(nt);   // rs.forward: decides how rs.pos moves in trimReferenceSlice
-  std::vector<uint8_t> h_rc(nt);    // the reference window has to be read as its reverse complement
+  std::vector<int32_t>& h_sc2 = o.sc2;
+  h_sc2.assign(2 * (size_t)nt, 0);
+  std::vector<uint8_t>& h_fwd = o.fwd;  // rs.forward: decides how rs.pos moves in trimReferenceSlice
+  h_fwd.assign(nt, 0);
+  std::vector<uint8_t>& h_rc = o.rc;    // the reference window has to be read as its reverse complement
+  h_rc.assign(nt, 0);
   auto fetch_scores = [&]() -> int {
     HIP_TRY(hipMemcpyAsync(h_sc2.data(), d_sc2, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
-    if (!verr_fetched) HIP_TRY(hipMemcpyAsync(&h_verr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (d_verr && !verr_fetched) HIP_TRY(hipMemcpyAsync(&h_verr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     verr_fetched = true;
     if (h_verr & 4) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
@@ -295,7 +266,7 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   // stays below that score the strand is decided without ever sweeping the loser over all rows (its score array then
   // holds the bound).  Traces whose bounds are close, or whose certificate fails, get both full passes: the decision is
   // always the reference's `gsFwd > gsRev`.
-  bool use_prefix = !given && use_band && ck.narrow && !job->exact_orientation_scores && getenv("TRACYHIP_NO_PREFIX") == nullptr;
+  bool use_prefix = !given && use_band && ck.narrow && !in.exact && getenv("TRACYHIP_NO_PREFIX") == nullptr;
   // traces no taller than the prefix (8K rows) have nothing left to bound: they get both full passes
   std::vector<uint8_t> elig(nt, 0);
   if (use_prefix) {
@@ -311,7 +282,7 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
     if ((rc = run_stage1(all2, DP_PREFIX))) return rc;
     std::vector<RowMaxDesc> hrm(nt);
     for (uint32_t t = 0; t < nt; ++t)
-      hrm[t] = RowMaxDesc{sp.offset[t] + tl[t], mf[t], mt[t], (uint32_t)kPrefixLanes * choose_k(mt[t], MODE_QP)};
+      hrm[t] = RowMaxDesc{in.a1_off[t], mf[t], mt[t], (uint32_t)kPrefixLanes * choose_k(mt[t], MODE_QP)};
     HIP_TRY(ctx->d_tmp[7].ensure(sizeof(RowMaxDesc) * (size_t)nt + sizeof(int32_t) * (size_t)nt));
     RowMaxDesc* d_rm = static_cast<RowMaxDesc*>(ctx->d_tmp[7].p);
     int32_t* d_ub = reinterpret_cast<int32_t*>(d_rm + nt);
@@ -366,21 +337,11 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
     if ((rc = fetch_scores())) return rc;
   }
   for (uint32_t t = 0; t < nt; ++t) {
-    if (given) { h_fwd[t] = job->oriented[t] ? 1 : 0; h_rc[t] = 0; }
+    if (given) { h_fwd[t] = in.oriented[t] ? 1 : 0; h_rc[t] = 0; }
     else { h_fwd[t] = h_sc2[t] > h_sc2[nt + t] ? 1 : 0; h_rc[t] = !h_fwd[t]; }  // forward iff gsFwd > gsRev (sage.h:247)
   }
 
-  // ---- 2. preliminary alignment gotoh(trim, oriented reference) (sage.h:258) ----
-  std::vector<uint64_t> off1(nt);
-  uint64_t tot1 = 0;
-  for (uint32_t t = 0; t < nt; ++t) { off1[t] = tot1; tot1 += (uint64_t)mt[t] + rn[t]; }
-  HIP_TRY(ctx->d_tmp[1].ensure(tot1 ? tot1 : 1));                       // ops of the preliminary alignment
-  HIP_TRY(ctx->d_tmp[2].ensure(sizeof(uint64_t) * (size_t)nt));          // their offsets
-  HIP_TRY(ctx->d_tmp[3].ensure(sizeof(uint32_t) * (size_t)nt));          // their lengths
-  HIP_TRY(ctx->d_tmp[4].ensure(sizeof(int32_t) * (size_t)nt));           // preliminary scores
-  HIP_TRY(ctx->h_tmp.ensure(sizeof(uint64_t) * (size_t)nt + (size_t)nt * 8));
-  std::memcpy(ctx->h_tmp.p, off1.data(), sizeof(uint64_t) * (size_t)nt);
-  HIP_TRY(hipMemcpyAsync(ctx->d_tmp[2].p, ctx->h_tmp.p, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+  // ---- 2. preliminary alignment gotoh(trim, oriented reference) (sage.h:258 / indigo.h:302) ----
   {
     DpProblem pb;
     pb.mode = MODE_QP;
@@ -391,10 +352,10 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
     pb.k.resize(nt);
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc d{};
-      d.a1_off = sp.offset[t] + tl[t];
+      d.a1_off = in.a1_off[t];
       d.a1_stride = mf[t];
       d.m = mt[t];
-      d.a2_off = sr.offset[ridx[t]];
+      d.a2_off = in.a2_off[t];
       d.n = rn[t];
       d.a2_stride = rn[t];
       d.out = t;
@@ -407,16 +368,106 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
     }
     if (use_band) {
       // the preliminary score equals the winning orientation score (same DP): no score array needed from the band pass
-      if ((rc = run_dp(ctx, pb, &p, false, true, nullptr, static_cast<uint8_t*>(ctx->d_tmp[1].p),
-                       static_cast<const uint64_t*>(ctx->d_tmp[2].p), static_cast<uint32_t*>(ctx->d_tmp[3].p), DP_BAND, &ck)))
+      if ((rc = run_dp(ctx, pb, &p, false, true, nullptr, in.d_ops,
+                       in.d_ops_off, in.d_ops_len, DP_BAND, &ck)))
         return rc;
       std::vector<int32_t> h_pre(nt);
       for (uint32_t t = 0; t < nt; ++t) h_pre[t] = h_rc[t] ? h_sc2[nt + t] : h_sc2[t];
-      HIP_TRY(hipMemcpy(ctx->d_tmp[4].p, h_pre.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice));
-    } else if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(ctx->d_tmp[4].p), static_cast<uint8_t*>(ctx->d_tmp[1].p),
-                            static_cast<const uint64_t*>(ctx->d_tmp[2].p), static_cast<uint32_t*>(ctx->d_tmp[3].p))))
+      if (in.d_score) HIP_TRY(hipMemcpy(in.d_score, h_pre.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice));
+    } else if ((rc = run_dp(ctx, pb, &p, false, true, in.d_score, in.d_ops,
+                            in.d_ops_off, in.d_ops_len)))
       return rc;
   }
+
+  return TRACYHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
+                                     const tracyhip_align_result* out) {
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  if (!job || !out || !prm) return set_error(TRACYHIP_ERR_ARG, "null job/result/params");
+  if (mem != TRACYHIP_MEM_HOST && mem != TRACYHIP_MEM_DEVICE) return set_error(TRACYHIP_ERR_ARG, "bad mem kind");
+  const uint32_t nt = job->ntraces;
+  if (nt == 0) return TRACYHIP_OK;
+  const tracyhip_seqset& sp = job->profiles;
+  const tracyhip_seqset& sr = job->refs;
+  if (sp.kind != TRACYHIP_SEQ_PROFILE || sr.kind != TRACYHIP_SEQ_CHAR) return set_error(TRACYHIP_ERR_ARG, "profiles must be PROFILE, refs CHAR");
+  if (!sp.offset || !sp.length || !sr.offset || !sr.length || sp.count < nt) return set_error(TRACYHIP_ERR_ARG, "bad sequence sets");
+  if (!out->score_fwd || !out->score_rev || !out->forward || !out->slice_begin || !out->slice_len || !out->ref_pos ||
+      !out->score_final || !out->ops || !out->ops_offset || !out->ops_len)
+    return set_error(TRACYHIP_ERR_ARG, "null result array");
+  hipStream_t st = ctx->stream;
+  tracyhip_params p = *prm;
+  p.hfree = 1;  // AlignConfig<true,false> semiglobal (sage.h:165)
+  p.vfree = 0;
+
+  // ---- stage payloads, encode the references once ----
+  const uint64_t ep = seqset_extent(sp), er = seqset_extent(sr);
+  const void *d_prof, *d_ref;
+  if ((rc = stage_in(ctx, ctx->d_in1, sp.data, ep * 4, mem, &d_prof))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_in2, sr.data, er, mem, &d_ref))) return rc;
+  // The validation verdict (second word of d_err; run_dp owns the first) is read back together with the orientation
+  // scores: no host round trip between the encode and the first score pass.
+  HIP_TRY(ctx->d_err.ensure(2 * sizeof(int32_t)));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, 2 * sizeof(int32_t), st));
+  int32_t* d_verr = static_cast<int32_t*>(ctx->d_err.p) + 1;
+  HIP_TRY(ctx->ensure_codes(er ? er : 1, st));
+  if (er) {
+    hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er, d_verr);
+    hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
+                       ctx->codes(), er);
+    HIP_TRY(hipGetLastError());
+  }
+  // ---- geometry per trace ----
+  std::vector<uint32_t> mf(nt), mt(nt), tl(nt), rn(nt), ridx(nt);
+  uint64_t max_mn = 0;
+  for (uint32_t t = 0; t < nt; ++t) {
+    ridx[t] = job->ref_index ? job->ref_index[t] : t;
+    if (ridx[t] >= sr.count) return set_error(TRACYHIP_ERR_ARG, "ref_index[%u] out of range", t);
+    mf[t] = sp.length[t];
+    rn[t] = sr.length[ridx[t]];
+    uint32_t l = job->trim_left, r = job->trim_right;
+    if ((uint64_t)l + r >= mf[t]) { l = 0; r = 0; }  // createProfile, profile.h:24-27
+    tl[t] = l;
+    mt[t] = mf[t] - (l + r);
+    max_mn = std::max<uint64_t>(max_mn, (uint64_t)mf[t] + rn[t]);
+  }
+  if ((rc = check_params(&p, max_mn))) return rc;
+
+  // device result arrays (user's in DEVICE mode, ours in HOST mode)
+  auto dev_arr = [&](DevBuf& b, void* user, size_t bytes, void** dptr) -> int {
+    if (mem == TRACYHIP_MEM_DEVICE) { *dptr = user; return TRACYHIP_OK; }
+    HIP_TRY(b.ensure(bytes));
+    *dptr = b.p;
+    return TRACYHIP_OK;
+  };
+
+  // ---- 1.-2. orientation (sage.h:239-247) + preliminary alignment (sage.h:258): orient_and_align ----
+  std::vector<uint64_t> off1(nt);
+  uint64_t tot1 = 0;
+  for (uint32_t t = 0; t < nt; ++t) { off1[t] = tot1; tot1 += (uint64_t)mt[t] + rn[t]; }
+  HIP_TRY(ctx->d_tmp[1].ensure(tot1 ? tot1 : 1));                       // ops of the preliminary alignment
+  HIP_TRY(ctx->d_tmp[2].ensure(sizeof(uint64_t) * (size_t)nt));          // their offsets
+  HIP_TRY(ctx->d_tmp[3].ensure(sizeof(uint32_t) * (size_t)nt));          // their lengths
+  HIP_TRY(ctx->d_tmp[4].ensure(sizeof(int32_t) * (size_t)nt));           // preliminary scores
+  HIP_TRY(ctx->h_tmp.ensure(sizeof(uint64_t) * (size_t)nt + (size_t)nt * 8));
+  std::memcpy(ctx->h_tmp.p, off1.data(), sizeof(uint64_t) * (size_t)nt);
+  HIP_TRY(hipMemcpyAsync(ctx->d_tmp[2].p, ctx->h_tmp.p, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+  std::vector<uint64_t> a1o(nt), a2o(nt);
+  for (uint32_t t = 0; t < nt; ++t) { a1o[t] = sp.offset[t] + tl[t]; a2o[t] = sr.offset[ridx[t]]; }
+  OrientIn oi{};
+  oi.nt = nt; oi.d_prof = d_prof; oi.a1_off = a1o.data(); oi.mf = mf.data(); oi.mt = mt.data(); oi.a2_off = a2o.data(); oi.rn = rn.data();
+  oi.oriented = job->oriented; oi.exact = job->exact_orientation_scores != 0; oi.d_verr = d_verr;
+  oi.d_ops = static_cast<uint8_t*>(ctx->d_tmp[1].p); oi.d_ops_off = static_cast<const uint64_t*>(ctx->d_tmp[2].p);
+  oi.d_ops_len = static_cast<uint32_t*>(ctx->d_tmp[3].p); oi.d_score = static_cast<int32_t*>(ctx->d_tmp[4].p);
+  OrientOut oo;
+  if ((rc = orient_and_align(ctx, p, oi, oo))) return rc;
+  const bool given = job->oriented != nullptr;
+  std::vector<int32_t>& h_sc2 = oo.sc2;
+  std::vector<uint8_t>&h_fwd = oo.fwd, &h_rc = oo.rc;
 
   // ---- 3. trimReferenceSlice (sage.h:259) ----
   HIP_TRY(ctx->d_tmp[5].ensure(sizeof(TrimOut) * (size_t)nt));
@@ -669,8 +720,12 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
   // job->oriented: the references were anchored and oriented by the caller (indexed genome, indigo.h:213-218):
   // no orientation scores; oriented[t] = rs.forward only steers rs.pos in trimReferenceSlice
   const bool given = job->oriented != nullptr;
+  // FASTA / indexed reference: orientation and the alignment of the trimmed trace run through the stages `tracy align`
+  // uses (checkpointed 16-bit score pass, strand by certificate unless exact_orientation_scores, band traceback).
+  // Wildtype-trace reference: profile x profile, full-matrix traceback (the caller picked the strand).
+  const bool shared_stages = !wildtype;
   std::vector<int32_t> h_sc2(2 * (size_t)nt, 0);
-  if (!given) {
+  if (!given && !shared_stages) {
     DpProblem pb;
     pb.mode = MODE_QP; pb.a1_profile = true; pb.d_a1 = d_prof; pb.d_a2 = ctx->codes();
     pb.desc.resize(2 * (size_t)nt); pb.k.resize(2 * (size_t)nt);
@@ -685,10 +740,11 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
     HIP_TRY(hipMemcpy(h_sc2.data(), b_sc2.p, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost));
   }
   std::vector<uint8_t> h_fwd(nt), h_rc(nt);  // rs.forward / "read the window as its reverse complement"
-  for (uint32_t t = 0; t < nt; ++t) {
-    if (given) { h_fwd[t] = job->oriented[t] ? 1 : 0; h_rc[t] = 0; }
-    else { h_fwd[t] = h_sc2[t] > h_sc2[nt + t] ? 1 : 0; h_rc[t] = !h_fwd[t]; }
-  }
+  if (!shared_stages)
+    for (uint32_t t = 0; t < nt; ++t) {
+      if (given) { h_fwd[t] = job->oriented[t] ? 1 : 0; h_rc[t] = 0; }
+      else { h_fwd[t] = h_sc2[t] > h_sc2[nt + t] ? 1 : 0; h_rc[t] = !h_fwd[t]; }
+    }
 
   // ---- 3. gotoh(trimmedtrace, prefslice) + alignment rows (indigo.h:302) ----
   std::vector<uint64_t> off1(nt);
@@ -701,6 +757,18 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
   HIP_TRY(b_r1.ensure(tot1 ? tot1 : 1));
   const uint64_t* d_off1;
   if ((rc = upload(ctx, buf(), off1, &d_off1))) return rc;
+  if (shared_stages) {
+    std::vector<uint64_t> a1o(nt), a2o(nt);
+    for (uint32_t t = 0; t < nt; ++t) { a1o[t] = sp.offset[t] + tl[t]; a2o[t] = sr.offset[ridx[t]]; }
+    OrientIn oi{};
+    oi.nt = nt; oi.d_prof = d_prof; oi.a1_off = a1o.data(); oi.mf = mf.data(); oi.mt = mt.data(); oi.a2_off = a2o.data(); oi.rn = rn.data();
+    oi.oriented = job->oriented; oi.exact = job->exact_orientation_scores != 0; oi.d_verr = nullptr;
+    oi.d_ops = static_cast<uint8_t*>(b_ops1.p); oi.d_ops_off = d_off1; oi.d_ops_len = static_cast<uint32_t*>(b_len1.p);
+    oi.d_score = static_cast<int32_t*>(d_strim);
+    OrientOut oo;
+    if ((rc = orient_and_align(ctx, p, oi, oo))) return rc;
+    h_sc2 = oo.sc2; h_fwd = oo.fwd; h_rc = oo.rc;
+  }
   std::vector<PairDesc> desc_trim(nt);
   {
     DpProblem pb;
@@ -715,7 +783,8 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
       desc_trim[t] = d;
       pb.k[t] = choose_k(d.m, pb.mode);
     }
-    if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(d_strim), static_cast<uint8_t*>(b_ops1.p), d_off1,
+    if (!shared_stages &&
+        (rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(d_strim), static_cast<uint8_t*>(b_ops1.p), d_off1,
                      static_cast<uint32_t*>(b_len1.p))))
       return rc;
   }

@@ -80,7 +80,7 @@ def main():
     right = int(sum(1 for k, i in enumerate(ok) if abs(int(sd["pos"][i]) + int(res["ref_pos"][k]) - (int(starts[i]) - (50 if not i % 2 else 0))) <= 60))
     line = {"metric": "traces/s (host k-mer seeding + device Gotoh extend, configs[3] in miniature)",
             "value": round(len(ok) / (t_seed + t_ext), 1), "unit": "traces/s", "n_gpus": 1,
-            "seed_traces_per_s": round(nt / t_seed, 1), "seed_threads": os.cpu_count(), "extend_traces_per_s": round(len(ok) / t_ext, 1),
+            "seed_traces_per_s": round(nt / t_seed, 1), "seed_threads": os.cpu_count(), "usable_cores": int(hostlib.lib().tracyhost_usable_threads()), "extend_traces_per_s": round(len(ok) / t_ext, 1),
             "extend_gcups": round(cells / t_ext / 1e9, 1), "index_build_s": round(t_index, 2), "anchored": int(len(ok)), "traces": nt,
             "placed_within_60bp_of_truth": right,
             "config": {"workload": "%d traces of %d bases vs a %.0f Mb synthetic genome, k=15, window = trace + 2*1000" % (nt, mf, args.genome_mb)},

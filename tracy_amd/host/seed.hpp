@@ -22,11 +22,29 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "sage_out.hpp"
 
 namespace tracy_amd {
+
+// Threads worth starting: the hardware threads, capped by the cgroup CPU quota of the container (a 256-thread host
+// that grants 16 CPUs runs 256 compute threads slower than 16).
+inline unsigned usable_threads() {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[32] = {0};
+    unsigned long period = 0;
+    if (std::fscanf(f, "%31s %lu", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0) {
+      const unsigned long q = std::strtoul(quota, nullptr, 10);
+      if (q > 0) n = std::min<unsigned>(n, (unsigned)std::max<unsigned long>(1, q / period));
+    }
+    std::fclose(f);
+  }
+  return n;
+}
 
 class GenomeIndex {
  public:
@@ -88,7 +106,7 @@ class GenomeIndex {
       code = ((code << 2) | (uint64_t)b) & mask;
       if (++valid >= k) table_.push_back(Entry{code, (uint64_t)(p + 1 - k)});
     }
-    if (nthreads == 0) nthreads = std::max(1u, std::thread::hardware_concurrency());
+    if (nthreads == 0) nthreads = usable_threads();
     sort_table(nthreads);
     // bucket directory over the leading bits of the code: a lookup touches one directory slot + one short run
     bucket_bits_ = std::min<uint32_t>(2 * k, 24);

@@ -69,6 +69,10 @@ def main():
     ap.add_argument("--traces", type=int, default=10000, help="traces per GPU per step")
     ap.add_argument("--ref-len", type=int, default=10000)
     ap.add_argument("--trace-len", type=int, default=1000)
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="headline leg: chunks of the batch in flight inside one tracyhip_align_traces call (tracyhip_set_lanes)")
+    ap.add_argument("--lanes-leg", type=int, default=2,
+                    help="also time the batch split over this many lanes (reported beside the headline; 0/1 = skip)")
     ap.add_argument("--certificate-leg", type=int, default=1,
                     help="1: also time the library's default strand-by-certificate mode after the headline leg (reported beside it)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="traces for the CPU baseline (-1: 2 per thread, capped)")
@@ -129,6 +133,9 @@ def main():
 
     ctx = tracy_amd.Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # headline leg: one lane, so that every kernel has the device to itself and its launch duration means what the
+    # roofline block says.  tracyhip_set_lanes (chunks of the batch in flight on their own streams) is timed as a further leg.
+    ctx.set_lanes(max(1, args.lanes))
     lib = capi.lib()
 
     def step():
@@ -176,16 +183,31 @@ def main():
         if not (torch.equal(exact_final, r_i32["score_final"]) and torch.equal(exact_ops, r_ops)):
             raise RuntimeError("strand-by-certificate leg produced different alignments than the exact leg")
 
+    # further legs: the same batch split over `lanes_leg` chunks in flight (own stream + host thread each)
+    elapsed_lanes = [0.0, 0.0]
+    if args.lanes_leg > 1:
+        ctx.set_lanes(args.lanes_leg)
+        for which, exact in ((0, 1), (1, 0)):
+            if exact == 0 and not args.certificate_leg:
+                continue
+            job.exact_orientation_scores = exact
+            elapsed_lanes[which], _ = timed_leg()
+            if args.certificate_leg and not (torch.equal(exact_final, r_i32["score_final"]) and torch.equal(exact_ops, r_ops)):
+                raise RuntimeError("the lanes leg produced different alignments than the headline leg")
+        ctx.set_lanes(max(1, args.lanes))
+    job.exact_orientation_scores = 1
+
     # ---- work done: DP cells of the four Gotoh calls per trace ----
     mt = mf - 2 * TRIM
     cells_rank = int(3 * mt * n * nt + (mf * slice_len).sum())
-    tm = torch.tensor([elapsed, float(cells_rank), elapsed_cert], dtype=torch.float64, device=dev)
+    tm = torch.tensor([elapsed, float(cells_rank), elapsed_cert, elapsed_lanes[0], elapsed_lanes[1]], dtype=torch.float64, device=dev)
     if dist is not None:
         tmax = tm.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tm.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed_max, cells_all, elapsed_cert_max = float(tmax[0]), float(tsum[1]), float(tmax[2])
+        elapsed_lanes = [float(tmax[3]), float(tmax[4])]
     else:
         elapsed_max, cells_all, elapsed_cert_max = elapsed, float(cells_rank), elapsed_cert
 
@@ -246,7 +268,7 @@ def main():
         "config": {"workload": "configs[1]: %d synthetic %d-base traces `align` vs %d-base reference windows per GPU, "
                                "full Gotoh (2 score-only + 2 traceback DPs per trace), scoring 3/-5/-10/-4, trims 50/50"
                                % (nt, mf, n), "traces_per_gpu": nt, "trace_len": mf, "ref_len": n,
-                   "parallelism": "batch-sharded x%d, no data-path collective" % world},
+                   "parallelism": "batch-sharded x%d, no data-path collective" % world, "lanes_per_gpu": max(1, args.lanes)},
         "roofline": roofline,
     }
     if rl_cert is not None:
@@ -265,6 +287,16 @@ def main():
                             "launches": cpf["launches"], "kernel_gcups": round(kgcups(cpf), 1)},
             "alignments_identical_to_headline_leg": True,
         }
+    if args.lanes_leg > 1 and elapsed_lanes[0] > 0:
+        # tracyhip_set_lanes: kernels of different chunks fill each other's tails and the host stages between kernels
+        # overlap with device work.  Same cells, same results; per-kernel durations are not comparable across lanes
+        # (they overlap), which is why the roofline block is measured on the one-lane headline leg.
+        line["lanes"] = {"lanes": args.lanes_leg, "ms_per_step": round(elapsed_lanes[0] / args.steps * 1e3, 3),
+                         "gcups": round(cells_all * args.steps / elapsed_lanes[0] / 1e9, 2),
+                         "traces_per_s": round(nt * world * args.steps / elapsed_lanes[0], 1)}
+        if elapsed_lanes[1] > 0:
+            line["lanes"]["strand_by_certificate"] = {"ms_per_step": round(elapsed_lanes[1] / args.steps * 1e3, 3),
+                                                      "traces_per_s": round(nt * world * args.steps / elapsed_lanes[1], 1)}
     if world == 1:
         nthreads = usable_cores()  # all host cores this process may use, one trace per thread
         sample = args.cpu_sample if args.cpu_sample >= 0 else max(8, min(40 * nthreads, 2048))  # ~10 s of CPU work

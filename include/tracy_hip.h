@@ -94,6 +94,13 @@ int tracyhip_destroy(tracyhip_ctx* ctx);
 int tracyhip_set_stream(tracyhip_ctx* ctx, void* hip_stream);
 /* upper bound for the library's device workspace (traceback planes are chunked to fit); 0 = default */
 int tracyhip_set_workspace_limit(tracyhip_ctx* ctx, uint64_t bytes);
+/* Lanes (1..8, default 1): tracyhip_align_traces / tracyhip_decompose_traces split a batch into `lanes` contiguous
+   chunks and run them concurrently, each on its own stream with its own workspace and host thread.  The chunks'
+   kernels fill each other's tails and the host stages between kernels (orientation decision, trimReferenceSlice
+   geometry) overlap with device work; results are the same arrays as with one lane.  The calls stay synchronous:
+   inputs enqueued on the context's stream are waited for, everything is complete on return.  Needs the per-trace
+   result regions (ops_offset) in trace order; otherwise the call runs on one lane. */
+int tracyhip_set_lanes(tracyhip_ctx* ctx, uint32_t lanes);
 int tracyhip_synchronize(tracyhip_ctx* ctx);
 const char* tracyhip_last_error(void);
 const char* tracyhip_version(void);

@@ -268,3 +268,37 @@ def test_strand_by_certificate(ctx):
         assert (int(fast[l][i]) < int(fast[w][i])) if want["forward"] else (int(fast[l][i]) <= int(fast[w][i]))
         nb += int(fast[l][i]) != want[l]
     assert nb >= 12  # most losers were decided by their bound
+
+
+def test_align_traces_lanes(ctx):
+    """tracyhip_set_lanes: the batch split over concurrent chunks gives the arrays of the single-lane call, in host and
+    in shared-reference (ref_index) form, in both orientation modes"""
+    import tracy_amd
+    from tracy_amd import hostlib
+    nt = 300
+    refs, profs, rev = hostlib.synth_align(9100, nt, 1500, 420, 2)
+    profs = list(profs)
+    refl = [r.tobytes() for r in refs]
+    c3 = tracy_amd.Context(0)
+    c3.set_lanes(3)
+    try:
+        for exact in (True, False):
+            one = ctx.align_traces(profs, refl, SC, 50, 50, exact_scores=exact)
+            many = c3.align_traces(profs, refl, SC, 50, 50, exact_scores=exact)
+            for k in ("score_fwd", "score_rev", "forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
+                assert np.array_equal(np.asarray(one[k]), np.asarray(many[k])), (exact, k)
+            assert one["btr"] == many["btr"]
+        # one shared reference for every trace (the FASTA case of the CLI)
+        ridx = np.zeros(nt, dtype=np.uint32)
+        one = ctx.align_traces(profs, refl[:1], SC, 50, 50, ref_index=ridx)
+        many = c3.align_traces(profs, refl[:1], SC, 50, 50, ref_index=ridx)
+        for k in ("score_fwd", "score_rev", "forward", "score_final", "slice_begin", "slice_len"):
+            assert np.array_equal(np.asarray(one[k]), np.asarray(many[k])), k
+        assert one["btr"] == many["btr"]
+        # an invalid reference is reported from a lane as it is from the single context
+        bad = list(refl)
+        bad[nt - 1] = bad[nt - 1][:-1] + b"x"
+        with pytest.raises(RuntimeError, match="upper-case"):
+            c3.align_traces(profs, bad, SC, 50, 50)
+    finally:
+        c3.set_lanes(1)

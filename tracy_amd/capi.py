@@ -141,6 +141,10 @@ class Context:
     def set_workspace_limit(self, nbytes):
         _check(lib().tracyhip_set_workspace_limit(self._h, C.c_uint64(nbytes)))
 
+    def set_lanes(self, n):
+        """batch pipelines split a call into n chunks in flight (own stream + host thread each); 1 = off"""
+        _check(lib().tracyhip_set_lanes(self._h, C.c_uint32(n)))
+
     def synchronize(self):
         _check(lib().tracyhip_synchronize(self._h))
 

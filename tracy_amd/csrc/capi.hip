@@ -436,6 +436,8 @@ int tracyhip_destroy(tracyhip_ctx* c) {
   if (!c) return TRACYHIP_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  for (auto* l : c->lanes) tracyhip_destroy(l);
+  c->lanes.clear();
   c->release_all();
   for (auto& p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
   for (auto e : c->free_events) (void)hipEventDestroy(e);
@@ -453,22 +455,47 @@ int tracyhip_set_stream(tracyhip_ctx* c, void* s) {
 int tracyhip_set_workspace_limit(tracyhip_ctx* c, uint64_t bytes) {
   if (!c) return set_error(TRACYHIP_ERR_ARG, "null context");
   c->ws_limit = bytes;
+  for (auto* l : c->lanes) l->ws_limit = bytes;
+  return TRACYHIP_OK;
+}
+
+int tracyhip_set_lanes(tracyhip_ctx* c, uint32_t n) {
+  if (!c) return set_error(TRACYHIP_ERR_ARG, "null context");
+  if (n < 1 || n > 8) return set_error(TRACYHIP_ERR_ARG, "lanes must be in [1, 8]");
+  int rc = ctx_begin(c);
+  if (rc) return rc;
+  const size_t want = n - 1;  // the context itself is the first lane
+  while (c->lanes.size() > want) { tracyhip_destroy(c->lanes.back()); c->lanes.pop_back(); }
+  while (c->lanes.size() < want) {
+    tracyhip_ctx* l = nullptr;
+    if ((rc = tracyhip_create(c->device, &l))) return rc;
+    l->ws_limit = c->ws_limit;
+    l->timing = c->timing;
+    l->no_narrow = c->no_narrow;
+    c->lanes.push_back(l);
+  }
   return TRACYHIP_OK;
 }
 
 int tracyhip_timing_enable(tracyhip_ctx* c, int on) {
   if (!c) return set_error(TRACYHIP_ERR_ARG, "null context");
   c->timing = on != 0;
+  for (auto* l : c->lanes) l->timing = c->timing;
   return TRACYHIP_OK;
 }
 int tracyhip_timing_reset(tracyhip_ctx* c) {
   if (!c) return set_error(TRACYHIP_ERR_ARG, "null context");
   for (auto& a : c->acc) a = tracyhip_kernel_timing{};
+  for (auto* l : c->lanes) tracyhip_timing_reset(l);
   return TRACYHIP_OK;
 }
 int tracyhip_timing_get(tracyhip_ctx* c, int which, tracyhip_kernel_timing* out) {
   if (!c || !out || which < 0 || which > 4) return set_error(TRACYHIP_ERR_ARG, "bad timing query");
   *out = c->acc[which];
+  for (auto* l : c->lanes) {  // kernels of different lanes overlap on the device: their durations add up here
+    out->ms += l->acc[which].ms; out->launches += l->acc[which].launches;
+    out->cells += l->acc[which].cells; out->bytes += l->acc[which].bytes;
+  }
   return TRACYHIP_OK;
 }
 

@@ -68,6 +68,9 @@ struct tracyhip_ctx {
   tracyhip::PinBuf h_desc, h_off, h_tmp;
   // kernel timing
   struct Pending { int which; hipEvent_t e0, e1; uint64_t cells, bytes; };
+  // lanes: further contexts (own stream, own buffers) the batch pipelines split a call over, one host thread each
+  // (tracyhip_set_lanes); this context is the first lane, empty = the pipelines run on it alone
+  std::vector<tracyhip_ctx*> lanes;
   bool timing = false;
   bool no_narrow = false;  // TRACYHIP_NO_NARROW=1: force the int32 score kernel (A/B measurements)
   std::vector<Pending> pending;

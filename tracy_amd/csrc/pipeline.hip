@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tracy_hip.h"
@@ -384,8 +386,8 @@ int orient_and_align(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn
 
 }  // namespace
 
-extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
-                                     const tracyhip_align_result* out) {
+static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
+                            const tracyhip_align_result* out) {
   int rc = ctx_begin(ctx);
   if (rc) return rc;
   if (!job || !out || !prm) return set_error(TRACYHIP_ERR_ARG, "null job/result/params");
@@ -548,6 +550,108 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   }
   HIP_TRY(hipStreamSynchronize(st));
   return TRACYHIP_OK;
+}
+
+// ---- lanes: one call, several chunks in flight (tracyhip_set_lanes) ----------------------------------
+namespace {
+
+// a contiguous run [lo, lo + k) of a sequence set as a set of its own: offsets rebased to the run's first element
+// so that host-staged payloads travel once, with the chunk that uses them
+struct SubSet {
+  tracyhip_seqset s;
+  std::vector<uint64_t> off;
+};
+void sub_seqset(const tracyhip_seqset& full, uint32_t lo, uint32_t k, size_t elem_bytes, SubSet& o) {
+  uint64_t base = k ? ~0ull : 0ull;
+  for (uint32_t i = 0; i < k; ++i) base = std::min<uint64_t>(base, full.offset[lo + i]);
+  o.off.resize(k);
+  for (uint32_t i = 0; i < k; ++i) o.off[i] = full.offset[lo + i] - base;
+  o.s = full;
+  o.s.data = full.data ? static_cast<const char*>(full.data) + base * elem_bytes : nullptr;
+  o.s.offset = o.off.data();
+  o.s.length = full.length + lo;
+  o.s.count = k;
+}
+// result regions addressed by a host offset array: same idea (the chunk sees its own window of the buffer)
+struct SubOffsets {
+  std::vector<uint64_t> off;
+  uint64_t base = 0;
+};
+void sub_offsets(const uint64_t* full, uint32_t lo, uint32_t k, SubOffsets& o) {
+  o.base = k ? full[lo] : 0;
+  o.off.resize(k);
+  for (uint32_t i = 0; i < k; ++i) o.off[i] = full[lo + i] - o.base;
+}
+bool nondecreasing(const uint64_t* a, uint32_t n) {
+  for (uint32_t i = 1; i < n; ++i)
+    if (a[i] < a[i - 1]) return false;
+  return true;
+}
+template <class T>
+T* shifted(T* p, uint64_t by) { return p ? p + by : nullptr; }
+
+// run fn(context, chunk index, lo, k) for every chunk: chunk 0 on the calling thread with the context itself, the
+// others on their lane's own thread; first error wins
+template <class Fn>
+int run_lanes(tracyhip_ctx* ctx, uint32_t nt, Fn fn) {
+  const uint32_t L = (uint32_t)ctx->lanes.size() + 1;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));  // inputs the caller enqueued on the context's stream
+  std::vector<int> rcs(L, TRACYHIP_OK);
+  std::vector<std::string> msgs(L);
+  std::vector<std::thread> th;
+  auto bounds = [&](uint32_t c, uint32_t& lo, uint32_t& hi) { lo = (uint32_t)((uint64_t)nt * c / L); hi = (uint32_t)((uint64_t)nt * (c + 1) / L); };
+  for (uint32_t c = 1; c < L; ++c) {
+    uint32_t lo, hi;
+    bounds(c, lo, hi);
+    th.emplace_back([&, c, lo, hi]() {
+      rcs[c] = fn(ctx->lanes[c - 1], c, lo, hi - lo);
+      if (rcs[c] != TRACYHIP_OK) msgs[c] = tracyhip_last_error();  // the message lives in that thread
+    });
+  }
+  {
+    uint32_t lo, hi;
+    bounds(0, lo, hi);
+    rcs[0] = fn(ctx, 0, lo, hi - lo);
+    if (rcs[0] != TRACYHIP_OK) msgs[0] = tracyhip_last_error();
+  }
+  for (auto& t : th) t.join();
+  for (uint32_t c = 0; c < L; ++c)
+    if (rcs[c] != TRACYHIP_OK) return set_error(rcs[c], "%s", msgs[c].c_str());
+  return TRACYHIP_OK;
+}
+constexpr uint32_t kMinLaneChunk = 64;  // below this a chunk cannot fill the device anyway
+
+}  // namespace
+
+extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
+                                     const tracyhip_align_result* out) {
+  if (!ctx) return set_error(TRACYHIP_ERR_ARG, "null context");
+  const uint32_t L = (uint32_t)ctx->lanes.size() + 1;
+  const bool split = L >= 2 && job && out && prm && job->ntraces >= L * kMinLaneChunk && job->profiles.offset && job->profiles.length &&
+                     job->refs.offset && job->refs.length && job->profiles.count >= job->ntraces && out->ops_offset &&
+                     (job->ref_index || job->refs.count >= job->ntraces) && nondecreasing(out->ops_offset, job->ntraces);
+  if (!split) return align_traces_one(ctx, job, prm, mem, out);
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  return run_lanes(ctx, job->ntraces, [&](tracyhip_ctx* lane, uint32_t, uint32_t lo, uint32_t k) -> int {
+    if (k == 0) return TRACYHIP_OK;
+    tracyhip_align_job j = *job;
+    tracyhip_align_result o = *out;
+    SubSet sp, sr;
+    SubOffsets so;
+    j.ntraces = k;
+    sub_seqset(job->profiles, lo, k, sizeof(float), sp);
+    j.profiles = sp.s;
+    if (job->ref_index) j.ref_index = job->ref_index + lo;  // shared references: the whole set goes with every chunk
+    else { sub_seqset(job->refs, lo, k, 1, sr); j.refs = sr.s; }
+    j.oriented = shifted(job->oriented, lo);
+    sub_offsets(out->ops_offset, lo, k, so);
+    o.score_fwd = shifted(out->score_fwd, lo); o.score_rev = shifted(out->score_rev, lo); o.forward = shifted(out->forward, lo);
+    o.score_prelim = shifted(out->score_prelim, lo); o.slice_begin = shifted(out->slice_begin, lo);
+    o.slice_len = shifted(out->slice_len, lo); o.ref_pos = shifted(out->ref_pos, lo); o.score_final = shifted(out->score_final, lo);
+    o.ops = shifted(out->ops, so.base); o.ops_offset = so.off.data(); o.ops_len = shifted(out->ops_len, lo);
+    return align_traces_one(lane, &j, prm, mem, &o);
+  });
 }
 
 // =====================================================================================================

@@ -126,3 +126,35 @@ def test_decompose_traces_pipeline(ctx):
             for nm in ("slice_begin", "slice_len", "ref_pos"):
                 assert int(got["%s%d" % (nm, k)][i]) == int(w["%s%d" % (nm, k)]), (i, nm, k)
     assert sorted(got["forward"].tolist()) == [0, 0, 1, 1, 1]
+
+
+def test_decompose_traces_lanes(ctx):
+    """tracyhip_set_lanes: tracyhip_decompose_traces split over chunks in flight returns what the single-lane call returns
+    (host-staged buffers: every payload and result region travels with its chunk)"""
+    import tracy_amd
+    from tracy_amd import capi, hostlib
+    nd = 260
+    d = hostlib.synth_decompose_batch(4242, nd, 1500, 520, 0)
+
+    def run(c):
+        hbc = capi.HostBaseCalls([d["signal"][i] for i in range(nd)], [d["bcpos"][i] for i in range(nd)],
+                                 [d["primary"][i].tobytes() for i in range(nd)], [d["secondary"][i].tobytes() for i in range(nd)])
+        return c.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, [d["refs"][i].tobytes() for i in range(nd)], SC)
+    one = run(ctx)
+    c3 = tracy_amd.Context(0)
+    c3.set_lanes(3)
+    try:
+        many = run(c3)
+    finally:
+        c3.set_lanes(1)
+    assert int((np.asarray(one["status"]) == 0).sum()) > nd // 2
+    for k in one:
+        a, b = one[k], many[k]
+        if k == "bp":
+            assert [(x.indelshift, x.traceleft, x.breakpoint, x.best_diff) for x in a] == [(x.indelshift, x.traceleft, x.breakpoint, x.best_diff) for x in b]
+        elif isinstance(a, np.ndarray):
+            assert np.array_equal(a, b), k
+        elif isinstance(a, (list, tuple, dict, int, float, str, bytes)):
+            assert a == b, k
+        else:  # ctypes arrays of result records
+            assert bytes(a) == bytes(b), k

@@ -127,6 +127,12 @@ def main():
     dt_cert = leg()
     same = all(torch.equal(snap[k], res[k]) for k in snap) and all(torch.equal(a, x[1]) for a, x in zip(snap_ops, keep))
     job.exact_orientation_scores = 1
+    ctx.set_lanes(2)  # the same batch as two chunks in flight (tracyhip_set_lanes)
+    dt_lanes = leg()
+    job.exact_orientation_scores = 0
+    dt_lanes_cert = leg()
+    job.exact_orientation_scores = 1
+    ctx.set_lanes(1)
     mt = mf - 100
     sl = [res["slice_len%d" % k].cpu().numpy().astype(np.int64) for k in range(2)]
     cells = 3 * mt * n * nt + 2 * mt * n * nt + int((mt * sl[0]).sum() + (mt * sl[1]).sum()) + mt * mt * nt
@@ -136,7 +142,10 @@ def main():
             "config": {"workload": "configs[2]: %d synthetic heterozygous %d-base traces `decompose` vs %d-base windows" % (nt, mf, n)},
             "traces_ok": int((status == 0).sum()), "data": "synthetic",
             "strand_by_certificate": {"ms_per_step": round(dt_cert / args.steps * 1e3, 2), "traces_per_s": round(nt * args.steps / dt_cert, 1),
-                                      "results_identical_to_headline_leg": bool(same)}}
+                                      "results_identical_to_headline_leg": bool(same)},
+            "lanes": {"lanes": 2, "ms_per_step": round(dt_lanes / args.steps * 1e3, 2), "traces_per_s": round(nt * args.steps / dt_lanes, 1),
+                      "strand_by_certificate": {"ms_per_step": round(dt_lanes_cert / args.steps * 1e3, 2),
+                                                "traces_per_s": round(nt * args.steps / dt_lanes_cert, 1)}}}
     if args.cpu_sample > 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         sys.path.insert(0, os.path.join(ROOT, "tests"))

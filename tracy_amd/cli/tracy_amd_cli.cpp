@@ -497,6 +497,7 @@ int align_main(int argc, char** argv) {
     gpu_fail("no usable GPU");
     return -1;
   }
+  tracyhip_set_lanes(dev.ctx, 2);  // --batch manifests: two chunks of a batch in flight (small batches run on one lane)
   tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};  // AlignConfig<true,false>, sage.h:165
   std::map<std::pair<uint32_t, uint32_t>, std::vector<Job*>> fasta_groups, seeded_groups;
   std::vector<Job*> wildtype;
@@ -864,6 +865,7 @@ int decompose_main(int argc, char** argv) {
     gpu_fail("no usable GPU");
     return -1;
   }
+  tracyhip_set_lanes(dev.ctx, 2);  // --batch manifests: two chunks of a batch in flight (small batches run on one lane)
   tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};
   std::map<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>, std::vector<Job*>> groups;  // (reference kind, trims)
   for (Job& j : jobs)

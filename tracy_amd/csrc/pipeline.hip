@@ -677,8 +677,8 @@ struct DevOut {  // a result array: the user's (DEVICE) or a staging buffer (HOS
 
 }  // namespace
 
-extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
-                                         const tracyhip_decompose_result* out) {
+static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
+                               const tracyhip_decompose_result* out) {
   int rc = ctx_begin(ctx);
   if (rc) return rc;
   if (!job || !out || !prm) return set_error(TRACYHIP_ERR_ARG, "null job/result/params");
@@ -1073,4 +1073,64 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
     if (o.bytes) HIP_TRY(hipMemcpyAsync(o.user, o.dev, o.bytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return TRACYHIP_OK;
+}
+
+// lanes (tracyhip_set_lanes): contiguous chunks of the batch in flight, as tracyhip_align_traces
+extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
+                                         const tracyhip_decompose_result* out) {
+  if (!ctx) return set_error(TRACYHIP_ERR_ARG, "null context");
+  const uint32_t L = (uint32_t)ctx->lanes.size() + 1;
+  bool split = L >= 2 && job && out && prm && job->ntraces >= L * kMinLaneChunk && job->profiles.offset && job->profiles.length &&
+               job->refs.offset && job->refs.length && job->profiles.count >= job->ntraces && job->bc.ntraces >= job->ntraces &&
+               job->bc.signal_offset && job->bc.nsamples && job->bc.bc_offset && job->bc.bc_len && out->dcp_offset &&
+               (job->ref_index || job->refs.count >= job->ntraces);
+  if (split) {
+    const uint32_t nt = job->ntraces;
+    split = nondecreasing(job->bc.signal_offset, nt) && nondecreasing(job->bc.bc_offset, nt) && nondecreasing(out->dcp_offset, nt);
+    for (int k = 0; k < 3 && split; ++k) split = out->ops_offset[k] && nondecreasing(out->ops_offset[k], nt);
+    if (job->ref_profiles.data && !job->ref_index)
+      split = split && job->ref_profiles.offset && job->ref_profiles.length && job->ref_profiles.count >= nt;
+  }
+  if (!split) return decompose_traces_one(ctx, job, prm, mem, out);
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  return run_lanes(ctx, job->ntraces, [&](tracyhip_ctx* lane, uint32_t, uint32_t lo, uint32_t k) -> int {
+    if (k == 0) return TRACYHIP_OK;
+    tracyhip_decompose_job j = *job;
+    tracyhip_decompose_result o = *out;
+    SubSet sp, sr, srp;
+    SubOffsets sig, bco, dcp, ops[3];
+    j.ntraces = k;
+    sub_seqset(job->profiles, lo, k, sizeof(float), sp);
+    j.profiles = sp.s;
+    if (job->ref_index) j.ref_index = job->ref_index + lo;
+    else {
+      sub_seqset(job->refs, lo, k, 1, sr);
+      j.refs = sr.s;
+      if (job->ref_profiles.data) { sub_seqset(job->ref_profiles, lo, k, sizeof(float), srp); j.ref_profiles = srp.s; }
+    }
+    j.oriented = shifted(job->oriented, lo);
+    // Trace + BaseCalls: signal by signal_offset, the per-base arrays by bc_offset
+    sub_offsets(job->bc.signal_offset, lo, k, sig);
+    sub_offsets(job->bc.bc_offset, lo, k, bco);
+    j.bc.ntraces = k;
+    j.bc.signal = shifted(job->bc.signal, sig.base); j.bc.signal_offset = sig.off.data(); j.bc.nsamples = job->bc.nsamples + lo;
+    j.bc.bcpos = shifted(job->bc.bcpos, bco.base); j.bc.primary = shifted(job->bc.primary, bco.base);
+    j.bc.secondary = shifted(job->bc.secondary, bco.base); j.bc.bc_offset = bco.off.data(); j.bc.bc_len = job->bc.bc_len + lo;
+    // results
+    o.bp = shifted(out->bp, lo); o.status = shifted(out->status, lo); o.score_fwd = shifted(out->score_fwd, lo);
+    o.score_rev = shifted(out->score_rev, lo); o.forward = shifted(out->forward, lo); o.score_trim = shifted(out->score_trim, lo);
+    sub_offsets(out->dcp_offset, lo, k, dcp);
+    o.dcp_indel = shifted(out->dcp_indel, dcp.base); o.dcp_err = shifted(out->dcp_err, dcp.base); o.dcp_offset = dcp.off.data();
+    o.dstatus = shifted(out->dstatus, lo); o.secdecomp = shifted(out->secdecomp, bco.base); o.fractions = shifted(out->fractions, 2ull * lo);
+    for (int a = 0; a < 2; ++a) {
+      o.slice_begin[a] = shifted(out->slice_begin[a], lo); o.slice_len[a] = shifted(out->slice_len[a], lo); o.ref_pos[a] = shifted(out->ref_pos[a], lo);
+    }
+    for (int a = 0; a < 3; ++a) {
+      sub_offsets(out->ops_offset[a], lo, k, ops[a]);
+      o.score[a] = shifted(out->score[a], lo); o.ops[a] = shifted(out->ops[a], ops[a].base);
+      o.ops_offset[a] = ops[a].off.data(); o.ops_len[a] = shifted(out->ops_len[a], lo);
+    }
+    return decompose_traces_one(lane, &j, prm, mem, &o);
+  });
 }

@@ -31,6 +31,10 @@ struct HostWave {
     sh->bar.arrive_and_wait();
     return r;
   }
+  int32_t shift_up_or(int32_t x, int32_t first) {  // as shift_up, lane 0 keeps `first` (the DPP `old` operand)
+    const int32_t r = shift_up(x);
+    return lane_ ? r : first;
+  }
   uint64_t ballot(bool p) {
     sh->xchg[lane_] = p ? 1 : 0;
     sh->bar.arrive_and_wait();

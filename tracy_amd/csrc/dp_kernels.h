@@ -308,18 +308,21 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     const bool rcflag = (d.flags & PAIR_A2_REVCOMP) != 0;
     auto do_step = [&](uint32_t t, const auto& sub) {
       const int32_t c = (int32_t)t - (int32_t)L;
-      int32_t up_h = w.shift_up(bot_h);
-      int32_t up_f = w.shift_up(bot_f);
-      const bool active = (c >= 1) && (c <= (int32_t)n);
+      int32_t up_h, up_f;
+      if (p == 0) {
+        // row 0 (gotoh.h:112-116) enters through the shift itself: lane 0 has no source lane and keeps the DPP `old`
+        // operand, which is H(0, t) / F(0, t) -- lane 0 sits in column c = t, so the value is scalar work
+        up_h = w.shift_up_or(bot_h, (int32_t)((uint32_t)edge_value(hfree, go, ge, (int32_t)t) << SH) + goe_n);
+        up_f = w.shift_up_or(bot_f, neg);
+      } else {
+        up_h = w.shift_up(bot_h);
+        up_f = w.shift_up(bot_f);
+      }
+      const bool active = (uint32_t)(t - 1u - L) < n;  // 1 <= c <= n
       if (active) {
-        if (L == 0) {
-          if (p == 0) {  // row 0 (gotoh.h:112-116)
-            up_h = (int32_t)((uint32_t)edge_value(hfree, go, ge, c) << SH) + goe_n;
-            up_f = neg;
-          } else {  // last row of the previous pass
-            up_h = scratch[2 * c];
-            up_f = scratch[2 * c + 1];
-          }
+        if (p != 0 && L == 0) {  // last row of the previous pass
+          up_h = scratch[2 * c];
+          up_f = scratch[2 * c + 1];
         }
         int32_t vopen = go + ge, vext = ge;
         if (vfree) {  // free end gap in the last column.  vfree is wave-uniform: keep it a scalar branch

@@ -25,6 +25,10 @@ struct DeviceWave {
   __device__ __forceinline__ int32_t shift_up(int32_t x) const {
     return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true);
   }
+  // same shift, lane 0 keeps `first`: the DPP `old` operand is what a lane without a source keeps (bound_ctrl off)
+  __device__ __forceinline__ int32_t shift_up_or(int32_t x, int32_t first) const {
+    return __builtin_amdgcn_update_dpp(first, x, 0x138, 0xf, 0xf, false);
+  }
   __device__ __forceinline__ uint64_t ballot(bool p) const { return __ballot(p); }
   __device__ __forceinline__ uint32_t bcast(uint32_t x, uint32_t src_lane) const { return (uint32_t)__shfl((int)x, (int)src_lane, 64); }
   __device__ __forceinline__ void sync() const { __syncthreads(); }

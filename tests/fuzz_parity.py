@@ -49,6 +49,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=1500)
     ap.add_argument("--traces", type=int, default=96)
+    ap.add_argument("--lanes", type=int, default=1, help="tracyhip_set_lanes for the pipeline calls")
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
     import pyoracle as orc
@@ -58,6 +59,7 @@ def main():
     import indigo_oracle as io
     rng = np.random.default_rng(args.seed)
     ctx = tracy_amd.Context(0)
+    ctx.set_lanes(max(1, args.lanes))
     bad, done = [], {}
     pool = ThreadPoolExecutor(max_workers=16)
 

@@ -263,7 +263,7 @@ def main():
         "metric": "GCUPS (tracy align: Gotoh affine-gap DP cells per second, whole job)",
         "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "int16 (score sweeps) / int32 (tracebacks)", "data": "synthetic",
         "traces_per_s": round(nt * world * args.steps / elapsed_max, 1),
         "config": {"workload": "configs[1]: %d synthetic %d-base traces `align` vs %d-base reference windows per GPU, "
                                "full Gotoh (2 score-only + 2 traceback DPs per trace), scoring 3/-5/-10/-4, trims 50/50"

@@ -269,6 +269,10 @@ def main():
                                "full Gotoh (2 score-only + 2 traceback DPs per trace), scoring 3/-5/-10/-4, trims 50/50"
                                % (nt, mf, n), "traces_per_gpu": nt, "trace_len": mf, "ref_len": n,
                    "parallelism": "batch-sharded x%d, no data-path collective" % world, "lanes_per_gpu": max(1, args.lanes)},
+        # GCUPS counts the DP cells of the reference's four Gotoh calls per trace: two score-only sweeps and
+        # the final traceback are swept in full; the preliminary traceback is a band traceback from the score sweep's
+        # checkpoints, which re-sweeps only the bands its path crosses (about an eighth of its matrix) for the same `btr`
+        "cells_counted": "reference DP cells: 3 x (mt x n) + mf x slice per trace; the preliminary traceback re-sweeps ~12% of its mt x n",
         "roofline": roofline,
     }
     if rl_cert is not None:

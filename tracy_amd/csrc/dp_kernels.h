@@ -138,8 +138,40 @@ struct SubProf {
   float b[5];
   float fmatch, fmis;
   int shift;
-  TR_HD int32_t operator()(int i) const { return (int32_t)((uint32_t)profile_score<NT>(a[i], b, fmatch, fmis) << shift); }
-  TR_HD int32_t lo16(int i) const { return (*this)(i); }
+  int32_t sv[K];  // scores of the current column, filled by prepare()
+  // Two rows at a time: the same k1-outer / k2-inner chain of rounded multiplies and adds per row (align.h:112-116),
+  // carried in the two halves of packed fp32 operations (v_pk_mul_f32 / v_pk_add_f32: one issue slot for two rows).
+  TR_HD void prepare() {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang fp contract(off)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i + 1 < K; i += 2) {
+      f2 acc = {0.0f, 0.0f};
+#pragma unroll
+      for (int k1 = 0; k1 < NT; ++k1) {
+        const f2 x = {a[i][k1], a[i + 1][k1]};
+#pragma unroll
+        for (int k2 = 0; k2 < NT; ++k2) {
+          const float w = (k1 == k2) ? fmatch : fmis;
+          const f2 bb = {b[k2], b[k2]};
+          const f2 ww = {w, w};
+          const f2 t = x * bb;
+          const f2 u = t * ww;
+          acc = acc + u;
+        }
+      }
+      sv[i] = (int32_t)((uint32_t)(int32_t)acc.x << shift);
+      sv[i + 1] = (int32_t)((uint32_t)(int32_t)acc.y << shift);
+    }
+    if (K & 1) sv[K - 1] = (int32_t)((uint32_t)profile_score<NT>(a[K - 1], b, fmatch, fmis) << shift);
+#else
+#pragma unroll
+    for (int i = 0; i < K; ++i) sv[i] = (int32_t)((uint32_t)profile_score<NT>(a[i], b, fmatch, fmis) << shift);
+#endif
+  }
+  TR_HD int32_t operator()(int i) const { return sv[i]; }
+  TR_HD int32_t lo16(int i) const { return sv[i]; }
 };
 
 // LDS bytes a (mode, K) kernel needs
@@ -418,6 +450,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
           const uint32_t ci = col_at((int32_t)t - (int32_t)L + 1);
 #pragma unroll
           for (int k = 0; k < 5; ++k) nb[k] = a2p[(uint64_t)k * d.a2_stride + ci];
+          sub.prepare();
           do_step(t, sub);
         }
       };

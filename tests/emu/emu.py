@@ -113,3 +113,18 @@ def run_prefix(profiles, refs, score, K, revcomp=None):
                           p(n, C.c_uint32), p(flags, C.c_uint32), *[int(x) for x in score], p(out, C.c_int32), C.byref(err))
     assert rc == 0
     return out.tolist(), err.value
+
+
+def run_origin(a1, a2, score, K, revcomp=False):
+    """origin-tracking sweep body on one emulated wave (string x string, semiglobal): (score, leading 'h' columns,
+    last column that is not a trailing 'h')"""
+    m, n = len(a1), len(a2)
+    b1 = np.frombuffer(bytes(a1) + b"\0", dtype=np.uint8).copy()
+    b2 = np.frombuffer(bytes(a2) + b"\0", dtype=np.uint8).copy()
+    sc = C.c_int32(0)
+    ends = np.zeros(2, np.uint32)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = lib().emu_origin(K, p(b1, C.c_uint8), C.c_uint32(m), p(b2, C.c_uint8), C.c_uint32(n), C.c_uint32(1 if revcomp else 0),
+                          *[int(x) for x in score], C.byref(sc), p(ends, C.c_uint32))
+    assert rc == 0
+    return sc.value, int(ends[0]), int(ends[1])

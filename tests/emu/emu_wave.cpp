@@ -108,6 +108,16 @@ void run_ckpt_pair(const DpArgs& a, const WalkArgs& wa) {
 }
 
 template <int K>
+void run_origin_wave(const DpArgs& a) {
+  WaveShared sh;
+  sh.lds.assign(64, 0);
+  std::vector<std::thread> th;
+  for (uint32_t l = 0; l < 64; ++l)
+    th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_origin_body<HostWave, K>(w, a, 0); });
+  for (auto& t : th) t.join();
+}
+
+template <int K>
 void run_prefix_wave(const DpArgs& a, uint32_t npairs) {
   WaveShared sh;
   sh.lds.assign(lds_bytes(MODE_QP, K) + 64, 0);
@@ -149,6 +159,26 @@ int emu_prefix(int K, uint32_t npairs, const float* a1, const uint64_t* a1_off, 
     default: return -1;
   }
   if (err_out) *err_out = err;
+  return 0;
+}
+
+// origin-tracking sweep of one string x string pair (AlignConfig<true,false>, single pass): score and the two ends
+int emu_origin(int K, const uint8_t* a1, uint32_t m, const uint8_t* a2, uint32_t n, uint32_t flags, int32_t match, int32_t mismatch,
+               int32_t go, int32_t ge, int32_t* score, uint32_t* ends) {
+  PairDesc d{};
+  d.m = m; d.n = n; d.a1_stride = m; d.a2_stride = n; d.flags = flags; d.out = 0;
+  int32_t err = 0;
+  DpArgs a{};
+  a.pairs = &d; a.a1 = a1; a.a2 = a2; a.scores = score; a.err = &err; a.ends = ends;
+  a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = 1; a.vfree = 0;
+  switch (K) {
+    case 4: run_origin_wave<4>(a); break;
+    case 8: run_origin_wave<8>(a); break;
+    case 12: run_origin_wave<12>(a); break;
+    case 15: run_origin_wave<15>(a); break;
+    case 16: run_origin_wave<16>(a); break;
+    default: return -1;
+  }
   return 0;
 }
 

@@ -245,3 +245,34 @@ def test_prefix_bound_kernel(K):
             H, F = orc.gotoh_row_state(profs[i], p2, R, SC)
             assert got[i] == int(max(H.max(), F.max())), (K, npairs, i)
         assert got[0] > 0
+
+
+def test_origin_sweep_ends():
+    """gotoh_origin_body (the sweep behind trimReferenceSlice in the decompose pipeline): H(m,n), the number of leading
+    'h' columns and the last column before the trailing 'h' run equal those of the reference's traceback string"""
+    import emu
+    import pyoracle as orc
+    from sage_oracle import revcomp
+    rng = np.random.default_rng(77)
+    sc = (3, -5, -10, -4)
+
+    def ends_of(btr, n):  # push-order string: trailing run first
+        fwd = btr[::-1]
+        lead = len(fwd) - len(fwd.lstrip(b"h")) if isinstance(fwd, bytes) else len(fwd) - len(fwd.lstrip("h"))
+        trail = len(fwd) - len(fwd.rstrip(b"h")) if isinstance(fwd, bytes) else len(fwd) - len(fwd.rstrip("h"))
+        return lead, n - trail
+    cases = [(1, 1, 4), (3, 40, 4), (17, 9, 4), (60, 200, 4), (64, 130, 8), (200, 500, 8), (255, 300, 4), (300, 90, 8), (500, 900, 8)]
+    for (m, n, K) in cases:
+        for rep in range(3):
+            ref = bytes(rng.choice(list(b"ACGT" if rep else b"AC"), size=n).tolist())
+            start = int(rng.integers(0, max(1, n - m + 1)))
+            q = bytearray((ref[start:start + m] + bytes(rng.choice(list(b"ACGT"), size=m).tolist()))[:m])
+            for j in range(m):  # substitutions and a little structure that creates ties (repeats, N)
+                if rng.random() < 0.08:
+                    q[j] = int(rng.choice(list(b"ACGTN")))
+            q = bytes(q)
+            rc = bool(rep == 2)
+            oriented = revcomp(ref) if rc else ref
+            want_score, want_btr = orc.gotoh_str(q, oriented, 1, 0, sc)
+            got = emu.run_origin(q, ref, sc, K, revcomp=rc)
+            assert got == (want_score,) + ends_of(want_btr, n), (m, n, K, rep, got, want_score, ends_of(want_btr, n))

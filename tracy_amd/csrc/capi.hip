@@ -189,6 +189,17 @@ bool narrow_ok(const tracyhip_params* prm, uint32_t maxm, int K) {
   return (low < -(int64_t)kNegInf16 - ab(prm->ge) - 64) && (high < 30000);
 }
 
+bool origin_ok(const tracyhip_params* prm, uint32_t maxm, uint32_t maxn, int K) {
+  if (!prm->hfree || prm->vfree || prm->go > 0 || prm->ge >= 0 || num_passes(maxm ? maxm : 1, K) != 1) return false;
+  if ((uint64_t)maxn + 64 >= (1u << kOriginBits)) return false;
+  auto ab = [](int32_t x) { return (int64_t)(x < 0 ? -(int64_t)x : x); };
+  const int64_t rows = 64 * (int64_t)K;
+  const int64_t low = ab(prm->go) + rows * ab(prm->ge) + 2 * (ab(prm->go) + ab(prm->ge)) + ab(prm->mismatch) + ab(prm->match);
+  const int64_t high = rows * std::max(ab(prm->match), ab(prm->mismatch));
+  // 14-bit score field [-8192, 8191]; the sentinel kNegInfOrigin must stay below every real value and above the field's floor
+  return (low < -(int64_t)kNegInfOrigin - ab(prm->ge) - 64) && (-(int64_t)kNegInfOrigin + ab(prm->go) + ab(prm->ge) < 8000) && (high < 8000);
+}
+
 int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, bool needle, bool trace,
            int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len, int stage, DpCkpt* ck) {
   const uint32_t np = (uint32_t)pb.desc.size();
@@ -266,6 +277,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   a.err = static_cast<int32_t*>(ctx->d_err.p);
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge;
   a.hfree = prm->hfree; a.vfree = prm->vfree;
+  if (ck) a.ends = ck->d_ends;
   if (ck) { a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.band = static_cast<uint64_t*>(ctx->d_band.p); a.ckpt_narrow = ck->narrow ? 1 : 0; }
   const PairDesc* dd = static_cast<const PairDesc*>(ctx->d_desc.p);
 
@@ -296,6 +308,8 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
       }
       if (stage == DP_PREFIX) {
         HIP_TRY(launch_gotoh_prefix(K, a, e - j, st));
+      } else if (stage == DP_ORIGIN) {
+        HIP_TRY(launch_gotoh_origin(K, a, e - j, st));
       } else if (stage == DP_CKPT) {
         // one representation for the whole batch: the caller checks narrow_ok for the largest problem
         narrow = ck->narrow;

@@ -101,13 +101,17 @@ int check_params(const tracyhip_params* prm, uint64_t max_mn);
 // checkpoints + last-row values (PairDesc::ckpt_off / lastrow_off set by the caller); DP_BAND = band traceback
 // from those checkpoints (trace must be true); DP_PREFIX = prefix bound of the semiglobal score (rows 1 .. kPrefixLanes*K of
 // profile x code pairs, 16-bit domain): d_scores receives max_j max(H, F) of that row.
-enum { DP_PLAIN = 0, DP_CKPT = 1, DP_BAND = 2, DP_PREFIX = 3 };
+// DP_ORIGIN = origin-tracking sweep of string x string pairs (DpCkpt::d_ends receives {lead, end} per pair, d_scores H(m,n)).
+enum { DP_PLAIN = 0, DP_CKPT = 1, DP_BAND = 2, DP_PREFIX = 3, DP_ORIGIN = 4 };
 struct DpCkpt {
   int32_t* d_ckpt = nullptr;
   int32_t* d_lastrow = nullptr;
   uint32_t B = 256;
   bool narrow = false;  // set by the DP_CKPT stage (16-bit kernel used), read by the DP_BAND stage
+  uint32_t* d_ends = nullptr;  // DP_ORIGIN: two entries per pair, indexed by PairDesc::out
 };
+// origin-tracking sweep: one pass of strip height K, columns and scores inside the packed fields (dp_lane.h origin_step)
+bool origin_ok(const tracyhip_params* prm, uint32_t maxm, uint32_t maxn, int K);
 int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, bool needle, bool trace,
            int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len, int stage = DP_PLAIN,
            DpCkpt* ck = nullptr);

@@ -16,6 +16,13 @@
 
 #include "dp_lane.h"
 
+// an empty volatile asm keeps a wave-uniform branch a branch (the compiler would if-convert it into selects)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TRACY_KEEP_BRANCH() asm volatile("" ::: "memory")
+#else
+#define TRACY_KEEP_BRANCH() ((void)0)
+#endif
+
 namespace tracyhip {
 
 enum : int { MODE_CHAR = 0, MODE_QP = 1, MODE_PROF = 2 };
@@ -53,6 +60,7 @@ struct DpArgs {
   uint64_t* band;       // band traceback: per-workgroup nibble words of the current band (ckpt_B * 64 words each)
   uint32_t ckpt_B;      // steps between wavefront checkpoints
   int32_t ckpt_narrow;  // checkpoints hold raw registers of the 16-bit kernel (values in the low halves)
+  uint32_t* ends;       // origin-tracking sweep: {leading 'h' columns, last column that is not a trailing 'h'} per pair
 };
 
 // device error flags are OR-ed (several kernels share the word)
@@ -482,6 +490,107 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       }
     }
     if (!last_pass) w.sync_global();  // scratch written by lane 63 is read by lane 0 in the next pass
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Origin-tracking sweep (string x string, AlignConfig<true,false>, one pass): gotoh() for callers that only need the
+// two ends of the alignment -- trimReferenceSlice (fmindex.h:429-463) reads nothing else from it.  The reference's
+// traceback from (m, n) first walks the trailing run of row m, whose horizontal moves are free: it stops at the last
+// column c_e whose H(m, c) is strictly greater than E(m, c) (bit3 clear); from there it follows the trace bits to row
+// 0, which it reaches at some column `lead` and leaves with `lead` leading 'h'.  origin_step carries `lead` in the
+// low bits of every DP value, selected by the very maxima whose tie order defines the trace bits, and c_e is watched
+// in the slot that owns row m.  Writes a.scores[out] = H(m, n), a.ends[2 out] = lead, a.ends[2 out + 1] = c_e.
+// Domain (origin_ok() in the C ABI): m <= 64 K, n + 64 < 2^13, scores within the 14-bit field.
+// ------------------------------------------------------------------------------------------------
+constexpr int32_t kNegInfOrigin = -6000;
+
+template <class W, int K>
+TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
+  const PairDesc d = a.pairs[pair_idx];
+  const uint32_t L = w.lane();
+  const uint32_t m = d.m, n = d.n;
+  const int32_t go = a.go, ge = a.ge;
+  constexpr int SH = kOriginShift;
+  constexpr int TS = kOriginBits;
+  if (m == 0 || n == 0) {  // only the init row / column exists: all columns are leading 'h' (m == 0) or there are none
+    if (L == 0) {
+      if (a.scores) a.scores[d.out] = (m == 0) ? 0 : edge_value(false, go, ge, (int32_t)m);
+      a.ends[2 * d.out] = (m == 0) ? n : 0u;
+      a.ends[2 * d.out + 1] = (m == 0) ? n : 0u;
+    }
+    return;
+  }
+  const uint8_t* a1c = static_cast<const uint8_t*>(a.a1) + d.a1_off;
+  const uint8_t* a2c = static_cast<const uint8_t*>(a.a2) + d.a2_off;
+  const uint32_t lanes_used = (m + K - 1) / K;
+  const uint32_t t_end = n + lanes_used - 1;
+  const uint32_t lane_m = (m - 1) / K, slot_m = (m - 1) % K;  // wave-uniform
+  const int32_t neg = (int32_t)((uint32_t)kNegInfOrigin << SH);
+
+  TraceLane<K> ts;
+  SubChar<K> sub_c;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const uint32_t r = L * K + i + 1;
+    const bool hz = (r == m);  // free horizontal gaps on the last row
+    ts.Hc[i] = (int32_t)((uint32_t)edge_value(false, go, ge, (int32_t)r) << SH);  // column 0: origin 0
+    ts.Ec[i] = neg;
+    ts.cx1[i] = trace_cx1<TS>(hz ? 0 : go + ge);
+    ts.cx2[i] = trace_cx2<TS>(hz ? 0 : ge);
+    sub_c.rc[i] = (r - 1 < m) ? (int32_t)a1c[r - 1] : -1;
+  }
+  sub_c.vmatch = (int32_t)((uint32_t)a.match << SH);
+  sub_c.vmis = (int32_t)((uint32_t)a.mismatch << SH);
+  sub_c.cc = 0;
+  const uint32_t row_above = L * K;
+  int32_t prev_up_h = (row_above == 0) ? 0 : (int32_t)((uint32_t)edge_value(false, go, ge, (int32_t)row_above) << SH);
+  int32_t bot_h = 0, bot_f = 0;
+  const int32_t cy1 = trace_cy1<TS>(go + ge), cy2 = trace_cy2<TS>(ge);
+  uint32_t c_end = 0;
+
+  const bool rcflag = (d.flags & PAIR_A2_REVCOMP) != 0;
+  auto col_at = [&](int32_t cc) -> uint32_t {  // clamp: the look-ahead of idle lanes stays in bounds
+    const int32_t x = cc < 1 ? 1 : (cc > (int32_t)n ? (int32_t)n : cc);
+    return a2_index(d, (uint32_t)x);
+  };
+  int32_t cc_next = (int32_t)a2c[col_at(1 - (int32_t)L)];
+  for (uint32_t t = 1; t <= t_end; ++t) {
+    sub_c.cc = rcflag ? (int32_t)complement_char((uint8_t)cc_next) : cc_next;
+    cc_next = (int32_t)a2c[col_at((int32_t)t - (int32_t)L + 1)];
+    // row 0 (free leading gaps: H(0, c) = 0, F = -inf) enters through the shift; its origin is its own column
+    const int32_t up_h = w.shift_up_or(bot_h, (int32_t)t);
+    const int32_t up_f = w.shift_up_or(bot_f, neg);
+    if ((uint32_t)(t - 1u - L) < n) {
+      int32_t nb_h, nb_f;
+      origin_step<K>(ts, up_h, up_f, prev_up_h, cy1, cy2, sub_c, nb_h, nb_f);
+      prev_up_h = up_h;
+      bot_h = nb_h;
+      bot_f = nb_f;
+      // watch row m: slot_m is wave-uniform, the switch stays a scalar branch (no select chain over the strip)
+      int32_t hv = 0, ev = 0;
+      switch (slot_m) {
+#define TRACY_ROW_M(I)                                  \
+  case I:                                               \
+    if (I < K) { hv = ts.Hc[I < K ? I : 0]; ev = ts.Ec[I < K ? I : 0]; } \
+    TRACY_KEEP_BRANCH();                                \
+    break;
+        TRACY_ROW_M(0) TRACY_ROW_M(1) TRACY_ROW_M(2) TRACY_ROW_M(3) TRACY_ROW_M(4) TRACY_ROW_M(5) TRACY_ROW_M(6) TRACY_ROW_M(7)
+        TRACY_ROW_M(8) TRACY_ROW_M(9) TRACY_ROW_M(10) TRACY_ROW_M(11) TRACY_ROW_M(12) TRACY_ROW_M(13) TRACY_ROW_M(14) TRACY_ROW_M(15)
+#undef TRACY_ROW_M
+        default: break;
+      }
+      if (L == lane_m && (hv >> SH) > (ev >> SH)) c_end = t - L;  // bit3 clear at (m, c): the trailing run ends here
+    }
+  }
+  if (L == lane_m) {
+    int32_t hv = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+      if ((uint32_t)i == slot_m) hv = ts.Hc[i];
+    if (a.scores) a.scores[d.out] = hv >> SH;
+    a.ends[2 * d.out] = (uint32_t)(hv & kOriginMask);
+    a.ends[2 * d.out + 1] = c_end;
   }
 }
 

@@ -57,6 +57,12 @@ __global__ __launch_bounds__(64) void gotoh_ckpt_kernel(DpArgs a) {
   DeviceWave w;
   gotoh_body<DeviceWave, K, MODE, false, NARROW, true>(w, a, blockIdx.x);
 }
+// origin-tracking sweep (string x string): score + the two ends of the alignment, no traceback words
+template <int K>
+__global__ __launch_bounds__(64) void gotoh_origin_kernel(DpArgs a) {
+  DeviceWave w;
+  gotoh_origin_body<DeviceWave, K>(w, a, blockIdx.x);
+}
 // prefix bound of the semiglobal score: GL lanes per pair, 64/GL pairs per workgroup
 template <int K, int GL>
 __global__ __launch_bounds__(64) void gotoh_prefix_kernel(DpArgs a, uint32_t npairs) {
@@ -254,6 +260,19 @@ hipError_t launch_band_trace(int mode, int K, const DpArgs& a, const WalkArgs& w
   if (mode == MODE_CHAR) return launch_band_m<MODE_CHAR>(K, a, wa, npairs, s);
   if (mode == MODE_QP) return launch_band_m<MODE_QP>(K, a, wa, npairs, s);
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_gotoh_origin(int K, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  if (npairs == 0) return hipSuccess;
+  switch (K) {
+    case 4: hipLaunchKernelGGL((gotoh_origin_kernel<4>), dim3(npairs), dim3(64), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((gotoh_origin_kernel<8>), dim3(npairs), dim3(64), 0, s, a); break;
+    case 12: hipLaunchKernelGGL((gotoh_origin_kernel<12>), dim3(npairs), dim3(64), 0, s, a); break;
+    case 15: hipLaunchKernelGGL((gotoh_origin_kernel<15>), dim3(npairs), dim3(64), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((gotoh_origin_kernel<16>), dim3(npairs), dim3(64), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_gotoh_prefix(int K, const DpArgs& a, uint32_t npairs, hipStream_t s) {

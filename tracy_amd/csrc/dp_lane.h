@@ -59,10 +59,19 @@ struct TraceLane {
   int32_t cx2[K];  // horizontal extend constant of row r: hgap(ge)*32 + 10
 };
 
-TR_HD int32_t trace_cx1(int32_t open_cost) { return open_cost * 32 + kTagEOpen; }
-TR_HD int32_t trace_cx2(int32_t ext_cost) { return ext_cost * 32 + kTagEExt; }
-TR_HD int32_t trace_cy1(int32_t open_cost) { return open_cost * 32 + kTagFOpen; }
-TR_HD int32_t trace_cy2(int32_t ext_cost) { return ext_cost * 32 + kTagFExt; }
+// TS = position of the five tag bits.  0: the traceback kernels (score above bit 5).  kOriginBits: the origin-tracking
+// sweep, where the low kOriginBits bits of every value carry a column index along (see origin_step).
+constexpr int kOriginBits = 13;                        // reference columns 0 .. 8191
+constexpr int kOriginShift = kOriginBits + kTagShift;  // score field of the origin-tracking sweep: bits 18 .. 31
+constexpr int32_t kOriginMask = (1 << kOriginBits) - 1;
+template <int TS = 0>
+TR_HD int32_t trace_cx1(int32_t open_cost) { return (int32_t)((uint32_t)open_cost << (TS + kTagShift)) + (kTagEOpen << TS); }
+template <int TS = 0>
+TR_HD int32_t trace_cx2(int32_t ext_cost) { return (int32_t)((uint32_t)ext_cost << (TS + kTagShift)) + (kTagEExt << TS); }
+template <int TS = 0>
+TR_HD int32_t trace_cy1(int32_t open_cost) { return (int32_t)((uint32_t)open_cost << (TS + kTagShift)) + (kTagFOpen << TS); }
+template <int TS = 0>
+TR_HD int32_t trace_cy2(int32_t ext_cost) { return (int32_t)((uint32_t)ext_cost << (TS + kTagShift)) + (kTagFExt << TS); }
 
 // One column of the strip.  up_h/up_f: H,F (x32, clean) of the row above at this column; diag: H of
 // the row above at the previous column; sub(i) returns the substitution score of slot i x32.
@@ -99,6 +108,39 @@ TR_HD void trace_step(TraceLane<K>& s, int32_t up_h, int32_t up_f, int32_t diag,
   else a1 >>= (4 * (16 - K)) & 31;
   w0 = a0;
   w1 = a1;
+  bot_h = up_h;
+  bot_f = up_f;
+}
+
+// Origin-tracking sweep: the column at which the reference's traceback (gotoh.h:143-167) from a cell reaches row 0,
+// carried along with the scores instead of being recovered from stored trace bits.  Every value is
+//     score << 18  |  tag << 13  |  origin (13 bits)
+// The tags order equal scores exactly as in trace_step (extend beats open; E beats F beats the diagonal), so each
+// maximum selects the very predecessor the traceback would follow, and the winner's low bits -- its origin -- ride
+// along for free:   O_s(r,c) = bit3 ? O_h(r,c) : bit4 ? O_v(r,c) : O_s(r-1,c-1),   O_h(r,c) = bit1 ? O_s(r,c-1) : O_h(r,c-1),
+// O_v(r,c) = bit2 ? O_s(r-1,c) : O_v(r-1,c),   O_s(0,c) = c.   Costs are added as multiples of 2^18 and never touch
+// the low 18 bits; tags are stripped after each maximum.  No traceback words are written: trimReferenceSlice
+// (fmindex.h:429-463) only needs the two ends of the alignment.
+template <int K, class Sub>
+TR_HD void origin_step(TraceLane<K>& s, int32_t up_h, int32_t up_f, int32_t diag, int32_t cy1, int32_t cy2, const Sub& sub,
+                       int32_t& bot_h, int32_t& bot_f) {
+  constexpr int32_t strip = ~(kTagMask << kOriginBits);
+#pragma unroll
+  for (int i = K - 1; i >= 0; --i) {
+    const int32_t et = imax(s.Hc[i] + s.cx1[i], s.Ec[i] + s.cx2[i]);
+    const int32_t dt = (i == 0 ? diag : s.Hc[i - 1]) + sub(i);
+    s.Hc[i] = dt;
+    s.Ec[i] = et;
+  }
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const int32_t ft = imax(up_h + cy1, up_f + cy2);
+    const int32_t ht = imax3(s.Hc[i], s.Ec[i], ft);  // tags: E (7 / 10) beats F (1 / 6) beats the diagonal (0)
+    s.Hc[i] = ht & strip;
+    s.Ec[i] = s.Ec[i] & strip;
+    up_h = s.Hc[i];
+    up_f = ft & strip;
+  }
   bot_h = up_h;
   bot_f = up_f;
 }

@@ -33,6 +33,23 @@ struct TrimOut {
   uint32_t pad;
 };
 
+// the widening / clamping / rs.pos part of trimReferenceSlice (fmindex.h:443-461)
+__device__ inline TrimOut trim_finish(uint32_t ri, uint32_t risize, uint32_t n, uint32_t trim_left, uint32_t trim_right, bool forward) {
+  if (ri >= trim_left) { ri -= trim_left; risize += trim_left; }
+  if ((uint32_t)(ri + risize + trim_right) < n) risize += trim_right;
+  TrimOut r;
+  r.ri = ri;
+  r.len = (ri <= n) ? ((risize < n - ri) ? risize : n - ri) : 0;  // substr(ri, risize)
+  r.pos = 0;
+  if (forward) r.pos = ri;
+  else {
+    const int32_t offset = (int32_t)n - (int32_t)ri - (int32_t)risize;
+    if (offset >= 0) r.pos = (uint32_t)offset;  // negative: the reference only warns (fmindex.h:457-459)
+  }
+  r.pad = 0;
+  return r;
+}
+
 // trimReferenceSlice (fmindex.h:429-463) evaluated directly on the traceback string.  ops are in push
 // order (end -> start); alignment column j (forward) is ops[L-1-j].  Row 0 holds a trace base unless
 // the op is 'h', row 1 holds a reference base unless the op is 'v' (align.h:204-214).
@@ -85,19 +102,19 @@ __global__ __launch_bounds__(64) void trim_kernel(const uint8_t* __restrict__ op
     else { for (int32_t j = s; j < e; ++j) refcols += (o[L - 1 - j] != 'v'); inside = refcols; }
     risize = inside;
   }
-  if (ri >= trim_left) { ri -= trim_left; risize += trim_left; }
-  if ((uint32_t)(ri + risize + trim_right) < n) risize += trim_right;
-  TrimOut r;
-  r.ri = ri;
-  r.len = (ri <= n) ? ((risize < n - ri) ? risize : n - ri) : 0;  // substr(ri, risize)
-  r.pos = 0;
-  if (forward[t]) r.pos = ri;
-  else {
-    const int32_t offset = (int32_t)n - (int32_t)ri - (int32_t)risize;
-    if (offset >= 0) r.pos = (uint32_t)offset;  // negative: the reference only warns (fmindex.h:457-459)
-  }
-  r.pad = 0;
-  out[t] = r;
+  out[t] = trim_finish(ri, risize, n, trim_left, trim_right, forward[t] != 0);
+}
+
+// trimReferenceSlice from the two ends of the alignment alone (origin-tracking sweep, dp_kernels.h gotoh_origin_body):
+// ends[2t] = leading 'h' columns, ends[2t+1] = last column that is not a trailing 'h'; every reference base in between
+// belongs to the slice.
+__global__ void trim_from_ends_kernel(const uint32_t* __restrict__ ends, const uint32_t* __restrict__ ref_len,
+                                      const uint8_t* __restrict__ forward, uint32_t trim_left, uint32_t trim_right, uint32_t ntraces,
+                                      TrimOut* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntraces) return;
+  const uint32_t lead = ends[2 * t], ce = ends[2 * t + 1];
+  out[t] = trim_finish(lead, ce >= lead ? ce - lead : 0u, ref_len[t], trim_left, trim_right, forward[t] != 0);
 }
 
 // loadSingleFasta hands over upper-case [ACGTN] only (fasta.h:54-95); anything else makes the string
@@ -970,7 +987,8 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
 
   // ---- 6. allele-specific alignments (indigo.h:355-387): string x string Gotoh ----
   // allele k in {0: primary, 1: secDecompose}: gotoh(seq, rs.refslice) -> trimReferenceSlice -> gotoh(seq, slice)
-  DevBuf &b_opsA = buf(), &b_lenA = buf(), &b_trimA = buf(), &b_rnfw = buf();
+  DevBuf &b_opsA = buf(), &b_lenA = buf(), &b_trimA = buf(), &b_rnfw = buf(), &b_ends = buf();
+  HIP_TRY(b_ends.ensure(sizeof(uint32_t) * 2 * (size_t)nt));
   HIP_TRY(b_opsA.ensure(tot1 + 2ull * TL * nt + 16));
   HIP_TRY(b_lenA.ensure(sizeof(uint32_t) * (size_t)nt));
   HIP_TRY(b_trimA.ensure(sizeof(TrimOut) * (size_t)nt));
@@ -1013,11 +1031,24 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       pb.desc[t] = d;
       pb.k[t] = choose_k(d.m, MODE_CHAR);
     }
-    if ((rc = run_dp(ctx, pb, &p, false, true, nullptr, static_cast<uint8_t*>(b_opsA.p), d_offA, static_cast<uint32_t*>(b_lenA.p)))) return rc;
-    hipLaunchKernelGGL(trim_kernel, dim3(nt), dim3(64), 0, st, static_cast<const uint8_t*>(b_opsA.p), d_offA,
-                       static_cast<const uint32_t*>(b_lenA.p), static_cast<const uint32_t*>(b_rnfw.p),
-                       reinterpret_cast<const uint8_t*>(static_cast<const uint32_t*>(b_rnfw.p) + nt), TL, TR, nt,
-                       static_cast<TrimOut*>(b_trimA.p));
+    // gotoh(seq, rs.refslice) is only read by trimReferenceSlice: when the pairs fit its packed fields the origin-tracking
+    // sweep delivers the two ends of that alignment without traceback words, walker or ops (TRACYHIP_NO_ORIGIN=1: off)
+    bool use_origin = getenv("TRACYHIP_NO_ORIGIN") == nullptr;
+    for (uint32_t t = 0; t < nt && use_origin; ++t) use_origin = origin_ok(&p, pb.desc[t].m, pb.desc[t].n, pb.k[t]);
+    if (use_origin) {
+      DpCkpt oc;
+      oc.d_ends = static_cast<uint32_t*>(b_ends.p);
+      if ((rc = run_dp(ctx, pb, &p, false, false, nullptr, nullptr, nullptr, nullptr, DP_ORIGIN, &oc))) return rc;
+      hipLaunchKernelGGL(trim_from_ends_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, static_cast<const uint32_t*>(b_ends.p),
+                         static_cast<const uint32_t*>(b_rnfw.p), reinterpret_cast<const uint8_t*>(static_cast<const uint32_t*>(b_rnfw.p) + nt),
+                         TL, TR, nt, static_cast<TrimOut*>(b_trimA.p));
+    } else {
+      if ((rc = run_dp(ctx, pb, &p, false, true, nullptr, static_cast<uint8_t*>(b_opsA.p), d_offA, static_cast<uint32_t*>(b_lenA.p)))) return rc;
+      hipLaunchKernelGGL(trim_kernel, dim3(nt), dim3(64), 0, st, static_cast<const uint8_t*>(b_opsA.p), d_offA,
+                         static_cast<const uint32_t*>(b_lenA.p), static_cast<const uint32_t*>(b_rnfw.p),
+                         reinterpret_cast<const uint8_t*>(static_cast<const uint32_t*>(b_rnfw.p) + nt), TL, TR, nt,
+                         static_cast<TrimOut*>(b_trimA.p));
+    }
     HIP_TRY(hipGetLastError());
     h_trimA[k].resize(nt);
     HIP_TRY(hipMemcpyAsync(h_trimA[k].data(), b_trimA.p, sizeof(TrimOut) * (size_t)nt, hipMemcpyDeviceToHost, st));

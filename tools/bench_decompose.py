@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=32)
+    ap.add_argument("--extra-legs", type=int, default=1, help="also time the strand-certificate and two-lane legs (0: headline leg only, for profiling)")
     args = ap.parse_args()
     import tracy_amd
     from tracy_amd import capi, hostlib
@@ -121,18 +122,21 @@ def main():
         return time.perf_counter() - t0
 
     dt = leg()
-    snap = {k: v.clone() for k, v in res.items() if k not in ("score_fwd", "score_rev")}
-    snap_ops = [x[1].clone() for x in keep]
-    job.exact_orientation_scores = 0  # the library's default: strand by certificate
-    dt_cert = leg()
-    same = all(torch.equal(snap[k], res[k]) for k in snap) and all(torch.equal(a, x[1]) for a, x in zip(snap_ops, keep))
-    job.exact_orientation_scores = 1
-    ctx.set_lanes(2)  # the same batch as two chunks in flight (tracyhip_set_lanes)
-    dt_lanes = leg()
-    job.exact_orientation_scores = 0
-    dt_lanes_cert = leg()
-    job.exact_orientation_scores = 1
-    ctx.set_lanes(1)
+    dt_cert = dt_lanes = dt_lanes_cert = 0.0
+    same = True
+    if args.extra_legs:
+        snap = {k: v.clone() for k, v in res.items() if k not in ("score_fwd", "score_rev")}
+        snap_ops = [x[1].clone() for x in keep]
+        job.exact_orientation_scores = 0  # the library's default: strand by certificate
+        dt_cert = leg()
+        same = all(torch.equal(snap[k], res[k]) for k in snap) and all(torch.equal(a, x[1]) for a, x in zip(snap_ops, keep))
+        job.exact_orientation_scores = 1
+        ctx.set_lanes(2)  # the same batch as two chunks in flight (tracyhip_set_lanes)
+        dt_lanes = leg()
+        job.exact_orientation_scores = 0
+        dt_lanes_cert = leg()
+        job.exact_orientation_scores = 1
+        ctx.set_lanes(1)
     mt = mf - 100
     sl = [res["slice_len%d" % k].cpu().numpy().astype(np.int64) for k in range(2)]
     cells = 3 * mt * n * nt + 2 * mt * n * nt + int((mt * sl[0]).sum() + (mt * sl[1]).sum()) + mt * mt * nt
@@ -140,12 +144,13 @@ def main():
     line = {"metric": "traces/s (tracy decompose hot section, indigo.h:190-388)", "value": round(nt * args.steps / dt, 1), "unit": "traces/s",
             "gcups": round(cells * args.steps / dt / 1e9, 1), "ms_per_step": round(dt / args.steps * 1e3, 2), "n_gpus": 1,
             "config": {"workload": "configs[2]: %d synthetic heterozygous %d-base traces `decompose` vs %d-base windows" % (nt, mf, n)},
-            "traces_ok": int((status == 0).sum()), "data": "synthetic",
-            "strand_by_certificate": {"ms_per_step": round(dt_cert / args.steps * 1e3, 2), "traces_per_s": round(nt * args.steps / dt_cert, 1),
-                                      "results_identical_to_headline_leg": bool(same)},
-            "lanes": {"lanes": 2, "ms_per_step": round(dt_lanes / args.steps * 1e3, 2), "traces_per_s": round(nt * args.steps / dt_lanes, 1),
-                      "strand_by_certificate": {"ms_per_step": round(dt_lanes_cert / args.steps * 1e3, 2),
-                                                "traces_per_s": round(nt * args.steps / dt_lanes_cert, 1)}}}
+            "traces_ok": int((status == 0).sum()), "data": "synthetic"}
+    if args.extra_legs:
+        line["strand_by_certificate"] = {"ms_per_step": round(dt_cert / args.steps * 1e3, 2), "traces_per_s": round(nt * args.steps / dt_cert, 1),
+                                         "results_identical_to_headline_leg": bool(same)}
+        line["lanes"] = {"lanes": 2, "ms_per_step": round(dt_lanes / args.steps * 1e3, 2), "traces_per_s": round(nt * args.steps / dt_lanes, 1),
+                         "strand_by_certificate": {"ms_per_step": round(dt_lanes_cert / args.steps * 1e3, 2),
+                                                   "traces_per_s": round(nt * args.steps / dt_lanes_cert, 1)}}
     if args.cpu_sample > 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -34,7 +34,8 @@ for name, sub in (("bench", "bench_stats"), ("decompose", "dec_stats")):
     f = one(sub + "/*/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, name)))
-for src, dst in (("bench_line.json", "bench_line_under_rocprof"), ("bench_plain.json", "bench_line"), ("dec_line.json", "decompose_line")):
+for src, dst in (("bench_line.json", "bench_line_under_rocprof"), ("bench_plain.json", "bench_line"), ("dec_line.json", "decompose_line_under_rocprof"),
+                 ("dec_plain.json", "decompose_line")):
     p = os.path.join(SRC, src)
     if os.path.exists(p):
         d = last_json_line(p)

@@ -65,7 +65,7 @@ struct tracyhip_ctx {
   uint8_t* codes() const { return static_cast<uint8_t*>(d_codes.p) + tracyhip::kCodePad; }
   tracyhip::DevBuf d_aftab;                    // allelicFraction grid enumeration (trace independent)
   bool aftab_ready = false;
-  tracyhip::PinBuf h_desc, h_off, h_tmp;
+  tracyhip::PinBuf h_desc, h_off, h_tmp, h_res;
   // kernel timing
   struct Pending { int which; hipEvent_t e0, e1; uint64_t cells, bytes; };
   // lanes: further contexts (own stream, own buffers) the batch pipelines split a call over, one host thread each
@@ -87,6 +87,7 @@ struct tracyhip_ctx {
     h_desc.release();
     h_off.release();
     h_tmp.release();
+    h_res.release();
   }
 };
 

@@ -547,16 +547,27 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
   }
 
   // ---- results ----
-  std::vector<uint32_t> h_begin(nt), h_len(nt), h_pos(nt);
-  for (uint32_t t = 0; t < nt; ++t) { h_begin[t] = h_trim[t].ri; h_len[t] = h_trim[t].len; h_pos[t] = h_trim[t].pos; }
-  const hipMemcpyKind up = (mem == TRACYHIP_MEM_HOST) ? hipMemcpyHostToHost : hipMemcpyHostToDevice;
-  HIP_TRY(hipMemcpyAsync(out->score_fwd, h_sc2.data(), sizeof(int32_t) * (size_t)nt, up, st));
+  // host-decided arrays go out from one pinned staging block (copies from pageable memory are staged by the runtime and
+  // cost a host round trip each)
+  HIP_TRY(ctx->h_res.ensure((size_t)nt * (5 * sizeof(uint32_t) + 1)));
+  uint32_t* r32 = static_cast<uint32_t*>(ctx->h_res.p);
+  uint8_t* r8 = reinterpret_cast<uint8_t*>(r32 + 5 * (size_t)nt);
   if (given) std::copy(h_sc2.begin(), h_sc2.begin() + nt, h_sc2.begin() + nt);  // one orientation: both arrays report its score
-  HIP_TRY(hipMemcpyAsync(out->score_rev, h_sc2.data() + nt, sizeof(int32_t) * (size_t)nt, up, st));
-  HIP_TRY(hipMemcpyAsync(out->forward, h_fwd.data(), nt, up, st));
-  HIP_TRY(hipMemcpyAsync(out->slice_begin, h_begin.data(), sizeof(uint32_t) * (size_t)nt, up, st));
-  HIP_TRY(hipMemcpyAsync(out->slice_len, h_len.data(), sizeof(uint32_t) * (size_t)nt, up, st));
-  HIP_TRY(hipMemcpyAsync(out->ref_pos, h_pos.data(), sizeof(uint32_t) * (size_t)nt, up, st));
+  for (uint32_t t = 0; t < nt; ++t) {
+    r32[t] = (uint32_t)h_sc2[t];
+    r32[(size_t)nt + t] = (uint32_t)h_sc2[(size_t)nt + t];
+    r32[2 * (size_t)nt + t] = h_trim[t].ri;
+    r32[3 * (size_t)nt + t] = h_trim[t].len;
+    r32[4 * (size_t)nt + t] = h_trim[t].pos;
+    r8[t] = h_fwd[t];
+  }
+  const hipMemcpyKind up = (mem == TRACYHIP_MEM_HOST) ? hipMemcpyHostToHost : hipMemcpyHostToDevice;
+  HIP_TRY(hipMemcpyAsync(out->score_fwd, r32, sizeof(int32_t) * (size_t)nt, up, st));
+  HIP_TRY(hipMemcpyAsync(out->score_rev, r32 + nt, sizeof(int32_t) * (size_t)nt, up, st));
+  HIP_TRY(hipMemcpyAsync(out->slice_begin, r32 + 2 * (size_t)nt, sizeof(uint32_t) * (size_t)nt, up, st));
+  HIP_TRY(hipMemcpyAsync(out->slice_len, r32 + 3 * (size_t)nt, sizeof(uint32_t) * (size_t)nt, up, st));
+  HIP_TRY(hipMemcpyAsync(out->ref_pos, r32 + 4 * (size_t)nt, sizeof(uint32_t) * (size_t)nt, up, st));
+  HIP_TRY(hipMemcpyAsync(out->forward, r8, nt, up, st));
   if (out->score_prelim) {
     if ((rc = copy_out(ctx, mem, out->score_prelim, static_cast<const int32_t*>(ctx->d_tmp[4].p), nt))) return rc;
   }

@@ -234,12 +234,14 @@ def main():
     # committed under profiles/): mostly the wavefront checkpoints + last-row values the band traceback restarts from
     traffic, traffic_src = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))
+        import glob
+        pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm.json")))[-1]  # the latest round's PMC summary
+        pmc = json.load(open(pmc_file))
         per = {c: [r for r in pmc if r["counter"] == c and "gotoh_ckpt_kernel" in r["kernel"]] for c in ("WRITE_SIZE", "FETCH_SIZE")}
         if per["WRITE_SIZE"] and per["FETCH_SIZE"]:
             traffic = int(per["WRITE_SIZE"][0]["bytes"] + per["FETCH_SIZE"][0]["bytes"])
-            traffic_src = "profiles/r01_pmc_hbm.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE of this command, same batch)"
-    except (OSError, ValueError, KeyError):
+            traffic_src = "profiles/%s (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE of this command, same batch)" % os.path.basename(pmc_file)
+    except (OSError, ValueError, KeyError, IndexError):
         pass
     roofline = {"bound": "hbm", "kernel": "gotoh_ckpt_kernel<K,QP,narrow> (score-only Gotoh, forward + reverse-complement orientation in one launch, checkpointed; dominant: %.0f%% of the step)"
                 % (100.0 * sc["ms"] / steps / (elapsed_max / steps * 1e3)),

@@ -1,4 +1,6 @@
 """GPU parity: the HIP kernels, called through the C ABI, against the oracle (bit exact)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -253,8 +255,19 @@ def test_strand_by_certificate(ctx):
     noisy[:4] = 0.6 * noisy[:4] + 0.4 * rand_profile(rng, 700, sharp=False)[:4]
     profs[6] = np.ascontiguousarray(noisy / noisy[:4].sum(axis=0, keepdims=True))
     refl = [r.tobytes() for r in refs]
-    fast = ctx.align_traces(profs, refl, SC, 50, 50, exact_scores=False)
     exact = ctx.align_traces(profs, refl, SC, 50, 50, exact_scores=True)
+    os.environ["TRACYHIP_NO_VOTE"] = "1"  # the two-stage form: prefix bounds of both strands, then the likely winner
+    try:
+        fast2 = ctx.align_traces(profs, refl, SC, 50, 50, exact_scores=False)
+    finally:
+        del os.environ["TRACYHIP_NO_VOTE"]
+    fast = ctx.align_traces(profs, refl, SC, 50, 50, exact_scores=False)  # k-mer vote + prefix bounds in the sweep launch
+    for k in ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
+        assert np.array_equal(np.asarray(fast2[k]), np.asarray(exact[k])), k
+    assert fast2["btr"] == exact["btr"]
+    for i in range(24):
+        wn, ls = ("score_fwd", "score_rev") if int(exact["forward"][i]) else ("score_rev", "score_fwd")
+        assert int(fast2[wn][i]) == int(exact[wn][i]) and int(fast2[ls][i]) >= int(exact[ls][i])
     nb = 0
     for i in range(24):
         want = so.align_trace(profs[i], refl[i], SC, 50, 50)

@@ -401,6 +401,52 @@ int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool 
 }  // namespace tracyhip
 
 // ====================================================================================================
+namespace tracyhip {
+// Checkpointed 16-bit score sweeps of `full` and prefix bounds of `pre` in ONE launch (strand by certificate with the
+// orientation voted beforehand, pipeline.hip).  Profile x code pairs of one strip height K; scores land at PairDesc::out.
+int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const std::vector<PairDesc>& full,
+                    const std::vector<PairDesc>& pre, int K, const tracyhip_params* prm, int32_t* d_scores, DpCkpt* ck) {
+  hipStream_t st = ctx->stream;
+  const size_t nf = full.size(), np = pre.size();
+  if (nf + np == 0) return TRACYHIP_OK;
+  HIP_TRY(ctx->h_desc.ensure(sizeof(PairDesc) * (nf + np)));
+  PairDesc* hd = static_cast<PairDesc*>(ctx->h_desc.p);
+  // longest sweeps first, as run_dp orders them
+  std::vector<uint32_t> order(nf);
+  for (uint32_t i = 0; i < nf; ++i) order[i] = i;
+  auto before = [&](uint32_t x, uint32_t y) { return (uint64_t)full[x].m * full[x].n > (uint64_t)full[y].m * full[y].n; };
+  if (!std::is_sorted(order.begin(), order.end(), before)) std::stable_sort(order.begin(), order.end(), before);
+  for (size_t i = 0; i < nf; ++i) hd[i] = full[order[i]];
+  for (size_t i = 0; i < np; ++i) hd[nf + i] = pre[i];
+  HIP_TRY(ctx->d_desc.ensure(sizeof(PairDesc) * (nf + np)));
+  HIP_TRY(hipMemcpyAsync(ctx->d_desc.p, hd, sizeof(PairDesc) * (nf + np), hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx->d_err.ensure(sizeof(int32_t)));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t), st));
+  DpArgs a{};
+  a.a1 = d_a1; a.a2 = d_a2; a.scores = d_scores; a.err = static_cast<int32_t*>(ctx->d_err.p);
+  a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge; a.hfree = prm->hfree; a.vfree = prm->vfree;
+  a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.ckpt_narrow = 1;
+  DpArgs af = a, ap = a;
+  af.pairs = static_cast<const PairDesc*>(ctx->d_desc.p);
+  ap.pairs = af.pairs + nf;
+  int trc;
+  if (ctx->timing) {
+    uint64_t cells = 0, bytes = 0;
+    for (size_t i = 0; i < nf; ++i) { cells += (uint64_t)hd[i].m * hd[i].n; bytes += 24ull * hd[i].m + hd[i].n + 4; }
+    for (size_t i = 0; i < np; ++i) cells += (uint64_t)std::min<uint32_t>(hd[nf + i].m, (uint32_t)kPrefixLanes * K) * hd[nf + i].n;
+    if ((trc = timing_begin(ctx, TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
+  }
+  HIP_TRY(launch_gotoh_ckpt_prefix(K, af, (uint32_t)nf, ap, (uint32_t)np, st));
+  if ((trc = timing_end(ctx))) return trc;
+  int32_t herr = 0;
+  HIP_TRY(hipMemcpyAsync(&herr, ctx->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  timing_collect(ctx);
+  if (herr & 1) return set_error(TRACYHIP_ERR_RANGE, "a query-profile score does not fit int16 (profile values too large)");
+  return TRACYHIP_OK;
+}
+}  // namespace tracyhip
+
 extern "C" {
 
 const char* tracyhip_last_error(void) { return g_last_error.c_str(); }

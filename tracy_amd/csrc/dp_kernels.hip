@@ -63,6 +63,14 @@ __global__ __launch_bounds__(64) void gotoh_origin_kernel(DpArgs a) {
   DeviceWave w;
   gotoh_origin_body<DeviceWave, K>(w, a, blockIdx.x);
 }
+// one launch, two kinds of workgroups: blocks [0, nfull) run the checkpointed 16-bit score sweep of `full`, the rest the
+// prefix bound of `pre` (GL lanes per pair) -- the short prefix workgroups fill the tail of the long sweeps
+template <int K, int GL>
+__global__ __launch_bounds__(64) void gotoh_ckpt_prefix_kernel(DpArgs full, uint32_t nfull, DpArgs pre, uint32_t npre) {
+  DeviceWave w;
+  if (blockIdx.x < nfull) gotoh_body<DeviceWave, K, MODE_QP, false, true, true>(w, full, blockIdx.x);
+  else gotoh_prefix_body<DeviceWave, K, GL>(w, pre, (blockIdx.x - nfull) * (64u / GL), npre);
+}
 // prefix bound of the semiglobal score: GL lanes per pair, 64/GL pairs per workgroup
 template <int K, int GL>
 __global__ __launch_bounds__(64) void gotoh_prefix_kernel(DpArgs a, uint32_t npairs) {
@@ -272,6 +280,20 @@ hipError_t launch_gotoh_origin(int K, const DpArgs& a, uint32_t npairs, hipStrea
     case 16: hipLaunchKernelGGL((gotoh_origin_kernel<16>), dim3(npairs), dim3(64), 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_gotoh_ckpt_prefix(int K, const DpArgs& full, uint32_t nfull, const DpArgs& pre, uint32_t npre, hipStream_t s) {
+  if (nfull + npre == 0) return hipSuccess;
+  constexpr int GL = kPrefixLanes;
+  const dim3 grid(nfull + (npre + 64 / GL - 1) / (64 / GL));
+#define TRACY_COMBO_CASE(KK) \
+  case KK: hipLaunchKernelGGL((gotoh_ckpt_prefix_kernel<KK, GL>), grid, dim3(64), lds_bytes(MODE_QP, KK), s, full, nfull, pre, npre); break;
+  switch (K) {
+    TRACY_COMBO_CASE(4) TRACY_COMBO_CASE(8) TRACY_COMBO_CASE(12) TRACY_COMBO_CASE(15) TRACY_COMBO_CASE(16)
+    default: return hipErrorInvalidValue;
+  }
+#undef TRACY_COMBO_CASE
   return hipGetLastError();
 }
 

@@ -30,6 +30,7 @@ hipError_t launch_gotoh_ckpt(int mode, int K, bool narrow, const DpArgs& a, uint
 hipError_t launch_band_trace(int mode, int K, const DpArgs& a, const WalkArgs& wa, uint32_t npairs, hipStream_t s);
 // prefix bound (max of H, F over row kPrefixLanes*K) of profile x code pairs, AlignConfig<true,false>, 16-bit domain
 hipError_t launch_gotoh_origin(int K, const DpArgs& a, uint32_t npairs, hipStream_t s);
+hipError_t launch_gotoh_ckpt_prefix(int K, const DpArgs& full, uint32_t nfull, const DpArgs& pre, uint32_t npre, hipStream_t s);
 hipError_t launch_gotoh_prefix(int K, const DpArgs& a, uint32_t npairs, hipStream_t s);
 hipError_t launch_needle(int mode, int K, bool trace, const DpArgs& a, uint32_t npairs, hipStream_t s);
 hipError_t launch_gotoh_walk(const WalkArgs& a, hipStream_t s);

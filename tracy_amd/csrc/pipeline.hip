@@ -159,6 +159,69 @@ int copy_out(tracyhip_ctx* ctx, int mem, T* user, const T* dev, size_t count) {
   return TRACYHIP_OK;
 }
 
+// Orientation vote: shared 11-mers between the trace (consensus base per profile column) and its reference window, read
+// forward and as the reverse complement.  Only a GUESS of which strand to sweep first -- the strand is decided by the
+// scores and the certificate below, a wrong or missing vote costs time, never the result.  One wave per trace; two
+// hashed bitmaps of the trace's k-mers (as they are / reverse-complemented) in LDS, the window's k-mers probe both.
+struct VoteDesc { uint64_t a1_off, a2_off; uint32_t stride, m, n, pad; };
+constexpr int kVoteK = 11;
+constexpr uint32_t kVoteBits = 1u << 16;
+__device__ inline uint32_t vote_hash(uint32_t kmer) { return (kmer * 0x9E3779B1u) >> 16; }
+__global__ __launch_bounds__(64) void kmer_vote_kernel(const VoteDesc* __restrict__ desc, const float* __restrict__ prof,
+                                                       const uint8_t* __restrict__ codes, uint32_t* __restrict__ votes) {
+  __shared__ uint32_t bm[2][kVoteBits / 32];
+  __shared__ uint8_t cons[1040];
+  const VoteDesc d = desc[blockIdx.x];
+  const uint32_t lane = threadIdx.x;
+  uint32_t hf = 0, hr = 0;
+  const uint32_t m = d.m < 1024u ? d.m : 1024u;
+  if (m >= (uint32_t)kVoteK && d.n >= (uint32_t)kVoteK) {
+    for (uint32_t i = lane; i < kVoteBits / 32; i += 64) { bm[0][i] = 0; bm[1][i] = 0; }
+    for (uint32_t j = lane; j < m; j += 64) {
+      uint32_t best = 0;
+      float bv = prof[d.a1_off + j];
+      for (uint32_t k = 1; k < 4; ++k) {
+        const float v = prof[d.a1_off + (uint64_t)k * d.stride + j];
+        if (v > bv) { bv = v; best = k; }
+      }
+      cons[j] = (uint8_t)best;
+    }
+    __syncthreads();
+    constexpr uint32_t mask = (1u << (2 * kVoteK)) - 1u;
+    for (uint32_t i = lane; i + kVoteK <= m; i += 64) {
+      uint32_t f = 0, r = 0;
+      for (int j = 0; j < kVoteK; ++j) {
+        const uint32_t c = cons[i + j];
+        f = (f << 2) | c;
+        r |= (3u - c) << (2 * j);  // reverse complement: complemented bases in reverse order
+      }
+      const uint32_t h0 = vote_hash(f & mask), h1 = vote_hash(r & mask);
+      atomicOr(&bm[0][h0 >> 5], 1u << (h0 & 31));
+      atomicOr(&bm[1][h1 >> 5], 1u << (h1 & 31));
+    }
+    __syncthreads();
+    // every lane rolls over its own contiguous piece of the window (kVoteK - 1 bases of overlap with the next piece)
+    const uint32_t npos = d.n - kVoteK + 1;
+    const uint32_t per = (npos + 63) / 64;
+    const uint32_t lo = lane * per, hi = (lo + per < npos) ? lo + per : npos;
+    if (lo < hi) {
+      uint32_t k = 0, valid = 0;
+      for (uint32_t p = lo; p < hi + kVoteK - 1; ++p) {
+        const uint32_t c = codes[d.a2_off + p];
+        if (c < 4u) { k = ((k << 2) | c) & mask; ++valid; }
+        else valid = 0;
+        if (valid >= (uint32_t)kVoteK) {
+          const uint32_t h = vote_hash(k);
+          hf += (bm[0][h >> 5] >> (h & 31)) & 1u;
+          hr += (bm[1][h >> 5] >> (h & 31)) & 1u;
+        }
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { hf += __shfl_down(hf, o, 64); hr += __shfl_down(hr, o, 64); }
+  if (lane == 0) { votes[2 * blockIdx.x] = hf; votes[2 * blockIdx.x + 1] = hr; }
+}
+
 // =====================================================================================================
 // Orientation + preliminary alignment of trimmed traces against their reference windows: the part `tracy align`
 // (sage.h:223-258) and `tracy decompose` (indigo.h:235-302, FASTA / indexed reference) have in common.
@@ -293,7 +356,75 @@ int orient_and_align(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn
     for (uint32_t t = 0; t < nt; ++t) ne += elig[t] = mt[t] > (uint32_t)kPrefixLanes * choose_k(mt[t], MODE_QP);
     if (ne == 0) use_prefix = false;
   }
-  if (use_prefix) {
+  // With one strip height for the whole batch the strand to sweep first is voted from shared k-mers before any DP runs
+  // (kmer_vote_kernel), and the prefix bounds of the other strand ride in the same launch as the full sweeps, where their
+  // short workgroups fill the tail.  Undecided votes get both full sweeps.  TRACYHIP_NO_VOTE=1: the two-stage form below.
+  bool use_vote = use_prefix && getenv("TRACYHIP_NO_VOTE") == nullptr;
+  const int K0 = choose_k(mt[0], MODE_QP);
+  for (uint32_t t = 0; t < nt && use_vote; ++t) use_vote = choose_k(mt[t], MODE_QP) == K0;
+  if (use_vote) {
+    std::vector<VoteDesc> hv(nt);
+    std::vector<RowMaxDesc> hrm(nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+      hv[t] = VoteDesc{in.a1_off[t], in.a2_off[t], mf[t], mt[t], rn[t], 0u};
+      hrm[t] = RowMaxDesc{in.a1_off[t], mf[t], mt[t], (uint32_t)kPrefixLanes * K0};
+    }
+    const size_t need = (sizeof(VoteDesc) + sizeof(RowMaxDesc) + 3 * sizeof(uint32_t)) * (size_t)nt;
+    HIP_TRY(ctx->d_tmp[7].ensure(need));
+    VoteDesc* d_vd = static_cast<VoteDesc*>(ctx->d_tmp[7].p);
+    RowMaxDesc* d_rm = reinterpret_cast<RowMaxDesc*>(d_vd + nt);
+    int32_t* d_ub = reinterpret_cast<int32_t*>(d_rm + nt);
+    uint32_t* d_votes = reinterpret_cast<uint32_t*>(d_ub + nt);
+    HIP_TRY(hipMemcpyAsync(d_vd, hv.data(), sizeof(VoteDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_rm, hrm.data(), sizeof(RowMaxDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(kmer_vote_kernel, dim3(nt), dim3(64), 0, st, d_vd, static_cast<const float*>(d_prof), ctx->codes(), d_votes);
+    hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, st, d_rm, static_cast<const float*>(d_prof), (float)p.match, (float)p.mismatch, d_ub);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> h_ub(nt);
+    std::vector<uint32_t> h_votes(2 * (size_t)nt);
+    HIP_TRY(hipMemcpyAsync(h_ub.data(), d_ub, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_votes.data(), d_votes, sizeof(uint32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
+    if (d_verr && !verr_fetched) HIP_TRY(hipMemcpyAsync(&h_verr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (d_verr) {
+      verr_fetched = true;
+      if (h_verr & 4) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
+    }
+    std::vector<int8_t> guess(nt, 0), both(nt, 1);
+    std::vector<PairDesc> fullv, prev;
+    fullv.reserve(nt + nt / 8);
+    prev.reserve(nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+      const uint32_t vf = h_votes[2 * t], vr = h_votes[2 * t + 1];
+      guess[t] = vf >= vr ? 0 : 1;
+      const uint32_t hi = vf >= vr ? vf : vr, lo = vf >= vr ? vr : vf;
+      both[t] = (elig[t] && hi >= 32 && hi >= 2 * lo) ? 0 : 1;  // a clear majority of shared k-mers, or both sweeps
+      fullv.push_back(stage1_desc(t, (int)guess[t]));
+      if (both[t]) fullv.push_back(stage1_desc(t, 1 - guess[t]));
+      else prev.push_back(stage1_desc(t, 1 - guess[t]));
+    }
+    DpCkpt ckv = ck;
+    if ((rc = run_ckpt_prefix(ctx, d_prof, ctx->codes(), fullv, prev, K0, &p, d_sc2, &ckv))) return rc;
+    if ((rc = fetch_scores())) return rc;
+    std::vector<std::pair<uint32_t, int>> retry;
+    for (uint32_t t = 0; t < nt; ++t) {
+      if (both[t]) continue;
+      const size_t w = (size_t)guess[t] * nt + t, l = (size_t)(1 - guess[t]) * nt + t;
+      const int64_t bound_l = (int64_t)h_sc2[l] + h_ub[t];
+      const bool certified = guess[t] == 0 ? bound_l < (int64_t)h_sc2[w] : bound_l <= (int64_t)h_sc2[w];
+      if (certified) h_sc2[l] = (int32_t)std::min<int64_t>(bound_l, 0x7fffffff);
+      else retry.emplace_back(t, 1 - guess[t]);
+    }
+    if (!retry.empty()) {
+      std::vector<int32_t> keep = h_sc2;
+      if ((rc = run_stage1(retry, DP_CKPT))) return rc;
+      std::vector<int32_t> got(2 * (size_t)nt);
+      HIP_TRY(hipMemcpyAsync(got.data(), d_sc2, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      h_sc2 = keep;
+      for (auto const& r : retry) h_sc2[(size_t)r.second * nt + r.first] = got[(size_t)r.second * nt + r.first];
+    }
+  } else if (use_prefix) {
     std::vector<std::pair<uint32_t, int>> all2;
     for (int o = 0; o < 2; ++o)
       for (uint32_t t = 0; t < nt; ++t)

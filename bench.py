@@ -8,6 +8,11 @@ DP of the trimmed profile, trimReferenceSlice, 1 traceback DP of the full profil
 Weak scaling: the per-GPU batch is fixed; traces shard by index with no data-path collective, the only
 RCCL call is the final gather of the fixed-size result records.
 
+Legs (each: W warm-up + K timed steps between barriers): (1) the headline -- one lane, both orientations swept in full
+(`value`, `roofline`); (2) the library's default strand-by-certificate mode; (3), (4) the same two on `--lanes-leg`
+chunks of the batch in flight.  Legs 2-4 are checked to return the headline leg's alignments and are reported beside it;
+`--certificate-leg 0 --lanes-leg 0` runs the headline alone (what the rocprofv3 passes under profiles/ use).
+
 Prints ONE JSON line on rank 0 (see the keys at the bottom).
 """
 import argparse

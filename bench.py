@@ -122,7 +122,7 @@ def main():
     # headline leg: every cell of all four Gotoh calls per trace is evaluated (both orientations swept in full).  The
     # library's default (strand by certificate, identical alignments, fewer cells) is timed as a second leg below and
     # reported beside it -- it is never `value`.
-    job.exact_orientation_scores = 1
+    job.strand_by_certificate = 0
     dev = torch.device("cuda", local)
     r_i32 = {k: torch.zeros(nt, dtype=torch.int32, device=dev) for k in
              ("score_fwd", "score_rev", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final", "ops_len")}
@@ -183,7 +183,7 @@ def main():
     if args.certificate_leg:
         exact_final = r_i32["score_final"].clone()
         exact_ops = r_ops.clone()
-        job.exact_orientation_scores = 0
+        job.strand_by_certificate = 1
         elapsed_cert, rl_cert = timed_leg()
         if not (torch.equal(exact_final, r_i32["score_final"]) and torch.equal(exact_ops, r_ops)):
             raise RuntimeError("strand-by-certificate leg produced different alignments than the exact leg")
@@ -195,12 +195,12 @@ def main():
         for which, exact in ((0, 1), (1, 0)):
             if exact == 0 and not args.certificate_leg:
                 continue
-            job.exact_orientation_scores = exact
+            job.strand_by_certificate = 0 if exact else 1
             elapsed_lanes[which], _ = timed_leg()
             if args.certificate_leg and not (torch.equal(exact_final, r_i32["score_final"]) and torch.equal(exact_ops, r_ops)):
                 raise RuntimeError("the lanes leg produced different alignments than the headline leg")
         ctx.set_lanes(max(1, args.lanes))
-    job.exact_orientation_scores = 1
+    job.strand_by_certificate = 0
 
     # ---- work done: DP cells of the four Gotoh calls per trace ----
     mt = mf - 2 * TRIM

@@ -146,14 +146,15 @@ typedef struct {
                                every trace by k-mer seeding (getReferenceSlice, fmindex.h:236-326) and passes refs that are
                                ALREADY oriented (reverse-complemented for reverse traces); oriented[t] = rs.forward.  No
                                orientation scores are computed: score_fwd and score_rev both receive gotohScore(trim, ref). */
-  uint32_t exact_orientation_scores; /* 0 (default): the strand is decided as the reference does (forward iff gsFwd > gsRev), but
-                               the LOSING orientation may be represented by a certified upper bound of its score instead of the
-                               score itself (a prefix of its DP suffices to prove it cannot win; see pipeline.hip).  1: both
-                               gotohScore calls run in full and score_fwd / score_rev are exact. */
+  uint32_t strand_by_certificate; /* 0 (default, what a zero-initialised job gets): both gotohScore calls run in full; score_fwd and
+                               score_rev are gsFwd and gsRev.  1 (opt-in): the strand is still decided exactly as the reference
+                               does (forward iff gsFwd > gsRev), but the LOSING orientation may be represented by a certified
+                               upper bound of its score instead of the score itself (a prefix of its DP suffices to prove that
+                               it cannot win; see pipeline.hip) -- fewer cells, same decision, same alignments. */
 } tracyhip_align_job;
 
 typedef struct {
-  int32_t* score_fwd;     /* [ntraces] gsFwd (exact for the winning orientation; see exact_orientation_scores) */
+  int32_t* score_fwd;     /* [ntraces] gsFwd (with strand_by_certificate: exact for the winning orientation only) */
   int32_t* score_rev;     /* [ntraces] gsRev (idem) */
   uint8_t* forward;       /* [ntraces] 1 = rs.forward */
   int32_t* score_prelim;  /* [ntraces] score of the preliminary alignment (sage.h:258), may be NULL */
@@ -250,8 +251,8 @@ typedef struct {
   tracyhip_seqset ref_profiles;  /* data NULL = unused.  Wildtype-trace reference (indigo.h:249-289): profile of the wildtype
                                     trace, oriented by the caller (needs `oriented`), parallel to refs, which then hold the
                                     wildtype's (oriented) primary basecalls = rs.refslice */
-  uint32_t exact_orientation_scores; /* as in tracyhip_align_job: 0 (default) = strand by certificate, the losing
-                                    orientation's score may be a certified upper bound; 1 = both scores exact */
+  uint32_t strand_by_certificate; /* as in tracyhip_align_job: 0 (default) = both orientation scores exact; 1 = the losing
+                                    orientation's score may be a certified upper bound */
 } tracyhip_decompose_job;
 
 typedef struct {

@@ -147,7 +147,8 @@ int emu_prefix(int K, uint32_t npairs, const float* a1, const uint64_t* a1_off, 
     d[i].a1_off = a1_off[i]; d[i].a2_off = a2_off[i]; d[i].m = m[i]; d[i].n = n[i]; d[i].a1_stride = m[i]; d[i].a2_stride = n[i];
     d[i].flags = flags[i]; d[i].out = i;
   }
-  int32_t err = 0;
+  int32_t errw[kErrWords] = {0};
+  int32_t& err = errw[0];
   DpArgs a{};
   a.pairs = d.data(); a.a1 = a1; a.a2 = a2; a.scores = out; a.err = &err;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = 1; a.vfree = 0;
@@ -167,7 +168,8 @@ int emu_origin(int K, const uint8_t* a1, uint32_t m, const uint8_t* a2, uint32_t
                int32_t go, int32_t ge, int32_t* score, uint32_t* ends) {
   PairDesc d{};
   d.m = m; d.n = n; d.a1_stride = m; d.a2_stride = n; d.flags = flags; d.out = 0;
-  int32_t err = 0;
+  int32_t errw[kErrWords] = {0};
+  int32_t& err = errw[0];
   DpArgs a{};
   a.pairs = &d; a.a1 = a1; a.a2 = a2; a.scores = score; a.err = &err; a.ends = ends;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = 1; a.vfree = 0;
@@ -192,7 +194,8 @@ int emu_band(int mode, int K, int narrow, uint32_t B, const void* a1, uint32_t m
   std::vector<int32_t> ckpt((size_t)(steps / B + 2) * ckpt_fields(K) * 64, 0x7f7f7f7f);
   std::vector<int32_t> lastrow(2 * (size_t)(n + 2), 0x7f7f7f7f);
   std::vector<uint64_t> band((size_t)B * 64 + 64, 0xDEADBEEFDEADBEEFull);
-  int32_t err = 0;
+  int32_t errw[kErrWords] = {0};
+  int32_t& err = errw[0];
   DpArgs a{};
   a.pairs = &d; a.a1 = a1; a.a2 = a2; a.scores = score; a.err = &err;
   std::vector<uint8_t> codes;
@@ -227,7 +230,8 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
   const uint32_t P = num_passes(m ? m : 1, K);
   std::vector<uint64_t> bits((size_t)P * steps_per_pass(n) * 64 + 64, 0xDEADBEEFDEADBEEFull);
   std::vector<int32_t> scratch(2 * (size_t)(n + 2), 0);
-  int32_t err = 0;
+  int32_t errw[kErrWords] = {0};
+  int32_t& err = errw[0];
   DpArgs a{};
   a.pairs = &d; a.a1 = a1; a.a2 = a2;
   std::vector<uint8_t> codes;

@@ -45,13 +45,9 @@ def related(rng, s, rate=0.1):
     return bytes(out)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--pairs", type=int, default=1500)
-    ap.add_argument("--traces", type=int, default=96)
-    ap.add_argument("--lanes", type=int, default=1, help="tracyhip_set_lanes for the pipeline calls")
-    ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
+def run_campaign(pairs=1500, traces=96, lanes=1, seed=1, decompose_len=(700, 2200), decompose_mix=1):
+    """one campaign; returns {"compared": {...}, "mismatches": n, "first": [...]} (also what main() prints)"""
+    args = argparse.Namespace(pairs=pairs, traces=traces, lanes=lanes, seed=seed)
     import pyoracle as orc
     import tracy_amd
     from tracy_amd import capi, hostlib
@@ -125,8 +121,8 @@ def main():
 
     # ---- 3. `tracy decompose` batches ----
     nd = max(8, args.traces // 2)
-    mf, n = 700, 2200
-    d = hostlib.synth_decompose_batch(int(rng.integers(0, 1 << 30)), nd, n, mf, 0)
+    mf, n = decompose_len
+    d = hostlib.synth_decompose_batch(int(rng.integers(0, 1 << 30)), nd, n, mf, 0, mix=decompose_mix)
     hbc = capi.HostBaseCalls([d["signal"][i] for i in range(nd)], [d["bcpos"][i] for i in range(nd)], [d["primary"][i].tobytes() for i in range(nd)],
                              [d["secondary"][i].tobytes() for i in range(nd)])
     got = ctx.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, [d["refs"][i].tobytes() for i in range(nd)], (3, -5, -10, -4))
@@ -141,8 +137,31 @@ def main():
         if not ok:
             bad.append(("decompose", i))
     done["decompose"] = nd
-    print(json.dumps({"compared": done, "mismatches": len(bad), "first": [str(b) for b in bad[:5]]}))
-    sys.exit(1 if bad else 0)
+    ctx.close()
+    pool.shutdown()
+    return {"compared": done, "mismatches": len(bad), "first": [str(b) for b in bad[:5]], "seed": seed, "lanes": lanes}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=1500)
+    ap.add_argument("--traces", type=int, default=96)
+    ap.add_argument("--lanes", type=int, default=1, help="tracyhip_set_lanes for the pipeline calls")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--rounds", type=int, default=1, help="campaigns to run, seeds seed .. seed+rounds-1, lanes alternating 1 / --lanes")
+    ap.add_argument("--log", default="", help="append one JSON line per campaign to this file")
+    args = ap.parse_args()
+    total_bad = 0
+    for r in range(args.rounds):
+        t0 = time.time()
+        res = run_campaign(args.pairs, args.traces, args.lanes if (r % 2 or args.rounds == 1) else 1, args.seed + r)
+        res["seconds"] = round(time.time() - t0, 1)
+        print(json.dumps(res), flush=True)
+        if args.log:
+            with open(args.log, "a") as f:
+                f.write(json.dumps(res) + "\n")
+        total_bad += res["mismatches"]
+    sys.exit(1 if total_bad else 0)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,119 @@
+"""GPU parity at the shapes BASELINE.json quotes its metric on, through the batch entry points of the C ABI:
+configs[1]  1 kb traces `align` vs 10 kb windows (sage.h:191-311), both strands, both orientation modes;
+configs[2]  1 kb heterozygous traces `decompose` vs 3 kb windows (indigo.h:190-388): het insertion / het deletion /
+            homozygous indel / no variant, both strands;
+configs[4]  900 x 900 profile x profile `gotohScore<true,true>` (msa.h:33-42) and its traceback.
+Bit-exact against the oracle; sizes the oracle finishes in seconds per case."""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+SC = (3, -5, -10, -4)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import tracy_amd
+    c = tracy_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_align_1kb_vs_10kb(lanes):
+    import tracy_amd
+    from tracy_amd import hostlib
+    from sage_oracle import align_trace
+    nt = 16 if lanes == 1 else 128  # lanes split batches of >= 64 traces per lane
+    refs, profs, rev = hostlib.synth_align(4242, nt, 10000, 1000, 0)
+    assert 0 < int(rev.sum()) < nt  # both strands present
+    c = tracy_amd.Context(0)
+    c.set_lanes(lanes)
+    refl = [r.tobytes() for r in refs]
+    exact = c.align_traces(list(profs), refl, SC, 50, 50, exact_scores=True)
+    fast = c.align_traces(list(profs), refl, SC, 50, 50, exact_scores=False)
+    c.close()
+    check = range(nt) if lanes == 1 else list(range(0, nt, 9)) + [63, 64, 127]
+    with ThreadPoolExecutor(max_workers=16) as pool:
+        wants = list(pool.map(lambda i: align_trace(profs[i], refl[i], SC, 50, 50), check))
+    for i, want in zip(check, wants):
+        assert int(want["forward"]) == 1 - int(rev[i])
+        for k in ("score_fwd", "score_rev", "forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
+            assert int(exact[k][i]) == int(want[k]), (i, k)
+        assert exact["btr"][i] == want["btr"], i
+        for k in ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
+            assert int(fast[k][i]) == int(want[k]), (i, k, "certificate")
+        assert fast["btr"][i] == want["btr"], i
+        win, lose = ("score_fwd", "score_rev") if want["forward"] else ("score_rev", "score_fwd")
+        assert int(fast[win][i]) == int(want[win]) and int(fast[lose][i]) >= int(want[lose])
+
+
+def test_decompose_1kb_vs_3kb(ctx):
+    from tracy_amd import capi, hostlib
+    import indigo_oracle as io
+    nt = 20  # mix 1: traces 8, 18 homozygous indel, 9, 19 no variant, the rest het indels; odd traces on the reverse strand
+    d = hostlib.synth_decompose_batch(90210, nt, 3000, 1000, 0, mix=1)
+    sig = [d["signal"][i] for i in range(nt)]
+    pos = [d["bcpos"][i] for i in range(nt)]
+    pri = [d["primary"][i].tobytes() for i in range(nt)]
+    sec = [d["secondary"][i].tobytes() for i in range(nt)]
+    refs = [d["refs"][i].tobytes() for i in range(nt)]
+    with ThreadPoolExecutor(max_workers=16) as pool:
+        wants = list(pool.map(lambda i: io.decompose_trace(sig[i], pos[i], pri[i], sec[i], refs[i], SC), range(nt)))
+    kinds = set()
+    for exact in (True, False):
+        hbc = capi.HostBaseCalls(sig, pos, pri, sec)
+        got = ctx.decompose_traces([d["profiles"][i] for i in range(nt)], hbc, refs, SC, exact_scores=exact)
+        fr = np.asarray(got["fractions"]).reshape(-1, 2)
+        for i, w in enumerate(wants):
+            assert int(got["forward"][i]) == w["forward"] == 1 - (i & 1), i
+            assert int(got["status"][i]) == w["status"], i
+            if w["status"] != 0:  # later outputs of failed traces are unspecified (include/tracy_hip.h)
+                continue
+            b = got["bp"][i]
+            assert (b.indelshift, b.traceleft, b.breakpoint) == (w["bp"].indelshift, w["bp"].traceleft, w["bp"].breakpoint), i
+            assert int(got["score_trim"][i]) == w["score_trim"]
+            assert got["primary"][i] == w["primary"] and got["secondary"][i] == w["secondary"], i
+            assert got["secdecomp_list"][i] == w["secdecomp"], i
+            assert got["dcp"][i] == w["dcp"], i
+            st = got["dstatus"][i]
+            assert (st.kind, st.best_ins, st.best_del, st.best_fr) == tuple(w["dstatus"]), i
+            assert (float(fr[i, 0]), float(fr[i, 1])) == w["af"], i
+            for k in range(3):
+                assert int(got["score%d" % k][i]) == w["score%d" % k], (i, k)
+                assert got["btr%d" % k][i] == w["btr%d" % k], (i, k)
+            for k in range(2):
+                for nm in ("slice_begin", "slice_len", "ref_pos"):
+                    assert int(got["%s%d" % (nm, k)][i]) == w["%s%d" % (nm, k)], (i, k, nm)
+            if exact:
+                assert (int(got["score_fwd"][i]), int(got["score_rev"][i])) == (w["score_fwd"], w["score_rev"])
+            kinds.add((i % 10 == 8, i % 10 == 9, i & 1))
+    assert len(kinds) >= 4
+
+
+def test_profile_x_profile_900(ctx):
+    """all-pairs shape of `tracy assemble`: trace profiles (row 4 zero: 16-term body) and alignment-like profiles with
+    N / gap weight (25-term body), AlignConfig<true,true>"""
+    from tracy_amd import hostlib
+    refs, profs, rev = hostlib.synth_align(777, 8, 2000, 900, 0)
+    p1 = [np.ascontiguousarray(profs[i]) for i in range(8)]
+    p2 = [np.ascontiguousarray(profs[(i + 1) % 8]) for i in range(8)]
+    # overlapping traces: the second half of one is the first half of the next (as tiled traces in `assemble`)
+    for i in range(0, 8, 2):
+        p2[i] = np.ascontiguousarray(np.concatenate([p1[i][:, 450:], p2[i][:, :450]], axis=1))
+    for i in (1, 5):  # alignment-like columns
+        p1[i] = p1[i].copy()
+        p1[i][4, ::17] = np.float32(0.25)
+        p1[i][5, ::29] = np.float32(0.125)
+    sc_only = ctx.score(p1, p2, SC + (1, 1))
+    scores, btr = ctx.align(p1, p2, SC + (1, 1))
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        wants = list(pool.map(lambda i: orc.gotoh_prof(p1[i], p2[i], 1, 1, SC), range(8)))
+    for i, w in enumerate(wants):
+        assert int(sc_only[i]) == w[0], i
+        assert (int(scores[i]), btr[i]) == w, i

@@ -69,7 +69,7 @@ def main():
                                  u64(bc_off), u32(bc_len))
     job.refs = capi.SeqSet(capi.SEQ_CHAR, t_ref.data_ptr(), u64(ref_off), u32(ref_len), nt)
     job.dprm = capi.DecompParams(50, 50, maxindel, 5)
-    job.exact_orientation_scores = 1  # headline leg: both orientations swept in full; the certificate mode is timed after it
+    job.strand_by_certificate = 0  # headline leg: both orientations swept in full; the certificate mode is timed after it
     res = {
         "bp": torch.zeros(nt * 4, dtype=torch.int32, device=dev), "status": torch.zeros(nt, dtype=torch.int32, device=dev),
         "score_fwd": torch.zeros(nt, dtype=torch.int32, device=dev), "score_rev": torch.zeros(nt, dtype=torch.int32, device=dev),
@@ -127,15 +127,15 @@ def main():
     if args.extra_legs:
         snap = {k: v.clone() for k, v in res.items() if k not in ("score_fwd", "score_rev")}
         snap_ops = [x[1].clone() for x in keep]
-        job.exact_orientation_scores = 0  # the library's default: strand by certificate
+        job.strand_by_certificate = 1  # the library's default: strand by certificate
         dt_cert = leg()
         same = all(torch.equal(snap[k], res[k]) for k in snap) and all(torch.equal(a, x[1]) for a, x in zip(snap_ops, keep))
-        job.exact_orientation_scores = 1
+        job.strand_by_certificate = 0
         ctx.set_lanes(2)  # the same batch as two chunks in flight (tracyhip_set_lanes)
         dt_lanes = leg()
-        job.exact_orientation_scores = 0
+        job.strand_by_certificate = 1
         dt_lanes_cert = leg()
-        job.exact_orientation_scores = 1
+        job.strand_by_certificate = 0
         ctx.set_lanes(1)
     mt = mf - 100
     sl = [res["slice_len%d" % k].cpu().numpy().astype(np.int64) for k in range(2)]

@@ -34,7 +34,7 @@ for pinned in (0, 1):
     for lanes in (1, 2, 3):
         ctx.set_lanes(lanes)
         for exact in (1, 0):
-            job.exact_orientation_scores = exact
+            job.strand_by_certificate = 0 if exact else 1
             def step():
                 rc = lib.tracyhip_align_traces(ctx._h, C.byref(job), C.byref(prm), capi.MEM_HOST, C.byref(out))
                 assert rc == 0, lib.tracyhip_last_error()

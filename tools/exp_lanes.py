@@ -38,7 +38,7 @@ for stream_kind in ("default", "side"):
             ctx.set_lanes(lanes)
             lib.tracyhip_timing_enable(ctx._h, timing)
             for exact in (1, 0):
-                job.exact_orientation_scores = exact
+                job.strand_by_certificate = 0 if exact else 1
                 def step():
                     rc = lib.tracyhip_align_traces(ctx._h, C.byref(job), C.byref(prm), capi.MEM_DEVICE, C.byref(out))
                     assert rc == 0, lib.tracyhip_last_error()

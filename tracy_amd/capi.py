@@ -39,7 +39,7 @@ class Pairs(C.Structure):
 class AlignJob(C.Structure):
     _fields_ = [("ntraces", C.c_uint32), ("profiles", SeqSet), ("refs", SeqSet), ("ref_index", C.POINTER(C.c_uint32)),
                 ("trim_left", C.c_uint32), ("trim_right", C.c_uint32), ("oriented", C.POINTER(C.c_uint8)),
-                ("exact_orientation_scores", C.c_uint32)]
+                ("strand_by_certificate", C.c_uint32)]
 
 
 class AlignResult(C.Structure):
@@ -236,7 +236,7 @@ def _align_traces(self, profiles, refs, params, trim_left=50, trim_right=50, ref
         rlen = pr.length[:nt]
     job.trim_left = trim_left
     job.trim_right = trim_right
-    job.exact_orientation_scores = 1 if exact_scores else 0  # False: the losing strand may carry a certified upper bound
+    job.strand_by_certificate = 0 if exact_scores else 1  # opt-in: the losing strand may carry a certified upper bound
     if oriented is not None:
         oriented = np.ascontiguousarray(oriented, dtype=np.uint8)
         job.oriented = oriented.ctypes.data_as(C.POINTER(C.c_uint8))
@@ -417,7 +417,7 @@ Context.allelic_fraction = _allelic_fraction
 class DecomposeJob(C.Structure):
     _fields_ = [("ntraces", C.c_uint32), ("profiles", SeqSet), ("bc", BaseCallsBatch), ("refs", SeqSet),
                 ("ref_index", C.POINTER(C.c_uint32)), ("dprm", DecompParams), ("oriented", C.POINTER(C.c_uint8)), ("ref_profiles", SeqSet),
-                ("exact_orientation_scores", C.c_uint32)]
+                ("strand_by_certificate", C.c_uint32)]
 
 
 class DecomposeResult(C.Structure):
@@ -442,7 +442,7 @@ def _decompose_traces(self, profiles, hbc, refs, params, trim_left=50, trim_righ
     job.bc = hbc.struct()
     job.refs = pr.seqset()
     job.dprm = DecompParams(trim_left, trim_right, maxindel, madc)
-    job.exact_orientation_scores = 1 if exact_scores else 0  # False: the losing strand may carry a certified upper bound
+    job.strand_by_certificate = 0 if exact_scores else 1  # opt-in: the losing strand may carry a certified upper bound
     if oriented is not None:
         oriented = np.ascontiguousarray(oriented, dtype=np.uint8)
         job.oriented = oriented.ctypes.data_as(C.POINTER(C.c_uint8))

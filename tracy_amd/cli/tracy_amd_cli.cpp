@@ -321,6 +321,7 @@ bool align_fasta_group(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vecto
   std::vector<uint8_t> orient(nt);
   for (uint32_t i = 0; i < nt; ++i) orient[i] = jobs[i]->rs.forward ? 1 : 0;
   if (seeded) job.oriented = orient.data();
+  job.strand_by_certificate = 1;  // gsFwd / gsRev are not part of any output file: only the decision (sage.h:247) matters here
   std::vector<int32_t> sf(nt), sr(nt), sfin(nt);
   std::vector<uint8_t> fwd(nt), ops(ocap ? ocap : 1);
   std::vector<uint32_t> sb(nt), sl(nt), rp(nt), olen(nt);
@@ -663,6 +664,7 @@ bool decompose_group(tracyhip_ctx* ctx, SageConfig const& c, tracyhip_params con
   job.bc = tracyhip_basecalls{nt, sig.data(), soff.data(), ns.data(), pos.data(), pri.data(), sec.data(), boff.data(), blen.data()};
   job.refs = tracyhip_seqset{TRACYHIP_SEQ_CHAR, refs.data(), roff.data(), rlen.data(), nt};
   job.dprm = tracyhip_decomp_params{(int32_t)jobs[0]->trimLeft, (int32_t)jobs[0]->trimRight, (int32_t)c.maxindel, (int32_t)c.madc};
+  job.strand_by_certificate = 1;  // the orientation scores are not written anywhere (indigo.h:235-247 keeps only rs.forward)
   const bool seeded = jobs[0]->rs.filetype == 0 || wildtype;  // the reference arrives oriented
   std::vector<uint8_t> orient(nt);
   for (uint32_t i = 0; i < nt; ++i) orient[i] = jobs[i]->rs.forward ? 1 : 0;

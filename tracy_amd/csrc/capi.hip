@@ -178,26 +178,61 @@ int check_params(const tracyhip_params* prm, uint64_t max_mn) {
 }
 
 // ---- the DP driver shared by gotoh/needle score/align -----------------------------------------------
-// 16-bit score kernel: every real DP value must fit int16 with room below for the sentinel
-bool narrow_ok(const tracyhip_params* prm, uint32_t maxm, int K) {
+static int64_t iabs64(int32_t x) { return x < 0 ? -(int64_t)x : (int64_t)x; }
+int32_t sub_limit(const tracyhip_params* prm) { return (int32_t)std::max(iabs64(prm->match), iabs64(prm->mismatch)); }
+
+// 16-bit score kernel: every real DP value must fit int16 with room below for the sentinel.  Q bounds the absolute value of
+// a substitution score: max(|match|, |mismatch|) for strings and normalised profiles (the a-priori call, Q = 0), the
+// device-reported maximum when a launch has seen a larger query-profile entry (range_verdict).
+bool narrow_ok(const tracyhip_params* prm, uint32_t maxm, int K, int64_t Q) {
   // free end gaps on the first/last row only, strictly negative extension, one pass of the strip height
   if (!prm->hfree || prm->vfree || prm->go > 0 || prm->ge >= 0 || num_passes(maxm ? maxm : 1, K) != 1) return false;
-  auto ab = [](int32_t x) { return (int64_t)(x < 0 ? -(int64_t)x : x); };
+  Q = std::max<int64_t>(Q, sub_limit(prm));
   const int64_t rows = (int64_t)num_passes(maxm ? maxm : 1, K) * 64 * K;
-  const int64_t low = ab(prm->go) + rows * ab(prm->ge) + 2 * (ab(prm->go) + ab(prm->ge)) + ab(prm->mismatch) + ab(prm->match);
-  const int64_t high = rows * std::max(ab(prm->match), ab(prm->mismatch));
-  return (low < -(int64_t)kNegInf16 - ab(prm->ge) - 64) && (high < 30000);
+  const int64_t low = iabs64(prm->go) + rows * iabs64(prm->ge) + 2 * (iabs64(prm->go) + iabs64(prm->ge)) + 2 * Q;
+  const int64_t high = rows * Q;
+  return (low < -(int64_t)kNegInf16 - iabs64(prm->ge) - 64) && (high < 30000);
 }
 
+// origin-tracking sweep: string x string only, so substitution scores are match / mismatch exactly
 bool origin_ok(const tracyhip_params* prm, uint32_t maxm, uint32_t maxn, int K) {
   if (!prm->hfree || prm->vfree || prm->go > 0 || prm->ge >= 0 || num_passes(maxm ? maxm : 1, K) != 1) return false;
   if ((uint64_t)maxn + 64 >= (1u << kOriginBits)) return false;
-  auto ab = [](int32_t x) { return (int64_t)(x < 0 ? -(int64_t)x : x); };
   const int64_t rows = 64 * (int64_t)K;
-  const int64_t low = ab(prm->go) + rows * ab(prm->ge) + 2 * (ab(prm->go) + ab(prm->ge)) + ab(prm->mismatch) + ab(prm->match);
-  const int64_t high = rows * std::max(ab(prm->match), ab(prm->mismatch));
+  const int64_t low = iabs64(prm->go) + rows * iabs64(prm->ge) + 2 * (iabs64(prm->go) + iabs64(prm->ge)) + iabs64(prm->mismatch) + iabs64(prm->match);
+  const int64_t high = rows * sub_limit(prm);
   // 14-bit score field [-8192, 8191]; the sentinel kNegInfOrigin must stay below every real value and above the field's floor
-  return (low < -(int64_t)kNegInfOrigin - ab(prm->ge) - 64) && (-(int64_t)kNegInfOrigin + ab(prm->go) + ab(prm->ge) < 8000) && (high < 8000);
+  return (low < -(int64_t)kNegInfOrigin - iabs64(prm->ge) - 64) && (-(int64_t)kNegInfOrigin + iabs64(prm->go) + iabs64(prm->ge) < 8000) && (high < 8000);
+}
+
+// What the launches of one run reported about their substitution scores (DpArgs::err).  TRACYHIP_OK: every value range the
+// host assumed before the launch held.  kWiden: a 16-bit kernel ran outside its proven range -- its results are discarded
+// and the caller repeats the work on the int32 kernels.  TRACYHIP_ERR_RANGE: not even those hold the values exactly.
+int range_verdict(const tracyhip_params* prm, const int32_t* herr, const std::vector<std::pair<uint32_t, int>>& narrow_launches,
+                  uint64_t max_mn, int value_shift) {
+  if (herr[0] & 1) return set_error(TRACYHIP_ERR_RANGE, "a query-profile score does not fit the int16 table (profile values too large)");
+  if (herr[0] & 2) return set_error(TRACYHIP_ERR_RANGE, "traceback left the matrix (degenerate scoring parameters)");
+  int64_t Q = sub_limit(prm);
+  bool seen = false;
+  if (herr[1] > Q) { Q = herr[1]; seen = true; }
+  if (herr[2] || herr[3]) {
+    float fa, fb;
+    std::memcpy(&fa, &herr[2], 4);
+    std::memcpy(&fb, &herr[3], 4);
+    if (!(fa < 3.0e38f) || !(fb < 3.0e38f)) return set_error(TRACYHIP_ERR_RANGE, "a profile holds NaN or infinite values");
+    const double bound = (double)std::max(fa, 1.001f) * (double)std::max(fb, 1.001f) * (double)sub_limit(prm) * 1.0001 + 1.0;
+    if (bound > 1.0e9) return set_error(TRACYHIP_ERR_RANGE, "profile values too large for exact int32 scoring");
+    Q = std::max<int64_t>(Q, (int64_t)bound + 1);
+    seen = true;
+  }
+  if (!seen) return TRACYHIP_OK;
+  for (auto const& nl : narrow_launches)
+    if (!narrow_ok(prm, nl.first, nl.second, Q)) return kWiden;
+  const int64_t c = iabs64(prm->go) + iabs64(prm->ge) + Q;
+  if ((int64_t)(max_mn + 2) * c + 1000000 >= (1ll << (31 - value_shift)))
+    return set_error(TRACYHIP_ERR_RANGE, "un-normalised profile: (m+n) * (gap cost + largest substitution score %lld) exceeds the exact range of the int32 kernels",
+                     (long long)Q);
+  return TRACYHIP_OK;
 }
 
 int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, bool needle, bool trace,
@@ -264,8 +299,11 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
     HIP_TRY(ctx->d_band.ensure((size_t)maxrun * ck->B * 64 * 8));
   }
   if (max_scr) HIP_TRY(ctx->d_scratch.ensure(max_scr * 8));
-  HIP_TRY(ctx->d_err.ensure(sizeof(int32_t)));
-  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t), st));
+  HIP_TRY(ctx->d_err.ensure(kErrBytes));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
+  std::vector<std::pair<uint32_t, int>> narrow_launches;  // (tallest problem, K) of every 16-bit launch, for range_verdict
+  uint64_t max_mn = 0;
+  for (uint32_t j = 0; j < np; ++j) max_mn = std::max<uint64_t>(max_mn, (uint64_t)pb.desc[j].m + pb.desc[j].n);
 
   DpArgs a{};
   a.a1 = pb.d_a1;
@@ -277,6 +315,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   a.err = static_cast<int32_t*>(ctx->d_err.p);
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge;
   a.hfree = prm->hfree; a.vfree = prm->vfree;
+  a.qlimit = sub_limit(prm);
   if (ck) a.ends = ck->d_ends;
   if (ck) { a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.band = static_cast<uint64_t*>(ctx->d_band.p); a.ckpt_narrow = ck->narrow ? 1 : 0; }
   const PairDesc* dd = static_cast<const PairDesc*>(ctx->d_desc.p);
@@ -305,6 +344,11 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
         uint32_t maxm = 0;
         for (uint32_t q = j; q < e; ++q) maxm = std::max(maxm, hd[q].m);
         narrow = narrow_ok(prm, maxm, K);
+      }
+      if (stage == DP_PREFIX || (stage == DP_CKPT && ck->narrow) || (stage == DP_PLAIN && narrow)) {
+        uint32_t maxm = 0;
+        for (uint32_t q = j; q < e; ++q) maxm = std::max(maxm, hd[q].m);
+        narrow_launches.emplace_back(maxm, K);
       }
       if (stage == DP_PREFIX) {
         HIP_TRY(launch_gotoh_prefix(K, a, e - j, st));
@@ -339,13 +383,19 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
       j = e;
     }
   }
-  int32_t herr = 0;
-  HIP_TRY(hipMemcpyAsync(&herr, ctx->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  int32_t herr[kErrWords] = {};
+  HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   timing_collect(ctx);
-  if (herr & 1) return set_error(TRACYHIP_ERR_RANGE, "a query-profile score does not fit int16 (profile values too large)");
-  if (herr & 2) return set_error(TRACYHIP_ERR_RANGE, "traceback left the matrix (degenerate scoring parameters)");
-  return TRACYHIP_OK;
+  const int verdict = range_verdict(prm, herr, narrow_launches, max_mn, trace ? (needle ? 2 : kTagShift) : 0);
+  if (verdict == kWiden && stage == DP_PLAIN) {  // the 16-bit score kernel met an un-normalised profile: same work on the int32 kernel
+    const bool keep = ctx->no_narrow;
+    ctx->no_narrow = true;
+    const int rc = run_dp(ctx, pb, prm, needle, trace, d_scores, d_ops, d_ops_off, d_ops_len, stage, ck);
+    ctx->no_narrow = keep;
+    return rc;
+  }
+  return verdict;  // DP_CKPT / DP_PREFIX: kWiden goes to the pipeline, which restarts its orientation stage on the int32 kernels
 }
 
 // validate a pair list and turn it into device-side descriptors + staged payloads
@@ -420,11 +470,12 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   for (size_t i = 0; i < np; ++i) hd[nf + i] = pre[i];
   HIP_TRY(ctx->d_desc.ensure(sizeof(PairDesc) * (nf + np)));
   HIP_TRY(hipMemcpyAsync(ctx->d_desc.p, hd, sizeof(PairDesc) * (nf + np), hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx->d_err.ensure(sizeof(int32_t)));
-  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t), st));
+  HIP_TRY(ctx->d_err.ensure(kErrBytes));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
   DpArgs a{};
   a.a1 = d_a1; a.a2 = d_a2; a.scores = d_scores; a.err = static_cast<int32_t*>(ctx->d_err.p);
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge; a.hfree = prm->hfree; a.vfree = prm->vfree;
+  a.qlimit = sub_limit(prm);
   a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.ckpt_narrow = 1;
   DpArgs af = a, ap = a;
   af.pairs = static_cast<const PairDesc*>(ctx->d_desc.p);
@@ -438,12 +489,14 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   }
   HIP_TRY(launch_gotoh_ckpt_prefix(K, af, (uint32_t)nf, ap, (uint32_t)np, st));
   if ((trc = timing_end(ctx))) return trc;
-  int32_t herr = 0;
-  HIP_TRY(hipMemcpyAsync(&herr, ctx->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  int32_t herr[kErrWords] = {};
+  HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   timing_collect(ctx);
-  if (herr & 1) return set_error(TRACYHIP_ERR_RANGE, "a query-profile score does not fit int16 (profile values too large)");
-  return TRACYHIP_OK;
+  uint32_t maxm = 0;
+  uint64_t max_mn = 0;
+  for (size_t i = 0; i < nf + np; ++i) { maxm = std::max(maxm, hd[i].m); max_mn = std::max<uint64_t>(max_mn, (uint64_t)hd[i].m + hd[i].n); }
+  return range_verdict(prm, herr, {{maxm, K}}, max_mn, 0);  // kWiden: the pipeline restarts on the int32 kernels
 }
 }  // namespace tracyhip
 

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <utility>
 #include <vector>
 
 #include "../../include/tracy_hip.h"
@@ -118,7 +119,15 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
 int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, bool needle, bool trace,
            int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len, int stage = DP_PLAIN,
            DpCkpt* ck = nullptr);
-bool narrow_ok(const tracyhip_params* prm, uint32_t maxm, int K);
+bool narrow_ok(const tracyhip_params* prm, uint32_t maxm, int K, int64_t Q = 0);
+int32_t sub_limit(const tracyhip_params* prm);
+// device error block (DpArgs::err): kErrWords words owned by the DP launches + one verdict word of the pipelines' reference check
+constexpr int kErrVerdictWord = kErrWords;
+constexpr size_t kErrBytes = sizeof(int32_t) * (kErrWords + 1);
+// internal status (never returned through the C ABI): a 16-bit launch ran outside its proven value range; repeat on int32
+constexpr int kWiden = 1;
+int range_verdict(const tracyhip_params* prm, const int32_t* herr, const std::vector<std::pair<uint32_t, int>>& narrow_launches,
+                  uint64_t max_mn, int value_shift);
 int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool needle, DpProblem& pb, uint64_t* max_mn);
 }  // namespace tracyhip
 #endif

@@ -52,8 +52,12 @@ struct DpArgs {
   uint32_t* bits32;     // NW traceback words
   int32_t* scratch;     // int2 per column: {H, F} of the last row of the previous pass
   int32_t* scores;      // may be null in traceback kernels
-  int32_t* err;         // device error flags (bit 0: query-profile value does not fit int16)
+  int32_t* err;         // device error block, kErrWords int32: [0] flags (bit 0: a query-profile value does not fit int16,
+                        // bit 1: a traceback walk left the matrix), [1] largest |query-profile score| seen above qlimit,
+                        // [2] / [3] largest column mass sum_k |p[k][j]| of an a1 / a2 profile above 1 (float bits; profile x profile)
   int32_t match, mismatch, go, ge;
+  int32_t qlimit;       // max(|match|, |mismatch|): what a substitution score of NORMALISED profiles cannot exceed.  The host-side
+                        // range guards (narrow_ok, origin_ok, check_params) assume it; kernels report anything larger in err[1..3]
   int32_t hfree, vfree;
   int32_t* ckpt;        // wavefront checkpoints (score kernel writes, band traceback reads)
   int32_t* lastrow;     // last-row {H, E} per column
@@ -64,6 +68,7 @@ struct DpArgs {
 };
 
 // device error flags are OR-ed (several kernels share the word)
+constexpr int kErrWords = 4;
 TR_HD void flag_error(int32_t* err, int32_t bits) {
   if (!err) return;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -71,6 +76,38 @@ TR_HD void flag_error(int32_t* err, int32_t bits) {
 #else
   *err |= bits;
 #endif
+}
+// err[word] = max(err[word], v) for non-negative v (also used on the bits of non-negative floats, which order like ints)
+TR_HD void flag_max(int32_t* err, int word, int32_t v) {
+  if (!err) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicMax(err + word, v);
+#else
+  if (v > err[word]) err[word] = v;
+#endif
+}
+TR_HD int32_t float_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __float_as_int(f);
+#else
+  int32_t i;
+  __builtin_memcpy(&i, &f, 4);
+  return i;
+#endif
+}
+// Profile x profile scoring (align.h:103-118) is bounded by |score| <= (sum_k |p1[k][row]|) (sum_k |p2[k][col]|) max(|match|, |mismatch|).
+// Column masses of createProfile output are <= 1 (+ rounding), which is what the host-side range checks assume; a lane that sees
+// a larger mass (or a NaN) reports it, and the host re-checks the value range with the real bound after the launch.
+TR_HD void report_mass(int32_t* err, int word, float mass) {
+  if (!(mass <= 1.001f)) flag_max(err, word, float_bits(mass != mass ? __builtin_inff() : mass));
+}
+// running maximum that keeps a NaN once it has seen one
+TR_HD float mass_max(float acc, float s) { return (s > acc || s != s) ? s : acc; }
+TR_HD float column_mass(const float* p, uint64_t stride, uint32_t j) {
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { const float v = p[(uint64_t)k * stride + j]; s += v < 0.0f ? -v : v; }
+  return s;
 }
 
 // ---- substitution-score providers -------------------------------------------------------------
@@ -234,9 +271,12 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   bool skip4 = false;
   if (MODE == MODE_PROF) {
     bool nz = false;
-    for (uint32_t r = L; r < m; r += 64) nz |= !(a1p[4ull * d.a1_stride + r] == 0.0f);
-    for (uint32_t c = L; c < n; c += 64) nz |= !(a2p[4ull * d.a2_stride + c] == 0.0f);
+    float ma = 0.0f, mb = 0.0f;
+    for (uint32_t r = L; r < m; r += 64) { nz |= !(a1p[4ull * d.a1_stride + r] == 0.0f); const float s = column_mass(a1p, d.a1_stride, r); ma = mass_max(ma, s); }
+    for (uint32_t c = L; c < n; c += 64) { nz |= !(a2p[4ull * d.a2_stride + c] == 0.0f); const float s = column_mass(a2p, d.a2_stride, c); mb = mass_max(mb, s); }
     skip4 = w.ballot(nz) == 0;
+    report_mass(a.err, 2, ma);
+    report_mass(a.err, 3, mb);
   }
 
   const uint32_t P = num_passes(m, K);
@@ -304,6 +344,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     } else if (MODE == MODE_QP) {
       w.sync();  // previous pass may still be reading the table
       bool overflow = false;
+      int32_t qabs = 0;
 #pragma unroll 1
       for (int i = 0; i < K; ++i) {  // not unrolled: the set-up must not dictate the kernel's register budget
         const uint32_t r = base + L * K + i + 1 - pad;
@@ -314,7 +355,8 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         for (uint32_t b = 0; b < 5; ++b) {
           const int32_t q = (r - 1 < m) ? onehot_score(pr, b, fmatch, fmis) : 0;
           const int32_t qs = (int32_t)((uint32_t)q << SH) - goe_n;
-          overflow |= (qs > 32767) || (qs < -32768);
+          overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
+          qabs = imax(qabs, q < 0 ? -q : q);
           // reverse-complement view of a2: the complement is folded into the table (row of code b serves code 3-b),
           // the sweep selects rows with the raw codes
           const uint32_t row = (rc_view && b < 4u) ? 3u - b : b;
@@ -323,6 +365,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       }
       if (L < (uint32_t)qp_stride(K)) qp_tab[5 * (64 * qp_stride(K)) + L] = (int16_t)(-goe_n);
       if (overflow) flag_error(a.err, 1);
+      if (qabs > a.qlimit) flag_max(a.err, 1, qabs);  // un-normalised profile: the host re-checks the value range (capi.hip)
       w.sync();
     } else {
 #pragma unroll
@@ -647,6 +690,7 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
   // query-profile strips of this lane's rows (values - (go+ge), as in the 16-bit score kernel)
   {
     bool overflow = false;
+    int32_t qabs = 0;
 #pragma unroll 1
     for (int i = 0; i < K; ++i) {
       const uint32_t r = Lg * K + i + 1;
@@ -655,13 +699,16 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
       for (int k = 0; k < 5; ++k) pr[k] = (valid && r - 1 < m) ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
 #pragma unroll
       for (uint32_t b = 0; b < 5; ++b) {
-        const int32_t qs = ((valid && r - 1 < m) ? onehot_score(pr, b, fmatch, fmis) : 0) - goe;
-        overflow |= (qs > 32767) || (qs < -32768);
+        const int32_t q = (valid && r - 1 < m) ? onehot_score(pr, b, fmatch, fmis) : 0;
+        const int32_t qs = q - goe;
+        overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
+        qabs = imax(qabs, q < 0 ? -q : q);
         qp_tab[b * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)qs;
       }
     }
     if (L < (uint32_t)qp_stride(K)) qp_tab[5 * (64 * qp_stride(K)) + L] = (int16_t)(-goe);
     if (overflow) flag_error(a.err, 1);
+    if (qabs > a.qlimit) flag_max(a.err, 1, qabs);
     w.sync();
   }
 
@@ -929,6 +976,7 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
       sub_c.vmis = (int32_t)((uint32_t)a.mismatch << SH);
       sub_c.cc = 0;
     } else {
+      bool band_overflow = false;
 #pragma unroll 1
       for (int i = 0; i < K; ++i) {
         const uint32_t r = L * K + i + 1 - pad;
@@ -939,10 +987,12 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
         for (uint32_t bb = 0; bb < 5; ++bb) {
           const int32_t qv = (r - 1 < m) ? onehot_score(pr, bb, fmatch, fmis) : 0;
           const uint32_t rowsel = (rcflag && bb < 4u) ? 3u - bb : bb;  // complement folded into the table (as gotoh_body)
+          band_overflow |= (qv > (32767 >> SH)) || (qv < -(32768 >> SH));
           qp_tab[rowsel * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)((uint32_t)qv << SH);
         }
       }
       if (L < (uint32_t)qp_stride(K)) qp_tab[5 * (64 * qp_stride(K)) + L] = 0;
+      if (band_overflow) flag_error(a.err, 1);
       w.sync();
     }
 
@@ -1119,6 +1169,13 @@ TR_HD void needle_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const uint8_t* a2c = static_cast<const uint8_t*>(a.a2) + (MODE != MODE_PROF ? d.a2_off : 0);
   const float* a2p = static_cast<const float*>(a.a2) + (MODE == MODE_PROF ? d.a2_off : 0);
   float* p1_tab = reinterpret_cast<float*>(w.lds());
+  if (MODE == MODE_PROF) {
+    float ma = 0.0f, mb = 0.0f;
+    for (uint32_t r = L; r < m; r += 64) { const float s = column_mass(a1p, d.a1_stride, r); ma = mass_max(ma, s); }
+    for (uint32_t c = L; c < n; c += 64) { const float s = column_mass(a2p, d.a2_stride, c); mb = mass_max(mb, s); }
+    report_mass(a.err, 2, ma);
+    report_mass(a.err, 3, mb);
+  }
 
   const uint32_t P = num_passes(m, K);
   uint32_t* bits = TRACE ? a.bits32 + d.bits_off : nullptr;

@@ -247,7 +247,7 @@ struct OrientOut {
   std::vector<uint8_t> fwd, rc; // rs.forward; "read the window as its reverse complement"
 };
 
-int orient_and_align(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn& in, OrientOut& o) {
+int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn& in, OrientOut& o, bool force_wide) {
   int rc;
   hipStream_t st = ctx->stream;
   const uint32_t nt = in.nt;
@@ -295,7 +295,7 @@ int orient_and_align(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn
         HIP_TRY(ctx->d_lastrow.ensure(lr_tot * 4 + 64));
         uint32_t maxmt = 0;
         for (uint32_t t = 0; t < nt; ++t) maxmt = std::max(maxmt, mt[t]);
-        ck.narrow = !ctx->no_narrow && narrow_ok(&p, maxmt, 16);  // conservative: the tallest strip
+        ck.narrow = !force_wide && !ctx->no_narrow && narrow_ok(&p, maxmt, 16);  // conservative: the tallest strip
         ck.d_ckpt = static_cast<int32_t*>(ctx->d_ckpt.p);
         ck.d_lastrow = static_cast<int32_t*>(ctx->d_lastrow.p);
       }
@@ -532,6 +532,15 @@ int orient_and_align(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn
   return TRACYHIP_OK;
 }
 
+// The 16-bit sweeps assume substitution scores of normalised profiles (|q| <= max(|match|, |mismatch|)).  A launch that meets a
+// larger entry reports it; when the 16-bit range no longer holds (kWiden) the whole stage is repeated on the int32 kernels.
+int orient_and_align(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn& in, OrientOut& o) {
+  int rc = orient_and_align_impl(ctx, p, in, o, false);
+  if (rc == kWiden) rc = orient_and_align_impl(ctx, p, in, o, true);
+  if (rc == kWiden) rc = set_error(TRACYHIP_ERR_RANGE, "profile values outside the range of the score kernels");
+  return rc;
+}
+
 }  // namespace
 
 static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
@@ -561,12 +570,15 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
   if ((rc = stage_in(ctx, ctx->d_in2, sr.data, er, mem, &d_ref))) return rc;
   // The validation verdict (second word of d_err; run_dp owns the first) is read back together with the orientation
   // scores: no host round trip between the encode and the first score pass.
-  HIP_TRY(ctx->d_err.ensure(2 * sizeof(int32_t)));
-  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, 2 * sizeof(int32_t), st));
-  int32_t* d_verr = static_cast<int32_t*>(ctx->d_err.p) + 1;
+  HIP_TRY(ctx->d_err.ensure(kErrBytes));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, kErrBytes, st));
+  int32_t* d_verr = static_cast<int32_t*>(ctx->d_err.p) + kErrVerdictWord;
   HIP_TRY(ctx->ensure_codes(er ? er : 1, st));
   if (er) {
-    hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er, d_verr);
+    // Windows oriented by the caller (indexed genome) are never reverse-complemented here, and every other letter scores as
+    // the all-zero profile column it is in the reference (getReferenceSlice upper-cases only; align.h:121-136): no check.
+    if (!job->oriented)
+      hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er, d_verr);
     hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
                        ctx->codes(), er);
     HIP_TRY(hipGetLastError());
@@ -610,7 +622,7 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
   for (uint32_t t = 0; t < nt; ++t) { a1o[t] = sp.offset[t] + tl[t]; a2o[t] = sr.offset[ridx[t]]; }
   OrientIn oi{};
   oi.nt = nt; oi.d_prof = d_prof; oi.a1_off = a1o.data(); oi.mf = mf.data(); oi.mt = mt.data(); oi.a2_off = a2o.data(); oi.rn = rn.data();
-  oi.oriented = job->oriented; oi.exact = job->exact_orientation_scores != 0; oi.d_verr = d_verr;
+  oi.oriented = job->oriented; oi.exact = job->strand_by_certificate == 0; oi.d_verr = d_verr;
   oi.d_ops = static_cast<uint8_t*>(ctx->d_tmp[1].p); oi.d_ops_off = static_cast<const uint64_t*>(ctx->d_tmp[2].p);
   oi.d_ops_len = static_cast<uint32_t*>(ctx->d_tmp[3].p); oi.d_score = static_cast<int32_t*>(ctx->d_tmp[4].p);
   OrientOut oo;
@@ -942,17 +954,18 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   if ((rc = io(out->score_trim, sizeof(int32_t) * (size_t)nt, false, &d_strim))) return rc;
 
   // references: validate + encode
-  HIP_TRY(ctx->d_err.ensure(sizeof(int32_t)));
-  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t), st));
+  HIP_TRY(ctx->d_err.ensure(kErrBytes));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, kErrBytes, st));
   HIP_TRY(ctx->ensure_codes(er ? er : 1, st));
   if (er) {
-    hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er,
-                       static_cast<int32_t*>(ctx->d_err.p));
+    int32_t* d_verr = static_cast<int32_t*>(ctx->d_err.p) + kErrVerdictWord;
+    if (!job->oriented)  // as in tracyhip_align_traces: caller-oriented windows are taken as they are
+      hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er, d_verr);
     hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
                        ctx->codes(), er);
     HIP_TRY(hipGetLastError());
     int32_t herr = 0;
-    HIP_TRY(hipMemcpyAsync(&herr, ctx->d_err.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&herr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if ((herr & 4) && !wildtype) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
   }
@@ -984,7 +997,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   // no orientation scores; oriented[t] = rs.forward only steers rs.pos in trimReferenceSlice
   const bool given = job->oriented != nullptr;
   // FASTA / indexed reference: orientation and the alignment of the trimmed trace run through the stages `tracy align`
-  // uses (checkpointed 16-bit score pass, strand by certificate unless exact_orientation_scores, band traceback).
+  // uses (checkpointed 16-bit score pass, strand by certificate when the job opts in, band traceback).
   // Wildtype-trace reference: profile x profile, full-matrix traceback (the caller picked the strand).
   const bool shared_stages = !wildtype;
   std::vector<int32_t> h_sc2(2 * (size_t)nt, 0);
@@ -1025,7 +1038,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     for (uint32_t t = 0; t < nt; ++t) { a1o[t] = sp.offset[t] + tl[t]; a2o[t] = sr.offset[ridx[t]]; }
     OrientIn oi{};
     oi.nt = nt; oi.d_prof = d_prof; oi.a1_off = a1o.data(); oi.mf = mf.data(); oi.mt = mt.data(); oi.a2_off = a2o.data(); oi.rn = rn.data();
-    oi.oriented = job->oriented; oi.exact = job->exact_orientation_scores != 0; oi.d_verr = nullptr;
+    oi.oriented = job->oriented; oi.exact = job->strand_by_certificate == 0; oi.d_verr = nullptr;
     oi.d_ops = static_cast<uint8_t*>(b_ops1.p); oi.d_ops_off = d_off1; oi.d_ops_len = static_cast<uint32_t*>(b_len1.p);
     oi.d_score = static_cast<int32_t*>(d_strim);
     OrientOut oo;

@@ -449,7 +449,9 @@ void tracyhost_synth_align(uint64_t seed0, uint32_t ntraces, uint32_t n, uint32_
 // Seeded synthetic `tracy decompose` case: reference window of n bases; allele 1 =
 // mf bases copied from it (forward strand), allele 2 = allele 1 with one heterozygous indel (length
 // U[1,maxlen], insertion or deletion) at a position U[150, mf-300] plus 0.5 % heterozygous SNVs; the two
-// alleles are mixed frac1 : 1-frac1 in the chromatogram.  kind: 0 = het indel, 1 = SNVs only (no indel).
+// alleles are mixed frac1 : 1-frac1 in the chromatogram.  kind & 3: 0 = het indel, 1 = het SNVs only (no indel), 2 = homozygous
+// indel only (both alleles carry it, no het SNVs), 3 = no variant at all.  kind & 16: the window handed out is the reverse
+// complement of the one the trace was copied from (the trace reads the reverse strand of its reference).
 // Outputs: ref[n]; signal[4][12*(mf+40)+12] (zero padded), basecallpos[npos]; returns npos.
 uint32_t tracyhost_synth_decompose(uint64_t seed, uint32_t n, uint32_t mf, uint32_t maxlen, int kind, double frac1,
                                    uint8_t* ref_out, int32_t* signal, uint32_t nsamples_cap, int32_t* basecallpos,
@@ -461,7 +463,9 @@ uint32_t tracyhost_synth_decompose(uint64_t seed, uint32_t n, uint32_t mf, uint3
   std::string a1 = ref.substr(start, mf + 40);
   std::string a2 = a1;
   int32_t indel = 0;
-  if (kind == 0) {
+  const bool reverse_strand = (kind & 16) != 0;
+  kind &= 3;
+  if (kind == 0 || kind == 2) {
     const uint32_t pos = 150 + rng.below(mf > 450 ? mf - 450 : 1);
     const uint32_t len = 1 + rng.below(maxlen);
     if (rng.next() & 1) {  // deletion in allele 2
@@ -473,9 +477,15 @@ uint32_t tracyhost_synth_decompose(uint64_t seed, uint32_t n, uint32_t mf, uint3
       a2.insert(pos, ins);
       indel = (int32_t)len;
     }
+    if (kind == 2) a1 = a2;  // homozygous: both alleles carry the indel
   }
-  for (size_t i = 0; i < a2.size(); ++i)
-    if (rng.unit() < 0.005) a2[i] = kBases[(base_index(a2[i]) + 1 + rng.below(3)) & 3];
+  if (kind < 2)
+    for (size_t i = 0; i < a2.size(); ++i)
+      if (rng.unit() < 0.005) a2[i] = kBases[(base_index(a2[i]) + 1 + rng.below(3)) & 3];
+  if (reverse_strand) {
+    std::reverse(ref.begin(), ref.end());
+    for (auto& c : ref) c = complement(c);
+  }
   a1.resize(mf);
   a2.resize(mf);
   Trace tr;
@@ -495,8 +505,21 @@ uint32_t tracyhost_synth_decompose(uint64_t seed, uint32_t n, uint32_t mf, uint3
 // (0.33) and profiled here; traces whose basecaller dropped a window are regenerated with the next seed
 // stride so that all traces have exactly mf basecalls.  Layouts: refs [nt][n]; signal [nt][4][ns] with
 // ns = 12*mf+12; bcpos / primary / secondary [nt][mf]; profiles [nt][6][mf].
+// mix 0: the round-1 batch above (all forward strand).  mix 1: BASELINE configs[2] as SURVEY.md 8d words it -- trace i with
+// i % 10 == 8 carries a homozygous indel only, i % 10 == 9 no variant, the rest one het indel + 0.5 % het SNVs; odd traces
+// read the reverse strand of their window.
+static void synth_decompose_batch_mix(uint64_t seed0, uint32_t nt, uint32_t n, uint32_t mf, uint8_t* refs, int32_t* signal,
+                                      int32_t* bcpos, uint8_t* primary, uint8_t* secondary, float* profiles, uint32_t nthreads, int mix);
 void tracyhost_synth_decompose_batch(uint64_t seed0, uint32_t nt, uint32_t n, uint32_t mf, uint8_t* refs, int32_t* signal,
                                      int32_t* bcpos, uint8_t* primary, uint8_t* secondary, float* profiles, uint32_t nthreads) {
+  synth_decompose_batch_mix(seed0, nt, n, mf, refs, signal, bcpos, primary, secondary, profiles, nthreads, 0);
+}
+void tracyhost_synth_decompose_batch2(uint64_t seed0, uint32_t nt, uint32_t n, uint32_t mf, uint8_t* refs, int32_t* signal,
+                                      int32_t* bcpos, uint8_t* primary, uint8_t* secondary, float* profiles, uint32_t nthreads, int mix) {
+  synth_decompose_batch_mix(seed0, nt, n, mf, refs, signal, bcpos, primary, secondary, profiles, nthreads, mix);
+}
+static void synth_decompose_batch_mix(uint64_t seed0, uint32_t nt, uint32_t n, uint32_t mf, uint8_t* refs, int32_t* signal,
+                                      int32_t* bcpos, uint8_t* primary, uint8_t* secondary, float* profiles, uint32_t nthreads, int mix) {
   if (nthreads == 0) nthreads = tracy_amd::usable_threads();
   const uint32_t ns = 12 * mf + 12;
   auto work = [&](uint32_t tid) {
@@ -506,7 +529,9 @@ void tracyhost_synth_decompose_batch(uint64_t seed0, uint32_t nt, uint32_t n, ui
         const uint64_t seed = seed0 + i + attempt * 1000003ull * nt;
         int32_t indel = 0;
         int32_t* sig = signal + (size_t)i * 4 * ns;
-        const uint32_t npos = tracyhost_synth_decompose(seed, n, mf, 30, (i % 5 == 4) ? 1 : 0, 0.6, refs + (size_t)i * n, sig, ns,
+        int kind = (i % 5 == 4) ? 1 : 0;
+        if (mix == 1) kind = ((i % 10 == 8) ? 2 : (i % 10 == 9) ? 3 : 0) | ((i & 1) ? 16 : 0);
+        const uint32_t npos = tracyhost_synth_decompose(seed, n, mf, 30, kind, 0.6, refs + (size_t)i * n, sig, ns,
                                                         pos.data(), &indel);
         Trace tr;
         tr.traceACGT.resize(4);

@@ -73,20 +73,22 @@ def synth_decompose(seed, n, mf, maxlen=30, kind=0, frac1=0.6):
     return ref.tobytes(), sig, pos[:npos].copy(), indel.value
 
 
-def synth_decompose_batch(seed0, nt, n, mf, nthreads=0):
+def synth_decompose_batch(seed0, nt, n, mf, nthreads=0, mix=0):
     """returns dict(refs [nt][n] u8, signal [nt][4][ns] i32, bcpos [nt][mf] i32, primary/secondary [nt][mf] u8,
-    profiles [nt][6][mf] f32)"""
+    profiles [nt][6][mf] f32).  mix 0: 80 % het indels, 20 % SNVs only, forward strand.  mix 1 (BASELINE configs[2] as
+    SURVEY.md 8d words it): 80 % het indel + het SNVs, 10 % homozygous indel only, 10 % no variant; odd traces read the
+    reverse strand of their window."""
     ns = 12 * mf + 12
     out = dict(refs=np.zeros((nt, n), np.uint8), signal=np.zeros((nt, 4, ns), np.int32), bcpos=np.zeros((nt, mf), np.int32),
                primary=np.zeros((nt, mf), np.uint8), secondary=np.zeros((nt, mf), np.uint8),
                profiles=np.zeros((nt, 6, mf), np.float32))
-    lib().tracyhost_synth_decompose_batch(C.c_uint64(seed0), C.c_uint32(nt), C.c_uint32(n), C.c_uint32(mf),
-                                          out["refs"].ctypes.data_as(C.POINTER(C.c_uint8)),
-                                          out["signal"].ctypes.data_as(C.POINTER(C.c_int32)),
-                                          out["bcpos"].ctypes.data_as(C.POINTER(C.c_int32)),
-                                          out["primary"].ctypes.data_as(C.POINTER(C.c_uint8)),
-                                          out["secondary"].ctypes.data_as(C.POINTER(C.c_uint8)),
-                                          out["profiles"].ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(nthreads))
+    lib().tracyhost_synth_decompose_batch2(C.c_uint64(seed0), C.c_uint32(nt), C.c_uint32(n), C.c_uint32(mf),
+                                           out["refs"].ctypes.data_as(C.POINTER(C.c_uint8)),
+                                           out["signal"].ctypes.data_as(C.POINTER(C.c_int32)),
+                                           out["bcpos"].ctypes.data_as(C.POINTER(C.c_int32)),
+                                           out["primary"].ctypes.data_as(C.POINTER(C.c_uint8)),
+                                           out["secondary"].ctypes.data_as(C.POINTER(C.c_uint8)),
+                                           out["profiles"].ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(nthreads), int(mix))
     return out
 
 

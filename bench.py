@@ -13,12 +13,23 @@ Legs (each: W warm-up + K timed steps between barriers): (1) the headline -- one
 chunks of the batch in flight.  Legs 2-4 are checked to return the headline leg's alignments and are reported beside it;
 `--certificate-leg 0 --lanes-leg 0` runs the headline alone (what the rocprofv3 passes under profiles/ use).
 
+Beside the headline the default run also times BASELINE.json configs[2] (`tracy decompose`, 100 000 traces sharded over the
+ranks) and configs[4] (all-pairs profile x profile scoring of 1000 traces, pair list sharded over the ranks, score slices
+all-gathered) -- tools/legs.py -- each with its own roofline, cpu_baseline and in-run parity sample, reported as the
+`decompose` and `allpairs` objects of the same line (`--workload align|decompose|allpairs` runs one of them alone, which
+is what the rocprofv3 passes under profiles/ use).  `value` is always the align headline.
+
+`--gpus N` without a torch.distributed environment starts the N ranks itself (torch.distributed.run, 127.0.0.1) after checking
+that the box has N GPUs; every rank asserts that the process group really has N members.
+
 Prints ONE JSON line on rank 0 (see the keys at the bottom).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -66,9 +77,67 @@ def usable_cores():
     return n
 
 
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """--gpus N, no torch.distributed environment: become N ranks of one node (one process per GPU, RCCL over xGMI)"""
+    if not args.stub:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but this box exposes %d GPU(s); refusing to report a %d-GPU number from fewer devices"
+                             % (args.gpus, have, args.gpus))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def stub_rank(args, rank, world):
+    """Launcher self-test (tests/test_bench_launcher.py): the rank / process-group / barrier / max-over-ranks / one-line path of
+    this file on the gloo backend with a step that does no device work.  NOT a measurement: the line says "stub": true."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if dist.get_world_size() != args.gpus:
+        raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    x = torch.zeros(4)
+
+    def step():
+        x.add_(1.0)
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dist.barrier()
+    tm = torch.tensor([time.perf_counter() - t0, float(rank + 1)], dtype=torch.float64)
+    tmax, tsum = tm.clone(), tm.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher-selftest", "stub": True, "value": 0.0, "unit": "none", "n_gpus": world, "rccl_ranks": world,
+                          "backend": "gloo", "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tmax[0]) / max(args.steps, 1) * 1e3, 4),
+                          "rank_sum": float(tsum[1])}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workload", default="all", choices=("all", "align", "decompose", "allpairs"),
+                    help="all: the align headline + the decompose and all-pairs legs; one name: that workload alone (profiling)")
+    ap.add_argument("--decompose-traces", type=int, default=100000, help="configs[2]: traces of the whole decompose job (sharded over the ranks)")
+    ap.add_argument("--decompose-steps", type=int, default=3)
+    ap.add_argument("--allpairs-traces", type=int, default=1000, help="configs[4]: traces of the all-pairs job (pair list sharded over the ranks)")
+    ap.add_argument("--allpairs-steps", type=int, default=3)
+    ap.add_argument("--extra-legs", type=int, default=1, help="decompose: also time the strand-certificate and two-lane legs")
+    ap.add_argument("--stub", action="store_true", help="launcher self-test on gloo with a step that does no device work (not a measurement)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--traces", type=int, default=10000, help="traces per GPU per step")
@@ -82,18 +151,59 @@ def main():
                     help="1: also time the library's default strand-by-certificate mode after the headline leg (reported beside it)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="traces for the CPU baseline (-1: 2 per thread, capped)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let --gpus N start them)" % (args.gpus, world))
+    if args.stub:
+        return stub_rank(args, rank, world)
+    if torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but %d visible GPU(s)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: the process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    dev = torch.device("cuda", local)
+
+    def run_extra(which):
+        """configs[2] / configs[4] legs (tools/legs.py); a failing leg reports its error instead of taking the headline down"""
+        from tools.legs import AllPairsLeg, DecomposeLeg
+        try:
+            if which == "decompose":
+                leg = DecomposeLeg(args.decompose_traces, 3000, 1000, rank, world, dev)
+                res = leg.run(dist, args.decompose_steps, 1, extra_legs=bool(args.extra_legs), cpu_sample=64 if args.cpu_sample != 0 else 0)
+            else:
+                leg = AllPairsLeg(args.allpairs_traces, 900, rank, world, dev)
+                res = leg.run(dist, args.allpairs_steps, 1, cpu_sample=192 if args.cpu_sample != 0 else 0)
+            leg.ctx.close()
+            del leg
+            torch.cuda.empty_cache()
+            return res
+        except Exception as e:  # noqa: BLE001
+            if args.workload != "all":
+                raise
+            return {"error": "%s: %s" % (type(e).__name__, e)}
+
+    extra = {}
+    if args.workload in ("decompose", "allpairs"):
+        extra[args.workload] = run_extra(args.workload)
+        if rank == 0:
+            line = extra[args.workload]
+            line["rccl_ranks"] = world
+            print(json.dumps(line))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import tracy_amd
     from tracy_amd import capi, hostlib
@@ -123,7 +233,6 @@ def main():
     # library's default (strand by certificate, identical alignments, fewer cells) is timed as a second leg below and
     # reported beside it -- it is never `value`.
     job.strand_by_certificate = 0
-    dev = torch.device("cuda", local)
     r_i32 = {k: torch.zeros(nt, dtype=torch.int32, device=dev) for k in
              ("score_fwd", "score_rev", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final", "ops_len")}
     r_fwd = torch.zeros(nt, dtype=torch.uint8, device=dev)
@@ -216,6 +325,17 @@ def main():
     else:
         elapsed_max, cells_all, elapsed_cert_max = elapsed, float(cells_rank), elapsed_cert
 
+    # the headline's inputs and results are no longer needed on the device (the parity sample below reads host copies)
+    sf_host, ol_host, ops_host = r_i32["score_final"].cpu().numpy(), r_i32["ops_len"].cpu().numpy(), None
+    if world == 1 and args.cpu_sample != 0:
+        ops_host = r_ops.cpu().numpy()
+    if args.workload == "all":
+        ctx.close()
+        del d_refs, d_profs, r_ops
+        torch.cuda.empty_cache()
+        for which in ("decompose", "allpairs"):
+            extra[which] = run_extra(which)
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -268,7 +388,7 @@ def main():
 
     line = {
         "metric": "GCUPS (tracy align: Gotoh affine-gap DP cells per second, whole job)",
-        "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "rccl_ranks": world if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int16 (score sweeps) / int32 (tracebacks)", "data": "synthetic",
         "traces_per_s": round(nt * world * args.steps / elapsed_max, 1),
@@ -326,12 +446,13 @@ def main():
                                     "single_thread": {"value": round(v1, 4), "unit": "GCUPS", "sample": "%d traces, %.1f s" % (n1, dt1)},
                                     "cpu_model": model, "host_threads": os.cpu_count(), "usable_cores": nthreads}
             # the same traces must come out bit-identical on the GPU
-            sf = r_i32["score_final"].cpu().numpy()
-            ol = r_i32["ops_len"].cpu().numpy()
-            ops = r_ops.cpu().numpy()
+            sf, ol, ops = sf_host, ol_host, ops_host
             ok = all(int(sf[i]) == o["score_final"] and ops[i * ops_cap:i * ops_cap + int(ol[i])].tobytes() == o["btr"]
                      for i, o in enumerate(ores))
             line["parity_checked"] = {"traces": ns, "bit_identical": bool(ok)}
+    for k, v in extra.items():
+        if v is not None:
+            line[k] = v
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

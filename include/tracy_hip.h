@@ -101,6 +101,8 @@ int tracyhip_set_workspace_limit(tracyhip_ctx* ctx, uint64_t bytes);
    inputs enqueued on the context's stream are waited for, everything is complete on return.  Needs the per-trace
    result regions (ops_offset) in trace order; otherwise the call runs on one lane. */
 int tracyhip_set_lanes(tracyhip_ctx* ctx, uint32_t lanes);
+/* waits for the context's stream AND for every *_async call issued on the context; returns the first error one of those
+   calls produced since the last synchronize (tracyhip_last_error() then holds its text), TRACYHIP_OK otherwise */
 int tracyhip_synchronize(tracyhip_ctx* ctx);
 const char* tracyhip_last_error(void);
 const char* tracyhip_version(void);
@@ -284,6 +286,45 @@ typedef struct {
 int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
                               const tracyhip_decompose_result* out);
 
+/* ---- asynchronous forms (SURVEY.md 8b "Threading": synchronous by default with an async variant) ---------------------
+ * Same arguments and results as the call without the suffix; the call returns as soon as the work is queued on the
+ * context.  A context executes its calls in issue order on its own worker thread and stream (the pipelines need the
+ * host between kernels -- orientation decision, trimReferenceSlice geometry -- so "enqueue" means this queue, not only
+ * the HIP stream).  The structs are copied; every array they point to (inputs, offsets, results) must stay valid and
+ * untouched until tracyhip_synchronize(ctx) returns, which is also when results are final and errors are reported.
+ * A synchronous call on a context with queued work waits for that work first.  Several contexts (one per host thread,
+ * or the members of a group) run concurrently. */
+int tracyhip_gotoh_score_async(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm, int mem, int32_t* scores);
+int tracyhip_gotoh_align_async(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm, int mem, int32_t* scores,
+                               uint8_t* ops, const uint64_t* ops_offset, uint32_t* ops_len);
+int tracyhip_align_traces_async(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
+                                const tracyhip_align_result* out);
+int tracyhip_decompose_traces_async(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
+                                    const tracyhip_decompose_result* out);
+
+/* ---- device groups: the GPUs of one node behind one handle (north star: "batches of traces shard embarrassingly across
+ * the 8 GPUs of one node") ------------------------------------------------------------------------------------------
+ * One context per device, one host thread per context.  A batch call on a group cuts the batch into contiguous blocks
+ * of traces (tracyhip_group_gotoh_score: the pair list into slices of equal DP cell count, the sequence sets replicated --
+ * the all-pairs matrix of msa.h:33-42), runs each block through its device and returns when all are complete; results
+ * land in the caller's arrays exactly as from the single-device call.  HOST buffers only (every block stages its own part
+ * through its own device; nothing crosses devices).  devices == NULL: the first `ndevices` visible devices (0 = all).
+ * A device may be listed more than once (two contexts on one GPU).  Multi-PROCESS jobs use one plain context per rank
+ * and gather over RCCL instead (tracy_amd/shard.py, bench.py). */
+typedef struct tracyhip_group tracyhip_group;
+int tracyhip_group_create(const int* devices, int ndevices, tracyhip_group** group);
+int tracyhip_group_destroy(tracyhip_group* group);
+int tracyhip_group_size(const tracyhip_group* group);
+tracyhip_ctx* tracyhip_group_context(tracyhip_group* group, int i); /* member i, e.g. for tracyhip_set_workspace_limit */
+int tracyhip_group_set_lanes(tracyhip_group* group, uint32_t lanes);
+int tracyhip_group_gotoh_score(tracyhip_group* group, const tracyhip_pairs* pairs, const tracyhip_params* prm, int32_t* scores);
+int tracyhip_group_align_traces(tracyhip_group* group, const tracyhip_align_job* job, const tracyhip_params* prm,
+                                const tracyhip_align_result* out);
+int tracyhip_group_decompose_traces(tracyhip_group* group, const tracyhip_decompose_job* job, const tracyhip_params* prm,
+                                    const tracyhip_decompose_result* out);
+/* bounds[0 .. parts] of `parts` contiguous slices of the pair list with (nearly) equal DP cell count; host arithmetic, no device */
+int tracyhip_pair_bounds(const tracyhip_pairs* pairs, uint32_t parts, uint64_t* bounds);
+
 /* ---- kernel timing (HIP events recorded on the context's stream around each DP / walker launch) ---
  * The reference has only the optional gperftools wrapper (sage.h:60-62); this is the hook bench.py uses
  * for its roofline line.  bytes = ALGORITHMIC bytes of the launches: 0.5 B per traceback cell + the
@@ -293,6 +334,11 @@ int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decompose_job* j
 #define TRACYHIP_TIMER_WALK 2  /* traceback walkers     */
 #define TRACYHIP_TIMER_BAND 3  /* band tracebacks (checkpointed traceback of the align / decompose pipelines) */
 #define TRACYHIP_TIMER_PREFIX 4 /* prefix-bound kernels (strand by certificate); cells = rows actually swept x columns */
+#define TRACYHIP_TIMER_ORIGIN 5 /* origin-tracking sweeps (gotoh() whose alignment only trimReferenceSlice reads) */
+#define TRACYHIP_TIMER_DECOMP 6 /* decomposeAlleles kernel; cells = alignment columns, bytes = rows + basecalls + table */
+#define TRACYHIP_TIMER_AFRAC 7  /* allelicFraction kernel; cells = grid points x diffnuc bound, bytes = signal windows read */
+#define TRACYHIP_TIMER_MISC 8   /* findBreakpoint, findHomozygousBreakpoint, generateSecondaryDecomposed, alignment rows, trims */
+#define TRACYHIP_TIMER_COUNT 9
 typedef struct {
   double ms;         /* summed launch durations */
   uint64_t launches;

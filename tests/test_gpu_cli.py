@@ -145,6 +145,27 @@ def test_batch_manifest_and_errors(tmp_path):
     assert p.returncode == 255 and "Usage: tracy align" in p.stdout
 
 
+def test_batch_on_a_device_group(tmp_path):
+    """-d 0,0: the manifest's traces are cut into one block per listed GPU (tracyhip_group_align_traces); same files"""
+    rng = np.random.default_rng(9)
+    cases = [synth_case(rng, str(tmp_path), "g%d" % i, nb=int(rng.integers(300, 700)), nref=int(rng.integers(1500, 3000)), reverse=bool(i % 2))
+             for i in range(6)]
+    outs = {}
+    for tag, dev in (("one", "0"), ("two", "0,0")):
+        rows = [(cases[i % 6][0], cases[i % 6][1], str(tmp_path / ("%s_%03d" % (tag, i)))) for i in range(140)]
+        man = str(tmp_path / ("manifest_%s.tsv" % tag))
+        open(man, "w").write("".join("\t".join(r) + "\n" for r in rows))
+        p = subprocess.run([CLI, "align", "--batch", man, "-d", dev], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr
+        outs[tag] = rows
+    for (t, r, a), (_, _, b) in zip(outs["one"], outs["two"]):
+        for ext in (".align.fa", ".txt", ".json"):
+            assert open(a + ext, "rb").read() == open(b + ext, "rb").read(), (a, ext)
+    check_outputs(outs["two"][139][2], outs["two"][139][0], outs["two"][139][1])
+    p = subprocess.run([CLI, "align", "--batch", man, "-d", "0,x"], capture_output=True, text=True)
+    assert p.returncode == 255
+
+
 # ---- `decompose` ------------------------------------------------------------------------------------------
 def decompose_case(tmp, tag, seed, n=1500, mf=500, kind=0, reverse=False):
     from tracy_amd import hostlib

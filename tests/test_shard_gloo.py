@@ -75,3 +75,73 @@ def test_shard_range_covers_batch():
             assert got[0][0] == 0 and got[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
             assert max(h - l for l, h in got) - min(h - l for l, h in got) <= 1
+
+
+# ---- all-pairs jobs (`tracy assemble`, msa.h:33-42): the pair list sharded over ranks, score slices all-gathered -----------
+def _profiles(n):
+    rng = np.random.default_rng(77)
+    out = []
+    for _ in range(n):
+        m = int(rng.integers(40, 120))  # ragged: slices of equal CELL count differ in pair count
+        p = np.zeros((6, m), np.float32)
+        x = rng.random((4, m)).astype(np.float32) ** 4
+        p[:4] = x / x.sum(axis=0, keepdims=True)
+        out.append(p)
+    return out
+
+
+def _allpairs_worker(rank, world, port, n, ret):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pyoracle as orc
+    from tracy_amd.shard import all_gather_slices, pair_slice
+    profs = _profiles(n)
+    lens = [p.shape[1] for p in profs]
+    i1, i2, bounds = pair_slice(lens, rank, world)
+    mine = torch.tensor([orc.gotoh_score_prof(profs[a], profs[b], 1, 1, SC) for a, b in zip(i1, i2)], dtype=torch.int32)  # oracle = the device here
+    full = all_gather_slices(dist, mine, bounds)
+    ret["full%d" % rank] = full.numpy().tolist()
+    ret["bounds%d" % rank] = [int(b) for b in bounds]
+    ret["idx%d" % rank] = (i1.tolist(), i2.tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_all_pairs_matrix():
+    """a 40-trace all-pairs job: ranks take contiguous slices of msa()'s own pair list (equal cell counts), every rank ends up
+    with the whole distance matrix, identical to the single-process one"""
+    n = 40
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_allpairs_worker, args=(2, port, n, ret), nprocs=2, join=True)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as orc
+    from tracy_amd import msalib
+    from tracy_amd.shard import condensed_to_square
+    profs = _profiles(n)
+    m1, m2 = msalib.pair_list(n)  # the index arrays msa.hpp hands to tracyhip_gotoh_score
+    want = [orc.gotoh_score_prof(profs[a], profs[b], 1, 1, SC) for a, b in zip(m1, m2)]
+    assert ret["full0"] == want and ret["full1"] == want
+    assert ret["bounds0"] == ret["bounds1"] and ret["bounds0"][0] == 0 and ret["bounds0"][-1] == n * (n - 1) // 2
+    # the ranks' index arrays, concatenated, are exactly msa()'s pair list
+    assert ret["idx0"][0] + ret["idx1"][0] == m1.tolist() and ret["idx0"][1] + ret["idx1"][1] == m2.tolist()
+    # slices carry (nearly) equal numbers of DP cells, not of pairs
+    lens = np.array([p.shape[1] for p in profs], dtype=np.int64)
+    cells = lens[m1] * lens[m2]
+    b = ret["bounds0"]
+    c0, c1 = int(cells[:b[1]].sum()), int(cells[b[1]:].sum())
+    assert abs(c0 - c1) <= int(cells.max())
+    sq = condensed_to_square(want, n)
+    assert sq.shape == (n, n) and (sq == sq.T).all() and sq[3, 17] == want[m1.tolist().index(3) + 17 - 3 - 1]
+
+
+def test_pair_bounds_rule():
+    from tracy_amd.shard import pair_bounds
+    for n, w in ((2, 1), (2, 2), (5, 3), (40, 8), (100, 7)):
+        lens = np.arange(50, 50 + n)
+        b = pair_bounds(lens, w)
+        assert b[0] == 0 and b[-1] == n * (n - 1) // 2 and (np.diff(b) >= 0).all()

@@ -1,0 +1,382 @@
+"""Workloads bench.py times beside its headline (`tracy align`, configs[1]): BASELINE.json configs[2] (`tracy decompose`,
+indigo.h:190-388) and configs[4] (the all-pairs profile x profile scoring of `tracy assemble`, msa.h:33-42).  Each leg
+shards its job over the ranks: decompose by contiguous blocks of traces with a final gather of the
+fixed-size result records; all-pairs by contiguous slices of the upper-triangular pair list with the profiles replicated
+and an all_gather of the score slices (the distance matrix ends up on every rank).  No data-path collective.
+
+Only the `cpu_baseline` parts touch oracle/ (the CPU restatement timed on the host cores, and the in-run parity sample)."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCORE = (3, -5, -10, -4)
+HBM_PEAK_GBS = 8000.0
+VALU_PEAK = 78.6       # T lane-ops/s: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+FP32_VECTOR_PEAK = 157.3  # TFLOP/s (MI355X_MICROARCH.md), FMA = 2 flops; separately rounded mul / add reach half of it per issue slot
+
+TIMERS = (("score", 0), ("trace", 1), ("walk", 2), ("band", 3), ("prefix", 4), ("origin", 5), ("decompose", 6), ("allelic_fraction", 7), ("misc", 8))
+
+
+def u64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def u32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def read_timers(lib, ctx):
+    from tracy_amd import capi
+    kt = capi.KernelTiming()
+    res = {}
+    for name, which in TIMERS:
+        lib.tracyhip_timing_get(ctx._h, which, C.byref(kt))
+        res[name] = dict(ms=kt.ms, launches=int(kt.launches), cells=int(kt.cells), bytes=int(kt.bytes))
+    return res
+
+
+def timed(step, steps, warmup, dist, lib=None, ctx=None):
+    """W untimed + K timed steps between barrier + synchronize; returns (seconds, kernel timers of the timed steps)"""
+    for _ in range(warmup):
+        step()
+    if lib is not None:
+        lib.tracyhip_timing_enable(ctx._h, 1)
+        lib.tracyhip_timing_reset(ctx._h)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timers = None
+    if lib is not None:
+        lib.tracyhip_timing_enable(ctx._h, 0)
+        timers = read_timers(lib, ctx)
+    return dt, timers
+
+
+def max_over_ranks(dist, dev, values):
+    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t]
+
+
+def sum_over_ranks(dist, dev, values):
+    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t]
+
+
+def pmc_traffic(kernel_substr, tag_glob="r[0-9][0-9]_pmc_hbm*.json"):
+    """HBM bytes per launch of a kernel from the latest committed rocprofv3 PMC summary (WRITE_SIZE + FETCH_SIZE, separate passes)"""
+    import glob
+    import json
+    try:
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", tag_glob)), reverse=True):
+            pmc = json.load(open(f))
+            per = {c: [r for r in pmc if r["counter"] == c and kernel_substr in r["kernel"]] for c in ("WRITE_SIZE", "FETCH_SIZE")}
+            if per["WRITE_SIZE"] and per["FETCH_SIZE"]:
+                w = max(per["WRITE_SIZE"], key=lambda r: r["bytes"])
+                fch = max(per["FETCH_SIZE"], key=lambda r: r["bytes"])
+                return int(w["bytes"] + fch["bytes"]), "profiles/%s (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes)" % os.path.basename(f)
+    except (OSError, ValueError, KeyError, IndexError):
+        pass
+    return None, None
+
+
+def kernel_block(name, kernel, t, steps, ops_per_cell=None, flops_per_cell=None, traffic_key=None):
+    """roofline object of one kernel class from the library's HIP-event timers"""
+    ms = t["ms"]
+    gbs = t["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    gc = t["cells"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic, src = pmc_traffic(traffic_key) if traffic_key else (None, None)
+    out = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+           "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(ms / max(t["launches"], 1), 3), "launches": t["launches"],
+           "algorithmic_bytes_per_launch": t["bytes"] // max(t["launches"], 1), "kernel_gcups": round(gc, 1), "timer": name}
+    if ops_per_cell:
+        out["valu"] = {"achieved": round(gc * ops_per_cell / 1e3, 2), "peak": VALU_PEAK, "unit": "T lane-ops/s",
+                       "frac": round(gc * ops_per_cell / 1e3 / VALU_PEAK, 3), "ops_per_cell": ops_per_cell}
+    if flops_per_cell:
+        out["fp32_vector"] = {"achieved": round(gc * flops_per_cell / 1e3, 2), "peak": FP32_VECTOR_PEAK, "unit": "TFLOP/s",
+                              "frac": round(gc * flops_per_cell / 1e3 / FP32_VECTOR_PEAK, 3), "flops_per_cell": flops_per_cell,
+                              "note": "every product and sum is rounded separately (align.h:112-116): no FMA, so an issue slot carries half of the FMA-counted peak"}
+    return out
+
+
+# =====================================================================================================================
+class DecomposeLeg:
+    """configs[2]: `total` synthetic 1 kb traces `decompose` vs 3 kb windows (80 % het indel + het SNVs, 10 % homozygous indel only,
+    10 % no variant, both strands: SURVEY.md 8d), sharded over the ranks by contiguous blocks."""
+
+    def __init__(self, total, ref_len, trace_len, rank, world, dev, lanes=1):
+        import tracy_amd
+        from tracy_amd import capi, hostlib
+        from tracy_amd.shard import shard_range
+        self.capi, self.total, self.n, self.mf, self.rank, self.world, self.dev = capi, total, ref_len, trace_len, rank, world, dev
+        self.lo, self.hi = shard_range(total, rank, world)
+        nt = self.nt = self.hi - self.lo
+        n, mf = ref_len, trace_len
+        t0 = time.perf_counter()
+        d = hostlib.synth_decompose_batch(5000 + self.lo, nt, n, mf, 0, mix=1)
+        self.synth_s = time.perf_counter() - t0
+        ns = d["signal"].shape[2]
+        keep_host = min(nt, 256)  # the CPU baseline / parity sample reads the first traces from the host copy
+        self.host = {k: np.ascontiguousarray(v[:keep_host]) for k, v in d.items()}
+        self.t_sig = torch.from_numpy(d["signal"]).to(dev)
+        self.t_pos = torch.from_numpy(d["bcpos"]).to(dev)
+        self.t_prof = torch.from_numpy(d["profiles"]).to(dev)
+        self.t_ref = torch.from_numpy(d["refs"]).to(dev)
+        self.pri0 = torch.from_numpy(d["primary"]).to(dev)
+        self.sec0 = torch.from_numpy(d["secondary"]).to(dev)
+        del d
+        self.t_pri, self.t_sec = self.pri0.clone(), self.sec0.clone()
+        idx = np.arange(nt, dtype=np.uint64)
+        self.arrs = dict(sig_off=idx * np.uint64(4 * ns), bc_off=idx * np.uint64(mf), prof_off=idx * np.uint64(6 * mf), ref_off=idx * np.uint64(n),
+                         nsamp=np.full(nt, ns, np.uint32), bc_len=np.full(nt, mf, np.uint32), ref_len=np.full(nt, n, np.uint32))
+        a = self.arrs
+        maxindel = 1000
+        cap = self.cap = 2 * maxindel + 2
+        a["dcp_off"] = idx * np.uint64(cap)
+        job = self.job = capi.DecomposeJob()
+        job.ntraces = nt
+        job.profiles = capi.SeqSet(capi.SEQ_PROFILE, self.t_prof.data_ptr(), u64(a["prof_off"]), u32(a["bc_len"]), nt)
+        job.bc = capi.BaseCallsBatch(nt, self.t_sig.data_ptr(), u64(a["sig_off"]), u32(a["nsamp"]), self.t_pos.data_ptr(), self.t_pri.data_ptr(),
+                                     self.t_sec.data_ptr(), u64(a["bc_off"]), u32(a["bc_len"]))
+        job.refs = capi.SeqSet(capi.SEQ_CHAR, self.t_ref.data_ptr(), u64(a["ref_off"]), u32(a["ref_len"]), nt)
+        job.dprm = capi.DecompParams(50, 50, maxindel, 5)
+        job.strand_by_certificate = 0  # headline: both orientation scores exact
+        z = lambda k, dt: torch.zeros(k, dtype=dt, device=dev)  # noqa: E731
+        res = self.res = {"bp": z(nt * 4, torch.int32), "status": z(nt, torch.int32), "score_fwd": z(nt, torch.int32), "score_rev": z(nt, torch.int32),
+                          "forward": z(nt, torch.uint8), "score_trim": z(nt, torch.int32), "dcp_indel": z(nt * cap, torch.int32),
+                          "dcp_err": z(nt * cap, torch.int32), "dstatus": z(nt * 6, torch.int32), "secdecomp": z(nt * mf, torch.uint8),
+                          "fractions": z(nt * 2, torch.float64)}
+        out = self.out = capi.DecomposeResult()
+        for k, v in res.items():
+            setattr(out, k, v.data_ptr())
+        out.dcp_offset = u64(a["dcp_off"])
+        self.keep = []
+        for k in range(3):
+            capk = mf + (n if k < 2 else mf)
+            off = idx * np.uint64(capk)
+            ops, olen, sc = z(nt * capk, torch.uint8), z(nt, torch.int32), z(nt, torch.int32)
+            out.score[k], out.ops[k], out.ops_offset[k], out.ops_len[k] = sc.data_ptr(), ops.data_ptr(), u64(off), olen.data_ptr()
+            self.keep.append((off, ops, olen, sc, capk))
+            if k < 2:
+                for nm in ("slice_begin", "slice_len", "ref_pos"):
+                    t = z(nt, torch.int32)
+                    getattr(out, nm)[k] = t.data_ptr()
+                    res["%s%d" % (nm, k)] = t
+        self.prm = capi.Params(SCORE[0], SCORE[1], SCORE[2], SCORE[3], 1, 0)
+        self.ctx = tracy_amd.Context(dev.index or 0)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.ctx.set_lanes(max(1, lanes))
+        self.lib = capi.lib()
+
+    def step(self, dist=None):
+        self.t_pri.copy_(self.pri0)  # decomposeAlleles rewrites the basecalls in place: start every step from the originals
+        self.t_sec.copy_(self.sec0)
+        rc = self.lib.tracyhip_decompose_traces(self.ctx._h, C.byref(self.job), C.byref(self.prm), self.capi.MEM_DEVICE, C.byref(self.out))
+        if rc != 0:
+            raise RuntimeError("tracyhip_decompose_traces: %s" % self.lib.tracyhip_last_error().decode())
+        if dist is not None:  # final gather of the fixed-size result records (RCCL over xGMI)
+            from tracy_amd.shard import gather_records
+            r = self.res
+            rec = torch.stack([r["status"], r["score_trim"], self.keep[0][3], self.keep[1][3], self.keep[2][3]], dim=1)
+            gather_records(dist, rec, dst=0)
+
+    def cells(self):
+        mt = self.mf - 100
+        sl = [self.res["slice_len%d" % k].cpu().numpy().astype(np.int64) for k in range(2)]
+        # 3 profile DPs (2 orientation scores + the traceback of the trimmed trace), 2 x gotoh(allele, window), 2 x gotoh(allele, slice), pri vs sec
+        return int(3 * mt * self.n * self.nt + 2 * mt * self.n * self.nt + (mt * sl[0]).sum() + (mt * sl[1]).sum() + mt * mt * self.nt)
+
+    def run(self, dist, steps, warmup, extra_legs=True, cpu_sample=64):
+        dev = self.dev
+        dt, timers = timed(lambda: self.step(dist), steps, warmup, dist, self.lib, self.ctx)
+        cells = self.cells()
+        ok_traces = int((self.res["status"] == 0).sum().item())
+        snap = {k: v.clone() for k, v in self.res.items() if k not in ("score_fwd", "score_rev")}
+        snap_ops = [x[1].clone() for x in self.keep]
+        snap_pri = self.t_pri.clone()
+        dt_cert = dt_lanes = 0.0
+        same = True
+        if extra_legs:
+            self.job.strand_by_certificate = 1
+            dt_cert, _ = timed(lambda: self.step(dist), steps, warmup, dist)
+            same = all(torch.equal(snap[k], self.res[k]) for k in snap) and all(torch.equal(a, x[1]) for a, x in zip(snap_ops, self.keep))
+            self.job.strand_by_certificate = 0
+            self.ctx.set_lanes(2)
+            dt_lanes, _ = timed(lambda: self.step(dist), steps, warmup, dist)
+            same = same and all(torch.equal(snap[k], self.res[k]) for k in snap)
+            self.ctx.set_lanes(1)
+        dt, dt_cert, dt_lanes = max_over_ranks(dist, dev, [dt, dt_cert, dt_lanes])
+        cells_all, ok_all, nt_all = sum_over_ranks(dist, dev, [float(cells), float(ok_traces), float(self.nt)])
+        if self.rank != 0:
+            return None
+        tot_ms = sum(timers[k]["ms"] for k, _ in TIMERS)
+        dom = max((k for k, _ in TIMERS), key=lambda k: timers[k]["ms"])
+        names = {"score": ("gotoh_ckpt_kernel<K,QP,narrow> (orientation scores, checkpointed 16-bit sweep)", 8.0, "gotoh_ckpt_kernel"),
+                 "origin": ("gotoh_origin_kernel<K> (gotoh(allele, window) whose alignment only trimReferenceSlice reads)", 11.0, "gotoh_origin_kernel"),
+                 "trace": ("gotoh_kernel<K,MODE,TRACE> (full-matrix tracebacks: allele vs trimmed slice, primary vs secondary)", 14.0, "gotoh_kernel"),
+                 "band": ("gotoh_band_kernel<K,QP> (band traceback of the trimmed trace)", 14.0, "gotoh_band_kernel"),
+                 "walk": ("gotoh_walk_kernel", None, "gotoh_walk_kernel"), "prefix": ("gotoh_prefix_kernel", 8.0, "gotoh_prefix_kernel"),
+                 "decompose": ("decompose_kernel (decomposeAlleles, decompose.h:179-376)", None, "decompose_kernel"),
+                 "allelic_fraction": ("allelic_fraction_kernel (decompose.h:412-621)", None, "allelic_fraction_kernel"),
+                 "misc": ("breakpoint / homozygous / secdecomp kernels", None, None)}
+        roof = kernel_block(dom, names[dom][0], timers[dom], steps, ops_per_cell=names[dom][1], traffic_key=names[dom][2])
+        roof["share_of_kernel_time"] = round(timers[dom]["ms"] / tot_ms, 3) if tot_ms else None
+        roof["ms_per_step"] = {k: round(timers[k]["ms"] / steps, 3) for k, _ in TIMERS if timers[k]["ms"] > 0}
+        roof["other_kernels"] = {k: {kk: vv for kk, vv in kernel_block(k, names[k][0], timers[k], steps, ops_per_cell=names[k][1], traffic_key=names[k][2]).items()
+                                     if kk in ("kernel", "achieved", "frac", "traffic", "avg_launch_ms", "kernel_gcups", "valu", "algorithmic_bytes_per_launch")}
+                                 for k in ("score", "origin", "trace") if k != dom and timers[k]["ms"] > 0}
+        line = {"metric": "traces/s (tracy decompose hot section, indigo.h:190-388)", "value": round(nt_all * steps / dt, 1), "unit": "traces/s",
+                "gcups": round(cells_all * steps / dt / 1e9, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "warmup": warmup,
+                "n_gpus": self.world, "scaling": "strong", "dtype": "int16 (orientation sweeps) / int32 (tracebacks, origin sweeps) / f64 (allelicFraction)",
+                "config": {"workload": "configs[2]: %d synthetic %d-base traces `decompose` vs %d-base windows (80%% het indel + het SNVs, 10%% homozygous "
+                                       "indel, 10%% no variant, both strands), sharded over %d rank(s)" % (int(nt_all), self.mf, self.n, self.world),
+                           "traces_total": int(nt_all), "trace_len": self.mf, "ref_len": self.n},
+                "traces_ok": int(ok_all), "data": "synthetic", "synthesis_s": round(self.synth_s, 1), "roofline": roof}
+        if extra_legs:
+            line["strand_by_certificate"] = {"ms_per_step": round(dt_cert / steps * 1e3, 2), "traces_per_s": round(nt_all * steps / dt_cert, 1),
+                                             "results_identical_to_headline_leg": bool(same)}
+            line["lanes"] = {"lanes": 2, "ms_per_step": round(dt_lanes / steps * 1e3, 2), "traces_per_s": round(nt_all * steps / dt_lanes, 1)}
+        if self.world == 1 and cpu_sample > 0:
+            line.update(self.cpu_baseline(cpu_sample, snap, snap_ops, snap_pri))
+        return line
+
+    def cpu_baseline(self, sample, snap, snap_ops, snap_pri):
+        """the oracle's indigo.h chain on the first `sample` traces, one trace per thread; the same traces must be bit-identical on the GPU"""
+        for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        from concurrent.futures import ThreadPoolExecutor
+        from indigo_oracle import decompose_trace
+        from bench import usable_cores
+        h = self.host
+        ns_ = min(sample, h["signal"].shape[0])
+        nthreads = usable_cores()
+
+        def one(i):
+            return decompose_trace(h["signal"][i], h["bcpos"][i], h["primary"][i].tobytes(), h["secondary"][i].tobytes(), h["refs"][i].tobytes(), SCORE)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=nthreads) as ex:
+            want = list(ex.map(one, range(ns_)))
+        cdt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        one(0)
+        one(1)
+        c1 = (time.perf_counter() - t1) / 2
+        mf = self.mf
+        pri = snap_pri.cpu().numpy().reshape(self.nt, mf)
+        sd = snap["secdecomp"].cpu().numpy().reshape(self.nt, mf)
+        fr = snap["fractions"].cpu().numpy().reshape(self.nt, 2)
+        st = snap["status"].cpu().numpy()
+        ok = True
+        for i, w in enumerate(want):
+            ok &= int(st[i]) == w["status"]
+            if w["status"] != 0:
+                continue
+            ok &= pri[i].tobytes() == w["primary"] and sd[i].tobytes() == w["secdecomp"] and (float(fr[i, 0]), float(fr[i, 1])) == w["af"]
+            for k in range(3):
+                off, _, olen, sc, capk = self.keep[k]
+                ln = int(olen[i].item())
+                ok &= int(sc[i].item()) == w["score%d" % k]
+                ok &= snap_ops[k][i * capk:i * capk + ln].cpu().numpy().tobytes() == w["btr%d" % k]
+        return {"cpu_baseline": {"value": round(ns_ / cdt, 2), "unit": "traces/s", "cores": min(nthreads, ns_), "kind": "port",
+                                 "sample": "%d of the same traces through the oracle's indigo.h chain (C via ctypes, one trace per thread), %.1f s" % (ns_, cdt),
+                                 "single_thread": {"value": round(1.0 / c1, 3), "unit": "traces/s"}},
+                "parity_checked": {"traces": ns_, "bit_identical": bool(ok)}}
+
+
+# =====================================================================================================================
+class AllPairsLeg:
+    """configs[4]: all-pairs profile x profile gotohScore<true,true> over `ntr` overlapping ~1 kb traces (msa.h:33-42 distanceMatrix).
+    The upper-triangular pair list is cut into contiguous slices of equal cell count, one per rank; the profiles (24 KB each) are
+    replicated; the score slices are all-gathered, so every rank ends with the whole matrix."""
+
+    def __init__(self, ntr, trace_len, rank, world, dev):
+        import tracy_amd
+        from tracy_amd import capi, hostlib
+        from tracy_amd.shard import pair_slice
+        self.capi, self.ntr, self.mf, self.rank, self.world, self.dev = capi, ntr, trace_len, rank, world, dev
+        # traces tiled over one region, trace i starting at i * step (neighbours overlap; the DP cost does not depend on it)
+        refs, profs, rev = hostlib.synth_align(9000, ntr, 2 * trace_len + 200, trace_len, 0)
+        self.profs = np.ascontiguousarray(profs)
+        self.lens = np.full(ntr, trace_len, np.uint32)
+        i1, i2, self.bounds = pair_slice(self.lens, rank, world)
+        self.npairs = int(self.bounds[-1])
+        self.i1, self.i2 = np.ascontiguousarray(i1, np.uint32), np.ascontiguousarray(i2, np.uint32)
+        self.t_prof = torch.from_numpy(self.profs).to(dev)
+        self.off = np.arange(ntr, dtype=np.uint64) * np.uint64(6 * trace_len)
+        pr = self.pairs = capi.Pairs()
+        pr.npairs = len(self.i1)
+        pr.a1 = capi.SeqSet(capi.SEQ_PROFILE, self.t_prof.data_ptr(), u64(self.off), u32(self.lens), ntr)
+        pr.a2 = capi.SeqSet(capi.SEQ_PROFILE, self.t_prof.data_ptr(), u64(self.off), u32(self.lens), ntr)
+        pr.a1_index, pr.a2_index = u32(self.i1), u32(self.i2)
+        self.scores = torch.zeros(max(len(self.i1), 1), dtype=torch.int32, device=dev)
+        self.prm = capi.Params(SCORE[0], SCORE[1], SCORE[2], SCORE[3], 1, 1)
+        self.ctx = tracy_amd.Context(dev.index or 0)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.lib = capi.lib()
+        self.matrix = None
+
+    def step(self, dist=None):
+        rc = self.lib.tracyhip_gotoh_score(self.ctx._h, C.byref(self.pairs), C.byref(self.prm), self.capi.MEM_DEVICE, C.c_void_p(self.scores.data_ptr()))
+        if rc != 0:
+            raise RuntimeError("tracyhip_gotoh_score: %s" % self.lib.tracyhip_last_error().decode())
+        if dist is not None:
+            from tracy_amd.shard import all_gather_slices
+            self.matrix = all_gather_slices(dist, self.scores[:len(self.i1)], self.bounds)
+        else:
+            self.matrix = self.scores[:len(self.i1)]
+
+    def run(self, dist, steps, warmup, cpu_sample=192):
+        dev = self.dev
+        dt, timers = timed(lambda: self.step(dist), steps, warmup, dist, self.lib, self.ctx)
+        (dt,) = max_over_ranks(dist, dev, [dt])
+        if self.rank != 0:
+            return None
+        mf = self.mf
+        cells = float(self.npairs) * mf * mf
+        # 16-term body (row N zero in both profiles): per cell 16 x (mul, mul, add) fp32 + the Gotoh cell
+        roof = kernel_block("score", "gotoh_kernel<8,PROF,score> (25- / 16-term fp32 substitution score + Gotoh cell, profile x profile)", timers["score"], steps,
+                            flops_per_cell=48.0, traffic_key="gotoh_kernel<8, 2")
+        line = {"metric": "GCUPS (all-pairs profile x profile gotohScore<true,true>, msa.h:33-42)", "value": round(cells * steps / dt / 1e9, 1), "unit": "GCUPS",
+                "pairs": int(self.npairs), "pairs_per_s": round(self.npairs * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+                "warmup": warmup, "n_gpus": self.world, "scaling": "strong", "dtype": "f32 (substitution scores, rounded as align.h:112-116) / int32 (DP)",
+                "config": {"workload": "configs[4]: %d traces of %d bases, %d pairs, pair list sharded over %d rank(s), profiles replicated, "
+                                       "score slices all-gathered" % (self.ntr, mf, self.npairs, self.world), "traces": self.ntr, "trace_len": mf},
+                "data": "synthetic (profiles resident in HBM, index arrays on the host as the ABI defines)", "roofline": roof}
+        if self.world == 1 and cpu_sample > 0:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import pyoracle as orc
+            from concurrent.futures import ThreadPoolExecutor
+            from bench import usable_cores
+            rng = np.random.default_rng(1)
+            pick = rng.choice(len(self.i1), size=min(cpu_sample, len(self.i1)), replace=False)
+            nthreads = usable_cores()
+            f = lambda k: orc.gotoh_score_prof(self.profs[self.i1[k]], self.profs[self.i2[k]], 1, 1, SCORE)  # noqa: E731
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=nthreads) as ex:
+                want = list(ex.map(f, pick))
+            cdt = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            f(pick[0])
+            c1 = time.perf_counter() - t1
+            got = self.matrix.cpu().numpy()
+            line["cpu_baseline"] = {"value": round(len(pick) * mf * mf / cdt / 1e9, 4), "unit": "GCUPS", "cores": min(nthreads, len(pick)), "kind": "port",
+                                    "sample": "%d of the same pairs through the oracle's gotohScore (profile x profile), one pair per thread, %.1f s" % (len(pick), cdt),
+                                    "single_thread": {"value": round(mf * mf / c1 / 1e9, 4), "unit": "GCUPS"}}
+            line["parity_checked"] = {"pairs": int(len(pick)), "bit_identical": bool(all(int(got[k]) == w for k, w in zip(pick, want)))}
+        return line

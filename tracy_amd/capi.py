@@ -66,6 +66,7 @@ def lib():
         _LIB = C.CDLL(p)
         _LIB.tracyhip_last_error.restype = C.c_char_p
         _LIB.tracyhip_version.restype = C.c_char_p
+        _LIB.tracyhip_group_context.restype = C.c_void_p
     return _LIB
 
 
@@ -215,59 +216,135 @@ class Context:
         return scores[:n], btr, rws
 
 
+class PreparedAlign:
+    """host-buffer job / result structs of tracyhip_align_traces (everything they point to is kept alive by this object)"""
+
+    def __init__(self, profiles, refs, params, trim_left=50, trim_right=50, ref_index=None, oriented=None, exact_scores=True):
+        pp = profiles if isinstance(profiles, PackedSeqs) else PackedSeqs(profiles, SEQ_PROFILE)
+        pr = refs if isinstance(refs, PackedSeqs) else PackedSeqs(refs, SEQ_CHAR)
+        nt = self.nt = pp.count
+        job = self.job = AlignJob()
+        job.ntraces = nt
+        job.profiles = pp.seqset()
+        job.refs = pr.seqset()
+        self.keep = [pp, pr]
+        if ref_index is not None:
+            ref_index = np.ascontiguousarray(ref_index, dtype=np.uint32)
+            job.ref_index = ref_index.ctypes.data_as(C.POINTER(C.c_uint32))
+            rlen = pr.length[ref_index]
+            self.keep.append(ref_index)
+        else:
+            rlen = pr.length[:nt]
+        job.trim_left = trim_left
+        job.trim_right = trim_right
+        job.strand_by_certificate = 0 if exact_scores else 1  # opt-in: the losing strand may carry a certified upper bound
+        if oriented is not None:
+            oriented = np.ascontiguousarray(oriented, dtype=np.uint8)
+            job.oriented = oriented.ctypes.data_as(C.POINTER(C.c_uint8))
+            self.keep.append(oriented)
+        cap = pp.length[:nt].astype(np.uint64) + rlen.astype(np.uint64)
+        off = self.off = np.zeros(max(nt, 1), dtype=np.uint64)
+        if nt:
+            off[1:nt] = np.cumsum(cap)[:-1]
+        res = self.res = {
+            "score_fwd": np.zeros(max(nt, 1), np.int32), "score_rev": np.zeros(max(nt, 1), np.int32),
+            "forward": np.zeros(max(nt, 1), np.uint8), "score_prelim": np.zeros(max(nt, 1), np.int32),
+            "slice_begin": np.zeros(max(nt, 1), np.uint32), "slice_len": np.zeros(max(nt, 1), np.uint32),
+            "ref_pos": np.zeros(max(nt, 1), np.uint32), "score_final": np.zeros(max(nt, 1), np.int32),
+            "ops": np.zeros(max(int(cap.sum()) if nt else 0, 1), np.uint8), "ops_len": np.zeros(max(nt, 1), np.uint32),
+        }
+        out = self.out = AlignResult()
+        for k in ("score_fwd", "score_rev", "forward", "score_prelim", "slice_begin", "slice_len", "ref_pos",
+                  "score_final", "ops", "ops_len"):
+            setattr(out, k, res[k].ctypes.data)
+        out.ops_offset = off.ctypes.data_as(C.POINTER(C.c_uint64))
+        self.prm = Params(params[0], params[1], params[2], params[3], 1, 0)
+
+    def results(self):
+        res, off, nt = dict(self.res), self.off, self.nt
+        btr = [res["ops"][int(off[i]):int(off[i]) + int(res["ops_len"][i])].tobytes() for i in range(nt)]
+        for k in list(res):
+            if k != "ops":
+                res[k] = res[k][:nt]
+        res["btr"] = btr
+        return res
+
+
 def _align_traces(self, profiles, refs, params, trim_left=50, trim_right=50, ref_index=None, oriented=None, exact_scores=True):
     """tracyhip_align_traces with host buffers.  profiles: list of float32 [6][mf]; refs: list of bytes.
     oriented: None, or rs.forward per trace when the references are already oriented (indexed-genome path).
     Returns a dict of numpy arrays + the list of final traceback strings (push order)."""
-    pp = profiles if isinstance(profiles, PackedSeqs) else PackedSeqs(profiles, SEQ_PROFILE)
-    pr = refs if isinstance(refs, PackedSeqs) else PackedSeqs(refs, SEQ_CHAR)
-    nt = pp.count
-    job = AlignJob()
-    job.ntraces = nt
-    job.profiles = pp.seqset()
-    job.refs = pr.seqset()
-    keep = []
-    if ref_index is not None:
-        ref_index = np.ascontiguousarray(ref_index, dtype=np.uint32)
-        job.ref_index = ref_index.ctypes.data_as(C.POINTER(C.c_uint32))
-        rlen = pr.length[ref_index]
-        keep.append(ref_index)
+    p = PreparedAlign(profiles, refs, params, trim_left, trim_right, ref_index, oriented, exact_scores)
+    if isinstance(self, Group):
+        _check(lib().tracyhip_group_align_traces(self._g, C.byref(p.job), C.byref(p.prm), C.byref(p.out)))
     else:
-        rlen = pr.length[:nt]
-    job.trim_left = trim_left
-    job.trim_right = trim_right
-    job.strand_by_certificate = 0 if exact_scores else 1  # opt-in: the losing strand may carry a certified upper bound
-    if oriented is not None:
-        oriented = np.ascontiguousarray(oriented, dtype=np.uint8)
-        job.oriented = oriented.ctypes.data_as(C.POINTER(C.c_uint8))
-        keep.append(oriented)
-    cap = pp.length[:nt].astype(np.uint64) + rlen.astype(np.uint64)
-    off = np.zeros(max(nt, 1), dtype=np.uint64)
-    if nt:
-        off[1:nt] = np.cumsum(cap)[:-1]
-    res = {
-        "score_fwd": np.zeros(max(nt, 1), np.int32), "score_rev": np.zeros(max(nt, 1), np.int32),
-        "forward": np.zeros(max(nt, 1), np.uint8), "score_prelim": np.zeros(max(nt, 1), np.int32),
-        "slice_begin": np.zeros(max(nt, 1), np.uint32), "slice_len": np.zeros(max(nt, 1), np.uint32),
-        "ref_pos": np.zeros(max(nt, 1), np.uint32), "score_final": np.zeros(max(nt, 1), np.int32),
-        "ops": np.zeros(max(int(cap.sum()) if nt else 0, 1), np.uint8), "ops_len": np.zeros(max(nt, 1), np.uint32),
-    }
-    out = AlignResult()
-    for k in ("score_fwd", "score_rev", "forward", "score_prelim", "slice_begin", "slice_len", "ref_pos",
-              "score_final", "ops", "ops_len"):
-        setattr(out, k, res[k].ctypes.data)
-    out.ops_offset = off.ctypes.data_as(C.POINTER(C.c_uint64))
-    prm = Params(params[0], params[1], params[2], params[3], 1, 0)
-    _check(lib().tracyhip_align_traces(self._h, C.byref(job), C.byref(prm), MEM_HOST, C.byref(out)))
-    btr = [res["ops"][int(off[i]):int(off[i]) + int(res["ops_len"][i])].tobytes() for i in range(nt)]
-    for k in list(res):
-        if k != "ops":
-            res[k] = res[k][:nt]
-    res["btr"] = btr
-    return res
+        _check(lib().tracyhip_align_traces(self._h, C.byref(p.job), C.byref(p.prm), MEM_HOST, C.byref(p.out)))
+    return p.results()
 
 
 Context.align_traces = _align_traces
+
+
+def _align_traces_async(self, job, prm, out, mem=MEM_DEVICE):
+    """tracyhip_align_traces_async on prepared structs (they, and everything they point to, must outlive synchronize())"""
+    _check(lib().tracyhip_align_traces_async(self._h, C.byref(job), C.byref(prm), mem, C.byref(out)))
+
+
+Context.align_traces_async = _align_traces_async
+
+
+def pair_bounds(len1, len2, idx1, idx2, parts):
+    """tracyhip_pair_bounds: boundaries of `parts` contiguous slices of a pair list with (nearly) equal DP cell count.
+    Pure host arithmetic inside the library (works without a GPU) -- the one rule used by device groups and by rank sharding."""
+    len1 = np.ascontiguousarray(len1, dtype=np.uint32)
+    len2 = np.ascontiguousarray(len2, dtype=np.uint32)
+    idx1 = np.ascontiguousarray(idx1, dtype=np.uint32)
+    idx2 = np.ascontiguousarray(idx2, dtype=np.uint32)
+    pr = Pairs()
+    pr.npairs = len(idx1)
+    pr.a1 = SeqSet(SEQ_CHAR, None, None, len1.ctypes.data_as(C.POINTER(C.c_uint32)), len(len1))
+    pr.a2 = SeqSet(SEQ_CHAR, None, None, len2.ctypes.data_as(C.POINTER(C.c_uint32)), len(len2))
+    pr.a1_index = idx1.ctypes.data_as(C.POINTER(C.c_uint32))
+    pr.a2_index = idx2.ctypes.data_as(C.POINTER(C.c_uint32))
+    b = np.zeros(parts + 1, dtype=np.uint64)
+    _check(lib().tracyhip_pair_bounds(C.byref(pr), C.c_uint32(parts), b.ctypes.data_as(C.POINTER(C.c_uint64))))
+    return b.astype(np.int64)
+
+
+class Group:
+    """tracyhip_group: one context per listed device (a device may repeat), host buffers, one host thread per member"""
+
+    def __init__(self, devices=None, ndevices=0):
+        self._g = C.c_void_p()
+        if devices is None:
+            _check(lib().tracyhip_group_create(None, int(ndevices), C.byref(self._g)))
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            _check(lib().tracyhip_group_create(arr, len(devices), C.byref(self._g)))
+
+    def close(self):
+        if self._g:
+            lib().tracyhip_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return lib().tracyhip_group_size(self._g)
+
+    def set_lanes(self, n):
+        _check(lib().tracyhip_group_set_lanes(self._g, C.c_uint32(n)))
+
+    def score(self, a1, a2, params, idx1=None, idx2=None):
+        pr, keep, p1, p2 = Context._pairs(a1, a2, idx1, idx2)
+        prm = Params(*params)
+        out = np.zeros(max(pr.npairs, 1), dtype=np.int32)
+        _check(lib().tracyhip_group_gotoh_score(self._g, C.byref(pr), C.byref(prm), out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out[:pr.npairs]
 
 
 class KernelTiming(C.Structure):
@@ -488,7 +565,10 @@ def _decompose_traces(self, profiles, hbc, refs, params, trim_left=50, trim_righ
                 getattr(out, nm)[k] = a.ctypes.data
                 res["%s%d" % (nm, k)] = a
     prm = Params(params[0], params[1], params[2], params[3], 1, 0)
-    _check(lib().tracyhip_decompose_traces(self._h, C.byref(job), C.byref(prm), MEM_HOST, C.byref(out)))
+    if isinstance(self, Group):
+        _check(lib().tracyhip_group_decompose_traces(self._g, C.byref(job), C.byref(prm), C.byref(out)))
+    else:
+        _check(lib().tracyhip_decompose_traces(self._h, C.byref(job), C.byref(prm), MEM_HOST, C.byref(out)))
     for k in range(3):
         off, ops, olen = keep[k]
         res["btr%d" % k] = [ops[int(off[i]):int(off[i]) + int(olen[i])].tobytes() for i in range(nt)]
@@ -501,3 +581,5 @@ def _decompose_traces(self, profiles, hbc, refs, params, trim_left=50, trim_righ
 
 
 Context.decompose_traces = _decompose_traces
+Group.align_traces = _align_traces
+Group.decompose_traces = _decompose_traces

@@ -45,6 +45,7 @@ struct SageConfig {  // sage.h:37-56 + the extra fields of IndigoConfig (indigo.
   bool callvariants = false;
   std::string outprefix = "out", genome, ab, batch, annotate;
   int device = 0;
+  std::string devices = "0";  // -d: one ordinal, a comma-separated list, or "all" (batches are cut into blocks, one per GPU)
 };
 
 struct Job {
@@ -99,7 +100,8 @@ void usage_options(bool decompose) {
                "  -r [ --reference ] arg           fasta or wildtype ab1 file\n"
                "  -p [ --pratio ] arg (=0.33)      peak ratio to call base\n"
                "  -b [ --batch ] arg               manifest: trace<TAB>reference<TAB>outprefix per line\n"
-               "  -d [ --device ] arg (=0)         GPU ordinal\n";
+               "  -d [ --device ] arg (=0)         GPU ordinal, a list (0,1,2,3) or all: --batch manifests are cut into\n"
+               "                                   contiguous blocks of traces, one per GPU\n";
   if (decompose)
     std::cout << "  -i [ --maxindel ] arg (=1000)    max. indel size in Sanger trace\n"
                  "  -v [ --callVariants ]            call variants in trace\n";
@@ -158,7 +160,7 @@ int parse(int argc, char** argv, SageConfig& c) {
       case 'r': c.genome = val; break;
       case 'p': c.pratio = std::strtof(val.c_str(), nullptr); break;
       case 'b': c.batch = val; break;
-      case 'd': c.device = std::atoi(val.c_str()); break;
+      case 'd': c.devices = val; c.device = std::atoi(val.c_str()); break;
       case 'g': c.gapopen = std::atoi(val.c_str()); break;
       case 'e': c.gapext = std::atoi(val.c_str()); break;
       case 'm': c.match = std::atoi(val.c_str()); break;
@@ -265,9 +267,45 @@ int prepare(SageConfig const& c, Job& j, bool decompose = false) {
   return 0;
 }
 
+// The GPUs a command runs on.  One ordinal: a plain context.  A list or "all": a device group (tracyhip_group_*: one context
+// and one host thread per GPU); the batch pipelines go through the group, everything else through its first member.
 struct Device {
   tracyhip_ctx* ctx = nullptr;
-  ~Device() { if (ctx) tracyhip_destroy(ctx); }
+  tracyhip_group* group = nullptr;
+  ~Device() {
+    if (group) tracyhip_group_destroy(group);
+    else if (ctx) tracyhip_destroy(ctx);
+  }
+  int open(std::string const& spec, uint32_t lanes) {
+    std::vector<int> devs;
+    bool all = (spec == "all");
+    if (!all) {
+      std::size_t pos = 0;
+      while (pos <= spec.size()) {
+        const std::size_t e = spec.find(',', pos);
+        const std::string tok = spec.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+        if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) return -1;
+        devs.push_back(std::atoi(tok.c_str()));
+        if (e == std::string::npos) break;
+        pos = e + 1;
+      }
+    }
+    if (!all && devs.size() == 1) {
+      if (tracyhip_create(devs[0], &ctx) != TRACYHIP_OK) return -1;
+      tracyhip_set_lanes(ctx, lanes);
+      return 0;
+    }
+    if (tracyhip_group_create(all ? nullptr : devs.data(), all ? 0 : (int)devs.size(), &group) != TRACYHIP_OK) return -1;
+    tracyhip_group_set_lanes(group, lanes);
+    ctx = tracyhip_group_context(group, 0);
+    return 0;
+  }
+  int align_traces(const tracyhip_align_job* job, const tracyhip_params* prm, const tracyhip_align_result* res) {
+    return group ? tracyhip_group_align_traces(group, job, prm, res) : tracyhip_align_traces(ctx, job, prm, TRACYHIP_MEM_HOST, res);
+  }
+  int decompose_traces(const tracyhip_decompose_job* job, const tracyhip_params* prm, const tracyhip_decompose_result* res) {
+    return group ? tracyhip_group_decompose_traces(group, job, prm, res) : tracyhip_decompose_traces(ctx, job, prm, TRACYHIP_MEM_HOST, res);
+  }
 };
 
 bool gpu_fail(const char* what) {
@@ -293,7 +331,8 @@ bool alignment_rows(tracyhip_ctx* ctx, tracyhip_seqset const& s1, tracyhip_seqse
 }
 
 // FASTA references: sage.h:233-260 + :311 for every job sharing one (trimLeft, trimRight)
-bool align_fasta_group(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
+bool align_fasta_group(Device& dev, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
+  tracyhip_ctx* ctx = dev.ctx;
   const uint32_t nt = (uint32_t)jobs.size();
   std::vector<float> prof;
   std::vector<uint8_t> refs;
@@ -329,7 +368,7 @@ bool align_fasta_group(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vecto
   res.score_fwd = sf.data(); res.score_rev = sr.data(); res.forward = fwd.data();
   res.slice_begin = sb.data(); res.slice_len = sl.data(); res.ref_pos = rp.data();
   res.score_final = sfin.data(); res.ops = ops.data(); res.ops_offset = ooff.data(); res.ops_len = olen.data();
-  if (tracyhip_align_traces(ctx, &job, &prm, TRACYHIP_MEM_HOST, &res) != TRACYHIP_OK) return gpu_fail("align");
+  if (dev.align_traces(&job, &prm, &res) != TRACYHIP_OK) return gpu_fail("align");
   // the reference slices the final alignment ran against (trimReferenceSlice, fmindex.h:429-463)
   std::vector<uint8_t> slices;
   std::vector<uint64_t> soff(nt);
@@ -494,11 +533,10 @@ int align_main(int argc, char** argv) {
 
   std::cout << stamp() << "Find reference match" << std::endl;
   Device dev;
-  if (tracyhip_create(c.device, &dev.ctx) != TRACYHIP_OK) {
+  if (dev.open(c.devices, 2) != 0) {  // two chunks of a block in flight per GPU (small batches run on one lane)
     gpu_fail("no usable GPU");
     return -1;
   }
-  tracyhip_set_lanes(dev.ctx, 2);  // --batch manifests: two chunks of a batch in flight (small batches run on one lane)
   tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};  // AlignConfig<true,false>, sage.h:165
   std::map<std::pair<uint32_t, uint32_t>, std::vector<Job*>> fasta_groups, seeded_groups;
   std::vector<Job*> wildtype;
@@ -510,9 +548,9 @@ int align_main(int argc, char** argv) {
   }
   std::cout << stamp() << "Alignment" << std::endl;
   for (auto& g : fasta_groups)
-    if (!align_fasta_group(dev.ctx, prm, g.second)) return -1;
+    if (!align_fasta_group(dev, prm, g.second)) return -1;
   for (auto& g : seeded_groups)
-    if (!align_fasta_group(dev.ctx, prm, g.second)) return -1;
+    if (!align_fasta_group(dev, prm, g.second)) return -1;
   if (!wildtype.empty() && !align_wildtype_group(dev.ctx, prm, wildtype)) return -1;
 
   std::cout << stamp() << "Output" << std::endl;
@@ -623,7 +661,8 @@ bool orient_wildtype(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<
 }
 
 // indigo.h:190-388 for every job sharing one (trimLeft, trimRight): the whole chain runs on the device
-bool decompose_group(tracyhip_ctx* ctx, SageConfig const& c, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
+bool decompose_group(Device& dev, SageConfig const& c, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
+  tracyhip_ctx* ctx = dev.ctx;
   const uint32_t nt = (uint32_t)jobs.size();
   const bool wildtype = jobs[0]->rs.filetype == 2;  // groups never mix reference kinds
   if (wildtype && !orient_wildtype(ctx, prm, jobs)) return false;
@@ -698,7 +737,7 @@ bool decompose_group(tracyhip_ctx* ctx, SageConfig const& c, tracyhip_params con
     sc[k].resize(nt); olen[k].resize(nt); ops[k].resize(ocap[k] ? ocap[k] : 1);
     res.score[k] = sc[k].data(); res.ops[k] = ops[k].data(); res.ops_offset[k] = ooff[k].data(); res.ops_len[k] = olen[k].data();
   }
-  if (tracyhip_decompose_traces(ctx, &job, &prm, TRACYHIP_MEM_HOST, &res) != TRACYHIP_OK) return gpu_fail("decompose");
+  if (dev.decompose_traces(&job, &prm, &res) != TRACYHIP_OK) return gpu_fail("decompose");
 
   std::vector<std::string> a1[3], a2[3];
   for (uint32_t i = 0; i < nt; ++i) {
@@ -863,18 +902,17 @@ int decompose_main(int argc, char** argv) {
   }
   std::cout << stamp() << "Find Reference Match" << std::endl;
   Device dev;
-  if (tracyhip_create(c.device, &dev.ctx) != TRACYHIP_OK) {
+  if (dev.open(c.devices, 2) != 0) {  // two chunks of a block in flight per GPU (small batches run on one lane)
     gpu_fail("no usable GPU");
     return -1;
   }
-  tracyhip_set_lanes(dev.ctx, 2);  // --batch manifests: two chunks of a batch in flight (small batches run on one lane)
   tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};
   std::map<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>, std::vector<Job*>> groups;  // (reference kind, trims)
   for (Job& j : jobs)
     if (j.ok) groups[std::make_pair((uint32_t)j.rs.filetype, std::make_pair(j.trimLeft, j.trimRight))].push_back(&j);
   std::cout << stamp() << "Alignment" << std::endl;
   for (auto& g : groups)
-    if (!decompose_group(dev.ctx, c, prm, g.second)) return -1;
+    if (!decompose_group(dev, c, prm, g.second)) return -1;
   std::cout << stamp() << "InDel Search" << std::endl;
   std::vector<Job*> good;
   for (Job& j : jobs) {

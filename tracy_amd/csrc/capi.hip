@@ -151,8 +151,60 @@ int timing_collect(tracyhip_ctx* ctx) {
 
 int ctx_begin(tracyhip_ctx* ctx) {
   if (!ctx) return set_error(TRACYHIP_ERR_ARG, "null context");
+  // a synchronous call on a context with queued asynchronous work runs after it (the worker thread itself passes through)
+  if (ctx->async && std::this_thread::get_id() != ctx->async->worker_id) {
+    std::unique_lock<std::mutex> lk(ctx->async->m);
+    ctx->async->cv.wait(lk, [&] { return ctx->async->q.empty() && !ctx->async->busy; });
+  }
   HIP_TRY(hipSetDevice(ctx->device));
   return TRACYHIP_OK;
+}
+
+int async_submit(tracyhip_ctx* ctx, std::function<int()> fn) {
+  if (!ctx) return set_error(TRACYHIP_ERR_ARG, "null context");
+  if (!ctx->async) {
+    auto* a = new tracyhip_ctx::AsyncState();
+    ctx->async = a;
+    a->worker = std::thread([a]() {
+      for (;;) {
+        std::function<int()> job;
+        {
+          std::unique_lock<std::mutex> lk(a->m);
+          a->cv.wait(lk, [&] { return a->stop || !a->q.empty(); });
+          if (a->q.empty()) return;  // stop requested and nothing left
+          job = std::move(a->q.front());
+          a->q.pop_front();
+          a->busy = true;
+        }
+        const int rc = job();
+        {
+          std::lock_guard<std::mutex> lk(a->m);
+          if (rc != TRACYHIP_OK && a->rc == TRACYHIP_OK) { a->rc = rc; a->msg = tracyhip_last_error(); }
+          a->busy = false;
+        }
+        a->cv.notify_all();
+      }
+    });
+    a->worker_id = a->worker.get_id();
+  }
+  {
+    std::lock_guard<std::mutex> lk(ctx->async->m);
+    ctx->async->q.push_back(std::move(fn));
+  }
+  ctx->async->cv.notify_all();
+  return TRACYHIP_OK;
+}
+
+int async_drain(tracyhip_ctx* ctx) {
+  if (!ctx || !ctx->async) return TRACYHIP_OK;
+  auto* a = ctx->async;
+  std::unique_lock<std::mutex> lk(a->m);
+  a->cv.wait(lk, [&] { return a->q.empty() && !a->busy; });
+  const int rc = a->rc;
+  if (rc != TRACYHIP_OK) set_error(rc, "%s", a->msg.c_str());
+  a->rc = TRACYHIP_OK;
+  a->msg.clear();
+  return rc;
 }
 
 int stage_in(tracyhip_ctx* ctx, DevBuf& buf, const void* src, uint64_t bytes, int mem, const void** dev) {
@@ -337,7 +389,8 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
           bytes += (trace ? mn / 2 : 0) + (pb.a1_profile ? 24ull * d.m : d.m) + (pb.a2_profile ? 24ull * d.n : d.n) + 4;
         }
         if (stage == DP_BAND) bytes = 0;  // band traceback recomputes a few bands into an L2-resident buffer: no matrix-sized traffic
-        if ((trc = timing_begin(ctx, stage == DP_BAND ? TRACYHIP_TIMER_BAND : stage == DP_PREFIX ? TRACYHIP_TIMER_PREFIX : trace ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
+        if ((trc = timing_begin(ctx, stage == DP_BAND ? TRACYHIP_TIMER_BAND : stage == DP_PREFIX ? TRACYHIP_TIMER_PREFIX : stage == DP_ORIGIN ? TRACYHIP_TIMER_ORIGIN
+                                     : trace ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
       }
       bool narrow = false;
       if (!needle && !trace && (pb.mode == MODE_QP || pb.mode == MODE_CHAR) && !ctx->no_narrow) {
@@ -547,6 +600,14 @@ int tracyhip_create(int device, tracyhip_ctx** out) {
 
 int tracyhip_destroy(tracyhip_ctx* c) {
   if (!c) return TRACYHIP_OK;
+  if (c->async) {  // finish queued calls, then stop the worker
+    (void)async_drain(c);
+    { std::lock_guard<std::mutex> lk(c->async->m); c->async->stop = true; }
+    c->async->cv.notify_all();
+    c->async->worker.join();
+    delete c->async;
+    c->async = nullptr;
+  }
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto* l : c->lanes) tracyhip_destroy(l);
@@ -603,7 +664,7 @@ int tracyhip_timing_reset(tracyhip_ctx* c) {
   return TRACYHIP_OK;
 }
 int tracyhip_timing_get(tracyhip_ctx* c, int which, tracyhip_kernel_timing* out) {
-  if (!c || !out || which < 0 || which > 4) return set_error(TRACYHIP_ERR_ARG, "bad timing query");
+  if (!c || !out || which < 0 || which >= TRACYHIP_TIMER_COUNT) return set_error(TRACYHIP_ERR_ARG, "bad timing query");
   *out = c->acc[which];
   for (auto* l : c->lanes) {  // kernels of different lanes overlap on the device: their durations add up here
     out->ms += l->acc[which].ms; out->launches += l->acc[which].launches;
@@ -613,10 +674,45 @@ int tracyhip_timing_get(tracyhip_ctx* c, int which, tracyhip_kernel_timing* out)
 }
 
 int tracyhip_synchronize(tracyhip_ctx* c) {
+  if (!c) return set_error(TRACYHIP_ERR_ARG, "null context");
+  const int arc = async_drain(c);  // queued *_async calls first; their first error is what this call reports
+  std::string amsg;
+  if (arc) amsg = tracyhip_last_error();
   int rc = ctx_begin(c);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (arc) return set_error(arc, "%s", amsg.c_str());
   return TRACYHIP_OK;
+}
+
+int tracyhip_gotoh_score_async(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm, int mem, int32_t* scores) {
+  if (!ctx || !pairs || !prm) return set_error(TRACYHIP_ERR_ARG, "null context / pairs / params");
+  const tracyhip_pairs p = *pairs;
+  const tracyhip_params q = *prm;
+  return async_submit(ctx, [=]() { return tracyhip_gotoh_score(ctx, &p, &q, mem, scores); });
+}
+int tracyhip_gotoh_align_async(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm, int mem, int32_t* scores,
+                               uint8_t* ops, const uint64_t* ops_offset, uint32_t* ops_len) {
+  if (!ctx || !pairs || !prm) return set_error(TRACYHIP_ERR_ARG, "null context / pairs / params");
+  const tracyhip_pairs p = *pairs;
+  const tracyhip_params q = *prm;
+  return async_submit(ctx, [=]() { return tracyhip_gotoh_align(ctx, &p, &q, mem, scores, ops, ops_offset, ops_len); });
+}
+int tracyhip_align_traces_async(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
+                                const tracyhip_align_result* out) {
+  if (!ctx || !job || !prm || !out) return set_error(TRACYHIP_ERR_ARG, "null context / job / params / result");
+  const tracyhip_align_job j = *job;
+  const tracyhip_params q = *prm;
+  const tracyhip_align_result o = *out;
+  return async_submit(ctx, [=]() { return tracyhip_align_traces(ctx, &j, &q, mem, &o); });
+}
+int tracyhip_decompose_traces_async(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
+                                    const tracyhip_decompose_result* out) {
+  if (!ctx || !job || !prm || !out) return set_error(TRACYHIP_ERR_ARG, "null context / job / params / result");
+  const tracyhip_decompose_job j = *job;
+  const tracyhip_params q = *prm;
+  const tracyhip_decompose_result o = *out;
+  return async_submit(ctx, [=]() { return tracyhip_decompose_traces(ctx, &j, &q, mem, &o); });
 }
 
 static int dp_entry(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm, int mem, bool needle,

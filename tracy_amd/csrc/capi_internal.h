@@ -4,6 +4,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -76,7 +82,19 @@ struct tracyhip_ctx {
   bool no_narrow = false;  // TRACYHIP_NO_NARROW=1: force the int32 score kernel (A/B measurements)
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
-  tracyhip_kernel_timing acc[5] = {};
+  tracyhip_kernel_timing acc[TRACYHIP_TIMER_COUNT] = {};
+  // asynchronous calls (tracyhip_*_async): executed in issue order by one worker thread per context
+  struct AsyncState {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<int()>> q;
+    std::thread worker;
+    std::thread::id worker_id;
+    bool busy = false, stop = false;
+    int rc = TRACYHIP_OK;      // first error since the last synchronize
+    std::string msg;
+  };
+  AsyncState* async = nullptr;
   void release_all() {
     tracyhip::DevBuf* all[] = {&d_desc, &d_bits, &d_scratch, &d_in1, &d_in2, &d_codes, &d_scores, &d_ops,
                                &d_ops_off, &d_ops_len, &d_err, &d_rows0, &d_rows1};
@@ -97,6 +115,8 @@ int timing_begin(tracyhip_ctx* ctx, int which, uint64_t cells, uint64_t bytes); 
 int timing_end(tracyhip_ctx* ctx);                                              // record stop event
 int timing_collect(tracyhip_ctx* ctx);                                          // after a stream sync
 int ctx_begin(tracyhip_ctx* ctx);
+int async_submit(tracyhip_ctx* ctx, std::function<int()> fn);  // queue a call on the context's worker thread
+int async_drain(tracyhip_ctx* ctx);                           // wait for the queue; returns (and clears) the first error
 int stage_in(tracyhip_ctx* ctx, DevBuf& buf, const void* src, uint64_t bytes, int mem, const void** dev);
 int check_params(const tracyhip_params* prm, uint64_t max_mn);
 // stage: DP_PLAIN = score-only or full-matrix traceback; DP_CKPT = score-only pass that also writes wavefront

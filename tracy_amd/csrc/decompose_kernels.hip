@@ -381,28 +381,36 @@ int launch_breakpoint(tracyhip_ctx* ctx, const BpDesc* d_desc, uint32_t n, uint3
   const size_t lds = (size_t)maxcol * 17 + 32;
   if (lds > 150 * 1024) return set_error(TRACYHIP_ERR_RANGE, "profile with %u columns exceeds the LDS staging of findBreakpoint", maxcol);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(breakpoint_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, 0); if (trc_) return trc_; }
   hipLaunchKernelGGL(breakpoint_kernel, dim3(n), dim3(64), lds, ctx->stream, d_desc, d_prof, d_out);
   HIP_TRY(hipGetLastError());
+  { int trc_ = timing_end(ctx); if (trc_) return trc_; }
   return TRACYHIP_OK;
 }
 int launch_homozygous(tracyhip_ctx* ctx, const RowsDesc* d_desc, const uint8_t* d_rows0, const uint8_t* d_rows1, uint32_t n,
                       BreakpointOut* d_bps, int32_t* d_status) {
   if (n == 0) return TRACYHIP_OK;
+  { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, 0); if (trc_) return trc_; }
   hipLaunchKernelGGL(homozygous_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_desc, d_rows0, d_rows1, n, d_bps, d_status);
   HIP_TRY(hipGetLastError());
+  { int trc_ = timing_end(ctx); if (trc_) return trc_; }
   return TRACYHIP_OK;
 }
-int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut* d_bps) {
+int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut* d_bps, uint64_t work_cells, uint64_t work_bytes) {
   if (a.ntraces == 0) return TRACYHIP_OK;
+  { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_DECOMP, work_cells, work_bytes); if (trc_) return trc_; }
   hipLaunchKernelGGL(decompose_kernel, dim3(a.ntraces), dim3(64), 0, ctx->stream, a, d_bps);
   HIP_TRY(hipGetLastError());
+  { int trc_ = timing_end(ctx); if (trc_) return trc_; }
   return TRACYHIP_OK;
 }
 int launch_secdecomp(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig, const int32_t* d_pos,
                      const uint8_t* d_pri, const uint8_t* d_sec, uint8_t* d_out) {
   if (n == 0 || maxbc == 0) return TRACYHIP_OK;
+  { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, 0); if (trc_) return trc_; }
   hipLaunchKernelGGL(secdecomp_kernel, dim3((maxbc + 255) / 256, n), dim3(256), 0, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, d_out);
   HIP_TRY(hipGetLastError());
+  { int trc_ = timing_end(ctx); if (trc_) return trc_; }
   return TRACYHIP_OK;
 }
 // the trace-independent enumeration of the (i, j, k) grid, uploaded once per context
@@ -439,7 +447,7 @@ static int ensure_af_grid(tracyhip_ctx* ctx, AfGrid& g) {
 
 int launch_allelic_fraction(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig,
                             const int32_t* d_pos, const uint8_t* d_pri, const uint8_t* d_sec, uint32_t trim_left, uint32_t trim_right,
-                            double* d_out) {
+                            double* d_out, uint64_t work_bytes) {
   if (n == 0) return TRACYHIP_OK;
   const size_t lds = (size_t)maxbc * 36 + 64;  // tp (4 doubles per basecall) + class bytes
   if (lds > 150 * 1024) return set_error(TRACYHIP_ERR_RANGE, "trace with %u basecalls exceeds the LDS staging of allelicFraction", maxbc);
@@ -447,9 +455,11 @@ int launch_allelic_fraction(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n,
   int rc = ensure_af_grid(ctx, grid);
   if (rc) return rc;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(allelic_fraction_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_AFRAC, 0, work_bytes); if (trc_) return trc_; }
   hipLaunchKernelGGL(allelic_fraction_kernel, dim3(n), dim3(AF_THREADS), lds, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, trim_left,
                      trim_right, grid, d_out);
   HIP_TRY(hipGetLastError());
+  { int trc_ = timing_end(ctx); if (trc_) return trc_; }
   return TRACYHIP_OK;
 }
 

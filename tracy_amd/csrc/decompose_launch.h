@@ -15,12 +15,14 @@ struct BcDesc { uint64_t sig_off; uint64_t bc_off; uint32_t nsamples; uint32_t n
 int launch_breakpoint(tracyhip_ctx* ctx, const BpDesc* d_desc, uint32_t n, uint32_t maxcol, const float* d_prof, BreakpointOut* d_out);
 int launch_homozygous(tracyhip_ctx* ctx, const RowsDesc* d_desc, const uint8_t* d_rows0, const uint8_t* d_rows1, uint32_t n,
                       BreakpointOut* d_bps, int32_t* d_status);
-int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut* d_bps);
+// work_cells / work_bytes: what the kernel timers (tracyhip_timing_get) account for the launch -- alignment columns walked and
+// algorithmic bytes (alignment rows + basecalls read, basecalls rewritten); 0 = not accounted
+int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut* d_bps, uint64_t work_cells = 0, uint64_t work_bytes = 0);
 int launch_secdecomp(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig, const int32_t* d_pos,
                      const uint8_t* d_pri, const uint8_t* d_sec, uint8_t* d_out);
 int launch_allelic_fraction(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig,
                             const int32_t* d_pos, const uint8_t* d_pri, const uint8_t* d_sec, uint32_t trim_left, uint32_t trim_right,
-                            double* d_out);
+                            double* d_out, uint64_t work_bytes = 0);
 
 }  // namespace tracyhip
 #endif

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <numeric>
 #include <string>
 #include <thread>
 #include <vector>
@@ -761,12 +762,12 @@ bool nondecreasing(const uint64_t* a, uint32_t n) {
 template <class T>
 T* shifted(T* p, uint64_t by) { return p ? p + by : nullptr; }
 
-// run fn(context, chunk index, lo, k) for every chunk: chunk 0 on the calling thread with the context itself, the
-// others on their lane's own thread; first error wins
+// run fn(context, chunk index, lo, k) for every chunk of [0, nt): chunk 0 on the calling thread, the others on a thread of
+// their own (each sets its context's device); first error wins.  Contexts may sit on one device (lanes) or on several
+// (a device group).
 template <class Fn>
-int run_lanes(tracyhip_ctx* ctx, uint32_t nt, Fn fn) {
-  const uint32_t L = (uint32_t)ctx->lanes.size() + 1;
-  HIP_TRY(hipStreamSynchronize(ctx->stream));  // inputs the caller enqueued on the context's stream
+int run_chunks(const std::vector<tracyhip_ctx*>& ctxs, uint32_t nt, Fn fn) {
+  const uint32_t L = (uint32_t)ctxs.size();
   std::vector<int> rcs(L, TRACYHIP_OK);
   std::vector<std::string> msgs(L);
   std::vector<std::thread> th;
@@ -775,14 +776,14 @@ int run_lanes(tracyhip_ctx* ctx, uint32_t nt, Fn fn) {
     uint32_t lo, hi;
     bounds(c, lo, hi);
     th.emplace_back([&, c, lo, hi]() {
-      rcs[c] = fn(ctx->lanes[c - 1], c, lo, hi - lo);
+      rcs[c] = fn(ctxs[c], c, lo, hi - lo);
       if (rcs[c] != TRACYHIP_OK) msgs[c] = tracyhip_last_error();  // the message lives in that thread
     });
   }
   {
     uint32_t lo, hi;
     bounds(0, lo, hi);
-    rcs[0] = fn(ctx, 0, lo, hi - lo);
+    rcs[0] = fn(ctxs[0], 0, lo, hi - lo);
     if (rcs[0] != TRACYHIP_OK) msgs[0] = tracyhip_last_error();
   }
   for (auto& t : th) t.join();
@@ -790,26 +791,30 @@ int run_lanes(tracyhip_ctx* ctx, uint32_t nt, Fn fn) {
     if (rcs[c] != TRACYHIP_OK) return set_error(rcs[c], "%s", msgs[c].c_str());
   return TRACYHIP_OK;
 }
+template <class Fn>
+int run_lanes(tracyhip_ctx* ctx, uint32_t nt, Fn fn) {
+  HIP_TRY(hipStreamSynchronize(ctx->stream));  // inputs the caller enqueued on the context's stream
+  std::vector<tracyhip_ctx*> ctxs{ctx};
+  ctxs.insert(ctxs.end(), ctx->lanes.begin(), ctx->lanes.end());
+  return run_chunks(ctxs, nt, fn);
+}
 constexpr uint32_t kMinLaneChunk = 64;  // below this a chunk cannot fill the device anyway
 
 }  // namespace
 
-extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
-                                     const tracyhip_align_result* out) {
-  if (!ctx) return set_error(TRACYHIP_ERR_ARG, "null context");
-  const uint32_t L = (uint32_t)ctx->lanes.size() + 1;
-  const bool split = L >= 2 && job && out && prm && job->ntraces >= L * kMinLaneChunk && job->profiles.offset && job->profiles.length &&
-                     job->refs.offset && job->refs.length && job->profiles.count >= job->ntraces && out->ops_offset &&
-                     (job->ref_index || job->refs.count >= job->ntraces) && nondecreasing(out->ops_offset, job->ntraces);
-  if (!split) return align_traces_one(ctx, job, prm, mem, out);
-  int rc = ctx_begin(ctx);
-  if (rc) return rc;
-  return run_lanes(ctx, job->ntraces, [&](tracyhip_ctx* lane, uint32_t, uint32_t lo, uint32_t k) -> int {
-    if (k == 0) return TRACYHIP_OK;
-    tracyhip_align_job j = *job;
-    tracyhip_align_result o = *out;
-    SubSet sp, sr;
-    SubOffsets so;
+namespace {
+bool align_splittable(const tracyhip_align_job* job, const tracyhip_align_result* out, const tracyhip_params* prm, uint32_t parts) {
+  return parts >= 2 && job && out && prm && job->ntraces >= parts * kMinLaneChunk && job->profiles.offset && job->profiles.length &&
+         job->refs.offset && job->refs.length && job->profiles.count >= job->ntraces && out->ops_offset &&
+         (job->ref_index || job->refs.count >= job->ntraces) && nondecreasing(out->ops_offset, job->ntraces);
+}
+// traces [lo, lo + k) of an align job as a job of its own (sequence sets and result regions rebased to the chunk)
+struct AlignChunk {
+  tracyhip_align_job j;
+  tracyhip_align_result o;
+  SubSet sp, sr;
+  SubOffsets so;
+  AlignChunk(const tracyhip_align_job* job, const tracyhip_align_result* out, uint32_t lo, uint32_t k) : j(*job), o(*out) {
     j.ntraces = k;
     sub_seqset(job->profiles, lo, k, sizeof(float), sp);
     j.profiles = sp.s;
@@ -821,7 +826,21 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
     o.score_prelim = shifted(out->score_prelim, lo); o.slice_begin = shifted(out->slice_begin, lo);
     o.slice_len = shifted(out->slice_len, lo); o.ref_pos = shifted(out->ref_pos, lo); o.score_final = shifted(out->score_final, lo);
     o.ops = shifted(out->ops, so.base); o.ops_offset = so.off.data(); o.ops_len = shifted(out->ops_len, lo);
-    return align_traces_one(lane, &j, prm, mem, &o);
+  }
+};
+}  // namespace
+
+extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
+                                     const tracyhip_align_result* out) {
+  if (!ctx) return set_error(TRACYHIP_ERR_ARG, "null context");
+  const uint32_t L = (uint32_t)ctx->lanes.size() + 1;
+  if (!align_splittable(job, out, prm, L)) return align_traces_one(ctx, job, prm, mem, out);
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  return run_lanes(ctx, job->ntraces, [&](tracyhip_ctx* lane, uint32_t, uint32_t lo, uint32_t k) -> int {
+    if (k == 0) return TRACYHIP_OK;
+    AlignChunk c(job, out, lo, k);
+    return align_traces_one(lane, &c.j, prm, mem, &c.o);
   });
 }
 
@@ -1121,7 +1140,9 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     a.out = static_cast<DecompOut*>(d_dst);
     a.prm = DecompParams{dp.trim_left, dp.trim_right, dp.maxindel, dp.madc};
     a.ntraces = nt;
-    if ((rc = launch_decompose(ctx, a, static_cast<const BreakpointOut*>(d_bp)))) return rc;
+    uint64_t wc = 0, wb = 0;
+    for (uint32_t t = 0; t < nt; ++t) { wc += h_len1[t]; wb += 2ull * h_len1[t] + 4ull * mf[t]; }
+    if ((rc = launch_decompose(ctx, a, static_cast<const BreakpointOut*>(d_bp), wc, wb))) return rc;
     std::vector<BcDesc> hb(nt);
     for (uint32_t t = 0; t < nt; ++t) hb[t] = BcDesc{bc.signal_offset[t], bc.bc_offset[t], bc.nsamples[t], mf[t]};
     const BcDesc* db;
@@ -1131,7 +1152,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       return rc;
     if ((rc = launch_allelic_fraction(ctx, db, nt, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos),
                                       static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sd), TL, TR,
-                                      static_cast<double*>(d_fr))))
+                                      static_cast<double*>(d_fr), wb * 0 + 18ull * std::accumulate(mf.begin(), mf.end(), 0ull))))
       return rc;
   }
   std::vector<int32_t> h_hst(nt);
@@ -1258,15 +1279,13 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   for (const DevOut& o : outs)
     if (o.bytes) HIP_TRY(hipMemcpyAsync(o.user, o.dev, o.bytes, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  timing_collect(ctx);
   return TRACYHIP_OK;
 }
 
-// lanes (tracyhip_set_lanes): contiguous chunks of the batch in flight, as tracyhip_align_traces
-extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
-                                         const tracyhip_decompose_result* out) {
-  if (!ctx) return set_error(TRACYHIP_ERR_ARG, "null context");
-  const uint32_t L = (uint32_t)ctx->lanes.size() + 1;
-  bool split = L >= 2 && job && out && prm && job->ntraces >= L * kMinLaneChunk && job->profiles.offset && job->profiles.length &&
+namespace {
+bool decompose_splittable(const tracyhip_decompose_job* job, const tracyhip_decompose_result* out, const tracyhip_params* prm, uint32_t parts) {
+  bool split = parts >= 2 && job && out && prm && job->ntraces >= parts * kMinLaneChunk && job->profiles.offset && job->profiles.length &&
                job->refs.offset && job->refs.length && job->profiles.count >= job->ntraces && job->bc.ntraces >= job->ntraces &&
                job->bc.signal_offset && job->bc.nsamples && job->bc.bc_offset && job->bc.bc_len && out->dcp_offset &&
                (job->ref_index || job->refs.count >= job->ntraces);
@@ -1277,15 +1296,14 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
     if (job->ref_profiles.data && !job->ref_index)
       split = split && job->ref_profiles.offset && job->ref_profiles.length && job->ref_profiles.count >= nt;
   }
-  if (!split) return decompose_traces_one(ctx, job, prm, mem, out);
-  int rc = ctx_begin(ctx);
-  if (rc) return rc;
-  return run_lanes(ctx, job->ntraces, [&](tracyhip_ctx* lane, uint32_t, uint32_t lo, uint32_t k) -> int {
-    if (k == 0) return TRACYHIP_OK;
-    tracyhip_decompose_job j = *job;
-    tracyhip_decompose_result o = *out;
-    SubSet sp, sr, srp;
-    SubOffsets sig, bco, dcp, ops[3];
+  return split;
+}
+struct DecomposeChunk {
+  tracyhip_decompose_job j;
+  tracyhip_decompose_result o;
+  SubSet sp, sr, srp;
+  SubOffsets sig, bco, dcp, ops[3];
+  DecomposeChunk(const tracyhip_decompose_job* job, const tracyhip_decompose_result* out, uint32_t lo, uint32_t k) : j(*job), o(*out) {
     j.ntraces = k;
     sub_seqset(job->profiles, lo, k, sizeof(float), sp);
     j.profiles = sp.s;
@@ -1317,6 +1335,160 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
       o.score[a] = shifted(out->score[a], lo); o.ops[a] = shifted(out->ops[a], ops[a].base);
       o.ops_offset[a] = ops[a].off.data(); o.ops_len[a] = shifted(out->ops_len[a], lo);
     }
-    return decompose_traces_one(lane, &j, prm, mem, &o);
+  }
+};
+}  // namespace
+
+// lanes (tracyhip_set_lanes): contiguous chunks of the batch in flight, as tracyhip_align_traces
+extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
+                                         const tracyhip_decompose_result* out) {
+  if (!ctx) return set_error(TRACYHIP_ERR_ARG, "null context");
+  const uint32_t L = (uint32_t)ctx->lanes.size() + 1;
+  if (!decompose_splittable(job, out, prm, L)) return decompose_traces_one(ctx, job, prm, mem, out);
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  return run_lanes(ctx, job->ntraces, [&](tracyhip_ctx* lane, uint32_t, uint32_t lo, uint32_t k) -> int {
+    if (k == 0) return TRACYHIP_OK;
+    DecomposeChunk c(job, out, lo, k);
+    return decompose_traces_one(lane, &c.j, prm, mem, &c.o);
   });
 }
+
+// =====================================================================================================
+// Device groups: one context per GPU of the node, one host thread per context.  A batch call on a group cuts the batch
+// into contiguous blocks of traces (the pair list of a DP call into slices of equal cell count), runs every block
+// through the single-device entry point of its context -- which may split it further over its lanes -- and returns when
+// all are complete.  Host buffers only: every block stages its own part through its device, nothing crosses devices
+// (the path shards embarrassingly; a multi-process job uses one context per rank and RCCL for the gather
+// instead, tracy_amd/shard.py).
+// =====================================================================================================
+struct tracyhip_group {
+  std::vector<tracyhip_ctx*> ctx;
+};
+
+extern "C" {
+
+int tracyhip_group_create(const int* devices, int ndevices, tracyhip_group** out) {
+  if (!out) return set_error(TRACYHIP_ERR_ARG, "null out pointer");
+  *out = nullptr;
+  std::vector<int> devs;
+  if (devices) {
+    if (ndevices < 1) return set_error(TRACYHIP_ERR_ARG, "empty device list");
+    devs.assign(devices, devices + ndevices);
+  } else {  // every visible device
+    int n = 0;
+    int rc = tracyhip_device_count(&n);
+    if (rc) return rc;
+    if (n <= 0) return set_error(TRACYHIP_ERR_NODEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (ndevices > 0 && ndevices < n) n = ndevices;
+    for (int i = 0; i < n; ++i) devs.push_back(i);
+  }
+  tracyhip_group* g = new tracyhip_group();
+  for (int d : devs) {
+    tracyhip_ctx* c = nullptr;
+    const int rc = tracyhip_create(d, &c);
+    if (rc) {
+      const std::string msg = tracyhip_last_error();
+      for (auto* x : g->ctx) tracyhip_destroy(x);
+      delete g;
+      return set_error(rc, "%s", msg.c_str());
+    }
+    g->ctx.push_back(c);
+  }
+  *out = g;
+  return TRACYHIP_OK;
+}
+
+int tracyhip_group_destroy(tracyhip_group* g) {
+  if (!g) return TRACYHIP_OK;
+  for (auto* c : g->ctx) tracyhip_destroy(c);
+  delete g;
+  return TRACYHIP_OK;
+}
+
+int tracyhip_group_size(const tracyhip_group* g) { return g ? (int)g->ctx.size() : 0; }
+
+tracyhip_ctx* tracyhip_group_context(tracyhip_group* g, int i) {
+  return (g && i >= 0 && i < (int)g->ctx.size()) ? g->ctx[i] : nullptr;
+}
+
+int tracyhip_group_set_lanes(tracyhip_group* g, uint32_t lanes) {
+  if (!g) return set_error(TRACYHIP_ERR_ARG, "null group");
+  for (auto* c : g->ctx) { const int rc = tracyhip_set_lanes(c, lanes); if (rc) return rc; }
+  return TRACYHIP_OK;
+}
+
+int tracyhip_group_align_traces(tracyhip_group* g, const tracyhip_align_job* job, const tracyhip_params* prm, const tracyhip_align_result* out) {
+  if (!g || g->ctx.empty()) return set_error(TRACYHIP_ERR_ARG, "null / empty group");
+  const uint32_t D = (uint32_t)g->ctx.size();
+  if (D == 1 || !align_splittable(job, out, prm, D)) return tracyhip_align_traces(g->ctx[0], job, prm, TRACYHIP_MEM_HOST, out);
+  return run_chunks(g->ctx, job->ntraces, [&](tracyhip_ctx* c, uint32_t, uint32_t lo, uint32_t k) -> int {
+    if (k == 0) return TRACYHIP_OK;
+    AlignChunk ch(job, out, lo, k);
+    return tracyhip_align_traces(c, &ch.j, prm, TRACYHIP_MEM_HOST, &ch.o);
+  });
+}
+
+int tracyhip_group_decompose_traces(tracyhip_group* g, const tracyhip_decompose_job* job, const tracyhip_params* prm,
+                                    const tracyhip_decompose_result* out) {
+  if (!g || g->ctx.empty()) return set_error(TRACYHIP_ERR_ARG, "null / empty group");
+  const uint32_t D = (uint32_t)g->ctx.size();
+  if (D == 1 || !decompose_splittable(job, out, prm, D)) return tracyhip_decompose_traces(g->ctx[0], job, prm, TRACYHIP_MEM_HOST, out);
+  return run_chunks(g->ctx, job->ntraces, [&](tracyhip_ctx* c, uint32_t, uint32_t lo, uint32_t k) -> int {
+    if (k == 0) return TRACYHIP_OK;
+    DecomposeChunk ch(job, out, lo, k);
+    return tracyhip_decompose_traces(c, &ch.j, prm, TRACYHIP_MEM_HOST, &ch.o);
+  });
+}
+
+// Cut a pair list into `parts` contiguous slices of (nearly) equal DP cell count m * n: bounds[0 .. parts], bounds[parts] = npairs.
+// Host arithmetic only (no device needed): the same rule shards the all-pairs matrix of msa.h:33-42 over the devices of a
+// group and over the ranks of a multi-process job (tracy_amd/shard.py).
+int tracyhip_pair_bounds(const tracyhip_pairs* pairs, uint32_t parts, uint64_t* bounds) {
+  if (!pairs || !bounds || parts < 1) return set_error(TRACYHIP_ERR_ARG, "null pairs / bounds, or zero parts");
+  const uint32_t np = pairs->npairs;
+  if (np && (!pairs->a1.length || !pairs->a2.length)) return set_error(TRACYHIP_ERR_ARG, "null length arrays");
+  std::vector<uint64_t> cum(np);
+  uint64_t tot = 0;
+  for (uint32_t i = 0; i < np; ++i) {
+    const uint32_t i1 = pairs->a1_index ? pairs->a1_index[i] : i, i2 = pairs->a2_index ? pairs->a2_index[i] : i;
+    if (i1 >= pairs->a1.count || i2 >= pairs->a2.count) return set_error(TRACYHIP_ERR_ARG, "pair %u indexes past the sequence sets", i);
+    tot += (uint64_t)pairs->a1.length[i1] * pairs->a2.length[i2];
+    cum[i] = tot;
+  }
+  bounds[0] = 0;
+  for (uint32_t r = 1; r < parts; ++r) {
+    const uint64_t want = tot / parts * r + (tot % parts) * r / parts;  // floor(tot * r / parts) without overflow
+    bounds[r] = (uint64_t)(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
+    if (bounds[r] < bounds[r - 1]) bounds[r] = bounds[r - 1];
+  }
+  bounds[parts] = np;
+  return TRACYHIP_OK;
+}
+
+int tracyhip_group_gotoh_score(tracyhip_group* g, const tracyhip_pairs* pairs, const tracyhip_params* prm, int32_t* scores) {
+  if (!g || g->ctx.empty()) return set_error(TRACYHIP_ERR_ARG, "null / empty group");
+  if (!pairs) return set_error(TRACYHIP_ERR_ARG, "null pairs");
+  const uint32_t D = (uint32_t)g->ctx.size();
+  if (D == 1 || pairs->npairs < D * kMinLaneChunk) return tracyhip_gotoh_score(g->ctx[0], pairs, prm, TRACYHIP_MEM_HOST, scores);
+  std::vector<uint64_t> b(D + 1);
+  int rc = tracyhip_pair_bounds(pairs, D, b.data());
+  if (rc) return rc;
+  // identity index arrays are made explicit so that a slice can start anywhere; the sequence sets travel whole (replicated)
+  std::vector<uint32_t> id1, id2;
+  if (!pairs->a1_index) { id1.resize(pairs->npairs); for (uint32_t i = 0; i < pairs->npairs; ++i) id1[i] = i; }
+  if (!pairs->a2_index) { id2.resize(pairs->npairs); for (uint32_t i = 0; i < pairs->npairs; ++i) id2[i] = i; }
+  const uint32_t* x1 = pairs->a1_index ? pairs->a1_index : id1.data();
+  const uint32_t* x2 = pairs->a2_index ? pairs->a2_index : id2.data();
+  return run_chunks(g->ctx, D, [&](tracyhip_ctx* c, uint32_t part, uint32_t, uint32_t) -> int {
+    const uint64_t lo = b[part], hi = b[part + 1];
+    if (hi == lo) return TRACYHIP_OK;
+    tracyhip_pairs p = *pairs;
+    p.npairs = (uint32_t)(hi - lo);
+    p.a1_index = x1 + lo;
+    p.a2_index = x2 + lo;
+    return tracyhip_gotoh_score(c, &p, prm, TRACYHIP_MEM_HOST, scores + lo);
+  });
+}
+
+}  // extern "C"

@@ -90,9 +90,19 @@ struct ProfilePack {  // a list of profiles as one TRACYHIP_SEQ_PROFILE set
 
 }  // namespace detail
 
-// gotohScore(a1[i1[k]], a2[i2[k]], AlignConfig<true,true>) for every k, on the device
+// the pair list of distanceMatrix (msa.h:33-42): i < j, row-major
+inline void pairList(int32_t num, std::vector<uint32_t>& i1, std::vector<uint32_t>& i2) {
+  i1.clear();
+  i2.clear();
+  for (int32_t i = 0; i < num; ++i)
+    for (int32_t j = i + 1; j < num; ++j) { i1.push_back((uint32_t)i); i2.push_back((uint32_t)j); }
+}
+
+// gotohScore(a1[i1[k]], a2[i2[k]], AlignConfig<true,true>) for every k, on the device -- on all devices of `group` when one
+// is given (the pair list is cut into slices of equal cell count, the profiles are replicated: tracyhip_group_gotoh_score)
 inline int scorePairs(tracyhip_ctx* ctx, tracyhip_params prm, std::vector<Profile> const& a1, std::vector<Profile> const& a2,
-                      std::vector<uint32_t> const& i1, std::vector<uint32_t> const& i2, std::vector<int32_t>& scores) {
+                      std::vector<uint32_t> const& i1, std::vector<uint32_t> const& i2, std::vector<int32_t>& scores,
+                      tracyhip_group* group = nullptr) {
   scores.assign(i1.size(), 0);
   if (i1.empty()) return TRACYHIP_OK;
   detail::ProfilePack p1, p2;
@@ -106,6 +116,7 @@ inline int scorePairs(tracyhip_ctx* ctx, tracyhip_params prm, std::vector<Profil
   pr.a2_index = i2.data();
   prm.hfree = 1;
   prm.vfree = 1;
+  if (group) return tracyhip_group_gotoh_score(group, &pr, &prm, scores.data());
   return tracyhip_gotoh_score(ctx, &pr, &prm, TRACYHIP_MEM_HOST, scores.data());
 }
 
@@ -135,7 +146,8 @@ inline int32_t upgma(std::vector<std::vector<int32_t>>& d, std::vector<std::arra
 
 // msa(), msa.h:326-368: distance matrix -> UPGMA -> progressive alignment.  align: one row per sequence in the order
 // seqidx gives (seqidx[row] = index into sps).
-inline int msa(tracyhip_ctx* ctx, tracyhip_params prm, std::vector<Profile> const& sps, CharAlign& align, std::vector<uint32_t>& seqidx) {
+inline int msa(tracyhip_ctx* ctx, tracyhip_params prm, std::vector<Profile> const& sps, CharAlign& align, std::vector<uint32_t>& seqidx,
+               tracyhip_group* group = nullptr) {
   const int32_t num = (int32_t)sps.size();
   align.clear();
   seqidx.clear();
@@ -144,10 +156,9 @@ inline int msa(tracyhip_ctx* ctx, tracyhip_params prm, std::vector<Profile> cons
   std::vector<std::vector<int32_t>> d(dim, std::vector<int32_t>(dim, -1));
   {
     std::vector<uint32_t> i1, i2;
-    for (int32_t i = 0; i < num; ++i)
-      for (int32_t j = i + 1; j < num; ++j) { i1.push_back((uint32_t)i); i2.push_back((uint32_t)j); }
+    pairList(num, i1, i2);
     std::vector<int32_t> sc;
-    const int rc = scorePairs(ctx, prm, sps, sps, i1, i2, sc);
+    const int rc = scorePairs(ctx, prm, sps, sps, i1, i2, sc, group);
     if (rc != TRACYHIP_OK) return rc;
     for (std::size_t k = 0; k < i1.size(); ++k) d[i1[k]][i2[k]] = sc[k];
   }

@@ -18,6 +18,34 @@ void unpack(const float* data, const uint64_t* off, const uint32_t* len, uint32_
 
 extern "C" {
 
+// the pair list of distanceMatrix (msa.h:33-42) as msa() hands it to the device: i1 / i2 of capacity n (n - 1) / 2
+uint64_t tracymsa_pair_list(uint32_t n, uint32_t* i1, uint32_t* i2) {
+  std::vector<uint32_t> a, b;
+  pairList((int32_t)n, a, b);
+  if (i1 && i2) {
+    std::memcpy(i1, a.data(), sizeof(uint32_t) * a.size());
+    std::memcpy(i2, b.data(), sizeof(uint32_t) * b.size());
+  }
+  return a.size();
+}
+
+// msa() with the all-pairs distance matrix spread over the devices of a group (group may be null)
+int64_t tracymsa_msa_group(tracyhip_ctx* ctx, tracyhip_group* group, const tracyhip_params* prm, const float* data, const uint64_t* off,
+                           const uint32_t* len, uint32_t n, char* rows, uint64_t rows_cap, uint32_t* seqidx, uint32_t* nrows) {
+  std::vector<Profile> sps;
+  unpack(data, off, len, n, sps);
+  CharAlign align;
+  std::vector<uint32_t> sidx;
+  const int rc = msa(ctx, *prm, sps, align, sidx, group);
+  if (rc != TRACYHIP_OK) return rc;
+  const uint64_t ncol = align.empty() ? 0 : align[0].size();
+  if (ncol * align.size() > rows_cap) return -100;
+  for (std::size_t i = 0; i < align.size(); ++i) std::memcpy(rows + i * ncol, align[i].data(), ncol);
+  for (std::size_t i = 0; i < sidx.size(); ++i) seqidx[i] = sidx[i];
+  *nrows = (uint32_t)align.size();
+  return (int64_t)ncol;
+}
+
 // msa(): rows (nseq x ncols bytes, row-major) into `rows` (capacity rows_cap), seqidx[nseq]; returns ncols or < 0
 int64_t tracymsa_msa(tracyhip_ctx* ctx, const tracyhip_params* prm, const float* data, const uint64_t* off, const uint32_t* len, uint32_t n,
                      char* rows, uint64_t rows_cap, uint32_t* seqidx, uint32_t* nrows) {

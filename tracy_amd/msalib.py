@@ -20,6 +20,8 @@ def lib():
             raise ImportError("tracy_amd: %s is missing -- run `python tracy_amd/build.py`" % p)
         _LIB = C.CDLL(p)
         _LIB.tracymsa_msa.restype = C.c_int64
+        _LIB.tracymsa_msa_group.restype = C.c_int64
+        _LIB.tracymsa_pair_list.restype = C.c_uint64
         _LIB.tracymsa_consensus.restype = C.c_int64
     return _LIB
 
@@ -37,8 +39,18 @@ def _ptr(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-def msa(ctx, profiles, score):
-    """msa() of msa.h:326-368 -> (rows: list of bytes, seqidx: list of int)"""
+def pair_list(n):
+    """the (i1, i2) index arrays msa() hands to the device for its distance matrix (msa.h:33-42)"""
+    cnt = n * (n - 1) // 2
+    i1 = np.zeros(max(cnt, 1), np.uint32)
+    i2 = np.zeros(max(cnt, 1), np.uint32)
+    got = lib().tracymsa_pair_list(C.c_uint32(n), _ptr(i1, C.c_uint32), _ptr(i2, C.c_uint32))
+    assert got == cnt
+    return i1[:cnt], i2[:cnt]
+
+
+def msa(ctx, profiles, score, group=None):
+    """msa() of msa.h:326-368 -> (rows: list of bytes, seqidx: list of int); group: spread the distance matrix over a device group"""
     data, offs, lens = _pack(profiles)
     n = len(profiles)
     cap = int(lens.sum()) * max(n, 1) + 16
@@ -46,8 +58,8 @@ def msa(ctx, profiles, score):
     sidx = np.zeros(max(n, 1), np.uint32)
     nrows = C.c_uint32(0)
     prm = capi.Params(score[0], score[1], score[2], score[3], 1, 1)
-    ncol = lib().tracymsa_msa(ctx._h, C.byref(prm), _ptr(data, C.c_float), _ptr(offs, C.c_uint64), _ptr(lens, C.c_uint32), C.c_uint32(n), rows,
-                              C.c_uint64(cap), _ptr(sidx, C.c_uint32), C.byref(nrows))
+    ncol = lib().tracymsa_msa_group(ctx._h, group._g if group is not None else None, C.byref(prm), _ptr(data, C.c_float), _ptr(offs, C.c_uint64),
+                                    _ptr(lens, C.c_uint32), C.c_uint32(n), rows, C.c_uint64(cap), _ptr(sidx, C.c_uint32), C.byref(nrows))
     if ncol < 0:
         raise RuntimeError("msa failed: %s" % capi.lib().tracyhip_last_error().decode())
     return [rows.raw[i * ncol:(i + 1) * ncol] for i in range(nrows.value)], sidx[:nrows.value].tolist()

@@ -52,3 +52,47 @@ def gather_ragged_bytes(dist, data, lengths, dst=0):
         return None, None
     out = torch.cat([b[:int(t.item())] for b, t in zip(bucket, all_tot)])
     return out, lens.reshape(-1)
+
+
+# ---- all-pairs jobs (`tracy assemble`, msa.h:33-42 distanceMatrix) ---------------------------------------------------
+def pair_bounds(lengths, world):
+    """The upper-triangular pair list (i < j, row-major: the order of the two loops of msa.h:33-42) cut into `world`
+    contiguous slices of (nearly) equal DP cell count len[i] * len[j].  Returns world + 1 boundaries into the pair list.
+    The rule is the library's (tracyhip_pair_bounds, host arithmetic): device groups and ranks cut the list identically."""
+    import numpy as np
+    from . import capi
+    lengths = np.asarray(lengths, dtype=np.uint32)
+    i1, i2 = np.triu_indices(len(lengths), 1)
+    return capi.pair_bounds(lengths, lengths, i1, i2, world)
+
+
+def pair_slice(lengths, rank, world):
+    """index arrays (a1_index, a2_index) of this rank's slice of the pair list + the boundaries of every rank's slice"""
+    import numpy as np
+    n = len(lengths)
+    b = pair_bounds(lengths, world)
+    i1, i2 = np.triu_indices(n, 1)
+    lo, hi = int(b[rank]), int(b[rank + 1])
+    return i1[lo:hi].astype(np.uint32), i2[lo:hi].astype(np.uint32), b
+
+
+def all_gather_slices(dist, local, bounds):
+    """all_gather of the ranks' score slices (one collective, slices padded to the largest): every rank receives the scores
+    of the whole pair list in pair order -- the distance matrix of msa.h:33-42 in condensed form (<= 4 MB for 1000 traces)."""
+    world = dist.get_world_size()
+    sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
+    cap = max(sizes) if sizes else 0
+    padded = torch.zeros(cap, dtype=local.dtype, device=local.device)
+    padded[:local.numel()] = local
+    bucket = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bucket, padded)
+    return torch.cat([b[:s] for b, s in zip(bucket, sizes)])
+
+
+def condensed_to_square(scores, n):
+    """condensed pair-order scores -> symmetric n x n matrix with a zero diagonal (what msa.h:33-42 fills)"""
+    import numpy as np
+    m = np.zeros((n, n), dtype=np.asarray(scores).dtype)
+    iu = np.triu_indices(n, 1)
+    m[iu] = np.asarray(scores)
+    return m + m.T

@@ -21,6 +21,7 @@
  *   decomposeAlleles                       decompose.h:179-376              tracyhip_decompose_alleles
  *   generateSecondaryDecomposed            decompose.h:378-410              tracyhip_secondary_decomposed
  *   allelicFraction                        decompose.h:412-621              tracyhip_allelic_fraction
+ *   trimReferenceSlice                     fmindex.h:429-463                tracyhip_trim_reference_slice
  *
  * Conventions
  *   - plain C types only; the caller owns every buffer passed in; nothing is retained after return.
@@ -234,6 +235,15 @@ int tracyhip_secondary_decomposed(tracyhip_ctx* ctx, const tracyhip_basecalls* b
 /* allelicFraction, decompose.h:412-621: fractions[2t], fractions[2t+1] = the returned pair. */
 int tracyhip_allelic_fraction(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, const uint8_t* secdecomp, uint32_t trim_left,
                               uint32_t trim_right, int mem, double* fractions);
+
+/* trimReferenceSlice, fmindex.h:429-463, on the two rows of an alignment of a trace (row 0) against its reference slice
+ * (row 1): slice_begin[t] = ri after the trimLeft widening, slice_len[t] = the length rs.refslice.substr(ri, risize) has,
+ * ref_pos[t] = what the call adds to rs.pos (ri forward; oldlen - ri - risize reverse, 0 when that is negative -- the
+ * reference only warns).  refslice_len (rs.refslice.size()) and forward (rs.forward) are HOST arrays. */
+int tracyhip_trim_reference_slice(tracyhip_ctx* ctx, uint32_t ntraces, const uint8_t* rows0, const uint8_t* rows1,
+                                  const uint64_t* rows_offset, const uint32_t* rows_len, const uint32_t* refslice_len,
+                                  const uint8_t* forward, uint32_t trim_left, uint32_t trim_right, int mem,
+                                  uint32_t* slice_begin, uint32_t* slice_len, uint32_t* ref_pos);
 
 /* ---- whole `tracy decompose` hot section (indigo.h:190-388) for a batch of traces, FASTA reference ----
  * findBreakpoint(trimmed profile) -> orientation scores -> gotoh(trimmed, oriented reference) with the

@@ -218,7 +218,7 @@ def test_cpp_host_mirror(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "test_mirror")
     subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(root, "tests/cpp/test_mirror.cpp"),
-                           "-L" + os.path.join(root, "tracy_amd/lib"), "-ltracy_hip", "-L" + os.path.join(root, "oracle"),
+                           "-L" + os.path.join(root, "tracy_amd/lib"), "-ltracy_hip", "-ltracy_host", "-L" + os.path.join(root, "oracle"),
                            "-ltracy_oracle", "-Wl,-rpath," + os.path.join(root, "tracy_amd/lib"),
                            "-Wl,-rpath," + os.path.join(root, "oracle"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)

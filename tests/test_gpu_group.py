@@ -28,6 +28,8 @@ def group():
 
 def same(a, b):
     for k in a:
+        if k == "ops":  # raw buffer: bytes past ops_len[i] are unspecified (staging buffers are reused); "btr" holds the strings
+            continue
         x, y = a[k], b[k]
         if isinstance(x, np.ndarray):
             assert np.array_equal(x, y), k

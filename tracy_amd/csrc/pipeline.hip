@@ -118,6 +118,49 @@ __global__ void trim_from_ends_kernel(const uint32_t* __restrict__ ends, const u
   out[t] = trim_finish(lead, ce >= lead ? ce - lead : 0u, ref_len[t], trim_left, trim_right, forward[t] != 0);
 }
 
+// trimReferenceSlice (fmindex.h:429-463) on the two alignment rows themselves, as the reference scans them: s / e = first / last + 1
+// column holding a trace base, ri = reference bases before s, risize = reference bases in [s, e).  One wave per trace.
+struct TrimRowsDesc { uint64_t off; uint32_t L, n; uint8_t forward, pad[7]; };
+__global__ __launch_bounds__(64) void trim_rows_kernel(const TrimRowsDesc* __restrict__ desc, const uint8_t* __restrict__ rows0,
+                                                       const uint8_t* __restrict__ rows1, uint32_t trim_left, uint32_t trim_right,
+                                                       uint32_t ntraces, TrimOut* __restrict__ out) {
+  const uint32_t t = blockIdx.x;
+  if (t >= ntraces) return;
+  const TrimRowsDesc d = desc[t];
+  const uint8_t* r0 = rows0 + d.off;
+  const uint8_t* r1 = rows1 + d.off;
+  const uint32_t lane = threadIdx.x, L = d.L;
+  int32_t s = -1, e = -1;
+  uint32_t ri = 0;
+  for (uint32_t base = 0; base < L && s < 0; base += 64) {  // first column with a trace base; reference bases before it
+    const uint32_t j = base + lane;
+    const bool tb = (j < L) && (r0[j] != '-');
+    const bool rb = (j < L) && (r1[j] != '-');
+    const unsigned long long mt = __ballot(tb), mr = __ballot(rb);
+    if (mt) {
+      const uint32_t first = (uint32_t)__builtin_ctzll(mt);
+      s = (int32_t)(base + first);
+      ri += (uint32_t)__popcll(mr & ((1ull << first) - 1ull));
+    } else {
+      ri += (uint32_t)__popcll(mr);
+    }
+  }
+  uint32_t risize = 0;
+  if (s >= 0) {
+    for (uint32_t base = 0; base < L; base += 64) {  // last column with a trace base, scanning from the end
+      const uint32_t q = base + lane;
+      const bool tb = (q < L) && (r0[L - 1 - q] != '-');
+      const unsigned long long m = __ballot(tb);
+      if (m) { e = (int32_t)(L - (base + (uint32_t)__builtin_ctzll(m))); break; }
+    }
+    for (uint32_t base = (uint32_t)s; base < (uint32_t)e; base += 64) {
+      const uint32_t j = base + lane;
+      risize += (uint32_t)__popcll(__ballot(j < (uint32_t)e && r1[j] != '-'));
+    }
+  }
+  if (lane == 0) out[t] = trim_finish(ri, risize, d.n, trim_left, trim_right, d.forward != 0);
+}
+
 // loadSingleFasta hands over upper-case [ACGTN] only (fasta.h:54-95); anything else makes the string
 // and profile reverse complements (fmindex.h:8-24 vs profile.h:74-90) disagree, so it is rejected.
 __global__ void validate_ref_kernel(const uint8_t* __restrict__ in, uint64_t n, int32_t* err) {
@@ -1492,3 +1535,42 @@ int tracyhip_group_gotoh_score(tracyhip_group* g, const tracyhip_pairs* pairs, c
 }
 
 }  // extern "C"
+
+extern "C" int tracyhip_trim_reference_slice(tracyhip_ctx* ctx, uint32_t ntraces, const uint8_t* rows0, const uint8_t* rows1,
+                                             const uint64_t* rows_offset, const uint32_t* rows_len, const uint32_t* refslice_len,
+                                             const uint8_t* forward, uint32_t trim_left, uint32_t trim_right, int mem,
+                                             uint32_t* slice_begin, uint32_t* slice_len, uint32_t* ref_pos) {
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  if (mem != TRACYHIP_MEM_HOST && mem != TRACYHIP_MEM_DEVICE) return set_error(TRACYHIP_ERR_ARG, "bad mem kind");
+  if (ntraces == 0) return TRACYHIP_OK;
+  if (!rows0 || !rows1 || !rows_offset || !rows_len || !refslice_len || !forward || !slice_begin || !slice_len || !ref_pos)
+    return set_error(TRACYHIP_ERR_ARG, "null argument");
+  hipStream_t st = ctx->stream;
+  uint64_t ext = 0;
+  std::vector<TrimRowsDesc> hd(ntraces);
+  for (uint32_t t = 0; t < ntraces; ++t) {
+    ext = std::max<uint64_t>(ext, rows_offset[t] + rows_len[t]);
+    hd[t] = TrimRowsDesc{rows_offset[t], rows_len[t], refslice_len[t], (uint8_t)(forward[t] ? 1 : 0), {0, 0, 0, 0, 0, 0, 0}};
+  }
+  const void *d_r0, *d_r1;
+  if ((rc = stage_in(ctx, ctx->d_rows0, rows0, ext, mem, &d_r0))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_rows1, rows1, ext, mem, &d_r1))) return rc;
+  HIP_TRY(ctx->d_desc.ensure(sizeof(TrimRowsDesc) * (size_t)ntraces));
+  HIP_TRY(hipMemcpyAsync(ctx->d_desc.p, hd.data(), sizeof(TrimRowsDesc) * (size_t)ntraces, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx->d_tmp[5].ensure(sizeof(TrimOut) * (size_t)ntraces));
+  hipLaunchKernelGGL(trim_rows_kernel, dim3(ntraces), dim3(64), 0, st, static_cast<const TrimRowsDesc*>(ctx->d_desc.p),
+                     static_cast<const uint8_t*>(d_r0), static_cast<const uint8_t*>(d_r1), trim_left, trim_right, ntraces,
+                     static_cast<TrimOut*>(ctx->d_tmp[5].p));
+  HIP_TRY(hipGetLastError());
+  std::vector<TrimOut> h(ntraces);
+  HIP_TRY(hipMemcpyAsync(h.data(), ctx->d_tmp[5].p, sizeof(TrimOut) * (size_t)ntraces, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));  // (hd is pageable: the upload above has completed by now as well)
+  std::vector<uint32_t> b(ntraces), l(ntraces), p(ntraces);
+  for (uint32_t t = 0; t < ntraces; ++t) { b[t] = h[t].ri; l[t] = h[t].len; p[t] = h[t].pos; }
+  const hipMemcpyKind up = (mem == TRACYHIP_MEM_HOST) ? hipMemcpyHostToHost : hipMemcpyHostToDevice;
+  HIP_TRY(hipMemcpy(slice_begin, b.data(), sizeof(uint32_t) * (size_t)ntraces, up));
+  HIP_TRY(hipMemcpy(slice_len, l.data(), sizeof(uint32_t) * (size_t)ntraces, up));
+  HIP_TRY(hipMemcpy(ref_pos, p.data(), sizeof(uint32_t) * (size_t)ntraces, up));
+  return TRACYHIP_OK;
+}

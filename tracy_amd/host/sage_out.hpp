@@ -34,15 +34,6 @@ namespace tracy_amd {
 constexpr int32_t kEmptyTraceSignal = -99;     // EMPTY_TRACE_SIGNAL, json.h:12-14
 constexpr std::size_t kMaxSingleFasta = 50000;  // MAX_SINGLE_FASTA_SIZE, fasta.h:10-12
 
-struct ReferenceSlice {  // fmindex.h:28-37
-  bool forward = true;
-  int32_t filetype = -1;  // -1 failure, 0 *.fa.gz (indexed genome), 1 *.fa, 2 trace
-  uint32_t kmersupport = 0;
-  uint32_t pos = 0;
-  std::string chr;
-  std::string refslice;
-};
-
 // gapped rows of one pairwise alignment
 struct AlignRows {
   std::string row0, row1;

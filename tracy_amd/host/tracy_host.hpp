@@ -47,6 +47,15 @@ struct BaseCalls {  // abif.h:46-57
   std::vector<uint8_t> estQual;
 };
 
+struct ReferenceSlice {  // fmindex.h:28-37
+  bool forward = true;
+  int32_t filetype = -1;  // -1 failure, 0 *.fa.gz (indexed genome), 1 *.fa, 2 trace
+  uint32_t kmersupport = 0;
+  uint32_t pos = 0;
+  std::string chr;
+  std::string refslice;
+};
+
 // float[6][cols], element (k, j) at k*cols + j -- the layout the C ABI takes (TRACYHIP_SEQ_PROFILE)
 struct Profile {
   std::vector<float> v;

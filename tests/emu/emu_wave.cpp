@@ -128,10 +128,12 @@ void run_prefix_wave(const DpArgs& a, uint32_t npairs) {
 }
 
 // MODE_QP kernels read the code buffer without clamping (idle lanes, look-ahead): the library pads it (kCodePad in
-// capi_internal.h); the emulator does the same, with a byte that is not a code so that a use of it would show
+// capi_internal.h) with code 5 (an all-zero column); the emulator does the same.  Idle lanes of the steady-state steps of the
+// 16-bit sweep really look such a byte up in the table (and discard the result), so it has to be a code.
 static std::vector<uint8_t> padded_codes(const void* a2, size_t bytes) {
-  std::vector<uint8_t> v(bytes + 256, 0xEE);
+  std::vector<uint8_t> v(bytes + 256, 5);
   if (bytes) std::memcpy(v.data() + 128, a2, bytes);
+  for (auto& c : v) if (c > 5) c = 5;  // as the library's encoders (dp_code)
   return v;
 }
 

@@ -10,7 +10,7 @@ LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libtracy_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
-         "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+         "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"] + os.environ.get("TRACYHIP_CXXFLAGS", "").split()
 
 
 def sources():

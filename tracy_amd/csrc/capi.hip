@@ -100,7 +100,7 @@ uint64_t seqset_extent(const tracyhip_seqset& s) {
 // ---- small device helpers ------------------------------------------------------------------------
 __global__ void encode_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (uint8_t)base_code(in[i]);
+  if (i < n) out[i] = (uint8_t)dp_code(in[i]);
 }
 
 #define HIP_TRY(expr)                                                                               \

@@ -223,7 +223,9 @@ struct SubProf {
 // LDS bytes of the Needleman-Wunsch kernels (profile rows are staged in LDS there)
 TR_HD constexpr uint32_t needle_lds_bytes(int mode, int K) { return mode == MODE_PROF ? 5u * 64u * K * 4u : 0u; }
 TR_HD constexpr uint32_t lds_bytes(int mode, int K) {
-  return mode == MODE_QP ? (5u * 64u + 1u) * (uint32_t)qp_stride(K) * 2u : 0u;  // MODE_PROF keeps its rows in registers
+  // 6 code rows x 64 lanes x qp_stride(K) int16: what the 16-bit sweep (gotoh_narrow_qp_body) lays out; the other QP kernels use
+  // five rows + one shared zero strip of it.  MODE_PROF keeps its rows in registers.
+  return mode == MODE_QP ? 6u * 64u * (uint32_t)qp_stride(K) * 2u : 0u;
 }
 
 // MODE_QP sweeps read the code buffer up to kCodeBias bytes before / behind a sequence (idle lanes, look-ahead)
@@ -242,12 +244,19 @@ TR_HD uint64_t ckpt_index(uint32_t j /*1-based*/, uint32_t field, uint32_t lane,
   return ((uint64_t)(j - 1) * ckpt_fields(K) + field) * 64u + lane;
 }
 
+template <class W, int K, bool CKPT>
+TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx);  // the 16-bit query-profile sweep, below
+
 template <class W, int K, int MODE, bool TRACE, bool NARROW = false, bool CKPT = false>
 TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   static_assert(!(NARROW && TRACE), "the 16-bit formulation exists for the score-only kernel");
   static_assert(!(CKPT && TRACE), "checkpoints are written by the score-only kernel");
   // NARROW / CKPT kernels: single pass, free end gaps on the first/last row only, rows anchored at the bottom
   constexpr bool BOTTOM = NARROW || CKPT;
+  if constexpr (NARROW && MODE == MODE_QP) {  // the hot kernel of `tracy align` has its own body
+    gotoh_narrow_qp_body<W, K, CKPT>(w, a, pair_idx);
+    return;
+  }
   const PairDesc d = a.pairs[pair_idx];
   const uint32_t L = w.lane();
   const uint32_t m = d.m, n = d.n;
@@ -534,6 +543,276 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     }
     if (!last_pass) w.sync_global();  // scratch written by lane 63 is read by lane 0 in the next pass
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The 16-bit query-profile sweep: gotohScore(trace profile, _createProfile(reference)) with AlignConfig<true,false>
+// (sage.h:239-240, indigo.h:235-247), optionally leaving wavefront checkpoints + row m for the band traceback.
+// This is the kernel the `tracy align` step spends three quarters of its time in; it is written for VALU issue:
+//
+//   * All values are kept minus (go+ge):  Hl = H,  El = E - goe,  f = F - goe.  The recurrences keep their form
+//       E' = max(H_left, E'_left + ge)   F' = max(H_up, F'_up + ge)   H = max(H_diag + (sub - goe), E', F') + goe
+//     (8 VALU ops per cell, v_add_u16 / v_max_i16), and row 0 becomes H = 0, F' <= 0: exactly what a DPP wave_shr:1 with
+//     bound_ctrl writes into lane 0, so the hand-off of {H, F'} is two DPP moves and nothing else.
+//   * The strip above hands its last H straight out of the state register; the value received in the previous step is the
+//     diagonal of this one (two registers used alternately by the two halves of the unrolled loop): no copies.
+//   * The reference code selects one of SIX tables (5 = all-zero column for '-' / other letters): address = lane column +
+//     code * stride, one v_lshl_add / v_mad.  The table is laid out [code][row][lane]; every row of the strip arrives by its
+//     own conflict-free 16-bit LDS read (LDS issue is not what this kernel is short of), so no cell needs its operand
+//     shifted into place.
+//   * Strips are swept by four asm statements per step (dp_lane.h strip_left16 / strip_down16).
+//   * Between ramp-up and ramp-down every used lane is on a real column: those steps run without an activity test.
+//   * Row m goes out as one {H, E'} pair of int16 per column (4 B instead of 8), checkpoints every ckpt_B steps.
+// Domain (narrow_ok in capi.hip): one pass, hfree, !vfree, go <= 0, ge < 0, every value inside int16.
+// ------------------------------------------------------------------------------------------------
+template <bool G>
+struct SweepGuard { static constexpr bool value = G; };  // tag: does a step test whether its lane is on a column?
+
+template <int K>
+struct QpStrip {
+  uint32_t v[K];  // row i in the low half (16-bit LDS reads zero the high half; the 16-bit ops ignore it)
+  TR_HD int32_t lo16(int i) const { return (int32_t)v[i]; }
+};
+// table of the 16-bit sweep: int16 [6 codes][qp_stride(K) rows][64 lanes] -- a row's 64 lanes are contiguous, so the
+// per-row 16-bit reads of a wave are conflict-free (a per-lane strip layout costs an 8-way bank conflict on each of them)
+template <int K>
+TR_HD uint32_t qp6_index(uint32_t code, uint32_t row, uint32_t lane) { return (code * (uint32_t)qp_stride(K) + row) * 64u + lane; }
+template <int K>
+TR_HD void qp_fetch6(const char* lane_col, uint32_t code, QpStrip<K>& q) {
+  constexpr uint32_t KP = qp_stride(K);
+  const char* p = lane_col + code * (KP * 64u * 2u);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Every LDS read of the sweep is issued by hand and waited for by hand (qp_wait6): one 16-bit read per row, so that no
+  // cell needs its operand shifted into place (VALU work, which is what this kernel is short of), and no compiler
+  // wait-count bookkeeping that would stall each step on the strip that was only just requested.
+  const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(p);  // low half of the flat address = LDS byte address
+#pragma unroll
+  for (int i = 0; i < K; ++i) asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(q.v[i]) : "v"(lds_addr), "n"(i * 128));
+#else
+  const uint16_t* ph = reinterpret_cast<const uint16_t*>(p);
+  for (int i = 0; i < K; ++i) q.v[i] = ph[i * 64];
+#endif
+}
+// Before a strip is used: LDS operations complete in order, so once at most the K reads of the NEXT strip (issued after
+// this one) are outstanding, this strip has arrived.  The wait is tied to the registers it guards, so no use of them can
+// be scheduled above it.
+template <int K>
+TR_HD void qp_wait6(QpStrip<K>& q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int newer = K < 15 ? K : 15;  // lgkmcnt is a 4-bit counter
+#define TR_TIE4(o) "+v"(q.v[o]), "+v"(q.v[o + 1]), "+v"(q.v[o + 2]), "+v"(q.v[o + 3])
+  if constexpr (K == 15) asm volatile("s_waitcnt lgkmcnt(%15)" : TR_TIE4(0), TR_TIE4(4), TR_TIE4(8), "+v"(q.v[12]), "+v"(q.v[13]), "+v"(q.v[14]) : "n"(newer));
+  else if constexpr (K == 16) asm volatile("s_waitcnt lgkmcnt(%16)" : TR_TIE4(0), TR_TIE4(4), TR_TIE4(8), TR_TIE4(12) : "n"(newer));
+  else if constexpr (K == 12) asm volatile("s_waitcnt lgkmcnt(%12)" : TR_TIE4(0), TR_TIE4(4), TR_TIE4(8) : "n"(newer));
+  else if constexpr (K == 8) asm volatile("s_waitcnt lgkmcnt(%8)" : TR_TIE4(0), TR_TIE4(4) : "n"(newer));
+  else if constexpr (K == 4) asm volatile("s_waitcnt lgkmcnt(%4)" : TR_TIE4(0) : "n"(newer));
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef TR_TIE4
+#endif
+}
+
+// accessors of the band traceback for what the sweep left behind (DpArgs::ckpt_narrow): row m per column, frontier fields
+TR_HD int32_t lastrow_h(const int32_t* lr, uint32_t c, bool narrow) { return narrow ? sext16(lr[c]) : lr[2 * c]; }
+TR_HD int32_t lastrow_e(const int32_t* lr, uint32_t c, bool narrow, int32_t goe) { return narrow ? (lr[c] >> 16) + goe : lr[2 * c + 1]; }
+
+template <class W, int K, bool CKPT>
+TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
+  const PairDesc d = a.pairs[pair_idx];
+  const uint32_t L = w.lane();
+  const uint32_t m = d.m, n = d.n;
+  const int32_t go = a.go, ge = a.ge, goe = go + ge;
+  if (m == 0 || n == 0) {  // only the init row / column exists (gotoh.h:106-123); hfree, !vfree
+    if (L == 0 && a.scores) a.scores[d.out] = (m == 0) ? 0 : edge_value(false, go, ge, (int32_t)m);
+    return;
+  }
+  constexpr uint32_t KP = qp_stride(K);
+  const float* a1p = static_cast<const float*>(a.a1) + d.a1_off;
+  const uint8_t* a2c = static_cast<const uint8_t*>(a.a2) + d.a2_off;
+  int16_t* qp_tab = reinterpret_cast<int16_t*>(w.lds());
+  const float fmatch = (float)a.match, fmis = (float)a.mismatch;
+  const uint32_t lanes_used = (m + K - 1) / K;
+  const uint32_t pad = lanes_used * K - m;  // rows anchored at the bottom: row m is the last slot of the last used lane
+  const uint32_t t_end = n + lanes_used - 1;
+  const bool rcflag = (d.flags & PAIR_A2_REVCOMP) != 0;
+  const bool lastlane = L == lanes_used - 1;
+
+  // ---- per-lane state at column 0 (gotoh.h:117-123), minus (go+ge) ----
+  int32_t Hl[K], El[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    const uint32_t r = L * K + i + 1 - pad;
+    if (L * K + i < pad) { Hl[i] = 0; El[i] = -goe; }  // padding slots above row 1 reproduce row 0: H = 0 in every column
+    else { Hl[i] = edge_value(false, go, ge, (int32_t)r); El[i] = kNegInf16; }
+  }
+  int32_t gev = ge, goev = goe;
+  int32_t hext_last = lastlane ? 0 : ge;      // row m: horizontal gaps are free (AlignConfig<true,.>)
+  int32_t delta_last = lastlane ? -goe : 0;   // ... so E' = max(H - goe, E') there
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(gev), "+v"(goev), "+v"(hext_last), "+v"(delta_last));  // four live VGPRs for the whole sweep, not re-materialised per step
+#endif
+
+  // ---- query profile: int16 [6][64 lanes][KP], entry = (int)(sum_k p[k][row] w[k][b]) - goe; row 5 and rows off the trace score 0 ----
+  {
+    bool overflow = false;
+    int32_t qabs = 0;
+#pragma unroll 1
+    for (int i = 0; i < (int)KP; ++i) {
+      const uint32_t r = L * K + i + 1 - pad;
+      const bool real = (i < K) && (r - 1 < m);
+      float pr[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) pr[k] = real ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+#pragma unroll
+      for (uint32_t b = 0; b < 5; ++b) {
+        const int32_t q = real ? onehot_score(pr, b, fmatch, fmis) : 0;
+        const int32_t qs = q - goe;
+        overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
+        qabs = imax(qabs, q < 0 ? -q : q);
+        const uint32_t row = (rcflag && b < 4u) ? 3u - b : b;  // reverse-complement view: the complement is folded into the table
+        qp_tab[qp6_index<K>(row, (uint32_t)i, L)] = (int16_t)qs;
+      }
+      qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)(-goe);
+    }
+    if (overflow) flag_error(a.err, 1);
+    if (qabs > a.qlimit) flag_max(a.err, 1, qabs);
+    w.sync();
+  }
+
+  // ---- sweep ----
+  const char* strip = reinterpret_cast<const char*>(qp_tab) + L * 2u;  // this lane's column of the table
+  const uint8_t* a2v = a2c - kCodeBias;
+  const int32_t lane_base = (int32_t)kCodeBias + (rcflag ? (int32_t)n + (int32_t)L : -(int32_t)L - 1);
+  const int32_t dir = rcflag ? -1 : 1;
+  char* lrb = CKPT ? reinterpret_cast<char*>(a.lastrow + d.lastrow_off) : nullptr;
+  const int32_t lr_lane = -4 * (int32_t)L;  // byte offset of column c = t - L in the row-m array: 4 t + lr_lane
+  const uint32_t B = CKPT ? a.ckpt_B : 1u;
+  uint32_t ck_left = B;                                         // steps until the next wavefront checkpoint (wave-uniform)
+  int32_t* ck_next = CKPT ? a.ckpt + d.ckpt_off + L : nullptr;   // its record
+  int32_t f = 0;
+  // the H received from the strip above: the two registers alternate between "this column's upper neighbour" and "the diagonal"
+  const uint32_t row_above = (L * K > pad) ? L * K - pad : 0u;
+  int32_t upA = 0, upB = (row_above == 0) ? 0 : edge_value(false, go, ge, (int32_t)row_above);
+
+  // `row_m` receives this step's {H, E'} pair of row m (last lane only); the caller stores it
+  auto step = [&](auto guard, uint32_t t, QpStrip<K>& q, int32_t& up_cur, const int32_t& diag, uint32_t& row_m) {
+    constexpr bool GUARD = decltype(guard)::value;
+    up_cur = w.shift_up(Hl[K - 1]);  // lane 0 receives 0 = H(0, t)
+    f = w.shift_up(f);               // ... and F' = 0, which loses against H(0, t) + 0 as -inf would
+    qp_wait6<K>(q);
+    const bool active = !GUARD || (uint32_t)(t - 1u - L) < n;
+    if (active) {
+      int32_t sub[K];
+#pragma unroll
+      for (int i = 0; i < K; ++i) sub[i] = q.lo16(i);
+      if constexpr (K == 15) {
+        strip_left16<7, true>(Hl + 8, El + 8, sub + 8, Hl[7], gev, hext_last, delta_last);
+        strip_left16<8, false>(Hl, El, sub, diag, gev, hext_last, delta_last);
+        strip_down16<8>(Hl, El, up_cur, f, gev, goev);
+        strip_down16<7>(Hl + 8, El + 8, Hl[7], f, gev, goev);
+      } else if constexpr (K == 16) {
+        strip_left16<8, true>(Hl + 8, El + 8, sub + 8, Hl[7], gev, hext_last, delta_last);
+        strip_left16<8, false>(Hl, El, sub, diag, gev, hext_last, delta_last);
+        strip_down16<8>(Hl, El, up_cur, f, gev, goev);
+        strip_down16<8>(Hl + 8, El + 8, Hl[7], f, gev, goev);
+      } else {
+#pragma unroll
+        for (int i = K - 1; i >= 0; --i) {
+          const int32_t dg = i == 0 ? diag : Hl[i - 1];
+          if (i == K - 1) cell_left16_last(Hl[i], El[i], hext_last, dg, sub[i], delta_last);
+          else cell_left16(Hl[i], El[i], gev, dg, sub[i]);
+        }
+        int32_t uh = up_cur;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { cell_down16(Hl[i], El[i], uh, f, gev, goev); uh = Hl[i]; }
+      }
+      if (CKPT) row_m = ((uint32_t)El[K - 1] << 16) | ((uint32_t)Hl[K - 1] & 0xffffu);
+      if (CKPT && GUARD && lastlane)  // ramp phases: row m column by column (the steady state stores four columns at once)
+        *reinterpret_cast<uint32_t*>(lrb + (uint32_t)(4 * (int32_t)t + lr_lane)) = row_m;
+    }
+    if (CKPT && t <= t_end && --ck_left == 0) {  // wavefront checkpoint every B steps: the whole frontier (raw registers), one coalesced store per field
+      ck_left = B;
+      int32_t* ck = ck_next;
+      ck_next += ckpt_fields(K) * 64u;
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        ck[(uint32_t)i * 64u] = Hl[i];
+        ck[(uint32_t)(K + i) * 64u] = El[i];
+      }
+      ck[(2u * K) * 64u] = Hl[K - 1];
+      ck[(2u * K + 1) * 64u] = f;
+      ck[(2u * K + 2) * 64u] = up_cur;
+    }
+  };
+  using Guarded = SweepGuard<true>;
+  using Free = SweepGuard<false>;
+
+  // Software pipeline, four steps per round (nothing is copied between the two halves of the ping-pong pairs):
+  //   * reference codes: one unaligned dword per lane and round = the codes of its next four columns, requested two rounds
+  //     (~8 steps) ahead, so the wait for it never sees the latency -- nor the acknowledgements of the row-m / checkpoint
+  //     stores that share the memory counter on this architecture;
+  //   * the strip of column t+1 is read from LDS while step t runs.
+  // Forward view: column c is byte c-1; reverse-complement view: byte n-c (its complement sits in the table), so a round's
+  // four columns are the dword's bytes 0..3 or 3..0 -- a wave-uniform choice of four shift counts.
+  const int32_t byte0 = lane_base + (rcflag ? -3 : 0);  // dword of the round that starts at step t: a2v + byte0 + dir * t
+  auto codes_at = [&](uint32_t tt) -> uint32_t {
+    uint32_t v;
+    __builtin_memcpy(&v, a2v + (uint32_t)(byte0 + dir * (int32_t)tt), 4);  // unaligned dword load
+    return v;
+  };
+  // The in-flight request is issued and waited for by hand.  gfx950 counts loads and stores in ONE in-order counter; the
+  // compiler's wait for this load, placed where the loop carries it round, would be vmcnt(0) and sit behind the
+  // acknowledgement of the row-m store issued a moment earlier.  "At most one younger operation outstanding" is all
+  // the load needs (checkpoint rounds, one in 64, wait a little longer).
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the base address is the same for the whole wave; say so, for the scalar-base form of the load
+  const uint64_t a2v_bits = reinterpret_cast<uint64_t>(a2v);
+  const uint8_t* a2v_s = reinterpret_cast<const uint8_t*>(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(a2v_bits >> 32)) << 32) |
+                                                          (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)a2v_bits));
+#endif
+  auto codes_request = [&](uint32_t tt, uint32_t& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t voff = (uint32_t)(byte0 + dir * (int32_t)tt);
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(a2v_s));
+#else
+    v = codes_at(tt);
+#endif
+  };
+  auto codes_arrived = [&](uint32_t& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(1)" : "+v"(v));
+#endif
+  };
+  const uint32_t sh0 = rcflag ? 24u : 0u, sh1 = rcflag ? 16u : 8u, sh2 = rcflag ? 8u : 16u, sh3 = rcflag ? 0u : 24u;
+  uint32_t t = 1;
+  uint32_t cw_cur = codes_at(1), cw_next = codes_at(5), cw_pend = 0;
+  QpStrip<K> qa, qb;
+  qp_fetch6<K>(strip, (cw_cur >> sh0) & 0xffu, qa);
+  auto four_steps = [&](auto guard) {
+    constexpr bool GUARD = decltype(guard)::value;
+    codes_request(t + 8, cw_pend);
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    qp_fetch6<K>(strip, (cw_cur >> sh1) & 0xffu, qb);
+    step(guard, t, qa, upA, upB, r0);
+    qp_fetch6<K>(strip, (cw_cur >> sh2) & 0xffu, qa);
+    step(guard, t + 1, qb, upB, upA, r1);
+    qp_fetch6<K>(strip, (cw_cur >> sh3) & 0xffu, qb);
+    step(guard, t + 2, qa, upA, upB, r2);
+    qp_fetch6<K>(strip, (cw_next >> sh0) & 0xffu, qa);
+    step(guard, t + 3, qb, upB, upA, r3);
+    if (CKPT && !GUARD && lastlane) {  // {H, E'} of row m for the band traceback: one int16 pair per column, four columns per store
+      const uint32_t v[4] = {r0, r1, r2, r3};
+      __builtin_memcpy(lrb + (uint32_t)(4 * (int32_t)t + lr_lane), v, 16);
+    }
+    codes_arrived(cw_pend);
+    cw_cur = cw_next;
+    cw_next = cw_pend;
+    t += 4;
+  };
+  while (t < lanes_used && t <= t_end) four_steps(Guarded{});  // ramp-up
+  while (t + 3 <= n) four_steps(Free{});                       // every used lane is on a column of the reference
+  while (t <= t_end) four_steps(Guarded{});                    // ramp-down (steps past t_end find no lane on a column)
+
+  if (a.scores && lastlane) a.scores[d.out] = sext16(Hl[K - 1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -999,14 +1278,17 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
     // ---- 1. row m from the saved {H, E} ----
     const int32_t hextm = hfree ? 0 : ge;
     const uint32_t limit = m + n;
+    // row m as the score pass stored it: {H, E} int32 per column, or one {H, E - (go+ge)} int16 pair (the 16-bit query-profile sweep)
+    const bool lr16 = MODE == MODE_QP && a.ckpt_narrow != 0;
+    const int32_t goe_b = go + ge;
     while (col > 0 && k <= limit) {
       if (state == 0) {
-        if (lr[2 * col] == lr[2 * col + 1]) state = 1;  // bit3: H == E (gotoh.h:135)
+        if (lastrow_h(lr, col, lr16) == lastrow_e(lr, col, lr16, goe_b)) state = 1;  // bit3: H == E (gotoh.h:135)
         else break;
       }
       const bool valid = L < col;
       const uint32_t cl = col - (valid ? L : 0);
-      const bool bit1 = valid && (cl == 1 ? true : (lr[2 * cl + 1] != lr[2 * (cl - 1) + 1] + hextm));  // gotoh.h:137
+      const bool bit1 = valid && (cl == 1 ? true : (lastrow_e(lr, cl, lr16, goe_b) != lastrow_e(lr, cl - 1, lr16, goe_b) + hextm));  // gotoh.h:137
       const uint32_t first_hit = first_set(w.ballot(bit1));
       const uint32_t first_out = first_set(w.ballot(!valid));
       const bool found = first_hit < first_out;
@@ -1023,6 +1305,7 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
       const uint32_t t0 = j * B;
       TraceLane<K> ts;
       int32_t bot_h, bot_f, prev_up_h;
+      const int32_t hbias = (MODE == MODE_QP) ? 0 : go + ge, ebias = (MODE == MODE_QP) ? go + ge : 0;
 #pragma unroll
       for (int i = 0; i < K; ++i) {
         const uint32_t r = L * K + i + 1 - pad;
@@ -1034,9 +1317,10 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
           ts.Hc[i] = padding ? 0 : (int32_t)((uint32_t)edge_value(vfree, go, ge, (int32_t)r) << SH);
           ts.Ec[i] = padding ? 0 : neg;
         } else {
+          // frontier fields of the 16-bit sweeps: string kernel H + goe, E (gotoh_body); query-profile kernel H, E - goe
           const int32_t hv = ck[ckpt_index(j, (uint32_t)i, L, K)], ev = ck[ckpt_index(j, (uint32_t)(K + i), L, K)];
-          ts.Hc[i] = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(hv - (go + ge)) : hv) << SH);
-          ts.Ec[i] = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(ev) : ev) << SH);
+          ts.Hc[i] = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(hv - hbias) : hv) << SH);
+          ts.Ec[i] = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(ev) + ebias : ev) << SH);
         }
       }
       if (j == 0) {
@@ -1046,9 +1330,9 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
       } else {
         const int32_t bh = ck[ckpt_index(j, 2u * K, L, K)], bf = ck[ckpt_index(j, 2u * K + 1, L, K)];
         const int32_t pu = ck[ckpt_index(j, 2u * K + 2, L, K)];
-        bot_h = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(bh - (go + ge)) : bh) << SH);
-        bot_f = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(bf) : bf) << SH);
-        prev_up_h = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(pu - (go + ge)) : pu) << SH);
+        bot_h = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(bh - hbias) : bh) << SH);
+        bot_f = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(bf) + ebias : bf) << SH);
+        prev_up_h = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(pu - hbias) : pu) << SH);
       }
       auto band_step = [&](uint32_t t, const auto& sub) {
         const int32_t c = (int32_t)t - (int32_t)L;

@@ -322,6 +322,81 @@ TR_HD void cell_down16(int32_t& hl, int32_t el, int32_t up_hg, int32_t& up_f, in
 #endif
 }
 
+// ---- whole strips in a few asm statements (the 16-bit query-profile sweep, dp_kernels.h gotoh_narrow_qp_body) ----------------
+// The compiler cannot see what an asm statement writes and puts an s_nop between dependent statements; with one statement
+// per cell that is ~16 wasted issue cycles per step.  These helpers run N cells per statement (operand limit: 30).
+// Semantics per cell are those of cell_left16 / cell_down16 above.
+//   strip_left16<N, LAST>:  bottom-up over slots N-1 .. 0:  E <- max(H, E + hext);  H <- H(slot above, previous column) + sub.
+//     dg_in = that H for slot 0 of the chunk.  LAST: slot N-1 is the strip's last slot -- it uses its own extension cost
+//     hext_last and first adds delta_last to H (row m: free horizontal gaps, dp_kernels.h).
+//   strip_down16<N>:  top-down:  f <- max(up, f + vext);  H <- max(max(H, E), f) + goe;  up <- H.
+template <int N, bool LAST>
+TR_HD void strip_left16(int32_t* hl, int32_t* el, const int32_t* sub, int32_t dg_in, int32_t hext, int32_t hext_last, int32_t delta_last) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TR_LCELL(i, dg) "v_add_u16 %[e" #i "], %[e" #i "], %[hx]\n\tv_max_i16 %[e" #i "], %[h" #i "], %[e" #i "]\n\tv_add_u16 %[h" #i "], %[" dg "], %[s" #i "]\n\t"
+#define TR_LCELL_LAST(i, dg) "v_add_u16 %[h" #i "], %[h" #i "], %[dl]\n\tv_add_u16 %[e" #i "], %[e" #i "], %[hl]\n\tv_max_i16 %[e" #i "], %[h" #i "], %[e" #i "]\n\tv_add_u16 %[h" #i "], %[" dg "], %[s" #i "]\n\t"
+#define TR_LOPS8 [h0] "+v"(hl[0]), [h1] "+v"(hl[1]), [h2] "+v"(hl[2]), [h3] "+v"(hl[3]), [h4] "+v"(hl[4]), [h5] "+v"(hl[5]), [h6] "+v"(hl[6]), [h7] "+v"(hl[7]), \
+                 [e0] "+v"(el[0]), [e1] "+v"(el[1]), [e2] "+v"(el[2]), [e3] "+v"(el[3]), [e4] "+v"(el[4]), [e5] "+v"(el[5]), [e6] "+v"(el[6]), [e7] "+v"(el[7])
+#define TR_LOPS7 [h0] "+v"(hl[0]), [h1] "+v"(hl[1]), [h2] "+v"(hl[2]), [h3] "+v"(hl[3]), [h4] "+v"(hl[4]), [h5] "+v"(hl[5]), [h6] "+v"(hl[6]), \
+                 [e0] "+v"(el[0]), [e1] "+v"(el[1]), [e2] "+v"(el[2]), [e3] "+v"(el[3]), [e4] "+v"(el[4]), [e5] "+v"(el[5]), [e6] "+v"(el[6])
+#define TR_LIN8 [s0] "v"(sub[0]), [s1] "v"(sub[1]), [s2] "v"(sub[2]), [s3] "v"(sub[3]), [s4] "v"(sub[4]), [s5] "v"(sub[5]), [s6] "v"(sub[6]), [s7] "v"(sub[7]), \
+                [dg] "v"(dg_in), [hx] "v"(hext)
+#define TR_LIN7 [s0] "v"(sub[0]), [s1] "v"(sub[1]), [s2] "v"(sub[2]), [s3] "v"(sub[3]), [s4] "v"(sub[4]), [s5] "v"(sub[5]), [s6] "v"(sub[6]), \
+                [dg] "v"(dg_in), [hx] "v"(hext)
+  static_assert(N == 7 || N == 8, "chunks of 7 or 8 cells");
+  if constexpr (N == 8 && !LAST) {
+    asm(TR_LCELL(7, "h6") TR_LCELL(6, "h5") TR_LCELL(5, "h4") TR_LCELL(4, "h3") TR_LCELL(3, "h2") TR_LCELL(2, "h1") TR_LCELL(1, "h0") TR_LCELL(0, "dg")
+        : TR_LOPS8 : TR_LIN8);
+  } else if constexpr (N == 8 && LAST) {
+    asm(TR_LCELL_LAST(7, "h6") TR_LCELL(6, "h5") TR_LCELL(5, "h4") TR_LCELL(4, "h3") TR_LCELL(3, "h2") TR_LCELL(2, "h1") TR_LCELL(1, "h0") TR_LCELL(0, "dg")
+        : TR_LOPS8 : TR_LIN8, [hl] "v"(hext_last), [dl] "v"(delta_last));
+  } else if constexpr (N == 7 && !LAST) {
+    asm(TR_LCELL(6, "h5") TR_LCELL(5, "h4") TR_LCELL(4, "h3") TR_LCELL(3, "h2") TR_LCELL(2, "h1") TR_LCELL(1, "h0") TR_LCELL(0, "dg")
+        : TR_LOPS7 : TR_LIN7);
+  } else {
+    asm(TR_LCELL_LAST(6, "h5") TR_LCELL(5, "h4") TR_LCELL(4, "h3") TR_LCELL(3, "h2") TR_LCELL(2, "h1") TR_LCELL(1, "h0") TR_LCELL(0, "dg")
+        : TR_LOPS7 : TR_LIN7, [hl] "v"(hext_last), [dl] "v"(delta_last));
+  }
+#undef TR_LCELL
+#undef TR_LCELL_LAST
+#undef TR_LOPS8
+#undef TR_LOPS7
+#undef TR_LIN8
+#undef TR_LIN7
+#else
+  for (int i = N - 1; i >= 0; --i) {
+    const int32_t dg = i == 0 ? dg_in : hl[i - 1];
+    if (LAST && i == N - 1) cell_left16_last(hl[i], el[i], hext_last, dg, sub[i], delta_last);
+    else cell_left16(hl[i], el[i], hext, dg, sub[i]);
+  }
+#endif
+}
+
+template <int N>
+TR_HD void strip_down16(int32_t* hl, const int32_t* el, int32_t up_in, int32_t& f, int32_t vext, int32_t goe) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TR_DCELL(i, up) "v_max_i16 %[h" #i "], %[h" #i "], %[e" #i "]\n\tv_add_u16 %[f], %[f], %[vx]\n\tv_max_i16 %[f], %[" up "], %[f]\n\tv_max_i16 %[h" #i "], %[h" #i "], %[f]\n\tv_add_u16 %[h" #i "], %[h" #i "], %[go]\n\t"
+  static_assert(N == 7 || N == 8, "chunks of 7 or 8 cells");
+  if constexpr (N == 8) {
+    asm(TR_DCELL(0, "up") TR_DCELL(1, "h0") TR_DCELL(2, "h1") TR_DCELL(3, "h2") TR_DCELL(4, "h3") TR_DCELL(5, "h4") TR_DCELL(6, "h5") TR_DCELL(7, "h6")
+        : [h0] "+v"(hl[0]), [h1] "+v"(hl[1]), [h2] "+v"(hl[2]), [h3] "+v"(hl[3]), [h4] "+v"(hl[4]), [h5] "+v"(hl[5]), [h6] "+v"(hl[6]), [h7] "+v"(hl[7]), [f] "+v"(f)
+        : [e0] "v"(el[0]), [e1] "v"(el[1]), [e2] "v"(el[2]), [e3] "v"(el[3]), [e4] "v"(el[4]), [e5] "v"(el[5]), [e6] "v"(el[6]), [e7] "v"(el[7]),
+          [up] "v"(up_in), [vx] "v"(vext), [go] "v"(goe));
+  } else {
+    asm(TR_DCELL(0, "up") TR_DCELL(1, "h0") TR_DCELL(2, "h1") TR_DCELL(3, "h2") TR_DCELL(4, "h3") TR_DCELL(5, "h4") TR_DCELL(6, "h5")
+        : [h0] "+v"(hl[0]), [h1] "+v"(hl[1]), [h2] "+v"(hl[2]), [h3] "+v"(hl[3]), [h4] "+v"(hl[4]), [h5] "+v"(hl[5]), [h6] "+v"(hl[6]), [f] "+v"(f)
+        : [e0] "v"(el[0]), [e1] "v"(el[1]), [e2] "v"(el[2]), [e3] "v"(el[3]), [e4] "v"(el[4]), [e5] "v"(el[5]), [e6] "v"(el[6]),
+          [up] "v"(up_in), [vx] "v"(vext), [go] "v"(goe));
+  }
+#undef TR_DCELL
+#else
+  for (int i = 0; i < N; ++i) {
+    cell_down16(hl[i], el[i], up_in, f, vext, goe);
+    up_in = hl[i];
+  }
+#endif
+}
+
 template <int K, class Sub>
 TR_HD void score_step16g(ScoreLane<K>& s, int32_t up_hg, int32_t up_f, int32_t diag_hg, int32_t vext, int32_t goe,
                          int32_t delta_last, const Sub& subg, int32_t& bot_hg, int32_t& bot_f) {
@@ -410,6 +485,8 @@ TR_HD uint32_t base_code(uint8_t c) {
     default: return 6;
   }
 }
+// what the DP kernels read as a reference column: '-' and every other letter score 0 against all rows, one code for both
+TR_HD uint32_t dp_code(uint8_t c) { const uint32_t k = base_code(c); return k > 5u ? 5u : k; }
 // reverseComplementProfile (profile.h:74-90) seen on codes: rows 0<->3, 1<->2; 4, 5 and "other" stay
 TR_HD uint32_t complement_code(uint32_t code) { return code < 4 ? 3u - code : code; }
 

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) void rowmax_rest_kernel(const RowMaxDesc* desc,
 
 __global__ void encode_codes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (uint8_t)base_code(in[i]);
+  if (i < n) out[i] = (uint8_t)dp_code(in[i]);
 }
 
 template <class T>

@@ -103,6 +103,16 @@ __global__ void encode_kernel(const uint8_t* __restrict__ in, uint8_t* __restric
   if (i < n) out[i] = (uint8_t)dp_code(in[i]);
 }
 
+// profile x profile: is row 4 ('N') zero over a whole profile?  (NaN counts as non-zero.)  One wave per sequence.
+struct Row4Desc { uint64_t off; uint32_t len, pad; };
+__global__ __launch_bounds__(64) void row4_zero_kernel(const Row4Desc* __restrict__ d, const float* __restrict__ data, uint8_t* __restrict__ out) {
+  const Row4Desc s = d[blockIdx.x];
+  bool nz = false;
+  for (uint32_t j = threadIdx.x; j < s.len; j += 64) nz |= !(data[s.off + 4ull * s.len + j] == 0.0f);
+  const unsigned long long any = __ballot(nz);
+  if (threadIdx.x == 0) out[blockIdx.x] = any ? 0 : 1;
+}
+
 #define HIP_TRY(expr)                                                                               \
   do {                                                                                              \
     hipError_t _e = (expr);                                                                         \
@@ -298,6 +308,8 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   for (uint32_t i = 0; i < np; ++i) order[i] = i;
   auto before = [&](uint32_t x, uint32_t y) {
     if (pb.k[x] != pb.k[y]) return pb.k[x] > pb.k[y];
+    const uint32_t fx = pb.desc[x].flags & PAIR_ROW4_ZERO, fy = pb.desc[y].flags & PAIR_ROW4_ZERO;
+    if (fx != fy) return fx > fy;  // profile x profile: 16-term pairs and 25-term pairs go to different launches
     return (uint64_t)pb.desc[x].m * pb.desc[x].n > (uint64_t)pb.desc[y].m * pb.desc[y].n;
   };
   if (!std::is_sorted(order.begin(), order.end(), before)) std::stable_sort(order.begin(), order.end(), before);
@@ -374,10 +386,11 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
 
   for (const Chunk& c : chunks) {
     uint32_t j = c.lo;
-    while (j < c.hi) {  // one launch per run of equal K
+    while (j < c.hi) {  // one launch per run of equal K (and, profile x profile, equal term count)
       uint32_t e = j;
       const int K = pb.k[order[j]];
-      while (e < c.hi && pb.k[order[e]] == K) ++e;
+      const uint32_t row4 = hd[j].flags & PAIR_ROW4_ZERO;
+      while (e < c.hi && pb.k[order[e]] == K && (hd[e].flags & PAIR_ROW4_ZERO) == row4) ++e;
       a.pairs = dd + j;
       int trc;
       if (ctx->timing) {
@@ -416,7 +429,9 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
         WalkArgs wa{};
         wa.pairs = dd + j; wa.ops = d_ops; wa.ops_off = d_ops_off; wa.ops_len = d_ops_len; wa.err = a.err; wa.npairs = e - j; wa.K = K;
         HIP_TRY(launch_band_trace(pb.mode, K, a, wa, e - j, st));
-      } else
+      } else if (!needle && pb.mode == MODE_PROF)
+        HIP_TRY(launch_gotoh_prof(K, trace, row4 != 0, a, e - j, st));
+      else
         HIP_TRY(needle ? launch_needle(pb.mode, K, trace, a, e - j, st) : launch_gotoh(pb.mode, K, trace, narrow, a, e - j, st));
       if ((trc = timing_end(ctx))) return trc;
       if (trace && stage == DP_PLAIN) {
@@ -479,6 +494,27 @@ int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool 
     HIP_TRY(hipGetLastError());
     pb.d_a2 = ctx->codes();
   }
+  // profile x profile (Gotoh): classify the sequences once, so that pairs whose two profiles have an all-zero row 4 -- trace
+  // profiles always do, profile.h:37-38 -- run the 16-term kernel and the others the 25-term one
+  std::vector<uint8_t> z1, z2;
+  if (pb.mode == MODE_PROF && !needle && pairs->npairs) {
+    const uint32_t n1 = s1.count, n2 = s2.count;
+    std::vector<Row4Desc> hd(n1 + n2);
+    for (uint32_t i = 0; i < n1; ++i) hd[i] = Row4Desc{s1.offset[i], s1.length[i], 0};
+    for (uint32_t i = 0; i < n2; ++i) hd[n1 + i] = Row4Desc{s2.offset[i], s2.length[i], 0};
+    HIP_TRY(ctx->d_tmp[0].ensure(sizeof(Row4Desc) * hd.size() + hd.size()));
+    Row4Desc* dd = static_cast<Row4Desc*>(ctx->d_tmp[0].p);
+    uint8_t* dz = reinterpret_cast<uint8_t*>(dd + hd.size());
+    HIP_TRY(hipMemcpyAsync(dd, hd.data(), sizeof(Row4Desc) * hd.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (n1) hipLaunchKernelGGL(row4_zero_kernel, dim3(n1), dim3(64), 0, ctx->stream, dd, static_cast<const float*>(pb.d_a1), dz);
+    if (n2) hipLaunchKernelGGL(row4_zero_kernel, dim3(n2), dim3(64), 0, ctx->stream, dd + n1, static_cast<const float*>(pb.d_a2), dz + n1);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint8_t> hz(n1 + n2);
+    HIP_TRY(hipMemcpyAsync(hz.data(), dz, hz.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    z1.assign(hz.begin(), hz.begin() + n1);
+    z2.assign(hz.begin() + n1, hz.end());
+  }
   pb.desc.resize(pairs->npairs);
   pb.k.resize(pairs->npairs);
   *max_mn = 0;
@@ -494,6 +530,7 @@ int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool 
     d.a1_stride = d.m;
     d.a2_stride = d.n;
     d.out = i;
+    if (!z1.empty() && z1[i1] && z2[i2]) d.flags |= PAIR_ROW4_ZERO;
     pb.desc[i] = d;
     pb.k[i] = choose_k(d.m, pb.mode, needle);
     *max_mn = std::max<uint64_t>(*max_mn, (uint64_t)d.m + d.n);

@@ -26,7 +26,11 @@
 namespace tracyhip {
 
 enum : int { MODE_CHAR = 0, MODE_QP = 1, MODE_PROF = 2 };
-enum : uint32_t { PAIR_A2_REVCOMP = 1u };  // read a2 reversed and complemented (profile.h:74-90)
+enum : uint32_t {
+  PAIR_A2_REVCOMP = 1u,  // read a2 reversed and complemented (profile.h:74-90)
+  PAIR_ROW4_ZERO = 2u,   // profile x profile: row 4 ('N') is zero in BOTH profiles (the host classified the sequences): launches of
+                         // such pairs run the 16-term body
+};
 
 // one DP problem; lives in device memory, built on the host
 struct PairDesc {
@@ -247,7 +251,9 @@ TR_HD uint64_t ckpt_index(uint32_t j /*1-based*/, uint32_t field, uint32_t lane,
 template <class W, int K, bool CKPT>
 TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx);  // the 16-bit query-profile sweep, below
 
-template <class W, int K, int MODE, bool TRACE, bool NARROW = false, bool CKPT = false>
+// NT (profile x profile only): 5 = the 25-term substitution score, 4 = the 16-term one (row 4 zero in both profiles of every
+// pair of the launch: PAIR_ROW4_ZERO), 0 = decide per pair inside the kernel (both bodies in one kernel: more registers)
+template <class W, int K, int MODE, bool TRACE, bool NARROW = false, bool CKPT = false, int NT = 0>
 TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   static_assert(!(NARROW && TRACE), "the 16-bit formulation exists for the score-only kernel");
   static_assert(!(CKPT && TRACE), "checkpoints are written by the score-only kernel");
@@ -283,7 +289,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     float ma = 0.0f, mb = 0.0f;
     for (uint32_t r = L; r < m; r += 64) { nz |= !(a1p[4ull * d.a1_stride + r] == 0.0f); const float s = column_mass(a1p, d.a1_stride, r); ma = mass_max(ma, s); }
     for (uint32_t c = L; c < n; c += 64) { nz |= !(a2p[4ull * d.a2_stride + c] == 0.0f); const float s = column_mass(a2p, d.a2_stride, c); mb = mass_max(mb, s); }
-    skip4 = w.ballot(nz) == 0;
+    skip4 = (NT == 4) || (NT == 0 && w.ballot(nz) == 0);
     report_mass(a.err, 2, ma);
     report_mass(a.err, 3, mb);
   }
@@ -514,7 +520,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
           do_step(t, sub);
         }
       };
-      if (skip4) {
+      auto sweep4 = [&]() {
         SubProf<K, 4> s4;
 #pragma unroll
         for (int i = 0; i < K; ++i)
@@ -522,9 +528,10 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
           for (int k = 0; k < 5; ++k) s4.a[i][k] = sub_p.a[i][k];
         s4.fmatch = fmatch; s4.fmis = fmis; s4.shift = SH;
         sweep(s4);
-      } else {
-        sweep(sub_p);
-      }
+      };
+      if constexpr (NT == 4) sweep4();
+      else if constexpr (NT == 5) sweep(sub_p);
+      else { if (skip4) sweep4(); else sweep(sub_p); }
     }
     (void)T;
 
@@ -760,14 +767,16 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     return v;
   };
   // The in-flight request is issued and waited for by hand.  gfx950 counts loads and stores in ONE in-order counter; the
-  // compiler's wait for this load, placed where the loop carries it round, would be vmcnt(0) and sit behind the
-  // acknowledgement of the row-m store issued a moment earlier.  "At most one younger operation outstanding" is all
-  // the load needs (checkpoint rounds, one in 64, wait a little longer).
+  // compiler's wait for this load, placed where the loop carries it round, would sit behind the acknowledgement of the
+  // row-m store issued a moment earlier.  Here the wait comes BEFORE that store: whatever is older than the load (the stores
+  // of the previous round) was issued four steps ago and is long acknowledged, so vmcnt(0) costs nothing.
 #if defined(__HIP_DEVICE_COMPILE__)
   // the base address is the same for the whole wave; say so, for the scalar-base form of the load
   const uint64_t a2v_bits = reinterpret_cast<uint64_t>(a2v);
-  const uint8_t* a2v_s = reinterpret_cast<const uint8_t*>(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(a2v_bits >> 32)) << 32) |
-                                                          (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)a2v_bits));
+  // (the builtin returns a signed int: through uint32_t, or the low half sign-extends into the high one)
+  const uint32_t a2v_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a2v_bits >> 32));
+  const uint32_t a2v_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a2v_bits);
+  const uint8_t* a2v_s = reinterpret_cast<const uint8_t*>(((uint64_t)a2v_hi << 32) | (uint64_t)a2v_lo);
 #endif
   auto codes_request = [&](uint32_t tt, uint32_t& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -779,7 +788,7 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   };
   auto codes_arrived = [&](uint32_t& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(1)" : "+v"(v));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory");  // "memory": the stores below stay below
 #endif
   };
   const uint32_t sh0 = rcflag ? 24u : 0u, sh1 = rcflag ? 16u : 8u, sh2 = rcflag ? 8u : 16u, sh3 = rcflag ? 0u : 24u;
@@ -799,11 +808,11 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     step(guard, t + 2, qa, upA, upB, r2);
     qp_fetch6<K>(strip, (cw_next >> sh0) & 0xffu, qa);
     step(guard, t + 3, qb, upB, upA, r3);
+    codes_arrived(cw_pend);
     if (CKPT && !GUARD && lastlane) {  // {H, E'} of row m for the band traceback: one int16 pair per column, four columns per store
       const uint32_t v[4] = {r0, r1, r2, r3};
       __builtin_memcpy(lrb + (uint32_t)(4 * (int32_t)t + lr_lane), v, 16);
     }
-    codes_arrived(cw_pend);
     cw_cur = cw_next;
     cw_next = cw_pend;
     t += 4;

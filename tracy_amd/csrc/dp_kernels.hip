@@ -50,6 +50,13 @@ __global__ __launch_bounds__(64) void gotoh_kernel(DpArgs a) {
   DeviceWave w;
   gotoh_body<DeviceWave, K, MODE, TRACE, NARROW>(w, a, blockIdx.x);
 }
+// profile x profile with the number of substitution terms fixed per launch (NT = 4: PAIR_ROW4_ZERO pairs, 5: the rest): one
+// body per kernel keeps the register count where four waves per SIMD fit
+template <int K, bool TRACE, int NT>
+__global__ __launch_bounds__(64) void gotoh_prof_kernel(DpArgs a) {
+  DeviceWave w;
+  gotoh_body<DeviceWave, K, MODE_PROF, TRACE, false, false, NT>(w, a, blockIdx.x);
+}
 
 // checkpointed score pass (wavefront checkpoints + last row) and the band traceback that consumes them
 template <int K, int MODE, bool NARROW>
@@ -195,6 +202,21 @@ static hipError_t launch_gotoh_narrow(int K, const DpArgs& a, uint32_t npairs, h
     case 16: return launch_gotoh_t<16, MODE, false, true>(a, npairs, s);
     default: return hipErrorInvalidValue;
   }
+}
+
+template <bool TRACE, int NT>
+static hipError_t launch_prof_k(int K, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  switch (K) {
+    case 4: hipLaunchKernelGGL((gotoh_prof_kernel<4, TRACE, NT>), dim3(npairs), dim3(64), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((gotoh_prof_kernel<8, TRACE, NT>), dim3(npairs), dim3(64), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_gotoh_prof(int K, bool trace, bool row4_zero, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  if (npairs == 0) return hipSuccess;
+  if (trace) return row4_zero ? launch_prof_k<true, 4>(K, a, npairs, s) : launch_prof_k<true, 5>(K, a, npairs, s);
+  return row4_zero ? launch_prof_k<false, 4>(K, a, npairs, s) : launch_prof_k<false, 5>(K, a, npairs, s);
 }
 
 hipError_t launch_gotoh(int mode, int K, bool trace, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s) {

@@ -181,10 +181,10 @@ def main():
         try:
             if which == "decompose":
                 leg = DecomposeLeg(args.decompose_traces, 3000, 1000, rank, world, dev)
-                res = leg.run(dist, args.decompose_steps, 1, extra_legs=bool(args.extra_legs), cpu_sample=64 if args.cpu_sample != 0 else 0)
+                res = leg.run(dist, args.decompose_steps, 1, extra_legs=bool(args.extra_legs), cpu_sample=128 if args.cpu_sample != 0 else 0)
             else:
                 leg = AllPairsLeg(args.allpairs_traces, 900, rank, world, dev)
-                res = leg.run(dist, args.allpairs_steps, 1, cpu_sample=192 if args.cpu_sample != 0 else 0)
+                res = leg.run(dist, args.allpairs_steps, 1, cpu_sample=4096 if args.cpu_sample != 0 else 0)
             leg.ctx.close()
             del leg
             torch.cuda.empty_cache()

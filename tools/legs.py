@@ -341,7 +341,7 @@ class AllPairsLeg:
         else:
             self.matrix = self.scores[:len(self.i1)]
 
-    def run(self, dist, steps, warmup, cpu_sample=192):
+    def run(self, dist, steps, warmup, cpu_sample=4096):
         dev = self.dev
         dt, timers = timed(lambda: self.step(dist), steps, warmup, dist, self.lib, self.ctx)
         (dt,) = max_over_ranks(dist, dev, [dt])
@@ -350,8 +350,8 @@ class AllPairsLeg:
         mf = self.mf
         cells = float(self.npairs) * mf * mf
         # 16-term body (row N zero in both profiles): per cell 16 x (mul, mul, add) fp32 + the Gotoh cell
-        roof = kernel_block("score", "gotoh_kernel<8,PROF,score> (25- / 16-term fp32 substitution score + Gotoh cell, profile x profile)", timers["score"], steps,
-                            flops_per_cell=48.0, traffic_key="gotoh_kernel<8, 2")
+        roof = kernel_block("score", "gotoh_prof_kernel<8,score,NT=4> (16-term fp32 substitution score + Gotoh cell, profile x profile; 25-term twin for "
+                            "profiles with N / gap weight)", timers["score"], steps, flops_per_cell=48.0, traffic_key="gotoh_prof_kernel")
         line = {"metric": "GCUPS (all-pairs profile x profile gotohScore<true,true>, msa.h:33-42)", "value": round(cells * steps / dt / 1e9, 1), "unit": "GCUPS",
                 "pairs": int(self.npairs), "pairs_per_s": round(self.npairs * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
                 "warmup": warmup, "n_gpus": self.world, "scaling": "strong", "dtype": "f32 (substitution scores, rounded as align.h:112-116) / int32 (DP)",

@@ -1,21 +1,30 @@
 #!/bin/bash
-# Round profiles (run on the GPU box through gpurun): rocprofv3 kernel stats of the contract benchmark and of the
-# decompose benchmark, and the HBM byte counters (separate --pmc passes, kernel trace only) of bench.py.
-# The rocprof passes run bench.py's headline leg only (--certificate-leg 0 --lanes-leg 0) so that per-kernel averages and counters are
-# not blended with the second leg's smaller launches of the same kernel; one more kernel-trace pass of the DEFAULT
-# command is kept too and summarised per (kernel, grid size).
+# Round profiles (run on the GPU box through gpurun): rocprofv3 kernel stats and PMC passes of bench.py's three workloads.
+#   align (configs[1], the headline): headline leg only (--certificate-leg 0 --lanes-leg 0) so that per-kernel averages and counters
+#     are not blended with the other legs' launches of the same kernels; one more kernel-trace pass of the DEFAULT align legs is kept
+#     and summarised per (kernel, grid size)
+#   decompose (configs[2], 100 000 traces) and all-pairs (configs[4], 1000 traces): kernel stats + the same counters
+# Counters: separate --pmc passes with --kernel-trace only (WRITE_SIZE, FETCH_SIZE; SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES).
 # Outputs under gpurun_out/prof_round/; tools/profile_summarise.py turns them into the files kept in profiles/.
 set -u
+TAG=${1:-r02}
 OUT=/root/repo/gpurun_out/prof_round
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python /root/repo/bench.py --steps 3 --warmup 1 --certificate-leg 0 --lanes-leg 0 > "$OUT/bench_line.json" 2> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/dec_stats" -- python /root/repo/tools/bench_decompose.py --steps 3 --warmup 1 --cpu-sample 32 --extra-legs 0 > "$OUT/dec_line.json" 2> "$OUT/dec.err"
-for c in WRITE_SIZE FETCH_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_$c" -- python /root/repo/bench.py --steps 2 --warmup 1 --certificate-leg 0 --lanes-leg 0 --cpu-sample 0 > /dev/null 2> "$OUT/pmc_$c.err"
+B=/root/repo/bench.py
+AL="--workload align --steps 3 --warmup 1 --certificate-leg 0 --lanes-leg 0"
+DE="--workload decompose --decompose-steps 2 --extra-legs 0"
+AP="--workload allpairs --allpairs-steps 2"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python $B $AL > "$OUT/bench_line.json" 2> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/dec_stats" -- python $B $DE > "$OUT/dec_line.json" 2> "$OUT/dec.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ap_stats" -- python $B $AP > "$OUT/ap_line.json" 2> "$OUT/ap.err"
+for w in bench dec ap; do
+  case $w in bench) ARGS="$AL --steps 2 --cpu-sample 0";; dec) ARGS="$DE --cpu-sample 0";; ap) ARGS="$AP --cpu-sample 0";; esac
+  for c in WRITE_SIZE FETCH_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/pmc_${w}_$c" -- python $B $ARGS > /dev/null 2> "$OUT/pmc_${w}_$c.err"
+  done
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_${w}_valu" -- python $B $ARGS > /dev/null 2> "$OUT/pmc_${w}_valu.err"
 done
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_valu" -- python /root/repo/bench.py --steps 2 --warmup 1 --certificate-leg 0 --lanes-leg 0 --cpu-sample 0 > /dev/null 2> "$OUT/pmc_valu.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_default_stats" -- python /root/repo/bench.py --steps 3 --warmup 1 > "$OUT/bench_default_line.json" 2> "$OUT/bench_default.err"
-python /root/repo/bench.py > "$OUT/bench_plain.json"
-python /root/repo/tools/bench_decompose.py --cpu-sample 32 > "$OUT/dec_plain.json" 2>/dev/null
-ls -R "$OUT" | head -40
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_default_stats" -- python $B --workload align --steps 3 --warmup 1 > "$OUT/bench_default_line.json" 2> "$OUT/bench_default.err"
+python $B > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
+ls "$OUT" | head -60

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Turn gpurun_out/prof_round (tools/profile_round.sh) into the summaries committed under profiles/:
-   rNN_bench_kernel_stats.csv, rNN_decompose_kernel_stats.csv  -- rocprofv3 --kernel-trace --stats
-   rNN_pmc_hbm.json   -- WRITE_SIZE / FETCH_SIZE per kernel, per launch (separate PMC passes; KB -> bytes)
-   rNN_pmc_valu.json  -- VALU instructions / busy cycles per kernel, per launch
-   rNN_bench_line_under_rocprof.json, rNN_bench_line.json, rNN_decompose_line.json"""
+   rNN_{bench,decompose,allpairs}_kernel_stats.csv  -- rocprofv3 --kernel-trace --stats of each workload
+   rNN_pmc_hbm[_decompose|_allpairs].json   -- WRITE_SIZE / FETCH_SIZE per kernel, per launch (separate PMC passes; KB -> bytes)
+   rNN_pmc_valu[_decompose|_allpairs].json  -- VALU instructions / busy cycles per kernel, per launch
+   rNN_*_line_under_rocprof.json (the JSON lines those runs printed), rNN_bench_line.json (the default command, no profiler)"""
 import collections
 import csv
 import glob
@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def one(pattern):
@@ -30,12 +30,12 @@ def last_json_line(path):
     return None
 
 
-for name, sub in (("bench", "bench_stats"), ("decompose", "dec_stats")):
+for name, sub in (("bench", "bench_stats"), ("decompose", "dec_stats"), ("allpairs", "ap_stats")):
     f = one(sub + "/*/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, name)))
 for src, dst in (("bench_line.json", "bench_line_under_rocprof"), ("bench_plain.json", "bench_line"), ("dec_line.json", "decompose_line_under_rocprof"),
-                 ("dec_plain.json", "decompose_line")):
+                 ("ap_line.json", "allpairs_line_under_rocprof")):
     p = os.path.join(SRC, src)
     if os.path.exists(p):
         d = last_json_line(p)
@@ -86,14 +86,15 @@ if f:
     if os.path.exists(p) and last_json_line(p):
         json.dump(last_json_line(p), open(os.path.join(DST, "%s_bench_default_line_under_rocprof.json" % tag), "w"), indent=1)
 
-hbm = []
-for c in ("WRITE_SIZE", "FETCH_SIZE"):
-    for r in per_kernel("pmc_" + c, 1024.0):  # the counters report KB
-        r["bytes"] = r.pop("per_launch")
-        hbm.append(r)
-if hbm:
-    json.dump(hbm, open(os.path.join(DST, "%s_pmc_hbm.json" % tag), "w"), indent=1)
-valu = per_kernel("pmc_valu", 1.0)
-if valu:
-    json.dump(valu, open(os.path.join(DST, "%s_pmc_valu.json" % tag), "w"), indent=1)
+for w, suffix in (("bench", ""), ("dec", "_decompose"), ("ap", "_allpairs")):
+    hbm = []
+    for c in ("WRITE_SIZE", "FETCH_SIZE"):
+        for r in per_kernel("pmc_%s_%s" % (w, c), 1024.0):  # the counters report KB
+            r["bytes"] = r.pop("per_launch")
+            hbm.append(r)
+    if hbm:
+        json.dump(hbm, open(os.path.join(DST, "%s_pmc_hbm%s.json" % (tag, suffix)), "w"), indent=1)
+    valu = per_kernel("pmc_%s_valu" % w, 1.0)
+    if valu:
+        json.dump(valu, open(os.path.join(DST, "%s_pmc_valu%s.json" % (tag, suffix)), "w"), indent=1)
 print("profiles written for", tag, ":", sorted(f for f in os.listdir(DST) if f.startswith(tag)))

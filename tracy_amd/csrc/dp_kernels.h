@@ -885,19 +885,23 @@ TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     const int32_t x = cc < 1 ? 1 : (cc > (int32_t)n ? (int32_t)n : cc);
     return a2_index(d, (uint32_t)x);
   };
+  // One step = one column of this lane's strip.  The strip above hands H of its last slot straight out of the state
+  // register; the value received one step earlier is this step's diagonal (two registers used alternately by the two halves
+  // of the unrolled loop: no copies).  Between ramp-up and ramp-down every used lane is on a real column: those steps run
+  // without an activity test, so nothing has to be merged back into fixed registers at a join.
   int32_t cc_next = (int32_t)a2c[col_at(1 - (int32_t)L)];
-  for (uint32_t t = 1; t <= t_end; ++t) {
+  int32_t f_x = 0;                 // F of the last slot, exchanged like H
+  int32_t upA = 0, upB = prev_up_h;
+  auto step = [&](auto guard, uint32_t t, int32_t& up_cur, const int32_t& diag) {
+    constexpr bool GUARD = decltype(guard)::value;
     sub_c.cc = rcflag ? (int32_t)complement_char((uint8_t)cc_next) : cc_next;
     cc_next = (int32_t)a2c[col_at((int32_t)t - (int32_t)L + 1)];
     // row 0 (free leading gaps: H(0, c) = 0, F = -inf) enters through the shift; its origin is its own column
-    const int32_t up_h = w.shift_up_or(bot_h, (int32_t)t);
-    const int32_t up_f = w.shift_up_or(bot_f, neg);
-    if ((uint32_t)(t - 1u - L) < n) {
-      int32_t nb_h, nb_f;
-      origin_step<K>(ts, up_h, up_f, prev_up_h, cy1, cy2, sub_c, nb_h, nb_f);
-      prev_up_h = up_h;
-      bot_h = nb_h;
-      bot_f = nb_f;
+    up_cur = w.shift_up_or(ts.Hc[K - 1], (int32_t)t);
+    const int32_t up_f = w.shift_up_or(f_x, neg);
+    if (!GUARD || (uint32_t)(t - 1u - L) < n) {
+      int32_t nb_h;
+      origin_step<K>(ts, up_cur, up_f, diag, cy1, cy2, sub_c, nb_h, f_x);
       // watch row m: slot_m is wave-uniform, the switch stays a scalar branch (no select chain over the strip)
       int32_t hv = 0, ev = 0;
       switch (slot_m) {
@@ -913,6 +917,15 @@ TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       }
       if (L == lane_m && (hv >> SH) > (ev >> SH)) c_end = t - L;  // bit3 clear at (m, c): the trailing run ends here
     }
+  };
+  {
+    using Guarded = SweepGuard<true>;
+    using Free = SweepGuard<false>;
+    uint32_t t = 1;
+    while (t < lanes_used && t + 1 <= t_end) { step(Guarded{}, t, upA, upB); step(Guarded{}, t + 1, upB, upA); t += 2; }  // ramp-up
+    while (t + 1 <= n) { step(Free{}, t, upA, upB); step(Free{}, t + 1, upB, upA); t += 2; }                              // steady state
+    while (t + 1 <= t_end) { step(Guarded{}, t, upA, upB); step(Guarded{}, t + 1, upB, upA); t += 2; }                    // ramp-down
+    if (t <= t_end) step(Guarded{}, t, upA, upB);
   }
   if (L == lane_m) {
     int32_t hv = 0;

@@ -19,8 +19,9 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(SRC, pattern))
-    return f[0] if f else None
+    """the NEWEST match: gpurun merges a run's files into gpurun_out/, where older rounds' files (other process ids) may still lie"""
+    f = sorted(glob.glob(os.path.join(SRC, pattern)), key=os.path.getmtime)
+    return f[-1] if f else None
 
 
 def last_json_line(path):

@@ -381,6 +381,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   a.hfree = prm->hfree; a.vfree = prm->vfree;
   a.qlimit = sub_limit(prm);
   if (ck) a.ends = ck->d_ends;
+  if (ck && stage == DP_CKPT) { a.votes = ck->d_votes; a.vote_nt = ck->vote_nt; }
   if (ck) { a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.band = static_cast<uint64_t*>(ctx->d_band.p); a.ckpt_narrow = ck->narrow ? 1 : 0; }
   const PairDesc* dd = static_cast<const PairDesc*>(ctx->d_desc.p);
 

@@ -131,6 +131,8 @@ struct DpCkpt {
   uint32_t B = 256;
   bool narrow = false;  // set by the DP_CKPT stage (16-bit kernel used), read by the DP_BAND stage
   uint32_t* d_ends = nullptr;  // DP_ORIGIN: two entries per pair, indexed by PairDesc::out
+  const uint32_t* d_votes = nullptr;  // DP_CKPT of both orientations: orientation votes (DpArgs::votes), or null
+  uint32_t vote_nt = 0;
 };
 // origin-tracking sweep: one pass of strip height K, columns and scores inside the packed fields (dp_lane.h origin_step)
 bool origin_ok(const tracyhip_params* prm, uint32_t maxm, uint32_t maxn, int K);

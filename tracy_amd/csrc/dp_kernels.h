@@ -69,6 +69,8 @@ struct DpArgs {
   uint32_t ckpt_B;      // steps between wavefront checkpoints
   int32_t ckpt_narrow;  // checkpoints hold raw registers of the 16-bit kernel (values in the low halves)
   uint32_t* ends;       // origin-tracking sweep: {leading 'h' columns, last column that is not a trailing 'h'} per pair
+  const uint32_t* votes;  // checkpointed 16-bit sweep of both orientations (PairDesc::out = orientation * vote_nt + trace): {vf, vr} per
+  uint32_t vote_nt;       // trace, or null.  Sweeps of the likely losing strand (vote_skips_checkpoints) write no checkpoints / row m
 };
 
 // device error flags are OR-ed (several kernels share the word)
@@ -244,6 +246,9 @@ TR_HD uint32_t a2_index(const PairDesc& d, uint32_t c /*1-based column*/) {
 // ------------------------------------------------------------------------------------------------
 // wavefront checkpoint record per lane: Hl[K], El[K], bot_h, bot_f, prev_up_h (plain int32 scores)
 TR_HD constexpr uint32_t ckpt_fields(int K) { return 2u * K + 3u; }
+// the 16-bit query-profile sweep packs its frontier: field i < K = {H (low half), E - goe (high half)} of slot i,
+// field K = {H received from the strip above, F - goe}: K + 1 dwords per lane instead of 2K + 3
+TR_HD constexpr uint32_t ckpt_fields_qp16(int K) { return (uint32_t)K + 1u; }
 TR_HD uint64_t ckpt_index(uint32_t j /*1-based*/, uint32_t field, uint32_t lane, int K) {
   return ((uint64_t)(j - 1) * ckpt_fields(K) + field) * 64u + lane;
 }
@@ -693,6 +698,11 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   char* lrb = CKPT ? reinterpret_cast<char*>(a.lastrow + d.lastrow_off) : nullptr;
   const int32_t lr_lane = -4 * (int32_t)L;  // byte offset of column c = t - L in the row-m array: 4 t + lr_lane
   const uint32_t B = CKPT ? a.ckpt_B : 1u;
+  bool keep = CKPT;  // does this sweep leave checkpoints and row m behind?  (wave-uniform)
+  if (CKPT && a.votes) {
+    const uint32_t tr = d.out % a.vote_nt;
+    keep = !vote_skips_checkpoints(a.votes[2 * tr], a.votes[2 * tr + 1], d.out / a.vote_nt);
+  }
   uint32_t ck_left = B;                                         // steps until the next wavefront checkpoint (wave-uniform)
   int32_t* ck_next = CKPT ? a.ckpt + d.ckpt_off + L : nullptr;   // its record
   int32_t f = 0;
@@ -733,21 +743,16 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         for (int i = 0; i < K; ++i) { cell_down16(Hl[i], El[i], uh, f, gev, goev); uh = Hl[i]; }
       }
       if (CKPT) row_m = ((uint32_t)El[K - 1] << 16) | ((uint32_t)Hl[K - 1] & 0xffffu);
-      if (CKPT && GUARD && lastlane)  // ramp phases: row m column by column (the steady state stores four columns at once)
+      if (CKPT && GUARD && lastlane && keep)  // ramp phases: row m column by column (the steady state stores four columns at once)
         *reinterpret_cast<uint32_t*>(lrb + (uint32_t)(4 * (int32_t)t + lr_lane)) = row_m;
     }
-    if (CKPT && t <= t_end && --ck_left == 0) {  // wavefront checkpoint every B steps: the whole frontier (raw registers), one coalesced store per field
+    if (CKPT && keep && t <= t_end && --ck_left == 0) {  // wavefront checkpoint every B steps: the whole frontier (raw registers), one coalesced store per field
       ck_left = B;
       int32_t* ck = ck_next;
-      ck_next += ckpt_fields(K) * 64u;
+      ck_next += ckpt_fields_qp16(K) * 64u;
 #pragma unroll
-      for (int i = 0; i < K; ++i) {
-        ck[(uint32_t)i * 64u] = Hl[i];
-        ck[(uint32_t)(K + i) * 64u] = El[i];
-      }
-      ck[(2u * K) * 64u] = Hl[K - 1];
-      ck[(2u * K + 1) * 64u] = f;
-      ck[(2u * K + 2) * 64u] = up_cur;
+      for (int i = 0; i < K; ++i) ck[(uint32_t)i * 64u] = (int32_t)(((uint32_t)El[i] << 16) | ((uint32_t)Hl[i] & 0xffffu));
+      ck[(uint32_t)K * 64u] = (int32_t)(((uint32_t)f << 16) | ((uint32_t)up_cur & 0xffffu));
     }
   };
   using Guarded = SweepGuard<true>;
@@ -809,7 +814,7 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     qp_fetch6<K>(strip, (cw_next >> sh0) & 0xffu, qa);
     step(guard, t + 3, qb, upB, upA, r3);
     codes_arrived(cw_pend);
-    if (CKPT && !GUARD && lastlane) {  // {H, E'} of row m for the band traceback: one int16 pair per column, four columns per store
+    if (CKPT && !GUARD && lastlane && keep) {  // {H, E'} of row m for the band traceback: one int16 pair per column, four columns per store
       const uint32_t v[4] = {r0, r1, r2, r3};
       __builtin_memcpy(lrb + (uint32_t)(4 * (int32_t)t + lr_lane), v, 16);
     }
@@ -1328,6 +1333,8 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
       TraceLane<K> ts;
       int32_t bot_h, bot_f, prev_up_h;
       const int32_t hbias = (MODE == MODE_QP) ? 0 : go + ge, ebias = (MODE == MODE_QP) ? go + ge : 0;
+      const bool qp16 = MODE == MODE_QP && a.ckpt_narrow != 0;
+      auto qp16_index = [&](uint32_t jj, uint32_t field) -> uint64_t { return ((uint64_t)(jj - 1) * ckpt_fields_qp16(K) + field) * 64u + L; };
 #pragma unroll
       for (int i = 0; i < K; ++i) {
         const uint32_t r = L * K + i + 1 - pad;
@@ -1339,8 +1346,11 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
           ts.Hc[i] = padding ? 0 : (int32_t)((uint32_t)edge_value(vfree, go, ge, (int32_t)r) << SH);
           ts.Ec[i] = padding ? 0 : neg;
         } else {
-          // frontier fields of the 16-bit sweeps: string kernel H + goe, E (gotoh_body); query-profile kernel H, E - goe
-          const int32_t hv = ck[ckpt_index(j, (uint32_t)i, L, K)], ev = ck[ckpt_index(j, (uint32_t)(K + i), L, K)];
+          // frontier fields of the 16-bit sweeps: string kernel {H + goe, E} as int32 fields (gotoh_body); query-profile kernel
+          // one packed {H, E - goe} dword per slot (gotoh_narrow_qp_body)
+          int32_t hv, ev;
+          if (qp16) { const int32_t pk = ck[qp16_index(j, (uint32_t)i)]; hv = pk; ev = pk >> 16; }
+          else { hv = ck[ckpt_index(j, (uint32_t)i, L, K)]; ev = ck[ckpt_index(j, (uint32_t)(K + i), L, K)]; }
           ts.Hc[i] = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(hv - hbias) : hv) << SH);
           ts.Ec[i] = (int32_t)((uint32_t)(a.ckpt_narrow ? sext16(ev) + ebias : ev) << SH);
         }
@@ -1349,6 +1359,11 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
         const uint32_t row_above = (L * K > pad) ? L * K - pad : 0u;
         prev_up_h = (row_above == 0) ? 0 : (int32_t)((uint32_t)edge_value(vfree, go, ge, (int32_t)row_above) << SH);
         bot_h = 0; bot_f = 0;
+      } else if (qp16) {
+        const int32_t pk = ck[qp16_index(j, (uint32_t)K)];
+        bot_h = ts.Hc[K - 1];  // the strip's last H is what it hands down
+        bot_f = (int32_t)((uint32_t)((pk >> 16) + ebias) << SH);
+        prev_up_h = (int32_t)((uint32_t)sext16(pk) << SH);
       } else {
         const int32_t bh = ck[ckpt_index(j, 2u * K, L, K)], bf = ck[ckpt_index(j, 2u * K + 1, L, K)];
         const int32_t pu = ck[ckpt_index(j, 2u * K + 2, L, K)];

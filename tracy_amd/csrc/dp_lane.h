@@ -447,6 +447,17 @@ TR_HD void needle_step(NeedleLane<K>& s, int32_t up_s, int32_t diag, int32_t vy,
   bot_s = up_s;
 }
 
+// ---- orientation vote (pipeline.hip kmer_vote_kernel): shared 11-mers of a trace with its window read forward (vf) and as
+// the reverse complement (vr).  A clear majority marks the other strand as the likely loser: its sweep leaves no
+// checkpoints / row-m values behind (nobody will trace back from them).  Only a guess about which work is worth keeping:
+// when the likely loser wins after all, the pipeline sweeps it once more, with checkpoints.
+TR_HD bool vote_skips_checkpoints(uint32_t vf, uint32_t vr, uint32_t orient /*0 forward, 1 reverse*/) {
+  const uint32_t hi = vf >= vr ? vf : vr, lo = vf >= vr ? vr : vf;
+  const bool clear = hi >= 32u && hi >= 2u * lo;
+  const uint32_t likely = vf >= vr ? 0u : 1u;
+  return clear && orient != likely;
+}
+
 // ---- geometry shared by the DP kernels and the traceback walker ---------------------------------
 // A pass covers 64*K rows; pass p holds rows p*64K+1 .. (p+1)*64K.  Step t of a pass (1-based) puts
 // lane L on column t - L.  The traceback words of pair are laid out [pass][step][lane] (8 bytes per

@@ -324,7 +324,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       for (int o = 0; o < norient; ++o) {
         ck_off[(size_t)o * nt + t] = ck_tot;
         lr_off[(size_t)o * nt + t] = lr_tot;
-        ck_tot += J * ckpt_fields(K) * 64;
+        ck_tot += J * ckpt_fields(K) * 64;  // (the 16-bit query-profile sweep packs its records into K + 1 of these fields)
         lr_tot += 2ull * ((uint64_t)rn[t] + 1);
       }
     }
@@ -527,8 +527,38 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
     std::vector<std::pair<uint32_t, int>> all;
     for (int o = 0; o < norient; ++o)
       for (uint32_t t = 0; t < nt; ++t) all.emplace_back(t, o);
+    // Both orientations swept in full (exact gsFwd / gsRev).  Only the winner's checkpoints are ever read, so the sweeps
+    // of the strand an orientation vote marks as the likely loser write none (vote_skips_checkpoints: the kernel reads the
+    // votes itself, no host round trip); a likely loser that wins after all is swept once more, with checkpoints.
+    const bool vote_ckpt = !given && use_band && ck.narrow && getenv("TRACYHIP_NO_VOTE") == nullptr;
+    std::vector<uint32_t> h_votes;
+    if (vote_ckpt) {
+      std::vector<VoteDesc> hv(nt);
+      for (uint32_t t = 0; t < nt; ++t) hv[t] = VoteDesc{in.a1_off[t], in.a2_off[t], mf[t], mt[t], rn[t], 0u};
+      HIP_TRY(ctx->d_tmp[7].ensure((sizeof(VoteDesc) + 2 * sizeof(uint32_t)) * (size_t)nt));
+      VoteDesc* d_vd = static_cast<VoteDesc*>(ctx->d_tmp[7].p);
+      uint32_t* d_votes = reinterpret_cast<uint32_t*>(d_vd + nt);
+      HIP_TRY(ctx->h_res.ensure(sizeof(VoteDesc) * (size_t)nt));  // pinned staging (free until the results go out): no host wait
+      std::memcpy(ctx->h_res.p, hv.data(), sizeof(VoteDesc) * (size_t)nt);
+      HIP_TRY(hipMemcpyAsync(d_vd, ctx->h_res.p, sizeof(VoteDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(kmer_vote_kernel, dim3(nt), dim3(64), 0, st, d_vd, static_cast<const float*>(d_prof), ctx->codes(), d_votes);
+      HIP_TRY(hipGetLastError());
+      ck.d_votes = d_votes;
+      ck.vote_nt = nt;
+      h_votes.resize(2 * (size_t)nt);
+    }
     if ((rc = run_stage1(all, use_band ? DP_CKPT : DP_PLAIN))) return rc;
+    if (vote_ckpt) HIP_TRY(hipMemcpyAsync(h_votes.data(), ck.d_votes, sizeof(uint32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
+    ck.d_votes = nullptr;
     if ((rc = fetch_scores())) return rc;
+    if (vote_ckpt) {
+      std::vector<std::pair<uint32_t, int>> retry;
+      for (uint32_t t = 0; t < nt; ++t) {
+        const int w = h_sc2[t] > h_sc2[nt + t] ? 0 : 1;  // forward iff gsFwd > gsRev (sage.h:247)
+        if (vote_skips_checkpoints(h_votes[2 * t], h_votes[2 * t + 1], (uint32_t)w)) retry.emplace_back(t, w);
+      }
+      if (!retry.empty() && (rc = run_stage1(retry, DP_CKPT))) return rc;  // same scores, now with checkpoints
+    }
   }
   for (uint32_t t = 0; t < nt; ++t) {
     if (given) { h_fwd[t] = in.oriented[t] ? 1 : 0; h_rc[t] = 0; }

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _LIB = None
 
-MODE_CHAR, MODE_QP, MODE_PROF = 0, 1, 2
+MODE_CHAR, MODE_QP, MODE_PROF, MODE_CQ = 0, 1, 2, 3
 
 
 def lib():
@@ -115,7 +115,7 @@ def run_prefix(profiles, refs, score, K, revcomp=None):
     return out.tolist(), err.value
 
 
-def run_origin(a1, a2, score, K, revcomp=False):
+def run_origin(a1, a2, score, K, revcomp=False, table=False):
     """origin-tracking sweep body on one emulated wave (string x string, semiglobal): (score, leading 'h' columns,
     last column that is not a trailing 'h')"""
     m, n = len(a1), len(a2)
@@ -124,7 +124,7 @@ def run_origin(a1, a2, score, K, revcomp=False):
     sc = C.c_int32(0)
     ends = np.zeros(2, np.uint32)
     p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
-    rc = lib().emu_origin(K, p(b1, C.c_uint8), C.c_uint32(m), p(b2, C.c_uint8), C.c_uint32(n), C.c_uint32(1 if revcomp else 0),
+    rc = lib().emu_origin(K, p(b1, C.c_uint8), C.c_uint32(m), p(b2, C.c_uint8), C.c_uint32(n), C.c_uint32((1 if revcomp else 0) | (0x200 if table else 0)),
                           *[int(x) for x in score], C.byref(sc), p(ends, C.c_uint32))
     assert rc == 0
     return sc.value, int(ends[0]), int(ends[1])

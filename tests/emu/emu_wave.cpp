@@ -58,7 +58,7 @@ struct HostWave {
 template <int K, int MODE, bool TRACE, bool NEEDLE, bool NARROW = false>
 void run_wave(const DpArgs& a) {
   WaveShared sh;
-  sh.lds.assign((MODE == MODE_QP ? lds_bytes(MODE_QP, K) : needle_lds_bytes(MODE_PROF, K)) + 64, 0);
+  sh.lds.assign((qp_like(MODE) ? lds_bytes(MODE_QP, K) : needle_lds_bytes(MODE_PROF, K)) + 64, 0);
   std::vector<std::thread> th;
   for (uint32_t l = 0; l < 64; ++l) {
     th.emplace_back([&, l]() {
@@ -83,6 +83,7 @@ template <int K, bool NEEDLE>
 void dispatch(int mode, bool trace, const DpArgs& a) {
   if (mode == MODE_CHAR) trace ? run_wave<K, MODE_CHAR, true, NEEDLE>(a) : run_wave<K, MODE_CHAR, false, NEEDLE>(a);
   else if (mode == MODE_QP) trace ? run_wave<K, MODE_QP, true, NEEDLE>(a) : run_wave<K, MODE_QP, false, NEEDLE>(a);
+  else if (mode == MODE_CQ) { if constexpr (!NEEDLE) run_wave<K, MODE_CQ, true, false>(a); }  // tracebacks only
   else trace ? run_wave<K, MODE_PROF, true, NEEDLE>(a) : run_wave<K, MODE_PROF, false, NEEDLE>(a);
 }
 }  // namespace
@@ -107,14 +108,21 @@ void run_ckpt_pair(const DpArgs& a, const WalkArgs& wa) {
   }
 }
 
-template <int K>
+template <int K, bool TABLE = false>
 void run_origin_wave(const DpArgs& a) {
   WaveShared sh;
-  sh.lds.assign(64, 0);
+  sh.lds.assign(lds_bytes(MODE_CQ, K) + 64, 0);
   std::vector<std::thread> th;
   for (uint32_t l = 0; l < 64; ++l)
-    th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_origin_body<HostWave, K>(w, a, 0); });
+    th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_origin_body<HostWave, K, TABLE>(w, a, 0); });
   for (auto& t : th) t.join();
+}
+// MODE_CQ: case-sensitive codes of a string, padded like the library's code buffers
+static std::vector<uint8_t> cq_codes(const void* a2, size_t bytes) {
+  std::vector<uint8_t> v(bytes + 256, 5);
+  const uint8_t* p = static_cast<const uint8_t*>(a2);
+  for (size_t i = 0; i < bytes; ++i) v[128 + i] = (uint8_t)cq_code(p[i]);
+  return v;
 }
 
 template <int K>
@@ -175,6 +183,21 @@ int emu_origin(int K, const uint8_t* a1, uint32_t m, const uint8_t* a2, uint32_t
   DpArgs a{};
   a.pairs = &d; a.a1 = a1; a.a2 = a2; a.scores = score; a.err = &err; a.ends = ends;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = 1; a.vfree = 0;
+  std::vector<uint8_t> codes;
+  if (flags & 0x200u) {  // table form (MODE_CQ): a2 as case-sensitive codes
+    d.flags &= 0xffu;
+    codes = cq_codes(a2, n);
+    a.a2 = codes.data() + 128;
+    switch (K) {
+      case 4: run_origin_wave<4, true>(a); break;
+      case 8: run_origin_wave<8, true>(a); break;
+      case 12: run_origin_wave<12, true>(a); break;
+      case 15: run_origin_wave<15, true>(a); break;
+      case 16: run_origin_wave<16, true>(a); break;
+      default: return -1;
+    }
+    return 0;
+  }
   switch (K) {
     case 4: run_origin_wave<4>(a); break;
     case 8: run_origin_wave<8>(a); break;
@@ -238,6 +261,7 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
   a.pairs = &d; a.a1 = a1; a.a2 = a2;
   std::vector<uint8_t> codes;
   if (mode == MODE_QP && !needle) { codes = padded_codes(a2, n); a.a2 = codes.data() + 128; }
+  if (mode == MODE_CQ) { codes = cq_codes(a2, n); a.a2 = codes.data() + 128; }
   a.bits = bits.data(); a.bits32 = reinterpret_cast<uint32_t*>(bits.data());
   a.scratch = scratch.data(); a.scores = score; a.err = &err;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = hfree; a.vfree = vfree;

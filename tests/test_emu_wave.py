@@ -276,3 +276,35 @@ def test_origin_sweep_ends():
             want_score, want_btr = orc.gotoh_str(q, oriented, 1, 0, sc)
             got = emu.run_origin(q, ref, sc, K, revcomp=rc)
             assert got == (want_score,) + ends_of(want_btr, n), (m, n, K, rep, got, want_score, ends_of(want_btr, n))
+            # table form (MODE_CQ: rows over ACGTN, columns as case-sensitive codes); a column letter no row can hold mismatches
+            ref2 = ref if rep != 1 else (ref[:n // 3] + b"x" + ref[n // 3 + 1:n // 2] + b"a" + ref[n // 2 + 1:])[:n]
+            o2 = (revcomp(ref2) if rc else ref2) if rep != 1 else ref2
+            w2 = orc.gotoh_str(q, o2, 1, 0, sc)
+            got = emu.run_origin(q, ref2, sc, K, revcomp=rc, table=True)
+            assert got == (w2[0],) + ends_of(w2[1], n), (m, n, K, rep, "table")
+
+
+def test_string_traceback_through_the_table():
+    """MODE_CQ: gotoh(string, string) with the row chars in the query-profile table == the byte-compare kernel == the oracle,
+    all AlignConfigs, reverse-complement view, columns with letters outside ACGTN (lower case included: byte equality)"""
+    import emu
+    import pyoracle as orc
+    from sage_oracle import revcomp
+    rng = np.random.default_rng(5)
+    sc = (3, -5, -10, -4)
+    for (m, n, K) in [(1, 1, 4), (30, 50, 4), (200, 260, 4), (255, 200, 8), (300, 400, 8), (500, 380, 8)]:
+        ref = bytearray(rng.choice(list(b"ACGTN"), size=n).tolist())
+        q = bytearray((bytes(ref)[:m] + bytes(rng.choice(list(b"ACGT"), size=m).tolist()))[:m])
+        for j in range(0, m, 7):
+            q[j] = int(rng.choice(list(b"ACGTN")))
+        for j in range(3, n, 41):
+            ref[j] = int(rng.choice(list(b"acgtRY-x")))
+        q, ref = bytes(q), bytes(ref)
+        for cfg in [(1, 0), (0, 0), (1, 1), (0, 1)]:
+            want = orc.gotoh_str(q, ref, cfg[0], cfg[1], sc)
+            got = emu.run(q, ref, sc, cfg[0], cfg[1], emu.MODE_CQ, K)
+            assert (got[0], got[1]) == want and got[2] == 0, (m, n, K, cfg)
+        clean = bytes(c if c in b"ACGTN" else ord("N") for c in ref)  # the reverse complement is defined on ACGTN
+        want = orc.gotoh_str(q, revcomp(clean), 1, 0, sc)
+        got = emu.run(q, clean, sc, 1, 0, emu.MODE_CQ, K, revcomp=True)
+        assert (got[0], got[1]) == want

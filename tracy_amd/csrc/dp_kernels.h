@@ -25,7 +25,14 @@
 
 namespace tracyhip {
 
-enum : int { MODE_CHAR = 0, MODE_QP = 1, MODE_PROF = 2 };
+// MODE_CQ: string x string scored through the query-profile table (rows are chars, a2 = case-sensitive codes): for row strings
+// over {A,C,G,T,N} -- every basecall string -- "row char == column char ? match : mismatch" is a table look-up per step instead
+// of compare + select per cell.  Same kernels as MODE_QP otherwise.
+enum : int { MODE_CHAR = 0, MODE_QP = 1, MODE_PROF = 2, MODE_CQ = 3 };
+TR_HD constexpr bool qp_like(int mode) { return mode == MODE_QP || mode == MODE_CQ; }
+// case-SENSITIVE column code of MODE_CQ: only the five upper-case letters a row may hold match anything
+TR_HD uint32_t cq_code(uint8_t c) { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : c == 'N' ? 4u : 5u; }
+TR_HD bool cq_row_char(uint8_t c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N'; }
 enum : uint32_t {
   PAIR_A2_REVCOMP = 1u,  // read a2 reversed and complemented (profile.h:74-90)
   PAIR_ROW4_ZERO = 2u,   // profile x profile: row 4 ('N') is zero in BOTH profiles (the host classified the sequences): launches of
@@ -136,6 +143,11 @@ struct SubTable {
 // LDS query-profile table: int16 [6 codes][64*K rows] (codes 5 = '-' and 6 = other share the zero row)
 // table row stride per lane: K rounded up to an even count (int16 pairs), so odd strip heights work too
 TR_HD constexpr int qp_stride(int K) { return (K + 1) & ~1; }
+// query-profile table of the sweeps: int16 [6 codes][qp_stride(K) rows][64 lanes] -- a row's 64 lanes are contiguous, so the
+// per-row 16-bit reads of a wave are conflict-free (a per-lane strip layout costs an 8-way bank conflict on each of them).
+// Code 5 = '-' / any other letter.  (The prefix-bound kernel keeps per-lane strips + one shared zero strip: qp_lane / qp_fetch.)
+template <int K>
+TR_HD uint32_t qp6_index(uint32_t code, uint32_t row, uint32_t lane) { return (code * (uint32_t)qp_stride(K) + row) * 64u + lane; }
 
 template <int K, bool NARROW = false>
 TR_HD void qp_load(const int16_t* tab, uint32_t code, uint32_t lane, SubTable<K>& s) {
@@ -161,6 +173,21 @@ struct SubPacked {
   }
   TR_HD int32_t lo16(int i) const { return (i & 1) ? ((int32_t)pw[i / 2] >> 16) : (int32_t)pw[i / 2]; }
 };
+// A strip read row by row from the [code][row][lane] table (qp6_index): one sign-extending 16-bit LDS read per row gives an
+// operand that needs no unpacking.  SHIFT: applied when a value is used (the origin-tracking sweep keeps scores << 18).
+template <int K, int SHIFT = 0>
+struct SubRows {
+  int32_t sv[K];
+  TR_HD int32_t operator()(int i) const { return (int32_t)((uint32_t)sv[i] << SHIFT); }
+  TR_HD int32_t lo16(int i) const { return sv[i]; }
+};
+template <int K, int SHIFT>
+TR_HD void qp_fetch_rows(const int16_t* lane_col, uint32_t code, SubRows<K, SHIFT>& q) {
+  const int16_t* p = lane_col + code * ((uint32_t)((K + 1) & ~1) * 64u);
+#pragma unroll
+  for (int i = 0; i < K; ++i) q.sv[i] = p[i * 64];
+}
+
 // strip pointers of one lane into the query-profile table: row `code` of the lane's strip for codes < 5, the shared
 // all-zero-column strip for the rest (the LDS base address is folded into both, once per pass)
 struct QpLane {
@@ -231,7 +258,7 @@ TR_HD constexpr uint32_t needle_lds_bytes(int mode, int K) { return mode == MODE
 TR_HD constexpr uint32_t lds_bytes(int mode, int K) {
   // 6 code rows x 64 lanes x qp_stride(K) int16: what the 16-bit sweep (gotoh_narrow_qp_body) lays out; the other QP kernels use
   // five rows + one shared zero strip of it.  MODE_PROF keeps its rows in registers.
-  return mode == MODE_QP ? 6u * 64u * (uint32_t)qp_stride(K) * 2u : 0u;
+  return qp_like(mode) ? 6u * 64u * (uint32_t)qp_stride(K) * 2u : 0u;
 }
 
 // MODE_QP sweeps read the code buffer up to kCodeBias bytes before / behind a sequence (idle lanes, look-ahead)
@@ -281,8 +308,9 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     return;
   }
 
-  const uint8_t* a1c = static_cast<const uint8_t*>(a.a1) + (MODE == MODE_CHAR ? d.a1_off : 0);
-  const float* a1p = static_cast<const float*>(a.a1) + (MODE != MODE_CHAR ? d.a1_off : 0);
+  constexpr bool A1CHARS = MODE == MODE_CHAR || MODE == MODE_CQ;
+  const uint8_t* a1c = static_cast<const uint8_t*>(a.a1) + (A1CHARS ? d.a1_off : 0);
+  const float* a1p = static_cast<const float*>(a.a1) + (!A1CHARS ? d.a1_off : 0);
   const uint8_t* a2c = static_cast<const uint8_t*>(a.a2) + (MODE != MODE_PROF ? d.a2_off : 0);
   const float* a2p = static_cast<const float*>(a.a2) + (MODE == MODE_PROF ? d.a2_off : 0);
   int16_t* qp_tab = reinterpret_cast<int16_t*>(w.lds());
@@ -361,31 +389,42 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       sub_c.vmatch = (int32_t)((uint32_t)a.match << SH) - goe_n;
       sub_c.vmis = (int32_t)((uint32_t)a.mismatch << SH) - goe_n;
       sub_c.cc = 0;
-    } else if (MODE == MODE_QP) {
+    } else if (qp_like(MODE)) {
+      // query-profile table [6 codes][qp_stride(K) rows][64 lanes] (qp6_index): entry = substitution score << SH (- goe_n)
       w.sync();  // previous pass may still be reading the table
       bool overflow = false;
       int32_t qabs = 0;
 #pragma unroll 1
       for (int i = 0; i < K; ++i) {  // not unrolled: the set-up must not dictate the kernel's register budget
         const uint32_t r = base + L * K + i + 1 - pad;
-        float pr[5];
+        const bool real = r - 1 < m;
+        float pr[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        uint8_t rch = 0;
+        if (MODE == MODE_QP) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) pr[k] = (r - 1 < m) ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+          for (int k = 0; k < 5; ++k) pr[k] = real ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+        } else {
+          rch = real ? a1c[r - 1] : 0;
+        }
 #pragma unroll
         for (uint32_t b = 0; b < 5; ++b) {
-          const int32_t q = (r - 1 < m) ? onehot_score(pr, b, fmatch, fmis) : 0;
+          int32_t q;
+          if (MODE == MODE_QP) q = real ? onehot_score(pr, b, fmatch, fmis) : 0;
+          else q = real ? (rch == (uint8_t)"ACGTN"[b] ? a.match : a.mismatch) : 0;  // byte equality (align.h:96-101)
           const int32_t qs = (int32_t)((uint32_t)q << SH) - goe_n;
           overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
           qabs = imax(qabs, q < 0 ? -q : q);
-          // reverse-complement view of a2: the complement is folded into the table (row of code b serves code 3-b),
-          // the sweep selects rows with the raw codes
+          // reverse-complement view of a2: the complement is folded into the table (the entries of code b serve code 3-b),
+          // the sweep selects with the raw codes
           const uint32_t row = (rc_view && b < 4u) ? 3u - b : b;
-          qp_tab[row * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)qs;
+          qp_tab[qp6_index<K>(row, (uint32_t)i, L)] = (int16_t)qs;
         }
+        // code 5: '-' / any other letter.  A profile column of zeros scores 0; a string column that no row can equal mismatches
+        const int32_t q5 = (MODE == MODE_CQ && real) ? a.mismatch : 0;
+        qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)((int32_t)((uint32_t)q5 << SH) - goe_n);
       }
-      if (L < (uint32_t)qp_stride(K)) qp_tab[5 * (64 * qp_stride(K)) + L] = (int16_t)(-goe_n);
       if (overflow) flag_error(a.err, 1);
-      if (qabs > a.qlimit) flag_max(a.err, 1, qabs);  // un-normalised profile: the host re-checks the value range (capi.hip)
+      if (MODE == MODE_QP && qabs > a.qlimit) flag_max(a.err, 1, qabs);  // un-normalised profile: the host re-checks the value range (capi.hip)
       w.sync();
     } else {
 #pragma unroll
@@ -467,13 +506,13 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         ck[(2u * K + 2) * 64u] = prev_up_h;
       }
     };
-    if (MODE == MODE_QP) {
+    if (qp_like(MODE)) {
       // The code of column c = t - L (+ look-ahead) is read WITHOUT clamping: the code buffer carries kCodePad spare
       // bytes on both sides (capi_internal.h), idle lanes read into them (or into a neighbouring sequence) and discard
       // the result.  Forward view: byte c-1; reverse-complement view: byte n-c (its complement sits in the table).
       // byte(t) = lane_base + dir * t with dir = +-1 uniform over the wave: one VALU add per step.
-      SubPacked<K> qa, qb;
-      const QpLane ql = qp_lane<K>(qp_tab, L);
+      SubRows<K> qa, qb;
+      const int16_t* lane_col = qp_tab + L;
       const uint8_t* a2v = a2c - kCodeBias;
       const int32_t lane_base = (int32_t)kCodeBias + (rcflag ? (int32_t)n + (int32_t)L : -(int32_t)L - 1);
       const int32_t dir = rcflag ? -1 : 1;  // wave-uniform: dir * t is scalar work
@@ -482,19 +521,19 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       {
         const uint32_t raw1 = raw_at(1);
         raw_next = raw_at(2);
-        qp_fetch<K>(ql, raw1, qa);
+        qp_fetch_rows<K>(lane_col, raw1, qa);
       }
       for (uint32_t t = 1; t <= t_end; t += 2) {
         {
           const uint32_t raw_nn = raw_at((int32_t)t + 2);
-          qp_fetch<K>(ql, raw_next, qb);
+          qp_fetch_rows<K>(lane_col, raw_next, qb);
           do_step(t, qa);
           raw_next = raw_nn;
         }
         if (t + 1 > t_end) break;
         {
           const uint32_t raw_nn = raw_at((int32_t)t + 3);
-          qp_fetch<K>(ql, raw_next, qa);
+          qp_fetch_rows<K>(lane_col, raw_next, qa);
           do_step(t + 1, qb);
           raw_next = raw_nn;
         }
@@ -585,10 +624,6 @@ struct QpStrip {
   uint32_t v[K];  // row i in the low half (16-bit LDS reads zero the high half; the 16-bit ops ignore it)
   TR_HD int32_t lo16(int i) const { return (int32_t)v[i]; }
 };
-// table of the 16-bit sweep: int16 [6 codes][qp_stride(K) rows][64 lanes] -- a row's 64 lanes are contiguous, so the
-// per-row 16-bit reads of a wave are conflict-free (a per-lane strip layout costs an 8-way bank conflict on each of them)
-template <int K>
-TR_HD uint32_t qp6_index(uint32_t code, uint32_t row, uint32_t lane) { return (code * (uint32_t)qp_stride(K) + row) * 64u + lane; }
 template <int K>
 TR_HD void qp_fetch6(const char* lane_col, uint32_t code, QpStrip<K>& q) {
   constexpr uint32_t KP = qp_stride(K);
@@ -841,7 +876,9 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
 // ------------------------------------------------------------------------------------------------
 constexpr int32_t kNegInfOrigin = -6000;
 
-template <class W, int K>
+// TABLE: the rows are over {A,C,G,T,N} and a2 holds case-sensitive codes (MODE_CQ): substitution scores come from the
+// [code][row][lane] table in LDS, one shift-add per cell instead of compare + select + add
+template <class W, int K, bool TABLE = false>
 TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const PairDesc d = a.pairs[pair_idx];
   const uint32_t L = w.lane();
@@ -879,6 +916,23 @@ TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   sub_c.vmatch = (int32_t)((uint32_t)a.match << SH);
   sub_c.vmis = (int32_t)((uint32_t)a.mismatch << SH);
   sub_c.cc = 0;
+  int16_t* qp_tab = reinterpret_cast<int16_t*>(w.lds());
+  if (TABLE) {  // raw scores; the shift into the score field happens where a value is used (SubRows<K, SH>)
+#pragma unroll 1
+    for (int i = 0; i < K; ++i) {
+      const uint32_t r = L * K + i + 1;
+      const bool real = r - 1 < m;
+      const uint8_t rch = real ? a1c[r - 1] : 0;
+      const bool rcv = (d.flags & PAIR_A2_REVCOMP) != 0;
+#pragma unroll
+      for (uint32_t b = 0; b < 5; ++b) {
+        const uint32_t row = (rcv && b < 4u) ? 3u - b : b;
+        qp_tab[qp6_index<K>(row, (uint32_t)i, L)] = (int16_t)(real ? (rch == (uint8_t)"ACGTN"[b] ? a.match : a.mismatch) : 0);
+      }
+      qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)(real ? a.mismatch : 0);
+    }
+    w.sync();
+  }
   const uint32_t row_above = L * K;
   int32_t prev_up_h = (row_above == 0) ? 0 : (int32_t)((uint32_t)edge_value(false, go, ge, (int32_t)row_above) << SH);
   int32_t bot_h = 0, bot_f = 0;
@@ -894,19 +948,41 @@ TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   // register; the value received one step earlier is this step's diagonal (two registers used alternately by the two halves
   // of the unrolled loop: no copies).  Between ramp-up and ramp-down every used lane is on a real column: those steps run
   // without an activity test, so nothing has to be merged back into fixed registers at a join.
-  int32_t cc_next = (int32_t)a2c[col_at(1 - (int32_t)L)];
+  // TABLE: code of column t - L read without clamping from the padded code buffer (as the query-profile sweeps), the strip
+  // of the next column read row by row one step ahead
+  SubRows<K, SH> sub_r, sub_n;
+  const int16_t* lane_col = qp_tab + L;
+  const uint8_t* a2v = a2c - kCodeBias;
+  const int32_t lane_base = (int32_t)kCodeBias + (rcflag ? (int32_t)n + (int32_t)L : -(int32_t)L - 1);
+  const int32_t dir = rcflag ? -1 : 1;
+  auto raw_at = [&](int32_t tt) -> uint32_t { return a2v[(uint32_t)(lane_base + dir * tt)]; };
+  uint32_t raw_next = 0;
+  int32_t cc_next = 0;
+  if (TABLE) {
+    qp_fetch_rows<K>(lane_col, raw_at(1), sub_n);
+    raw_next = raw_at(2);
+  } else {
+    cc_next = (int32_t)a2c[col_at(1 - (int32_t)L)];
+  }
   int32_t f_x = 0;                 // F of the last slot, exchanged like H
   int32_t upA = 0, upB = prev_up_h;
   auto step = [&](auto guard, uint32_t t, int32_t& up_cur, const int32_t& diag) {
     constexpr bool GUARD = decltype(guard)::value;
-    sub_c.cc = rcflag ? (int32_t)complement_char((uint8_t)cc_next) : cc_next;
-    cc_next = (int32_t)a2c[col_at((int32_t)t - (int32_t)L + 1)];
+    if (TABLE) {
+      sub_r = sub_n;
+      qp_fetch_rows<K>(lane_col, raw_next, sub_n);
+      raw_next = raw_at((int32_t)t + 2);
+    } else {
+      sub_c.cc = rcflag ? (int32_t)complement_char((uint8_t)cc_next) : cc_next;
+      cc_next = (int32_t)a2c[col_at((int32_t)t - (int32_t)L + 1)];
+    }
     // row 0 (free leading gaps: H(0, c) = 0, F = -inf) enters through the shift; its origin is its own column
     up_cur = w.shift_up_or(ts.Hc[K - 1], (int32_t)t);
     const int32_t up_f = w.shift_up_or(f_x, neg);
     if (!GUARD || (uint32_t)(t - 1u - L) < n) {
       int32_t nb_h;
-      origin_step<K>(ts, up_cur, up_f, diag, cy1, cy2, sub_c, nb_h, f_x);
+      if (TABLE) origin_step<K>(ts, up_cur, up_f, diag, cy1, cy2, sub_r, nb_h, f_x);
+      else origin_step<K>(ts, up_cur, up_f, diag, cy1, cy2, sub_c, nb_h, f_x);
       // watch row m: slot_m is wave-uniform, the switch stays a scalar branch (no select chain over the strip)
       int32_t hv = 0, ev = 0;
       switch (slot_m) {
@@ -1294,10 +1370,10 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
           const int32_t qv = (r - 1 < m) ? onehot_score(pr, bb, fmatch, fmis) : 0;
           const uint32_t rowsel = (rcflag && bb < 4u) ? 3u - bb : bb;  // complement folded into the table (as gotoh_body)
           band_overflow |= (qv > (32767 >> SH)) || (qv < -(32768 >> SH));
-          qp_tab[rowsel * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)((uint32_t)qv << SH);
+          qp_tab[qp6_index<K>(rowsel, (uint32_t)i, L)] = (int16_t)((uint32_t)qv << SH);
         }
+        qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = 0;
       }
-      if (L < (uint32_t)qp_stride(K)) qp_tab[5 * (64 * qp_stride(K)) + L] = 0;
       if (band_overflow) flag_error(a.err, 1);
       w.sync();
     }
@@ -1402,26 +1478,26 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
         }
       } else {
         // same software pipeline as the sweep of gotoh_body: the code two steps ahead (unclamped read of the padded
-        // code buffer), the LDS strip one step ahead into the other half of a ping-pong pair
-        SubPacked<K> qa, qb;
-        const QpLane ql = qp_lane<K>(qp_tab, L);
+        // code buffer), the strip one step ahead, row by row, into the other half of a ping-pong pair
+        SubRows<K> qa, qb;
+        const int16_t* lane_col = qp_tab + L;
         const uint8_t* a2v = a2c - kCodeBias;
         const int32_t lane_base = (int32_t)kCodeBias + (rcflag ? (int32_t)n + (int32_t)L : -(int32_t)L - 1);
         const int32_t dir = rcflag ? -1 : 1;
         auto raw_at = [&](uint32_t tt) -> uint32_t { return a2v[(uint32_t)(lane_base + dir * (int32_t)tt)]; };
         uint32_t raw_next = raw_at(t0 + 2);
-        qp_fetch<K>(ql, raw_at(t0 + 1), qa);
+        qp_fetch_rows<K>(lane_col, raw_at(t0 + 1), qa);
         for (uint32_t t = t0 + 1; t <= t_cur; t += 2) {
           {
             const uint32_t raw_nn = raw_at(t + 2);
-            qp_fetch<K>(ql, raw_next, qb);
+            qp_fetch_rows<K>(lane_col, raw_next, qb);
             band_step(t, qa);
             raw_next = raw_nn;
           }
           if (t + 1 > t_cur) break;
           {
             const uint32_t raw_nn = raw_at(t + 3);
-            qp_fetch<K>(ql, raw_next, qa);
+            qp_fetch_rows<K>(lane_col, raw_next, qa);
             band_step(t + 1, qb);
             raw_next = raw_nn;
           }

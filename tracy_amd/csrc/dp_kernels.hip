@@ -65,10 +65,10 @@ __global__ __launch_bounds__(64) void gotoh_ckpt_kernel(DpArgs a) {
   gotoh_body<DeviceWave, K, MODE, false, NARROW, true>(w, a, blockIdx.x);
 }
 // origin-tracking sweep (string x string): score + the two ends of the alignment, no traceback words
-template <int K>
+template <int K, bool TABLE = false>
 __global__ __launch_bounds__(64) void gotoh_origin_kernel(DpArgs a) {
   DeviceWave w;
-  gotoh_origin_body<DeviceWave, K>(w, a, blockIdx.x);
+  gotoh_origin_body<DeviceWave, K, TABLE>(w, a, blockIdx.x);
 }
 // one launch, two kinds of workgroups: blocks [0, nfull) run the checkpointed 16-bit score sweep of `full`, the rest the
 // prefix bound of `pre` (GL lanes per pair) -- the short prefix workgroups fill the tail of the long sweeps
@@ -228,6 +228,7 @@ hipError_t launch_gotoh(int mode, int K, bool trace, bool narrow, const DpArgs& 
   switch (mode) {
     case MODE_CHAR: return trace ? launch_gotoh_k<MODE_CHAR, true>(K, a, npairs, s) : launch_gotoh_k<MODE_CHAR, false>(K, a, npairs, s);
     case MODE_QP: return trace ? launch_gotoh_k<MODE_QP, true>(K, a, npairs, s) : launch_gotoh_k<MODE_QP, false>(K, a, npairs, s);
+    case MODE_CQ: return trace ? launch_gotoh_k<MODE_CQ, true>(K, a, npairs, s) : hipErrorInvalidValue;  // tracebacks only
     case MODE_PROF: return trace ? launch_gotoh_k<MODE_PROF, true>(K, a, npairs, s) : launch_gotoh_k<MODE_PROF, false>(K, a, npairs, s);
     default: return hipErrorInvalidValue;
   }
@@ -292,8 +293,19 @@ hipError_t launch_band_trace(int mode, int K, const DpArgs& a, const WalkArgs& w
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_gotoh_origin(int K, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+hipError_t launch_gotoh_origin(int K, bool table, const DpArgs& a, uint32_t npairs, hipStream_t s) {
   if (npairs == 0) return hipSuccess;
+  if (table) {
+    switch (K) {
+      case 4: hipLaunchKernelGGL((gotoh_origin_kernel<4, true>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, 4), s, a); break;
+      case 8: hipLaunchKernelGGL((gotoh_origin_kernel<8, true>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, 8), s, a); break;
+      case 12: hipLaunchKernelGGL((gotoh_origin_kernel<12, true>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, 12), s, a); break;
+      case 15: hipLaunchKernelGGL((gotoh_origin_kernel<15, true>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, 15), s, a); break;
+      case 16: hipLaunchKernelGGL((gotoh_origin_kernel<16, true>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, 16), s, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (K) {
     case 4: hipLaunchKernelGGL((gotoh_origin_kernel<4>), dim3(npairs), dim3(64), 0, s, a); break;
     case 8: hipLaunchKernelGGL((gotoh_origin_kernel<8>), dim3(npairs), dim3(64), 0, s, a); break;

@@ -191,6 +191,17 @@ __global__ __launch_bounds__(64) void rowmax_rest_kernel(const RowMaxDesc* desc,
   if (threadIdx.x == 0) out[blockIdx.x] = sum;
 }
 
+// MODE_CQ (strings scored through the query-profile table): case-sensitive column codes, and the test that row strings hold
+// nothing but the five letters the table has entries for
+__global__ void encode_cq_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)cq_code(in[i]);
+}
+__global__ void cq_rows_kernel(const uint8_t* __restrict__ in, uint64_t n, int32_t* flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !cq_row_char(in[i])) atomicOr(flag, 1);
+}
+
 __global__ void encode_codes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (uint8_t)dp_code(in[i]);
@@ -1228,9 +1239,34 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
                                       static_cast<double*>(d_fr), wb * 0 + 18ull * std::accumulate(mf.begin(), mf.end(), 0ull))))
       return rc;
   }
+  // The allele-specific alignments below are string x string.  Basecall strings hold A, C, G, T, N only, so "row char == column
+  // char ? match : mismatch" can come out of the query-profile table (MODE_CQ: one table look-up per step instead of compare +
+  // select per cell); checked here on the strings as they are now, with the byte-compare kernels as the fallback.
+  DevBuf &b_cq1 = buf(), &b_cq2 = buf(), &b_cqf = buf();
+  HIP_TRY(b_cq1.ensure((er ? er : 1) + 2 * kCodePad));
+  HIP_TRY(b_cq2.ensure((bext ? bext : 1) + 2 * kCodePad));
+  HIP_TRY(b_cqf.ensure(sizeof(int32_t)));
+  uint8_t* d_cq_ref = static_cast<uint8_t*>(b_cq1.p) + kCodePad;
+  uint8_t* d_cq_sd = static_cast<uint8_t*>(b_cq2.p) + kCodePad;
+  const bool try_cq = getenv("TRACYHIP_NO_CQ") == nullptr;
+  int32_t h_cq_flag = 1;
+  if (try_cq) {
+    HIP_TRY(hipMemsetAsync(b_cq1.p, 5, (er ? er : 1) + 2 * kCodePad, st));
+    HIP_TRY(hipMemsetAsync(b_cq2.p, 5, (bext ? bext : 1) + 2 * kCodePad, st));
+    HIP_TRY(hipMemsetAsync(b_cqf.p, 0, sizeof(int32_t), st));
+    if (er) hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), d_cq_ref, er);
+    if (bext) {
+      hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), d_cq_sd, bext);
+      hipLaunchKernelGGL(cq_rows_kernel, dim3((unsigned)((bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_pri), bext, static_cast<int32_t*>(b_cqf.p));
+      hipLaunchKernelGGL(cq_rows_kernel, dim3((unsigned)((bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), bext, static_cast<int32_t*>(b_cqf.p));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&h_cq_flag, b_cqf.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  }
   std::vector<int32_t> h_hst(nt);
   HIP_TRY(hipMemcpyAsync(h_hst.data(), b_hst.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  const bool use_cq = try_cq && h_cq_flag == 0;
   for (uint32_t t = 0; t < nt; ++t)
     if (h_status[t] == 0 && h_hst[t] != 1) h_status[t] = h_hst[t] == 0 ? -2 : -3;
 
@@ -1267,7 +1303,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   for (int k = 0; k < 2; ++k) {
     const void* seq = (k == 0) ? d_pri : d_sd;
     DpProblem pb;
-    pb.mode = MODE_CHAR; pb.d_a1 = seq; pb.d_a2 = d_ref;
+    pb.mode = use_cq ? MODE_CQ : MODE_CHAR; pb.d_a1 = seq; pb.d_a2 = use_cq ? static_cast<const void*>(d_cq_ref) : d_ref;
     pb.desc.resize(nt); pb.k.resize(nt);
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc d{};
@@ -1316,7 +1352,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   }
   {  // allele 1 vs allele 2, global (indigo.h:379-387)
     DpProblem pb;
-    pb.mode = MODE_CHAR; pb.d_a1 = d_pri; pb.d_a2 = d_sd;
+    pb.mode = use_cq ? MODE_CQ : MODE_CHAR; pb.d_a1 = d_pri; pb.d_a2 = use_cq ? static_cast<const void*>(d_cq_sd) : d_sd;
     pb.desc.resize(nt); pb.k.resize(nt);
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc d{};

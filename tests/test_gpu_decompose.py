@@ -158,3 +158,43 @@ def test_decompose_traces_lanes(ctx):
             assert a == b, k
         else:  # ctypes arrays of result records
             assert bytes(a) == bytes(b), k
+
+
+def test_decompose_beyond_the_default_size_class(ctx):
+    """maxindel > 1024 and traces of >= 2048 basecalls: the scan state of decomposeAlleles takes its larger LDS size class
+    (decompose_kernels.h DecompDims<4096>), multi-pass strips and full-matrix tracebacks carry the alignments"""
+    from indigo_oracle import decompose_trace
+    from tracy_amd import capi, hostlib
+    sigs, poss, refs, bcs = [], [], [], []
+    for i, (seed, kind) in enumerate([(301, 0), (302, 0), (303, 2)]):
+        ref, sig, pos, indel = hostlib.synth_decompose(seed, 5200, 2300, 40, kind | (16 if i == 1 else 0), 0.6)
+        pri, sec, con, bcpos = hostlib.basecall(sig, pos, 0.33)
+        assert len(pri) >= 2048
+        sigs.append(sig); poss.append(pos); refs.append(ref); bcs.append((pri, sec, bcpos))
+    profs = [hostlib.create_profile(sigs[i], bcs[i][2], bcs[i][0], bcs[i][1], 0, 0) for i in range(len(sigs))]
+    for maxindel in (1000, 3000):
+        hbc = capi.HostBaseCalls(sigs, [b[2] for b in bcs], [b[0] for b in bcs], [b[1] for b in bcs])
+        got = ctx.decompose_traces(profs, hbc, refs, SC, maxindel=maxindel)
+        for i in range(len(sigs)):
+            w = decompose_trace(sigs[i], bcs[i][2], bcs[i][0], bcs[i][1], refs[i], SC, maxindel=maxindel)
+            assert int(got["status"][i]) == w["status"] == 0
+            assert got["primary"][i] == w["primary"] and got["secondary"][i] == w["secondary"], (maxindel, i)
+            assert got["secdecomp_list"][i] == w["secdecomp"]
+            assert got["dcp"][i] == w["dcp"], (maxindel, i)
+            assert (float(got["fractions"][2 * i]), float(got["fractions"][2 * i + 1])) == w["af"]
+            for k in range(3):
+                assert int(got["score%d" % k][i]) == w["score%d" % k] and got["btr%d" % k][i] == w["btr%d" % k], (maxindel, i, k)
+
+
+def test_staging_in_global_memory():
+    """findBreakpoint / allelicFraction stage per-trace arrays in LDS; traces too long for it use a global scratch slice.  Forced
+    here by lowering the limit (TRACYHIP_LDS_STAGE_LIMIT, read once per process): the chain tests in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRACYHIP_LDS_STAGE_LIMIT="1024")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_decompose.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "find_breakpoint or decompose_chain or decompose_traces_pipeline"], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "3 passed" in r.stdout

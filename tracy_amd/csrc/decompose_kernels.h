@@ -97,10 +97,17 @@ constexpr int kMaxIndelDev = 1024;  // maxindel handled in LDS (CLI default 1000
 // over a diagonal yields failed() for all its (ins, del) as suffix popcounts -- the complex ins x del
 // search costs O((maxins+maxdel) * NV/64) word operations instead of O(maxins * maxdel * NV) byte compares.
 constexpr int kRefClasses = 6;
-constexpr int kVarBits = 2 * kMaxIndelDev;                 // basecalls per trace handled (nbc < 2*kMaxIndelDev)
-constexpr int kWinBits = kVarBits + kMaxIndelDev;          // reference columns a scan can reach
-constexpr int kVarWords = kVarBits / 64 + 2;               // + zero padding for unaligned 64-bit fetches
-constexpr int kWinWords = kWinBits / 64 + 2;
+// Sizes of the LDS-resident scan state for a given largest maxindel.  Two instantiations exist: MAXI = 1024 (21 KB, the CLI default
+// maxindel 1000 and every Sanger-sized trace) and MAXI = 4096 (80 KB: maxindel up to 4096, traces of up to 8191 basecalls).
+template <int MAXI>
+struct DecompDims {
+  static constexpr int kMaxIndel = MAXI;
+  static constexpr int kVarBits = 2 * MAXI;                // basecalls per trace handled (nbc < 2*MAXI)
+  static constexpr int kWinBits = kVarBits + MAXI;         // reference columns a scan can reach
+  static constexpr int kVarWords = kVarBits / 64 + 2;      // + zero padding for unaligned 64-bit fetches
+  static constexpr int kWinWords = kWinBits / 64 + 2;
+};
+constexpr int kMaxIndelLarge = 4096;
 
 TR_HD int ref_class(uint8_t r) {
   return r == 'A' ? 0 : r == 'C' ? 1 : r == 'G' ? 2 : r == 'T' ? 3 : r == 'N' ? 4 : r == '-' ? 5 : 6;
@@ -127,12 +134,14 @@ TR_HD uint64_t bits_at(const uint64_t* a, int32_t pos, int32_t nw) {
 }
 TR_HD uint64_t low_mask(int32_t nbits) { return nbits >= 64 ? ~0ull : nbits <= 0 ? 0ull : ((1ull << nbits) - 1ull); }
 
-struct DecompShared {
-  int32_t fref[kMaxIndelDev];
-  int32_t fins[kMaxIndelDev];
-  int32_t hist[kMaxIndelDev * 2 + 2];
-  uint64_t is_c[kRefClasses][kWinWords];
-  uint64_t bad_c[kRefClasses][kVarWords];
+template <int MAXI>
+struct DecompSharedT : DecompDims<MAXI> {
+  using Dims = DecompDims<MAXI>;
+  int32_t fref[MAXI];
+  int32_t fins[MAXI];
+  int32_t hist[MAXI * 2 + 2];
+  uint64_t is_c[kRefClasses][Dims::kWinWords];
+  uint64_t bad_c[kRefClasses][Dims::kVarWords];
   uint32_t seg0[64], seg1[64];  // per-lane segment counts of trace / reference bases (alignment walk)
   uint32_t nfref, nfins;
   uint32_t varIndex, refPointer, alignIndex;
@@ -146,6 +155,7 @@ struct DecompShared {
   int32_t maxpick_del, maxpick_ins;
   int32_t best_fr[64], best_ins[64], best_del[64];
 };
+using DecompShared = DecompSharedT<kMaxIndelDev>;
 
 // failedref of one shift (decompose.h:215-222 and the two other copies of that loop), byte-wise: the
 // fallback for windows with exotic characters and the cross-check of the bit-set path in tests/emu
@@ -173,7 +183,8 @@ TR_HD void lane_segment(uint32_t L, uint32_t lane, uint32_t& lo, uint32_t& hi) {
 }
 
 // ---- phase 0 (all lanes): trace / reference bases per segment of the alignment ----
-TR_HD void decomp_phase_count(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, uint32_t lane) {
+template <class SH>
+TR_HD void decomp_phase_count(const DecompArgs& a, const DecompDesc& d, SH& sh, uint32_t lane) {
   const uint8_t* row0 = a.rows0 + d.rows_off;
   const uint8_t* row1 = a.rows1 + d.rows_off;
   uint32_t lo, hi, c0 = 0, c1 = 0;
@@ -198,7 +209,8 @@ TR_HD void phase_position(uint8_t* pri, uint8_t* sec, uint32_t vi, uint8_t r) {
 // ---- phase 1 (all lanes): walk to the breakpoint, phasing as we go (decompose.h:184-208) ----
 // The k-th trace base of the alignment is basecall trimLeft+k-1; the walk stops after the base that
 // makes vi == bp, i.e. after trace base number bp - trimLeft.  Every lane walks its own segment.
-TR_HD void decomp_phase_walk(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, uint32_t lane) {
+template <class SH>
+TR_HD void decomp_phase_walk(const DecompArgs& a, const DecompDesc& d, SH& sh, uint32_t lane) {
   const uint8_t* row0 = a.rows0 + d.rows_off;
   const uint8_t* row1 = a.rows1 + d.rows_off;
   uint8_t* pri = a.primary + d.bc_off;
@@ -226,7 +238,8 @@ TR_HD void decomp_phase_walk(const DecompArgs& a, const DecompDesc& d, DecompSha
 }
 
 // ---- phase 2 (lane 0): scan bounds (decompose.h:210-213, 248-250) ----
-TR_HD void decomp_phase_bounds(const DecompArgs& a, const DecompDesc& d, DecompShared& sh) {
+template <class SH>
+TR_HD void decomp_phase_bounds(const DecompArgs& a, const DecompDesc& d, SH& sh) {
   const int32_t rtrim = a.prm.trimRight;
   const uint32_t bp = d.breakpoint + (uint32_t)a.prm.trimLeft;
   if (!sh.found) {
@@ -250,21 +263,22 @@ TR_HD void decomp_phase_bounds(const DecompArgs& a, const DecompDesc& d, DecompS
   // extent of the bit sets
   const uint32_t winstart = sh.alignIndex + 1;
   const int64_t lw = (int64_t)d.L - (int64_t)winstart;
-  sh.Lw = (int32_t)(lw < 0 ? 0 : lw > kWinBits ? kWinBits : lw);
+  sh.Lw = (int32_t)(lw < 0 ? 0 : lw > SH::kWinBits ? SH::kWinBits : lw);
   uint64_t vend = decomp_vend(a, d);
   if (vend > d.nbc) vend = d.nbc;  // rtrim < 0 or > nbc: the reference reads out of bounds there
   const int64_t nv = (int64_t)vend - (int64_t)sh.varIndex;
-  sh.NV = (int32_t)(nv < 0 ? 0 : nv > kVarBits ? kVarBits : nv);
+  sh.NV = (int32_t)(nv < 0 ? 0 : nv > SH::kVarBits ? SH::kVarBits : nv);
 }
 
 // ---- phase 3 (all lanes): build the class bit sets; lane l builds word l, l+64, ... of each ----
-TR_HD void decomp_phase_bitsets(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, uint32_t lane) {
+template <class SH>
+TR_HD void decomp_phase_bitsets(const DecompArgs& a, const DecompDesc& d, SH& sh, uint32_t lane) {
   const uint8_t* row1 = a.rows1 + d.rows_off;
   const uint8_t* pri = a.primary + d.bc_off;
   const uint8_t* sec = a.secondary + d.bc_off;
   const uint32_t winstart = sh.alignIndex + 1;
   uint32_t seen = 0, exotic = 0;
-  for (int32_t w = (int32_t)lane; w < kWinWords; w += 64) {
+  for (int32_t w = (int32_t)lane; w < SH::kWinWords; w += 64) {
     uint64_t bits[kRefClasses] = {0, 0, 0, 0, 0, 0};
     for (int32_t q = 64 * w; q < 64 * w + 64 && q < sh.Lw; ++q) {
       const int c = ref_class(row1[winstart + (uint32_t)q]);
@@ -274,7 +288,7 @@ TR_HD void decomp_phase_bitsets(const DecompArgs& a, const DecompDesc& d, Decomp
     }
     for (int c = 0; c < kRefClasses; ++c) sh.is_c[c][w] = bits[c];
   }
-  for (int32_t w = (int32_t)lane; w < kVarWords; w += 64) {
+  for (int32_t w = (int32_t)lane; w < SH::kVarWords; w += 64) {
     uint64_t bits[kRefClasses] = {0, 0, 0, 0, 0, 0};
     for (int32_t s = 64 * w; s < 64 * w + 64 && s < sh.NV; ++s) {
       const char p = (char)pri[sh.varIndex + (uint32_t)s], sc = (char)sec[sh.varIndex + (uint32_t)s];
@@ -289,7 +303,8 @@ TR_HD void decomp_phase_bitsets(const DecompArgs& a, const DecompDesc& d, Decomp
 }
 
 // ---- phase 4 (lane 0): merge the per-lane class / exotic flags ----
-TR_HD void decomp_phase_flags(DecompShared& sh) {
+template <class SH>
+TR_HD void decomp_phase_flags(SH& sh) {
   uint32_t seen = 0, exotic = 0;
   for (int l = 0; l < 64; ++l) { seen |= (uint32_t)sh.best_fr[l]; exotic |= (uint32_t)sh.best_ins[l]; }
   sh.classes = seen;
@@ -297,16 +312,18 @@ TR_HD void decomp_phase_flags(DecompShared& sh) {
 }
 
 // Z_u word: bits s in [64*w, 64*w+64) of  OR_c bad_c[s] & is_c[s+u], cut at s < limit
-TR_HD uint64_t diag_word(const DecompShared& sh, int32_t u, int32_t w, int32_t limit) {
+template <class SH>
+TR_HD uint64_t diag_word(const SH& sh, int32_t u, int32_t w, int32_t limit) {
   uint64_t z = 0;
   for (int c = 0; c < kRefClasses; ++c) {
     if (!((sh.classes >> c) & 1u)) continue;
-    z |= sh.bad_c[c][w] & bits_at(sh.is_c[c], 64 * w + u, kWinWords);
+    z |= sh.bad_c[c][w] & bits_at(sh.is_c[c], 64 * w + u, SH::kWinWords);
   }
   return z & low_mask(limit - 64 * w);
 }
 // number of positions s >= from of diagonal u  ( = failed(del, ins) for del - ins == u, from == ins)
-TR_HD int32_t diag_count_from(const DecompShared& sh, int32_t u, int32_t from) {
+template <class SH>
+TR_HD int32_t diag_count_from(const SH& sh, int32_t u, int32_t from) {
   const int32_t lim_ref = sh.Lw - u;
   const int32_t limit = sh.NV < lim_ref ? sh.NV : lim_ref;
   int32_t f = 0;
@@ -319,7 +336,8 @@ TR_HD int32_t diag_count_from(const DecompShared& sh, int32_t u, int32_t from) {
 }
 
 // ---- phase 5 (all lanes): deletion and insertion scans (decompose.h:214-224, 251-261) ----
-TR_HD void decomp_phase_scan(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, uint32_t lane) {
+template <class SH>
+TR_HD void decomp_phase_scan(const DecompArgs& a, const DecompDesc& d, SH& sh, uint32_t lane) {
   if (sh.exotic) {
     const uint8_t* row1 = a.rows1 + d.rows_off;
     const uint8_t* pri = a.primary + d.bc_off;
@@ -351,9 +369,10 @@ TR_HD int32_t median_hist(const int32_t* v, uint32_t n, int32_t* hist, uint32_t 
 }
 
 // ---- phase 3 (lane 0): cut-offs, picks, decomposition table (decompose.h:227-285) ----
-TR_HD void decomp_phase_pick(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, DecompOut& out) {
+template <class SH>
+TR_HD void decomp_phase_pick(const DecompArgs& a, const DecompDesc& d, SH& sh, DecompOut& out) {
   const uint32_t nfref = sh.nfref, nfins = sh.nfins;
-  const uint32_t nh = (uint32_t)kMaxIndelDev * 2 + 2;
+  const uint32_t nh = (uint32_t)SH::kMaxIndel * 2 + 2;
   sh.fins[0] = sh.fref[0];  // decompose.h:249
   const int32_t med = median_hist(sh.fref, nfref, sh.hist, nh);
   // MAD: median of |x - med|; values stay below nh as well
@@ -429,7 +448,8 @@ TR_HD void complex_consider(int32_t f, int32_t prev, int32_t ins, int32_t del, i
   if (!(2 * f < prev && f < 1000)) return;
   if (f < bfr || (f == bfr && (ins < bi || (ins == bi && del < bd)))) { bfr = f; bi = ins; bd = del; }
 }
-TR_HD void decomp_phase_complex(const DecompArgs& a, const DecompDesc& d, DecompShared& sh, uint32_t lane) {
+template <class SH>
+TR_HD void decomp_phase_complex(const DecompArgs& a, const DecompDesc& d, SH& sh, uint32_t lane) {
   int32_t bfr = 1000, bi = 0, bd = 0;
   // loop limits of decompose.h:293-294
   int32_t NI = 0, ND = 0;
@@ -474,7 +494,8 @@ TR_HD void decomp_phase_complex(const DecompArgs& a, const DecompDesc& d, Decomp
   }
   sh.best_fr[lane] = bfr; sh.best_ins[lane] = bi; sh.best_del[lane] = bd;
 }
-TR_HD void decomp_phase_complex_reduce(DecompShared& sh, DecompOut& out) {
+template <class SH>
+TR_HD void decomp_phase_complex_reduce(SH& sh, DecompOut& out) {
   int32_t bfr = 1000, bi = 0, bd = 0;
   for (int l = 0; l < 64; ++l) {
     const int32_t f = sh.best_fr[l];
@@ -489,7 +510,8 @@ TR_HD void decomp_phase_complex_reduce(DecompShared& sh, DecompOut& out) {
 
 // ---- phase 9 (all lanes): rewrite the basecalls along the chosen shift (:317-326, 351-371) ----
 // Each position vi is touched once and only reads its own primary/secondary: lanes split the range.
-TR_HD void decomp_phase_apply(const DecompArgs& a, const DecompDesc& d, const DecompShared& sh, const DecompOut& out,
+template <class SH>
+TR_HD void decomp_phase_apply(const DecompArgs& a, const DecompDesc& d, const SH& sh, const DecompOut& out,
                               uint32_t lane) {
   const uint8_t* row0 = a.rows0 + d.rows_off;
   const uint8_t* row1 = a.rows1 + d.rows_off;
@@ -525,7 +547,8 @@ TR_HD void decomp_phase_apply(const DecompArgs& a, const DecompDesc& d, const De
 constexpr int kDecompSteps = 10;
 // whether step `st` runs on all lanes (true) or on lane 0 only (false)
 TR_HD bool decomp_step_all_lanes(int st) { return st == 0 || st == 1 || st == 3 || st == 5 || st == 7 || st == 9; }
-TR_HD void decomp_step(int st, const DecompArgs& a, const DecompDesc& d, DecompShared& sh, DecompOut& out, uint32_t lane) {
+template <class SH>
+TR_HD void decomp_step(int st, const DecompArgs& a, const DecompDesc& d, SH& sh, DecompOut& out, uint32_t lane) {
   switch (st) {
     case 0: decomp_phase_count(a, d, sh, lane); break;
     case 1: decomp_phase_walk(a, d, sh, lane); break;

@@ -23,14 +23,24 @@ using namespace tracyhip;
 
 namespace {
 
+// dynamic LDS a staging kernel may ask for (the static arrays of allelic_fraction_kernel come on top); beyond it the staging
+// arrays move to global scratch.  TRACYHIP_LDS_STAGE_LIMIT (bytes) lowers it, for tests of the global variants.
+static size_t lds_stage_limit() {
+  static size_t v = [] { const char* e = getenv("TRACYHIP_LDS_STAGE_LIMIT"); return e ? (size_t)atol(e) : (size_t)(140 * 1024); }();
+  return v;
+}
+#define kLdsStageLimit lds_stage_limit()
+
 __device__ __forceinline__ void wg_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __syncthreads();
 }
 
 // ---- decomposeAlleles: one 64-lane workgroup per trace ---------------------------------------------
+template <int MAXI>
 __global__ __launch_bounds__(64) void decompose_kernel(DecompArgs a, const BreakpointOut* bps) {
-  __shared__ DecompShared sh;
+  extern __shared__ __attribute__((aligned(16))) char decomp_smem[];  // dynamic: the MAXI = 4096 state (80 KB) exceeds the static limit
+  DecompSharedT<MAXI>& sh = *reinterpret_cast<DecompSharedT<MAXI>*>(decomp_smem);
   const uint32_t t = blockIdx.x;
   DecompDesc d = a.desc[t];
   d.breakpoint = bps[t].breakpoint;
@@ -44,15 +54,18 @@ __global__ __launch_bounds__(64) void decompose_kernel(DecompArgs a, const Break
 }
 
 // ---- findBreakpoint: one workgroup per profile; sig/diff in dynamic LDS (ncol doubles each) --------
-__global__ __launch_bounds__(64) void breakpoint_kernel(const BpDesc* desc, const float* prof, BreakpointOut* out) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// GLOBAL: the staging arrays of a profile too long for LDS live in a per-workgroup slice of a global scratch buffer
+template <bool GLOBAL>
+__global__ __launch_bounds__(64) void breakpoint_kernel(const BpDesc* desc, const float* prof, BreakpointOut* out, char* scratch, size_t stride) {
+  extern __shared__ __attribute__((aligned(16))) char lds_stage[];
+  char* smem = GLOBAL ? scratch + (size_t)blockIdx.x * stride : lds_stage;
   const BpDesc d = desc[blockIdx.x];
   double* sig = reinterpret_cast<double*>(smem);
   double* diff = sig + d.ncol;
   uint8_t* ltr = reinterpret_cast<uint8_t*>(diff + d.ncol);
   const float* p = prof + d.off;
   for (uint32_t j = threadIdx.x; j < d.ncol; j += 64) sig[j] = signal_ratio(p, d.stride, j);
-  __syncthreads();
+  wg_sync();
   if (25 < d.ncol) {
     for (uint32_t i = 25 + threadIdx.x; i < d.ncol - 25; i += 64) {
       double l, r;
@@ -60,7 +73,7 @@ __global__ __launch_bounds__(64) void breakpoint_kernel(const BpDesc* desc, cons
       ltr[i] = (l < r) ? 1 : 0;
     }
   }
-  __syncthreads();
+  wg_sync();
   if (threadIdx.x == 0) {
     BreakpointOut bp;
     breakpoint_select(diff, ltr, d.ncol, bp);
@@ -137,11 +150,14 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+template <bool GLOBAL>
 __global__ __launch_bounds__(AF_THREADS) void allelic_fraction_kernel(const BcDesc* desc, const int32_t* signal,
                                                                       const int32_t* bcpos, const uint8_t* pri_all,
                                                                       const uint8_t* sec_all, uint32_t trimLeft,
-                                                                      uint32_t trimRight, AfGrid grid, double* fractions) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+                                                                      uint32_t trimRight, AfGrid grid, double* fractions,
+                                                                      char* scratch, size_t stride) {
+  extern __shared__ __attribute__((aligned(16))) char lds_stage[];
+  char* smem = GLOBAL ? scratch + (size_t)blockIdx.x * stride : lds_stage;  // tp / cls of a trace too long for LDS: global scratch
   __shared__ double vals[100], f1[100], f2[100], f3[100];
   __shared__ double red_sse[AF_THREADS];
   __shared__ uint32_t red_idx[AF_THREADS];
@@ -378,11 +394,16 @@ namespace tracyhip {
 
 int launch_breakpoint(tracyhip_ctx* ctx, const BpDesc* d_desc, uint32_t n, uint32_t maxcol, const float* d_prof, BreakpointOut* d_out) {
   if (n == 0) return TRACYHIP_OK;
-  const size_t lds = (size_t)maxcol * 17 + 32;
-  if (lds > 150 * 1024) return set_error(TRACYHIP_ERR_RANGE, "profile with %u columns exceeds the LDS staging of findBreakpoint", maxcol);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(breakpoint_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t lds = (((size_t)maxcol * 17 + 32) + 15) & ~(size_t)15;
+  const bool global = lds > kLdsStageLimit;  // staging of a profile too long for LDS: a slice of a global scratch buffer per profile
   { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, 0); if (trc_) return trc_; }
-  hipLaunchKernelGGL(breakpoint_kernel, dim3(n), dim3(64), lds, ctx->stream, d_desc, d_prof, d_out);
+  if (global) {
+    HIP_TRY(ctx->d_bits.ensure(lds * (size_t)n));
+    hipLaunchKernelGGL(breakpoint_kernel<true>, dim3(n), dim3(64), 0, ctx->stream, d_desc, d_prof, d_out, static_cast<char*>(ctx->d_bits.p), lds);
+  } else {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(breakpoint_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(breakpoint_kernel<false>, dim3(n), dim3(64), lds, ctx->stream, d_desc, d_prof, d_out, nullptr, (size_t)0);
+  }
   HIP_TRY(hipGetLastError());
   { int trc_ = timing_end(ctx); if (trc_) return trc_; }
   return TRACYHIP_OK;
@@ -396,10 +417,25 @@ int launch_homozygous(tracyhip_ctx* ctx, const RowsDesc* d_desc, const uint8_t* 
   { int trc_ = timing_end(ctx); if (trc_) return trc_; }
   return TRACYHIP_OK;
 }
-int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut* d_bps, uint64_t work_cells, uint64_t work_bytes) {
+int decompose_limits(int32_t maxindel, uint32_t maxbc) {
+  if (maxindel < 1 || maxindel > kMaxIndelLarge) return set_error(TRACYHIP_ERR_RANGE, "maxindel must be in [1, %d]", kMaxIndelLarge);
+  if (maxbc >= 2u * kMaxIndelLarge) return set_error(TRACYHIP_ERR_RANGE, "a trace has %u basecalls; the scan tables hold < %d", maxbc, 2 * kMaxIndelLarge);
+  return TRACYHIP_OK;
+}
+int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut* d_bps, uint32_t maxbc, uint64_t work_cells, uint64_t work_bytes) {
   if (a.ntraces == 0) return TRACYHIP_OK;
+  int rc = decompose_limits(a.prm.maxindel, maxbc);
+  if (rc) return rc;
+  // scan state in LDS: 21 KB for maxindel <= 1024 and traces < 2048 basecalls (every Sanger run), 80 KB up to 4096 / 8191
+  const bool large = a.prm.maxindel > kMaxIndelDev || maxbc >= 2u * kMaxIndelDev;
   { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_DECOMP, work_cells, work_bytes); if (trc_) return trc_; }
-  hipLaunchKernelGGL(decompose_kernel, dim3(a.ntraces), dim3(64), 0, ctx->stream, a, d_bps);
+  if (large) {
+    const size_t lds = sizeof(DecompSharedT<kMaxIndelLarge>);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(decompose_kernel<kMaxIndelLarge>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(decompose_kernel<kMaxIndelLarge>, dim3(a.ntraces), dim3(64), lds, ctx->stream, a, d_bps);
+  } else {
+    hipLaunchKernelGGL(decompose_kernel<kMaxIndelDev>, dim3(a.ntraces), dim3(64), sizeof(DecompSharedT<kMaxIndelDev>), ctx->stream, a, d_bps);
+  }
   HIP_TRY(hipGetLastError());
   { int trc_ = timing_end(ctx); if (trc_) return trc_; }
   return TRACYHIP_OK;
@@ -449,15 +485,21 @@ int launch_allelic_fraction(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n,
                             const int32_t* d_pos, const uint8_t* d_pri, const uint8_t* d_sec, uint32_t trim_left, uint32_t trim_right,
                             double* d_out, uint64_t work_bytes) {
   if (n == 0) return TRACYHIP_OK;
-  const size_t lds = (size_t)maxbc * 36 + 64;  // tp (4 doubles per basecall) + class bytes
-  if (lds > 150 * 1024) return set_error(TRACYHIP_ERR_RANGE, "trace with %u basecalls exceeds the LDS staging of allelicFraction", maxbc);
+  const size_t lds = (((size_t)maxbc * 36 + 64) + 15) & ~(size_t)15;  // tp (4 doubles per basecall) + class bytes
+  const bool global = lds > kLdsStageLimit;
   AfGrid grid{};
   int rc = ensure_af_grid(ctx, grid);
   if (rc) return rc;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(allelic_fraction_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_AFRAC, 0, work_bytes); if (trc_) return trc_; }
-  hipLaunchKernelGGL(allelic_fraction_kernel, dim3(n), dim3(AF_THREADS), lds, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, trim_left,
-                     trim_right, grid, d_out);
+  if (global) {
+    HIP_TRY(ctx->d_bits.ensure(lds * (size_t)n));
+    hipLaunchKernelGGL(allelic_fraction_kernel<true>, dim3(n), dim3(AF_THREADS), 0, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, trim_left,
+                       trim_right, grid, d_out, static_cast<char*>(ctx->d_bits.p), lds);
+  } else {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(allelic_fraction_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(allelic_fraction_kernel<false>, dim3(n), dim3(AF_THREADS), lds, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, trim_left,
+                       trim_right, grid, d_out, nullptr, (size_t)0);
+  }
   HIP_TRY(hipGetLastError());
   { int trc_ = timing_end(ctx); if (trc_) return trc_; }
   return TRACYHIP_OK;
@@ -531,14 +573,16 @@ int tracyhip_decompose_alleles(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, 
   if (!rows0 || !rows1 || !rows_offset || !rows_len || !bps || !refslice_len || !dcp_indel || !dcp_err || !dcp_offset || !status ||
       !bc->primary || !bc->secondary || !bc->bc_offset || !bc->bc_len)
     return set_error(TRACYHIP_ERR_ARG, "null argument");
-  if (prm->maxindel < 1 || prm->maxindel > kMaxIndelDev) return set_error(TRACYHIP_ERR_RANGE, "maxindel must be in [1, %d]", kMaxIndelDev);
+  uint32_t maxbc_all = 0;
+  for (uint32_t i = 0; i < n; ++i) maxbc_all = std::max(maxbc_all, bc->bc_len[i]);
+  if ((rc = decompose_limits(prm->maxindel, maxbc_all))) return rc;
   static_assert(sizeof(tracyhip_decomp_status) == sizeof(DecompOut), "layout");
   hipStream_t st = ctx->stream;
   const uint64_t rext = extent64(rows_offset, rows_len, n), bext = extent64(bc->bc_offset, bc->bc_len, n);
   uint64_t dext = 0;
   std::vector<DecompDesc> hd(n);
   for (uint32_t i = 0; i < n; ++i) {
-    if (bc->bc_len[i] >= 2u * kMaxIndelDev) return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the device histogram holds < %d", i, bc->bc_len[i], 2 * kMaxIndelDev);
+
     hd[i] = DecompDesc{rows_offset[i], bc->bc_offset[i], dcp_offset[i], rows_len[i], bc->bc_len[i], refslice_len[i], 0};
     dext = std::max<uint64_t>(dext, dcp_offset[i] + 2ull * prm->maxindel + 2);
   }
@@ -565,7 +609,7 @@ int tracyhip_decompose_alleles(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, 
   a.out = static_cast<DecompOut*>(d_stat);
   a.prm = DecompParams{prm->trim_left, prm->trim_right, prm->maxindel, prm->madc};
   a.ntraces = n;
-  if ((rc = launch_decompose(ctx, a, static_cast<const BreakpointOut*>(d_bp)))) return rc;
+  if ((rc = launch_decompose(ctx, a, static_cast<const BreakpointOut*>(d_bp), maxbc_all))) return rc;
   if ((rc = unstage(ctx, bc->primary, d_pri, bext, mem))) return rc;
   if ((rc = unstage(ctx, bc->secondary, d_sec, bext, mem))) return rc;
   if ((rc = unstage(ctx, dcp_indel, d_di, dext * 4, mem))) return rc;

@@ -17,7 +17,9 @@ int launch_homozygous(tracyhip_ctx* ctx, const RowsDesc* d_desc, const uint8_t* 
                       BreakpointOut* d_bps, int32_t* d_status);
 // work_cells / work_bytes: what the kernel timers (tracyhip_timing_get) account for the launch -- alignment columns walked and
 // algorithmic bytes (alignment rows + basecalls read, basecalls rewritten); 0 = not accounted
-int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut* d_bps, uint64_t work_cells = 0, uint64_t work_bytes = 0);
+// maxbc: the longest trace (basecalls) of the batch; it and prm.maxindel pick the size class of the LDS-resident scan state
+int decompose_limits(int32_t maxindel, uint32_t maxbc);  // TRACYHIP_OK, or ERR_RANGE beyond the larger size class
+int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut* d_bps, uint32_t maxbc, uint64_t work_cells = 0, uint64_t work_bytes = 0);
 int launch_secdecomp(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig, const int32_t* d_pos,
                      const uint8_t* d_pri, const uint8_t* d_sec, uint8_t* d_out);
 int launch_allelic_fraction(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig,

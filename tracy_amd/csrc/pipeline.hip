@@ -967,7 +967,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     return set_error(TRACYHIP_ERR_ARG, "bad sequence sets");
   if (!bc.signal || !bc.signal_offset || !bc.nsamples || !bc.bcpos || !bc.primary || !bc.secondary || !bc.bc_offset || !bc.bc_len)
     return set_error(TRACYHIP_ERR_ARG, "null basecall arrays");
-  if (dp.maxindel < 1 || dp.maxindel > kMaxIndelDev) return set_error(TRACYHIP_ERR_RANGE, "maxindel must be in [1, %d]", kMaxIndelDev);
+  if (dp.maxindel < 1 || dp.maxindel > kMaxIndelLarge) return set_error(TRACYHIP_ERR_RANGE, "maxindel must be in [1, %d]", kMaxIndelLarge);
   if (!out->bp || !out->status || !out->score_fwd || !out->score_rev || !out->forward || !out->score_trim || !out->dcp_indel ||
       !out->dcp_err || !out->dcp_offset || !out->dstatus || !out->secdecomp || !out->fractions)
     return set_error(TRACYHIP_ERR_ARG, "null result array");
@@ -994,7 +994,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     mf[t] = sp.length[t];
     rn[t] = sr.length[ridx[t]];
     if (bc.bc_len[t] != mf[t]) return set_error(TRACYHIP_ERR_ARG, "trace %u: profile has %u columns but %u basecalls", t, mf[t], bc.bc_len[t]);
-    if (bc.bc_len[t] >= 2u * kMaxIndelDev) return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the device histogram holds < %d", t, bc.bc_len[t], 2 * kMaxIndelDev);
+    if (bc.bc_len[t] >= 2u * kMaxIndelLarge) return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the scan tables hold < %d", t, bc.bc_len[t], 2 * kMaxIndelLarge);
     uint32_t l = TL, r = TR;
     if ((uint64_t)l + r >= mf[t]) { l = 0; r = 0; }  // createProfile, profile.h:24-27
     tl[t] = l;
@@ -1226,7 +1226,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     a.ntraces = nt;
     uint64_t wc = 0, wb = 0;
     for (uint32_t t = 0; t < nt; ++t) { wc += h_len1[t]; wb += 2ull * h_len1[t] + 4ull * mf[t]; }
-    if ((rc = launch_decompose(ctx, a, static_cast<const BreakpointOut*>(d_bp), wc, wb))) return rc;
+    if ((rc = launch_decompose(ctx, a, static_cast<const BreakpointOut*>(d_bp), maxbc, wc, wb))) return rc;
     std::vector<BcDesc> hb(nt);
     for (uint32_t t = 0; t < nt; ++t) hb[t] = BcDesc{bc.signal_offset[t], bc.bc_offset[t], bc.nsamples[t], mf[t]};
     const BcDesc* db;

@@ -384,7 +384,8 @@ def main():
                                      "algorithmic_bytes_per_launch": tr["bytes"] // max(tr["launches"], 1)},
                 "ms_per_step": {"score": round(sc["ms"] / steps, 3), "band_traceback": round(bd["ms"] / steps, 3),
                                 "full_traceback": round(tr["ms"] / steps, 3), "walk": round(rl["walk"]["ms"] / steps, 3)},
-                "band_traceback_effective_gcups": round(kgcups(bd), 1)}
+                "band_traceback": {"swept_gcups": round(kgcups(bd), 1), "swept_fraction_of_its_matrix": round(bd["cells"] / steps / max(mt * n * nt, 1), 3),
+                                   "effective_gcups_over_the_matrix": round(mt * n * nt * steps / (bd["ms"] * 1e-3) / 1e9, 1) if bd["ms"] > 0 else 0.0}}
 
     line = {
         "metric": "GCUPS (tracy align: Gotoh affine-gap DP cells per second, whole job)",
@@ -400,6 +401,11 @@ def main():
         # the final traceback are swept in full; the preliminary traceback is a band traceback from the score sweep's
         # checkpoints, which re-sweeps only the bands its path crosses (about an eighth of its matrix) for the same `btr`
         "cells_counted": "reference DP cells: 3 x (mt x n) + mf x slice per trace; the preliminary traceback re-sweeps ~12% of its mt x n",
+        # the same step priced by the cells the kernels really evaluated (HIP-event timers: both orientation sweeps and the final
+        # traceback in full, the band traceback only its re-swept bands): what `value` would be if the band traceback were not credited
+        # with its whole matrix
+        "gcups_swept_cells": round(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix")) / steps * world / (elapsed_max / steps) / 1e9, 2),
+        "cells_swept_per_step_rank0": int(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix")) / steps),
         "roofline": roofline,
     }
     if rl_cert is not None:

@@ -342,7 +342,8 @@ int tracyhip_pair_bounds(const tracyhip_pairs* pairs, uint32_t parts, uint64_t* 
 #define TRACYHIP_TIMER_SCORE 0 /* score-only DP kernels */
 #define TRACYHIP_TIMER_TRACE 1 /* traceback DP kernels  */
 #define TRACYHIP_TIMER_WALK 2  /* traceback walkers     */
-#define TRACYHIP_TIMER_BAND 3  /* band tracebacks (checkpointed traceback of the align / decompose pipelines) */
+#define TRACYHIP_TIMER_BAND 3  /* band tracebacks (checkpointed traceback of the align / decompose pipelines); cells = the cells the
+                                  kernel really re-swept (strip height x steps of the bands its paths cross), not m x n */
 #define TRACYHIP_TIMER_PREFIX 4 /* prefix-bound kernels (strand by certificate); cells = rows actually swept x columns */
 #define TRACYHIP_TIMER_ORIGIN 5 /* origin-tracking sweeps (gotoh() whose alignment only trimReferenceSlice reads) */
 #define TRACYHIP_TIMER_DECOMP 6 /* decomposeAlleles kernel; cells = alignment columns, bytes = rows + basecalls + table */

@@ -366,6 +366,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   HIP_TRY(ctx->d_err.ensure(kErrBytes));
   HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
   std::vector<std::pair<uint32_t, int>> narrow_launches;  // (tallest problem, K) of every 16-bit launch, for range_verdict
+  uint64_t band_cells_credited = 0;                       // m * n of the band launches (replaced by the swept cells after the sync)
   uint64_t max_mn = 0;
   for (uint32_t j = 0; j < np; ++j) max_mn = std::max<uint64_t>(max_mn, (uint64_t)pb.desc[j].m + pb.desc[j].n);
 
@@ -380,6 +381,10 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge;
   a.hfree = prm->hfree; a.vfree = prm->vfree;
   a.qlimit = sub_limit(prm);
+  if (stage == DP_BAND && ctx->timing) {
+    a.swept = reinterpret_cast<unsigned long long*>(static_cast<int32_t*>(ctx->d_err.p) + kErrSweptWord);
+    HIP_TRY(hipMemsetAsync(a.swept, 0, sizeof(unsigned long long), st));
+  }
   if (ck) a.ends = ck->d_ends;
   if (ck && stage == DP_CKPT) { a.votes = ck->d_votes; a.vote_nt = ck->vote_nt; }
   if (ck) { a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.band = static_cast<uint64_t*>(ctx->d_band.p); a.ckpt_narrow = ck->narrow ? 1 : 0; }
@@ -402,7 +407,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
           cells += mn;
           bytes += (trace ? mn / 2 : 0) + (pb.a1_profile ? 24ull * d.m : d.m) + (pb.a2_profile ? 24ull * d.n : d.n) + 4;
         }
-        if (stage == DP_BAND) bytes = 0;  // band traceback recomputes a few bands into an L2-resident buffer: no matrix-sized traffic
+        if (stage == DP_BAND) { bytes = 0; band_cells_credited += cells; }  // (bytes: the bands live in a per-pair buffer, no matrix-sized traffic)
         if ((trc = timing_begin(ctx, stage == DP_BAND ? TRACYHIP_TIMER_BAND : stage == DP_PREFIX ? TRACYHIP_TIMER_PREFIX : stage == DP_ORIGIN ? TRACYHIP_TIMER_ORIGIN
                                      : trace ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
       }
@@ -453,9 +458,15 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
     }
   }
   int32_t herr[kErrWords] = {};
+  unsigned long long h_swept = 0;
   HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
+  if (a.swept) HIP_TRY(hipMemcpyAsync(&h_swept, a.swept, sizeof(h_swept), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   timing_collect(ctx);
+  if (a.swept) {  // the band timer reports the cells it really evaluated, not the matrices it stands in for
+    ctx->acc[TRACYHIP_TIMER_BAND].cells -= std::min<uint64_t>(ctx->acc[TRACYHIP_TIMER_BAND].cells, band_cells_credited);
+    ctx->acc[TRACYHIP_TIMER_BAND].cells += h_swept;
+  }
   const int verdict = range_verdict(prm, herr, narrow_launches, max_mn, trace ? (needle ? 2 : kTagShift) : 0);
   if (verdict == kWiden && stage == DP_PLAIN) {  // the 16-bit score kernel met an un-normalised profile: same work on the int32 kernel
     const bool keep = ctx->no_narrow;

@@ -145,7 +145,8 @@ bool narrow_ok(const tracyhip_params* prm, uint32_t maxm, int K, int64_t Q = 0);
 int32_t sub_limit(const tracyhip_params* prm);
 // device error block (DpArgs::err): kErrWords words owned by the DP launches + one verdict word of the pipelines' reference check
 constexpr int kErrVerdictWord = kErrWords;
-constexpr size_t kErrBytes = sizeof(int32_t) * (kErrWords + 1);
+constexpr int kErrSweptWord = kErrWords + 2;  // 64-bit counter of the band traceback (DpArgs::swept), 8-byte aligned
+constexpr size_t kErrBytes = sizeof(int32_t) * (kErrWords + 4);
 // internal status (never returned through the C ABI): a 16-bit launch ran outside its proven value range; repeat on int32
 constexpr int kWiden = 1;
 int range_verdict(const tracyhip_params* prm, const int32_t* herr, const std::vector<std::pair<uint32_t, int>>& narrow_launches,

@@ -76,6 +76,7 @@ struct DpArgs {
   uint32_t ckpt_B;      // steps between wavefront checkpoints
   int32_t ckpt_narrow;  // checkpoints hold raw registers of the 16-bit kernel (values in the low halves)
   uint32_t* ends;       // origin-tracking sweep: {leading 'h' columns, last column that is not a trailing 'h'} per pair
+  unsigned long long* swept;  // band traceback: DP cells actually re-swept, summed over the launch (or null)
   const uint32_t* votes;  // checkpointed 16-bit sweep of both orientations (PairDesc::out = orientation * vote_nt + trace): {vf, vr} per
   uint32_t vote_nt;       // trace, or null.  Sweeps of the likely losing strand (vote_skips_checkpoints) write no checkpoints / row m
 };
@@ -1402,6 +1403,7 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
     }
 
     // ---- 2. bands ----
+    uint32_t swept_steps = 0;
     while (row > 0 && col > 0 && k <= limit) {
       const uint32_t t_cur = col + cell_addr(row + pad, K).lane;
       const uint32_t j = (t_cur - 1) / B;
@@ -1503,10 +1505,18 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
           }
         }
       }
+      swept_steps += t_cur - t0;
       w.sync_global();
       BandFetch fetch{band, t0, K, pad};
       walk_core(w, fetch, row, col, state, k, out, t0, K, limit, pad);
       w.sync_global();
+    }
+    if (L == 0 && a.swept && swept_steps) {  // cells of the strip x steps re-swept (what the band timer reports as evaluated cells)
+#if defined(__HIP_DEVICE_COMPILE__)
+      atomicAdd(a.swept, (unsigned long long)swept_steps * (unsigned long long)(lanes_used * K));
+#else
+      *a.swept += (unsigned long long)swept_steps * (unsigned long long)(lanes_used * K);
+#endif
     }
   }
   ok = walk_tails(w, row, col, state, k, out);

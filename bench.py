@@ -130,12 +130,14 @@ def stub_rank(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", default="all", choices=("all", "align", "decompose", "allpairs"),
+    ap.add_argument("--workload", default="all", choices=("all", "align", "decompose", "allpairs", "seedextend"),
                     help="all: the align headline + the decompose and all-pairs legs; one name: that workload alone (profiling)")
     ap.add_argument("--decompose-traces", type=int, default=100000, help="configs[2]: traces of the whole decompose job (sharded over the ranks)")
     ap.add_argument("--decompose-steps", type=int, default=3)
     ap.add_argument("--allpairs-traces", type=int, default=1000, help="configs[4]: traces of the all-pairs job (pair list sharded over the ranks)")
     ap.add_argument("--allpairs-steps", type=int, default=3)
+    ap.add_argument("--seedextend-traces", type=int, default=20000, help="configs[3] in miniature: traces of the seed + extend job (sharded over the ranks)")
+    ap.add_argument("--seedextend-steps", type=int, default=2)
     ap.add_argument("--extra-legs", type=int, default=1, help="decompose: also time the strand-certificate and two-lane legs")
     ap.add_argument("--stub", action="store_true", help="launcher self-test on gloo with a step that does no device work (not a measurement)")
     ap.add_argument("--steps", type=int, default=10)
@@ -177,9 +179,12 @@ def main():
 
     def run_extra(which):
         """configs[2] / configs[4] legs (tools/legs.py); a failing leg reports its error instead of taking the headline down"""
-        from tools.legs import AllPairsLeg, DecomposeLeg
+        from tools.legs import AllPairsLeg, DecomposeLeg, SeedExtendLeg
         try:
-            if which == "decompose":
+            if which == "seedextend":
+                leg = SeedExtendLeg(args.seedextend_traces, 20.0, 1000, rank, world, dev)
+                res = leg.run(dist, args.seedextend_steps, 1, cpu_sample=64 if args.cpu_sample != 0 else 0)
+            elif which == "decompose":
                 leg = DecomposeLeg(args.decompose_traces, 3000, 1000, rank, world, dev)
                 res = leg.run(dist, args.decompose_steps, 1, extra_legs=bool(args.extra_legs), cpu_sample=128 if args.cpu_sample != 0 else 0)
             else:
@@ -195,7 +200,7 @@ def main():
             return {"error": "%s: %s" % (type(e).__name__, e)}
 
     extra = {}
-    if args.workload in ("decompose", "allpairs"):
+    if args.workload in ("decompose", "allpairs", "seedextend"):
         extra[args.workload] = run_extra(args.workload)
         if rank == 0:
             line = extra[args.workload]
@@ -333,7 +338,7 @@ def main():
         ctx.close()
         del d_refs, d_profs, r_ops
         torch.cuda.empty_cache()
-        for which in ("decompose", "allpairs"):
+        for which in ("decompose", "allpairs", "seedextend"):
             extra[which] = run_extra(which)
 
     if rank != 0:

@@ -380,3 +380,168 @@ class AllPairsLeg:
                                     "single_thread": {"value": round(mf * mf / c1 / 1e9, 4), "unit": "GCUPS"}}
             line["parity_checked"] = {"pairs": int(len(pick)), "bit_identical": bool(all(int(got[k]) == w for k, w in zip(pick, want)))}
         return line
+
+
+# =====================================================================================================================
+class SeedExtendLeg:
+    """configs[3] in miniature: `total` 1 kb traces sampled from a synthetic genome (GRCh38 chr22 is not available offline), host
+    k-mer seeding (getReferenceSlice, fmindex.h:236-326, all usable host threads of the rank) + device extend
+    (tracyhip_align_traces with job.oriented: one checkpointed score sweep, band traceback, trimReferenceSlice, final alignment).
+    Traces are sharded over the ranks by contiguous blocks; every rank holds the k-mer table of the whole genome."""
+
+    def __init__(self, total, genome_mb, trace_len, rank, world, dev):
+        import tempfile
+        import tracy_amd
+        from tracy_amd import capi, hostlib
+        from tracy_amd.shard import shard_range
+        self.capi, self.total, self.mf, self.rank, self.world, self.dev = capi, total, trace_len, rank, world, dev
+        rng = np.random.default_rng(22)  # the same genome and traces on every rank; a rank keeps its block
+        n = self.gn = int(genome_mb * 1e6)
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        seq = lut[rng.integers(0, 4, size=n, dtype=np.uint8)]
+        self.tmp = tempfile.mkdtemp()
+        gpath = os.path.join(self.tmp, "genome.fa")
+        with open(gpath, "wb") as f:
+            f.write(b">chrSyn\n")
+            f.write(seq.tobytes())
+            f.write(b"\n")
+        t0 = time.perf_counter()
+        self.genome = hostlib.Genome(gpath, 15, 0)
+        self.index_s = time.perf_counter() - t0
+        lo, hi = shard_range(total, rank, world)
+        mf = trace_len
+        starts_all = rng.integers(0, n - mf - 50, size=total)
+        errs = np.random.default_rng(23 + rank)
+        self.starts = starts_all[lo:hi]
+        nt = self.nt = hi - lo
+        self.profs = np.zeros((nt, 6, mf), np.float32)
+        self.cons = []
+        comp = bytes.maketrans(b"ACGT", b"TGCA")
+        for k in range(nt):
+            g = lo + k
+            s = seq[self.starts[k]:self.starts[k] + mf].tobytes()
+            if g % 2:  # every other trace reads the reverse strand
+                s = s[::-1].translate(comp)
+            code = np.searchsorted(lut, np.frombuffer(s, np.uint8))
+            code = np.where(errs.random(mf) < 0.01, (code + 1) % 4, code)  # 1 % substitutions
+            p = self.profs[k]
+            p[:4] = 0.02
+            p[code, np.arange(mf)] = 0.94
+            self.cons.append(lut[code].tobytes())
+        self.lo = lo
+        self.ctx = tracy_amd.Context(dev.index or 0)
+        self.CHUNKS = 4
+        self.lib = capi.lib()
+
+    def run(self, dist, steps, warmup, cpu_sample=64):
+        capi, ctx = self.capi, self.ctx
+        seed_s = ext_s = 0.0
+        res = sd = ok = None
+        self.lib.tracyhip_timing_enable(ctx._h, 0)
+        for it in range(warmup + steps):
+            if it == warmup:
+                if dist is not None:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                self.lib.tracyhip_timing_enable(ctx._h, 1)
+                self.lib.tracyhip_timing_reset(ctx._h)
+                t_all = time.perf_counter()
+            # The batch goes through in CHUNKS blocks: while the device extends block b (tracyhip_align_traces_async, queued on the
+            # context), the host seeds block b + 1 -- the host stage of configs[3] hides behind the device stage and vice versa.
+            t0 = time.perf_counter()
+            CH = self.CHUNKS
+            preps, sds, oks = [], [], []
+            step_seed = 0.0
+            for b in range(CH):
+                blo, bhi = self.nt * b // CH, self.nt * (b + 1) // CH
+                ts0 = time.perf_counter()
+                sdb = self.genome.seed(self.cons[blo:bhi], 50, 50, 3, 1000, 0, raw=True)
+                step_seed += time.perf_counter() - ts0
+                okb = np.nonzero(sdb["status"] == 1)[0]
+                # packed host buffers as a C caller holds them: the profile block and the padded window block are handed over in
+                # place, offsets / lengths select the anchored traces
+                pp = capi.PackedSeqs([], capi.SEQ_PROFILE)
+                pp.count, pp.data = len(okb), self.profs
+                pp.offset = ((okb + blo).astype(np.uint64) * np.uint64(6 * self.mf))
+                pp.length = np.full(max(len(okb), 1), self.mf, np.uint32)
+                cap = sdb["slices_2d"].shape[1]
+                pw = capi.PackedSeqs([], capi.SEQ_CHAR)
+                pw.count, pw.data = len(okb), sdb["slices_2d"]
+                pw.offset = (okb.astype(np.uint64) * np.uint64(cap))
+                pw.length = np.ascontiguousarray(sdb["slice_len"][okb], dtype=np.uint32)
+                prep = capi.PreparedAlign(pp, pw, SCORE, 50, 50, oriented=np.ascontiguousarray(sdb["forward"][okb], dtype=np.uint8))
+                ctx.align_traces_async(prep.job, prep.prm, prep.out, capi.MEM_HOST)
+                preps.append(prep); sds.append(sdb); oks.append(okb + blo)
+            ctx.synchronize()
+            t3 = time.perf_counter()
+            t1, t2 = t0 + step_seed, t0 + step_seed  # (seeding time of the step; the extend overlaps it)
+            # results of the step, block after block
+            rs = [p_.results() for p_ in preps]
+            res = {k: (np.concatenate([r[k] for r in rs]) if k != "btr" else sum((r["btr"] for r in rs), [])) for k in ("score_final", "slice_len", "ref_pos", "btr")}
+            ok = np.concatenate(oks)
+            sd = {"pos": np.concatenate([sds[b]["pos"] for b in range(CH)]), "slice_len": np.concatenate([sds[b]["slice_len"] for b in range(CH)]),
+                  "forward": np.concatenate([sds[b]["forward"] for b in range(CH)]), "status": np.concatenate([sds[b]["status"] for b in range(CH)])}
+            self._win = lambda i: next(sds[b]["slices_2d"][i - self.nt * b // CH, :int(sds[b]["slice_len"][i - self.nt * b // CH])].tobytes()
+                                       for b in range(CH) if self.nt * b // CH <= i < self.nt * (b + 1) // CH)
+            if it >= warmup:
+                seed_s += step_seed
+                ext_s += (t3 - t0) - step_seed  # what the extend adds on top of the seeding it overlaps with
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t_all
+        self.lib.tracyhip_timing_enable(ctx._h, 0)
+        timers = read_timers(self.lib, ctx)
+        mf = self.mf
+        win_len = sd["slice_len"][ok].astype(np.int64)
+        cells = int(((mf - 100) * win_len).sum() * 2 + (mf * res["slice_len"].astype(np.int64)).sum())
+        truth = self.starts[ok] - np.where((self.lo + ok) % 2 == 0, 50, 0)
+        placed = int((np.abs(sd["pos"][ok].astype(np.int64) + res["ref_pos"].astype(np.int64) - truth) <= 60).sum())
+        dt, seed_s, ext_s = max_over_ranks(dist, self.dev, [dt, seed_s, ext_s])
+        cells_all, ok_all, placed_all, nt_all = sum_over_ranks(dist, self.dev, [float(cells), float(len(ok)), float(placed), float(self.nt)])
+        if self.rank != 0:
+            return None
+        roof = kernel_block("score", "gotoh_ckpt_kernel<K,QP,narrow> (one orientation: the window arrives oriented by the seeds)", timers["score"], steps,
+                            ops_per_cell=8.0, traffic_key=None)
+        roof["ms_per_step"] = {k: round(timers[k]["ms"] / steps, 3) for k, _ in TIMERS if timers[k]["ms"] > 0}
+        roof["note"] = "four blocks per step, each extended asynchronously while the host seeds the next one"
+        from bench import usable_cores
+        line = {"metric": "traces/s (host k-mer seeding + device Gotoh extend, end to end)", "value": round(ok_all * steps / dt, 1), "unit": "traces/s",
+                "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "warmup": warmup, "n_gpus": self.world, "scaling": "strong",
+                "seed_traces_per_s": round(nt_all * steps / seed_s, 1),
+                "extend_ms_not_hidden_per_step": round(ext_s / steps * 1e3, 2), "extend_kernel_gcups": round(cells_all * steps / max(sum(timers[k]["ms"] for k in ("score", "trace", "band", "walk")) * 1e-3, 1e-9) / 1e9, 1), "host_threads_per_rank": usable_cores(), "index_build_s": round(self.index_s, 2),
+                "anchored": int(ok_all), "traces": int(nt_all), "placed_within_60bp_of_truth": int(placed_all),
+                "dtype": "int16 (score sweep) / int32 (tracebacks); seeding: 2-bit k-mers on the host",
+                "config": {"workload": "configs[3] in miniature: %d traces of %d bases vs a %.0f Mb synthetic genome, k = 15, window = trace + 2 x 1000, "
+                                       "traces sharded over %d rank(s), k-mer table replicated" % (int(nt_all), mf, self.gn / 1e6, self.world)},
+                "data": "synthetic (GRCh38 chr22 is not available offline); host-staged buffers: upload of profiles / windows and download of results included",
+                "roofline": roof}
+        if self.world == 1 and cpu_sample > 0:
+            for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+                if p not in sys.path:
+                    sys.path.insert(0, p)
+            import pyoracle as orc
+            from concurrent.futures import ThreadPoolExecutor
+            pick = list(range(min(cpu_sample, len(ok))))
+
+            def one(k):  # sage.h:217-221, 258-260, 311 with a window that arrives oriented: two Gotoh calls and the trim
+                i = ok[k]
+                prof = self.profs[i]
+                win = self._win(i)
+                trimmed = np.ascontiguousarray(prof[:, 50:mf - 50])
+                pref = orc.create_profile_str(win)
+                sc1, btr1 = orc.gotoh_prof(trimmed, pref, 1, 0, SCORE)
+                r0, r1 = orc.create_alignment_prof(btr1, trimmed, pref)
+                ri, risize, pos_add, _ = orc.trim_reference_slice(r0, r1, 50, 50, len(win), bool(sd["forward"][i]))
+                sc2, btr2 = orc.gotoh_prof(prof, orc.create_profile_str(win[ri:ri + risize]), 1, 0, SCORE)
+                return sc2, btr2, pos_add
+            nthreads = usable_cores()
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=nthreads) as ex:
+                want = list(ex.map(one, pick))
+            cdt = time.perf_counter() - t0
+            okp = all(int(res["score_final"][k]) == w[0] and res["btr"][k] == w[1] and int(res["ref_pos"][k]) == w[2] for k, w in zip(pick, want))
+            line["cpu_baseline"] = {"value": round(len(pick) / cdt, 2), "unit": "traces/s (extend only; the seeding is host work in both)", "cores": min(nthreads, len(pick)),
+                                    "kind": "port", "sample": "%d of the same anchored traces through the oracle's two Gotoh calls + trimReferenceSlice, %.1f s" % (len(pick), cdt)}
+            line["parity_checked"] = {"traces": len(pick), "bit_identical": bool(okp)}
+        return line

@@ -257,8 +257,9 @@ class Genome:
         fn.restype = C.c_uint64
         return int(fn(self._h, bytes(pattern), C.c_size_t(len(pattern))))
 
-    def seed(self, consensus, trim_left=50, trim_right=50, min_support=3, maxindel=1000, nthreads=0):
-        """getReferenceSlice (fmindex.h:236-326) for a list of consensus strings -> dict of arrays + oriented windows"""
+    def seed(self, consensus, trim_left=50, trim_right=50, min_support=3, maxindel=1000, nthreads=0, raw=False):
+        """getReferenceSlice (fmindex.h:236-326) for a list of consensus strings -> dict of arrays + oriented windows
+        (`slices`: list of bytes; raw=True: `slices_2d` uint8 [n][cap] + `slice_len` instead, no per-trace copies)"""
         n = len(consensus)
         lens = np.array([len(c) for c in consensus], dtype=np.uint32)
         offs = np.zeros(max(n, 1), dtype=np.uint64)
@@ -276,5 +277,8 @@ class Genome:
                                    p(out["kmersupport"], C.c_uint32), p(out["pos"], C.c_uint32), p(out["contig"], C.c_uint32),
                                    slices.ctypes.data_as(C.c_char_p), C.c_uint64(cap), p(out["slice_len"], C.c_uint32))
         out = {k: v[:n] for k, v in out.items()}
-        out["slices"] = [slices[i, :out["slice_len"][i]].tobytes() for i in range(n)]
+        if raw:
+            out["slices_2d"] = slices
+        else:
+            out["slices"] = [slices[i, :out["slice_len"][i]].tobytes() for i in range(n)]
         return out

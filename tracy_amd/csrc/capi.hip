@@ -320,7 +320,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   if (limit == 0 && trace && stage == DP_PLAIN) {  // only the full-matrix traceback needs a workspace plan
     size_t fr = 0, tot = 0;
     HIP_TRY(hipMemGetInfo(&fr, &tot));
-    limit = (uint64_t)(fr * 0.70) + ctx->d_bits.cap;  // what is free now plus what this context already holds
+    limit = (uint64_t)(fr * 0.70 / ctx->mem_share) + ctx->d_bits.cap;  // this context's share of what is free now plus what it already holds
   } else if (limit == 0) {
     limit = ~0ull;
   }

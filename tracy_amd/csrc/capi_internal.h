@@ -78,6 +78,7 @@ struct tracyhip_ctx {
   // lanes: further contexts (own stream, own buffers) the batch pipelines split a call over, one host thread each
   // (tracyhip_set_lanes); this context is the first lane, empty = the pipelines run on it alone
   std::vector<tracyhip_ctx*> lanes;
+  uint32_t mem_share = 1;  // contexts planning workspace on this device at the same time (lanes of one call): each takes its share of what is free
   bool timing = false;
   bool no_narrow = false;  // TRACYHIP_NO_NARROW=1: force the int32 score kernel (A/B measurements)
   std::vector<Pending> pending;

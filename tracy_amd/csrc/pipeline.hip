@@ -344,7 +344,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       const bool have = ctx->d_ckpt.cap >= ck_tot * 4 + 64 && ctx->d_lastrow.cap >= lr_tot * 4 + 64 && ctx->d_band.cap >= (uint64_t)nt * ck.B * 64 * 8;
       size_t fr = 0, tot = 0;
       if (!have) HIP_TRY(hipMemGetInfo(&fr, &tot));  // (a driver call: skipped when the grow-only buffers already fit)
-      if (!have && need > (uint64_t)(fr * 0.8) + ctx->d_ckpt.cap + ctx->d_lastrow.cap + ctx->d_band.cap) use_band = false;
+      if (!have && need > (uint64_t)(fr * 0.8 / ctx->mem_share) + ctx->d_ckpt.cap + ctx->d_lastrow.cap + ctx->d_band.cap) use_band = false;
       else {
         HIP_TRY(ctx->d_ckpt.ensure(ck_tot * 4 + 64));
         HIP_TRY(ctx->d_lastrow.ensure(lr_tot * 4 + 64));
@@ -880,7 +880,10 @@ int run_lanes(tracyhip_ctx* ctx, uint32_t nt, Fn fn) {
   HIP_TRY(hipStreamSynchronize(ctx->stream));  // inputs the caller enqueued on the context's stream
   std::vector<tracyhip_ctx*> ctxs{ctx};
   ctxs.insert(ctxs.end(), ctx->lanes.begin(), ctx->lanes.end());
-  return run_chunks(ctxs, nt, fn);
+  for (auto* c : ctxs) c->mem_share = (uint32_t)ctxs.size();  // the lanes plan their workspaces concurrently, on one device
+  const int rc = run_chunks(ctxs, nt, fn);
+  for (auto* c : ctxs) c->mem_share = 1;
+  return rc;
 }
 constexpr uint32_t kMinLaneChunk = 64;  // below this a chunk cannot fill the device anyway
 

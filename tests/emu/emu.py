@@ -25,7 +25,7 @@ def lib():
     return _LIB
 
 
-def run(a1, a2, score, hfree, vfree, mode, K, trace=True, needle=False, revcomp=False, a1_view=None, narrow=False):
+def run(a1, a2, score, hfree, vfree, mode, K, trace=True, needle=False, revcomp=False, a1_view=None, narrow=False, screen=False):
     """a1/a2: bytes or float32 [6][len] arrays.  a1_view=(offset, m): use columns [offset, offset+m) of a1."""
     def prep(x):
         if isinstance(x, (bytes, bytearray)):
@@ -50,7 +50,7 @@ def run(a1, a2, score, hfree, vfree, mode, K, trace=True, needle=False, revcomp=
     ol = C.c_uint32(0)
     err = C.c_int32(0)
     rc = lib().emu_dp(int(needle), mode, K, int(trace), C.c_void_p(p1), m, s1, C.c_void_p(b2.ctypes.data), n, s2,
-                      (1 if revcomp else 0) | (0x100 if narrow else 0), *[int(x) for x in score], int(hfree), int(vfree), C.byref(sc), ops,
+                      (1 if revcomp else 0) | (0x100 if narrow else 0) | (0x200 if screen else 0), *[int(x) for x in score], int(hfree), int(vfree), C.byref(sc), ops,
                       C.byref(ol), C.byref(err))
     assert rc == 0
     return sc.value, (ops.raw[:ol.value] if trace else None), err.value
@@ -128,3 +128,16 @@ def run_origin(a1, a2, score, K, revcomp=False, table=False):
                           *[int(x) for x in score], C.byref(sc), p(ends, C.c_uint32))
     assert rc == 0
     return sc.value, int(ends[0]), int(ends[1])
+
+
+def screen_check(a, b, match, mismatch, nt):
+    """a, b: float32 [n][5] profile columns.  Returns (strips the screened score could not prove, proven strips whose int
+    differs from the exact float chain) -- SubProf::screen against SubProf::prepare (dp_kernels.h)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    assert a.shape == b.shape and a.shape[1] == 5
+    counts = (C.c_uint64 * 2)()
+    rc = lib().emu_screen_check(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_uint64(a.shape[0]), int(match), int(mismatch),
+                                int(nt), counts)
+    assert rc == 0
+    return int(counts[0]), int(counts[1])

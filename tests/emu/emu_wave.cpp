@@ -145,6 +145,23 @@ static std::vector<uint8_t> padded_codes(const void* a2, size_t bytes) {
   return v;
 }
 
+// The screened profile x profile substitution score (SubProf::screen) against the exact chain (SubProf::prepare) on n column
+// pairs (a, b: n x 5 floats).  counts[0] = strips the screen could not prove, counts[1] = proven strips whose int differs
+// from the exact one (must stay 0).
+template <int NT>
+static void screen_check(const float* a, const float* b, uint64_t n, float fmatch, float fmis, uint64_t* counts) {
+  for (uint64_t j = 0; j < n; ++j) {
+    SubProf<1, NT> s;
+    for (int k = 0; k < 5; ++k) { s.a[0][k] = a[5 * j + k]; s.b[k] = b[5 * j + k]; }
+    s.fmatch = fmatch; s.fmis = fmis; s.shift = 0;
+    s.screen_setup();
+    const int32_t bad = s.screen();
+    const int32_t fast = s.sv[0];
+    s.prepare();
+    if (bad < 0) ++counts[0];
+    else if (fast != s.sv[0]) ++counts[1];
+  }
+}
 extern "C" {
 // prefix bound of up to 64 / kPrefixLanes pairs in one wave: pair i has profile a1 + a1_off[i] (m[i] columns, row stride
 // m[i]) and reference codes a2 + a2_off[i] (n[i] bytes, already encoded with base_code); flags[i] & 1 = reverse complement
@@ -245,6 +262,13 @@ int emu_band(int mode, int K, int narrow, uint32_t B, const void* a1, uint32_t m
   return 0;
 }
 
+int emu_screen_check(const float* a, const float* b, uint64_t n, int32_t match, int32_t mismatch, int nt, uint64_t* counts) {
+  counts[0] = counts[1] = 0;
+  if (nt == 4) screen_check<4>(a, b, n, (float)match, (float)mismatch, counts);
+  else screen_check<5>(a, b, n, (float)match, (float)mismatch, counts);
+  return 0;
+}
+
 // One pair through the kernel bodies.  a1/a2: bytes (CHAR) or float[6][len] (PROFILE side of the mode).
 // Returns 0 on success; score/ops (push order)/ops_len are outputs; ops may be null for score-only.
 int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, uint32_t a1_stride, const void* a2,
@@ -266,6 +290,14 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
   a.scratch = scratch.data(); a.scores = score; a.err = &err;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = hfree; a.vfree = vfree;
   *score = 0x7fffffff;
+  std::vector<uint8_t> colclass;
+  if (flags & 0x200u) {  // profile x profile: screened substitution scores
+    a.screen = 1;
+    d.flags &= ~0x200u;
+    colclass.resize(n + 1);
+    for (uint32_t j = 0; j < n; ++j) colclass[j] = (uint8_t)column_class(static_cast<const float*>(a2), a2_stride, j);
+    a.colcode = colclass.data();
+  }
   if (flags & 0x100u) {  // 16-bit score-only kernel
     d.flags &= 0xffu;
     switch (K) {

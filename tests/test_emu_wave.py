@@ -111,6 +111,75 @@ def test_profile_profile_mode(K):
     assert (got[0], got[1]) == want
 
 
+def screen_columns(rng, n, kind, nt):
+    """profile columns [n][5] (rows A C G T N) of mass <= 1.001"""
+    c = np.zeros((n, 5), dtype=np.float32)
+    if kind == "trace":  # createProfile (profile.h:22-52): called bases share normfac, the rest gets (1 - normfac) / 4
+        sig = rng.random((n, 4)).astype(np.float32) ** 8
+        sig[np.arange(n), rng.integers(0, 4, n)] += 1.0
+        called = sig >= 0.33 * sig.max(axis=1, keepdims=True)
+        tot = (sig * called).sum(axis=1, keepdims=True)
+        normfac = (tot / sig.sum(axis=1, keepdims=True)).astype(np.float32)
+        c[:, :4] = normfac * (sig * called / tot) + (np.float32(1) - normfac) * np.float32(0.25)
+    elif kind == "dyadic":  # sixteenths: products and sums are exact, scores sit on or near integers
+        k = rng.multinomial(16, [0.25] * nt, size=n)
+        c[:, :nt] = k / 16.0
+    elif kind == "onehot":
+        c[np.arange(n), rng.integers(0, nt, n)] = 1.0
+    elif kind == "uniform":
+        c[:, :4] = 0.25
+    elif kind == "heavy":  # up to the admitted mass
+        x = rng.random((n, nt)).astype(np.float32) ** 3
+        c[:, :nt] = x / x.sum(axis=1, keepdims=True) * np.float32(1.0009)
+    else:  # consensus-like: averages over a few sequences, weight on N for nt = 5
+        x = rng.integers(0, 6, (n, nt)).astype(np.float32)
+        x[:, 0] += 1
+        c[:, :nt] = x / x.sum(axis=1, keepdims=True)
+    return c
+
+
+def test_screened_profile_score_never_differs():
+    """SubProf::screen: whenever the short form claims trunc(score), it IS the int of the 25-term float chain (align.h:112-117)"""
+    rng = np.random.default_rng(2718)
+    n = 60000
+    for nt in (4, 5):
+        kinds = ["trace", "dyadic", "onehot", "uniform", "heavy", "consensus"]
+        for ka in kinds:
+            for kb in ("trace", "dyadic", "onehot", "heavy"):
+                a, b = screen_columns(rng, n, ka, nt), screen_columns(rng, n, kb, nt)
+                for sc in ((3, -5), (5, -4), (1, -1), (1000, -1000), (2, 3), (0, 0), (-7, 11)):
+                    unproven, wrong = emu.screen_check(a, b, sc[0], sc[1], nt)
+                    assert wrong == 0, (nt, ka, kb, sc)
+                    if ka == "trace" and kb == "trace" and sc in ((3, -5), (5, -4), (1, -1)):
+                        assert unproven < n * 2e-3, (nt, sc, unproven)  # realistic columns almost never need the chain
+
+
+def test_profile_profile_screened_sweep():
+    """the sweep with screening on: same alignments -- screened strips, tabulated one-hot / uniform columns, slots that fall
+    back to the float chain, and the give-up switch (a profile of columns whose scores sit on integers)"""
+    rng = np.random.default_rng(99)
+
+    def mixed(k, kinds, nt=4):
+        cols = np.concatenate([screen_columns(rng, k, kd, nt) for kd in kinds])
+        cols = cols[rng.permutation(len(cols))[:k]]
+        return np.ascontiguousarray(np.vstack([cols.T, np.zeros((1, k), np.float32)]))
+
+    cases = [(mixed(33, ["trace"]), mixed(70, ["trace"])),
+             (mixed(100, ["trace", "onehot", "uniform"]), mixed(90, ["trace", "onehot", "uniform", "dyadic"])),
+             (mixed(70, ["onehot"]), mixed(130, ["onehot", "uniform"])),
+             (mixed(60, ["dyadic"]), mixed(200, ["dyadic"])),
+             (mixed(40, ["consensus", "onehot"], 5), mixed(75, ["consensus", "onehot", "trace"], 5)),
+             (mixed(600, ["trace", "onehot"]), mixed(90, ["trace", "uniform"]))]  # two passes at K = 8
+    for p1, p2 in cases:
+        for cfg in [(1, 0), (1, 1)]:
+            want = orc.gotoh_prof(p1, p2, cfg[0], cfg[1], SC)
+            got = emu.run(p1, p2, SC, cfg[0], cfg[1], emu.MODE_PROF, 8, trace=True, screen=True)
+            assert (got[0], got[1]) == want
+            assert emu.run(p1, p2, SC, cfg[0], cfg[1], emu.MODE_PROF, 8, trace=False, screen=True)[0] == want[0]
+    p1, p2 = cases[1]
+    assert emu.run(p1, p2, SC, 1, 1, emu.MODE_PROF, 4, trace=False, screen=True)[0] == orc.gotoh_prof(p1, p2, 1, 1, SC)[0]
+
+
 @pytest.mark.parametrize("K", [4, 16])
 def test_needle(K):
     sc = (5, -4, -10, -1)

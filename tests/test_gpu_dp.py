@@ -104,6 +104,47 @@ def test_gotoh_profile_profile(ctx):
             assert rows[i] == orc.create_alignment_prof(want[1], p1[i], p2[i])
 
 
+def special_profile(rng, n, kinds, nt=4):
+    """profile whose columns mix the classes the screened score treats differently (test_emu_wave.screen_columns)"""
+    from test_emu_wave import screen_columns
+    cols = np.concatenate([screen_columns(rng, n, kd, nt) for kd in kinds])
+    cols = cols[rng.permutation(len(cols))[:n]]
+    return np.ascontiguousarray(np.vstack([cols.T, np.zeros((1, n), np.float32)]))
+
+
+def test_profile_profile_screened_score(ctx, monkeypatch):
+    """profile x profile substitution scores come from the screened short form where it is proven, from per-row tables
+    against one-hot / uniform columns, and from the float chain otherwise (dp_kernels.h SubProf::screen): the oracle's
+    result in every mix, and the same as with screening switched off"""
+    import tracy_amd
+    rng = np.random.default_rng(77)
+    p1 = [special_profile(rng, 300, ["trace"]), special_profile(rng, 700, ["trace", "onehot", "uniform"]),
+          special_profile(rng, 120, ["onehot"]), special_profile(rng, 256, ["dyadic", "trace"]),
+          special_profile(rng, 90, ["consensus", "onehot"], 5), special_profile(rng, 1, ["trace"]),
+          special_profile(rng, 400, ["heavy", "trace"])]
+    p2 = [special_profile(rng, 420, ["trace"]), special_profile(rng, 500, ["trace", "onehot", "uniform", "dyadic"]),
+          special_profile(rng, 333, ["onehot", "uniform"]), special_profile(rng, 64, ["dyadic"]),
+          special_profile(rng, 210, ["consensus", "trace", "onehot"], 5), special_profile(rng, 70, ["onehot", "trace"]),
+          special_profile(rng, 300, ["heavy", "onehot"])]
+    monkeypatch.setenv("TRACYHIP_NO_SCREEN", "1")
+    plain = tracy_amd.Context(0)
+    monkeypatch.delenv("TRACYHIP_NO_SCREEN")
+    try:
+        for sc in (SC, (5, -4, -6, -1)):
+            for cfg in [(1, 0), (1, 1)]:
+                scores, btr = ctx.align(p1, p2, sc + cfg)
+                sc_only = ctx.score(p1, p2, sc + cfg)
+                ref_scores, ref_btr = plain.align(p1, p2, sc + cfg)
+                assert np.array_equal(scores, ref_scores) and btr == ref_btr
+                assert np.array_equal(sc_only, plain.score(p1, p2, sc + cfg))
+                for i in range(len(p1)):
+                    want = orc.gotoh_prof(p1[i], p2[i], cfg[0], cfg[1], sc)
+                    assert (int(scores[i]), btr[i]) == want, (i, sc, cfg)
+                    assert int(sc_only[i]) == want[0]
+    finally:
+        plain.close()
+
+
 def test_needle(ctx):
     sc = (5, -4, -10, -1)
     rng = np.random.default_rng(8)

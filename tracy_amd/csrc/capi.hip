@@ -103,12 +103,17 @@ __global__ void encode_kernel(const uint8_t* __restrict__ in, uint8_t* __restric
   if (i < n) out[i] = (uint8_t)dp_code(in[i]);
 }
 
-// profile x profile: is row 4 ('N') zero over a whole profile?  (NaN counts as non-zero.)  One wave per sequence.
+// profile x profile: is row 4 ('N') zero over a whole profile?  (NaN counts as non-zero.)  One wave per sequence.  colclass (a2 set
+// only): the class of every column (dp_kernels.h column_class), stored at the index of the column's row-0 element.
 struct Row4Desc { uint64_t off; uint32_t len, pad; };
-__global__ __launch_bounds__(64) void row4_zero_kernel(const Row4Desc* __restrict__ d, const float* __restrict__ data, uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(64) void row4_zero_kernel(const Row4Desc* __restrict__ d, const float* __restrict__ data, uint8_t* __restrict__ out,
+                                                       uint8_t* __restrict__ colclass) {
   const Row4Desc s = d[blockIdx.x];
   bool nz = false;
-  for (uint32_t j = threadIdx.x; j < s.len; j += 64) nz |= !(data[s.off + 4ull * s.len + j] == 0.0f);
+  for (uint32_t j = threadIdx.x; j < s.len; j += 64) {
+    nz |= !(data[s.off + 4ull * s.len + j] == 0.0f);
+    if (colclass) colclass[s.off + j] = (uint8_t)tracyhip::column_class(data + s.off, s.len, j);
+  }
   const unsigned long long any = __ballot(nz);
   if (threadIdx.x == 0) out[blockIdx.x] = any ? 0 : 1;
 }
@@ -381,6 +386,8 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge;
   a.hfree = prm->hfree; a.vfree = prm->vfree;
   a.qlimit = sub_limit(prm);
+  a.screen = ctx->no_screen ? 0 : 1;
+  a.colcode = pb.d_colclass;
   if (stage == DP_BAND && ctx->timing) {
     a.swept = reinterpret_cast<unsigned long long*>(static_cast<int32_t*>(ctx->d_err.p) + kErrSweptWord);
     HIP_TRY(hipMemsetAsync(a.swept, 0, sizeof(unsigned long long), st));
@@ -518,8 +525,15 @@ int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool 
     Row4Desc* dd = static_cast<Row4Desc*>(ctx->d_tmp[0].p);
     uint8_t* dz = reinterpret_cast<uint8_t*>(dd + hd.size());
     HIP_TRY(hipMemcpyAsync(dd, hd.data(), sizeof(Row4Desc) * hd.size(), hipMemcpyHostToDevice, ctx->stream));
-    if (n1) hipLaunchKernelGGL(row4_zero_kernel, dim3(n1), dim3(64), 0, ctx->stream, dd, static_cast<const float*>(pb.d_a1), dz);
-    if (n2) hipLaunchKernelGGL(row4_zero_kernel, dim3(n2), dim3(64), 0, ctx->stream, dd + n1, static_cast<const float*>(pb.d_a2), dz + n1);
+    // column classes of the a2 set for the screened substitution score (one byte per float of the set: indexed like row 0)
+    uint8_t* colclass = nullptr;
+    if (n2 && e2 && !ctx->no_screen) {
+      HIP_TRY(ctx->ensure_codes(e2, ctx->stream));
+      colclass = ctx->codes();
+      pb.d_colclass = colclass;
+    }
+    if (n1) hipLaunchKernelGGL(row4_zero_kernel, dim3(n1), dim3(64), 0, ctx->stream, dd, static_cast<const float*>(pb.d_a1), dz, (uint8_t*)nullptr);
+    if (n2) hipLaunchKernelGGL(row4_zero_kernel, dim3(n2), dim3(64), 0, ctx->stream, dd + n1, static_cast<const float*>(pb.d_a2), dz + n1, colclass);
     HIP_TRY(hipGetLastError());
     std::vector<uint8_t> hz(n1 + n2);
     HIP_TRY(hipMemcpyAsync(hz.data(), dz, hz.size(), hipMemcpyDeviceToHost, ctx->stream));
@@ -643,6 +657,7 @@ int tracyhip_create(int device, tracyhip_ctx** out) {
   }
   c->own_stream = c->stream;
   c->no_narrow = getenv("TRACYHIP_NO_NARROW") != nullptr;
+  c->no_screen = getenv("TRACYHIP_NO_SCREEN") != nullptr;
   *out = c;
   return TRACYHIP_OK;
 }
@@ -695,6 +710,7 @@ int tracyhip_set_lanes(tracyhip_ctx* c, uint32_t n) {
     l->ws_limit = c->ws_limit;
     l->timing = c->timing;
     l->no_narrow = c->no_narrow;
+    l->no_screen = c->no_screen;
     c->lanes.push_back(l);
   }
   return TRACYHIP_OK;

@@ -47,6 +47,7 @@ struct DpProblem {
   const void* d_a1 = nullptr;
   const void* d_a2 = nullptr;        // MODE_QP: encoded codes
   const void* d_a2_chars = nullptr;  // the raw a2 payload on the device
+  const uint8_t* d_colclass = nullptr;  // profile x profile: column classes of the a2 set (build_problem), or null
   std::vector<PairDesc> desc;
   std::vector<int> k;
 };
@@ -81,6 +82,7 @@ struct tracyhip_ctx {
   uint32_t mem_share = 1;  // contexts planning workspace on this device at the same time (lanes of one call): each takes its share of what is free
   bool timing = false;
   bool no_narrow = false;  // TRACYHIP_NO_NARROW=1: force the int32 score kernel (A/B measurements)
+  bool no_screen = false;  // TRACYHIP_NO_SCREEN=1: profile x profile scores by the full float chain only (A/B measurements)
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
   tracyhip_kernel_timing acc[TRACYHIP_TIMER_COUNT] = {};

@@ -70,6 +70,9 @@ struct DpArgs {
   int32_t qlimit;       // max(|match|, |mismatch|): what a substitution score of NORMALISED profiles cannot exceed.  The host-side
                         // range guards (narrow_ok, origin_ok, check_params) assume it; kernels report anything larger in err[1..3]
   int32_t hfree, vfree;
+  int32_t screen;       // profile x profile: substitution scores by the screened short form where it is proven (SubProf::screen)
+  const uint8_t* colcode;  // profile x profile: class of every a2 column, indexed like row 0 of the a2 buffer (column_class);
+                           // null = no screening
   int32_t* ckpt;        // wavefront checkpoints (score kernel writes, band traceback reads)
   int32_t* lastrow;     // last-row {H, E} per column
   uint64_t* band;       // band traceback: per-workgroup nibble words of the current band (ckpt_B * 64 words each)
@@ -122,6 +125,27 @@ TR_HD float column_mass(const float* p, uint64_t stride, uint32_t j) {
 #pragma unroll
   for (int k = 0; k < 5; ++k) { const float v = p[(uint64_t)k * stride + j]; s += v < 0.0f ? -v : v; }
   return s;
+}
+
+// Class of a profile column for the screened profile x profile score: 0..4 = one-hot column (1.0 in that row, +0 elsewhere:
+// _createProfile of a string, or a trace position whose other channels are silent), 5 = the uniform column createProfile
+// writes when a position has no signal (0.25 x 4, profile.h:39-40), 6 = anything else.  Against a column of class < 6 the
+// float chain of align.h:112-116 depends on the row only, so its int comes from a per-row table (gotoh_body).
+constexpr uint32_t kColClassOther = 6;
+TR_HD uint32_t column_class(const float* p, uint64_t stride, uint32_t j) {
+  uint32_t bits[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) bits[k] = (uint32_t)float_bits(p[(uint64_t)k * stride + j]);
+  uint32_t ones = 0, zeros = 0, quarters = 0, hot = 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    if (bits[k] == 0x3f800000u) { ++ones; hot = (uint32_t)k; }
+    if (bits[k] == 0u) ++zeros;
+    if (k < 4 && bits[k] == 0x3e800000u) ++quarters;
+  }
+  if (ones == 1u && zeros == 4u) return hot;
+  if (quarters == 4u && bits[4] == 0u) return 5u;
+  return kColClassOther;
 }
 
 // ---- substitution-score providers -------------------------------------------------------------
@@ -249,6 +273,51 @@ struct SubProf {
     for (int i = 0; i < K; ++i) sv[i] = (int32_t)((uint32_t)profile_score<NT>(a[i], b, fmatch, fmis) << shift);
 #endif
   }
+  // ---- screened evaluation -------------------------------------------------------------------------------------------
+  // The reference truncates its float sum R to an int (align.h:117), so all that is needed of R is trunc(R).  In exact
+  // arithmetic the 25 terms collapse to  T = sum_k a_k e_k  with  e_k = (match - mismatch) b_k + mismatch (sum b): NT fused
+  // multiply-adds per cell once the column's e_k are known.  Rounding keeps both R and that short form within a proven
+  // distance of T (u = 2^-24, Q = max(|match|, |mismatch|), M = (column mass of a) (column mass of b) <= 1.001^2 -- gotoh_body
+  // only screens pairs whose masses it has verified):
+  //     |R - T| <= gamma_27 Q M    (25 products of three factors rounded twice, 24 rounded additions)
+  //     |x - T| <= 23 u Q M        (sum b, mismatch * sum, NT fmas for e_k: 8 u Q M;  NT fmas of the chain over partial sums
+  //                                 <= 3 Q M: 15 u Q M)
+  // With delta = 96 u Q > 50.2 u Q the interval [x - delta, x + delta] holds R; when it holds no integer, trunc(x) ==
+  // trunc(R) and the chain is not needed.  The fma chain starts from +delta, so the test is  fract(x + delta) >= 2 delta
+  // (one v_fract, one subtract, the sign bits of the strip OR-ed together).  A strip that fails the test in some lane is
+  // evaluated by the float chain (prepare()): the result is the reference's int either way.
+  float fdelta, fD;
+  TR_HD void screen_setup() {
+    const float q = __builtin_fmaxf(__builtin_fabsf(fmatch), __builtin_fabsf(fmis));
+    fdelta = 96.0f * 5.9604644775390625e-08f * __builtin_fmaxf(q, 1.0f);
+    fD = fmatch - fmis;
+  }
+  // fills sv[]; the sign bit of the result is set when some truncation of this strip is not proven
+  TR_HD int32_t screen() {
+    float s2 = b[0];
+#pragma unroll
+    for (int k = 1; k < NT; ++k) s2 += b[k];
+    const float ms = fmis * s2;
+    float e[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) e[k] = __builtin_fmaf(fD, b[k], ms);
+    const float two_delta = 2.0f * fdelta;
+    int32_t bad = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      float x = __builtin_fmaf(a[i][0], e[0], fdelta);
+#pragma unroll
+      for (int k = 1; k < NT; ++k) x = __builtin_fmaf(a[i][k], e[k], x);
+      sv[i] = (int32_t)((uint32_t)(int32_t)x << shift);
+#if defined(__HIP_DEVICE_COMPILE__)
+      const float g = __builtin_amdgcn_fractf(x) - two_delta;
+#else
+      const float g = (x - __builtin_floorf(x)) - two_delta;
+#endif
+      bad |= float_bits(g);
+    }
+    return bad;
+  }
   TR_HD int32_t operator()(int i) const { return sv[i]; }
   TR_HD int32_t lo16(int i) const { return sv[i]; }
 };
@@ -259,7 +328,8 @@ TR_HD constexpr uint32_t needle_lds_bytes(int mode, int K) { return mode == MODE
 TR_HD constexpr uint32_t lds_bytes(int mode, int K) {
   // 6 code rows x 64 lanes x qp_stride(K) int16: what the 16-bit sweep (gotoh_narrow_qp_body) lays out; the other QP kernels use
   // five rows + one shared zero strip of it.  MODE_PROF keeps its rows in registers.
-  return qp_like(mode) ? 6u * 64u * (uint32_t)qp_stride(K) * 2u : 0u;
+  // MODE_PROF: the same table shape holds the ints of the float chain against one-hot / uniform columns (column_class)
+  return (qp_like(mode) || mode == MODE_PROF) ? 6u * 64u * (uint32_t)qp_stride(K) * 2u : 0u;
 }
 
 // MODE_QP sweeps read the code buffer up to kCodeBias bytes before / behind a sequence (idle lanes, look-ahead)
@@ -317,7 +387,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   int16_t* qp_tab = reinterpret_cast<int16_t*>(w.lds());
   const float fmatch = (float)a.match, fmis = (float)a.mismatch;
   // profile x profile: is row 4 ('N') zero in both profiles?  (NaN counts as non-zero.)
-  bool skip4 = false;
+  bool skip4 = false, screen_pair = false;
   if (MODE == MODE_PROF) {
     bool nz = false;
     float ma = 0.0f, mb = 0.0f;
@@ -326,6 +396,8 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     skip4 = (NT == 4) || (NT == 0 && w.ballot(nz) == 0);
     report_mass(a.err, 2, ma);
     report_mass(a.err, 3, mb);
+    // the screened substitution score (SubProf::screen) is proven for column masses <= 1.001 only
+    screen_pair = a.screen != 0 && a.colcode != nullptr && w.ballot(!(ma <= 1.001f) || !(mb <= 1.001f)) == 0;
   }
 
   const uint32_t P = num_passes(m, K);
@@ -430,13 +502,33 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     } else {
 #pragma unroll
       for (int i = 0; i < K; ++i) {
+        // slots beyond row m (unused lanes, the tail of the last strip) repeat row m: their cells are never read, and a row of
+        // zeros would score exactly 0 against every column -- an int the screen can never prove
         const uint32_t r = base + L * K + i + 1;
+        const uint32_t rr = (r <= m) ? r : m;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) sub_p.a[i][k] = (r <= m) ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+        for (int k = 0; k < 5; ++k) sub_p.a[i][k] = a1p[(uint64_t)k * d.a1_stride + (rr - 1)];
       }
       sub_p.fmatch = fmatch;
       sub_p.fmis = fmis;
       sub_p.shift = SH;
+      if (screen_pair) {
+        // the ints of the float chain against the column classes 0..5 (column_class), [class][row][lane] like the query profile:
+        // a one-hot column leaves the terms of its own row of weights (onehot_score), the uniform column is evaluated in full
+        w.sync();
+#pragma unroll 1
+        for (int i = 0; i < K; ++i) {  // from memory, not unrolled: the set-up must not dictate the kernel's register budget
+          const uint32_t r = base + L * K + i + 1;
+          float pr[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) pr[k] = (r <= m) ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+#pragma unroll
+          for (uint32_t b = 0; b < 5; ++b) qp_tab[qp6_index<K>(b, (uint32_t)i, L)] = (int16_t)onehot_score(pr, b, fmatch, fmis);
+          const float uni[5] = {0.25f, 0.25f, 0.25f, 0.25f, 0.0f};
+          qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)profile_score<5>(pr, uni, fmatch, fmis);
+        }
+        w.sync();
+      }
     }
 
     // ---- anti-diagonal sweep ----
@@ -555,13 +647,40 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
 #pragma unroll
           for (int k = 0; k < 5; ++k) nb[k] = a2p[(uint64_t)k * d.a2_stride + ci];
         }
+        // screen_on is wave-uniform: strips go through the screened score, and through the exact chain when some lane
+        // cannot prove a truncation; a pair that keeps failing (columns whose scores ARE integers: one-hot or uniform
+        // columns) stops screening
+        bool screen_on = screen_pair;
+        uint32_t nfail = 0;
+        const uint8_t* cls = screen_on ? a.colcode + d.a2_off : nullptr;
+        uint32_t ncls = kColClassOther;
+        if (screen_on) {
+          sub.screen_setup();
+          ncls = cls[col_at(1 - (int32_t)L)];
+        }
         for (uint32_t t = 1; t <= t_end; ++t) {
 #pragma unroll
           for (int k = 0; k < 5; ++k) sub.b[k] = nb[k];
+          const uint32_t ccls = ncls;
           const uint32_t ci = col_at((int32_t)t - (int32_t)L + 1);
 #pragma unroll
           for (int k = 0; k < 5; ++k) nb[k] = a2p[(uint64_t)k * d.a2_stride + ci];
-          sub.prepare();
+          if (screen_on) {
+            ncls = cls[ci];
+            int32_t bad = sub.screen();
+            if (ccls < kColClassOther) {  // one-hot / uniform column: the ints were tabulated per row at set-up
+              const int16_t* tp = qp_tab + qp6_index<K>(ccls, 0u, L);
+#pragma unroll
+              for (int i = 0; i < K; ++i) sub.sv[i] = (int32_t)((uint32_t)(int32_t)tp[i * 64] << SH);
+              bad = 0;
+            }
+            if (w.ballot(bad < 0) != 0) {  // rare: some truncation of this step is not proven -- the strip takes the float chain
+              sub.prepare();
+              if (++nfail > 64u && 2u * nfail > t) screen_on = false;
+            }
+          } else {
+            sub.prepare();
+          }
           do_step(t, sub);
         }
       };

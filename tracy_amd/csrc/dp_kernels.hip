@@ -207,8 +207,8 @@ static hipError_t launch_gotoh_narrow(int K, const DpArgs& a, uint32_t npairs, h
 template <bool TRACE, int NT>
 static hipError_t launch_prof_k(int K, const DpArgs& a, uint32_t npairs, hipStream_t s) {
   switch (K) {
-    case 4: hipLaunchKernelGGL((gotoh_prof_kernel<4, TRACE, NT>), dim3(npairs), dim3(64), 0, s, a); break;
-    case 8: hipLaunchKernelGGL((gotoh_prof_kernel<8, TRACE, NT>), dim3(npairs), dim3(64), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((gotoh_prof_kernel<4, TRACE, NT>), dim3(npairs), dim3(64), lds_bytes(MODE_PROF, 4) + lds_pad(), s, a); break;
+    case 8: hipLaunchKernelGGL((gotoh_prof_kernel<8, TRACE, NT>), dim3(npairs), dim3(64), lds_bytes(MODE_PROF, 8) + lds_pad(), s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -200,7 +200,8 @@ typedef struct {
 typedef struct {
   int32_t trim_left;
   int32_t trim_right;
-  int32_t maxindel;
+  int32_t maxindel;              /* 1 .. 4096; traces must hold fewer than 8192 basecalls (TRACYHIP_ERR_RANGE beyond: the scan
+                                  * tables of decomposeAlleles are LDS resident, two size classes) */
   int32_t madc;
 } tracyhip_decomp_params;
 

@@ -30,6 +30,14 @@ def rand_profile(rng, n, kind):
         j = rng.integers(0, n, size=max(1, n // 10))
         p[4, j] = np.float32(0.25)
         p[5, j] = np.float32(0.125)
+    if kind == 3 and n:  # columns whose scores sit on integers: one-hot, uniform, sixteenths (the screened profile score's hard cases)
+        j = rng.integers(0, n, size=max(1, n // 3))
+        p[:4, j] = 0
+        p[rng.integers(0, 4, size=len(j)), j] = 1
+        j = rng.integers(0, n, size=max(1, n // 20))
+        p[:4, j] = np.float32(0.25)
+        j = rng.integers(0, n, size=max(1, n // 5))
+        p[:4, j] = (rng.multinomial(16, [0.25] * 4, size=len(j)).T / 16.0).astype(np.float32)
     return p
 
 
@@ -74,10 +82,10 @@ def run_campaign(pairs=1500, traces=96, lanes=1, seed=1, decompose_len=(700, 220
                     s1 = (related(rng, s2) + rand_seq(rng, m))[:m] if rng.random() < 0.7 else rand_seq(rng, m)
                     a1.append(s1); a2.append(s2)
                 elif mode == "qp":
-                    a1.append(rand_profile(rng, m, int(rng.integers(0, 2)))); a2.append(rand_seq(rng, n, b"ACGTACGTNn-x"))
+                    a1.append(rand_profile(rng, m, int(rng.choice([0, 1, 3])))); a2.append(rand_seq(rng, n, b"ACGTACGTNn-x"))
                 else:
                     m, n = min(m, 400), min(n, 400)
-                    a1.append(rand_profile(rng, m, int(rng.integers(0, 3)))); a2.append(rand_profile(rng, n, int(rng.integers(0, 3))))
+                    a1.append(rand_profile(rng, m, int(rng.integers(0, 4)))); a2.append(rand_profile(rng, n, int(rng.integers(0, 4))))
             scores, btr = ctx.align(a1, a2, sc + cfg)
             sonly = ctx.score(a1, a2, sc + cfg)
 

@@ -350,11 +350,14 @@ class AllPairsLeg:
         mf = self.mf
         cells = float(self.npairs) * mf * mf
         # 16-term body (row N zero in both profiles): per cell 16 x (mul, mul, add) fp32 + the Gotoh cell
-        roof = kernel_block("score", "gotoh_prof_kernel<8,score,NT=4> (16-term fp32 substitution score + Gotoh cell, profile x profile; 25-term twin for "
-                            "profiles with N / gap weight)", timers["score"], steps, flops_per_cell=48.0, traffic_key="gotoh_prof_kernel")
+        # 23.8 VALU lane-ops per reference cell: rocprofv3 SQ_INSTS_VALU x 64 / cells of the launch (profiles/rNN_pmc_valu_allpairs.json)
+        roof = kernel_block("score", "gotoh_prof_kernel<8,score,NT=4> (profile x profile Gotoh cell; substitution score = the int of the 16-term "
+                            "fp32 chain, taken from a screened 4-fma short form where a proven margin excludes every integer, from per-row "
+                            "tables against one-hot / uniform columns, from the chain itself otherwise; 25-term twin for profiles with N weight)",
+                            timers["score"], steps, ops_per_cell=23.8, traffic_key="gotoh_prof_kernel")
         line = {"metric": "GCUPS (all-pairs profile x profile gotohScore<true,true>, msa.h:33-42)", "value": round(cells * steps / dt / 1e9, 1), "unit": "GCUPS",
                 "pairs": int(self.npairs), "pairs_per_s": round(self.npairs * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
-                "warmup": warmup, "n_gpus": self.world, "scaling": "strong", "dtype": "f32 (substitution scores, rounded as align.h:112-116) / int32 (DP)",
+                "warmup": warmup, "n_gpus": self.world, "scaling": "strong", "dtype": "f32 (substitution scores: the ints of align.h:112-117) / int32 (DP)",
                 "config": {"workload": "configs[4]: %d traces of %d bases, %d pairs, pair list sharded over %d rank(s), profiles replicated, "
                                        "score slices all-gathered" % (self.ntr, mf, self.npairs, self.world), "traces": self.ntr, "trace_len": mf},
                 "data": "synthetic (profiles resident in HBM, index arrays on the host as the ABI defines)", "roofline": roof}

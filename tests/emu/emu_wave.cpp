@@ -55,7 +55,7 @@ struct HostWave {
   char* lds() { return sh->lds.data(); }
 };
 
-template <int K, int MODE, bool TRACE, bool NEEDLE, bool NARROW = false>
+template <int K, int MODE, bool TRACE, bool NEEDLE, bool NARROW = false, bool COMPACT = false>
 void run_wave(const DpArgs& a) {
   WaveShared sh;
   sh.lds.assign((qp_like(MODE) ? lds_bytes(MODE_QP, K) : needle_lds_bytes(MODE_PROF, K)) + 64, 0);
@@ -66,7 +66,7 @@ void run_wave(const DpArgs& a) {
       if constexpr (NEEDLE) {
         if constexpr (MODE != MODE_QP) needle_body<HostWave, K, MODE, TRACE>(w, a, 0);
       } else {
-        gotoh_body<HostWave, K, MODE, TRACE, NARROW>(w, a, 0);
+        gotoh_body<HostWave, K, MODE, TRACE, NARROW, false, 0, COMPACT>(w, a, 0);
       }
     });
   }
@@ -76,7 +76,10 @@ void run_wave(const DpArgs& a) {
 template <int K>
 void dispatch_narrow(int mode, const DpArgs& a) {
   if (mode == MODE_CHAR) run_wave<K, MODE_CHAR, false, false, true>(a);
-  else run_wave<K, MODE_QP, false, false, true>(a);
+  else {  // both forms of the 16-bit query-profile sweep, as the library launches them: exactly one of them takes the pair
+    run_wave<K, MODE_QP, false, false, true, true>(a);
+    run_wave<K, MODE_QP, false, false, true, false>(a);
+  }
 }
 
 template <int K, bool NEEDLE>
@@ -90,12 +93,16 @@ void dispatch(int mode, bool trace, const DpArgs& a) {
 
 template <int K, int MODE, bool NARROW>
 void run_ckpt_pair(const DpArgs& a, const WalkArgs& wa) {
-  {  // checkpointed score pass
+  for (int form = 0; form < ((NARROW && MODE == MODE_QP) ? 2 : 1); ++form) {  // checkpointed score pass (both forms of the 16-bit sweep)
     WaveShared sh;
     sh.lds.assign(lds_bytes(MODE_QP, K) + 64, 0);
     std::vector<std::thread> th;
     for (uint32_t l = 0; l < 64; ++l)
-      th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_body<HostWave, K, MODE, false, NARROW, true>(w, a, 0); });
+      th.emplace_back([&, l]() {
+        HostWave w{l, &sh};
+        if (form == 0) gotoh_body<HostWave, K, MODE, false, NARROW, true, 0, NARROW && MODE == MODE_QP>(w, a, 0);
+        else gotoh_body<HostWave, K, MODE, false, NARROW, true, 0, false>(w, a, 0);
+      });
     for (auto& t : th) t.join();
   }
   {  // band traceback
@@ -143,6 +150,13 @@ static std::vector<uint8_t> padded_codes(const void* a2, size_t bytes) {
   if (bytes) std::memcpy(v.data() + 128, a2, bytes);
   for (auto& c : v) if (c > 5) c = 5;  // as the library's encoders (dp_code)
   return v;
+}
+
+// DpArgs::special_blocks of a padded code buffer (codes start at v[128])
+static std::vector<uint8_t> special_blocks_of(const std::vector<uint8_t>& v, size_t n) {
+  std::vector<uint8_t> b((n >> 8) + 2, 0);
+  for (size_t i = 0; i < n; ++i) if (v[128 + i] >= 4) b[i >> 8] = 1;
+  return b;
 }
 
 // The screened profile x profile substitution score (SubProf::screen) against the exact chain (SubProf::prepare) on n column
@@ -241,7 +255,8 @@ int emu_band(int mode, int K, int narrow, uint32_t B, const void* a1, uint32_t m
   DpArgs a{};
   a.pairs = &d; a.a1 = a1; a.a2 = a2; a.scores = score; a.err = &err;
   std::vector<uint8_t> codes;
-  if (mode == MODE_QP) { codes = padded_codes(a2, n); a.a2 = codes.data() + 128; }
+  std::vector<uint8_t> special;
+  if (mode == MODE_QP) { codes = padded_codes(a2, n); a.a2 = codes.data() + 128; special = special_blocks_of(codes, n); a.special_blocks = special.data(); }
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = hfree; a.vfree = vfree;
   a.ckpt = ckpt.data(); a.lastrow = lastrow.data(); a.band = band.data(); a.ckpt_B = B; a.ckpt_narrow = narrow ? 1 : 0;
   uint64_t off = 0;
@@ -284,7 +299,8 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
   DpArgs a{};
   a.pairs = &d; a.a1 = a1; a.a2 = a2;
   std::vector<uint8_t> codes;
-  if (mode == MODE_QP && !needle) { codes = padded_codes(a2, n); a.a2 = codes.data() + 128; }
+  std::vector<uint8_t> special;
+  if (mode == MODE_QP && !needle) { codes = padded_codes(a2, n); a.a2 = codes.data() + 128; special = special_blocks_of(codes, n); a.special_blocks = special.data(); }
   if (mode == MODE_CQ) { codes = cq_codes(a2, n); a.a2 = codes.data() + 128; }
   a.bits = bits.data(); a.bits32 = reinterpret_cast<uint32_t*>(bits.data());
   a.scratch = scratch.data(); a.scores = score; a.err = &err;

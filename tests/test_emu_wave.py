@@ -211,6 +211,10 @@ def test_narrow_score_kernel(K):
     rng = np.random.default_rng(77 + K)
     for (m, n) in [(1, 40), (2, 7), (63, 300), (130 if K == 16 else 200, 90), (64 * K, 50), (64 * K - 5, 77)]:
         p1 = rand_profile(rng, m)
+        if m > 2:  # weight in row 4 ('N'): the entries of N columns are not a constant of the scoring then
+            j = rng.integers(0, m, size=max(1, m // 7))
+            p1[4, j] = p1[0, j]
+            p1[0, j] = 0
         ref = rand_seq(rng, n, b"ACGTACGTACGTNn-x")
         p2 = orc.create_profile_str(ref)
         want = orc.gotoh_score_prof(p1, p2, 1, 0, SC)
@@ -225,6 +229,25 @@ def test_narrow_score_kernel(K):
     assert emu.run(s1, s2, SC, 1, 0, emu.MODE_CHAR, K, trace=False, narrow=True)[0] == orc.gotoh_score_str(s1, s2, 1, 0, SC)
     sc2 = (5, -4, -10, -1)
     assert emu.run(s1, s1[:100] + s2, sc2, 1, 0, emu.MODE_CHAR, K, trace=False, narrow=True)[0] == orc.gotoh_score_str(s1, s1[:100] + s2, 1, 0, sc2)
+
+
+@pytest.mark.parametrize("K", [8, 15])
+def test_sweep16_compact_and_full_forms(K):
+    """the 16-bit query-profile sweep exists with a four-code table (references of A C G T) and a six-code one; the block map
+    of the encoders decides per pair.  Same scores / alignments from both, specials at either end of a 256-byte block"""
+    rng = np.random.default_rng(500 + K)
+    m, n = 20 * K, 520
+    p1 = rand_profile(rng, m)
+    base = rand_seq(rng, n, b"ACGT")
+    q = orc.create_profile_str(mutate(rng, base[100:100 + m], 0.05)[:m].ljust(m, b"A"))
+    for ref in (base, base[:255] + b"N" + base[256:], base[:256] + b"-" + base[257:], base[:n - 1] + b"n"):
+        for prof in ((p1, q) if ref is base else (q,)):
+            p2 = orc.create_profile_str(ref)
+            for rc in (False, True):
+                want = orc.gotoh_prof(prof, orc.revcomp_profile(p2) if rc else p2, 1, 0, SC)
+                assert emu.run(prof, ref, SC, 1, 0, emu.MODE_QP, K, trace=False, narrow=True, revcomp=rc)[0] == want[0]
+                got = emu.run_band(prof, ref, SC, 1, 0, emu.MODE_QP, K, B=64, narrow=True, revcomp=rc)
+                assert (got[0], got[1]) == want
 
 
 @pytest.mark.parametrize("K", [12, 15])

@@ -150,6 +150,8 @@ def test_decompose_traces_lanes(ctx):
     assert int((np.asarray(one["status"]) == 0).sum()) > nd // 2
     for k in one:
         a, b = one[k], many[k]
+        if k in ("dcp_indel", "dcp_err"):  # raw tables: rows past dstatus[t].dcp_n are unspecified ("dcp" holds the rows written)
+            continue
         if k == "bp":
             assert [(x.indelshift, x.traceleft, x.breakpoint, x.best_diff) for x in a] == [(x.indelshift, x.traceleft, x.breakpoint, x.best_diff) for x in b]
         elif isinstance(a, np.ndarray):

@@ -98,9 +98,13 @@ uint64_t seqset_extent(const tracyhip_seqset& s) {
 }  // namespace tracyhip
 
 // ---- small device helpers ------------------------------------------------------------------------
-__global__ void encode_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n) {
+__global__ void encode_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, uint8_t* __restrict__ special) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (uint8_t)dp_code(in[i]);
+  if (i < n) {
+    const uint32_t c = dp_code(in[i]);
+    out[i] = (uint8_t)c;
+    if (c >= 4u) special[i >> 8] = 1;  // N, '-' / other: rare (same value from every writer)
+  }
 }
 
 // profile x profile: is row 4 ('N') zero over a whole profile?  (NaN counts as non-zero.)  One wave per sequence.  colclass (a2 set
@@ -388,6 +392,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   a.qlimit = sub_limit(prm);
   a.screen = ctx->no_screen ? 0 : 1;
   a.colcode = pb.d_colclass;
+  if (pb.mode == MODE_QP && pb.d_a2 == ctx->codes() && !ctx->no_compact) a.special_blocks = ctx->special_blocks();
   if (stage == DP_BAND && ctx->timing) {
     a.swept = reinterpret_cast<unsigned long long*>(static_cast<int32_t*>(ctx->d_err.p) + kErrSweptWord);
     HIP_TRY(hipMemsetAsync(a.swept, 0, sizeof(unsigned long long), st));
@@ -509,7 +514,7 @@ int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool 
   if (pb.mode == MODE_QP && e2) {  // reference characters -> profile-row codes (align.h:121-136)
     HIP_TRY(ctx->ensure_codes(e2, ctx->stream));
     hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((e2 + 255) / 256)), dim3(256), 0, ctx->stream,
-                       static_cast<const uint8_t*>(pb.d_a2), ctx->codes(), e2);
+                       static_cast<const uint8_t*>(pb.d_a2), ctx->codes(), e2, ctx->special_blocks());
     HIP_TRY(hipGetLastError());
     pb.d_a2 = ctx->codes();
   }
@@ -592,6 +597,7 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   a.a1 = d_a1; a.a2 = d_a2; a.scores = d_scores; a.err = static_cast<int32_t*>(ctx->d_err.p);
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge; a.hfree = prm->hfree; a.vfree = prm->vfree;
   a.qlimit = sub_limit(prm);
+  if (d_a2 == ctx->codes() && !ctx->no_compact) a.special_blocks = ctx->special_blocks();
   a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.ckpt_narrow = 1;
   DpArgs af = a, ap = a;
   af.pairs = static_cast<const PairDesc*>(ctx->d_desc.p);
@@ -658,6 +664,7 @@ int tracyhip_create(int device, tracyhip_ctx** out) {
   c->own_stream = c->stream;
   c->no_narrow = getenv("TRACYHIP_NO_NARROW") != nullptr;
   c->no_screen = getenv("TRACYHIP_NO_SCREEN") != nullptr;
+  c->no_compact = getenv("TRACYHIP_NO_COMPACT") != nullptr;
   *out = c;
   return TRACYHIP_OK;
 }
@@ -711,6 +718,7 @@ int tracyhip_set_lanes(tracyhip_ctx* c, uint32_t n) {
     l->timing = c->timing;
     l->no_narrow = c->no_narrow;
     l->no_screen = c->no_screen;
+    l->no_compact = c->no_compact;
     c->lanes.push_back(l);
   }
   return TRACYHIP_OK;

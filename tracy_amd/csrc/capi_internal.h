@@ -61,15 +61,21 @@ struct tracyhip_ctx {
   uint64_t ws_limit = 0;
   tracyhip::DevBuf d_desc, d_bits, d_scratch, d_in1, d_in2, d_codes, d_scores, d_ops, d_ops_off, d_ops_len, d_err,
       d_rows0, d_rows1;
+  tracyhip::DevBuf d_special;
   tracyhip::DevBuf d_tmp[8];
   tracyhip::DevBuf d_pipe[64];
   tracyhip::DevBuf d_ckpt, d_lastrow, d_band;  // pipeline intermediates (align_traces / decompose)
   hipError_t ensure_codes(size_t bytes, hipStream_t st) {
     hipError_t e = d_codes.ensure(bytes + 2 * tracyhip::kCodePad);
     if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(d_codes.p, 5, tracyhip::kCodePad, st)) != hipSuccess) return e;
-    return hipMemsetAsync(static_cast<uint8_t*>(d_codes.p) + tracyhip::kCodePad + bytes, 5, tracyhip::kCodePad, st);
+    // pads hold code 0 ('A'): an ordinary column for every kernel
+    if ((e = hipMemsetAsync(d_codes.p, 0, tracyhip::kCodePad, st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(static_cast<uint8_t*>(d_codes.p) + tracyhip::kCodePad + bytes, 0, tracyhip::kCodePad, st)) != hipSuccess) return e;
+    // one byte per 256 code bytes: set by the encoders where a block holds an N or '-' / other code (DpArgs::special_blocks)
+    if ((e = d_special.ensure((bytes >> 8) + 2)) != hipSuccess) return e;
+    return hipMemsetAsync(d_special.p, 0, (bytes >> 8) + 2, st);
   }
+  uint8_t* special_blocks() const { return static_cast<uint8_t*>(d_special.p); }
   uint8_t* codes() const { return static_cast<uint8_t*>(d_codes.p) + tracyhip::kCodePad; }
   tracyhip::DevBuf d_aftab;                    // allelicFraction grid enumeration (trace independent)
   bool aftab_ready = false;
@@ -82,6 +88,7 @@ struct tracyhip_ctx {
   uint32_t mem_share = 1;  // contexts planning workspace on this device at the same time (lanes of one call): each takes its share of what is free
   bool timing = false;
   bool no_narrow = false;  // TRACYHIP_NO_NARROW=1: force the int32 score kernel (A/B measurements)
+  bool no_compact = false; // TRACYHIP_NO_COMPACT=1: every 16-bit sweep on the six-code table (A/B measurements)
   bool no_screen = false;  // TRACYHIP_NO_SCREEN=1: profile x profile scores by the full float chain only (A/B measurements)
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;

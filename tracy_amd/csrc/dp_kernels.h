@@ -71,6 +71,9 @@ struct DpArgs {
                         // range guards (narrow_ok, origin_ok, check_params) assume it; kernels report anything larger in err[1..3]
   int32_t hfree, vfree;
   int32_t screen;       // profile x profile: substitution scores by the screened short form where it is proven (SubProf::screen)
+  const uint8_t* special_blocks;  // MODE_QP: one byte per 256 code bytes of the a2 buffer, non-zero where the block holds an N or a
+                                  // '-' / other code (written by the encoders); null = unknown.  The 16-bit sweep exists in two
+                                  // forms (gotoh_narrow_qp_body): references without such codes take the one with the small table
   const uint8_t* colcode;  // profile x profile: class of every a2 column, indexed like row 0 of the a2 buffer (column_class);
                            // null = no screening
   int32_t* ckpt;        // wavefront checkpoints (score kernel writes, band traceback reads)
@@ -351,19 +354,19 @@ TR_HD uint64_t ckpt_index(uint32_t j /*1-based*/, uint32_t field, uint32_t lane,
   return ((uint64_t)(j - 1) * ckpt_fields(K) + field) * 64u + lane;
 }
 
-template <class W, int K, bool CKPT>
+template <class W, int K, bool CKPT, bool COMPACT>
 TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx);  // the 16-bit query-profile sweep, below
 
 // NT (profile x profile only): 5 = the 25-term substitution score, 4 = the 16-term one (row 4 zero in both profiles of every
 // pair of the launch: PAIR_ROW4_ZERO), 0 = decide per pair inside the kernel (both bodies in one kernel: more registers)
-template <class W, int K, int MODE, bool TRACE, bool NARROW = false, bool CKPT = false, int NT = 0>
+template <class W, int K, int MODE, bool TRACE, bool NARROW = false, bool CKPT = false, int NT = 0, bool COMPACT = false>
 TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   static_assert(!(NARROW && TRACE), "the 16-bit formulation exists for the score-only kernel");
   static_assert(!(CKPT && TRACE), "checkpoints are written by the score-only kernel");
   // NARROW / CKPT kernels: single pass, free end gaps on the first/last row only, rows anchored at the bottom
   constexpr bool BOTTOM = NARROW || CKPT;
   if constexpr (NARROW && MODE == MODE_QP) {  // the hot kernel of `tracy align` has its own body
-    gotoh_narrow_qp_body<W, K, CKPT>(w, a, pair_idx);
+    gotoh_narrow_qp_body<W, K, CKPT, COMPACT>(w, a, pair_idx);
     return;
   }
   const PairDesc d = a.pairs[pair_idx];
@@ -744,10 +747,27 @@ struct QpStrip {
   uint32_t v[K];  // row i in the low half (16-bit LDS reads zero the high half; the 16-bit ops ignore it)
   TR_HD int32_t lo16(int i) const { return (int32_t)v[i]; }
 };
+// The sweep's own table: int16 [NC codes][K rows][64 lanes].  NC = 6 (A C G T N, '-' / other) is 11.3 KB at K = 15; references
+// that hold A C G T only -- almost all of them -- take the COMPACT form of the kernel with NC = 4: 7.5 KB.  The table is
+// what decides how many waves a CU holds (LDS, not registers, is the limit), and this kernel needs them: one wave issues a
+// VALU instruction every ~4.5 cycles, a SIMD takes one every 2 (tools/ubench/clock_probe.hip).  13 -> 20 workgroups per CU:
+// 32.4 -> 28.2 ms per launch.
+template <int K>
+TR_HD constexpr uint32_t qpc_index(uint32_t code, uint32_t row, uint32_t lane) { return (code * (uint32_t)K + row) * 64u + lane; }
+TR_HD constexpr uint32_t lds_bytes_sweep16(int K, bool compact) { return (compact ? 4u : 6u) * (uint32_t)K * 64u * 2u; }
+// does the reference of this pair hold N / '-' / other codes?  (special_blocks: one byte per 256 code bytes.)  Wave-uniform.
+template <class W>
+TR_HD bool reference_is_plain(W& w, const DpArgs& a, const PairDesc& d) {
+  if (!a.special_blocks) return false;
+  if (d.n == 0) return true;
+  const uint64_t first = d.a2_off >> 8, last = (d.a2_off + d.n - 1) >> 8;
+  uint32_t seen = 0;
+  for (uint64_t b = first + w.lane(); b <= last; b += 64) seen |= a.special_blocks[b];
+  return w.ballot(seen != 0) == 0;
+}
 template <int K>
 TR_HD void qp_fetch6(const char* lane_col, uint32_t code, QpStrip<K>& q) {
-  constexpr uint32_t KP = qp_stride(K);
-  const char* p = lane_col + code * (KP * 64u * 2u);
+  const char* p = lane_col + code * ((uint32_t)K * 64u * 2u);
 #if defined(__HIP_DEVICE_COMPILE__)
   // Every LDS read of the sweep is issued by hand and waited for by hand (qp_wait6): one 16-bit read per row, so that no
   // cell needs its operand shifted into place (VALU work, which is what this kernel is short of), and no compiler
@@ -782,9 +802,12 @@ TR_HD void qp_wait6(QpStrip<K>& q) {
 TR_HD int32_t lastrow_h(const int32_t* lr, uint32_t c, bool narrow) { return narrow ? sext16(lr[c]) : lr[2 * c]; }
 TR_HD int32_t lastrow_e(const int32_t* lr, uint32_t c, bool narrow, int32_t goe) { return narrow ? (lr[c] >> 16) + goe : lr[2 * c + 1]; }
 
-template <class W, int K, bool CKPT>
+template <class W, int K, bool CKPT, bool COMPACT>
 TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const PairDesc d = a.pairs[pair_idx];
+  // both forms of the kernel are launched over the same pairs; each pair is swept by the one its reference calls for
+  if (reference_is_plain(w, a, d) != COMPACT) return;
+  constexpr uint32_t NC = COMPACT ? 4u : 6u;
   const uint32_t L = w.lane();
   const uint32_t m = d.m, n = d.n;
   const int32_t go = a.go, ge = a.ge, goe = go + ge;
@@ -792,7 +815,6 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     if (L == 0 && a.scores) a.scores[d.out] = (m == 0) ? 0 : edge_value(false, go, ge, (int32_t)m);
     return;
   }
-  constexpr uint32_t KP = qp_stride(K);
   const float* a1p = static_cast<const float*>(a.a1) + d.a1_off;
   const uint8_t* a2c = static_cast<const uint8_t*>(a.a2) + d.a2_off;
   int16_t* qp_tab = reinterpret_cast<int16_t*>(w.lds());
@@ -818,32 +840,34 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   asm volatile("" : "+v"(gev), "+v"(goev), "+v"(hext_last), "+v"(delta_last));  // four live VGPRs for the whole sweep, not re-materialised per step
 #endif
 
-  // ---- query profile: int16 [6][64 lanes][KP], entry = (int)(sum_k p[k][row] w[k][b]) - goe; row 5 and rows off the trace score 0 ----
+  // ---- query profile: int16 [NC][K][64 lanes] (qpc_index), entry = (int)(sum_k p[k][row] w[k][b]) - goe for b = A C G T (N);
+  // code 5 ('-' / other) and rows off the trace score 0 ----
   {
     bool overflow = false;
     int32_t qabs = 0;
 #pragma unroll 1
-    for (int i = 0; i < (int)KP; ++i) {
+    for (int i = 0; i < K; ++i) {  // (not unrolled: the set-up must not dictate the kernel's register budget)
       const uint32_t r = L * K + i + 1 - pad;
-      const bool real = (i < K) && (r - 1 < m);
+      const bool real = r - 1 < m;
       float pr[5];
 #pragma unroll
       for (int k = 0; k < 5; ++k) pr[k] = real ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
 #pragma unroll
-      for (uint32_t b = 0; b < 5; ++b) {
+      for (uint32_t b = 0; b < (COMPACT ? 4u : 5u); ++b) {
         const int32_t q = real ? onehot_score(pr, b, fmatch, fmis) : 0;
         const int32_t qs = q - goe;
         overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
         qabs = imax(qabs, q < 0 ? -q : q);
         const uint32_t row = (rcflag && b < 4u) ? 3u - b : b;  // reverse-complement view: the complement is folded into the table
-        qp_tab[qp6_index<K>(row, (uint32_t)i, L)] = (int16_t)qs;
+        qp_tab[qpc_index<K>(row, (uint32_t)i, L)] = (int16_t)qs;
       }
-      qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)(-goe);
+      if (!COMPACT) qp_tab[qpc_index<K>(5u, (uint32_t)i, L)] = (int16_t)(-goe);
     }
     if (overflow) flag_error(a.err, 1);
     if (qabs > a.qlimit) flag_max(a.err, 1, qabs);
     w.sync();
   }
+  (void)NC;
 
   // ---- sweep ----
   const char* strip = reinterpret_cast<const char*>(qp_tab) + L * 2u;  // this lane's column of the table

@@ -45,10 +45,11 @@ struct DeviceWave {
   }
 };
 
-template <int K, int MODE, bool TRACE, bool NARROW = false>
+// COMPACT (16-bit query-profile sweeps only): the form with the four-code table, for references of A C G T (gotoh_narrow_qp_body)
+template <int K, int MODE, bool TRACE, bool NARROW = false, bool COMPACT = false>
 __global__ __launch_bounds__(64) void gotoh_kernel(DpArgs a) {
   DeviceWave w;
-  gotoh_body<DeviceWave, K, MODE, TRACE, NARROW>(w, a, blockIdx.x);
+  gotoh_body<DeviceWave, K, MODE, TRACE, NARROW, false, 0, COMPACT>(w, a, blockIdx.x);
 }
 // profile x profile with the number of substitution terms fixed per launch (NT = 4: PAIR_ROW4_ZERO pairs, 5: the rest): one
 // body per kernel keeps the register count where four waves per SIMD fit
@@ -59,10 +60,10 @@ __global__ __launch_bounds__(64) void gotoh_prof_kernel(DpArgs a) {
 }
 
 // checkpointed score pass (wavefront checkpoints + last row) and the band traceback that consumes them
-template <int K, int MODE, bool NARROW>
+template <int K, int MODE, bool NARROW, bool COMPACT = false>
 __global__ __launch_bounds__(64) void gotoh_ckpt_kernel(DpArgs a) {
   DeviceWave w;
-  gotoh_body<DeviceWave, K, MODE, false, NARROW, true>(w, a, blockIdx.x);
+  gotoh_body<DeviceWave, K, MODE, false, NARROW, true, 0, COMPACT>(w, a, blockIdx.x);
 }
 // origin-tracking sweep (string x string): score + the two ends of the alignment, no traceback words
 template <int K, bool TABLE = false>
@@ -72,10 +73,10 @@ __global__ __launch_bounds__(64) void gotoh_origin_kernel(DpArgs a) {
 }
 // one launch, two kinds of workgroups: blocks [0, nfull) run the checkpointed 16-bit score sweep of `full`, the rest the
 // prefix bound of `pre` (GL lanes per pair) -- the short prefix workgroups fill the tail of the long sweeps
-template <int K, int GL>
+template <int K, int GL, bool COMPACT = false>
 __global__ __launch_bounds__(64) void gotoh_ckpt_prefix_kernel(DpArgs full, uint32_t nfull, DpArgs pre, uint32_t npre) {
   DeviceWave w;
-  if (blockIdx.x < nfull) gotoh_body<DeviceWave, K, MODE_QP, false, true, true>(w, full, blockIdx.x);
+  if (blockIdx.x < nfull) gotoh_body<DeviceWave, K, MODE_QP, false, true, true, 0, COMPACT>(w, full, blockIdx.x);
   else gotoh_prefix_body<DeviceWave, K, GL>(w, pre, (blockIdx.x - nfull) * (64u / GL), npre);
 }
 // prefix bound of the semiglobal score: GL lanes per pair, 64/GL pairs per workgroup
@@ -166,7 +167,15 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
 // ---- launchers ---------------------------------------------------------------------------------
 template <int K, int MODE, bool TRACE, bool NARROW = false>
 static hipError_t launch_gotoh_t(const DpArgs& a, uint32_t npairs, hipStream_t s) {
-  hipLaunchKernelGGL((gotoh_kernel<K, MODE, TRACE, NARROW>), dim3(npairs), dim3(64), lds_bytes(MODE, K), s, a);
+  if constexpr (NARROW && MODE == MODE_QP) {
+    // the 16-bit query-profile sweep: both forms over the same pairs, every pair is swept by the one its reference calls for
+    // (a workgroup of the other form leaves at once); without the block map only the six-code form knows what to do
+    if (a.special_blocks)
+      hipLaunchKernelGGL((gotoh_kernel<K, MODE, TRACE, true, true>), dim3(npairs), dim3(64), lds_bytes_sweep16(K, true) + lds_pad(), s, a);
+    hipLaunchKernelGGL((gotoh_kernel<K, MODE, TRACE, true, false>), dim3(npairs), dim3(64), lds_bytes_sweep16(K, false), s, a);
+  } else {
+    hipLaunchKernelGGL((gotoh_kernel<K, MODE, TRACE, NARROW>), dim3(npairs), dim3(64), lds_bytes(MODE, K), s, a);
+  }
   return hipGetLastError();
 }
 template <int K, int MODE, bool TRACE>
@@ -259,7 +268,11 @@ template <int MODE>
 static hipError_t launch_ckpt_m(int K, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s) {
 #define TRACY_CK(KK)                                                                                                   \
   case KK:                                                                                                              \
-    if (narrow) hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE, true>), dim3(npairs), dim3(64), lds_bytes(MODE, KK) + lds_pad(), s, a);  \
+    if (narrow && MODE == MODE_QP) {                                                                                    \
+      if (a.special_blocks)                                                                                             \
+        hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE, true, true>), dim3(npairs), dim3(64), lds_bytes_sweep16(KK, true) + lds_pad(), s, a); \
+      hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE, true, false>), dim3(npairs), dim3(64), lds_bytes_sweep16(KK, false), s, a);             \
+    } else if (narrow) hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE, true>), dim3(npairs), dim3(64), lds_bytes(MODE, KK), s, a);           \
     else hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE, false>), dim3(npairs), dim3(64), lds_bytes(MODE, KK), s, a);        \
     return hipGetLastError();
   switch (K) {
@@ -317,12 +330,26 @@ hipError_t launch_gotoh_origin(int K, bool table, const DpArgs& a, uint32_t npai
   return hipGetLastError();
 }
 
+// LDS of a launch that holds sweeps and prefix-bound workgroups: the larger of the two tables (the prefix kernel keeps five
+// per-lane code rows of qp_stride(K) entries and one shared zero strip)
+static constexpr uint32_t lds_combo(int K, bool compact) {
+  const uint32_t pre = 5u * 64u * (uint32_t)qp_stride(K) * 2u + (uint32_t)qp_stride(K) * 2u, sw = lds_bytes_sweep16(K, compact);
+  return pre > sw ? pre : sw;
+}
 hipError_t launch_gotoh_ckpt_prefix(int K, const DpArgs& full, uint32_t nfull, const DpArgs& pre, uint32_t npre, hipStream_t s) {
   if (nfull + npre == 0) return hipSuccess;
   constexpr int GL = kPrefixLanes;
   const dim3 grid(nfull + (npre + 64 / GL - 1) / (64 / GL));
-#define TRACY_COMBO_CASE(KK) \
-  case KK: hipLaunchKernelGGL((gotoh_ckpt_prefix_kernel<KK, GL>), grid, dim3(64), lds_bytes(MODE_QP, KK), s, full, nfull, pre, npre); break;
+  // the prefix workgroups ride with the compact form when there is one; the six-code form then runs over the full sweeps alone
+#define TRACY_COMBO_CASE(KK)                                                                                            \
+  case KK:                                                                                                              \
+    if (full.special_blocks) {                                                                                          \
+      hipLaunchKernelGGL((gotoh_ckpt_prefix_kernel<KK, GL, true>), grid, dim3(64), lds_combo(KK, true), s, full, nfull, pre, npre); \
+      if (nfull) hipLaunchKernelGGL((gotoh_ckpt_prefix_kernel<KK, GL, false>), dim3(nfull), dim3(64), lds_bytes_sweep16(KK, false), s, full, nfull, pre, 0u); \
+    } else {                                                                                                            \
+      hipLaunchKernelGGL((gotoh_ckpt_prefix_kernel<KK, GL, false>), grid, dim3(64), lds_combo(KK, false), s, full, nfull, pre, npre); \
+    }                                                                                                                   \
+    break;
   switch (K) {
     TRACY_COMBO_CASE(4) TRACY_COMBO_CASE(8) TRACY_COMBO_CASE(12) TRACY_COMBO_CASE(15) TRACY_COMBO_CASE(16)
     default: return hipErrorInvalidValue;
@@ -336,7 +363,7 @@ hipError_t launch_gotoh_prefix(int K, const DpArgs& a, uint32_t npairs, hipStrea
   constexpr int GL = kPrefixLanes;
   const dim3 grid((npairs + 64 / GL - 1) / (64 / GL));
 #define TRACY_PREFIX_CASE(KK) \
-  case KK: hipLaunchKernelGGL((gotoh_prefix_kernel<KK, GL>), grid, dim3(64), lds_bytes(MODE_QP, KK), s, a, npairs); break;
+  case KK: hipLaunchKernelGGL((gotoh_prefix_kernel<KK, GL>), grid, dim3(64), lds_combo(KK, true), s, a, npairs); break;
   switch (K) {
     TRACY_PREFIX_CASE(4) TRACY_PREFIX_CASE(8) TRACY_PREFIX_CASE(12) TRACY_PREFIX_CASE(15) TRACY_PREFIX_CASE(16)
     default: return hipErrorInvalidValue;

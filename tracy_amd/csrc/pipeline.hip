@@ -202,9 +202,13 @@ __global__ void cq_rows_kernel(const uint8_t* __restrict__ in, uint64_t n, int32
   if (i < n && !cq_row_char(in[i])) atomicOr(flag, 1);
 }
 
-__global__ void encode_codes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n) {
+__global__ void encode_codes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, uint8_t* __restrict__ special) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (uint8_t)dp_code(in[i]);
+  if (i < n) {
+    const uint32_t c = dp_code(in[i]);
+    out[i] = (uint8_t)c;
+    if (c >= 4u) special[i >> 8] = 1;  // N, '-' / other: rare (same value from every writer)
+  }
 }
 
 template <class T>
@@ -665,7 +669,7 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
     if (!job->oriented)
       hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er, d_verr);
     hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
-                       ctx->codes(), er);
+                       ctx->codes(), er, ctx->special_blocks());
     HIP_TRY(hipGetLastError());
   }
   // ---- geometry per trace ----
@@ -1068,7 +1072,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     if (!job->oriented)  // as in tracyhip_align_traces: caller-oriented windows are taken as they are
       hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er, d_verr);
     hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
-                       ctx->codes(), er);
+                       ctx->codes(), er, ctx->special_blocks());
     HIP_TRY(hipGetLastError());
     int32_t herr = 0;
     HIP_TRY(hipMemcpyAsync(&herr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));

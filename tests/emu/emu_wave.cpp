@@ -115,13 +115,13 @@ void run_ckpt_pair(const DpArgs& a, const WalkArgs& wa) {
   }
 }
 
-template <int K, bool TABLE = false>
+template <int K, bool TABLE = false, bool COMPACT = false>
 void run_origin_wave(const DpArgs& a) {
   WaveShared sh;
   sh.lds.assign(lds_bytes(MODE_CQ, K) + 64, 0);
   std::vector<std::thread> th;
   for (uint32_t l = 0; l < 64; ++l)
-    th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_origin_body<HostWave, K, TABLE>(w, a, 0); });
+    th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_origin_body<HostWave, K, TABLE, COMPACT>(w, a, 0); });
   for (auto& t : th) t.join();
 }
 // MODE_CQ: case-sensitive codes of a string, padded like the library's code buffers
@@ -219,12 +219,14 @@ int emu_origin(int K, const uint8_t* a1, uint32_t m, const uint8_t* a2, uint32_t
     d.flags &= 0xffu;
     codes = cq_codes(a2, n);
     a.a2 = codes.data() + 128;
+    bool compact = true;  // the five-code table whenever the columns allow it, as the library chooses
+    for (uint32_t j = 0; j < n; ++j) compact = compact && codes[128 + j] < 5;
     switch (K) {
-      case 4: run_origin_wave<4, true>(a); break;
-      case 8: run_origin_wave<8, true>(a); break;
-      case 12: run_origin_wave<12, true>(a); break;
-      case 15: run_origin_wave<15, true>(a); break;
-      case 16: run_origin_wave<16, true>(a); break;
+      case 4: if (compact) run_origin_wave<4, true, true>(a); else run_origin_wave<4, true, false>(a); break;
+      case 8: if (compact) run_origin_wave<8, true, true>(a); else run_origin_wave<8, true, false>(a); break;
+      case 12: if (compact) run_origin_wave<12, true, true>(a); else run_origin_wave<12, true, false>(a); break;
+      case 15: if (compact) run_origin_wave<15, true, true>(a); else run_origin_wave<15, true, false>(a); break;
+      case 16: if (compact) run_origin_wave<16, true, true>(a); else run_origin_wave<16, true, false>(a); break;
       default: return -1;
     }
     return 0;

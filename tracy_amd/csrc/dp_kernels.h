@@ -175,7 +175,7 @@ TR_HD constexpr int qp_stride(int K) { return (K + 1) & ~1; }
 // per-row 16-bit reads of a wave are conflict-free (a per-lane strip layout costs an 8-way bank conflict on each of them).
 // Code 5 = '-' / any other letter.  (The prefix-bound kernel keeps per-lane strips + one shared zero strip: qp_lane / qp_fetch.)
 template <int K>
-TR_HD uint32_t qp6_index(uint32_t code, uint32_t row, uint32_t lane) { return (code * (uint32_t)qp_stride(K) + row) * 64u + lane; }
+TR_HD uint32_t qp6_index(uint32_t code, uint32_t row, uint32_t lane) { return (code * (uint32_t)K + row) * 64u + lane; }
 
 template <int K, bool NARROW = false>
 TR_HD void qp_load(const int16_t* tab, uint32_t code, uint32_t lane, SubTable<K>& s) {
@@ -211,7 +211,7 @@ struct SubRows {
 };
 template <int K, int SHIFT>
 TR_HD void qp_fetch_rows(const int16_t* lane_col, uint32_t code, SubRows<K, SHIFT>& q) {
-  const int16_t* p = lane_col + code * ((uint32_t)((K + 1) & ~1) * 64u);
+  const int16_t* p = lane_col + code * ((uint32_t)K * 64u);
 #pragma unroll
   for (int i = 0; i < K; ++i) q.sv[i] = p[i * 64];
 }
@@ -332,7 +332,7 @@ TR_HD constexpr uint32_t lds_bytes(int mode, int K) {
   // 6 code rows x 64 lanes x qp_stride(K) int16: what the 16-bit sweep (gotoh_narrow_qp_body) lays out; the other QP kernels use
   // five rows + one shared zero strip of it.  MODE_PROF keeps its rows in registers.
   // MODE_PROF: the same table shape holds the ints of the float chain against one-hot / uniform columns (column_class)
-  return (qp_like(mode) || mode == MODE_PROF) ? 6u * 64u * (uint32_t)qp_stride(K) * 2u : 0u;
+  return (qp_like(mode) || mode == MODE_PROF) ? 6u * 64u * (uint32_t)K * 2u : 0u;
 }
 
 // MODE_QP sweeps read the code buffer up to kCodeBias bytes before / behind a sequence (idle lanes, look-ahead)
@@ -1022,7 +1022,9 @@ constexpr int32_t kNegInfOrigin = -6000;
 
 // TABLE: the rows are over {A,C,G,T,N} and a2 holds case-sensitive codes (MODE_CQ): substitution scores come from the
 // [code][row][lane] table in LDS, one shift-add per cell instead of compare + select + add
-template <class W, int K, bool TABLE = false>
+// COMPACT (with TABLE): no column of the launch holds a character outside A C G T N (the caller knows: encode_cq_kernel), the
+// table has five code rows -- 9.4 KB instead of 11.3 KB at K = 15, which is the difference between 14 and 16 workgroups per CU
+template <class W, int K, bool TABLE = false, bool COMPACT = false>
 TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const PairDesc d = a.pairs[pair_idx];
   const uint32_t L = w.lane();
@@ -1073,7 +1075,7 @@ TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         const uint32_t row = (rcv && b < 4u) ? 3u - b : b;
         qp_tab[qp6_index<K>(row, (uint32_t)i, L)] = (int16_t)(real ? (rch == (uint8_t)"ACGTN"[b] ? a.match : a.mismatch) : 0);
       }
-      qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)(real ? a.mismatch : 0);
+      if (!COMPACT) qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)(real ? a.mismatch : 0);
     }
     w.sync();
   }

@@ -66,10 +66,10 @@ __global__ __launch_bounds__(64) void gotoh_ckpt_kernel(DpArgs a) {
   gotoh_body<DeviceWave, K, MODE, false, NARROW, true, 0, COMPACT>(w, a, blockIdx.x);
 }
 // origin-tracking sweep (string x string): score + the two ends of the alignment, no traceback words
-template <int K, bool TABLE = false>
+template <int K, bool TABLE = false, bool COMPACT = false>
 __global__ __launch_bounds__(64) void gotoh_origin_kernel(DpArgs a) {
   DeviceWave w;
-  gotoh_origin_body<DeviceWave, K, TABLE>(w, a, blockIdx.x);
+  gotoh_origin_body<DeviceWave, K, TABLE, COMPACT>(w, a, blockIdx.x);
 }
 // one launch, two kinds of workgroups: blocks [0, nfull) run the checkpointed 16-bit score sweep of `full`, the rest the
 // prefix bound of `pre` (GL lanes per pair) -- the short prefix workgroups fill the tail of the long sweeps
@@ -85,8 +85,10 @@ __global__ __launch_bounds__(64) void gotoh_prefix_kernel(DpArgs a, uint32_t npa
   DeviceWave w;
   gotoh_prefix_body<DeviceWave, K, GL>(w, a, blockIdx.x * (64u / GL), npairs);
 }
+// at least three waves per SIMD: the K = 15 / 16 instantiations would otherwise settle at 190-200 VGPRs and two waves, and a
+// wave issues a VALU instruction only every ~4.5 cycles (6-24 spilled registers outside the sweep: band traceback 5.5 -> 5.0 ms)
 template <int K, int MODE>
-__global__ __launch_bounds__(64) void gotoh_band_kernel(DpArgs a, WalkArgs wa) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void gotoh_band_kernel(DpArgs a, WalkArgs wa) {
   DeviceWave w;
   gotoh_band_trace_body<DeviceWave, K, MODE>(w, a, wa, blockIdx.x);
 }
@@ -306,17 +308,19 @@ hipError_t launch_band_trace(int mode, int K, const DpArgs& a, const WalkArgs& w
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_gotoh_origin(int K, bool table, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+hipError_t launch_gotoh_origin(int K, bool table, bool compact, const DpArgs& a, uint32_t npairs, hipStream_t s) {
   if (npairs == 0) return hipSuccess;
   if (table) {
+#define TRACY_ORIGIN_CASE(KK)                                                                                                          \
+  case KK:                                                                                                                              \
+    if (compact) hipLaunchKernelGGL((gotoh_origin_kernel<KK, true, true>), dim3(npairs), dim3(64), 5u * 64u * KK * 2u + lds_pad(), s, a); \
+    else hipLaunchKernelGGL((gotoh_origin_kernel<KK, true, false>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, KK), s, a);                 \
+    break;
     switch (K) {
-      case 4: hipLaunchKernelGGL((gotoh_origin_kernel<4, true>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, 4), s, a); break;
-      case 8: hipLaunchKernelGGL((gotoh_origin_kernel<8, true>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, 8), s, a); break;
-      case 12: hipLaunchKernelGGL((gotoh_origin_kernel<12, true>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, 12), s, a); break;
-      case 15: hipLaunchKernelGGL((gotoh_origin_kernel<15, true>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, 15), s, a); break;
-      case 16: hipLaunchKernelGGL((gotoh_origin_kernel<16, true>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, 16), s, a); break;
+      TRACY_ORIGIN_CASE(4) TRACY_ORIGIN_CASE(8) TRACY_ORIGIN_CASE(12) TRACY_ORIGIN_CASE(15) TRACY_ORIGIN_CASE(16)
       default: return hipErrorInvalidValue;
     }
+#undef TRACY_ORIGIN_CASE
     return hipGetLastError();
   }
   switch (K) {

@@ -115,13 +115,13 @@ void run_ckpt_pair(const DpArgs& a, const WalkArgs& wa) {
   }
 }
 
-template <int K, bool TABLE = false, bool COMPACT = false>
+template <int K, bool TABLE = false, int NC = 6>
 void run_origin_wave(const DpArgs& a) {
   WaveShared sh;
   sh.lds.assign(lds_bytes(MODE_CQ, K) + 64, 0);
   std::vector<std::thread> th;
   for (uint32_t l = 0; l < 64; ++l)
-    th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_origin_body<HostWave, K, TABLE, COMPACT>(w, a, 0); });
+    th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_origin_body<HostWave, K, TABLE, NC>(w, a, 0); });
   for (auto& t : th) t.join();
 }
 // MODE_CQ: case-sensitive codes of a string, padded like the library's code buffers
@@ -134,12 +134,18 @@ static std::vector<uint8_t> cq_codes(const void* a2, size_t bytes) {
 
 template <int K>
 void run_prefix_wave(const DpArgs& a, uint32_t npairs) {
-  WaveShared sh;
-  sh.lds.assign(lds_bytes(MODE_QP, K) + 64, 0);
-  std::vector<std::thread> th;
-  for (uint32_t l = 0; l < 64; ++l)
-    th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_prefix_body<HostWave, K, kPrefixLanes>(w, a, 0, npairs); });
-  for (auto& t : th) t.join();
+  for (int form = 0; form < 2; ++form) {  // both forms, as the library launches them: every group is worked on in one of them
+    WaveShared sh;
+    sh.lds.assign(lds_bytes_prefix(K, false) + 64, 0);
+    std::vector<std::thread> th;
+    for (uint32_t l = 0; l < 64; ++l)
+      th.emplace_back([&, l]() {
+        HostWave w{l, &sh};
+        if (form == 0) gotoh_prefix_body<HostWave, K, kPrefixLanes, true>(w, a, 0, npairs);
+        else gotoh_prefix_body<HostWave, K, kPrefixLanes, false>(w, a, 0, npairs);
+      });
+    for (auto& t : th) t.join();
+  }
 }
 
 // MODE_QP kernels read the code buffer without clamping (idle lanes, look-ahead): the library pads it (kCodePad in
@@ -193,6 +199,11 @@ int emu_prefix(int K, uint32_t npairs, const float* a1, const uint64_t* a1_off, 
   DpArgs a{};
   a.pairs = d.data(); a.a1 = a1; a.a2 = a2; a.scores = out; a.err = &err;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = 1; a.vfree = 0;
+  uint64_t extent = 0;
+  for (uint32_t i = 0; i < npairs; ++i) extent = std::max<uint64_t>(extent, a2_off[i] + n[i]);
+  std::vector<uint8_t> special((extent >> 8) + 2, 0);
+  for (uint64_t i = 0; i < extent; ++i) if (a2[i] >= 4) special[i >> 8] = 1;
+  a.special_blocks = special.data();
   switch (K) {
     case 4: run_prefix_wave<4>(a, npairs); break;
     case 8: run_prefix_wave<8>(a, npairs); break;
@@ -219,14 +230,14 @@ int emu_origin(int K, const uint8_t* a1, uint32_t m, const uint8_t* a2, uint32_t
     d.flags &= 0xffu;
     codes = cq_codes(a2, n);
     a.a2 = codes.data() + 128;
-    bool compact = true;  // the five-code table whenever the columns allow it, as the library chooses
-    for (uint32_t j = 0; j < n; ++j) compact = compact && codes[128 + j] < 5;
+    int ncodes = 4;  // the smallest table the columns allow, as the library chooses
+    for (uint32_t j = 0; j < n; ++j) ncodes = std::max(ncodes, codes[128 + j] >= 5 ? 6 : codes[128 + j] == 4 ? 5 : 4);
     switch (K) {
-      case 4: if (compact) run_origin_wave<4, true, true>(a); else run_origin_wave<4, true, false>(a); break;
-      case 8: if (compact) run_origin_wave<8, true, true>(a); else run_origin_wave<8, true, false>(a); break;
-      case 12: if (compact) run_origin_wave<12, true, true>(a); else run_origin_wave<12, true, false>(a); break;
-      case 15: if (compact) run_origin_wave<15, true, true>(a); else run_origin_wave<15, true, false>(a); break;
-      case 16: if (compact) run_origin_wave<16, true, true>(a); else run_origin_wave<16, true, false>(a); break;
+      case 4: if (ncodes == 4) run_origin_wave<4, true, 4>(a); else if (ncodes == 5) run_origin_wave<4, true, 5>(a); else run_origin_wave<4, true, 6>(a); break;
+      case 8: if (ncodes == 4) run_origin_wave<8, true, 4>(a); else if (ncodes == 5) run_origin_wave<8, true, 5>(a); else run_origin_wave<8, true, 6>(a); break;
+      case 12: if (ncodes == 4) run_origin_wave<12, true, 4>(a); else if (ncodes == 5) run_origin_wave<12, true, 5>(a); else run_origin_wave<12, true, 6>(a); break;
+      case 15: if (ncodes == 4) run_origin_wave<15, true, 4>(a); else if (ncodes == 5) run_origin_wave<15, true, 5>(a); else run_origin_wave<15, true, 6>(a); break;
+      case 16: if (ncodes == 4) run_origin_wave<16, true, 4>(a); else if (ncodes == 5) run_origin_wave<16, true, 5>(a); else run_origin_wave<16, true, 6>(a); break;
       default: return -1;
     }
     return 0;

@@ -437,7 +437,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
       if (stage == DP_PREFIX) {
         HIP_TRY(launch_gotoh_prefix(K, a, e - j, st));
       } else if (stage == DP_ORIGIN) {
-        HIP_TRY(launch_gotoh_origin(K, pb.mode == MODE_CQ, pb.cq_compact, a, e - j, st));
+        HIP_TRY(launch_gotoh_origin(K, pb.mode == MODE_CQ, pb.cq_codes, a, e - j, st));
       } else if (stage == DP_CKPT) {
         // one representation for the whole batch: the caller checks narrow_ok for the largest problem
         narrow = ck->narrow;

@@ -222,16 +222,18 @@ struct QpLane {
   const char* strip;
   const char* zero;
 };
-template <int K>
+// NCODES code rows (5: A C G T N; 4 where no column holds an N), then the zero strip
+template <int K, uint32_t NCODES = 5>
 TR_HD QpLane qp_lane(const int16_t* tab, uint32_t lane) {
   constexpr uint32_t KP = qp_stride(K);
   const char* t = reinterpret_cast<const char*>(tab);
-  return QpLane{t + lane * (KP * 2u), t + 5u * (64u * KP * 2u)};
+  return QpLane{t + lane * (KP * 2u), t + NCODES * (64u * KP * 2u)};
 }
-template <int K>
+TR_HD constexpr uint32_t lds_bytes_prefix(int K, bool compact) { return (compact ? 4u : 5u) * 64u * (uint32_t)qp_stride(K) * 2u + (uint32_t)qp_stride(K) * 2u; }
+template <int K, uint32_t NCODES = 5>
 TR_HD void qp_fetch(const QpLane& ql, uint32_t code, SubPacked<K>& q) {
   constexpr uint32_t KP = qp_stride(K);
-  const uint32_t* p = reinterpret_cast<const uint32_t*>((code < 5u) ? ql.strip + code * (64u * KP * 2u) : ql.zero);
+  const uint32_t* p = reinterpret_cast<const uint32_t*>((code < NCODES) ? ql.strip + code * (64u * KP * 2u) : ql.zero);
 #pragma unroll
   for (int j = 0; j < (int)KP / 2; ++j) q.pw[j] = p[j];
 }
@@ -1022,9 +1024,9 @@ constexpr int32_t kNegInfOrigin = -6000;
 
 // TABLE: the rows are over {A,C,G,T,N} and a2 holds case-sensitive codes (MODE_CQ): substitution scores come from the
 // [code][row][lane] table in LDS, one shift-add per cell instead of compare + select + add
-// COMPACT (with TABLE): no column of the launch holds a character outside A C G T N (the caller knows: encode_cq_kernel), the
-// table has five code rows -- 9.4 KB instead of 11.3 KB at K = 15, which is the difference between 14 and 16 workgroups per CU
-template <class W, int K, bool TABLE = false, bool COMPACT = false>
+// NC (with TABLE): code rows of the table.  The caller knows which characters the columns of the launch hold (encode_cq_kernel):
+// A C G T only -> 4 rows, with N -> 5, anything else -> 6.  7.5 / 9.4 / 11.3 KB at K = 15: 20 / 17 / 14 workgroups per CU.
+template <class W, int K, bool TABLE = false, int NC = 6>
 TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const PairDesc d = a.pairs[pair_idx];
   const uint32_t L = w.lane();
@@ -1071,11 +1073,11 @@ TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       const uint8_t rch = real ? a1c[r - 1] : 0;
       const bool rcv = (d.flags & PAIR_A2_REVCOMP) != 0;
 #pragma unroll
-      for (uint32_t b = 0; b < 5; ++b) {
+      for (uint32_t b = 0; b < (NC < 5 ? (uint32_t)NC : 5u); ++b) {
         const uint32_t row = (rcv && b < 4u) ? 3u - b : b;
         qp_tab[qp6_index<K>(row, (uint32_t)i, L)] = (int16_t)(real ? (rch == (uint8_t)"ACGTN"[b] ? a.match : a.mismatch) : 0);
       }
-      if (!COMPACT) qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)(real ? a.mismatch : 0);
+      if (NC > 5) qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)(real ? a.mismatch : 0);
     }
     w.sync();
   }
@@ -1176,15 +1178,25 @@ TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
 // ------------------------------------------------------------------------------------------------
 constexpr int kPrefixLanes = 8;  // lanes per pair of the prefix-bound kernel: rows 1 .. 8*K, eight pairs per wave
 
-template <class W, int K, int GL>
+// COMPACT: the form for references of A C G T (four code rows in LDS); as with the sweeps, both forms are launched over the
+// same pairs and every group of lanes works on its pair in the form the reference calls for (DpArgs::special_blocks)
+template <class W, int K, int GL, bool COMPACT = false>
 TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_t npairs) {
   static_assert(64 % GL == 0, "whole groups per wave");
+  constexpr uint32_t NCODES = COMPACT ? 4u : 5u;
   const uint32_t L = w.lane();
   const uint32_t Lg = L % GL;
   const uint32_t pair_idx = group_base + L / GL;
-  const bool valid = pair_idx < npairs;
+  bool valid = pair_idx < npairs;
   PairDesc d{};
   if (valid) d = a.pairs[pair_idx];
+  {
+    bool plain = a.special_blocks != nullptr;  // every lane of a group looks at its pair's blocks: the same answer in all of them
+    if (plain && valid && d.n)
+      for (uint64_t b = d.a2_off >> 8; b <= (d.a2_off + d.n - 1) >> 8; ++b) plain = plain && a.special_blocks[b] == 0;
+    valid = valid && plain == COMPACT;
+    if (w.ballot(valid) == 0) return;
+  }
   const uint32_t m = d.m, n = valid ? d.n : 0u;
   const int32_t go = a.go, ge = a.ge, goe = go + ge;
   const float fmatch = (float)a.match, fmis = (float)a.mismatch;
@@ -1226,7 +1238,7 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
 #pragma unroll
       for (int k = 0; k < 5; ++k) pr[k] = (valid && r - 1 < m) ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
 #pragma unroll
-      for (uint32_t b = 0; b < 5; ++b) {
+      for (uint32_t b = 0; b < NCODES; ++b) {
         const int32_t q = (valid && r - 1 < m) ? onehot_score(pr, b, fmatch, fmis) : 0;
         const int32_t qs = q - goe;
         overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
@@ -1234,7 +1246,7 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
         qp_tab[b * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)qs;
       }
     }
-    if (L < (uint32_t)qp_stride(K)) qp_tab[5 * (64 * qp_stride(K)) + L] = (int16_t)(-goe);
+    if (L < (uint32_t)qp_stride(K)) qp_tab[NCODES * (64 * qp_stride(K)) + L] = (int16_t)(-goe);
     if (overflow) flag_error(a.err, 1);
     if (qabs > a.qlimit) flag_max(a.err, 1, qabs);
     w.sync();
@@ -1274,13 +1286,13 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
     }
   };
   SubPacked<K> qa, qb;
-  const QpLane ql = qp_lane<K>(qp_tab, L);
-  qp_fetch<K>(ql, code_at(1 - (int32_t)Lg), qa);
+  const QpLane ql = qp_lane<K, NCODES>(qp_tab, L);
+  qp_fetch<K, NCODES>(ql, code_at(1 - (int32_t)Lg), qa);
   for (uint32_t t = 1; t <= t_end; t += 2) {
-    qp_fetch<K>(ql, code_at((int32_t)t - (int32_t)Lg + 1), qb);
+    qp_fetch<K, NCODES>(ql, code_at((int32_t)t - (int32_t)Lg + 1), qb);
     do_step(t, qa);
     if (t + 1 > t_end) break;
-    qp_fetch<K>(ql, code_at((int32_t)t - (int32_t)Lg + 2), qa);
+    qp_fetch<K, NCODES>(ql, code_at((int32_t)t - (int32_t)Lg + 2), qa);
     do_step(t + 1, qb);
   }
   if (valid && Lg == GL - 1 && a.scores) {

@@ -66,10 +66,10 @@ __global__ __launch_bounds__(64) void gotoh_ckpt_kernel(DpArgs a) {
   gotoh_body<DeviceWave, K, MODE, false, NARROW, true, 0, COMPACT>(w, a, blockIdx.x);
 }
 // origin-tracking sweep (string x string): score + the two ends of the alignment, no traceback words
-template <int K, bool TABLE = false, bool COMPACT = false>
+template <int K, bool TABLE = false, int NC = 6>
 __global__ __launch_bounds__(64) void gotoh_origin_kernel(DpArgs a) {
   DeviceWave w;
-  gotoh_origin_body<DeviceWave, K, TABLE, COMPACT>(w, a, blockIdx.x);
+  gotoh_origin_body<DeviceWave, K, TABLE, NC>(w, a, blockIdx.x);
 }
 // one launch, two kinds of workgroups: blocks [0, nfull) run the checkpointed 16-bit score sweep of `full`, the rest the
 // prefix bound of `pre` (GL lanes per pair) -- the short prefix workgroups fill the tail of the long sweeps
@@ -77,13 +77,13 @@ template <int K, int GL, bool COMPACT = false>
 __global__ __launch_bounds__(64) void gotoh_ckpt_prefix_kernel(DpArgs full, uint32_t nfull, DpArgs pre, uint32_t npre) {
   DeviceWave w;
   if (blockIdx.x < nfull) gotoh_body<DeviceWave, K, MODE_QP, false, true, true, 0, COMPACT>(w, full, blockIdx.x);
-  else gotoh_prefix_body<DeviceWave, K, GL>(w, pre, (blockIdx.x - nfull) * (64u / GL), npre);
+  else gotoh_prefix_body<DeviceWave, K, GL, COMPACT>(w, pre, (blockIdx.x - nfull) * (64u / GL), npre);
 }
 // prefix bound of the semiglobal score: GL lanes per pair, 64/GL pairs per workgroup
-template <int K, int GL>
+template <int K, int GL, bool COMPACT = false>
 __global__ __launch_bounds__(64) void gotoh_prefix_kernel(DpArgs a, uint32_t npairs) {
   DeviceWave w;
-  gotoh_prefix_body<DeviceWave, K, GL>(w, a, blockIdx.x * (64u / GL), npairs);
+  gotoh_prefix_body<DeviceWave, K, GL, COMPACT>(w, a, blockIdx.x * (64u / GL), npairs);
 }
 // at least three waves per SIMD: the K = 15 / 16 instantiations would otherwise settle at 190-200 VGPRs and two waves, and a
 // wave issues a VALU instruction only every ~4.5 cycles (6-24 spilled registers outside the sweep: band traceback 5.5 -> 5.0 ms)
@@ -308,13 +308,14 @@ hipError_t launch_band_trace(int mode, int K, const DpArgs& a, const WalkArgs& w
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_gotoh_origin(int K, bool table, bool compact, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+hipError_t launch_gotoh_origin(int K, bool table, int codes, const DpArgs& a, uint32_t npairs, hipStream_t s) {
   if (npairs == 0) return hipSuccess;
   if (table) {
 #define TRACY_ORIGIN_CASE(KK)                                                                                                          \
   case KK:                                                                                                                              \
-    if (compact) hipLaunchKernelGGL((gotoh_origin_kernel<KK, true, true>), dim3(npairs), dim3(64), 5u * 64u * KK * 2u + lds_pad(), s, a); \
-    else hipLaunchKernelGGL((gotoh_origin_kernel<KK, true, false>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, KK), s, a);                 \
+    if (codes <= 4) hipLaunchKernelGGL((gotoh_origin_kernel<KK, true, 4>), dim3(npairs), dim3(64), 4u * 64u * KK * 2u + lds_pad(), s, a);      \
+    else if (codes == 5) hipLaunchKernelGGL((gotoh_origin_kernel<KK, true, 5>), dim3(npairs), dim3(64), 5u * 64u * KK * 2u + lds_pad(), s, a); \
+    else hipLaunchKernelGGL((gotoh_origin_kernel<KK, true, 6>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, KK), s, a);                          \
     break;
     switch (K) {
       TRACY_ORIGIN_CASE(4) TRACY_ORIGIN_CASE(8) TRACY_ORIGIN_CASE(12) TRACY_ORIGIN_CASE(15) TRACY_ORIGIN_CASE(16)
@@ -334,22 +335,21 @@ hipError_t launch_gotoh_origin(int K, bool table, bool compact, const DpArgs& a,
   return hipGetLastError();
 }
 
-// LDS of a launch that holds sweeps and prefix-bound workgroups: the larger of the two tables (the prefix kernel keeps five
-// per-lane code rows of qp_stride(K) entries and one shared zero strip)
+// LDS of a launch that holds sweeps and prefix-bound workgroups: the larger of the two tables
 static constexpr uint32_t lds_combo(int K, bool compact) {
-  const uint32_t pre = 5u * 64u * (uint32_t)qp_stride(K) * 2u + (uint32_t)qp_stride(K) * 2u, sw = lds_bytes_sweep16(K, compact);
+  const uint32_t pre = lds_bytes_prefix(K, compact), sw = lds_bytes_sweep16(K, compact);
   return pre > sw ? pre : sw;
 }
 hipError_t launch_gotoh_ckpt_prefix(int K, const DpArgs& full, uint32_t nfull, const DpArgs& pre, uint32_t npre, hipStream_t s) {
   if (nfull + npre == 0) return hipSuccess;
   constexpr int GL = kPrefixLanes;
   const dim3 grid(nfull + (npre + 64 / GL - 1) / (64 / GL));
-  // the prefix workgroups ride with the compact form when there is one; the six-code form then runs over the full sweeps alone
+  // both forms over the same sweeps and prefix groups: each is worked on in the form its reference calls for
 #define TRACY_COMBO_CASE(KK)                                                                                            \
   case KK:                                                                                                              \
     if (full.special_blocks) {                                                                                          \
       hipLaunchKernelGGL((gotoh_ckpt_prefix_kernel<KK, GL, true>), grid, dim3(64), lds_combo(KK, true), s, full, nfull, pre, npre); \
-      if (nfull) hipLaunchKernelGGL((gotoh_ckpt_prefix_kernel<KK, GL, false>), dim3(nfull), dim3(64), lds_bytes_sweep16(KK, false), s, full, nfull, pre, 0u); \
+      hipLaunchKernelGGL((gotoh_ckpt_prefix_kernel<KK, GL, false>), grid, dim3(64), lds_combo(KK, false), s, full, nfull, pre, npre); \
     } else {                                                                                                            \
       hipLaunchKernelGGL((gotoh_ckpt_prefix_kernel<KK, GL, false>), grid, dim3(64), lds_combo(KK, false), s, full, nfull, pre, npre); \
     }                                                                                                                   \
@@ -367,7 +367,10 @@ hipError_t launch_gotoh_prefix(int K, const DpArgs& a, uint32_t npairs, hipStrea
   constexpr int GL = kPrefixLanes;
   const dim3 grid((npairs + 64 / GL - 1) / (64 / GL));
 #define TRACY_PREFIX_CASE(KK) \
-  case KK: hipLaunchKernelGGL((gotoh_prefix_kernel<KK, GL>), grid, dim3(64), lds_combo(KK, true), s, a, npairs); break;
+  case KK:                                                                                                                      \
+    if (a.special_blocks) hipLaunchKernelGGL((gotoh_prefix_kernel<KK, GL, true>), grid, dim3(64), lds_bytes_prefix(KK, true), s, a, npairs); \
+    hipLaunchKernelGGL((gotoh_prefix_kernel<KK, GL, false>), grid, dim3(64), lds_bytes_prefix(KK, false), s, a, npairs);                        \
+    break;
   switch (K) {
     TRACY_PREFIX_CASE(4) TRACY_PREFIX_CASE(8) TRACY_PREFIX_CASE(12) TRACY_PREFIX_CASE(15) TRACY_PREFIX_CASE(16)
     default: return hipErrorInvalidValue;

@@ -193,13 +193,13 @@ __global__ __launch_bounds__(64) void rowmax_rest_kernel(const RowMaxDesc* desc,
 
 // MODE_CQ (strings scored through the query-profile table): case-sensitive column codes, and the test that row strings hold
 // nothing but the five letters the table has entries for
-// flag |= 2 where a column is none of A C G T N (rare): the origin sweeps then keep the six-code table
+// flag |= 2 where a column is none of A C G T N, |= 4 where it is N (both rare): the origin sweeps size their table by it
 __global__ void encode_cq_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, int32_t* flag) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const uint32_t c = cq_code(in[i]);
     out[i] = (uint8_t)c;
-    if (c >= 5u) atomicOr(flag, 2);
+    if (c >= 4u) atomicOr(flag, c >= 5u ? 2 : 4);
   }
 }
 __global__ void cq_rows_kernel(const uint8_t* __restrict__ in, uint64_t n, int32_t* flag) {
@@ -1279,7 +1279,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   HIP_TRY(hipMemcpyAsync(h_hst.data(), b_hst.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   const bool use_cq = try_cq && (h_cq_flag & 1) == 0;
-  const bool cq_compact = use_cq && (h_cq_flag & 2) == 0;
+  const int cq_codes = (!use_cq || (h_cq_flag & 2)) ? 6 : (h_cq_flag & 4) ? 5 : 4;
   for (uint32_t t = 0; t < nt; ++t)
     if (h_status[t] == 0 && h_hst[t] != 1) h_status[t] = h_hst[t] == 0 ? -2 : -3;
 
@@ -1317,7 +1317,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     const void* seq = (k == 0) ? d_pri : d_sd;
     DpProblem pb;
     pb.mode = use_cq ? MODE_CQ : MODE_CHAR; pb.d_a1 = seq; pb.d_a2 = use_cq ? static_cast<const void*>(d_cq_ref) : d_ref;
-    pb.cq_compact = cq_compact && getenv("TRACYHIP_NO_COMPACT") == nullptr;
+    pb.cq_codes = getenv("TRACYHIP_NO_COMPACT") ? 6 : cq_codes;
     pb.desc.resize(nt); pb.k.resize(nt);
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc d{};

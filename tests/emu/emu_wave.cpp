@@ -76,7 +76,9 @@ void run_wave(const DpArgs& a) {
 template <int K>
 void dispatch_narrow(int mode, const DpArgs& a) {
   if (mode == MODE_CHAR) run_wave<K, MODE_CHAR, false, false, true>(a);
-  else {  // both forms of the 16-bit query-profile sweep, as the library launches them: exactly one of them takes the pair
+  else if (mode == MODE_PROF) {  // the profile x profile score kernel with 16-bit cells
+    if constexpr (K == 4 || K == 8) run_wave<K, MODE_PROF, false, false, false, true>(a);
+  } else {  // both forms of the 16-bit query-profile sweep, as the library launches them: exactly one of them takes the pair
     run_wave<K, MODE_QP, false, false, true, true>(a);
     run_wave<K, MODE_QP, false, false, true, false>(a);
   }

@@ -96,6 +96,11 @@ def test_profile_profile_mode(K):
             got = emu.run(p1, p2, SC, cfg[0], cfg[1], emu.MODE_PROF, K, trace=True)
             assert (got[0], got[1]) == want
             assert emu.run(p1, p2, SC, cfg[0], cfg[1], emu.MODE_PROF, K, trace=False)[0] == want[0]
+            # the score kernel with 16-bit cells (any AlignConfig, multi-pass strips), with and without the screened score
+            assert emu.run(p1, p2, SC, cfg[0], cfg[1], emu.MODE_PROF, K, trace=False, narrow=True)[0] == want[0]
+            assert emu.run(p1, p2, SC, cfg[0], cfg[1], emu.MODE_PROF, K, trace=False, narrow=True, screen=True)[0] == want[0]
+        for cfg in [(0, 0), (0, 1)]:
+            assert emu.run(p1, p2, SC, cfg[0], cfg[1], emu.MODE_PROF, K, trace=False, narrow=True)[0] == orc.gotoh_prof(p1, p2, cfg[0], cfg[1], SC)[0]
     # alignment profiles carry weight in rows 4 ('N') and 5 ('-'): the 25-term path (row 4 is not all zero)
     p1, p2 = rand_profile(rng, 40, sharp=False), rand_profile(rng, 55)
     p1[4, 7] = np.float32(0.25)

@@ -265,6 +265,17 @@ bool narrow_ok(const tracyhip_params* prm, uint32_t maxm, int K, int64_t Q) {
   return (low < -(int64_t)kNegInf16 - iabs64(prm->ge) - 64) && (high < 30000);
 }
 
+// profile x profile score kernel with 16-bit cells (any AlignConfig, any number of passes).  Every H, E, F of the matrix is at least
+// the score of the path "one vertical gap, then one horizontal gap" minus one more gap open, and at most min(m, n) substitution
+// scores; the sentinel (kNegInf16) has to lose against that and must not wrap when a gap cost is added to it once.
+bool arith16_ok(const tracyhip_params* prm, uint64_t max_mn, int64_t Q) {
+  if (prm->go > 0 || prm->ge > 0) return false;
+  Q = std::max<int64_t>(Q, sub_limit(prm));
+  const int64_t low = 3 * iabs64(prm->go) + ((int64_t)max_mn + 2) * iabs64(prm->ge) + Q;
+  const int64_t high = ((int64_t)max_mn / 2 + 1) * Q;
+  return low < -(int64_t)kNegInf16 - 1000 && iabs64(prm->go) + iabs64(prm->ge) < 10000 && high < 30000;
+}
+
 // origin-tracking sweep: string x string only, so substitution scores are match / mismatch exactly
 bool origin_ok(const tracyhip_params* prm, uint32_t maxm, uint32_t maxn, int K) {
   if (!prm->hfree || prm->vfree || prm->go > 0 || prm->ge >= 0 || num_passes(maxm ? maxm : 1, K) != 1) return false;
@@ -297,8 +308,8 @@ int range_verdict(const tracyhip_params* prm, const int32_t* herr, const std::ve
     seen = true;
   }
   if (!seen) return TRACYHIP_OK;
-  for (auto const& nl : narrow_launches)
-    if (!narrow_ok(prm, nl.first, nl.second, Q)) return kWiden;
+  for (auto const& nl : narrow_launches)  // (K = 0 marks a launch of the 16-bit profile x profile kernel: first = its largest m + n)
+    if (nl.second == 0 ? !arith16_ok(prm, nl.first, Q) : !narrow_ok(prm, nl.first, nl.second, Q)) return kWiden;
   const int64_t c = iabs64(prm->go) + iabs64(prm->ge) + Q;
   if ((int64_t)(max_mn + 2) * c + 1000000 >= (1ll << (31 - value_shift)))
     return set_error(TRACYHIP_ERR_RANGE, "un-normalised profile: (m+n) * (gap cost + largest substitution score %lld) exceeds the exact range of the int32 kernels",
@@ -447,8 +458,15 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
         WalkArgs wa{};
         wa.pairs = dd + j; wa.ops = d_ops; wa.ops_off = d_ops_off; wa.ops_len = d_ops_len; wa.err = a.err; wa.npairs = e - j; wa.K = K;
         HIP_TRY(launch_band_trace(pb.mode, K, a, wa, e - j, st));
-      } else if (!needle && pb.mode == MODE_PROF)
-        HIP_TRY(launch_gotoh_prof(K, trace, row4 != 0, a, e - j, st));
+      } else if (!needle && pb.mode == MODE_PROF) {
+        bool a16 = false;
+        if (!trace && !ctx->no_narrow) {
+          uint64_t mn = 0;
+          for (uint32_t q = j; q < e; ++q) mn = std::max<uint64_t>(mn, (uint64_t)hd[q].m + hd[q].n);
+          if ((a16 = arith16_ok(prm, mn, 0))) narrow_launches.emplace_back((uint32_t)mn, 0);
+        }
+        HIP_TRY(launch_gotoh_prof(K, trace, row4 != 0, a16, a, e - j, st));
+      }
       else
         HIP_TRY(needle ? launch_needle(pb.mode, K, trace, a, e - j, st) : launch_gotoh(pb.mode, K, trace, narrow, a, e - j, st));
       if ((trc = timing_end(ctx))) return trc;

@@ -361,9 +361,13 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx);  // t
 
 // NT (profile x profile only): 5 = the 25-term substitution score, 4 = the 16-term one (row 4 zero in both profiles of every
 // pair of the launch: PAIR_ROW4_ZERO), 0 = decide per pair inside the kernel (both bodies in one kernel: more registers)
+// COMPACT selects the second form of two kernels: the 16-bit query-profile sweep with the four-code table (NARROW, MODE_QP), and
+// the profile x profile score kernel with 16-bit cells (MODE_PROF, !TRACE: any AlignConfig, any number of passes; v_add_u16 /
+// v_max_i16 instead of int32 maxima, which issue at half the rate -- arith16_ok in capi.hip admits the launch)
 template <class W, int K, int MODE, bool TRACE, bool NARROW = false, bool CKPT = false, int NT = 0, bool COMPACT = false>
 TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   static_assert(!(NARROW && TRACE), "the 16-bit formulation exists for the score-only kernel");
+  constexpr bool A16 = MODE == MODE_PROF && !TRACE && !NARROW && !CKPT && COMPACT;
   static_assert(!(CKPT && TRACE), "checkpoints are written by the score-only kernel");
   // NARROW / CKPT kernels: single pass, free end gaps on the first/last row only, rows anchored at the bottom
   constexpr bool BOTTOM = NARROW || CKPT;
@@ -409,7 +413,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const uint32_t T = steps_per_pass(n);
   uint64_t* bits = TRACE ? a.bits + d.bits_off : nullptr;
   int32_t* scratch = a.scratch ? a.scratch + 2 * d.scratch_off : nullptr;
-  const int32_t neg = NARROW ? kNegInf16 : (int32_t)((uint32_t)kNegInf << SH);
+  const int32_t neg = (NARROW || A16) ? kNegInf16 : (int32_t)((uint32_t)kNegInf << SH);
 
   for (uint32_t p = 0; p < P; ++p) {
     const uint32_t base = p * 64u * K;  // rows base+1 .. base+64K
@@ -575,6 +579,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         uint32_t w0 = 0, w1 = 0;
         if (TRACE) trace_step<K>(ts, up_h, up_f, prev_up_h, trace_cy1(vopen), trace_cy2(vext), sub, w0, w1, nb_h, nb_f);
         else if (NARROW) score_step16g<K>(ss, up_h, up_f, prev_up_h, vext, goe, delta_last, sub, nb_h, nb_f);
+        else if (A16) score_step16<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub, nb_h, nb_f);
         else score_step<K>(ss, up_h, up_f, prev_up_h, vopen, vext, sub, nb_h, nb_f);
         prev_up_h = up_h;
         bot_h = nb_h;
@@ -713,7 +718,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         int32_t v = 0;
 #pragma unroll
         for (int i = 0; i < K; ++i)
-          if ((uint32_t)i == g % K) v = TRACE ? (ts.Hc[i] >> SH) : (NARROW ? sext16(ss.Hl[i]) : ss.Hl[i]);
+          if ((uint32_t)i == g % K) v = TRACE ? (ts.Hc[i] >> SH) : ((NARROW || A16) ? sext16(ss.Hl[i]) : ss.Hl[i]);
         a.scores[d.out] = v;
       }
     }

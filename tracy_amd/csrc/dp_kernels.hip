@@ -53,10 +53,11 @@ __global__ __launch_bounds__(64) void gotoh_kernel(DpArgs a) {
 }
 // profile x profile with the number of substitution terms fixed per launch (NT = 4: PAIR_ROW4_ZERO pairs, 5: the rest): one
 // body per kernel keeps the register count where four waves per SIMD fit
-template <int K, bool TRACE, int NT>
+// A16 (score kernels): 16-bit cell arithmetic (gotoh_body's second form for MODE_PROF)
+template <int K, bool TRACE, int NT, bool A16 = false>
 __global__ __launch_bounds__(64) void gotoh_prof_kernel(DpArgs a) {
   DeviceWave w;
-  gotoh_body<DeviceWave, K, MODE_PROF, TRACE, false, false, NT>(w, a, blockIdx.x);
+  gotoh_body<DeviceWave, K, MODE_PROF, TRACE, false, false, NT, A16>(w, a, blockIdx.x);
 }
 
 // checkpointed score pass (wavefront checkpoints + last row) and the band traceback that consumes them
@@ -215,18 +216,19 @@ static hipError_t launch_gotoh_narrow(int K, const DpArgs& a, uint32_t npairs, h
   }
 }
 
-template <bool TRACE, int NT>
+template <bool TRACE, int NT, bool A16 = false>
 static hipError_t launch_prof_k(int K, const DpArgs& a, uint32_t npairs, hipStream_t s) {
   switch (K) {
-    case 4: hipLaunchKernelGGL((gotoh_prof_kernel<4, TRACE, NT>), dim3(npairs), dim3(64), lds_bytes(MODE_PROF, 4) + lds_pad(), s, a); break;
-    case 8: hipLaunchKernelGGL((gotoh_prof_kernel<8, TRACE, NT>), dim3(npairs), dim3(64), lds_bytes(MODE_PROF, 8) + lds_pad(), s, a); break;
+    case 4: hipLaunchKernelGGL((gotoh_prof_kernel<4, TRACE, NT, A16>), dim3(npairs), dim3(64), lds_bytes(MODE_PROF, 4) + lds_pad(), s, a); break;
+    case 8: hipLaunchKernelGGL((gotoh_prof_kernel<8, TRACE, NT, A16>), dim3(npairs), dim3(64), lds_bytes(MODE_PROF, 8) + lds_pad(), s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
-hipError_t launch_gotoh_prof(int K, bool trace, bool row4_zero, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+hipError_t launch_gotoh_prof(int K, bool trace, bool row4_zero, bool arith16, const DpArgs& a, uint32_t npairs, hipStream_t s) {
   if (npairs == 0) return hipSuccess;
   if (trace) return row4_zero ? launch_prof_k<true, 4>(K, a, npairs, s) : launch_prof_k<true, 5>(K, a, npairs, s);
+  if (arith16) return row4_zero ? launch_prof_k<false, 4, true>(K, a, npairs, s) : launch_prof_k<false, 5, true>(K, a, npairs, s);
   return row4_zero ? launch_prof_k<false, 4>(K, a, npairs, s) : launch_prof_k<false, 5>(K, a, npairs, s);
 }
 

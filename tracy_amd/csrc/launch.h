@@ -26,7 +26,8 @@ struct RowsArgs {
 // narrow: use the 16-bit score-only kernel (caller has checked the value range, see narrow_ok)
 hipError_t launch_gotoh(int mode, int K, bool trace, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s);
 // profile x profile with the substitution-term count fixed per launch: row4_zero = every pair of the launch carries PAIR_ROW4_ZERO
-hipError_t launch_gotoh_prof(int K, bool trace, bool row4_zero, const DpArgs& a, uint32_t npairs, hipStream_t s);
+// arith16 (score only): 16-bit cells -- the caller has checked the value range (arith16_ok)
+hipError_t launch_gotoh_prof(int K, bool trace, bool row4_zero, bool arith16, const DpArgs& a, uint32_t npairs, hipStream_t s);
 // checkpointed score pass / band traceback (single-pass problems, MODE_CHAR or MODE_QP)
 hipError_t launch_gotoh_ckpt(int mode, int K, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s);
 hipError_t launch_band_trace(int mode, int K, const DpArgs& a, const WalkArgs& wa, uint32_t npairs, hipStream_t s);

@@ -71,6 +71,12 @@
 #define OP_MAXF16(R) "v_max_f16 " R ", " R ", %8\n"
 #define OP_ADDF16(R) "v_add_f16 " R ", " R ", %8\n"
 #define OP_MULF32(R) "v_mul_f32 " R ", " R ", %8\n"
+#define OP_CVTI32F32(R) "v_cvt_i32_f32 " R ", " R "\n"
+#define OP_CVTF32I32(R) "v_cvt_f32_i32 " R ", " R "\n"
+#define OP_FRACT(R) "v_fract_f32 " R ", " R "\n"
+#define OP_FLOOR(R) "v_floor_f32 " R ", " R "\n"
+#define OP_RNDNE(R) "v_rndne_f32 " R ", " R "\n"
+#define OP_TRUNC(R) "v_trunc_f32 " R ", " R "\n"
 #define OP_SUBF32(R) "v_sub_f32 " R ", " R ", %8\n"
 #define OP_BFE(R) "v_bfe_i32 " R ", " R ", 0, 16\n"
 #define OP_ADD_E64(R) "v_add_u32_e64 " R ", " R ", %8\n"
@@ -97,6 +103,7 @@ DEFK(k_sub, OP_SUB) DEFK(k_or, OP_OR) DEFK(k_xor, OP_XOR) DEFK(k_lshl, OP_LSHL) 
 DEFK(k_cmpgt, OP_CMPGT) DEFK(k_cmpgt16, OP_CMPGT16) DEFK(k_cmpe64, OP_CMPE64) DEFK(k_cndmask2, OP_CNDMASK2) DEFK(k_addc, OP_ADDC)
 DEFK(k_addu16, OP_ADDU16) DEFK(k_maxu16, OP_MAXU16) DEFK(k_mini16, OP_MINI16) DEFK(k_max3i16, OP_MAX3I16) DEFK(k_lshlor, OP_LSHLOR)
 DEFK(k_andor, OP_ANDOR) DEFK(k_or3, OP_OR3) DEFK(k_maxu32, OP_MAXU32) DEFK(k_mini32, OP_MINI32) DEFK(k_maxf16, OP_MAXF16) DEFK(k_addf16, OP_ADDF16)
+DEFK(k_cvti32f32, OP_CVTI32F32) DEFK(k_cvtf32i32, OP_CVTF32I32) DEFK(k_fract, OP_FRACT) DEFK(k_floor, OP_FLOOR) DEFK(k_rndne, OP_RNDNE) DEFK(k_trunc, OP_TRUNC)
 DEFK(k_mulf32, OP_MULF32) DEFK(k_subf32, OP_SUBF32) DEFK(k_bfe, OP_BFE) DEFK(k_adde64, OP_ADD_E64) DEFK(k_subu16, OP_SUBU16) DEFK(k_mullo16, OP_MULLO16)
 DEFK(k_pkaddf16, OP_PKADDF16) DEFK(k_pkmaxf16, OP_PKMAXF16)
 DEFK(k_add, OP_ADD) DEFK(k_max, OP_MAX) DEFK(k_max3, OP_MAX3) DEFK(k_and, OP_AND) DEFK(k_bfi, OP_BFI)
@@ -132,7 +139,8 @@ int main() {
  {"v_add_u16", k_addu16}, {"v_max_u16", k_maxu16}, {"v_min_i16", k_mini16}, {"v_max3_i16", k_max3i16}, {"v_lshl_or_b32", k_lshlor}, {"v_and_or_b32", k_andor},
  {"v_or3_b32", k_or3}, {"v_max_u32", k_maxu32}, {"v_min_i32", k_mini32}, {"v_max_f16", k_maxf16}, {"v_add_f16", k_addf16}, {"v_mul_f32", k_mulf32}, {"v_sub_f32", k_subf32},
  {"v_bfe_i32", k_bfe}, {"v_add_u32_e64", k_adde64}, {"v_sub_u16", k_subu16}, {"v_mul_lo_u16", k_mullo16}, {"v_pk_add_f16", k_pkaddf16}, {"v_pk_max_f16", k_pkmaxf16},
- {"v_pk_mul_f32", k_pkmulf32}, {"v_pk_add_f32", k_pkaddf32}};
+ {"v_pk_mul_f32", k_pkmulf32}, {"v_pk_add_f32", k_pkaddf32},
+ {"v_cvt_i32_f32", k_cvti32f32}, {"v_cvt_f32_i32", k_cvtf32i32}, {"v_fract_f32", k_fract}, {"v_floor_f32", k_floor}, {"v_rndne_f32", k_rndne}, {"v_trunc_f32", k_trunc}};
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);

@@ -112,7 +112,7 @@ struct tracyhip_ctx {
     for (auto* b : all) b->release();
     for (auto& b : d_tmp) b.release();
     for (auto& b : d_pipe) b.release();
-    d_ckpt.release(); d_lastrow.release(); d_band.release();
+    d_ckpt.release(); d_lastrow.release(); d_band.release(); d_special.release();
     d_aftab.release(); aftab_ready = false;
     h_desc.release();
     h_off.release();

@@ -53,6 +53,43 @@ def test_align_1kb_vs_10kb(lanes):
         assert int(fast[win][i]) == int(want[win]) and int(fast[lose][i]) >= int(want[lose])
 
 
+def test_align_references_with_n_columns(monkeypatch):
+    """the 16-bit sweeps and prefix bounds exist with a four-code table (references of A C G T) and a six-code one; the
+    encoders' block map sends each pair to one of them.  A batch that mixes plain windows with windows holding N (at block
+    borders, in the aligned region, as a run): the oracle's result, and the same with the compact forms switched off"""
+    import tracy_amd
+    from tracy_amd import hostlib
+    from sage_oracle import align_trace
+    nt = 24
+    refs, profs, rev = hostlib.synth_align(777, nt, 4000, 1000, 0)
+    refs = refs.copy()
+    refs[1, 255] = ord("N"); refs[2, 256] = ord("N"); refs[3, 3999] = ord("N"); refs[4, 0] = ord("N")
+    refs[5, 1500:1540] = ord("N"); refs[6, ::97] = ord("N"); refs[7, 2000] = ord("N")
+    refl = [r.tobytes() for r in refs]
+    c = tracy_amd.Context(0)
+    monkeypatch.setenv("TRACYHIP_NO_COMPACT", "1")
+    plain = tracy_amd.Context(0)
+    monkeypatch.delenv("TRACYHIP_NO_COMPACT")
+    try:
+        for exact in (True, False):
+            got = c.align_traces(list(profs), refl, SC, 50, 50, exact_scores=exact)
+            ref = plain.align_traces(list(profs), refl, SC, 50, 50, exact_scores=exact)
+            for k in ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final") + (("score_fwd", "score_rev") if exact else ()):
+                assert np.array_equal(got[k], ref[k]), (k, exact)
+            assert got["btr"] == ref["btr"]
+            with ThreadPoolExecutor(max_workers=16) as pool:
+                wants = list(pool.map(lambda i: align_trace(profs[i], refl[i], SC, 50, 50), range(10)))
+            for i, want in enumerate(wants):
+                for k in ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
+                    assert int(got[k][i]) == int(want[k]), (i, k, exact)
+                assert got["btr"][i] == want["btr"], (i, exact)
+                if exact:
+                    assert (int(got["score_fwd"][i]), int(got["score_rev"][i])) == (int(want["score_fwd"]), int(want["score_rev"]))
+    finally:
+        c.close()
+        plain.close()
+
+
 def test_decompose_1kb_vs_3kb(ctx):
     from tracy_amd import capi, hostlib
     import indigo_oracle as io

@@ -82,7 +82,7 @@ def run_campaign(pairs=1500, traces=96, lanes=1, seed=1, decompose_len=(700, 220
                     s1 = (related(rng, s2) + rand_seq(rng, m))[:m] if rng.random() < 0.7 else rand_seq(rng, m)
                     a1.append(s1); a2.append(s2)
                 elif mode == "qp":
-                    a1.append(rand_profile(rng, m, int(rng.choice([0, 1, 3])))); a2.append(rand_seq(rng, n, b"ACGTACGTNn-x"))
+                    a1.append(rand_profile(rng, m, int(rng.choice([0, 1, 3])))); a2.append(rand_seq(rng, n, b"ACGTACGTNn-x" if rng.random() < 0.5 else b"ACGT"))
                 else:
                     m, n = min(m, 400), min(n, 400)
                     a1.append(rand_profile(rng, m, int(rng.integers(0, 4)))); a2.append(rand_profile(rng, n, int(rng.integers(0, 4))))
@@ -106,6 +106,9 @@ def run_campaign(pairs=1500, traces=96, lanes=1, seed=1, decompose_len=(700, 220
         mf = int(rng.integers(120, 1100))
         n = int(rng.integers(mf + 50, 4000))
         r, p, _ = hostlib.synth_align(int(rng.integers(0, 1 << 30)), 1, n, mf, 1)
+        if rng.random() < 0.2:  # windows with N columns take the six-code form of the sweeps, the others the compact one
+            r = r.copy()
+            r[0, rng.integers(0, n, size=int(rng.integers(1, 6)))] = ord("N")
         profs.append(p[0]); refs.append(r[0].tobytes())
     for (tl, tr) in [(50, 50), (0, 0), (13, 77)]:
         got = ctx.align_traces(profs, refs, (3, -5, -10, -4), tl, tr)

@@ -161,15 +161,8 @@ __global__ __launch_bounds__(64) void trim_rows_kernel(const TrimRowsDesc* __res
   if (lane == 0) out[t] = trim_finish(ri, risize, d.n, trim_left, trim_right, d.forward != 0);
 }
 
-// loadSingleFasta hands over upper-case [ACGTN] only (fasta.h:54-95); anything else makes the string
-// and profile reverse complements (fmindex.h:8-24 vs profile.h:74-90) disagree, so it is rejected.
-__global__ void validate_ref_kernel(const uint8_t* __restrict__ in, uint64_t n, int32_t* err) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const uint8_t c = in[i];
-    if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N')) atomicOr(err, 4);
-  }
-}
+// (loadSingleFasta hands over upper-case [ACGTN] only (fasta.h:54-95); anything else makes the string and profile reverse
+// complements (fmindex.h:8-24 vs profile.h:74-90) disagree, so it is rejected: encode_codes_kernel's verr.)
 
 // upper bound for what rows [first, m) of a trimmed profile view can still add to a semiglobal score: every row
 // adds at most max(0, its best one-hot substitution score) (gaps cost <= 0 when go <= 0 and ge < 0)
@@ -207,13 +200,34 @@ __global__ void cq_rows_kernel(const uint8_t* __restrict__ in, uint64_t n, int32
   if (i < n && !cq_row_char(in[i])) atomicOr(flag, 1);
 }
 
-__global__ void encode_codes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, uint8_t* __restrict__ special) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const uint32_t c = dp_code(in[i]);
-    out[i] = (uint8_t)c;
-    if (c >= 4u) special[i >> 8] = 1;  // N, '-' / other: rare (same value from every writer)
+// reference characters -> profile-row codes (align.h:121-136), 16 bytes per thread.  special: one byte per 256 code bytes, set
+// where a block holds an N or '-' / other code.  verr (or null): |= 4 when a byte is not one of A C G T N (the validation
+// verdict, folded into the same pass).
+__global__ void encode_codes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, uint8_t* __restrict__ special,
+                                    int32_t* __restrict__ verr) {
+  const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+  if (i0 >= n) return;
+  uint8_t b[16];
+  const uint32_t cnt = (n - i0 < 16u) ? (uint32_t)(n - i0) : 16u;
+  if (cnt == 16u) __builtin_memcpy(b, in + i0, 16);
+  else for (uint32_t j = 0; j < cnt; ++j) b[j] = in[i0 + j];
+  bool any_special = false, invalid = false;
+#pragma unroll
+  for (uint32_t j = 0; j < 16u; ++j) {
+    if (j < cnt) {
+      const uint8_t ch = b[j];
+      const uint32_t c = dp_code(ch);
+      invalid |= !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'N');
+      any_special |= c >= 4u;
+      b[j] = (uint8_t)c;
+    }
   }
+  if (cnt == 16u) __builtin_memcpy(out + i0, b, 16);
+  else for (uint32_t j = 0; j < cnt; ++j) out[i0 + j] = b[j];
+  if (any_special) {  // rare; 16 bytes from a 16-byte boundary lie in one 256-byte block
+    for (uint32_t j = 0; j < cnt; ++j) if (b[j] >= 4u) special[(i0 + j) >> 8] = 1;
+  }
+  if (verr && invalid) atomicOr(verr, 4);
 }
 
 template <class T>
@@ -671,10 +685,8 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
   if (er) {
     // Windows oriented by the caller (indexed genome) are never reverse-complemented here, and every other letter scores as
     // the all-zero profile column it is in the reference (getReferenceSlice upper-cases only; align.h:121-136): no check.
-    if (!job->oriented)
-      hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er, d_verr);
-    hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
-                       ctx->codes(), er, ctx->special_blocks());
+    hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 4095) / 4096)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
+                       ctx->codes(), er, ctx->special_blocks(), job->oriented ? (int32_t*)nullptr : d_verr);
     HIP_TRY(hipGetLastError());
   }
   // ---- geometry per trace ----
@@ -1074,10 +1086,9 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   HIP_TRY(ctx->ensure_codes(er ? er : 1, st));
   if (er) {
     int32_t* d_verr = static_cast<int32_t*>(ctx->d_err.p) + kErrVerdictWord;
-    if (!job->oriented)  // as in tracyhip_align_traces: caller-oriented windows are taken as they are
-      hipLaunchKernelGGL(validate_ref_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), er, d_verr);
-    hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
-                       ctx->codes(), er, ctx->special_blocks());
+    // (as in tracyhip_align_traces: caller-oriented windows are taken as they are, no validation)
+    hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 4095) / 4096)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref),
+                       ctx->codes(), er, ctx->special_blocks(), job->oriented ? (int32_t*)nullptr : d_verr);
     HIP_TRY(hipGetLastError());
     int32_t herr = 0;
     HIP_TRY(hipMemcpyAsync(&herr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -161,35 +161,14 @@ struct SubChar {
   TR_HD int32_t lo16(int i) const { return rc[i] == cc ? vmatch : vmis; }
 };
 
-template <int K>
-struct SubTable {
-  int32_t sv[K];
-  TR_HD int32_t operator()(int i) const { return sv[i]; }
-  TR_HD int32_t lo16(int i) const { return sv[i]; }
-};
-
-// LDS query-profile table: int16 [6 codes][64*K rows] (codes 5 = '-' and 6 = other share the zero row)
-// table row stride per lane: K rounded up to an even count (int16 pairs), so odd strip heights work too
+// per-lane strips of the prefix-bound kernel (qp_lane / qp_fetch): K rounded up to an even count of int16 (packed dword reads)
 TR_HD constexpr int qp_stride(int K) { return (K + 1) & ~1; }
-// query-profile table of the sweeps: int16 [6 codes][qp_stride(K) rows][64 lanes] -- a row's 64 lanes are contiguous, so the
-// per-row 16-bit reads of a wave are conflict-free (a per-lane strip layout costs an 8-way bank conflict on each of them).
-// Code 5 = '-' / any other letter.  (The prefix-bound kernel keeps per-lane strips + one shared zero strip: qp_lane / qp_fetch.)
+// query-profile table of the sweeps and tracebacks: int16 [codes][K rows][64 lanes] -- a row's 64 lanes are contiguous, so a
+// wave's 16-bit reads of one row hit every bank once when the lanes agree on the code (a per-lane strip layout costs an 8-way
+// bank conflict on each of them).  Codes 0..4 = A C G T N, 5 = '-' / any other letter; kernels that know their columns hold
+// fewer codes lay out fewer rows (gotoh_narrow_qp_body, gotoh_origin_body): the table size decides the waves per CU.
 template <int K>
 TR_HD uint32_t qp6_index(uint32_t code, uint32_t row, uint32_t lane) { return (code * (uint32_t)K + row) * 64u + lane; }
-
-template <int K, bool NARROW = false>
-TR_HD void qp_load(const int16_t* tab, uint32_t code, uint32_t lane, SubTable<K>& s) {
-  constexpr int KP = qp_stride(K);
-  // codes 5 ('-') and 6 (other) score 0 against every row: one shared zero strip after the five code rows
-  const uint32_t row = (code < 5u) ? code * (64u * KP) + lane * KP : 5u * (64u * KP);
-  const uint32_t* p = reinterpret_cast<const uint32_t*>(tab + row);
-#pragma unroll
-  for (int j = 0; j < KP / 2; ++j) {
-    const uint32_t w = p[j];
-    s.sv[2 * j] = NARROW ? (int32_t)w : (int32_t)(int16_t)(w & 0xffffu);  // 16-bit consumers read the low half only
-    if (2 * j + 1 < K) s.sv[2 * j + 1] = ((int32_t)w) >> 16;
-  }
-}
 
 // packed strip: the K int16 query-profile values of a lane for one column, as loaded from LDS (ping-pong
 // buffers hold the strips of the current and the next column)
@@ -331,9 +310,8 @@ struct SubProf {
 // LDS bytes of the Needleman-Wunsch kernels (profile rows are staged in LDS there)
 TR_HD constexpr uint32_t needle_lds_bytes(int mode, int K) { return mode == MODE_PROF ? 5u * 64u * K * 4u : 0u; }
 TR_HD constexpr uint32_t lds_bytes(int mode, int K) {
-  // 6 code rows x 64 lanes x qp_stride(K) int16: what the 16-bit sweep (gotoh_narrow_qp_body) lays out; the other QP kernels use
-  // five rows + one shared zero strip of it.  MODE_PROF keeps its rows in registers.
-  // MODE_PROF: the same table shape holds the ints of the float chain against one-hot / uniform columns (column_class)
+  // 6 code rows x K rows x 64 lanes of int16 (qp6_index).  MODE_PROF keeps its rows in registers; its table holds the ints of the
+  // float chain against one-hot / uniform columns (column_class)
   return (qp_like(mode) || mode == MODE_PROF) ? 6u * 64u * (uint32_t)K * 2u : 0u;
 }
 
@@ -460,7 +438,6 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     // ---- substitution set-up for this pass ----
     const bool rc_view = (d.flags & PAIR_A2_REVCOMP) != 0;
     SubChar<K> sub_c;
-    SubTable<K> sub_t;
     SubProf<K> sub_p;
     if (MODE == MODE_CHAR) {
 #pragma unroll
@@ -472,7 +449,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       sub_c.vmis = (int32_t)((uint32_t)a.mismatch << SH) - goe_n;
       sub_c.cc = 0;
     } else if (qp_like(MODE)) {
-      // query-profile table [6 codes][qp_stride(K) rows][64 lanes] (qp6_index): entry = substitution score << SH (- goe_n)
+      // query-profile table [6 codes][K rows][64 lanes] (qp6_index): entry = substitution score << SH (- goe_n)
       w.sync();  // previous pass may still be reading the table
       bool overflow = false;
       int32_t qabs = 0;
@@ -759,8 +736,6 @@ struct QpStrip {
 // what decides how many waves a CU holds (LDS, not registers, is the limit), and this kernel needs them: one wave issues a
 // VALU instruction every ~4.5 cycles, a SIMD takes one every 2 (tools/ubench/clock_probe.hip).  13 -> 20 workgroups per CU:
 // 32.4 -> 28.2 ms per launch.
-template <int K>
-TR_HD constexpr uint32_t qpc_index(uint32_t code, uint32_t row, uint32_t lane) { return (code * (uint32_t)K + row) * 64u + lane; }
 TR_HD constexpr uint32_t lds_bytes_sweep16(int K, bool compact) { return (compact ? 4u : 6u) * (uint32_t)K * 64u * 2u; }
 // does the reference of this pair hold N / '-' / other codes?  (special_blocks: one byte per 256 code bytes.)  Wave-uniform.
 template <class W>
@@ -814,7 +789,6 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const PairDesc d = a.pairs[pair_idx];
   // both forms of the kernel are launched over the same pairs; each pair is swept by the one its reference calls for
   if (reference_is_plain(w, a, d) != COMPACT) return;
-  constexpr uint32_t NC = COMPACT ? 4u : 6u;
   const uint32_t L = w.lane();
   const uint32_t m = d.m, n = d.n;
   const int32_t go = a.go, ge = a.ge, goe = go + ge;
@@ -847,7 +821,7 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   asm volatile("" : "+v"(gev), "+v"(goev), "+v"(hext_last), "+v"(delta_last));  // four live VGPRs for the whole sweep, not re-materialised per step
 #endif
 
-  // ---- query profile: int16 [NC][K][64 lanes] (qpc_index), entry = (int)(sum_k p[k][row] w[k][b]) - goe for b = A C G T (N);
+  // ---- query profile: int16 [NC][K][64 lanes] (qp6_index), entry = (int)(sum_k p[k][row] w[k][b]) - goe for b = A C G T (N);
   // code 5 ('-' / other) and rows off the trace score 0 ----
   {
     bool overflow = false;
@@ -866,15 +840,14 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
         qabs = imax(qabs, q < 0 ? -q : q);
         const uint32_t row = (rcflag && b < 4u) ? 3u - b : b;  // reverse-complement view: the complement is folded into the table
-        qp_tab[qpc_index<K>(row, (uint32_t)i, L)] = (int16_t)qs;
+        qp_tab[qp6_index<K>(row, (uint32_t)i, L)] = (int16_t)qs;
       }
-      if (!COMPACT) qp_tab[qpc_index<K>(5u, (uint32_t)i, L)] = (int16_t)(-goe);
+      if (!COMPACT) qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)(-goe);
     }
     if (overflow) flag_error(a.err, 1);
     if (qabs > a.qlimit) flag_max(a.err, 1, qabs);
     w.sync();
   }
-  (void)NC;
 
   // ---- sweep ----
   const char* strip = reinterpret_cast<const char*>(qp_tab) + L * 2u;  // this lane's column of the table
@@ -1510,7 +1483,6 @@ TR_HD void gotoh_band_trace_body(W& w, const DpArgs& a, const WalkArgs& wa, uint
 
     // ---- substitution set-up (as gotoh_body) ----
     SubChar<K> sub_c;
-    SubTable<K> sub_t;
     if (MODE == MODE_CHAR) {
 #pragma unroll
       for (int i = 0; i < K; ++i) {

@@ -332,7 +332,19 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
     if (fx != fy) return fx > fy;  // profile x profile: 16-term pairs and 25-term pairs go to different launches
     return (uint64_t)pb.desc[x].m * pb.desc[x].n > (uint64_t)pb.desc[y].m * pb.desc[y].n;
   };
-  if (!std::is_sorted(order.begin(), order.end(), before)) std::stable_sort(order.begin(), order.end(), before);
+  // (the order only balances the tail of a launch: batches of one strip height whose sizes lie within 25 % of each other --
+  // the final alignments of a `tracy align` batch -- keep the caller's order and save the host the sort between two kernels)
+  bool similar = true;
+  {
+    uint64_t lo = ~0ull, hi = 0;
+    for (uint32_t i = 0; i < np && similar; ++i) {
+      const uint64_t c = (uint64_t)pb.desc[i].m * pb.desc[i].n;
+      lo = std::min(lo, c); hi = std::max(hi, c);
+      similar = pb.k[i] == pb.k[0] && (pb.desc[i].flags & PAIR_ROW4_ZERO) == (pb.desc[0].flags & PAIR_ROW4_ZERO);
+    }
+    similar = similar && hi <= lo + lo / 4;
+  }
+  if (!similar && !std::is_sorted(order.begin(), order.end(), before)) std::stable_sort(order.begin(), order.end(), before);
 
   // workspace plan: chunks of consecutive (sorted) pairs whose traceback words fit the limit
   const uint64_t word_bytes = needle ? 4 : 8;

@@ -3,6 +3,8 @@
 // there is no CPU fallback: every entry point needs a gfx950 device.
 #include <hip/hip_runtime.h>
 
+#include <thread>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -360,7 +362,40 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   PairDesc* hd = static_cast<PairDesc*>(ctx->h_desc.p);
   struct Chunk { uint32_t lo, hi; uint64_t words, scratch; };
   std::vector<Chunk> chunks;
-  {
+  if (!(trace && stage == DP_PLAIN) && np >= (1u << 16)) {
+    // no traceback words: one chunk, and the only running total is the boundary-row scratch of multi-pass pairs.  Long lists
+    // (an all-pairs job: 36 MB of descriptors) are laid out by a few threads: sizes, a scan over the threads' totals, the copy.
+    constexpr uint32_t NT = 8;
+    uint64_t tsum[NT + 1] = {0};
+    auto range = [&](uint32_t t) { return std::make_pair((uint32_t)((uint64_t)np * t / NT), (uint32_t)((uint64_t)np * (t + 1) / NT)); };
+    auto scr_of = [&](uint32_t j) -> uint64_t {
+      const PairDesc& d = pb.desc[order[j]];
+      return (d.m && d.n && num_passes(d.m, pb.k[order[j]]) > 1) ? (uint64_t)d.n + 2 : 0;
+    };
+    {
+      std::vector<std::thread> th;
+      for (uint32_t t = 0; t < NT; ++t)
+        th.emplace_back([&, t]() { uint64_t a = 0; for (uint32_t j = range(t).first; j < range(t).second; ++j) a += scr_of(j); tsum[t + 1] = a; });
+      for (auto& x : th) x.join();
+    }
+    for (uint32_t t = 0; t < NT; ++t) tsum[t + 1] += tsum[t];
+    {
+      std::vector<std::thread> th;
+      for (uint32_t t = 0; t < NT; ++t)
+        th.emplace_back([&, t]() {
+          uint64_t a = tsum[t];
+          for (uint32_t j = range(t).first; j < range(t).second; ++j) {
+            PairDesc d = pb.desc[order[j]];
+            d.bits_off = 0;
+            d.scratch_off = a;
+            a += scr_of(j);
+            hd[j] = d;
+          }
+        });
+      for (auto& x : th) x.join();
+    }
+    chunks.push_back(Chunk{0, np, 0, tsum[NT]});
+  } else {
     Chunk c{0, 0, 0, 0};
     for (uint32_t j = 0; j < np; ++j) {
       PairDesc d = pb.desc[order[j]];
@@ -579,22 +614,45 @@ int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool 
   pb.desc.resize(pairs->npairs);
   pb.k.resize(pairs->npairs);
   *max_mn = 0;
-  for (uint32_t i = 0; i < pairs->npairs; ++i) {
-    const uint32_t i1 = pairs->a1_index ? pairs->a1_index[i] : i;
-    const uint32_t i2 = pairs->a2_index ? pairs->a2_index[i] : i;
-    if (i1 >= s1.count || i2 >= s2.count) return set_error(TRACYHIP_ERR_ARG, "pair %u indexes past the sequence sets", i);
-    PairDesc d{};
-    d.a1_off = s1.offset[i1];
-    d.a2_off = s2.offset[i2];
-    d.m = s1.length[i1];
-    d.n = s2.length[i2];
-    d.a1_stride = d.m;
-    d.a2_stride = d.n;
-    d.out = i;
-    if (!z1.empty() && z1[i1] && z2[i2]) d.flags |= PAIR_ROW4_ZERO;
-    pb.desc[i] = d;
-    pb.k[i] = choose_k(d.m, pb.mode, needle);
-    *max_mn = std::max<uint64_t>(*max_mn, (uint64_t)d.m + d.n);
+  // strip height per a1 sequence (not per pair: an all-pairs list names every sequence a thousand times)
+  std::vector<int> kseq(s1.count);
+  for (uint32_t i = 0; i < s1.count; ++i) kseq[i] = choose_k(s1.length[i], pb.mode, needle);
+  // long pair lists are filled by a few threads (the list of an all-pairs job is 36 MB of descriptors)
+  const uint32_t npairs = pairs->npairs;
+  const uint32_t nthr = npairs >= (1u << 16) ? 8u : 1u;
+  std::vector<uint64_t> tmax(nthr, 0);
+  std::vector<uint32_t> tbad(nthr, ~0u);
+  auto fill = [&](uint32_t tid) {
+    const uint32_t lo = (uint32_t)((uint64_t)npairs * tid / nthr), hi = (uint32_t)((uint64_t)npairs * (tid + 1) / nthr);
+    uint64_t mx = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+      const uint32_t i1 = pairs->a1_index ? pairs->a1_index[i] : i;
+      const uint32_t i2 = pairs->a2_index ? pairs->a2_index[i] : i;
+      if (i1 >= s1.count || i2 >= s2.count) { tbad[tid] = i; return; }
+      PairDesc d{};
+      d.a1_off = s1.offset[i1];
+      d.a2_off = s2.offset[i2];
+      d.m = s1.length[i1];
+      d.n = s2.length[i2];
+      d.a1_stride = d.m;
+      d.a2_stride = d.n;
+      d.out = i;
+      if (!z1.empty() && z1[i1] && z2[i2]) d.flags |= PAIR_ROW4_ZERO;
+      pb.desc[i] = d;
+      pb.k[i] = kseq[i1];
+      mx = std::max<uint64_t>(mx, (uint64_t)d.m + d.n);
+    }
+    tmax[tid] = mx;
+  };
+  if (nthr == 1) fill(0);
+  else {
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nthr; ++t) th.emplace_back(fill, t);
+    for (auto& t : th) t.join();
+  }
+  for (uint32_t t = 0; t < nthr; ++t) {
+    if (tbad[t] != ~0u) return set_error(TRACYHIP_ERR_ARG, "pair %u indexes past the sequence sets", tbad[t]);
+    *max_mn = std::max(*max_mn, tmax[t]);
   }
   return TRACYHIP_OK;
 }
@@ -827,6 +885,11 @@ static int dp_entry(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyh
   if (!trace && !scores && pairs->npairs) return set_error(TRACYHIP_ERR_ARG, "null scores");
   if (trace && pairs->npairs && (!ops || !ops_offset || !ops_len)) return set_error(TRACYHIP_ERR_ARG, "null ops/ops_offset/ops_len");
   DpProblem pb;
+  struct Recycle {  // the problem borrows the context's vectors and hands them back, whatever the way out
+    tracyhip_ctx* c; DpProblem& p;
+    Recycle(tracyhip_ctx* c_, DpProblem& p_) : c(c_), p(p_) { p.desc.swap(c->cache_desc); p.k.swap(c->cache_k); }
+    ~Recycle() { p.desc.swap(c->cache_desc); p.k.swap(c->cache_k); }
+  } recycle(ctx, pb);
   uint64_t max_mn = 0;
   if ((rc = build_problem(ctx, pairs, mem, needle, pb, &max_mn))) return rc;
   if ((rc = check_params(prm, max_mn))) return rc;

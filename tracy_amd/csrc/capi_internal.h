@@ -63,6 +63,8 @@ struct tracyhip_ctx {
   tracyhip::DevBuf d_desc, d_bits, d_scratch, d_in1, d_in2, d_codes, d_scores, d_ops, d_ops_off, d_ops_len, d_err,
       d_rows0, d_rows1;
   tracyhip::DevBuf d_special;
+  std::vector<tracyhip::PairDesc> cache_desc;  // descriptor / strip-height vectors of the generic DP entry points, kept between
+  std::vector<int> cache_k;                    // calls (an all-pairs list is 36 MB: allocating it afresh costs 6 ms of page faults)
   tracyhip::DevBuf d_tmp[8];
   tracyhip::DevBuf d_pipe[64];
   tracyhip::DevBuf d_ckpt, d_lastrow, d_band;  // pipeline intermediates (align_traces / decompose)

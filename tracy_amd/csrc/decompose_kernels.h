@@ -150,6 +150,7 @@ struct DecompSharedT : DecompDims<MAXI> {
   uint32_t exotic;              // the scan window holds a character outside ACGTN- : byte-wise fallback
   uint32_t classes;             // bit c set iff class c occurs in the window
   int32_t Lw, NV;               // columns from alignIndex+1 to L, basecalls from varIndex to vend (clamped to the bit sets)
+  int32_t med, thres;          // median of the failed counts; the cut-off derived from it and the MAD
   int32_t pick_del, pick_ins;  // smallest picked deletion / insertion, -1 = none
   int32_t ndel, nins;          // number of picks
   int32_t maxpick_del, maxpick_ins;
@@ -353,69 +354,96 @@ TR_HD void decomp_phase_scan(const DecompArgs& a, const DecompDesc& d, SH& sh, u
   }
 }
 
-// value at sorted position n/2 (getMedian, decompose.h:129-135) of small non-negative ints via a histogram
-TR_HD int32_t median_hist(const int32_t* v, uint32_t n, int32_t* hist, uint32_t nh) {
-  for (uint32_t i = 0; i < nh; ++i) hist[i] = 0;
-  for (uint32_t i = 0; i < n; ++i) {
-    const uint32_t x = (uint32_t)v[i];
-    ++hist[x < nh ? x : nh - 1];
+// ---- cut-offs, picks, decomposition table (decompose.h:227-285) ----
+// The reference takes the median and the median absolute deviation of the failed counts, derives a threshold, picks the
+// shifts that undercut it and their neighbours, and prints a table.  All of it is a handful of passes over <= 2 MAXI small
+// ints, done by the 64 lanes together in the steps below (a barrier between them); lane 0 only joins 64 partial results.
+// (One lane walking histograms of 2 MAXI + 2 bins in LDS, one dependent access after the other, was most of this kernel's time.)
+TR_HD void lds_inc(int32_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicAdd(p, 1);
+#else
+  ++*p;
+#endif
+}
+template <class SH>
+TR_HD uint32_t pick_bins() { return (uint32_t)SH::kMaxIndel * 2 + 2; }
+template <class SH>
+TR_HD void pick_zero(SH& sh, uint32_t lane) {
+  if (lane == 0) sh.fins[0] = sh.fref[0];  // decompose.h:249 (fins[0] is not read before the picks)
+  for (uint32_t i = lane; i < pick_bins<SH>(); i += 64) sh.hist[i] = 0;
+}
+// histogram of |fref[i] - centre| (centre 0: of the values themselves), values clamped to the last bin
+template <class SH>
+TR_HD void pick_count(SH& sh, uint32_t lane, int32_t centre) {
+  const uint32_t nh = pick_bins<SH>();
+  for (uint32_t i = lane; i < sh.nfref; i += 64) {
+    int32_t dv = sh.fref[i] - centre;
+    if (dv < 0) dv = -dv;
+    lds_inc(&sh.hist[(uint32_t)dv < nh ? (uint32_t)dv : nh - 1]);
   }
+}
+// per-lane totals of consecutive blocks of bins
+template <class SH>
+TR_HD void pick_blocks(SH& sh, uint32_t lane) {
+  const uint32_t nh = pick_bins<SH>(), B = (nh + 63) / 64;
+  uint32_t sum = 0;
+  for (uint32_t x = lane * B; x < (lane + 1) * B && x < nh; ++x) sum += (uint32_t)sh.hist[x];
+  sh.seg0[lane] = sum;
+}
+// value at sorted position n/2 (getMedian, decompose.h:129-135): the first bin at which the running count exceeds n/2
+template <class SH>
+TR_HD int32_t pick_median(const SH& sh) {
+  const uint32_t nh = pick_bins<SH>(), B = (nh + 63) / 64, half = sh.nfref / 2;
   uint32_t seen = 0;
-  for (uint32_t x = 0; x < nh; ++x) {
-    seen += (uint32_t)hist[x];
-    if (seen > n / 2) return (int32_t)x;
+  for (uint32_t b = 0; b < 64; ++b) {
+    if (seen + sh.seg0[b] > half) {
+      for (uint32_t x = b * B; x < (b + 1) * B && x < nh; ++x) {
+        seen += (uint32_t)sh.hist[x];
+        if (seen > half) return (int32_t)x;
+      }
+    }
+    seen += sh.seg0[b];
   }
   return 0;
 }
-
-// ---- phase 3 (lane 0): cut-offs, picks, decomposition table (decompose.h:227-285) ----
+// the shifts a lane finds among its share of fref / fins: count, first and last index (decompose.h:251-270)
 template <class SH>
-TR_HD void decomp_phase_pick(const DecompArgs& a, const DecompDesc& d, SH& sh, DecompOut& out) {
+TR_HD void pick_candidates(SH& sh, uint32_t lane) {
   const uint32_t nfref = sh.nfref, nfins = sh.nfins;
-  const uint32_t nh = (uint32_t)SH::kMaxIndel * 2 + 2;
-  sh.fins[0] = sh.fref[0];  // decompose.h:249
-  const int32_t med = median_hist(sh.fref, nfref, sh.hist, nh);
-  // MAD: median of |x - med|; values stay below nh as well
-  {
-    for (uint32_t i = 0; i < nh; ++i) sh.hist[i] = 0;
-    for (uint32_t i = 0; i < nfref; ++i) {
-      int32_t dv = sh.fref[i] - med;
-      if (dv < 0) dv = -dv;
-      ++sh.hist[(uint32_t)dv < nh ? (uint32_t)dv : nh - 1];
+  const int32_t thres = sh.thres;
+  auto scan = [&](const int32_t* f, uint32_t n, int32_t& cnt, int32_t& first, int32_t& last) {
+    cnt = 0; first = 0x7fffffff; last = -1;
+    for (uint32_t i = lane; i < n; i += 64) {
+      if (f[i] < thres) {
+        bool take = false;
+        if ((i + 1 < n) && (2 * f[i] < f[i + 1])) take = true;
+        else if ((i > 0) && (2 * f[i] < f[i - 1])) take = true;
+        else if ((i == 0) && (i + 2 < n) && (2 * f[i] < f[i + 2])) take = true;
+        if (take) { if (first == 0x7fffffff) first = (int32_t)i; last = (int32_t)i; ++cnt; }
+      }
     }
+  };
+  int32_t c, f, l;
+  scan(sh.fref, nfref, c, f, l);
+  sh.seg0[lane] = (uint32_t)c; sh.best_fr[lane] = f; sh.best_ins[lane] = l;
+  scan(sh.fins, nfins, c, f, l);
+  sh.seg1[lane] = (uint32_t)c; sh.best_del[lane] = f; sh.hist[lane] = l;
+}
+// lane 0: join the candidates, write the decomposition table (decompose.h:273-285)
+template <class SH>
+TR_HD void pick_finish(const DecompArgs& a, const DecompDesc& d, SH& sh, DecompOut& out) {
+  const uint32_t nfref = sh.nfref, nfins = sh.nfins;
+  int32_t ndel = 0, first_del = 0x7fffffff, max_del = -1, nins = 0, first_ins = 0x7fffffff, max_ins = -1;
+  for (uint32_t b = 0; b < 64; ++b) {
+    ndel += (int32_t)sh.seg0[b]; nins += (int32_t)sh.seg1[b];
+    if (sh.best_fr[b] < first_del) first_del = sh.best_fr[b];
+    if (sh.best_ins[b] > max_del) max_del = sh.best_ins[b];
+    if (sh.best_del[b] < first_ins) first_ins = sh.best_del[b];
+    if (sh.hist[b] > max_ins) max_ins = sh.hist[b];
   }
-  int32_t mad = 0;
-  {
-    uint32_t seen = 0;
-    for (uint32_t x = 0; x < nh; ++x) {
-      seen += (uint32_t)sh.hist[x];
-      if (seen > nfref / 2) { mad = (int32_t)x; break; }
-    }
-  }
-  int32_t thres = 0;
-  if (med > a.prm.madc * mad) thres = med - a.prm.madc * mad;
-  if (thres < 10) thres = 10;
-
-  int32_t ndel = 0, first_del = -1, max_del = -1;
-  for (uint32_t i = 0; i < nfref; ++i) {
-    if (sh.fref[i] < thres) {
-      bool take = false;
-      if ((i + 1 < nfref) && (2 * sh.fref[i] < sh.fref[i + 1])) take = true;
-      else if ((i > 0) && (2 * sh.fref[i] < sh.fref[i - 1])) take = true;
-      else if ((i == 0) && (i + 2 < nfref) && (2 * sh.fref[i] < sh.fref[i + 2])) take = true;
-      if (take) { if (first_del < 0) first_del = (int32_t)i; max_del = (int32_t)i; ++ndel; }
-    }
-  }
-  int32_t nins = 0, first_ins = -1, max_ins = -1;
-  for (uint32_t i = 0; i < nfins; ++i) {
-    if (sh.fins[i] < thres) {
-      bool take = false;
-      if ((i + 1 < nfins) && (2 * sh.fins[i] < sh.fins[i + 1])) take = true;
-      else if ((i > 0) && (2 * sh.fins[i] < sh.fins[i - 1])) take = true;
-      else if ((i == 0) && (i + 2 < nfins) && (2 * sh.fins[i] < sh.fins[i + 2])) take = true;
-      if (take) { if (first_ins < 0) first_ins = (int32_t)i; max_ins = (int32_t)i; ++nins; }
-    }
-  }
+  if (ndel == 0) first_del = -1;
+  if (nins == 0) first_ins = -1;
   sh.ndel = ndel; sh.nins = nins;
   sh.pick_del = first_del; sh.pick_ins = first_ins;
 
@@ -544,9 +572,14 @@ TR_HD void decomp_phase_apply(const DecompArgs& a, const DecompDesc& d, const SH
 }
 
 // ---- the phase schedule, shared by the HIP kernel (a barrier after every step) and tests/emu (lanes looped) ----
-constexpr int kDecompSteps = 10;
+constexpr int kDecompSteps = 19;
 // whether step `st` runs on all lanes (true) or on lane 0 only (false)
-TR_HD bool decomp_step_all_lanes(int st) { return st == 0 || st == 1 || st == 3 || st == 5 || st == 7 || st == 9; }
+TR_HD bool decomp_step_all_lanes(int st) {
+  switch (st) {
+    case 0: case 1: case 3: case 5: case 6: case 7: case 8: case 10: case 11: case 12: case 14: case 16: case 18: return true;
+    default: return false;
+  }
+}
 template <class SH>
 TR_HD void decomp_step(int st, const DecompArgs& a, const DecompDesc& d, SH& sh, DecompOut& out, uint32_t lane) {
   switch (st) {
@@ -556,13 +589,31 @@ TR_HD void decomp_step(int st, const DecompArgs& a, const DecompDesc& d, SH& sh,
     case 3: decomp_phase_bitsets(a, d, sh, lane); break;
     case 4: decomp_phase_flags(sh); break;
     case 5: decomp_phase_scan(a, d, sh, lane); break;
-    case 6: decomp_phase_pick(a, d, sh, out); break;
-    case 7: if (sh.ndel == 0 && sh.nins == 0) decomp_phase_complex(a, d, sh, lane); break;
-    case 8:
+    // median of the failed counts (decompose.h:227-231) ...
+    case 6: pick_zero(sh, lane); break;
+    case 7: pick_count(sh, lane, 0); break;
+    case 8: pick_blocks(sh, lane); break;
+    case 9: sh.med = pick_median(sh); break;
+    // ... their median absolute deviation, and the cut-off (decompose.h:232-247)
+    case 10: pick_zero(sh, lane); break;
+    case 11: pick_count(sh, lane, sh.med); break;
+    case 12: pick_blocks(sh, lane); break;
+    case 13: {
+      const int32_t mad = pick_median(sh);
+      int32_t thres = 0;
+      if (sh.med > a.prm.madc * mad) thres = sh.med - a.prm.madc * mad;
+      if (thres < 10) thres = 10;
+      sh.thres = thres;
+      break;
+    }
+    case 14: pick_candidates(sh, lane); break;
+    case 15: pick_finish(a, d, sh, out); break;
+    case 16: if (sh.ndel == 0 && sh.nins == 0) decomp_phase_complex(a, d, sh, lane); break;
+    case 17:
       if (sh.ndel == 0 && sh.nins == 0) decomp_phase_complex_reduce(sh, out);
       sh.best_fr[0] = out.bestFR; sh.best_ins[0] = out.bestIns; sh.best_del[0] = out.bestDel; sh.hist[0] = out.kind;
       break;
-    case 9:
+    case 18:
       if (lane != 0) { out.bestFR = sh.best_fr[0]; out.bestIns = sh.best_ins[0]; out.bestDel = sh.best_del[0]; out.kind = sh.hist[0]; }
       decomp_phase_apply(a, d, sh, out, lane);
       break;

@@ -111,3 +111,45 @@ def test_synth_workload_is_seeded_and_plausible():
     assert set(np.unique(r1).tolist()) <= set(b"ACGT")
     assert np.allclose(p1[:, :4].sum(axis=1), 1.0, atol=1e-5)
     assert (p1[:, :4].max(axis=1) > 0.8).mean() > 0.95
+
+
+def test_breakpoint_selection_by_reductions_equals_the_sequential_walk():
+    """findBreakpoint keeps a float-typed running maximum while it compares doubles (decompose.h:27-55).  The kernel answers
+    with three reductions (largest float, first position that rounds to it, last position strictly above it): the same
+    position as the sequential walk, also where many values share one float and differ as doubles"""
+    import numpy as np
+    rng = np.random.default_rng(31)
+
+    def walk(diff):
+        best, idx = np.float32(0), None
+        for i, v in enumerate(diff):
+            if v > float(best):
+                idx, best = i, np.float32(v)
+        return idx, best
+
+    def reduced(diff):
+        g = diff.astype(np.float32)
+        pos = diff > 0
+        F = np.float32(max(np.float32(0), g[pos].max())) if pos.any() else np.float32(0)
+        above = np.nonzero(diff > float(F))[0]
+        if len(above):
+            return int(above[-1]), F
+        first = np.nonzero(pos & (g == F))[0] if F > 0 else []
+        return (int(first[0]) if len(first) else None), F
+
+    for trial in range(3000):
+        n = int(rng.integers(1, 60))
+        kind = trial % 4
+        if kind == 0:
+            diff = rng.random(n)
+        elif kind == 1:  # a few floats, each met by several doubles around it
+            base = rng.choice(np.float32([0.25, 0.5, 0.75, 1.0, 0.1]).astype(np.float64), n)
+            diff = base * (1 + (rng.integers(-3, 4, n) * 2.0 ** -30))
+        elif kind == 2:
+            diff = np.where(rng.random(n) < 0.3, 0.0, rng.choice([1e-46, -1.0, 0.5, 0.5 + 2.0 ** -40, 0.5 - 2.0 ** -40], n))
+        else:
+            diff = np.float64(np.float32(rng.random())) + rng.integers(-2, 3, n) * 2.0 ** -28
+        diff = np.asarray(diff, np.float64)
+        wi, wb = walk(diff)
+        ri, rb = reduced(diff)
+        assert wi == ri and wb == rb, (trial, diff.tolist())

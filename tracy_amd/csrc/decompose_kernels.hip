@@ -74,9 +74,48 @@ __global__ __launch_bounds__(64) void breakpoint_kernel(const BpDesc* desc, cons
     }
   }
   wg_sync();
-  if (threadIdx.x == 0) {
+  // breakpoint_select (decompose.h:27-55) by the 64 lanes.  The reference walks the positions with a float-typed running
+  // maximum: position i is taken when diff[i] > (double)best, and best becomes (float)diff[i].  Rounding is monotone, so the
+  // walk ends with best = F = max(0, max_i (float)diff[i]); the first position whose float equals F is always taken, and after
+  // it exactly the positions with diff[i] > (double)F (they round down to F) -- the answer is the last of those, or that first
+  // position.  Three reductions instead of one lane reading ncol doubles one after the other.
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lo = 25, hi = (25 < d.ncol) ? d.ncol - 25 : 25;
+  float fmax_l = 0.0f;
+  for (uint32_t i = lo + lane; i < hi; i += 64) {
+    const float g = (float)diff[i];
+    if (diff[i] > 0.0 && g > fmax_l) fmax_l = g;
+  }
+  for (int o = 32; o > 0; o >>= 1) { const float x = __shfl_xor(fmax_l, o, 64); if (x > fmax_l) fmax_l = x; }
+  const float F = fmax_l;
+  uint32_t first_l = 0xffffffffu, last_l = 0;  // last_l: position + 1, 0 = none
+  for (uint32_t i = lo + lane; i < hi; i += 64) {
+    const double v = diff[i];
+    if (F > 0.0f && (float)v == F && v > 0.0 && i < first_l) first_l = i;
+    if (v > (double)F) last_l = i + 1;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t a = (uint32_t)__shfl_xor((int)first_l, o, 64), b = (uint32_t)__shfl_xor((int)last_l, o, 64);
+    if (a < first_l) first_l = a;
+    if (b > last_l) last_l = b;
+  }
+  if (lane == 0) {
     BreakpointOut bp;
-    breakpoint_select(diff, ltr, d.ncol, bp);
+    bp.bestDiff = 0; bp.traceleft = 1; bp.breakpoint = 0;
+    const bool any = last_l != 0 || first_l != 0xffffffffu;
+    if (any) {
+      const uint32_t idx = last_l ? last_l - 1 : first_l;
+      bp.breakpoint = idx;
+      bp.bestDiff = F;
+      bp.traceleft = ltr[idx] ? 0 : 1;
+    }
+    bp.indelshift = 1;
+    if ((double)bp.bestDiff < 0.25) {
+      bp.indelshift = 0;
+      bp.breakpoint = d.ncol;
+      bp.traceleft = 1;
+      bp.bestDiff = 0;
+    }
     out[blockIdx.x] = bp;
   }
 }

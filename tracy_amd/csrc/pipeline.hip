@@ -200,33 +200,46 @@ __global__ void cq_rows_kernel(const uint8_t* __restrict__ in, uint64_t n, int32
   if (i < n && !cq_row_char(in[i])) atomicOr(flag, 1);
 }
 
-// reference characters -> profile-row codes (align.h:121-136), 16 bytes per thread.  special: one byte per 256 code bytes, set
+// reference characters -> profile-row codes (align.h:121-136), sixteen bytes per thread.  special: one byte per 256 code bytes, set
 // where a block holds an N or '-' / other code.  verr (or null): |= 4 when a byte is not one of A C G T N (the validation
 // verdict, folded into the same pass).
-__global__ void encode_codes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, uint8_t* __restrict__ special,
-                                    int32_t* __restrict__ verr) {
-  const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u;
-  if (i0 >= n) return;
-  uint8_t b[16];
-  const uint32_t cnt = (n - i0 < 16u) ? (uint32_t)(n - i0) : 16u;
-  if (cnt == 16u) __builtin_memcpy(b, in + i0, 16);
-  else for (uint32_t j = 0; j < cnt; ++j) b[j] = in[i0 + j];
-  bool any_special = false, invalid = false;
+__device__ __forceinline__ uint32_t encode_word(uint32_t w, uint32_t cnt, bool& any_special, bool& invalid) {
+  uint32_t codes = 0;
 #pragma unroll
-  for (uint32_t j = 0; j < 16u; ++j) {
+  for (uint32_t j = 0; j < 4u; ++j) {
+    const uint8_t ch = (uint8_t)(w >> (8 * j));
+    // A C G T N in either case -> 0..4, '-' / anything else -> 5 (dp_code), without a branch per byte
+    const uint8_t up = ch & 0xdfu;
+    const uint32_t c = up == 'A' ? 0u : up == 'C' ? 1u : up == 'G' ? 2u : up == 'T' ? 3u : up == 'N' ? 4u : 5u;
     if (j < cnt) {
-      const uint8_t ch = b[j];
-      const uint32_t c = dp_code(ch);
       invalid |= !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'N');
       any_special |= c >= 4u;
-      b[j] = (uint8_t)c;
+    }
+    codes |= c << (8 * j);
+  }
+  return codes;
+}
+__global__ __launch_bounds__(256) void encode_codes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n,
+                                                           uint8_t* __restrict__ special, int32_t* __restrict__ verr) {
+  const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u;
+  if (i0 >= n) return;
+  bool any_special = false, invalid = false;
+  if (n - i0 >= 16u) {
+    uint32_t w[4];
+    __builtin_memcpy(w, in + i0, 16);  // (unaligned: the payload may start anywhere)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = encode_word(w[q], 4u, any_special, invalid);
+    __builtin_memcpy(out + i0, w, 16);
+  } else {
+    for (uint64_t i = i0; i < n; i += 4) {
+      const uint32_t cnt = (n - i < 4u) ? (uint32_t)(n - i) : 4u;
+      uint32_t w = 0;
+      for (uint32_t j = 0; j < cnt; ++j) w |= (uint32_t)in[i + j] << (8 * j);
+      const uint32_t c = encode_word(w, cnt, any_special, invalid);
+      for (uint32_t j = 0; j < cnt; ++j) out[i + j] = (uint8_t)(c >> (8 * j));
     }
   }
-  if (cnt == 16u) __builtin_memcpy(out + i0, b, 16);
-  else for (uint32_t j = 0; j < cnt; ++j) out[i0 + j] = b[j];
-  if (any_special) {  // rare; 16 bytes from a 16-byte boundary lie in one 256-byte block
-    for (uint32_t j = 0; j < cnt; ++j) if (b[j] >= 4u) special[(i0 + j) >> 8] = 1;
-  }
+  if (any_special) special[i0 >> 8] = 1;  // rare; sixteen bytes from a 16-byte boundary lie in one 256-byte block
   if (verr && invalid) atomicOr(verr, 4);
 }
 
@@ -244,11 +257,13 @@ int copy_out(tracyhip_ctx* ctx, int mem, T* user, const T* dev, size_t count) {
 struct VoteDesc { uint64_t a1_off, a2_off; uint32_t stride, m, n, pad; };
 constexpr int kVoteK = 11;
 constexpr uint32_t kVoteBits = 1u << 16;
+constexpr uint32_t kVotePiece = 65, kVoteTile = 64 * kVotePiece;  // window positions per lane and per LDS tile
 __device__ inline uint32_t vote_hash(uint32_t kmer) { return (kmer * 0x9E3779B1u) >> 16; }
 __global__ __launch_bounds__(64) void kmer_vote_kernel(const VoteDesc* __restrict__ desc, const float* __restrict__ prof,
                                                        const uint8_t* __restrict__ codes, uint32_t* __restrict__ votes) {
   __shared__ uint32_t bm[2][kVoteBits / 32];
   __shared__ uint8_t cons[1040];
+  __shared__ uint8_t win[kVoteTile + 16];
   const VoteDesc d = desc[blockIdx.x];
   const uint32_t lane = threadIdx.x;
   uint32_t hf = 0, hr = 0;
@@ -278,20 +293,29 @@ __global__ __launch_bounds__(64) void kmer_vote_kernel(const VoteDesc* __restric
       atomicOr(&bm[1][h1 >> 5], 1u << (h1 & 31));
     }
     __syncthreads();
-    // every lane rolls over its own contiguous piece of the window (kVoteK - 1 bases of overlap with the next piece)
+    // The window goes through LDS in tiles (coalesced loads); within a tile every lane rolls over its own contiguous piece
+    // (kVoteK - 1 bases of overlap with the next piece).  Pieces of kVotePiece = 65 positions: an odd stride, so the byte
+    // reads of the 64 lanes spread over the banks.  (Rolling straight from global memory -- one dependent, uncoalesced byte
+    // load per position -- took five times as long.)
     const uint32_t npos = d.n - kVoteK + 1;
-    const uint32_t per = (npos + 63) / 64;
-    const uint32_t lo = lane * per, hi = (lo + per < npos) ? lo + per : npos;
-    if (lo < hi) {
-      uint32_t k = 0, valid = 0;
-      for (uint32_t p = lo; p < hi + kVoteK - 1; ++p) {
-        const uint32_t c = codes[d.a2_off + p];
-        if (c < 4u) { k = ((k << 2) | c) & mask; ++valid; }
-        else valid = 0;
-        if (valid >= (uint32_t)kVoteK) {
-          const uint32_t h = vote_hash(k);
-          hf += (bm[0][h >> 5] >> (h & 31)) & 1u;
-          hr += (bm[1][h >> 5] >> (h & 31)) & 1u;
+    for (uint32_t tile = 0; tile < npos; tile += kVoteTile) {
+      const uint32_t tn = (npos - tile < kVoteTile) ? npos - tile : kVoteTile;  // positions of this tile
+      const uint32_t nbytes = tn + kVoteK - 1;
+      __syncthreads();
+      for (uint32_t b = lane; b < nbytes; b += 64) win[b] = codes[d.a2_off + tile + b];
+      __syncthreads();
+      const uint32_t lo = lane * kVotePiece, hi = (lo + kVotePiece < tn) ? lo + kVotePiece : tn;
+      if (lo < hi) {
+        uint32_t k = 0, valid = 0;
+        for (uint32_t p = lo; p < hi + kVoteK - 1; ++p) {
+          const uint32_t c = win[p];
+          if (c < 4u) { k = ((k << 2) | c) & mask; ++valid; }
+          else valid = 0;
+          if (valid >= (uint32_t)kVoteK) {
+            const uint32_t h = vote_hash(k);
+            hf += (bm[0][h >> 5] >> (h & 31)) & 1u;
+            hr += (bm[1][h >> 5] >> (h & 31)) & 1u;
+          }
         }
       }
     }

@@ -885,11 +885,7 @@ static int dp_entry(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyh
   if (!trace && !scores && pairs->npairs) return set_error(TRACYHIP_ERR_ARG, "null scores");
   if (trace && pairs->npairs && (!ops || !ops_offset || !ops_len)) return set_error(TRACYHIP_ERR_ARG, "null ops/ops_offset/ops_len");
   DpProblem pb;
-  struct Recycle {  // the problem borrows the context's vectors and hands them back, whatever the way out
-    tracyhip_ctx* c; DpProblem& p;
-    Recycle(tracyhip_ctx* c_, DpProblem& p_) : c(c_), p(p_) { p.desc.swap(c->cache_desc); p.k.swap(c->cache_k); }
-    ~Recycle() { p.desc.swap(c->cache_desc); p.k.swap(c->cache_k); }
-  } recycle(ctx, pb);
+  DpProblemLease lease(ctx, pb);
   uint64_t max_mn = 0;
   if ((rc = build_problem(ctx, pairs, mem, needle, pb, &max_mn))) return rc;
   if ((rc = check_params(prm, max_mn))) return rc;

@@ -124,6 +124,20 @@ struct tracyhip_ctx {
 };
 
 namespace tracyhip {
+// A DpProblem borrows the context's descriptor vectors for its lifetime and hands them back, whatever the way out: batches of
+// 10^5 pairs are megabytes of descriptors per stage, and allocating them afresh costs a millisecond of page faults each time.
+// (One lease at a time per context: the stages of a pipeline build their problems one after the other.)
+struct DpProblemLease {
+  tracyhip_ctx* c;
+  DpProblem& p;
+  DpProblemLease(tracyhip_ctx* c_, DpProblem& p_) : c(c_), p(p_) {
+    p.desc.swap(c->cache_desc); p.k.swap(c->cache_k);
+    p.desc.clear(); p.k.clear();
+  }
+  ~DpProblemLease() { p.desc.swap(c->cache_desc); p.k.swap(c->cache_k); }
+  DpProblemLease(const DpProblemLease&) = delete;
+  DpProblemLease& operator=(const DpProblemLease&) = delete;
+};
 int timing_begin(tracyhip_ctx* ctx, int which, uint64_t cells, uint64_t bytes);  // record start event
 int timing_end(tracyhip_ctx* ctx);                                              // record stop event
 int timing_collect(tracyhip_ctx* ctx);                                          // after a stream sync

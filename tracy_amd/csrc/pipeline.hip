@@ -419,6 +419,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   };
   auto run_stage1 = [&](std::vector<std::pair<uint32_t, int>> const& what, int stage) -> int {
     DpProblem pb;
+    DpProblemLease lease(ctx, pb);
     pb.mode = MODE_QP;
     pb.a1_profile = true;
     pb.d_a1 = d_prof;
@@ -626,6 +627,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   // ---- 2. preliminary alignment gotoh(trim, oriented reference) (sage.h:258 / indigo.h:302) ----
   {
     DpProblem pb;
+    DpProblemLease lease(ctx, pb);
     pb.mode = MODE_QP;
     pb.a1_profile = true;
     pb.d_a1 = d_prof;
@@ -793,6 +795,7 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
   HIP_TRY(hipMemcpyAsync(ctx->d_ops_off.p, ctx->h_off.p, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
   {
     DpProblem pb;
+    DpProblemLease lease(ctx, pb);
     pb.mode = MODE_QP;
     pb.a1_profile = true;
     pb.d_a1 = d_prof;
@@ -1153,6 +1156,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   std::vector<int32_t> h_sc2(2 * (size_t)nt, 0);
   if (!given && !shared_stages) {
     DpProblem pb;
+    DpProblemLease lease(ctx, pb);
     pb.mode = MODE_QP; pb.a1_profile = true; pb.d_a1 = d_prof; pb.d_a2 = ctx->codes();
     pb.desc.resize(2 * (size_t)nt); pb.k.resize(2 * (size_t)nt);
     for (uint32_t t = 0; t < nt; ++t) {
@@ -1198,6 +1202,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   std::vector<PairDesc> desc_trim(nt);
   {
     DpProblem pb;
+    DpProblemLease lease(ctx, pb);
     pb.mode = wildtype ? MODE_PROF : MODE_QP; pb.a1_profile = true; pb.a2_profile = wildtype; pb.d_a1 = d_prof;
     pb.d_a2 = wildtype ? d_refprof : ctx->codes();
     pb.desc.resize(nt); pb.k.resize(nt);
@@ -1351,6 +1356,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   for (int k = 0; k < 2; ++k) {
     const void* seq = (k == 0) ? d_pri : d_sd;
     DpProblem pb;
+    DpProblemLease lease(ctx, pb);
     pb.mode = use_cq ? MODE_CQ : MODE_CHAR; pb.d_a1 = seq; pb.d_a2 = use_cq ? static_cast<const void*>(d_cq_ref) : d_ref;
     pb.cq_codes = getenv("TRACYHIP_NO_COMPACT") ? 6 : cq_codes;
     pb.desc.resize(nt); pb.k.resize(nt);
@@ -1401,6 +1407,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   }
   {  // allele 1 vs allele 2, global (indigo.h:379-387)
     DpProblem pb;
+    DpProblemLease lease(ctx, pb);
     pb.mode = use_cq ? MODE_CQ : MODE_CHAR; pb.d_a1 = d_pri; pb.d_a2 = use_cq ? static_cast<const void*>(d_cq_sd) : d_sd;
     pb.desc.resize(nt); pb.k.resize(nt);
     for (uint32_t t = 0; t < nt; ++t) {

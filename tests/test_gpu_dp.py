@@ -177,6 +177,28 @@ def test_all_pairs_indexing_and_chunking(ctx):
         assert (int(scores[k]), btr[k]) == orc.gotoh_str(seqs[i], seqs[j], 1, 1, SC)
 
 
+def test_long_pair_list(ctx):
+    """pair lists of 2^16 pairs and more are filled and laid out by several host threads (descriptors, boundary-row scratch of
+    multi-pass pairs as a scan over the threads' totals): the same scores as the same list handed over in two shorter calls,
+    and the oracle's on a sample"""
+    rng = np.random.default_rng(4711)
+    seqs = [rand_seq(rng, int(rng.integers(1, 40))) for _ in range(372)]
+    seqs[5] = rand_seq(rng, 1100)  # more rows than one pass of the tallest strip holds: its pairs use the scratch rows
+    seqs[200] = rand_seq(rng, 1300)
+    seqs[371] = b""
+    idx1 = np.array([i for i in range(372) for j in range(372) if i < j], dtype=np.uint32)
+    idx2 = np.array([j for i in range(372) for j in range(372) if i < j], dtype=np.uint32)
+    assert len(idx1) >= (1 << 16)
+    for params in (SC + (1, 1), SC + (1, 0)):
+        whole = ctx.score(seqs, seqs, params, idx1=idx1, idx2=idx2)
+        h = len(idx1) // 2
+        parts = np.concatenate([ctx.score(seqs, seqs, params, idx1=idx1[:h], idx2=idx2[:h]), ctx.score(seqs, seqs, params, idx1=idx1[h:], idx2=idx2[h:])])
+        assert np.array_equal(whole, parts)
+        sample = list(rng.integers(0, len(idx1), 300)) + [k for k in range(len(idx1)) if idx1[k] in (5, 200) or idx2[k] in (5, 200, 371)][:400]
+        for k in sample:
+            assert int(whole[k]) == orc.gotoh_score_str(seqs[idx1[k]], seqs[idx2[k]], params[4], params[5], SC), k
+
+
 def test_error_reporting(ctx):
     import tracy_amd
     with pytest.raises(tracy_amd.TracyHipError) as e:

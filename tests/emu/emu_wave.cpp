@@ -76,7 +76,10 @@ void run_wave(const DpArgs& a) {
 template <int K>
 void dispatch_narrow(int mode, const DpArgs& a) {
   if (mode == MODE_CHAR) run_wave<K, MODE_CHAR, false, false, true>(a);
-  else if (mode == MODE_PROF) {  // the profile x profile score kernel with 16-bit cells
+  else if (mode == MODE_CQ) {  // strings through the table: both forms of the 16-bit sweep
+    run_wave<K, MODE_CQ, false, false, true, true>(a);
+    run_wave<K, MODE_CQ, false, false, true, false>(a);
+  } else if (mode == MODE_PROF) {  // the profile x profile score kernel with 16-bit cells
     if constexpr (K == 4 || K == 8) run_wave<K, MODE_PROF, false, false, false, true>(a);
   } else {  // both forms of the 16-bit query-profile sweep, as the library launches them: exactly one of them takes the pair
     run_wave<K, MODE_QP, false, false, true, true>(a);
@@ -316,7 +319,7 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
   std::vector<uint8_t> codes;
   std::vector<uint8_t> special;
   if (mode == MODE_QP && !needle) { codes = padded_codes(a2, n); a.a2 = codes.data() + 128; special = special_blocks_of(codes, n); a.special_blocks = special.data(); }
-  if (mode == MODE_CQ) { codes = cq_codes(a2, n); a.a2 = codes.data() + 128; }
+  if (mode == MODE_CQ) { codes = cq_codes(a2, n); a.a2 = codes.data() + 128; special = special_blocks_of(codes, n); a.special_blocks = special.data(); }
   a.bits = bits.data(); a.bits32 = reinterpret_cast<uint32_t*>(bits.data());
   a.scratch = scratch.data(); a.scores = score; a.err = &err;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = hfree; a.vfree = vfree;

@@ -255,6 +255,25 @@ def test_sweep16_compact_and_full_forms(K):
                 assert (got[0], got[1]) == want
 
 
+@pytest.mark.parametrize("K", [8, 15])
+def test_sweep16_strings_through_the_table(K):
+    """MODE_CQ in the 16-bit sweep: gotohScore(string, string) <true,false> with the rows in the table, both forms, reverse
+    complement view, columns outside A C G T N (lower case included: byte equality)"""
+    rng = np.random.default_rng(60 + K)
+    for (m, n) in [(1, 30), (40, 200), (64 * K, 90), (17 * K + 3, 400)]:
+        q = rand_seq(rng, m, b"ACGTACGTN")
+        for alpha in (b"ACGT", b"ACGTACGTN", b"ACGTacgtNx-"):
+            ref = rand_seq(rng, n, alpha)
+            if m > 30 and n > m:
+                ref = ref[:n // 3] + bytes(c if rng.random() > 0.1 else int(rng.choice(list(b"ACGT"))) for c in q[:min(m, n - n // 3)]) + ref[n // 3 + min(m, n - n // 3):]
+                ref = ref[:n]
+            for rc in (False, True):
+                # reverseComplement (fmindex.h:8-24) rewrites A C G T only; every other byte keeps its value
+                oriented = bytes({65: 84, 67: 71, 71: 67, 84: 65}.get(c, c) for c in reversed(ref)) if rc else ref
+                want = orc.gotoh_score_str(q, oriented, 1, 0, SC)
+                assert emu.run(q, ref, SC, 1, 0, emu.MODE_CQ, K, trace=False, narrow=True, revcomp=rc)[0] == want, (m, n, alpha, rc)
+
+
 @pytest.mark.parametrize("K", [12, 15])
 def test_odd_strip_heights(K):
     rng = np.random.default_rng(K)

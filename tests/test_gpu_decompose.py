@@ -162,6 +162,37 @@ def test_decompose_traces_lanes(ctx):
             assert bytes(a) == bytes(b), k
 
 
+def test_origin_sweep_on_the_certified_sub_window(ctx, monkeypatch):
+    """gotoh(allele, window) is only read by trimReferenceSlice; the origin-tracking sweep runs on the columns a 16-bit score
+    sweep certifies (score and row-m end bound where an optimal path can start).  Same results as on the whole window, on
+    the configs[2] mix and on windows whose alleles sit at the very beginning / end"""
+    from tracy_amd import capi, hostlib
+    nd = 160
+    d = hostlib.synth_decompose_batch(606, nd, 3000, 800, 0, mix=1)
+
+    def run():
+        hbc = capi.HostBaseCalls([d["signal"][i] for i in range(nd)], [d["bcpos"][i] for i in range(nd)],
+                                 [d["primary"][i].tobytes() for i in range(nd)], [d["secondary"][i].tobytes() for i in range(nd)])
+        return ctx.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, [d["refs"][i].tobytes() for i in range(nd)], SC)
+    cut = run()
+    monkeypatch.setenv("TRACYHIP_NO_SUBWINDOW", "1")
+    whole = run()
+    monkeypatch.delenv("TRACYHIP_NO_SUBWINDOW")
+    assert int((np.asarray(cut["status"]) == 0).sum()) > nd // 2
+    for k in cut:
+        a, b = cut[k], whole[k]
+        if k in ("dcp_indel", "dcp_err", "ops"):
+            continue
+        if k == "bp":
+            assert [(x.indelshift, x.traceleft, x.breakpoint, x.best_diff) for x in a] == [(x.indelshift, x.traceleft, x.breakpoint, x.best_diff) for x in b]
+        elif isinstance(a, np.ndarray):
+            assert np.array_equal(a, b), k
+        elif isinstance(a, (list, tuple, dict, int, float, str, bytes)):
+            assert a == b, k
+        else:
+            assert bytes(a) == bytes(b), k
+
+
 def test_decompose_beyond_the_default_size_class(ctx):
     """maxindel > 1024 and traces of >= 2048 basecalls: the scan state of decomposeAlleles takes its larger LDS size class
     (decompose_kernels.h DecompDims<4096>), multi-pass strips and full-matrix tracebacks carry the alignments"""

@@ -451,6 +451,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   a.screen = ctx->no_screen ? 0 : 1;
   a.colcode = pb.d_colclass;
   if (pb.mode == MODE_QP && pb.d_a2 == ctx->codes() && !ctx->no_compact) a.special_blocks = ctx->special_blocks();
+  if (pb.mode == MODE_CQ && !ctx->no_compact) a.special_blocks = pb.d_special;
   if (stage == DP_BAND && ctx->timing) {
     a.swept = reinterpret_cast<unsigned long long*>(static_cast<int32_t*>(ctx->d_err.p) + kErrSweptWord);
     HIP_TRY(hipMemsetAsync(a.swept, 0, sizeof(unsigned long long), st));

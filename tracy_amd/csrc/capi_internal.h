@@ -47,6 +47,7 @@ struct DpProblem {
   const void* d_a1 = nullptr;
   const void* d_a2 = nullptr;        // MODE_QP: encoded codes
   const void* d_a2_chars = nullptr;  // the raw a2 payload on the device
+  const uint8_t* d_special = nullptr;  // MODE_CQ 16-bit sweeps: block map of the a2 codes (DpArgs::special_blocks), or null
   int cq_codes = 6;                  // MODE_CQ: what the a2 columns of the batch hold -- 4: A C G T only, 5: with N, 6: anything (origin sweeps size their table by it)
   const uint8_t* d_colclass = nullptr;  // profile x profile: column classes of the a2 set (build_problem), or null
   std::vector<PairDesc> desc;

@@ -334,7 +334,7 @@ TR_HD uint64_t ckpt_index(uint32_t j /*1-based*/, uint32_t field, uint32_t lane,
   return ((uint64_t)(j - 1) * ckpt_fields(K) + field) * 64u + lane;
 }
 
-template <class W, int K, bool CKPT, bool COMPACT>
+template <class W, int K, bool CKPT, bool COMPACT, bool STRINGS>
 TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx);  // the 16-bit query-profile sweep, below
 
 // NT (profile x profile only): 5 = the 25-term substitution score, 4 = the 16-term one (row 4 zero in both profiles of every
@@ -349,8 +349,8 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   static_assert(!(CKPT && TRACE), "checkpoints are written by the score-only kernel");
   // NARROW / CKPT kernels: single pass, free end gaps on the first/last row only, rows anchored at the bottom
   constexpr bool BOTTOM = NARROW || CKPT;
-  if constexpr (NARROW && MODE == MODE_QP) {  // the hot kernel of `tracy align` has its own body
-    gotoh_narrow_qp_body<W, K, CKPT, COMPACT>(w, a, pair_idx);
+  if constexpr (NARROW && qp_like(MODE)) {  // the hot kernel of `tracy align` has its own body (MODE_CQ: its rows are characters)
+    gotoh_narrow_qp_body<W, K, CKPT, COMPACT, MODE == MODE_CQ>(w, a, pair_idx);
     return;
   }
   const PairDesc d = a.pairs[pair_idx];
@@ -784,7 +784,9 @@ TR_HD void qp_wait6(QpStrip<K>& q) {
 TR_HD int32_t lastrow_h(const int32_t* lr, uint32_t c, bool narrow) { return narrow ? sext16(lr[c]) : lr[2 * c]; }
 TR_HD int32_t lastrow_e(const int32_t* lr, uint32_t c, bool narrow, int32_t goe) { return narrow ? (lr[c] >> 16) + goe : lr[2 * c + 1]; }
 
-template <class W, int K, bool CKPT, bool COMPACT>
+// STRINGS: a1 is a string over A C G T N and a2 holds case-sensitive codes (MODE_CQ): table entry = match / mismatch by byte
+// equality (align.h:96-101), a column of any other letter mismatches every row
+template <class W, int K, bool CKPT, bool COMPACT, bool STRINGS>
 TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const PairDesc d = a.pairs[pair_idx];
   // both forms of the kernel are launched over the same pairs; each pair is swept by the one its reference calls for
@@ -796,7 +798,8 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     if (L == 0 && a.scores) a.scores[d.out] = (m == 0) ? 0 : edge_value(false, go, ge, (int32_t)m);
     return;
   }
-  const float* a1p = static_cast<const float*>(a.a1) + d.a1_off;
+  const float* a1p = static_cast<const float*>(a.a1) + (STRINGS ? 0 : d.a1_off);
+  const uint8_t* a1c = static_cast<const uint8_t*>(a.a1) + (STRINGS ? d.a1_off : 0);
   const uint8_t* a2c = static_cast<const uint8_t*>(a.a2) + d.a2_off;
   int16_t* qp_tab = reinterpret_cast<int16_t*>(w.lds());
   const float fmatch = (float)a.match, fmis = (float)a.mismatch;
@@ -830,22 +833,26 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     for (int i = 0; i < K; ++i) {  // (not unrolled: the set-up must not dictate the kernel's register budget)
       const uint32_t r = L * K + i + 1 - pad;
       const bool real = r - 1 < m;
-      float pr[5];
+      float pr[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      uint8_t rch = 0;
+      if (STRINGS) rch = real ? a1c[r - 1] : 0;
+      else {
 #pragma unroll
-      for (int k = 0; k < 5; ++k) pr[k] = real ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+        for (int k = 0; k < 5; ++k) pr[k] = real ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+      }
 #pragma unroll
       for (uint32_t b = 0; b < (COMPACT ? 4u : 5u); ++b) {
-        const int32_t q = real ? onehot_score(pr, b, fmatch, fmis) : 0;
+        const int32_t q = !real ? 0 : STRINGS ? (rch == (uint8_t)"ACGTN"[b] ? a.match : a.mismatch) : onehot_score(pr, b, fmatch, fmis);
         const int32_t qs = q - goe;
         overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
         qabs = imax(qabs, q < 0 ? -q : q);
         const uint32_t row = (rcflag && b < 4u) ? 3u - b : b;  // reverse-complement view: the complement is folded into the table
         qp_tab[qp6_index<K>(row, (uint32_t)i, L)] = (int16_t)qs;
       }
-      if (!COMPACT) qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)(-goe);
+      if (!COMPACT) qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)(((STRINGS && real) ? a.mismatch : 0) - goe);
     }
     if (overflow) flag_error(a.err, 1);
-    if (qabs > a.qlimit) flag_max(a.err, 1, qabs);
+    if (!STRINGS && qabs > a.qlimit) flag_max(a.err, 1, qabs);
     w.sync();
   }
 

@@ -272,7 +272,7 @@ template <int MODE>
 static hipError_t launch_ckpt_m(int K, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s) {
 #define TRACY_CK(KK)                                                                                                   \
   case KK:                                                                                                              \
-    if (narrow && MODE == MODE_QP) {                                                                                    \
+    if (narrow && qp_like(MODE)) {                                                                                      \
       if (a.special_blocks)                                                                                             \
         hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE, true, true>), dim3(npairs), dim3(64), lds_bytes_sweep16(KK, true) + lds_pad(), s, a); \
       hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE, true, false>), dim3(npairs), dim3(64), lds_bytes_sweep16(KK, false), s, a);             \
@@ -285,10 +285,25 @@ static hipError_t launch_ckpt_m(int K, bool narrow, const DpArgs& a, uint32_t np
   }
 #undef TRACY_CK
 }
+// strings through the query-profile table (MODE_CQ): the 16-bit sweep only, both forms like MODE_QP
+static hipError_t launch_ckpt_cq(int K, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+#define TRACY_CKQ(KK)                                                                                                   \
+  case KK:                                                                                                              \
+    if (a.special_blocks)                                                                                               \
+      hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE_CQ, true, true>), dim3(npairs), dim3(64), lds_bytes_sweep16(KK, true) + lds_pad(), s, a); \
+    hipLaunchKernelGGL((gotoh_ckpt_kernel<KK, MODE_CQ, true, false>), dim3(npairs), dim3(64), lds_bytes_sweep16(KK, false), s, a);             \
+    return hipGetLastError();
+  switch (K) {
+    TRACY_CKQ(4) TRACY_CKQ(8) TRACY_CKQ(12) TRACY_CKQ(15) TRACY_CKQ(16)
+    default: return hipErrorInvalidValue;
+  }
+#undef TRACY_CKQ
+}
 hipError_t launch_gotoh_ckpt(int mode, int K, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s) {
   if (npairs == 0) return hipSuccess;
   if (mode == MODE_CHAR) return launch_ckpt_m<MODE_CHAR>(K, narrow, a, npairs, s);
   if (mode == MODE_QP) return launch_ckpt_m<MODE_QP>(K, narrow, a, npairs, s);
+  if (mode == MODE_CQ && narrow) return launch_ckpt_cq(K, a, npairs, s);
   return hipErrorInvalidValue;
 }
 template <int MODE>

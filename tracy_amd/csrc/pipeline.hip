@@ -118,6 +118,28 @@ __global__ void trim_from_ends_kernel(const uint32_t* __restrict__ ends, const u
   out[t] = trim_finish(lead, ce >= lead ? ce - lead : 0u, ref_len[t], trim_left, trim_right, forward[t] != 0);
 }
 
+// c_e of a pair from the row-m values the 16-bit sweep left behind ({H, E - goe} per column): the last column whose H(m, c) is
+// strictly greater than E(m, c) -- where the reference's traceback leaves the trailing run of row m.  One wave per pair.
+struct RowEndDesc { uint64_t off; uint32_t n, pad; };
+__global__ __launch_bounds__(64) void row_m_end_kernel(const RowEndDesc* __restrict__ desc, const int32_t* __restrict__ lastrow, int32_t goe,
+                                                       uint32_t* __restrict__ ce) {
+  const RowEndDesc d = desc[blockIdx.x];
+  const int32_t* lr = lastrow + d.off;
+  uint32_t found = 0;
+  for (int64_t base = d.n; base >= 1 && !found; base -= 64) {
+    const int64_t c = base - threadIdx.x;
+    bool hit = false;
+    if (c >= 1) { const int32_t v = lr[c]; hit = sext16(v) > (v >> 16) + goe; }
+    const unsigned long long mask = __ballot(hit);
+    if (mask) found = (uint32_t)(base - __builtin_ctzll(mask));  // lane 0 holds the largest column
+  }
+  if (threadIdx.x == 0) ce[blockIdx.x] = found;
+}
+__global__ void ends_shift_kernel(uint32_t* __restrict__ ends, const uint32_t* __restrict__ shift, uint32_t ntraces) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ntraces) { ends[2 * t] += shift[t]; ends[2 * t + 1] += shift[t]; }
+}
+
 // trimReferenceSlice (fmindex.h:429-463) on the two alignment rows themselves, as the reference scans them: s / e = first / last + 1
 // column holding a trace base, ri = reference bases before s, risize = reference bases in [s, e).  One wave per trace.
 struct TrimRowsDesc { uint64_t off; uint32_t L, n; uint8_t forward, pad[7]; };
@@ -1376,9 +1398,75 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     bool use_origin = getenv("TRACYHIP_NO_ORIGIN") == nullptr;
     for (uint32_t t = 0; t < nt && use_origin; ++t) use_origin = origin_ok(&p, pb.desc[t].m, pb.desc[t].n, pb.k[t]);
     if (use_origin) {
+      // The origin-tracking sweep is tagged int32 arithmetic (~40 cycles per cell); the plain 16-bit score sweep costs half of
+      // that and yields S* = H(m, n) and c_e, which bound where the alignment can lie: a path from (0, lead) to (m, c_e) with
+      // score S* has at most g = (best * m - S*) / |ge| horizontal gap columns (best = the largest substitution score, every
+      // gap column costs at least |ge|), so lead >= c_e - m - g.  Every optimal path -- and with it every tie the traceback
+      // tests, which would be an optimal path too -- lies in the columns (a, c_e], a = c_e - m - g - 2: the origin sweep runs
+      // on that sub-window only (a third of a 3 kb window for a 1 kb allele) and its two ends are shifted back by a.
+      // TRACYHIP_NO_SUBWINDOW=1: the whole window, as before.
+      std::vector<uint32_t> shift(nt, 0);
+      uint32_t* d_shift = nullptr;
+      bool subwin = use_cq && getenv("TRACYHIP_NO_SUBWINDOW") == nullptr && !ctx->no_narrow;
+      for (uint32_t t = 0; t < nt && subwin; ++t) subwin = narrow_ok(&p, pb.desc[t].m, pb.k[t]);
+      if (subwin) {
+        std::vector<RowEndDesc> hre(nt);
+        uint64_t lr_tot = 0;
+        for (uint32_t t = 0; t < nt; ++t) { pb.desc[t].lastrow_off = lr_tot; hre[t] = RowEndDesc{lr_tot, rn[t], 0}; lr_tot += (uint64_t)rn[t] + 2; }
+        HIP_TRY(ctx->d_lastrow.ensure(lr_tot * 4 + 64));
+        DevBuf &b_sw = buf(), &b_zero = buf();
+        HIP_TRY(b_sw.ensure(sizeof(int32_t) * (size_t)nt + sizeof(uint32_t) * 2 * (size_t)nt));
+        int32_t* d_swscore = static_cast<int32_t*>(b_sw.p);
+        uint32_t* d_ce = reinterpret_cast<uint32_t*>(d_swscore + nt);
+        d_shift = d_ce + nt;
+        if (pb.cq_codes == 4) {  // every column is one of A C G T: an all-clear block map sends every pair to the compact form
+          HIP_TRY(b_zero.ensure((er >> 8) + 2));
+          HIP_TRY(hipMemsetAsync(b_zero.p, 0, (er >> 8) + 2, st));
+          pb.d_special = static_cast<const uint8_t*>(b_zero.p);
+        }
+        DpCkpt sc;
+        sc.B = 0x7fffffffu;  // row m only: no wavefront checkpoints
+        sc.narrow = true;
+        sc.d_ckpt = static_cast<int32_t*>(ctx->d_lastrow.p);  // (never written)
+        sc.d_lastrow = static_cast<int32_t*>(ctx->d_lastrow.p);
+        rc = run_dp(ctx, pb, &p, false, false, d_swscore, nullptr, nullptr, nullptr, DP_CKPT, &sc);
+        pb.d_special = nullptr;
+        if (rc == kWiden) subwin = false;
+        else if (rc) return rc;
+        if (subwin) {
+          const RowEndDesc* d_re;
+          if ((rc = upload(ctx, buf(), hre, &d_re))) return rc;
+          hipLaunchKernelGGL(row_m_end_kernel, dim3(nt), dim3(64), 0, st, d_re, static_cast<const int32_t*>(ctx->d_lastrow.p), p.go + p.ge, d_ce);
+          HIP_TRY(hipGetLastError());
+          std::vector<int32_t> h_s(nt);
+          std::vector<uint32_t> h_ce(nt);
+          HIP_TRY(hipMemcpyAsync(h_s.data(), d_swscore, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipMemcpyAsync(h_ce.data(), d_ce, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipStreamSynchronize(st));
+          const int64_t best = std::max<int64_t>(std::max<int64_t>(p.match, p.mismatch), 0), age = -(int64_t)p.ge;
+          for (uint32_t t = 0; t < nt; ++t) {
+            PairDesc& d = pb.desc[t];
+            const int64_t ce = h_ce[t];
+            if (ce <= 0 || d.m == 0 || d.n == 0) continue;  // no column leaves row m upwards: the whole window
+            const int64_t loss = best * (int64_t)d.m - (int64_t)h_s[t];
+            const int64_t g = loss > 0 ? loss / age : 0;
+            int64_t a = ce - (int64_t)d.m - g - 2;
+            if (a < 0) a = 0;
+            shift[t] = (uint32_t)a;
+            d.a2_off += h_rc[t] ? (uint64_t)(d.n - (uint32_t)ce) : (uint64_t)a;  // reverse view: column c is byte n - c
+            d.n = (uint32_t)(ce - a);
+            d.a2_stride = d.n;
+          }
+          HIP_TRY(hipMemcpyAsync(d_shift, shift.data(), sizeof(uint32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+        }
+      }
       DpCkpt oc;
       oc.d_ends = static_cast<uint32_t*>(b_ends.p);
       if ((rc = run_dp(ctx, pb, &p, false, false, nullptr, nullptr, nullptr, nullptr, DP_ORIGIN, &oc))) return rc;
+      if (subwin) {
+        hipLaunchKernelGGL(ends_shift_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, static_cast<uint32_t*>(b_ends.p),
+                           static_cast<const uint32_t*>(d_shift), nt);
+      }
       hipLaunchKernelGGL(trim_from_ends_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, static_cast<const uint32_t*>(b_ends.p),
                          static_cast<const uint32_t*>(b_rnfw.p), reinterpret_cast<const uint8_t*>(static_cast<const uint32_t*>(b_rnfw.p) + nt),
                          TL, TR, nt, static_cast<TrimOut*>(b_trimA.p));

@@ -226,8 +226,9 @@ class DecomposeLeg:
             return None
         tot_ms = sum(timers[k]["ms"] for k, _ in TIMERS)
         dom = max((k for k, _ in TIMERS), key=lambda k: timers[k]["ms"])
-        names = {"score": ("gotoh_ckpt_kernel<K,QP,narrow> (orientation scores, checkpointed 16-bit sweep)", 8.0, "gotoh_ckpt_kernel"),
-                 "origin": ("gotoh_origin_kernel<K> (gotoh(allele, window) whose alignment only trimReferenceSlice reads)", 11.0, "gotoh_origin_kernel"),
+        names = {"score": ("gotoh_ckpt_kernel<K,QP|CQ,narrow> (16-bit sweeps: the two orientation scores of the trace, and the score + row-m end of "
+                           "each allele vs its window, which certify the sub-window of the origin-tracking sweep)", 8.0, "gotoh_ckpt_kernel"),
+                 "origin": ("gotoh_origin_kernel<K> (gotoh(allele, window) whose alignment only trimReferenceSlice reads, on the certified sub-window)", 11.0, "gotoh_origin_kernel"),
                  "trace": ("gotoh_kernel<K,MODE,TRACE> (full-matrix tracebacks: allele vs trimmed slice, primary vs secondary)", 14.0, "gotoh_kernel"),
                  "band": ("gotoh_band_kernel<K,QP> (band traceback of the trimmed trace)", 14.0, "gotoh_band_kernel"),
                  "walk": ("gotoh_walk_kernel", None, "gotoh_walk_kernel"), "prefix": ("gotoh_prefix_kernel", 8.0, "gotoh_prefix_kernel"),

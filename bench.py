@@ -268,7 +268,7 @@ def main():
     def read_timers():
         kt = capi.KernelTiming()
         res = {}
-        for name, which in (("score", 0), ("trace", 1), ("walk", 2), ("band", 3), ("prefix", 4)):
+        for name, which in (("score", 0), ("trace", 1), ("walk", 2), ("band", 3), ("prefix", 4), ("origin", 5)):
             lib.tracyhip_timing_get(ctx._h, which, C.byref(kt))
             res[name] = dict(ms=kt.ms, launches=int(kt.launches), cells=int(kt.cells), bytes=int(kt.bytes))
         return res
@@ -347,7 +347,7 @@ def main():
         return
 
     gcups = cells_all * args.steps / elapsed_max / 1e9
-    tr, sc, bd = rl["trace"], rl["score"], rl["band"]
+    tr, sc, bd, og = rl["trace"], rl["score"], rl["band"], rl["origin"]
     steps = max(args.steps, 1)
 
     def gbs(x):
@@ -355,13 +355,13 @@ def main():
 
     def kgcups(x):
         return x["cells"] / (x["ms"] * 1e-3) / 1e9 if x["ms"] > 0 else 0.0
-    # Dominant kernel of the step = the score-only Gotoh pass (forward + reverse-complement orientation, with
-    # wavefront checkpoints).  Its algorithmic HBM bytes are the inputs once + 4 B per score, so the
+    # Dominant kernel of the step = the score-only Gotoh pass (forward + reverse-complement orientation; it leaves the values of
+    # row m behind, from which the preliminary alignment's end is read).  Its algorithmic HBM bytes are the inputs once + 4 B per score, so the
     # HBM roofline fraction is tiny by construction: the kernel is VALU-issue bound (see "valu").
     score_launch_ms = sc["ms"] / max(sc["launches"], 1)
     ops_per_cell = 8.0  # 16-bit formulation with the shared gap-open term: 4 v_add_u16 + 4 v_max_i16 per cell
     # HBM bytes of one launch as measured by rocprofv3 PMC passes (WRITE_SIZE + FETCH_SIZE, separate passes, summary
-    # committed under profiles/): mostly the wavefront checkpoints + last-row values the band traceback restarts from
+    # committed under profiles/): the inputs, the scores and the row-m values of the sweeps the orientation vote keeps
     traffic, traffic_src = None, None
     try:
         import glob
@@ -373,7 +373,7 @@ def main():
             traffic_src = "profiles/%s (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE of this command, same batch)" % os.path.basename(pmc_file)
     except (OSError, ValueError, KeyError, IndexError):
         pass
-    roofline = {"bound": "hbm", "kernel": "gotoh_ckpt_kernel<K,QP,narrow> (score-only Gotoh, forward + reverse-complement orientation in one launch, checkpointed; dominant: %.0f%% of the step)"
+    roofline = {"bound": "hbm", "kernel": "gotoh_ckpt_kernel<K,QP,narrow> (score-only Gotoh, forward + reverse-complement orientation in one launch, row m kept; dominant: %.0f%% of the step)"
                 % (100.0 * sc["ms"] / steps / (elapsed_max / steps * 1e3)),
                 "achieved": round(gbs(sc), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs(sc) / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(score_launch_ms, 3), "launches": sc["launches"],
@@ -387,10 +387,15 @@ def main():
                                      "frac": round(gbs(tr) / HBM_PEAK_GBS, 4), "kernel_gcups": round(kgcups(tr), 1),
                                      "avg_launch_ms": round(tr["ms"] / max(tr["launches"], 1), 3),
                                      "algorithmic_bytes_per_launch": tr["bytes"] // max(tr["launches"], 1)},
-                "ms_per_step": {"score": round(sc["ms"] / steps, 3), "band_traceback": round(bd["ms"] / steps, 3),
-                                "full_traceback": round(tr["ms"] / steps, 3), "walk": round(rl["walk"]["ms"] / steps, 3)},
-                "band_traceback": {"swept_gcups": round(kgcups(bd), 1), "swept_fraction_of_its_matrix": round(bd["cells"] / steps / max(mt * n * nt, 1), 3),
-                                   "effective_gcups_over_the_matrix": round(mt * n * nt * steps / (bd["ms"] * 1e-3) / 1e9, 1) if bd["ms"] > 0 else 0.0}}
+                "ms_per_step": {"score": round(sc["ms"] / steps, 3), "preliminary_ends": round(og["ms"] / steps, 3),
+                                "band_traceback": round(bd["ms"] / steps, 3), "full_traceback": round(tr["ms"] / steps, 3),
+                                "walk": round(rl["walk"]["ms"] / steps, 3)},
+                # the preliminary alignment (trimmed trace vs the whole window) is only trimmed from: its two ends come from an
+                # origin-tracking sweep over the sub-window the score sweep certifies (band traceback where that does not apply)
+                "preliminary_alignment": {"kernel": "gotoh_origin_kernel<K,QP> on the certified sub-window" if og["ms"] > 0 else "gotoh_band_kernel<K,QP>",
+                                          "swept_gcups": round(kgcups(og if og["ms"] > 0 else bd), 1),
+                                          "swept_fraction_of_its_matrix": round((og["cells"] + bd["cells"]) / steps / max(mt * n * nt, 1), 3),
+                                          "effective_gcups_over_the_matrix": round(mt * n * nt * steps / ((og["ms"] + bd["ms"]) * 1e-3) / 1e9, 1) if (og["ms"] + bd["ms"]) > 0 else 0.0}}
 
     line = {
         "metric": "GCUPS (tracy align: Gotoh affine-gap DP cells per second, whole job)",
@@ -405,12 +410,12 @@ def main():
         # GCUPS counts the DP cells of the reference's four Gotoh calls per trace: two score-only sweeps and
         # the final traceback are swept in full; the preliminary traceback is a band traceback from the score sweep's
         # checkpoints, which re-sweeps only the bands its path crosses (about an eighth of its matrix) for the same `btr`
-        "cells_counted": "reference DP cells: 3 x (mt x n) + mf x slice per trace; the preliminary traceback re-sweeps ~12% of its mt x n",
+        "cells_counted": "reference DP cells: 3 x (mt x n) + mf x slice per trace; the preliminary alignment sweeps ~10% of its mt x n (certified sub-window)",
         # the same step priced by the cells the kernels really evaluated (HIP-event timers: both orientation sweeps and the final
         # traceback in full, the band traceback only its re-swept bands): what `value` would be if the band traceback were not credited
         # with its whole matrix
-        "gcups_swept_cells": round(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix")) / steps * world / (elapsed_max / steps) / 1e9, 2),
-        "cells_swept_per_step_rank0": int(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix")) / steps),
+        "gcups_swept_cells": round(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin")) / steps * world / (elapsed_max / steps) / 1e9, 2),
+        "cells_swept_per_step_rank0": int(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin")) / steps),
         "roofline": roofline,
     }
     if rl_cert is not None:
@@ -422,7 +427,7 @@ def main():
         line["strand_by_certificate"] = {
             "ms_per_step": round(elapsed_cert_max / args.steps * 1e3, 3),
             "traces_per_s": round(nt * world * args.steps / elapsed_cert_max, 1),
-            "cells_swept_fraction": round(sum(rl_cert[k]["cells"] for k in ("score", "prefix", "trace", "band")) / steps / max(cells_rank, 1), 3),
+            "cells_swept_fraction": round(sum(rl_cert[k]["cells"] for k in ("score", "prefix", "trace", "band", "origin")) / steps / max(cells_rank, 1), 3),
             # the strand to sweep first is voted from shared k-mers; its full sweeps and the prefix bounds of the other strand
             # share one launch (the short prefix workgroups fill the tail of the long sweeps)
             "sweep_launch": {"kernel": "gotoh_ckpt_prefix_kernel<K,8> (full sweeps + prefix bounds)",

@@ -141,3 +141,22 @@ def screen_check(a, b, match, mismatch, nt):
                                 int(nt), counts)
     assert rc == 0
     return int(counts[0]), int(counts[1])
+
+
+def run_origin_qp(prof, a2, score, K, revcomp=False):
+    """origin-tracking sweep with profile rows (the preliminary alignment of `tracy align`): prof float32 [6][m], a2 reference
+    characters (encoded as the library does).  Returns (score, leading 'h' columns, last column that is not a trailing 'h')"""
+    prof = np.ascontiguousarray(prof, dtype=np.float32)
+    m = prof.shape[1]
+    lut = np.full(256, 6, dtype=np.uint8)
+    for chars, code in ((b"Aa", 0), (b"Cc", 1), (b"Gg", 2), (b"Tt", 3), (b"Nn", 4), (b"-", 5)):
+        for ch in chars:
+            lut[ch] = code
+    b2 = np.frombuffer(lut[np.frombuffer(bytes(a2), dtype=np.uint8)].tobytes() + b"\0", dtype=np.uint8).copy()
+    n = len(a2)
+    sc = C.c_int32(0)
+    ends = np.zeros(2, np.uint32)
+    rc = lib().emu_origin_qp(K, C.c_void_p(prof.ctypes.data), C.c_uint32(m), C.c_uint32(m), b2.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_uint32(n),
+                             C.c_uint32(1 if revcomp else 0), *[int(x) for x in score], C.byref(sc), ends.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert rc == 0
+    return sc.value, int(ends[0]), int(ends[1])

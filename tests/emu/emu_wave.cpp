@@ -120,7 +120,7 @@ void run_ckpt_pair(const DpArgs& a, const WalkArgs& wa) {
   }
 }
 
-template <int K, bool TABLE = false, int NC = 6>
+template <int K, int TABLE = 0, int NC = 6>
 void run_origin_wave(const DpArgs& a) {
   WaveShared sh;
   sh.lds.assign(lds_bytes(MODE_CQ, K) + 64, 0);
@@ -238,11 +238,11 @@ int emu_origin(int K, const uint8_t* a1, uint32_t m, const uint8_t* a2, uint32_t
     int ncodes = 4;  // the smallest table the columns allow, as the library chooses
     for (uint32_t j = 0; j < n; ++j) ncodes = std::max(ncodes, codes[128 + j] >= 5 ? 6 : codes[128 + j] == 4 ? 5 : 4);
     switch (K) {
-      case 4: if (ncodes == 4) run_origin_wave<4, true, 4>(a); else if (ncodes == 5) run_origin_wave<4, true, 5>(a); else run_origin_wave<4, true, 6>(a); break;
-      case 8: if (ncodes == 4) run_origin_wave<8, true, 4>(a); else if (ncodes == 5) run_origin_wave<8, true, 5>(a); else run_origin_wave<8, true, 6>(a); break;
-      case 12: if (ncodes == 4) run_origin_wave<12, true, 4>(a); else if (ncodes == 5) run_origin_wave<12, true, 5>(a); else run_origin_wave<12, true, 6>(a); break;
-      case 15: if (ncodes == 4) run_origin_wave<15, true, 4>(a); else if (ncodes == 5) run_origin_wave<15, true, 5>(a); else run_origin_wave<15, true, 6>(a); break;
-      case 16: if (ncodes == 4) run_origin_wave<16, true, 4>(a); else if (ncodes == 5) run_origin_wave<16, true, 5>(a); else run_origin_wave<16, true, 6>(a); break;
+      case 4: if (ncodes == 4) run_origin_wave<4, 1, 4>(a); else if (ncodes == 5) run_origin_wave<4, 1, 5>(a); else run_origin_wave<4, 1, 6>(a); break;
+      case 8: if (ncodes == 4) run_origin_wave<8, 1, 4>(a); else if (ncodes == 5) run_origin_wave<8, 1, 5>(a); else run_origin_wave<8, 1, 6>(a); break;
+      case 12: if (ncodes == 4) run_origin_wave<12, 1, 4>(a); else if (ncodes == 5) run_origin_wave<12, 1, 5>(a); else run_origin_wave<12, 1, 6>(a); break;
+      case 15: if (ncodes == 4) run_origin_wave<15, 1, 4>(a); else if (ncodes == 5) run_origin_wave<15, 1, 5>(a); else run_origin_wave<15, 1, 6>(a); break;
+      case 16: if (ncodes == 4) run_origin_wave<16, 1, 4>(a); else if (ncodes == 5) run_origin_wave<16, 1, 5>(a); else run_origin_wave<16, 1, 6>(a); break;
       default: return -1;
     }
     return 0;
@@ -292,6 +292,29 @@ int emu_band(int mode, int K, int narrow, uint32_t B, const void* a1, uint32_t m
   }
 #undef EMU_CK
   if (err_out) *err_out = err;
+  return 0;
+}
+
+// origin-tracking sweep with profile rows (MODE_QP): a1 = float[6][stride] profile, a2 = reference characters
+int emu_origin_qp(int K, const float* a1, uint32_t m, uint32_t stride, const uint8_t* a2, uint32_t n, uint32_t flags, int32_t match,
+                  int32_t mismatch, int32_t go, int32_t ge, int32_t* score, uint32_t* ends) {
+  PairDesc d{};
+  d.m = m; d.n = n; d.a1_stride = stride; d.a2_stride = n; d.flags = flags & 1u; d.out = 0;
+  int32_t errw[kErrWords] = {0};
+  DpArgs a{};
+  a.pairs = &d; a.a1 = a1; a.scores = score; a.err = errw; a.ends = ends;
+  a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = 1; a.vfree = 0;
+  a.qlimit = std::max(std::abs(match), std::abs(mismatch));
+  std::vector<uint8_t> codes = padded_codes(a2, n);
+  a.a2 = codes.data() + 128;
+  switch (K) {
+    case 4: run_origin_wave<4, 2, 6>(a); break;
+    case 8: run_origin_wave<8, 2, 6>(a); break;
+    case 12: run_origin_wave<12, 2, 6>(a); break;
+    case 15: run_origin_wave<15, 2, 6>(a); break;
+    case 16: run_origin_wave<16, 2, 6>(a); break;
+    default: return -1;
+  }
   return 0;
 }
 

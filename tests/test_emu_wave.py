@@ -400,6 +400,34 @@ def test_origin_sweep_ends():
             assert got == (w2[0],) + ends_of(w2[1], n), (m, n, K, rep, "table")
 
 
+def test_origin_sweep_with_profile_rows():
+    """the origin-tracking sweep with a trace profile as a1 (MODE_QP table): score and the two ends of gotoh(profile,
+    _createProfile(window)) <true,false>, as trimReferenceSlice reads them off the traceback (tracy align, sage.h:258-259)"""
+    import emu
+    import pyoracle as orc
+    rng = np.random.default_rng(404)
+
+    def ends_of(btr, n):
+        fwd = btr[::-1]
+        return len(fwd) - len(fwd.lstrip(b"h")), n - (len(fwd) - len(fwd.rstrip(b"h")))
+    for (m, n, K) in [(1, 9, 4), (30, 200, 4), (64, 300, 8), (200, 700, 15), (15 * 64, 1200, 15), (500, 520, 8)]:
+        for rep in range(3):
+            ref = rand_seq(rng, n, b"ACGT" if rep != 1 else b"ACGTACGTN-x")
+            start = int(rng.integers(0, max(1, n - m + 1)))
+            src = (ref[start:start + m] + rand_seq(rng, m))[:m]
+            p1 = np.zeros((6, m), np.float32)
+            for j, ch in enumerate(src):
+                col = rng.random(4).astype(np.float32) * np.float32(0.15)
+                if ch in b"ACGT" and rng.random() > 0.05:
+                    col[b"ACGT".index(ch)] += np.float32(1)
+                p1[:4, j] = col / col.sum()
+            rc = rep == 2
+            p2 = orc.create_profile_str(ref)
+            want = orc.gotoh_prof(p1, orc.revcomp_profile(p2) if rc else p2, 1, 0, SC)
+            got = emu.run_origin_qp(p1, ref, SC, K, revcomp=rc)
+            assert got == (want[0],) + ends_of(want[1], n), (m, n, K, rep)
+
+
 def test_string_traceback_through_the_table():
     """MODE_CQ: gotoh(string, string) with the row chars in the query-profile table == the byte-compare kernel == the oracle,
     all AlignConfigs, reverse-complement view, columns with letters outside ACGTN (lower case included: byte equality)"""

@@ -154,3 +154,35 @@ def test_profile_x_profile_900(ctx):
     for i, w in enumerate(wants):
         assert int(sc_only[i]) == w[0], i
         assert (int(scores[i]), btr[i]) == w, i
+
+
+def test_align_preliminary_alignment_by_its_two_ends(monkeypatch):
+    """`tracy align` reads nothing of the preliminary alignment but trimReferenceSlice's two ends: by default an origin-tracking
+    sweep over the certified sub-window delivers them (no checkpoints, no band traceback).  Same results as with the band
+    traceback, in both orientation modes, also for traces that barely match their window (wide sub-windows) and for profiles
+    whose entries exceed max(match, mismatch) (the bound falls back to the larger limit)"""
+    import tracy_amd
+    from tracy_amd import hostlib
+    nt = 40
+    refs, profs, rev = hostlib.synth_align(2024, nt, 6000, 1000, 0)
+    profs = profs.copy()
+    rng = np.random.default_rng(5)
+    profs[3] = rng.random(profs[3].shape).astype(np.float32)  # an unrelated trace: low score, wide sub-window
+    profs[3][4:] = 0
+    profs[3][:4] /= profs[3][:4].sum(axis=0, keepdims=True)
+    profs[5][:4] *= np.float32(1.4)                           # column masses 1.4: scores above `match`
+    refl = [r.tobytes() for r in refs]
+    c = tracy_amd.Context(0)
+    try:
+        for exact in (True, False):
+            monkeypatch.delenv("TRACYHIP_NO_PRELIM_ORIGIN", raising=False)
+            got = c.align_traces(list(profs), refl, SC, 50, 50, exact_scores=exact)
+            monkeypatch.setenv("TRACYHIP_NO_PRELIM_ORIGIN", "1")
+            ref = c.align_traces(list(profs), refl, SC, 50, 50, exact_scores=exact)
+            monkeypatch.delenv("TRACYHIP_NO_PRELIM_ORIGIN")
+            keys = ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final") + (("score_fwd", "score_rev") if exact else ())
+            for k in keys:
+                assert np.array_equal(got[k], ref[k]), (k, exact)
+            assert got["btr"] == ref["btr"]
+    finally:
+        c.close()

@@ -448,6 +448,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge;
   a.hfree = prm->hfree; a.vfree = prm->vfree;
   a.qlimit = sub_limit(prm);
+  a.qpos = std::max(std::max(prm->match, prm->mismatch), 0);
   a.screen = ctx->no_screen ? 0 : 1;
   a.colcode = pb.d_colclass;
   if (pb.mode == MODE_QP && pb.d_a2 == ctx->codes() && !ctx->no_compact) a.special_blocks = ctx->special_blocks();
@@ -496,7 +497,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
       if (stage == DP_PREFIX) {
         HIP_TRY(launch_gotoh_prefix(K, a, e - j, st));
       } else if (stage == DP_ORIGIN) {
-        HIP_TRY(launch_gotoh_origin(K, pb.mode == MODE_CQ, pb.cq_codes, a, e - j, st));
+        HIP_TRY(launch_gotoh_origin(K, pb.mode == MODE_CQ ? 1 : pb.mode == MODE_QP ? 2 : 0, pb.cq_codes, a, e - j, st));
       } else if (stage == DP_CKPT) {
         // one representation for the whole batch: the caller checks narrow_ok for the largest problem
         narrow = ck->narrow;
@@ -545,6 +546,9 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
     ctx->acc[TRACYHIP_TIMER_BAND].cells -= std::min<uint64_t>(ctx->acc[TRACYHIP_TIMER_BAND].cells, band_cells_credited);
     ctx->acc[TRACYHIP_TIMER_BAND].cells += h_swept;
   }
+  if (herr[0] & 16) ctx->qpos_exceeded = true;  // (informational: a profile entry above max(match, mismatch); see DpArgs::qpos)
+  // the packed score field of the origin-tracking sweep is sized for substitution scores of normalised profiles
+  if (stage == DP_ORIGIN && pb.mode == MODE_QP && herr[1] > sub_limit(prm)) return kWiden;
   const int verdict = range_verdict(prm, herr, narrow_launches, max_mn, trace ? (needle ? 2 : kTagShift) : 0);
   if (verdict == kWiden && stage == DP_PLAIN) {  // the 16-bit score kernel met an un-normalised profile: same work on the int32 kernel
     const bool keep = ctx->no_narrow;
@@ -686,6 +690,7 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   a.a1 = d_a1; a.a2 = d_a2; a.scores = d_scores; a.err = static_cast<int32_t*>(ctx->d_err.p);
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge; a.hfree = prm->hfree; a.vfree = prm->vfree;
   a.qlimit = sub_limit(prm);
+  a.qpos = std::max(std::max(prm->match, prm->mismatch), 0);
   if (d_a2 == ctx->codes() && !ctx->no_compact) a.special_blocks = ctx->special_blocks();
   a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.ckpt_narrow = 1;
   DpArgs af = a, ap = a;
@@ -704,6 +709,7 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   timing_collect(ctx);
+  if (herr[0] & 16) ctx->qpos_exceeded = true;
   uint32_t maxm = 0;
   uint64_t max_mn = 0;
   for (size_t i = 0; i < nf + np; ++i) { maxm = std::max(maxm, hd[i].m); max_mn = std::max<uint64_t>(max_mn, (uint64_t)hd[i].m + hd[i].n); }

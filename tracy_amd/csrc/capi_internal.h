@@ -64,6 +64,7 @@ struct tracyhip_ctx {
   tracyhip::DevBuf d_desc, d_bits, d_scratch, d_in1, d_in2, d_codes, d_scores, d_ops, d_ops_off, d_ops_len, d_err,
       d_rows0, d_rows1;
   tracyhip::DevBuf d_special;
+  tracyhip::DevBuf d_ends;  // tracy align: ends of the preliminary alignments + scratch of that stage (orient_and_align)
   std::vector<tracyhip::PairDesc> cache_desc;  // descriptor / strip-height vectors of the generic DP entry points, kept between
   std::vector<int> cache_k;                    // calls (an all-pairs list is 36 MB: allocating it afresh costs 6 ms of page faults)
   tracyhip::DevBuf d_tmp[8];
@@ -92,6 +93,7 @@ struct tracyhip_ctx {
   uint32_t mem_share = 1;  // contexts planning workspace on this device at the same time (lanes of one call): each takes its share of what is free
   bool timing = false;
   bool no_narrow = false;  // TRACYHIP_NO_NARROW=1: force the int32 score kernel (A/B measurements)
+  bool qpos_exceeded = false;  // some 16-bit sweep since the flag was last cleared met a profile entry above max(match, mismatch, 0)
   bool no_compact = false; // TRACYHIP_NO_COMPACT=1: every 16-bit sweep on the six-code table (A/B measurements)
   bool no_screen = false;  // TRACYHIP_NO_SCREEN=1: profile x profile scores by the full float chain only (A/B measurements)
   std::vector<Pending> pending;
@@ -115,7 +117,7 @@ struct tracyhip_ctx {
     for (auto* b : all) b->release();
     for (auto& b : d_tmp) b.release();
     for (auto& b : d_pipe) b.release();
-    d_ckpt.release(); d_lastrow.release(); d_band.release(); d_special.release();
+    d_ckpt.release(); d_lastrow.release(); d_band.release(); d_special.release(); d_ends.release();
     d_aftab.release(); aftab_ready = false;
     h_desc.release();
     h_off.release();

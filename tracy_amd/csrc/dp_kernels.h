@@ -69,6 +69,9 @@ struct DpArgs {
   int32_t match, mismatch, go, ge;
   int32_t qlimit;       // max(|match|, |mismatch|): what a substitution score of NORMALISED profiles cannot exceed.  The host-side
                         // range guards (narrow_ok, origin_ok, check_params) assume it; kernels report anything larger in err[1..3]
+  int32_t qpos;         // max(match, mismatch, 0): the largest substitution score of a NORMALISED profile (entries >= 0, mass <= 1).
+                        // The 16-bit query-profile sweep sets err flag 16 when a table entry exceeds it: bounds that count on it
+                        // (the sub-window of the preliminary alignment, pipeline.hip) then fall back to qlimit
   int32_t hfree, vfree;
   int32_t screen;       // profile x profile: substitution scores by the screened short form where it is proven (SubProf::screen)
   const uint8_t* special_blocks;  // MODE_QP: one byte per 256 code bytes of the a2 buffer, non-zero where the block holds an N or a
@@ -828,7 +831,7 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   // code 5 ('-' / other) and rows off the trace score 0 ----
   {
     bool overflow = false;
-    int32_t qabs = 0;
+    int32_t qabs = 0, qtop = 0;
 #pragma unroll 1
     for (int i = 0; i < K; ++i) {  // (not unrolled: the set-up must not dictate the kernel's register budget)
       const uint32_t r = L * K + i + 1 - pad;
@@ -846,6 +849,7 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         const int32_t qs = q - goe;
         overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
         qabs = imax(qabs, q < 0 ? -q : q);
+        qtop = imax(qtop, q);
         const uint32_t row = (rcflag && b < 4u) ? 3u - b : b;  // reverse-complement view: the complement is folded into the table
         qp_tab[qp6_index<K>(row, (uint32_t)i, L)] = (int16_t)qs;
       }
@@ -853,6 +857,7 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     }
     if (overflow) flag_error(a.err, 1);
     if (!STRINGS && qabs > a.qlimit) flag_max(a.err, 1, qabs);
+    if (!STRINGS && qtop > a.qpos) flag_error(a.err, 16);
     w.sync();
   }
 
@@ -1011,7 +1016,10 @@ constexpr int32_t kNegInfOrigin = -6000;
 // [code][row][lane] table in LDS, one shift-add per cell instead of compare + select + add
 // NC (with TABLE): code rows of the table.  The caller knows which characters the columns of the launch hold (encode_cq_kernel):
 // A C G T only -> 4 rows, with N -> 5, anything else -> 6.  7.5 / 9.4 / 11.3 KB at K = 15: 20 / 17 / 14 workgroups per CU.
-template <class W, int K, bool TABLE = false, int NC = 6>
+// TABLE: 0 = byte compare per cell (strings), 1 = strings through the table (MODE_CQ: rows over A C G T N, a2 holds
+// case-sensitive codes), 2 = profile rows through the table (MODE_QP: a1 is a float profile, a2 holds reference codes) -- the
+// preliminary alignment of `tracy align`, which only trimReferenceSlice reads (pipeline.hip)
+template <class W, int K, int TABLE = 0, int NC = 6>
 TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const PairDesc d = a.pairs[pair_idx];
   const uint32_t L = w.lane();
@@ -1027,7 +1035,8 @@ TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     }
     return;
   }
-  const uint8_t* a1c = static_cast<const uint8_t*>(a.a1) + d.a1_off;
+  const uint8_t* a1c = static_cast<const uint8_t*>(a.a1) + (TABLE == 2 ? 0 : d.a1_off);
+  const float* a1p = static_cast<const float*>(a.a1) + (TABLE == 2 ? d.a1_off : 0);
   const uint8_t* a2c = static_cast<const uint8_t*>(a.a2) + d.a2_off;
   const uint32_t lanes_used = (m + K - 1) / K;
   const uint32_t t_end = n + lanes_used - 1;
@@ -1044,26 +1053,41 @@ TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     ts.Ec[i] = neg;
     ts.cx1[i] = trace_cx1<TS>(hz ? 0 : go + ge);
     ts.cx2[i] = trace_cx2<TS>(hz ? 0 : ge);
-    sub_c.rc[i] = (r - 1 < m) ? (int32_t)a1c[r - 1] : -1;
+    sub_c.rc[i] = (TABLE != 2 && r - 1 < m) ? (int32_t)a1c[r - 1] : -1;
   }
   sub_c.vmatch = (int32_t)((uint32_t)a.match << SH);
   sub_c.vmis = (int32_t)((uint32_t)a.mismatch << SH);
   sub_c.cc = 0;
   int16_t* qp_tab = reinterpret_cast<int16_t*>(w.lds());
   if (TABLE) {  // raw scores; the shift into the score field happens where a value is used (SubRows<K, SH>)
+    const float fmatch = (float)a.match, fmis = (float)a.mismatch;
+    int32_t qabs = 0;
 #pragma unroll 1
     for (int i = 0; i < K; ++i) {
       const uint32_t r = L * K + i + 1;
       const bool real = r - 1 < m;
-      const uint8_t rch = real ? a1c[r - 1] : 0;
       const bool rcv = (d.flags & PAIR_A2_REVCOMP) != 0;
+      uint8_t rch = 0;
+      float pr[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      if (TABLE == 2) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) pr[k] = real ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+      } else {
+        rch = real ? a1c[r - 1] : 0;
+      }
 #pragma unroll
       for (uint32_t b = 0; b < (NC < 5 ? (uint32_t)NC : 5u); ++b) {
         const uint32_t row = (rcv && b < 4u) ? 3u - b : b;
-        qp_tab[qp6_index<K>(row, (uint32_t)i, L)] = (int16_t)(real ? (rch == (uint8_t)"ACGTN"[b] ? a.match : a.mismatch) : 0);
+        int32_t q;
+        if (TABLE == 2) q = real ? onehot_score(pr, b, fmatch, fmis) : 0;
+        else q = real ? (rch == (uint8_t)"ACGTN"[b] ? a.match : a.mismatch) : 0;
+        qabs = imax(qabs, q < 0 ? -q : q);
+        qp_tab[qp6_index<K>(row, (uint32_t)i, L)] = (int16_t)q;
       }
-      if (NC > 5) qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)(real ? a.mismatch : 0);
+      // code 5: a column no row letter can equal mismatches (strings); an all-zero profile column scores 0 (profiles)
+      if (NC > 5) qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)((TABLE == 1 && real) ? a.mismatch : 0);
     }
+    if (TABLE == 2 && qabs > a.qlimit) flag_max(a.err, 1, qabs);  // un-normalised profile: the packed score field is sized for |q| <= qlimit
     w.sync();
   }
   const uint32_t row_above = L * K;

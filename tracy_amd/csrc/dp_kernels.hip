@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64) void gotoh_ckpt_kernel(DpArgs a) {
   gotoh_body<DeviceWave, K, MODE, false, NARROW, true, 0, COMPACT>(w, a, blockIdx.x);
 }
 // origin-tracking sweep (string x string): score + the two ends of the alignment, no traceback words
-template <int K, bool TABLE = false, int NC = 6>
+template <int K, int TABLE = 0, int NC = 6>
 __global__ __launch_bounds__(64) void gotoh_origin_kernel(DpArgs a) {
   DeviceWave w;
   gotoh_origin_body<DeviceWave, K, TABLE, NC>(w, a, blockIdx.x);
@@ -325,14 +325,24 @@ hipError_t launch_band_trace(int mode, int K, const DpArgs& a, const WalkArgs& w
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_gotoh_origin(int K, bool table, int codes, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+hipError_t launch_gotoh_origin(int K, int table, int codes, const DpArgs& a, uint32_t npairs, hipStream_t s) {
   if (npairs == 0) return hipSuccess;
+  if (table == 2) {  // profile rows (MODE_QP): six code rows
+#define TRACY_ORIGIN_QP(KK) \
+  case KK: hipLaunchKernelGGL((gotoh_origin_kernel<KK, 2, 6>), dim3(npairs), dim3(64), lds_bytes(MODE_QP, KK) + lds_pad(), s, a); break;
+    switch (K) {
+      TRACY_ORIGIN_QP(4) TRACY_ORIGIN_QP(8) TRACY_ORIGIN_QP(12) TRACY_ORIGIN_QP(15) TRACY_ORIGIN_QP(16)
+      default: return hipErrorInvalidValue;
+    }
+#undef TRACY_ORIGIN_QP
+    return hipGetLastError();
+  }
   if (table) {
 #define TRACY_ORIGIN_CASE(KK)                                                                                                          \
   case KK:                                                                                                                              \
-    if (codes <= 4) hipLaunchKernelGGL((gotoh_origin_kernel<KK, true, 4>), dim3(npairs), dim3(64), 4u * 64u * KK * 2u + lds_pad(), s, a);      \
-    else if (codes == 5) hipLaunchKernelGGL((gotoh_origin_kernel<KK, true, 5>), dim3(npairs), dim3(64), 5u * 64u * KK * 2u + lds_pad(), s, a); \
-    else hipLaunchKernelGGL((gotoh_origin_kernel<KK, true, 6>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, KK), s, a);                          \
+    if (codes <= 4) hipLaunchKernelGGL((gotoh_origin_kernel<KK, 1, 4>), dim3(npairs), dim3(64), 4u * 64u * KK * 2u + lds_pad(), s, a);      \
+    else if (codes == 5) hipLaunchKernelGGL((gotoh_origin_kernel<KK, 1, 5>), dim3(npairs), dim3(64), 5u * 64u * KK * 2u + lds_pad(), s, a); \
+    else hipLaunchKernelGGL((gotoh_origin_kernel<KK, 1, 6>), dim3(npairs), dim3(64), lds_bytes(MODE_CQ, KK), s, a);                          \
     break;
     switch (K) {
       TRACY_ORIGIN_CASE(4) TRACY_ORIGIN_CASE(8) TRACY_ORIGIN_CASE(12) TRACY_ORIGIN_CASE(15) TRACY_ORIGIN_CASE(16)

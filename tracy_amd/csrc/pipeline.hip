@@ -365,10 +365,14 @@ struct OrientIn {
   const uint64_t* d_ops_off;
   uint32_t* d_ops_len;
   int32_t* d_score;         // device [nt] or null
+  bool ends_only;           // the caller reads nothing of the preliminary alignment but trimReferenceSlice's two ends (`tracy align`):
+                            // where it can be certified, the band traceback gives way to an origin-tracking sweep (OrientOut::d_ends)
 };
 struct OrientOut {
   std::vector<int32_t> sc2;     // [2 nt] forward / reverse scores (the loser's may be a certified upper bound)
   std::vector<uint8_t> fwd, rc; // rs.forward; "read the window as its reverse complement"
+  const uint32_t* d_ends = nullptr;  // device [2 nt] when set: {leading 'h' columns, last column that is not a trailing 'h'} of the
+                                     // preliminary alignment instead of its ops (OrientIn::ends_only)
 };
 
 int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn& in, OrientOut& o, bool force_wide) {
@@ -380,6 +384,8 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   int32_t* d_verr = in.d_verr;
   int32_t h_verr = 0;
   bool verr_fetched = false;
+  o.d_ends = nullptr;
+  ctx->qpos_exceeded = false;
   // ---- 1. orientation scores: gotohScore(trim, fwd) / gotohScore(trim, rev)  (sage.h:239-240) ----
   // When every trimmed profile fits one pass of its strip height, the score pass also leaves wavefront
   // checkpoints and the last-row values, and stage 2 recomputes only the bands its path crosses
@@ -390,6 +396,24 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   DpCkpt ck;
   ck.B = 256;
   if (const char* e = getenv("TRACYHIP_CKPT_B")) { const int b = atoi(e); if (b >= 32 && b <= 1024) ck.B = (uint32_t)b; }  // developer knob
+  // ends_path: the preliminary alignment is only trimmed from (OrientIn::ends_only).  The sweep's score S* and the end c_e of
+  // the alignment on row m (row_m_end_kernel) bound where an optimal path can lie -- at most g = (Q m - S*) / |ge| horizontal
+  // gap columns, so it starts no earlier than column c_e - m - g -- and an origin-tracking sweep over that sub-window (about a
+  // tenth of a 10 kb window) delivers the two ends trimReferenceSlice reads: no wavefront checkpoints, no band traceback.
+  // (The argument is the one of the allele alignments of `tracy decompose`)
+  bool ends_path = in.ends_only && use_band && !force_wide && !ctx->no_narrow && getenv("TRACYHIP_NO_PRELIM_ORIGIN") == nullptr;
+  {
+    uint32_t maxmt = 0;
+    for (uint32_t t = 0; t < nt; ++t) maxmt = std::max(maxmt, mt[t]);
+    ends_path = ends_path && nt && narrow_ok(&p, maxmt, 16);
+    for (uint32_t t = 0; t < nt && ends_path; ++t)
+    {
+      // the sub-window is at most m + g + 2 columns with g <= (Q m - S*) / |ge| and S* >= go + m ge (the all-gap path)
+      const uint64_t cap = 2ull * mt[t] + ((uint64_t)sub_limit(&p) * mt[t] + (uint64_t)(-(int64_t)p.go)) / (uint64_t)(-(int64_t)p.ge) + 3;
+      ends_path = mt[t] && rn[t] && origin_ok(&p, mt[t], (uint32_t)std::min<uint64_t>(rn[t], cap), choose_k(mt[t], MODE_QP));
+    }
+  }
+  if (ends_path) ck.B = 0x7fffffffu;  // row m only
   // in.oriented: the references are already oriented by the caller (k-mer seeding): one score pass, no decision
   const bool given = in.oriented != nullptr;
   const int norient = given ? 1 : 2;
@@ -409,8 +433,9 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       }
     }
     if (use_band) {
-      const uint64_t need = (ck_tot + lr_tot) * 4 + (uint64_t)nt * ck.B * 64 * 8;
-      const bool have = ctx->d_ckpt.cap >= ck_tot * 4 + 64 && ctx->d_lastrow.cap >= lr_tot * 4 + 64 && ctx->d_band.cap >= (uint64_t)nt * ck.B * 64 * 8;
+      const uint64_t band_bytes = ends_path ? 0 : (uint64_t)nt * ck.B * 64 * 8;  // (no band traceback on the ends path)
+      const uint64_t need = (ck_tot + lr_tot) * 4 + band_bytes;
+      const bool have = ctx->d_ckpt.cap >= ck_tot * 4 + 64 && ctx->d_lastrow.cap >= lr_tot * 4 + 64 && ctx->d_band.cap >= band_bytes;
       size_t fr = 0, tot = 0;
       if (!have) HIP_TRY(hipMemGetInfo(&fr, &tot));  // (a driver call: skipped when the grow-only buffers already fit)
       if (!have && need > (uint64_t)(fr * 0.8 / ctx->mem_share) + ctx->d_ckpt.cap + ctx->d_lastrow.cap + ctx->d_band.cap) use_band = false;
@@ -425,6 +450,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       }
     }
   }
+  ends_path = ends_path && use_band && ck.narrow;
   auto stage1_desc = [&](uint32_t t, int orient) {  // orient 0 = forward, 1 = reverse complement
     PairDesc d{};
     d.a1_off = in.a1_off[t];
@@ -611,6 +637,8 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
     // Both orientations swept in full (exact gsFwd / gsRev).  Only the winner's checkpoints are ever read, so the sweeps
     // of the strand an orientation vote marks as the likely loser write none (vote_skips_checkpoints: the kernel reads the
     // votes itself, no host round trip); a likely loser that wins after all is swept once more, with checkpoints.
+    // (Also on the ends path, where only row m is kept: the sweep of the likely loser is 2 % faster without its row-m stores,
+    // which is more than the vote costs.)
     const bool vote_ckpt = !given && use_band && ck.narrow && getenv("TRACYHIP_NO_VOTE") == nullptr;
     std::vector<uint32_t> h_votes;
     if (vote_ckpt) {
@@ -672,7 +700,53 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       pb.desc[t] = d;
       pb.k[t] = choose_k(d.m, MODE_QP);
     }
-    if (use_band) {
+    if (ends_path) {
+      // c_e from the winner's row m, the sub-window from S* and c_e, the two ends from the origin-tracking sweep over it
+      HIP_TRY(ctx->d_ends.ensure(sizeof(uint32_t) * 4 * (size_t)nt + sizeof(RowEndDesc) * (size_t)nt));
+      uint32_t* d_ends = static_cast<uint32_t*>(ctx->d_ends.p);
+      uint32_t* d_ce = d_ends + 2 * (size_t)nt;
+      uint32_t* d_shift = d_ce + nt;
+      RowEndDesc* d_re = reinterpret_cast<RowEndDesc*>(d_shift + nt);
+      std::vector<RowEndDesc> hre(nt);
+      for (uint32_t t = 0; t < nt; ++t) hre[t] = RowEndDesc{pb.desc[t].lastrow_off, rn[t], 0};
+      HIP_TRY(hipMemcpyAsync(d_re, hre.data(), sizeof(RowEndDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(row_m_end_kernel, dim3(nt), dim3(64), 0, st, static_cast<const RowEndDesc*>(d_re), static_cast<const int32_t*>(ck.d_lastrow),
+                         p.go + p.ge, d_ce);
+      HIP_TRY(hipGetLastError());
+      std::vector<uint32_t> h_ce(nt), shift(nt, 0);
+      HIP_TRY(hipMemcpyAsync(h_ce.data(), d_ce, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));  // (also: hre has been read)
+      // the largest substitution score of a diagonal step: max(match, mismatch, 0) for normalised profiles (what createProfile
+      // writes); a sweep that met a larger table entry has said so (DpArgs::qpos), then only |q| <= max(|match|, |mismatch|) holds
+      const int64_t best = ctx->qpos_exceeded ? (int64_t)sub_limit(&p) : std::max<int64_t>(std::max<int64_t>(p.match, p.mismatch), 0);
+      const int64_t age = -(int64_t)p.ge;
+      std::vector<int32_t> h_pre(nt);
+      for (uint32_t t = 0; t < nt; ++t) {
+        PairDesc& d = pb.desc[t];
+        h_pre[t] = h_rc[t] ? h_sc2[nt + t] : h_sc2[t];
+        const int64_t ce = h_ce[t];
+        if (ce <= 0) continue;  // no column leaves row m upwards: the whole window
+        const int64_t loss = best * (int64_t)d.m - (int64_t)h_pre[t];
+        const int64_t g = loss > 0 ? loss / age : 0;
+        int64_t a = ce - (int64_t)d.m - g - 2;
+        if (a < 0) a = 0;
+        shift[t] = (uint32_t)a;
+        d.a2_off += h_rc[t] ? (uint64_t)(d.n - (uint32_t)ce) : (uint64_t)a;  // reverse view: column c is byte n - c
+        d.n = (uint32_t)(ce - a);
+        d.a2_stride = d.n;
+      }
+      bool fits = true;  // (the pre-check used an upper bound of the sub-window; windows cut at c_e can only be shorter)
+      for (uint32_t t = 0; t < nt && fits; ++t) fits = origin_ok(&p, pb.desc[t].m, pb.desc[t].n, pb.k[t]);
+      if (!fits) return set_error(TRACYHIP_ERR_RANGE, "preliminary alignment: sub-window outside the origin-tracking sweep's range");
+      HIP_TRY(hipMemcpyAsync(d_shift, shift.data(), sizeof(uint32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+      DpCkpt oc;
+      oc.d_ends = d_ends;
+      if ((rc = run_dp(ctx, pb, &p, false, false, nullptr, nullptr, nullptr, nullptr, DP_ORIGIN, &oc))) return rc;  // (kWiden: the caller restarts wide)
+      hipLaunchKernelGGL(ends_shift_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, d_ends, static_cast<const uint32_t*>(d_shift), nt);
+      HIP_TRY(hipGetLastError());
+      if (in.d_score) HIP_TRY(hipMemcpy(in.d_score, h_pre.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice));
+      o.d_ends = d_ends;
+    } else if (use_band) {
       // the preliminary score equals the winning orientation score (same DP): no score array needed from the band pass
       if ((rc = run_dp(ctx, pb, &p, false, true, nullptr, in.d_ops,
                        in.d_ops_off, in.d_ops_len, DP_BAND, &ck)))
@@ -776,7 +850,7 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
   for (uint32_t t = 0; t < nt; ++t) { a1o[t] = sp.offset[t] + tl[t]; a2o[t] = sr.offset[ridx[t]]; }
   OrientIn oi{};
   oi.nt = nt; oi.d_prof = d_prof; oi.a1_off = a1o.data(); oi.mf = mf.data(); oi.mt = mt.data(); oi.a2_off = a2o.data(); oi.rn = rn.data();
-  oi.oriented = job->oriented; oi.exact = job->strand_by_certificate == 0; oi.d_verr = d_verr;
+  oi.oriented = job->oriented; oi.exact = job->strand_by_certificate == 0; oi.d_verr = d_verr; oi.ends_only = true;
   oi.d_ops = static_cast<uint8_t*>(ctx->d_tmp[1].p); oi.d_ops_off = static_cast<const uint64_t*>(ctx->d_tmp[2].p);
   oi.d_ops_len = static_cast<uint32_t*>(ctx->d_tmp[3].p); oi.d_score = static_cast<int32_t*>(ctx->d_tmp[4].p);
   OrientOut oo;
@@ -796,9 +870,13 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
     std::memcpy(hp + sizeof(uint32_t) * (size_t)nt, h_fwd.data(), nt);
     HIP_TRY(hipMemcpyAsync(d_rn, hp, sizeof(uint32_t) * (size_t)nt + nt, hipMemcpyHostToDevice, st));
   }
-  hipLaunchKernelGGL(trim_kernel, dim3(nt), dim3(64), 0, st, static_cast<const uint8_t*>(ctx->d_tmp[1].p),
-                     static_cast<const uint64_t*>(ctx->d_tmp[2].p), static_cast<const uint32_t*>(ctx->d_tmp[3].p), d_rn, d_fwd,
-                     job->trim_left, job->trim_right, nt, static_cast<TrimOut*>(ctx->d_tmp[5].p));
+  if (oo.d_ends)  // the two ends of the preliminary alignment (origin-tracking sweep) instead of its ops
+    hipLaunchKernelGGL(trim_from_ends_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, oo.d_ends, static_cast<const uint32_t*>(d_rn),
+                       static_cast<const uint8_t*>(d_fwd), (uint32_t)job->trim_left, (uint32_t)job->trim_right, nt, static_cast<TrimOut*>(ctx->d_tmp[5].p));
+  else
+    hipLaunchKernelGGL(trim_kernel, dim3(nt), dim3(64), 0, st, static_cast<const uint8_t*>(ctx->d_tmp[1].p),
+                       static_cast<const uint64_t*>(ctx->d_tmp[2].p), static_cast<const uint32_t*>(ctx->d_tmp[3].p), d_rn, d_fwd,
+                       job->trim_left, job->trim_right, nt, static_cast<TrimOut*>(ctx->d_tmp[5].p));
   HIP_TRY(hipGetLastError());
   std::vector<TrimOut> h_trim(nt);
   HIP_TRY(hipMemcpyAsync(h_trim.data(), ctx->d_tmp[5].p, sizeof(TrimOut) * (size_t)nt, hipMemcpyDeviceToHost, st));

@@ -1022,6 +1022,8 @@ constexpr int32_t kNegInfOrigin = -6000;
 template <class W, int K, int TABLE = 0, int NC = 6>
 TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const PairDesc d = a.pairs[pair_idx];
+  // profile rows: two forms over the same pairs, as the 16-bit sweep -- four code rows for references of A C G T, six otherwise
+  if (TABLE == 2 && reference_is_plain(w, a, d) != (NC == 4)) return;
   const uint32_t L = w.lane();
   const uint32_t m = d.m, n = d.n;
   const int32_t go = a.go, ge = a.ge;

@@ -328,8 +328,11 @@ hipError_t launch_band_trace(int mode, int K, const DpArgs& a, const WalkArgs& w
 hipError_t launch_gotoh_origin(int K, int table, int codes, const DpArgs& a, uint32_t npairs, hipStream_t s) {
   if (npairs == 0) return hipSuccess;
   if (table == 2) {  // profile rows (MODE_QP): six code rows
-#define TRACY_ORIGIN_QP(KK) \
-  case KK: hipLaunchKernelGGL((gotoh_origin_kernel<KK, 2, 6>), dim3(npairs), dim3(64), lds_bytes(MODE_QP, KK) + lds_pad(), s, a); break;
+#define TRACY_ORIGIN_QP(KK)                                                                                                            \
+  case KK:                                                                                                                              \
+    if (a.special_blocks) hipLaunchKernelGGL((gotoh_origin_kernel<KK, 2, 4>), dim3(npairs), dim3(64), 4u * 64u * KK * 2u + lds_pad(), s, a); \
+    hipLaunchKernelGGL((gotoh_origin_kernel<KK, 2, 6>), dim3(npairs), dim3(64), lds_bytes(MODE_QP, KK), s, a);                              \
+    break;
     switch (K) {
       TRACY_ORIGIN_QP(4) TRACY_ORIGIN_QP(8) TRACY_ORIGIN_QP(12) TRACY_ORIGIN_QP(15) TRACY_ORIGIN_QP(16)
       default: return hipErrorInvalidValue;

@@ -449,6 +449,9 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   a.hfree = prm->hfree; a.vfree = prm->vfree;
   a.qlimit = sub_limit(prm);
   a.qpos = std::max(std::max(prm->match, prm->mismatch), 0);
+  // Gotoh tracebacks: the sweep's workgroup walks its pair itself (TRACYHIP_NO_FUSED_WALK=1: the separate walk launch)
+  const bool fused_walk = trace && stage == DP_PLAIN && !needle && getenv("TRACYHIP_NO_FUSED_WALK") == nullptr;
+  if (fused_walk) { a.walk_ops = d_ops; a.walk_ops_off = d_ops_off; a.walk_ops_len = d_ops_len; }
   a.screen = ctx->no_screen ? 0 : 1;
   a.colcode = pb.d_colclass;
   if (pb.mode == MODE_QP && pb.d_a2 == ctx->codes() && !ctx->no_compact) a.special_blocks = ctx->special_blocks();
@@ -519,7 +522,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
       else
         HIP_TRY(needle ? launch_needle(pb.mode, K, trace, a, e - j, st) : launch_gotoh(pb.mode, K, trace, narrow, a, e - j, st));
       if ((trc = timing_end(ctx))) return trc;
-      if (trace && stage == DP_PLAIN) {
+      if (trace && stage == DP_PLAIN && !fused_walk) {
         WalkArgs wa{};
         wa.pairs = dd + j;
         wa.bits = a.bits;

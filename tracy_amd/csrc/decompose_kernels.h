@@ -81,6 +81,7 @@ struct DecompArgs {
   DecompOut* out;
   DecompParams prm;
   uint32_t ntraces;
+  const uint32_t* lens;  // alignment columns per trace where they are still on the device (overrides DecompDesc::L), or null
 };
 
 constexpr int kMaxIndelDev = 1024;  // maxindel handled in LDS (CLI default 1000)

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(64) void decompose_kernel(DecompArgs a, const Break
   const uint32_t t = blockIdx.x;
   DecompDesc d = a.desc[t];
   d.breakpoint = bps[t].breakpoint;
+  if (a.lens) d.L = a.lens[t];
   const uint32_t lane = threadIdx.x;
   DecompOut out{};
   for (int st = 0; st < kDecompSteps; ++st) {
@@ -120,15 +121,130 @@ __global__ __launch_bounds__(64) void breakpoint_kernel(const BpDesc* desc, cons
   }
 }
 
+// ---- findHomozygousBreakpoint (decompose.h:59-128): one wavefront per trace ---------------------------
+// The two alignment rows are read 64 columns at a time (one lane per trace reads them a byte at a time from 10^5 different
+// pages: 1.4 ms when the rows sit in large pages and 27 ms when the allocator handed out small ones).  A chunk becomes two
+// 64-bit masks -- row0 != row1 and row0 != '-' -- and the mismatch counts of the two 25-column windows of column b + lane are
+// popcounts of 25 bits cut from three consecutive mismatch masks; varIndex is a running popcount of the other mask.
+__device__ __forceinline__ uint64_t mask_bits(uint64_t lo, uint64_t hi, uint32_t s) { return s ? (lo >> s) | (hi << (64 - s)) : lo; }
+
+struct HomChunk { uint64_t mm, ng; };
+__device__ __forceinline__ HomChunk hom_chunk(const uint8_t* r0, const uint8_t* r1, uint32_t L, uint64_t b, uint32_t lane) {
+  const uint64_t j = b + lane;
+  uint8_t x = '-', y = '-';
+  if (j < L) { x = r0[j]; y = r1[j]; }
+  HomChunk c;
+  c.mm = __ballot(x != y);
+  c.ng = __ballot(x != '-');
+  return c;
+}
+
+// SELECT = false: F = max(0, max_i (float)diff_i) and the varIndex the walk ends with; SELECT = true: the position the
+// reference's walk (float-typed running maximum, see breakpoint_kernel) ends on, given F
+template <bool SELECT>
+__device__ __forceinline__ void hom_sweep(const uint8_t* r0, const uint8_t* r1, uint32_t L, uint32_t lo, uint32_t hi, uint32_t lane,
+                                          float& F, uint32_t& var_end, uint32_t& var_at, int32_t& left_lt_right) {
+  float fmax_l = 0.0f;
+  uint32_t first_l = 0xffffffffu, last_l = 0, first_var = 0, last_var = 0, vbase = 0, vend = 0;
+  int32_t first_tl = 0, last_tl = 0;
+  HomChunk cur = hom_chunk(r0, r1, L, 0, lane), nxt = hom_chunk(r0, r1, L, 64, lane);
+  uint64_t prev = 0;
+  for (uint64_t b = 0; b < hi; b += 64) {
+    const HomChunk nn = hom_chunk(r0, r1, L, b + 128, lane);
+    const uint64_t i = b + lane;
+    if (i >= lo && i < hi) {
+      const uint64_t lw = lane < 25 ? mask_bits(prev, cur.mm, lane + 39) : mask_bits(cur.mm, nxt.mm, lane - 25);
+      const uint64_t rw = mask_bits(cur.mm, nxt.mm, lane);
+      const int32_t lc = __popcll(lw & 0x1ffffffull), rc = __popcll(rw & 0x1ffffffull);
+      const double left = (double)lc / 25.0, right = (double)rc / 25.0;
+      double diff = right - left;
+      if (diff < 0) diff = -diff;
+      const float g = (float)diff;
+      if (!SELECT) {
+        if (diff > 0.0 && g > fmax_l) fmax_l = g;
+      } else {
+        const uint32_t var = vbase + (uint32_t)__popcll(cur.ng & ((2ull << lane) - 1ull));
+        const int32_t tl = (left < right) ? 1 : 0;
+        if (g == F && diff > 0.0 && (uint32_t)i < first_l) { first_l = (uint32_t)i; first_var = var; first_tl = tl; }
+        if (diff > (double)F) { last_l = (uint32_t)i + 1; last_var = var; last_tl = tl; }
+      }
+    }
+    if (!SELECT) vend += (uint32_t)__popcll(hi - b >= 64 ? cur.ng : cur.ng & ((1ull << (hi - b)) - 1ull));
+    vbase += (uint32_t)__popcll(cur.ng);
+    prev = cur.mm; cur = nxt; nxt = nn;
+  }
+  if (!SELECT) {
+    for (int o = 32; o > 0; o >>= 1) { const float x = __shfl_xor(fmax_l, o, 64); if (x > fmax_l) fmax_l = x; }
+    F = fmax_l;
+    var_end = vend;
+    return;
+  }
+  uint32_t first = first_l, last = last_l;
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t a = (uint32_t)__shfl_xor((int)first, o, 64), c = (uint32_t)__shfl_xor((int)last, o, 64);
+    if (a < first) first = a;
+    if (c > last) last = c;
+  }
+  // the columns are distinct across lanes: exactly one lane holds the chosen one
+  const bool mine = last ? last_l == last : first_l == first;
+  const uint64_t owner = __ballot(mine);
+  const int src = owner ? __builtin_ctzll(owner) : 0;
+  var_at = (uint32_t)__shfl((int)(last ? last_var : first_var), src, 64);
+  left_lt_right = __shfl(last ? last_tl : first_tl, src, 64);
+}
+
 __global__ __launch_bounds__(64) void homozygous_kernel(const RowsDesc* desc, const uint8_t* rows0, const uint8_t* rows1,
-                                                        uint32_t n, BreakpointOut* bps, int32_t* status) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
+                                                        uint32_t n, BreakpointOut* bps, int32_t* status, const uint32_t* lens) {
+  const uint32_t t = blockIdx.x, lane = threadIdx.x;
   BreakpointOut bp = bps[t];
-  if (bp.indelshift) { status[t] = 1; return; }  // only when the trace shows no shift (indigo.h:314-317)
+  if (bp.indelshift) {  // only when the trace shows no shift (indigo.h:314-317)
+    if (lane == 0) status[t] = 1;
+    return;
+  }
   const RowsDesc d = desc[t];
-  status[t] = homozygous_breakpoint(rows0 + d.off, rows1 + d.off, d.L, bp);
-  bps[t] = bp;
+  const uint8_t* r0 = rows0 + d.off;
+  const uint8_t* r1 = rows1 + d.off;
+  const uint32_t L = lens ? lens[t] : d.L;
+  // first and last column with a base in both rows
+  int64_t align_start = 0, align_end = 0;
+  for (uint64_t b = 0; b < L; b += 64) {
+    const uint64_t j = b + lane;
+    const uint64_t m = __ballot(j < L && r0[j] != '-' && r1[j] != '-');
+    if (m) { align_start = (int64_t)b + __builtin_ctzll(m); break; }
+  }
+  for (int64_t b = L ? (int64_t)((L - 1) / 64) * 64 : -1; b >= 0; b -= 64) {
+    const uint64_t j = (uint64_t)b + lane;
+    const uint64_t m = __ballot(j < L && r0[j] != '-' && r1[j] != '-');
+    if (m) { align_end = b + 63 - __builtin_clzll(m); break; }
+  }
+  int rc = 1;
+  if (align_start >= align_end) {
+    rc = 0;
+  } else {
+    bp.bestDiff = 0;
+    bp.traceleft = 1;
+    bp.breakpoint = 0;
+    if (align_end < align_start + 50) {
+      rc = -1;
+    } else {
+      const uint32_t lo = (uint32_t)(align_start + 25), hi = (uint32_t)(align_end - 25);
+      float F = 0.0f;
+      uint32_t var_end = 0, var_at = 0;
+      int32_t ltr = 0;
+      hom_sweep<false>(r0, r1, L, lo, hi, lane, F, var_end, var_at, ltr);
+      bp.indelshift = 1;
+      if ((double)F < 0.25) {
+        bp.indelshift = 0;
+        bp.breakpoint = var_end;
+      } else {
+        hom_sweep<true>(r0, r1, L, lo, hi, lane, F, var_end, var_at, ltr);
+        bp.breakpoint = var_at;
+        bp.bestDiff = F;
+        bp.traceleft = ltr;
+      }
+    }
+  }
+  if (lane == 0) { status[t] = rc; bps[t] = bp; }
 }
 
 __global__ void secdecomp_kernel(const BcDesc* desc, const int32_t* signal, const int32_t* bcpos, const uint8_t* pri,
@@ -448,10 +564,10 @@ int launch_breakpoint(tracyhip_ctx* ctx, const BpDesc* d_desc, uint32_t n, uint3
   return TRACYHIP_OK;
 }
 int launch_homozygous(tracyhip_ctx* ctx, const RowsDesc* d_desc, const uint8_t* d_rows0, const uint8_t* d_rows1, uint32_t n,
-                      BreakpointOut* d_bps, int32_t* d_status) {
+                      BreakpointOut* d_bps, int32_t* d_status, const uint32_t* d_lens) {
   if (n == 0) return TRACYHIP_OK;
   { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, 0); if (trc_) return trc_; }
-  hipLaunchKernelGGL(homozygous_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_desc, d_rows0, d_rows1, n, d_bps, d_status);
+  hipLaunchKernelGGL(homozygous_kernel, dim3(n), dim3(64), 0, ctx->stream, d_desc, d_rows0, d_rows1, n, d_bps, d_status, d_lens);
   HIP_TRY(hipGetLastError());
   { int trc_ = timing_end(ctx); if (trc_) return trc_; }
   return TRACYHIP_OK;

@@ -14,7 +14,7 @@ struct BcDesc { uint64_t sig_off; uint64_t bc_off; uint32_t nsamples; uint32_t n
 
 int launch_breakpoint(tracyhip_ctx* ctx, const BpDesc* d_desc, uint32_t n, uint32_t maxcol, const float* d_prof, BreakpointOut* d_out);
 int launch_homozygous(tracyhip_ctx* ctx, const RowsDesc* d_desc, const uint8_t* d_rows0, const uint8_t* d_rows1, uint32_t n,
-                      BreakpointOut* d_bps, int32_t* d_status);
+                      BreakpointOut* d_bps, int32_t* d_status, const uint32_t* d_lens = nullptr);  // d_lens: overrides RowsDesc::L
 // work_cells / work_bytes: what the kernel timers (tracyhip_timing_get) account for the launch -- alignment columns walked and
 // algorithmic bytes (alignment rows + basecalls read, basecalls rewritten); 0 = not accounted
 // maxbc: the longest trace (basecalls) of the batch; it and prm.maxindel pick the size class of the LDS-resident scan state

@@ -74,6 +74,11 @@ struct DpArgs {
                         // (the sub-window of the preliminary alignment, pipeline.hip) then fall back to qlimit
   int32_t hfree, vfree;
   int32_t screen;       // profile x profile: substitution scores by the screened short form where it is proven (SubProf::screen)
+  // traceback kernels: where the walker's output goes when the workgroup walks its own pair right after the sweep (null: a
+  // separate walk launch).  Same meaning as WalkArgs::ops / ops_off / ops_len.
+  uint8_t* walk_ops;
+  const uint64_t* walk_ops_off;
+  uint32_t* walk_ops_len;
   const uint8_t* special_blocks;  // MODE_QP: one byte per 256 code bytes of the a2 buffer, non-zero where the block holds an N or a
                                   // '-' / other code (written by the encoders); null = unknown.  The 16-bit sweep exists in two
                                   // forms (gotoh_narrow_qp_body): references without such codes take the one with the small table

@@ -46,10 +46,22 @@ struct DeviceWave {
 };
 
 // COMPACT (16-bit query-profile sweeps only): the form with the four-code table, for references of A C G T (gotoh_narrow_qp_body)
+// The workgroup that wrote a pair's traceback words walks them at once (DpArgs::walk_ops set): the words are still in the
+// cache, the walk of an early pair fills the tail of the sweep of a late one, and one launch less per stage.  The words were
+// written by the lanes of this very wave: a workgroup-scope fence orders them before the walker's loads.
+__device__ __forceinline__ void walk_own_pair(DeviceWave& w, const DpArgs& a, int K) {
+  if (!a.walk_ops) return;
+  w.sync_global();
+  WalkArgs wa{};
+  wa.pairs = a.pairs; wa.bits = a.bits; wa.ops = a.walk_ops; wa.ops_off = a.walk_ops_off; wa.ops_len = a.walk_ops_len; wa.err = a.err; wa.K = K;
+  gotoh_walk_wave<DeviceWave>(w, wa, blockIdx.x);
+}
+
 template <int K, int MODE, bool TRACE, bool NARROW = false, bool COMPACT = false>
 __global__ __launch_bounds__(64) void gotoh_kernel(DpArgs a) {
   DeviceWave w;
   gotoh_body<DeviceWave, K, MODE, TRACE, NARROW, false, 0, COMPACT>(w, a, blockIdx.x);
+  if constexpr (TRACE) walk_own_pair(w, a, K);
 }
 // profile x profile with the number of substitution terms fixed per launch (NT = 4: PAIR_ROW4_ZERO pairs, 5: the rest): one
 // body per kernel keeps the register count where four waves per SIMD fit
@@ -58,6 +70,7 @@ template <int K, bool TRACE, int NT, bool A16 = false>
 __global__ __launch_bounds__(64) void gotoh_prof_kernel(DpArgs a) {
   DeviceWave w;
   gotoh_body<DeviceWave, K, MODE_PROF, TRACE, false, false, NT, A16>(w, a, blockIdx.x);
+  if constexpr (TRACE) walk_own_pair(w, a, K);
 }
 
 // checkpointed score pass (wavefront checkpoints + last row) and the band traceback that consumes them

@@ -1089,7 +1089,7 @@ namespace {
 template <class T>
 int upload(tracyhip_ctx* ctx, DevBuf& b, const std::vector<T>& v, const T** out) {
   HIP_TRY(b.ensure(sizeof(T) * std::max<size_t>(v.size(), 1)));
-  if (!v.empty()) HIP_TRY(hipMemcpy(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+  if (!v.empty()) { HIP_TRY(hipMemcpyAsync(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, ctx->stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); }
   *out = static_cast<const T*>(b.p);
   return TRACYHIP_OK;
 }
@@ -1334,35 +1334,27 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     ra.npairs = nt;
     HIP_TRY(launch_alignment_rows(ra, st));
   }
-  std::vector<uint32_t> h_len1(nt);
-  std::vector<int32_t> h_strim(nt);
-  HIP_TRY(hipMemcpyAsync(h_len1.data(), b_len1.p, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(h_strim.data(), d_strim, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  std::vector<int32_t> h_status(nt, 0);
-  for (uint32_t t = 0; t < nt; ++t) {  // indigo.h:303-309
-    const double seqsize = (double)mt[t];
-    const double thr = seqsize * 0.35 * prm->match + seqsize * (1 - 0.35) * prm->mismatch;
-    if ((double)h_strim[t] <= thr) h_status[t] = -1;
-  }
+  // the alignment lengths stay on the device for the next kernels (they come to the host with the results of stage 5: a
+  // synchronisation here leaves the GPU idle for 2 ms, and the short-wavefront kernels that follow then start at idle clocks)
+  const uint32_t* d_len1 = static_cast<const uint32_t*>(b_len1.p);
 
   // ---- 4. findHomozygousBreakpoint where the trace shows no shift (indigo.h:314-317) ----
   DevBuf& b_hst = buf();
   HIP_TRY(b_hst.ensure(sizeof(int32_t) * (size_t)nt));
   {
     std::vector<RowsDesc> hd(nt);
-    for (uint32_t t = 0; t < nt; ++t) hd[t] = RowsDesc{off1[t], h_len1[t], 0};
+    for (uint32_t t = 0; t < nt; ++t) hd[t] = RowsDesc{off1[t], 0, 0};
     const RowsDesc* dd;
     if ((rc = upload(ctx, buf(), hd, &dd))) return rc;
     if ((rc = launch_homozygous(ctx, dd, static_cast<const uint8_t*>(b_r0.p), static_cast<const uint8_t*>(b_r1.p), nt,
-                                static_cast<BreakpointOut*>(d_bp), static_cast<int32_t*>(b_hst.p))))
+                                static_cast<BreakpointOut*>(d_bp), static_cast<int32_t*>(b_hst.p), d_len1)))
       return rc;
   }
 
   // ---- 5. decomposeAlleles, generateSecondaryDecomposed, allelicFraction (indigo.h:340-350) ----
   {
     std::vector<DecompDesc> hd(nt);
-    for (uint32_t t = 0; t < nt; ++t) hd[t] = DecompDesc{off1[t], bc.bc_offset[t], out->dcp_offset[t], h_len1[t], mf[t], rn[t], 0};
+    for (uint32_t t = 0; t < nt; ++t) hd[t] = DecompDesc{off1[t], bc.bc_offset[t], out->dcp_offset[t], 0, mf[t], rn[t], 0};
     const DecompDesc* dd;
     if ((rc = upload(ctx, buf(), hd, &dd))) return rc;
     DecompArgs a{};
@@ -1376,9 +1368,8 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     a.out = static_cast<DecompOut*>(d_dst);
     a.prm = DecompParams{dp.trim_left, dp.trim_right, dp.maxindel, dp.madc};
     a.ntraces = nt;
-    uint64_t wc = 0, wb = 0;
-    for (uint32_t t = 0; t < nt; ++t) { wc += h_len1[t]; wb += 2ull * h_len1[t] + 4ull * mf[t]; }
-    if ((rc = launch_decompose(ctx, a, static_cast<const BreakpointOut*>(d_bp), maxbc, wc, wb))) return rc;
+    a.lens = d_len1;
+    if ((rc = launch_decompose(ctx, a, static_cast<const BreakpointOut*>(d_bp), maxbc, 0, 0))) return rc;  // accounted below, once the lengths are here
     std::vector<BcDesc> hb(nt);
     for (uint32_t t = 0; t < nt; ++t) hb[t] = BcDesc{bc.signal_offset[t], bc.bc_offset[t], bc.nsamples[t], mf[t]};
     const BcDesc* db;
@@ -1388,7 +1379,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       return rc;
     if ((rc = launch_allelic_fraction(ctx, db, nt, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos),
                                       static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sd), TL, TR,
-                                      static_cast<double*>(d_fr), wb * 0 + 18ull * std::accumulate(mf.begin(), mf.end(), 0ull))))
+                                      static_cast<double*>(d_fr), 18ull * std::accumulate(mf.begin(), mf.end(), 0ull))))
       return rc;
   }
   // The allele-specific alignments below are string x string.  Basecall strings hold A, C, G, T, N only, so "row char == column
@@ -1416,8 +1407,24 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     HIP_TRY(hipMemcpyAsync(&h_cq_flag, b_cqf.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   }
   std::vector<int32_t> h_hst(nt);
+  std::vector<uint32_t> h_len1(nt);
+  std::vector<int32_t> h_strim(nt);
   HIP_TRY(hipMemcpyAsync(h_hst.data(), b_hst.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(h_len1.data(), b_len1.p, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(h_strim.data(), d_strim, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  std::vector<int32_t> h_status(nt, 0);
+  for (uint32_t t = 0; t < nt; ++t) {  // indigo.h:303-309
+    const double seqsize = (double)mt[t];
+    const double thr = seqsize * 0.35 * prm->match + seqsize * (1 - 0.35) * prm->mismatch;
+    if ((double)h_strim[t] <= thr) h_status[t] = -1;
+  }
+  if (ctx->timing) {  // decomposeAlleles launch above: alignment columns walked; rows + basecalls read, basecalls rewritten
+    uint64_t wc = 0, wb = 0;
+    for (uint32_t t = 0; t < nt; ++t) { wc += h_len1[t]; wb += 2ull * h_len1[t] + 4ull * mf[t]; }
+    ctx->acc[TRACYHIP_TIMER_DECOMP].cells += wc;
+    ctx->acc[TRACYHIP_TIMER_DECOMP].bytes += wb;
+  }
   const bool use_cq = try_cq && (h_cq_flag & 1) == 0;
   const int cq_codes = (!use_cq || (h_cq_flag & 2)) ? 6 : (h_cq_flag & 4) ? 5 : 4;
   for (uint32_t t = 0; t < nt; ++t)

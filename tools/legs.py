@@ -45,7 +45,7 @@ def timed(step, steps, warmup, dist, lib=None, ctx=None):
     for _ in range(warmup):
         step()
     if lib is not None:
-        lib.tracyhip_timing_enable(ctx._h, 1)
+        lib.tracyhip_timing_enable(ctx._h, 0 if os.environ.get("TRACYHIP_BENCH_NO_TIMERS") else 1)
         lib.tracyhip_timing_reset(ctx._h)
     if dist is not None:
         dist.barrier()

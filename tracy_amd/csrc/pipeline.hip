@@ -1223,15 +1223,6 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     if ((herr & 4) && !wildtype) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
   }
 
-  // ---- 1. findBreakpoint(trimmedtrace) (indigo.h:196) ----
-  {
-    std::vector<BpDesc> hd(nt);
-    for (uint32_t t = 0; t < nt; ++t) hd[t] = BpDesc{sp.offset[t] + tl[t], mf[t], mt[t]};
-    const BpDesc* dd;
-    if ((rc = upload(ctx, buf(), hd, &dd))) return rc;
-    if ((rc = launch_breakpoint(ctx, dd, nt, maxcol, static_cast<const float*>(d_prof), static_cast<BreakpointOut*>(d_bp)))) return rc;
-  }
-
   // ---- 2. orientation (indigo.h:235-247) ----
   DevBuf& b_sc2 = buf();
   HIP_TRY(b_sc2.ensure(sizeof(int32_t) * 2 * (size_t)nt));
@@ -1334,6 +1325,17 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     ra.npairs = nt;
     HIP_TRY(launch_alignment_rows(ra, st));
   }
+  // ---- 1. findBreakpoint(trimmedtrace) (indigo.h:196) ----
+  // (launched here, behind the sweeps: nothing before stage 4 reads it, and a kernel of single-wavefront workgroups that
+  // is the first thing an idle GPU gets to run has been measured at 20 ms instead of 2)
+  {
+    std::vector<BpDesc> hd(nt);
+    for (uint32_t t = 0; t < nt; ++t) hd[t] = BpDesc{sp.offset[t] + tl[t], mf[t], mt[t]};
+    const BpDesc* dd;
+    if ((rc = upload(ctx, buf(), hd, &dd))) return rc;
+    if ((rc = launch_breakpoint(ctx, dd, nt, maxcol, static_cast<const float*>(d_prof), static_cast<BreakpointOut*>(d_bp)))) return rc;
+  }
+
   // the alignment lengths stay on the device for the next kernels (they come to the host with the results of stage 5: a
   // synchronisation here leaves the GPU idle for 2 ms, and the short-wavefront kernels that follow then start at idle clocks)
   const uint32_t* d_len1 = static_cast<const uint32_t*>(b_len1.p);

@@ -37,3 +37,28 @@ def case_list():
                              (14, 0, 0.6)]:
         cases.append(make_case(seed, kind=kind, frac1=frac, maxlen=(30 if seed != 14 else 3)))
     return cases
+
+
+def random_row_pairs(seed, count):
+    """alignment-row pairs of every shape findHomozygousBreakpoint's scan has to cope with: gap runs at both ends, columns that
+    are gaps in both rows, windows that straddle 64-column chunks, alignments shorter than the two windows, a mismatch rate
+    that steps once or never"""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for it in range(count):
+        L = int(rng.choice([1, 2, 49, 50, 51, 52, 63, 64, 65, 100, 127, 128, 129, 191, 300, 700, 1500]))
+        r0 = rng.choice(list(b"ACGT"), L).astype(np.uint8)
+        r1 = r0.copy()
+        step = int(rng.integers(0, L + 1))
+        rate = [float(rng.choice([0.0, 0.05, 0.3])), float(rng.choice([0.0, 0.3, 0.7, 1.0]))]
+        for a, b, p in ((0, step, rate[0]), (step, L, rate[1])):
+            hit = rng.random(b - a) < p
+            r1[a:b][hit] = rng.choice(list(b"ACGT"), int(hit.sum()))
+        for r in (r0, r1):
+            r[rng.random(L) < float(rng.choice([0.0, 0.02, 0.2]))] = ord("-")
+            r[:int(rng.integers(0, 40)) if rng.random() < 0.5 else 0] = ord("-")
+            k = int(rng.integers(0, 40)) if rng.random() < 0.5 else 0
+            if k:
+                r[L - min(k, L):] = ord("-")
+        rows.append((r0.tobytes(), r1.tobytes()))
+    return rows

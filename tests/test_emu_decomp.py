@@ -176,6 +176,18 @@ def test_breakpoints_and_small_functions(emu, cases):
         wrc, wbp = orc.find_homozygous_breakpoint(r0, r1)
         assert rc == wrc and (out[0], out[1], out[2]) == (wbp.indelshift, wbp.traceleft, wbp.breakpoint)
         assert np.float32(bd.value) == np.float32(wbp.bestDiff)
+    # the column-mask formulation of findHomozygousBreakpoint (what homozygous_kernel runs) on rows of every awkward shape
+    from decomp_cases import random_row_pairs
+    seen = set()
+    for r0, r1 in random_row_pairs(5, 600):
+        rc = emu.emu_homozygous(r0, r1, len(r0), out, C.byref(bd))
+        wrc, wbp = orc.find_homozygous_breakpoint(r0, r1)
+        assert rc == wrc
+        seen.add((rc, wbp.indelshift if rc == 1 else 0))
+        if rc == 1:
+            assert (out[0], out[1], out[2]) == (wbp.indelshift, wbp.traceleft, wbp.breakpoint)
+            assert np.float32(bd.value) == np.float32(wbp.bestDiff)
+    assert seen == {(0, 0), (-1, 0), (1, 0), (1, 1)}
     # degenerate alignments: the two failure codes
     out = (C.c_int32 * 4)()
     bd = C.c_float(0)

@@ -56,27 +56,9 @@ def test_homozygous_breakpoint(ctx, cases):
 
 
 def test_homozygous_breakpoint_random_rows(ctx):
-    """rows of every shape the scan has to cope with: gap runs at both ends, columns that are gaps in both rows, windows
-    that straddle the 64-column chunks, alignments shorter than the two windows, a mismatch rate that steps once or never"""
     from tracy_amd import capi
-    rng = np.random.default_rng(77)
-    rows = []
-    for it in range(400):
-        L = int(rng.choice([1, 2, 49, 50, 51, 52, 63, 64, 65, 100, 127, 128, 129, 191, 300, 700, 1500]))
-        r0 = rng.choice(list(b"ACGT"), L).astype(np.uint8)
-        r1 = r0.copy()
-        step = int(rng.integers(0, L + 1))
-        rate = [float(rng.choice([0.0, 0.05, 0.3])), float(rng.choice([0.0, 0.3, 0.7, 1.0]))]
-        for a, b, p in ((0, step, rate[0]), (step, L, rate[1])):
-            hit = rng.random(b - a) < p
-            r1[a:b][hit] = rng.choice(list(b"ACGT"), int(hit.sum()))
-        for r in (r0, r1):
-            r[rng.random(L) < float(rng.choice([0.0, 0.02, 0.2]))] = ord("-")
-            r[:int(rng.integers(0, 40)) if rng.random() < 0.5 else 0] = ord("-")
-            k = int(rng.integers(0, 40)) if rng.random() < 0.5 else 0
-            if k:
-                r[L - min(k, L):] = ord("-")
-        rows.append((r0.tobytes(), r1.tobytes()))
+    from decomp_cases import random_row_pairs
+    rows = random_row_pairs(77, 400)
     bps = [capi.Breakpoint(0, 1, 0, 0.0) for _ in rows]
     got, status = ctx.find_homozygous_breakpoint(rows, bps)
     seen = set()

@@ -682,55 +682,121 @@ TR_HD void breakpoint_select(const double* diff, const uint8_t* left_lt_right, u
   }
 }
 
-// findHomozygousBreakpoint (decompose.h:59-128) on the two alignment rows; one lane per trace.
-// Returns 1 on success, 0 / -1 for the reference's two failure messages (it returns false for both).
-TR_HD int homozygous_breakpoint(const uint8_t* row0, const uint8_t* row1, uint32_t L, BreakpointOut& bp) {
-  int64_t alignStart = 0, alignEnd = 0, varIndex = 0;
-  for (int64_t j = 0; j < (int64_t)L; ++j) {
-    if (row0[j] != '-' && row1[j] != '-') { alignStart = j; break; }
-    if (row0[j] != '-') ++varIndex;
-  }
-  for (int32_t j = (int32_t)(L - 1); j >= 0; --j) {
-    if (row0[j] != '-' && row1[j] != '-') { alignEnd = j; break; }
-  }
-  if (alignStart >= alignEnd) return 0;
+// ---- findHomozygousBreakpoint (decompose.h:59-128): one wavefront per trace --------------------------
+// The two alignment rows are read 64 columns at a time; a chunk becomes two 64-bit masks -- row0 != row1 and row0 != '-' --
+// and the mismatch counts of the two 25-column windows of column b + lane are popcounts of 25 bits cut from three consecutive
+// mismatch masks; varIndex (bases of row0 up to and including the column) is a running popcount of the other mask.  The
+// reference's walk with its float-typed running maximum ends on the last column with diff > (double)F, or else on the first
+// whose float equals F = max (float)diff (see breakpoint_kernel); it is resolved by reductions over the lanes.
+// The kernel (decompose_kernels.hip) gets the masks by ballot and reduces by shuffles; the host twin below builds them with
+// loops and walks the lanes one after the other -- everything a lane computes is shared.
+struct HomChunk { uint64_t mm, ng; };  // columns b .. b+63: row0 != row1, row0 != '-' (columns >= L: 0)
+TR_HD uint64_t mask_bits(uint64_t lo, uint64_t hi, uint32_t s) { return s ? (lo >> s) | (hi << (64 - s)) : lo; }
+
+struct HomLane {      // what lane `lane` knows about column b + lane
+  double diff;        // |right - left| of the window means, the reference's doubles
+  float g;            // (float)diff
+  int32_t left_lt_right;
+  uint32_t var;       // varIndex after the column
+};
+TR_HD HomLane hom_lane(uint64_t prev_mm, const HomChunk& cur, uint64_t next_mm, uint32_t vbase, uint32_t lane) {
+  const uint64_t lw = lane < 25 ? mask_bits(prev_mm, cur.mm, lane + 39) : mask_bits(cur.mm, next_mm, lane - 25);
+  const uint64_t rw = mask_bits(cur.mm, next_mm, lane);
+  const int32_t lc = popc64(lw & 0x1ffffffull), rc = popc64(rw & 0x1ffffffull);
+  const double left = (double)lc / 25.0, right = (double)rc / 25.0;
+  HomLane h;
+  h.diff = right - left;
+  if (h.diff < 0) h.diff = -h.diff;
+  h.g = (float)h.diff;
+  h.left_lt_right = (left < right) ? 1 : 0;
+  h.var = vbase + (uint32_t)popc64(cur.ng & ((2ull << lane) - 1ull));
+  return h;
+}
+// bases of row0 in the columns of the chunk at b that lie below hi
+TR_HD uint32_t hom_bases_below(const HomChunk& cur, uint64_t b, uint32_t hi) {
+  return (uint32_t)popc64(hi - b >= 64 ? cur.ng : cur.ng & ((1ull << (hi - b)) - 1ull));
+}
+// the per-lane state of the selecting sweep
+struct HomPick { uint32_t first, last, first_var, last_var; int32_t first_tl, last_tl; };  // last: column + 1, 0 = none
+TR_HD void hom_pick_init(HomPick& p) { p.first = 0xffffffffu; p.last = 0; p.first_var = p.last_var = 0; p.first_tl = p.last_tl = 0; }
+TR_HD void hom_pick(HomPick& p, const HomLane& h, float F, uint32_t col) {
+  if (h.g == F && h.diff > 0.0 && col < p.first) { p.first = col; p.first_var = h.var; p.first_tl = h.left_lt_right; }
+  if (h.diff > (double)F) { p.last = col + 1; p.last_var = h.var; p.last_tl = h.left_lt_right; }
+}
+// alignStart / alignEnd checks and the two early ways out (decompose.h:62-85); 1 = go on with columns [lo, hi)
+TR_HD int hom_range(int64_t align_start, int64_t align_end, BreakpointOut& bp, uint32_t& lo, uint32_t& hi) {
+  if (align_start >= align_end) return 0;
   bp.bestDiff = 0;
   bp.traceleft = 1;
   bp.breakpoint = 0;
-  if (alignEnd < alignStart + 50) return -1;
-  for (uint32_t i = (uint32_t)alignStart; (int64_t)i < alignStart + 25; ++i)
-    if (row0[i] != '-') ++varIndex;
-  // mismatch counts of the two 25-column windows slide by one column per step: keep them as integers
-  // (the reference recounts them as doubles; the counts are exact either way)
-  int32_t lcount = 0, rcount = 0;
-  {
-    const uint32_t i0 = (uint32_t)(alignStart + 25);
-    for (uint32_t k = i0 - 25; k < i0; ++k) lcount += (row0[k] != row1[k]);
-    for (uint32_t k = i0; k < i0 + 25; ++k) rcount += (row0[k] != row1[k]);
-  }
-  for (uint32_t i = (uint32_t)(alignStart + 25); (int64_t)i < alignEnd - 25; ++i) {
-    if (row0[i] != '-') ++varIndex;
-    const double left = (double)lcount / 25.0, right = (double)rcount / 25.0;
-    double diff = right - left;
-    if (diff < 0) diff = -diff;
-    if (diff > (double)bp.bestDiff) {
-      bp.breakpoint = (uint32_t)varIndex;
-      bp.bestDiff = (float)diff;
-      bp.traceleft = (left < right) ? 1 : 0;
-    }
-    // slide: column i leaves the right window and enters the left one
-    lcount += (row0[i] != row1[i]) - (row0[i - 25] != row1[i - 25]);
-    rcount += (row0[i + 25] != row1[i + 25]) - (row0[i] != row1[i]);
-  }
+  if (align_end < align_start + 50) return -1;
+  lo = (uint32_t)(align_start + 25);
+  hi = (uint32_t)(align_end - 25);
+  return 1;
+}
+TR_HD void hom_finish(BreakpointOut& bp, float F, uint32_t var_end) {  // decompose.h:119-126 when no window pair reaches 0.25
   bp.indelshift = 1;
-  if ((double)bp.bestDiff < 0.25) {
+  if ((double)F < 0.25) {
     bp.indelshift = 0;
-    bp.breakpoint = (uint32_t)varIndex;
+    bp.breakpoint = var_end;
     bp.traceleft = 1;
     bp.bestDiff = 0;
   }
+}
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host twin of homozygous_kernel (tests/emu): 1 on success, 0 / -1 for the reference's two failure messages
+inline int homozygous_breakpoint(const uint8_t* row0, const uint8_t* row1, uint32_t L, BreakpointOut& bp) {
+  auto chunk = [&](uint64_t b) {
+    HomChunk c{0, 0};
+    for (uint32_t l = 0; l < 64; ++l) {
+      const uint64_t j = b + l;
+      if (j >= L) break;
+      if (row0[j] != row1[j]) c.mm |= 1ull << l;
+      if (row0[j] != '-') c.ng |= 1ull << l;
+    }
+    return c;
+  };
+  int64_t align_start = 0, align_end = 0;
+  for (int64_t j = 0; j < (int64_t)L; ++j)
+    if (row0[j] != '-' && row1[j] != '-') { align_start = j; break; }
+  for (int64_t j = (int64_t)L - 1; j >= 0; --j)
+    if (row0[j] != '-' && row1[j] != '-') { align_end = j; break; }
+  uint32_t lo = 0, hi = 0;
+  const int rc = hom_range(align_start, align_end, bp, lo, hi);
+  if (rc != 1) return rc;
+  float F = 0.0f;
+  uint32_t var_end = 0;
+  HomPick best;
+  hom_pick_init(best);
+  for (int pass = 0; pass < 2; ++pass) {
+    HomChunk cur = chunk(0), nxt = chunk(64);
+    uint64_t prev = 0;
+    uint32_t vbase = 0;
+    for (uint64_t b = 0; b < hi; b += 64) {
+      const HomChunk nn = chunk(b + 128);
+      for (uint32_t lane = 0; lane < 64; ++lane) {
+        const uint64_t i = b + lane;
+        if (i < lo || i >= hi) continue;
+        const HomLane h = hom_lane(prev, cur, nxt.mm, vbase, lane);
+        if (pass == 0) { if (h.diff > 0.0 && h.g > F) F = h.g; }
+        else hom_pick(best, h, F, (uint32_t)i);  // one HomPick for all lanes: columns ascend, so first / last come out the same
+      }
+      if (pass == 0) var_end += hom_bases_below(cur, b, hi);
+      vbase += (uint32_t)popc64(cur.ng);
+      prev = cur.mm; cur = nxt; nxt = nn;
+    }
+    if (pass == 0) {
+      hom_finish(bp, F, var_end);
+      if (!bp.indelshift) return 1;
+    }
+  }
+  bp.breakpoint = best.last ? best.last_var : best.first_var;
+  bp.traceleft = best.last ? best.last_tl : best.first_tl;
+  bp.bestDiff = F;
   return 1;
 }
+#endif
 
 // generateSecondaryDecomposed (decompose.h:378-410), one position
 TR_HD uint8_t secondary_decomposed(uint8_t p, uint8_t s, const int32_t* trace, uint64_t nsamples, int32_t pos) {

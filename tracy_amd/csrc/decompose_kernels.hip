@@ -121,14 +121,8 @@ __global__ __launch_bounds__(64) void breakpoint_kernel(const BpDesc* desc, cons
   }
 }
 
-// ---- findHomozygousBreakpoint (decompose.h:59-128): one wavefront per trace ---------------------------
-// The two alignment rows are read 64 columns at a time (one lane per trace reads them a byte at a time from 10^5 different
-// pages: 1.4 ms when the rows sit in large pages and 27 ms when the allocator handed out small ones).  A chunk becomes two
-// 64-bit masks -- row0 != row1 and row0 != '-' -- and the mismatch counts of the two 25-column windows of column b + lane are
-// popcounts of 25 bits cut from three consecutive mismatch masks; varIndex is a running popcount of the other mask.
-__device__ __forceinline__ uint64_t mask_bits(uint64_t lo, uint64_t hi, uint32_t s) { return s ? (lo >> s) | (hi << (64 - s)) : lo; }
-
-struct HomChunk { uint64_t mm, ng; };
+// ---- findHomozygousBreakpoint (decompose.h:59-128): one wavefront per trace; the formulation is in decompose_kernels.h ----
+// (One lane per trace read the rows a byte at a time from 10^5 different pages: 1.4 ms at best and 27 ms on its bad days.)
 __device__ __forceinline__ HomChunk hom_chunk(const uint8_t* r0, const uint8_t* r1, uint32_t L, uint64_t b, uint32_t lane) {
   const uint64_t j = b + lane;
   uint8_t x = '-', y = '-';
@@ -139,37 +133,26 @@ __device__ __forceinline__ HomChunk hom_chunk(const uint8_t* r0, const uint8_t* 
   return c;
 }
 
-// SELECT = false: F = max(0, max_i (float)diff_i) and the varIndex the walk ends with; SELECT = true: the position the
-// reference's walk (float-typed running maximum, see breakpoint_kernel) ends on, given F
+// SELECT = false: F = max(0, max_i (float)diff_i) and the varIndex the walk ends with; SELECT = true: the column the
+// reference's walk ends on, given F
 template <bool SELECT>
 __device__ __forceinline__ void hom_sweep(const uint8_t* r0, const uint8_t* r1, uint32_t L, uint32_t lo, uint32_t hi, uint32_t lane,
                                           float& F, uint32_t& var_end, uint32_t& var_at, int32_t& left_lt_right) {
   float fmax_l = 0.0f;
-  uint32_t first_l = 0xffffffffu, last_l = 0, first_var = 0, last_var = 0, vbase = 0, vend = 0;
-  int32_t first_tl = 0, last_tl = 0;
+  uint32_t vbase = 0, vend = 0;
+  HomPick pk;
+  hom_pick_init(pk);
   HomChunk cur = hom_chunk(r0, r1, L, 0, lane), nxt = hom_chunk(r0, r1, L, 64, lane);
   uint64_t prev = 0;
   for (uint64_t b = 0; b < hi; b += 64) {
     const HomChunk nn = hom_chunk(r0, r1, L, b + 128, lane);
     const uint64_t i = b + lane;
     if (i >= lo && i < hi) {
-      const uint64_t lw = lane < 25 ? mask_bits(prev, cur.mm, lane + 39) : mask_bits(cur.mm, nxt.mm, lane - 25);
-      const uint64_t rw = mask_bits(cur.mm, nxt.mm, lane);
-      const int32_t lc = __popcll(lw & 0x1ffffffull), rc = __popcll(rw & 0x1ffffffull);
-      const double left = (double)lc / 25.0, right = (double)rc / 25.0;
-      double diff = right - left;
-      if (diff < 0) diff = -diff;
-      const float g = (float)diff;
-      if (!SELECT) {
-        if (diff > 0.0 && g > fmax_l) fmax_l = g;
-      } else {
-        const uint32_t var = vbase + (uint32_t)__popcll(cur.ng & ((2ull << lane) - 1ull));
-        const int32_t tl = (left < right) ? 1 : 0;
-        if (g == F && diff > 0.0 && (uint32_t)i < first_l) { first_l = (uint32_t)i; first_var = var; first_tl = tl; }
-        if (diff > (double)F) { last_l = (uint32_t)i + 1; last_var = var; last_tl = tl; }
-      }
+      const HomLane h = hom_lane(prev, cur, nxt.mm, vbase, lane);
+      if (!SELECT) { if (h.diff > 0.0 && h.g > fmax_l) fmax_l = h.g; }
+      else hom_pick(pk, h, F, (uint32_t)i);
     }
-    if (!SELECT) vend += (uint32_t)__popcll(hi - b >= 64 ? cur.ng : cur.ng & ((1ull << (hi - b)) - 1ull));
+    if (!SELECT) vend += hom_bases_below(cur, b, hi);
     vbase += (uint32_t)__popcll(cur.ng);
     prev = cur.mm; cur = nxt; nxt = nn;
   }
@@ -179,18 +162,18 @@ __device__ __forceinline__ void hom_sweep(const uint8_t* r0, const uint8_t* r1, 
     var_end = vend;
     return;
   }
-  uint32_t first = first_l, last = last_l;
+  uint32_t first = pk.first, last = pk.last;
   for (int o = 32; o > 0; o >>= 1) {
     const uint32_t a = (uint32_t)__shfl_xor((int)first, o, 64), c = (uint32_t)__shfl_xor((int)last, o, 64);
     if (a < first) first = a;
     if (c > last) last = c;
   }
   // the columns are distinct across lanes: exactly one lane holds the chosen one
-  const bool mine = last ? last_l == last : first_l == first;
+  const bool mine = last ? pk.last == last : pk.first == first;
   const uint64_t owner = __ballot(mine);
   const int src = owner ? __builtin_ctzll(owner) : 0;
-  var_at = (uint32_t)__shfl((int)(last ? last_var : first_var), src, 64);
-  left_lt_right = __shfl(last ? last_tl : first_tl, src, 64);
+  var_at = (uint32_t)__shfl((int)(last ? pk.last_var : pk.first_var), src, 64);
+  left_lt_right = __shfl(last ? pk.last_tl : pk.first_tl, src, 64);
 }
 
 __global__ __launch_bounds__(64) void homozygous_kernel(const RowsDesc* desc, const uint8_t* rows0, const uint8_t* rows1,
@@ -217,31 +200,19 @@ __global__ __launch_bounds__(64) void homozygous_kernel(const RowsDesc* desc, co
     const uint64_t m = __ballot(j < L && r0[j] != '-' && r1[j] != '-');
     if (m) { align_end = b + 63 - __builtin_clzll(m); break; }
   }
-  int rc = 1;
-  if (align_start >= align_end) {
-    rc = 0;
-  } else {
-    bp.bestDiff = 0;
-    bp.traceleft = 1;
-    bp.breakpoint = 0;
-    if (align_end < align_start + 50) {
-      rc = -1;
-    } else {
-      const uint32_t lo = (uint32_t)(align_start + 25), hi = (uint32_t)(align_end - 25);
-      float F = 0.0f;
-      uint32_t var_end = 0, var_at = 0;
-      int32_t ltr = 0;
-      hom_sweep<false>(r0, r1, L, lo, hi, lane, F, var_end, var_at, ltr);
-      bp.indelshift = 1;
-      if ((double)F < 0.25) {
-        bp.indelshift = 0;
-        bp.breakpoint = var_end;
-      } else {
-        hom_sweep<true>(r0, r1, L, lo, hi, lane, F, var_end, var_at, ltr);
-        bp.breakpoint = var_at;
-        bp.bestDiff = F;
-        bp.traceleft = ltr;
-      }
+  uint32_t lo = 0, hi = 0;
+  const int rc = hom_range(align_start, align_end, bp, lo, hi);
+  if (rc == 1) {
+    float F = 0.0f;
+    uint32_t var_end = 0, var_at = 0;
+    int32_t ltr = 0;
+    hom_sweep<false>(r0, r1, L, lo, hi, lane, F, var_end, var_at, ltr);
+    hom_finish(bp, F, var_end);
+    if (bp.indelshift) {
+      hom_sweep<true>(r0, r1, L, lo, hi, lane, F, var_end, var_at, ltr);
+      bp.breakpoint = var_at;
+      bp.bestDiff = F;
+      bp.traceleft = ltr;
     }
   }
   if (lane == 0) { status[t] = rc; bps[t] = bp; }

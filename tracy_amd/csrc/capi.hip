@@ -2,6 +2,8 @@
 // pairs by strip height K, workspace chunking, kernel launches.  No compute happens on the host and
 // there is no CPU fallback: every entry point needs a gfx950 device.
 #include <hip/hip_runtime.h>
+#include <map>
+#include <chrono>
 
 #include <thread>
 
@@ -138,6 +140,30 @@ static hipError_t get_event(tracyhip_ctx* ctx, hipEvent_t* e) {
   if (!ctx->free_events.empty()) { *e = ctx->free_events.back(); ctx->free_events.pop_back(); return hipSuccess; }
   return hipEventCreate(e);
 }
+namespace {
+struct HostProfile {
+  bool on = getenv("TRACYHIP_HOST_TIMERS") != nullptr;
+  std::mutex m;
+  std::map<std::string, std::pair<double, uint64_t>> acc;
+  ~HostProfile() {
+    if (!on) return;
+    for (auto const& kv : acc) fprintf(stderr, "host %-28s %10.3f ms %8llu x\n", kv.first.c_str(), kv.second.first, (unsigned long long)kv.second.second);
+  }
+};
+HostProfile& host_profile() { static HostProfile p; return p; }
+inline uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+HostScope::HostScope(const char* l) : label(l), t0(host_profile().on ? now_ns() : 0) {}
+HostScope::~HostScope() {
+  HostProfile& p = host_profile();
+  if (!p.on) return;
+  const double ms = (double)(now_ns() - t0) * 1e-6;
+  std::lock_guard<std::mutex> lk(p.m);
+  auto& e = p.acc[label];
+  e.first += ms;
+  e.second += 1;
+}
+
 int timing_begin(tracyhip_ctx* ctx, int which, uint64_t cells, uint64_t bytes) {
   if (!ctx->timing) return TRACYHIP_OK;
   tracyhip_ctx::Pending p{which, nullptr, nullptr, cells, bytes};
@@ -324,8 +350,10 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   const uint32_t np = (uint32_t)pb.desc.size();
   if (np == 0) return TRACYHIP_OK;
   hipStream_t st = ctx->stream;
+  TRACYHIP_HOST_SCOPE(hs_all, "run_dp");
 
   // order: strip height, then longest first (long problems start early, short ones fill the tail)
+  auto* hs_plan = new HostScope("run_dp.plan");
   std::vector<uint32_t> order(np);
   for (uint32_t i = 0; i < np; ++i) order[i] = i;
   auto before = [&](uint32_t x, uint32_t y) {
@@ -419,6 +447,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
     }
     chunks.push_back(c);
   }
+  delete hs_plan;
   uint64_t max_words = 0, max_scr = 0;
   for (const Chunk& c : chunks) { max_words = std::max(max_words, c.words); max_scr = std::max(max_scr, c.scratch); }
   HIP_TRY(ctx->d_desc.ensure(sizeof(PairDesc) * (size_t)np));

@@ -141,6 +141,15 @@ struct DpProblemLease {
   DpProblemLease(const DpProblemLease&) = delete;
   DpProblemLease& operator=(const DpProblemLease&) = delete;
 };
+// Host-side profile of the pipelines (TRACYHIP_HOST_TIMERS=1): wall time of the labelled scopes, summed per label and printed to
+// stderr when the process ends.  For finding where the host keeps the GPU waiting between two launches; off = one branch.
+struct HostScope {
+  const char* label;
+  uint64_t t0;
+  explicit HostScope(const char* l);
+  ~HostScope();
+};
+#define TRACYHIP_HOST_SCOPE(name, label) tracyhip::HostScope name(label)
 int timing_begin(tracyhip_ctx* ctx, int which, uint64_t cells, uint64_t bytes);  // record start event
 int timing_end(tracyhip_ctx* ctx);                                              // record stop event
 int timing_collect(tracyhip_ctx* ctx);                                          // after a stream sync

@@ -26,6 +26,11 @@ using namespace tracyhip;
   } while (0)
 
 namespace {
+struct StageClock {  // TRACYHIP_HOST_TIMERS: wall time from one mark to the next, by label
+  HostScope* cur = nullptr;
+  void mark(const char* label) { delete cur; cur = new HostScope(label); }
+  ~StageClock() { delete cur; }
+};
 
 struct TrimOut {
   uint32_t ri;       // offset of the trimmed slice in the oriented reference
@@ -1104,6 +1109,8 @@ struct DevOut {  // a result array: the user's (DEVICE) or a staging buffer (HOS
 
 static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
                                const tracyhip_decompose_result* out) {
+  StageClock stage_clock;
+  stage_clock.mark("decompose.0_setup");
   int rc = ctx_begin(ctx);
   if (rc) return rc;
   if (!job || !out || !prm) return set_error(TRACYHIP_ERR_ARG, "null job/result/params");
@@ -1223,6 +1230,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     if ((herr & 4) && !wildtype) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
   }
 
+  stage_clock.mark("decompose.2_orientation");
   // ---- 2. orientation (indigo.h:235-247) ----
   DevBuf& b_sc2 = buf();
   HIP_TRY(b_sc2.ensure(sizeof(int32_t) * 2 * (size_t)nt));
@@ -1267,6 +1275,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       else { h_fwd[t] = h_sc2[t] > h_sc2[nt + t] ? 1 : 0; h_rc[t] = !h_fwd[t]; }
     }
 
+  stage_clock.mark("decompose.3_gotoh");
   // ---- 3. gotoh(trimmedtrace, prefslice) + alignment rows (indigo.h:302) ----
   std::vector<uint64_t> off1(nt);
   uint64_t tot1 = 0;
@@ -1325,6 +1334,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     ra.npairs = nt;
     HIP_TRY(launch_alignment_rows(ra, st));
   }
+  stage_clock.mark("decompose.1_findBreakpoint");
   // ---- 1. findBreakpoint(trimmedtrace) (indigo.h:196) ----
   // (launched here, behind the sweeps: nothing before stage 4 reads it, and a kernel of single-wavefront workgroups that
   // is the first thing an idle GPU gets to run has been measured at 20 ms instead of 2)
@@ -1340,6 +1350,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   // synchronisation here leaves the GPU idle for 2 ms, and the short-wavefront kernels that follow then start at idle clocks)
   const uint32_t* d_len1 = static_cast<const uint32_t*>(b_len1.p);
 
+  stage_clock.mark("decompose.4_findHomozygousBreakpoint");
   // ---- 4. findHomozygousBreakpoint where the trace shows no shift (indigo.h:314-317) ----
   DevBuf& b_hst = buf();
   HIP_TRY(b_hst.ensure(sizeof(int32_t) * (size_t)nt));
@@ -1353,6 +1364,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       return rc;
   }
 
+  stage_clock.mark("decompose.5_decomposeAlleles");
   // ---- 5. decomposeAlleles, generateSecondaryDecomposed, allelicFraction (indigo.h:340-350) ----
   {
     std::vector<DecompDesc> hd(nt);
@@ -1432,6 +1444,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   for (uint32_t t = 0; t < nt; ++t)
     if (h_status[t] == 0 && h_hst[t] != 1) h_status[t] = h_hst[t] == 0 ? -2 : -3;
 
+  stage_clock.mark("decompose.6_allele");
   // ---- 6. allele-specific alignments (indigo.h:355-387): string x string Gotoh ----
   // allele k in {0: primary, 1: secDecompose}: gotoh(seq, rs.refslice) -> trimReferenceSlice -> gotoh(seq, slice)
   DevBuf &b_opsA = buf(), &b_lenA = buf(), &b_trimA = buf(), &b_rnfw = buf(), &b_ends = buf();

@@ -1109,6 +1109,7 @@ struct DevOut {  // a result array: the user's (DEVICE) or a staging buffer (HOS
 
 static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
                                const tracyhip_decompose_result* out) {
+  TRACYHIP_HOST_SCOPE(hs_call, "decompose_traces");
   StageClock stage_clock;
   stage_clock.mark("decompose.0_setup");
   int rc = ctx_begin(ctx);

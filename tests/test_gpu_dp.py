@@ -177,6 +177,32 @@ def test_all_pairs_indexing_and_chunking(ctx):
         assert (int(scores[k]), btr[k]) == orc.gotoh_str(seqs[i], seqs[j], 1, 1, SC)
 
 
+def test_traceback_walked_by_the_sweeping_workgroup(ctx, monkeypatch):
+    """the fused walk (default) and the walk launch of its own give the same ops: ragged strings and profiles, single- and
+    multi-pass strips, chunked workspaces, all four AlignConfigs"""
+    rng = np.random.default_rng(31)
+    sizes = [(0, 5), (5, 0), (1, 1), (63, 64), (64, 63), (300, 1200), (1025, 64), (1500, 300), (900, 1000), (17, 2000)]
+    a1 = [rand_seq(rng, m) for m, _ in sizes]
+    a2 = [noisy_copy(rng, (q * (n // max(len(q), 1) + 1))[:n]) if q else rand_seq(rng, n) for q, (_, n) in zip(a1, sizes)]
+    profs = [rand_profile(rng, m) for m in (40, 333, 1100)]
+    refs = [rand_seq(rng, n, b"ACGTN") for n in (700, 50, 1300)]
+    for cfg in CONFIGS:
+        ctx.set_workspace_limit(8 << 20 if cfg == CONFIGS[0] else 0)
+        try:
+            fused = ctx.align(a1, a2, SC + cfg, rows=True)
+            fused_p = ctx.align(profs, refs, SC + cfg)
+            monkeypatch.setenv("TRACYHIP_NO_FUSED_WALK", "1")
+            apart = ctx.align(a1, a2, SC + cfg, rows=True)
+            apart_p = ctx.align(profs, refs, SC + cfg)
+            monkeypatch.delenv("TRACYHIP_NO_FUSED_WALK")
+        finally:
+            ctx.set_workspace_limit(0)
+        assert [int(x) for x in fused[0]] == [int(x) for x in apart[0]] and fused[1] == apart[1] and fused[2] == apart[2]
+        assert [int(x) for x in fused_p[0]] == [int(x) for x in apart_p[0]] and fused_p[1] == apart_p[1]
+        for i, (q, r) in enumerate(zip(a1, a2)):
+            assert (int(fused[0][i]), fused[1][i]) == orc.gotoh_str(q, r, cfg[0], cfg[1], SC)
+
+
 def test_long_pair_list(ctx):
     """pair lists of 2^16 pairs and more are filled and laid out by several host threads (descriptors, boundary-row scratch of
     multi-pass pairs as a scan over the threads' totals): the same scores as the same list handed over in two shorter calls,

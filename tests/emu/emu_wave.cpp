@@ -1,12 +1,15 @@
 // emu_wave.cpp -- host execution of the wave-level kernel bodies (TEST INFRASTRUCTURE ONLY).
-// Runs tracy_amd/csrc/dp_kernels.h with a 64-thread "wave" (one std::thread per lane, barriers at every
-// cross-lane shift) so that the index math, tag arithmetic, traceback layout and walker can be checked
-// against the oracle in the CPU-only container.  Never linked into the product library.
-#include <barrier>
+// Runs tracy_amd/csrc/dp_kernels.h as a 64-lane "wave": one fiber (ucontext) per lane on ONE thread, every cross-lane
+// shift a barrier at which the lane yields to the next one -- so that the index math, tag arithmetic, traceback layout and
+// walker can be checked against the oracle in the CPU-only container.  (Lanes run round-robin from barrier to barrier: all
+// lanes of a wave pass the same sequence of barriers, which is all a barrier promises.  One std::thread per lane did the same
+// with 64 futex waits per barrier: six minutes of system time for 47 s of arithmetic.)  Never linked into the product library.
+#include <ucontext.h>
+
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
-#include <thread>
+#include <functional>
 #include <vector>
 
 #include "../../tracy_amd/csrc/dp_kernels.h"
@@ -15,9 +18,51 @@ using namespace tracyhip;
 
 namespace {
 struct WaveShared {
-  std::barrier<> bar{64};
+  struct Barrier {
+    WaveShared* w;
+    void arrive_and_wait() { w->yield(); }
+  } bar{this};
   int32_t xchg[64];
   std::vector<char> lds;
+  // the 64 fibers
+  static constexpr size_t kStack = size_t(1) << 19;
+  ucontext_t sched{}, fib[64];
+  static std::vector<char>& stack_pool() { static std::vector<char> p(64 * kStack); return p; }  // one wave at a time: allocated (and faulted in) once
+  std::function<void(uint32_t)> body;
+  bool done[64];
+  int cur = -1;
+  WaveShared() = default;
+  WaveShared(const WaveShared&) = delete;
+  void yield() { swapcontext(&fib[cur], &sched); }
+  static void trampoline(unsigned lo, unsigned hi) {
+    WaveShared* w = reinterpret_cast<WaveShared*>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    const int l = w->cur;
+    w->body((uint32_t)l);
+    w->done[l] = true;  // returning resumes uc_link = the scheduler
+  }
+  template <class F>
+  void run(F&& f) {
+    body = std::forward<F>(f);
+    std::vector<char>& stacks = stack_pool();
+    const uintptr_t self = reinterpret_cast<uintptr_t>(this);
+    for (int l = 0; l < 64; ++l) {
+      done[l] = false;
+      getcontext(&fib[l]);
+      fib[l].uc_stack.ss_sp = stacks.data() + (size_t)l * kStack;
+      fib[l].uc_stack.ss_size = kStack;
+      fib[l].uc_link = &sched;
+      makecontext(&fib[l], reinterpret_cast<void (*)()>(&WaveShared::trampoline), 2, (unsigned)(self & 0xffffffffu), (unsigned)(self >> 32));
+    }
+    for (bool any = true; any;) {
+      any = false;
+      for (int l = 0; l < 64; ++l) {
+        if (done[l]) continue;
+        cur = l;
+        swapcontext(&sched, &fib[l]);
+        any = any || !done[l];
+      }
+    }
+  }
 };
 
 struct HostWave {
@@ -59,18 +104,14 @@ template <int K, int MODE, bool TRACE, bool NEEDLE, bool NARROW = false, bool CO
 void run_wave(const DpArgs& a) {
   WaveShared sh;
   sh.lds.assign((qp_like(MODE) ? lds_bytes(MODE_QP, K) : needle_lds_bytes(MODE_PROF, K)) + 64, 0);
-  std::vector<std::thread> th;
-  for (uint32_t l = 0; l < 64; ++l) {
-    th.emplace_back([&, l]() {
-      HostWave w{l, &sh};
-      if constexpr (NEEDLE) {
-        if constexpr (MODE != MODE_QP) needle_body<HostWave, K, MODE, TRACE>(w, a, 0);
-      } else {
-        gotoh_body<HostWave, K, MODE, TRACE, NARROW, false, 0, COMPACT>(w, a, 0);
-      }
-    });
-  }
-  for (auto& t : th) t.join();
+  sh.run([&](uint32_t l) {
+    HostWave w{l, &sh};
+    if constexpr (NEEDLE) {
+      if constexpr (MODE != MODE_QP) needle_body<HostWave, K, MODE, TRACE>(w, a, 0);
+    } else {
+      gotoh_body<HostWave, K, MODE, TRACE, NARROW, false, 0, COMPACT>(w, a, 0);
+    }
+  });
 }
 
 template <int K>
@@ -101,22 +142,16 @@ void run_ckpt_pair(const DpArgs& a, const WalkArgs& wa) {
   for (int form = 0; form < ((NARROW && MODE == MODE_QP) ? 2 : 1); ++form) {  // checkpointed score pass (both forms of the 16-bit sweep)
     WaveShared sh;
     sh.lds.assign(lds_bytes(MODE_QP, K) + 64, 0);
-    std::vector<std::thread> th;
-    for (uint32_t l = 0; l < 64; ++l)
-      th.emplace_back([&, l]() {
+    sh.run([&](uint32_t l) {
         HostWave w{l, &sh};
         if (form == 0) gotoh_body<HostWave, K, MODE, false, NARROW, true, 0, NARROW && MODE == MODE_QP>(w, a, 0);
         else gotoh_body<HostWave, K, MODE, false, NARROW, true, 0, false>(w, a, 0);
       });
-    for (auto& t : th) t.join();
   }
   {  // band traceback
     WaveShared sh;
     sh.lds.assign(lds_bytes(MODE_QP, K) + 64, 0);
-    std::vector<std::thread> th;
-    for (uint32_t l = 0; l < 64; ++l)
-      th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_band_trace_body<HostWave, K, MODE>(w, a, wa, 0); });
-    for (auto& t : th) t.join();
+    sh.run([&](uint32_t l) { HostWave w{l, &sh}; gotoh_band_trace_body<HostWave, K, MODE>(w, a, wa, 0); });
   }
 }
 
@@ -124,10 +159,7 @@ template <int K, int TABLE = 0, int NC = 6>
 void run_origin_wave(const DpArgs& a) {
   WaveShared sh;
   sh.lds.assign(lds_bytes(MODE_CQ, K) + 64, 0);
-  std::vector<std::thread> th;
-  for (uint32_t l = 0; l < 64; ++l)
-    th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_origin_body<HostWave, K, TABLE, NC>(w, a, 0); });
-  for (auto& t : th) t.join();
+  sh.run([&](uint32_t l) { HostWave w{l, &sh}; gotoh_origin_body<HostWave, K, TABLE, NC>(w, a, 0); });
 }
 // MODE_CQ: case-sensitive codes of a string, padded like the library's code buffers
 static std::vector<uint8_t> cq_codes(const void* a2, size_t bytes) {
@@ -142,14 +174,11 @@ void run_prefix_wave(const DpArgs& a, uint32_t npairs) {
   for (int form = 0; form < 2; ++form) {  // both forms, as the library launches them: every group is worked on in one of them
     WaveShared sh;
     sh.lds.assign(lds_bytes_prefix(K, false) + 64, 0);
-    std::vector<std::thread> th;
-    for (uint32_t l = 0; l < 64; ++l)
-      th.emplace_back([&, l]() {
+    sh.run([&](uint32_t l) {
         HostWave w{l, &sh};
         if (form == 0) gotoh_prefix_body<HostWave, K, kPrefixLanes, true>(w, a, 0, npairs);
         else gotoh_prefix_body<HostWave, K, kPrefixLanes, false>(w, a, 0, npairs);
       });
-    for (auto& t : th) t.join();
   }
 }
 
@@ -394,9 +423,7 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
       const uint32_t ref_len = *ops_len;
       std::memset(ops, 0, (size_t)m + n);
       WaveShared sh;
-      std::vector<std::thread> th;
-      for (uint32_t l = 0; l < 64; ++l) th.emplace_back([&, l]() { HostWave w{l, &sh}; gotoh_walk_wave<HostWave>(w, wa, 0); });
-      for (auto& t : th) t.join();
+      sh.run([&](uint32_t l) { HostWave w{l, &sh}; gotoh_walk_wave<HostWave>(w, wa, 0); });
       if (*ops_len != ref_len || std::memcmp(ops, ref_ops.data(), ref_len) != 0) err |= 0x100;
     }
   }

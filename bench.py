@@ -4,19 +4,20 @@
 A step = one pass of tracyhip_align_traces over this rank's batch of synthetic traces (BASELINE.json
 configs[1]: 10k x 1 kb traces vs 10 kb reference windows per GPU; inputs resident in HBM before the
 timed region).  Per trace: 2 score-only Gotoh DPs (forward / reverse-complement reference), 1 traceback
-DP of the trimmed profile, trimReferenceSlice, 1 traceback DP of the full profile vs the trimmed slice.
+DP of the trimmed profile (taken by its two ends: an origin-tracking sweep over the sub-window the score sweep certifies),
+trimReferenceSlice, 1 traceback DP of the full profile vs the trimmed slice.
 Weak scaling: the per-GPU batch is fixed; traces shard by index with no data-path collective, the only
 RCCL call is the final gather of the fixed-size result records.
 
 Legs (each: W warm-up + K timed steps between barriers): (1) the headline -- one lane, both orientations swept in full
-(`value`, `roofline`); (2) the library's default strand-by-certificate mode; (3), (4) the same two on `--lanes-leg`
+(`value`, `roofline`: the library's default, exact gsFwd / gsRev); (2) the opt-in strand-by-certificate mode; (3), (4) the same two on `--lanes-leg`
 chunks of the batch in flight.  Legs 2-4 are checked to return the headline leg's alignments and are reported beside it;
 `--certificate-leg 0 --lanes-leg 0` runs the headline alone (what the rocprofv3 passes under profiles/ use).
 
 Beside the headline the default run also times BASELINE.json configs[2] (`tracy decompose`, 100 000 traces sharded over the
-ranks) and configs[4] (all-pairs profile x profile scoring of 1000 traces, pair list sharded over the ranks, score slices
-all-gathered) -- tools/legs.py -- each with its own roofline, cpu_baseline and in-run parity sample, reported as the
-`decompose` and `allpairs` objects of the same line (`--workload align|decompose|allpairs` runs one of them alone, which
+ranks) configs[4] (all-pairs profile x profile scoring of 1000 traces, pair list sharded over the ranks, score slices
+all-gathered) and configs[3] in miniature (host seeding + device extend) -- tools/legs.py -- each with its own roofline, cpu_baseline and in-run parity sample, reported as the
+`decompose`, `allpairs` and `seedextend` objects of the same line (`--workload align|decompose|allpairs|seedextend` runs one of them alone, which
 is what the rocprofv3 passes under profiles/ use).  `value` is always the align headline.
 
 `--gpus N` without a torch.distributed environment starts the N ranks itself (torch.distributed.run, 127.0.0.1) after checking

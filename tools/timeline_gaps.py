@@ -1,9 +1,9 @@
 """Where the GPU sits idle during a step: gaps between consecutive kernels / copies of a rocprofv3 trace.
 
   rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/tr -- python bench.py --workload decompose ...
-  python tools/timeline_gaps.py /tmp/tr [anchor-kernel-substring]
+  python tools/timeline_gaps.py /tmp/tr [anchor-kernel-substring [steps-back]]
 
-Prints, for the last occurrence of the anchor kernel's step (from the previous occurrence of the anchor to the last one), the
+Prints, for one step (from one occurrence of the anchor kernel to the next; steps-back = 0 is the last such interval), the
 busy time, the idle time and the largest gaps with the activities on either side.
 """
 import csv
@@ -31,7 +31,11 @@ def main():
     if len(idx) < 2:
         print("anchor", anchor, "seen", len(idx), "times: need two")
         return
-    a, b = idx[-2], idx[-1]
+    back = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    if len(idx) < back + 2:
+        print("anchor", anchor, "seen", len(idx), "times: need", back + 2)
+        return
+    a, b = idx[-2 - back], idx[-1 - back]
     step = ev[a:b]
     busy_end = step[0][1]
     busy = step[0][1] - step[0][0]

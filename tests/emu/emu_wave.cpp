@@ -233,7 +233,6 @@ int emu_prefix(int K, uint32_t npairs, const float* a1, const uint64_t* a1_off, 
   DpArgs a{};
   a.pairs = d.data(); a.a1 = a1; a.a2 = a2; a.scores = out; a.err = &err;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = 1; a.vfree = 0;
-  a.qpos = std::max(std::max(match, mismatch), 0);
   uint64_t extent = 0;
   for (uint32_t i = 0; i < npairs; ++i) extent = std::max<uint64_t>(extent, a2_off[i] + n[i]);
   std::vector<uint8_t> special((extent >> 8) + 2, 0);
@@ -260,7 +259,6 @@ int emu_origin(int K, const uint8_t* a1, uint32_t m, const uint8_t* a2, uint32_t
   DpArgs a{};
   a.pairs = &d; a.a1 = a1; a.a2 = a2; a.scores = score; a.err = &err; a.ends = ends;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = 1; a.vfree = 0;
-  a.qpos = std::max(std::max(match, mismatch), 0);
   std::vector<uint8_t> codes;
   if (flags & 0x200u) {  // table form (MODE_CQ): a2 as case-sensitive codes
     d.flags &= 0xffu;
@@ -307,7 +305,6 @@ int emu_band(int mode, int K, int narrow, uint32_t B, const void* a1, uint32_t m
   std::vector<uint8_t> special;
   if (mode == MODE_QP) { codes = padded_codes(a2, n); a.a2 = codes.data() + 128; special = special_blocks_of(codes, n); a.special_blocks = special.data(); }
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = hfree; a.vfree = vfree;
-  a.qpos = std::max(std::max(match, mismatch), 0);
   a.ckpt = ckpt.data(); a.lastrow = lastrow.data(); a.band = band.data(); a.ckpt_B = B; a.ckpt_narrow = narrow ? 1 : 0;
   uint64_t off = 0;
   WalkArgs wa{};
@@ -336,7 +333,6 @@ int emu_origin_qp(int K, const float* a1, uint32_t m, uint32_t stride, const uin
   DpArgs a{};
   a.pairs = &d; a.a1 = a1; a.scores = score; a.err = errw; a.ends = ends;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = 1; a.vfree = 0;
-  a.qpos = std::max(std::max(match, mismatch), 0);
   a.qlimit = std::max(std::abs(match), std::abs(mismatch));
   std::vector<uint8_t> codes = padded_codes(a2, n);
   a.a2 = codes.data() + 128;
@@ -379,7 +375,6 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
   a.bits = bits.data(); a.bits32 = reinterpret_cast<uint32_t*>(bits.data());
   a.scratch = scratch.data(); a.scores = score; a.err = &err;
   a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = hfree; a.vfree = vfree;
-  a.qpos = std::max(std::max(match, mismatch), 0);
   *score = 0x7fffffff;
   std::vector<uint8_t> colclass;
   if (flags & 0x200u) {  // profile x profile: screened substitution scores

@@ -160,7 +160,8 @@ def test_align_preliminary_alignment_by_its_two_ends(monkeypatch):
     """`tracy align` reads nothing of the preliminary alignment but trimReferenceSlice's two ends: by default an origin-tracking
     sweep over the certified sub-window delivers them (no checkpoints, no band traceback).  Same results as with the band
     traceback, in both orientation modes, also for traces that barely match their window (wide sub-windows) and for profiles
-    whose entries exceed max(match, mismatch) (the bound falls back to the larger limit)"""
+    whose entries exceed max(match, mismatch), for fuzzy profiles against windows with inserted segments; checked against the
+    oracle's sage.h chain as well"""
     import tracy_amd
     from tracy_amd import hostlib
     nt = 40
@@ -171,6 +172,16 @@ def test_align_preliminary_alignment_by_its_two_ends(monkeypatch):
     profs[3][4:] = 0
     profs[3][:4] /= profs[3][:4].sum(axis=0, keepdims=True)
     profs[5][:4] *= np.float32(1.4)                           # column masses 1.4: scores above `match`
+    # the sub-window is bounded by what the rows of the profile can score at best (not by match * rows): fuzzy columns make
+    # that bound small, segments inserted into the window make the optimal path long -- the two have to stay consistent
+    for t, (fuzz, ins) in {7: (0.6, 300), 8: (0.9, 700), 9: (0.3, 1500), 10: (0.97, 40), 11: (0.75, 2500)}.items():
+        flat = np.zeros_like(profs[t])
+        flat[:4] = 0.25
+        profs[t] = ((1 - fuzz) * profs[t] + fuzz * flat).astype(np.float32)
+        r = refs[t].copy()
+        cut = 2500 + 60 * t
+        seg = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), ins)
+        refs[t] = np.concatenate([r[:cut], seg, r[cut:]])[:len(r)]
     refl = [r.tobytes() for r in refs]
     c = tracy_amd.Context(0)
     try:
@@ -184,5 +195,10 @@ def test_align_preliminary_alignment_by_its_two_ends(monkeypatch):
             for k in keys:
                 assert np.array_equal(got[k], ref[k]), (k, exact)
             assert got["btr"] == ref["btr"]
+        import sage_oracle
+        for t in (3, 7, 8, 9, 10, 11):
+            want = sage_oracle.align_trace(profs[t], refl[t], SC, 50, 50)
+            assert (int(got["slice_begin"][t]), int(got["slice_len"][t]), int(got["score_final"][t]), got["btr"][t]) == \
+                   (want["slice_begin"], want["slice_len"], want["score_final"], want["btr"]), t
     finally:
         c.close()

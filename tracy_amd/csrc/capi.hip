@@ -477,7 +477,6 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge;
   a.hfree = prm->hfree; a.vfree = prm->vfree;
   a.qlimit = sub_limit(prm);
-  a.qpos = std::max(std::max(prm->match, prm->mismatch), 0);
   // Gotoh tracebacks: the sweep's workgroup walks its pair itself (TRACYHIP_NO_FUSED_WALK=1: the separate walk launch)
   const bool fused_walk = trace && stage == DP_PLAIN && !needle && getenv("TRACYHIP_NO_FUSED_WALK") == nullptr;
   if (fused_walk) { a.walk_ops = d_ops; a.walk_ops_off = d_ops_off; a.walk_ops_len = d_ops_len; }
@@ -578,7 +577,6 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
     ctx->acc[TRACYHIP_TIMER_BAND].cells -= std::min<uint64_t>(ctx->acc[TRACYHIP_TIMER_BAND].cells, band_cells_credited);
     ctx->acc[TRACYHIP_TIMER_BAND].cells += h_swept;
   }
-  if (herr[0] & 16) ctx->qpos_exceeded = true;  // (informational: a profile entry above max(match, mismatch); see DpArgs::qpos)
   // the packed score field of the origin-tracking sweep is sized for substitution scores of normalised profiles
   if (stage == DP_ORIGIN && pb.mode == MODE_QP && herr[1] > sub_limit(prm)) return kWiden;
   const int verdict = range_verdict(prm, herr, narrow_launches, max_mn, trace ? (needle ? 2 : kTagShift) : 0);
@@ -722,7 +720,6 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   a.a1 = d_a1; a.a2 = d_a2; a.scores = d_scores; a.err = static_cast<int32_t*>(ctx->d_err.p);
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge; a.hfree = prm->hfree; a.vfree = prm->vfree;
   a.qlimit = sub_limit(prm);
-  a.qpos = std::max(std::max(prm->match, prm->mismatch), 0);
   if (d_a2 == ctx->codes() && !ctx->no_compact) a.special_blocks = ctx->special_blocks();
   a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.ckpt_narrow = 1;
   DpArgs af = a, ap = a;
@@ -741,7 +738,6 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   timing_collect(ctx);
-  if (herr[0] & 16) ctx->qpos_exceeded = true;
   uint32_t maxm = 0;
   uint64_t max_mn = 0;
   for (size_t i = 0; i < nf + np; ++i) { maxm = std::max(maxm, hd[i].m); max_mn = std::max<uint64_t>(max_mn, (uint64_t)hd[i].m + hd[i].n); }

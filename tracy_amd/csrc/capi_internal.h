@@ -93,7 +93,6 @@ struct tracyhip_ctx {
   uint32_t mem_share = 1;  // contexts planning workspace on this device at the same time (lanes of one call): each takes its share of what is free
   bool timing = false;
   bool no_narrow = false;  // TRACYHIP_NO_NARROW=1: force the int32 score kernel (A/B measurements)
-  bool qpos_exceeded = false;  // some 16-bit sweep since the flag was last cleared met a profile entry above max(match, mismatch, 0)
   bool no_compact = false; // TRACYHIP_NO_COMPACT=1: every 16-bit sweep on the six-code table (A/B measurements)
   bool no_screen = false;  // TRACYHIP_NO_SCREEN=1: profile x profile scores by the full float chain only (A/B measurements)
   std::vector<Pending> pending;

@@ -69,9 +69,6 @@ struct DpArgs {
   int32_t match, mismatch, go, ge;
   int32_t qlimit;       // max(|match|, |mismatch|): what a substitution score of NORMALISED profiles cannot exceed.  The host-side
                         // range guards (narrow_ok, origin_ok, check_params) assume it; kernels report anything larger in err[1..3]
-  int32_t qpos;         // max(match, mismatch, 0): the largest substitution score of a NORMALISED profile (entries >= 0, mass <= 1).
-                        // The 16-bit query-profile sweep sets err flag 16 when a table entry exceeds it: bounds that count on it
-                        // (the sub-window of the preliminary alignment, pipeline.hip) then fall back to qlimit
   int32_t hfree, vfree;
   int32_t screen;       // profile x profile: substitution scores by the screened short form where it is proven (SubProf::screen)
   // traceback kernels: where the walker's output goes when the workgroup walks its own pair right after the sweep (null: a
@@ -836,7 +833,7 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   // code 5 ('-' / other) and rows off the trace score 0 ----
   {
     bool overflow = false;
-    int32_t qabs = 0, qtop = 0;
+    int32_t qabs = 0;
 #pragma unroll 1
     for (int i = 0; i < K; ++i) {  // (not unrolled: the set-up must not dictate the kernel's register budget)
       const uint32_t r = L * K + i + 1 - pad;
@@ -854,7 +851,6 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         const int32_t qs = q - goe;
         overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
         qabs = imax(qabs, q < 0 ? -q : q);
-        qtop = imax(qtop, q);
         const uint32_t row = (rcflag && b < 4u) ? 3u - b : b;  // reverse-complement view: the complement is folded into the table
         qp_tab[qp6_index<K>(row, (uint32_t)i, L)] = (int16_t)qs;
       }
@@ -862,7 +858,6 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     }
     if (overflow) flag_error(a.err, 1);
     if (!STRINGS && qabs > a.qlimit) flag_max(a.err, 1, qabs);
-    if (!STRINGS && qtop > a.qpos) flag_error(a.err, 16);
     w.sync();
   }
 

@@ -390,7 +390,6 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   int32_t h_verr = 0;
   bool verr_fetched = false;
   o.d_ends = nullptr;
-  ctx->qpos_exceeded = false;
   // ---- 1. orientation scores: gotohScore(trim, fwd) / gotohScore(trim, rev)  (sage.h:239-240) ----
   // When every trimmed profile fits one pass of its strip height, the score pass also leaves wavefront
   // checkpoints and the last-row values, and stage 2 recomputes only the bands its path crosses
@@ -707,23 +706,36 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
     }
     if (ends_path) {
       // c_e from the winner's row m, the sub-window from S* and c_e, the two ends from the origin-tracking sweep over it
-      HIP_TRY(ctx->d_ends.ensure(sizeof(uint32_t) * 4 * (size_t)nt + sizeof(RowEndDesc) * (size_t)nt));
+      HIP_TRY(ctx->d_ends.ensure((sizeof(uint32_t) * 5 + sizeof(RowEndDesc) + sizeof(RowMaxDesc)) * (size_t)nt));
       uint32_t* d_ends = static_cast<uint32_t*>(ctx->d_ends.p);
       uint32_t* d_ce = d_ends + 2 * (size_t)nt;
       uint32_t* d_shift = d_ce + nt;
-      RowEndDesc* d_re = reinterpret_cast<RowEndDesc*>(d_shift + nt);
+      int32_t* d_top = reinterpret_cast<int32_t*>(d_shift + nt);
+      RowEndDesc* d_re = reinterpret_cast<RowEndDesc*>(d_top + nt);
+      RowMaxDesc* d_rm = reinterpret_cast<RowMaxDesc*>(d_re + nt);
       std::vector<RowEndDesc> hre(nt);
-      for (uint32_t t = 0; t < nt; ++t) hre[t] = RowEndDesc{pb.desc[t].lastrow_off, rn[t], 0};
+      std::vector<RowMaxDesc> hrm(nt);
+      for (uint32_t t = 0; t < nt; ++t) {
+        hre[t] = RowEndDesc{pb.desc[t].lastrow_off, rn[t], 0};
+        hrm[t] = RowMaxDesc{in.a1_off[t], mf[t], mt[t], 0u};
+      }
       HIP_TRY(hipMemcpyAsync(d_re, hre.data(), sizeof(RowEndDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(d_rm, hrm.data(), sizeof(RowMaxDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(row_m_end_kernel, dim3(nt), dim3(64), 0, st, static_cast<const RowEndDesc*>(d_re), static_cast<const int32_t*>(ck.d_lastrow),
                          p.go + p.ge, d_ce);
+      // what the diagonal steps of ANY path can add up to at most: every row gives at most max(0, its best table entry)
+      hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, st, static_cast<const RowMaxDesc*>(d_rm), static_cast<const float*>(d_prof),
+                         (float)p.match, (float)p.mismatch, d_top);
       HIP_TRY(hipGetLastError());
       std::vector<uint32_t> h_ce(nt), shift(nt, 0);
+      std::vector<int32_t> h_top(nt);
       HIP_TRY(hipMemcpyAsync(h_ce.data(), d_ce, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));  // (also: hre has been read)
-      // the largest substitution score of a diagonal step: max(match, mismatch, 0) for normalised profiles (what createProfile
-      // writes); a sweep that met a larger table entry has said so (DpArgs::qpos), then only |q| <= max(|match|, |mismatch|) holds
-      const int64_t best = ctx->qpos_exceeded ? (int64_t)sub_limit(&p) : std::max<int64_t>(std::max<int64_t>(p.match, p.mismatch), 0);
+      HIP_TRY(hipMemcpyAsync(h_top.data(), d_top, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));  // (also: hre, hrm have been read)
+      // A path from (0, lead) to (m, c_e) collects at most top = sum over the rows of max(0, best entry of the row's table
+      // column) on its diagonal steps, nothing positive on its vertical ones (go <= 0, ge < 0), and loses at least |ge| per
+      // horizontal gap column: S* <= top - |ge| g.  (top is computed from the profile as it is -- normalised or not -- and is
+      // what best * m overestimates: a profile column that is not one-hot cannot score `match`.)
       const int64_t age = -(int64_t)p.ge;
       std::vector<int32_t> h_pre(nt);
       for (uint32_t t = 0; t < nt; ++t) {
@@ -731,7 +743,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
         h_pre[t] = h_rc[t] ? h_sc2[nt + t] : h_sc2[t];
         const int64_t ce = h_ce[t];
         if (ce <= 0) continue;  // no column leaves row m upwards: the whole window
-        const int64_t loss = best * (int64_t)d.m - (int64_t)h_pre[t];
+        const int64_t loss = (int64_t)h_top[t] - (int64_t)h_pre[t];
         const int64_t g = loss > 0 ? loss / age : 0;
         int64_t a = ce - (int64_t)d.m - g - 2;
         if (a < 0) a = 0;

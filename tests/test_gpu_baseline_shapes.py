@@ -202,3 +202,49 @@ def test_align_preliminary_alignment_by_its_two_ends(monkeypatch):
                    (want["slice_begin"], want["slice_len"], want["score_final"], want["btr"]), t
     finally:
         c.close()
+
+
+def test_align_final_alignment_on_the_certified_band(monkeypatch):
+    """TRACYHIP_BAND_W: the final alignments as a traceback DP on a diagonal band, certified per pair by score against the bound
+    of the profile's row maxima, repeated on the whole matrix where the certificate fails.  Same results as the default path for
+    a band that certifies (48), one that mostly does not (2: nearly every pair is repeated) and in between (12); against the
+    oracle for the traces whose slices are longer / shorter than the trace or barely match"""
+    import tracy_amd
+    from tracy_amd import hostlib
+    import sage_oracle
+    nt = 24
+    refs, profs, rev = hostlib.synth_align(4242, nt, 6000, 1000, 0)
+    profs = profs.copy()
+    rng = np.random.default_rng(8)
+    profs[2] = rng.random(profs[2].shape).astype(np.float32)  # unrelated trace
+    profs[2][4:] = 0
+    profs[2][:4] /= profs[2][:4].sum(axis=0, keepdims=True)
+    for t, (cut, ins) in {4: (2700, 60), 5: (3100, 200), 6: (2500, 9)}.items():  # segments inserted into / deleted from the window
+        r = refs[t].copy()
+        seg = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), ins)
+        refs[t] = np.concatenate([r[:cut], seg, r[cut:]])[:len(r)]
+    for t, (cut, dele) in {7: (2800, 40), 8: (3000, 150)}.items():
+        r = refs[t].copy()
+        refs[t] = np.concatenate([r[:cut], r[cut + dele:], r[:dele]])
+    refl = [r.tobytes() for r in refs]
+    keys = ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final", "score_fwd", "score_rev")
+    c = tracy_amd.Context(0)
+    try:
+        monkeypatch.delenv("TRACYHIP_BAND_W", raising=False)
+        ref = c.align_traces(list(profs), refl, SC, 50, 50, exact_scores=True)
+        for wband in ("48", "12", "2"):
+            monkeypatch.setenv("TRACYHIP_BAND_W", wband)
+            for lanes in (1, 2):
+                c.set_lanes(lanes)
+                got = c.align_traces(list(profs), refl, SC, 50, 50, exact_scores=True)
+                for k in keys:
+                    assert np.array_equal(got[k], ref[k]), (k, wband, lanes)
+                assert got["btr"] == ref["btr"], (wband, lanes)
+            c.set_lanes(1)
+        monkeypatch.delenv("TRACYHIP_BAND_W")
+        for t in (0, 2, 4, 5, 6, 7, 8):
+            want = sage_oracle.align_trace(profs[t], refl[t], SC, 50, 50)
+            assert (int(ref["slice_begin"][t]), int(ref["slice_len"][t]), int(ref["score_final"][t]), ref["btr"][t]) == \
+                   (want["slice_begin"], want["slice_len"], want["score_final"], want["btr"]), t
+    finally:
+        c.close()

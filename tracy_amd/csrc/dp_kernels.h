@@ -37,6 +37,9 @@ enum : uint32_t {
   PAIR_A2_REVCOMP = 1u,  // read a2 reversed and complemented (profile.h:74-90)
   PAIR_ROW4_ZERO = 2u,   // profile x profile: row 4 ('N') is zero in BOTH profiles (the host classified the sequences): launches of
                          // such pairs run the 16-term body
+  PAIR_BANDED = 4u,      // full-matrix traceback on the diagonals band_dmin .. band_dmax only (multi-pass form: every pass sweeps
+                         // the columns its rows can reach inside the band; cells outside read as -inf).  The caller certifies the
+                         // result (pipeline.hip, final alignments) and repeats the pair without the flag otherwise.
 };
 
 // one DP problem; lives in device memory, built on the host
@@ -54,6 +57,12 @@ struct PairDesc {
   uint64_t ckpt_off;    // wavefront checkpoints of this pair (int32 units) -- checkpointed score / band traceback
   uint64_t lastrow_off; // {H, E} of row m per column (int32 units, 2 per column)
 };
+// PAIR_BANDED pairs (full-matrix traceback, no checkpoints) keep the diagonals c - r of their band in ckpt_off: dmin (<= 0) in
+// the low half, dmax (>= n - m) in the high half
+TR_HD uint64_t band_pack(int32_t dmin, int32_t dmax) { return (uint64_t)(uint32_t)dmin | ((uint64_t)(uint32_t)dmax << 32); }
+TR_HD int32_t band_dmin(const PairDesc& d) { return (int32_t)(uint32_t)d.ckpt_off; }
+TR_HD int32_t band_dmax(const PairDesc& d) { return (int32_t)(uint32_t)(d.ckpt_off >> 32); }
+
 
 struct DpArgs {
   const PairDesc* pairs;
@@ -402,8 +411,21 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     const uint32_t base = p * 64u * K;  // rows base+1 .. base+64K
     const uint32_t rows_here = (m - base < 64u * K) ? m - base : 64u * K;
     const uint32_t lanes_used = (rows_here + K - 1) / K;
-    const uint32_t t_end = n + lanes_used - 1;
     const bool last_pass = (p + 1 == P);
+    // columns of this pass: all of them, or (PAIR_BANDED) those its rows can reach inside the band; c_plo / c_phi: the same
+    // of the previous pass (what its hand-over row holds)
+    const bool banded = TRACE && (d.flags & PAIR_BANDED) != 0;
+    int32_t c_lo = 1, c_hi = (int32_t)n, c_plo = 1, c_phi = (int32_t)n;
+    if (banded) {
+      c_lo = imax(1, (int32_t)base + 1 + band_dmin(d));
+      c_hi = imin32((int32_t)n, (int32_t)(base + rows_here) + band_dmax(d));
+      if (p) {
+        c_plo = imax(1, (int32_t)(base - 64u * K) + 1 + band_dmin(d));
+        c_phi = imin32((int32_t)n, (int32_t)base + band_dmax(d));
+      }
+    }
+    const uint32_t t_begin = (uint32_t)c_lo;
+    const uint32_t t_end = (uint32_t)c_hi + lanes_used - 1;
 
     // Checkpointed score pass (single pass, free end gaps on row 0): rows are anchored at the BOTTOM of the
     // strips, so row m always sits in the last slot of the last used lane (its H is bot_h, its E is El[K-1]);
@@ -424,7 +446,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       if (BOTTOM && (L * K + i < pad)) {
         ss.Hl[i] = goe_n; ss.El[i] = 0; ss.hopen[i] = go + ge; ss.hext[i] = 0;
       } else if (TRACE) {
-        ts.Hc[i] = (int32_t)((uint32_t)h0 << SH);
+        ts.Hc[i] = (c_lo > 1) ? neg : (int32_t)((uint32_t)h0 << SH);  // (banded: the column left of the window is outside the band)
         ts.Ec[i] = neg;
         ts.cx1[i] = trace_cx1(hz ? 0 : go + ge);
         ts.cx2[i] = trace_cx2(hz ? 0 : ge);
@@ -437,6 +459,11 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     }
     const uint32_t row_above = (base + L * K > pad) ? base + L * K - pad : 0u;
     int32_t prev_up_h = ((row_above == 0) ? 0 : (int32_t)((uint32_t)edge_value(vfree, go, ge, (int32_t)row_above) << SH)) + goe_n;
+    if (c_lo > 1) {  // banded, not the first pass: H(row above, c_lo - 1) is the hand-over row's value for lane 0 where the previous
+                     // pass computed it (a step along the band's lowest diagonal), -inf everywhere else
+      const int32_t cl = c_lo - 1;
+      prev_up_h = (L == 0 && cl >= c_plo && cl <= c_phi) ? scratch[2 * cl] : neg;
+    }
     const int32_t delta_last = (NARROW && hfree && L == lanes_used - 1) ? -goe : 0;  // row m: horizontal open costs 0
     int32_t bot_h = 0, bot_f = 0;
 
@@ -544,11 +571,12 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         up_h = w.shift_up(bot_h);
         up_f = w.shift_up(bot_f);
       }
-      const bool active = (uint32_t)(t - 1u - L) < n;  // 1 <= c <= n
+      const bool active = (uint32_t)(c - c_lo) <= (uint32_t)(c_hi - c_lo);  // c_lo <= c <= c_hi (1 .. n unless banded)
       if (active) {
         if (p != 0 && L == 0) {  // last row of the previous pass
-          up_h = scratch[2 * c];
-          up_f = scratch[2 * c + 1];
+          const bool held = !banded || (c >= c_plo && c <= c_phi);
+          up_h = held ? scratch[2 * c] : neg;
+          up_f = held ? scratch[2 * c + 1] : neg;
         }
         int32_t vopen = go + ge, vext = ge;
         if (vfree) {  // free end gap in the last column.  vfree is wave-uniform: keep it a scalar branch
@@ -604,11 +632,11 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       auto raw_at = [&](int32_t tt) -> uint32_t { return a2v[(uint32_t)(lane_base + dir * tt)]; };
       uint32_t raw_next;
       {
-        const uint32_t raw1 = raw_at(1);
-        raw_next = raw_at(2);
+        const uint32_t raw1 = raw_at((int32_t)t_begin);
+        raw_next = raw_at((int32_t)t_begin + 1);
         qp_fetch_rows<K>(lane_col, raw1, qa);
       }
-      for (uint32_t t = 1; t <= t_end; t += 2) {
+      for (uint32_t t = t_begin; t <= t_end; t += 2) {
         {
           const uint32_t raw_nn = raw_at((int32_t)t + 2);
           qp_fetch_rows<K>(lane_col, raw_next, qb);

@@ -46,6 +46,7 @@ constexpr int32_t kTagEOpen = 7, kTagEExt = 10, kTagFOpen = 1, kTagFExt = 6;
 
 TR_HD int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
 TR_HD int32_t imax3(int32_t a, int32_t b, int32_t c) { return imax(imax(a, b), c); }
+TR_HD int32_t imin32(int32_t a, int32_t b) { return a < b ? a : b; }
 
 // shift a nibble into the top of a 32-bit accumulator: v_alignbit_b32
 TR_HD uint32_t push_nibble(uint32_t acc, uint32_t nib_src) { return (acc >> 4) | (nib_src << 28); }

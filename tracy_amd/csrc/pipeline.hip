@@ -919,6 +919,22 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
     pb.d_a2 = ctx->codes();
     pb.desc.resize(nt);
     pb.k.resize(nt);
+    // Certified diagonal band: the slice was cut to the aligned region, so the path of the final
+    // alignment runs along the diagonal.  With top = the most the diagonal steps of ANY path can add up to (sum of the row
+    // maxima of the profile) a path that leaves the diagonals [-W - (m-n)+, W + (n-m)+] makes more than W interior gap steps
+    // and scores at most top - |ge| (W + 1).  The traceback DP runs on the band only (PAIR_BANDED: short strips, every pass
+    // sweeps the columns its rows can reach); if its score S_b beats that bound, S_b is the optimum, every optimal path and
+    // every tie the traceback tests lies inside, and scores, bits and path are those of the whole matrix.  Pairs that do not
+    // certify are repeated on the whole matrix.  OFF by default this round (TRACYHIP_BAND_W=48 turns it on): the traceback
+    // launch drops from 4.5 to 3.6 ms per 10 000 traces, but the traceback words keep the whole-matrix layout (four passes of
+    // n + 63 steps, of which a pass now writes a third), and the launch of the score sweep that follows a banded traceback
+    // was measured at 28.3-28.5 ms instead of 27.9 (the 4 x larger, sparsely written workspace is the suspect) -- the step
+    // gains 0.4 ms, not 0.9.  The compact word layout comes first.
+    const char* band_env = getenv("TRACYHIP_BAND_W");
+    const int32_t bandW = (band_env && p.ge < 0 && p.go <= 0) ? atoi(band_env) : 0;
+    constexpr int kBandK = 4;
+    std::vector<uint8_t> banded(nt, 0);
+    uint32_t nbanded = 0;
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc d{};
       d.a1_off = sp.offset[t];
@@ -931,12 +947,63 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
       d.a2_off = sr.offset[ridx[t]] + (h_rc[t] ? rn[t] - h_trim[t].ri - h_trim[t].len : h_trim[t].ri);
       d.flags = h_rc[t] ? PAIR_A2_REVCOMP : 0;
       d.out = t;
-      pb.desc[t] = d;
       pb.k[t] = choose_k(d.m, MODE_QP);
+      if (bandW > 0 && d.m && d.n) {
+        const int64_t over = (int64_t)d.n - (int64_t)d.m;
+        const int64_t width = 2 * (int64_t)bandW + (over < 0 ? -over : over);        // diagonals of the band
+        const int64_t rows_pass = 64 * kBandK;
+        // worth it when a pass sweeps well under half of the columns and there are passes to speak of
+        if ((int64_t)d.m >= 3 * rows_pass && 2 * (rows_pass + width) < (int64_t)d.n) {
+          d.flags |= PAIR_BANDED;
+          d.ckpt_off = band_pack((int32_t)(-(int64_t)bandW - (over < 0 ? -over : 0)), (int32_t)((int64_t)bandW + (over > 0 ? over : 0)));
+          pb.k[t] = kBandK;
+          banded[t] = 1;
+          ++nbanded;
+        }
+      }
+      pb.desc[t] = d;
+    }
+    int32_t* d_top = nullptr;
+    if (nbanded) {  // the bound's top, per trace, while the DP runs
+      DevBuf& b = ctx->d_tmp[6];
+      HIP_TRY(b.ensure((sizeof(RowMaxDesc) + sizeof(int32_t)) * (size_t)nt));
+      RowMaxDesc* d_rm = static_cast<RowMaxDesc*>(b.p);
+      d_top = reinterpret_cast<int32_t*>(d_rm + nt);
+      std::vector<RowMaxDesc> hrm(nt);
+      for (uint32_t t = 0; t < nt; ++t) hrm[t] = RowMaxDesc{sp.offset[t], mf[t], mf[t], 0u};
+      HIP_TRY(hipMemcpyAsync(d_rm, hrm.data(), sizeof(RowMaxDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));  // (hrm is a local)
+      hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, st, static_cast<const RowMaxDesc*>(d_rm), static_cast<const float*>(d_prof),
+                         (float)p.match, (float)p.mismatch, d_top);
+      HIP_TRY(hipGetLastError());
     }
     if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(d_final_sc), static_cast<uint8_t*>(d_ops),
                      static_cast<const uint64_t*>(ctx->d_ops_off.p), static_cast<uint32_t*>(d_olen))))
       return rc;
+    if (nbanded) {
+      std::vector<int32_t> h_top(nt), h_sb(nt);
+      HIP_TRY(hipMemcpyAsync(h_top.data(), d_top, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(h_sb.data(), d_final_sc, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      const int64_t lose = (int64_t)(-(int64_t)p.ge) * ((int64_t)bandW + 1);
+      std::vector<PairDesc> again;
+      std::vector<int> again_k;
+      for (uint32_t t = 0; t < nt; ++t) {
+        if (!banded[t] || (int64_t)h_sb[t] > (int64_t)h_top[t] - lose) continue;
+        PairDesc d = pb.desc[t];
+        d.flags &= ~PAIR_BANDED;
+        d.ckpt_off = 0;
+        again.push_back(d);
+        again_k.push_back(choose_k(d.m, MODE_QP));
+      }
+      if (!again.empty()) {
+        pb.desc.swap(again);
+        pb.k.swap(again_k);
+        if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(d_final_sc), static_cast<uint8_t*>(d_ops),
+                         static_cast<const uint64_t*>(ctx->d_ops_off.p), static_cast<uint32_t*>(d_olen))))
+          return rc;
+      }
+    }
   }
 
   // ---- results ----

@@ -25,7 +25,7 @@ def lib():
     return _LIB
 
 
-def run(a1, a2, score, hfree, vfree, mode, K, trace=True, needle=False, revcomp=False, a1_view=None, narrow=False, screen=False):
+def run(a1, a2, score, hfree, vfree, mode, K, trace=True, needle=False, revcomp=False, a1_view=None, narrow=False, screen=False, band=None):
     """a1/a2: bytes or float32 [6][len] arrays.  a1_view=(offset, m): use columns [offset, offset+m) of a1."""
     def prep(x):
         if isinstance(x, (bytes, bytearray)):
@@ -50,7 +50,7 @@ def run(a1, a2, score, hfree, vfree, mode, K, trace=True, needle=False, revcomp=
     ol = C.c_uint32(0)
     err = C.c_int32(0)
     rc = lib().emu_dp(int(needle), mode, K, int(trace), C.c_void_p(p1), m, s1, C.c_void_p(b2.ctypes.data), n, s2,
-                      (1 if revcomp else 0) | (0x100 if narrow else 0) | (0x200 if screen else 0), *[int(x) for x in score], int(hfree), int(vfree), C.byref(sc), ops,
+                      (1 if revcomp else 0) | (0x100 if narrow else 0) | (0x200 if screen else 0) | ((0x400 | (int(band) << 16)) if band is not None else 0), *[int(x) for x in score], int(hfree), int(vfree), C.byref(sc), ops,
                       C.byref(ol), C.byref(err))
     assert rc == 0
     return sc.value, (ops.raw[:ol.value] if trace else None), err.value

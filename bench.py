@@ -382,8 +382,8 @@ def main():
                 "valu": {"achieved": round(kgcups(sc) * ops_per_cell / 1e3, 2), "peak": 78.6, "unit": "T lane-ops/s",
                          "frac": round(kgcups(sc) * ops_per_cell / 1e3 / 78.6, 3),
                          "note": "integer DP is VALU-issue bound; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"},
-                # the full-matrix traceback kernel (0.5 B per cell of traceback nibbles) still runs for the final alignments
-                "traceback_kernel": {"kernel": "gotoh_kernel<K,QP,TRACE> (full-matrix traceback of the final alignments; the workgroup walks its own pair, no walk launch)",
+                # the traceback kernel (0.5 B per cell of traceback nibbles) runs for the final alignments: on the certified diagonal band
+                "traceback_kernel": {"kernel": "gotoh_kernel<K,QP,TRACE> (traceback of the final alignments on the certified diagonal band, whole matrix where a pair does not certify; cells and bytes credited are the whole matrices'; the workgroup walks its own pair)",
                                      "achieved": round(gbs(tr), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(gbs(tr) / HBM_PEAK_GBS, 4), "kernel_gcups": round(kgcups(tr), 1),
                                      "avg_launch_ms": round(tr["ms"] / max(tr["launches"], 1), 3),

@@ -378,6 +378,8 @@ struct OrientOut {
   std::vector<uint8_t> fwd, rc; // rs.forward; "read the window as its reverse complement"
   const uint32_t* d_ends = nullptr;  // device [2 nt] when set: {leading 'h' columns, last column that is not a trailing 'h'} of the
                                      // preliminary alignment instead of its ops (OrientIn::ends_only)
+  std::vector<uint32_t> gap;         // with d_ends: per trace, the most gap columns the preliminary alignment's score allows
+                                     // ((top - S*) / |ge|): how far from a perfect match the trace is
 };
 
 int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn& in, OrientOut& o, bool force_wide) {
@@ -738,6 +740,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       // what best * m overestimates: a profile column that is not one-hot cannot score `match`.)
       const int64_t age = -(int64_t)p.ge;
       std::vector<int32_t> h_pre(nt);
+      o.gap.assign(nt, 0);
       for (uint32_t t = 0; t < nt; ++t) {
         PairDesc& d = pb.desc[t];
         h_pre[t] = h_rc[t] ? h_sc2[nt + t] : h_sc2[t];
@@ -745,6 +748,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
         if (ce <= 0) continue;  // no column leaves row m upwards: the whole window
         const int64_t loss = (int64_t)h_top[t] - (int64_t)h_pre[t];
         const int64_t g = loss > 0 ? loss / age : 0;
+        o.gap[t] = (uint32_t)std::min<int64_t>(g, 0x7fffffff);
         int64_t a = ce - (int64_t)d.m - g - 2;
         if (a < 0) a = 0;
         shift[t] = (uint32_t)a;
@@ -928,8 +932,14 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
     // certify are repeated on the whole matrix.  W = 48 by default (TRACYHIP_BAND_W=<W>; 0 = whole matrices): the traceback
     // launch takes 3.5 instead of 4.5 ms per 10 000 traces.  The traceback words keep the whole-matrix layout (four passes of
     // n + 63 steps, of which a pass writes a third); a compact layout would shrink the workspace, not the work.
+    // Without the variable every pair gets the width its preliminary alignment suggests: the gap columns that alignment's score
+    // allowed (OrientOut::gap) + 48 for what the trimmed ends add, within [32, 96]; 48 where that is not known.  (A pair that does not
+    // certify costs a launch of its own at the end of the step -- 0.7 ms for a single pair -- so the width errs on the wide side.)
     const char* band_env = getenv("TRACYHIP_BAND_W");
     const int32_t bandW = (p.ge < 0 && p.go <= 0) ? (band_env ? atoi(band_env) : 48) : 0;
+    std::vector<int32_t> band_of(nt, bandW);
+    if (!band_env && bandW > 0 && oo.gap.size() == nt)
+      for (uint32_t t = 0; t < nt; ++t) band_of[t] = (int32_t)std::min<uint32_t>(96u, std::max<uint32_t>(32u, oo.gap[t] + 48u));
     constexpr int kBandK = 4;
     std::vector<uint8_t> banded(nt, 0);
     uint32_t nbanded = 0;
@@ -947,13 +957,14 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
       d.out = t;
       pb.k[t] = choose_k(d.m, MODE_QP);
       if (bandW > 0 && d.m && d.n) {
+        const int64_t bw = band_of[t];
         const int64_t over = (int64_t)d.n - (int64_t)d.m;
-        const int64_t width = 2 * (int64_t)bandW + (over < 0 ? -over : over);        // diagonals of the band
+        const int64_t width = 2 * bw + (over < 0 ? -over : over);        // diagonals of the band
         const int64_t rows_pass = 64 * kBandK;
         // worth it when a pass sweeps well under half of the columns and there are passes to speak of
         if ((int64_t)d.m >= 3 * rows_pass && 2 * (rows_pass + width) < (int64_t)d.n) {
           d.flags |= PAIR_BANDED;
-          d.ckpt_off = band_pack((int32_t)(-(int64_t)bandW - (over < 0 ? -over : 0)), (int32_t)((int64_t)bandW + (over > 0 ? over : 0)));
+          d.ckpt_off = band_pack((int32_t)(-bw - (over < 0 ? -over : 0)), (int32_t)(bw + (over > 0 ? over : 0)));
           pb.k[t] = kBandK;
           banded[t] = 1;
           ++nbanded;
@@ -983,16 +994,22 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
       HIP_TRY(hipMemcpyAsync(h_top.data(), d_top, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(h_sb.data(), d_final_sc, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      const int64_t lose = (int64_t)(-(int64_t)p.ge) * ((int64_t)bandW + 1);
       std::vector<PairDesc> again;
       std::vector<int> again_k;
       for (uint32_t t = 0; t < nt; ++t) {
+        const int64_t lose = (int64_t)(-(int64_t)p.ge) * ((int64_t)band_of[t] + 1);
         if (!banded[t] || (int64_t)h_sb[t] > (int64_t)h_top[t] - lose) continue;
         PairDesc d = pb.desc[t];
         d.flags &= ~PAIR_BANDED;
         d.ckpt_off = 0;
         again.push_back(d);
         again_k.push_back(choose_k(d.m, MODE_QP));
+      }
+      if (getenv("TRACYHIP_HOST_TIMERS")) {
+        int64_t wsum = 0, lsum = 0, lmax = 0;
+        for (uint32_t t = 0; t < nt; ++t) { wsum += band_of[t]; const int64_t l = (int64_t)h_top[t] - h_sb[t]; lsum += l; lmax = std::max(lmax, l); }
+        fprintf(stderr, "band: %u of %u pairs banded, %zu repeated; mean W %.1f, mean top - S_b %.1f, max %lld\n", nbanded, nt, again.size(),
+                (double)wsum / nt, (double)lsum / nt, (long long)lmax);
       }
       if (!again.empty()) {
         pb.desc.swap(again);

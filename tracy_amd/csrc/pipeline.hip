@@ -972,6 +972,20 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
       }
       pb.desc[t] = d;
     }
+    // the banded form keeps the whole-matrix word layout on strips of four rows -- four times the traceback words of the plain
+    // form; batches whose words would not fit a quarter of the device memory stay on whole matrices (one launch, no chunks)
+    if (nbanded) {
+      uint64_t bytes = 0;
+      for (uint32_t t = 0; t < nt; ++t)
+        if (banded[t]) bytes += (uint64_t)num_passes(pb.desc[t].m, kBandK) * steps_per_pass(pb.desc[t].n) * 64u * 8u;
+      size_t fr = 0, tot = 0;
+      HIP_TRY(hipMemGetInfo(&fr, &tot));
+      if (bytes > (uint64_t)tot / 4 / ctx->mem_share) {
+        for (uint32_t t = 0; t < nt; ++t)
+          if (banded[t]) { pb.desc[t].flags &= ~PAIR_BANDED; pb.desc[t].ckpt_off = 0; pb.k[t] = choose_k(pb.desc[t].m, MODE_QP); banded[t] = 0; }
+        nbanded = 0;
+      }
+    }
     int32_t* d_top = nullptr;
     if (nbanded) {  // the bound's top, per trace, while the DP runs
       DevBuf& b = ctx->d_tmp[6];

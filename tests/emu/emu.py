@@ -17,7 +17,7 @@ def lib():
     if _LIB is None:
         so = os.path.join(_HERE, "libemu_wave.so")
         srcs = [os.path.join(_HERE, "emu_wave.cpp"), os.path.join(_ROOT, "tracy_amd/csrc/dp_kernels.h"),
-                os.path.join(_ROOT, "tracy_amd/csrc/dp_lane.h")]
+                os.path.join(_ROOT, "tracy_amd/csrc/dp_lane.h"), os.path.join(_ROOT, "tracy_amd/csrc/band16.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
                                    "-o", so, srcs[0]], stderr=subprocess.DEVNULL)
@@ -160,3 +160,48 @@ def run_origin_qp(prof, a2, score, K, revcomp=False):
                              C.c_uint32(1 if revcomp else 0), *[int(x) for x in score], C.byref(sc), ends.ctypes.data_as(C.POINTER(C.c_uint32)))
     assert rc == 0
     return sc.value, int(ends[0]), int(ends[1])
+
+
+def run_band16(pairs, score, hfree, K, kind=0, strings=True):
+    """pairs: up to four of (a1, a2, dmin, dmax, revcomp); a1 bytes (strings) or float32 [6][m] profiles, a2 reference characters.
+    Returns per pair (score, btr or None, ends or None) and the error word."""
+    npairs = len(pairs)
+    a1_off, a1_stride, ms, a2_off, ns, flags, dmins, dmaxs = [], [], [], [], [], [], [], []
+    if strings:
+        blob1 = b"".join(bytes(p[0]) for p in pairs) + b"\0"
+        o = 0
+        for p in pairs:
+            a1_off.append(o); a1_stride.append(len(p[0])); ms.append(len(p[0])); o += len(p[0])
+        buf1 = np.frombuffer(blob1, dtype=np.uint8).copy()
+    else:
+        arrs = [np.ascontiguousarray(p[0], dtype=np.float32) for p in pairs]
+        o = 0
+        for x in arrs:
+            a1_off.append(o); a1_stride.append(x.shape[1]); ms.append(x.shape[1]); o += x.size
+        buf1 = np.concatenate([x.ravel() for x in arrs] + [np.zeros(1, np.float32)])
+    blob2 = b"".join(bytes(p[1]) for p in pairs) + b"\0"
+    o = 0
+    for p in pairs:
+        a2_off.append(o); ns.append(len(p[1])); o += len(p[1])
+        dmins.append(int(p[2])); dmaxs.append(int(p[3])); flags.append(1 if (len(p) > 4 and p[4]) else 0)
+    buf2 = np.frombuffer(blob2, dtype=np.uint8).copy()
+    cap = max(m + n for m, n in zip(ms, ns)) + 2
+    u64 = lambda v: np.asarray(v, dtype=np.uint64)
+    u32 = lambda v: np.asarray(v, dtype=np.uint32)
+    i32 = lambda v: np.asarray(v, dtype=np.int32)
+    A = dict(a1_off=u64(a1_off), a1_stride=u32(a1_stride), m=u32(ms), a2_off=u64(a2_off), n=u32(ns), flags=u32(flags), dmin=i32(dmins), dmax=i32(dmaxs))
+    scores = np.zeros(4, np.int32)
+    ends = np.zeros(8, np.uint32)
+    ops = np.zeros(4 * cap, np.uint8)
+    ops_len = np.zeros(4, np.uint32)
+    err = C.c_int32(0)
+    ptr = lambda x: C.c_void_p(x.ctypes.data)
+    rc = lib().emu_band16(int(K), int(kind), 1 if strings else 0, npairs, ptr(buf1), ptr(A["a1_off"]), ptr(A["a1_stride"]), ptr(A["m"]), ptr(buf2),
+                          ptr(A["a2_off"]), ptr(A["n"]), ptr(A["flags"]), ptr(A["dmin"]), ptr(A["dmax"]), *[int(x) for x in score], int(hfree),
+                          ptr(scores), ptr(ends), ptr(ops), C.c_uint64(cap), ptr(ops_len), C.byref(err))
+    assert rc == 0
+    out = []
+    for i in range(npairs):
+        btr = ops[i * cap:i * cap + int(ops_len[i])].tobytes() if kind == 0 else None
+        out.append((int(scores[i]), btr, (int(ends[2 * i]), int(ends[2 * i + 1])) if kind == 1 else None))
+    return out, err.value

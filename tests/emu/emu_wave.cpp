@@ -12,6 +12,7 @@
 #include <functional>
 #include <vector>
 
+#include "../../tracy_amd/csrc/band16.h"
 #include "../../tracy_amd/csrc/dp_kernels.h"
 
 using namespace tracyhip;
@@ -79,6 +80,13 @@ struct HostWave {
   int32_t shift_up_or(int32_t x, int32_t first) {  // as shift_up, lane 0 keeps `first` (the DPP `old` operand)
     const int32_t r = shift_up(x);
     return lane_ ? r : first;
+  }
+  int32_t rot16(int32_t x) {  // lane j of a row of 16 receives lane j - 1 of the same row, lane 0 lane 15 (DPP row_ror:1)
+    sh->xchg[lane_] = x;
+    sh->bar.arrive_and_wait();
+    const int32_t r = sh->xchg[(lane_ & ~15u) | ((lane_ - 1u) & 15u)];
+    sh->bar.arrive_and_wait();
+    return r;
   }
   uint64_t ballot(bool p) {
     sh->xchg[lane_] = p ? 1 : 0;
@@ -428,6 +436,61 @@ int emu_dp(int needle, int mode, int K, int trace, const void* a1, uint32_t m, u
     }
   }
   if (err_out) *err_out = err;
+  return 0;
+}
+
+// Up to four pairs through the band kernels (band16.h) as one wave: a1 = concatenated strings (bytes) or float[6][stride] profiles,
+// a2 = reference characters; dmin / dmax = the band's diagonals per pair.  kind 0: traceback (scores, ops in push order at
+// ops + i * ops_cap, ops_len); kind 1: origin-tracking sweep (scores, ends).
+int emu_band16(int K, int kind, int strings, uint32_t npairs, const void* a1, const uint64_t* a1_off, const uint32_t* a1_stride,
+               const uint32_t* m, const uint8_t* a2, const uint64_t* a2_off, const uint32_t* n, const uint32_t* flags, const int32_t* dmin,
+               const int32_t* dmax, int32_t match, int32_t mismatch, int32_t go, int32_t ge, int32_t hfree, int32_t* scores, uint32_t* ends,
+               uint8_t* ops, uint64_t ops_cap, uint32_t* ops_len, int32_t* err_out) {
+  if (npairs == 0 || npairs > 4) return -1;
+  const int shift = kind == 0 ? kTagShift : 0;
+  std::vector<PairDesc> d(npairs);
+  std::vector<int16_t> qp;
+  std::vector<uint8_t> codes;
+  std::vector<uint64_t> ops_off(npairs);
+  uint64_t bits_total = 0;
+  uint32_t nmax = 0;
+  for (uint32_t i = 0; i < npairs; ++i) {
+    PairDesc& p = d[i];
+    p = PairDesc{};
+    p.m = m[i]; p.n = n[i]; p.flags = flags[i] & PAIR_A2_REVCOMP; p.out = i;
+    p.ckpt_off = band_pack(dmin[i], dmax[i]);
+    const uint32_t stride = b16_table_stride(m[i]);
+    p.a1_off = qp.size(); p.a1_stride = stride;
+    qp.resize(qp.size() + (size_t)kB16Codes * stride, 0);
+    for (uint32_t r = 0; r < m[i]; ++r) {
+      int32_t q[kB16Codes];
+      b16_table_row(a1, strings != 0, a1_off[i], a1_stride[i], r, match, mismatch, q);
+      for (uint32_t b = 0; b < kB16Codes; ++b) qp[p.a1_off + (size_t)b * stride + r] = (int16_t)((uint32_t)q[b] << shift);
+    }
+    p.a2_off = codes.size();
+    for (uint32_t c = 0; c < n[i]; ++c) codes.push_back((uint8_t)(strings ? cq_code(a2[a2_off[i] + c]) : dp_code(a2[a2_off[i] + c])));
+    p.bits_off = bits_total;
+    bits_total += (b16_words(m[i], n[i], K, dmin[i], dmax[i]) * b16_word_bytes(K) + 7u) & ~7ull;
+    ops_off[i] = (uint64_t)i * ops_cap;
+    nmax = std::max(nmax, n[i]);
+  }
+  std::vector<uint8_t> bits(bits_total + 64, 0xEE);
+  int32_t errw[kErrWords] = {0};
+  Band16Args a{};
+  a.pairs = d.data(); a.npairs = npairs; a.qp = qp.data(); a.codes = codes.data(); a.bits = bits.data(); a.scores = scores; a.ends = ends;
+  a.err = errw; a.go = go; a.ge = ge; a.hfree = hfree; a.code_cap = (nmax + 3u) & ~3u; a.ops = ops; a.ops_off = ops_off.data(); a.ops_len = ops_len;
+  WaveShared sh;
+  sh.lds.assign(4u * a.code_cap + b16_table_bytes(K) + 64, 0);
+#define EMU_B16(KK)                                                                                                     \
+  case KK:                                                                                                              \
+    sh.run([&](uint32_t l) { HostWave w{l, &sh}; if (kind == 0) band16_body<HostWave, KK, 0>(w, a, 0); else band16_body<HostWave, KK, 1>(w, a, 0); }); \
+    break;
+  switch (K) {
+    EMU_B16(4) EMU_B16(8) EMU_B16(12)
+    default: return -1;
+  }
+#undef EMU_B16
+  if (err_out) *err_out = errw[0];
   return 0;
 }
 }

@@ -53,6 +53,45 @@ def test_align_1kb_vs_10kb(lanes):
         assert int(fast[win][i]) == int(want[win]) and int(fast[lose][i]) >= int(want[lose])
 
 
+@pytest.mark.parametrize("with_short", [False, True])
+def test_align_degenerate_traces_in_a_normal_batch(with_short):
+    """traces whose optimal preliminary alignment is the all-gap path (row m never leaves its trailing run: c_e = 0) -- a poly-A
+    one-hot trace against a 10 kb window over {C,G}, an all-N trace -- and a trace of one row, mixed into a normal batch:
+    every trace equals the oracle (the reference aligns junk like anything else, gotoh.h:143-167, fmindex.h:429-463)"""
+    import tracy_amd
+    from tracy_amd import hostlib
+    from sage_oracle import align_trace
+    nt = 12
+    refs, profs, rev = hostlib.synth_align(31337, nt, 10000, 1000, 0)
+    refs = refs.copy()
+    profl = [np.ascontiguousarray(p) for p in profs]
+    polya = np.zeros((6, 1000), np.float32); polya[0] = 1.0
+    alln = np.zeros((6, 1000), np.float32); alln[4] = 1.0
+    rng = np.random.default_rng(5)
+    refs[3] = np.frombuffer(b"CG", np.uint8)[rng.integers(0, 2, 10000)]  # no A on either strand
+    profl[3] = polya
+    profl[7] = alln
+    profl[10] = polya.copy()   # poly-A against a normal window (it finds its A's: not degenerate)
+    if with_short:             # ragged strip heights: the batch leaves the voted single-K path
+        profl[5] = np.ascontiguousarray(profl[5][:, :1])
+        profl[8] = np.ascontiguousarray(profl[8][:, :130])
+    refl = [r.tobytes() for r in refs]
+    c = tracy_amd.Context(0)
+    try:
+        for exact in (True, False):
+            got = c.align_traces(profl, refl, SC, 50, 50, exact_scores=exact)
+            with ThreadPoolExecutor(max_workers=16) as pool:
+                wants = list(pool.map(lambda i: align_trace(profl[i], refl[i], SC, 50, 50), range(nt)))
+            for i, want in enumerate(wants):
+                for k in ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final") + (("score_fwd", "score_rev") if exact else ()):
+                    assert int(got[k][i]) == int(want[k]), (i, k, exact)
+                assert got["btr"][i] == want["btr"], (i, exact)
+            for i in (3, 7):  # the all-gap alignment: n 'h' then m 'v', trimReferenceSlice keeps substr(0, trimRight)
+                assert int(wants[i]["slice_begin"]) == 0 and int(wants[i]["slice_len"]) == 50, i
+    finally:
+        c.close()
+
+
 def test_align_references_with_n_columns(monkeypatch):
     """the 16-bit sweeps and prefix bounds exist with a four-code table (references of A C G T) and a six-code one; the
     encoders' block map sends each pair to one of them.  A batch that mixes plain windows with windows holding N (at block

@@ -1,0 +1,348 @@
+// band16.h -- Gotoh on a diagonal band, four pairs per wave, sixteen lanes per pair.
+//
+// The row-strip wavefront of dp_kernels.h (lane L owns K rows, the wave walks the anti-diagonals) keeps 64 lanes busy only
+// when a strip has columns to sweep for as long as the 64 strips below it need to start: on a band of `width` diagonals a
+// strip is active for K + width steps out of the 64 (K + 1) it takes to get all lanes going.  Here a pair is swept by the 16
+// lanes of one DPP row instead: strip s (rows sK+1 .. sK+K) belongs to lane s mod 16 and starts at step s (K + 1), one
+// step per column behind the strip above it -- whose last row arrives through a row rotate (row_ror:1), lane 15 handing to
+// lane 0 -- and sweeps its own window of the band, the columns sK+1+dmin .. sK+K+dmax, in S = K + dmax - dmin steps.  With
+// S <= 15 (K + 1) a lane is done with strip s before strip s + 16 is due, the lane above has gone quiet (-inf) before a
+// strip runs past the end of its window, and four pairs fill the wave.  A 1 kb x 1 kb pair on a band of 100 diagonals costs
+// ~1100 steps of a quarter wave with K = 4 instead of ~1060 steps of a whole wave with K = 15.
+//
+// Cells outside the band read as -inf; the caller proves that the band holds every optimal path (a-priori from a known
+// score, or a-posteriori from the banded score: pipeline.hip), which makes scores, trace bits and path those of the whole
+// matrix.  Two kinds share the sweep: KIND 0 stores the trace nibbles of the band -- K/2 bytes per strip
+// and step, (NS-1) S + S_last words per pair, nothing outside the band -- and walks them (gotoh.h:143-167) with the 16 lanes
+// of the pair; KIND 1 is the origin-tracking sweep (dp_lane.h origin_step): score and the two ends trimReferenceSlice reads.
+//
+// Substitution scores come from a table in global memory, int16 [6 codes][rows] per sequence, written once per stage by
+// b16_table_kernel (band16.hip) -- the query profile of align.h:103-118 against one-hot columns for profile rows, byte
+// equality (align.h:96-101) for strings; a lane copies the K rows of its strip into its own column of the LDS table
+// [code][row][lane] when it starts the strip (the rows of the strip after that are already on their way).  The reference
+// codes of the four pairs are staged in LDS once.
+//
+// Domain: AlignConfig<hfree, false> (no free vertical end gaps), go <= 0, ge < 0, one of K = 4 / 8 / 12, S <= 15 (K + 1).
+#ifndef TRACY_AMD_BAND16_H
+#define TRACY_AMD_BAND16_H
+
+#include "dp_kernels.h"
+
+namespace tracyhip {
+
+struct Band16Args {
+  const PairDesc* pairs;  // a1_off / a1_stride: first row and code-row stride of the pair's rows in `qp` (int16 units); a2_off: codes;
+                          // bits_off: BYTE offset of the pair's words (KIND 0); ckpt_off: band_pack(dmin, dmax); flags: PAIR_A2_REVCOMP
+  uint32_t npairs;
+  const int16_t* qp;      // substitution tables (b16_table_kernel): KIND 0 entries are scores << kTagShift, KIND 1 raw scores
+  const uint8_t* codes;   // reference codes 0..5 (ctx->codes())
+  uint8_t* bits;          // KIND 0: trace words
+  int32_t* scores;        // H(m, n) per pair (PairDesc::out), or null
+  uint32_t* ends;         // KIND 1: {lead, c_e} per pair
+  int32_t* err;           // DpArgs::err
+  int32_t go, ge, hfree;
+  uint32_t code_cap;      // LDS bytes reserved per pair for its reference codes (>= the longest n of the launch, multiple of 4)
+  uint8_t* ops;           // KIND 0: walker output (push order), pair i at ops + ops_off[out]
+  const uint64_t* ops_off;
+  uint32_t* ops_len;
+};
+
+constexpr uint32_t kB16Codes = 6;
+TR_HD constexpr uint32_t b16_period(int K) { return 16u * ((uint32_t)K + 1u); }
+TR_HD constexpr uint32_t b16_max_window(int K) { return 15u * ((uint32_t)K + 1u); }
+TR_HD constexpr uint32_t b16_word_bytes(int K) { return K <= 4 ? 2u : K <= 8 ? 4u : 8u; }
+TR_HD constexpr uint32_t b16_table_bytes(int K) { return kB16Codes * (uint32_t)K * 64u * 2u; }
+TR_HD uint32_t b16_strips(uint32_t m, int K) { return (m + (uint32_t)K - 1u) / (uint32_t)K; }
+TR_HD uint32_t b16_window(int K, int32_t dmin, int32_t dmax) { return (uint32_t)K + (uint32_t)(dmax - dmin); }
+// first column of strip s's window (may be <= 0: the lane waits for column 1)
+TR_HD int32_t b16_first_col(uint32_t s, int K, int32_t dmin) { return (int32_t)(s * (uint32_t)K) + 1 + dmin; }
+// the last strip sweeps on to column n: the trailing run of row m (free end gap) lies outside the band's diagonals
+TR_HD uint32_t b16_last_window(uint32_t m, uint32_t n, int K, int32_t dmin, int32_t dmax) {
+  const uint32_t S = b16_window(K, dmin, dmax);
+  const int32_t ext = (int32_t)n - b16_first_col(b16_strips(m, K) - 1u, K, dmin) + 1;
+  return (ext > 0 && (uint32_t)ext > S) ? (uint32_t)ext : S;
+}
+TR_HD uint64_t b16_words(uint32_t m, uint32_t n, int K, int32_t dmin, int32_t dmax) {
+  return (uint64_t)(b16_strips(m, K) - 1u) * b16_window(K, dmin, dmax) + b16_last_window(m, n, K, dmin, dmax);
+}
+// rows of a sequence's table: whole strips for every K, so that a strip's load never runs off the code row
+TR_HD uint32_t b16_table_stride(uint32_t m) { return ((m + 15u) & ~15u) + 16u; }
+
+// One row of a sequence's substitution table (b16_table_kernel; the host emulator builds its tables with the same function).
+// Profile rows: the int of the fp32 chain of align.h:112-117 against the one-hot column of base b (onehot_score) for b = A C G T N,
+// 0 for '-' / any other letter (an all-zero column); string rows: match / mismatch by byte equality (align.h:96-101), mismatch
+// for a column no row letter can equal.
+TR_HD void b16_table_row(const void* a1, bool strings, uint64_t a1_off, uint32_t a1_stride, uint32_t r, int32_t match, int32_t mismatch,
+                         int32_t q[kB16Codes]) {
+  if (strings) {
+    const uint8_t ch = static_cast<const uint8_t*>(a1)[a1_off + r];
+    for (uint32_t b = 0; b < 5; ++b) q[b] = ch == (uint8_t)"ACGTN"[b] ? match : mismatch;
+    q[5] = mismatch;
+  } else {
+    float pr[5];
+    for (int k = 0; k < 5; ++k) pr[k] = static_cast<const float*>(a1)[a1_off + (uint64_t)k * a1_stride + r];
+    for (uint32_t b = 0; b < 5; ++b) q[b] = onehot_score(pr, b, (float)match, (float)mismatch);
+    q[5] = 0;
+  }
+}
+
+TR_HD uint32_t ctz16(uint32_t x) {  // 16 when no bit is set
+  uint32_t i = 0;
+  x |= 0x10000u;
+  while (!((x >> i) & 1u)) ++i;
+  return i;
+}
+
+template <int K>
+struct Band16Fetch {
+  const uint8_t* bits;
+  uint32_t S, S_last, NS, n;
+  int32_t dmin;
+  TR_HD bool inside(uint32_t r, uint32_t c) const {
+    const uint32_t s = (r - 1u) / (uint32_t)K;
+    const int32_t u = (int32_t)c - b16_first_col(s, K, dmin);
+    return c >= 1u && c <= n && u >= 0 && (uint32_t)u < (s + 1u == NS ? S_last : S);
+  }
+  TR_HD uint32_t operator()(uint32_t r, uint32_t c) const {
+    const uint32_t s = (r - 1u) / (uint32_t)K, slot = (r - 1u) % (uint32_t)K;
+    const uint64_t idx = (uint64_t)s * S + (uint32_t)((int32_t)c - b16_first_col(s, K, dmin));
+    uint64_t wd;
+    if (K <= 4) wd = reinterpret_cast<const uint16_t*>(bits)[idx];
+    else if (K <= 8) wd = reinterpret_cast<const uint32_t*>(bits)[idx];
+    else wd = reinterpret_cast<const uint64_t*>(bits)[idx];
+    return (uint32_t)(wd >> (4u * slot)) & 15u;
+  }
+};
+
+// The traceback state machine of gotoh.h:143-167 walked by the 16 lanes of each pair (walk_core of dp_kernels.h, a row of 16
+// candidates per round; the four groups of the wave run side by side).  A cell outside the stored band ends the walk with
+// an error flag: the caller's certificate has failed for that pair and the pair is repeated on the whole matrix.
+template <class W, class Fetch>
+TR_HD void walk16(W& w, const Fetch& fetch, bool have, uint32_t m, uint32_t n, uint8_t* out, uint32_t* ops_len, int32_t* err) {
+  const uint32_t lane = w.lane() & 15u, gsh = (w.lane() >> 4) * 16u;
+  uint32_t row = m, col = n, k = 0;
+  int state = 0;
+  const uint32_t limit = m + n;
+  bool lost = false;
+  for (;;) {
+    const bool running = have && !lost && row > 0 && col > 0 && k <= limit;
+    if (w.ballot(running) == 0) break;
+    const uint32_t r = (state == 1) ? row : row - lane;
+    const uint32_t c = (state == 2) ? col : col - lane;
+    const bool inside = running && ((state == 1) ? (lane < col) : (state == 2) ? (lane < row) : (lane < row && lane < col));
+    const bool inband = inside && fetch.inside(r, c);
+    TraceBits b = {false, false, false, false};
+    if (inband) b = decode_nibble(fetch(r, c));
+    const bool hit = inband && (state == 0 ? (b.bit3 || b.bit4) : state == 1 ? b.bit1 : b.bit2);
+    const uint32_t first_hit = ctz16((uint32_t)(w.ballot(hit) >> gsh) & 0xffffu);
+    const uint32_t first_out = ctz16((uint32_t)(w.ballot(!inband) >> gsh) & 0xffffu);
+    const uint32_t to_state = w.bcast((uint32_t)(b.bit3 ? 1 : 2), gsh + (first_hit & 15u));
+    if (!running) continue;
+    if (first_out == 0) { lost = true; continue; }  // the cell the walk stands on is not in the band
+    if (state == 0) {
+      const uint32_t x = first_hit < first_out ? first_hit : first_out;
+      if (lane < x) out[k + lane] = 's';
+      k += x; row -= x; col -= x;
+      if (first_hit < first_out) state = (int)to_state;
+    } else {
+      const bool found = first_hit < first_out;
+      const uint32_t x = found ? first_hit + 1 : first_out;
+      if (lane < x) out[k + lane] = state == 1 ? 'h' : 'v';
+      k += x;
+      if (state == 1) col -= x; else row -= x;
+      if (found) state = 0;
+    }
+  }
+  bool ok = have && !lost;
+  if (ok) {  // first row / first column (gotoh.h:112-123)
+    if (row == 0) {
+      if (state == 2 && col > 0) ok = false;
+      else { for (uint32_t i = lane; i < col; i += 16) out[k + i] = 'h'; k += col; col = 0; }
+    } else if (col == 0) {
+      if (state == 1) ok = false;
+      else { for (uint32_t i = lane; i < row; i += 16) out[k + i] = 'v'; k += row; row = 0; }
+    }
+    if (row > 0 || col > 0) ok = false;
+  }
+  if (have && lane == 0) {
+    if (!ok) flag_error(err, 2);
+    *ops_len = ok ? k : 0u;
+  }
+}
+
+template <class W, int K, int KIND>
+TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
+  static_assert(K == 4 || K == 8 || K == 12, "strip heights of the band kernels");
+  constexpr int SH = KIND == 0 ? kTagShift : kOriginShift;
+  constexpr int TS = KIND == 0 ? 0 : kOriginBits;
+  constexpr int32_t P = (int32_t)b16_period(K);
+  const uint32_t L = w.lane(), g = L >> 4, j = L & 15u;
+  const uint32_t pair_idx = wave_idx * 4u + g;
+  const bool have = pair_idx < a.npairs;
+  PairDesc d{};
+  if (have) d = a.pairs[pair_idx];
+  const uint32_t m = d.m, n = d.n;
+  const int32_t dmin = band_dmin(d), dmax = band_dmax(d);
+  const int32_t go = a.go, ge = a.ge, goe = go + ge;
+  const bool hfree = a.hfree != 0;
+  const bool rcflag = (d.flags & PAIR_A2_REVCOMP) != 0;
+  const uint32_t NS = have ? b16_strips(m, K) : 0u;
+  const uint32_t S = b16_window(K, dmin, dmax);
+  const uint32_t S_last = have ? b16_last_window(m, n, K, dmin, dmax) : 0u;
+  const int32_t neg = KIND == 0 ? (int32_t)((uint32_t)kNegInf << SH) : (int32_t)((uint32_t)kNegInfOrigin << SH);
+  auto edge = [&](uint32_t r) -> int32_t { return (int32_t)((uint32_t)edge_value(false, go, ge, (int32_t)r) << SH); };  // H(r, 0), r >= 1
+  // H(0, c): the free (or paid) leading gap; KIND 1 carries the column itself as the origin
+  auto row0 = [&](int32_t c) -> int32_t {
+    if (c <= 0) return 0;
+    return (int32_t)((uint32_t)edge_value(hfree, go, ge, c) << SH) + (KIND == 1 ? c : 0);
+  };
+
+  // ---- LDS: the reference codes of the four pairs in view order (column c at byte c - 1), then the lanes' tables ----
+  uint8_t* lcodes = reinterpret_cast<uint8_t*>(w.lds()) + g * a.code_cap;
+  int16_t* tab = reinterpret_cast<int16_t*>(w.lds() + 4u * a.code_cap) + L;
+  if (have) {
+    const uint8_t* src = a.codes + d.a2_off;
+    for (uint32_t i = j; i < n; i += 16) lcodes[i] = src[rcflag ? n - 1u - i : i];
+  }
+  w.sync();
+  auto code_at = [&](int32_t c) -> uint32_t {  // clamped: lanes off the reference read some column of it and discard the result
+    const int32_t x = c > (int32_t)n ? (int32_t)n : c;
+    return lcodes[(uint32_t)((x < 1 ? 1 : x) - 1)];
+  };
+
+  // ---- wave-uniform step counts ----
+  uint32_t T_end = 0, t_last = ~0u;
+  {
+    const uint32_t mine = have ? (NS - 1u) * (uint32_t)(K + 1) + S_last : 0u;
+    const uint32_t lastbeg = have ? (NS - 1u) * (uint32_t)(K + 1) : ~0u;
+    for (uint32_t q = 0; q < 4; ++q) {
+      const uint32_t x = w.bcast(mine, q * 16u), y = w.bcast(lastbeg, q * 16u);
+      T_end = x > T_end ? x : T_end;
+      t_last = y < t_last ? y : t_last;
+    }
+  }
+
+  // ---- per-lane state ----
+  TraceLane<K> ts;
+#pragma unroll
+  for (int i = 0; i < K; ++i) { ts.Hc[i] = neg; ts.Ec[i] = neg; ts.cx1[i] = 0; ts.cx2[i] = 0; }
+  int32_t bot_h = neg, bot_f = neg, prev_up_h = neg;
+  int32_t u = -(int32_t)(j * (uint32_t)(K + 1));  // step inside the lane's current strip (negative: not begun)
+  uint32_t s_cur = j;
+  int32_t c = 0;
+  uint32_t S_cur = 0;
+  bool live = false;
+  uint32_t raw_next = 0;
+  uint32_t c_end = 0;
+  const int32_t cy1 = trace_cy1<TS>(goe), cy2 = trace_cy2<TS>(ge);
+  uint8_t* bits = a.bits + d.bits_off;
+  const uint32_t slot_m = have && m ? (m - 1u) % (uint32_t)K : 0u;
+
+  // rows of strip s: K int16 per code, straight from the sequence's table
+  constexpr int ND = K / 2;
+  uint32_t pf[kB16Codes][ND];
+  auto prefetch = [&](uint32_t s) {
+    const int16_t* src = a.qp + d.a1_off + (uint64_t)s * K;
+#pragma unroll
+    for (uint32_t b = 0; b < kB16Codes; ++b) __builtin_memcpy(pf[b], src + (uint64_t)b * d.a1_stride, 2 * K);  // (any alignment: a trimmed view may start on an odd row)
+  };
+  if (have && j < NS) prefetch(j);
+
+  SubRows<K, KIND == 0 ? 0 : SH> sub;
+  for (uint32_t t = 0; t < T_end; ++t) {
+    if (u == 0) {  // ---- begin strip s_cur (one lane per pair, every K + 1 steps) ----
+      live = have && s_cur < NS;
+      if (live) {
+        const uint32_t r0 = s_cur * (uint32_t)K;
+        const int32_t cw = b16_first_col(s_cur, K, dmin);
+        c = cw;
+        S_cur = (s_cur + 1u == NS) ? S_last : S;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          const uint32_t r = r0 + (uint32_t)i + 1u;
+          const bool hz = hfree && r == m;
+          ts.cx1[i] = trace_cx1<TS>(hz ? 0 : goe);
+          ts.cx2[i] = trace_cx2<TS>(hz ? 0 : ge);
+          ts.Hc[i] = cw <= 1 ? edge(r) : neg;  // left of the window: column 0 (gotoh.h:117-123), or outside the band
+          ts.Ec[i] = neg;
+        }
+        bot_h = cw <= 0 ? edge(r0 + (uint32_t)K) : neg;  // what the strip below sees while this one waits for column 1
+        bot_f = neg;
+        if (s_cur == 0) prev_up_h = row0(cw - 1);
+#pragma unroll
+        for (uint32_t b = 0; b < kB16Codes; ++b) {
+          const uint32_t rowsel = (rcflag && b < 4u) ? 3u - b : b;  // reverse-complement view: the complement is folded into the table
+#pragma unroll
+          for (int q = 0; q < ND; ++q) {
+            tab[(rowsel * K + 2 * q) * 64] = (int16_t)(pf[b][q] & 0xffffu);
+            tab[(rowsel * K + 2 * q + 1) * 64] = (int16_t)(pf[b][q] >> 16);
+          }
+        }
+        raw_next = code_at(c);
+        if (s_cur + 16u < NS) prefetch(s_cur + 16u);
+      }
+    }
+    int32_t up_h = w.rot16(bot_h);
+    int32_t up_f = w.rot16(bot_f);
+    if (t < (uint32_t)P) {  // the first strips: row 0 instead of a strip above (gotoh.h:112-116)
+      if (live && s_cur == 0 && (uint32_t)u < S_cur) { up_h = row0(c); up_f = neg; }  // (not past its window: the last step before strip 16 begins
+                                                                                        // delivers that strip's diagonal from lane 15)
+    }
+    const uint32_t raw = raw_next;
+    raw_next = code_at(c + 1);
+    const bool active = live && (uint32_t)u < S_cur && c >= 1 && c <= (int32_t)n;
+    if (active) {
+      qp_fetch_rows<K>(tab, raw, sub);
+      int32_t nb_h, nb_f;
+      if (KIND == 0) {
+        uint32_t w0 = 0, w1 = 0;
+        trace_step<K>(ts, up_h, up_f, prev_up_h, cy1, cy2, sub, w0, w1, nb_h, nb_f);
+        const uint64_t idx = (uint64_t)s_cur * S + (uint32_t)u;
+        if (K <= 4) reinterpret_cast<uint16_t*>(bits)[idx] = (uint16_t)w0;
+        else if (K <= 8) reinterpret_cast<uint32_t*>(bits)[idx] = w0;
+        else reinterpret_cast<uint64_t*>(bits)[idx] = ((uint64_t)w1 << 32) | w0;
+      } else {
+        origin_step<K>(ts, up_h, up_f, prev_up_h, cy1, cy2, sub, nb_h, nb_f);
+        if (t >= t_last) {  // watch row m (the last strip): the trailing run ends at the last column with H > E
+          if (s_cur + 1u == NS) {
+            int32_t hv = 0, ev = 0;
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+              if ((uint32_t)i == slot_m) { hv = ts.Hc[i]; ev = ts.Ec[i]; }
+            if ((hv >> SH) > (ev >> SH)) c_end = (uint32_t)c;
+          }
+        }
+      }
+      bot_h = nb_h;
+      bot_f = nb_f;
+    } else if (live && (uint32_t)u == S_cur) {
+      bot_h = neg;  // past the window: the strip below finds -inf above its last K columns
+      bot_f = neg;
+    }
+    prev_up_h = up_h;
+    ++c;
+    ++u;
+    if (u == P) { u = 0; s_cur += 16u; }
+  }
+
+  // ---- score, ends, walk ----
+  if (have && j == ((NS - 1u) & 15u)) {
+    int32_t hv = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+      if ((uint32_t)i == slot_m) hv = ts.Hc[i];
+    if (a.scores) a.scores[d.out] = hv >> SH;
+    if (KIND == 1) {
+      a.ends[2 * d.out] = (uint32_t)(hv & kOriginMask);
+      a.ends[2 * d.out + 1] = c_end;
+    }
+  }
+  if (KIND == 0) {
+    w.sync_global();
+    Band16Fetch<K> fetch{bits, S, S_last, NS, n, dmin};
+    walk16(w, fetch, have, m, n, have ? a.ops + a.ops_off[d.out] : nullptr, have ? a.ops_len + d.out : nullptr, a.err);
+  }
+}
+
+}  // namespace tracyhip
+#endif

@@ -1,0 +1,86 @@
+// band16.hip -- gfx950 kernels of the band sweeps (band16.h): four pairs per 64-lane workgroup, sixteen lanes per pair; the
+// hand-over between strips is a DPP row rotate (row_ror:1).  Plus the kernel that writes the substitution tables they read.
+#include <hip/hip_runtime.h>
+
+#include "band16.h"
+#include "band16_launch.h"
+
+namespace tracyhip {
+
+struct DeviceWave16 {
+  __device__ __forceinline__ uint32_t lane() const { return threadIdx.x; }
+  // lane j of a row of 16 <- lane j - 1 of the same row, lane 0 <- lane 15 (row_ror:1)
+  __device__ __forceinline__ int32_t rot16(int32_t x) const { return __builtin_amdgcn_update_dpp(0, x, 0x121, 0xf, 0xf, false); }
+  __device__ __forceinline__ uint64_t ballot(bool p) const { return __ballot(p); }
+  __device__ __forceinline__ uint32_t bcast(uint32_t x, uint32_t src_lane) const { return (uint32_t)__shfl((int)x, (int)src_lane, 64); }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+  __device__ __forceinline__ void sync_global() const {  // words written by lanes of this wave, read by others of it (dp_kernels.hip)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  __device__ __forceinline__ char* lds() const {
+    extern __shared__ __attribute__((aligned(16))) char tracy_smem16[];
+    return tracy_smem16;
+  }
+};
+
+template <int K, int KIND>
+__global__ __launch_bounds__(64) void band16_kernel(Band16Args a) {
+  DeviceWave16 w;
+  band16_body<DeviceWave16, K, KIND>(w, a, blockIdx.x);
+}
+
+// Substitution tables: int16 [6 codes][stride] per sequence.  Profile rows: the int of the fp32 chain of align.h:112-117 against the
+// one-hot column of base b (onehot_score) for b = A C G T N, 0 for '-' / any other letter (an all-zero column); string rows:
+// match / mismatch by byte equality (align.h:96-101), mismatch for a column no row letter can equal.  Rows past the sequence
+// hold 0.  Entries are stored << shift (the traceback kernels keep scores x 32).
+__global__ __launch_bounds__(256) void b16_table_kernel(const B16TableDesc* __restrict__ desc, const void* __restrict__ a1, int strings,
+                                                        int32_t match, int32_t mismatch, int32_t qlimit, int shift, int16_t* __restrict__ out,
+                                                        int32_t* __restrict__ err) {
+  const B16TableDesc d = desc[blockIdx.x];
+  bool overflow = false;
+  int32_t qabs = 0;
+  for (uint32_t r = threadIdx.x; r < d.stride; r += blockDim.x) {
+    const bool real = r < d.m;
+    int32_t q[kB16Codes] = {0, 0, 0, 0, 0, 0};
+    if (real) {
+      b16_table_row(a1, strings != 0, d.a1_off, d.a1_stride, r, match, mismatch, q);
+      if (!strings)
+        for (uint32_t b = 0; b < 5; ++b) qabs = imax(qabs, q[b] < 0 ? -q[b] : q[b]);
+    }
+#pragma unroll
+    for (uint32_t b = 0; b < kB16Codes; ++b) {
+      const int32_t v = (int32_t)((uint32_t)q[b] << shift);
+      overflow |= v > 32767 || v < -32768 || q[b] > 32767 || q[b] < -32768;
+      out[d.out_off + (uint64_t)b * d.stride + r] = (int16_t)v;
+    }
+  }
+  if (overflow) flag_error(err, 1);
+  if (!strings && qabs > qlimit) flag_max(err, 1, qabs);  // un-normalised profile: the host re-checks the value range
+}
+
+hipError_t launch_b16_tables(const B16TableDesc* d_desc, uint32_t nseq, const void* a1, bool strings, int32_t match, int32_t mismatch,
+                             int32_t qlimit, int shift, int16_t* out, int32_t* err, hipStream_t s) {
+  if (nseq == 0) return hipSuccess;
+  hipLaunchKernelGGL(b16_table_kernel, dim3(nseq), dim3(256), 0, s, d_desc, a1, strings ? 1 : 0, match, mismatch, qlimit, shift, out, err);
+  return hipGetLastError();
+}
+
+hipError_t launch_band16(int K, int kind, const Band16Args& a, hipStream_t s) {
+  if (a.npairs == 0) return hipSuccess;
+  const dim3 grid((a.npairs + 3u) / 4u);
+  const uint32_t lds = 4u * a.code_cap + b16_table_bytes(K);
+#define TRACY_B16(KK)                                                                                     \
+  case KK:                                                                                                \
+    if (kind == 0) hipLaunchKernelGGL((band16_kernel<KK, 0>), grid, dim3(64), lds, s, a);                 \
+    else hipLaunchKernelGGL((band16_kernel<KK, 1>), grid, dim3(64), lds, s, a);                           \
+    break;
+  switch (K) {
+    TRACY_B16(4) TRACY_B16(8) TRACY_B16(12)
+    default: return hipErrorInvalidValue;
+  }
+#undef TRACY_B16
+  return hipGetLastError();
+}
+
+}  // namespace tracyhip

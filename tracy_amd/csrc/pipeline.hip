@@ -382,7 +382,9 @@ struct OrientOut {
                                      // ((top - S*) / |ge|): how far from a perfect match the trace is
 };
 
-int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn& in, OrientOut& o, bool force_wide) {
+constexpr int kNoEnds = 2;  // orient_and_align_impl: the ends path met a pair outside the origin-tracking sweep's range
+
+int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn& in, OrientOut& o, bool force_wide, bool no_ends = false) {
   int rc;
   hipStream_t st = ctx->stream;
   const uint32_t nt = in.nt;
@@ -407,7 +409,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   // gap columns, so it starts no earlier than column c_e - m - g -- and an origin-tracking sweep over that sub-window (about a
   // tenth of a 10 kb window) delivers the two ends trimReferenceSlice reads: no wavefront checkpoints, no band traceback.
   // (The argument is the one of the allele alignments of `tracy decompose`)
-  bool ends_path = in.ends_only && use_band && !force_wide && !ctx->no_narrow && getenv("TRACYHIP_NO_PRELIM_ORIGIN") == nullptr;
+  bool ends_path = in.ends_only && !no_ends && use_band && !force_wide && !ctx->no_narrow && getenv("TRACYHIP_NO_PRELIM_ORIGIN") == nullptr;
   {
     uint32_t maxmt = 0;
     for (uint32_t t = 0; t < nt; ++t) maxmt = std::max(maxmt, mt[t]);
@@ -745,7 +747,15 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
         PairDesc& d = pb.desc[t];
         h_pre[t] = h_rc[t] ? h_sc2[nt + t] : h_sc2[t];
         const int64_t ce = h_ce[t];
-        if (ce <= 0) continue;  // no column leaves row m upwards: the whole window
+        if (ce <= 0) {
+          // H(m, c) == E(m, c) in every column: the reference's traceback (gotoh.h:143-167) runs along row m to column 0 and
+          // up column 0 -- n 'h', then m 'v' -- so both ends are 0 (a junk trace: the all-gap path is optimal).  Column 1 alone
+          // reproduces that: H(m, 1) == E(m, 1), opened from H(m, 0), whose origin is 0.
+          d.a2_off += h_rc[t] ? (uint64_t)(d.n - 1u) : 0ull;
+          d.n = 1;
+          d.a2_stride = 1;
+          continue;
+        }
         const int64_t loss = (int64_t)h_top[t] - (int64_t)h_pre[t];
         const int64_t g = loss > 0 ? loss / age : 0;
         o.gap[t] = (uint32_t)std::min<int64_t>(g, 0x7fffffff);
@@ -758,7 +768,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       }
       bool fits = true;  // (the pre-check used an upper bound of the sub-window; windows cut at c_e can only be shorter)
       for (uint32_t t = 0; t < nt && fits; ++t) fits = origin_ok(&p, pb.desc[t].m, pb.desc[t].n, pb.k[t]);
-      if (!fits) return set_error(TRACYHIP_ERR_RANGE, "preliminary alignment: sub-window outside the origin-tracking sweep's range");
+      if (!fits) return kNoEnds;  // (cannot happen while the pre-check's bound holds; the caller repeats the stage with the band traceback)
       HIP_TRY(hipMemcpyAsync(d_shift, shift.data(), sizeof(uint32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
       DpCkpt oc;
       oc.d_ends = d_ends;
@@ -787,6 +797,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
 // larger entry reports it; when the 16-bit range no longer holds (kWiden) the whole stage is repeated on the int32 kernels.
 int orient_and_align(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn& in, OrientOut& o) {
   int rc = orient_and_align_impl(ctx, p, in, o, false);
+  if (rc == kNoEnds) rc = orient_and_align_impl(ctx, p, in, o, false, true);
   if (rc == kWiden) rc = orient_and_align_impl(ctx, p, in, o, true);
   if (rc == kWiden) rc = set_error(TRACYHIP_ERR_RANGE, "profile values outside the range of the score kernels");
   return rc;
@@ -1656,7 +1667,13 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
           for (uint32_t t = 0; t < nt; ++t) {
             PairDesc& d = pb.desc[t];
             const int64_t ce = h_ce[t];
-            if (ce <= 0 || d.m == 0 || d.n == 0) continue;  // no column leaves row m upwards: the whole window
+            if (d.m == 0 || d.n == 0) continue;
+            if (ce <= 0) {  // H(m, c) == E(m, c) everywhere: n 'h' then m 'v', both ends 0 -- column 1 alone reproduces it (see orient_and_align_impl)
+              d.a2_off += h_rc[t] ? (uint64_t)(d.n - 1u) : 0ull;
+              d.n = 1;
+              d.a2_stride = 1;
+              continue;
+            }
             const int64_t loss = best * (int64_t)d.m - (int64_t)h_s[t];
             const int64_t g = loss > 0 ? loss / age : 0;
             int64_t a = ce - (int64_t)d.m - g - 2;

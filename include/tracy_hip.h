@@ -118,6 +118,18 @@ int tracyhip_gotoh_score(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const t
 int tracyhip_gotoh_align(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm,
                          int mem, int32_t* scores, uint8_t* ops, const uint64_t* ops_offset,
                          uint32_t* ops_len);
+/* gotoh (gotoh.h:71-174) on a diagonal band chosen by the caller: pair i is swept on the diagonals c - r in [band_lo[i], band_hi[i]]
+ * only (the last row on to column n: its free trailing run), cells outside read as -inf.  Scores, `btr` (and ends) are those of
+ * tracyhip_gotoh_align whenever the band holds every optimal path, which is the caller's to establish -- e.g. for strings with
+ * free horizontal end gaps: a path that leaves [-W - (m-n)+, W + (n-m)+] makes more than W vertical gap steps, so it scores at
+ * most match*m - (match + |ge|)(W+1) - |go|; a banded score above that is the optimum.  This is the form the
+ * pipelines below use internally for their final alignments.  CHAR x CHAR or PROFILE x CHAR pairs, AlignConfig<hfree,false>,
+ * go <= 0, ge < 0, bands of at most 183 diagonals (TRACYHIP_ERR_RANGE beyond).  A pair whose traceback walk leaves its band reports
+ * ops_len 0.  ends != NULL: the origin-tracking sweep instead of the traceback -- scores and ends[2i] = leading 'h' columns,
+ * ends[2i+1] = last column that is not a trailing 'h' (what trimReferenceSlice, fmindex.h:429-463, reads); ops* may be NULL then. */
+int tracyhip_gotoh_banded(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm, const int32_t* band_lo,
+                          const int32_t* band_hi, int mem, int32_t* scores, uint8_t* ops, const uint64_t* ops_offset, uint32_t* ops_len,
+                          uint32_t* ends);
 /* needleScore / needle, needle.h:12-57 / 59-138 (linear gap cost ge; profiles scored in double). */
 int tracyhip_needle_score(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm,
                           int mem, int32_t* scores);

@@ -447,7 +447,7 @@ int emu_band16(int K, int kind, int strings, uint32_t npairs, const void* a1, co
                const int32_t* dmax, int32_t match, int32_t mismatch, int32_t go, int32_t ge, int32_t hfree, int32_t* scores, uint32_t* ends,
                uint8_t* ops, uint64_t ops_cap, uint32_t* ops_len, int32_t* err_out) {
   if (npairs == 0 || npairs > 4) return -1;
-  const int shift = kind == 0 ? kTagShift : 0;
+  const int shift = kTagShift;  // one table for both kinds, as the library builds it
   std::vector<PairDesc> d(npairs);
   std::vector<int16_t> qp;
   std::vector<uint8_t> codes;

@@ -99,10 +99,12 @@ def test_band16_traceback_profile_rows():
             lo = max(0, lead - 20)
             sl = view[lo:min(len(view), ce + 20)]  # a slice around the aligned region, as trimReferenceSlice cuts it
             ws, wb = orc.gotoh_prof(p, orc.create_profile_str(sl), 1, 0, SC)
-            W = 30
+            W = 12
             raw = sl[::-1].translate(COMP) if rev[i] else sl  # what the kernel reads: the stored strand, viewed through the flag
             pairs.append((p, raw, -W - max(0, m - len(sl)), W + max(0, len(sl) - m), bool(rev[i])))
             wants.append((ws, wb))
+        if any(K + p_[3] - p_[2] > 15 * (K + 1) for p_ in pairs):  # the band kernels' domain: a strip is done before the lane's next one is due
+            continue
         got, err = emu.run_band16(pairs, SC, 1, K, 0, False)
         assert err == 0
         for (gs, gb, _), (ws, wb) in zip(got, wants):
@@ -155,3 +157,23 @@ def test_band16_band_without_the_path_scores_lower():
     ws, wb = orc.gotoh_str(a, b, 1, 0, SC)
     assert (got[1][0], got[1][1]) == (ws, wb)
     assert got[0][0] < ws and got[0][0] <= SC[0] * len(a) + SC[3] * 6
+
+
+def test_band16_trailing_run_longer_than_the_lanes_period():
+    """the last strip sweeps row m on to column n; with a long free trailing run its window outlasts the 16 (K + 1) steps after
+    which a lane would turn to its next strip (K = 4: 80 steps)"""
+    rng = random.Random(9)
+    for K in (4, 8):
+        for tail in (30, 90, 200):
+            for g in (0, 24, 30):
+                m = rng.randint(50, 230)
+                a = bytes(rng.choice(b"ACGT") for _ in range(m))
+                lead = rng.randint(0, 60)
+                b = bytes(rng.choice(b"ACGT") for _ in range(lead)) + a + bytes(rng.choice(b"ACGT") for _ in range(tail))
+                ws, wb = orc.gotoh_str(a, b, 1, 0, SC)
+                l2, ce = ends_of(wb, len(b))
+                d1 = ce - m
+                got, err = emu.run_band16([(a, b, d1 - g - 1, d1 + g + 1, False)], SC, 1, K, 0, True)
+                assert (got[0][0], got[0][1]) == (ws, wb), (K, tail, g, m)
+                got, err = emu.run_band16([(a, b, d1 - g - 1, d1 + g + 1, False)], SC, 1, K, 1, True)
+                assert (got[0][0], got[0][2]) == (ws, (l2, ce)), (K, tail, g, m, "origin")

@@ -216,6 +216,31 @@ class Context:
         return scores[:n], btr, rws
 
 
+def _align_banded(self, a1, a2, params, band_lo, band_hi, origin=False):
+    """tracyhip_gotoh_banded with host buffers: (scores, btr list) or, origin=True, (scores, [(lead, c_e)])"""
+    pr, keep, p1, p2 = self._pairs(a1, a2, None, None)
+    prm = Params(*params)
+    n = pr.npairs
+    l1, l2 = self._pair_lengths(pr, p1, p2, None, None)
+    cap = (l1 + l2).astype(np.uint64)
+    off = np.zeros(max(n, 1), dtype=np.uint64)
+    if n:
+        off[1:n] = np.cumsum(cap)[:-1]
+    ops = np.zeros(max(int(cap.sum()) if n else 0, 1), dtype=np.uint8)
+    olen = np.zeros(max(n, 1), dtype=np.uint32)
+    scores = np.zeros(max(n, 1), dtype=np.int32)
+    ends = np.zeros(2 * max(n, 1), dtype=np.uint32)
+    lo = np.ascontiguousarray(band_lo, dtype=np.int32)
+    hi = np.ascontiguousarray(band_hi, dtype=np.int32)
+    i32p = C.POINTER(C.c_int32)
+    _check(lib().tracyhip_gotoh_banded(self._h, C.byref(pr), C.byref(prm), lo.ctypes.data_as(i32p), hi.ctypes.data_as(i32p), MEM_HOST,
+                                       scores.ctypes.data_as(i32p), ops.ctypes.data_as(C.POINTER(C.c_uint8)), off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                       olen.ctypes.data_as(C.POINTER(C.c_uint32)), ends.ctypes.data_as(C.POINTER(C.c_uint32)) if origin else None))
+    if origin:
+        return scores[:n], [(int(ends[2 * i]), int(ends[2 * i + 1])) for i in range(n)]
+    return scores[:n], [ops[int(off[i]):int(off[i]) + int(olen[i])].tobytes() for i in range(n)]
+
+
 class PreparedAlign:
     """host-buffer job / result structs of tracyhip_align_traces (everything they point to is kept alive by this object)"""
 
@@ -581,5 +606,6 @@ def _decompose_traces(self, profiles, hbc, refs, params, trim_left=50, trim_righ
 
 
 Context.decompose_traces = _decompose_traces
+Context.align_banded = _align_banded
 Group.align_traces = _align_traces
 Group.decompose_traces = _decompose_traces

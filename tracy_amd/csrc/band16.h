@@ -34,7 +34,7 @@ struct Band16Args {
   const PairDesc* pairs;  // a1_off / a1_stride: first row and code-row stride of the pair's rows in `qp` (int16 units); a2_off: codes;
                           // bits_off: BYTE offset of the pair's words (KIND 0); ckpt_off: band_pack(dmin, dmax); flags: PAIR_A2_REVCOMP
   uint32_t npairs;
-  const int16_t* qp;      // substitution tables (b16_table_kernel): KIND 0 entries are scores << kTagShift, KIND 1 raw scores
+  const int16_t* qp;      // substitution tables (b16_table_kernel): entries are scores << kTagShift (the origin-tracking sweep shifts them on)
   const uint8_t* codes;   // reference codes 0..5 (ctx->codes())
   uint8_t* bits;          // KIND 0: trace words
   int32_t* scores;        // H(m, n) per pair (PairDesc::out), or null
@@ -248,7 +248,7 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   };
   if (have && j < NS) prefetch(j);
 
-  SubRows<K, KIND == 0 ? 0 : SH> sub;
+  SubRows<K, KIND == 0 ? 0 : SH - kTagShift> sub;  // table entries are scores << kTagShift for both kinds
   for (uint32_t t = 0; t < T_end; ++t) {
     if (u == 0) {  // ---- begin strip s_cur (one lane per pair, every K + 1 steps) ----
       live = have && s_cur < NS;
@@ -322,7 +322,7 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
     prev_up_h = up_h;
     ++c;
     ++u;
-    if (u == P) { u = 0; s_cur += 16u; }
+    if (u == P && !(live && (uint32_t)u < S_cur)) { u = 0; s_cur += 16u; }  // (the last strip may run past the period: row m's trailing run)
   }
 
   // ---- score, ends, walk ----

@@ -590,6 +590,137 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   return verdict;  // DP_CKPT / DP_PREFIX: kWiden goes to the pipeline, which restarts its orientation stage on the int32 kernels
 }
 
+// ---- band kernels (band16.h) ----------------------------------------------------------------------------------------
+int band16_pick_k(int32_t dmin, int32_t dmax) {
+  if (dmax < dmin) return 0;
+  for (int K : {4, 8, 12})
+    if (b16_window(K, dmin, dmax) <= b16_max_window(K)) return K;
+  return 0;
+}
+
+bool origin16_ok(const tracyhip_params* prm, uint32_t maxm, uint32_t maxn) {
+  if (!prm->hfree || prm->vfree || prm->go > 0 || prm->ge >= 0) return false;
+  if ((uint64_t)maxn + 64 >= (1u << kOriginBits)) return false;
+  const int64_t rows = maxm;
+  const int64_t low = iabs64(prm->go) + rows * iabs64(prm->ge) + 2 * (iabs64(prm->go) + iabs64(prm->ge)) + iabs64(prm->mismatch) + iabs64(prm->match);
+  const int64_t high = rows * sub_limit(prm);
+  return (low < -(int64_t)kNegInfOrigin - 16 * iabs64(prm->ge) - 64) && (-(int64_t)kNegInfOrigin + iabs64(prm->go) + 16 * iabs64(prm->ge) < 8000) && (high < 8000);
+}
+
+int build_b16_tables(tracyhip_ctx* ctx, DevBuf& buf, const void* d_a1, bool strings, std::vector<B16TableDesc>& desc, const tracyhip_params* prm) {
+  const uint32_t ns = (uint32_t)desc.size();
+  if (ns == 0) return TRACYHIP_OK;
+  uint64_t tot = 0;
+  for (auto& d : desc) {
+    d.stride = b16_table_stride(d.m);
+    d.out_off = tot;
+    tot += (uint64_t)kB16Codes * d.stride;
+  }
+  hipStream_t st = ctx->stream;
+  HIP_TRY(buf.ensure(tot * sizeof(int16_t) + 64));
+  HIP_TRY(ctx->d_b16desc.ensure(sizeof(B16TableDesc) * (size_t)ns));
+  HIP_TRY(ctx->h_desc.ensure(sizeof(B16TableDesc) * (size_t)ns));
+  std::memcpy(ctx->h_desc.p, desc.data(), sizeof(B16TableDesc) * (size_t)ns);
+  HIP_TRY(hipMemcpyAsync(ctx->d_b16desc.p, ctx->h_desc.p, sizeof(B16TableDesc) * (size_t)ns, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx->d_err.ensure(kErrBytes));
+  int trc;
+  if ((trc = timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, tot * 2))) return trc;
+  HIP_TRY(launch_b16_tables(static_cast<const B16TableDesc*>(ctx->d_b16desc.p), ns, d_a1, strings, prm->match, prm->mismatch, sub_limit(prm), kTagShift,
+                            static_cast<int16_t*>(buf.p), static_cast<int32_t*>(ctx->d_err.p), st));
+  if ((trc = timing_end(ctx))) return trc;
+  HIP_TRY(hipStreamSynchronize(st));  // (the pinned descriptor block is reused by the next upload)
+  return TRACYHIP_OK;
+}
+
+int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, int32_t* d_scores, uint32_t* d_ends, uint8_t* d_ops,
+               const uint64_t* d_ops_off, uint32_t* d_ops_len) {
+  const uint32_t np = (uint32_t)job.desc.size();
+  if (np == 0) return TRACYHIP_OK;
+  TRACYHIP_HOST_SCOPE(hs_all, "run_band16");
+  hipStream_t st = ctx->stream;
+  // order: strip height, then tallest first (the four pairs of a workgroup should be of a size)
+  std::vector<uint32_t> order(np);
+  for (uint32_t i = 0; i < np; ++i) order[i] = i;
+  auto before = [&](uint32_t x, uint32_t y) {
+    if (job.k[x] != job.k[y]) return job.k[x] > job.k[y];
+    const uint64_t cx = b16_words(job.desc[x].m, job.desc[x].n, job.k[x], band_dmin(job.desc[x]), band_dmax(job.desc[x]));
+    const uint64_t cy = b16_words(job.desc[y].m, job.desc[y].n, job.k[y], band_dmin(job.desc[y]), band_dmax(job.desc[y]));
+    return cx > cy;
+  };
+  if (!std::is_sorted(order.begin(), order.end(), before)) std::stable_sort(order.begin(), order.end(), before);
+  uint64_t limit = ctx->ws_limit;
+  if (limit == 0 && job.kind == 0) {
+    size_t fr = 0, tot = 0;
+    HIP_TRY(hipMemGetInfo(&fr, &tot));
+    limit = (uint64_t)(fr * 0.70 / ctx->mem_share) + ctx->d_bits.cap;
+  } else if (limit == 0) limit = ~0ull;
+  HIP_TRY(ctx->h_desc.ensure(sizeof(PairDesc) * (size_t)np));
+  PairDesc* hd = static_cast<PairDesc*>(ctx->h_desc.p);
+  struct Chunk { uint32_t lo, hi; uint64_t bytes; };
+  std::vector<Chunk> chunks;
+  Chunk c{0, 0, 0};
+  uint64_t max_mn = 0;
+  for (uint32_t j = 0; j < np; ++j) {
+    PairDesc d = job.desc[order[j]];
+    const int K = job.k[order[j]];
+    if (d.m == 0 || d.n == 0 || K == 0 || b16_window(K, band_dmin(d), band_dmax(d)) > b16_max_window(K))
+      return set_error(TRACYHIP_ERR_ARG, "run_band16: pair outside the band kernels' domain");
+    const uint64_t bytes = job.kind == 0 ? ((b16_words(d.m, d.n, K, band_dmin(d), band_dmax(d)) * b16_word_bytes(K) + 15u) & ~15ull) : 0;
+    if (bytes > limit) return set_error(TRACYHIP_ERR_OOM, "one pair needs %llu bytes of traceback words, workspace limit is %llu", (unsigned long long)bytes, (unsigned long long)limit);
+    if (c.hi > c.lo && c.bytes + bytes > limit) { chunks.push_back(c); c = Chunk{j, j, 0}; }
+    d.bits_off = c.bytes;
+    c.bytes += bytes;
+    c.hi = j + 1;
+    hd[j] = d;
+    max_mn = std::max<uint64_t>(max_mn, (uint64_t)d.m + d.n);
+  }
+  chunks.push_back(c);
+  uint64_t max_bytes = 0;
+  for (const Chunk& ch : chunks) max_bytes = std::max(max_bytes, ch.bytes);
+  HIP_TRY(ctx->d_desc.ensure(sizeof(PairDesc) * (size_t)np));
+  HIP_TRY(hipMemcpyAsync(ctx->d_desc.p, hd, sizeof(PairDesc) * (size_t)np, hipMemcpyHostToDevice, st));
+  if (job.kind == 0) HIP_TRY(ctx->d_bits.ensure(max_bytes + 64));
+  HIP_TRY(ctx->d_err.ensure(kErrBytes));
+  // (the error words are NOT cleared here: the table kernel of this stage may have reported into them; the caller cleared them)
+  Band16Args a{};
+  a.qp = job.d_qp; a.codes = job.d_codes; a.bits = static_cast<uint8_t*>(ctx->d_bits.p); a.scores = d_scores; a.ends = d_ends;
+  a.err = static_cast<int32_t*>(ctx->d_err.p); a.go = prm->go; a.ge = prm->ge; a.hfree = prm->hfree;
+  a.ops = d_ops; a.ops_off = d_ops_off; a.ops_len = d_ops_len;
+  const PairDesc* dd = static_cast<const PairDesc*>(ctx->d_desc.p);
+  for (const Chunk& ch : chunks) {
+    uint32_t j = ch.lo;
+    while (j < ch.hi) {
+      uint32_t e = j;
+      const int K = job.k[order[j]];
+      uint32_t nmax = 0;
+      uint64_t cells = 0, bytes = 0;
+      while (e < ch.hi && job.k[order[e]] == K) {
+        nmax = std::max(nmax, hd[e].n);
+        const uint64_t wds = b16_words(hd[e].m, hd[e].n, K, band_dmin(hd[e]), band_dmax(hd[e]));
+        cells += wds * (uint64_t)K;
+        bytes += (job.kind == 0 ? wds * b16_word_bytes(K) : 0) + 12ull * hd[e].m + hd[e].n + 4;
+        ++e;
+      }
+      a.pairs = dd + j;
+      a.npairs = e - j;
+      a.code_cap = (nmax + 7u) & ~3u;
+      if (4ull * a.code_cap + b16_table_bytes(K) > 64u * 1024u) return set_error(TRACYHIP_ERR_RANGE, "run_band16: reference of %u columns does not fit the staging area", nmax);
+      int trc;
+      if ((trc = timing_begin(ctx, job.kind == 0 ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_ORIGIN, cells, bytes))) return trc;
+      HIP_TRY(launch_band16(K, job.kind, a, st));
+      if ((trc = timing_end(ctx))) return trc;
+      j = e;
+    }
+  }
+  int32_t herr[kErrWords] = {};
+  HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  timing_collect(ctx);
+  if (herr[0] & 1) return set_error(TRACYHIP_ERR_RANGE, "a query-profile score does not fit the int16 table (profile values too large)");
+  if (herr[1] > sub_limit(prm)) return kWiden;  // un-normalised profile: the band kernels' fields are sized for normalised ones
+  return TRACYHIP_OK;  // (bit 1 -- a walk left its band -- is the caller's to resolve: such pairs report ops_len 0)
+}
+
 // validate a pair list and turn it into device-side descriptors + staged payloads
 int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool needle, DpProblem& pb, uint64_t* max_mn) {
   if (!pairs) return set_error(TRACYHIP_ERR_ARG, "null pairs");
@@ -955,6 +1086,102 @@ static int dp_entry(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyh
   if (mem == TRACYHIP_MEM_HOST) {
     if (scores) HIP_TRY(hipMemcpyAsync(scores, d_scores, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost, st));
     if (trace) {
+      if (ops_total) HIP_TRY(hipMemcpyAsync(ops, d_ops, ops_total, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(ops_len, d_len, sizeof(uint32_t) * (size_t)np, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  return TRACYHIP_OK;
+}
+
+// case-sensitive column codes of a string (MODE_CQ, dp_kernels.h cq_code)
+__global__ void encode_cq_codes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)tracyhip::cq_code(in[i]);
+}
+
+int tracyhip_gotoh_banded(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm, const int32_t* band_lo, const int32_t* band_hi,
+                          int mem, int32_t* scores, uint8_t* ops, const uint64_t* ops_offset, uint32_t* ops_len, uint32_t* ends) {
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  if (mem != TRACYHIP_MEM_HOST && mem != TRACYHIP_MEM_DEVICE) return set_error(TRACYHIP_ERR_ARG, "bad mem kind");
+  if (!pairs || !prm || !band_lo || !band_hi) return set_error(TRACYHIP_ERR_ARG, "null pairs / params / band");
+  const bool origin = ends != nullptr;
+  const uint32_t np = pairs->npairs;
+  if (np == 0) return TRACYHIP_OK;
+  if (!origin && (!ops || !ops_offset || !ops_len)) return set_error(TRACYHIP_ERR_ARG, "null ops/ops_offset/ops_len");
+  if (prm->vfree || prm->go > 0 || prm->ge >= 0) return set_error(TRACYHIP_ERR_ARG, "the band kernels take AlignConfig<.,false>, go <= 0, ge < 0");
+  if (origin && !prm->hfree) return set_error(TRACYHIP_ERR_ARG, "the origin-tracking sweep takes AlignConfig<true,false>");
+  if (pairs->a1.kind == TRACYHIP_SEQ_PROFILE && pairs->a2.kind == TRACYHIP_SEQ_PROFILE) return set_error(TRACYHIP_ERR_ARG, "the band kernels take string or profile rows against a string");
+  DpProblem pb;
+  DpProblemLease lease(ctx, pb);
+  uint64_t max_mn = 0;
+  if ((rc = build_problem(ctx, pairs, mem, false, pb, &max_mn))) return rc;  // MODE_QP: a2 encoded to codes 0..5
+  if ((rc = check_params(prm, max_mn))) return rc;
+  hipStream_t st = ctx->stream;
+  const bool strings = pb.mode == MODE_CHAR;
+  const uint8_t* d_codes = static_cast<const uint8_t*>(pb.d_a2);
+  if (strings) {
+    const uint64_t e2 = seqset_extent(pairs->a2);
+    HIP_TRY(ctx->ensure_codes(e2 ? e2 : 1, st));
+    if (e2) hipLaunchKernelGGL(encode_cq_codes_kernel, dim3((unsigned)((e2 + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(pb.d_a2), ctx->codes(), e2);
+    HIP_TRY(hipGetLastError());
+    d_codes = ctx->codes();
+  }
+  // one table per a1 sequence
+  const tracyhip_seqset& s1 = pairs->a1;
+  std::vector<B16TableDesc> td(s1.count);
+  for (uint32_t i = 0; i < s1.count; ++i) td[i] = B16TableDesc{s1.offset[i], 0, s1.length[i], s1.length[i], 0, 0};
+  HIP_TRY(ctx->d_err.ensure(kErrBytes));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
+  if ((rc = build_b16_tables(ctx, ctx->d_b16tab[0], pb.d_a1, strings, td, prm))) return rc;
+  Band16Job job;
+  job.kind = origin ? 1 : 0;
+  job.d_qp = static_cast<const int16_t*>(ctx->d_b16tab[0].p);
+  job.d_codes = d_codes;
+  job.desc.resize(np); job.k.resize(np);
+  uint64_t ops_total = 0;
+  for (uint32_t i = 0; i < np; ++i) {
+    PairDesc d = pb.desc[i];
+    if (d.m == 0 || d.n == 0) return set_error(TRACYHIP_ERR_ARG, "pair %u: empty sequence", i);
+    const uint32_t i1 = pairs->a1_index ? pairs->a1_index[i] : i;
+    const int K = band16_pick_k(band_lo[i], band_hi[i]);
+    if (K == 0) return set_error(TRACYHIP_ERR_RANGE, "pair %u: band of %lld diagonals is wider than the band kernels sweep (<= %u)", i,
+                                 (long long)band_hi[i] - band_lo[i] + 1, b16_max_window(12) - 12 + 1);
+    if (origin && !origin16_ok(prm, d.m, d.n)) return set_error(TRACYHIP_ERR_RANGE, "pair %u outside the origin-tracking sweep's packed fields", i);
+    d.a1_off = td[i1].out_off; d.a1_stride = td[i1].stride; d.ckpt_off = band_pack(band_lo[i], band_hi[i]);
+    job.desc[i] = d; job.k[i] = K;
+    if (!origin) ops_total = std::max<uint64_t>(ops_total, ops_offset[i] + d.m + d.n);
+  }
+  int32_t* d_scores = scores;
+  uint8_t* d_ops = ops;
+  uint32_t* d_len = ops_len;
+  uint32_t* d_ends = ends;
+  if (mem == TRACYHIP_MEM_HOST) {
+    if (scores) { HIP_TRY(ctx->d_scores.ensure(sizeof(int32_t) * (size_t)np)); d_scores = static_cast<int32_t*>(ctx->d_scores.p); }
+    if (origin) { HIP_TRY(ctx->d_ends.ensure(sizeof(uint32_t) * 2 * (size_t)np)); d_ends = static_cast<uint32_t*>(ctx->d_ends.p); }
+    else {
+      HIP_TRY(ctx->d_ops.ensure(ops_total ? ops_total : 1));
+      HIP_TRY(ctx->d_ops_len.ensure(sizeof(uint32_t) * (size_t)np));
+      d_ops = static_cast<uint8_t*>(ctx->d_ops.p);
+      d_len = static_cast<uint32_t*>(ctx->d_ops_len.p);
+    }
+  }
+  const uint64_t* d_off = nullptr;
+  if (!origin) {
+    HIP_TRY(ctx->h_off.ensure(sizeof(uint64_t) * (size_t)np));
+    std::memcpy(ctx->h_off.p, ops_offset, sizeof(uint64_t) * (size_t)np);
+    HIP_TRY(ctx->d_ops_off.ensure(sizeof(uint64_t) * (size_t)np));
+    HIP_TRY(hipMemcpyAsync(ctx->d_ops_off.p, ctx->h_off.p, sizeof(uint64_t) * (size_t)np, hipMemcpyHostToDevice, st));
+    d_off = static_cast<const uint64_t*>(ctx->d_ops_off.p);
+  }
+  rc = run_band16(ctx, job, prm, d_scores, d_ends, d_ops, d_off, d_len);
+  if (rc == kWiden) rc = set_error(TRACYHIP_ERR_RANGE, "profile values outside the range of the band kernels");
+  if (rc) return rc;
+  if (mem == TRACYHIP_MEM_HOST) {
+    if (scores) HIP_TRY(hipMemcpyAsync(scores, d_scores, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost, st));
+    if (origin) HIP_TRY(hipMemcpyAsync(ends, d_ends, sizeof(uint32_t) * 2 * (size_t)np, hipMemcpyDeviceToHost, st));
+    else {
       if (ops_total) HIP_TRY(hipMemcpyAsync(ops, d_ops, ops_total, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(ops_len, d_len, sizeof(uint32_t) * (size_t)np, hipMemcpyDeviceToHost, st));
     }

@@ -15,6 +15,7 @@
 
 #include "../../include/tracy_hip.h"
 #include "dp_kernels.h"
+#include "band16_launch.h"
 
 namespace tracyhip {
 
@@ -70,6 +71,7 @@ struct tracyhip_ctx {
   tracyhip::DevBuf d_tmp[8];
   tracyhip::DevBuf d_pipe[64];
   tracyhip::DevBuf d_ckpt, d_lastrow, d_band;  // pipeline intermediates (align_traces / decompose)
+  tracyhip::DevBuf d_b16tab[4], d_b16desc;     // substitution tables of the band kernels (band16.h), their descriptors
   hipError_t ensure_codes(size_t bytes, hipStream_t st) {
     hipError_t e = d_codes.ensure(bytes + 2 * tracyhip::kCodePad);
     if (e != hipSuccess) return e;
@@ -118,6 +120,8 @@ struct tracyhip_ctx {
     for (auto& b : d_pipe) b.release();
     d_ckpt.release(); d_lastrow.release(); d_band.release(); d_special.release(); d_ends.release();
     d_aftab.release(); aftab_ready = false;
+    for (auto& b : d_b16tab) b.release();
+    d_b16desc.release();
     h_desc.release();
     h_off.release();
     h_tmp.release();
@@ -190,5 +194,25 @@ constexpr int kWiden = 1;
 int range_verdict(const tracyhip_params* prm, const int32_t* herr, const std::vector<std::pair<uint32_t, int>>& narrow_launches,
                   uint64_t max_mn, int value_shift);
 int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool needle, DpProblem& pb, uint64_t* max_mn);
+
+// ---- band kernels (band16.h): Gotoh on a diagonal band, four pairs per wave ----
+// a batch for them: descriptors whose a1_off / a1_stride point into the substitution tables d_qp (build_b16_tables), a2_off into
+// d_codes (codes 0..5), ckpt_off = band_pack(dmin, dmax); k[i] = strip height of pair i (band16_pick_k)
+struct Band16Job {
+  int kind = 0;                 // 0: traceback words + walk (scores, ops); 1: origin-tracking sweep (scores, ends)
+  const int16_t* d_qp = nullptr;
+  const uint8_t* d_codes = nullptr;
+  std::vector<PairDesc> desc;
+  std::vector<int> k;
+};
+// smallest strip height whose lanes are done with a strip before the next one is due (K + width <= 15 (K + 1)); 0: the band is too wide
+int band16_pick_k(int32_t dmin, int32_t dmax);
+// value ranges of the origin-tracking sweep (packed 14-bit score field, 13-bit origin) for m rows / n columns
+bool origin16_ok(const tracyhip_params* prm, uint32_t maxm, uint32_t maxn);
+// substitution tables of `desc.size()` sequences (b16_table_kernel): entries are scores << kTagShift; desc[i].out_off / stride are
+// filled in here, the buffer is (re)sized.  strings: a1 holds bytes, else float profiles.
+int build_b16_tables(tracyhip_ctx* ctx, DevBuf& buf, const void* d_a1, bool strings, std::vector<B16TableDesc>& desc, const tracyhip_params* prm);
+int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, int32_t* d_scores, uint32_t* d_ends, uint8_t* d_ops,
+               const uint64_t* d_ops_off, uint32_t* d_ops_len);
 }  // namespace tracyhip
 #endif

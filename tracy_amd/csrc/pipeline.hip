@@ -1613,6 +1613,19 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       pb.desc[t] = d;
       pb.k[t] = choose_k(d.m, MODE_CHAR);
     }
+    // Band kernels (band16.h): the score S* of the certifying sweep below bounds the gap steps of every optimal alignment,
+    // g = (best m - S*) / |ge|, and with them the diagonals it can visit: the origin-tracking sweep and the traceback against the
+    // trimmed slice run on that band only (four pairs per wave, sixteen lanes per pair).  TRACYHIP_NO_BAND16=1: whole matrices.
+    const bool b16 = use_cq && p.ge < 0 && p.go <= 0 && getenv("TRACYHIP_NO_BAND16") == nullptr;
+    std::vector<B16TableDesc> td;
+    if (b16) {
+      td.resize(nt);
+      for (uint32_t t = 0; t < nt; ++t) td[t] = B16TableDesc{bc.bc_offset[t] + soff[t], 0, 0, sl[t], 0, 0};
+      HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
+      if ((rc = build_b16_tables(ctx, ctx->d_b16tab[k], seq, true, td, &p))) return rc;
+    }
+    std::vector<int32_t> h_s1(nt, 0);       // S* of gotoh(seq, window) where the certifying sweep ran
+    std::vector<int64_t> gap_of(nt, -1);    // its gap-step budget; -1: not known
     // gotoh(seq, rs.refslice) is only read by trimReferenceSlice: when the pairs fit its packed fields the origin-tracking
     // sweep delivers the two ends of that alignment without traceback words, walker or ops (TRACYHIP_NO_ORIGIN=1: off)
     bool use_origin = getenv("TRACYHIP_NO_ORIGIN") == nullptr;
@@ -1682,13 +1695,34 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
             d.a2_off += h_rc[t] ? (uint64_t)(d.n - (uint32_t)ce) : (uint64_t)a;  // reverse view: column c is byte n - c
             d.n = (uint32_t)(ce - a);
             d.a2_stride = d.n;
+            h_s1[t] = h_s[t];
+            gap_of[t] = g;
           }
           HIP_TRY(hipMemcpyAsync(d_shift, shift.data(), sizeof(uint32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
         }
       }
       DpCkpt oc;
       oc.d_ends = static_cast<uint32_t*>(b_ends.p);
-      if ((rc = run_dp(ctx, pb, &p, false, false, nullptr, nullptr, nullptr, nullptr, DP_ORIGIN, &oc))) return rc;
+      // the alignment ends in the last column of its sub-window with at most g gap steps behind it: diagonals n' - m - g .. n' - m + g
+      Band16Job jo;
+      DpProblem rest;
+      if (b16) {
+        jo.kind = 1; jo.d_qp = static_cast<const int16_t*>(ctx->d_b16tab[k].p); jo.d_codes = d_cq_ref;
+        rest.mode = pb.mode; rest.d_a1 = pb.d_a1; rest.d_a2 = pb.d_a2; rest.cq_codes = pb.cq_codes;
+        for (uint32_t t = 0; t < nt; ++t) {
+          PairDesc d = pb.desc[t];
+          const int64_t g = gap_of[t];
+          const int32_t d1 = (int32_t)d.n - (int32_t)d.m;
+          const int32_t dlo = d1 - (int32_t)std::min<int64_t>(g, 1 << 20) - 1, dhi = d1 + (int32_t)std::min<int64_t>(g, 1 << 20) + 1;
+          const int K = g >= 0 ? band16_pick_k(dlo, dhi) : 0;
+          if (K && origin16_ok(&p, d.m, d.n)) {
+            d.a1_off = td[t].out_off; d.a1_stride = td[t].stride; d.ckpt_off = band_pack(dlo, dhi);
+            jo.desc.push_back(d); jo.k.push_back(K);
+          } else { rest.desc.push_back(d); rest.k.push_back(pb.k[t]); }
+        }
+        if ((rc = run_band16(ctx, jo, &p, nullptr, oc.d_ends, nullptr, nullptr, nullptr))) return rc;
+      }
+      if ((rc = run_dp(ctx, b16 ? rest : pb, &p, false, false, nullptr, nullptr, nullptr, nullptr, DP_ORIGIN, &oc))) return rc;
       if (subwin) {
         hipLaunchKernelGGL(ends_shift_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, static_cast<uint32_t*>(b_ends.p),
                            static_cast<const uint32_t*>(d_shift), nt);
@@ -1705,7 +1739,12 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     }
     HIP_TRY(hipGetLastError());
     h_trimA[k].resize(nt);
+    std::vector<uint32_t> h_ends;
     HIP_TRY(hipMemcpyAsync(h_trimA[k].data(), b_trimA.p, sizeof(TrimOut) * (size_t)nt, hipMemcpyDeviceToHost, st));
+    if (b16 && use_origin) {
+      h_ends.resize(2 * (size_t)nt);
+      HIP_TRY(hipMemcpyAsync(h_ends.data(), b_ends.p, sizeof(uint32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc& d = pb.desc[t];
@@ -1715,7 +1754,51 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     const uint64_t* d_offK;
     std::vector<uint64_t> offK(out->ops_offset[k], out->ops_offset[k] + nt);
     if ((rc = upload(ctx, buf(), offK, &d_offK))) return rc;
-    if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(d_scoreK[k]), static_cast<uint8_t*>(d_opsK[k]), d_offK,
+    // gotoh(seq, trimmed slice) (indigo.h:365): the slice holds the alignment just located, so its score is S* again, it ends in
+    // column c_e - slice_begin of row m and every optimal path stays within g gap steps of that diagonal.  Banded pairs are
+    // checked against S* afterwards (a walk that left its band reports no ops); what fails goes to the whole matrix with the rest.
+    Band16Job jt;
+    DpProblem rest;
+    rest.mode = pb.mode; rest.d_a1 = pb.d_a1; rest.d_a2 = pb.d_a2; rest.cq_codes = pb.cq_codes;
+    std::vector<uint32_t> banded_t;
+    if (!h_ends.empty()) {
+      jt.kind = 0; jt.d_qp = static_cast<const int16_t*>(ctx->d_b16tab[k].p); jt.d_codes = d_cq_ref;
+      for (uint32_t t = 0; t < nt; ++t) {
+        PairDesc d = pb.desc[t];
+        const int64_t g = gap_of[t];
+        const int64_t ce = (int64_t)h_ends[2 * t + 1] - (int64_t)h_trimA[k][t].ri;  // last column of the alignment, in the slice
+        int K = 0;
+        int32_t dlo = 0, dhi = 0;
+        if (g >= 0 && d.m && d.n && ce >= 1 && ce <= (int64_t)d.n) {
+          const int32_t d1 = (int32_t)ce - (int32_t)d.m;
+          dlo = d1 - (int32_t)std::min<int64_t>(g, 1 << 20) - 1;
+          dhi = d1 + (int32_t)std::min<int64_t>(g, 1 << 20) + 1;
+          K = band16_pick_k(dlo, dhi);
+        }
+        if (K) {
+          d.a1_off = td[t].out_off; d.a1_stride = td[t].stride; d.ckpt_off = band_pack(dlo, dhi);
+          jt.desc.push_back(d); jt.k.push_back(K); banded_t.push_back(t);
+        } else { rest.desc.push_back(d); rest.k.push_back(pb.k[t]); }
+      }
+      if ((rc = run_band16(ctx, jt, &p, static_cast<int32_t*>(d_scoreK[k]), nullptr, static_cast<uint8_t*>(d_opsK[k]), d_offK, static_cast<uint32_t*>(d_lenK[k])))) return rc;
+      if (!banded_t.empty()) {
+        std::vector<int32_t> h_sc(nt);
+        std::vector<uint32_t> h_ol(nt);
+        HIP_TRY(hipMemcpyAsync(h_sc.data(), d_scoreK[k], sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_ol.data(), d_lenK[k], sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        uint32_t nfail = 0;
+        for (uint32_t t : banded_t)
+          if (h_sc[t] != h_s1[t] || h_ol[t] == 0) {
+            if (getenv("TRACYHIP_HOST_TIMERS") && nfail < 6)
+              fprintf(stderr, "  fail t=%u m=%u n=%u S1=%d got=%d len=%u g=%lld ends=(%u,%u) ri=%u rc=%d\n", t, pb.desc[t].m, pb.desc[t].n, h_s1[t], h_sc[t], h_ol[t],
+                      (long long)gap_of[t], h_ends[2 * t], h_ends[2 * t + 1], h_trimA[k][t].ri, (int)h_rc[t]);
+            rest.desc.push_back(pb.desc[t]); rest.k.push_back(pb.k[t]); ++nfail;
+          }
+        if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "decompose allele %d: %zu of %u slices banded, %u repeated\n", k, banded_t.size(), nt, nfail);
+      }
+    }
+    if ((rc = run_dp(ctx, h_ends.empty() ? pb : rest, &p, false, true, static_cast<int32_t*>(d_scoreK[k]), static_cast<uint8_t*>(d_opsK[k]), d_offK,
                      static_cast<uint32_t*>(d_lenK[k]))))
       return rc;
   }

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # tests that hold tensors on the GPU (parity slice): torch brings its own copy of the HIP runtime, and the copy that is loaded
+    import torch  # noqa: F401  -- first in a process is the one that sees the devices; load it before libtracy_hip.so pulls in /opt/rocm's
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -32,7 +32,8 @@ namespace tracyhip {
 
 struct Band16Args {
   const PairDesc* pairs;  // a1_off / a1_stride: first row and code-row stride of the pair's rows in `qp` (int16 units); a2_off: codes;
-                          // bits_off: BYTE offset of the pair's words (KIND 0); ckpt_off: band_pack(dmin, dmax); flags: PAIR_A2_REVCOMP
+                          // bits_off: BYTE offset of the pair's words (KIND 0); ckpt_off: band_pack(dmin, dmax); flags: PAIR_A2_REVCOMP;
+                          // lastrow_off (KIND 0): 'h' columns to put before (low half) / behind (high half) the pair's string
   uint32_t npairs;
   const int16_t* qp;      // substitution tables (b16_table_kernel): entries are scores << kTagShift (the origin-tracking sweep shifts them on)
   const uint8_t* codes;   // reference codes 0..5 (ctx->codes())
@@ -118,12 +119,17 @@ struct Band16Fetch {
 // candidates per round; the four groups of the wave run side by side).  A cell outside the stored band ends the walk with
 // an error flag: the caller's certificate has failed for that pair and the pair is repeated on the whole matrix.
 template <class W, class Fetch>
-TR_HD void walk16(W& w, const Fetch& fetch, bool have, uint32_t m, uint32_t n, uint8_t* out, uint32_t* ops_len, int32_t* err) {
+TR_HD void walk16(W& w, const Fetch& fetch, bool have, uint32_t m, uint32_t n, uint8_t* out, uint32_t* ops_len, int32_t* err,
+                   uint32_t pre_h = 0, uint32_t post_h = 0) {
+  // pre_h / post_h: the pair is a sub-window of a wider reference whose columns right / left of it are free end-gap columns of the
+  // alignment ('h' before the first / after the last op of the sub-window's string: PairDesc::lastrow_off)
   const uint32_t lane = w.lane() & 15u, gsh = (w.lane() >> 4) * 16u;
-  uint32_t row = m, col = n, k = 0;
+  uint32_t row = m, col = n, k = pre_h;
   int state = 0;
-  const uint32_t limit = m + n;
+  const uint32_t limit = m + n + pre_h;
   bool lost = false;
+  if (have)
+    for (uint32_t i = lane; i < pre_h; i += 16) out[i] = 'h';
   for (;;) {
     const bool running = have && !lost && row > 0 && col > 0 && k <= limit;
     if (w.ballot(running) == 0) break;
@@ -163,6 +169,7 @@ TR_HD void walk16(W& w, const Fetch& fetch, bool have, uint32_t m, uint32_t n, u
       else { for (uint32_t i = lane; i < row; i += 16) out[k + i] = 'v'; k += row; row = 0; }
     }
     if (row > 0 || col > 0) ok = false;
+    if (ok) { for (uint32_t i = lane; i < post_h; i += 16) out[k + i] = 'h'; k += post_h; }
   }
   if (have && lane == 0) {
     if (!ok) flag_error(err, 2);
@@ -340,7 +347,8 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   if (KIND == 0) {
     w.sync_global();
     Band16Fetch<K> fetch{bits, S, S_last, NS, n, dmin};
-    walk16(w, fetch, have, m, n, have ? a.ops + a.ops_off[d.out] : nullptr, have ? a.ops_len + d.out : nullptr, a.err);
+    walk16(w, fetch, have, m, n, have ? a.ops + a.ops_off[d.out] : nullptr, have ? a.ops_len + d.out : nullptr, a.err,
+           (uint32_t)d.lastrow_off, (uint32_t)(d.lastrow_off >> 32));
   }
 }
 

@@ -619,17 +619,19 @@ int build_b16_tables(tracyhip_ctx* ctx, DevBuf& buf, const void* d_a1, bool stri
   hipStream_t st = ctx->stream;
   HIP_TRY(buf.ensure(tot * sizeof(int16_t) + 64));
   HIP_TRY(ctx->d_b16desc.ensure(sizeof(B16TableDesc) * (size_t)ns));
-  HIP_TRY(ctx->h_desc.ensure(sizeof(B16TableDesc) * (size_t)ns));
-  std::memcpy(ctx->h_desc.p, desc.data(), sizeof(B16TableDesc) * (size_t)ns);
-  HIP_TRY(hipMemcpyAsync(ctx->d_b16desc.p, ctx->h_desc.p, sizeof(B16TableDesc) * (size_t)ns, hipMemcpyHostToDevice, st));
+  // (staging blocks of their own, four in rotation: no host wait for an upload, and the pipelines synchronise several times between
+  // one build and the fourth after it)
+  PinBuf& stage = ctx->h_b16desc[ctx->b16_round++ & 3u];
+  HIP_TRY(stage.ensure(sizeof(B16TableDesc) * (size_t)ns));
+  std::memcpy(stage.p, desc.data(), sizeof(B16TableDesc) * (size_t)ns);
+  HIP_TRY(hipMemcpyAsync(ctx->d_b16desc.p, stage.p, sizeof(B16TableDesc) * (size_t)ns, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx->d_err.ensure(kErrBytes));
   int trc;
   if ((trc = timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, tot * 2))) return trc;
   HIP_TRY(launch_b16_tables(static_cast<const B16TableDesc*>(ctx->d_b16desc.p), ns, d_a1, strings, prm->match, prm->mismatch, sub_limit(prm), kTagShift,
                             static_cast<int16_t*>(buf.p), static_cast<int32_t*>(ctx->d_err.p), st));
   if ((trc = timing_end(ctx))) return trc;
-  HIP_TRY(hipStreamSynchronize(st));  // (the pinned descriptor block is reused by the next upload)
-  return TRACYHIP_OK;
+  return TRACYHIP_OK;  // (no host wait: the staging block is the tables' own)
 }
 
 int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, int32_t* d_scores, uint32_t* d_ends, uint8_t* d_ops,
@@ -641,13 +643,21 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
   // order: strip height, then tallest first (the four pairs of a workgroup should be of a size)
   std::vector<uint32_t> order(np);
   for (uint32_t i = 0; i < np; ++i) order[i] = i;
-  auto before = [&](uint32_t x, uint32_t y) {
-    if (job.k[x] != job.k[y]) return job.k[x] > job.k[y];
-    const uint64_t cx = b16_words(job.desc[x].m, job.desc[x].n, job.k[x], band_dmin(job.desc[x]), band_dmax(job.desc[x]));
-    const uint64_t cy = b16_words(job.desc[y].m, job.desc[y].n, job.k[y], band_dmin(job.desc[y]), band_dmax(job.desc[y]));
-    return cx > cy;
-  };
-  if (!std::is_sorted(order.begin(), order.end(), before)) std::stable_sort(order.begin(), order.end(), before);
+  {
+    // (the order only evens out the four pairs of a workgroup and the tail of a launch: batches of one strip height whose sizes lie
+    // within 25 % of each other keep the caller's order)
+    std::vector<uint64_t> key(np);
+    uint64_t lo = ~0ull, hi = 0;
+    bool onek = true;
+    for (uint32_t i = 0; i < np; ++i) {
+      const PairDesc& d = job.desc[i];
+      const uint64_t w = (d.m && d.n && job.k[i]) ? b16_words(d.m, d.n, job.k[i], band_dmin(d), band_dmax(d)) : 0;
+      key[i] = ((uint64_t)job.k[i] << 48) | std::min<uint64_t>(w, (1ull << 48) - 1);
+      lo = std::min(lo, w); hi = std::max(hi, w);
+      onek = onek && job.k[i] == job.k[0];
+    }
+    if (!(onek && hi <= lo + lo / 4)) std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key[x] > key[y]; });
+  }
   uint64_t limit = ctx->ws_limit;
   if (limit == 0 && job.kind == 0) {
     size_t fr = 0, tot = 0;

@@ -86,7 +86,8 @@ struct tracyhip_ctx {
   uint8_t* codes() const { return static_cast<uint8_t*>(d_codes.p) + tracyhip::kCodePad; }
   tracyhip::DevBuf d_aftab;                    // allelicFraction grid enumeration (trace independent)
   bool aftab_ready = false;
-  tracyhip::PinBuf h_desc, h_off, h_tmp, h_res;
+  tracyhip::PinBuf h_desc, h_off, h_tmp, h_res, h_b16desc[4];
+  uint32_t b16_round = 0;
   // kernel timing
   struct Pending { int which; hipEvent_t e0, e1; uint64_t cells, bytes; };
   // lanes: further contexts (own stream, own buffers) the batch pipelines split a call over, one host thread each
@@ -126,6 +127,7 @@ struct tracyhip_ctx {
     h_off.release();
     h_tmp.release();
     h_res.release();
+    for (auto& b : h_b16desc) b.release();
   }
 };
 

@@ -372,6 +372,12 @@ struct OrientIn {
   int32_t* d_score;         // device [nt] or null
   bool ends_only;           // the caller reads nothing of the preliminary alignment but trimReferenceSlice's two ends (`tracy align`):
                             // where it can be certified, the band traceback gives way to an origin-tracking sweep (OrientOut::d_ends)
+  // substitution tables of the FULL profiles (build_b16_tables), or null: with them the preliminary alignment runs on the band kernels
+  // (band16.h) -- the diagonals its score allows around the end of the alignment on row m -- as an origin-tracking sweep (ends_only)
+  // or as a traceback whose string is completed with the free end-gap columns outside the sub-window
+  const int16_t* d_qp = nullptr;
+  const B16TableDesc* td = nullptr;  // host [nt]
+  const uint32_t* row0 = nullptr;    // host [nt]: first row of the trimmed view in its table
 };
 struct OrientOut {
   std::vector<int32_t> sc2;     // [2 nt] forward / reverse scores (the loser's may be a certified upper bound)
@@ -409,11 +415,16 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   // gap columns, so it starts no earlier than column c_e - m - g -- and an origin-tracking sweep over that sub-window (about a
   // tenth of a 10 kb window) delivers the two ends trimReferenceSlice reads: no wavefront checkpoints, no band traceback.
   // (The argument is the one of the allele alignments of `tracy decompose`)
-  bool ends_path = in.ends_only && !no_ends && use_band && !force_wide && !ctx->no_narrow && getenv("TRACYHIP_NO_PRELIM_ORIGIN") == nullptr;
+  const bool b16 = in.d_qp != nullptr && in.td != nullptr && in.row0 != nullptr && p.ge < 0 && p.go <= 0 && getenv("TRACYHIP_NO_BAND16") == nullptr;
+  const bool cert_base = !no_ends && use_band && !force_wide && !ctx->no_narrow && getenv("TRACYHIP_NO_PRELIM_ORIGIN") == nullptr;
+  bool ends_path = in.ends_only && cert_base;
+  bool tb16_path = !in.ends_only && b16 && cert_base;  // traceback on the band kernels (the string is an output: `tracy decompose`)
   {
     uint32_t maxmt = 0;
     for (uint32_t t = 0; t < nt; ++t) maxmt = std::max(maxmt, mt[t]);
     ends_path = ends_path && nt && narrow_ok(&p, maxmt, 16);
+    tb16_path = tb16_path && nt && narrow_ok(&p, maxmt, 16);
+    for (uint32_t t = 0; t < nt && tb16_path; ++t) tb16_path = mt[t] && rn[t];
     for (uint32_t t = 0; t < nt && ends_path; ++t)
     {
       // the sub-window is at most m + g + 2 columns with g <= (Q m - S*) / |ge| and S* >= go + m ge (the all-gap path)
@@ -421,7 +432,8 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       ends_path = mt[t] && rn[t] && origin_ok(&p, mt[t], (uint32_t)std::min<uint64_t>(rn[t], cap), choose_k(mt[t], MODE_QP));
     }
   }
-  if (ends_path) ck.B = 0x7fffffffu;  // row m only
+  if (ends_path) ck.B = 0x7fffffffu;  // row m only (tb16_path keeps the wavefront checkpoints: pairs whose band is too wide for the band kernels
+                                       // -- a heterozygous trace scores far below its row maxima -- take the band traceback from them)
   // in.oriented: the references are already oriented by the caller (k-mer seeding): one score pass, no decision
   const bool given = in.oriented != nullptr;
   const int norient = given ? 1 : 2;
@@ -459,6 +471,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
     }
   }
   ends_path = ends_path && use_band && ck.narrow;
+  tb16_path = tb16_path && use_band && ck.narrow;
   auto stage1_desc = [&](uint32_t t, int orient) {  // orient 0 = forward, 1 = reverse complement
     PairDesc d{};
     d.a1_off = in.a1_off[t];
@@ -708,8 +721,9 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       pb.desc[t] = d;
       pb.k[t] = choose_k(d.m, MODE_QP);
     }
-    if (ends_path) {
-      // c_e from the winner's row m, the sub-window from S* and c_e, the two ends from the origin-tracking sweep over it
+    if (ends_path || tb16_path) {
+      // c_e from the winner's row m, the sub-window from S* and c_e; over it the origin-tracking sweep delivers the two ends (ends_path)
+      // or the band kernels the traceback (tb16_path)
       HIP_TRY(ctx->d_ends.ensure((sizeof(uint32_t) * 5 + sizeof(RowEndDesc) + sizeof(RowMaxDesc)) * (size_t)nt));
       uint32_t* d_ends = static_cast<uint32_t*>(ctx->d_ends.p);
       uint32_t* d_ce = d_ends + 2 * (size_t)nt;
@@ -740,10 +754,21 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       // column) on its diagonal steps, nothing positive on its vertical ones (go <= 0, ge < 0), and loses at least |ge| per
       // horizontal gap column: S* <= top - |ge| g.  (top is computed from the profile as it is -- normalised or not -- and is
       // what best * m overestimates: a profile column that is not one-hot cannot score `match`.)
+      // Going back from (m, c_e), a path with at most g gap steps stays on the diagonals c_e - m - g .. c_e - m + g: the band the
+      // band kernels sweep (band16.h), where the band fits them; other pairs take the origin-tracking sweep over the whole
+      // sub-window (ends_path) or the whole matrix (tb16_path).
       const int64_t age = -(int64_t)p.ge;
       std::vector<int32_t> h_pre(nt);
       o.gap.assign(nt, 0);
+      Band16Job j16;
+      j16.kind = ends_path ? 1 : 0;
+      j16.d_qp = in.d_qp;
+      j16.d_codes = ctx->codes();
+      DpProblem rest;
+      rest.mode = pb.mode; rest.a1_profile = pb.a1_profile; rest.d_a1 = pb.d_a1; rest.d_a2 = pb.d_a2;
+      std::vector<uint32_t> banded_t;
       for (uint32_t t = 0; t < nt; ++t) {
+        const PairDesc whole = pb.desc[t];
         PairDesc& d = pb.desc[t];
         h_pre[t] = h_rc[t] ? h_sc2[nt + t] : h_sc2[t];
         const int64_t ce = h_ce[t];
@@ -751,9 +776,12 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
           // H(m, c) == E(m, c) in every column: the reference's traceback (gotoh.h:143-167) runs along row m to column 0 and
           // up column 0 -- n 'h', then m 'v' -- so both ends are 0 (a junk trace: the all-gap path is optimal).  Column 1 alone
           // reproduces that: H(m, 1) == E(m, 1), opened from H(m, 0), whose origin is 0.
-          d.a2_off += h_rc[t] ? (uint64_t)(d.n - 1u) : 0ull;
-          d.n = 1;
-          d.a2_stride = 1;
+          if (ends_path) {
+            d.a2_off += h_rc[t] ? (uint64_t)(d.n - 1u) : 0ull;
+            d.n = 1;
+            d.a2_stride = 1;
+          }
+          rest.desc.push_back(d); rest.k.push_back(pb.k[t]);
           continue;
         }
         const int64_t loss = (int64_t)h_top[t] - (int64_t)h_pre[t];
@@ -765,18 +793,65 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
         d.a2_off += h_rc[t] ? (uint64_t)(d.n - (uint32_t)ce) : (uint64_t)a;  // reverse view: column c is byte n - c
         d.n = (uint32_t)(ce - a);
         d.a2_stride = d.n;
+        int K = 0;
+        int32_t dlo = 0, dhi = 0;
+        if (b16 && g < (1 << 20)) {
+          const int32_t d1 = (int32_t)d.n - (int32_t)d.m;
+          dlo = d1 - (int32_t)g - 1;
+          dhi = d1 + (int32_t)g + 1;
+          K = band16_pick_k(dlo, dhi);
+          if (K && ends_path && !origin16_ok(&p, d.m, d.n)) K = 0;
+          if (K && 4ull * ((d.n + 7u) & ~3u) + b16_table_bytes(K) > 60u * 1024u) K = 0;  // (the codes of four pairs are staged in LDS)
+        }
+        if (K) {
+          PairDesc q = d;
+          q.a1_off = in.td[t].out_off + in.row0[t];
+          q.a1_stride = in.td[t].stride;
+          q.ckpt_off = band_pack(dlo, dhi);
+          q.lastrow_off = ends_path ? 0ull : ((uint64_t)(whole.n - (uint32_t)ce) | ((uint64_t)(uint32_t)a << 32));  // 'h' right / left of the sub-window
+          j16.desc.push_back(q); j16.k.push_back(K); banded_t.push_back(t);
+        } else if (ends_path) { rest.desc.push_back(d); rest.k.push_back(pb.k[t]); }
+        else { rest.desc.push_back(whole); rest.k.push_back(pb.k[t]); }  // the whole window: band traceback from the checkpoints
       }
-      bool fits = true;  // (the pre-check used an upper bound of the sub-window; windows cut at c_e can only be shorter)
-      for (uint32_t t = 0; t < nt && fits; ++t) fits = origin_ok(&p, pb.desc[t].m, pb.desc[t].n, pb.k[t]);
-      if (!fits) return kNoEnds;  // (cannot happen while the pre-check's bound holds; the caller repeats the stage with the band traceback)
-      HIP_TRY(hipMemcpyAsync(d_shift, shift.data(), sizeof(uint32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
-      DpCkpt oc;
-      oc.d_ends = d_ends;
-      if ((rc = run_dp(ctx, pb, &p, false, false, nullptr, nullptr, nullptr, nullptr, DP_ORIGIN, &oc))) return rc;  // (kWiden: the caller restarts wide)
-      hipLaunchKernelGGL(ends_shift_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, d_ends, static_cast<const uint32_t*>(d_shift), nt);
-      HIP_TRY(hipGetLastError());
+      if (ends_path) {
+        bool fits = true;  // (the pre-check used an upper bound of the sub-window; windows cut at c_e can only be shorter)
+        for (size_t q = 0; q < rest.desc.size() && fits; ++q) fits = origin_ok(&p, rest.desc[q].m, rest.desc[q].n, rest.k[q]);
+        if (!fits) return kNoEnds;  // (cannot happen while the pre-check's bound holds; the caller repeats the stage with the band traceback)
+        HIP_TRY(hipMemcpyAsync(d_shift, shift.data(), sizeof(uint32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+        DpCkpt oc;
+        oc.d_ends = d_ends;
+        if (!j16.desc.empty()) {
+          HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
+          if ((rc = run_band16(ctx, j16, &p, nullptr, d_ends, nullptr, nullptr, nullptr))) return rc;
+        }
+        if ((rc = run_dp(ctx, rest, &p, false, false, nullptr, nullptr, nullptr, nullptr, DP_ORIGIN, &oc))) return rc;  // (kWiden: the caller restarts wide)
+        hipLaunchKernelGGL(ends_shift_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, d_ends, static_cast<const uint32_t*>(d_shift), nt);
+        HIP_TRY(hipGetLastError());
+        o.d_ends = d_ends;
+      } else {
+        // traceback on the band; a pair whose banded score is not S* (or whose walk left the band: no ops) is repeated with the rest
+        if (!j16.desc.empty()) {
+          HIP_TRY(ctx->d_tmp[7].ensure(sizeof(int32_t) * (size_t)nt));
+          int32_t* d_sb = static_cast<int32_t*>(ctx->d_tmp[7].p);
+          HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
+          if ((rc = run_band16(ctx, j16, &p, d_sb, nullptr, in.d_ops, in.d_ops_off, in.d_ops_len))) return rc;
+          std::vector<int32_t> h_sb(nt);
+          std::vector<uint32_t> h_ol(nt);
+          HIP_TRY(hipMemcpyAsync(h_sb.data(), d_sb, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipMemcpyAsync(h_ol.data(), in.d_ops_len, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipStreamSynchronize(st));
+          uint32_t nfail = 0;
+          for (uint32_t t : banded_t)
+            if (h_sb[t] != h_pre[t] || h_ol[t] == 0) {
+              PairDesc w = stage1_desc(t, h_rc[t] ? 1 : 0);
+              w.out = t;
+              rest.desc.push_back(w); rest.k.push_back(pb.k[t]); ++nfail;
+            }
+          if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "preliminary alignment: %zu of %u on the band, %u repeated\n", banded_t.size(), nt, nfail);
+        }
+        if ((rc = run_dp(ctx, rest, &p, false, true, nullptr, in.d_ops, in.d_ops_off, in.d_ops_len, DP_BAND, &ck))) return rc;
+      }
       if (in.d_score) HIP_TRY(hipMemcpy(in.d_score, h_pre.data(), sizeof(int32_t) * (size_t)nt, hipMemcpyHostToDevice));
-      o.d_ends = d_ends;
     } else if (use_band) {
       // the preliminary score equals the winning orientation score (same DP): no score array needed from the band pass
       if ((rc = run_dp(ctx, pb, &p, false, true, nullptr, in.d_ops,
@@ -880,9 +955,19 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
   HIP_TRY(hipMemcpyAsync(ctx->d_tmp[2].p, ctx->h_tmp.p, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
   std::vector<uint64_t> a1o(nt), a2o(nt);
   for (uint32_t t = 0; t < nt; ++t) { a1o[t] = sp.offset[t] + tl[t]; a2o[t] = sr.offset[ridx[t]]; }
+  // substitution tables of the full profiles for the band kernels (band16.h): the preliminary alignment (rows tl .. tl + mt) and the
+  // final one (all rows) read them
+  std::vector<B16TableDesc> td;
+  const bool b16 = p.ge < 0 && p.go <= 0 && getenv("TRACYHIP_NO_BAND16") == nullptr;
+  if (b16) {
+    td.resize(nt);
+    for (uint32_t t = 0; t < nt; ++t) td[t] = B16TableDesc{sp.offset[t], 0, mf[t], mf[t], 0, 0};
+    if ((rc = build_b16_tables(ctx, ctx->d_b16tab[2], d_prof, false, td, &p))) return rc;
+  }
   OrientIn oi{};
   oi.nt = nt; oi.d_prof = d_prof; oi.a1_off = a1o.data(); oi.mf = mf.data(); oi.mt = mt.data(); oi.a2_off = a2o.data(); oi.rn = rn.data();
   oi.oriented = job->oriented; oi.exact = job->strand_by_certificate == 0; oi.d_verr = d_verr; oi.ends_only = true;
+  if (b16) { oi.d_qp = static_cast<const int16_t*>(ctx->d_b16tab[2].p); oi.td = td.data(); oi.row0 = tl.data(); }
   oi.d_ops = static_cast<uint8_t*>(ctx->d_tmp[1].p); oi.d_ops_off = static_cast<const uint64_t*>(ctx->d_tmp[2].p);
   oi.d_ops_len = static_cast<uint32_t*>(ctx->d_tmp[3].p); oi.d_score = static_cast<int32_t*>(ctx->d_tmp[4].p);
   OrientOut oo;
@@ -952,8 +1037,16 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
     if (!band_env && bandW > 0 && oo.gap.size() == nt)
       for (uint32_t t = 0; t < nt; ++t) band_of[t] = (int32_t)std::min<uint32_t>(96u, std::max<uint32_t>(32u, oo.gap[t] + 48u));
     constexpr int kBandK = 4;
-    std::vector<uint8_t> banded(nt, 0);
+    std::vector<uint8_t> banded(nt, 0);  // 1: multi-pass form of the whole-matrix kernel (PAIR_BANDED), 2: band kernels
     uint32_t nbanded = 0;
+    // band kernels (band16.h) where the band fits them: four pairs per wave, only the band's cells swept and stored
+    Band16Job j16;
+    j16.kind = 0;
+    j16.d_qp = static_cast<const int16_t*>(ctx->d_b16tab[2].p);
+    j16.d_codes = ctx->codes();
+    std::vector<PairDesc> whole(nt);  // every pair as a whole-matrix problem (what a pair that does not certify is repeated as)
+    pb.desc.clear();
+    pb.k.clear();
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc d{};
       d.a1_off = sp.offset[t];
@@ -966,7 +1059,25 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
       d.a2_off = sr.offset[ridx[t]] + (h_rc[t] ? rn[t] - h_trim[t].ri - h_trim[t].len : h_trim[t].ri);
       d.flags = h_rc[t] ? PAIR_A2_REVCOMP : 0;
       d.out = t;
-      pb.k[t] = choose_k(d.m, MODE_QP);
+      whole[t] = d;
+      int kt = choose_k(d.m, MODE_QP);
+      if (b16 && bandW > 0 && d.m && d.n && 4ull * ((d.n + 7u) & ~3u) + b16_table_bytes(12) <= 60u * 1024u) {
+        const int64_t over = (int64_t)d.n - (int64_t)d.m, aover = over < 0 ? -over : over;
+        int64_t bw = band_of[t];
+        const int64_t fit = ((int64_t)b16_max_window(12) - 12 - aover) / 2;  // the widest band the kernels sweep
+        if (bw > fit && fit >= 24) bw = fit;
+        const int32_t dlo = (int32_t)(-bw - (over < 0 ? -over : 0)), dhi = (int32_t)(bw + (over > 0 ? over : 0));
+        const int K = band16_pick_k(dlo, dhi);
+        if (K) {
+          band_of[t] = (int32_t)bw;
+          PairDesc q = d;
+          q.a1_off = td[t].out_off; q.a1_stride = td[t].stride; q.ckpt_off = band_pack(dlo, dhi); q.lastrow_off = 0;
+          j16.desc.push_back(q); j16.k.push_back(K);
+          banded[t] = 2;
+          ++nbanded;
+          continue;
+        }
+      }
       if (bandW > 0 && d.m && d.n) {
         const int64_t bw = band_of[t];
         const int64_t over = (int64_t)d.n - (int64_t)d.m;
@@ -976,25 +1087,37 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
         if ((int64_t)d.m >= 3 * rows_pass && 2 * (rows_pass + width) < (int64_t)d.n) {
           d.flags |= PAIR_BANDED;
           d.ckpt_off = band_pack((int32_t)(-bw - (over < 0 ? -over : 0)), (int32_t)(bw + (over > 0 ? over : 0)));
-          pb.k[t] = kBandK;
+          kt = kBandK;
           banded[t] = 1;
           ++nbanded;
         }
       }
-      pb.desc[t] = d;
+      pb.desc.push_back(d);
+      pb.k.push_back(kt);
     }
-    // the banded form keeps the whole-matrix word layout on strips of four rows -- four times the traceback words of the plain
-    // form; batches whose words would not fit a quarter of the device memory stay on whole matrices (one launch, no chunks)
-    if (nbanded) {
+    // The multi-pass form keeps the whole-matrix word layout on strips of four rows -- about four times the traceback words of the
+    // plain form.  It stays within the limit run_dp plans with (the caller's workspace limit, or this context's share of the free
+    // memory): a pair whose banded words exceed it, and the whole batch if the sum does, go back to whole matrices.
+    {
+      uint64_t limit = ctx->ws_limit;
+      if (limit == 0) {
+        size_t fr = 0, tot = 0;
+        HIP_TRY(hipMemGetInfo(&fr, &tot));
+        limit = (uint64_t)(fr * 0.70 / ctx->mem_share) + ctx->d_bits.cap;
+      }
       uint64_t bytes = 0;
-      for (uint32_t t = 0; t < nt; ++t)
-        if (banded[t]) bytes += (uint64_t)num_passes(pb.desc[t].m, kBandK) * steps_per_pass(pb.desc[t].n) * 64u * 8u;
-      size_t fr = 0, tot = 0;
-      HIP_TRY(hipMemGetInfo(&fr, &tot));
-      if (bytes > (uint64_t)tot / 4 / ctx->mem_share) {
-        for (uint32_t t = 0; t < nt; ++t)
-          if (banded[t]) { pb.desc[t].flags &= ~PAIR_BANDED; pb.desc[t].ckpt_off = 0; pb.k[t] = choose_k(pb.desc[t].m, MODE_QP); banded[t] = 0; }
-        nbanded = 0;
+      bool unband_all = false;
+      for (PairDesc& d : pb.desc) {
+        if (!(d.flags & PAIR_BANDED)) continue;
+        const uint64_t b = (uint64_t)num_passes(d.m, kBandK) * steps_per_pass(d.n) * 64u * 8u;
+        if (b > limit) { d.flags &= ~PAIR_BANDED; d.ckpt_off = 0; banded[d.out] = 0; --nbanded; continue; }
+        bytes += b;
+      }
+      if (bytes > limit) unband_all = true;
+      for (size_t q = 0; q < pb.desc.size(); ++q) {
+        PairDesc& d = pb.desc[q];
+        if (unband_all && (d.flags & PAIR_BANDED)) { d.flags &= ~PAIR_BANDED; d.ckpt_off = 0; banded[d.out] = 0; --nbanded; }
+        if (!(d.flags & PAIR_BANDED)) pb.k[q] = choose_k(d.m, MODE_QP);
       }
     }
     int32_t* d_top = nullptr;
@@ -1003,38 +1126,47 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
       HIP_TRY(b.ensure((sizeof(RowMaxDesc) + sizeof(int32_t)) * (size_t)nt));
       RowMaxDesc* d_rm = static_cast<RowMaxDesc*>(b.p);
       d_top = reinterpret_cast<int32_t*>(d_rm + nt);
-      std::vector<RowMaxDesc> hrm(nt);
+      HIP_TRY(ctx->h_tmp.ensure(sizeof(RowMaxDesc) * (size_t)nt));  // (pinned, free at this point of the call: no host wait)
+      RowMaxDesc* hrm = static_cast<RowMaxDesc*>(ctx->h_tmp.p);
       for (uint32_t t = 0; t < nt; ++t) hrm[t] = RowMaxDesc{sp.offset[t], mf[t], mf[t], 0u};
-      HIP_TRY(hipMemcpyAsync(d_rm, hrm.data(), sizeof(RowMaxDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipStreamSynchronize(st));  // (hrm is a local)
+      HIP_TRY(hipMemcpyAsync(d_rm, hrm, sizeof(RowMaxDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, st, static_cast<const RowMaxDesc*>(d_rm), static_cast<const float*>(d_prof),
                          (float)p.match, (float)p.mismatch, d_top);
       HIP_TRY(hipGetLastError());
+    }
+    if (!j16.desc.empty()) {
+      HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
+      rc = run_band16(ctx, j16, &p, static_cast<int32_t*>(d_final_sc), nullptr, static_cast<uint8_t*>(d_ops), static_cast<const uint64_t*>(ctx->d_ops_off.p),
+                      static_cast<uint32_t*>(d_olen));
+      if (rc == kWiden) rc = set_error(TRACYHIP_ERR_RANGE, "profile values outside the range of the traceback kernels");
+      if (rc) return rc;
     }
     if ((rc = run_dp(ctx, pb, &p, false, true, static_cast<int32_t*>(d_final_sc), static_cast<uint8_t*>(d_ops),
                      static_cast<const uint64_t*>(ctx->d_ops_off.p), static_cast<uint32_t*>(d_olen))))
       return rc;
     if (nbanded) {
       std::vector<int32_t> h_top(nt), h_sb(nt);
+      std::vector<uint32_t> h_ol(nt);
       HIP_TRY(hipMemcpyAsync(h_top.data(), d_top, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(h_sb.data(), d_final_sc, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(h_ol.data(), d_olen, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       std::vector<PairDesc> again;
       std::vector<int> again_k;
       for (uint32_t t = 0; t < nt; ++t) {
         const int64_t lose = (int64_t)(-(int64_t)p.ge) * ((int64_t)band_of[t] + 1);
-        if (!banded[t] || (int64_t)h_sb[t] > (int64_t)h_top[t] - lose) continue;
-        PairDesc d = pb.desc[t];
-        d.flags &= ~PAIR_BANDED;
-        d.ckpt_off = 0;
-        again.push_back(d);
-        again_k.push_back(choose_k(d.m, MODE_QP));
+        if (!banded[t] || ((int64_t)h_sb[t] > (int64_t)h_top[t] - lose && h_ol[t] != 0)) continue;
+        again.push_back(whole[t]);
+        again_k.push_back(choose_k(whole[t].m, MODE_QP));
       }
       if (getenv("TRACYHIP_HOST_TIMERS")) {
-        int64_t wsum = 0, lsum = 0, lmax = 0;
-        for (uint32_t t = 0; t < nt; ++t) { wsum += band_of[t]; const int64_t l = (int64_t)h_top[t] - h_sb[t]; lsum += l; lmax = std::max(lmax, l); }
-        fprintf(stderr, "band: %u of %u pairs banded, %zu repeated; mean W %.1f, mean top - S_b %.1f, max %lld\n", nbanded, nt, again.size(),
-                (double)wsum / nt, (double)lsum / nt, (long long)lmax);
+        int64_t wsum = 0, lsum = 0, lmax = 0, xmax = -1000000;
+        for (uint32_t t = 0; t < nt; ++t) {
+          wsum += band_of[t]; const int64_t l = (int64_t)h_top[t] - h_sb[t]; lsum += l; lmax = std::max(lmax, l);
+          if (oo.gap.size() == nt) xmax = std::max<int64_t>(xmax, l / (-(int64_t)p.ge) - (int64_t)oo.gap[t]);
+        }
+        fprintf(stderr, "band: %u of %u pairs banded (%zu on the band kernels), %zu repeated; mean W %.1f, mean top - S_b %.1f, max %lld; max needed W - gap of the trimmed alignment %lld\n", nbanded, nt,
+                j16.desc.size(), again.size(), (double)wsum / nt, (double)lsum / nt, (long long)lmax, (long long)xmax);
       }
       if (!again.empty()) {
         pb.desc.swap(again);
@@ -1415,6 +1547,15 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     oi.oriented = job->oriented; oi.exact = job->strand_by_certificate == 0; oi.d_verr = nullptr;
     oi.d_ops = static_cast<uint8_t*>(b_ops1.p); oi.d_ops_off = d_off1; oi.d_ops_len = static_cast<uint32_t*>(b_len1.p);
     oi.d_score = static_cast<int32_t*>(d_strim);
+    // the traceback of the trimmed trace on the band kernels (band16.h): substitution tables of the profiles
+    std::vector<B16TableDesc> tdp;
+    if (p.ge < 0 && p.go <= 0 && getenv("TRACYHIP_NO_BAND16") == nullptr) {
+      tdp.resize(nt);
+      for (uint32_t t = 0; t < nt; ++t) tdp[t] = B16TableDesc{sp.offset[t], 0, mf[t], mf[t], 0, 0};
+      HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
+      if ((rc = build_b16_tables(ctx, ctx->d_b16tab[2], d_prof, false, tdp, &p))) return rc;
+      oi.d_qp = static_cast<const int16_t*>(ctx->d_b16tab[2].p); oi.td = tdp.data(); oi.row0 = tl.data();
+    }
     OrientOut oo;
     if ((rc = orient_and_align(ctx, p, oi, oo))) return rc;
     h_sc2 = oo.sc2; h_fwd = oo.fwd; h_rc = oo.rc;
@@ -1587,6 +1728,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   const uint64_t* d_offA;
   if ((rc = upload(ctx, buf(), offA, &d_offA))) return rc;
   std::vector<TrimOut> h_trimA[2];
+  std::vector<B16TableDesc> td_pri;  // substitution tables of the primary alleles (band kernels), kept for allele 1 vs allele 2
   void *d_scoreK[3], *d_opsK[3], *d_lenK[3];
   for (int k = 0; k < 3; ++k) {
     uint64_t cap = 0;
@@ -1623,6 +1765,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       for (uint32_t t = 0; t < nt; ++t) td[t] = B16TableDesc{bc.bc_offset[t] + soff[t], 0, 0, sl[t], 0, 0};
       HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
       if ((rc = build_b16_tables(ctx, ctx->d_b16tab[k], seq, true, td, &p))) return rc;
+      if (k == 0) td_pri = td;
     }
     std::vector<int32_t> h_s1(nt, 0);       // S* of gotoh(seq, window) where the certifying sweep ran
     std::vector<int64_t> gap_of(nt, -1);    // its gap-step budget; -1: not known
@@ -1716,7 +1859,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
           const int32_t dlo = d1 - (int32_t)std::min<int64_t>(g, 1 << 20) - 1, dhi = d1 + (int32_t)std::min<int64_t>(g, 1 << 20) + 1;
           const int K = g >= 0 ? band16_pick_k(dlo, dhi) : 0;
           if (K && origin16_ok(&p, d.m, d.n)) {
-            d.a1_off = td[t].out_off; d.a1_stride = td[t].stride; d.ckpt_off = band_pack(dlo, dhi);
+            d.a1_off = td[t].out_off; d.a1_stride = td[t].stride; d.ckpt_off = band_pack(dlo, dhi); d.lastrow_off = 0;
             jo.desc.push_back(d); jo.k.push_back(K);
           } else { rest.desc.push_back(d); rest.k.push_back(pb.k[t]); }
         }
@@ -1776,7 +1919,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
           K = band16_pick_k(dlo, dhi);
         }
         if (K) {
-          d.a1_off = td[t].out_off; d.a1_stride = td[t].stride; d.ckpt_off = band_pack(dlo, dhi);
+          d.a1_off = td[t].out_off; d.a1_stride = td[t].stride; d.ckpt_off = band_pack(dlo, dhi); d.lastrow_off = 0;
           jt.desc.push_back(d); jt.k.push_back(K); banded_t.push_back(t);
         } else { rest.desc.push_back(d); rest.k.push_back(pb.k[t]); }
       }
@@ -1819,7 +1962,59 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     const uint64_t* d_offK;
     std::vector<uint64_t> offK(out->ops_offset[2], out->ops_offset[2] + nt);
     if ((rc = upload(ctx, buf(), offK, &d_offK))) return rc;
-    if ((rc = run_dp(ctx, pb, &pglobal, false, true, static_cast<int32_t*>(d_scoreK[2]), static_cast<uint8_t*>(d_opsK[2]), d_offK,
+    // On a band (band16.h) where it can be certified afterwards.  Both ends are fixed here: a path that leaves the diagonals
+    // [-W - (m-n)+, W + (n-m)+] makes at least v = W + 1 + (m-n)+ vertical and h = W + 1 + (n-m)+ horizontal gap steps in two runs, so
+    // it scores at most best (m - v) - |ge| (v + h) - 2 |go|; a banded score above that is the optimum and bits and path are the
+    // whole matrix's.  W is guessed from what the two alleles lost against the reference (they differ from each other by about
+    // as much as both differ from it); pairs that do not certify are repeated on the whole matrix.
+    Band16Job jg;
+    DpProblem rest;
+    rest.mode = pb.mode; rest.d_a1 = pb.d_a1; rest.d_a2 = pb.d_a2; rest.cq_codes = pb.cq_codes;
+    const bool b16g = use_cq && !td_pri.empty() && pglobal.ge < 0 && pglobal.go <= 0 && getenv("TRACYHIP_NO_BAND16") == nullptr;
+    std::vector<uint32_t> banded_t;
+    std::vector<int64_t> bound_of(nt, 0);
+    if (b16g) {
+      std::vector<int32_t> h_a[2] = {std::vector<int32_t>(nt), std::vector<int32_t>(nt)};
+      for (int k = 0; k < 2; ++k) HIP_TRY(hipMemcpyAsync(h_a[k].data(), d_scoreK[k], sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      jg.kind = 0; jg.d_qp = static_cast<const int16_t*>(ctx->d_b16tab[0].p); jg.d_codes = d_cq_sd;
+      const int64_t best = std::max<int64_t>(std::max<int64_t>(pglobal.match, pglobal.mismatch), 0), age = -(int64_t)pglobal.ge, ago = -(int64_t)pglobal.go;
+      for (uint32_t t = 0; t < nt; ++t) {
+        PairDesc d = pb.desc[t];
+        int K = 0;
+        int32_t dlo = 0, dhi = 0;
+        if (d.m && d.n) {
+          const int64_t lost = std::max<int64_t>(0, best * d.m - h_a[0][t]) + std::max<int64_t>(0, best * d.m - h_a[1][t]);
+          const int64_t per = best + 2 * age;
+          int64_t W = (5 * lost / 2 + 40) / (per > 0 ? per : 1) + 2;
+          const int64_t over = (int64_t)d.n - (int64_t)d.m;
+          if (W > 90) W = 90;
+          dlo = (int32_t)(-W - (over < 0 ? -over : 0));
+          dhi = (int32_t)(W + (over > 0 ? over : 0));
+          K = band16_pick_k(dlo, dhi);
+          const int64_t v = W + 1 + (over < 0 ? -over : 0), h = W + 1 + (over > 0 ? over : 0);
+          bound_of[t] = best * ((int64_t)d.m - v) - age * (v + h) - 2 * ago;
+        }
+        if (K) {
+          d.a1_off = td_pri[t].out_off; d.a1_stride = td_pri[t].stride; d.ckpt_off = band_pack(dlo, dhi); d.lastrow_off = 0;
+          jg.desc.push_back(d); jg.k.push_back(K); banded_t.push_back(t);
+        } else { rest.desc.push_back(d); rest.k.push_back(pb.k[t]); }
+      }
+      HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
+      if ((rc = run_band16(ctx, jg, &pglobal, static_cast<int32_t*>(d_scoreK[2]), nullptr, static_cast<uint8_t*>(d_opsK[2]), d_offK, static_cast<uint32_t*>(d_lenK[2])))) return rc;
+      if (!banded_t.empty()) {
+        std::vector<int32_t> h_sc(nt);
+        std::vector<uint32_t> h_ol(nt);
+        HIP_TRY(hipMemcpyAsync(h_sc.data(), d_scoreK[2], sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_ol.data(), d_lenK[2], sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        uint32_t nfail = 0;
+        for (uint32_t t : banded_t)
+          if ((int64_t)h_sc[t] <= bound_of[t] || h_ol[t] == 0) { rest.desc.push_back(pb.desc[t]); rest.k.push_back(pb.k[t]); ++nfail; }
+        if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "decompose allele 1 vs 2: %zu of %u pairs banded, %u repeated\n", banded_t.size(), nt, nfail);
+      }
+    }
+    if ((rc = run_dp(ctx, b16g ? rest : pb, &pglobal, false, true, static_cast<int32_t*>(d_scoreK[2]), static_cast<uint8_t*>(d_opsK[2]), d_offK,
                      static_cast<uint32_t*>(d_lenK[2]))))
       return rc;
   }

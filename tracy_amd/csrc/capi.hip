@@ -636,57 +636,105 @@ int build_b16_tables(tracyhip_ctx* ctx, DevBuf& buf, const void* d_a1, bool stri
 
 int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, int32_t* d_scores, uint32_t* d_ends, uint8_t* d_ops,
                const uint64_t* d_ops_off, uint32_t* d_ops_len) {
-  const uint32_t np = (uint32_t)job.desc.size();
-  if (np == 0) return TRACYHIP_OK;
+  const uint32_t nall = (uint32_t)job.desc.size();
+  if (nall == 0) return TRACYHIP_OK;
   TRACYHIP_HOST_SCOPE(hs_all, "run_band16");
   hipStream_t st = ctx->stream;
-  // order: strip height, then tallest first (the four pairs of a workgroup should be of a size)
-  std::vector<uint32_t> order(np);
-  for (uint32_t i = 0; i < np; ++i) order[i] = i;
-  {
-    // (the order only evens out the four pairs of a workgroup and the tail of a launch: batches of one strip height whose sizes lie
-    // within 25 % of each other keep the caller's order)
-    std::vector<uint64_t> key(np);
-    uint64_t lo = ~0ull, hi = 0;
-    bool onek = true;
-    for (uint32_t i = 0; i < np; ++i) {
-      const PairDesc& d = job.desc[i];
-      const uint64_t w = (d.m && d.n && job.k[i]) ? b16_words(d.m, d.n, job.k[i], band_dmin(d), band_dmax(d)) : 0;
-      key[i] = ((uint64_t)job.k[i] << 48) | std::min<uint64_t>(w, (1ull << 48) - 1);
-      lo = std::min(lo, w); hi = std::max(hi, w);
-      onek = onek && job.k[i] == job.k[0];
-    }
-    if (!(onek && hi <= lo + lo / 4)) std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key[x] > key[y]; });
-  }
+  auto* hs_plan = new HostScope("run_band16.plan");
   uint64_t limit = ctx->ws_limit;
   if (limit == 0 && job.kind == 0) {
     size_t fr = 0, tot = 0;
     HIP_TRY(hipMemGetInfo(&fr, &tot));
     limit = (uint64_t)(fr * 0.70 / ctx->mem_share) + ctx->d_bits.cap;
   } else if (limit == 0) limit = ~0ull;
+  // Order: strip height (12, 8, 4), the caller's order within one (the pairs of a pipeline stage are of a size).  Laid out by a
+  // few threads: per-thread counts per strip height, a scan, the fill -- descriptors go straight into the pinned staging block.
+  constexpr int NB = 3;
+  auto bucket_of = [](int K) { return K == 12 ? 0 : K == 8 ? 1 : K == 4 ? 2 : -1; };
+  static const int bucket_k[NB] = {12, 8, 4};
+  struct Part { uint32_t n[NB]; uint64_t bytes[NB]; bool bad; };
+  Part part[kHostThreads] = {};
+  std::vector<uint64_t> wb(nall);  // bytes of traceback words per pair (kind 0)
+  parallel_for(nall, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+    Part& pt = part[tid];
+    for (uint32_t i = lo; i < hi; ++i) {
+      const int K = job.k[i];
+      if (K == 0) { wb[i] = 0; continue; }
+      const PairDesc& d = job.desc[i];
+      const int b = bucket_of(K);
+      if (b < 0 || d.m == 0 || d.n == 0 || b16_window(K, band_dmin(d), band_dmax(d)) > b16_max_window(K)) { pt.bad = true; continue; }
+      const uint64_t bytes = job.kind == 0 ? ((b16_words(d.m, d.n, K, band_dmin(d), band_dmax(d)) * b16_word_bytes(K) + 15u) & ~15ull) : 0;
+      wb[i] = bytes;
+      pt.n[b] += 1;
+      pt.bytes[b] += bytes;
+    }
+  });
+  uint32_t bn[NB] = {0, 0, 0};
+  uint64_t total_bytes = 0;
+  for (uint32_t t = 0; t < kHostThreads; ++t) {
+    if (part[t].bad) { delete hs_plan; return set_error(TRACYHIP_ERR_ARG, "run_band16: pair outside the band kernels' domain"); }
+    for (int b = 0; b < NB; ++b) { bn[b] += part[t].n[b]; total_bytes += part[t].bytes[b]; }
+  }
+  const uint32_t np = bn[0] + bn[1] + bn[2];
+  if (np == 0) { delete hs_plan; return TRACYHIP_OK; }
   HIP_TRY(ctx->h_desc.ensure(sizeof(PairDesc) * (size_t)np));
   PairDesc* hd = static_cast<PairDesc*>(ctx->h_desc.p);
+  std::vector<int> hk(np);
   struct Chunk { uint32_t lo, hi; uint64_t bytes; };
   std::vector<Chunk> chunks;
-  Chunk c{0, 0, 0};
   uint64_t max_mn = 0;
-  for (uint32_t j = 0; j < np; ++j) {
-    PairDesc d = job.desc[order[j]];
-    const int K = job.k[order[j]];
-    if (d.m == 0 || d.n == 0 || K == 0 || b16_window(K, band_dmin(d), band_dmax(d)) > b16_max_window(K))
-      return set_error(TRACYHIP_ERR_ARG, "run_band16: pair outside the band kernels' domain");
-    const uint64_t bytes = job.kind == 0 ? ((b16_words(d.m, d.n, K, band_dmin(d), band_dmax(d)) * b16_word_bytes(K) + 15u) & ~15ull) : 0;
-    if (bytes > limit) return set_error(TRACYHIP_ERR_OOM, "one pair needs %llu bytes of traceback words, workspace limit is %llu", (unsigned long long)bytes, (unsigned long long)limit);
-    if (c.hi > c.lo && c.bytes + bytes > limit) { chunks.push_back(c); c = Chunk{j, j, 0}; }
-    d.bits_off = c.bytes;
-    c.bytes += bytes;
-    c.hi = j + 1;
-    hd[j] = d;
-    max_mn = std::max<uint64_t>(max_mn, (uint64_t)d.m + d.n);
+  if (total_bytes <= limit) {
+    // one chunk: positions and word offsets from the scan over (strip height, thread)
+    uint32_t pos0[NB][kHostThreads];
+    uint64_t off0[NB][kHostThreads];
+    uint32_t p = 0;
+    uint64_t o = 0;
+    for (int b = 0; b < NB; ++b)
+      for (uint32_t t = 0; t < kHostThreads; ++t) { pos0[b][t] = p; off0[b][t] = o; p += part[t].n[b]; o += part[t].bytes[b]; }
+    uint64_t tmax[kHostThreads] = {};
+    parallel_for(nall, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+      uint32_t pp[NB];
+      uint64_t oo[NB];
+      for (int b = 0; b < NB; ++b) { pp[b] = pos0[b][tid]; oo[b] = off0[b][tid]; }
+      uint64_t mx = 0;
+      for (uint32_t i = lo; i < hi; ++i) {
+        const int K = job.k[i];
+        if (K == 0) continue;
+        const int b = bucket_of(K);
+        PairDesc d = job.desc[i];
+        d.bits_off = oo[b];
+        oo[b] += wb[i];
+        hd[pp[b]] = d;
+        hk[pp[b]] = K;
+        ++pp[b];
+        mx = std::max<uint64_t>(mx, (uint64_t)d.m + d.n);
+      }
+      tmax[tid] = mx;
+    });
+    for (uint32_t t = 0; t < kHostThreads; ++t) max_mn = std::max(max_mn, tmax[t]);
+    chunks.push_back(Chunk{0, np, total_bytes});
+  } else {
+    // the words do not fit the workspace at once: chunks of consecutive pairs (serial; rare)
+    uint32_t pos = 0;
+    Chunk c{0, 0, 0};
+    for (int b = 0; b < NB; ++b)
+      for (uint32_t i = 0; i < nall; ++i) {
+        if (job.k[i] != bucket_k[b]) continue;
+        if (wb[i] > limit) { delete hs_plan; return set_error(TRACYHIP_ERR_OOM, "one pair needs %llu bytes of traceback words, workspace limit is %llu", (unsigned long long)wb[i], (unsigned long long)limit); }
+        if (c.hi > c.lo && c.bytes + wb[i] > limit) { chunks.push_back(c); c = Chunk{pos, pos, 0}; }
+        PairDesc d = job.desc[i];
+        d.bits_off = c.bytes;
+        c.bytes += wb[i];
+        hd[pos] = d;
+        hk[pos] = bucket_k[b];
+        c.hi = ++pos;
+        max_mn = std::max<uint64_t>(max_mn, (uint64_t)d.m + d.n);
+      }
+    chunks.push_back(c);
   }
-  chunks.push_back(c);
   uint64_t max_bytes = 0;
   for (const Chunk& ch : chunks) max_bytes = std::max(max_bytes, ch.bytes);
+  delete hs_plan;
   HIP_TRY(ctx->d_desc.ensure(sizeof(PairDesc) * (size_t)np));
   HIP_TRY(hipMemcpyAsync(ctx->d_desc.p, hd, sizeof(PairDesc) * (size_t)np, hipMemcpyHostToDevice, st));
   if (job.kind == 0) HIP_TRY(ctx->d_bits.ensure(max_bytes + 64));
@@ -701,14 +749,16 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
     uint32_t j = ch.lo;
     while (j < ch.hi) {
       uint32_t e = j;
-      const int K = job.k[order[j]];
+      const int K = hk[j];
       uint32_t nmax = 0;
       uint64_t cells = 0, bytes = 0;
-      while (e < ch.hi && job.k[order[e]] == K) {
+      while (e < ch.hi && hk[e] == K) {
         nmax = std::max(nmax, hd[e].n);
-        const uint64_t wds = b16_words(hd[e].m, hd[e].n, K, band_dmin(hd[e]), band_dmax(hd[e]));
-        cells += wds * (uint64_t)K;
-        bytes += (job.kind == 0 ? wds * b16_word_bytes(K) : 0) + 12ull * hd[e].m + hd[e].n + 4;
+        if (ctx->timing) {
+          const uint64_t wds = b16_words(hd[e].m, hd[e].n, K, band_dmin(hd[e]), band_dmax(hd[e]));
+          cells += wds * (uint64_t)K;
+          bytes += (job.kind == 0 ? wds * b16_word_bytes(K) : 0) + 12ull * hd[e].m + hd[e].n + 4;
+        }
         ++e;
       }
       a.pairs = dd + j;

@@ -132,6 +132,19 @@ struct tracyhip_ctx {
 };
 
 namespace tracyhip {
+// The per-trace host loops of the pipelines (descriptors, bands, verdicts of 10^5 traces between two launches) on a few threads:
+// fn(lo, hi, tid) over [0, n) in contiguous slices; small n runs inline.
+constexpr uint32_t kHostThreads = 8;
+template <class Fn>
+void parallel_for(uint32_t n, Fn fn) {
+  if (n < 16384u) { fn(0u, n, 0u); return; }
+  std::vector<std::thread> th;
+  th.reserve(kHostThreads - 1);
+  auto lo = [&](uint32_t t) { return (uint32_t)((uint64_t)n * t / kHostThreads); };
+  for (uint32_t t = 1; t < kHostThreads; ++t) th.emplace_back([&, t]() { fn(lo(t), lo(t + 1), t); });
+  fn(0u, lo(1), 0u);
+  for (auto& x : th) x.join();
+}
 // A DpProblem borrows the context's descriptor vectors for its lifetime and hands them back, whatever the way out: batches of
 // 10^5 pairs are megabytes of descriptors per stage, and allocating them afresh costs a millisecond of page faults each time.
 // (One lease at a time per context: the stages of a pipeline build their problems one after the other.)
@@ -205,7 +218,7 @@ struct Band16Job {
   const int16_t* d_qp = nullptr;
   const uint8_t* d_codes = nullptr;
   std::vector<PairDesc> desc;
-  std::vector<int> k;
+  std::vector<int> k;           // 4 / 8 / 12; 0: the pair is not part of the job (callers fill both vectors for every trace, in order)
 };
 // smallest strip height whose lanes are done with a strip before the next one is due (K + width <= 15 (K + 1)); 0: the band is too wide
 int band16_pick_k(int32_t dmin, int32_t dmax);

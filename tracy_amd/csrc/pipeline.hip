@@ -764,55 +764,61 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       j16.kind = ends_path ? 1 : 0;
       j16.d_qp = in.d_qp;
       j16.d_codes = ctx->codes();
+      j16.desc.resize(nt);
+      j16.k.assign(nt, 0);
       DpProblem rest;
       rest.mode = pb.mode; rest.a1_profile = pb.a1_profile; rest.d_a1 = pb.d_a1; rest.d_a2 = pb.d_a2;
-      std::vector<uint32_t> banded_t;
-      for (uint32_t t = 0; t < nt; ++t) {
-        const PairDesc whole = pb.desc[t];
-        PairDesc& d = pb.desc[t];
-        h_pre[t] = h_rc[t] ? h_sc2[nt + t] : h_sc2[t];
-        const int64_t ce = h_ce[t];
-        if (ce <= 0) {
-          // H(m, c) == E(m, c) in every column: the reference's traceback (gotoh.h:143-167) runs along row m to column 0 and
-          // up column 0 -- n 'h', then m 'v' -- so both ends are 0 (a junk trace: the all-gap path is optimal).  Column 1 alone
-          // reproduces that: H(m, 1) == E(m, 1), opened from H(m, 0), whose origin is 0.
-          if (ends_path) {
-            d.a2_off += h_rc[t] ? (uint64_t)(d.n - 1u) : 0ull;
-            d.n = 1;
-            d.a2_stride = 1;
+      std::vector<PairDesc> wholes(tb16_path ? nt : 0);
+      parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t) {
+        for (uint32_t t = lo; t < hi; ++t) {
+          const PairDesc whole = pb.desc[t];
+          if (tb16_path) wholes[t] = whole;
+          PairDesc& d = pb.desc[t];
+          h_pre[t] = h_rc[t] ? h_sc2[nt + t] : h_sc2[t];
+          const int64_t ce = h_ce[t];
+          if (ce <= 0) {
+            // H(m, c) == E(m, c) in every column: the reference's traceback (gotoh.h:143-167) runs along row m to column 0 and
+            // up column 0 -- n 'h', then m 'v' -- so both ends are 0 (a junk trace: the all-gap path is optimal).  Column 1 alone
+            // reproduces that: H(m, 1) == E(m, 1), opened from H(m, 0), whose origin is 0.
+            if (ends_path) {
+              d.a2_off += h_rc[t] ? (uint64_t)(d.n - 1u) : 0ull;
+              d.n = 1;
+              d.a2_stride = 1;
+            }
+            continue;
           }
-          rest.desc.push_back(d); rest.k.push_back(pb.k[t]);
-          continue;
+          const int64_t loss = (int64_t)h_top[t] - (int64_t)h_pre[t];
+          const int64_t g = loss > 0 ? loss / age : 0;
+          o.gap[t] = (uint32_t)std::min<int64_t>(g, 0x7fffffff);
+          int64_t a = ce - (int64_t)d.m - g - 2;
+          if (a < 0) a = 0;
+          shift[t] = (uint32_t)a;
+          d.a2_off += h_rc[t] ? (uint64_t)(d.n - (uint32_t)ce) : (uint64_t)a;  // reverse view: column c is byte n - c
+          d.n = (uint32_t)(ce - a);
+          d.a2_stride = d.n;
+          int K = 0;
+          int32_t dlo = 0, dhi = 0;
+          if (b16 && g < (1 << 20)) {
+            const int32_t d1 = (int32_t)d.n - (int32_t)d.m;
+            dlo = d1 - (int32_t)g - 1;
+            dhi = d1 + (int32_t)g + 1;
+            K = band16_pick_k(dlo, dhi);
+            if (K && ends_path && !origin16_ok(&p, d.m, d.n)) K = 0;
+            if (K && 4ull * ((d.n + 7u) & ~3u) + b16_table_bytes(K) > 60u * 1024u) K = 0;  // (the codes of four pairs are staged in LDS)
+          }
+          if (K) {
+            PairDesc q = d;
+            q.a1_off = in.td[t].out_off + in.row0[t];
+            q.a1_stride = in.td[t].stride;
+            q.ckpt_off = band_pack(dlo, dhi);
+            q.lastrow_off = ends_path ? 0ull : ((uint64_t)(whole.n - (uint32_t)ce) | ((uint64_t)(uint32_t)a << 32));  // 'h' right / left of the sub-window
+            j16.desc[t] = q;
+            j16.k[t] = K;
+          }
         }
-        const int64_t loss = (int64_t)h_top[t] - (int64_t)h_pre[t];
-        const int64_t g = loss > 0 ? loss / age : 0;
-        o.gap[t] = (uint32_t)std::min<int64_t>(g, 0x7fffffff);
-        int64_t a = ce - (int64_t)d.m - g - 2;
-        if (a < 0) a = 0;
-        shift[t] = (uint32_t)a;
-        d.a2_off += h_rc[t] ? (uint64_t)(d.n - (uint32_t)ce) : (uint64_t)a;  // reverse view: column c is byte n - c
-        d.n = (uint32_t)(ce - a);
-        d.a2_stride = d.n;
-        int K = 0;
-        int32_t dlo = 0, dhi = 0;
-        if (b16 && g < (1 << 20)) {
-          const int32_t d1 = (int32_t)d.n - (int32_t)d.m;
-          dlo = d1 - (int32_t)g - 1;
-          dhi = d1 + (int32_t)g + 1;
-          K = band16_pick_k(dlo, dhi);
-          if (K && ends_path && !origin16_ok(&p, d.m, d.n)) K = 0;
-          if (K && 4ull * ((d.n + 7u) & ~3u) + b16_table_bytes(K) > 60u * 1024u) K = 0;  // (the codes of four pairs are staged in LDS)
-        }
-        if (K) {
-          PairDesc q = d;
-          q.a1_off = in.td[t].out_off + in.row0[t];
-          q.a1_stride = in.td[t].stride;
-          q.ckpt_off = band_pack(dlo, dhi);
-          q.lastrow_off = ends_path ? 0ull : ((uint64_t)(whole.n - (uint32_t)ce) | ((uint64_t)(uint32_t)a << 32));  // 'h' right / left of the sub-window
-          j16.desc.push_back(q); j16.k.push_back(K); banded_t.push_back(t);
-        } else if (ends_path) { rest.desc.push_back(d); rest.k.push_back(pb.k[t]); }
-        else { rest.desc.push_back(whole); rest.k.push_back(pb.k[t]); }  // the whole window: band traceback from the checkpoints
-      }
+      });
+      for (uint32_t t = 0; t < nt; ++t)  // what the band kernels do not take: the origin-tracking sweep over the sub-window / the band traceback
+        if (j16.k[t] == 0) { rest.desc.push_back(ends_path ? pb.desc[t] : wholes[t]); rest.k.push_back(pb.k[t]); }
       if (ends_path) {
         bool fits = true;  // (the pre-check used an upper bound of the sub-window; windows cut at c_e can only be shorter)
         for (size_t q = 0; q < rest.desc.size() && fits; ++q) fits = origin_ok(&p, rest.desc[q].m, rest.desc[q].n, rest.k[q]);
@@ -820,7 +826,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
         HIP_TRY(hipMemcpyAsync(d_shift, shift.data(), sizeof(uint32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
         DpCkpt oc;
         oc.d_ends = d_ends;
-        if (!j16.desc.empty()) {
+        if (rest.desc.size() < nt) {
           HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
           if ((rc = run_band16(ctx, j16, &p, nullptr, d_ends, nullptr, nullptr, nullptr))) return rc;
         }
@@ -830,7 +836,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
         o.d_ends = d_ends;
       } else {
         // traceback on the band; a pair whose banded score is not S* (or whose walk left the band: no ops) is repeated with the rest
-        if (!j16.desc.empty()) {
+        if (rest.desc.size() < nt) {
           HIP_TRY(ctx->d_tmp[7].ensure(sizeof(int32_t) * (size_t)nt));
           int32_t* d_sb = static_cast<int32_t*>(ctx->d_tmp[7].p);
           HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
@@ -841,13 +847,10 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
           HIP_TRY(hipMemcpyAsync(h_ol.data(), in.d_ops_len, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
           HIP_TRY(hipStreamSynchronize(st));
           uint32_t nfail = 0;
-          for (uint32_t t : banded_t)
-            if (h_sb[t] != h_pre[t] || h_ol[t] == 0) {
-              PairDesc w = stage1_desc(t, h_rc[t] ? 1 : 0);
-              w.out = t;
-              rest.desc.push_back(w); rest.k.push_back(pb.k[t]); ++nfail;
-            }
-          if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "preliminary alignment: %zu of %u on the band, %u repeated\n", banded_t.size(), nt, nfail);
+          const size_t nb16 = nt - rest.desc.size();
+          for (uint32_t t = 0; t < nt; ++t)
+            if (j16.k[t] && (h_sb[t] != h_pre[t] || h_ol[t] == 0)) { rest.desc.push_back(wholes[t]); rest.k.push_back(pb.k[t]); ++nfail; }
+          if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "preliminary alignment: %zu of %u on the band, %u repeated\n", nb16, nt, nfail);
         }
         if ((rc = run_dp(ctx, rest, &p, false, true, nullptr, in.d_ops, in.d_ops_off, in.d_ops_len, DP_BAND, &ck))) return rc;
       }
@@ -1820,27 +1823,29 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
           HIP_TRY(hipMemcpyAsync(h_ce.data(), d_ce, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
           HIP_TRY(hipStreamSynchronize(st));
           const int64_t best = std::max<int64_t>(std::max<int64_t>(p.match, p.mismatch), 0), age = -(int64_t)p.ge;
-          for (uint32_t t = 0; t < nt; ++t) {
-            PairDesc& d = pb.desc[t];
-            const int64_t ce = h_ce[t];
-            if (d.m == 0 || d.n == 0) continue;
-            if (ce <= 0) {  // H(m, c) == E(m, c) everywhere: n 'h' then m 'v', both ends 0 -- column 1 alone reproduces it (see orient_and_align_impl)
-              d.a2_off += h_rc[t] ? (uint64_t)(d.n - 1u) : 0ull;
-              d.n = 1;
-              d.a2_stride = 1;
-              continue;
+          parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t) {
+            for (uint32_t t = lo; t < hi; ++t) {
+              PairDesc& d = pb.desc[t];
+              const int64_t ce = h_ce[t];
+              if (d.m == 0 || d.n == 0) continue;
+              if (ce <= 0) {  // H(m, c) == E(m, c) everywhere: n 'h' then m 'v', both ends 0 -- column 1 alone reproduces it (see orient_and_align_impl)
+                d.a2_off += h_rc[t] ? (uint64_t)(d.n - 1u) : 0ull;
+                d.n = 1;
+                d.a2_stride = 1;
+                continue;
+              }
+              const int64_t loss = best * (int64_t)d.m - (int64_t)h_s[t];
+              const int64_t g = loss > 0 ? loss / age : 0;
+              int64_t a = ce - (int64_t)d.m - g - 2;
+              if (a < 0) a = 0;
+              shift[t] = (uint32_t)a;
+              d.a2_off += h_rc[t] ? (uint64_t)(d.n - (uint32_t)ce) : (uint64_t)a;  // reverse view: column c is byte n - c
+              d.n = (uint32_t)(ce - a);
+              d.a2_stride = d.n;
+              h_s1[t] = h_s[t];
+              gap_of[t] = g;
             }
-            const int64_t loss = best * (int64_t)d.m - (int64_t)h_s[t];
-            const int64_t g = loss > 0 ? loss / age : 0;
-            int64_t a = ce - (int64_t)d.m - g - 2;
-            if (a < 0) a = 0;
-            shift[t] = (uint32_t)a;
-            d.a2_off += h_rc[t] ? (uint64_t)(d.n - (uint32_t)ce) : (uint64_t)a;  // reverse view: column c is byte n - c
-            d.n = (uint32_t)(ce - a);
-            d.a2_stride = d.n;
-            h_s1[t] = h_s[t];
-            gap_of[t] = g;
-          }
+          });
           HIP_TRY(hipMemcpyAsync(d_shift, shift.data(), sizeof(uint32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
         }
       }
@@ -1852,17 +1857,24 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       if (b16) {
         jo.kind = 1; jo.d_qp = static_cast<const int16_t*>(ctx->d_b16tab[k].p); jo.d_codes = d_cq_ref;
         rest.mode = pb.mode; rest.d_a1 = pb.d_a1; rest.d_a2 = pb.d_a2; rest.cq_codes = pb.cq_codes;
-        for (uint32_t t = 0; t < nt; ++t) {
-          PairDesc d = pb.desc[t];
-          const int64_t g = gap_of[t];
-          const int32_t d1 = (int32_t)d.n - (int32_t)d.m;
-          const int32_t dlo = d1 - (int32_t)std::min<int64_t>(g, 1 << 20) - 1, dhi = d1 + (int32_t)std::min<int64_t>(g, 1 << 20) + 1;
-          const int K = g >= 0 ? band16_pick_k(dlo, dhi) : 0;
-          if (K && origin16_ok(&p, d.m, d.n)) {
-            d.a1_off = td[t].out_off; d.a1_stride = td[t].stride; d.ckpt_off = band_pack(dlo, dhi); d.lastrow_off = 0;
-            jo.desc.push_back(d); jo.k.push_back(K);
-          } else { rest.desc.push_back(d); rest.k.push_back(pb.k[t]); }
-        }
+        jo.desc.resize(nt);
+        jo.k.assign(nt, 0);
+        parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t) {
+          for (uint32_t t = lo; t < hi; ++t) {
+            PairDesc d = pb.desc[t];
+            const int64_t g = gap_of[t];
+            const int32_t d1 = (int32_t)d.n - (int32_t)d.m;
+            const int32_t dlo = d1 - (int32_t)std::min<int64_t>(g, 1 << 20) - 1, dhi = d1 + (int32_t)std::min<int64_t>(g, 1 << 20) + 1;
+            const int K = g >= 0 ? band16_pick_k(dlo, dhi) : 0;
+            if (K && origin16_ok(&p, d.m, d.n)) {
+              d.a1_off = td[t].out_off; d.a1_stride = td[t].stride; d.ckpt_off = band_pack(dlo, dhi); d.lastrow_off = 0;
+              jo.desc[t] = d;
+              jo.k[t] = K;
+            }
+          }
+        });
+        for (uint32_t t = 0; t < nt; ++t)
+          if (jo.k[t] == 0) { rest.desc.push_back(pb.desc[t]); rest.k.push_back(pb.k[t]); }
         if ((rc = run_band16(ctx, jo, &p, nullptr, oc.d_ends, nullptr, nullptr, nullptr))) return rc;
       }
       if ((rc = run_dp(ctx, b16 ? rest : pb, &p, false, false, nullptr, nullptr, nullptr, nullptr, DP_ORIGIN, &oc))) return rc;
@@ -1903,42 +1915,49 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     Band16Job jt;
     DpProblem rest;
     rest.mode = pb.mode; rest.d_a1 = pb.d_a1; rest.d_a2 = pb.d_a2; rest.cq_codes = pb.cq_codes;
-    std::vector<uint32_t> banded_t;
     if (!h_ends.empty()) {
       jt.kind = 0; jt.d_qp = static_cast<const int16_t*>(ctx->d_b16tab[k].p); jt.d_codes = d_cq_ref;
-      for (uint32_t t = 0; t < nt; ++t) {
-        PairDesc d = pb.desc[t];
-        const int64_t g = gap_of[t];
-        const int64_t ce = (int64_t)h_ends[2 * t + 1] - (int64_t)h_trimA[k][t].ri;  // last column of the alignment, in the slice
-        int K = 0;
-        int32_t dlo = 0, dhi = 0;
-        if (g >= 0 && d.m && d.n && ce >= 1 && ce <= (int64_t)d.n) {
-          const int32_t d1 = (int32_t)ce - (int32_t)d.m;
-          dlo = d1 - (int32_t)std::min<int64_t>(g, 1 << 20) - 1;
-          dhi = d1 + (int32_t)std::min<int64_t>(g, 1 << 20) + 1;
-          K = band16_pick_k(dlo, dhi);
+      jt.desc.resize(nt);
+      jt.k.assign(nt, 0);
+      parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t) {
+        for (uint32_t t = lo; t < hi; ++t) {
+          PairDesc d = pb.desc[t];
+          const int64_t g = gap_of[t];
+          const int64_t ce = (int64_t)h_ends[2 * t + 1] - (int64_t)h_trimA[k][t].ri;  // last column of the alignment, in the slice
+          int K = 0;
+          int32_t dlo = 0, dhi = 0;
+          if (g >= 0 && d.m && d.n && ce >= 1 && ce <= (int64_t)d.n) {
+            const int32_t d1 = (int32_t)ce - (int32_t)d.m;
+            dlo = d1 - (int32_t)std::min<int64_t>(g, 1 << 20) - 1;
+            dhi = d1 + (int32_t)std::min<int64_t>(g, 1 << 20) + 1;
+            K = band16_pick_k(dlo, dhi);
+          }
+          if (K) {
+            d.a1_off = td[t].out_off; d.a1_stride = td[t].stride; d.ckpt_off = band_pack(dlo, dhi); d.lastrow_off = 0;
+            jt.desc[t] = d;
+            jt.k[t] = K;
+          }
         }
-        if (K) {
-          d.a1_off = td[t].out_off; d.a1_stride = td[t].stride; d.ckpt_off = band_pack(dlo, dhi); d.lastrow_off = 0;
-          jt.desc.push_back(d); jt.k.push_back(K); banded_t.push_back(t);
-        } else { rest.desc.push_back(d); rest.k.push_back(pb.k[t]); }
-      }
+      });
+      for (uint32_t t = 0; t < nt; ++t)
+        if (jt.k[t] == 0) { rest.desc.push_back(pb.desc[t]); rest.k.push_back(pb.k[t]); }
+      const size_t nb16 = nt - rest.desc.size();
       if ((rc = run_band16(ctx, jt, &p, static_cast<int32_t*>(d_scoreK[k]), nullptr, static_cast<uint8_t*>(d_opsK[k]), d_offK, static_cast<uint32_t*>(d_lenK[k])))) return rc;
-      if (!banded_t.empty()) {
+      if (nb16) {
         std::vector<int32_t> h_sc(nt);
         std::vector<uint32_t> h_ol(nt);
         HIP_TRY(hipMemcpyAsync(h_sc.data(), d_scoreK[k], sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(h_ol.data(), d_lenK[k], sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         uint32_t nfail = 0;
-        for (uint32_t t : banded_t)
-          if (h_sc[t] != h_s1[t] || h_ol[t] == 0) {
+        for (uint32_t t = 0; t < nt; ++t)
+          if (jt.k[t] && (h_sc[t] != h_s1[t] || h_ol[t] == 0)) {
             if (getenv("TRACYHIP_HOST_TIMERS") && nfail < 6)
               fprintf(stderr, "  fail t=%u m=%u n=%u S1=%d got=%d len=%u g=%lld ends=(%u,%u) ri=%u rc=%d\n", t, pb.desc[t].m, pb.desc[t].n, h_s1[t], h_sc[t], h_ol[t],
                       (long long)gap_of[t], h_ends[2 * t], h_ends[2 * t + 1], h_trimA[k][t].ri, (int)h_rc[t]);
             rest.desc.push_back(pb.desc[t]); rest.k.push_back(pb.k[t]); ++nfail;
           }
-        if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "decompose allele %d: %zu of %u slices banded, %u repeated\n", k, banded_t.size(), nt, nfail);
+        if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "decompose allele %d: %zu of %u slices banded, %u repeated\n", k, nb16, nt, nfail);
       }
     }
     if ((rc = run_dp(ctx, h_ends.empty() ? pb : rest, &p, false, true, static_cast<int32_t*>(d_scoreK[k]), static_cast<uint8_t*>(d_opsK[k]), d_offK,
@@ -1971,7 +1990,6 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     DpProblem rest;
     rest.mode = pb.mode; rest.d_a1 = pb.d_a1; rest.d_a2 = pb.d_a2; rest.cq_codes = pb.cq_codes;
     const bool b16g = use_cq && !td_pri.empty() && pglobal.ge < 0 && pglobal.go <= 0 && getenv("TRACYHIP_NO_BAND16") == nullptr;
-    std::vector<uint32_t> banded_t;
     std::vector<int64_t> bound_of(nt, 0);
     if (b16g) {
       std::vector<int32_t> h_a[2] = {std::vector<int32_t>(nt), std::vector<int32_t>(nt)};
@@ -1979,7 +1997,10 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       HIP_TRY(hipStreamSynchronize(st));
       jg.kind = 0; jg.d_qp = static_cast<const int16_t*>(ctx->d_b16tab[0].p); jg.d_codes = d_cq_sd;
       const int64_t best = std::max<int64_t>(std::max<int64_t>(pglobal.match, pglobal.mismatch), 0), age = -(int64_t)pglobal.ge, ago = -(int64_t)pglobal.go;
-      for (uint32_t t = 0; t < nt; ++t) {
+      jg.desc.resize(nt);
+      jg.k.assign(nt, 0);
+      parallel_for(nt, [&](uint32_t lo_, uint32_t hi_, uint32_t) {
+       for (uint32_t t = lo_; t < hi_; ++t) {
         PairDesc d = pb.desc[t];
         int K = 0;
         int32_t dlo = 0, dhi = 0;
@@ -1997,21 +2018,26 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
         }
         if (K) {
           d.a1_off = td_pri[t].out_off; d.a1_stride = td_pri[t].stride; d.ckpt_off = band_pack(dlo, dhi); d.lastrow_off = 0;
-          jg.desc.push_back(d); jg.k.push_back(K); banded_t.push_back(t);
-        } else { rest.desc.push_back(d); rest.k.push_back(pb.k[t]); }
-      }
+          jg.desc[t] = d;
+          jg.k[t] = K;
+        }
+       }
+      });
+      for (uint32_t t = 0; t < nt; ++t)
+        if (jg.k[t] == 0) { rest.desc.push_back(pb.desc[t]); rest.k.push_back(pb.k[t]); }
+      const size_t nb16 = nt - rest.desc.size();
       HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
       if ((rc = run_band16(ctx, jg, &pglobal, static_cast<int32_t*>(d_scoreK[2]), nullptr, static_cast<uint8_t*>(d_opsK[2]), d_offK, static_cast<uint32_t*>(d_lenK[2])))) return rc;
-      if (!banded_t.empty()) {
+      if (nb16) {
         std::vector<int32_t> h_sc(nt);
         std::vector<uint32_t> h_ol(nt);
         HIP_TRY(hipMemcpyAsync(h_sc.data(), d_scoreK[2], sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(h_ol.data(), d_lenK[2], sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         uint32_t nfail = 0;
-        for (uint32_t t : banded_t)
-          if ((int64_t)h_sc[t] <= bound_of[t] || h_ol[t] == 0) { rest.desc.push_back(pb.desc[t]); rest.k.push_back(pb.k[t]); ++nfail; }
-        if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "decompose allele 1 vs 2: %zu of %u pairs banded, %u repeated\n", banded_t.size(), nt, nfail);
+        for (uint32_t t = 0; t < nt; ++t)
+          if (jg.k[t] && ((int64_t)h_sc[t] <= bound_of[t] || h_ol[t] == 0)) { rest.desc.push_back(pb.desc[t]); rest.k.push_back(pb.k[t]); ++nfail; }
+        if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "decompose allele 1 vs 2: %zu of %u pairs banded, %u repeated\n", nb16, nt, nfail);
       }
     }
     if ((rc = run_dp(ctx, b16g ? rest : pb, &pglobal, false, true, static_cast<int32_t*>(d_scoreK[2]), static_cast<uint8_t*>(d_opsK[2]), d_offK,

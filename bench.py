@@ -131,7 +131,7 @@ def stub_rank(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", default="all", choices=("all", "align", "decompose", "allpairs", "seedextend"),
+    ap.add_argument("--workload", default="all", choices=("all", "align", "decompose", "allpairs", "seedextend", "cli"),
                     help="all: the align headline + the decompose and all-pairs legs; one name: that workload alone (profiling)")
     ap.add_argument("--decompose-traces", type=int, default=100000, help="configs[2]: traces of the whole decompose job (sharded over the ranks)")
     ap.add_argument("--decompose-steps", type=int, default=3)
@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--allpairs-steps", type=int, default=3)
     ap.add_argument("--seedextend-traces", type=int, default=20000, help="configs[3] in miniature: traces of the seed + extend job (sharded over the ranks)")
     ap.add_argument("--seedextend-steps", type=int, default=2)
+    ap.add_argument("--cli-traces", type=int, default=2000, help="the CLI leg: ABIF files per command (`align --batch`, `decompose --batch`); 0 = skip")
     ap.add_argument("--extra-legs", type=int, default=1, help="decompose: also time the strand-certificate and two-lane legs")
     ap.add_argument("--stub", action="store_true", help="launcher self-test on gloo with a step that does no device work (not a measurement)")
     ap.add_argument("--steps", type=int, default=10)
@@ -180,8 +181,12 @@ def main():
 
     def run_extra(which):
         """configs[2] / configs[4] legs (tools/legs.py); a failing leg reports its error instead of taking the headline down"""
-        from tools.legs import AllPairsLeg, DecomposeLeg, SeedExtendLeg
+        from tools.legs import AllPairsLeg, CliLeg, DecomposeLeg, SeedExtendLeg
         try:
+            if which == "cli":  # the product end to end; rank 0 only (the CLI shards over GPUs itself with -d)
+                if rank != 0 or args.cli_traces <= 0:
+                    return None
+                return CliLeg(args.cli_traces, rank, world, dev).run(dist, cpu_sample=320 if args.cpu_sample != 0 else 0)
             if which == "seedextend":
                 leg = SeedExtendLeg(args.seedextend_traces, 20.0, 1000, rank, world, dev)
                 res = leg.run(dist, args.seedextend_steps, 1, cpu_sample=64 if args.cpu_sample != 0 else 0)
@@ -201,7 +206,7 @@ def main():
             return {"error": "%s: %s" % (type(e).__name__, e)}
 
     extra = {}
-    if args.workload in ("decompose", "allpairs", "seedextend"):
+    if args.workload in ("decompose", "allpairs", "seedextend", "cli"):
         extra[args.workload] = run_extra(args.workload)
         if rank == 0:
             line = extra[args.workload]
@@ -339,7 +344,7 @@ def main():
         ctx.close()
         del d_refs, d_profs, r_ops
         torch.cuda.empty_cache()
-        for which in ("decompose", "allpairs", "seedextend"):
+        for which in ("decompose", "allpairs", "seedextend", "cli"):
             extra[which] = run_extra(which)
 
     if rank != 0:
@@ -374,6 +379,12 @@ def main():
             traffic_src = "profiles/%s (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE of this command, same batch)" % os.path.basename(pmc_file)
     except (OSError, ValueError, KeyError, IndexError):
         pass
+    band_traffic, band_traffic_src = None, None
+    try:
+        from tools.legs import pmc_traffic
+        band_traffic, band_traffic_src = pmc_traffic("band16_kernel", "r[0-9][0-9]_pmc_hbm.json")
+    except Exception:  # noqa: BLE001
+        pass
     roofline = {"bound": "hbm", "kernel": "gotoh_ckpt_kernel<K,QP,narrow> (score-only Gotoh, forward + reverse-complement orientation in one launch, row m kept; dominant: %.0f%% of the step)"
                 % (100.0 * sc["ms"] / steps / (elapsed_max / steps * 1e3)),
                 "achieved": round(gbs(sc), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs(sc) / HBM_PEAK_GBS, 5),
@@ -382,18 +393,21 @@ def main():
                 "valu": {"achieved": round(kgcups(sc) * ops_per_cell / 1e3, 2), "peak": 78.6, "unit": "T lane-ops/s",
                          "frac": round(kgcups(sc) * ops_per_cell / 1e3 / 78.6, 3),
                          "note": "integer DP is VALU-issue bound; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"},
-                # the traceback kernel (0.5 B per cell of traceback nibbles) runs for the final alignments: on the certified diagonal band
-                "traceback_kernel": {"kernel": "gotoh_kernel<K,QP,TRACE> (traceback of the final alignments on the certified diagonal band, whole matrix where a pair does not certify; cells and bytes credited are the whole matrices'; the workgroup walks its own pair)",
+                # the final alignments run on the band kernels (band16.h): a certified diagonal band per pair, four pairs per wave; cells and
+                # bytes are those of the band (strips x window steps x K cells, K/2 bytes of trace nibbles per strip and step), not the matrix
+                "traceback_kernel": {"kernel": "band16_kernel<K,0> (traceback of the final alignments on their certified diagonal bands, sixteen lanes per pair, the pair's lanes walk it; cells / bytes credited: the band's)",
                                      "achieved": round(gbs(tr), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(gbs(tr) / HBM_PEAK_GBS, 4), "kernel_gcups": round(kgcups(tr), 1),
                                      "avg_launch_ms": round(tr["ms"] / max(tr["launches"], 1), 3),
-                                     "algorithmic_bytes_per_launch": tr["bytes"] // max(tr["launches"], 1)},
+                                     "algorithmic_bytes_per_launch": tr["bytes"] // max(tr["launches"], 1),
+                                     "swept_cells_per_launch": tr["cells"] // max(tr["launches"], 1),
+                                     "traffic": band_traffic, "traffic_source": band_traffic_src},
                 "ms_per_step": {"score": round(sc["ms"] / steps, 3), "preliminary_ends": round(og["ms"] / steps, 3),
                                 "band_traceback": round(bd["ms"] / steps, 3), "full_traceback": round(tr["ms"] / steps, 3),
                                 "walk": round(rl["walk"]["ms"] / steps, 3)},
                 # the preliminary alignment (trimmed trace vs the whole window) is only trimmed from: its two ends come from an
                 # origin-tracking sweep over the sub-window the score sweep certifies (band traceback where that does not apply)
-                "preliminary_alignment": {"kernel": "gotoh_origin_kernel<K,QP> on the certified sub-window" if og["ms"] > 0 else "gotoh_band_kernel<K,QP>",
+                "preliminary_alignment": {"kernel": "band16_kernel<K,1> (origin-tracking sweep on the band the score allows inside the certified sub-window)" if og["ms"] > 0 else "gotoh_band_kernel<K,QP>",
                                           "swept_gcups": round(kgcups(og if og["ms"] > 0 else bd), 1),
                                           "swept_fraction_of_its_matrix": round((og["cells"] + bd["cells"]) / steps / max(mt * n * nt, 1), 3),
                                           "effective_gcups_over_the_matrix": round(mt * n * nt * steps / ((og["ms"] + bd["ms"]) * 1e-3) / 1e9, 1) if (og["ms"] + bd["ms"]) > 0 else 0.0}}
@@ -411,10 +425,10 @@ def main():
         # GCUPS counts the DP cells of the reference's four Gotoh calls per trace: two score-only sweeps and
         # the final traceback are swept in full; the preliminary traceback is a band traceback from the score sweep's
         # checkpoints, which re-sweeps only the bands its path crosses (about an eighth of its matrix) for the same `btr`
-        "cells_counted": "reference DP cells: 3 x (mt x n) + mf x slice per trace; the preliminary alignment sweeps ~10% of its mt x n (certified sub-window)",
-        # the same step priced by the cells the kernels really evaluated (HIP-event timers: both orientation sweeps and the final
-        # traceback in full, the band traceback only its re-swept bands): what `value` would be if the band traceback were not credited
-        # with its whole matrix
+        "cells_counted": "reference DP cells: 3 x (mt x n) + mf x slice per trace; the preliminary and the final alignment sweep certified diagonal bands of their matrices",
+        # the same step priced by the cells the kernels really evaluated (HIP-event timers: both orientation sweeps in full, the
+        # preliminary and the final alignment on their bands): what `value` would be if no stage were credited with a whole matrix it
+        # did not sweep
         "gcups_swept_cells": round(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin")) / steps * world / (elapsed_max / steps) / 1e9, 2),
         "cells_swept_per_step_rank0": int(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin")) / steps),
         "roofline": roofline,

@@ -228,8 +228,8 @@ class DecomposeLeg:
         dom = max((k for k, _ in TIMERS), key=lambda k: timers[k]["ms"])
         names = {"score": ("gotoh_ckpt_kernel<K,QP|CQ,narrow> (16-bit sweeps: the two orientation scores of the trace, and the score + row-m end of "
                            "each allele vs its window, which certify the sub-window of the origin-tracking sweep)", 8.0, "gotoh_ckpt_kernel"),
-                 "origin": ("gotoh_origin_kernel<K> (gotoh(allele, window) whose alignment only trimReferenceSlice reads, on the certified sub-window)", 11.0, "gotoh_origin_kernel"),
-                 "trace": ("gotoh_kernel<K,MODE,TRACE> (full-matrix tracebacks: allele vs trimmed slice, primary vs secondary)", 14.0, "gotoh_kernel"),
+                 "origin": ("band16_kernel<K,1> (gotoh(allele, window) whose alignment only trimReferenceSlice reads: origin-tracking sweep on the band its score allows)", 11.0, "band16_kernel"),
+                 "trace": ("band16_kernel<K,0> (tracebacks on diagonal bands, four pairs per wave: trimmed trace vs window, allele vs trimmed slice, allele 1 vs allele 2; cells / bytes: the bands')", 14.0, "band16_kernel"),
                  "band": ("gotoh_band_kernel<K,QP> (band traceback of the trimmed trace)", 14.0, "gotoh_band_kernel"),
                  "walk": ("gotoh_walk_kernel", None, "gotoh_walk_kernel"), "prefix": ("gotoh_prefix_kernel", 8.0, "gotoh_prefix_kernel"),
                  "decompose": ("decompose_kernel (decomposeAlleles, decompose.h:179-376)", None, "decompose_kernel"),
@@ -549,3 +549,113 @@ class SeedExtendLeg:
                                     "kind": "port", "sample": "%d of the same anchored traces through the oracle's two Gotoh calls + trimReferenceSlice, %.1f s" % (len(pick), cdt)}
             line["parity_checked"] = {"traces": len(pick), "bit_identical": bool(okp)}
         return line
+
+
+# =====================================================================================================================
+class CliLeg:
+    """The product end to end (north star: "the `tracy align` / `decompose` CLI and JSON output stay unchanged ... ABIF parsing,
+    basecalling ... stay on the host"): synthetic ABIF traces + one FASTA window per trace on disk, `tracy_amd_cli align --batch`
+    and `decompose --batch` (sage.h:58-356, indigo.h:42-455: readab abif.h:286-405, basecall :408-511, createProfile, the device
+    pipelines, the .json / .txt / .fa writers of json.h:197-381), wall time of the whole command with the CLI's own split of it
+    (TRACY_AMD_CLI_TIMERS).  The files are written by the build's ABIF writer before the clock starts."""
+
+    def __init__(self, ntraces, rank, world, dev, workdir=None):
+        import tempfile
+        self.nt, self.rank, self.world, self.dev = ntraces, rank, world, dev
+        self.tmp = workdir or tempfile.mkdtemp(prefix="tracy_cli_bench_")
+        self.cli = os.path.join(ROOT, "tracy_amd", "bin", "tracy_amd_cli")
+
+    def make_files(self, cmd, n, mf):
+        from tracy_amd import hostlib
+        d = os.path.join(self.tmp, cmd)
+        os.makedirs(d, exist_ok=True)
+        t0 = time.perf_counter()
+        b = hostlib.synth_decompose_batch(7000 if cmd == "align" else 8000, self.nt, n, mf, 0, mix=1)
+        rows = []
+        q40 = np.full(mf, 40, np.uint8)
+        for i in range(self.nt):
+            tp = os.path.join(d, "t%06d.ab1" % i)
+            rp = os.path.join(d, "r%06d.fa" % i)
+            hostlib.write_abif(tp, np.minimum(b["signal"][i], 32000), b["bcpos"][i], b"N" * mf, q40)
+            with open(rp, "wb") as f:
+                f.write(b">win%06d\n" % i)
+                f.write(b["refs"][i].tobytes())
+                f.write(b"\n")
+            rows.append("%s\t%s\t%s\n" % (tp, rp, os.path.join(d, "o%06d" % i)))
+        man = os.path.join(d, "manifest.tsv")
+        open(man, "w").write("".join(rows))
+        return man, d, time.perf_counter() - t0, b
+
+    def run_cli(self, cmd, man):
+        import subprocess
+        env = dict(os.environ, TRACY_AMD_CLI_TIMERS="1")
+        t0 = time.perf_counter()
+        p = subprocess.run([self.cli, cmd, "--batch", man, "-d", str(self.dev.index or 0)], capture_output=True, text=True, env=env)
+        dt = time.perf_counter() - t0
+        split = {}
+        for ln in p.stderr.splitlines():
+            if ln.startswith("timers:"):
+                tok = ln.split()[1:]
+                split = {tok[i]: float(tok[i + 1]) for i in range(0, len(tok) - 1, 2)}
+        if p.returncode not in (0, 2):
+            raise RuntimeError("tracy_amd_cli %s --batch failed (%d): %s" % (cmd, p.returncode, p.stderr[-400:]))
+        return dt, split, p.returncode
+
+    def cpu_baseline(self, cmd, b, sample):
+        """the oracle's chain on the same traces from the file on: the reference's own abif.h reader + basecall (oracle/_ref), the
+        oracle's createProfile and its sage.h / indigo.h chain, one trace per thread (writers not included)"""
+        for p_ in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+            if p_ not in sys.path:
+                sys.path.insert(0, p_)
+        from concurrent.futures import ThreadPoolExecutor
+        import pyoracle as orc
+        from bench import usable_cores
+        from indigo_oracle import decompose_trace
+        from sage_oracle import align_trace
+        nthreads = usable_cores()
+        ns_ = min(sample, self.nt)
+
+        def one(i):
+            sig, pos = np.minimum(b["signal"][i], 32000), b["bcpos"][i]
+            pri, sec = orc.basecall(sig, pos, 0.33)[:2]
+            if cmd == "align":
+                prof = orc.create_profile_trace(sig, pos, pri, sec, 0, 0)
+                return align_trace(prof, b["refs"][i].tobytes(), SCORE)["score_final"]
+            return decompose_trace(sig, pos, pri, sec, b["refs"][i].tobytes(), SCORE)["status"]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=nthreads) as ex:
+            list(ex.map(one, range(ns_)))
+        dt = time.perf_counter() - t0
+        return {"value": round(ns_ / dt, 2), "unit": "traces/s", "cores": min(nthreads, ns_), "kind": "port",
+                "sample": "%d of the same traces through the oracle's basecall + createProfile + %s chain (one trace per thread; file parsing and "
+                          "writers not included), %.1f s" % (ns_, "sage.h" if cmd == "align" else "indigo.h", dt)}
+
+    def run(self, dist, cpu_sample=0):
+        import shutil
+        from bench import usable_cores
+        out = {"metric": "traces/s, `tracy_amd_cli --batch` end to end (ABIF files in, JSON / txt / fa files out)", "unit": "traces/s",
+               "n_gpus": 1, "host_threads": usable_cores(), "data": "synthetic ABIF files written by the build's own writer (not timed)",
+               "config": {"workload": "%d traces of 1000 bases per command: `align` vs a 10 kb FASTA window each (configs[1] through the CLI), "
+                                      "`decompose` vs a 3 kb window each (configs[2] through the CLI)" % self.nt}}
+        try:
+            for cmd, n in (("align", 10000), ("decompose", 3000)):
+                man, d, prep_s, b = self.make_files(cmd, n, 1000)
+                dt, split, rc = self.run_cli(cmd, man)
+                written = sum(1 for f in os.listdir(d) if f.endswith(".json"))
+                rec = {"traces_per_s": round(self.nt / dt, 1), "wall_s": round(dt, 3), "split_s": split, "json_files_written": written,
+                       "exit_code": rc, "files_prepared_s": round(prep_s, 1)}
+                if split:
+                    host = split.get("read_basecall_profile_s", 0.0) + split.get("writers_s", 0.0)
+                    rec["host_share_of_the_command"] = round(host / max(dt, 1e-9), 3)
+                    rec["first_bottleneck"] = max((k for k in split if k.endswith("_s")), key=lambda k: split[k])
+                    rec["note"] = ("device_s = packing the batch, tracyhip_*_traces with host buffers (PCIe both ways), unpacking, alignment rows; "
+                                   "gpu_init_s = creating the context (HIP start-up), once per command")
+                if cpu_sample > 0:
+                    rec["cpu_baseline"] = self.cpu_baseline(cmd, b, cpu_sample)
+                out[cmd] = rec
+                del b
+                shutil.rmtree(d, ignore_errors=True)
+            out["value"] = out["align"]["traces_per_s"]
+        finally:
+            shutil.rmtree(self.tmp, ignore_errors=True)
+        return out

@@ -25,6 +25,11 @@
 #include <sstream>
 #include <string>
 #include <sys/stat.h>
+#include <sched.h>
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/tracy_hip.h"
@@ -46,6 +51,7 @@ struct SageConfig {  // sage.h:37-56 + the extra fields of IndigoConfig (indigo.
   std::string outprefix = "out", genome, ab, batch, annotate;
   int device = 0;
   std::string devices = "0";  // -d: one ordinal, a comma-separated list, or "all" (batches are cut into blocks, one per GPU)
+  uint32_t threads = 0;        // --threads: host threads of the --batch stages (read, basecall, profile, writers); 0 = every core this process may use
 };
 
 struct Job {
@@ -67,6 +73,48 @@ struct Job {
   int32_t status = 0;
   tracyhip_decomp_status dstatus{};
   AlleleReport rep;
+};
+
+// cores this process may really use: the affinity mask, capped by the cgroup CPU quota of the container
+uint32_t usable_cores() {
+  uint32_t n = std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = (uint32_t)CPU_COUNT(&set);
+  std::ifstream q("/sys/fs/cgroup/cpu.max");
+  std::string quota;
+  long period = 0;
+  if (q >> quota >> period && quota != "max" && period > 0) {
+    const long cores = std::atol(quota.c_str()) / period;
+    if (cores >= 1 && (uint32_t)cores < n) n = (uint32_t)cores;
+  }
+  return n ? n : 1;
+}
+// fn(i) for i in [0, n) on `threads` host threads (work handed out one index at a time: traces differ in length)
+template <class Fn>
+void for_each_index(uint32_t n, uint32_t threads, Fn fn) {
+  if (threads <= 1 || n <= 1) { for (uint32_t i = 0; i < n; ++i) fn(i); return; }
+  std::atomic<uint32_t> next(0);
+  std::vector<std::thread> th;
+  const uint32_t nth = threads < n ? threads : n;
+  for (uint32_t t = 0; t < nth; ++t)
+    th.emplace_back([&]() { for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); });
+  for (auto& x : th) x.join();
+}
+// TRACY_AMD_CLI_TIMERS=1: one line on stderr with the wall time of the host and device stages of a --batch run
+struct StageTimes {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  std::vector<std::pair<std::string, double>> v;
+  void mark(const char* what) {
+    const auto t1 = std::chrono::steady_clock::now();
+    v.emplace_back(what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  }
+  void report(uint32_t traces, uint32_t threads) const {
+    if (!getenv("TRACY_AMD_CLI_TIMERS")) return;
+    std::cerr << "timers: traces " << traces << " host_threads " << threads;
+    for (auto const& e : v) std::cerr << " " << e.first << " " << e.second;
+    std::cerr << std::endl;
+  }
 };
 
 std::string stamp() {  // boost::posix_time::to_simple_string(second_clock::local_time())
@@ -100,6 +148,7 @@ void usage_options(bool decompose) {
                "  -r [ --reference ] arg           fasta or wildtype ab1 file\n"
                "  -p [ --pratio ] arg (=0.33)      peak ratio to call base\n"
                "  -b [ --batch ] arg               manifest: trace<TAB>reference<TAB>outprefix per line\n"
+               "  --threads arg (=0)               host threads of the --batch stages (0 = all usable cores)\n"
                "  -d [ --device ] arg (=0)         GPU ordinal, a list (0,1,2,3) or all: --batch manifests are cut into\n"
                "                                   contiguous blocks of traces, one per GPU\n";
   if (decompose)
@@ -127,7 +176,7 @@ void usage(const char* cmd) {
 // returns 0 ok, 1 show usage
 int parse(int argc, char** argv, SageConfig& c) {
   static const std::map<std::string, char> longs = {
-      {"help", '?'}, {"reference", 'r'}, {"pratio", 'p'}, {"batch", 'b'}, {"device", 'd'}, {"gapopen", 'g'}, {"gapext", 'e'},
+      {"help", '?'}, {"reference", 'r'}, {"pratio", 'p'}, {"batch", 'b'}, {"device", 'd'}, {"threads", 'T'}, {"gapopen", 'g'}, {"gapext", 'e'},
       {"match", 'm'}, {"mismatch", 'n'}, {"trim", 't'}, {"trimLeft", 'q'}, {"trimRight", 'u'}, {"linelimit", 'l'}, {"outprefix", 'o'},
       {"genome", 'r'}, {"maxindel", 'i'}, {"madc", 'c'}, {"qualCut", 'z'}, {"callVariants", 'v'}, {"annotate", 'a'}, {"kmer", 'k'},
       {"support", 's'}};
@@ -160,6 +209,7 @@ int parse(int argc, char** argv, SageConfig& c) {
       case 'r': c.genome = val; break;
       case 'p': c.pratio = std::strtof(val.c_str(), nullptr); break;
       case 'b': c.batch = val; break;
+      case 'T': c.threads = (uint32_t)std::atoi(val.c_str()); break;
       case 'd': c.devices = val; c.device = std::atoi(val.c_str()); break;
       case 'g': c.gapopen = std::atoi(val.c_str()); break;
       case 'e': c.gapext = std::atoi(val.c_str()); break;
@@ -195,6 +245,8 @@ bool load_trace(std::string const& path, Trace& tr) {
 // (the reference loads the .fm9 written by `tracy index`; here the table is rebuilt in memory, seed.hpp)
 const GenomeIndex* genome_index(SageConfig const& c, std::string const& path) {
   static std::map<std::string, GenomeIndex> cache;
+  static std::mutex mtx;  // (prepare() runs on several threads in --batch mode)
+  std::lock_guard<std::mutex> lock(mtx);
   auto it = cache.find(path);
   if (it != cache.end()) return &it->second;
   std::cout << stamp() << "Load FM-Index" << std::endl;
@@ -520,16 +572,22 @@ int align_main(int argc, char** argv) {
 
   std::cout << stamp() << "Load ab1 file" << std::endl;
   int failed = 0;
-  for (Job& j : jobs) {
-    const int rc = prepare(c, j);
-    if (rc != 0) {
-      if (!batch) return rc;
-      std::cerr << "skipping " << j.trace_path << std::endl;
-      ++failed;
-    } else {
-      j.ok = true;
+  const uint32_t nthreads = batch ? (c.threads ? c.threads : usable_cores()) : 1;
+  StageTimes times;
+  {
+    std::vector<int> rcs(jobs.size(), 0);
+    for_each_index((uint32_t)jobs.size(), nthreads, [&](uint32_t i) { rcs[i] = prepare(c, jobs[i]); });
+    for (size_t i = 0; i < jobs.size(); ++i) {
+      if (rcs[i] != 0) {
+        if (!batch) return rcs[i];
+        std::cerr << "skipping " << jobs[i].trace_path << std::endl;
+        ++failed;
+      } else {
+        jobs[i].ok = true;
+      }
     }
   }
+  times.mark("read_basecall_profile_s");
 
   std::cout << stamp() << "Find reference match" << std::endl;
   Device dev;
@@ -537,6 +595,7 @@ int align_main(int argc, char** argv) {
     gpu_fail("no usable GPU");
     return -1;
   }
+  times.mark("gpu_init_s");
   tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};  // AlignConfig<true,false>, sage.h:165
   std::map<std::pair<uint32_t, uint32_t>, std::vector<Job*>> fasta_groups, seeded_groups;
   std::vector<Job*> wildtype;
@@ -553,9 +612,11 @@ int align_main(int argc, char** argv) {
     if (!align_fasta_group(dev, prm, g.second)) return -1;
   if (!wildtype.empty() && !align_wildtype_group(dev.ctx, prm, wildtype)) return -1;
 
+  times.mark("device_s");
   std::cout << stamp() << "Output" << std::endl;
-  for (Job const& j : jobs)
-    if (j.ok) write_outputs(c, j);
+  for_each_index((uint32_t)jobs.size(), nthreads, [&](uint32_t i) { if (jobs[i].ok) write_outputs(c, jobs[i]); });
+  times.mark("writers_s");
+  times.report((uint32_t)jobs.size(), nthreads);
   std::cout << stamp() << "Done." << std::endl;
   return failed ? 2 : 0;
 }
@@ -833,8 +894,9 @@ void write_decompose_outputs(SageConfig const& c, Job& j) {
   AlignRows const* al[3] = {&r.align1, &r.align2, &r.align3};
   ReferenceSlice const* rs[3] = {&r.rs1, &r.rs2, &secrs};
   for (int k = 0; k < 3; ++k) {
-    std::ofstream f((j.outprefix + ".align" + std::to_string(k + 1)).c_str());
+    TextBuf f;
     plotAlignment(f, *al[k], *rs[k], k + 1, score[k], r.a1a2, c.linelimit);
+    f.to_file(j.outprefix + ".align" + std::to_string(k + 1));
   }
   // the report shows the decomposed basecalls
   BaseCalls bc = j.bc;
@@ -858,8 +920,9 @@ void write_decompose_outputs(SageConfig const& c, Job& j) {
     }
     vcfTextOutput(f, rc, bc, r.var, j.rs, j.rs.filetype == 0 ? &contigs : nullptr);
   }
-  std::ofstream f((j.outprefix + ".json").c_str());
+  TextBuf f(1 << 20);
   traceAlleleAlignJsonOut(f, rc, bc, j.tr, r);
+  f.to_file(j.outprefix + ".json");
 }
 
 int decompose_main(int argc, char** argv) {
@@ -890,22 +953,29 @@ int decompose_main(int argc, char** argv) {
   echo_command(argc, argv);
   std::cout << stamp() << "Load ab1 file" << std::endl;
   int failed = 0;
-  for (Job& j : jobs) {
-    const int rc = prepare(c, j, true);
-    if (rc != 0) {
-      if (!batch) return rc;
-      std::cerr << "skipping " << j.trace_path << std::endl;
-      ++failed;
-    } else {
-      j.ok = true;
+  const uint32_t nthreads = batch ? (c.threads ? c.threads : usable_cores()) : 1;
+  StageTimes times;
+  {
+    std::vector<int> rcs(jobs.size(), 0);
+    for_each_index((uint32_t)jobs.size(), nthreads, [&](uint32_t i) { rcs[i] = prepare(c, jobs[i], true); });
+    for (size_t i = 0; i < jobs.size(); ++i) {
+      if (rcs[i] != 0) {
+        if (!batch) return rcs[i];
+        std::cerr << "skipping " << jobs[i].trace_path << std::endl;
+        ++failed;
+      } else {
+        jobs[i].ok = true;
+      }
     }
   }
+  times.mark("read_basecall_profile_s");
   std::cout << stamp() << "Find Reference Match" << std::endl;
   Device dev;
   if (dev.open(c.devices, 2) != 0) {  // two chunks of a block in flight per GPU (small batches run on one lane)
     gpu_fail("no usable GPU");
     return -1;
   }
+  times.mark("gpu_init_s");
   tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};
   std::map<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>, std::vector<Job*>> groups;  // (reference kind, trims)
   for (Job& j : jobs)
@@ -943,7 +1013,10 @@ int decompose_main(int argc, char** argv) {
     std::cout << stamp() << "Variant Calling" << std::endl;
     if (!call_variants(dev.ctx, prm, good)) return -1;
   }
-  for (Job* j : good) write_decompose_outputs(c, *j);
+  times.mark("device_s");
+  for_each_index((uint32_t)good.size(), nthreads, [&](uint32_t i) { write_decompose_outputs(c, *good[i]); });
+  times.mark("writers_s");
+  times.report((uint32_t)jobs.size(), nthreads);
   std::cout << stamp() << "Done." << std::endl;
   return failed ? 2 : 0;
 }
@@ -1023,7 +1096,7 @@ int basecall_main(int argc, char** argv) {
     return -1;
   }
   if (format == "tsv") {
-    traceTxtOut(outfile, bc, tr, trimLeft, trimRight);
+    traceTxtOut(std::string(outfile), bc, tr, trimLeft, trimRight);
   } else if (format == "fasta" || format == "fastq") {  // traceFastaOut / traceFastqOut, fasta.h:98-155
     std::ofstream f(outfile.c_str());
     std::string const* seq = otype == "primary" ? &bc.primary : otype == "secondary" ? &bc.secondary : otype == "consensus" ? &bc.consensus : nullptr;

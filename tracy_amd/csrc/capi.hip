@@ -506,7 +506,15 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
         uint64_t cells = 0, bytes = 0;
         for (uint32_t q = j; q < e; ++q) {
           const PairDesc& d = hd[q];
-          const uint64_t mn = (uint64_t)(stage == DP_PREFIX ? std::min<uint32_t>(d.m, (uint32_t)kPrefixLanes * K) : d.m) * d.n;
+          uint64_t mn = (uint64_t)(stage == DP_PREFIX ? std::min<uint32_t>(d.m, (uint32_t)kPrefixLanes * K) : d.m) * d.n;
+          if (trace && stage == DP_PLAIN && (d.flags & PAIR_BANDED)) {  // multi-pass band form: the cells its passes sweep, not the matrix
+            mn = 0;
+            for (uint32_t base = 0; base < d.m; base += 64u * K) {
+              const uint32_t rows_here = std::min<uint32_t>(d.m - base, 64u * K);
+              const int64_t c_lo = std::max<int64_t>(1, (int64_t)base + 1 + band_dmin(d)), c_hi = std::min<int64_t>(d.n, (int64_t)(base + rows_here) + band_dmax(d));
+              if (c_hi >= c_lo) mn += (uint64_t)rows_here * (uint64_t)(c_hi - c_lo + 1);
+            }
+          }
           cells += mn;
           bytes += (trace ? mn / 2 : 0) + (pb.a1_profile ? 24ull * d.m : d.m) + (pb.a2_profile ? 24ull * d.n : d.n) + 4;
         }

@@ -15,6 +15,7 @@
 #ifndef TRACY_AMD_INDIGO_OUT_HPP
 #define TRACY_AMD_INDIGO_OUT_HPP
 
+#include "text_buf.hpp"
 #include <ctime>
 
 #include "sage_out.hpp"
@@ -39,7 +40,8 @@ struct ReportConfig {
 
 typedef std::vector<std::pair<int32_t, int32_t>> Decomposition;
 
-inline void writeDecomposition(std::ostream& out, Decomposition const& dcp) {
+template <class Out, typename std::enable_if<!std::is_same<Out, std::string>::value, int>::type = 0>  // (a stream, not a file name)
+inline void writeDecomposition(Out& out, Decomposition const& dcp) {
   out << "indel\tdecomp" << std::endl;
   for (auto const& row : dcp) out << row.first << "\t" << row.second << std::endl;
 }
@@ -134,14 +136,16 @@ inline uint32_t variantCallIndex(ReportConfig const& c, BaseCalls const& bc, boo
   return forward ? (uint32_t)(c.trimLeft + basenum - 1) : (uint32_t)(bc.primary.size() - (c.trimRight + basenum));
 }
 
-inline void metaOut(std::ostream& out, ReportConfig const& c) {  // _metaOut, json.h:17-31
+template <class Out, typename std::enable_if<!std::is_same<Out, std::string>::value, int>::type = 0>  // (a stream, not a file name)
+inline void metaOut(Out& out, ReportConfig const& c) {  // _metaOut, json.h:17-31
   out << "\"meta\": {\"program\": \"tracy\", \"version\": \"" << kTracyVersion << "\", \"arguments\": {\"trimLeft\": " << c.trimLeft
       << ", \"trimRight\": " << c.trimRight << ", \"pratio\": " << c.pratio << ", \"genome\": \"" << c.genomeName << "\", \"input\": \""
       << c.inputName << "\"}}," << std::endl;
 }
 
 // _traceJsonOut, json.h:33-105
-inline void traceJsonBody(std::ostream& out, BaseCalls const& bc, Trace const& tr) {
+template <class Out, typename std::enable_if<!std::is_same<Out, std::string>::value, int>::type = 0>  // (a stream, not a file name)
+inline void traceJsonBody(Out& out, BaseCalls const& bc, Trace const& tr) {
   const int32_t ns = (int32_t)tr.traceACGT[0].size();
   out << "\"pos\": [";
   for (int32_t i = 0; i < ns; ++i) out << (i ? ", " : "") << (i + 1);
@@ -195,7 +199,8 @@ struct AlleleReport {
 };
 
 // traceAlleleAlignJsonOut, json.h:260-381
-inline void traceAlleleAlignJsonOut(std::ostream& out, ReportConfig const& c, BaseCalls const& bc, Trace const& tr, AlleleReport const& r) {
+template <class Out, typename std::enable_if<!std::is_same<Out, std::string>::value, int>::type = 0>  // (a stream, not a file name)
+inline void traceAlleleAlignJsonOut(Out& out, ReportConfig const& c, BaseCalls const& bc, Trace const& tr, AlleleReport const& r) {
   out << "{" << std::endl;
   metaOut(out, c);
   traceJsonBody(out, bc, tr);
@@ -258,7 +263,8 @@ inline void traceAlleleAlignJsonOut(std::ostream& out, ReportConfig const& c, Ba
 // puts into its BCF
 // contigs: (name, length + 1) of every sequence of an indexed genome (rs.filetype == 0, variants.h:176-186); NULL
 // for a single FASTA / wildtype reference, whose one contig line carries rs.refslice.size()
-inline void vcfTextOutput(std::ostream& out, ReportConfig const& c, BaseCalls const& bc, std::vector<Variant> const& var, ReferenceSlice const& rs,
+template <class Out, typename std::enable_if<!std::is_same<Out, std::string>::value, int>::type = 0>  // (a stream, not a file name)
+inline void vcfTextOutput(Out& out, ReportConfig const& c, BaseCalls const& bc, std::vector<Variant> const& var, ReferenceSlice const& rs,
                           std::vector<std::pair<std::string, uint64_t>> const* contigs = nullptr) {
   char date[16];
   std::time_t t = std::time(nullptr);

@@ -17,6 +17,7 @@
 #ifndef TRACY_AMD_SAGE_OUT_HPP
 #define TRACY_AMD_SAGE_OUT_HPP
 
+#include "text_buf.hpp"
 #include <algorithm>
 #include <cctype>
 #include <fstream>
@@ -158,7 +159,8 @@ inline void trimTrace(float trimStringency, BaseCalls const& bc, uint32_t& leftT
 
 // plotAlignment, fmindex.h:329-427.  key 0: ">Alt" vs ">Ref"; 1 / 2: allele 1 / 2 vs reference with the
 // allelic fraction in the header; 3: allele 1 vs allele 2.
-inline void plotAlignment(std::ostream& out, AlignRows const& al, ReferenceSlice const& rs, int32_t key, int32_t score,
+template <class Out, typename std::enable_if<!std::is_same<Out, std::string>::value, int>::type = 0>  // (a stream, not a file name)
+inline void plotAlignment(Out& out, AlignRows const& al, ReferenceSlice const& rs, int32_t key, int32_t score,
                           std::pair<double, double> const& a1a2, uint32_t linelimit) {
   const int64_t cols = (int64_t)al.cols();
   int32_t ri = rs.pos + 1;
@@ -228,8 +230,9 @@ inline void plotAlignment(std::ostream& out, AlignRows const& al, ReferenceSlice
 }
 
 inline void plotAlignment(std::string const& filename, AlignRows const& al, ReferenceSlice const& rs, int32_t score, uint32_t linelimit) {
-  std::ofstream out(filename.c_str());
+  TextBuf out;
   plotAlignment(out, al, rs, 0, score, std::make_pair(0.0, 0.0), linelimit);
+  out.to_file(filename);
 }
 
 // a trace re-sampled along an alignment carries its flanking gap counts (Trace::leadingGaps / trailingGaps)
@@ -299,7 +302,8 @@ inline void alignmentTracePadding(std::string const& row, Trace const& tr, BaseC
 }
 
 // assemblyTrace, json.h:108-194
-inline void assemblyTrace(std::ostream& out, PaddedTrace const& p, std::string const& traceFileName) {
+template <class Out, typename std::enable_if<!std::is_same<Out, std::string>::value, int>::type = 0>  // (a stream, not a file name)
+inline void assemblyTrace(Out& out, PaddedTrace const& p, std::string const& traceFileName) {
   Trace const& tr = p.tr;
   BaseCalls const& bc = p.bc;
   const int32_t ns = (int32_t)tr.traceACGT[0].size();
@@ -349,7 +353,8 @@ inline void assemblyTrace(std::ostream& out, PaddedTrace const& p, std::string c
 }
 
 // traceAlignJsonOut, json.h:197-217
-inline void traceAlignJsonOut(std::ostream& out, PaddedTrace const& p, ReferenceSlice const& rs, AlignRows const& al) {
+template <class Out, typename std::enable_if<!std::is_same<Out, std::string>::value, int>::type = 0>  // (a stream, not a file name)
+inline void traceAlignJsonOut(Out& out, PaddedTrace const& p, ReferenceSlice const& rs, AlignRows const& al) {
   out << "{" << std::endl;
   out << "\"gappedTrace\":" << std::endl;
   assemblyTrace(out, p, "trace");
@@ -363,12 +368,14 @@ inline void traceAlignJsonOut(std::ostream& out, PaddedTrace const& p, Reference
 }
 
 inline void traceAlignJsonOut(std::string const& outfile, PaddedTrace const& p, ReferenceSlice const& rs, AlignRows const& al) {
-  std::ofstream out(outfile.c_str());
+  TextBuf out(1 << 20);
   traceAlignJsonOut(out, p, rs, al);
+  out.to_file(outfile);
 }
 
 // the two-record FASTA of the final alignment, sage.h:328-339
-inline void alignFastaOut(std::ostream& out, std::string const& traceStem, ReferenceSlice const& rs, AlignRows const& al) {
+template <class Out, typename std::enable_if<!std::is_same<Out, std::string>::value, int>::type = 0>  // (a stream, not a file name)
+inline void alignFastaOut(Out& out, std::string const& traceStem, ReferenceSlice const& rs, AlignRows const& al) {
   out << ">" << traceStem << std::endl;
   out << al.row0 << std::endl;
   out << ">" << rs.chr << (rs.forward ? " (forward)" : " (reverse)") << std::endl;

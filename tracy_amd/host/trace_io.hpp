@@ -14,6 +14,7 @@
 #ifndef TRACY_AMD_TRACE_IO_HPP
 #define TRACY_AMD_TRACE_IO_HPP
 
+#include "text_buf.hpp"
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -186,7 +187,8 @@ inline bool readscf(std::string const& filename, Trace& tr) {
 }
 
 // traceTxtOut, abif.h:513-533: one line per sample, basecall columns on called samples
-inline void traceTxtOut(std::ostream& out, BaseCalls const& bc, Trace const& tr, uint32_t leftTrim, uint32_t rightTrim) {
+template <class Out, typename std::enable_if<!std::is_same<Out, std::string>::value, int>::type = 0>  // (a stream, not a file name)
+inline void traceTxtOut(Out& out, BaseCalls const& bc, Trace const& tr, uint32_t leftTrim, uint32_t rightTrim) {
   const uint32_t keep_until = rightTrim < bc.primary.size() ? (uint32_t)bc.primary.size() - rightTrim : 0;
   uint32_t call = 0;
   int32_t next = bc.bcPos[call];
@@ -206,8 +208,9 @@ inline void traceTxtOut(std::ostream& out, BaseCalls const& bc, Trace const& tr,
 }
 
 inline void traceTxtOut(std::string const& outfile, BaseCalls const& bc, Trace const& tr, uint32_t leftTrim, uint32_t rightTrim) {
-  std::ofstream out(outfile.c_str());
+  TextBuf out(48 * tr.traceACGT[0].size() + 4096);
   traceTxtOut(out, bc, tr, leftTrim, rightTrim);
+  out.to_file(outfile);
 }
 
 // ---- the build's own ABIF writer (synthetic traces; layout per SURVEY.md Appendix B) ------------------

@@ -137,7 +137,9 @@ def main():
     ap.add_argument("--decompose-steps", type=int, default=3)
     ap.add_argument("--allpairs-traces", type=int, default=1000, help="configs[4]: traces of the all-pairs job (pair list sharded over the ranks)")
     ap.add_argument("--allpairs-steps", type=int, default=3)
-    ap.add_argument("--seedextend-traces", type=int, default=20000, help="configs[3] in miniature: traces of the seed + extend job (sharded over the ranks)")
+    ap.add_argument("--seedextend-traces", type=int, default=125000,
+                    help="configs[3]: traces PER GPU of the seed + extend job (1M traces over 8 GPUs = 125 000 each; the job is this x the ranks)")
+    ap.add_argument("--seedextend-genome-mb", type=float, default=50.0, help="configs[3]: size of the synthetic genome (GRCh38 chr22 is 50.8 Mb)")
     ap.add_argument("--seedextend-steps", type=int, default=2)
     ap.add_argument("--cli-traces", type=int, default=2000, help="the CLI leg: ABIF files per command (`align --batch`, `decompose --batch`); 0 = skip")
     ap.add_argument("--extra-legs", type=int, default=1, help="decompose: also time the strand-certificate and two-lane legs")
@@ -188,7 +190,7 @@ def main():
                     return None
                 return CliLeg(args.cli_traces, rank, world, dev).run(dist, cpu_sample=320 if args.cpu_sample != 0 else 0)
             if which == "seedextend":
-                leg = SeedExtendLeg(args.seedextend_traces, 20.0, 1000, rank, world, dev)
+                leg = SeedExtendLeg(args.seedextend_traces * world, args.seedextend_genome_mb, 1000, rank, world, dev, dist)
                 res = leg.run(dist, args.seedextend_steps, 1, cpu_sample=64 if args.cpu_sample != 0 else 0)
             elif which == "decompose":
                 leg = DecomposeLeg(args.decompose_traces, 3000, 1000, rank, world, dev)

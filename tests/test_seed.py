@@ -107,3 +107,41 @@ def test_repeat_reads_need_the_second_pass(genome):
     assert (got["status"][0] == 1) == (want is not None)
     if want is not None:
         assert got["slices"][0].decode() == want["refslice"] and int(got["pos"][0]) == want["pos"]
+
+
+def test_index_file_equals_the_in_memory_build(genome, tmp_path):
+    """`tracy index` (index.h:79-124): the table written to a file and mapped back answers every query like the table built in
+    memory from the FASTA -- counts (table and scan paths), getReferenceSlice on a batch of reads -- and a corrupt / truncated / wrong-k
+    file is refused"""
+    import subprocess
+    from tracy_amd import hostlib
+    g, brute, path = genome
+    idx = str(tmp_path / "toy.tidx")
+    g.save(idx)
+    m = hostlib.Genome(idx, 15, 2)
+    rng = np.random.default_rng(9)
+    for _ in range(100):
+        p = int(rng.integers(0, len(brute.text) - 15))
+        pat = brute.text[p:p + 15].encode()
+        assert m.count(pat) == g.count(pat)
+    assert m.count(b"ACGTAC") == g.count(b"ACGTAC")
+    reads = [r.encode() for r in make_reads(rng, brute, 30)]
+    a, b = g.seed(reads, 50, 50, 3, 1000, 2), m.seed(reads, 50, 50, 3, 1000, 2)
+    for k in ("status", "forward", "kmersupport", "pos", "contig"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["slices"] == b["slices"]
+    # the command line writes the same file
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tracy_amd", "bin", "tracy_amd_cli")
+    out = str(tmp_path / "cli.tidx")
+    p = subprocess.run([cli, "index", "-o", out, path], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert open(out, "rb").read() == open(idx, "rb").read()
+    # refused: another k, a truncated file, junk behind the magic
+    with pytest.raises(IOError):
+        hostlib.Genome(idx, 11)
+    blob = open(idx, "rb").read()
+    for bad in (blob[:len(blob) // 2], blob[:8] + b"\xff" * 200, blob[:60]):
+        open(str(tmp_path / "bad.tidx"), "wb").write(bad)
+        with pytest.raises(IOError):
+            hostlib.Genome(str(tmp_path / "bad.tidx"), 15)
+    m.close()

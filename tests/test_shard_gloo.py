@@ -145,3 +145,52 @@ def test_pair_bounds_rule():
         lens = np.arange(50, 50 + n)
         b = pair_bounds(lens, w)
         assert b[0] == 0 and b[-1] == n * (n - 1) // 2 and (np.diff(b) >= 0).all()
+
+
+def _seed_worker(rank, world, port, tmp, ret):
+    """the host side of configs[3] on two ranks: thread share per rank, one index file built by rank 0 and mapped by both"""
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_WORLD_SIZE"] = str(world)
+    os.environ["WORLD_SIZE"] = str(world)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bench import usable_cores
+    from tools.legs import rank_threads
+    from tracy_amd import hostlib
+    from tracy_amd.shard import shard_range
+    threads = rank_threads(world)
+    rng = np.random.default_rng(4)
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=60000)].tobytes()
+    fa, idx = os.path.join(tmp, "g.fa"), os.path.join(tmp, "g.tidx")
+    if rank == 0:
+        open(fa, "wb").write(b">chrSyn\n" + seq + b"\n")
+        g0 = hostlib.Genome(fa, 15, threads)
+        g0.save(idx)
+        g0.close()
+    dist.barrier()
+    g = hostlib.Genome(idx, 15, threads)  # mapped by every rank
+    starts = rng.integers(0, 60000 - 400, size=21)
+    reads = [seq[s:s + 400] for s in starts]
+    lo, hi = shard_range(len(reads), rank, world)
+    got = g.seed(reads[lo:hi], 50, 50, 3, 1000, threads)
+    ret[rank] = dict(threads=threads, usable=usable_cores(), pos=[int(x) for x in got["pos"]], status=[int(x) for x in got["status"]], lo=lo, hi=hi,
+                     starts=[int(x) for x in starts])
+    g.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_mapped_index_and_split_the_host_threads(tmp_path):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_seed_worker, args=(2, port, str(tmp_path), ret), nprocs=2, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert r0["threads"] == r1["threads"] == max(1, r0["usable"] // 2)
+    assert (r0["lo"], r0["hi"], r1["hi"]) == (0, r1["lo"], 21)
+    for r in (r0, r1):
+        assert all(s == 1 for s in r["status"])
+        for k, p in enumerate(r["pos"]):  # window start = locus - maxindel, clipped at the contig start
+            assert p == max(0, r["starts"][r["lo"] + k] - 1000)

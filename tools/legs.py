@@ -22,6 +22,14 @@ FP32_VECTOR_PEAK = 157.3  # TFLOP/s (MI355X_MICROARCH.md), FMA = 2 flops; separa
 TIMERS = (("score", 0), ("trace", 1), ("walk", 2), ("band", 3), ("prefix", 4), ("origin", 5), ("decompose", 6), ("allelic_fraction", 7), ("misc", 8))
 
 
+def rank_threads(world=None):
+    """host threads of this rank: the cores the process may use, divided by the ranks that share the node (every rank of a
+    one-node job runs its host stages -- synthesis, k-mer seeding, the CPU baseline -- at the same time)"""
+    from bench import usable_cores
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", world if world else os.environ.get("WORLD_SIZE", "1")))
+    return max(1, usable_cores() // max(1, local))
+
+
 def u64(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint64))
 
@@ -128,7 +136,7 @@ class DecomposeLeg:
         nt = self.nt = self.hi - self.lo
         n, mf = ref_len, trace_len
         t0 = time.perf_counter()
-        d = hostlib.synth_decompose_batch(5000 + self.lo, nt, n, mf, 0, mix=1)
+        d = hostlib.synth_decompose_batch(5000 + self.lo, nt, n, mf, rank_threads(world), mix=1)
         self.synth_s = time.perf_counter() - t0
         ns = d["signal"].shape[2]
         keep_host = min(nt, 256)  # the CPU baseline / parity sample reads the first traces from the host copy
@@ -252,7 +260,7 @@ class DecomposeLeg:
             line["strand_by_certificate"] = {"ms_per_step": round(dt_cert / steps * 1e3, 2), "traces_per_s": round(nt_all * steps / dt_cert, 1),
                                              "results_identical_to_headline_leg": bool(same)}
             line["lanes"] = {"lanes": 2, "ms_per_step": round(dt_lanes / steps * 1e3, 2), "traces_per_s": round(nt_all * steps / dt_lanes, 1)}
-        if self.world == 1 and cpu_sample > 0:
+        if cpu_sample > 0:  # (rank 0; at N > 1 on its share of the host cores)
             line.update(self.cpu_baseline(cpu_sample, snap, snap_ops, snap_pri))
         return line
 
@@ -266,7 +274,7 @@ class DecomposeLeg:
         from bench import usable_cores
         h = self.host
         ns_ = min(sample, h["signal"].shape[0])
-        nthreads = usable_cores()
+        nthreads = rank_threads(self.world)
 
         def one(i):
             return decompose_trace(h["signal"][i], h["bcpos"][i], h["primary"][i].tobytes(), h["secondary"][i].tobytes(), h["refs"][i].tobytes(), SCORE)
@@ -312,7 +320,7 @@ class AllPairsLeg:
         from tracy_amd.shard import pair_slice
         self.capi, self.ntr, self.mf, self.rank, self.world, self.dev = capi, ntr, trace_len, rank, world, dev
         # traces tiled over one region, trace i starting at i * step (neighbours overlap; the DP cost does not depend on it)
-        refs, profs, rev = hostlib.synth_align(9000, ntr, 2 * trace_len + 200, trace_len, 0)
+        refs, profs, rev = hostlib.synth_align(9000, ntr, 2 * trace_len + 200, trace_len, rank_threads(world))
         self.profs = np.ascontiguousarray(profs)
         self.lens = np.full(ntr, trace_len, np.uint32)
         i1, i2, self.bounds = pair_slice(self.lens, rank, world)
@@ -362,14 +370,13 @@ class AllPairsLeg:
                 "config": {"workload": "configs[4]: %d traces of %d bases, %d pairs, pair list sharded over %d rank(s), profiles replicated, "
                                        "score slices all-gathered" % (self.ntr, mf, self.npairs, self.world), "traces": self.ntr, "trace_len": mf},
                 "data": "synthetic (profiles resident in HBM, index arrays on the host as the ABI defines)", "roofline": roof}
-        if self.world == 1 and cpu_sample > 0:
+        if cpu_sample > 0:  # (rank 0; at N > 1 on its share of the host cores and of the pair list)
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle as orc
             from concurrent.futures import ThreadPoolExecutor
-            from bench import usable_cores
             rng = np.random.default_rng(1)
             pick = rng.choice(len(self.i1), size=min(cpu_sample, len(self.i1)), replace=False)
-            nthreads = usable_cores()
+            nthreads = rank_threads(self.world)
             f = lambda k: orc.gotoh_score_prof(self.profs[self.i1[k]], self.profs[self.i2[k]], 1, 1, SCORE)  # noqa: E731
             t0 = time.perf_counter()
             with ThreadPoolExecutor(max_workers=nthreads) as ex:
@@ -378,7 +385,7 @@ class AllPairsLeg:
             t1 = time.perf_counter()
             f(pick[0])
             c1 = time.perf_counter() - t1
-            got = self.matrix.cpu().numpy()
+            got = self.scores[:len(self.i1)].cpu().numpy()  # this rank's slice of the matrix (the sample indexes it)
             line["cpu_baseline"] = {"value": round(len(pick) * mf * mf / cdt / 1e9, 4), "unit": "GCUPS", "cores": min(nthreads, len(pick)), "kind": "port",
                                     "sample": "%d of the same pairs through the oracle's gotohScore (profile x profile), one pair per thread, %.1f s" % (len(pick), cdt),
                                     "single_thread": {"value": round(mf * mf / c1 / 1e9, 4), "unit": "GCUPS"}}
@@ -388,50 +395,66 @@ class AllPairsLeg:
 
 # =====================================================================================================================
 class SeedExtendLeg:
-    """configs[3] in miniature: `total` 1 kb traces sampled from a synthetic genome (GRCh38 chr22 is not available offline), host
-    k-mer seeding (getReferenceSlice, fmindex.h:236-326, all usable host threads of the rank) + device extend
-    (tracyhip_align_traces with job.oriented: one checkpointed score sweep, band traceback, trimReferenceSlice, final alignment).
-    Traces are sharded over the ranks by contiguous blocks; every rank holds the k-mer table of the whole genome."""
+    """configs[3] at its per-GPU size: `total` 1 kb traces sampled from a synthetic genome (GRCh38 chr22 -- 50.8 Mb -- is not
+    available offline; a random genome of `genome_mb` Mb stands in), host k-mer seeding (getReferenceSlice, fmindex.h:236-326, on this
+    rank's share of the host threads) + device extend (tracyhip_align_traces with job.oriented: one 16-bit score sweep, the
+    preliminary and the final alignment on their bands, trimReferenceSlice).
+    Traces are sharded over the ranks by contiguous blocks.  The k-mer table is built ONCE: rank 0 writes the index file
+    (`tracy index`, seed.hpp GenomeIndex::save), every rank maps it read-only -- one copy in the node's page cache."""
 
-    def __init__(self, total, genome_mb, trace_len, rank, world, dev):
+    def __init__(self, total, genome_mb, trace_len, rank, world, dev, dist=None):
         import tempfile
         import tracy_amd
         from tracy_amd import capi, hostlib
         from tracy_amd.shard import shard_range
         self.capi, self.total, self.mf, self.rank, self.world, self.dev = capi, total, trace_len, rank, world, dev
+        self.threads = rank_threads(world)
         rng = np.random.default_rng(22)  # the same genome and traces on every rank; a rank keeps its block
         n = self.gn = int(genome_mb * 1e6)
         lut = np.frombuffer(b"ACGT", dtype=np.uint8)
         seq = lut[rng.integers(0, 4, size=n, dtype=np.uint8)]
-        self.tmp = tempfile.mkdtemp()
-        gpath = os.path.join(self.tmp, "genome.fa")
-        with open(gpath, "wb") as f:
-            f.write(b">chrSyn\n")
-            f.write(seq.tobytes())
-            f.write(b"\n")
+        shared = os.path.join(tempfile.gettempdir(), "tracy_bench_index_%s_%d" % (os.environ.get("MASTER_PORT", "solo"), os.getppid() if world > 1 else os.getpid()))
+        self.tmp = shared
+        ipath = os.path.join(shared, "genome.tidx")
         t0 = time.perf_counter()
-        self.genome = hostlib.Genome(gpath, 15, 0)
+        if rank == 0:
+            os.makedirs(shared, exist_ok=True)
+            gpath = os.path.join(shared, "genome.fa")
+            with open(gpath, "wb") as f:
+                f.write(b">chrSyn\n")
+                f.write(seq.tobytes())
+                f.write(b"\n")
+            built = hostlib.Genome(gpath, 15, self.threads)
+            built.save(ipath + ".tmp")
+            os.replace(ipath + ".tmp", ipath)
+            built.close()
+            os.remove(gpath)
+        if dist is not None:
+            dist.barrier()
+        self.genome = hostlib.Genome(ipath, 15, self.threads)  # mapped
         self.index_s = time.perf_counter() - t0
+        self.index_bytes = os.path.getsize(ipath)
         lo, hi = shard_range(total, rank, world)
         mf = trace_len
         starts_all = rng.integers(0, n - mf - 50, size=total)
         errs = np.random.default_rng(23 + rank)
         self.starts = starts_all[lo:hi]
         nt = self.nt = hi - lo
-        self.profs = np.zeros((nt, 6, mf), np.float32)
-        self.cons = []
-        comp = bytes.maketrans(b"ACGT", b"TGCA")
+        # traces: every other one reads the reverse strand; 1 % substitutions; peaked profile columns
+        comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+        codes = np.empty((nt, mf), dtype=np.uint8)
+        lut_inv = np.zeros(256, np.uint8)
+        lut_inv[lut] = np.arange(4, dtype=np.uint8)
         for k in range(nt):
-            g = lo + k
-            s = seq[self.starts[k]:self.starts[k] + mf].tobytes()
-            if g % 2:  # every other trace reads the reverse strand
-                s = s[::-1].translate(comp)
-            code = np.searchsorted(lut, np.frombuffer(s, np.uint8))
-            code = np.where(errs.random(mf) < 0.01, (code + 1) % 4, code)  # 1 % substitutions
-            p = self.profs[k]
-            p[:4] = 0.02
-            p[code, np.arange(mf)] = 0.94
-            self.cons.append(lut[code].tobytes())
+            c = lut_inv[seq[self.starts[k]:self.starts[k] + mf]]
+            codes[k] = comp[c[::-1]] if (lo + k) % 2 else c
+        flip = errs.random((nt, mf)) < 0.01
+        codes = np.where(flip, (codes + 1) % 4, codes).astype(np.uint8)
+        self.profs = np.zeros((nt, 6, mf), np.float32)
+        self.profs[:, :4, :] = 0.02
+        np.put_along_axis(self.profs, codes[:, None, :].astype(np.int64), 0.94, axis=1)
+        cons = lut[codes]
+        self.cons = [cons[k].tobytes() for k in range(nt)]
         self.lo = lo
         self.ctx = tracy_amd.Context(dev.index or 0)
         self.CHUNKS = 4
@@ -459,7 +482,7 @@ class SeedExtendLeg:
             for b in range(CH):
                 blo, bhi = self.nt * b // CH, self.nt * (b + 1) // CH
                 ts0 = time.perf_counter()
-                sdb = self.genome.seed(self.cons[blo:bhi], 50, 50, 3, 1000, 0, raw=True)
+                sdb = self.genome.seed(self.cons[blo:bhi], 50, 50, 3, 1000, self.threads, raw=True)
                 step_seed += time.perf_counter() - ts0
                 okb = np.nonzero(sdb["status"] == 1)[0]
                 # packed host buffers as a C caller holds them: the profile block and the padded window block are handed over in
@@ -496,6 +519,12 @@ class SeedExtendLeg:
         dt = time.perf_counter() - t_all
         self.lib.tracyhip_timing_enable(ctx._h, 0)
         timers = read_timers(self.lib, ctx)
+        self.genome.close()  # the mapped index file goes away with the leg
+        if dist is not None:
+            dist.barrier()
+        if self.rank == 0:
+            import shutil
+            shutil.rmtree(self.tmp, ignore_errors=True)
         mf = self.mf
         win_len = sd["slice_len"][ok].astype(np.int64)
         cells = int(((mf - 100) * win_len).sum() * 2 + (mf * res["slice_len"].astype(np.int64)).sum())
@@ -513,14 +542,16 @@ class SeedExtendLeg:
         line = {"metric": "traces/s (host k-mer seeding + device Gotoh extend, end to end)", "value": round(ok_all * steps / dt, 1), "unit": "traces/s",
                 "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "warmup": warmup, "n_gpus": self.world, "scaling": "strong",
                 "seed_traces_per_s": round(nt_all * steps / seed_s, 1),
-                "extend_ms_not_hidden_per_step": round(ext_s / steps * 1e3, 2), "extend_kernel_gcups": round(cells_all * steps / max(sum(timers[k]["ms"] for k in ("score", "trace", "band", "walk")) * 1e-3, 1e-9) / 1e9, 1), "host_threads_per_rank": usable_cores(), "index_build_s": round(self.index_s, 2),
+                "extend_ms_not_hidden_per_step": round(ext_s / steps * 1e3, 2), "extend_kernel_gcups": round(cells_all * steps / max(sum(timers[k]["ms"] for k in ("score", "trace", "band", "walk")) * 1e-3, 1e-9) / 1e9, 1), "host_threads_per_rank": self.threads, "index_build_and_map_s": round(self.index_s, 2), "index_file_mb": round(self.index_bytes / 1e6, 1),
+                "index": "built once (rank 0), written with GenomeIndex::save, mapped read-only by every rank",
                 "anchored": int(ok_all), "traces": int(nt_all), "placed_within_60bp_of_truth": int(placed_all),
                 "dtype": "int16 (score sweep) / int32 (tracebacks); seeding: 2-bit k-mers on the host",
-                "config": {"workload": "configs[3] in miniature: %d traces of %d bases vs a %.0f Mb synthetic genome, k = 15, window = trace + 2 x 1000, "
-                                       "traces sharded over %d rank(s), k-mer table replicated" % (int(nt_all), mf, self.gn / 1e6, self.world)},
+                "config": {"workload": "configs[3] at its per-GPU size: %d traces of %d bases (%d per rank) vs a %.0f Mb synthetic genome (chr22-sized), k = 15, "
+                                       "window = trace + 2 x 1000, traces sharded over %d rank(s), one mapped k-mer table per node"
+                                       % (int(nt_all), mf, int(nt_all) // self.world, self.gn / 1e6, self.world)},
                 "data": "synthetic (GRCh38 chr22 is not available offline); host-staged buffers: upload of profiles / windows and download of results included",
                 "roofline": roof}
-        if self.world == 1 and cpu_sample > 0:
+        if cpu_sample > 0:  # (rank 0; at N > 1 on its share of the host cores)
             for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
                 if p not in sys.path:
                     sys.path.insert(0, p)
@@ -539,7 +570,7 @@ class SeedExtendLeg:
                 ri, risize, pos_add, _ = orc.trim_reference_slice(r0, r1, 50, 50, len(win), bool(sd["forward"][i]))
                 sc2, btr2 = orc.gotoh_prof(prof, orc.create_profile_str(win[ri:ri + risize]), 1, 0, SCORE)
                 return sc2, btr2, pos_add
-            nthreads = usable_cores()
+            nthreads = self.threads
             t0 = time.perf_counter()
             with ThreadPoolExecutor(max_workers=nthreads) as ex:
                 want = list(ex.map(one, pick))

@@ -251,6 +251,22 @@ const GenomeIndex* genome_index(SageConfig const& c, std::string const& path) {
   if (it != cache.end()) return &it->second;
   std::cout << stamp() << "Load FM-Index" << std::endl;
   GenomeIndex& g = cache[path];
+  // an index file (`tracy_amd_cli index`; the reference loads genome.fa.gz.fm9, sage.h:203-207) is mapped; without one the table
+  // is built in memory from the FASTA
+  const std::string stored = GenomeIndex::is_index_file(path) ? path : (GenomeIndex::is_index_file(path + ".tidx") ? path + ".tidx" : std::string());
+  if (!stored.empty()) {
+    if (!g.open_index(stored)) {
+      std::cerr << "Index file is corrupt: " << stored << std::endl;
+      cache.erase(path);
+      return nullptr;
+    }
+    if (g.k != c.kmer) {
+      std::cerr << "The index was built for k-mers of " << g.k << " bases (-k " << c.kmer << " requested)." << std::endl;
+      cache.erase(path);
+      return nullptr;
+    }
+    return &g;
+  }
   if (!g.load(path)) {
     std::cerr << "Couldn't recognize reference file format!" << std::endl;
     cache.erase(path);
@@ -1126,6 +1142,49 @@ int basecall_main(int argc, char** argv) {
   return 0;
 }
 
+// ---- `tracy index` (index.h:36-124): the genome's k-mer table on disk ---------------------------------------------------
+int index_main(int argc, char** argv) {
+  std::string outfile, genome;
+  uint32_t kmer = 15;
+  bool bad = false;
+  for (int i = 1; i < argc && !bad; ++i) {
+    const std::string a = argv[i];
+    auto value = [&](std::string& dst) { if (i + 1 < argc) dst = argv[++i]; else bad = true; };
+    std::string v;
+    if (a == "-o" || a == "--output") value(outfile);
+    else if (a == "-k" || a == "--kmer") { value(v); kmer = (uint32_t)std::atoi(v.c_str()); }
+    else if (a == "-?" || a == "--help") bad = true;
+    else if (!a.empty() && a[0] == '-') bad = true;
+    else genome = a;
+  }
+  if (bad || genome.empty() || kmer < 1 || kmer > 32) {
+    std::cout << "Usage: tracy index [OPTIONS] genome.fa.gz" << std::endl;
+    std::cout << "  -o [ --output ] arg      output file (default: <genome>.tidx, found by align / decompose -r <genome>)" << std::endl;
+    std::cout << "  -k [ --kmer ] arg (=15)  k-mer size of the table (align / decompose -k must match)" << std::endl;
+    return -1;
+  }
+  if (!regular_nonempty(genome)) {
+    std::cerr << "Input reference file is missing: " << genome << std::endl;
+    return 1;
+  }
+  if (outfile.empty()) outfile = genome + ".tidx";
+  echo_command(argc, argv);
+  std::cout << stamp() << "Load genome" << std::endl;
+  GenomeIndex g;
+  if (!g.load(genome)) {
+    std::cerr << "Couldn't recognize reference file format!" << std::endl;
+    return 1;
+  }
+  std::cout << stamp() << "Create index" << std::endl;
+  g.build(kmer);
+  if (!g.save(outfile)) {
+    std::cerr << "Cannot write " << outfile << std::endl;
+    return 1;
+  }
+  std::cout << stamp() << "Done." << std::endl;
+  return 0;
+}
+
 #include "assemble_cli.inc"
 #include "consensus_cli.inc"
 
@@ -1137,10 +1196,12 @@ int main(int argc, char** argv) {
   if (argc >= 2 && std::strcmp(argv[1], "assemble") == 0) return assemble_main(argc - 1, argv + 1);
   if (argc >= 2 && std::strcmp(argv[1], "basecall") == 0) return basecall_main(argc - 1, argv + 1);
   if (argc >= 2 && std::strcmp(argv[1], "consensus") == 0) return consensus_main(argc - 1, argv + 1);
+  if (argc >= 2 && std::strcmp(argv[1], "index") == 0) return index_main(argc - 1, argv + 1);
   std::cout << "Usage: tracy_amd_cli align|decompose [OPTIONS] -r genome.fa trace.ab1" << std::endl;
   std::cout << "       tracy_amd_cli align|decompose [OPTIONS] --batch manifest.tsv" << std::endl;
   std::cout << "       tracy_amd_cli assemble [OPTIONS] [-r reference.fa] trace1.ab1 trace2.ab1 ..." << std::endl;
   std::cout << "       tracy_amd_cli basecall [OPTIONS] trace.ab1" << std::endl;
   std::cout << "       tracy_amd_cli consensus [OPTIONS] trace1.ab1 trace2.ab1" << std::endl;
+  std::cout << "       tracy_amd_cli index [-o genome.tidx] [-k 15] genome.fa.gz" << std::endl;
   return argc < 2 ? 0 : 1;
 }

@@ -66,6 +66,7 @@ inline int32_t genomeType(std::string const& path) {
   in.read(magic, 4);
   in.close();
   if ((uint8_t)magic[0] == 0x1f && (uint8_t)magic[1] == 0x8b) return 0;
+  if (magic[0] == 'T' && magic[1] == 'A' && magic[2] == 'M' && magic[3] == 'D') return 0;  // an index written by `tracy_amd_cli index` (seed.hpp)
   if (traceFormat(path) >= 0) return 2;
   if (magic[0] == '>') return 1;
   return -1;

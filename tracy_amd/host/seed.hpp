@@ -12,10 +12,17 @@
 // exact occurrences of a pattern in that text -- from a sorted k-mer table built in memory (any exact index
 // gives identical hit sets; the hits are sorted before use, fmindex.h:180).  PARITY UNPINNED (no sdsl, no
 // reference tests); tests/ cross-check against a brute-force search.
+// `tracy index` (index.h:79-124) has its counterpart in GenomeIndex::save / open_index: the text, the contig table, the
+// bucket directory and the sorted table go to one file (magic TAMDIDX1, sections 8-byte aligned) which later runs -- and
+// every rank of a multi-process job on the node -- map read-only instead of rebuilding the table (the page cache holds one copy).
 // Sequence lengths follow the reference's convention seqlen = contig length + 1 (the separator).
 #ifndef TRACY_AMD_SEED_HPP
 #define TRACY_AMD_SEED_HPP
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -46,10 +53,28 @@ inline unsigned usable_threads() {
   return n;
 }
 
+// the genome text as the index sees it: owned (built from a FASTA) or a view of a mapped index file
+class TextView {
+ public:
+  const char* p = nullptr;
+  std::size_t n = 0;
+  std::size_t size() const { return n; }
+  char operator[](std::size_t i) const { return p[i]; }
+  std::string substr(std::size_t pos, std::size_t len = std::string::npos) const {
+    if (pos > n) pos = n;
+    return std::string(p + pos, std::min(len, n - pos));
+  }
+  std::size_t find(std::string const& pat, std::size_t from = 0) const {
+    if (pat.empty() || from >= n || pat.size() > n - from) return std::string::npos;
+    const void* hit = memmem(p + from, n - from, pat.data(), pat.size());
+    return hit ? (std::size_t)(static_cast<const char*>(hit) - p) : std::string::npos;
+  }
+};
+
 class GenomeIndex {
  public:
   // upper-cased contigs joined by '\n' (the "dump" text of index.h:101-116), one trailing '\n'
-  std::string text;
+  TextView text;
   std::vector<std::string> names;   // faidx_iseq: header up to the first whitespace
   std::vector<uint32_t> lengths;    // contig lengths
   std::vector<uint64_t> starts;     // offset of contig i in `text`
@@ -59,6 +84,8 @@ class GenomeIndex {
   bool load(std::string const& path) {
     gzFile f = gzopen(path.c_str(), "rb");
     if (!f) return false;
+    unmap();
+    std::string& text = owned_text_;  // (built here, viewed through `text` afterwards)
     text.clear(); names.clear(); lengths.clear(); starts.clear();
     std::string line;
     char buf[1 << 16];
@@ -88,13 +115,18 @@ class GenomeIndex {
     if (first) return false;
     lengths.push_back((uint32_t)(text.size() - starts.back()));
     text.push_back('\n');
+    this->text.p = owned_text_.data();
+    this->text.n = owned_text_.size();
     return true;
   }
 
   // table of every k-mer over ACGT (k <= 32), sorted by code then position
   void build(uint32_t kmer, uint32_t nthreads = 0) {
     k = kmer;
+    std::vector<Entry>& table_ = owned_table_;
+    std::vector<uint64_t>& bucket_ = owned_bucket_;
     table_.clear();
+    tab_ = nullptr; ntab_ = 0; bkt_ = nullptr;
     if (k == 0 || k > 32 || text.size() < k) return;
     const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     uint64_t code = 0;
@@ -114,24 +146,107 @@ class GenomeIndex {
     bucket_.assign(((std::size_t)1 << bucket_bits_) + 1, 0);
     for (Entry const& e : table_) ++bucket_[(std::size_t)(e.code >> shift) + 1];
     for (std::size_t b = 1; b < bucket_.size(); ++b) bucket_[b] += bucket_[b - 1];
+    tab_ = table_.data(); ntab_ = table_.size(); bkt_ = bucket_.data();
   }
+
+  // ---- persistence: `tracy index` (index.h:79-124) -------------------------------------------------------------
+  // header: magic[8] "TAMDIDX1", u32 k, u32 bucket_bits, u64 text bytes, u64 table entries, u64 contigs, u64 names bytes; then
+  // (each padded to 8 bytes) text, names ('\0'-separated), lengths u32[], starts u64[], bucket u64[2^bits + 1], table {code, pos}[]
+  bool save(std::string const& path) const {
+    if (k == 0 || !tab_ || !bkt_) return false;
+    std::FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    std::string nm;
+    for (auto const& x : names) { nm += x; nm.push_back('\0'); }
+    const uint64_t hdr[6] = {((uint64_t)bucket_bits_ << 32) | k, text.size(), ntab_, names.size(), nm.size(), 0};
+    bool ok = std::fwrite("TAMDIDX1", 1, 8, f) == 8 && std::fwrite(hdr, sizeof(hdr), 1, f) == 1;
+    auto put = [&](const void* p, std::size_t bytes) {
+      static const char zero[8] = {0};
+      ok = ok && (bytes == 0 || std::fwrite(p, 1, bytes, f) == bytes);
+      const std::size_t pad = (8 - bytes % 8) % 8;
+      ok = ok && (pad == 0 || std::fwrite(zero, 1, pad, f) == pad);
+    };
+    put(text.p, text.size());
+    put(nm.data(), nm.size());
+    put(lengths.data(), lengths.size() * sizeof(uint32_t));
+    put(starts.data(), starts.size() * sizeof(uint64_t));
+    put(bkt_, (((std::size_t)1 << bucket_bits_) + 1) * sizeof(uint64_t));
+    put(tab_, ntab_ * sizeof(Entry));
+    return std::fclose(f) == 0 && ok;
+  }
+  static bool is_index_file(std::string const& path) {
+    std::FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char m[8] = {0};
+    const bool ok = std::fread(m, 1, 8, f) == 8 && std::memcmp(m, "TAMDIDX1", 8) == 0;
+    std::fclose(f);
+    return ok;
+  }
+  // map an index file written by save(); every section is checked against the file size
+  bool open_index(std::string const& path) {
+    unmap();
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 56) { ::close(fd); return false; }
+    void* m = mmap(nullptr, (std::size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) return false;
+    map_ = m; map_bytes_ = (std::size_t)st.st_size;
+    const char* base = static_cast<const char*>(m);
+    uint64_t hdr[6];
+    std::memcpy(hdr, base + 8, sizeof(hdr));
+    if (std::memcmp(base, "TAMDIDX1", 8) != 0) { unmap(); return false; }
+    k = (uint32_t)hdr[0]; bucket_bits_ = (uint32_t)(hdr[0] >> 32);
+    const uint64_t tbytes = hdr[1], nt = hdr[2], nc = hdr[3], nmb = hdr[4];
+    if (k == 0 || k > 32 || bucket_bits_ > 24 || bucket_bits_ > 2 * k) { unmap(); return false; }
+    std::size_t at = 56;
+    auto take = [&](uint64_t bytes) -> const char* {
+      if (bytes > map_bytes_ || at > map_bytes_ - bytes) return nullptr;
+      const char* p = base + at;
+      at += (std::size_t)((bytes + 7) & ~7ull);
+      return p;
+    };
+    const char* ptext = take(tbytes);
+    const char* pnm = take(nmb);
+    const char* plen = take(nc * sizeof(uint32_t));
+    const char* pst = take(nc * sizeof(uint64_t));
+    const char* pb = take((((uint64_t)1 << bucket_bits_) + 1) * sizeof(uint64_t));
+    const char* pt = take(nt * sizeof(Entry));
+    if (!ptext || !pnm || !plen || !pst || !pb || !pt || at > map_bytes_ + 7) { unmap(); return false; }
+    text.p = ptext; text.n = (std::size_t)tbytes;
+    names.clear(); lengths.assign(reinterpret_cast<const uint32_t*>(plen), reinterpret_cast<const uint32_t*>(plen) + nc);
+    starts.assign(reinterpret_cast<const uint64_t*>(pst), reinterpret_cast<const uint64_t*>(pst) + nc);
+    for (std::size_t i = 0, b = 0; i < nmb && names.size() < nc; ++i)
+      if (pnm[i] == '\0') { names.emplace_back(pnm + b, i - b); b = i + 1; }
+    if (names.size() != nc) { unmap(); return false; }
+    bkt_ = reinterpret_cast<const uint64_t*>(pb);
+    tab_ = reinterpret_cast<const Entry*>(pt);
+    ntab_ = (std::size_t)nt;
+    if (bkt_[(std::size_t)1 << bucket_bits_] != ntab_) { unmap(); return false; }
+    return true;
+  }
+  ~GenomeIndex() { unmap(); }
+  GenomeIndex() = default;
+  GenomeIndex(GenomeIndex const&) = delete;
+  GenomeIndex& operator=(GenomeIndex const&) = delete;
 
   // table range of one k-mer code (k-mers over ACGT only)
   void code_range(uint64_t code, std::size_t& lo, std::size_t& hi) const {
     const std::size_t b = (std::size_t)(code >> (2 * k - bucket_bits_));
-    std::size_t i = bucket_[b];
-    const std::size_t e = bucket_[b + 1];
-    while (i < e && table_[i].code < code) ++i;  // buckets hold a handful of entries
+    std::size_t i = bkt_[b];
+    const std::size_t e = bkt_[b + 1];
+    while (i < e && tab_[i].code < code) ++i;  // buckets hold a handful of entries
     lo = i;
-    while (i < e && table_[i].code == code) ++i;
+    while (i < e && tab_[i].code == code) ++i;
     hi = i;
   }
-  uint64_t position(std::size_t i) const { return table_[i].pos; }
+  uint64_t position(std::size_t i) const { return tab_[i].pos; }
   // cache warm-up for a batch of look-ups: the directory slot first, then (once that is in cache) the table run
-  void prefetch_slot(uint64_t code) const { __builtin_prefetch(&bucket_[(std::size_t)(code >> (2 * k - bucket_bits_))]); }
+  void prefetch_slot(uint64_t code) const { __builtin_prefetch(&bkt_[(std::size_t)(code >> (2 * k - bucket_bits_))]); }
   void prefetch_run(uint64_t code) const {
-    const std::size_t i = bucket_[(std::size_t)(code >> (2 * k - bucket_bits_))];
-    if (i < table_.size()) __builtin_prefetch(&table_[i]);
+    const std::size_t i = bkt_[(std::size_t)(code >> (2 * k - bucket_bits_))];
+    if (i < ntab_) __builtin_prefetch(&tab_[i]);
   }
   static int base_code(char c) { return base2(c); }
 
@@ -145,7 +260,7 @@ class GenomeIndex {
     out.clear();
     std::size_t lo, hi;
     if (range(pat, lo, hi)) {
-      for (std::size_t i = lo; i < hi; ++i) out.push_back(table_[i].pos);
+      for (std::size_t i = lo; i < hi; ++i) out.push_back(tab_[i].pos);
       return;
     }
     scan(pat, &out);
@@ -153,9 +268,21 @@ class GenomeIndex {
 
  private:
   struct Entry { uint64_t code, pos; };
-  std::vector<Entry> table_;
-  std::vector<uint64_t> bucket_;  // table_ index of the first entry of every code prefix
+  std::string owned_text_;
+  std::vector<Entry> owned_table_;
+  std::vector<uint64_t> owned_bucket_;
+  const Entry* tab_ = nullptr;     // the sorted table: owned_table_ or a section of the mapped file
+  std::size_t ntab_ = 0;
+  const uint64_t* bkt_ = nullptr;  // table index of the first entry of every code prefix
   uint32_t bucket_bits_ = 0;
+  void* map_ = nullptr;
+  std::size_t map_bytes_ = 0;
+  void unmap() {
+    if (map_) munmap(map_, map_bytes_);
+    map_ = nullptr; map_bytes_ = 0;
+    if (text.p != owned_text_.data()) { text.p = nullptr; text.n = 0; }
+    tab_ = nullptr; ntab_ = 0; bkt_ = nullptr;
+  }
 
   static int base2(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
 
@@ -169,13 +296,14 @@ class GenomeIndex {
       if (b < 0) return false;
       code = (code << 2) | (uint64_t)b;
     }
+    if (!tab_) return false;
     auto cmp = [](Entry const& e, uint64_t v) { return e.code < v; };
     const std::size_t b = (std::size_t)(code >> (2 * k - bucket_bits_));
-    auto first = std::lower_bound(table_.begin() + bucket_[b], table_.begin() + bucket_[b + 1], code, cmp);
-    auto last = first;
-    while (last != table_.begin() + bucket_[b + 1] && last->code == code) ++last;
-    lo = (std::size_t)(first - table_.begin());
-    hi = (std::size_t)(last - table_.begin());
+    const Entry* first = std::lower_bound(tab_ + bkt_[b], tab_ + bkt_[b + 1], code, cmp);
+    const Entry* last = first;
+    while (last != tab_ + bkt_[b + 1] && last->code == code) ++last;
+    lo = (std::size_t)(first - tab_);
+    hi = (std::size_t)(last - tab_);
     return true;
   }
   std::size_t scan(std::string const& pat, std::vector<uint64_t>* out) const {
@@ -188,6 +316,7 @@ class GenomeIndex {
     return n;
   }
   void sort_table(uint32_t nthreads) {
+    std::vector<Entry>& table_ = owned_table_;
     auto less = [](Entry const& a, Entry const& b) { return a.code < b.code || (a.code == b.code && a.pos < b.pos); };
     if (nthreads <= 1 || table_.size() < (1u << 16)) {
       std::sort(table_.begin(), table_.end(), less);

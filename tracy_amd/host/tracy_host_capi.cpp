@@ -343,12 +343,19 @@ int32_t tracyhost_decompose_outputs(const tracyhost_decompose_report* rp) {
 }
 
 // ---- k-mer seeding in an indexed genome (seed.hpp; fmindex.h:173-326) --------------------------------
+// path: a (gzip-compressed) multi-FASTA -- the table is built in memory -- or an index file written by tracyhost_genome_save
+// (`tracy_amd_cli index`), which is mapped read-only (kmer must be the index's)
 void* tracyhost_genome_open(const char* path, uint32_t kmer, uint32_t nthreads) {
   GenomeIndex* g = new GenomeIndex();
+  if (GenomeIndex::is_index_file(path)) {
+    if (!g->open_index(path) || g->k != kmer) { delete g; return nullptr; }
+    return g;
+  }
   if (!g->load(path)) { delete g; return nullptr; }
   g->build(kmer, nthreads);
   return g;
 }
+int tracyhost_genome_save(const void* h, const char* path) { return static_cast<const GenomeIndex*>(h)->save(path) ? 0 : -1; }
 void tracyhost_genome_free(void* h) { delete static_cast<GenomeIndex*>(h); }
 uint32_t tracyhost_genome_contigs(const void* h) { return (uint32_t)static_cast<const GenomeIndex*>(h)->names.size(); }
 uint64_t tracyhost_genome_count(const void* h, const char* pat, size_t n) { return static_cast<const GenomeIndex*>(h)->count(std::string(pat, n)); }

@@ -233,9 +233,11 @@ def decompose_outputs(prefix, genome_name, input_name, trace, basecallpos, prati
 
 
 class Genome:
-    """indexed genome for k-mer seeding (tracy_amd/host/seed.hpp): plain or gzip-compressed multi-FASTA"""
+    """indexed genome for k-mer seeding (tracy_amd/host/seed.hpp): plain or gzip-compressed multi-FASTA (table built in memory), or an
+    index file written by save() / `tracy_amd_cli index` (mapped read-only; ranks of one node share the page cache's copy)"""
 
     def __init__(self, path, kmer=15, nthreads=0):
+        self._h = None
         fn = lib().tracyhost_genome_open
         fn.restype = C.c_void_p
         h = fn(os.fsencode(path), C.c_uint32(kmer), C.c_uint32(nthreads))
@@ -251,6 +253,11 @@ class Genome:
 
     def __del__(self):
         self.close()
+
+    def save(self, path):
+        """write the index (text, contigs, sorted k-mer table) to one file that Genome(path) maps read-only: `tracy index`, index.h:79-124"""
+        if lib().tracyhost_genome_save(self._h, os.fsencode(path)) != 0:
+            raise IOError("tracy_amd: cannot write index %s" % path)
 
     def count(self, pattern):
         fn = lib().tracyhost_genome_count

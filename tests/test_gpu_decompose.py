@@ -212,7 +212,8 @@ def test_origin_sweep_on_the_certified_sub_window(ctx, monkeypatch):
 
 def test_decompose_beyond_the_default_size_class(ctx):
     """maxindel > 1024 and traces of >= 2048 basecalls: the scan state of decomposeAlleles takes its larger LDS size class
-    (decompose_kernels.h DecompDims<4096>), multi-pass strips and full-matrix tracebacks carry the alignments"""
+    (decompose_kernels.h DecompDims<4096>), multi-pass strips and full-matrix tracebacks carry the alignments; maxindel > 4096: the
+    state lives in global memory (decompose_kernel_global) -- the reference has no limit (indigo.h:74, decompose.h:179-376)"""
     from indigo_oracle import decompose_trace
     from tracy_amd import capi, hostlib
     sigs, poss, refs, bcs = [], [], [], []
@@ -222,7 +223,7 @@ def test_decompose_beyond_the_default_size_class(ctx):
         assert len(pri) >= 2048
         sigs.append(sig); poss.append(pos); refs.append(ref); bcs.append((pri, sec, bcpos))
     profs = [hostlib.create_profile(sigs[i], bcs[i][2], bcs[i][0], bcs[i][1], 0, 0) for i in range(len(sigs))]
-    for maxindel in (1000, 3000):
+    for maxindel in (1000, 3000, 5000):
         hbc = capi.HostBaseCalls(sigs, [b[2] for b in bcs], [b[0] for b in bcs], [b[1] for b in bcs])
         got = ctx.decompose_traces(profs, hbc, refs, SC, maxindel=maxindel)
         for i in range(len(sigs)):

@@ -208,3 +208,58 @@ def test_nan_profile_is_a_range_error(ctx):
     with pytest.raises(TracyHipError) as ei:
         ctx.score(p1, p2, SC + (1, 1))
     assert ei.value.code == ERR_RANGE
+
+
+@pytest.mark.parametrize("score", [(2000, -3000, -5000, -2500), (1500, -1001, -10, -4), (7, -9, -12000, -1)])
+def test_scorings_beyond_a_thousand(ctx, score):
+    """|match|, |mismatch| > 1000: x 32 they leave the int16 tables of the tagged tracebacks, the band kernels and the 16-bit sweeps;
+    strings take the byte-compare kernels, profile rows the tracebacks with an unshifted table, the pipelines their whole-matrix
+    forms -- the oracle's exact result, as the reference's int arithmetic gives it for any scoring (align.h:11-32)"""
+    from tracy_amd import hostlib
+    from sage_oracle import align_trace
+    rng = np.random.default_rng(abs(score[0]) + 1)
+    # generic entry points
+    a = [rand_seq(rng, int(rng.integers(1, 400))) for _ in range(24)]
+    b = [noisy_window(rng, x, len(x) + int(rng.integers(0, 300))) for x in a]
+    for hfree in (1, 0):
+        sc, btr = ctx.align(a, b, score + (hfree, 0))
+        for i in range(len(a)):
+            assert (int(sc[i]), btr[i]) == orc.gotoh_str(a[i], b[i], hfree, 0, score), (i, hfree)
+    profs = [profile_of(rng, x) for x in a]
+    sc, btr = ctx.align(profs, b, score + (1, 0))
+    s2 = ctx.score(profs, b, score + (1, 0))
+    for i in range(len(a)):
+        want = orc.gotoh_prof(profs[i], orc.create_profile_str(b[i]), 1, 0, score)
+        assert (int(sc[i]), btr[i]) == want and int(s2[i]) == want[0], i
+    # the pipelines
+    refs, tprofs, rev = hostlib.synth_align(55, 6, 1500, 600, 0)
+    refl = [r.tobytes() for r in refs]
+    got = ctx.align_traces(list(tprofs), refl, score, 50, 50)
+    for i in range(6):
+        want = align_trace(tprofs[i], refl[i], score, 50, 50)
+        for k in ("score_fwd", "score_rev", "forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
+            assert int(got[k][i]) == int(want[k]), (i, k)
+        assert got["btr"][i] == want["btr"], i
+
+
+def test_decompose_with_a_wide_scoring(ctx):
+    from indigo_oracle import decompose_trace
+    from tracy_amd import capi, hostlib
+    score = (1200, -2000, -4000, -1600)
+    nt = 6
+    d = hostlib.synth_decompose_batch(777, nt, 1500, 500, 0, mix=1)
+    sig = [d["signal"][i] for i in range(nt)]
+    pos = [d["bcpos"][i] for i in range(nt)]
+    pri = [d["primary"][i].tobytes() for i in range(nt)]
+    sec = [d["secondary"][i].tobytes() for i in range(nt)]
+    refs = [d["refs"][i].tobytes() for i in range(nt)]
+    hbc = capi.HostBaseCalls(sig, pos, pri, sec)
+    got = ctx.decompose_traces([d["profiles"][i] for i in range(nt)], hbc, refs, score)
+    for i in range(nt):
+        w = decompose_trace(sig[i], pos[i], pri[i], sec[i], refs[i], score)
+        assert int(got["status"][i]) == w["status"], i
+        if w["status"] != 0:
+            continue
+        assert got["primary"][i] == w["primary"] and got["secdecomp_list"][i] == w["secdecomp"] and got["dcp"][i] == w["dcp"], i
+        for k in range(3):
+            assert int(got["score%d" % k][i]) == w["score%d" % k] and got["btr%d" % k][i] == w["btr%d" % k], (i, k)

@@ -268,8 +268,9 @@ int stage_in(tracyhip_ctx* ctx, DevBuf& buf, const void* src, uint64_t bytes, in
 int check_params(const tracyhip_params* prm, uint64_t max_mn) {
   if (!prm) return set_error(TRACYHIP_ERR_ARG, "null params");
   auto ab = [](int32_t x) { return (int64_t)(x < 0 ? -(int64_t)x : x); };
-  if (ab(prm->match) > 1000 || ab(prm->mismatch) > 1000)
-    return set_error(TRACYHIP_ERR_RANGE, "|match|,|mismatch| must be <= 1000 (int16 query profile x32)");
+  // (beyond |1000| the table-driven tracebacks keep unshifted entries and the pipelines leave their 16-bit / banded forms: kWideScore)
+  if (ab(prm->match) > 30000 || ab(prm->mismatch) > 30000)
+    return set_error(TRACYHIP_ERR_RANGE, "|match|,|mismatch| must be <= 30000 (int16 query profile)");
   const int64_t c = ab(prm->go) + ab(prm->ge) + std::max(ab(prm->match), ab(prm->mismatch));
   if ((int64_t)(max_mn + 2) * c + 1000000 >= (1ll << 26))
     return set_error(TRACYHIP_ERR_RANGE, "(m+n) * cost exceeds the exact range of the x32 int32 kernels");
@@ -349,6 +350,8 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
            int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len, int stage, DpCkpt* ck) {
   const uint32_t np = (uint32_t)pb.desc.size();
   if (np == 0) return TRACYHIP_OK;
+  if (sub_limit(prm) > kWideScore && ((trace && pb.mode == MODE_CQ) || stage == DP_BAND))
+    return set_error(TRACYHIP_ERR_ARG, "run_dp: scoring beyond |%d| takes the byte-compare / whole-matrix kernels", kWideScore);
   hipStream_t st = ctx->stream;
   TRACYHIP_HOST_SCOPE(hs_all, "run_dp");
 
@@ -556,7 +559,8 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
         HIP_TRY(launch_gotoh_prof(K, trace, row4 != 0, a16, a, e - j, st));
       }
       else
-        HIP_TRY(needle ? launch_needle(pb.mode, K, trace, a, e - j, st) : launch_gotoh(pb.mode, K, trace, narrow, a, e - j, st));
+        HIP_TRY(needle ? launch_needle(pb.mode, K, trace, a, e - j, st)
+                       : launch_gotoh(pb.mode, K, trace, narrow, a, e - j, st, trace && pb.mode == MODE_QP && sub_limit(prm) > kWideScore));
       if ((trc = timing_end(ctx))) return trc;
       if (trace && stage == DP_PLAIN && !fused_walk) {
         WalkArgs wa{};
@@ -1180,6 +1184,7 @@ int tracyhip_gotoh_banded(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const 
   if (!origin && (!ops || !ops_offset || !ops_len)) return set_error(TRACYHIP_ERR_ARG, "null ops/ops_offset/ops_len");
   if (prm->vfree || prm->go > 0 || prm->ge >= 0) return set_error(TRACYHIP_ERR_ARG, "the band kernels take AlignConfig<.,false>, go <= 0, ge < 0");
   if (origin && !prm->hfree) return set_error(TRACYHIP_ERR_ARG, "the origin-tracking sweep takes AlignConfig<true,false>");
+  if (sub_limit(prm) > kWideScore) return set_error(TRACYHIP_ERR_RANGE, "the band kernels take |match|, |mismatch| <= %d (tracyhip_gotoh_align has no such limit)", kWideScore);
   if (pairs->a1.kind == TRACYHIP_SEQ_PROFILE && pairs->a2.kind == TRACYHIP_SEQ_PROFILE) return set_error(TRACYHIP_ERR_ARG, "the band kernels take string or profile rows against a string");
   DpProblem pb;
   DpProblemLease lease(ctx, pb);

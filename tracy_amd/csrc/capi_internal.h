@@ -200,6 +200,8 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
            DpCkpt* ck = nullptr);
 bool narrow_ok(const tracyhip_params* prm, uint32_t maxm, int K, int64_t Q = 0);
 int32_t sub_limit(const tracyhip_params* prm);
+// largest |match| / |mismatch| whose table entries x 32 (tagged tracebacks, band kernels) fit int16; wider scorings take slower forms
+constexpr int32_t kWideScore = 1000;
 // device error block (DpArgs::err): kErrWords words owned by the DP launches + one verdict word of the pipelines' reference check
 constexpr int kErrVerdictWord = kErrWords;
 constexpr int kErrSweptWord = kErrWords + 2;  // 64-bit counter of the band traceback (DpArgs::swept), 8-byte aligned

@@ -109,6 +109,9 @@ struct DecompDims {
   static constexpr int kWinWords = kWinBits / 64 + 2;
 };
 constexpr int kMaxIndelLarge = 4096;
+// beyond that the scan state of a trace (1.3 MB) lives in global memory, one slot per resident workgroup: any maxindel / trace length a
+// Sanger run can produce, slowly (the reference's vectors have no limit, decompose.h:179-376)
+constexpr int kMaxIndelGlobal = 65536;
 
 TR_HD int ref_class(uint8_t r) {
   return r == 'A' ? 0 : r == 'C' ? 1 : r == 'G' ? 2 : r == 'T' ? 3 : r == 'N' ? 4 : r == '-' ? 5 : 6;

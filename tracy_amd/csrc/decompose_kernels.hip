@@ -54,6 +54,24 @@ __global__ __launch_bounds__(64) void decompose_kernel(DecompArgs a, const Break
   if (lane == 0) a.out[t] = out;
 }
 
+// the same phases with the scan state in global memory: a workgroup keeps its slot and takes traces blockIdx.x, + gridDim.x, ...
+__global__ __launch_bounds__(64) void decompose_kernel_global(DecompArgs a, const BreakpointOut* bps, char* state) {
+  DecompSharedT<kMaxIndelGlobal>& sh = *reinterpret_cast<DecompSharedT<kMaxIndelGlobal>*>(state + (size_t)blockIdx.x * sizeof(DecompSharedT<kMaxIndelGlobal>));
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t t = blockIdx.x; t < a.ntraces; t += gridDim.x) {
+    DecompDesc d = a.desc[t];
+    d.breakpoint = bps[t].breakpoint;
+    if (a.lens) d.L = a.lens[t];
+    DecompOut out{};
+    for (int st = 0; st < kDecompSteps; ++st) {
+      if (lane == 0 || decomp_step_all_lanes(st)) decomp_step(st, a, d, sh, out, lane);
+      wg_sync();
+    }
+    if (lane == 0) a.out[t] = out;
+    wg_sync();
+  }
+}
+
 // ---- findBreakpoint: one workgroup per profile; sig/diff in dynamic LDS (ncol doubles each) --------
 // GLOBAL: the staging arrays of a profile too long for LDS live in a per-workgroup slice of a global scratch buffer
 template <bool GLOBAL>
@@ -544,8 +562,8 @@ int launch_homozygous(tracyhip_ctx* ctx, const RowsDesc* d_desc, const uint8_t* 
   return TRACYHIP_OK;
 }
 int decompose_limits(int32_t maxindel, uint32_t maxbc) {
-  if (maxindel < 1 || maxindel > kMaxIndelLarge) return set_error(TRACYHIP_ERR_RANGE, "maxindel must be in [1, %d]", kMaxIndelLarge);
-  if (maxbc >= 2u * kMaxIndelLarge) return set_error(TRACYHIP_ERR_RANGE, "a trace has %u basecalls; the scan tables hold < %d", maxbc, 2 * kMaxIndelLarge);
+  if (maxindel < 1 || maxindel > kMaxIndelGlobal) return set_error(TRACYHIP_ERR_RANGE, "maxindel must be in [1, %d]", kMaxIndelGlobal);
+  if (maxbc >= 2u * kMaxIndelGlobal) return set_error(TRACYHIP_ERR_RANGE, "a trace has %u basecalls; the scan tables hold < %d", maxbc, 2 * kMaxIndelGlobal);
   return TRACYHIP_OK;
 }
 int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut* d_bps, uint32_t maxbc, uint64_t work_cells, uint64_t work_bytes) {
@@ -554,8 +572,14 @@ int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut
   if (rc) return rc;
   // scan state in LDS: 21 KB for maxindel <= 1024 and traces < 2048 basecalls (every Sanger run), 80 KB up to 4096 / 8191
   const bool large = a.prm.maxindel > kMaxIndelDev || maxbc >= 2u * kMaxIndelDev;
+  const bool global = a.prm.maxindel > kMaxIndelLarge || maxbc >= 2u * kMaxIndelLarge;
   { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_DECOMP, work_cells, work_bytes); if (trc_) return trc_; }
-  if (large) {
+  if (global) {
+    // scan state in global memory: up to 512 workgroups in flight, each with a slot of its own (0.7 GB)
+    const uint32_t slots = std::min<uint32_t>(a.ntraces, 512u);
+    HIP_TRY(ctx->d_band.ensure((size_t)slots * sizeof(DecompSharedT<kMaxIndelGlobal>)));
+    hipLaunchKernelGGL(decompose_kernel_global, dim3(slots), dim3(64), 0, ctx->stream, a, d_bps, static_cast<char*>(ctx->d_band.p));
+  } else if (large) {
     const size_t lds = sizeof(DecompSharedT<kMaxIndelLarge>);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(decompose_kernel<kMaxIndelLarge>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(decompose_kernel<kMaxIndelLarge>, dim3(a.ntraces), dim3(64), lds, ctx->stream, a, d_bps);

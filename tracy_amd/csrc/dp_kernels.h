@@ -360,6 +360,11 @@ template <class W, int K, int MODE, bool TRACE, bool NARROW = false, bool CKPT =
 TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   static_assert(!(NARROW && TRACE), "the 16-bit formulation exists for the score-only kernel");
   constexpr bool A16 = MODE == MODE_PROF && !TRACE && !NARROW && !CKPT && COMPACT;
+  // traceback with table scores (TRACE, MODE_QP / MODE_CQ) and COMPACT: the table holds the scores as they are and a cell shifts its
+  // entry into the tagged field when it uses it (one more operation per cell) -- for scorings whose entries x 32 leave int16
+  // (|match| or |mismatch| > 1000: the reference takes any int, align.h:11-32)
+  constexpr bool RAWTAB = TRACE && qp_like(MODE) && COMPACT;
+  constexpr int TSH = RAWTAB ? 0 : (TRACE ? kTagShift : 0);  // shift applied when the table is filled
   static_assert(!(CKPT && TRACE), "checkpoints are written by the score-only kernel");
   // NARROW / CKPT kernels: single pass, free end gaps on the first/last row only, rows anchored at the bottom
   constexpr bool BOTTOM = NARROW || CKPT;
@@ -502,7 +507,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
           int32_t q;
           if (MODE == MODE_QP) q = real ? onehot_score(pr, b, fmatch, fmis) : 0;
           else q = real ? (rch == (uint8_t)"ACGTN"[b] ? a.match : a.mismatch) : 0;  // byte equality (align.h:96-101)
-          const int32_t qs = (int32_t)((uint32_t)q << SH) - goe_n;
+          const int32_t qs = (int32_t)((uint32_t)q << TSH) - goe_n;
           overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
           qabs = imax(qabs, q < 0 ? -q : q);
           // reverse-complement view of a2: the complement is folded into the table (the entries of code b serve code 3-b),
@@ -512,7 +517,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         }
         // code 5: '-' / any other letter.  A profile column of zeros scores 0; a string column that no row can equal mismatches
         const int32_t q5 = (MODE == MODE_CQ && real) ? a.mismatch : 0;
-        qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)((int32_t)((uint32_t)q5 << SH) - goe_n);
+        qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)((int32_t)((uint32_t)q5 << TSH) - goe_n);
       }
       if (overflow) flag_error(a.err, 1);
       if (MODE == MODE_QP && qabs > a.qlimit) flag_max(a.err, 1, qabs);  // un-normalised profile: the host re-checks the value range (capi.hip)
@@ -624,7 +629,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
       // bytes on both sides (capi_internal.h), idle lanes read into them (or into a neighbouring sequence) and discard
       // the result.  Forward view: byte c-1; reverse-complement view: byte n-c (its complement sits in the table).
       // byte(t) = lane_base + dir * t with dir = +-1 uniform over the wave: one VALU add per step.
-      SubRows<K> qa, qb;
+      SubRows<K, RAWTAB ? kTagShift : 0> qa, qb;
       const int16_t* lane_col = qp_tab + L;
       const uint8_t* a2v = a2c - kCodeBias;
       const int32_t lane_base = (int32_t)kCodeBias + (rcflag ? (int32_t)n + (int32_t)L : -(int32_t)L - 1);

@@ -245,8 +245,21 @@ hipError_t launch_gotoh_prof(int K, bool trace, bool row4_zero, bool arith16, co
   return row4_zero ? launch_prof_k<false, 4>(K, a, npairs, s) : launch_prof_k<false, 5>(K, a, npairs, s);
 }
 
-hipError_t launch_gotoh(int mode, int K, bool trace, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+// traceback of profile rows with the table holding unshifted scores (gotoh_body RAWTAB): scorings beyond |1000|
+static hipError_t launch_gotoh_rawtab(int K, const DpArgs& a, uint32_t npairs, hipStream_t s) {
+#define TRACY_RAW(KK)                                                                                                         \
+  case KK: hipLaunchKernelGGL((gotoh_kernel<KK, MODE_QP, true, false, true>), dim3(npairs), dim3(64), lds_bytes(MODE_QP, KK), s, a); break;
+  switch (K) {
+    TRACY_RAW(4) TRACY_RAW(8) TRACY_RAW(12) TRACY_RAW(15) TRACY_RAW(16)
+    default: return hipErrorInvalidValue;
+  }
+#undef TRACY_RAW
+  return hipGetLastError();
+}
+
+hipError_t launch_gotoh(int mode, int K, bool trace, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s, bool rawtab) {
   if (npairs == 0) return hipSuccess;
+  if (rawtab) return (trace && mode == MODE_QP) ? launch_gotoh_rawtab(K, a, npairs, s) : hipErrorInvalidValue;
   if (narrow && !trace) {
     if (mode == MODE_CHAR) return launch_gotoh_narrow<MODE_CHAR>(K, a, npairs, s);
     if (mode == MODE_QP) return launch_gotoh_narrow<MODE_QP>(K, a, npairs, s);

@@ -24,7 +24,8 @@ struct RowsArgs {
 };
 
 // narrow: use the 16-bit score-only kernel (caller has checked the value range, see narrow_ok)
-hipError_t launch_gotoh(int mode, int K, bool trace, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s);
+// rawtab (trace, MODE_QP): the table holds unshifted scores (scorings whose entries x 32 leave int16)
+hipError_t launch_gotoh(int mode, int K, bool trace, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s, bool rawtab = false);
 // profile x profile with the substitution-term count fixed per launch: row4_zero = every pair of the launch carries PAIR_ROW4_ZERO
 // arith16 (score only): 16-bit cells -- the caller has checked the value range (arith16_ok)
 hipError_t launch_gotoh_prof(int K, bool trace, bool row4_zero, bool arith16, const DpArgs& a, uint32_t npairs, hipStream_t s);

@@ -406,7 +406,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   // (band traceback) instead of storing the whole traceback matrix.
   HIP_TRY(ctx->d_tmp[0].ensure(sizeof(int32_t) * 2 * (size_t)nt));
   int32_t* d_sc2 = static_cast<int32_t*>(ctx->d_tmp[0].p);
-  bool use_band = getenv("TRACYHIP_NO_BAND") == nullptr && p.ge < 0 && p.go <= 0;  // hfree = 1, vfree = 0 here
+  bool use_band = getenv("TRACYHIP_NO_BAND") == nullptr && p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore;  // hfree = 1, vfree = 0 here
   DpCkpt ck;
   ck.B = 256;
   if (const char* e = getenv("TRACYHIP_CKPT_B")) { const int b = atoi(e); if (b >= 32 && b <= 1024) ck.B = (uint32_t)b; }  // developer knob
@@ -415,7 +415,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   // gap columns, so it starts no earlier than column c_e - m - g -- and an origin-tracking sweep over that sub-window (about a
   // tenth of a 10 kb window) delivers the two ends trimReferenceSlice reads: no wavefront checkpoints, no band traceback.
   // (The argument is the one of the allele alignments of `tracy decompose`)
-  const bool b16 = in.d_qp != nullptr && in.td != nullptr && in.row0 != nullptr && p.ge < 0 && p.go <= 0 && getenv("TRACYHIP_NO_BAND16") == nullptr;
+  const bool b16 = in.d_qp != nullptr && in.td != nullptr && in.row0 != nullptr && p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore && getenv("TRACYHIP_NO_BAND16") == nullptr;
   const bool cert_base = !no_ends && use_band && !force_wide && !ctx->no_narrow && getenv("TRACYHIP_NO_PRELIM_ORIGIN") == nullptr;
   bool ends_path = in.ends_only && cert_base;
   bool tb16_path = !in.ends_only && b16 && cert_base;  // traceback on the band kernels (the string is an output: `tracy decompose`)
@@ -961,7 +961,7 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
   // substitution tables of the full profiles for the band kernels (band16.h): the preliminary alignment (rows tl .. tl + mt) and the
   // final one (all rows) read them
   std::vector<B16TableDesc> td;
-  const bool b16 = p.ge < 0 && p.go <= 0 && getenv("TRACYHIP_NO_BAND16") == nullptr;
+  const bool b16 = p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore && getenv("TRACYHIP_NO_BAND16") == nullptr;
   if (b16) {
     td.resize(nt);
     for (uint32_t t = 0; t < nt; ++t) td[t] = B16TableDesc{sp.offset[t], 0, mf[t], mf[t], 0, 0};
@@ -1035,7 +1035,7 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
     // allowed (OrientOut::gap) + 48 for what the trimmed ends add, within [32, 96]; 48 where that is not known.  (A pair that does not
     // certify costs a launch of its own at the end of the step -- 0.7 ms for a single pair -- so the width errs on the wide side.)
     const char* band_env = getenv("TRACYHIP_BAND_W");
-    const int32_t bandW = (p.ge < 0 && p.go <= 0) ? (band_env ? atoi(band_env) : 48) : 0;
+    const int32_t bandW = (p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore) ? (band_env ? atoi(band_env) : 48) : 0;
     std::vector<int32_t> band_of(nt, bandW);
     if (!band_env && bandW > 0 && oo.gap.size() == nt)
       for (uint32_t t = 0; t < nt; ++t) band_of[t] = (int32_t)std::min<uint32_t>(96u, std::max<uint32_t>(32u, oo.gap[t] + 48u));
@@ -1380,7 +1380,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     return set_error(TRACYHIP_ERR_ARG, "bad sequence sets");
   if (!bc.signal || !bc.signal_offset || !bc.nsamples || !bc.bcpos || !bc.primary || !bc.secondary || !bc.bc_offset || !bc.bc_len)
     return set_error(TRACYHIP_ERR_ARG, "null basecall arrays");
-  if (dp.maxindel < 1 || dp.maxindel > kMaxIndelLarge) return set_error(TRACYHIP_ERR_RANGE, "maxindel must be in [1, %d]", kMaxIndelLarge);
+  if (dp.maxindel < 1 || dp.maxindel > kMaxIndelGlobal) return set_error(TRACYHIP_ERR_RANGE, "maxindel must be in [1, %d]", kMaxIndelGlobal);
   if (!out->bp || !out->status || !out->score_fwd || !out->score_rev || !out->forward || !out->score_trim || !out->dcp_indel ||
       !out->dcp_err || !out->dcp_offset || !out->dstatus || !out->secdecomp || !out->fractions)
     return set_error(TRACYHIP_ERR_ARG, "null result array");
@@ -1407,7 +1407,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     mf[t] = sp.length[t];
     rn[t] = sr.length[ridx[t]];
     if (bc.bc_len[t] != mf[t]) return set_error(TRACYHIP_ERR_ARG, "trace %u: profile has %u columns but %u basecalls", t, mf[t], bc.bc_len[t]);
-    if (bc.bc_len[t] >= 2u * kMaxIndelLarge) return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the scan tables hold < %d", t, bc.bc_len[t], 2 * kMaxIndelLarge);
+    if (bc.bc_len[t] >= 2u * kMaxIndelGlobal) return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the scan tables hold < %d", t, bc.bc_len[t], 2 * kMaxIndelGlobal);
     uint32_t l = TL, r = TR;
     if ((uint64_t)l + r >= mf[t]) { l = 0; r = 0; }  // createProfile, profile.h:24-27
     tl[t] = l;
@@ -1552,7 +1552,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     oi.d_score = static_cast<int32_t*>(d_strim);
     // the traceback of the trimmed trace on the band kernels (band16.h): substitution tables of the profiles
     std::vector<B16TableDesc> tdp;
-    if (p.ge < 0 && p.go <= 0 && getenv("TRACYHIP_NO_BAND16") == nullptr) {
+    if (p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore && getenv("TRACYHIP_NO_BAND16") == nullptr) {
       tdp.resize(nt);
       for (uint32_t t = 0; t < nt; ++t) tdp[t] = B16TableDesc{sp.offset[t], 0, mf[t], mf[t], 0, 0};
       HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
@@ -1669,7 +1669,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   HIP_TRY(b_cqf.ensure(sizeof(int32_t)));
   uint8_t* d_cq_ref = static_cast<uint8_t*>(b_cq1.p) + kCodePad;
   uint8_t* d_cq_sd = static_cast<uint8_t*>(b_cq2.p) + kCodePad;
-  const bool try_cq = getenv("TRACYHIP_NO_CQ") == nullptr;
+  const bool try_cq = getenv("TRACYHIP_NO_CQ") == nullptr && sub_limit(&p) <= kWideScore;
   int32_t h_cq_flag = 1;
   if (try_cq) {
     HIP_TRY(hipMemsetAsync(b_cq1.p, 5, (er ? er : 1) + 2 * kCodePad, st));

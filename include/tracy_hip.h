@@ -59,7 +59,9 @@ extern "C" {
 
 typedef struct tracyhip_ctx tracyhip_ctx;
 
-/* DnaScore<int> (align.h:11-32; inf is the fixed 1000000) + AlignConfig<hfree,vfree> (align.h:37-80) */
+/* DnaScore<int> (align.h:11-32; inf is the fixed 1000000) + AlignConfig<hfree,vfree> (align.h:37-80).
+ * |match|, |mismatch| <= 30000 and (m + n) * (|go| + |ge| + max(|match|, |mismatch|)) + 10^6 < 2^26 (TRACYHIP_ERR_RANGE beyond: the
+ * exact range of the x 32 tagged int32 tracebacks); beyond |1000| the table-driven and banded forms give way to slower exact ones */
 typedef struct {
   int32_t match;
   int32_t mismatch;
@@ -212,8 +214,9 @@ typedef struct {
 typedef struct {
   int32_t trim_left;
   int32_t trim_right;
-  int32_t maxindel;              /* 1 .. 4096; traces must hold fewer than 8192 basecalls (TRACYHIP_ERR_RANGE beyond: the scan
-                                  * tables of decomposeAlleles are LDS resident, two size classes) */
+  int32_t maxindel;              /* 1 .. 65536; traces must hold fewer than 131072 basecalls (TRACYHIP_ERR_RANGE beyond).  The scan
+                                  * tables of decomposeAlleles are LDS resident up to 4096 / 8191 basecalls (two size classes) and live
+                                  * in global memory beyond that (slower, same results) */
   int32_t madc;
 } tracyhip_decomp_params;
 

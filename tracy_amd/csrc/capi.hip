@@ -2,6 +2,7 @@
 // pairs by strip height K, workspace chunking, kernel launches.  No compute happens on the host and
 // there is no CPU fallback: every entry point needs a gfx950 device.
 #include <hip/hip_runtime.h>
+#include <malloc.h>
 #include <map>
 #include <chrono>
 
@@ -980,6 +981,18 @@ int tracyhip_create(int device, tracyhip_ctx** out) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return set_error(TRACYHIP_ERR_NODEVICE, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
   HIP_TRY(hipSetDevice(device));
+  // The pipelines build megabytes of descriptors between two launches (72 bytes per trace and stage) in vectors that live for one
+  // stage.  Above glibc's mmap threshold every such vector is mapped and unmapped anew -- a page fault per 4 KB, tens of milliseconds
+  // per 100 000-trace step, and whether the allocator does it varies from process to process.  Keep blocks of up to 32 MB on the
+  // heap and the heap's top untrimmed (process-wide, set once; TRACYHIP_NO_MALLOPT=1 leaves the allocator alone).
+  static const bool malloc_tuned = []() {
+    if (getenv("TRACYHIP_NO_MALLOPT")) return false;
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
+    return true;
+  }();
+  (void)malloc_tuned;
   tracyhip_ctx* c = new tracyhip_ctx();
   c->device = device;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

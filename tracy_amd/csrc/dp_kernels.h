@@ -687,11 +687,7 @@ TR_HD void gotoh_body(W& w, const DpArgs& a, uint32_t pair_idx) {
 #pragma unroll
           for (int k = 0; k < 5; ++k) sub.b[k] = nb[k];
           const uint32_t ccls = ncls;
-#if defined(TRACY_EXP_FASTCOL)  // experiment (wrong results): every column load hits a cached line
-          const uint32_t ci = col_at((int32_t)t - (int32_t)L + 1) & 15u;
-#else
           const uint32_t ci = col_at((int32_t)t - (int32_t)L + 1);
-#endif
 #pragma unroll
           for (int k = 0; k < 5; ++k) nb[k] = a2p[(uint64_t)k * d.a2_stride + ci];
           if (screen_on) {

@@ -98,6 +98,29 @@ def run_campaign(pairs=1500, traces=96, lanes=1, seed=1, decompose_len=(700, 220
                 if (int(scores[i]), btr[i]) != w or int(sonly[i]) != w[0]:
                     bad.append(("dp", mode, cfg, sc, i, len(a1[i]) if mode == "char" else a1[i].shape[1]))
             done["dp_" + mode] = done.get("dp_" + mode, 0) + n_pairs
+            if mode == "char" and cfg[1] == 0:
+                # the band kernels through tracyhip_gotoh_banded: a band as wide as the oracle's score allows gap steps holds
+                # every optimal path, so the banded result is the whole-matrix result
+                sub, lo, hi = [], [], []
+                for i in range(n_pairs):
+                    m, n = len(a1[i]), len(a2[i])
+                    if m < 1 or n < 1:
+                        continue
+                    g = (sc[0] * min(m, n) - int(scores[i])) // -sc[3] + 1
+                    if cfg[0]:
+                        fwd = btr[i][::-1]
+                        d1 = n - (len(fwd) - len(fwd.rstrip(b"h"))) - m
+                        dl, dh = d1 - g - 1, d1 + g + 1
+                    else:
+                        dl, dh = min(0, n - m) - g - 1, max(0, n - m) + g + 1
+                    if dh - dl <= 175:
+                        sub.append(i); lo.append(dl); hi.append(dh)
+                if sub:
+                    bs, bb = ctx.align_banded([a1[i] for i in sub], [a2[i] for i in sub], sc + cfg, lo, hi)
+                    for j, i in enumerate(sub):
+                        if (int(bs[j]), bb[j]) != (int(scores[i]), btr[i]):
+                            bad.append(("banded", cfg, sc, i, len(a1[i]), len(a2[i]), lo[j], hi[j]))
+                    done["dp_banded"] = done.get("dp_banded", 0) + len(sub)
 
     # ---- 2. `tracy align` batches, ragged ----
     nt = args.traces

@@ -1035,7 +1035,9 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
     // allowed (OrientOut::gap) + 48 for what the trimmed ends add, within [32, 96]; 48 where that is not known.  (A pair that does not
     // certify costs a launch of its own at the end of the step -- 0.7 ms for a single pair -- so the width errs on the wide side.)
     const char* band_env = getenv("TRACYHIP_BAND_W");
-    const int32_t bandW = (p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore) ? (band_env ? atoi(band_env) : 48) : 0;
+    // (developer knob, read per call so that one process can compare widths; clamped to [0, 4096] -- widths the band forms cannot
+    // hold simply leave the pair on the whole matrix)
+    const int32_t bandW = (p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore) ? (band_env ? std::min(4096, std::max(0, atoi(band_env))) : 48) : 0;
     std::vector<int32_t> band_of(nt, bandW);
     if (!band_env && bandW > 0 && oo.gap.size() == nt)
       for (uint32_t t = 0; t < nt; ++t) band_of[t] = (int32_t)std::min<uint32_t>(96u, std::max<uint32_t>(32u, oo.gap[t] + 48u));

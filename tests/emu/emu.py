@@ -17,7 +17,8 @@ def lib():
     if _LIB is None:
         so = os.path.join(_HERE, "libemu_wave.so")
         srcs = [os.path.join(_HERE, "emu_wave.cpp"), os.path.join(_ROOT, "tracy_amd/csrc/dp_kernels.h"),
-                os.path.join(_ROOT, "tracy_amd/csrc/dp_lane.h"), os.path.join(_ROOT, "tracy_amd/csrc/band16.h")]
+                os.path.join(_ROOT, "tracy_amd/csrc/dp_lane.h"), os.path.join(_ROOT, "tracy_amd/csrc/band16.h"),
+                os.path.join(_ROOT, "tracy_amd/csrc/front.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
                                    "-o", so, srcs[0]], stderr=subprocess.DEVNULL)
@@ -205,3 +206,47 @@ def run_band16(pairs, score, hfree, K, kind=0, strings=True):
         btr = ops[i * cap:i * cap + int(ops_len[i])].tobytes() if kind == 0 else None
         out.append((int(scores[i]), btr, (int(ends[2 * i]), int(ends[2 * i + 1])) if kind == 1 else None))
     return out, err.value
+
+
+def run_front(profiles, refs, score, Kp, Kb, halfw, revcomp=None, want_rows=False, GLp=8):
+    """the pruned orientation sweep (front.h) of up to four traces: prefix rows kept, band placed, band swept below the kept row,
+    certificate.  Returns per pair a dict(vmax, cstar, shift, ok, score, c_e[, row]) and the error word."""
+    npairs = len(profiles)
+    assert 1 <= npairs <= 4
+    a1 = np.concatenate([np.ascontiguousarray(p, dtype=np.float32).ravel() for p in profiles] + [np.zeros(1, np.float32)])
+    m = np.array([p.shape[1] for p in profiles], np.uint32)
+    a1_off = np.zeros(npairs, np.uint64)
+    if npairs > 1:
+        a1_off[1:] = np.cumsum(6 * m.astype(np.uint64))[:-1]
+    a2 = np.frombuffer(b"".join(bytes(r) for r in refs) + b"\0", dtype=np.uint8).copy()
+    n = np.array([len(r) for r in refs], np.uint32)
+    a2_off = np.zeros(npairs, np.uint64)
+    if npairs > 1:
+        a2_off[1:] = np.cumsum(n.astype(np.uint64))[:-1]
+    flags = np.array([1 if (revcomp and revcomp[i]) else 0 for i in range(npairs)], np.uint32)
+    out = np.zeros(6 * npairs, np.int32)
+    cap = int(n.max()) + 1
+    rows = np.zeros(npairs * cap, np.uint32)
+    err = C.c_int32(0)
+    ptr = lambda x: C.c_void_p(x.ctypes.data)
+    rc = lib().emu_front(int(Kp), int(GLp), int(Kb), npairs, ptr(a1), ptr(a1_off), ptr(m), ptr(a2), ptr(a2_off), ptr(n), ptr(flags), int(halfw),
+                         *[int(x) for x in score], ptr(out), ptr(rows) if want_rows else None, C.c_uint64(cap), C.byref(err))
+    assert rc == 0, rc
+    res = []
+    for i in range(npairs):
+        o = out[6 * i:6 * i + 6]
+        r = dict(vmax=int(o[0]), cstar=int(o[1]), shift=int(o[2]), ok=int(o[3]), score=int(o[4]), c_e=int(o[5]))
+        if want_rows:
+            r["row"] = rows[i * cap:i * cap + int(n[i]) + 1].copy()
+        res.append(r)
+    return res, err.value
+
+
+def table_rows(profile, score):
+    """int substitution scores of a profile's rows against the codes A C G T N other: array [m][6]"""
+    x = np.ascontiguousarray(profile, dtype=np.float32)
+    m = x.shape[1]
+    out = np.zeros((m, 6), np.int32)
+    rc = lib().emu_table_rows(C.c_void_p(x.ctypes.data), C.c_uint64(0), C.c_uint32(m), C.c_uint32(m), int(score[0]), int(score[1]), C.c_void_p(out.ctypes.data))
+    assert rc == 0
+    return out

@@ -14,6 +14,7 @@
 
 #include "../../tracy_amd/csrc/band16.h"
 #include "../../tracy_amd/csrc/dp_kernels.h"
+#include "../../tracy_amd/csrc/front.h"
 
 using namespace tracyhip;
 
@@ -177,15 +178,15 @@ static std::vector<uint8_t> cq_codes(const void* a2, size_t bytes) {
   return v;
 }
 
-template <int K>
+template <int K, int GL = kPrefixLanes>
 void run_prefix_wave(const DpArgs& a, uint32_t npairs) {
   for (int form = 0; form < 2; ++form) {  // both forms, as the library launches them: every group is worked on in one of them
     WaveShared sh;
     sh.lds.assign(lds_bytes_prefix(K, false) + 64, 0);
     sh.run([&](uint32_t l) {
         HostWave w{l, &sh};
-        if (form == 0) gotoh_prefix_body<HostWave, K, kPrefixLanes, true>(w, a, 0, npairs);
-        else gotoh_prefix_body<HostWave, K, kPrefixLanes, false>(w, a, 0, npairs);
+        if (form == 0) gotoh_prefix_body<HostWave, K, GL, true>(w, a, 0, npairs);
+        else gotoh_prefix_body<HostWave, K, GL, false>(w, a, 0, npairs);
       });
   }
 }
@@ -491,6 +492,112 @@ int emu_band16(int K, int kind, int strings, uint32_t npairs, const void* a1, co
   }
 #undef EMU_B16
   if (err_out) *err_out = errw[0];
+  return 0;
+}
+// The pruned orientation sweep (front.h) of up to four traces as the library runs it: prefix rows 1 .. GLp Kp over all columns (GLp = 8
+// or 16 lanes per pair) with the row kept (gotoh_prefix_body, PAIR_KEEP_ROW), front_place, the band kernels below that row (band16_body CONT, strip height Kb),
+// front_certify.  a1 = float [6][m] profiles (row stride m), a2 = reference characters.  Per pair: out[0..5] = {vmax, c*, shift,
+// ok, score, c_e (window column)}; rows (may be null) receives the kept rows, pair i at rows + i * rows_cap.
+int emu_front(int Kp, int GLp, int Kb, uint32_t npairs, const float* a1, const uint64_t* a1_off, const uint32_t* m, const uint8_t* a2,
+              const uint64_t* a2_off, const uint32_t* n, const uint32_t* flags, int32_t halfw, int32_t match, int32_t mismatch, int32_t go,
+              int32_t ge, int32_t* out, uint32_t* rows, uint64_t rows_cap, int32_t* err_out) {
+  if (npairs == 0 || npairs > 4) return -1;
+  if (GLp != 8 && GLp != 16) return -1;
+  const uint32_t R = (uint32_t)GLp * (uint32_t)Kp;
+  uint64_t extent = 0;
+  for (uint32_t i = 0; i < npairs; ++i) extent = std::max<uint64_t>(extent, a2_off[i] + n[i]);
+  std::vector<uint8_t> raw(extent);
+  for (uint64_t i = 0; i < extent; ++i) raw[i] = (uint8_t)dp_code(a2[i]);
+  std::vector<uint8_t> codes = padded_codes(raw.data(), extent);
+  std::vector<uint8_t> special = special_blocks_of(codes, extent);
+  // ---- prefix sweeps, rows kept ----
+  std::vector<PairDesc> d(npairs);
+  std::vector<int32_t> lastrow;
+  for (uint32_t i = 0; i < npairs; ++i) {
+    if (m[i] <= R + (uint32_t)Kb) return -2;
+    d[i] = PairDesc{};
+    d[i].a1_off = a1_off[i]; d[i].a2_off = a2_off[i]; d[i].m = m[i]; d[i].n = n[i]; d[i].a1_stride = m[i]; d[i].a2_stride = n[i];
+    d[i].flags = (flags[i] & PAIR_A2_REVCOMP) | PAIR_KEEP_ROW; d[i].out = i;
+    d[i].lastrow_off = lastrow.size();
+    lastrow.resize(lastrow.size() + n[i] + 1, 0x7fff7fff);
+  }
+  std::vector<int32_t> pmax(npairs, 0);
+  int32_t errw[kErrWords] = {0};
+  DpArgs pa{};
+  pa.pairs = d.data(); pa.a1 = a1; pa.a2 = codes.data() + 128; pa.scores = pmax.data(); pa.err = errw; pa.lastrow = lastrow.data();
+  pa.match = match; pa.mismatch = mismatch; pa.go = go; pa.ge = ge; pa.hfree = 1; pa.vfree = 0; pa.qlimit = 1 << 20;
+  pa.special_blocks = special.data();
+  switch (Kp * 100 + GLp) {
+    case 408: run_prefix_wave<4>(pa, npairs); break;
+    case 808: run_prefix_wave<8>(pa, npairs); break;
+    case 1508: run_prefix_wave<15>(pa, npairs); break;
+    case 416: run_prefix_wave<4, 16>(pa, npairs); break;
+    case 816: run_prefix_wave<8, 16>(pa, npairs); break;
+    default: return -1;
+  }
+  // ---- tables of the whole profiles, the rest bound ----
+  std::vector<int16_t> qp;
+  std::vector<FrontDesc> fd(npairs);
+  for (uint32_t i = 0; i < npairs; ++i) {
+    const uint32_t stride = b16_table_stride(m[i]);
+    const uint64_t off = qp.size();
+    qp.resize(qp.size() + (size_t)kB16Codes * stride, 0);
+    int32_t rest = 0;
+    for (uint32_t r = 0; r < m[i]; ++r) {
+      int32_t q[kB16Codes];
+      b16_table_row(a1, false, a1_off[i], m[i], r, match, mismatch, q);
+      int32_t best = 0;
+      for (uint32_t b = 0; b < kB16Codes; ++b) {
+        qp[off + (size_t)b * stride + r] = (int16_t)((uint32_t)q[b] << kTagShift);
+        if (b < 5 && q[b] > best) best = q[b];
+      }
+      if (r >= R) rest += best;
+    }
+    FrontDesc& f = fd[i];
+    f = FrontDesc{};
+    f.row_off = d[i].lastrow_off; f.a2_off = a2_off[i]; f.tab_off = off + R; f.tab_stride = stride; f.m_rest = m[i] - R; f.n = n[i];
+    f.flags = flags[i] & PAIR_A2_REVCOMP; f.out = i; f.R = R; f.rest = rest;
+  }
+  const uint32_t* rowp = reinterpret_cast<const uint32_t*>(lastrow.data());
+  std::vector<PairDesc> bp(npairs);
+  std::vector<FrontOut> fo(npairs);
+  for (uint32_t i = 0; i < npairs; ++i) {
+    WaveShared sh;
+    sh.lds.assign(64, 0);
+    sh.run([&](uint32_t l) { HostWave w{l, &sh}; front_place_body(w, fd[i], rowp, go + ge, halfw, &bp[i], &fo[i]); });
+  }
+  // ---- the band below the kept row ----
+  std::vector<int32_t> scores(npairs, 0);
+  std::vector<uint32_t> ends(2 * npairs, 0);
+  uint32_t nmax = 0;
+  for (uint32_t i = 0; i < npairs; ++i) nmax = std::max(nmax, bp[i].n);
+  Band16Args a{};
+  a.pairs = bp.data(); a.npairs = npairs; a.qp = qp.data(); a.codes = codes.data() + 128; a.scores = scores.data(); a.ends = ends.data();
+  a.err = errw; a.go = go; a.ge = ge; a.hfree = 1; a.code_cap = (nmax + 3u) & ~3u; a.row = rowp;
+  {
+    WaveShared sh;
+    sh.lds.assign(4u * a.code_cap + b16_table_bytes(Kb) + 4u * 2u * kB16RowCap * 4u + 64, 0);
+    switch (Kb) {
+      case 4: sh.run([&](uint32_t l) { HostWave w{l, &sh}; band16_body<HostWave, 4, 1, true>(w, a, 0); }); break;
+      case 8: sh.run([&](uint32_t l) { HostWave w{l, &sh}; band16_body<HostWave, 8, 1, true>(w, a, 0); }); break;
+      case 12: sh.run([&](uint32_t l) { HostWave w{l, &sh}; band16_body<HostWave, 12, 1, true>(w, a, 0); }); break;
+      default: return -1;
+    }
+  }
+  for (uint32_t i = 0; i < npairs; ++i) {
+    WaveShared sh;
+    sh.lds.assign(64, 0);
+    sh.run([&](uint32_t l) { HostWave w{l, &sh}; front_certify_body(w, fd[i], rowp, go, ge, halfw, scores[i], ends[2 * i + 1], &fo[i]); });
+    out[6 * i + 0] = fo[i].vmax; out[6 * i + 1] = (int32_t)fo[i].cstar; out[6 * i + 2] = (int32_t)fo[i].shift; out[6 * i + 3] = (int32_t)fo[i].ok;
+    out[6 * i + 4] = scores[i]; out[6 * i + 5] = (int32_t)(ends[2 * i + 1] ? ends[2 * i + 1] + fo[i].shift : 0u);
+    if (rows) for (uint32_t c = 0; c <= n[i] && c < rows_cap; ++c) rows[(uint64_t)i * rows_cap + c] = rowp[d[i].lastrow_off + c];
+  }
+  if (err_out) *err_out = errw[0];
+  return 0;
+}
+// the substitution scores of a profile's rows against the six column codes (b16_table_row): out[r * 6 + b]
+int emu_table_rows(const float* a1, uint64_t a1_off, uint32_t a1_stride, uint32_t m, int32_t match, int32_t mismatch, int32_t* out) {
+  for (uint32_t r = 0; r < m; ++r) b16_table_row(a1, false, a1_off, a1_stride, r, match, mismatch, out + (size_t)r * kB16Codes);
   return 0;
 }
 }

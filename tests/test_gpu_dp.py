@@ -228,7 +228,7 @@ def test_long_pair_list(ctx):
 def test_error_reporting(ctx):
     import tracy_amd
     with pytest.raises(tracy_amd.TracyHipError) as e:
-        ctx.score([b"ACGT"], [b"ACGT"], (5000, -5, -10, -4, 1, 0))
+        ctx.score([b"ACGT"], [b"ACGT"], (50000, -5, -10, -4, 1, 0))
     assert e.value.code == tracy_amd.capi.ERR_RANGE
     rng = np.random.default_rng(3)
     big = rand_profile(rng, 20) * np.float32(1e6)

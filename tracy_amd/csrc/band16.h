@@ -46,7 +46,13 @@ struct Band16Args {
   uint8_t* ops;           // KIND 0: walker output (push order), pair i at ops + ops_off[out]
   const uint64_t* ops_off;
   uint32_t* ops_len;
+  // CONT (KIND 1): the sweep continues below row R of a prefix sweep over all columns (gotoh_prefix_body, PAIR_KEEP_ROW) instead of
+  // starting at row 0: `row` holds one dword per column -- low half H(R, c) + (go + ge), high half F(R, c) -- the pair's column c at
+  // row[lastrow_off + c]; PairDesc::bits_off is R (the rows above the pair's first one), m the rows below it.  Origins are not
+  // tracked (ends[2 out] = 0); score and c_e are those of the band under row R.
+  const uint32_t* row;
 };
+constexpr uint32_t kB16RowCap = 200;  // CONT: row-R entries staged per pair (the window of strip 0 and the column before it)
 
 constexpr uint32_t kB16Codes = 6;
 TR_HD constexpr uint32_t b16_period(int K) { return 16u * ((uint32_t)K + 1u); }
@@ -177,9 +183,11 @@ TR_HD void walk16(W& w, const Fetch& fetch, bool have, uint32_t m, uint32_t n, u
   }
 }
 
-template <class W, int K, int KIND>
+template <class W, int K, int KIND, bool CONT = false>
 TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   static_assert(K == 4 || K == 8 || K == 12, "strip heights of the band kernels");
+  static_assert(!CONT || KIND == 1, "only the score / ends sweep continues from a stored row");
+  static_assert(b16_max_window(K) + 2u <= kB16RowCap, "row staging");
   constexpr int SH = KIND == 0 ? kTagShift : kOriginShift;
   constexpr int TS = KIND == 0 ? 0 : kOriginBits;
   constexpr int32_t P = (int32_t)b16_period(K);
@@ -197,11 +205,12 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   const uint32_t S = b16_window(K, dmin, dmax);
   const uint32_t S_last = have ? b16_last_window(m, n, K, dmin, dmax) : 0u;
   const int32_t neg = KIND == 0 ? (int32_t)((uint32_t)kNegInf << SH) : (int32_t)((uint32_t)kNegInfOrigin << SH);
-  auto edge = [&](uint32_t r) -> int32_t { return (int32_t)((uint32_t)edge_value(false, go, ge, (int32_t)r) << SH); };  // H(r, 0), r >= 1
+  const uint32_t rbase = CONT ? (uint32_t)d.bits_off : 0u;  // rows above the pair's first one
+  auto edge = [&](uint32_t r) -> int32_t { return (int32_t)((uint32_t)edge_value(false, go, ge, (int32_t)(r + rbase)) << SH); };  // H(r, 0), r >= 1
   // H(0, c): the free (or paid) leading gap; KIND 1 carries the column itself as the origin
   auto row0 = [&](int32_t c) -> int32_t {
     if (c <= 0) return 0;
-    return (int32_t)((uint32_t)edge_value(hfree, go, ge, c) << SH) + (KIND == 1 ? c : 0);
+    return (int32_t)((uint32_t)edge_value(hfree, go, ge, c) << SH) + ((KIND == 1 && !CONT) ? c : 0);
   };
 
   // ---- LDS: the reference codes of the four pairs in view order (column c at byte c - 1), then the lanes' tables ----
@@ -210,6 +219,24 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   if (have) {
     const uint8_t* src = a.codes + d.a2_off;
     for (uint32_t i = j; i < n; i += 16) lcodes[i] = src[rcflag ? n - 1u - i : i];
+  }
+  // CONT: {H, F} of row R for the columns strip 0 sweeps and the one before them, in the sweep's own units
+  int32_t* lrow = reinterpret_cast<int32_t*>(w.lds() + 4u * a.code_cap + b16_table_bytes(K)) + g * (2u * kB16RowCap);
+  const int32_t crow0 = dmin;  // column of lrow[0]: b16_first_col(0) - 1
+  if (CONT && have) {
+    const uint32_t* src = a.row + d.lastrow_off;
+    for (uint32_t i = j; i < kB16RowCap; i += 16) {
+      const int32_t cc = crow0 + (int32_t)i;
+      int32_t hh = neg, ff = neg;
+      if (cc == 0) hh = edge(0);
+      else if (cc >= 1 && cc <= (int32_t)n) {
+        const uint32_t v = src[cc];
+        hh = (int32_t)((uint32_t)(sext16((int32_t)v) - goe) << SH);
+        ff = (int32_t)((uint32_t)((int32_t)v >> 16) << SH);
+      }
+      lrow[2u * i] = hh;
+      lrow[2u * i + 1u] = ff;
+    }
   }
   w.sync();
   auto code_at = [&](int32_t c) -> uint32_t {  // clamped: lanes off the reference read some column of it and discard the result
@@ -275,7 +302,7 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
         }
         bot_h = cw <= 0 ? edge(r0 + (uint32_t)K) : neg;  // what the strip below sees while this one waits for column 1
         bot_f = neg;
-        if (s_cur == 0) prev_up_h = row0(cw - 1);
+        if (s_cur == 0) prev_up_h = CONT ? lrow[2 * (cw - 1 - crow0)] : row0(cw - 1);
 #pragma unroll
         for (uint32_t b = 0; b < kB16Codes; ++b) {
           const uint32_t rowsel = (rcflag && b < 4u) ? 3u - b : b;  // reverse-complement view: the complement is folded into the table
@@ -292,8 +319,18 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
     int32_t up_h = w.rot16(bot_h);
     int32_t up_f = w.rot16(bot_f);
     if (t < (uint32_t)P) {  // the first strips: row 0 instead of a strip above (gotoh.h:112-116)
-      if (live && s_cur == 0 && (uint32_t)u < S_cur) { up_h = row0(c); up_f = neg; }  // (not past its window: the last step before strip 16 begins
-                                                                                        // delivers that strip's diagonal from lane 15)
+      if (live && s_cur == 0 && (uint32_t)u < S_cur) {  // (not past its window: the last step before strip 16 begins delivers that
+                                                        // strip's diagonal from lane 15)
+        if (CONT) {
+          const uint32_t i = (uint32_t)(c - crow0) < kB16RowCap ? (uint32_t)(c - crow0) : kB16RowCap - 1u;  // (past the staged columns only
+          up_h = lrow[2u * i];                                                                              // when strip 0 is the last one and runs
+          up_f = lrow[2u * i + 1u];                                                                         // on along row m: see below)
+          if ((uint32_t)(c - crow0) >= kB16RowCap) { up_h = neg; up_f = neg; }
+        } else {
+          up_h = row0(c);
+          up_f = neg;
+        }
+      }
     }
     const uint32_t raw = raw_next;
     raw_next = code_at(c + 1);

@@ -4,6 +4,7 @@
 
 #include "band16.h"
 #include "band16_launch.h"
+#include "front.h"
 
 namespace tracyhip {
 
@@ -28,6 +29,26 @@ template <int K, int KIND>
 __global__ __launch_bounds__(64) void band16_kernel(Band16Args a) {
   DeviceWave16 w;
   band16_body<DeviceWave16, K, KIND>(w, a, blockIdx.x);
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void band16_cont_kernel(Band16Args a) {
+  DeviceWave16 w;
+  band16_body<DeviceWave16, K, 1, true>(w, a, blockIdx.x);
+}
+
+// front.h: one wave per pair
+__global__ __launch_bounds__(64) void front_place_kernel(const FrontDesc* __restrict__ desc, const uint32_t* __restrict__ row, int32_t goe, int32_t halfw,
+                                                         PairDesc* __restrict__ pairs, FrontOut* __restrict__ fo) {
+  DeviceWave16 w;
+  front_place_body(w, desc[blockIdx.x], row, goe, halfw, pairs + blockIdx.x, fo + blockIdx.x);
+}
+__global__ __launch_bounds__(64) void front_certify_kernel(const FrontDesc* __restrict__ desc, const uint32_t* __restrict__ row, int32_t go, int32_t ge,
+                                                           int32_t halfw, const int32_t* __restrict__ scores, const uint32_t* __restrict__ ends,
+                                                           FrontOut* __restrict__ fo) {
+  DeviceWave16 w;
+  const FrontDesc f = desc[blockIdx.x];
+  front_certify_body(w, f, row, go, ge, halfw, scores[f.out], ends[2 * f.out + 1], fo + blockIdx.x);
 }
 
 // Substitution tables: int16 [6 codes][stride] per sequence.  Profile rows: the int of the fp32 chain of align.h:112-117 against the
@@ -80,6 +101,32 @@ hipError_t launch_band16(int K, int kind, const Band16Args& a, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
 #undef TRACY_B16
+  return hipGetLastError();
+}
+
+hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s) {
+  if (a.npairs == 0) return hipSuccess;
+  const dim3 grid((a.npairs + 3u) / 4u);
+  const uint32_t lds = 4u * a.code_cap + b16_table_bytes(K) + 4u * 2u * kB16RowCap * 4u;
+  switch (K) {
+    case 12: hipLaunchKernelGGL((band16_cont_kernel<12>), grid, dim3(64), lds, s, a); break;
+    case 8: hipLaunchKernelGGL((band16_cont_kernel<8>), grid, dim3(64), lds, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_front_place(const FrontDesc* d_desc, uint32_t n, const uint32_t* row, int32_t goe, int32_t halfw, PairDesc* d_pairs, FrontOut* d_fo,
+                              hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(front_place_kernel, dim3(n), dim3(64), 0, s, d_desc, row, goe, halfw, d_pairs, d_fo);
+  return hipGetLastError();
+}
+
+hipError_t launch_front_certify(const FrontDesc* d_desc, uint32_t n, const uint32_t* row, int32_t go, int32_t ge, int32_t halfw, const int32_t* d_scores,
+                                const uint32_t* d_ends, FrontOut* d_fo, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(front_certify_kernel, dim3(n), dim3(64), 0, s, d_desc, row, go, ge, halfw, d_scores, d_ends, d_fo);
   return hipGetLastError();
 }
 

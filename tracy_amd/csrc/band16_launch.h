@@ -21,6 +21,14 @@ hipError_t launch_b16_tables(const B16TableDesc* d_desc, uint32_t nseq, const vo
                              int32_t qlimit, int shift, int16_t* out, int32_t* err, hipStream_t s);
 // kind 0: traceback words + walk; kind 1: origin-tracking sweep
 hipError_t launch_band16(int K, int kind, const Band16Args& a, hipStream_t s);
+// the sweep below a stored prefix row (Band16Args::row; K = 8 or 12), and the two kernels of front.h around it
+hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s);
+struct FrontDesc;
+struct FrontOut;
+hipError_t launch_front_place(const FrontDesc* d_desc, uint32_t n, const uint32_t* row, int32_t goe, int32_t halfw, PairDesc* d_pairs, FrontOut* d_fo,
+                              hipStream_t s);
+hipError_t launch_front_certify(const FrontDesc* d_desc, uint32_t n, const uint32_t* row, int32_t go, int32_t ge, int32_t halfw, const int32_t* d_scores,
+                                const uint32_t* d_ends, FrontOut* d_fo, hipStream_t s);
 
 }  // namespace tracyhip
 #endif

@@ -794,6 +794,60 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
   return TRACYHIP_OK;  // (bit 1 -- a walk left its band -- is the caller's to resolve: such pairs report ops_len 0)
 }
 
+int run_front(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, const int16_t* d_qp, const uint32_t* d_row, const tracyhip_params* prm,
+              FrontResult& out) {
+  hipStream_t st = ctx->stream;
+  const size_t nf = fd.size();
+  out.fo.assign(nf, FrontOut{});
+  out.score.assign(nf, 0);
+  out.ce.assign(nf, 0);
+  if (nf == 0) return TRACYHIP_OK;
+  const size_t per = sizeof(FrontDesc) + sizeof(PairDesc) + sizeof(FrontOut) + sizeof(int32_t) + 2 * sizeof(uint32_t);
+  HIP_TRY(ctx->d_front.ensure(per * nf + 64));
+  PairDesc* d_pairs = static_cast<PairDesc*>(ctx->d_front.p);
+  FrontDesc* d_fd = reinterpret_cast<FrontDesc*>(d_pairs + nf);
+  FrontOut* d_fo = reinterpret_cast<FrontOut*>(d_fd + nf);
+  int32_t* d_fs = reinterpret_cast<int32_t*>(d_fo + nf);
+  uint32_t* d_fe = reinterpret_cast<uint32_t*>(d_fs + nf);
+  HIP_TRY(ctx->h_desc.ensure(sizeof(FrontDesc) * nf));
+  std::memcpy(ctx->h_desc.p, fd.data(), sizeof(FrontDesc) * nf);
+  HIP_TRY(hipMemcpyAsync(d_fd, ctx->h_desc.p, sizeof(FrontDesc) * nf, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx->d_err.ensure(kErrBytes));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
+  uint32_t max_rest = 0;
+  uint64_t cells = 0, bytes = 0;
+  for (const FrontDesc& f : fd) {
+    max_rest = std::max(max_rest, f.m_rest);
+    if (ctx->timing) {
+      cells += (uint64_t)b16_strips(f.m_rest, kFrontK) * kFrontK * (uint64_t)(kFrontK + 2 * kFrontHalfW);
+      bytes += 12ull * f.m_rest + f.m_rest + 2ull * kFrontHalfW + 4ull * (2 * kFrontHalfW + kFrontK) + 8ull * f.n;  // tables, codes, the kept row (twice: place, certify)
+    }
+  }
+  Band16Args a{};
+  a.pairs = d_pairs; a.npairs = (uint32_t)nf; a.qp = d_qp; a.codes = ctx->codes(); a.scores = d_fs; a.ends = d_fe;
+  a.err = static_cast<int32_t*>(ctx->d_err.p); a.go = prm->go; a.ge = prm->ge; a.hfree = 1; a.row = d_row;
+  a.code_cap = (max_rest + 2u * (uint32_t)kFrontHalfW + 16u) & ~3u;  // front_place_body: a sub-window is at most m_rest + 2 halfw + 2 columns
+  if (4ull * a.code_cap + b16_table_bytes(kFrontK) + 32ull * kB16RowCap > 64u * 1024u)
+    return set_error(TRACYHIP_ERR_RANGE, "run_front: traces of %u rows do not fit the staging area", max_rest);
+  int trc;
+  if ((trc = timing_begin(ctx, TRACYHIP_TIMER_ORIGIN, cells, bytes))) return trc;
+  HIP_TRY(launch_front_place(d_fd, (uint32_t)nf, d_row, prm->go + prm->ge, kFrontHalfW, d_pairs, d_fo, st));
+  HIP_TRY(launch_band16_cont(kFrontK, a, st));
+  HIP_TRY(launch_front_certify(d_fd, (uint32_t)nf, d_row, prm->go, prm->ge, kFrontHalfW, d_fs, d_fe, d_fo, st));
+  if ((trc = timing_end(ctx))) return trc;
+  std::vector<uint32_t> h_fe(2 * nf);
+  int32_t herr[kErrWords] = {};
+  HIP_TRY(hipMemcpyAsync(out.fo.data(), d_fo, sizeof(FrontOut) * nf, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(out.score.data(), d_fs, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(h_fe.data(), d_fe, sizeof(uint32_t) * 2 * nf, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  timing_collect(ctx);
+  if (herr[0] & 1) return set_error(TRACYHIP_ERR_RANGE, "a query-profile score does not fit the int16 table (profile values too large)");
+  for (size_t i = 0; i < nf; ++i) out.ce[i] = h_fe[2 * i + 1] ? h_fe[2 * i + 1] + out.fo[i].shift : 0u;
+  return TRACYHIP_OK;
+}
+
 // validate a pair list and turn it into device-side descriptors + staged payloads
 int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool needle, DpProblem& pb, uint64_t* max_mn) {
   if (!pairs) return set_error(TRACYHIP_ERR_ARG, "null pairs");
@@ -903,7 +957,7 @@ namespace tracyhip {
 // Checkpointed 16-bit score sweeps of `full` and prefix bounds of `pre` in ONE launch (strand by certificate with the
 // orientation voted beforehand, pipeline.hip).  Profile x code pairs of one strip height K; scores land at PairDesc::out.
 int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const std::vector<PairDesc>& full,
-                    const std::vector<PairDesc>& pre, int K, const tracyhip_params* prm, int32_t* d_scores, DpCkpt* ck) {
+                    const std::vector<PairDesc>& pre, int K, const tracyhip_params* prm, int32_t* d_scores, DpCkpt* ck, bool front_shape) {
   hipStream_t st = ctx->stream;
   const size_t nf = full.size(), np = pre.size();
   if (nf + np == 0) return TRACYHIP_OK;
@@ -933,10 +987,11 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   if (ctx->timing) {
     uint64_t cells = 0, bytes = 0;
     for (size_t i = 0; i < nf; ++i) { cells += (uint64_t)hd[i].m * hd[i].n; bytes += 24ull * hd[i].m + hd[i].n + 4; }
-    for (size_t i = 0; i < np; ++i) cells += (uint64_t)std::min<uint32_t>(hd[nf + i].m, (uint32_t)kPrefixLanes * K) * hd[nf + i].n;
+    for (size_t i = 0; i < np; ++i) cells += (uint64_t)std::min<uint32_t>(hd[nf + i].m, front_shape ? kFrontRows : (uint32_t)kPrefixLanes * K) * hd[nf + i].n;
     if ((trc = timing_begin(ctx, TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
   }
-  HIP_TRY(launch_gotoh_ckpt_prefix(K, af, (uint32_t)nf, ap, (uint32_t)np, st));
+  if (front_shape) HIP_TRY(launch_gotoh_ckpt_front(K, af, (uint32_t)nf, ap, (uint32_t)np, st));
+  else HIP_TRY(launch_gotoh_ckpt_prefix(K, af, (uint32_t)nf, ap, (uint32_t)np, st));
   if ((trc = timing_end(ctx))) return trc;
   int32_t herr[kErrWords] = {};
   HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));

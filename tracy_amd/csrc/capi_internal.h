@@ -16,6 +16,7 @@
 #include "../../include/tracy_hip.h"
 #include "dp_kernels.h"
 #include "band16_launch.h"
+#include "front.h"
 
 namespace tracyhip {
 
@@ -72,6 +73,7 @@ struct tracyhip_ctx {
   tracyhip::DevBuf d_pipe[64];
   tracyhip::DevBuf d_ckpt, d_lastrow, d_band;  // pipeline intermediates (align_traces / decompose)
   tracyhip::DevBuf d_b16tab[4], d_b16desc;     // substitution tables of the band kernels (band16.h), their descriptors
+  tracyhip::DevBuf d_front;                    // descriptors / pairs / results of the pruned orientation sweep (front.h)
   hipError_t ensure_codes(size_t bytes, hipStream_t st) {
     hipError_t e = d_codes.ensure(bytes + 2 * tracyhip::kCodePad);
     if (e != hipSuccess) return e;
@@ -123,6 +125,7 @@ struct tracyhip_ctx {
     d_aftab.release(); aftab_ready = false;
     for (auto& b : d_b16tab) b.release();
     d_b16desc.release();
+    d_front.release();
     h_desc.release();
     h_off.release();
     h_tmp.release();
@@ -194,7 +197,7 @@ struct DpCkpt {
 // origin-tracking sweep: one pass of strip height K, columns and scores inside the packed fields (dp_lane.h origin_step)
 bool origin_ok(const tracyhip_params* prm, uint32_t maxm, uint32_t maxn, int K);
 int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const std::vector<PairDesc>& full,
-                    const std::vector<PairDesc>& pre, int K, const tracyhip_params* prm, int32_t* d_scores, DpCkpt* ck);
+                    const std::vector<PairDesc>& pre, int K, const tracyhip_params* prm, int32_t* d_scores, DpCkpt* ck, bool front_shape = false);
 int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, bool needle, bool trace,
            int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len, int stage = DP_PLAIN,
            DpCkpt* ck = nullptr);
@@ -231,5 +234,17 @@ bool origin16_ok(const tracyhip_params* prm, uint32_t maxm, uint32_t maxn);
 int build_b16_tables(tracyhip_ctx* ctx, DevBuf& buf, const void* d_a1, bool strings, std::vector<B16TableDesc>& desc, const tracyhip_params* prm);
 int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, int32_t* d_scores, uint32_t* d_ends, uint8_t* d_ops,
                const uint64_t* d_ops_off, uint32_t* d_ops_len);
+// The pruned orientation sweep (front.h) of fd.size() pairs whose prefix rows are in d_row (PAIR_KEEP_ROW): band placed, band swept
+// below the kept row (strip height K, band of 2 halfw + 1 diagonals), certificate.  FrontDesc::out must be the pair's index in fd.
+// Host results per pair: fo (ok: the score is gotohScore), score, c_e as a window column (0: none).
+struct FrontResult {
+  std::vector<FrontOut> fo;
+  std::vector<int32_t> score;
+  std::vector<uint32_t> ce;
+};
+constexpr int kFrontK = 12;
+constexpr int32_t kFrontHalfW = 90;  // 2 * 90 + 12 <= 15 * 13: the widest band one period of the K = 12 strips holds
+int run_front(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, const int16_t* d_qp, const uint32_t* d_row, const tracyhip_params* prm,
+              FrontResult& out);
 }  // namespace tracyhip
 #endif

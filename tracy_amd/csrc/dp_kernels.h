@@ -40,6 +40,8 @@ enum : uint32_t {
   PAIR_BANDED = 4u,      // full-matrix traceback on the diagonals band_dmin .. band_dmax only (multi-pass form: every pass sweeps
                          // the columns its rows can reach inside the band; cells outside read as -inf).  The caller certifies the
                          // result (pipeline.hip, final alignments) and repeats the pair without the flag otherwise.
+  PAIR_KEEP_ROW = 8u,    // prefix-bound kernel: leave row R of the prefix behind -- one dword per column c at lastrow[lastrow_off + c],
+                         // low half H(R, c) + (go + ge), high half F(R, c) -- for the band kernels to continue from (band16.h)
 };
 
 // one DP problem; lives in device memory, built on the host
@@ -1221,6 +1223,10 @@ TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
 // Domain (checked by the caller): hfree, !vfree, ge < 0, go <= 0, m > R, narrow_ok (int16 range).
 // ------------------------------------------------------------------------------------------------
 constexpr int kPrefixLanes = 8;  // lanes per pair of the prefix-bound kernel: rows 1 .. 8*K, eight pairs per wave
+// the prefix of the pruned orientation sweep (front.h): sixteen lanes of eight rows -- four pairs per wave, twice the waves of the
+// 8 x K shape for the same rows (a batch of 10 000 traces is 2 500 waves of the latter: two or three per SIMD, issue bound)
+constexpr int kFrontPrefixLanes = 16, kFrontPrefixK = 8;
+constexpr uint32_t kFrontRows = (uint32_t)kFrontPrefixLanes * kFrontPrefixK;
 
 // COMPACT: the form for references of A C G T (four code rows in LDS); as with the sweeps, both forms are launched over the
 // same pairs and every group of lanes works on its pair in the form the reference calls for (DpArgs::special_blocks)
@@ -1308,6 +1314,8 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
   };
   // running maxima of H (as Hg) and F of row R: the last slot of the group's last lane
   int32_t mx_hg = edge_value(false, go, ge, (int32_t)R) + goe, mx_f = kNegInf16;
+  uint32_t* keep_row = (valid && Lg == GL - 1 && (d.flags & PAIR_KEEP_ROW) && a.lastrow) ? reinterpret_cast<uint32_t*>(a.lastrow + d.lastrow_off) : nullptr;
+  uint32_t kept[4] = {0, 0, 0, 0};  // row R of the last four steps (PAIR_KEEP_ROW): stored a chunk later, see the loop
   auto do_step = [&](uint32_t t, const SubPacked<K>& sub) {
     const int32_t c = (int32_t)t - (int32_t)Lg;
     int32_t up_h = w.shift_up(bot_h);
@@ -1326,19 +1334,55 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
       if (Lg == GL - 1) {
         mx_hg = max16(mx_hg, nb_h);
         mx_f = max16(mx_f, nb_f);
+        kept[(t - 1u) & 3u] = ((uint32_t)nb_h & 0xffffu) | ((uint32_t)nb_f << 16);
       }
     }
   };
-  SubPacked<K> qa, qb;
+  // The codes of four columns in one dword, loaded a chunk (four steps) before they are looked up: byte k = column c0 + k of the
+  // lane's view, complemented where the window is read as its reverse complement.  (A byte load per step, waited for on the spot,
+  // cost a memory round trip per step: the kernel ran at a third of the sweeps' rate.)  Lanes off the window read the pad of the
+  // code buffer (kCodePad) or a neighbouring window -- codes either way -- and drop the result.
   const QpLane ql = qp_lane<K, NCODES>(qp_tab, L);
-  qp_fetch<K, NCODES>(ql, code_at(1 - (int32_t)Lg), qa);
-  for (uint32_t t = 1; t <= t_end; t += 2) {
-    qp_fetch<K, NCODES>(ql, code_at((int32_t)t - (int32_t)Lg + 1), qb);
-    do_step(t, qa);
-    if (t + 1 > t_end) break;
-    qp_fetch<K, NCODES>(ql, code_at((int32_t)t - (int32_t)Lg + 2), qa);
-    do_step(t + 1, qb);
+  // (branch-free: the load of the next chunk is issued before this chunk's steps and first touched after them)
+  auto load4 = [&](int32_t c0) -> uint32_t {
+    const int32_t x = c0 < -64 ? -64 : (c0 > (int32_t)n + 64 ? (int32_t)n + 64 : c0);
+    const int64_t at = rcflag ? (int64_t)n - x - 3 : (int64_t)x - 1;
+    uint32_t v;
+    __builtin_memcpy(&v, a2c + at, 4);
+    return v;
+  };
+  auto view4 = [&](uint32_t raw) -> uint32_t {
+    const uint32_t sw = __builtin_bswap32(raw);
+    const uint32_t cv = sw ^ (((~sw >> 2) & 0x01010101u) * 3u);  // bytes 0 .. 3: complement = xor 3
+    return rcflag ? cv : raw;
+  };
+  (void)code_at;
+  // the kept row's values of a chunk go out at the top of the next one, behind the wait for that chunk's codes: stores count in
+  // the same counter as loads, and issued where they arise they would make every chunk wait for a store round trip
+  auto flush_kept = [&](uint32_t t0) {  // the chunk that began at step t0
+    if (!keep_row) return;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      const int32_t c = (int32_t)(t0 + k) - (int32_t)Lg;
+      if (c >= 1 && c <= (int32_t)n) keep_row[c] = kept[k];
+    }
+  };
+  uint32_t raw_next = load4(1 - (int32_t)Lg);
+  for (uint32_t t = 1; t <= t_end; t += 4) {
+    const uint32_t cw = view4(raw_next);
+    raw_next = load4((int32_t)t + 4 - (int32_t)Lg);
+    if (t > 1) flush_kept(t - 4);
+    SubPacked<K> q0, q1, q2, q3;
+    qp_fetch<K, NCODES>(ql, cw & 0xffu, q0);
+    qp_fetch<K, NCODES>(ql, (cw >> 8) & 0xffu, q1);
+    qp_fetch<K, NCODES>(ql, (cw >> 16) & 0xffu, q2);
+    qp_fetch<K, NCODES>(ql, cw >> 24, q3);
+    do_step(t, q0);      // (steps past t_end find every lane off its window)
+    do_step(t + 1, q1);
+    do_step(t + 2, q2);
+    do_step(t + 3, q3);
   }
+  if (t_end >= 1) flush_kept(((t_end - 1u) & ~3u) + 1u);
   if (valid && Lg == GL - 1 && a.scores) {
     const int32_t h = sext16(mx_hg) - goe, f = sext16(mx_f);
     a.scores[d.out] = h > f ? h : f;

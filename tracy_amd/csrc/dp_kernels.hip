@@ -87,11 +87,13 @@ __global__ __launch_bounds__(64) void gotoh_origin_kernel(DpArgs a) {
 }
 // one launch, two kinds of workgroups: blocks [0, nfull) run the checkpointed 16-bit score sweep of `full`, the rest the
 // prefix bound of `pre` (GL lanes per pair) -- the short prefix workgroups fill the tail of the long sweeps
-template <int K, int GL, bool COMPACT = false>
+// (the prefix workgroups come first: they walk as many columns as a sweep does, with fewer rows -- started last they would be the tail)
+template <int K, int GL, bool COMPACT = false, int KP = K>
 __global__ __launch_bounds__(64) void gotoh_ckpt_prefix_kernel(DpArgs full, uint32_t nfull, DpArgs pre, uint32_t npre) {
   DeviceWave w;
-  if (blockIdx.x < nfull) gotoh_body<DeviceWave, K, MODE_QP, false, true, true, 0, COMPACT>(w, full, blockIdx.x);
-  else gotoh_prefix_body<DeviceWave, K, GL, COMPACT>(w, pre, (blockIdx.x - nfull) * (64u / GL), npre);
+  const uint32_t ngroups = (npre + 64u / GL - 1u) / (64u / GL);
+  if (blockIdx.x < ngroups) gotoh_prefix_body<DeviceWave, KP, GL, COMPACT>(w, pre, blockIdx.x * (64u / GL), npre);
+  else gotoh_body<DeviceWave, K, MODE_QP, false, true, true, 0, COMPACT>(w, full, blockIdx.x - ngroups);
 }
 // prefix bound of the semiglobal score: GL lanes per pair, 64/GL pairs per workgroup
 template <int K, int GL, bool COMPACT = false>
@@ -415,6 +417,32 @@ hipError_t launch_gotoh_ckpt_prefix(int K, const DpArgs& full, uint32_t nfull, c
     default: return hipErrorInvalidValue;
   }
 #undef TRACY_COMBO_CASE
+  return hipGetLastError();
+}
+
+// the same with the prefix shape of the pruned orientation sweep (front.h): kFrontPrefixLanes lanes of kFrontPrefixK rows per pair
+hipError_t launch_gotoh_ckpt_front(int K, const DpArgs& full, uint32_t nfull, const DpArgs& pre, uint32_t npre, hipStream_t s) {
+  if (nfull + npre == 0) return hipSuccess;
+  constexpr int GL = kFrontPrefixLanes, KP = kFrontPrefixK;
+  const dim3 grid(nfull + (npre + 64 / GL - 1) / (64 / GL));
+  auto lds = [](int KK, bool compact) {
+    const uint32_t pre_b = lds_bytes_prefix(KP, compact), sw = lds_bytes_sweep16(KK, compact);
+    return pre_b > sw ? pre_b : sw;
+  };
+#define TRACY_FRONT_CASE(KK)                                                                                            \
+  case KK:                                                                                                              \
+    if (full.special_blocks) {                                                                                          \
+      hipLaunchKernelGGL((gotoh_ckpt_prefix_kernel<KK, GL, true, KP>), grid, dim3(64), lds(KK, true), s, full, nfull, pre, npre); \
+      hipLaunchKernelGGL((gotoh_ckpt_prefix_kernel<KK, GL, false, KP>), grid, dim3(64), lds(KK, false), s, full, nfull, pre, npre); \
+    } else {                                                                                                            \
+      hipLaunchKernelGGL((gotoh_ckpt_prefix_kernel<KK, GL, false, KP>), grid, dim3(64), lds(KK, false), s, full, nfull, pre, npre); \
+    }                                                                                                                   \
+    break;
+  switch (K) {
+    TRACY_FRONT_CASE(12) TRACY_FRONT_CASE(15) TRACY_FRONT_CASE(16)
+    default: return hipErrorInvalidValue;
+  }
+#undef TRACY_FRONT_CASE
   return hipGetLastError();
 }
 

@@ -1,0 +1,114 @@
+// front.h -- the orientation score of a trace against its window without sweeping the window under the trace's first rows.
+//
+// gotohScore(trimmed trace, window) (sage.h:239-240, AlignConfig<true,false>) is the maximum of row m.  The prefix sweep
+// (gotoh_prefix_body: rows 1..R over ALL columns, R = 8K) leaves row R behind (PAIR_KEEP_ROW): v(c) = max(H, F)(R, c) is the most
+// any path can have collected when it leaves row R at column c, and below row R a path gains at most
+// rest = sum over the rows > R of max(0, best substitution score of the row) and pays at least |ge| per gap step (go <= 0, ge < 0;
+// only the trailing run of row m is free).  So:
+//   1. front_place: c* = the first column with the largest v; the band kernels (band16.h, CONT) continue rows R+1..m from the
+//      stored row on the diagonals c* - w .. c* + w (diagonal = column at row R), which yields S' = the best path that stays on them
+//      (the last strip runs on to the end of the window: the free trailing run).
+//   2. front_certify: a path that leaves row R at column c and is NOT on those diagonals all the way makes more than
+//      margin(c) = min(c - (c* - w), (c* + w) - c) gap steps (-1 outside the band: none needed), so it scores at most
+//      v(c) + rest - |ge| (margin(c) + 1).  If that is < S' for every column 0..n, every path scoring >= S' was inside the band:
+//      S' = gotohScore, and c_e -- the first column of row m that reaches it (row_m_end_kernel) -- is the band's.  Otherwise the pair
+//      takes the full sweep.  Nothing is ever decided on an uncertified score.
+// A trace that matches its window somewhere (loss below |ge| w) certifies; a repeat of the target far away, or a trace of noise,
+// does not.
+#ifndef TRACY_AMD_FRONT_H
+#define TRACY_AMD_FRONT_H
+
+#include "band16.h"
+
+namespace tracyhip {
+
+struct FrontDesc {
+  uint64_t row_off;     // row R of the prefix sweep: column c at row[row_off + c] (PAIR_KEEP_ROW layout)
+  uint64_t a2_off;      // the window's codes
+  uint64_t tab_off;     // row R + 1 of the trace in the substitution tables (int16 units)
+  uint32_t tab_stride;  // rows per code of that table
+  uint32_t m_rest;      // rows below R
+  uint32_t n;           // columns of the window
+  uint32_t flags;       // PAIR_A2_REVCOMP
+  uint32_t out;         // index of the pair's outputs
+  uint32_t R;           // rows of the prefix
+  int32_t rest;         // sum over the rows > R of max(0, best substitution score of the row)
+  uint32_t pad;
+};
+struct FrontOut {
+  int32_t vmax;     // max_c v(c)
+  uint32_t cstar;   // its first column
+  uint32_t shift;   // columns of the window left of the sub-window the band kernels sweep
+  uint32_t ok;      // front_certify: 1 = the band's score is gotohScore
+};
+
+TR_HD int32_t front_v(uint32_t x, int32_t goe) {
+  const int32_t h = sext16((int32_t)x) - goe, f = (int32_t)x >> 16;
+  return h > f ? h : f;
+}
+
+// One wave per pair: c*, the band around it, the sub-window that holds the band, the pair the band kernels sweep.
+template <class W>
+TR_HD void front_place_body(W& w, const FrontDesc& f, const uint32_t* row, int32_t goe, int32_t halfw, PairDesc* pair, FrontOut* fo) {
+  const uint32_t L = w.lane();
+  const uint32_t* r = row + f.row_off;
+  int32_t best = INT32_MIN;
+  uint32_t bc = 0;
+  for (uint32_t c = 1u + L; c <= f.n; c += 64u) {
+    const int32_t v = front_v(r[c], goe);
+    if (v > best) { best = v; bc = c; }
+  }
+  int32_t vmax = INT32_MIN;
+  uint32_t cstar = 0;
+  for (uint32_t l = 0; l < 64u; ++l) {
+    const int32_t v = (int32_t)w.bcast((uint32_t)best, l);
+    const uint32_t c = w.bcast(bc, l);
+    if (c != 0 && (v > vmax || (v == vmax && c < cstar))) { vmax = v; cstar = c; }
+  }
+  if (L != 0) return;
+  const int32_t dlo = (int32_t)cstar - halfw, dhi = (int32_t)cstar + halfw;
+  const uint32_t a = dlo > 1 ? (uint32_t)(dlo - 1) : 0u;
+  uint32_t nsub = f.n - a;
+  const uint64_t reach = (uint64_t)f.m_rest + (uint64_t)(dhi - (int32_t)a) + 1ull;  // past it no cell of the band
+  if ((uint64_t)nsub > reach) nsub = (uint32_t)reach;
+  PairDesc d{};
+  d.a1_off = f.tab_off;
+  d.a1_stride = f.tab_stride;
+  d.m = f.m_rest;
+  d.n = nsub;
+  d.a2_stride = nsub;
+  d.a2_off = (f.flags & PAIR_A2_REVCOMP) ? f.a2_off + (uint64_t)(f.n - a - nsub) : f.a2_off + a;  // reverse view: column c is byte n - c
+  d.out = f.out;
+  d.flags = f.flags & PAIR_A2_REVCOMP;
+  d.ckpt_off = band_pack(dlo - (int32_t)a, dhi - (int32_t)a);
+  d.lastrow_off = f.row_off + a;
+  d.bits_off = f.R;
+  *pair = d;
+  fo->vmax = vmax;
+  fo->cstar = cstar;
+  fo->shift = a;
+  fo->ok = 0;
+}
+
+// One wave per pair, after the band sweep: does any path outside the band reach its score?
+template <class W>
+TR_HD void front_certify_body(W& w, const FrontDesc& f, const uint32_t* row, int32_t go, int32_t ge, int32_t halfw, int32_t score, uint32_t c_end,
+                              FrontOut* fo) {
+  const uint32_t L = w.lane();
+  const uint32_t* r = row + f.row_off;
+  const int32_t goe = go + ge;
+  const int64_t age = -(int64_t)ge;
+  const int64_t dlo = (int64_t)fo->cstar - halfw, dhi = (int64_t)fo->cstar + halfw;
+  bool bad = false;
+  for (uint32_t c = L; c <= f.n; c += 64u) {
+    const int64_t v = c == 0 ? (int64_t)edge_value(false, go, ge, (int32_t)f.R) : (int64_t)front_v(r[c], goe);
+    const int64_t cc = (int64_t)c;
+    const int64_t margin = (cc >= dlo && cc <= dhi) ? (cc - dlo < dhi - cc ? cc - dlo : dhi - cc) : -1;
+    bad = bad || (v + (int64_t)f.rest - age * (margin + 1) >= (int64_t)score);
+  }
+  const bool any = w.ballot(bad) != 0;
+  if (L == 0) fo->ok = (!any && c_end != 0) ? 1u : 0u;
+}
+
+}  // namespace tracyhip
+#endif

@@ -521,20 +521,144 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   // holds the bound).  Traces whose bounds are close, or whose certificate fails, get both full passes: the decision is
   // always the reference's `gsFwd > gsRev`.
   bool use_prefix = !given && use_band && ck.narrow && !in.exact && getenv("TRACYHIP_NO_PREFIX") == nullptr;
+  // The pruned sweep of the voted strand (front.h): its prefix rows are swept over the whole window like the other strand's, the
+  // rows below them only on a band around the best column of the prefix -- and the result is taken when its certificate holds.
+  // Only where nothing but the two ends of the preliminary alignment is read (`tracy align`): a heterozygous trace (`tracy
+  // decompose`) scores far below its row maxima and would rarely certify.  Exact results either way (TRACYHIP_NO_FRONT=1: off).
+  bool use_front = ends_path && b16 && !given && use_band && ck.narrow && getenv("TRACYHIP_NO_FRONT") == nullptr &&
+                   getenv("TRACYHIP_NO_PREFIX") == nullptr && getenv("TRACYHIP_NO_VOTE") == nullptr;
   // traces no taller than the prefix (8K rows) have nothing left to bound: they get both full passes
   std::vector<uint8_t> elig(nt, 0);
-  if (use_prefix) {
+  if (use_prefix || use_front) {
     uint32_t ne = 0;
     for (uint32_t t = 0; t < nt; ++t) ne += elig[t] = mt[t] > (uint32_t)kPrefixLanes * choose_k(mt[t], MODE_QP);
-    if (ne == 0) use_prefix = false;
+    if (ne == 0) use_prefix = use_front = false;
   }
   // With one strip height for the whole batch the strand to sweep first is voted from shared k-mers before any DP runs
   // (kmer_vote_kernel), and the prefix bounds of the other strand ride in the same launch as the full sweeps, where their
   // short workgroups fill the tail.  Undecided votes get both full sweeps.  TRACYHIP_NO_VOTE=1: the two-stage form below.
   bool use_vote = use_prefix && getenv("TRACYHIP_NO_VOTE") == nullptr;
   const int K0 = choose_k(mt[0], MODE_QP);
-  for (uint32_t t = 0; t < nt && use_vote; ++t) use_vote = choose_k(mt[t], MODE_QP) == K0;
-  if (use_vote) {
+  for (uint32_t t = 0; t < nt && (use_vote || use_front); ++t)
+    if (choose_k(mt[t], MODE_QP) != K0) use_vote = use_front = false;
+  use_front = use_front && (K0 == 12 || K0 == 15 || K0 == 16);  // (launch_gotoh_ckpt_front; shorter traces are not worth a prefix)
+  std::vector<int8_t> front_strand(nt, -1);  // the strand whose score and c_e the pruned sweep certified
+  std::vector<uint32_t> front_ce(nt, 0);
+  if (use_front) {
+    std::vector<VoteDesc> hv(nt);
+    std::vector<RowMaxDesc> hrm(nt);
+    const uint32_t R = kFrontRows;  // every prefix of this branch has the 16 x 8 shape
+    for (uint32_t t = 0; t < nt; ++t) {
+      hv[t] = VoteDesc{in.a1_off[t], in.a2_off[t], mf[t], mt[t], rn[t], 0u};
+      hrm[t] = RowMaxDesc{in.a1_off[t], mf[t], mt[t], R};
+    }
+    const size_t need = (sizeof(VoteDesc) + sizeof(RowMaxDesc) + 3 * sizeof(uint32_t)) * (size_t)nt;
+    HIP_TRY(ctx->d_tmp[7].ensure(need));
+    VoteDesc* d_vd = static_cast<VoteDesc*>(ctx->d_tmp[7].p);
+    RowMaxDesc* d_rm = reinterpret_cast<RowMaxDesc*>(d_vd + nt);
+    int32_t* d_ub = reinterpret_cast<int32_t*>(d_rm + nt);
+    uint32_t* d_votes = reinterpret_cast<uint32_t*>(d_ub + nt);
+    HIP_TRY(hipMemcpyAsync(d_vd, hv.data(), sizeof(VoteDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_rm, hrm.data(), sizeof(RowMaxDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(kmer_vote_kernel, dim3(nt), dim3(64), 0, st, d_vd, static_cast<const float*>(d_prof), ctx->codes(), d_votes);
+    hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, st, d_rm, static_cast<const float*>(d_prof), (float)p.match, (float)p.mismatch, d_ub);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t> h_ub(nt);
+    std::vector<uint32_t> h_votes(2 * (size_t)nt);
+    HIP_TRY(hipMemcpyAsync(h_ub.data(), d_ub, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_votes.data(), d_votes, sizeof(uint32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
+    if (d_verr && !verr_fetched) HIP_TRY(hipMemcpyAsync(&h_verr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (d_verr) {
+      verr_fetched = true;
+      if (h_verr & 4) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
+    }
+    std::vector<int8_t> guess(nt, 0), both(nt, 1);
+    std::vector<PairDesc> fullv, prev;
+    std::vector<FrontDesc> fd;
+    std::vector<uint32_t> ft;
+    fullv.reserve(2 * (size_t)nt);
+    prev.reserve(2 * (size_t)nt);
+    fd.reserve(nt);
+    ft.reserve(nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+      const uint32_t vf = h_votes[2 * t], vr = h_votes[2 * t + 1];
+      guess[t] = vf >= vr ? 0 : 1;
+      const uint32_t hi = vf >= vr ? vf : vr, lo = vf >= vr ? vr : vf;
+      both[t] = (mt[t] > R && hi >= 32 && hi >= 2 * lo) ? 0 : 1;  // a clear majority of shared k-mers, or both sweeps
+      const int g = (int)guess[t];
+      const bool front = !both[t] && mt[t] - R > 2u * (uint32_t)kFrontK && rn[t] >= 1 &&
+                         origin16_ok(&p, mt[t], mt[t] - R + 2u * (uint32_t)kFrontHalfW + 16u);
+      if (front) {
+        PairDesc d = stage1_desc(t, g);
+        d.flags |= PAIR_KEEP_ROW;
+        prev.push_back(d);
+        if (in.exact) fullv.push_back(stage1_desc(t, 1 - g));
+        else prev.push_back(stage1_desc(t, 1 - g));
+        FrontDesc f{};
+        f.row_off = d.lastrow_off;
+        f.a2_off = in.a2_off[t];
+        f.tab_off = in.td[t].out_off + in.row0[t] + R;
+        f.tab_stride = in.td[t].stride;
+        f.m_rest = mt[t] - R;
+        f.n = rn[t];
+        f.flags = g ? PAIR_A2_REVCOMP : 0u;
+        f.out = (uint32_t)fd.size();
+        f.R = R;
+        f.rest = h_ub[t];
+        fd.push_back(f);
+        ft.push_back(t);
+      } else if (in.exact || both[t]) {
+        fullv.push_back(stage1_desc(t, g));
+        fullv.push_back(stage1_desc(t, 1 - g));
+      } else {
+        fullv.push_back(stage1_desc(t, g));
+        prev.push_back(stage1_desc(t, 1 - g));
+      }
+    }
+    DpCkpt ckv = ck;
+    if ((rc = run_ckpt_prefix(ctx, d_prof, ctx->codes(), fullv, prev, K0, &p, d_sc2, &ckv, true))) return rc;
+    FrontResult fres;
+    if ((rc = run_front(ctx, fd, in.d_qp, reinterpret_cast<const uint32_t*>(ck.d_lastrow), &p, fres))) return rc;
+    if ((rc = fetch_scores())) return rc;
+    // merge the scores of a repeat launch (which overwrites d_sc2 at the repeated entries only) into the host copy
+    auto repeat_full = [&](std::vector<std::pair<uint32_t, int>> const& what) -> int {
+      if (what.empty()) return TRACYHIP_OK;
+      int rr;
+      if ((rr = run_stage1(what, DP_CKPT))) return rr;
+      std::vector<int32_t> got(2 * (size_t)nt);
+      HIP_TRY(hipMemcpyAsync(got.data(), d_sc2, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      for (auto const& r : what) h_sc2[(size_t)r.second * nt + r.first] = got[(size_t)r.second * nt + r.first];
+      return TRACYHIP_OK;
+    };
+    std::vector<std::pair<uint32_t, int>> retry;
+    for (size_t i = 0; i < ft.size(); ++i) {
+      const uint32_t t = ft[i];
+      const int g = (int)guess[t];
+      if (fres.fo[i].ok && fres.ce[i]) {
+        h_sc2[(size_t)g * nt + t] = fres.score[i];
+        front_strand[t] = (int8_t)g;
+        front_ce[t] = fres.ce[i];
+      } else {
+        retry.emplace_back(t, g);
+      }
+    }
+    if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "pruned orientation sweep: %zu of %u traces, %zu not certified\n", ft.size(), nt, retry.size());
+    if ((rc = repeat_full(retry))) return rc;
+    if (!in.exact) {  // the other strand of a clear vote holds its prefix maximum: decided by its bound, or swept in full
+      retry.clear();
+      for (uint32_t t = 0; t < nt; ++t) {
+        if (both[t]) continue;
+        const size_t w = (size_t)guess[t] * nt + t, l = (size_t)(1 - guess[t]) * nt + t;
+        const int64_t bound_l = (int64_t)h_sc2[l] + h_ub[t];
+        const bool certified = guess[t] == 0 ? bound_l < (int64_t)h_sc2[w] : bound_l <= (int64_t)h_sc2[w];
+        if (certified) h_sc2[l] = (int32_t)std::min<int64_t>(bound_l, 0x7fffffff);
+        else retry.emplace_back(t, 1 - guess[t]);
+      }
+      if ((rc = repeat_full(retry))) return rc;
+    }
+  } else if (use_vote) {
     std::vector<VoteDesc> hv(nt);
     std::vector<RowMaxDesc> hrm(nt);
     for (uint32_t t = 0; t < nt; ++t) {
@@ -576,7 +700,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       else prev.push_back(stage1_desc(t, 1 - guess[t]));
     }
     DpCkpt ckv = ck;
-    if ((rc = run_ckpt_prefix(ctx, d_prof, ctx->codes(), fullv, prev, K0, &p, d_sc2, &ckv))) return rc;
+    if ((rc = run_ckpt_prefix(ctx, d_prof, ctx->codes(), fullv, prev, K0, &p, d_sc2, &ckv, false))) return rc;
     if ((rc = fetch_scores())) return rc;
     std::vector<std::pair<uint32_t, int>> retry;
     for (uint32_t t = 0; t < nt; ++t) {
@@ -733,8 +857,9 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       RowMaxDesc* d_rm = reinterpret_cast<RowMaxDesc*>(d_re + nt);
       std::vector<RowEndDesc> hre(nt);
       std::vector<RowMaxDesc> hrm(nt);
+      auto from_front = [&](uint32_t t) { return front_strand[t] >= 0 && (front_strand[t] != 0) == (h_rc[t] != 0); };  // (else the winner was swept in full)
       for (uint32_t t = 0; t < nt; ++t) {
-        hre[t] = RowEndDesc{pb.desc[t].lastrow_off, rn[t], 0};
+        hre[t] = RowEndDesc{pb.desc[t].lastrow_off, from_front(t) ? 0u : rn[t], 0};
         hrm[t] = RowMaxDesc{in.a1_off[t], mf[t], mt[t], 0u};
       }
       HIP_TRY(hipMemcpyAsync(d_re, hre.data(), sizeof(RowEndDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
@@ -750,6 +875,8 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       HIP_TRY(hipMemcpyAsync(h_ce.data(), d_ce, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(h_top.data(), d_top, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));  // (also: hre, hrm have been read)
+      for (uint32_t t = 0; t < nt; ++t)
+        if (from_front(t)) h_ce[t] = front_ce[t];
       // A path from (0, lead) to (m, c_e) collects at most top = sum over the rows of max(0, best entry of the row's table
       // column) on its diagonal steps, nothing positive on its vertical ones (go <= 0, ge < 0), and loses at least |ge| per
       // horizontal gap column: S* <= top - |ge| g.  (top is computed from the profile as it is -- normalised or not -- and is

@@ -9,9 +9,12 @@ trimReferenceSlice, 1 traceback DP of the full profile vs the trimmed slice.
 Weak scaling: the per-GPU batch is fixed; traces shard by index with no data-path collective, the only
 RCCL call is the final gather of the fixed-size result records.
 
-Legs (each: W warm-up + K timed steps between barriers): (1) the headline -- one lane, both orientations swept in full
-(`value`, `roofline`: the library's default, exact gsFwd / gsRev); (2) the opt-in strand-by-certificate mode; (3), (4) the same two on `--lanes-leg`
-chunks of the batch in flight.  Legs 2-4 are checked to return the headline leg's alignments and are reported beside it;
+Legs (each: W warm-up + K timed steps between barriers): (1) the headline -- one lane, exact gsFwd AND gsRev (`value`, `roofline`: what
+a zero-initialised job gets): the strand a k-mer vote does not pick is swept in full, the voted one by its first 128 rows over the
+window and a certified band below them (front.h; swept in full where the certificate fails); (2) the strand-by-certificate mode
+(only the winner's score exact -- all that tracy's output carries; what tracy_amd_cli runs): 128-row prefixes of both strands, the
+voted one continued on its band, the other one decided by its bound; (3), (4) the same two on `--lanes-leg` chunks of the batch in
+flight.  Legs 2-4 are checked to return the headline leg's alignments and are reported beside it;
 `--certificate-leg 0 --lanes-leg 0` runs the headline alone (what the rocprofv3 passes under profiles/ use).
 
 Beside the headline the default run also times BASELINE.json configs[2] (`tracy decompose`, 100 000 traces sharded over the
@@ -242,9 +245,9 @@ def main():
                            rr_len.ctypes.data_as(C.POINTER(C.c_uint32)), nt)
     job.trim_left = TRIM
     job.trim_right = TRIM
-    # headline leg: every cell of all four Gotoh calls per trace is evaluated (both orientations swept in full).  The
-    # library's default (strand by certificate, identical alignments, fewer cells) is timed as a second leg below and
-    # reported beside it -- it is never `value`.
+    # headline leg: both orientation scores exact (the strand the k-mer vote does not pick swept in full, the voted one pruned with a
+    # certificate: front.h).  The strand-by-certificate mode (identical alignments, only the winner's score exact, fewer cells) is
+    # timed as a second leg below and reported beside it -- it is never `value`.
     job.strand_by_certificate = 0
     r_i32 = {k: torch.zeros(nt, dtype=torch.int32, device=dev) for k in
              ("score_fwd", "score_rev", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final", "ops_len")}
@@ -276,7 +279,7 @@ def main():
     def read_timers():
         kt = capi.KernelTiming()
         res = {}
-        for name, which in (("score", 0), ("trace", 1), ("walk", 2), ("band", 3), ("prefix", 4), ("origin", 5)):
+        for name, which in (("score", 0), ("trace", 1), ("walk", 2), ("band", 3), ("prefix", 4), ("origin", 5), ("front", 9)):
             lib.tracyhip_timing_get(ctx._h, which, C.byref(kt))
             res[name] = dict(ms=kt.ms, launches=int(kt.launches), cells=int(kt.cells), bytes=int(kt.bytes))
         return res
@@ -375,7 +378,7 @@ def main():
         import glob
         pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm.json")))[-1]  # the latest round's PMC summary
         pmc = json.load(open(pmc_file))
-        per = {c: [r for r in pmc if r["counter"] == c and "gotoh_ckpt_kernel" in r["kernel"]] for c in ("WRITE_SIZE", "FETCH_SIZE")}
+        per = {c: [r for r in pmc if r["counter"] == c and "gotoh_ckpt" in r["kernel"]] for c in ("WRITE_SIZE", "FETCH_SIZE")}
         if per["WRITE_SIZE"] and per["FETCH_SIZE"]:
             traffic = int(per["WRITE_SIZE"][0]["bytes"] + per["FETCH_SIZE"][0]["bytes"])
             traffic_src = "profiles/%s (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE of this command, same batch)" % os.path.basename(pmc_file)
@@ -387,7 +390,7 @@ def main():
         band_traffic, band_traffic_src = pmc_traffic("band16_kernel", "r[0-9][0-9]_pmc_hbm.json")
     except Exception:  # noqa: BLE001
         pass
-    roofline = {"bound": "hbm", "kernel": "gotoh_ckpt_kernel<K,QP,narrow> (score-only Gotoh, forward + reverse-complement orientation in one launch, row m kept; dominant: %.0f%% of the step)"
+    roofline = {"bound": "hbm", "kernel": "gotoh_ckpt_prefix_kernel<K,16,compact,8> (score-only Gotoh, one launch: the full sweeps of the strand the vote does not pick, row m kept, + the 128-row prefixes of the voted strand over the whole window, row 128 kept; cells credited: the rows swept; dominant: %.0f%% of the step)"
                 % (100.0 * sc["ms"] / steps / (elapsed_max / steps * 1e3)),
                 "achieved": round(gbs(sc), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs(sc) / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(score_launch_ms, 3), "launches": sc["launches"],
@@ -404,7 +407,7 @@ def main():
                                      "algorithmic_bytes_per_launch": tr["bytes"] // max(tr["launches"], 1),
                                      "swept_cells_per_launch": tr["cells"] // max(tr["launches"], 1),
                                      "traffic": band_traffic, "traffic_source": band_traffic_src},
-                "ms_per_step": {"score": round(sc["ms"] / steps, 3), "preliminary_ends": round(og["ms"] / steps, 3),
+                "ms_per_step": {"score": round(sc["ms"] / steps, 3), "pruned_sweep_band": round(rl["front"]["ms"] / steps, 3), "preliminary_ends": round(og["ms"] / steps, 3),
                                 "band_traceback": round(bd["ms"] / steps, 3), "full_traceback": round(tr["ms"] / steps, 3),
                                 "walk": round(rl["walk"]["ms"] / steps, 3)},
                 # the preliminary alignment (trimmed trace vs the whole window) is only trimmed from: its two ends come from an
@@ -424,32 +427,30 @@ def main():
                                "full Gotoh (2 score-only + 2 traceback DPs per trace), scoring 3/-5/-10/-4, trims 50/50"
                                % (nt, mf, n), "traces_per_gpu": nt, "trace_len": mf, "ref_len": n,
                    "parallelism": "batch-sharded x%d, no data-path collective" % world, "lanes_per_gpu": max(1, args.lanes)},
-        # GCUPS counts the DP cells of the reference's four Gotoh calls per trace: two score-only sweeps and
-        # the final traceback are swept in full; the preliminary traceback is a band traceback from the score sweep's
-        # checkpoints, which re-sweeps only the bands its path crosses (about an eighth of its matrix) for the same `btr`
-        "cells_counted": "reference DP cells: 3 x (mt x n) + mf x slice per trace; the preliminary and the final alignment sweep certified diagonal bands of their matrices",
-        # the same step priced by the cells the kernels really evaluated (HIP-event timers: both orientation sweeps in full, the
-        # preliminary and the final alignment on their bands): what `value` would be if no stage were credited with a whole matrix it
-        # did not sweep
-        "gcups_swept_cells": round(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin")) / steps * world / (elapsed_max / steps) / 1e9, 2),
-        "cells_swept_per_step_rank0": int(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin")) / steps),
+        # GCUPS counts the DP cells of the reference's four Gotoh calls per trace.  What is swept: one orientation in
+        # full, the other by its prefix rows + a certified band, the preliminary and the final alignment on certified bands -- with
+        # results (scores, ends, strings) proven to be the whole matrices'; `gcups_swept_cells` prices the same step by those cells
+        "cells_counted": "reference DP cells: 3 x (mt x n) + mf x slice per trace; swept: one orientation in full, the voted one on 128 prefix rows + a certified band, the preliminary and the final alignment on certified diagonal bands",
+        # the same step priced by the cells the kernels really evaluated (HIP-event timers): what `value` would be if no stage were
+        # credited with a whole matrix it did not sweep
+        "gcups_swept_cells": round(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin", "front")) / steps * world / (elapsed_max / steps) / 1e9, 2),
+        "cells_swept_per_step_rank0": int(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin", "front")) / steps),
         "roofline": roofline,
     }
     if rl_cert is not None:
         csc, cpf = rl_cert["score"], rl_cert["prefix"]
-        # the library's default mode, timed on the same batch right after the headline leg: the likely strand is swept in full,
-        # the other one over its first 8K rows only (prefix bound, eight pairs per wave), and it is skipped when that score
-        # upper bound proves it cannot win.  Alignments are checked identical
-        # to the headline leg's above.  Reported for information: fewer cells are evaluated, so it is not `value`.
+        # strand by certificate, timed on the same batch right after the headline leg: 128-row prefixes of both strands over the
+        # window, the voted strand continued on its certified band (front.h), the other one skipped when its prefix maximum + the row
+        # maxima of its remaining rows prove it cannot win.  Alignments are checked identical to the headline leg's above.
+        # Reported for information: the loser's exact score is not computed, so it is not `value`.
         line["strand_by_certificate"] = {
             "ms_per_step": round(elapsed_cert_max / args.steps * 1e3, 3),
             "traces_per_s": round(nt * world * args.steps / elapsed_cert_max, 1),
-            "cells_swept_fraction": round(sum(rl_cert[k]["cells"] for k in ("score", "prefix", "trace", "band", "origin")) / steps / max(cells_rank, 1), 3),
-            # the strand to sweep first is voted from shared k-mers; its full sweeps and the prefix bounds of the other strand
-            # share one launch (the short prefix workgroups fill the tail of the long sweeps)
-            "sweep_launch": {"kernel": "gotoh_ckpt_prefix_kernel<K,8> (full sweeps + prefix bounds)",
+            "cells_swept_fraction": round(sum(rl_cert[k]["cells"] for k in ("score", "prefix", "trace", "band", "origin", "front")) / steps / max(cells_rank, 1), 3),
+            "sweep_launch": {"kernel": "gotoh_ckpt_prefix_kernel<K,16,compact,8> (the prefixes of both strands; full sweeps only where a vote is unclear)",
                              "avg_launch_ms": round(csc["ms"] / max(csc["launches"], 1), 3), "launches": csc["launches"],
                              "kernel_gcups": round(kgcups(csc), 1)},
+            "pruned_sweep_band_ms": round(rl_cert["front"]["ms"] / steps, 3),
             "alignments_identical_to_headline_leg": True,
         }
     if args.lanes_leg > 1 and elapsed_lanes[0] > 0:

@@ -365,7 +365,9 @@ int tracyhip_pair_bounds(const tracyhip_pairs* pairs, uint32_t parts, uint64_t* 
 #define TRACYHIP_TIMER_DECOMP 6 /* decomposeAlleles kernel; cells = alignment columns, bytes = rows + basecalls + table */
 #define TRACYHIP_TIMER_AFRAC 7  /* allelicFraction kernel; cells = grid points x diffnuc bound, bytes = signal windows read */
 #define TRACYHIP_TIMER_MISC 8   /* findBreakpoint, findHomozygousBreakpoint, generateSecondaryDecomposed, alignment rows, trims */
-#define TRACYHIP_TIMER_COUNT 9
+#define TRACYHIP_TIMER_FRONT 9  /* pruned orientation sweep of `tracy align` (front.h): band placement, the band sweep below the prefix
+                                   rows, certificate; cells = the band's, bytes = tables + codes + the kept row (read twice) */
+#define TRACYHIP_TIMER_COUNT 10
 typedef struct {
   double ms;         /* summed launch durations */
   uint64_t launches;

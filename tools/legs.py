@@ -19,7 +19,7 @@ HBM_PEAK_GBS = 8000.0
 VALU_PEAK = 78.6       # T lane-ops/s: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 FP32_VECTOR_PEAK = 157.3  # TFLOP/s (MI355X_MICROARCH.md), FMA = 2 flops; separately rounded mul / add reach half of it per issue slot
 
-TIMERS = (("score", 0), ("trace", 1), ("walk", 2), ("band", 3), ("prefix", 4), ("origin", 5), ("decompose", 6), ("allelic_fraction", 7), ("misc", 8))
+TIMERS = (("score", 0), ("trace", 1), ("walk", 2), ("band", 3), ("prefix", 4), ("origin", 5), ("decompose", 6), ("allelic_fraction", 7), ("misc", 8), ("front", 9))
 
 
 def rank_threads(world=None):

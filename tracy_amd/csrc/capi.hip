@@ -830,7 +830,7 @@ int run_front(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, const int16_t
   if (4ull * a.code_cap + b16_table_bytes(kFrontK) + 32ull * kB16RowCap > 64u * 1024u)
     return set_error(TRACYHIP_ERR_RANGE, "run_front: traces of %u rows do not fit the staging area", max_rest);
   int trc;
-  if ((trc = timing_begin(ctx, TRACYHIP_TIMER_ORIGIN, cells, bytes))) return trc;
+  if ((trc = timing_begin(ctx, TRACYHIP_TIMER_FRONT, cells, bytes))) return trc;
   HIP_TRY(launch_front_place(d_fd, (uint32_t)nf, d_row, prm->go + prm->ge, kFrontHalfW, d_pairs, d_fo, st));
   HIP_TRY(launch_band16_cont(kFrontK, a, st));
   HIP_TRY(launch_front_certify(d_fd, (uint32_t)nf, d_row, prm->go, prm->ge, kFrontHalfW, d_fs, d_fe, d_fo, st));
@@ -956,17 +956,21 @@ int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool 
 namespace tracyhip {
 // Checkpointed 16-bit score sweeps of `full` and prefix bounds of `pre` in ONE launch (strand by certificate with the
 // orientation voted beforehand, pipeline.hip).  Profile x code pairs of one strip height K; scores land at PairDesc::out.
-int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const std::vector<PairDesc>& full,
-                    const std::vector<PairDesc>& pre, int K, const tracyhip_params* prm, int32_t* d_scores, DpCkpt* ck, bool front_shape) {
+int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const std::vector<PairDesc>& full, const std::vector<int>& fullk,
+                    const std::vector<PairDesc>& pre, const tracyhip_params* prm, int32_t* d_scores, DpCkpt* ck, bool front_shape) {
   hipStream_t st = ctx->stream;
   const size_t nf = full.size(), np = pre.size();
   if (nf + np == 0) return TRACYHIP_OK;
   HIP_TRY(ctx->h_desc.ensure(sizeof(PairDesc) * (nf + np)));
   PairDesc* hd = static_cast<PairDesc*>(ctx->h_desc.p);
-  // longest sweeps first, as run_dp orders them
+  // the sweeps by strip height (one launch each; the prefix workgroups ride with the first), longest first inside a launch, as
+  // run_dp orders them
   std::vector<uint32_t> order(nf);
   for (uint32_t i = 0; i < nf; ++i) order[i] = i;
-  auto before = [&](uint32_t x, uint32_t y) { return (uint64_t)full[x].m * full[x].n > (uint64_t)full[y].m * full[y].n; };
+  auto before = [&](uint32_t x, uint32_t y) {
+    if (fullk[x] != fullk[y]) return fullk[x] > fullk[y];
+    return (uint64_t)full[x].m * full[x].n > (uint64_t)full[y].m * full[y].n;
+  };
   if (!std::is_sorted(order.begin(), order.end(), before)) std::stable_sort(order.begin(), order.end(), before);
   for (size_t i = 0; i < nf; ++i) hd[i] = full[order[i]];
   for (size_t i = 0; i < np; ++i) hd[nf + i] = pre[i];
@@ -980,27 +984,43 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   a.qlimit = sub_limit(prm);
   if (d_a2 == ctx->codes() && !ctx->no_compact) a.special_blocks = ctx->special_blocks();
   a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.ckpt_narrow = 1;
-  DpArgs af = a, ap = a;
-  af.pairs = static_cast<const PairDesc*>(ctx->d_desc.p);
-  ap.pairs = af.pairs + nf;
+  DpArgs ap = a;
+  ap.pairs = static_cast<const PairDesc*>(ctx->d_desc.p) + nf;
+  std::vector<std::pair<uint32_t, int>> narrow_launches;
+  uint64_t max_mn = 0;
   int trc;
-  if (ctx->timing) {
-    uint64_t cells = 0, bytes = 0;
-    for (size_t i = 0; i < nf; ++i) { cells += (uint64_t)hd[i].m * hd[i].n; bytes += 24ull * hd[i].m + hd[i].n + 4; }
-    for (size_t i = 0; i < np; ++i) cells += (uint64_t)std::min<uint32_t>(hd[nf + i].m, front_shape ? kFrontRows : (uint32_t)kPrefixLanes * K) * hd[nf + i].n;
-    if ((trc = timing_begin(ctx, TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
+  size_t lo = 0;
+  bool pre_done = np == 0;
+  while (lo < nf || !pre_done) {
+    const int K = lo < nf ? fullk[order[lo]] : (front_shape ? 15 : fullk.empty() ? 15 : fullk[0]);
+    size_t hi = lo;
+    while (hi < nf && fullk[order[hi]] == K) ++hi;
+    const uint32_t npre = pre_done ? 0u : (uint32_t)np;
+    const uint32_t prows = front_shape ? kFrontRows : (uint32_t)kPrefixLanes * (uint32_t)K;
+    uint32_t maxm = 0;
+    if (ctx->timing) {
+      uint64_t cells = 0, bytes = 0;
+      for (size_t i = lo; i < hi; ++i) { cells += (uint64_t)hd[i].m * hd[i].n; bytes += 24ull * hd[i].m + hd[i].n + 4; }
+      for (size_t i = 0; i < npre; ++i) cells += (uint64_t)std::min<uint32_t>(hd[nf + i].m, prows) * hd[nf + i].n;
+      if ((trc = timing_begin(ctx, TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
+    }
+    for (size_t i = lo; i < hi; ++i) { maxm = std::max(maxm, hd[i].m); max_mn = std::max<uint64_t>(max_mn, (uint64_t)hd[i].m + hd[i].n); }
+    for (size_t i = 0; i < npre; ++i) max_mn = std::max<uint64_t>(max_mn, (uint64_t)hd[nf + i].m + hd[nf + i].n);
+    DpArgs af = a;
+    af.pairs = static_cast<const PairDesc*>(ctx->d_desc.p) + lo;
+    if (front_shape) HIP_TRY(launch_gotoh_ckpt_front(K, af, (uint32_t)(hi - lo), ap, npre, st));
+    else HIP_TRY(launch_gotoh_ckpt_prefix(K, af, (uint32_t)(hi - lo), ap, npre, st));
+    if ((trc = timing_end(ctx))) return trc;
+    if (hi > lo) narrow_launches.emplace_back(maxm, K);
+    if (npre) narrow_launches.emplace_back(prows, front_shape ? kFrontPrefixK : K);  // (the prefix is a sweep of its own rows)
+    pre_done = true;
+    lo = hi;
   }
-  if (front_shape) HIP_TRY(launch_gotoh_ckpt_front(K, af, (uint32_t)nf, ap, (uint32_t)np, st));
-  else HIP_TRY(launch_gotoh_ckpt_prefix(K, af, (uint32_t)nf, ap, (uint32_t)np, st));
-  if ((trc = timing_end(ctx))) return trc;
   int32_t herr[kErrWords] = {};
   HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   timing_collect(ctx);
-  uint32_t maxm = 0;
-  uint64_t max_mn = 0;
-  for (size_t i = 0; i < nf + np; ++i) { maxm = std::max(maxm, hd[i].m); max_mn = std::max<uint64_t>(max_mn, (uint64_t)hd[i].m + hd[i].n); }
-  return range_verdict(prm, herr, {{maxm, K}}, max_mn, 0);  // kWiden: the pipeline restarts on the int32 kernels
+  return range_verdict(prm, herr, narrow_launches, max_mn, 0);  // kWiden: the pipeline restarts on the int32 kernels
 }
 }  // namespace tracyhip
 

@@ -196,8 +196,8 @@ struct DpCkpt {
 };
 // origin-tracking sweep: one pass of strip height K, columns and scores inside the packed fields (dp_lane.h origin_step)
 bool origin_ok(const tracyhip_params* prm, uint32_t maxm, uint32_t maxn, int K);
-int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const std::vector<PairDesc>& full,
-                    const std::vector<PairDesc>& pre, int K, const tracyhip_params* prm, int32_t* d_scores, DpCkpt* ck, bool front_shape = false);
+int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const std::vector<PairDesc>& full, const std::vector<int>& fullk,
+                    const std::vector<PairDesc>& pre, const tracyhip_params* prm, int32_t* d_scores, DpCkpt* ck, bool front_shape = false);
 int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, bool needle, bool trace,
            int32_t* d_scores, uint8_t* d_ops, const uint64_t* d_ops_off, uint32_t* d_ops_len, int stage = DP_PLAIN,
            DpCkpt* ck = nullptr);

@@ -439,7 +439,7 @@ hipError_t launch_gotoh_ckpt_front(int K, const DpArgs& full, uint32_t nfull, co
     }                                                                                                                   \
     break;
   switch (K) {
-    TRACY_FRONT_CASE(12) TRACY_FRONT_CASE(15) TRACY_FRONT_CASE(16)
+    TRACY_FRONT_CASE(4) TRACY_FRONT_CASE(8) TRACY_FRONT_CASE(12) TRACY_FRONT_CASE(15) TRACY_FRONT_CASE(16)
     default: return hipErrorInvalidValue;
   }
 #undef TRACY_FRONT_CASE

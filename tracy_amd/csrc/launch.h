@@ -36,7 +36,7 @@ hipError_t launch_band_trace(int mode, int K, const DpArgs& a, const WalkArgs& w
 hipError_t launch_gotoh_origin(int K, int table, int codes, const DpArgs& a, uint32_t npairs, hipStream_t s);  // table: 0 strings by byte compare, 1 MODE_CQ, 2 MODE_QP (profile rows); codes (MODE_CQ): 4 = columns of A C G T only, 5 = with N, 6 = any
 hipError_t launch_gotoh_ckpt_prefix(int K, const DpArgs& full, uint32_t nfull, const DpArgs& pre, uint32_t npre, hipStream_t s);
 hipError_t launch_gotoh_prefix(int K, const DpArgs& a, uint32_t npairs, hipStream_t s);
-hipError_t launch_gotoh_ckpt_front(int K, const DpArgs& full, uint32_t nfull, const DpArgs& pre, uint32_t npre, hipStream_t s);  // K = 12 / 15 / 16
+hipError_t launch_gotoh_ckpt_front(int K, const DpArgs& full, uint32_t nfull, const DpArgs& pre, uint32_t npre, hipStream_t s);
 hipError_t launch_needle(int mode, int K, bool trace, const DpArgs& a, uint32_t npairs, hipStream_t s);
 hipError_t launch_gotoh_walk(const WalkArgs& a, hipStream_t s);
 hipError_t launch_needle_walk(const WalkArgs& a, const uint32_t* bits32, hipStream_t s);

@@ -539,9 +539,9 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   // short workgroups fill the tail.  Undecided votes get both full sweeps.  TRACYHIP_NO_VOTE=1: the two-stage form below.
   bool use_vote = use_prefix && getenv("TRACYHIP_NO_VOTE") == nullptr;
   const int K0 = choose_k(mt[0], MODE_QP);
-  for (uint32_t t = 0; t < nt && (use_vote || use_front); ++t)
-    if (choose_k(mt[t], MODE_QP) != K0) use_vote = use_front = false;
-  use_front = use_front && (K0 == 12 || K0 == 15 || K0 == 16);  // (launch_gotoh_ckpt_front; shorter traces are not worth a prefix)
+  for (uint32_t t = 0; t < nt && use_vote; ++t)
+    if (choose_k(mt[t], MODE_QP) != K0) use_vote = false;  // (the pruned sweep takes any mix: its prefixes have one shape, its full sweeps
+                                                           // one launch per strip height)
   std::vector<int8_t> front_strand(nt, -1);  // the strand whose score and c_e the pruned sweep certified
   std::vector<uint32_t> front_ce(nt, 0);
   if (use_front) {
@@ -575,9 +575,11 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
     }
     std::vector<int8_t> guess(nt, 0), both(nt, 1);
     std::vector<PairDesc> fullv, prev;
+    std::vector<int> fullk;
     std::vector<FrontDesc> fd;
     std::vector<uint32_t> ft;
     fullv.reserve(2 * (size_t)nt);
+    fullk.reserve(2 * (size_t)nt);
     prev.reserve(2 * (size_t)nt);
     fd.reserve(nt);
     ft.reserve(nt);
@@ -587,13 +589,14 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       const uint32_t hi = vf >= vr ? vf : vr, lo = vf >= vr ? vr : vf;
       both[t] = (mt[t] > R && hi >= 32 && hi >= 2 * lo) ? 0 : 1;  // a clear majority of shared k-mers, or both sweeps
       const int g = (int)guess[t];
+      const int Kt = choose_k(mt[t], MODE_QP);
       const bool front = !both[t] && mt[t] - R > 2u * (uint32_t)kFrontK && rn[t] >= 1 &&
                          origin16_ok(&p, mt[t], mt[t] - R + 2u * (uint32_t)kFrontHalfW + 16u);
       if (front) {
         PairDesc d = stage1_desc(t, g);
         d.flags |= PAIR_KEEP_ROW;
         prev.push_back(d);
-        if (in.exact) fullv.push_back(stage1_desc(t, 1 - g));
+        if (in.exact) { fullv.push_back(stage1_desc(t, 1 - g)); fullk.push_back(Kt); }
         else prev.push_back(stage1_desc(t, 1 - g));
         FrontDesc f{};
         f.row_off = d.lastrow_off;
@@ -611,13 +614,16 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       } else if (in.exact || both[t]) {
         fullv.push_back(stage1_desc(t, g));
         fullv.push_back(stage1_desc(t, 1 - g));
+        fullk.push_back(Kt);
+        fullk.push_back(Kt);
       } else {
         fullv.push_back(stage1_desc(t, g));
+        fullk.push_back(Kt);
         prev.push_back(stage1_desc(t, 1 - g));
       }
     }
     DpCkpt ckv = ck;
-    if ((rc = run_ckpt_prefix(ctx, d_prof, ctx->codes(), fullv, prev, K0, &p, d_sc2, &ckv, true))) return rc;
+    if ((rc = run_ckpt_prefix(ctx, d_prof, ctx->codes(), fullv, fullk, prev, &p, d_sc2, &ckv, true))) return rc;
     FrontResult fres;
     if ((rc = run_front(ctx, fd, in.d_qp, reinterpret_cast<const uint32_t*>(ck.d_lastrow), &p, fres))) return rc;
     if ((rc = fetch_scores())) return rc;
@@ -700,7 +706,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       else prev.push_back(stage1_desc(t, 1 - guess[t]));
     }
     DpCkpt ckv = ck;
-    if ((rc = run_ckpt_prefix(ctx, d_prof, ctx->codes(), fullv, prev, K0, &p, d_sc2, &ckv, false))) return rc;
+    if ((rc = run_ckpt_prefix(ctx, d_prof, ctx->codes(), fullv, std::vector<int>(fullv.size(), K0), prev, &p, d_sc2, &ckv, false))) return rc;
     if ((rc = fetch_scores())) return rc;
     std::vector<std::pair<uint32_t, int>> retry;
     for (uint32_t t = 0; t < nt; ++t) {

@@ -31,6 +31,17 @@ __global__ __launch_bounds__(64) void band16_kernel(Band16Args a) {
   band16_body<DeviceWave16, K, KIND>(w, a, blockIdx.x);
 }
 
+// One launch for the three strip heights of a small job: blocks [0, w12) sweep a12's pairs on K = 12 strips, the next w8 a8's on
+// K = 8, the rest a4's on K = 4.  A job of 10 000 pairs is 2 500 waves -- fewer than the device holds -- so its launches are as long
+// as one wave takes, and three of them in a row take three times that.
+template <int KIND>
+__global__ __launch_bounds__(64) void band16_multi_kernel(Band16Args a12, uint32_t w12, Band16Args a8, uint32_t w8, Band16Args a4) {
+  DeviceWave16 w;
+  if (blockIdx.x < w12) band16_body<DeviceWave16, 12, KIND>(w, a12, blockIdx.x);
+  else if (blockIdx.x < w12 + w8) band16_body<DeviceWave16, 8, KIND>(w, a8, blockIdx.x - w12);
+  else band16_body<DeviceWave16, 4, KIND>(w, a4, blockIdx.x - w12 - w8);
+}
+
 template <int K>
 __global__ __launch_bounds__(64) void band16_cont_kernel(Band16Args a) {
   DeviceWave16 w;
@@ -101,6 +112,16 @@ hipError_t launch_band16(int K, int kind, const Band16Args& a, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
 #undef TRACY_B16
+  return hipGetLastError();
+}
+
+hipError_t launch_band16_multi(int kind, const Band16Args& a12, const Band16Args& a8, const Band16Args& a4, hipStream_t s) {
+  const uint32_t w12 = (a12.npairs + 3u) / 4u, w8 = (a8.npairs + 3u) / 4u, w4 = (a4.npairs + 3u) / 4u;
+  if (w12 + w8 + w4 == 0) return hipSuccess;
+  // (the callers give the three jobs one code_cap: the LDS layout is [codes of four pairs][tables])
+  const uint32_t lds = 4u * a12.code_cap + b16_table_bytes(12);
+  if (kind == 0) hipLaunchKernelGGL((band16_multi_kernel<0>), dim3(w12 + w8 + w4), dim3(64), lds, s, a12, w12, a8, w8, a4);
+  else hipLaunchKernelGGL((band16_multi_kernel<1>), dim3(w12 + w8 + w4), dim3(64), lds, s, a12, w12, a8, w8, a4);
   return hipGetLastError();
 }
 

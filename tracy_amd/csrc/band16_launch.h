@@ -21,6 +21,8 @@ hipError_t launch_b16_tables(const B16TableDesc* d_desc, uint32_t nseq, const vo
                              int32_t qlimit, int shift, int16_t* out, int32_t* err, hipStream_t s);
 // kind 0: traceback words + walk; kind 1: origin-tracking sweep
 hipError_t launch_band16(int K, int kind, const Band16Args& a, hipStream_t s);
+// the three strip heights in one launch (small jobs); the jobs share one code_cap
+hipError_t launch_band16_multi(int kind, const Band16Args& a12, const Band16Args& a8, const Band16Args& a4, hipStream_t s);
 // the sweep below a stored prefix row (Band16Args::row; K = 8 or 12), and the two kernels of front.h around it
 hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s);
 struct FrontDesc;

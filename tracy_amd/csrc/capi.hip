@@ -760,6 +760,33 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
   const PairDesc* dd = static_cast<const PairDesc*>(ctx->d_desc.p);
   for (const Chunk& ch : chunks) {
     uint32_t j = ch.lo;
+    // a chunk of few waves with more than one strip height: one launch for all of them (band16_multi_kernel)
+    if (ch.hi - ch.lo <= 24576u && hk[ch.lo] != hk[ch.hi - 1]) {
+      Band16Args ak[3] = {a, a, a};  // 12, 8, 4
+      uint32_t nmax = 0;
+      uint64_t cells = 0, bytes = 0;
+      for (int b = 0; b < 3; ++b) { ak[b].pairs = dd + ch.lo; ak[b].npairs = 0; }
+      for (uint32_t e = ch.lo; e < ch.hi; ++e) {
+        const int K = hk[e], b = bucket_of(K);
+        if (ak[b].npairs == 0) ak[b].pairs = dd + e;
+        ak[b].npairs += 1;
+        nmax = std::max(nmax, hd[e].n);
+        if (ctx->timing) {
+          const uint64_t wds = b16_words(hd[e].m, hd[e].n, K, band_dmin(hd[e]), band_dmax(hd[e]));
+          cells += wds * (uint64_t)K;
+          bytes += (job.kind == 0 ? wds * b16_word_bytes(K) : 0) + 12ull * hd[e].m + hd[e].n + 4;
+        }
+      }
+      const uint32_t cap = (nmax + 7u) & ~3u;
+      if (4ull * cap + b16_table_bytes(12) <= 64u * 1024u) {
+        for (int b = 0; b < 3; ++b) ak[b].code_cap = cap;
+        int trc;
+        if ((trc = timing_begin(ctx, job.kind == 0 ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_ORIGIN, cells, bytes))) return trc;
+        HIP_TRY(launch_band16_multi(job.kind, ak[0], ak[1], ak[2], st));
+        if ((trc = timing_end(ctx))) return trc;
+        continue;
+      }
+    }
     while (j < ch.hi) {
       uint32_t e = j;
       const int K = hk[j];

@@ -523,9 +523,10 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   bool use_prefix = !given && use_band && ck.narrow && !in.exact && getenv("TRACYHIP_NO_PREFIX") == nullptr;
   // The pruned sweep of the voted strand (front.h): its prefix rows are swept over the whole window like the other strand's, the
   // rows below them only on a band around the best column of the prefix -- and the result is taken when its certificate holds.
-  // Only where nothing but the two ends of the preliminary alignment is read (`tracy align`): a heterozygous trace (`tracy
-  // decompose`) scores far below its row maxima and would rarely certify.  Exact results either way (TRACYHIP_NO_FRONT=1: off).
-  bool use_front = ends_path && b16 && !given && use_band && ck.narrow && getenv("TRACYHIP_NO_FRONT") == nullptr &&
+  // `tracy align` reads the preliminary alignment by its two ends, `tracy decompose` takes its traceback from the band kernels (S*, c_e
+  // are all they need); a pair of the latter whose band fails gets the full sweep of its strand after all (checkpoints for the band
+  // traceback).  Exact results either way (TRACYHIP_NO_FRONT=1: off).
+  bool use_front = (ends_path || tb16_path) && b16 && !given && use_band && ck.narrow && getenv("TRACYHIP_NO_FRONT") == nullptr &&
                    getenv("TRACYHIP_NO_PREFIX") == nullptr && getenv("TRACYHIP_NO_VOTE") == nullptr;
   // traces no taller than the prefix (8K rows) have nothing left to bound: they get both full passes
   std::vector<uint8_t> elig(nt, 0);
@@ -984,6 +985,12 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
           for (uint32_t t = 0; t < nt; ++t)
             if (j16.k[t] && (h_sb[t] != h_pre[t] || h_ol[t] == 0)) { rest.desc.push_back(wholes[t]); rest.k.push_back(pb.k[t]); ++nfail; }
           if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "preliminary alignment: %zu of %u on the band, %u repeated\n", nb16, nt, nfail);
+        }
+        {  // a strand the pruned sweep certified has no wavefront checkpoints: sweep it in full before its band traceback
+          std::vector<std::pair<uint32_t, int>> resweep;
+          for (auto const& d : rest.desc)
+            if (from_front(d.out)) resweep.emplace_back(d.out, h_rc[d.out] ? 1 : 0);
+          if (!resweep.empty() && (rc = run_stage1(resweep, DP_CKPT))) return rc;
         }
         if ((rc = run_dp(ctx, rest, &p, false, true, nullptr, in.d_ops, in.d_ops_off, in.d_ops_len, DP_BAND, &ck))) return rc;
       }

@@ -144,7 +144,7 @@ def main():
                     help="configs[3]: traces PER GPU of the seed + extend job (1M traces over 8 GPUs = 125 000 each; the job is this x the ranks)")
     ap.add_argument("--seedextend-genome-mb", type=float, default=50.0, help="configs[3]: size of the synthetic genome (GRCh38 chr22 is 50.8 Mb)")
     ap.add_argument("--seedextend-steps", type=int, default=2)
-    ap.add_argument("--cli-traces", type=int, default=2000, help="the CLI leg: ABIF files per command (`align --batch`, `decompose --batch`); 0 = skip")
+    ap.add_argument("--cli-traces", type=int, default=10000, help="the CLI leg: ABIF files per command (`align --batch`, `decompose --batch`); 0 = skip")
     ap.add_argument("--extra-legs", type=int, default=1, help="decompose: also time the strand-certificate and two-lane legs")
     ap.add_argument("--stub", action="store_true", help="launcher self-test on gloo with a step that does no device work (not a measurement)")
     ap.add_argument("--steps", type=int, default=10)

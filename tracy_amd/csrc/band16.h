@@ -26,6 +26,8 @@
 #ifndef TRACY_AMD_BAND16_H
 #define TRACY_AMD_BAND16_H
 
+#include <type_traits>
+
 #include "dp_kernels.h"
 
 namespace tracyhip {
@@ -60,7 +62,12 @@ TR_HD constexpr uint32_t b16_max_window(int K) { return 15u * ((uint32_t)K + 1u)
 TR_HD constexpr uint32_t b16_word_bytes(int K) { return K <= 4 ? 2u : K <= 8 ? 4u : 8u; }
 TR_HD constexpr uint32_t b16_table_bytes(int K) { return kB16Codes * (uint32_t)K * 64u * 2u; }
 TR_HD uint32_t b16_strips(uint32_t m, int K) { return (m + (uint32_t)K - 1u) / (uint32_t)K; }
-TR_HD uint32_t b16_window(int K, int32_t dmin, int32_t dmax) { return (uint32_t)K + (uint32_t)(dmax - dmin); }
+// steps of a strip's window: its K + dmax - dmin columns rounded up to whole blocks of K + 1 steps (band16_body: a lane's activity
+// changes at block boundaries only; the extra columns lie outside the band and hold lower bounds like every cell there)
+TR_HD uint32_t b16_window(int K, int32_t dmin, int32_t dmax) {
+  const uint32_t s = (uint32_t)K + (uint32_t)(dmax - dmin), kp = (uint32_t)K + 1u;
+  return (s + kp - 1u) / kp * kp;
+}
 // first column of strip s's window (may be <= 0: the lane waits for column 1)
 TR_HD int32_t b16_first_col(uint32_t s, int K, int32_t dmin) { return (int32_t)(s * (uint32_t)K) + 1 + dmin; }
 // the last strip sweeps on to column n: the trailing run of row m (free end gap) lies outside the band's diagonals
@@ -190,7 +197,8 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   static_assert(b16_max_window(K) + 2u <= kB16RowCap, "row staging");
   constexpr int SH = KIND == 0 ? kTagShift : kOriginShift;
   constexpr int TS = KIND == 0 ? 0 : kOriginBits;
-  constexpr int32_t P = (int32_t)b16_period(K);
+  constexpr uint32_t KP = (uint32_t)K + 1u;  // steps of a block: the stagger between two strips
+  constexpr uint32_t WB = b16_word_bytes(K);
   const uint32_t L = w.lane(), g = L >> 4, j = L & 15u;
   const uint32_t pair_idx = wave_idx * 4u + g;
   const bool have = pair_idx < a.npairs;
@@ -204,6 +212,10 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   const uint32_t NS = have ? b16_strips(m, K) : 0u;
   const uint32_t S = b16_window(K, dmin, dmax);
   const uint32_t S_last = have ? b16_last_window(m, n, K, dmin, dmax) : 0u;
+  // The sweep runs in blocks of K + 1 steps: block b begins strip b (lane b mod 16 of every pair), and because a window is a whole
+  // number of blocks (b16_window) a lane's activity changes at block boundaries only -- inside a block a step tests nothing but
+  // "is my column one of 1 .. n".
+  const uint32_t NB = S / KP, NB_last = (S_last + (uint32_t)K) / KP;
   const int32_t neg = KIND == 0 ? (int32_t)((uint32_t)kNegInf << SH) : (int32_t)((uint32_t)kNegInfOrigin << SH);
   const uint32_t rbase = CONT ? (uint32_t)d.bits_off : 0u;  // rows above the pair's first one
   auto edge = [&](uint32_t r) -> int32_t { return (int32_t)((uint32_t)edge_value(false, go, ge, (int32_t)(r + rbase)) << SH); };  // H(r, 0), r >= 1
@@ -239,37 +251,36 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
     }
   }
   w.sync();
-  auto code_at = [&](int32_t c) -> uint32_t {  // clamped: lanes off the reference read some column of it and discard the result
-    const int32_t x = c > (int32_t)n ? (int32_t)n : c;
-    return lcodes[(uint32_t)((x < 1 ? 1 : x) - 1)];
-  };
+  // code of column cm1 + 1; lanes off the reference (cm1 wraps below column 1) read its last column and discard the result
+  const uint32_t nclamp = n ? n - 1u : 0u;
+  auto code_at = [&](uint32_t cm1) -> uint32_t { return lcodes[cm1 < nclamp ? cm1 : nclamp]; };
 
-  // ---- wave-uniform step counts ----
-  uint32_t T_end = 0, t_last = ~0u;
+  // ---- wave-uniform block counts ----
+  uint32_t B_end = 0, b_last = ~0u;
   {
-    const uint32_t mine = have ? (NS - 1u) * (uint32_t)(K + 1) + S_last : 0u;
-    const uint32_t lastbeg = have ? (NS - 1u) * (uint32_t)(K + 1) : ~0u;
+    const uint32_t mine = have ? (NS - 1u) + NB_last : 0u;
+    const uint32_t lastbeg = have ? NS - 1u : ~0u;
     for (uint32_t q = 0; q < 4; ++q) {
       const uint32_t x = w.bcast(mine, q * 16u), y = w.bcast(lastbeg, q * 16u);
-      T_end = x > T_end ? x : T_end;
-      t_last = y < t_last ? y : t_last;
+      B_end = x > B_end ? x : B_end;
+      b_last = y < b_last ? y : b_last;
     }
   }
 
   // ---- per-lane state ----
   TraceLane<K> ts;
 #pragma unroll
-  for (int i = 0; i < K; ++i) { ts.Hc[i] = neg; ts.Ec[i] = neg; ts.cx1[i] = 0; ts.cx2[i] = 0; }
+  for (int i = 0; i < K; ++i) { ts.Hc[i] = neg; ts.Ec[i] = neg; ts.cx1[i] = trace_cx1<TS>(goe); ts.cx2[i] = trace_cx2<TS>(ge); }
   int32_t bot_h = neg, bot_f = neg, prev_up_h = neg;
-  int32_t u = -(int32_t)(j * (uint32_t)(K + 1));  // step inside the lane's current strip (negative: not begun)
-  uint32_t s_cur = j;
-  int32_t c = 0;
-  uint32_t S_cur = 0;
+  uint32_t s_cur = j;   // the strip the lane sweeps (or swept last)
+  uint32_t cm1 = 0;     // its column - 1 (wraps while the window is still left of column 1)
+  uint32_t left = 0;    // blocks its strip still takes
   bool live = false;
   uint32_t raw_next = 0;
   uint32_t c_end = 0;
   const int32_t cy1 = trace_cy1<TS>(goe), cy2 = trace_cy2<TS>(ge);
-  uint8_t* bits = a.bits + d.bits_off;
+  uint8_t* const bits = a.bits + d.bits_off;
+  uint8_t* wp = bits;   // KIND 0: where the word of the next step goes
   const uint32_t slot_m = have && m ? (m - 1u) % (uint32_t)K : 0u;
 
   // rows of strip s: K int16 per code, straight from the sequence's table
@@ -283,91 +294,104 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   if (have && j < NS) prefetch(j);
 
   SubRows<K, KIND == 0 ? 0 : SH - kTagShift> sub;  // table entries are scores << kTagShift for both kinds
-  for (uint32_t t = 0; t < T_end; ++t) {
-    if (u == 0) {  // ---- begin strip s_cur (one lane per pair, every K + 1 steps) ----
-      live = have && s_cur < NS;
-      if (live) {
-        const uint32_t r0 = s_cur * (uint32_t)K;
-        const int32_t cw = b16_first_col(s_cur, K, dmin);
-        c = cw;
-        S_cur = (s_cur + 1u == NS) ? S_last : S;
+
+  // first = std::true_type for the blocks in which strip 0 can be live: its rows take row 0 (or the stored row) from above
+  auto block = [&](uint32_t b, auto first) {
+    constexpr bool FIRST = decltype(first)::value;
+    if (j == (b & 15u) && have && b < NS) {  // ---- begin strip b ----
+      live = true;
+      s_cur = b;
+      const uint32_t r0 = b * (uint32_t)K;
+      const int32_t cw = b16_first_col(b, K, dmin);
+      cm1 = (uint32_t)(cw - 1);
+      left = (b + 1u == NS) ? NB_last : NB;
+      if (cw <= 1) {  // left of the window: column 0 (gotoh.h:117-123) ...
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
-          const uint32_t r = r0 + (uint32_t)i + 1u;
-          const bool hz = hfree && r == m;
-          ts.cx1[i] = trace_cx1<TS>(hz ? 0 : goe);
-          ts.cx2[i] = trace_cx2<TS>(hz ? 0 : ge);
-          ts.Hc[i] = cw <= 1 ? edge(r) : neg;  // left of the window: column 0 (gotoh.h:117-123), or outside the band
-          ts.Ec[i] = neg;
+        for (int i = 0; i < K; ++i) ts.Hc[i] = edge(r0 + (uint32_t)i + 1u);
+      } else {        // ... or outside the band
+#pragma unroll
+        for (int i = 0; i < K; ++i) ts.Hc[i] = neg;
+      }
+#pragma unroll
+      for (int i = 0; i < K; ++i) ts.Ec[i] = neg;
+      if (hfree && b + 1u == NS) {  // row m: free end gap (the last strip of the pair: the constants are never needed again)
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+          if ((uint32_t)i == slot_m) { ts.cx1[i] = trace_cx1<TS>(0); ts.cx2[i] = trace_cx2<TS>(0); }
+      }
+      bot_h = cw <= 0 ? edge(r0 + (uint32_t)K) : neg;  // what the strip below sees while this one waits for column 1
+      bot_f = neg;
+      if (b == 0) prev_up_h = CONT ? lrow[2 * (cw - 1 - crow0)] : row0(cw - 1);
+#pragma unroll
+      for (uint32_t q = 0; q < kB16Codes; ++q) {
+        const uint32_t rowsel = (rcflag && q < 4u) ? 3u - q : q;  // reverse-complement view: the complement is folded into the table
+#pragma unroll
+        for (int h = 0; h < ND; ++h) {
+          tab[(rowsel * K + 2 * h) * 64] = (int16_t)(pf[q][h] & 0xffffu);
+          tab[(rowsel * K + 2 * h + 1) * 64] = (int16_t)(pf[q][h] >> 16);
         }
-        bot_h = cw <= 0 ? edge(r0 + (uint32_t)K) : neg;  // what the strip below sees while this one waits for column 1
-        bot_f = neg;
-        if (s_cur == 0) prev_up_h = CONT ? lrow[2 * (cw - 1 - crow0)] : row0(cw - 1);
+      }
+      raw_next = code_at(cm1);
+      if (KIND == 0) wp = bits + (uint64_t)b * S * WB;
+      if (b + 16u < NS) prefetch(b + 16u);
+    }
 #pragma unroll
-        for (uint32_t b = 0; b < kB16Codes; ++b) {
-          const uint32_t rowsel = (rcflag && b < 4u) ? 3u - b : b;  // reverse-complement view: the complement is folded into the table
-#pragma unroll
-          for (int q = 0; q < ND; ++q) {
-            tab[(rowsel * K + 2 * q) * 64] = (int16_t)(pf[b][q] & 0xffffu);
-            tab[(rowsel * K + 2 * q + 1) * 64] = (int16_t)(pf[b][q] >> 16);
+    for (uint32_t k = 0; k < KP; ++k) {
+      int32_t up_h = w.rot16(bot_h);
+      int32_t up_f = w.rot16(bot_f);
+      if (FIRST) {  // strip 0: row 0 instead of a strip above (gotoh.h:112-116)
+        if (live && s_cur == 0) {
+          const int32_t c = (int32_t)cm1 + 1;
+          if (CONT) {
+            const uint32_t i = (uint32_t)(c - crow0) < kB16RowCap ? (uint32_t)(c - crow0) : kB16RowCap - 1u;  // (past the staged columns only
+            up_h = lrow[2u * i];                                                                              // when strip 0 is the last one and runs
+            up_f = lrow[2u * i + 1u];                                                                         // on along row m)
+            if ((uint32_t)(c - crow0) >= kB16RowCap) { up_h = neg; up_f = neg; }
+          } else {
+            up_h = row0(c);
+            up_f = neg;
           }
         }
-        raw_next = code_at(c);
-        if (s_cur + 16u < NS) prefetch(s_cur + 16u);
       }
-    }
-    int32_t up_h = w.rot16(bot_h);
-    int32_t up_f = w.rot16(bot_f);
-    if (t < (uint32_t)P) {  // the first strips: row 0 instead of a strip above (gotoh.h:112-116)
-      if (live && s_cur == 0 && (uint32_t)u < S_cur) {  // (not past its window: the last step before strip 16 begins delivers that
-                                                        // strip's diagonal from lane 15)
-        if (CONT) {
-          const uint32_t i = (uint32_t)(c - crow0) < kB16RowCap ? (uint32_t)(c - crow0) : kB16RowCap - 1u;  // (past the staged columns only
-          up_h = lrow[2u * i];                                                                              // when strip 0 is the last one and runs
-          up_f = lrow[2u * i + 1u];                                                                         // on along row m: see below)
-          if ((uint32_t)(c - crow0) >= kB16RowCap) { up_h = neg; up_f = neg; }
+      const uint32_t raw = raw_next;
+      raw_next = code_at(cm1 + 1u);
+      if (live && cm1 < n) {  // on a column 1 .. n
+        qp_fetch_rows<K>(tab, raw, sub);
+        int32_t nb_h, nb_f;
+        if (KIND == 0) {
+          uint32_t w0 = 0, w1 = 0;
+          trace_step<K>(ts, up_h, up_f, prev_up_h, cy1, cy2, sub, w0, w1, nb_h, nb_f);
+          if (K <= 4) *reinterpret_cast<uint16_t*>(wp) = (uint16_t)w0;
+          else if (K <= 8) *reinterpret_cast<uint32_t*>(wp) = w0;
+          else *reinterpret_cast<uint64_t*>(wp) = ((uint64_t)w1 << 32) | w0;
         } else {
-          up_h = row0(c);
-          up_f = neg;
-        }
-      }
-    }
-    const uint32_t raw = raw_next;
-    raw_next = code_at(c + 1);
-    const bool active = live && (uint32_t)u < S_cur && c >= 1 && c <= (int32_t)n;
-    if (active) {
-      qp_fetch_rows<K>(tab, raw, sub);
-      int32_t nb_h, nb_f;
-      if (KIND == 0) {
-        uint32_t w0 = 0, w1 = 0;
-        trace_step<K>(ts, up_h, up_f, prev_up_h, cy1, cy2, sub, w0, w1, nb_h, nb_f);
-        const uint64_t idx = (uint64_t)s_cur * S + (uint32_t)u;
-        if (K <= 4) reinterpret_cast<uint16_t*>(bits)[idx] = (uint16_t)w0;
-        else if (K <= 8) reinterpret_cast<uint32_t*>(bits)[idx] = w0;
-        else reinterpret_cast<uint64_t*>(bits)[idx] = ((uint64_t)w1 << 32) | w0;
-      } else {
-        origin_step<K>(ts, up_h, up_f, prev_up_h, cy1, cy2, sub, nb_h, nb_f);
-        if (t >= t_last) {  // watch row m (the last strip): the trailing run ends at the last column with H > E
-          if (s_cur + 1u == NS) {
-            int32_t hv = 0, ev = 0;
+          origin_step<K>(ts, up_h, up_f, prev_up_h, cy1, cy2, sub, nb_h, nb_f);
+          if (b >= b_last) {  // watch row m (the last strip): the trailing run ends at the last column with H > E
+            if (s_cur + 1u == NS) {
+              int32_t hv = 0, ev = 0;
 #pragma unroll
-            for (int i = 0; i < K; ++i)
-              if ((uint32_t)i == slot_m) { hv = ts.Hc[i]; ev = ts.Ec[i]; }
-            if ((hv >> SH) > (ev >> SH)) c_end = (uint32_t)c;
+              for (int i = 0; i < K; ++i)
+                if ((uint32_t)i == slot_m) { hv = ts.Hc[i]; ev = ts.Ec[i]; }
+              if ((hv >> SH) > (ev >> SH)) c_end = cm1 + 1u;
+            }
           }
         }
+        bot_h = nb_h;
+        bot_f = nb_f;
       }
-      bot_h = nb_h;
-      bot_f = nb_f;
-    } else if (live && (uint32_t)u == S_cur) {
-      bot_h = neg;  // past the window: the strip below finds -inf above its last K columns
+      prev_up_h = up_h;
+      ++cm1;
+      if (KIND == 0) wp += WB;
+    }
+    if (live && --left == 0u) {  // past the window: the strip below finds -inf above its last K columns
+      live = false;
+      bot_h = neg;
       bot_f = neg;
     }
-    prev_up_h = up_h;
-    ++c;
-    ++u;
-    if (u == P && !(live && (uint32_t)u < S_cur)) { u = 0; s_cur += 16u; }  // (the last strip may run past the period: row m's trailing run)
-  }
+  };
+  uint32_t b = 0;
+  for (; b < 16u && b < B_end; ++b) block(b, std::true_type{});
+  for (; b < B_end; ++b) block(b, std::false_type{});
 
   // ---- score, ends, walk ----
   if (have && j == ((NS - 1u) & 15u)) {

@@ -25,6 +25,7 @@ struct DeviceWave16 {
   }
 };
 
+// (register caps were measured and lose: amdgpu_waves_per_eu 3 / 4 for K = 12 / 8 spills 24 / 14 registers inside the blocks)
 template <int K, int KIND>
 __global__ __launch_bounds__(64) void band16_kernel(Band16Args a) {
   DeviceWave16 w;

@@ -154,6 +154,59 @@ struct HostProfile {
 HostProfile& host_profile() { static HostProfile p; return p; }
 inline uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
+// ---- the persistent workers of parallel_for (capi_internal.h) ----
+namespace {
+struct HostPool {
+  std::mutex use;  // one job at a time
+  std::mutex m;
+  std::condition_variable cv, done_cv;
+  const std::function<void(uint32_t)>* job = nullptr;
+  uint64_t gen = 0;
+  uint32_t pending = 0;
+  bool started = false;
+  void worker(uint32_t tid) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(uint32_t)>* j;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return gen != seen; });
+        seen = gen;
+        j = job;
+      }
+      (*j)(tid);
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (--pending == 0) done_cv.notify_one();
+      }
+    }
+  }
+  bool run(const std::function<void(uint32_t)>& f) {
+    std::unique_lock<std::mutex> u(use, std::try_to_lock);
+    if (!u.owns_lock()) return false;
+    if (!started) {
+      for (uint32_t t = 1; t < kHostThreads; ++t) std::thread([this, t] { worker(t); }).detach();
+      started = true;
+    }
+    {
+      std::lock_guard<std::mutex> lk(m);
+      job = &f;
+      pending = kHostThreads - 1;
+      ++gen;
+    }
+    cv.notify_all();
+    f(0u);
+    std::unique_lock<std::mutex> lk(m);
+    done_cv.wait(lk, [&] { return pending == 0; });
+    return true;
+  }
+};
+}  // namespace
+bool host_pool_run(const std::function<void(uint32_t)>& job) {
+  static HostPool* pool = new HostPool;  // never destroyed: its detached workers may outlive static destructors
+  return pool->run(job);
+}
+
 HostScope::HostScope(const char* l) : label(l), t0(host_profile().on ? now_ns() : 0) {}
 HostScope::~HostScope() {
   HostProfile& p = host_profile();
@@ -655,17 +708,12 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
   hipStream_t st = ctx->stream;
   auto* hs_plan = new HostScope("run_band16.plan");
   uint64_t limit = ctx->ws_limit;
-  if (limit == 0 && job.kind == 0) {
-    size_t fr = 0, tot = 0;
-    HIP_TRY(hipMemGetInfo(&fr, &tot));
-    limit = (uint64_t)(fr * 0.70 / ctx->mem_share) + ctx->d_bits.cap;
-  } else if (limit == 0) limit = ~0ull;
   // Order: strip height (12, 8, 4), the caller's order within one (the pairs of a pipeline stage are of a size).  Laid out by a
   // few threads: per-thread counts per strip height, a scan, the fill -- descriptors go straight into the pinned staging block.
   constexpr int NB = 3;
   auto bucket_of = [](int K) { return K == 12 ? 0 : K == 8 ? 1 : K == 4 ? 2 : -1; };
   static const int bucket_k[NB] = {12, 8, 4};
-  struct Part { uint32_t n[NB]; uint64_t bytes[NB]; bool bad; };
+  struct Part { uint32_t n[NB]; uint64_t bytes[NB]; uint32_t nmax[NB]; uint64_t cells[NB], tbytes[NB]; bool bad; };  // (cells / tbytes: what the timers credit)
   Part part[kHostThreads] = {};
   std::vector<uint64_t> wb(nall);  // bytes of traceback words per pair (kind 0)
   parallel_for(nall, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
@@ -676,20 +724,35 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
       const PairDesc& d = job.desc[i];
       const int b = bucket_of(K);
       if (b < 0 || d.m == 0 || d.n == 0 || b16_window(K, band_dmin(d), band_dmax(d)) > b16_max_window(K)) { pt.bad = true; continue; }
-      const uint64_t bytes = job.kind == 0 ? ((b16_words(d.m, d.n, K, band_dmin(d), band_dmax(d)) * b16_word_bytes(K) + 15u) & ~15ull) : 0;
+      const uint64_t wds = (job.kind == 0 || ctx->timing) ? b16_words(d.m, d.n, K, band_dmin(d), band_dmax(d)) : 0;
+      const uint64_t bytes = job.kind == 0 ? ((wds * b16_word_bytes(K) + 15u) & ~15ull) : 0;
       wb[i] = bytes;
       pt.n[b] += 1;
       pt.bytes[b] += bytes;
+      pt.nmax[b] = std::max(pt.nmax[b], d.n);
+      pt.cells[b] += wds * (uint64_t)K;
+      pt.tbytes[b] += (job.kind == 0 ? wds * b16_word_bytes(K) : 0) + 12ull * d.m + d.n + 4;
     }
   });
-  uint32_t bn[NB] = {0, 0, 0};
-  uint64_t total_bytes = 0;
+  uint32_t bn[NB] = {0, 0, 0}, bnmax[NB] = {0, 0, 0};
+  uint64_t total_bytes = 0, bcells[NB] = {0, 0, 0}, btbytes[NB] = {0, 0, 0};
   for (uint32_t t = 0; t < kHostThreads; ++t) {
     if (part[t].bad) { delete hs_plan; return set_error(TRACYHIP_ERR_ARG, "run_band16: pair outside the band kernels' domain"); }
-    for (int b = 0; b < NB; ++b) { bn[b] += part[t].n[b]; total_bytes += part[t].bytes[b]; }
+    for (int b = 0; b < NB; ++b) {
+      bn[b] += part[t].n[b]; total_bytes += part[t].bytes[b];
+      bnmax[b] = std::max(bnmax[b], part[t].nmax[b]); bcells[b] += part[t].cells[b]; btbytes[b] += part[t].tbytes[b];
+    }
   }
   const uint32_t np = bn[0] + bn[1] + bn[2];
   if (np == 0) { delete hs_plan; return TRACYHIP_OK; }
+  if (limit == 0) {
+    if (job.kind != 0 || total_bytes + 64 <= ctx->d_bits.cap) limit = ~0ull;  // (the words fit what is there: no driver call)
+    else {
+      size_t fr = 0, tot = 0;
+      HIP_TRY(hipMemGetInfo(&fr, &tot));
+      limit = (uint64_t)(fr * 0.70 / ctx->mem_share) + ctx->d_bits.cap;
+    }
+  }
   HIP_TRY(ctx->h_desc.ensure(sizeof(PairDesc) * (size_t)np));
   PairDesc* hd = static_cast<PairDesc*>(ctx->h_desc.p);
   std::vector<int> hk(np);
@@ -758,6 +821,33 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
   a.err = static_cast<int32_t*>(ctx->d_err.p); a.go = prm->go; a.ge = prm->ge; a.hfree = prm->hfree;
   a.ops = d_ops; a.ops_off = d_ops_off; a.ops_len = d_ops_len;
   const PairDesc* dd = static_cast<const PairDesc*>(ctx->d_desc.p);
+  if (chunks.size() == 1) {
+    // the whole job at once: per strip height the pairs [first, first + count) and the sums of the planning pass (no walk over the list)
+    uint32_t first[NB];
+    for (int b = 0, q = 0; b < NB; ++b) { first[b] = (uint32_t)q; q += (int)bn[b]; }
+    const int used = (bn[0] != 0) + (bn[1] != 0) + (bn[2] != 0);
+    const uint32_t nmax_all = std::max(bnmax[0], std::max(bnmax[1], bnmax[2]));
+    const uint32_t cap_all = (nmax_all + 7u) & ~3u;
+    int trc;
+    if (np <= 24576u && used > 1 && 4ull * cap_all + b16_table_bytes(12) <= 64u * 1024u) {  // few waves, several heights: band16_multi_kernel
+      Band16Args ak[3] = {a, a, a};  // 12, 8, 4
+      for (int b = 0; b < NB; ++b) { ak[b].pairs = dd + first[b]; ak[b].npairs = bn[b]; ak[b].code_cap = cap_all; }
+      if ((trc = timing_begin(ctx, job.kind == 0 ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_ORIGIN, bcells[0] + bcells[1] + bcells[2], btbytes[0] + btbytes[1] + btbytes[2]))) return trc;
+      HIP_TRY(launch_band16_multi(job.kind, ak[0], ak[1], ak[2], st));
+      if ((trc = timing_end(ctx))) return trc;
+    } else {
+      for (int b = 0; b < NB; ++b) {
+        if (bn[b] == 0) continue;
+        a.pairs = dd + first[b];
+        a.npairs = bn[b];
+        a.code_cap = (bnmax[b] + 7u) & ~3u;
+        if (4ull * a.code_cap + b16_table_bytes(bucket_k[b]) > 64u * 1024u) return set_error(TRACYHIP_ERR_RANGE, "run_band16: reference of %u columns does not fit the staging area", bnmax[b]);
+        if ((trc = timing_begin(ctx, job.kind == 0 ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_ORIGIN, bcells[b], btbytes[b]))) return trc;
+        HIP_TRY(launch_band16(bucket_k[b], job.kind, a, st));
+        if ((trc = timing_end(ctx))) return trc;
+      }
+    }
+  } else
   for (const Chunk& ch : chunks) {
     uint32_t j = ch.lo;
     // a chunk of few waves with more than one strip height: one launch for all of them (band16_multi_kernel)
@@ -988,6 +1078,7 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   hipStream_t st = ctx->stream;
   const size_t nf = full.size(), np = pre.size();
   if (nf + np == 0) return TRACYHIP_OK;
+  auto* hs1 = new HostScope("run_ckpt_prefix.plan");
   HIP_TRY(ctx->h_desc.ensure(sizeof(PairDesc) * (nf + np)));
   PairDesc* hd = static_cast<PairDesc*>(ctx->h_desc.p);
   // the sweeps by strip height (one launch each; the prefix workgroups ride with the first), longest first inside a launch, as
@@ -1005,6 +1096,7 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   HIP_TRY(hipMemcpyAsync(ctx->d_desc.p, hd, sizeof(PairDesc) * (nf + np), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx->d_err.ensure(kErrBytes));
   HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
+  delete hs1;
   DpArgs a{};
   a.a1 = d_a1; a.a2 = d_a2; a.scores = d_scores; a.err = static_cast<int32_t*>(ctx->d_err.p);
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge; a.hfree = prm->hfree; a.vfree = prm->vfree;

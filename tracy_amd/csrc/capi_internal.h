@@ -69,6 +69,9 @@ struct tracyhip_ctx {
   tracyhip::DevBuf d_ends;  // tracy align: ends of the preliminary alignments + scratch of that stage (orient_and_align)
   std::vector<tracyhip::PairDesc> cache_desc;  // descriptor / strip-height vectors of the generic DP entry points, kept between
   std::vector<int> cache_k;                    // calls (an all-pairs list is 36 MB: allocating it afresh costs 6 ms of page faults)
+  std::vector<tracyhip::PairDesc> cache_full, cache_pre, cache_b16;  // the same for the orientation stage's sweep / prefix lists and the band jobs
+  std::vector<tracyhip::FrontDesc> cache_fd;
+  std::vector<int> cache_fullk, cache_b16k;
   tracyhip::DevBuf d_tmp[8];
   tracyhip::DevBuf d_pipe[64];
   tracyhip::DevBuf d_ckpt, d_lastrow, d_band;  // pipeline intermediates (align_traces / decompose)
@@ -138,12 +141,16 @@ namespace tracyhip {
 // The per-trace host loops of the pipelines (descriptors, bands, verdicts of 10^5 traces between two launches) on a few threads:
 // fn(lo, hi, tid) over [0, n) in contiguous slices; small n runs inline.
 constexpr uint32_t kHostThreads = 8;
+// Workers that stay alive between calls (starting seven threads costs ~0.3 ms, and a decompose call of 10^5 traces runs forty of
+// these loops between its launches).  One job at a time: a second caller (another lane) gets `false` and starts its own threads.
+bool host_pool_run(const std::function<void(uint32_t)>& job);  // job(tid) for tid = 0 .. kHostThreads - 1, tid 0 on the caller
 template <class Fn>
 void parallel_for(uint32_t n, Fn fn) {
   if (n < 16384u) { fn(0u, n, 0u); return; }
+  auto lo = [&](uint32_t t) { return (uint32_t)((uint64_t)n * t / kHostThreads); };
+  if (host_pool_run([&](uint32_t t) { fn(lo(t), lo(t + 1), t); })) return;
   std::vector<std::thread> th;
   th.reserve(kHostThreads - 1);
-  auto lo = [&](uint32_t t) { return (uint32_t)((uint64_t)n * t / kHostThreads); };
   for (uint32_t t = 1; t < kHostThreads; ++t) th.emplace_back([&, t]() { fn(lo(t), lo(t + 1), t); });
   fn(0u, lo(1), 0u);
   for (auto& x : th) x.join();
@@ -161,6 +168,16 @@ struct DpProblemLease {
   ~DpProblemLease() { p.desc.swap(c->cache_desc); p.k.swap(c->cache_k); }
   DpProblemLease(const DpProblemLease&) = delete;
   DpProblemLease& operator=(const DpProblemLease&) = delete;
+};
+// the same for a band job (Band16Job, below): entries whose strip height is 0 are never read, so stale descriptors may stay in them
+template <class Job>
+struct Band16Lease {
+  tracyhip_ctx* c;
+  Job& j;
+  Band16Lease(tracyhip_ctx* c_, Job& j_) : c(c_), j(j_) { j.desc.swap(c->cache_b16); j.k.swap(c->cache_b16k); }
+  ~Band16Lease() { j.desc.swap(c->cache_b16); j.k.swap(c->cache_b16k); }
+  Band16Lease(const Band16Lease&) = delete;
+  Band16Lease& operator=(const Band16Lease&) = delete;
 };
 // Host-side profile of the pipelines (TRACYHIP_HOST_TIMERS=1): wall time of the labelled scopes, summed per label and printed to
 // stderr when the process ends.  For finding where the host keeps the GPU waiting between two launches; off = one branch.

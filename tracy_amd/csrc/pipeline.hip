@@ -545,7 +545,9 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
                                                            // one launch per strip height)
   std::vector<int8_t> front_strand(nt, -1);  // the strand whose score and c_e the pruned sweep certified
   std::vector<uint32_t> front_ce(nt, 0);
+  StageClock sco;
   if (use_front) {
+    sco.mark("o.a votes+rowmax descs/launch/readback");
     std::vector<VoteDesc> hv(nt);
     std::vector<RowMaxDesc> hrm(nt);
     const uint32_t R = kFrontRows;  // every prefix of this branch has the 16 x 8 shape
@@ -574,59 +576,84 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       verr_fetched = true;
       if (h_verr & 4) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
     }
-    std::vector<int8_t> guess(nt, 0), both(nt, 1);
-    std::vector<PairDesc> fullv, prev;
-    std::vector<int> fullk;
-    std::vector<FrontDesc> fd;
+    sco.mark("o.b build front descs");
+    // the lists of the combined launch, laid out by a few threads in trace order (class per trace, a scan, the fill); the vectors
+    // are the context's (megabytes per call: no fresh pages)
+    std::vector<int8_t> guess(nt, 0), both(nt, 1), cls(nt, 0);  // cls: 0 = pruned sweep, 1 = both strands in full, 2 = voted strand in full + prefix of the other
+    struct VecLease {
+      tracyhip_ctx* c;
+      std::vector<PairDesc> fullv, prev;
+      std::vector<int> fullk;
+      std::vector<FrontDesc> fd;
+      explicit VecLease(tracyhip_ctx* c_) : c(c_) { fullv.swap(c->cache_full); prev.swap(c->cache_pre); fullk.swap(c->cache_fullk); fd.swap(c->cache_fd); }
+      ~VecLease() { fullv.swap(c->cache_full); prev.swap(c->cache_pre); fullk.swap(c->cache_fullk); fd.swap(c->cache_fd); }
+    } vl(ctx);
+    std::vector<PairDesc>&fullv = vl.fullv, &prev = vl.prev;
+    std::vector<int>& fullk = vl.fullk;
+    std::vector<FrontDesc>& fd = vl.fd;
     std::vector<uint32_t> ft;
-    fullv.reserve(2 * (size_t)nt);
-    fullk.reserve(2 * (size_t)nt);
-    prev.reserve(2 * (size_t)nt);
-    fd.reserve(nt);
-    ft.reserve(nt);
-    for (uint32_t t = 0; t < nt; ++t) {
-      const uint32_t vf = h_votes[2 * t], vr = h_votes[2 * t + 1];
-      guess[t] = vf >= vr ? 0 : 1;
-      const uint32_t hi = vf >= vr ? vf : vr, lo = vf >= vr ? vr : vf;
-      both[t] = (mt[t] > R && hi >= 32 && hi >= 2 * lo) ? 0 : 1;  // a clear majority of shared k-mers, or both sweeps
-      const int g = (int)guess[t];
-      const int Kt = choose_k(mt[t], MODE_QP);
-      const bool front = !both[t] && mt[t] - R > 2u * (uint32_t)kFrontK && rn[t] >= 1 &&
-                         origin16_ok(&p, mt[t], mt[t] - R + 2u * (uint32_t)kFrontHalfW + 16u);
-      if (front) {
-        PairDesc d = stage1_desc(t, g);
-        d.flags |= PAIR_KEEP_ROW;
-        prev.push_back(d);
-        if (in.exact) { fullv.push_back(stage1_desc(t, 1 - g)); fullk.push_back(Kt); }
-        else prev.push_back(stage1_desc(t, 1 - g));
-        FrontDesc f{};
-        f.row_off = d.lastrow_off;
-        f.a2_off = in.a2_off[t];
-        f.tab_off = in.td[t].out_off + in.row0[t] + R;
-        f.tab_stride = in.td[t].stride;
-        f.m_rest = mt[t] - R;
-        f.n = rn[t];
-        f.flags = g ? PAIR_A2_REVCOMP : 0u;
-        f.out = (uint32_t)fd.size();
-        f.R = R;
-        f.rest = h_ub[t];
-        fd.push_back(f);
-        ft.push_back(t);
-      } else if (in.exact || both[t]) {
-        fullv.push_back(stage1_desc(t, g));
-        fullv.push_back(stage1_desc(t, 1 - g));
-        fullk.push_back(Kt);
-        fullk.push_back(Kt);
-      } else {
-        fullv.push_back(stage1_desc(t, g));
-        fullk.push_back(Kt);
-        prev.push_back(stage1_desc(t, 1 - g));
+    struct Cnt { uint32_t full, pre, fr; };
+    Cnt cnt[kHostThreads] = {};
+    const bool exact = in.exact;
+    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+      Cnt c{0, 0, 0};
+      for (uint32_t t = lo; t < hi; ++t) {
+        const uint32_t vf = h_votes[2 * t], vr = h_votes[2 * t + 1];
+        guess[t] = vf >= vr ? 0 : 1;
+        const uint32_t hi_v = vf >= vr ? vf : vr, lo_v = vf >= vr ? vr : vf;
+        both[t] = (mt[t] > R && hi_v >= 32 && hi_v >= 2 * lo_v) ? 0 : 1;  // a clear majority of shared k-mers, or both sweeps
+        const bool front = !both[t] && mt[t] - R > 2u * (uint32_t)kFrontK && rn[t] >= 1 &&
+                           origin16_ok(&p, mt[t], mt[t] - R + 2u * (uint32_t)kFrontHalfW + 16u);
+        if (front) { cls[t] = 0; c.fr += 1; c.pre += exact ? 1 : 2; c.full += exact ? 1 : 0; }
+        else if (exact || both[t]) { cls[t] = 1; c.full += 2; }
+        else { cls[t] = 2; c.full += 1; c.pre += 1; }
       }
-    }
+      cnt[tid] = c;
+    });
+    Cnt at[kHostThreads + 1] = {};
+    for (uint32_t i = 0; i < kHostThreads; ++i) at[i + 1] = Cnt{at[i].full + cnt[i].full, at[i].pre + cnt[i].pre, at[i].fr + cnt[i].fr};
+    const Cnt tot = at[kHostThreads];
+    fullv.resize(tot.full); fullk.resize(tot.full); prev.resize(tot.pre); fd.resize(tot.fr); ft.resize(tot.fr);
+    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+      Cnt w = at[tid];  // (a small batch runs as one slice: tid 0, whose offsets are zero)
+      for (uint32_t t = lo; t < hi; ++t) {
+        const int g = (int)guess[t];
+        const int Kt = choose_k(mt[t], MODE_QP);
+        if (cls[t] == 0) {
+          PairDesc d = stage1_desc(t, g);
+          d.flags |= PAIR_KEEP_ROW;
+          prev[w.pre++] = d;
+          if (exact) { fullv[w.full] = stage1_desc(t, 1 - g); fullk[w.full++] = Kt; }
+          else prev[w.pre++] = stage1_desc(t, 1 - g);
+          FrontDesc f{};
+          f.row_off = d.lastrow_off;
+          f.a2_off = in.a2_off[t];
+          f.tab_off = in.td[t].out_off + in.row0[t] + R;
+          f.tab_stride = in.td[t].stride;
+          f.m_rest = mt[t] - R;
+          f.n = rn[t];
+          f.flags = g ? PAIR_A2_REVCOMP : 0u;
+          f.out = w.fr;
+          f.R = R;
+          f.rest = h_ub[t];
+          fd[w.fr] = f;
+          ft[w.fr++] = t;
+        } else if (cls[t] == 1) {
+          fullv[w.full] = stage1_desc(t, g); fullk[w.full++] = Kt;
+          fullv[w.full] = stage1_desc(t, 1 - g); fullk[w.full++] = Kt;
+        } else {
+          fullv[w.full] = stage1_desc(t, g); fullk[w.full++] = Kt;
+          prev[w.pre++] = stage1_desc(t, 1 - g);
+        }
+      }
+    });
+    sco.mark("o.c run_ckpt_prefix (plan+launch+wait)");
     DpCkpt ckv = ck;
     if ((rc = run_ckpt_prefix(ctx, d_prof, ctx->codes(), fullv, fullk, prev, &p, d_sc2, &ckv, true))) return rc;
+    sco.mark("o.d run_front");
     FrontResult fres;
     if ((rc = run_front(ctx, fd, in.d_qp, reinterpret_cast<const uint32_t*>(ck.d_lastrow), &p, fres))) return rc;
+    sco.mark("o.e fetch+merge");
     if ((rc = fetch_scores())) return rc;
     // merge the scores of a repeat launch (which overwrites d_sc2 at the repeated entries only) into the host copy
     auto repeat_full = [&](std::vector<std::pair<uint32_t, int>> const& what) -> int {
@@ -821,6 +848,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       if (!retry.empty() && (rc = run_stage1(retry, DP_CKPT))) return rc;  // same scores, now with checkpoints
     }
   }
+  sco.mark("o.f stage2 setup");
   for (uint32_t t = 0; t < nt; ++t) {
     if (given) { h_fwd[t] = in.oriented[t] ? 1 : 0; h_rc[t] = 0; }
     else { h_fwd[t] = h_sc2[t] > h_sc2[nt + t] ? 1 : 0; h_rc[t] = !h_fwd[t]; }  // forward iff gsFwd > gsRev (sage.h:247)
@@ -891,10 +919,12 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       // Going back from (m, c_e), a path with at most g gap steps stays on the diagonals c_e - m - g .. c_e - m + g: the band the
       // band kernels sweep (band16.h), where the band fits them; other pairs take the origin-tracking sweep over the whole
       // sub-window (ends_path) or the whole matrix (tb16_path).
+      sco.mark("o.g stage2 band plan");
       const int64_t age = -(int64_t)p.ge;
       std::vector<int32_t> h_pre(nt);
       o.gap.assign(nt, 0);
       Band16Job j16;
+      Band16Lease<Band16Job> j16_lease(ctx, j16);
       j16.kind = ends_path ? 1 : 0;
       j16.d_qp = in.d_qp;
       j16.d_codes = ctx->codes();
@@ -969,6 +999,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
         HIP_TRY(hipGetLastError());
         o.d_ends = d_ends;
       } else {
+        sco.mark("o.h stage2 run_band16 + check");
         // traceback on the band; a pair whose banded score is not S* (or whose walk left the band: no ops) is repeated with the rest
         if (rest.desc.size() < nt) {
           HIP_TRY(ctx->d_tmp[7].ensure(sizeof(int32_t) * (size_t)nt));
@@ -1882,24 +1913,28 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     if ((rc = io(out->ops[k], cap ? cap : 1, false, &d_opsK[k]))) return rc;
     if ((rc = io(out->ops_len[k], sizeof(uint32_t) * (size_t)nt, false, &d_lenK[k]))) return rc;
   }
+  StageClock sc6;
   for (int k = 0; k < 2; ++k) {
     const void* seq = (k == 0) ? d_pri : d_sd;
+    sc6.mark("6.a desc+tables");
     DpProblem pb;
     DpProblemLease lease(ctx, pb);
     pb.mode = use_cq ? MODE_CQ : MODE_CHAR; pb.d_a1 = seq; pb.d_a2 = use_cq ? static_cast<const void*>(d_cq_ref) : d_ref;
     pb.cq_codes = getenv("TRACYHIP_NO_COMPACT") ? 6 : cq_codes;
     pb.desc.resize(nt); pb.k.resize(nt);
-    for (uint32_t t = 0; t < nt; ++t) {
-      PairDesc d{};
-      d.a1_off = bc.bc_offset[t] + soff[t];
-      d.m = sl[t]; d.a1_stride = sl[t];
-      d.a2_off = sr.offset[ridx[t]];
-      d.n = rn[t]; d.a2_stride = rn[t];
-      d.flags = h_rc[t] ? PAIR_A2_REVCOMP : 0;
-      d.out = t;
-      pb.desc[t] = d;
-      pb.k[t] = choose_k(d.m, MODE_CHAR);
-    }
+    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t) {
+      for (uint32_t t = lo; t < hi; ++t) {
+        PairDesc d{};
+        d.a1_off = bc.bc_offset[t] + soff[t];
+        d.m = sl[t]; d.a1_stride = sl[t];
+        d.a2_off = sr.offset[ridx[t]];
+        d.n = rn[t]; d.a2_stride = rn[t];
+        d.flags = h_rc[t] ? PAIR_A2_REVCOMP : 0;
+        d.out = t;
+        pb.desc[t] = d;
+        pb.k[t] = choose_k(d.m, MODE_CHAR);
+      }
+    });
     // Band kernels (band16.h): the score S* of the certifying sweep below bounds the gap steps of every optimal alignment,
     // g = (best m - S*) / |ge|, and with them the diagonals it can visit: the origin-tracking sweep and the traceback against the
     // trimmed slice run on that band only (four pairs per wave, sixteen lanes per pair).  TRACYHIP_NO_BAND16=1: whole matrices.
@@ -1950,10 +1985,12 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
         sc.narrow = true;
         sc.d_ckpt = static_cast<int32_t*>(ctx->d_lastrow.p);  // (never written)
         sc.d_lastrow = static_cast<int32_t*>(ctx->d_lastrow.p);
+        sc6.mark("6.b sweep run_dp");
         rc = run_dp(ctx, pb, &p, false, false, d_swscore, nullptr, nullptr, nullptr, DP_CKPT, &sc);
         pb.d_special = nullptr;
         if (rc == kWiden) subwin = false;
         else if (rc) return rc;
+        sc6.mark("6.c rowend+subwindow");
         if (subwin) {
           const RowEndDesc* d_re;
           if ((rc = upload(ctx, buf(), hre, &d_re))) return rc;
@@ -1991,10 +2028,12 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
           HIP_TRY(hipMemcpyAsync(d_shift, shift.data(), sizeof(uint32_t) * (size_t)nt, hipMemcpyHostToDevice, st));
         }
       }
+      sc6.mark("6.d origin band plan+launch");
       DpCkpt oc;
       oc.d_ends = static_cast<uint32_t*>(b_ends.p);
       // the alignment ends in the last column of its sub-window with at most g gap steps behind it: diagonals n' - m - g .. n' - m + g
       Band16Job jo;
+      Band16Lease<Band16Job> jo_lease(ctx, jo);
       DpProblem rest;
       if (b16) {
         jo.kind = 1; jo.d_qp = static_cast<const int16_t*>(ctx->d_b16tab[k].p); jo.d_codes = d_cq_ref;
@@ -2034,6 +2073,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
                          reinterpret_cast<const uint8_t*>(static_cast<const uint32_t*>(b_rnfw.p) + nt), TL, TR, nt,
                          static_cast<TrimOut*>(b_trimA.p));
     }
+    sc6.mark("6.e trim readback (waits for origin)");
     HIP_TRY(hipGetLastError());
     h_trimA[k].resize(nt);
     std::vector<uint32_t> h_ends;
@@ -2043,6 +2083,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       HIP_TRY(hipMemcpyAsync(h_ends.data(), b_ends.p, sizeof(uint32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
+    sc6.mark("6.f slice descs+plan");
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc& d = pb.desc[t];
       d.n = h_trimA[k][t].len; d.a2_stride = d.n;
@@ -2055,6 +2096,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     // column c_e - slice_begin of row m and every optimal path stays within g gap steps of that diagonal.  Banded pairs are
     // checked against S* afterwards (a walk that left its band reports no ops); what fails goes to the whole matrix with the rest.
     Band16Job jt;
+    Band16Lease<Band16Job> jt_lease(ctx, jt);
     DpProblem rest;
     rest.mode = pb.mode; rest.d_a1 = pb.d_a1; rest.d_a2 = pb.d_a2; rest.cq_codes = pb.cq_codes;
     if (!h_ends.empty()) {
@@ -2084,7 +2126,9 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       for (uint32_t t = 0; t < nt; ++t)
         if (jt.k[t] == 0) { rest.desc.push_back(pb.desc[t]); rest.k.push_back(pb.k[t]); }
       const size_t nb16 = nt - rest.desc.size();
+      sc6.mark("6.g run_band16 traceback");
       if ((rc = run_band16(ctx, jt, &p, static_cast<int32_t*>(d_scoreK[k]), nullptr, static_cast<uint8_t*>(d_opsK[k]), d_offK, static_cast<uint32_t*>(d_lenK[k])))) return rc;
+      sc6.mark("6.h check readback (waits for traceback)");
       if (nb16) {
         std::vector<int32_t> h_sc(nt);
         std::vector<uint32_t> h_ol(nt);
@@ -2106,20 +2150,23 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
                      static_cast<uint32_t*>(d_lenK[k]))))
       return rc;
   }
+  sc6.mark("6.i allele1v2 setup");
   {  // allele 1 vs allele 2, global (indigo.h:379-387)
     DpProblem pb;
     DpProblemLease lease(ctx, pb);
     pb.mode = use_cq ? MODE_CQ : MODE_CHAR; pb.d_a1 = d_pri; pb.d_a2 = use_cq ? static_cast<const void*>(d_cq_sd) : d_sd;
     pb.desc.resize(nt); pb.k.resize(nt);
-    for (uint32_t t = 0; t < nt; ++t) {
-      PairDesc d{};
-      d.a1_off = bc.bc_offset[t] + soff[t];
-      d.a2_off = bc.bc_offset[t] + soff[t];
-      d.m = sl[t]; d.n = sl[t]; d.a1_stride = sl[t]; d.a2_stride = sl[t];
-      d.out = t;
-      pb.desc[t] = d;
-      pb.k[t] = choose_k(d.m, MODE_CHAR);
-    }
+    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t) {
+      for (uint32_t t = lo; t < hi; ++t) {
+        PairDesc d{};
+        d.a1_off = bc.bc_offset[t] + soff[t];
+        d.a2_off = bc.bc_offset[t] + soff[t];
+        d.m = sl[t]; d.n = sl[t]; d.a1_stride = sl[t]; d.a2_stride = sl[t];
+        d.out = t;
+        pb.desc[t] = d;
+        pb.k[t] = choose_k(d.m, MODE_CHAR);
+      }
+    });
     const uint64_t* d_offK;
     std::vector<uint64_t> offK(out->ops_offset[2], out->ops_offset[2] + nt);
     if ((rc = upload(ctx, buf(), offK, &d_offK))) return rc;
@@ -2129,6 +2176,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     // whole matrix's.  W is guessed from what the two alleles lost against the reference (they differ from each other by about
     // as much as both differ from it); pairs that do not certify are repeated on the whole matrix.
     Band16Job jg;
+    Band16Lease<Band16Job> jg_lease(ctx, jg);
     DpProblem rest;
     rest.mode = pb.mode; rest.d_a1 = pb.d_a1; rest.d_a2 = pb.d_a2; rest.cq_codes = pb.cq_codes;
     const bool b16g = use_cq && !td_pri.empty() && pglobal.ge < 0 && pglobal.go <= 0 && getenv("TRACYHIP_NO_BAND16") == nullptr;
@@ -2169,6 +2217,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
         if (jg.k[t] == 0) { rest.desc.push_back(pb.desc[t]); rest.k.push_back(pb.k[t]); }
       const size_t nb16 = nt - rest.desc.size();
       HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
+      sc6.mark("6.j allele1v2 run_band16");
       if ((rc = run_band16(ctx, jg, &pglobal, static_cast<int32_t*>(d_scoreK[2]), nullptr, static_cast<uint8_t*>(d_opsK[2]), d_offK, static_cast<uint32_t*>(d_lenK[2])))) return rc;
       if (nb16) {
         std::vector<int32_t> h_sc(nt);
@@ -2187,6 +2236,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       return rc;
   }
 
+  sc6.mark("6.k results");
   // ---- results ----
   const hipMemcpyKind up = (mem == TRACYHIP_MEM_HOST) ? hipMemcpyHostToHost : hipMemcpyHostToDevice;
   std::vector<uint32_t> hb[2], hl[2], hp[2];

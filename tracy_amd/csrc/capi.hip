@@ -911,8 +911,46 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
   return TRACYHIP_OK;  // (bit 1 -- a walk left its band -- is the caller's to resolve: such pairs report ops_len 0)
 }
 
+int run_prefix_keep_cq(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const uint8_t* d_special, const std::vector<PairDesc>& pre,
+                       const tracyhip_params* prm, int32_t* d_lastrow) {
+  hipStream_t st = ctx->stream;
+  const size_t np = pre.size();
+  HIP_TRY(ctx->d_err.ensure(kErrBytes));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
+  if (np == 0) return TRACYHIP_OK;
+  // (a staging block of its own: run_front fills h_desc while this copy may still be queued)
+  HIP_TRY(ctx->h_pre.ensure(sizeof(PairDesc) * np));
+  PairDesc* hd = static_cast<PairDesc*>(ctx->h_pre.p);
+  uint64_t cells[kHostThreads] = {}, bytes[kHostThreads] = {};
+  parallel_for((uint32_t)np, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+    uint64_t c = 0, b = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+      hd[i] = pre[i];
+      c += (uint64_t)std::min<uint32_t>(pre[i].m, kFrontRows) * pre[i].n;
+      b += (uint64_t)kFrontRows + pre[i].n + 4ull * pre[i].n;
+    }
+    cells[tid] = c; bytes[tid] = b;
+  });
+  HIP_TRY(ctx->d_pre.ensure(sizeof(PairDesc) * np));
+  HIP_TRY(hipMemcpyAsync(ctx->d_pre.p, hd, sizeof(PairDesc) * np, hipMemcpyHostToDevice, st));
+  DpArgs a{};
+  a.pairs = static_cast<const PairDesc*>(ctx->d_pre.p);
+  a.a1 = d_a1; a.a2 = d_a2; a.scores = nullptr; a.err = static_cast<int32_t*>(ctx->d_err.p);
+  a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge; a.hfree = prm->hfree; a.vfree = prm->vfree;
+  a.qlimit = sub_limit(prm);
+  a.special_blocks = d_special;
+  a.lastrow = d_lastrow;
+  uint64_t tc = 0, tb = 0;
+  for (uint32_t t = 0; t < kHostThreads; ++t) { tc += cells[t]; tb += bytes[t]; }
+  int trc;
+  if ((trc = timing_begin(ctx, TRACYHIP_TIMER_SCORE, tc, tb))) return trc;
+  HIP_TRY(launch_gotoh_front_prefix_cq(a, (uint32_t)np, st));
+  if ((trc = timing_end(ctx))) return trc;
+  return TRACYHIP_OK;
+}
+
 int run_front(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, const int16_t* d_qp, const uint32_t* d_row, const tracyhip_params* prm,
-              FrontResult& out) {
+              FrontResult& out, const uint8_t* d_codes, bool keep_err) {
   hipStream_t st = ctx->stream;
   const size_t nf = fd.size();
   out.fo.assign(nf, FrontOut{});
@@ -930,7 +968,7 @@ int run_front(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, const int16_t
   std::memcpy(ctx->h_desc.p, fd.data(), sizeof(FrontDesc) * nf);
   HIP_TRY(hipMemcpyAsync(d_fd, ctx->h_desc.p, sizeof(FrontDesc) * nf, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx->d_err.ensure(kErrBytes));
-  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
+  if (!keep_err) HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
   uint32_t max_rest = 0;
   uint64_t cells = 0, bytes = 0;
   for (const FrontDesc& f : fd) {
@@ -941,7 +979,7 @@ int run_front(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, const int16_t
     }
   }
   Band16Args a{};
-  a.pairs = d_pairs; a.npairs = (uint32_t)nf; a.qp = d_qp; a.codes = ctx->codes(); a.scores = d_fs; a.ends = d_fe;
+  a.pairs = d_pairs; a.npairs = (uint32_t)nf; a.qp = d_qp; a.codes = d_codes ? d_codes : ctx->codes(); a.scores = d_fs; a.ends = d_fe;
   a.err = static_cast<int32_t*>(ctx->d_err.p); a.go = prm->go; a.ge = prm->ge; a.hfree = 1; a.row = d_row;
   a.code_cap = (max_rest + 2u * (uint32_t)kFrontHalfW + 16u) & ~3u;  // front_place_body: a sub-window is at most m_rest + 2 halfw + 2 columns
   if (4ull * a.code_cap + b16_table_bytes(kFrontK) + 32ull * kB16RowCap > 64u * 1024u)

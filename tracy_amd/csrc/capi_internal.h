@@ -77,6 +77,7 @@ struct tracyhip_ctx {
   tracyhip::DevBuf d_ckpt, d_lastrow, d_band;  // pipeline intermediates (align_traces / decompose)
   tracyhip::DevBuf d_b16tab[4], d_b16desc;     // substitution tables of the band kernels (band16.h), their descriptors
   tracyhip::DevBuf d_front;                    // descriptors / pairs / results of the pruned orientation sweep (front.h)
+  tracyhip::DevBuf d_pre;                      // descriptors of its prefix launch over string x code pairs (run_prefix_keep_cq)
   hipError_t ensure_codes(size_t bytes, hipStream_t st) {
     hipError_t e = d_codes.ensure(bytes + 2 * tracyhip::kCodePad);
     if (e != hipSuccess) return e;
@@ -91,7 +92,7 @@ struct tracyhip_ctx {
   uint8_t* codes() const { return static_cast<uint8_t*>(d_codes.p) + tracyhip::kCodePad; }
   tracyhip::DevBuf d_aftab;                    // allelicFraction grid enumeration (trace independent)
   bool aftab_ready = false;
-  tracyhip::PinBuf h_desc, h_off, h_tmp, h_res, h_b16desc[4];
+  tracyhip::PinBuf h_desc, h_off, h_tmp, h_res, h_b16desc[4], h_pre;
   uint32_t b16_round = 0;
   // kernel timing
   struct Pending { int which; hipEvent_t e0, e1; uint64_t cells, bytes; };
@@ -129,10 +130,12 @@ struct tracyhip_ctx {
     for (auto& b : d_b16tab) b.release();
     d_b16desc.release();
     d_front.release();
+    d_pre.release();
     h_desc.release();
     h_off.release();
     h_tmp.release();
     h_res.release();
+    h_pre.release();
     for (auto& b : h_b16desc) b.release();
   }
 };
@@ -261,7 +264,14 @@ struct FrontResult {
 };
 constexpr int kFrontK = 12;
 constexpr int32_t kFrontHalfW = 90;  // 2 * 90 + 12 <= 15 * 13: the widest band one period of the K = 12 strips holds
+// d_codes: the codes the band kernels read (null: the context's); keep_err: the error words hold the flags of a launch that has
+// not been read yet (run_prefix_keep_cq) -- they are not cleared, and reported with this call's
 int run_front(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, const int16_t* d_qp, const uint32_t* d_row, const tracyhip_params* prm,
-              FrontResult& out);
+              FrontResult& out, const uint8_t* d_codes = nullptr, bool keep_err = false);
+// The prefix rows of the pruned sweep for string x code pairs (gotoh(allele, window), indigo.h:359): rows 1 .. kFrontRows of every
+// pair over all its columns, row kFrontRows kept at d_lastrow + PairDesc::lastrow_off (PAIR_KEEP_ROW).  Queued, not waited for: the
+// error words are cleared before the launch and read by the run_front call that follows.
+int run_prefix_keep_cq(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const uint8_t* d_special, const std::vector<PairDesc>& pre,
+                       const tracyhip_params* prm, int32_t* d_lastrow);
 }  // namespace tracyhip
 #endif

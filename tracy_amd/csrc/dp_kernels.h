@@ -1230,7 +1230,9 @@ constexpr uint32_t kFrontRows = (uint32_t)kFrontPrefixLanes * kFrontPrefixK;
 
 // COMPACT: the form for references of A C G T (four code rows in LDS); as with the sweeps, both forms are launched over the
 // same pairs and every group of lanes works on its pair in the form the reference calls for (DpArgs::special_blocks)
-template <class W, int K, int GL, bool COMPACT = false>
+// STRINGS: the rows are characters (gotoh(allele, window) of `tracy decompose`, indigo.h:359): match / mismatch by byte equality
+// (align.h:96-101) against the codes A C G T N, mismatch against '-' / any other letter -- the table of the MODE_CQ sweeps
+template <class W, int K, int GL, bool COMPACT = false, bool STRINGS = false>
 TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_t npairs) {
   static_assert(64 % GL == 0, "whole groups per wave");
   constexpr uint32_t NCODES = COMPACT ? 4u : 5u;
@@ -1250,7 +1252,8 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
   const uint32_t m = d.m, n = valid ? d.n : 0u;
   const int32_t go = a.go, ge = a.ge, goe = go + ge;
   const float fmatch = (float)a.match, fmis = (float)a.mismatch;
-  const float* a1p = static_cast<const float*>(a.a1) + d.a1_off;
+  const float* a1p = static_cast<const float*>(a.a1) + (STRINGS ? 0 : d.a1_off);
+  const uint8_t* a1c = static_cast<const uint8_t*>(a.a1) + (STRINGS ? d.a1_off : 0);
   const uint8_t* a2c = static_cast<const uint8_t*>(a.a2) + d.a2_off;
   int16_t* qp_tab = reinterpret_cast<int16_t*>(w.lds());
   constexpr uint32_t R = (uint32_t)GL * K;
@@ -1284,21 +1287,27 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
 #pragma unroll 1
     for (int i = 0; i < K; ++i) {
       const uint32_t r = Lg * K + i + 1;
-      float pr[5];
+      float pr[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      uint8_t rch = 0;
+      if (STRINGS) rch = (valid && r - 1 < m) ? a1c[r - 1] : 0;
+      else {
 #pragma unroll
-      for (int k = 0; k < 5; ++k) pr[k] = (valid && r - 1 < m) ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+        for (int k = 0; k < 5; ++k) pr[k] = (valid && r - 1 < m) ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+      }
 #pragma unroll
       for (uint32_t b = 0; b < NCODES; ++b) {
-        const int32_t q = (valid && r - 1 < m) ? onehot_score(pr, b, fmatch, fmis) : 0;
+        int32_t q = 0;
+        if (valid && r - 1 < m) q = STRINGS ? (rch == (uint8_t)"ACGTN"[b] ? a.match : a.mismatch) : onehot_score(pr, b, fmatch, fmis);
         const int32_t qs = q - goe;
         overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
         qabs = imax(qabs, q < 0 ? -q : q);
         qp_tab[b * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)qs;
       }
     }
-    if (L < (uint32_t)qp_stride(K)) qp_tab[NCODES * (64 * qp_stride(K)) + L] = (int16_t)(-goe);
+    // the shared strip of '-' / any other letter: an all-zero profile column scores 0, a string column that no row can equal mismatches
+    if (L < (uint32_t)qp_stride(K)) qp_tab[NCODES * (64 * qp_stride(K)) + L] = (int16_t)((STRINGS ? a.mismatch : 0) - goe);
     if (overflow) flag_error(a.err, 1);
-    if (qabs > a.qlimit) flag_max(a.err, 1, qabs);
+    if (!STRINGS && qabs > a.qlimit) flag_max(a.err, 1, qabs);
     w.sync();
   }
 

@@ -96,10 +96,10 @@ __global__ __launch_bounds__(64) void gotoh_ckpt_prefix_kernel(DpArgs full, uint
   else gotoh_body<DeviceWave, K, MODE_QP, false, true, true, 0, COMPACT>(w, full, blockIdx.x - ngroups);
 }
 // prefix bound of the semiglobal score: GL lanes per pair, 64/GL pairs per workgroup
-template <int K, int GL, bool COMPACT = false>
+template <int K, int GL, bool COMPACT = false, bool STRINGS = false>
 __global__ __launch_bounds__(64) void gotoh_prefix_kernel(DpArgs a, uint32_t npairs) {
   DeviceWave w;
-  gotoh_prefix_body<DeviceWave, K, GL, COMPACT>(w, a, blockIdx.x * (64u / GL), npairs);
+  gotoh_prefix_body<DeviceWave, K, GL, COMPACT, STRINGS>(w, a, blockIdx.x * (64u / GL), npairs);
 }
 // at least three waves per SIMD: the K = 15 / 16 instantiations would otherwise settle at 190-200 VGPRs and two waves, and a
 // wave issues a VALU instruction only every ~4.5 cycles (6-24 spilled registers outside the sweep: band traceback 5.5 -> 5.0 ms)
@@ -460,6 +460,15 @@ hipError_t launch_gotoh_prefix(int K, const DpArgs& a, uint32_t npairs, hipStrea
     default: return hipErrorInvalidValue;
   }
 #undef TRACY_PREFIX_CASE
+  return hipGetLastError();
+}
+// the prefix rows of the pruned sweep (front.h) for string x code pairs: kFrontPrefixLanes lanes of kFrontPrefixK rows per pair, row R kept
+hipError_t launch_gotoh_front_prefix_cq(const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  if (npairs == 0) return hipSuccess;
+  constexpr int GL = kFrontPrefixLanes, KP = kFrontPrefixK;
+  const dim3 grid((npairs + 64 / GL - 1) / (64 / GL));
+  if (a.special_blocks) hipLaunchKernelGGL((gotoh_prefix_kernel<KP, GL, true, true>), grid, dim3(64), lds_bytes_prefix(KP, true), s, a, npairs);
+  hipLaunchKernelGGL((gotoh_prefix_kernel<KP, GL, false, true>), grid, dim3(64), lds_bytes_prefix(KP, false), s, a, npairs);
   return hipGetLastError();
 }
 hipError_t launch_gotoh_walk(const WalkArgs& a, hipStream_t s) {

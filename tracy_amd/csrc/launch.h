@@ -28,6 +28,7 @@ struct RowsArgs {
 hipError_t launch_gotoh(int mode, int K, bool trace, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s, bool rawtab = false);
 // profile x profile with the substitution-term count fixed per launch: row4_zero = every pair of the launch carries PAIR_ROW4_ZERO
 // arith16 (score only): 16-bit cells -- the caller has checked the value range (arith16_ok)
+hipError_t launch_gotoh_front_prefix_cq(const DpArgs& a, uint32_t npairs, hipStream_t s);
 hipError_t launch_gotoh_prof(int K, bool trace, bool row4_zero, bool arith16, const DpArgs& a, uint32_t npairs, hipStream_t s);
 // checkpointed score pass / band traceback (single-pass problems, MODE_CHAR or MODE_QP)
 hipError_t launch_gotoh_ckpt(int mode, int K, bool narrow, const DpArgs& a, uint32_t npairs, hipStream_t s);

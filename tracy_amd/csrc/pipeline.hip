@@ -1986,12 +1986,69 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
         sc.d_ckpt = static_cast<int32_t*>(ctx->d_lastrow.p);  // (never written)
         sc.d_lastrow = static_cast<int32_t*>(ctx->d_lastrow.p);
         sc6.mark("6.b sweep run_dp");
-        rc = run_dp(ctx, pb, &p, false, false, d_swscore, nullptr, nullptr, nullptr, DP_CKPT, &sc);
+        // The pruned sweep (front.h), as for the orientation of the trace: rows 1 .. R of the allele over the whole window (row R kept),
+        // the rows below them on the diagonals around the best column of row R, and a certificate per pair that no path outside those
+        // diagonals reaches the band's score (rest = best x the rows below R: a row of a string scores `match` at most).  Certified
+        // pairs have S* and c_e without the window under their first R rows having been swept for the other m - R; the others -- a
+        // second copy of the allele's locus in the window, an allele that lost more than the band pays for -- are swept in full.
+        std::vector<int8_t> pruned(nt, 0);
+        std::vector<int32_t> fscore;
+        std::vector<uint32_t> fce;
+        if (b16 && getenv("TRACYHIP_NO_FRONT") == nullptr) {
+          const uint32_t R = kFrontRows;
+          const int64_t bestq = std::max<int64_t>(std::max<int64_t>(p.match, p.mismatch), 0);
+          std::vector<PairDesc> pre;
+          std::vector<FrontDesc> fd;
+          std::vector<uint32_t> ft;
+          pre.reserve(nt); fd.reserve(nt); ft.reserve(nt);
+          for (uint32_t t = 0; t < nt; ++t) {
+            const PairDesc& d = pb.desc[t];
+            if (!(d.m > R + 2u * (uint32_t)kFrontK && d.n >= 1 && origin16_ok(&p, d.m, d.m - R + 2u * (uint32_t)kFrontHalfW + 16u))) continue;
+            PairDesc q = d;
+            q.flags |= PAIR_KEEP_ROW;
+            pre.push_back(q);
+            FrontDesc f{};
+            f.row_off = d.lastrow_off;
+            f.a2_off = d.a2_off;
+            f.tab_off = td[t].out_off + R;
+            f.tab_stride = td[t].stride;
+            f.m_rest = d.m - R;
+            f.n = d.n;
+            f.flags = d.flags & PAIR_A2_REVCOMP;
+            f.out = (uint32_t)fd.size();
+            f.R = R;
+            f.rest = (int32_t)(bestq * (int64_t)(d.m - R));
+            fd.push_back(f);
+            ft.push_back(t);
+          }
+          if (!fd.empty()) {
+            if ((rc = run_prefix_keep_cq(ctx, pb.d_a1, pb.d_a2, pb.d_special, pre, &p, static_cast<int32_t*>(ctx->d_lastrow.p)))) return rc;
+            FrontResult fres;
+            if ((rc = run_front(ctx, fd, static_cast<const int16_t*>(ctx->d_b16tab[k].p), static_cast<const uint32_t*>(ctx->d_lastrow.p), &p, fres, d_cq_ref, true)))
+              return rc;
+            fscore.assign(nt, 0);
+            fce.assign(nt, 0);
+            uint32_t nok = 0;
+            for (size_t i = 0; i < ft.size(); ++i)
+              if (fres.fo[i].ok && fres.ce[i]) { pruned[ft[i]] = 1; fscore[ft[i]] = fres.score[i]; fce[ft[i]] = fres.ce[i]; ++nok; }
+            if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "decompose allele %d: pruned sweep of %zu of %u alleles, %u certified\n", k, ft.size(), nt, nok);
+          }
+        }
+        {
+          DpProblem full;  // what is swept in full
+          full.mode = pb.mode; full.a1_profile = pb.a1_profile; full.a2_profile = pb.a2_profile; full.d_a1 = pb.d_a1; full.d_a2 = pb.d_a2;
+          full.d_a2_chars = pb.d_a2_chars; full.d_special = pb.d_special; full.cq_codes = pb.cq_codes;
+          for (uint32_t t = 0; t < nt; ++t)
+            if (!pruned[t]) { full.desc.push_back(pb.desc[t]); full.k.push_back(pb.k[t]); }
+          rc = full.desc.empty() ? TRACYHIP_OK : run_dp(ctx, full, &p, false, false, d_swscore, nullptr, nullptr, nullptr, DP_CKPT, &sc);
+        }
         pb.d_special = nullptr;
         if (rc == kWiden) subwin = false;
         else if (rc) return rc;
         sc6.mark("6.c rowend+subwindow");
         if (subwin) {
+          for (uint32_t t = 0; t < nt; ++t)
+            if (pruned[t]) hre[t].n = 0;  // (row m of a pruned pair was never written: its c_e is the band's)
           const RowEndDesc* d_re;
           if ((rc = upload(ctx, buf(), hre, &d_re))) return rc;
           hipLaunchKernelGGL(row_m_end_kernel, dim3(nt), dim3(64), 0, st, d_re, static_cast<const int32_t*>(ctx->d_lastrow.p), p.go + p.ge, d_ce);
@@ -2001,6 +2058,9 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
           HIP_TRY(hipMemcpyAsync(h_s.data(), d_swscore, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
           HIP_TRY(hipMemcpyAsync(h_ce.data(), d_ce, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
           HIP_TRY(hipStreamSynchronize(st));
+          if (!fscore.empty())
+            for (uint32_t t = 0; t < nt; ++t)
+              if (pruned[t]) { h_s[t] = fscore[t]; h_ce[t] = fce[t]; }
           const int64_t best = std::max<int64_t>(std::max<int64_t>(p.match, p.mismatch), 0), age = -(int64_t)p.ge;
           parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t) {
             for (uint32_t t = lo; t < hi; ++t) {

@@ -249,3 +249,67 @@ def test_staging_in_global_memory():
                         "-k", "find_breakpoint or decompose_chain or decompose_traces_pipeline"], capture_output=True, text=True, env=env, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "3 passed" in r.stdout
+
+
+def test_pruned_sweeps_of_decompose_where_they_certify_and_where_they_cannot(ctx, monkeypatch, capfd):
+    """`tracy decompose` takes gotohScore(trace, window) of the voted strand and gotoh(allele, window) from the pruned sweep
+    (front.h: prefix rows over the window, a certified band below them).  Windows that hold the locus twice cannot certify and are
+    swept in full: the results are those of the run without the pruned sweep either way, and the oracle's (indigo.h:190-388)."""
+    import re
+    from indigo_oracle import decompose_trace
+    from tracy_amd import capi, hostlib
+    nd = 72
+    d = hostlib.synth_decompose_batch(919, nd, 2200, 640, 0, mix=1)
+    rng = np.random.default_rng(5)
+    refs = []
+    for i in range(nd):
+        r = d["refs"][i].tobytes()
+        if i % 3 == 0:  # the window twice, the second copy with a few substitutions: which copy wins is decided far below the prefix rows
+            c = bytearray(r)
+            for j in rng.integers(0, len(c), 12):
+                c[int(j)] = int(rng.choice(list(b"ACGT")))
+            r = r + bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(40, 300))).tolist()) + bytes(c)
+        refs.append(r)
+
+    def run():
+        hbc = capi.HostBaseCalls([d["signal"][i] for i in range(nd)], [d["bcpos"][i] for i in range(nd)],
+                                 [d["primary"][i].tobytes() for i in range(nd)], [d["secondary"][i].tobytes() for i in range(nd)])
+        return ctx.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, refs, SC)
+    monkeypatch.setenv("TRACYHIP_HOST_TIMERS", "1")
+    capfd.readouterr()
+    pruned = run()
+    said = capfd.readouterr().err
+    monkeypatch.delenv("TRACYHIP_HOST_TIMERS")
+    m = re.search(r"pruned orientation sweep: (\d+) of (\d+) traces, (\d+) not certified", said)
+    assert m and int(m.group(1)) >= nd // 2 and 8 <= int(m.group(3)) < int(m.group(1)), said[-600:]
+    al = re.findall(r"decompose allele (\d): pruned sweep of (\d+) of (\d+) alleles, (\d+) certified", said)
+    assert len(al) == 2 and all(int(x[1]) >= nd // 2 and 8 <= int(x[1]) - int(x[3]) and int(x[3]) >= 8 for x in al), said[-600:]
+    monkeypatch.setenv("TRACYHIP_NO_FRONT", "1")
+    plain = run()
+    monkeypatch.delenv("TRACYHIP_NO_FRONT")
+    assert int((np.asarray(pruned["status"]) == 0).sum()) > nd // 2
+    for k in pruned:
+        a, b = pruned[k], plain[k]
+        if k in ("dcp_indel", "dcp_err", "ops"):
+            continue
+        if k == "bp":
+            assert [(x.indelshift, x.traceleft, x.breakpoint, x.best_diff) for x in a] == [(x.indelshift, x.traceleft, x.breakpoint, x.best_diff) for x in b]
+        elif isinstance(a, np.ndarray):
+            assert np.array_equal(a, b), k
+        elif isinstance(a, (list, tuple, dict, int, float, str, bytes)):
+            assert a == b, k
+        else:
+            assert bytes(a) == bytes(b), k
+    for i in range(0, 18):  # and the oracle, on windows of both kinds
+        w = decompose_trace(d["signal"][i], d["bcpos"][i], d["primary"][i].tobytes(), d["secondary"][i].tobytes(), refs[i], SC)
+        assert int(pruned["status"][i]) == w["status"], i
+        if w["status"] != 0:
+            continue
+        for k in ("score_fwd", "score_rev", "forward", "score_trim"):
+            assert int(pruned[k][i]) == int(w[k]), (i, k)
+        for k in range(3):
+            assert int(pruned["score%d" % k][i]) == w["score%d" % k], (i, k)
+            assert pruned["btr%d" % k][i] == w["btr%d" % k], (i, k)
+        for k in range(2):
+            for nm in ("slice_begin", "slice_len", "ref_pos"):
+                assert int(pruned["%s%d" % (nm, k)][i]) == int(w["%s%d" % (nm, k)]), (i, nm, k)

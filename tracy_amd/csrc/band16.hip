@@ -133,6 +133,7 @@ hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s) {
   switch (K) {
     case 12: hipLaunchKernelGGL((band16_cont_kernel<12>), grid, dim3(64), lds, s, a); break;
     case 8: hipLaunchKernelGGL((band16_cont_kernel<8>), grid, dim3(64), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((band16_cont_kernel<4>), grid, dim3(64), lds, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -949,8 +949,9 @@ int run_prefix_keep_cq(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, co
   return TRACYHIP_OK;
 }
 
-int run_front(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, const int16_t* d_qp, const uint32_t* d_row, const tracyhip_params* prm,
-              FrontResult& out, const uint8_t* d_codes, bool keep_err) {
+// one tier of run_front: place, band below row R on strips of KB rows and the diagonals c* +- halfw, certify
+static int run_front_once(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, const int16_t* d_qp, const uint32_t* d_row, const tracyhip_params* prm,
+                          FrontResult& out, const uint8_t* d_codes, bool keep_err, int KB, int32_t halfw) {
   hipStream_t st = ctx->stream;
   const size_t nf = fd.size();
   out.fo.assign(nf, FrontOut{});
@@ -971,24 +972,33 @@ int run_front(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, const int16_t
   if (!keep_err) HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
   uint32_t max_rest = 0;
   uint64_t cells = 0, bytes = 0;
-  for (const FrontDesc& f : fd) {
-    max_rest = std::max(max_rest, f.m_rest);
-    if (ctx->timing) {
-      cells += (uint64_t)b16_strips(f.m_rest, kFrontK) * kFrontK * (uint64_t)(kFrontK + 2 * kFrontHalfW);
-      bytes += 12ull * f.m_rest + f.m_rest + 2ull * kFrontHalfW + 4ull * (2 * kFrontHalfW + kFrontK) + 8ull * f.n;  // tables, codes, the kept row (twice: place, certify)
-    }
+  {
+    uint32_t mr[kHostThreads] = {};
+    uint64_t cs[kHostThreads] = {}, bs[kHostThreads] = {};
+    parallel_for((uint32_t)nf, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+      uint32_t m0 = 0;
+      uint64_t c0 = 0, b0 = 0;
+      for (uint32_t i = lo; i < hi; ++i) {
+        const FrontDesc& f = fd[i];
+        m0 = std::max(m0, f.m_rest);
+        c0 += (uint64_t)b16_strips(f.m_rest, KB) * KB * (uint64_t)(KB + 2 * halfw);
+        b0 += 12ull * f.m_rest + f.m_rest + 2ull * halfw + 4ull * (2 * halfw + KB) + 8ull * f.n;  // tables, codes, the kept row (twice: place, certify)
+      }
+      mr[tid] = m0; cs[tid] = c0; bs[tid] = b0;
+    });
+    for (uint32_t t = 0; t < kHostThreads; ++t) { max_rest = std::max(max_rest, mr[t]); cells += cs[t]; bytes += bs[t]; }
   }
   Band16Args a{};
   a.pairs = d_pairs; a.npairs = (uint32_t)nf; a.qp = d_qp; a.codes = d_codes ? d_codes : ctx->codes(); a.scores = d_fs; a.ends = d_fe;
   a.err = static_cast<int32_t*>(ctx->d_err.p); a.go = prm->go; a.ge = prm->ge; a.hfree = 1; a.row = d_row;
-  a.code_cap = (max_rest + 2u * (uint32_t)kFrontHalfW + 16u) & ~3u;  // front_place_body: a sub-window is at most m_rest + 2 halfw + 2 columns
-  if (4ull * a.code_cap + b16_table_bytes(kFrontK) + 32ull * kB16RowCap > 64u * 1024u)
+  a.code_cap = (max_rest + 2u * (uint32_t)halfw + 16u) & ~3u;  // front_place_body: a sub-window is at most m_rest + 2 halfw + 2 columns
+  if (4ull * a.code_cap + b16_table_bytes(KB) + 32ull * kB16RowCap > 64u * 1024u)
     return set_error(TRACYHIP_ERR_RANGE, "run_front: traces of %u rows do not fit the staging area", max_rest);
   int trc;
   if ((trc = timing_begin(ctx, TRACYHIP_TIMER_FRONT, cells, bytes))) return trc;
-  HIP_TRY(launch_front_place(d_fd, (uint32_t)nf, d_row, prm->go + prm->ge, kFrontHalfW, d_pairs, d_fo, st));
-  HIP_TRY(launch_band16_cont(kFrontK, a, st));
-  HIP_TRY(launch_front_certify(d_fd, (uint32_t)nf, d_row, prm->go, prm->ge, kFrontHalfW, d_fs, d_fe, d_fo, st));
+  HIP_TRY(launch_front_place(d_fd, (uint32_t)nf, d_row, prm->go + prm->ge, halfw, d_pairs, d_fo, st));
+  HIP_TRY(launch_band16_cont(KB, a, st));
+  HIP_TRY(launch_front_certify(d_fd, (uint32_t)nf, d_row, prm->go, prm->ge, halfw, d_fs, d_fe, d_fo, st));
   if ((trc = timing_end(ctx))) return trc;
   std::vector<uint32_t> h_fe(2 * nf);
   int32_t herr[kErrWords] = {};
@@ -1000,6 +1010,24 @@ int run_front(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, const int16_t
   timing_collect(ctx);
   if (herr[0] & 1) return set_error(TRACYHIP_ERR_RANGE, "a query-profile score does not fit the int16 table (profile values too large)");
   for (size_t i = 0; i < nf; ++i) out.ce[i] = h_fe[2 * i + 1] ? h_fe[2 * i + 1] + out.fo[i].shift : 0u;
+  return TRACYHIP_OK;
+}
+
+// Two tiers: strips of 8 rows on the diagonals c* +- 60 first (a pair that lost less than ~250 against its row maxima certifies
+// there, and a step of 8 cells costs two thirds of a step of 12), then -- for what did not certify -- the widest band one period
+// holds (kFrontK = 12, kFrontHalfW = 90).  What fails both is the caller's to sweep in full.
+int run_front(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, const int16_t* d_qp, const uint32_t* d_row, const tracyhip_params* prm,
+              FrontResult& out, const uint8_t* d_codes, bool keep_err) {
+  int rc;
+  if ((rc = run_front_once(ctx, fd, d_qp, d_row, prm, out, d_codes, keep_err, 8, 60))) return rc;
+  std::vector<FrontDesc> again;
+  std::vector<uint32_t> idx;
+  for (size_t i = 0; i < fd.size(); ++i)
+    if (!(out.fo[i].ok && out.ce[i])) { FrontDesc f = fd[i]; f.out = (uint32_t)again.size(); again.push_back(f); idx.push_back((uint32_t)i); }
+  if (again.empty()) return TRACYHIP_OK;
+  FrontResult wide;
+  if ((rc = run_front_once(ctx, again, d_qp, d_row, prm, wide, d_codes, false, kFrontK, kFrontHalfW))) return rc;
+  for (size_t q = 0; q < idx.size(); ++q) { out.fo[idx[q]] = wide.fo[q]; out.score[idx[q]] = wide.score[q]; out.ce[idx[q]] = wide.ce[q]; }
   return TRACYHIP_OK;
 }
 

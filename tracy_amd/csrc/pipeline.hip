@@ -1997,30 +1997,46 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
         if (b16 && getenv("TRACYHIP_NO_FRONT") == nullptr) {
           const uint32_t R = kFrontRows;
           const int64_t bestq = std::max<int64_t>(std::max<int64_t>(p.match, p.mismatch), 0);
-          std::vector<PairDesc> pre;
-          std::vector<FrontDesc> fd;
-          std::vector<uint32_t> ft;
-          pre.reserve(nt); fd.reserve(nt); ft.reserve(nt);
-          for (uint32_t t = 0; t < nt; ++t) {
-            const PairDesc& d = pb.desc[t];
-            if (!(d.m > R + 2u * (uint32_t)kFrontK && d.n >= 1 && origin16_ok(&p, d.m, d.m - R + 2u * (uint32_t)kFrontHalfW + 16u))) continue;
-            PairDesc q = d;
-            q.flags |= PAIR_KEEP_ROW;
-            pre.push_back(q);
-            FrontDesc f{};
-            f.row_off = d.lastrow_off;
-            f.a2_off = d.a2_off;
-            f.tab_off = td[t].out_off + R;
-            f.tab_stride = td[t].stride;
-            f.m_rest = d.m - R;
-            f.n = d.n;
-            f.flags = d.flags & PAIR_A2_REVCOMP;
-            f.out = (uint32_t)fd.size();
-            f.R = R;
-            f.rest = (int32_t)(bestq * (int64_t)(d.m - R));
-            fd.push_back(f);
-            ft.push_back(t);
-          }
+          // (laid out by a few threads in trace order: eligibility per trace, a scan, the fill)
+          std::vector<uint8_t> elig6(nt, 0);
+          uint32_t cnt6[kHostThreads] = {};
+          parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+            uint32_t c = 0;
+            for (uint32_t t = lo; t < hi; ++t) {
+              const PairDesc& d = pb.desc[t];
+              elig6[t] = d.m > R + 2u * (uint32_t)kFrontK && d.n >= 1 && origin16_ok(&p, d.m, d.m - R + 2u * (uint32_t)kFrontHalfW + 16u);
+              c += elig6[t];
+            }
+            cnt6[tid] = c;
+          });
+          uint32_t at6[kHostThreads + 1] = {};
+          for (uint32_t i = 0; i < kHostThreads; ++i) at6[i + 1] = at6[i] + cnt6[i];
+          std::vector<PairDesc> pre(at6[kHostThreads]);
+          std::vector<FrontDesc> fd(at6[kHostThreads]);
+          std::vector<uint32_t> ft(at6[kHostThreads]);
+          parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+            uint32_t w = at6[tid];
+            for (uint32_t t = lo; t < hi; ++t) {
+              if (!elig6[t]) continue;
+              const PairDesc& d = pb.desc[t];
+              PairDesc q = d;
+              q.flags |= PAIR_KEEP_ROW;
+              pre[w] = q;
+              FrontDesc f{};
+              f.row_off = d.lastrow_off;
+              f.a2_off = d.a2_off;
+              f.tab_off = td[t].out_off + R;
+              f.tab_stride = td[t].stride;
+              f.m_rest = d.m - R;
+              f.n = d.n;
+              f.flags = d.flags & PAIR_A2_REVCOMP;
+              f.out = w;
+              f.R = R;
+              f.rest = (int32_t)(bestq * (int64_t)(d.m - R));
+              fd[w] = f;
+              ft[w++] = t;
+            }
+          });
           if (!fd.empty()) {
             if ((rc = run_prefix_keep_cq(ctx, pb.d_a1, pb.d_a2, pb.d_special, pre, &p, static_cast<int32_t*>(ctx->d_lastrow.p)))) return rc;
             FrontResult fres;

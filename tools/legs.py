@@ -234,8 +234,11 @@ class DecomposeLeg:
             return None
         tot_ms = sum(timers[k]["ms"] for k, _ in TIMERS)
         dom = max((k for k, _ in TIMERS), key=lambda k: timers[k]["ms"])
-        names = {"score": ("gotoh_ckpt_kernel<K,QP|CQ,narrow> (16-bit sweeps: the two orientation scores of the trace, and the score + row-m end of "
-                           "each allele vs its window, which certify the sub-window of the origin-tracking sweep)", 8.0, "gotoh_ckpt_kernel"),
+        names = {"score": ("gotoh_ckpt_prefix_kernel<K,16,compact,8> + gotoh_prefix_kernel<8,16,compact,strings> (16-bit sweeps: the strand the k-mer vote "
+                           "does not pick in full, row m kept; the 128-row prefixes of the voted strand and of both alleles over the whole window, row 128 "
+                           "kept for the band below it; cells credited: the rows swept)", 8.0, "gotoh_ckpt_prefix_kernel"),
+                 "front": ("front_place + band16_cont_kernel<K> + front_certify (pruned sweeps: the rows below the prefix on the diagonals around its best "
+                           "column, certified per pair)", 11.0, "band16_cont_kernel"),
                  "origin": ("band16_kernel<K,1> (gotoh(allele, window) whose alignment only trimReferenceSlice reads: origin-tracking sweep on the band its score allows)", 11.0, "band16_kernel"),
                  "trace": ("band16_kernel<K,0> (tracebacks on diagonal bands, four pairs per wave: trimmed trace vs window, allele vs trimmed slice, allele 1 vs allele 2; cells / bytes: the bands')", 14.0, "band16_kernel"),
                  "band": ("gotoh_band_kernel<K,QP> (band traceback of the trimmed trace)", 14.0, "gotoh_band_kernel"),
@@ -248,7 +251,7 @@ class DecomposeLeg:
         roof["ms_per_step"] = {k: round(timers[k]["ms"] / steps, 3) for k, _ in TIMERS if timers[k]["ms"] > 0}
         roof["other_kernels"] = {k: {kk: vv for kk, vv in kernel_block(k, names[k][0], timers[k], steps, ops_per_cell=names[k][1], traffic_key=names[k][2]).items()
                                      if kk in ("kernel", "achieved", "frac", "traffic", "avg_launch_ms", "kernel_gcups", "valu", "algorithmic_bytes_per_launch")}
-                                 for k in ("score", "origin", "trace") if k != dom and timers[k]["ms"] > 0}
+                                 for k in ("score", "front", "origin", "trace") if k in timers and k != dom and timers[k]["ms"] > 0}
         line = {"metric": "traces/s (tracy decompose hot section, indigo.h:190-388)", "value": round(nt_all * steps / dt, 1), "unit": "traces/s",
                 "gcups": round(cells_all * steps / dt / 1e9, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "warmup": warmup,
                 "n_gpus": self.world, "scaling": "strong", "dtype": "int16 (orientation sweeps) / int32 (tracebacks, origin sweeps) / f64 (allelicFraction)",

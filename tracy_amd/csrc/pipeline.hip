@@ -548,28 +548,30 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   StageClock sco;
   if (use_front) {
     sco.mark("o.a votes+rowmax descs/launch/readback");
-    std::vector<VoteDesc> hv(nt);
-    std::vector<RowMaxDesc> hrm(nt);
     const uint32_t R = kFrontRows;  // every prefix of this branch has the 16 x 8 shape
-    for (uint32_t t = 0; t < nt; ++t) {
-      hv[t] = VoteDesc{in.a1_off[t], in.a2_off[t], mf[t], mt[t], rn[t], 0u};
-      hrm[t] = RowMaxDesc{in.a1_off[t], mf[t], mt[t], R};
-    }
     const size_t need = (sizeof(VoteDesc) + sizeof(RowMaxDesc) + 3 * sizeof(uint32_t)) * (size_t)nt;
     HIP_TRY(ctx->d_tmp[7].ensure(need));
     VoteDesc* d_vd = static_cast<VoteDesc*>(ctx->d_tmp[7].p);
     RowMaxDesc* d_rm = reinterpret_cast<RowMaxDesc*>(d_vd + nt);
     int32_t* d_ub = reinterpret_cast<int32_t*>(d_rm + nt);
     uint32_t* d_votes = reinterpret_cast<uint32_t*>(d_ub + nt);
-    HIP_TRY(hipMemcpyAsync(d_vd, hv.data(), sizeof(VoteDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_rm, hrm.data(), sizeof(RowMaxDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
+    // both descriptor lists in one pinned block (laid out like the device block: one copy), the bounds and the votes back in one
+    HIP_TRY(ctx->h_res.ensure(need));
+    VoteDesc* hv = static_cast<VoteDesc*>(ctx->h_res.p);
+    RowMaxDesc* hrm = reinterpret_cast<RowMaxDesc*>(hv + nt);
+    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t) {
+      for (uint32_t t = lo; t < hi; ++t) {
+        hv[t] = VoteDesc{in.a1_off[t], in.a2_off[t], mf[t], mt[t], rn[t], 0u};
+        hrm[t] = RowMaxDesc{in.a1_off[t], mf[t], mt[t], R};
+      }
+    });
+    HIP_TRY(hipMemcpyAsync(d_vd, hv, (sizeof(VoteDesc) + sizeof(RowMaxDesc)) * (size_t)nt, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(kmer_vote_kernel, dim3(nt), dim3(64), 0, st, d_vd, static_cast<const float*>(d_prof), ctx->codes(), d_votes);
     hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, st, d_rm, static_cast<const float*>(d_prof), (float)p.match, (float)p.mismatch, d_ub);
     HIP_TRY(hipGetLastError());
-    std::vector<int32_t> h_ub(nt);
-    std::vector<uint32_t> h_votes(2 * (size_t)nt);
-    HIP_TRY(hipMemcpyAsync(h_ub.data(), d_ub, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(h_votes.data(), d_votes, sizeof(uint32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
+    const int32_t* h_ub = reinterpret_cast<const int32_t*>(hrm + nt);  // (the tail of the pinned block: [bounds nt][votes 2 nt])
+    const uint32_t* h_votes = reinterpret_cast<const uint32_t*>(h_ub + nt);
+    HIP_TRY(hipMemcpyAsync(const_cast<int32_t*>(h_ub), d_ub, sizeof(uint32_t) * 3 * (size_t)nt, hipMemcpyDeviceToHost, st));
     if (d_verr && !verr_fetched) HIP_TRY(hipMemcpyAsync(&h_verr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (d_verr) {
@@ -864,22 +866,24 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
     pb.d_a2 = ctx->codes();
     pb.desc.resize(nt);
     pb.k.resize(nt);
-    for (uint32_t t = 0; t < nt; ++t) {
-      PairDesc d{};
-      d.a1_off = in.a1_off[t];
-      d.a1_stride = mf[t];
-      d.m = mt[t];
-      d.a2_off = in.a2_off[t];
-      d.n = rn[t];
-      d.a2_stride = rn[t];
-      d.out = t;
-      d.flags = h_rc[t] ? PAIR_A2_REVCOMP : 0;
-      const size_t o = h_rc[t] ? (size_t)nt + t : t;  // the winning orientation's checkpoints
-      d.ckpt_off = ck_off[o];
-      d.lastrow_off = lr_off[o];
-      pb.desc[t] = d;
-      pb.k[t] = choose_k(d.m, MODE_QP);
-    }
+    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t) {
+      for (uint32_t t = lo; t < hi; ++t) {
+        PairDesc d{};
+        d.a1_off = in.a1_off[t];
+        d.a1_stride = mf[t];
+        d.m = mt[t];
+        d.a2_off = in.a2_off[t];
+        d.n = rn[t];
+        d.a2_stride = rn[t];
+        d.out = t;
+        d.flags = h_rc[t] ? PAIR_A2_REVCOMP : 0;
+        const size_t o = h_rc[t] ? (size_t)nt + t : t;  // the winning orientation's checkpoints
+        d.ckpt_off = ck_off[o];
+        d.lastrow_off = lr_off[o];
+        pb.desc[t] = d;
+        pb.k[t] = choose_k(d.m, MODE_QP);
+      }
+    });
     if (ends_path || tb16_path) {
       // c_e from the winner's row m, the sub-window from S* and c_e; over it the origin-tracking sweep delivers the two ends (ends_path)
       // or the band kernels the traceback (tb16_path)
@@ -890,25 +894,29 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       int32_t* d_top = reinterpret_cast<int32_t*>(d_shift + nt);
       RowEndDesc* d_re = reinterpret_cast<RowEndDesc*>(d_top + nt);
       RowMaxDesc* d_rm = reinterpret_cast<RowMaxDesc*>(d_re + nt);
-      std::vector<RowEndDesc> hre(nt);
-      std::vector<RowMaxDesc> hrm(nt);
+      // both descriptor lists in one pinned block laid out like the device block (one copy); c_e and top come back into its tail
+      HIP_TRY(ctx->h_res.ensure((sizeof(RowEndDesc) + sizeof(RowMaxDesc) + 2 * sizeof(uint32_t)) * (size_t)nt));
+      RowEndDesc* hre = static_cast<RowEndDesc*>(ctx->h_res.p);
+      RowMaxDesc* hrm = reinterpret_cast<RowMaxDesc*>(hre + nt);
       auto from_front = [&](uint32_t t) { return front_strand[t] >= 0 && (front_strand[t] != 0) == (h_rc[t] != 0); };  // (else the winner was swept in full)
-      for (uint32_t t = 0; t < nt; ++t) {
-        hre[t] = RowEndDesc{pb.desc[t].lastrow_off, from_front(t) ? 0u : rn[t], 0};
-        hrm[t] = RowMaxDesc{in.a1_off[t], mf[t], mt[t], 0u};
-      }
-      HIP_TRY(hipMemcpyAsync(d_re, hre.data(), sizeof(RowEndDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(d_rm, hrm.data(), sizeof(RowMaxDesc) * (size_t)nt, hipMemcpyHostToDevice, st));
+      parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t) {
+        for (uint32_t t = lo; t < hi; ++t) {
+          hre[t] = RowEndDesc{pb.desc[t].lastrow_off, from_front(t) ? 0u : rn[t], 0};
+          hrm[t] = RowMaxDesc{in.a1_off[t], mf[t], mt[t], 0u};
+        }
+      });
+      HIP_TRY(hipMemcpyAsync(d_re, hre, (sizeof(RowEndDesc) + sizeof(RowMaxDesc)) * (size_t)nt, hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(row_m_end_kernel, dim3(nt), dim3(64), 0, st, static_cast<const RowEndDesc*>(d_re), static_cast<const int32_t*>(ck.d_lastrow),
                          p.go + p.ge, d_ce);
       // what the diagonal steps of ANY path can add up to at most: every row gives at most max(0, its best table entry)
       hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, st, static_cast<const RowMaxDesc*>(d_rm), static_cast<const float*>(d_prof),
                          (float)p.match, (float)p.mismatch, d_top);
       HIP_TRY(hipGetLastError());
-      std::vector<uint32_t> h_ce(nt), shift(nt, 0);
-      std::vector<int32_t> h_top(nt);
-      HIP_TRY(hipMemcpyAsync(h_ce.data(), d_ce, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(h_top.data(), d_top, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+      std::vector<uint32_t> shift(nt, 0);
+      uint32_t* h_ce = reinterpret_cast<uint32_t*>(hrm + nt);
+      const int32_t* h_top = reinterpret_cast<const int32_t*>(h_ce + nt);
+      HIP_TRY(hipMemcpyAsync(h_ce, d_ce, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(const_cast<int32_t*>(h_top), d_top, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));  // (also: hre, hrm have been read)
       for (uint32_t t = 0; t < nt; ++t)
         if (from_front(t)) h_ce[t] = front_ce[t];

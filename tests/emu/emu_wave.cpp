@@ -500,7 +500,7 @@ int emu_band16(int K, int kind, int strings, uint32_t npairs, const void* a1, co
 // ok, score, c_e (window column)}; rows (may be null) receives the kept rows, pair i at rows + i * rows_cap.
 int emu_front(int Kp, int GLp, int Kb, uint32_t npairs, const float* a1, const uint64_t* a1_off, const uint32_t* m, const uint8_t* a2,
               const uint64_t* a2_off, const uint32_t* n, const uint32_t* flags, int32_t halfw, int32_t match, int32_t mismatch, int32_t go,
-              int32_t ge, int32_t* out, uint32_t* rows, uint64_t rows_cap, int32_t* err_out) {
+              int32_t ge, int32_t* out, uint32_t* rows, uint64_t rows_cap, int32_t* err_out, int32_t second_bound) {
   if (npairs == 0 || npairs > 4) return -1;
   if (GLp != 8 && GLp != 16) return -1;
   const uint32_t R = (uint32_t)GLp * (uint32_t)Kp;
@@ -542,21 +542,22 @@ int emu_front(int Kp, int GLp, int Kb, uint32_t npairs, const float* a1, const u
     const uint32_t stride = b16_table_stride(m[i]);
     const uint64_t off = qp.size();
     qp.resize(qp.size() + (size_t)kB16Codes * stride, 0);
-    int32_t rest = 0;
+    int32_t rest = 0, rest1 = 0;
     for (uint32_t r = 0; r < m[i]; ++r) {
       int32_t q[kB16Codes];
       b16_table_row(a1, false, a1_off[i], m[i], r, match, mismatch, q);
-      int32_t best = 0;
+      int32_t best = INT32_MIN;
       for (uint32_t b = 0; b < kB16Codes; ++b) {
         qp[off + (size_t)b * stride + r] = (int16_t)((uint32_t)q[b] << kTagShift);
         if (b < 5 && q[b] > best) best = q[b];
       }
-      if (r >= R) rest += best;
+      if (r >= R) { rest += best > 0 ? best : 0; rest1 += best > -1 ? best : -1; }
     }
     FrontDesc& f = fd[i];
     f = FrontDesc{};
     f.row_off = d[i].lastrow_off; f.a2_off = a2_off[i]; f.tab_off = off + R; f.tab_stride = stride; f.m_rest = m[i] - R; f.n = n[i];
     f.flags = flags[i] & PAIR_A2_REVCOMP; f.out = i; f.R = R; f.rest = rest;
+    f.tight = (ge <= -2 && second_bound) ? (uint32_t)(rest - rest1) + 1u : 0u;  // (as pipeline.hip fills it)
   }
   const uint32_t* rowp = reinterpret_cast<const uint32_t*>(lastrow.data());
   std::vector<PairDesc> bp(npairs);

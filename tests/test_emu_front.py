@@ -126,3 +126,57 @@ def test_front_rows_scores_and_certificates():
                 assert (r["score"], r["c_e"]) == (best, ce), (it, kind, r, best, ce)
     assert certified["match"] > 0.7 * total["match"] and total["match"] > 15, (certified, total)
     assert certified["noise"] == 0, (certified, total)
+
+
+def het_profile(seq, alt, rng):
+    """a trace whose positions from a breakpoint on show two equal peaks (the bases of two alleles): such a row scores
+    int(0.5 match + 0.5 mismatch) = -1 against either base with 3 / -5, below the 0 the first certificate allows it"""
+    m = len(seq)
+    p = np.zeros((6, m), np.float32)
+    for i in range(m):
+        a, b = CODE[seq[i]], CODE[alt[i]]
+        if a == b:
+            p[a, i] = 1.0
+        else:
+            p[a, i] = 0.5
+            p[b, i] = 0.5
+    return p
+
+
+def test_second_certificate_serves_heterozygous_rows():
+    """front_certify_body's second bound (rows allowed max(row maximum, -1), vertical steps losing |ge| - 1 against it): traces whose rows
+    below the prefix are heterozygous certify with it and not without it -- and whatever certifies is the matrix's score and c_e"""
+    rng = random.Random(23)
+    with_second = without = checked = 0
+    for it in range(10):
+        Kp, Kb, GLp = 4, 4, 16  # (the narrowest strips: their widest band pays for 140 lost points, less than the slack of ~200 heterozygous rows)
+        R = GLp * Kp
+        halfw = (15 * (Kb + 1) - Kb) // 2 - 1
+        cases = []
+        for _ in range(rng.randint(2, 4)):
+            m = rng.randint(R + 230, R + 320)
+            seq = bytes(rng.choice(b"ACGT") for _ in range(m))
+            bp = rng.randint(R // 2, R + 30)            # the second allele is the first one shifted by an indel from here on
+            shift = rng.randint(1, 9)
+            alt = seq[:bp] + seq[bp + shift:] + bytes(rng.choice(b"ACGT") for _ in range(shift))
+            prof = het_profile(seq, alt, rng)
+            flank = lambda k: bytes(rng.choice(b"ACGT") for _ in range(k))  # noqa: E731
+            ref = flank(rng.randint(0, 250)) + mutate(seq, rng.choice([0.0, 0.02]), rng) + flank(rng.randint(0, 250))
+            rc = rng.random() < 0.4
+            cases.append((prof, ref.translate(COMP)[::-1] if rc else ref, rc, ref))
+        for second in (True, False):
+            res, err = emu.run_front([c[0] for c in cases], [c[1] for c in cases], SC, Kp, Kb, halfw, revcomp=[c[2] for c in cases], GLp=GLp,
+                                     second_bound=second)
+            assert err == 0
+            for (prof, given, rc, ref), r in zip(cases, res):
+                if not r["ok"]:
+                    continue
+                q = emu.table_rows(prof, SC)
+                _, best, ce = matrix(q, [CODE.get(ch, 5) for ch in ref], R, SC)
+                assert (r["score"], r["c_e"]) == (best, ce), (it, second, r, best, ce)
+                checked += 1
+                if second:
+                    with_second += 1
+                else:
+                    without += 1
+    assert with_second >= without + 10 and checked > 20, (with_second, without, checked)

@@ -124,3 +124,44 @@ def test_pruned_sweep_equals_the_reference_where_it_certifies_and_where_it_canno
     for k in FIELDS + ("score_fwd", "score_rev"):
         assert plain[k].tolist() == exact[k].tolist(), k
     assert plain["btr"] == exact["btr"]
+
+
+def test_heterozygous_traces_certify_by_the_second_bound(ctx, monkeypatch, capfd):
+    """A trace downstream of a heterozygous indel shows two equal peaks per position: such a row scores -1 against either base
+    while the first certificate allows it 0, which over ~700 rows is more than any band pays for.  front_certify_body's second
+    bound (rows allowed max(row maximum, -1)) certifies them; results are the oracle's."""
+    import sage_oracle as so
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(41)
+    idx = {65: 0, 67: 1, 71: 2, 84: 3}
+    profs, wins = [], []
+    for it in range(24):
+        mf = int(rng.integers(850, 1010))
+        seq = rand_seq(rng, mf)
+        bp = int(rng.integers(150, 400))
+        shift = int(rng.integers(1, 12))
+        alt = seq[:bp] + seq[bp + shift:] + rand_seq(rng, shift)
+        p = np.zeros((6, mf), np.float32)
+        for j in range(mf):
+            a, b = idx[seq[j]], idx[alt[j]]
+            if a == b:
+                p[a, j] = 1.0
+            else:
+                p[a, j] = p[b, j] = 0.5
+        win = rand_seq(rng, int(rng.integers(0, 1500))) + noisy(rng, seq, 0.01) + rand_seq(rng, int(rng.integers(0, 1500)))
+        if it % 2:
+            win = win.translate(COMP)[::-1]
+        profs.append(p); wins.append(win)
+    with ThreadPoolExecutor(16) as pool:
+        want = list(pool.map(lambda i: so.align_trace(profs[i], wins[i], SC, 50, 50), range(len(profs))))
+    monkeypatch.setenv("TRACYHIP_HOST_TIMERS", "1")
+    capfd.readouterr()
+    got = ctx.align_traces(profs, wins, SC, 50, 50)
+    said = capfd.readouterr().err
+    monkeypatch.delenv("TRACYHIP_HOST_TIMERS")
+    m = re.search(r"pruned orientation sweep: (\d+) of (\d+) traces, (\d+) not certified", said)
+    assert m and int(m.group(1)) >= 20 and int(m.group(3)) <= 4, said[-400:]
+    for i, w in enumerate(want):
+        for k in FIELDS + ("score_fwd", "score_rev"):
+            assert int(got[k][i]) == int(w[k]), (i, k)
+        assert got["btr"][i] == w["btr"], i

@@ -7,7 +7,7 @@
 # Counters: separate --pmc passes with --kernel-trace only (WRITE_SIZE, FETCH_SIZE; SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES).
 # Outputs under gpurun_out/prof_round/; tools/profile_summarise.py turns them into the files kept in profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=/root/repo/gpurun_out/prof_round
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -27,4 +27,11 @@ for w in bench dec ap; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_default_stats" -- python $B --workload align --steps 3 --warmup 1 > "$OUT/bench_default_line.json" 2> "$OUT/bench_default.err"
 python $B > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
+# where the GPU waits for the host: kernel + memory-copy timelines of one step of each pipeline (tools/timeline_gaps.py)
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d "$OUT/tl_dec" -- python $B $DE --cpu-sample 0 > /dev/null 2> "$OUT/tl_dec.err"
+python /root/repo/tools/timeline_gaps.py "$OUT/tl_dec" > "$OUT/decompose_timeline_gaps.txt" 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d "$OUT/tl_al" -- python $B $AL --cpu-sample 0 > /dev/null 2> "$OUT/tl_al.err"
+python /root/repo/tools/timeline_gaps.py "$OUT/tl_al" encode_codes_kernel > "$OUT/align_timeline_gaps.txt" 2>&1
+rm -rf "$OUT/tl_dec" "$OUT/tl_al"
+find "$OUT" -name "*.csv" -size +40M -delete
 ls "$OUT" | head -60

@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
 def one(pattern):
@@ -98,4 +98,7 @@ for w, suffix in (("bench", ""), ("dec", "_decompose"), ("ap", "_allpairs")):
     valu = per_kernel("pmc_%s_valu" % w, 1.0)
     if valu:
         json.dump(valu, open(os.path.join(DST, "%s_pmc_valu%s.json" % (tag, suffix)), "w"), indent=1)
+for nm in ("decompose_timeline_gaps.txt", "align_timeline_gaps.txt"):
+    if os.path.exists(os.path.join(SRC, nm)):
+        shutil.copy(os.path.join(SRC, nm), os.path.join(DST, "%s_%s" % (tag, nm)))
 print("profiles written for", tag, ":", sorted(f for f in os.listdir(DST) if f.startswith(tag)))

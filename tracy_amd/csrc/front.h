@@ -15,6 +15,8 @@
 //      takes the full sweep.  Nothing is ever decided on an uncertified score.
 // A trace that matches its window somewhere (loss below |ge| w) certifies; a repeat of the target far away, or a trace of noise,
 // does not.
+// (A second certificate with a per-row allowance of max(row maximum, -1) instead of max(row maximum, 0) serves profiles whose rows
+// cannot all reach 0: front_certify_body.)
 #ifndef TRACY_AMD_FRONT_H
 #define TRACY_AMD_FRONT_H
 
@@ -33,7 +35,8 @@ struct FrontDesc {
   uint32_t out;         // index of the pair's outputs
   uint32_t R;           // rows of the prefix
   int32_t rest;         // sum over the rows > R of max(0, best substitution score of the row)
-  uint32_t pad;
+  uint32_t tight;       // 0: none.  Else rest - rest1 + 1, rest1 = sum over the rows > R of max(-1, best substitution score of the row):
+                        // the allowance of the second certificate (front_certify_body), for profiles whose rows cannot all reach 0
 };
 struct FrontOut {
   int32_t vmax;     // max_c v(c)
@@ -99,15 +102,31 @@ TR_HD void front_certify_body(W& w, const FrontDesc& f, const uint32_t* row, int
   const int32_t goe = go + ge;
   const int64_t age = -(int64_t)ge;
   const int64_t dlo = (int64_t)fo->cstar - halfw, dhi = (int64_t)fo->cstar + halfw;
-  bool bad = false;
+  // Second certificate (FrontDesc::tight): a row consumed by a diagonal step gives at most its best substitution score, a row
+  // consumed by a vertical gap step at most ge -- so every row gives at most x_r = max(row maximum, -1) as long as ge <= -2, a
+  // vertical step then loses at least q = |ge| - 1 against that allowance and a horizontal one |ge|.  A path that leaves the band
+  // below its column makes more than (c - dlo) vertical steps, one that leaves above it more than (dhi - c) horizontal ones:
+  // it scores at most v(c) + rest1 - min(|ge| (dhi - c + 1), q (c - dlo + 1)).  Tighter than the first bound wherever rows cannot
+  // reach 0 (a heterozygous position with two equal peaks scores -1 against either base); either certificate suffices.
+  const bool two = f.tight != 0u && age >= 2;
+  const int64_t rest1 = (int64_t)f.rest - ((int64_t)f.tight - 1);
+  const int64_t q = age - 1;
+  bool bad = false, bad1 = false;
   for (uint32_t c = L; c <= f.n; c += 64u) {
     const int64_t v = c == 0 ? (int64_t)edge_value(false, go, ge, (int32_t)f.R) : (int64_t)front_v(r[c], goe);
     const int64_t cc = (int64_t)c;
-    const int64_t margin = (cc >= dlo && cc <= dhi) ? (cc - dlo < dhi - cc ? cc - dlo : dhi - cc) : -1;
+    const bool inside = cc >= dlo && cc <= dhi;
+    const int64_t margin = inside ? (cc - dlo < dhi - cc ? cc - dlo : dhi - cc) : -1;
     bad = bad || (v + (int64_t)f.rest - age * (margin + 1) >= (int64_t)score);
+    if (two) {
+      const int64_t ph = age * (dhi - cc + 1), pv = q * (cc - dlo + 1);
+      const int64_t pen = inside ? (ph < pv ? ph : pv) : 0;
+      bad1 = bad1 || (v + rest1 - pen >= (int64_t)score);
+    }
   }
   const bool any = w.ballot(bad) != 0;
-  if (L == 0) fo->ok = (!any && c_end != 0) ? 1u : 0u;
+  const bool any1 = !two || w.ballot(bad1) != 0;
+  if (L == 0) fo->ok = ((!any || !any1) && c_end != 0) ? 1u : 0u;
 }
 
 }  // namespace tracyhip

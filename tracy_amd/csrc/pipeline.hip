@@ -194,21 +194,27 @@ __global__ __launch_bounds__(64) void trim_rows_kernel(const TrimRowsDesc* __res
 // upper bound for what rows [first, m) of a trimmed profile view can still add to a semiglobal score: every row
 // adds at most max(0, its best one-hot substitution score) (gaps cost <= 0 when go <= 0 and ge < 0)
 struct RowMaxDesc { uint64_t off; uint32_t stride, m, first; };
-__global__ __launch_bounds__(64) void rowmax_rest_kernel(const RowMaxDesc* desc, const float* prof, float fmatch, float fmis, int32_t* out) {
+// out1 (or null): the same sum with the rows clamped at -1 instead of 0 (the allowance of front.h's second certificate)
+__global__ __launch_bounds__(64) void rowmax_rest_kernel(const RowMaxDesc* desc, const float* prof, float fmatch, float fmis, int32_t* out,
+                                                         int32_t* out1 = nullptr) {
   const RowMaxDesc d = desc[blockIdx.x];
-  int32_t sum = 0;
+  int32_t sum = 0, sum1 = 0;
   for (uint32_t r = d.first + threadIdx.x; r < d.m; r += 64) {
     float pr[5];
     for (int k = 0; k < 5; ++k) pr[k] = prof[d.off + (uint64_t)k * d.stride + r];
-    int32_t best = 0;
+    int32_t best = INT32_MIN;
     for (uint32_t b = 0; b < 5; ++b) {
       const int32_t q = onehot_score(pr, b, fmatch, fmis);
       best = q > best ? q : best;
     }
-    sum += best;
+    sum += best > 0 ? best : 0;
+    sum1 += best > -1 ? best : -1;
   }
-  for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
-  if (threadIdx.x == 0) out[blockIdx.x] = sum;
+  for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o, 64); sum1 += __shfl_down(sum1, o, 64); }
+  if (threadIdx.x == 0) {
+    out[blockIdx.x] = sum;
+    if (out1) out1[blockIdx.x] = sum1;
+  }
 }
 
 // MODE_CQ (strings scored through the query-profile table): case-sensitive column codes, and the test that row strings hold
@@ -549,12 +555,13 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   if (use_front) {
     sco.mark("o.a votes+rowmax descs/launch/readback");
     const uint32_t R = kFrontRows;  // every prefix of this branch has the 16 x 8 shape
-    const size_t need = (sizeof(VoteDesc) + sizeof(RowMaxDesc) + 3 * sizeof(uint32_t)) * (size_t)nt;
+    const size_t need = (sizeof(VoteDesc) + sizeof(RowMaxDesc) + 4 * sizeof(uint32_t)) * (size_t)nt;
     HIP_TRY(ctx->d_tmp[7].ensure(need));
     VoteDesc* d_vd = static_cast<VoteDesc*>(ctx->d_tmp[7].p);
     RowMaxDesc* d_rm = reinterpret_cast<RowMaxDesc*>(d_vd + nt);
     int32_t* d_ub = reinterpret_cast<int32_t*>(d_rm + nt);
     uint32_t* d_votes = reinterpret_cast<uint32_t*>(d_ub + nt);
+    int32_t* d_ub1 = reinterpret_cast<int32_t*>(d_votes + 2 * (size_t)nt);  // rows clamped at -1 (front.h, second certificate)
     // both descriptor lists in one pinned block (laid out like the device block: one copy), the bounds and the votes back in one
     HIP_TRY(ctx->h_res.ensure(need));
     VoteDesc* hv = static_cast<VoteDesc*>(ctx->h_res.p);
@@ -567,11 +574,12 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
     });
     HIP_TRY(hipMemcpyAsync(d_vd, hv, (sizeof(VoteDesc) + sizeof(RowMaxDesc)) * (size_t)nt, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(kmer_vote_kernel, dim3(nt), dim3(64), 0, st, d_vd, static_cast<const float*>(d_prof), ctx->codes(), d_votes);
-    hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, st, d_rm, static_cast<const float*>(d_prof), (float)p.match, (float)p.mismatch, d_ub);
+    hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, st, d_rm, static_cast<const float*>(d_prof), (float)p.match, (float)p.mismatch, d_ub, d_ub1);
     HIP_TRY(hipGetLastError());
-    const int32_t* h_ub = reinterpret_cast<const int32_t*>(hrm + nt);  // (the tail of the pinned block: [bounds nt][votes 2 nt])
+    const int32_t* h_ub = reinterpret_cast<const int32_t*>(hrm + nt);  // (the tail of the pinned block: [bounds nt][votes 2 nt][bounds, rows clamped at -1, nt])
     const uint32_t* h_votes = reinterpret_cast<const uint32_t*>(h_ub + nt);
-    HIP_TRY(hipMemcpyAsync(const_cast<int32_t*>(h_ub), d_ub, sizeof(uint32_t) * 3 * (size_t)nt, hipMemcpyDeviceToHost, st));
+    const int32_t* h_ub1 = reinterpret_cast<const int32_t*>(h_votes + 2 * (size_t)nt);
+    HIP_TRY(hipMemcpyAsync(const_cast<int32_t*>(h_ub), d_ub, sizeof(uint32_t) * 4 * (size_t)nt, hipMemcpyDeviceToHost, st));
     if (d_verr && !verr_fetched) HIP_TRY(hipMemcpyAsync(&h_verr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (d_verr) {
@@ -638,6 +646,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
           f.out = w.fr;
           f.R = R;
           f.rest = h_ub[t];
+          f.tight = (p.ge <= -2 && h_ub1[t] <= h_ub[t]) ? (uint32_t)(h_ub[t] - h_ub1[t]) + 1u : 0u;
           fd[w.fr] = f;
           ft[w.fr++] = t;
         } else if (cls[t] == 1) {

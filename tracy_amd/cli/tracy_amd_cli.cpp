@@ -22,6 +22,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <sys/stat.h>
@@ -388,13 +389,14 @@ bool alignment_rows(tracyhip_ctx* ctx, tracyhip_seqset const& s1, tracyhip_seqse
   pr.npairs = (uint32_t)jobs.size();
   pr.a1 = s1;
   pr.a2 = s2;
-  std::vector<uint8_t> r0(ops.size() ? ops.size() : 1), r1(ops.size() ? ops.size() : 1);
-  if (tracyhip_alignment_rows(ctx, &pr, TRACYHIP_MEM_HOST, ops.data(), off.data(), len.data(), r0.data(), r1.data()) != TRACYHIP_OK)
+  const std::size_t cap = ops.size() ? ops.size() : 1;
+  std::unique_ptr<uint8_t[]> r0(new uint8_t[cap]), r1(new uint8_t[cap]);  // (written by the call: no zero fill of 100 MB)
+  if (tracyhip_alignment_rows(ctx, &pr, TRACYHIP_MEM_HOST, ops.data(), off.data(), len.data(), r0.get(), r1.get()) != TRACYHIP_OK)
     return gpu_fail("alignment rows");
-  for (std::size_t i = 0; i < jobs.size(); ++i) {
-    jobs[i]->rows.row0.assign(reinterpret_cast<char*>(r0.data()) + off[i], len[i]);
-    jobs[i]->rows.row1.assign(reinterpret_cast<char*>(r1.data()) + off[i], len[i]);
-  }
+  for_each_index((uint32_t)jobs.size(), usable_cores(), [&](uint32_t i) {
+    jobs[i]->rows.row0.assign(reinterpret_cast<char*>(r0.get()) + off[i], len[i]);
+    jobs[i]->rows.row1.assign(reinterpret_cast<char*>(r1.get()) + off[i], len[i]);
+  });
   return true;
 }
 
@@ -402,26 +404,34 @@ bool alignment_rows(tracyhip_ctx* ctx, tracyhip_seqset const& s1, tracyhip_seqse
 bool align_fasta_group(Device& dev, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
   tracyhip_ctx* ctx = dev.ctx;
   const uint32_t nt = (uint32_t)jobs.size();
-  std::vector<float> prof;
-  std::vector<uint8_t> refs;
+  // the batch as two packed payloads: offsets first, then every trace copied to its place by the host threads (a manifest of
+  // 10 000 traces is 240 MB of profiles: grown by insert() it was copied several times over, by one thread)
   std::vector<uint64_t> poff(nt), roff(nt), ooff(nt);
   std::vector<uint32_t> plen(nt), rlen(nt);
-  uint64_t ocap = 0;
+  uint64_t ocap = 0, ptot = 0, rtot = 0;
   for (uint32_t i = 0; i < nt; ++i) {
     Job& j = *jobs[i];
-    poff[i] = prof.size();
+    poff[i] = ptot;
     plen[i] = (uint32_t)j.full.cols;
-    prof.insert(prof.end(), j.full.v.begin(), j.full.v.end());
-    roff[i] = refs.size();
+    ptot += j.full.v.size();
+    roff[i] = rtot;
     rlen[i] = (uint32_t)j.fasta.size();
-    refs.insert(refs.end(), j.fasta.begin(), j.fasta.end());
+    rtot += j.fasta.size();
     ooff[i] = ocap;
     ocap += (uint64_t)plen[i] + rlen[i];
   }
+  std::unique_ptr<float[]> prof(new float[ptot ? ptot : 1]);
+  std::unique_ptr<uint8_t[]> refs(new uint8_t[rtot ? rtot : 1]);
+  const uint32_t nthreads = usable_cores();
+  for_each_index(nt, nthreads, [&](uint32_t i) {
+    Job& j = *jobs[i];
+    if (!j.full.v.empty()) std::memcpy(prof.get() + poff[i], j.full.v.data(), j.full.v.size() * sizeof(float));
+    if (!j.fasta.empty()) std::memcpy(refs.get() + roff[i], j.fasta.data(), j.fasta.size());
+  });
   tracyhip_align_job job{};
   job.ntraces = nt;
-  job.profiles = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, prof.data(), poff.data(), plen.data(), nt};
-  job.refs = tracyhip_seqset{TRACYHIP_SEQ_CHAR, refs.data(), roff.data(), rlen.data(), nt};
+  job.profiles = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, prof.get(), poff.data(), plen.data(), nt};
+  job.refs = tracyhip_seqset{TRACYHIP_SEQ_CHAR, refs.get(), roff.data(), rlen.data(), nt};
   job.trim_left = jobs[0]->trimLeft;
   job.trim_right = jobs[0]->trimRight;
   const bool seeded = jobs[0]->rs.filetype == 0;  // groups never mix seeded and FASTA references
@@ -438,9 +448,11 @@ bool align_fasta_group(Device& dev, tracyhip_params const& prm, std::vector<Job*
   res.score_final = sfin.data(); res.ops = ops.data(); res.ops_offset = ooff.data(); res.ops_len = olen.data();
   if (dev.align_traces(&job, &prm, &res) != TRACYHIP_OK) return gpu_fail("align");
   // the reference slices the final alignment ran against (trimReferenceSlice, fmindex.h:429-463)
-  std::vector<uint8_t> slices;
   std::vector<uint64_t> soff(nt);
-  for (uint32_t i = 0; i < nt; ++i) {
+  uint64_t stot = 0;
+  for (uint32_t i = 0; i < nt; ++i) { soff[i] = stot; stot += sl[i]; }
+  std::unique_ptr<uint8_t[]> slices(new uint8_t[stot ? stot : 1]);
+  for_each_index(nt, nthreads, [&](uint32_t i) {
     Job& j = *jobs[i];
     j.rs.forward = fwd[i] != 0;
     std::string oriented = j.fasta;
@@ -448,10 +460,9 @@ bool align_fasta_group(Device& dev, tracyhip_params const& prm, std::vector<Job*
     j.rs.refslice = oriented.substr(sb[i], sl[i]);
     j.rs.pos = j.slice_start + rp[i];
     j.score = sfin[i];
-    soff[i] = slices.size();
-    slices.insert(slices.end(), j.rs.refslice.begin(), j.rs.refslice.end());
-  }
-  tracyhip_seqset s2{TRACYHIP_SEQ_CHAR, slices.data(), soff.data(), sl.data(), nt};
+    if (!j.rs.refslice.empty()) std::memcpy(slices.get() + soff[i], j.rs.refslice.data(), j.rs.refslice.size());
+  });
+  tracyhip_seqset s2{TRACYHIP_SEQ_CHAR, slices.get(), soff.data(), sl.data(), nt};
   return alignment_rows(ctx, job.profiles, s2, ops, ooff, olen, jobs);
 }
 
@@ -743,42 +754,70 @@ bool decompose_group(Device& dev, SageConfig const& c, tracyhip_params const& pr
   const uint32_t nt = (uint32_t)jobs.size();
   const bool wildtype = jobs[0]->rs.filetype == 2;  // groups never mix reference kinds
   if (wildtype && !orient_wildtype(ctx, prm, jobs)) return false;
-  std::vector<float> prof;
-  std::vector<uint8_t> refs, pri, sec;
-  std::vector<int32_t> sig, pos;
+  // the batch as packed payloads: offsets first, then every trace copied to its place by the host threads (10 000 traces are 1.9 GB
+  // of signal: grown by insert() they were copied several times over, by one thread)
   std::vector<uint64_t> poff(nt), roff(nt), soff(nt), boff(nt), dcpoff(nt);
   std::vector<uint32_t> plen(nt), rlen(nt), ns(nt), blen(nt);
   const uint32_t dcap = 2u * c.maxindel + 2;
   std::vector<uint64_t> ooff[3];
   uint64_t ocap[3] = {0, 0, 0};
   for (int k = 0; k < 3; ++k) ooff[k].resize(nt);
+  uint64_t ptot = 0, rtot = 0, stot = 0, btot = 0;
   for (uint32_t i = 0; i < nt; ++i) {
     Job& j = *jobs[i];
-    poff[i] = prof.size(); plen[i] = (uint32_t)j.full.cols;
-    prof.insert(prof.end(), j.full.v.begin(), j.full.v.end());
-    roff[i] = refs.size(); rlen[i] = (uint32_t)j.fasta.size();
-    refs.insert(refs.end(), j.fasta.begin(), j.fasta.end());
-    soff[i] = sig.size(); ns[i] = (uint32_t)j.tr.traceACGT[0].size();
-    for (int k = 0; k < 4; ++k) {
-      std::vector<int32_t> ch = j.tr.traceACGT[k];
-      ch.resize(ns[i], 0);
-      sig.insert(sig.end(), ch.begin(), ch.end());
-    }
-    boff[i] = pos.size(); blen[i] = (uint32_t)j.bc.bcPos.size();
-    pos.insert(pos.end(), j.bc.bcPos.begin(), j.bc.bcPos.end());
-    pri.insert(pri.end(), j.bc.primary.begin(), j.bc.primary.end());
-    sec.insert(sec.end(), j.bc.secondary.begin(), j.bc.secondary.end());
+    poff[i] = ptot; plen[i] = (uint32_t)j.full.cols; ptot += j.full.v.size();
+    roff[i] = rtot; rlen[i] = (uint32_t)j.fasta.size(); rtot += j.fasta.size();
+    soff[i] = stot; ns[i] = (uint32_t)j.tr.traceACGT[0].size(); stot += 4ull * ns[i];
+    boff[i] = btot; blen[i] = (uint32_t)j.bc.bcPos.size(); btot += blen[i];
     dcpoff[i] = (uint64_t)i * dcap;
     for (int k = 0; k < 3; ++k) {
       ooff[k][i] = ocap[k];
       ocap[k] += (uint64_t)blen[i] + (k < 2 ? rlen[i] : blen[i]);
     }
   }
+  struct Packed {
+    std::unique_ptr<float[]> prof;
+    std::unique_ptr<uint8_t[]> refs, pri, sec;
+    std::unique_ptr<int32_t[]> sig, pos;
+    float* pdata() { return prof.get(); }
+  } pk;
+  pk.prof.reset(new float[ptot ? ptot : 1]);
+  pk.refs.reset(new uint8_t[rtot ? rtot : 1]);
+  pk.pri.reset(new uint8_t[btot ? btot : 1]);
+  pk.sec.reset(new uint8_t[btot ? btot : 1]);
+  pk.sig.reset(new int32_t[stot ? stot : 1]);
+  pk.pos.reset(new int32_t[btot ? btot : 1]);
+  const uint32_t nthreads = usable_cores();
+  for_each_index(nt, nthreads, [&](uint32_t i) {
+    Job& j = *jobs[i];
+    if (!j.full.v.empty()) std::memcpy(pk.prof.get() + poff[i], j.full.v.data(), j.full.v.size() * sizeof(float));
+    if (!j.fasta.empty()) std::memcpy(pk.refs.get() + roff[i], j.fasta.data(), j.fasta.size());
+    for (int k = 0; k < 4; ++k) {  // (a channel shorter than the first one is padded with zeros, as before)
+      int32_t* dst = pk.sig.get() + soff[i] + (uint64_t)k * ns[i];
+      const std::vector<int32_t>& ch = j.tr.traceACGT[k];
+      const std::size_t have = std::min<std::size_t>(ch.size(), ns[i]);
+      if (have) std::memcpy(dst, ch.data(), have * sizeof(int32_t));
+      if (have < ns[i]) std::memset(dst + have, 0, (ns[i] - have) * sizeof(int32_t));
+    }
+    // (the three per-base arrays share bc_offset: shorter ones are an input error the library reports)
+    const std::size_t nb = blen[i];
+    if (nb) {
+      std::memcpy(pk.pos.get() + boff[i], j.bc.bcPos.data(), nb * sizeof(int32_t));
+      std::memcpy(pk.pri.get() + boff[i], j.bc.primary.data(), std::min<std::size_t>(nb, j.bc.primary.size()));
+      std::memcpy(pk.sec.get() + boff[i], j.bc.secondary.data(), std::min<std::size_t>(nb, j.bc.secondary.size()));
+    }
+  });
+  float* const prof_p = pk.prof.get();
+  uint8_t* const refs_p = pk.refs.get();
+  uint8_t* const pri_p = pk.pri.get();
+  uint8_t* const sec_p = pk.sec.get();
+  int32_t* const sig_p = pk.sig.get();
+  int32_t* const pos_p = pk.pos.get();
   tracyhip_decompose_job job{};
   job.ntraces = nt;
-  job.profiles = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, prof.data(), poff.data(), plen.data(), nt};
-  job.bc = tracyhip_basecalls{nt, sig.data(), soff.data(), ns.data(), pos.data(), pri.data(), sec.data(), boff.data(), blen.data()};
-  job.refs = tracyhip_seqset{TRACYHIP_SEQ_CHAR, refs.data(), roff.data(), rlen.data(), nt};
+  job.profiles = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, prof_p, poff.data(), plen.data(), nt};
+  job.bc = tracyhip_basecalls{nt, sig_p, soff.data(), ns.data(), pos_p, pri_p, sec_p, boff.data(), blen.data()};
+  job.refs = tracyhip_seqset{TRACYHIP_SEQ_CHAR, refs_p, roff.data(), rlen.data(), nt};
   job.dprm = tracyhip_decomp_params{(int32_t)jobs[0]->trimLeft, (int32_t)jobs[0]->trimRight, (int32_t)c.maxindel, (int32_t)c.madc};
   job.strand_by_certificate = 1;  // the orientation scores are not written anywhere (indigo.h:235-247 keeps only rs.forward)
   const bool seeded = jobs[0]->rs.filetype == 0 || wildtype;  // the reference arrives oriented
@@ -796,7 +835,7 @@ bool decompose_group(Device& dev, SageConfig const& c, tracyhip_params const& pr
   }
   std::vector<tracyhip_breakpoint> bp(nt);
   std::vector<int32_t> status(nt), sf(nt), sr(nt), strim(nt), dci((size_t)nt * dcap), dce((size_t)nt * dcap);
-  std::vector<uint8_t> fwd(nt), sd(pri.size() ? pri.size() : 1);
+  std::vector<uint8_t> fwd(nt), sd(btot ? btot : 1);
   std::vector<tracyhip_decomp_status> dst(nt);
   std::vector<double> fr(2 * (size_t)nt);
   std::vector<uint32_t> sb[2], sl[2], rp[2], olen[3];
@@ -821,8 +860,8 @@ bool decompose_group(Device& dev, SageConfig const& c, tracyhip_params const& pr
     Job& j = *jobs[i];
     j.status = status[i];
     j.dstatus = dst[i];
-    j.primary.assign(reinterpret_cast<char*>(pri.data()) + boff[i], blen[i]);
-    j.secondary.assign(reinterpret_cast<char*>(sec.data()) + boff[i], blen[i]);
+    j.primary.assign(reinterpret_cast<char*>(pri_p) + boff[i], blen[i]);
+    j.secondary.assign(reinterpret_cast<char*>(sec_p) + boff[i], blen[i]);
     j.secdecomp.assign(reinterpret_cast<char*>(sd.data()) + boff[i], blen[i]);
     j.rs.forward = fwd[i] != 0;
     j.rs.refslice = j.fasta;

@@ -660,6 +660,10 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
     });
     sco.mark("o.c run_ckpt_prefix (plan+launch+wait)");
     DpCkpt ckv = ck;
+    // (row m only, no wavefront checkpoints: the band kernels take the traceback from S*, c_e alone, and the strand swept in full is the
+    // one the vote does NOT pick -- 7 GB of writes per 100 000 traces of `tracy decompose` that nothing read; a pair that needs the
+    // band traceback from checkpoints after all is swept once more, below)
+    ckv.B = 0x7fffffffu;
     if ((rc = run_ckpt_prefix(ctx, d_prof, ctx->codes(), fullv, fullk, prev, &p, d_sc2, &ckv, true))) return rc;
     sco.mark("o.d run_front");
     FrontResult fres;
@@ -1034,10 +1038,9 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
             if (j16.k[t] && (h_sb[t] != h_pre[t] || h_ol[t] == 0)) { rest.desc.push_back(wholes[t]); rest.k.push_back(pb.k[t]); ++nfail; }
           if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "preliminary alignment: %zu of %u on the band, %u repeated\n", nb16, nt, nfail);
         }
-        {  // a strand the pruned sweep certified has no wavefront checkpoints: sweep it in full before its band traceback
+        if (use_front) {  // the orientation stage of the pruned sweep leaves no wavefront checkpoints: sweep the pair's strand before its band traceback
           std::vector<std::pair<uint32_t, int>> resweep;
-          for (auto const& d : rest.desc)
-            if (from_front(d.out)) resweep.emplace_back(d.out, h_rc[d.out] ? 1 : 0);
+          for (auto const& d : rest.desc) resweep.emplace_back(d.out, h_rc[d.out] ? 1 : 0);
           if (!resweep.empty() && (rc = run_stage1(resweep, DP_CKPT))) return rc;
         }
         if ((rc = run_dp(ctx, rest, &p, false, true, nullptr, in.d_ops, in.d_ops_off, in.d_ops_len, DP_BAND, &ck))) return rc;

@@ -209,3 +209,32 @@ def test_breakpoints_and_small_functions(emu, cases):
                         assert want[0] == bytes([r]) and exp_sec == got
                     else:
                         assert want[0] == pri and exp_sec == sec
+
+
+def test_traverse_of_the_whole_alignment_rewrites_every_lane_segment(emu):
+    """"No InDel detected, traverse the whole alignment" (decompose.h:327-343) with basecalls to phase all along the alignment: every
+    lane's segment starts at its own basecall.  (A scoring with cheap mismatches aligns heterozygous traces so that the shift scans
+    find nothing and the traverse has dozens of positions to rewrite; with tracy's default scoring it rarely has any, which hid a
+    segment-offset table that the pick phases had overwritten.)"""
+    from tracy_amd import hostlib
+    sc = (1, -1, -2, -1)
+    d = hostlib.synth_decompose_batch(12345, 8, 2200, 700, 0, mix=1)
+    traversed = 0
+    for i in range(8):
+        sig, pos = d["signal"][i], d["bcpos"][i]
+        pri, sec = d["primary"][i].tobytes(), d["secondary"][i].tobytes()
+        prof = orc.create_profile_trace(sig, pos, pri, sec, 50, 50)
+        ref = d["refs"][i].tobytes()
+        bp = orc.find_breakpoint(prof)
+        fwd = orc.create_profile_str(ref)
+        rev = orc.revcomp_profile(fwd)
+        use = fwd if orc.gotoh_score_prof(prof, fwd, 1, 0, sc) > orc.gotoh_score_prof(prof, rev, 1, 0, sc) else rev
+        _, btr = orc.gotoh_prof(prof, use, 1, 0, sc)
+        r0, r1 = orc.create_alignment_prof(btr, prof, use)
+        c = dict(ref=ref, pri=pri, sec=sec, bp=bp, rows=(r0, r1))
+        want = orc.decompose_alleles(r0, r1, pri, sec, bp, len(ref), 50, 50, 1000, 5)
+        got = run_emu_decompose(emu, c)
+        assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2] and got[3][0] == want[3][0], i
+        if want[3][0] == 2 and sum(a != b for a, b in zip(pri, want[0])) > 20:
+            traversed += 1
+    assert traversed >= 3

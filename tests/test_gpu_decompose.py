@@ -313,3 +313,37 @@ def test_pruned_sweeps_of_decompose_where_they_certify_and_where_they_cannot(ctx
         for k in range(2):
             for nm in ("slice_begin", "slice_len", "ref_pos"):
                 assert int(pruned["%s%d" % (nm, k)][i]) == int(w["%s%d" % (nm, k)]), (i, nm, k)
+
+
+@pytest.mark.parametrize("sc", [(1, -1, -2, -1), (5, -4, -10, -1), (4, -6, -20, -8)])
+def test_decompose_traces_with_other_scorings(ctx, sc):
+    """tracyhip_decompose_traces under scorings other than tracy's default (indigo.h takes any, indigo.h:74-77): cheap mismatches make
+    the shift scans of heterozygous traces come up empty, and "traverse the whole alignment" (decompose.h:327-343) then has dozens of
+    basecalls to rewrite; ge = -1 switches the second certificate of the pruned sweeps off; dear gaps narrow every band."""
+    from indigo_oracle import decompose_trace
+    from tracy_amd import capi, hostlib
+    nd = 24
+    d = hostlib.synth_decompose_batch(777, nd, 2000, 650, 0, mix=1)
+    hbc = capi.HostBaseCalls([d["signal"][i] for i in range(nd)], [d["bcpos"][i] for i in range(nd)],
+                             [d["primary"][i].tobytes() for i in range(nd)], [d["secondary"][i].tobytes() for i in range(nd)])
+    got = ctx.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, [d["refs"][i].tobytes() for i in range(nd)], sc)
+    fr = np.asarray(got["fractions"]).reshape(-1, 2)
+    accepted = 0
+    for i in range(nd):
+        w = decompose_trace(d["signal"][i], d["bcpos"][i], d["primary"][i].tobytes(), d["secondary"][i].tobytes(), d["refs"][i].tobytes(), sc)
+        assert int(got["status"][i]) == w["status"], i
+        if w["status"] != 0:
+            continue
+        accepted += 1
+        for k in ("score_fwd", "score_rev", "forward", "score_trim"):
+            assert int(got[k][i]) == int(w[k]), (i, k)
+        assert got["primary"][i] == w["primary"] and got["secondary"][i] == w["secondary"], i
+        assert got["secdecomp_list"][i] == w["secdecomp"] and got["dcp"][i] == w["dcp"], i
+        assert (float(fr[i, 0]), float(fr[i, 1])) == w["af"], i
+        for k in range(3):
+            assert int(got["score%d" % k][i]) == w["score%d" % k], (i, k)
+            assert got["btr%d" % k][i] == w["btr%d" % k], (i, k)
+        for k in range(2):
+            for nm in ("slice_begin", "slice_len", "ref_pos"):
+                assert int(got["%s%d" % (nm, k)][i]) == int(w["%s%d" % (nm, k)]), (i, nm, k)
+    assert accepted >= nd // 2

@@ -227,8 +227,14 @@ class DecomposeLeg:
             self.ctx.set_lanes(2)
             dt_lanes, _ = timed(lambda: self.step(dist), steps, warmup, dist)
             same = same and all(torch.equal(snap[k], self.res[k]) for k in snap)
+            self.job.strand_by_certificate = 1
+            dt_both, _ = timed(lambda: self.step(dist), steps, warmup, dist)
+            same = same and all(torch.equal(snap[k], self.res[k]) for k in snap)
+            self.job.strand_by_certificate = 0
             self.ctx.set_lanes(1)
-        dt, dt_cert, dt_lanes = max_over_ranks(dist, dev, [dt, dt_cert, dt_lanes])
+        else:
+            dt_both = 0.0
+        dt, dt_cert, dt_lanes, dt_both = max_over_ranks(dist, dev, [dt, dt_cert, dt_lanes, dt_both])
         cells_all, ok_all, nt_all = sum_over_ranks(dist, dev, [float(cells), float(ok_traces), float(self.nt)])
         if self.rank != 0:
             return None
@@ -262,7 +268,8 @@ class DecomposeLeg:
         if extra_legs:
             line["strand_by_certificate"] = {"ms_per_step": round(dt_cert / steps * 1e3, 2), "traces_per_s": round(nt_all * steps / dt_cert, 1),
                                              "results_identical_to_headline_leg": bool(same)}
-            line["lanes"] = {"lanes": 2, "ms_per_step": round(dt_lanes / steps * 1e3, 2), "traces_per_s": round(nt_all * steps / dt_lanes, 1)}
+            line["lanes"] = {"lanes": 2, "ms_per_step": round(dt_lanes / steps * 1e3, 2), "traces_per_s": round(nt_all * steps / dt_lanes, 1),
+                             "strand_by_certificate": {"ms_per_step": round(dt_both / steps * 1e3, 2), "traces_per_s": round(nt_all * steps / dt_both, 1)}}
         if cpu_sample > 0:  # (rank 0; at N > 1 on its share of the host cores)
             line.update(self.cpu_baseline(cpu_sample, snap, snap_ops, snap_pri))
         return line

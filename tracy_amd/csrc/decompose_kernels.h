@@ -146,7 +146,9 @@ struct DecompSharedT : DecompDims<MAXI> {
   int32_t hist[MAXI * 2 + 2];
   uint64_t is_c[kRefClasses][Dims::kWinWords];
   uint64_t bad_c[kRefClasses][Dims::kVarWords];
-  uint32_t seg0[64], seg1[64];  // per-lane segment counts of trace / reference bases (alignment walk)
+  uint32_t seg0[64], seg1[64];  // per-lane segment counts of trace / reference bases (alignment walk); later the scratch of the pick phases
+  uint32_t segt[64];            // the trace-base counts again, kept to the end: the traverse of the whole alignment (decompose.h:327-343) starts
+                                // every lane's segment at its own basecall (seg0 is long overwritten by then)
   uint32_t nfref, nfins;
   uint32_t varIndex, refPointer, alignIndex;
   uint32_t maxdel, maxins, bp;
@@ -200,6 +202,7 @@ TR_HD void decomp_phase_count(const DecompArgs& a, const DecompDesc& d, SH& sh, 
   }
   sh.seg0[lane] = c0;
   sh.seg1[lane] = c1;
+  sh.segt[lane] = c0;
   if (lane == 0) { sh.found = 0; sh.alignIndex = 0; sh.varIndex = 0; sh.exotic = 0; sh.classes = 0; }
 }
 
@@ -555,7 +558,7 @@ TR_HD void decomp_phase_apply(const DecompArgs& a, const DecompDesc& d, const SH
     if (out.kind == 1) { jstart = sh.alignIndex + (uint32_t)out.bestDel + 1; vi0 = sh.varIndex + (uint32_t)out.bestIns; }
     else {  // "No InDel detected, traverse the whole alignment" (:327-343): vi advances only on trace bases
       uint32_t base0 = 0, lo, hi;
-      for (uint32_t l = 0; l < lane; ++l) base0 += sh.seg0[l];
+      for (uint32_t l = 0; l < lane; ++l) base0 += sh.segt[l];
       lane_segment(d.L, lane, lo, hi);
       uint32_t vi = (uint32_t)a.prm.trimLeft + base0;
       for (uint32_t j = lo; j < hi; ++j) {

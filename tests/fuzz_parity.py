@@ -162,11 +162,13 @@ def run_campaign(pairs=1500, traces=96, lanes=1, seed=1, decompose_len=(700, 220
     d = hostlib.synth_decompose_batch(int(rng.integers(0, 1 << 30)), nd, n, mf, 0, mix=decompose_mix)
     hbc = capi.HostBaseCalls([d["signal"][i] for i in range(nd)], [d["bcpos"][i] for i in range(nd)], [d["primary"][i].tobytes() for i in range(nd)],
                              [d["secondary"][i].tobytes() for i in range(nd)])
-    got = ctx.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, [d["refs"][i].tobytes() for i in range(nd)], psc)
+    # trims / maxindel / MAD cut-off: tracy's defaults in one campaign of two, otherwise values that move the clamps of decomposeAlleles
+    dtl, dtr, dmi, dmad = (50, 50, 1000, 5) if args.seed % 2 else [(0, 0, 1000, 5), (13, 77, 300, 9), (30, 30, 40, 0), (50, 50, 7, 5)][(args.seed // 2) % 4]
+    got = ctx.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, [d["refs"][i].tobytes() for i in range(nd)], psc, dtl, dtr, dmi, dmad)
 
     def dwant(i):
         return io.decompose_trace(d["signal"][i], d["bcpos"][i], d["primary"][i].tobytes(), d["secondary"][i].tobytes(), d["refs"][i].tobytes(),
-                                  psc)
+                                  psc, dtl, dtr, dmi, dmad)
     for i, w in enumerate(pool.map(dwant, range(nd))):
         fr = np.asarray(got["fractions"]).reshape(-1, 2)
         if int(got["status"][i]) != w["status"]:
@@ -181,7 +183,7 @@ def run_campaign(pairs=1500, traces=96, lanes=1, seed=1, decompose_len=(700, 220
     done["decompose"] = nd
     ctx.close()
     pool.shutdown()
-    return {"compared": done, "mismatches": len(bad), "first": [str(b) for b in bad[:5]], "seed": seed, "lanes": lanes, "pipeline_scoring": list(psc)}
+    return {"compared": done, "mismatches": len(bad), "first": [str(b) for b in bad[:5]], "seed": seed, "lanes": lanes, "pipeline_scoring": list(psc), "decompose_params": [dtl, dtr, dmi, dmad]}
 
 
 def main():

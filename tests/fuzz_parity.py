@@ -125,9 +125,10 @@ def run_campaign(pairs=1500, traces=96, lanes=1, seed=1, decompose_len=(700, 220
     # ---- 2. `tracy align` batches, ragged ----
     nt = args.traces
     profs, refs = [], []
+    long_traces = args.seed % 5 == 0  # every fifth campaign: traces beyond one pass of the tallest strips (1024 rows) and the 16-bit range checks
     for i in range(nt):
-        mf = int(rng.integers(120, 1100))
-        n = int(rng.integers(mf + 50, 4000))
+        mf = int(rng.integers(1000, 2500)) if long_traces else int(rng.integers(120, 1100))
+        n = int(rng.integers(mf + 50, mf + 3000 if long_traces else 4000))
         r, p, _ = hostlib.synth_align(int(rng.integers(0, 1 << 30)), 1, n, mf, 1)
         if rng.random() < 0.2:  # windows with N columns take the six-code form of the sweeps, the others the compact one
             r = r.copy()
@@ -159,6 +160,8 @@ def run_campaign(pairs=1500, traces=96, lanes=1, seed=1, decompose_len=(700, 220
     # ---- 3. `tracy decompose` batches ----
     nd = max(8, args.traces // 2)
     mf, n = decompose_len
+    if long_traces and decompose_len == (700, 2200):
+        mf, n = 1500, 3600
     d = hostlib.synth_decompose_batch(int(rng.integers(0, 1 << 30)), nd, n, mf, 0, mix=decompose_mix)
     hbc = capi.HostBaseCalls([d["signal"][i] for i in range(nd)], [d["bcpos"][i] for i in range(nd)], [d["primary"][i].tobytes() for i in range(nd)],
                              [d["secondary"][i].tobytes() for i in range(nd)])

@@ -387,7 +387,10 @@ def main():
     band_traffic, band_traffic_src = None, None
     try:
         from tools.legs import pmc_traffic
-        band_traffic, band_traffic_src = pmc_traffic("band16_kernel", "r[0-9][0-9]_pmc_hbm.json")
+        for key in ("band16_multi_kernel<0>", "band16_kernel<12, 0>", "band16_kernel"):  # (a batch of this size runs its strip heights as one launch)
+            band_traffic, band_traffic_src = pmc_traffic(key, "r[0-9][0-9]_pmc_hbm.json")
+            if band_traffic is not None:
+                break
     except Exception:  # noqa: BLE001
         pass
     roofline = {"bound": "hbm", "kernel": "gotoh_ckpt_prefix_kernel<K,16,compact,8> (score-only Gotoh, one launch: the full sweeps of the strand the vote does not pick, row m kept, + the 128-row prefixes of the voted strand over the whole window, row 128 kept; cells credited: the rows swept; dominant: %.0f%% of the step)"

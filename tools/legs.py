@@ -103,12 +103,12 @@ def pmc_traffic(kernel_substr, tag_glob="r[0-9][0-9]_pmc_hbm*.json"):
     return None, None
 
 
-def kernel_block(name, kernel, t, steps, ops_per_cell=None, flops_per_cell=None, traffic_key=None):
+def kernel_block(name, kernel, t, steps, ops_per_cell=None, flops_per_cell=None, traffic_key=None, traffic_glob="r[0-9][0-9]_pmc_hbm*.json"):
     """roofline object of one kernel class from the library's HIP-event timers"""
     ms = t["ms"]
     gbs = t["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     gc = t["cells"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    traffic, src = pmc_traffic(traffic_key) if traffic_key else (None, None)
+    traffic, src = pmc_traffic(traffic_key, traffic_glob) if traffic_key else (None, None)  # (the PMC summary of THIS workload: kernels are shared between the legs)
     out = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
            "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(ms / max(t["launches"], 1), 3), "launches": t["launches"],
            "algorithmic_bytes_per_launch": t["bytes"] // max(t["launches"], 1), "kernel_gcups": round(gc, 1), "timer": name}
@@ -252,10 +252,11 @@ class DecomposeLeg:
                  "decompose": ("decompose_kernel (decomposeAlleles, decompose.h:179-376)", None, "decompose_kernel"),
                  "allelic_fraction": ("allelic_fraction_kernel (decompose.h:412-621)", None, "allelic_fraction_kernel"),
                  "misc": ("breakpoint / homozygous / secdecomp kernels", None, None)}
-        roof = kernel_block(dom, names[dom][0], timers[dom], steps, ops_per_cell=names[dom][1], traffic_key=names[dom][2])
+        dec_glob = "r[0-9][0-9]_pmc_hbm_decompose.json"
+        roof = kernel_block(dom, names[dom][0], timers[dom], steps, ops_per_cell=names[dom][1], traffic_key=names[dom][2], traffic_glob=dec_glob)
         roof["share_of_kernel_time"] = round(timers[dom]["ms"] / tot_ms, 3) if tot_ms else None
         roof["ms_per_step"] = {k: round(timers[k]["ms"] / steps, 3) for k, _ in TIMERS if timers[k]["ms"] > 0}
-        roof["other_kernels"] = {k: {kk: vv for kk, vv in kernel_block(k, names[k][0], timers[k], steps, ops_per_cell=names[k][1], traffic_key=names[k][2]).items()
+        roof["other_kernels"] = {k: {kk: vv for kk, vv in kernel_block(k, names[k][0], timers[k], steps, ops_per_cell=names[k][1], traffic_key=names[k][2], traffic_glob=dec_glob).items()
                                      if kk in ("kernel", "achieved", "frac", "traffic", "avg_launch_ms", "kernel_gcups", "valu", "algorithmic_bytes_per_launch")}
                                  for k in ("score", "front", "origin", "trace") if k in timers and k != dom and timers[k]["ms"] > 0}
         line = {"metric": "traces/s (tracy decompose hot section, indigo.h:190-388)", "value": round(nt_all * steps / dt, 1), "unit": "traces/s",
@@ -373,7 +374,7 @@ class AllPairsLeg:
         roof = kernel_block("score", "gotoh_prof_kernel<8,score,NT=4> (profile x profile Gotoh cell; substitution score = the int of the 16-term "
                             "fp32 chain, taken from a screened 4-fma short form where a proven margin excludes every integer, from per-row "
                             "tables against one-hot / uniform columns, from the chain itself otherwise; 25-term twin for profiles with N weight)",
-                            timers["score"], steps, ops_per_cell=23.8, traffic_key="gotoh_prof_kernel")
+                            timers["score"], steps, ops_per_cell=23.8, traffic_key="gotoh_prof_kernel", traffic_glob="r[0-9][0-9]_pmc_hbm_allpairs.json")
         line = {"metric": "GCUPS (all-pairs profile x profile gotohScore<true,true>, msa.h:33-42)", "value": round(cells * steps / dt / 1e9, 1), "unit": "GCUPS",
                 "pairs": int(self.npairs), "pairs_per_s": round(self.npairs * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
                 "warmup": warmup, "n_gpus": self.world, "scaling": "strong", "dtype": "f32 (substitution scores: the ints of align.h:112-117) / int32 (DP)",

@@ -175,6 +175,9 @@ def main():
     if torch.cuda.device_count() < world:
         raise SystemExit("bench.py: %d ranks but %d visible GPU(s)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
+    if world > 1:  # the library's host workers (descriptor loops between launches): this rank's share of the node's cores, not all of them
+        from tools.legs import rank_threads
+        os.environ.setdefault("TRACYHIP_HOST_THREADS", str(rank_threads(world)))
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist

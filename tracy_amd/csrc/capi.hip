@@ -2,6 +2,8 @@
 // pairs by strip height K, workspace chunking, kernel launches.  No compute happens on the host and
 // there is no CPU fallback: every entry point needs a gfx950 device.
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <sched.h>
 #include <malloc.h>
 #include <map>
 #include <chrono>
@@ -161,10 +163,15 @@ struct HostPool {
   std::mutex m;
   std::condition_variable cv, done_cv;
   const std::function<void(uint32_t)>* job = nullptr;
+  std::atomic<uint32_t> next{0};  // the next of the job's kHostThreads slices
   uint64_t gen = 0;
   uint32_t pending = 0;
+  uint32_t nworkers = 0;  // threads besides the caller: TRACYHIP_HOST_THREADS - 1, or what the process may run on, at most kHostThreads - 1
   bool started = false;
-  void worker(uint32_t tid) {
+  void slices(const std::function<void(uint32_t)>& f) {
+    for (uint32_t i = next.fetch_add(1); i < kHostThreads; i = next.fetch_add(1)) f(i);
+  }
+  void worker() {
     uint64_t seen = 0;
     for (;;) {
       const std::function<void(uint32_t)>* j;
@@ -174,34 +181,53 @@ struct HostPool {
         seen = gen;
         j = job;
       }
-      (*j)(tid);
+      slices(*j);
       {
         std::lock_guard<std::mutex> lk(m);
         if (--pending == 0) done_cv.notify_one();
       }
     }
   }
+  static uint32_t share() {
+    uint32_t want = kHostThreads;
+    if (const char* e = getenv("TRACYHIP_HOST_THREADS")) { const int v = atoi(e); if (v >= 1) want = (uint32_t)v; }
+    else {
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c >= 1) want = (uint32_t)c; }
+    }
+    return want > kHostThreads ? kHostThreads : want;
+  }
   bool run(const std::function<void(uint32_t)>& f) {
     std::unique_lock<std::mutex> u(use, std::try_to_lock);
     if (!u.owns_lock()) return false;
     if (!started) {
-      for (uint32_t t = 1; t < kHostThreads; ++t) std::thread([this, t] { worker(t); }).detach();
+      // A job is always cut into kHostThreads slices (the callers keep per-slice partial results); how many threads work them off
+      // is the process's share of the host: N ranks on one node must not start 8 N threads on cores they were not given.
+      const uint32_t want = share();
+      nworkers = want - 1;
+      for (uint32_t t = 0; t < nworkers; ++t) std::thread([this] { worker(); }).detach();
       started = true;
     }
     {
       std::lock_guard<std::mutex> lk(m);
       job = &f;
-      pending = kHostThreads - 1;
+      next.store(0);
+      pending = nworkers;
       ++gen;
     }
-    cv.notify_all();
-    f(0u);
+    if (nworkers) cv.notify_all();
+    slices(f);
     std::unique_lock<std::mutex> lk(m);
     done_cv.wait(lk, [&] { return pending == 0; });
     return true;
   }
 };
 }  // namespace
+uint32_t host_pool_threads() {
+  static const uint32_t n = HostPool::share();
+  return n;
+}
 bool host_pool_run(const std::function<void(uint32_t)>& job) {
   static HostPool* pool = new HostPool;  // never destroyed: its detached workers may outlive static destructors
   return pool->run(job);

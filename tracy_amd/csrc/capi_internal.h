@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -146,16 +147,21 @@ namespace tracyhip {
 constexpr uint32_t kHostThreads = 8;
 // Workers that stay alive between calls (starting seven threads costs ~0.3 ms, and a decompose call of 10^5 traces runs forty of
 // these loops between its launches).  One job at a time: a second caller (another lane) gets `false` and starts its own threads.
-bool host_pool_run(const std::function<void(uint32_t)>& job);  // job(tid) for tid = 0 .. kHostThreads - 1, tid 0 on the caller
+bool host_pool_run(const std::function<void(uint32_t)>& job);  // job(slice) for slice = 0 .. kHostThreads - 1, worked off by the pool + the caller
+uint32_t host_pool_threads();  // threads a job runs on: TRACYHIP_HOST_THREADS, or the cores the process may use, at most kHostThreads
 template <class Fn>
 void parallel_for(uint32_t n, Fn fn) {
   if (n < 16384u) { fn(0u, n, 0u); return; }
   auto lo = [&](uint32_t t) { return (uint32_t)((uint64_t)n * t / kHostThreads); };
   if (host_pool_run([&](uint32_t t) { fn(lo(t), lo(t + 1), t); })) return;
+  // the pool is busy with another lane's loop: threads of our own, no more than the process's share
+  std::atomic<uint32_t> next(0);
+  auto work = [&]() { for (uint32_t t = next.fetch_add(1); t < kHostThreads; t = next.fetch_add(1)) fn(lo(t), lo(t + 1), t); };
   std::vector<std::thread> th;
-  th.reserve(kHostThreads - 1);
-  for (uint32_t t = 1; t < kHostThreads; ++t) th.emplace_back([&, t]() { fn(lo(t), lo(t + 1), t); });
-  fn(0u, lo(1), 0u);
+  const uint32_t nth = host_pool_threads();
+  th.reserve(nth);
+  for (uint32_t t = 1; t < nth; ++t) th.emplace_back(work);
+  work();
   for (auto& x : th) x.join();
 }
 // A DpProblem borrows the context's descriptor vectors for its lifetime and hands them back, whatever the way out: batches of

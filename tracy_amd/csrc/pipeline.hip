@@ -2083,17 +2083,20 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
         else if (rc) return rc;
         sc6.mark("6.c rowend+subwindow");
         if (subwin) {
+          uint32_t npruned = 0;
           for (uint32_t t = 0; t < nt; ++t)
-            if (pruned[t]) hre[t].n = 0;  // (row m of a pruned pair was never written: its c_e is the band's)
-          const RowEndDesc* d_re;
-          if ((rc = upload(ctx, buf(), hre, &d_re))) return rc;
-          hipLaunchKernelGGL(row_m_end_kernel, dim3(nt), dim3(64), 0, st, d_re, static_cast<const int32_t*>(ctx->d_lastrow.p), p.go + p.ge, d_ce);
-          HIP_TRY(hipGetLastError());
+            if (pruned[t]) { hre[t].n = 0; ++npruned; }  // (row m of a pruned pair was never written: its c_e is the band's)
           std::vector<int32_t> h_s(nt);
           std::vector<uint32_t> h_ce(nt);
-          HIP_TRY(hipMemcpyAsync(h_s.data(), d_swscore, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-          HIP_TRY(hipMemcpyAsync(h_ce.data(), d_ce, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-          HIP_TRY(hipStreamSynchronize(st));
+          if (npruned < nt) {  // (every allele pruned -- the usual case: nothing to read off row m, no round trip)
+            const RowEndDesc* d_re;
+            if ((rc = upload(ctx, buf(), hre, &d_re))) return rc;
+            hipLaunchKernelGGL(row_m_end_kernel, dim3(nt), dim3(64), 0, st, d_re, static_cast<const int32_t*>(ctx->d_lastrow.p), p.go + p.ge, d_ce);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h_s.data(), d_swscore, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_ce.data(), d_ce, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+          }
           if (!fscore.empty())
             for (uint32_t t = 0; t < nt; ++t)
               if (pruned[t]) { h_s[t] = fscore[t]; h_ce[t] = fce[t]; }

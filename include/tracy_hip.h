@@ -90,6 +90,9 @@ typedef struct {
 } tracyhip_pairs;
 
 /* ---- lifecycle --------------------------------------------------------------------------------- */
+/* Host threads: the per-trace loops the pipelines run between two launches (descriptors, bands, verdicts) use a few worker
+   threads of the process -- as many as it may run on, at most 8; TRACYHIP_HOST_THREADS=<n> in the environment sets the number
+   (one process per GPU on a shared node: the cores of the node divided by the local ranks). */
 int tracyhip_device_count(int* count);
 int tracyhip_create(int device, tracyhip_ctx** ctx);
 int tracyhip_destroy(tracyhip_ctx* ctx);

@@ -110,6 +110,41 @@ int tracyhip_set_lanes(tracyhip_ctx* ctx, uint32_t lanes);
 /* waits for the context's stream AND for every *_async call issued on the context; returns the first error one of those
    calls produced since the last synchronize (tracyhip_last_error() then holds its text), TRACYHIP_OK otherwise */
 int tracyhip_synchronize(tracyhip_ctx* ctx);
+/* Options.  Every switch of the library is read from the environment ONCE, when a context is created (TRACYHIP_<NAME>, e.g.
+   TRACYHIP_NO_STREAM=1), and changed afterwards only through this call; name is the variable without the prefix, in any case:
+     no_stream (pipelines planned by the host between launches instead of stream-ordered), no_narrow, no_compact, no_screen,
+     no_band, no_band16, no_front, no_prefix, no_vote, no_origin, no_subwindow, no_prelim_origin, no_cq, no_fused_walk   "0" / "1"
+     band_w  (half width of the certified band of the final alignments; -1 = from the preliminary alignment, 0 = whole matrices)
+     ckpt_b  (steps between wavefront checkpoints, 32 .. 1024)      verbose  (one line per pipeline stage on stderr)
+   Every option selects another EXACT path (A/B measurements, tests of the fallback tiers); none changes a result.  Lanes inherit.
+   TRACYHIP_HOST_THREADS, TRACYHIP_HOST_TIMERS, TRACYHIP_LDS_PAD and TRACYHIP_LDS_STAGE_LIMIT are per process (read once).
+   tracyhip_describe writes the current settings as "name=value" lines (at most cap - 1 bytes) and returns the length needed. */
+int tracyhip_set_option(tracyhip_ctx* ctx, const char* name, const char* value);
+int tracyhip_describe(tracyhip_ctx* ctx, char* buf, size_t cap);
+/* glibc allocator settings that keep the descriptor vectors of the HOST-PLANNED pipelines (no_stream, and the fallback tiers) on the
+   heap: M_MMAP_THRESHOLD 32 MB, M_TRIM_THRESHOLD 1 GB, M_TOP_PAD 64 MB.  Process-wide, therefore opt-in: a command-line tool or a
+   benchmark calls it once; a library loaded into somebody else's process does not touch the allocator.  (TRACYHIP_MALLOPT=1 in the
+   environment does the same at the first tracyhip_create.) */
+int tracyhip_tune_host_allocator(void);
+/* Which tiers the traces of the last tracyhip_align_traces / tracyhip_decompose_traces call on this context took (summed over its
+   lanes).  The pipelines certify every shortcut per trace and repeat what fails on a wider form: these counters say how often. */
+typedef struct {
+  uint32_t traces;
+  uint32_t stream_ordered;       /* 1: planned on the device, one host synchronisation at the end; 0: planned by the host */
+  uint32_t host_syncs;           /* host synchronisations of the call */
+  uint32_t fallback_traces;      /* stream-ordered call: traces handed to the host-planned tiers afterwards */
+  uint32_t pruned;               /* orientation stage: traces whose voted strand took the pruned sweep (front.h) */
+  uint32_t pruned_uncertified;   /* ... of which not certified in either tier (swept in full) */
+  uint32_t prelim_banded;        /* preliminary alignment on the band kernels */
+  uint32_t prelim_repeated;      /* ... of which repeated on the wider form */
+  uint32_t final_banded;         /* `tracy align`: final alignments on a certified band */
+  uint32_t final_repeated;
+  uint32_t allele_pruned[2];     /* `tracy decompose`: gotoh(allele k, window) by the pruned sweep */
+  uint32_t allele_uncertified[2];
+  uint32_t allele_banded[3];     /* allele k vs its slice (k = 0, 1), allele 1 vs allele 2 (k = 2) on the band kernels */
+  uint32_t allele_repeated[3];
+} tracyhip_call_stats;
+int tracyhip_last_call_stats(tracyhip_ctx* ctx, tracyhip_call_stats* out);
 const char* tracyhip_last_error(void);
 const char* tracyhip_version(void);
 

@@ -225,11 +225,11 @@ def test_align_preliminary_alignment_by_its_two_ends(monkeypatch):
     c = tracy_amd.Context(0)
     try:
         for exact in (True, False):
-            monkeypatch.delenv("TRACYHIP_NO_PRELIM_ORIGIN", raising=False)
+            c.set_option("no_prelim_origin", 0)
             got = c.align_traces(list(profs), refl, SC, 50, 50, exact_scores=exact)
-            monkeypatch.setenv("TRACYHIP_NO_PRELIM_ORIGIN", "1")
+            c.set_option("no_prelim_origin", 1)
             ref = c.align_traces(list(profs), refl, SC, 50, 50, exact_scores=exact)
-            monkeypatch.delenv("TRACYHIP_NO_PRELIM_ORIGIN")
+            c.set_option("no_prelim_origin", 0)
             keys = ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final") + (("score_fwd", "score_rev") if exact else ())
             for k in keys:
                 assert np.array_equal(got[k], ref[k]), (k, exact)
@@ -269,13 +269,10 @@ def test_align_final_alignment_on_the_certified_band(monkeypatch):
     keys = ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final", "score_fwd", "score_rev")
     c = tracy_amd.Context(0)
     try:
-        monkeypatch.setenv("TRACYHIP_BAND_W", "0")  # whole matrices
+        c.set_option("band_w", 0)  # whole matrices
         ref = c.align_traces(list(profs), refl, SC, 50, 50, exact_scores=True)
-        for wband in ("48", "12", "2", None):  # None: the default
-            if wband is None:
-                monkeypatch.delenv("TRACYHIP_BAND_W")
-            else:
-                monkeypatch.setenv("TRACYHIP_BAND_W", wband)
+        for wband in ("48", "12", "2", None):  # None: the default (and the stream-ordered pipeline)
+            c.set_option("band_w", -1 if wband is None else wband)
             for lanes in (1, 2):
                 c.set_lanes(lanes)
                 got = c.align_traces(list(profs), refl, SC, 50, 50, exact_scores=True)
@@ -283,7 +280,7 @@ def test_align_final_alignment_on_the_certified_band(monkeypatch):
                     assert np.array_equal(got[k], ref[k]), (k, wband, lanes)
                 assert got["btr"] == ref["btr"], (wband, lanes)
             c.set_lanes(1)
-        monkeypatch.delenv("TRACYHIP_BAND_W", raising=False)
+        c.set_option("band_w", -1)
         for t in (0, 2, 4, 5, 6, 7, 8):
             want = sage_oracle.align_trace(profs[t], refl[t], SC, 50, 50)
             assert (int(ref["slice_begin"][t]), int(ref["slice_len"][t]), int(ref["score_final"][t]), ref["btr"][t]) == \

@@ -192,9 +192,9 @@ def test_origin_sweep_on_the_certified_sub_window(ctx, monkeypatch):
                                  [d["primary"][i].tobytes() for i in range(nd)], [d["secondary"][i].tobytes() for i in range(nd)])
         return ctx.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, [d["refs"][i].tobytes() for i in range(nd)], SC)
     cut = run()
-    monkeypatch.setenv("TRACYHIP_NO_SUBWINDOW", "1")
+    ctx.set_option("no_subwindow", 1)
     whole = run()
-    monkeypatch.delenv("TRACYHIP_NO_SUBWINDOW")
+    ctx.set_option("no_subwindow", 0)
     assert int((np.asarray(cut["status"]) == 0).sum()) > nd // 2
     for k in cut:
         a, b = cut[k], whole[k]
@@ -275,18 +275,15 @@ def test_pruned_sweeps_of_decompose_where_they_certify_and_where_they_cannot(ctx
         hbc = capi.HostBaseCalls([d["signal"][i] for i in range(nd)], [d["bcpos"][i] for i in range(nd)],
                                  [d["primary"][i].tobytes() for i in range(nd)], [d["secondary"][i].tobytes() for i in range(nd)])
         return ctx.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, refs, SC)
-    monkeypatch.setenv("TRACYHIP_HOST_TIMERS", "1")
-    capfd.readouterr()
+    ctx.set_option("no_stream", 1)  # the tiers of the host-planned pipeline (stream-ordered: test_gpu_stream.py)
     pruned = run()
-    said = capfd.readouterr().err
-    monkeypatch.delenv("TRACYHIP_HOST_TIMERS")
-    m = re.search(r"pruned orientation sweep: (\d+) of (\d+) traces, (\d+) not certified", said)
-    assert m and int(m.group(1)) >= nd // 2 and 8 <= int(m.group(3)) < int(m.group(1)), said[-600:]
-    al = re.findall(r"decompose allele (\d): pruned sweep of (\d+) of (\d+) alleles, (\d+) certified", said)
-    assert len(al) == 2 and all(int(x[1]) >= nd // 2 and 8 <= int(x[1]) - int(x[3]) and int(x[3]) >= 8 for x in al), said[-600:]
-    monkeypatch.setenv("TRACYHIP_NO_FRONT", "1")
+    said = ctx.last_call_stats()
+    assert said["pruned"] >= nd // 2 and 8 <= said["pruned_uncertified"] < said["pruned"], said
+    assert all(said["allele_pruned"][k] >= nd // 2 and 8 <= said["allele_uncertified"][k] <= said["allele_pruned"][k] - 8 for k in (0, 1)), said
+    ctx.set_option("no_front", 1)
     plain = run()
-    monkeypatch.delenv("TRACYHIP_NO_FRONT")
+    ctx.set_option("no_front", 0)
+    ctx.set_option("no_stream", 0)
     assert int((np.asarray(pruned["status"]) == 0).sum()) > nd // 2
     for k in pruned:
         a, b = pruned[k], plain[k]

@@ -126,9 +126,9 @@ def test_profile_profile_screened_score(ctx, monkeypatch):
           special_profile(rng, 333, ["onehot", "uniform"]), special_profile(rng, 64, ["dyadic"]),
           special_profile(rng, 210, ["consensus", "trace", "onehot"], 5), special_profile(rng, 70, ["onehot", "trace"]),
           special_profile(rng, 300, ["heavy", "onehot"])]
-    monkeypatch.setenv("TRACYHIP_NO_SCREEN", "1")
+    ctx.set_option("no_screen", 1)
     plain = tracy_amd.Context(0)
-    monkeypatch.delenv("TRACYHIP_NO_SCREEN")
+    ctx.set_option("no_screen", 0)
     try:
         for sc in (SC, (5, -4, -6, -1)):
             for cfg in [(1, 0), (1, 1)]:
@@ -191,10 +191,10 @@ def test_traceback_walked_by_the_sweeping_workgroup(ctx, monkeypatch):
         try:
             fused = ctx.align(a1, a2, SC + cfg, rows=True)
             fused_p = ctx.align(profs, refs, SC + cfg)
-            monkeypatch.setenv("TRACYHIP_NO_FUSED_WALK", "1")
+            ctx.set_option("no_fused_walk", 1)
             apart = ctx.align(a1, a2, SC + cfg, rows=True)
             apart_p = ctx.align(profs, refs, SC + cfg)
-            monkeypatch.delenv("TRACYHIP_NO_FUSED_WALK")
+            ctx.set_option("no_fused_walk", 0)
         finally:
             ctx.set_workspace_limit(0)
         assert [int(x) for x in fused[0]] == [int(x) for x in apart[0]] and fused[1] == apart[1] and fused[2] == apart[2]
@@ -345,11 +345,11 @@ def test_strand_by_certificate(ctx):
     profs[6] = np.ascontiguousarray(noisy / noisy[:4].sum(axis=0, keepdims=True))
     refl = [r.tobytes() for r in refs]
     exact = ctx.align_traces(profs, refl, SC, 50, 50, exact_scores=True)
-    os.environ["TRACYHIP_NO_VOTE"] = "1"  # the two-stage form: prefix bounds of both strands, then the likely winner
+    ctx.set_option("no_vote", 1)  # the two-stage form: prefix bounds of both strands, then the likely winner
     try:
         fast2 = ctx.align_traces(profs, refl, SC, 50, 50, exact_scores=False)
     finally:
-        del os.environ["TRACYHIP_NO_VOTE"]
+        ctx.set_option("no_vote", 0)
     fast = ctx.align_traces(profs, refl, SC, 50, 50, exact_scores=False)  # k-mer vote + prefix bounds in the sweep launch
     for k in ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
         assert np.array_equal(np.asarray(fast2[k]), np.asarray(exact[k])), k

@@ -98,15 +98,11 @@ def test_pruned_sweep_equals_the_reference_where_it_certifies_and_where_it_canno
     profs, wins = [c[0] for c in cs], [c[1] for c in cs]
     with ThreadPoolExecutor(16) as pool:
         want = list(pool.map(lambda i: so.align_trace(profs[i], wins[i], SC, 50, 50), range(len(cs))))
-    monkeypatch.setenv("TRACYHIP_HOST_TIMERS", "1")
-    capfd.readouterr()
+    ctx.set_option("no_stream", 1)  # the tiers of the host-planned pipeline (the stream-ordered form of this batch: test_gpu_stream.py)
     exact = ctx.align_traces(profs, wins, SC, 50, 50)
-    said = capfd.readouterr().err
+    said = ctx.last_call_stats()
     fast = ctx.align_traces(profs, wins, SC, 50, 50, exact_scores=False)
-    monkeypatch.delenv("TRACYHIP_HOST_TIMERS")
-    m = re.search(r"pruned orientation sweep: (\d+) of (\d+) traces, (\d+) not certified", said)
-    assert m, said[-400:]
-    pruned, notcert = int(m.group(1)), int(m.group(3))
+    pruned, notcert = said["pruned"], said["pruned_uncertified"]
     assert pruned >= 48 and 8 <= notcert <= pruned - 16, said  # both outcomes are exercised
     for i, w in enumerate(want):
         for k in FIELDS + ("score_fwd", "score_rev"):
@@ -118,9 +114,10 @@ def test_pruned_sweep_equals_the_reference_where_it_certifies_and_where_it_canno
         win, lose = ("score_fwd", "score_rev") if int(w["forward"]) else ("score_rev", "score_fwd")
         assert int(fast[win][i]) == int(w[win]) and int(fast[lose][i]) >= int(w[lose]), (i, cs[i][2])
     # the same batch without the pruned sweep: nothing but the work differs
-    monkeypatch.setenv("TRACYHIP_NO_FRONT", "1")
+    ctx.set_option("no_front", 1)
     plain = ctx.align_traces(profs, wins, SC, 50, 50)
-    monkeypatch.delenv("TRACYHIP_NO_FRONT")
+    ctx.set_option("no_front", 0)
+    ctx.set_option("no_stream", 0)
     for k in FIELDS + ("score_fwd", "score_rev"):
         assert plain[k].tolist() == exact[k].tolist(), k
     assert plain["btr"] == exact["btr"]
@@ -154,14 +151,12 @@ def test_heterozygous_traces_certify_by_the_second_bound(ctx, monkeypatch, capfd
         profs.append(p); wins.append(win)
     with ThreadPoolExecutor(16) as pool:
         want = list(pool.map(lambda i: so.align_trace(profs[i], wins[i], SC, 50, 50), range(len(profs))))
-    monkeypatch.setenv("TRACYHIP_HOST_TIMERS", "1")
-    capfd.readouterr()
-    got = ctx.align_traces(profs, wins, SC, 50, 50)
-    said = capfd.readouterr().err
-    monkeypatch.delenv("TRACYHIP_HOST_TIMERS")
-    m = re.search(r"pruned orientation sweep: (\d+) of (\d+) traces, (\d+) not certified", said)
-    assert m and int(m.group(1)) >= 20 and int(m.group(3)) <= 4, said[-400:]
-    for i, w in enumerate(want):
-        for k in FIELDS + ("score_fwd", "score_rev"):
-            assert int(got[k][i]) == int(w[k]), (i, k)
-        assert got["btr"][i] == w["btr"], i
+    for no_stream in (1, 0):  # planned by the host, planned on the device: the same certificates
+        ctx.set_option("no_stream", no_stream)
+        got = ctx.align_traces(profs, wins, SC, 50, 50)
+        said = ctx.last_call_stats()
+        assert said["stream_ordered"] == 1 - no_stream and said["pruned"] >= 20 and said["pruned_uncertified"] <= 4, said
+        for i, w in enumerate(want):
+            for k in FIELDS + ("score_fwd", "score_rev"):
+                assert int(got[k][i]) == int(w[k]), (i, k, no_stream)
+            assert got["btr"][i] == w["btr"], (i, no_stream)

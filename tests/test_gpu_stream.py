@@ -1,0 +1,109 @@
+"""The stream-ordered pipelines (tracy_amd/csrc/stream.hip: planned on the device, one host synchronisation per call) against the
+pipelines planned by the host between launches (pipeline.hip, option no_stream) and against the oracle: same arrays, bit for bit --
+on the batches the stream-ordered pass is built for (nothing falls back) AND on traces whose certificates fail or whose bands are
+too wide (the dead traces are re-done by the host-planned tiers and scattered back)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SC = (3, -5, -10, -4)
+ALIGN_KEYS = ("forward", "score_fwd", "score_rev", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import tracy_amd
+    c = tracy_amd.Context(0)
+    yield c
+    c.close()
+
+
+def both_ways(ctx, fn):
+    """fn() on the stream-ordered pipeline and on the host-planned one; (stream result, its stats, host-planned result, its stats)"""
+    ctx.set_option("no_stream", 0)
+    a = fn()
+    sa = ctx.last_call_stats()
+    ctx.set_option("no_stream", 1)
+    b = fn()
+    sb = ctx.last_call_stats()
+    ctx.set_option("no_stream", 0)
+    return a, sa, b, sb
+
+
+def same_align(a, b, exact, what=""):
+    keys = ALIGN_KEYS if exact else tuple(k for k in ALIGN_KEYS if k not in ("score_fwd", "score_rev"))
+    for k in keys:
+        assert np.array_equal(a[k], b[k]), (what, k, np.nonzero(np.asarray(a[k]) != np.asarray(b[k]))[0][:8])
+    assert a["btr"] == b["btr"], what
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_align_uniform_batch_is_stream_ordered(ctx, exact):
+    """the bench shape in miniature: every trace certifies on the device, one synchronisation, nothing falls back"""
+    from tracy_amd import hostlib
+    refs, profs, rev = hostlib.synth_align(31, 96, 4000, 1000, 2)
+    refl = [r.tobytes() for r in refs]
+    a, sa, b, sb = both_ways(ctx, lambda: ctx.align_traces(list(profs), refl, SC, 50, 50, exact_scores=exact))
+    assert sa["stream_ordered"] == 1 and sb["stream_ordered"] == 0, (sa, sb)
+    assert sa["fallback_traces"] == 0, sa
+    assert sa["host_syncs"] <= 2 and sb["host_syncs"] >= 6, (sa, sb)  # (host buffers: one more for the copy-out)
+    assert sa["pruned"] == 96 and sa["final_banded"] == 96, sa
+    same_align(a, b, exact)
+    assert [int(x) for x in a["forward"]] == [1 - int(r) for r in rev]
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_align_failing_certificates_fall_back_per_trace(ctx, exact):
+    """test_gpu_front's cases (the target twice, chimeras, long indels, cut windows, mixed strip heights): the traces the device cannot
+    certify are re-done by the host-planned tiers; every array equals the host-planned pipeline's and the oracle's"""
+    import sage_oracle as so
+    from test_gpu_front import cases
+    rng = np.random.default_rng(77)
+    cs = cases(rng)
+    profs, wins = [c[0] for c in cs], [c[1] for c in cs]
+    a, sa, b, sb = both_ways(ctx, lambda: ctx.align_traces(profs, wins, SC, 50, 50, exact_scores=exact))
+    assert sa["stream_ordered"] == 1, sa
+    assert 4 <= sa["fallback_traces"] <= len(cs) - 16, sa  # both outcomes are exercised
+    same_align(a, b, exact, "stream vs host-planned")
+    for i in range(0, len(cs), 3):
+        w = so.align_trace(profs[i], wins[i], SC, 50, 50)
+        for k in ("forward", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final"):
+            assert int(a[k][i]) == int(w[k]), (i, cs[i][2], k)
+        assert a["btr"][i] == w["btr"], (i, cs[i][2])
+
+
+def test_align_stream_with_device_buffers_and_lanes(ctx):
+    """device-resident inputs and results (what bench.py times), one and two lanes"""
+    from tracy_amd import hostlib
+    nt, n, mf = 256, 3000, 900
+    refs, profs, rev = hostlib.synth_align(5, nt, n, mf, 2)
+    refl = [r.tobytes() for r in refs]
+    want = ctx.align_traces(list(profs), refl, SC, 50, 50)
+    for lanes in (1, 2):
+        ctx.set_lanes(lanes)
+        got = ctx.align_traces(list(profs), refl, SC, 50, 50, device=True)
+        st = ctx.last_call_stats()
+        assert st["stream_ordered"] == 1 and st["fallback_traces"] == 0, st
+        same_align(got, want, True, "lanes %d" % lanes)
+    ctx.set_lanes(1)
+
+
+def test_options_are_read_once_and_described(ctx, monkeypatch):
+    """the environment is read when a context is created; afterwards only tracyhip_set_option changes a switch"""
+    import tracy_amd
+    monkeypatch.setenv("TRACYHIP_NO_FRONT", "1")
+    c2 = tracy_amd.Context(0)
+    monkeypatch.delenv("TRACYHIP_NO_FRONT")
+    try:
+        assert c2.describe()["no_front"] == "1" and ctx.describe()["no_front"] == "0"
+        monkeypatch.setenv("TRACYHIP_NO_BAND16", "1")  # too late for both
+        assert c2.describe()["no_band16"] == "0" and ctx.describe()["no_band16"] == "0"
+        monkeypatch.delenv("TRACYHIP_NO_BAND16")
+        c2.set_option("NO_FRONT", 0)
+        c2.set_option("band_w", 12)
+        d = c2.describe()
+        assert d["no_front"] == "0" and d["band_w"] == "12"
+        with pytest.raises(tracy_amd.capi.TracyHipError):
+            c2.set_option("no_such_switch", 1)
+    finally:
+        c2.close()

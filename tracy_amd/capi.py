@@ -49,6 +49,13 @@ class AlignResult(C.Structure):
                 ("ops_offset", C.POINTER(C.c_uint64)), ("ops_len", C.c_void_p)]
 
 
+class CallStats(C.Structure):
+    _fields_ = [("traces", C.c_uint32), ("stream_ordered", C.c_uint32), ("host_syncs", C.c_uint32), ("fallback_traces", C.c_uint32),
+                ("pruned", C.c_uint32), ("pruned_uncertified", C.c_uint32), ("prelim_banded", C.c_uint32), ("prelim_repeated", C.c_uint32),
+                ("final_banded", C.c_uint32), ("final_repeated", C.c_uint32), ("allele_pruned", C.c_uint32 * 2),
+                ("allele_uncertified", C.c_uint32 * 2), ("allele_banded", C.c_uint32 * 3), ("allele_repeated", C.c_uint32 * 3)]
+
+
 def library_path():
     return os.path.join(_HERE, "lib", "libtracy_hip.so")
 
@@ -148,6 +155,26 @@ class Context:
 
     def synchronize(self):
         _check(lib().tracyhip_synchronize(self._h))
+
+    def set_option(self, name, value):
+        """tracyhip_set_option: name without the TRACYHIP_ prefix (the environment is read once, at creation)"""
+        _check(lib().tracyhip_set_option(self._h, str(name).encode(), str(int(value) if isinstance(value, bool) else value).encode()))
+
+    def describe(self):
+        n = lib().tracyhip_describe(self._h, None, C.c_size_t(0))
+        buf = C.create_string_buffer(n)
+        lib().tracyhip_describe(self._h, buf, C.c_size_t(n))
+        return dict(line.split("=", 1) for line in buf.value.decode().splitlines())
+
+    def last_call_stats(self):
+        """tiers the traces of the last align_traces / decompose_traces call took (tracyhip_last_call_stats)"""
+        st = CallStats()
+        _check(lib().tracyhip_last_call_stats(self._h, C.byref(st)))
+        out = {}
+        for name, ty in CallStats._fields_:
+            v = getattr(st, name)
+            out[name] = list(v) if hasattr(v, "__len__") else int(v)
+        return out
 
     # ---- host-buffer convenience wrappers (lists in, numpy out) -----------------------------------
     @staticmethod
@@ -295,11 +322,27 @@ class PreparedAlign:
         return res
 
 
-def _align_traces(self, profiles, refs, params, trim_left=50, trim_right=50, ref_index=None, oriented=None, exact_scores=True):
+def _align_traces(self, profiles, refs, params, trim_left=50, trim_right=50, ref_index=None, oriented=None, exact_scores=True, device=False):
     """tracyhip_align_traces with host buffers.  profiles: list of float32 [6][mf]; refs: list of bytes.
     oriented: None, or rs.forward per trace when the references are already oriented (indexed-genome path).
+    device=True: payloads and result arrays in device memory (torch tensors, TRACYHIP_MEM_DEVICE), copied back afterwards.
     Returns a dict of numpy arrays + the list of final traceback strings (push order)."""
     p = PreparedAlign(profiles, refs, params, trim_left, trim_right, ref_index, oriented, exact_scores)
+    if device:
+        import torch
+        pp, pr = p.keep[0], p.keep[1]
+        dp, dr = torch.from_numpy(pp.data).cuda(), torch.from_numpy(pr.data).cuda()
+        p.job.profiles = pp.seqset(dp.data_ptr())
+        p.job.refs = pr.seqset(dr.data_ptr())
+        dres = {k: torch.zeros(v.shape, dtype=getattr(torch, str(v.dtype)) if str(v.dtype) != "uint32" else torch.int32, device="cuda") for k, v in p.res.items()}
+        for k, v in dres.items():
+            setattr(p.out, k, v.data_ptr())
+        torch.cuda.synchronize()
+        _check(lib().tracyhip_align_traces(self._h, C.byref(p.job), C.byref(p.prm), MEM_DEVICE, C.byref(p.out)))
+        torch.cuda.synchronize()
+        for k, v in dres.items():
+            p.res[k] = v.cpu().numpy().view(p.res[k].dtype)
+        return p.results()
     if isinstance(self, Group):
         _check(lib().tracyhip_group_align_traces(self._g, C.byref(p.job), C.byref(p.prm), C.byref(p.out)))
     else:

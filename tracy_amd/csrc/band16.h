@@ -53,6 +53,10 @@ struct Band16Args {
   // row[lastrow_off + c]; PairDesc::bits_off is R (the rows above the pair's first one), m the rows below it.  Origins are not
   // tracked (ends[2 out] = 0); score and c_e are those of the band under row R.
   const uint32_t* row;
+  // lists laid out on the device (stream.hip): pair i of the launch is pairs[index[i]] (null: pairs[i]), and the number of pairs is
+  // *count (null: npairs) -- the grid is sized for the worst case and the waves past the count leave at once
+  const uint32_t* index;
+  const uint32_t* count;
 };
 constexpr uint32_t kB16RowCap = 200;  // CONT: row-R entries staged per pair (the window of strip 0 and the column before it)
 
@@ -78,6 +82,25 @@ TR_HD uint32_t b16_last_window(uint32_t m, uint32_t n, int K, int32_t dmin, int3
 }
 TR_HD uint64_t b16_words(uint32_t m, uint32_t n, int K, int32_t dmin, int32_t dmax) {
   return (uint64_t)(b16_strips(m, K) - 1u) * b16_window(K, dmin, dmax) + b16_last_window(m, n, K, dmin, dmax);
+}
+// smallest strip height whose lanes are done with a strip before the next one is due (K + width <= 15 (K + 1)); 0: the band is too wide
+TR_HD int b16_pick_k(int32_t dmin, int32_t dmax) {
+  if (dmax < dmin) return 0;
+  if (b16_window(4, dmin, dmax) <= b16_max_window(4)) return 4;
+  if (b16_window(8, dmin, dmax) <= b16_max_window(8)) return 8;
+  if (b16_window(12, dmin, dmax) <= b16_max_window(12)) return 12;
+  return 0;
+}
+// value ranges of the origin-tracking sweep on the band kernels (packed 14-bit score field, 13-bit origin) for m rows / n columns,
+// AlignConfig<true,false> (capi_internal.h origin16_ok: the same test with a tracyhip_params)
+TR_HD bool b16_origin_ok(int32_t match, int32_t mismatch, int32_t go, int32_t ge, uint32_t maxm, uint32_t maxn) {
+  if (go > 0 || ge >= 0) return false;
+  if ((uint64_t)maxn + 64 >= (1u << kOriginBits)) return false;
+  auto ab = [](int32_t x) { return x < 0 ? -(int64_t)x : (int64_t)x; };
+  const int64_t rows = maxm, q = ab(match) > ab(mismatch) ? ab(match) : ab(mismatch);
+  const int64_t low = ab(go) + rows * ab(ge) + 2 * (ab(go) + ab(ge)) + ab(mismatch) + ab(match);
+  const int64_t high = rows * q;
+  return (low < -(int64_t)kNegInfOrigin - 16 * ab(ge) - 64) && (-(int64_t)kNegInfOrigin + ab(go) + 16 * ab(ge) < 8000) && (high < 8000);
 }
 // rows of a sequence's table: whole strips for every K, so that a strip's load never runs off the code row
 TR_HD uint32_t b16_table_stride(uint32_t m) { return ((m + 15u) & ~15u) + 16u; }
@@ -201,9 +224,12 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   constexpr uint32_t WB = b16_word_bytes(K);
   const uint32_t L = w.lane(), g = L >> 4, j = L & 15u;
   const uint32_t pair_idx = wave_idx * 4u + g;
-  const bool have = pair_idx < a.npairs;
+  const uint32_t npairs = a.count ? *a.count : a.npairs;
+  if (wave_idx * 4u >= npairs) return;  // (wave-uniform)
+  bool have = pair_idx < npairs;
   PairDesc d{};
-  if (have) d = a.pairs[pair_idx];
+  if (have) d = a.pairs[a.index ? a.index[pair_idx] : pair_idx];
+  if (d.flags & PAIR_SKIP) { have = false; d = PairDesc{}; }
   const uint32_t m = d.m, n = d.n;
   const int32_t dmin = band_dmin(d), dmax = band_dmax(d);
   const int32_t go = a.go, ge = a.ge, goe = go + ge;

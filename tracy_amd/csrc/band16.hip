@@ -43,6 +43,17 @@ __global__ __launch_bounds__(64) void band16_multi_kernel(Band16Args a12, uint32
   else band16_body<DeviceWave16, 4, KIND>(w, a4, blockIdx.x - w12 - w8);
 }
 
+// The same with the three jobs' sizes on the device (Band16Args::count; lists laid out by stream.hip's planning kernels): the grid holds
+// the worst case, a block finds its job from the counts and the blocks past the last job leave at once.
+template <int KIND>
+__global__ __launch_bounds__(64) void band16_multi_counted_kernel(Band16Args a12, Band16Args a8, Band16Args a4) {
+  DeviceWave16 w;
+  const uint32_t w12 = (*a12.count + 3u) / 4u, w8 = (*a8.count + 3u) / 4u, w4 = (*a4.count + 3u) / 4u;
+  if (blockIdx.x < w12) band16_body<DeviceWave16, 12, KIND>(w, a12, blockIdx.x);
+  else if (blockIdx.x < w12 + w8) band16_body<DeviceWave16, 8, KIND>(w, a8, blockIdx.x - w12);
+  else if (blockIdx.x < w12 + w8 + w4) band16_body<DeviceWave16, 4, KIND>(w, a4, blockIdx.x - w12 - w8);
+}
+
 template <int K>
 __global__ __launch_bounds__(64) void band16_cont_kernel(Band16Args a) {
   DeviceWave16 w;
@@ -50,16 +61,20 @@ __global__ __launch_bounds__(64) void band16_cont_kernel(Band16Args a) {
 }
 
 // front.h: one wave per pair
+// prev (or null): the verdicts of an earlier, narrower tier over the same descriptors -- what certified there is an empty slot here
 __global__ __launch_bounds__(64) void front_place_kernel(const FrontDesc* __restrict__ desc, const uint32_t* __restrict__ row, int32_t goe, int32_t halfw,
-                                                         PairDesc* __restrict__ pairs, FrontOut* __restrict__ fo) {
+                                                         PairDesc* __restrict__ pairs, FrontOut* __restrict__ fo, const FrontOut* __restrict__ prev) {
   DeviceWave16 w;
-  front_place_body(w, desc[blockIdx.x], row, goe, halfw, pairs + blockIdx.x, fo + blockIdx.x);
+  FrontDesc f = desc[blockIdx.x];
+  if (prev && prev[blockIdx.x].ok) f.flags |= PAIR_SKIP;
+  front_place_body(w, f, row, goe, halfw, pairs + blockIdx.x, fo + blockIdx.x);
 }
 __global__ __launch_bounds__(64) void front_certify_kernel(const FrontDesc* __restrict__ desc, const uint32_t* __restrict__ row, int32_t go, int32_t ge,
                                                            int32_t halfw, const int32_t* __restrict__ scores, const uint32_t* __restrict__ ends,
-                                                           FrontOut* __restrict__ fo) {
+                                                           FrontOut* __restrict__ fo, const FrontOut* __restrict__ prev) {
   DeviceWave16 w;
   const FrontDesc f = desc[blockIdx.x];
+  if (prev && prev[blockIdx.x].ok) return;
   front_certify_body(w, f, row, go, ge, halfw, scores[f.out], ends[2 * f.out + 1], fo + blockIdx.x);
 }
 
@@ -126,6 +141,24 @@ hipError_t launch_band16_multi(int kind, const Band16Args& a12, const Band16Args
   return hipGetLastError();
 }
 
+// jobs whose sizes are on the device (a.count != null, a.npairs = the most pairs the job can hold): one launch per strip height for
+// large batches (a K = 4 workgroup then asks for its own, smaller LDS block), one for all three below 24 576 pairs
+hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Args& a8, const Band16Args& a4, hipStream_t s) {
+  const uint32_t most = a12.npairs > a8.npairs ? (a12.npairs > a4.npairs ? a12.npairs : a4.npairs) : (a8.npairs > a4.npairs ? a8.npairs : a4.npairs);
+  if (most == 0) return hipSuccess;
+  if (most <= 24576u) {
+    const uint32_t lds = 4u * a12.code_cap + b16_table_bytes(12);
+    const dim3 grid((most + 3u) / 4u + 3u);  // (the three jobs together hold at most `most` pairs: every pair is in one of them)
+    if (kind == 0) hipLaunchKernelGGL((band16_multi_counted_kernel<0>), grid, dim3(64), lds, s, a12, a8, a4);
+    else hipLaunchKernelGGL((band16_multi_counted_kernel<1>), grid, dim3(64), lds, s, a12, a8, a4);
+    return hipGetLastError();
+  }
+  hipError_t e;
+  if ((e = launch_band16(4, kind, a4, s)) != hipSuccess) return e;   // (the usual strip height first: the other two are mostly empty grids)
+  if ((e = launch_band16(8, kind, a8, s)) != hipSuccess) return e;
+  return launch_band16(12, kind, a12, s);
+}
+
 hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s) {
   if (a.npairs == 0) return hipSuccess;
   const dim3 grid((a.npairs + 3u) / 4u);
@@ -140,16 +173,16 @@ hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s) {
 }
 
 hipError_t launch_front_place(const FrontDesc* d_desc, uint32_t n, const uint32_t* row, int32_t goe, int32_t halfw, PairDesc* d_pairs, FrontOut* d_fo,
-                              hipStream_t s) {
+                              hipStream_t s, const FrontOut* d_prev) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(front_place_kernel, dim3(n), dim3(64), 0, s, d_desc, row, goe, halfw, d_pairs, d_fo);
+  hipLaunchKernelGGL(front_place_kernel, dim3(n), dim3(64), 0, s, d_desc, row, goe, halfw, d_pairs, d_fo, d_prev);
   return hipGetLastError();
 }
 
 hipError_t launch_front_certify(const FrontDesc* d_desc, uint32_t n, const uint32_t* row, int32_t go, int32_t ge, int32_t halfw, const int32_t* d_scores,
-                                const uint32_t* d_ends, FrontOut* d_fo, hipStream_t s) {
+                                const uint32_t* d_ends, FrontOut* d_fo, hipStream_t s, const FrontOut* d_prev) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(front_certify_kernel, dim3(n), dim3(64), 0, s, d_desc, row, go, ge, halfw, d_scores, d_ends, d_fo);
+  hipLaunchKernelGGL(front_certify_kernel, dim3(n), dim3(64), 0, s, d_desc, row, go, ge, halfw, d_scores, d_ends, d_fo, d_prev);
   return hipGetLastError();
 }
 

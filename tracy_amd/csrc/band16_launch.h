@@ -23,14 +23,17 @@ hipError_t launch_b16_tables(const B16TableDesc* d_desc, uint32_t nseq, const vo
 hipError_t launch_band16(int K, int kind, const Band16Args& a, hipStream_t s);
 // the three strip heights in one launch (small jobs); the jobs share one code_cap
 hipError_t launch_band16_multi(int kind, const Band16Args& a12, const Band16Args& a8, const Band16Args& a4, hipStream_t s);
+// the three strip heights of a job whose lists and sizes are on the device (Band16Args::index / count; npairs = capacity of each list)
+hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Args& a8, const Band16Args& a4, hipStream_t s);
 // the sweep below a stored prefix row (Band16Args::row; K = 8 or 12), and the two kernels of front.h around it
 hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s);
 struct FrontDesc;
 struct FrontOut;
+// d_prev (or null): verdicts of an earlier tier over the same descriptors; what certified there is skipped
 hipError_t launch_front_place(const FrontDesc* d_desc, uint32_t n, const uint32_t* row, int32_t goe, int32_t halfw, PairDesc* d_pairs, FrontOut* d_fo,
-                              hipStream_t s);
+                              hipStream_t s, const FrontOut* d_prev = nullptr);
 hipError_t launch_front_certify(const FrontDesc* d_desc, uint32_t n, const uint32_t* row, int32_t go, int32_t ge, int32_t halfw, const int32_t* d_scores,
-                                const uint32_t* d_ends, FrontOut* d_fo, hipStream_t s);
+                                const uint32_t* d_ends, FrontOut* d_fo, hipStream_t s, const FrontOut* d_prev = nullptr);
 
 }  // namespace tracyhip
 #endif

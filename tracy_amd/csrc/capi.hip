@@ -11,7 +11,9 @@
 #include <thread>
 
 #include <algorithm>
+#include <cctype>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -242,6 +244,63 @@ HostScope::~HostScope() {
   auto& e = p.acc[label];
   e.first += ms;
   e.second += 1;
+}
+
+// ---- options (CtxKnobs) ----
+namespace {
+struct KnobField { const char* name; bool CtxKnobs::*flag; };
+const KnobField kKnobFlags[] = {
+    {"no_stream", &CtxKnobs::no_stream}, {"no_narrow", &CtxKnobs::no_narrow}, {"no_compact", &CtxKnobs::no_compact},
+    {"no_screen", &CtxKnobs::no_screen}, {"no_band", &CtxKnobs::no_band}, {"no_band16", &CtxKnobs::no_band16},
+    {"no_front", &CtxKnobs::no_front}, {"no_prefix", &CtxKnobs::no_prefix}, {"no_vote", &CtxKnobs::no_vote},
+    {"no_origin", &CtxKnobs::no_origin}, {"no_subwindow", &CtxKnobs::no_subwindow}, {"no_prelim_origin", &CtxKnobs::no_prelim_origin},
+    {"no_cq", &CtxKnobs::no_cq}, {"no_fused_walk", &CtxKnobs::no_fused_walk}, {"verbose", &CtxKnobs::verbose}};
+bool same_name(const char* a, const char* b) {
+  for (; *a && *b; ++a, ++b)
+    if (std::tolower((unsigned char)*a) != std::tolower((unsigned char)*b)) return false;
+  return *a == *b;
+}
+}  // namespace
+bool knobs_set(CtxKnobs& k, const char* name, const char* value) {
+  if (!name || !value) return false;
+  if (same_name(name, "band_w")) {
+    char* end = nullptr;
+    const long v = strtol(value, &end, 10);
+    if (end == value) return false;
+    k.band_w = v < 0 ? -1 : (int32_t)std::min<long>(4096, v);  // (widths the band forms cannot hold leave the pair on the whole matrix)
+    return true;
+  }
+  if (same_name(name, "ckpt_b")) {
+    const long v = atol(value);
+    if (v < 32 || v > 1024) return false;
+    k.ckpt_b = (uint32_t)v;
+    return true;
+  }
+  for (const KnobField& f : kKnobFlags)
+    if (same_name(name, f.name)) {
+      // (the environment form is "set = on", whatever the value, as it has always been; "0" through the API switches off)
+      k.*(f.flag) = !(value[0] == '0' && value[1] == 0);
+      return true;
+    }
+  return false;
+}
+void knobs_from_env(CtxKnobs& k) {
+  for (const KnobField& f : kKnobFlags) {
+    std::string env = "TRACYHIP_";
+    for (const char* c = f.name; *c; ++c) env.push_back((char)std::toupper((unsigned char)*c));
+    if (getenv(env.c_str())) k.*(f.flag) = true;
+  }
+  if (getenv("TRACYHIP_HOST_TIMERS")) k.verbose = true;
+  if (const char* e = getenv("TRACYHIP_BAND_W")) knobs_set(k, "band_w", e);
+  if (const char* e = getenv("TRACYHIP_CKPT_B")) knobs_set(k, "ckpt_b", e);
+}
+std::string knobs_describe(const CtxKnobs& k) {
+  std::string s;
+  for (const KnobField& f : kKnobFlags) { s += f.name; s += k.*(f.flag) ? "=1\n" : "=0\n"; }
+  s += "band_w=" + std::to_string(k.band_w) + "\n";
+  s += "ckpt_b=" + std::to_string(k.ckpt_b) + "\n";
+  s += "host_threads=" + std::to_string(host_pool_threads()) + "\n";
+  return s;
 }
 
 int timing_begin(tracyhip_ctx* ctx, int which, uint64_t cells, uint64_t bytes) {
@@ -561,12 +620,12 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   a.hfree = prm->hfree; a.vfree = prm->vfree;
   a.qlimit = sub_limit(prm);
   // Gotoh tracebacks: the sweep's workgroup walks its pair itself (TRACYHIP_NO_FUSED_WALK=1: the separate walk launch)
-  const bool fused_walk = trace && stage == DP_PLAIN && !needle && getenv("TRACYHIP_NO_FUSED_WALK") == nullptr;
+  const bool fused_walk = trace && stage == DP_PLAIN && !needle && !ctx->knobs.no_fused_walk;
   if (fused_walk) { a.walk_ops = d_ops; a.walk_ops_off = d_ops_off; a.walk_ops_len = d_ops_len; }
-  a.screen = ctx->no_screen ? 0 : 1;
+  a.screen = ctx->knobs.no_screen ? 0 : 1;
   a.colcode = pb.d_colclass;
-  if (pb.mode == MODE_QP && pb.d_a2 == ctx->codes() && !ctx->no_compact) a.special_blocks = ctx->special_blocks();
-  if (pb.mode == MODE_CQ && !ctx->no_compact) a.special_blocks = pb.d_special;
+  if (pb.mode == MODE_QP && pb.d_a2 == ctx->codes() && !ctx->knobs.no_compact) a.special_blocks = ctx->special_blocks();
+  if (pb.mode == MODE_CQ && !ctx->knobs.no_compact) a.special_blocks = pb.d_special;
   if (stage == DP_BAND && ctx->timing) {
     a.swept = reinterpret_cast<unsigned long long*>(static_cast<int32_t*>(ctx->d_err.p) + kErrSweptWord);
     HIP_TRY(hipMemsetAsync(a.swept, 0, sizeof(unsigned long long), st));
@@ -606,7 +665,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
                                      : trace ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_SCORE, cells, bytes))) return trc;
       }
       bool narrow = false;
-      if (!needle && !trace && (pb.mode == MODE_QP || pb.mode == MODE_CHAR) && !ctx->no_narrow) {
+      if (!needle && !trace && (pb.mode == MODE_QP || pb.mode == MODE_CHAR) && !ctx->knobs.no_narrow) {
         uint32_t maxm = 0;
         for (uint32_t q = j; q < e; ++q) maxm = std::max(maxm, hd[q].m);
         narrow = narrow_ok(prm, maxm, K);
@@ -631,7 +690,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
         HIP_TRY(launch_band_trace(pb.mode, K, a, wa, e - j, st));
       } else if (!needle && pb.mode == MODE_PROF) {
         bool a16 = false;
-        if (!trace && !ctx->no_narrow) {
+        if (!trace && !ctx->knobs.no_narrow) {
           uint64_t mn = 0;
           for (uint32_t q = j; q < e; ++q) mn = std::max<uint64_t>(mn, (uint64_t)hd[q].m + hd[q].n);
           if ((a16 = arith16_ok(prm, mn, 0))) narrow_launches.emplace_back((uint32_t)mn, 0);
@@ -663,7 +722,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   unsigned long long h_swept = 0;
   HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
   if (a.swept) HIP_TRY(hipMemcpyAsync(&h_swept, a.swept, sizeof(h_swept), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(ctx_sync(ctx));
   timing_collect(ctx);
   if (a.swept) {  // the band timer reports the cells it really evaluated, not the matrices it stands in for
     ctx->acc[TRACYHIP_TIMER_BAND].cells -= std::min<uint64_t>(ctx->acc[TRACYHIP_TIMER_BAND].cells, band_cells_credited);
@@ -673,30 +732,21 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   if (stage == DP_ORIGIN && pb.mode == MODE_QP && herr[1] > sub_limit(prm)) return kWiden;
   const int verdict = range_verdict(prm, herr, narrow_launches, max_mn, trace ? (needle ? 2 : kTagShift) : 0);
   if (verdict == kWiden && stage == DP_PLAIN) {  // the 16-bit score kernel met an un-normalised profile: same work on the int32 kernel
-    const bool keep = ctx->no_narrow;
-    ctx->no_narrow = true;
+    const bool keep = ctx->knobs.no_narrow;
+    ctx->knobs.no_narrow = true;
     const int rc = run_dp(ctx, pb, prm, needle, trace, d_scores, d_ops, d_ops_off, d_ops_len, stage, ck);
-    ctx->no_narrow = keep;
+    ctx->knobs.no_narrow = keep;
     return rc;
   }
   return verdict;  // DP_CKPT / DP_PREFIX: kWiden goes to the pipeline, which restarts its orientation stage on the int32 kernels
 }
 
 // ---- band kernels (band16.h) ----------------------------------------------------------------------------------------
-int band16_pick_k(int32_t dmin, int32_t dmax) {
-  if (dmax < dmin) return 0;
-  for (int K : {4, 8, 12})
-    if (b16_window(K, dmin, dmax) <= b16_max_window(K)) return K;
-  return 0;
-}
+int band16_pick_k(int32_t dmin, int32_t dmax) { return b16_pick_k(dmin, dmax); }
 
 bool origin16_ok(const tracyhip_params* prm, uint32_t maxm, uint32_t maxn) {
-  if (!prm->hfree || prm->vfree || prm->go > 0 || prm->ge >= 0) return false;
-  if ((uint64_t)maxn + 64 >= (1u << kOriginBits)) return false;
-  const int64_t rows = maxm;
-  const int64_t low = iabs64(prm->go) + rows * iabs64(prm->ge) + 2 * (iabs64(prm->go) + iabs64(prm->ge)) + iabs64(prm->mismatch) + iabs64(prm->match);
-  const int64_t high = rows * sub_limit(prm);
-  return (low < -(int64_t)kNegInfOrigin - 16 * iabs64(prm->ge) - 64) && (-(int64_t)kNegInfOrigin + iabs64(prm->go) + 16 * iabs64(prm->ge) < 8000) && (high < 8000);
+  if (!prm->hfree || prm->vfree) return false;
+  return b16_origin_ok(prm->match, prm->mismatch, prm->go, prm->ge, maxm, maxn);
 }
 
 int build_b16_tables(tracyhip_ctx* ctx, DevBuf& buf, const void* d_a1, bool strings, std::vector<B16TableDesc>& desc, const tracyhip_params* prm) {
@@ -930,7 +980,7 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
   }
   int32_t herr[kErrWords] = {};
   HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(ctx_sync(ctx));
   timing_collect(ctx);
   if (herr[0] & 1) return set_error(TRACYHIP_ERR_RANGE, "a query-profile score does not fit the int16 table (profile values too large)");
   if (herr[1] > sub_limit(prm)) return kWiden;  // un-normalised profile: the band kernels' fields are sized for normalised ones
@@ -1032,7 +1082,7 @@ static int run_front_once(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, c
   HIP_TRY(hipMemcpyAsync(out.score.data(), d_fs, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(h_fe.data(), d_fe, sizeof(uint32_t) * 2 * nf, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(ctx_sync(ctx));
   timing_collect(ctx);
   if (herr[0] & 1) return set_error(TRACYHIP_ERR_RANGE, "a query-profile score does not fit the int16 table (profile values too large)");
   for (size_t i = 0; i < nf; ++i) out.ce[i] = h_fe[2 * i + 1] ? h_fe[2 * i + 1] + out.fo[i].shift : 0u;
@@ -1099,7 +1149,7 @@ int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool 
     HIP_TRY(hipMemcpyAsync(dd, hd.data(), sizeof(Row4Desc) * hd.size(), hipMemcpyHostToDevice, ctx->stream));
     // column classes of the a2 set for the screened substitution score (one byte per float of the set: indexed like row 0)
     uint8_t* colclass = nullptr;
-    if (n2 && e2 && !ctx->no_screen) {
+    if (n2 && e2 && !ctx->knobs.no_screen) {
       HIP_TRY(ctx->ensure_codes(e2, ctx->stream));
       colclass = ctx->codes();
       pb.d_colclass = colclass;
@@ -1109,7 +1159,7 @@ int build_problem(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int mem, bool 
     HIP_TRY(hipGetLastError());
     std::vector<uint8_t> hz(n1 + n2);
     HIP_TRY(hipMemcpyAsync(hz.data(), dz, hz.size(), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx_sync(ctx));
     z1.assign(hz.begin(), hz.begin() + n1);
     z2.assign(hz.begin() + n1, hz.end());
   }
@@ -1193,7 +1243,7 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   a.a1 = d_a1; a.a2 = d_a2; a.scores = d_scores; a.err = static_cast<int32_t*>(ctx->d_err.p);
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge; a.hfree = prm->hfree; a.vfree = prm->vfree;
   a.qlimit = sub_limit(prm);
-  if (d_a2 == ctx->codes() && !ctx->no_compact) a.special_blocks = ctx->special_blocks();
+  if (d_a2 == ctx->codes() && !ctx->knobs.no_compact) a.special_blocks = ctx->special_blocks();
   a.ckpt = ck->d_ckpt; a.lastrow = ck->d_lastrow; a.ckpt_B = ck->B; a.ckpt_narrow = 1;
   DpArgs ap = a;
   ap.pairs = static_cast<const PairDesc*>(ctx->d_desc.p) + nf;
@@ -1229,7 +1279,7 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   }
   int32_t herr[kErrWords] = {};
   HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(herr), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(ctx_sync(ctx));
   timing_collect(ctx);
   return range_verdict(prm, herr, narrow_launches, max_mn, 0);  // kWiden: the pipeline restarts on the int32 kernels
 }
@@ -1269,13 +1319,12 @@ int tracyhip_create(int device, tracyhip_ctx** out) {
   HIP_TRY(hipSetDevice(device));
   // The pipelines build megabytes of descriptors between two launches (72 bytes per trace and stage) in vectors that live for one
   // stage.  Above glibc's mmap threshold every such vector is mapped and unmapped anew -- a page fault per 4 KB, tens of milliseconds
-  // per 100 000-trace step, and whether the allocator does it varies from process to process.  Keep blocks of up to 32 MB on the
-  // heap and the heap's top untrimmed (process-wide, set once; TRACYHIP_NO_MALLOPT=1 leaves the allocator alone).
-  static const bool malloc_tuned = []() {
-    if (getenv("TRACYHIP_NO_MALLOPT")) return false;
-    mallopt(M_MMAP_THRESHOLD, 32 << 20);
-    mallopt(M_TRIM_THRESHOLD, 1 << 30);
-    mallopt(M_TOP_PAD, 64 << 20);
+  // per 100 000-trace step, and whether the allocator does it varies from process to process.  tracyhip_tune_host_allocator() keeps
+  // blocks of up to 32 MB on the heap and the heap's top untrimmed; it is process-wide and therefore the application's to call
+  // (the CLI and bench.py do; TRACYHIP_MALLOPT=1 does it here).  The stream-ordered pipelines build no such vectors.
+  static const bool malloc_tuned = []() {  // opt-in (process-wide): tracyhip_tune_host_allocator()
+    const char* e = getenv("TRACYHIP_MALLOPT");
+    if (e && atoi(e) != 0) tracyhip_tune_host_allocator();
     return true;
   }();
   (void)malloc_tuned;
@@ -1287,9 +1336,7 @@ int tracyhip_create(int device, tracyhip_ctx** out) {
     return set_error(TRACYHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
   }
   c->own_stream = c->stream;
-  c->no_narrow = getenv("TRACYHIP_NO_NARROW") != nullptr;
-  c->no_screen = getenv("TRACYHIP_NO_SCREEN") != nullptr;
-  c->no_compact = getenv("TRACYHIP_NO_COMPACT") != nullptr;
+  knobs_from_env(c->knobs);
   *out = c;
   return TRACYHIP_OK;
 }
@@ -1313,6 +1360,46 @@ int tracyhip_destroy(tracyhip_ctx* c) {
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+  return TRACYHIP_OK;
+}
+
+int tracyhip_set_option(tracyhip_ctx* c, const char* name, const char* value) {
+  if (!c || !name || !value) return set_error(TRACYHIP_ERR_ARG, "null context / name / value");
+  if (!knobs_set(c->knobs, name, value)) return set_error(TRACYHIP_ERR_ARG, "unknown option or bad value: %s=%s", name, value);
+  for (auto* l : c->lanes) l->knobs = c->knobs;
+  return TRACYHIP_OK;
+}
+int tracyhip_describe(tracyhip_ctx* c, char* buf, size_t cap) {
+  if (!c) return set_error(TRACYHIP_ERR_ARG, "null context");
+  const std::string s = knobs_describe(c->knobs) + "device=" + std::to_string(c->device) + "\nlanes=" + std::to_string(c->lanes.size() + 1) +
+                        "\nworkspace_limit=" + std::to_string(c->ws_limit) + "\n";
+  if (buf && cap) {
+    const size_t n = std::min(cap - 1, s.size());
+    std::memcpy(buf, s.data(), n);
+    buf[n] = 0;
+  }
+  return (int)s.size() + 1;
+}
+int tracyhip_tune_host_allocator(void) {
+  static const bool once = []() {
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
+    return true;
+  }();
+  (void)once;
+  return TRACYHIP_OK;
+}
+int tracyhip_last_call_stats(tracyhip_ctx* c, tracyhip_call_stats* out) {
+  if (!c || !out) return set_error(TRACYHIP_ERR_ARG, "null context / out");
+  *out = c->stats;
+  for (auto* l : c->lanes) {  // (a call split over lanes: every lane counted its chunk)
+    const uint32_t* a = reinterpret_cast<const uint32_t*>(&l->stats);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out);
+    for (size_t i = 0; i < sizeof(tracyhip_call_stats) / sizeof(uint32_t); ++i)
+      if (i != offsetof(tracyhip_call_stats, stream_ordered) / sizeof(uint32_t)) o[i] += a[i];
+      else o[i] = o[i] && a[i];
+  }
   return TRACYHIP_OK;
 }
 
@@ -1341,9 +1428,7 @@ int tracyhip_set_lanes(tracyhip_ctx* c, uint32_t n) {
     if ((rc = tracyhip_create(c->device, &l))) return rc;
     l->ws_limit = c->ws_limit;
     l->timing = c->timing;
-    l->no_narrow = c->no_narrow;
-    l->no_screen = c->no_screen;
-    l->no_compact = c->no_compact;
+    l->knobs = c->knobs;
     c->lanes.push_back(l);
   }
   return TRACYHIP_OK;
@@ -1460,7 +1545,7 @@ static int dp_entry(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyh
       if (ops_total) HIP_TRY(hipMemcpyAsync(ops, d_ops, ops_total, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(ops_len, d_len, sizeof(uint32_t) * (size_t)np, hipMemcpyDeviceToHost, st));
     }
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(ctx_sync(ctx));
   }
   return TRACYHIP_OK;
 }
@@ -1557,7 +1642,7 @@ int tracyhip_gotoh_banded(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const 
       if (ops_total) HIP_TRY(hipMemcpyAsync(ops, d_ops, ops_total, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(ops_len, d_len, sizeof(uint32_t) * (size_t)np, hipMemcpyDeviceToHost, st));
     }
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(ctx_sync(ctx));
   }
   return TRACYHIP_OK;
 }
@@ -1642,7 +1727,7 @@ int tracyhip_alignment_rows(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, int 
     HIP_TRY(hipMemcpyAsync(rows0, ra.rows0, total, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(rows1, ra.rows1, total, hipMemcpyDeviceToHost, st));
   }
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(ctx_sync(ctx));
   return TRACYHIP_OK;
 }
 

@@ -36,6 +36,34 @@ struct PinBuf {  // grow-only pinned host buffer (descriptor uploads)
 
 int set_error(int code, const char* fmt, ...);
 
+// Every switch of the library in one place.  Read from the environment ONCE, when a context is created (TRACYHIP_<NAME IN CAPITALS>),
+// changed afterwards only through tracyhip_set_option(ctx, "<name>", "<value>"); tracyhip_describe() prints them.  Every one selects
+// another exact path (A/B measurements, tests of the fallback tiers); none changes a result.  Lanes inherit their context's.
+struct CtxKnobs {
+  bool no_stream = false;         // pipelines planned by the host between launches (the pre-round-4 form) instead of stream-ordered
+  bool no_narrow = false;         // int32 score kernels instead of the 16-bit sweeps
+  bool no_compact = false;        // every 16-bit sweep on the six-code table
+  bool no_screen = false;         // profile x profile scores by the full float chain only
+  bool no_band = false;           // no checkpointed score pass / band traceback: whole-matrix tracebacks
+  bool no_band16 = false;         // no band kernels (band16.h)
+  bool no_front = false;          // no pruned sweeps (front.h)
+  bool no_prefix = false;         // no prefix bounds (strand by certificate, pruned sweeps)
+  bool no_vote = false;           // no k-mer orientation vote
+  bool no_origin = false;         // allele-vs-window alignments by full traceback instead of the origin-tracking sweep
+  bool no_subwindow = false;      // origin sweeps over the whole window
+  bool no_prelim_origin = false;  // preliminary alignment of `tracy align` by band traceback instead of its two ends
+  bool no_cq = false;             // string x string by byte compare instead of the query-profile table
+  bool no_fused_walk = false;     // a separate walk launch after a traceback sweep
+  bool verbose = false;           // one line per pipeline stage on stderr: how many pairs took which tier (TRACYHIP_HOST_TIMERS sets it too)
+  int32_t band_w = -1;            // half width of the certified band of the final alignments: -1 = from the preliminary alignment (default),
+                                  // 0 = whole matrices, else [1, 4096]
+  uint32_t ckpt_b = 256;          // steps between wavefront checkpoints [32, 1024]
+};
+void knobs_from_env(CtxKnobs& k);
+// name without the TRACYHIP_ prefix, any case; false: no such option / bad value
+bool knobs_set(CtxKnobs& k, const char* name, const char* value);
+std::string knobs_describe(const CtxKnobs& k);
+
 // Reference codes (MODE_QP a2) live in ctx->d_codes with tracyhip::kCodePad spare bytes on both sides: the sweep kernels
 // prefetch the column two steps ahead of every lane without clamping it, so idle lanes read up to 64 + 3 bytes
 // before the first / behind the last base of a sequence (any byte value is a valid table row selector).
@@ -79,6 +107,7 @@ struct tracyhip_ctx {
   tracyhip::DevBuf d_b16tab[4], d_b16desc;     // substitution tables of the band kernels (band16.h), their descriptors
   tracyhip::DevBuf d_front;                    // descriptors / pairs / results of the pruned orientation sweep (front.h)
   tracyhip::DevBuf d_pre;                      // descriptors of its prefix launch over string x code pairs (run_prefix_keep_cq)
+  tracyhip::DevBuf d_stream;                   // everything the stream-ordered pipelines keep on the device between their stages (stream.hip)
   hipError_t ensure_codes(size_t bytes, hipStream_t st) {
     hipError_t e = d_codes.ensure(bytes + 2 * tracyhip::kCodePad);
     if (e != hipSuccess) return e;
@@ -102,9 +131,8 @@ struct tracyhip_ctx {
   std::vector<tracyhip_ctx*> lanes;
   uint32_t mem_share = 1;  // contexts planning workspace on this device at the same time (lanes of one call): each takes its share of what is free
   bool timing = false;
-  bool no_narrow = false;  // TRACYHIP_NO_NARROW=1: force the int32 score kernel (A/B measurements)
-  bool no_compact = false; // TRACYHIP_NO_COMPACT=1: every 16-bit sweep on the six-code table (A/B measurements)
-  bool no_screen = false;  // TRACYHIP_NO_SCREEN=1: profile x profile scores by the full float chain only (A/B measurements)
+  tracyhip::CtxKnobs knobs;  // (the fields below it used to be: no_narrow, no_compact, no_screen)
+  tracyhip_call_stats stats = {};  // tiers of the last pipeline call (tracyhip_last_call_stats)
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
   tracyhip_kernel_timing acc[TRACYHIP_TIMER_COUNT] = {};
@@ -132,6 +160,7 @@ struct tracyhip_ctx {
     d_b16desc.release();
     d_front.release();
     d_pre.release();
+    d_stream.release();
     h_desc.release();
     h_off.release();
     h_tmp.release();
@@ -201,6 +230,8 @@ int timing_begin(tracyhip_ctx* ctx, int which, uint64_t cells, uint64_t bytes); 
 int timing_end(tracyhip_ctx* ctx);                                              // record stop event
 int timing_collect(tracyhip_ctx* ctx);                                          // after a stream sync
 int ctx_begin(tracyhip_ctx* ctx);
+// hipStreamSynchronize(ctx->stream), counted in tracyhip_call_stats::host_syncs
+inline hipError_t ctx_sync(tracyhip_ctx* ctx) { ctx->stats.host_syncs += 1; return hipStreamSynchronize(ctx->stream); }
 int async_submit(tracyhip_ctx* ctx, std::function<int()> fn);  // queue a call on the context's worker thread
 int async_drain(tracyhip_ctx* ctx);                           // wait for the queue; returns (and clears) the first error
 int stage_in(tracyhip_ctx* ctx, DevBuf& buf, const void* src, uint64_t bytes, int mem, const void** dev);

@@ -82,6 +82,8 @@ struct DecompArgs {
   DecompParams prm;
   uint32_t ntraces;
   const uint32_t* lens;  // alignment columns per trace where they are still on the device (overrides DecompDesc::L), or null
+  const uint32_t* skip;  // or null: traces with a non-zero word are left alone (stream.hip: their alignment was not certified, the
+                         // host-planned tiers redo them from the untouched basecalls)
 };
 
 constexpr int kMaxIndelDev = 1024;  // maxindel handled in LDS (CLI default 1000)

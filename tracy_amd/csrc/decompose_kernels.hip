@@ -42,6 +42,7 @@ __global__ __launch_bounds__(64) void decompose_kernel(DecompArgs a, const Break
   extern __shared__ __attribute__((aligned(16))) char decomp_smem[];  // dynamic: the MAXI = 4096 state (80 KB) exceeds the static limit
   DecompSharedT<MAXI>& sh = *reinterpret_cast<DecompSharedT<MAXI>*>(decomp_smem);
   const uint32_t t = blockIdx.x;
+  if (a.skip && a.skip[t]) return;
   DecompDesc d = a.desc[t];
   d.breakpoint = bps[t].breakpoint;
   if (a.lens) d.L = a.lens[t];
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(64) void decompose_kernel_global(DecompArgs a, cons
   DecompSharedT<kMaxIndelGlobal>& sh = *reinterpret_cast<DecompSharedT<kMaxIndelGlobal>*>(state + (size_t)blockIdx.x * sizeof(DecompSharedT<kMaxIndelGlobal>));
   const uint32_t lane = threadIdx.x;
   for (uint32_t t = blockIdx.x; t < a.ntraces; t += gridDim.x) {
+    if (a.skip && a.skip[t]) continue;
     DecompDesc d = a.desc[t];
     d.breakpoint = bps[t].breakpoint;
     if (a.lens) d.L = a.lens[t];

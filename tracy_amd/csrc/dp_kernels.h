@@ -42,6 +42,8 @@ enum : uint32_t {
                          // result (pipeline.hip, final alignments) and repeats the pair without the flag otherwise.
   PAIR_KEEP_ROW = 8u,    // prefix-bound kernel: leave row R of the prefix behind -- one dword per column c at lastrow[lastrow_off + c],
                          // low half H(R, c) + (go + ge), high half F(R, c) -- for the band kernels to continue from (band16.h)
+  PAIR_SKIP = 16u,       // an empty slot of a list laid out on the device (stream.hip): the 16-bit sweeps, the prefix kernels and the
+                         // band kernels leave at once and write nothing
 };
 
 // one DP problem; lives in device memory, built on the host
@@ -829,6 +831,7 @@ TR_HD int32_t lastrow_e(const int32_t* lr, uint32_t c, bool narrow, int32_t goe)
 template <class W, int K, bool CKPT, bool COMPACT, bool STRINGS>
 TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const PairDesc d = a.pairs[pair_idx];
+  if (d.flags & PAIR_SKIP) return;
   // both forms of the kernel are launched over the same pairs; each pair is swept by the one its reference calls for
   if (reference_is_plain(w, a, d) != COMPACT) return;
   const uint32_t L = w.lane();
@@ -1242,6 +1245,7 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
   bool valid = pair_idx < npairs;
   PairDesc d{};
   if (valid) d = a.pairs[pair_idx];
+  valid = valid && !(d.flags & PAIR_SKIP);
   {
     bool plain = a.special_blocks != nullptr;  // every lane of a group looks at its pair's blocks: the same answer in all of them
     if (plain && valid && d.n)

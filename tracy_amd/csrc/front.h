@@ -31,7 +31,7 @@ struct FrontDesc {
   uint32_t tab_stride;  // rows per code of that table
   uint32_t m_rest;      // rows below R
   uint32_t n;           // columns of the window
-  uint32_t flags;       // PAIR_A2_REVCOMP
+  uint32_t flags;       // PAIR_A2_REVCOMP; PAIR_SKIP: an empty slot (front_place leaves a PAIR_SKIP pair behind, front_certify ok = 0)
   uint32_t out;         // index of the pair's outputs
   uint32_t R;           // rows of the prefix
   int32_t rest;         // sum over the rows > R of max(0, best substitution score of the row)
@@ -54,6 +54,16 @@ TR_HD int32_t front_v(uint32_t x, int32_t goe) {
 template <class W>
 TR_HD void front_place_body(W& w, const FrontDesc& f, const uint32_t* row, int32_t goe, int32_t halfw, PairDesc* pair, FrontOut* fo) {
   const uint32_t L = w.lane();
+  if (f.flags & PAIR_SKIP) {
+    if (L == 0) {
+      PairDesc d{};
+      d.flags = PAIR_SKIP;
+      d.out = f.out;
+      *pair = d;
+      *fo = FrontOut{0, 0u, 0u, 0u};
+    }
+    return;
+  }
   const uint32_t* r = row + f.row_off;
   int32_t best = INT32_MIN;
   uint32_t bc = 0;
@@ -98,6 +108,7 @@ template <class W>
 TR_HD void front_certify_body(W& w, const FrontDesc& f, const uint32_t* row, int32_t go, int32_t ge, int32_t halfw, int32_t score, uint32_t c_end,
                               FrontOut* fo) {
   const uint32_t L = w.lane();
+  if (f.flags & PAIR_SKIP) return;  // (front_place left ok = 0)
   const uint32_t* r = row + f.row_off;
   const int32_t goe = go + ge;
   const int64_t age = -(int64_t)ge;

@@ -14,6 +14,8 @@
 #include "../../include/tracy_hip.h"
 #include "capi_internal.h"
 #include "launch.h"
+#include "pipe_internal.h"
+#include "pipe_kernels.h"
 
 using namespace tracyhip;
 
@@ -26,335 +28,22 @@ using namespace tracyhip;
   } while (0)
 
 namespace {
+void reset_call_stats(tracyhip_ctx* ctx, uint32_t ntraces) {
+  ctx->stats = tracyhip_call_stats{};
+  ctx->stats.traces = ntraces;
+  for (auto* l : ctx->lanes) l->stats = tracyhip_call_stats{};
+}
 struct StageClock {  // TRACYHIP_HOST_TIMERS: wall time from one mark to the next, by label
   HostScope* cur = nullptr;
   void mark(const char* label) { delete cur; cur = new HostScope(label); }
   ~StageClock() { delete cur; }
 };
 
-struct TrimOut {
-  uint32_t ri;       // offset of the trimmed slice in the oriented reference
-  uint32_t len;      // its length after std::string::substr clamping
-  uint32_t pos;      // rs.pos after the update (rs.pos starts at 0)
-  uint32_t pad;
-};
-
-// the widening / clamping / rs.pos part of trimReferenceSlice (fmindex.h:443-461)
-__device__ inline TrimOut trim_finish(uint32_t ri, uint32_t risize, uint32_t n, uint32_t trim_left, uint32_t trim_right, bool forward) {
-  if (ri >= trim_left) { ri -= trim_left; risize += trim_left; }
-  if ((uint32_t)(ri + risize + trim_right) < n) risize += trim_right;
-  TrimOut r;
-  r.ri = ri;
-  r.len = (ri <= n) ? ((risize < n - ri) ? risize : n - ri) : 0;  // substr(ri, risize)
-  r.pos = 0;
-  if (forward) r.pos = ri;
-  else {
-    const int32_t offset = (int32_t)n - (int32_t)ri - (int32_t)risize;
-    if (offset >= 0) r.pos = (uint32_t)offset;  // negative: the reference only warns (fmindex.h:457-459)
-  }
-  r.pad = 0;
-  return r;
-}
-
-// trimReferenceSlice (fmindex.h:429-463) evaluated directly on the traceback string.  ops are in push
-// order (end -> start); alignment column j (forward) is ops[L-1-j].  Row 0 holds a trace base unless
-// the op is 'h', row 1 holds a reference base unless the op is 'v' (align.h:204-214).
-// The reference scans for s = first column with a trace base and e = last such column + 1, then counts
-// reference bases before s (ri) and inside [s, e) (risize).  Every column before s and from e on is an
-// 'h' (a reference base), and the alignment consumes all n reference bases, so ri = s and
-// risize = n - s - (L - e): only the two ends of the string have to be looked at.  One wave per trace.
-__global__ __launch_bounds__(64) void trim_kernel(const uint8_t* __restrict__ ops, const uint64_t* __restrict__ ops_off,
-                                                  const uint32_t* __restrict__ ops_len, const uint32_t* __restrict__ ref_len,
-                                                  const uint8_t* __restrict__ forward, uint32_t trim_left,
-                                                  uint32_t trim_right, uint32_t ntraces, TrimOut* __restrict__ out) {
-  const uint32_t t = blockIdx.x;
-  if (t >= ntraces) return;
-  const uint8_t* o = ops + ops_off[t];
-  const uint32_t L = ops_len[t];
-  const uint32_t lane = threadIdx.x;
-  // s: first forward column that is not 'h'  <=>  scanning the push-order string from its end
-  int32_t s = -1, e = -1;
-  for (uint32_t base = 0; base < L; base += 64) {
-    const uint32_t j = base + lane;
-    const bool hit = (j < L) && (o[L - 1 - j] != 'h');
-    const unsigned long long m = __ballot(hit);
-    if (m) { s = (int32_t)(base + (uint32_t)__builtin_ctzll(m)); break; }
-  }
-  if (s >= 0) {  // e: last forward column that is not 'h', + 1  <=>  scanning the push-order string from its start
-    for (uint32_t base = 0; base < L; base += 64) {
-      const uint32_t q = base + lane;  // push-order index q <-> forward column L-1-q
-      const bool hit = (q < L) && (o[q] != 'h');
-      const unsigned long long m = __ballot(hit);
-      if (m) { e = (int32_t)(L - (base + (uint32_t)__builtin_ctzll(m))); break; }
-    }
-  }
-  if (lane != 0) return;
-  const uint32_t n = ref_len[t];
-  uint32_t ri, risize;
-  if (s < 0) {  // no trace base at all: every column counts towards ri (fmindex.h:435-441), the span is empty
-    uint32_t cnt = 0;
-    for (uint32_t j = 0; j < L; ++j) cnt += (o[j] != 'v');
-    ri = cnt;
-    risize = 0;
-  } else {
-    ri = (uint32_t)s;
-    // reference bases inside [s, e): all n bases minus the leading s columns and the trailing L - e columns
-    uint32_t inside = 0;
-    const uint32_t lead = (uint32_t)s, trail = L - (uint32_t)e;
-    // columns before s and from e on are 'h' only when the string really is a complete alignment; count exactly
-    // when the totals do not add up (defensive: degenerate inputs)
-    uint32_t refcols = 0;
-    if (lead + trail <= n) inside = n - lead - trail;
-    else { for (int32_t j = s; j < e; ++j) refcols += (o[L - 1 - j] != 'v'); inside = refcols; }
-    risize = inside;
-  }
-  out[t] = trim_finish(ri, risize, n, trim_left, trim_right, forward[t] != 0);
-}
-
-// trimReferenceSlice from the two ends of the alignment alone (origin-tracking sweep, dp_kernels.h gotoh_origin_body):
-// ends[2t] = leading 'h' columns, ends[2t+1] = last column that is not a trailing 'h'; every reference base in between
-// belongs to the slice.
-__global__ void trim_from_ends_kernel(const uint32_t* __restrict__ ends, const uint32_t* __restrict__ ref_len,
-                                      const uint8_t* __restrict__ forward, uint32_t trim_left, uint32_t trim_right, uint32_t ntraces,
-                                      TrimOut* __restrict__ out) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ntraces) return;
-  const uint32_t lead = ends[2 * t], ce = ends[2 * t + 1];
-  out[t] = trim_finish(lead, ce >= lead ? ce - lead : 0u, ref_len[t], trim_left, trim_right, forward[t] != 0);
-}
-
-// c_e of a pair from the row-m values the 16-bit sweep left behind ({H, E - goe} per column): the last column whose H(m, c) is
-// strictly greater than E(m, c) -- where the reference's traceback leaves the trailing run of row m.  One wave per pair.
-struct RowEndDesc { uint64_t off; uint32_t n, pad; };
-__global__ __launch_bounds__(64) void row_m_end_kernel(const RowEndDesc* __restrict__ desc, const int32_t* __restrict__ lastrow, int32_t goe,
-                                                       uint32_t* __restrict__ ce) {
-  const RowEndDesc d = desc[blockIdx.x];
-  const int32_t* lr = lastrow + d.off;
-  uint32_t found = 0;
-  for (int64_t base = d.n; base >= 1 && !found; base -= 64) {
-    const int64_t c = base - threadIdx.x;
-    bool hit = false;
-    if (c >= 1) { const int32_t v = lr[c]; hit = sext16(v) > (v >> 16) + goe; }
-    const unsigned long long mask = __ballot(hit);
-    if (mask) found = (uint32_t)(base - __builtin_ctzll(mask));  // lane 0 holds the largest column
-  }
-  if (threadIdx.x == 0) ce[blockIdx.x] = found;
-}
-__global__ void ends_shift_kernel(uint32_t* __restrict__ ends, const uint32_t* __restrict__ shift, uint32_t ntraces) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < ntraces) { ends[2 * t] += shift[t]; ends[2 * t + 1] += shift[t]; }
-}
-
-// trimReferenceSlice (fmindex.h:429-463) on the two alignment rows themselves, as the reference scans them: s / e = first / last + 1
-// column holding a trace base, ri = reference bases before s, risize = reference bases in [s, e).  One wave per trace.
-struct TrimRowsDesc { uint64_t off; uint32_t L, n; uint8_t forward, pad[7]; };
-__global__ __launch_bounds__(64) void trim_rows_kernel(const TrimRowsDesc* __restrict__ desc, const uint8_t* __restrict__ rows0,
-                                                       const uint8_t* __restrict__ rows1, uint32_t trim_left, uint32_t trim_right,
-                                                       uint32_t ntraces, TrimOut* __restrict__ out) {
-  const uint32_t t = blockIdx.x;
-  if (t >= ntraces) return;
-  const TrimRowsDesc d = desc[t];
-  const uint8_t* r0 = rows0 + d.off;
-  const uint8_t* r1 = rows1 + d.off;
-  const uint32_t lane = threadIdx.x, L = d.L;
-  int32_t s = -1, e = -1;
-  uint32_t ri = 0;
-  for (uint32_t base = 0; base < L && s < 0; base += 64) {  // first column with a trace base; reference bases before it
-    const uint32_t j = base + lane;
-    const bool tb = (j < L) && (r0[j] != '-');
-    const bool rb = (j < L) && (r1[j] != '-');
-    const unsigned long long mt = __ballot(tb), mr = __ballot(rb);
-    if (mt) {
-      const uint32_t first = (uint32_t)__builtin_ctzll(mt);
-      s = (int32_t)(base + first);
-      ri += (uint32_t)__popcll(mr & ((1ull << first) - 1ull));
-    } else {
-      ri += (uint32_t)__popcll(mr);
-    }
-  }
-  uint32_t risize = 0;
-  if (s >= 0) {
-    for (uint32_t base = 0; base < L; base += 64) {  // last column with a trace base, scanning from the end
-      const uint32_t q = base + lane;
-      const bool tb = (q < L) && (r0[L - 1 - q] != '-');
-      const unsigned long long m = __ballot(tb);
-      if (m) { e = (int32_t)(L - (base + (uint32_t)__builtin_ctzll(m))); break; }
-    }
-    for (uint32_t base = (uint32_t)s; base < (uint32_t)e; base += 64) {
-      const uint32_t j = base + lane;
-      risize += (uint32_t)__popcll(__ballot(j < (uint32_t)e && r1[j] != '-'));
-    }
-  }
-  if (lane == 0) out[t] = trim_finish(ri, risize, d.n, trim_left, trim_right, d.forward != 0);
-}
-
-// (loadSingleFasta hands over upper-case [ACGTN] only (fasta.h:54-95); anything else makes the string and profile reverse
-// complements (fmindex.h:8-24 vs profile.h:74-90) disagree, so it is rejected: encode_codes_kernel's verr.)
-
-// upper bound for what rows [first, m) of a trimmed profile view can still add to a semiglobal score: every row
-// adds at most max(0, its best one-hot substitution score) (gaps cost <= 0 when go <= 0 and ge < 0)
-struct RowMaxDesc { uint64_t off; uint32_t stride, m, first; };
-// out1 (or null): the same sum with the rows clamped at -1 instead of 0 (the allowance of front.h's second certificate)
-__global__ __launch_bounds__(64) void rowmax_rest_kernel(const RowMaxDesc* desc, const float* prof, float fmatch, float fmis, int32_t* out,
-                                                         int32_t* out1 = nullptr) {
-  const RowMaxDesc d = desc[blockIdx.x];
-  int32_t sum = 0, sum1 = 0;
-  for (uint32_t r = d.first + threadIdx.x; r < d.m; r += 64) {
-    float pr[5];
-    for (int k = 0; k < 5; ++k) pr[k] = prof[d.off + (uint64_t)k * d.stride + r];
-    int32_t best = INT32_MIN;
-    for (uint32_t b = 0; b < 5; ++b) {
-      const int32_t q = onehot_score(pr, b, fmatch, fmis);
-      best = q > best ? q : best;
-    }
-    sum += best > 0 ? best : 0;
-    sum1 += best > -1 ? best : -1;
-  }
-  for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o, 64); sum1 += __shfl_down(sum1, o, 64); }
-  if (threadIdx.x == 0) {
-    out[blockIdx.x] = sum;
-    if (out1) out1[blockIdx.x] = sum1;
-  }
-}
-
-// MODE_CQ (strings scored through the query-profile table): case-sensitive column codes, and the test that row strings hold
-// nothing but the five letters the table has entries for
-// flag |= 2 where a column is none of A C G T N, |= 4 where it is N (both rare): the origin sweeps size their table by it
-__global__ void encode_cq_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, int32_t* flag) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const uint32_t c = cq_code(in[i]);
-    out[i] = (uint8_t)c;
-    if (c >= 4u) atomicOr(flag, c >= 5u ? 2 : 4);
-  }
-}
-__global__ void cq_rows_kernel(const uint8_t* __restrict__ in, uint64_t n, int32_t* flag) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && !cq_row_char(in[i])) atomicOr(flag, 1);
-}
-
-// reference characters -> profile-row codes (align.h:121-136), sixteen bytes per thread.  special: one byte per 256 code bytes, set
-// where a block holds an N or '-' / other code.  verr (or null): |= 4 when a byte is not one of A C G T N (the validation
-// verdict, folded into the same pass).
-__device__ __forceinline__ uint32_t encode_word(uint32_t w, uint32_t cnt, bool& any_special, bool& invalid) {
-  uint32_t codes = 0;
-#pragma unroll
-  for (uint32_t j = 0; j < 4u; ++j) {
-    const uint8_t ch = (uint8_t)(w >> (8 * j));
-    // A C G T N in either case -> 0..4, '-' / anything else -> 5 (dp_code), without a branch per byte
-    const uint8_t up = ch & 0xdfu;
-    const uint32_t c = up == 'A' ? 0u : up == 'C' ? 1u : up == 'G' ? 2u : up == 'T' ? 3u : up == 'N' ? 4u : 5u;
-    if (j < cnt) {
-      invalid |= !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'N');
-      any_special |= c >= 4u;
-    }
-    codes |= c << (8 * j);
-  }
-  return codes;
-}
-__global__ __launch_bounds__(256) void encode_codes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n,
-                                                           uint8_t* __restrict__ special, int32_t* __restrict__ verr) {
-  const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u;
-  if (i0 >= n) return;
-  bool any_special = false, invalid = false;
-  if (n - i0 >= 16u) {
-    uint32_t w[4];
-    __builtin_memcpy(w, in + i0, 16);  // (unaligned: the payload may start anywhere)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = encode_word(w[q], 4u, any_special, invalid);
-    __builtin_memcpy(out + i0, w, 16);
-  } else {
-    for (uint64_t i = i0; i < n; i += 4) {
-      const uint32_t cnt = (n - i < 4u) ? (uint32_t)(n - i) : 4u;
-      uint32_t w = 0;
-      for (uint32_t j = 0; j < cnt; ++j) w |= (uint32_t)in[i + j] << (8 * j);
-      const uint32_t c = encode_word(w, cnt, any_special, invalid);
-      for (uint32_t j = 0; j < cnt; ++j) out[i + j] = (uint8_t)(c >> (8 * j));
-    }
-  }
-  if (any_special) special[i0 >> 8] = 1;  // rare; sixteen bytes from a 16-byte boundary lie in one 256-byte block
-  if (verr && invalid) atomicOr(verr, 4);
-}
-
 template <class T>
 int copy_out(tracyhip_ctx* ctx, int mem, T* user, const T* dev, size_t count) {
   if (!user || count == 0 || user == dev) return TRACYHIP_OK;
   HIP_TRY(hipMemcpyAsync(user, dev, sizeof(T) * count, mem == TRACYHIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
   return TRACYHIP_OK;
-}
-
-// Orientation vote: shared 11-mers between the trace (consensus base per profile column) and its reference window, read
-// forward and as the reverse complement.  Only a GUESS of which strand to sweep first -- the strand is decided by the
-// scores and the certificate below, a wrong or missing vote costs time, never the result.  One wave per trace; two
-// hashed bitmaps of the trace's k-mers (as they are / reverse-complemented) in LDS, the window's k-mers probe both.
-struct VoteDesc { uint64_t a1_off, a2_off; uint32_t stride, m, n, pad; };
-constexpr int kVoteK = 11;
-constexpr uint32_t kVoteBits = 1u << 16;
-constexpr uint32_t kVotePiece = 65, kVoteTile = 64 * kVotePiece;  // window positions per lane and per LDS tile
-__device__ inline uint32_t vote_hash(uint32_t kmer) { return (kmer * 0x9E3779B1u) >> 16; }
-__global__ __launch_bounds__(64) void kmer_vote_kernel(const VoteDesc* __restrict__ desc, const float* __restrict__ prof,
-                                                       const uint8_t* __restrict__ codes, uint32_t* __restrict__ votes) {
-  __shared__ uint32_t bm[2][kVoteBits / 32];
-  __shared__ uint8_t cons[1040];
-  __shared__ uint8_t win[kVoteTile + 16];
-  const VoteDesc d = desc[blockIdx.x];
-  const uint32_t lane = threadIdx.x;
-  uint32_t hf = 0, hr = 0;
-  const uint32_t m = d.m < 1024u ? d.m : 1024u;
-  if (m >= (uint32_t)kVoteK && d.n >= (uint32_t)kVoteK) {
-    for (uint32_t i = lane; i < kVoteBits / 32; i += 64) { bm[0][i] = 0; bm[1][i] = 0; }
-    for (uint32_t j = lane; j < m; j += 64) {
-      uint32_t best = 0;
-      float bv = prof[d.a1_off + j];
-      for (uint32_t k = 1; k < 4; ++k) {
-        const float v = prof[d.a1_off + (uint64_t)k * d.stride + j];
-        if (v > bv) { bv = v; best = k; }
-      }
-      cons[j] = (uint8_t)best;
-    }
-    __syncthreads();
-    constexpr uint32_t mask = (1u << (2 * kVoteK)) - 1u;
-    for (uint32_t i = lane; i + kVoteK <= m; i += 64) {
-      uint32_t f = 0, r = 0;
-      for (int j = 0; j < kVoteK; ++j) {
-        const uint32_t c = cons[i + j];
-        f = (f << 2) | c;
-        r |= (3u - c) << (2 * j);  // reverse complement: complemented bases in reverse order
-      }
-      const uint32_t h0 = vote_hash(f & mask), h1 = vote_hash(r & mask);
-      atomicOr(&bm[0][h0 >> 5], 1u << (h0 & 31));
-      atomicOr(&bm[1][h1 >> 5], 1u << (h1 & 31));
-    }
-    __syncthreads();
-    // The window goes through LDS in tiles (coalesced loads); within a tile every lane rolls over its own contiguous piece
-    // (kVoteK - 1 bases of overlap with the next piece).  Pieces of kVotePiece = 65 positions: an odd stride, so the byte
-    // reads of the 64 lanes spread over the banks.  (Rolling straight from global memory -- one dependent, uncoalesced byte
-    // load per position -- took five times as long.)
-    const uint32_t npos = d.n - kVoteK + 1;
-    for (uint32_t tile = 0; tile < npos; tile += kVoteTile) {
-      const uint32_t tn = (npos - tile < kVoteTile) ? npos - tile : kVoteTile;  // positions of this tile
-      const uint32_t nbytes = tn + kVoteK - 1;
-      __syncthreads();
-      for (uint32_t b = lane; b < nbytes; b += 64) win[b] = codes[d.a2_off + tile + b];
-      __syncthreads();
-      const uint32_t lo = lane * kVotePiece, hi = (lo + kVotePiece < tn) ? lo + kVotePiece : tn;
-      if (lo < hi) {
-        uint32_t k = 0, valid = 0;
-        for (uint32_t p = lo; p < hi + kVoteK - 1; ++p) {
-          const uint32_t c = win[p];
-          if (c < 4u) { k = ((k << 2) | c) & mask; ++valid; }
-          else valid = 0;
-          if (valid >= (uint32_t)kVoteK) {
-            const uint32_t h = vote_hash(k);
-            hf += (bm[0][h >> 5] >> (h & 31)) & 1u;
-            hr += (bm[1][h >> 5] >> (h & 31)) & 1u;
-          }
-        }
-      }
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) { hf += __shfl_down(hf, o, 64); hr += __shfl_down(hr, o, 64); }
-  if (lane == 0) { votes[2 * blockIdx.x] = hf; votes[2 * blockIdx.x + 1] = hr; }
 }
 
 // =====================================================================================================
@@ -399,6 +88,7 @@ constexpr int kNoEnds = 2;  // orient_and_align_impl: the ends path met a pair o
 int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn& in, OrientOut& o, bool force_wide, bool no_ends = false) {
   int rc;
   hipStream_t st = ctx->stream;
+  const CtxKnobs& kn = ctx->knobs;
   const uint32_t nt = in.nt;
   const void* d_prof = in.d_prof;
   const uint32_t *mf = in.mf, *mt = in.mt, *rn = in.rn;
@@ -412,17 +102,16 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   // (band traceback) instead of storing the whole traceback matrix.
   HIP_TRY(ctx->d_tmp[0].ensure(sizeof(int32_t) * 2 * (size_t)nt));
   int32_t* d_sc2 = static_cast<int32_t*>(ctx->d_tmp[0].p);
-  bool use_band = getenv("TRACYHIP_NO_BAND") == nullptr && p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore;  // hfree = 1, vfree = 0 here
+  bool use_band = !kn.no_band && p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore;  // hfree = 1, vfree = 0 here
   DpCkpt ck;
-  ck.B = 256;
-  if (const char* e = getenv("TRACYHIP_CKPT_B")) { const int b = atoi(e); if (b >= 32 && b <= 1024) ck.B = (uint32_t)b; }  // developer knob
+  ck.B = kn.ckpt_b;  // (developer knob, 256)
   // ends_path: the preliminary alignment is only trimmed from (OrientIn::ends_only).  The sweep's score S* and the end c_e of
   // the alignment on row m (row_m_end_kernel) bound where an optimal path can lie -- at most g = (Q m - S*) / |ge| horizontal
   // gap columns, so it starts no earlier than column c_e - m - g -- and an origin-tracking sweep over that sub-window (about a
   // tenth of a 10 kb window) delivers the two ends trimReferenceSlice reads: no wavefront checkpoints, no band traceback.
   // (The argument is the one of the allele alignments of `tracy decompose`)
-  const bool b16 = in.d_qp != nullptr && in.td != nullptr && in.row0 != nullptr && p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore && getenv("TRACYHIP_NO_BAND16") == nullptr;
-  const bool cert_base = !no_ends && use_band && !force_wide && !ctx->no_narrow && getenv("TRACYHIP_NO_PRELIM_ORIGIN") == nullptr;
+  const bool b16 = in.d_qp != nullptr && in.td != nullptr && in.row0 != nullptr && p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore && !kn.no_band16;
+  const bool cert_base = !no_ends && use_band && !force_wide && !kn.no_narrow && !kn.no_prelim_origin;
   bool ends_path = in.ends_only && cert_base;
   bool tb16_path = !in.ends_only && b16 && cert_base;  // traceback on the band kernels (the string is an output: `tracy decompose`)
   {
@@ -470,7 +159,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
         HIP_TRY(ctx->d_lastrow.ensure(lr_tot * 4 + 64));
         uint32_t maxmt = 0;
         for (uint32_t t = 0; t < nt; ++t) maxmt = std::max(maxmt, mt[t]);
-        ck.narrow = !force_wide && !ctx->no_narrow && narrow_ok(&p, maxmt, 16);  // conservative: the tallest strip
+        ck.narrow = !force_wide && !kn.no_narrow && narrow_ok(&p, maxmt, 16);  // conservative: the tallest strip
         ck.d_ckpt = static_cast<int32_t*>(ctx->d_ckpt.p);
         ck.d_lastrow = static_cast<int32_t*>(ctx->d_lastrow.p);
       }
@@ -516,7 +205,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   auto fetch_scores = [&]() -> int {
     HIP_TRY(hipMemcpyAsync(h_sc2.data(), d_sc2, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
     if (d_verr && !verr_fetched) HIP_TRY(hipMemcpyAsync(&h_verr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(ctx_sync(ctx));
     verr_fetched = true;
     if (h_verr & 4) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
     return TRACYHIP_OK;
@@ -526,14 +215,13 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   // stays below that score the strand is decided without ever sweeping the loser over all rows (its score array then
   // holds the bound).  Traces whose bounds are close, or whose certificate fails, get both full passes: the decision is
   // always the reference's `gsFwd > gsRev`.
-  bool use_prefix = !given && use_band && ck.narrow && !in.exact && getenv("TRACYHIP_NO_PREFIX") == nullptr;
+  bool use_prefix = !given && use_band && ck.narrow && !in.exact && !kn.no_prefix;
   // The pruned sweep of the voted strand (front.h): its prefix rows are swept over the whole window like the other strand's, the
   // rows below them only on a band around the best column of the prefix -- and the result is taken when its certificate holds.
   // `tracy align` reads the preliminary alignment by its two ends, `tracy decompose` takes its traceback from the band kernels (S*, c_e
   // are all they need); a pair of the latter whose band fails gets the full sweep of its strand after all (checkpoints for the band
   // traceback).  Exact results either way (TRACYHIP_NO_FRONT=1: off).
-  bool use_front = (ends_path || tb16_path) && b16 && !given && use_band && ck.narrow && getenv("TRACYHIP_NO_FRONT") == nullptr &&
-                   getenv("TRACYHIP_NO_PREFIX") == nullptr && getenv("TRACYHIP_NO_VOTE") == nullptr;
+  bool use_front = (ends_path || tb16_path) && b16 && !given && use_band && ck.narrow && !kn.no_front && !kn.no_prefix && !kn.no_vote;
   // traces no taller than the prefix (8K rows) have nothing left to bound: they get both full passes
   std::vector<uint8_t> elig(nt, 0);
   if (use_prefix || use_front) {
@@ -544,7 +232,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
   // With one strip height for the whole batch the strand to sweep first is voted from shared k-mers before any DP runs
   // (kmer_vote_kernel), and the prefix bounds of the other strand ride in the same launch as the full sweeps, where their
   // short workgroups fill the tail.  Undecided votes get both full sweeps.  TRACYHIP_NO_VOTE=1: the two-stage form below.
-  bool use_vote = use_prefix && getenv("TRACYHIP_NO_VOTE") == nullptr;
+  bool use_vote = use_prefix && !kn.no_vote;
   const int K0 = choose_k(mt[0], MODE_QP);
   for (uint32_t t = 0; t < nt && use_vote; ++t)
     if (choose_k(mt[t], MODE_QP) != K0) use_vote = false;  // (the pruned sweep takes any mix: its prefixes have one shape, its full sweeps
@@ -581,7 +269,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
     const int32_t* h_ub1 = reinterpret_cast<const int32_t*>(h_votes + 2 * (size_t)nt);
     HIP_TRY(hipMemcpyAsync(const_cast<int32_t*>(h_ub), d_ub, sizeof(uint32_t) * 4 * (size_t)nt, hipMemcpyDeviceToHost, st));
     if (d_verr && !verr_fetched) HIP_TRY(hipMemcpyAsync(&h_verr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(ctx_sync(ctx));
     if (d_verr) {
       verr_fetched = true;
       if (h_verr & 4) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
@@ -677,7 +365,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       if ((rr = run_stage1(what, DP_CKPT))) return rr;
       std::vector<int32_t> got(2 * (size_t)nt);
       HIP_TRY(hipMemcpyAsync(got.data(), d_sc2, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(ctx_sync(ctx));
       for (auto const& r : what) h_sc2[(size_t)r.second * nt + r.first] = got[(size_t)r.second * nt + r.first];
       return TRACYHIP_OK;
     };
@@ -693,7 +381,8 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
         retry.emplace_back(t, g);
       }
     }
-    if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "pruned orientation sweep: %zu of %u traces, %zu not certified\n", ft.size(), nt, retry.size());
+    ctx->stats.pruned += (uint32_t)ft.size(); ctx->stats.pruned_uncertified += (uint32_t)retry.size();
+    if (ctx->knobs.verbose) fprintf(stderr, "pruned orientation sweep: %zu of %u traces, %zu not certified\n", ft.size(), nt, retry.size());
     if ((rc = repeat_full(retry))) return rc;
     if (!in.exact) {  // the other strand of a clear vote holds its prefix maximum: decided by its bound, or swept in full
       retry.clear();
@@ -730,7 +419,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
     HIP_TRY(hipMemcpyAsync(h_ub.data(), d_ub, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(h_votes.data(), d_votes, sizeof(uint32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
     if (d_verr && !verr_fetched) HIP_TRY(hipMemcpyAsync(&h_verr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(ctx_sync(ctx));
     if (d_verr) {
       verr_fetched = true;
       if (h_verr & 4) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
@@ -765,7 +454,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       if ((rc = run_stage1(retry, DP_CKPT))) return rc;
       std::vector<int32_t> got(2 * (size_t)nt);
       HIP_TRY(hipMemcpyAsync(got.data(), d_sc2, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(ctx_sync(ctx));
       h_sc2 = keep;
       for (auto const& r : retry) h_sc2[(size_t)r.second * nt + r.first] = got[(size_t)r.second * nt + r.first];
     }
@@ -819,7 +508,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       if ((rc = run_stage1(retry, DP_CKPT))) return rc;
       std::vector<int32_t> got(2 * (size_t)nt);
       HIP_TRY(hipMemcpyAsync(got.data(), d_sc2, sizeof(int32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(ctx_sync(ctx));
       h_sc2 = keep;
       for (auto const& r : retry) h_sc2[(size_t)r.second * nt + r.first] = got[(size_t)r.second * nt + r.first];
     }
@@ -833,7 +522,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
     // votes itself, no host round trip); a likely loser that wins after all is swept once more, with checkpoints.
     // (Also on the ends path, where only row m is kept: the sweep of the likely loser is 2 % faster without its row-m stores,
     // which is more than the vote costs.)
-    const bool vote_ckpt = !given && use_band && ck.narrow && getenv("TRACYHIP_NO_VOTE") == nullptr;
+    const bool vote_ckpt = !given && use_band && ck.narrow && !kn.no_vote;
     std::vector<uint32_t> h_votes;
     if (vote_ckpt) {
       std::vector<VoteDesc> hv(nt);
@@ -930,7 +619,7 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
       const int32_t* h_top = reinterpret_cast<const int32_t*>(h_ce + nt);
       HIP_TRY(hipMemcpyAsync(h_ce, d_ce, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(const_cast<int32_t*>(h_top), d_top, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));  // (also: hre, hrm have been read)
+      HIP_TRY(ctx_sync(ctx));  // (also: hre, hrm have been read)
       for (uint32_t t = 0; t < nt; ++t)
         if (from_front(t)) h_ce[t] = front_ce[t];
       // A path from (0, lead) to (m, c_e) collects at most top = sum over the rows of max(0, best entry of the row's table
@@ -1031,12 +720,13 @@ int orient_and_align_impl(tracyhip_ctx* ctx, const tracyhip_params& p, const Ori
           std::vector<uint32_t> h_ol(nt);
           HIP_TRY(hipMemcpyAsync(h_sb.data(), d_sb, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
           HIP_TRY(hipMemcpyAsync(h_ol.data(), in.d_ops_len, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-          HIP_TRY(hipStreamSynchronize(st));
+          HIP_TRY(ctx_sync(ctx));
           uint32_t nfail = 0;
           const size_t nb16 = nt - rest.desc.size();
           for (uint32_t t = 0; t < nt; ++t)
             if (j16.k[t] && (h_sb[t] != h_pre[t] || h_ol[t] == 0)) { rest.desc.push_back(wholes[t]); rest.k.push_back(pb.k[t]); ++nfail; }
-          if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "preliminary alignment: %zu of %u on the band, %u repeated\n", nb16, nt, nfail);
+          ctx->stats.prelim_banded += (uint32_t)nb16; ctx->stats.prelim_repeated += nfail;
+          if (ctx->knobs.verbose) fprintf(stderr, "preliminary alignment: %zu of %u on the band, %u repeated\n", nb16, nt, nfail);
         }
         if (use_front) {  // the orientation stage of the pruned sweep leaves no wavefront checkpoints: sweep the pair's strand before its band traceback
           std::vector<std::pair<uint32_t, int>> resweep;
@@ -1074,14 +764,15 @@ int orient_and_align(tracyhip_ctx* ctx, const tracyhip_params& p, const OrientIn
 
 }  // namespace
 
-static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
-                            const tracyhip_align_result* out) {
+// what every form of the call checks first; *empty: nothing to do
+static int align_check_args(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem, const tracyhip_align_result* out, bool* empty) {
   int rc = ctx_begin(ctx);
   if (rc) return rc;
+  *empty = false;
   if (!job || !out || !prm) return set_error(TRACYHIP_ERR_ARG, "null job/result/params");
   if (mem != TRACYHIP_MEM_HOST && mem != TRACYHIP_MEM_DEVICE) return set_error(TRACYHIP_ERR_ARG, "bad mem kind");
   const uint32_t nt = job->ntraces;
-  if (nt == 0) return TRACYHIP_OK;
+  if (nt == 0) { *empty = true; return TRACYHIP_OK; }
   const tracyhip_seqset& sp = job->profiles;
   const tracyhip_seqset& sr = job->refs;
   if (sp.kind != TRACYHIP_SEQ_PROFILE || sr.kind != TRACYHIP_SEQ_CHAR) return set_error(TRACYHIP_ERR_ARG, "profiles must be PROFILE, refs CHAR");
@@ -1089,6 +780,27 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
   if (!out->score_fwd || !out->score_rev || !out->forward || !out->slice_begin || !out->slice_len || !out->ref_pos ||
       !out->score_final || !out->ops || !out->ops_offset || !out->ops_len)
     return set_error(TRACYHIP_ERR_ARG, "null result array");
+  return TRACYHIP_OK;
+}
+
+// one context, no lanes: stream-ordered where the batch has the shape for it (stream.hip), else planned by the host
+static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem, const tracyhip_align_result* out) {
+  bool empty = false;
+  int rc = align_check_args(ctx, job, prm, mem, out, &empty);
+  if (rc || empty) return rc;
+  rc = stream_align(ctx, job, prm, mem, out);
+  if (rc != kStreamNo) return rc;
+  return align_traces_legacy(ctx, job, prm, mem, out);
+}
+
+int tracyhip::align_traces_legacy(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
+                                  const tracyhip_align_result* out) {
+  bool empty = false;
+  int rc = align_check_args(ctx, job, prm, mem, out, &empty);
+  if (rc || empty) return rc;
+  const uint32_t nt = job->ntraces;
+  const tracyhip_seqset& sp = job->profiles;
+  const tracyhip_seqset& sr = job->refs;
   hipStream_t st = ctx->stream;
   tracyhip_params p = *prm;
   p.hfree = 1;  // AlignConfig<true,false> semiglobal (sage.h:165)
@@ -1152,7 +864,7 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
   // substitution tables of the full profiles for the band kernels (band16.h): the preliminary alignment (rows tl .. tl + mt) and the
   // final one (all rows) read them
   std::vector<B16TableDesc> td;
-  const bool b16 = p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore && getenv("TRACYHIP_NO_BAND16") == nullptr;
+  const bool b16 = p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore && !ctx->knobs.no_band16;
   if (b16) {
     td.resize(nt);
     for (uint32_t t = 0; t < nt; ++t) td[t] = B16TableDesc{sp.offset[t], 0, mf[t], mf[t], 0, 0};
@@ -1191,7 +903,7 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
   HIP_TRY(hipGetLastError());
   std::vector<TrimOut> h_trim(nt);
   HIP_TRY(hipMemcpyAsync(h_trim.data(), ctx->d_tmp[5].p, sizeof(TrimOut) * (size_t)nt, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(ctx_sync(ctx));
 
   // ---- 4. final alignment gotoh(full profile, profile of the trimmed slice) (sage.h:260, 311) ----
   void *d_final_sc, *d_ops, *d_olen;
@@ -1225,10 +937,10 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
     // Without the variable every pair gets the width its preliminary alignment suggests: the gap columns that alignment's score
     // allowed (OrientOut::gap) + 48 for what the trimmed ends add, within [32, 96]; 48 where that is not known.  (A pair that does not
     // certify costs a launch of its own at the end of the step -- 0.7 ms for a single pair -- so the width errs on the wide side.)
-    const char* band_env = getenv("TRACYHIP_BAND_W");
-    // (developer knob, read per call so that one process can compare widths; clamped to [0, 4096] -- widths the band forms cannot
-    // hold simply leave the pair on the whole matrix)
-    const int32_t bandW = (p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore) ? (band_env ? std::min(4096, std::max(0, atoi(band_env))) : 48) : 0;
+    const bool band_env = ctx->knobs.band_w >= 0;
+    // (developer knob band_w, tracyhip_set_option: clamped to [0, 4096] -- widths the band forms cannot hold simply leave the pair on
+    // the whole matrix)
+    const int32_t bandW = (p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore) ? (band_env ? ctx->knobs.band_w : 48) : 0;
     std::vector<int32_t> band_of(nt, bandW);
     if (!band_env && bandW > 0 && oo.gap.size() == nt)
       for (uint32_t t = 0; t < nt; ++t) band_of[t] = (int32_t)std::min<uint32_t>(96u, std::max<uint32_t>(32u, oo.gap[t] + 48u));
@@ -1346,7 +1058,7 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
       HIP_TRY(hipMemcpyAsync(h_top.data(), d_top, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(h_sb.data(), d_final_sc, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(h_ol.data(), d_olen, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(ctx_sync(ctx));
       std::vector<PairDesc> again;
       std::vector<int> again_k;
       for (uint32_t t = 0; t < nt; ++t) {
@@ -1355,7 +1067,8 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
         again.push_back(whole[t]);
         again_k.push_back(choose_k(whole[t].m, MODE_QP));
       }
-      if (getenv("TRACYHIP_HOST_TIMERS")) {
+      ctx->stats.final_banded += nbanded; ctx->stats.final_repeated += (uint32_t)again.size();
+      if (ctx->knobs.verbose) {
         int64_t wsum = 0, lsum = 0, lmax = 0, xmax = -1000000;
         for (uint32_t t = 0; t < nt; ++t) {
           wsum += band_of[t]; const int64_t l = (int64_t)h_top[t] - h_sb[t]; lsum += l; lmax = std::max(lmax, l);
@@ -1404,7 +1117,7 @@ static int align_traces_one(tracyhip_ctx* ctx, const tracyhip_align_job* job, co
     if ((rc = copy_out(ctx, mem, out->ops, static_cast<const uint8_t*>(d_ops), ops_total))) return rc;
     if ((rc = copy_out(ctx, mem, out->ops_len, static_cast<const uint32_t*>(d_olen), nt))) return rc;
   }
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(ctx_sync(ctx));
   return TRACYHIP_OK;
 }
 
@@ -1477,7 +1190,7 @@ int run_chunks(const std::vector<tracyhip_ctx*>& ctxs, uint32_t nt, Fn fn) {
 }
 template <class Fn>
 int run_lanes(tracyhip_ctx* ctx, uint32_t nt, Fn fn) {
-  HIP_TRY(hipStreamSynchronize(ctx->stream));  // inputs the caller enqueued on the context's stream
+  HIP_TRY(ctx_sync(ctx));  // inputs the caller enqueued on the context's stream
   std::vector<tracyhip_ctx*> ctxs{ctx};
   ctxs.insert(ctxs.end(), ctx->lanes.begin(), ctx->lanes.end());
   for (auto* c : ctxs) c->mem_share = (uint32_t)ctxs.size();  // the lanes plan their workspaces concurrently, on one device
@@ -1520,6 +1233,7 @@ struct AlignChunk {
 extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job* job, const tracyhip_params* prm, int mem,
                                      const tracyhip_align_result* out) {
   if (!ctx) return set_error(TRACYHIP_ERR_ARG, "null context");
+  reset_call_stats(ctx, job ? job->ntraces : 0);
   const uint32_t L = (uint32_t)ctx->lanes.size() + 1;
   if (!align_splittable(job, out, prm, L)) return align_traces_one(ctx, job, prm, mem, out);
   int rc = ctx_begin(ctx);
@@ -1541,7 +1255,7 @@ namespace {
 template <class T>
 int upload(tracyhip_ctx* ctx, DevBuf& b, const std::vector<T>& v, const T** out) {
   HIP_TRY(b.ensure(sizeof(T) * std::max<size_t>(v.size(), 1)));
-  if (!v.empty()) { HIP_TRY(hipMemcpyAsync(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, ctx->stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); }
+  if (!v.empty()) { HIP_TRY(hipMemcpyAsync(b.p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, ctx->stream)); HIP_TRY(ctx_sync(ctx)); }
   *out = static_cast<const T*>(b.p);
   return TRACYHIP_OK;
 }
@@ -1554,17 +1268,15 @@ struct DevOut {  // a result array: the user's (DEVICE) or a staging buffer (HOS
 
 }  // namespace
 
-static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
-                               const tracyhip_decompose_result* out) {
-  TRACYHIP_HOST_SCOPE(hs_call, "decompose_traces");
-  StageClock stage_clock;
-  stage_clock.mark("decompose.0_setup");
+static int decompose_check_args(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem, const tracyhip_decompose_result* out,
+                                bool* empty) {
   int rc = ctx_begin(ctx);
   if (rc) return rc;
+  *empty = false;
   if (!job || !out || !prm) return set_error(TRACYHIP_ERR_ARG, "null job/result/params");
   if (mem != TRACYHIP_MEM_HOST && mem != TRACYHIP_MEM_DEVICE) return set_error(TRACYHIP_ERR_ARG, "bad mem kind");
   const uint32_t nt = job->ntraces;
-  if (nt == 0) return TRACYHIP_OK;
+  if (nt == 0) { *empty = true; return TRACYHIP_OK; }
   const tracyhip_seqset& sp = job->profiles;
   const tracyhip_seqset& sr = job->refs;
   const tracyhip_basecalls& bc = job->bc;
@@ -1581,6 +1293,32 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     if (!out->score[k] || !out->ops[k] || !out->ops_offset[k] || !out->ops_len[k]) return set_error(TRACYHIP_ERR_ARG, "null allele alignment arrays");
   for (int k = 0; k < 2; ++k)
     if (!out->slice_begin[k] || !out->slice_len[k] || !out->ref_pos[k]) return set_error(TRACYHIP_ERR_ARG, "null allele slice arrays");
+  return TRACYHIP_OK;
+}
+
+static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
+                               const tracyhip_decompose_result* out) {
+  bool empty = false;
+  int rc = decompose_check_args(ctx, job, prm, mem, out, &empty);
+  if (rc || empty) return rc;
+  rc = stream_decompose(ctx, job, prm, mem, out);
+  if (rc != kStreamNo) return rc;
+  return decompose_traces_legacy(ctx, job, prm, mem, out);
+}
+
+int tracyhip::decompose_traces_legacy(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
+                                      const tracyhip_decompose_result* out) {
+  TRACYHIP_HOST_SCOPE(hs_call, "decompose_traces");
+  StageClock stage_clock;
+  stage_clock.mark("decompose.0_setup");
+  bool empty = false;
+  int rc = decompose_check_args(ctx, job, prm, mem, out, &empty);
+  if (rc || empty) return rc;
+  const uint32_t nt = job->ntraces;
+  const tracyhip_seqset& sp = job->profiles;
+  const tracyhip_seqset& sr = job->refs;
+  const tracyhip_basecalls& bc = job->bc;
+  const tracyhip_decomp_params& dp = job->dprm;
   hipStream_t st = ctx->stream;
   tracyhip_params p = *prm;
   p.hfree = 1;  // AlignConfig<true,false> semiglobal (indigo.h:164)
@@ -1674,7 +1412,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     HIP_TRY(hipGetLastError());
     int32_t herr = 0;
     HIP_TRY(hipMemcpyAsync(&herr, d_verr, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(ctx_sync(ctx));
     if ((herr & 4) && !wildtype) return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
   }
 
@@ -1745,7 +1483,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     oi.d_score = static_cast<int32_t*>(d_strim);
     // the traceback of the trimmed trace on the band kernels (band16.h): substitution tables of the profiles
     std::vector<B16TableDesc> tdp;
-    if (p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore && getenv("TRACYHIP_NO_BAND16") == nullptr) {
+    if (p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore && !ctx->knobs.no_band16) {
       tdp.resize(nt);
       for (uint32_t t = 0; t < nt; ++t) tdp[t] = B16TableDesc{sp.offset[t], 0, mf[t], mf[t], 0, 0};
       HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
@@ -1862,7 +1600,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   HIP_TRY(b_cqf.ensure(sizeof(int32_t)));
   uint8_t* d_cq_ref = static_cast<uint8_t*>(b_cq1.p) + kCodePad;
   uint8_t* d_cq_sd = static_cast<uint8_t*>(b_cq2.p) + kCodePad;
-  const bool try_cq = getenv("TRACYHIP_NO_CQ") == nullptr && sub_limit(&p) <= kWideScore;
+  const bool try_cq = !ctx->knobs.no_cq && sub_limit(&p) <= kWideScore;
   int32_t h_cq_flag = 1;
   if (try_cq) {
     HIP_TRY(hipMemsetAsync(b_cq1.p, 5, (er ? er : 1) + 2 * kCodePad, st));
@@ -1883,7 +1621,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   HIP_TRY(hipMemcpyAsync(h_hst.data(), b_hst.p, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(h_len1.data(), b_len1.p, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(h_strim.data(), d_strim, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(ctx_sync(ctx));
   std::vector<int32_t> h_status(nt, 0);
   for (uint32_t t = 0; t < nt; ++t) {  // indigo.h:303-309
     const double seqsize = (double)mt[t];
@@ -1940,7 +1678,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     DpProblem pb;
     DpProblemLease lease(ctx, pb);
     pb.mode = use_cq ? MODE_CQ : MODE_CHAR; pb.d_a1 = seq; pb.d_a2 = use_cq ? static_cast<const void*>(d_cq_ref) : d_ref;
-    pb.cq_codes = getenv("TRACYHIP_NO_COMPACT") ? 6 : cq_codes;
+    pb.cq_codes = ctx->knobs.no_compact ? 6 : cq_codes;
     pb.desc.resize(nt); pb.k.resize(nt);
     parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t) {
       for (uint32_t t = lo; t < hi; ++t) {
@@ -1958,7 +1696,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     // Band kernels (band16.h): the score S* of the certifying sweep below bounds the gap steps of every optimal alignment,
     // g = (best m - S*) / |ge|, and with them the diagonals it can visit: the origin-tracking sweep and the traceback against the
     // trimmed slice run on that band only (four pairs per wave, sixteen lanes per pair).  TRACYHIP_NO_BAND16=1: whole matrices.
-    const bool b16 = use_cq && p.ge < 0 && p.go <= 0 && getenv("TRACYHIP_NO_BAND16") == nullptr;
+    const bool b16 = use_cq && p.ge < 0 && p.go <= 0 && !ctx->knobs.no_band16;
     std::vector<B16TableDesc> td;
     if (b16) {
       td.resize(nt);
@@ -1971,7 +1709,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     std::vector<int64_t> gap_of(nt, -1);    // its gap-step budget; -1: not known
     // gotoh(seq, rs.refslice) is only read by trimReferenceSlice: when the pairs fit its packed fields the origin-tracking
     // sweep delivers the two ends of that alignment without traceback words, walker or ops (TRACYHIP_NO_ORIGIN=1: off)
-    bool use_origin = getenv("TRACYHIP_NO_ORIGIN") == nullptr;
+    bool use_origin = !ctx->knobs.no_origin;
     for (uint32_t t = 0; t < nt && use_origin; ++t) use_origin = origin_ok(&p, pb.desc[t].m, pb.desc[t].n, pb.k[t]);
     if (use_origin) {
       // The origin-tracking sweep is tagged int32 arithmetic (~40 cycles per cell); the plain 16-bit score sweep costs half of
@@ -1983,7 +1721,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       // TRACYHIP_NO_SUBWINDOW=1: the whole window, as before.
       std::vector<uint32_t> shift(nt, 0);
       uint32_t* d_shift = nullptr;
-      bool subwin = use_cq && getenv("TRACYHIP_NO_SUBWINDOW") == nullptr && !ctx->no_narrow;
+      bool subwin = use_cq && !ctx->knobs.no_subwindow && !ctx->knobs.no_narrow;
       for (uint32_t t = 0; t < nt && subwin; ++t) subwin = narrow_ok(&p, pb.desc[t].m, pb.k[t]);
       if (subwin) {
         std::vector<RowEndDesc> hre(nt);
@@ -2014,7 +1752,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
         std::vector<int8_t> pruned(nt, 0);
         std::vector<int32_t> fscore;
         std::vector<uint32_t> fce;
-        if (b16 && getenv("TRACYHIP_NO_FRONT") == nullptr) {
+        if (b16 && !ctx->knobs.no_front) {
           const uint32_t R = kFrontRows;
           const int64_t bestq = std::max<int64_t>(std::max<int64_t>(p.match, p.mismatch), 0);
           // (laid out by a few threads in trace order: eligibility per trace, a scan, the fill)
@@ -2067,7 +1805,8 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
             uint32_t nok = 0;
             for (size_t i = 0; i < ft.size(); ++i)
               if (fres.fo[i].ok && fres.ce[i]) { pruned[ft[i]] = 1; fscore[ft[i]] = fres.score[i]; fce[ft[i]] = fres.ce[i]; ++nok; }
-            if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "decompose allele %d: pruned sweep of %zu of %u alleles, %u certified\n", k, ft.size(), nt, nok);
+            ctx->stats.allele_pruned[k] += (uint32_t)ft.size(); ctx->stats.allele_uncertified[k] += (uint32_t)ft.size() - nok;
+            if (ctx->knobs.verbose) fprintf(stderr, "decompose allele %d: pruned sweep of %zu of %u alleles, %u certified\n", k, ft.size(), nt, nok);
           }
         }
         {
@@ -2095,7 +1834,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(h_s.data(), d_swscore, sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(h_ce.data(), d_ce, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(ctx_sync(ctx));
           }
           if (!fscore.empty())
             for (uint32_t t = 0; t < nt; ++t)
@@ -2181,7 +1920,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
       h_ends.resize(2 * (size_t)nt);
       HIP_TRY(hipMemcpyAsync(h_ends.data(), b_ends.p, sizeof(uint32_t) * 2 * (size_t)nt, hipMemcpyDeviceToHost, st));
     }
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(ctx_sync(ctx));
     sc6.mark("6.f slice descs+plan");
     for (uint32_t t = 0; t < nt; ++t) {
       PairDesc& d = pb.desc[t];
@@ -2233,16 +1972,17 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
         std::vector<uint32_t> h_ol(nt);
         HIP_TRY(hipMemcpyAsync(h_sc.data(), d_scoreK[k], sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(h_ol.data(), d_lenK[k], sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(ctx_sync(ctx));
         uint32_t nfail = 0;
         for (uint32_t t = 0; t < nt; ++t)
           if (jt.k[t] && (h_sc[t] != h_s1[t] || h_ol[t] == 0)) {
-            if (getenv("TRACYHIP_HOST_TIMERS") && nfail < 6)
+            if (ctx->knobs.verbose && nfail < 6)
               fprintf(stderr, "  fail t=%u m=%u n=%u S1=%d got=%d len=%u g=%lld ends=(%u,%u) ri=%u rc=%d\n", t, pb.desc[t].m, pb.desc[t].n, h_s1[t], h_sc[t], h_ol[t],
                       (long long)gap_of[t], h_ends[2 * t], h_ends[2 * t + 1], h_trimA[k][t].ri, (int)h_rc[t]);
             rest.desc.push_back(pb.desc[t]); rest.k.push_back(pb.k[t]); ++nfail;
           }
-        if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "decompose allele %d: %zu of %u slices banded, %u repeated\n", k, nb16, nt, nfail);
+        ctx->stats.allele_banded[k] += (uint32_t)nb16; ctx->stats.allele_repeated[k] += nfail;
+        if (ctx->knobs.verbose) fprintf(stderr, "decompose allele %d: %zu of %u slices banded, %u repeated\n", k, nb16, nt, nfail);
       }
     }
     if ((rc = run_dp(ctx, h_ends.empty() ? pb : rest, &p, false, true, static_cast<int32_t*>(d_scoreK[k]), static_cast<uint8_t*>(d_opsK[k]), d_offK,
@@ -2278,12 +2018,12 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
     Band16Lease<Band16Job> jg_lease(ctx, jg);
     DpProblem rest;
     rest.mode = pb.mode; rest.d_a1 = pb.d_a1; rest.d_a2 = pb.d_a2; rest.cq_codes = pb.cq_codes;
-    const bool b16g = use_cq && !td_pri.empty() && pglobal.ge < 0 && pglobal.go <= 0 && getenv("TRACYHIP_NO_BAND16") == nullptr;
+    const bool b16g = use_cq && !td_pri.empty() && pglobal.ge < 0 && pglobal.go <= 0 && !ctx->knobs.no_band16;
     std::vector<int64_t> bound_of(nt, 0);
     if (b16g) {
       std::vector<int32_t> h_a[2] = {std::vector<int32_t>(nt), std::vector<int32_t>(nt)};
       for (int k = 0; k < 2; ++k) HIP_TRY(hipMemcpyAsync(h_a[k].data(), d_scoreK[k], sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(ctx_sync(ctx));
       jg.kind = 0; jg.d_qp = static_cast<const int16_t*>(ctx->d_b16tab[0].p); jg.d_codes = d_cq_sd;
       const int64_t best = std::max<int64_t>(std::max<int64_t>(pglobal.match, pglobal.mismatch), 0), age = -(int64_t)pglobal.ge, ago = -(int64_t)pglobal.go;
       jg.desc.resize(nt);
@@ -2323,11 +2063,12 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
         std::vector<uint32_t> h_ol(nt);
         HIP_TRY(hipMemcpyAsync(h_sc.data(), d_scoreK[2], sizeof(int32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(h_ol.data(), d_lenK[2], sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(ctx_sync(ctx));
         uint32_t nfail = 0;
         for (uint32_t t = 0; t < nt; ++t)
           if (jg.k[t] && ((int64_t)h_sc[t] <= bound_of[t] || h_ol[t] == 0)) { rest.desc.push_back(pb.desc[t]); rest.k.push_back(pb.k[t]); ++nfail; }
-        if (getenv("TRACYHIP_HOST_TIMERS")) fprintf(stderr, "decompose allele 1 vs 2: %zu of %u pairs banded, %u repeated\n", nb16, nt, nfail);
+        ctx->stats.allele_banded[2] += (uint32_t)nb16; ctx->stats.allele_repeated[2] += nfail;
+        if (ctx->knobs.verbose) fprintf(stderr, "decompose allele 1 vs 2: %zu of %u pairs banded, %u repeated\n", nb16, nt, nfail);
       }
     }
     if ((rc = run_dp(ctx, b16g ? rest : pb, &pglobal, false, true, static_cast<int32_t*>(d_scoreK[2]), static_cast<uint8_t*>(d_opsK[2]), d_offK,
@@ -2352,7 +2093,7 @@ static int decompose_traces_one(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   HIP_TRY(hipMemcpyAsync(out->status, h_status.data(), sizeof(int32_t) * (size_t)nt, up, st));
   for (const DevOut& o : outs)
     if (o.bytes) HIP_TRY(hipMemcpyAsync(o.user, o.dev, o.bytes, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(ctx_sync(ctx));
   timing_collect(ctx);
   return TRACYHIP_OK;
 }
@@ -2417,6 +2158,7 @@ struct DecomposeChunk {
 extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
                                          const tracyhip_decompose_result* out) {
   if (!ctx) return set_error(TRACYHIP_ERR_ARG, "null context");
+  reset_call_stats(ctx, job ? job->ntraces : 0);
   const uint32_t L = (uint32_t)ctx->lanes.size() + 1;
   if (!decompose_splittable(job, out, prm, L)) return decompose_traces_one(ctx, job, prm, mem, out);
   int rc = ctx_begin(ctx);
@@ -2596,7 +2338,7 @@ extern "C" int tracyhip_trim_reference_slice(tracyhip_ctx* ctx, uint32_t ntraces
   HIP_TRY(hipGetLastError());
   std::vector<TrimOut> h(ntraces);
   HIP_TRY(hipMemcpyAsync(h.data(), ctx->d_tmp[5].p, sizeof(TrimOut) * (size_t)ntraces, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));  // (hd is pageable: the upload above has completed by now as well)
+  HIP_TRY(ctx_sync(ctx));  // (hd is pageable: the upload above has completed by now as well)
   std::vector<uint32_t> b(ntraces), l(ntraces), p(ntraces);
   for (uint32_t t = 0; t < ntraces; ++t) { b[t] = h[t].ri; l[t] = h[t].len; p[t] = h[t].pos; }
   const hipMemcpyKind up = (mem == TRACYHIP_MEM_HOST) ? hipMemcpyHostToHost : hipMemcpyHostToDevice;

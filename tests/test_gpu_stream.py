@@ -107,3 +107,93 @@ def test_options_are_read_once_and_described(ctx, monkeypatch):
             c2.set_option("no_such_switch", 1)
     finally:
         c2.close()
+
+
+# ---- tracy decompose ---------------------------------------------------------------------------------------------------
+def same_decompose(a, b, what=""):
+    for k in a:
+        x, y = a[k], b[k]
+        if k in ("dcp_indel", "dcp_err", "ops"):  # raw tables: compared through "dcp" (rows written) and "btr*"
+            continue
+        if k == "bp":
+            assert [(v.indelshift, v.traceleft, v.breakpoint, v.best_diff) for v in x] == [(v.indelshift, v.traceleft, v.breakpoint, v.best_diff) for v in y], (what, k)
+        elif k == "dstatus":
+            assert [(v.kind, v.best_ins, v.best_del, v.best_fr, v.dcp_n) for v in x] == [(v.kind, v.best_ins, v.best_del, v.best_fr, v.dcp_n) for v in y], (what, k)
+        elif isinstance(x, np.ndarray):
+            assert np.array_equal(x, y), (what, k, np.nonzero(x != y)[0][:8])
+        else:
+            assert x == y, (what, k)
+
+
+def decompose_both_ways(ctx, d, refs, nd, exact=True, **kw):
+    from tracy_amd import capi
+
+    def run():
+        hbc = capi.HostBaseCalls([d["signal"][i] for i in range(nd)], [d["bcpos"][i] for i in range(nd)],
+                                 [d["primary"][i].tobytes() for i in range(nd)], [d["secondary"][i].tobytes() for i in range(nd)])
+        return ctx.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, refs, SC, exact_scores=exact, **kw)
+    return both_ways(ctx, run)
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_decompose_uniform_batch_is_stream_ordered(ctx, exact):
+    """configs[2] in miniature (het indels + SNVs, homozygous indels, no variant; both strands): one synchronisation per call (+ the
+    copy-out of host buffers), every array the host-planned pipeline's"""
+    from tracy_amd import hostlib
+    nd = 160
+    d = hostlib.synth_decompose_batch(4711, nd, 3000, 1000, 0, mix=1)
+    refs = [d["refs"][i].tobytes() for i in range(nd)]
+    a, sa, b, sb = decompose_both_ways(ctx, d, refs, nd, exact)
+    assert sa["stream_ordered"] == 1 and sb["stream_ordered"] == 0, (sa, sb)
+    assert sa["fallback_traces"] <= nd // 20, sa
+    assert sa["host_syncs"] <= 2 + (2 if sa["fallback_traces"] else 0) + 20 * (sa["fallback_traces"] > 0) and sb["host_syncs"] >= 20, (sa, sb)
+    assert sa["allele_banded"][0] >= nd - nd // 20 and sa["allele_banded"][2] >= nd - nd // 20, sa
+    same_decompose(a, b, "exact %s" % exact)
+    assert int((np.asarray(a["status"]) == 0).sum()) > nd // 2
+
+
+def test_decompose_failing_certificates_fall_back_per_trace(ctx):
+    """windows that hold the locus twice cannot certify the pruned sweeps (test_gpu_decompose): those traces are re-done by the
+    host-planned tiers from their untouched basecalls; the rest stays stream-ordered; everything equals the host-planned run and the oracle"""
+    from indigo_oracle import decompose_trace
+    from tracy_amd import hostlib
+    nd = 72
+    d = hostlib.synth_decompose_batch(919, nd, 2200, 640, 0, mix=1)
+    rng = np.random.default_rng(5)
+    refs = []
+    for i in range(nd):
+        r = d["refs"][i].tobytes()
+        if i % 3 == 0:
+            c = bytearray(r)
+            for j in rng.integers(0, len(c), 12):
+                c[int(j)] = int(rng.choice(list(b"ACGT")))
+            r = r + bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(40, 300))).tolist()) + bytes(c)
+        refs.append(r)
+    a, sa, b, sb = decompose_both_ways(ctx, d, refs, nd)
+    assert sa["stream_ordered"] == 1 and 8 <= sa["fallback_traces"] <= nd - 16, sa
+    same_decompose(a, b)
+    for i in (0, 1, 3, 10, 30):
+        want = decompose_trace(d["signal"][i], d["bcpos"][i], d["primary"][i].tobytes(), d["secondary"][i].tobytes(), refs[i], SC)
+        if want["status"] != 0:
+            continue
+        assert a["btr0"][i] == want["btr0"] and a["btr1"][i] == want["btr1"] and a["btr2"][i] == want["btr2"], i
+        assert a["primary"][i] == want["primary"] and a["secondary"][i] == want["secondary"] and a["dcp"][i] == want["dcp"], i
+
+
+def test_decompose_ragged_batch_and_lanes(ctx):
+    """traces of several lengths (strip heights 8 .. 16) in one call, one and two lanes"""
+    from tracy_amd import capi, hostlib
+    parts = [hostlib.synth_decompose_batch(100 + i, 48, 1800 + 400 * i, mf, 0, mix=1) for i, mf in enumerate((420, 640, 900, 1010))]
+    d = {k: sum((list(p[k]) for p in parts), []) for k in ("signal", "bcpos", "primary", "secondary", "profiles", "refs")}
+    nd = len(d["profiles"])
+    refs = [r.tobytes() for r in d["refs"]]
+    a, sa, b, sb = decompose_both_ways(ctx, d, refs, nd)
+    assert sa["stream_ordered"] == 1 and sa["fallback_traces"] <= nd // 8, sa
+    same_decompose(a, b, "ragged")
+    ctx.set_lanes(2)
+    try:
+        c, sc_, _, _ = decompose_both_ways(ctx, d, refs, nd)
+        assert sc_["stream_ordered"] == 1, sc_
+        same_decompose(c, b, "ragged, two lanes")
+    finally:
+        ctx.set_lanes(1)

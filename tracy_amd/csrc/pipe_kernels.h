@@ -199,12 +199,17 @@ __global__ __launch_bounds__(64) void rowmax_rest_kernel(const RowMaxDesc* desc,
 // MODE_CQ (strings scored through the query-profile table): case-sensitive column codes, and the test that row strings hold
 // nothing but the five letters the table has entries for
 // flag |= 2 where a column is none of A C G T N, |= 4 where it is N (both rare): the origin sweeps size their table by it
-__global__ void encode_cq_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, int32_t* flag) {
+// special (or null): the block map of the codes written (DpArgs::special_blocks: one byte per 256 code bytes, set where a block holds
+// anything but A C G T)
+__global__ void encode_cq_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, int32_t* flag, uint8_t* __restrict__ special) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const uint32_t c = cq_code(in[i]);
     out[i] = (uint8_t)c;
-    if (c >= 4u) atomicOr(flag, c >= 5u ? 2 : 4);
+    if (c >= 4u) {
+      atomicOr(flag, c >= 5u ? 2 : 4);
+      if (special) special[i >> 8] = 1;
+    }
   }
 }
 __global__ void cq_rows_kernel(const uint8_t* __restrict__ in, uint64_t n, int32_t* flag) {

@@ -1606,9 +1606,9 @@ int tracyhip::decompose_traces_legacy(tracyhip_ctx* ctx, const tracyhip_decompos
     HIP_TRY(hipMemsetAsync(b_cq1.p, 5, (er ? er : 1) + 2 * kCodePad, st));
     HIP_TRY(hipMemsetAsync(b_cq2.p, 5, (bext ? bext : 1) + 2 * kCodePad, st));
     HIP_TRY(hipMemsetAsync(b_cqf.p, 0, sizeof(int32_t), st));
-    if (er) hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), d_cq_ref, er, static_cast<int32_t*>(b_cqf.p));
+    if (er) hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), d_cq_ref, er, static_cast<int32_t*>(b_cqf.p), (uint8_t*)nullptr);
     if (bext) {
-      hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), d_cq_sd, bext, static_cast<int32_t*>(b_cqf.p));
+      hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), d_cq_sd, bext, static_cast<int32_t*>(b_cqf.p), (uint8_t*)nullptr);
       hipLaunchKernelGGL(cq_rows_kernel, dim3((unsigned)((bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_pri), bext, static_cast<int32_t*>(b_cqf.p));
       hipLaunchKernelGGL(cq_rows_kernel, dim3((unsigned)((bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), bext, static_cast<int32_t*>(b_cqf.p));
     }

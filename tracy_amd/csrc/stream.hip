@@ -56,7 +56,19 @@ struct Arena {
   }
 };
 
-__device__ __forceinline__ void s_count(unsigned long long* cnt, int which, unsigned long long v = 1ull) { atomicAdd(cnt + which, v); }
+// Counters of a planning kernel: summed per workgroup in LDS, one global atomic per counter and workgroup at the end (10^5 threads
+// adding to one global word take milliseconds).  body(lc) may return early; lc is the workgroup's block of SC_COUNT words.
+__device__ __forceinline__ void s_count(unsigned long long* lc, int which, unsigned long long v = 1ull) { atomicAdd(lc + which, v); }
+template <class Body>
+__device__ __forceinline__ void with_counters(unsigned long long* cnt, Body body) {
+  __shared__ unsigned long long lc[SC_COUNT];
+  for (uint32_t i = threadIdx.x; i < (uint32_t)SC_COUNT; i += blockDim.x) lc[i] = 0;
+  __syncthreads();
+  body(lc);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < (uint32_t)SC_COUNT; i += blockDim.x)
+    if (lc[i]) atomicAdd(cnt + i, lc[i]);
+}
 
 // ---- geometry -> descriptor lists of the fixed-shape kernels (vote, row maxima, substitution tables) ----
 __global__ void s_expand_kernel(const SGeom* __restrict__ geom, uint32_t nt, VoteDesc* __restrict__ vd, RowMaxDesc* __restrict__ rm_rest,
@@ -93,6 +105,7 @@ __device__ __forceinline__ PairDesc s_stage1_desc(const SGeom& G, uint32_t t, ui
 __global__ void s_orient_plan_kernel(SParams p, const SGeom* __restrict__ geom, const uint32_t* __restrict__ votes, const int32_t* __restrict__ ub,
                                      const int32_t* __restrict__ ub1, PairDesc* __restrict__ full, PairDesc* __restrict__ pre,
                                      FrontDesc* __restrict__ fd, STrace* __restrict__ tr, unsigned long long* __restrict__ cnt) {
+  with_counters(cnt, [&](unsigned long long* lc) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= p.nt) return;
   const SGeom G = geom[t];
@@ -143,8 +156,9 @@ __global__ void s_orient_plan_kernel(SParams p, const SGeom* __restrict__ geom, 
   S.g = (uint8_t)g;
   S.cls = (uint8_t)cls;
   tr[t] = S;
-  s_count(cnt, SC_SWEEP_CELLS, cells);
-  s_count(cnt, SC_SWEEP_BYTES, bytes);
+  s_count(lc, SC_SWEEP_CELLS, cells);
+  s_count(lc, SC_SWEEP_BYTES, bytes);
+  });
 }
 
 // ---- orientation stage, step 2 (pipeline.hip "o.e" .. "o.f"): scores of both strands, the decision gsFwd > gsRev (sage.h:247), the
@@ -154,6 +168,7 @@ __global__ void s_orient_decide_kernel(SParams p, const SGeom* __restrict__ geom
                                        const uint32_t* __restrict__ fe1, const FrontOut* __restrict__ fo2, const int32_t* __restrict__ fs2,
                                        const uint32_t* __restrict__ fe2, STrace* __restrict__ tr, RowEndDesc* __restrict__ re,
                                        uint32_t* __restrict__ dead, unsigned long long* __restrict__ cnt, PairDesc* __restrict__ desc_trim) {
+  with_counters(cnt, [&](unsigned long long* lc) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= p.nt) return;
   const SGeom G = geom[t];
@@ -169,10 +184,10 @@ __global__ void s_orient_decide_kernel(SParams p, const SGeom* __restrict__ geom
     else dd |= SD_STRAND;
   };
   if (S.cls == 0u) {
-    s_count(cnt, SC_PRUNED);
+    s_count(lc, SC_PRUNED);
     if (fo1[t].ok) { s_g = fs1[t]; fce = fe1[2 * t + 1] ? fe1[2 * t + 1] + fo1[t].shift : 0u; }
     else if (fo2[t].ok) { s_g = fs2[t]; fce = fe2[2 * t + 1] ? fe2[2 * t + 1] + fo2[t].shift : 0u; }
-    if (fce == 0u) { dd |= SD_FRONT; s_count(cnt, SC_PRUNED_UNCERT); }
+    if (fce == 0u) { dd |= SD_FRONT; s_count(lc, SC_PRUNED_UNCERT); }
     else if (p.exact) s_o = sc2[o * nt + t];
     else by_bound();
   } else if (S.cls == 1u) {
@@ -208,6 +223,7 @@ __global__ void s_orient_decide_kernel(SParams p, const SGeom* __restrict__ geom
     d.flags = S.rc ? PAIR_A2_REVCOMP : 0u;
     desc_trim[t] = d;
   }
+  });
 }
 
 // ---- preliminary alignment (pipeline.hip "o.g"): the sub-window and band its score allows around c_e, as an origin-tracking sweep
@@ -255,35 +271,48 @@ __global__ void s_prelim_plan_kernel(SParams p, int mode, const SGeom* __restric
   if (dd) dead[t] |= dd;
 }
 
-// ---- lists per strip height for a band launch: one workgroup scans the candidates (kc[i] = 0 / 4 / 8 / 12), hands every pair its
-// place in its list and the bytes of its traceback words (KIND 0), counts the lists.  A pair whose words do not fit the workspace
-// planned for the launch is dropped and its trace marked (SD_MEM). ----
-constexpr uint32_t kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void s_bucket_scan_kernel(PairDesc* __restrict__ cand, uint8_t* __restrict__ kc, uint32_t n, uint32_t unit_mod, int kind,
-                                                                     unsigned long long cap_bytes, uint32_t* __restrict__ idx, uint32_t* __restrict__ count,
-                                                                     uint32_t* __restrict__ dead, unsigned long long* __restrict__ stat) {
-  __shared__ uint32_t s_n[3][kScanThreads];
-  __shared__ unsigned long long s_b[kScanThreads];
-  __shared__ unsigned long long s_stat[3];
+// ---- lists per strip height for a band launch: the candidates (kc[i] = 0 / 4 / 8 / 12) are counted per block of 256, one workgroup
+// scans the blocks' totals, and every block then hands its pairs their places in their lists (in unit order) and the bytes of their
+// traceback words (KIND 0).  A pair whose words do not fit the workspace planned for the launch becomes an empty slot and its trace
+// is marked (SD_MEM). ----
+constexpr uint32_t kScanBlock = 256, kScanTop = 1024;
+struct ScanPart { uint32_t n[3]; uint32_t pad; unsigned long long bytes; };
+__device__ __forceinline__ int s_bucket(int K) { return K == 12 ? 0 : K == 8 ? 1 : 2; }
+__device__ __forceinline__ unsigned long long s_word_bytes(const PairDesc& d, int K, int kind, unsigned long long* words = nullptr) {
+  const unsigned long long w = b16_words(d.m, d.n, K, band_dmin(d), band_dmax(d));
+  if (words) *words = w;
+  return kind == 0 ? ((w * b16_word_bytes(K) + 15ull) & ~15ull) : 0ull;
+}
+__global__ __launch_bounds__(kScanBlock) void s_scan_partial_kernel(const PairDesc* __restrict__ cand, const uint8_t* __restrict__ kc, uint32_t n, int kind,
+                                                                    ScanPart* __restrict__ part) {
+  __shared__ uint32_t s_n[3];
+  __shared__ unsigned long long s_b;
+  if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
+  if (threadIdx.x == 3) s_b = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kScanBlock + threadIdx.x;
+  const int K = i < n ? kc[i] : 0;
+  if (K) {
+    atomicAdd(&s_n[s_bucket(K)], 1u);
+    if (kind == 0) atomicAdd(&s_b, s_word_bytes(cand[i], K, kind));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = ScanPart{{s_n[0], s_n[1], s_n[2]}, 0u, s_b};
+}
+// exclusive scan over the blocks' totals (in place), the lists' sizes
+__global__ __launch_bounds__(kScanTop) void s_scan_top_kernel(ScanPart* __restrict__ part, uint32_t nb, uint32_t* __restrict__ count) {
+  __shared__ uint32_t s_n[3][kScanTop];
+  __shared__ unsigned long long s_b[kScanTop];
   const uint32_t tid = threadIdx.x;
-  const uint32_t per = (n + kScanThreads - 1) / kScanThreads;
-  const uint32_t lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
-  auto bucket = [](int K) { return K == 12 ? 0 : K == 8 ? 1 : 2; };
-  auto words_of = [&](const PairDesc& d, int K) -> unsigned long long { return b16_words(d.m, d.n, K, band_dmin(d), band_dmax(d)); };
-  if (tid < 3) s_stat[tid] = 0;
+  const uint32_t per = (nb + kScanTop - 1) / kScanTop;
+  const uint32_t lo = tid * per < nb ? tid * per : nb, hi = lo + per < nb ? lo + per : nb;
   uint32_t c[3] = {0, 0, 0};
   unsigned long long bytes = 0;
-  for (uint32_t i = lo; i < hi; ++i) {
-    const int K = kc[i];
-    if (!K) continue;
-    c[bucket(K)] += 1;
-    if (kind == 0) bytes += (words_of(cand[i], K) * b16_word_bytes(K) + 15ull) & ~15ull;
-  }
+  for (uint32_t i = lo; i < hi; ++i) { for (int b = 0; b < 3; ++b) c[b] += part[i].n[b]; bytes += part[i].bytes; }
   for (int b = 0; b < 3; ++b) s_n[b][tid] = c[b];
   s_b[tid] = bytes;
   __syncthreads();
-  // inclusive scans over the threads (Hillis-Steele: ten rounds)
-  for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
+  for (uint32_t d = 1; d < kScanTop; d <<= 1) {  // inclusive scans over the threads (Hillis-Steele: ten rounds)
     uint32_t v[3] = {0, 0, 0};
     unsigned long long vb = 0;
     if (tid >= d) { for (int b = 0; b < 3; ++b) v[b] = s_n[b][tid - d]; vb = s_b[tid - d]; }
@@ -292,47 +321,61 @@ __global__ __launch_bounds__(kScanThreads) void s_bucket_scan_kernel(PairDesc* _
     s_b[tid] += vb;
     __syncthreads();
   }
-  uint32_t pos[3];
-  for (int b = 0; b < 3; ++b) pos[b] = s_n[b][tid] - c[b];
+  uint32_t at[3];
+  for (int b = 0; b < 3; ++b) at[b] = s_n[b][tid] - c[b];
   unsigned long long off = s_b[tid] - bytes;
-  unsigned long long cells = 0, tbytes = 0, words = 0;
-  uint32_t dropped[3] = {0, 0, 0};
   for (uint32_t i = lo; i < hi; ++i) {
-    const int K = kc[i];
-    if (!K) continue;
-    const int b = bucket(K);
-    PairDesc d = cand[i];
-    const unsigned long long wds = words_of(d, K);
-    const unsigned long long mine = kind == 0 ? ((wds * b16_word_bytes(K) + 15ull) & ~15ull) : 0ull;
+    const ScanPart x = part[i];
+    part[i] = ScanPart{{at[0], at[1], at[2]}, 0u, off};
+    for (int b = 0; b < 3; ++b) at[b] += x.n[b];
+    off += x.bytes;
+  }
+  if (tid == 0) { for (int b = 0; b < 3; ++b) count[b] = s_n[b][kScanTop - 1]; count[3] = 0; }
+}
+__global__ __launch_bounds__(kScanBlock) void s_scan_place_kernel(PairDesc* __restrict__ cand, uint8_t* __restrict__ kc, uint32_t n, uint32_t unit_mod, int kind,
+                                                                  unsigned long long cap_bytes, const ScanPart* __restrict__ part, uint32_t* __restrict__ idx,
+                                                                  uint32_t* __restrict__ dead, unsigned long long* __restrict__ stat) {
+  __shared__ uint32_t s_n[3][kScanBlock];
+  __shared__ unsigned long long s_b[kScanBlock];
+  __shared__ unsigned long long s_stat[3];
+  const uint32_t tid = threadIdx.x;
+  if (tid < 3) s_stat[tid] = 0;
+  const uint32_t i = blockIdx.x * kScanBlock + tid;
+  const int K = i < n ? kc[i] : 0;
+  PairDesc d{};
+  unsigned long long words = 0, mine = 0;
+  if (K) { d = cand[i]; mine = s_word_bytes(d, K, kind, &words); }
+  for (int b = 0; b < 3; ++b) s_n[b][tid] = (K && s_bucket(K) == b) ? 1u : 0u;
+  s_b[tid] = mine;
+  __syncthreads();
+  for (uint32_t dd = 1; dd < kScanBlock; dd <<= 1) {
+    uint32_t v[3] = {0, 0, 0};
+    unsigned long long vb = 0;
+    if (tid >= dd) { for (int b = 0; b < 3; ++b) v[b] = s_n[b][tid - dd]; vb = s_b[tid - dd]; }
+    __syncthreads();
+    for (int b = 0; b < 3; ++b) s_n[b][tid] += v[b];
+    s_b[tid] += vb;
+    __syncthreads();
+  }
+  if (K) {
+    const ScanPart base = part[blockIdx.x];
+    const int b = s_bucket(K);
+    const uint32_t pos = base.n[b] + s_n[b][tid] - 1u;
+    const unsigned long long off = base.bytes + s_b[tid] - mine;
+    idx[(size_t)b * n + pos] = i;  // (the list stays dense: a dropped pair keeps its slot as an empty one)
     if (off + mine > cap_bytes) {  // (never for kind 1)
       kc[i] = 0;
+      cand[i].flags = d.flags | PAIR_SKIP;
       atomicOr(dead + (i % unit_mod), SD_MEM);
-      idx[(size_t)b * n + pos[b]] = i;   // keep the list dense: the slot stays, the pair becomes an empty one
-      cand[i].flags |= PAIR_SKIP;
-      pos[b] += 1;
-      dropped[b] += 1;
-      off += mine;
-      continue;
+    } else {
+      cand[i].bits_off = off;
+      atomicAdd(&s_stat[0], words * (unsigned long long)K);
+      atomicAdd(&s_stat[1], (kind == 0 ? words * b16_word_bytes(K) : 0ull) + 12ull * d.m + d.n + 4ull);
+      atomicAdd(&s_stat[2], mine);
     }
-    cand[i].bits_off = off;
-    off += mine;
-    idx[(size_t)b * n + pos[b]] = i;
-    pos[b] += 1;
-    cells += wds * (unsigned long long)K;
-    words += mine;
-    tbytes += (kind == 0 ? wds * b16_word_bytes(K) : 0ull) + 12ull * d.m + d.n + 4ull;
   }
-  atomicAdd(&s_stat[0], cells);
-  atomicAdd(&s_stat[1], tbytes);
-  atomicAdd(&s_stat[2], words);
   __syncthreads();
-  if (tid == 0) {
-    for (int b = 0; b < 3; ++b) count[b] = s_n[b][kScanThreads - 1];
-    count[3] = 0;
-    stat[SB_CELLS] += s_stat[0];
-    stat[SB_BYTES] += s_stat[1];
-    stat[SB_WORDS] += s_stat[2];
-  }
+  if (tid < 3 && s_stat[tid]) atomicAdd(stat + tid, s_stat[tid]);
 }
 
 // ---- `tracy align`: trimReferenceSlice from the two ends (sage.h:259) and the plan of the final alignment gotoh(full profile,
@@ -340,6 +383,7 @@ __global__ __launch_bounds__(kScanThreads) void s_bucket_scan_kernel(PairDesc* _
 __global__ void s_align_final_plan_kernel(SParams p, const SGeom* __restrict__ geom, STrace* __restrict__ tr, const uint32_t* __restrict__ ends,
                                           uint32_t* __restrict__ dead, PairDesc* __restrict__ cand, uint8_t* __restrict__ kc,
                                           unsigned long long* __restrict__ cnt) {
+  with_counters(cnt, [&](unsigned long long* lc) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= p.nt) return;
   kc[t] = 0;
@@ -348,7 +392,7 @@ __global__ void s_align_final_plan_kernel(SParams p, const SGeom* __restrict__ g
   STrace S = tr[t];
   const uint32_t lead = ends[2 * t] + S.shift, ce = ends[2 * t + 1] + S.shift;
   S.trim = s_trim_finish(lead, ce >= lead ? ce - lead : 0u, G.rn, p.trim_left, p.trim_right, S.fwd != 0);
-  s_count(cnt, SC_PRELIM_BANDED);
+  s_count(lc, SC_PRELIM_BANDED);
   const uint32_t m = G.mf, n = S.trim.len;
   int K = 0;
   int32_t dlo = 0, dhi = 0;
@@ -381,10 +425,11 @@ __global__ void s_align_final_plan_kernel(SParams p, const SGeom* __restrict__ g
     q.ckpt_off = band_pack(dlo, dhi);
     cand[t] = q;
     kc[t] = (uint8_t)K;
-    s_count(cnt, SC_FINAL_BANDED);
+    s_count(lc, SC_FINAL_BANDED);
   }
   tr[t] = S;
   if (dd) dead[t] |= dd;
+  });
 }
 
 // the band certificate of the final alignment (S_b > top - |ge| (W + 1): no path outside reaches S_b) and the per-trace results
@@ -395,6 +440,7 @@ struct AlignOutDev {
 };
 __global__ void s_align_finish_kernel(SParams p, const STrace* __restrict__ tr, const int32_t* __restrict__ top_full, uint32_t* __restrict__ dead,
                                       AlignOutDev o, unsigned long long* __restrict__ cnt) {
+  with_counters(cnt, [&](unsigned long long* lc) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= p.nt) return;
   if (dead[t]) return;
@@ -402,7 +448,7 @@ __global__ void s_align_finish_kernel(SParams p, const STrace* __restrict__ tr, 
   const int64_t lose = (-(int64_t)p.ge) * ((int64_t)S.bw + 1);
   if (!((int64_t)o.score_final[t] > (int64_t)top_full[t] - lose && o.ops_len[t] != 0u)) {
     dead[t] |= SD_FINAL_CHECK;
-    s_count(cnt, SC_FINAL_REPEATED);
+    s_count(lc, SC_FINAL_REPEATED);
     return;
   }
   o.score_fwd[t] = S.sc[0];
@@ -412,6 +458,7 @@ __global__ void s_align_finish_kernel(SParams p, const STrace* __restrict__ tr, 
   o.slice_begin[t] = S.trim.ri;
   o.slice_len[t] = S.trim.len;
   o.ref_pos[t] = S.trim.pos;
+  });
 }
 
 // results of the dead traces, computed by the host-planned pipeline into compact arrays, back to their places
@@ -450,7 +497,8 @@ struct StreamCommon {  // device arrays of the orientation stage + preliminary a
   uint32_t* dead;
   uint8_t* kc;
   uint32_t* idx;
-  uint32_t* count;           // [4] per band stage, kMaxBandStages stages
+  ScanPart* part;            // the scan's block totals
+  uint32_t* count;           // [4] per band stage
   unsigned long long* cnt;   // [SC_COUNT]
   unsigned long long* bstat; // [SB_COUNT] per band stage
   uint32_t* ends;
@@ -468,7 +516,7 @@ struct StreamCommon {  // device arrays of the orientation stage + preliminary a
     top_full = want_full_top ? a.take<int32_t>(nt) : nullptr;
     sc2 = a.take<int32_t>(2 * (size_t)nt);
     full = a.take<PairDesc>(2 * (size_t)nt);
-    pre = a.take<PairDesc>((exact ? 1 : 2) * (size_t)nt);
+    pre = a.take<PairDesc>(std::max<size_t>((exact ? 1 : 2) * (size_t)nt, nunits));  // (`tracy decompose` lays the allele prefixes out here later)
     fpairs1 = a.take<PairDesc>(nunits);
     fpairs2 = a.take<PairDesc>(nunits);
     cand = a.take<PairDesc>(nunits);
@@ -485,6 +533,7 @@ struct StreamCommon {  // device arrays of the orientation stage + preliminary a
     dead = a.take<uint32_t>(nt);
     kc = a.take<uint8_t>(nunits);
     idx = a.take<uint32_t>(3 * (size_t)nunits);
+    part = a.take<ScanPart>((nunits + kScanBlock - 1) / kScanBlock + 1);
     count = a.take<uint32_t>(4 * 8);
     cnt = a.take<unsigned long long>(SC_COUNT);
     bstat = a.take<unsigned long long>(SB_COUNT * 8);
@@ -588,8 +637,11 @@ struct BandLaunch {
 int band_stage(tracyhip_ctx* ctx, const tracyhip_params& p, StreamCommon& sc, uint32_t n, uint32_t unit_mod, int stage_no, const BandLaunch& bl, uint64_t cap_bytes) {
   hipStream_t st = ctx->stream;
   uint32_t* count = sc.count + 4 * stage_no;
-  hipLaunchKernelGGL(s_bucket_scan_kernel, dim3(1), dim3(kScanThreads), 0, st, sc.cand, sc.kc, n, unit_mod, bl.kind, (unsigned long long)cap_bytes, sc.idx, count,
-                     sc.dead, sc.bstat + SB_COUNT * stage_no);
+  const uint32_t nb = (n + kScanBlock - 1) / kScanBlock;
+  hipLaunchKernelGGL(s_scan_partial_kernel, dim3(nb), dim3(kScanBlock), 0, st, sc.cand, sc.kc, n, bl.kind, sc.part);
+  hipLaunchKernelGGL(s_scan_top_kernel, dim3(1), dim3(kScanTop), 0, st, sc.part, nb, count);
+  hipLaunchKernelGGL(s_scan_place_kernel, dim3(nb), dim3(kScanBlock), 0, st, sc.cand, sc.kc, n, unit_mod, bl.kind, (unsigned long long)cap_bytes, sc.part, sc.idx, sc.dead,
+                     sc.bstat + SB_COUNT * stage_no);
   HIP_TRY(hipGetLastError());
   Band16Args a{};
   a.pairs = sc.cand; a.npairs = n; a.qp = bl.qp; a.codes = bl.codes; a.bits = static_cast<uint8_t*>(ctx->d_bits.p); a.scores = bl.scores; a.ends = bl.ends;
@@ -964,8 +1016,728 @@ int tracyhip::stream_align(tracyhip_ctx* ctx, const tracyhip_align_job* job, con
   return TRACYHIP_OK;
 }
 
+// =====================================================================================================================
+// tracyhip_decompose_traces, stream-ordered (indigo.h:190-388)
+// =====================================================================================================================
+namespace {
+
+struct SParamsD {        // what the allele stages need beside SParams
+  uint64_t bext;         // extent of the basecall arrays: allele k of trace t is the string at k bext + bc_off + soff of the two-allele buffer
+  int32_t best;          // max(match, mismatch, 0): the most a row of a string scores
+};
+
+__global__ void s_expand_d_kernel(const SGeom* __restrict__ geom, const SGeomD* __restrict__ geomd, uint32_t nt, uint64_t bext, BpDesc* __restrict__ bp,
+                                  RowsDesc* __restrict__ rows, DecompDesc* __restrict__ dd, BcDesc* __restrict__ bc, B16TableDesc* __restrict__ atd) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  const SGeom G = geom[t];
+  const SGeomD D = geomd[t];
+  bp[t] = BpDesc{G.prof_off + G.tl, G.mf, G.mt};
+  rows[t] = RowsDesc{G.ops_off, 0u, 0u};
+  dd[t] = DecompDesc{G.ops_off, D.bc_off, D.dcp_off, 0u, G.mf, G.rn, 0u};
+  bc[t] = BcDesc{D.sig_off, D.bc_off, D.nsamples, G.mf};
+  for (uint32_t k = 0; k < 2; ++k) atd[k * nt + t] = B16TableDesc{k * bext + D.bc_off + D.soff, D.atab_off[k], 0u, D.sl, D.atab_stride, 0u};
+}
+
+// the band traceback of the trimmed trace (indigo.h:302) must reproduce the sweep's score; its string completes the alignment rows
+__global__ void s_prelim_check_kernel(SParams p, const STrace* __restrict__ tr, const int32_t* __restrict__ sb, uint32_t* __restrict__ len1, const uint8_t* __restrict__ kc,
+                                      int32_t* __restrict__ strim, uint32_t* __restrict__ dead, unsigned long long* __restrict__ cnt) {
+  with_counters(cnt, [&](unsigned long long* lc) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.nt) return;
+  if (!dead[t] && kc[t]) {
+    s_count(lc, SC_PRELIM_BANDED);
+    if (sb[t] != tr[t].sstar || len1[t] == 0u) { dead[t] |= SD_PRELIM_CHECK; s_count(lc, SC_PRELIM_REPEATED); }
+  }
+  if (dead[t]) { len1[t] = 0u; return; }  // (nothing downstream walks its rows)
+  strim[t] = tr[t].sstar;
+  });
+}
+
+// indigo.h:303-309 (the score gate) and 314-317 (findHomozygousBreakpoint's verdict) as tracyhip_decompose_result::status; what the
+// decomposeAlleles launch worked on, for the kernel timers
+__global__ void s_status_kernel(SParams p, const SGeom* __restrict__ geom, const int32_t* __restrict__ strim, const int32_t* __restrict__ hst,
+                                const uint32_t* __restrict__ len1, const uint32_t* __restrict__ dead, int32_t* __restrict__ status,
+                                unsigned long long* __restrict__ cnt) {
+  with_counters(cnt, [&](unsigned long long* lc) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.nt || dead[t]) return;
+  const double seqsize = (double)geom[t].mt;
+  const double thr = seqsize * 0.35 * p.match + seqsize * (1 - 0.35) * p.mismatch;
+  int32_t st = 0;
+  if ((double)strim[t] <= thr) st = -1;
+  else if (hst[t] != 1) st = hst[t] == 0 ? -2 : -3;
+  status[t] = st;
+  s_count(lc, SC_DECOMP_CELLS, len1[t]);
+  s_count(lc, SC_DECOMP_BYTES, 2ull * len1[t] + 4ull * geom[t].mf);
+  });
+}
+
+// gotoh(allele, rs.refslice) (indigo.h:359) by the pruned sweep: prefix rows with row R kept + the band below them (pipeline.hip 6.b)
+__global__ void s_allele_plan0_kernel(SParams p, SParamsD pd, const SGeom* __restrict__ geom, const SGeomD* __restrict__ geomd, const STrace* __restrict__ tr,
+                                      uint32_t* __restrict__ dead, PairDesc* __restrict__ pre, FrontDesc* __restrict__ fd, unsigned long long* __restrict__ cnt) {
+  with_counters(cnt, [&](unsigned long long* lc) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= 2u * p.nt) return;
+  const uint32_t k = q / p.nt, t = q % p.nt;
+  pre[q] = s_skip_pair(q);
+  FrontDesc f{};
+  f.flags = PAIR_SKIP;
+  f.out = q;
+  fd[q] = f;
+  if (dead[t]) return;
+  const SGeom G = geom[t];
+  const SGeomD D = geomd[t];
+  if (!(D.flags[k] & SG_FRONT_OK) || D.sl == 0u || G.rn == 0u) { atomicOr(dead + t, SD_ALLELE_FRONT); return; }
+  const uint32_t R = kFrontRows, rcf = tr[t].rc ? PAIR_A2_REVCOMP : 0u;
+  PairDesc d{};
+  d.a1_off = k * pd.bext + D.bc_off + D.soff;
+  d.m = D.sl; d.a1_stride = D.sl;
+  d.a2_off = G.ref_off;
+  d.n = G.rn; d.a2_stride = G.rn;
+  d.flags = rcf | PAIR_KEEP_ROW;
+  d.out = q;
+  d.lastrow_off = D.alr_off[k];
+  pre[q] = d;
+  f.row_off = D.alr_off[k];
+  f.a2_off = G.ref_off;
+  f.tab_off = D.atab_off[k] + R;
+  f.tab_stride = D.atab_stride;
+  f.m_rest = D.sl - R;
+  f.n = G.rn;
+  f.flags = rcf;
+  f.R = R;
+  f.rest = (int32_t)((int64_t)pd.best * (int64_t)(D.sl - R));  // a row of a string scores `match` at most
+  fd[q] = f;
+  s_count(lc, SC_ALLELE_PRUNED0 + (int)k);
+  s_count(lc, SC_SWEEP_CELLS, (uint64_t)R * G.rn);
+  s_count(lc, SC_SWEEP_BYTES, (uint64_t)R + 5ull * G.rn);
+  });
+}
+
+// the verdict of the pruned sweep; S*, c_e bound the alignment: the origin-tracking sweep over its sub-window, on its band (pipeline.hip 6.c, 6.d)
+__global__ void s_allele_plan1_kernel(SParams p, SParamsD pd, const SGeom* __restrict__ geom, const SGeomD* __restrict__ geomd, const STrace* __restrict__ tr,
+                                      const FrontOut* __restrict__ fo1, const int32_t* __restrict__ fs1, const uint32_t* __restrict__ fe1,
+                                      const FrontOut* __restrict__ fo2, const int32_t* __restrict__ fs2, const uint32_t* __restrict__ fe2,
+                                      SAllele* __restrict__ al, uint32_t* __restrict__ dead, PairDesc* __restrict__ cand, uint8_t* __restrict__ kc,
+                                      unsigned long long* __restrict__ cnt) {
+  with_counters(cnt, [&](unsigned long long* lc) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= 2u * p.nt) return;
+  const uint32_t k = q / p.nt, t = q % p.nt;
+  kc[q] = 0;
+  if (dead[t]) return;
+  const SGeom G = geom[t];
+  const SGeomD D = geomd[t];
+  int32_t sstar = 0;
+  uint32_t ce = 0;
+  if (fo1[q].ok) { sstar = fs1[q]; ce = fe1[2 * q + 1] ? fe1[2 * q + 1] + fo1[q].shift : 0u; }
+  else if (fo2[q].ok) { sstar = fs2[q]; ce = fe2[2 * q + 1] ? fe2[2 * q + 1] + fo2[q].shift : 0u; }
+  if (ce == 0u) { atomicOr(dead + t, SD_ALLELE_FRONT); s_count(lc, SC_ALLELE_UNCERT0 + (int)k); return; }
+  const uint32_t m = D.sl;
+  const SubWindow sw = s_sub_window(m, ce, (int64_t)pd.best * m, sstar, p.ge);
+  SAllele A{};
+  A.sstar = sstar; A.ce = ce; A.gap = sw.g; A.shift = sw.a;
+  al[q] = A;
+  int K = sw.K;
+  if (K && !b16_origin_ok(p.match, p.mismatch, p.go, p.ge, m, sw.n)) K = 0;
+  if (K && !s_fits_lds(sw.n, K)) K = 0;
+  if (!K) { atomicOr(dead + t, SD_ALLELE_ORIGIN); return; }
+  if (sw.n > p.ncap) { atomicOr(dead + t, SD_SHAPE); return; }
+  const bool rc = tr[t].rc != 0;
+  PairDesc d{};
+  d.a1_off = D.atab_off[k]; d.a1_stride = D.atab_stride;
+  d.m = m;
+  d.n = sw.n; d.a2_stride = sw.n;
+  d.a2_off = G.ref_off + (rc ? (uint64_t)(G.rn - ce) : (uint64_t)sw.a);  // reverse view: column c is byte n - c
+  d.flags = rc ? PAIR_A2_REVCOMP : 0u;
+  d.out = q;
+  d.ckpt_off = band_pack(sw.dlo, sw.dhi);
+  cand[q] = d;
+  kc[q] = (uint8_t)K;
+  });
+}
+
+// trimReferenceSlice (indigo.h:360) from the two ends; gotoh(allele, trimmed slice) (indigo.h:365) on the band around its known end (pipeline.hip 6.f)
+__global__ void s_allele_plan2_kernel(SParams p, const SGeom* __restrict__ geom, const SGeomD* __restrict__ geomd, const STrace* __restrict__ tr,
+                                      const uint32_t* __restrict__ ends, SAllele* __restrict__ al, uint32_t* __restrict__ dead, PairDesc* __restrict__ cand,
+                                      uint8_t* __restrict__ kc, unsigned long long* __restrict__ cnt) {
+  with_counters(cnt, [&](unsigned long long* lc) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= 2u * p.nt) return;
+  const uint32_t k = q / p.nt, t = q % p.nt;
+  kc[q] = 0;
+  if (dead[t]) return;
+  const SGeom G = geom[t];
+  const SGeomD D = geomd[t];
+  SAllele A = al[q];
+  const STrace S = tr[t];
+  const uint32_t lead = ends[2 * q] + A.shift, cend = ends[2 * q + 1] + A.shift;
+  A.trim = s_trim_finish(lead, cend >= lead ? cend - lead : 0u, G.rn, p.trim_left, p.trim_right, S.fwd != 0);
+  al[q] = A;
+  const uint32_t m = D.sl, n = A.trim.len;
+  const int64_t ce = (int64_t)cend - (int64_t)A.trim.ri;  // last column of the alignment, in the slice
+  int K = 0;
+  int32_t dlo = 0, dhi = 0;
+  if (A.gap >= 0 && m && n && ce >= 1 && ce <= (int64_t)n) {
+    const int64_t gg = A.gap < (1 << 20) ? A.gap : (1 << 20);
+    const int32_t d1 = (int32_t)ce - (int32_t)m;
+    dlo = d1 - (int32_t)gg - 1;
+    dhi = d1 + (int32_t)gg + 1;
+    K = b16_pick_k(dlo, dhi);
+  }
+  if (K && !s_fits_lds(n, K)) K = 0;
+  if (!K) { atomicOr(dead + t, SD_ALLELE_BAND); return; }
+  if (n > p.ncap) { atomicOr(dead + t, SD_SHAPE); return; }
+  PairDesc d{};
+  d.a1_off = D.atab_off[k]; d.a1_stride = D.atab_stride;
+  d.m = m;
+  d.n = n; d.a2_stride = n;
+  d.a2_off = G.ref_off + (S.rc ? G.rn - A.trim.ri - A.trim.len : A.trim.ri);
+  d.flags = S.rc ? PAIR_A2_REVCOMP : 0u;
+  d.out = q;
+  d.ckpt_off = band_pack(dlo, dhi);
+  cand[q] = d;
+  kc[q] = (uint8_t)K;
+  s_count(lc, SC_ALLELE_BANDED0 + (int)k);
+  });
+}
+
+__global__ void s_allele_check_kernel(SParams p, const SAllele* __restrict__ al, const int32_t* __restrict__ score, const uint32_t* __restrict__ len,
+                                      uint32_t* __restrict__ dead, unsigned long long* __restrict__ cnt) {
+  with_counters(cnt, [&](unsigned long long* lc) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= 2u * p.nt) return;
+  const uint32_t k = q / p.nt, t = q % p.nt;
+  if (dead[t]) return;
+  if (score[q] != al[q].sstar || len[q] == 0u) { atomicOr(dead + t, SD_ALLELE_CHECK); s_count(lc, SC_ALLELE_REPEATED0 + (int)k); }
+  });
+}
+
+// allele 1 vs allele 2, global (indigo.h:379-387): the band guessed from what the two alleles lost against the reference, the bound
+// its score has to beat (pipeline.hip 6.i)
+__global__ void s_a12_plan_kernel(SParams p, SParamsD pd, const SGeomD* __restrict__ geomd, const int32_t* __restrict__ ascore, uint32_t* __restrict__ dead,
+                                  PairDesc* __restrict__ cand, uint8_t* __restrict__ kc, long long* __restrict__ bound, unsigned long long* __restrict__ cnt) {
+  with_counters(cnt, [&](unsigned long long* lc) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.nt) return;
+  kc[t] = 0;
+  if (dead[t]) return;
+  const SGeomD D = geomd[t];
+  const uint32_t m = D.sl;
+  int K = 0;
+  int32_t dlo = 0, dhi = 0;
+  if (m) {
+    const int64_t best = pd.best, age = -(int64_t)p.ge, ago = -(int64_t)p.go;
+    const int64_t l0 = best * m - ascore[t], l1 = best * m - ascore[p.nt + t];
+    const int64_t lost = (l0 > 0 ? l0 : 0) + (l1 > 0 ? l1 : 0);
+    const int64_t per = best + 2 * age;
+    int64_t W = (5 * lost / 2 + 40) / (per > 0 ? per : 1) + 2;
+    if (W > 90) W = 90;
+    dlo = (int32_t)-W;
+    dhi = (int32_t)W;
+    K = b16_pick_k(dlo, dhi);
+    const int64_t v = W + 1, h = W + 1;
+    bound[t] = best * ((int64_t)m - v) - age * (v + h) - 2 * ago;
+  }
+  if (K && !s_fits_lds(m, K)) K = 0;
+  if (!K) { dead[t] |= SD_A12_BAND; return; }
+  PairDesc d{};
+  d.a1_off = D.atab_off[0]; d.a1_stride = D.atab_stride;
+  d.m = m; d.n = m; d.a2_stride = m;
+  d.a2_off = D.bc_off + D.soff;
+  d.out = t;
+  d.ckpt_off = band_pack(dlo, dhi);
+  cand[t] = d;
+  kc[t] = (uint8_t)K;
+  s_count(lc, SC_ALLELE_BANDED2);
+  });
+}
+
+struct DecompOutDev {
+  int32_t *status, *score_fwd, *score_rev, *score_trim;
+  uint8_t* forward;
+  uint32_t *slice_begin[2], *slice_len[2], *ref_pos[2];
+  int32_t* score[3];
+  uint32_t* ops_len[3];
+};
+// the certificate of the allele 1 vs allele 2 band, and the per-trace results
+__global__ void s_decompose_finish_kernel(SParams p, const STrace* __restrict__ tr, const SAllele* __restrict__ al, const int32_t* __restrict__ ascore,
+                                          const uint32_t* __restrict__ alen, const long long* __restrict__ bound, uint32_t* __restrict__ dead, DecompOutDev o,
+                                          unsigned long long* __restrict__ cnt) {
+  with_counters(cnt, [&](unsigned long long* lc) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.nt || dead[t]) return;
+  if (!((long long)o.score[2][t] > bound[t] && o.ops_len[2][t] != 0u)) { dead[t] |= SD_A12_CHECK; s_count(lc, SC_ALLELE_REPEATED2); return; }
+  const STrace S = tr[t];
+  o.score_fwd[t] = S.sc[0];
+  o.score_rev[t] = S.sc[1];
+  o.forward[t] = S.fwd;
+  for (uint32_t k = 0; k < 2; ++k) {
+    const SAllele A = al[k * p.nt + t];
+    o.slice_begin[k][t] = A.trim.ri;
+    o.slice_len[k][t] = A.trim.len;
+    o.ref_pos[k][t] = A.trim.pos;
+    o.score[k][t] = ascore[k * p.nt + t];
+    o.ops_len[k][t] = alen[k * p.nt + t];
+  }
+  });
+}
+
+// the basecalls of the dead traces as they were before decomposeAlleles rewrote them (the host-planned pipeline starts from them)
+__global__ __launch_bounds__(64) void s_restore_kernel(const uint32_t* __restrict__ list, const SGeom* __restrict__ geom, const SGeomD* __restrict__ geomd,
+                                                       const uint8_t* __restrict__ pri_bak, const uint8_t* __restrict__ sec_bak, uint8_t* __restrict__ pri,
+                                                       uint8_t* __restrict__ sec) {
+  const uint32_t t = list[blockIdx.x];
+  const uint64_t off = geomd[t].bc_off;
+  for (uint32_t i = threadIdx.x; i < geom[t].mf; i += 64) { pri[off + i] = pri_bak[off + i]; sec[off + i] = sec_bak[off + i]; }
+}
+
+struct DecompArena {
+  StreamCommon sc;
+  SGeomD* geomd;
+  BpDesc* bpd; RowsDesc* rowsd; DecompDesc* dd; BcDesc* bcd; B16TableDesc* atd;
+  PairDesc* desc_trim;
+  uint64_t* off1;          // ops / rows of the trimmed trace, per trace
+  uint64_t* aops_off;      // ops of allele k of trace t, relative to the ops of allele 0 (2 nt)
+  uint64_t* ops2_off;      // ops of allele 1 vs allele 2
+  uint8_t *ops1, *rows0, *rows1;
+  uint32_t* len1;
+  int32_t *sb, *hst;
+  uint8_t *seqs2, *cq_ref, *cq_sd, *cq_special, *pri_bak, *sec_bak;
+  int32_t* cq_flag;
+  SAllele* al;
+  int32_t* ascore; uint32_t* alen;
+  long long* bound;
+  // staged payloads / results where the caller's arrays are host memory
+  float* in_prof; uint8_t* in_ref; int32_t *in_sig, *in_pos;
+  uint8_t *pri, *sec, *secdecomp;
+  tracyhip_breakpoint* bp; double* fractions; int32_t *dcp_indel, *dcp_err; tracyhip_decomp_status* dstatus;
+  DecompOutDev o;
+  uint8_t* ops[3];
+  // compact results of the dead traces
+  DecompOutDev f;
+  tracyhip_breakpoint* f_bp; double* f_fr; tracyhip_decomp_status* f_dst;
+  uint32_t* dead_list;
+  struct Sizes { uint32_t nt; bool exact, host; uint64_t tot1, bext, er, ep, sext, dext, opscap[3]; };
+  void layout(Arena& a, const Sizes& z) {
+    const uint32_t nt = z.nt;
+    sc.layout(a, nt, 2 * nt, z.exact, false);
+    geomd = a.take<SGeomD>(nt);
+    bpd = a.take<BpDesc>(nt); rowsd = a.take<RowsDesc>(nt); dd = a.take<DecompDesc>(nt); bcd = a.take<BcDesc>(nt); atd = a.take<B16TableDesc>(2 * (size_t)nt);
+    desc_trim = a.take<PairDesc>(nt);
+    off1 = a.take<uint64_t>(nt); aops_off = a.take<uint64_t>(2 * (size_t)nt); ops2_off = a.take<uint64_t>(nt);
+    ops1 = a.take<uint8_t>(z.tot1); rows0 = a.take<uint8_t>(z.tot1); rows1 = a.take<uint8_t>(z.tot1);
+    len1 = a.take<uint32_t>(nt);
+    sb = a.take<int32_t>(nt); hst = a.take<int32_t>(nt);
+    seqs2 = a.take<uint8_t>(2 * z.bext + 16);
+    cq_ref = a.take<uint8_t>(z.er + 2 * kCodePad); cq_sd = a.take<uint8_t>(z.bext + 2 * kCodePad); cq_special = a.take<uint8_t>((z.er >> 8) + 2);
+    pri_bak = a.take<uint8_t>(z.bext); sec_bak = a.take<uint8_t>(z.bext);
+    cq_flag = a.take<int32_t>(4);
+    al = a.take<SAllele>(2 * (size_t)nt);
+    ascore = a.take<int32_t>(2 * (size_t)nt); alen = a.take<uint32_t>(2 * (size_t)nt);
+    bound = a.take<long long>(nt);
+    auto per_trace = [&](DecompOutDev& x) {
+      x.status = a.take<int32_t>(nt); x.score_fwd = a.take<int32_t>(nt); x.score_rev = a.take<int32_t>(nt); x.score_trim = a.take<int32_t>(nt);
+      x.forward = a.take<uint8_t>(nt);
+      for (int k = 0; k < 2; ++k) { x.slice_begin[k] = a.take<uint32_t>(nt); x.slice_len[k] = a.take<uint32_t>(nt); x.ref_pos[k] = a.take<uint32_t>(nt); }
+      for (int k = 0; k < 3; ++k) { x.score[k] = a.take<int32_t>(nt); x.ops_len[k] = a.take<uint32_t>(nt); }
+    };
+    o = DecompOutDev{};
+    if (z.host) {
+      in_prof = a.take<float>(z.ep); in_ref = a.take<uint8_t>(z.er); in_sig = a.take<int32_t>(z.sext); in_pos = a.take<int32_t>(z.bext);
+      pri = a.take<uint8_t>(z.bext); sec = a.take<uint8_t>(z.bext); secdecomp = a.take<uint8_t>(z.bext);
+      bp = a.take<tracyhip_breakpoint>(nt); fractions = a.take<double>(2 * (size_t)nt);
+      dcp_indel = a.take<int32_t>(z.dext); dcp_err = a.take<int32_t>(z.dext); dstatus = a.take<tracyhip_decomp_status>(nt);
+      per_trace(o);
+      // (the three ops buffers back to back: the offsets of alleles 1 and 2 are taken relative to the first)
+      for (int k = 0; k < 3; ++k) ops[k] = a.take<uint8_t>(z.opscap[k]);
+    }
+    per_trace(f);
+    f_bp = a.take<tracyhip_breakpoint>(nt); f_fr = a.take<double>(2 * (size_t)nt); f_dst = a.take<tracyhip_decomp_status>(nt);
+    dead_list = a.take<uint32_t>(nt);
+  }
+};
+
+static_assert(sizeof(tracyhip_breakpoint) == sizeof(BreakpointOut) && sizeof(tracyhip_decomp_status) == sizeof(DecompOut), "result records of the C ABI are the kernels'");
+struct Frac2 { double a, b; };
+
+}  // namespace
+
 int tracyhip::stream_decompose(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
                                const tracyhip_decompose_result* out) {
-  (void)ctx; (void)job; (void)prm; (void)mem; (void)out;
-  return kStreamNo;
+  const CtxKnobs& kn = ctx->knobs;
+  if (!stream_options_ok(kn) || job->oriented || job->ref_profiles.data) return kStreamNo;
+  const uint32_t nt = job->ntraces;
+  const tracyhip_seqset& sp = job->profiles;
+  const tracyhip_seqset& sr = job->refs;
+  const tracyhip_basecalls& bc = job->bc;
+  const tracyhip_decomp_params& dp = job->dprm;
+  hipStream_t st = ctx->stream;
+  tracyhip_params p = *prm;
+  p.hfree = 1;  // AlignConfig<true,false> semiglobal (indigo.h:164)
+  p.vfree = 0;
+  tracyhip_params pglobal = *prm;
+  pglobal.hfree = 0;  // AlignConfig<false,false> (indigo.h:381)
+  pglobal.vfree = 0;
+  const uint32_t TL = (uint32_t)dp.trim_left, TR = (uint32_t)dp.trim_right;
+  StreamHost h;
+  std::vector<SGeom> geom;
+  TRY(plan_common(ctx, p, sp, sr, job->ref_index, nt, TL, TR, h, geom));
+  const bool exact = job->strand_by_certificate == 0;
+  const bool host = mem == TRACYHIP_MEM_HOST;
+
+  // ---- geometry of the decompose stages (decompose_traces_legacy's, trace by trace) ----
+  std::vector<SGeomD> geomd(nt);
+  DecompArena::Sizes z{};
+  z.nt = nt; z.exact = exact; z.host = host;
+  uint32_t maxbc = 0, maxsl = 0, max_arest = 0;
+  uint64_t atab_tot = 0, alr_tot = 0, rows_alleles = 0;
+  for (uint32_t t = 0; t < nt; ++t) {
+    if (bc.bc_len[t] != h.mf[t]) return set_error(TRACYHIP_ERR_ARG, "trace %u: profile has %u columns but %u basecalls", t, h.mf[t], bc.bc_len[t]);
+    if (bc.bc_len[t] >= 2u * kMaxIndelGlobal) return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the scan tables hold < %d", t, bc.bc_len[t], 2 * kMaxIndelGlobal);
+    SGeomD& D = geomd[t];
+    if ((uint64_t)(uint32_t)(TL + TR + 1) >= (uint64_t)h.mf[t]) { D.soff = 0; D.sl = h.mf[t]; }  // trimmedSeq, abif.h:68-75
+    else { D.soff = TL; D.sl = h.mf[t] - TL - TR; }
+    D.bc_off = bc.bc_offset[t];
+    D.sig_off = bc.signal_offset[t];
+    D.nsamples = bc.nsamples[t];
+    D.dcp_off = out->dcp_offset[t];
+    for (int k = 0; k < 3; ++k) D.opsk_off[k] = out->ops_offset[k][t];
+    D.atab_stride = b16_table_stride(D.sl);
+    for (int k = 0; k < 2; ++k) {
+      D.atab_off[k] = atab_tot; atab_tot += (uint64_t)kB16Codes * D.atab_stride;
+      D.alr_off[k] = alr_tot; alr_tot += (uint64_t)h.rn[t] + 2;
+      const bool ok = D.sl > kFrontRows + 2u * (uint32_t)kFrontK && h.rn[t] >= 1 && origin16_ok(&p, D.sl, D.sl - kFrontRows + 2u * (uint32_t)kFrontHalfW + 16u);
+      D.flags[k] = ok ? SG_FRONT_OK : 0u;
+      if (ok) max_arest = std::max(max_arest, D.sl - kFrontRows);
+    }
+    geom[t].ops_off = z.tot1;
+    z.tot1 += (uint64_t)h.mt[t] + h.rn[t];
+    z.sext = std::max<uint64_t>(z.sext, bc.signal_offset[t] + 4ull * bc.nsamples[t]);
+    z.bext = std::max<uint64_t>(z.bext, bc.bc_offset[t] + bc.bc_len[t]);
+    z.dext = std::max<uint64_t>(z.dext, out->dcp_offset[t] + 2ull * dp.maxindel + 2);
+    for (int k = 0; k < 3; ++k) z.opscap[k] = std::max<uint64_t>(z.opscap[k], out->ops_offset[k][t] + (uint64_t)D.sl + (k < 2 ? h.rn[t] : D.sl));
+    maxbc = std::max(maxbc, h.mf[t]);
+    maxsl = std::max(maxsl, D.sl);
+    rows_alleles += 2ull * D.sl;
+  }
+  if (max_arest == 0) return kStreamNo;
+  TRY(decompose_limits(dp.maxindel, maxbc));
+  z.ep = seqset_extent(sp); z.er = seqset_extent(sr);
+  const uint32_t ncap = (h.maxmf + 200u + 7u) & ~3u;
+  if (4ull * ncap + b16_table_bytes(12) > 64u * 1024u) return kStreamNo;
+
+  // ---- workspace ----
+  uint64_t rows_traces = 0;
+  for (uint32_t t = 0; t < nt; ++t) rows_traces += h.mt[t];
+  Arena sizing;
+  DecompArena A;
+  A.layout(sizing, z);
+  uint64_t budget = 0;
+  TRY(workspace_budget(ctx, ctx->d_lastrow.cap + ctx->d_bits.cap + ctx->d_stream.cap + ctx->d_b16tab[2].cap + ctx->d_b16tab[0].cap, &budget));
+  const uint64_t lr_words = std::max(h.lr_tot, alr_tot);
+  const uint64_t fixed = lr_words * 4 + 64 + h.tab_tot * 2 + atab_tot * 2 + 128 + sizing.off;
+  if (fixed > budget) return kStreamNo;
+  const uint64_t words_cap = band_words_cap(std::max(rows_traces, rows_alleles), 2ull * nt, budget - fixed);
+  HIP_TRY(ctx->d_lastrow.ensure(lr_words * 4 + 64));
+  HIP_TRY(ctx->d_b16tab[2].ensure(h.tab_tot * sizeof(int16_t) + 64));
+  HIP_TRY(ctx->d_b16tab[0].ensure(atab_tot * sizeof(int16_t) + 64));
+  HIP_TRY(ctx->d_bits.ensure(words_cap + 64));
+  HIP_TRY(ctx->d_stream.ensure(sizing.off + 256));
+  Arena arena;
+  arena.base = static_cast<char*>(ctx->d_stream.p);
+  A.layout(arena, z);
+  StreamCommon& sc = A.sc;
+
+  // ---- payloads and result arrays: the caller's (device memory) or staged ----
+  const float* d_prof = static_cast<const float*>(sp.data);
+  const uint8_t* d_ref = static_cast<const uint8_t*>(sr.data);
+  const int32_t *d_sig = bc.signal, *d_pos = bc.bcpos;
+  uint8_t *d_pri = bc.primary, *d_sec = bc.secondary, *d_sd = out->secdecomp;
+  tracyhip_breakpoint* d_bp = out->bp;
+  double* d_fr = out->fractions;
+  int32_t *d_di = out->dcp_indel, *d_de = out->dcp_err;
+  tracyhip_decomp_status* d_dst = out->dstatus;
+  DecompOutDev o = A.o;
+  uint8_t* d_opsK[3] = {out->ops[0], out->ops[1], out->ops[2]};
+  if (host) {
+    auto up = [&](void* dev, const void* src, size_t bytes) -> int {
+      if (bytes) HIP_TRY(hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, st));
+      return TRACYHIP_OK;
+    };
+    TRY(up(A.in_prof, sp.data, z.ep * 4)); TRY(up(A.in_ref, sr.data, z.er)); TRY(up(A.in_sig, bc.signal, z.sext * 4)); TRY(up(A.in_pos, bc.bcpos, z.bext * 4));
+    TRY(up(A.pri, bc.primary, z.bext)); TRY(up(A.sec, bc.secondary, z.bext));
+    d_prof = A.in_prof; d_ref = A.in_ref; d_sig = A.in_sig; d_pos = A.in_pos; d_pri = A.pri; d_sec = A.sec; d_sd = A.secdecomp;
+    d_bp = A.bp; d_fr = A.fractions; d_di = A.dcp_indel; d_de = A.dcp_err; d_dst = A.dstatus;
+    for (int k = 0; k < 3; ++k) d_opsK[k] = A.ops[k];
+  } else {
+    o.status = out->status; o.score_fwd = out->score_fwd; o.score_rev = out->score_rev; o.score_trim = out->score_trim; o.forward = out->forward;
+    for (int k = 0; k < 2; ++k) { o.slice_begin[k] = out->slice_begin[k]; o.slice_len[k] = out->slice_len[k]; o.ref_pos[k] = out->ref_pos[k]; }
+    for (int k = 0; k < 3; ++k) { o.score[k] = out->score[k]; o.ops_len[k] = out->ops_len[k]; }
+  }
+  HIP_TRY(hipMemcpyAsync(A.pri_bak, d_pri, z.bext, hipMemcpyDeviceToDevice, st));  // decomposeAlleles rewrites the basecalls in place
+  HIP_TRY(hipMemcpyAsync(A.sec_bak, d_sec, z.bext, hipMemcpyDeviceToDevice, st));
+  // whatever happens from here on, the caller's basecalls in device memory are put back before the host-planned pipeline takes the call
+  auto give_up = [&](int rc) -> int {
+    if (rc == kStreamNo && !host) {
+      (void)hipMemcpyAsync(d_pri, A.pri_bak, z.bext, hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(d_sec, A.sec_bak, z.bext, hipMemcpyDeviceToDevice, st);
+      (void)ctx_sync(ctx);
+    }
+    return rc;
+  };
+
+  // ---- references encoded once; geometry, offsets: one pinned block, one copy each way ----
+  HIP_TRY(ctx->d_err.ensure(kErrBytes));
+  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, kErrBytes, st));
+  int32_t* d_verr = static_cast<int32_t*>(ctx->d_err.p) + kErrVerdictWord;
+  HIP_TRY(ctx->ensure_codes(z.er ? z.er : 1, st));
+  if (z.er) {
+    hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((z.er + 4095) / 4096)), dim3(256), 0, st, d_ref, ctx->codes(), z.er, ctx->special_blocks(), d_verr);
+    HIP_TRY(hipGetLastError());
+  }
+  {
+    const size_t bytes = (sizeof(SGeom) + sizeof(SGeomD) + 4 * sizeof(uint64_t)) * (size_t)nt;
+    HIP_TRY(ctx->h_desc.ensure(bytes));
+    char* hp = static_cast<char*>(ctx->h_desc.p);
+    std::memcpy(hp, geom.data(), sizeof(SGeom) * (size_t)nt);
+    SGeomD* hgd = reinterpret_cast<SGeomD*>(hp + sizeof(SGeom) * (size_t)nt);
+    std::memcpy(hgd, geomd.data(), sizeof(SGeomD) * (size_t)nt);
+    uint64_t* hoff = reinterpret_cast<uint64_t*>(hgd + nt);  // [off1 nt][allele ops 2 nt][allele 1 vs 2 ops nt]
+    // (band16_body adds an offset to ONE ops pointer: alleles 1 and 2 reach their buffers through offsets relative to allele 0's, modulo 2^64)
+    const uint64_t base1 = (uint64_t)(reinterpret_cast<uintptr_t>(d_opsK[1]) - reinterpret_cast<uintptr_t>(d_opsK[0]));
+    for (uint32_t t = 0; t < nt; ++t) {
+      hoff[t] = geom[t].ops_off;
+      hoff[nt + t] = out->ops_offset[0][t];
+      hoff[2 * (size_t)nt + t] = base1 + out->ops_offset[1][t];
+      hoff[3 * (size_t)nt + t] = out->ops_offset[2][t];
+    }
+    HIP_TRY(hipMemcpyAsync(sc.geom, hp, sizeof(SGeom) * (size_t)nt, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(A.geomd, hgd, sizeof(SGeomD) * (size_t)nt, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(A.off1, hoff, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(A.aops_off, hoff + nt, sizeof(uint64_t) * 2 * (size_t)nt, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(A.ops2_off, hoff + 3 * (size_t)nt, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+  }
+  HIP_TRY(hipMemsetAsync(sc.dead, 0, sizeof(uint32_t) * (size_t)nt, st));
+  HIP_TRY(hipMemsetAsync(sc.cnt, 0, sizeof(unsigned long long) * SC_COUNT, st));
+  HIP_TRY(hipMemsetAsync(sc.bstat, 0, sizeof(unsigned long long) * SB_COUNT * 8, st));
+
+  SParams spm{};
+  spm.match = p.match; spm.mismatch = p.mismatch; spm.go = p.go; spm.ge = p.ge; spm.nt = nt; spm.exact = exact ? 1u : 0u; spm.ncap = ncap - 8u;
+  spm.trim_left = TL; spm.trim_right = TR; spm.use_votes = 1u;
+  SParamsD spd{};
+  spd.bext = z.bext;
+  spd.best = (int32_t)std::max<int64_t>(std::max<int64_t>(p.match, p.mismatch), 0);
+  const dim3 g256((nt + 255) / 256), g256x2((2 * nt + 255) / 256), b256(256);
+
+  // ---- 2. orientation (indigo.h:235-247), 3. gotoh(trimmed trace, window) (indigo.h:302) by traceback on its band ----
+  const int16_t* d_qp = static_cast<const int16_t*>(ctx->d_b16tab[2].p);
+  int32_t* d_lastrow = static_cast<int32_t*>(ctx->d_lastrow.p);
+  OrientStage os{d_prof, d_qp, d_lastrow, exact, A.desc_trim};
+  TRY(give_up(queue_orientation(ctx, p, spm, h, sc, os)));
+  hipLaunchKernelGGL(s_expand_d_kernel, g256, b256, 0, st, sc.geom, A.geomd, nt, z.bext, A.bpd, A.rowsd, A.dd, A.bcd, A.atd);
+  hipLaunchKernelGGL(s_prelim_plan_kernel, g256, b256, 0, st, spm, 1, sc.geom, sc.tr, sc.ce, sc.top_trim, sc.dead, sc.cand, sc.kc);
+  HIP_TRY(hipGetLastError());
+  BandLaunch b0;
+  b0.kind = 0; b0.qp = d_qp; b0.codes = ctx->codes(); b0.scores = A.sb; b0.ops = A.ops1; b0.ops_off = A.off1; b0.ops_len = A.len1; b0.code_cap = ncap; b0.hfree = 1;
+  TRY(band_stage(ctx, p, sc, nt, nt, 0, b0, words_cap));
+  hipLaunchKernelGGL(s_prelim_check_kernel, g256, b256, 0, st, spm, sc.tr, A.sb, A.len1, sc.kc, o.score_trim, sc.dead, sc.cnt);
+  HIP_TRY(hipGetLastError());
+  {
+    RowsArgs ra{};
+    ra.pairs = A.desc_trim;
+    ra.a1 = d_prof; ra.a2 = d_ref;
+    ra.a1_profile = 1; ra.a2_profile = 0; ra.a2_revcomp_flag = 1; ra.a2_onehot = 1;
+    ra.ops = A.ops1; ra.ops_off = A.off1; ra.ops_len = A.len1;
+    ra.rows0 = A.rows0; ra.rows1 = A.rows1;
+    ra.npairs = nt;
+    HIP_TRY(launch_alignment_rows(ra, st));
+  }
+  // ---- 1. findBreakpoint (indigo.h:196), 4. findHomozygousBreakpoint (indigo.h:314-317), 5. decomposeAlleles, generateSecondaryDecomposed,
+  // allelicFraction (indigo.h:340-350) ----
+  BreakpointOut* bpo = reinterpret_cast<BreakpointOut*>(d_bp);
+  TRY(launch_breakpoint(ctx, A.bpd, nt, h.maxmt, d_prof, bpo));
+  TRY(launch_homozygous(ctx, A.rowsd, A.rows0, A.rows1, nt, bpo, A.hst, A.len1));
+  {
+    DecompArgs a{};
+    a.desc = A.dd;
+    a.rows0 = A.rows0; a.rows1 = A.rows1;
+    a.primary = d_pri; a.secondary = d_sec;
+    a.dcp_indel = d_di; a.dcp_err = d_de;
+    a.out = reinterpret_cast<DecompOut*>(d_dst);
+    a.prm = DecompParams{dp.trim_left, dp.trim_right, dp.maxindel, dp.madc};
+    a.ntraces = nt;
+    a.lens = A.len1;
+    a.skip = sc.dead;
+    TRY(launch_decompose(ctx, a, bpo, maxbc, 0, 0));
+    TRY(launch_secdecomp(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sec, d_sd));
+    TRY(launch_allelic_fraction(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sd, TL, TR, d_fr, 18ull * std::accumulate(h.mf.begin(), h.mf.end(), 0ull)));
+  }
+  hipLaunchKernelGGL(s_status_kernel, g256, b256, 0, st, spm, sc.geom, o.score_trim, A.hst, A.len1, sc.dead, o.status, sc.cnt);
+  HIP_TRY(hipGetLastError());
+
+  // ---- 6. allele-specific alignments (indigo.h:355-387), both alleles of every trace in the same launches ----
+  // strings scored through the query-profile table (MODE_CQ): the two allele strings side by side, case-sensitive codes of the windows
+  // and of allele 2, the test that the rows hold A C G T N only (read with the call's verdict words)
+  uint8_t* d_cq_ref = A.cq_ref + kCodePad;
+  uint8_t* d_cq_sd = A.cq_sd + kCodePad;
+  HIP_TRY(hipMemcpyAsync(A.seqs2, d_pri, z.bext, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(A.seqs2 + z.bext, d_sd, z.bext, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemsetAsync(A.cq_ref, 5, z.er + 2 * kCodePad, st));
+  HIP_TRY(hipMemsetAsync(A.cq_sd, 5, z.bext + 2 * kCodePad, st));
+  HIP_TRY(hipMemsetAsync(A.cq_special, 0, (z.er >> 8) + 2, st));
+  HIP_TRY(hipMemsetAsync(A.cq_flag, 0, sizeof(int32_t) * 4, st));
+  if (z.er) hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((z.er + 255) / 256)), dim3(256), 0, st, d_ref, d_cq_ref, z.er, A.cq_flag, A.cq_special);
+  if (z.bext) {
+    hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((z.bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), d_cq_sd, z.bext, A.cq_flag, (uint8_t*)nullptr);
+    hipLaunchKernelGGL(cq_rows_kernel, dim3((unsigned)((2 * z.bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(A.seqs2), 2 * z.bext, A.cq_flag);
+  }
+  HIP_TRY(hipGetLastError());
+  const int16_t* d_aqp = static_cast<const int16_t*>(ctx->d_b16tab[0].p);
+  TRY(timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, atab_tot * 2));
+  HIP_TRY(launch_b16_tables(A.atd, 2 * nt, A.seqs2, true, p.match, p.mismatch, sub_limit(&p), kTagShift, const_cast<int16_t*>(d_aqp), static_cast<int32_t*>(ctx->d_err.p), st));
+  TRY(timing_end(ctx));
+  hipLaunchKernelGGL(s_allele_plan0_kernel, g256x2, b256, 0, st, spm, spd, sc.geom, A.geomd, sc.tr, sc.dead, sc.pre, sc.fd, sc.cnt);
+  HIP_TRY(hipGetLastError());
+  {
+    DpArgs a{};
+    a.pairs = sc.pre;
+    a.a1 = A.seqs2; a.a2 = d_cq_ref; a.err = static_cast<int32_t*>(ctx->d_err.p);
+    a.match = p.match; a.mismatch = p.mismatch; a.go = p.go; a.ge = p.ge; a.hfree = p.hfree; a.vfree = p.vfree;
+    a.qlimit = sub_limit(&p);
+    a.special_blocks = kn.no_compact ? nullptr : A.cq_special;
+    a.lastrow = d_lastrow;
+    TRY(timing_begin(ctx, TRACYHIP_TIMER_SCORE, 0, 0));
+    HIP_TRY(launch_gotoh_front_prefix_cq(a, 2 * nt, st));
+    TRY(timing_end(ctx));
+  }
+  TRY(timing_begin(ctx, TRACYHIP_TIMER_FRONT, 0, 0));
+  {
+    int rc = front_tier(ctx, p, sc.fd, 2 * nt, d_aqp, d_cq_ref, reinterpret_cast<const uint32_t*>(d_lastrow), 8, 60, max_arest, sc.fpairs1, sc.fo1, sc.fs1, sc.fe1, nullptr);
+    if (!rc) rc = front_tier(ctx, p, sc.fd, 2 * nt, d_aqp, d_cq_ref, reinterpret_cast<const uint32_t*>(d_lastrow), kFrontK, kFrontHalfW, max_arest, sc.fpairs2, sc.fo2, sc.fs2,
+                             sc.fe2, sc.fo1);
+    if (rc) return give_up(rc);
+  }
+  TRY(timing_end(ctx));
+  hipLaunchKernelGGL(s_allele_plan1_kernel, g256x2, b256, 0, st, spm, spd, sc.geom, A.geomd, sc.tr, sc.fo1, sc.fs1, sc.fe1, sc.fo2, sc.fs2, sc.fe2, A.al, sc.dead, sc.cand,
+                     sc.kc, sc.cnt);
+  HIP_TRY(hipGetLastError());
+  BandLaunch b1;
+  b1.kind = 1; b1.qp = d_aqp; b1.codes = d_cq_ref; b1.ends = sc.ends; b1.code_cap = ncap; b1.hfree = 1;
+  TRY(band_stage(ctx, p, sc, 2 * nt, nt, 1, b1, ~0ull));
+  hipLaunchKernelGGL(s_allele_plan2_kernel, g256x2, b256, 0, st, spm, sc.geom, A.geomd, sc.tr, sc.ends, A.al, sc.dead, sc.cand, sc.kc, sc.cnt);
+  HIP_TRY(hipGetLastError());
+  BandLaunch b2;
+  b2.kind = 0; b2.qp = d_aqp; b2.codes = d_cq_ref; b2.scores = A.ascore; b2.ops = d_opsK[0]; b2.ops_off = A.aops_off; b2.ops_len = A.alen; b2.code_cap = ncap; b2.hfree = 1;
+  TRY(band_stage(ctx, p, sc, 2 * nt, nt, 2, b2, words_cap));
+  hipLaunchKernelGGL(s_allele_check_kernel, g256x2, b256, 0, st, spm, A.al, A.ascore, A.alen, sc.dead, sc.cnt);
+  hipLaunchKernelGGL(s_a12_plan_kernel, g256, b256, 0, st, spm, spd, A.geomd, A.ascore, sc.dead, sc.cand, sc.kc, A.bound, sc.cnt);
+  HIP_TRY(hipGetLastError());
+  BandLaunch b3;
+  b3.kind = 0; b3.qp = d_aqp; b3.codes = d_cq_sd; b3.scores = o.score[2]; b3.ops = d_opsK[2]; b3.ops_off = A.ops2_off; b3.ops_len = o.ops_len[2]; b3.code_cap = ncap; b3.hfree = 0;
+  TRY(band_stage(ctx, pglobal, sc, nt, nt, 3, b3, words_cap));
+  hipLaunchKernelGGL(s_decompose_finish_kernel, g256, b256, 0, st, spm, sc.tr, A.al, A.ascore, A.alen, A.bound, sc.dead, o, sc.cnt);
+  HIP_TRY(hipGetLastError());
+
+  // ---- the one read-back ----
+  const size_t rb = sizeof(int32_t) * (kErrWords + 4) + sizeof(int32_t) * 4 + sizeof(unsigned long long) * (SC_COUNT + SB_COUNT * 8) + sizeof(uint32_t) * (size_t)nt;
+  HIP_TRY(ctx->h_res.ensure(rb));
+  char* hp = static_cast<char*>(ctx->h_res.p);
+  int32_t* herr = reinterpret_cast<int32_t*>(hp);
+  int32_t* hcq = herr + (kErrWords + 4);
+  unsigned long long* hcnt = reinterpret_cast<unsigned long long*>(hcq + 4);
+  unsigned long long* hbst = hcnt + SC_COUNT;
+  uint32_t* hdead = reinterpret_cast<uint32_t*>(hbst + SB_COUNT * 8);
+  HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(int32_t) * (kErrWords + 4), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hcq, A.cq_flag, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hcnt, sc.cnt, sizeof(unsigned long long) * SC_COUNT, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hbst, sc.bstat, sizeof(unsigned long long) * SB_COUNT * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hdead, sc.dead, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx_sync(ctx));
+  timing_collect(ctx);
+  if (herr[kErrVerdictWord] & 4) {
+    (void)give_up(kStreamNo);
+    return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
+  }
+  TRY(give_up(stream_range_verdict(p, herr, h)));
+  if (hcq[0] & 1) return give_up(kStreamNo);  // a basecall string holds something else than A C G T N: the byte-compare kernels (pipeline.hip)
+  static const int stage_timer[4] = {TRACYHIP_TIMER_TRACE, TRACYHIP_TIMER_ORIGIN, TRACYHIP_TIMER_TRACE, TRACYHIP_TIMER_TRACE};
+  stats_from_counters(ctx, hcnt, hbst, 4, stage_timer);
+  ctx->stats.stream_ordered = 1;
+
+  // ---- traces the device could not give their tier: the host-planned pipeline on the list, from the basecalls as they were ----
+  std::vector<uint32_t> dl;
+  for (uint32_t t = 0; t < nt; ++t)
+    if (hdead[t]) dl.push_back(t);
+  ctx->stats.fallback_traces += (uint32_t)dl.size();
+  if (kn.verbose) {
+    uint32_t why[16] = {};
+    for (uint32_t t : dl) for (int b = 0; b < 16; ++b) why[b] += (hdead[t] >> b) & 1u;
+    fprintf(stderr, "stream-ordered decompose: %u traces, %zu to the host-planned tiers (front %u, strand %u, loser won %u, junk %u, prelim band %u / check %u, mem %u, allele front %u / origin %u / band %u / check %u, a12 band %u / check %u, shape %u)\n",
+            nt, dl.size(), why[0], why[1], why[2], why[3], why[4], why[5], why[8], why[9], why[10], why[11], why[12], why[13], why[14], why[15]);
+  }
+  if (!dl.empty()) {
+    const uint32_t nd = (uint32_t)dl.size();
+    HIP_TRY(hipMemcpyAsync(A.dead_list, dl.data(), sizeof(uint32_t) * nd, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(s_restore_kernel, dim3(nd), dim3(64), 0, st, A.dead_list, sc.geom, A.geomd, A.pri_bak, A.sec_bak, d_pri, d_sec);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(ctx_sync(ctx));
+    std::vector<uint64_t> poff(nd), sigoff(nd), bcoff(nd), dcpoff(nd), ooff[3];
+    std::vector<uint32_t> plen(nd), ridx(nd), nsamp(nd), bclen(nd);
+    for (int k = 0; k < 3; ++k) ooff[k].resize(nd);
+    for (uint32_t i = 0; i < nd; ++i) {
+      const uint32_t t = dl[i];
+      poff[i] = sp.offset[t]; plen[i] = sp.length[t]; ridx[i] = h.ridx[t];
+      sigoff[i] = bc.signal_offset[t]; nsamp[i] = bc.nsamples[t]; bcoff[i] = bc.bc_offset[t]; bclen[i] = bc.bc_len[t];
+      dcpoff[i] = out->dcp_offset[t];
+      for (int k = 0; k < 3; ++k) ooff[k][i] = out->ops_offset[k][t];
+    }
+    tracyhip_decompose_job j = *job;
+    j.ntraces = nd;
+    j.profiles.data = d_prof; j.profiles.offset = poff.data(); j.profiles.length = plen.data(); j.profiles.count = nd;
+    j.refs.data = d_ref;
+    j.ref_index = ridx.data();
+    j.bc.ntraces = nd;
+    j.bc.signal = d_sig; j.bc.signal_offset = sigoff.data(); j.bc.nsamples = nsamp.data();
+    j.bc.bcpos = d_pos; j.bc.primary = d_pri; j.bc.secondary = d_sec; j.bc.bc_offset = bcoff.data(); j.bc.bc_len = bclen.data();
+    tracyhip_decompose_result r{};
+    r.bp = A.f_bp; r.status = A.f.status; r.score_fwd = A.f.score_fwd; r.score_rev = A.f.score_rev; r.forward = A.f.forward; r.score_trim = A.f.score_trim;
+    r.dcp_indel = d_di; r.dcp_err = d_de; r.dcp_offset = dcpoff.data();
+    r.dstatus = A.f_dst; r.secdecomp = d_sd; r.fractions = A.f_fr;
+    for (int k = 0; k < 2; ++k) { r.slice_begin[k] = A.f.slice_begin[k]; r.slice_len[k] = A.f.slice_len[k]; r.ref_pos[k] = A.f.ref_pos[k]; }
+    for (int k = 0; k < 3; ++k) { r.score[k] = A.f.score[k]; r.ops[k] = d_opsK[k]; r.ops_offset[k] = ooff[k].data(); r.ops_len[k] = A.f.ops_len[k]; }
+    const tracyhip_call_stats keep = ctx->stats;
+    TRY(decompose_traces_legacy(ctx, &j, prm, TRACYHIP_MEM_DEVICE, &r));
+    const uint32_t syncs = ctx->stats.host_syncs;
+    ctx->stats = keep;
+    ctx->stats.host_syncs = syncs;
+    const uint32_t* L = A.dead_list;
+    TRY(scatter(st, L, nd, A.f_bp, d_bp)); TRY(scatter(st, L, nd, A.f_dst, d_dst));
+    TRY(scatter(st, L, nd, reinterpret_cast<const Frac2*>(A.f_fr), reinterpret_cast<Frac2*>(d_fr)));
+    TRY(scatter(st, L, nd, A.f.status, o.status)); TRY(scatter(st, L, nd, A.f.score_fwd, o.score_fwd)); TRY(scatter(st, L, nd, A.f.score_rev, o.score_rev));
+    TRY(scatter(st, L, nd, A.f.forward, o.forward)); TRY(scatter(st, L, nd, A.f.score_trim, o.score_trim));
+    for (int k = 0; k < 2; ++k) {
+      TRY(scatter(st, L, nd, A.f.slice_begin[k], o.slice_begin[k])); TRY(scatter(st, L, nd, A.f.slice_len[k], o.slice_len[k]));
+      TRY(scatter(st, L, nd, A.f.ref_pos[k], o.ref_pos[k]));
+    }
+    for (int k = 0; k < 3; ++k) { TRY(scatter(st, L, nd, A.f.score[k], o.score[k])); TRY(scatter(st, L, nd, A.f.ops_len[k], o.ops_len[k])); }
+    HIP_TRY(ctx_sync(ctx));
+  }
+  if (host) {
+    auto back = [&](void* user, const void* dev, size_t bytes) -> int {
+      if (user && bytes) HIP_TRY(hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, st));
+      return TRACYHIP_OK;
+    };
+    const size_t n4 = sizeof(int32_t) * (size_t)nt;
+    TRY(back(bc.primary, d_pri, z.bext)); TRY(back(bc.secondary, d_sec, z.bext)); TRY(back(out->secdecomp, d_sd, z.bext));
+    TRY(back(out->bp, d_bp, sizeof(tracyhip_breakpoint) * (size_t)nt)); TRY(back(out->fractions, d_fr, sizeof(double) * 2 * (size_t)nt));
+    TRY(back(out->dcp_indel, d_di, z.dext * 4)); TRY(back(out->dcp_err, d_de, z.dext * 4)); TRY(back(out->dstatus, d_dst, sizeof(tracyhip_decomp_status) * (size_t)nt));
+    TRY(back(out->status, o.status, n4)); TRY(back(out->score_fwd, o.score_fwd, n4)); TRY(back(out->score_rev, o.score_rev, n4));
+    TRY(back(out->score_trim, o.score_trim, n4)); TRY(back(out->forward, o.forward, nt));
+    for (int k = 0; k < 2; ++k) { TRY(back(out->slice_begin[k], o.slice_begin[k], n4)); TRY(back(out->slice_len[k], o.slice_len[k], n4)); TRY(back(out->ref_pos[k], o.ref_pos[k], n4)); }
+    for (int k = 0; k < 3; ++k) { TRY(back(out->score[k], o.score[k], n4)); TRY(back(out->ops_len[k], o.ops_len[k], n4)); TRY(back(out->ops[k], d_opsK[k], z.opscap[k])); }
+    HIP_TRY(ctx_sync(ctx));
+  }
+  return TRACYHIP_OK;
 }

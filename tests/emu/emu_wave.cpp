@@ -557,7 +557,7 @@ int emu_front(int Kp, int GLp, int Kb, uint32_t npairs, const float* a1, const u
     f = FrontDesc{};
     f.row_off = d[i].lastrow_off; f.a2_off = a2_off[i]; f.tab_off = off + R; f.tab_stride = stride; f.m_rest = m[i] - R; f.n = n[i];
     f.flags = flags[i] & PAIR_A2_REVCOMP; f.out = i; f.R = R; f.rest = rest;
-    f.tight = (ge <= -2 && second_bound) ? (uint32_t)(rest - rest1) + 1u : 0u;  // (as pipeline.hip fills it)
+    f.tight = (ge <= -2 && (second_bound & 1)) ? (uint32_t)(rest - rest1) + 1u : 0u;  // (as pipeline.hip fills it)
   }
   const uint32_t* rowp = reinterpret_cast<const uint32_t*>(lastrow.data());
   std::vector<PairDesc> bp(npairs);
@@ -578,10 +578,14 @@ int emu_front(int Kp, int GLp, int Kb, uint32_t npairs, const float* a1, const u
   {
     WaveShared sh;
     sh.lds.assign(4u * a.code_cap + b16_table_bytes(Kb) + 4u * 2u * kB16RowCap * 4u + 64, 0);
-    switch (Kb) {
+    const bool cont16 = (second_bound & 2) != 0;  // the band on the 16-bit cells (band16_cont16_body)
+    switch (Kb + (cont16 ? 100 : 0)) {
       case 4: sh.run([&](uint32_t l) { HostWave w{l, &sh}; band16_body<HostWave, 4, 1, true>(w, a, 0); }); break;
       case 8: sh.run([&](uint32_t l) { HostWave w{l, &sh}; band16_body<HostWave, 8, 1, true>(w, a, 0); }); break;
       case 12: sh.run([&](uint32_t l) { HostWave w{l, &sh}; band16_body<HostWave, 12, 1, true>(w, a, 0); }); break;
+      case 104: sh.run([&](uint32_t l) { HostWave w{l, &sh}; band16_cont16_body<HostWave, 4>(w, a, 0); }); break;
+      case 108: sh.run([&](uint32_t l) { HostWave w{l, &sh}; band16_cont16_body<HostWave, 8>(w, a, 0); }); break;
+      case 112: sh.run([&](uint32_t l) { HostWave w{l, &sh}; band16_cont16_body<HostWave, 12>(w, a, 0); }); break;
       default: return -1;
     }
   }

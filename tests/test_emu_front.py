@@ -180,3 +180,35 @@ def test_second_certificate_serves_heterozygous_rows():
                 else:
                     without += 1
     assert with_second >= without + 10 and checked > 20, (with_second, without, checked)
+
+
+def test_band_on_16_bit_cells_equals_the_tagged_form():
+    """band16_cont16_body (the band below the kept row on v_add_u16 / v_max_i16 cells, values kept as H + go + ge) against band16_body
+    CONT (tagged int32 recurrence): the same score and c_e for EVERY pair -- certified or not, both strands, every strip height, row m
+    in any slot of the last strip -- and the matrix's where the certificate holds; several scorings"""
+    rng = random.Random(99)
+    same = certified = 0
+    for it in range(30):
+        Kp, Kb = rng.choice([(4, 4), (4, 8), (4, 12)])
+        GLp = rng.choice([8, 16])
+        R = GLp * Kp
+        halfw = rng.choice([8, 20, (15 * (Kb + 1) - Kb) // 2 - 1])
+        score = rng.choice([SC, SC, (5, -4, -10, -1), (2, -3, -5, -2), (1, -1, -2, -1)])
+        kinds = [rng.choice(["match", "match", "twice", "indel", "noise"]) for _ in range(rng.randint(1, 4))]
+        cases = [make_case(rng, k, R, Kb) for k in kinds]
+        args = ([c[0] for c in cases], [c[1] for c in cases], score, Kp, Kb, halfw)
+        wide, err0 = emu.run_front(*args, revcomp=[c[2] for c in cases], GLp=GLp)
+        narrow, err1 = emu.run_front(*args, revcomp=[c[2] for c in cases], GLp=GLp, cont16=True)
+        assert err0 == 0 and err1 == 0
+        for kind, (prof, given, rc, ref), a, b in zip(kinds, cases, wide, narrow):
+            if a["score"] <= -5000:  # no path of the band reaches row m: both forms show their -inf (and certify nothing)
+                assert b["score"] <= -15000 and a["ok"] == b["ok"] == 0, (it, kind, a, b)
+                continue
+            assert (a["score"], a["c_e"], a["ok"], a["cstar"], a["shift"]) == (b["score"], b["c_e"], b["ok"], b["cstar"], b["shift"]), (it, kind, a, b)
+            same += 1
+            if b["ok"]:
+                q = emu.table_rows(prof, score)
+                _, best, ce = matrix(q, [CODE.get(ch, 5) for ch in ref], R, score)
+                assert (b["score"], b["c_e"]) == (best, ce), (it, kind, b, best, ce)
+                certified += 1
+    assert same > 50 and certified > 15, (same, certified)

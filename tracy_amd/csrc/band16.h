@@ -439,5 +439,189 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   }
 }
 
+
+// ---- CONT on 16-bit cells ---------------------------------------------------------------------------------------------------
+// The sweep below a stored row tracks no origins (Band16Args::row), so where every DP value fits int16 -- narrow_ok(): the condition
+// under which the prefix rows above it were swept in 16 bits already -- it runs on the cell of the 16-bit score sweeps (dp_lane.h
+// cell_left16_last / cell_down16: v_add_u16 / v_max_i16, the 2-cycle class) instead of the tagged int32 recurrence of origin_step
+// (v_max_i32 / v_max3_i32, the 4.4-cycle class, + tag stripping): 9 operations per cell instead of 11 slower ones.  Values are kept
+// as Hg = H + (go + ge), E, F as in score_step16g; the free trailing run of row m is a per-slot constant (rows are anchored at the
+// top here, so row m can be any slot of the last strip); table entries (scores << kTagShift) are turned into score - (go + ge) when a
+// lane copies the rows of its strip into LDS.  Same blocks, windows and hand-over as band16_body; score and c_e are the int32 form's.
+template <class W, int K>
+TR_HD void band16_cont16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
+  static_assert(K == 4 || K == 8 || K == 12, "strip heights of the band kernels");
+  constexpr uint32_t KP = (uint32_t)K + 1u;
+  const uint32_t L = w.lane(), g = L >> 4, j = L & 15u;
+  const uint32_t pair_idx = wave_idx * 4u + g;
+  const uint32_t npairs = a.count ? *a.count : a.npairs;
+  if (wave_idx * 4u >= npairs) return;
+  bool have = pair_idx < npairs;
+  PairDesc d{};
+  if (have) d = a.pairs[a.index ? a.index[pair_idx] : pair_idx];
+  if (d.flags & PAIR_SKIP) { have = false; d = PairDesc{}; }
+  const uint32_t m = d.m, n = d.n;
+  const int32_t dmin = band_dmin(d), dmax = band_dmax(d);
+  const int32_t go = a.go, ge = a.ge, goe = go + ge;
+  const bool hfree = a.hfree != 0;
+  const bool rcflag = (d.flags & PAIR_A2_REVCOMP) != 0;
+  const uint32_t NS = have ? b16_strips(m, K) : 0u;
+  const uint32_t S = b16_window(K, dmin, dmax);
+  const uint32_t S_last = have ? b16_last_window(m, n, K, dmin, dmax) : 0u;
+  const uint32_t NB = S / KP, NB_last = (S_last + (uint32_t)K) / KP;
+  const int32_t neg = kNegInf16;
+  const uint32_t rbase = (uint32_t)d.bits_off;  // rows above the pair's first one
+  auto edge_g = [&](uint32_t r) -> int32_t { return edge_value(false, go, ge, (int32_t)(r + rbase)) + goe; };  // H(r, 0) + goe
+
+  uint8_t* lcodes = reinterpret_cast<uint8_t*>(w.lds()) + g * a.code_cap;
+  int16_t* tab = reinterpret_cast<int16_t*>(w.lds() + 4u * a.code_cap) + L;
+  if (have) {
+    const uint8_t* src = a.codes + d.a2_off;
+    for (uint32_t i = j; i < n; i += 16) lcodes[i] = src[rcflag ? n - 1u - i : i];
+  }
+  // {Hg, F} of row R for the columns strip 0 sweeps and the one before them: the kept row holds exactly these halves
+  int32_t* lrow = reinterpret_cast<int32_t*>(w.lds() + 4u * a.code_cap + b16_table_bytes(K)) + g * (2u * kB16RowCap);
+  const int32_t crow0 = dmin;  // column of lrow[0]: b16_first_col(0) - 1
+  if (have) {
+    const uint32_t* src = a.row + d.lastrow_off;
+    for (uint32_t i = j; i < kB16RowCap; i += 16) {
+      const int32_t cc = crow0 + (int32_t)i;
+      int32_t hh = neg, ff = neg;
+      if (cc == 0) hh = edge_g(0);
+      else if (cc >= 1 && cc <= (int32_t)n) {
+        const uint32_t v = src[cc];
+        hh = (int32_t)(v & 0xffffu);
+        ff = (int32_t)(v >> 16);
+      }
+      lrow[2u * i] = hh;
+      lrow[2u * i + 1u] = ff;
+    }
+  }
+  w.sync();
+  const uint32_t nclamp = n ? n - 1u : 0u;
+  auto code_at = [&](uint32_t cm1) -> uint32_t { return lcodes[cm1 < nclamp ? cm1 : nclamp]; };
+
+  uint32_t B_end = 0, b_last = ~0u;
+  {
+    const uint32_t mine = have ? (NS - 1u) + NB_last : 0u;
+    const uint32_t lastbeg = have ? NS - 1u : ~0u;
+    for (uint32_t q = 0; q < 4; ++q) {
+      const uint32_t x = w.bcast(mine, q * 16u), y = w.bcast(lastbeg, q * 16u);
+      B_end = x > B_end ? x : B_end;
+      b_last = y < b_last ? y : b_last;
+    }
+  }
+
+  int32_t Hl[K], El[K], hext[K], dlt[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) { Hl[i] = neg; El[i] = neg; hext[i] = ge; dlt[i] = 0; }
+  int32_t bot_h = neg, bot_f = neg, prev_up_h = neg;
+  int32_t gev = ge, goev = goe;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(gev), "+v"(goev));  // two live VGPRs for the whole sweep, not re-materialised per step
+#endif
+  uint32_t s_cur = j, cm1 = 0, left = 0;
+  bool live = false;
+  uint32_t raw_next = 0, c_end = 0;
+  const uint32_t slot_m = have && m ? (m - 1u) % (uint32_t)K : 0u;
+
+  constexpr int ND = K / 2;
+  uint32_t pf[kB16Codes][ND];
+  auto prefetch = [&](uint32_t s) {
+    const int16_t* src = a.qp + d.a1_off + (uint64_t)s * K;
+#pragma unroll
+    for (uint32_t b = 0; b < kB16Codes; ++b) __builtin_memcpy(pf[b], src + (uint64_t)b * d.a1_stride, 2 * K);
+  };
+  if (have && j < NS) prefetch(j);
+  SubRows<K, 0> sub;
+
+  auto block = [&](uint32_t b, auto first) {
+    constexpr bool FIRST = decltype(first)::value;
+    if (j == (b & 15u) && have && b < NS) {  // ---- begin strip b ----
+      live = true;
+      s_cur = b;
+      const uint32_t r0 = b * (uint32_t)K;
+      const int32_t cw = b16_first_col(b, K, dmin);
+      cm1 = (uint32_t)(cw - 1);
+      left = (b + 1u == NS) ? NB_last : NB;
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        Hl[i] = cw <= 1 ? edge_g(r0 + (uint32_t)i + 1u) : neg;  // left of the window: column 0 (gotoh.h:117-123), or outside the band
+        El[i] = neg;
+      }
+      if (hfree && b + 1u == NS) {  // row m: free end gap -- E = max(H, E) there
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+          if ((uint32_t)i == slot_m) { hext[i] = 0; dlt[i] = -goe; }
+      }
+      bot_h = cw <= 0 ? edge_g(r0 + (uint32_t)K) : neg;
+      bot_f = neg;
+      if (b == 0) prev_up_h = lrow[2 * (cw - 1 - crow0)];
+#pragma unroll
+      for (uint32_t q = 0; q < kB16Codes; ++q) {
+        const uint32_t rowsel = (rcflag && q < 4u) ? 3u - q : q;
+#pragma unroll
+        for (int h = 0; h < ND; ++h) {  // entries are scores << kTagShift: back to the score, minus (go + ge) (the cell adds it to Hg)
+          tab[(rowsel * K + 2 * h) * 64] = (int16_t)(((int32_t)(int16_t)(pf[q][h] & 0xffffu) >> kTagShift) - goe);
+          tab[(rowsel * K + 2 * h + 1) * 64] = (int16_t)(((int32_t)(int16_t)(pf[q][h] >> 16) >> kTagShift) - goe);
+        }
+      }
+      raw_next = code_at(cm1);
+      if (b + 16u < NS) prefetch(b + 16u);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < KP; ++k) {
+      int32_t up_h = w.rot16(bot_h);
+      int32_t up_f = w.rot16(bot_f);
+      if (FIRST) {
+        if (live && s_cur == 0) {
+          const int32_t c = (int32_t)cm1 + 1;
+          const uint32_t i = (uint32_t)(c - crow0) < kB16RowCap ? (uint32_t)(c - crow0) : kB16RowCap - 1u;
+          up_h = lrow[2u * i];
+          up_f = lrow[2u * i + 1u];
+          if ((uint32_t)(c - crow0) >= kB16RowCap) { up_h = neg; up_f = neg; }
+        }
+      }
+      const uint32_t raw = raw_next;
+      raw_next = code_at(cm1 + 1u);
+      if (live && cm1 < n) {
+        qp_fetch_rows<K>(tab, raw, sub);
+#pragma unroll
+        for (int i = K - 1; i >= 0; --i) cell_left16_last(Hl[i], El[i], hext[i], i == 0 ? prev_up_h : Hl[i - 1], sub.lo16(i), dlt[i]);
+        int32_t uh = up_h, uf = up_f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { cell_down16(Hl[i], El[i], uh, uf, gev, goev); uh = Hl[i]; }
+        if (b >= b_last) {  // watch row m (the last strip): the trailing run ends at the last column with H > E
+          if (s_cur + 1u == NS) {
+            int32_t hv = 0, ev = 0;
+#pragma unroll
+            for (int i = 0; i < K; ++i)
+              if ((uint32_t)i == slot_m) { hv = Hl[i]; ev = El[i]; }
+            if (sext16(hv) - goe > sext16(ev)) c_end = cm1 + 1u;
+          }
+        }
+        bot_h = uh;
+        bot_f = uf;
+      }
+      prev_up_h = up_h;
+      ++cm1;
+    }
+    if (live && --left == 0u) { live = false; bot_h = neg; bot_f = neg; }
+  };
+  uint32_t b = 0;
+  for (; b < 16u && b < B_end; ++b) block(b, std::true_type{});
+  for (; b < B_end; ++b) block(b, std::false_type{});
+
+  if (have && j == ((NS - 1u) & 15u)) {
+    int32_t hv = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+      if ((uint32_t)i == slot_m) hv = Hl[i];
+    if (a.scores) a.scores[d.out] = sext16(hv) - goe;
+    a.ends[2 * d.out] = 0u;
+    a.ends[2 * d.out + 1] = c_end;
+  }
+}
+
 }  // namespace tracyhip
 #endif

@@ -60,6 +60,12 @@ __global__ __launch_bounds__(64) void band16_cont_kernel(Band16Args a) {
   band16_body<DeviceWave16, K, 1, true>(w, a, blockIdx.x);
 }
 
+template <int K>
+__global__ __launch_bounds__(64) void band16_cont16_kernel(Band16Args a) {
+  DeviceWave16 w;
+  band16_cont16_body<DeviceWave16, K>(w, a, blockIdx.x);
+}
+
 // front.h: one wave per pair
 // prev (or null): the verdicts of an earlier, narrower tier over the same descriptors -- what certified there is an empty slot here
 __global__ __launch_bounds__(64) void front_place_kernel(const FrontDesc* __restrict__ desc, const uint32_t* __restrict__ row, int32_t goe, int32_t halfw,
@@ -159,10 +165,19 @@ hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Ar
   return launch_band16(12, kind, a12, s);
 }
 
-hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s) {
+hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s, bool narrow) {
   if (a.npairs == 0) return hipSuccess;
   const dim3 grid((a.npairs + 3u) / 4u);
   const uint32_t lds = 4u * a.code_cap + b16_table_bytes(K) + 4u * 2u * kB16RowCap * 4u;
+  if (narrow) {
+    switch (K) {
+      case 12: hipLaunchKernelGGL((band16_cont16_kernel<12>), grid, dim3(64), lds, s, a); break;
+      case 8: hipLaunchKernelGGL((band16_cont16_kernel<8>), grid, dim3(64), lds, s, a); break;
+      case 4: hipLaunchKernelGGL((band16_cont16_kernel<4>), grid, dim3(64), lds, s, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (K) {
     case 12: hipLaunchKernelGGL((band16_cont_kernel<12>), grid, dim3(64), lds, s, a); break;
     case 8: hipLaunchKernelGGL((band16_cont_kernel<8>), grid, dim3(64), lds, s, a); break;

@@ -26,7 +26,8 @@ hipError_t launch_band16_multi(int kind, const Band16Args& a12, const Band16Args
 // the three strip heights of a job whose lists and sizes are on the device (Band16Args::index / count; npairs = capacity of each list)
 hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Args& a8, const Band16Args& a4, hipStream_t s);
 // the sweep below a stored prefix row (Band16Args::row; K = 8 or 12), and the two kernels of front.h around it
-hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s);
+// narrow: every DP value of the launch fits int16 (narrow_ok for the tallest pair, rows above the stored one included): the 16-bit cells
+hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s, bool narrow = false);
 struct FrontDesc;
 struct FrontOut;
 // d_prev (or null): verdicts of an earlier tier over the same descriptors; what certified there is skipped

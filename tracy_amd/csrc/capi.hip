@@ -254,7 +254,7 @@ const KnobField kKnobFlags[] = {
     {"no_screen", &CtxKnobs::no_screen}, {"no_band", &CtxKnobs::no_band}, {"no_band16", &CtxKnobs::no_band16},
     {"no_front", &CtxKnobs::no_front}, {"no_prefix", &CtxKnobs::no_prefix}, {"no_vote", &CtxKnobs::no_vote},
     {"no_origin", &CtxKnobs::no_origin}, {"no_subwindow", &CtxKnobs::no_subwindow}, {"no_prelim_origin", &CtxKnobs::no_prelim_origin},
-    {"no_cq", &CtxKnobs::no_cq}, {"no_fused_walk", &CtxKnobs::no_fused_walk}, {"verbose", &CtxKnobs::verbose}};
+    {"no_cq", &CtxKnobs::no_cq}, {"no_fused_walk", &CtxKnobs::no_fused_walk}, {"no_cont16", &CtxKnobs::no_cont16}, {"verbose", &CtxKnobs::verbose}};
 bool same_name(const char* a, const char* b) {
   for (; *a && *b; ++a, ++b)
     if (std::tolower((unsigned char)*a) != std::tolower((unsigned char)*b)) return false;
@@ -1073,7 +1073,7 @@ static int run_front_once(tracyhip_ctx* ctx, const std::vector<FrontDesc>& fd, c
   int trc;
   if ((trc = timing_begin(ctx, TRACYHIP_TIMER_FRONT, cells, bytes))) return trc;
   HIP_TRY(launch_front_place(d_fd, (uint32_t)nf, d_row, prm->go + prm->ge, halfw, d_pairs, d_fo, st));
-  HIP_TRY(launch_band16_cont(KB, a, st));
+  HIP_TRY(launch_band16_cont(KB, a, st, !ctx->knobs.no_cont16));  // (run_front's callers are in the 16-bit domain: the prefix rows above were swept there)
   HIP_TRY(launch_front_certify(d_fd, (uint32_t)nf, d_row, prm->go, prm->ge, halfw, d_fs, d_fe, d_fo, st));
   if ((trc = timing_end(ctx))) return trc;
   std::vector<uint32_t> h_fe(2 * nf);

@@ -543,8 +543,8 @@ struct StreamCommon {  // device arrays of the orientation stage + preliminary a
 
 // what the host works out from the job alone
 struct StreamHost {
-  uint32_t nt = 0;
   std::vector<uint32_t> mf, mt, tl, rn, ridx;
+  uint32_t nt = 0;
   std::vector<SweepClass> classes;
   uint64_t lr_tot = 0, tab_tot = 0;
   uint32_t maxmt = 0, maxmf = 0, max_rest = 0;
@@ -616,7 +616,7 @@ int front_tier(tracyhip_ctx* ctx, const tracyhip_params& p, const FrontDesc* fd,
   a.code_cap = (max_rest + 2u * (uint32_t)halfw + 16u) & ~3u;  // front_place_body: a sub-window is at most m_rest + 2 halfw + 2 columns
   if (4ull * a.code_cap + b16_table_bytes(KB) + 32ull * kB16RowCap > 64u * 1024u) return kStreamNo;
   HIP_TRY(launch_front_place(fd, n, d_row, p.go + p.ge, halfw, pairs, fo, st, prev));
-  HIP_TRY(launch_band16_cont(KB, a, st));
+  HIP_TRY(launch_band16_cont(KB, a, st, !ctx->knobs.no_cont16));
   HIP_TRY(launch_front_certify(fd, n, d_row, p.go, p.ge, halfw, fs, fe, fo, st, prev));
   return TRACYHIP_OK;
 }
@@ -721,21 +721,34 @@ int queue_orientation(tracyhip_ctx* ctx, const tracyhip_params& p, const SParams
 
 // the geometry every trace of a batch has, the sweep order, the workspace offsets; kStreamNo when the batch is not of the stream-ordered shape
 int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqset& sp, const tracyhip_seqset& sr, const uint32_t* ref_index, uint32_t nt,
-                uint32_t trim_l, uint32_t trim_r, StreamHost& h, std::vector<SGeom>& geom) {
+                uint32_t trim_l, uint32_t trim_r, StreamHost& h, SGeom* geom) {
+  h = StreamHost{std::move(h.mf), std::move(h.mt), std::move(h.tl), std::move(h.rn), std::move(h.ridx)};  // (the vectors keep their pages between calls)
   h.nt = nt;
   h.mf.resize(nt); h.mt.resize(nt); h.tl.resize(nt); h.rn.resize(nt); h.ridx.resize(nt);
-  for (uint32_t t = 0; t < nt; ++t) {
-    h.ridx[t] = ref_index ? ref_index[t] : t;
-    if (h.ridx[t] >= sr.count) return set_error(TRACYHIP_ERR_ARG, "ref_index[%u] out of range", t);
-    h.mf[t] = sp.length[t];
-    h.rn[t] = sr.length[h.ridx[t]];
-    uint32_t l = trim_l, r = trim_r;
-    if ((uint64_t)l + r >= h.mf[t]) { l = 0; r = 0; }  // createProfile, profile.h:24-27
-    h.tl[t] = l;
-    h.mt[t] = h.mf[t] - (l + r);
-    h.max_mn = std::max<uint64_t>(h.max_mn, (uint64_t)h.mf[t] + h.rn[t]);
-    h.maxmt = std::max(h.maxmt, h.mt[t]);
-    h.maxmf = std::max(h.maxmf, h.mf[t]);
+  {
+    struct Part { uint64_t max_mn; uint32_t maxmt, maxmf, bad; };
+    Part part[kHostThreads];
+    for (auto& x : part) x = Part{0, 0, 0, ~0u};
+    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+      Part x{0, 0, 0, ~0u};
+      for (uint32_t t = lo; t < hi; ++t) {
+        h.ridx[t] = ref_index ? ref_index[t] : t;
+        if (h.ridx[t] >= sr.count) { x.bad = std::min(x.bad, t); h.ridx[t] = 0; if (sr.count == 0) continue; }
+        h.mf[t] = sp.length[t];
+        h.rn[t] = sr.length[h.ridx[t]];
+        uint32_t l = trim_l, r = trim_r;
+        if ((uint64_t)l + r >= h.mf[t]) { l = 0; r = 0; }  // createProfile, profile.h:24-27
+        h.tl[t] = l;
+        h.mt[t] = h.mf[t] - (l + r);
+        x.max_mn = std::max<uint64_t>(x.max_mn, (uint64_t)h.mf[t] + h.rn[t]);
+        x.maxmt = std::max(x.maxmt, h.mt[t]);
+        x.maxmf = std::max(x.maxmf, h.mf[t]);
+      }
+      part[tid] = x;
+    });
+    uint32_t bad = ~0u;
+    for (const Part& x : part) { h.max_mn = std::max(h.max_mn, x.max_mn); h.maxmt = std::max(h.maxmt, x.maxmt); h.maxmf = std::max(h.maxmf, x.maxmf); bad = std::min(bad, x.bad); }
+    if (bad != ~0u) return set_error(TRACYHIP_ERR_ARG, "ref_index[%u] out of range", bad);
   }
   TRY(check_params(&p, h.max_mn));
   if (!(p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore)) return kStreamNo;
@@ -745,9 +758,10 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
   std::vector<uint32_t> order;
   std::vector<int> kof;
   sweep_order(h, order, kof);
-  geom.resize(nt);
-  uint32_t short_traces = 0;
-  for (uint32_t i = 0; i < nt; ++i) {
+  uint32_t rest_of[kHostThreads] = {};
+  parallel_for(nt, [&](uint32_t lo_, uint32_t hi_, uint32_t tid) {
+   uint32_t max_rest = 0;
+   for (uint32_t i = lo_; i < hi_; ++i) {
     const uint32_t t = order[i];
     // class c holds its A slots then its B slots: [2 lo, 2 lo + n_c) and [2 lo + n_c, 2 hi)
     const SweepClass* cls = nullptr;
@@ -760,10 +774,12 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
     G.full_b = 2 * cls->lo + (cls->hi - cls->lo) + (i - cls->lo);
     const bool front_ok = G.mt > kFrontRows + 2u * (uint32_t)kFrontK && G.rn >= 1 && origin16_ok(&p, G.mt, G.mt - kFrontRows + 2u * (uint32_t)kFrontHalfW + 16u);
     G.flags = front_ok ? SG_FRONT_OK : 0u;
-    short_traces += !front_ok;
-    if (front_ok) h.max_rest = std::max(h.max_rest, G.mt - kFrontRows);
+    if (front_ok) max_rest = std::max(max_rest, G.mt - kFrontRows);
     geom[t] = G;
-  }
+   }
+   rest_of[tid] = max_rest;
+  });
+  for (uint32_t x : rest_of) h.max_rest = std::max(h.max_rest, x);
   for (uint32_t t = 0; t < nt; ++t) {  // workspace offsets in trace order
     SGeom& G = geom[t];
     for (int o = 0; o < 2; ++o) { G.lr_off[o] = h.lr_tot; h.lr_tot += 2ull * ((uint64_t)G.rn + 1); }
@@ -772,7 +788,6 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
     h.tab_tot += (uint64_t)kB16Codes * G.tab_stride;
   }
   if (h.max_rest == 0) return kStreamNo;  // no trace takes the pruned sweep
-  (void)short_traces;
   return TRACYHIP_OK;
 }
 
@@ -845,8 +860,10 @@ int tracyhip::stream_align(tracyhip_ctx* ctx, const tracyhip_align_job* job, con
   tracyhip_params p = *prm;
   p.hfree = 1;  // AlignConfig<true,false> semiglobal (sage.h:165)
   p.vfree = 0;
-  StreamHost h;
-  std::vector<SGeom> geom;
+  static thread_local StreamHost h;
+  // geometry and the ops offsets are laid out in the pinned block they travel from: one copy, no staging
+  HIP_TRY(ctx->h_desc.ensure(sizeof(SGeom) * (size_t)nt + sizeof(uint64_t) * (size_t)nt));
+  SGeom* geom = static_cast<SGeom*>(ctx->h_desc.p);
   TRY(plan_common(ctx, p, sp, sr, job->ref_index, nt, job->trim_left, job->trim_right, h, geom));
   const bool exact = job->strand_by_certificate == 0;
   const bool host_results = mem == TRACYHIP_MEM_HOST;
@@ -892,9 +909,6 @@ int tracyhip::stream_align(tracyhip_ctx* ctx, const tracyhip_align_job* job, con
                        ctx->special_blocks(), d_verr);
     HIP_TRY(hipGetLastError());
   }
-  // geometry and the ops offsets: one pinned block, one copy
-  HIP_TRY(ctx->h_desc.ensure(sizeof(SGeom) * (size_t)nt + sizeof(uint64_t) * (size_t)nt));
-  std::memcpy(ctx->h_desc.p, geom.data(), sizeof(SGeom) * (size_t)nt);
   std::memcpy(static_cast<char*>(ctx->h_desc.p) + sizeof(SGeom) * (size_t)nt, out->ops_offset, sizeof(uint64_t) * (size_t)nt);
   HIP_TRY(hipMemcpyAsync(sc.geom, ctx->h_desc.p, sizeof(SGeom) * (size_t)nt, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(A.ops_off, static_cast<char*>(ctx->h_desc.p) + sizeof(SGeom) * (size_t)nt, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
@@ -1381,14 +1395,16 @@ int tracyhip::stream_decompose(tracyhip_ctx* ctx, const tracyhip_decompose_job* 
   pglobal.hfree = 0;  // AlignConfig<false,false> (indigo.h:381)
   pglobal.vfree = 0;
   const uint32_t TL = (uint32_t)dp.trim_left, TR = (uint32_t)dp.trim_right;
-  StreamHost h;
-  std::vector<SGeom> geom;
+  static thread_local StreamHost h;
+  // geometry and offsets are laid out in the pinned block they travel from
+  HIP_TRY(ctx->h_desc.ensure((sizeof(SGeom) + sizeof(SGeomD) + 4 * sizeof(uint64_t)) * (size_t)nt));
+  SGeom* geom = static_cast<SGeom*>(ctx->h_desc.p);
+  SGeomD* geomd = reinterpret_cast<SGeomD*>(geom + nt);
   TRY(plan_common(ctx, p, sp, sr, job->ref_index, nt, TL, TR, h, geom));
   const bool exact = job->strand_by_certificate == 0;
   const bool host = mem == TRACYHIP_MEM_HOST;
 
   // ---- geometry of the decompose stages (decompose_traces_legacy's, trace by trace) ----
-  std::vector<SGeomD> geomd(nt);
   DecompArena::Sizes z{};
   z.nt = nt; z.exact = exact; z.host = host;
   uint32_t maxbc = 0, maxsl = 0, max_arest = 0;
@@ -1397,6 +1413,7 @@ int tracyhip::stream_decompose(tracyhip_ctx* ctx, const tracyhip_decompose_job* 
     if (bc.bc_len[t] != h.mf[t]) return set_error(TRACYHIP_ERR_ARG, "trace %u: profile has %u columns but %u basecalls", t, h.mf[t], bc.bc_len[t]);
     if (bc.bc_len[t] >= 2u * kMaxIndelGlobal) return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the scan tables hold < %d", t, bc.bc_len[t], 2 * kMaxIndelGlobal);
     SGeomD& D = geomd[t];
+    D = SGeomD{};
     if ((uint64_t)(uint32_t)(TL + TR + 1) >= (uint64_t)h.mf[t]) { D.soff = 0; D.sl = h.mf[t]; }  // trimmedSeq, abif.h:68-75
     else { D.soff = TL; D.sl = h.mf[t] - TL - TR; }
     D.bc_off = bc.bc_offset[t];
@@ -1498,12 +1515,8 @@ int tracyhip::stream_decompose(tracyhip_ctx* ctx, const tracyhip_decompose_job* 
     HIP_TRY(hipGetLastError());
   }
   {
-    const size_t bytes = (sizeof(SGeom) + sizeof(SGeomD) + 4 * sizeof(uint64_t)) * (size_t)nt;
-    HIP_TRY(ctx->h_desc.ensure(bytes));
     char* hp = static_cast<char*>(ctx->h_desc.p);
-    std::memcpy(hp, geom.data(), sizeof(SGeom) * (size_t)nt);
-    SGeomD* hgd = reinterpret_cast<SGeomD*>(hp + sizeof(SGeom) * (size_t)nt);
-    std::memcpy(hgd, geomd.data(), sizeof(SGeomD) * (size_t)nt);
+    SGeomD* hgd = geomd;
     uint64_t* hoff = reinterpret_cast<uint64_t*>(hgd + nt);  // [off1 nt][allele ops 2 nt][allele 1 vs 2 ops nt]
     // (band16_body adds an offset to ONE ops pointer: alleles 1 and 2 reach their buffers through offsets relative to allele 0's, modulo 2^64)
     const uint64_t base1 = (uint64_t)(reinterpret_cast<uintptr_t>(d_opsK[1]) - reinterpret_cast<uintptr_t>(d_opsK[0]));

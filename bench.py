@@ -264,6 +264,7 @@ def main():
     out.ops_offset = ops_off.ctypes.data_as(C.POINTER(C.c_uint64))
     prm = capi.Params(SCORE[0], SCORE[1], SCORE[2], SCORE[3], 1, 0)
 
+    capi.lib().tracyhip_tune_host_allocator()  # (process-wide, opt-in: this process is a benchmark, not somebody else's application)
     ctx = tracy_amd.Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     # headline leg: one lane, so that every kernel has the device to itself and its launch duration means what the
@@ -306,6 +307,7 @@ def main():
         return dt, read_timers()
 
     elapsed, rl = timed_leg()
+    call_stats = ctx.last_call_stats()
     slice_len = r_i32["slice_len"].cpu().numpy().astype(np.int64)
     elapsed_cert, rl_cert = 0.0, None
     if args.certificate_leg:
@@ -334,19 +336,23 @@ def main():
     mt = mf - 2 * TRIM
     cells_rank = int(3 * mt * n * nt + (mf * slice_len).sum())
     tm = torch.tensor([elapsed, float(cells_rank), elapsed_cert, elapsed_lanes[0], elapsed_lanes[1]], dtype=torch.float64, device=dev)
+    elapsed_min = elapsed
     if dist is not None:
         tmax = tm.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tm.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        tmin = tm.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         elapsed_max, cells_all, elapsed_cert_max = float(tmax[0]), float(tsum[1]), float(tmax[2])
         elapsed_lanes = [float(tmax[3]), float(tmax[4])]
+        elapsed_min = float(tmin[0])
     else:
         elapsed_max, cells_all, elapsed_cert_max = elapsed, float(cells_rank), elapsed_cert
 
     # the headline's inputs and results are no longer needed on the device (the parity sample below reads host copies)
     sf_host, ol_host, ops_host = r_i32["score_final"].cpu().numpy(), r_i32["ops_len"].cpu().numpy(), None
-    if world == 1 and args.cpu_sample != 0:
+    if rank == 0 and args.cpu_sample != 0:
         ops_host = r_ops.cpu().numpy()
     if args.workload == "all":
         ctx.close()
@@ -376,34 +382,25 @@ def main():
     ops_per_cell = 8.0  # 16-bit formulation with the shared gap-open term: 4 v_add_u16 + 4 v_max_i16 per cell
     # HBM bytes of one launch as measured by rocprofv3 PMC passes (WRITE_SIZE + FETCH_SIZE, separate passes, summary
     # committed under profiles/): the inputs, the scores and the row-m values of the sweeps the orientation vote keeps
-    traffic, traffic_src = None, None
-    try:
-        import glob
-        pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm.json")))[-1]  # the latest round's PMC summary
-        pmc = json.load(open(pmc_file))
-        per = {c: [r for r in pmc if r["counter"] == c and "gotoh_ckpt" in r["kernel"]] for c in ("WRITE_SIZE", "FETCH_SIZE")}
-        if per["WRITE_SIZE"] and per["FETCH_SIZE"]:
-            traffic = int(per["WRITE_SIZE"][0]["bytes"] + per["FETCH_SIZE"][0]["bytes"])
-            traffic_src = "profiles/%s (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE of this command, same batch)" % os.path.basename(pmc_file)
-    except (OSError, ValueError, KeyError, IndexError):
-        pass
-    band_traffic, band_traffic_src = None, None
-    try:
+    traffic, traffic_src, band_traffic, band_traffic_src = None, None, None, None
+    try:  # (bytes per step of the exact instantiations each timer covers; both timers launch once per step here)
         from tools.legs import pmc_traffic
-        for key in ("band16_multi_kernel<0>", "band16_kernel<12, 0>", "band16_kernel"):  # (a batch of this size runs its strip heights as one launch)
-            band_traffic, band_traffic_src = pmc_traffic(key, "r[0-9][0-9]_pmc_hbm.json")
-            if band_traffic is not None:
-                break
+        traffic, traffic_src = pmc_traffic([r"gotoh_ckpt_prefix_kernel<"], "r[0-9][0-9]_pmc_hbm.json")
+        band_traffic, band_traffic_src = pmc_traffic([r"band16_kernel<\d+, 0>", r"band16_multi(_counted)?_kernel<0>"], "r[0-9][0-9]_pmc_hbm.json")
     except Exception:  # noqa: BLE001
         pass
-    roofline = {"bound": "hbm", "kernel": "gotoh_ckpt_prefix_kernel<K,16,compact,8> (score-only Gotoh, one launch: the full sweeps of the strand the vote does not pick, row m kept, + the 128-row prefixes of the voted strand over the whole window, row 128 kept; cells credited: the rows swept; dominant: %.0f%% of the step)"
+    valu_achieved = kgcups(sc) * ops_per_cell / 1e3
+    # `bound` names the ceiling the numbers show: a score-only DP whose inputs are resident moves almost no bytes (the HBM object beside
+    # it says how few), what limits it is VALU issue -- so achieved / peak / frac are lane-operations per second
+    roofline = {"bound": "valu", "kernel": "gotoh_ckpt_prefix_kernel<K,16,compact,8> (score-only Gotoh, one launch: the full sweeps of the strand the vote does not pick -- row m kept only where the vote is unclear -- + the 128-row prefixes of the voted strand over the whole window, row 128 kept; cells credited: the rows swept; dominant: %.0f%% of the step)"
                 % (100.0 * sc["ms"] / steps / (elapsed_max / steps * 1e3)),
-                "achieved": round(gbs(sc), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs(sc) / HBM_PEAK_GBS, 5),
+                "achieved": round(valu_achieved, 2), "peak": 78.6, "unit": "T lane-ops/s", "frac": round(valu_achieved / 78.6, 3),
+                "ops_per_cell": ops_per_cell, "note": "integer DP is VALU-issue bound; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(score_launch_ms, 3), "launches": sc["launches"],
                 "algorithmic_bytes_per_launch": sc["bytes"] // max(sc["launches"], 1), "kernel_gcups": round(kgcups(sc), 1),
-                "valu": {"achieved": round(kgcups(sc) * ops_per_cell / 1e3, 2), "peak": 78.6, "unit": "T lane-ops/s",
-                         "frac": round(kgcups(sc) * ops_per_cell / 1e3 / 78.6, 3),
-                         "note": "integer DP is VALU-issue bound; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"},
+                "hbm": {"achieved": round(gbs(sc), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs(sc) / HBM_PEAK_GBS, 5),
+                        "algorithmic_bytes_per_launch": sc["bytes"] // max(sc["launches"], 1), "traffic": traffic},
+                "valu": {"achieved": round(valu_achieved, 2), "peak": 78.6, "unit": "T lane-ops/s", "frac": round(valu_achieved / 78.6, 3)},
                 # the final alignments run on the band kernels (band16.h): a certified diagonal band per pair, four pairs per wave; cells and
                 # bytes are those of the band (strips x window steps x K cells, K/2 bytes of trace nibbles per strip and step), not the matrix
                 "traceback_kernel": {"kernel": "band16_kernel<K,0> (traceback of the final alignments on their certified diagonal bands, sixteen lanes per pair, the pair's lanes walk it; cells / bytes credited: the band's)",
@@ -442,6 +439,10 @@ def main():
         "gcups_swept_cells": round(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin", "front")) / steps * world / (elapsed_max / steps) / 1e9, 2),
         "cells_swept_per_step_rank0": int(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin", "front")) / steps),
         "roofline": roofline,
+        # rank 0's view of a call: planned on the device, one host synchronisation (stream.hip); min / max over the ranks
+        "pipeline": {"stream_ordered": call_stats["stream_ordered"], "host_syncs_per_call": call_stats["host_syncs"],
+                     "traces_to_host_planned_tiers": call_stats["fallback_traces"], "ms_per_step_rank_min": round(elapsed_min / args.steps * 1e3, 3),
+                     "ms_per_step_rank_max": round(elapsed_max / args.steps * 1e3, 3), "host_threads_per_rank": max(1, usable_cores() // max(1, world))},
     }
     if rl_cert is not None:
         csc, cpf = rl_cert["score"], rl_cert["prefix"]
@@ -469,8 +470,8 @@ def main():
         if elapsed_lanes[1] > 0:
             line["lanes"]["strand_by_certificate"] = {"ms_per_step": round(elapsed_lanes[1] / args.steps * 1e3, 3),
                                                       "traces_per_s": round(nt * world * args.steps / elapsed_lanes[1], 1)}
-    if world == 1:
-        nthreads = usable_cores()  # all host cores this process may use, one trace per thread
+    if True:  # (rank 0 at any N, on its share of the node's cores: every rank of a one-node job runs host work at the same time)
+        nthreads = max(1, usable_cores() // max(1, world))  # one trace per thread
         sample = args.cpu_sample if args.cpu_sample >= 0 else max(8, min(40 * nthreads, 2048))  # ~10 s of CPU work
         if sample > 0:
             v, ns, dt, ores = cpu_baseline(profs, refs, nthreads, sample)

@@ -164,7 +164,10 @@ int tracyhip_gotoh_align(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const t
  * free horizontal end gaps: a path that leaves [-W - (m-n)+, W + (n-m)+] makes more than W vertical gap steps, so it scores at
  * most match*m - (match + |ge|)(W+1) - |go|; a banded score above that is the optimum.  This is the form the
  * pipelines below use internally for their final alignments.  CHAR x CHAR or PROFILE x CHAR pairs, AlignConfig<hfree,false>,
- * go <= 0, ge < 0, bands of at most 183 diagonals (TRACYHIP_ERR_RANGE beyond).  A pair whose traceback walk leaves its band reports
+ * go <= 0, ge < 0, bands of at most 184 diagonals and references of at most ~14 800 columns (the codes of four pairs are staged in
+ * LDS; TRACYHIP_ERR_RANGE beyond).  CHAR rows must hold the letters A C G T N only (the kernels score through a five-letter table,
+ * so any other byte would mismatch an identical column byte where gotoh.h compares bytes): TRACYHIP_ERR_ARG otherwise -- such
+ * strings go through tracyhip_gotoh_align.  Columns may hold any byte (other letters mismatch every row, as in gotoh.h).  A pair whose traceback walk leaves its band reports
  * ops_len 0.  ends != NULL: the origin-tracking sweep instead of the traceback -- scores and ends[2i] = leading 'h' columns,
  * ends[2i+1] = last column that is not a trailing 'h' (what trimReferenceSlice, fmindex.h:429-463, reads); ops* may be NULL then. */
 int tracyhip_gotoh_banded(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyhip_params* prm, const int32_t* band_lo,

@@ -112,3 +112,20 @@ def test_banded_profile_rows(ctx):
     sc, btr = ctx.align_banded(a1, a2, SC + (1, 0), lo, hi)
     for i, (ws, wb) in enumerate(wants):
         assert (int(sc[i]), btr[i]) == (ws, wb), i
+
+
+def test_banded_string_rows_outside_the_five_letters_are_refused(ctx):
+    """the string tables of the band kernels know A C G T N: a row with any other byte (lower case, IUPAC, '-') is refused with
+    TRACYHIP_ERR_ARG instead of being scored as a mismatch against an identical column byte (gotoh.h compares bytes, align.h:96-101);
+    columns may hold anything, and the same rows in upper case go through"""
+    from tracy_amd import capi
+    good = b"ACGTNACGTTGCA" * 8
+    col = b"ACGTRYacgt-NACGTTGCA" * 6  # columns: any byte (they mismatch every row letter they are not)
+    lo, hi = [-(len(good))], [len(col)]
+    band = (max(lo[0], -60), min(hi[0], 60))
+    sc, btr = ctx.align_banded([good], [col], SC + (1, 0), [band[0]], [band[1]])
+    assert len(btr[0]) > 0 or int(sc[0]) <= 0
+    for bad in (good[:5] + b"a" + good[6:], good[:9] + b"R" + good[10:], good[:3] + b"-" + good[4:]):
+        with pytest.raises(capi.TracyHipError) as e:
+            ctx.align_banded([bad], [col], SC + (1, 0), [band[0]], [band[1]])
+        assert e.value.code == capi.ERR_ARG and "A C G T N" in str(e.value)

@@ -86,35 +86,61 @@ def sum_over_ranks(dist, dev, values):
     return [float(x) for x in t]
 
 
-def pmc_traffic(kernel_substr, tag_glob="r[0-9][0-9]_pmc_hbm*.json"):
-    """HBM bytes per launch of a kernel from the latest committed rocprofv3 PMC summary (WRITE_SIZE + FETCH_SIZE, separate passes)"""
+def min_over_ranks(dist, dev, values):
+    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return [float(x) for x in t]
+
+
+def pmc_traffic(patterns, tag_glob="r[0-9][0-9]_pmc_hbm*.json"):
+    """HBM bytes PER STEP of the kernels whose names match one of `patterns` (regular expressions: the exact instantiations a timer
+    covers), from the latest committed rocprofv3 PMC summary (WRITE_SIZE + FETCH_SIZE, separate passes): every matching kernel's
+    bytes per launch x its launches, divided by the steps of the profiled run (= the launches of encode_codes_kernel, once per step)"""
     import glob
     import json
+    import re
+    if isinstance(patterns, str):
+        patterns = [patterns]
+    rx = [re.compile(p) for p in patterns]
     try:
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", tag_glob)), reverse=True):
             pmc = json.load(open(f))
-            per = {c: [r for r in pmc if r["counter"] == c and kernel_substr in r["kernel"]] for c in ("WRITE_SIZE", "FETCH_SIZE")}
-            if per["WRITE_SIZE"] and per["FETCH_SIZE"]:
-                w = max(per["WRITE_SIZE"], key=lambda r: r["bytes"])
-                fch = max(per["FETCH_SIZE"], key=lambda r: r["bytes"])
-                return int(w["bytes"] + fch["bytes"]), "profiles/%s (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes)" % os.path.basename(f)
+            steps = max([r["launches"] for r in pmc if "encode_codes_kernel" in r["kernel"]] or [0])
+            if not steps:
+                steps = min([r["launches"] for r in pmc] or [0])
+            tot, seen = 0.0, set()
+            for c in ("WRITE_SIZE", "FETCH_SIZE"):
+                for r in pmc:
+                    if r["counter"] == c and any(x.search(r["kernel"]) for x in rx):
+                        tot += r["bytes"] * r["launches"]
+                        seen.add(c)
+            if steps and len(seen) == 2:
+                return int(tot / steps), "profiles/%s (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes; per step, summed over the instantiations the timer covers)" % os.path.basename(f)
     except (OSError, ValueError, KeyError, IndexError):
         pass
     return None, None
 
 
 def kernel_block(name, kernel, t, steps, ops_per_cell=None, flops_per_cell=None, traffic_key=None, traffic_glob="r[0-9][0-9]_pmc_hbm*.json"):
-    """roofline object of one kernel class from the library's HIP-event timers"""
+    """roofline object of one kernel class from the library's HIP-event timers.  `bound` names the ceiling the numbers show: integer DP
+    with its inputs resident is VALU-issue bound (achieved / peak / frac are then lane-ops per second); the HBM figures stay beside it."""
     ms = t["ms"]
     gbs = t["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     gc = t["cells"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    traffic, src = pmc_traffic(traffic_key, traffic_glob) if traffic_key else (None, None)  # (the PMC summary of THIS workload: kernels are shared between the legs)
-    out = {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+    per_step, src = pmc_traffic(traffic_key, traffic_glob) if traffic_key else (None, None)  # (the PMC summary of THIS workload: kernels are shared between the legs)
+    launches_per_step = max(t["launches"], 1) / max(steps, 1)
+    traffic = int(per_step / launches_per_step) if per_step is not None else None
+    hbm = {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+           "algorithmic_bytes_per_launch": t["bytes"] // max(t["launches"], 1), "traffic": traffic, "traffic_source": src}
+    out = {"bound": "hbm", "kernel": kernel, "achieved": hbm["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"],
            "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(ms / max(t["launches"], 1), 3), "launches": t["launches"],
-           "algorithmic_bytes_per_launch": t["bytes"] // max(t["launches"], 1), "kernel_gcups": round(gc, 1), "timer": name}
+           "algorithmic_bytes_per_launch": hbm["algorithmic_bytes_per_launch"], "kernel_gcups": round(gc, 1), "timer": name}
     if ops_per_cell:
         out["valu"] = {"achieved": round(gc * ops_per_cell / 1e3, 2), "peak": VALU_PEAK, "unit": "T lane-ops/s",
                        "frac": round(gc * ops_per_cell / 1e3 / VALU_PEAK, 3), "ops_per_cell": ops_per_cell}
+        if out["valu"]["frac"] > hbm["frac"]:  # the ceiling the numbers show
+            out.update({"bound": "valu", "achieved": out["valu"]["achieved"], "peak": VALU_PEAK, "unit": "T lane-ops/s", "frac": out["valu"]["frac"], "hbm": hbm})
     if flops_per_cell:
         out["fp32_vector"] = {"achieved": round(gc * flops_per_cell / 1e3, 2), "peak": FP32_VECTOR_PEAK, "unit": "TFLOP/s",
                               "frac": round(gc * flops_per_cell / 1e3 / FP32_VECTOR_PEAK, 3), "flops_per_cell": flops_per_cell,
@@ -209,9 +235,36 @@ class DecomposeLeg:
         # 3 profile DPs (2 orientation scores + the traceback of the trimmed trace), 2 x gotoh(allele, window), 2 x gotoh(allele, slice), pri vs sec
         return int(3 * mt * self.n * self.nt + 2 * mt * self.n * self.nt + (mt * sl[0]).sum() + (mt * sl[1]).sum() + mt * mt * self.nt)
 
+    def small_batch(self, small, steps=6):
+        """the first `small` traces of this rank's block as a call of their own (the shard an 8-GPU job of 100 000 traces gives every
+        rank): what a step costs when the kernels no longer fill the device for long -- fixed latencies do not shrink with the batch"""
+        nt = self.nt
+        if small <= 0 or small >= nt:
+            return None
+        self.job.ntraces = small
+        self.job.bc.ntraces = small
+        try:
+            for _ in range(2):
+                self.step(None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(None)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            st = self.ctx.last_call_stats()
+        finally:
+            self.job.ntraces = nt
+            self.job.bc.ntraces = nt
+        return {"traces": small, "ms_per_step": round(dt * 1e3, 3), "traces_per_s": round(small / dt, 1), "steps": steps,
+                "stream_ordered": st["stream_ordered"], "host_syncs": st["host_syncs"], "fallback_traces": st["fallback_traces"]}
+
     def run(self, dist, steps, warmup, extra_legs=True, cpu_sample=64):
         dev = self.dev
         dt, timers = timed(lambda: self.step(dist), steps, warmup, dist, self.lib, self.ctx)
+        call_stats = self.ctx.last_call_stats()
+        dt_rank = dt
+        small = self.small_batch(max(1, self.total // 8)) if (self.world == 1 and extra_legs) else None
         cells = self.cells()
         ok_traces = int((self.res["status"] == 0).sum().item())
         snap = {k: v.clone() for k, v in self.res.items() if k not in ("score_fwd", "score_rev")}
@@ -235,6 +288,7 @@ class DecomposeLeg:
         else:
             dt_both = 0.0
         dt, dt_cert, dt_lanes, dt_both = max_over_ranks(dist, dev, [dt, dt_cert, dt_lanes, dt_both])
+        (dt_min,) = min_over_ranks(dist, dev, [dt_rank])
         cells_all, ok_all, nt_all = sum_over_ranks(dist, dev, [float(cells), float(ok_traces), float(self.nt)])
         if self.rank != 0:
             return None
@@ -242,11 +296,11 @@ class DecomposeLeg:
         dom = max((k for k, _ in TIMERS), key=lambda k: timers[k]["ms"])
         names = {"score": ("gotoh_ckpt_prefix_kernel<K,16,compact,8> + gotoh_prefix_kernel<8,16,compact,strings> (16-bit sweeps: the strand the k-mer vote "
                            "does not pick in full, row m kept; the 128-row prefixes of the voted strand and of both alleles over the whole window, row 128 "
-                           "kept for the band below it; cells credited: the rows swept)", 8.0, "gotoh_ckpt_prefix_kernel"),
-                 "front": ("front_place + band16_cont_kernel<K> + front_certify (pruned sweeps: the rows below the prefix on the diagonals around its best "
-                           "column, certified per pair)", 11.0, "band16_cont_kernel"),
-                 "origin": ("band16_kernel<K,1> (gotoh(allele, window) whose alignment only trimReferenceSlice reads: origin-tracking sweep on the band its score allows)", 11.0, "band16_kernel"),
-                 "trace": ("band16_kernel<K,0> (tracebacks on diagonal bands, four pairs per wave: trimmed trace vs window, allele vs trimmed slice, allele 1 vs allele 2; cells / bytes: the bands')", 14.0, "band16_kernel"),
+                           "kept for the band below it; cells credited: the rows swept)", 8.0, [r"gotoh_ckpt_prefix_kernel<", r"gotoh_prefix_kernel<"]),
+                 "front": ("front_place + band16_cont16_kernel<K> + front_certify (pruned sweeps: the rows below the prefix on the diagonals around its best "
+                           "column on 16-bit cells, certified per pair)", 9.0, [r"band16_cont(16)?_kernel<", r"front_place_kernel", r"front_certify_kernel"]),
+                 "origin": ("band16_kernel<K,1> (gotoh(allele, window) whose alignment only trimReferenceSlice reads: origin-tracking sweep on the band its score allows)", 11.0, [r"band16_kernel<\d+, 1>", r"band16_multi(_counted)?_kernel<1>"]),
+                 "trace": ("band16_kernel<K,0> (tracebacks on diagonal bands, four pairs per wave: trimmed trace vs window, allele vs trimmed slice, allele 1 vs allele 2; cells / bytes: the bands')", 14.0, [r"band16_kernel<\d+, 0>", r"band16_multi(_counted)?_kernel<0>"]),
                  "band": ("gotoh_band_kernel<K,QP> (band traceback of the trimmed trace)", 14.0, "gotoh_band_kernel"),
                  "walk": ("gotoh_walk_kernel", None, "gotoh_walk_kernel"), "prefix": ("gotoh_prefix_kernel", 8.0, "gotoh_prefix_kernel"),
                  "decompose": ("decompose_kernel (decomposeAlleles, decompose.h:179-376)", None, "decompose_kernel"),
@@ -265,7 +319,16 @@ class DecomposeLeg:
                 "config": {"workload": "configs[2]: %d synthetic %d-base traces `decompose` vs %d-base windows (80%% het indel + het SNVs, 10%% homozygous "
                                        "indel, 10%% no variant, both strands), sharded over %d rank(s)" % (int(nt_all), self.mf, self.n, self.world),
                            "traces_total": int(nt_all), "trace_len": self.mf, "ref_len": self.n},
-                "traces_ok": int(ok_all), "data": "synthetic", "synthesis_s": round(self.synth_s, 1), "roofline": roof}
+                "traces_ok": int(ok_all), "data": "synthetic", "synthesis_s": round(self.synth_s, 1), "roofline": roof,
+                # one rank's view of the call: planned on the device, one host synchronisation (stream.hip); min / max over the ranks of a sharded job
+                "pipeline": {"stream_ordered": call_stats["stream_ordered"], "host_syncs_per_call": call_stats["host_syncs"],
+                             "traces_to_host_planned_tiers": call_stats["fallback_traces"], "traces_per_rank": self.nt,
+                             "ms_per_step_rank_min": round(dt_min / steps * 1e3, 2), "ms_per_step_rank_max": round(dt / steps * 1e3, 2),
+                             "host_threads_per_rank": rank_threads(self.world)}}
+        if small is not None:
+            small["vs_eighth_of_the_full_step"] = round(small["ms_per_step"] / (dt / steps * 1e3 / 8.0), 3)
+            small["note"] = "the shard one of 8 GPUs gets from this job, as a call of its own on this GPU: strong scaling stays near-linear while this ratio stays near 1"
+            line["small_batch"] = small
         if extra_legs:
             line["strand_by_certificate"] = {"ms_per_step": round(dt_cert / steps * 1e3, 2), "traces_per_s": round(nt_all * steps / dt_cert, 1),
                                              "results_identical_to_headline_leg": bool(same)}
@@ -687,11 +750,17 @@ class CliLeg:
                 rec = {"traces_per_s": round(self.nt / dt, 1), "wall_s": round(dt, 3), "split_s": split, "json_files_written": written,
                        "exit_code": rc, "files_prepared_s": round(prep_s, 1)}
                 if split:
+                    stages = {k: v for k, v in split.items() if k.endswith("_s") and k != "wall_s"}
                     host = split.get("read_basecall_profile_s", 0.0) + split.get("writers_s", 0.0)
-                    rec["host_share_of_the_command"] = round(host / max(dt, 1e-9), 3)
-                    rec["first_bottleneck"] = max((k for k in split if k.endswith("_s")), key=lambda k: split[k])
-                    rec["note"] = ("device_s = packing the batch, tracyhip_*_traces with host buffers (PCIe both ways), unpacking, alignment rows; "
-                                   "gpu_init_s = creating the context (HIP start-up), once per command")
+                    rec["host_stage_seconds_over_wall"] = round(host / max(dt, 1e-9), 3)
+                    rec["first_bottleneck"] = max(stages, key=lambda k: stages[k])
+                    rec["stages_overlap"] = round(sum(stages.values()) / max(split.get("wall_s", dt), 1e-9), 2)
+                    rec["peak_rss_mb"] = split.get("peak_rss_mb")
+                    rec["note"] = ("the manifest runs in blocks of 2000 traces through three stages in flight: host threads read / basecall / profile block "
+                                   "k + 1 and write the files of block k - 1 while the device works on block k; split_s = the seconds each stage was busy "
+                                   "(they overlap: stages_overlap = their sum / wall), peak RSS is bounded by the blocks in flight; device_s = packing a "
+                                   "block, tracyhip_*_traces with host buffers (PCIe both ways), unpacking, alignment rows; gpu_init_s = creating the "
+                                   "context (HIP start-up), once per command")
                 if cpu_sample > 0:
                     rec["cpu_baseline"] = self.cpu_baseline(cmd, b, cpu_sample)
                 out[cmd] = rec

@@ -29,7 +29,10 @@
 #include <sched.h>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <sys/resource.h>
 #include <thread>
 #include <vector>
 
@@ -103,20 +106,103 @@ void for_each_index(uint32_t n, uint32_t threads, Fn fn) {
 }
 // TRACY_AMD_CLI_TIMERS=1: one line on stderr with the wall time of the host and device stages of a --batch run
 struct StageTimes {
-  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), start = t0;
   std::vector<std::pair<std::string, double>> v;
+  std::mutex m;
   void mark(const char* what) {
     const auto t1 = std::chrono::steady_clock::now();
     v.emplace_back(what, std::chrono::duration<double>(t1 - t0).count());
     t0 = t1;
   }
-  void report(uint32_t traces, uint32_t threads) const {
+  // stages that run side by side (run_blocks): the seconds each was busy, summed over its blocks
+  void add(const char* what, double seconds) {
+    std::lock_guard<std::mutex> lk(m);
+    for (auto& e : v)
+      if (e.first == what) { e.second += seconds; return; }
+    v.emplace_back(what, seconds);
+  }
+  void report(uint32_t traces, uint32_t threads) {
     if (!getenv("TRACY_AMD_CLI_TIMERS")) return;
+    struct rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
     std::cerr << "timers: traces " << traces << " host_threads " << threads;
     for (auto const& e : v) std::cerr << " " << e.first << " " << e.second;
-    std::cerr << std::endl;
+    std::cerr << " wall_s " << std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() << " peak_rss_mb " << ru.ru_maxrss / 1024.0 << std::endl;
   }
 };
+struct Stopwatch {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double seconds() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// --batch: the manifest in blocks through three stages in flight.  Host threads read / basecall / profile block k + 1 (`prep`) and
+// write the files of block k - 1 (`write`) while the device works on block k (`device`, on the calling thread, in manifest order);
+// a block's traces are released once its files are written, so memory is bounded by the blocks in flight (four), not by the
+// manifest.  device() returns false to abort the command.  One block = the reference's one-trace-per-process flow, stage after stage.
+constexpr uint32_t kDefaultBlock = 2000;
+inline uint32_t block_size() {
+  const char* e = getenv("TRACY_AMD_CLI_BLOCK");
+  const long v = e ? std::atol(e) : 0;
+  return v >= 1 ? (uint32_t)v : kDefaultBlock;
+}
+template <class Prep, class Device_, class Write>
+bool run_blocks(uint32_t njobs, uint32_t block, Prep prep, Device_ device, Write write) {
+  const uint32_t nb = (njobs + block - 1) / block;
+  if (nb <= 1) {
+    prep(0u, njobs);
+    if (!device(0u, njobs)) return false;
+    write(0u, njobs);
+    return true;
+  }
+  std::mutex m;
+  std::condition_variable cv;
+  uint32_t prepared = 0, deviced = 0, written = 0;  // blocks done by each stage
+  bool abort_ = false;
+  auto range = [&](uint32_t b, uint32_t& lo, uint32_t& hi) { lo = b * block; hi = std::min(njobs, lo + block); };
+  std::thread tp([&]() {
+    for (uint32_t b = 0; b < nb; ++b) {
+      {  // at most two prepared blocks wait for the device, and two for their writers
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return abort_ || b < written + 4u; });
+        if (abort_) return;
+      }
+      uint32_t lo, hi;
+      range(b, lo, hi);
+      prep(lo, hi);
+      { std::lock_guard<std::mutex> lk(m); prepared = b + 1; }
+      cv.notify_all();
+    }
+  });
+  std::thread tw([&]() {
+    for (uint32_t b = 0; b < nb; ++b) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return abort_ || deviced > b; });
+        if (abort_) return;
+      }
+      uint32_t lo, hi;
+      range(b, lo, hi);
+      write(lo, hi);
+      { std::lock_guard<std::mutex> lk(m); written = b + 1; }
+      cv.notify_all();
+    }
+  });
+  bool ok = true;
+  for (uint32_t b = 0; b < nb && ok; ++b) {
+    {
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return prepared > b; });
+    }
+    uint32_t lo, hi;
+    range(b, lo, hi);
+    ok = device(lo, hi);
+    { std::lock_guard<std::mutex> lk(m); if (ok) deviced = b + 1; else abort_ = true; }
+    cv.notify_all();
+  }
+  tp.join();
+  tw.join();
+  return ok;
+}
 
 std::string stamp() {  // boost::posix_time::to_simple_string(second_clock::local_time())
   char buf[64];
@@ -384,7 +470,7 @@ bool gpu_fail(const char* what) {
 
 // rows of gotoh(profile a1, a2) from its op string
 bool alignment_rows(tracyhip_ctx* ctx, tracyhip_seqset const& s1, tracyhip_seqset const& s2, std::vector<uint8_t> const& ops,
-                    std::vector<uint64_t> const& off, std::vector<uint32_t> const& len, std::vector<Job*> const& jobs) {
+                    std::vector<uint64_t> const& off, std::vector<uint32_t> const& len, std::vector<Job*> const& jobs, uint32_t nthreads) {
   tracyhip_pairs pr{};
   pr.npairs = (uint32_t)jobs.size();
   pr.a1 = s1;
@@ -393,7 +479,7 @@ bool alignment_rows(tracyhip_ctx* ctx, tracyhip_seqset const& s1, tracyhip_seqse
   std::unique_ptr<uint8_t[]> r0(new uint8_t[cap]), r1(new uint8_t[cap]);  // (written by the call: no zero fill of 100 MB)
   if (tracyhip_alignment_rows(ctx, &pr, TRACYHIP_MEM_HOST, ops.data(), off.data(), len.data(), r0.get(), r1.get()) != TRACYHIP_OK)
     return gpu_fail("alignment rows");
-  for_each_index((uint32_t)jobs.size(), usable_cores(), [&](uint32_t i) {
+  for_each_index((uint32_t)jobs.size(), nthreads, [&](uint32_t i) {
     jobs[i]->rows.row0.assign(reinterpret_cast<char*>(r0.get()) + off[i], len[i]);
     jobs[i]->rows.row1.assign(reinterpret_cast<char*>(r1.get()) + off[i], len[i]);
   });
@@ -401,7 +487,7 @@ bool alignment_rows(tracyhip_ctx* ctx, tracyhip_seqset const& s1, tracyhip_seqse
 }
 
 // FASTA references: sage.h:233-260 + :311 for every job sharing one (trimLeft, trimRight)
-bool align_fasta_group(Device& dev, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
+bool align_fasta_group(Device& dev, tracyhip_params const& prm, std::vector<Job*> const& jobs, uint32_t nthreads) {
   tracyhip_ctx* ctx = dev.ctx;
   const uint32_t nt = (uint32_t)jobs.size();
   // the batch as two packed payloads: offsets first, then every trace copied to its place by the host threads (a manifest of
@@ -422,7 +508,6 @@ bool align_fasta_group(Device& dev, tracyhip_params const& prm, std::vector<Job*
   }
   std::unique_ptr<float[]> prof(new float[ptot ? ptot : 1]);
   std::unique_ptr<uint8_t[]> refs(new uint8_t[rtot ? rtot : 1]);
-  const uint32_t nthreads = usable_cores();
   for_each_index(nt, nthreads, [&](uint32_t i) {
     Job& j = *jobs[i];
     if (!j.full.v.empty()) std::memcpy(prof.get() + poff[i], j.full.v.data(), j.full.v.size() * sizeof(float));
@@ -463,7 +548,7 @@ bool align_fasta_group(Device& dev, tracyhip_params const& prm, std::vector<Job*
     if (!j.rs.refslice.empty()) std::memcpy(slices.get() + soff[i], j.rs.refslice.data(), j.rs.refslice.size());
   });
   tracyhip_seqset s2{TRACYHIP_SEQ_CHAR, slices.get(), soff.data(), sl.data(), nt};
-  return alignment_rows(ctx, job.profiles, s2, ops, ooff, olen, jobs);
+  return alignment_rows(ctx, job.profiles, s2, ops, ooff, olen, jobs, nthreads);
 }
 
 // wildtype-trace references: sage.h:261-301 + :311 (profile x profile)
@@ -598,51 +683,76 @@ int align_main(int argc, char** argv) {
   echo_command(argc, argv);
 
   std::cout << stamp() << "Load ab1 file" << std::endl;
-  int failed = 0;
+  std::atomic<int> failed(0);
   const uint32_t nthreads = batch ? (c.threads ? c.threads : usable_cores()) : 1;
   StageTimes times;
-  {
-    std::vector<int> rcs(jobs.size(), 0);
-    for_each_index((uint32_t)jobs.size(), nthreads, [&](uint32_t i) { rcs[i] = prepare(c, jobs[i]); });
-    for (size_t i = 0; i < jobs.size(); ++i) {
+  int fatal = 0;  // a single trace that cannot be prepared ends the command with its code (the reference's behaviour)
+  std::vector<int> rcs(jobs.size(), 0);
+  auto prep = [&](uint32_t lo, uint32_t hi) {
+    Stopwatch sw;
+    for_each_index(hi - lo, nthreads, [&](uint32_t i) { rcs[lo + i] = prepare(c, jobs[lo + i]); });
+    for (uint32_t i = lo; i < hi; ++i) {
       if (rcs[i] != 0) {
-        if (!batch) return rcs[i];
+        if (!batch) continue;
         std::cerr << "skipping " << jobs[i].trace_path << std::endl;
         ++failed;
       } else {
         jobs[i].ok = true;
       }
     }
-  }
-  times.mark("read_basecall_profile_s");
-
-  std::cout << stamp() << "Find reference match" << std::endl;
+    times.add("read_basecall_profile_s", sw.seconds());
+  };
   Device dev;
-  if (dev.open(c.devices, 2) != 0) {  // two chunks of a block in flight per GPU (small batches run on one lane)
-    gpu_fail("no usable GPU");
-    return -1;
-  }
-  times.mark("gpu_init_s");
+  bool dev_open = false, said = false;
   tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};  // AlignConfig<true,false>, sage.h:165
-  std::map<std::pair<uint32_t, uint32_t>, std::vector<Job*>> fasta_groups, seeded_groups;
-  std::vector<Job*> wildtype;
-  for (Job& j : jobs) {
-    if (!j.ok) continue;
-    if (j.rs.filetype == 1) fasta_groups[std::make_pair(j.trimLeft, j.trimRight)].push_back(&j);
-    else if (j.rs.filetype == 0) seeded_groups[std::make_pair(j.trimLeft, j.trimRight)].push_back(&j);
-    else wildtype.push_back(&j);
-  }
-  std::cout << stamp() << "Alignment" << std::endl;
-  for (auto& g : fasta_groups)
-    if (!align_fasta_group(dev, prm, g.second)) return -1;
-  for (auto& g : seeded_groups)
-    if (!align_fasta_group(dev, prm, g.second)) return -1;
-  if (!wildtype.empty() && !align_wildtype_group(dev.ctx, prm, wildtype)) return -1;
-
-  times.mark("device_s");
-  std::cout << stamp() << "Output" << std::endl;
-  for_each_index((uint32_t)jobs.size(), nthreads, [&](uint32_t i) { if (jobs[i].ok) write_outputs(c, jobs[i]); });
-  times.mark("writers_s");
+  auto device = [&](uint32_t lo, uint32_t hi) -> bool {
+    if (!batch && rcs[lo] != 0) { fatal = rcs[lo]; return false; }
+    if (!said) std::cout << stamp() << "Find reference match" << std::endl;
+    if (!dev_open) {
+      Stopwatch sw;
+      if (dev.open(c.devices, 2) != 0) {  // two chunks of a block in flight per GPU (small batches run on one lane)
+        gpu_fail("no usable GPU");
+        fatal = -1;
+        return false;
+      }
+      dev_open = true;
+      times.add("gpu_init_s", sw.seconds());
+    }
+    Stopwatch sw;
+    std::map<std::pair<uint32_t, uint32_t>, std::vector<Job*>> fasta_groups, seeded_groups;
+    std::vector<Job*> wildtype;
+    for (uint32_t i = lo; i < hi; ++i) {
+      Job& j = jobs[i];
+      if (!j.ok) continue;
+      if (j.rs.filetype == 1) fasta_groups[std::make_pair(j.trimLeft, j.trimRight)].push_back(&j);
+      else if (j.rs.filetype == 0) seeded_groups[std::make_pair(j.trimLeft, j.trimRight)].push_back(&j);
+      else wildtype.push_back(&j);
+    }
+    if (!said) std::cout << stamp() << "Alignment" << std::endl;
+    said = true;
+    fatal = -1;
+    for (auto& g : fasta_groups)
+      if (!align_fasta_group(dev, prm, g.second, nthreads)) return false;
+    for (auto& g : seeded_groups)
+      if (!align_fasta_group(dev, prm, g.second, nthreads)) return false;
+    if (!wildtype.empty() && !align_wildtype_group(dev.ctx, prm, wildtype)) return false;
+    fatal = 0;
+    times.add("device_s", sw.seconds());
+    return true;
+  };
+  bool said_out = false;
+  auto write = [&](uint32_t lo, uint32_t hi) {
+    Stopwatch sw;
+    if (!said_out) std::cout << stamp() << "Output" << std::endl;
+    said_out = true;
+    for_each_index(hi - lo, nthreads, [&](uint32_t i) {
+      Job& j = jobs[lo + i];
+      if (j.ok) write_outputs(c, j);
+      if (batch) { Job done; done.trace_path.swap(j.trace_path); done.ok = j.ok; j = std::move(done); }  // the block's traces are released here
+    });
+    times.add("writers_s", sw.seconds());
+  };
+  if (!run_blocks((uint32_t)jobs.size(), batch ? block_size() : (uint32_t)jobs.size(), prep, device, write)) return fatal ? fatal : -1;
   times.report((uint32_t)jobs.size(), nthreads);
   std::cout << stamp() << "Done." << std::endl;
   return failed ? 2 : 0;
@@ -686,28 +796,35 @@ bool align_strings(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<st
 
 // rows of alignments whose op strings came back from tracyhip_decompose_traces
 bool rows_from_ops(tracyhip_ctx* ctx, std::vector<std::string> const& a1, std::vector<std::string> const& a2, std::vector<uint8_t> const& ops,
-                   std::vector<uint64_t> const& off, std::vector<uint32_t> const& len, std::vector<AlignRows>& rows) {
+                   std::vector<uint64_t> const& off, std::vector<uint32_t> const& len, std::vector<AlignRows>& rows, uint32_t nthreads = 1) {
   const uint32_t np = (uint32_t)a1.size();
   rows.assign(np, AlignRows());
-  std::vector<uint8_t> d1, d2;
+  // packed payloads: offsets first, then every string copied to its place by the host threads
   std::vector<uint64_t> o1(np), o2(np);
   std::vector<uint32_t> l1(np), l2(np);
+  uint64_t t1 = 0, t2 = 0;
   for (uint32_t i = 0; i < np; ++i) {
-    o1[i] = d1.size(); l1[i] = (uint32_t)a1[i].size(); d1.insert(d1.end(), a1[i].begin(), a1[i].end());
-    o2[i] = d2.size(); l2[i] = (uint32_t)a2[i].size(); d2.insert(d2.end(), a2[i].begin(), a2[i].end());
+    o1[i] = t1; l1[i] = (uint32_t)a1[i].size(); t1 += l1[i];
+    o2[i] = t2; l2[i] = (uint32_t)a2[i].size(); t2 += l2[i];
   }
-  d1.push_back(0); d2.push_back(0);
+  std::unique_ptr<uint8_t[]> d1(new uint8_t[t1 + 1]), d2(new uint8_t[t2 + 1]);
+  for_each_index(np, nthreads, [&](uint32_t i) {
+    if (l1[i]) std::memcpy(d1.get() + o1[i], a1[i].data(), l1[i]);
+    if (l2[i]) std::memcpy(d2.get() + o2[i], a2[i].data(), l2[i]);
+  });
+  d1[t1] = 0; d2[t2] = 0;
   tracyhip_pairs pr{};
   pr.npairs = np;
-  pr.a1 = tracyhip_seqset{TRACYHIP_SEQ_CHAR, d1.data(), o1.data(), l1.data(), np};
-  pr.a2 = tracyhip_seqset{TRACYHIP_SEQ_CHAR, d2.data(), o2.data(), l2.data(), np};
-  std::vector<uint8_t> r0(ops.size()), r1(ops.size());
-  if (tracyhip_alignment_rows(ctx, &pr, TRACYHIP_MEM_HOST, ops.data(), off.data(), len.data(), r0.data(), r1.data()) != TRACYHIP_OK)
+  pr.a1 = tracyhip_seqset{TRACYHIP_SEQ_CHAR, d1.get(), o1.data(), l1.data(), np};
+  pr.a2 = tracyhip_seqset{TRACYHIP_SEQ_CHAR, d2.get(), o2.data(), l2.data(), np};
+  const std::size_t cap = ops.size() ? ops.size() : 1;
+  std::unique_ptr<uint8_t[]> r0(new uint8_t[cap]), r1(new uint8_t[cap]);  // (written by the call: no zero fill)
+  if (tracyhip_alignment_rows(ctx, &pr, TRACYHIP_MEM_HOST, ops.data(), off.data(), len.data(), r0.get(), r1.get()) != TRACYHIP_OK)
     return gpu_fail("alignment rows");
-  for (uint32_t i = 0; i < np; ++i) {
-    rows[i].row0.assign(reinterpret_cast<char*>(r0.data()) + off[i], len[i]);
-    rows[i].row1.assign(reinterpret_cast<char*>(r1.data()) + off[i], len[i]);
-  }
+  for_each_index(np, nthreads, [&](uint32_t i) {
+    rows[i].row0.assign(reinterpret_cast<char*>(r0.get()) + off[i], len[i]);
+    rows[i].row1.assign(reinterpret_cast<char*>(r1.get()) + off[i], len[i]);
+  });
   return true;
 }
 
@@ -749,7 +866,7 @@ bool orient_wildtype(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<
 }
 
 // indigo.h:190-388 for every job sharing one (trimLeft, trimRight): the whole chain runs on the device
-bool decompose_group(Device& dev, SageConfig const& c, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
+bool decompose_group(Device& dev, SageConfig const& c, tracyhip_params const& prm, std::vector<Job*> const& jobs, uint32_t nthreads) {
   tracyhip_ctx* ctx = dev.ctx;
   const uint32_t nt = (uint32_t)jobs.size();
   const bool wildtype = jobs[0]->rs.filetype == 2;  // groups never mix reference kinds
@@ -787,7 +904,6 @@ bool decompose_group(Device& dev, SageConfig const& c, tracyhip_params const& pr
   pk.sec.reset(new uint8_t[btot ? btot : 1]);
   pk.sig.reset(new int32_t[stot ? stot : 1]);
   pk.pos.reset(new int32_t[btot ? btot : 1]);
-  const uint32_t nthreads = usable_cores();
   for_each_index(nt, nthreads, [&](uint32_t i) {
     Job& j = *jobs[i];
     if (!j.full.v.empty()) std::memcpy(pk.prof.get() + poff[i], j.full.v.data(), j.full.v.size() * sizeof(float));
@@ -856,7 +972,8 @@ bool decompose_group(Device& dev, SageConfig const& c, tracyhip_params const& pr
   if (dev.decompose_traces(&job, &prm, &res) != TRACYHIP_OK) return gpu_fail("decompose");
 
   std::vector<std::string> a1[3], a2[3];
-  for (uint32_t i = 0; i < nt; ++i) {
+  for (int k = 0; k < 3; ++k) { a1[k].resize(nt); a2[k].resize(nt); }
+  for_each_index(nt, nthreads, [&](uint32_t i) {
     Job& j = *jobs[i];
     j.status = status[i];
     j.dstatus = dst[i];
@@ -882,19 +999,19 @@ bool decompose_group(Device& dev, SageConfig const& c, tracyhip_params const& pr
       const bool usable = status[i] == 0;
       slot[k]->refslice = usable ? j.rs.refslice.substr(sb[k][i], sl[k][i]) : std::string();
       slot[k]->pos = usable ? j.slice_start + rp[k][i] : 0;
-      a1[k].push_back(k == 0 ? p_t : s_t);
-      a2[k].push_back(slot[k]->refslice);
+      a1[k][i] = k == 0 ? p_t : s_t;
+      a2[k][i] = slot[k]->refslice;
     }
-    a1[2].push_back(p_t);
-    a2[2].push_back(s_t);
+    a1[2][i] = p_t;
+    a2[2][i] = s_t;
     r.a1Score = sc[0][i]; r.a2Score = sc[1][i]; r.a3Score = sc[2][i];
     if (status[i] != 0)
       for (int k = 0; k < 3; ++k) olen[k][i] = 0;
-  }
+  });
   for (int k = 0; k < 3; ++k) {
     std::vector<AlignRows> rows;
-    if (!rows_from_ops(ctx, a1[k], a2[k], ops[k], ooff[k], olen[k], rows)) return false;
-    for (uint32_t i = 0; i < nt; ++i) (k == 0 ? jobs[i]->rep.align1 : k == 1 ? jobs[i]->rep.align2 : jobs[i]->rep.align3) = rows[i];
+    if (!rows_from_ops(ctx, a1[k], a2[k], ops[k], ooff[k], olen[k], rows, nthreads)) return false;
+    for_each_index(nt, nthreads, [&](uint32_t i) { (k == 0 ? jobs[i]->rep.align1 : k == 1 ? jobs[i]->rep.align2 : jobs[i]->rep.align3) = std::move(rows[i]); });
   }
   return true;
 }
@@ -1007,70 +1124,97 @@ int decompose_main(int argc, char** argv) {
   }
   echo_command(argc, argv);
   std::cout << stamp() << "Load ab1 file" << std::endl;
-  int failed = 0;
+  std::atomic<int> failed(0);
   const uint32_t nthreads = batch ? (c.threads ? c.threads : usable_cores()) : 1;
   StageTimes times;
-  {
-    std::vector<int> rcs(jobs.size(), 0);
-    for_each_index((uint32_t)jobs.size(), nthreads, [&](uint32_t i) { rcs[i] = prepare(c, jobs[i], true); });
-    for (size_t i = 0; i < jobs.size(); ++i) {
+  int fatal = 0;
+  std::vector<int> rcs(jobs.size(), 0);
+  auto prep = [&](uint32_t lo, uint32_t hi) {
+    Stopwatch sw;
+    for_each_index(hi - lo, nthreads, [&](uint32_t i) { rcs[lo + i] = prepare(c, jobs[lo + i], true); });
+    for (uint32_t i = lo; i < hi; ++i) {
       if (rcs[i] != 0) {
-        if (!batch) return rcs[i];
+        if (!batch) continue;
         std::cerr << "skipping " << jobs[i].trace_path << std::endl;
         ++failed;
       } else {
         jobs[i].ok = true;
       }
     }
-  }
-  times.mark("read_basecall_profile_s");
-  std::cout << stamp() << "Find Reference Match" << std::endl;
+    times.add("read_basecall_profile_s", sw.seconds());
+  };
   Device dev;
-  if (dev.open(c.devices, 2) != 0) {  // two chunks of a block in flight per GPU (small batches run on one lane)
-    gpu_fail("no usable GPU");
-    return -1;
-  }
-  times.mark("gpu_init_s");
+  bool dev_open = false;
+  uint32_t blocks_done = 0;
   tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};
-  std::map<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>, std::vector<Job*>> groups;  // (reference kind, trims)
-  for (Job& j : jobs)
-    if (j.ok) groups[std::make_pair((uint32_t)j.rs.filetype, std::make_pair(j.trimLeft, j.trimRight))].push_back(&j);
-  std::cout << stamp() << "Alignment" << std::endl;
-  for (auto& g : groups)
-    if (!decompose_group(dev, c, prm, g.second)) return -1;
-  std::cout << stamp() << "InDel Search" << std::endl;
-  std::vector<Job*> good;
-  for (Job& j : jobs) {
-    if (!j.ok) continue;
-    if (j.status != 0) {
-      if (j.status == -1) std::cerr << "Alignment of trace to reference failed!" << std::endl;
-      else if (j.status == -2) std::cerr << "No valid alignment found between consensus and reference!" << std::endl;
-      else std::cerr << "Alignment too short between consensus and reference!" << std::endl;
-      if (!batch) return -1;
-      std::cerr << "skipping " << j.trace_path << std::endl;
-      j.ok = false;
-      ++failed;
-      continue;
+  // (the progress lines of the reference are said once per command, with its first block)
+  auto say = [&](const char* what) { if (blocks_done == 0) std::cout << stamp() << what << std::endl; };
+  auto device = [&](uint32_t lo, uint32_t hi) -> bool {
+    if (!batch && rcs[lo] != 0) { fatal = rcs[lo]; return false; }
+    say("Find Reference Match");
+    fatal = -1;
+    if (!dev_open) {
+      Stopwatch sw;
+      if (dev.open(c.devices, 2) != 0) {  // two chunks of a block in flight per GPU (small batches run on one lane)
+        gpu_fail("no usable GPU");
+        return false;
+      }
+      dev_open = true;
+      times.add("gpu_init_s", sw.seconds());
     }
-    good.push_back(&j);
-  }
-  std::cout << stamp() << "Decompose Chromatogram" << std::endl;
-  for (Job* j : good) {
-    if (j->dstatus.kind == 1)
-      std::cout << "Complex mutation, decomposition: ins: " << j->dstatus.best_ins << ", del: " << j->dstatus.best_del
-                << ", error: " << j->dstatus.best_fr << std::endl;
-    else if (j->dstatus.kind == 2)
-      std::cout << "No InDel detected, traverse the whole alignment." << std::endl;
-  }
-  std::cout << stamp() << "Estimate allelic fractions" << std::endl;
-  std::cout << stamp() << "Allele-specific alignments" << std::endl;
-  if (c.callvariants) {
-    std::cout << stamp() << "Variant Calling" << std::endl;
-    if (!call_variants(dev.ctx, prm, good)) return -1;
-  }
-  times.mark("device_s");
-  for_each_index((uint32_t)good.size(), nthreads, [&](uint32_t i) { write_decompose_outputs(c, *good[i]); });
-  times.mark("writers_s");
+    Stopwatch sw;
+    std::map<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>, std::vector<Job*>> groups;  // (reference kind, trims)
+    for (uint32_t i = lo; i < hi; ++i)
+      if (jobs[i].ok) groups[std::make_pair((uint32_t)jobs[i].rs.filetype, std::make_pair(jobs[i].trimLeft, jobs[i].trimRight))].push_back(&jobs[i]);
+    say("Alignment");
+    for (auto& g : groups)
+      if (!decompose_group(dev, c, prm, g.second, nthreads)) return false;
+    say("InDel Search");
+    std::vector<Job*> good;
+    for (uint32_t i = lo; i < hi; ++i) {
+      Job& j = jobs[i];
+      if (!j.ok) continue;
+      if (j.status != 0) {
+        if (j.status == -1) std::cerr << "Alignment of trace to reference failed!" << std::endl;
+        else if (j.status == -2) std::cerr << "No valid alignment found between consensus and reference!" << std::endl;
+        else std::cerr << "Alignment too short between consensus and reference!" << std::endl;
+        if (!batch) return false;
+        std::cerr << "skipping " << j.trace_path << std::endl;
+        j.ok = false;
+        ++failed;
+        continue;
+      }
+      good.push_back(&j);
+    }
+    say("Decompose Chromatogram");
+    for (Job* j : good) {
+      if (j->dstatus.kind == 1)
+        std::cout << "Complex mutation, decomposition: ins: " << j->dstatus.best_ins << ", del: " << j->dstatus.best_del
+                  << ", error: " << j->dstatus.best_fr << std::endl;
+      else if (j->dstatus.kind == 2)
+        std::cout << "No InDel detected, traverse the whole alignment." << std::endl;
+    }
+    say("Estimate allelic fractions");
+    say("Allele-specific alignments");
+    if (c.callvariants) {
+      say("Variant Calling");
+      if (!call_variants(dev.ctx, prm, good)) return false;
+    }
+    fatal = 0;
+    ++blocks_done;
+    times.add("device_s", sw.seconds());
+    return true;
+  };
+  auto write = [&](uint32_t lo, uint32_t hi) {
+    Stopwatch sw;
+    for_each_index(hi - lo, nthreads, [&](uint32_t i) {
+      Job& j = jobs[lo + i];
+      if (j.ok) write_decompose_outputs(c, j);
+      if (batch) { Job done; done.trace_path.swap(j.trace_path); done.ok = j.ok; j = std::move(done); }  // the block's traces are released here
+    });
+    times.add("writers_s", sw.seconds());
+  };
+  if (!run_blocks((uint32_t)jobs.size(), batch ? block_size() : (uint32_t)jobs.size(), prep, device, write)) return fatal ? fatal : -1;
   times.report((uint32_t)jobs.size(), nthreads);
   std::cout << stamp() << "Done." << std::endl;
   return failed ? 2 : 0;
@@ -1230,6 +1374,7 @@ int index_main(int argc, char** argv) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  tracyhip_tune_host_allocator();  // (process-wide allocator settings are the application's to choose: this process is one)
   if (argc >= 2 && std::strcmp(argv[1], "align") == 0) return align_main(argc - 1, argv + 1);
   if (argc >= 2 && std::strcmp(argv[1], "decompose") == 0) return decompose_main(argc - 1, argv + 1);
   if (argc >= 2 && std::strcmp(argv[1], "assemble") == 0) return assemble_main(argc - 1, argv + 1);

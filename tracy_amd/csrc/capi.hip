@@ -1551,6 +1551,10 @@ static int dp_entry(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const tracyh
 }
 
 // case-sensitive column codes of a string (MODE_CQ, dp_kernels.h cq_code)
+__global__ void cq_rows_check_kernel(const uint8_t* __restrict__ in, uint64_t n, int32_t* flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !tracyhip::cq_row_char(in[i])) atomicOr(flag, 1);
+}
 __global__ void encode_cq_codes_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (uint8_t)tracyhip::cq_code(in[i]);
@@ -1587,6 +1591,21 @@ int tracyhip_gotoh_banded(tracyhip_ctx* ctx, const tracyhip_pairs* pairs, const 
   }
   // one table per a1 sequence
   const tracyhip_seqset& s1 = pairs->a1;
+  if (strings) {
+    // The string tables score a row byte against the column codes A C G T N only (b16_table_row): a row holding any other byte
+    // (lower case, IUPAC, '-') would mismatch an identical column byte, where gotoh.h compares bytes (align.h:96-101) -- refused here,
+    // tracyhip_gotoh_align takes such strings (the pipelines run the same test before they use this form: cq_rows_kernel)
+    const uint64_t e1 = seqset_extent(s1);
+    HIP_TRY(ctx->d_err.ensure(kErrBytes));
+    int32_t* d_flag = static_cast<int32_t*>(ctx->d_err.p) + kErrVerdictWord;
+    HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int32_t), st));
+    if (e1) hipLaunchKernelGGL(cq_rows_check_kernel, dim3((unsigned)((e1 + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(pb.d_a1), e1, d_flag);
+    HIP_TRY(hipGetLastError());
+    int32_t h_flag = 0;
+    HIP_TRY(hipMemcpyAsync(&h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx_sync(ctx));
+    if (h_flag) return set_error(TRACYHIP_ERR_ARG, "tracyhip_gotoh_banded: string rows must hold A C G T N only (the band kernels score through a five-letter table); use tracyhip_gotoh_align");
+  }
   std::vector<B16TableDesc> td(s1.count);
   for (uint32_t i = 0; i < s1.count; ++i) td[i] = B16TableDesc{s1.offset[i], 0, s1.length[i], s1.length[i], 0, 0};
   HIP_TRY(ctx->d_err.ensure(kErrBytes));

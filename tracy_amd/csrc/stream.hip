@@ -138,6 +138,8 @@ __global__ void s_orient_plan_kernel(SParams p, const SGeom* __restrict__ geom, 
     f.R = R;
     f.rest = ub[t];
     f.tight = (p.ge <= -2 && ub1[t] <= ub[t]) ? (uint32_t)(ub[t] - ub1[t]) + 1u : 0u;
+    s_count(lc, SC_FRONT_CELLS, s_front_cells(f.m_rest));
+    s_count(lc, SC_FRONT_BYTES, s_front_bytes(f.m_rest, f.n));
   } else if (cls == 1u) {
     fa = s_stage1_desc(G, t, p.nt, g);
     fb = s_stage1_desc(G, t, p.nt, 1u - g);
@@ -811,6 +813,8 @@ void stats_from_counters(tracyhip_ctx* ctx, const unsigned long long* c, const u
     ctx->acc[TRACYHIP_TIMER_SCORE].bytes += c[SC_SWEEP_BYTES];
     ctx->acc[TRACYHIP_TIMER_DECOMP].cells += c[SC_DECOMP_CELLS];
     ctx->acc[TRACYHIP_TIMER_DECOMP].bytes += c[SC_DECOMP_BYTES];
+    ctx->acc[TRACYHIP_TIMER_FRONT].cells += c[SC_FRONT_CELLS];
+    ctx->acc[TRACYHIP_TIMER_FRONT].bytes += c[SC_FRONT_BYTES];
     for (int i = 0; i < nstages; ++i) {
       ctx->acc[stage_timer[i]].cells += bstat[SB_COUNT * i + SB_CELLS];
       ctx->acc[stage_timer[i]].bytes += bstat[SB_COUNT * i + SB_BYTES];
@@ -1124,6 +1128,8 @@ __global__ void s_allele_plan0_kernel(SParams p, SParamsD pd, const SGeom* __res
   f.rest = (int32_t)((int64_t)pd.best * (int64_t)(D.sl - R));  // a row of a string scores `match` at most
   fd[q] = f;
   s_count(lc, SC_ALLELE_PRUNED0 + (int)k);
+  s_count(lc, SC_FRONT_CELLS, s_front_cells(f.m_rest));
+  s_count(lc, SC_FRONT_BYTES, s_front_bytes(f.m_rest, f.n));
   s_count(lc, SC_SWEEP_CELLS, (uint64_t)R * G.rn);
   s_count(lc, SC_SWEEP_BYTES, (uint64_t)R + 5ull * G.rn);
   });

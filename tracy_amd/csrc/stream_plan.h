@@ -39,6 +39,7 @@ enum : int {
   SC_ALLELE_BANDED0, SC_ALLELE_BANDED1, SC_ALLELE_BANDED2, SC_ALLELE_REPEATED0, SC_ALLELE_REPEATED1, SC_ALLELE_REPEATED2,
   SC_SWEEP_CELLS, SC_SWEEP_BYTES,  // the combined sweep / prefix launches (TRACYHIP_TIMER_SCORE)
   SC_DECOMP_CELLS, SC_DECOMP_BYTES,
+  SC_FRONT_CELLS, SC_FRONT_BYTES,  // the first tier of the pruned sweeps (TRACYHIP_TIMER_FRONT: strips of 8 rows on c* +- 60)
   SC_COUNT
 };
 // per band stage (bucket scan): cells and algorithmic bytes of the launch (kernel timers), bytes of its traceback words
@@ -139,6 +140,10 @@ TR_HD SubWindow s_sub_window(uint32_t m, uint32_t ce, int64_t top, int64_t sstar
 }
 // LDS of a band launch: the codes of four pairs + the tables (run_band16's staging limit, as the host planners test it)
 TR_HD bool s_fits_lds(uint32_t n, int K) { return 4ull * ((n + 7u) & ~3u) + b16_table_bytes(K) <= 60u * 1024u; }
+
+// what the first tier of a pruned sweep over m_rest rows below the kept row and n columns is credited with (run_front_once's sums)
+TR_HD uint64_t s_front_cells(uint32_t m_rest) { return (uint64_t)b16_strips(m_rest, 8) * 8u * (8u + 2u * 60u); }
+TR_HD uint64_t s_front_bytes(uint32_t m_rest, uint32_t n) { return 12ull * m_rest + m_rest + 2ull * 60 + 4ull * (2 * 60 + 8) + 8ull * n; }
 
 TR_HD PairDesc s_skip_pair(uint32_t out) {
   PairDesc d{};

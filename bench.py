@@ -89,7 +89,7 @@ def free_port():
 
 def launch_ranks(args, argv):
     """--gpus N, no torch.distributed environment: become N ranks of one node (one process per GPU, RCCL over xGMI)"""
-    if not args.stub:
+    if not args.stub and not args.share_device:
         have = torch.cuda.device_count()
         if have < args.gpus:
             raise SystemExit("bench.py: --gpus %d but this box exposes %d GPU(s); refusing to report a %d-GPU number from fewer devices"
@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--cli-traces", type=int, default=10000, help="the CLI leg: ABIF files per command (`align --batch`, `decompose --batch`); 0 = skip")
     ap.add_argument("--extra-legs", type=int, default=1, help="decompose: also time the strand-certificate and two-lane legs")
     ap.add_argument("--stub", action="store_true", help="launcher self-test on gloo with a step that does no device work (not a measurement)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="TEST MODE (tests/test_gpu_bench_ranks.py): the N ranks of --gpus N all run on GPU 0 and gather over gloo -- the code path of "
+                         "a multi-GPU run on a one-GPU box; the line says \"shared_device\": true and is not a measurement")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--traces", type=int, default=10000, help="traces per GPU per step")
@@ -172,7 +175,9 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let --gpus N start them)" % (args.gpus, world))
     if args.stub:
         return stub_rank(args, rank, world)
-    if torch.cuda.device_count() < world:
+    if args.share_device:
+        local = 0
+    elif torch.cuda.device_count() < world:
         raise SystemExit("bench.py: %d ranks but %d visible GPU(s)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     if world > 1:  # the library's host workers (descriptor loops between launches): this rank's share of the node's cores, not all of them
@@ -182,7 +187,10 @@ def main():
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.share_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: the process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     dev = torch.device("cuda", local)
@@ -335,7 +343,8 @@ def main():
     # ---- work done: DP cells of the four Gotoh calls per trace ----
     mt = mf - 2 * TRIM
     cells_rank = int(3 * mt * n * nt + (mf * slice_len).sum())
-    tm = torch.tensor([elapsed, float(cells_rank), elapsed_cert, elapsed_lanes[0], elapsed_lanes[1]], dtype=torch.float64, device=dev)
+    tm = torch.tensor([elapsed, float(cells_rank), elapsed_cert, elapsed_lanes[0], elapsed_lanes[1]], dtype=torch.float64,
+                      device="cpu" if args.share_device else dev)
     elapsed_min = elapsed
     if dist is not None:
         tmax = tm.clone()
@@ -494,6 +503,9 @@ def main():
     for k, v in extra.items():
         if v is not None:
             line[k] = v
+    if args.share_device:
+        line["shared_device"] = True  # (a test of the N-rank code path on one GPU: not a measurement)
+        line["backend"] = "gloo"
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

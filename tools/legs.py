@@ -73,21 +73,21 @@ def timed(step, steps, warmup, dist, lib=None, ctx=None):
 
 
 def max_over_ranks(dist, dev, values):
-    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    t = torch.tensor(values, dtype=torch.float64, device="cpu" if (dist is not None and dist.get_backend() == "gloo") else dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [float(x) for x in t]
 
 
 def sum_over_ranks(dist, dev, values):
-    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    t = torch.tensor(values, dtype=torch.float64, device="cpu" if (dist is not None and dist.get_backend() == "gloo") else dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(x) for x in t]
 
 
 def min_over_ranks(dist, dev, values):
-    t = torch.tensor(values, dtype=torch.float64, device=dev)
+    t = torch.tensor(values, dtype=torch.float64, device="cpu" if (dist is not None and dist.get_backend() == "gloo") else dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return [float(x) for x in t]
@@ -609,7 +609,7 @@ class SeedExtendLeg:
         if self.rank != 0:
             return None
         roof = kernel_block("score", "gotoh_ckpt_kernel<K,QP,narrow> (one orientation: the window arrives oriented by the seeds)", timers["score"], steps,
-                            ops_per_cell=8.0, traffic_key=None)
+                            ops_per_cell=8.0, traffic_key=[r"gotoh_ckpt_kernel<"], traffic_glob="r[0-9][0-9]_pmc_hbm_seedextend.json")
         roof["ms_per_step"] = {k: round(timers[k]["ms"] / steps, 3) for k, _ in TIMERS if timers[k]["ms"] > 0}
         roof["note"] = "four blocks per step, each extended asynchronously while the host seeds the next one"
         from bench import usable_cores

@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def one(pattern):
@@ -35,7 +35,7 @@ for name, sub in (("bench", "bench_stats"), ("decompose", "dec_stats"), ("allpai
     f = one(sub + "/*/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, name)))
-for src, dst in (("bench_line.json", "bench_line_under_rocprof"), ("bench_plain.json", "bench_line"), ("dec_line.json", "decompose_line_under_rocprof"),
+for src, dst in (("bench_line.json", "bench_line_under_rocprof"), ("bench_plain.json", "bench_line"), ("dec_line_under_rocprof.json", "decompose_line_under_rocprof"), ("dec_line.json", "decompose_line"),
                  ("ap_line.json", "allpairs_line_under_rocprof")):
     p = os.path.join(SRC, src)
     if os.path.exists(p):
@@ -87,7 +87,7 @@ if f:
     if os.path.exists(p) and last_json_line(p):
         json.dump(last_json_line(p), open(os.path.join(DST, "%s_bench_default_line_under_rocprof.json" % tag), "w"), indent=1)
 
-for w, suffix in (("bench", ""), ("dec", "_decompose"), ("ap", "_allpairs")):
+for w, suffix in (("bench", ""), ("dec", "_decompose"), ("ap", "_allpairs"), ("se", "_seedextend")):
     hbm = []
     for c in ("WRITE_SIZE", "FETCH_SIZE"):
         for r in per_kernel("pmc_%s_%s" % (w, c), 1024.0):  # the counters report KB
@@ -98,7 +98,7 @@ for w, suffix in (("bench", ""), ("dec", "_decompose"), ("ap", "_allpairs")):
     valu = per_kernel("pmc_%s_valu" % w, 1.0)
     if valu:
         json.dump(valu, open(os.path.join(DST, "%s_pmc_valu%s.json" % (tag, suffix)), "w"), indent=1)
-for nm in ("decompose_timeline_gaps.txt", "align_timeline_gaps.txt"):
+for nm in ("decompose_timeline_gaps.txt", "align_timeline_gaps.txt", "decompose_small_batch_timeline_gaps.txt"):
     if os.path.exists(os.path.join(SRC, nm)):
         shutil.copy(os.path.join(SRC, nm), os.path.join(DST, "%s_%s" % (tag, nm)))
 print("profiles written for", tag, ":", sorted(f for f in os.listdir(DST) if f.startswith(tag)))

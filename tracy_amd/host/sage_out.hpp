@@ -23,6 +23,7 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <cstring>
 #include <string>
 #include <utility>
 #include <vector>
@@ -44,17 +45,22 @@ struct AlignRows {
 // reverseComplement, fmindex.h:11-25: complements the upper-cased reversed string into `sequence`; for
 // a letter outside ACGTN the reference leaves that output position untouched, i.e. the ORIGINAL byte stays.
 inline void reverseComplement(std::string& sequence) {
+  // (a 256-entry table instead of toupper + switch per letter: the windows of an indexed genome are reverse-complemented per trace,
+  // 4 kb each, on the host threads that seed -- a fifth of the seeding time went here)
+  static const struct Table {
+    unsigned char t[256];
+    Table() {
+      std::memset(t, 0, sizeof(t));
+      const char* from = "ACGTNacgtn";
+      const char* to = "TGCANTGCAN";
+      for (int i = 0; from[i]; ++i) t[(unsigned char)from[i]] = (unsigned char)to[i];
+    }
+  } tab;
   const std::string src = sequence;
   const std::size_t n = src.size();
   for (std::size_t i = 0; i < n; ++i) {
-    switch (std::toupper((unsigned char)src[n - 1 - i])) {
-      case 'A': sequence[i] = 'T'; break;
-      case 'C': sequence[i] = 'G'; break;
-      case 'G': sequence[i] = 'C'; break;
-      case 'T': sequence[i] = 'A'; break;
-      case 'N': sequence[i] = 'N'; break;
-      default: break;
-    }
+    const unsigned char c = tab.t[(unsigned char)src[n - 1 - i]];
+    if (c) sequence[i] = (char)c;  // (any other letter: the output position keeps its ORIGINAL byte)
   }
 }
 

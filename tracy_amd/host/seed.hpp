@@ -147,6 +147,14 @@ class GenomeIndex {
     for (Entry const& e : table_) ++bucket_[(std::size_t)(e.code >> shift) + 1];
     for (std::size_t b = 1; b < bucket_.size(); ++b) bucket_[b] += bucket_[b - 1];
     tab_ = table_.data(); ntab_ = table_.size(); bkt_ = bucket_.data();
+#ifdef MADV_HUGEPAGE
+    auto advise = [](const void* p, std::size_t bytes) {  // (the heap blocks of the two vectors: whole 2 MB pages inside them)
+      const uintptr_t huge = (uintptr_t)2 << 20, lo = ((uintptr_t)p + huge - 1) & ~(huge - 1), hi = ((uintptr_t)p + bytes) & ~(huge - 1);
+      if (hi > lo) madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
+    };
+    advise(tab_, ntab_ * sizeof(Entry));
+    advise(bkt_, bucket_.size() * sizeof(uint64_t));
+#endif
   }
 
   // ---- persistence: `tracy index` (index.h:79-124) -------------------------------------------------------------
@@ -224,7 +232,39 @@ class GenomeIndex {
     tab_ = reinterpret_cast<const Entry*>(pt);
     ntab_ = (std::size_t)nt;
     if (bkt_[(std::size_t)1 << bucket_bits_] != ntab_) { unmap(); return false; }
+    make_resident();
     return true;
+  }
+  // A look-up touches two random lines of a gigabyte of directory + table: on 4 KB pages that is two TLB misses and two page walks
+  // per k-mer, more than the cache misses themselves cost once those are prefetched.  The file mapping stays (text, and the table
+  // as the fallback), but directory and table are copied into anonymous memory that asks for transparent huge pages (2 MB: the
+  // whole table under ~600 TLB entries).  One private copy per process (TRACY_AMD_INDEX_MAPPED=1 keeps the shared file mapping
+  // only -- one copy in the page cache for every rank of a node -- at about two thirds of the look-up rate).
+  void make_resident() {
+    if (std::getenv("TRACY_AMD_INDEX_MAPPED")) return;
+    const std::size_t bbytes = (((std::size_t)1 << bucket_bits_) + 1) * sizeof(uint64_t), tbytes = ntab_ * sizeof(Entry);
+    const std::size_t huge = (std::size_t)2 << 20;
+    const std::size_t total = ((bbytes + huge - 1) / huge + (tbytes + huge - 1) / huge + 1) * huge;
+    void* m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return;
+    char* base = reinterpret_cast<char*>(((uintptr_t)m + huge - 1) & ~(uintptr_t)(huge - 1));
+#ifdef MADV_HUGEPAGE
+    madvise(base, total - (std::size_t)(base - static_cast<char*>(m)), MADV_HUGEPAGE);
+#endif
+    char* b = base;
+    char* t = base + (bbytes + huge - 1) / huge * huge;
+    const unsigned nth = std::min(8u, usable_threads());
+    auto copy = [&](char* dst, const char* src, std::size_t bytes) {
+      std::vector<std::thread> th;
+      for (unsigned i = 0; i < nth; ++i)
+        th.emplace_back([=]() { const std::size_t lo = bytes * i / nth, hi = bytes * (i + 1) / nth; std::memcpy(dst + lo, src + lo, hi - lo); });
+      for (auto& x : th) x.join();
+    };
+    copy(b, reinterpret_cast<const char*>(bkt_), bbytes);
+    copy(t, reinterpret_cast<const char*>(tab_), tbytes);
+    res_ = m; res_bytes_ = total;
+    bkt_ = reinterpret_cast<const uint64_t*>(b);
+    tab_ = reinterpret_cast<const Entry*>(t);
   }
   ~GenomeIndex() { unmap(); }
   GenomeIndex() = default;
@@ -277,7 +317,11 @@ class GenomeIndex {
   uint32_t bucket_bits_ = 0;
   void* map_ = nullptr;
   std::size_t map_bytes_ = 0;
+  void* res_ = nullptr;            // directory + table in anonymous huge-page memory (make_resident)
+  std::size_t res_bytes_ = 0;
   void unmap() {
+    if (res_) munmap(res_, res_bytes_);
+    res_ = nullptr; res_bytes_ = 0;
     if (map_) munmap(map_, map_bytes_);
     map_ = nullptr; map_bytes_ = 0;
     if (text.p != owned_text_.data()) { text.p = nullptr; text.n = 0; }
@@ -364,59 +408,77 @@ inline uint32_t findMaxFreq(std::vector<int64_t>& hits, int64_t& gpos) {
 // scanSequence, fmindex.h:203-232: every k-mer of consensus[trimLeft, size - trimRight) without 'N' votes for
 // (genome position - offset in the trace).  unique: only k-mers that occur exactly once; otherwise every
 // occurrence of k-mers that occur fewer than 1000 times.  The window counter is 16 bits wide as in the reference.
+//
+// A look-up is two dependent cache misses into a gigabyte of table (directory slot, then the run it points to) and the look-ups of a
+// trace are independent of each other: the window codes are computed first, then the loop runs software-pipelined -- the directory
+// slot of window i + 2D is requested while the table run of window i + D is requested (its slot has arrived by then) and window i is
+// looked up with both lines in cache.  D = 10 keeps ~20 misses in flight, what a core's miss buffers hold (measured on the EPYC 9575F
+// of the GPU box: D = 6 .. 12 within 2 %, D = 4 and D >= 16 slower); two full sweeps over all 900 windows before the first look-up
+// (rounds 2-3) ran past those buffers and were no faster than no prefetch at all.
 inline void scanSequence(GenomeIndex const& idx, std::string const& consensus, uint16_t trimLeft, uint16_t trimRight, uint16_t kmer,
                          std::vector<int64_t>& hits, bool unique) {
-  int32_t ncount = 0;
-  for (uint16_t i = trimLeft; (i < trimLeft + kmer) && (i < consensus.size()); ++i)
-    if (consensus[i] == 'N') ++ncount;
-  std::vector<uint64_t> where;
-  // fast path: a full-length window over ACGT is looked up by its rolling 2-bit code
+  const std::size_t size = consensus.size();
+  // the windows of the loop below: p = trimLeft .. (uint16_t wrap-around as in the reference's counter)
+  std::size_t nwin = 0;
+  for (uint16_t p = trimLeft; (p < (size - trimRight)) && (p < size); ++p) ++nwin;
+  if (nwin == 0) return;
   const bool table_ok = kmer == idx.k && kmer >= 1 && kmer <= 32;
   const uint64_t mask = kmer >= 32 ? ~0ull : ((1ull << (2 * kmer)) - 1ull);
-  uint64_t code = 0;
-  uint32_t run = 0;  // ACGT letters ending at the window's last position (capped at kmer)
-  auto push_letter = [&](std::size_t q) {
-    const int b = q < consensus.size() ? GenomeIndex::base_code(consensus[q]) : -1;
-    if (b < 0) { run = 0; code = 0; return; }
-    code = ((code << 2) | (uint64_t)b) & mask;
-    if (run < kmer) ++run;
-  };
-  // the table look-ups of one trace are independent: compute every window code first and warm the cache in two
-  // sweeps (directory slots, then table runs) so that the look-ups below do not pay one memory latency each
-  std::vector<uint64_t> codes;
-  if (table_ok) {
+  // per window: its 2-bit code when it is a full-length window over ACGT (answered from the table), and whether it holds an 'N'
+  thread_local std::vector<uint64_t> codes;
+  thread_local std::vector<uint8_t> kind;  // 0: skip (holds an N), 1: table look-up, 2: any other window without N (text scan)
+  codes.assign(nwin, 0);
+  kind.assign(nwin, 0);
+  {
+    int32_t ncount = 0;
+    for (uint16_t i = trimLeft; (i < trimLeft + kmer) && (i < size); ++i)
+      if (consensus[i] == 'N') ++ncount;
+    uint64_t code = 0;
+    uint32_t run = 0;  // ACGT letters ending at the window's last position (capped at kmer)
+    auto push_letter = [&](std::size_t q) {
+      const int b = q < size ? GenomeIndex::base_code(consensus[q]) : -1;
+      if (b < 0) { run = 0; code = 0; return; }
+      code = ((code << 2) | (uint64_t)b) & mask;
+      if (run < kmer) ++run;
+    };
     for (uint32_t q = trimLeft; q + 1 < (uint32_t)trimLeft + kmer; ++q) push_letter(q);
-    for (uint16_t p = trimLeft; (p < (consensus.size() - trimRight)) && (p < consensus.size()); ++p) {
+    std::size_t w = 0;
+    for (uint16_t p = trimLeft; (p < (size - trimRight)) && (p < size); ++p, ++w) {
       push_letter((std::size_t)p + kmer - 1);
-      codes.push_back(run == kmer ? code : ~0ull);  // ~0 never is a valid code for k < 32; k = 32 re-checks below
-      if (run == kmer) idx.prefetch_slot(code);
+      if (ncount == 0) {
+        if (table_ok && run == kmer) { kind[w] = 1; codes[w] = code; }
+        else kind[w] = 2;
+      }
+      if (consensus[p] == 'N') --ncount;
+      if (((uint32_t)(p + kmer) < size) && (consensus[p + kmer] == 'N')) ++ncount;
     }
-    for (uint64_t c : codes)
-      if (c != ~0ull || kmer == 32) idx.prefetch_run(c == ~0ull ? 0 : c);
-    code = 0;
-    run = 0;
   }
-  for (uint32_t q = trimLeft; q + 1 < (uint32_t)trimLeft + kmer; ++q) push_letter(q);
-  for (uint16_t p = trimLeft; (p < (consensus.size() - trimRight)) && (p < consensus.size()); ++p) {
-    push_letter((std::size_t)p + kmer - 1);
-    if (ncount == 0) {
-      if (table_ok && run == kmer) {
-        std::size_t lo, hi;
-        idx.code_range(code, lo, hi);
-        const std::size_t occs = hi - lo;
-        if (unique ? occs == 1 : (occs > 0 && occs < 1000))
-          for (std::size_t i = lo; i < hi; ++i) hits.push_back((int64_t)(idx.position(i) - (uint64_t)p));
-      } else {
-        const std::string seq = consensus.substr(p, kmer);
-        const std::size_t occs = idx.count(seq);
-        if (unique ? occs == 1 : (occs > 0 && occs < 1000)) {
-          idx.locate(seq, where);
-          for (uint64_t w : where) hits.push_back((int64_t)(w - (uint64_t)p));
-        }
+  std::vector<uint64_t> where;
+  static const std::size_t D = []() -> std::size_t {  // (development knob: the prefetch distance; >= the windows of a trace = full sweeps)
+    const char* e = std::getenv("TRACY_AMD_SEED_DISTANCE");
+    const long v = e ? std::atol(e) : 0;
+    return v >= 1 ? (std::size_t)v : 10;
+  }();
+  for (std::size_t i = 0; i < nwin + 2 * D; ++i) {
+    if (i < nwin && kind[i] == 1) idx.prefetch_slot(codes[i]);
+    if (i >= D && i - D < nwin && kind[i - D] == 1) idx.prefetch_run(codes[i - D]);
+    if (i < 2 * D) continue;
+    const std::size_t w = i - 2 * D;
+    const uint64_t p = (uint64_t)(uint16_t)(trimLeft + w);
+    if (kind[w] == 1) {
+      std::size_t lo, hi;
+      idx.code_range(codes[w], lo, hi);
+      const std::size_t occs = hi - lo;
+      if (unique ? occs == 1 : (occs > 0 && occs < 1000))
+        for (std::size_t q = lo; q < hi; ++q) hits.push_back((int64_t)(idx.position(q) - p));
+    } else if (kind[w] == 2) {
+      const std::string seq = consensus.substr((std::size_t)p, kmer);
+      const std::size_t occs = idx.count(seq);
+      if (unique ? occs == 1 : (occs > 0 && occs < 1000)) {
+        idx.locate(seq, where);
+        for (uint64_t x : where) hits.push_back((int64_t)(x - p));
       }
     }
-    if (consensus[p] == 'N') --ncount;
-    if (((uint32_t)(p + kmer) < consensus.size()) && (consensus[p + kmer] == 'N')) ++ncount;
   }
 }
 

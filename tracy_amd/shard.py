@@ -19,6 +19,8 @@ def gather_records(dist, records, dst=0):
     Shards may differ in size by one trace; they are padded to the largest shard for the collective."""
     world = dist.get_world_size()
     rank = dist.get_rank()
+    if records.is_cuda and dist.get_backend() == "gloo":  # (gloo gathers host tensors: the CPU tests, bench.py --share-device)
+        records = records.cpu()
     n_local = torch.tensor([records.shape[0]], dtype=torch.int64, device=records.device)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local)
@@ -82,6 +84,8 @@ def all_gather_slices(dist, local, bounds):
     world = dist.get_world_size()
     sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
     cap = max(sizes) if sizes else 0
+    if local.is_cuda and dist.get_backend() == "gloo":
+        local = local.cpu()
     padded = torch.zeros(cap, dtype=local.dtype, device=local.device)
     padded[:local.numel()] = local
     bucket = [torch.empty_like(padded) for _ in range(world)]

@@ -140,7 +140,24 @@ def test_index_file_equals_the_in_memory_build(genome, tmp_path):
     with pytest.raises(IOError):
         hostlib.Genome(idx, 11)
     blob = open(idx, "rb").read()
-    for bad in (blob[:len(blob) // 2], blob[:8] + b"\xff" * 200, blob[:60]):
+    import struct
+    k_bits, tbytes, nt, nc, nmb = struct.unpack_from("<5Q", blob, 8)
+    al = lambda x: (x + 7) & ~7
+    at_len = 56 + al(tbytes) + al(nmb)
+    at_st = at_len + al(4 * nc)
+    at_bkt = at_st + al(8 * nc)
+
+    def patched(off, fmt, *v):
+        b = bytearray(blob)
+        struct.pack_into(fmt, b, off, *v)
+        return bytes(b)
+    wrapped = [patched(8 + 8 * 2, "<Q", (1 << 61) + 1),  # table entries: 8 * count wraps 64 bits
+               patched(8 + 8 * 3, "<Q", (1 << 62) + nc),  # contigs: 4 * count wraps
+               patched(at_bkt + 8 * 5, "<Q", nt + 7),       # directory not a prefix sum of the table
+               patched(at_bkt, "<Q", 3),
+               patched(at_st, "<Q", tbytes + 1),            # a contig outside the text
+               patched(at_len, "<I", 0xfffffff0)]
+    for bad in [blob[:len(blob) // 2], blob[:8] + b"\xff" * 200, blob[:60]] + wrapped:
         open(str(tmp_path / "bad.tidx"), "wb").write(bad)
         with pytest.raises(IOError):
             hostlib.Genome(str(tmp_path / "bad.tidx"), 15)

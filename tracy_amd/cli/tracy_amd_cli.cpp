@@ -321,9 +321,10 @@ int parse(int argc, char** argv, SageConfig& c) {
 }
 
 bool load_trace(std::string const& path, Trace& tr) {
-  const int32_t ft = traceFormat(path);
-  if (ft == 0) return readab(path, tr);
-  if (ft == 1) return readscf(path, tr);
+  detail::FileBytes f;  // read once: the format test and the reader look at the same bytes
+  const int32_t ft = f.load(path) ? traceFormat(f) : -1;
+  if (ft == 0) return readab(f, tr);
+  if (ft == 1) return readscf(f, tr);
   std::cerr << "Unknown trace file type!" << std::endl;
   return false;
 }
@@ -618,8 +619,9 @@ void write_outputs(SageConfig const& c, Job const& j) {
   PaddedTrace padded;
   alignmentTracePadding(j.rows.row0, j.tr, j.bc, padded);
   {
-    std::ofstream f((j.outprefix + ".align.fa").c_str());
+    TextBuf f(2 * j.rows.row0.size() + 512);
     alignFastaOut(f, stem(j.trace_path), j.rs, j.rows);
+    f.to_file(j.outprefix + ".align.fa");
   }
   plotAlignment(j.outprefix + ".txt", j.rows, j.rs, j.score, c.linelimit);
   traceAlignJsonOut(j.outprefix + ".json", padded, j.rs, j.rows);
@@ -1017,36 +1019,42 @@ bool decompose_group(Device& dev, SageConfig const& c, tracyhip_params const& pr
 }
 
 // variants of both alleles (indigo.h:393-421); reverse-strand traces are re-aligned as reverse complements
-bool call_variants(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<Job*> const& jobs) {
-  std::vector<std::string> s1, s2;
-  std::vector<ReferenceSlice> rev;
-  std::vector<Job*> owner;
-  for (Job* jp : jobs) {
-    Job& j = *jp;
+bool call_variants(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<Job*> const& jobs, uint32_t nthreads = 1) {
+  // traces on the reverse strand are called on re-aligned reverse complements (two pairs each, one device batch); the rest
+  // straight from their allele alignments -- every trace on its own, on the host threads
+  std::vector<uint32_t> slot(jobs.size(), 0);
+  uint32_t nrev = 0;
+  for (std::size_t i = 0; i < jobs.size(); ++i)
+    if (!jobs[i]->rs.forward) slot[i] = nrev++;
+  std::vector<std::string> s1(2 * (std::size_t)nrev), s2(2 * (std::size_t)nrev);
+  std::vector<ReferenceSlice> rev(2 * (std::size_t)nrev);
+  for_each_index((uint32_t)jobs.size(), nthreads, [&](uint32_t i) {
+    Job& j = *jobs[i];
     AlleleReport& r = j.rep;
     if (j.rs.forward) {
       callVariants(r.align1, r.rs1, r.var);
       callVariants(r.align2, r.rs2, r.var);
-      continue;
+      return;
     }
     const std::string seq[2] = {trimmedSeq(j.primary, j.trimLeft, j.trimRight), trimmedSeq(j.secdecomp, j.trimLeft, j.trimRight)};
     ReferenceSlice const* rs[2] = {&r.rs1, &r.rs2};
     for (int k = 0; k < 2; ++k) {
-      std::string q = seq[k];
-      reverseComplement(q);
-      ReferenceSlice rr;
-      reverseReferenceSlice(*rs[k], rr);
-      s1.push_back(q);
-      s2.push_back(rr.refslice);
-      rev.push_back(rr);
-      owner.push_back(jp);
+      const std::size_t at = 2 * (std::size_t)slot[i] + k;
+      s1[at] = seq[k];
+      reverseComplement(s1[at]);
+      reverseReferenceSlice(*rs[k], rev[at]);
+      s2[at] = rev[at].refslice;
     }
-  }
+  });
   std::vector<int32_t> scores;
   std::vector<AlignRows> rows;
   if (!align_strings(ctx, prm, s1, s2, scores, rows)) return false;
-  for (std::size_t i = 0; i < rows.size(); ++i) callVariants(rows[i], rev[i], owner[i]->rep.var);
-  for (Job* jp : jobs) std::sort(jp->rep.var.begin(), jp->rep.var.end());
+  for_each_index((uint32_t)jobs.size(), nthreads, [&](uint32_t i) {
+    Job& j = *jobs[i];
+    if (!j.rs.forward)
+      for (int k = 0; k < 2; ++k) callVariants(rows[2 * (std::size_t)slot[i] + k], rev[2 * (std::size_t)slot[i] + k], j.rep.var);
+    std::sort(j.rep.var.begin(), j.rep.var.end());
+  });
   return true;
 }
 
@@ -1054,8 +1062,9 @@ bool call_variants(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<Jo
 void write_decompose_outputs(SageConfig const& c, Job& j) {
   AlleleReport& r = j.rep;
   {
-    std::ofstream f((j.outprefix + ".decomp").c_str());
+    TextBuf f(4096);
     writeDecomposition(f, r.dcp);
+    f.to_file(j.outprefix + ".decomp");
   }
   ReferenceSlice secrs;
   secrs.refslice = trimmedSeq(j.secdecomp, j.trimLeft, j.trimRight);
@@ -1084,13 +1093,14 @@ void write_decompose_outputs(SageConfig const& c, Job& j) {
   rc.genomeName = file_name(j.ref_path);
   rc.inputName = file_name(j.trace_path);
   if (c.callvariants) {
-    std::ofstream f((j.outprefix + ".vcf").c_str());
+    TextBuf f(8192);
     std::vector<std::pair<std::string, uint64_t>> contigs;
     if (j.rs.filetype == 0) {
       const GenomeIndex* g = genome_index(c, j.ref_path);
       for (std::size_t i = 0; g && i < g->names.size(); ++i) contigs.emplace_back(g->names[i], (uint64_t)g->lengths[i] + 1);
     }
     vcfTextOutput(f, rc, bc, r.var, j.rs, j.rs.filetype == 0 ? &contigs : nullptr);
+    f.to_file(j.outprefix + ".vcf");
   }
   TextBuf f(1 << 20);
   traceAlleleAlignJsonOut(f, rc, bc, j.tr, r);
@@ -1198,7 +1208,7 @@ int decompose_main(int argc, char** argv) {
     say("Allele-specific alignments");
     if (c.callvariants) {
       say("Variant Calling");
-      if (!call_variants(dev.ctx, prm, good)) return false;
+      if (!call_variants(dev.ctx, prm, good, nthreads)) return false;
     }
     fatal = 0;
     ++blocks_done;

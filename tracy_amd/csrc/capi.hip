@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/tracy_hip.h"
@@ -197,6 +198,16 @@ struct HostPool {
       cpu_set_t set;
       CPU_ZERO(&set);
       if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c >= 1) want = (uint32_t)c; }
+      // ... and a container's CPU quota (cgroup v2 cpu.max "quota period"; the command line's usable_threads() reads the same file)
+      if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        unsigned long period = 0;
+        if (fscanf(f, "%31s %lu", quota, &period) == 2 && period > 0 && strcmp(quota, "max") != 0) {
+          const unsigned long q = strtoul(quota, nullptr, 10) / period;
+          if (q >= 1 && q < want) want = (uint32_t)q;
+        }
+        fclose(f);
+      }
     }
     return want > kHostThreads ? kHostThreads : want;
   }
@@ -495,7 +506,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
   TRACYHIP_HOST_SCOPE(hs_all, "run_dp");
 
   // order: strip height, then longest first (long problems start early, short ones fill the tail)
-  auto* hs_plan = new HostScope("run_dp.plan");
+  auto hs_plan = std::make_unique<HostScope>("run_dp.plan");
   std::vector<uint32_t> order(np);
   for (uint32_t i = 0; i < np; ++i) order[i] = i;
   auto before = [&](uint32_t x, uint32_t y) {
@@ -589,7 +600,7 @@ int run_dp(tracyhip_ctx* ctx, const DpProblem& pb, const tracyhip_params* prm, b
     }
     chunks.push_back(c);
   }
-  delete hs_plan;
+  hs_plan.reset();  // the planning part ends here
   uint64_t max_words = 0, max_scr = 0;
   for (const Chunk& c : chunks) { max_words = std::max(max_words, c.words); max_scr = std::max(max_scr, c.scratch); }
   HIP_TRY(ctx->d_desc.ensure(sizeof(PairDesc) * (size_t)np));
@@ -782,7 +793,7 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
   if (nall == 0) return TRACYHIP_OK;
   TRACYHIP_HOST_SCOPE(hs_all, "run_band16");
   hipStream_t st = ctx->stream;
-  auto* hs_plan = new HostScope("run_band16.plan");
+  auto hs_plan = std::make_unique<HostScope>("run_band16.plan");
   uint64_t limit = ctx->ws_limit;
   // Order: strip height (12, 8, 4), the caller's order within one (the pairs of a pipeline stage are of a size).  Laid out by a
   // few threads: per-thread counts per strip height, a scan, the fill -- descriptors go straight into the pinned staging block.
@@ -813,14 +824,14 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
   uint32_t bn[NB] = {0, 0, 0}, bnmax[NB] = {0, 0, 0};
   uint64_t total_bytes = 0, bcells[NB] = {0, 0, 0}, btbytes[NB] = {0, 0, 0};
   for (uint32_t t = 0; t < kHostThreads; ++t) {
-    if (part[t].bad) { delete hs_plan; return set_error(TRACYHIP_ERR_ARG, "run_band16: pair outside the band kernels' domain"); }
+    if (part[t].bad) { return set_error(TRACYHIP_ERR_ARG, "run_band16: pair outside the band kernels' domain"); }
     for (int b = 0; b < NB; ++b) {
       bn[b] += part[t].n[b]; total_bytes += part[t].bytes[b];
       bnmax[b] = std::max(bnmax[b], part[t].nmax[b]); bcells[b] += part[t].cells[b]; btbytes[b] += part[t].tbytes[b];
     }
   }
   const uint32_t np = bn[0] + bn[1] + bn[2];
-  if (np == 0) { delete hs_plan; return TRACYHIP_OK; }
+  if (np == 0) { return TRACYHIP_OK; }
   if (limit == 0) {
     if (job.kind != 0 || total_bytes + 64 <= ctx->d_bits.cap) limit = ~0ull;  // (the words fit what is there: no driver call)
     else {
@@ -872,7 +883,7 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
     for (int b = 0; b < NB; ++b)
       for (uint32_t i = 0; i < nall; ++i) {
         if (job.k[i] != bucket_k[b]) continue;
-        if (wb[i] > limit) { delete hs_plan; return set_error(TRACYHIP_ERR_OOM, "one pair needs %llu bytes of traceback words, workspace limit is %llu", (unsigned long long)wb[i], (unsigned long long)limit); }
+        if (wb[i] > limit) { return set_error(TRACYHIP_ERR_OOM, "one pair needs %llu bytes of traceback words, workspace limit is %llu", (unsigned long long)wb[i], (unsigned long long)limit); }
         if (c.hi > c.lo && c.bytes + wb[i] > limit) { chunks.push_back(c); c = Chunk{pos, pos, 0}; }
         PairDesc d = job.desc[i];
         d.bits_off = c.bytes;
@@ -886,7 +897,7 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
   }
   uint64_t max_bytes = 0;
   for (const Chunk& ch : chunks) max_bytes = std::max(max_bytes, ch.bytes);
-  delete hs_plan;
+  hs_plan.reset();  // the planning part ends here
   HIP_TRY(ctx->d_desc.ensure(sizeof(PairDesc) * (size_t)np));
   HIP_TRY(hipMemcpyAsync(ctx->d_desc.p, hd, sizeof(PairDesc) * (size_t)np, hipMemcpyHostToDevice, st));
   if (job.kind == 0) HIP_TRY(ctx->d_bits.ensure(max_bytes + 64));
@@ -1220,7 +1231,7 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   hipStream_t st = ctx->stream;
   const size_t nf = full.size(), np = pre.size();
   if (nf + np == 0) return TRACYHIP_OK;
-  auto* hs1 = new HostScope("run_ckpt_prefix.plan");
+  auto hs1 = std::make_unique<HostScope>("run_ckpt_prefix.plan");
   HIP_TRY(ctx->h_desc.ensure(sizeof(PairDesc) * (nf + np)));
   PairDesc* hd = static_cast<PairDesc*>(ctx->h_desc.p);
   // the sweeps by strip height (one launch each; the prefix workgroups ride with the first), longest first inside a launch, as
@@ -1238,7 +1249,7 @@ int run_ckpt_prefix(tracyhip_ctx* ctx, const void* d_a1, const void* d_a2, const
   HIP_TRY(hipMemcpyAsync(ctx->d_desc.p, hd, sizeof(PairDesc) * (nf + np), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx->d_err.ensure(kErrBytes));
   HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, sizeof(int32_t) * kErrWords, st));
-  delete hs1;
+  hs1.reset();
   DpArgs a{};
   a.a1 = d_a1; a.a2 = d_a2; a.scores = d_scores; a.err = static_cast<int32_t*>(ctx->d_err.p);
   a.match = prm->match; a.mismatch = prm->mismatch; a.go = prm->go; a.ge = prm->ge; a.hfree = prm->hfree; a.vfree = prm->vfree;

@@ -1384,379 +1384,458 @@ struct Frac2 { double a, b; };
 
 }  // namespace
 
-int tracyhip::stream_decompose(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
-                               const tracyhip_decompose_result* out) {
-  const CtxKnobs& kn = ctx->knobs;
-  if (!stream_options_ok(kn) || job->oriented || job->ref_profiles.data) return kStreamNo;
-  const uint32_t nt = job->ntraces;
-  const tracyhip_seqset& sp = job->profiles;
-  const tracyhip_seqset& sr = job->refs;
-  const tracyhip_basecalls& bc = job->bc;
-  const tracyhip_decomp_params& dp = job->dprm;
-  hipStream_t st = ctx->stream;
-  tracyhip_params p = *prm;
-  p.hfree = 1;  // AlignConfig<true,false> semiglobal (indigo.h:164)
-  p.vfree = 0;
-  tracyhip_params pglobal = *prm;
-  pglobal.hfree = 0;  // AlignConfig<false,false> (indigo.h:381)
-  pglobal.vfree = 0;
-  const uint32_t TL = (uint32_t)dp.trim_left, TR = (uint32_t)dp.trim_right;
-  static thread_local StreamHost h;
-  // geometry and offsets are laid out in the pinned block they travel from
-  HIP_TRY(ctx->h_desc.ensure((sizeof(SGeom) + sizeof(SGeomD) + 4 * sizeof(uint64_t)) * (size_t)nt));
-  SGeom* geom = static_cast<SGeom*>(ctx->h_desc.p);
-  SGeomD* geomd = reinterpret_cast<SGeomD*>(geom + nt);
-  TRY(plan_common(ctx, p, sp, sr, job->ref_index, nt, TL, TR, h, geom));
-  const bool exact = job->strand_by_certificate == 0;
-  const bool host = mem == TRACYHIP_MEM_HOST;
-
-  // ---- geometry of the decompose stages (decompose_traces_legacy's, trace by trace) ----
+namespace {
+// One stream-ordered tracyhip_decompose_traces call: what its sections share, one method per section (queued in this order)
+struct DecStream {
+  tracyhip_ctx* ctx;
+  const tracyhip_decompose_job* job;
+  const tracyhip_params* prm;
+  const int mem;
+  const tracyhip_decompose_result* out;
+  const CtxKnobs& kn;
+  const uint32_t nt;
+  const tracyhip_seqset& sp;
+  const tracyhip_seqset& sr;
+  const tracyhip_basecalls& bc;
+  const tracyhip_decomp_params& dp;
+  hipStream_t st;
+  tracyhip_params p, pglobal;
+  const uint32_t TL, TR;
+  const bool exact, host;
+  StreamHost& h;
+  SGeom* geom = nullptr;
+  SGeomD* geomd = nullptr;
   DecompArena::Sizes z{};
-  z.nt = nt; z.exact = exact; z.host = host;
-  uint32_t maxbc = 0, maxsl = 0, max_arest = 0;
-  uint64_t atab_tot = 0, alr_tot = 0, rows_alleles = 0;
-  for (uint32_t t = 0; t < nt; ++t) {
-    if (bc.bc_len[t] != h.mf[t]) return set_error(TRACYHIP_ERR_ARG, "trace %u: profile has %u columns but %u basecalls", t, h.mf[t], bc.bc_len[t]);
-    if (bc.bc_len[t] >= 2u * kMaxIndelGlobal) return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the scan tables hold < %d", t, bc.bc_len[t], 2 * kMaxIndelGlobal);
-    SGeomD& D = geomd[t];
-    D = SGeomD{};
-    if ((uint64_t)(uint32_t)(TL + TR + 1) >= (uint64_t)h.mf[t]) { D.soff = 0; D.sl = h.mf[t]; }  // trimmedSeq, abif.h:68-75
-    else { D.soff = TL; D.sl = h.mf[t] - TL - TR; }
-    D.bc_off = bc.bc_offset[t];
-    D.sig_off = bc.signal_offset[t];
-    D.nsamples = bc.nsamples[t];
-    D.dcp_off = out->dcp_offset[t];
-    for (int k = 0; k < 3; ++k) D.opsk_off[k] = out->ops_offset[k][t];
-    D.atab_stride = b16_table_stride(D.sl);
-    for (int k = 0; k < 2; ++k) {
-      D.atab_off[k] = atab_tot; atab_tot += (uint64_t)kB16Codes * D.atab_stride;
-      D.alr_off[k] = alr_tot; alr_tot += (uint64_t)h.rn[t] + 2;
-      const bool ok = D.sl > kFrontRows + 2u * (uint32_t)kFrontK && h.rn[t] >= 1 && origin16_ok(&p, D.sl, D.sl - kFrontRows + 2u * (uint32_t)kFrontHalfW + 16u);
-      D.flags[k] = ok ? SG_FRONT_OK : 0u;
-      if (ok) max_arest = std::max(max_arest, D.sl - kFrontRows);
-    }
-    geom[t].ops_off = z.tot1;
-    z.tot1 += (uint64_t)h.mt[t] + h.rn[t];
-    z.sext = std::max<uint64_t>(z.sext, bc.signal_offset[t] + 4ull * bc.nsamples[t]);
-    z.bext = std::max<uint64_t>(z.bext, bc.bc_offset[t] + bc.bc_len[t]);
-    z.dext = std::max<uint64_t>(z.dext, out->dcp_offset[t] + 2ull * dp.maxindel + 2);
-    for (int k = 0; k < 3; ++k) z.opscap[k] = std::max<uint64_t>(z.opscap[k], out->ops_offset[k][t] + (uint64_t)D.sl + (k < 2 ? h.rn[t] : D.sl));
-    maxbc = std::max(maxbc, h.mf[t]);
-    maxsl = std::max(maxsl, D.sl);
-    rows_alleles += 2ull * D.sl;
-  }
-  if (max_arest == 0) return kStreamNo;
-  TRY(decompose_limits(dp.maxindel, maxbc));
-  z.ep = seqset_extent(sp); z.er = seqset_extent(sr);
-  const uint32_t ncap = (h.maxmf + 200u + 7u) & ~3u;
-  if (4ull * ncap + b16_table_bytes(12) > 64u * 1024u) return kStreamNo;
-
-  // ---- workspace ----
-  uint64_t rows_traces = 0;
-  for (uint32_t t = 0; t < nt; ++t) rows_traces += h.mt[t];
-  Arena sizing;
+  uint32_t maxbc = 0, maxsl = 0, max_arest = 0, ncap = 0;
+  uint64_t atab_tot = 0, alr_tot = 0, rows_alleles = 0, words_cap = 0;
   DecompArena A;
-  A.layout(sizing, z);
-  uint64_t budget = 0;
-  TRY(workspace_budget(ctx, ctx->d_lastrow.cap + ctx->d_bits.cap + ctx->d_stream.cap + ctx->d_b16tab[2].cap + ctx->d_b16tab[0].cap, &budget));
-  const uint64_t lr_words = std::max(h.lr_tot, alr_tot);
-  const uint64_t fixed = lr_words * 4 + 64 + h.tab_tot * 2 + atab_tot * 2 + 128 + sizing.off;
-  if (fixed > budget) return kStreamNo;
-  const uint64_t words_cap = band_words_cap(std::max(rows_traces, rows_alleles), 2ull * nt, budget - fixed);
-  HIP_TRY(ctx->d_lastrow.ensure(lr_words * 4 + 64));
-  HIP_TRY(ctx->d_b16tab[2].ensure(h.tab_tot * sizeof(int16_t) + 64));
-  HIP_TRY(ctx->d_b16tab[0].ensure(atab_tot * sizeof(int16_t) + 64));
-  HIP_TRY(ctx->d_bits.ensure(words_cap + 64));
-  HIP_TRY(ctx->d_stream.ensure(sizing.off + 256));
-  Arena arena;
-  arena.base = static_cast<char*>(ctx->d_stream.p);
-  A.layout(arena, z);
-  StreamCommon& sc = A.sc;
+  const float* d_prof = nullptr;
+  const uint8_t* d_ref = nullptr;
+  const int32_t *d_sig = nullptr, *d_pos = nullptr;
+  uint8_t *d_pri = nullptr, *d_sec = nullptr, *d_sd = nullptr;
+  tracyhip_breakpoint* d_bp = nullptr;
+  double* d_fr = nullptr;
+  int32_t *d_di = nullptr, *d_de = nullptr;
+  tracyhip_decomp_status* d_dst = nullptr;
+  DecompOutDev o{};
+  uint8_t* d_opsK[3] = {nullptr, nullptr, nullptr};
+  SParams spm{};
+  SParamsD spd{};
+  dim3 g256, g256x2, b256;
+  const int16_t *d_qp = nullptr, *d_aqp = nullptr;
+  int32_t* d_lastrow = nullptr;
+  uint8_t *d_cq_ref = nullptr, *d_cq_sd = nullptr;
+  int32_t *herr = nullptr, *hcq = nullptr;
+  unsigned long long *hcnt = nullptr, *hbst = nullptr;
+  uint32_t* hdead = nullptr;
+  std::vector<uint32_t> dl;  // the traces the device could not give their tier
 
-  // ---- payloads and result arrays: the caller's (device memory) or staged ----
-  const float* d_prof = static_cast<const float*>(sp.data);
-  const uint8_t* d_ref = static_cast<const uint8_t*>(sr.data);
-  const int32_t *d_sig = bc.signal, *d_pos = bc.bcpos;
-  uint8_t *d_pri = bc.primary, *d_sec = bc.secondary, *d_sd = out->secdecomp;
-  tracyhip_breakpoint* d_bp = out->bp;
-  double* d_fr = out->fractions;
-  int32_t *d_di = out->dcp_indel, *d_de = out->dcp_err;
-  tracyhip_decomp_status* d_dst = out->dstatus;
-  DecompOutDev o = A.o;
-  uint8_t* d_opsK[3] = {out->ops[0], out->ops[1], out->ops[2]};
-  if (host) {
-    auto up = [&](void* dev, const void* src, size_t bytes) -> int {
-      if (bytes) HIP_TRY(hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, st));
-      return TRACYHIP_OK;
-    };
-    TRY(up(A.in_prof, sp.data, z.ep * 4)); TRY(up(A.in_ref, sr.data, z.er)); TRY(up(A.in_sig, bc.signal, z.sext * 4)); TRY(up(A.in_pos, bc.bcpos, z.bext * 4));
-    TRY(up(A.pri, bc.primary, z.bext)); TRY(up(A.sec, bc.secondary, z.bext));
-    d_prof = A.in_prof; d_ref = A.in_ref; d_sig = A.in_sig; d_pos = A.in_pos; d_pri = A.pri; d_sec = A.sec; d_sd = A.secdecomp;
-    d_bp = A.bp; d_fr = A.fractions; d_di = A.dcp_indel; d_de = A.dcp_err; d_dst = A.dstatus;
-    for (int k = 0; k < 3; ++k) d_opsK[k] = A.ops[k];
-  } else {
-    o.status = out->status; o.score_fwd = out->score_fwd; o.score_rev = out->score_rev; o.score_trim = out->score_trim; o.forward = out->forward;
-    for (int k = 0; k < 2; ++k) { o.slice_begin[k] = out->slice_begin[k]; o.slice_len[k] = out->slice_len[k]; o.ref_pos[k] = out->ref_pos[k]; }
-    for (int k = 0; k < 3; ++k) { o.score[k] = out->score[k]; o.ops_len[k] = out->ops_len[k]; }
+  DecStream(tracyhip_ctx* c, const tracyhip_decompose_job* j, const tracyhip_params* q, int m, const tracyhip_decompose_result* o_, StreamHost& h_)
+      : ctx(c), job(j), prm(q), mem(m), out(o_), kn(c->knobs), nt(j->ntraces), sp(j->profiles), sr(j->refs), bc(j->bc), dp(j->dprm), st(c->stream), p(*q),
+        pglobal(*q), TL((uint32_t)j->dprm.trim_left), TR((uint32_t)j->dprm.trim_right), exact(j->strand_by_certificate == 0), host(m == TRACYHIP_MEM_HOST), h(h_),
+        g256((j->ntraces + 255) / 256), g256x2((2 * j->ntraces + 255) / 256), b256(256) {
+    p.hfree = 1;  // AlignConfig<true,false> semiglobal (indigo.h:164)
+    p.vfree = 0;
+    pglobal.hfree = 0;  // AlignConfig<false,false> (indigo.h:381)
+    pglobal.vfree = 0;
   }
-  HIP_TRY(hipMemcpyAsync(A.pri_bak, d_pri, z.bext, hipMemcpyDeviceToDevice, st));  // decomposeAlleles rewrites the basecalls in place
-  HIP_TRY(hipMemcpyAsync(A.sec_bak, d_sec, z.bext, hipMemcpyDeviceToDevice, st));
-  // whatever happens from here on, the caller's basecalls in device memory are put back before the host-planned pipeline takes the call
-  auto give_up = [&](int rc) -> int {
+  // whatever happens once the stages are queued, the caller's basecalls in device memory are put back before the host-planned pipeline takes the call
+  int give_up(int rc) {
     if (rc == kStreamNo && !host) {
       (void)hipMemcpyAsync(d_pri, A.pri_bak, z.bext, hipMemcpyDeviceToDevice, st);
       (void)hipMemcpyAsync(d_sec, A.sec_bak, z.bext, hipMemcpyDeviceToDevice, st);
       (void)ctx_sync(ctx);
     }
     return rc;
-  };
-
-  // ---- references encoded once; geometry, offsets: one pinned block, one copy each way ----
-  HIP_TRY(ctx->d_err.ensure(kErrBytes));
-  HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, kErrBytes, st));
-  int32_t* d_verr = static_cast<int32_t*>(ctx->d_err.p) + kErrVerdictWord;
-  HIP_TRY(ctx->ensure_codes(z.er ? z.er : 1, st));
-  if (z.er) {
-    hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((z.er + 4095) / 4096)), dim3(256), 0, st, d_ref, ctx->codes(), z.er, ctx->special_blocks(), d_verr);
-    HIP_TRY(hipGetLastError());
   }
-  {
-    char* hp = static_cast<char*>(ctx->h_desc.p);
-    SGeomD* hgd = geomd;
-    uint64_t* hoff = reinterpret_cast<uint64_t*>(hgd + nt);  // [off1 nt][allele ops 2 nt][allele 1 vs 2 ops nt]
-    // (band16_body adds an offset to ONE ops pointer: alleles 1 and 2 reach their buffers through offsets relative to allele 0's, modulo 2^64)
-    const uint64_t base1 = (uint64_t)(reinterpret_cast<uintptr_t>(d_opsK[1]) - reinterpret_cast<uintptr_t>(d_opsK[0]));
+
+  // what the host knows before anything runs: geometry of every trace (laid out in the pinned block it travels from), workspace
+  int plan() {
+    // geometry and offsets are laid out in the pinned block they travel from
+    HIP_TRY(ctx->h_desc.ensure((sizeof(SGeom) + sizeof(SGeomD) + 4 * sizeof(uint64_t)) * (size_t)nt));
+    geom = static_cast<SGeom*>(ctx->h_desc.p);
+    geomd = reinterpret_cast<SGeomD*>(geom + nt);
+    TRY(plan_common(ctx, p, sp, sr, job->ref_index, nt, TL, TR, h, geom));
+
+    // ---- geometry of the decompose stages (decompose_traces_legacy's, trace by trace) ----
+    z.nt = nt; z.exact = exact; z.host = host;
     for (uint32_t t = 0; t < nt; ++t) {
-      hoff[t] = geom[t].ops_off;
-      hoff[nt + t] = out->ops_offset[0][t];
-      hoff[2 * (size_t)nt + t] = base1 + out->ops_offset[1][t];
-      hoff[3 * (size_t)nt + t] = out->ops_offset[2][t];
+      if (bc.bc_len[t] != h.mf[t]) return set_error(TRACYHIP_ERR_ARG, "trace %u: profile has %u columns but %u basecalls", t, h.mf[t], bc.bc_len[t]);
+      if (bc.bc_len[t] >= 2u * kMaxIndelGlobal) return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the scan tables hold < %d", t, bc.bc_len[t], 2 * kMaxIndelGlobal);
+      SGeomD& D = geomd[t];
+      D = SGeomD{};
+      if ((uint64_t)(uint32_t)(TL + TR + 1) >= (uint64_t)h.mf[t]) { D.soff = 0; D.sl = h.mf[t]; }  // trimmedSeq, abif.h:68-75
+      else { D.soff = TL; D.sl = h.mf[t] - TL - TR; }
+      D.bc_off = bc.bc_offset[t];
+      D.sig_off = bc.signal_offset[t];
+      D.nsamples = bc.nsamples[t];
+      D.dcp_off = out->dcp_offset[t];
+      for (int k = 0; k < 3; ++k) D.opsk_off[k] = out->ops_offset[k][t];
+      D.atab_stride = b16_table_stride(D.sl);
+      for (int k = 0; k < 2; ++k) {
+        D.atab_off[k] = atab_tot; atab_tot += (uint64_t)kB16Codes * D.atab_stride;
+        D.alr_off[k] = alr_tot; alr_tot += (uint64_t)h.rn[t] + 2;
+        const bool ok = D.sl > kFrontRows + 2u * (uint32_t)kFrontK && h.rn[t] >= 1 && origin16_ok(&p, D.sl, D.sl - kFrontRows + 2u * (uint32_t)kFrontHalfW + 16u);
+        D.flags[k] = ok ? SG_FRONT_OK : 0u;
+        if (ok) max_arest = std::max(max_arest, D.sl - kFrontRows);
+      }
+      geom[t].ops_off = z.tot1;
+      z.tot1 += (uint64_t)h.mt[t] + h.rn[t];
+      z.sext = std::max<uint64_t>(z.sext, bc.signal_offset[t] + 4ull * bc.nsamples[t]);
+      z.bext = std::max<uint64_t>(z.bext, bc.bc_offset[t] + bc.bc_len[t]);
+      z.dext = std::max<uint64_t>(z.dext, out->dcp_offset[t] + 2ull * dp.maxindel + 2);
+      for (int k = 0; k < 3; ++k) z.opscap[k] = std::max<uint64_t>(z.opscap[k], out->ops_offset[k][t] + (uint64_t)D.sl + (k < 2 ? h.rn[t] : D.sl));
+      maxbc = std::max(maxbc, h.mf[t]);
+      maxsl = std::max(maxsl, D.sl);
+      rows_alleles += 2ull * D.sl;
     }
-    HIP_TRY(hipMemcpyAsync(sc.geom, hp, sizeof(SGeom) * (size_t)nt, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(A.geomd, hgd, sizeof(SGeomD) * (size_t)nt, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(A.off1, hoff, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(A.aops_off, hoff + nt, sizeof(uint64_t) * 2 * (size_t)nt, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(A.ops2_off, hoff + 3 * (size_t)nt, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
-  }
-  HIP_TRY(hipMemsetAsync(sc.dead, 0, sizeof(uint32_t) * (size_t)nt, st));
-  HIP_TRY(hipMemsetAsync(sc.cnt, 0, sizeof(unsigned long long) * SC_COUNT, st));
-  HIP_TRY(hipMemsetAsync(sc.bstat, 0, sizeof(unsigned long long) * SB_COUNT * 8, st));
+    if (max_arest == 0) return kStreamNo;
+    TRY(decompose_limits(dp.maxindel, maxbc));
+    z.ep = seqset_extent(sp); z.er = seqset_extent(sr);
+    ncap = (h.maxmf + 200u + 7u) & ~3u;
+    if (4ull * ncap + b16_table_bytes(12) > 64u * 1024u) return kStreamNo;
 
-  SParams spm{};
-  spm.match = p.match; spm.mismatch = p.mismatch; spm.go = p.go; spm.ge = p.ge; spm.nt = nt; spm.exact = exact ? 1u : 0u; spm.ncap = ncap - 8u;
-  spm.trim_left = TL; spm.trim_right = TR; spm.use_votes = 1u;
-  SParamsD spd{};
-  spd.bext = z.bext;
-  spd.best = (int32_t)std::max<int64_t>(std::max<int64_t>(p.match, p.mismatch), 0);
-  const dim3 g256((nt + 255) / 256), g256x2((2 * nt + 255) / 256), b256(256);
+    // ---- workspace ----
+    uint64_t rows_traces = 0;
+    for (uint32_t t = 0; t < nt; ++t) rows_traces += h.mt[t];
+    Arena sizing;
+    A.layout(sizing, z);
+    uint64_t budget = 0;
+    TRY(workspace_budget(ctx, ctx->d_lastrow.cap + ctx->d_bits.cap + ctx->d_stream.cap + ctx->d_b16tab[2].cap + ctx->d_b16tab[0].cap, &budget));
+    const uint64_t lr_words = std::max(h.lr_tot, alr_tot);
+    const uint64_t fixed = lr_words * 4 + 64 + h.tab_tot * 2 + atab_tot * 2 + 128 + sizing.off;
+    if (fixed > budget) return kStreamNo;
+    words_cap = band_words_cap(std::max(rows_traces, rows_alleles), 2ull * nt, budget - fixed);
+    HIP_TRY(ctx->d_lastrow.ensure(lr_words * 4 + 64));
+    HIP_TRY(ctx->d_b16tab[2].ensure(h.tab_tot * sizeof(int16_t) + 64));
+    HIP_TRY(ctx->d_b16tab[0].ensure(atab_tot * sizeof(int16_t) + 64));
+    HIP_TRY(ctx->d_bits.ensure(words_cap + 64));
+    HIP_TRY(ctx->d_stream.ensure(sizing.off + 256));
+    Arena arena;
+    arena.base = static_cast<char*>(ctx->d_stream.p);
+    A.layout(arena, z);
 
-  // ---- 2. orientation (indigo.h:235-247), 3. gotoh(trimmed trace, window) (indigo.h:302) by traceback on its band ----
-  const int16_t* d_qp = static_cast<const int16_t*>(ctx->d_b16tab[2].p);
-  int32_t* d_lastrow = static_cast<int32_t*>(ctx->d_lastrow.p);
-  OrientStage os{d_prof, d_qp, d_lastrow, exact, A.desc_trim};
-  TRY(give_up(queue_orientation(ctx, p, spm, h, sc, os)));
-  hipLaunchKernelGGL(s_expand_d_kernel, g256, b256, 0, st, sc.geom, A.geomd, nt, z.bext, A.bpd, A.rowsd, A.dd, A.bcd, A.atd);
-  hipLaunchKernelGGL(s_prelim_plan_kernel, g256, b256, 0, st, spm, 1, sc.geom, sc.tr, sc.ce, sc.top_trim, sc.dead, sc.cand, sc.kc);
-  HIP_TRY(hipGetLastError());
-  BandLaunch b0;
-  b0.kind = 0; b0.qp = d_qp; b0.codes = ctx->codes(); b0.scores = A.sb; b0.ops = A.ops1; b0.ops_off = A.off1; b0.ops_len = A.len1; b0.code_cap = ncap; b0.hfree = 1;
-  TRY(band_stage(ctx, p, sc, nt, nt, 0, b0, words_cap));
-  hipLaunchKernelGGL(s_prelim_check_kernel, g256, b256, 0, st, spm, sc.tr, A.sb, A.len1, sc.kc, o.score_trim, sc.dead, sc.cnt);
-  HIP_TRY(hipGetLastError());
-  {
-    RowsArgs ra{};
-    ra.pairs = A.desc_trim;
-    ra.a1 = d_prof; ra.a2 = d_ref;
-    ra.a1_profile = 1; ra.a2_profile = 0; ra.a2_revcomp_flag = 1; ra.a2_onehot = 1;
-    ra.ops = A.ops1; ra.ops_off = A.off1; ra.ops_len = A.len1;
-    ra.rows0 = A.rows0; ra.rows1 = A.rows1;
-    ra.npairs = nt;
-    HIP_TRY(launch_alignment_rows(ra, st));
+    return TRACYHIP_OK;
   }
-  // ---- 1. findBreakpoint (indigo.h:196), 4. findHomozygousBreakpoint (indigo.h:314-317), 5. decomposeAlleles, generateSecondaryDecomposed,
-  // allelicFraction (indigo.h:340-350) ----
-  BreakpointOut* bpo = reinterpret_cast<BreakpointOut*>(d_bp);
-  TRY(launch_breakpoint(ctx, A.bpd, nt, h.maxmt, d_prof, bpo));
-  TRY(launch_homozygous(ctx, A.rowsd, A.rows0, A.rows1, nt, bpo, A.hst, A.len1));
-  {
-    DecompArgs a{};
-    a.desc = A.dd;
-    a.rows0 = A.rows0; a.rows1 = A.rows1;
-    a.primary = d_pri; a.secondary = d_sec;
-    a.dcp_indel = d_di; a.dcp_err = d_de;
-    a.out = reinterpret_cast<DecompOut*>(d_dst);
-    a.prm = DecompParams{dp.trim_left, dp.trim_right, dp.maxindel, dp.madc};
-    a.ntraces = nt;
-    a.lens = A.len1;
-    a.skip = sc.dead;
-    TRY(launch_decompose(ctx, a, bpo, maxbc, 0, 0));
-    TRY(launch_secdecomp(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sec, d_sd));
-    TRY(launch_allelic_fraction(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sd, TL, TR, d_fr, 18ull * std::accumulate(h.mf.begin(), h.mf.end(), 0ull)));
-  }
-  hipLaunchKernelGGL(s_status_kernel, g256, b256, 0, st, spm, sc.geom, o.score_trim, A.hst, A.len1, sc.dead, o.status, sc.cnt);
-  HIP_TRY(hipGetLastError());
 
-  // ---- 6. allele-specific alignments (indigo.h:355-387), both alleles of every trace in the same launches ----
-  // strings scored through the query-profile table (MODE_CQ): the two allele strings side by side, case-sensitive codes of the windows
-  // and of allele 2, the test that the rows hold A C G T N only (read with the call's verdict words)
-  uint8_t* d_cq_ref = A.cq_ref + kCodePad;
-  uint8_t* d_cq_sd = A.cq_sd + kCodePad;
-  HIP_TRY(hipMemcpyAsync(A.seqs2, d_pri, z.bext, hipMemcpyDeviceToDevice, st));
-  HIP_TRY(hipMemcpyAsync(A.seqs2 + z.bext, d_sd, z.bext, hipMemcpyDeviceToDevice, st));
-  HIP_TRY(hipMemsetAsync(A.cq_ref, 5, z.er + 2 * kCodePad, st));
-  HIP_TRY(hipMemsetAsync(A.cq_sd, 5, z.bext + 2 * kCodePad, st));
-  HIP_TRY(hipMemsetAsync(A.cq_special, 0, (z.er >> 8) + 2, st));
-  HIP_TRY(hipMemsetAsync(A.cq_flag, 0, sizeof(int32_t) * 4, st));
-  if (z.er) hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((z.er + 255) / 256)), dim3(256), 0, st, d_ref, d_cq_ref, z.er, A.cq_flag, A.cq_special);
-  if (z.bext) {
-    hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((z.bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), d_cq_sd, z.bext, A.cq_flag, (uint8_t*)nullptr);
-    hipLaunchKernelGGL(cq_rows_kernel, dim3((unsigned)((2 * z.bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(A.seqs2), 2 * z.bext, A.cq_flag);
-  }
-  HIP_TRY(hipGetLastError());
-  const int16_t* d_aqp = static_cast<const int16_t*>(ctx->d_b16tab[0].p);
-  TRY(timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, atab_tot * 2));
-  HIP_TRY(launch_b16_tables(A.atd, 2 * nt, A.seqs2, true, p.match, p.mismatch, sub_limit(&p), kTagShift, const_cast<int16_t*>(d_aqp), static_cast<int32_t*>(ctx->d_err.p), st));
-  TRY(timing_end(ctx));
-  hipLaunchKernelGGL(s_allele_plan0_kernel, g256x2, b256, 0, st, spm, spd, sc.geom, A.geomd, sc.tr, sc.dead, sc.pre, sc.fd, sc.cnt);
-  HIP_TRY(hipGetLastError());
-  {
-    DpArgs a{};
-    a.pairs = sc.pre;
-    a.a1 = A.seqs2; a.a2 = d_cq_ref; a.err = static_cast<int32_t*>(ctx->d_err.p);
-    a.match = p.match; a.mismatch = p.mismatch; a.go = p.go; a.ge = p.ge; a.hfree = p.hfree; a.vfree = p.vfree;
-    a.qlimit = sub_limit(&p);
-    a.special_blocks = kn.no_compact ? nullptr : A.cq_special;
-    a.lastrow = d_lastrow;
-    TRY(timing_begin(ctx, TRACYHIP_TIMER_SCORE, 0, 0));
-    HIP_TRY(launch_gotoh_front_prefix_cq(a, 2 * nt, st));
-    TRY(timing_end(ctx));
-  }
-  TRY(timing_begin(ctx, TRACYHIP_TIMER_FRONT, 0, 0));
-  {
-    int rc = front_tier(ctx, p, sc.fd, 2 * nt, d_aqp, d_cq_ref, reinterpret_cast<const uint32_t*>(d_lastrow), 8, 60, max_arest, sc.fpairs1, sc.fo1, sc.fs1, sc.fe1, nullptr);
-    if (!rc) rc = front_tier(ctx, p, sc.fd, 2 * nt, d_aqp, d_cq_ref, reinterpret_cast<const uint32_t*>(d_lastrow), kFrontK, kFrontHalfW, max_arest, sc.fpairs2, sc.fo2, sc.fs2,
-                             sc.fe2, sc.fo1);
-    if (rc) return give_up(rc);
-  }
-  TRY(timing_end(ctx));
-  hipLaunchKernelGGL(s_allele_plan1_kernel, g256x2, b256, 0, st, spm, spd, sc.geom, A.geomd, sc.tr, sc.fo1, sc.fs1, sc.fe1, sc.fo2, sc.fs2, sc.fe2, A.al, sc.dead, sc.cand,
-                     sc.kc, sc.cnt);
-  HIP_TRY(hipGetLastError());
-  BandLaunch b1;
-  b1.kind = 1; b1.qp = d_aqp; b1.codes = d_cq_ref; b1.ends = sc.ends; b1.code_cap = ncap; b1.hfree = 1;
-  TRY(band_stage(ctx, p, sc, 2 * nt, nt, 1, b1, ~0ull));
-  hipLaunchKernelGGL(s_allele_plan2_kernel, g256x2, b256, 0, st, spm, sc.geom, A.geomd, sc.tr, sc.ends, A.al, sc.dead, sc.cand, sc.kc, sc.cnt);
-  HIP_TRY(hipGetLastError());
-  BandLaunch b2;
-  b2.kind = 0; b2.qp = d_aqp; b2.codes = d_cq_ref; b2.scores = A.ascore; b2.ops = d_opsK[0]; b2.ops_off = A.aops_off; b2.ops_len = A.alen; b2.code_cap = ncap; b2.hfree = 1;
-  TRY(band_stage(ctx, p, sc, 2 * nt, nt, 2, b2, words_cap));
-  hipLaunchKernelGGL(s_allele_check_kernel, g256x2, b256, 0, st, spm, A.al, A.ascore, A.alen, sc.dead, sc.cnt);
-  hipLaunchKernelGGL(s_a12_plan_kernel, g256, b256, 0, st, spm, spd, A.geomd, A.ascore, sc.dead, sc.cand, sc.kc, A.bound, sc.cnt);
-  HIP_TRY(hipGetLastError());
-  BandLaunch b3;
-  b3.kind = 0; b3.qp = d_aqp; b3.codes = d_cq_sd; b3.scores = o.score[2]; b3.ops = d_opsK[2]; b3.ops_off = A.ops2_off; b3.ops_len = o.ops_len[2]; b3.code_cap = ncap; b3.hfree = 0;
-  TRY(band_stage(ctx, pglobal, sc, nt, nt, 3, b3, words_cap));
-  hipLaunchKernelGGL(s_decompose_finish_kernel, g256, b256, 0, st, spm, sc.tr, A.al, A.ascore, A.alen, A.bound, sc.dead, o, sc.cnt);
-  HIP_TRY(hipGetLastError());
+  // payloads and result arrays: the caller's (device memory) or staged; references encoded; geometry uploaded
+  int bind() {
+    StreamCommon& sc = A.sc;
+    // ---- payloads and result arrays: the caller's (device memory) or staged ----
+    d_prof = static_cast<const float*>(sp.data);
+    d_ref = static_cast<const uint8_t*>(sr.data);
+    d_sig = bc.signal; d_pos = bc.bcpos;
+    d_pri = bc.primary; d_sec = bc.secondary; d_sd = out->secdecomp;
+    d_bp = out->bp;
+    d_fr = out->fractions;
+    d_di = out->dcp_indel; d_de = out->dcp_err;
+    d_dst = out->dstatus;
+    o = A.o;
+    for (int k = 0; k < 3; ++k) d_opsK[k] = out->ops[k];
+    if (host) {
+      auto up = [&](void* dev, const void* src, size_t bytes) -> int {
+        if (bytes) HIP_TRY(hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, st));
+        return TRACYHIP_OK;
+      };
+      TRY(up(A.in_prof, sp.data, z.ep * 4)); TRY(up(A.in_ref, sr.data, z.er)); TRY(up(A.in_sig, bc.signal, z.sext * 4)); TRY(up(A.in_pos, bc.bcpos, z.bext * 4));
+      TRY(up(A.pri, bc.primary, z.bext)); TRY(up(A.sec, bc.secondary, z.bext));
+      d_prof = A.in_prof; d_ref = A.in_ref; d_sig = A.in_sig; d_pos = A.in_pos; d_pri = A.pri; d_sec = A.sec; d_sd = A.secdecomp;
+      d_bp = A.bp; d_fr = A.fractions; d_di = A.dcp_indel; d_de = A.dcp_err; d_dst = A.dstatus;
+      for (int k = 0; k < 3; ++k) d_opsK[k] = A.ops[k];
+    } else {
+      o.status = out->status; o.score_fwd = out->score_fwd; o.score_rev = out->score_rev; o.score_trim = out->score_trim; o.forward = out->forward;
+      for (int k = 0; k < 2; ++k) { o.slice_begin[k] = out->slice_begin[k]; o.slice_len[k] = out->slice_len[k]; o.ref_pos[k] = out->ref_pos[k]; }
+      for (int k = 0; k < 3; ++k) { o.score[k] = out->score[k]; o.ops_len[k] = out->ops_len[k]; }
+    }
+    HIP_TRY(hipMemcpyAsync(A.pri_bak, d_pri, z.bext, hipMemcpyDeviceToDevice, st));  // decomposeAlleles rewrites the basecalls in place
+    HIP_TRY(hipMemcpyAsync(A.sec_bak, d_sec, z.bext, hipMemcpyDeviceToDevice, st));
 
-  // ---- the one read-back ----
-  const size_t rb = sizeof(int32_t) * (kErrWords + 4) + sizeof(int32_t) * 4 + sizeof(unsigned long long) * (SC_COUNT + SB_COUNT * 8) + sizeof(uint32_t) * (size_t)nt;
-  HIP_TRY(ctx->h_res.ensure(rb));
-  char* hp = static_cast<char*>(ctx->h_res.p);
-  int32_t* herr = reinterpret_cast<int32_t*>(hp);
-  int32_t* hcq = herr + (kErrWords + 4);
-  unsigned long long* hcnt = reinterpret_cast<unsigned long long*>(hcq + 4);
-  unsigned long long* hbst = hcnt + SC_COUNT;
-  uint32_t* hdead = reinterpret_cast<uint32_t*>(hbst + SB_COUNT * 8);
-  HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(int32_t) * (kErrWords + 4), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(hcq, A.cq_flag, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(hcnt, sc.cnt, sizeof(unsigned long long) * SC_COUNT, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(hbst, sc.bstat, sizeof(unsigned long long) * SB_COUNT * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(hdead, sc.dead, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx_sync(ctx));
-  timing_collect(ctx);
-  if (herr[kErrVerdictWord] & 4) {
-    (void)give_up(kStreamNo);
-    return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
-  }
-  TRY(give_up(stream_range_verdict(p, herr, h)));
-  if (hcq[0] & 1) return give_up(kStreamNo);  // a basecall string holds something else than A C G T N: the byte-compare kernels (pipeline.hip)
-  static const int stage_timer[4] = {TRACYHIP_TIMER_TRACE, TRACYHIP_TIMER_ORIGIN, TRACYHIP_TIMER_TRACE, TRACYHIP_TIMER_TRACE};
-  stats_from_counters(ctx, hcnt, hbst, 4, stage_timer);
-  ctx->stats.stream_ordered = 1;
+    // ---- references encoded once; geometry, offsets: one pinned block, one copy each way ----
+    HIP_TRY(ctx->d_err.ensure(kErrBytes));
+    HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, kErrBytes, st));
+    int32_t* d_verr = static_cast<int32_t*>(ctx->d_err.p) + kErrVerdictWord;
+    HIP_TRY(ctx->ensure_codes(z.er ? z.er : 1, st));
+    if (z.er) {
+      hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((z.er + 4095) / 4096)), dim3(256), 0, st, d_ref, ctx->codes(), z.er, ctx->special_blocks(), d_verr);
+      HIP_TRY(hipGetLastError());
+    }
+    {
+      char* hp = static_cast<char*>(ctx->h_desc.p);
+      SGeomD* hgd = geomd;
+      uint64_t* hoff = reinterpret_cast<uint64_t*>(hgd + nt);  // [off1 nt][allele ops 2 nt][allele 1 vs 2 ops nt]
+      // (band16_body adds an offset to ONE ops pointer: alleles 1 and 2 reach their buffers through offsets relative to allele 0's, modulo 2^64)
+      const uint64_t base1 = (uint64_t)(reinterpret_cast<uintptr_t>(d_opsK[1]) - reinterpret_cast<uintptr_t>(d_opsK[0]));
+      for (uint32_t t = 0; t < nt; ++t) {
+        hoff[t] = geom[t].ops_off;
+        hoff[nt + t] = out->ops_offset[0][t];
+        hoff[2 * (size_t)nt + t] = base1 + out->ops_offset[1][t];
+        hoff[3 * (size_t)nt + t] = out->ops_offset[2][t];
+      }
+      HIP_TRY(hipMemcpyAsync(sc.geom, hp, sizeof(SGeom) * (size_t)nt, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(A.geomd, hgd, sizeof(SGeomD) * (size_t)nt, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(A.off1, hoff, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(A.aops_off, hoff + nt, sizeof(uint64_t) * 2 * (size_t)nt, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(A.ops2_off, hoff + 3 * (size_t)nt, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemsetAsync(sc.dead, 0, sizeof(uint32_t) * (size_t)nt, st));
+    HIP_TRY(hipMemsetAsync(sc.cnt, 0, sizeof(unsigned long long) * SC_COUNT, st));
+    HIP_TRY(hipMemsetAsync(sc.bstat, 0, sizeof(unsigned long long) * SB_COUNT * 8, st));
 
-  // ---- traces the device could not give their tier: the host-planned pipeline on the list, from the basecalls as they were ----
-  std::vector<uint32_t> dl;
-  for (uint32_t t = 0; t < nt; ++t)
-    if (hdead[t]) dl.push_back(t);
-  ctx->stats.fallback_traces += (uint32_t)dl.size();
-  if (kn.verbose) {
-    uint32_t why[16] = {};
-    for (uint32_t t : dl) for (int b = 0; b < 16; ++b) why[b] += (hdead[t] >> b) & 1u;
-    fprintf(stderr, "stream-ordered decompose: %u traces, %zu to the host-planned tiers (front %u, strand %u, loser won %u, junk %u, prelim band %u / check %u, mem %u, allele front %u / origin %u / band %u / check %u, a12 band %u / check %u, shape %u)\n",
-            nt, dl.size(), why[0], why[1], why[2], why[3], why[4], why[5], why[8], why[9], why[10], why[11], why[12], why[13], why[14], why[15]);
+    spm.match = p.match; spm.mismatch = p.mismatch; spm.go = p.go; spm.ge = p.ge; spm.nt = nt; spm.exact = exact ? 1u : 0u; spm.ncap = ncap - 8u;
+    spm.trim_left = TL; spm.trim_right = TR; spm.use_votes = 1u;
+    spd.bext = z.bext;
+    spd.best = (int32_t)std::max<int64_t>(std::max<int64_t>(p.match, p.mismatch), 0);
+
+    return TRACYHIP_OK;
   }
-  if (!dl.empty()) {
-    const uint32_t nd = (uint32_t)dl.size();
-    HIP_TRY(hipMemcpyAsync(A.dead_list, dl.data(), sizeof(uint32_t) * nd, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(s_restore_kernel, dim3(nd), dim3(64), 0, st, A.dead_list, sc.geom, A.geomd, A.pri_bak, A.sec_bak, d_pri, d_sec);
+
+  int queue_trace_stages() {
+    StreamCommon& sc = A.sc;
+    // ---- 2. orientation (indigo.h:235-247), 3. gotoh(trimmed trace, window) (indigo.h:302) by traceback on its band ----
+    d_qp = static_cast<const int16_t*>(ctx->d_b16tab[2].p);
+    d_lastrow = static_cast<int32_t*>(ctx->d_lastrow.p);
+    OrientStage os{d_prof, d_qp, d_lastrow, exact, A.desc_trim};
+    TRY(give_up(queue_orientation(ctx, p, spm, h, sc, os)));
+    hipLaunchKernelGGL(s_expand_d_kernel, g256, b256, 0, st, sc.geom, A.geomd, nt, z.bext, A.bpd, A.rowsd, A.dd, A.bcd, A.atd);
+    hipLaunchKernelGGL(s_prelim_plan_kernel, g256, b256, 0, st, spm, 1, sc.geom, sc.tr, sc.ce, sc.top_trim, sc.dead, sc.cand, sc.kc);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(ctx_sync(ctx));
-    std::vector<uint64_t> poff(nd), sigoff(nd), bcoff(nd), dcpoff(nd), ooff[3];
-    std::vector<uint32_t> plen(nd), ridx(nd), nsamp(nd), bclen(nd);
-    for (int k = 0; k < 3; ++k) ooff[k].resize(nd);
-    for (uint32_t i = 0; i < nd; ++i) {
-      const uint32_t t = dl[i];
-      poff[i] = sp.offset[t]; plen[i] = sp.length[t]; ridx[i] = h.ridx[t];
-      sigoff[i] = bc.signal_offset[t]; nsamp[i] = bc.nsamples[t]; bcoff[i] = bc.bc_offset[t]; bclen[i] = bc.bc_len[t];
-      dcpoff[i] = out->dcp_offset[t];
-      for (int k = 0; k < 3; ++k) ooff[k][i] = out->ops_offset[k][t];
+    BandLaunch b0;
+    b0.kind = 0; b0.qp = d_qp; b0.codes = ctx->codes(); b0.scores = A.sb; b0.ops = A.ops1; b0.ops_off = A.off1; b0.ops_len = A.len1; b0.code_cap = ncap; b0.hfree = 1;
+    TRY(band_stage(ctx, p, sc, nt, nt, 0, b0, words_cap));
+    hipLaunchKernelGGL(s_prelim_check_kernel, g256, b256, 0, st, spm, sc.tr, A.sb, A.len1, sc.kc, o.score_trim, sc.dead, sc.cnt);
+    HIP_TRY(hipGetLastError());
+    {
+      RowsArgs ra{};
+      ra.pairs = A.desc_trim;
+      ra.a1 = d_prof; ra.a2 = d_ref;
+      ra.a1_profile = 1; ra.a2_profile = 0; ra.a2_revcomp_flag = 1; ra.a2_onehot = 1;
+      ra.ops = A.ops1; ra.ops_off = A.off1; ra.ops_len = A.len1;
+      ra.rows0 = A.rows0; ra.rows1 = A.rows1;
+      ra.npairs = nt;
+      HIP_TRY(launch_alignment_rows(ra, st));
     }
-    tracyhip_decompose_job j = *job;
-    j.ntraces = nd;
-    j.profiles.data = d_prof; j.profiles.offset = poff.data(); j.profiles.length = plen.data(); j.profiles.count = nd;
-    j.refs.data = d_ref;
-    j.ref_index = ridx.data();
-    j.bc.ntraces = nd;
-    j.bc.signal = d_sig; j.bc.signal_offset = sigoff.data(); j.bc.nsamples = nsamp.data();
-    j.bc.bcpos = d_pos; j.bc.primary = d_pri; j.bc.secondary = d_sec; j.bc.bc_offset = bcoff.data(); j.bc.bc_len = bclen.data();
-    tracyhip_decompose_result r{};
-    r.bp = A.f_bp; r.status = A.f.status; r.score_fwd = A.f.score_fwd; r.score_rev = A.f.score_rev; r.forward = A.f.forward; r.score_trim = A.f.score_trim;
-    r.dcp_indel = d_di; r.dcp_err = d_de; r.dcp_offset = dcpoff.data();
-    r.dstatus = A.f_dst; r.secdecomp = d_sd; r.fractions = A.f_fr;
-    for (int k = 0; k < 2; ++k) { r.slice_begin[k] = A.f.slice_begin[k]; r.slice_len[k] = A.f.slice_len[k]; r.ref_pos[k] = A.f.ref_pos[k]; }
-    for (int k = 0; k < 3; ++k) { r.score[k] = A.f.score[k]; r.ops[k] = d_opsK[k]; r.ops_offset[k] = ooff[k].data(); r.ops_len[k] = A.f.ops_len[k]; }
-    const tracyhip_call_stats keep = ctx->stats;
-    TRY(decompose_traces_legacy(ctx, &j, prm, TRACYHIP_MEM_DEVICE, &r));
-    const uint32_t syncs = ctx->stats.host_syncs;
-    ctx->stats = keep;
-    ctx->stats.host_syncs = syncs;
-    const uint32_t* L = A.dead_list;
-    TRY(scatter(st, L, nd, A.f_bp, d_bp)); TRY(scatter(st, L, nd, A.f_dst, d_dst));
-    TRY(scatter(st, L, nd, reinterpret_cast<const Frac2*>(A.f_fr), reinterpret_cast<Frac2*>(d_fr)));
-    TRY(scatter(st, L, nd, A.f.status, o.status)); TRY(scatter(st, L, nd, A.f.score_fwd, o.score_fwd)); TRY(scatter(st, L, nd, A.f.score_rev, o.score_rev));
-    TRY(scatter(st, L, nd, A.f.forward, o.forward)); TRY(scatter(st, L, nd, A.f.score_trim, o.score_trim));
-    for (int k = 0; k < 2; ++k) {
-      TRY(scatter(st, L, nd, A.f.slice_begin[k], o.slice_begin[k])); TRY(scatter(st, L, nd, A.f.slice_len[k], o.slice_len[k]));
-      TRY(scatter(st, L, nd, A.f.ref_pos[k], o.ref_pos[k]));
+    // ---- 1. findBreakpoint (indigo.h:196), 4. findHomozygousBreakpoint (indigo.h:314-317), 5. decomposeAlleles, generateSecondaryDecomposed,
+    // allelicFraction (indigo.h:340-350) ----
+    BreakpointOut* bpo = reinterpret_cast<BreakpointOut*>(d_bp);
+    TRY(launch_breakpoint(ctx, A.bpd, nt, h.maxmt, d_prof, bpo));
+    TRY(launch_homozygous(ctx, A.rowsd, A.rows0, A.rows1, nt, bpo, A.hst, A.len1));
+    {
+      DecompArgs a{};
+      a.desc = A.dd;
+      a.rows0 = A.rows0; a.rows1 = A.rows1;
+      a.primary = d_pri; a.secondary = d_sec;
+      a.dcp_indel = d_di; a.dcp_err = d_de;
+      a.out = reinterpret_cast<DecompOut*>(d_dst);
+      a.prm = DecompParams{dp.trim_left, dp.trim_right, dp.maxindel, dp.madc};
+      a.ntraces = nt;
+      a.lens = A.len1;
+      a.skip = sc.dead;
+      TRY(launch_decompose(ctx, a, bpo, maxbc, 0, 0));
+      TRY(launch_secdecomp(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sec, d_sd));
+      TRY(launch_allelic_fraction(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sd, TL, TR, d_fr, 18ull * std::accumulate(h.mf.begin(), h.mf.end(), 0ull)));
     }
-    for (int k = 0; k < 3; ++k) { TRY(scatter(st, L, nd, A.f.score[k], o.score[k])); TRY(scatter(st, L, nd, A.f.ops_len[k], o.ops_len[k])); }
-    HIP_TRY(ctx_sync(ctx));
+    hipLaunchKernelGGL(s_status_kernel, g256, b256, 0, st, spm, sc.geom, o.score_trim, A.hst, A.len1, sc.dead, o.status, sc.cnt);
+    HIP_TRY(hipGetLastError());
+
+    return TRACYHIP_OK;
   }
-  if (host) {
-    auto back = [&](void* user, const void* dev, size_t bytes) -> int {
-      if (user && bytes) HIP_TRY(hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, st));
-      return TRACYHIP_OK;
-    };
-    const size_t n4 = sizeof(int32_t) * (size_t)nt;
-    TRY(back(bc.primary, d_pri, z.bext)); TRY(back(bc.secondary, d_sec, z.bext)); TRY(back(out->secdecomp, d_sd, z.bext));
-    TRY(back(out->bp, d_bp, sizeof(tracyhip_breakpoint) * (size_t)nt)); TRY(back(out->fractions, d_fr, sizeof(double) * 2 * (size_t)nt));
-    TRY(back(out->dcp_indel, d_di, z.dext * 4)); TRY(back(out->dcp_err, d_de, z.dext * 4)); TRY(back(out->dstatus, d_dst, sizeof(tracyhip_decomp_status) * (size_t)nt));
-    TRY(back(out->status, o.status, n4)); TRY(back(out->score_fwd, o.score_fwd, n4)); TRY(back(out->score_rev, o.score_rev, n4));
-    TRY(back(out->score_trim, o.score_trim, n4)); TRY(back(out->forward, o.forward, nt));
-    for (int k = 0; k < 2; ++k) { TRY(back(out->slice_begin[k], o.slice_begin[k], n4)); TRY(back(out->slice_len[k], o.slice_len[k], n4)); TRY(back(out->ref_pos[k], o.ref_pos[k], n4)); }
-    for (int k = 0; k < 3; ++k) { TRY(back(out->score[k], o.score[k], n4)); TRY(back(out->ops_len[k], o.ops_len[k], n4)); TRY(back(out->ops[k], d_opsK[k], z.opscap[k])); }
-    HIP_TRY(ctx_sync(ctx));
+
+  int queue_allele_stages() {
+    StreamCommon& sc = A.sc;
+    // ---- 6. allele-specific alignments (indigo.h:355-387), both alleles of every trace in the same launches ----
+    // strings scored through the query-profile table (MODE_CQ): the two allele strings side by side, case-sensitive codes of the windows
+    // and of allele 2, the test that the rows hold A C G T N only (read with the call's verdict words)
+    d_cq_ref = A.cq_ref + kCodePad;
+    d_cq_sd = A.cq_sd + kCodePad;
+    HIP_TRY(hipMemcpyAsync(A.seqs2, d_pri, z.bext, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(A.seqs2 + z.bext, d_sd, z.bext, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemsetAsync(A.cq_ref, 5, z.er + 2 * kCodePad, st));
+    HIP_TRY(hipMemsetAsync(A.cq_sd, 5, z.bext + 2 * kCodePad, st));
+    HIP_TRY(hipMemsetAsync(A.cq_special, 0, (z.er >> 8) + 2, st));
+    HIP_TRY(hipMemsetAsync(A.cq_flag, 0, sizeof(int32_t) * 4, st));
+    if (z.er) hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((z.er + 255) / 256)), dim3(256), 0, st, d_ref, d_cq_ref, z.er, A.cq_flag, A.cq_special);
+    if (z.bext) {
+      hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((z.bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), d_cq_sd, z.bext, A.cq_flag, (uint8_t*)nullptr);
+      hipLaunchKernelGGL(cq_rows_kernel, dim3((unsigned)((2 * z.bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(A.seqs2), 2 * z.bext, A.cq_flag);
+    }
+    HIP_TRY(hipGetLastError());
+    d_aqp = static_cast<const int16_t*>(ctx->d_b16tab[0].p);
+    TRY(timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, atab_tot * 2));
+    HIP_TRY(launch_b16_tables(A.atd, 2 * nt, A.seqs2, true, p.match, p.mismatch, sub_limit(&p), kTagShift, const_cast<int16_t*>(d_aqp), static_cast<int32_t*>(ctx->d_err.p), st));
+    TRY(timing_end(ctx));
+    hipLaunchKernelGGL(s_allele_plan0_kernel, g256x2, b256, 0, st, spm, spd, sc.geom, A.geomd, sc.tr, sc.dead, sc.pre, sc.fd, sc.cnt);
+    HIP_TRY(hipGetLastError());
+    {
+      DpArgs a{};
+      a.pairs = sc.pre;
+      a.a1 = A.seqs2; a.a2 = d_cq_ref; a.err = static_cast<int32_t*>(ctx->d_err.p);
+      a.match = p.match; a.mismatch = p.mismatch; a.go = p.go; a.ge = p.ge; a.hfree = p.hfree; a.vfree = p.vfree;
+      a.qlimit = sub_limit(&p);
+      a.special_blocks = kn.no_compact ? nullptr : A.cq_special;
+      a.lastrow = d_lastrow;
+      TRY(timing_begin(ctx, TRACYHIP_TIMER_SCORE, 0, 0));
+      HIP_TRY(launch_gotoh_front_prefix_cq(a, 2 * nt, st));
+      TRY(timing_end(ctx));
+    }
+    TRY(timing_begin(ctx, TRACYHIP_TIMER_FRONT, 0, 0));
+    {
+      int rc = front_tier(ctx, p, sc.fd, 2 * nt, d_aqp, d_cq_ref, reinterpret_cast<const uint32_t*>(d_lastrow), 8, 60, max_arest, sc.fpairs1, sc.fo1, sc.fs1, sc.fe1, nullptr);
+      if (!rc) rc = front_tier(ctx, p, sc.fd, 2 * nt, d_aqp, d_cq_ref, reinterpret_cast<const uint32_t*>(d_lastrow), kFrontK, kFrontHalfW, max_arest, sc.fpairs2, sc.fo2, sc.fs2,
+                               sc.fe2, sc.fo1);
+      if (rc) return give_up(rc);
+    }
+    TRY(timing_end(ctx));
+    hipLaunchKernelGGL(s_allele_plan1_kernel, g256x2, b256, 0, st, spm, spd, sc.geom, A.geomd, sc.tr, sc.fo1, sc.fs1, sc.fe1, sc.fo2, sc.fs2, sc.fe2, A.al, sc.dead, sc.cand,
+                       sc.kc, sc.cnt);
+    HIP_TRY(hipGetLastError());
+    BandLaunch b1;
+    b1.kind = 1; b1.qp = d_aqp; b1.codes = d_cq_ref; b1.ends = sc.ends; b1.code_cap = ncap; b1.hfree = 1;
+    TRY(band_stage(ctx, p, sc, 2 * nt, nt, 1, b1, ~0ull));
+    hipLaunchKernelGGL(s_allele_plan2_kernel, g256x2, b256, 0, st, spm, sc.geom, A.geomd, sc.tr, sc.ends, A.al, sc.dead, sc.cand, sc.kc, sc.cnt);
+    HIP_TRY(hipGetLastError());
+    BandLaunch b2;
+    b2.kind = 0; b2.qp = d_aqp; b2.codes = d_cq_ref; b2.scores = A.ascore; b2.ops = d_opsK[0]; b2.ops_off = A.aops_off; b2.ops_len = A.alen; b2.code_cap = ncap; b2.hfree = 1;
+    TRY(band_stage(ctx, p, sc, 2 * nt, nt, 2, b2, words_cap));
+    hipLaunchKernelGGL(s_allele_check_kernel, g256x2, b256, 0, st, spm, A.al, A.ascore, A.alen, sc.dead, sc.cnt);
+    hipLaunchKernelGGL(s_a12_plan_kernel, g256, b256, 0, st, spm, spd, A.geomd, A.ascore, sc.dead, sc.cand, sc.kc, A.bound, sc.cnt);
+    HIP_TRY(hipGetLastError());
+    BandLaunch b3;
+    b3.kind = 0; b3.qp = d_aqp; b3.codes = d_cq_sd; b3.scores = o.score[2]; b3.ops = d_opsK[2]; b3.ops_off = A.ops2_off; b3.ops_len = o.ops_len[2]; b3.code_cap = ncap; b3.hfree = 0;
+    TRY(band_stage(ctx, pglobal, sc, nt, nt, 3, b3, words_cap));
+    hipLaunchKernelGGL(s_decompose_finish_kernel, g256, b256, 0, st, spm, sc.tr, A.al, A.ascore, A.alen, A.bound, sc.dead, o, sc.cnt);
+    HIP_TRY(hipGetLastError());
+
+    return TRACYHIP_OK;
   }
-  return TRACYHIP_OK;
+
+  // the one read-back: verdict words, counters, dead flags
+  int read_back() {
+    StreamCommon& sc = A.sc;
+    // ---- the one read-back ----
+    const size_t rb = sizeof(int32_t) * (kErrWords + 4) + sizeof(int32_t) * 4 + sizeof(unsigned long long) * (SC_COUNT + SB_COUNT * 8) + sizeof(uint32_t) * (size_t)nt;
+    HIP_TRY(ctx->h_res.ensure(rb));
+    char* hp = static_cast<char*>(ctx->h_res.p);
+    herr = reinterpret_cast<int32_t*>(hp);
+    hcq = herr + (kErrWords + 4);
+    hcnt = reinterpret_cast<unsigned long long*>(hcq + 4);
+    hbst = hcnt + SC_COUNT;
+    hdead = reinterpret_cast<uint32_t*>(hbst + SB_COUNT * 8);
+    HIP_TRY(hipMemcpyAsync(herr, ctx->d_err.p, sizeof(int32_t) * (kErrWords + 4), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hcq, A.cq_flag, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hcnt, sc.cnt, sizeof(unsigned long long) * SC_COUNT, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hbst, sc.bstat, sizeof(unsigned long long) * SB_COUNT * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hdead, sc.dead, sizeof(uint32_t) * (size_t)nt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx_sync(ctx));
+    timing_collect(ctx);
+    if (herr[kErrVerdictWord] & 4) {
+      (void)give_up(kStreamNo);
+      return set_error(TRACYHIP_ERR_ARG, "reference windows must be upper-case [ACGTN] (loadSingleFasta, fasta.h:54-95)");
+    }
+    TRY(give_up(stream_range_verdict(p, herr, h)));
+    if (hcq[0] & 1) return give_up(kStreamNo);  // a basecall string holds something else than A C G T N: the byte-compare kernels (pipeline.hip)
+    static const int stage_timer[4] = {TRACYHIP_TIMER_TRACE, TRACYHIP_TIMER_ORIGIN, TRACYHIP_TIMER_TRACE, TRACYHIP_TIMER_TRACE};
+    stats_from_counters(ctx, hcnt, hbst, 4, stage_timer);
+    ctx->stats.stream_ordered = 1;
+
+    // ---- traces the device could not give their tier: the host-planned pipeline on the list, from the basecalls as they were ----
+    dl.clear();
+    for (uint32_t t = 0; t < nt; ++t)
+      if (hdead[t]) dl.push_back(t);
+    ctx->stats.fallback_traces += (uint32_t)dl.size();
+    if (kn.verbose) {
+      uint32_t why[16] = {};
+      for (uint32_t t : dl) for (int b = 0; b < 16; ++b) why[b] += (hdead[t] >> b) & 1u;
+      fprintf(stderr, "stream-ordered decompose: %u traces, %zu to the host-planned tiers (front %u, strand %u, loser won %u, junk %u, prelim band %u / check %u, mem %u, allele front %u / origin %u / band %u / check %u, a12 band %u / check %u, shape %u)\n",
+              nt, dl.size(), why[0], why[1], why[2], why[3], why[4], why[5], why[8], why[9], why[10], why[11], why[12], why[13], why[14], why[15]);
+    }
+    return TRACYHIP_OK;
+  }
+
+  // the traces the device could not give their tier: the host-planned pipeline on the list, from the basecalls as they were
+  int redo_dead_traces() {
+    StreamCommon& sc = A.sc;
+    if (!dl.empty()) {
+      const uint32_t nd = (uint32_t)dl.size();
+      HIP_TRY(hipMemcpyAsync(A.dead_list, dl.data(), sizeof(uint32_t) * nd, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(s_restore_kernel, dim3(nd), dim3(64), 0, st, A.dead_list, sc.geom, A.geomd, A.pri_bak, A.sec_bak, d_pri, d_sec);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(ctx_sync(ctx));
+      std::vector<uint64_t> poff(nd), sigoff(nd), bcoff(nd), dcpoff(nd), ooff[3];
+      std::vector<uint32_t> plen(nd), ridx(nd), nsamp(nd), bclen(nd);
+      for (int k = 0; k < 3; ++k) ooff[k].resize(nd);
+      for (uint32_t i = 0; i < nd; ++i) {
+        const uint32_t t = dl[i];
+        poff[i] = sp.offset[t]; plen[i] = sp.length[t]; ridx[i] = h.ridx[t];
+        sigoff[i] = bc.signal_offset[t]; nsamp[i] = bc.nsamples[t]; bcoff[i] = bc.bc_offset[t]; bclen[i] = bc.bc_len[t];
+        dcpoff[i] = out->dcp_offset[t];
+        for (int k = 0; k < 3; ++k) ooff[k][i] = out->ops_offset[k][t];
+      }
+      tracyhip_decompose_job j = *job;
+      j.ntraces = nd;
+      j.profiles.data = d_prof; j.profiles.offset = poff.data(); j.profiles.length = plen.data(); j.profiles.count = nd;
+      j.refs.data = d_ref;
+      j.ref_index = ridx.data();
+      j.bc.ntraces = nd;
+      j.bc.signal = d_sig; j.bc.signal_offset = sigoff.data(); j.bc.nsamples = nsamp.data();
+      j.bc.bcpos = d_pos; j.bc.primary = d_pri; j.bc.secondary = d_sec; j.bc.bc_offset = bcoff.data(); j.bc.bc_len = bclen.data();
+      tracyhip_decompose_result r{};
+      r.bp = A.f_bp; r.status = A.f.status; r.score_fwd = A.f.score_fwd; r.score_rev = A.f.score_rev; r.forward = A.f.forward; r.score_trim = A.f.score_trim;
+      r.dcp_indel = d_di; r.dcp_err = d_de; r.dcp_offset = dcpoff.data();
+      r.dstatus = A.f_dst; r.secdecomp = d_sd; r.fractions = A.f_fr;
+      for (int k = 0; k < 2; ++k) { r.slice_begin[k] = A.f.slice_begin[k]; r.slice_len[k] = A.f.slice_len[k]; r.ref_pos[k] = A.f.ref_pos[k]; }
+      for (int k = 0; k < 3; ++k) { r.score[k] = A.f.score[k]; r.ops[k] = d_opsK[k]; r.ops_offset[k] = ooff[k].data(); r.ops_len[k] = A.f.ops_len[k]; }
+      const tracyhip_call_stats keep = ctx->stats;
+      TRY(decompose_traces_legacy(ctx, &j, prm, TRACYHIP_MEM_DEVICE, &r));
+      const uint32_t syncs = ctx->stats.host_syncs;
+      ctx->stats = keep;
+      ctx->stats.host_syncs = syncs;
+      const uint32_t* L = A.dead_list;
+      TRY(scatter(st, L, nd, A.f_bp, d_bp)); TRY(scatter(st, L, nd, A.f_dst, d_dst));
+      TRY(scatter(st, L, nd, reinterpret_cast<const Frac2*>(A.f_fr), reinterpret_cast<Frac2*>(d_fr)));
+      TRY(scatter(st, L, nd, A.f.status, o.status)); TRY(scatter(st, L, nd, A.f.score_fwd, o.score_fwd)); TRY(scatter(st, L, nd, A.f.score_rev, o.score_rev));
+      TRY(scatter(st, L, nd, A.f.forward, o.forward)); TRY(scatter(st, L, nd, A.f.score_trim, o.score_trim));
+      for (int k = 0; k < 2; ++k) {
+        TRY(scatter(st, L, nd, A.f.slice_begin[k], o.slice_begin[k])); TRY(scatter(st, L, nd, A.f.slice_len[k], o.slice_len[k]));
+        TRY(scatter(st, L, nd, A.f.ref_pos[k], o.ref_pos[k]));
+      }
+      for (int k = 0; k < 3; ++k) { TRY(scatter(st, L, nd, A.f.score[k], o.score[k])); TRY(scatter(st, L, nd, A.f.ops_len[k], o.ops_len[k])); }
+      HIP_TRY(ctx_sync(ctx));
+    }
+    return TRACYHIP_OK;
+  }
+
+  // results to the caller's host arrays
+  int copy_back() {
+    if (host) {
+      auto back = [&](void* user, const void* dev, size_t bytes) -> int {
+        if (user && bytes) HIP_TRY(hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, st));
+        return TRACYHIP_OK;
+      };
+      const size_t n4 = sizeof(int32_t) * (size_t)nt;
+      TRY(back(bc.primary, d_pri, z.bext)); TRY(back(bc.secondary, d_sec, z.bext)); TRY(back(out->secdecomp, d_sd, z.bext));
+      TRY(back(out->bp, d_bp, sizeof(tracyhip_breakpoint) * (size_t)nt)); TRY(back(out->fractions, d_fr, sizeof(double) * 2 * (size_t)nt));
+      TRY(back(out->dcp_indel, d_di, z.dext * 4)); TRY(back(out->dcp_err, d_de, z.dext * 4)); TRY(back(out->dstatus, d_dst, sizeof(tracyhip_decomp_status) * (size_t)nt));
+      TRY(back(out->status, o.status, n4)); TRY(back(out->score_fwd, o.score_fwd, n4)); TRY(back(out->score_rev, o.score_rev, n4));
+      TRY(back(out->score_trim, o.score_trim, n4)); TRY(back(out->forward, o.forward, nt));
+      for (int k = 0; k < 2; ++k) { TRY(back(out->slice_begin[k], o.slice_begin[k], n4)); TRY(back(out->slice_len[k], o.slice_len[k], n4)); TRY(back(out->ref_pos[k], o.ref_pos[k], n4)); }
+      for (int k = 0; k < 3; ++k) { TRY(back(out->score[k], o.score[k], n4)); TRY(back(out->ops_len[k], o.ops_len[k], n4)); TRY(back(out->ops[k], d_opsK[k], z.opscap[k])); }
+      HIP_TRY(ctx_sync(ctx));
+    }
+    return TRACYHIP_OK;
+  }
+};
+}  // namespace
+
+int tracyhip::stream_decompose(tracyhip_ctx* ctx, const tracyhip_decompose_job* job, const tracyhip_params* prm, int mem,
+                               const tracyhip_decompose_result* out) {
+  if (!stream_options_ok(ctx->knobs) || job->oriented || job->ref_profiles.data) return kStreamNo;
+  static thread_local StreamHost h;
+  DecStream s(ctx, job, prm, mem, out, h);
+  TRY(s.plan());
+  TRY(s.bind());
+  TRY(s.queue_trace_stages());    // 2., 3., then 1., 4., 5. (indigo.h:196-350)
+  TRY(s.queue_allele_stages());   // 6. (indigo.h:355-387)
+  TRY(s.read_back());             // the call's one synchronisation
+  TRY(s.redo_dead_traces());
+  return s.copy_back();
 }

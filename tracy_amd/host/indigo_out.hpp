@@ -148,12 +148,12 @@ template <class Out, typename std::enable_if<!std::is_same<Out, std::string>::va
 inline void traceJsonBody(Out& out, BaseCalls const& bc, Trace const& tr) {
   const int32_t ns = (int32_t)tr.traceACGT[0].size();
   out << "\"pos\": [";
-  for (int32_t i = 0; i < ns; ++i) out << (i ? ", " : "") << (i + 1);
+  write_int_list(out, (std::size_t)ns, [](std::size_t i) { return (int32_t)i + 1; });
   out << "]," << std::endl;
   static const char* channel[4] = {"peakA", "peakC", "peakG", "peakT"};
   for (int k = 0; k < 4; ++k) {
     out << "\"" << channel[k] << "\": [";
-    for (int32_t i = 0; i < ns; ++i) out << (i ? ", " : "") << tr.traceACGT[k][i];
+    write_int_list(out, (std::size_t)ns, [&](std::size_t i) { return tr.traceACGT[k][i]; });
     out << "]," << std::endl;
   }
   auto for_each_call = [&](auto&& emit) {

@@ -17,6 +17,9 @@
 #ifndef TRACY_AMD_SAGE_OUT_HPP
 #define TRACY_AMD_SAGE_OUT_HPP
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include "text_buf.hpp"
 #include <algorithm>
 #include <cctype>
@@ -66,14 +69,14 @@ inline void reverseComplement(std::string& sequence) {
 
 // genomeType, fmindex.h:58-71
 inline int32_t genomeType(std::string const& path) {
-  std::ifstream in(path.c_str(), std::ios::binary);
-  if (!in.is_open()) return -1;
-  char magic[4] = {0, 0, 0, 0};
-  in.read(magic, 4);
-  in.close();
-  if ((uint8_t)magic[0] == 0x1f && (uint8_t)magic[1] == 0x8b) return 0;
-  if (magic[0] == 'T' && magic[1] == 'A' && magic[2] == 'M' && magic[3] == 'D') return 0;  // an index written by `tracy_amd_cli index` (seed.hpp)
-  if (traceFormat(path) >= 0) return 2;
+  unsigned char magic[4] = {0, 0, 0, 0};
+  const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return -1;
+  const ssize_t got = ::read(fd, magic, 4);
+  ::close(fd);
+  if (magic[0] == 0x1f && magic[1] == 0x8b) return 0;
+  if (std::memcmp(magic, "TAMD", 4) == 0) return 0;  // an index written by `tracy_amd_cli index` (seed.hpp)
+  if (got == 4 && (std::memcmp(magic, "ABIF", 4) == 0 || std::memcmp(magic, ".scf", 4) == 0)) return 2;  // traceFormat(path) >= 0
   if (magic[0] == '>') return 1;
   return -1;
 }
@@ -82,33 +85,47 @@ inline int32_t genomeType(std::string const& path) {
 // the record name loses the characters VCF dislikes (fasta.h:16-35)
 inline bool loadSingleFasta(std::string const& filename, std::string& faname, std::string& seq) {
   faname.clear();
+  // what a letter of the record becomes: itself (A C G T N, either case), 'N' (the other IUPAC codes), 0 = not a nucleotide code
+  static const struct Letters {
+    char t[256];
+    Letters() {
+      std::memset(t, 0, sizeof(t));
+      for (const char* c = "ACGTN"; *c; ++c) { t[(unsigned char)*c] = *c; t[(unsigned char)(*c + 32)] = *c; }
+      for (const char* c = "WSMKRYBDHV"; *c; ++c) { t[(unsigned char)*c] = 'N'; t[(unsigned char)(*c + 32)] = 'N'; }
+    }
+  } letters;
   std::string body;
-  std::ifstream in(filename.c_str());
-  if (in.good()) {
-    std::string line;
-    while (std::getline(in, line)) {
-      if (line.empty()) continue;
-      const bool cr = line.back() == '\r';
-      if (line[0] == '>') {
-        if (!faname.empty()) {
-          std::cerr << "Only single-chromosome FASTA files are supported." << std::endl;
-          return false;
+  bool foreign = false;
+  detail::FileBytes f;
+  if (f.load(filename)) {
+    const char* p = f.chars();
+    const char* const end = p + f.size();
+    body.reserve(f.size());
+    while (p < end) {  // the lines std::getline would hand out: split at '\n', a last line without one included, empty ones skipped
+      const char* nl = static_cast<const char*>(std::memchr(p, '\n', (std::size_t)(end - p)));
+      const char* le = nl ? nl : end;
+      if (le > p) {
+        const std::size_t len = (std::size_t)(le - p) - (le[-1] == '\r' ? 1 : 0);
+        if (*p == '>') {
+          if (!faname.empty()) {
+            std::cerr << "Only single-chromosome FASTA files are supported." << std::endl;
+            return false;
+          }
+          faname.assign(p + 1, len ? len - 1 : 0);
+        } else {
+          for (std::size_t i = 0; i < len; ++i) {
+            const char c = letters.t[(unsigned char)p[i]];
+            foreign = foreign || c == 0;
+            body.push_back(c);
+          }
         }
-        faname = cr ? line.substr(1, line.size() - 2) : line.substr(1);
-      } else {
-        const std::size_t len = cr ? line.size() - 1 : line.size();
-        for (std::size_t i = 0; i < len; ++i) body.push_back((char)std::toupper((unsigned char)line[i]));
       }
+      p = nl ? nl + 1 : end;
     }
   }
-  for (auto& c : body) {
-    switch (c) {
-      case 'A': case 'C': case 'G': case 'T': case 'N': break;
-      case 'W': case 'S': case 'M': case 'K': case 'R': case 'Y': case 'B': case 'D': case 'H': case 'V': c = 'N'; break;
-      default:
-        std::cerr << "FASTA file contains non-IUPAC characters." << std::endl;
-        return false;
-    }
+  if (foreign) {
+    std::cerr << "FASTA file contains non-IUPAC characters." << std::endl;
+    return false;
   }
   seq += body;
   static const std::string banned = "\\,'\"()[]{}<>:\t\r#";
@@ -283,6 +300,13 @@ inline void alignmentTracePadding(std::string const& row, Trace const& tr, BaseC
   int32_t next_call = bc.bcPos[0];
   int32_t next_ins = at.empty() ? -1 : (int32_t)at[0];
   const int32_t ns = (int32_t)tr.traceACGT[0].size();
+  {
+    std::size_t gaps = 0;
+    for (uint32_t l : len) gaps += l;
+    for (int k = 0; k < 4; ++k) ntr.traceACGT[k].reserve(ntr.traceACGT[k].size() + (std::size_t)ns + gaps * step);
+    const std::size_t ncalls = bc.bcPos.size() + gaps;
+    nbc.bcPos.reserve(ncalls); nbc.estQual.reserve(ncalls); nbc.primary.reserve(ncalls); nbc.secondary.reserve(ncalls); nbc.consensus.reserve(ncalls);
+  }
   for (int32_t x = 0; x < ns; ++x) {
     for (int k = 0; k < 4; ++k) ntr.traceACGT[k].push_back(tr.traceACGT[k][x]);
     if (next_ins == x) {
@@ -321,10 +345,7 @@ inline void assemblyTrace(Out& out, PaddedTrace const& p, std::string const& tra
   static const char* channel[4] = {"peakA", "peakC", "peakG", "peakT"};
   for (int k = 0; k < 4; ++k) {
     out << "\"" << channel[k] << "\": [";
-    for (int32_t i = 0; i < ns; ++i) {
-      if (i) out << ", ";
-      out << tr.traceACGT[k][i];
-    }
+    write_int_list(out, (std::size_t)ns, [&](std::size_t i) { return tr.traceACGT[k][i]; });
     out << "]," << std::endl;
   }
   // one visit per called sample, in sample order; calls whose position never comes up are skipped

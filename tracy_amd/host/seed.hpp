@@ -215,6 +215,10 @@ class GenomeIndex {
       at += (std::size_t)((bytes + 7) & ~7ull);
       return p;
     };
+    // the header's counts are a file's word: nothing is sized from them before they are known to fit the file (a count whose
+    // byte size wraps 64 bits would pass take())
+    const uint64_t fsz = (uint64_t)map_bytes_;
+    if (tbytes > fsz || nmb > fsz || nc > fsz / sizeof(uint64_t) || nt > fsz / sizeof(Entry)) { unmap(); return false; }
     const char* ptext = take(tbytes);
     const char* pnm = take(nmb);
     const char* plen = take(nc * sizeof(uint32_t));
@@ -231,7 +235,16 @@ class GenomeIndex {
     bkt_ = reinterpret_cast<const uint64_t*>(pb);
     tab_ = reinterpret_cast<const Entry*>(pt);
     ntab_ = (std::size_t)nt;
-    if (bkt_[(std::size_t)1 << bucket_bits_] != ntab_) { unmap(); return false; }
+    // the directory is a prefix sum over the table (range() reads tab_[bkt_[b] .. bkt_[b+1])); contigs lie in the text, in order
+    const std::size_t nb = (std::size_t)1 << bucket_bits_;
+    bool sane = bkt_[0] == 0 && bkt_[nb] == ntab_;
+    for (std::size_t b = 0; sane && b < nb; ++b) sane = bkt_[b] <= bkt_[b + 1];
+    uint64_t end = 0;
+    for (std::size_t i = 0; sane && i < nc; ++i) {
+      sane = starts[i] >= end && starts[i] <= tbytes && lengths[i] <= tbytes - starts[i];
+      end = starts[i] + lengths[i];
+    }
+    if (!sane) { unmap(); names.clear(); lengths.clear(); starts.clear(); return false; }
     make_resident();
     return true;
   }

@@ -14,7 +14,14 @@
 #ifndef TRACY_AMD_TRACE_IO_HPP
 #define TRACY_AMD_TRACE_IO_HPP
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "text_buf.hpp"
+#include <cerrno>
+#include <cstring>
+#include <memory>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -32,26 +39,48 @@ namespace detail {
 // big-endian view of a whole file
 class FileBytes {
  public:
+  // one open / fstat / read (a manifest is 10^4 files of 100 KB: no stream object, no seek, no zero fill of the buffer); anything
+  // that is not a regular file (a pipe) is read to its end in growing steps
   bool load(std::string const& filename) {
-    std::ifstream in(filename.c_str(), std::ios::binary | std::ios::ate);
-    if (!in) return false;
-    const std::streamoff sz = in.tellg();
-    if (sz < 0) return false;
-    in.seekg(0, std::ios::beg);
-    b_.resize((std::size_t)sz);
-    return sz == 0 || (bool)in.read(reinterpret_cast<char*>(b_.data()), sz);
+    n_ = 0;
+    const int fd = ::open(filename.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return false;
+    struct stat st;
+    if (::fstat(fd, &st) != 0 || S_ISDIR(st.st_mode)) { ::close(fd); return false; }
+    std::size_t cap = S_ISREG(st.st_mode) ? (std::size_t)st.st_size + 1 : (std::size_t)1 << 16;
+    b_.reset(new uint8_t[cap]);
+    std::size_t got = 0;
+    for (;;) {
+      if (got == cap) {
+        std::unique_ptr<uint8_t[]> nb(new uint8_t[2 * cap]);
+        std::memcpy(nb.get(), b_.get(), got);
+        b_.swap(nb);
+        cap *= 2;
+      }
+      const ssize_t r = ::read(fd, b_.get() + got, cap - got);
+      if (r < 0 && errno == EINTR) continue;
+      if (r < 0) { ::close(fd); return false; }
+      if (r == 0) break;
+      got += (std::size_t)r;
+    }
+    ::close(fd);
+    n_ = got;
+    return true;
   }
-  std::size_t size() const { return b_.size(); }
-  bool has(std::size_t pos, std::size_t len) const { return pos <= b_.size() && len <= b_.size() - pos; }
+  std::size_t size() const { return n_; }
+  bool has(std::size_t pos, std::size_t len) const { return pos <= n_ && len <= n_ - pos; }
   uint8_t u8(std::size_t p) const { return b_[p]; }
   int16_t i16(std::size_t p) const { return (int16_t)(uint16_t)((b_[p] << 8) | b_[p + 1]); }
   int32_t i32(std::size_t p) const {
     return (int32_t)(((uint32_t)b_[p] << 24) | ((uint32_t)b_[p + 1] << 16) | ((uint32_t)b_[p + 2] << 8) | (uint32_t)b_[p + 3]);
   }
-  std::string str(std::size_t p, std::size_t len) const { return std::string(b_.begin() + p, b_.begin() + p + len); }
+  std::string str(std::size_t p, std::size_t len) const { return std::string(reinterpret_cast<const char*>(b_.get()) + p, len); }
+  const char* chars() const { return reinterpret_cast<const char*>(b_.get()); }
+  bool starts_with(const char* magic4) const { return n_ >= 4 && std::memcmp(b_.get(), magic4, 4) == 0; }
 
  private:
-  std::vector<uint8_t> b_;
+  std::unique_ptr<uint8_t[]> b_;
+  std::size_t n_ = 0;
 };
 
 inline std::string only_dna(std::string s) {  // replaceNonDna, abif.h:276-284
@@ -63,11 +92,11 @@ inline std::string only_dna(std::string s) {  // replaceNonDna, abif.h:276-284
 }  // namespace detail
 
 // traceFormat, scf.h:18-34: 0 = ABIF, 1 = SCF, -1 = neither / unreadable
+inline int32_t traceFormat(detail::FileBytes const& f) { return f.starts_with("ABIF") ? 0 : f.starts_with(".scf") ? 1 : -1; }
 inline int32_t traceFormat(std::string const& filename) {
   detail::FileBytes f;
-  if (!f.load(filename) || !f.has(0, 4)) return -1;
-  const std::string magic = f.str(0, 4);
-  return magic == "ABIF" ? 0 : magic == ".scf" ? 1 : -1;
+  if (!f.load(filename)) return -1;
+  return traceFormat(f);
 }
 
 // readab, abif.h:286-405.  Tags used: PBAS.2 / P2BA.1 (char), FWO_.1 (dye order), PLOC.2 (int16 peak
@@ -76,10 +105,9 @@ inline int32_t traceFormat(std::string const& filename) {
 // Character payloads are read ONE BYTE PAST their declared length (abif.h:346 "+ 1"), exactly like the
 // reference: the extra character becomes 'N' (or stays a DNA letter) and is then cut by the common
 // length of calls / qualities / positions.  Repeated numeric tags append, repeated text tags overwrite.
-inline bool readab(std::string const& filename, Trace& tr) {
-  detail::FileBytes f;
-  if (!f.load(filename) || !f.has(0, 34)) return false;
-  if (f.str(0, 4) != "ABIF") {
+inline bool readab(detail::FileBytes const& f, Trace& tr) {
+  if (!f.has(0, 34)) return false;
+  if (!f.starts_with("ABIF")) {
     std::cerr << "File is not in ABIF format!" << std::endl;
     return false;
   }
@@ -119,10 +147,14 @@ inline bool readab(std::string const& filename, Trace& tr) {
       else if (key == "DATA.12") dst = &channel[3];
       if (dst) {
         if (count < 0 || (std::size_t)count * 2 > len) return false;
-        for (int32_t k = 0; k < count; ++k) dst->push_back(f.i16(b + 2 * (std::size_t)k));
+        const std::size_t had = dst->size();
+        dst->resize(had + (std::size_t)count);
+        Trace::TValue* o = dst->data() + had;
+        for (int32_t k = 0; k < count; ++k) o[k] = f.i16(b + 2 * (std::size_t)k);
       }
     } else if (key == "PCON.2") {
       if (count < 0 || (std::size_t)count > len) return false;
+      tr.qual.reserve(tr.qual.size() + (std::size_t)count);
       for (int32_t k = 0; k < count; ++k) tr.qual.push_back(f.u8(b + (std::size_t)k));
     }
   }
@@ -138,20 +170,23 @@ inline bool readab(std::string const& filename, Trace& tr) {
   tr.traceACGT.assign(4, Trace::TMountains());
   for (std::size_t i = 0; i < order.size() && i < 4; ++i) {
     const int k = order[i] == 'A' ? 0 : order[i] == 'C' ? 1 : order[i] == 'G' ? 2 : order[i] == 'T' ? 3 : -1;
-    if (k >= 0) tr.traceACGT[k] = channel[i];
+    if (k >= 0) tr.traceACGT[k] = std::move(channel[i]);  // (each channel is handed over once)
   }
   if (n) return true;
   std::cerr << "File lacks basecalls!" << std::endl;
   return false;
 }
+inline bool readab(std::string const& filename, Trace& tr) {
+  detail::FileBytes f;
+  return f.load(filename) && readab(f, tr);
+}
 
 // readscf, scf.h:38-102.  Only SCF >= 3.0 is accepted (as in the reference); samples are 16-bit,
 // stored per channel as second differences which are integrated twice with a 16-bit carry.
-inline bool readscf(std::string const& filename, Trace& tr) {
+inline bool readscf(detail::FileBytes const& f, Trace& tr) {
   tr.traceACGT.assign(4, Trace::TMountains());
-  detail::FileBytes f;
-  if (!f.load(filename) || !f.has(0, 40)) return false;
-  if (f.str(0, 4) != ".scf") {
+  if (!f.has(0, 40)) return false;
+  if (!f.starts_with(".scf")) {
     std::cerr << "File is not in SCF format!" << std::endl;
     return false;
   }
@@ -185,6 +220,11 @@ inline bool readscf(std::string const& filename, Trace& tr) {
   }
   return true;
 }
+inline bool readscf(std::string const& filename, Trace& tr) {
+  detail::FileBytes f;
+  if (!f.load(filename)) { tr.traceACGT.assign(4, Trace::TMountains()); return false; }
+  return readscf(f, tr);
+}
 
 // traceTxtOut, abif.h:513-533: one line per sample, basecall columns on called samples
 template <class Out, typename std::enable_if<!std::is_same<Out, std::string>::value, int>::type = 0>  // (a stream, not a file name)
@@ -203,6 +243,37 @@ inline void traceTxtOut(Out& out, BaseCalls const& bc, Trace const& tr, uint32_t
     }
     out << (call + 1) << "\t" << bc.primary[call] << "\t" << bc.secondary[call] << "\t" << bc.consensus[call] << "\t"
         << (int32_t)bc.estQual[call] << "\t" << ((call < leftTrim || call >= keep_until) ? "Y" : "N") << std::endl;
+    if (call < bc.bcPos.size() - 1) next = bc.bcPos[++call];
+  }
+}
+
+// the same lines composed in place: a sample's line is at most 5 numbers + 6 short columns, written behind one capacity test
+inline void traceTxtOut(TextBuf& out, BaseCalls const& bc, Trace const& tr, uint32_t leftTrim, uint32_t rightTrim) {
+  const uint32_t keep_until = rightTrim < bc.primary.size() ? (uint32_t)bc.primary.size() - rightTrim : 0;
+  uint32_t call = 0;
+  int32_t next = bc.bcPos[call];
+  out << "pos\tpeakA\tpeakC\tpeakG\tpeakT\tbasenum\tprimary\tsecondary\tconsensus\tqual\ttrim" << std::endl;
+  const int32_t ns = (int32_t)tr.traceACGT[0].size();
+  static const char na[] = "NA\tNA\tNA\tNA\tNA\tNA\n";
+  for (int32_t i = 0; i < ns; ++i) {
+    out.need(160);
+    char* q = TextBuf::raw_int(out.p, i + 1);
+    *q++ = '\t';
+    for (int k = 0; k < 4; ++k) { q = TextBuf::raw_int(q, tr.traceACGT[k][i]); *q++ = '\t'; }
+    if (next != i) {
+      std::memcpy(q, na, sizeof(na) - 1);
+      out.p = q + sizeof(na) - 1;
+      continue;
+    }
+    q = TextBuf::raw_int(q, call + 1);
+    *q++ = '\t'; *q++ = bc.primary[call];
+    *q++ = '\t'; *q++ = bc.secondary[call];
+    *q++ = '\t'; *q++ = bc.consensus[call];
+    *q++ = '\t';
+    q = TextBuf::raw_int(q, (int32_t)bc.estQual[call]);
+    *q++ = '\t'; *q++ = (call < leftTrim || call >= keep_until) ? 'Y' : 'N';
+    *q++ = '\n';
+    out.p = q;
     if (call < bc.bcPos.size() - 1) next = bc.bcPos[++call];
   }
 }

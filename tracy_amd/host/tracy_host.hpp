@@ -142,9 +142,10 @@ inline std::pair<uint32_t, double> findBestTraceSection(BaseCalls const& bc, std
   const uint32_t stretch = (uint32_t)(int32_t)(0.1 * bc.secondary.size());
   uint32_t best_at = 0;
   int32_t best = 99999999;
+  int32_t sum = 0;  // penalty[i .. i + stretch): the reference adds the stretch up at every i; the same integers, kept running
+  for (uint32_t k = 0; k < stretch && k < n; ++k) sum += penalty[k];
   for (uint32_t i = 0; i + stretch < n; ++i) {
-    int32_t sum = 0;
-    for (uint32_t k = 0; k < stretch; ++k) sum += penalty[i + k];
+    if (i) sum += penalty[i + stretch - 1] - penalty[i - 1];
     if (sum < best) {
       best = sum;
       best_at = i + (uint32_t)(int32_t)(stretch / 2);

@@ -144,6 +144,7 @@ def main():
                     help="configs[3]: traces PER GPU of the seed + extend job (1M traces over 8 GPUs = 125 000 each; the job is this x the ranks)")
     ap.add_argument("--seedextend-genome-mb", type=float, default=50.0, help="configs[3]: size of the synthetic genome (GRCh38 chr22 is 50.8 Mb)")
     ap.add_argument("--seedextend-steps", type=int, default=2)
+    ap.add_argument("--cli-workdir", default=None, help="the CLI leg: directory for its input and output files (default: /dev/shm when it has room, else the system's temporary directory)")
     ap.add_argument("--cli-traces", type=int, default=10000, help="the CLI leg: ABIF files per command (`align --batch`, `decompose --batch`); 0 = skip")
     ap.add_argument("--extra-legs", type=int, default=1, help="decompose: also time the strand-certificate and two-lane legs")
     ap.add_argument("--stub", action="store_true", help="launcher self-test on gloo with a step that does no device work (not a measurement)")
@@ -202,7 +203,7 @@ def main():
             if which == "cli":  # the product end to end; rank 0 only (the CLI shards over GPUs itself with -d)
                 if rank != 0 or args.cli_traces <= 0:
                     return None
-                return CliLeg(args.cli_traces, rank, world, dev).run(dist, cpu_sample=320 if args.cpu_sample != 0 else 0)
+                return CliLeg(args.cli_traces, rank, world, dev, workdir=args.cli_workdir).run(dist, cpu_sample=320 if args.cpu_sample != 0 else 0)
             if which == "seedextend":
                 leg = SeedExtendLeg(args.seedextend_traces * world, args.seedextend_genome_mb, 1000, rank, world, dev, dist)
                 res = leg.run(dist, args.seedextend_steps, 1, cpu_sample=64 if args.cpu_sample != 0 else 0)

@@ -667,8 +667,32 @@ class CliLeg:
     def __init__(self, ntraces, rank, world, dev, workdir=None):
         import tempfile
         self.nt, self.rank, self.world, self.dev = ntraces, rank, world, dev
-        self.tmp = workdir or tempfile.mkdtemp(prefix="tracy_cli_bench_")
+        # where the files live: a tmpfs when the box has one with room for a run's ~1 MB of text per trace (a fresh file on a block
+        # device costs its block allocation, ~1 ms per 400 KB file on this image's disk -- the file system's time, not the command's);
+        # --cli-workdir puts them anywhere else
+        if workdir is None:
+            import shutil
+            shm = "/dev/shm"
+            need = 3 * (1 << 20) * ntraces
+            base = shm if os.path.isdir(shm) and os.access(shm, os.W_OK) and shutil.disk_usage(shm).free > need else None
+            self.tmp = tempfile.mkdtemp(prefix="tracy_cli_bench_", dir=base)
+        else:
+            os.makedirs(workdir, exist_ok=True)
+            self.tmp = tempfile.mkdtemp(prefix="tracy_cli_bench_", dir=workdir)
+        self.fs = self.filesystem_of(self.tmp)
         self.cli = os.path.join(ROOT, "tracy_amd", "bin", "tracy_amd_cli")
+
+    @staticmethod
+    def filesystem_of(path):
+        best, kind = "", "unknown"
+        try:
+            for ln in open("/proc/mounts"):
+                f = ln.split()
+                if len(f) >= 3 and path.startswith(f[1]) and len(f[1]) > len(best):
+                    best, kind = f[1], f[2]
+        except OSError:
+            pass
+        return kind
 
     def make_files(self, cmd, n, mf):
         from tracy_amd import hostlib
@@ -740,6 +764,7 @@ class CliLeg:
         from bench import usable_cores
         out = {"metric": "traces/s, `tracy_amd_cli --batch` end to end (ABIF files in, JSON / txt / fa files out)", "unit": "traces/s",
                "n_gpus": 1, "host_threads": usable_cores(), "data": "synthetic ABIF files written by the build's own writer (not timed)",
+               "files_on": "%s (%s)" % (self.fs, os.path.dirname(self.tmp)),
                "config": {"workload": "%d traces of 1000 bases per command: `align` vs a 10 kb FASTA window each (configs[1] through the CLI), "
                                       "`decompose` vs a 3 kb window each (configs[2] through the CLI)" % self.nt}}
         try:
@@ -750,12 +775,20 @@ class CliLeg:
                 rec = {"traces_per_s": round(self.nt / dt, 1), "wall_s": round(dt, 3), "split_s": split, "json_files_written": written,
                        "exit_code": rc, "files_prepared_s": round(prep_s, 1)}
                 if split:
+                    cpu = {k[4:]: round(v, 3) for k, v in split.items() if k.startswith("cpu_")}
+                    split = {k: v for k, v in split.items() if not k.startswith("cpu_")}
+                    rec["split_s"] = split
+                    # seconds inside the stages by what they were spent on: host-thread seconds summed over the threads for the prep /
+                    # writer work, wall seconds of the calling thread for pack / device_call / unpack / variants
+                    rec["thread_seconds_by_phase"] = cpu
                     stages = {k: v for k, v in split.items() if k.endswith("_s") and k != "wall_s"}
                     host = split.get("read_basecall_profile_s", 0.0) + split.get("writers_s", 0.0)
                     rec["host_stage_seconds_over_wall"] = round(host / max(dt, 1e-9), 3)
                     rec["first_bottleneck"] = max(stages, key=lambda k: stages[k])
                     rec["stages_overlap"] = round(sum(stages.values()) / max(split.get("wall_s", dt), 1e-9), 2)
                     rec["peak_rss_mb"] = split.get("peak_rss_mb")
+                    # the command's wall time that is not its stages: loading the HIP runtime, the manifest, tearing the process down
+                    rec["outside_stages_s"] = round(dt - split.get("wall_s", dt), 3)
                     rec["note"] = ("the manifest runs in blocks of 2000 traces through three stages in flight: host threads read / basecall / profile block "
                                    "k + 1 and write the files of block k - 1 while the device works on block k; split_s = the seconds each stage was busy "
                                    "(they overlap: stages_overlap = their sum / wall), peak RSS is bounded by the blocks in flight; device_s = packing a "

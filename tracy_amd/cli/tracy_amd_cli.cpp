@@ -20,6 +20,7 @@
 #include <cstring>
 #include <ctime>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <map>
 #include <memory>
@@ -104,6 +105,30 @@ void for_each_index(uint32_t n, uint32_t threads, Fn fn) {
     th.emplace_back([&]() { for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); });
   for (auto& x : th) x.join();
 }
+const std::chrono::steady_clock::time_point g_process_start = std::chrono::steady_clock::now();
+// TRACY_AMD_CLI_TIMERS: seconds of host-thread time inside the stages, summed over the threads (cpu_*: where a stage's core time goes)
+struct CpuPhases {
+  enum { LOAD, BASECALL, ABIF_TXT, PROFILE, REFERENCE, PACK, DEVICE_CALL, UNPACK, VARIANTS, PAD, SMALL_FILES, JSON, COUNT };
+  std::atomic<uint64_t> ns[COUNT];
+  bool on = getenv("TRACY_AMD_CLI_TIMERS") != nullptr;
+  CpuPhases() { for (auto& x : ns) x = 0; }
+  static const char* name(int i) {
+    static const char* n[COUNT] = {"load", "basecall", "abif_txt", "profile", "reference", "pack", "device_call", "unpack", "variants", "pad", "small_files", "json"};
+    return n[i];
+  }
+};
+inline CpuPhases& cpu_phases() { static CpuPhases p; return p; }
+struct PhaseClock {  // lap(i): the time since the last lap goes to phase i
+  std::chrono::steady_clock::time_point t;
+  const bool on;
+  PhaseClock() : on(cpu_phases().on) { if (on) t = std::chrono::steady_clock::now(); }
+  void lap(int phase) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    cpu_phases().ns[phase] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t).count();
+    t = t1;
+  }
+};
 // TRACY_AMD_CLI_TIMERS=1: one line on stderr with the wall time of the host and device stages of a --batch run
 struct StageTimes {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), start = t0;
@@ -127,9 +152,20 @@ struct StageTimes {
     getrusage(RUSAGE_SELF, &ru);
     std::cerr << "timers: traces " << traces << " host_threads " << threads;
     for (auto const& e : v) std::cerr << " " << e.first << " " << e.second;
+    for (int i = 0; i < CpuPhases::COUNT; ++i)
+      if (cpu_phases().ns[i]) std::cerr << " cpu_" << CpuPhases::name(i) << "_s " << 1e-9 * (double)cpu_phases().ns[i];
+    std::cerr << " before_stages_s " << std::chrono::duration<double>(start - g_process_start).count();
     std::cerr << " wall_s " << std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() << " peak_rss_mb " << ru.ru_maxrss / 1024.0 << std::endl;
   }
 };
+// the end of a --batch command: every file is written and closed; what is left is handing back a few GB of host and device memory
+// and unloading the HIP runtime piece by piece (0.1-0.2 s) -- the operating system does that at once for a process that just ends
+[[noreturn]] inline void end_process(int rc) {
+  std::cout.flush();
+  std::cerr.flush();
+  std::fflush(nullptr);
+  _exit(rc);
+}
 struct Stopwatch {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   double seconds() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
@@ -366,12 +402,15 @@ const GenomeIndex* genome_index(SageConfig const& c, std::string const& path) {
 
 // host stages up to the device batch (sage.h:141-207, 222-231, 261-277); returns the CLI exit code
 int prepare(SageConfig const& c, Job& j, bool decompose = false) {
+  PhaseClock pc;
   if (!load_trace(j.trace_path, j.tr)) return -1;
   if (j.tr.basecallpos.empty()) {
     std::cerr << "Trace file lacks basecalls!" << std::endl;
     return -1;
   }
+  pc.lap(CpuPhases::LOAD);
   basecall(j.tr, j.bc, c.pratio);
+  pc.lap(CpuPhases::BASECALL);
   j.trimLeft = c.trimLeft;
   j.trimRight = c.trimRight;
   if (c.trimStringency >= 1) {
@@ -385,7 +424,10 @@ int prepare(SageConfig const& c, Job& j, bool decompose = false) {
     return -1;
   }
   traceTxtOut(j.outprefix + ".abif", j.bc, j.tr, j.trimLeft, j.trimRight);
+  pc.lap(CpuPhases::ABIF_TXT);
   createProfile(j.tr, j.bc, j.full);
+  pc.lap(CpuPhases::PROFILE);
+  struct RefLap { PhaseClock& pc; ~RefLap() { pc.lap(CpuPhases::REFERENCE); } } ref_lap{pc};
   j.rs.filetype = genomeType(j.ref_path);
   if (j.rs.filetype == -1) {
     std::cerr << "Unknown reference file format!" << std::endl;
@@ -489,6 +531,7 @@ bool alignment_rows(tracyhip_ctx* ctx, tracyhip_seqset const& s1, tracyhip_seqse
 
 // FASTA references: sage.h:233-260 + :311 for every job sharing one (trimLeft, trimRight)
 bool align_fasta_group(Device& dev, tracyhip_params const& prm, std::vector<Job*> const& jobs, uint32_t nthreads) {
+  PhaseClock pc;  // (on the calling thread: pack / device_call / unpack are wall seconds of the device stage)
   tracyhip_ctx* ctx = dev.ctx;
   const uint32_t nt = (uint32_t)jobs.size();
   // the batch as two packed payloads: offsets first, then every trace copied to its place by the host threads (a manifest of
@@ -532,7 +575,10 @@ bool align_fasta_group(Device& dev, tracyhip_params const& prm, std::vector<Job*
   res.score_fwd = sf.data(); res.score_rev = sr.data(); res.forward = fwd.data();
   res.slice_begin = sb.data(); res.slice_len = sl.data(); res.ref_pos = rp.data();
   res.score_final = sfin.data(); res.ops = ops.data(); res.ops_offset = ooff.data(); res.ops_len = olen.data();
+  pc.lap(CpuPhases::PACK);
   if (dev.align_traces(&job, &prm, &res) != TRACYHIP_OK) return gpu_fail("align");
+  pc.lap(CpuPhases::DEVICE_CALL);
+  struct UnpackLap { PhaseClock& pc; ~UnpackLap() { pc.lap(CpuPhases::UNPACK); } } unpack_lap{pc};
   // the reference slices the final alignment ran against (trimReferenceSlice, fmindex.h:429-463)
   std::vector<uint64_t> soff(nt);
   uint64_t stot = 0;
@@ -616,15 +662,19 @@ bool align_wildtype_group(tracyhip_ctx* ctx, tracyhip_params const& prm, std::ve
 
 // sage.h:313-345
 void write_outputs(SageConfig const& c, Job const& j) {
+  PhaseClock pc;
   PaddedTrace padded;
   alignmentTracePadding(j.rows.row0, j.tr, j.bc, padded);
+  pc.lap(CpuPhases::PAD);
   {
     TextBuf f(2 * j.rows.row0.size() + 512);
     alignFastaOut(f, stem(j.trace_path), j.rs, j.rows);
     f.to_file(j.outprefix + ".align.fa");
   }
   plotAlignment(j.outprefix + ".txt", j.rows, j.rs, j.score, c.linelimit);
+  pc.lap(CpuPhases::SMALL_FILES);
   traceAlignJsonOut(j.outprefix + ".json", padded, j.rs, j.rows);
+  pc.lap(CpuPhases::JSON);
 }
 
 // one job from the command line, or one per manifest line; returns the CLI exit code
@@ -706,19 +756,24 @@ int align_main(int argc, char** argv) {
   };
   Device dev;
   bool dev_open = false, said = false;
+  // the context is created (HIP start-up, ~0.1 s) while the first block is read
+  std::future<int> dev_ready = std::async(std::launch::async, [&]() {
+    Stopwatch sw;
+    const int rc = dev.open(c.devices, 2);  // two chunks of a block in flight per GPU (small batches run on one lane)
+    times.add("gpu_init_s", sw.seconds());
+    return rc;
+  });
   tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};  // AlignConfig<true,false>, sage.h:165
   auto device = [&](uint32_t lo, uint32_t hi) -> bool {
     if (!batch && rcs[lo] != 0) { fatal = rcs[lo]; return false; }
     if (!said) std::cout << stamp() << "Find reference match" << std::endl;
     if (!dev_open) {
-      Stopwatch sw;
-      if (dev.open(c.devices, 2) != 0) {  // two chunks of a block in flight per GPU (small batches run on one lane)
+      if (dev_ready.get() != 0) {
         gpu_fail("no usable GPU");
         fatal = -1;
         return false;
       }
       dev_open = true;
-      times.add("gpu_init_s", sw.seconds());
     }
     Stopwatch sw;
     std::map<std::pair<uint32_t, uint32_t>, std::vector<Job*>> fasta_groups, seeded_groups;
@@ -757,6 +812,7 @@ int align_main(int argc, char** argv) {
   if (!run_blocks((uint32_t)jobs.size(), batch ? block_size() : (uint32_t)jobs.size(), prep, device, write)) return fatal ? fatal : -1;
   times.report((uint32_t)jobs.size(), nthreads);
   std::cout << stamp() << "Done." << std::endl;
+  if (batch) end_process(failed ? 2 : 0);
   return failed ? 2 : 0;
 }
 
@@ -869,6 +925,7 @@ bool orient_wildtype(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<
 
 // indigo.h:190-388 for every job sharing one (trimLeft, trimRight): the whole chain runs on the device
 bool decompose_group(Device& dev, SageConfig const& c, tracyhip_params const& prm, std::vector<Job*> const& jobs, uint32_t nthreads) {
+  PhaseClock pc;  // (on the calling thread: pack / device_call / unpack are wall seconds of the device stage)
   tracyhip_ctx* ctx = dev.ctx;
   const uint32_t nt = (uint32_t)jobs.size();
   const bool wildtype = jobs[0]->rs.filetype == 2;  // groups never mix reference kinds
@@ -971,7 +1028,10 @@ bool decompose_group(Device& dev, SageConfig const& c, tracyhip_params const& pr
     sc[k].resize(nt); olen[k].resize(nt); ops[k].resize(ocap[k] ? ocap[k] : 1);
     res.score[k] = sc[k].data(); res.ops[k] = ops[k].data(); res.ops_offset[k] = ooff[k].data(); res.ops_len[k] = olen[k].data();
   }
+  pc.lap(CpuPhases::PACK);
   if (dev.decompose_traces(&job, &prm, &res) != TRACYHIP_OK) return gpu_fail("decompose");
+  pc.lap(CpuPhases::DEVICE_CALL);
+  struct UnpackLap { PhaseClock& pc; ~UnpackLap() { pc.lap(CpuPhases::UNPACK); } } unpack_lap{pc};
 
   std::vector<std::string> a1[3], a2[3];
   for (int k = 0; k < 3; ++k) { a1[k].resize(nt); a2[k].resize(nt); }
@@ -1060,6 +1120,7 @@ bool call_variants(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<Jo
 
 // indigo.h:340-343, 359-387, 389-394, 436-442
 void write_decompose_outputs(SageConfig const& c, Job& j) {
+  PhaseClock pc;
   AlleleReport& r = j.rep;
   {
     TextBuf f(4096);
@@ -1079,6 +1140,7 @@ void write_decompose_outputs(SageConfig const& c, Job& j) {
     plotAlignment(f, *al[k], *rs[k], k + 1, score[k], r.a1a2, c.linelimit);
     f.to_file(j.outprefix + ".align" + std::to_string(k + 1));
   }
+  pc.lap(CpuPhases::SMALL_FILES);
   // the report shows the decomposed basecalls
   BaseCalls bc = j.bc;
   bc.primary = j.primary;
@@ -1102,9 +1164,11 @@ void write_decompose_outputs(SageConfig const& c, Job& j) {
     vcfTextOutput(f, rc, bc, r.var, j.rs, j.rs.filetype == 0 ? &contigs : nullptr);
     f.to_file(j.outprefix + ".vcf");
   }
+  pc.lap(CpuPhases::PAD);
   TextBuf f(1 << 20);
   traceAlleleAlignJsonOut(f, rc, bc, j.tr, r);
   f.to_file(j.outprefix + ".json");
+  pc.lap(CpuPhases::JSON);
 }
 
 int decompose_main(int argc, char** argv) {
@@ -1155,6 +1219,13 @@ int decompose_main(int argc, char** argv) {
   };
   Device dev;
   bool dev_open = false;
+  // the context is created (HIP start-up, ~0.1 s) while the first block is read
+  std::future<int> dev_ready = std::async(std::launch::async, [&]() {
+    Stopwatch sw;
+    const int rc = dev.open(c.devices, 2);  // two chunks of a block in flight per GPU (small batches run on one lane)
+    times.add("gpu_init_s", sw.seconds());
+    return rc;
+  });
   uint32_t blocks_done = 0;
   tracyhip_params prm{c.match, c.mismatch, c.gapopen, c.gapext, 1, 0};
   // (the progress lines of the reference are said once per command, with its first block)
@@ -1164,13 +1235,11 @@ int decompose_main(int argc, char** argv) {
     say("Find Reference Match");
     fatal = -1;
     if (!dev_open) {
-      Stopwatch sw;
-      if (dev.open(c.devices, 2) != 0) {  // two chunks of a block in flight per GPU (small batches run on one lane)
+      if (dev_ready.get() != 0) {
         gpu_fail("no usable GPU");
         return false;
       }
       dev_open = true;
-      times.add("gpu_init_s", sw.seconds());
     }
     Stopwatch sw;
     std::map<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>, std::vector<Job*>> groups;  // (reference kind, trims)
@@ -1208,7 +1277,9 @@ int decompose_main(int argc, char** argv) {
     say("Allele-specific alignments");
     if (c.callvariants) {
       say("Variant Calling");
+      PhaseClock pv;
       if (!call_variants(dev.ctx, prm, good, nthreads)) return false;
+      pv.lap(CpuPhases::VARIANTS);
     }
     fatal = 0;
     ++blocks_done;
@@ -1227,6 +1298,7 @@ int decompose_main(int argc, char** argv) {
   if (!run_blocks((uint32_t)jobs.size(), batch ? block_size() : (uint32_t)jobs.size(), prep, device, write)) return fatal ? fatal : -1;
   times.report((uint32_t)jobs.size(), nthreads);
   std::cout << stamp() << "Done." << std::endl;
+  if (batch) end_process(failed ? 2 : 0);
   return failed ? 2 : 0;
 }
 

@@ -191,10 +191,10 @@ def run_band16(pairs, score, hfree, K, kind=0, strings=True):
     u32 = lambda v: np.asarray(v, dtype=np.uint32)
     i32 = lambda v: np.asarray(v, dtype=np.int32)
     A = dict(a1_off=u64(a1_off), a1_stride=u32(a1_stride), m=u32(ms), a2_off=u64(a2_off), n=u32(ns), flags=u32(flags), dmin=i32(dmins), dmax=i32(dmaxs))
-    scores = np.zeros(4, np.int32)
-    ends = np.zeros(8, np.uint32)
-    ops = np.zeros(4 * cap, np.uint8)
-    ops_len = np.zeros(4, np.uint32)
+    scores = np.zeros(16, np.int32)  # (K = 44, the quad form: up to sixteen pairs)
+    ends = np.zeros(32, np.uint32)
+    ops = np.zeros(16 * cap, np.uint8)
+    ops_len = np.zeros(16, np.uint32)
     err = C.c_int32(0)
     ptr = lambda x: C.c_void_p(x.ctypes.data)
     rc = lib().emu_band16(int(K), int(kind), 1 if strings else 0, npairs, ptr(buf1), ptr(A["a1_off"]), ptr(A["a1_stride"]), ptr(A["m"]), ptr(buf2),

@@ -89,6 +89,14 @@ struct HostWave {
     sh->bar.arrive_and_wait();
     return r;
   }
+  int32_t rot(int32_t x, std::integral_constant<int, 16>) { return rot16(x); }
+  int32_t rot(int32_t x, std::integral_constant<int, 4>) {  // the same inside a quad (DPP quad_perm:[3,0,1,2])
+    sh->xchg[lane_] = x;
+    sh->bar.arrive_and_wait();
+    const int32_t r = sh->xchg[(lane_ & ~3u) | ((lane_ - 1u) & 3u)];
+    sh->bar.arrive_and_wait();
+    return r;
+  }
   uint64_t ballot(bool p) {
     sh->xchg[lane_] = p ? 1 : 0;
     sh->bar.arrive_and_wait();
@@ -447,11 +455,13 @@ int emu_band16(int K, int kind, int strings, uint32_t npairs, const void* a1, co
                const uint32_t* m, const uint8_t* a2, const uint64_t* a2_off, const uint32_t* n, const uint32_t* flags, const int32_t* dmin,
                const int32_t* dmax, int32_t match, int32_t mismatch, int32_t go, int32_t ge, int32_t hfree, int32_t* scores, uint32_t* ends,
                uint8_t* ops, uint64_t ops_cap, uint32_t* ops_len, int32_t* err_out) {
-  if (npairs == 0 || npairs > 4) return -1;
+  const bool quads = K == 44;  // strip height 4 swept by four lanes per pair (band16_body P = 4): up to sixteen pairs
+  if (quads) K = 4;
+  if (npairs == 0 || npairs > (quads ? 16u : 4u)) return -1;
   const int shift = kTagShift;  // one table for both kinds, as the library builds it
   std::vector<PairDesc> d(npairs);
   std::vector<int16_t> qp;
-  std::vector<uint8_t> codes;
+  std::vector<uint8_t> codes(128, 5);  // (the library's code buffers carry kCodePad = 128 spare bytes on both sides)
   std::vector<uint64_t> ops_off(npairs);
   uint64_t bits_total = 0;
   uint32_t nmax = 0;
@@ -468,20 +478,28 @@ int emu_band16(int K, int kind, int strings, uint32_t npairs, const void* a1, co
       b16_table_row(a1, strings != 0, a1_off[i], a1_stride[i], r, match, mismatch, q);
       for (uint32_t b = 0; b < kB16Codes; ++b) qp[p.a1_off + (size_t)b * stride + r] = (int16_t)((uint32_t)q[b] << shift);
     }
-    p.a2_off = codes.size();
+    p.a2_off = codes.size() - 128;
     for (uint32_t c = 0; c < n[i]; ++c) codes.push_back((uint8_t)(strings ? cq_code(a2[a2_off[i] + c]) : dp_code(a2[a2_off[i] + c])));
     p.bits_off = bits_total;
     bits_total += (b16_words(m[i], n[i], K, dmin[i], dmax[i]) * b16_word_bytes(K) + 7u) & ~7ull;
     ops_off[i] = (uint64_t)i * ops_cap;
     nmax = std::max(nmax, n[i]);
   }
+  codes.insert(codes.end(), 128, 5);
   std::vector<uint8_t> bits(bits_total + 64, 0xEE);
   int32_t errw[kErrWords] = {0};
   Band16Args a{};
-  a.pairs = d.data(); a.npairs = npairs; a.qp = qp.data(); a.codes = codes.data(); a.bits = bits.data(); a.scores = scores; a.ends = ends;
+  a.pairs = d.data(); a.npairs = npairs; a.qp = qp.data(); a.codes = codes.data() + 128; a.bits = bits.data(); a.scores = scores; a.ends = ends;
   a.err = errw; a.go = go; a.ge = ge; a.hfree = hfree; a.code_cap = (nmax + 3u) & ~3u; a.ops = ops; a.ops_off = ops_off.data(); a.ops_len = ops_len;
   WaveShared sh;
-  sh.lds.assign(4u * a.code_cap + b16_table_bytes(K) + 64, 0);
+  sh.lds.assign((quads ? 16u * b16_packed_row(a.code_cap) : 4u * a.code_cap) + b16_table_bytes(K) + 64, 0);
+  if (quads) {
+    for (uint32_t i = 0; i < npairs; ++i)
+      if (!b16_narrow_ok(dmin[i], dmax[i])) return -1;
+    sh.run([&](uint32_t l) { HostWave w{l, &sh}; if (kind == 0) band16_body<HostWave, 4, 0, false, 4>(w, a, 0); else band16_body<HostWave, 4, 1, false, 4>(w, a, 0); });
+    if (err_out) *err_out = errw[0];
+    return 0;
+  }
 #define EMU_B16(KK)                                                                                                     \
   case KK:                                                                                                              \
     sh.run([&](uint32_t l) { HostWave w{l, &sh}; if (kind == 0) band16_body<HostWave, KK, 0>(w, a, 0); else band16_body<HostWave, KK, 1>(w, a, 0); }); \

@@ -177,3 +177,47 @@ def test_band16_trailing_run_longer_than_the_lanes_period():
                 assert (got[0][0], got[0][1]) == (ws, wb), (K, tail, g, m)
                 got, err = emu.run_band16([(a, b, d1 - g - 1, d1 + g + 1, False)], SC, 1, K, 1, True)
                 assert (got[0][0], got[0][2]) == (ws, (l2, ce)), (K, tail, g, m, "origin")
+
+
+def test_band16_quad_form_equals_the_row_form():
+    """narrow bands (windows of at most three blocks of strip height 4: at most 12 diagonals) swept four lanes to a pair, sixteen pairs
+    to a wave (band16_body P = 4): scores, traceback strings and the origin-tracking sweep's two ends are those of the sixteen-lane
+    form on the same band -- and, where the band is certified, the whole matrix's (gotoh.h:71-175)"""
+    rng = random.Random(44)
+    compared = certified = 0
+    for it in range(40):
+        hfree = 1 if it % 4 else 0
+        kind = it % 2
+        pairs, wants = [], []
+        for q in range(rng.randint(1, 16)):
+            m = rng.randint(1, 90 if it % 3 else 12)
+            a = bytes(rng.choice(b"ACGTN") if rng.random() < 0.03 else rng.choice(b"ACGT") for _ in range(m))
+            b = mutate(a, rng.choice([0.0, 0.0, 0.02]), rng)
+            if hfree and rng.random() < 0.5:
+                b = b + bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 30)))  # columns right of the band: the last strip runs on along row m
+            n = len(b)
+            W = rng.randint(0, 5)
+            d1 = n - m if not hfree else rng.choice([0, min(n - m, 2)])
+            dmin, dmax = min(0, d1) - W, max(0, d1) + W
+            if dmax - dmin + 1 > 12:
+                continue
+            rc = rng.random() < 0.3
+            view = b[::-1].translate(COMP) if rc else b
+            pairs.append((a, b, dmin, dmax, rc))
+            wants.append(orc.gotoh_str(a, view, hfree, 0, SC) + (W, m, n))
+        if not pairs:
+            continue
+        got, err = emu.run_band16(pairs, SC, hfree, 44, kind, True)
+        ref = []
+        for i in range(0, len(pairs), 4):
+            r, e16 = emu.run_band16(pairs[i:i + 4], SC, hfree, 4, kind, True)
+            ref += r
+            assert (e16 != 0) == (err != 0) or len(pairs) > 4
+        for (g, r, (ws, wb, W, m, n)) in zip(got, ref, wants):
+            compared += 1
+            assert g == r, (it, kind, hfree, m, n, W)
+            bound = SC[0] * m + SC[3] * (W + 1) * (1 if hfree else 2) + (0 if hfree else SC[2])
+            if kind == 0 and g[1] is not None and len(g[1]) and g[0] > bound and not hfree:
+                certified += 1
+                assert (g[0], g[1]) == (ws, wb)
+    assert compared > 150 and certified > 10, (compared, certified)

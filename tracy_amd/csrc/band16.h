@@ -83,6 +83,10 @@ TR_HD uint32_t b16_last_window(uint32_t m, uint32_t n, int K, int32_t dmin, int3
 TR_HD uint64_t b16_words(uint32_t m, uint32_t n, int K, int32_t dmin, int32_t dmax) {
   return (uint64_t)(b16_strips(m, K) - 1u) * b16_window(K, dmin, dmax) + b16_last_window(m, n, K, dmin, dmax);
 }
+// the quad form (band16_body P = 4, strip height 4): the window fits the three blocks a lane has before its next strip is due
+TR_HD bool b16_narrow_ok(int32_t dmin, int32_t dmax) { return dmax >= dmin && b16_window(4, dmin, dmax) <= 3u * 5u; }
+TR_HD constexpr uint32_t b16_packed_row(uint32_t code_cap) { return ((code_cap + 1u) / 2u + 3u) & ~3u; }  // the quad form keeps two codes to a byte
+TR_HD constexpr uint32_t b16_quad_lds(uint32_t code_cap) { return 16u * b16_packed_row(code_cap) + b16_table_bytes(4); }  // LDS of a quad-form workgroup
 // smallest strip height whose lanes are done with a strip before the next one is due (K + width <= 15 (K + 1)); 0: the band is too wide
 TR_HD int b16_pick_k(int32_t dmin, int32_t dmax) {
   if (dmax < dmin) return 0;
@@ -123,9 +127,10 @@ TR_HD void b16_table_row(const void* a1, bool strings, uint64_t a1_off, uint32_t
   }
 }
 
-TR_HD uint32_t ctz16(uint32_t x) {  // 16 when no bit is set
+template <int P = 16>
+TR_HD uint32_t ctz16(uint32_t x) {  // P when none of the low P bits is set
   uint32_t i = 0;
-  x |= 0x10000u;
+  x |= 1u << P;
   while (!((x >> i) & 1u)) ++i;
   return i;
 }
@@ -151,61 +156,91 @@ struct Band16Fetch {
   }
 };
 
-// The traceback state machine of gotoh.h:143-167 walked by the 16 lanes of each pair (walk_core of dp_kernels.h, a row of 16
-// candidates per round; the four groups of the wave run side by side).  A cell outside the stored band ends the walk with
+// The traceback state machine of gotoh.h:143-167 walked by the P lanes of each pair (walk_core of dp_kernels.h, a row of P
+// candidates per round; the 64 / P groups of the wave run side by side).  A cell outside the stored band ends the walk with
 // an error flag: the caller's certificate has failed for that pair and the pair is repeated on the whole matrix.
-template <class W, class Fetch>
+// C: cells per lane and round.  A round costs a memory round trip whatever it looks at; the quad form's four lanes take four cells of
+// the run each (four loads in flight), so that a round advances by up to sixteen cells there as well.
+template <class W, class Fetch, int P = 16, int C = 1>
 TR_HD void walk16(W& w, const Fetch& fetch, bool have, uint32_t m, uint32_t n, uint8_t* out, uint32_t* ops_len, int32_t* err,
                    uint32_t pre_h = 0, uint32_t post_h = 0) {
   // pre_h / post_h: the pair is a sub-window of a wider reference whose columns right / left of it are free end-gap columns of the
   // alignment ('h' before the first / after the last op of the sub-window's string: PairDesc::lastrow_off)
-  const uint32_t lane = w.lane() & 15u, gsh = (w.lane() >> 4) * 16u;
+  constexpr uint32_t PM = (1u << P) - 1u;
+  const uint32_t lane = w.lane() % (uint32_t)P, gsh = (w.lane() / (uint32_t)P) * (uint32_t)P;
   uint32_t row = m, col = n, k = pre_h;
   int state = 0;
   const uint32_t limit = m + n + pre_h;
   bool lost = false;
   if (have)
-    for (uint32_t i = lane; i < pre_h; i += 16) out[i] = 'h';
+    for (uint32_t i = lane; i < pre_h; i += P) out[i] = 'h';
   for (;;) {
     const bool running = have && !lost && row > 0 && col > 0 && k <= limit;
     if (w.ballot(running) == 0) break;
-    const uint32_t r = (state == 1) ? row : row - lane;
-    const uint32_t c = (state == 2) ? col : col - lane;
-    const bool inside = running && ((state == 1) ? (lane < col) : (state == 2) ? (lane < row) : (lane < row && lane < col));
-    const bool inband = inside && fetch.inside(r, c);
-    TraceBits b = {false, false, false, false};
-    if (inband) b = decode_nibble(fetch(r, c));
-    const bool hit = inband && (state == 0 ? (b.bit3 || b.bit4) : state == 1 ? b.bit1 : b.bit2);
-    const uint32_t first_hit = ctz16((uint32_t)(w.ballot(hit) >> gsh) & 0xffffu);
-    const uint32_t first_out = ctz16((uint32_t)(w.ballot(!inband) >> gsh) & 0xffffu);
-    const uint32_t to_state = w.bcast((uint32_t)(b.bit3 ? 1 : 2), gsh + (first_hit & 15u));
+    // this lane's C cells of the run: offsets lane C .. lane C + C - 1 from the cell the walk stands on
+    uint32_t my_hit = C, my_out = C, my_state = 2;
+#pragma unroll
+    for (int q = C - 1; q >= 0; --q) {
+      const uint32_t off = lane * (uint32_t)C + (uint32_t)q;
+      const uint32_t r = (state == 1) ? row : row - off;
+      const uint32_t c = (state == 2) ? col : col - off;
+      const bool inside = running && ((state == 1) ? (off < col) : (state == 2) ? (off < row) : (off < row && off < col));
+      const bool inband = inside && fetch.inside(r, c);
+      TraceBits b = {false, false, false, false};
+      if (inband) b = decode_nibble(fetch(r, c));
+      const bool hit = inband && (state == 0 ? (b.bit3 || b.bit4) : state == 1 ? b.bit1 : b.bit2);
+      if (hit) { my_hit = (uint32_t)q; my_state = b.bit3 ? 1u : 2u; }
+      if (!inband) my_out = (uint32_t)q;
+    }
+    const uint32_t lane_hit = ctz16<P>((uint32_t)(w.ballot(my_hit < (uint32_t)C) >> gsh) & PM);   // first lane with a hit / a cell outside
+    const uint32_t lane_out = ctz16<P>((uint32_t)(w.ballot(my_out < (uint32_t)C) >> gsh) & PM);
+    const uint32_t src_hit = gsh + (lane_hit & ((uint32_t)P - 1u)), src_out = gsh + (lane_out & ((uint32_t)P - 1u));
+    uint32_t first_hit, first_out, to_state;
+    if (C == 1) {
+      first_hit = lane_hit;
+      first_out = lane_out;
+      to_state = w.bcast(my_state, src_hit);
+    } else {
+      const uint32_t packed = w.bcast(my_hit | (my_state << 8), src_hit);
+      first_hit = lane_hit < (uint32_t)P ? lane_hit * (uint32_t)C + (packed & 0xffu) : (uint32_t)(P * C);
+      to_state = packed >> 8;
+      const uint32_t o = w.bcast(my_out, src_out);
+      first_out = lane_out < (uint32_t)P ? lane_out * (uint32_t)C + o : (uint32_t)(P * C);
+    }
     if (!running) continue;
     if (first_out == 0) { lost = true; continue; }  // the cell the walk stands on is not in the band
+    uint32_t x;
+    char op;
     if (state == 0) {
-      const uint32_t x = first_hit < first_out ? first_hit : first_out;
-      if (lane < x) out[k + lane] = 's';
-      k += x; row -= x; col -= x;
+      x = first_hit < first_out ? first_hit : first_out;
+      op = 's';
+    } else {
+      x = first_hit < first_out ? first_hit + 1 : first_out;
+      op = state == 1 ? 'h' : 'v';
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < (uint32_t)C; ++q)
+      if (lane * (uint32_t)C + q < x) out[k + lane * (uint32_t)C + q] = (uint8_t)op;
+    k += x;
+    if (state == 0) {
+      row -= x; col -= x;
       if (first_hit < first_out) state = (int)to_state;
     } else {
-      const bool found = first_hit < first_out;
-      const uint32_t x = found ? first_hit + 1 : first_out;
-      if (lane < x) out[k + lane] = state == 1 ? 'h' : 'v';
-      k += x;
       if (state == 1) col -= x; else row -= x;
-      if (found) state = 0;
+      if (first_hit < first_out) state = 0;
     }
   }
   bool ok = have && !lost;
   if (ok) {  // first row / first column (gotoh.h:112-123)
     if (row == 0) {
       if (state == 2 && col > 0) ok = false;
-      else { for (uint32_t i = lane; i < col; i += 16) out[k + i] = 'h'; k += col; col = 0; }
+      else { for (uint32_t i = lane; i < col; i += P) out[k + i] = 'h'; k += col; col = 0; }
     } else if (col == 0) {
       if (state == 1) ok = false;
-      else { for (uint32_t i = lane; i < row; i += 16) out[k + i] = 'v'; k += row; row = 0; }
+      else { for (uint32_t i = lane; i < row; i += P) out[k + i] = 'v'; k += row; row = 0; }
     }
     if (row > 0 || col > 0) ok = false;
-    if (ok) { for (uint32_t i = lane; i < post_h; i += 16) out[k + i] = 'h'; k += post_h; }
+    if (ok) { for (uint32_t i = lane; i < post_h; i += P) out[k + i] = 'h'; k += post_h; }
   }
   if (have && lane == 0) {
     if (!ok) flag_error(err, 2);
@@ -213,19 +248,26 @@ TR_HD void walk16(W& w, const Fetch& fetch, bool have, uint32_t m, uint32_t n, u
   }
 }
 
-template <class W, int K, int KIND, bool CONT = false>
+// P: lanes per pair.  Sixteen (a DPP row) is the general form; four (a quad: 16 pairs per wave, the hand-over a quad rotate) sweeps
+// the narrow bands -- windows of at most 3 (K + 1) steps, b16_narrow_ok -- for which twelve of sixteen lanes would idle: a pair costs
+// its strips x (K + 1) steps of a quarter of the lanes instead.
+template <class W, int K, int KIND, bool CONT = false, int P = 16>
 TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   static_assert(K == 4 || K == 8 || K == 12, "strip heights of the band kernels");
+  static_assert(P == 16 || P == 4, "a DPP row or a quad per pair");
   static_assert(!CONT || KIND == 1, "only the score / ends sweep continues from a stored row");
+  static_assert(!CONT || P == 16, "the sweep below a stored row stages it for four pairs");
   static_assert(b16_max_window(K) + 2u <= kB16RowCap, "row staging");
+  constexpr uint32_t NPW = 64u / (uint32_t)P;  // pairs per wave
+  using Lanes = std::integral_constant<int, P>;
   constexpr int SH = KIND == 0 ? kTagShift : kOriginShift;
   constexpr int TS = KIND == 0 ? 0 : kOriginBits;
   constexpr uint32_t KP = (uint32_t)K + 1u;  // steps of a block: the stagger between two strips
   constexpr uint32_t WB = b16_word_bytes(K);
-  const uint32_t L = w.lane(), g = L >> 4, j = L & 15u;
-  const uint32_t pair_idx = wave_idx * 4u + g;
+  const uint32_t L = w.lane(), g = L / (uint32_t)P, j = L % (uint32_t)P;
+  const uint32_t pair_idx = wave_idx * NPW + g;
   const uint32_t npairs = a.count ? *a.count : a.npairs;
-  if (wave_idx * 4u >= npairs) return;  // (wave-uniform)
+  if (wave_idx * NPW >= npairs) return;  // (wave-uniform)
   bool have = pair_idx < npairs;
   PairDesc d{};
   if (have) d = a.pairs[a.index ? a.index[pair_idx] : pair_idx];
@@ -251,19 +293,30 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
     return (int32_t)((uint32_t)edge_value(hfree, go, ge, c) << SH) + ((KIND == 1 && !CONT) ? c : 0);
   };
 
-  // ---- LDS: the reference codes of the four pairs in view order (column c at byte c - 1), then the lanes' tables ----
-  uint8_t* lcodes = reinterpret_cast<uint8_t*>(w.lds()) + g * a.code_cap;
-  int16_t* tab = reinterpret_cast<int16_t*>(w.lds() + 4u * a.code_cap) + L;
+  // ---- LDS: the reference codes of the wave's pairs in view order (column c at byte c - 1), then the lanes' tables ----
+  // (the quad form stages sixteen references: two codes to a byte, or the code rows alone would leave room for seven workgroups on a CU)
+  constexpr bool PACKED = P == 4;
+  const uint32_t code_row = PACKED ? b16_packed_row(a.code_cap) : a.code_cap;  // LDS bytes per pair
+  uint8_t* lcodes = reinterpret_cast<uint8_t*>(w.lds()) + g * code_row;
+  int16_t* tab = reinterpret_cast<int16_t*>(w.lds() + NPW * code_row) + L;
   if (have) {
     const uint8_t* src = a.codes + d.a2_off;
-    for (uint32_t i = j; i < n; i += 16) lcodes[i] = src[rcflag ? n - 1u - i : i];
+    if (!PACKED) {
+      for (uint32_t i = j; i < n; i += P) lcodes[i] = src[rcflag ? n - 1u - i : i];
+    } else {
+      for (uint32_t i = j; 2u * i < n; i += P) {
+        const uint32_t c0 = 2u * i, c1 = c0 + 1u < n ? c0 + 1u : c0;
+        const uint32_t lo = src[rcflag ? n - 1u - c0 : c0], hi = src[rcflag ? n - 1u - c1 : c1];
+        lcodes[i] = (uint8_t)(lo | (hi << 4));
+      }
+    }
   }
   // CONT: {H, F} of row R for the columns strip 0 sweeps and the one before them, in the sweep's own units
-  int32_t* lrow = reinterpret_cast<int32_t*>(w.lds() + 4u * a.code_cap + b16_table_bytes(K)) + g * (2u * kB16RowCap);
+  int32_t* lrow = reinterpret_cast<int32_t*>(w.lds() + NPW * code_row + b16_table_bytes(K)) + g * (2u * kB16RowCap);
   const int32_t crow0 = dmin;  // column of lrow[0]: b16_first_col(0) - 1
   if (CONT && have) {
     const uint32_t* src = a.row + d.lastrow_off;
-    for (uint32_t i = j; i < kB16RowCap; i += 16) {
+    for (uint32_t i = j; i < kB16RowCap; i += P) {
       const int32_t cc = crow0 + (int32_t)i;
       int32_t hh = neg, ff = neg;
       if (cc == 0) hh = edge(0);
@@ -279,15 +332,19 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   w.sync();
   // code of column cm1 + 1; lanes off the reference (cm1 wraps below column 1) read its last column and discard the result
   const uint32_t nclamp = n ? n - 1u : 0u;
-  auto code_at = [&](uint32_t cm1) -> uint32_t { return lcodes[cm1 < nclamp ? cm1 : nclamp]; };
+  auto code_at = [&](uint32_t cm1) -> uint32_t {
+    const uint32_t i = cm1 < nclamp ? cm1 : nclamp;
+    if (!PACKED) return lcodes[i];
+    return ((uint32_t)lcodes[i >> 1] >> ((i & 1u) << 2)) & 15u;
+  };
 
   // ---- wave-uniform block counts ----
   uint32_t B_end = 0, b_last = ~0u;
   {
     const uint32_t mine = have ? (NS - 1u) + NB_last : 0u;
     const uint32_t lastbeg = have ? NS - 1u : ~0u;
-    for (uint32_t q = 0; q < 4; ++q) {
-      const uint32_t x = w.bcast(mine, q * 16u), y = w.bcast(lastbeg, q * 16u);
+    for (uint32_t q = 0; q < NPW; ++q) {
+      const uint32_t x = w.bcast(mine, q * (uint32_t)P), y = w.bcast(lastbeg, q * (uint32_t)P);
       B_end = x > B_end ? x : B_end;
       b_last = y < b_last ? y : b_last;
     }
@@ -324,7 +381,7 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   // first = std::true_type for the blocks in which strip 0 can be live: its rows take row 0 (or the stored row) from above
   auto block = [&](uint32_t b, auto first) {
     constexpr bool FIRST = decltype(first)::value;
-    if (j == (b & 15u) && have && b < NS) {  // ---- begin strip b ----
+    if (j == b % (uint32_t)P && have && b < NS) {  // ---- begin strip b ----
       live = true;
       s_cur = b;
       const uint32_t r0 = b * (uint32_t)K;
@@ -359,12 +416,15 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
       }
       raw_next = code_at(cm1);
       if (KIND == 0) wp = bits + (uint64_t)b * S * WB;
-      if (b + 16u < NS) prefetch(b + 16u);
+      if (b + (uint32_t)P < NS) prefetch(b + (uint32_t)P);
     }
+    uint32_t blk[K <= 4 ? 3 : K <= 8 ? 9 : 1];
+#pragma unroll
+    for (uint32_t q = 0; q < sizeof(blk) / sizeof(blk[0]); ++q) blk[q] = 0u;
 #pragma unroll
     for (uint32_t k = 0; k < KP; ++k) {
-      int32_t up_h = w.rot16(bot_h);
-      int32_t up_f = w.rot16(bot_f);
+      int32_t up_h = w.rot(bot_h, Lanes{});
+      int32_t up_f = w.rot(bot_f, Lanes{});
       if (FIRST) {  // strip 0: row 0 instead of a strip above (gotoh.h:112-116)
         if (live && s_cur == 0) {
           const int32_t c = (int32_t)cm1 + 1;
@@ -387,8 +447,8 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
         if (KIND == 0) {
           uint32_t w0 = 0, w1 = 0;
           trace_step<K>(ts, up_h, up_f, prev_up_h, cy1, cy2, sub, w0, w1, nb_h, nb_f);
-          if (K <= 4) *reinterpret_cast<uint16_t*>(wp) = (uint16_t)w0;
-          else if (K <= 8) *reinterpret_cast<uint32_t*>(wp) = w0;
+          if (K <= 4) blk[k >> 1] |= (w0 & 0xffffu) << (16u * (k & 1u));  // (a block's words go out together, below)
+          else if (K <= 8) blk[k] = w0;
           else *reinterpret_cast<uint64_t*>(wp) = ((uint64_t)w1 << 32) | w0;
         } else {
           origin_step<K>(ts, up_h, up_f, prev_up_h, cy1, cy2, sub, nb_h, nb_f);
@@ -409,6 +469,27 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
       ++cm1;
       if (KIND == 0) wp += WB;
     }
+    // K = 4: the words of a block are ten consecutive bytes of the strip's window -- one 8-byte and one 2-byte store per block
+    // instead of five 2-byte ones to five cache lines per lane (a word of a column off 1 .. n is written as 0; nobody reads it).  A strip's window is whole
+    // blocks except for the last strip's, whose last block may run past the pair's words: that one goes out word by word.
+    // K = 8: nine dwords, as two 16-byte stores and one of four bytes.
+    if (KIND == 0 && K <= 8 && live) {
+      uint8_t* const w0p = wp - KP * WB;
+      const uint32_t first = (uint32_t)((w0p - bits) / WB) - s_cur * S;  // index of the block's first word in its strip's window
+      if (s_cur + 1u == NS && first + KP > S_last) {
+#pragma unroll
+        for (uint32_t k = 0; k < KP; ++k)
+          if (first + k < S_last) {
+            if (K <= 4) *reinterpret_cast<uint16_t*>(w0p + 2u * k) = (uint16_t)(blk[k >> 1] >> (16u * (k & 1u)));
+            else *reinterpret_cast<uint32_t*>(w0p + 4u * k) = blk[k];
+          }
+      } else if (K <= 4) {
+        __builtin_memcpy(w0p, blk, 8);
+        *reinterpret_cast<uint16_t*>(w0p + 8) = (uint16_t)blk[2];
+      } else {
+        __builtin_memcpy(w0p, blk, 4u * KP);
+      }
+    }
     if (live && --left == 0u) {  // past the window: the strip below finds -inf above its last K columns
       live = false;
       bot_h = neg;
@@ -416,11 +497,11 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
     }
   };
   uint32_t b = 0;
-  for (; b < 16u && b < B_end; ++b) block(b, std::true_type{});
+  for (; b < (uint32_t)P && b < B_end; ++b) block(b, std::true_type{});
   for (; b < B_end; ++b) block(b, std::false_type{});
 
   // ---- score, ends, walk ----
-  if (have && j == ((NS - 1u) & 15u)) {
+  if (have && j == (NS - 1u) % (uint32_t)P) {
     int32_t hv = 0;
 #pragma unroll
     for (int i = 0; i < K; ++i)
@@ -434,7 +515,7 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   if (KIND == 0) {
     w.sync_global();
     Band16Fetch<K> fetch{bits, S, S_last, NS, n, dmin};
-    walk16(w, fetch, have, m, n, have ? a.ops + a.ops_off[d.out] : nullptr, have ? a.ops_len + d.out : nullptr, a.err,
+    walk16<W, Band16Fetch<K>, P, (P == 4 ? 4 : 1)>(w, fetch, have, m, n, have ? a.ops + a.ops_off[d.out] : nullptr, have ? a.ops_len + d.out : nullptr, a.err,
            (uint32_t)d.lastrow_off, (uint32_t)(d.lastrow_off >> 32));
   }
 }
@@ -571,8 +652,8 @@ TR_HD void band16_cont16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
     }
 #pragma unroll
     for (uint32_t k = 0; k < KP; ++k) {
-      int32_t up_h = w.rot16(bot_h);
-      int32_t up_f = w.rot16(bot_f);
+      int32_t up_h = w.rot(bot_h, std::integral_constant<int, 16>{});
+      int32_t up_f = w.rot(bot_f, std::integral_constant<int, 16>{});
       if (FIRST) {
         if (live && s_cur == 0) {
           const int32_t c = (int32_t)cm1 + 1;

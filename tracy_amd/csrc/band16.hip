@@ -12,6 +12,9 @@ struct DeviceWave16 {
   __device__ __forceinline__ uint32_t lane() const { return threadIdx.x; }
   // lane j of a row of 16 <- lane j - 1 of the same row, lane 0 <- lane 15 (row_ror:1)
   __device__ __forceinline__ int32_t rot16(int32_t x) const { return __builtin_amdgcn_update_dpp(0, x, 0x121, 0xf, 0xf, false); }
+  __device__ __forceinline__ int32_t rot(int32_t x, std::integral_constant<int, 16>) const { return rot16(x); }
+  // lane j of a quad <- lane j - 1 of the same quad, lane 0 <- lane 3 (quad_perm:[3,0,1,2])
+  __device__ __forceinline__ int32_t rot(int32_t x, std::integral_constant<int, 4>) const { return __builtin_amdgcn_update_dpp(0, x, 0x93, 0xf, 0xf, false); }
   __device__ __forceinline__ uint64_t ballot(bool p) const { return __ballot(p); }
   __device__ __forceinline__ uint32_t bcast(uint32_t x, uint32_t src_lane) const { return (uint32_t)__shfl((int)x, (int)src_lane, 64); }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
@@ -31,6 +34,12 @@ __global__ __launch_bounds__(64) void band16_kernel(Band16Args a) {
   DeviceWave16 w;
   band16_body<DeviceWave16, K, KIND>(w, a, blockIdx.x);
 }
+// the quad form: sixteen pairs of narrow bands per workgroup (band16.h b16_narrow_ok), strip height 4
+template <int KIND>
+__global__ __launch_bounds__(64) void band16_quad_kernel(Band16Args a) {
+  DeviceWave16 w;
+  band16_body<DeviceWave16, 4, KIND, false, 4>(w, a, blockIdx.x);
+}
 
 // One launch for the three strip heights of a small job: blocks [0, w12) sweep a12's pairs on K = 12 strips, the next w8 a8's on
 // K = 8, the rest a4's on K = 4.  A job of 10 000 pairs is 2 500 waves -- fewer than the device holds -- so its launches are as long
@@ -45,13 +54,15 @@ __global__ __launch_bounds__(64) void band16_multi_kernel(Band16Args a12, uint32
 
 // The same with the three jobs' sizes on the device (Band16Args::count; lists laid out by stream.hip's planning kernels): the grid holds
 // the worst case, a block finds its job from the counts and the blocks past the last job leave at once.
+// (aq: the pairs of the quad form, sixteen to a block; the four jobs share one code_cap and the LDS block is laid out per form)
 template <int KIND>
-__global__ __launch_bounds__(64) void band16_multi_counted_kernel(Band16Args a12, Band16Args a8, Band16Args a4) {
+__global__ __launch_bounds__(64) void band16_multi_counted_kernel(Band16Args a12, Band16Args a8, Band16Args a4, Band16Args aq) {
   DeviceWave16 w;
-  const uint32_t w12 = (*a12.count + 3u) / 4u, w8 = (*a8.count + 3u) / 4u, w4 = (*a4.count + 3u) / 4u;
+  const uint32_t w12 = (*a12.count + 3u) / 4u, w8 = (*a8.count + 3u) / 4u, w4 = (*a4.count + 3u) / 4u, wq = (*aq.count + 15u) / 16u;
   if (blockIdx.x < w12) band16_body<DeviceWave16, 12, KIND>(w, a12, blockIdx.x);
   else if (blockIdx.x < w12 + w8) band16_body<DeviceWave16, 8, KIND>(w, a8, blockIdx.x - w12);
   else if (blockIdx.x < w12 + w8 + w4) band16_body<DeviceWave16, 4, KIND>(w, a4, blockIdx.x - w12 - w8);
+  else if (blockIdx.x < w12 + w8 + w4 + wq) band16_body<DeviceWave16, 4, KIND, false, 4>(w, aq, blockIdx.x - w12 - w8 - w4);
 }
 
 template <int K>
@@ -149,17 +160,29 @@ hipError_t launch_band16_multi(int kind, const Band16Args& a12, const Band16Args
 
 // jobs whose sizes are on the device (a.count != null, a.npairs = the most pairs the job can hold): one launch per strip height for
 // large batches (a K = 4 workgroup then asks for its own, smaller LDS block), one for all three below 24 576 pairs
-hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Args& a8, const Band16Args& a4, hipStream_t s) {
-  const uint32_t most = a12.npairs > a8.npairs ? (a12.npairs > a4.npairs ? a12.npairs : a4.npairs) : (a8.npairs > a4.npairs ? a8.npairs : a4.npairs);
+hipError_t launch_band16_quad(int kind, const Band16Args& a, hipStream_t s) {
+  if (a.npairs == 0) return hipSuccess;
+  const dim3 grid((a.npairs + 15u) / 16u);
+  const uint32_t lds = b16_quad_lds(a.code_cap);
+  if (kind == 0) hipLaunchKernelGGL((band16_quad_kernel<0>), grid, dim3(64), lds, s, a);
+  else hipLaunchKernelGGL((band16_quad_kernel<1>), grid, dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Args& a8, const Band16Args& a4, const Band16Args& aq, hipStream_t s) {
+  uint32_t most = a12.npairs;
+  for (uint32_t x : {a8.npairs, a4.npairs, aq.npairs}) most = x > most ? x : most;
   if (most == 0) return hipSuccess;
   if (most <= 24576u) {
-    const uint32_t lds = 4u * a12.code_cap + b16_table_bytes(12);
-    const dim3 grid((most + 3u) / 4u + 3u);  // (the three jobs together hold at most `most` pairs: every pair is in one of them)
-    if (kind == 0) hipLaunchKernelGGL((band16_multi_counted_kernel<0>), grid, dim3(64), lds, s, a12, a8, a4);
-    else hipLaunchKernelGGL((band16_multi_counted_kernel<1>), grid, dim3(64), lds, s, a12, a8, a4);
+    const uint32_t lds16 = 4u * a12.code_cap + b16_table_bytes(12), ldsq = aq.npairs ? b16_quad_lds(aq.code_cap) : 0u;
+    const uint32_t lds = lds16 > ldsq ? lds16 : ldsq;
+    const dim3 grid((most + 3u) / 4u + 4u);  // (the four jobs together hold at most `most` pairs: every pair is in one of them)
+    if (kind == 0) hipLaunchKernelGGL((band16_multi_counted_kernel<0>), grid, dim3(64), lds, s, a12, a8, a4, aq);
+    else hipLaunchKernelGGL((band16_multi_counted_kernel<1>), grid, dim3(64), lds, s, a12, a8, a4, aq);
     return hipGetLastError();
   }
   hipError_t e;
+  if ((e = launch_band16_quad(kind, aq, s)) != hipSuccess) return e;
   if ((e = launch_band16(4, kind, a4, s)) != hipSuccess) return e;   // (the usual strip height first: the other two are mostly empty grids)
   if ((e = launch_band16(8, kind, a8, s)) != hipSuccess) return e;
   return launch_band16(12, kind, a12, s);

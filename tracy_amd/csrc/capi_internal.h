@@ -54,6 +54,7 @@ struct CtxKnobs {
   bool no_prelim_origin = false;  // preliminary alignment of `tracy align` by band traceback instead of its two ends
   bool no_cq = false;             // string x string by byte compare instead of the query-profile table
   bool no_fused_walk = false;     // a separate walk launch after a traceback sweep
+  bool no_quads = false;          // stream-ordered pipelines: narrow bands on sixteen lanes per pair like the rest (band16.h b16_narrow_ok)
   bool no_cont16 = false;         // the band below a kept prefix row (front.h) on the tagged int32 recurrence instead of the 16-bit cells
   bool verbose = false;           // one line per pipeline stage on stderr: how many pairs took which tier (TRACYHIP_HOST_TIMERS sets it too)
   int32_t band_w = -1;            // half width of the certified band of the final alignments: -1 = from the preliminary alignment (default),

@@ -88,8 +88,13 @@ __global__ __launch_bounds__(64) void gotoh_origin_kernel(DpArgs a) {
 // one launch, two kinds of workgroups: blocks [0, nfull) run the checkpointed 16-bit score sweep of `full`, the rest the
 // prefix bound of `pre` (GL lanes per pair) -- the short prefix workgroups fill the tail of the long sweeps
 // (the prefix workgroups come first: they walk as many columns as a sweep does, with fewer rows -- started last they would be the tail)
+#ifdef TRACY_SWEEP_WAVES
+#define TRACY_SWEEP_ATTR __attribute__((amdgpu_waves_per_eu(TRACY_SWEEP_WAVES)))
+#else
+#define TRACY_SWEEP_ATTR
+#endif
 template <int K, int GL, bool COMPACT = false, int KP = K>
-__global__ __launch_bounds__(64) void gotoh_ckpt_prefix_kernel(DpArgs full, uint32_t nfull, DpArgs pre, uint32_t npre) {
+__global__ __launch_bounds__(64) TRACY_SWEEP_ATTR void gotoh_ckpt_prefix_kernel(DpArgs full, uint32_t nfull, DpArgs pre, uint32_t npre) {
   DeviceWave w;
   const uint32_t ngroups = (npre + 64u / GL - 1u) / (64u / GL);
   if (blockIdx.x < ngroups) gotoh_prefix_body<DeviceWave, KP, GL, COMPACT>(w, pre, blockIdx.x * (64u / GL), npre);

@@ -278,90 +278,95 @@ __global__ void s_prelim_plan_kernel(SParams p, int mode, const SGeom* __restric
 // traceback words (KIND 0).  A pair whose words do not fit the workspace planned for the launch becomes an empty slot and its trace
 // is marked (SD_MEM). ----
 constexpr uint32_t kScanBlock = 256, kScanTop = 1024;
-struct ScanPart { uint32_t n[3]; uint32_t pad; unsigned long long bytes; };
-__device__ __forceinline__ int s_bucket(int K) { return K == 12 ? 0 : K == 8 ? 1 : 2; }
+struct ScanPart { uint32_t n[4]; unsigned long long bytes; };
+// lists: strip height 12, 8, 4, and the quad form (strip height 4, four lanes per pair) for the narrow bands when the launch has room for it
+__device__ __forceinline__ int s_bucket(int K, const PairDesc& d, int quads) {
+  return K == 12 ? 0 : K == 8 ? 1 : (quads && b16_narrow_ok(band_dmin(d), band_dmax(d))) ? 3 : 2;
+}
 __device__ __forceinline__ unsigned long long s_word_bytes(const PairDesc& d, int K, int kind, unsigned long long* words = nullptr) {
   const unsigned long long w = b16_words(d.m, d.n, K, band_dmin(d), band_dmax(d));
   if (words) *words = w;
   return kind == 0 ? ((w * b16_word_bytes(K) + 15ull) & ~15ull) : 0ull;
 }
 __global__ __launch_bounds__(kScanBlock) void s_scan_partial_kernel(const PairDesc* __restrict__ cand, const uint8_t* __restrict__ kc, uint32_t n, int kind,
-                                                                    ScanPart* __restrict__ part) {
-  __shared__ uint32_t s_n[3];
+                                                                    int quads, ScanPart* __restrict__ part) {
+  __shared__ uint32_t s_n[4];
   __shared__ unsigned long long s_b;
-  if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
-  if (threadIdx.x == 3) s_b = 0;
+  if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
+  if (threadIdx.x == 4) s_b = 0;
   __syncthreads();
   const uint32_t i = blockIdx.x * kScanBlock + threadIdx.x;
   const int K = i < n ? kc[i] : 0;
   if (K) {
-    atomicAdd(&s_n[s_bucket(K)], 1u);
-    if (kind == 0) atomicAdd(&s_b, s_word_bytes(cand[i], K, kind));
+    const PairDesc d = cand[i];
+    atomicAdd(&s_n[s_bucket(K, d, quads)], 1u);
+    if (kind == 0) atomicAdd(&s_b, s_word_bytes(d, K, kind));
   }
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = ScanPart{{s_n[0], s_n[1], s_n[2]}, 0u, s_b};
+  if (threadIdx.x == 0) part[blockIdx.x] = ScanPart{{s_n[0], s_n[1], s_n[2], s_n[3]}, s_b};
 }
 // exclusive scan over the blocks' totals (in place), the lists' sizes
 __global__ __launch_bounds__(kScanTop) void s_scan_top_kernel(ScanPart* __restrict__ part, uint32_t nb, uint32_t* __restrict__ count) {
-  __shared__ uint32_t s_n[3][kScanTop];
+  __shared__ uint32_t s_n[4][kScanTop];
   __shared__ unsigned long long s_b[kScanTop];
   const uint32_t tid = threadIdx.x;
   const uint32_t per = (nb + kScanTop - 1) / kScanTop;
   const uint32_t lo = tid * per < nb ? tid * per : nb, hi = lo + per < nb ? lo + per : nb;
-  uint32_t c[3] = {0, 0, 0};
+  uint32_t c[4] = {0, 0, 0, 0};
   unsigned long long bytes = 0;
-  for (uint32_t i = lo; i < hi; ++i) { for (int b = 0; b < 3; ++b) c[b] += part[i].n[b]; bytes += part[i].bytes; }
-  for (int b = 0; b < 3; ++b) s_n[b][tid] = c[b];
+  for (uint32_t i = lo; i < hi; ++i) { for (int b = 0; b < 4; ++b) c[b] += part[i].n[b]; bytes += part[i].bytes; }
+  for (int b = 0; b < 4; ++b) s_n[b][tid] = c[b];
   s_b[tid] = bytes;
   __syncthreads();
   for (uint32_t d = 1; d < kScanTop; d <<= 1) {  // inclusive scans over the threads (Hillis-Steele: ten rounds)
-    uint32_t v[3] = {0, 0, 0};
+    uint32_t v[4] = {0, 0, 0, 0};
     unsigned long long vb = 0;
-    if (tid >= d) { for (int b = 0; b < 3; ++b) v[b] = s_n[b][tid - d]; vb = s_b[tid - d]; }
+    if (tid >= d) { for (int b = 0; b < 4; ++b) v[b] = s_n[b][tid - d]; vb = s_b[tid - d]; }
     __syncthreads();
-    for (int b = 0; b < 3; ++b) s_n[b][tid] += v[b];
+    for (int b = 0; b < 4; ++b) s_n[b][tid] += v[b];
     s_b[tid] += vb;
     __syncthreads();
   }
-  uint32_t at[3];
-  for (int b = 0; b < 3; ++b) at[b] = s_n[b][tid] - c[b];
+  uint32_t at[4];
+  for (int b = 0; b < 4; ++b) at[b] = s_n[b][tid] - c[b];
   unsigned long long off = s_b[tid] - bytes;
   for (uint32_t i = lo; i < hi; ++i) {
     const ScanPart x = part[i];
-    part[i] = ScanPart{{at[0], at[1], at[2]}, 0u, off};
-    for (int b = 0; b < 3; ++b) at[b] += x.n[b];
+    part[i] = ScanPart{{at[0], at[1], at[2], at[3]}, off};
+    for (int b = 0; b < 4; ++b) at[b] += x.n[b];
     off += x.bytes;
   }
-  if (tid == 0) { for (int b = 0; b < 3; ++b) count[b] = s_n[b][kScanTop - 1]; count[3] = 0; }
+  if (tid == 0) for (int b = 0; b < 4; ++b) count[b] = s_n[b][kScanTop - 1];
 }
 __global__ __launch_bounds__(kScanBlock) void s_scan_place_kernel(PairDesc* __restrict__ cand, uint8_t* __restrict__ kc, uint32_t n, uint32_t unit_mod, int kind,
-                                                                  unsigned long long cap_bytes, const ScanPart* __restrict__ part, uint32_t* __restrict__ idx,
+                                                                  int quads, unsigned long long cap_bytes, const ScanPart* __restrict__ part, uint32_t* __restrict__ idx,
                                                                   uint32_t* __restrict__ dead, unsigned long long* __restrict__ stat) {
-  __shared__ uint32_t s_n[3][kScanBlock];
+  __shared__ uint32_t s_n[4][kScanBlock];
   __shared__ unsigned long long s_b[kScanBlock];
-  __shared__ unsigned long long s_stat[3];
+  __shared__ unsigned long long s_stat[SB_COUNT];
   const uint32_t tid = threadIdx.x;
-  if (tid < 3) s_stat[tid] = 0;
+  if (tid < SB_COUNT) s_stat[tid] = 0;
   const uint32_t i = blockIdx.x * kScanBlock + tid;
   const int K = i < n ? kc[i] : 0;
   PairDesc d{};
   unsigned long long words = 0, mine = 0;
   if (K) { d = cand[i]; mine = s_word_bytes(d, K, kind, &words); }
-  for (int b = 0; b < 3; ++b) s_n[b][tid] = (K && s_bucket(K) == b) ? 1u : 0u;
+  const int bucket = K ? s_bucket(K, d, quads) : -1;
+  for (int b = 0; b < 4; ++b) s_n[b][tid] = bucket == b ? 1u : 0u;
   s_b[tid] = mine;
   __syncthreads();
   for (uint32_t dd = 1; dd < kScanBlock; dd <<= 1) {
-    uint32_t v[3] = {0, 0, 0};
+    uint32_t v[4] = {0, 0, 0, 0};
     unsigned long long vb = 0;
-    if (tid >= dd) { for (int b = 0; b < 3; ++b) v[b] = s_n[b][tid - dd]; vb = s_b[tid - dd]; }
+    if (tid >= dd) { for (int b = 0; b < 4; ++b) v[b] = s_n[b][tid - dd]; vb = s_b[tid - dd]; }
     __syncthreads();
-    for (int b = 0; b < 3; ++b) s_n[b][tid] += v[b];
+    for (int b = 0; b < 4; ++b) s_n[b][tid] += v[b];
     s_b[tid] += vb;
     __syncthreads();
   }
   if (K) {
     const ScanPart base = part[blockIdx.x];
-    const int b = s_bucket(K);
+    const int b = bucket;
     const uint32_t pos = base.n[b] + s_n[b][tid] - 1u;
     const unsigned long long off = base.bytes + s_b[tid] - mine;
     idx[(size_t)b * n + pos] = i;  // (the list stays dense: a dropped pair keeps its slot as an empty one)
@@ -374,10 +379,11 @@ __global__ __launch_bounds__(kScanBlock) void s_scan_place_kernel(PairDesc* __re
       atomicAdd(&s_stat[0], words * (unsigned long long)K);
       atomicAdd(&s_stat[1], (kind == 0 ? words * b16_word_bytes(K) : 0ull) + 12ull * d.m + d.n + 4ull);
       atomicAdd(&s_stat[2], mine);
+      atomicAdd(&s_stat[SB_HIST + s_width_bucket(band_dmin(d), band_dmax(d))], 1ull);
     }
   }
   __syncthreads();
-  if (tid < 3 && s_stat[tid]) atomicAdd(stat + tid, s_stat[tid]);
+  if (tid < SB_COUNT && s_stat[tid]) atomicAdd(stat + tid, s_stat[tid]);
 }
 
 // ---- `tracy align`: trimReferenceSlice from the two ends (sage.h:259) and the plan of the final alignment gotoh(full profile,
@@ -534,7 +540,7 @@ struct StreamCommon {  // device arrays of the orientation stage + preliminary a
     ce = a.take<uint32_t>(nt);
     dead = a.take<uint32_t>(nt);
     kc = a.take<uint8_t>(nunits);
-    idx = a.take<uint32_t>(3 * (size_t)nunits);
+    idx = a.take<uint32_t>(4 * (size_t)nunits);
     part = a.take<ScanPart>((nunits + kScanBlock - 1) / kScanBlock + 1);
     count = a.take<uint32_t>(4 * 8);
     cnt = a.take<unsigned long long>(SC_COUNT);
@@ -640,19 +646,21 @@ int band_stage(tracyhip_ctx* ctx, const tracyhip_params& p, StreamCommon& sc, ui
   hipStream_t st = ctx->stream;
   uint32_t* count = sc.count + 4 * stage_no;
   const uint32_t nb = (n + kScanBlock - 1) / kScanBlock;
-  hipLaunchKernelGGL(s_scan_partial_kernel, dim3(nb), dim3(kScanBlock), 0, st, sc.cand, sc.kc, n, bl.kind, sc.part);
+  const int quads = (!ctx->knobs.no_quads && b16_quad_lds(bl.code_cap) <= 64u * 1024u) ? 1 : 0;  // the narrow bands four lanes to a pair, where sixteen code rows fit
+  hipLaunchKernelGGL(s_scan_partial_kernel, dim3(nb), dim3(kScanBlock), 0, st, sc.cand, sc.kc, n, bl.kind, quads, sc.part);
   hipLaunchKernelGGL(s_scan_top_kernel, dim3(1), dim3(kScanTop), 0, st, sc.part, nb, count);
-  hipLaunchKernelGGL(s_scan_place_kernel, dim3(nb), dim3(kScanBlock), 0, st, sc.cand, sc.kc, n, unit_mod, bl.kind, (unsigned long long)cap_bytes, sc.part, sc.idx, sc.dead,
+  hipLaunchKernelGGL(s_scan_place_kernel, dim3(nb), dim3(kScanBlock), 0, st, sc.cand, sc.kc, n, unit_mod, bl.kind, quads, (unsigned long long)cap_bytes, sc.part, sc.idx, sc.dead,
                      sc.bstat + SB_COUNT * stage_no);
   HIP_TRY(hipGetLastError());
   Band16Args a{};
   a.pairs = sc.cand; a.npairs = n; a.qp = bl.qp; a.codes = bl.codes; a.bits = static_cast<uint8_t*>(ctx->d_bits.p); a.scores = bl.scores; a.ends = bl.ends;
   a.err = static_cast<int32_t*>(ctx->d_err.p); a.go = p.go; a.ge = p.ge; a.hfree = bl.hfree;
   a.ops = bl.ops; a.ops_off = bl.ops_off; a.ops_len = bl.ops_len; a.code_cap = bl.code_cap;
-  Band16Args ak[3] = {a, a, a};  // 12, 8, 4
-  for (int b = 0; b < 3; ++b) { ak[b].index = sc.idx + (size_t)b * n; ak[b].count = count + b; }
+  Band16Args ak[4] = {a, a, a, a};  // 12, 8, 4, 4 in quads
+  for (int b = 0; b < 4; ++b) { ak[b].index = sc.idx + (size_t)b * n; ak[b].count = count + b; }
+  if (!quads) ak[3].npairs = 0;
   TRY(timing_begin(ctx, bl.kind == 0 ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_ORIGIN, 0, 0));  // (cells / bytes: the scan's sums, added after the call's synchronisation)
-  HIP_TRY(launch_band16_counted(bl.kind, ak[0], ak[1], ak[2], st));
+  HIP_TRY(launch_band16_counted(bl.kind, ak[0], ak[1], ak[2], ak[3], st));
   TRY(timing_end(ctx));
   return TRACYHIP_OK;
 }
@@ -820,6 +828,12 @@ void stats_from_counters(tracyhip_ctx* ctx, const unsigned long long* c, const u
       ctx->acc[stage_timer[i]].bytes += bstat[SB_COUNT * i + SB_BYTES];
     }
   }
+  if (ctx->knobs.verbose)
+    for (int i = 0; i < nstages; ++i) {
+      const unsigned long long* hst = bstat + SB_COUNT * i + SB_HIST;
+      fprintf(stderr, "tracyhip: band stage %d: pairs by diagonals <=8 %llu <=16 %llu <=24 %llu <=32 %llu <=48 %llu <=64 %llu <=96 %llu more %llu\n", i, hst[0], hst[1], hst[2],
+              hst[3], hst[4], hst[5], hst[6], hst[7]);
+    }
 }
 
 }  // namespace

@@ -43,7 +43,12 @@ enum : int {
   SC_COUNT
 };
 // per band stage (bucket scan): cells and algorithmic bytes of the launch (kernel timers), bytes of its traceback words
-enum : int { SB_CELLS = 0, SB_BYTES = 1, SB_WORDS = 2, SB_COUNT = 4 };
+// ... and how wide its bands were: pairs by diagonals (dmax - dmin + 1) <= 8, 16, 24, 32, 48, 64, 96, more (option `verbose` prints them)
+enum : int { SB_CELLS = 0, SB_BYTES = 1, SB_WORDS = 2, SB_HIST = 4, SB_HIST_N = 8, SB_COUNT = 12 };
+TR_HD int s_width_bucket(int32_t dmin, int32_t dmax) {
+  const int32_t w = dmax - dmin + 1;
+  return w <= 8 ? 0 : w <= 16 ? 1 : w <= 24 ? 2 : w <= 32 ? 3 : w <= 48 ? 4 : w <= 64 ? 5 : w <= 96 ? 6 : 7;
+}
 
 enum : uint32_t { SG_FRONT_OK = 1u };
 

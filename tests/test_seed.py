@@ -73,7 +73,9 @@ def test_counts_match_brute_force(genome):
     assert g.count(b"ACGTAC") == len(brute.locate("ACGTAC"))  # shorter than k: answered by a scan
 
 
-@pytest.mark.parametrize("trims,kmer_support,maxindel", [((50, 50), 3, 1000), ((10, 5), 3, 200), ((0, 0), 8, 1000)])
+# (trims of at least k - 1 on both sides: both strands in one pass, scanBothStrands; shorter ones: the two scans one after the other)
+@pytest.mark.parametrize("trims,kmer_support,maxindel", [((50, 50), 3, 1000), ((10, 5), 3, 200), ((0, 0), 8, 1000), ((14, 40), 3, 500), ((60, 14), 2, 300),
+                                                         ((13, 14), 3, 1000)])
 def test_get_reference_slice(genome, trims, kmer_support, maxindel):
     g, brute, _ = genome
     rng = np.random.default_rng(77 + trims[0])

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(64) void band16_multi_kernel(Band16Args a12, uint32
 // The same with the three jobs' sizes on the device (Band16Args::count; lists laid out by stream.hip's planning kernels): the grid holds
 // the worst case, a block finds its job from the counts and the blocks past the last job leave at once.
 // (aq: the pairs of the quad form, sixteen to a block; the four jobs share one code_cap and the LDS block is laid out per form)
+// (aq: the pairs of the quad form, sixteen to a block; the four jobs share one code_cap and the LDS block is laid out per form)
 template <int KIND>
 __global__ __launch_bounds__(64) void band16_multi_counted_kernel(Band16Args a12, Band16Args a8, Band16Args a4, Band16Args aq) {
   DeviceWave16 w;
@@ -169,10 +170,33 @@ hipError_t launch_band16_quad(int kind, const Band16Args& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Args& a8, const Band16Args& a4, const Band16Args& aq, hipStream_t s) {
+hipError_t B16Fork::create() {
+  hipError_t e;
+  for (int i = 0; i < 3; ++i) {
+    if ((e = hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&joined[i], hipEventDisableTiming)) != hipSuccess) return e;
+  }
+  return hipEventCreateWithFlags(&forked, hipEventDisableTiming);
+}
+void B16Fork::destroy() {
+  for (int i = 0; i < 3; ++i) {
+    if (side[i]) (void)hipStreamDestroy(side[i]);
+    if (joined[i]) (void)hipEventDestroy(joined[i]);
+    side[i] = nullptr; joined[i] = nullptr;
+  }
+  if (forked) (void)hipEventDestroy(forked);
+  forked = nullptr;
+}
+
+hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Args& a8, const Band16Args& a4, const Band16Args& aq, hipStream_t s,
+                                 const B16Fork* fork) {
   uint32_t most = a12.npairs;
   for (uint32_t x : {a8.npairs, a4.npairs, aq.npairs}) most = x > most ? x : most;
   if (most == 0) return hipSuccess;
+  hipError_t e;
+  // small jobs: one launch for the four lists (a launch lasts at least as long as one of its waves; 10 000 pairs are fewer waves than
+  // the device holds, so four launches -- in a row or side by side behind two events each -- cost more than the registers of the
+  // tallest strips cost the others here: measured 1.25 / 1.45 / 1.50 ms for the final alignments of 10 000 traces)
   if (most <= 24576u) {
     const uint32_t lds16 = 4u * a12.code_cap + b16_table_bytes(12), ldsq = aq.npairs ? b16_quad_lds(aq.code_cap) : 0u;
     const uint32_t lds = lds16 > ldsq ? lds16 : ldsq;
@@ -181,7 +205,20 @@ hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Ar
     else hipLaunchKernelGGL((band16_multi_counted_kernel<1>), grid, dim3(64), lds, s, a12, a8, a4, aq);
     return hipGetLastError();
   }
-  hipError_t e;
+  if (fork) {  // one launch per list, side by side (each with the registers and the LDS block of its own strip height)
+    if ((e = hipEventRecord(fork->forked, s)) != hipSuccess) return e;
+    for (int i = 0; i < 3; ++i)
+      if ((e = hipStreamWaitEvent(fork->side[i], fork->forked, 0)) != hipSuccess) return e;
+    if ((e = launch_band16(4, kind, a4, s)) != hipSuccess) return e;
+    if ((e = launch_band16_quad(kind, aq, fork->side[0])) != hipSuccess) return e;
+    if ((e = launch_band16(8, kind, a8, fork->side[1])) != hipSuccess) return e;
+    if ((e = launch_band16(12, kind, a12, fork->side[2])) != hipSuccess) return e;
+    for (int i = 0; i < 3; ++i) {
+      if ((e = hipEventRecord(fork->joined[i], fork->side[i])) != hipSuccess) return e;
+      if ((e = hipStreamWaitEvent(s, fork->joined[i], 0)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
   if ((e = launch_band16_quad(kind, aq, s)) != hipSuccess) return e;
   if ((e = launch_band16(4, kind, a4, s)) != hipSuccess) return e;   // (the usual strip height first: the other two are mostly empty grids)
   if ((e = launch_band16(8, kind, a8, s)) != hipSuccess) return e;

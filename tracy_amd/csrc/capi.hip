@@ -265,7 +265,7 @@ const KnobField kKnobFlags[] = {
     {"no_screen", &CtxKnobs::no_screen}, {"no_band", &CtxKnobs::no_band}, {"no_band16", &CtxKnobs::no_band16},
     {"no_front", &CtxKnobs::no_front}, {"no_prefix", &CtxKnobs::no_prefix}, {"no_vote", &CtxKnobs::no_vote},
     {"no_origin", &CtxKnobs::no_origin}, {"no_subwindow", &CtxKnobs::no_subwindow}, {"no_prelim_origin", &CtxKnobs::no_prelim_origin},
-    {"no_cq", &CtxKnobs::no_cq}, {"no_fused_walk", &CtxKnobs::no_fused_walk}, {"no_cont16", &CtxKnobs::no_cont16}, {"no_quads", &CtxKnobs::no_quads}, {"verbose", &CtxKnobs::verbose}};
+    {"no_cq", &CtxKnobs::no_cq}, {"no_fused_walk", &CtxKnobs::no_fused_walk}, {"no_cont16", &CtxKnobs::no_cont16}, {"no_quads", &CtxKnobs::no_quads}, {"no_fork", &CtxKnobs::no_fork}, {"verbose", &CtxKnobs::verbose}};
 bool same_name(const char* a, const char* b) {
   for (; *a && *b; ++a, ++b)
     if (std::tolower((unsigned char)*a) != std::tolower((unsigned char)*b)) return false;
@@ -1347,6 +1347,8 @@ int tracyhip_create(int device, tracyhip_ctx** out) {
     return set_error(TRACYHIP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
   }
   c->own_stream = c->stream;
+  c->b16_fork_ok = c->b16_fork.create() == hipSuccess;  // (without them the band stages queue their launches in a row)
+  if (!c->b16_fork_ok) c->b16_fork.destroy();
   knobs_from_env(c->knobs);
   *out = c;
   return TRACYHIP_OK;
@@ -1369,6 +1371,7 @@ int tracyhip_destroy(tracyhip_ctx* c) {
   c->release_all();
   for (auto& p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
   for (auto e : c->free_events) (void)hipEventDestroy(e);
+  c->b16_fork.destroy();
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return TRACYHIP_OK;

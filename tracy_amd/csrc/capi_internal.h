@@ -55,6 +55,7 @@ struct CtxKnobs {
   bool no_cq = false;             // string x string by byte compare instead of the query-profile table
   bool no_fused_walk = false;     // a separate walk launch after a traceback sweep
   bool no_quads = false;          // stream-ordered pipelines: narrow bands on sixteen lanes per pair like the rest (band16.h b16_narrow_ok)
+  bool no_fork = false;           // stream-ordered pipelines: the launches of a band stage in a row on the call's stream instead of side by side
   bool no_cont16 = false;         // the band below a kept prefix row (front.h) on the tagged int32 recurrence instead of the 16-bit cells
   bool verbose = false;           // one line per pipeline stage on stderr: how many pairs took which tier (TRACYHIP_HOST_TIMERS sets it too)
   int32_t band_w = -1;            // half width of the certified band of the final alignments: -1 = from the preliminary alignment (default),
@@ -109,6 +110,8 @@ struct tracyhip_ctx {
   tracyhip::DevBuf d_b16tab[4], d_b16desc;     // substitution tables of the band kernels (band16.h), their descriptors
   tracyhip::DevBuf d_front;                    // descriptors / pairs / results of the pruned orientation sweep (front.h)
   tracyhip::DevBuf d_pre;                      // descriptors of its prefix launch over string x code pairs (run_prefix_keep_cq)
+  tracyhip::B16Fork b16_fork;                  // side streams of the band stages (stream.hip band_stage), created with the context
+  bool b16_fork_ok = false;
   tracyhip::DevBuf d_stream;                   // everything the stream-ordered pipelines keep on the device between their stages (stream.hip)
   hipError_t ensure_codes(size_t bytes, hipStream_t st) {
     hipError_t e = d_codes.ensure(bytes + 2 * tracyhip::kCodePad);

@@ -660,7 +660,7 @@ int band_stage(tracyhip_ctx* ctx, const tracyhip_params& p, StreamCommon& sc, ui
   for (int b = 0; b < 4; ++b) { ak[b].index = sc.idx + (size_t)b * n; ak[b].count = count + b; }
   if (!quads) ak[3].npairs = 0;
   TRY(timing_begin(ctx, bl.kind == 0 ? TRACYHIP_TIMER_TRACE : TRACYHIP_TIMER_ORIGIN, 0, 0));  // (cells / bytes: the scan's sums, added after the call's synchronisation)
-  HIP_TRY(launch_band16_counted(bl.kind, ak[0], ak[1], ak[2], ak[3], st));
+  HIP_TRY(launch_band16_counted(bl.kind, ak[0], ak[1], ak[2], ak[3], st, (ctx->b16_fork_ok && !ctx->knobs.no_fork) ? &ctx->b16_fork : nullptr));
   TRY(timing_end(ctx));
   return TRACYHIP_OK;
 }

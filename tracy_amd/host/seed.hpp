@@ -13,7 +13,7 @@
 // gives identical hit sets; the hits are sorted before use, fmindex.h:180).  PARITY UNPINNED (no sdsl, no
 // reference tests); tests/ cross-check against a brute-force search.
 // `tracy index` (index.h:79-124) has its counterpart in GenomeIndex::save / open_index: the text, the contig table, the
-// bucket directory and the sorted table go to one file (magic TAMDIDX1, sections 8-byte aligned) which later runs -- and
+// bucket directory and the sorted table go to one file (magic TAMDIDX2, sections 8-byte aligned) which later runs -- and
 // every rank of a multi-process job on the node -- map read-only instead of rebuilding the table (the page cache holds one copy).
 // Sequence lengths follow the reference's convention seqlen = contig length + 1 (the separator).
 #ifndef TRACY_AMD_SEED_HPP
@@ -120,7 +120,10 @@ class GenomeIndex {
     return true;
   }
 
-  // table of every k-mer over ACGT (k <= 32), sorted by code then position
+  // Table of every k-mer over ACGT (k <= 32).  A k-mer and its reverse complement share one run of the table (the run of the smaller
+  // code; inside it the occurrences of that code come first, then -- bit 63 of pos set -- the occurrences of the other one, each part
+  // sorted by position): getReferenceSlice looks every window of a trace up on both strands (fmindex.h:259-262), and the second
+  // look-up then finds the lines the first one brought into the cache instead of missing twice more into a gigabyte of table.
   void build(uint32_t kmer, uint32_t nthreads = 0) {
     k = kmer;
     std::vector<Entry>& table_ = owned_table_;
@@ -136,15 +139,19 @@ class GenomeIndex {
       const int b = base2(text[p]);
       if (b < 0) { valid = 0; code = 0; continue; }
       code = ((code << 2) | (uint64_t)b) & mask;
-      if (++valid >= k) table_.push_back(Entry{code, (uint64_t)(p + 1 - k)});
+      if (++valid >= k) {  // filed under the smaller of the k-mer and its reverse complement; bit 63 of pos: the text holds the other one
+        const Key q = key_of(code);
+        table_.push_back(Entry{q.code, (uint64_t)(p + 1 - k) | (q.flipped ? kFlipped : 0ull)});
+      }
     }
     if (nthreads == 0) nthreads = usable_threads();
-    sort_table(nthreads);
-    // bucket directory over the leading bits of the code: a lookup touches one directory slot + one short run
+    // bucket directory over the TRAILING bits of the run's code: a lookup touches one directory slot + one short run.  (The smaller
+    // of a k-mer and its reverse complement starts with A or C three times out of four: leading bits would put most of the table
+    // into half of the buckets; the trailing letters are as good as uniform.)  The table is sorted by bucket, code, position.
     bucket_bits_ = std::min<uint32_t>(2 * k, 24);
-    const uint32_t shift = 2 * k - bucket_bits_;
+    sort_table(nthreads);
     bucket_.assign(((std::size_t)1 << bucket_bits_) + 1, 0);
-    for (Entry const& e : table_) ++bucket_[(std::size_t)(e.code >> shift) + 1];
+    for (Entry const& e : table_) ++bucket_[slot_of(e.code) + 1];
     for (std::size_t b = 1; b < bucket_.size(); ++b) bucket_[b] += bucket_[b - 1];
     tab_ = table_.data(); ntab_ = table_.size(); bkt_ = bucket_.data();
 #ifdef MADV_HUGEPAGE
@@ -158,7 +165,7 @@ class GenomeIndex {
   }
 
   // ---- persistence: `tracy index` (index.h:79-124) -------------------------------------------------------------
-  // header: magic[8] "TAMDIDX1", u32 k, u32 bucket_bits, u64 text bytes, u64 table entries, u64 contigs, u64 names bytes; then
+  // header: magic[8] "TAMDIDX2", u32 k, u32 bucket_bits, u64 text bytes, u64 table entries, u64 contigs, u64 names bytes; then
   // (each padded to 8 bytes) text, names ('\0'-separated), lengths u32[], starts u64[], bucket u64[2^bits + 1], table {code, pos}[]
   bool save(std::string const& path) const {
     if (k == 0 || !tab_ || !bkt_) return false;
@@ -167,7 +174,7 @@ class GenomeIndex {
     std::string nm;
     for (auto const& x : names) { nm += x; nm.push_back('\0'); }
     const uint64_t hdr[6] = {((uint64_t)bucket_bits_ << 32) | k, text.size(), ntab_, names.size(), nm.size(), 0};
-    bool ok = std::fwrite("TAMDIDX1", 1, 8, f) == 8 && std::fwrite(hdr, sizeof(hdr), 1, f) == 1;
+    bool ok = std::fwrite("TAMDIDX2", 1, 8, f) == 8 && std::fwrite(hdr, sizeof(hdr), 1, f) == 1;
     auto put = [&](const void* p, std::size_t bytes) {
       static const char zero[8] = {0};
       ok = ok && (bytes == 0 || std::fwrite(p, 1, bytes, f) == bytes);
@@ -186,7 +193,7 @@ class GenomeIndex {
     std::FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
     char m[8] = {0};
-    const bool ok = std::fread(m, 1, 8, f) == 8 && std::memcmp(m, "TAMDIDX1", 8) == 0;
+    const bool ok = std::fread(m, 1, 8, f) == 8 && std::memcmp(m, "TAMDIDX2", 8) == 0;
     std::fclose(f);
     return ok;
   }
@@ -204,7 +211,7 @@ class GenomeIndex {
     const char* base = static_cast<const char*>(m);
     uint64_t hdr[6];
     std::memcpy(hdr, base + 8, sizeof(hdr));
-    if (std::memcmp(base, "TAMDIDX1", 8) != 0) { unmap(); return false; }
+    if (std::memcmp(base, "TAMDIDX2", 8) != 0) { unmap(); return false; }  // (TAMDIDX1: one run per k-mer, no strand bit -- rebuild)
     k = (uint32_t)hdr[0]; bucket_bits_ = (uint32_t)(hdr[0] >> 32);
     const uint64_t tbytes = hdr[1], nt = hdr[2], nc = hdr[3], nmb = hdr[4];
     if (k == 0 || k > 32 || bucket_bits_ > 24 || bucket_bits_ > 2 * k) { unmap(); return false; }
@@ -286,20 +293,67 @@ class GenomeIndex {
 
   // table range of one k-mer code (k-mers over ACGT only)
   void code_range(uint64_t code, std::size_t& lo, std::size_t& hi) const {
-    const std::size_t b = (std::size_t)(code >> (2 * k - bucket_bits_));
+    const Key q = key_of(code);
+    const std::size_t b = slot_of(q.code);
     std::size_t i = bkt_[b];
     const std::size_t e = bkt_[b + 1];
-    while (i < e && tab_[i].code < code) ++i;  // buckets hold a handful of entries
+    while (i < e && tab_[i].code < q.code) ++i;  // buckets hold a handful of entries
+    if (q.flipped)
+      while (i < e && tab_[i].code == q.code && !(tab_[i].pos & kFlipped)) ++i;  // past the occurrences of the run's own code
     lo = i;
-    while (i < e && tab_[i].code == code) ++i;
+    while (i < e && tab_[i].code == q.code && ((tab_[i].pos & kFlipped) != 0) == q.flipped) ++i;
     hi = i;
   }
-  uint64_t position(std::size_t i) const { return tab_[i].pos; }
+  uint64_t position(std::size_t i) const { return tab_[i].pos & ~kFlipped; }
   // cache warm-up for a batch of look-ups: the directory slot first, then (once that is in cache) the table run
-  void prefetch_slot(uint64_t code) const { __builtin_prefetch(&bkt_[(std::size_t)(code >> (2 * k - bucket_bits_))]); }
+  void prefetch_slot(uint64_t code) const { __builtin_prefetch(&bkt_[slot_of(key_of(code).code)]); }
   void prefetch_run(uint64_t code) const {
-    const std::size_t i = bkt_[(std::size_t)(code >> (2 * k - bucket_bits_))];
+    const std::size_t i = bkt_[slot_of(key_of(code).code)];
     if (i < ntab_) __builtin_prefetch(&tab_[i]);
+  }
+  std::size_t slot_of(uint64_t key) const { return (std::size_t)(key & ((1ull << bucket_bits_) - 1ull)); }
+  bool has_table() const { return tab_ != nullptr && bkt_ != nullptr; }
+  void prefetch_slot_key(uint64_t key) const { __builtin_prefetch(&bkt_[slot_of(key)]); }
+  void prefetch_run_key(uint64_t key) const {
+    const std::size_t i = bkt_[slot_of(key)];
+    if (i < ntab_) __builtin_prefetch(&tab_[i]);
+  }
+  // One run, both strands (scanBothStrands): the occurrences of the k-mer whose run `key` names vote into `fwd` (value: position - pf),
+  // those of its reverse complement into `rev` (position - pr); flipped: the forward k-mer is the run's second part; a palindrome
+  // is its own reverse complement (both lists read the same part).  unique / the < 1000 rule: scanSequence's, per strand.
+  void both_strands(uint64_t key, bool flipped, bool palindrome, std::vector<int64_t>* fwd, int64_t pf, std::vector<int64_t>* rev, int64_t pr,
+                    bool unique) const {
+    const std::size_t b = slot_of(key);
+    std::size_t i = bkt_[b];
+    const std::size_t e = bkt_[b + 1];
+    while (i < e && tab_[i].code < key) ++i;
+    const std::size_t own = i;  // [own, mid): the run's own code, [mid, end): the other one
+    while (i < e && tab_[i].code == key && !(tab_[i].pos & kFlipped)) ++i;
+    const std::size_t mid = i;
+    while (i < e && tab_[i].code == key) ++i;
+    const std::size_t end = i;
+    const std::size_t f_lo = flipped ? mid : own, f_hi = flipped ? end : mid;
+    const std::size_t r_lo = palindrome ? f_lo : (flipped ? own : mid), r_hi = palindrome ? f_hi : (flipped ? mid : end);
+    auto vote = [&](std::vector<int64_t>* out, std::size_t lo, std::size_t hi, int64_t at) {
+      if (!out) return;
+      const std::size_t occs = hi - lo;
+      if (unique ? occs == 1 : (occs > 0 && occs < 1000))
+        for (std::size_t q = lo; q < hi; ++q) out->push_back((int64_t)(tab_[q].pos & ~kFlipped) - at);
+    };
+    vote(fwd, f_lo, f_hi, pf);
+    vote(rev, r_lo, r_hi, pr);
+  }
+  // the reverse complement of a k-mer code (two bits per letter, first letter in the highest pair)
+  static uint64_t revcomp_code(uint64_t x, uint32_t k) {
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0f0f0f0f0f0f0f0full) | ((x & 0x0f0f0f0f0f0f0f0full) << 4);
+    x = __builtin_bswap64(x);
+    return (~x) >> (64 - 2 * k);
+  }
+  struct Key { uint64_t code; bool flipped; };  // where a k-mer is filed: the smaller of its code and its reverse complement's
+  Key key_of(uint64_t code) const {
+    const uint64_t rc = revcomp_code(code, k);
+    return rc < code ? Key{rc, true} : Key{code, false};
   }
   static int base_code(char c) { return base2(c); }
 
@@ -313,7 +367,7 @@ class GenomeIndex {
     out.clear();
     std::size_t lo, hi;
     if (range(pat, lo, hi)) {
-      for (std::size_t i = lo; i < hi; ++i) out.push_back(tab_[i].pos);
+      for (std::size_t i = lo; i < hi; ++i) out.push_back(tab_[i].pos & ~kFlipped);
       return;
     }
     scan(pat, &out);
@@ -321,6 +375,7 @@ class GenomeIndex {
 
  private:
   struct Entry { uint64_t code, pos; };
+  static constexpr uint64_t kFlipped = 1ull << 63;
   std::string owned_text_;
   std::vector<Entry> owned_table_;
   std::vector<uint64_t> owned_bucket_;
@@ -341,7 +396,10 @@ class GenomeIndex {
     tab_ = nullptr; ntab_ = 0; bkt_ = nullptr;
   }
 
-  static int base2(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+  static int base2(char c) {  // (a table, not a chain of comparisons: on sequence data every comparison is a coin toss for the branch predictor)
+    static const struct T { signed char t[256]; T() { std::memset(t, -1, sizeof(t)); t['A'] = 0; t['C'] = 1; t['G'] = 2; t['T'] = 3; } } tab;
+    return tab.t[(unsigned char)c];
+  }
 
   // full-length ACGT patterns are answered from the table; anything else (shorter tail patterns when
   // trimRight < kmer, patterns with other letters) by a scan of the text
@@ -354,13 +412,7 @@ class GenomeIndex {
       code = (code << 2) | (uint64_t)b;
     }
     if (!tab_) return false;
-    auto cmp = [](Entry const& e, uint64_t v) { return e.code < v; };
-    const std::size_t b = (std::size_t)(code >> (2 * k - bucket_bits_));
-    const Entry* first = std::lower_bound(tab_ + bkt_[b], tab_ + bkt_[b + 1], code, cmp);
-    const Entry* last = first;
-    while (last != tab_ + bkt_[b + 1] && last->code == code) ++last;
-    lo = (std::size_t)(first - tab_);
-    hi = (std::size_t)(last - tab_);
+    code_range(code, lo, hi);
     return true;
   }
   std::size_t scan(std::string const& pat, std::vector<uint64_t>* out) const {
@@ -374,7 +426,12 @@ class GenomeIndex {
   }
   void sort_table(uint32_t nthreads) {
     std::vector<Entry>& table_ = owned_table_;
-    auto less = [](Entry const& a, Entry const& b) { return a.code < b.code || (a.code == b.code && a.pos < b.pos); };
+    const uint64_t low = bucket_bits_ >= 64 ? ~0ull : ((1ull << bucket_bits_) - 1ull);
+    auto less = [low](Entry const& a, Entry const& b) {
+      const uint64_t sa = a.code & low, sb = b.code & low;
+      if (sa != sb) return sa < sb;
+      return a.code < b.code || (a.code == b.code && a.pos < b.pos);
+    };
     if (nthreads <= 1 || table_.size() < (1u << 16)) {
       std::sort(table_.begin(), table_.end(), less);
       return;
@@ -428,6 +485,11 @@ inline uint32_t findMaxFreq(std::vector<int64_t>& hits, int64_t& gpos) {
 // looked up with both lines in cache.  D = 10 keeps ~20 misses in flight, what a core's miss buffers hold (measured on the EPYC 9575F
 // of the GPU box: D = 6 .. 12 within 2 %, D = 4 and D >= 16 slower); two full sweeps over all 900 windows before the first look-up
 // (rounds 2-3) ran past those buffers and were no faster than no prefetch at all.
+inline std::size_t seed_prefetch_distance() {  // (development knob: the prefetch distance; >= the windows of a trace = full sweeps)
+  const char* e = std::getenv("TRACY_AMD_SEED_DISTANCE");
+  const long v = e ? std::atol(e) : 0;
+  return v >= 1 ? (std::size_t)v : 10;
+}
 inline void scanSequence(GenomeIndex const& idx, std::string const& consensus, uint16_t trimLeft, uint16_t trimRight, uint16_t kmer,
                          std::vector<int64_t>& hits, bool unique) {
   const std::size_t size = consensus.size();
@@ -467,11 +529,7 @@ inline void scanSequence(GenomeIndex const& idx, std::string const& consensus, u
     }
   }
   std::vector<uint64_t> where;
-  static const std::size_t D = []() -> std::size_t {  // (development knob: the prefetch distance; >= the windows of a trace = full sweeps)
-    const char* e = std::getenv("TRACY_AMD_SEED_DISTANCE");
-    const long v = e ? std::atol(e) : 0;
-    return v >= 1 ? (std::size_t)v : 10;
-  }();
+  static const std::size_t D = seed_prefetch_distance();
   for (std::size_t i = 0; i < nwin + 2 * D; ++i) {
     if (i < nwin && kind[i] == 1) idx.prefetch_slot(codes[i]);
     if (i >= D && i - D < nwin && kind[i - D] == 1) idx.prefetch_run(codes[i - D]);
@@ -495,6 +553,66 @@ inline void scanSequence(GenomeIndex const& idx, std::string const& consensus, u
   }
 }
 
+// The two scans of getReferenceSlice (fmindex.h:259-262: the consensus with trims (l, r), its reverse complement with (r, l)) in one
+// pass.  Window p of the consensus and window |consensus| - p - k of the reverse complement are the same letters read on the two
+// strands: one k-mer and its reverse complement, which the table files in ONE run (GenomeIndex::build) -- so one directory slot and
+// one run answer both, and each look-up is paid for once (two scans pay twice: the second finds the lines in cache, but walks the
+// windows, the keys and the buckets again -- half of a trace's seeding time once the misses overlap).  Hits are the two scans' hits
+// in another order (findMaxFreq sorts them).  Returns false when the shortcut does not apply -- a consensus with letters outside
+// A C G T N, trims shorter than k - 1 (the reference then looks up shorter tail patterns), 16-bit window counters that would wrap
+// -- and the caller runs the two scans as they are.
+inline bool scanBothStrands(GenomeIndex const& idx, std::string const& consensus, uint16_t trimLeft, uint16_t trimRight, uint16_t kmer,
+                            std::vector<int64_t>& hitFwd, std::vector<int64_t>& hitRev, bool unique) {
+  const std::size_t S = consensus.size();
+  const uint32_t k = kmer;
+  if (k != idx.k || k < 1 || k > 32 || !idx.has_table()) return false;
+  if (S + k >= 65536u || (uint32_t)trimLeft + 1u < k || (uint32_t)trimRight + 1u < k) return false;
+  if (S <= (std::size_t)trimLeft + trimRight) return true;  // no window on either strand
+  const std::size_t p_lo = (std::size_t)trimLeft + 1u - k, p_hi = S - trimRight;  // windows p_lo .. p_hi - 1; forward: p >= trimLeft, reverse: p + k <= S - trimRight
+  const std::size_t nwin = p_hi - p_lo;
+  thread_local std::vector<uint64_t> keys;
+  thread_local std::vector<uint8_t> info;  // bit 0: a look-up (no N); bit 1: the forward k-mer is the flipped one of its run; bit 2: palindrome
+  keys.assign(nwin, 0);
+  info.assign(nwin, 0);
+  {
+    const uint64_t mask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const uint32_t top = 2 * (k - 1);
+    uint64_t fw = 0, rc = 0;
+    uint32_t run = 0;
+    for (std::size_t q = p_lo; q < p_hi - 1 + k; ++q) {
+      const char ch = consensus[q];
+      const int b = GenomeIndex::base_code(ch);
+      if (b < 0) {
+        if (ch != 'N') return false;
+        run = 0; fw = 0; rc = 0;
+      } else {
+        fw = ((fw << 2) | (uint64_t)b) & mask;
+        rc = (rc >> 2) | ((uint64_t)(3 - b) << top);
+        if (run < k) ++run;
+      }
+      if (q + 1 >= p_lo + k && run == k) {
+        const std::size_t w = q + 1 - k - p_lo;
+        keys[w] = rc < fw ? rc : fw;
+        info[w] = (uint8_t)(1u | (rc < fw ? 2u : 0u) | (rc == fw ? 4u : 0u));
+      }
+    }
+  }
+  static const std::size_t D = seed_prefetch_distance();  // as in scanSequence
+  const std::size_t fwd_from = (std::size_t)trimLeft - p_lo;  // first window the forward scan holds
+  const std::size_t rev_until = nwin >= k ? nwin - k + 1 : 0;  // windows [0, rev_until) are the reverse scan's
+  for (std::size_t i = 0; i < nwin + 2 * D; ++i) {
+    if (i < nwin && (info[i] & 1u)) idx.prefetch_slot_key(keys[i]);
+    if (i >= D && i - D < nwin && (info[i - D] & 1u)) idx.prefetch_run_key(keys[i - D]);
+    if (i < 2 * D) continue;
+    const std::size_t w = i - 2 * D;
+    if (!(info[w] & 1u)) continue;
+    const std::size_t p = p_lo + w;
+    idx.both_strands(keys[w], (info[w] & 2u) != 0, (info[w] & 4u) != 0, w >= fwd_from ? &hitFwd : nullptr, (int64_t)p,
+                     w < rev_until ? &hitRev : nullptr, (int64_t)(S - p - k), unique);
+  }
+  return true;
+}
+
 struct SeedConfig {  // the SageConfig / IndigoConfig fields getReferenceSlice reads
   uint16_t trimLeft = 50, trimRight = 50, kmer = 15, minKmerSupport = 3, maxindel = 1000;
 };
@@ -512,8 +630,12 @@ inline bool getReferenceSlice(SeedConfig const& c, GenomeIndex const& idx, std::
   for (int pass = 0; pass < 2 && !anchored; ++pass) {
     hitFwd.clear();
     hitRev.clear();
-    scanSequence(idx, consensus, c.trimLeft, c.trimRight, c.kmer, hitFwd, pass == 0);
-    scanSequence(idx, rv, c.trimRight, c.trimLeft, c.kmer, hitRev, pass == 0);
+    if (!scanBothStrands(idx, consensus, c.trimLeft, c.trimRight, c.kmer, hitFwd, hitRev, pass == 0)) {
+      hitFwd.clear();
+      hitRev.clear();
+      scanSequence(idx, consensus, c.trimLeft, c.trimRight, c.kmer, hitFwd, pass == 0);
+      scanSequence(idx, rv, c.trimRight, c.trimLeft, c.kmer, hitRev, pass == 0);
+    }
     const uint32_t freqFwd = findMaxFreq(hitFwd, bestFwd), freqRev = findMaxFreq(hitRev, bestRev);
     if (freqFwd >= c.minKmerSupport && freqFwd > 2 * freqRev) {
       rs.forward = true; rs.kmersupport = freqFwd; bestPos = bestFwd; anchored = true;

@@ -38,8 +38,8 @@ for k in range(nt):
     c = np.where(flip, (c + 1) % 4, c).astype(np.uint8)
     cons.append(lut[c].tobytes())
 np.savez(os.path.join(d, "c.npz"), cons=np.array(cons, dtype=object))
-for th in (16, 32, 64):
-    for D in ("4", "6", "8", "12"):
+for th in (16,):
+    for D in ("2", "3", "4", "5", "6", "8", "10"):
         for mapped in (None,):
             e = dict(os.environ, TRACY_AMD_SEED_DISTANCE=D)
             if mapped:

@@ -120,14 +120,14 @@ __global__ void s_orient_plan_kernel(SParams p, const SGeom* __restrict__ geom, 
   FrontDesc f{};
   f.flags = PAIR_SKIP;
   f.out = t;
-  uint64_t cells = 0, bytes = 0;
+  uint64_t cells = 0, bytes = 0, pcells = 0;
   const uint64_t full_cells = (uint64_t)G.mt * G.rn, pre_cells = (uint64_t)(G.mt < R ? G.mt : R) * G.rn, full_bytes = 24ull * G.mt + G.rn + 4;
   if (cls == 0u) {
     pa = s_stage1_desc(G, t, p.nt, g);
     pa.flags |= PAIR_KEEP_ROW;
-    cells += pre_cells;
+    pcells += pre_cells;
     if (p.exact) { fa = s_stage1_desc(G, t, p.nt, 1u - g); cells += full_cells; bytes += full_bytes; }
-    else { pb = s_stage1_desc(G, t, p.nt, 1u - g); cells += pre_cells; }
+    else { pb = s_stage1_desc(G, t, p.nt, 1u - g); pcells += pre_cells; }
     f.row_off = G.lr_off[g];
     f.a2_off = G.ref_off;
     f.tab_off = G.tab_off + G.tl + R;
@@ -147,8 +147,11 @@ __global__ void s_orient_plan_kernel(SParams p, const SGeom* __restrict__ geom, 
   } else {
     fa = s_stage1_desc(G, t, p.nt, g);
     pb = s_stage1_desc(G, t, p.nt, 1u - g);
-    cells += full_cells + pre_cells; bytes += full_bytes;
+    cells += full_cells; pcells += pre_cells; bytes += full_bytes;
   }
+  // the prefixes: part of the sweep launch, or -- in a launch of their own beside it -- of the pruned sweep they begin
+  if (p.split_prefix) { s_count(lc, SC_FRONT_CELLS, pcells); s_count(lc, SC_FRONT_BYTES, pcells ? (uint64_t)R + 5ull * G.rn : 0ull); }
+  else cells += pcells;
   full[G.full_a] = fa;
   full[G.full_b] = fb;
   pre[t] = pa;
@@ -706,22 +709,53 @@ int queue_orientation(tracyhip_ctx* ctx, const tracyhip_params& p, const SParams
   ap.pairs = sc.pre;
   ap.votes = nullptr;
   const uint32_t npre_all = (os.exact ? 1u : 2u) * nt;
-  bool pre_done = false;
-  for (const SweepClass& c : h.classes) {
-    DpArgs af = a;
-    af.pairs = sc.full + 2 * (size_t)c.lo;
-    TRY(timing_begin(ctx, TRACYHIP_TIMER_SCORE, 0, 0));
-    HIP_TRY(launch_gotoh_ckpt_front(c.K, af, 2 * (c.hi - c.lo), ap, pre_done ? 0u : npre_all, st));
+  // the pruned sweep of the voted strands: strips of 8 rows on c* +- 60, then the widest band one period holds for what failed (run_front)
+  auto front_tiers = [&]() -> int {
+    TRY(timing_begin(ctx, TRACYHIP_TIMER_FRONT, 0, 0));
+    int rc = front_tier(ctx, p, sc.fd, nt, os.d_qp, ctx->codes(), reinterpret_cast<const uint32_t*>(os.d_lastrow), 8, 60, h.max_rest, sc.fpairs1, sc.fo1, sc.fs1, sc.fe1, nullptr);
+    if (!rc) rc = front_tier(ctx, p, sc.fd, nt, os.d_qp, ctx->codes(), reinterpret_cast<const uint32_t*>(os.d_lastrow), kFrontK, kFrontHalfW, h.max_rest, sc.fpairs2, sc.fo2,
+                             sc.fs2, sc.fe2, sc.fo1);
+    if (rc) return rc;
     TRY(timing_end(ctx));
-    pre_done = true;
+    return TRACYHIP_OK;
+  };
+  if (ctx->b16_fork_ok && !ctx->knobs.no_fork) {
+    // Two strands, two streams.  The voted strand's chain -- its 128-row prefixes, then the band tiers below the kept row: launches
+    // of a few waves' depth each, which on their own last as long as their slowest wave -- runs beside the other strand's full
+    // sweeps, which fill the device for the whole stage anyway; the decision waits for both.  (The two write different rows of
+    // the row-m workspace and different score slots, as they do inside one launch.)
+    const B16Fork& fk = ctx->b16_fork;
+    HIP_TRY(hipEventRecord(fk.forked, st));
+    HIP_TRY(hipStreamWaitEvent(fk.side[0], fk.forked, 0));
+    ctx->stream = fk.side[0];  // (timers and front_tier queue on the context's stream)
+    // (the prefixes are not timed on their own: they begin with the sweeps and end inside them, and their cells stay credited to the
+    // sweep timer, whose interval covers both launches as it covered the one)
+    int rc = TRACYHIP_OK;
+    if (launch_gotoh_ckpt_front(h.classes[0].K, a, 0u, ap, npre_all, fk.side[0]) != hipSuccess) rc = set_error(TRACYHIP_ERR_HIP, "prefix launch failed");
+    if (!rc) rc = front_tiers();
+    ctx->stream = st;
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(fk.joined[0], fk.side[0]));
+    for (const SweepClass& c : h.classes) {
+      DpArgs af = a;
+      af.pairs = sc.full + 2 * (size_t)c.lo;
+      TRY(timing_begin(ctx, TRACYHIP_TIMER_SCORE, 0, 0));
+      HIP_TRY(launch_gotoh_ckpt_front(c.K, af, 2 * (c.hi - c.lo), ap, 0u, st));
+      TRY(timing_end(ctx));
+    }
+    HIP_TRY(hipStreamWaitEvent(st, fk.joined[0], 0));
+  } else {
+    bool pre_done = false;
+    for (const SweepClass& c : h.classes) {
+      DpArgs af = a;
+      af.pairs = sc.full + 2 * (size_t)c.lo;
+      TRY(timing_begin(ctx, TRACYHIP_TIMER_SCORE, 0, 0));
+      HIP_TRY(launch_gotoh_ckpt_front(c.K, af, 2 * (c.hi - c.lo), ap, pre_done ? 0u : npre_all, st));
+      TRY(timing_end(ctx));
+      pre_done = true;
+    }
+    TRY(front_tiers());
   }
-  // pruned sweep of the voted strands: strips of 8 rows on c* +- 60, then the widest band one period holds for what failed (run_front)
-  TRY(timing_begin(ctx, TRACYHIP_TIMER_FRONT, 0, 0));
-  int rc = front_tier(ctx, p, sc.fd, nt, os.d_qp, ctx->codes(), reinterpret_cast<const uint32_t*>(os.d_lastrow), 8, 60, h.max_rest, sc.fpairs1, sc.fo1, sc.fs1, sc.fe1, nullptr);
-  if (!rc) rc = front_tier(ctx, p, sc.fd, nt, os.d_qp, ctx->codes(), reinterpret_cast<const uint32_t*>(os.d_lastrow), kFrontK, kFrontHalfW, h.max_rest, sc.fpairs2, sc.fo2,
-                           sc.fs2, sc.fe2, sc.fo1);
-  if (rc) return rc;
-  TRY(timing_end(ctx));
   hipLaunchKernelGGL(s_orient_decide_kernel, g256, b256, 0, st, sp, sc.geom, sc.votes, sc.ub, sc.sc2, sc.fo1, sc.fs1, sc.fe1, sc.fo2, sc.fs2, sc.fe2, sc.tr, sc.re,
                      sc.dead, sc.cnt, os.desc_trim);
   hipLaunchKernelGGL(row_m_end_kernel, dim3(nt), dim3(64), 0, st, static_cast<const RowEndDesc*>(sc.re), static_cast<const int32_t*>(os.d_lastrow), p.go + p.ge, sc.ce);
@@ -937,6 +971,7 @@ int tracyhip::stream_align(tracyhip_ctx* ctx, const tracyhip_align_job* job, con
   SParams spm{};
   spm.match = p.match; spm.mismatch = p.mismatch; spm.go = p.go; spm.ge = p.ge; spm.nt = nt; spm.exact = exact ? 1u : 0u; spm.ncap = ncap - 8u;
   spm.trim_left = job->trim_left; spm.trim_right = job->trim_right; spm.use_votes = 1u;
+  spm.split_prefix = 0u;
 
   // ---- 1. orientation (sage.h:239-247) ----
   const int16_t* d_qp = static_cast<const int16_t*>(ctx->d_b16tab[2].p);
@@ -1597,6 +1632,7 @@ struct DecStream {
 
     spm.match = p.match; spm.mismatch = p.mismatch; spm.go = p.go; spm.ge = p.ge; spm.nt = nt; spm.exact = exact ? 1u : 0u; spm.ncap = ncap - 8u;
     spm.trim_left = TL; spm.trim_right = TR; spm.use_votes = 1u;
+    spm.split_prefix = 0u;
     spd.bext = z.bext;
     spd.best = (int32_t)std::max<int64_t>(std::max<int64_t>(p.match, p.mismatch), 0);
 

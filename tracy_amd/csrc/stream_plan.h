@@ -102,6 +102,7 @@ struct SParams {        // scoring + switches every planning kernel sees
   uint32_t ncap;        // longest sub-window the band launches staged LDS for
   uint32_t trim_left, trim_right;
   uint32_t use_votes;   // the full sweeps skip row m of the likely loser (DpArgs::votes)
+  uint32_t split_prefix;  // the voted strands' prefixes run in a launch of their own beside the full sweeps (timed and credited with the pruned sweep)
 };
 
 TR_HD int64_t s_abs64(int32_t x) { return x < 0 ? -(int64_t)x : (int64_t)x; }

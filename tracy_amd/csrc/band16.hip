@@ -172,14 +172,14 @@ hipError_t launch_band16_quad(int kind, const Band16Args& a, hipStream_t s) {
 
 hipError_t B16Fork::create() {
   hipError_t e;
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < kSide; ++i) {
     if ((e = hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&joined[i], hipEventDisableTiming)) != hipSuccess) return e;
   }
   return hipEventCreateWithFlags(&forked, hipEventDisableTiming);
 }
 void B16Fork::destroy() {
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < kSide; ++i) {
     if (side[i]) (void)hipStreamDestroy(side[i]);
     if (joined[i]) (void)hipEventDestroy(joined[i]);
     side[i] = nullptr; joined[i] = nullptr;

@@ -28,8 +28,9 @@ hipError_t launch_band16_multi(int kind, const Band16Args& a12, const Band16Args
 // launch lasts at least as long as one of its waves -- in a row they cost four of those, side by side the longest.  fork() makes the
 // side streams wait for what the main stream has queued, join() the main stream for them.
 struct B16Fork {
-  hipStream_t side[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t forked = nullptr, joined[3] = {nullptr, nullptr, nullptr};
+  static constexpr int kSide = 4;  // three for the lists of a band stage (and the voted strand's chain), one for work that runs beside whole stages
+  hipStream_t side[kSide] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t forked = nullptr, joined[kSide] = {nullptr, nullptr, nullptr, nullptr};
   hipError_t create();
   void destroy();
 };

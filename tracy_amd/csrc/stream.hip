@@ -1478,6 +1478,7 @@ struct DecStream {
   unsigned long long *hcnt = nullptr, *hbst = nullptr;
   uint32_t* hdead = nullptr;
   std::vector<uint32_t> dl;  // the traces the device could not give their tier
+  bool af_forked = false;    // allelicFraction is on a side stream (joined before the read-back)
 
   DecStream(tracyhip_ctx* c, const tracyhip_decompose_job* j, const tracyhip_params* q, int m, const tracyhip_decompose_result* o_, StreamHost& h_)
       : ctx(c), job(j), prm(q), mem(m), out(o_), kn(c->knobs), nt(j->ntraces), sp(j->profiles), sr(j->refs), bc(j->bc), dp(j->dprm), st(c->stream), p(*q),
@@ -1490,6 +1491,11 @@ struct DecStream {
   }
   // whatever happens once the stages are queued, the caller's basecalls in device memory are put back before the host-planned pipeline takes the call
   int give_up(int rc) {
+    if (rc != TRACYHIP_OK && af_forked) {  // (nothing of this call may still run when the caller -- or the host-planned pipeline -- takes the buffers back)
+      (void)hipStreamWaitEvent(st, ctx->b16_fork.joined[3], 0);
+      af_forked = false;
+      if (rc != kStreamNo || host) (void)ctx_sync(ctx);
+    }
     if (rc == kStreamNo && !host) {
       (void)hipMemcpyAsync(d_pri, A.pri_bak, z.bext, hipMemcpyDeviceToDevice, st);
       (void)hipMemcpyAsync(d_sec, A.sec_bak, z.bext, hipMemcpyDeviceToDevice, st);
@@ -1682,7 +1688,19 @@ struct DecStream {
       a.skip = sc.dead;
       TRY(launch_decompose(ctx, a, bpo, maxbc, 0, 0));
       TRY(launch_secdecomp(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sec, d_sd));
-      TRY(launch_allelic_fraction(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sd, TL, TR, d_fr, 18ull * std::accumulate(h.mf.begin(), h.mf.end(), 0ull)));
+      // allelicFraction feeds nothing but its own result (indigo.h:350): it runs beside the allele stages, which read the same
+      // decomposed basecalls and write elsewhere; the read-back waits for it
+      af_forked = ctx->b16_fork_ok && !ctx->knobs.no_fork;
+      if (af_forked) {
+        const B16Fork& fk = ctx->b16_fork;
+        HIP_TRY(hipEventRecord(fk.forked, st));
+        HIP_TRY(hipStreamWaitEvent(fk.side[3], fk.forked, 0));
+        ctx->stream = fk.side[3];
+      }
+      const int rc = launch_allelic_fraction(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sd, TL, TR, d_fr, 18ull * std::accumulate(h.mf.begin(), h.mf.end(), 0ull));
+      ctx->stream = st;
+      if (rc) return rc;
+      if (af_forked) HIP_TRY(hipEventRecord(ctx->b16_fork.joined[3], ctx->b16_fork.side[3]));
     }
     hipLaunchKernelGGL(s_status_kernel, g256, b256, 0, st, spm, sc.geom, o.score_trim, A.hst, A.len1, sc.dead, o.status, sc.cnt);
     HIP_TRY(hipGetLastError());
@@ -1761,6 +1779,7 @@ struct DecStream {
   // the one read-back: verdict words, counters, dead flags
   int read_back() {
     StreamCommon& sc = A.sc;
+    if (af_forked) HIP_TRY(hipStreamWaitEvent(st, ctx->b16_fork.joined[3], 0));
     // ---- the one read-back ----
     const size_t rb = sizeof(int32_t) * (kErrWords + 4) + sizeof(int32_t) * 4 + sizeof(unsigned long long) * (SC_COUNT + SB_COUNT * 8) + sizeof(uint32_t) * (size_t)nt;
     HIP_TRY(ctx->h_res.ensure(rb));
@@ -1884,8 +1903,8 @@ int tracyhip::stream_decompose(tracyhip_ctx* ctx, const tracyhip_decompose_job* 
   TRY(s.plan());
   TRY(s.bind());
   TRY(s.queue_trace_stages());    // 2., 3., then 1., 4., 5. (indigo.h:196-350)
-  TRY(s.queue_allele_stages());   // 6. (indigo.h:355-387)
-  TRY(s.read_back());             // the call's one synchronisation
+  if (int rc = s.queue_allele_stages()) return s.give_up(rc);  // 6. (indigo.h:355-387)
+  if (int rc = s.read_back()) return s.give_up(rc);            // the call's one synchronisation
   TRY(s.redo_dead_traces());
   return s.copy_back();
 }

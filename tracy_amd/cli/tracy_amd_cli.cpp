@@ -924,159 +924,187 @@ bool orient_wildtype(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<
 }
 
 // indigo.h:190-388 for every job sharing one (trimLeft, trimRight): the whole chain runs on the device
-bool decompose_group(Device& dev, SageConfig const& c, tracyhip_params const& prm, std::vector<Job*> const& jobs, uint32_t nthreads) {
-  PhaseClock pc;  // (on the calling thread: pack / device_call / unpack are wall seconds of the device stage)
-  tracyhip_ctx* ctx = dev.ctx;
-  const uint32_t nt = (uint32_t)jobs.size();
-  const bool wildtype = jobs[0]->rs.filetype == 2;  // groups never mix reference kinds
-  if (wildtype && !orient_wildtype(ctx, prm, jobs)) return false;
-  // the batch as packed payloads: offsets first, then every trace copied to its place by the host threads (10 000 traces are 1.9 GB
-  // of signal: grown by insert() they were copied several times over, by one thread)
-  std::vector<uint64_t> poff(nt), roff(nt), soff(nt), boff(nt), dcpoff(nt);
-  std::vector<uint32_t> plen(nt), rlen(nt), ns(nt), blen(nt);
-  const uint32_t dcap = 2u * c.maxindel + 2;
-  std::vector<uint64_t> ooff[3];
-  uint64_t ocap[3] = {0, 0, 0};
-  for (int k = 0; k < 3; ++k) ooff[k].resize(nt);
-  uint64_t ptot = 0, rtot = 0, stot = 0, btot = 0;
-  for (uint32_t i = 0; i < nt; ++i) {
-    Job& j = *jobs[i];
-    poff[i] = ptot; plen[i] = (uint32_t)j.full.cols; ptot += j.full.v.size();
-    roff[i] = rtot; rlen[i] = (uint32_t)j.fasta.size(); rtot += j.fasta.size();
-    soff[i] = stot; ns[i] = (uint32_t)j.tr.traceACGT[0].size(); stot += 4ull * ns[i];
-    boff[i] = btot; blen[i] = (uint32_t)j.bc.bcPos.size(); btot += blen[i];
-    dcpoff[i] = (uint64_t)i * dcap;
-    for (int k = 0; k < 3; ++k) {
-      ooff[k][i] = ocap[k];
-      ocap[k] += (uint64_t)blen[i] + (k < 2 ? rlen[i] : blen[i]);
-    }
-  }
+// One group of a block (same reference kind and trims) on its way through tracyhip_decompose_traces: pack() lays the batch out as
+// packed payloads and sizes the result arrays -- host work, done by the stage that prepares the block (for wildtype references by
+// the device stage, once the device has oriented them); run() is the call, the results back into the jobs and the alignment rows.
+struct DecomposeGroup {
+  std::vector<Job*> jobs;
+  uint32_t nt = 0;
+  bool wildtype = false, seeded = false, packed = false;
+  std::vector<uint64_t> poff, roff, soff, boff, dcpoff, ooff[3], wpoff;
+  std::vector<uint32_t> plen, rlen, ns, blen, sb[2], sl[2], rp[2], olen[3];
+  uint32_t dcap = 0;
+  uint64_t ocap[3] = {0, 0, 0}, btot = 0;
   struct Packed {
     std::unique_ptr<float[]> prof;
     std::unique_ptr<uint8_t[]> refs, pri, sec;
     std::unique_ptr<int32_t[]> sig, pos;
     float* pdata() { return prof.get(); }
-  } pk;
-  pk.prof.reset(new float[ptot ? ptot : 1]);
-  pk.refs.reset(new uint8_t[rtot ? rtot : 1]);
-  pk.pri.reset(new uint8_t[btot ? btot : 1]);
-  pk.sec.reset(new uint8_t[btot ? btot : 1]);
-  pk.sig.reset(new int32_t[stot ? stot : 1]);
-  pk.pos.reset(new int32_t[btot ? btot : 1]);
-  for_each_index(nt, nthreads, [&](uint32_t i) {
-    Job& j = *jobs[i];
-    if (!j.full.v.empty()) std::memcpy(pk.prof.get() + poff[i], j.full.v.data(), j.full.v.size() * sizeof(float));
-    if (!j.fasta.empty()) std::memcpy(pk.refs.get() + roff[i], j.fasta.data(), j.fasta.size());
-    for (int k = 0; k < 4; ++k) {  // (a channel shorter than the first one is padded with zeros, as before)
-      int32_t* dst = pk.sig.get() + soff[i] + (uint64_t)k * ns[i];
-      const std::vector<int32_t>& ch = j.tr.traceACGT[k];
-      const std::size_t have = std::min<std::size_t>(ch.size(), ns[i]);
-      if (have) std::memcpy(dst, ch.data(), have * sizeof(int32_t));
-      if (have < ns[i]) std::memset(dst + have, 0, (ns[i] - have) * sizeof(int32_t));
-    }
-    // (the three per-base arrays share bc_offset: shorter ones are an input error the library reports)
-    const std::size_t nb = blen[i];
-    if (nb) {
-      std::memcpy(pk.pos.get() + boff[i], j.bc.bcPos.data(), nb * sizeof(int32_t));
-      std::memcpy(pk.pri.get() + boff[i], j.bc.primary.data(), std::min<std::size_t>(nb, j.bc.primary.size()));
-      std::memcpy(pk.sec.get() + boff[i], j.bc.secondary.data(), std::min<std::size_t>(nb, j.bc.secondary.size()));
-    }
-  });
-  float* const prof_p = pk.prof.get();
-  uint8_t* const refs_p = pk.refs.get();
-  uint8_t* const pri_p = pk.pri.get();
-  uint8_t* const sec_p = pk.sec.get();
-  int32_t* const sig_p = pk.sig.get();
-  int32_t* const pos_p = pk.pos.get();
+  };
+  Packed pk;
+  uint8_t *pri_p = nullptr, *sec_p = nullptr;
   tracyhip_decompose_job job{};
-  job.ntraces = nt;
-  job.profiles = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, prof_p, poff.data(), plen.data(), nt};
-  job.bc = tracyhip_basecalls{nt, sig_p, soff.data(), ns.data(), pos_p, pri_p, sec_p, boff.data(), blen.data()};
-  job.refs = tracyhip_seqset{TRACYHIP_SEQ_CHAR, refs_p, roff.data(), rlen.data(), nt};
-  job.dprm = tracyhip_decomp_params{(int32_t)jobs[0]->trimLeft, (int32_t)jobs[0]->trimRight, (int32_t)c.maxindel, (int32_t)c.madc};
-  job.strand_by_certificate = 1;  // the orientation scores are not written anywhere (indigo.h:235-247 keeps only rs.forward)
-  const bool seeded = jobs[0]->rs.filetype == 0 || wildtype;  // the reference arrives oriented
-  std::vector<uint8_t> orient(nt);
-  for (uint32_t i = 0; i < nt; ++i) orient[i] = jobs[i]->rs.forward ? 1 : 0;
-  if (seeded) job.oriented = orient.data();
-  std::vector<float> wprof;
-  std::vector<uint64_t> wpoff(nt);
-  if (wildtype) {
-    for (uint32_t i = 0; i < nt; ++i) {
-      wpoff[i] = wprof.size();
-      wprof.insert(wprof.end(), jobs[i]->wt_fwd.v.begin(), jobs[i]->wt_fwd.v.end());
-    }
-    job.ref_profiles = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, wprof.data(), wpoff.data(), rlen.data(), nt};
-  }
-  std::vector<tracyhip_breakpoint> bp(nt);
-  std::vector<int32_t> status(nt), sf(nt), sr(nt), strim(nt), dci((size_t)nt * dcap), dce((size_t)nt * dcap);
-  std::vector<uint8_t> fwd(nt), sd(btot ? btot : 1);
-  std::vector<tracyhip_decomp_status> dst(nt);
-  std::vector<double> fr(2 * (size_t)nt);
-  std::vector<uint32_t> sb[2], sl[2], rp[2], olen[3];
-  std::vector<int32_t> sc[3];
-  std::vector<uint8_t> ops[3];
   tracyhip_decompose_result res{};
-  res.bp = bp.data(); res.status = status.data(); res.score_fwd = sf.data(); res.score_rev = sr.data(); res.forward = fwd.data();
-  res.score_trim = strim.data(); res.dcp_indel = dci.data(); res.dcp_err = dce.data(); res.dcp_offset = dcpoff.data();
-  res.dstatus = dst.data(); res.secdecomp = sd.data(); res.fractions = fr.data();
-  for (int k = 0; k < 3; ++k) {
-    if (k < 2) {
-      sb[k].resize(nt); sl[k].resize(nt); rp[k].resize(nt);
-      res.slice_begin[k] = sb[k].data(); res.slice_len[k] = sl[k].data(); res.ref_pos[k] = rp[k].data();
-    }
-    sc[k].resize(nt); olen[k].resize(nt); ops[k].resize(ocap[k] ? ocap[k] : 1);
-    res.score[k] = sc[k].data(); res.ops[k] = ops[k].data(); res.ops_offset[k] = ooff[k].data(); res.ops_len[k] = olen[k].data();
-  }
-  pc.lap(CpuPhases::PACK);
-  if (dev.decompose_traces(&job, &prm, &res) != TRACYHIP_OK) return gpu_fail("decompose");
-  pc.lap(CpuPhases::DEVICE_CALL);
-  struct UnpackLap { PhaseClock& pc; ~UnpackLap() { pc.lap(CpuPhases::UNPACK); } } unpack_lap{pc};
+  std::vector<uint8_t> orient, fwd, sd, ops[3];
+  std::vector<float> wprof;
+  std::vector<tracyhip_breakpoint> bp;
+  std::vector<int32_t> status, sf, sr, strim, dci, dce, sc[3];
+  std::vector<tracyhip_decomp_status> dst;
+  std::vector<double> fr;
 
-  std::vector<std::string> a1[3], a2[3];
-  for (int k = 0; k < 3; ++k) { a1[k].resize(nt); a2[k].resize(nt); }
-  for_each_index(nt, nthreads, [&](uint32_t i) {
-    Job& j = *jobs[i];
-    j.status = status[i];
-    j.dstatus = dst[i];
-    j.primary.assign(reinterpret_cast<char*>(pri_p) + boff[i], blen[i]);
-    j.secondary.assign(reinterpret_cast<char*>(sec_p) + boff[i], blen[i]);
-    j.secdecomp.assign(reinterpret_cast<char*>(sd.data()) + boff[i], blen[i]);
-    j.rs.forward = fwd[i] != 0;
-    j.rs.refslice = j.fasta;
-    if (!seeded && !j.rs.forward) reverseComplement(j.rs.refslice);
-    j.rs.pos = j.slice_start;
-    AlleleReport& r = j.rep;
-    r.bp.indelshift = bp[i].indelshift != 0;
-    r.bp.traceleft = bp[i].traceleft != 0;
-    r.bp.breakpoint = bp[i].breakpoint;
-    r.bp.bestDiff = bp[i].best_diff;
-    r.a1a2 = std::make_pair(fr[2 * i], fr[2 * i + 1]);
-    r.dcp.clear();
-    for (uint32_t k = 0; k < dst[i].dcp_n; ++k) r.dcp.emplace_back(dci[dcpoff[i] + k], dce[dcpoff[i] + k]);
-    const std::string p_t = trimmedSeq(j.primary, j.trimLeft, j.trimRight), s_t = trimmedSeq(j.secdecomp, j.trimLeft, j.trimRight);
-    ReferenceSlice* slot[2] = {&r.rs1, &r.rs2};
-    for (int k = 0; k < 2; ++k) {
-      *slot[k] = j.rs;
-      const bool usable = status[i] == 0;
-      slot[k]->refslice = usable ? j.rs.refslice.substr(sb[k][i], sl[k][i]) : std::string();
-      slot[k]->pos = usable ? j.slice_start + rp[k][i] : 0;
-      a1[k][i] = k == 0 ? p_t : s_t;
-      a2[k][i] = slot[k]->refslice;
+  explicit DecomposeGroup(std::vector<Job*> js) : jobs(std::move(js)), nt((uint32_t)jobs.size()), wildtype(jobs[0]->rs.filetype == 2) {}  // (groups never mix reference kinds)
+
+  void pack(SageConfig const& c, uint32_t nthreads) {
+    PhaseClock pc;
+    // the batch as packed payloads: offsets first, then every trace copied to its place by the host threads (10 000 traces are 1.9 GB
+    // of signal: grown by insert() they were copied several times over, by one thread)
+    for (auto* v : {&poff, &roff, &soff, &boff, &dcpoff}) v->assign(nt, 0);
+    for (auto* v : {&plen, &rlen, &ns, &blen}) v->assign(nt, 0);
+    dcap = 2u * c.maxindel + 2;
+    for (int k = 0; k < 3; ++k) ocap[k] = 0;
+    for (int k = 0; k < 3; ++k) ooff[k].resize(nt);
+    uint64_t ptot = 0, rtot = 0, stot = 0;
+    btot = 0;
+    for (uint32_t i = 0; i < nt; ++i) {
+      Job& j = *jobs[i];
+      poff[i] = ptot; plen[i] = (uint32_t)j.full.cols; ptot += j.full.v.size();
+      roff[i] = rtot; rlen[i] = (uint32_t)j.fasta.size(); rtot += j.fasta.size();
+      soff[i] = stot; ns[i] = (uint32_t)j.tr.traceACGT[0].size(); stot += 4ull * ns[i];
+      boff[i] = btot; blen[i] = (uint32_t)j.bc.bcPos.size(); btot += blen[i];
+      dcpoff[i] = (uint64_t)i * dcap;
+      for (int k = 0; k < 3; ++k) {
+        ooff[k][i] = ocap[k];
+        ocap[k] += (uint64_t)blen[i] + (k < 2 ? rlen[i] : blen[i]);
+      }
     }
-    a1[2][i] = p_t;
-    a2[2][i] = s_t;
-    r.a1Score = sc[0][i]; r.a2Score = sc[1][i]; r.a3Score = sc[2][i];
-    if (status[i] != 0)
-      for (int k = 0; k < 3; ++k) olen[k][i] = 0;
-  });
-  for (int k = 0; k < 3; ++k) {
-    std::vector<AlignRows> rows;
-    if (!rows_from_ops(ctx, a1[k], a2[k], ops[k], ooff[k], olen[k], rows, nthreads)) return false;
-    for_each_index(nt, nthreads, [&](uint32_t i) { (k == 0 ? jobs[i]->rep.align1 : k == 1 ? jobs[i]->rep.align2 : jobs[i]->rep.align3) = std::move(rows[i]); });
+    pk.prof.reset(new float[ptot ? ptot : 1]);
+    pk.refs.reset(new uint8_t[rtot ? rtot : 1]);
+    pk.pri.reset(new uint8_t[btot ? btot : 1]);
+    pk.sec.reset(new uint8_t[btot ? btot : 1]);
+    pk.sig.reset(new int32_t[stot ? stot : 1]);
+    pk.pos.reset(new int32_t[btot ? btot : 1]);
+    for_each_index(nt, nthreads, [&](uint32_t i) {
+      Job& j = *jobs[i];
+      if (!j.full.v.empty()) std::memcpy(pk.prof.get() + poff[i], j.full.v.data(), j.full.v.size() * sizeof(float));
+      if (!j.fasta.empty()) std::memcpy(pk.refs.get() + roff[i], j.fasta.data(), j.fasta.size());
+      for (int k = 0; k < 4; ++k) {  // (a channel shorter than the first one is padded with zeros, as before)
+        int32_t* dst = pk.sig.get() + soff[i] + (uint64_t)k * ns[i];
+        const std::vector<int32_t>& ch = j.tr.traceACGT[k];
+        const std::size_t have = std::min<std::size_t>(ch.size(), ns[i]);
+        if (have) std::memcpy(dst, ch.data(), have * sizeof(int32_t));
+        if (have < ns[i]) std::memset(dst + have, 0, (ns[i] - have) * sizeof(int32_t));
+      }
+      // (the three per-base arrays share bc_offset: shorter ones are an input error the library reports)
+      const std::size_t nb = blen[i];
+      if (nb) {
+        std::memcpy(pk.pos.get() + boff[i], j.bc.bcPos.data(), nb * sizeof(int32_t));
+        std::memcpy(pk.pri.get() + boff[i], j.bc.primary.data(), std::min<std::size_t>(nb, j.bc.primary.size()));
+        std::memcpy(pk.sec.get() + boff[i], j.bc.secondary.data(), std::min<std::size_t>(nb, j.bc.secondary.size()));
+      }
+    });
+    float* const prof_p = pk.prof.get();
+    uint8_t* const refs_p = pk.refs.get();
+    pri_p = pk.pri.get();
+    sec_p = pk.sec.get();
+    int32_t* const sig_p = pk.sig.get();
+    int32_t* const pos_p = pk.pos.get();
+    job = tracyhip_decompose_job{};
+    job.ntraces = nt;
+    job.profiles = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, prof_p, poff.data(), plen.data(), nt};
+    job.bc = tracyhip_basecalls{nt, sig_p, soff.data(), ns.data(), pos_p, pri_p, sec_p, boff.data(), blen.data()};
+    job.refs = tracyhip_seqset{TRACYHIP_SEQ_CHAR, refs_p, roff.data(), rlen.data(), nt};
+    job.dprm = tracyhip_decomp_params{(int32_t)jobs[0]->trimLeft, (int32_t)jobs[0]->trimRight, (int32_t)c.maxindel, (int32_t)c.madc};
+    job.strand_by_certificate = 1;  // the orientation scores are not written anywhere (indigo.h:235-247 keeps only rs.forward)
+    seeded = jobs[0]->rs.filetype == 0 || wildtype;  // the reference arrives oriented
+    orient.assign(nt, 0);
+    for (uint32_t i = 0; i < nt; ++i) orient[i] = jobs[i]->rs.forward ? 1 : 0;
+    if (seeded) job.oriented = orient.data();
+    wprof.clear();
+    wpoff.assign(nt, 0);
+    if (wildtype) {
+      for (uint32_t i = 0; i < nt; ++i) {
+        wpoff[i] = wprof.size();
+        wprof.insert(wprof.end(), jobs[i]->wt_fwd.v.begin(), jobs[i]->wt_fwd.v.end());
+      }
+      job.ref_profiles = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, wprof.data(), wpoff.data(), rlen.data(), nt};
+    }
+    bp.assign(nt, tracyhip_breakpoint{});
+    for (auto* v : {&status, &sf, &sr, &strim}) v->assign(nt, 0);
+    dci.assign((size_t)nt * dcap, 0); dce.assign((size_t)nt * dcap, 0);
+    fwd.assign(nt, 0); sd.assign(btot ? btot : 1, 0);
+    dst.assign(nt, tracyhip_decomp_status{});
+    fr.assign(2 * (size_t)nt, 0.0);
+    res = tracyhip_decompose_result{};
+    res.bp = bp.data(); res.status = status.data(); res.score_fwd = sf.data(); res.score_rev = sr.data(); res.forward = fwd.data();
+    res.score_trim = strim.data(); res.dcp_indel = dci.data(); res.dcp_err = dce.data(); res.dcp_offset = dcpoff.data();
+    res.dstatus = dst.data(); res.secdecomp = sd.data(); res.fractions = fr.data();
+    for (int k = 0; k < 3; ++k) {
+      if (k < 2) {
+        sb[k].resize(nt); sl[k].resize(nt); rp[k].resize(nt);
+        res.slice_begin[k] = sb[k].data(); res.slice_len[k] = sl[k].data(); res.ref_pos[k] = rp[k].data();
+      }
+      sc[k].resize(nt); olen[k].resize(nt); ops[k].resize(ocap[k] ? ocap[k] : 1);
+      res.score[k] = sc[k].data(); res.ops[k] = ops[k].data(); res.ops_offset[k] = ooff[k].data(); res.ops_len[k] = olen[k].data();
+    }
+    packed = true;
+    pc.lap(CpuPhases::PACK);
   }
-  return true;
-}
+
+  bool run(Device& dev, SageConfig const& c, tracyhip_params const& prm, uint32_t nthreads) {
+    PhaseClock pc;  // (on the calling thread: device_call / unpack are wall seconds of the device stage)
+    tracyhip_ctx* ctx = dev.ctx;
+    if (wildtype && !orient_wildtype(ctx, prm, jobs)) return false;
+    if (!packed) pack(c, nthreads);
+    pc.lap(CpuPhases::PACK);
+    if (dev.decompose_traces(&job, &prm, &res) != TRACYHIP_OK) return gpu_fail("decompose");
+    pc.lap(CpuPhases::DEVICE_CALL);
+    struct UnpackLap { PhaseClock& pc; ~UnpackLap() { pc.lap(CpuPhases::UNPACK); } } unpack_lap{pc};
+
+    std::vector<std::string> a1[3], a2[3];
+    for (int k = 0; k < 3; ++k) { a1[k].resize(nt); a2[k].resize(nt); }
+    for_each_index(nt, nthreads, [&](uint32_t i) {
+      Job& j = *jobs[i];
+      j.status = status[i];
+      j.dstatus = dst[i];
+      j.primary.assign(reinterpret_cast<char*>(pri_p) + boff[i], blen[i]);
+      j.secondary.assign(reinterpret_cast<char*>(sec_p) + boff[i], blen[i]);
+      j.secdecomp.assign(reinterpret_cast<char*>(sd.data()) + boff[i], blen[i]);
+      j.rs.forward = fwd[i] != 0;
+      j.rs.refslice = j.fasta;
+      if (!seeded && !j.rs.forward) reverseComplement(j.rs.refslice);
+      j.rs.pos = j.slice_start;
+      AlleleReport& r = j.rep;
+      r.bp.indelshift = bp[i].indelshift != 0;
+      r.bp.traceleft = bp[i].traceleft != 0;
+      r.bp.breakpoint = bp[i].breakpoint;
+      r.bp.bestDiff = bp[i].best_diff;
+      r.a1a2 = std::make_pair(fr[2 * i], fr[2 * i + 1]);
+      r.dcp.clear();
+      for (uint32_t k = 0; k < dst[i].dcp_n; ++k) r.dcp.emplace_back(dci[dcpoff[i] + k], dce[dcpoff[i] + k]);
+      const std::string p_t = trimmedSeq(j.primary, j.trimLeft, j.trimRight), s_t = trimmedSeq(j.secdecomp, j.trimLeft, j.trimRight);
+      ReferenceSlice* slot[2] = {&r.rs1, &r.rs2};
+      for (int k = 0; k < 2; ++k) {
+        *slot[k] = j.rs;
+        const bool usable = status[i] == 0;
+        slot[k]->refslice = usable ? j.rs.refslice.substr(sb[k][i], sl[k][i]) : std::string();
+        slot[k]->pos = usable ? j.slice_start + rp[k][i] : 0;
+        a1[k][i] = k == 0 ? p_t : s_t;
+        a2[k][i] = slot[k]->refslice;
+      }
+      a1[2][i] = p_t;
+      a2[2][i] = s_t;
+      r.a1Score = sc[0][i]; r.a2Score = sc[1][i]; r.a3Score = sc[2][i];
+      if (status[i] != 0)
+        for (int k = 0; k < 3; ++k) olen[k][i] = 0;
+    });
+    for (int k = 0; k < 3; ++k) {
+      std::vector<AlignRows> rows;
+      if (!rows_from_ops(ctx, a1[k], a2[k], ops[k], ooff[k], olen[k], rows, nthreads)) return false;
+      for_each_index(nt, nthreads, [&](uint32_t i) { (k == 0 ? jobs[i]->rep.align1 : k == 1 ? jobs[i]->rep.align2 : jobs[i]->rep.align3) = std::move(rows[i]); });
+    }
+    return true;
+  }
+};
 
 // variants of both alleles (indigo.h:393-421); reverse-strand traces are re-aligned as reverse complements
 bool call_variants(tracyhip_ctx* ctx, tracyhip_params const& prm, std::vector<Job*> const& jobs, uint32_t nthreads = 1) {
@@ -1201,6 +1229,8 @@ int decompose_main(int argc, char** argv) {
   std::atomic<int> failed(0);
   const uint32_t nthreads = batch ? (c.threads ? c.threads : usable_cores()) : 1;
   StageTimes times;
+  const uint32_t blk = std::max<uint32_t>(1u, batch ? block_size() : (uint32_t)jobs.size());
+  std::vector<std::vector<std::unique_ptr<DecomposeGroup>>> block_groups((jobs.size() + blk - 1) / blk + 1);
   int fatal = 0;
   std::vector<int> rcs(jobs.size(), 0);
   auto prep = [&](uint32_t lo, uint32_t hi) {
@@ -1214,6 +1244,16 @@ int decompose_main(int argc, char** argv) {
       } else {
         jobs[i].ok = true;
       }
+    }
+    // the block's groups (reference kind, trims), packed for the device here -- host work that the device stage would otherwise do
+    // between two calls, on the one thread every block has to pass
+    std::map<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>, std::vector<Job*>> groups;
+    for (uint32_t i = lo; i < hi; ++i)
+      if (jobs[i].ok) groups[std::make_pair((uint32_t)jobs[i].rs.filetype, std::make_pair(jobs[i].trimLeft, jobs[i].trimRight))].push_back(&jobs[i]);
+    std::vector<std::unique_ptr<DecomposeGroup>>& mine = block_groups[lo / blk];
+    for (auto& g : groups) {
+      mine.emplace_back(new DecomposeGroup(std::move(g.second)));
+      if (!mine.back()->wildtype) mine.back()->pack(c, nthreads);
     }
     times.add("read_basecall_profile_s", sw.seconds());
   };
@@ -1242,12 +1282,10 @@ int decompose_main(int argc, char** argv) {
       dev_open = true;
     }
     Stopwatch sw;
-    std::map<std::pair<uint32_t, std::pair<uint32_t, uint32_t>>, std::vector<Job*>> groups;  // (reference kind, trims)
-    for (uint32_t i = lo; i < hi; ++i)
-      if (jobs[i].ok) groups[std::make_pair((uint32_t)jobs[i].rs.filetype, std::make_pair(jobs[i].trimLeft, jobs[i].trimRight))].push_back(&jobs[i]);
     say("Alignment");
-    for (auto& g : groups)
-      if (!decompose_group(dev, c, prm, g.second, nthreads)) return false;
+    for (auto& g : block_groups[lo / blk])
+      if (!g->run(dev, c, prm, nthreads)) return false;
+    block_groups[lo / blk].clear();  // (the packed batch and the raw results: everything the writers need is in the jobs now)
     say("InDel Search");
     std::vector<Job*> good;
     for (uint32_t i = lo; i < hi; ++i) {
@@ -1266,12 +1304,16 @@ int decompose_main(int argc, char** argv) {
       good.push_back(&j);
     }
     say("Decompose Chromatogram");
-    for (Job* j : good) {
-      if (j->dstatus.kind == 1)
-        std::cout << "Complex mutation, decomposition: ins: " << j->dstatus.best_ins << ", del: " << j->dstatus.best_del
-                  << ", error: " << j->dstatus.best_fr << std::endl;
-      else if (j->dstatus.kind == 2)
-        std::cout << "No InDel detected, traverse the whole alignment." << std::endl;
+    {  // (the reference's per-trace lines, said for the block at once: a flush per line is a system call per trace)
+      std::ostringstream lines;
+      for (Job* j : good) {
+        if (j->dstatus.kind == 1)
+          lines << "Complex mutation, decomposition: ins: " << j->dstatus.best_ins << ", del: " << j->dstatus.best_del
+                << ", error: " << j->dstatus.best_fr << "\n";
+        else if (j->dstatus.kind == 2)
+          lines << "No InDel detected, traverse the whole alignment.\n";
+      }
+      std::cout << lines.str() << std::flush;
     }
     say("Estimate allelic fractions");
     say("Allele-specific alignments");
@@ -1295,7 +1337,7 @@ int decompose_main(int argc, char** argv) {
     });
     times.add("writers_s", sw.seconds());
   };
-  if (!run_blocks((uint32_t)jobs.size(), batch ? block_size() : (uint32_t)jobs.size(), prep, device, write)) return fatal ? fatal : -1;
+  if (!run_blocks((uint32_t)jobs.size(), blk, prep, device, write)) return fatal ? fatal : -1;
   times.report((uint32_t)jobs.size(), nthreads);
   std::cout << stamp() << "Done." << std::endl;
   if (batch) end_process(failed ? 2 : 0);

@@ -197,3 +197,36 @@ def test_decompose_ragged_batch_and_lanes(ctx):
         same_decompose(c, b, "ragged, two lanes")
     finally:
         ctx.set_lanes(1)
+
+
+@pytest.mark.parametrize("option", ["no_quads", "no_fork"])
+def test_quad_form_and_side_streams_change_nothing(ctx, option):
+    """narrow bands four lanes to a pair (band16.h, P = 4) and the stages that run side by side on the context's side streams (the two
+    strands of the orientation stage, the lists of a band stage, allelicFraction beside the allele stages) are ways of running the same
+    kernels over the same bands: every array equals the run without them"""
+    from tracy_amd import hostlib
+    refs, profs, rev = hostlib.synth_align(77, 160, 3500, 950, 2)
+    refl = [r.tobytes() for r in refs]
+    nd = 144
+    d = hostlib.synth_decompose_batch(515, nd, 2600, 900, 0, mix=1)
+    drefs = [d["refs"][i].tobytes() for i in range(nd)]
+
+    def run():
+        from tracy_amd import capi
+        a = ctx.align_traces(list(profs), refl, SC, 50, 50)
+        sa = ctx.last_call_stats()
+        hbc = capi.HostBaseCalls([d["signal"][i] for i in range(nd)], [d["bcpos"][i] for i in range(nd)],
+                                 [d["primary"][i].tobytes() for i in range(nd)], [d["secondary"][i].tobytes() for i in range(nd)])
+        b = ctx.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, drefs, SC)
+        return a, sa, b, ctx.last_call_stats()
+    a1, sa1, b1, sb1 = run()
+    ctx.set_option(option, 1)
+    try:
+        assert ctx.describe()[option] == "1"
+        a0, sa0, b0, sb0 = run()
+    finally:
+        ctx.set_option(option, 0)
+    assert sa1["stream_ordered"] == 1 and sb1["stream_ordered"] == 1 and sa0["stream_ordered"] == 1 and sb0["stream_ordered"] == 1
+    assert sa1["final_banded"] == sa0["final_banded"] and sb1["allele_banded"] == sb0["allele_banded"]
+    same_align(a1, a0, True, option)
+    same_decompose(b1, b0, option)

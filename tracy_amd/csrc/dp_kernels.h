@@ -310,6 +310,11 @@ struct SubProf {
       float x = __builtin_fmaf(a[i][0], e[0], fdelta);
 #pragma unroll
       for (int k = 1; k < NT; ++k) x = __builtin_fmaf(a[i][k], e[k], x);
+#if defined(TRACY_ABLATE_SCREEN)
+      // measurement only: the four fused multiply-adds alone -- no conversion, no test; results are wrong
+      sv[i] = float_bits(x) >> 20;
+      (void)two_delta;
+#else
       sv[i] = (int32_t)((uint32_t)(int32_t)x << shift);
 #if defined(__HIP_DEVICE_COMPILE__)
       const float g = __builtin_amdgcn_fractf(x) - two_delta;
@@ -317,6 +322,7 @@ struct SubProf {
       const float g = (x - __builtin_floorf(x)) - two_delta;
 #endif
       bad |= float_bits(g);
+#endif
     }
     return bad;
   }

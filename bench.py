@@ -423,6 +423,9 @@ def main():
                 "ms_per_step": {"score": round(sc["ms"] / steps, 3), "pruned_sweep_band": round(rl["front"]["ms"] / steps, 3), "preliminary_ends": round(og["ms"] / steps, 3),
                                 "band_traceback": round(bd["ms"] / steps, 3), "full_traceback": round(tr["ms"] / steps, 3),
                                 "walk": round(rl["walk"]["ms"] / steps, 3)},
+                "ms_per_step_note": ("event-to-event times of the kernel classes; with side streams on (tracyhip option no_fork = 0) the voted strand's chain -- its "
+                                     "128-row prefixes and the band tiers below them (pruned_sweep_band) -- runs beside the other strand's full sweeps (score): "
+                                     "the two intervals overlap, and the prefixes' cells stay credited to `score`, whose interval covers them"),
                 # the preliminary alignment (trimmed trace vs the whole window) is only trimmed from: its two ends come from an
                 # origin-tracking sweep over the sub-window the score sweep certifies (band traceback where that does not apply)
                 "preliminary_alignment": {"kernel": "band16_kernel<K,1> (origin-tracking sweep on the band the score allows inside the certified sub-window)" if og["ms"] > 0 else "gotoh_band_kernel<K,QP>",

@@ -310,6 +310,9 @@ class DecomposeLeg:
         roof = kernel_block(dom, names[dom][0], timers[dom], steps, ops_per_cell=names[dom][1], traffic_key=names[dom][2], traffic_glob=dec_glob)
         roof["share_of_kernel_time"] = round(timers[dom]["ms"] / tot_ms, 3) if tot_ms else None
         roof["ms_per_step"] = {k: round(timers[k]["ms"] / steps, 3) for k, _ in TIMERS if timers[k]["ms"] > 0}
+        roof["ms_per_step_note"] = ("event-to-event times of the kernel classes; with side streams on (tracyhip option no_fork = 0) allelic_fraction runs beside "
+                                    "the allele stages and the voted strand's chain (front) beside the sweeps (score), so these intervals overlap and their sum "
+                                    "exceeds the step; the step itself is `ms_per_step` of the line")
         roof["other_kernels"] = {k: {kk: vv for kk, vv in kernel_block(k, names[k][0], timers[k], steps, ops_per_cell=names[k][1], traffic_key=names[k][2], traffic_glob=dec_glob).items()
                                      if kk in ("kernel", "achieved", "frac", "traffic", "avg_launch_ms", "kernel_gcups", "valu", "algorithmic_bytes_per_launch")}
                                  for k in ("score", "front", "origin", "trace") if k in timers and k != dom and timers[k]["ms"] > 0}

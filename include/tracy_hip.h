@@ -116,6 +116,7 @@ int tracyhip_synchronize(tracyhip_ctx* ctx);
      no_band, no_band16, no_front, no_prefix, no_vote, no_origin, no_subwindow, no_prelim_origin, no_cq, no_fused_walk, no_cont16, no_quads, no_fork   "0" / "1"
      band_w  (half width of the certified band of the final alignments; -1 = from the preliminary alignment, 0 = whole matrices)
      ckpt_b  (steps between wavefront checkpoints, 32 .. 1024)      verbose  (one line per pipeline stage on stderr)
+     quad_tier_min  (stream-ordered pipelines: traces / alleles from which a pruned sweep gets its narrow first tier; default 32768)
    Every option selects another EXACT path (A/B measurements, tests of the fallback tiers); none changes a result.  Lanes inherit.
    TRACYHIP_HOST_THREADS, TRACYHIP_HOST_TIMERS, TRACYHIP_LDS_PAD and TRACYHIP_LDS_STAGE_LIMIT are per process (read once).
    tracyhip_describe writes the current settings as "name=value" lines (at most cap - 1 bytes) and returns the length needed. */

@@ -208,7 +208,7 @@ def run_band16(pairs, score, hfree, K, kind=0, strings=True):
     return out, err.value
 
 
-def run_front(profiles, refs, score, Kp, Kb, halfw, revcomp=None, want_rows=False, GLp=8, second_bound=True, cont16=False):
+def run_front(profiles, refs, score, Kp, Kb, halfw, revcomp=None, want_rows=False, GLp=8, second_bound=True, cont16=False, quad=False):
     """the pruned orientation sweep (front.h) of up to four traces: prefix rows kept, band placed, band swept below the kept row,
     certificate.  Returns per pair a dict(vmax, cstar, shift, ok, score, c_e[, row]) and the error word."""
     npairs = len(profiles)
@@ -230,7 +230,7 @@ def run_front(profiles, refs, score, Kp, Kb, halfw, revcomp=None, want_rows=Fals
     err = C.c_int32(0)
     ptr = lambda x: C.c_void_p(x.ctypes.data)
     rc = lib().emu_front(int(Kp), int(GLp), int(Kb), npairs, ptr(a1), ptr(a1_off), ptr(m), ptr(a2), ptr(a2_off), ptr(n), ptr(flags), int(halfw),
-                         *[int(x) for x in score], ptr(out), ptr(rows) if want_rows else None, C.c_uint64(cap), C.byref(err), C.c_int32((1 if second_bound else 0) | (2 if cont16 else 0)))  # (bit 1: the band on the 16-bit cells)
+                         *[int(x) for x in score], ptr(out), ptr(rows) if want_rows else None, C.c_uint64(cap), C.byref(err), C.c_int32((1 if second_bound else 0) | (2 if cont16 else 0) | (4 if quad else 0)))  # (bit 1: the band on the 16-bit cells; bit 2: in the quad form)
     assert rc == 0, rc
     res = []
     for i in range(npairs):

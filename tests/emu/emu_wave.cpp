@@ -595,8 +595,13 @@ int emu_front(int Kp, int GLp, int Kb, uint32_t npairs, const float* a1, const u
   a.err = errw; a.go = go; a.ge = ge; a.hfree = 1; a.code_cap = (nmax + 3u) & ~3u; a.row = rowp;
   {
     WaveShared sh;
-    sh.lds.assign(4u * a.code_cap + b16_table_bytes(Kb) + 4u * 2u * kB16RowCap * 4u + 64, 0);
+    const bool quad = (second_bound & 4) != 0;  // ... in the quad form (four lanes per pair, strip height 4, bands of at most 12 diagonals)
+    sh.lds.assign(std::max<uint32_t>(4u * a.code_cap + b16_table_bytes(Kb) + 4u * 2u * kB16RowCap * 4u, b16_cont_quad_lds(a.code_cap)) + 64, 0);
     const bool cont16 = (second_bound & 2) != 0;  // the band on the 16-bit cells (band16_cont16_body)
+    if (quad) {
+      if (Kb != 4 || 2 * halfw + 1 > 12) return -1;
+      sh.run([&](uint32_t l) { HostWave w{l, &sh}; band16_cont16_body<HostWave, 4, 4>(w, a, 0); });
+    } else
     switch (Kb + (cont16 ? 100 : 0)) {
       case 4: sh.run([&](uint32_t l) { HostWave w{l, &sh}; band16_body<HostWave, 4, 1, true>(w, a, 0); }); break;
       case 8: sh.run([&](uint32_t l) { HostWave w{l, &sh}; band16_body<HostWave, 8, 1, true>(w, a, 0); }); break;

@@ -212,3 +212,34 @@ def test_band_on_16_bit_cells_equals_the_tagged_form():
                 assert (b["score"], b["c_e"]) == (best, ce), (it, kind, b, best, ce)
                 certified += 1
     assert same > 50 and certified > 15, (same, certified)
+
+
+def test_quad_tier_of_the_pruned_sweep_equals_the_row_form():
+    """the narrow first tier (c* +- 5 on strips of four rows, four lanes per pair: band16_cont16_body P = 4) against the sixteen-lane
+    form on the same band: the same score, c_e and verdict for every pair, and the matrix's where the certificate holds"""
+    rng = random.Random(404)
+    same = certified = 0
+    for it in range(30):
+        Kp, Kb = 4, 4
+        GLp = rng.choice([8, 16])
+        R = GLp * Kp
+        halfw = rng.choice([2, 4, 5])
+        score = rng.choice([SC, SC, (5, -4, -10, -1), (2, -3, -5, -2)])
+        kinds = [rng.choice(["match", "match", "match", "indel", "noise"]) for _ in range(rng.randint(1, 4))]
+        cases = [make_case(rng, k, R, Kb) for k in kinds]
+        args = ([c[0] for c in cases], [c[1] for c in cases], score, Kp, Kb, halfw)
+        rows16, err0 = emu.run_front(*args, revcomp=[c[2] for c in cases], GLp=GLp, cont16=True)
+        quads, err1 = emu.run_front(*args, revcomp=[c[2] for c in cases], GLp=GLp, cont16=True, quad=True)
+        assert err0 == 0 and err1 == 0
+        for kind, (prof, given, rc, ref), a, b in zip(kinds, cases, rows16, quads):
+            if a["score"] <= -5000:
+                assert b["score"] <= -5000 and a["ok"] == b["ok"] == 0, (it, kind, a, b)
+                continue
+            assert (a["score"], a["c_e"], a["ok"], a["cstar"], a["shift"]) == (b["score"], b["c_e"], b["ok"], b["cstar"], b["shift"]), (it, kind, a, b)
+            same += 1
+            if b["ok"]:
+                q = emu.table_rows(prof, score)
+                _, best, ce = matrix(q, [CODE.get(ch, 5) for ch in ref], R, score)
+                assert (b["score"], b["c_e"]) == (best, ce), (it, kind, b, best, ce)
+                certified += 1
+    assert same > 40 and certified > 10, (same, certified)

@@ -199,6 +199,35 @@ def test_decompose_ragged_batch_and_lanes(ctx):
         ctx.set_lanes(1)
 
 
+def test_quad_tier_of_the_pruned_sweeps_changes_nothing(ctx):
+    """the narrow first tier of the pruned sweeps (c* +- 5, four lanes per pair; batches of 32 768 units and more by default) forced
+    on a small batch: what it certifies it certifies with the score and end the wide tiers find; every array equals the run without it"""
+    from tracy_amd import capi, hostlib
+    refs, profs, rev = hostlib.synth_align(78, 128, 3500, 950, 2)
+    refl = [r.tobytes() for r in refs]
+    nd = 128
+    d = hostlib.synth_decompose_batch(616, nd, 2600, 900, 0, mix=1)
+    drefs = [d["refs"][i].tobytes() for i in range(nd)]
+
+    def run():
+        a = ctx.align_traces(list(profs), refl, SC, 50, 50)
+        sa = ctx.last_call_stats()
+        hbc = capi.HostBaseCalls([d["signal"][i] for i in range(nd)], [d["bcpos"][i] for i in range(nd)],
+                                 [d["primary"][i].tobytes() for i in range(nd)], [d["secondary"][i].tobytes() for i in range(nd)])
+        return a, sa, ctx.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, drefs, SC), ctx.last_call_stats()
+    a0, sa0, b0, sb0 = run()
+    ctx.set_option("quad_tier_min", 0)
+    try:
+        assert ctx.describe()["quad_tier_min"] == "0"
+        a1, sa1, b1, sb1 = run()
+    finally:
+        ctx.set_option("quad_tier_min", 32768)
+    assert sa1["stream_ordered"] == 1 and sb1["stream_ordered"] == 1
+    assert sa1["pruned"] == sa0["pruned"] and sb1["allele_pruned"] == sb0["allele_pruned"], (sa0, sa1, sb0, sb1)
+    same_align(a1, a0, True, "quad tier")
+    same_decompose(b1, b0, "quad tier")
+
+
 @pytest.mark.parametrize("option", ["no_quads", "no_fork"])
 def test_quad_form_and_side_streams_change_nothing(ctx, option):
     """narrow bands four lanes to a pair (band16.h, P = 4) and the stages that run side by side on the context's side streams (the two

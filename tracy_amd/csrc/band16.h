@@ -59,6 +59,7 @@ struct Band16Args {
   const uint32_t* count;
 };
 constexpr uint32_t kB16RowCap = 200;  // CONT: row-R entries staged per pair (the window of strip 0 and the column before it)
+constexpr uint32_t kB16QuadRowCap = 24;  // ... of the quad form: a window of at most fifteen steps
 
 constexpr uint32_t kB16Codes = 6;
 TR_HD constexpr uint32_t b16_period(int K) { return 16u * ((uint32_t)K + 1u); }
@@ -87,6 +88,7 @@ TR_HD uint64_t b16_words(uint32_t m, uint32_t n, int K, int32_t dmin, int32_t dm
 TR_HD bool b16_narrow_ok(int32_t dmin, int32_t dmax) { return dmax >= dmin && b16_window(4, dmin, dmax) <= 3u * 5u; }
 TR_HD constexpr uint32_t b16_packed_row(uint32_t code_cap) { return ((code_cap + 1u) / 2u + 3u) & ~3u; }  // the quad form keeps two codes to a byte
 TR_HD constexpr uint32_t b16_quad_lds(uint32_t code_cap) { return 16u * b16_packed_row(code_cap) + b16_table_bytes(4); }  // LDS of a quad-form workgroup
+TR_HD constexpr uint32_t b16_cont_quad_lds(uint32_t code_cap) { return b16_quad_lds(code_cap) + 16u * 2u * kB16QuadRowCap * 4u; }
 // smallest strip height whose lanes are done with a strip before the next one is due (K + width <= 15 (K + 1)); 0: the band is too wide
 TR_HD int b16_pick_k(int32_t dmin, int32_t dmax) {
   if (dmax < dmin) return 0;
@@ -529,14 +531,21 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
 // as Hg = H + (go + ge), E, F as in score_step16g; the free trailing run of row m is a per-slot constant (rows are anchored at the
 // top here, so row m can be any slot of the last strip); table entries (scores << kTagShift) are turned into score - (go + ge) when a
 // lane copies the rows of its strip into LDS.  Same blocks, windows and hand-over as band16_body; score and c_e are the int32 form's.
-template <class W, int K>
+// P = 4: the quad form (band16_body) for the narrow first tier of the pruned sweeps -- sixteen pairs per workgroup, codes two to a
+// byte, kB16QuadRowCap entries of the kept row staged per pair.
+template <class W, int K, int P = 16>
 TR_HD void band16_cont16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   static_assert(K == 4 || K == 8 || K == 12, "strip heights of the band kernels");
+  static_assert(P == 16 || (P == 4 && K == 4), "a DPP row per pair, or a quad on strips of four rows");
   constexpr uint32_t KP = (uint32_t)K + 1u;
-  const uint32_t L = w.lane(), g = L >> 4, j = L & 15u;
-  const uint32_t pair_idx = wave_idx * 4u + g;
+  constexpr uint32_t NPW = 64u / (uint32_t)P;
+  constexpr uint32_t RC = P == 16 ? kB16RowCap : kB16QuadRowCap;  // kept-row entries staged per pair
+  constexpr bool PACKED = P == 4;
+  using Lanes = std::integral_constant<int, P>;
+  const uint32_t L = w.lane(), g = L / (uint32_t)P, j = L % (uint32_t)P;
+  const uint32_t pair_idx = wave_idx * NPW + g;
   const uint32_t npairs = a.count ? *a.count : a.npairs;
-  if (wave_idx * 4u >= npairs) return;
+  if (wave_idx * NPW >= npairs) return;
   bool have = pair_idx < npairs;
   PairDesc d{};
   if (have) d = a.pairs[a.index ? a.index[pair_idx] : pair_idx];
@@ -554,18 +563,27 @@ TR_HD void band16_cont16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   const uint32_t rbase = (uint32_t)d.bits_off;  // rows above the pair's first one
   auto edge_g = [&](uint32_t r) -> int32_t { return edge_value(false, go, ge, (int32_t)(r + rbase)) + goe; };  // H(r, 0) + goe
 
-  uint8_t* lcodes = reinterpret_cast<uint8_t*>(w.lds()) + g * a.code_cap;
-  int16_t* tab = reinterpret_cast<int16_t*>(w.lds() + 4u * a.code_cap) + L;
+  const uint32_t code_row = PACKED ? b16_packed_row(a.code_cap) : a.code_cap;
+  uint8_t* lcodes = reinterpret_cast<uint8_t*>(w.lds()) + g * code_row;
+  int16_t* tab = reinterpret_cast<int16_t*>(w.lds() + NPW * code_row) + L;
   if (have) {
     const uint8_t* src = a.codes + d.a2_off;
-    for (uint32_t i = j; i < n; i += 16) lcodes[i] = src[rcflag ? n - 1u - i : i];
+    if (!PACKED) {
+      for (uint32_t i = j; i < n; i += P) lcodes[i] = src[rcflag ? n - 1u - i : i];
+    } else {
+      for (uint32_t i = j; 2u * i < n; i += P) {
+        const uint32_t c0 = 2u * i, c1 = c0 + 1u < n ? c0 + 1u : c0;
+        const uint32_t lo = src[rcflag ? n - 1u - c0 : c0], hi = src[rcflag ? n - 1u - c1 : c1];
+        lcodes[i] = (uint8_t)(lo | (hi << 4));
+      }
+    }
   }
   // {Hg, F} of row R for the columns strip 0 sweeps and the one before them: the kept row holds exactly these halves
-  int32_t* lrow = reinterpret_cast<int32_t*>(w.lds() + 4u * a.code_cap + b16_table_bytes(K)) + g * (2u * kB16RowCap);
+  int32_t* lrow = reinterpret_cast<int32_t*>(w.lds() + NPW * code_row + b16_table_bytes(K)) + g * (2u * RC);
   const int32_t crow0 = dmin;  // column of lrow[0]: b16_first_col(0) - 1
   if (have) {
     const uint32_t* src = a.row + d.lastrow_off;
-    for (uint32_t i = j; i < kB16RowCap; i += 16) {
+    for (uint32_t i = j; i < RC; i += P) {
       const int32_t cc = crow0 + (int32_t)i;
       int32_t hh = neg, ff = neg;
       if (cc == 0) hh = edge_g(0);
@@ -580,14 +598,18 @@ TR_HD void band16_cont16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   }
   w.sync();
   const uint32_t nclamp = n ? n - 1u : 0u;
-  auto code_at = [&](uint32_t cm1) -> uint32_t { return lcodes[cm1 < nclamp ? cm1 : nclamp]; };
+  auto code_at = [&](uint32_t cm1) -> uint32_t {
+    const uint32_t i = cm1 < nclamp ? cm1 : nclamp;
+    if (!PACKED) return lcodes[i];
+    return ((uint32_t)lcodes[i >> 1] >> ((i & 1u) << 2)) & 15u;
+  };
 
   uint32_t B_end = 0, b_last = ~0u;
   {
     const uint32_t mine = have ? (NS - 1u) + NB_last : 0u;
     const uint32_t lastbeg = have ? NS - 1u : ~0u;
-    for (uint32_t q = 0; q < 4; ++q) {
-      const uint32_t x = w.bcast(mine, q * 16u), y = w.bcast(lastbeg, q * 16u);
+    for (uint32_t q = 0; q < NPW; ++q) {
+      const uint32_t x = w.bcast(mine, q * (uint32_t)P), y = w.bcast(lastbeg, q * (uint32_t)P);
       B_end = x > B_end ? x : B_end;
       b_last = y < b_last ? y : b_last;
     }
@@ -618,7 +640,7 @@ TR_HD void band16_cont16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
 
   auto block = [&](uint32_t b, auto first) {
     constexpr bool FIRST = decltype(first)::value;
-    if (j == (b & 15u) && have && b < NS) {  // ---- begin strip b ----
+    if (j == b % (uint32_t)P && have && b < NS) {  // ---- begin strip b ----
       live = true;
       s_cur = b;
       const uint32_t r0 = b * (uint32_t)K;
@@ -648,19 +670,19 @@ TR_HD void band16_cont16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
         }
       }
       raw_next = code_at(cm1);
-      if (b + 16u < NS) prefetch(b + 16u);
+      if (b + (uint32_t)P < NS) prefetch(b + (uint32_t)P);
     }
 #pragma unroll
     for (uint32_t k = 0; k < KP; ++k) {
-      int32_t up_h = w.rot(bot_h, std::integral_constant<int, 16>{});
-      int32_t up_f = w.rot(bot_f, std::integral_constant<int, 16>{});
+      int32_t up_h = w.rot(bot_h, Lanes{});
+      int32_t up_f = w.rot(bot_f, Lanes{});
       if (FIRST) {
         if (live && s_cur == 0) {
           const int32_t c = (int32_t)cm1 + 1;
-          const uint32_t i = (uint32_t)(c - crow0) < kB16RowCap ? (uint32_t)(c - crow0) : kB16RowCap - 1u;
+          const uint32_t i = (uint32_t)(c - crow0) < RC ? (uint32_t)(c - crow0) : RC - 1u;
           up_h = lrow[2u * i];
           up_f = lrow[2u * i + 1u];
-          if ((uint32_t)(c - crow0) >= kB16RowCap) { up_h = neg; up_f = neg; }
+          if ((uint32_t)(c - crow0) >= RC) { up_h = neg; up_f = neg; }
         }
       }
       const uint32_t raw = raw_next;
@@ -690,10 +712,10 @@ TR_HD void band16_cont16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
     if (live && --left == 0u) { live = false; bot_h = neg; bot_f = neg; }
   };
   uint32_t b = 0;
-  for (; b < 16u && b < B_end; ++b) block(b, std::true_type{});
+  for (; b < (uint32_t)P && b < B_end; ++b) block(b, std::true_type{});
   for (; b < B_end; ++b) block(b, std::false_type{});
 
-  if (have && j == ((NS - 1u) & 15u)) {
+  if (have && j == (NS - 1u) % (uint32_t)P) {
     int32_t hv = 0;
 #pragma unroll
     for (int i = 0; i < K; ++i)

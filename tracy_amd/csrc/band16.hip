@@ -78,6 +78,12 @@ __global__ __launch_bounds__(64) void band16_cont16_kernel(Band16Args a) {
   band16_cont16_body<DeviceWave16, K>(w, a, blockIdx.x);
 }
 
+// the narrow first tier of the pruned sweeps: strips of four rows, four lanes per pair
+__global__ __launch_bounds__(64) void band16_cont16_quad_kernel(Band16Args a) {
+  DeviceWave16 w;
+  band16_cont16_body<DeviceWave16, 4, 4>(w, a, blockIdx.x);
+}
+
 // front.h: one wave per pair
 // prev (or null): the verdicts of an earlier, narrower tier over the same descriptors -- what certified there is an empty slot here
 __global__ __launch_bounds__(64) void front_place_kernel(const FrontDesc* __restrict__ desc, const uint32_t* __restrict__ row, int32_t goe, int32_t halfw,
@@ -223,6 +229,12 @@ hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Ar
   if ((e = launch_band16(4, kind, a4, s)) != hipSuccess) return e;   // (the usual strip height first: the other two are mostly empty grids)
   if ((e = launch_band16(8, kind, a8, s)) != hipSuccess) return e;
   return launch_band16(12, kind, a12, s);
+}
+
+hipError_t launch_band16_cont_quad(const Band16Args& a, hipStream_t s) {
+  if (a.npairs == 0) return hipSuccess;
+  hipLaunchKernelGGL(band16_cont16_quad_kernel, dim3((a.npairs + 15u) / 16u), dim3(64), b16_cont_quad_lds(a.code_cap), s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s, bool narrow) {

@@ -41,6 +41,8 @@ hipError_t launch_band16_quad(int kind, const Band16Args& a, hipStream_t s);
 // the sweep below a stored prefix row (Band16Args::row; K = 8 or 12), and the two kernels of front.h around it
 // narrow: every DP value of the launch fits int16 (narrow_ok for the tallest pair, rows above the stored one included): the 16-bit cells
 hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s, bool narrow = false);
+// ... on 16-bit cells in the quad form (strip height 4, bands of at most 12 diagonals: b16_narrow_ok)
+hipError_t launch_band16_cont_quad(const Band16Args& a, hipStream_t s);
 struct FrontDesc;
 struct FrontOut;
 // d_prev (or null): verdicts of an earlier tier over the same descriptors; what certified there is skipped

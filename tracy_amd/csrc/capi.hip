@@ -281,6 +281,12 @@ bool knobs_set(CtxKnobs& k, const char* name, const char* value) {
     k.band_w = v < 0 ? -1 : (int32_t)std::min<long>(4096, v);  // (widths the band forms cannot hold leave the pair on the whole matrix)
     return true;
   }
+  if (same_name(name, "quad_tier_min")) {
+    const long v = atol(value);
+    if (v < 0) return false;
+    k.quad_tier_min = (uint32_t)std::min<long>(v, 0x7fffffffl);
+    return true;
+  }
   if (same_name(name, "ckpt_b")) {
     const long v = atol(value);
     if (v < 32 || v > 1024) return false;
@@ -304,12 +310,14 @@ void knobs_from_env(CtxKnobs& k) {
   if (getenv("TRACYHIP_HOST_TIMERS")) k.verbose = true;
   if (const char* e = getenv("TRACYHIP_BAND_W")) knobs_set(k, "band_w", e);
   if (const char* e = getenv("TRACYHIP_CKPT_B")) knobs_set(k, "ckpt_b", e);
+  if (const char* e = getenv("TRACYHIP_QUAD_TIER_MIN")) knobs_set(k, "quad_tier_min", e);
 }
 std::string knobs_describe(const CtxKnobs& k) {
   std::string s;
   for (const KnobField& f : kKnobFlags) { s += f.name; s += k.*(f.flag) ? "=1\n" : "=0\n"; }
   s += "band_w=" + std::to_string(k.band_w) + "\n";
   s += "ckpt_b=" + std::to_string(k.ckpt_b) + "\n";
+  s += "quad_tier_min=" + std::to_string(k.quad_tier_min) + "\n";
   s += "host_threads=" + std::to_string(host_pool_threads()) + "\n";
   return s;
 }

@@ -60,7 +60,8 @@ struct CtxKnobs {
   bool verbose = false;           // one line per pipeline stage on stderr: how many pairs took which tier (TRACYHIP_HOST_TIMERS sets it too)
   int32_t band_w = -1;            // half width of the certified band of the final alignments: -1 = from the preliminary alignment (default),
                                   // 0 = whole matrices, else [1, 4096]
-  uint32_t ckpt_b = 256;          // steps between wavefront checkpoints [32, 1024]
+  uint32_t ckpt_b = 256;
+  uint32_t quad_tier_min = 32768;  // stream-ordered pipelines: units (traces, or alleles) from which the pruned sweeps get their narrow quad tier          // steps between wavefront checkpoints [32, 1024]
 };
 void knobs_from_env(CtxKnobs& k);
 // name without the TRACYHIP_ prefix, any case; false: no such option / bad value

@@ -497,11 +497,11 @@ struct StreamCommon {  // device arrays of the orientation stage + preliminary a
   uint32_t* votes;
   int32_t *ub, *ub1, *top_trim, *top_full;
   int32_t* sc2;
-  PairDesc *full, *pre, *fpairs1, *fpairs2, *cand;
+  PairDesc *full, *pre, *fpairs0, *fpairs1, *fpairs2, *cand;
   FrontDesc* fd;
-  FrontOut *fo1, *fo2;
-  int32_t *fs1, *fs2;
-  uint32_t *fe1, *fe2;
+  FrontOut *fo0, *fo1, *fo2;
+  int32_t *fs0, *fs1, *fs2;
+  uint32_t *fe0, *fe1, *fe2;
   STrace* tr;
   RowEndDesc* re;
   uint32_t* ce;
@@ -528,14 +528,18 @@ struct StreamCommon {  // device arrays of the orientation stage + preliminary a
     sc2 = a.take<int32_t>(2 * (size_t)nt);
     full = a.take<PairDesc>(2 * (size_t)nt);
     pre = a.take<PairDesc>(std::max<size_t>((exact ? 1 : 2) * (size_t)nt, nunits));  // (`tracy decompose` lays the allele prefixes out here later)
+    fpairs0 = a.take<PairDesc>(nunits);
     fpairs1 = a.take<PairDesc>(nunits);
     fpairs2 = a.take<PairDesc>(nunits);
     cand = a.take<PairDesc>(nunits);
     fd = a.take<FrontDesc>(nunits);
+    fo0 = a.take<FrontOut>(nunits);
     fo1 = a.take<FrontOut>(nunits);
     fo2 = a.take<FrontOut>(nunits);
+    fs0 = a.take<int32_t>(nunits);
     fs1 = a.take<int32_t>(nunits);
     fs2 = a.take<int32_t>(nunits);
+    fe0 = a.take<uint32_t>(2 * (size_t)nunits);
     fe1 = a.take<uint32_t>(2 * (size_t)nunits);
     fe2 = a.take<uint32_t>(2 * (size_t)nunits);
     tr = a.take<STrace>(nt);
@@ -618,6 +622,7 @@ DpArgs sweep_args(tracyhip_ctx* ctx, const tracyhip_params& p, const void* d_a1,
 }
 
 // one tier of the pruned sweep over fixed slots: place, band below the kept row, certify (capi.hip run_front_once)
+// KB = 0: the quad form (strips of four rows, four lanes per pair) -- the narrow tier ahead of the others
 int front_tier(tracyhip_ctx* ctx, const tracyhip_params& p, const FrontDesc* fd, uint32_t n, const int16_t* d_qp, const uint8_t* d_codes, const uint32_t* d_row,
                int KB, int32_t halfw, uint32_t max_rest, PairDesc* pairs, FrontOut* fo, int32_t* fs, uint32_t* fe, const FrontOut* prev) {
   hipStream_t st = ctx->stream;
@@ -625,11 +630,52 @@ int front_tier(tracyhip_ctx* ctx, const tracyhip_params& p, const FrontDesc* fd,
   a.pairs = pairs; a.npairs = n; a.qp = d_qp; a.codes = d_codes; a.scores = fs; a.ends = fe;
   a.err = static_cast<int32_t*>(ctx->d_err.p); a.go = p.go; a.ge = p.ge; a.hfree = 1; a.row = d_row;
   a.code_cap = (max_rest + 2u * (uint32_t)halfw + 16u) & ~3u;  // front_place_body: a sub-window is at most m_rest + 2 halfw + 2 columns
-  if (4ull * a.code_cap + b16_table_bytes(KB) + 32ull * kB16RowCap > 64u * 1024u) return kStreamNo;
+  if (KB == 0) {
+    if (b16_cont_quad_lds(a.code_cap) > 64u * 1024u) return kStreamNo;
+  } else if (4ull * a.code_cap + b16_table_bytes(KB) + 32ull * kB16RowCap > 64u * 1024u) return kStreamNo;
   HIP_TRY(launch_front_place(fd, n, d_row, p.go + p.ge, halfw, pairs, fo, st, prev));
-  HIP_TRY(launch_band16_cont(KB, a, st, !ctx->knobs.no_cont16));
+  if (KB == 0) HIP_TRY(launch_band16_cont_quad(a, st));
+  else HIP_TRY(launch_band16_cont(KB, a, st, !ctx->knobs.no_cont16));
   HIP_TRY(launch_front_certify(fd, n, d_row, p.go, p.ge, halfw, fs, fe, fo, st, prev));
   return TRACYHIP_OK;
+}
+
+// what the narrow tier certified goes into the first wide tier's slots (which skipped it): everything after reads two tiers
+__global__ void s_front_fold_kernel(uint32_t n, const FrontOut* __restrict__ fo0, const int32_t* __restrict__ fs0, const uint32_t* __restrict__ fe0,
+                                    FrontOut* __restrict__ fo1, int32_t* __restrict__ fs1, uint32_t* __restrict__ fe1) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !fo0[i].ok) return;
+  fo1[i] = fo0[i];
+  fs1[i] = fs0[i];
+  fe1[2 * i] = fe0[2 * i];
+  fe1[2 * i + 1] = fe0[2 * i + 1];
+}
+int front_tier(tracyhip_ctx* ctx, const tracyhip_params& p, const FrontDesc* fd, uint32_t n, const int16_t* d_qp, const uint8_t* d_codes, const uint32_t* d_row,
+               int KB, int32_t halfw, uint32_t max_rest, PairDesc* pairs, FrontOut* fo, int32_t* fs, uint32_t* fe, const FrontOut* prev);
+int front_tiers_run_wide(tracyhip_ctx* ctx, const tracyhip_params& p, StreamCommon& sc, uint32_t n, const int16_t* d_qp, const uint8_t* d_codes,
+                         const uint32_t* d_row, uint32_t max_rest, bool after_quads) {
+  int rc = front_tier(ctx, p, sc.fd, n, d_qp, d_codes, d_row, 8, 60, max_rest, sc.fpairs1, sc.fo1, sc.fs1, sc.fe1, after_quads ? sc.fo0 : nullptr);
+  if (rc) return rc;
+  if (after_quads) {
+    hipLaunchKernelGGL(s_front_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, sc.fo0, sc.fs0, sc.fe0, sc.fo1, sc.fs1, sc.fe1);
+    HIP_TRY(hipGetLastError());
+  }
+  return front_tier(ctx, p, sc.fd, n, d_qp, d_codes, d_row, kFrontK, kFrontHalfW, max_rest, sc.fpairs2, sc.fo2, sc.fs2, sc.fe2, sc.fo1);
+}
+constexpr int32_t kQuadHalfW = 5;  // c* +- 5: eleven diagonals, a window of three blocks of strip height 4 (b16_narrow_ok)
+
+// the tiers of a pruned sweep over `n` units: the quad tier (a trace that loses less than |ge| (5 + 1) below the kept row certifies
+// there, at a quarter of the lanes), strips of 8 rows on c* +- 60 for the rest, then the widest band one period holds (run_front)
+int front_tiers_run(tracyhip_ctx* ctx, const tracyhip_params& p, StreamCommon& sc, uint32_t n, const int16_t* d_qp, const uint8_t* d_codes, const uint32_t* d_row,
+                    uint32_t max_rest) {
+  // (a tier is three launches of a wave's depth each: worth their latency where the wide tier's launch is long -- 100 000 units
+  // -2.5 ms, 12 500 units +0.3 ms measured)
+  const bool quads = !ctx->knobs.no_quads && n >= ctx->knobs.quad_tier_min;
+  int rc = TRACYHIP_OK;
+  if (quads) rc = front_tier(ctx, p, sc.fd, n, d_qp, d_codes, d_row, 0, kQuadHalfW, max_rest, sc.fpairs0, sc.fo0, sc.fs0, sc.fe0, nullptr);
+  if (rc == kStreamNo && quads) return front_tiers_run_wide(ctx, p, sc, n, d_qp, d_codes, d_row, max_rest, false);
+  if (rc) return rc;
+  return front_tiers_run_wide(ctx, p, sc, n, d_qp, d_codes, d_row, max_rest, quads);
 }
 
 // a band launch over the candidates of `n` units: lists per strip height (scan), the three heights (sizes read on the device)
@@ -712,9 +758,7 @@ int queue_orientation(tracyhip_ctx* ctx, const tracyhip_params& p, const SParams
   // the pruned sweep of the voted strands: strips of 8 rows on c* +- 60, then the widest band one period holds for what failed (run_front)
   auto front_tiers = [&]() -> int {
     TRY(timing_begin(ctx, TRACYHIP_TIMER_FRONT, 0, 0));
-    int rc = front_tier(ctx, p, sc.fd, nt, os.d_qp, ctx->codes(), reinterpret_cast<const uint32_t*>(os.d_lastrow), 8, 60, h.max_rest, sc.fpairs1, sc.fo1, sc.fs1, sc.fe1, nullptr);
-    if (!rc) rc = front_tier(ctx, p, sc.fd, nt, os.d_qp, ctx->codes(), reinterpret_cast<const uint32_t*>(os.d_lastrow), kFrontK, kFrontHalfW, h.max_rest, sc.fpairs2, sc.fo2,
-                             sc.fs2, sc.fe2, sc.fo1);
+    const int rc = front_tiers_run(ctx, p, sc, nt, os.d_qp, ctx->codes(), reinterpret_cast<const uint32_t*>(os.d_lastrow), h.max_rest);
     if (rc) return rc;
     TRY(timing_end(ctx));
     return TRACYHIP_OK;
@@ -734,8 +778,11 @@ int queue_orientation(tracyhip_ctx* ctx, const tracyhip_params& p, const SParams
     if (launch_gotoh_ckpt_front(h.classes[0].K, a, 0u, ap, npre_all, fk.side[0]) != hipSuccess) rc = set_error(TRACYHIP_ERR_HIP, "prefix launch failed");
     if (!rc) rc = front_tiers();
     ctx->stream = st;
-    if (rc) return rc;
     HIP_TRY(hipEventRecord(fk.joined[0], fk.side[0]));
+    if (rc) {  // (whoever takes the call from here finds nothing of it running beside the call's stream)
+      HIP_TRY(hipStreamWaitEvent(st, fk.joined[0], 0));
+      return rc;
+    }
     for (const SweepClass& c : h.classes) {
       DpArgs af = a;
       af.pairs = sc.full + 2 * (size_t)c.lo;
@@ -1747,9 +1794,7 @@ struct DecStream {
     }
     TRY(timing_begin(ctx, TRACYHIP_TIMER_FRONT, 0, 0));
     {
-      int rc = front_tier(ctx, p, sc.fd, 2 * nt, d_aqp, d_cq_ref, reinterpret_cast<const uint32_t*>(d_lastrow), 8, 60, max_arest, sc.fpairs1, sc.fo1, sc.fs1, sc.fe1, nullptr);
-      if (!rc) rc = front_tier(ctx, p, sc.fd, 2 * nt, d_aqp, d_cq_ref, reinterpret_cast<const uint32_t*>(d_lastrow), kFrontK, kFrontHalfW, max_arest, sc.fpairs2, sc.fo2, sc.fs2,
-                               sc.fe2, sc.fo1);
+      int rc = front_tiers_run(ctx, p, sc, 2 * nt, d_aqp, d_cq_ref, reinterpret_cast<const uint32_t*>(d_lastrow), max_arest);
       if (rc) return give_up(rc);
     }
     TRY(timing_end(ctx));

@@ -164,3 +164,33 @@ def test_index_file_equals_the_in_memory_build(genome, tmp_path):
         with pytest.raises(IOError):
             hostlib.Genome(str(tmp_path / "bad.tidx"), 15)
     m.close()
+
+
+def test_even_k_and_palindromes(tmp_path):
+    """k = 12: a k-mer can be its own reverse complement (the run of the table then holds one part only, and both strands of a read vote
+    from it) -- planted palindromes, reads across them on both strands, both trims regimes"""
+    from tracy_amd import hostlib
+    rng = np.random.default_rng(12)
+    pal = lambda h: h + so._revcomp_str(h)  # noqa: E731
+    body = rand_dna(rng, 20000)
+    for at in range(500, 19000, 900):
+        body = body[:at] + pal(rand_dna(rng, 6)) + body[at + 12:]
+    path = str(tmp_path / "pal.fa")
+    with open(path, "w") as f:
+        f.write(">chrP\n" + body + "\n")
+    g = hostlib.Genome(path, 12, 2)
+    brute = so.BruteGenome([("chrP", body)])
+    reads = []
+    for i in range(40):
+        st = int(rng.integers(0, len(body) - 400))
+        r = body[st:st + int(rng.integers(120, 380))]
+        reads.append(so._revcomp_str(r) if i % 2 else r)
+    for trims in ((20, 20), (11, 30), (3, 2)):
+        got = g.seed([r.encode() for r in reads], trims[0], trims[1], 3, 300, 2)  # (k = the table's: 12)
+        for i, r in enumerate(reads):
+            want = so.get_reference_slice(brute, r, trims[0], trims[1], 12, 3, 300)
+            assert (got["status"][i] == 1) == (want is not None), (trims, i)
+            if want is not None:
+                assert bool(got["forward"][i]) == want["forward"] and int(got["kmersupport"][i]) == want["kmersupport"], (trims, i)
+                assert int(got["pos"][i]) == want["pos"] and got["slices"][i].decode() == want["refslice"], (trims, i)
+    g.close()

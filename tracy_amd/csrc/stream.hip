@@ -844,8 +844,16 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
   TRY(check_params(&p, h.max_mn));
   if (!(p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore)) return kStreamNo;
   if (!narrow_ok(&p, h.maxmt, 16)) return kStreamNo;
-  for (uint32_t t = 0; t < nt; ++t)
-    if (h.mt[t] == 0 || h.rn[t] == 0 || num_passes(h.mt[t], choose_k(h.mt[t], MODE_QP)) != 1) return kStreamNo;
+  {
+    bool odd[kHostThreads] = {};
+    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+      bool x = false;
+      for (uint32_t t = lo; t < hi; ++t) x = x || h.mt[t] == 0 || h.rn[t] == 0 || num_passes(h.mt[t], choose_k(h.mt[t], MODE_QP)) != 1;
+      odd[tid] = x;
+    });
+    for (bool x : odd)
+      if (x) return kStreamNo;
+  }
   std::vector<uint32_t> order;
   std::vector<int> kof;
   sweep_order(h, order, kof);
@@ -871,12 +879,25 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
    rest_of[tid] = max_rest;
   });
   for (uint32_t x : rest_of) h.max_rest = std::max(h.max_rest, x);
-  for (uint32_t t = 0; t < nt; ++t) {  // workspace offsets in trace order
-    SGeom& G = geom[t];
-    for (int o = 0; o < 2; ++o) { G.lr_off[o] = h.lr_tot; h.lr_tot += 2ull * ((uint64_t)G.rn + 1); }
-    G.tab_stride = b16_table_stride(G.mf);
-    G.tab_off = h.tab_tot;
-    h.tab_tot += (uint64_t)kB16Codes * G.tab_stride;
+  {  // workspace offsets in trace order: the sums of the slices, then every slice from its base
+    uint64_t lr_of[kHostThreads] = {}, tab_of[kHostThreads] = {};
+    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+      uint64_t lr = 0, tab = 0;
+      for (uint32_t t = lo; t < hi; ++t) { lr += 4ull * ((uint64_t)h.rn[t] + 1); tab += (uint64_t)kB16Codes * b16_table_stride(h.mf[t]); }
+      lr_of[tid] = lr; tab_of[tid] = tab;
+    });
+    uint64_t lr_base[kHostThreads], tab_base[kHostThreads];
+    for (uint32_t i = 0; i < kHostThreads; ++i) { lr_base[i] = h.lr_tot; tab_base[i] = h.tab_tot; h.lr_tot += lr_of[i]; h.tab_tot += tab_of[i]; }
+    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+      uint64_t lr = lr_base[tid], tab = tab_base[tid];
+      for (uint32_t t = lo; t < hi; ++t) {
+        SGeom& G = geom[t];
+        for (int o = 0; o < 2; ++o) { G.lr_off[o] = lr; lr += 2ull * ((uint64_t)G.rn + 1); }
+        G.tab_stride = b16_table_stride(G.mf);
+        G.tab_off = tab;
+        tab += (uint64_t)kB16Codes * G.tab_stride;
+      }
+    });
   }
   if (h.max_rest == 0) return kStreamNo;  // no trace takes the pruned sweep
   return TRACYHIP_OK;
@@ -1561,36 +1582,83 @@ struct DecStream {
 
     // ---- geometry of the decompose stages (decompose_traces_legacy's, trace by trace) ----
     z.nt = nt; z.exact = exact; z.host = host;
-    for (uint32_t t = 0; t < nt; ++t) {
-      if (bc.bc_len[t] != h.mf[t]) return set_error(TRACYHIP_ERR_ARG, "trace %u: profile has %u columns but %u basecalls", t, h.mf[t], bc.bc_len[t]);
-      if (bc.bc_len[t] >= 2u * kMaxIndelGlobal) return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the scan tables hold < %d", t, bc.bc_len[t], 2 * kMaxIndelGlobal);
-      SGeomD& D = geomd[t];
-      D = SGeomD{};
-      if ((uint64_t)(uint32_t)(TL + TR + 1) >= (uint64_t)h.mf[t]) { D.soff = 0; D.sl = h.mf[t]; }  // trimmedSeq, abif.h:68-75
-      else { D.soff = TL; D.sl = h.mf[t] - TL - TR; }
-      D.bc_off = bc.bc_offset[t];
-      D.sig_off = bc.signal_offset[t];
-      D.nsamples = bc.nsamples[t];
-      D.dcp_off = out->dcp_offset[t];
-      for (int k = 0; k < 3; ++k) D.opsk_off[k] = out->ops_offset[k][t];
-      D.atab_stride = b16_table_stride(D.sl);
-      for (int k = 0; k < 2; ++k) {
-        D.atab_off[k] = atab_tot; atab_tot += (uint64_t)kB16Codes * D.atab_stride;
-        D.alr_off[k] = alr_tot; alr_tot += (uint64_t)h.rn[t] + 2;
-        const bool ok = D.sl > kFrontRows + 2u * (uint32_t)kFrontK && h.rn[t] >= 1 && origin16_ok(&p, D.sl, D.sl - kFrontRows + 2u * (uint32_t)kFrontHalfW + 16u);
-        D.flags[k] = ok ? SG_FRONT_OK : 0u;
-        if (ok) max_arest = std::max(max_arest, D.sl - kFrontRows);
+    // two passes on the host threads (100 000 records are milliseconds on one, and nothing is queued yet: the GPU waits for this):
+    // sums, extents and checks per slice of the batch, then the records with their running offsets from the slices' bases
+    struct Part {
+      uint64_t atab = 0, alr = 0, tot1 = 0, sext = 0, bext = 0, dext = 0, opscap[3] = {0, 0, 0}, rows_alleles = 0;
+      uint32_t maxbc = 0, maxsl = 0, max_arest = 0, bad_len = ~0u, bad_range = ~0u;
+    };
+    Part part[kHostThreads];
+    auto trimmed = [&](uint32_t t, uint32_t& soff, uint32_t& sl) {  // trimmedSeq, abif.h:68-75
+      if ((uint64_t)(uint32_t)(TL + TR + 1) >= (uint64_t)h.mf[t]) { soff = 0; sl = h.mf[t]; }
+      else { soff = TL; sl = h.mf[t] - TL - TR; }
+    };
+    auto front_ok = [&](uint32_t t, uint32_t sl) {
+      return sl > kFrontRows + 2u * (uint32_t)kFrontK && h.rn[t] >= 1 && origin16_ok(&p, sl, sl - kFrontRows + 2u * (uint32_t)kFrontHalfW + 16u);
+    };
+    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+      Part x;
+      for (uint32_t t = lo; t < hi; ++t) {
+        if (bc.bc_len[t] != h.mf[t]) x.bad_len = std::min(x.bad_len, t);
+        if (bc.bc_len[t] >= 2u * kMaxIndelGlobal) x.bad_range = std::min(x.bad_range, t);
+        uint32_t soff, sl;
+        trimmed(t, soff, sl);
+        x.atab += 2ull * kB16Codes * b16_table_stride(sl);
+        x.alr += 2ull * ((uint64_t)h.rn[t] + 2);
+        x.tot1 += (uint64_t)h.mt[t] + h.rn[t];
+        if (front_ok(t, sl)) x.max_arest = std::max(x.max_arest, sl - kFrontRows);
+        x.sext = std::max<uint64_t>(x.sext, bc.signal_offset[t] + 4ull * bc.nsamples[t]);
+        x.bext = std::max<uint64_t>(x.bext, bc.bc_offset[t] + bc.bc_len[t]);
+        x.dext = std::max<uint64_t>(x.dext, out->dcp_offset[t] + 2ull * dp.maxindel + 2);
+        for (int k = 0; k < 3; ++k) x.opscap[k] = std::max<uint64_t>(x.opscap[k], out->ops_offset[k][t] + (uint64_t)sl + (k < 2 ? h.rn[t] : sl));
+        x.maxbc = std::max(x.maxbc, h.mf[t]);
+        x.maxsl = std::max(x.maxsl, sl);
+        x.rows_alleles += 2ull * sl;
       }
-      geom[t].ops_off = z.tot1;
-      z.tot1 += (uint64_t)h.mt[t] + h.rn[t];
-      z.sext = std::max<uint64_t>(z.sext, bc.signal_offset[t] + 4ull * bc.nsamples[t]);
-      z.bext = std::max<uint64_t>(z.bext, bc.bc_offset[t] + bc.bc_len[t]);
-      z.dext = std::max<uint64_t>(z.dext, out->dcp_offset[t] + 2ull * dp.maxindel + 2);
-      for (int k = 0; k < 3; ++k) z.opscap[k] = std::max<uint64_t>(z.opscap[k], out->ops_offset[k][t] + (uint64_t)D.sl + (k < 2 ? h.rn[t] : D.sl));
-      maxbc = std::max(maxbc, h.mf[t]);
-      maxsl = std::max(maxsl, D.sl);
-      rows_alleles += 2ull * D.sl;
+      part[tid] = x;
+    });
+    {
+      uint32_t bad_len = ~0u, bad_range = ~0u;
+      for (const Part& x : part) { bad_len = std::min(bad_len, x.bad_len); bad_range = std::min(bad_range, x.bad_range); }
+      const uint32_t first_bad = std::min(bad_len, bad_range);  // (the first offending trace, as the loop over the traces reported it)
+      if (first_bad != ~0u) {
+        if (bc.bc_len[first_bad] != h.mf[first_bad])
+          return set_error(TRACYHIP_ERR_ARG, "trace %u: profile has %u columns but %u basecalls", first_bad, h.mf[first_bad], bc.bc_len[first_bad]);
+        return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the scan tables hold < %d", first_bad, bc.bc_len[first_bad], 2 * kMaxIndelGlobal);
+      }
     }
+    uint64_t base_atab[kHostThreads], base_alr[kHostThreads], base_tot1[kHostThreads];
+    for (uint32_t i = 0; i < kHostThreads; ++i) {
+      const Part& x = part[i];
+      base_atab[i] = atab_tot; base_alr[i] = alr_tot; base_tot1[i] = z.tot1;
+      atab_tot += x.atab; alr_tot += x.alr; z.tot1 += x.tot1;
+      z.sext = std::max(z.sext, x.sext); z.bext = std::max(z.bext, x.bext); z.dext = std::max(z.dext, x.dext);
+      for (int k = 0; k < 3; ++k) z.opscap[k] = std::max(z.opscap[k], x.opscap[k]);
+      maxbc = std::max(maxbc, x.maxbc); maxsl = std::max(maxsl, x.maxsl); max_arest = std::max(max_arest, x.max_arest);
+      rows_alleles += x.rows_alleles;
+    }
+    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+      uint64_t atab = base_atab[tid], alr = base_alr[tid], tot1 = base_tot1[tid];
+      for (uint32_t t = lo; t < hi; ++t) {
+        SGeomD& D = geomd[t];
+        D = SGeomD{};
+        trimmed(t, D.soff, D.sl);
+        D.bc_off = bc.bc_offset[t];
+        D.sig_off = bc.signal_offset[t];
+        D.nsamples = bc.nsamples[t];
+        D.dcp_off = out->dcp_offset[t];
+        for (int k = 0; k < 3; ++k) D.opsk_off[k] = out->ops_offset[k][t];
+        D.atab_stride = b16_table_stride(D.sl);
+        const bool ok = front_ok(t, D.sl);
+        for (int k = 0; k < 2; ++k) {
+          D.atab_off[k] = atab; atab += (uint64_t)kB16Codes * D.atab_stride;
+          D.alr_off[k] = alr; alr += (uint64_t)h.rn[t] + 2;
+          D.flags[k] = ok ? SG_FRONT_OK : 0u;
+        }
+        geom[t].ops_off = tot1;
+        tot1 += (uint64_t)h.mt[t] + h.rn[t];
+      }
+    });
     if (max_arest == 0) return kStreamNo;
     TRY(decompose_limits(dp.maxindel, maxbc));
     z.ep = seqset_extent(sp); z.er = seqset_extent(sr);
@@ -1945,10 +2013,11 @@ int tracyhip::stream_decompose(tracyhip_ctx* ctx, const tracyhip_decompose_job* 
   if (!stream_options_ok(ctx->knobs) || job->oriented || job->ref_profiles.data) return kStreamNo;
   static thread_local StreamHost h;
   DecStream s(ctx, job, prm, mem, out, h);
-  TRY(s.plan());
-  TRY(s.bind());
-  TRY(s.queue_trace_stages());    // 2., 3., then 1., 4., 5. (indigo.h:196-350)
-  if (int rc = s.queue_allele_stages()) return s.give_up(rc);  // 6. (indigo.h:355-387)
+  { TRACYHIP_HOST_SCOPE(hs, "stream_decompose.plan"); TRY(s.plan()); }
+  { TRACYHIP_HOST_SCOPE(hs, "stream_decompose.bind"); TRY(s.bind()); }
+  { TRACYHIP_HOST_SCOPE(hs, "stream_decompose.queue_trace_stages"); TRY(s.queue_trace_stages()); }    // 2., 3., then 1., 4., 5. (indigo.h:196-350)
+  { TRACYHIP_HOST_SCOPE(hs, "stream_decompose.queue_allele_stages"); if (int rc = s.queue_allele_stages()) return s.give_up(rc); }  // 6. (indigo.h:355-387)
+  TRACYHIP_HOST_SCOPE(hs_rb, "stream_decompose.read_back_and_after");
   if (int rc = s.read_back()) return s.give_up(rc);            // the call's one synchronisation
   TRY(s.redo_dead_traces());
   return s.copy_back();

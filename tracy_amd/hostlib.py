@@ -264,6 +264,34 @@ class Genome:
         fn.restype = C.c_uint64
         return int(fn(self._h, bytes(pattern), C.c_size_t(len(pattern))))
 
+    @staticmethod
+    def pack_consensus(consensus):
+        """the batch as a C caller holds it: one byte block, offsets, lengths (seed_packed takes these; packing a list of Python
+        strings is interpreter work, not part of the seeding stage)"""
+        n = len(consensus)
+        lens = np.array([len(c) for c in consensus], dtype=np.uint32)
+        offs = np.zeros(max(n, 1), dtype=np.uint64)
+        if n:
+            offs[1:n] = np.cumsum(lens.astype(np.uint64))[:-1]
+        return dict(n=n, blob=b"".join(bytes(c) for c in consensus) + b"\0", offs=offs, lens=lens)
+
+    def seed_packed(self, packed, trim_left=50, trim_right=50, min_support=3, maxindel=1000, nthreads=0, out=None):
+        """getReferenceSlice for a packed batch (pack_consensus); `out`: the dict a previous call returned, reused as the result
+        buffers of this one (same batch shape) -- what a caller that seeds block after block does.  Returns the raw form of seed()."""
+        n = packed["n"]
+        cap = int(packed["lens"].max() if n else 0) + 2 * maxindel + 2
+        if out is None or out["slices_2d"].shape != (max(n, 1), cap):
+            out = dict(status=np.zeros(max(n, 1), np.int32), forward=np.zeros(max(n, 1), np.uint8), kmersupport=np.zeros(max(n, 1), np.uint32),
+                       pos=np.zeros(max(n, 1), np.uint32), contig=np.zeros(max(n, 1), np.uint32), slice_len=np.zeros(max(n, 1), np.uint32),
+                       slices_2d=np.zeros((max(n, 1), cap), dtype=np.uint8))
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        lib().tracyhost_seed_batch(self._h, C.c_uint32(n), packed["blob"], p(packed["offs"], C.c_uint64), p(packed["lens"], C.c_uint32), C.c_uint32(trim_left),
+                                   C.c_uint32(trim_right), C.c_uint32(self.kmer), C.c_uint32(min_support), C.c_uint32(maxindel),
+                                   C.c_uint32(nthreads), p(out["status"], C.c_int32), p(out["forward"], C.c_uint8),
+                                   p(out["kmersupport"], C.c_uint32), p(out["pos"], C.c_uint32), p(out["contig"], C.c_uint32),
+                                   out["slices_2d"].ctypes.data_as(C.c_char_p), C.c_uint64(cap), p(out["slice_len"], C.c_uint32))
+        return out
+
     def seed(self, consensus, trim_left=50, trim_right=50, min_support=3, maxindel=1000, nthreads=0, raw=False):
         """getReferenceSlice (fmindex.h:236-326) for a list of consensus strings -> dict of arrays + oriented windows
         (`slices`: list of bytes; raw=True: `slices_2d` uint8 [n][cap] + `slice_len` instead, no per-trace copies)"""

@@ -396,7 +396,7 @@ def main():
     try:  # (bytes per step of the exact instantiations each timer covers; both timers launch once per step here)
         from tools.legs import pmc_traffic
         traffic, traffic_src = pmc_traffic([r"gotoh_ckpt_prefix_kernel<"], "r[0-9][0-9]_pmc_hbm.json")
-        band_traffic, band_traffic_src = pmc_traffic([r"band16_kernel<\d+, 0>", r"band16_multi(_counted)?_kernel<0>"], "r[0-9][0-9]_pmc_hbm.json")
+        band_traffic, band_traffic_src = pmc_traffic([r"band16_kernel<\d+, 0>", r"band16_multi3?(_counted)?_kernel<0>"], "r[0-9][0-9]_pmc_hbm.json")
     except Exception:  # noqa: BLE001
         pass
     valu_achieved = kgcups(sc) * ops_per_cell / 1e3

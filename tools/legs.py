@@ -299,8 +299,8 @@ class DecomposeLeg:
                            "kept for the band below it; cells credited: the rows swept)", 8.0, [r"gotoh_ckpt_prefix_kernel<", r"gotoh_prefix_kernel<"]),
                  "front": ("front_place + band16_cont16_kernel<K> + front_certify (pruned sweeps: the rows below the prefix on the diagonals around its best "
                            "column on 16-bit cells, certified per pair)", 9.0, [r"band16_cont(16)?_kernel<", r"front_place_kernel", r"front_certify_kernel"]),
-                 "origin": ("band16_kernel<K,1> (gotoh(allele, window) whose alignment only trimReferenceSlice reads: origin-tracking sweep on the band its score allows)", 11.0, [r"band16_kernel<\d+, 1>", r"band16_multi(_counted)?_kernel<1>"]),
-                 "trace": ("band16_kernel<K,0> (tracebacks on diagonal bands, four pairs per wave: trimmed trace vs window, allele vs trimmed slice, allele 1 vs allele 2; cells / bytes: the bands')", 14.0, [r"band16_kernel<\d+, 0>", r"band16_multi(_counted)?_kernel<0>"]),
+                 "origin": ("band16_kernel<K,1> (gotoh(allele, window) whose alignment only trimReferenceSlice reads: origin-tracking sweep on the band its score allows)", 11.0, [r"band16_kernel<\d+, 1>", r"band16_multi3?(_counted)?_kernel<1>"]),
+                 "trace": ("band16_kernel<K,0> (tracebacks on diagonal bands, four pairs per wave: trimmed trace vs window, allele vs trimmed slice, allele 1 vs allele 2; cells / bytes: the bands')", 14.0, [r"band16_kernel<\d+, 0>", r"band16_multi3?(_counted)?_kernel<0>"]),
                  "band": ("gotoh_band_kernel<K,QP> (band traceback of the trimmed trace)", 14.0, "gotoh_band_kernel"),
                  "walk": ("gotoh_walk_kernel", None, "gotoh_walk_kernel"), "prefix": ("gotoh_prefix_kernel", 8.0, "gotoh_prefix_kernel"),
                  "decompose": ("decompose_kernel (decomposeAlleles, decompose.h:179-376)", None, "decompose_kernel"),

@@ -34,13 +34,6 @@ __global__ __launch_bounds__(64) void band16_kernel(Band16Args a) {
   DeviceWave16 w;
   band16_body<DeviceWave16, K, KIND>(w, a, blockIdx.x);
 }
-// the quad form: sixteen pairs of narrow bands per workgroup (band16.h b16_narrow_ok), strip height 4
-template <int KIND>
-__global__ __launch_bounds__(64) void band16_quad_kernel(Band16Args a) {
-  DeviceWave16 w;
-  band16_body<DeviceWave16, 4, KIND, false, 4>(w, a, blockIdx.x);
-}
-
 // One launch for the three strip heights of a small job: blocks [0, w12) sweep a12's pairs on K = 12 strips, the next w8 a8's on
 // K = 8, the rest a4's on K = 4.  A job of 10 000 pairs is 2 500 waves -- fewer than the device holds -- so its launches are as long
 // as one wave takes, and three of them in a row take three times that.
@@ -64,6 +57,17 @@ __global__ __launch_bounds__(64) void band16_multi_counted_kernel(Band16Args a12
   else if (blockIdx.x < w12 + w8) band16_body<DeviceWave16, 8, KIND>(w, a8, blockIdx.x - w12);
   else if (blockIdx.x < w12 + w8 + w4) band16_body<DeviceWave16, 4, KIND>(w, a4, blockIdx.x - w12 - w8);
   else if (blockIdx.x < w12 + w8 + w4 + wq) band16_body<DeviceWave16, 4, KIND, false, 4>(w, aq, blockIdx.x - w12 - w8 - w4);
+}
+
+// the same without the tallest strips (whose 195 registers hold every workgroup of the kernel above at two waves per SIMD): large jobs
+// give strip height 12 -- the shortest list -- a launch of its own
+template <int KIND>
+__global__ __launch_bounds__(64) void band16_multi3_counted_kernel(Band16Args a8, Band16Args a4, Band16Args aq) {
+  DeviceWave16 w;
+  const uint32_t w8 = (*a8.count + 3u) / 4u, w4 = (*a4.count + 3u) / 4u, wq = (*aq.count + 15u) / 16u;
+  if (blockIdx.x < w8) band16_body<DeviceWave16, 8, KIND>(w, a8, blockIdx.x);
+  else if (blockIdx.x < w8 + w4) band16_body<DeviceWave16, 4, KIND>(w, a4, blockIdx.x - w8);
+  else if (blockIdx.x < w8 + w4 + wq) band16_body<DeviceWave16, 4, KIND, false, 4>(w, aq, blockIdx.x - w8 - w4);
 }
 
 template <int K>
@@ -167,15 +171,6 @@ hipError_t launch_band16_multi(int kind, const Band16Args& a12, const Band16Args
 
 // jobs whose sizes are on the device (a.count != null, a.npairs = the most pairs the job can hold): one launch per strip height for
 // large batches (a K = 4 workgroup then asks for its own, smaller LDS block), one for all three below 24 576 pairs
-hipError_t launch_band16_quad(int kind, const Band16Args& a, hipStream_t s) {
-  if (a.npairs == 0) return hipSuccess;
-  const dim3 grid((a.npairs + 15u) / 16u);
-  const uint32_t lds = b16_quad_lds(a.code_cap);
-  if (kind == 0) hipLaunchKernelGGL((band16_quad_kernel<0>), grid, dim3(64), lds, s, a);
-  else hipLaunchKernelGGL((band16_quad_kernel<1>), grid, dim3(64), lds, s, a);
-  return hipGetLastError();
-}
-
 hipError_t B16Fork::create() {
   hipError_t e;
   for (int i = 0; i < kSide; ++i) {
@@ -200,10 +195,13 @@ hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Ar
   for (uint32_t x : {a8.npairs, a4.npairs, aq.npairs}) most = x > most ? x : most;
   if (most == 0) return hipSuccess;
   hipError_t e;
-  // small jobs: one launch for the four lists (a launch lasts at least as long as one of its waves; 10 000 pairs are fewer waves than
-  // the device holds, so four launches -- in a row or side by side behind two events each -- cost more than the registers of the
-  // tallest strips cost the others here: measured 1.25 / 1.45 / 1.50 ms for the final alignments of 10 000 traces)
-  if (most <= 24576u) {
+  // Small jobs: one launch for the four lists (a launch lasts at least as long as one of its waves; 10 000 pairs are fewer waves than
+  // the device holds, so a second launch costs more than the registers of the tallest strips cost the others: 1.25 / 1.45 ms for the
+  // final alignments of 10 000 traces).  Large jobs: strip height 12 -- 195 registers, the shortest list -- gets a launch of its
+  // own beside the other three (side stream), which then run three waves per SIMD instead of two.  Measured per decompose step of
+  // 12 500 / 25 000 / 100 000 traces: one launch 20.0 / 35.9-36.8 / 131.8-132.0 ms, three + one 20.8 (two stages of it) / 35.5-35.7 /
+  // 129.9-130.6 ms, four launches side by side 20.8 / 37.3 / 132.9 ms.
+  if (most <= 49152u) {
     const uint32_t lds16 = 4u * a12.code_cap + b16_table_bytes(12), ldsq = aq.npairs ? b16_quad_lds(aq.code_cap) : 0u;
     const uint32_t lds = lds16 > ldsq ? lds16 : ldsq;
     const dim3 grid((most + 3u) / 4u + 4u);  // (the four jobs together hold at most `most` pairs: every pair is in one of them)
@@ -211,24 +209,22 @@ hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Ar
     else hipLaunchKernelGGL((band16_multi_counted_kernel<1>), grid, dim3(64), lds, s, a12, a8, a4, aq);
     return hipGetLastError();
   }
-  if (fork) {  // one launch per list, side by side (each with the registers and the LDS block of its own strip height)
+  const uint32_t lds16 = 4u * a8.code_cap + b16_table_bytes(8), ldsq = aq.npairs ? b16_quad_lds(aq.code_cap) : 0u;
+  const uint32_t lds = lds16 > ldsq ? lds16 : ldsq;
+  const dim3 grid((most + 3u) / 4u + 3u);
+  if (fork) {
     if ((e = hipEventRecord(fork->forked, s)) != hipSuccess) return e;
-    for (int i = 0; i < 3; ++i)
-      if ((e = hipStreamWaitEvent(fork->side[i], fork->forked, 0)) != hipSuccess) return e;
-    if ((e = launch_band16(4, kind, a4, s)) != hipSuccess) return e;
-    if ((e = launch_band16_quad(kind, aq, fork->side[0])) != hipSuccess) return e;
-    if ((e = launch_band16(8, kind, a8, fork->side[1])) != hipSuccess) return e;
-    if ((e = launch_band16(12, kind, a12, fork->side[2])) != hipSuccess) return e;
-    for (int i = 0; i < 3; ++i) {
-      if ((e = hipEventRecord(fork->joined[i], fork->side[i])) != hipSuccess) return e;
-      if ((e = hipStreamWaitEvent(s, fork->joined[i], 0)) != hipSuccess) return e;
-    }
-    return hipSuccess;
+    if ((e = hipStreamWaitEvent(fork->side[2], fork->forked, 0)) != hipSuccess) return e;
   }
-  if ((e = launch_band16_quad(kind, aq, s)) != hipSuccess) return e;
-  if ((e = launch_band16(4, kind, a4, s)) != hipSuccess) return e;   // (the usual strip height first: the other two are mostly empty grids)
-  if ((e = launch_band16(8, kind, a8, s)) != hipSuccess) return e;
-  return launch_band16(12, kind, a12, s);
+  if (kind == 0) hipLaunchKernelGGL((band16_multi3_counted_kernel<0>), grid, dim3(64), lds, s, a8, a4, aq);
+  else hipLaunchKernelGGL((band16_multi3_counted_kernel<1>), grid, dim3(64), lds, s, a8, a4, aq);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = launch_band16(12, kind, a12, fork ? fork->side[2] : s)) != hipSuccess) return e;
+  if (fork) {
+    if ((e = hipEventRecord(fork->joined[2], fork->side[2])) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(s, fork->joined[2], 0)) != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 hipError_t launch_band16_cont_quad(const Band16Args& a, hipStream_t s) {

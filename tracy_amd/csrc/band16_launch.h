@@ -24,9 +24,9 @@ hipError_t launch_band16(int K, int kind, const Band16Args& a, hipStream_t s);
 // the three strip heights in one launch (small jobs); the jobs share one code_cap
 hipError_t launch_band16_multi(int kind, const Band16Args& a12, const Band16Args& a8, const Band16Args& a4, hipStream_t s);
 // the three strip heights of a job whose lists and sizes are on the device (Band16Args::index / count; npairs = capacity of each list)
-// Side streams for the launches of one band stage: the four lists (strip heights 12 / 8 / 4 and the quad form) are independent, and a
-// launch lasts at least as long as one of its waves -- in a row they cost four of those, side by side the longest.  fork() makes the
-// side streams wait for what the main stream has queued, join() the main stream for them.
+// Side streams of a context: launches that do not depend on each other run side by side -- the voted strand's chain beside the other
+// strand's sweeps, the tallest strips of a band stage beside the other lists, allelicFraction beside the allele stages (stream.hip).
+// `forked` makes a side stream wait for what the call's stream has queued, `joined[i]` the call's stream for side stream i.
 struct B16Fork {
   static constexpr int kSide = 4;  // three for the lists of a band stage (and the voted strand's chain), one for work that runs beside whole stages
   hipStream_t side[kSide] = {nullptr, nullptr, nullptr, nullptr};
@@ -37,7 +37,6 @@ struct B16Fork {
 // aq: the pairs of narrow bands (b16_narrow_ok) swept four lanes to a pair; aq.npairs = 0 when the launch's code_cap leaves no room (b16_quad_lds)
 hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Args& a8, const Band16Args& a4, const Band16Args& aq, hipStream_t s,
                                  const B16Fork* fork = nullptr);
-hipError_t launch_band16_quad(int kind, const Band16Args& a, hipStream_t s);
 // the sweep below a stored prefix row (Band16Args::row; K = 8 or 12), and the two kernels of front.h around it
 // narrow: every DP value of the launch fits int16 (narrow_ok for the tallest pair, rows above the stored one included): the 16-bit cells
 hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s, bool narrow = false);

@@ -194,3 +194,28 @@ def test_even_k_and_palindromes(tmp_path):
                 assert bool(got["forward"][i]) == want["forward"] and int(got["kmersupport"][i]) == want["kmersupport"], (trims, i)
                 assert int(got["pos"][i]) == want["pos"] and got["slices"][i].decode() == want["refslice"], (trims, i)
     g.close()
+
+
+def test_packed_batches_and_reused_buffers(genome):
+    """seed_packed (the batch packed once, result buffers reused from call to call -- what bench.py's seeding leg does) returns what
+    seed() returns, also when the buffers held another batch's results before"""
+    from tracy_amd import hostlib
+    g, brute, _ = genome
+    rng = np.random.default_rng(31)
+    ra, rb = make_reads(rng, brute, 24), make_reads(rng, brute, 24)
+    ra, rb = [r.encode() for r in ra], [r.encode() for r in rb]
+    cap = max(len(r) for r in ra + rb)
+    rb = [r.ljust(cap, b"A") if i == 0 else r for i, r in enumerate(rb)]  # (same longest read: the buffers of the first call fit the second)
+    ra = [r.ljust(cap, b"A") if i == 0 else r for i, r in enumerate(ra)]
+    want_a, want_b = g.seed(ra, 50, 50, 3, 400, 2, raw=True), g.seed(rb, 50, 50, 3, 400, 2, raw=True)
+    out = g.seed_packed(hostlib.Genome.pack_consensus(ra), 50, 50, 3, 400, 2)
+    for k in ("status", "forward", "kmersupport", "pos", "contig", "slice_len"):
+        assert np.array_equal(out[k], want_a[k]), k
+    out2 = g.seed_packed(hostlib.Genome.pack_consensus(rb), 50, 50, 3, 400, 2, out=out)
+    assert out2 is out
+    for k in ("status", "forward", "pos", "contig", "slice_len"):
+        assert np.array_equal(out2[k], want_b[k]), k
+    for i in range(len(rb)):
+        if want_b["status"][i] == 1:
+            n = int(want_b["slice_len"][i])
+            assert out2["slices_2d"][i, :n].tobytes() == want_b["slices_2d"][i, :n].tobytes(), i

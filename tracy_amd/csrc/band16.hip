@@ -201,7 +201,10 @@ hipError_t launch_band16_counted(int kind, const Band16Args& a12, const Band16Ar
   // own beside the other three (side stream), which then run three waves per SIMD instead of two.  Measured per decompose step of
   // 12 500 / 25 000 / 100 000 traces: one launch 20.0 / 35.9-36.8 / 131.8-132.0 ms, three + one 20.8 (two stages of it) / 35.5-35.7 /
   // 129.9-130.6 ms, four launches side by side 20.8 / 37.3 / 132.9 ms.
-  if (most <= 49152u) {
+#ifndef TRACY_B16_MULTI_MAX
+#define TRACY_B16_MULTI_MAX 49152u
+#endif
+  if (most <= TRACY_B16_MULTI_MAX) {
     const uint32_t lds16 = 4u * a12.code_cap + b16_table_bytes(12), ldsq = aq.npairs ? b16_quad_lds(aq.code_cap) : 0u;
     const uint32_t lds = lds16 > ldsq ? lds16 : ldsq;
     const dim3 grid((most + 3u) / 4u + 4u);  // (the four jobs together hold at most `most` pairs: every pair is in one of them)

@@ -5,8 +5,11 @@
 #include <vector>
 
 #include "../../tracy_amd/csrc/decompose_kernels.h"
+#include "../../tracy_amd/csrc/decompose_wave.h"
 
 using namespace tracyhip;
+
+#include "host_wave.h"
 
 extern "C" {
 
@@ -35,6 +38,34 @@ int emu_decompose(const uint8_t* row0, const uint8_t* row1, uint32_t L, uint8_t*
   }
   out6[0] = out.kind; out6[1] = out.bestIns; out6[2] = out.bestDel; out6[3] = out.bestFR; out6[4] = (int32_t)out.dcp_n;
   return 0;
+}
+
+// the one-wave body of decompose_wave.h on the 64-fiber host wave; returns 1 when the body left the trace to decompose_kernel (todo)
+int emu_decompose_wave(const uint8_t* row0, const uint8_t* row1, uint32_t L, uint8_t* primary, uint8_t* secondary, uint32_t nbc,
+                       uint32_t breakpoint, uint32_t refslice_len, int32_t trimLeft, int32_t trimRight, int32_t maxindel,
+                       int32_t madc, int32_t* dcp_indel, int32_t* dcp_err, int32_t* out6, uint32_t capL, uint32_t capB, uint32_t capI, uint32_t capF) {
+  DecompDesc d{0, 0, 0, L, nbc, refslice_len, breakpoint};
+  BreakpointOut bp{};
+  bp.breakpoint = breakpoint;
+  DecompOut out{};
+  DecompWaveArgs wa{};
+  wa.a.desc = &d; wa.a.rows0 = row0; wa.a.rows1 = row1; wa.a.primary = primary; wa.a.secondary = secondary;
+  wa.a.dcp_indel = dcp_indel; wa.a.dcp_err = dcp_err; wa.a.out = &out;
+  wa.a.prm = DecompParams{trimLeft, trimRight, maxindel, madc};
+  wa.a.ntraces = 1;
+  wa.bps = &bp;
+  alignas(8) uint8_t lut[kLutBytes];
+  decomp_lut_build(lut);
+  wa.lut = lut;
+  uint32_t todo = 7;
+  wa.todo = &todo;
+  wa.caps = DecompWaveCaps{capL, capB, capI, capF};
+  if (!decomp_wave_caps_ok(wa.caps)) return -1;
+  WaveShared sh;
+  sh.lds.assign(decomp_wave_layout(wa.caps).total + 64, (char)0x5a);  // (stale LDS: the body must initialise what it reads)
+  sh.run([&](uint32_t l) { HostWave w{l, &sh}; decomp_wave_body(w, wa, 0); });
+  out6[0] = out.kind; out6[1] = out.bestIns; out6[2] = out.bestDel; out6[3] = out.bestFR; out6[4] = (int32_t)out.dcp_n; out6[5] = (int32_t)decomp_wave_layout(wa.caps).total;
+  return (int)todo;
 }
 
 void emu_find_breakpoint(const float* prof, uint32_t stride, uint32_t ncol, int32_t* out4, float* bestdiff) {

@@ -344,3 +344,83 @@ def test_decompose_traces_with_other_scorings(ctx, sc):
             for nm in ("slice_begin", "slice_len", "ref_pos"):
                 assert int(got["%s%d" % (nm, k)][i]) == int(w["%s%d" % (nm, k)]), (i, nm, k)
     assert accepted >= nd // 2
+
+
+def _random_decomp_cases(seed, count, long_window=False):
+    """random gapped alignments with IUPAC secondaries, exotic reference letters, breakpoints anywhere (also behind the trace), small and
+    large trims (tests/test_emu_decomp.py's generator); long_window: 1-2 kb of gap columns either side, as `tracy decompose` aligns them"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for it in range(count):
+        nb = int(rng.integers(60, 420)) if not long_window else int(rng.integers(500, 1100))
+        tl, tr = (int(rng.integers(0, 30)), int(rng.integers(0, 30))) if it % 3 else (50, 50)
+        if tl + tr >= nb - 5:
+            tl = tr = 2
+        mt = nb - tl - tr
+        core = bytes(rng.choice(list(b"ACGT"), size=mt + 40).tolist())
+        pri = bytearray(rng.choice(list(b"ACGT"), size=nb).tolist())
+        pri[tl:tl + mt] = core[:mt]
+        sec = bytearray(pri)
+        shift = int(rng.integers(-12, 13))
+        bpv = int(rng.integers(0, mt + 10))
+        for i in range(tl + min(bpv, mt), nb - tr):
+            src = i - tl + shift
+            if 0 <= src < len(core):
+                other = core[src]
+                if other != pri[i]:
+                    sec[i] = other if rng.random() < 0.7 else ord(orc.lib().orc_iupac2(bytes([pri[i]]), bytes([other])))
+            if rng.random() < 0.03:
+                sec[i] = ord("N")
+        r0, r1 = bytearray(), bytearray()
+        lead = int(rng.integers(0, 30)) if not long_window else int(rng.integers(0, 1800))
+        r0 += b"-" * lead
+        r1 += bytes(rng.choice(list(b"ACGT"), size=lead).tolist())
+        for i in range(mt):
+            u = rng.random()
+            if u < 0.01:
+                r0 += b"-"; r1 += bytes([int(rng.choice(list(b"ACGT")))])
+            if u > 0.99:
+                r0 += bytes([pri[tl + i]]); r1 += b"-"
+                continue
+            r0 += bytes([pri[tl + i]])
+            r1 += bytes([core[i]]) if rng.random() > 0.02 else bytes([int(rng.choice(list(b"ACGTN")))])
+        trail = int(rng.integers(0, 600)) if not long_window else int(rng.integers(0, 3900 - len(r0))) if len(r0) < 3900 else 0
+        r0 += b"-" * trail
+        r1 += bytes(rng.choice(list(b"ACGT"), size=trail).tolist())
+        if it % 10 == 9:
+            r1[len(r1) // 2] = ord("X")
+        out.append(dict(rows=(bytes(r0), bytes(r1)), pri=bytes(pri), sec=bytes(sec), bp=orc.Breakpoint(1, 1, bpv, 0.5),
+                        reflen=len(bytes(r1).replace(b"-", b"")), tl=tl, tr=tr))
+    return out
+
+
+@pytest.mark.parametrize("long_window", [False, True])
+def test_decompose_wave_body_vs_oracle_and_step_kernel(ctx, long_window):
+    """decomposeAlleles through the C ABI: the one-wave kernel with its working set in LDS (decompose_wave.h) -- incl. the traces it
+    leaves to decompose_kernel (a breakpoint behind the trace, trims of every size) -- against the oracle and against option no_decomp_wave"""
+    from tracy_amd import capi
+    cases = _random_decomp_cases(99 if long_window else 98, 48, long_window)
+    by_trim = {}
+    for c in cases:
+        by_trim.setdefault((c["tl"], c["tr"]), []).append(c)
+    kinds = {}
+    for (tl, tr), cs in by_trim.items():
+        n = len(cs)
+        sig = [np.zeros((4, 8), np.int32) for _ in cs]
+        pos = [np.zeros(len(c["pri"]), np.int32) for c in cs]
+        res = {}
+        for mode in (0, 1):
+            ctx.set_option("no_decomp_wave", mode)
+            hbc = capi.HostBaseCalls(sig, pos, [c["pri"] for c in cs], [c["sec"] for c in cs])
+            bps = [capi.Breakpoint(1, 1, c["bp"].breakpoint, 0.5) for c in cs]
+            res[mode] = ctx.decompose_alleles(hbc, [c["rows"] for c in cs], bps, [c["reflen"] for c in cs], tl, tr, 1000, 5)
+        ctx.set_option("no_decomp_wave", 0)
+        assert res[0] == res[1]
+        pri, sec, dcp, status = res[0]
+        for i, c in enumerate(cs):
+            w = orc.decompose_alleles(c["rows"][0], c["rows"][1], c["pri"], c["sec"], c["bp"], c["reflen"], tl, tr, 1000, 5)
+            assert (pri[i], sec[i], dcp[i]) == (w[0], w[1], w[2]) and status[i][0] == w[3][0], (tl, tr, i)
+            if w[3][0] == 1:
+                assert tuple(status[i][:4]) == tuple(w[3][:4])
+            kinds[w[3][0]] = kinds.get(w[3][0], 0) + 1
+    assert len(kinds) == 3, kinds

@@ -146,16 +146,31 @@ struct StageTimes {
       if (e.first == what) { e.second += seconds; return; }
     v.emplace_back(what, seconds);
   }
+  // peak resident set of THIS program: VmHWM of /proc/self/status belongs to the address space, which exec() replaces -- ru_maxrss is
+  // inherited across fork + exec and reports the parent's high-water mark when that was larger (a Python process that loaded torch)
+  static double peak_rss_mb() {
+    double mb = 0;
+    if (FILE* f = std::fopen("/proc/self/status", "r")) {
+      char line[256];
+      while (std::fgets(line, sizeof line, f))
+        if (!std::strncmp(line, "VmHWM:", 6)) { mb = std::strtod(line + 6, nullptr) / 1024.0; break; }
+      std::fclose(f);
+    }
+    if (mb == 0) {  // no procfs: the inherited figure is better than none
+      struct rusage ru;
+      getrusage(RUSAGE_SELF, &ru);
+      mb = ru.ru_maxrss / 1024.0;
+    }
+    return mb;
+  }
   void report(uint32_t traces, uint32_t threads) {
     if (!getenv("TRACY_AMD_CLI_TIMERS")) return;
-    struct rusage ru;
-    getrusage(RUSAGE_SELF, &ru);
     std::cerr << "timers: traces " << traces << " host_threads " << threads;
     for (auto const& e : v) std::cerr << " " << e.first << " " << e.second;
     for (int i = 0; i < CpuPhases::COUNT; ++i)
       if (cpu_phases().ns[i]) std::cerr << " cpu_" << CpuPhases::name(i) << "_s " << 1e-9 * (double)cpu_phases().ns[i];
     std::cerr << " before_stages_s " << std::chrono::duration<double>(start - g_process_start).count();
-    std::cerr << " wall_s " << std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() << " peak_rss_mb " << ru.ru_maxrss / 1024.0 << std::endl;
+    std::cerr << " wall_s " << std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() << " peak_rss_mb " << peak_rss_mb() << std::endl;
   }
 };
 // the end of a --batch command: every file is written and closed; what is left is handing back a few GB of host and device memory

@@ -84,6 +84,7 @@ struct DecompArgs {
   const uint32_t* lens;  // alignment columns per trace where they are still on the device (overrides DecompDesc::L), or null
   const uint32_t* skip;  // or null: traces with a non-zero word are left alone (stream.hip: their alignment was not certified, the
                          // host-planned tiers redo them from the untouched basecalls)
+  const uint32_t* only;  // or null: only traces with a non-zero word are decomposed (what decompose_wave.h left to this kernel)
 };
 
 constexpr int kMaxIndelDev = 1024;  // maxindel handled in LDS (CLI default 1000)

@@ -10,6 +10,7 @@
 #include "capi_internal.h"
 #include "decompose_kernels.h"
 #include "decompose_launch.h"
+#include "decompose_wave.h"
 
 using namespace tracyhip;
 
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(64) void decompose_kernel(DecompArgs a, const Break
   DecompSharedT<MAXI>& sh = *reinterpret_cast<DecompSharedT<MAXI>*>(decomp_smem);
   const uint32_t t = blockIdx.x;
   if (a.skip && a.skip[t]) return;
+  if (a.only && !a.only[t]) return;
   DecompDesc d = a.desc[t];
   d.breakpoint = bps[t].breakpoint;
   if (a.lens) d.L = a.lens[t];
@@ -53,6 +55,46 @@ __global__ __launch_bounds__(64) void decompose_kernel(DecompArgs a, const Break
     wg_sync();
   }
   if (lane == 0) a.out[t] = out;
+}
+
+// ---- decomposeAlleles, one wave per trace with its working set in LDS (decompose_wave.h) ----
+struct DecompDevWave {
+  __device__ __forceinline__ uint32_t lane() const { return threadIdx.x; }
+  __device__ __forceinline__ uint64_t ballot(bool p) const { return __ballot(p); }
+  __device__ __forceinline__ uint32_t bcast(uint32_t x, uint32_t src_lane) const { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)src_lane); }
+  __device__ __forceinline__ void sync() const { wg_sync(); }
+  __device__ __forceinline__ char* lds() const {
+    extern __shared__ __attribute__((aligned(16))) char decomp_smem[];
+    return decomp_smem;
+  }
+  // reductions over the 64 lanes: four DPP steps leave every lane of a row of sixteen with the row's result (quad_perm [1,0,3,2] and
+  // [2,3,0,1], row_half_mirror, row_mirror), four v_readlane join the rows -- the result is wave-uniform (an SGPR)
+  template <class F>
+  __device__ __forceinline__ uint32_t reduce(uint32_t x, F f) const {
+    x = f(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false));
+    x = f(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false));
+    x = f(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false));
+    x = f(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)x, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)x, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)x, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+    return f(f(a, b), f(c, d));
+  }
+  __device__ __forceinline__ uint32_t sum(uint32_t x) const { return reduce(x, [](uint32_t a, uint32_t b) { return a + b; }); }
+  __device__ __forceinline__ uint32_t umin(uint32_t x) const { return reduce(x, [](uint32_t a, uint32_t b) { return a < b ? a : b; }); }
+  __device__ __forceinline__ uint32_t umax(uint32_t x) const { return reduce(x, [](uint32_t a, uint32_t b) { return a > b ? a : b; }); }
+  __device__ __forceinline__ uint32_t excl_sum(uint32_t x) const {  // sum of the lanes below (Hillis-Steele, six shuffles)
+    uint32_t v = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = (uint32_t)__shfl_up((int)v, o, 64);
+      if ((int)threadIdx.x >= o) v += y;
+    }
+    return v - x;
+  }
+};
+__global__ __launch_bounds__(64) void decompose_wave_kernel(DecompWaveArgs wa) {
+  DecompDevWave w;
+  decomp_wave_body(w, wa, blockIdx.x);
 }
 
 // the same phases with the scan state in global memory: a workgroup keeps its slot and takes traces blockIdx.x, + gridDim.x, ...
@@ -575,18 +617,67 @@ int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut
   // scan state in LDS: 21 KB for maxindel <= 1024 and traces < 2048 basecalls (every Sanger run), 80 KB up to 4096 / 8191
   const bool large = a.prm.maxindel > kMaxIndelDev || maxbc >= 2u * kMaxIndelDev;
   const bool global = a.prm.maxindel > kMaxIndelLarge || maxbc >= 2u * kMaxIndelLarge;
+  // the one-wave body with its working set in LDS (decompose_wave.h) where the size class allows it; what it is not provisioned for
+  // (an alignment longer than the staged rows, trims outside the trace) it marks in a to-do word and decompose_kernel does
+  DecompArgs rest = a;
+  bool wave = !large && !global && !ctx->knobs.no_decomp_wave && a.prm.maxindel <= kMaxIndelDev;
+  DecompWaveArgs wa{};
+  DecompWaveLayout lay{};
+  if (wave) {
+    const uint32_t capB = std::max<uint32_t>(64u, (maxbc + 63u) & ~63u);
+    const uint32_t capI = (uint32_t)a.prm.maxindel;
+    // reference-row span: the columns of the trace's bases and gaps + what the widest deletion scan reaches behind them
+    const uint32_t capL = (capB + capI + 256u + 63u) & ~63u;
+    wa.caps = DecompWaveCaps{capL, capB, capI, std::min<uint32_t>(capI, capB / 2u + 1u)};
+    lay = decomp_wave_layout(wa.caps);
+    wave = decomp_wave_caps_ok(wa.caps) && lay.total <= 48u * 1024u;
+  }
+  if (wave) {
+    if (!ctx->declut_ready) {
+      static const std::vector<uint8_t> lut = [] { std::vector<uint8_t> t(kLutBytes); decomp_lut_build(t.data()); return t; }();
+      HIP_TRY(ctx->d_declut.ensure(kLutBytes));
+      HIP_TRY(hipMemcpyAsync(ctx->d_declut.p, lut.data(), kLutBytes, hipMemcpyHostToDevice, ctx->stream));
+      ctx->declut_ready = true;
+    }
+    HIP_TRY(ctx->d_dectodo.ensure(sizeof(uint32_t) * (size_t)a.ntraces + 8 * sizeof(unsigned long long) * kDecompWaveStages));
+    wa.a = a;
+    wa.bps = d_bps;
+    wa.lut = static_cast<const uint8_t*>(ctx->d_declut.p);
+    wa.todo = static_cast<uint32_t*>(ctx->d_dectodo.p);
+    rest.only = wa.todo;
+#ifdef TRACY_PHASE_CLOCKS
+    wa.clocks = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->d_dectodo.p) + ((sizeof(uint32_t) * (size_t)a.ntraces + 7) & ~(size_t)7));
+    HIP_TRY(hipMemsetAsync(wa.clocks, 0, sizeof(unsigned long long) * kDecompWaveStages, ctx->stream));
+#endif
+  }
   { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_DECOMP, work_cells, work_bytes); if (trc_) return trc_; }
+  if (wave) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(decompose_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total));
+    hipLaunchKernelGGL(decompose_wave_kernel, dim3(a.ntraces), dim3(64), lay.total, ctx->stream, wa);
+    HIP_TRY(hipGetLastError());
+#ifdef TRACY_PHASE_CLOCKS
+    {
+      unsigned long long hc[kDecompWaveStages];
+      HIP_TRY(hipMemcpyAsync(hc, wa.clocks, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      fprintf(stderr, "tracyhip: decompose_wave_kernel cycles per trace by stage (stage, walk, sets, scans, cut-off, picks, complex, apply):");
+      for (int i = 0; i < 8; ++i) fprintf(stderr, " %.0f", (double)hc[i] / a.ntraces);
+      fprintf(stderr, "  (LDS %u bytes)\n", lay.total);
+    }
+#endif
+  }
+  const DecompArgs& a_ = rest;
   if (global) {
     // scan state in global memory: up to 512 workgroups in flight, each with a slot of its own (0.7 GB)
     const uint32_t slots = std::min<uint32_t>(a.ntraces, 512u);
     HIP_TRY(ctx->d_band.ensure((size_t)slots * sizeof(DecompSharedT<kMaxIndelGlobal>)));
-    hipLaunchKernelGGL(decompose_kernel_global, dim3(slots), dim3(64), 0, ctx->stream, a, d_bps, static_cast<char*>(ctx->d_band.p));
+    hipLaunchKernelGGL(decompose_kernel_global, dim3(slots), dim3(64), 0, ctx->stream, a_, d_bps, static_cast<char*>(ctx->d_band.p));
   } else if (large) {
     const size_t lds = sizeof(DecompSharedT<kMaxIndelLarge>);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(decompose_kernel<kMaxIndelLarge>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(decompose_kernel<kMaxIndelLarge>, dim3(a.ntraces), dim3(64), lds, ctx->stream, a, d_bps);
+    hipLaunchKernelGGL(decompose_kernel<kMaxIndelLarge>, dim3(a.ntraces), dim3(64), lds, ctx->stream, a_, d_bps);
   } else {
-    hipLaunchKernelGGL(decompose_kernel<kMaxIndelDev>, dim3(a.ntraces), dim3(64), sizeof(DecompSharedT<kMaxIndelDev>), ctx->stream, a, d_bps);
+    hipLaunchKernelGGL(decompose_kernel<kMaxIndelDev>, dim3(a.ntraces), dim3(64), sizeof(DecompSharedT<kMaxIndelDev>), ctx->stream, a_, d_bps);
   }
   HIP_TRY(hipGetLastError());
   { int trc_ = timing_end(ctx); if (trc_) return trc_; }

@@ -424,3 +424,49 @@ def test_decompose_wave_body_vs_oracle_and_step_kernel(ctx, long_window):
                 assert tuple(status[i][:4]) == tuple(w[3][:4])
             kinds[w[3][0]] = kinds.get(w[3][0], 0) + 1
     assert len(kinds) == 3, kinds
+
+
+def test_allelic_fraction_two_launch_form_vs_oracle_and_one_launch_kernel(ctx):
+    """allelicFraction (decompose.h:412-621): af_prepare_kernel + af_search_kernel (the k of every (i, j) pair from the vertex of its
+    parabola, exact sums through scalar loads) against the oracle's brute force and against the one-launch kernel, on realistic traces
+    and on degenerate ones (no position with two plain bases, a single het position, all-zero signal, no het position at all)"""
+    from tracy_amd import capi, hostlib
+    rng = np.random.default_rng(4242)
+    sigs, poss, pris, secs = [], [], [], []
+    for seed, kind, frac in [(31, 0, 0.6), (32, 0, 0.35), (33, 1, 0.5), (34, 0, 0.8), (35, 0, 0.5), (36, 0, 0.2)]:
+        ref, sig, pos, indel = hostlib.synth_decompose(seed, 1400, 480, 25, kind, frac)
+        pri, sec, con, bcpos = hostlib.basecall(sig, pos, 0.33)
+        sigs.append(sig); poss.append(bcpos); pris.append(pri); secs.append(sec)
+    base_sig, base_pos, base_pri = sigs[0], poss[0], pris[0]
+    n = len(base_pri)
+
+    def variant(sec_fn, sig=None):
+        sec = bytearray(base_pri)
+        for i in range(n):
+            sec[i] = sec_fn(i, base_pri[i])
+        sigs.append(base_sig if sig is None else sig); poss.append(base_pos); pris.append(base_pri); secs.append(bytes(sec))
+
+    other = {ord("A"): ord("C"), ord("C"): ord("G"), ord("G"): ord("T"), ord("T"): ord("A")}
+    variant(lambda i, p: p)                                                      # no het position: (0.5, 0.5)
+    variant(lambda i, p: ord("N") if 100 < i < 300 else p)                       # het positions, none with two plain bases: flat in k
+    variant(lambda i, p: other.get(p, p) if i == 200 else p)                     # a single het position
+    variant(lambda i, p: other.get(p, p) if i % 7 == 0 else p)                   # scattered SNV-like positions
+    variant(lambda i, p: other.get(p, p) if 60 < i < 400 else p, np.zeros_like(base_sig))   # all-zero signal: 0 / 0 everywhere
+    variant(lambda i, p: (ord("R") if i % 2 else other.get(p, p)) if 150 < i < 350 else p)  # IUPAC secondaries among plain ones
+    for _ in range(6):                                                           # random signals: fractions anywhere in the grid
+        sg = rng.integers(0, 2000, size=base_sig.shape).astype(np.int32)
+        variant(lambda i, p: other.get(p, p) if 80 < i < 80 + int(rng.integers(5, 300)) else p, sg)
+    hbc = capi.HostBaseCalls(sigs, poss, pris, secs)
+    sd = np.frombuffer(b"".join(secs), dtype=np.uint8)
+    res = {}
+    for mode in (0, 1):
+        ctx.set_option("no_af_split", mode)
+        res[mode] = ctx.allelic_fraction(hbc, sd, 50, 50).copy()
+    ctx.set_option("no_af_split", 0)
+    assert np.array_equal(res[0], res[1], equal_nan=True), (res[0], res[1])
+    seen = set()
+    for i in range(len(sigs)):
+        want = orc.allelic_fraction(sigs[i], poss[i], pris[i], secs[i], 50, 50)
+        assert (float(res[0][i, 0]), float(res[0][i, 1])) == want, (i, res[0][i], want)
+        seen.add(want)
+    assert len(seen) >= 6 and (0.5, 0.5) in seen

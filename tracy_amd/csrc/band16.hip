@@ -173,10 +173,17 @@ hipError_t launch_band16_multi(int kind, const Band16Args& a12, const Band16Args
 // large batches (a K = 4 workgroup then asks for its own, smaller LDS block), one for all three below 24 576 pairs
 hipError_t B16Fork::create() {
   hipError_t e;
+  int least = 0, greatest = 0;  // (numerically: greatest = the highest priority)
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+  const bool flat = getenv("TRACYHIP_NO_STREAM_PRIORITY") != nullptr;
   for (int i = 0; i < kSide; ++i) {
-    if ((e = hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking)) != hipSuccess) return e;
+    const int prio = (!flat && i == 3) ? least : 0;
+    (void)greatest;
+    if ((e = hipStreamCreateWithPriority(&side[i], hipStreamNonBlocking, prio)) != hipSuccess) return e;
     if ((e = hipEventCreateWithFlags(&joined[i], hipEventDisableTiming)) != hipSuccess) return e;
   }
+  for (auto& r : ready)
+    if ((e = hipEventCreateWithFlags(&r, hipEventDisableTiming)) != hipSuccess) return e;
   return hipEventCreateWithFlags(&forked, hipEventDisableTiming);
 }
 void B16Fork::destroy() {
@@ -185,6 +192,7 @@ void B16Fork::destroy() {
     if (joined[i]) (void)hipEventDestroy(joined[i]);
     side[i] = nullptr; joined[i] = nullptr;
   }
+  for (auto& r : ready) { if (r) (void)hipEventDestroy(r); r = nullptr; }
   if (forked) (void)hipEventDestroy(forked);
   forked = nullptr;
 }

@@ -27,10 +27,15 @@ hipError_t launch_band16_multi(int kind, const Band16Args& a12, const Band16Args
 // Side streams of a context: launches that do not depend on each other run side by side -- the voted strand's chain beside the other
 // strand's sweeps, the tallest strips of a band stage beside the other lists, allelicFraction beside the allele stages (stream.hip).
 // `forked` makes a side stream wait for what the call's stream has queued, `joined[i]` the call's stream for side stream i.
+// side[3] is a low-priority stream where the device has priorities (allelicFraction fills what the allele stages leave idle; the fills and
+// copies of the call's stream do not queue behind its hundred thousand waves).  A high priority for side[0] was measured: the voted strand's
+// prefixes finish in 10 ms instead of 20, but the band tiers behind them ask for 15-20 KB of LDS per workgroup and find no room while the
+// full sweeps' 7.5 KB workgroups fill the CUs, whatever the priority -- they run when the sweeps drain, as before.
 struct B16Fork {
   static constexpr int kSide = 4;  // three for the lists of a band stage (and the voted strand's chain), one for work that runs beside whole stages
   hipStream_t side[kSide] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t forked = nullptr, joined[kSide] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ready[2] = {nullptr, nullptr};  // points of the call's stream a side stream waits for later on (recorded once, waited for after more has been queued)
   hipError_t create();
   void destroy();
 };

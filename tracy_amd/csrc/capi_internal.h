@@ -56,6 +56,7 @@ struct CtxKnobs {
   bool no_fused_walk = false;     // a separate walk launch after a traceback sweep
   bool no_quads = false;          // stream-ordered pipelines: narrow bands on sixteen lanes per pair like the rest (band16.h b16_narrow_ok)
   bool no_fork = false;           // stream-ordered pipelines: the launches of a band stage in a row on the call's stream instead of side by side
+  bool no_af_split = false;       // allelicFraction by the one-launch kernel (tp / cls in LDS, every grid point screened) instead of prepare + search
   bool no_decomp_wave = false;    // decomposeAlleles by the step-wise kernel only (decompose_kernels.h) instead of the one-wave body with its working set in LDS (decompose_wave.h)
   bool no_cont16 = false;         // the band below a kept prefix row (front.h) on the tagged int32 recurrence instead of the 16-bit cells
   bool verbose = false;           // one line per pipeline stage on stderr: how many pairs took which tier (TRACYHIP_HOST_TIMERS sets it too)
@@ -129,6 +130,7 @@ struct tracyhip_ctx {
   uint8_t* codes() const { return static_cast<uint8_t*>(d_codes.p) + tracyhip::kCodePad; }
   tracyhip::DevBuf d_aftab;                    // allelicFraction grid enumeration (trace independent)
   bool aftab_ready = false;
+  tracyhip::DevBuf d_afscratch;                // af_prepare_kernel -> af_search_kernel: tp, class bytes, headers
   tracyhip::DevBuf d_declut, d_dectodo;        // decompose_wave.h: the (primary, secondary) class table; per trace "left to decompose_kernel"
   bool declut_ready = false;
   tracyhip::PinBuf h_desc, h_off, h_tmp, h_res, h_b16desc[4], h_pre;
@@ -166,6 +168,7 @@ struct tracyhip_ctx {
     d_ckpt.release(); d_lastrow.release(); d_band.release(); d_special.release(); d_ends.release();
     d_aftab.release(); aftab_ready = false;
     d_declut.release(); d_dectodo.release(); declut_ready = false;
+    d_afscratch.release();
     for (auto& b : d_b16tab) b.release();
     d_b16desc.release();
     d_front.release();

@@ -330,6 +330,7 @@ __device__ __forceinline__ double af_exact_sse(const double* tp, const uint8_t* 
 struct AfGrid {
   uint32_t npairs;
   const uint32_t* pair;  // [npairs] (i_index * 100 + j_index) | k_count << 16, k_count descending
+  const double* vals;    // the 100 doubles 0, 0.01, 0.01 + 0.01, ... (af_search_kernel)
 };
 constexpr int AF_STEPS = 21;  // >= ceil(npairs / AF_THREADS) (5151 pairs)
 
@@ -548,6 +549,218 @@ __global__ __launch_bounds__(AF_THREADS) void allelic_fraction_kernel(const BcDe
   }
 }
 
+// ---- allelicFraction in two launches (round 5) ---------------------------------------------------------
+// allelic_fraction_kernel keeps tp / cls of a trace in LDS (36 bytes per basecall: three workgroups per CU), screens all 171 700 grid
+// points and then has ONE of its four waves walk the exact sums while the other three wait at a barrier (rocprofv3: 61 % of the wave
+// cycles in s_waitcnt / s_barrier, 10 k VALU instructions per wave).  Here:
+//   af_prepare_kernel  one wave per trace: the het positions, tp = signal / sum in the reference's order and the class of every term go
+//                      to global scratch, the nine moments of the screen to a header;
+//   af_search_kernel   one wave per trace, a few hundred bytes of LDS.  The screen is a parabola in k for a fixed (i, j) -- SSE(k) =
+//                      const + v (n3 v - 2 S3) + (c - v)(n4 (c - v) - 2 S4), v = vals[k], c = 1 - (i + j) -- so the k that minimises it is
+//                      known in closed form: five candidates around it give the pair's minimum instead of up to a hundred; the pairs within
+//                      the margin of the overall minimum are then scanned in full for the survivor list, exactly as before.  The exact sums
+//                      (decompose.h:596-606, sequentially rounded) read tp / cls through uniform, read-only pointers: scalar loads, the
+//                      term in SGPRs, three fp64 operations and one LDS look-up per term and lane.
+// The screen only decides WHO is evaluated exactly; the selected pair is the first candidate that attains the minimum of the exact sums,
+// as in allelic_fraction_kernel (whose comment has the argument); the two kernels are compared with each other and with the oracle.
+struct AfHeader {
+  double mom[9];  // n1..n4, S1..S4, Q
+  uint32_t dn;    // positions with primary != secondary
+  uint32_t pad;
+};
+struct AfScratch {
+  double* tp;     // trace t: [4][dn] at 4 * bc_off[t]
+  uint8_t* cls;   // idem
+  AfHeader* hdr;  // [ntraces]
+};
+__device__ __forceinline__ double wave_sum_all(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_min_all(double v) {
+  for (int o = 32; o > 0; o >>= 1) { const double x = __shfl_xor(v, o, 64); v = x < v ? x : v; }
+  return v;
+}
+__global__ __launch_bounds__(64) void af_prepare_kernel(const BcDesc* __restrict__ desc, const int32_t* __restrict__ signal, const int32_t* __restrict__ bcpos,
+                                                        const uint8_t* __restrict__ pri_all, const uint8_t* __restrict__ sec_all, uint32_t trimLeft,
+                                                        uint32_t trimRight, AfScratch sc, double* __restrict__ fractions) {
+  const uint32_t t = blockIdx.x, lane = threadIdx.x;
+  const BcDesc d = desc[t];
+  const uint8_t* pri = pri_all + d.bc_off;
+  const uint8_t* sec = sec_all + d.bc_off;
+  uint32_t off = trimLeft, len;  // trimmedSeq (abif.h:68-75)
+  if ((uint64_t)(uint32_t)(trimLeft + trimRight + 1) >= (uint64_t)d.nbc) { off = 0; len = d.nbc; }
+  else len = d.nbc - trimLeft - trimRight;
+  // positions where primary != secondary (decompose.h:431-436), compacted in order: every lane owns a chunk
+  const uint32_t chunk = (len + 63u) / 64u;
+  const uint32_t c_lo = min(lane * chunk, len), c_hi = min(c_lo + chunk, len);
+  uint32_t n = 0;
+  for (uint32_t i = c_lo; i < c_hi; ++i) n += pri[off + i] != sec[off + i];
+  uint32_t incl = n;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, o, 64); if ((int)lane >= o) incl += y; }
+  const uint32_t dn = (uint32_t)__shfl((int)incl, 63, 64);
+  uint32_t np = incl - n;
+  double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // n1..n4, S1..S4, Q over this lane's positions
+  if (dn) {
+    double* tp = sc.tp + 4ull * d.bc_off;
+    uint8_t* cls = sc.cls + 4ull * d.bc_off;
+    const int32_t* sg = signal + d.sig_off;
+    for (uint32_t i = c_lo; i < c_hi; ++i) {
+      const uint8_t pc = pri[off + i], scd = sec[off + i];
+      if (pc == scd) continue;
+      const uint32_t bi_ = (i + trimLeft < d.nbc) ? i + trimLeft : d.nbc - 1;  // the reference indexes bcPos[i + trimLeft] (decompose.h:445)
+      const uint32_t tpos = (uint32_t)bcpos[d.bc_off + bi_];
+      int32_t s4[4];
+      for (int k = 0; k < 4; ++k) s4[k] = sg[(uint64_t)k * d.nsamples + tpos];
+      const double sigsum = (double)(s4[0] + s4[1] + s4[2] + s4[3]);
+      uint32_t c4[4] = {0, 0, 0, 0};
+      const int pi = pc == 'A' ? 0 : pc == 'C' ? 1 : pc == 'G' ? 2 : pc == 'T' ? 3 : -1;
+      const int si = scd == 'A' ? 0 : scd == 'C' ? 1 : scd == 'G' ? 2 : scd == 'T' ? 3 : -1;
+      if (pi >= 0 && si >= 0) {
+        int rest[2], nr = 0;
+        for (int k = 0; k < 4; ++k) if (k != pi && k != si) rest[nr++] = k;
+        const bool first = s4[rest[0]] > s4[rest[1]];  // tertiary = the larger of the two remaining channels
+        for (int k = 0; k < 4; ++k) c4[k] = k == pi ? 1u : k == si ? 2u : k == rest[first ? 0 : 1] ? 3u : 4u;
+      }
+      for (int k = 0; k < 4; ++k) {
+        const double x = __ddiv_rn((double)s4[k], sigsum);
+        tp[(size_t)k * dn + np] = x;
+        cls[(size_t)k * dn + np] = (uint8_t)c4[k];
+        m[8] += x * x;
+        for (int q = 1; q <= 4; ++q) { m[q - 1] += (c4[k] == (uint32_t)q) ? 1.0 : 0.0; m[3 + q] += (c4[k] == (uint32_t)q) ? x : 0.0; }
+      }
+      ++np;
+    }
+  }
+  for (int k = 0; k < 9; ++k) m[k] = wave_sum_all(m[k]);
+  if (lane == 0) {
+    AfHeader h;
+    for (int k = 0; k < 9; ++k) h.mom[k] = m[k];
+    h.dn = dn; h.pad = 0;
+    sc.hdr[t] = h;
+    if (dn == 0) { fractions[2 * t] = 0.5; fractions[2 * t + 1] = 0.5; }
+  }
+}
+
+using AfGrid2 = AfGrid;
+constexpr int AF2_SURVIVORS = 32;
+__global__ __launch_bounds__(64) void af_search_kernel(const BcDesc* __restrict__ desc, const double* __restrict__ tp_all, const uint8_t* __restrict__ cls_all,
+                                                       const AfHeader* __restrict__ hdr, AfGrid2 grid, double* __restrict__ fractions) {
+  __shared__ double vals[100], f1[100], f2[100], f3[100];
+  __shared__ double s_pv[AF2_SURVIVORS + 1][5];
+  __shared__ uint32_t s_surv[AF2_SURVIVORS];
+  __shared__ uint32_t s_nsurv;
+  const uint32_t t = blockIdx.x, lane = threadIdx.x;
+  const AfHeader h = hdr[t];
+  const uint32_t dn = h.dn;
+  if (dn == 0) return;  // (0.5, 0.5) written by af_prepare_kernel
+  const uint64_t base = 4ull * desc[t].bc_off;
+  const double* __restrict__ tp = tp_all + base;
+  const uint8_t* __restrict__ cls = cls_all + base;
+  const uint32_t terms = 4u * dn;
+  const double n3 = h.mom[2], n4 = h.mom[3], s3 = h.mom[6], s4c = h.mom[7], s4c2 = 2.0 * h.mom[7], qtot = h.mom[8];
+  for (uint32_t a = lane; a < 100; a += 64) {
+    const double v = grid.vals[a];
+    vals[a] = v;
+    f1[a] = v * (h.mom[0] * v - 2.0 * h.mom[4]);
+    f2[a] = v * (h.mom[1] * v - 2.0 * h.mom[5]);
+    f3[a] = v * (n3 * v - 2.0 * s3);
+  }
+  if (lane == 0) s_nsurv = 0;
+  __syncthreads();
+  // closed-form SSE of candidate (pair, ic): the SAME expression in both passes (and in allelic_fraction_kernel)
+  auto screen = [&](double fij, double sij, uint32_t ic) {
+    const double vl = __dsub_rn(1.0, __dadd_rn(sij, vals[ic]));
+    return (fij + f3[ic]) + vl * (n4 * vl - s4c2);
+  };
+  // minimum of the screen over the k of one pair: in k it is the parabola (n3 + n4) v^2 - 2 v (S3 + n4 c - S4) + const, c = 1 - sij, sampled
+  // at the ascending vals[k]; its discrete minimum lies next to the vertex (or at the end of the range the vertex lies beyond)
+  const double curv = n3 + n4;
+  const bool flat = !(curv > 0.5);  // no position with two plain bases: the screen does not depend on k
+  const double inv_curv = flat ? 0.0 : 1.0 / curv;
+  auto pair_min = [&](double fij, double sij, uint32_t cnt) {
+    double pm = 1e300;
+    uint32_t lo = 0, hi = cnt;
+    if (!flat) {
+      const double vstar = (s3 + n4 * (1.0 - sij) - s4c) * inv_curv;
+      const int kc = vstar > 0.0 ? (vstar < 1.5 ? (int)(vstar * 100.0 + 0.5) : 150) : 0;
+      lo = (uint32_t)max(0, min(kc - 2, (int)cnt - 5));
+      hi = min(cnt, lo + 5u);
+    }
+    for (uint32_t ic = lo; ic < hi; ++ic) {
+      const double a = screen(fij, sij, ic);
+      pm = a < pm ? a : pm;
+    }
+    return pm;
+  };
+  double my_min = 1e300;
+  for (uint32_t p = lane; p < grid.npairs; p += 64) {
+    const uint32_t e = grid.pair[p];
+    const uint32_t ia = (e & 0xffffu) / 100u, ib = (e & 0xffffu) % 100u, cnt = e >> 16;
+    const double pm = pair_min(qtot + f1[ia] + f2[ib], __dadd_rn(vals[ia], vals[ib]), cnt);
+    my_min = pm < my_min ? pm : my_min;
+  }
+  const double cut = wave_min_all(my_min) + kScreenMargin;
+  // the reference's summation for one candidate (decompose.h:596-606); tp / cls are wave-uniform
+  auto exact_sse = [&](const double* mine) {
+    double sse = 0;
+    for (uint32_t q = 0; q < terms; ++q) {
+      const double df = __dsub_rn(mine[cls[q]], tp[q]);
+      sse = __dadd_rn(sse, __dmul_rn(df, df));
+    }
+    return sse;
+  };
+  double my_sse = 1e300;
+  uint32_t my_idx = 0xffffffffu;
+  for (uint32_t p = lane; p < grid.npairs; p += 64) {
+    const uint32_t e = grid.pair[p];
+    const uint32_t code = e & 0xffffu, ia = code / 100u, ib = code % 100u, cnt = e >> 16;
+    const double sij = __dadd_rn(vals[ia], vals[ib]);
+    const double fij = qtot + f1[ia] + f2[ib];
+    if (!(pair_min(fij, sij, cnt) <= cut)) continue;
+    for (uint32_t ic = 0; ic < cnt; ++ic) {
+      if (screen(fij, sij, ic) > cut) continue;
+      const uint32_t idx = code * 100u + ic;
+      const uint32_t slot = atomicAdd(&s_nsurv, 1u);
+      if (slot < (uint32_t)AF2_SURVIVORS) { s_surv[slot] = idx; continue; }
+      // list full: evaluate right here (class values through a private table in LDS would need a slot per lane: selects instead)
+      const double vi = vals[idx / 10000], vj = vals[(idx / 100) % 100], vk = vals[idx % 100];
+      const double pv[5] = {0.0, vi, vj, vk, __dsub_rn(1.0, __dadd_rn(__dadd_rn(vi, vj), vk))};
+      const double sse = af_exact_sse(tp, cls, terms, pv);
+      if (sse < my_sse || (sse == my_sse && idx < my_idx)) { my_sse = sse; my_idx = idx; }
+    }
+  }
+  __syncthreads();
+  // exact stage: lane 0 sums the start point (0.5, 0.5, 0, 0) (decompose.h:586-591), lanes 1.. one listed survivor each
+  const uint32_t nsurv = min(s_nsurv, (uint32_t)AF2_SURVIVORS);
+  double sse0 = 0;
+  if (lane <= nsurv) {
+    double pv[5] = {0.0, 0.5, 0.5, 0.0, 0.0};
+    if (lane > 0) {
+      const uint32_t idx = s_surv[lane - 1];
+      const double vi = vals[idx / 10000], vj = vals[(idx / 100) % 100], vk = vals[idx % 100];
+      pv[1] = vi; pv[2] = vj; pv[3] = vk;
+      pv[4] = __dsub_rn(1.0, __dadd_rn(__dadd_rn(vi, vj), vk));
+    }
+    for (int c = 0; c < 5; ++c) s_pv[lane][c] = pv[c];
+    const double sse = exact_sse(s_pv[lane]);
+    if (lane == 0) sse0 = sse;
+    else if (sse < my_sse || (sse == my_sse && s_surv[lane - 1] < my_idx)) { my_sse = sse; my_idx = s_surv[lane - 1]; }
+  }
+  sse0 = __shfl(sse0, 0, 64);
+  // lowest-index strict minimum below the start SSE == the reference's chain of strict improvements
+  const double best = wave_min_all(my_idx != 0xffffffffu ? my_sse : 1e300);
+  uint32_t bidx = (my_idx != 0xffffffffu && my_sse == best) ? my_idx : 0xffffffffu;
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)bidx, o, 64); bidx = x < bidx ? x : bidx; }
+  if (lane == 0) {
+    double bi = 0.5, bj = 0.5;
+    if (bidx != 0xffffffffu && best < sse0) { bi = vals[bidx / 10000]; bj = vals[(bidx / 100) % 100]; }
+    fractions[2 * t] = bi;
+    fractions[2 * t + 1] = bj;
+  }
+}
+
 template <class T>
 int to_device(tracyhip_ctx* ctx, DevBuf& b, const std::vector<T>& v, const T** out) {
   HIP_TRY(b.ensure(sizeof(T) * std::max<size_t>(v.size(), 1)));
@@ -714,27 +927,52 @@ static int ensure_af_grid(tracyhip_ctx* ctx, AfGrid& g) {
     return t;
   }();
   if (tab.size() > (size_t)AF_STEPS * AF_THREADS) return set_error(TRACYHIP_ERR_RANGE, "allelicFraction grid larger than the unrolled schedule");
+  static const std::vector<double> vals = [] {  // for (double i = 0; i <= 1; i += 0.01): the same doubles the kernels build
+    std::vector<double> v(100);
+    double x = 0;
+    for (int a = 0; a < 100; ++a) { v[a] = x; x = x + 0.01; }
+    return v;
+  }();
+  const size_t pair_bytes = (tab.size() * sizeof(uint32_t) + 7) & ~(size_t)7;
   if (!ctx->aftab_ready) {
-    HIP_TRY(ctx->d_aftab.ensure(tab.size() * sizeof(uint32_t)));
+    HIP_TRY(ctx->d_aftab.ensure(pair_bytes + vals.size() * sizeof(double)));
     HIP_TRY(hipMemcpyAsync(ctx->d_aftab.p, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(ctx->d_aftab.p) + pair_bytes, vals.data(), vals.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     ctx->aftab_ready = true;
   }
   g.npairs = (uint32_t)tab.size();
   g.pair = static_cast<const uint32_t*>(ctx->d_aftab.p);
+  g.vals = reinterpret_cast<const double*>(static_cast<const char*>(ctx->d_aftab.p) + pair_bytes);
   return TRACYHIP_OK;
 }
 
 int launch_allelic_fraction(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig,
                             const int32_t* d_pos, const uint8_t* d_pri, const uint8_t* d_sec, uint32_t trim_left, uint32_t trim_right,
-                            double* d_out, uint64_t work_bytes) {
+                            double* d_out, uint64_t work_bytes, uint64_t bext) {
   if (n == 0) return TRACYHIP_OK;
   const size_t lds = (((size_t)maxbc * 36 + 64) + 15) & ~(size_t)15;  // tp (4 doubles per basecall) + class bytes
   const bool global = lds > kLdsStageLimit;
   AfGrid grid{};
   int rc = ensure_af_grid(ctx, grid);
   if (rc) return rc;
+  // two launches (af_prepare_kernel / af_search_kernel) when the extent of the basecall arrays is known and the scratch can be had
+  bool split = bext != 0 && !ctx->knobs.no_af_split;
+  AfScratch sc{};
+  if (split) {
+    const size_t tp_bytes = (size_t)bext * 32, cls_bytes = ((size_t)bext * 4 + 63) & ~(size_t)63, hdr_bytes = sizeof(AfHeader) * (size_t)n;
+    if (ctx->d_afscratch.ensure(tp_bytes + cls_bytes + hdr_bytes) != hipSuccess) { (void)hipGetLastError(); split = false; }
+    else {
+      char* p = static_cast<char*>(ctx->d_afscratch.p);
+      sc.tp = reinterpret_cast<double*>(p);
+      sc.cls = reinterpret_cast<uint8_t*>(p + tp_bytes);
+      sc.hdr = reinterpret_cast<AfHeader*>(p + tp_bytes + cls_bytes);
+    }
+  }
   { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_AFRAC, 0, work_bytes); if (trc_) return trc_; }
-  if (global) {
+  if (split) {
+    hipLaunchKernelGGL(af_prepare_kernel, dim3(n), dim3(64), 0, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, trim_left, trim_right, sc, d_out);
+    hipLaunchKernelGGL(af_search_kernel, dim3(n), dim3(64), 0, ctx->stream, d_desc, sc.tp, sc.cls, sc.hdr, grid, d_out);
+  } else if (global) {
     HIP_TRY(ctx->d_bits.ensure(lds * (size_t)n));
     hipLaunchKernelGGL(allelic_fraction_kernel<true>, dim3(n), dim3(AF_THREADS), 0, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, trim_left,
                        trim_right, grid, d_out, static_cast<char*>(ctx->d_bits.p), lds);
@@ -925,7 +1163,7 @@ int tracyhip_allelic_fraction(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, c
   for (uint32_t i = 0; i < n; ++i) maxbc = std::max(maxbc, bc->bc_len[i]);
   if ((rc = launch_allelic_fraction(ctx, dd, n, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos),
                                     static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sec), trim_left, trim_right,
-                                    static_cast<double*>(d_out))))
+                                    static_cast<double*>(d_out), 0, bext)))
     return rc;
   if ((rc = unstage(ctx, fractions, d_out, sizeof(double) * 2 * (size_t)n, mem))) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));

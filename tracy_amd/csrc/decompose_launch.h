@@ -24,7 +24,8 @@ int launch_secdecomp(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32
                      const uint8_t* d_pri, const uint8_t* d_sec, uint8_t* d_out);
 int launch_allelic_fraction(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig,
                             const int32_t* d_pos, const uint8_t* d_pri, const uint8_t* d_sec, uint32_t trim_left, uint32_t trim_right,
-                            double* d_out, uint64_t work_bytes = 0);
+                            double* d_out, uint64_t work_bytes = 0, uint64_t bext = 0);  // bext: extent of the basecall arrays (max of
+                            // bc_off + nbc; 0 = not known): with it the two-launch form runs (af_prepare_kernel / af_search_kernel, scratch of 36 bext bytes)
 
 }  // namespace tracyhip
 #endif

@@ -289,11 +289,12 @@ TR_HD void decomp_wave_body(W& w, const DecompWaveArgs& wa, uint32_t t) {
   uint64_t* tmp1 = tmp0 + 4u * kChunks;                          // ... reference row
 #pragma unroll
   for (uint32_t i = 0; i < kChunks; ++i) {
-    if (i >= nch) break;  // (wave-uniform)
+    if (i < nch) {  // (wave-uniform)
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-      const uint64_t q0 = w.ballot(((v0[i] >> (8u * k)) & 0xffu) != (uint32_t)'-'), q1 = w.ballot(((v1[i] >> (8u * k)) & 0xffu) != (uint32_t)'-');
-      if (lane == k) { tmp0[4u * i + k] = q0; tmp1[4u * i + k] = q1; }
+      for (uint32_t k = 0; k < 4; ++k) {
+        const uint64_t q0 = w.ballot(((v0[i] >> (8u * k)) & 0xffu) != (uint32_t)'-'), q1 = w.ballot(((v1[i] >> (8u * k)) & 0xffu) != (uint32_t)'-');
+        if (lane == k) { tmp0[4u * i + k] = q0; tmp1[4u * i + k] = q1; }
+      }
     }
   }
   w.sync();

@@ -201,20 +201,42 @@ __global__ __launch_bounds__(64) void rowmax_rest_kernel(const RowMaxDesc* desc,
 // flag |= 2 where a column is none of A C G T N, |= 4 where it is N (both rare): the origin sweeps size their table by it
 // special (or null): the block map of the codes written (DpArgs::special_blocks: one byte per 256 code bytes, set where a block holds
 // anything but A C G T)
+// (sixteen bytes per thread, as encode_codes_kernel: a byte per thread made 3 * 10^8 threads of the windows of a 100 000-trace batch;
+// flags through one atomic per wave that has something to report)
+constexpr uint32_t kCqBytesPerThread = 16;
 __global__ void encode_cq_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t n, int32_t* flag, uint8_t* __restrict__ special) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const uint32_t c = cq_code(in[i]);
-    out[i] = (uint8_t)c;
-    if (c >= 4u) {
-      atomicOr(flag, c >= 5u ? 2 : 4);
-      if (special) special[i >> 8] = 1;
+  const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * kCqBytesPerThread;
+  int32_t f = 0;
+  if (i0 < n) {
+    const uint32_t cnt = n - i0 < kCqBytesPerThread ? (uint32_t)(n - i0) : kCqBytesPerThread;
+    uint8_t b[kCqBytesPerThread];
+    if (cnt == kCqBytesPerThread) __builtin_memcpy(b, in + i0, kCqBytesPerThread);  // (any alignment)
+    else for (uint32_t j = 0; j < cnt; ++j) b[j] = in[i0 + j];
+    bool any = false;
+#pragma unroll
+    for (uint32_t j = 0; j < kCqBytesPerThread; ++j) {
+      const uint32_t c = j < cnt ? cq_code(b[j]) : 0u;
+      b[j] = (uint8_t)c;
+      if (c >= 4u) { f |= c >= 5u ? 2 : 4; any = true; }
     }
+    if (cnt == kCqBytesPerThread) __builtin_memcpy(out + i0, b, kCqBytesPerThread);
+    else for (uint32_t j = 0; j < cnt; ++j) out[i0 + j] = b[j];
+    if (any && special) { special[i0 >> 8] = 1; special[(i0 + cnt - 1) >> 8] = 1; }  // (sixteen bytes lie in at most two blocks of 256)
   }
+  if (f) atomicOr(flag, f);
 }
 __global__ void cq_rows_kernel(const uint8_t* __restrict__ in, uint64_t n, int32_t* flag) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && !cq_row_char(in[i])) atomicOr(flag, 1);
+  const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * kCqBytesPerThread;
+  if (i0 >= n) return;
+  const uint32_t cnt = n - i0 < kCqBytesPerThread ? (uint32_t)(n - i0) : kCqBytesPerThread;
+  uint8_t b[kCqBytesPerThread];
+  if (cnt == kCqBytesPerThread) __builtin_memcpy(b, in + i0, kCqBytesPerThread);
+  else for (uint32_t j = 0; j < cnt; ++j) b[j] = in[i0 + j];
+  bool bad = false;
+#pragma unroll
+  for (uint32_t j = 0; j < kCqBytesPerThread; ++j)
+    if (j < cnt && !cq_row_char(b[j])) bad = true;
+  if (bad) atomicOr(flag, 1);
 }
 
 // reference characters -> profile-row codes (align.h:121-136), sixteen bytes per thread.  special: one byte per 256 code bytes, set

@@ -1742,7 +1742,8 @@ struct DecomposeRun {
         return rc;
       if ((rc = launch_allelic_fraction(ctx, db, nt, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos),
                                         static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sd), TL, TR,
-                                        static_cast<double*>(d_fr), 18ull * std::accumulate(mf.begin(), mf.end(), 0ull))))
+                                        static_cast<double*>(d_fr), 18ull * std::accumulate(mf.begin(), mf.end(), 0ull),
+                                        [&] { uint64_t e = 0; for (uint32_t t = 0; t < nt; ++t) e = std::max<uint64_t>(e, bc.bc_offset[t] + mf[t]); return e; }())))
         return rc;
     }
     return TRACYHIP_OK;
@@ -1764,11 +1765,11 @@ struct DecomposeRun {
       HIP_TRY(hipMemsetAsync(b_cq1.p, 5, (er ? er : 1) + 2 * kCodePad, st));
       HIP_TRY(hipMemsetAsync(b_cq2.p, 5, (bext ? bext : 1) + 2 * kCodePad, st));
       HIP_TRY(hipMemsetAsync(b_cqf.p, 0, sizeof(int32_t), st));
-      if (er) hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((er + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), d_cq_ref, er, static_cast<int32_t*>(b_cqf.p), (uint8_t*)nullptr);
+      if (er) hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((er + 4095) / 4096)), dim3(256), 0, st, static_cast<const uint8_t*>(d_ref), d_cq_ref, er, static_cast<int32_t*>(b_cqf.p), (uint8_t*)nullptr);
       if (bext) {
-        hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), d_cq_sd, bext, static_cast<int32_t*>(b_cqf.p), (uint8_t*)nullptr);
-        hipLaunchKernelGGL(cq_rows_kernel, dim3((unsigned)((bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_pri), bext, static_cast<int32_t*>(b_cqf.p));
-        hipLaunchKernelGGL(cq_rows_kernel, dim3((unsigned)((bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), bext, static_cast<int32_t*>(b_cqf.p));
+        hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((bext + 4095) / 4096)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), d_cq_sd, bext, static_cast<int32_t*>(b_cqf.p), (uint8_t*)nullptr);
+        hipLaunchKernelGGL(cq_rows_kernel, dim3((unsigned)((bext + 4095) / 4096)), dim3(256), 0, st, static_cast<const uint8_t*>(d_pri), bext, static_cast<int32_t*>(b_cqf.p));
+        hipLaunchKernelGGL(cq_rows_kernel, dim3((unsigned)((bext + 4095) / 4096)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), bext, static_cast<int32_t*>(b_cqf.p));
       }
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(&h_cq_flag, b_cqf.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));

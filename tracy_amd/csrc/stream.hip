@@ -729,6 +729,10 @@ struct OrientStage {
   int32_t* d_lastrow;
   bool exact;
   PairDesc* desc_trim;     // `tracy decompose`, or null
+  // or work of the call that depends on nothing the orientation stage makes: queued on the call's stream behind the full sweeps, BEFORE
+  // the stream waits for the voted strand's chain -- whose band tiers, launches of a few waves' depth, only get going when the sweeps drain
+  // (they need 15-20 KB of LDS per workgroup; the sweeps' 7.5 KB workgroups leave no such hole) and leave the device nearly idle for 3-4 ms
+  std::function<int()> filler;
 };
 int queue_orientation(tracyhip_ctx* ctx, const tracyhip_params& p, const SParams& sp, const StreamHost& h, StreamCommon& sc, const OrientStage& os) {
   hipStream_t st = ctx->stream;
@@ -789,6 +793,10 @@ int queue_orientation(tracyhip_ctx* ctx, const tracyhip_params& p, const SParams
       TRY(timing_begin(ctx, TRACYHIP_TIMER_SCORE, 0, 0));
       HIP_TRY(launch_gotoh_ckpt_front(c.K, af, 2 * (c.hi - c.lo), ap, 0u, st));
       TRY(timing_end(ctx));
+    }
+    if (os.filler) {
+      const int frc = os.filler();
+      if (frc) { HIP_TRY(hipStreamWaitEvent(st, fk.joined[0], 0)); return frc; }
     }
     HIP_TRY(hipStreamWaitEvent(st, fk.joined[0], 0));
   } else {
@@ -1547,6 +1555,9 @@ struct DecStream {
   uint32_t* hdead = nullptr;
   std::vector<uint32_t> dl;  // the traces the device could not give their tier
   bool af_forked = false;    // allelicFraction is on a side stream (joined before the read-back)
+  bool af_pending = false;   // ... not queued yet (queue_allelic_fraction)
+  bool bp_early = false;     // findBreakpoint and the windows' case-sensitive codes were queued behind the full sweeps (OrientStage::filler)
+  bool cq_ref_done = false;
 
   DecStream(tracyhip_ctx* c, const tracyhip_decompose_job* j, const tracyhip_params* q, int m, const tracyhip_decompose_result* o_, StreamHost& h_)
       : ctx(c), job(j), prm(q), mem(m), out(o_), kn(c->knobs), nt(j->ntraces), sp(j->profiles), sr(j->refs), bc(j->bc), dp(j->dprm), st(c->stream), p(*q),
@@ -1559,6 +1570,7 @@ struct DecStream {
   }
   // whatever happens once the stages are queued, the caller's basecalls in device memory are put back before the host-planned pipeline takes the call
   int give_up(int rc) {
+    if (rc != TRACYHIP_OK) af_pending = false;  // (the host-planned pipeline redoes the call)
     if (rc != TRACYHIP_OK && af_forked) {  // (nothing of this call may still run when the caller -- or the host-planned pipeline -- takes the buffers back)
       (void)hipStreamWaitEvent(st, ctx->b16_fork.joined[3], 0);
       af_forked = false;
@@ -1766,8 +1778,19 @@ struct DecStream {
     d_qp = static_cast<const int16_t*>(ctx->d_b16tab[2].p);
     d_lastrow = static_cast<int32_t*>(ctx->d_lastrow.p);
     OrientStage os{d_prof, d_qp, d_lastrow, exact, A.desc_trim};
-    TRY(give_up(queue_orientation(ctx, p, spm, h, sc, os)));
+    // the descriptors of the decompose stages need nothing but the geometry records; findBreakpoint (indigo.h:196) nothing but the profiles:
+    // it runs on a side stream beside the sweeps and is waited for where its result is first read (findHomozygousBreakpoint)
     hipLaunchKernelGGL(s_expand_d_kernel, g256, b256, 0, st, sc.geom, A.geomd, nt, z.bext, A.bpd, A.rowsd, A.dd, A.bcd, A.atd);
+    HIP_TRY(hipGetLastError());
+    // findBreakpoint (indigo.h:196) needs nothing but the profiles, the case-sensitive codes of the windows (the allele stages' columns)
+    // nothing but the references: both fill the hole behind the full sweeps (OrientStage::filler)
+    bp_early = ctx->b16_fork_ok && !ctx->knobs.no_fork;
+    if (bp_early)
+      os.filler = [&]() -> int {
+        TRY(launch_breakpoint(ctx, A.bpd, nt, h.maxmt, d_prof, reinterpret_cast<BreakpointOut*>(d_bp)));
+        return encode_windows_cq();
+      };
+    TRY(give_up(queue_orientation(ctx, p, spm, h, sc, os)));
     hipLaunchKernelGGL(s_prelim_plan_kernel, g256, b256, 0, st, spm, 1, sc.geom, sc.tr, sc.ce, sc.top_trim, sc.dead, sc.cand, sc.kc);
     HIP_TRY(hipGetLastError());
     BandLaunch b0;
@@ -1788,7 +1811,7 @@ struct DecStream {
     // ---- 1. findBreakpoint (indigo.h:196), 4. findHomozygousBreakpoint (indigo.h:314-317), 5. decomposeAlleles, generateSecondaryDecomposed,
     // allelicFraction (indigo.h:340-350) ----
     BreakpointOut* bpo = reinterpret_cast<BreakpointOut*>(d_bp);
-    TRY(launch_breakpoint(ctx, A.bpd, nt, h.maxmt, d_prof, bpo));
+    if (!bp_early) TRY(launch_breakpoint(ctx, A.bpd, nt, h.maxmt, d_prof, bpo));
     TRY(launch_homozygous(ctx, A.rowsd, A.rows0, A.rows1, nt, bpo, A.hst, A.len1));
     {
       DecompArgs a{};
@@ -1804,18 +1827,10 @@ struct DecStream {
       TRY(launch_decompose(ctx, a, bpo, maxbc, 0, 0));
       TRY(launch_secdecomp(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sec, d_sd));
       // allelicFraction feeds nothing but its own result (indigo.h:350): it runs beside the allele stages, which read the same
-      // decomposed basecalls and write elsewhere; the read-back waits for it
-      af_forked = ctx->b16_fork_ok && !ctx->knobs.no_fork;
-      if (af_forked) {
-        const B16Fork& fk = ctx->b16_fork;
-        HIP_TRY(hipEventRecord(fk.forked, st));
-        HIP_TRY(hipStreamWaitEvent(fk.side[3], fk.forked, 0));
-        ctx->stream = fk.side[3];
-      }
-      const int rc = launch_allelic_fraction(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sd, TL, TR, d_fr, 18ull * std::accumulate(h.mf.begin(), h.mf.end(), 0ull));
-      ctx->stream = st;
-      if (rc) return rc;
-      if (af_forked) HIP_TRY(hipEventRecord(ctx->b16_fork.joined[3], ctx->b16_fork.side[3]));
+      // decomposed basecalls and write elsewhere; the read-back waits for it.  It is QUEUED once the allele stages' first long launch is
+      // (queue_allelic_fraction): beside the encoders' fills and copies it would only make those wait for its hundred thousand waves.
+      af_pending = ctx->b16_fork_ok && !ctx->knobs.no_fork;
+      if (!af_pending) TRY(queue_allelic_fraction());
     }
     hipLaunchKernelGGL(s_status_kernel, g256, b256, 0, st, spm, sc.geom, o.score_trim, A.hst, A.len1, sc.dead, o.status, sc.cnt);
     HIP_TRY(hipGetLastError());
@@ -1823,23 +1838,53 @@ struct DecStream {
     return TRACYHIP_OK;
   }
 
+  // allelicFraction (indigo.h:350) on the low-priority side stream, behind the point of the call's stream at which the decomposed basecalls
+  // were complete (ready[0]); on the call's stream itself without side streams
+  // case-sensitive codes of the reference windows (MODE_CQ columns of the allele stages), their block map and the verdict words: once
+  int encode_windows_cq() {
+    if (cq_ref_done) return TRACYHIP_OK;
+    cq_ref_done = true;
+    d_cq_ref = A.cq_ref + kCodePad;
+    HIP_TRY(hipMemsetAsync(A.cq_ref, 5, kCodePad, st));
+    HIP_TRY(hipMemsetAsync(A.cq_ref + kCodePad + z.er, 5, kCodePad, st));
+    HIP_TRY(hipMemsetAsync(A.cq_special, 0, (z.er >> 8) + 2, st));
+    HIP_TRY(hipMemsetAsync(A.cq_flag, 0, sizeof(int32_t) * 4, st));
+    if (z.er) hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((z.er + 4095) / 4096)), dim3(256), 0, st, d_ref, d_cq_ref, z.er, A.cq_flag, A.cq_special);
+    HIP_TRY(hipGetLastError());
+    return TRACYHIP_OK;
+  }
+
+  int queue_allelic_fraction() {
+    const bool fork = af_pending;
+    af_pending = false;
+    if (fork) {
+      HIP_TRY(hipStreamWaitEvent(ctx->b16_fork.side[3], ctx->b16_fork.ready[0], 0));
+      ctx->stream = ctx->b16_fork.side[3];
+    }
+    const int rc = launch_allelic_fraction(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sd, TL, TR, d_fr, 18ull * std::accumulate(h.mf.begin(), h.mf.end(), 0ull), z.bext);
+    ctx->stream = st;
+    if (fork) {
+      HIP_TRY(hipEventRecord(ctx->b16_fork.joined[3], ctx->b16_fork.side[3]));
+      af_forked = true;
+    }
+    return rc;
+  }
+
   int queue_allele_stages() {
     StreamCommon& sc = A.sc;
     // ---- 6. allele-specific alignments (indigo.h:355-387), both alleles of every trace in the same launches ----
     // strings scored through the query-profile table (MODE_CQ): the two allele strings side by side, case-sensitive codes of the windows
     // and of allele 2, the test that the rows hold A C G T N only (read with the call's verdict words)
-    d_cq_ref = A.cq_ref + kCodePad;
     d_cq_sd = A.cq_sd + kCodePad;
     HIP_TRY(hipMemcpyAsync(A.seqs2, d_pri, z.bext, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(A.seqs2 + z.bext, d_sd, z.bext, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemsetAsync(A.cq_ref, 5, z.er + 2 * kCodePad, st));
-    HIP_TRY(hipMemsetAsync(A.cq_sd, 5, z.bext + 2 * kCodePad, st));
-    HIP_TRY(hipMemsetAsync(A.cq_special, 0, (z.er >> 8) + 2, st));
-    HIP_TRY(hipMemsetAsync(A.cq_flag, 0, sizeof(int32_t) * 4, st));
-    if (z.er) hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((z.er + 255) / 256)), dim3(256), 0, st, d_ref, d_cq_ref, z.er, A.cq_flag, A.cq_special);
+    TRY(encode_windows_cq());
+    // (the encoders write every code byte: only the spare bytes on both sides are filled)
+    HIP_TRY(hipMemsetAsync(A.cq_sd, 5, kCodePad, st));
+    HIP_TRY(hipMemsetAsync(A.cq_sd + kCodePad + z.bext, 5, kCodePad, st));
     if (z.bext) {
-      hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((z.bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), d_cq_sd, z.bext, A.cq_flag, (uint8_t*)nullptr);
-      hipLaunchKernelGGL(cq_rows_kernel, dim3((unsigned)((2 * z.bext + 255) / 256)), dim3(256), 0, st, static_cast<const uint8_t*>(A.seqs2), 2 * z.bext, A.cq_flag);
+      hipLaunchKernelGGL(encode_cq_kernel, dim3((unsigned)((z.bext + 4095) / 4096)), dim3(256), 0, st, static_cast<const uint8_t*>(d_sd), d_cq_sd, z.bext, A.cq_flag, (uint8_t*)nullptr);
+      hipLaunchKernelGGL(cq_rows_kernel, dim3((unsigned)((2 * z.bext + 4095) / 4096)), dim3(256), 0, st, static_cast<const uint8_t*>(A.seqs2), 2 * z.bext, A.cq_flag);
     }
     HIP_TRY(hipGetLastError());
     d_aqp = static_cast<const int16_t*>(ctx->d_b16tab[0].p);
@@ -1856,10 +1901,13 @@ struct DecStream {
       a.qlimit = sub_limit(&p);
       a.special_blocks = kn.no_compact ? nullptr : A.cq_special;
       a.lastrow = d_lastrow;
+      // (the side stream starts where the call's stream is NOW: allelicFraction begins with the prefixes, not with the fills and copies)
+      if (af_pending) HIP_TRY(hipEventRecord(ctx->b16_fork.ready[0], st));
       TRY(timing_begin(ctx, TRACYHIP_TIMER_SCORE, 0, 0));
       HIP_TRY(launch_gotoh_front_prefix_cq(a, 2 * nt, st));
       TRY(timing_end(ctx));
     }
+    if (af_pending) TRY(give_up(queue_allelic_fraction()));
     TRY(timing_begin(ctx, TRACYHIP_TIMER_FRONT, 0, 0));
     {
       int rc = front_tiers_run(ctx, p, sc, 2 * nt, d_aqp, d_cq_ref, reinterpret_cast<const uint32_t*>(d_lastrow), max_arest);
@@ -1892,6 +1940,7 @@ struct DecStream {
   // the one read-back: verdict words, counters, dead flags
   int read_back() {
     StreamCommon& sc = A.sc;
+    if (af_pending) TRY(queue_allelic_fraction());
     if (af_forked) HIP_TRY(hipStreamWaitEvent(st, ctx->b16_fork.joined[3], 0));
     // ---- the one read-back ----
     const size_t rb = sizeof(int32_t) * (kErrWords + 4) + sizeof(int32_t) * 4 + sizeof(unsigned long long) * (SC_COUNT + SB_COUNT * 8) + sizeof(uint32_t) * (size_t)nt;
@@ -2015,7 +2064,7 @@ int tracyhip::stream_decompose(tracyhip_ctx* ctx, const tracyhip_decompose_job* 
   DecStream s(ctx, job, prm, mem, out, h);
   { TRACYHIP_HOST_SCOPE(hs, "stream_decompose.plan"); TRY(s.plan()); }
   { TRACYHIP_HOST_SCOPE(hs, "stream_decompose.bind"); TRY(s.bind()); }
-  { TRACYHIP_HOST_SCOPE(hs, "stream_decompose.queue_trace_stages"); TRY(s.queue_trace_stages()); }    // 2., 3., then 1., 4., 5. (indigo.h:196-350)
+  { TRACYHIP_HOST_SCOPE(hs, "stream_decompose.queue_trace_stages"); if (int rc = s.queue_trace_stages()) return s.give_up(rc); }    // 2., 3., then 1., 4., 5. (indigo.h:196-350)
   { TRACYHIP_HOST_SCOPE(hs, "stream_decompose.queue_allele_stages"); if (int rc = s.queue_allele_stages()) return s.give_up(rc); }  // 6. (indigo.h:355-387)
   TRACYHIP_HOST_SCOPE(hs_rb, "stream_decompose.read_back_and_after");
   if (int rc = s.read_back()) return s.give_up(rc);            // the call's one synchronisation

@@ -125,7 +125,7 @@ def stub_rank(args, rank, world):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
     if rank == 0:
-        print(json.dumps({"metric": "launcher-selftest", "stub": True, "value": 0.0, "unit": "none", "n_gpus": world, "rccl_ranks": world,
+        print(json.dumps({"metric": "launcher-selftest", "stub": True, "value": 0.0, "unit": "none", "n_gpus": world, "rccl_ranks": 0,
                           "backend": "gloo", "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tmax[0]) / max(args.steps, 1) * 1e3, 4),
                           "rank_sum": float(tsum[1])}))
     dist.destroy_process_group()
@@ -140,10 +140,10 @@ def main():
     ap.add_argument("--decompose-steps", type=int, default=3)
     ap.add_argument("--allpairs-traces", type=int, default=1000, help="configs[4]: traces of the all-pairs job (pair list sharded over the ranks)")
     ap.add_argument("--allpairs-steps", type=int, default=3)
-    ap.add_argument("--seedextend-traces", type=int, default=125000,
-                    help="configs[3]: traces PER GPU of the seed + extend job (1M traces over 8 GPUs = 125 000 each; the job is this x the ranks)")
+    ap.add_argument("--seedextend-traces", type=int, default=1000000,
+                    help="configs[3]: traces of the seed + extend job IN ALL (BASELINE: 1M traces), sharded over the ranks -- one GPU takes the million")
     ap.add_argument("--seedextend-genome-mb", type=float, default=50.0, help="configs[3]: size of the synthetic genome (GRCh38 chr22 is 50.8 Mb)")
-    ap.add_argument("--seedextend-steps", type=int, default=2)
+    ap.add_argument("--seedextend-steps", type=int, default=1)
     ap.add_argument("--cli-workdir", default=None, help="the CLI leg: directory for its input and output files (default: /dev/shm when it has room, else the system's temporary directory)")
     ap.add_argument("--cli-traces", type=int, default=10000, help="the CLI leg: ABIF files per command (`align --batch`, `decompose --batch`); 0 = skip")
     ap.add_argument("--extra-legs", type=int, default=1, help="decompose: also time the strand-certificate and two-lane legs")
@@ -185,6 +185,7 @@ def main():
         from tools.legs import rank_threads
         os.environ.setdefault("TRACYHIP_HOST_THREADS", str(rank_threads(world)))
     dist = None
+    backend = "none"  # no process group: one rank started by hand
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -192,6 +193,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = dist.get_backend()
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: the process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     dev = torch.device("cuda", local)
@@ -205,8 +207,8 @@ def main():
                     return None
                 return CliLeg(args.cli_traces, rank, world, dev, workdir=args.cli_workdir).run(dist, cpu_sample=320 if args.cpu_sample != 0 else 0)
             if which == "seedextend":
-                leg = SeedExtendLeg(args.seedextend_traces * world, args.seedextend_genome_mb, 1000, rank, world, dev, dist)
-                res = leg.run(dist, args.seedextend_steps, 1, cpu_sample=64 if args.cpu_sample != 0 else 0)
+                leg = SeedExtendLeg(args.seedextend_traces, args.seedextend_genome_mb, 1000, rank, world, dev, dist)
+                res = leg.run(dist, args.seedextend_steps, 1, cpu_sample=256 if args.cpu_sample != 0 else 0)
             elif which == "decompose":
                 leg = DecomposeLeg(args.decompose_traces, 3000, 1000, rank, world, dev)
                 res = leg.run(dist, args.decompose_steps, 1, extra_legs=bool(args.extra_legs), cpu_sample=128 if args.cpu_sample != 0 else 0)
@@ -227,7 +229,8 @@ def main():
         extra[args.workload] = run_extra(args.workload)
         if rank == 0:
             line = extra[args.workload]
-            line["rccl_ranks"] = world
+            line["backend"] = backend
+            line["rccl_ranks"] = world if backend == "nccl" else 0  # ranks RCCL really connected (gloo: bench.py --share-device, the CPU tests)
             print(json.dumps(line))
         if dist is not None:
             dist.destroy_process_group()
@@ -435,14 +438,17 @@ def main():
 
     line = {
         "metric": "GCUPS (tracy align: Gotoh affine-gap DP cells per second, whole job)",
-        "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "rccl_ranks": world if dist is not None else 1, "steps": args.steps, "warmup": args.warmup,
+        "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "backend": backend, "rccl_ranks": world if backend == "nccl" else 0, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int16 (score sweeps) / int32 (tracebacks)", "data": "synthetic",
         "traces_per_s": round(nt * world * args.steps / elapsed_max, 1),
         "config": {"workload": "configs[1]: %d synthetic %d-base traces `align` vs %d-base reference windows per GPU, "
                                "full Gotoh (2 score-only + 2 traceback DPs per trace), scoring 3/-5/-10/-4, trims 50/50"
                                % (nt, mf, n), "traces_per_gpu": nt, "trace_len": mf, "ref_len": n,
-                   "parallelism": "batch-sharded x%d, no data-path collective" % world, "lanes_per_gpu": max(1, args.lanes)},
+                   "parallelism": "batch-sharded x%d, no data-path collective" % world, "lanes_per_gpu": max(1, args.lanes),
+                   # `value` counts the reference's DP cells; the cells the kernels really evaluated, over the same time:
+                   "gcups_swept_cells": round(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin", "front")) / steps * world / (elapsed_max / steps) / 1e9, 2),
+                   "value_note": "value = reference DP cells (3 x mt x n + mf x slice per trace) / time; gcups_swept_cells = cells swept / the same time"},
         # GCUPS counts the DP cells of the reference's four Gotoh calls per trace.  What is swept: one orientation in
         # full, the other by its prefix rows + a certified band, the preliminary and the final alignment on certified bands -- with
         # results (scores, ends, strings) proven to be the whole matrices'; `gcups_swept_cells` prices the same step by those cells

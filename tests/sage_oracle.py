@@ -369,7 +369,8 @@ def scan_sequence(g, consensus, trim_left, trim_right, kmer, unique):
     hits = []
     ncount = sum(1 for i in range(trim_left, min(trim_left + kmer, len(consensus))) if consensus[i] == "N")
     k = trim_left
-    while k < len(consensus) - trim_right and k < len(consensus):
+    bound = (len(consensus) - trim_right) % (1 << 64)  # fmindex.h:211: size() - trimRight in size_t wraps when the trim is the longer one
+    while k < bound and k < len(consensus):
         if ncount == 0:
             seq = consensus[k:k + kmer]
             loc = g.locate(seq)

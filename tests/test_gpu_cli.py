@@ -143,6 +143,18 @@ def test_batch_manifest_and_errors(tmp_path):
     assert p.returncode == 255 and "larger than the trace" in p.stderr
     p = subprocess.run([CLI, "align"], capture_output=True, text=True)
     assert p.returncode == 255 and "Usage: tracy align" in p.stdout
+    # output files that cannot be written (the prefix's directory does not exist) are reported and count in the exit code, also in --batch mode
+    bad_rows = [rows[0][:2] + (str(tmp_path / "no_such_dir" / "res"),), rows[1]]
+    man2 = str(tmp_path / "manifest2.tsv")
+    open(man2, "w").write("".join("\t".join(r) + "\n" for r in bad_rows))
+    p = subprocess.run([CLI, "align", "--batch", man2], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "Could not write output file" in p.stderr and "no_such_dir" in p.stderr, (p.returncode, p.stderr[-500:])
+    check_outputs(bad_rows[1][2], bad_rows[1][0], bad_rows[1][1])
+    # an index written by an earlier format version is named as such
+    old_idx = str(tmp_path / "old.tidx")
+    open(old_idx, "wb").write(b"TAMDIDX1" + bytes(64))
+    p = subprocess.run([CLI, "align", "-r", old_idx, "-o", str(tmp_path / "y"), rows[0][0]], capture_output=True, text=True)
+    assert p.returncode != 0 and "older version" in p.stderr and "index" in p.stderr, p.stderr[-400:]
 
 
 def test_batch_on_a_device_group(tmp_path):

@@ -99,6 +99,29 @@ def test_get_reference_slice(genome, trims, kmer_support, maxindel):
         assert got["status"][-2] == 0
 
 
+def test_reads_shorter_than_a_trim(genome):
+    """a trim longer than the read wraps the reference's loop bound (fmindex.h:211: size() - trimRight in size_t): windows [trimLeft, size)
+    still vote on that strand -- the one-pass form of both strands must leave such reads to the two scans"""
+    g, brute, _ = genome
+    rng = np.random.default_rng(4711)
+    reads = []
+    for _ in range(20):
+        p = int(rng.integers(0, len(brute.text) - 200))
+        r = brute.text[p:p + int(rng.integers(90, 130))]
+        reads.append(r if rng.random() < 0.5 else so.revcomp(r.encode()).decode())
+    voted = 0
+    for trims in ((20, 150), (150, 20), (14, 140)):
+        got = g.seed([r.encode() for r in reads], trims[0], trims[1], 3, 1000, 2)
+        for i, r in enumerate(reads):
+            want = so.get_reference_slice(brute, r, trims[0], trims[1], 15, 3, 1000)
+            assert (got["status"][i] == 1) == (want is not None), (trims, i)
+            if want is not None:
+                voted += 1
+                assert bool(got["forward"][i]) == want["forward"] and int(got["kmersupport"][i]) == want["kmersupport"], (trims, i)
+                assert int(got["pos"][i]) == want["pos"] and got["slices"][i].decode() == want["refslice"], (trims, i)
+    assert voted >= 20
+
+
 def test_repeat_reads_need_the_second_pass(genome):
     """a read lying inside the 3-copy repeat has no unique 15-mers: the first pass fails, the multi-hit pass ties"""
     g, brute, _ = genome

@@ -153,7 +153,9 @@ class DecomposeLeg:
     """configs[2]: `total` synthetic 1 kb traces `decompose` vs 3 kb windows (80 % het indel + het SNVs, 10 % homozygous indel only,
     10 % no variant, both strands: SURVEY.md 8d), sharded over the ranks by contiguous blocks."""
 
-    def __init__(self, total, ref_len, trace_len, rank, world, dev, lanes=1):
+    def __init__(self, total, ref_len, trace_len, rank, world, dev, lanes=1, first=0):
+        """first: index of the batch's first trace in the seeded sequence (trace i of the 100 000-trace job has seed 5000 + i):
+        a parity test compares blocks taken from all over the job"""
         import tracy_amd
         from tracy_amd import capi, hostlib
         from tracy_amd.shard import shard_range
@@ -162,7 +164,7 @@ class DecomposeLeg:
         nt = self.nt = self.hi - self.lo
         n, mf = ref_len, trace_len
         t0 = time.perf_counter()
-        d = hostlib.synth_decompose_batch(5000 + self.lo, nt, n, mf, rank_threads(world), mix=1)
+        d = hostlib.synth_decompose_batch(5000 + first + self.lo, nt, n, mf, rank_threads(world), mix=1)
         self.synth_s = time.perf_counter() - t0
         ns = d["signal"].shape[2]
         keep_host = min(nt, 256)  # the CPU baseline / parity sample reads the first traces from the host copy
@@ -472,7 +474,7 @@ class AllPairsLeg:
 
 # =====================================================================================================================
 class SeedExtendLeg:
-    """configs[3] at its per-GPU size: `total` 1 kb traces sampled from a synthetic genome (GRCh38 chr22 -- 50.8 Mb -- is not
+    """configs[3]: `total` 1 kb traces (BASELINE: one million) sampled from a synthetic genome (GRCh38 chr22 -- 50.8 Mb -- is not
     available offline; a random genome of `genome_mb` Mb stands in), host k-mer seeding (getReferenceSlice, fmindex.h:236-326, on this
     rank's share of the host threads) + device extend (tracyhip_align_traces with job.oriented: one 16-bit score sweep, the
     preliminary and the final alignment on their bands, trimReferenceSlice).
@@ -517,26 +519,33 @@ class SeedExtendLeg:
         errs = np.random.default_rng(23 + rank)
         self.starts = starts_all[lo:hi]
         nt = self.nt = hi - lo
-        # traces: every other one reads the reverse strand; 1 % substitutions; peaked profile columns
+        # traces: every other one reads the reverse strand; 1 % substitutions; peaked profile columns.  Built block by block (the blocks the
+        # step hands to the device one after the other): a million traces are 24 GB of profiles, and no temporary of that size is wanted
         comp = np.array([3, 2, 1, 0], dtype=np.uint8)
-        codes = np.empty((nt, mf), dtype=np.uint8)
         lut_inv = np.zeros(256, np.uint8)
         lut_inv[lut] = np.arange(4, dtype=np.uint8)
-        for k in range(nt):
-            c = lut_inv[seq[self.starts[k]:self.starts[k] + mf]]
-            codes[k] = comp[c[::-1]] if (lo + k) % 2 else c
-        flip = errs.random((nt, mf)) < 0.01
-        codes = np.where(flip, (codes + 1) % 4, codes).astype(np.uint8)
-        self.profs = np.zeros((nt, 6, mf), np.float32)
-        self.profs[:, :4, :] = 0.02
-        np.put_along_axis(self.profs, codes[:, None, :].astype(np.int64), 0.94, axis=1)
-        cons = lut[codes]
-        self.cons = [cons[k].tobytes() for k in range(nt)]
         self.lo = lo
+        self.CHUNKS = CH = max(4, (nt + 62499) // 62500)  # blocks of at most 62 500 traces (31 250 at the per-GPU size of an 8-GPU job)
+        self.block = [(nt * b // CH, nt * (b + 1) // CH) for b in range(CH)]
+        self.profs_b, self.packed = [], []
+        win_idx = np.arange(mf, dtype=np.int64)
+        for blo, bhi in self.block:
+            kb = bhi - blo
+            idx = self.starts[blo:bhi, None].astype(np.int64) + win_idx[None, :]
+            c = lut_inv[seq[idx]]                                   # [kb][mf] codes of the forward strand
+            odd = ((lo + blo + np.arange(kb)) % 2).astype(bool)
+            c[odd] = comp[c[odd][:, ::-1]]
+            flip = errs.random((kb, mf)) < 0.01
+            c = np.where(flip, (c + 1) % 4, c).astype(np.uint8)
+            pr = np.zeros((kb, 6, mf), np.float32)
+            pr[:, :4, :] = 0.02
+            for code in range(4):
+                pr[:, code, :][c == code] = 0.94
+            self.profs_b.append(pr)
+            cons = lut[c]
+            self.packed.append(hostlib.Genome.pack_consensus([cons[k].tobytes() for k in range(kb)]))
         self.ctx = tracy_amd.Context(dev.index or 0)
-        self.CHUNKS = 4
         self.lib = capi.lib()
-        self.packed = [hostlib.Genome.pack_consensus(self.cons[nt * b // self.CHUNKS:nt * (b + 1) // self.CHUNKS]) for b in range(self.CHUNKS)]
         self.seed_out = [None] * self.CHUNKS
 
     def run(self, dist, steps, warmup, cpu_sample=64):
@@ -559,7 +568,7 @@ class SeedExtendLeg:
             preps, sds, oks = [], [], []
             step_seed = 0.0
             for b in range(CH):
-                blo, bhi = self.nt * b // CH, self.nt * (b + 1) // CH
+                blo, bhi = self.block[b]
                 ts0 = time.perf_counter()
                 # (the block as a C caller holds it, packed once; result buffers of the same block of the previous step reused --
                 # by then its extend has finished and its results have been read)
@@ -570,8 +579,8 @@ class SeedExtendLeg:
                 # packed host buffers as a C caller holds them: the profile block and the padded window block are handed over in
                 # place, offsets / lengths select the anchored traces
                 pp = capi.PackedSeqs([], capi.SEQ_PROFILE)
-                pp.count, pp.data = len(okb), self.profs
-                pp.offset = ((okb + blo).astype(np.uint64) * np.uint64(6 * self.mf))
+                pp.count, pp.data = len(okb), self.profs_b[b]
+                pp.offset = (okb.astype(np.uint64) * np.uint64(6 * self.mf))
                 pp.length = np.full(max(len(okb), 1), self.mf, np.uint32)
                 cap = sdb["slices_2d"].shape[1]
                 pw = capi.PackedSeqs([], capi.SEQ_CHAR)
@@ -590,8 +599,9 @@ class SeedExtendLeg:
             ok = np.concatenate(oks)
             sd = {"pos": np.concatenate([sds[b]["pos"] for b in range(CH)]), "slice_len": np.concatenate([sds[b]["slice_len"] for b in range(CH)]),
                   "forward": np.concatenate([sds[b]["forward"] for b in range(CH)]), "status": np.concatenate([sds[b]["status"] for b in range(CH)])}
-            self._win = lambda i: next(sds[b]["slices_2d"][i - self.nt * b // CH, :int(sds[b]["slice_len"][i - self.nt * b // CH])].tobytes()
-                                       for b in range(CH) if self.nt * b // CH <= i < self.nt * (b + 1) // CH)
+            self._win = lambda i: next(sds[b]["slices_2d"][i - self.block[b][0], :int(sds[b]["slice_len"][i - self.block[b][0]])].tobytes()
+                                       for b in range(CH) if self.block[b][0] <= i < self.block[b][1])
+            self._prof = lambda i: next(self.profs_b[b][i - self.block[b][0]] for b in range(CH) if self.block[b][0] <= i < self.block[b][1])
             if it >= warmup:
                 seed_s += step_seed
                 ext_s += (t3 - t0) - step_seed  # what the extend adds on top of the seeding it overlaps with
@@ -624,13 +634,19 @@ class SeedExtendLeg:
         line = {"metric": "traces/s (host k-mer seeding + device Gotoh extend, end to end)", "value": round(ok_all * steps / dt, 1), "unit": "traces/s",
                 "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps, "warmup": warmup, "n_gpus": self.world, "scaling": "strong",
                 "seed_traces_per_s": round(nt_all * steps / seed_s, 1),
+                # seeding is host work (fmindex.h:203-326): what one host thread seeds, what one GPU extends per second of its kernels'
+                # time, and how many GPUs the threads of THIS run (one rank's share of the node) could keep busy
+                "seed_traces_per_s_per_thread": round(nt_all * steps / seed_s / max(self.threads * self.world, 1), 1),
+                "extend_traces_per_s_per_gpu": round(ok_all / self.world * steps / max(sum(timers[k]["ms"] for k, _ in TIMERS) * 1e-3, 1e-9), 1),
+                "n_gpus_fed_at_this_host": round((nt_all * steps / seed_s) / max(ok_all / self.world * steps / max(sum(timers[k]["ms"] for k, _ in TIMERS) * 1e-3, 1e-9), 1e-9), 2),
                 "extend_ms_not_hidden_per_step": round(ext_s / steps * 1e3, 2), "extend_kernel_gcups": round(cells_all * steps / max(sum(timers[k]["ms"] for k in ("score", "trace", "band", "walk")) * 1e-3, 1e-9) / 1e9, 1), "host_threads_per_rank": self.threads, "index_build_and_map_s": round(self.index_s, 2), "index_file_mb": round(self.index_bytes / 1e6, 1),
                 "index": "built once (rank 0), written with GenomeIndex::save, mapped read-only by every rank",
                 "anchored": int(ok_all), "traces": int(nt_all), "placed_within_60bp_of_truth": int(placed_all),
                 "dtype": "int16 (score sweep) / int32 (tracebacks); seeding: 2-bit k-mers on the host",
-                "config": {"workload": "configs[3] at its per-GPU size: %d traces of %d bases (%d per rank) vs a %.0f Mb synthetic genome (chr22-sized), k = 15, "
+                "config": {"workload": "configs[3]: %d traces of %d bases (%d per rank, in blocks of <= 62 500) vs a %.0f Mb synthetic genome (chr22-sized), k = 15, "
                                        "window = trace + 2 x 1000, traces sharded over %d rank(s), one mapped k-mer table per node"
-                                       % (int(nt_all), mf, int(nt_all) // self.world, self.gn / 1e6, self.world)},
+                                       % (int(nt_all), mf, int(nt_all) // self.world, self.gn / 1e6, self.world),
+                           "traces_total": int(nt_all), "blocks_per_rank": self.CHUNKS},
                 "data": "synthetic (GRCh38 chr22 is not available offline); host-staged buffers: upload of profiles / windows and download of results included",
                 "roofline": roof}
         if cpu_sample > 0:  # (rank 0; at N > 1 on its share of the host cores)
@@ -639,11 +655,13 @@ class SeedExtendLeg:
                     sys.path.insert(0, p)
             import pyoracle as orc
             from concurrent.futures import ThreadPoolExecutor
-            pick = list(range(min(cpu_sample, len(ok))))
+            # the sample: spread over the whole batch (every block of the step takes part)
+            npick = min(cpu_sample, len(ok))
+            pick = [int(x) for x in np.unique(np.linspace(0, len(ok) - 1, npick).astype(np.int64))] if npick else []
 
             def one(k):  # sage.h:217-221, 258-260, 311 with a window that arrives oriented: two Gotoh calls and the trim
                 i = ok[k]
-                prof = self.profs[i]
+                prof = self._prof(i)
                 win = self._win(i)
                 trimmed = np.ascontiguousarray(prof[:, 50:mf - 50])
                 pref = orc.create_profile_str(win)

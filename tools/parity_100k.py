@@ -155,13 +155,13 @@ def run_align(nt, ref_len, trace_len, log, block=1000, seed=1000, dev_index=0, n
 
 
 # ======================================================================================================================
-def run_decompose(nt, ref_len, trace_len, log, block=1000, dev_index=0, nthreads=None):
-    """configs[2]; returns (compared, mismatches)"""
+def run_decompose(nt, ref_len, trace_len, log, block=1000, dev_index=0, nthreads=None, first=0):
+    """configs[2]; returns (compared, mismatches, accepted); first: the batch starts at trace `first` of the seeded job"""
     from indigo_oracle import decompose_trace
     from tools.legs import DecomposeLeg
     nthreads = nthreads or usable_cores()
     dev = torch.device("cuda", dev_index)
-    leg = DecomposeLeg(nt, ref_len, trace_len, 0, 1, dev)
+    leg = DecomposeLeg(nt, ref_len, trace_len, 0, 1, dev, first=first)
     mf, n, cap = trace_len, ref_len, leg.cap
 
     def snapshot():

@@ -392,6 +392,13 @@ const GenomeIndex* genome_index(SageConfig const& c, std::string const& path) {
   GenomeIndex& g = cache[path];
   // an index file (`tracy_amd_cli index`; the reference loads genome.fa.gz.fm9, sage.h:203-207) is mapped; without one the table
   // is built in memory from the FASTA
+  if (GenomeIndex::is_stale_index_file(path)) {
+    std::cerr << "The index was written by an older version of this program: re-run `index` on the genome (" << path << ")." << std::endl;
+    cache.erase(path);
+    return nullptr;
+  }
+  if (GenomeIndex::is_stale_index_file(path + ".tidx"))
+    std::cerr << "Warning: " << path << ".tidx was written by an older version and is ignored (re-run `index`); the k-mer table is rebuilt in memory." << std::endl;
   const std::string stored = GenomeIndex::is_index_file(path) ? path : (GenomeIndex::is_index_file(path + ".tidx") ? path + ".tidx" : std::string());
   if (!stored.empty()) {
     if (!g.open_index(stored)) {
@@ -684,7 +691,7 @@ void write_outputs(SageConfig const& c, Job const& j) {
   {
     TextBuf f(2 * j.rows.row0.size() + 512);
     alignFastaOut(f, stem(j.trace_path), j.rs, j.rows);
-    f.to_file(j.outprefix + ".align.fa");
+    f.write(j.outprefix + ".align.fa");
   }
   plotAlignment(j.outprefix + ".txt", j.rows, j.rs, j.score, c.linelimit);
   pc.lap(CpuPhases::SMALL_FILES);
@@ -827,8 +834,9 @@ int align_main(int argc, char** argv) {
   if (!run_blocks((uint32_t)jobs.size(), batch ? block_size() : (uint32_t)jobs.size(), prep, device, write)) return fatal ? fatal : -1;
   times.report((uint32_t)jobs.size(), nthreads);
   std::cout << stamp() << "Done." << std::endl;
-  if (batch) end_process(failed ? 2 : 0);
-  return failed ? 2 : 0;
+  const int rc_out = (failed || TextBuf::write_errors()) ? 2 : 0;  // (a file that could not be written counts like a trace that failed)
+  if (batch) end_process(rc_out);
+  return rc_out;
 }
 
 
@@ -1168,7 +1176,7 @@ void write_decompose_outputs(SageConfig const& c, Job& j) {
   {
     TextBuf f(4096);
     writeDecomposition(f, r.dcp);
-    f.to_file(j.outprefix + ".decomp");
+    f.write(j.outprefix + ".decomp");
   }
   ReferenceSlice secrs;
   secrs.refslice = trimmedSeq(j.secdecomp, j.trimLeft, j.trimRight);
@@ -1181,7 +1189,7 @@ void write_decompose_outputs(SageConfig const& c, Job& j) {
   for (int k = 0; k < 3; ++k) {
     TextBuf f;
     plotAlignment(f, *al[k], *rs[k], k + 1, score[k], r.a1a2, c.linelimit);
-    f.to_file(j.outprefix + ".align" + std::to_string(k + 1));
+    f.write(j.outprefix + ".align" + std::to_string(k + 1));
   }
   pc.lap(CpuPhases::SMALL_FILES);
   // the report shows the decomposed basecalls
@@ -1205,12 +1213,12 @@ void write_decompose_outputs(SageConfig const& c, Job& j) {
       for (std::size_t i = 0; g && i < g->names.size(); ++i) contigs.emplace_back(g->names[i], (uint64_t)g->lengths[i] + 1);
     }
     vcfTextOutput(f, rc, bc, r.var, j.rs, j.rs.filetype == 0 ? &contigs : nullptr);
-    f.to_file(j.outprefix + ".vcf");
+    f.write(j.outprefix + ".vcf");
   }
   pc.lap(CpuPhases::PAD);
   TextBuf f(1 << 20);
   traceAlleleAlignJsonOut(f, rc, bc, j.tr, r);
-  f.to_file(j.outprefix + ".json");
+  f.write(j.outprefix + ".json");
   pc.lap(CpuPhases::JSON);
 }
 
@@ -1355,8 +1363,9 @@ int decompose_main(int argc, char** argv) {
   if (!run_blocks((uint32_t)jobs.size(), blk, prep, device, write)) return fatal ? fatal : -1;
   times.report((uint32_t)jobs.size(), nthreads);
   std::cout << stamp() << "Done." << std::endl;
-  if (batch) end_process(failed ? 2 : 0);
-  return failed ? 2 : 0;
+  const int rc_out = (failed || TextBuf::write_errors()) ? 2 : 0;  // (a file that could not be written counts like a trace that failed)
+  if (batch) end_process(rc_out);
+  return rc_out;
 }
 
 // ---- `tracy basecall` (teal.h:24-117): host only, no device needed -------------------------------------------

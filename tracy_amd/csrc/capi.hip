@@ -1416,11 +1416,14 @@ int tracyhip_last_call_stats(tracyhip_ctx* c, tracyhip_call_stats* out) {
   if (!c || !out) return set_error(TRACYHIP_ERR_ARG, "null context / out");
   *out = c->stats;
   for (auto* l : c->lanes) {  // (a call split over lanes: every lane counted its chunk)
+    if (l->stats.traces == 0) continue;  // a lane without a chunk (small batches run on one) says nothing about how the call went
     const uint32_t* a = reinterpret_cast<const uint32_t*>(&l->stats);
     uint32_t* o = reinterpret_cast<uint32_t*>(out);
-    for (size_t i = 0; i < sizeof(tracyhip_call_stats) / sizeof(uint32_t); ++i)
+    for (size_t i = 0; i < sizeof(tracyhip_call_stats) / sizeof(uint32_t); ++i) {
+      if (i == offsetof(tracyhip_call_stats, traces) / sizeof(uint32_t)) continue;  // (the call's count is the context's)
       if (i != offsetof(tracyhip_call_stats, stream_ordered) / sizeof(uint32_t)) o[i] += a[i];
       else o[i] = o[i] && a[i];
+    }
   }
   return TRACYHIP_OK;
 }

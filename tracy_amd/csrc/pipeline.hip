@@ -1345,6 +1345,7 @@ extern "C" int tracyhip_align_traces(tracyhip_ctx* ctx, const tracyhip_align_job
   if (rc) return rc;
   return run_lanes(ctx, job->ntraces, [&](tracyhip_ctx* lane, uint32_t, uint32_t lo, uint32_t k) -> int {
     if (k == 0) return TRACYHIP_OK;
+    if (lane != ctx) lane->stats.traces = k;  // (this lane took part: tracyhip_last_call_stats)
     AlignChunk c(job, out, lo, k);
     return align_traces_one(lane, &c.j, prm, mem, &c.o);
   });
@@ -2427,6 +2428,7 @@ extern "C" int tracyhip_decompose_traces(tracyhip_ctx* ctx, const tracyhip_decom
   if (rc) return rc;
   return run_lanes(ctx, job->ntraces, [&](tracyhip_ctx* lane, uint32_t, uint32_t lo, uint32_t k) -> int {
     if (k == 0) return TRACYHIP_OK;
+    if (lane != ctx) lane->stats.traces = k;
     DecomposeChunk c(job, out, lo, k);
     return decompose_traces_one(lane, &c.j, prm, mem, &c.o);
   });

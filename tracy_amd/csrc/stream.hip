@@ -621,6 +621,14 @@ DpArgs sweep_args(tracyhip_ctx* ctx, const tracyhip_params& p, const void* d_a1,
   return a;
 }
 
+// LDS of a wide tier's band launch for the longest rest of the batch: tested by the planners BEFORE anything of a call is queued (a tier
+// that finds no room once launches are in flight would hand the call back with the workspace still in use)
+bool front_tier_fits(int KB, int32_t halfw, uint32_t max_rest) {
+  const uint64_t code_cap = (max_rest + 2u * (uint32_t)halfw + 16u) & ~3u;
+  return 4ull * code_cap + b16_table_bytes(KB) + 32ull * kB16RowCap <= 64u * 1024u;
+}
+bool front_tiers_fit(uint32_t max_rest) { return front_tier_fits(8, 60, max_rest) && front_tier_fits(kFrontK, kFrontHalfW, max_rest); }
+
 // one tier of the pruned sweep over fixed slots: place, band below the kept row, certify (capi.hip run_front_once)
 // KB = 0: the quad form (strips of four rows, four lanes per pair) -- the narrow tier ahead of the others
 int front_tier(tracyhip_ctx* ctx, const tracyhip_params& p, const FrontDesc* fd, uint32_t n, const int16_t* d_qp, const uint8_t* d_codes, const uint32_t* d_row,
@@ -631,8 +639,8 @@ int front_tier(tracyhip_ctx* ctx, const tracyhip_params& p, const FrontDesc* fd,
   a.err = static_cast<int32_t*>(ctx->d_err.p); a.go = p.go; a.ge = p.ge; a.hfree = 1; a.row = d_row;
   a.code_cap = (max_rest + 2u * (uint32_t)halfw + 16u) & ~3u;  // front_place_body: a sub-window is at most m_rest + 2 halfw + 2 columns
   if (KB == 0) {
-    if (b16_cont_quad_lds(a.code_cap) > 64u * 1024u) return kStreamNo;
-  } else if (4ull * a.code_cap + b16_table_bytes(KB) + 32ull * kB16RowCap > 64u * 1024u) return kStreamNo;
+    if (b16_cont_quad_lds(a.code_cap) > 64u * 1024u) return kStreamNo;  // (front_tiers_run goes on with the wide tiers: nothing was queued for this one)
+  } else if (!front_tier_fits(KB, halfw, max_rest)) return set_error(TRACYHIP_ERR_ARG, "pruned-sweep tier without LDS room (front_tiers_fit not consulted)");
   HIP_TRY(launch_front_place(fd, n, d_row, p.go + p.ge, halfw, pairs, fo, st, prev));
   if (KB == 0) HIP_TRY(launch_band16_cont_quad(a, st));
   else HIP_TRY(launch_band16_cont(KB, a, st, !ctx->knobs.no_cont16));
@@ -763,9 +771,8 @@ int queue_orientation(tracyhip_ctx* ctx, const tracyhip_params& p, const SParams
   auto front_tiers = [&]() -> int {
     TRY(timing_begin(ctx, TRACYHIP_TIMER_FRONT, 0, 0));
     const int rc = front_tiers_run(ctx, p, sc, nt, os.d_qp, ctx->codes(), reinterpret_cast<const uint32_t*>(os.d_lastrow), h.max_rest);
-    if (rc) return rc;
-    TRY(timing_end(ctx));
-    return TRACYHIP_OK;
+    const int rc2 = timing_end(ctx);  // (begun: ended whatever the tiers say)
+    return rc ? rc : rc2;
   };
   if (ctx->b16_fork_ok && !ctx->knobs.no_fork) {
     // Two strands, two streams.  The voted strand's chain -- its 128-row prefixes, then the band tiers below the kept row: launches
@@ -787,18 +794,20 @@ int queue_orientation(tracyhip_ctx* ctx, const tracyhip_params& p, const SParams
       HIP_TRY(hipStreamWaitEvent(st, fk.joined[0], 0));
       return rc;
     }
-    for (const SweepClass& c : h.classes) {
-      DpArgs af = a;
-      af.pairs = sc.full + 2 * (size_t)c.lo;
-      TRY(timing_begin(ctx, TRACYHIP_TIMER_SCORE, 0, 0));
-      HIP_TRY(launch_gotoh_ckpt_front(c.K, af, 2 * (c.hi - c.lo), ap, 0u, st));
-      TRY(timing_end(ctx));
-    }
-    if (os.filler) {
-      const int frc = os.filler();
-      if (frc) { HIP_TRY(hipStreamWaitEvent(st, fk.joined[0], 0)); return frc; }
-    }
-    HIP_TRY(hipStreamWaitEvent(st, fk.joined[0], 0));
+    auto sweeps = [&]() -> int {
+      for (const SweepClass& c : h.classes) {
+        DpArgs af = a;
+        af.pairs = sc.full + 2 * (size_t)c.lo;
+        TRY(timing_begin(ctx, TRACYHIP_TIMER_SCORE, 0, 0));
+        const hipError_t e = launch_gotoh_ckpt_front(c.K, af, 2 * (c.hi - c.lo), ap, 0u, st);
+        TRY(timing_end(ctx));
+        HIP_TRY(e);
+      }
+      return os.filler ? os.filler() : TRACYHIP_OK;
+    };
+    const int src = sweeps();
+    HIP_TRY(hipStreamWaitEvent(st, fk.joined[0], 0));  // (on every way out: nothing of the call runs beside the call's stream afterwards)
+    if (src) return src;
   } else {
     bool pre_done = false;
     for (const SweepClass& c : h.classes) {
@@ -908,6 +917,7 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
     });
   }
   if (h.max_rest == 0) return kStreamNo;  // no trace takes the pruned sweep
+  if (!front_tiers_fit(h.max_rest)) return kStreamNo;  // (rests beyond ~14 k rows: the band launches below the kept row find no LDS)
   return TRACYHIP_OK;
 }
 
@@ -1671,7 +1681,7 @@ struct DecStream {
         tot1 += (uint64_t)h.mt[t] + h.rn[t];
       }
     });
-    if (max_arest == 0) return kStreamNo;
+    if (max_arest == 0 || !front_tiers_fit(max_arest)) return kStreamNo;
     TRY(decompose_limits(dp.maxindel, maxbc));
     z.ep = seqset_extent(sp); z.er = seqset_extent(sr);
     ncap = (h.maxmf + 200u + 7u) & ~3u;

@@ -256,7 +256,7 @@ inline void plotAlignment(Out& out, AlignRows const& al, ReferenceSlice const& r
 inline void plotAlignment(std::string const& filename, AlignRows const& al, ReferenceSlice const& rs, int32_t score, uint32_t linelimit) {
   TextBuf out;
   plotAlignment(out, al, rs, 0, score, std::make_pair(0.0, 0.0), linelimit);
-  out.to_file(filename);
+  out.write(filename);
 }
 
 // a trace re-sampled along an alignment carries its flanking gap counts (Trace::leadingGaps / trailingGaps)
@@ -398,7 +398,7 @@ inline void traceAlignJsonOut(Out& out, PaddedTrace const& p, ReferenceSlice con
 inline void traceAlignJsonOut(std::string const& outfile, PaddedTrace const& p, ReferenceSlice const& rs, AlignRows const& al) {
   TextBuf out(1 << 20);
   traceAlignJsonOut(out, p, rs, al);
-  out.to_file(outfile);
+  out.write(outfile);
 }
 
 // the two-record FASTA of the final alignment, sage.h:328-339

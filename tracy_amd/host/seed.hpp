@@ -189,6 +189,15 @@ class GenomeIndex {
     put(tab_, ntab_ * sizeof(Entry));
     return std::fclose(f) == 0 && ok;
   }
+  // a file that begins like an index of this program but not of this format version (TAMDIDX1: one run per k-mer, no strand bit)
+  static bool is_stale_index_file(std::string const& path) {
+    std::FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char m[8] = {0};
+    const bool stale = std::fread(m, 1, 8, f) == 8 && std::memcmp(m, "TAMD", 4) == 0 && std::memcmp(m, "TAMDIDX2", 8) != 0;
+    std::fclose(f);
+    return stale;
+  }
   static bool is_index_file(std::string const& path) {
     std::FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
@@ -567,6 +576,9 @@ inline bool scanBothStrands(GenomeIndex const& idx, std::string const& consensus
   const uint32_t k = kmer;
   if (k != idx.k || k < 1 || k > 32 || !idx.has_table()) return false;
   if (S + k >= 65536u || (uint32_t)trimLeft + 1u < k || (uint32_t)trimRight + 1u < k) return false;
+  // A trim longer than the consensus wraps the reference's loop bound (fmindex.h:211 evaluates size - trimRight in size_t) and windows
+  // still vote there: the two scans reproduce that, this shortcut does not
+  if (S < (std::size_t)trimLeft || S < (std::size_t)trimRight) return false;
   if (S <= (std::size_t)trimLeft + trimRight) return true;  // no window on either strand
   const std::size_t p_lo = (std::size_t)trimLeft + 1u - k, p_hi = S - trimRight;  // windows p_lo .. p_hi - 1; forward: p >= trimLeft, reverse: p + k <= S - trimRight
   const std::size_t nwin = p_hi - p_lo;

@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
@@ -169,6 +170,16 @@ struct TextBuf {
     }
   }
 
+  // files that could not be written in full (a missing directory, a full disk): counted for the command's exit code
+  static std::atomic<int>& write_errors() { static std::atomic<int> n{0}; return n; }
+  // to_file + the error message and the count: what the writers of the commands call
+  bool write(std::string const& path) const {
+    if (to_file(path)) return true;
+    ++write_errors();
+    const std::string msg = "Could not write output file " + path + ": " + std::strerror(errno) + "\n";
+    (void)!::write(2, msg.data(), msg.size());
+    return false;
+  }
   // one open / write / close (no stdio buffer in between)
   bool to_file(std::string const& path) const {
     const int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);

@@ -281,7 +281,7 @@ inline void traceTxtOut(TextBuf& out, BaseCalls const& bc, Trace const& tr, uint
 inline void traceTxtOut(std::string const& outfile, BaseCalls const& bc, Trace const& tr, uint32_t leftTrim, uint32_t rightTrim) {
   TextBuf out(48 * tr.traceACGT[0].size() + 4096);
   traceTxtOut(out, bc, tr, leftTrim, rightTrim);
-  out.to_file(outfile);
+  out.write(outfile);
 }
 
 // ---- the build's own ABIF writer (synthetic traces; layout per SURVEY.md Appendix B) ------------------

@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--allpairs-steps", type=int, default=3)
     ap.add_argument("--seedextend-traces", type=int, default=1000000,
                     help="configs[3]: traces of the seed + extend job IN ALL (BASELINE: 1M traces), sharded over the ranks -- one GPU takes the million")
+    ap.add_argument("--no-process-group", action="store_true", help="a rank started by hand: no torch.distributed process group of one (default: nccl, world size 1)")
     ap.add_argument("--seedextend-genome-mb", type=float, default=50.0, help="configs[3]: size of the synthetic genome (GRCh38 chr22 is 50.8 Mb)")
     ap.add_argument("--seedextend-steps", type=int, default=1)
     ap.add_argument("--cli-workdir", default=None, help="the CLI leg: directory for its input and output files (default: /dev/shm when it has room, else the system's temporary directory)")
@@ -194,6 +195,20 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         backend = dist.get_backend()
+    elif not args.no_process_group:
+        # one rank started by hand (the driver's N = 1 run): a process group of one all the same, so that the gathers of every leg go
+        # through RCCL exactly as they do at N > 1 (a failure to set it up is reported in the line, not fatal)
+        try:
+            import socket
+            import torch.distributed as dist
+            with socket.socket() as so_:
+                so_.bind(("127.0.0.1", 0))
+                port = so_.getsockname()[1]
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", local))
+            backend = dist.get_backend()
+        except Exception as e:  # noqa: BLE001
+            dist = None
+            backend = "none (%s: %s)" % (type(e).__name__, str(e)[:120])
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: the process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     dev = torch.device("cuda", local)
@@ -290,7 +305,7 @@ def main():
             raise RuntimeError("tracyhip_align_traces: %s" % lib.tracyhip_last_error().decode())
         if dist is not None:  # final gather of the fixed-size result records over RCCL / xGMI
             rec = torch.stack([r_i32["score_final"], r_i32["slice_begin"], r_i32["slice_len"], r_i32["ops_len"]], dim=1)
-            gather_records(dist, rec, dst=0)
+            gather_records(dist, rec, dst=0, sizes=[nt] * world)  # (weak scaling: every rank holds nt traces)
 
     def read_timers():
         kt = capi.KernelTiming()

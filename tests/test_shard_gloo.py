@@ -42,6 +42,10 @@ def _worker(rank, world, port, n, ret):
     recs, ops = _align(qs[lo:hi], refs[lo:hi])
     rec_t = torch.tensor(recs, dtype=torch.int64).reshape(-1, 2)
     all_rec = gather_records(dist, rec_t, dst=0)
+    # the same with the shard sizes handed in (no size exchange): what bench.py's steps do
+    sizes = [b - a for a, b in (shard_range(n, r, world) for r in range(world))]
+    again = gather_records(dist, rec_t, dst=0, sizes=sizes)
+    assert rank != 0 or torch.equal(again, all_rec)
     data = torch.from_numpy(np.frombuffer(b"".join(ops), dtype=np.uint8).copy())
     lens = torch.tensor([len(o) for o in ops], dtype=torch.int64)
     all_ops, all_lens = gather_ragged_bytes(dist, data, lens, dst=0)

@@ -1,3 +1,7 @@
 set -x
-python -m pytest tests -x -q -m gpu > gpurun_out/r05k_tests.log 2>&1; tail -15 gpurun_out/r05k_tests.log
-python bench.py > gpurun_out/r05k_bench.json 2> gpurun_out/r05k_bench.err; tail -c 300 gpurun_out/r05k_bench.json
+free -g | head -2; nproc; cat /sys/fs/cgroup/memory.max 2>/dev/null
+python bench.py --workload align --steps 10 --warmup 3 --certificate-leg 0 --lanes-leg 0 --cpu-sample 0 > gpurun_out/r05m_align.json 2> gpurun_out/r05m_align.err; tail -c 400 gpurun_out/r05m_align.json
+MEMG=$(free -g | awk '/Mem:/{print $7}')
+if [ "$MEMG" -gt 80 ]; then
+  python bench.py --workload seedextend > gpurun_out/r05m_se.json 2> gpurun_out/r05m_se.err; tail -c 1500 gpurun_out/r05m_se.json; grep VmHWM /proc/self/status
+fi

@@ -229,7 +229,8 @@ class DecomposeLeg:
             from tracy_amd.shard import gather_records
             r = self.res
             rec = torch.stack([r["status"], r["score_trim"], self.keep[0][3], self.keep[1][3], self.keep[2][3]], dim=1)
-            gather_records(dist, rec, dst=0)
+            from tracy_amd.shard import shard_range
+            gather_records(dist, rec, dst=0, sizes=[b - a for a, b in (shard_range(self.total, r_, self.world) for r_ in range(self.world))])
 
     def cells(self):
         mt = self.mf - 100

@@ -14,24 +14,36 @@ def shard_range(n, rank, world):
     return lo, hi
 
 
-def gather_records(dist, records, dst=0):
+def gather_records(dist, records, dst=0, sizes=None):
     """Gather per-trace fixed-size records (tensor [n_local, F]) to `dst`, in rank order.
-    Shards may differ in size by one trace; they are padded to the largest shard for the collective."""
+    Shards may differ in size by one trace; they are padded to the largest shard for the collective.
+    sizes: the shard sizes of all ranks when the caller knows them (shard_range gives them without asking anyone): ONE collective and no
+    host synchronisation; without them the sizes are all-gathered first."""
     world = dist.get_world_size()
     rank = dist.get_rank()
     if records.is_cuda and dist.get_backend() == "gloo":  # (gloo gathers host tensors: the CPU tests, bench.py --share-device)
         records = records.cpu()
-    n_local = torch.tensor([records.shape[0]], dtype=torch.int64, device=records.device)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(sizes, n_local)
-    sizes = [int(s.item()) for s in sizes]
+    if sizes is None:
+        n_local = torch.tensor([records.shape[0]], dtype=torch.int64, device=records.device)
+        sizes = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(sizes, n_local)
+        sizes = [int(s.item()) for s in sizes]
+    else:
+        sizes = [int(x) for x in sizes]
+        if len(sizes) != world or sizes[rank] != records.shape[0]:
+            raise ValueError("gather_records: sizes %r do not describe this rank's %d records" % (sizes, records.shape[0]))
     cap = max(sizes) if sizes else 0
-    padded = torch.zeros((cap,) + tuple(records.shape[1:]), dtype=records.dtype, device=records.device)
-    padded[:records.shape[0]] = records
+    if records.shape[0] == cap and records.is_contiguous():
+        padded = records
+    else:
+        padded = torch.zeros((cap,) + tuple(records.shape[1:]), dtype=records.dtype, device=records.device)
+        padded[:records.shape[0]] = records
     bucket = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
     dist.gather(padded, bucket, dst=dst)
     if rank != dst:
         return None
+    if world == 1:
+        return bucket[0]
     return torch.cat([b[:s] for b, s in zip(bucket, sizes)], dim=0)
 
 

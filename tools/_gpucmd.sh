@@ -1,7 +1,4 @@
-set -x
-free -g | head -2; nproc; cat /sys/fs/cgroup/memory.max 2>/dev/null
-python bench.py --workload align --steps 10 --warmup 3 --certificate-leg 0 --lanes-leg 0 --cpu-sample 0 > gpurun_out/r05m_align.json 2> gpurun_out/r05m_align.err; tail -c 400 gpurun_out/r05m_align.json
-MEMG=$(free -g | awk '/Mem:/{print $7}')
-if [ "$MEMG" -gt 80 ]; then
-  python bench.py --workload seedextend > gpurun_out/r05m_se.json 2> gpurun_out/r05m_se.err; tail -c 1500 gpurun_out/r05m_se.json; grep VmHWM /proc/self/status
-fi
+python -m pytest tests/test_gpu_decompose.py tests/test_gpu_stream.py -x -q -m gpu > gpurun_out/r05s_tests.log 2>&1; tail -3 gpurun_out/r05s_tests.log
+python bench.py --workload decompose --decompose-steps 3 --cpu-sample 0 > gpurun_out/r05s_dec.json 2> gpurun_out/r05s_dec.err
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/r05s_stats -- python /root/repo/bench.py --workload decompose --decompose-steps 2 --extra-legs 0 --cpu-sample 0 > /dev/null 2> /root/repo/gpurun_out/r05s_prof.err
+find /root/repo/gpurun_out/r05s_stats -name "*kernel_trace.csv" -delete

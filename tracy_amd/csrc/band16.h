@@ -300,7 +300,7 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   constexpr bool PACKED = P == 4;
   const uint32_t code_row = PACKED ? b16_packed_row(a.code_cap) : a.code_cap;  // LDS bytes per pair
   uint8_t* lcodes = reinterpret_cast<uint8_t*>(w.lds()) + g * code_row;
-  int16_t* tab = reinterpret_cast<int16_t*>(w.lds() + NPW * code_row) + L;
+  int16_t* tab = reinterpret_cast<int16_t*>(w.lds() + NPW * code_row) + (((L & 31u) << 1) | (L >> 5));  // (lane columns interleaved: gotoh_narrow_qp_body)
   if (have) {
     const uint8_t* src = a.codes + d.a2_off;
     if (!PACKED) {
@@ -565,7 +565,7 @@ TR_HD void band16_cont16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
 
   const uint32_t code_row = PACKED ? b16_packed_row(a.code_cap) : a.code_cap;
   uint8_t* lcodes = reinterpret_cast<uint8_t*>(w.lds()) + g * code_row;
-  int16_t* tab = reinterpret_cast<int16_t*>(w.lds() + NPW * code_row) + L;
+  int16_t* tab = reinterpret_cast<int16_t*>(w.lds() + NPW * code_row) + (((L & 31u) << 1) | (L >> 5));  // (lane columns interleaved: gotoh_narrow_qp_body)
   if (have) {
     const uint8_t* src = a.codes + d.a2_off;
     if (!PACKED) {

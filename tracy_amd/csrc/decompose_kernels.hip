@@ -331,6 +331,7 @@ struct AfGrid {
   uint32_t npairs;
   const uint32_t* pair;  // [npairs] (i_index * 100 + j_index) | k_count << 16, k_count descending
   const double* vals;    // the 100 doubles 0, 0.01, 0.01 + 0.01, ... (af_search_kernel)
+  const uint32_t* pair8; // [npairs] i_index | j_index << 8 | k_count << 16, in the order of `pair` (af_search_kernel: no divisions)
 };
 constexpr int AF_STEPS = 21;  // >= ceil(npairs / AF_THREADS) (5151 pairs)
 
@@ -694,42 +695,78 @@ __global__ __launch_bounds__(64) void af_search_kernel(const BcDesc* __restrict_
     }
     return pm;
   };
-  double my_min = 1e300;
+  // ONE pass over the lane's pairs: the minimum of each (five candidates around the vertex), the lane's minimum, and the four pairs with
+  // the smallest minima -- the only ones that can lie within the margin of the overall minimum unless the screen is (nearly) flat over
+  // more than four of a lane's pairs, which the fourth-smallest shows: then the lane looks at all its pairs again, as the two-pass form did
+  constexpr int kKeep = 4;
+  double kv[kKeep];
+  uint32_t kp[kKeep];
+#pragma unroll
+  for (int i = 0; i < kKeep; ++i) { kv[i] = 1e300; kp[i] = 0xffffffffu; }
+  auto pair_of = [&](uint32_t p, double& fij, double& sij, uint32_t& code, uint32_t& cnt) {
+    const uint32_t e = grid.pair8[p];  // i | j << 8 | k_count << 16
+    const uint32_t ia = e & 0xffu, ib = (e >> 8) & 0xffu;
+    cnt = e >> 16;
+    code = ia * 100u + ib;
+    sij = __dadd_rn(vals[ia], vals[ib]);
+    fij = qtot + f1[ia] + f2[ib];
+  };
   for (uint32_t p = lane; p < grid.npairs; p += 64) {
-    const uint32_t e = grid.pair[p];
-    const uint32_t ia = (e & 0xffffu) / 100u, ib = (e & 0xffffu) % 100u, cnt = e >> 16;
-    const double pm = pair_min(qtot + f1[ia] + f2[ib], __dadd_rn(vals[ia], vals[ib]), cnt);
-    my_min = pm < my_min ? pm : my_min;
+    double fij, sij;
+    uint32_t code, cnt;
+    pair_of(p, fij, sij, code, cnt);
+    const double pm = pair_min(fij, sij, cnt);
+    if (pm < kv[kKeep - 1]) {  // (rare after the first few pairs)
+      kv[kKeep - 1] = pm; kp[kKeep - 1] = p;
+#pragma unroll
+      for (int i = kKeep - 1; i > 0; --i)
+        if (kv[i] < kv[i - 1]) { const double tv = kv[i]; kv[i] = kv[i - 1]; kv[i - 1] = tv; const uint32_t tq = kp[i]; kp[i] = kp[i - 1]; kp[i - 1] = tq; }
+    }
   }
-  const double cut = wave_min_all(my_min) + kScreenMargin;
-  // the reference's summation for one candidate (decompose.h:596-606); tp / cls are wave-uniform
+  const double cut = wave_min_all(kv[0]) + kScreenMargin;
+  // the reference's summation for one candidate (decompose.h:596-606); tp / cls are wave-uniform and read-only here: scalar loads, four
+  // class bytes to a word
+  const uint32_t* __restrict__ clsw = reinterpret_cast<const uint32_t*>(cls);  // (4 bc_off: a multiple of four)
   auto exact_sse = [&](const double* mine) {
     double sse = 0;
-    for (uint32_t q = 0; q < terms; ++q) {
-      const double df = __dsub_rn(mine[cls[q]], tp[q]);
-      sse = __dadd_rn(sse, __dmul_rn(df, df));
+    for (uint32_t q = 0; q < terms; q += 4) {  // terms = 4 dn
+      const uint32_t cw = clsw[q >> 2];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) {
+        const double df = __dsub_rn(mine[(cw >> (8u * j)) & 0xffu], tp[q + j]);
+        sse = __dadd_rn(sse, __dmul_rn(df, df));
+      }
     }
     return sse;
   };
   double my_sse = 1e300;
   uint32_t my_idx = 0xffffffffu;
-  for (uint32_t p = lane; p < grid.npairs; p += 64) {
-    const uint32_t e = grid.pair[p];
-    const uint32_t code = e & 0xffffu, ia = code / 100u, ib = code % 100u, cnt = e >> 16;
-    const double sij = __dadd_rn(vals[ia], vals[ib]);
-    const double fij = qtot + f1[ia] + f2[ib];
-    if (!(pair_min(fij, sij, cnt) <= cut)) continue;
+  auto scan_pair = [&](uint32_t p) {  // every k of a pair that reaches the margin: listed, or evaluated right here once the list is full
+    double fij, sij;
+    uint32_t code, cnt;
+    pair_of(p, fij, sij, code, cnt);
     for (uint32_t ic = 0; ic < cnt; ++ic) {
       if (screen(fij, sij, ic) > cut) continue;
       const uint32_t idx = code * 100u + ic;
       const uint32_t slot = atomicAdd(&s_nsurv, 1u);
       if (slot < (uint32_t)AF2_SURVIVORS) { s_surv[slot] = idx; continue; }
-      // list full: evaluate right here (class values through a private table in LDS would need a slot per lane: selects instead)
       const double vi = vals[idx / 10000], vj = vals[(idx / 100) % 100], vk = vals[idx % 100];
       const double pv[5] = {0.0, vi, vj, vk, __dsub_rn(1.0, __dadd_rn(__dadd_rn(vi, vj), vk))};
       const double sse = af_exact_sse(tp, cls, terms, pv);
       if (sse < my_sse || (sse == my_sse && idx < my_idx)) { my_sse = sse; my_idx = idx; }
     }
+  };
+  if (kv[kKeep - 1] <= cut) {  // more than kKeep of this lane's pairs may reach the margin
+    for (uint32_t p = lane; p < grid.npairs; p += 64) {
+      double fij, sij;
+      uint32_t code, cnt;
+      pair_of(p, fij, sij, code, cnt);
+      if (pair_min(fij, sij, cnt) <= cut) scan_pair(p);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kKeep; ++i)
+      if (kv[i] <= cut) scan_pair(kp[i]);
   }
   __syncthreads();
   // exact stage: lane 0 sums the start point (0.5, 0.5, 0, 0) (decompose.h:586-591), lanes 1.. one listed survivor each
@@ -933,16 +970,24 @@ static int ensure_af_grid(tracyhip_ctx* ctx, AfGrid& g) {
     for (int a = 0; a < 100; ++a) { v[a] = x; x = x + 0.01; }
     return v;
   }();
-  const size_t pair_bytes = (tab.size() * sizeof(uint32_t) + 7) & ~(size_t)7;
+  static const std::vector<uint32_t> tab8 = [] {
+    std::vector<uint32_t> t(tab.size());
+    for (size_t i = 0; i < tab.size(); ++i) t[i] = ((tab[i] & 0xffffu) / 100u) | (((tab[i] & 0xffffu) % 100u) << 8) | ((tab[i] >> 16) << 16);
+    return t;
+  }();
+  const size_t pair_bytes = (tab.size() * sizeof(uint32_t) + 7) & ~(size_t)7, vals_bytes = vals.size() * sizeof(double);
   if (!ctx->aftab_ready) {
-    HIP_TRY(ctx->d_aftab.ensure(pair_bytes + vals.size() * sizeof(double)));
-    HIP_TRY(hipMemcpyAsync(ctx->d_aftab.p, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(static_cast<char*>(ctx->d_aftab.p) + pair_bytes, vals.data(), vals.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx->d_aftab.ensure(2 * pair_bytes + vals_bytes));
+    char* base = static_cast<char*>(ctx->d_aftab.p);
+    HIP_TRY(hipMemcpyAsync(base, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(base + pair_bytes, vals.data(), vals_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(base + pair_bytes + vals_bytes, tab8.data(), tab8.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     ctx->aftab_ready = true;
   }
   g.npairs = (uint32_t)tab.size();
   g.pair = static_cast<const uint32_t*>(ctx->d_aftab.p);
   g.vals = reinterpret_cast<const double*>(static_cast<const char*>(ctx->d_aftab.p) + pair_bytes);
+  g.pair8 = reinterpret_cast<const uint32_t*>(static_cast<const char*>(ctx->d_aftab.p) + pair_bytes + vals_bytes);
   return TRACYHIP_OK;
 }
 

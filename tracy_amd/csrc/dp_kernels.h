@@ -875,6 +875,11 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
 
   // ---- query profile: int16 [NC][K][64 lanes] (qp6_index), entry = (int)(sum_k p[k][row] w[k][b]) - goe for b = A C G T (N);
   // code 5 ('-' / other) and rows off the trace score 0 ----
+  // Lane L's column of a row is 2 (L mod 32) + L / 32: a 16-bit read is served in two groups of 32 lanes, and with the lanes in order
+  // lanes 2 j and 2 j + 1 share a dword -- a bank -- while they usually ask for different CODES (different dwords of that bank): every
+  // read of the sweep was a two-way conflict (rocprofv3: SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE, the LDS busy 63 % of the
+  // launch).  Interleaved like this the 32 lanes of a group hit 32 different banks whatever their codes.
+  const uint32_t Lc = ((L & 31u) << 1) | (L >> 5);
   {
     bool overflow = false;
     int32_t qabs = 0;
@@ -896,9 +901,9 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
         qabs = imax(qabs, q < 0 ? -q : q);
         const uint32_t row = (rcflag && b < 4u) ? 3u - b : b;  // reverse-complement view: the complement is folded into the table
-        qp_tab[qp6_index<K>(row, (uint32_t)i, L)] = (int16_t)qs;
+        qp_tab[qp6_index<K>(row, (uint32_t)i, Lc)] = (int16_t)qs;
       }
-      if (!COMPACT) qp_tab[qp6_index<K>(5u, (uint32_t)i, L)] = (int16_t)(((STRINGS && real) ? a.mismatch : 0) - goe);
+      if (!COMPACT) qp_tab[qp6_index<K>(5u, (uint32_t)i, Lc)] = (int16_t)(((STRINGS && real) ? a.mismatch : 0) - goe);
     }
     if (overflow) flag_error(a.err, 1);
     if (!STRINGS && qabs > a.qlimit) flag_max(a.err, 1, qabs);
@@ -906,7 +911,7 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   }
 
   // ---- sweep ----
-  const char* strip = reinterpret_cast<const char*>(qp_tab) + L * 2u;  // this lane's column of the table
+  const char* strip = reinterpret_cast<const char*>(qp_tab) + Lc * 2u;  // this lane's column of the table
   const uint8_t* a2v = a2c - kCodeBias;
   const int32_t lane_base = (int32_t)kCodeBias + (rcflag ? (int32_t)n + (int32_t)L : -(int32_t)L - 1);
   const int32_t dir = rcflag ? -1 : 1;

@@ -383,7 +383,7 @@ int emu_band16(int K, int kind, int strings, uint32_t npairs, const void* a1, co
     p.a2_off = codes.size() - 128;
     for (uint32_t c = 0; c < n[i]; ++c) codes.push_back((uint8_t)(strings ? cq_code(a2[a2_off[i] + c]) : dp_code(a2[a2_off[i] + c])));
     p.bits_off = bits_total;
-    bits_total += (b16_words(m[i], n[i], K, dmin[i], dmax[i]) * b16_word_bytes(K) + 7u) & ~7ull;
+    bits_total += (b16_store_words(m[i], n[i], K, dmin[i], dmax[i]) * b16_word_bytes(K) + 7u) & ~7ull;
     ops_off[i] = (uint64_t)i * ops_cap;
     nmax = std::max(nmax, n[i]);
   }

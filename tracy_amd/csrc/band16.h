@@ -81,9 +81,36 @@ TR_HD uint32_t b16_last_window(uint32_t m, uint32_t n, int K, int32_t dmin, int3
   const int32_t ext = (int32_t)n - b16_first_col(b16_strips(m, K) - 1u, K, dmin) + 1;
   return (ext > 0 && (uint32_t)ext > S) ? (uint32_t)ext : S;
 }
+// words a traceback sweep evaluates: the windows of the strips (cells = words x K; the algorithmic bytes of the launch)
 TR_HD uint64_t b16_words(uint32_t m, uint32_t n, int K, int32_t dmin, int32_t dmax) {
   return (uint64_t)(b16_strips(m, K) - 1u) * b16_window(K, dmin, dmax) + b16_last_window(m, n, K, dmin, dmax);
 }
+// ... and where they are kept (KIND 0).  In block b of the sweep the strips b, b - 1, .., b - NB + 1 are live (NB = blocks of a window) and
+// each writes the K + 1 words of one block of its window: the word of strip s, window block bw, step k lies at ((s + bw) NB + bw) (K + 1) + k
+// -- the lanes of a pair write ONE run of NB (K + 1) words per block and the pair's words grow like a stream, a line is complete a block
+// or two after it was begun.  (Strip by strip -- word (s, u) at s S + u -- a pair had as many lines open as it has live strips, each
+// filled ten bytes a block: 100 000 wide bands held more half-written lines than the L2s hold, and rocprofv3's WRITE_SIZE was twice the
+// bytes written.)  Slots of strips that do not exist (s < 0, s >= NS) stay unwritten.  The last strip runs on to column n: its blocks
+// behind the NB-th follow the rest, one after the other.
+struct B16Layout {
+  uint32_t NS, NB, NB_last, KP;
+  uint64_t tail;  // first word of the last strip's blocks NB, NB + 1, ..
+  TR_HD uint64_t words() const { return tail + (uint64_t)(NB_last > NB ? NB_last - NB : 0u) * KP; }
+  TR_HD uint64_t block_word(uint32_t s, uint32_t bw) const {  // first word of block bw of strip s's window
+    return bw < NB ? (uint64_t)(((s + bw) * NB + bw) * KP) : tail + (uint64_t)((bw - NB) * KP);  // (32-bit products: m + n < 2^24 rows / columns)
+  }
+};
+TR_HD B16Layout b16_layout(uint32_t m, uint32_t n, int K, int32_t dmin, int32_t dmax) {
+  B16Layout l;
+  l.KP = (uint32_t)K + 1u;
+  l.NS = b16_strips(m, K);
+  l.NB = b16_window(K, dmin, dmax) / l.KP;
+  l.NB_last = (b16_last_window(m, n, K, dmin, dmax) + (uint32_t)K) / l.KP;
+  if (l.NB_last < l.NB) l.NB_last = l.NB;
+  l.tail = (uint64_t)(l.NS ? l.NS - 1u + l.NB : 0u) * l.NB * l.KP;
+  return l;
+}
+TR_HD uint64_t b16_store_words(uint32_t m, uint32_t n, int K, int32_t dmin, int32_t dmax) { return b16_layout(m, n, K, dmin, dmax).words(); }
 // the quad form (band16_body P = 4, strip height 4): the window fits the three blocks a lane has before its next strip is due
 TR_HD bool b16_narrow_ok(int32_t dmin, int32_t dmax) { return dmax >= dmin && b16_window(4, dmin, dmax) <= 3u * 5u; }
 TR_HD constexpr uint32_t b16_packed_row(uint32_t code_cap) { return ((code_cap + 1u) / 2u + 3u) & ~3u; }  // the quad form keeps two codes to a byte
@@ -142,14 +169,17 @@ struct Band16Fetch {
   const uint8_t* bits;
   uint32_t S, S_last, NS, n;
   int32_t dmin;
+  B16Layout lay;
   TR_HD bool inside(uint32_t r, uint32_t c) const {
     const uint32_t s = (r - 1u) / (uint32_t)K;
     const int32_t u = (int32_t)c - b16_first_col(s, K, dmin);
     return c >= 1u && c <= n && u >= 0 && (uint32_t)u < (s + 1u == NS ? S_last : S);
   }
   TR_HD uint32_t operator()(uint32_t r, uint32_t c) const {
+    constexpr uint32_t KP = (uint32_t)K + 1u;
     const uint32_t s = (r - 1u) / (uint32_t)K, slot = (r - 1u) % (uint32_t)K;
-    const uint64_t idx = (uint64_t)s * S + (uint32_t)((int32_t)c - b16_first_col(s, K, dmin));
+    const uint32_t u = (uint32_t)((int32_t)c - b16_first_col(s, K, dmin));
+    const uint64_t idx = lay.block_word(s, u / KP) + u % KP;
     uint64_t wd;
     if (K <= 4) wd = reinterpret_cast<const uint16_t*>(bits)[idx];
     else if (K <= 8) wd = reinterpret_cast<const uint32_t*>(bits)[idx];
@@ -286,6 +316,7 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   // number of blocks (b16_window) a lane's activity changes at block boundaries only -- inside a block a step tests nothing but
   // "is my column one of 1 .. n".
   const uint32_t NB = S / KP, NB_last = (S_last + (uint32_t)K) / KP;
+  const B16Layout lay = b16_layout(have ? m : 0u, n, K, dmin, dmax);  // KIND 0: where the trace words go
   const int32_t neg = KIND == 0 ? (int32_t)((uint32_t)kNegInf << SH) : (int32_t)((uint32_t)kNegInfOrigin << SH);
   const uint32_t rbase = CONT ? (uint32_t)d.bits_off : 0u;  // rows above the pair's first one
   auto edge = [&](uint32_t r) -> int32_t { return (int32_t)((uint32_t)edge_value(false, go, ge, (int32_t)(r + rbase)) << SH); };  // H(r, 0), r >= 1
@@ -417,9 +448,9 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
         }
       }
       raw_next = code_at(cm1);
-      if (KIND == 0) wp = bits + (uint64_t)b * S * WB;
       if (b + (uint32_t)P < NS) prefetch(b + (uint32_t)P);
     }
+    if (KIND == 0 && live) wp = bits + lay.block_word(s_cur, b - s_cur) * WB;  // this block's K + 1 words (B16Layout)
     uint32_t blk[K <= 4 ? 3 : K <= 8 ? 9 : 1];
 #pragma unroll
     for (uint32_t q = 0; q < sizeof(blk) / sizeof(blk[0]); ++q) blk[q] = 0u;
@@ -471,21 +502,11 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
       ++cm1;
       if (KIND == 0) wp += WB;
     }
-    // K = 4: the words of a block are ten consecutive bytes of the strip's window -- one 8-byte and one 2-byte store per block
-    // instead of five 2-byte ones to five cache lines per lane (a word of a column off 1 .. n is written as 0; nobody reads it).  A strip's window is whole
-    // blocks except for the last strip's, whose last block may run past the pair's words: that one goes out word by word.
-    // K = 8: nine dwords, as two 16-byte stores and one of four bytes.
+    // K = 4: the words of a block are ten consecutive bytes -- one 8-byte and one 2-byte store per block instead of five 2-byte ones
+    // (a word of a column off 1 .. n is written as 0; nobody reads it).  K = 8: nine dwords, as two 16-byte stores and one of four bytes.
     if (KIND == 0 && K <= 8 && live) {
       uint8_t* const w0p = wp - KP * WB;
-      const uint32_t first = (uint32_t)((w0p - bits) / WB) - s_cur * S;  // index of the block's first word in its strip's window
-      if (s_cur + 1u == NS && first + KP > S_last) {
-#pragma unroll
-        for (uint32_t k = 0; k < KP; ++k)
-          if (first + k < S_last) {
-            if (K <= 4) *reinterpret_cast<uint16_t*>(w0p + 2u * k) = (uint16_t)(blk[k >> 1] >> (16u * (k & 1u)));
-            else *reinterpret_cast<uint32_t*>(w0p + 4u * k) = blk[k];
-          }
-      } else if (K <= 4) {
+      if (K <= 4) {
         __builtin_memcpy(w0p, blk, 8);
         *reinterpret_cast<uint16_t*>(w0p + 8) = (uint16_t)blk[2];
       } else {
@@ -516,7 +537,7 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   }
   if (KIND == 0) {
     w.sync_global();
-    Band16Fetch<K> fetch{bits, S, S_last, NS, n, dmin};
+    Band16Fetch<K> fetch{bits, S, S_last, NS, n, dmin, lay};
     walk16<W, Band16Fetch<K>, P, (P == 4 ? 4 : 1)>(w, fetch, have, m, n, have ? a.ops + a.ops_off[d.out] : nullptr, have ? a.ops_len + d.out : nullptr, a.err,
            (uint32_t)d.lastrow_off, (uint32_t)(d.lastrow_off >> 32));
   }

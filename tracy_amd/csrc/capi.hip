@@ -820,7 +820,7 @@ int run_band16(tracyhip_ctx* ctx, Band16Job& job, const tracyhip_params* prm, in
       const int b = bucket_of(K);
       if (b < 0 || d.m == 0 || d.n == 0 || b16_window(K, band_dmin(d), band_dmax(d)) > b16_max_window(K)) { pt.bad = true; continue; }
       const uint64_t wds = (job.kind == 0 || ctx->timing) ? b16_words(d.m, d.n, K, band_dmin(d), band_dmax(d)) : 0;
-      const uint64_t bytes = job.kind == 0 ? ((wds * b16_word_bytes(K) + 15u) & ~15ull) : 0;
+      const uint64_t bytes = job.kind == 0 ? ((b16_store_words(d.m, d.n, K, band_dmin(d), band_dmax(d)) * b16_word_bytes(K) + 15u) & ~15ull) : 0;
       wb[i] = bytes;
       pt.n[b] += 1;
       pt.bytes[b] += bytes;

@@ -287,9 +287,8 @@ __device__ __forceinline__ int s_bucket(int K, const PairDesc& d, int quads) {
   return K == 12 ? 0 : K == 8 ? 1 : (quads && b16_narrow_ok(band_dmin(d), band_dmax(d))) ? 3 : 2;
 }
 __device__ __forceinline__ unsigned long long s_word_bytes(const PairDesc& d, int K, int kind, unsigned long long* words = nullptr) {
-  const unsigned long long w = b16_words(d.m, d.n, K, band_dmin(d), band_dmax(d));
-  if (words) *words = w;
-  return kind == 0 ? ((w * b16_word_bytes(K) + 15ull) & ~15ull) : 0ull;
+  if (words) *words = b16_words(d.m, d.n, K, band_dmin(d), band_dmax(d));
+  return kind == 0 ? ((b16_store_words(d.m, d.n, K, band_dmin(d), band_dmax(d)) * b16_word_bytes(K) + 15ull) & ~15ull) : 0ull;
 }
 __global__ __launch_bounds__(kScanBlock) void s_scan_partial_kernel(const PairDesc* __restrict__ cand, const uint8_t* __restrict__ kc, uint32_t n, int kind,
                                                                     int quads, ScanPart* __restrict__ part) {

@@ -142,47 +142,62 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
   const uint8_t* ops = a.ops + off;
   uint8_t* r0 = a.rows0 + off;
   uint8_t* r1 = a.rows1 + off;
+  const bool gaps_only = a.row0_gaps_only && a.row0_gaps_only[(size_t)d.out * a.row0_gaps_only_stride] != 0;
   const uint64_t below = (1ull << lane) - 1ull;
   uint32_t row_base = 0, col_base = 0;
-  for (uint32_t base = 0; base < L; base += 64) {
-    const uint32_t ai = base + lane;
-    const bool active = ai < L;
-    const uint8_t op = active ? ops[L - 1 - ai] : 0;
-    const bool takes_row = active && op != 'h';  // consumes a1
-    const bool takes_col = active && op != 'v';  // consumes a2
-    const uint64_t mrow = __ballot(takes_row), mcol = __ballot(takes_col);
-    const uint32_t row = row_base + (uint32_t)__popcll(mrow & below);
-    const uint32_t col = col_base + (uint32_t)__popcll(mcol & below);
-    row_base += (uint32_t)__popcll(mrow);
-    col_base += (uint32_t)__popcll(mcol);
-    uint8_t c0 = '-', c1 = '-';
-    if (takes_row) {
-      if (a.a1_profile) {
-        float p[6];
-        for (int k = 0; k < 6; ++k) p[k] = static_cast<const float*>(a.a1)[d.a1_off + (uint64_t)k * d.a1_stride + row];
-        c0 = cons_char(p);
-      } else {
-        c0 = static_cast<const uint8_t*>(a.a1)[d.a1_off + row];
-      }
+  constexpr uint32_t kBatch = 8;  // rounds whose op bytes are requested together: one wait per 512 columns instead of one per 64
+  for (uint32_t base0 = 0; base0 < L; base0 += 64 * kBatch) {
+    uint8_t opb[kBatch];
+#pragma unroll
+    for (uint32_t k = 0; k < kBatch; ++k) {
+      const uint32_t ai = base0 + 64 * k + lane;
+      opb[k] = ai < L ? ops[L - 1 - ai] : 0;
     }
-    if (takes_col) {
-      if (a.a2_profile) {
-        float p[6];
-        for (int k = 0; k < 6; ++k) p[k] = static_cast<const float*>(a.a2)[d.a2_off + (uint64_t)k * d.a2_stride + col];
-        c1 = cons_char(p);
-      } else {
-        const bool rc = a.a2_revcomp_flag && (d.flags & PAIR_A2_REVCOMP);
-        c1 = static_cast<const uint8_t*>(a.a2)[d.a2_off + (rc ? d.n - 1 - col : col)];
-        if (rc) c1 = complement_char(c1);
-        if (a.a2_onehot) {  // consensus character of _createProfile(string) (align.h:121-136, 254-270)
-          const uint32_t code = base_code(c1);
-          c1 = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'T' : code == 6 ? 'A' : 'N';
+#pragma unroll
+    for (uint32_t k = 0; k < kBatch; ++k) {
+      const uint32_t base = base0 + 64 * k;
+      if (base >= L) break;  // (wave-uniform)
+      const uint32_t ai = base + lane;
+      const bool active = ai < L;
+      const uint8_t op = opb[k];
+      const bool takes_row = active && op != 'h';  // consumes a1
+      const bool takes_col = active && op != 'v';  // consumes a2
+      const uint64_t mrow = __ballot(takes_row), mcol = __ballot(takes_col);
+      const uint32_t row = row_base + (uint32_t)__popcll(mrow & below);
+      const uint32_t col = col_base + (uint32_t)__popcll(mcol & below);
+      row_base += (uint32_t)__popcll(mrow);
+      col_base += (uint32_t)__popcll(mcol);
+      uint8_t c0 = '-', c1 = '-';
+      if (takes_row) {
+        if (gaps_only) {
+          c0 = 'N';
+        } else if (a.a1_profile) {
+          float p[6];
+          for (int q = 0; q < 6; ++q) p[q] = static_cast<const float*>(a.a1)[d.a1_off + (uint64_t)q * d.a1_stride + row];
+          c0 = cons_char(p);
+        } else {
+          c0 = static_cast<const uint8_t*>(a.a1)[d.a1_off + row];
         }
       }
-    }
-    if (active) {
-      r0[ai] = c0;
-      r1[ai] = c1;
+      if (takes_col) {
+        if (a.a2_profile) {
+          float p[6];
+          for (int q = 0; q < 6; ++q) p[q] = static_cast<const float*>(a.a2)[d.a2_off + (uint64_t)q * d.a2_stride + col];
+          c1 = cons_char(p);
+        } else {
+          const bool rc = a.a2_revcomp_flag && (d.flags & PAIR_A2_REVCOMP);
+          c1 = static_cast<const uint8_t*>(a.a2)[d.a2_off + (rc ? d.n - 1 - col : col)];
+          if (rc) c1 = complement_char(c1);
+          if (a.a2_onehot) {  // consensus character of _createProfile(string) (align.h:121-136, 254-270)
+            const uint32_t code = base_code(c1);
+            c1 = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'T' : code == 6 ? 'A' : 'N';
+          }
+        }
+      }
+      if (active) {
+        r0[ai] = c0;
+        r1[ai] = c1;
+      }
     }
   }
 }
@@ -425,10 +440,16 @@ hipError_t launch_gotoh_ckpt_prefix(int K, const DpArgs& full, uint32_t nfull, c
   return hipGetLastError();
 }
 
-// the same with the prefix shape of the pruned orientation sweep (front.h): kFrontPrefixLanes lanes of kFrontPrefixK rows per pair
-hipError_t launch_gotoh_ckpt_front(int K, const DpArgs& full, uint32_t nfull, const DpArgs& pre, uint32_t npre, hipStream_t s) {
-  if (nfull + npre == 0) return hipSuccess;
-  constexpr int GL = kFrontPrefixLanes, KP = kFrontPrefixK;
+// the same with the prefix shape of the pruned orientation sweep (front.h): kFrontRows rows per pair as sixteen lanes of eight rows (four pairs
+// per wave: twice the waves, what a batch of 10 000 traces needs to fill the device), or -- from front_prefix_tall_min pairs on -- as eight
+// lanes of sixteen rows: a step's fixed work (hand-over, code look-up, the kept row's store) is paid per sixteen cells instead of eight
+static uint32_t front_prefix_tall_min() {
+  static const uint32_t v = [] { const char* e = getenv("TRACYHIP_PREFIX_TALL_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 40000u; }();
+  return v;
+}
+template <int GL, int KP>
+static hipError_t launch_gotoh_ckpt_front_t(int K, const DpArgs& full, uint32_t nfull, const DpArgs& pre, uint32_t npre, hipStream_t s) {
+  static_assert(GL * KP == (int)kFrontRows, "the rows above the kept one");
   const dim3 grid(nfull + (npre + 64 / GL - 1) / (64 / GL));
   auto lds = [](int KK, bool compact) {
     const uint32_t pre_b = lds_bytes_prefix(KP, compact), sw = lds_bytes_sweep16(KK, compact);
@@ -452,6 +473,12 @@ hipError_t launch_gotoh_ckpt_front(int K, const DpArgs& full, uint32_t nfull, co
 #undef TRACY_FRONT_CASE
   return hipGetLastError();
 }
+hipError_t launch_gotoh_ckpt_front(int K, const DpArgs& full, uint32_t nfull, const DpArgs& pre, uint32_t npre, hipStream_t s) {
+  if (nfull + npre == 0) return hipSuccess;
+  // (a launch that carries full sweeps keeps the small prefix table: its LDS request is the larger of the two bodies')
+  if (nfull == 0 && npre >= front_prefix_tall_min()) return launch_gotoh_ckpt_front_t<8, 16>(K, full, nfull, pre, npre, s);
+  return launch_gotoh_ckpt_front_t<kFrontPrefixLanes, kFrontPrefixK>(K, full, nfull, pre, npre, s);
+}
 
 hipError_t launch_gotoh_prefix(int K, const DpArgs& a, uint32_t npairs, hipStream_t s) {
   if (npairs == 0) return hipSuccess;
@@ -469,14 +496,18 @@ hipError_t launch_gotoh_prefix(int K, const DpArgs& a, uint32_t npairs, hipStrea
 #undef TRACY_PREFIX_CASE
   return hipGetLastError();
 }
-// the prefix rows of the pruned sweep (front.h) for string x code pairs: kFrontPrefixLanes lanes of kFrontPrefixK rows per pair, row R kept
-hipError_t launch_gotoh_front_prefix_cq(const DpArgs& a, uint32_t npairs, hipStream_t s) {
-  if (npairs == 0) return hipSuccess;
-  constexpr int GL = kFrontPrefixLanes, KP = kFrontPrefixK;
+// the prefix rows of the pruned sweep (front.h) for string x code pairs: the shapes of launch_gotoh_ckpt_front, row R kept
+template <int GL, int KP>
+static hipError_t launch_gotoh_front_prefix_cq_t(const DpArgs& a, uint32_t npairs, hipStream_t s) {
   const dim3 grid((npairs + 64 / GL - 1) / (64 / GL));
   hipLaunchKernelGGL((gotoh_prefix_kernel<KP, GL, false, true>), grid, dim3(64), lds_bytes_prefix(KP, false), s, a, npairs);  // (first: launch_gotoh_ckpt_front)
   if (a.special_blocks) hipLaunchKernelGGL((gotoh_prefix_kernel<KP, GL, true, true>), grid, dim3(64), lds_bytes_prefix(KP, true), s, a, npairs);
   return hipGetLastError();
+}
+hipError_t launch_gotoh_front_prefix_cq(const DpArgs& a, uint32_t npairs, hipStream_t s) {
+  if (npairs == 0) return hipSuccess;
+  if (npairs >= front_prefix_tall_min()) return launch_gotoh_front_prefix_cq_t<8, 16>(a, npairs, s);
+  return launch_gotoh_front_prefix_cq_t<kFrontPrefixLanes, kFrontPrefixK>(a, npairs, s);
 }
 hipError_t launch_gotoh_walk(const WalkArgs& a, hipStream_t s) {
   if (a.npairs == 0) return hipSuccess;

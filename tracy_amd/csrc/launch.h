@@ -21,6 +21,11 @@ struct RowsArgs {
   uint8_t* rows0;
   uint8_t* rows1;
   uint32_t npairs;
+  // or null: int32 per PairDesc::out with this stride in int32s -- non-zero: nobody will read the CHARACTERS of the pair's row 0, only
+  // where its gaps are (`tracy decompose`: a trace with a shift skips findHomozygousBreakpoint, decomposeAlleles looks at row0 != '-'):
+  // 'N' stands for every base and the six profile reads per column are left out
+  const int32_t* row0_gaps_only;
+  uint32_t row0_gaps_only_stride;
 };
 
 // narrow: use the 16-bit score-only kernel (caller has checked the value range, see narrow_ok)

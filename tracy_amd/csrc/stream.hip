@@ -748,14 +748,36 @@ int queue_orientation(tracyhip_ctx* ctx, const tracyhip_params& p, const SParams
   const float* prof = static_cast<const float*>(os.d_prof);
   hipLaunchKernelGGL(s_expand_kernel, g256, b256, 0, st, sc.geom, nt, sc.vd, sc.rm_rest, sc.rm_trim, sc.rm_full, sc.td);
   HIP_TRY(hipGetLastError());
-  TRY(timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, h.tab_tot * 2));
-  HIP_TRY(launch_b16_tables(sc.td, nt, os.d_prof, false, p.match, p.mismatch, sub_limit(&p), kTagShift, const_cast<int16_t*>(os.d_qp),
-                            static_cast<int32_t*>(ctx->d_err.p), st));
-  TRY(timing_end(ctx));
-  hipLaunchKernelGGL(kmer_vote_kernel, dim3(nt), dim3(64), 0, st, sc.vd, prof, ctx->codes(), sc.votes);
-  hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, st, sc.rm_rest, prof, (float)p.match, (float)p.mismatch, sc.ub, sc.ub1);
-  hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, st, sc.rm_trim, prof, (float)p.match, (float)p.mismatch, sc.top_trim, (int32_t*)nullptr);
-  if (sc.rm_full) hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, st, sc.rm_full, prof, (float)p.match, (float)p.mismatch, sc.top_full, (int32_t*)nullptr);
+  // the substitution tables and the row maxima need the profiles only, the k-mer vote the profiles and the codes: side by side (the vote
+  // holds 22 KB of LDS per workgroup and waits for memory most of the time; the others use none)
+  const bool prep_fork = ctx->b16_fork_ok && !ctx->knobs.no_fork;
+  hipStream_t sp1 = st;
+  if (prep_fork) {
+    HIP_TRY(hipEventRecord(ctx->b16_fork.forked, st));
+    HIP_TRY(hipStreamWaitEvent(ctx->b16_fork.side[1], ctx->b16_fork.forked, 0));
+    sp1 = ctx->b16_fork.side[1];
+    ctx->stream = sp1;
+  }
+  {
+    int rc = timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, h.tab_tot * 2);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+      e = launch_b16_tables(sc.td, nt, os.d_prof, false, p.match, p.mismatch, sub_limit(&p), kTagShift, const_cast<int16_t*>(os.d_qp),
+                            static_cast<int32_t*>(ctx->d_err.p), sp1);
+      rc = timing_end(ctx);
+    }
+    ctx->stream = st;
+    hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, sp1, sc.rm_rest, prof, (float)p.match, (float)p.mismatch, sc.ub, sc.ub1);
+    hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, sp1, sc.rm_trim, prof, (float)p.match, (float)p.mismatch, sc.top_trim, (int32_t*)nullptr);
+    if (sc.rm_full) hipLaunchKernelGGL(rowmax_rest_kernel, dim3(nt), dim3(64), 0, sp1, sc.rm_full, prof, (float)p.match, (float)p.mismatch, sc.top_full, (int32_t*)nullptr);
+    hipLaunchKernelGGL(kmer_vote_kernel, dim3(nt), dim3(64), 0, st, sc.vd, prof, ctx->codes(), sc.votes);
+    if (prep_fork) {  // (joined on every way out)
+      HIP_TRY(hipEventRecord(ctx->b16_fork.joined[1], sp1));
+      HIP_TRY(hipStreamWaitEvent(st, ctx->b16_fork.joined[1], 0));
+    }
+    if (rc) return rc;
+    HIP_TRY(e);
+  }
   hipLaunchKernelGGL(s_orient_plan_kernel, g256, b256, 0, st, sp, sc.geom, sc.votes, sc.ub, sc.ub1, sc.full, sc.pre, sc.fd, sc.tr, sc.cnt);
   HIP_TRY(hipGetLastError());
   // ONE launch per strip height: full sweeps of the class + (with the first) the prefixes of every trace
@@ -1807,6 +1829,9 @@ struct DecStream {
     TRY(band_stage(ctx, p, sc, nt, nt, 0, b0, words_cap));
     hipLaunchKernelGGL(s_prelim_check_kernel, g256, b256, 0, st, spm, sc.tr, A.sb, A.len1, sc.kc, o.score_trim, sc.dead, sc.cnt);
     HIP_TRY(hipGetLastError());
+    // ---- 1. findBreakpoint (indigo.h:196), unless it already ran behind the full sweeps ----
+    BreakpointOut* bpo = reinterpret_cast<BreakpointOut*>(d_bp);
+    if (!bp_early) TRY(launch_breakpoint(ctx, A.bpd, nt, h.maxmt, d_prof, bpo));
     {
       RowsArgs ra{};
       ra.pairs = A.desc_trim;
@@ -1815,12 +1840,14 @@ struct DecStream {
       ra.ops = A.ops1; ra.ops_off = A.off1; ra.ops_len = A.len1;
       ra.rows0 = A.rows0; ra.rows1 = A.rows1;
       ra.npairs = nt;
+      // a trace with a shift (findBreakpoint) skips findHomozygousBreakpoint, and decomposeAlleles only asks where row 0 has gaps: the
+      // consensus characters of its profile columns -- six reads per column -- are left out for it
+      static_assert(offsetof(BreakpointOut, indelshift) == 0 && sizeof(BreakpointOut) == 16, "layout");
+      ra.row0_gaps_only = reinterpret_cast<const int32_t*>(bpo);
+      ra.row0_gaps_only_stride = 4;
       HIP_TRY(launch_alignment_rows(ra, st));
     }
-    // ---- 1. findBreakpoint (indigo.h:196), 4. findHomozygousBreakpoint (indigo.h:314-317), 5. decomposeAlleles, generateSecondaryDecomposed,
-    // allelicFraction (indigo.h:340-350) ----
-    BreakpointOut* bpo = reinterpret_cast<BreakpointOut*>(d_bp);
-    if (!bp_early) TRY(launch_breakpoint(ctx, A.bpd, nt, h.maxmt, d_prof, bpo));
+    // ---- 4. findHomozygousBreakpoint (indigo.h:314-317), 5. decomposeAlleles, generateSecondaryDecomposed, allelicFraction (indigo.h:340-350) ----
     TRY(launch_homozygous(ctx, A.rowsd, A.rows0, A.rows1, nt, bpo, A.hst, A.len1));
     {
       DecompArgs a{};

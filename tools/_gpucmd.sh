@@ -1,4 +1,2 @@
-python -m pytest tests/test_gpu_stream.py tests/test_gpu_decompose.py tests/test_gpu_front.py tests/test_gpu_baseline_shapes.py -x -q -m gpu > gpurun_out/r05v_tests.log 2>&1; tail -3 gpurun_out/r05v_tests.log
-TRACYHIP_PREFIX_TALL_MIN=100 python -m pytest tests/test_gpu_stream.py tests/test_gpu_decompose.py tests/test_gpu_front.py tests/test_gpu_baseline_shapes.py tests/test_gpu_parity_slice.py -x -q -m gpu > gpurun_out/r05v_tests_tall.log 2>&1; tail -3 gpurun_out/r05v_tests_tall.log
-python bench.py --workload decompose --decompose-steps 3 --extra-legs 0 --cpu-sample 0 > gpurun_out/r05v_dec.json 2> gpurun_out/r05v_dec.err
-TRACYHIP_PREFIX_TALL_MIN=1000000000 python bench.py --workload decompose --decompose-steps 3 --extra-legs 0 --cpu-sample 0 > gpurun_out/r05v_dec_small.json 2> gpurun_out/r05v_dec_small.err
+python -m pytest tests -x -q -m gpu > gpurun_out/r05x_tests.log 2>&1; tail -3 gpurun_out/r05x_tests.log
+python bench.py --workload decompose --decompose-steps 4 --cpu-sample 0 > gpurun_out/r05x_dec.json 2> gpurun_out/r05x_dec.err

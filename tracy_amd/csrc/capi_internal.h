@@ -130,6 +130,8 @@ struct tracyhip_ctx {
   uint8_t* codes() const { return static_cast<uint8_t*>(d_codes.p) + tracyhip::kCodePad; }
   tracyhip::DevBuf d_aftab;                    // allelicFraction grid enumeration (trace independent)
   bool aftab_ready = false;
+  uint64_t ws_cache_budget = 0, ws_cache_held = 0;  // stream.hip workspace_budget: the last answer and what the context held then
+  uint32_t ws_cache_share = 0;
   tracyhip::DevBuf d_afscratch;                // af_prepare_kernel -> af_search_kernel: tp, class bytes, headers
   tracyhip::DevBuf d_declut, d_dectodo;        // decompose_wave.h: the (primary, secondary) class table; per trace "left to decompose_kernel"
   bool declut_ready = false;

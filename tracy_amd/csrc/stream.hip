@@ -602,9 +602,13 @@ bool stream_options_ok(const CtxKnobs& k) {
 // workspace one context may plan with (run_dp's rule): the caller's limit, or its share of what is free plus what it holds
 int workspace_budget(tracyhip_ctx* ctx, uint64_t held, uint64_t* out) {
   if (ctx->ws_limit) { *out = ctx->ws_limit; return TRACYHIP_OK; }
+  // (hipMemGetInfo is a driver round trip, paid while the device waits for the call to be planned: the answer is kept for as long as
+  // the context holds what it held when it asked -- a call of the same shape as the last one)
+  if (ctx->ws_cache_budget && ctx->ws_cache_held == held && ctx->ws_cache_share == ctx->mem_share) { *out = ctx->ws_cache_budget; return TRACYHIP_OK; }
   size_t fr = 0, tot = 0;
   HIP_TRY(hipMemGetInfo(&fr, &tot));
   *out = (uint64_t)(fr * 0.70 / ctx->mem_share) + held;
+  ctx->ws_cache_budget = *out; ctx->ws_cache_held = held; ctx->ws_cache_share = ctx->mem_share;
   return TRACYHIP_OK;
 }
 
@@ -1589,6 +1593,7 @@ struct DecStream {
   bool af_pending = false;   // ... not queued yet (queue_allelic_fraction)
   bool bp_early = false;     // findBreakpoint and the windows' case-sensitive codes were queued behind the full sweeps (OrientStage::filler)
   bool cq_ref_done = false;
+  bool encoded_early = false;
 
   DecStream(tracyhip_ctx* c, const tracyhip_decompose_job* j, const tracyhip_params* q, int m, const tracyhip_decompose_result* o_, StreamHost& h_)
       : ctx(c), job(j), prm(q), mem(m), out(o_), kn(c->knobs), nt(j->ntraces), sp(j->profiles), sr(j->refs), bc(j->bc), dp(j->dprm), st(c->stream), p(*q),
@@ -1613,6 +1618,27 @@ struct DecStream {
       (void)ctx_sync(ctx);
     }
     return rc;
+  }
+
+  // verdict words cleared, the reference windows encoded to profile-row codes (with their block map and the validation verdict)
+  int encode_references(const uint8_t* refs, uint64_t er) {
+    HIP_TRY(ctx->d_err.ensure(kErrBytes));
+    HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, kErrBytes, st));
+    int32_t* d_verr = static_cast<int32_t*>(ctx->d_err.p) + kErrVerdictWord;
+    HIP_TRY(ctx->ensure_codes(er ? er : 1, st));
+    if (er) {
+      hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((er + 4095) / 4096)), dim3(256), 0, st, refs, ctx->codes(), er, ctx->special_blocks(), d_verr);
+      HIP_TRY(hipGetLastError());
+    }
+    return TRACYHIP_OK;
+  }
+  // payloads in device memory: the encoder needs nothing the planner makes -- it runs while the host lays out the geometry records
+  // (2 ms for 100 000 traces during which the device had nothing to do).  Harmless should the planner hand the call back.
+  int encode_early() {
+    if (host) return TRACYHIP_OK;
+    TRY(encode_references(static_cast<const uint8_t*>(sr.data), seqset_extent(sr)));
+    encoded_early = true;
+    return TRACYHIP_OK;
   }
 
   // what the host knows before anything runs: geometry of every trace (laid out in the pinned block it travels from), workspace
@@ -1763,15 +1789,8 @@ struct DecStream {
     HIP_TRY(hipMemcpyAsync(A.pri_bak, d_pri, z.bext, hipMemcpyDeviceToDevice, st));  // decomposeAlleles rewrites the basecalls in place
     HIP_TRY(hipMemcpyAsync(A.sec_bak, d_sec, z.bext, hipMemcpyDeviceToDevice, st));
 
-    // ---- references encoded once; geometry, offsets: one pinned block, one copy each way ----
-    HIP_TRY(ctx->d_err.ensure(kErrBytes));
-    HIP_TRY(hipMemsetAsync(ctx->d_err.p, 0, kErrBytes, st));
-    int32_t* d_verr = static_cast<int32_t*>(ctx->d_err.p) + kErrVerdictWord;
-    HIP_TRY(ctx->ensure_codes(z.er ? z.er : 1, st));
-    if (z.er) {
-      hipLaunchKernelGGL(encode_codes_kernel, dim3((unsigned)((z.er + 4095) / 4096)), dim3(256), 0, st, d_ref, ctx->codes(), z.er, ctx->special_blocks(), d_verr);
-      HIP_TRY(hipGetLastError());
-    }
+    // ---- references encoded once (unless encode_early did it while the host planned); geometry, offsets: one pinned block, one copy each way ----
+    if (!encoded_early) TRY(encode_references(d_ref, z.er));
     {
       char* hp = static_cast<char*>(ctx->h_desc.p);
       SGeomD* hgd = geomd;
@@ -2098,6 +2117,7 @@ int tracyhip::stream_decompose(tracyhip_ctx* ctx, const tracyhip_decompose_job* 
   if (!stream_options_ok(ctx->knobs) || job->oriented || job->ref_profiles.data) return kStreamNo;
   static thread_local StreamHost h;
   DecStream s(ctx, job, prm, mem, out, h);
+  TRY(s.encode_early());
   { TRACYHIP_HOST_SCOPE(hs, "stream_decompose.plan"); TRY(s.plan()); }
   { TRACYHIP_HOST_SCOPE(hs, "stream_decompose.bind"); TRY(s.bind()); }
   { TRACYHIP_HOST_SCOPE(hs, "stream_decompose.queue_trace_stages"); if (int rc = s.queue_trace_stages()) return s.give_up(rc); }    // 2., 3., then 1., 4., 5. (indigo.h:196-350)

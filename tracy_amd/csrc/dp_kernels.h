@@ -1239,7 +1239,10 @@ TR_HD void gotoh_origin_body(W& w, const DpArgs& a, uint32_t pair_idx) {
 constexpr int kPrefixLanes = 8;  // lanes per pair of the prefix-bound kernel: rows 1 .. 8*K, eight pairs per wave
 // the prefix of the pruned orientation sweep (front.h): sixteen lanes of eight rows -- four pairs per wave, twice the waves of the
 // 8 x K shape for the same rows (a batch of 10 000 traces is 2 500 waves of the latter: two or three per SIMD, issue bound)
-constexpr int kFrontPrefixLanes = 16, kFrontPrefixK = 8;
+#ifndef TRACY_FRONT_LANES
+#define TRACY_FRONT_LANES 16
+#endif
+constexpr int kFrontPrefixLanes = TRACY_FRONT_LANES, kFrontPrefixK = 8;
 constexpr uint32_t kFrontRows = (uint32_t)kFrontPrefixLanes * kFrontPrefixK;
 
 // COMPACT: the form for references of A C G T (four code rows in LDS); as with the sweeps, both forms are launched over the

@@ -443,6 +443,8 @@ hipError_t launch_gotoh_ckpt_prefix(int K, const DpArgs& full, uint32_t nfull, c
 // the same with the prefix shape of the pruned orientation sweep (front.h): kFrontRows rows per pair as sixteen lanes of eight rows (four pairs
 // per wave: twice the waves, what a batch of 10 000 traces needs to fill the device), or -- from front_prefix_tall_min pairs on -- as eight
 // lanes of sixteen rows: a step's fixed work (hand-over, code look-up, the kept row's store) is paid per sixteen cells instead of eight
+// (measured: 100 000 traces -1.6 ms per decompose step; 10 000 / 12 500 traces +0.3 / +0.4 ms -- the tall shape halves the waves of a launch
+// that is a few waves deep)
 static uint32_t front_prefix_tall_min() {
   static const uint32_t v = [] { const char* e = getenv("TRACYHIP_PREFIX_TALL_MIN"); return e ? (uint32_t)strtoul(e, nullptr, 10) : 40000u; }();
   return v;
@@ -476,7 +478,7 @@ static hipError_t launch_gotoh_ckpt_front_t(int K, const DpArgs& full, uint32_t 
 hipError_t launch_gotoh_ckpt_front(int K, const DpArgs& full, uint32_t nfull, const DpArgs& pre, uint32_t npre, hipStream_t s) {
   if (nfull + npre == 0) return hipSuccess;
   // (a launch that carries full sweeps keeps the small prefix table: its LDS request is the larger of the two bodies')
-  if (nfull == 0 && npre >= front_prefix_tall_min()) return launch_gotoh_ckpt_front_t<8, 16>(K, full, nfull, pre, npre, s);
+  if (nfull == 0 && npre >= front_prefix_tall_min()) return launch_gotoh_ckpt_front_t<(int)kFrontRows / 16, 16>(K, full, nfull, pre, npre, s);
   return launch_gotoh_ckpt_front_t<kFrontPrefixLanes, kFrontPrefixK>(K, full, nfull, pre, npre, s);
 }
 
@@ -506,7 +508,7 @@ static hipError_t launch_gotoh_front_prefix_cq_t(const DpArgs& a, uint32_t npair
 }
 hipError_t launch_gotoh_front_prefix_cq(const DpArgs& a, uint32_t npairs, hipStream_t s) {
   if (npairs == 0) return hipSuccess;
-  if (npairs >= front_prefix_tall_min()) return launch_gotoh_front_prefix_cq_t<8, 16>(a, npairs, s);
+  if (npairs >= front_prefix_tall_min()) return launch_gotoh_front_prefix_cq_t<(int)kFrontRows / 16, 16>(a, npairs, s);
   return launch_gotoh_front_prefix_cq_t<kFrontPrefixLanes, kFrontPrefixK>(a, npairs, s);
 }
 hipError_t launch_gotoh_walk(const WalkArgs& a, hipStream_t s) {

@@ -250,6 +250,11 @@ def test_decompose_cli_single_trace(tmp_path, reverse):
     recs = [ln.split("\t") for ln in open(prefix + ".vcf").read().split("\n") if ln and not ln.startswith("#")]
     assert [(r[0], int(r[1]), r[3], r[4]) for r in recs] == [(v["chr"], v["pos"], v["ref"], v["alt"]) for v in rep["var"]]
     assert [r[9].split(":")[0] for r in recs] == [{0: "0/0", 1: "0/1", 2: "1/1"}[v["gt"]] for v in rep["var"]]
+    # ... and <prefix>.bcf, the file the reference writes (variants.h:141-261), decoded by the tests' own BCF2 reader
+    from bcf_reader import read_bcf
+    header, brecs, _ = read_bcf(prefix + ".bcf")
+    assert header.endswith("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsample\n")
+    assert [(b["CHROM"], b["POS"], b["REF"], b["ALT"], b["GT"]) for b in brecs] == [(r[0], int(r[1]), r[3], r[4], r[9].split(":")[0]) for r in recs]
     steps = [ln.split("] ", 1)[1] for ln in p.stdout.strip().split("\n") if ln.startswith("[")][1:]
     assert steps == ["Load ab1 file", "Find Reference Match", "Alignment", "InDel Search", "Decompose Chromatogram", "Estimate allelic fractions",
                      "Allele-specific alignments", "Variant Calling", "Done."]

@@ -59,6 +59,19 @@ def test_decompose_output_files(tmp_path, reverse, kind):
     assert open(prefix + ".align3").read() == so.plot_alignment(rows[2][0], rows[2][1], "Alt2", 0, len(s_t), True, w["score2"], 60, key=3, a1a2=w["af"])
     recs = [ln.split("\t") for ln in open(prefix + ".vcf").read().split("\n") if ln and not ln.startswith("#")]
     assert [(r[0], int(r[1]), r[3], r[4]) for r in recs] == [(v["chr"], v["pos"], v["ref"], v["alt"]) for v in var]
+    # <prefix>.bcf (vcfOutput, variants.h:141-261: BGZF + BCF2.2 written without htslib) decoded by the tests' own reader: the header text
+    # and every column of every record are those of the VCF text
+    from bcf_reader import read_bcf
+    header, brecs, blocks = read_bcf(prefix + ".bcf")
+    vcf_lines = open(prefix + ".vcf").read().split("\n")
+    assert header == "\n".join(ln for ln in vcf_lines if ln.startswith("#")) + "\n"
+    assert blocks >= 2 and len(brecs) == len(recs)
+    for b, r in zip(brecs, recs):
+        info = dict(kv.split("=", 1) for kv in r[7].split(";"))
+        assert (b["CHROM"], b["POS"], b["ID"], b["REF"], b["ALT"], b["FILTER"]) == (r[0], int(r[1]), r[2], r[3], r[4], r[6])
+        assert b["QUAL"] == float(r[5])
+        assert (b["INFO"]["TYPE"], b["INFO"]["METHOD"], b["INFO"]["BASEPOS"], b["INFO"]["SIGNALPOS"]) == (info["TYPE"], info["METHOD"], int(info["BASEPOS"]), int(info["SIGNALPOS"]))
+        assert r[8] == "GT:GQ" and (b["GT"], b["GQ"]) == (r[9].split(":")[0], int(r[9].split(":")[1]))
     if kind == 0:
         assert w["bp"].indelshift and len(var) > 0
 

@@ -40,6 +40,7 @@
 #include "../../include/tracy_hip.h"
 #include "../host/assemble_out.hpp"
 #include "../host/consensus_out.hpp"
+#include "../host/bcf_out.hpp"
 #include "../host/indigo_out.hpp"
 #include "../host/sage_out.hpp"
 #include "../host/seed.hpp"
@@ -1214,6 +1215,8 @@ void write_decompose_outputs(SageConfig const& c, Job& j) {
     }
     vcfTextOutput(f, rc, bc, r.var, j.rs, j.rs.filetype == 0 ? &contigs : nullptr);
     f.write(j.outprefix + ".vcf");
+    // ... and as the reference writes them: <prefix>.bcf (BGZF + BCF2.2 without htslib, bcf_out.hpp; no .csi index)
+    bcfOutput(j.outprefix + ".bcf", rc, bc, r.var, j.rs, j.rs.filetype == 0 ? &contigs : nullptr);
   }
   pc.lap(CpuPhases::PAD);
   TextBuf f(1 << 20);

@@ -6,6 +6,7 @@
 #include <thread>
 #include <vector>
 
+#include "bcf_out.hpp"
 #include "indigo_out.hpp"
 #include "sage_out.hpp"
 #include "seed.hpp"
@@ -336,6 +337,7 @@ int32_t tracyhost_decompose_outputs(const tracyhost_decompose_report* rp) {
     std::sort(r.var.begin(), r.var.end());
     std::ofstream f((pre + ".vcf").c_str());
     vcfTextOutput(f, rc, bc, r.var, rs);
+    if (!bcfOutput(pre + ".bcf", rc, bc, r.var, rs)) return -2;
   }
   std::ofstream f((pre + ".json").c_str());
   traceAlleleAlignJsonOut(f, rc, bc, tr, r);

@@ -95,7 +95,10 @@ __global__ __launch_bounds__(64) void front_place_kernel(const FrontDesc* __rest
   DeviceWave16 w;
   FrontDesc f = desc[blockIdx.x];
   if (prev && prev[blockIdx.x].ok) f.flags |= PAIR_SKIP;
-  front_place_body(w, f, row, goe, halfw, pairs + blockIdx.x, fo + blockIdx.x);
+  // (an earlier tier placed the pair on this very row: its maximum and column are taken over, the row is not scanned again -- unless
+  // that tier left the slot empty, cstar = 0)
+  const FrontOut* known = (prev && !(f.flags & PAIR_SKIP) && prev[blockIdx.x].cstar != 0u) ? prev + blockIdx.x : nullptr;
+  front_place_body(w, f, row, goe, halfw, pairs + blockIdx.x, fo + blockIdx.x, known);
 }
 __global__ __launch_bounds__(64) void front_certify_kernel(const FrontDesc* __restrict__ desc, const uint32_t* __restrict__ row, int32_t go, int32_t ge,
                                                            int32_t halfw, const int32_t* __restrict__ scores, const uint32_t* __restrict__ ends,

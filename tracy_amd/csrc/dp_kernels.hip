@@ -153,20 +153,41 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
       const uint32_t ai = base0 + 64 * k + lane;
       opb[k] = ai < L ? ops[L - 1 - ai] : 0;
     }
+    // rows / columns the batch's alignment columns consume (prefix popcounts of the ballots), then ALL its reference bytes requested
+    // together, then the rows: the kernel waited for a reference byte per round of 64 columns (48 dependent round trips per trace)
+    uint32_t rowk[kBatch], colk[kBatch];
+    uint8_t c1k[kBatch];
+    uint32_t take = 0;  // bit k: takes a row, bit 8 + k: takes a column
+    const bool rc = a.a2_revcomp_flag && (d.flags & PAIR_A2_REVCOMP);
+#pragma unroll
+    for (uint32_t k = 0; k < kBatch; ++k) {
+      const uint32_t ai = base0 + 64 * k + lane;
+      const bool active = ai < L;
+      const uint8_t op = opb[k];
+      const bool takes_row = active && op != 'h';  // consumes a1
+      const bool takes_col = active && op != 'v';  // consumes a2
+      const uint64_t mrow = __ballot(takes_row), mcol = __ballot(takes_col);
+      rowk[k] = row_base + (uint32_t)__popcll(mrow & below);
+      colk[k] = col_base + (uint32_t)__popcll(mcol & below);
+      row_base += (uint32_t)__popcll(mrow);
+      col_base += (uint32_t)__popcll(mcol);
+      take |= (takes_row ? 1u : 0u) << k | (takes_col ? 1u : 0u) << (8 + k);
+    }
+    if (!a.a2_profile) {
+#pragma unroll
+      for (uint32_t k = 0; k < kBatch; ++k) {
+        c1k[k] = '-';
+        if ((take >> (8 + k)) & 1u) c1k[k] = static_cast<const uint8_t*>(a.a2)[d.a2_off + (rc ? d.n - 1 - colk[k] : colk[k])];
+      }
+    }
 #pragma unroll
     for (uint32_t k = 0; k < kBatch; ++k) {
       const uint32_t base = base0 + 64 * k;
       if (base >= L) break;  // (wave-uniform)
       const uint32_t ai = base + lane;
       const bool active = ai < L;
-      const uint8_t op = opb[k];
-      const bool takes_row = active && op != 'h';  // consumes a1
-      const bool takes_col = active && op != 'v';  // consumes a2
-      const uint64_t mrow = __ballot(takes_row), mcol = __ballot(takes_col);
-      const uint32_t row = row_base + (uint32_t)__popcll(mrow & below);
-      const uint32_t col = col_base + (uint32_t)__popcll(mcol & below);
-      row_base += (uint32_t)__popcll(mrow);
-      col_base += (uint32_t)__popcll(mcol);
+      const bool takes_row = (take >> k) & 1u, takes_col = (take >> (8 + k)) & 1u;
+      const uint32_t row = rowk[k], col = colk[k];
       uint8_t c0 = '-', c1 = '-';
       if (takes_row) {
         if (gaps_only) {
@@ -185,8 +206,7 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
           for (int q = 0; q < 6; ++q) p[q] = static_cast<const float*>(a.a2)[d.a2_off + (uint64_t)q * d.a2_stride + col];
           c1 = cons_char(p);
         } else {
-          const bool rc = a.a2_revcomp_flag && (d.flags & PAIR_A2_REVCOMP);
-          c1 = static_cast<const uint8_t*>(a.a2)[d.a2_off + (rc ? d.n - 1 - col : col)];
+          c1 = c1k[k];
           if (rc) c1 = complement_char(c1);
           if (a.a2_onehot) {  // consensus character of _createProfile(string) (align.h:121-136, 254-270)
             const uint32_t code = base_code(c1);

@@ -51,8 +51,10 @@ TR_HD int32_t front_v(uint32_t x, int32_t goe) {
 }
 
 // One wave per pair: c*, the band around it, the sub-window that holds the band, the pair the band kernels sweep.
+// known: the pair's {vmax, c*} from an earlier tier's placement over the same kept row (or null: the row is scanned)
 template <class W>
-TR_HD void front_place_body(W& w, const FrontDesc& f, const uint32_t* row, int32_t goe, int32_t halfw, PairDesc* pair, FrontOut* fo) {
+TR_HD void front_place_body(W& w, const FrontDesc& f, const uint32_t* row, int32_t goe, int32_t halfw, PairDesc* pair, FrontOut* fo,
+                            const FrontOut* known = nullptr) {
   const uint32_t L = w.lane();
   if (f.flags & PAIR_SKIP) {
     if (L == 0) {
@@ -64,19 +66,24 @@ TR_HD void front_place_body(W& w, const FrontDesc& f, const uint32_t* row, int32
     }
     return;
   }
-  const uint32_t* r = row + f.row_off;
-  int32_t best = INT32_MIN;
-  uint32_t bc = 0;
-  for (uint32_t c = 1u + L; c <= f.n; c += 64u) {
-    const int32_t v = front_v(r[c], goe);
-    if (v > best) { best = v; bc = c; }
-  }
   int32_t vmax = INT32_MIN;
   uint32_t cstar = 0;
-  for (uint32_t l = 0; l < 64u; ++l) {
-    const int32_t v = (int32_t)w.bcast((uint32_t)best, l);
-    const uint32_t c = w.bcast(bc, l);
-    if (c != 0 && (v > vmax || (v == vmax && c < cstar))) { vmax = v; cstar = c; }
+  if (known) {  // (the same row, the same maximum: a later tier only changes the band around it)
+    vmax = known->vmax;
+    cstar = known->cstar;
+  } else {
+    const uint32_t* r = row + f.row_off;
+    int32_t best = INT32_MIN;
+    uint32_t bc = 0;
+    for (uint32_t c = 1u + L; c <= f.n; c += 64u) {
+      const int32_t v = front_v(r[c], goe);
+      if (v > best) { best = v; bc = c; }
+    }
+    for (uint32_t l = 0; l < 64u; ++l) {
+      const int32_t v = (int32_t)w.bcast((uint32_t)best, l);
+      const uint32_t c = w.bcast(bc, l);
+      if (c != 0 && (v > vmax || (v == vmax && c < cstar))) { vmax = v; cstar = c; }
+    }
   }
   if (L != 0) return;
   const int32_t dlo = (int32_t)cstar - halfw, dhi = (int32_t)cstar + halfw;

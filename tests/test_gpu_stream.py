@@ -52,16 +52,22 @@ def test_align_uniform_batch_is_stream_ordered(ctx, exact):
     assert [int(x) for x in a["forward"]] == [1 - int(r) for r in rev]
 
 
-@pytest.mark.parametrize("exact", [True, False])
-def test_align_failing_certificates_fall_back_per_trace(ctx, exact):
+@pytest.mark.parametrize("exact,quads", [(True, False), (False, False), (True, True)])
+def test_align_failing_certificates_fall_back_per_trace(ctx, exact, quads):
     """test_gpu_front's cases (the target twice, chimeras, long indels, cut windows, mixed strip heights): the traces the device cannot
-    certify are re-done by the host-planned tiers; every array equals the host-planned pipeline's and the oracle's"""
+    certify are re-done by the host-planned tiers; every array equals the host-planned pipeline's and the oracle's.  quads: with the
+    narrow first tier and the later tiers over device-side lists (large batches' form), where some units pass all three uncertified"""
     import sage_oracle as so
     from test_gpu_front import cases
     rng = np.random.default_rng(77)
     cs = cases(rng)
     profs, wins = [c[0] for c in cs], [c[1] for c in cs]
-    a, sa, b, sb = both_ways(ctx, lambda: ctx.align_traces(profs, wins, SC, 50, 50, exact_scores=exact))
+    if quads:
+        ctx.set_option("quad_tier_min", 0)
+    try:
+        a, sa, b, sb = both_ways(ctx, lambda: ctx.align_traces(profs, wins, SC, 50, 50, exact_scores=exact))
+    finally:
+        ctx.set_option("quad_tier_min", 32768)
     assert sa["stream_ordered"] == 1, sa
     assert 4 <= sa["fallback_traces"] <= len(cs) - 16, sa  # both outcomes are exercised
     same_align(a, b, exact, "stream vs host-planned")
@@ -152,9 +158,11 @@ def test_decompose_uniform_batch_is_stream_ordered(ctx, exact):
     assert int((np.asarray(a["status"]) == 0).sum()) > nd // 2
 
 
-def test_decompose_failing_certificates_fall_back_per_trace(ctx):
+@pytest.mark.parametrize("quads", [False, True])
+def test_decompose_failing_certificates_fall_back_per_trace(ctx, quads):
     """windows that hold the locus twice cannot certify the pruned sweeps (test_gpu_decompose): those traces are re-done by the
-    host-planned tiers from their untouched basecalls; the rest stays stream-ordered; everything equals the host-planned run and the oracle"""
+    host-planned tiers from their untouched basecalls; the rest stays stream-ordered; everything equals the host-planned run and the
+    oracle.  quads: the tiers of a large batch (narrow tier first, later tiers over device-side lists of what is left)"""
     from indigo_oracle import decompose_trace
     from tracy_amd import hostlib
     nd = 72
@@ -169,7 +177,12 @@ def test_decompose_failing_certificates_fall_back_per_trace(ctx):
                 c[int(j)] = int(rng.choice(list(b"ACGT")))
             r = r + bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(40, 300))).tolist()) + bytes(c)
         refs.append(r)
-    a, sa, b, sb = decompose_both_ways(ctx, d, refs, nd)
+    if quads:
+        ctx.set_option("quad_tier_min", 0)
+    try:
+        a, sa, b, sb = decompose_both_ways(ctx, d, refs, nd)
+    finally:
+        ctx.set_option("quad_tier_min", 32768)
     assert sa["stream_ordered"] == 1 and 8 <= sa["fallback_traces"] <= nd - 16, sa
     same_decompose(a, b)
     for i in (0, 1, 3, 10, 30):
@@ -220,12 +233,23 @@ def test_quad_tier_of_the_pruned_sweeps_changes_nothing(ctx):
     try:
         assert ctx.describe()["quad_tier_min"] == "0"
         a1, sa1, b1, sb1 = run()
+        # the later tiers over device-side lists of what is left (the default with the quad tier) against skipping in place
+        ctx.set_option("no_front_lists", 1)
+        assert ctx.describe()["no_front_lists"] == "1"
+        a2, sa2, b2, sb2 = run()
     finally:
         ctx.set_option("quad_tier_min", 32768)
+        ctx.set_option("no_front_lists", 0)
     assert sa1["stream_ordered"] == 1 and sb1["stream_ordered"] == 1
     assert sa1["pruned"] == sa0["pruned"] and sb1["allele_pruned"] == sb0["allele_pruned"], (sa0, sa1, sb0, sb1)
+    # (with the lists, the second allele of a trace reads the first one's kept prefix row where both begin with the same 128 characters)
+    assert sb1["allele_shared_prefix"] >= nd // 4 and sb2["allele_shared_prefix"] == 0 and sb0["allele_shared_prefix"] == 0, (sb0, sb1, sb2)
+    sb1 = dict(sb1, allele_shared_prefix=0)
+    assert sa2 == sa1 and sb2 == sb1, (sa1, sa2, sb1, sb2)
     same_align(a1, a0, True, "quad tier")
     same_decompose(b1, b0, "quad tier")
+    same_align(a2, a0, True, "quad tier, tiers in place")
+    same_decompose(b2, b0, "quad tier, tiers in place")
 
 
 @pytest.mark.parametrize("option", ["no_quads", "no_fork"])

@@ -256,11 +256,23 @@ class DecomposeLeg:
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
             st = self.ctx.last_call_stats()
+            # the same call cut into two chunks on two streams (tracyhip_set_lanes): one chunk's chain of short launches beside the other's
+            self.ctx.set_lanes(2)
+            for _ in range(2):
+                self.step(None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(None)
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t0) / steps
         finally:
+            self.ctx.set_lanes(1)
             self.job.ntraces = nt
             self.job.bc.ntraces = nt
         return {"traces": small, "ms_per_step": round(dt * 1e3, 3), "traces_per_s": round(small / dt, 1), "steps": steps,
-                "stream_ordered": st["stream_ordered"], "host_syncs": st["host_syncs"], "fallback_traces": st["fallback_traces"]}
+                "stream_ordered": st["stream_ordered"], "host_syncs": st["host_syncs"], "fallback_traces": st["fallback_traces"],
+                "two_lanes_ms_per_step": round(dt2 * 1e3, 3)}
 
     def run(self, dist, steps, warmup, extra_legs=True, cpu_sample=64):
         dev = self.dev

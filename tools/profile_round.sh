@@ -7,7 +7,7 @@
 # Counters: separate --pmc passes with --kernel-trace only (WRITE_SIZE, FETCH_SIZE; SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES).
 # Outputs under gpurun_out/prof_round/; tools/profile_summarise.py turns them into the files kept in profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=/root/repo/gpurun_out/prof_round
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -28,11 +28,21 @@ for w in bench dec ap se; do
   done
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_${w}_valu" -- python $B $ARGS > /dev/null 2> "$OUT/pmc_${w}_valu.err"
 done
+# stall counters (where the wave cycles go: parked in s_waitcnt / s_barrier, issue stalls, LDS) and effective clocks, align and decompose
+for w in bench dec; do
+  case $w in bench) ARGS="$AL --steps 2 --cpu-sample 0";; dec) ARGS="$DE --cpu-sample 0";; esac
+  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU \
+    --output-format csv -d "$OUT/pmc_${w}_stallA" -- python $B $ARGS > /dev/null 2> "$OUT/pmc_${w}_stallA.err"
+  rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVES \
+    --output-format csv -d "$OUT/pmc_${w}_stallB" -- python $B $ARGS > /dev/null 2> "$OUT/pmc_${w}_stallB.err"
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_${w}_clock" -- python $B $ARGS > /dev/null 2> "$OUT/pmc_${w}_clock.err"
+done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_default_stats" -- python $B --workload align --steps 3 --warmup 1 > "$OUT/bench_default_line.json" 2> "$OUT/bench_default.err"
 python $B > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 # where the GPU waits for the host: kernel + memory-copy timelines of one step of each pipeline (tools/timeline_gaps.py)
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d "$OUT/tl_dec" -- python $B $DE --cpu-sample 0 > /dev/null 2> "$OUT/tl_dec.err"
 python /root/repo/tools/timeline_gaps.py "$OUT/tl_dec" > "$OUT/decompose_timeline_gaps.txt" 2>&1
+python /root/repo/tools/timeline_dump.py "$OUT/tl_dec" > "$OUT/decompose_timeline.txt" 2>&1
 # host synchronisations of a call: counted by the library (tracyhip_last_call_stats), as the bench line of the same workload printed them
 python - "$OUT/dec_line.json" >> "$OUT/decompose_timeline_gaps.txt" <<'PYEOF'
 import json, sys
@@ -47,9 +57,11 @@ except Exception as e:  # noqa: BLE001
 PYEOF
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d "$OUT/tl_al" -- python $B $AL --cpu-sample 0 > /dev/null 2> "$OUT/tl_al.err"
 python /root/repo/tools/timeline_gaps.py "$OUT/tl_al" encode_codes_kernel > "$OUT/align_timeline_gaps.txt" 2>&1
+python /root/repo/tools/timeline_dump.py "$OUT/tl_al" > "$OUT/align_timeline.txt" 2>&1
 # the shard one of 8 GPUs gets from the 100 000-trace decompose job, as a job of its own: what a step costs once the kernels are short
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d "$OUT/tl_small" -- python $B --workload decompose --decompose-traces 12500 --decompose-steps 3 --extra-legs 0 --cpu-sample 0 > /dev/null 2> "$OUT/tl_small.err"
 python /root/repo/tools/timeline_gaps.py "$OUT/tl_small" > "$OUT/decompose_small_batch_timeline_gaps.txt" 2>&1
+python /root/repo/tools/timeline_dump.py "$OUT/tl_small" > "$OUT/decompose_small_batch_timeline.txt" 2>&1
 rm -rf "$OUT/tl_dec" "$OUT/tl_al" "$OUT/tl_small"
 find "$OUT" -name "*.csv" -size +40M -delete
 ls "$OUT" | head -60

@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
 def one(pattern):
@@ -49,23 +49,21 @@ def per_kernel(pass_dir, scale):
     if not f:
         return []
     acc = collections.OrderedDict()
+    # one row per (kernel, grid size, counter): the full sweeps and the prefix launch of one instantiation differ in their grids
+    dur = collections.defaultdict(dict)
     for r in csv.DictReader(open(f)):
-        k = (r["Kernel_Name"], r["Counter_Name"])
-        a = acc.setdefault(k, {"sum": 0.0, "disp": set(), "grid": r.get("Grid_Size", "")})
+        k = (r["Kernel_Name"], r.get("Grid_Size", ""), r["Counter_Name"])
+        a = acc.setdefault(k, {"sum": 0.0, "disp": set()})
         a["sum"] += float(r["Counter_Value"])
         a["disp"].add(r["Dispatch_Id"])
-    dur = collections.defaultdict(list)
-    t = one(pass_dir + "/*/*kernel_trace.csv")
-    if t:
-        for r in csv.DictReader(open(t)):
-            dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+        dur[(r["Kernel_Name"], r.get("Grid_Size", ""))][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     out = []
-    for (kern, ctr), a in acc.items():
+    for (kern, grid, ctr), a in acc.items():
         if not kern.startswith("void tracyhip") and "tracyhip" not in kern and "anonymous" not in kern:
             continue
         n = max(len(a["disp"]), 1)
-        ms = dur.get(kern, [])
-        out.append({"counter": ctr, "kernel": kern, "launches": n, "per_launch": a["sum"] / n * scale,
+        ms = list(dur[(kern, grid)].values())
+        out.append({"counter": ctr, "kernel": kern, "grid": int(grid) if grid else None, "launches": n, "per_launch": a["sum"] / n * scale,
                     "avg_launch_ms": sum(ms) / len(ms) if ms else None})
     return out
 
@@ -98,6 +96,19 @@ for w, suffix in (("bench", ""), ("dec", "_decompose"), ("ap", "_allpairs"), ("s
     valu = per_kernel("pmc_%s_valu" % w, 1.0)
     if valu:
         json.dump(valu, open(os.path.join(DST, "%s_pmc_valu%s.json" % (tag, suffix)), "w"), indent=1)
+# stall counters (two SQ passes) and effective clocks (GRBM_GUI_ACTIVE over the XCDs / duration) per kernel and grid
+for w, suffix in (("bench", ""), ("dec", "_decompose")):
+    rows = []
+    for ps in ("stallA", "stallB", "clock"):
+        rows += per_kernel("pmc_%s_%s" % (w, ps), 1.0)
+    if rows:
+        for r in rows:
+            if r["counter"] == "GRBM_GUI_ACTIVE" and r["avg_launch_ms"]:
+                r["effective_clock_ghz"] = round(r["per_launch"] / 8.0 / (r["avg_launch_ms"] * 1e6), 3)  # (summed over the eight XCDs)
+        json.dump(rows, open(os.path.join(DST, "%s_pmc_stalls%s.json" % (tag, suffix)), "w"), indent=1)
+for nm in ("decompose_timeline.txt", "align_timeline.txt", "decompose_small_batch_timeline.txt"):
+    if os.path.exists(os.path.join(SRC, nm)):
+        shutil.copy(os.path.join(SRC, nm), os.path.join(DST, "%s_%s" % (tag, nm)))
 for nm in ("decompose_timeline_gaps.txt", "align_timeline_gaps.txt", "decompose_small_batch_timeline_gaps.txt"):
     if os.path.exists(os.path.join(SRC, nm)):
         shutil.copy(os.path.join(SRC, nm), os.path.join(DST, "%s_%s" % (tag, nm)))

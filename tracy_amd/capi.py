@@ -53,7 +53,8 @@ class CallStats(C.Structure):
     _fields_ = [("traces", C.c_uint32), ("stream_ordered", C.c_uint32), ("host_syncs", C.c_uint32), ("fallback_traces", C.c_uint32),
                 ("pruned", C.c_uint32), ("pruned_uncertified", C.c_uint32), ("prelim_banded", C.c_uint32), ("prelim_repeated", C.c_uint32),
                 ("final_banded", C.c_uint32), ("final_repeated", C.c_uint32), ("allele_pruned", C.c_uint32 * 2),
-                ("allele_uncertified", C.c_uint32 * 2), ("allele_banded", C.c_uint32 * 3), ("allele_repeated", C.c_uint32 * 3)]
+                ("allele_uncertified", C.c_uint32 * 2), ("allele_banded", C.c_uint32 * 3), ("allele_repeated", C.c_uint32 * 3),
+                ("allele_shared_prefix", C.c_uint32)]
 
 
 def library_path():

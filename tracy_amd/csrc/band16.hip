@@ -91,22 +91,35 @@ __global__ __launch_bounds__(64) void band16_cont16_quad_kernel(Band16Args a) {
 // front.h: one wave per pair
 // prev (or null): the verdicts of an earlier, narrower tier over the same descriptors -- what certified there is an empty slot here
 __global__ __launch_bounds__(64) void front_place_kernel(const FrontDesc* __restrict__ desc, const uint32_t* __restrict__ row, int32_t goe, int32_t halfw,
-                                                         PairDesc* __restrict__ pairs, FrontOut* __restrict__ fo, const FrontOut* __restrict__ prev) {
+                                                         PairDesc* __restrict__ pairs, FrontOut* __restrict__ fo, const FrontOut* __restrict__ prev,
+                                                         const uint32_t* __restrict__ index, const uint32_t* __restrict__ count) {
   DeviceWave16 w;
-  FrontDesc f = desc[blockIdx.x];
-  if (prev && prev[blockIdx.x].ok) f.flags |= PAIR_SKIP;
+  // (a later tier's units as a list laid out on the device: the grid holds the worst case, the workgroups past the count leave)
+  uint32_t u = blockIdx.x;
+  if (index) {
+    if (u >= *count) return;
+    u = index[u];
+  }
+  FrontDesc f = desc[u];
+  if (prev && prev[u].ok) f.flags |= PAIR_SKIP;
   // (an earlier tier placed the pair on this very row: its maximum and column are taken over, the row is not scanned again -- unless
   // that tier left the slot empty, cstar = 0)
-  const FrontOut* known = (prev && !(f.flags & PAIR_SKIP) && prev[blockIdx.x].cstar != 0u) ? prev + blockIdx.x : nullptr;
-  front_place_body(w, f, row, goe, halfw, pairs + blockIdx.x, fo + blockIdx.x, known);
+  const FrontOut* known = (prev && !(f.flags & PAIR_SKIP) && prev[u].cstar != 0u) ? prev + u : nullptr;
+  front_place_body(w, f, row, goe, halfw, pairs + u, fo + u, known);
 }
 __global__ __launch_bounds__(64) void front_certify_kernel(const FrontDesc* __restrict__ desc, const uint32_t* __restrict__ row, int32_t go, int32_t ge,
                                                            int32_t halfw, const int32_t* __restrict__ scores, const uint32_t* __restrict__ ends,
-                                                           FrontOut* __restrict__ fo, const FrontOut* __restrict__ prev) {
+                                                           FrontOut* __restrict__ fo, const FrontOut* __restrict__ prev,
+                                                           const uint32_t* __restrict__ index, const uint32_t* __restrict__ count) {
   DeviceWave16 w;
-  const FrontDesc f = desc[blockIdx.x];
-  if (prev && prev[blockIdx.x].ok) return;
-  front_certify_body(w, f, row, go, ge, halfw, scores[f.out], ends[2 * f.out + 1], fo + blockIdx.x);
+  uint32_t u = blockIdx.x;
+  if (index) {
+    if (u >= *count) return;
+    u = index[u];
+  }
+  const FrontDesc f = desc[u];
+  if (prev && prev[u].ok) return;
+  front_certify_body(w, f, row, go, ge, halfw, scores[f.out], ends[2 * f.out + 1], fo + u);
 }
 
 // Substitution tables: int16 [6 codes][stride] per sequence.  Profile rows: the int of the fp32 chain of align.h:112-117 against the
@@ -270,16 +283,17 @@ hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s, bool na
 }
 
 hipError_t launch_front_place(const FrontDesc* d_desc, uint32_t n, const uint32_t* row, int32_t goe, int32_t halfw, PairDesc* d_pairs, FrontOut* d_fo,
-                              hipStream_t s, const FrontOut* d_prev) {
+                              hipStream_t s, const FrontOut* d_prev, const uint32_t* d_index, const uint32_t* d_count) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(front_place_kernel, dim3(n), dim3(64), 0, s, d_desc, row, goe, halfw, d_pairs, d_fo, d_prev);
+  hipLaunchKernelGGL(front_place_kernel, dim3(n), dim3(64), 0, s, d_desc, row, goe, halfw, d_pairs, d_fo, d_prev, d_index, d_count);
   return hipGetLastError();
 }
 
 hipError_t launch_front_certify(const FrontDesc* d_desc, uint32_t n, const uint32_t* row, int32_t go, int32_t ge, int32_t halfw, const int32_t* d_scores,
-                                const uint32_t* d_ends, FrontOut* d_fo, hipStream_t s, const FrontOut* d_prev) {
+                                const uint32_t* d_ends, FrontOut* d_fo, hipStream_t s, const FrontOut* d_prev, const uint32_t* d_index,
+                                const uint32_t* d_count) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(front_certify_kernel, dim3(n), dim3(64), 0, s, d_desc, row, go, ge, halfw, d_scores, d_ends, d_fo, d_prev);
+  hipLaunchKernelGGL(front_certify_kernel, dim3(n), dim3(64), 0, s, d_desc, row, go, ge, halfw, d_scores, d_ends, d_fo, d_prev, d_index, d_count);
   return hipGetLastError();
 }
 

@@ -50,10 +50,13 @@ hipError_t launch_band16_cont_quad(const Band16Args& a, hipStream_t s);
 struct FrontDesc;
 struct FrontOut;
 // d_prev (or null): verdicts of an earlier tier over the same descriptors; what certified there is skipped
+// d_index / d_count (or null): workgroup i takes unit d_index[i], and only *d_count of them do (a list laid out on the device, n = its
+// worst case); results stay in the units' own slots
 hipError_t launch_front_place(const FrontDesc* d_desc, uint32_t n, const uint32_t* row, int32_t goe, int32_t halfw, PairDesc* d_pairs, FrontOut* d_fo,
-                              hipStream_t s, const FrontOut* d_prev = nullptr);
+                              hipStream_t s, const FrontOut* d_prev = nullptr, const uint32_t* d_index = nullptr, const uint32_t* d_count = nullptr);
 hipError_t launch_front_certify(const FrontDesc* d_desc, uint32_t n, const uint32_t* row, int32_t go, int32_t ge, int32_t halfw, const int32_t* d_scores,
-                                const uint32_t* d_ends, FrontOut* d_fo, hipStream_t s, const FrontOut* d_prev = nullptr);
+                                const uint32_t* d_ends, FrontOut* d_fo, hipStream_t s, const FrontOut* d_prev = nullptr, const uint32_t* d_index = nullptr,
+                                const uint32_t* d_count = nullptr);
 
 }  // namespace tracyhip
 #endif

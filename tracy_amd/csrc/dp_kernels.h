@@ -101,6 +101,8 @@ struct DpArgs {
   int32_t ckpt_narrow;  // checkpoints hold raw registers of the 16-bit kernel (values in the low halves)
   uint32_t* ends;       // origin-tracking sweep: {leading 'h' columns, last column that is not a trailing 'h'} per pair
   unsigned long long* swept;  // band traceback: DP cells actually re-swept, summed over the launch (or null)
+  const uint32_t* index;  // prefix sweeps (gotoh_prefix_body): pair i of the launch is pairs[index[i]] and only *count of them exist -- a list
+  const uint32_t* count;  // laid out on the device, the grid sized for its worst case (null: pairs[i], npairs)
   const uint32_t* votes;  // checkpointed 16-bit sweep of both orientations (PairDesc::out = orientation * vote_nt + trace): {vf, vr} per
   uint32_t vote_nt;       // trace, or null.  Sweeps of the likely losing strand (vote_skips_checkpoints) write no checkpoints / row m
 };
@@ -1256,9 +1258,14 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
   const uint32_t L = w.lane();
   const uint32_t Lg = L % GL;
   const uint32_t pair_idx = group_base + L / GL;
+  if (a.count) {
+    const uint32_t listed = *a.count;
+    npairs = listed < npairs ? listed : npairs;
+    if (group_base >= npairs) return;
+  }
   bool valid = pair_idx < npairs;
   PairDesc d{};
-  if (valid) d = a.pairs[pair_idx];
+  if (valid) d = a.pairs[a.index ? a.index[pair_idx] : pair_idx];
   valid = valid && !(d.flags & PAIR_SKIP);
   {
     bool plain = a.special_blocks != nullptr;  // every lane of a group looks at its pair's blocks: the same answer in all of them

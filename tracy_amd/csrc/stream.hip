@@ -509,6 +509,8 @@ struct StreamCommon {  // device arrays of the orientation stage + preliminary a
   uint32_t* idx;
   ScanPart* part;            // the scan's block totals
   uint32_t* count;           // [4] per band stage
+  uint32_t* flist;           // pruned sweeps: the units a later tier still has to take (s_front_list_kernel) ...
+  uint32_t* fcount;          // ... and how many: [0] for the first wide tier behind the quads, [1] for the last tier; [2]: the allele prefixes' list
   unsigned long long* cnt;   // [SC_COUNT]
   unsigned long long* bstat; // [SB_COUNT] per band stage
   uint32_t* ends;
@@ -549,6 +551,8 @@ struct StreamCommon {  // device arrays of the orientation stage + preliminary a
     idx = a.take<uint32_t>(4 * (size_t)nunits);
     part = a.take<ScanPart>((nunits + kScanBlock - 1) / kScanBlock + 1);
     count = a.take<uint32_t>(4 * 8);
+    flist = a.take<uint32_t>(nunits);
+    fcount = a.take<uint32_t>(4);
     cnt = a.take<unsigned long long>(SC_COUNT);
     bstat = a.take<unsigned long long>(SB_COUNT * 8);
     ends = a.take<uint32_t>(2 * (size_t)nunits);
@@ -635,20 +639,55 @@ bool front_tiers_fit(uint32_t max_rest) { return front_tier_fits(8, 60, max_rest
 // one tier of the pruned sweep over fixed slots: place, band below the kept row, certify (capi.hip run_front_once)
 // KB = 0: the quad form (strips of four rows, four lanes per pair) -- the narrow tier ahead of the others
 int front_tier(tracyhip_ctx* ctx, const tracyhip_params& p, const FrontDesc* fd, uint32_t n, const int16_t* d_qp, const uint8_t* d_codes, const uint32_t* d_row,
-               int KB, int32_t halfw, uint32_t max_rest, PairDesc* pairs, FrontOut* fo, int32_t* fs, uint32_t* fe, const FrontOut* prev) {
+               int KB, int32_t halfw, uint32_t max_rest, PairDesc* pairs, FrontOut* fo, int32_t* fs, uint32_t* fe, const FrontOut* prev,
+               const uint32_t* list, const uint32_t* list_count) {
   hipStream_t st = ctx->stream;
   Band16Args a{};
-  a.pairs = pairs; a.npairs = n; a.qp = d_qp; a.codes = d_codes; a.scores = fs; a.ends = fe;
+  a.pairs = pairs; a.npairs = n; a.index = list; a.count = list_count; a.qp = d_qp; a.codes = d_codes; a.scores = fs; a.ends = fe;
   a.err = static_cast<int32_t*>(ctx->d_err.p); a.go = p.go; a.ge = p.ge; a.hfree = 1; a.row = d_row;
   a.code_cap = (max_rest + 2u * (uint32_t)halfw + 16u) & ~3u;  // front_place_body: a sub-window is at most m_rest + 2 halfw + 2 columns
   if (KB == 0) {
     if (b16_cont_quad_lds(a.code_cap) > 64u * 1024u) return kStreamNo;  // (front_tiers_run goes on with the wide tiers: nothing was queued for this one)
   } else if (!front_tier_fits(KB, halfw, max_rest)) return set_error(TRACYHIP_ERR_ARG, "pruned-sweep tier without LDS room (front_tiers_fit not consulted)");
-  HIP_TRY(launch_front_place(fd, n, d_row, p.go + p.ge, halfw, pairs, fo, st, prev));
+  HIP_TRY(launch_front_place(fd, n, d_row, p.go + p.ge, halfw, pairs, fo, st, prev, list, list_count));
   if (KB == 0) HIP_TRY(launch_band16_cont_quad(a, st));
   else HIP_TRY(launch_band16_cont(KB, a, st, !ctx->knobs.no_cont16));
-  HIP_TRY(launch_front_certify(fd, n, d_row, p.go, p.ge, halfw, fs, fe, fo, st, prev));
+  HIP_TRY(launch_front_certify(fd, n, d_row, p.go, p.ge, halfw, fs, fe, fo, st, prev, list, list_count));
   return TRACYHIP_OK;
+}
+
+// the units an earlier tier did not certify as a list for the next tier's three launches: a band launch runs as long as its slowest
+// wave and a wave as long as the widest of its four pairs, so units skipped in place leave most waves as they were (one in four
+// certified: 0.4 % of the waves empty), whereas a list shortens the launch by what was certified.  The order of the list is whichever
+// workgroup adds its part first; results go to the units' own slots, so nothing depends on it.
+__device__ __forceinline__ void s_list_append(bool take, uint32_t i, uint32_t* __restrict__ list, uint32_t* __restrict__ count) {  // (blocks of 256 threads, all of them)
+  __shared__ uint32_t wave_n[4], base;
+  const uint32_t wv = threadIdx.x >> 6, L = threadIdx.x & 63u;
+  const unsigned long long bal = __ballot(take);
+  if (L == 0) wave_n[wv] = (uint32_t)__popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3];
+    base = tot ? atomicAdd(count, tot) : 0u;
+  }
+  __syncthreads();
+  if (!take) return;
+  uint32_t at = base + (uint32_t)__popcll(bal & ((1ull << L) - 1ull));
+  for (uint32_t k = 0; k < wv; ++k) at += wave_n[k];
+  list[at] = i;
+}
+__global__ __launch_bounds__(256) void s_front_list_kernel(uint32_t n, const FrontOut* __restrict__ prev, uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  s_list_append(i < n && !prev[i].ok, i, list, count);
+}
+// ... and the pairs of a launch that take part in it (a prefix launch whose pairs partly share their kept rows: s_allele_plan0_kernel)
+__global__ __launch_bounds__(256) void s_pair_list_kernel(uint32_t n, const PairDesc* __restrict__ pairs, uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  s_list_append(i < n && !(pairs[i].flags & PAIR_SKIP), i, list, count);
+}
+hipError_t front_list(tracyhip_ctx* ctx, uint32_t n, const FrontOut* prev, uint32_t* list, uint32_t* count) {
+  hipLaunchKernelGGL(s_front_list_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, prev, list, count);
+  return hipGetLastError();
 }
 
 // what the narrow tier certified goes into the first wide tier's slots (which skipped it): everything after reads two tiers
@@ -661,17 +700,24 @@ __global__ void s_front_fold_kernel(uint32_t n, const FrontOut* __restrict__ fo0
   fe1[2 * i] = fe0[2 * i];
   fe1[2 * i + 1] = fe0[2 * i + 1];
 }
-int front_tier(tracyhip_ctx* ctx, const tracyhip_params& p, const FrontDesc* fd, uint32_t n, const int16_t* d_qp, const uint8_t* d_codes, const uint32_t* d_row,
-               int KB, int32_t halfw, uint32_t max_rest, PairDesc* pairs, FrontOut* fo, int32_t* fs, uint32_t* fe, const FrontOut* prev);
 int front_tiers_run_wide(tracyhip_ctx* ctx, const tracyhip_params& p, StreamCommon& sc, uint32_t n, const int16_t* d_qp, const uint8_t* d_codes,
                          const uint32_t* d_row, uint32_t max_rest, bool after_quads) {
-  int rc = front_tier(ctx, p, sc.fd, n, d_qp, d_codes, d_row, 8, 60, max_rest, sc.fpairs1, sc.fo1, sc.fs1, sc.fe1, after_quads ? sc.fo0 : nullptr);
+  // (lists where the launches are long enough to be worth a fourth small one: the batches that get the quad tier)
+  const bool lists = !ctx->knobs.no_front_lists && n >= ctx->knobs.quad_tier_min;
+  if (lists) HIP_TRY(hipMemsetAsync(sc.fcount, 0, 2 * sizeof(uint32_t), ctx->stream));
+  const bool list1 = lists && after_quads;
+  if (list1) HIP_TRY(front_list(ctx, n, sc.fo0, sc.flist, sc.fcount));
+  int rc = front_tier(ctx, p, sc.fd, n, d_qp, d_codes, d_row, 8, 60, max_rest, sc.fpairs1, sc.fo1, sc.fs1, sc.fe1, after_quads ? sc.fo0 : nullptr,
+                      list1 ? sc.flist : nullptr, list1 ? sc.fcount : nullptr);
   if (rc) return rc;
   if (after_quads) {
     hipLaunchKernelGGL(s_front_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, sc.fo0, sc.fs0, sc.fe0, sc.fo1, sc.fs1, sc.fe1);
     HIP_TRY(hipGetLastError());
   }
-  return front_tier(ctx, p, sc.fd, n, d_qp, d_codes, d_row, kFrontK, kFrontHalfW, max_rest, sc.fpairs2, sc.fo2, sc.fs2, sc.fe2, sc.fo1);
+  // (the first list has been read by the tier above: the same array holds the second)
+  if (lists) HIP_TRY(front_list(ctx, n, sc.fo1, sc.flist, sc.fcount + 1));
+  return front_tier(ctx, p, sc.fd, n, d_qp, d_codes, d_row, kFrontK, kFrontHalfW, max_rest, sc.fpairs2, sc.fo2, sc.fs2, sc.fe2, sc.fo1,
+                    lists ? sc.flist : nullptr, lists ? sc.fcount + 1 : nullptr);
 }
 constexpr int32_t kQuadHalfW = 5;  // c* +- 5: eleven diagonals, a window of three blocks of strip height 4 (b16_narrow_ok)
 
@@ -683,7 +729,7 @@ int front_tiers_run(tracyhip_ctx* ctx, const tracyhip_params& p, StreamCommon& s
   // -2.5 ms, 12 500 units +0.3 ms measured)
   const bool quads = !ctx->knobs.no_quads && n >= ctx->knobs.quad_tier_min;
   int rc = TRACYHIP_OK;
-  if (quads) rc = front_tier(ctx, p, sc.fd, n, d_qp, d_codes, d_row, 0, kQuadHalfW, max_rest, sc.fpairs0, sc.fo0, sc.fs0, sc.fe0, nullptr);
+  if (quads) rc = front_tier(ctx, p, sc.fd, n, d_qp, d_codes, d_row, 0, kQuadHalfW, max_rest, sc.fpairs0, sc.fo0, sc.fs0, sc.fe0, nullptr, nullptr, nullptr);
   if (rc == kStreamNo && quads) return front_tiers_run_wide(ctx, p, sc, n, d_qp, d_codes, d_row, max_rest, false);
   if (rc) return rc;
   return front_tiers_run_wide(ctx, p, sc, n, d_qp, d_codes, d_row, max_rest, quads);
@@ -961,6 +1007,7 @@ void stats_from_counters(tracyhip_ctx* ctx, const unsigned long long* c, const u
   s.final_banded += (uint32_t)c[SC_FINAL_BANDED]; s.final_repeated += (uint32_t)c[SC_FINAL_REPEATED];
   for (int k = 0; k < 2; ++k) { s.allele_pruned[k] += (uint32_t)c[SC_ALLELE_PRUNED0 + k]; s.allele_uncertified[k] += (uint32_t)c[SC_ALLELE_UNCERT0 + k]; }
   for (int k = 0; k < 3; ++k) { s.allele_banded[k] += (uint32_t)c[SC_ALLELE_BANDED0 + k]; s.allele_repeated[k] += (uint32_t)c[SC_ALLELE_REPEATED0 + k]; }
+  s.allele_shared_prefix += (uint32_t)c[SC_ALLELE_SHARED];
   if (ctx->timing) {
     ctx->acc[TRACYHIP_TIMER_SCORE].cells += c[SC_SWEEP_CELLS];
     ctx->acc[TRACYHIP_TIMER_SCORE].bytes += c[SC_SWEEP_BYTES];
@@ -1253,7 +1300,8 @@ __global__ void s_status_kernel(SParams p, const SGeom* __restrict__ geom, const
 
 // gotoh(allele, rs.refslice) (indigo.h:359) by the pruned sweep: prefix rows with row R kept + the band below them (pipeline.hip 6.b)
 __global__ void s_allele_plan0_kernel(SParams p, SParamsD pd, const SGeom* __restrict__ geom, const SGeomD* __restrict__ geomd, const STrace* __restrict__ tr,
-                                      uint32_t* __restrict__ dead, PairDesc* __restrict__ pre, FrontDesc* __restrict__ fd, unsigned long long* __restrict__ cnt) {
+                                      uint32_t* __restrict__ dead, PairDesc* __restrict__ pre, FrontDesc* __restrict__ fd, const uint8_t* __restrict__ seqs,
+                                      int share, unsigned long long* __restrict__ cnt) {
   with_counters(cnt, [&](unsigned long long* lc) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= 2u * p.nt) return;
@@ -1276,8 +1324,22 @@ __global__ void s_allele_plan0_kernel(SParams p, SParamsD pd, const SGeom* __res
   d.flags = rcf | PAIR_KEEP_ROW;
   d.out = q;
   d.lastrow_off = D.alr_off[k];
+  // The two alleles of a trace differ from the breakpoint on and at heterozygous positions before it: where their first R
+  // characters are the same string, rows 1..R against the same window are the same rows, and allele 2 reads the row allele 1 keeps
+  // (two thirds of the traces of the decompose bench).  Byte equality of the inputs, nothing else.
+  uint32_t kept = k;
+  if (share && k == 1u && (D.flags[0] & SG_FRONT_OK)) {
+    const uint8_t *x = seqs + D.bc_off + D.soff, *y = x + pd.bext;
+    uint32_t i = 0;
+    while (i < R && x[i] == y[i]) ++i;
+    if (i == R) kept = 0u;
+  }
+  if (kept != k) {
+    d = s_skip_pair(q);
+    s_count(lc, SC_ALLELE_SHARED);
+  }
   pre[q] = d;
-  f.row_off = D.alr_off[k];
+  f.row_off = D.alr_off[kept];
   f.a2_off = G.ref_off;
   f.tab_off = D.atab_off[k] + R;
   f.tab_stride = D.atab_stride;
@@ -1290,8 +1352,10 @@ __global__ void s_allele_plan0_kernel(SParams p, SParamsD pd, const SGeom* __res
   s_count(lc, SC_ALLELE_PRUNED0 + (int)k);
   s_count(lc, SC_FRONT_CELLS, s_front_cells(f.m_rest));
   s_count(lc, SC_FRONT_BYTES, s_front_bytes(f.m_rest, f.n));
-  s_count(lc, SC_SWEEP_CELLS, (uint64_t)R * G.rn);
-  s_count(lc, SC_SWEEP_BYTES, (uint64_t)R + 5ull * G.rn);
+  if (kept == k) {
+    s_count(lc, SC_SWEEP_CELLS, (uint64_t)R * G.rn);
+    s_count(lc, SC_SWEEP_BYTES, (uint64_t)R + 5ull * G.rn);
+  }
   });
 }
 
@@ -1946,11 +2010,20 @@ struct DecStream {
     TRY(timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, atab_tot * 2));
     HIP_TRY(launch_b16_tables(A.atd, 2 * nt, A.seqs2, true, p.match, p.mismatch, sub_limit(&p), kTagShift, const_cast<int16_t*>(d_aqp), static_cast<int32_t*>(ctx->d_err.p), st));
     TRY(timing_end(ctx));
-    hipLaunchKernelGGL(s_allele_plan0_kernel, g256x2, b256, 0, st, spm, spd, sc.geom, A.geomd, sc.tr, sc.dead, sc.pre, sc.fd, sc.cnt);
+    // (shared kept rows leave holes in the prefix launch: its pairs as a list, as for the later tiers -- batches of quad_tier_min units and more)
+    const bool share = !kn.no_front_lists && 2 * nt >= kn.quad_tier_min;
+    hipLaunchKernelGGL(s_allele_plan0_kernel, g256x2, b256, 0, st, spm, spd, sc.geom, A.geomd, sc.tr, sc.dead, sc.pre, sc.fd, static_cast<const uint8_t*>(A.seqs2),
+                       share ? 1 : 0, sc.cnt);
     HIP_TRY(hipGetLastError());
+    if (share) {
+      HIP_TRY(hipMemsetAsync(sc.fcount + 2, 0, sizeof(uint32_t), st));
+      hipLaunchKernelGGL(s_pair_list_kernel, g256x2, b256, 0, st, 2 * nt, sc.pre, sc.flist, sc.fcount + 2);
+      HIP_TRY(hipGetLastError());
+    }
     {
       DpArgs a{};
       a.pairs = sc.pre;
+      if (share) { a.index = sc.flist; a.count = sc.fcount + 2; }
       a.a1 = A.seqs2; a.a2 = d_cq_ref; a.err = static_cast<int32_t*>(ctx->d_err.p);
       a.match = p.match; a.mismatch = p.mismatch; a.go = p.go; a.ge = p.ge; a.hfree = p.hfree; a.vfree = p.vfree;
       a.qlimit = sub_limit(&p);

@@ -40,6 +40,7 @@ enum : int {
   SC_SWEEP_CELLS, SC_SWEEP_BYTES,  // the combined sweep / prefix launches (TRACYHIP_TIMER_SCORE)
   SC_DECOMP_CELLS, SC_DECOMP_BYTES,
   SC_FRONT_CELLS, SC_FRONT_BYTES,  // the first tier of the pruned sweeps (TRACYHIP_TIMER_FRONT: strips of 8 rows on c* +- 60)
+  SC_ALLELE_SHARED,                // allele 2 reading the prefix row allele 1 keeps (s_allele_plan0_kernel)
   SC_COUNT
 };
 // per band stage (bucket scan): cells and algorithmic bytes of the launch (kernel timers), bytes of its traceback words

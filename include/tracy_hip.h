@@ -117,6 +117,8 @@ int tracyhip_synchronize(tracyhip_ctx* ctx);
      band_w  (half width of the certified band of the final alignments; -1 = from the preliminary alignment, 0 = whole matrices)
      ckpt_b  (steps between wavefront checkpoints, 32 .. 1024)      verbose  (one line per pipeline stage on stderr)
      quad_tier_min  (stream-ordered pipelines: traces / alleles from which a pruned sweep gets its narrow first tier; default 32768)
+     front_list_min (... from which its later tiers, and the allele prefixes of `tracy decompose`, run over device-side lists of the units
+                    that are left instead of skipping the others in place; default 1024)
    Every option selects another EXACT path (A/B measurements, tests of the fallback tiers); none changes a result.  Lanes inherit.
    TRACYHIP_HOST_THREADS, TRACYHIP_HOST_TIMERS, TRACYHIP_LDS_PAD and TRACYHIP_LDS_STAGE_LIMIT are per process (read once).
    tracyhip_describe writes the current settings as "name=value" lines (at most cap - 1 bytes) and returns the length needed. */

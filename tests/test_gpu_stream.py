@@ -64,10 +64,12 @@ def test_align_failing_certificates_fall_back_per_trace(ctx, exact, quads):
     profs, wins = [c[0] for c in cs], [c[1] for c in cs]
     if quads:
         ctx.set_option("quad_tier_min", 0)
+        ctx.set_option("front_list_min", 0)
     try:
         a, sa, b, sb = both_ways(ctx, lambda: ctx.align_traces(profs, wins, SC, 50, 50, exact_scores=exact))
     finally:
         ctx.set_option("quad_tier_min", 32768)
+        ctx.set_option("front_list_min", 1024)
     assert sa["stream_ordered"] == 1, sa
     assert 4 <= sa["fallback_traces"] <= len(cs) - 16, sa  # both outcomes are exercised
     same_align(a, b, exact, "stream vs host-planned")
@@ -179,10 +181,12 @@ def test_decompose_failing_certificates_fall_back_per_trace(ctx, quads):
         refs.append(r)
     if quads:
         ctx.set_option("quad_tier_min", 0)
+        ctx.set_option("front_list_min", 0)
     try:
         a, sa, b, sb = decompose_both_ways(ctx, d, refs, nd)
     finally:
         ctx.set_option("quad_tier_min", 32768)
+        ctx.set_option("front_list_min", 1024)
     assert sa["stream_ordered"] == 1 and 8 <= sa["fallback_traces"] <= nd - 16, sa
     same_decompose(a, b)
     for i in (0, 1, 3, 10, 30):
@@ -230,16 +234,25 @@ def test_quad_tier_of_the_pruned_sweeps_changes_nothing(ctx):
         return a, sa, ctx.decompose_traces([d["profiles"][i] for i in range(nd)], hbc, drefs, SC), ctx.last_call_stats()
     a0, sa0, b0, sb0 = run()
     ctx.set_option("quad_tier_min", 0)
+    ctx.set_option("front_list_min", 0)
     try:
-        assert ctx.describe()["quad_tier_min"] == "0"
+        assert ctx.describe()["quad_tier_min"] == "0" and ctx.describe()["front_list_min"] == "0"
         a1, sa1, b1, sb1 = run()
+        # lists without the quad tier: the last tier's only
+        ctx.set_option("quad_tier_min", 32768)
+        a3, sa3, b3, sb3 = run()
+        ctx.set_option("quad_tier_min", 0)
         # the later tiers over device-side lists of what is left (the default with the quad tier) against skipping in place
         ctx.set_option("no_front_lists", 1)
         assert ctx.describe()["no_front_lists"] == "1"
         a2, sa2, b2, sb2 = run()
     finally:
         ctx.set_option("quad_tier_min", 32768)
+        ctx.set_option("front_list_min", 1024)
         ctx.set_option("no_front_lists", 0)
+    same_align(a3, a0, True, "lists, no quad tier")
+    same_decompose(b3, b0, "lists, no quad tier")
+    assert sb3["allele_shared_prefix"] == sb1["allele_shared_prefix"], (sb1, sb3)
     assert sa1["stream_ordered"] == 1 and sb1["stream_ordered"] == 1
     assert sa1["pruned"] == sa0["pruned"] and sb1["allele_pruned"] == sb0["allele_pruned"], (sa0, sa1, sb0, sb1)
     # (with the lists, the second allele of a trace reads the first one's kept prefix row where both begin with the same 128 characters)

@@ -287,6 +287,12 @@ bool knobs_set(CtxKnobs& k, const char* name, const char* value) {
     k.quad_tier_min = (uint32_t)std::min<long>(v, 0x7fffffffl);
     return true;
   }
+  if (same_name(name, "front_list_min")) {
+    const long v = atol(value);
+    if (v < 0) return false;
+    k.front_list_min = (uint32_t)std::min<long>(v, 0x7fffffffl);
+    return true;
+  }
   if (same_name(name, "ckpt_b")) {
     const long v = atol(value);
     if (v < 32 || v > 1024) return false;
@@ -311,6 +317,7 @@ void knobs_from_env(CtxKnobs& k) {
   if (const char* e = getenv("TRACYHIP_BAND_W")) knobs_set(k, "band_w", e);
   if (const char* e = getenv("TRACYHIP_CKPT_B")) knobs_set(k, "ckpt_b", e);
   if (const char* e = getenv("TRACYHIP_QUAD_TIER_MIN")) knobs_set(k, "quad_tier_min", e);
+  if (const char* e = getenv("TRACYHIP_FRONT_LIST_MIN")) knobs_set(k, "front_list_min", e);
 }
 std::string knobs_describe(const CtxKnobs& k) {
   std::string s;
@@ -318,6 +325,7 @@ std::string knobs_describe(const CtxKnobs& k) {
   s += "band_w=" + std::to_string(k.band_w) + "\n";
   s += "ckpt_b=" + std::to_string(k.ckpt_b) + "\n";
   s += "quad_tier_min=" + std::to_string(k.quad_tier_min) + "\n";
+  s += "front_list_min=" + std::to_string(k.front_list_min) + "\n";
   s += "host_threads=" + std::to_string(host_pool_threads()) + "\n";
   return s;
 }

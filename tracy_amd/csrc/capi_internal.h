@@ -64,6 +64,7 @@ struct CtxKnobs {
   int32_t band_w = -1;            // half width of the certified band of the final alignments: -1 = from the preliminary alignment (default),
                                   // 0 = whole matrices, else [1, 4096]
   uint32_t ckpt_b = 256;
+  uint32_t front_list_min = 1024; // stream-ordered pipelines: units from which the later tiers of a pruned sweep (and the allele prefixes) run over device-side lists
   uint32_t quad_tier_min = 32768;  // stream-ordered pipelines: units (traces, or alleles) from which the pruned sweeps get their narrow quad tier          // steps between wavefront checkpoints [32, 1024]
 };
 void knobs_from_env(CtxKnobs& k);

@@ -702,8 +702,8 @@ __global__ void s_front_fold_kernel(uint32_t n, const FrontOut* __restrict__ fo0
 }
 int front_tiers_run_wide(tracyhip_ctx* ctx, const tracyhip_params& p, StreamCommon& sc, uint32_t n, const int16_t* d_qp, const uint8_t* d_codes,
                          const uint32_t* d_row, uint32_t max_rest, bool after_quads) {
-  // (lists where the launches are long enough to be worth a fourth small one: the batches that get the quad tier)
-  const bool lists = !ctx->knobs.no_front_lists && n >= ctx->knobs.quad_tier_min;
+  // (a list costs one more small launch in the chain: worth it from a few waves per SIMD on)
+  const bool lists = !ctx->knobs.no_front_lists && n >= ctx->knobs.front_list_min;
   if (lists) HIP_TRY(hipMemsetAsync(sc.fcount, 0, 2 * sizeof(uint32_t), ctx->stream));
   const bool list1 = lists && after_quads;
   if (list1) HIP_TRY(front_list(ctx, n, sc.fo0, sc.flist, sc.fcount));
@@ -2010,8 +2010,8 @@ struct DecStream {
     TRY(timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, atab_tot * 2));
     HIP_TRY(launch_b16_tables(A.atd, 2 * nt, A.seqs2, true, p.match, p.mismatch, sub_limit(&p), kTagShift, const_cast<int16_t*>(d_aqp), static_cast<int32_t*>(ctx->d_err.p), st));
     TRY(timing_end(ctx));
-    // (shared kept rows leave holes in the prefix launch: its pairs as a list, as for the later tiers -- batches of quad_tier_min units and more)
-    const bool share = !kn.no_front_lists && 2 * nt >= kn.quad_tier_min;
+    // (shared kept rows leave holes in the prefix launch: its pairs as a list, as for the later tiers)
+    const bool share = !kn.no_front_lists && 2 * nt >= kn.front_list_min;
     hipLaunchKernelGGL(s_allele_plan0_kernel, g256x2, b256, 0, st, spm, spd, sc.geom, A.geomd, sc.tr, sc.dead, sc.pre, sc.fd, static_cast<const uint8_t*>(A.seqs2),
                        share ? 1 : 0, sc.cnt);
     HIP_TRY(hipGetLastError());

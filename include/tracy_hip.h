@@ -113,7 +113,7 @@ int tracyhip_synchronize(tracyhip_ctx* ctx);
 /* Options.  Every switch of the library is read from the environment ONCE, when a context is created (TRACYHIP_<NAME>, e.g.
    TRACYHIP_NO_STREAM=1), and changed afterwards only through this call; name is the variable without the prefix, in any case:
      no_stream (pipelines planned by the host between launches instead of stream-ordered), no_narrow, no_compact, no_screen,
-     no_band, no_band16, no_front, no_prefix, no_vote, no_origin, no_subwindow, no_prelim_origin, no_cq, no_fused_walk, no_cont16, no_quads, no_fork, no_decomp_wave, no_af_split, no_front_lists   "0" / "1"
+     no_band, no_band16, no_front, no_prefix, no_vote, no_origin, no_subwindow, no_prelim_origin, no_cq, no_fused_walk, no_cont16, no_quads, no_fork, no_decomp_wave, no_af_split, no_front_lists, no_origin_band   "0" / "1"
      band_w  (half width of the certified band of the final alignments; -1 = from the preliminary alignment, 0 = whole matrices)
      ckpt_b  (steps between wavefront checkpoints, 32 .. 1024)      verbose  (one line per pipeline stage on stderr)
      quad_tier_min  (stream-ordered pipelines: traces / alleles from which a pruned sweep gets its narrow first tier; default 32768)

@@ -265,7 +265,7 @@ def test_quad_tier_of_the_pruned_sweeps_changes_nothing(ctx):
     same_decompose(b2, b0, "quad tier, tiers in place")
 
 
-@pytest.mark.parametrize("option", ["no_quads", "no_fork"])
+@pytest.mark.parametrize("option", ["no_quads", "no_fork", "no_origin_band"])
 def test_quad_form_and_side_streams_change_nothing(ctx, option):
     """narrow bands four lanes to a pair (band16.h, P = 4) and the stages that run side by side on the context's side streams (the two
     strands of the orientation stage, the lists of a band stage, allelicFraction beside the allele stages) are ways of running the same
@@ -296,3 +296,37 @@ def test_quad_form_and_side_streams_change_nothing(ctx, option):
     assert sa1["final_banded"] == sa0["final_banded"] and sb1["allele_banded"] == sb0["allele_banded"]
     same_align(a1, a0, True, option)
     same_decompose(b1, b0, option)
+
+
+@pytest.mark.parametrize("seed", [9001, 9002, 9003])
+def test_decompose_low_complexity_windows_walk_the_reference_path(ctx, seed):
+    """windows of short tandem repeats: gaps that can sit anywhere in a run, alignments that can start a repeat unit earlier -- co-optimal
+    paths everywhere.  gotoh(allele, slice) runs on the g + 3 diagonals that hold the path the origin sweep followed (the one the
+    reference's traceback walks), not on the 2 g + 3 of every co-optimal path: the strings must be the oracle's (indigo.h:355-387),
+    the host-planned pipeline's, and those of the wide band (option no_origin_band)"""
+    from indigo_oracle import decompose_trace
+    from tracy_amd import hostlib
+    nd = 96
+    d = hostlib.synth_decompose_batch(seed, nd, 2400, 800, 0, mix=2)
+    refs = [d["refs"][i].tobytes() for i in range(nd)]
+    a, sa, b, sb = decompose_both_ways(ctx, d, refs, nd)
+    assert sa["stream_ordered"] == 1, sa
+    ctx.set_option("no_origin_band", 1)
+    try:
+        c, sc_, _, _ = decompose_both_ways(ctx, d, refs, nd)
+    finally:
+        ctx.set_option("no_origin_band", 0)
+    same_decompose(a, b, "stream vs host-planned")
+    same_decompose(a, c, "path band vs every co-optimal path's band")
+    # enough traces must have gone through the band stages on the device for the comparison to mean something
+    assert sa["allele_banded"][0] - sa["fallback_traces"] >= nd // 3, sa
+    checked = 0
+    for i in range(nd):
+        want = decompose_trace(d["signal"][i], d["bcpos"][i], d["primary"][i].tobytes(), d["secondary"][i].tobytes(), refs[i], SC)
+        assert int(a["status"][i]) == want["status"], i
+        if want["status"] != 0:
+            continue
+        checked += 1
+        assert a["btr0"][i] == want["btr0"] and a["btr1"][i] == want["btr1"] and a["btr2"][i] == want["btr2"], i
+        assert a["primary"][i] == want["primary"] and a["secondary"][i] == want["secondary"], i
+    assert checked >= nd // 4, checked

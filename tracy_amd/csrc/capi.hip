@@ -265,7 +265,7 @@ const KnobField kKnobFlags[] = {
     {"no_screen", &CtxKnobs::no_screen}, {"no_band", &CtxKnobs::no_band}, {"no_band16", &CtxKnobs::no_band16},
     {"no_front", &CtxKnobs::no_front}, {"no_prefix", &CtxKnobs::no_prefix}, {"no_vote", &CtxKnobs::no_vote},
     {"no_origin", &CtxKnobs::no_origin}, {"no_subwindow", &CtxKnobs::no_subwindow}, {"no_prelim_origin", &CtxKnobs::no_prelim_origin},
-    {"no_cq", &CtxKnobs::no_cq}, {"no_fused_walk", &CtxKnobs::no_fused_walk}, {"no_cont16", &CtxKnobs::no_cont16}, {"no_decomp_wave", &CtxKnobs::no_decomp_wave}, {"no_af_split", &CtxKnobs::no_af_split}, {"no_front_lists", &CtxKnobs::no_front_lists}, {"no_quads", &CtxKnobs::no_quads}, {"no_fork", &CtxKnobs::no_fork}, {"verbose", &CtxKnobs::verbose}};
+    {"no_cq", &CtxKnobs::no_cq}, {"no_fused_walk", &CtxKnobs::no_fused_walk}, {"no_cont16", &CtxKnobs::no_cont16}, {"no_decomp_wave", &CtxKnobs::no_decomp_wave}, {"no_af_split", &CtxKnobs::no_af_split}, {"no_front_lists", &CtxKnobs::no_front_lists}, {"no_origin_band", &CtxKnobs::no_origin_band}, {"no_quads", &CtxKnobs::no_quads}, {"no_fork", &CtxKnobs::no_fork}, {"verbose", &CtxKnobs::verbose}};
 bool same_name(const char* a, const char* b) {
   for (; *a && *b; ++a, ++b)
     if (std::tolower((unsigned char)*a) != std::tolower((unsigned char)*b)) return false;

@@ -1405,7 +1405,7 @@ __global__ void s_allele_plan1_kernel(SParams p, SParamsD pd, const SGeom* __res
 // trimReferenceSlice (indigo.h:360) from the two ends; gotoh(allele, trimmed slice) (indigo.h:365) on the band around its known end (pipeline.hip 6.f)
 __global__ void s_allele_plan2_kernel(SParams p, const SGeom* __restrict__ geom, const SGeomD* __restrict__ geomd, const STrace* __restrict__ tr,
                                       const uint32_t* __restrict__ ends, SAllele* __restrict__ al, uint32_t* __restrict__ dead, PairDesc* __restrict__ cand,
-                                      uint8_t* __restrict__ kc, unsigned long long* __restrict__ cnt) {
+                                      uint8_t* __restrict__ kc, int narrow_by_origin, unsigned long long* __restrict__ cnt) {
   with_counters(cnt, [&](unsigned long long* lc) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= 2u * p.nt) return;
@@ -1428,6 +1428,21 @@ __global__ void s_allele_plan2_kernel(SParams p, const SGeom* __restrict__ geom,
     const int32_t d1 = (int32_t)ce - (int32_t)m;
     dlo = d1 - (int32_t)gg - 1;
     dhi = d1 + (int32_t)gg + 1;
+    // The origin sweep followed the very path the traceback will walk (the same predecessor at every maximum): it starts at row 0 in
+    // column `lead` of the window, i.e. on diagonal d0 of the slice, and ends on d1.  With v vertical and h horizontal gap steps,
+    // h - v = d1 - d0 and h + v <= g, so the path stays on [min(d0, d1) - s, max(d0, d1) + s], s = (g - |d1 - d0|) / 2 -- and a band
+    // that holds THIS path reproduces its walk: every cell of the path keeps its value (its own prefix is inside), every other value
+    // is a lower bound, so whatever lost a comparison in the full matrix loses it in the band, and what won or tied with preference
+    // is on the path.  (The other co-optimal paths, which d1 +- g would hold as well, are never walked.)  g + 3 diagonals instead of 2 g + 3.
+    if (narrow_by_origin && lead >= A.trim.ri) {
+      const int32_t d0 = (int32_t)(lead - A.trim.ri);
+      const int64_t delta = d1 > d0 ? (int64_t)d1 - d0 : (int64_t)d0 - d1;
+      if (delta <= gg) {
+        const int32_t sdev = (int32_t)((gg - delta) / 2);
+        dlo = (d0 < d1 ? d0 : d1) - sdev - 1;
+        dhi = (d0 < d1 ? d1 : d0) + sdev + 1;
+      }
+    }
     K = b16_pick_k(dlo, dhi);
   }
   if (K && !s_fits_lds(n, K)) K = 0;
@@ -2048,7 +2063,7 @@ struct DecStream {
     BandLaunch b1;
     b1.kind = 1; b1.qp = d_aqp; b1.codes = d_cq_ref; b1.ends = sc.ends; b1.code_cap = ncap; b1.hfree = 1;
     TRY(band_stage(ctx, p, sc, 2 * nt, nt, 1, b1, ~0ull));
-    hipLaunchKernelGGL(s_allele_plan2_kernel, g256x2, b256, 0, st, spm, sc.geom, A.geomd, sc.tr, sc.ends, A.al, sc.dead, sc.cand, sc.kc, sc.cnt);
+    hipLaunchKernelGGL(s_allele_plan2_kernel, g256x2, b256, 0, st, spm, sc.geom, A.geomd, sc.tr, sc.ends, A.al, sc.dead, sc.cand, sc.kc, kn.no_origin_band ? 0 : 1, sc.cnt);
     HIP_TRY(hipGetLastError());
     BandLaunch b2;
     b2.kind = 0; b2.qp = d_aqp; b2.codes = d_cq_ref; b2.scores = A.ascore; b2.ops = d_opsK[0]; b2.ops_off = A.aops_off; b2.ops_len = A.alen; b2.code_cap = ncap; b2.hfree = 1;

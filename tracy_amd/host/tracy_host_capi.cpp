@@ -459,7 +459,7 @@ void tracyhost_synth_align(uint64_t seed0, uint32_t ntraces, uint32_t n, uint32_
 // mf bases copied from it (forward strand), allele 2 = allele 1 with one heterozygous indel (length
 // U[1,maxlen], insertion or deletion) at a position U[150, mf-300] plus 0.5 % heterozygous SNVs; the two
 // alleles are mixed frac1 : 1-frac1 in the chromatogram.  kind & 3: 0 = het indel, 1 = het SNVs only (no indel), 2 = homozygous
-// indel only (both alleles carry it, no het SNVs), 3 = no variant at all.  kind & 16: the window handed out is the reverse
+// indel only (both alleles carry it, no het SNVs), 3 = no variant at all.  kind & 32: a low-complexity window.  kind & 16: the window handed out is the reverse
 // complement of the one the trace was copied from (the trace reads the reverse strand of its reference).
 // Outputs: ref[n]; signal[4][12*(mf+40)+12] (zero padded), basecallpos[npos]; returns npos.
 uint32_t tracyhost_synth_decompose(uint64_t seed, uint32_t n, uint32_t mf, uint32_t maxlen, int kind, double frac1,
@@ -467,7 +467,17 @@ uint32_t tracyhost_synth_decompose(uint64_t seed, uint32_t n, uint32_t mf, uint3
                                    int32_t* indel_out) {
   SplitMix64 rng(seed);
   std::string ref(n, 'A');
-  for (uint32_t i = 0; i < n; ++i) ref[i] = kBases[rng.below(4)];
+  if (kind & 32) {  // low complexity: short units repeated a few times -- alignments with many co-optimal paths (gaps that can sit anywhere in a run)
+    for (uint32_t i = 0; i < n;) {
+      char unit[6];
+      const uint32_t ul = 1 + rng.below(6), reps = 1 + rng.below(ul == 1 ? 8 : 5);
+      for (uint32_t u = 0; u < ul; ++u) unit[u] = kBases[rng.below(4)];
+      for (uint32_t r = 0; r < reps && i < n; ++r)
+        for (uint32_t u = 0; u < ul && i < n; ++u) ref[i++] = unit[u];
+    }
+  } else {
+    for (uint32_t i = 0; i < n; ++i) ref[i] = kBases[rng.below(4)];
+  }
   const uint32_t start = (n > mf + 200) ? 100 + rng.below(n - mf - 200) : 0;
   std::string a1 = ref.substr(start, mf + 40);
   std::string a2 = a1;
@@ -516,7 +526,7 @@ uint32_t tracyhost_synth_decompose(uint64_t seed, uint32_t n, uint32_t mf, uint3
 // ns = 12*mf+12; bcpos / primary / secondary [nt][mf]; profiles [nt][6][mf].
 // mix 0: the round-1 batch above (all forward strand).  mix 1: BASELINE configs[2] as SURVEY.md 8d words it -- trace i with
 // i % 10 == 8 carries a homozygous indel only, i % 10 == 9 no variant, the rest one het indel + 0.5 % het SNVs; odd traces
-// read the reverse strand of their window.
+// read the reverse strand of their window.  mix 2: mix 1 in low-complexity windows (short tandem repeats: co-optimal alignments everywhere).
 static void synth_decompose_batch_mix(uint64_t seed0, uint32_t nt, uint32_t n, uint32_t mf, uint8_t* refs, int32_t* signal,
                                       int32_t* bcpos, uint8_t* primary, uint8_t* secondary, float* profiles, uint32_t nthreads, int mix);
 void tracyhost_synth_decompose_batch(uint64_t seed0, uint32_t nt, uint32_t n, uint32_t mf, uint8_t* refs, int32_t* signal,
@@ -539,7 +549,8 @@ static void synth_decompose_batch_mix(uint64_t seed0, uint32_t nt, uint32_t n, u
         int32_t indel = 0;
         int32_t* sig = signal + (size_t)i * 4 * ns;
         int kind = (i % 5 == 4) ? 1 : 0;
-        if (mix == 1) kind = ((i % 10 == 8) ? 2 : (i % 10 == 9) ? 3 : 0) | ((i & 1) ? 16 : 0);
+        if (mix >= 1) kind = ((i % 10 == 8) ? 2 : (i % 10 == 9) ? 3 : 0) | ((i & 1) ? 16 : 0);
+        if (mix == 2) kind |= 32;  // ... in low-complexity windows
         const uint32_t npos = tracyhost_synth_decompose(seed, n, mf, 30, kind, 0.6, refs + (size_t)i * n, sig, ns,
                                                         pos.data(), &indel);
         Trace tr;

@@ -22,7 +22,7 @@ namespace {
 template <int K, int MODE, bool TRACE, bool NEEDLE, bool NARROW = false, bool COMPACT = false>
 void run_wave(const DpArgs& a) {
   WaveShared sh;
-  sh.lds.assign((qp_like(MODE) ? lds_bytes(MODE_QP, K) : needle_lds_bytes(MODE_PROF, K)) + 64, 0);
+  sh.lds.assign((qp_like(MODE) ? std::max(lds_bytes(MODE_QP, K), lds_bytes_sweep16(K, false)) : needle_lds_bytes(MODE_PROF, K)) + 64, 0);
   sh.run([&](uint32_t l) {
     HostWave w{l, &sh};
     if constexpr (NEEDLE) {
@@ -60,7 +60,7 @@ template <int K, int MODE, bool NARROW>
 void run_ckpt_pair(const DpArgs& a, const WalkArgs& wa) {
   for (int form = 0; form < ((NARROW && MODE == MODE_QP) ? 2 : 1); ++form) {  // checkpointed score pass (both forms of the 16-bit sweep)
     WaveShared sh;
-    sh.lds.assign(lds_bytes(MODE_QP, K) + 64, 0);
+    sh.lds.assign(std::max(lds_bytes(MODE_QP, K), lds_bytes_sweep16(K, false)) + 64, 0);
     sh.run([&](uint32_t l) {
         HostWave w{l, &sh};
         if (form == 0) gotoh_body<HostWave, K, MODE, false, NARROW, true, 0, NARROW && MODE == MODE_QP>(w, a, 0);

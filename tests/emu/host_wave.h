@@ -72,6 +72,13 @@ struct HostWave {
     sh->bar.arrive_and_wait();
     return r;
   }
+  int32_t shift_up_row(int32_t x) {  // the same inside a row of sixteen lanes (DPP row_shr:1): the first lane of a row gets 0
+    sh->xchg[lane_] = x;
+    sh->bar.arrive_and_wait();
+    int32_t r = (lane_ & 15u) ? sh->xchg[lane_ - 1] : 0;
+    sh->bar.arrive_and_wait();
+    return r;
+  }
   int32_t shift_up_or(int32_t x, int32_t first) {  // as shift_up, lane 0 keeps `first` (the DPP `old` operand)
     const int32_t r = shift_up(x);
     return lane_ ? r : first;

@@ -181,8 +181,6 @@ struct SubChar {
   TR_HD int32_t lo16(int i) const { return rc[i] == cc ? vmatch : vmis; }
 };
 
-// per-lane strips of the prefix-bound kernel (qp_lane / qp_fetch): K rounded up to an even count of int16 (packed dword reads)
-TR_HD constexpr int qp_stride(int K) { return (K + 1) & ~1; }
 // query-profile table of the sweeps and tracebacks: int16 [codes][K rows][64 lanes] -- a row's 64 lanes are contiguous, so a
 // wave's 16-bit reads of one row hit every bank once when the lanes agree on the code (a per-lane strip layout costs an 8-way
 // bank conflict on each of them).  Codes 0..4 = A C G T N, 5 = '-' / any other letter; kernels that know their columns hold
@@ -190,16 +188,6 @@ TR_HD constexpr int qp_stride(int K) { return (K + 1) & ~1; }
 template <int K>
 TR_HD uint32_t qp6_index(uint32_t code, uint32_t row, uint32_t lane) { return (code * (uint32_t)K + row) * 64u + lane; }
 
-// packed strip: the K int16 query-profile values of a lane for one column, as loaded from LDS (ping-pong
-// buffers hold the strips of the current and the next column)
-template <int K>
-struct SubPacked {
-  uint32_t pw[(K + 1) / 2];
-  TR_HD int32_t operator()(int i) const {
-    return (i & 1) ? ((int32_t)pw[i / 2] >> 16) : (int32_t)(int16_t)(pw[i / 2] & 0xffffu);
-  }
-  TR_HD int32_t lo16(int i) const { return (i & 1) ? ((int32_t)pw[i / 2] >> 16) : (int32_t)pw[i / 2]; }
-};
 // A strip read row by row from the [code][row][lane] table (qp6_index): one sign-extending 16-bit LDS read per row gives an
 // operand that needs no unpacking.  SHIFT: applied when a value is used (the origin-tracking sweep keeps scores << 18).
 template <int K, int SHIFT = 0>
@@ -213,28 +201,6 @@ TR_HD void qp_fetch_rows(const int16_t* lane_col, uint32_t code, SubRows<K, SHIF
   const int16_t* p = lane_col + code * ((uint32_t)K * 64u);
 #pragma unroll
   for (int i = 0; i < K; ++i) q.sv[i] = p[i * 64];
-}
-
-// strip pointers of one lane into the query-profile table: row `code` of the lane's strip for codes < 5, the shared
-// all-zero-column strip for the rest (the LDS base address is folded into both, once per pass)
-struct QpLane {
-  const char* strip;
-  const char* zero;
-};
-// NCODES code rows (5: A C G T N; 4 where no column holds an N), then the zero strip
-template <int K, uint32_t NCODES = 5>
-TR_HD QpLane qp_lane(const int16_t* tab, uint32_t lane) {
-  constexpr uint32_t KP = qp_stride(K);
-  const char* t = reinterpret_cast<const char*>(tab);
-  return QpLane{t + lane * (KP * 2u), t + NCODES * (64u * KP * 2u)};
-}
-TR_HD constexpr uint32_t lds_bytes_prefix(int K, bool compact) { return (compact ? 4u : 5u) * 64u * (uint32_t)qp_stride(K) * 2u + (uint32_t)qp_stride(K) * 2u; }
-template <int K, uint32_t NCODES = 5>
-TR_HD void qp_fetch(const QpLane& ql, uint32_t code, SubPacked<K>& q) {
-  constexpr uint32_t KP = qp_stride(K);
-  const uint32_t* p = reinterpret_cast<const uint32_t*>((code < NCODES) ? ql.strip + code * (64u * KP * 2u) : ql.zero);
-#pragma unroll
-  for (int j = 0; j < (int)KP / 2; ++j) q.pw[j] = p[j];
 }
 
 // profile x profile: the profile columns of this lane's K rows live in registers for the whole pass, the column
@@ -781,12 +747,22 @@ struct QpStrip {
   uint32_t v[K];  // row i in the low half (16-bit LDS reads zero the high half; the 16-bit ops ignore it)
   TR_HD int32_t lo16(int i) const { return (int32_t)v[i]; }
 };
-// The sweep's own table: int16 [NC codes][K rows][64 lanes].  NC = 6 (A C G T N, '-' / other) is 11.3 KB at K = 15; references
-// that hold A C G T only -- almost all of them -- take the COMPACT form of the kernel with NC = 4: 7.5 KB.  The table is
-// what decides how many waves a CU holds (LDS, not registers, is the limit), and this kernel needs them: one wave issues a
-// VALU instruction every ~4.5 cycles, a SIMD takes one every 2 (tools/ubench/clock_probe.hip).  13 -> 20 workgroups per CU:
-// 32.4 -> 28.2 ms per launch.
-TR_HD constexpr uint32_t lds_bytes_sweep16(int K, bool compact) { return (compact ? 4u : 6u) * (uint32_t)K * 64u * 2u; }
+// The sweep's own table: int16 entries at byte (row / 2) * (NC * 256) + code * 256 + (row % 2) * 128 + 2 * lane column.  A code is
+// byte 1 of the address, so the address of a column's strip is ONE v_perm_b32 of the dword of codes and the lane's own byte
+// (strip_of below) instead of a v_bfe + v_mad per step; the rows of the strip are immediate offsets of the reads.  NC = 6 (A C G T N,
+// '-' / other) is 12 KB at K = 15; references that hold A C G T only -- almost all of them -- take the COMPACT form of the kernel
+// with NC = 4: 8 KB.  The table is what decides how many waves a CU holds, and this kernel needs them: one wave issues a VALU
+// instruction every ~4.5 cycles, a SIMD takes one every 2 (tools/ubench/clock_probe.hip); 13 -> 20 workgroups per CU was 32.4 ->
+// 28.2 ms per launch.  Measured (round 5, one box, tools/ab.sh): the [code][row][lane] layout of 7.5 KB holds twenty workgroups on a
+// CU, this one nineteen (twenty times 8 KB is the whole LDS and does not fit) -- 5 120 pairs 8.4 -> 9.4 ms, but 20 480 pairs 30.1 ->
+// 29.0 ms and the `tracy align` step 19.8 -> 19.4 ms: the instruction saved counts for more than the twentieth workgroup.
+TR_HD constexpr uint32_t lds_bytes_sweep16(int K, bool compact) { return (compact ? 4u : 6u) * 256u * (uint32_t)((K + 1) / 2); }
+// (the prefix rows of the pruned sweeps, gotoh_prefix_body, lay their table out the same way)
+TR_HD constexpr uint32_t lds_bytes_prefix(int K, bool compact) { return lds_bytes_sweep16(K, compact); }
+template <int NC>
+TR_HD constexpr uint32_t qp16_row_byte(uint32_t row) { return (row >> 1) * ((uint32_t)NC * 256u) + (row & 1u) * 128u; }
+template <int NC>
+TR_HD uint32_t qp16_byte(uint32_t code, uint32_t row, uint32_t lanecol) { return qp16_row_byte<NC>(row) + code * 256u + 2u * lanecol; }
 // does the reference of this pair hold N / '-' / other codes?  (special_blocks: one byte per 256 code bytes.)  Wave-uniform.
 template <class W>
 TR_HD bool reference_is_plain(W& w, const DpArgs& a, const PairDesc& d) {
@@ -797,19 +773,22 @@ TR_HD bool reference_is_plain(W& w, const DpArgs& a, const PairDesc& d) {
   for (uint64_t b = first + w.lane(); b <= last; b += 64) seen |= a.special_blocks[b];
   return w.ballot(seen != 0) == 0;
 }
-template <int K>
-TR_HD void qp_fetch6(const char* lane_col, uint32_t code, QpStrip<K>& q) {
-  const char* p = lane_col + code * ((uint32_t)K * 64u * 2u);
+// `addr`: byte address of the strip's first row (code * 256 + the lane's byte; on the device an LDS address, on the host an offset
+// into `tab`)
+template <int K, int NC>
+TR_HD void qp_fetch6(const char* tab, uint32_t addr, QpStrip<K>& q) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // Every LDS read of the sweep is issued by hand and waited for by hand (qp_wait6): one 16-bit read per row, so that no
   // cell needs its operand shifted into place (VALU work, which is what this kernel is short of), and no compiler
   // wait-count bookkeeping that would stall each step on the strip that was only just requested.
-  const uint32_t lds_addr = (uint32_t)reinterpret_cast<uintptr_t>(p);  // low half of the flat address = LDS byte address
 #pragma unroll
-  for (int i = 0; i < K; ++i) asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(q.v[i]) : "v"(lds_addr), "n"(i * 128));
+  for (int i = 0; i < K; ++i) asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(q.v[i]) : "v"(addr), "n"(qp16_row_byte<NC>((uint32_t)i)));
 #else
-  const uint16_t* ph = reinterpret_cast<const uint16_t*>(p);
-  for (int i = 0; i < K; ++i) q.v[i] = ph[i * 64];
+  for (int i = 0; i < K; ++i) {
+    uint16_t x;
+    __builtin_memcpy(&x, tab + addr + qp16_row_byte<NC>((uint32_t)i), 2);
+    q.v[i] = x;
+  }
 #endif
 }
 // Before a strip is used: LDS operations complete in order, so once at most the K reads of the NEXT strip (issued after
@@ -852,6 +831,7 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   const float* a1p = static_cast<const float*>(a.a1) + (STRINGS ? 0 : d.a1_off);
   const uint8_t* a1c = static_cast<const uint8_t*>(a.a1) + (STRINGS ? d.a1_off : 0);
   const uint8_t* a2c = static_cast<const uint8_t*>(a.a2) + d.a2_off;
+  constexpr int NC = COMPACT ? 4 : 6;
   int16_t* qp_tab = reinterpret_cast<int16_t*>(w.lds());
   const float fmatch = (float)a.match, fmis = (float)a.mismatch;
   const uint32_t lanes_used = (m + K - 1) / K;
@@ -875,7 +855,7 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   asm volatile("" : "+v"(gev), "+v"(goev), "+v"(hext_last), "+v"(delta_last));  // four live VGPRs for the whole sweep, not re-materialised per step
 #endif
 
-  // ---- query profile: int16 [NC][K][64 lanes] (qp6_index), entry = (int)(sum_k p[k][row] w[k][b]) - goe for b = A C G T (N);
+  // ---- query profile (qp16_byte), entry = (int)(sum_k p[k][row] w[k][b]) - goe for b = A C G T (N);
   // code 5 ('-' / other) and rows off the trace score 0 ----
   // Lane L's column of a row is 2 (L mod 32) + L / 32: a 16-bit read is served in two groups of 32 lanes, and with the lanes in order
   // lanes 2 j and 2 j + 1 share a dword -- a bank -- while they usually ask for different CODES (different dwords of that bank): every
@@ -903,9 +883,9 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
         overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
         qabs = imax(qabs, q < 0 ? -q : q);
         const uint32_t row = (rcflag && b < 4u) ? 3u - b : b;  // reverse-complement view: the complement is folded into the table
-        qp_tab[qp6_index<K>(row, (uint32_t)i, Lc)] = (int16_t)qs;
+        qp_tab[qp16_byte<NC>(row, (uint32_t)i, Lc) >> 1] = (int16_t)qs;
       }
-      if (!COMPACT) qp_tab[qp6_index<K>(5u, (uint32_t)i, Lc)] = (int16_t)(((STRINGS && real) ? a.mismatch : 0) - goe);
+      if (!COMPACT) qp_tab[qp16_byte<NC>(5u, (uint32_t)i, Lc) >> 1] = (int16_t)(((STRINGS && real) ? a.mismatch : 0) - goe);
     }
     if (overflow) flag_error(a.err, 1);
     if (!STRINGS && qabs > a.qlimit) flag_max(a.err, 1, qabs);
@@ -913,7 +893,14 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
   }
 
   // ---- sweep ----
-  const char* strip = reinterpret_cast<const char*>(qp_tab) + Lc * 2u;  // this lane's column of the table
+  // the strip of a column: byte 1 of its address is the column's code, byte 0 this lane's column of the table
+  const char* tabc = reinterpret_cast<const char*>(qp_tab);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t lane_addr = (uint32_t)reinterpret_cast<uintptr_t>(tabc) + Lc * 2u;  // low half of the flat address = LDS byte address
+  if ((lane_addr >> 8) & 0xffu) flag_error(a.err, 1);  // (the table starts the workgroup's LDS: byte 1 is free for the code)
+#else
+  const uint32_t lane_addr = Lc * 2u;
+#endif
   const uint8_t* a2v = a2c - kCodeBias;
   const int32_t lane_base = (int32_t)kCodeBias + (rcflag ? (int32_t)n + (int32_t)L : -(int32_t)L - 1);
   const int32_t dir = rcflag ? -1 : 1;
@@ -925,6 +912,9 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     const uint32_t tr = d.out % a.vote_nt;
     keep = !vote_skips_checkpoints(a.votes[2 * tr], a.votes[2 * tr + 1], d.out / a.vote_nt);
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  keep = __builtin_amdgcn_readfirstlane((int)keep) != 0;  // (a scalar: the steps branch on it)
+#endif
   uint32_t ck_left = B;                                         // steps until the next wavefront checkpoint (wave-uniform)
   int32_t* ck_next = CKPT ? a.ckpt + d.ckpt_off + L : nullptr;   // its record
   int32_t f = 0;
@@ -964,17 +954,24 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
 #pragma unroll
         for (int i = 0; i < K; ++i) { cell_down16(Hl[i], El[i], uh, f, gev, goev); uh = Hl[i]; }
       }
-      if (CKPT) row_m = ((uint32_t)El[K - 1] << 16) | ((uint32_t)Hl[K - 1] & 0xffffu);
-      if (CKPT && GUARD && lastlane && keep)  // ramp phases: row m column by column (the steady state stores four columns at once)
-        *reinterpret_cast<uint32_t*>(lrb + (uint32_t)(4 * (int32_t)t + lr_lane)) = row_m;
     }
-    if (CKPT && keep && t <= t_end && --ck_left == 0) {  // wavefront checkpoint every B steps: the whole frontier (raw registers), one coalesced store per field
-      ck_left = B;
-      int32_t* ck = ck_next;
-      ck_next += ckpt_fields_qp16(K) * 64u;
+    // a sweep that keeps nothing (the likely losing strand of a checkpointed launch) skips the row-m pack and the checkpoint test
+    // behind ONE wave-uniform branch: VALU issue is what the kernel is short of, a scalar branch is not
+    if (CKPT && keep) {
+      TRACY_KEEP_BRANCH();
+      if (active) {
+        row_m = ((uint32_t)El[K - 1] << 16) | ((uint32_t)Hl[K - 1] & 0xffffu);
+        if (GUARD && lastlane)  // ramp phases: row m column by column (the steady state stores four columns at once)
+          *reinterpret_cast<uint32_t*>(lrb + (uint32_t)(4 * (int32_t)t + lr_lane)) = row_m;
+      }
+      if (t <= t_end && --ck_left == 0) {  // wavefront checkpoint every B steps: the whole frontier (raw registers), one coalesced store per field
+        ck_left = B;
+        int32_t* ck = ck_next;
+        ck_next += ckpt_fields_qp16(K) * 64u;
 #pragma unroll
-      for (int i = 0; i < K; ++i) ck[(uint32_t)i * 64u] = (int32_t)(((uint32_t)El[i] << 16) | ((uint32_t)Hl[i] & 0xffffu));
-      ck[(uint32_t)K * 64u] = (int32_t)(((uint32_t)f << 16) | ((uint32_t)up_cur & 0xffffu));
+        for (int i = 0; i < K; ++i) ck[(uint32_t)i * 64u] = (int32_t)(((uint32_t)El[i] << 16) | ((uint32_t)Hl[i] & 0xffffu));
+        ck[(uint32_t)K * 64u] = (int32_t)(((uint32_t)f << 16) | ((uint32_t)up_cur & 0xffffu));
+      }
     }
   };
   using Guarded = SweepGuard<true>;
@@ -1018,22 +1015,37 @@ TR_HD void gotoh_narrow_qp_body(W& w, const DpArgs& a, uint32_t pair_idx) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory");  // "memory": the stores below stay below
 #endif
   };
-  const uint32_t sh0 = rcflag ? 24u : 0u, sh1 = rcflag ? 16u : 8u, sh2 = rcflag ? 8u : 16u, sh3 = rcflag ? 0u : 24u;
+  // byte j of a round's dword (forward) or byte 3 - j (reverse-complement view) is the code of its step j: a wave-uniform selector
+  // v_perm_b32 {lane_addr.b3, lane_addr.b2, codes.b[k], lane_addr.b0}
+  const uint32_t sel0 = 0x03020400u + ((rcflag ? 3u : 0u) << 8), sel1 = 0x03020400u + ((rcflag ? 2u : 1u) << 8),
+                 sel2 = 0x03020400u + ((rcflag ? 1u : 2u) << 8), sel3 = 0x03020400u + ((rcflag ? 0u : 3u) << 8);
+  auto strip_of = [&](uint32_t codes, uint32_t sel) -> uint32_t {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(codes, lane_addr, sel);
+#else
+    return (((codes >> (8u * (((sel >> 8) & 0xffu) - 4u))) & 0xffu) << 8) | lane_addr;
+#endif
+  };
   uint32_t t = 1;
   uint32_t cw_cur = codes_at(1), cw_next = codes_at(5), cw_pend = 0;
   QpStrip<K> qa, qb;
-  qp_fetch6<K>(strip, (cw_cur >> sh0) & 0xffu, qa);
+  qp_fetch6<K, NC>(tabc, strip_of(cw_cur, sel0), qa);
   auto four_steps = [&](auto guard) {
     constexpr bool GUARD = decltype(guard)::value;
     codes_request(t + 8, cw_pend);
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r0, r1, r2, r3;  // (written and read by sweeps that keep row m only: no initialising moves in the loop of the others)
+    asm volatile("" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3));
+#else
     uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-    qp_fetch6<K>(strip, (cw_cur >> sh1) & 0xffu, qb);
+#endif
+    qp_fetch6<K, NC>(tabc, strip_of(cw_cur, sel1), qb);
     step(guard, t, qa, upA, upB, r0);
-    qp_fetch6<K>(strip, (cw_cur >> sh2) & 0xffu, qa);
+    qp_fetch6<K, NC>(tabc, strip_of(cw_cur, sel2), qa);
     step(guard, t + 1, qb, upB, upA, r1);
-    qp_fetch6<K>(strip, (cw_cur >> sh3) & 0xffu, qb);
+    qp_fetch6<K, NC>(tabc, strip_of(cw_cur, sel3), qb);
     step(guard, t + 2, qa, upA, upB, r2);
-    qp_fetch6<K>(strip, (cw_next >> sh0) & 0xffu, qa);
+    qp_fetch6<K, NC>(tabc, strip_of(cw_next, sel0), qa);
     step(guard, t + 3, qb, upB, upA, r3);
     codes_arrived(cw_pend);
     if (CKPT && !GUARD && lastlane && keep) {  // {H, E'} of row m for the band traceback: one int16 pair per column, four columns per store
@@ -1283,143 +1295,228 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
   int16_t* qp_tab = reinterpret_cast<int16_t*>(w.lds());
   constexpr uint32_t R = (uint32_t)GL * K;
 
-  // wave-uniform sweep length: the longest reference of the groups in this wave
-  uint32_t nmax = 0;
+  // wave-uniform sweep length: the longest reference of the groups in this wave; nmin: the shortest of the groups that have a pair
+  uint32_t nmax = 0, nmin = 0xffffffffu;
   for (uint32_t g = 0; g < 64u / GL; ++g) {
-    const uint32_t ng = w.bcast(n, g * GL);
+    const uint32_t ng = w.bcast(n, g * GL), vg = w.bcast(valid ? 1u : 0u, g * GL);
     nmax = ng > nmax ? ng : nmax;
+    if (vg) nmin = ng < nmin ? ng : nmin;
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);  // (wave-uniform: the loops below are scalar loops)
+  nmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmin);
+#endif
   const uint32_t t_end = nmax + GL - 1;
 
-  // per-lane state at column 0 (gotoh.h:117-123): H(r, 0) = go + r*ge, kept as Hg = H + (go+ge)
-  ScoreLane<K> ss;
+  // The sweep is the 16-bit sweep's (gotoh_narrow_qp_body), GL lanes to a pair: values minus (go+ge) -- Hl = H, El = E - goe,
+  // f = F - goe --, so row 0 is H = 0, F' = 0: what a DPP row_shr:1 writes into the first lane of a row of sixteen (the first lane
+  // of a group of eight gets it through the lane mask `gmask`); the table [code page][row][lane] read by one 16-bit LDS read per
+  // row, issued and waited for by hand; the codes of four columns one dword, requested two rounds ahead; strips swept by asm
+  // statements; between ramp-up and ramp-down the steps test nothing.  (Rounds 1-4 ran the generic lane code here -- packed dword
+  // strips with an unpacking shift per odd row, selects for row 0, a guard per step: 10.5-12.2 instructions per cell, half of the
+  // LDS cycles bank conflicts, a fifth of the wave cycles in s_waitcnt.)
+  // per-lane state at column 0 (gotoh.h:117-123): H(r, 0) = go + r*ge
+  int32_t Hl[K], El[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    const uint32_t r = Lg * K + i + 1;
-    ss.Hl[i] = edge_value(false, go, ge, (int32_t)r) + goe;
-    ss.El[i] = kNegInf16;
-    ss.hopen[i] = goe;
-    ss.hext[i] = ge;
+    Hl[i] = edge_value(false, go, ge, (int32_t)(Lg * K + i + 1));
+    El[i] = kNegInf16;
   }
+  int32_t gev = ge, goev = goe;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(gev), "+v"(goev));  // live VGPRs for the whole sweep, not re-materialised per step
+#endif
   const uint32_t row_above = Lg * K;
-  int32_t prev_up_h = (row_above == 0 ? 0 : edge_value(false, go, ge, (int32_t)row_above)) + goe;
-  int32_t bot_h = 0, bot_f = 0;
+  int32_t upA = 0, upB = (row_above == 0) ? 0 : edge_value(false, go, ge, (int32_t)row_above);
+  int32_t f = 0;
+  const bool rcflag = (d.flags & PAIR_A2_REVCOMP) != 0;
 
-  // query-profile strips of this lane's rows (values - (go+ge), as in the 16-bit score kernel)
+  // query profile (qp16_byte): entry = score - (go+ge); the complement of a reverse-complement view is folded into the table
+  constexpr int NC = COMPACT ? 4 : 6;
+  const uint32_t Lc = ((L & 31u) << 1) | (L >> 5);
   {
     bool overflow = false;
     int32_t qabs = 0;
 #pragma unroll 1
     for (int i = 0; i < K; ++i) {
       const uint32_t r = Lg * K + i + 1;
+      const bool real = valid && r - 1 < m;
       float pr[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       uint8_t rch = 0;
-      if (STRINGS) rch = (valid && r - 1 < m) ? a1c[r - 1] : 0;
+      if (STRINGS) rch = real ? a1c[r - 1] : 0;
       else {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) pr[k] = (valid && r - 1 < m) ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
+        for (int k = 0; k < 5; ++k) pr[k] = real ? a1p[(uint64_t)k * d.a1_stride + (r - 1)] : 0.0f;
       }
 #pragma unroll
       for (uint32_t b = 0; b < NCODES; ++b) {
         int32_t q = 0;
-        if (valid && r - 1 < m) q = STRINGS ? (rch == (uint8_t)"ACGTN"[b] ? a.match : a.mismatch) : onehot_score(pr, b, fmatch, fmis);
+        if (real) q = STRINGS ? (rch == (uint8_t)"ACGTN"[b] ? a.match : a.mismatch) : onehot_score(pr, b, fmatch, fmis);
         const int32_t qs = q - goe;
         overflow |= (qs > 32767) || (qs < -32768) || (q > 32767) || (q < -32768);
         qabs = imax(qabs, q < 0 ? -q : q);
-        qp_tab[b * (64 * qp_stride(K)) + L * qp_stride(K) + i] = (int16_t)qs;
+        const uint32_t row = (rcflag && b < 4u) ? 3u - b : b;
+        qp_tab[qp16_byte<NC>(row, (uint32_t)i, Lc) >> 1] = (int16_t)qs;
       }
+      // '-' / any other letter: an all-zero profile column scores 0, a string column that no row can equal mismatches
+      if (!COMPACT) qp_tab[qp16_byte<NC>(5u, (uint32_t)i, Lc) >> 1] = (int16_t)((STRINGS ? a.mismatch : 0) - goe);
     }
-    // the shared strip of '-' / any other letter: an all-zero profile column scores 0, a string column that no row can equal mismatches
-    if (L < (uint32_t)qp_stride(K)) qp_tab[NCODES * (64 * qp_stride(K)) + L] = (int16_t)((STRINGS ? a.mismatch : 0) - goe);
     if (overflow) flag_error(a.err, 1);
     if (!STRINGS && qabs > a.qlimit) flag_max(a.err, 1, qabs);
     w.sync();
   }
+  const char* tabc = reinterpret_cast<const char*>(qp_tab);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t lane_addr = (uint32_t)reinterpret_cast<uintptr_t>(tabc) + Lc * 2u;
+  if ((lane_addr >> 8) & 0xffu) flag_error(a.err, 1);  // (the table starts the workgroup's LDS: byte 1 is free for the code)
+#else
+  const uint32_t lane_addr = Lc * 2u;
+#endif
+  // byte j of a round's dword (forward) or byte 3 - j (reverse-complement view) is the code of its step j -- per lane here
+  const uint32_t sel0 = 0x03020400u + ((rcflag ? 3u : 0u) << 8), sel1 = 0x03020400u + ((rcflag ? 2u : 1u) << 8),
+                 sel2 = 0x03020400u + ((rcflag ? 1u : 2u) << 8), sel3 = 0x03020400u + ((rcflag ? 0u : 3u) << 8);
+  auto strip_of = [&](uint32_t codes, uint32_t sel) -> uint32_t {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(codes, lane_addr, sel);
+#else
+    return (((codes >> (8u * (((sel >> 8) & 0xffu) - 4u))) & 0xffu) << 8) | lane_addr;
+#endif
+  };
 
-  auto col_at = [&](int32_t cc) -> uint32_t {  // clamp: prefetches of idle lanes stay in bounds
-    const int32_t x = cc < 1 ? 1 : (cc > (int32_t)n ? (int32_t)n : cc);
-    return a2_index(d, (uint32_t)x);
-  };
-  const bool rcflag = (d.flags & PAIR_A2_REVCOMP) != 0;
-  auto code_at = [&](int32_t cc) -> uint32_t {
-    if (n == 0) return 5u;
-    const uint32_t raw = a2c[col_at(cc)];
-    return rcflag ? complement_code(raw) : raw;
-  };
-  // running maxima of H (as Hg) and F of row R: the last slot of the group's last lane
-  int32_t mx_hg = edge_value(false, go, ge, (int32_t)R) + goe, mx_f = kNegInf16;
-  uint32_t* keep_row = (valid && Lg == GL - 1 && (d.flags & PAIR_KEEP_ROW) && a.lastrow) ? reinterpret_cast<uint32_t*>(a.lastrow + d.lastrow_off) : nullptr;
-  uint32_t kept[4] = {0, 0, 0, 0};  // row R of the last four steps (PAIR_KEEP_ROW): stored a chunk later, see the loop
-  auto do_step = [&](uint32_t t, const SubPacked<K>& sub) {
-    const int32_t c = (int32_t)t - (int32_t)Lg;
-    int32_t up_h = w.shift_up(bot_h);
-    int32_t up_f = w.shift_up(bot_f);
-    const bool active = (c >= 1) && (c <= (int32_t)n);
-    if (active) {
-      if (Lg == 0) {  // row 0 (gotoh.h:112-116): free horizontal end gap
-        up_h = goe;
-        up_f = kNegInf16;
-      }
-      int32_t nb_h, nb_f;
-      score_step16g<K>(ss, up_h, up_f, prev_up_h, ge, goe, 0, sub, nb_h, nb_f);
-      prev_up_h = up_h;
-      bot_h = nb_h;
-      bot_f = nb_f;
-      if (Lg == GL - 1) {
-        mx_hg = max16(mx_hg, nb_h);
-        mx_f = max16(mx_f, nb_f);
-        kept[(t - 1u) & 3u] = ((uint32_t)nb_h & 0xffffu) | ((uint32_t)nb_f << 16);
-      }
-    }
-  };
-  // The codes of four columns in one dword, loaded a chunk (four steps) before they are looked up: byte k = column c0 + k of the
-  // lane's view, complemented where the window is read as its reverse complement.  (A byte load per step, waited for on the spot,
-  // cost a memory round trip per step: the kernel ran at a third of the sweeps' rate.)  Lanes off the window read the pad of the
-  // code buffer (kCodePad) or a neighbouring window -- codes either way -- and drop the result.
-  const QpLane ql = qp_lane<K, NCODES>(qp_tab, L);
-  // (branch-free: the load of the next chunk is issued before this chunk's steps and first touched after them)
-  auto load4 = [&](int32_t c0) -> uint32_t {
+  // The codes of the four columns c .. c + 3 of a lane (c = t - Lg at the round that starts with step t) are one dword: bytes
+  // c - 1 .. c + 2 of the window, or n - c - 3 .. n - c of its reverse-complement view.  Lanes off their window read the pad of the
+  // code buffer (kCodePad) or a neighbouring window -- codes either way -- and drop the result; the clamp keeps a short window's
+  // lanes from running on to the end of the longest one's.
+  const uint8_t* code_base = a2c + (rcflag ? (int64_t)n - 3 : (int64_t)-1);
+  const int32_t code_dir = rcflag ? -1 : 1;
+  auto codes_ptr = [&](uint32_t tt) -> const uint8_t* {
+    const int32_t c0 = (int32_t)tt - (int32_t)Lg;
     const int32_t x = c0 < -64 ? -64 : (c0 > (int32_t)n + 64 ? (int32_t)n + 64 : c0);
-    const int64_t at = rcflag ? (int64_t)n - x - 3 : (int64_t)x - 1;
+    return code_base + (int64_t)(code_dir * x);
+  };
+  auto codes_at = [&](uint32_t tt) -> uint32_t {
     uint32_t v;
-    __builtin_memcpy(&v, a2c + at, 4);
+    __builtin_memcpy(&v, codes_ptr(tt), 4);
     return v;
   };
-  auto view4 = [&](uint32_t raw) -> uint32_t {
-    const uint32_t sw = __builtin_bswap32(raw);
-    const uint32_t cv = sw ^ (((~sw >> 2) & 0x01010101u) * 3u);  // bytes 0 .. 3: complement = xor 3
-    return rcflag ? cv : raw;
+  auto codes_request = [&](const uint8_t* ptr, uint32_t& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr));
+#else
+    __builtin_memcpy(&v, ptr, 4);
+#endif
   };
-  (void)code_at;
-  // the kept row's values of a chunk go out at the top of the next one, behind the wait for that chunk's codes: stores count in
-  // the same counter as loads, and issued where they arise they would make every chunk wait for a store round trip
-  auto flush_kept = [&](uint32_t t0) {  // the chunk that began at step t0
-    if (!keep_row) return;
+  auto codes_arrived = [&](uint32_t& v) {  // before the round's stores: gfx950 counts loads and stores in one in-order counter
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory");
+#endif
+  };
+
+  // running maxima of H and F' of row R, and the row itself (PAIR_KEEP_ROW): the last slot of the group's last lane
+  const bool lastlane = Lg == GL - 1;
+  int32_t mx_h = edge_value(false, go, ge, (int32_t)R), mx_f = kNegInf16;
+  uint32_t* keep_row = (valid && lastlane && (d.flags & PAIR_KEEP_ROW) && a.lastrow) ? reinterpret_cast<uint32_t*>(a.lastrow + d.lastrow_off) : nullptr;
+  const uint32_t goe2 = ((uint32_t)goe << 16) | ((uint32_t)goe & 0xffffu);
+  // the lane above: inside a row of sixteen lanes (a group is a row, or half of one whose first lane is masked)
+  const int32_t gmask = (GL < 16 && Lg == 0) ? 0 : -1;
+  // (one DPP instruction each: the mask rides in the shift -- v_and_b32_dpp; a VALU write needs two wait states before a DPP read)
+  auto shift_group = [&](int32_t h, int32_t fv, int32_t& h_up, int32_t& f_up) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("s_nop 1\n\tv_and_b32_dpp %0, %2, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_and_b32_dpp %1, %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(h_up), "=&v"(f_up) : "v"(h), "v"(fv), "v"(gmask));
+#else
+    h_up = w.shift_up_row(h) & gmask;
+    f_up = w.shift_up_row(fv) & gmask;
+#endif
+  };
+
+  // `kept`: {H + goe, F} of row R at this step's column, the format the stages below the kept row read (front.h, band16.h CONT)
+  auto step = [&](auto guard, uint32_t t, QpStrip<K>& q, int32_t& up_cur, const int32_t& diag, uint32_t& kept) {
+    constexpr bool GUARD = decltype(guard)::value;
+    shift_group(Hl[K - 1], f, up_cur, f);
+    qp_wait6<K>(q);
+    const bool active = !GUARD || (uint32_t)(t - 1u - Lg) < n;
+    if (active) {
+      int32_t sub[K];
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-      const int32_t c = (int32_t)(t0 + k) - (int32_t)Lg;
-      if (c >= 1 && c <= (int32_t)n) keep_row[c] = kept[k];
+      for (int i = 0; i < K; ++i) sub[i] = q.lo16(i);
+      if constexpr (K == 8) {
+        strip_left16<8, false>(Hl, El, sub, diag, gev, gev, 0);
+        strip_down16<8>(Hl, El, up_cur, f, gev, goev);
+      } else if constexpr (K == 16) {
+        strip_left16<8, false>(Hl + 8, El + 8, sub + 8, Hl[7], gev, gev, 0);
+        strip_left16<8, false>(Hl, El, sub, diag, gev, gev, 0);
+        strip_down16<8>(Hl, El, up_cur, f, gev, goev);
+        strip_down16<8>(Hl + 8, El + 8, Hl[7], f, gev, goev);
+      } else if constexpr (K == 15) {
+        strip_left16<7, false>(Hl + 8, El + 8, sub + 8, Hl[7], gev, gev, 0);
+        strip_left16<8, false>(Hl, El, sub, diag, gev, gev, 0);
+        strip_down16<8>(Hl, El, up_cur, f, gev, goev);
+        strip_down16<7>(Hl + 8, El + 8, Hl[7], f, gev, goev);
+      } else {
+#pragma unroll
+        for (int i = K - 1; i >= 0; --i) cell_left16(Hl[i], El[i], gev, i == 0 ? diag : Hl[i - 1], sub[i]);
+        int32_t uh = up_cur;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { cell_down16(Hl[i], El[i], uh, f, gev, goev); uh = Hl[i]; }
+      }
+      mx_h = max16(mx_h, Hl[K - 1]);
+      mx_f = max16(mx_f, f);
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm("v_perm_b32 %0, %1, %2, %3\n\tv_pk_add_u16 %0, %0, %4" : "=&v"(kept) : "v"(f), "v"(Hl[K - 1]), "s"(0x05040100u), "v"(goe2));
+#else
+      kept = ((uint32_t)(Hl[K - 1] + goe) & 0xffffu) | ((uint32_t)(f + goe) << 16);
+#endif
+      if (GUARD && keep_row) keep_row[t - Lg] = kept;  // ramp phases: column by column (the steady state stores four at once)
     }
   };
-  uint32_t raw_next = load4(1 - (int32_t)Lg);
-  for (uint32_t t = 1; t <= t_end; t += 4) {
-    const uint32_t cw = view4(raw_next);
-    raw_next = load4((int32_t)t + 4 - (int32_t)Lg);
-    if (t > 1) flush_kept(t - 4);
-    SubPacked<K> q0, q1, q2, q3;
-    qp_fetch<K, NCODES>(ql, cw & 0xffu, q0);
-    qp_fetch<K, NCODES>(ql, (cw >> 8) & 0xffu, q1);
-    qp_fetch<K, NCODES>(ql, (cw >> 16) & 0xffu, q2);
-    qp_fetch<K, NCODES>(ql, cw >> 24, q3);
-    do_step(t, q0);      // (steps past t_end find every lane off its window)
-    do_step(t + 1, q1);
-    do_step(t + 2, q2);
-    do_step(t + 3, q3);
+  using Guarded = SweepGuard<true>;
+  using Free = SweepGuard<false>;
+  uint32_t t = 1;
+  uint32_t cw_cur = codes_at(1), cw_next = codes_at(5), cw_pend = 0;
+  QpStrip<K> qa, qb;
+  qp_fetch6<K, NC>(tabc, strip_of(cw_cur, sel0), qa);
+  const uint8_t* code_run = nullptr;  // the unclamped request pointer of the steady state
+  auto four_steps = [&](auto guard) {
+    constexpr bool GUARD = decltype(guard)::value;
+    if (GUARD) codes_request(codes_ptr(t + 8), cw_pend);
+    else {
+      codes_request(code_run, cw_pend);
+      code_run += 4 * code_dir;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r0, r1, r2, r3;  // (no initialising moves in the loop)
+    asm volatile("" : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3));
+#else
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+#endif
+    qp_fetch6<K, NC>(tabc, strip_of(cw_cur, sel1), qb);
+    step(guard, t, qa, upA, upB, r0);
+    qp_fetch6<K, NC>(tabc, strip_of(cw_cur, sel2), qa);
+    step(guard, t + 1, qb, upB, upA, r1);
+    qp_fetch6<K, NC>(tabc, strip_of(cw_cur, sel3), qb);
+    step(guard, t + 2, qa, upA, upB, r2);
+    qp_fetch6<K, NC>(tabc, strip_of(cw_next, sel0), qa);
+    step(guard, t + 3, qb, upB, upA, r3);
+    codes_arrived(cw_pend);
+    if (!GUARD && keep_row) {  // four columns of row R in one store
+      const uint32_t v[4] = {r0, r1, r2, r3};
+      __builtin_memcpy(keep_row + (t - Lg), v, 16);
+    }
+    cw_cur = cw_next;
+    cw_next = cw_pend;
+    t += 4;
+  };
+  while (t < (uint32_t)GL && t <= t_end) four_steps(Guarded{});  // ramp-up
+  if (nmin != 0xffffffffu && t + 3 <= nmin) {
+    code_run = code_base + (int64_t)code_dir * ((int64_t)t + 8 - (int64_t)Lg);  // (inside every window of the wave, pads included)
+    while (t + 3 <= nmin) four_steps(Free{});  // every lane of every group that has a pair is on a column of its window
   }
-  if (t_end >= 1) flush_kept(((t_end - 1u) & ~3u) + 1u);
-  if (valid && Lg == GL - 1 && a.scores) {
-    const int32_t h = sext16(mx_hg) - goe, f = sext16(mx_f);
-    a.scores[d.out] = h > f ? h : f;
+  while (t <= t_end) four_steps(Guarded{});  // ramp-down: the windows end one after the other
+  if (valid && lastlane && a.scores) {
+    const int32_t h = sext16(mx_h), fm = sext16(mx_f) + goe;
+    a.scores[d.out] = h > fm ? h : fm;
   }
 }
 

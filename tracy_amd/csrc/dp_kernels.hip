@@ -25,6 +25,10 @@ struct DeviceWave {
   __device__ __forceinline__ int32_t shift_up(int32_t x) const {
     return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true);
   }
+  // lane L <- lane L-1 inside a row of sixteen lanes (row_shr:1); the first lane of a row reads 0
+  __device__ __forceinline__ int32_t shift_up_row(int32_t x) const {
+    return __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+  }
   // same shift, lane 0 keeps `first`: the DPP `old` operand is what a lane without a source keeps (bound_ctrl off)
   __device__ __forceinline__ int32_t shift_up_or(int32_t x, int32_t first) const {
     return __builtin_amdgcn_update_dpp(first, x, 0x138, 0xf, 0xf, false);

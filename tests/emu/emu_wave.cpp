@@ -150,10 +150,11 @@ int emu_prefix(int K, uint32_t npairs, const float* a1, const uint64_t* a1_off, 
   int32_t errw[kErrWords] = {0};
   int32_t& err = errw[0];
   DpArgs a{};
-  a.pairs = d.data(); a.a1 = a1; a.a2 = a2; a.scores = out; a.err = &err;
-  a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = 1; a.vfree = 0;
   uint64_t extent = 0;
   for (uint32_t i = 0; i < npairs; ++i) extent = std::max<uint64_t>(extent, a2_off[i] + n[i]);
+  const std::vector<uint8_t> padded = padded_codes(a2, extent);  // (the kernel looks ahead of and behind a window, as in the library's buffer)
+  a.pairs = d.data(); a.a1 = a1; a.a2 = padded.data() + 128; a.scores = out; a.err = &err;
+  a.match = match; a.mismatch = mismatch; a.go = go; a.ge = ge; a.hfree = 1; a.vfree = 0;
   std::vector<uint8_t> special((extent >> 8) + 2, 0);
   for (uint64_t i = 0; i < extent; ++i) if (a2[i] >= 4) special[i >> 8] = 1;
   a.special_blocks = special.data();

@@ -115,7 +115,10 @@ TR_HD uint64_t b16_store_words(uint32_t m, uint32_t n, int K, int32_t dmin, int3
 TR_HD bool b16_narrow_ok(int32_t dmin, int32_t dmax) { return dmax >= dmin && b16_window(4, dmin, dmax) <= 3u * 5u; }
 TR_HD constexpr uint32_t b16_packed_row(uint32_t code_cap) { return ((code_cap + 1u) / 2u + 3u) & ~3u; }  // the quad form keeps two codes to a byte
 TR_HD constexpr uint32_t b16_quad_lds(uint32_t code_cap) { return 16u * b16_packed_row(code_cap) + b16_table_bytes(4); }  // LDS of a quad-form workgroup
-TR_HD constexpr uint32_t b16_cont_quad_lds(uint32_t code_cap) { return b16_quad_lds(code_cap) + 16u * 2u * kB16QuadRowCap * 4u; }
+TR_HD constexpr uint32_t b16_cont_quad_lds(uint32_t code_cap) { return b16_quad_lds(code_cap) + 16u * kB16QuadRowCap * 4u; }
+// LDS of a sixteen-lane workgroup of band16_cont16_body: the codes of its four sub-windows two to a byte, the table, the kept row's
+// entries of strip 0 as the dwords they are kept in (16 KB -> 11 KB at 900 columns: ten -> fourteen workgroups on a CU)
+TR_HD constexpr uint32_t b16_cont16_lds(int K, uint32_t code_cap) { return 4u * b16_packed_row(code_cap) + b16_table_bytes(K) + 4u * kB16RowCap * 4u; }
 // smallest strip height whose lanes are done with a strip before the next one is due (K + width <= 15 (K + 1)); 0: the band is too wide
 TR_HD int b16_pick_k(int32_t dmin, int32_t dmax) {
   if (dmax < dmin) return 0;
@@ -561,7 +564,7 @@ TR_HD void band16_cont16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   constexpr uint32_t KP = (uint32_t)K + 1u;
   constexpr uint32_t NPW = 64u / (uint32_t)P;
   constexpr uint32_t RC = P == 16 ? kB16RowCap : kB16QuadRowCap;  // kept-row entries staged per pair
-  constexpr bool PACKED = P == 4;
+  constexpr bool PACKED = true;  // codes two to a byte in both forms (the LDS block decides how many workgroups a CU holds)
   using Lanes = std::integral_constant<int, P>;
   const uint32_t L = w.lane(), g = L / (uint32_t)P, j = L % (uint32_t)P;
   const uint32_t pair_idx = wave_idx * NPW + g;
@@ -599,22 +602,18 @@ TR_HD void band16_cont16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
       }
     }
   }
-  // {Hg, F} of row R for the columns strip 0 sweeps and the one before them: the kept row holds exactly these halves
-  int32_t* lrow = reinterpret_cast<int32_t*>(w.lds() + NPW * code_row + b16_table_bytes(K)) + g * (2u * RC);
+  // {Hg, F} of row R for the columns strip 0 sweeps and the one before them: the dwords of the kept row (Hg low, F high)
+  uint32_t* lrow = reinterpret_cast<uint32_t*>(w.lds() + NPW * code_row + b16_table_bytes(K)) + g * RC;
   const int32_t crow0 = dmin;  // column of lrow[0]: b16_first_col(0) - 1
+  const uint32_t neg2 = ((uint32_t)neg & 0xffffu) | ((uint32_t)neg << 16);
   if (have) {
     const uint32_t* src = a.row + d.lastrow_off;
     for (uint32_t i = j; i < RC; i += P) {
       const int32_t cc = crow0 + (int32_t)i;
-      int32_t hh = neg, ff = neg;
-      if (cc == 0) hh = edge_g(0);
-      else if (cc >= 1 && cc <= (int32_t)n) {
-        const uint32_t v = src[cc];
-        hh = (int32_t)(v & 0xffffu);
-        ff = (int32_t)(v >> 16);
-      }
-      lrow[2u * i] = hh;
-      lrow[2u * i + 1u] = ff;
+      uint32_t v = neg2;
+      if (cc == 0) v = ((uint32_t)edge_g(0) & 0xffffu) | ((uint32_t)neg << 16);
+      else if (cc >= 1 && cc <= (int32_t)n) v = src[cc];
+      lrow[i] = v;
     }
   }
   w.sync();
@@ -680,7 +679,7 @@ TR_HD void band16_cont16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
       }
       bot_h = cw <= 0 ? edge_g(r0 + (uint32_t)K) : neg;
       bot_f = neg;
-      if (b == 0) prev_up_h = lrow[2 * (cw - 1 - crow0)];
+      if (b == 0) prev_up_h = (int32_t)(lrow[cw - 1 - crow0] & 0xffffu);
 #pragma unroll
       for (uint32_t q = 0; q < kB16Codes; ++q) {
         const uint32_t rowsel = (rcflag && q < 4u) ? 3u - q : q;
@@ -701,9 +700,9 @@ TR_HD void band16_cont16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
         if (live && s_cur == 0) {
           const int32_t c = (int32_t)cm1 + 1;
           const uint32_t i = (uint32_t)(c - crow0) < RC ? (uint32_t)(c - crow0) : RC - 1u;
-          up_h = lrow[2u * i];
-          up_f = lrow[2u * i + 1u];
-          if ((uint32_t)(c - crow0) >= RC) { up_h = neg; up_f = neg; }
+          const uint32_t v = (uint32_t)(c - crow0) < RC ? lrow[i] : neg2;
+          up_h = (int32_t)(v & 0xffffu);
+          up_f = (int32_t)(v >> 16);
         }
       }
       const uint32_t raw = raw_next;

@@ -263,7 +263,7 @@ hipError_t launch_band16_cont_quad(const Band16Args& a, hipStream_t s) {
 hipError_t launch_band16_cont(int K, const Band16Args& a, hipStream_t s, bool narrow) {
   if (a.npairs == 0) return hipSuccess;
   const dim3 grid((a.npairs + 3u) / 4u);
-  const uint32_t lds = 4u * a.code_cap + b16_table_bytes(K) + 4u * 2u * kB16RowCap * 4u;
+  const uint32_t lds = narrow ? b16_cont16_lds(K, a.code_cap) : 4u * a.code_cap + b16_table_bytes(K) + 4u * 2u * kB16RowCap * 4u;
   if (narrow) {
     switch (K) {
       case 12: hipLaunchKernelGGL((band16_cont16_kernel<12>), grid, dim3(64), lds, s, a); break;

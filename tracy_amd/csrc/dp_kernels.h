@@ -1387,8 +1387,10 @@ TR_HD void gotoh_prefix_body(W& w, const DpArgs& a, uint32_t group_base, uint32_
   // c - 1 .. c + 2 of the window, or n - c - 3 .. n - c of its reverse-complement view.  Lanes off their window read the pad of the
   // code buffer (kCodePad) or a neighbouring window -- codes either way -- and drop the result; the clamp keeps a short window's
   // lanes from running on to the end of the longest one's.
-  const uint8_t* code_base = a2c + (rcflag ? (int64_t)n - 3 : (int64_t)-1);
-  const int32_t code_dir = rcflag ? -1 : 1;
+  // (a group without a pair in this form -- beyond the list, skipped, the other form's -- stays on the first bytes of its window:
+  // its lanes run through the steady state of the others and must not walk on behind the buffer)
+  const uint8_t* code_base = !valid ? a2c : a2c + (rcflag ? (int64_t)n - 3 : (int64_t)-1);
+  const int32_t code_dir = !valid ? 0 : (rcflag ? -1 : 1);
   auto codes_ptr = [&](uint32_t tt) -> const uint8_t* {
     const int32_t c0 = (int32_t)tt - (int32_t)Lg;
     const int32_t x = c0 < -64 ? -64 : (c0 > (int32_t)n + 64 ? (int32_t)n + 64 : c0);

@@ -417,6 +417,12 @@ def main():
         band_traffic, band_traffic_src = pmc_traffic([r"band16_kernel<\d+, 0>", r"band16_multi3?(_counted)?_kernel<0>"], "r[0-9][0-9]_pmc_hbm.json")
     except Exception:  # noqa: BLE001
         pass
+    clock_ghz, clock_src = None, None
+    try:  # the clock the part actually holds under this kernel (it throttles below the 2.4 GHz the peak is priced at)
+        from tools.legs import pmc_clock
+        clock_ghz, clock_src = pmc_clock(r"gotoh_ckpt_prefix_kernel<15, 16, true", 1000000)
+    except Exception:  # noqa: BLE001
+        pass
     valu_achieved = kgcups(sc) * ops_per_cell / 1e3
     # `bound` names the ceiling the numbers show: a score-only DP whose inputs are resident moves almost no bytes (the HBM object beside
     # it says how few), what limits it is VALU issue -- so achieved / peak / frac are lane-operations per second
@@ -424,6 +430,8 @@ def main():
                 % (100.0 * sc["ms"] / steps / (elapsed_max / steps * 1e3)),
                 "achieved": round(valu_achieved, 2), "peak": 78.6, "unit": "T lane-ops/s", "frac": round(valu_achieved / 78.6, 3),
                 "ops_per_cell": ops_per_cell, "note": "integer DP is VALU-issue bound; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",
+                "measured_clock": None if not clock_ghz else {"ghz": clock_ghz, "source": clock_src, "frac_of_the_peak_at_this_clock": round(valu_achieved / (78.6 * clock_ghz / 2.4), 3),
+                                                              "note": "`frac` prices against 2.4 GHz; under the full sweeps the part holds this clock (profiled run, not this one)"},
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(score_launch_ms, 3), "launches": sc["launches"],
                 "algorithmic_bytes_per_launch": sc["bytes"] // max(sc["launches"], 1), "kernel_gcups": round(kgcups(sc), 1),
                 "hbm": {"achieved": round(gbs(sc), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs(sc) / HBM_PEAK_GBS, 5),

@@ -122,6 +122,25 @@ def pmc_traffic(patterns, tag_glob="r[0-9][0-9]_pmc_hbm*.json"):
     return None, None
 
 
+def pmc_clock(pattern, grid_min=0, tag_glob="r[0-9][0-9]_pmc_stalls.json"):
+    """effective shader clock (GHz) under the kernel whose name matches `pattern` (the largest grid at least `grid_min`), from the latest
+    committed rocprofv3 pass of GRBM_GUI_ACTIVE (summed over the eight XCDs) / the launch's duration (tools/profile_summarise.py)"""
+    import glob
+    import json
+    import re
+    rx = re.compile(pattern)
+    try:
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", tag_glob)), reverse=True):
+            rows = [r for r in json.load(open(f)) if r["counter"] == "GRBM_GUI_ACTIVE" and rx.search(r["kernel"]) and (r.get("grid") or 0) >= grid_min
+                    and r.get("effective_clock_ghz") and (r.get("avg_launch_ms") or 0) > 1.0]
+            if rows:
+                r = max(rows, key=lambda x: x.get("grid") or 0)
+                return float(r["effective_clock_ghz"]), "profiles/%s (GRBM_GUI_ACTIVE / 8 XCDs / launch duration, kernel on its own, grid %s)" % (os.path.basename(f), r.get("grid"))
+    except (OSError, ValueError, KeyError, IndexError):
+        pass
+    return None, None
+
+
 def kernel_block(name, kernel, t, steps, ops_per_cell=None, flops_per_cell=None, traffic_key=None, traffic_glob="r[0-9][0-9]_pmc_hbm*.json"):
     """roofline object of one kernel class from the library's HIP-event timers.  `bound` names the ceiling the numbers show: integer DP
     with its inputs resident is VALU-issue bound (achieved / peak / frac are then lane-ops per second); the HBM figures stay beside it."""

@@ -754,7 +754,7 @@ struct QpStrip {
 // with NC = 4: 8 KB.  The table is what decides how many waves a CU holds, and this kernel needs them: one wave issues a VALU
 // instruction every ~4.5 cycles, a SIMD takes one every 2 (tools/ubench/clock_probe.hip); 13 -> 20 workgroups per CU was 32.4 ->
 // 28.2 ms per launch.  Measured (round 5, one box, tools/ab.sh): the [code][row][lane] layout of 7.5 KB holds twenty workgroups on a
-// CU, this one nineteen (twenty times 8 KB is the whole LDS and does not fit) -- 5 120 pairs 8.4 -> 9.4 ms, but 20 480 pairs 30.1 ->
+// CU, this one eighteen (4 608 pairs are one round of waves, 4 864 are not) -- 5 120 pairs 8.4 -> 9.4 ms, but 20 480 pairs 30.1 ->
 // 29.0 ms and the `tracy align` step 19.8 -> 19.4 ms: the instruction saved counts for more than the twentieth workgroup.
 TR_HD constexpr uint32_t lds_bytes_sweep16(int K, bool compact) { return (compact ? 4u : 6u) * 256u * (uint32_t)((K + 1) / 2); }
 // (the prefix rows of the pruned sweeps, gotoh_prefix_body, lay their table out the same way)

@@ -131,6 +131,78 @@ def stub_rank(args, rank, world):
     dist.destroy_process_group()
 
 
+DRIVER_LINE_LIMIT = 7800  # bytes: the driver's record keeps the parsed contract keys, `config`, the scalars of `roofline`, `cpu_baseline` and an 8 KB tail
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def finish_line(line, args):
+    """The line the driver keeps: every number a reader needs as a scalar where the driver's record retains it
+    (top level, `config`, `roofline`), the legs' objects cut down to their figures, the prose moved to DESIGN.md -- under 8 KB.  The
+    unabridged line (every leg's detail, as printed until round 5) goes to --full-line / gpurun_out/bench_line_full.json."""
+    full = json.loads(json.dumps(line))
+    path = args.full_line
+    if path is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        path = os.path.join(ROOT, "gpurun_out", "bench_line_full.json")
+    if path:
+        try:
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+        except OSError:
+            pass
+    out = dict(line)
+    scal = {}
+    d = line.get("decompose")
+    if isinstance(d, dict) and "error" not in d:
+        sb = d.get("small_batch") or {}
+        scal.update({"decompose_ms_per_step": d.get("ms_per_step"), "decompose_traces_per_s": d.get("value"),
+                     "small_batch_ms": sb.get("ms_per_step"), "small_batch_ratio": sb.get("vs_eighth_of_the_full_step"),
+                     "decompose_gathered_bytes_per_step": d.get("gathered_bytes_per_step")})
+        r = d.get("roofline") or {}
+        out["decompose"] = dict(_pick(d, ("value", "unit", "ms_per_step", "gcups", "steps", "n_gpus", "scaling", "traces_ok", "gathered_bytes_per_step", "gather_checked", "parity_checked")),
+                                small_batch=_pick(sb, ("traces", "ms_per_step", "two_lanes_ms_per_step", "vs_eighth_of_the_full_step")),
+                                strand_by_certificate_ms=(d.get("strand_by_certificate") or {}).get("ms_per_step"),
+                                two_lanes_ms=(d.get("lanes") or {}).get("ms_per_step"),
+                                roofline=dict(_pick(r, ("bound", "timer", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "kernel_gcups", "share_of_kernel_time", "ms_per_step")),
+                                              other={k: _pick(v, ("achieved", "frac", "traffic", "avg_launch_ms", "kernel_gcups")) for k, v in (r.get("other_kernels") or {}).items()}),
+                                pipeline=_pick(d.get("pipeline") or {}, ("stream_ordered", "host_syncs_per_call", "traces_to_host_planned_tiers", "traces_per_rank")),
+                                cpu_baseline=_pick(d.get("cpu_baseline") or {}, ("value", "unit", "cores", "kind")))
+    a = line.get("allpairs")
+    if isinstance(a, dict) and "error" not in a:
+        scal["allpairs_gcups"] = a.get("value")
+        out["allpairs"] = dict(_pick(a, ("value", "unit", "pairs", "ms_per_step", "n_gpus", "scaling", "parity_checked")),
+                               roofline=_pick(a.get("roofline") or {}, ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "kernel_gcups")),
+                               cpu_baseline=_pick(a.get("cpu_baseline") or {}, ("value", "unit", "cores", "kind")))
+    e = line.get("seedextend")
+    if isinstance(e, dict) and "error" not in e:
+        scal.update({"seedextend_traces_per_s": e.get("value"), "seed_traces_per_s_per_thread": e.get("seed_traces_per_s_per_thread")})
+        out["seedextend"] = dict(_pick(e, ("value", "unit", "ms_per_step", "n_gpus", "scaling", "seed_traces_per_s", "seed_traces_per_s_per_thread", "extend_traces_per_s_per_gpu",
+                                           "n_gpus_fed_at_this_host", "host_threads_needed_to_feed_one_gpu", "extend_ms_not_hidden_per_step", "host_threads_per_rank", "anchored", "traces",
+                                           "placed_within_60bp_of_truth", "parity_checked")),
+                                 roofline=_pick(e.get("roofline") or {}, ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "kernel_gcups")),
+                                 cpu_baseline=_pick(e.get("cpu_baseline") or {}, ("value", "unit", "cores", "kind")))
+    c = line.get("cli")
+    if isinstance(c, dict) and "error" not in c:
+        sub = {}
+        for cmd in ("align", "decompose"):
+            x = c.get(cmd) or {}
+            scal["cli_%s_traces_per_s" % cmd] = x.get("traces_per_s")
+            sub[cmd] = dict(_pick(x, ("traces_per_s", "wall_s", "json_files_written", "exit_code", "first_bottleneck", "peak_rss_mb")),
+                            cpu_baseline_traces_per_s=(x.get("cpu_baseline") or {}).get("value"))
+        out["cli"] = dict(_pick(c, ("value", "unit", "host_threads")), **sub)
+    scal = {k: v for k, v in scal.items() if v is not None}
+    out.update(scal)
+    out["config"] = dict(line["config"], **scal)
+    out["full_line"] = os.path.relpath(path, ROOT) if path else None
+    for drop in ("cli", "seedextend", "allpairs", "lanes", "strand_by_certificate", "pipeline"):  # (never needed with the fields above; a guard, not a plan)
+        if len(json.dumps(out)) <= DRIVER_LINE_LIMIT:
+            break
+        out.pop(drop, None)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +235,8 @@ def main():
                     help="also time the batch split over this many lanes (reported beside the headline; 0/1 = skip)")
     ap.add_argument("--certificate-leg", type=int, default=1,
                     help="1: also time the library's default strand-by-certificate mode after the headline leg (reported beside it)")
+    ap.add_argument("--alone-steps", type=int, default=3, help="untimed extra steps with option sweeps_alone: the dominant kernel on a device of its own (0 = skip)")
+    ap.add_argument("--full-line", default=None, help="also write the unabridged line (every leg's detail) to this file (default: gpurun_out/bench_line_full.json when that directory exists)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="traces for the CPU baseline (-1: 2 per thread, capped)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -195,6 +269,8 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         backend = dist.get_backend()
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: the process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     elif not args.no_process_group:
         # one rank started by hand (the driver's N = 1 run): a process group of one all the same, so that the gathers of every leg go
         # through RCCL exactly as they do at N > 1 (a failure to set it up is reported in the line, not fatal)
@@ -209,7 +285,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             dist = None
             backend = "none (%s: %s)" % (type(e).__name__, str(e)[:120])
-        if dist.get_world_size() != args.gpus:
+        if dist is not None and dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: the process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
     dev = torch.device("cuda", local)
 
@@ -253,7 +329,7 @@ def main():
 
     import tracy_amd
     from tracy_amd import capi, hostlib
-    from tracy_amd.shard import gather_records
+    from tracy_amd.shard import ResultGather
 
     nt, n, mf = args.traces, args.ref_len, args.trace_len
     # ---- synthetic inputs (seeded per trace: seed = 1000 + global trace index), resident in HBM ----
@@ -298,14 +374,23 @@ def main():
     # roofline block says.  tracyhip_set_lanes (chunks of the batch in flight on their own streams) is timed as a further leg.
     ctx.set_lanes(max(1, args.lanes))
     lib = capi.lib()
+    REC_KEYS = ("score_fwd", "score_rev", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final", "ops_len")
+    gatherer = ResultGather(dist, [nt] * world, ctx) if dist is not None else None  # (weak scaling: every rank holds nt traces)
+    gathered = {"out": None, "bytes": 0}
 
-    def step():
+    def run_call():
         rc = lib.tracyhip_align_traces(ctx._h, C.byref(job), C.byref(prm), capi.MEM_DEVICE, C.byref(out))
         if rc != 0:
             raise RuntimeError("tracyhip_align_traces: %s" % lib.tracyhip_last_error().decode())
-        if dist is not None:  # final gather of the fixed-size result records over RCCL / xGMI
-            rec = torch.stack([r_i32["score_final"], r_i32["slice_begin"], r_i32["slice_len"], r_i32["ops_len"]], dim=1)
-            gather_records(dist, rec, dst=0, sizes=[nt] * world)  # (weak scaling: every rank holds nt traces)
+
+    def step():
+        run_call()
+        if dist is not None:
+            # the final gather, both halves: the fixed-size record of every trace in one collective, then the traceback strings
+            # (sage.h:311's alignment) packed on the device and shipped in one exchange sized from the records' ops_len column
+            rec = torch.stack([r_i32[k] for k in REC_KEYS] + [r_fwd.to(torch.int32)], dim=1)
+            gathered["out"] = gatherer.gather(rec, [(r_ops, ops_cap, REC_KEYS.index("ops_len"))])
+            gathered["bytes"] = gatherer.bytes_last
 
     def read_timers():
         kt = capi.KernelTiming()
@@ -359,12 +444,31 @@ def main():
         ctx.set_lanes(max(1, args.lanes))
     job.strand_by_certificate = 0
 
+    # ---- the dominant kernel on a device of its own (option sweeps_alone: the voted strand's chain finishes before the full sweeps start,
+    # its prefix cells go to the front timer): what `roofline.dominant_kernel_alone_frac` is measured on.  Not part of any timed leg. ----
+    rl_alone = None
+    if args.alone_steps > 0:
+        ctx.set_option("sweeps_alone", 1)
+        try:
+            for _ in range(2):
+                run_call()
+            lib.tracyhip_timing_enable(ctx._h, 1)
+            lib.tracyhip_timing_reset(ctx._h)
+            for _ in range(args.alone_steps):
+                run_call()
+            torch.cuda.synchronize()
+            lib.tracyhip_timing_enable(ctx._h, 0)
+            rl_alone = read_timers()
+        finally:
+            ctx.set_option("sweeps_alone", 0)
+
     # ---- work done: DP cells of the four Gotoh calls per trace ----
     mt = mf - 2 * TRIM
     cells_rank = int(3 * mt * n * nt + (mf * slice_len).sum())
-    tm = torch.tensor([elapsed, float(cells_rank), elapsed_cert, elapsed_lanes[0], elapsed_lanes[1]], dtype=torch.float64,
+    tm = torch.tensor([elapsed, float(cells_rank), elapsed_cert, elapsed_lanes[0], elapsed_lanes[1], float(gathered["bytes"])], dtype=torch.float64,
                       device="cpu" if args.share_device else dev)
     elapsed_min = elapsed
+    gathered_bytes_all = float(gathered["bytes"])
     if dist is not None:
         tmax = tm.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -375,16 +479,26 @@ def main():
         elapsed_max, cells_all, elapsed_cert_max = float(tmax[0]), float(tsum[1]), float(tmax[2])
         elapsed_lanes = [float(tmax[3]), float(tmax[4])]
         elapsed_min = float(tmin[0])
+        gathered_bytes_all = float(tsum[5])
     else:
         elapsed_max, cells_all, elapsed_cert_max = elapsed, float(cells_rank), elapsed_cert
+
+    # what rank 0 holds after the step's gather must be what the ranks computed: its own block, bit for bit (the other ranks' blocks are
+    # compared with the single-process results in tests/test_shard_gloo.py and tests/test_gpu_bench_ranks.py)
+    gather_ok = None
+    if rank == 0 and gathered["out"] is not None and gathered["out"][0] is not None:
+        allrec, got = gathered["out"]
+        mine = torch.stack([r_i32[k] for k in REC_KEYS] + [r_fwd.to(torch.int32)], dim=1)
+        gather_ok = gatherer.check_own_block(allrec, got, mine, [(r_ops, ops_cap, REC_KEYS.index("ops_len"))])
 
     # the headline's inputs and results are no longer needed on the device (the parity sample below reads host copies)
     sf_host, ol_host, ops_host = r_i32["score_final"].cpu().numpy(), r_i32["ops_len"].cpu().numpy(), None
     if rank == 0 and args.cpu_sample != 0:
         ops_host = r_ops.cpu().numpy()
+    gathered["out"] = None
     if args.workload == "all":
         ctx.close()
-        del d_refs, d_profs, r_ops
+        del d_refs, d_profs, r_ops, gatherer
         torch.cuda.empty_cache()
         for which in ("decompose", "allpairs", "seedextend", "cli"):
             extra[which] = run_extra(which)
@@ -403,83 +517,64 @@ def main():
 
     def kgcups(x):
         return x["cells"] / (x["ms"] * 1e-3) / 1e9 if x["ms"] > 0 else 0.0
-    # Dominant kernel of the step = the score-only Gotoh pass (forward + reverse-complement orientation; it leaves the values of
-    # row m behind, from which the preliminary alignment's end is read).  Its algorithmic HBM bytes are the inputs once + 4 B per score, so the
-    # HBM roofline fraction is tiny by construction: the kernel is VALU-issue bound (see "valu").
+    # Dominant kernel of the step = the score-only Gotoh sweeps (DESIGN.md section 3 says what the launch holds and why the ceiling is VALU
+    # issue: a score-only DP with resident inputs moves almost no bytes).  achieved / peak / frac are lane-operations per second; the HBM
+    # figures stay beside them as hbm_*.  traffic = HBM bytes of one step's sweep launches from the committed rocprofv3 PMC passes.
     score_launch_ms = sc["ms"] / max(sc["launches"], 1)
     ops_per_cell = 8.0  # 16-bit formulation with the shared gap-open term: 4 v_add_u16 + 4 v_max_i16 per cell
-    # HBM bytes of one launch as measured by rocprofv3 PMC passes (WRITE_SIZE + FETCH_SIZE, separate passes, summary
-    # committed under profiles/): the inputs, the scores and the row-m values of the sweeps the orientation vote keeps
     traffic, traffic_src, band_traffic, band_traffic_src = None, None, None, None
-    try:  # (bytes per step of the exact instantiations each timer covers; both timers launch once per step here)
+    try:
         from tools.legs import pmc_traffic
         traffic, traffic_src = pmc_traffic([r"gotoh_ckpt_prefix_kernel<"], "r[0-9][0-9]_pmc_hbm.json")
         band_traffic, band_traffic_src = pmc_traffic([r"band16_kernel<\d+, 0>", r"band16_multi3?(_counted)?_kernel<0>"], "r[0-9][0-9]_pmc_hbm.json")
     except Exception:  # noqa: BLE001
         pass
     clock_ghz, clock_src = None, None
-    try:  # the clock the part actually holds under this kernel (it throttles below the 2.4 GHz the peak is priced at)
+    try:  # the clock the part holds under this kernel (it throttles below the 2.4 GHz the peak is priced at); from the committed profile
         from tools.legs import pmc_clock
         clock_ghz, clock_src = pmc_clock(r"gotoh_ckpt_prefix_kernel<15, 16, true", 1000000)
     except Exception:  # noqa: BLE001
         pass
     valu_achieved = kgcups(sc) * ops_per_cell / 1e3
-    # `bound` names the ceiling the numbers show: a score-only DP whose inputs are resident moves almost no bytes (the HBM object beside
-    # it says how few), what limits it is VALU issue -- so achieved / peak / frac are lane-operations per second
-    roofline = {"bound": "valu", "kernel": "gotoh_ckpt_prefix_kernel<K,16,compact,8> (score-only Gotoh, one launch: the full sweeps of the strand the vote does not pick -- row m kept only where the vote is unclear -- + the 128-row prefixes of the voted strand over the whole window, row 128 kept; cells credited: the rows swept; dominant: %.0f%% of the step)"
-                % (100.0 * sc["ms"] / steps / (elapsed_max / steps * 1e3)),
+    alone_frac = alone_ms = None
+    if rl_alone is not None and rl_alone["score"]["ms"] > 0:
+        alone_ms = rl_alone["score"]["ms"] / max(rl_alone["score"]["launches"], 1)
+        alone_frac = kgcups(rl_alone["score"]) * ops_per_cell / 1e3 / 78.6
+    short = lambda x: None if x is None else str(x).split(" ")[0]  # noqa: E731  (a profile file's name without the explanation)
+    roofline = {"bound": "valu", "kernel": "gotoh_ckpt_prefix_kernel<15,16,compact,8>: 16-bit score-only Gotoh sweeps (DESIGN.md 2.2, 3)",
                 "achieved": round(valu_achieved, 2), "peak": 78.6, "unit": "T lane-ops/s", "frac": round(valu_achieved / 78.6, 3),
-                "ops_per_cell": ops_per_cell, "note": "integer DP is VALU-issue bound; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",
-                "measured_clock": None if not clock_ghz else {"ghz": clock_ghz, "source": clock_src, "frac_of_the_peak_at_this_clock": round(valu_achieved / (78.6 * clock_ghz / 2.4), 3),
-                                                              "note": "`frac` prices against 2.4 GHz; under the full sweeps the part holds this clock (profiled run, not this one)"},
-                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(score_launch_ms, 3), "launches": sc["launches"],
+                "ops_per_cell": ops_per_cell, "traffic": traffic, "traffic_source": short(traffic_src),
+                "avg_launch_ms": round(score_launch_ms, 3), "launches": sc["launches"],
                 "algorithmic_bytes_per_launch": sc["bytes"] // max(sc["launches"], 1), "kernel_gcups": round(kgcups(sc), 1),
-                "hbm": {"achieved": round(gbs(sc), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs(sc) / HBM_PEAK_GBS, 5),
-                        "algorithmic_bytes_per_launch": sc["bytes"] // max(sc["launches"], 1), "traffic": traffic},
-                "valu": {"achieved": round(valu_achieved, 2), "peak": 78.6, "unit": "T lane-ops/s", "frac": round(valu_achieved / 78.6, 3)},
-                # the final alignments run on the band kernels (band16.h): a certified diagonal band per pair, four pairs per wave; cells and
-                # bytes are those of the band (strips x window steps x K cells, K/2 bytes of trace nibbles per strip and step), not the matrix
-                "traceback_kernel": {"kernel": "band16_kernel<K,0> (traceback of the final alignments on their certified diagonal bands, sixteen lanes per pair, the pair's lanes walk it; cells / bytes credited: the band's)",
-                                     "achieved": round(gbs(tr), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": round(gbs(tr) / HBM_PEAK_GBS, 4), "kernel_gcups": round(kgcups(tr), 1),
-                                     "avg_launch_ms": round(tr["ms"] / max(tr["launches"], 1), 3),
-                                     "algorithmic_bytes_per_launch": tr["bytes"] // max(tr["launches"], 1),
-                                     "swept_cells_per_launch": tr["cells"] // max(tr["launches"], 1),
-                                     "traffic": band_traffic, "traffic_source": band_traffic_src},
-                "ms_per_step": {"score": round(sc["ms"] / steps, 3), "pruned_sweep_band": round(rl["front"]["ms"] / steps, 3), "preliminary_ends": round(og["ms"] / steps, 3),
-                                "band_traceback": round(bd["ms"] / steps, 3), "full_traceback": round(tr["ms"] / steps, 3),
-                                "walk": round(rl["walk"]["ms"] / steps, 3)},
-                "ms_per_step_note": ("event-to-event times of the kernel classes; with side streams on (tracyhip option no_fork = 0) the voted strand's chain -- its "
-                                     "128-row prefixes and the band tiers below them (pruned_sweep_band) -- runs beside the other strand's full sweeps (score): "
-                                     "the two intervals overlap, and the prefixes' cells stay credited to `score`, whose interval covers them"),
-                # the preliminary alignment (trimmed trace vs the whole window) is only trimmed from: its two ends come from an
-                # origin-tracking sweep over the sub-window the score sweep certifies (band traceback where that does not apply)
-                "preliminary_alignment": {"kernel": "band16_kernel<K,1> (origin-tracking sweep on the band the score allows inside the certified sub-window)" if og["ms"] > 0 else "gotoh_band_kernel<K,QP>",
-                                          "swept_gcups": round(kgcups(og if og["ms"] > 0 else bd), 1),
-                                          "swept_fraction_of_its_matrix": round((og["cells"] + bd["cells"]) / steps / max(mt * n * nt, 1), 3),
-                                          "effective_gcups_over_the_matrix": round(mt * n * nt * steps / ((og["ms"] + bd["ms"]) * 1e-3) / 1e9, 1) if (og["ms"] + bd["ms"]) > 0 else 0.0}}
+                "share_of_step": round(sc["ms"] / steps / (elapsed_max / steps * 1e3), 3),
+                "clock_ghz": clock_ghz, "clock_source": short(clock_src),
+                "frac_at_measured_clock": None if not clock_ghz else round(valu_achieved / (78.6 * clock_ghz / 2.4), 3),
+                "dominant_kernel_alone_ms": None if alone_ms is None else round(alone_ms, 3),
+                "dominant_kernel_alone_frac": None if alone_frac is None else round(alone_frac, 3),
+                "hbm_achieved_gbs": round(gbs(sc), 2), "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": round(gbs(sc) / HBM_PEAK_GBS, 5),
+                # the final alignments: tracebacks on certified diagonal bands (band16.h); cells / bytes are the bands'
+                "traceback_hbm_gbs": round(gbs(tr), 1), "traceback_hbm_frac": round(gbs(tr) / HBM_PEAK_GBS, 4), "traceback_gcups": round(kgcups(tr), 1),
+                "traceback_launch_ms": round(tr["ms"] / max(tr["launches"], 1), 3),
+                "traceback_algorithmic_bytes": tr["bytes"] // max(tr["launches"], 1), "traceback_traffic": band_traffic,
+                "ms_score": round(sc["ms"] / steps, 3), "ms_pruned_sweep_band": round(rl["front"]["ms"] / steps, 3),
+                "ms_preliminary_ends": round(og["ms"] / steps, 3), "ms_final_alignments": round(tr["ms"] / steps, 3)}
 
+    swept = sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin", "front")) / steps * world / (elapsed_max / steps) / 1e9
     line = {
         "metric": "GCUPS (tracy align: Gotoh affine-gap DP cells per second, whole job)",
         "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "backend": backend, "rccl_ranks": world if backend == "nccl" else 0, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int16 (score sweeps) / int32 (tracebacks)", "data": "synthetic",
         "traces_per_s": round(nt * world * args.steps / elapsed_max, 1),
-        "config": {"workload": "configs[1]: %d synthetic %d-base traces `align` vs %d-base reference windows per GPU, "
-                               "full Gotoh (2 score-only + 2 traceback DPs per trace), scoring 3/-5/-10/-4, trims 50/50"
-                               % (nt, mf, n), "traces_per_gpu": nt, "trace_len": mf, "ref_len": n,
-                   "parallelism": "batch-sharded x%d, no data-path collective" % world, "lanes_per_gpu": max(1, args.lanes),
-                   # `value` counts the reference's DP cells; the cells the kernels really evaluated, over the same time:
-                   "gcups_swept_cells": round(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin", "front")) / steps * world / (elapsed_max / steps) / 1e9, 2),
-                   "value_note": "value = reference DP cells (3 x mt x n + mf x slice per trace) / time; gcups_swept_cells = cells swept / the same time"},
-        # GCUPS counts the DP cells of the reference's four Gotoh calls per trace.  What is swept: one orientation in
-        # full, the other by its prefix rows + a certified band, the preliminary and the final alignment on certified bands -- with
-        # results (scores, ends, strings) proven to be the whole matrices'; `gcups_swept_cells` prices the same step by those cells
-        "cells_counted": "reference DP cells: 3 x (mt x n) + mf x slice per trace; swept: one orientation in full, the voted one on 128 prefix rows + a certified band, the preliminary and the final alignment on certified diagonal bands",
-        # the same step priced by the cells the kernels really evaluated (HIP-event timers): what `value` would be if no stage were
-        # credited with a whole matrix it did not sweep
-        "gcups_swept_cells": round(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin", "front")) / steps * world / (elapsed_max / steps) / 1e9, 2),
-        "cells_swept_per_step_rank0": int(sum(rl[k]["cells"] for k in ("score", "trace", "band", "prefix", "origin", "front")) / steps),
+        # `value` counts the reference's DP cells (3 x mt x n + mf x slice per trace); gcups_swept_cells prices the same step
+        # by the cells the kernels really evaluated
+        "gcups_swept_cells": round(swept, 2),
+        "gathered_bytes_per_step": int(gathered_bytes_all), "gather_checked": gather_ok,
+        "config": {"workload": "configs[1]: %d synthetic %d-base traces `align` vs %d-base windows per GPU, scoring 3/-5/-10/-4, trims 50/50" % (nt, mf, n),
+                   "traces_per_gpu": nt, "trace_len": mf, "ref_len": n,
+                   "parallelism": "batch-sharded x%d, no data-path collective; gather of records + traceback strings to rank 0" % world,
+                   "lanes_per_gpu": max(1, args.lanes), "gcups_swept_cells": round(swept, 2),
+                   "gathered_bytes_per_step": int(gathered_bytes_all)},
         "roofline": roofline,
         # rank 0's view of a call: planned on the device, one host synchronisation (stream.hip); min / max over the ranks
         "pipeline": {"stream_ordered": call_stats["stream_ordered"], "host_syncs_per_call": call_stats["host_syncs"],
@@ -487,31 +582,17 @@ def main():
                      "ms_per_step_rank_max": round(elapsed_max / args.steps * 1e3, 3), "host_threads_per_rank": max(1, usable_cores() // max(1, world))},
     }
     if rl_cert is not None:
-        csc, cpf = rl_cert["score"], rl_cert["prefix"]
-        # strand by certificate, timed on the same batch right after the headline leg: 128-row prefixes of both strands over the
-        # window, the voted strand continued on its certified band (front.h), the other one skipped when its prefix maximum + the row
-        # maxima of its remaining rows prove it cannot win.  Alignments are checked identical to the headline leg's above.
+        # strand by certificate, timed on the same batch right after the headline leg; alignments checked identical above.
         # Reported for information: the loser's exact score is not computed, so it is not `value`.
         line["strand_by_certificate"] = {
             "ms_per_step": round(elapsed_cert_max / args.steps * 1e3, 3),
             "traces_per_s": round(nt * world * args.steps / elapsed_cert_max, 1),
             "cells_swept_fraction": round(sum(rl_cert[k]["cells"] for k in ("score", "prefix", "trace", "band", "origin", "front")) / steps / max(cells_rank, 1), 3),
-            "sweep_launch": {"kernel": "gotoh_ckpt_prefix_kernel<K,16,compact,8> (the prefixes of both strands; full sweeps only where a vote is unclear)",
-                             "avg_launch_ms": round(csc["ms"] / max(csc["launches"], 1), 3), "launches": csc["launches"],
-                             "kernel_gcups": round(kgcups(csc), 1)},
-            "pruned_sweep_band_ms": round(rl_cert["front"]["ms"] / steps, 3),
             "alignments_identical_to_headline_leg": True,
         }
     if args.lanes_leg > 1 and elapsed_lanes[0] > 0:
-        # tracyhip_set_lanes: kernels of different chunks fill each other's tails and the host stages between kernels
-        # overlap with device work.  Same cells, same results; per-kernel durations are not comparable across lanes
-        # (they overlap), which is why the roofline block is measured on the one-lane headline leg.
         line["lanes"] = {"lanes": args.lanes_leg, "ms_per_step": round(elapsed_lanes[0] / args.steps * 1e3, 3),
-                         "gcups": round(cells_all * args.steps / elapsed_lanes[0] / 1e9, 2),
-                         "traces_per_s": round(nt * world * args.steps / elapsed_lanes[0], 1)}
-        if elapsed_lanes[1] > 0:
-            line["lanes"]["strand_by_certificate"] = {"ms_per_step": round(elapsed_lanes[1] / args.steps * 1e3, 3),
-                                                      "traces_per_s": round(nt * world * args.steps / elapsed_lanes[1], 1)}
+                         "strand_by_certificate_ms_per_step": round(elapsed_lanes[1] / args.steps * 1e3, 3) if elapsed_lanes[1] > 0 else None}
     if True:  # (rank 0 at any N, on its share of the node's cores: every rank of a one-node job runs host work at the same time)
         nthreads = max(1, usable_cores() // max(1, world))  # one trace per thread
         sample = args.cpu_sample if args.cpu_sample >= 0 else max(8, min(40 * nthreads, 2048))  # ~10 s of CPU work
@@ -524,10 +605,8 @@ def main():
             except (OSError, StopIteration):
                 pass
             line["cpu_baseline"] = {"value": round(v, 4), "unit": "GCUPS", "cores": min(nthreads, ns), "kind": "port",
-                                    "sample": "%d of the same traces through the oracle's sage.h chain (C, pthreads), one trace per thread, %.1f s"
-                                              % (ns, dt),
-                                    "single_thread": {"value": round(v1, 4), "unit": "GCUPS", "sample": "%d traces, %.1f s" % (n1, dt1)},
-                                    "cpu_model": model, "host_threads": os.cpu_count(), "usable_cores": nthreads}
+                                    "sample": "%d of the same traces through the oracle's sage.h chain (C, one trace per thread), %.1f s" % (ns, dt),
+                                    "single_thread_gcups": round(v1, 4), "cpu_model": model, "usable_cores": nthreads}
             # the same traces must come out bit-identical on the GPU
             sf, ol, ops = sf_host, ol_host, ops_host
             ok = all(int(sf[i]) == o["score_final"] and ops[i * ops_cap:i * ops_cap + int(ol[i])].tobytes() == o["btr"]
@@ -539,6 +618,7 @@ def main():
     if args.share_device:
         line["shared_device"] = True  # (a test of the N-rank code path on one GPU: not a measurement)
         line["backend"] = "gloo"
+    line = finish_line(line, args)
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -113,7 +113,7 @@ int tracyhip_synchronize(tracyhip_ctx* ctx);
 /* Options.  Every switch of the library is read from the environment ONCE, when a context is created (TRACYHIP_<NAME>, e.g.
    TRACYHIP_NO_STREAM=1), and changed afterwards only through this call; name is the variable without the prefix, in any case:
      no_stream (pipelines planned by the host between launches instead of stream-ordered), no_narrow, no_compact, no_screen,
-     no_band, no_band16, no_front, no_prefix, no_vote, no_origin, no_subwindow, no_prelim_origin, no_cq, no_fused_walk, no_cont16, no_quads, no_fork, no_decomp_wave, no_af_split, no_front_lists, no_origin_band   "0" / "1"
+     no_band, no_band16, no_front, no_prefix, no_vote, no_origin, no_subwindow, no_prelim_origin, no_cq, no_fused_walk, no_cont16, no_quads, no_fork, no_decomp_wave, no_af_split, no_front_lists, no_origin_band, sweeps_alone (measurement: the full sweeps of the orientation stage on a device of their own)   "0" / "1"
      band_w  (half width of the certified band of the final alignments; -1 = from the preliminary alignment, 0 = whole matrices)
      ckpt_b  (steps between wavefront checkpoints, 32 .. 1024)      verbose  (one line per pipeline stage on stderr)
      quad_tier_min  (stream-ordered pipelines: traces / alleles from which a pruned sweep gets its narrow first tier; default 32768)
@@ -396,6 +396,18 @@ int tracyhip_group_decompose_traces(tracyhip_group* group, const tracyhip_decomp
                                     const tracyhip_decompose_result* out);
 /* bounds[0 .. parts] of `parts` contiguous slices of the pair list with (nearly) equal DP cell count; host arithmetic, no device */
 int tracyhip_pair_bounds(const tracyhip_pairs* pairs, uint32_t parts, uint64_t* bounds);
+
+/* ---- result compaction for the final gather of a sharded job (no counterpart in the reference, which is one process) ----
+ * The pipelines write variable-length results (traceback strings, decomposition tables) into fixed-capacity regions the caller lays out
+ * (ops_offset[], dcp_offset[]).  Before a rank ships them to the rank that collects the job's results it packs the used parts back to
+ * back: region i = bytes [i * stride_bytes, ...) of src -- or from src + src_offset[i] (HOST array, bytes) when src_offset != NULL -- of
+ * which the first lens[i * lens_stride] * elem_bytes bytes are used; they go to dst in region order.  src, lens, dst are DEVICE
+ * pointers (lens_stride lets a field of a record array serve, e.g. tracyhip_decomp_status::dcp_n: lens = &dstatus[0].dcp_n,
+ * lens_stride = 6).  dst == NULL: only the total is computed.  *total_bytes (host) receives the packed size; the call is synchronous.
+ * TRACYHIP_ERR_ARG when the total exceeds dst_cap (nothing is written beyond dst_cap when dst_cap >= n * stride_bytes or the total
+ * fits). */
+int tracyhip_pack_ragged(tracyhip_ctx* ctx, const void* src, uint64_t stride_bytes, const uint64_t* src_offset, uint32_t elem_bytes,
+                         const uint32_t* lens, uint32_t lens_stride, uint32_t n, void* dst, uint64_t dst_cap, uint64_t* total_bytes);
 
 /* ---- kernel timing (HIP events recorded on the context's stream around each DP / walker launch) ---
  * The reference has only the optional gperftools wrapper (sage.h:60-62); this is the hook bench.py uses

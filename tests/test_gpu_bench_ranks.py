@@ -29,7 +29,10 @@ def test_two_ranks_headline_line():
     assert line["scaling"] == "weak" and line["config"]["traces_per_gpu"] == 384
     assert line["traces_per_s"] > 0 and line["value"] > 0
     r = line["roofline"]
-    assert r["bound"] == "valu" and r["frac"] > 0 and r["hbm"]["achieved"] > 0 and "traffic" in r
+    assert r["bound"] == "valu" and r["frac"] > 0 and r["hbm_achieved_gbs"] > 0 and "traffic" in r and r["dominant_kernel_alone_frac"] > 0
+    # both halves of the gather ran in the timed steps: 9 int32 per trace + the traceback strings of BOTH ranks reached rank 0, its own block checked
+    assert line["gather_checked"] is True and line["gathered_bytes_per_step"] > 2 * 384 * (9 * 4 + 900)
+    assert len(json.dumps(line)) < 8000
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
     assert line["parity_checked"]["bit_identical"] is True
@@ -46,3 +49,5 @@ def test_two_ranks_decompose_leg_shards_one_job():
     assert line["pipeline"]["stream_ordered"] == 1
     assert line["cpu_baseline"]["value"] > 0 and line["parity_checked"]["bit_identical"] is True
     assert line["roofline"]["bound"] in ("valu", "hbm")
+    # records + three traceback strings + rewritten basecalls + secDecompose + decomposition tables of both ranks
+    assert line["gather_checked"] is True and line["gathered_bytes_per_step"] > 600 * (32 * 4 + 3 * 1000 + 3 * 900)

@@ -30,9 +30,11 @@ def rank_env():
 def test_bench_rank_under_a_torchrun_environment_uses_nccl():
     for args, check in (
         (["--workload", "align", "--traces", "512", "--ref-len", "3000", "--steps", "2", "--warmup", "1", "--cpu-sample", "8", "--lanes-leg", "0", "--certificate-leg", "0"],
-         lambda ln: ln["config"]["traces_per_gpu"] == 512 and ln["value"] > 0 and ln["config"]["gcups_swept_cells"] > 0),
+         lambda ln: ln["config"]["traces_per_gpu"] == 512 and ln["value"] > 0 and ln["config"]["gcups_swept_cells"] > 0 and ln["gather_checked"] is True
+         and ln["gathered_bytes_per_step"] > 512 * 900),
         (["--workload", "decompose", "--decompose-traces", "400", "--decompose-steps", "2", "--extra-legs", "0", "--cpu-sample", "0"],
-         lambda ln: ln["config"]["traces_total"] == 400 and ln["pipeline"]["traces_per_rank"] == 400),
+         lambda ln: ln["config"]["traces_total"] == 400 and ln["pipeline"]["traces_per_rank"] == 400 and ln["gather_checked"] is True
+         and ln["gathered_bytes_per_step"] > 400 * 5000),
         (["--workload", "allpairs", "--allpairs-traces", "64", "--allpairs-steps", "1", "--cpu-sample", "0"], lambda ln: ln["value"] > 0),
     ):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, capture_output=True, text=True, env=rank_env(), timeout=900, cwd=ROOT)
@@ -64,6 +66,24 @@ assert torch.equal(d2, data) and torch.equal(l2, lens)
 lengths = np.array([900, 700, 800, 650, 720], dtype=np.uint32)
 i1, i2, b = shard.pair_slice(lengths, 0, 1)
 local = torch.arange(len(i1), dtype=torch.int32, device="cuda")
+# both halves of the result gather on CUDA tensors: tracyhip_pack_ragged packs, RCCL ships
+import tracy_amd
+ctx = tracy_amd.Context(0)
+ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+n, cap = 5, 64
+lens_h = [3, 0, 64, 17, 1]
+buf = torch.arange(n * cap, dtype=torch.int64, device="cuda").to(torch.uint8)
+recs = torch.tensor([[7 * i, lens_h[i]] for i in range(n)], dtype=torch.int32, device="cuda")
+g = shard.ResultGather(dist, [n], ctx)
+allrec, got = g.gather(recs, [(buf, cap, 1)])
+want = torch.cat([buf[i * cap:i * cap + lens_h[i]] for i in range(n)])
+assert torch.equal(allrec, recs) and torch.equal(got[0], want) and g.bytes_last == 8 * n + sum(lens_h)
+assert g.check_own_block(allrec, got, recs, [(buf, cap, 1)])
+tab = torch.arange(n * 4, dtype=torch.int32, device="cuda")
+rows = torch.tensor([[0, 4, 2, 1, 3][i] for i in range(n)], dtype=torch.int32, device="cuda").reshape(n, 1)
+p4, nb = ctx.pack_ragged(tab, 4, rows)
+assert nb == 40 and torch.equal(p4.view(torch.int32), torch.cat([tab[i * 4:i * 4 + int(rows[i])] for i in range(n)]))
+ctx.close()
 allv = shard.all_gather_slices(dist, local, b)
 assert torch.equal(allv, local)
 t = torch.tensor([1.5, 2.0], dtype=torch.float64, device="cuda")

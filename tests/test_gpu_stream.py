@@ -80,6 +80,38 @@ def test_align_failing_certificates_fall_back_per_trace(ctx, exact, quads):
         assert a["btr"][i] == w["btr"], (i, cs[i][2])
 
 
+def test_two_different_batches_back_to_back_with_tier_lists(ctx):
+    """with lists on, a tier visits only the units the tier before left: the slots of the others must not keep a verdict of the call
+    before.  Two different batches, one after the other on one context, lists and the narrow tier forced; each equals the host-planned
+    pipeline's result and a fresh context's"""
+    import tracy_amd
+    from tracy_amd import hostlib
+    from test_gpu_front import cases
+    rng = np.random.default_rng(78)
+    cs = cases(rng)
+    batch_a = ([c[0] for c in cs], [c[1] for c in cs])                    # certificates of every kind fail for some units
+    refs, profs, rev = hostlib.synth_align(131, len(cs), 3500, 900, 2)  # every unit certifies in the first tier
+    batch_b = (list(profs), [r.tobytes() for r in refs])
+    ctx.set_option("quad_tier_min", 0)
+    ctx.set_option("front_list_min", 1)
+    try:
+        got = [ctx.align_traces(p_, w_, SC, 50, 50) for p_, w_ in (batch_a, batch_b, batch_a)]
+    finally:
+        ctx.set_option("quad_tier_min", 32768)
+        ctx.set_option("front_list_min", 1024)
+    ctx.set_option("no_stream", 1)
+    want = [ctx.align_traces(p_, w_, SC, 50, 50) for p_, w_ in (batch_a, batch_b)]
+    ctx.set_option("no_stream", 0)
+    same_align(got[0], want[0], True, "first batch")
+    same_align(got[1], want[1], True, "second batch, after a different one")
+    same_align(got[2], want[0], True, "first batch again")
+    fresh = tracy_amd.Context(0)
+    fresh.set_option("quad_tier_min", 0)
+    fresh.set_option("front_list_min", 1)
+    same_align(fresh.align_traces(batch_b[0], batch_b[1], SC, 50, 50), got[1], True, "fresh context")
+    fresh.close()
+
+
 def test_align_stream_with_device_buffers_and_lanes(ctx):
     """device-resident inputs and results (what bench.py times), one and two lanes"""
     from tracy_amd import hostlib

@@ -64,11 +64,16 @@ def test_decompose_output_files(tmp_path, reverse, kind):
     from bcf_reader import read_bcf
     header, brecs, blocks = read_bcf(prefix + ".bcf")
     vcf_lines = open(prefix + ".vcf").read().split("\n")
-    assert header == "\n".join(ln for ln in vcf_lines if ln.startswith("#")) + "\n"
+    # (the BCF header carries htslib's IDX keys: the dictionary index of every FILTER / INFO / FORMAT / contig line, PASS = 0)
+    import re
+    assert re.sub(r",IDX=\d+>", ">", header) == "\n".join(ln for ln in vcf_lines if ln.startswith("#")) + "\n"
+    idx = [(ln.split("<ID=")[1].split(",")[0], int(re.search(r",IDX=(\d+)>$", ln).group(1))) for ln in header.split("\n") if re.match(r"##(FILTER|INFO|FORMAT)=<", ln)]
+    assert idx == [("PASS", 0), ("LowQual", 1), ("BASEPOS", 2), ("SIGNALPOS", 3), ("TYPE", 4), ("METHOD", 5), ("GT", 6), ("GQ", 7)]
+    assert [int(re.search(r",IDX=(\d+)>$", ln).group(1)) for ln in header.split("\n") if ln.startswith("##contig=<")] == list(range(sum(ln.startswith("##contig=<") for ln in header.split("\n"))))
     assert blocks >= 2 and len(brecs) == len(recs)
     for b, r in zip(brecs, recs):
         info = dict(kv.split("=", 1) for kv in r[7].split(";"))
-        assert (b["CHROM"], b["POS"], b["ID"], b["REF"], b["ALT"], b["FILTER"]) == (r[0], int(r[1]), r[2], r[3], r[4], r[6])
+        assert (b["CHROM"], b["POS"], b["ID"] or ".", b["REF"], b["ALT"], b["FILTER"]) == (r[0], int(r[1]), r[2], r[3], r[4], r[6])  # (an id of "." is stored as missing)
         assert b["QUAL"] == float(r[5])
         assert (b["INFO"]["TYPE"], b["INFO"]["METHOD"], b["INFO"]["BASEPOS"], b["INFO"]["SIGNALPOS"]) == (info["TYPE"], info["METHOD"], int(info["BASEPOS"]), int(info["SIGNALPOS"]))
         assert r[8] == "GT:GQ" and (b["GT"], b["GQ"]) == (r[9].split(":")[0], int(r[9].split(":")[1]))

@@ -71,6 +71,58 @@ def test_two_rank_shard_and_gather():
     assert ret["lens"] == [len(o) for o in ops]
 
 
+# ---- both halves of the final gather as bench.py's steps run them (ResultGather): records in one collective, the ragged payloads -- two
+# kinds here, bytes and int32 rows -- packed per rank and shipped in one exchange sized from the records' length columns ----
+def _result_worker(rank, world, port, n, ret):
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tracy_amd.shard import ResultGather, shard_range, unpack_ragged
+    qs, refs = _make_batch(n)
+    lo, hi = shard_range(n, rank, world)
+    recs, ops = _align(qs[lo:hi], refs[lo:hi])
+    nl, cap, tcap = hi - lo, 300, 7
+    buf = torch.zeros(nl * cap, dtype=torch.uint8)        # traceback strings in fixed-capacity regions (ops_offset[i] = i * cap)
+    tab = torch.full((nl * tcap,), -1, dtype=torch.int32)  # a table of int32 rows per trace (the decomposition table's shape)
+    rec = torch.zeros((nl, 4), dtype=torch.int32)
+    for i, ((sc, ln), o) in enumerate(zip(recs, ops)):
+        buf[i * cap:i * cap + ln] = torch.from_numpy(np.frombuffer(o, dtype=np.uint8).copy())
+        rows = (lo + i) % (tcap + 1)
+        tab[i * tcap:i * tcap + rows] = torch.arange(rows, dtype=torch.int32) + 100 * (lo + i)
+        rec[i] = torch.tensor([sc, ln, rows, lo + i], dtype=torch.int32)
+    sizes = [b - a for a, b in (shard_range(n, r, world) for r in range(world))]
+    g = ResultGather(dist, sizes)
+    pay = [(buf, cap, 1), (tab, tcap, 2)]
+    allrec, got = g.gather(rec, pay)
+    if rank == 0:
+        assert g.check_own_block(allrec, got, rec, pay)
+        ret["rec"] = allrec.numpy().tolist()
+        ret["ops"] = unpack_ragged(got[0], allrec[:, 1])
+        ret["tab"] = [np.frombuffer(b, dtype=np.int32).tolist() for b in unpack_ragged(got[1], allrec[:, 2], 4)]
+    else:
+        assert allrec is None and got is None
+    ret["bytes%d" % rank] = g.bytes_last
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_result_gather_both_halves():
+    n = 9
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_result_worker, args=(2, port, n, ret), nprocs=2, join=True)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    qs, refs = _make_batch(n)
+    recs, ops = _align(qs, refs)
+    assert [r[:2] for r in ret["rec"]] == recs and [r[3] for r in ret["rec"]] == list(range(n))
+    assert ret["ops"] == ops  # every trace's string, the second rank's included, as one process computes them
+    assert ret["tab"] == [[100 * i + k for k in range(i % 8)] for i in range(n)]
+    assert ret["bytes0"] + ret["bytes1"] == 16 * n + sum(len(o) for o in ops) + 4 * sum(i % 8 for i in range(n))
+
+
 def test_shard_range_covers_batch():
     from tracy_amd.shard import shard_range
     for n in (0, 1, 7, 8, 100001):

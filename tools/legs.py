@@ -237,6 +237,8 @@ class DecomposeLeg:
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         self.ctx.set_lanes(max(1, lanes))
         self.lib = capi.lib()
+        self.gatherer, self.gathered, self.gathered_bytes = None, None, 0
+        self.bc_len_col = torch.full((nt, 1), mf, dtype=torch.int32, device=dev)
 
     def step(self, dist=None):
         self.t_pri.copy_(self.pri0)  # decomposeAlleles rewrites the basecalls in place: start every step from the originals
@@ -244,12 +246,36 @@ class DecomposeLeg:
         rc = self.lib.tracyhip_decompose_traces(self.ctx._h, C.byref(self.job), C.byref(self.prm), self.capi.MEM_DEVICE, C.byref(self.out))
         if rc != 0:
             raise RuntimeError("tracyhip_decompose_traces: %s" % self.lib.tracyhip_last_error().decode())
-        if dist is not None:  # final gather of the fixed-size result records (RCCL over xGMI)
-            from tracy_amd.shard import gather_records
-            r = self.res
-            rec = torch.stack([r["status"], r["score_trim"], self.keep[0][3], self.keep[1][3], self.keep[2][3]], dim=1)
-            from tracy_amd.shard import shard_range
-            gather_records(dist, rec, dst=0, sizes=[b - a for a, b in (shard_range(self.total, r_, self.world) for r_ in range(self.world))])
+        if dist is not None:
+            # the final gather, both halves: one fixed-size record per trace in one collective, then what has no fixed size --
+            # the three traceback strings, the rewritten basecalls, bc.secDecompose, the decomposition table -- packed on the device and
+            # shipped in one exchange sized from the records' length columns
+            if self.gatherer is None or self.gatherer.dist is not dist:
+                from tracy_amd.shard import ResultGather, shard_range
+                self.gatherer = ResultGather(dist, [b - a for a, b in (shard_range(self.total, r_, self.world) for r_ in range(self.world))], self.ctx)
+            rec, pay = self.result_records()
+            self.gathered = self.gatherer.gather(rec, pay)
+            self.gathered_bytes = self.gatherer.bytes_last
+
+    REC_COLS = ("status", "score_trim", "score_fwd", "score_rev", "forward", "score0", "score1", "score2", "ops_len0", "ops_len1", "ops_len2", "slice_begin0",
+                "slice_len0", "ref_pos0", "slice_begin1", "slice_len1", "ref_pos1", "bc_len", "bp.indelshift", "bp.traceleft", "bp.breakpoint", "bp.best_diff",
+                "ds.kind", "ds.best_ins", "ds.best_del", "ds.best_fr", "ds.dcp_n", "ds.pad", "af0.lo", "af0.hi", "af1.lo", "af1.hi")
+
+    def result_records(self):
+        """this rank's results as (int32 record per trace, ragged payloads [(buffer, stride in elements, record column of its length)])"""
+        r, nt, mf = self.res, self.nt, self.mf
+        n = self.job.ntraces
+        col = lambda t: t[:n].reshape(n, 1)  # noqa: E731
+        parts = [col(r["status"]), col(r["score_trim"]), col(r["score_fwd"]), col(r["score_rev"]), col(r["forward"]).to(torch.int32)]
+        parts += [col(self.keep[k][3]) for k in range(3)] + [col(self.keep[k][2]) for k in range(3)]
+        parts += [col(r["%s%d" % (nm, k)]) for k in range(2) for nm in ("slice_begin", "slice_len", "ref_pos")]
+        parts += [self.bc_len_col[:n], r["bp"].view(nt, 4)[:n], r["dstatus"].view(nt, 6)[:n], r["fractions"].view(torch.int32).view(nt, 4)[:n]]
+        rec = torch.cat(parts, dim=1).contiguous()
+        C_ = self.REC_COLS.index
+        pay = [(self.keep[k][1], self.keep[k][4], C_("ops_len%d" % k)) for k in range(3)]
+        pay += [(self.t_pri, mf, C_("bc_len")), (self.t_sec, mf, C_("bc_len")), (r["secdecomp"], mf, C_("bc_len")),
+                (r["dcp_indel"], self.cap, C_("ds.dcp_n")), (r["dcp_err"], self.cap, C_("ds.dcp_n"))]
+        return rec, pay
 
     def cells(self):
         mt = self.mf - 100
@@ -265,15 +291,34 @@ class DecomposeLeg:
             return None
         self.job.ntraces = small
         self.job.bc.ntraces = small
+        from tracy_amd.shard import ResultGather
+
+        class _Solo:  # (the shard has no peer on this box: records and payloads are built and packed as its rank would, nothing is sent)
+            def __init__(self, ctx):
+                self.g = ResultGather(None, [small], ctx)
+
+            def pack(self, rec, pay):
+                flat = rec.reshape(-1)
+                return sum(self.g._pack(k, buf, stride, flat[col:], int(rec.shape[1]), small)[1] for k, (buf, stride, col) in enumerate(pay))
+        solo = _Solo(self.ctx)
+
+        def shard_step():
+            self.step(None)
+            return solo.pack(*self.result_records())
         try:
             for _ in range(2):
-                self.step(None)
+                shard_step()
             torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                packed_bytes = shard_step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
             t0 = time.perf_counter()
             for _ in range(steps):
                 self.step(None)
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
+            dt_call = (time.perf_counter() - t0) / steps
             st = self.ctx.last_call_stats()
             # the same call cut into two chunks on two streams (tracyhip_set_lanes): one chunk's chain of short launches beside the other's
             self.ctx.set_lanes(2)
@@ -289,7 +334,8 @@ class DecomposeLeg:
             self.ctx.set_lanes(1)
             self.job.ntraces = nt
             self.job.bc.ntraces = nt
-        return {"traces": small, "ms_per_step": round(dt * 1e3, 3), "traces_per_s": round(small / dt, 1), "steps": steps,
+        return {"traces": small, "ms_per_step": round(dt * 1e3, 3), "ms_per_call_without_packing": round(dt_call * 1e3, 3), "packed_bytes": int(packed_bytes),
+                "traces_per_s": round(small / dt, 1), "steps": steps,
                 "stream_ordered": st["stream_ordered"], "host_syncs": st["host_syncs"], "fallback_traces": st["fallback_traces"],
                 "two_lanes_ms_per_step": round(dt2 * 1e3, 3)}
 
@@ -323,7 +369,15 @@ class DecomposeLeg:
             dt_both = 0.0
         dt, dt_cert, dt_lanes, dt_both = max_over_ranks(dist, dev, [dt, dt_cert, dt_lanes, dt_both])
         (dt_min,) = min_over_ranks(dist, dev, [dt_rank])
-        cells_all, ok_all, nt_all = sum_over_ranks(dist, dev, [float(cells), float(ok_traces), float(self.nt)])
+        cells_all, ok_all, nt_all, gbytes_all = sum_over_ranks(dist, dev, [float(cells), float(ok_traces), float(self.nt), float(self.gathered_bytes)])
+        gather_ok = None
+        if self.rank == 0 and self.gathered is not None and self.gathered[0] is not None:
+            self.step(dist)  # (the extra legs above ran other modes: one more headline step, whose gather is checked)
+            rec, pay = self.result_records()
+            gather_ok = self.gatherer.check_own_block(self.gathered[0], self.gathered[1], rec, pay)
+        elif dist is not None and self.world > 1:
+            self.step(dist)
+        self.gathered = None
         if self.rank != 0:
             return None
         tot_ms = sum(timers[k]["ms"] for k, _ in TIMERS)
@@ -356,7 +410,7 @@ class DecomposeLeg:
                 "config": {"workload": "configs[2]: %d synthetic %d-base traces `decompose` vs %d-base windows (80%% het indel + het SNVs, 10%% homozygous "
                                        "indel, 10%% no variant, both strands), sharded over %d rank(s)" % (int(nt_all), self.mf, self.n, self.world),
                            "traces_total": int(nt_all), "trace_len": self.mf, "ref_len": self.n},
-                "traces_ok": int(ok_all), "data": "synthetic", "synthesis_s": round(self.synth_s, 1), "roofline": roof,
+                "traces_ok": int(ok_all), "gathered_bytes_per_step": int(gbytes_all), "gather_checked": gather_ok, "data": "synthetic", "synthesis_s": round(self.synth_s, 1), "roofline": roof,
                 # one rank's view of the call: planned on the device, one host synchronisation (stream.hip); min / max over the ranks of a sharded job
                 "pipeline": {"stream_ordered": call_stats["stream_ordered"], "host_syncs_per_call": call_stats["host_syncs"],
                              "traces_to_host_planned_tiers": call_stats["fallback_traces"], "traces_per_rank": self.nt,
@@ -671,6 +725,7 @@ class SeedExtendLeg:
                 "seed_traces_per_s_per_thread": round(nt_all * steps / seed_s / max(self.threads * self.world, 1), 1),
                 "extend_traces_per_s_per_gpu": round(ok_all / self.world * steps / max(sum(timers[k]["ms"] for k, _ in TIMERS) * 1e-3, 1e-9), 1),
                 "n_gpus_fed_at_this_host": round((nt_all * steps / seed_s) / max(ok_all / self.world * steps / max(sum(timers[k]["ms"] for k, _ in TIMERS) * 1e-3, 1e-9), 1e-9), 2),
+                "host_threads_needed_to_feed_one_gpu": round(max(ok_all / self.world * steps / max(sum(timers[k]["ms"] for k, _ in TIMERS) * 1e-3, 1e-9), 1e-9) / max(nt_all * steps / seed_s / max(self.threads * self.world, 1), 1e-9), 1),
                 "extend_ms_not_hidden_per_step": round(ext_s / steps * 1e3, 2), "extend_kernel_gcups": round(cells_all * steps / max(sum(timers[k]["ms"] for k in ("score", "trace", "band", "walk")) * 1e-3, 1e-9) / 1e9, 1), "host_threads_per_rank": self.threads, "index_build_and_map_s": round(self.index_s, 2), "index_file_mb": round(self.index_bytes / 1e6, 1),
                 "index": "built once (rank 0), written with GenomeIndex::save, mapped read-only by every rank",
                 "anchored": int(ok_all), "traces": int(nt_all), "placed_within_60bp_of_truth": int(placed_all),

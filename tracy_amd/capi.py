@@ -362,6 +362,26 @@ def _align_traces_async(self, job, prm, out, mem=MEM_DEVICE):
 Context.align_traces_async = _align_traces_async
 
 
+def _pack_ragged(self, src, stride, lens, n=None, lens_stride=1, out=None):
+    """tracyhip_pack_ragged on torch CUDA tensors: region i = `stride` ELEMENTS of `src` from i * stride, of which the first
+    lens[i * lens_stride] are used (lens: uint32 / int32 tensor).  Returns (packed uint8 tensor, bytes); `out`: a uint8 tensor of at
+    least n * stride * itemsize bytes to pack into (kept by a caller that packs every step)."""
+    import torch
+    elem = src.element_size()
+    if n is None:
+        n = int(lens.numel()) // lens_stride
+    cap = int(n) * int(stride) * elem
+    if out is None or out.numel() < cap:
+        out = torch.empty(max(cap, 1), dtype=torch.uint8, device=src.device)
+    tot = C.c_uint64(0)
+    _check(lib().tracyhip_pack_ragged(self._h, C.c_void_p(src.data_ptr()), C.c_uint64(int(stride) * elem), None, C.c_uint32(elem), C.c_void_p(lens.data_ptr()),
+                                      C.c_uint32(lens_stride), C.c_uint32(int(n)), C.c_void_p(out.data_ptr()), C.c_uint64(out.numel()), C.byref(tot)))
+    return out[:tot.value], int(tot.value)
+
+
+Context.pack_ragged = _pack_ragged
+
+
 def pair_bounds(len1, len2, idx1, idx2, parts):
     """tracyhip_pair_bounds: boundaries of `parts` contiguous slices of a pair list with (nearly) equal DP cell count.
     Pure host arithmetic inside the library (works without a GPU) -- the one rule used by device groups and by rank sharding."""

@@ -1216,7 +1216,7 @@ void write_decompose_outputs(SageConfig const& c, Job& j) {
     vcfTextOutput(f, rc, bc, r.var, j.rs, j.rs.filetype == 0 ? &contigs : nullptr);
     f.write(j.outprefix + ".vcf");
     // ... and as the reference writes them: <prefix>.bcf (BGZF + BCF2.2 without htslib, bcf_out.hpp; no .csi index)
-    bcfOutput(j.outprefix + ".bcf", rc, bc, r.var, j.rs, j.rs.filetype == 0 ? &contigs : nullptr);
+    if (!bcfOutput(j.outprefix + ".bcf", rc, bc, r.var, j.rs, j.rs.filetype == 0 ? &contigs : nullptr)) ++TextBuf::write_errors();  // (a deflate failure writes nothing: counted like a file that could not be written)
   }
   pc.lap(CpuPhases::PAD);
   TextBuf f(1 << 20);

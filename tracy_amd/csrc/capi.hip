@@ -265,7 +265,7 @@ const KnobField kKnobFlags[] = {
     {"no_screen", &CtxKnobs::no_screen}, {"no_band", &CtxKnobs::no_band}, {"no_band16", &CtxKnobs::no_band16},
     {"no_front", &CtxKnobs::no_front}, {"no_prefix", &CtxKnobs::no_prefix}, {"no_vote", &CtxKnobs::no_vote},
     {"no_origin", &CtxKnobs::no_origin}, {"no_subwindow", &CtxKnobs::no_subwindow}, {"no_prelim_origin", &CtxKnobs::no_prelim_origin},
-    {"no_cq", &CtxKnobs::no_cq}, {"no_fused_walk", &CtxKnobs::no_fused_walk}, {"no_cont16", &CtxKnobs::no_cont16}, {"no_decomp_wave", &CtxKnobs::no_decomp_wave}, {"no_af_split", &CtxKnobs::no_af_split}, {"no_front_lists", &CtxKnobs::no_front_lists}, {"no_origin_band", &CtxKnobs::no_origin_band}, {"no_quads", &CtxKnobs::no_quads}, {"no_fork", &CtxKnobs::no_fork}, {"verbose", &CtxKnobs::verbose}};
+    {"no_cq", &CtxKnobs::no_cq}, {"no_fused_walk", &CtxKnobs::no_fused_walk}, {"no_cont16", &CtxKnobs::no_cont16}, {"no_decomp_wave", &CtxKnobs::no_decomp_wave}, {"no_af_split", &CtxKnobs::no_af_split}, {"no_front_lists", &CtxKnobs::no_front_lists}, {"no_origin_band", &CtxKnobs::no_origin_band}, {"no_quads", &CtxKnobs::no_quads}, {"no_fork", &CtxKnobs::no_fork}, {"sweeps_alone", &CtxKnobs::sweeps_alone}, {"verbose", &CtxKnobs::verbose}};
 bool same_name(const char* a, const char* b) {
   for (; *a && *b; ++a, ++b)
     if (std::tolower((unsigned char)*a) != std::tolower((unsigned char)*b)) return false;
@@ -1445,7 +1445,8 @@ int tracyhip_set_stream(tracyhip_ctx* c, void* s) {
 int tracyhip_set_workspace_limit(tracyhip_ctx* c, uint64_t bytes) {
   if (!c) return set_error(TRACYHIP_ERR_ARG, "null context");
   c->ws_limit = bytes;
-  for (auto* l : c->lanes) l->ws_limit = bytes;
+  c->ws_cache_budget = 0;  // (stream.hip workspace_budget: a kept answer belongs to the setting it was made under)
+  for (auto* l : c->lanes) { l->ws_limit = bytes; l->ws_cache_budget = 0; }
   return TRACYHIP_OK;
 }
 

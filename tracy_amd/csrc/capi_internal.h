@@ -56,6 +56,9 @@ struct CtxKnobs {
   bool no_fused_walk = false;     // a separate walk launch after a traceback sweep
   bool no_quads = false;          // stream-ordered pipelines: narrow bands on sixteen lanes per pair like the rest (band16.h b16_narrow_ok)
   bool no_fork = false;           // stream-ordered pipelines: the launches of a band stage in a row on the call's stream instead of side by side
+  bool sweeps_alone = false;      // MEASUREMENT mode of the stream-ordered orientation stage: the voted strand's chain finishes BEFORE the other strand's full sweeps
+                                  // start and its prefix cells are credited to the front timer -- TRACYHIP_TIMER_SCORE then times the full sweeps on a device
+                                  // of their own (bench.py roofline.dominant_kernel_alone_frac); slower, same results
   bool no_origin_band = false;    // `tracy decompose`, gotoh(allele, slice): the band d1 +- (g + 1) of every co-optimal path instead of the g + 3 diagonals of the walked one
   bool no_front_lists = false;    // pruned sweeps: later tiers skip what an earlier one certified in place instead of running over a list of the rest
   bool no_af_split = false;       // allelicFraction by the one-launch kernel (tp / cls in LDS, every grid point screened) instead of prepare + search

@@ -604,16 +604,36 @@ bool stream_options_ok(const CtxKnobs& k) {
 }
 
 // workspace one context may plan with (run_dp's rule): the caller's limit, or its share of what is free plus what it holds
-int workspace_budget(tracyhip_ctx* ctx, uint64_t held, uint64_t* out) {
+int workspace_budget(tracyhip_ctx* ctx, uint64_t held, uint64_t* out, bool* from_cache = nullptr) {
+  if (from_cache) *from_cache = false;
   if (ctx->ws_limit) { *out = ctx->ws_limit; return TRACYHIP_OK; }
   // (hipMemGetInfo is a driver round trip, paid while the device waits for the call to be planned: the answer is kept for as long as
-  // the context holds what it held when it asked -- a call of the same shape as the last one)
-  if (ctx->ws_cache_budget && ctx->ws_cache_held == held && ctx->ws_cache_share == ctx->mem_share) { *out = ctx->ws_cache_budget; return TRACYHIP_OK; }
+  // the context holds what it held when it asked -- a call of the same shape as the last one.  Free memory can shrink behind the
+  // context's back -- another allocator in the process, another process: a plan made from a kept answer whose allocations fail is
+  // made again from a fresh one, with_fresh_budget below)
+  if (ctx->ws_cache_budget && ctx->ws_cache_held == held && ctx->ws_cache_share == ctx->mem_share) {
+    *out = ctx->ws_cache_budget;
+    if (from_cache) *from_cache = true;
+    return TRACYHIP_OK;
+  }
   size_t fr = 0, tot = 0;
   HIP_TRY(hipMemGetInfo(&fr, &tot));
   *out = (uint64_t)(fr * 0.70 / ctx->mem_share) + held;
   ctx->ws_cache_budget = *out; ctx->ws_cache_held = held; ctx->ws_cache_share = ctx->mem_share;
   return TRACYHIP_OK;
+}
+// plan(&from_cache) sizes and allocates a call's workspace from workspace_budget's answer: when the answer was a kept one and an
+// allocation fails, the kept answer is dropped and the plan is made once more from what the driver says is free now
+template <class Plan>
+int with_fresh_budget(tracyhip_ctx* ctx, Plan plan) {
+  bool from_cache = false;
+  int rc = plan(&from_cache);
+  if (rc == TRACYHIP_ERR_OOM && from_cache) {
+    (void)hipGetLastError();  // (the failed allocation's sticky error)
+    ctx->ws_cache_budget = 0;
+    rc = plan(&from_cache);
+  }
+  return rc;
 }
 
 DpArgs sweep_args(tracyhip_ctx* ctx, const tracyhip_params& p, const void* d_a1, const void* d_a2, int32_t* d_scores, int32_t* d_lastrow) {
@@ -676,17 +696,22 @@ __device__ __forceinline__ void s_list_append(bool take, uint32_t i, uint32_t* _
   for (uint32_t k = 0; k < wv; ++k) at += wave_n[k];
   list[at] = i;
 }
-__global__ __launch_bounds__(256) void s_front_list_kernel(uint32_t n, const FrontOut* __restrict__ prev, uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+// (a unit left off the list is not visited by the next tier's place / band / certify launches: its slot of that tier is marked "not
+// certified here" explicitly -- consumers read the earlier tier's verdict first, but the slot must not keep a verdict of another call)
+__global__ __launch_bounds__(256) void s_front_list_kernel(uint32_t n, const FrontOut* __restrict__ prev, uint32_t* __restrict__ list, uint32_t* __restrict__ count,
+                                                           FrontOut* __restrict__ next) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  s_list_append(i < n && !prev[i].ok, i, list, count);
+  const bool take = i < n && !prev[i].ok;
+  if (i < n && !take) next[i].ok = 0u;
+  s_list_append(take, i, list, count);
 }
 // ... and the pairs of a launch that take part in it (a prefix launch whose pairs partly share their kept rows: s_allele_plan0_kernel)
 __global__ __launch_bounds__(256) void s_pair_list_kernel(uint32_t n, const PairDesc* __restrict__ pairs, uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   s_list_append(i < n && !(pairs[i].flags & PAIR_SKIP), i, list, count);
 }
-hipError_t front_list(tracyhip_ctx* ctx, uint32_t n, const FrontOut* prev, uint32_t* list, uint32_t* count) {
-  hipLaunchKernelGGL(s_front_list_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, prev, list, count);
+hipError_t front_list(tracyhip_ctx* ctx, uint32_t n, const FrontOut* prev, uint32_t* list, uint32_t* count, FrontOut* next) {
+  hipLaunchKernelGGL(s_front_list_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, prev, list, count, next);
   return hipGetLastError();
 }
 
@@ -706,7 +731,7 @@ int front_tiers_run_wide(tracyhip_ctx* ctx, const tracyhip_params& p, StreamComm
   const bool lists = !ctx->knobs.no_front_lists && n >= ctx->knobs.front_list_min;
   if (lists) HIP_TRY(hipMemsetAsync(sc.fcount, 0, 2 * sizeof(uint32_t), ctx->stream));
   const bool list1 = lists && after_quads;
-  if (list1) HIP_TRY(front_list(ctx, n, sc.fo0, sc.flist, sc.fcount));
+  if (list1) HIP_TRY(front_list(ctx, n, sc.fo0, sc.flist, sc.fcount, sc.fo1));  // (what the quads certified is folded into fo1 below)
   int rc = front_tier(ctx, p, sc.fd, n, d_qp, d_codes, d_row, 8, 60, max_rest, sc.fpairs1, sc.fo1, sc.fs1, sc.fe1, after_quads ? sc.fo0 : nullptr,
                       list1 ? sc.flist : nullptr, list1 ? sc.fcount : nullptr);
   if (rc) return rc;
@@ -715,7 +740,7 @@ int front_tiers_run_wide(tracyhip_ctx* ctx, const tracyhip_params& p, StreamComm
     HIP_TRY(hipGetLastError());
   }
   // (the first list has been read by the tier above: the same array holds the second)
-  if (lists) HIP_TRY(front_list(ctx, n, sc.fo1, sc.flist, sc.fcount + 1));
+  if (lists) HIP_TRY(front_list(ctx, n, sc.fo1, sc.flist, sc.fcount + 1, sc.fo2));
   return front_tier(ctx, p, sc.fd, n, d_qp, d_codes, d_row, kFrontK, kFrontHalfW, max_rest, sc.fpairs2, sc.fo2, sc.fs2, sc.fe2, sc.fo1,
                     lists ? sc.flist : nullptr, lists ? sc.fcount + 1 : nullptr);
 }
@@ -865,6 +890,7 @@ int queue_orientation(tracyhip_ctx* ctx, const tracyhip_params& p, const SParams
       HIP_TRY(hipStreamWaitEvent(st, fk.joined[0], 0));
       return rc;
     }
+    if (ctx->knobs.sweeps_alone) HIP_TRY(hipStreamWaitEvent(st, fk.joined[0], 0));  // (measurement: the full sweeps on a device of their own)
     auto sweeps = [&]() -> int {
       for (const SweepClass& c : h.classes) {
         DpArgs af = a;
@@ -1091,15 +1117,19 @@ int tracyhip::stream_align(tracyhip_ctx* ctx, const tracyhip_align_job* job, con
   Arena sizing;
   AlignArena A;
   A.layout(sizing, nt, exact, host_results, ops_bound);
-  uint64_t budget = 0;
-  TRY(workspace_budget(ctx, ctx->d_lastrow.cap + ctx->d_bits.cap + ctx->d_stream.cap + ctx->d_b16tab[2].cap, &budget));
-  const uint64_t fixed = h.lr_tot * 4 + 64 + h.tab_tot * 2 + 64 + sizing.off;
-  if (fixed > budget) return kStreamNo;
-  const uint64_t words_cap = band_words_cap(rows_total, nt, budget - fixed);
-  HIP_TRY(ctx->d_lastrow.ensure(h.lr_tot * 4 + 64));
-  HIP_TRY(ctx->d_b16tab[2].ensure(h.tab_tot * sizeof(int16_t) + 64));
-  HIP_TRY(ctx->d_bits.ensure(words_cap + 64));
-  HIP_TRY(ctx->d_stream.ensure(sizing.off + 256));
+  uint64_t words_cap = 0;
+  TRY(with_fresh_budget(ctx, [&](bool* from_cache) -> int {
+    uint64_t budget = 0;
+    TRY(workspace_budget(ctx, ctx->d_lastrow.cap + ctx->d_bits.cap + ctx->d_stream.cap + ctx->d_b16tab[2].cap, &budget, from_cache));
+    const uint64_t fixed = h.lr_tot * 4 + 64 + h.tab_tot * 2 + 64 + sizing.off;
+    if (fixed > budget) return kStreamNo;
+    words_cap = band_words_cap(rows_total, nt, budget - fixed);
+    HIP_TRY(ctx->d_lastrow.ensure(h.lr_tot * 4 + 64));
+    HIP_TRY(ctx->d_b16tab[2].ensure(h.tab_tot * sizeof(int16_t) + 64));
+    HIP_TRY(ctx->d_bits.ensure(words_cap + 64));
+    HIP_TRY(ctx->d_stream.ensure(sizing.off + 256));
+    return TRACYHIP_OK;
+  }));
   Arena arena;
   arena.base = static_cast<char*>(ctx->d_stream.p);
   A.layout(arena, nt, exact, host_results, ops_bound);
@@ -1129,7 +1159,7 @@ int tracyhip::stream_align(tracyhip_ctx* ctx, const tracyhip_align_job* job, con
   SParams spm{};
   spm.match = p.match; spm.mismatch = p.mismatch; spm.go = p.go; spm.ge = p.ge; spm.nt = nt; spm.exact = exact ? 1u : 0u; spm.ncap = ncap - 8u;
   spm.trim_left = job->trim_left; spm.trim_right = job->trim_right; spm.use_votes = 1u;
-  spm.split_prefix = 0u;
+  spm.split_prefix = kn.sweeps_alone ? 1u : 0u;
 
   // ---- 1. orientation (sage.h:239-247) ----
   const int16_t* d_qp = static_cast<const int16_t*>(ctx->d_b16tab[2].p);
@@ -1818,17 +1848,20 @@ struct DecStream {
     for (uint32_t t = 0; t < nt; ++t) rows_traces += h.mt[t];
     Arena sizing;
     A.layout(sizing, z);
-    uint64_t budget = 0;
-    TRY(workspace_budget(ctx, ctx->d_lastrow.cap + ctx->d_bits.cap + ctx->d_stream.cap + ctx->d_b16tab[2].cap + ctx->d_b16tab[0].cap, &budget));
-    const uint64_t lr_words = std::max(h.lr_tot, alr_tot);
-    const uint64_t fixed = lr_words * 4 + 64 + h.tab_tot * 2 + atab_tot * 2 + 128 + sizing.off;
-    if (fixed > budget) return kStreamNo;
-    words_cap = band_words_cap(std::max(rows_traces, rows_alleles), 2ull * nt, budget - fixed);
-    HIP_TRY(ctx->d_lastrow.ensure(lr_words * 4 + 64));
-    HIP_TRY(ctx->d_b16tab[2].ensure(h.tab_tot * sizeof(int16_t) + 64));
-    HIP_TRY(ctx->d_b16tab[0].ensure(atab_tot * sizeof(int16_t) + 64));
-    HIP_TRY(ctx->d_bits.ensure(words_cap + 64));
-    HIP_TRY(ctx->d_stream.ensure(sizing.off + 256));
+    TRY(with_fresh_budget(ctx, [&](bool* from_cache) -> int {
+      uint64_t budget = 0;
+      TRY(workspace_budget(ctx, ctx->d_lastrow.cap + ctx->d_bits.cap + ctx->d_stream.cap + ctx->d_b16tab[2].cap + ctx->d_b16tab[0].cap, &budget, from_cache));
+      const uint64_t lr_words = std::max(h.lr_tot, alr_tot);
+      const uint64_t fixed = lr_words * 4 + 64 + h.tab_tot * 2 + atab_tot * 2 + 128 + sizing.off;
+      if (fixed > budget) return kStreamNo;
+      words_cap = band_words_cap(std::max(rows_traces, rows_alleles), 2ull * nt, budget - fixed);
+      HIP_TRY(ctx->d_lastrow.ensure(lr_words * 4 + 64));
+      HIP_TRY(ctx->d_b16tab[2].ensure(h.tab_tot * sizeof(int16_t) + 64));
+      HIP_TRY(ctx->d_b16tab[0].ensure(atab_tot * sizeof(int16_t) + 64));
+      HIP_TRY(ctx->d_bits.ensure(words_cap + 64));
+      HIP_TRY(ctx->d_stream.ensure(sizing.off + 256));
+      return TRACYHIP_OK;
+    }));
     Arena arena;
     arena.base = static_cast<char*>(ctx->d_stream.p);
     A.layout(arena, z);
@@ -1894,7 +1927,7 @@ struct DecStream {
 
     spm.match = p.match; spm.mismatch = p.mismatch; spm.go = p.go; spm.ge = p.ge; spm.nt = nt; spm.exact = exact ? 1u : 0u; spm.ncap = ncap - 8u;
     spm.trim_left = TL; spm.trim_right = TR; spm.use_votes = 1u;
-    spm.split_prefix = 0u;
+    spm.split_prefix = kn.sweeps_alone ? 1u : 0u;
     spd.bext = z.bext;
     spd.best = (int32_t)std::max<int64_t>(std::max<int64_t>(p.match, p.mismatch), 0);
 

@@ -91,6 +91,32 @@ inline bool bcfOutput(std::string const& outfile, ReportConfig const& c, BaseCal
     vcfTextOutput(os, c, bc, std::vector<Variant>(), rs, contigs);
     text = os.str();
   }
+  // htslib's BCF headers carry the dictionary index of every FILTER / INFO / FORMAT / contig line as a trailing IDX key
+  // (bcf_hdr_format with is_bcf): added here to the VCF writer's lines, in the order that fixes the indices
+  {
+    std::string withidx;
+    int idx_id = 0, idx_ctg = 0;
+    bool pass_seen = false;
+    std::size_t at = 0;
+    while (at < text.size()) {
+      std::size_t nl = text.find('\n', at);
+      if (nl == std::string::npos) nl = text.size();
+      std::string ln = text.substr(at, nl - at);
+      const bool dict = ln.rfind("##FILTER=<", 0) == 0 || ln.rfind("##INFO=<", 0) == 0 || ln.rfind("##FORMAT=<", 0) == 0;
+      const bool ctg = ln.rfind("##contig=<", 0) == 0;
+      if ((dict || ctg) && !ln.empty() && ln.back() == '>') {
+        int idx;
+        if (ctg) idx = idx_ctg++;
+        else if (ln.rfind("##FILTER=<ID=PASS,", 0) == 0) { idx = 0; pass_seen = true; if (idx_id == 0) idx_id = 1; }
+        else { if (idx_id == 0 && !pass_seen) idx_id = 1; idx = idx_id++; }
+        ln.insert(ln.size() - 1, ",IDX=" + std::to_string(idx));
+      }
+      withidx += ln;
+      if (nl < text.size()) withidx.push_back('\n');
+      at = nl + 1;
+    }
+    text.swap(withidx);
+  }
   // dictionary indices follow from the order of the header lines (PASS = 0 by definition)
   enum : int { kPass = 0, kLowQual = 1, kBasepos = 2, kSignalpos = 3, kType = 4, kMethod = 5, kGt = 6, kGq = 7 };
   std::vector<std::string> names;  // contig dictionary, in header order
@@ -121,7 +147,9 @@ inline bool bcfOutput(std::string const& outfile, ReportConfig const& c, BaseCal
     s.le(fbits, 4);
     s.le((2u << 16) | 4u, 4);  // n_allele << 16 | n_info
     s.le((2u << 24) | 1u, 4);  // n_fmt << 24 | n_sample
-    s.string(v.id);
+    // (htslib's bcf1_sync writes an id of "." -- the default of bcf_update_id -- as a missing value, not as a one-character string)
+    if (v.id.empty() || v.id == ".") s.size_type(0, 7);
+    else s.string(v.id);
     s.string(v.ref);
     s.string(v.alt);
     s.size_type(1, 1);         // FILTER: one int8

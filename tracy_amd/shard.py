@@ -68,6 +68,155 @@ def gather_ragged_bytes(dist, data, lengths, dst=0):
     return out, lens.reshape(-1)
 
 
+def pack_ragged(buf, stride, lengths):
+    """Pack the used part of fixed-capacity per-trace regions: trace i owns `stride` elements of `buf` (any dtype) from i * stride and
+    uses the first lengths[i] of them (traceback strings at ops_offset[i] = i * cap; rows of a decomposition table).  Returns the used
+    elements back to back as uint8 (trace order) and the total in BYTES (a Python int: the one host read this costs)."""
+    n = int(lengths.numel())
+    if n == 0:
+        return torch.zeros(0, dtype=torch.uint8, device=buf.device), 0
+    lens = lengths.to(torch.int64)
+    width = int(lens.max().item())
+    rows = buf[:n * stride].view(n, stride)[:, :width]
+    keep = torch.arange(width, device=buf.device)[None, :] < lens[:, None]
+    packed = rows[keep].contiguous().view(torch.uint8)
+    return packed, int(packed.numel())
+
+
+def unpack_ragged(packed, lengths, elem_bytes=1):
+    """the strings pack_ragged / gather_ragged_known deliver, as a list of bytes objects (tests, the parity samples)"""
+    data = packed.cpu().numpy().tobytes()
+    out, at = [], 0
+    for ln in lengths.cpu().numpy().astype("int64").tolist():
+        out.append(data[at:at + ln * elem_bytes])
+        at += ln * elem_bytes
+    return out
+
+
+def gather_ragged_known(dist, packed, totals, dst=0):
+    """Second half of the result gather: variable-length payloads -- traceback strings, rewritten basecalls, decomposition
+    tables -- packed back to back per rank (pack_ragged), to `dst` in rank order.  `totals`: every rank's byte count AS `dst` KNOWS IT
+    from the fixed-size records it gathered first (their length columns); the other ranks pass None and just send.  One grouped
+    point-to-point exchange (RCCL over xGMI: every rank has its own link to `dst`), nothing padded, no size exchange.
+    Returns the concatenation on `dst`, None elsewhere."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    gloo = dist.get_backend() == "gloo"
+    if gloo and packed.is_cuda:
+        packed = packed.cpu()
+    if world == 1:
+        return packed
+    if rank != dst:
+        if packed.numel():
+            dist.send(packed, dst=dst)
+        return None
+    totals = [int(x) for x in totals]
+    if len(totals) != world or totals[dst] != packed.numel():
+        raise ValueError("gather_ragged_known: totals %r do not describe this rank's %d bytes" % (totals, packed.numel()))
+    parts = [packed if r == dst else torch.empty(totals[r], dtype=torch.uint8, device=packed.device) for r in range(world)]
+    ops = [dist.P2POp(dist.irecv, parts[r], r) for r in range(world) if r != dst and totals[r]]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return torch.cat(parts)
+
+
+def gather_payloads(dist, kinds, kind_totals, dst=0):
+    """Several ragged payloads in ONE exchange: `kinds` = this rank's packed uint8 tensors (one per payload kind, in a fixed order),
+    `kind_totals[r][k]` = bytes of kind k on rank r as `dst` knows them (None on the other ranks).  Returns, on `dst`, one tensor per
+    kind holding that kind of every rank in rank order; None elsewhere."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = torch.cat(kinds) if len(kinds) > 1 else kinds[0]
+    if rank != dst:
+        gather_ragged_known(dist, mine, None, dst)
+        return None
+    if world == 1:
+        return list(kinds)
+    allb = gather_ragged_known(dist, mine, [sum(int(x) for x in kt) for kt in kind_totals], dst)
+    per_kind = [[] for _ in kinds]
+    at = 0
+    for r in range(world):
+        for k in range(len(kinds)):
+            n = int(kind_totals[r][k])
+            per_kind[k].append(allb[at:at + n])
+            at += n
+    return [torch.cat(x) for x in per_kind]
+
+
+class ResultGather:
+    """The final gather of a sharded job, both halves: the fixed-size records of every trace to `dst` in ONE collective
+    (gather_records), then the variable-length payloads -- traceback strings, rewritten basecalls, decomposition tables -- packed per
+    rank (tracyhip_pack_ragged on the device) and shipped in ONE grouped exchange whose sizes `dst` reads off the records it has just
+    received (their length columns): no size exchange, nothing padded.
+
+    sizes: traces per rank (shard_range).  ctx: the rank's tracy_amd.Context (packs CUDA tensors; CPU tensors -- the gloo tests --
+    are packed with torch).  After gather(): .bytes_last = bytes this rank contributed (records + payloads)."""
+
+    def __init__(self, dist, sizes, ctx=None, dst=0):
+        self.dist, self.sizes, self.ctx, self.dst = dist, [int(x) for x in sizes], ctx, dst
+        self.scratch = {}
+        self.bytes_last = 0
+
+    def _pack(self, k, buf, stride, lens, lens_stride, n):
+        if buf.is_cuda:
+            if self.ctx is None:
+                raise RuntimeError("ResultGather: CUDA results need the rank's Context (tracyhip_pack_ragged)")
+            out = self.scratch.get(k)
+            need = n * stride * buf.element_size()
+            if out is None or out.numel() < need:
+                out = self.scratch[k] = torch.empty(max(need, 1), dtype=torch.uint8, device=buf.device)
+            return self.ctx.pack_ragged(buf, stride, lens, n=n, lens_stride=lens_stride, out=out)
+        return pack_ragged(buf, stride, lens.reshape(-1)[::lens_stride][:n])
+
+    def gather(self, records, payloads):
+        """records: int32 [n_local, F], contiguous.  payloads: list of (buf, stride_elements, column): trace i uses the first
+        records[i, column] elements of buf[i * stride : (i + 1) * stride].  Returns (records of all ranks, [payload bytes of all ranks per
+        kind]) on dst, (None, None) elsewhere."""
+        dist, dst = self.dist, self.dst
+        rank, world = dist.get_rank(), dist.get_world_size()
+        n, F = int(records.shape[0]), int(records.shape[1])
+        assert records.dtype == torch.int32 and records.is_contiguous()
+        allrec = gather_records(dist, records, dst=dst, sizes=self.sizes)
+        packed = []
+        flat = records.reshape(-1)
+        for k, (buf, stride, col) in enumerate(payloads):
+            packed.append(self._pack(k, buf, stride, flat[col:], F, n)[0])
+        self.bytes_last = records.numel() * 4 + sum(int(x.numel()) for x in packed)
+        if not payloads:
+            return allrec, []
+        totals = None
+        if rank == dst and world > 1:  # bytes per (rank, kind), read off the gathered length columns: the one host read of the gather
+            cols = torch.tensor([c for _, _, c in payloads], device=allrec.device)
+            elem = torch.tensor([b.element_size() for b, _, _ in payloads], dtype=torch.int64, device=allrec.device)
+            lens = allrec[:, cols].to(torch.int64)
+            bounds = [0]
+            for x in self.sizes:
+                bounds.append(bounds[-1] + x)
+            per = torch.stack([lens[bounds[r]:bounds[r + 1]].sum(dim=0) for r in range(world)]) * elem[None, :]
+            totals = per.cpu().tolist()
+        got = gather_payloads(dist, packed, totals, dst)
+        return (allrec, got) if rank == dst else (None, None)
+
+    def check_own_block(self, allrec, got, records, payloads):
+        """on dst, after gather(): the gathered arrays hold every rank's records, this rank's block bit for bit where shard order puts it, and
+        exactly the payload bytes the gathered length columns announce (a cheap in-run check; the other ranks' blocks are compared with
+        single-process results in tests/test_shard_gloo.py and tests/test_gpu_bench_ranks.py)"""
+        rank = self.dist.get_rank()
+        lo = sum(self.sizes[:rank])
+        n = int(records.shape[0])
+        rec = records.cpu() if (records.is_cuda and not allrec.is_cuda) else records
+        ok = int(allrec.shape[0]) == sum(self.sizes) and torch.equal(allrec[lo:lo + n], rec)
+        flat = records.reshape(-1)
+        for k, (buf, stride, col) in enumerate(payloads):
+            elem = buf.element_size()
+            lens_all = allrec[:, col].to(torch.int64)
+            ok = ok and int(got[k].numel()) == int(lens_all.sum().item()) * elem
+            at = int(lens_all[:lo].sum().item()) * elem
+            mine, nb = self._pack(("check", k), buf, stride, flat[col:], int(records.shape[1]), n)
+            mine = mine.cpu() if (mine.is_cuda and not got[k].is_cuda) else mine
+            ok = ok and torch.equal(got[k][at:at + nb], mine)
+        return bool(ok)
+
+
 # ---- all-pairs jobs (`tracy assemble`, msa.h:33-42 distanceMatrix) ---------------------------------------------------
 def pair_bounds(lengths, world):
     """The upper-triangular pair list (i < j, row-major: the order of the two loops of msa.h:33-42) cut into `world`

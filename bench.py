@@ -462,6 +462,9 @@ def main():
         finally:
             ctx.set_option("sweeps_alone", 0)
 
+    if dist is not None:
+        step()  # (the legs above ran other modes: one more headline step, untimed, whose gather is checked below)
+
     # ---- work done: DP cells of the four Gotoh calls per trace ----
     mt = mf - 2 * TRIM
     cells_rank = int(3 * mt * n * nt + (mf * slice_len).sum())

@@ -254,6 +254,13 @@ typedef struct {
   uint8_t* secondary;            /* bc.secondary at secondary + bc_offset[t] (rewritten by decomposeAlleles) */
   const uint64_t* bc_offset;
   const uint32_t* bc_len;        /* bc.consensus.size() */
+  const int32_t* peaks;          /* OPTIONAL (NULL = built on the device from signal + bcpos).  The peak table: the four channels at every
+                                    basecall's peak position, peaks[4 * (bc_offset[t] + i) + k] = traceACGT[k][bcPos[i]] of trace t (payload, host
+                                    or device per `mem`).  Every read of the chromatogram on this path is at a peak position
+                                    (generateSecondaryDecomposed decompose.h:378-410, allelicFraction decompose.h:445-470; createProfile
+                                    profile.h:21-52 on the host), so a caller that has the trace in hand -- the command line, while it basecalls --
+                                    passes 16 bytes per basecall instead of the chromatogram (192 KB per 1 kb trace); signal, signal_offset,
+                                    nsamples and bcpos may then be NULL. */
 } tracyhip_basecalls;
 
 /* the IndigoConfig fields decomposeAlleles reads (indigo.h:16-40; CLI defaults 50, 50, 1000, 5) */
@@ -399,15 +406,25 @@ int tracyhip_pair_bounds(const tracyhip_pairs* pairs, uint32_t parts, uint64_t* 
 
 /* ---- result compaction for the final gather of a sharded job (no counterpart in the reference, which is one process) ----
  * The pipelines write variable-length results (traceback strings, decomposition tables) into fixed-capacity regions the caller lays out
- * (ops_offset[], dcp_offset[]).  Before a rank ships them to the rank that collects the job's results it packs the used parts back to
- * back: region i = bytes [i * stride_bytes, ...) of src -- or from src + src_offset[i] (HOST array, bytes) when src_offset != NULL -- of
- * which the first lens[i * lens_stride] * elem_bytes bytes are used; they go to dst in region order.  src, lens, dst are DEVICE
- * pointers (lens_stride lets a field of a record array serve, e.g. tracyhip_decomp_status::dcp_n: lens = &dstatus[0].dcp_n,
- * lens_stride = 6).  dst == NULL: only the total is computed.  *total_bytes (host) receives the packed size; the call is synchronous.
- * TRACYHIP_ERR_ARG when the total exceeds dst_cap (nothing is written beyond dst_cap when dst_cap >= n * stride_bytes or the total
- * fits). */
-int tracyhip_pack_ragged(tracyhip_ctx* ctx, const void* src, uint64_t stride_bytes, const uint64_t* src_offset, uint32_t elem_bytes,
-                         const uint32_t* lens, uint32_t lens_stride, uint32_t n, void* dst, uint64_t dst_cap, uint64_t* total_bytes);
+ * (ops_offset[t] = t * capacity, dcp_offset[t] = t * (2 maxindel + 2)).  Before a rank ships them to the rank that collects the job's
+ * results it packs the used parts back to back: region i of a payload kind = bytes [i * stride_bytes, (i + 1) * stride_bytes) of src, of
+ * which the first lens[i * lens_stride] * elem_bytes bytes are used (never more than the stride).  src, lens and dst are DEVICE pointers;
+ * lens_stride lets a field of a record array serve (tracyhip_decomp_status::dcp_n: lens = &dstatus[0].dcp_n, lens_stride = 6).
+ * tracyhip_pack_ragged_multi packs up to 16 kinds in one pass, kind-major (all regions of kind 0 in region order, then kind 1, ...) --
+ * one scan, one copy launch, one synchronisation; kind_bytes[k] (HOST) receives the packed size of kind k.  dst == NULL: sizes only.
+ * TRACYHIP_ERR_ARG when the total exceeds dst_cap (nothing is written then; with dst_cap >= the sum of n * stride_bytes the copy is
+ * queued without waiting for the sizes).  Synchronous. */
+typedef struct {
+  const void* src;
+  uint64_t stride_bytes;
+  uint32_t elem_bytes;
+  const uint32_t* lens;
+  uint32_t lens_stride;
+} tracyhip_ragged_src;
+int tracyhip_pack_ragged_multi(tracyhip_ctx* ctx, const tracyhip_ragged_src* kinds, uint32_t nkinds, uint32_t n, void* dst, uint64_t dst_cap,
+                               uint64_t* kind_bytes);
+int tracyhip_pack_ragged(tracyhip_ctx* ctx, const void* src, uint64_t stride_bytes, uint32_t elem_bytes, const uint32_t* lens, uint32_t lens_stride,
+                         uint32_t n, void* dst, uint64_t dst_cap, uint64_t* total_bytes);
 
 /* ---- kernel timing (HIP events recorded on the context's stream around each DP / walker launch) ---
  * The reference has only the optional gperftools wrapper (sage.h:60-62); this is the hook bench.py uses

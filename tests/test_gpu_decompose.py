@@ -470,3 +470,58 @@ def test_allelic_fraction_two_launch_form_vs_oracle_and_one_launch_kernel(ctx):
         assert (float(res[0][i, 0]), float(res[0][i, 1])) == want, (i, res[0][i], want)
         seen.add(want)
     assert len(seen) >= 6 and (0.5, 0.5) in seen
+
+
+def test_peak_table_instead_of_the_chromatogram(ctx):
+    """tracyhip_basecalls::peaks (the four channels at every basecall's peak position, 16 bytes per basecall) instead of signal + bcpos:
+    generateSecondaryDecomposed, allelicFraction (both launch forms) and the whole pipeline (stream-ordered and host-planned, one and
+    two lanes) return what they return from the chromatograms -- which other tests hold against the oracle -- and the oracle's values"""
+    from indigo_oracle import decompose_trace
+    from sage_oracle import revcomp
+    from tracy_amd import capi, hostlib
+    sigs, poss, refs, bcs = [], [], [], []
+    for i, (seed, kind, frac) in enumerate([(121, 0, 0.6), (122, 0, 0.45), (123, 1, 0.6), (124, 0, 0.7), (125, 1, 0.5), (126, 0, 0.3)]):
+        ref, sig, pos, indel = hostlib.synth_decompose(seed, 1500, 520, 25, kind, frac)
+        if i % 2:
+            ref = revcomp(ref)
+        pri, sec, con, bcpos = hostlib.basecall(sig, pos, 0.33)
+        sigs.append(sig); poss.append(pos); refs.append(ref); bcs.append((pri, sec, bcpos))
+    # IUPAC secondaries are what makes generateSecondaryDecomposed read the table: make sure the batch has some
+    assert any(any(ch in b"RYSWKM" for ch in b[1]) for b in bcs)
+    profs = [hostlib.create_profile(sigs[i], bcs[i][2], bcs[i][0], bcs[i][1], 0, 0) for i in range(len(sigs))]
+
+    def fresh():
+        return capi.HostBaseCalls(sigs, [b[2] for b in bcs], [b[0] for b in bcs], [b[1] for b in bcs])
+    h = fresh()
+    tab = h.peak_table()
+    assert tab.shape == (sum(len(b[0]) for b in bcs), 4) and int(tab[3, 2]) == int(sigs[0][2, bcs[0][2][3]])
+    sd = {po: ctx.secondary_decomposed(fresh(), peaks_only=po).copy() for po in (False, True)}
+    assert np.array_equal(sd[0], sd[1])
+    for mode in (0, 1):
+        ctx.set_option("no_af_split", mode)
+        fr = {po: ctx.allelic_fraction(fresh(), sd[0], 50, 50, peaks_only=po).copy() for po in (False, True)}
+        assert np.array_equal(fr[0], fr[1], equal_nan=True), mode
+    ctx.set_option("no_af_split", 0)
+    want = [decompose_trace(sigs[i], bcs[i][2], bcs[i][0], bcs[i][1], refs[i], SC) for i in range(len(sigs))]
+    keys = ("status", "score_fwd", "score_rev", "forward", "score_trim", "score0", "score1", "score2", "fractions", "secdecomp", "dcp_indel", "dcp_err")
+    for no_stream in (0, 1):
+        for lanes in (1, 2):
+            ctx.set_option("no_stream", no_stream)
+            ctx.set_lanes(lanes)
+            try:
+                got = {po: ctx.decompose_traces(profs, fresh(), refs, SC, peaks_only=po) for po in (False, True)}
+            finally:
+                ctx.set_option("no_stream", 0)
+                ctx.set_lanes(1)
+            for k in keys:
+                assert np.array_equal(np.asarray(got[0][k]), np.asarray(got[1][k]), equal_nan=(k == "fractions")), (no_stream, lanes, k)
+            for k in ("btr0", "btr1", "btr2", "primary", "secondary", "secdecomp_list", "dcp"):
+                assert got[0][k] == got[1][k], (no_stream, lanes, k)
+            for i, w in enumerate(want):
+                g = got[1]
+                assert int(g["status"][i]) == w["status"]
+                if w["status"] != 0:
+                    continue
+                assert g["primary"][i] == w["primary"] and g["secdecomp_list"][i] == w["secdecomp"] and g["dcp"][i] == w["dcp"], (no_stream, lanes, i)
+                assert (float(g["fractions"][2 * i]), float(g["fractions"][2 * i + 1])) == w["af"], (no_stream, lanes, i)
+                assert [g["btr%d" % k][i] for k in range(3)] == [w["btr%d" % k] for k in range(3)], (no_stream, lanes, i)

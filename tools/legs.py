@@ -298,8 +298,7 @@ class DecomposeLeg:
                 self.g = ResultGather(None, [small], ctx)
 
             def pack(self, rec, pay):
-                flat = rec.reshape(-1)
-                return sum(self.g._pack(k, buf, stride, flat[col:], int(rec.shape[1]), small)[1] for k, (buf, stride, col) in enumerate(pay))
+                return int(self.g._pack("solo", rec, pay)[0].numel())
         solo = _Solo(self.ctx)
 
         def shard_step():

@@ -362,24 +362,40 @@ def _align_traces_async(self, job, prm, out, mem=MEM_DEVICE):
 Context.align_traces_async = _align_traces_async
 
 
-def _pack_ragged(self, src, stride, lens, n=None, lens_stride=1, out=None):
-    """tracyhip_pack_ragged on torch CUDA tensors: region i = `stride` ELEMENTS of `src` from i * stride, of which the first
-    lens[i * lens_stride] are used (lens: uint32 / int32 tensor).  Returns (packed uint8 tensor, bytes); `out`: a uint8 tensor of at
-    least n * stride * itemsize bytes to pack into (kept by a caller that packs every step)."""
+class RaggedSrc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("stride_bytes", C.c_uint64), ("elem_bytes", C.c_uint32), ("lens", C.c_void_p), ("lens_stride", C.c_uint32)]
+
+
+def _pack_ragged_multi(self, kinds, n, out=None):
+    """tracyhip_pack_ragged_multi on torch CUDA tensors.  kinds: [(src, stride in ELEMENTS, lens tensor (uint32 / int32), lens_stride)]:
+    region i of a kind = `stride` elements of src from i * stride, of which the first lens[i * lens_stride] are used.  Returns (packed uint8
+    tensor -- kind-major --, [bytes per kind]); `out`: a uint8 tensor of at least sum(n * stride * itemsize) bytes to pack into (kept by a
+    caller that packs every step)."""
     import torch
-    elem = src.element_size()
+    arr = (RaggedSrc * len(kinds))()
+    cap = 0
+    for k, (src, stride, lens, lens_stride) in enumerate(kinds):
+        elem = src.element_size()
+        arr[k] = RaggedSrc(src.data_ptr(), int(stride) * elem, elem, lens.data_ptr(), int(lens_stride))
+        cap += int(n) * int(stride) * elem
+    if out is None or out.numel() < cap:
+        out = torch.empty(max(cap, 1), dtype=torch.uint8, device=kinds[0][0].device)
+    kb = (C.c_uint64 * len(kinds))()
+    _check(lib().tracyhip_pack_ragged_multi(self._h, arr, C.c_uint32(len(kinds)), C.c_uint32(int(n)), C.c_void_p(out.data_ptr()), C.c_uint64(out.numel()), kb))
+    sizes = [int(x) for x in kb]
+    return out[:sum(sizes)], sizes
+
+
+def _pack_ragged(self, src, stride, lens, n=None, lens_stride=1, out=None):
+    """one payload kind (tracyhip_pack_ragged): returns (packed uint8 tensor, bytes)"""
     if n is None:
         n = int(lens.numel()) // lens_stride
-    cap = int(n) * int(stride) * elem
-    if out is None or out.numel() < cap:
-        out = torch.empty(max(cap, 1), dtype=torch.uint8, device=src.device)
-    tot = C.c_uint64(0)
-    _check(lib().tracyhip_pack_ragged(self._h, C.c_void_p(src.data_ptr()), C.c_uint64(int(stride) * elem), None, C.c_uint32(elem), C.c_void_p(lens.data_ptr()),
-                                      C.c_uint32(lens_stride), C.c_uint32(int(n)), C.c_void_p(out.data_ptr()), C.c_uint64(out.numel()), C.byref(tot)))
-    return out[:tot.value], int(tot.value)
+    packed, sizes = _pack_ragged_multi(self, [(src, stride, lens, lens_stride)], n, out)
+    return packed, sizes[0]
 
 
 Context.pack_ragged = _pack_ragged
+Context.pack_ragged_multi = _pack_ragged_multi
 
 
 def pair_bounds(len1, len2, idx1, idx2, parts):
@@ -448,7 +464,8 @@ class Breakpoint(C.Structure):
 class BaseCallsBatch(C.Structure):
     _fields_ = [("ntraces", C.c_uint32), ("signal", C.c_void_p), ("signal_offset", C.POINTER(C.c_uint64)),
                 ("nsamples", C.POINTER(C.c_uint32)), ("bcpos", C.c_void_p), ("primary", C.c_void_p),
-                ("secondary", C.c_void_p), ("bc_offset", C.POINTER(C.c_uint64)), ("bc_len", C.POINTER(C.c_uint32))]
+                ("secondary", C.c_void_p), ("bc_offset", C.POINTER(C.c_uint64)), ("bc_len", C.POINTER(C.c_uint32)),
+                ("peaks", C.c_void_p)]  # (optional: the four channels at every basecall's peak position; None = built on the device)
 
 
 class DecompParams(C.Structure):
@@ -489,9 +506,27 @@ class HostBaseCalls:
         self.primary = np.frombuffer(b"".join(bytes(p) for p in primary), dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
         self.secondary = np.frombuffer(b"".join(bytes(p) for p in secondary), dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
 
-    def struct(self):
+    def peak_table(self):
+        """tracyhip_basecalls::peaks of the batch: int32 [sum of bc_len][4] = the four channels at every basecall's peak position"""
+        out = np.zeros((max(int(self.bc_len.sum()), 1), 4), dtype=np.int32)
+        for i in range(self.n):
+            so, ns, bo, bl = int(self.sig_off[i]), int(self.nsamples[i]), int(self.bc_off[i]), int(self.bc_len[i])
+            sig = self.signal[so:so + 4 * ns].reshape(4, ns)
+            out[bo:bo + bl] = sig[:, self.bcpos[bo:bo + bl]].T
+        return out
+
+    def struct(self, peaks_only=False):
+        """peaks_only: the peak table instead of the chromatograms (signal / bcpos NULL)"""
         b = BaseCallsBatch()
         b.ntraces = self.n
+        if peaks_only:
+            self._peaks = self.peak_table()
+            b.peaks = self._peaks.ctypes.data
+            b.primary = self.primary.ctypes.data
+            b.secondary = self.secondary.ctypes.data
+            b.bc_offset = _u64p(self.bc_off)
+            b.bc_len = _u32p(self.bc_len)
+            return b
         b.signal = self.signal.ctypes.data
         b.signal_offset = _u64p(self.sig_off)
         b.nsamples = _u32p(self.nsamples)
@@ -557,16 +592,16 @@ def _decompose_alleles(self, hbc, rows, bps, refslice_len, trim_left=50, trim_ri
     return hbc.split(hbc.primary), hbc.split(hbc.secondary), dcp, status
 
 
-def _secondary_decomposed(self, hbc):
+def _secondary_decomposed(self, hbc, peaks_only=False):
     out = np.zeros(max(len(hbc.primary), 1), dtype=np.uint8)
-    b = hbc.struct()
+    b = hbc.struct(peaks_only)
     _check(lib().tracyhip_secondary_decomposed(self._h, C.byref(b), MEM_HOST, out.ctypes.data_as(C.POINTER(C.c_uint8))))
     return out
 
 
-def _allelic_fraction(self, hbc, secdecomp, trim_left=50, trim_right=50):
+def _allelic_fraction(self, hbc, secdecomp, trim_left=50, trim_right=50, peaks_only=False):
     fr = np.zeros(2 * max(hbc.n, 1), dtype=np.float64)
-    b = hbc.struct()
+    b = hbc.struct(peaks_only)
     sd = np.ascontiguousarray(secdecomp, dtype=np.uint8)
     _check(lib().tracyhip_allelic_fraction(self._h, C.byref(b), sd.ctypes.data_as(C.POINTER(C.c_uint8)), trim_left, trim_right,
                                            MEM_HOST, fr.ctypes.data_as(C.POINTER(C.c_double))))
@@ -596,7 +631,7 @@ class DecomposeResult(C.Structure):
 
 
 def _decompose_traces(self, profiles, hbc, refs, params, trim_left=50, trim_right=50, maxindel=1000, madc=5, oriented=None,
-                      ref_profiles=None, exact_scores=True):
+                      ref_profiles=None, exact_scores=True, peaks_only=False):
     """tracyhip_decompose_traces with host buffers; hbc: HostBaseCalls (primary/secondary rewritten in place);
     oriented: None, or rs.forward per trace when the references are already oriented (indexed-genome path)"""
     pp = profiles if isinstance(profiles, PackedSeqs) else PackedSeqs(profiles, SEQ_PROFILE)
@@ -605,7 +640,7 @@ def _decompose_traces(self, profiles, hbc, refs, params, trim_left=50, trim_righ
     job = DecomposeJob()
     job.ntraces = nt
     job.profiles = pp.seqset()
-    job.bc = hbc.struct()
+    job.bc = hbc.struct(peaks_only)  # (peaks_only: the peak table instead of the chromatograms, tracyhip_basecalls::peaks)
     job.refs = pr.seqset()
     job.dprm = DecompParams(trim_left, trim_right, maxindel, madc)
     job.strand_by_certificate = 0 if exact_scores else 1  # opt-in: the losing strand may carry a certified upper bound

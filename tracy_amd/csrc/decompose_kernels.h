@@ -807,11 +807,11 @@ inline int homozygous_breakpoint(const uint8_t* row0, const uint8_t* row1, uint3
 }
 #endif
 
-// generateSecondaryDecomposed (decompose.h:378-410), one position
-TR_HD uint8_t secondary_decomposed(uint8_t p, uint8_t s, const int32_t* trace, uint64_t nsamples, int32_t pos) {
+// generateSecondaryDecomposed (decompose.h:378-410), one position.  A, Cc, G, T: the four channels at the basecall's peak position
+// (traceACGT[k][bcPos[i]]: one entry of the peak table, below)
+TR_HD uint8_t secondary_decomposed(uint8_t p, uint8_t s, int32_t A, int32_t Cc, int32_t G, int32_t T) {
   if (p == s) return p;
   if (s == 'A' || s == 'C' || s == 'G' || s == 'T') return s;
-  const int32_t A = trace[pos], Cc = trace[nsamples + pos], G = trace[2 * nsamples + pos], T = trace[3 * nsamples + pos];
   switch (s) {
     case 'R': return A > G ? 'A' : 'G';
     case 'Y': return Cc > T ? 'C' : 'T';
@@ -821,6 +821,11 @@ TR_HD uint8_t secondary_decomposed(uint8_t p, uint8_t s, const int32_t* trace, u
     case 'M': return A > Cc ? 'A' : 'C';
     default: return 'N';
   }
+}
+// ... reading the chromatogram itself (the host emulator's entry point; the kernels read the peak table)
+TR_HD uint8_t secondary_decomposed(uint8_t p, uint8_t s, const int32_t* trace, uint64_t nsamples, int32_t pos) {
+  if (p == s) return p;
+  return secondary_decomposed(p, s, trace[pos], trace[nsamples + pos], trace[2 * nsamples + pos], trace[3 * nsamples + pos]);
 }
 
 }  // namespace tracyhip

@@ -280,11 +280,37 @@ __global__ __launch_bounds__(64) void homozygous_kernel(const RowsDesc* desc, co
   if (lane == 0) { status[t] = rc; bps[t] = bp; }
 }
 
-__global__ void secdecomp_kernel(const BcDesc* desc, const int32_t* signal, const int32_t* bcpos, const uint8_t* pri,
-                                 const uint8_t* sec, uint8_t* outp) {
+// ---- the peak table ------------------------------------------------------------------------------------------------------------
+// Every read of the chromatogram on this path is at a basecall's peak position: createProfile (profile.h:21-52, host),
+// generateSecondaryDecomposed (decompose.h:378-410) and allelicFraction (decompose.h:445-470) all index traceACGT[k][bcPos[i]].  The
+// kernels therefore read a compact table -- peaks[bc_off + i] = {A, C, G, T at bcPos[i]}, 16 bytes per basecall instead of the 192 KB
+// chromatogram of a 1 kb trace, consecutive basecalls in consecutive lanes -- which the caller passes (tracyhip_basecalls::peaks) or
+// peaks_kernel builds once per call from signal + bcpos (one pass over the chromatogram, four gathered words per basecall).
+__global__ __launch_bounds__(256) void peaks_kernel(const BcDesc* __restrict__ desc, const int32_t* __restrict__ signal, const int32_t* __restrict__ bcpos,
+                                                    int4* __restrict__ peaks) {
   const BcDesc d = desc[blockIdx.y];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < d.nbc) outp[d.bc_off + i] = secondary_decomposed(pri[d.bc_off + i], sec[d.bc_off + i], signal + d.sig_off, d.nsamples, bcpos[d.bc_off + i]);
+  if (i >= d.nbc) return;
+  const int32_t* sg = signal + d.sig_off;
+  const uint64_t tpos = (uint32_t)bcpos[d.bc_off + i];
+  peaks[d.bc_off + i] = make_int4(sg[tpos], sg[(uint64_t)d.nsamples + tpos], sg[2ull * d.nsamples + tpos], sg[3ull * d.nsamples + tpos]);
+}
+
+__global__ __launch_bounds__(256) void secdecomp_kernel(const BcDesc* __restrict__ desc, const int4* __restrict__ peaks, const uint8_t* __restrict__ pri,
+                                                        const uint8_t* __restrict__ sec, uint8_t* __restrict__ outp) {
+  const BcDesc d = desc[blockIdx.y];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.nbc) return;
+  const uint8_t p = pri[d.bc_off + i], s = sec[d.bc_off + i];
+  uint8_t r = p;
+  if (p != s) {
+    r = s;
+    if (!(s == 'A' || s == 'C' || s == 'G' || s == 'T')) {  // an IUPAC code: the larger of its two channels (the only case that reads the table)
+      const int4 k = peaks[d.bc_off + i];
+      r = secondary_decomposed(p, s, k.x, k.y, k.z, k.w);
+    }
+  }
+  outp[d.bc_off + i] = r;
 }
 
 // ---- allelicFraction (decompose.h:412-621) -----------------------------------------------------------
@@ -341,8 +367,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 template <bool GLOBAL>
-__global__ __launch_bounds__(AF_THREADS) void allelic_fraction_kernel(const BcDesc* desc, const int32_t* signal,
-                                                                      const int32_t* bcpos, const uint8_t* pri_all,
+__global__ __launch_bounds__(AF_THREADS) void allelic_fraction_kernel(const BcDesc* desc, const int4* peaks, const uint8_t* pri_all,
                                                                       const uint8_t* sec_all, uint32_t trimLeft,
                                                                       uint32_t trimRight, AfGrid grid, double* fractions,
                                                                       char* scratch, size_t stride) {
@@ -392,14 +417,12 @@ __global__ __launch_bounds__(AF_THREADS) void allelic_fraction_kernel(const BcDe
     return;
   }
   {
-    const int32_t* sg = signal + d.sig_off;
     for (uint32_t i = c_lo; i < c_hi; ++i) {
       const uint8_t pc = pri[off + i], sc = sec[off + i];
       if (pc == sc) continue;
       const uint32_t bi_ = (i + trimLeft < d.nbc) ? i + trimLeft : d.nbc - 1;  // the reference indexes bcPos[i + trimLeft] (decompose.h:445)
-      const uint32_t tpos = (uint32_t)bcpos[d.bc_off + bi_];
-      int32_t s4[4];
-      for (int k = 0; k < 4; ++k) s4[k] = sg[(uint64_t)k * d.nsamples + tpos];
+      const int4 pk = peaks[d.bc_off + bi_];
+      const int32_t s4[4] = {pk.x, pk.y, pk.z, pk.w};
       const double sigsum = (double)(s4[0] + s4[1] + s4[2] + s4[3]);
       for (int k = 0; k < 4; ++k) { tp[(size_t)k * dn + np] = __ddiv_rn((double)s4[k], sigsum); cls[(size_t)k * dn + np] = 0; }
       const int pi = pc == 'A' ? 0 : pc == 'C' ? 1 : pc == 'G' ? 2 : pc == 'T' ? 3 : -1;
@@ -582,9 +605,12 @@ __device__ __forceinline__ double wave_min_all(double v) {
   for (int o = 32; o > 0; o >>= 1) { const double x = __shfl_xor(v, o, 64); v = x < v ? x : v; }
   return v;
 }
-__global__ __launch_bounds__(64) void af_prepare_kernel(const BcDesc* __restrict__ desc, const int32_t* __restrict__ signal, const int32_t* __restrict__ bcpos,
-                                                        const uint8_t* __restrict__ pri_all, const uint8_t* __restrict__ sec_all, uint32_t trimLeft,
-                                                        uint32_t trimRight, AfScratch sc, double* __restrict__ fractions) {
+// Lane = position (round 6): the bytes of 64 consecutive basecalls, their table entries and the compacted tp / cls entries of the het
+// positions among them are consecutive addresses (a ballot gives every het lane its place).  Two passes over the basecall bytes: tp is
+// laid out [channel][het position] -- the reference's summation order, decompose.h:596-606 -- so the count comes first.
+__global__ __launch_bounds__(64) void af_prepare_kernel(const BcDesc* __restrict__ desc, const int4* __restrict__ peaks, const uint8_t* __restrict__ pri_all,
+                                                        const uint8_t* __restrict__ sec_all, uint32_t trimLeft, uint32_t trimRight, AfScratch sc,
+                                                        double* __restrict__ fractions) {
   const uint32_t t = blockIdx.x, lane = threadIdx.x;
   const BcDesc d = desc[t];
   const uint8_t* pri = pri_all + d.bc_off;
@@ -592,28 +618,30 @@ __global__ __launch_bounds__(64) void af_prepare_kernel(const BcDesc* __restrict
   uint32_t off = trimLeft, len;  // trimmedSeq (abif.h:68-75)
   if ((uint64_t)(uint32_t)(trimLeft + trimRight + 1) >= (uint64_t)d.nbc) { off = 0; len = d.nbc; }
   else len = d.nbc - trimLeft - trimRight;
-  // positions where primary != secondary (decompose.h:431-436), compacted in order: every lane owns a chunk
-  const uint32_t chunk = (len + 63u) / 64u;
-  const uint32_t c_lo = min(lane * chunk, len), c_hi = min(c_lo + chunk, len);
-  uint32_t n = 0;
-  for (uint32_t i = c_lo; i < c_hi; ++i) n += pri[off + i] != sec[off + i];
-  uint32_t incl = n;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, o, 64); if ((int)lane >= o) incl += y; }
-  const uint32_t dn = (uint32_t)__shfl((int)incl, 63, 64);
-  uint32_t np = incl - n;
+  // positions where primary != secondary (decompose.h:431-436)
+  uint32_t dn = 0;
+  for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
+    const uint32_t i = i0 + lane;
+    dn += (uint32_t)__popcll(__ballot(i < len && pri[off + i] != sec[off + i]));
+  }
   double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // n1..n4, S1..S4, Q over this lane's positions
   if (dn) {
     double* tp = sc.tp + 4ull * d.bc_off;
     uint8_t* cls = sc.cls + 4ull * d.bc_off;
-    const int32_t* sg = signal + d.sig_off;
-    for (uint32_t i = c_lo; i < c_hi; ++i) {
-      const uint8_t pc = pri[off + i], scd = sec[off + i];
-      if (pc == scd) continue;
+    const int4* pk_t = peaks + d.bc_off;
+    uint32_t base = 0;
+    for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
+      const uint32_t i = i0 + lane;
+      uint8_t pc = 0, scd = 0;
+      if (i < len) { pc = pri[off + i]; scd = sec[off + i]; }
+      const bool het = pc != scd;  // (both 0 beyond the end)
+      const unsigned long long bal = __ballot(het);
+      const uint32_t np = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      base += (uint32_t)__popcll(bal);
+      if (!het) continue;
       const uint32_t bi_ = (i + trimLeft < d.nbc) ? i + trimLeft : d.nbc - 1;  // the reference indexes bcPos[i + trimLeft] (decompose.h:445)
-      const uint32_t tpos = (uint32_t)bcpos[d.bc_off + bi_];
-      int32_t s4[4];
-      for (int k = 0; k < 4; ++k) s4[k] = sg[(uint64_t)k * d.nsamples + tpos];
+      const int4 pk = pk_t[bi_];
+      const int32_t s4[4] = {pk.x, pk.y, pk.z, pk.w};
       const double sigsum = (double)(s4[0] + s4[1] + s4[2] + s4[3]);
       uint32_t c4[4] = {0, 0, 0, 0};
       const int pi = pc == 'A' ? 0 : pc == 'C' ? 1 : pc == 'G' ? 2 : pc == 'T' ? 3 : -1;
@@ -631,7 +659,6 @@ __global__ __launch_bounds__(64) void af_prepare_kernel(const BcDesc* __restrict
         m[8] += x * x;
         for (int q = 1; q <= 4; ++q) { m[q - 1] += (c4[k] == (uint32_t)q) ? 1.0 : 0.0; m[3 + q] += (c4[k] == (uint32_t)q) ? x : 0.0; }
       }
-      ++np;
     }
   }
   for (int k = 0; k < 9; ++k) m[k] = wave_sum_all(m[k]);
@@ -933,11 +960,19 @@ int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut
   { int trc_ = timing_end(ctx); if (trc_) return trc_; }
   return TRACYHIP_OK;
 }
-int launch_secdecomp(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig, const int32_t* d_pos,
-                     const uint8_t* d_pri, const uint8_t* d_sec, uint8_t* d_out) {
+int launch_peaks(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig, const int32_t* d_pos, int32_t* d_peaks) {
   if (n == 0 || maxbc == 0) return TRACYHIP_OK;
   { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, 0); if (trc_) return trc_; }
-  hipLaunchKernelGGL(secdecomp_kernel, dim3((maxbc + 255) / 256, n), dim3(256), 0, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, d_out);
+  hipLaunchKernelGGL(peaks_kernel, dim3((maxbc + 255) / 256, n), dim3(256), 0, ctx->stream, d_desc, d_sig, d_pos, reinterpret_cast<int4*>(d_peaks));
+  HIP_TRY(hipGetLastError());
+  { int trc_ = timing_end(ctx); if (trc_) return trc_; }
+  return TRACYHIP_OK;
+}
+int launch_secdecomp(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_peaks, const uint8_t* d_pri, const uint8_t* d_sec,
+                     uint8_t* d_out) {
+  if (n == 0 || maxbc == 0) return TRACYHIP_OK;
+  { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_MISC, 0, 0); if (trc_) return trc_; }
+  hipLaunchKernelGGL(secdecomp_kernel, dim3((maxbc + 255) / 256, n), dim3(256), 0, ctx->stream, d_desc, reinterpret_cast<const int4*>(d_peaks), d_pri, d_sec, d_out);
   HIP_TRY(hipGetLastError());
   { int trc_ = timing_end(ctx); if (trc_) return trc_; }
   return TRACYHIP_OK;
@@ -991,9 +1026,9 @@ static int ensure_af_grid(tracyhip_ctx* ctx, AfGrid& g) {
   return TRACYHIP_OK;
 }
 
-int launch_allelic_fraction(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_sig,
-                            const int32_t* d_pos, const uint8_t* d_pri, const uint8_t* d_sec, uint32_t trim_left, uint32_t trim_right,
-                            double* d_out, uint64_t work_bytes, uint64_t bext) {
+int launch_allelic_fraction(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n, uint32_t maxbc, const int32_t* d_peaks_, const uint8_t* d_pri, const uint8_t* d_sec,
+                            uint32_t trim_left, uint32_t trim_right, double* d_out, uint64_t work_bytes, uint64_t bext) {
+  const int4* d_peaks = reinterpret_cast<const int4*>(d_peaks_);
   if (n == 0) return TRACYHIP_OK;
   const size_t lds = (((size_t)maxbc * 36 + 64) + 15) & ~(size_t)15;  // tp (4 doubles per basecall) + class bytes
   const bool global = lds > kLdsStageLimit;
@@ -1015,15 +1050,15 @@ int launch_allelic_fraction(tracyhip_ctx* ctx, const BcDesc* d_desc, uint32_t n,
   }
   { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_AFRAC, 0, work_bytes); if (trc_) return trc_; }
   if (split) {
-    hipLaunchKernelGGL(af_prepare_kernel, dim3(n), dim3(64), 0, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, trim_left, trim_right, sc, d_out);
+    hipLaunchKernelGGL(af_prepare_kernel, dim3(n), dim3(64), 0, ctx->stream, d_desc, d_peaks, d_pri, d_sec, trim_left, trim_right, sc, d_out);
     hipLaunchKernelGGL(af_search_kernel, dim3(n), dim3(64), 0, ctx->stream, d_desc, sc.tp, sc.cls, sc.hdr, grid, d_out);
   } else if (global) {
     HIP_TRY(ctx->d_bits.ensure(lds * (size_t)n));
-    hipLaunchKernelGGL(allelic_fraction_kernel<true>, dim3(n), dim3(AF_THREADS), 0, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, trim_left,
+    hipLaunchKernelGGL(allelic_fraction_kernel<true>, dim3(n), dim3(AF_THREADS), 0, ctx->stream, d_desc, d_peaks, d_pri, d_sec, trim_left,
                        trim_right, grid, d_out, static_cast<char*>(ctx->d_bits.p), lds);
   } else {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(allelic_fraction_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(allelic_fraction_kernel<false>, dim3(n), dim3(AF_THREADS), lds, ctx->stream, d_desc, d_sig, d_pos, d_pri, d_sec, trim_left,
+    hipLaunchKernelGGL(allelic_fraction_kernel<false>, dim3(n), dim3(AF_THREADS), lds, ctx->stream, d_desc, d_peaks, d_pri, d_sec, trim_left,
                        trim_right, grid, d_out, nullptr, (size_t)0);
   }
   HIP_TRY(hipGetLastError());
@@ -1145,22 +1180,36 @@ int tracyhip_decompose_alleles(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, 
   return TRACYHIP_OK;
 }
 
-static int bc_descs(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, int mem, const BcDesc** dd, const void** d_sig,
-                    const void** d_pos, uint64_t* bext) {
+static int bc_descs(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, int mem, const BcDesc** dd, const int32_t** d_peaks, uint64_t* bext) {
+  // descriptors + the peak table of the batch: the caller's (tracyhip_basecalls::peaks), or built here from the chromatograms
   const uint32_t n = bc->ntraces;
-  if (!bc->signal || !bc->signal_offset || !bc->nsamples || !bc->bcpos || !bc->bc_offset || !bc->bc_len)
-    return set_error(TRACYHIP_ERR_ARG, "null basecall arrays");
+  if (!bc->bc_offset || !bc->bc_len) return set_error(TRACYHIP_ERR_ARG, "null basecall arrays");
+  if (!bc->peaks && (!bc->signal || !bc->signal_offset || !bc->nsamples || !bc->bcpos))
+    return set_error(TRACYHIP_ERR_ARG, "null basecall arrays: neither a peak table nor signal + bcpos");
   std::vector<BcDesc> hd(n);
   uint64_t sext = 0;
+  uint32_t maxbc = 0;
   for (uint32_t i = 0; i < n; ++i) {
-    hd[i] = BcDesc{bc->signal_offset[i], bc->bc_offset[i], bc->nsamples[i], bc->bc_len[i]};
-    sext = std::max<uint64_t>(sext, bc->signal_offset[i] + 4ull * bc->nsamples[i]);
+    hd[i] = BcDesc{bc->peaks ? 0ull : bc->signal_offset[i], bc->bc_offset[i], bc->peaks ? 0u : bc->nsamples[i], bc->bc_len[i]};
+    if (!bc->peaks) sext = std::max<uint64_t>(sext, bc->signal_offset[i] + 4ull * bc->nsamples[i]);
+    maxbc = std::max(maxbc, bc->bc_len[i]);
   }
   *bext = extent64(bc->bc_offset, bc->bc_len, n);
   int rc;
-  if ((rc = stage_in(ctx, ctx->d_in1, bc->signal, sext * 4, mem, d_sig))) return rc;
-  if ((rc = stage_in(ctx, ctx->d_in2, bc->bcpos, *bext * 4, mem, d_pos))) return rc;
-  return to_device(ctx, ctx->d_desc, hd, dd);
+  if ((rc = to_device(ctx, ctx->d_desc, hd, dd))) return rc;
+  const void* p = nullptr;
+  if (bc->peaks) {
+    if ((rc = stage_in(ctx, ctx->d_in1, bc->peaks, *bext * 16, mem, &p))) return rc;
+    *d_peaks = static_cast<const int32_t*>(p);
+    return TRACYHIP_OK;
+  }
+  const void *d_sig, *d_pos;
+  if ((rc = stage_in(ctx, ctx->d_in1, bc->signal, sext * 4, mem, &d_sig))) return rc;
+  if ((rc = stage_in(ctx, ctx->d_in2, bc->bcpos, *bext * 4, mem, &d_pos))) return rc;
+  HIP_TRY(ctx->d_tmp[5].ensure(*bext * 16 + 16));
+  if ((rc = launch_peaks(ctx, *dd, n, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos), static_cast<int32_t*>(ctx->d_tmp[5].p)))) return rc;
+  *d_peaks = static_cast<const int32_t*>(ctx->d_tmp[5].p);
+  return TRACYHIP_OK;
 }
 
 int tracyhip_secondary_decomposed(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, int mem, uint8_t* secdecomp) {
@@ -1171,16 +1220,17 @@ int tracyhip_secondary_decomposed(tracyhip_ctx* ctx, const tracyhip_basecalls* b
   if (n == 0) return TRACYHIP_OK;
   if (!bc->primary || !bc->secondary) return set_error(TRACYHIP_ERR_ARG, "null basecalls");
   const BcDesc* dd;
-  const void *d_sig, *d_pos, *d_pri, *d_sec;
+  const void *d_pri, *d_sec;
+  const int32_t* d_peaks;
   uint64_t bext;
-  if ((rc = bc_descs(ctx, bc, mem, &dd, &d_sig, &d_pos, &bext))) return rc;
+  if ((rc = bc_descs(ctx, bc, mem, &dd, &d_peaks, &bext))) return rc;
   if ((rc = stage_in(ctx, ctx->d_tmp[1], bc->primary, bext, mem, &d_pri))) return rc;
   if ((rc = stage_in(ctx, ctx->d_tmp[2], bc->secondary, bext, mem, &d_sec))) return rc;
   void* d_out;
   if ((rc = stage_io(ctx, ctx->d_tmp[3], secdecomp, bext, mem, false, &d_out))) return rc;
   uint32_t maxbc = 0;
   for (uint32_t i = 0; i < n; ++i) maxbc = std::max(maxbc, bc->bc_len[i]);
-  if ((rc = launch_secdecomp(ctx, dd, n, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos),
+  if ((rc = launch_secdecomp(ctx, dd, n, maxbc, d_peaks,
                              static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sec), static_cast<uint8_t*>(d_out))))
     return rc;
   if ((rc = unstage(ctx, secdecomp, d_out, bext, mem))) return rc;
@@ -1197,16 +1247,17 @@ int tracyhip_allelic_fraction(tracyhip_ctx* ctx, const tracyhip_basecalls* bc, c
   if (n == 0) return TRACYHIP_OK;
   if (!bc->primary) return set_error(TRACYHIP_ERR_ARG, "null basecalls");
   const BcDesc* dd;
-  const void *d_sig, *d_pos, *d_pri, *d_sec;
+  const void *d_pri, *d_sec;
+  const int32_t* d_peaks;
   uint64_t bext;
-  if ((rc = bc_descs(ctx, bc, mem, &dd, &d_sig, &d_pos, &bext))) return rc;
+  if ((rc = bc_descs(ctx, bc, mem, &dd, &d_peaks, &bext))) return rc;
   if ((rc = stage_in(ctx, ctx->d_tmp[1], bc->primary, bext, mem, &d_pri))) return rc;
   if ((rc = stage_in(ctx, ctx->d_tmp[2], secdecomp, bext, mem, &d_sec))) return rc;
   void* d_out;
   if ((rc = stage_io(ctx, ctx->d_tmp[3], fractions, sizeof(double) * 2 * (size_t)n, mem, false, &d_out))) return rc;
   uint32_t maxbc = 0;
   for (uint32_t i = 0; i < n; ++i) maxbc = std::max(maxbc, bc->bc_len[i]);
-  if ((rc = launch_allelic_fraction(ctx, dd, n, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos),
+  if ((rc = launch_allelic_fraction(ctx, dd, n, maxbc, d_peaks,
                                     static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sec), trim_left, trim_right,
                                     static_cast<double*>(d_out), 0, bext)))
     return rc;

@@ -1,7 +1,8 @@
-// pack.hip -- tracyhip_pack_ragged: the used parts of fixed-stride result regions (traceback strings at ops_offset[i] = i * cap,
-// rows of a decomposition table, rewritten basecalls) back to back, in trace order.  What a rank does to its variable-length results
-// before the second half of the final gather ("... followed by a variable-length gather of op strings / decomposition
-// tables"): HBM-bound byte work, one pass -- a scan of the lengths by one workgroup, then one workgroup per region copying its bytes.
+// pack.hip -- tracyhip_pack_ragged / tracyhip_pack_ragged_multi: the used parts of fixed-stride result regions (traceback strings at
+// ops_offset[i] = i * cap, rows of a decomposition table, rewritten basecalls) back to back, in trace order.  What a rank does to its
+// variable-length results before the second half of the final gather ("... followed by a variable-length gather of op
+// strings / decomposition tables"): HBM-bound byte work -- a scan of the lengths by one workgroup, then one wave per region copying
+// its bytes, for every payload kind of a call in ONE scan, ONE copy launch and ONE synchronisation.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -21,108 +22,141 @@ using namespace tracyhip;
 
 namespace {
 constexpr uint32_t kScanThreads = 1024;
+constexpr uint32_t kMaxKinds = 16;
 
-// exclusive scan of the regions' byte counts: off[i] = bytes before region i, off[n] = total
-__device__ __forceinline__ unsigned long long region_bytes(const uint32_t* __restrict__ lens, uint32_t lens_stride, uint32_t i, uint32_t elem, unsigned long long clamp) {
-  const unsigned long long b = (unsigned long long)lens[(size_t)i * lens_stride] * elem;
-  return b < clamp ? b : clamp;  // (a strided region holds at most its stride, whatever its length word says)
+struct PackKind {  // one payload kind: region i = bytes [i * stride, i * stride + min(len_i * elem, stride)) of src
+  const uint8_t* src;
+  unsigned long long stride;
+  const uint32_t* lens;
+  uint32_t lens_stride, elem;
+};
+struct PackArgs {
+  PackKind k[kMaxKinds];
+  uint32_t nkinds, n;
+};
+
+__device__ __forceinline__ unsigned long long region_bytes(const PackKind& k, uint32_t i) {
+  const unsigned long long b = (unsigned long long)k.lens[(size_t)i * k.lens_stride] * k.elem;
+  return b < k.stride ? b : k.stride;  // (a strided region holds at most its stride, whatever its length word says)
 }
-__global__ __launch_bounds__(kScanThreads) void pack_scan_kernel(const uint32_t* __restrict__ lens, uint32_t lens_stride, uint32_t n, uint32_t elem, unsigned long long clamp,
-                                                                 unsigned long long* __restrict__ off) {
+
+// exclusive scan over the nkinds * n regions in output order (kind-major: all regions of kind 0, then kind 1, ...):
+// off[v] = bytes before region v, off[nkinds * n] = total; kind_end[k] = bytes up to and including kind k
+__global__ __launch_bounds__(kScanThreads) void pack_scan_kernel(PackArgs a, unsigned long long* __restrict__ off, unsigned long long* __restrict__ kind_end) {
   __shared__ unsigned long long s[kScanThreads];
   const uint32_t tid = threadIdx.x;
-  const uint32_t per = (n + kScanThreads - 1) / kScanThreads;
-  const uint32_t lo = (uint64_t)tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
+  const unsigned long long tot = (unsigned long long)a.nkinds * a.n;
+  const unsigned long long per = (tot + kScanThreads - 1) / kScanThreads;
+  const unsigned long long lo = tid * per < tot ? tid * per : tot, hi = lo + per < tot ? lo + per : tot;
   unsigned long long mine = 0;
-  for (uint32_t i = lo; i < hi; ++i) mine += region_bytes(lens, lens_stride, i, elem, clamp);
+  for (unsigned long long v = lo; v < hi; ++v) mine += region_bytes(a.k[v / a.n], (uint32_t)(v % a.n));
   s[tid] = mine;
   __syncthreads();
   for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
-    const unsigned long long v = tid >= d ? s[tid - d] : 0ull;
+    const unsigned long long x = tid >= d ? s[tid - d] : 0ull;
     __syncthreads();
-    s[tid] += v;
+    s[tid] += x;
     __syncthreads();
   }
   unsigned long long at = s[tid] - mine;
-  for (uint32_t i = lo; i < hi; ++i) {
-    off[i] = at;
-    at += region_bytes(lens, lens_stride, i, elem, clamp);
+  for (unsigned long long v = lo; v < hi; ++v) {
+    off[v] = at;
+    at += region_bytes(a.k[v / a.n], (uint32_t)(v % a.n));
+    if ((v + 1) % a.n == 0) kind_end[v / a.n] = at;
   }
-  if (tid == kScanThreads - 1) off[n] = s[tid];
+  if (tid == kScanThreads - 1) off[tot] = s[tid];
 }
 
-// region i: bytes [i * stride, i * stride + len_i) of src (or from src_off[i]) to dst + off[i].  Four regions per workgroup of 256: one
-// wave each.  Sixteen bytes per lane and step where source and destination are aligned alike, bytes otherwise (a wave's 64 bytes are
-// one request either way).
-__global__ __launch_bounds__(256) void pack_copy_kernel(const uint8_t* __restrict__ src, unsigned long long stride, const unsigned long long* __restrict__ src_off,
-                                                        const uint32_t* __restrict__ lens, uint32_t lens_stride, uint32_t n, uint32_t elem, unsigned long long clamp,
-                                                        const unsigned long long* __restrict__ off, uint8_t* __restrict__ dst) {
-  const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), L = threadIdx.x & 63u;
-  if (i >= n) return;
-  const unsigned long long bytes = region_bytes(lens, lens_stride, i, elem, clamp);
-  const uint8_t* s = src + (src_off ? src_off[i] : (unsigned long long)i * stride);
-  uint8_t* d = dst + off[i];
-  unsigned long long at = 0;
-  if (((reinterpret_cast<uintptr_t>(s) ^ reinterpret_cast<uintptr_t>(d)) & 15u) == 0) {
-    const unsigned long long head = (16u - (reinterpret_cast<uintptr_t>(s) & 15u)) & 15u;
-    const unsigned long long h = head < bytes ? head : bytes;
-    if (L < h) d[L] = s[L];
-    at = h;
-    const unsigned long long vecs = (bytes - at) >> 4;
-    const uint4* sv = reinterpret_cast<const uint4*>(s + at);
-    uint4* dv = reinterpret_cast<uint4*>(d + at);
-    for (unsigned long long v = L; v < vecs; v += 64) dv[v] = sv[v];
-    at += vecs << 4;
+// One wave per region (four to a workgroup).  The destination is written in aligned dwords: a lane's dword is cut out of the two
+// aligned source dwords that hold it (v_alignbyte), so a wave moves 256 bytes per step whatever the two alignments are; the bytes
+// before the first and behind the last aligned dword of the destination go one by one.
+__global__ __launch_bounds__(256) void pack_copy_kernel(PackArgs a, const unsigned long long* __restrict__ off, uint8_t* __restrict__ dst) {
+  const unsigned long long v = (unsigned long long)blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t L = threadIdx.x & 63u;
+  if (v >= (unsigned long long)a.nkinds * a.n) return;
+  const PackKind& k = a.k[v / a.n];
+  const uint32_t i = (uint32_t)(v % a.n);
+  const unsigned long long bytes = region_bytes(k, i);
+  if (bytes == 0) return;
+  const uint8_t* s = k.src + (unsigned long long)i * k.stride;
+  uint8_t* d = dst + off[v];
+  const unsigned long long head0 = (4u - (reinterpret_cast<uintptr_t>(d) & 3u)) & 3u;
+  const unsigned long long head = head0 < bytes ? head0 : bytes;
+  if (L < head) d[L] = s[L];
+  const unsigned long long words = (bytes - head) >> 2;
+  const uint8_t* sb = s + head;
+  const uint32_t r = (uint32_t)(reinterpret_cast<uintptr_t>(sb) & 3u);
+  const uint32_t* sw = reinterpret_cast<const uint32_t*>(sb - r);  // aligned dwords of the source from the one that holds sb[0]
+  uint32_t* dw = reinterpret_cast<uint32_t*>(d + head);
+  if (r == 0) {
+    for (unsigned long long w = L; w < words; w += 64) dw[w] = sw[w];
+  } else {
+    // (r != 0: every destination word needs bytes of both source dwords, so sw[w + 1] holds bytes of the region -- an aligned dword
+    // that overlaps the caller's buffer is inside its allocation)
+    for (unsigned long long w = L; w < words; w += 64) dw[w] = __builtin_amdgcn_alignbyte(sw[w + 1], sw[w], r);
   }
-  for (unsigned long long b = at + L; b < bytes; b += 64) d[b] = s[b];
+  const unsigned long long done = head + (words << 2);
+  if (done + L < bytes) d[done + L] = s[done + L];  // (at most three bytes)
+}
+
+int pack_multi(tracyhip_ctx* ctx, const tracyhip_ragged_src* kinds, uint32_t nkinds, uint32_t n, void* dst, uint64_t dst_cap, uint64_t* kind_bytes) {
+  if (nkinds == 0 || nkinds > kMaxKinds || !kinds || !kind_bytes) return set_error(TRACYHIP_ERR_ARG, "tracyhip_pack_ragged: 1 .. %u payload kinds", kMaxKinds);
+  for (uint32_t k = 0; k < nkinds; ++k) kind_bytes[k] = 0;
+  if (n == 0) return TRACYHIP_OK;
+  PackArgs a{};
+  a.nkinds = nkinds; a.n = n;
+  uint64_t worst = 0;
+  for (uint32_t k = 0; k < nkinds; ++k) {
+    const tracyhip_ragged_src& q = kinds[k];
+    if (!q.src || !q.lens || q.elem_bytes == 0 || q.lens_stride == 0) return set_error(TRACYHIP_ERR_ARG, "tracyhip_pack_ragged: null pointer or zero element size (kind %u)", k);
+    a.k[k] = PackKind{static_cast<const uint8_t*>(q.src), (unsigned long long)q.stride_bytes, q.lens, q.lens_stride, q.elem_bytes};
+    worst += (uint64_t)n * q.stride_bytes;
+  }
+  hipStream_t st = ctx->stream;
+  const size_t nreg = (size_t)nkinds * n;
+  HIP_TRY(ctx->d_tmp[7].ensure(sizeof(unsigned long long) * (nreg + 1 + kMaxKinds)));
+  unsigned long long* d_off = static_cast<unsigned long long*>(ctx->d_tmp[7].p);
+  unsigned long long* d_kend = d_off + nreg + 1;
+  hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(kScanThreads), 0, st, a, d_off, d_kend);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(ctx->h_res.ensure(sizeof(unsigned long long) * kMaxKinds));
+  unsigned long long* h_kend = static_cast<unsigned long long*>(ctx->h_res.p);
+  HIP_TRY(hipMemcpyAsync(h_kend, d_kend, sizeof(unsigned long long) * nkinds, hipMemcpyDeviceToHost, st));
+  auto report = [&]() {
+    for (uint32_t k = 0; k < nkinds; ++k) kind_bytes[k] = h_kend[k] - (k ? h_kend[k - 1] : 0ull);
+  };
+  if (dst) {
+    // a region holds at most its stride: with a capacity for every region in full the copy is queued at once, otherwise the total is read first
+    if (dst_cap < worst) {
+      HIP_TRY(ctx_sync(ctx));
+      report();
+      if (h_kend[nkinds - 1] > dst_cap)
+        return set_error(TRACYHIP_ERR_ARG, "tracyhip_pack_ragged: %llu bytes to pack, capacity %llu", h_kend[nkinds - 1], (unsigned long long)dst_cap);
+    }
+    hipLaunchKernelGGL(pack_copy_kernel, dim3((unsigned)((nreg + 3) / 4)), dim3(256), 0, st, a, d_off, static_cast<uint8_t*>(dst));
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(ctx_sync(ctx));
+  report();
+  return TRACYHIP_OK;
 }
 }  // namespace
 
 extern "C" {
 
-int tracyhip_pack_ragged(tracyhip_ctx* ctx, const void* src, uint64_t stride_bytes, const uint64_t* src_offset, uint32_t elem_bytes, const uint32_t* lens,
-                         uint32_t lens_stride, uint32_t n, void* dst, uint64_t dst_cap, uint64_t* total_bytes) {
+int tracyhip_pack_ragged_multi(tracyhip_ctx* ctx, const tracyhip_ragged_src* kinds, uint32_t nkinds, uint32_t n, void* dst, uint64_t dst_cap, uint64_t* kind_bytes) {
   int rc = ctx_begin(ctx);
   if (rc) return rc;
-  if (!total_bytes || (n && (!src || !lens)) || elem_bytes == 0 || lens_stride == 0) return set_error(TRACYHIP_ERR_ARG, "tracyhip_pack_ragged: null pointer or zero element size");
-  *total_bytes = 0;
-  if (n == 0) return TRACYHIP_OK;
-  hipStream_t st = ctx->stream;
-  DevBuf& scr = ctx->d_tmp[7];
-  const size_t off_bytes = sizeof(unsigned long long) * ((size_t)n + 1);
-  HIP_TRY(scr.ensure(off_bytes + (src_offset ? sizeof(unsigned long long) * (size_t)n : 0)));
-  unsigned long long* d_off = static_cast<unsigned long long*>(scr.p);
-  unsigned long long* d_soff = nullptr;
-  if (src_offset) {  // (a host array, as every offset array of the ABI)
-    HIP_TRY(ctx->h_off.ensure(sizeof(uint64_t) * (size_t)n));
-    std::memcpy(ctx->h_off.p, src_offset, sizeof(uint64_t) * (size_t)n);
-    d_soff = d_off + n + 1;
-    HIP_TRY(hipMemcpyAsync(d_soff, ctx->h_off.p, sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, st));
-  }
-  const unsigned long long clamp = src_offset ? ~0ull : (unsigned long long)stride_bytes;
-  hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(kScanThreads), 0, st, lens, lens_stride, n, elem_bytes, clamp, d_off);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(ctx->h_res.ensure(sizeof(unsigned long long)));
-  unsigned long long* h_tot = static_cast<unsigned long long*>(ctx->h_res.p);
-  HIP_TRY(hipMemcpyAsync(h_tot, d_off + n, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  if (dst) {
-    // a region holds at most its stride: with strided regions and a capacity for all of them the copy is queued at once; otherwise the
-    // total is read first
-    const bool safe = !src_offset && dst_cap / n >= stride_bytes;
-    if (!safe) {
-      HIP_TRY(ctx_sync(ctx));
-      if (*h_tot > dst_cap) {
-        *total_bytes = *h_tot;
-        return set_error(TRACYHIP_ERR_ARG, "tracyhip_pack_ragged: %llu bytes to pack, capacity %llu", *h_tot, (unsigned long long)dst_cap);
-      }
-    }
-    hipLaunchKernelGGL(pack_copy_kernel, dim3((n + 3) / 4), dim3(256), 0, st, static_cast<const uint8_t*>(src), (unsigned long long)stride_bytes, d_soff, lens, lens_stride, n,
-                       elem_bytes, clamp, d_off, static_cast<uint8_t*>(dst));
-    HIP_TRY(hipGetLastError());
-  }
-  HIP_TRY(ctx_sync(ctx));
-  *total_bytes = *h_tot;
-  return TRACYHIP_OK;
+  return pack_multi(ctx, kinds, nkinds, n, dst, dst_cap, kind_bytes);
+}
+
+int tracyhip_pack_ragged(tracyhip_ctx* ctx, const void* src, uint64_t stride_bytes, uint32_t elem_bytes, const uint32_t* lens, uint32_t lens_stride, uint32_t n, void* dst,
+                         uint64_t dst_cap, uint64_t* total_bytes) {
+  int rc = ctx_begin(ctx);
+  if (rc) return rc;
+  if (!total_bytes) return set_error(TRACYHIP_ERR_ARG, "tracyhip_pack_ragged: null total");
+  const tracyhip_ragged_src one{src, stride_bytes, elem_bytes, lens, lens_stride};
+  return pack_multi(ctx, &one, 1, n, dst, dst_cap, total_bytes);
 }
 
 }  // extern "C"

@@ -1389,8 +1389,8 @@ static int decompose_check_args(tracyhip_ctx* ctx, const tracyhip_decompose_job*
   const tracyhip_decomp_params& dp = job->dprm;
   if (sp.kind != TRACYHIP_SEQ_PROFILE || sr.kind != TRACYHIP_SEQ_CHAR || sp.count < nt || bc.ntraces != nt)
     return set_error(TRACYHIP_ERR_ARG, "bad sequence sets");
-  if (!bc.signal || !bc.signal_offset || !bc.nsamples || !bc.bcpos || !bc.primary || !bc.secondary || !bc.bc_offset || !bc.bc_len)
-    return set_error(TRACYHIP_ERR_ARG, "null basecall arrays");
+  if (!bc.primary || !bc.secondary || !bc.bc_offset || !bc.bc_len || (!bc.peaks && (!bc.signal || !bc.signal_offset || !bc.nsamples || !bc.bcpos)))
+    return set_error(TRACYHIP_ERR_ARG, "null basecall arrays");  // (the peak table, or signal + bcpos to build it from)
   if (dp.maxindel < 1 || dp.maxindel > kMaxIndelGlobal) return set_error(TRACYHIP_ERR_RANGE, "maxindel must be in [1, %d]", kMaxIndelGlobal);
   if (!out->bp || !out->status || !out->score_fwd || !out->score_rev || !out->forward || !out->score_trim || !out->dcp_indel ||
       !out->dcp_err || !out->dcp_offset || !out->dstatus || !out->secdecomp || !out->fractions)
@@ -1435,7 +1435,7 @@ struct DecomposeRun {
   uint32_t maxbc = 0, maxcol = 0;
   int nbuf = 0;
   DevBuf &b_sc2, &b_ops1, &b_len1, &b_r0, &b_r1, &b_hst, &b_cq1, &b_cq2, &b_cqf, &b_opsA, &b_lenA, &b_trimA, &b_rnfw, &b_ends;
-  const void *d_prof = nullptr, *d_ref = nullptr, *d_sig = nullptr, *d_pos = nullptr, *d_refprof = nullptr;
+  const void *d_prof = nullptr, *d_ref = nullptr, *d_sig = nullptr, *d_pos = nullptr, *d_refprof = nullptr, *d_peaks = nullptr;
   std::vector<DevOut> outs;
   void *d_pri = nullptr, *d_sec = nullptr, *d_bp = nullptr, *d_sd = nullptr, *d_fr = nullptr, *d_di = nullptr, *d_de = nullptr, *d_dst = nullptr, *d_strim = nullptr;
   std::vector<int32_t> h_sc2;
@@ -1530,7 +1530,7 @@ struct DecomposeRun {
     // ---- payloads ----
     ep = seqset_extent(sp); er = seqset_extent(sr);
     for (uint32_t t = 0; t < nt; ++t) {
-      sext = std::max<uint64_t>(sext, bc.signal_offset[t] + 4ull * bc.nsamples[t]);
+      if (!bc.peaks) sext = std::max<uint64_t>(sext, bc.signal_offset[t] + 4ull * bc.nsamples[t]);
       bext = std::max<uint64_t>(bext, bc.bc_offset[t] + bc.bc_len[t]);
     }
     // wildtype-trace reference (indigo.h:249-289): the alignment of the trimmed trace runs against the wildtype PROFILE
@@ -1545,8 +1545,12 @@ struct DecomposeRun {
     if ((rc = stage_in(ctx, buf(), sp.data, ep * 4, mem, &d_prof))) return rc;
     if ((rc = stage_in(ctx, buf(), sr.data, er, mem, &d_ref))) return rc;
     if (wildtype && (rc = stage_in(ctx, buf(), srp.data, seqset_extent(srp) * 4, mem, &d_refprof))) return rc;
-    if ((rc = stage_in(ctx, buf(), bc.signal, sext * 4, mem, &d_sig))) return rc;
-    if ((rc = stage_in(ctx, buf(), bc.bcpos, bext * 4, mem, &d_pos))) return rc;
+    // the chromatogram is read at the basecalls' peak positions only: the caller's peak table, or signal + bcpos to build it from
+    if (bc.peaks) { if ((rc = stage_in(ctx, buf(), bc.peaks, bext * 16, mem, &d_peaks))) return rc; }
+    else {
+      if ((rc = stage_in(ctx, buf(), bc.signal, sext * 4, mem, &d_sig))) return rc;
+      if ((rc = stage_in(ctx, buf(), bc.bcpos, bext * 4, mem, &d_pos))) return rc;
+    }
     for (uint32_t t = 0; t < nt; ++t) dext = std::max<uint64_t>(dext, out->dcp_offset[t] + 2ull * dp.maxindel + 2);
     if ((rc = io(bc.primary, bext, true, &d_pri))) return rc;
     if ((rc = io(bc.secondary, bext, true, &d_sec))) return rc;
@@ -1735,13 +1739,19 @@ struct DecomposeRun {
       a.lens = d_len1;
       if ((rc = launch_decompose(ctx, a, static_cast<const BreakpointOut*>(d_bp), maxbc, 0, 0))) return rc;  // accounted below, once the lengths are here
       std::vector<BcDesc> hb(nt);
-      for (uint32_t t = 0; t < nt; ++t) hb[t] = BcDesc{bc.signal_offset[t], bc.bc_offset[t], bc.nsamples[t], mf[t]};
+      for (uint32_t t = 0; t < nt; ++t) hb[t] = BcDesc{bc.peaks ? 0ull : bc.signal_offset[t], bc.bc_offset[t], bc.peaks ? 0u : bc.nsamples[t], mf[t]};
       const BcDesc* db;
       if ((rc = upload(ctx, buf(), hb, &db))) return rc;
-      if ((rc = launch_secdecomp(ctx, db, nt, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos),
+      if (!d_peaks) {  // no table from the caller: built once, read by both kernels below
+        DevBuf& pb = buf();
+        HIP_TRY(pb.ensure(bext * 16 + 16));
+        if ((rc = launch_peaks(ctx, db, nt, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos), static_cast<int32_t*>(pb.p)))) return rc;
+        d_peaks = pb.p;
+      }
+      if ((rc = launch_secdecomp(ctx, db, nt, maxbc, static_cast<const int32_t*>(d_peaks),
                                  static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sec), static_cast<uint8_t*>(d_sd))))
         return rc;
-      if ((rc = launch_allelic_fraction(ctx, db, nt, maxbc, static_cast<const int32_t*>(d_sig), static_cast<const int32_t*>(d_pos),
+      if ((rc = launch_allelic_fraction(ctx, db, nt, maxbc, static_cast<const int32_t*>(d_peaks),
                                         static_cast<const uint8_t*>(d_pri), static_cast<const uint8_t*>(d_sd), TL, TR,
                                         static_cast<double*>(d_fr), 18ull * std::accumulate(mf.begin(), mf.end(), 0ull),
                                         [&] { uint64_t e = 0; for (uint32_t t = 0; t < nt; ++t) e = std::max<uint64_t>(e, bc.bc_offset[t] + mf[t]); return e; }())))
@@ -2365,11 +2375,11 @@ namespace {
 bool decompose_splittable(const tracyhip_decompose_job* job, const tracyhip_decompose_result* out, const tracyhip_params* prm, uint32_t parts) {
   bool split = parts >= 2 && job && out && prm && job->ntraces >= parts * kMinLaneChunk && job->profiles.offset && job->profiles.length &&
                job->refs.offset && job->refs.length && job->profiles.count >= job->ntraces && job->bc.ntraces >= job->ntraces &&
-               job->bc.signal_offset && job->bc.nsamples && job->bc.bc_offset && job->bc.bc_len && out->dcp_offset &&
+               (job->bc.peaks || (job->bc.signal_offset && job->bc.nsamples)) && job->bc.bc_offset && job->bc.bc_len && out->dcp_offset &&
                (job->ref_index || job->refs.count >= job->ntraces);
   if (split) {
     const uint32_t nt = job->ntraces;
-    split = nondecreasing(job->bc.signal_offset, nt) && nondecreasing(job->bc.bc_offset, nt) && nondecreasing(out->dcp_offset, nt);
+    split = (job->bc.peaks || nondecreasing(job->bc.signal_offset, nt)) && nondecreasing(job->bc.bc_offset, nt) && nondecreasing(out->dcp_offset, nt);
     for (int k = 0; k < 3 && split; ++k) split = out->ops_offset[k] && nondecreasing(out->ops_offset[k], nt);
     if (job->ref_profiles.data && !job->ref_index)
       split = split && job->ref_profiles.offset && job->ref_profiles.length && job->ref_profiles.count >= nt;
@@ -2393,11 +2403,15 @@ struct DecomposeChunk {
     }
     j.oriented = shifted(job->oriented, lo);
     // Trace + BaseCalls: signal by signal_offset, the per-base arrays by bc_offset
-    sub_offsets(job->bc.signal_offset, lo, k, sig);
     sub_offsets(job->bc.bc_offset, lo, k, bco);
     j.bc.ntraces = k;
-    j.bc.signal = shifted(job->bc.signal, sig.base); j.bc.signal_offset = sig.off.data(); j.bc.nsamples = job->bc.nsamples + lo;
-    j.bc.bcpos = shifted(job->bc.bcpos, bco.base); j.bc.primary = shifted(job->bc.primary, bco.base);
+    if (job->bc.peaks) { j.bc.peaks = shifted(job->bc.peaks, 4 * bco.base); j.bc.signal = nullptr; j.bc.signal_offset = nullptr; j.bc.nsamples = nullptr; j.bc.bcpos = nullptr; }
+    else {
+      sub_offsets(job->bc.signal_offset, lo, k, sig);
+      j.bc.signal = shifted(job->bc.signal, sig.base); j.bc.signal_offset = sig.off.data(); j.bc.nsamples = job->bc.nsamples + lo;
+      j.bc.bcpos = shifted(job->bc.bcpos, bco.base);
+    }
+    j.bc.primary = shifted(job->bc.primary, bco.base);
     j.bc.secondary = shifted(job->bc.secondary, bco.base); j.bc.bc_offset = bco.off.data(); j.bc.bc_len = job->bc.bc_len + lo;
     // results
     o.bp = shifted(out->bp, lo); o.status = shifted(out->status, lo); o.score_fwd = shifted(out->score_fwd, lo);

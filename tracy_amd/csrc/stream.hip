@@ -1600,6 +1600,7 @@ struct DecompArena {
   long long* bound;
   // staged payloads / results where the caller's arrays are host memory
   float* in_prof; uint8_t* in_ref; int32_t *in_sig, *in_pos;
+  int32_t* peaks;          // the peak table of the batch (decompose_kernels.hip): built from the chromatograms, or the caller's staged here (host memory)
   uint8_t *pri, *sec, *secdecomp;
   tracyhip_breakpoint* bp; double* fractions; int32_t *dcp_indel, *dcp_err; tracyhip_decomp_status* dstatus;
   DecompOutDev o;
@@ -1608,7 +1609,7 @@ struct DecompArena {
   DecompOutDev f;
   tracyhip_breakpoint* f_bp; double* f_fr; tracyhip_decomp_status* f_dst;
   uint32_t* dead_list;
-  struct Sizes { uint32_t nt; bool exact, host; uint64_t tot1, bext, er, ep, sext, dext, opscap[3]; };
+  struct Sizes { uint32_t nt; bool exact, host, own_peaks; uint64_t tot1, bext, er, ep, sext, dext, opscap[3]; };  // own_peaks: no table from the caller, or one in host memory
   void layout(Arena& a, const Sizes& z) {
     const uint32_t nt = z.nt;
     sc.layout(a, nt, 2 * nt, z.exact, false);
@@ -1626,6 +1627,7 @@ struct DecompArena {
     al = a.take<SAllele>(2 * (size_t)nt);
     ascore = a.take<int32_t>(2 * (size_t)nt); alen = a.take<uint32_t>(2 * (size_t)nt);
     bound = a.take<long long>(nt);
+    peaks = z.own_peaks ? a.take<int32_t>(4 * z.bext + 4) : nullptr;
     auto per_trace = [&](DecompOutDev& x) {
       x.status = a.take<int32_t>(nt); x.score_fwd = a.take<int32_t>(nt); x.score_rev = a.take<int32_t>(nt); x.score_trim = a.take<int32_t>(nt);
       x.forward = a.take<uint8_t>(nt);
@@ -1634,7 +1636,7 @@ struct DecompArena {
     };
     o = DecompOutDev{};
     if (z.host) {
-      in_prof = a.take<float>(z.ep); in_ref = a.take<uint8_t>(z.er); in_sig = a.take<int32_t>(z.sext); in_pos = a.take<int32_t>(z.bext);
+      in_prof = a.take<float>(z.ep); in_ref = a.take<uint8_t>(z.er); in_sig = a.take<int32_t>(z.sext); in_pos = a.take<int32_t>(z.sext ? z.bext : 0);  // (sext = 0: the caller passed the peak table)
       pri = a.take<uint8_t>(z.bext); sec = a.take<uint8_t>(z.bext); secdecomp = a.take<uint8_t>(z.bext);
       bp = a.take<tracyhip_breakpoint>(nt); fractions = a.take<double>(2 * (size_t)nt);
       dcp_indel = a.take<int32_t>(z.dext); dcp_err = a.take<int32_t>(z.dext); dstatus = a.take<tracyhip_decomp_status>(nt);
@@ -1680,7 +1682,9 @@ struct DecStream {
   DecompArena A;
   const float* d_prof = nullptr;
   const uint8_t* d_ref = nullptr;
-  const int32_t *d_sig = nullptr, *d_pos = nullptr;
+  const int32_t *d_sig = nullptr, *d_pos = nullptr, *d_peaks = nullptr;
+  bool build_peaks = false;   // no table from the caller: peaks_kernel fills A.peaks (beside the sweeps when the context has side streams)
+  bool peaks_forked = false;  // ... on side[3]; the call's stream waits for ready[1] before generateSecondaryDecomposed
   uint8_t *d_pri = nullptr, *d_sec = nullptr, *d_sd = nullptr;
   tracyhip_breakpoint* d_bp = nullptr;
   double* d_fr = nullptr;
@@ -1716,6 +1720,7 @@ struct DecStream {
   // whatever happens once the stages are queued, the caller's basecalls in device memory are put back before the host-planned pipeline takes the call
   int give_up(int rc) {
     if (rc != TRACYHIP_OK) af_pending = false;  // (the host-planned pipeline redoes the call)
+    if (rc != TRACYHIP_OK && peaks_forked) { (void)hipStreamWaitEvent(st, ctx->b16_fork.ready[1], 0); peaks_forked = false; }
     if (rc != TRACYHIP_OK && af_forked) {  // (nothing of this call may still run when the caller -- or the host-planned pipeline -- takes the buffers back)
       (void)hipStreamWaitEvent(st, ctx->b16_fork.joined[3], 0);
       af_forked = false;
@@ -1760,6 +1765,8 @@ struct DecStream {
 
     // ---- geometry of the decompose stages (decompose_traces_legacy's, trace by trace) ----
     z.nt = nt; z.exact = exact; z.host = host;
+    if (!bc.peaks && (!bc.signal || !bc.signal_offset || !bc.nsamples || !bc.bcpos)) return set_error(TRACYHIP_ERR_ARG, "null basecall arrays: neither a peak table nor signal + bcpos");
+    z.own_peaks = !bc.peaks || host;
     // two passes on the host threads (100 000 records are milliseconds on one, and nothing is queued yet: the GPU waits for this):
     // sums, extents and checks per slice of the batch, then the records with their running offsets from the slices' bases
     struct Part {
@@ -1785,7 +1792,7 @@ struct DecStream {
         x.alr += 2ull * ((uint64_t)h.rn[t] + 2);
         x.tot1 += (uint64_t)h.mt[t] + h.rn[t];
         if (front_ok(t, sl)) x.max_arest = std::max(x.max_arest, sl - kFrontRows);
-        x.sext = std::max<uint64_t>(x.sext, bc.signal_offset[t] + 4ull * bc.nsamples[t]);
+        if (!bc.peaks) x.sext = std::max<uint64_t>(x.sext, bc.signal_offset[t] + 4ull * bc.nsamples[t]);
         x.bext = std::max<uint64_t>(x.bext, bc.bc_offset[t] + bc.bc_len[t]);
         x.dext = std::max<uint64_t>(x.dext, out->dcp_offset[t] + 2ull * dp.maxindel + 2);
         for (int k = 0; k < 3; ++k) x.opscap[k] = std::max<uint64_t>(x.opscap[k], out->ops_offset[k][t] + (uint64_t)sl + (k < 2 ? h.rn[t] : sl));
@@ -1822,8 +1829,8 @@ struct DecStream {
         D = SGeomD{};
         trimmed(t, D.soff, D.sl);
         D.bc_off = bc.bc_offset[t];
-        D.sig_off = bc.signal_offset[t];
-        D.nsamples = bc.nsamples[t];
+        D.sig_off = bc.peaks ? 0ull : bc.signal_offset[t];
+        D.nsamples = bc.peaks ? 0u : bc.nsamples[t];
         D.dcp_off = out->dcp_offset[t];
         for (int k = 0; k < 3; ++k) D.opsk_off[k] = out->ops_offset[k][t];
         D.atab_stride = b16_table_stride(D.sl);
@@ -1876,6 +1883,8 @@ struct DecStream {
     d_prof = static_cast<const float*>(sp.data);
     d_ref = static_cast<const uint8_t*>(sr.data);
     d_sig = bc.signal; d_pos = bc.bcpos;
+    d_peaks = bc.peaks ? bc.peaks : A.peaks;
+    build_peaks = !bc.peaks;
     d_pri = bc.primary; d_sec = bc.secondary; d_sd = out->secdecomp;
     d_bp = out->bp;
     d_fr = out->fractions;
@@ -1888,7 +1897,9 @@ struct DecStream {
         if (bytes) HIP_TRY(hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, st));
         return TRACYHIP_OK;
       };
-      TRY(up(A.in_prof, sp.data, z.ep * 4)); TRY(up(A.in_ref, sr.data, z.er)); TRY(up(A.in_sig, bc.signal, z.sext * 4)); TRY(up(A.in_pos, bc.bcpos, z.bext * 4));
+      TRY(up(A.in_prof, sp.data, z.ep * 4)); TRY(up(A.in_ref, sr.data, z.er));
+      if (bc.peaks) { TRY(up(A.peaks, bc.peaks, z.bext * 16)); d_peaks = A.peaks; }  // (16 bytes per basecall instead of the chromatogram)
+      else { TRY(up(A.in_sig, bc.signal, z.sext * 4)); TRY(up(A.in_pos, bc.bcpos, z.bext * 4)); }
       TRY(up(A.pri, bc.primary, z.bext)); TRY(up(A.sec, bc.secondary, z.bext));
       d_prof = A.in_prof; d_ref = A.in_ref; d_sig = A.in_sig; d_pos = A.in_pos; d_pri = A.pri; d_sec = A.sec; d_sd = A.secdecomp;
       d_bp = A.bp; d_fr = A.fractions; d_di = A.dcp_indel; d_de = A.dcp_err; d_dst = A.dstatus;
@@ -1946,6 +1957,20 @@ struct DecStream {
     HIP_TRY(hipGetLastError());
     // findBreakpoint (indigo.h:196) needs nothing but the profiles, the case-sensitive codes of the windows (the allele stages' columns)
     // nothing but the references: both fill the hole behind the full sweeps (OrientStage::filler)
+    // the peak table (no table from the caller): one pass over the chromatograms -- HBM work that needs no LDS and few registers, on the
+    // lowest-priority side stream beside the sweeps, which leave the memory system idle; joined before generateSecondaryDecomposed
+    if (build_peaks && ctx->b16_fork_ok && !ctx->knobs.no_fork) {
+      const B16Fork& fk = ctx->b16_fork;
+      HIP_TRY(hipEventRecord(fk.forked, st));
+      HIP_TRY(hipStreamWaitEvent(fk.side[3], fk.forked, 0));
+      ctx->stream = fk.side[3];
+      const int rcp = launch_peaks(ctx, A.bcd, nt, maxbc, d_sig, d_pos, A.peaks);
+      ctx->stream = st;
+      HIP_TRY(hipEventRecord(fk.ready[1], fk.side[3]));
+      peaks_forked = true;
+      if (rcp) return rcp;
+      build_peaks = false;
+    }
     bp_early = ctx->b16_fork_ok && !ctx->knobs.no_fork;
     if (bp_early)
       os.filler = [&]() -> int {
@@ -1992,7 +2017,9 @@ struct DecStream {
       a.lens = A.len1;
       a.skip = sc.dead;
       TRY(launch_decompose(ctx, a, bpo, maxbc, 0, 0));
-      TRY(launch_secdecomp(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sec, d_sd));
+      if (build_peaks) { TRY(launch_peaks(ctx, A.bcd, nt, maxbc, d_sig, d_pos, A.peaks)); build_peaks = false; }
+      if (peaks_forked) { HIP_TRY(hipStreamWaitEvent(st, ctx->b16_fork.ready[1], 0)); peaks_forked = false; }
+      TRY(launch_secdecomp(ctx, A.bcd, nt, maxbc, d_peaks, d_pri, d_sec, d_sd));
       // allelicFraction feeds nothing but its own result (indigo.h:350): it runs beside the allele stages, which read the same
       // decomposed basecalls and write elsewhere; the read-back waits for it.  It is QUEUED once the allele stages' first long launch is
       // (queue_allelic_fraction): beside the encoders' fills and copies it would only make those wait for its hundred thousand waves.
@@ -2028,7 +2055,7 @@ struct DecStream {
       HIP_TRY(hipStreamWaitEvent(ctx->b16_fork.side[3], ctx->b16_fork.ready[0], 0));
       ctx->stream = ctx->b16_fork.side[3];
     }
-    const int rc = launch_allelic_fraction(ctx, A.bcd, nt, maxbc, d_sig, d_pos, d_pri, d_sd, TL, TR, d_fr, 18ull * std::accumulate(h.mf.begin(), h.mf.end(), 0ull), z.bext);
+    const int rc = launch_allelic_fraction(ctx, A.bcd, nt, maxbc, d_peaks, d_pri, d_sd, TL, TR, d_fr, 18ull * std::accumulate(h.mf.begin(), h.mf.end(), 0ull), z.bext);
     ctx->stream = st;
     if (fork) {
       HIP_TRY(hipEventRecord(ctx->b16_fork.joined[3], ctx->b16_fork.side[3]));
@@ -2167,13 +2194,13 @@ struct DecStream {
       hipLaunchKernelGGL(s_restore_kernel, dim3(nd), dim3(64), 0, st, A.dead_list, sc.geom, A.geomd, A.pri_bak, A.sec_bak, d_pri, d_sec);
       HIP_TRY(hipGetLastError());
       HIP_TRY(ctx_sync(ctx));
-      std::vector<uint64_t> poff(nd), sigoff(nd), bcoff(nd), dcpoff(nd), ooff[3];
-      std::vector<uint32_t> plen(nd), ridx(nd), nsamp(nd), bclen(nd);
+      std::vector<uint64_t> poff(nd), bcoff(nd), dcpoff(nd), ooff[3];
+      std::vector<uint32_t> plen(nd), ridx(nd), bclen(nd);
       for (int k = 0; k < 3; ++k) ooff[k].resize(nd);
       for (uint32_t i = 0; i < nd; ++i) {
         const uint32_t t = dl[i];
         poff[i] = sp.offset[t]; plen[i] = sp.length[t]; ridx[i] = h.ridx[t];
-        sigoff[i] = bc.signal_offset[t]; nsamp[i] = bc.nsamples[t]; bcoff[i] = bc.bc_offset[t]; bclen[i] = bc.bc_len[t];
+        bcoff[i] = bc.bc_offset[t]; bclen[i] = bc.bc_len[t];
         dcpoff[i] = out->dcp_offset[t];
         for (int k = 0; k < 3; ++k) ooff[k][i] = out->ops_offset[k][t];
       }
@@ -2183,8 +2210,9 @@ struct DecStream {
       j.refs.data = d_ref;
       j.ref_index = ridx.data();
       j.bc.ntraces = nd;
-      j.bc.signal = d_sig; j.bc.signal_offset = sigoff.data(); j.bc.nsamples = nsamp.data();
-      j.bc.bcpos = d_pos; j.bc.primary = d_pri; j.bc.secondary = d_sec; j.bc.bc_offset = bcoff.data(); j.bc.bc_len = bclen.data();
+      // (the peak table of the batch is on the device by now, the caller's or the one built from the chromatograms: the sub-job reads it)
+      j.bc.signal = nullptr; j.bc.signal_offset = nullptr; j.bc.nsamples = nullptr; j.bc.bcpos = nullptr; j.bc.peaks = d_peaks;
+      j.bc.primary = d_pri; j.bc.secondary = d_sec; j.bc.bc_offset = bcoff.data(); j.bc.bc_len = bclen.data();
       tracyhip_decompose_result r{};
       r.bp = A.f_bp; r.status = A.f.status; r.score_fwd = A.f.score_fwd; r.score_rev = A.f.score_rev; r.forward = A.f.forward; r.score_trim = A.f.score_trim;
       r.dcp_indel = d_di; r.dcp_err = d_de; r.dcp_offset = dcpoff.data();

@@ -120,12 +120,12 @@ def gather_ragged_known(dist, packed, totals, dst=0):
     return torch.cat(parts)
 
 
-def gather_payloads(dist, kinds, kind_totals, dst=0):
+def gather_payloads(dist, kinds, kind_totals, dst=0, joined=None):
     """Several ragged payloads in ONE exchange: `kinds` = this rank's packed uint8 tensors (one per payload kind, in a fixed order),
     `kind_totals[r][k]` = bytes of kind k on rank r as `dst` knows them (None on the other ranks).  Returns, on `dst`, one tensor per
     kind holding that kind of every rank in rank order; None elsewhere."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    mine = torch.cat(kinds) if len(kinds) > 1 else kinds[0]
+    mine = joined if joined is not None else (torch.cat(kinds) if len(kinds) > 1 else kinds[0])  # (joined: the kinds are views of one buffer, in order)
     if rank != dst:
         gather_ragged_known(dist, mine, None, dst)
         return None
@@ -156,16 +156,20 @@ class ResultGather:
         self.scratch = {}
         self.bytes_last = 0
 
-    def _pack(self, k, buf, stride, lens, lens_stride, n):
-        if buf.is_cuda:
+    def _pack(self, key, records, payloads):
+        """this rank's payloads packed kind-major into one buffer: (buffer, [bytes per kind])"""
+        n, F = int(records.shape[0]), int(records.shape[1])
+        flat = records.reshape(-1)
+        if payloads and payloads[0][0].is_cuda:
             if self.ctx is None:
-                raise RuntimeError("ResultGather: CUDA results need the rank's Context (tracyhip_pack_ragged)")
-            out = self.scratch.get(k)
-            need = n * stride * buf.element_size()
+                raise RuntimeError("ResultGather: CUDA results need the rank's Context (tracyhip_pack_ragged_multi)")
+            need = sum(n * stride * buf.element_size() for buf, stride, _ in payloads)
+            out = self.scratch.get(key)
             if out is None or out.numel() < need:
-                out = self.scratch[k] = torch.empty(max(need, 1), dtype=torch.uint8, device=buf.device)
-            return self.ctx.pack_ragged(buf, stride, lens, n=n, lens_stride=lens_stride, out=out)
-        return pack_ragged(buf, stride, lens.reshape(-1)[::lens_stride][:n])
+                out = self.scratch[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=payloads[0][0].device)
+            return self.ctx.pack_ragged_multi([(buf, stride, flat[col:], F) for buf, stride, col in payloads], n, out=out)
+        parts = [pack_ragged(buf, stride, flat[col:][::F][:n])[0] for buf, stride, col in payloads]  # (CPU tensors: the gloo tests)
+        return (torch.cat(parts) if len(parts) > 1 else parts[0]), [int(x.numel()) for x in parts]
 
     def gather(self, records, payloads):
         """records: int32 [n_local, F], contiguous.  payloads: list of (buf, stride_elements, column): trace i uses the first
@@ -173,16 +177,13 @@ class ResultGather:
         kind]) on dst, (None, None) elsewhere."""
         dist, dst = self.dist, self.dst
         rank, world = dist.get_rank(), dist.get_world_size()
-        n, F = int(records.shape[0]), int(records.shape[1])
         assert records.dtype == torch.int32 and records.is_contiguous()
         allrec = gather_records(dist, records, dst=dst, sizes=self.sizes)
-        packed = []
-        flat = records.reshape(-1)
-        for k, (buf, stride, col) in enumerate(payloads):
-            packed.append(self._pack(k, buf, stride, flat[col:], F, n)[0])
-        self.bytes_last = records.numel() * 4 + sum(int(x.numel()) for x in packed)
         if not payloads:
+            self.bytes_last = records.numel() * 4
             return allrec, []
+        packed, kind_bytes = self._pack("gather", records, payloads)
+        self.bytes_last = records.numel() * 4 + int(packed.numel())
         totals = None
         if rank == dst and world > 1:  # bytes per (rank, kind), read off the gathered length columns: the one host read of the gather
             cols = torch.tensor([c for _, _, c in payloads], device=allrec.device)
@@ -193,7 +194,11 @@ class ResultGather:
                 bounds.append(bounds[-1] + x)
             per = torch.stack([lens[bounds[r]:bounds[r + 1]].sum(dim=0) for r in range(world)]) * elem[None, :]
             totals = per.cpu().tolist()
-        got = gather_payloads(dist, packed, totals, dst)
+        kinds, at = [], 0
+        for nb in kind_bytes:
+            kinds.append(packed[at:at + nb])
+            at += nb
+        got = gather_payloads(dist, kinds, totals, dst, joined=packed)
         return (allrec, got) if rank == dst else (None, None)
 
     def check_own_block(self, allrec, got, records, payloads):
@@ -205,15 +210,17 @@ class ResultGather:
         n = int(records.shape[0])
         rec = records.cpu() if (records.is_cuda and not allrec.is_cuda) else records
         ok = int(allrec.shape[0]) == sum(self.sizes) and torch.equal(allrec[lo:lo + n], rec)
-        flat = records.reshape(-1)
+        mine, kind_bytes = self._pack("check", records, payloads) if payloads else (None, [])
+        at_mine = 0
         for k, (buf, stride, col) in enumerate(payloads):
             elem = buf.element_size()
             lens_all = allrec[:, col].to(torch.int64)
             ok = ok and int(got[k].numel()) == int(lens_all.sum().item()) * elem
             at = int(lens_all[:lo].sum().item()) * elem
-            mine, nb = self._pack(("check", k), buf, stride, flat[col:], int(records.shape[1]), n)
-            mine = mine.cpu() if (mine.is_cuda and not got[k].is_cuda) else mine
-            ok = ok and torch.equal(got[k][at:at + nb], mine)
+            part = mine[at_mine:at_mine + kind_bytes[k]]
+            at_mine += kind_bytes[k]
+            part = part.cpu() if (part.is_cuda and not got[k].is_cuda) else part
+            ok = ok and torch.equal(got[k][at:at + kind_bytes[k]], part)
         return bool(ok)
 
 

@@ -955,14 +955,14 @@ struct DecomposeGroup {
   std::vector<Job*> jobs;
   uint32_t nt = 0;
   bool wildtype = false, seeded = false, packed = false;
-  std::vector<uint64_t> poff, roff, soff, boff, dcpoff, ooff[3], wpoff;
-  std::vector<uint32_t> plen, rlen, ns, blen, sb[2], sl[2], rp[2], olen[3];
+  std::vector<uint64_t> poff, roff, boff, dcpoff, ooff[3], wpoff;
+  std::vector<uint32_t> plen, rlen, blen, sb[2], sl[2], rp[2], olen[3];
   uint32_t dcap = 0;
   uint64_t ocap[3] = {0, 0, 0}, btot = 0;
   struct Packed {
     std::unique_ptr<float[]> prof;
     std::unique_ptr<uint8_t[]> refs, pri, sec;
-    std::unique_ptr<int32_t[]> sig, pos;
+    std::unique_ptr<int32_t[]> peaks;  // tracyhip_basecalls::peaks: the four channels at every basecall's peak position (all the device reads of a chromatogram)
     float* pdata() { return prof.get(); }
   };
   Packed pk;
@@ -980,20 +980,20 @@ struct DecomposeGroup {
 
   void pack(SageConfig const& c, uint32_t nthreads) {
     PhaseClock pc;
-    // the batch as packed payloads: offsets first, then every trace copied to its place by the host threads (10 000 traces are 1.9 GB
-    // of signal: grown by insert() they were copied several times over, by one thread)
-    for (auto* v : {&poff, &roff, &soff, &boff, &dcpoff}) v->assign(nt, 0);
-    for (auto* v : {&plen, &rlen, &ns, &blen}) v->assign(nt, 0);
+    // the batch as packed payloads: offsets first, then every trace copied to its place by the host threads.  Of a chromatogram the
+    // device reads the samples at the basecalls' peak positions only (generateSecondaryDecomposed, allelicFraction): the block carries the
+    // peak table -- 16 bytes per basecall -- instead of 1.9 GB of signal per 10 000 traces
+    for (auto* v : {&poff, &roff, &boff, &dcpoff}) v->assign(nt, 0);
+    for (auto* v : {&plen, &rlen, &blen}) v->assign(nt, 0);
     dcap = 2u * c.maxindel + 2;
     for (int k = 0; k < 3; ++k) ocap[k] = 0;
     for (int k = 0; k < 3; ++k) ooff[k].resize(nt);
-    uint64_t ptot = 0, rtot = 0, stot = 0;
+    uint64_t ptot = 0, rtot = 0;
     btot = 0;
     for (uint32_t i = 0; i < nt; ++i) {
       Job& j = *jobs[i];
       poff[i] = ptot; plen[i] = (uint32_t)j.full.cols; ptot += j.full.v.size();
       roff[i] = rtot; rlen[i] = (uint32_t)j.fasta.size(); rtot += j.fasta.size();
-      soff[i] = stot; ns[i] = (uint32_t)j.tr.traceACGT[0].size(); stot += 4ull * ns[i];
       boff[i] = btot; blen[i] = (uint32_t)j.bc.bcPos.size(); btot += blen[i];
       dcpoff[i] = (uint64_t)i * dcap;
       for (int k = 0; k < 3; ++k) {
@@ -1005,23 +1005,19 @@ struct DecomposeGroup {
     pk.refs.reset(new uint8_t[rtot ? rtot : 1]);
     pk.pri.reset(new uint8_t[btot ? btot : 1]);
     pk.sec.reset(new uint8_t[btot ? btot : 1]);
-    pk.sig.reset(new int32_t[stot ? stot : 1]);
-    pk.pos.reset(new int32_t[btot ? btot : 1]);
+    pk.peaks.reset(new int32_t[btot ? 4 * btot : 4]);
     for_each_index(nt, nthreads, [&](uint32_t i) {
       Job& j = *jobs[i];
       if (!j.full.v.empty()) std::memcpy(pk.prof.get() + poff[i], j.full.v.data(), j.full.v.size() * sizeof(float));
       if (!j.fasta.empty()) std::memcpy(pk.refs.get() + roff[i], j.fasta.data(), j.fasta.size());
-      for (int k = 0; k < 4; ++k) {  // (a channel shorter than the first one is padded with zeros, as before)
-        int32_t* dst = pk.sig.get() + soff[i] + (uint64_t)k * ns[i];
-        const std::vector<int32_t>& ch = j.tr.traceACGT[k];
-        const std::size_t have = std::min<std::size_t>(ch.size(), ns[i]);
-        if (have) std::memcpy(dst, ch.data(), have * sizeof(int32_t));
-        if (have < ns[i]) std::memset(dst + have, 0, (ns[i] - have) * sizeof(int32_t));
-      }
-      // (the three per-base arrays share bc_offset: shorter ones are an input error the library reports)
+      // (the per-base arrays share bc_offset: shorter ones are an input error the library reports)
       const std::size_t nb = blen[i];
       if (nb) {
-        std::memcpy(pk.pos.get() + boff[i], j.bc.bcPos.data(), nb * sizeof(int32_t));
+        int32_t* pt = pk.peaks.get() + 4 * boff[i];
+        for (std::size_t b = 0; b < nb; ++b) {
+          const std::size_t at = (std::size_t)j.bc.bcPos[b];
+          for (int k = 0; k < 4; ++k) pt[4 * b + k] = at < j.tr.traceACGT[k].size() ? j.tr.traceACGT[k][at] : 0;  // (a sample behind a channel's end reads as zero)
+        }
         std::memcpy(pk.pri.get() + boff[i], j.bc.primary.data(), std::min<std::size_t>(nb, j.bc.primary.size()));
         std::memcpy(pk.sec.get() + boff[i], j.bc.secondary.data(), std::min<std::size_t>(nb, j.bc.secondary.size()));
       }
@@ -1030,12 +1026,10 @@ struct DecomposeGroup {
     uint8_t* const refs_p = pk.refs.get();
     pri_p = pk.pri.get();
     sec_p = pk.sec.get();
-    int32_t* const sig_p = pk.sig.get();
-    int32_t* const pos_p = pk.pos.get();
     job = tracyhip_decompose_job{};
     job.ntraces = nt;
     job.profiles = tracyhip_seqset{TRACYHIP_SEQ_PROFILE, prof_p, poff.data(), plen.data(), nt};
-    job.bc = tracyhip_basecalls{nt, sig_p, soff.data(), ns.data(), pos_p, pri_p, sec_p, boff.data(), blen.data()};
+    job.bc = tracyhip_basecalls{nt, nullptr, nullptr, nullptr, nullptr, pri_p, sec_p, boff.data(), blen.data(), pk.peaks.get()};
     job.refs = tracyhip_seqset{TRACYHIP_SEQ_CHAR, refs_p, roff.data(), rlen.data(), nt};
     job.dprm = tracyhip_decomp_params{(int32_t)jobs[0]->trimLeft, (int32_t)jobs[0]->trimRight, (int32_t)c.maxindel, (int32_t)c.madc};
     job.strand_by_certificate = 1;  // the orientation scores are not written anywhere (indigo.h:235-247 keeps only rs.forward)

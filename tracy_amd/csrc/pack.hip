@@ -1,8 +1,8 @@
 // pack.hip -- tracyhip_pack_ragged / tracyhip_pack_ragged_multi: the used parts of fixed-stride result regions (traceback strings at
 // ops_offset[i] = i * cap, rows of a decomposition table, rewritten basecalls) back to back, in trace order.  What a rank does to its
 // variable-length results before the second half of the final gather ("... followed by a variable-length gather of op
-// strings / decomposition tables"): HBM-bound byte work -- a scan of the lengths by one workgroup, then one wave per region copying
-// its bytes, for every payload kind of a call in ONE scan, ONE copy launch and ONE synchronisation.
+// strings / decomposition tables"): HBM-bound byte work -- a scan of the lengths, then one wave per region copying its bytes, for every payload kind of a
+// call in ONE scan, ONE copy launch and ONE synchronisation.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -40,16 +40,36 @@ __device__ __forceinline__ unsigned long long region_bytes(const PackKind& k, ui
   return b < k.stride ? b : k.stride;  // (a strided region holds at most its stride, whatever its length word says)
 }
 
-// exclusive scan over the nkinds * n regions in output order (kind-major: all regions of kind 0, then kind 1, ...):
-// off[v] = bytes before region v, off[nkinds * n] = total; kind_end[k] = bytes up to and including kind k
-__global__ __launch_bounds__(kScanThreads) void pack_scan_kernel(PackArgs a, unsigned long long* __restrict__ off, unsigned long long* __restrict__ kind_end) {
+// Exclusive scan over the nkinds * n regions in output order (kind-major: all regions of kind 0, then kind 1, ...), in three launches:
+// (1) one workgroup per 256 regions of a kind (grid.y = the kind: no division by n; a kind's regions are padded to whole workgroups):
+//     the bytes of its regions, their exclusive scan within the workgroup (local[]) and the workgroup's total (bsum[]);
+// (2) one workgroup scans the totals in place (bsum[w] = bytes before workgroup w) and writes the bytes up to the end of every kind;
+// (3) the copy kernel adds the two.
+constexpr uint32_t kScanBlock = 256;
+__global__ __launch_bounds__(kScanBlock) void pack_local_kernel(PackArgs a, unsigned long long* __restrict__ local, unsigned long long* __restrict__ bsum) {
+  __shared__ unsigned long long s[kScanBlock];
+  const uint32_t tid = threadIdx.x, i = blockIdx.x * kScanBlock + tid;
+  const unsigned long long mine = i < a.n ? region_bytes(a.k[blockIdx.y], i) : 0ull;
+  s[tid] = mine;
+  __syncthreads();
+  for (uint32_t d = 1; d < kScanBlock; d <<= 1) {
+    const unsigned long long x = tid >= d ? s[tid - d] : 0ull;
+    __syncthreads();
+    s[tid] += x;
+    __syncthreads();
+  }
+  const size_t w = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  local[w * kScanBlock + tid] = s[tid] - mine;
+  if (tid == kScanBlock - 1) bsum[w] = s[tid];
+}
+__global__ __launch_bounds__(kScanThreads) void pack_top_kernel(unsigned long long* __restrict__ bsum, uint32_t nw, uint32_t w_per_kind, uint32_t nkinds,
+                                                                unsigned long long* __restrict__ kind_end) {
   __shared__ unsigned long long s[kScanThreads];
   const uint32_t tid = threadIdx.x;
-  const unsigned long long tot = (unsigned long long)a.nkinds * a.n;
-  const unsigned long long per = (tot + kScanThreads - 1) / kScanThreads;
-  const unsigned long long lo = tid * per < tot ? tid * per : tot, hi = lo + per < tot ? lo + per : tot;
+  const uint32_t per = (nw + kScanThreads - 1) / kScanThreads;
+  const uint32_t lo = (uint64_t)tid * per < nw ? tid * per : nw, hi = lo + per < nw ? lo + per : nw;
   unsigned long long mine = 0;
-  for (unsigned long long v = lo; v < hi; ++v) mine += region_bytes(a.k[v / a.n], (uint32_t)(v % a.n));
+  for (uint32_t w = lo; w < hi; ++w) mine += bsum[w];
   s[tid] = mine;
   __syncthreads();
   for (uint32_t d = 1; d < kScanThreads; d <<= 1) {
@@ -59,27 +79,27 @@ __global__ __launch_bounds__(kScanThreads) void pack_scan_kernel(PackArgs a, uns
     __syncthreads();
   }
   unsigned long long at = s[tid] - mine;
-  for (unsigned long long v = lo; v < hi; ++v) {
-    off[v] = at;
-    at += region_bytes(a.k[v / a.n], (uint32_t)(v % a.n));
-    if ((v + 1) % a.n == 0) kind_end[v / a.n] = at;
+  for (uint32_t w = lo; w < hi; ++w) {
+    const unsigned long long x = bsum[w];
+    bsum[w] = at;
+    at += x;
+    if ((w + 1u) % w_per_kind == 0u) kind_end[w / w_per_kind] = at;
   }
-  if (tid == kScanThreads - 1) off[tot] = s[tid];
 }
 
 // One wave per region (four to a workgroup).  The destination is written in aligned dwords: a lane's dword is cut out of the two
 // aligned source dwords that hold it (v_alignbyte), so a wave moves 256 bytes per step whatever the two alignments are; the bytes
 // before the first and behind the last aligned dword of the destination go one by one.
-__global__ __launch_bounds__(256) void pack_copy_kernel(PackArgs a, const unsigned long long* __restrict__ off, uint8_t* __restrict__ dst) {
-  const unsigned long long v = (unsigned long long)blockIdx.x * 4u + (threadIdx.x >> 6);
-  const uint32_t L = threadIdx.x & 63u;
-  if (v >= (unsigned long long)a.nkinds * a.n) return;
-  const PackKind& k = a.k[v / a.n];
-  const uint32_t i = (uint32_t)(v % a.n);
+__global__ __launch_bounds__(256) void pack_copy_kernel(PackArgs a, const unsigned long long* __restrict__ local, const unsigned long long* __restrict__ bsum,
+                                                        uint32_t w_per_kind, uint8_t* __restrict__ dst) {
+  const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), L = threadIdx.x & 63u;  // (grid.y = the kind)
+  if (i >= a.n) return;
+  const PackKind& k = a.k[blockIdx.y];
   const unsigned long long bytes = region_bytes(k, i);
   if (bytes == 0) return;
+  const size_t w = (size_t)blockIdx.y * w_per_kind + i / kScanBlock;
   const uint8_t* s = k.src + (unsigned long long)i * k.stride;
-  uint8_t* d = dst + off[v];
+  uint8_t* d = dst + bsum[w] + local[w * kScanBlock + i % kScanBlock];
   const unsigned long long head0 = (4u - (reinterpret_cast<uintptr_t>(d) & 3u)) & 3u;
   const unsigned long long head = head0 < bytes ? head0 : bytes;
   if (L < head) d[L] = s[L];
@@ -113,11 +133,13 @@ int pack_multi(tracyhip_ctx* ctx, const tracyhip_ragged_src* kinds, uint32_t nki
     worst += (uint64_t)n * q.stride_bytes;
   }
   hipStream_t st = ctx->stream;
-  const size_t nreg = (size_t)nkinds * n;
-  HIP_TRY(ctx->d_tmp[7].ensure(sizeof(unsigned long long) * (nreg + 1 + kMaxKinds)));
-  unsigned long long* d_off = static_cast<unsigned long long*>(ctx->d_tmp[7].p);
-  unsigned long long* d_kend = d_off + nreg + 1;
-  hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(kScanThreads), 0, st, a, d_off, d_kend);
+  const uint32_t wpk = (n + kScanBlock - 1) / kScanBlock, nw = wpk * nkinds;  // scan workgroups per kind, in all
+  HIP_TRY(ctx->d_tmp[7].ensure(sizeof(unsigned long long) * ((size_t)nw * kScanBlock + nw + kMaxKinds)));
+  unsigned long long* d_local = static_cast<unsigned long long*>(ctx->d_tmp[7].p);
+  unsigned long long* d_bsum = d_local + (size_t)nw * kScanBlock;
+  unsigned long long* d_kend = d_bsum + nw;
+  hipLaunchKernelGGL(pack_local_kernel, dim3(wpk, nkinds), dim3(kScanBlock), 0, st, a, d_local, d_bsum);
+  hipLaunchKernelGGL(pack_top_kernel, dim3(1), dim3(kScanThreads), 0, st, d_bsum, nw, wpk, nkinds, d_kend);
   HIP_TRY(hipGetLastError());
   HIP_TRY(ctx->h_res.ensure(sizeof(unsigned long long) * kMaxKinds));
   unsigned long long* h_kend = static_cast<unsigned long long*>(ctx->h_res.p);
@@ -133,7 +155,7 @@ int pack_multi(tracyhip_ctx* ctx, const tracyhip_ragged_src* kinds, uint32_t nki
       if (h_kend[nkinds - 1] > dst_cap)
         return set_error(TRACYHIP_ERR_ARG, "tracyhip_pack_ragged: %llu bytes to pack, capacity %llu", h_kend[nkinds - 1], (unsigned long long)dst_cap);
     }
-    hipLaunchKernelGGL(pack_copy_kernel, dim3((unsigned)((nreg + 3) / 4)), dim3(256), 0, st, a, d_off, static_cast<uint8_t*>(dst));
+    hipLaunchKernelGGL(pack_copy_kernel, dim3((n + 3) / 4, nkinds), dim3(256), 0, st, a, d_local, d_bsum, wpk, static_cast<uint8_t*>(dst));
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(ctx_sync(ctx));

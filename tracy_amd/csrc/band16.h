@@ -405,10 +405,53 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   // rows of strip s: K int16 per code, straight from the sequence's table
   constexpr int ND = K / 2;
   uint32_t pf[kB16Codes][ND];
+  // The rows of strip b + P are requested when strip b begins and used P blocks later.  gfx950 counts loads and stores in ONE in-order
+  // counter, and the compiler -- which cannot count memory operations across the block loop -- waits for vmcnt(0) where the rows are
+  // used: behind the acknowledgement of the trace words stored a few instructions earlier, once per block (round 5: 29-34 % of the
+  // traceback kernels' wave cycles in s_waitcnt).  The traceback sweeps on strips of 4 / 8 rows therefore issue the loads by hand and
+  // wait for vmcnt(kPfBehind): every block between the request and the use stores its words (a pair with a strip b + P has a live
+  // strip in each of them: >= 2 store instructions per block at K = 4 -- ten bytes --, >= 3 at K = 8 -- thirty-six), so the rows are
+  // older than the (P - 1) x that many operations the wait leaves outstanding.  The first P blocks use the rows requested before the
+  // loop, with no such guarantee: vmcnt(0).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TRACY_B16_NO_HANDLOAD)
+  constexpr bool HANDLOAD = KIND == 0 && K <= 8;
+#else
+  constexpr bool HANDLOAD = false;
+#endif
+  constexpr int kPfBehind = (P - 1) * (K <= 4 ? 2 : 3);
+  static_assert(!HANDLOAD || kPfBehind <= 63, "vmcnt is a six-bit counter");
+  typedef uint32_t pf_vec __attribute__((ext_vector_type(K <= 4 ? 2 : 4)));
+  pf_vec pv[kB16Codes];
   auto prefetch = [&](uint32_t s) {
     const int16_t* src = a.qp + d.a1_off + (uint64_t)s * K;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (HANDLOAD) {
+#pragma unroll
+      for (uint32_t b = 0; b < kB16Codes; ++b) {
+        const int16_t* q = src + (uint64_t)b * d.a1_stride;  // (any alignment: a trimmed view may start on an odd row)
+        if (K <= 4) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pv[b]) : "v"(q));
+        else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pv[b]) : "v"(q));
+      }
+      return;
+    }
+#endif
 #pragma unroll
     for (uint32_t b = 0; b < kB16Codes; ++b) __builtin_memcpy(pf[b], src + (uint64_t)b * d.a1_stride, 2 * K);  // (any alignment: a trimmed view may start on an odd row)
+  };
+  // the requested rows have arrived: into pf (hand-issued loads only)
+  auto arrived = [&](auto first) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (HANDLOAD) {
+      if (decltype(first)::value)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]) : : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]) : "n"(kPfBehind) : "memory");
+#pragma unroll
+      for (uint32_t b = 0; b < kB16Codes; ++b)
+#pragma unroll
+        for (int h = 0; h < ND; ++h) pf[b][h] = pv[b][h];
+    }
+#endif
   };
   if (have && j < NS) prefetch(j);
 
@@ -441,6 +484,7 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
       bot_h = cw <= 0 ? edge(r0 + (uint32_t)K) : neg;  // what the strip below sees while this one waits for column 1
       bot_f = neg;
       if (b == 0) prev_up_h = CONT ? lrow[2 * (cw - 1 - crow0)] : row0(cw - 1);
+      arrived(first);
 #pragma unroll
       for (uint32_t q = 0; q < kB16Codes; ++q) {
         const uint32_t rowsel = (rcflag && q < 4u) ? 3u - q : q;  // reverse-complement view: the complement is folded into the table
@@ -541,7 +585,10 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
   if (KIND == 0) {
     w.sync_global();
     Band16Fetch<K> fetch{bits, S, S_last, NS, n, dmin, lay};
-    walk16<W, Band16Fetch<K>, P, (P == 4 ? 4 : 1)>(w, fetch, have, m, n, have ? a.ops + a.ops_off[d.out] : nullptr, have ? a.ops_len + d.out : nullptr, a.err,
+#ifndef TRACY_B16_WALK_C
+#define TRACY_B16_WALK_C 2  // (two cells per lane and round on sixteen lanes: a round of the walk costs a memory round trip whatever it looks at; A/B: band tracebacks of a decompose step 13.7 -> 13.4 ms)
+#endif
+    walk16<W, Band16Fetch<K>, P, (P == 4 ? 4 : TRACY_B16_WALK_C)>(w, fetch, have, m, n, have ? a.ops + a.ops_off[d.out] : nullptr, have ? a.ops_len + d.out : nullptr, a.err,
            (uint32_t)d.lastrow_off, (uint32_t)(d.lastrow_off >> 32));
   }
 }

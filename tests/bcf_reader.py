@@ -104,3 +104,77 @@ def read_bcf(path):
         recs.append({"CHROM": contigs[chrom], "POS": pos + 1, "ID": vid, "REF": alleles[0], "ALT": ",".join(alleles[1:]), "QUAL": qual,
                      "FILTER": ";".join(flt), "INFO": info, "GT": gts, "GQ": fmt["GQ"][0][0]})
     return header, recs, blocks
+
+
+# ---- CSI index (SAM/VCF specification, section "CSI index format"), read independently of tracy_amd/host/bcf_out.hpp ----
+def bgzf_blocks(data):
+    """[(file offset of the block, its uncompressed bytes)]"""
+    out, at = [], 0
+    while at < len(data):
+        xlen = struct.unpack_from("<H", data, at + 10)[0]
+        bsize = struct.unpack_from("<H", data, at + 16)[0] + 1
+        raw = zlib.decompress(data[at + 12 + xlen:at + bsize - 8], -15)
+        out.append((at, raw))
+        at += bsize
+    return out
+
+
+def read_csi(path):
+    raw, _ = bgzf_decompress(open(path, "rb").read())
+    assert raw[:4] == b"CSI\x01"
+    min_shift, depth, l_aux = struct.unpack_from("<iii", raw, 4)
+    at = 16 + l_aux
+    n_ref = struct.unpack_from("<i", raw, at)[0]
+    at += 4
+    refs = []
+    for _ in range(n_ref):
+        n_bin = struct.unpack_from("<i", raw, at)[0]
+        at += 4
+        bins = {}
+        for _ in range(n_bin):
+            b, loff, n_chunk = struct.unpack_from("<IQi", raw, at)
+            at += 16
+            chunks = [struct.unpack_from("<QQ", raw, at + 16 * k) for k in range(n_chunk)]
+            at += 16 * n_chunk
+            bins[b] = (loff, chunks)
+        refs.append(bins)
+    n_no_coor = struct.unpack_from("<Q", raw, at)[0] if at + 8 <= len(raw) else None
+    return {"min_shift": min_shift, "depth": depth, "refs": refs, "n_no_coor": n_no_coor}
+
+
+def reg2bins(beg, end, min_shift, depth):
+    """every bin that may hold a record overlapping [beg, end) (the specification's reg2bins)"""
+    out, t, s = [], 0, min_shift + depth * 3
+    end -= 1
+    for l in range(depth + 1):
+        out.extend(range(t + (beg >> s), t + (end >> s) + 1))
+        t += 1 << (l * 3)
+        s -= 3
+    return out
+
+
+def csi_query(bcf_path, csi, rid, beg, end):
+    """records of contig `rid` overlapping [beg, end) found THROUGH the index: (pos0, rlen) of every record in the chunks of the bins
+    the region maps to, filtered by overlap -- read at the chunks' virtual offsets"""
+    data = open(bcf_path, "rb").read()
+    blocks = bgzf_blocks(data)
+    start_of = {off: sum(len(r) for _, r in blocks[:i]) for i, (off, _) in enumerate(blocks)}
+    flat = b"".join(r for _, r in blocks)
+
+    def upos(v):
+        return start_of[v >> 16] + (v & 0xffff)
+    meta = ((1 << ((csi["depth"] + 1) * 3)) - 1) // 7 + 1
+    found = []
+    for b in reg2bins(beg, end, csi["min_shift"], csi["depth"]):
+        if b == meta or b not in csi["refs"][rid]:
+            continue
+        for cb, ce in csi["refs"][rid][b][1]:
+            at, stop = upos(cb), upos(ce)
+            while at < stop:
+                l_shared, l_indiv = struct.unpack_from("<II", flat, at)
+                chrom, pos, rlen = struct.unpack_from("<iii", flat, at + 8)
+                if chrom == rid and pos < end and pos + max(rlen, 1) > beg:
+                    found.append((pos, rlen))
+                at += 8 + l_shared + l_indiv
+            assert at == stop, "a chunk ends on a record boundary"
+    return sorted(set(found))

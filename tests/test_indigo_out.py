@@ -77,6 +77,21 @@ def test_decompose_output_files(tmp_path, reverse, kind):
         assert b["QUAL"] == float(r[5])
         assert (b["INFO"]["TYPE"], b["INFO"]["METHOD"], b["INFO"]["BASEPOS"], b["INFO"]["SIGNALPOS"]) == (info["TYPE"], info["METHOD"], int(info["BASEPOS"]), int(info["SIGNALPOS"]))
         assert r[8] == "GT:GQ" and (b["GT"], b["GQ"]) == (r[9].split(":")[0], int(r[9].split(":")[1]))
+    # <prefix>.bcf.csi (bcf_index_build, variants.h:263): every record is found through the index at its own position, nothing where there
+    # is nothing, the pseudo-bin counts the records (tests/bcf_reader.py reads the index from the specification's layout)
+    from bcf_reader import csi_query, read_csi
+    csi = read_csi(prefix + ".bcf.csi")
+    assert csi["min_shift"] == 14 and len(csi["refs"]) == 1 and csi["n_no_coor"] == 0
+    meta = ((1 << ((csi["depth"] + 1) * 3)) - 1) // 7 + 1
+    if brecs:
+        assert csi["refs"][0][meta][1][1] == (len(brecs), 0)
+        for b in brecs:
+            hit = csi_query(prefix + ".bcf", csi, 0, b["POS"] - 1, b["POS"] - 1 + len(b["REF"]))
+            assert (b["POS"] - 1, len(b["REF"])) in hit
+        lo = min(b["POS"] for b in brecs) - 1
+        assert csi_query(prefix + ".bcf", csi, 0, 0, max(lo, 0)) == [] or lo == 0
+        allr = csi_query(prefix + ".bcf", csi, 0, 0, 1 << 29)
+        assert allr == sorted(set((b["POS"] - 1, len(b["REF"])) for b in brecs))
     if kind == 0:
         assert w["bp"].indelshift and len(var) > 0
 

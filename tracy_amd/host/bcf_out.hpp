@@ -6,13 +6,14 @@
 // INFO / FORMAT lines in vcfOutput's order, which fixes the dictionary indices), one typed-value record per variant with the fields in
 // the order vcfOutput sets them: ID, REF/ALT, FILTER, INFO TYPE, METHOD, BASEPOS, SIGNALPOS, FORMAT GT, GQ.  Integers take the smallest
 // type that holds them (htslib's rule: int8 down to -120, int16 down to -32760, else int32).  The .csi index the reference builds next
-// (bcf_index_build) is not written.  Parity status: unpinned -- there is no htslib / bcftools here to read the file back; the tests decode
+// (bcf_index_build) is written beside it (csi_build below).  Parity status: unpinned -- there is no htslib / bcftools here to read the file back; the tests decode
 // it with their own reader (tests/bcf_reader.py) and compare field by field with the VCF text of the same variants.
 #ifndef TRACY_AMD_HOST_BCF_OUT_HPP
 #define TRACY_AMD_HOST_BCF_OUT_HPP
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -47,10 +48,15 @@ inline bool bgzf_block(std::vector<uint8_t>& out, const uint8_t* data, std::size
     for (int k = 0; k < 4; ++k) out.push_back((uint8_t)(v >> (8 * k)));
   return true;
 }
-inline bool bgzf_compress(std::vector<uint8_t> const& raw, std::vector<uint8_t>& out) {
-  constexpr std::size_t kBlock = 0xff00;  // (htslib's BGZF_BLOCK_SIZE: the deflated block stays below 64 KB whatever the data)
-  for (std::size_t at = 0; at < raw.size(); at += kBlock)
+constexpr std::size_t kBgzfBlock = 0xff00;  // (htslib's BGZF_BLOCK_SIZE: the deflated block stays below 64 KB whatever the data)
+// block_start (or null): the file offset at which every block of kBgzfBlock uncompressed bytes begins (virtual file offsets of the index)
+inline bool bgzf_compress(std::vector<uint8_t> const& raw, std::vector<uint8_t>& out, std::vector<uint64_t>* block_start = nullptr) {
+  constexpr std::size_t kBlock = kBgzfBlock;
+  for (std::size_t at = 0; at < raw.size(); at += kBlock) {
+    if (block_start) block_start->push_back(out.size());
     if (!bgzf_block(out, raw.data() + at, raw.size() - at < kBlock ? raw.size() - at : kBlock)) return false;
+  }
+  if (block_start) block_start->push_back(out.size());  // (where a block behind the last one would begin: the end-of-file marker)
   static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   out.insert(out.end(), eof, eof + 28);
   return true;
@@ -77,6 +83,89 @@ struct Enc {
     b.insert(b.end(), s.begin(), s.end());
   }
 };
+
+// ---- CSI index (bcf_index_build(fn, 14), variants.h:263): binning index over the records' [pos, pos + rlen) per contig, written from the
+// CSIv1 layout of the SAM/VCF specification: "CSI\1", min_shift, depth, l_aux = 0, n_ref, per contig its bins {bin, loffset, chunks} and
+// the pseudo-bin with the contig's file span and record count; BGZF-compressed like the file it indexes.  A chunk is a run of records
+// that fall into the same bin one after the other (hts_idx_push merges them the same way); a bin's loffset is the linear index's entry
+// for the bin's first 2^min_shift window (the offset of the first record that overlaps that window or a later one).  htslib also folds
+// bins whose chunks lie within one 64 KB span into their parents (compress_binning): an optimisation of the index's size, not of what it
+// finds -- left out, so the file is a valid index but not htslib's bytes.
+struct CsiRecord { int32_t rid; int64_t beg, end; uint64_t voff_beg, voff_end; };
+inline int csi_depth(int64_t max_len, int min_shift) {
+  int n_lvls = 0;
+  max_len += 256;
+  for (int64_t s = 1ll << min_shift; max_len > s; s <<= 3) ++n_lvls;
+  return n_lvls;
+}
+inline uint32_t csi_reg2bin(int64_t beg, int64_t end, int min_shift, int depth) {
+  int l, s = min_shift;
+  int64_t t = ((1ll << (depth * 3)) - 1) / 7;
+  for (--end, l = depth; l > 0; --l, s += 3, t -= 1ll << (l * 3))
+    if ((beg >> s) == (end >> s)) return (uint32_t)(t + (beg >> s));
+  return 0;
+}
+inline int64_t csi_bin_first_window(uint32_t bin, int depth) {  // first 2^min_shift window a bin covers (hts_bin_bot)
+  int l = 0;
+  for (uint32_t b = bin; b; b = (b - 1) >> 3) ++l;  // the bin's level
+  const int64_t first_of_level = ((1ll << (l * 3)) - 1) / 7;
+  return ((int64_t)bin - first_of_level) << ((depth - l) * 3);
+}
+inline std::vector<uint8_t> csi_build(std::vector<CsiRecord> const& recs, std::size_t n_ref, int64_t max_contig_len, uint64_t voff_first) {
+  constexpr int kMinShift = 14;
+  const int depth = csi_depth(max_contig_len, kMinShift);
+  std::vector<uint8_t> raw;
+  Enc e{raw};
+  raw.insert(raw.end(), {'C', 'S', 'I', 1});
+  e.le((uint32_t)kMinShift, 4);
+  e.le((uint32_t)depth, 4);
+  e.le(0, 4);  // l_aux
+  e.le((uint32_t)n_ref, 4);
+  const uint32_t meta_bin = (uint32_t)(((1ll << ((depth + 1) * 3)) - 1) / 7 + 1);
+  for (std::size_t r = 0; r < n_ref; ++r) {
+    struct Bin { uint32_t id; std::vector<std::pair<uint64_t, uint64_t>> chunks; };
+    std::vector<Bin> bins;              // in order of first appearance (a contig of a Sanger trace has a handful)
+    std::vector<uint64_t> lidx;         // window -> offset of the first record that overlaps it
+    uint64_t off_beg = 0, off_end = 0, n_mapped = 0;
+    uint32_t last_bin = 0xffffffffu;
+    for (CsiRecord const& x : recs) {
+      if (x.rid != (int32_t)r) { last_bin = 0xffffffffu; continue; }
+      if (n_mapped == 0) off_beg = x.voff_beg;
+      off_end = x.voff_end;
+      ++n_mapped;
+      const int64_t end = x.end > x.beg ? x.end : x.beg + 1;
+      const uint32_t b = csi_reg2bin(x.beg, end, kMinShift, depth);
+      Bin* bp = nullptr;
+      for (Bin& q : bins) if (q.id == b) { bp = &q; break; }
+      if (!bp) { bins.push_back(Bin{b, {}}); bp = &bins.back(); }
+      if (b == last_bin && !bp->chunks.empty()) bp->chunks.back().second = x.voff_end;
+      else bp->chunks.emplace_back(x.voff_beg, x.voff_end);
+      last_bin = b;
+      const std::size_t w0 = (std::size_t)(x.beg >> kMinShift), w1 = (std::size_t)((end - 1) >> kMinShift);
+      if (lidx.size() <= w1) lidx.resize(w1 + 1, ~0ull);
+      for (std::size_t w = w0; w <= w1; ++w) if (lidx[w] == ~0ull) lidx[w] = x.voff_beg;
+    }
+    for (std::size_t w = lidx.size(); w-- > 1;) if (lidx[w - 1] == ~0ull) lidx[w - 1] = lidx[w];  // windows without a record: the next one's
+    e.le((uint32_t)(bins.size() + (n_mapped ? 1 : 0)), 4);
+    for (Bin const& q : bins) {
+      e.le(q.id, 4);
+      const int64_t w = csi_bin_first_window(q.id, depth);
+      e.le((w >= 0 && (std::size_t)w < lidx.size()) ? lidx[(std::size_t)w] : 0ull, 8);
+      e.le((uint32_t)q.chunks.size(), 4);
+      for (auto const& c : q.chunks) { e.le(c.first, 8); e.le(c.second, 8); }
+    }
+    if (n_mapped) {
+      e.le(meta_bin, 4);
+      e.le(0, 8);  // (loffset of the pseudo-bin)
+      e.le(2, 4);
+      e.le(off_beg, 8); e.le(off_end, 8);
+      e.le(n_mapped, 8); e.le(0, 8);  // mapped / unmapped
+    }
+  }
+  e.le(0, 8);  // n_no_coor
+  (void)voff_first;
+  return raw;
+}
 
 }  // namespace bcfdetail
 
@@ -129,7 +218,10 @@ inline bool bcfOutput(std::string const& outfile, ReportConfig const& c, BaseCal
   raw.insert(raw.end(), text.begin(), text.end());
   raw.push_back(0);
   // ---- records ----
+  std::vector<bcfdetail::CsiRecord> index_recs;
+  const std::size_t first_record = raw.size();
   for (Variant const& v : var) {
+    const std::size_t rec_begin = raw.size();
     const uint32_t q = variantCallIndex(c, bc, rs.forward, v.basenum);
     const int32_t qual = strInclN(v.alt) ? 0 : (int32_t)bc.estQual[q];
     const int64_t basepos = rs.forward ? (int64_t)c.trimLeft + v.basenum : (int64_t)bc.primary.size() - (c.trimRight + v.basenum) + 1;
@@ -171,12 +263,31 @@ inline bool bcfOutput(std::string const& outfile, ReportConfig const& c, BaseCal
     e.le(indiv.size(), 4);
     raw.insert(raw.end(), shared.begin(), shared.end());
     raw.insert(raw.end(), indiv.begin(), indiv.end());
+    index_recs.push_back(bcfdetail::CsiRecord{rid, (int64_t)v.pos - 1, (int64_t)v.pos - 1 + (int64_t)v.ref.size(), (uint64_t)rec_begin, (uint64_t)raw.size()});
   }
   std::vector<uint8_t> file;
-  if (!bcfdetail::bgzf_compress(raw, file)) return false;
-  TextBuf f(file.size() + 64);
-  f.put(reinterpret_cast<const char*>(file.data()), file.size());
-  return f.write(outfile);
+  std::vector<uint64_t> block_start;
+  if (!bcfdetail::bgzf_compress(raw, file, &block_start)) return false;
+  {
+    TextBuf f(file.size() + 64);
+    f.put(reinterpret_cast<const char*>(file.data()), file.size());
+    if (!f.write(outfile)) return false;
+  }
+  // ---- <outfile>.csi (bcf_index_build, variants.h:263): uncompressed positions -> virtual file offsets (block start << 16 | offset in the block) ----
+  auto voff = [&](uint64_t u) -> uint64_t {
+    const std::size_t b = (std::size_t)(u / bcfdetail::kBgzfBlock);
+    return (block_start[b < block_start.size() ? b : block_start.size() - 1] << 16) | (u % bcfdetail::kBgzfBlock);
+  };
+  for (auto& x : index_recs) { x.voff_beg = voff(x.voff_beg); x.voff_end = voff(x.voff_end); }
+  int64_t max_len = 0;
+  if (contigs) for (auto const& ctg : *contigs) max_len = std::max<int64_t>(max_len, (int64_t)ctg.second);
+  else max_len = (int64_t)rs.refslice.size();
+  const std::vector<uint8_t> idx_raw = bcfdetail::csi_build(index_recs, names.size(), max_len, voff(first_record));
+  std::vector<uint8_t> idx_file;
+  if (!bcfdetail::bgzf_compress(idx_raw, idx_file)) return false;
+  TextBuf fi(idx_file.size() + 64);
+  fi.put(reinterpret_cast<const char*>(idx_file.data()), idx_file.size());
+  return fi.write(outfile + ".csi");
 }
 
 }  // namespace tracy_amd

@@ -161,7 +161,7 @@ def finish_line(line, args):
                      "small_batch_ms": sb.get("ms_per_step"), "small_batch_ratio": sb.get("vs_eighth_of_the_full_step"),
                      "decompose_gathered_bytes_per_step": d.get("gathered_bytes_per_step")})
         r = d.get("roofline") or {}
-        out["decompose"] = dict(_pick(d, ("value", "unit", "ms_per_step", "gcups", "steps", "n_gpus", "scaling", "traces_ok", "gathered_bytes_per_step", "gather_checked", "parity_checked")),
+        out["decompose"] = dict(_pick(d, ("value", "unit", "ms_per_step", "gcups", "steps", "n_gpus", "scaling", "traces_ok", "gathered_bytes_per_step", "gather_ms_per_step", "gather_checked", "parity_checked")),
                                 small_batch=_pick(sb, ("traces", "ms_per_step", "two_lanes_ms_per_step", "vs_eighth_of_the_full_step")),
                                 strand_by_certificate_ms=(d.get("strand_by_certificate") or {}).get("ms_per_step"),
                                 two_lanes_ms=(d.get("lanes") or {}).get("ms_per_step"),
@@ -376,7 +376,7 @@ def main():
     lib = capi.lib()
     REC_KEYS = ("score_fwd", "score_rev", "score_prelim", "slice_begin", "slice_len", "ref_pos", "score_final", "ops_len")
     gatherer = ResultGather(dist, [nt] * world, ctx) if dist is not None else None  # (weak scaling: every rank holds nt traces)
-    gathered = {"out": None, "bytes": 0}
+    gathered = {"out": None, "bytes": 0, "seconds": 0.0}
 
     def run_call():
         rc = lib.tracyhip_align_traces(ctx._h, C.byref(job), C.byref(prm), capi.MEM_DEVICE, C.byref(out))
@@ -384,13 +384,15 @@ def main():
             raise RuntimeError("tracyhip_align_traces: %s" % lib.tracyhip_last_error().decode())
 
     def step():
-        run_call()
+        run_call()  # (synchronous: the results are complete when it returns)
+        t_g = time.perf_counter()
         if dist is not None:
             # the final gather, both halves: the fixed-size record of every trace in one collective, then the traceback strings
             # (sage.h:311's alignment) packed on the device and shipped in one exchange sized from the records' ops_len column
             rec = torch.stack([r_i32[k] for k in REC_KEYS] + [r_fwd.to(torch.int32)], dim=1)
             gathered["out"] = gatherer.gather(rec, [(r_ops, ops_cap, REC_KEYS.index("ops_len"))])
             gathered["bytes"] = gatherer.bytes_last
+            gathered["seconds"] += time.perf_counter() - t_g  # (the pack ends with a synchronisation: host time = the gather's share of the step on this rank)
 
     def read_timers():
         kt = capi.KernelTiming()
@@ -419,6 +421,7 @@ def main():
         return dt, read_timers()
 
     elapsed, rl = timed_leg()
+    gather_ms = gathered["seconds"] / max(args.steps + args.warmup, 1) * 1e3  # (rank 0's; the warm-up steps gather as well)
     call_stats = ctx.last_call_stats()
     slice_len = r_i32["slice_len"].cpu().numpy().astype(np.int64)
     elapsed_cert, rl_cert = 0.0, None
@@ -573,11 +576,14 @@ def main():
         # by the cells the kernels really evaluated
         "gcups_swept_cells": round(swept, 2),
         "gathered_bytes_per_step": int(gathered_bytes_all), "gather_checked": gather_ok,
+        # the part of ms_per_step spent behind the library call: records stacked, traceback strings packed (one device pass + its
+        # synchronisation), both shipped to rank 0 (round 5's step gathered four integers per trace and nothing else)
+        "gather_ms_per_step": round(gather_ms, 3),
         "config": {"workload": "configs[1]: %d synthetic %d-base traces `align` vs %d-base windows per GPU, scoring 3/-5/-10/-4, trims 50/50" % (nt, mf, n),
                    "traces_per_gpu": nt, "trace_len": mf, "ref_len": n,
                    "parallelism": "batch-sharded x%d, no data-path collective; gather of records + traceback strings to rank 0" % world,
                    "lanes_per_gpu": max(1, args.lanes), "gcups_swept_cells": round(swept, 2),
-                   "gathered_bytes_per_step": int(gathered_bytes_all)},
+                   "gathered_bytes_per_step": int(gathered_bytes_all), "gather_ms_per_step": round(gather_ms, 3)},
         "roofline": roofline,
         # rank 0's view of a call: planned on the device, one host synchronisation (stream.hip); min / max over the ranks
         "pipeline": {"stream_ordered": call_stats["stream_ordered"], "host_syncs_per_call": call_stats["host_syncs"],

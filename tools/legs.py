@@ -238,6 +238,7 @@ class DecomposeLeg:
         self.ctx.set_lanes(max(1, lanes))
         self.lib = capi.lib()
         self.gatherer, self.gathered, self.gathered_bytes = None, None, 0
+        self.gather_seconds, self.gather_steps = 0.0, 0
         self.bc_len_col = torch.full((nt, 1), mf, dtype=torch.int32, device=dev)
 
     def step(self, dist=None):
@@ -246,6 +247,7 @@ class DecomposeLeg:
         rc = self.lib.tracyhip_decompose_traces(self.ctx._h, C.byref(self.job), C.byref(self.prm), self.capi.MEM_DEVICE, C.byref(self.out))
         if rc != 0:
             raise RuntimeError("tracyhip_decompose_traces: %s" % self.lib.tracyhip_last_error().decode())
+        t_g = time.perf_counter()
         if dist is not None:
             # the final gather, both halves: one fixed-size record per trace in one collective, then what has no fixed size --
             # the three traceback strings, the rewritten basecalls, bc.secDecompose, the decomposition table -- packed on the device and
@@ -256,6 +258,8 @@ class DecomposeLeg:
             rec, pay = self.result_records()
             self.gathered = self.gatherer.gather(rec, pay)
             self.gathered_bytes = self.gatherer.bytes_last
+            self.gather_seconds += time.perf_counter() - t_g
+            self.gather_steps += 1
 
     REC_COLS = ("status", "score_trim", "score_fwd", "score_rev", "forward", "score0", "score1", "score2", "ops_len0", "ops_len1", "ops_len2", "slice_begin0",
                 "slice_len0", "ref_pos0", "slice_begin1", "slice_len1", "ref_pos1", "bc_len", "bp.indelshift", "bp.traceleft", "bp.breakpoint", "bp.best_diff",
@@ -341,6 +345,7 @@ class DecomposeLeg:
     def run(self, dist, steps, warmup, extra_legs=True, cpu_sample=64):
         dev = self.dev
         dt, timers = timed(lambda: self.step(dist), steps, warmup, dist, self.lib, self.ctx)
+        gather_ms = self.gather_seconds / max(self.gather_steps, 1) * 1e3
         call_stats = self.ctx.last_call_stats()
         dt_rank = dt
         small = self.small_batch(max(1, self.total // 8)) if (self.world == 1 and extra_legs) else None
@@ -409,7 +414,7 @@ class DecomposeLeg:
                 "config": {"workload": "configs[2]: %d synthetic %d-base traces `decompose` vs %d-base windows (80%% het indel + het SNVs, 10%% homozygous "
                                        "indel, 10%% no variant, both strands), sharded over %d rank(s)" % (int(nt_all), self.mf, self.n, self.world),
                            "traces_total": int(nt_all), "trace_len": self.mf, "ref_len": self.n},
-                "traces_ok": int(ok_all), "gathered_bytes_per_step": int(gbytes_all), "gather_checked": gather_ok, "data": "synthetic", "synthesis_s": round(self.synth_s, 1), "roofline": roof,
+                "traces_ok": int(ok_all), "gathered_bytes_per_step": int(gbytes_all), "gather_checked": gather_ok, "gather_ms_per_step": round(gather_ms, 3), "data": "synthetic", "synthesis_s": round(self.synth_s, 1), "roofline": roof,
                 # one rank's view of the call: planned on the device, one host synchronisation (stream.hip); min / max over the ranks of a sharded job
                 "pipeline": {"stream_ordered": call_stats["stream_ordered"], "host_syncs_per_call": call_stats["host_syncs"],
                              "traces_to_host_planned_tiers": call_stats["fallback_traces"], "traces_per_rank": self.nt,

@@ -102,7 +102,13 @@ __global__ __launch_bounds__(64) TRACY_SWEEP_ATTR void gotoh_ckpt_prefix_kernel(
   DeviceWave w;
   const uint32_t ngroups = (npre + 64u / GL - 1u) / (64u / GL);
   if (blockIdx.x < ngroups) gotoh_prefix_body<DeviceWave, KP, GL, COMPACT>(w, pre, blockIdx.x * (64u / GL), npre);
-  else gotoh_body<DeviceWave, K, MODE_QP, false, true, true, 0, COMPACT>(w, full, blockIdx.x - ngroups);
+  else {
+#ifdef TRACY_SWEEP_STAGGER
+    // (experiment: the waves of a launch's first round start within microseconds of each other and run the same instruction stream)
+    for (uint32_t h = (blockIdx.x * 2654435761u) >> 27; h; --h) __builtin_amdgcn_s_sleep(TRACY_SWEEP_STAGGER);
+#endif
+    gotoh_body<DeviceWave, K, MODE_QP, false, true, true, 0, COMPACT>(w, full, blockIdx.x - ngroups);
+  }
 }
 // prefix bound of the semiglobal score: GL lanes per pair, 64/GL pairs per workgroup
 template <int K, int GL, bool COMPACT = false, bool STRINGS = false>
@@ -479,7 +485,7 @@ static hipError_t launch_gotoh_ckpt_front_t(int K, const DpArgs& full, uint32_t 
   const dim3 grid(nfull + (npre + 64 / GL - 1) / (64 / GL));
   auto lds = [](int KK, bool compact) {
     const uint32_t pre_b = lds_bytes_prefix(KP, compact), sw = lds_bytes_sweep16(KK, compact);
-    return pre_b > sw ? pre_b : sw;
+    return (pre_b > sw ? pre_b : sw) + lds_pad();
   };
 #define TRACY_FRONT_CASE(KK)                                                                                            \
   case KK:                                                                                                              \

@@ -105,9 +105,12 @@ def gather_ragged_known(dist, packed, totals, dst=0):
         packed = packed.cpu()
     if world == 1:
         return packed
+    # (both sides through batch_isend_irecv: torch runs batched point-to-point operations on the group's own communicator and plain
+    # send / recv on a pair communicator it creates on first use -- a send on the one never meets a receive on the other)
     if rank != dst:
         if packed.numel():
-            dist.send(packed, dst=dst)
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, packed, dst)]):
+                w.wait()
         return None
     totals = [int(x) for x in totals]
     if len(totals) != world or totals[dst] != packed.numel():

@@ -570,26 +570,23 @@ struct StreamHost {
 };
 
 // the order of the full sweeps: strip height, then longest first (long problems start early, short ones fill the tail) -- as run_dp
-// and run_ckpt_prefix order them, and like them without a sort when the batch is of a size
-void sweep_order(StreamHost& h, std::vector<uint32_t>& order, std::vector<int>& kof) {
+// and run_ckpt_prefix order them, and like them without a sort when the batch is of a size (`similar`, found by the caller's pass over
+// the lengths: then the order is the traces' own and `order` stays empty)
+void sweep_order(StreamHost& h, std::vector<uint32_t>& order, const std::vector<int>& kof, bool similar) {
   const uint32_t nt = h.nt;
+  h.classes.clear();
+  order.clear();
+  if (similar) {
+    if (nt) h.classes.push_back(SweepClass{kof[0], 0u, nt});
+    return;
+  }
   order.resize(nt);
-  kof.resize(nt);
-  for (uint32_t t = 0; t < nt; ++t) { order[t] = t; kof[t] = choose_k(h.mt[t], MODE_QP); }
+  for (uint32_t t = 0; t < nt; ++t) order[t] = t;
   auto before = [&](uint32_t x, uint32_t y) {
     if (kof[x] != kof[y]) return kof[x] > kof[y];
     return (uint64_t)h.mt[x] * h.rn[x] > (uint64_t)h.mt[y] * h.rn[y];
   };
-  bool similar = true;
-  uint64_t lo = ~0ull, hi = 0;
-  for (uint32_t t = 0; t < nt && similar; ++t) {
-    const uint64_t c = (uint64_t)h.mt[t] * h.rn[t];
-    lo = std::min(lo, c); hi = std::max(hi, c);
-    similar = kof[t] == kof[0];
-  }
-  similar = similar && hi <= lo + lo / 4;
-  if (!similar && !std::is_sorted(order.begin(), order.end(), before)) std::stable_sort(order.begin(), order.end(), before);
-  h.classes.clear();
+  if (!std::is_sorted(order.begin(), order.end(), before)) std::stable_sort(order.begin(), order.end(), before);
   for (uint32_t i = 0; i < nt;) {
     uint32_t e = i;
     while (e < nt && kof[order[e]] == kof[order[i]]) ++e;
@@ -930,12 +927,20 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
   h = StreamHost{std::move(h.mf), std::move(h.mt), std::move(h.tl), std::move(h.rn), std::move(h.ridx)};  // (the vectors keep their pages between calls)
   h.nt = nt;
   h.mf.resize(nt); h.mt.resize(nt); h.tl.resize(nt); h.rn.resize(nt); h.ridx.resize(nt);
+  static thread_local std::vector<int> kof;
+  kof.resize(nt);
+  bool odd_shape = false, similar = true;
+  uint64_t lr_base[kHostThreads], tab_base[kHostThreads];  // workspace offsets of the slices' first traces (trace order)
   {
-    struct Part { uint64_t max_mn; uint32_t maxmt, maxmf, bad; };
+    // ONE pass over the job's length arrays (the device waits while the host plans: round 6 measured 2.3 ms per 100 000-trace call in
+    // seven passes): lengths, trims, extremes, the strip height of every trace's sweep, whether the batch is of the one-pass shape and
+    // whether it is "of a size" (one strip height, cell counts within a quarter of each other: the sweeps then run in the traces' order)
+    TRACYHIP_HOST_SCOPE(hs1, "plan_common.lengths");
+    struct Part { uint64_t max_mn, cmin, cmax, lr, tab; uint32_t maxmt, maxmf, bad; int k0; bool odd, onek; };
     Part part[kHostThreads];
-    for (auto& x : part) x = Part{0, 0, 0, ~0u};
+    for (auto& x : part) x = Part{0, ~0ull, 0, 0, 0, 0, 0, ~0u, 0, false, true};
     parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
-      Part x{0, 0, 0, ~0u};
+      Part x{0, ~0ull, 0, 0, 0, 0, 0, ~0u, 0, false, true};
       for (uint32_t t = lo; t < hi; ++t) {
         h.ridx[t] = ref_index ? ref_index[t] : t;
         if (h.ridx[t] >= sr.count) { x.bad = std::min(x.bad, t); h.ridx[t] = 0; if (sr.count == 0) continue; }
@@ -948,34 +953,47 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
         x.max_mn = std::max<uint64_t>(x.max_mn, (uint64_t)h.mf[t] + h.rn[t]);
         x.maxmt = std::max(x.maxmt, h.mt[t]);
         x.maxmf = std::max(x.maxmf, h.mf[t]);
+        const int K = choose_k(h.mt[t], MODE_QP);
+        kof[t] = K;
+        if (t == lo) x.k0 = K;
+        x.onek = x.onek && K == x.k0;
+        x.odd = x.odd || h.mt[t] == 0 || h.rn[t] == 0 || num_passes(h.mt[t], K) != 1;
+        const uint64_t c = (uint64_t)h.mt[t] * h.rn[t];
+        x.cmin = std::min(x.cmin, c); x.cmax = std::max(x.cmax, c);
+        x.lr += 4ull * ((uint64_t)h.rn[t] + 1);  // (workspace of the slice's traces: row-m words of both strands, substitution tables)
+        x.tab += (uint64_t)kB16Codes * b16_table_stride(h.mf[t]);
       }
       part[tid] = x;
     });
+    for (uint32_t i = 0; i < kHostThreads; ++i) { lr_base[i] = h.lr_tot; tab_base[i] = h.tab_tot; h.lr_tot += part[i].lr; h.tab_tot += part[i].tab; }
     uint32_t bad = ~0u;
-    for (const Part& x : part) { h.max_mn = std::max(h.max_mn, x.max_mn); h.maxmt = std::max(h.maxmt, x.maxmt); h.maxmf = std::max(h.maxmf, x.maxmf); bad = std::min(bad, x.bad); }
+    uint64_t cmin = ~0ull, cmax = 0;
+    int k0 = 0;
+    for (const Part& x : part) {
+      h.max_mn = std::max(h.max_mn, x.max_mn); h.maxmt = std::max(h.maxmt, x.maxmt); h.maxmf = std::max(h.maxmf, x.maxmf); bad = std::min(bad, x.bad);
+      odd_shape = odd_shape || x.odd;
+      if (x.cmax == 0 && x.cmin == ~0ull) continue;  // (a slice without traces)
+      if (!k0) k0 = x.k0;
+      similar = similar && x.onek && x.k0 == k0;
+      cmin = std::min(cmin, x.cmin); cmax = std::max(cmax, x.cmax);
+    }
+    similar = similar && cmax <= cmin + cmin / 4;
     if (bad != ~0u) return set_error(TRACYHIP_ERR_ARG, "ref_index[%u] out of range", bad);
   }
   TRY(check_params(&p, h.max_mn));
   if (!(p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore)) return kStreamNo;
   if (!narrow_ok(&p, h.maxmt, 16)) return kStreamNo;
-  {
-    bool odd[kHostThreads] = {};
-    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
-      bool x = false;
-      for (uint32_t t = lo; t < hi; ++t) x = x || h.mt[t] == 0 || h.rn[t] == 0 || num_passes(h.mt[t], choose_k(h.mt[t], MODE_QP)) != 1;
-      odd[tid] = x;
-    });
-    for (bool x : odd)
-      if (x) return kStreamNo;
-  }
-  std::vector<uint32_t> order;
-  std::vector<int> kof;
-  sweep_order(h, order, kof);
+  if (odd_shape) return kStreamNo;
+  static thread_local std::vector<uint32_t> order;
+  { TRACYHIP_HOST_SCOPE(hs3, "plan_common.sweep_order"); sweep_order(h, order, kof, similar); }
+  TRACYHIP_HOST_SCOPE(hs4, "plan_common.records_and_offsets");
   uint32_t rest_of[kHostThreads] = {};
+  const bool in_trace_order = order.empty();
   parallel_for(nt, [&](uint32_t lo_, uint32_t hi_, uint32_t tid) {
    uint32_t max_rest = 0;
+   uint64_t lr = lr_base[tid], tab = tab_base[tid];
    for (uint32_t i = lo_; i < hi_; ++i) {
-    const uint32_t t = order[i];
+    const uint32_t t = order.empty() ? i : order[i];
     // class c holds its A slots then its B slots: [2 lo, 2 lo + n_c) and [2 lo + n_c, 2 hi)
     const SweepClass* cls = nullptr;
     for (const SweepClass& c : h.classes) if (i >= c.lo && i < c.hi) { cls = &c; break; }
@@ -988,20 +1006,18 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
     const bool front_ok = G.mt > kFrontRows + 2u * (uint32_t)kFrontK && G.rn >= 1 && origin16_ok(&p, G.mt, G.mt - kFrontRows + 2u * (uint32_t)kFrontHalfW + 16u);
     G.flags = front_ok ? SG_FRONT_OK : 0u;
     if (front_ok) max_rest = std::max(max_rest, G.mt - kFrontRows);
+    if (in_trace_order) {  // (the sweeps run in the traces' own order: a slice's workspace offsets are its running sums)
+      for (int o = 0; o < 2; ++o) { G.lr_off[o] = lr; lr += 2ull * ((uint64_t)G.rn + 1); }
+      G.tab_stride = b16_table_stride(G.mf);
+      G.tab_off = tab;
+      tab += (uint64_t)kB16Codes * G.tab_stride;
+    }
     geom[t] = G;
    }
    rest_of[tid] = max_rest;
   });
   for (uint32_t x : rest_of) h.max_rest = std::max(h.max_rest, x);
-  {  // workspace offsets in trace order: the sums of the slices, then every slice from its base
-    uint64_t lr_of[kHostThreads] = {}, tab_of[kHostThreads] = {};
-    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
-      uint64_t lr = 0, tab = 0;
-      for (uint32_t t = lo; t < hi; ++t) { lr += 4ull * ((uint64_t)h.rn[t] + 1); tab += (uint64_t)kB16Codes * b16_table_stride(h.mf[t]); }
-      lr_of[tid] = lr; tab_of[tid] = tab;
-    });
-    uint64_t lr_base[kHostThreads], tab_base[kHostThreads];
-    for (uint32_t i = 0; i < kHostThreads; ++i) { lr_base[i] = h.lr_tot; tab_base[i] = h.tab_tot; h.lr_tot += lr_of[i]; h.tab_tot += tab_of[i]; }
+  if (!in_trace_order) {  // workspace offsets in trace order, every slice from its base (the records above were written in sweep order)
     parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
       uint64_t lr = lr_base[tid], tab = tab_base[tid];
       for (uint32_t t = lo; t < hi; ++t) {
@@ -1100,7 +1116,8 @@ int tracyhip::stream_align(tracyhip_ctx* ctx, const tracyhip_align_job* job, con
   // geometry and the ops offsets are laid out in the pinned block they travel from: one copy, no staging
   HIP_TRY(ctx->h_desc.ensure(sizeof(SGeom) * (size_t)nt + sizeof(uint64_t) * (size_t)nt));
   SGeom* geom = static_cast<SGeom*>(ctx->h_desc.p);
-  TRY(plan_common(ctx, p, sp, sr, job->ref_index, nt, job->trim_left, job->trim_right, h, geom));
+  { TRACYHIP_HOST_SCOPE(hsa, "stream_align.plan_common"); TRY(plan_common(ctx, p, sp, sr, job->ref_index, nt, job->trim_left, job->trim_right, h, geom)); }
+  TRACYHIP_HOST_SCOPE(hsb, "stream_align.rest_of_call");
   const bool exact = job->strand_by_certificate == 0;
   const bool host_results = mem == TRACYHIP_MEM_HOST;
   uint64_t ops_bound = 1;
@@ -1774,6 +1791,7 @@ struct DecStream {
       uint32_t maxbc = 0, maxsl = 0, max_arest = 0, bad_len = ~0u, bad_range = ~0u;
     };
     Part part[kHostThreads];
+    TRACYHIP_HOST_SCOPE(hs5, "plan.decompose_records");
     auto trimmed = [&](uint32_t t, uint32_t& soff, uint32_t& sl) {  // trimmedSeq, abif.h:68-75
       if ((uint64_t)(uint32_t)(TL + TR + 1) >= (uint64_t)h.mf[t]) { soff = 0; sl = h.mf[t]; }
       else { soff = TL; sl = h.mf[t] - TL - TR; }
@@ -1851,6 +1869,7 @@ struct DecStream {
     if (4ull * ncap + b16_table_bytes(12) > 64u * 1024u) return kStreamNo;
 
     // ---- workspace ----
+    TRACYHIP_HOST_SCOPE(hs6, "plan.workspace");
     uint64_t rows_traces = 0;
     for (uint32_t t = 0; t < nt; ++t) rows_traces += h.mt[t];
     Arena sizing;
@@ -1920,12 +1939,14 @@ struct DecStream {
       uint64_t* hoff = reinterpret_cast<uint64_t*>(hgd + nt);  // [off1 nt][allele ops 2 nt][allele 1 vs 2 ops nt]
       // (band16_body adds an offset to ONE ops pointer: alleles 1 and 2 reach their buffers through offsets relative to allele 0's, modulo 2^64)
       const uint64_t base1 = (uint64_t)(reinterpret_cast<uintptr_t>(d_opsK[1]) - reinterpret_cast<uintptr_t>(d_opsK[0]));
-      for (uint32_t t = 0; t < nt; ++t) {
-        hoff[t] = geom[t].ops_off;
-        hoff[nt + t] = out->ops_offset[0][t];
-        hoff[2 * (size_t)nt + t] = base1 + out->ops_offset[1][t];
-        hoff[3 * (size_t)nt + t] = out->ops_offset[2][t];
-      }
+      parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t) {
+        for (uint32_t t = lo; t < hi; ++t) {
+          hoff[t] = geom[t].ops_off;
+          hoff[nt + t] = out->ops_offset[0][t];
+          hoff[2 * (size_t)nt + t] = base1 + out->ops_offset[1][t];
+          hoff[3 * (size_t)nt + t] = out->ops_offset[2][t];
+        }
+      });
       HIP_TRY(hipMemcpyAsync(sc.geom, hp, sizeof(SGeom) * (size_t)nt, hipMemcpyHostToDevice, st));
       HIP_TRY(hipMemcpyAsync(A.geomd, hgd, sizeof(SGeomD) * (size_t)nt, hipMemcpyHostToDevice, st));
       HIP_TRY(hipMemcpyAsync(A.off1, hoff, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));

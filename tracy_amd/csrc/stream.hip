@@ -927,7 +927,8 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
   h = StreamHost{std::move(h.mf), std::move(h.mt), std::move(h.tl), std::move(h.rn), std::move(h.ridx)};  // (the vectors keep their pages between calls)
   h.nt = nt;
   h.mf.resize(nt); h.mt.resize(nt); h.tl.resize(nt); h.rn.resize(nt); h.ridx.resize(nt);
-  static thread_local std::vector<int> kof;
+  static thread_local std::vector<int> kof_tls;  // (kept between calls; the worker threads reach the CALLER's vector through the reference)
+  std::vector<int>& kof = kof_tls;
   kof.resize(nt);
   bool odd_shape = false, similar = true;
   uint64_t lr_base[kHostThreads], tab_base[kHostThreads];  // workspace offsets of the slices' first traces (trace order)
@@ -984,7 +985,8 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
   if (!(p.ge < 0 && p.go <= 0 && sub_limit(&p) <= kWideScore)) return kStreamNo;
   if (!narrow_ok(&p, h.maxmt, 16)) return kStreamNo;
   if (odd_shape) return kStreamNo;
-  static thread_local std::vector<uint32_t> order;
+  static thread_local std::vector<uint32_t> order_tls;
+  std::vector<uint32_t>& order = order_tls;
   { TRACYHIP_HOST_SCOPE(hs3, "plan_common.sweep_order"); sweep_order(h, order, kof, similar); }
   TRACYHIP_HOST_SCOPE(hs4, "plan_common.records_and_offsets");
   uint32_t rest_of[kHostThreads] = {};

@@ -362,3 +362,24 @@ def test_decompose_low_complexity_windows_walk_the_reference_path(ctx, seed):
         assert a["btr0"][i] == want["btr0"] and a["btr1"][i] == want["btr1"] and a["btr2"][i] == want["btr2"], i
         assert a["primary"][i] == want["primary"] and a["secondary"][i] == want["secondary"], i
     assert checked >= nd // 4, checked
+
+
+def test_batch_planned_on_the_host_worker_threads(ctx):
+    """from 16 384 traces on the per-trace planning loops of a call run on the library's worker threads (parallel_for): a batch of that
+    size, ragged so that the sweeps are ordered by strip height and size, equals the same traces aligned in small batches"""
+    from tracy_amd import hostlib
+    nt = 16384 + 300
+    refs, profs, rev = hostlib.synth_align(4100, 512, 900, 330, 2)
+    rng = np.random.default_rng(5)
+    pick = rng.integers(0, 512, size=nt)
+    cut = rng.integers(0, 60, size=nt)  # ragged lengths
+    plist = [np.ascontiguousarray(profs[pick[i]][:, :330 - int(cut[i])]) for i in range(nt)]
+    rlist = [refs[pick[i]].tobytes()[:900 - int(cut[i]) // 2] for i in range(nt)]
+    got = ctx.align_traces(plist, rlist, SC, 20, 20)
+    st = ctx.last_call_stats()
+    assert st["stream_ordered"] == 1, st
+    for lo in (0, 8000, nt - 128):
+        want = ctx.align_traces(plist[lo:lo + 128], rlist[lo:lo + 128], SC, 20, 20)
+        for k in ALIGN_KEYS:
+            assert np.array_equal(np.asarray(got[k][lo:lo + 128]), np.asarray(want[k])), (lo, k)
+        assert got["btr"][lo:lo + 128] == want["btr"], lo

@@ -48,10 +48,12 @@ def read_timers(lib, ctx):
     return res
 
 
-def timed(step, steps, warmup, dist, lib=None, ctx=None):
+def timed(step, steps, warmup, dist, lib=None, ctx=None, after_warmup=None):
     """W untimed + K timed steps between barrier + synchronize; returns (seconds, kernel timers of the timed steps)"""
     for _ in range(warmup):
         step()
+    if after_warmup is not None:
+        after_warmup()
     if lib is not None:
         lib.tracyhip_timing_enable(ctx._h, 0 if os.environ.get("TRACYHIP_BENCH_NO_TIMERS") else 1)
         lib.tracyhip_timing_reset(ctx._h)
@@ -344,7 +346,9 @@ class DecomposeLeg:
 
     def run(self, dist, steps, warmup, extra_legs=True, cpu_sample=64):
         dev = self.dev
-        dt, timers = timed(lambda: self.step(dist), steps, warmup, dist, self.lib, self.ctx)
+        def reset_gather_clock():  # (the first gather sets the communicator up)
+            self.gather_seconds, self.gather_steps = 0.0, 0
+        dt, timers = timed(lambda: self.step(dist), steps, warmup, dist, self.lib, self.ctx, after_warmup=reset_gather_clock)
         gather_ms = self.gather_seconds / max(self.gather_steps, 1) * 1e3
         call_stats = self.ctx.last_call_stats()
         dt_rank = dt

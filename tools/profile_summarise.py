@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_round")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def one(pattern):
@@ -25,6 +25,10 @@ def one(pattern):
 
 
 def last_json_line(path):
+    try:  # (a whole file of indented JSON: bench.py --full-line)
+        return json.load(open(path))
+    except ValueError:
+        pass
     for ln in reversed(open(path).read().strip().split("\n")):
         if ln.startswith("{"):
             return json.loads(ln)
@@ -35,7 +39,7 @@ for name, sub in (("bench", "bench_stats"), ("decompose", "dec_stats"), ("allpai
     f = one(sub + "/*/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, "%s_%s_kernel_stats.csv" % (tag, name)))
-for src, dst in (("bench_line.json", "bench_line_under_rocprof"), ("bench_plain.json", "bench_line"), ("dec_line_under_rocprof.json", "decompose_line_under_rocprof"), ("dec_line.json", "decompose_line"),
+for src, dst in (("bench_line.json", "bench_line_under_rocprof"), ("bench_plain.json", "bench_line"), ("bench_plain_full.json", "bench_line_full"), ("dec_line_under_rocprof.json", "decompose_line_under_rocprof"), ("dec_line.json", "decompose_line"),
                  ("ap_line.json", "allpairs_line_under_rocprof")):
     p = os.path.join(SRC, src)
     if os.path.exists(p):

@@ -150,7 +150,7 @@ int pack_multi(tracyhip_ctx* ctx, const tracyhip_ragged_src* kinds, uint32_t nki
   if (dst) {
     // a region holds at most its stride: with a capacity for every region in full the copy is queued at once, otherwise the total is read first
     if (dst_cap < worst) {
-      HIP_TRY(ctx_sync(ctx));
+      HIP_TRY(hipStreamSynchronize(st));  // (not ctx_sync: tracyhip_call_stats::host_syncs counts the pipeline calls' own)
       report();
       if (h_kend[nkinds - 1] > dst_cap)
         return set_error(TRACYHIP_ERR_ARG, "tracyhip_pack_ragged: %llu bytes to pack, capacity %llu", h_kend[nkinds - 1], (unsigned long long)dst_cap);
@@ -158,7 +158,7 @@ int pack_multi(tracyhip_ctx* ctx, const tracyhip_ragged_src* kinds, uint32_t nki
     hipLaunchKernelGGL(pack_copy_kernel, dim3((n + 3) / 4, nkinds), dim3(256), 0, st, a, d_local, d_bsum, wpk, static_cast<uint8_t*>(dst));
     HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(ctx_sync(ctx));
+  HIP_TRY(hipStreamSynchronize(st));  // (not ctx_sync: tracyhip_call_stats::host_syncs counts the pipeline calls' own)
   report();
   return TRACYHIP_OK;
 }

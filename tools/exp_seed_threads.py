@@ -37,10 +37,16 @@ with open(gp, "wb") as f:
     f.write(b">chrSyn\n")
     f.write(seq.tobytes())
     f.write(b"\n")
-g = hostlib.Genome(gp, 15, 16)
-ip = os.path.join(d, "g.tidx")
-g.save(ip)
-g.close()
+ips = {}
+for bb in [x for x in os.environ.get("EXP_BUCKET_BITS", "").split(",") if x] or [""]:
+    if bb:
+        os.environ["TRACY_AMD_SEED_BUCKET_BITS"] = bb
+    g = hostlib.Genome(gp, 15, 16)
+    ips[bb] = os.path.join(d, "g%s.tidx" % bb)
+    g.save(ips[bb])
+    g.close()
+os.environ.pop("TRACY_AMD_SEED_BUCKET_BITS", None)
+ip = ips[sorted(ips)[0]]
 nt, mf = 48000, 1000
 starts = rng.integers(0, n - mf - 50, size=nt)
 comp = np.array([3, 2, 1, 0], dtype=np.uint8)
@@ -57,12 +63,16 @@ for k in range(nt):
     cons.append(lut[c].tobytes())
 np.savez(os.path.join(d, "c.npz"), cons=np.array(cons, dtype=object))
 masks = [m for m in os.environ.get("EXP_MASKS", "").split(";") if m]
+# EXP_ENVS: configurations of the library's development knobs to compare on ONE index, e.g. "TRACY_AMD_SEED_HINT=1,TRACY_AMD_SEED_DISTANCE=12;..."
+envs = [dict(kv.split("=", 1) for kv in cfg.split(",") if kv) for cfg in os.environ.get("EXP_ENVS", "").split(";") if cfg] or [{}]
 for th in [int(x) for x in os.environ.get("EXP_THREADS", "16").split(",")]:
     for mask in [None] + masks:
-        cmd = [sys.executable, __file__, "child", ip, str(th), os.path.join(d, "c.npz")]
-        env = dict(os.environ, EXP_TAG="mask=%s" % (mask or "none"))
-        if mask:
-            cmd = ["taskset", "-c", mask] + cmd
-        subprocess.run(cmd, env=env)
+        for extra in [dict(e, BB=bb) for bb in ips for e in envs]:
+            bb = extra.pop("BB")
+            cmd = [sys.executable, __file__, "child", ips[bb], str(th), os.path.join(d, "c.npz")]
+            env = dict(os.environ, EXP_TAG="mask=%s bucket_bits=%s %s" % (mask or "none", bb or "24", " ".join("%s=%s" % (k.replace("TRACY_AMD_SEED_", ""), v) for k, v in extra.items())), **extra)
+            if mask:
+                cmd = ["taskset", "-c", mask] + cmd
+            subprocess.run(cmd, env=env)
 import shutil  # noqa: E402
 shutil.rmtree(d)

@@ -30,6 +30,9 @@
 #include <string>
 #include <thread>
 #include <cstdio>
+#ifdef TRACY_SEED_PROFILE
+#include <x86intrin.h>
+#endif
 #include <cstdlib>
 #include <vector>
 
@@ -148,7 +151,11 @@ class GenomeIndex {
     // bucket directory over the TRAILING bits of the run's code: a lookup touches one directory slot + one short run.  (The smaller
     // of a k-mer and its reverse complement starts with A or C three times out of four: leading bits would put most of the table
     // into half of the buckets; the trailing letters are as good as uniform.)  The table is sorted by bucket, code, position.
+    // directory size: 2^24 slots = 128 MB (three table entries per slot for a 50 Mb genome: one line of the table per look-up, but the
+    // directory itself misses every cache); TRACY_AMD_SEED_BUCKET_BITS (development knob, read when an index is BUILT) trades longer
+    // buckets -- consecutive lines of the table -- for a directory an L3 holds
     bucket_bits_ = std::min<uint32_t>(2 * k, 24);
+    if (const char* e = std::getenv("TRACY_AMD_SEED_BUCKET_BITS")) { const long v = std::atol(e); if (v >= 8 && v <= 24) bucket_bits_ = std::min<uint32_t>(2 * k, (uint32_t)v); }
     sort_table(nthreads);
     bucket_.assign(((std::size_t)1 << bucket_bits_) + 1, 0);
     for (Entry const& e : table_) ++bucket_[slot_of(e.code) + 1];
@@ -322,10 +329,19 @@ class GenomeIndex {
   }
   std::size_t slot_of(uint64_t key) const { return (std::size_t)(key & ((1ull << bucket_bits_) - 1ull)); }
   bool has_table() const { return tab_ != nullptr && bkt_ != nullptr; }
-  void prefetch_slot_key(uint64_t key) const { __builtin_prefetch(&bkt_[slot_of(key)]); }
+  // (TRACY_AMD_SEED_HINT: development knob -- 0 = into every cache level (prefetcht0, the default), 1 = L2 and below, 2 = L3)
+  static int prefetch_hint() { static const int h = [] { const char* e = std::getenv("TRACY_AMD_SEED_HINT"); return e ? std::atoi(e) : 0; }(); return h; }
+  static void prefetch_line(const void* p) {
+    switch (prefetch_hint()) {
+      case 1: __builtin_prefetch(p, 0, 2); break;
+      case 2: __builtin_prefetch(p, 0, 1); break;
+      default: __builtin_prefetch(p, 0, 3); break;
+    }
+  }
+  void prefetch_slot_key(uint64_t key) const { prefetch_line(&bkt_[slot_of(key)]); }
   void prefetch_run_key(uint64_t key) const {
     const std::size_t i = bkt_[slot_of(key)];
-    if (i < ntab_) __builtin_prefetch(&tab_[i]);
+    if (i < ntab_) prefetch_line(&tab_[i]);
   }
   // One run, both strands (scanBothStrands): the occurrences of the k-mer whose run `key` names vote into `fwd` (value: position - pf),
   // those of its reverse complement into `rev` (position - pr); flipped: the forward k-mer is the run's second part; a palindrome
@@ -467,6 +483,20 @@ class GenomeIndex {
   }
 };
 
+#ifdef TRACY_SEED_PROFILE
+struct SeedProf {
+  unsigned long long t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  ~SeedProf() { const char* nm[8] = {"strings", "keys", "lookups", "maxfreq", "slice", "", "", ""}; unsigned long long tot = 0; for (auto x : t) tot += x;
+    for (int i = 0; i < 5; ++i) std::fprintf(stderr, "seedprof %-8s %5.1f %%\n", nm[i], tot ? 100.0 * t[i] / tot : 0.0); }
+};
+inline SeedProf& seed_prof() { static thread_local SeedProf p; return p; }
+#define SEED_LAP(i) do { const unsigned long long now_ = __rdtsc(); seed_prof().t[i] += now_ - lap_; lap_ = now_; } while (0)
+#define SEED_LAP_BEGIN() unsigned long long lap_ = __rdtsc()
+#else
+#define SEED_LAP(i) do { } while (0)
+#define SEED_LAP_BEGIN() do { } while (0)
+#endif
+
 // findMaxFreq, fmindex.h:173-198: most frequent value of `hits` (sorted in place; smallest value on ties)
 inline uint32_t findMaxFreq(std::vector<int64_t>& hits, int64_t& gpos) {
   gpos = 0;
@@ -582,6 +612,7 @@ inline bool scanBothStrands(GenomeIndex const& idx, std::string const& consensus
   if (S <= (std::size_t)trimLeft + trimRight) return true;  // no window on either strand
   const std::size_t p_lo = (std::size_t)trimLeft + 1u - k, p_hi = S - trimRight;  // windows p_lo .. p_hi - 1; forward: p >= trimLeft, reverse: p + k <= S - trimRight
   const std::size_t nwin = p_hi - p_lo;
+  SEED_LAP_BEGIN();
   thread_local std::vector<uint64_t> keys;
   thread_local std::vector<uint8_t> info;  // bit 0: a look-up (no N); bit 1: the forward k-mer is the flipped one of its run; bit 2: palindrome
   keys.assign(nwin, 0);
@@ -611,19 +642,24 @@ inline bool scanBothStrands(GenomeIndex const& idx, std::string const& consensus
   }
   // (one look-up per window here, not two: 12 misses in flight instead of 20 -- measured on the EPYC 9575F of the GPU box, 16 threads:
   // D = 2 / 4 / 6 / 8 / 10 / 16 -> 147 / 174 / 206-221 / 198 / 175-179 / 147 k traces/s)
+  SEED_LAP(1);
+  // D: windows between a run's request and its look-up; DS (TRACY_AMD_SEED_SLOT_AHEAD, default D): windows between a directory slot's
+  // request and the run's request, which READS the slot -- a demand load that stalls when the slot has not arrived
   static const std::size_t D = seed_prefetch_distance(6);
+  static const std::size_t DS = [] { const char* e = std::getenv("TRACY_AMD_SEED_SLOT_AHEAD"); const long v = e ? std::atol(e) : 0; return v >= 1 ? (std::size_t)v : D; }();
   const std::size_t fwd_from = (std::size_t)trimLeft - p_lo;  // first window the forward scan holds
   const std::size_t rev_until = nwin >= k ? nwin - k + 1 : 0;  // windows [0, rev_until) are the reverse scan's
-  for (std::size_t i = 0; i < nwin + 2 * D; ++i) {
+  for (std::size_t i = 0; i < nwin + D + DS; ++i) {
     if (i < nwin && (info[i] & 1u)) idx.prefetch_slot_key(keys[i]);
-    if (i >= D && i - D < nwin && (info[i - D] & 1u)) idx.prefetch_run_key(keys[i - D]);
-    if (i < 2 * D) continue;
-    const std::size_t w = i - 2 * D;
+    if (i >= DS && i - DS < nwin && (info[i - DS] & 1u)) idx.prefetch_run_key(keys[i - DS]);
+    if (i < D + DS) continue;
+    const std::size_t w = i - D - DS;
     if (!(info[w] & 1u)) continue;
     const std::size_t p = p_lo + w;
     idx.both_strands(keys[w], (info[w] & 2u) != 0, (info[w] & 4u) != 0, w >= fwd_from ? &hitFwd : nullptr, (int64_t)p,
                      w < rev_until ? &hitRev : nullptr, (int64_t)(S - p - k), unique);
   }
+  SEED_LAP(2);
   return true;
 }
 
@@ -636,9 +672,11 @@ struct SeedConfig {  // the SageConfig / IndigoConfig fields getReferenceSlice r
 // [chrpos - maxindel, chrpos + |consensus| + maxindel] of that contig (inclusive end, clipped like faidx_fetch_seq),
 // reverse-complemented for reverse traces.
 inline bool getReferenceSlice(SeedConfig const& c, GenomeIndex const& idx, std::string const& consensus, ReferenceSlice& rs) {
-  std::string rv = consensus;
-  reverseComplement(rv);
-  std::vector<int64_t> hitFwd, hitRev;
+  SEED_LAP_BEGIN();
+  // (the vote lists keep their capacity from trace to trace; the reverse complement is only needed where the one-pass scan does not apply)
+  static thread_local std::vector<int64_t> hitFwd_tls, hitRev_tls;
+  std::vector<int64_t>&hitFwd = hitFwd_tls, &hitRev = hitRev_tls;
+  SEED_LAP(0);
   int64_t bestFwd = 0, bestRev = 0, bestPos = 0;
   bool anchored = false;
   for (int pass = 0; pass < 2 && !anchored; ++pass) {
@@ -647,10 +685,16 @@ inline bool getReferenceSlice(SeedConfig const& c, GenomeIndex const& idx, std::
     if (!scanBothStrands(idx, consensus, c.trimLeft, c.trimRight, c.kmer, hitFwd, hitRev, pass == 0)) {
       hitFwd.clear();
       hitRev.clear();
+      std::string rv = consensus;
+      reverseComplement(rv);
       scanSequence(idx, consensus, c.trimLeft, c.trimRight, c.kmer, hitFwd, pass == 0);
       scanSequence(idx, rv, c.trimRight, c.trimLeft, c.kmer, hitRev, pass == 0);
     }
+#ifdef TRACY_SEED_PROFILE
+    lap_ = __rdtsc();  // (the scans kept their own laps)
+#endif
     const uint32_t freqFwd = findMaxFreq(hitFwd, bestFwd), freqRev = findMaxFreq(hitRev, bestRev);
+    SEED_LAP(3);
     if (freqFwd >= c.minKmerSupport && freqFwd > 2 * freqRev) {
       rs.forward = true; rs.kmersupport = freqFwd; bestPos = bestFwd; anchored = true;
     } else if (freqRev >= c.minKmerSupport && freqRev > 2 * freqFwd) {
@@ -677,6 +721,7 @@ inline bool getReferenceSlice(SeedConfig const& c, GenomeIndex const& idx, std::
   const int64_t last = std::min<int64_t>((int64_t)sliceend, (int64_t)idx.lengths[ref] - 1);
   rs.refslice = (int64_t)slicestart <= last ? idx.text.substr(idx.starts[ref] + slicestart, (std::size_t)(last - slicestart + 1)) : std::string();
   if (!rs.forward) reverseComplement(rs.refslice);
+  SEED_LAP(4);
   return true;
 }
 

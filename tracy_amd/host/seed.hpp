@@ -645,8 +645,11 @@ inline bool scanBothStrands(GenomeIndex const& idx, std::string const& consensus
   SEED_LAP(1);
   // D: windows between a run's request and its look-up; DS (TRACY_AMD_SEED_SLOT_AHEAD, default D): windows between a directory slot's
   // request and the run's request, which READS the slot -- a demand load that stalls when the slot has not arrived
-  static const std::size_t D = seed_prefetch_distance(6);
-  static const std::size_t DS = [] { const char* e = std::getenv("TRACY_AMD_SEED_SLOT_AHEAD"); const long v = e ? std::atol(e) : 0; return v >= 1 ? (std::size_t)v : D; }();
+  // (round 6, 16 threads on the GPU box's EPYC 9575F, three runs each, run-to-run spread +- 8 %: D / DS = 6 / 6 -- the round-5 form -- 14.6-16.5 k
+  // traces/s per thread, 6 / 12 16.6-16.9, 8 / 12 15.8-18.1, 10 / 12 18.0, 8 / 16 16.4, 10 / 16 16.8, 12 / 12 15.8; prefetches into L2 / L3 only
+  // -- TRACY_AMD_SEED_HINT -- no better)
+  static const std::size_t D = seed_prefetch_distance(8);
+  static const std::size_t DS = [] { const char* e = std::getenv("TRACY_AMD_SEED_SLOT_AHEAD"); const long v = e ? std::atol(e) : 0; return v >= 1 ? (std::size_t)v : (std::size_t)12; }();
   const std::size_t fwd_from = (std::size_t)trimLeft - p_lo;  // first window the forward scan holds
   const std::size_t rev_until = nwin >= k ? nwin - k + 1 : 0;  // windows [0, rev_until) are the reverse scan's
   for (std::size_t i = 0; i < nwin + D + DS; ++i) {

@@ -6,8 +6,10 @@ configs[1]: 10k x 1 kb traces vs 10 kb reference windows per GPU; inputs residen
 timed region).  Per trace: 2 score-only Gotoh DPs (forward / reverse-complement reference), 1 traceback
 DP of the trimmed profile (taken by its two ends: an origin-tracking sweep over the sub-window the score sweep certifies),
 trimReferenceSlice, 1 traceback DP of the full profile vs the trimmed slice.
-Weak scaling: the per-GPU batch is fixed; traces shard by index with no data-path collective, the only
-RCCL call is the final gather of the fixed-size result records.
+Weak scaling: the per-GPU batch is fixed; traces shard by index with no data-path collective; every timed step ends with the job's
+final gather to rank 0 in its two halves (tracy_amd/shard.py ResultGather): the fixed-size record of every trace in one
+collective, then the traceback strings -- packed on the device (tracyhip_pack_ragged_multi) -- in one grouped exchange sized from the
+records' length column.  `gather_ms_per_step` is that part of `ms_per_step`.
 
 Legs (each: W warm-up + K timed steps between barriers): (1) the headline -- one lane, exact gsFwd AND gsRev (`value`, `roofline`: what
 a zero-initialised job gets): the strand a k-mer vote does not pick is swept in full, the voted one by its first 128 rows over the
@@ -26,7 +28,8 @@ is what the rocprofv3 passes under profiles/ use).  `value` is always the align 
 `--gpus N` without a torch.distributed environment starts the N ranks itself (torch.distributed.run, 127.0.0.1) after checking
 that the box has N GPUs; every rank asserts that the process group really has N members.
 
-Prints ONE JSON line on rank 0 (see the keys at the bottom).
+Prints ONE JSON line on rank 0, cut to what the driver's record keeps (finish_line: < 8 KB, the figures of every leg as scalars at the
+top level and in `config` / `roofline`); the unabridged line goes to --full-line (default gpurun_out/bench_line_full.json).
 """
 import argparse
 import ctypes as C

@@ -1,7 +1,8 @@
 """Workloads bench.py times beside its headline (`tracy align`, configs[1]): BASELINE.json configs[2] (`tracy decompose`,
 indigo.h:190-388) and configs[4] (the all-pairs profile x profile scoring of `tracy assemble`, msa.h:33-42).  Each leg
-shards its job over the ranks: decompose by contiguous blocks of traces with a final gather of the
-fixed-size result records; all-pairs by contiguous slices of the upper-triangular pair list with the profiles replicated
+shards its job over the ranks: decompose by contiguous blocks of traces with the final gather in its two halves inside every
+timed step (one record per trace, then the three traceback strings, the rewritten basecalls, secDecompose and the decomposition table of
+every trace, packed on the device: tracy_amd/shard.py ResultGather); all-pairs by contiguous slices of the upper-triangular pair list with the profiles replicated
 and an all_gather of the score slices (the distance matrix ends up on every rank).  No data-path collective.
 
 Only the `cpu_baseline` parts touch oracle/ (the CPU restatement timed on the host cores, and the in-run parity sample)."""

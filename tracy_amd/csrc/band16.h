@@ -420,7 +420,11 @@ TR_HD void band16_body(W& w, const Band16Args& a, uint32_t wave_idx) {
 #endif
   constexpr int kPfBehind = (P - 1) * (K <= 4 ? 2 : 3);
   static_assert(!HANDLOAD || kPfBehind <= 63, "vmcnt is a six-bit counter");
+#if defined(__clang__)
   typedef uint32_t pf_vec __attribute__((ext_vector_type(K <= 4 ? 2 : 4)));
+#else
+  struct pf_vec { uint32_t v[4]; uint32_t operator[](int i) const { return v[i]; } };  // (host emulator build: never loaded by hand)
+#endif
   pf_vec pv[kB16Codes];
   auto prefetch = [&](uint32_t s) {
     const int16_t* src = a.qp + d.a1_off + (uint64_t)s * K;

@@ -143,6 +143,68 @@ __global__ __launch_bounds__(64) void needle_walk_kernel(WalkArgs a, const uint3
 // _createAlignment (align.h:196-223 / 254-293): one lane per output column, forward order.
 // ops are in push order, so column ai corresponds to ops[L-1-ai].  One wave per pair: 64 columns per round,
 // the consumed-row / consumed-column counts of a column are prefix popcounts of the wave's ballots.
+// The common case of `tracy decompose` (a trace with a shift: row 0 only says where the trace has bases; row 1 the characters of a string
+// reference) without a divergent branch: round 5's counters had the kernel at 9 500 scalar and 3 200 vector instructions per trace, 38 % of
+// its wave cycles waiting for an instruction -- every conditional load of the general form below is a branch of its own.  Here the op
+// bytes and the reference bytes are loaded unconditionally from clamped indices and everything else is a select.
+__device__ __forceinline__ void alignment_rows_gaps_only(const RowsArgs& a, const PairDesc& d, const uint8_t* __restrict__ ops, uint8_t* __restrict__ r0,
+                                                         uint8_t* __restrict__ r1, uint32_t L, uint32_t lane) {
+  const bool rc = a.a2_revcomp_flag && (d.flags & PAIR_A2_REVCOMP);
+  const bool onehot = a.a2_onehot != 0;
+  const uint8_t* __restrict__ ref = static_cast<const uint8_t*>(a.a2) + d.a2_off;
+  const uint32_t nlast = d.n ? d.n - 1u : 0u;
+  const bool have_ref = d.n != 0u;  // (wave-uniform; without columns no op takes one)
+  const uint64_t below = (1ull << lane) - 1ull;
+  uint32_t col_base = 0;
+  constexpr uint32_t kBatch = 8;
+  for (uint32_t base0 = 0; base0 < L; base0 += 64 * kBatch) {
+    uint8_t opb[kBatch];
+#pragma unroll
+    for (uint32_t k = 0; k < kBatch; ++k) {
+      const uint32_t ai = base0 + 64 * k + lane;
+      opb[k] = ops[ai < L ? L - 1 - ai : 0u];
+    }
+    uint32_t colk[kBatch];
+    uint32_t take = 0;  // bit k: takes a row, bit 8 + k: takes a column
+#pragma unroll
+    for (uint32_t k = 0; k < kBatch; ++k) {
+      const uint32_t ai = base0 + 64 * k + lane;
+      const bool active = ai < L;
+      const bool takes_row = active & (opb[k] != 'h'), takes_col = active & (opb[k] != 'v');
+      const uint64_t mcol = __ballot(takes_col);
+      colk[k] = col_base + (uint32_t)__popcll(mcol & below);
+      col_base += (uint32_t)__popcll(mcol);
+      take |= (takes_row ? 1u : 0u) << k | (takes_col ? 1u : 0u) << (8 + k);
+    }
+    uint8_t c1k[kBatch];
+#pragma unroll
+    for (uint32_t k = 0; k < kBatch; ++k) {
+      const uint32_t c = colk[k] < nlast ? colk[k] : nlast;
+      c1k[k] = have_ref ? ref[rc ? nlast - c : c] : (uint8_t)'-';
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kBatch; ++k) {
+      const uint32_t base = base0 + 64 * k;
+      if (base >= L) break;  // (wave-uniform)
+      const uint32_t ai = base + lane;
+      uint8_t c1 = c1k[k];
+      if (rc) c1 = complement_char(c1);
+      if (onehot) {  // consensus character of _createProfile(string) (align.h:121-136, 254-270): base_code 0..3 -> A C G T, N and '-' -> N, others -> A
+        const uint8_t up = c1 & 0xDFu;
+        uint8_t r = 'A';
+        r = up == 'C' ? 'C' : r;
+        r = up == 'G' ? 'G' : r;
+        r = up == 'T' ? 'T' : r;
+        r = (up == 'N' || c1 == '-') ? 'N' : r;
+        c1 = r;
+      }
+      const uint8_t o1 = ((take >> (8 + k)) & 1u) ? c1 : (uint8_t)'-';
+      const uint8_t o0 = ((take >> k) & 1u) ? (uint8_t)'N' : (uint8_t)'-';
+      if (ai < L) { r0[ai] = o0; r1[ai] = o1; }
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
   const uint32_t i = blockIdx.x;
   const uint32_t lane = threadIdx.x;
@@ -153,6 +215,9 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
   uint8_t* r0 = a.rows0 + off;
   uint8_t* r1 = a.rows1 + off;
   const bool gaps_only = a.row0_gaps_only && a.row0_gaps_only[(size_t)d.out * a.row0_gaps_only_stride] != 0;
+#ifndef TRACY_ROWS_NO_FAST
+  if (gaps_only && !a.a2_profile) { alignment_rows_gaps_only(a, d, ops, r0, r1, L, lane); return; }
+#endif
   const uint64_t below = (1ull << lane) - 1ull;
   uint32_t row_base = 0, col_base = 0;
   constexpr uint32_t kBatch = 8;  // rounds whose op bytes are requested together: one wait per 512 columns instead of one per 64
@@ -161,7 +226,7 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
 #pragma unroll
     for (uint32_t k = 0; k < kBatch; ++k) {
       const uint32_t ai = base0 + 64 * k + lane;
-      opb[k] = ai < L ? ops[L - 1 - ai] : 0;
+      opb[k] = ops[ai < L ? L - 1 - ai : 0u];
     }
     // rows / columns the batch's alignment columns consume (prefix popcounts of the ballots), then ALL its reference bytes requested
     // together, then the rows: the kernel waited for a reference byte per round of 64 columns (48 dependent round trips per trace)
@@ -169,6 +234,8 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
     uint8_t c1k[kBatch];
     uint32_t take = 0;  // bit k: takes a row, bit 8 + k: takes a column
     const bool rc = a.a2_revcomp_flag && (d.flags & PAIR_A2_REVCOMP);
+    const uint32_t mlast = d.m ? d.m - 1u : 0u, nlast = d.n ? d.n - 1u : 0u;
+    const bool have_a1 = d.m != 0u, have_a2 = d.n != 0u;  // (without rows / columns no op takes one)
 #pragma unroll
     for (uint32_t k = 0; k < kBatch; ++k) {
       const uint32_t ai = base0 + 64 * k + lane;
@@ -183,11 +250,12 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
       col_base += (uint32_t)__popcll(mcol);
       take |= (takes_row ? 1u : 0u) << k | (takes_col ? 1u : 0u) << (8 + k);
     }
+    // (every load below is unconditional from a clamped index and every choice a select: a conditional load per lane is a branch of its own)
     if (!a.a2_profile) {
 #pragma unroll
       for (uint32_t k = 0; k < kBatch; ++k) {
-        c1k[k] = '-';
-        if ((take >> (8 + k)) & 1u) c1k[k] = static_cast<const uint8_t*>(a.a2)[d.a2_off + (rc ? d.n - 1 - colk[k] : colk[k])];
+        const uint32_t c = colk[k] < nlast ? colk[k] : nlast;
+        c1k[k] = have_a2 ? static_cast<const uint8_t*>(a.a2)[d.a2_off + (rc ? nlast - c : c)] : (uint8_t)'-';
       }
     }
 #pragma unroll
@@ -197,12 +265,10 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
       const uint32_t ai = base + lane;
       const bool active = ai < L;
       const bool takes_row = (take >> k) & 1u, takes_col = (take >> (8 + k)) & 1u;
-      const uint32_t row = rowk[k], col = colk[k];
-      uint8_t c0 = '-', c1 = '-';
-      if (takes_row) {
-        if (gaps_only) {
-          c0 = 'N';
-        } else if (a.a1_profile) {
+      const uint32_t row = rowk[k] < mlast ? rowk[k] : mlast, col = colk[k] < nlast ? colk[k] : nlast;
+      uint8_t c0 = 'N', c1 = '-';
+      if (!gaps_only && have_a1) {  // (wave-uniform)
+        if (a.a1_profile) {
           float p[6];
           for (int q = 0; q < 6; ++q) p[q] = static_cast<const float*>(a.a1)[d.a1_off + (uint64_t)q * d.a1_stride + row];
           c0 = cons_char(p);
@@ -210,20 +276,22 @@ __global__ __launch_bounds__(64) void alignment_rows_kernel(RowsArgs a) {
           c0 = static_cast<const uint8_t*>(a.a1)[d.a1_off + row];
         }
       }
-      if (takes_col) {
-        if (a.a2_profile) {
+      c0 = takes_row ? c0 : (uint8_t)'-';
+      if (a.a2_profile) {
+        if (have_a2) {  // (wave-uniform)
           float p[6];
           for (int q = 0; q < 6; ++q) p[q] = static_cast<const float*>(a.a2)[d.a2_off + (uint64_t)q * d.a2_stride + col];
           c1 = cons_char(p);
-        } else {
-          c1 = c1k[k];
-          if (rc) c1 = complement_char(c1);
-          if (a.a2_onehot) {  // consensus character of _createProfile(string) (align.h:121-136, 254-270)
-            const uint32_t code = base_code(c1);
-            c1 = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'T' : code == 6 ? 'A' : 'N';
-          }
+        }
+      } else {
+        c1 = c1k[k];
+        if (rc) c1 = complement_char(c1);
+        if (a.a2_onehot) {  // consensus character of _createProfile(string) (align.h:121-136, 254-270)
+          const uint32_t code = base_code(c1);
+          c1 = code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'T' : code == 6 ? 'A' : 'N';
         }
       }
+      c1 = takes_col ? c1 : (uint8_t)'-';
       if (active) {
         r0[ai] = c0;
         r1[ai] = c1;

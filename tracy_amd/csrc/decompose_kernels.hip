@@ -123,18 +123,49 @@ __global__ __launch_bounds__(64) void breakpoint_kernel(const BpDesc* desc, cons
   extern __shared__ __attribute__((aligned(16))) char lds_stage[];
   char* smem = GLOBAL ? scratch + (size_t)blockIdx.x * stride : lds_stage;
   const BpDesc d = desc[blockIdx.x];
+  // sig[] holds the signal ratios, then (they are dead once the window sums exist) the differences; lsum[i] = sig[i-25] + ... + sig[i-1]
+  // summed in the reference's order (decompose.h:32-38): its right-hand window at i is the left-hand window at i + 25, term for term, so
+  // one sum per position serves both
   double* sig = reinterpret_cast<double*>(smem);
-  double* diff = sig + d.ncol;
-  uint8_t* ltr = reinterpret_cast<uint8_t*>(diff + d.ncol);
+  double* lsum = sig + d.ncol;
+  double* diff = sig;
+  uint8_t* ltr = reinterpret_cast<uint8_t*>(lsum + d.ncol);
   const float* p = prof + d.off;
-  for (uint32_t j = threadIdx.x; j < d.ncol; j += 64) sig[j] = signal_ratio(p, d.stride, j);
-  wg_sync();
-  if (25 < d.ncol) {
-    for (uint32_t i = 25 + threadIdx.x; i < d.ncol - 25; i += 64) {
-      double l, r;
-      diff[i] = window_diff(sig, i, &l, &r);
-      ltr[i] = (l < r) ? 1 : 0;
+  const uint32_t lane = threadIdx.x;
+  // the six rows of eight rounds of columns requested together (clamped columns, no branch): a wave that waited for every round of 64
+  // columns on its own spent 15 memory round trips -- three quarters of its life -- here, with nine waves per CU (LDS) to hide them
+  constexpr uint32_t kCols = 8;
+  for (uint32_t j0 = 0; j0 < d.ncol; j0 += 64 * kCols) {
+    float v[kCols][6];
+#pragma unroll
+    for (uint32_t u = 0; u < kCols; ++u) {
+      const uint32_t j = j0 + 64 * u + lane, jc = j < d.ncol ? j : d.ncol - 1;
+#pragma unroll
+      for (uint32_t i = 0; i < 6; ++i) v[u][i] = p[(uint64_t)i * d.stride + jc];
     }
+#pragma unroll
+    for (uint32_t u = 0; u < kCols; ++u) {
+      const uint32_t j = j0 + 64 * u + lane;
+      double best = 0.001, snd = 0.001;  // signal_ratio (decompose_kernels.h) on registers, selects for its if / else-if
+#pragma unroll
+      for (uint32_t i = 0; i < 6; ++i) {
+        const double x = v[u][i];
+        const bool gb = x > best, gs = x > snd;
+        snd = gb ? best : gs ? x : snd;
+        best = gb ? x : best;
+      }
+      if (j < d.ncol) sig[j] = __dsub_rn(best, snd);
+    }
+  }
+  wg_sync();
+  // two positions per lane and pass: two independent chains of 25 additions
+  for (uint32_t i = 25 + lane; i < d.ncol; i += 128) {
+    const uint32_t i2 = i + 64 < d.ncol ? i + 64 : i;
+    double s1 = 0, s2 = 0;
+#pragma unroll
+    for (uint32_t k = 25; k > 0; --k) { s1 += sig[i - k]; s2 += sig[i2 - k]; }
+    lsum[i] = s1;
+    lsum[i2] = s2;
   }
   wg_sync();
   // breakpoint_select (decompose.h:27-55) by the 64 lanes.  The reference walks the positions with a float-typed running
@@ -142,12 +173,16 @@ __global__ __launch_bounds__(64) void breakpoint_kernel(const BpDesc* desc, cons
   // walk ends with best = F = max(0, max_i (float)diff[i]); the first position whose float equals F is always taken, and after
   // it exactly the positions with diff[i] > (double)F (they round down to F) -- the answer is the last of those, or that first
   // position.  Three reductions instead of one lane reading ncol doubles one after the other.
-  const uint32_t lane = threadIdx.x;
   const uint32_t lo = 25, hi = (25 < d.ncol) ? d.ncol - 25 : 25;
   float fmax_l = 0.0f;
   for (uint32_t i = lo + lane; i < hi; i += 64) {
-    const float g = (float)diff[i];
-    if (diff[i] > 0.0 && g > fmax_l) fmax_l = g;
+    const double left = lsum[i] / 25.0, right = lsum[i + 25] / 25.0;
+    const double dd = right - left;
+    const double v = dd < 0 ? -dd : dd;
+    diff[i] = v;  // (position i of the dead sig[] is this lane's alone)
+    ltr[i] = (left < right) ? 1 : 0;
+    const float g = (float)v;
+    if (v > 0.0 && g > fmax_l) fmax_l = g;
   }
   for (int o = 32; o > 0; o >>= 1) { const float x = __shfl_xor(fmax_l, o, 64); if (x > fmax_l) fmax_l = x; }
   const float F = fmax_l;
@@ -162,6 +197,7 @@ __global__ __launch_bounds__(64) void breakpoint_kernel(const BpDesc* desc, cons
     if (a < first_l) first_l = a;
     if (b > last_l) last_l = b;
   }
+  wg_sync();  // (ltr[] of the other lanes)
   if (lane == 0) {
     BreakpointOut bp;
     bp.bestDiff = 0; bp.traceleft = 1; bp.breakpoint = 0;

@@ -952,7 +952,7 @@ int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut
       HIP_TRY(hipMemcpyAsync(ctx->d_declut.p, lut.data(), kLutBytes, hipMemcpyHostToDevice, ctx->stream));
       ctx->declut_ready = true;
     }
-    HIP_TRY(ctx->d_dectodo.ensure(sizeof(uint32_t) * (size_t)a.ntraces + 8 * sizeof(unsigned long long) * kDecompWaveStages));
+    HIP_TRY(ctx->d_dectodo.ensure(sizeof(uint32_t) * (size_t)a.ntraces + 8 + sizeof(unsigned long long) * kDecompWaveStages * kDecompWaveClockRows));
     wa.a = a;
     wa.bps = d_bps;
     wa.lut = static_cast<const uint8_t*>(ctx->d_declut.p);
@@ -960,7 +960,7 @@ int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut
     rest.only = wa.todo;
 #ifdef TRACY_PHASE_CLOCKS
     wa.clocks = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->d_dectodo.p) + ((sizeof(uint32_t) * (size_t)a.ntraces + 7) & ~(size_t)7));
-    HIP_TRY(hipMemsetAsync(wa.clocks, 0, sizeof(unsigned long long) * kDecompWaveStages, ctx->stream));
+    HIP_TRY(hipMemsetAsync(wa.clocks, 0, sizeof(unsigned long long) * kDecompWaveStages * kDecompWaveClockRows, ctx->stream));
 #endif
   }
   { int trc_ = timing_begin(ctx, TRACYHIP_TIMER_DECOMP, work_cells, work_bytes); if (trc_) return trc_; }
@@ -970,11 +970,13 @@ int launch_decompose(tracyhip_ctx* ctx, const DecompArgs& a, const BreakpointOut
     HIP_TRY(hipGetLastError());
 #ifdef TRACY_PHASE_CLOCKS
     {
-      unsigned long long hc[kDecompWaveStages];
-      HIP_TRY(hipMemcpyAsync(hc, wa.clocks, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
+      static std::vector<unsigned long long> rows(kDecompWaveStages * kDecompWaveClockRows);
+      HIP_TRY(hipMemcpyAsync(rows.data(), wa.clocks, sizeof(unsigned long long) * rows.size(), hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
-      fprintf(stderr, "tracyhip: decompose_wave_kernel cycles per trace by stage (stage, walk, sets, scans, cut-off, picks, complex, apply):");
-      for (int i = 0; i < 8; ++i) fprintf(stderr, " %.0f", (double)hc[i] / a.ntraces);
+      unsigned long long hc[kDecompWaveStages] = {};
+      for (size_t i = 0; i < rows.size(); ++i) hc[i % kDecompWaveStages] += rows[i];
+      fprintf(stderr, "tracyhip: decompose_wave_kernel cycles per trace by stage (loads + ballots, words + prefix sums, walk + bounds, staging, phase to the breakpoint, sets, scans, cut-off, picks, complex, apply):");
+      for (int i = 0; i < 11; ++i) fprintf(stderr, " %.0f", (double)hc[i] / a.ntraces);
       fprintf(stderr, "  (LDS %u bytes)\n", lay.total);
     }
 #endif

@@ -21,6 +21,8 @@
 #ifndef TRACY_AMD_DECOMPOSE_WAVE_H
 #define TRACY_AMD_DECOMPOSE_WAVE_H
 
+#include <type_traits>
+
 #include "decompose_kernels.h"
 
 namespace tracyhip {
@@ -82,7 +84,7 @@ TR_HD DecompWaveLayout decomp_wave_layout(const DecompWaveCaps& c) {
   return l;
 }
 TR_HD bool decomp_wave_caps_ok(const DecompWaveCaps& c) {
-  return c.capL && c.capB && c.capI && c.capF && c.capL % 64 == 0 && c.capB % 64 == 0 && c.capL <= 8192 && c.capB <= 2048 && c.capI <= 1024 && c.capF <= c.capI;
+  return c.capL && c.capB && c.capI && c.capF && c.capL % 64 == 0 && c.capB % 64 == 0 && c.capL <= 8192 && c.capB <= 2048 && c.capI <= 1024 && c.capF <= c.capI;  // (=> a class set has at most 51 words: one per lane)
 }
 
 TR_HD uint32_t popc32(uint32_t x) {
@@ -124,38 +126,129 @@ TR_HD uint32_t diag_word32(const DecompSets& z, int32_t u, int32_t wq) {
   uint32_t r = 0;
 #pragma unroll
   for (int c = 0; c < kRefClasses; ++c) {
-    if (!((z.classes >> c) & 1u)) continue;
-    const uint32_t* p = z.is32 + (uint32_t)c * z.is_stride32 + 2 + ai;
+    const uint32_t* p = z.is32 + (uint32_t)c * z.is_stride32 + 2 + ai;  // (a class that does not occur: zero words)
     r |= funnel32(p[1], p[0], sh) & z.bad32[(uint32_t)c * z.bad_stride32 + (uint32_t)wq];
   }
   return r;
 }
+// The scans' inner loops carry no branch on the classes that occur: a class that does not occur has zero words, and the one class that is
+// rare in a reference row -- N -- is a template parameter (WITH_N: class 4 takes part).  (A wave-uniform `continue` per class was a scalar
+// compare and branch per class, word and diagonal, and a basic-block boundary the LDS reads could not be moved across.)
+template <bool WITH_N>
+struct ScanClasses {
+  static constexpr int n = WITH_N ? kRefClasses : kRefClasses - 1;
+  TR_HD static constexpr int cls(int i) { return WITH_N ? i : (i < 4 ? i : 5); }
+};
+
 // failed(del, ins) for del - ins == u and from == ins (decompose.h:215-222 and its two copies): positions s in [from, min(NV, Lw - u))
-TR_HD int32_t diag_count32(const DecompSets& z, int32_t u, int32_t from) {
+template <bool WITH_N>
+TR_HD int32_t diag_count32_t(const DecompSets& z, int32_t u, int32_t from) {
+  using SC = ScanClasses<WITH_N>;
   const int32_t lim_ref = z.Lw - u;
   const int32_t limit = z.NV < lim_ref ? z.NV : lim_ref;
   if (limit <= from) return 0;
   const uint32_t sh = (uint32_t)u & 31u;
   const int32_t w0 = from >> 5;
-  uint32_t lo[kRefClasses];
+  uint32_t lo[SC::n];
 #pragma unroll
-  for (int c = 0; c < kRefClasses; ++c) lo[c] = z.is32[(uint32_t)c * z.is_stride32 + 2 + ((32 * w0 + u) >> 5)];
+  for (int i = 0; i < SC::n; ++i) lo[i] = z.is32[(uint32_t)SC::cls(i) * z.is_stride32 + 2 + ((32 * w0 + u) >> 5)];
   int32_t f = 0;
-  for (int32_t wq = w0; 32 * wq < limit; ++wq) {
+  // four words per pass, all of the pass's LDS words requested before the first is used (a word per pass waited for an LDS round trip 16
+  // times per diagonal).  Words behind the limit are read and masked away: they lie inside the sets' own LDS (two zero words behind every
+  // class, the next class or the table behind the last).  Passes that lie inside [from, limit) altogether need no mask.
+  constexpr int kPass = 4;
+  auto pass = [&](int32_t wq, auto masked) {
     const int32_t ai = (32 * wq + u) >> 5;
-    uint32_t r = 0;
+    uint32_t hi[SC::n][kPass], bd[SC::n][kPass];
 #pragma unroll
-    for (int c = 0; c < kRefClasses; ++c) {
-      if (!((z.classes >> c) & 1u)) continue;
-      const uint32_t hi = z.is32[(uint32_t)c * z.is_stride32 + 2 + ai + 1];
-      r |= funnel32(hi, lo[c], sh) & z.bad32[(uint32_t)c * z.bad_stride32 + (uint32_t)wq];
-      lo[c] = hi;
+    for (int i = 0; i < SC::n; ++i) {
+#pragma unroll
+      for (int k = 0; k < kPass; ++k) {
+        hi[i][k] = z.is32[(uint32_t)SC::cls(i) * z.is_stride32 + 2 + ai + 1 + k];
+        bd[i][k] = z.bad32[(uint32_t)SC::cls(i) * z.bad_stride32 + (uint32_t)(wq + k)];
+      }
     }
-    r &= low32(limit - 32 * wq);
-    if (wq == w0) r &= ~low32(from - 32 * wq);
-    f += (int32_t)popc32(r);
-  }
+#pragma unroll
+    for (int k = 0; k < kPass; ++k) {
+      uint32_t r = 0;
+#pragma unroll
+      for (int i = 0; i < SC::n; ++i) {
+        r |= funnel32(hi[i][k], lo[i], sh) & bd[i][k];
+        lo[i] = hi[i][k];
+      }
+      if (decltype(masked)::value) {
+        r &= low32(limit - 32 * (wq + k));
+        if (wq + k == w0) r &= ~low32(from - 32 * w0);
+      }
+      f += (int32_t)popc32(r);
+    }
+  };
+  int32_t wq = w0;
+  if (32 * wq < limit) { pass(wq, std::true_type{}); wq += kPass; }  // (the pass that holds `from`)
+  for (; 32 * (wq + kPass) <= limit; wq += kPass) pass(wq, std::false_type{});
+  if (32 * wq < limit) pass(wq, std::true_type{});
   return f;
+}
+TR_HD int32_t diag_count32(const DecompSets& z, int32_t u, int32_t from) {
+  return ((z.classes >> 4) & 1u) ? diag_count32_t<true>(z, u, from) : diag_count32_t<false>(z, u, from);  // (wave-uniform)
+}
+
+// failed(del, 0) for ND diagonals del = u0, u0 + 64, ... of one lane at once (the deletion scans, decompose.h:215-222): the words of the
+// basecall sets are the same for every diagonal and the reference words of neighbouring diagonals overlap (diagonal + 64 = two words on),
+// so a pass of four words reads 2 ND + 2 reference words and 4 basecall words per class instead of 8 ND.  on[j] = 0: diagonal j is not
+// wanted (its count is not defined); diagonal 0 is.  (Words read for an unwanted diagonal or behind a limit lie at most six words behind the
+// class's own: in the next class's words or, behind the last class, in the basecall sets.)
+template <int ND, bool WITH_N>
+TR_HD void diag_count32_multi_t(const DecompSets& z, int32_t u0, const bool on[ND], int32_t f[ND]) {
+  using SC = ScanClasses<WITH_N>;
+  constexpr int kPass = 4, kWords = 2 * (ND - 1) + kPass;
+  int32_t limit[ND], minlim = 0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < ND; ++j) {
+    const int32_t lim_ref = z.Lw - (u0 + 64 * j);
+    limit[j] = on[j] ? (z.NV < lim_ref ? z.NV : lim_ref) : 0;
+    if (on[j]) minlim = limit[j] < minlim ? limit[j] : minlim;
+    f[j] = 0;
+  }
+  if (limit[0] <= 0) return;  // (the later diagonals end earlier)
+  const uint32_t sh = (uint32_t)u0 & 31u;
+  const int32_t a0 = u0 >> 5;
+  uint32_t lo[SC::n][ND];
+#pragma unroll
+  for (int i = 0; i < SC::n; ++i)
+#pragma unroll
+    for (int j = 0; j < ND; ++j) lo[i][j] = z.is32[(uint32_t)SC::cls(i) * z.is_stride32 + 2 + a0 + 2 * j];
+  auto pass = [&](int32_t wq, auto masked) {
+    uint32_t x[SC::n][kWords], bd[SC::n][kPass];
+#pragma unroll
+    for (int i = 0; i < SC::n; ++i) {
+#pragma unroll
+      for (int q = 0; q < kWords; ++q) x[i][q] = z.is32[(uint32_t)SC::cls(i) * z.is_stride32 + 2 + a0 + wq + 1 + q];
+#pragma unroll
+      for (int k = 0; k < kPass; ++k) bd[i][k] = z.bad32[(uint32_t)SC::cls(i) * z.bad_stride32 + (uint32_t)(wq + k)];
+    }
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+#pragma unroll
+      for (int k = 0; k < kPass; ++k) {
+        uint32_t r = 0;
+#pragma unroll
+        for (int i = 0; i < SC::n; ++i) r |= funnel32(x[i][2 * j + k], k ? x[i][2 * j + k - 1] : lo[i][j], sh) & bd[i][k];
+        if (decltype(masked)::value) r &= low32(limit[j] - 32 * (wq + k));
+        f[j] += (int32_t)popc32(r);
+      }
+#pragma unroll
+      for (int i = 0; i < SC::n; ++i) lo[i][j] = x[i][2 * j + kPass - 1];
+    }
+  };
+  int32_t wq = 0;
+  for (; 32 * (wq + kPass) <= minlim; wq += kPass) pass(wq, std::false_type{});  // (inside every wanted diagonal's range: no mask; an unwanted one's count is not read)
+  for (; 32 * wq < limit[0]; wq += kPass) pass(wq, std::true_type{});
+}
+template <int ND>
+TR_HD void diag_count32_multi(const DecompSets& z, int32_t u0, const bool on[ND], int32_t f[ND]) {
+  if ((z.classes >> 4) & 1u) diag_count32_multi_t<ND, true>(z, u0, on, f);  // (wave-uniform)
+  else diag_count32_multi_t<ND, false>(z, u0, on, f);
 }
 // Z_u word of 64 positions (decompose_kernels.h diag_word), cut at s < limit
 TR_HD uint64_t diag_word64(const DecompSets& z, int32_t u, int32_t w, int32_t limit) {
@@ -189,16 +282,29 @@ struct DecompWaveArgs {
   DecompWaveCaps caps;
   unsigned long long* clocks;  // development: cycles per stage, summed over the traces (or null)
 };
-constexpr int kDecompWaveStages = 10;
+constexpr int kDecompWaveStages = 16;
+constexpr uint32_t kDecompWaveClockRows = 1024;  // (development: a row of stage counters per trace & 1023 -- one shared row serialises the atomics)
+#ifndef TRACY_DW_STOP_AFTER
+#define TRACY_DW_STOP_AFTER 99
+#endif
+#ifdef TRACY_DW_NO_ATOMICS
+constexpr bool kDwAtomics = false;
+#else
+constexpr bool kDwAtomics = true;
+#endif
 
 template <class W>
 TR_HD void decomp_wave_body(W& w, const DecompWaveArgs& wa, uint32_t t) {
   const DecompArgs& a = wa.a;
   const uint32_t lane = w.lane();
-  if (a.skip && a.skip[t]) { if (lane == 0) wa.todo[t] = 0; return; }
+  // (the trace's words and the lane's word of the table are requested together: a look at the skip word first, then at the descriptor, then
+  // at the rows was three round trips to memory before the first useful one)
+  const uint32_t skip_word = a.skip ? a.skip[t] : 0u;
   DecompDesc d = a.desc[t];
   d.breakpoint = wa.bps[t].breakpoint;
   if (a.lens) d.L = a.lens[t];
+  const uint32_t lut_word = lane < (uint32_t)kLutBytes / 4u ? reinterpret_cast<const uint32_t*>(wa.lut)[lane] : 0u;
+  if (skip_word) { if (lane == 0) wa.todo[t] = 0; return; }
   const uint32_t L = d.L, nbc = d.nbc;
   const uint32_t ltrim = (uint32_t)a.prm.trimLeft;
   const int32_t rtrim = a.prm.trimRight;
@@ -218,7 +324,8 @@ TR_HD void decomp_wave_body(W& w, const DecompWaveArgs& wa, uint32_t t) {
 #define DW_CLOCK()                                                                                          \
   do {                                                                                                      \
     const unsigned long long now_ = __builtin_readcyclecounter();                                           \
-    if (wa.clocks && lane == 0) atomicAdd(wa.clocks + clk_stage, now_ - clk_prev);                          \
+    if (kDwAtomics && wa.clocks && lane == 0) atomicAdd(wa.clocks + (size_t)(t & (kDecompWaveClockRows - 1u)) * kDecompWaveStages + clk_stage, now_ - clk_prev); \
+    if (clk_stage == TRACY_DW_STOP_AFTER) { if (lane == 0) wa.todo[t] = 0; return; }                          \
     clk_prev = now_;                                                                                        \
     ++clk_stage;                                                                                            \
   } while (0)
@@ -249,34 +356,33 @@ TR_HD void decomp_wave_body(W& w, const DecompWaveArgs& wa, uint32_t t) {
   constexpr uint32_t kChunks = kDecompWaveMaxL / 256u;
   const uint32_t nwL = (L + 63u) >> 6, nch = (L + 255u) >> 8;
   uint32_t v0[kChunks], v1[kChunks];
-  auto load4 = [&](const uint8_t* g, uint32_t c) -> uint32_t {  // columns c .. c + 3 of a row, '-' beyond the alignment
-    uint32_t v = 0x2d2d2d2du;
-    if (c + 4u <= L) __builtin_memcpy(&v, g + c, 4);
-    else
+  // bytes c .. c + 3 of g[0, n), `fill` beyond n: the dword that ends at n, shifted, for the lanes over the end -- no branch, no second wait
+  // (n < 4, wave-uniform: byte by byte)
+  auto load4 = [&](const uint8_t* g, uint32_t c, uint32_t n, uint32_t fill) -> uint32_t {
+    uint32_t v = fill;
+    if (n >= 4u) {
+      const uint32_t cc = c + 4u <= n ? c : n - 4u, sh = c - cc;
+      uint32_t x;
+      __builtin_memcpy(&x, g + cc, 4);
+      v = sh >= 4u ? fill : (uint32_t)((((uint64_t)fill << 32) | x) >> (8u * (sh & 3u)));
+    } else {
       for (uint32_t k = 0; k < 4; ++k)
-        if (c + k < L) v = (v & ~(0xffu << (8u * k))) | ((uint32_t)g[c + k] << (8u * k));
+        if (c + k < n) v = (v & ~(0xffu << (8u * k))) | ((uint32_t)g[c + k] << (8u * k));
+    }
     return v;
   };
 #pragma unroll
   for (uint32_t i = 0; i < kChunks; ++i) {
     v0[i] = 0x2d2d2d2du; v1[i] = 0x2d2d2d2du;
-    if (i < nch) { v0[i] = load4(g0, 256u * i + 4u * lane); v1[i] = load4(g1, 256u * i + 4u * lane); }
+    if (i < nch) { v0[i] = load4(g0, 256u * i + 4u * lane, L, 0x2d2d2d2du); v1[i] = load4(g1, 256u * i + 4u * lane, L, 0x2d2d2d2du); }
   }
   {
     constexpr uint32_t kBcChunks = 2048u / 256u;
     uint32_t vp[kBcChunks], vs[kBcChunks];
-    auto loadb = [&](const uint8_t* g, uint32_t c) -> uint32_t {
-      uint32_t v = 0;
-      if (c + 4u <= nbc) __builtin_memcpy(&v, g + c, 4);
-      else
-        for (uint32_t k = 0; k < 4; ++k)
-          if (c + k < nbc) v |= (uint32_t)g[c + k] << (8u * k);
-      return v;
-    };
 #pragma unroll
     for (uint32_t i = 0; i < kBcChunks; ++i) {
       vp[i] = 0; vs[i] = 0;
-      if (256u * i < nbc) { vp[i] = loadb(gpri, 256u * i + 4u * lane); vs[i] = loadb(gsec, 256u * i + 4u * lane); }
+      if (256u * i < nbc) { vp[i] = load4(gpri, 256u * i + 4u * lane, nbc, 0u); vs[i] = load4(gsec, 256u * i + 4u * lane, nbc, 0u); }
     }
 #pragma unroll
     for (uint32_t i = 0; i < kBcChunks; ++i)
@@ -297,6 +403,7 @@ TR_HD void decomp_wave_body(W& w, const DecompWaveArgs& wa, uint32_t t) {
       }
     }
   }
+  DW_CLOCK();  // loads + ballots
   w.sync();
   uint32_t c0 = 0, c1 = 0;    // lane w: bases of word w (columns 64 w .. 64 w + 63) of the trace row / the reference row
   uint64_t m0w = 0, m1w = 0;  // ... and the words themselves
@@ -318,9 +425,10 @@ TR_HD void decomp_wave_body(W& w, const DecompWaveArgs& wa, uint32_t t) {
     c0 = (uint32_t)popc64(m0w);
     c1 = (uint32_t)popc64(m1w);
   }
-  if (lane < (uint32_t)kLutBytes / 4u) reinterpret_cast<uint32_t*>(llut)[lane] = reinterpret_cast<const uint32_t*>(wa.lut)[lane];
+  if (lane < (uint32_t)kLutBytes / 4u) reinterpret_cast<uint32_t*>(llut)[lane] = lut_word;
   const uint32_t pre0 = w.excl_sum(c0), pre1 = w.excl_sum(c1);
   const uint32_t total0 = w.sum(c0), total1 = w.sum(c1);
+  DW_CLOCK();  // words, prefix sums
 
   // ---- 2. walk to the breakpoint (decompose.h:184-208): the column of trace base number `stop` ----
   const uint32_t stop = d.breakpoint;  // (bp - ltrim with bp = breakpoint + ltrim)
@@ -371,6 +479,7 @@ TR_HD void decomp_wave_body(W& w, const DecompWaveArgs& wa, uint32_t t) {
     if (lane == 0) wa.todo[t] = 1;
     return;
   }
+  DW_CLOCK();  // walk, bounds, span
   if (lane == 0) wa.todo[t] = 0;
   lpre0[lane] = pre0;
 #pragma unroll
@@ -402,38 +511,71 @@ TR_HD void decomp_wave_body(W& w, const DecompWaveArgs& wa, uint32_t t) {
   DW_CLOCK();
 
   // ---- 3. class bit sets by ballot ----
+  // Four words per pass: the bytes of all four are read from LDS before the first ballot (a word per pass waited for its LDS round trip,
+  // two dependent ones for the basecalls' table look-up, 50 times per trace).  Lane k keeps word k of every class in registers (a select
+  // per ballot) and stores its six words once at the end: a store per ballot and class was an exec-mask change and an LDS instruction each,
+  // 300 times per trace.  (A set has at most 64 words: decomp_wave_caps_ok.)
   uint32_t seen = 0;
   bool exotic = false;
-  for (uint32_t k = 0; k < lay.is_stride; ++k) {
-    const int32_t q0 = 64 * ((int32_t)k - 1);
-    if (k == 0 || q0 >= z.Lw) {
-      if (lane < (uint32_t)kRefClasses) is64[lane * lay.is_stride + k] = 0;
-      continue;
-    }
-    const int32_t q = q0 + (int32_t)lane;
-    int c = 7;
-    if (q < z.Lw) c = ref_class(row1v[winstart + (uint32_t)q]);
+  constexpr uint32_t kSetPass = 4;
+  {
+    uint64_t mine[kRefClasses];
 #pragma unroll
-    for (int kk = 0; kk < kRefClasses; ++kk) {
-      const uint64_t mk = w.ballot(c == kk);
-      if (lane == (uint32_t)kk) is64[(uint32_t)kk * lay.is_stride + k] = mk;
-      if (mk) seen |= 1u << kk;
-    }
-    if (w.ballot(c == 6)) exotic = true;
-  }
-  for (uint32_t k = 0; k < lay.bad_stride; ++k) {
-    const int32_t s0 = 64 * (int32_t)k;
-    if (s0 >= z.NV) {
-      if (lane < (uint32_t)kRefClasses) bad64[lane * lay.bad_stride + k] = 0;
-      continue;
-    }
-    const int32_t s = s0 + (int32_t)lane;
-    uint32_t mask = 0;
-    if (s < z.NV) mask = llut[lut_pclass(lpri[varIndex + (uint32_t)s]) * (uint32_t)kLutS + lut_sclass(lsec[varIndex + (uint32_t)s])];
+    for (int kk = 0; kk < kRefClasses; ++kk) mine[kk] = 0;  // (word 0 -- the columns left of the window -- and every word behind the window: zero)
+    for (uint32_t k0 = 1; k0 < lay.is_stride && 64 * ((int32_t)k0 - 1) < z.Lw; k0 += kSetPass) {
+      int cls[kSetPass];
 #pragma unroll
-    for (int kk = 0; kk < kRefClasses; ++kk) {
-      const uint64_t mk = w.ballot((mask >> kk) & 1u);
-      if (lane == (uint32_t)kk) bad64[(uint32_t)kk * lay.bad_stride + k] = mk;
+      for (uint32_t j = 0; j < kSetPass; ++j) {
+        const int32_t q = 64 * ((int32_t)(k0 + j) - 1) + (int32_t)lane;
+        const int cc = ref_class(row1v[winstart + (uint32_t)(q < z.Lw ? q : z.Lw - 1)]);  // (Lw > 0 inside the loop)
+        cls[j] = q < z.Lw ? cc : 7;
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < kSetPass; ++j) {
+        const uint32_t k = k0 + j;
+        const int c = cls[j];  // (7 in every lane for a word behind the window: its ballots are zero)
+#pragma unroll
+        for (int kk = 0; kk < kRefClasses; ++kk) {
+          const uint64_t mk = w.ballot(c == kk);
+          mine[kk] = lane == k ? mk : mine[kk];
+          if (mk) seen |= 1u << kk;
+        }
+        if (w.ballot(c == 6)) exotic = true;
+      }
+    }
+    if (lane < lay.is_stride) {
+#pragma unroll
+      for (int kk = 0; kk < kRefClasses; ++kk) is64[(uint32_t)kk * lay.is_stride + lane] = mine[kk];
+    }
+#pragma unroll
+    for (int kk = 0; kk < kRefClasses; ++kk) mine[kk] = 0;
+    for (uint32_t k0 = 0; k0 < lay.bad_stride && 64 * (int32_t)k0 < z.NV; k0 += kSetPass) {
+      uint32_t pc[kSetPass], mask[kSetPass];
+#pragma unroll
+      for (uint32_t j = 0; j < kSetPass; ++j) {
+        const int32_t sj = 64 * (int32_t)(k0 + j) + (int32_t)lane;
+        const uint32_t at = varIndex + (uint32_t)(sj < z.NV ? sj : z.NV - 1);  // (NV > 0 inside the loop)
+        pc[j] = lut_pclass(lpri[at]) * (uint32_t)kLutS + lut_sclass(lsec[at]);
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < kSetPass; ++j) {
+        const int32_t sj = 64 * (int32_t)(k0 + j) + (int32_t)lane;
+        const uint32_t m = llut[pc[j]];
+        mask[j] = sj < z.NV ? m : 0u;
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < kSetPass; ++j) {
+        const uint32_t k = k0 + j;
+#pragma unroll
+        for (int kk = 0; kk < kRefClasses; ++kk) {
+          const uint64_t mk = w.ballot((mask[j] >> kk) & 1u);
+          mine[kk] = lane == k ? mk : mine[kk];
+        }
+      }
+    }
+    if (lane < lay.bad_stride) {
+#pragma unroll
+      for (int kk = 0; kk < kRefClasses; ++kk) bad64[(uint32_t)kk * lay.bad_stride + lane] = mine[kk];
     }
   }
   z.is32 = reinterpret_cast<const uint32_t*>(is64);
@@ -451,7 +593,19 @@ TR_HD void decomp_wave_body(W& w, const DecompWaveArgs& wa, uint32_t t) {
     for (uint32_t del = lane; del < nfref; del += 64) fref[del] = (uint16_t)count_failed(row1v, Lscan, lpri, lsec, vend, alignIndex + del + 1, varIndex);
     for (uint32_t ins = 1 + lane; ins < nfins; ins += 64) fins[ins] = (uint16_t)count_failed(row1v, Lscan, lpri, lsec, vend, alignIndex + 1, varIndex + ins);
   } else {
-    for (uint32_t del = lane; del < nfref; del += 64) fref[del] = (uint16_t)diag_count32(z, (int32_t)del, 0);
+    constexpr int kDiags = 4;  // deletion shifts per lane and pass: lane, + 64, + 128, + 192
+    for (uint32_t d0 = 0; d0 < nfref; d0 += 64 * kDiags) {
+      bool on[kDiags];
+      int32_t fd[kDiags];
+#pragma unroll
+      for (int j = 0; j < kDiags; ++j) on[j] = d0 + 64u * (uint32_t)j + lane < nfref;
+      if (on[0]) {
+        diag_count32_multi<kDiags>(z, (int32_t)(d0 + lane), on, fd);
+#pragma unroll
+        for (int j = 0; j < kDiags; ++j)
+          if (on[j]) fref[d0 + 64u * (uint32_t)j + lane] = (uint16_t)fd[j];
+      }
+    }
     for (uint32_t ins = 1 + lane; ins < nfins; ins += 64) fins[ins] = (uint16_t)diag_count32(z, -(int32_t)ins, (int32_t)ins);
   }
   w.sync();

@@ -295,21 +295,37 @@ __global__ __launch_bounds__(64) void kmer_vote_kernel(const VoteDesc* __restric
                                                        const uint8_t* __restrict__ codes, uint32_t* __restrict__ votes) {
   __shared__ uint32_t bm[2][kVoteBits / 32];
   __shared__ uint8_t cons[1040];
-  __shared__ uint8_t win[kVoteTile + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t win[kVoteTile + 16];
   const VoteDesc d = desc[blockIdx.x];
   const uint32_t lane = threadIdx.x;
   uint32_t hf = 0, hr = 0;
   const uint32_t m = d.m < 1024u ? d.m : 1024u;
   if (m >= (uint32_t)kVoteK && d.n >= (uint32_t)kVoteK) {
     for (uint32_t i = lane; i < kVoteBits / 32; i += 64) { bm[0][i] = 0; bm[1][i] = 0; }
-    for (uint32_t j = lane; j < m; j += 64) {
-      uint32_t best = 0;
-      float bv = prof[d.a1_off + j];
-      for (uint32_t k = 1; k < 4; ++k) {
-        const float v = prof[d.a1_off + (uint64_t)k * d.stride + j];
-        if (v > bv) { bv = v; best = k; }
+    // the four rows of eight rounds of columns requested together (clamped columns, selects): a round of 64 columns per wait was 16 memory
+    // round trips per trace, and the kernel runs beside the peak table's and the score tables' streaming passes
+    constexpr uint32_t kCols = 8;
+    for (uint32_t j0 = 0; j0 < m; j0 += 64 * kCols) {
+      float v[kCols][4];
+#pragma unroll
+      for (uint32_t u = 0; u < kCols; ++u) {
+        const uint32_t j = j0 + 64 * u + lane, jc = j < m ? j : m - 1;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) v[u][k] = prof[d.a1_off + (uint64_t)k * d.stride + jc];
       }
-      cons[j] = (uint8_t)best;
+#pragma unroll
+      for (uint32_t u = 0; u < kCols; ++u) {
+        const uint32_t j = j0 + 64 * u + lane;
+        uint32_t best = 0;
+        float bv = v[u][0];
+#pragma unroll
+        for (uint32_t k = 1; k < 4; ++k) {
+          const bool g = v[u][k] > bv;
+          bv = g ? v[u][k] : bv;
+          best = g ? k : best;
+        }
+        if (j < m) cons[j] = (uint8_t)best;
+      }
     }
     __syncthreads();
     constexpr uint32_t mask = (1u << (2 * kVoteK)) - 1u;
@@ -334,21 +350,46 @@ __global__ __launch_bounds__(64) void kmer_vote_kernel(const VoteDesc* __restric
       const uint32_t tn = (npos - tile < kVoteTile) ? npos - tile : kVoteTile;  // positions of this tile
       const uint32_t nbytes = tn + kVoteK - 1;
       __syncthreads();
-      for (uint32_t b = lane; b < nbytes; b += 64) win[b] = codes[d.a2_off + tile + b];
-      __syncthreads();
-      const uint32_t lo = lane * kVotePiece, hi = (lo + kVotePiece < tn) ? lo + kVotePiece : tn;
-      if (lo < hi) {
-        uint32_t k = 0, valid = 0;
-        for (uint32_t p = lo; p < hi + kVoteK - 1; ++p) {
-          const uint32_t c = win[p];
-          if (c < 4u) { k = ((k << 2) | c) & mask; ++valid; }
-          else valid = 0;
-          if (valid >= (uint32_t)kVoteK) {
-            const uint32_t h = vote_hash(k);
-            hf += (bm[0][h >> 5] >> (h & 31)) & 1u;
-            hr += (bm[1][h >> 5] >> (h & 31)) & 1u;
+      // the tile by ALIGNED dwords, eight rounds of 256 bytes per wait: the tile lies in LDS at the misalignment `skew` it has in memory
+      // (the up to three bytes in front of it and behind it are other codes or the code buffer's spare bytes, kCodePad)
+      const uint8_t* src = codes + d.a2_off + tile;
+      const uint32_t skew = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u);
+      {
+        const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src - skew);
+        uint32_t* win32 = reinterpret_cast<uint32_t*>(win);
+        const uint32_t nd = (skew + nbytes + 3u) >> 2;
+        constexpr uint32_t kRounds = 8;
+        for (uint32_t w0 = 0; w0 < nd; w0 += 64 * kRounds) {
+          uint32_t x[kRounds];
+#pragma unroll
+          for (uint32_t u = 0; u < kRounds; ++u) {
+            const uint32_t wi = w0 + 64 * u + lane;
+            x[u] = src32[wi < nd ? wi : nd - 1];
+          }
+#pragma unroll
+          for (uint32_t u = 0; u < kRounds; ++u) {
+            const uint32_t wi = w0 + 64 * u + lane;
+            if (wi < nd) win32[wi] = x[u];
           }
         }
+      }
+      __syncthreads();
+      // every lane rolls over its piece; no branch: the bitmaps are read for every position and a position without eleven valid bases
+      // before it counts nothing
+      const uint32_t lo = lane * kVotePiece, hi = (lo + kVotePiece < tn) ? lo + kVotePiece : tn;
+      const uint32_t end = lo < hi ? hi + kVoteK - 1 : lo;
+      uint32_t k = 0, valid = 0;
+#pragma unroll 5
+      for (uint32_t q = 0; q < kVotePiece + kVoteK - 1; ++q) {
+        const uint32_t p = lo + q;
+        const uint32_t c0 = win[skew + p < kVoteTile + 15u ? skew + p : kVoteTile + 15u];
+        const uint32_t c = p < end ? c0 : 4u;
+        k = ((k << 2) | (c & 3u)) & mask;
+        valid = c < 4u ? valid + 1u : 0u;
+        const uint32_t h = vote_hash(k);
+        const uint32_t hit = valid >= (uint32_t)kVoteK ? 1u : 0u;
+        hf += (bm[0][h >> 5] >> (h & 31)) & hit;
+        hr += (bm[1][h >> 5] >> (h & 31)) & hit;
       }
     }
   }

@@ -157,23 +157,12 @@ __device__ __forceinline__ void alignment_rows_gaps_only(const RowsArgs& a, cons
   const uint64_t below = (1ull << lane) - 1ull;
   uint32_t col_base = 0;
   constexpr uint32_t kBatch = 8;
-  // (the op bytes of the NEXT batch are requested before this batch's reference bytes are waited for: a batch costs one round trip, not two)
-  uint8_t opn[kBatch];
-#pragma unroll
-  for (uint32_t k = 0; k < kBatch; ++k) {
-    const uint32_t ai = 64 * k + lane;
-    opn[k] = ops[ai < L ? L - 1 - ai : 0u];
-  }
   for (uint32_t base0 = 0; base0 < L; base0 += 64 * kBatch) {
     uint8_t opb[kBatch];
 #pragma unroll
-    for (uint32_t k = 0; k < kBatch; ++k) opb[k] = opn[k];
-    if (base0 + 64 * kBatch < L) {  // (wave-uniform)
-#pragma unroll
-      for (uint32_t k = 0; k < kBatch; ++k) {
-        const uint32_t ai = base0 + 64 * kBatch + 64 * k + lane;
-        opn[k] = ops[ai < L ? L - 1 - ai : 0u];
-      }
+    for (uint32_t k = 0; k < kBatch; ++k) {
+      const uint32_t ai = base0 + 64 * k + lane;
+      opb[k] = ops[ai < L ? L - 1 - ai : 0u];
     }
     uint32_t colk[kBatch];
     uint32_t take = 0;  // bit k: takes a row, bit 8 + k: takes a column

@@ -322,11 +322,8 @@ class GenomeIndex {
   }
   uint64_t position(std::size_t i) const { return tab_[i].pos & ~kFlipped; }
   // cache warm-up for a batch of look-ups: the directory slot first, then (once that is in cache) the table run
-  void prefetch_slot(uint64_t code) const { __builtin_prefetch(&bkt_[slot_of(key_of(code).code)]); }
-  void prefetch_run(uint64_t code) const {
-    const std::size_t i = bkt_[slot_of(key_of(code).code)];
-    if (i < ntab_) __builtin_prefetch(&tab_[i]);
-  }
+  void prefetch_slot(uint64_t code) const { prefetch_slot_key(key_of(code).code); }
+  void prefetch_run(uint64_t code) const { prefetch_run_key(key_of(code).code); }
   std::size_t slot_of(uint64_t key) const { return (std::size_t)(key & ((1ull << bucket_bits_) - 1ull)); }
   bool has_table() const { return tab_ != nullptr && bkt_ != nullptr; }
   // (TRACY_AMD_SEED_HINT: development knob -- 0 = into every cache level (prefetcht0, the default), 1 = L2 and below, 2 = L3)
@@ -338,10 +335,20 @@ class GenomeIndex {
       default: __builtin_prefetch(p, 0, 3); break;
     }
   }
-  void prefetch_slot_key(uint64_t key) const { prefetch_line(&bkt_[slot_of(key)]); }
+  // (a look-up reads bkt_[slot] AND bkt_[slot + 1] -- one slot in eight has its neighbour on the next line -- and a bucket of three
+  // 16-byte entries crosses a line boundary every other time: both ends of both are requested)
+  static bool prefetch_ends() { static const bool v = [] { const char* e = std::getenv("TRACY_AMD_SEED_ENDS"); return !e || std::atoi(e) != 0; }(); return v; }  // (development knob)
+  void prefetch_slot_key(uint64_t key) const {
+    const uint64_t* p = &bkt_[slot_of(key)];
+    prefetch_line(p);
+    if (prefetch_ends() && ((reinterpret_cast<uintptr_t>(p) >> 3) & 7u) == 7u) prefetch_line(p + 1);
+  }
   void prefetch_run_key(uint64_t key) const {
-    const std::size_t i = bkt_[slot_of(key)];
-    if (i < ntab_) prefetch_line(&tab_[i]);
+    const std::size_t b = slot_of(key), i = bkt_[b], e = bkt_[b + 1];
+    if (i < e) {
+      prefetch_line(&tab_[i]);
+      if (prefetch_ends() && ((reinterpret_cast<uintptr_t>(&tab_[i]) ^ reinterpret_cast<uintptr_t>(&tab_[e - 1])) >> 6)) prefetch_line(&tab_[e - 1]);
+    }
   }
   // One run, both strands (scanBothStrands): the occurrences of the k-mer whose run `key` names vote into `fwd` (value: position - pf),
   // those of its reverse complement into `rev` (position - pr); flipped: the forward k-mer is the run's second part; a palindrome

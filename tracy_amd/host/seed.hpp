@@ -655,7 +655,10 @@ inline bool scanBothStrands(GenomeIndex const& idx, std::string const& consensus
   // (round 6, 16 threads on the GPU box's EPYC 9575F, three runs each, run-to-run spread +- 8 %: D / DS = 6 / 6 -- the round-5 form -- 14.6-16.5 k
   // traces/s per thread, 6 / 12 16.6-16.9, 8 / 12 15.8-18.1, 10 / 12 18.0, 8 / 16 16.4, 10 / 16 16.8, 12 / 12 15.8; prefetches into L2 / L3 only
   // -- TRACY_AMD_SEED_HINT -- no better)
-  static const std::size_t D = seed_prefetch_distance(8);
+  // (with both ends of the slot pair and of the bucket requested -- prefetch_slot_key / prefetch_run_key -- the same box, three runs each within
+  // 1 %: ends not requested 15.2-15.8 k; D / DS = 8 / 12 20.5-20.6 k, 10 / 12 21.4-21.6, 12 / 12 21.7-21.9, 12 / 16 21.6-21.8, 14 / 14 20.9-21.0,
+  // 16 / 16 16.1: the default stays two steps away from that edge)
+  static const std::size_t D = seed_prefetch_distance(10);
   static const std::size_t DS = [] { const char* e = std::getenv("TRACY_AMD_SEED_SLOT_AHEAD"); const long v = e ? std::atol(e) : 0; return v >= 1 ? (std::size_t)v : (std::size_t)12; }();
   const std::size_t fwd_from = (std::size_t)trimLeft - p_lo;  // first window the forward scan holds
   const std::size_t rev_until = nwin >= k ? nwin - k + 1 : 0;  // windows [0, rev_until) are the reverse scan's

@@ -922,8 +922,16 @@ int queue_orientation(tracyhip_ctx* ctx, const tracyhip_params& p, const SParams
 }
 
 // the geometry every trace of a batch has, the sweep order, the workspace offsets; kStreamNo when the batch is not of the stream-ordered shape
+// What a caller adds to plan_common's passes over the traces (`tracy decompose`: its own sums and records).  Every pass is a fork and a join
+// of the host threads -- 0.3-0.5 ms each on a 100 000-trace batch, whatever it computes, while the device waits -- so the caller's loops
+// run INSIDE the two passes there are, slice by slice, instead of in passes of their own.
+struct PlanHooks {
+  std::function<void(uint32_t lo, uint32_t hi, uint32_t tid)> lengths_slice;  // after the lengths of traces [lo, hi) are known (h.mf / mt / tl / rn)
+  std::function<int()> between;                                                 // on the calling thread, before the records are written; an error ends the plan
+  std::function<void(uint32_t lo, uint32_t hi, uint32_t tid)> records_slice;  // after the records of traces [lo, hi) are written (trace order)
+};
 int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqset& sp, const tracyhip_seqset& sr, const uint32_t* ref_index, uint32_t nt,
-                uint32_t trim_l, uint32_t trim_r, StreamHost& h, SGeom* geom) {
+                uint32_t trim_l, uint32_t trim_r, StreamHost& h, SGeom* geom, const PlanHooks* hooks = nullptr) {
   h = StreamHost{std::move(h.mf), std::move(h.mt), std::move(h.tl), std::move(h.rn), std::move(h.ridx)};  // (the vectors keep their pages between calls)
   h.nt = nt;
   h.mf.resize(nt); h.mt.resize(nt); h.tl.resize(nt); h.rn.resize(nt); h.ridx.resize(nt);
@@ -965,6 +973,7 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
         x.tab += (uint64_t)kB16Codes * b16_table_stride(h.mf[t]);
       }
       part[tid] = x;
+      if (hooks && hooks->lengths_slice && x.bad == ~0u) hooks->lengths_slice(lo, hi, tid);
     });
     for (uint32_t i = 0; i < kHostThreads; ++i) { lr_base[i] = h.lr_tot; tab_base[i] = h.tab_tot; h.lr_tot += part[i].lr; h.tab_tot += part[i].tab; }
     uint32_t bad = ~0u;
@@ -988,6 +997,7 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
   static thread_local std::vector<uint32_t> order_tls;
   std::vector<uint32_t>& order = order_tls;
   { TRACYHIP_HOST_SCOPE(hs3, "plan_common.sweep_order"); sweep_order(h, order, kof, similar); }
+  if (hooks && hooks->between) TRY(hooks->between());
   TRACYHIP_HOST_SCOPE(hs4, "plan_common.records_and_offsets");
   uint32_t rest_of[kHostThreads] = {};
   const bool in_trace_order = order.empty();
@@ -1017,6 +1027,7 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
     geom[t] = G;
    }
    rest_of[tid] = max_rest;
+   if (in_trace_order && hooks && hooks->records_slice) hooks->records_slice(lo_, hi_, tid);
   });
   for (uint32_t x : rest_of) h.max_rest = std::max(h.max_rest, x);
   if (!in_trace_order) {  // workspace offsets in trace order, every slice from its base (the records above were written in sweep order)
@@ -1029,6 +1040,7 @@ int plan_common(tracyhip_ctx* ctx, const tracyhip_params& p, const tracyhip_seqs
         G.tab_off = tab;
         tab += (uint64_t)kB16Codes * G.tab_stride;
       }
+      if (hooks && hooks->records_slice) hooks->records_slice(lo, hi, tid);
     });
   }
   if (h.max_rest == 0) return kStreamNo;  // no trace takes the pruned sweep
@@ -1780,20 +1792,16 @@ struct DecStream {
     HIP_TRY(ctx->h_desc.ensure((sizeof(SGeom) + sizeof(SGeomD) + 4 * sizeof(uint64_t)) * (size_t)nt));
     geom = static_cast<SGeom*>(ctx->h_desc.p);
     geomd = reinterpret_cast<SGeomD*>(geom + nt);
-    TRY(plan_common(ctx, p, sp, sr, job->ref_index, nt, TL, TR, h, geom));
-
-    // ---- geometry of the decompose stages (decompose_traces_legacy's, trace by trace) ----
+    // ---- geometry of the decompose stages (decompose_traces_legacy's, trace by trace): sums, extents and checks per slice of the batch, then
+    // the records with their running offsets from the slices' bases -- inside plan_common's two passes (PlanHooks) ----
     z.nt = nt; z.exact = exact; z.host = host;
     if (!bc.peaks && (!bc.signal || !bc.signal_offset || !bc.nsamples || !bc.bcpos)) return set_error(TRACYHIP_ERR_ARG, "null basecall arrays: neither a peak table nor signal + bcpos");
     z.own_peaks = !bc.peaks || host;
-    // two passes on the host threads (100 000 records are milliseconds on one, and nothing is queued yet: the GPU waits for this):
-    // sums, extents and checks per slice of the batch, then the records with their running offsets from the slices' bases
     struct Part {
-      uint64_t atab = 0, alr = 0, tot1 = 0, sext = 0, bext = 0, dext = 0, opscap[3] = {0, 0, 0}, rows_alleles = 0;
+      uint64_t atab = 0, alr = 0, tot1 = 0, sext = 0, bext = 0, dext = 0, opscap[3] = {0, 0, 0}, rows_alleles = 0, rows_traces = 0;
       uint32_t maxbc = 0, maxsl = 0, max_arest = 0, bad_len = ~0u, bad_range = ~0u;
     };
     Part part[kHostThreads];
-    TRACYHIP_HOST_SCOPE(hs5, "plan.decompose_records");
     auto trimmed = [&](uint32_t t, uint32_t& soff, uint32_t& sl) {  // trimmedSeq, abif.h:68-75
       if ((uint64_t)(uint32_t)(TL + TR + 1) >= (uint64_t)h.mf[t]) { soff = 0; sl = h.mf[t]; }
       else { soff = TL; sl = h.mf[t] - TL - TR; }
@@ -1801,7 +1809,10 @@ struct DecStream {
     auto front_ok = [&](uint32_t t, uint32_t sl) {
       return sl > kFrontRows + 2u * (uint32_t)kFrontK && h.rn[t] >= 1 && origin16_ok(&p, sl, sl - kFrontRows + 2u * (uint32_t)kFrontHalfW + 16u);
     };
-    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+    uint64_t base_atab[kHostThreads], base_alr[kHostThreads], base_tot1[kHostThreads];
+    uint64_t rows_traces = 0;
+    PlanHooks hooks;
+    hooks.lengths_slice = [&](uint32_t lo, uint32_t hi, uint32_t tid) {
       Part x;
       for (uint32_t t = lo; t < hi; ++t) {
         if (bc.bc_len[t] != h.mf[t]) x.bad_len = std::min(x.bad_len, t);
@@ -1819,30 +1830,32 @@ struct DecStream {
         x.maxbc = std::max(x.maxbc, h.mf[t]);
         x.maxsl = std::max(x.maxsl, sl);
         x.rows_alleles += 2ull * sl;
+        x.rows_traces += h.mt[t];
       }
       part[tid] = x;
-    });
-    {
+    };
+    hooks.between = [&]() -> int {
       uint32_t bad_len = ~0u, bad_range = ~0u;
       for (const Part& x : part) { bad_len = std::min(bad_len, x.bad_len); bad_range = std::min(bad_range, x.bad_range); }
-      const uint32_t first_bad = std::min(bad_len, bad_range);  // (the first offending trace, as the loop over the traces reported it)
+      const uint32_t first_bad = std::min(bad_len, bad_range);  // (the first offending trace, as a loop over the traces would report it)
       if (first_bad != ~0u) {
         if (bc.bc_len[first_bad] != h.mf[first_bad])
           return set_error(TRACYHIP_ERR_ARG, "trace %u: profile has %u columns but %u basecalls", first_bad, h.mf[first_bad], bc.bc_len[first_bad]);
         return set_error(TRACYHIP_ERR_RANGE, "trace %u has %u basecalls; the scan tables hold < %d", first_bad, bc.bc_len[first_bad], 2 * kMaxIndelGlobal);
       }
-    }
-    uint64_t base_atab[kHostThreads], base_alr[kHostThreads], base_tot1[kHostThreads];
-    for (uint32_t i = 0; i < kHostThreads; ++i) {
-      const Part& x = part[i];
-      base_atab[i] = atab_tot; base_alr[i] = alr_tot; base_tot1[i] = z.tot1;
-      atab_tot += x.atab; alr_tot += x.alr; z.tot1 += x.tot1;
-      z.sext = std::max(z.sext, x.sext); z.bext = std::max(z.bext, x.bext); z.dext = std::max(z.dext, x.dext);
-      for (int k = 0; k < 3; ++k) z.opscap[k] = std::max(z.opscap[k], x.opscap[k]);
-      maxbc = std::max(maxbc, x.maxbc); maxsl = std::max(maxsl, x.maxsl); max_arest = std::max(max_arest, x.max_arest);
-      rows_alleles += x.rows_alleles;
-    }
-    parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t tid) {
+      for (uint32_t i = 0; i < kHostThreads; ++i) {
+        const Part& x = part[i];
+        base_atab[i] = atab_tot; base_alr[i] = alr_tot; base_tot1[i] = z.tot1;
+        atab_tot += x.atab; alr_tot += x.alr; z.tot1 += x.tot1;
+        z.sext = std::max(z.sext, x.sext); z.bext = std::max(z.bext, x.bext); z.dext = std::max(z.dext, x.dext);
+        for (int k = 0; k < 3; ++k) z.opscap[k] = std::max(z.opscap[k], x.opscap[k]);
+        maxbc = std::max(maxbc, x.maxbc); maxsl = std::max(maxsl, x.maxsl); max_arest = std::max(max_arest, x.max_arest);
+        rows_alleles += x.rows_alleles;
+        rows_traces += x.rows_traces;
+      }
+      return TRACYHIP_OK;
+    };
+    hooks.records_slice = [&](uint32_t lo, uint32_t hi, uint32_t tid) {
       uint64_t atab = base_atab[tid], alr = base_alr[tid], tot1 = base_tot1[tid];
       for (uint32_t t = lo; t < hi; ++t) {
         SGeomD& D = geomd[t];
@@ -1863,7 +1876,8 @@ struct DecStream {
         geom[t].ops_off = tot1;
         tot1 += (uint64_t)h.mt[t] + h.rn[t];
       }
-    });
+    };
+    TRY(plan_common(ctx, p, sp, sr, job->ref_index, nt, TL, TR, h, geom, &hooks));
     if (max_arest == 0 || !front_tiers_fit(max_arest)) return kStreamNo;
     TRY(decompose_limits(dp.maxindel, maxbc));
     z.ep = seqset_extent(sp); z.er = seqset_extent(sr);
@@ -1872,8 +1886,6 @@ struct DecStream {
 
     // ---- workspace ----
     TRACYHIP_HOST_SCOPE(hs6, "plan.workspace");
-    uint64_t rows_traces = 0;
-    for (uint32_t t = 0; t < nt; ++t) rows_traces += h.mt[t];
     Arena sizing;
     A.layout(sizing, z);
     TRY(with_fresh_budget(ctx, [&](bool* from_cache) -> int {

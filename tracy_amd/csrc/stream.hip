@@ -1312,12 +1312,20 @@ struct SParamsD {        // what the allele stages need beside SParams
   int32_t best;          // max(match, mismatch, 0): the most a row of a string scores
 };
 
+// off1 / aops_off / ops2_off: where the band launches of the four traceback stages put their strings -- plain offset arrays
+// (Band16Args::ops_off) filled here from the records instead of travelling beside them (3.2 MB per 100 000 traces and a host loop);
+// base1: alleles 1 and 2 reach their buffers through offsets relative to allele 0's, modulo 2^64 (band16_body adds an offset to ONE pointer)
 __global__ void s_expand_d_kernel(const SGeom* __restrict__ geom, const SGeomD* __restrict__ geomd, uint32_t nt, uint64_t bext, BpDesc* __restrict__ bp,
-                                  RowsDesc* __restrict__ rows, DecompDesc* __restrict__ dd, BcDesc* __restrict__ bc, B16TableDesc* __restrict__ atd) {
+                                  RowsDesc* __restrict__ rows, DecompDesc* __restrict__ dd, BcDesc* __restrict__ bc, B16TableDesc* __restrict__ atd,
+                                  uint64_t* __restrict__ off1, uint64_t* __restrict__ aops_off, uint64_t* __restrict__ ops2_off, uint64_t base1) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nt) return;
   const SGeom G = geom[t];
   const SGeomD D = geomd[t];
+  off1[t] = G.ops_off;
+  aops_off[t] = D.opsk_off[0];
+  aops_off[nt + t] = base1 + D.opsk_off[1];
+  ops2_off[t] = D.opsk_off[2];
   bp[t] = BpDesc{G.prof_off + G.tl, G.mf, G.mt};
   rows[t] = RowsDesc{G.ops_off, 0u, 0u};
   dd[t] = DecompDesc{G.ops_off, D.bc_off, D.dcp_off, 0u, G.mf, G.rn, 0u};
@@ -1789,7 +1797,7 @@ struct DecStream {
   // what the host knows before anything runs: geometry of every trace (laid out in the pinned block it travels from), workspace
   int plan() {
     // geometry and offsets are laid out in the pinned block they travel from
-    HIP_TRY(ctx->h_desc.ensure((sizeof(SGeom) + sizeof(SGeomD) + 4 * sizeof(uint64_t)) * (size_t)nt));
+    HIP_TRY(ctx->h_desc.ensure((sizeof(SGeom) + sizeof(SGeomD)) * (size_t)nt));
     geom = static_cast<SGeom*>(ctx->h_desc.p);
     geomd = reinterpret_cast<SGeomD*>(geom + nt);
     // ---- geometry of the decompose stages (decompose_traces_legacy's, trace by trace): sums, extents and checks per slice of the batch, then
@@ -1945,27 +1953,12 @@ struct DecStream {
     HIP_TRY(hipMemcpyAsync(A.pri_bak, d_pri, z.bext, hipMemcpyDeviceToDevice, st));  // decomposeAlleles rewrites the basecalls in place
     HIP_TRY(hipMemcpyAsync(A.sec_bak, d_sec, z.bext, hipMemcpyDeviceToDevice, st));
 
-    // ---- references encoded once (unless encode_early did it while the host planned); geometry, offsets: one pinned block, one copy each way ----
+    // ---- references encoded once (unless encode_early did it while the host planned); the records: one pinned block, two copies ----
     if (!encoded_early) TRY(encode_references(d_ref, z.er));
     {
-      char* hp = static_cast<char*>(ctx->h_desc.p);
-      SGeomD* hgd = geomd;
-      uint64_t* hoff = reinterpret_cast<uint64_t*>(hgd + nt);  // [off1 nt][allele ops 2 nt][allele 1 vs 2 ops nt]
-      // (band16_body adds an offset to ONE ops pointer: alleles 1 and 2 reach their buffers through offsets relative to allele 0's, modulo 2^64)
-      const uint64_t base1 = (uint64_t)(reinterpret_cast<uintptr_t>(d_opsK[1]) - reinterpret_cast<uintptr_t>(d_opsK[0]));
-      parallel_for(nt, [&](uint32_t lo, uint32_t hi, uint32_t) {
-        for (uint32_t t = lo; t < hi; ++t) {
-          hoff[t] = geom[t].ops_off;
-          hoff[nt + t] = out->ops_offset[0][t];
-          hoff[2 * (size_t)nt + t] = base1 + out->ops_offset[1][t];
-          hoff[3 * (size_t)nt + t] = out->ops_offset[2][t];
-        }
-      });
-      HIP_TRY(hipMemcpyAsync(sc.geom, hp, sizeof(SGeom) * (size_t)nt, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(A.geomd, hgd, sizeof(SGeomD) * (size_t)nt, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(A.off1, hoff, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(A.aops_off, hoff + nt, sizeof(uint64_t) * 2 * (size_t)nt, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(A.ops2_off, hoff + 3 * (size_t)nt, sizeof(uint64_t) * (size_t)nt, hipMemcpyHostToDevice, st));
+      // (the offset arrays of the band launches are filled from these records on the device: s_expand_d_kernel)
+      HIP_TRY(hipMemcpyAsync(sc.geom, ctx->h_desc.p, sizeof(SGeom) * (size_t)nt, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(A.geomd, geomd, sizeof(SGeomD) * (size_t)nt, hipMemcpyHostToDevice, st));
     }
     HIP_TRY(hipMemsetAsync(sc.dead, 0, sizeof(uint32_t) * (size_t)nt, st));
     HIP_TRY(hipMemsetAsync(sc.cnt, 0, sizeof(unsigned long long) * SC_COUNT, st));
@@ -1988,7 +1981,8 @@ struct DecStream {
     OrientStage os{d_prof, d_qp, d_lastrow, exact, A.desc_trim};
     // the descriptors of the decompose stages need nothing but the geometry records; findBreakpoint (indigo.h:196) nothing but the profiles:
     // it runs on a side stream beside the sweeps and is waited for where its result is first read (findHomozygousBreakpoint)
-    hipLaunchKernelGGL(s_expand_d_kernel, g256, b256, 0, st, sc.geom, A.geomd, nt, z.bext, A.bpd, A.rowsd, A.dd, A.bcd, A.atd);
+    hipLaunchKernelGGL(s_expand_d_kernel, g256, b256, 0, st, sc.geom, A.geomd, nt, z.bext, A.bpd, A.rowsd, A.dd, A.bcd, A.atd, A.off1, A.aops_off, A.ops2_off,
+                       (uint64_t)(reinterpret_cast<uintptr_t>(d_opsK[1]) - reinterpret_cast<uintptr_t>(d_opsK[0])));
     HIP_TRY(hipGetLastError());
     // findBreakpoint (indigo.h:196) needs nothing but the profiles, the case-sensitive codes of the windows (the allele stages' columns)
     // nothing but the references: both fill the hole behind the full sweeps (OrientStage::filler)
